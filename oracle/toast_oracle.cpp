@@ -1,0 +1,703 @@
+// toast_oracle.cpp -- CPU restatement of hpc4cmb/toast's map-making hot path.
+//
+// TEST INFRASTRUCTURE ONLY.  Nothing under toast_amd/ may import, link or call this
+// file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it,
+// and only as the checker / reported CPU baseline.  The shipped path is the HIP library.
+//
+// Parity status: PINNED.  Every function below is checked bit-for-bit (integer and
+// per-sample floating point outputs) or to accumulation-order rounding (zmap) against
+// oracle/_ref (the reference's own C++ compiled in place, oracle/ref_build.sh) by
+// tests/test_oracle_vs_ref.py in the build container, and against the committed
+// fixtures in tests/golden/ (made by tests/golden/make_golden.py from oracle/_ref)
+// everywhere else.  cov_apply_diag is the exception: its reference translation unit
+// needs LAPACK (absent here), so it is pinned against the reference's documented
+// packed-upper-triangle semantics by a numpy dense mat-vec in the tests.
+//
+// Each function cites the reference file:line it restates (paths relative to
+// /root/reference/src/toast/_libtoast/ unless given in full).  Operation order of every
+// floating point expression follows the reference so results are bit-identical when
+// built with -ffp-contract=off (see oracle/Makefile).
+//
+// Build: make -C oracle   ->  oracle/libtoast_oracle.so   (plain g++, OpenMP)
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <vector>
+
+#ifdef _OPENMP
+# include <omp.h>
+#endif
+
+extern "C" {
+
+// intervals.hpp:10-15 -- 32-byte POD; kernels treat [first, last) as half open
+// (e.g. ops_scan_map.cpp:253-255 `isamp < last`).
+struct OracleInterval {
+    double start;
+    double stop;
+    int64_t first;
+    int64_t last;
+};
+
+}  // extern "C"
+
+namespace {
+
+constexpr double kTwoThirds = 0.66666666666666666667;  // ops_pixels_healpix.cpp:16
+
+// ---------------------------------------------------------------------------------
+// HEALPix scalar math
+// ---------------------------------------------------------------------------------
+
+// Bit-spread table, ops_pixels_healpix.cpp:20-27: bit k of m moves to bit 2k.
+struct SpreadTable {
+    int64_t u[256];
+    int64_t c[256];
+    SpreadTable() {
+        for (int64_t m = 0; m < 256; ++m) {
+            int64_t v = 0;
+            for (int b = 0; b < 8; ++b) v |= ((m >> b) & 1) << (2 * b);
+            u[m] = v;
+            // compress table, ops_pixels_healpix.cpp:29-36: even bits -> low nibble,
+            // odd bits -> bits 8..11
+            int64_t w = 0;
+            for (int b = 0; b < 4; ++b) {
+                w |= ((m >> (2 * b)) & 1) << b;
+                w |= ((m >> (2 * b + 1)) & 1) << (8 + b);
+            }
+            c[m] = w;
+        }
+    }
+};
+const SpreadTable kTab;
+
+// ops_pixels_healpix.cpp:78-85
+inline int64_t morton_xy(int64_t x, int64_t y) {
+    const int64_t * t = kTab.u;
+    return t[x & 0xff] | (t[(x >> 8) & 0xff] << 16) | (t[(x >> 16) & 0xff] << 32) |
+           (t[(x >> 24) & 0xff] << 48) | (t[y & 0xff] << 1) | (t[(y >> 8) & 0xff] << 17) |
+           (t[(y >> 16) & 0xff] << 33) | (t[(y >> 24) & 0xff] << 49);
+}
+
+// ops_pixels_healpix.cpp:87-102
+inline void morton_inv(int64_t pix, int64_t & x, int64_t & y) {
+    const int64_t * t = kTab.c;
+    uint64_t p = (uint64_t)pix;
+    int64_t raw = (p & 0x5555ull) | ((p & 0x55550000ull) >> 15) |
+                  ((p & 0x555500000000ull) >> 16) | ((p & 0x5555000000000000ull) >> 31);
+    x = t[raw & 0xff] | (t[(raw >> 8) & 0xff] << 4) | (t[(raw >> 16) & 0xff] << 16) |
+        (t[(raw >> 24) & 0xff] << 20);
+    raw = ((p & 0xaaaaull) >> 1) | ((p & 0xaaaa0000ull) >> 16) |
+          ((p & 0xaaaa00000000ull) >> 17) | ((p & 0xaaaa000000000000ull) >> 32);
+    y = t[raw & 0xff] | (t[(raw >> 8) & 0xff] << 4) | (t[(raw >> 16) & 0xff] << 16) |
+        (t[(raw >> 24) & 0xff] << 20);
+}
+
+// Rotate v by unit quaternion q (scalar last).  ops_pixels_healpix.cpp:50-76 and the
+// identical copy ops_stokes_weights.cpp:21-48.
+inline void quat_rotate(const double * q, const double * v, double * out) {
+    const double xw = q[3] * q[0], yw = q[3] * q[1], zw = q[3] * q[2];
+    const double x2 = -q[0] * q[0], xy = q[0] * q[1], xz = q[0] * q[2];
+    const double y2 = -q[1] * q[1], yz = q[1] * q[2], z2 = -q[2] * q[2];
+    out[0] = 2 * ((y2 + z2) * v[0] + (xy - zw) * v[1] + (yw + xz) * v[2]) + v[0];
+    out[1] = 2 * ((zw + xy) * v[0] + (x2 + z2) * v[1] + (yz - xw) * v[2]) + v[1];
+    out[2] = 2 * ((xz - yw) * v[0] + (xw + yz) * v[1] + (x2 + y2) * v[2]) + v[2];
+}
+
+struct ZPhi {
+    double phi, z, rtz;
+    int region;  // sign(z) * (1 if |z| <= 2/3 else 2)
+};
+
+inline void classify_z(double z, ZPhi & o) {
+    o.z = z;
+    const double za = std::fabs(z);
+    const int s = (z > 0.0) ? 1 : -1;
+    o.region = (za <= kTwoThirds) ? s : s + s;
+    o.rtz = std::sqrt(3.0 * (1.0 - za));
+}
+
+// ops_pixels_healpix.cpp:104-120
+inline ZPhi vec_to_zphi(const double * v) {
+    ZPhi o;
+    classify_z(v[2], o);
+    o.phi = std::atan2(v[1], v[0]);
+    return o;
+}
+
+// ops_pixels_healpix.cpp:304-317
+inline ZPhi theta_to_zphi(double theta, double phi) {
+    ZPhi o;
+    classify_z(std::cos(theta), o);
+    o.phi = phi;
+    return o;
+}
+
+// phi -> tt in [0,4): truncating fmod (ops_pixels_healpix.cpp:44-48), snap of
+// |phi mod 2pi| < 10 eps to zero and wrap of negatives (:132-139 / :219-226).
+inline double phi_to_tt(double phi) {
+    const double tol = 10.0 * std::numeric_limits<double>::epsilon();
+    const double period = 2 * M_PI;
+    const double div = phi / period;
+    double pm = period * (div - (double)((int64_t)div));
+    if ((pm < tol) && (pm > -tol)) pm = 0.0;
+    return (pm >= 0.0) ? pm * M_2_PI : pm * M_2_PI + 4.0;
+}
+
+// ops_pixels_healpix.cpp:122-208
+inline int64_t zphi_to_nest(int64_t nside, int64_t factor, const ZPhi & a) {
+    const double tt = phi_to_tt(a.phi);
+    const double dn = (double)nside;
+    const int64_t nm1 = nside - 1;
+    int64_t x, y, face;
+    if (a.region == 1 || a.region == -1) {
+        const double t1 = 0.5 * dn + dn * tt;
+        const double t2 = (0.75 * dn) * a.z;
+        const int64_t jp = (int64_t)(t1 - t2);
+        const int64_t jm = (int64_t)(t1 + t2);
+        const int64_t ifp = jp >> factor;
+        const int64_t ifm = jm >> factor;
+        if (ifp == ifm) {
+            face = (ifp == 4) ? (int64_t)4 : ifp + 4;
+        } else if (ifp < ifm) {
+            face = ifp;
+        } else {
+            face = ifm + 8;
+        }
+        x = jm & nm1;
+        y = nm1 - (jp & nm1);
+    } else {
+        const int64_t ntt = (int64_t)tt;
+        const double tp = tt - (double)ntt;
+        const double t1 = dn * a.rtz;
+        int64_t jp = (int64_t)(tp * t1);
+        int64_t jm = (int64_t)((1.0 - tp) * t1);
+        if (jp >= nside) jp = nm1;
+        if (jm >= nside) jm = nm1;
+        if (a.z >= 0) {
+            face = ntt;
+            x = nm1 - jm;
+            y = nm1 - jp;
+        } else {
+            face = ntt + 8;
+            x = jp;
+            y = jm;
+        }
+    }
+    return morton_xy(x, y) + (face << (2 * factor));
+}
+
+// ops_pixels_healpix.cpp:210-276
+inline int64_t zphi_to_ring(int64_t nside, int64_t /*factor*/, const ZPhi & a) {
+    const double tt = phi_to_tt(a.phi);
+    const double dn = (double)nside;
+    const int64_t n4 = 4 * nside;
+    const int64_t ncap = 2 * (nside * nside - nside);
+    const int64_t npix = 12 * nside * nside;
+    if (a.region == 1 || a.region == -1) {
+        const double t1 = 0.5 * dn + dn * tt;
+        const double t2 = (0.75 * dn) * a.z;
+        const int64_t jp = (int64_t)(t1 - t2);
+        const int64_t jm = (int64_t)(t1 + t2);
+        const int64_t ir = (nside + 1) + jp - jm;
+        const int64_t kshift = 1 - (ir & 1);
+        int64_t ip = (jp + jm - nside + kshift + 1) >> 1;
+        ip = ip % n4;
+        return ncap + ((ir - 1) * n4 + ip);
+    }
+    const double tp = tt - std::floor(tt);
+    const double t1 = dn * a.rtz;
+    const int64_t jp = (int64_t)(tp * t1);
+    const int64_t jm = (int64_t)((1.0 - tp) * t1);
+    const int64_t ir = jp + jm + 1;
+    int64_t ip = (int64_t)(tt * (double)ir);
+    ip -= (int64_t)(ip / (4 * ir));
+    return (a.region > 0) ? (2 * ir * (ir - 1) + ip) : (npix - 2 * ir * (ir + 1) + ip);
+}
+
+inline int64_t ilog2(int64_t nside) {
+    int64_t f = 0;
+    while (nside != (1ll << f)) ++f;  // ops_pixels_healpix.cpp:1216-1219
+    return f;
+}
+
+const int64_t kJr[12] = {2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4};
+const int64_t kJp[12] = {1, 3, 5, 7, 0, 2, 4, 6, 1, 3, 5, 7};
+
+// ops_pixels_healpix.cpp:383-473
+inline int64_t ring_to_nest(int64_t nside, int64_t factor, int64_t ringpix) {
+    const int64_t npix = 12 * nside * nside;
+    const int64_t ncap = 2 * (nside * nside - nside);
+    int64_t fc, nr, kshift, iring, iphi;
+    if (ringpix < ncap) {
+        iring = (int64_t)(0.5 * (1.0 + std::sqrt((double)(1 + 2 * ringpix))));
+        iphi = (ringpix + 1) - 2 * iring * (iring - 1);
+        kshift = 0;
+        nr = iring;
+        fc = 0;
+        int64_t tmp = iphi - 1;
+        if (tmp >= 2 * iring) {
+            fc = 2;
+            tmp -= 2 * iring;
+        }
+        if (tmp >= iring) ++fc;
+    } else if (ringpix < (npix - ncap)) {
+        const int64_t ip = ringpix - ncap;
+        iring = (ip >> (factor + 2)) + nside;
+        iphi = (ip & (4 * nside - 1)) + 1;
+        kshift = (iring + nside) & 1;
+        nr = nside;
+        const int64_t ire = iring - nside + 1;
+        const int64_t irm = 2 * nside + 2 - ire;
+        const int64_t ifm = (iphi - (ire / 2) + nside - 1) >> factor;
+        const int64_t ifp = (iphi - (irm / 2) + nside - 1) >> factor;
+        if (ifp == ifm) {
+            fc = (ifp == 4) ? 4 : ifp + 4;
+        } else if (ifp < ifm) {
+            fc = ifp;
+        } else {
+            fc = ifm + 8;
+        }
+    } else {
+        const int64_t ip = npix - ringpix;
+        iring = (int64_t)(0.5 * (1.0 + std::sqrt((double)(2 * ip - 1))));
+        iphi = 4 * iring + 1 - (ip - 2 * iring * (iring - 1));
+        kshift = 0;
+        nr = iring;
+        iring = 4 * nside - iring;
+        fc = 8;
+        int64_t tmp = iphi - 1;
+        if (tmp >= 2 * nr) {
+            fc = 10;
+            tmp -= 2 * nr;
+        }
+        if (tmp >= nr) ++fc;
+    }
+    const int64_t irt = iring - kJr[fc] * nside + 1;
+    int64_t ipt = 2 * iphi - kJp[fc] * nr - kshift - 1;
+    if (ipt >= 2 * nside) ipt -= 8 * nside;
+    const int64_t x = (ipt - irt) >> 1;
+    const int64_t y = (-(ipt + irt)) >> 1;
+    return morton_xy(x, y) + (fc << (2 * factor));
+}
+
+// ops_pixels_healpix.cpp:475-520
+inline int64_t nest_to_ring(int64_t nside, int64_t factor, int64_t nestpix) {
+    const int64_t npix = 12 * nside * nside;
+    const int64_t ncap = 2 * (nside * nside - nside);
+    const int64_t fc = nestpix >> (2 * factor);
+    int64_t x, y;
+    morton_inv(nestpix & (nside * nside - 1), x, y);
+    const int64_t jr = (kJr[fc] * nside) - x - y - 1;
+    int64_t nr, n_before, kshift;
+    if (jr < nside) {
+        nr = jr;
+        n_before = 2 * nr * (nr - 1);
+        kshift = 0;
+    } else if (jr > 3 * nside) {
+        nr = 4 * nside - jr;
+        n_before = npix - 2 * (nr + 1) * nr;
+        kshift = 0;
+    } else {
+        nr = nside;
+        n_before = ncap + (jr - nside) * 4 * nside;
+        kshift = (jr - nside) & 1;
+    }
+    int64_t jp = (kJp[fc] * nr + x - y + 1 + kshift) / 2;
+    if (jp > 4 * nside) {
+        jp -= 4 * nside;
+    } else if (jp < 1) {
+        jp += 4 * nside;
+    }
+    return n_before + jp - 1;
+}
+
+// Detector polarisation angle, ops_stokes_weights.cpp:50-75.
+inline double pol_alpha(const double * q) {
+    const double xaxis[3] = {1.0, 0.0, 0.0};
+    const double zaxis[3] = {0.0, 0.0, 1.0};
+    double vd[3], vo[3];
+    quat_rotate(q, zaxis, vd);
+    quat_rotate(q, xaxis, vo);
+    const double ang_xy = std::atan2(vd[1], vd[0]);
+    const double vm_x = vd[2] * std::cos(ang_xy);
+    const double vm_y = vd[2] * std::sin(ang_xy);
+    const double vm_z = -std::sqrt(1.0 - vd[2] * vd[2]);
+    const double alpha_y = (vd[0] * (vm_y * vo[2] - vm_z * vo[1]) -
+                            vd[1] * (vm_x * vo[2] - vm_z * vo[0]) +
+                            vd[2] * (vm_x * vo[1] - vm_y * vo[0]));
+    const double alpha_x = (vm_x * vo[0] + vm_y * vo[1] + vm_z * vo[2]);
+    return std::atan2(alpha_y, alpha_x);
+}
+
+template <typename T>
+void scan_map_impl(const int64_t * g2l, int64_t nps, const T * map, double * tod,
+                   const int32_t * d_idx, const int64_t * pix, const int32_t * p_idx,
+                   const double * wts, const int32_t * w_idx, int64_t nnz,
+                   const OracleInterval * ivl, int64_t n_view, int64_t n_det, int64_t n_samp,
+                   double scale, int zero, int subtract, int mult) {
+    // ops_scan_map.cpp:15-78 (per sample) and :246-281 (host loop nest)
+    for (int64_t idet = 0; idet < n_det; ++idet) {
+        const int64_t prow = (int64_t)p_idx[idet] * n_samp;
+        const int64_t wrow = (int64_t)w_idx[idet] * n_samp;
+        const int64_t drow = (int64_t)d_idx[idet] * n_samp;
+        for (int64_t iv = 0; iv < n_view; ++iv) {
+#pragma omp parallel for schedule(static)
+            for (int64_t s = ivl[iv].first; s < ivl[iv].last; ++s) {
+                double * d = tod + drow + s;
+                if (zero) *d = 0.0;
+                const int64_t p = pix[prow + s];
+                if (p < 0) continue;
+                const int64_t gsm = p / nps;
+                const int64_t lsm = g2l[gsm];
+                const int64_t sub = p - gsm * nps;
+                const T * m = map + nnz * (lsm * nps + sub);
+                const double * w = wts + nnz * (wrow + s);
+                double v = 0.0;
+                for (int64_t k = 0; k < nnz; ++k) v += w[k] * m[k];
+                v *= scale;
+                if (subtract) {
+                    *d -= v;
+                } else if (mult) {
+                    *d *= v;
+                } else {
+                    *d += v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------
+// HEALPix utilities (host-only in the reference too); used for the known-answer tests
+// the reference keeps in src/toast/tests/healpix.py.
+// ---------------------------------------------------------------------------------
+
+// ops_pixels_healpix.cpp:319-349 via the vector wrappers :780-900
+void oracle_healpix_ang2pix(int64_t nside, int nest, int64_t n, const double * theta,
+                            const double * phi, int64_t * pix) {
+    const int64_t f = ilog2(nside);
+    for (int64_t i = 0; i < n; ++i) {
+        const ZPhi a = theta_to_zphi(theta[i], phi[i]);
+        pix[i] = nest ? zphi_to_nest(nside, f, a) : zphi_to_ring(nside, f, a);
+    }
+}
+
+// ops_pixels_healpix.cpp:351-381
+void oracle_healpix_vec2pix(int64_t nside, int nest, int64_t n, const double * vec,
+                            int64_t * pix) {
+    const int64_t f = ilog2(nside);
+    for (int64_t i = 0; i < n; ++i) {
+        const ZPhi a = vec_to_zphi(vec + 3 * i);
+        pix[i] = nest ? zphi_to_nest(nside, f, a) : zphi_to_ring(nside, f, a);
+    }
+}
+
+void oracle_healpix_ring2nest(int64_t nside, int64_t n, const int64_t * in, int64_t * out) {
+    const int64_t f = ilog2(nside);
+    for (int64_t i = 0; i < n; ++i) out[i] = ring_to_nest(nside, f, in[i]);
+}
+
+void oracle_healpix_nest2ring(int64_t nside, int64_t n, const int64_t * in, int64_t * out) {
+    const int64_t f = ilog2(nside);
+    for (int64_t i = 0; i < n; ++i) out[i] = nest_to_ring(nside, f, in[i]);
+}
+
+// ---------------------------------------------------------------------------------
+// pointing_detector: ops_pointing_detector.cpp:21-68 (inner), :198-224 (host loops)
+// ---------------------------------------------------------------------------------
+void oracle_pointing_detector(const double * fp, const double * bore, const int32_t * q_idx,
+                              double * quats, const OracleInterval * ivl, int64_t n_view,
+                              const uint8_t * flags, int64_t n_flags, uint8_t mask,
+                              int64_t n_det, int64_t n_samp) {
+    const bool use_flags = (n_flags == n_samp);  // :121-129
+    for (int64_t idet = 0; idet < n_det; ++idet) {
+        const double * q = fp + 4 * idet;
+        double * row = quats + (int64_t)q_idx[idet] * 4 * n_samp;
+        for (int64_t iv = 0; iv < n_view; ++iv) {
+#pragma omp parallel for schedule(static)
+            for (int64_t s = ivl[iv].first; s < ivl[iv].last; ++s) {
+                double p[4] = {0.0, 0.0, 0.0, 1.0};
+                if (!(use_flags && (flags[s] & mask))) {
+                    std::memcpy(p, bore + 4 * s, sizeof p);
+                }
+                double * r = row + 4 * s;
+                r[0] = p[0] * q[3] + p[1] * q[2] - p[2] * q[1] + p[3] * q[0];
+                r[1] = -p[0] * q[2] + p[1] * q[3] + p[2] * q[0] + p[3] * q[1];
+                r[2] = p[0] * q[1] - p[1] * q[0] + p[2] * q[3] + p[3] * q[2];
+                r[3] = -p[0] * q[0] - p[1] * q[1] - p[2] * q[2] + p[3] * q[3];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// pixels_healpix: ops_pixels_healpix.cpp:586-666 (inner), :1356-1415 (host loops)
+// ---------------------------------------------------------------------------------
+void oracle_pixels_healpix(const int32_t * q_idx, const double * quats, const uint8_t * flags,
+                           int64_t n_flags, uint8_t mask, const int32_t * p_idx,
+                           int64_t * pixels, const OracleInterval * ivl, int64_t n_view,
+                           uint8_t * hsub, int64_t n_pix_submap, int64_t nside, int nest,
+                           int64_t n_det, int64_t n_samp) {
+    const bool use_flags = (n_flags == n_samp);  // :1204-1211
+    const int64_t factor = ilog2(nside);
+    const double zaxis[3] = {0.0, 0.0, 1.0};
+    for (int64_t idet = 0; idet < n_det; ++idet) {
+        const double * qrow = quats + (int64_t)q_idx[idet] * 4 * n_samp;
+        int64_t * prow = pixels + (int64_t)p_idx[idet] * n_samp;
+        for (int64_t iv = 0; iv < n_view; ++iv) {
+#pragma omp parallel for schedule(static)
+            for (int64_t s = ivl[iv].first; s < ivl[iv].last; ++s) {
+                double dir[3];
+                quat_rotate(qrow + 4 * s, zaxis, dir);
+                const ZPhi a = vec_to_zphi(dir);
+                const int64_t p =
+                    nest ? zphi_to_nest(nside, factor, a) : zphi_to_ring(nside, factor, a);
+                if (use_flags && ((flags[s] & mask) != 0)) {
+                    prow[s] = -1;
+                } else {
+                    prow[s] = p;
+                    hsub[p / n_pix_submap] = 1;  // benign same-value race, as in the reference
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// stokes_weights: ops_stokes_weights.cpp:77-140 (inner), :340-394 / :498-505 (host loops)
+// ---------------------------------------------------------------------------------
+void oracle_stokes_weights_IQU(const int32_t * q_idx, const double * quats,
+                               const int32_t * w_idx, double * weights, const double * hwp,
+                               int64_t n_hwp, const OracleInterval * ivl, int64_t n_view,
+                               const double * epsilon, const double * gamma, const double * cal,
+                               int iau, int64_t n_det, int64_t n_samp) {
+    const bool use_hwp = (n_hwp == n_samp);  // :192-200
+    const double usign = iau ? -1.0 : 1.0;   // :219-222
+    for (int64_t idet = 0; idet < n_det; ++idet) {
+        const double eta = (1.0 - epsilon[idet]) / (1.0 + epsilon[idet]);
+        const double * qrow = quats + (int64_t)q_idx[idet] * 4 * n_samp;
+        double * wrow = weights + (int64_t)w_idx[idet] * 3 * n_samp;
+        for (int64_t iv = 0; iv < n_view; ++iv) {
+#pragma omp parallel for schedule(static)
+            for (int64_t s = ivl[iv].first; s < ivl[iv].last; ++s) {
+                const double alpha = pol_alpha(qrow + 4 * s);
+                double * w = wrow + 3 * s;
+                w[0] = cal[idet];
+                if (use_hwp) {
+                    const double ang = 2.0 * (2.0 * (gamma[idet] - hwp[s]) - alpha);
+                    w[1] = std::cos(ang) * eta * cal[idet];
+                    w[2] = -std::sin(ang) * eta * cal[idet] * usign;
+                } else {
+                    const double ang = alpha * 2.0;
+                    w[1] = std::cos(ang) * eta * cal[idet];
+                    w[2] = std::sin(ang) * eta * cal[idet] * usign;
+                }
+            }
+        }
+    }
+}
+
+// ops_stokes_weights.cpp:398-505
+void oracle_stokes_weights_I(const int32_t * w_idx, double * weights, const OracleInterval * ivl,
+                             int64_t n_view, const double * cal, int64_t n_det,
+                             int64_t n_samp) {
+    for (int64_t idet = 0; idet < n_det; ++idet) {
+        double * wrow = weights + (int64_t)w_idx[idet] * n_samp;
+        for (int64_t iv = 0; iv < n_view; ++iv) {
+            for (int64_t s = ivl[iv].first; s < ivl[iv].last; ++s) wrow[s] = cal[idet];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// scan_map, four map dtypes: ops_scan_map.cpp:84-292
+// ---------------------------------------------------------------------------------
+#define ORACLE_SCAN_MAP(NAME, T)                                                              \
+    void NAME(const int64_t * g2l, int64_t nps, const T * map, double * tod,                  \
+              const int32_t * d_idx, const int64_t * pix, const int32_t * p_idx,              \
+              const double * wts, const int32_t * w_idx, int64_t nnz,                         \
+              const OracleInterval * ivl, int64_t n_view, int64_t n_det, int64_t n_samp,      \
+              double scale, int zero, int subtract, int mult) {                               \
+        scan_map_impl<T>(g2l, nps, map, tod, d_idx, pix, p_idx, wts, w_idx, nnz, ivl, n_view, \
+                         n_det, n_samp, scale, zero, subtract, mult);                         \
+    }
+ORACLE_SCAN_MAP(oracle_scan_map_f64, double)
+ORACLE_SCAN_MAP(oracle_scan_map_f32, float)
+ORACLE_SCAN_MAP(oracle_scan_map_i64, int64_t)
+ORACLE_SCAN_MAP(oracle_scan_map_i32, int32_t)
+
+// ---------------------------------------------------------------------------------
+// build_noise_weighted: ops_mapmaker_utils.cpp:294-378 (host path).  Every OpenMP thread
+// owns a sub-pixel range of *every* submap and walks all samples, so each map element is
+// summed in strict (det, view, sample) order whatever the thread count.
+// n_flag_idx mirrors the reference quirk: flag_index has n_det entries (or [-1] when
+// det flags are unused and n_det == 1).
+// ---------------------------------------------------------------------------------
+void oracle_build_noise_weighted(const int64_t * g2l, double * zmap, int64_t nps, int64_t nnz,
+                                 const int32_t * p_idx, const int64_t * pix,
+                                 const int32_t * w_idx, const double * wts,
+                                 const int32_t * d_idx, const double * tod,
+                                 const int32_t * f_idx, const uint8_t * dflags,
+                                 int64_t dflags_n_samp, const double * det_scale, uint8_t dmask,
+                                 const OracleInterval * ivl, int64_t n_view,
+                                 const uint8_t * sflags, int64_t n_sflags, uint8_t smask,
+                                 int64_t n_det, int64_t n_samp) {
+    const bool use_shared = (n_sflags == n_samp);    // :181-188
+    const bool use_det = (dflags_n_samp == n_samp);  // :190-197
+#pragma omp parallel
+    {
+        int nt = 1, me = 0;
+#ifdef _OPENMP
+        nt = omp_get_num_threads();
+        me = omp_get_thread_num();
+#endif
+        const int64_t span = nps / nt;
+        const int64_t lo = me * span;
+        const int64_t hi = (me == nt - 1) ? nps : (me + 1) * span;
+        for (int64_t idet = 0; idet < n_det; ++idet) {
+            const int64_t prow = (int64_t)p_idx[idet] * n_samp;
+            const int64_t wrow = (int64_t)w_idx[idet] * n_samp;
+            const int64_t drow = (int64_t)d_idx[idet] * n_samp;
+            const int64_t frow = (int64_t)f_idx[idet] * n_samp;
+            for (int64_t iv = 0; iv < n_view; ++iv) {
+                for (int64_t s = ivl[iv].first; s < ivl[iv].last; ++s) {
+                    if (use_det && (dflags[frow + s] & dmask)) continue;
+                    if (use_shared && (sflags[s] & smask)) continue;
+                    const int64_t p = pix[prow + s];
+                    if (p < 0) continue;
+                    const int64_t gsm = p / nps;
+                    const int64_t sub = p - gsm * nps;
+                    if (sub < lo || sub >= hi) continue;
+                    double * z = zmap + nnz * (g2l[gsm] * nps + sub);
+                    const double * w = wts + nnz * (wrow + s);
+                    const double sd = tod[drow + s] * det_scale[idet];
+                    for (int64_t k = 0; k < nnz; ++k) z[k] += sd * w[k];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// noise_weight: ops_noise_weight.cpp:11-119
+// ---------------------------------------------------------------------------------
+void oracle_noise_weight(double * tod, const int32_t * d_idx, const OracleInterval * ivl,
+                         int64_t n_view, const double * det_w, int64_t n_det,
+                         int64_t n_samp) {
+    for (int64_t idet = 0; idet < n_det; ++idet) {
+        double * row = tod + (int64_t)d_idx[idet] * n_samp;
+        const double w = det_w[idet];
+        for (int64_t iv = 0; iv < n_view; ++iv) {
+#pragma omp parallel for schedule(static)
+            for (int64_t s = ivl[iv].first; s < ivl[iv].last; ++s) row[s] *= w;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// Offset template: template_offset.cpp:16-147 / :149-332 / :334-408
+// ---------------------------------------------------------------------------------
+void oracle_offset_add_to_signal(int64_t step, int64_t amp_off, const int64_t * n_amp_views,
+                                 const double * amps, const uint8_t * amp_flags,
+                                 int32_t d_index, double * tod, const OracleInterval * ivl,
+                                 int64_t n_view, int64_t n_samp) {
+    int64_t voff = 0;  // running amplitude offset of the view, :57-63
+    for (int64_t iv = 0; iv < n_view; ++iv) {
+        double * row = tod + (int64_t)d_index * n_samp;
+        for (int64_t s = ivl[iv].first; s < ivl[iv].last; ++s) {
+            const int64_t a = amp_off + voff + (s - ivl[iv].first) / step;
+            if (amp_flags[a] == 0) row[s] += amps[a];
+        }
+        voff += n_amp_views[iv];
+    }
+}
+
+// Host path: one add per sample in sample order (template_offset.cpp:296-326).
+void oracle_offset_project_signal(int32_t d_index, const double * tod, int32_t f_index,
+                                  const uint8_t * dflags, uint8_t fmask, int64_t step,
+                                  int64_t amp_off, const int64_t * n_amp_views, double * amps,
+                                  const uint8_t * amp_flags, const OracleInterval * ivl,
+                                  int64_t n_view, int64_t n_samp) {
+    const bool use_flags = (f_index >= 0);  // :213-221
+    int64_t voff = 0;
+    for (int64_t iv = 0; iv < n_view; ++iv) {
+        for (int64_t s = ivl[iv].first; s < ivl[iv].last; ++s) {
+            const int64_t a = amp_off + voff + (s - ivl[iv].first) / step;
+            if (amp_flags[a] != 0) continue;
+            double c = tod[(int64_t)d_index * n_samp + s];
+            if (use_flags && (dflags[(int64_t)f_index * n_samp + s] & fmask)) c = 0.0;
+            amps[a] += c;
+        }
+        voff += n_amp_views[iv];
+    }
+}
+
+void oracle_offset_apply_diag_precond(const double * offset_var, const double * amp_in,
+                                      const uint8_t * amp_flags, double * amp_out,
+                                      int64_t n_amp) {
+    for (int64_t i = 0; i < n_amp; ++i) {
+        amp_out[i] = (amp_flags[i] == 0) ? amp_in[i] * offset_var[i] : 0.0;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// cov_apply_diag: /root/reference/src/libtoast/src/toast_map_cov.cpp:471-528.
+// mat = packed upper triangle (row major) per pixel, vec <- Sym(mat) vec, with the
+// reference's accumulation order (row k then mirrored terms).
+// ---------------------------------------------------------------------------------
+void oracle_cov_apply_diag(int64_t nsub, int64_t subsize, int64_t nnz, const double * mat,
+                           double * vec) {
+    const int64_t block = nnz * (nnz + 1) / 2;
+    std::vector<double> t(nnz);
+    for (int64_t px = 0; px < nsub * subsize; ++px) {
+        const double * m = mat + px * block;
+        double * v = vec + px * nnz;
+        if (nnz == 1) {
+            v[0] *= m[0];
+            continue;
+        }
+        std::fill(t.begin(), t.end(), 0.0);
+        int64_t off = 0;
+        for (int64_t k = 0; k < nnz; ++k) {
+            for (int64_t j = k; j < nnz; ++j, ++off) {
+                t[k] += m[off] * v[j];
+                if (j != k) t[j] += m[off] * v[k];
+            }
+        }
+        for (int64_t k = 0; k < nnz; ++k) v[k] = t[k];
+    }
+}
+
+// libm primitives exactly as the reference calls them (ops_pixels_healpix.cpp:117-118),
+// exposed so the device math can be compared per operation.
+void oracle_atan2(int64_t n, const double * y, const double * x, double * out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) out[i] = std::atan2(y[i], x[i]);
+}
+
+void oracle_sqrt(int64_t n, const double * x, double * out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) out[i] = std::sqrt(x[i]);
+}
+
+void oracle_div(int64_t n, const double * a, const double * b, double * out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) out[i] = a[i] / b[i];
+}
+
+int oracle_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+}  // extern "C"

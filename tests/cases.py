@@ -1,0 +1,120 @@
+"""Seeded input builders shared by the golden-fixture generator, the CPU tests and the
+GPU parity tests.  A "case" is everything one pass of the hot path needs, at the
+reference's buffer layouts."""
+
+import numpy as np
+
+from toast_amd import synth
+
+interval_dtype = synth.interval_dtype
+
+
+def make_case(
+    n_det=4,
+    n_samp=2000,
+    nside=64,
+    rate=10.0,
+    n_split=1,
+    gap=0,
+    with_shared_flags=True,
+    with_det_flags=True,
+    with_hwp=False,
+    extra_rows=0,
+    seed=7,
+    spin_period_s=30.0,
+    spin_angle_deg=3.0,
+    prec_period_s=300.0,
+    prec_angle_deg=7.0,
+    nside_submap=16,
+    random_pointing=False,
+):
+    """Inputs of one observation.
+
+    The default scan values are the reference unit-test fixture's (spin 0.5 min @3 deg,
+    precession 5 min @7 deg: src/toast/tests/helpers/space.py:172-198).  ``extra_rows`` adds
+    unused detector rows to every detdata buffer and shuffles the index arrays, to exercise
+    the ``*_index`` indirection.  ``random_pointing`` replaces the scan by random unit
+    quaternions (worst-case map locality).
+    """
+    rng = np.random.default_rng(seed)
+    fp, gamma = synth.hex_focalplane(n_det, fov_deg=10.0)
+    if random_pointing:
+        bore = synth.quat_normalize(rng.standard_normal((n_samp, 4)))
+    else:
+        bore = synth.satellite_boresight(
+            n_samp, rate, spin_period_s, spin_angle_deg, prec_period_s, prec_angle_deg
+        )
+    ivl = synth.make_intervals(n_samp, n_split=n_split, rate=rate, gap=gap)
+    rows = n_det + extra_rows
+    perm = rng.permutation(rows)[:n_det].astype(np.int32) if extra_rows else np.arange(n_det, dtype=np.int32)
+    case = dict(
+        n_det=n_det,
+        n_samp=n_samp,
+        nside=nside,
+        rate=rate,
+        rows=rows,
+        n_pix_submap=12 * nside_submap * nside_submap if nside >= nside_submap else 12 * nside * nside,
+        focalplane=fp,
+        gamma=np.ascontiguousarray(gamma),
+        epsilon=np.ascontiguousarray(0.02 * rng.random(n_det)),
+        cal=np.ascontiguousarray(1.0 + 0.1 * rng.random(n_det)),
+        boresight=bore,
+        intervals=ivl,
+        quat_index=perm.copy(),
+        pixel_index=np.ascontiguousarray(perm[::-1].copy()) if extra_rows else perm.copy(),
+        weight_index=perm.copy(),
+        data_index=perm.copy(),
+        flag_index=perm.copy(),
+        shared_flags=(synth.shared_flags_block(n_samp, 0.05, value=3) if with_shared_flags else np.zeros(1, np.uint8)),
+        det_flags=(synth.det_flags_random(rows, n_samp, 0.02, value=5, seed=seed + 1) if with_det_flags else np.zeros((1, 1), np.uint8)),
+        hwp=(np.ascontiguousarray(2 * np.pi * ((np.arange(n_samp) * (9.0 / 60.0) / rate) % 1.0)) if with_hwp else np.zeros(1, np.float64)),
+        tod=np.ascontiguousarray(rng.standard_normal((rows, n_samp))),
+        det_scale=np.ascontiguousarray(0.5 + rng.random(n_det)),
+    )
+    n_pix = 12 * nside * nside
+    case["n_submap"] = (n_pix + case["n_pix_submap"] - 1) // case["n_pix_submap"]
+    if not with_det_flags and n_det != 1:
+        # reference quirk: flag_index must still have n_det entries
+        case["flag_index"] = np.zeros(n_det, dtype=np.int32)
+    return case
+
+
+def run_chain(impl, case, nest=True, iau=False, shared_mask=1, det_mask=1, map_dtype=np.float64,
+              scan_scale=1.0, tail=()):
+    """Run pointing_detector -> pixels_healpix -> stokes_weights_IQU ->
+    build_noise_weighted -> scan_map(subtract) -> noise_weight through ``impl`` (any object
+    exposing the reference kernel names: oracle/_ref, the oracle restatement, or the HIP
+    binding) and return every intermediate product.  ``tail`` is appended to every call
+    (``(False,)`` = the trailing ``use_accel`` of the pybind signatures)."""
+    c = case
+    rows, n_samp = c["rows"], c["n_samp"]
+    quats = np.zeros((rows, n_samp, 4), dtype=np.float64)
+    impl.pointing_detector(c["focalplane"], c["boresight"], c["quat_index"], quats, c["intervals"],
+                           c["shared_flags"], shared_mask, *tail)
+    pixels = np.full((rows, n_samp), -7, dtype=np.int64)
+    hsub = np.zeros(c["n_submap"], dtype=np.uint8)
+    impl.pixels_healpix(c["quat_index"], quats, c["shared_flags"], shared_mask, c["pixel_index"], pixels,
+                        c["intervals"], hsub, c["n_pix_submap"], c["nside"], nest, *tail)
+    weights = np.zeros((rows, n_samp, 3), dtype=np.float64)
+    impl.stokes_weights_IQU(c["quat_index"], quats, c["weight_index"], weights, c["hwp"], c["intervals"],
+                            c["epsilon"], c["gamma"], c["cal"], iau, *tail)
+    g2l, hit = synth.global_to_local(hsub)
+    zmap = np.zeros((max(hit.size, 1), c["n_pix_submap"], 3), dtype=np.float64)
+    # pixel rows were written through pixel_index; weights through weight_index
+    impl.build_noise_weighted(g2l, zmap, c["pixel_index"], pixels, c["weight_index"], weights,
+                              c["data_index"], c["tod"], c["flag_index"], c["det_flags"], c["det_scale"],
+                              det_mask, c["intervals"], c["shared_flags"], shared_mask, *tail)
+    tod2 = c["tod"].copy()
+    if np.issubdtype(map_dtype, np.integer):
+        mapdata = np.ascontiguousarray(np.round(zmap * 7.0).astype(map_dtype))
+    else:
+        mapdata = np.ascontiguousarray(zmap.astype(map_dtype))
+    scan = getattr(impl, "scan_map", None)
+    if scan is None:
+        name = {np.float64: "ops_scan_map_float64", np.float32: "ops_scan_map_float32",
+                np.int64: "ops_scan_map_int64", np.int32: "ops_scan_map_int32"}[map_dtype]
+        scan = getattr(impl, name)
+    scan(g2l, c["n_pix_submap"], mapdata, tod2, c["data_index"], pixels, c["pixel_index"], weights,
+         c["weight_index"], c["intervals"], scan_scale, False, True, False, *tail)
+    impl.noise_weight(tod2, c["data_index"], c["intervals"], c["det_scale"], *tail)
+    return dict(quats=quats, pixels=pixels, hsub=hsub, weights=weights, g2l=g2l, zmap=zmap, tod=tod2)

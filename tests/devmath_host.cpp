@@ -1,0 +1,44 @@
+// Host build of toast_amd/csrc/hpix_math.hpp (the device pointing math) so that its
+// bit-parity with the oracle can be measured on a CPU: tests/test_devmath_host.py.
+// Test harness only -- the product never runs this code on the host.
+#include <cstdint>
+#include "../toast_amd/csrc/hpix_math.hpp"
+
+using namespace toast_hip;
+
+extern "C" {
+
+void devmath_atan2(int64_t n, const double * y, const double * x, double * out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) out[i] = atan2_dd(y[i], x[i], kAtanTab);
+}
+
+void devmath_pixels(int64_t n, const double * quats, int64_t nside, int nest, int64_t * pix) {
+    int factor = 0;
+    while (nside != (int64_t(1) << factor)) ++factor;
+    const double zaxis[3] = {0.0, 0.0, 1.0};
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        double dir[3];
+        quat_rotate(quats + 4 * i, zaxis, dir);
+        const ZPhi a = zphi_from_vec(dir, kAtanTab);
+        pix[i] = nest ? zphi_to_nest(nside, factor, a) : zphi_to_ring(nside, factor, a);
+    }
+}
+
+void devmath_vec2pix(int64_t n, const double * vec, int64_t nside, int nest, int64_t * pix) {
+    int factor = 0;
+    while (nside != (int64_t(1) << factor)) ++factor;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        const ZPhi a = zphi_from_vec(vec + 3 * i, kAtanTab);
+        pix[i] = nest ? zphi_to_nest(nside, factor, a) : zphi_to_ring(nside, factor, a);
+    }
+}
+
+void devmath_fastdiv(int64_t n, const int64_t * num, int64_t d, int64_t * q) {
+    const FastDiv f = make_fastdiv(d);
+    for (int64_t i = 0; i < n; ++i) q[i] = fastdiv(num[i], f);
+}
+
+}

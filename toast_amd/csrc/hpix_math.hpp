@@ -1,0 +1,326 @@
+// hpix_math.hpp -- per-sample pointing math of the MI355X map-making path.
+//
+// Device functions for gfx950 (also compilable by g++ for the CPU self-check in
+// tests/devmath_host.cpp, which is how bit-parity of this arithmetic with the reference
+// is verified without a GPU).  What each function mirrors in the reference
+// (paths relative to /root/reference/src/toast/_libtoast/):
+//
+//   quat_rotate                   ops_pixels_healpix.cpp:50-76, ops_stokes_weights.cpp:21-48
+//   quat_mult                     ops_pointing_detector.cpp:21-31
+//   atan2_dd                      libm atan2 as called at ops_pixels_healpix.cpp:118
+//   zphi_from_vec                 ops_pixels_healpix.cpp:104-120
+//   phi_to_tt                     ops_pixels_healpix.cpp:44-48, 132-139
+//   zphi_to_nest / zphi_to_ring   ops_pixels_healpix.cpp:122-208 / 210-276
+//   stokes_alpha                  ops_stokes_weights.cpp:50-75
+//
+// Bit-exactness strategy (HEALPix indices must equal libtoast's CPU result exactly):
+//   * this file is always compiled with -ffp-contract=off, so every *, + below is one
+//     IEEE-754 operation, in the reference's order; fma() appears only where written;
+//   * f64 division and sqrt are correctly rounded on gfx950 (checked on the GPU by
+//     tests/test_gpu_math.py), as they are on x86-64;
+//   * the only libm transcendental on the pixel path is atan2.  glibc's is accurate to
+//     well under 1 ulp; atan2_dd evaluates atan2 in double-double (~2^-66 relative) and
+//     rounds once, so the two agree except when the exact value lies within ~1e-4 ulp of
+//     a rounding boundary, and a differing phi changes the pixel only if the sample also
+//     sits within 1 ulp of a pixel edge.  Tests count mismatches (expected, observed: 0).
+//   * the Morton interleave is done with shift/mask steps (bit-identical to the
+//     reference's 256-entry table, without the memory traffic).
+#pragma once
+
+#include <cstdint>
+
+#if defined(__HIPCC__)
+# include <hip/hip_runtime.h>
+# define TOAST_HD __host__ __device__ __forceinline__
+# define TOAST_HD_CONST static __device__ const
+#else
+# include <cmath>
+# define TOAST_HD inline
+# define TOAST_HD_CONST static const
+#endif
+
+namespace toast_hip {
+
+#include "atan_table.inc"
+
+#define TOAST_TWOTHIRDS 0.66666666666666666667  // ops_pixels_healpix.cpp:16
+#define TOAST_TWOPI (2 * 3.14159265358979323846)  // 2 * M_PI
+#define TOAST_2_OVER_PI 0.63661977236758134308   // M_2_PI
+
+TOAST_HD double f_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+TOAST_HD double f_abs(double a) { return __builtin_fabs(a); }
+TOAST_HD double f_sqrt(double a) { return __builtin_sqrt(a); }
+TOAST_HD double f_floor(double a) { return __builtin_floor(a); }
+
+// ------------------------------------------------------------------ double-double
+struct dd {
+    double hi;
+    double lo;
+};
+
+TOAST_HD dd two_sum(double a, double b) {
+    const double s = a + b;
+    const double bb = s - a;
+    return dd{s, (a - (s - bb)) + (b - bb)};
+}
+
+TOAST_HD dd quick_two_sum(double a, double b) {  // requires |a| >= |b| or a == 0
+    const double s = a + b;
+    return dd{s, b - (s - a)};
+}
+
+TOAST_HD dd two_prod(double a, double b) {
+    const double p = a * b;
+    return dd{p, f_fma(a, b, -p)};
+}
+
+TOAST_HD dd dd_add(dd a, dd b) {
+    dd s = two_sum(a.hi, b.hi);
+    s.lo += a.lo + b.lo;
+    return quick_two_sum(s.hi, s.lo);
+}
+
+TOAST_HD dd dd_sub(dd a, dd b) { return dd_add(a, dd{-b.hi, -b.lo}); }
+
+// a / b with one IEEE reciprocal and fma residuals (~2^-100 relative).
+TOAST_HD dd dd_div(dd a, dd b) {
+    const double r = 1.0 / b.hi;
+    const double q = a.hi * r;
+    const double e = f_fma(-q, b.hi, a.hi);
+    const double ql = ((e + a.lo) - q * b.lo) * r;
+    return quick_two_sum(q, ql);
+}
+
+// atan2 evaluated in double-double and rounded once.  `tab` points at the interleaved
+// {hi, lo} atan(i/32) table (an LDS copy on the device, kAtanTab itself on the host).
+TOAST_HD double atan2_dd(double y, double x, const double * tab) {
+    const double ax = f_abs(x);
+    const double ay = f_abs(y);
+    const bool xneg = __builtin_signbit(x);
+    const bool yneg = __builtin_signbit(y);
+    if (!(ax == ax) || !(ay == ay)) return x + y;  // NaN in, NaN out
+    const bool swap = ay > ax;
+    const double big = swap ? ay : ax;
+    const double small = swap ? ax : ay;
+    dd a;  // atan(small / big), in [0, pi/4]
+    if (small == 0.0) {
+        a = dd{0.0, 0.0};  // covers (0,0) too
+    } else if (big == small) {
+        a = dd{tab[64], tab[65]};
+    } else {
+        const dd t = dd_div(dd{small, 0.0}, dd{big, 0.0});
+        const int i = (int)(t.hi * 32.0 + 0.5);
+        dd u = t;
+        if (i != 0) {
+            // u = (t - c) / (1 + t c); t.hi - c is exact because |t - c| <= 1/64 <= c/2
+            const double c = (double)i * 0.03125;
+            const dd num = two_sum(t.hi - c, t.lo);
+            const dd tc = two_prod(t.hi, c);
+            dd den = two_sum(1.0, tc.hi);
+            den.lo += tc.lo + t.lo * c;
+            u = dd_div(num, den);
+        }
+        // atan(u) = u + u * p(u^2) for |u| <= 1/64 (next term u^13/13 < 2^-75 relative)
+        const double s = u.hi * u.hi;
+        double p = -1.0 / 11.0;
+        p = f_fma(p, s, 1.0 / 9.0);
+        p = f_fma(p, s, -1.0 / 7.0);
+        p = f_fma(p, s, 1.0 / 5.0);
+        p = f_fma(p, s, -1.0 / 3.0);
+        p = p * s;
+        const dd au = quick_two_sum(u.hi, u.lo + u.hi * p);
+        a = dd_add(dd{tab[2 * i], tab[2 * i + 1]}, au);
+    }
+    if (swap) a = dd_sub(dd{kHalfPi_HI, kHalfPi_LO}, a);
+    if (xneg) a = dd_sub(dd{kPi_HI, kPi_LO}, a);
+    const double r = a.hi + a.lo;
+    return yneg ? -r : r;
+}
+
+// ------------------------------------------------------------------ quaternions
+// Rotate v by unit quaternion q = [x, y, z, w]; literal operation order of the reference.
+TOAST_HD void quat_rotate(const double * q, const double * v, double * out) {
+    const double xw = q[3] * q[0], yw = q[3] * q[1], zw = q[3] * q[2];
+    const double x2 = -q[0] * q[0], xy = q[0] * q[1], xz = q[0] * q[2];
+    const double y2 = -q[1] * q[1], yz = q[1] * q[2], z2 = -q[2] * q[2];
+    out[0] = 2 * ((y2 + z2) * v[0] + (xy - zw) * v[1] + (yw + xz) * v[2]) + v[0];
+    out[1] = 2 * ((zw + xy) * v[0] + (x2 + z2) * v[1] + (yz - xw) * v[2]) + v[1];
+    out[2] = 2 * ((xz - yw) * v[0] + (xw + yz) * v[1] + (x2 + y2) * v[2]) + v[2];
+}
+
+// r = p * q (scalar last), reference term order.
+TOAST_HD void quat_mult(const double * p, const double * q, double * r) {
+    r[0] = p[0] * q[3] + p[1] * q[2] - p[2] * q[1] + p[3] * q[0];
+    r[1] = -p[0] * q[2] + p[1] * q[3] + p[2] * q[0] + p[3] * q[1];
+    r[2] = p[0] * q[1] - p[1] * q[0] + p[2] * q[3] + p[3] * q[2];
+    r[3] = -p[0] * q[0] - p[1] * q[1] - p[2] * q[2] + p[3] * q[3];
+}
+
+// ------------------------------------------------------------------ HEALPix
+struct ZPhi {
+    double phi;
+    double z;
+    double rtz;
+    int region;  // sign(z) * (1 if |z| <= 2/3 else 2)
+};
+
+TOAST_HD ZPhi zphi_from_vec(const double * v, const double * atan_tab) {
+    ZPhi o;
+    o.z = v[2];
+    const double za = f_abs(o.z);
+    const int s = (o.z > 0.0) ? 1 : -1;
+    o.region = (za <= TOAST_TWOTHIRDS) ? s : s + s;
+    o.rtz = f_sqrt(3.0 * (1.0 - za));
+    o.phi = atan2_dd(v[1], v[0], atan_tab);
+    return o;
+}
+
+TOAST_HD double phi_to_tt(double phi) {
+    const double tol = 10.0 * 2.220446049250313e-16;
+    const double period = TOAST_TWOPI;
+    const double div = phi / period;
+    double pm = period * (div - (double)((int64_t)div));
+    if ((pm < tol) && (pm > -tol)) pm = 0.0;
+    return (pm >= 0.0) ? pm * TOAST_2_OVER_PI : pm * TOAST_2_OVER_PI + 4.0;
+}
+
+// bit k of the low 32 bits of v -> bit 2k  (== reference utab composition, :20-27, :78-85)
+TOAST_HD uint64_t spread_bits(uint64_t v) {
+    v &= 0xffffffffull;
+    v = (v | (v << 16)) & 0x0000ffff0000ffffull;
+    v = (v | (v << 8)) & 0x00ff00ff00ff00ffull;
+    v = (v | (v << 4)) & 0x0f0f0f0f0f0f0f0full;
+    v = (v | (v << 2)) & 0x3333333333333333ull;
+    v = (v | (v << 1)) & 0x5555555555555555ull;
+    return v;
+}
+
+TOAST_HD int64_t zphi_to_nest(int64_t nside, int factor, const ZPhi & a) {
+    const double tt = phi_to_tt(a.phi);
+    const double dn = (double)nside;
+    const int64_t nm1 = nside - 1;
+    int64_t x, y, face;
+    if (a.region == 1 || a.region == -1) {
+        const double t1 = 0.5 * dn + dn * tt;
+        const double t2 = (0.75 * dn) * a.z;
+        const int64_t jp = (int64_t)(t1 - t2);
+        const int64_t jm = (int64_t)(t1 + t2);
+        const int64_t ifp = jp >> factor;
+        const int64_t ifm = jm >> factor;
+        if (ifp == ifm) {
+            face = (ifp == 4) ? (int64_t)4 : ifp + 4;
+        } else if (ifp < ifm) {
+            face = ifp;
+        } else {
+            face = ifm + 8;
+        }
+        x = jm & nm1;
+        y = nm1 - (jp & nm1);
+    } else {
+        const int64_t ntt = (int64_t)tt;
+        const double tp = tt - (double)ntt;
+        const double t1 = dn * a.rtz;
+        int64_t jp = (int64_t)(tp * t1);
+        int64_t jm = (int64_t)((1.0 - tp) * t1);
+        if (jp >= nside) jp = nm1;
+        if (jm >= nside) jm = nm1;
+        if (a.z >= 0) {
+            face = ntt;
+            x = nm1 - jm;
+            y = nm1 - jp;
+        } else {
+            face = ntt + 8;
+            x = jp;
+            y = jm;
+        }
+    }
+    const int64_t sipf = (int64_t)(spread_bits((uint64_t)x) | (spread_bits((uint64_t)y) << 1));
+    return sipf + (face << (2 * factor));
+}
+
+TOAST_HD int64_t zphi_to_ring(int64_t nside, int /*factor*/, const ZPhi & a) {
+    const double tt = phi_to_tt(a.phi);
+    const double dn = (double)nside;
+    const int64_t n4 = 4 * nside;
+    if (a.region == 1 || a.region == -1) {
+        const int64_t ncap = 2 * (nside * nside - nside);
+        const double t1 = 0.5 * dn + dn * tt;
+        const double t2 = (0.75 * dn) * a.z;
+        const int64_t jp = (int64_t)(t1 - t2);
+        const int64_t jm = (int64_t)(t1 + t2);
+        const int64_t ir = (nside + 1) + jp - jm;
+        const int64_t kshift = 1 - (ir & 1);
+        int64_t ip = (jp + jm - nside + kshift + 1) >> 1;
+        // ip % (4 nside) with C truncation semantics; 4 nside is a power of two
+        ip = (ip >= 0) ? (ip & (n4 - 1)) : -((-ip) & (n4 - 1));
+        return ncap + ((ir - 1) * n4 + ip);
+    }
+    const double tp = tt - f_floor(tt);
+    const double t1 = dn * a.rtz;
+    const int64_t jp = (int64_t)(tp * t1);
+    const int64_t jm = (int64_t)((1.0 - tp) * t1);
+    const int64_t ir = jp + jm + 1;
+    int64_t ip = (int64_t)(tt * (double)ir);
+    // longpart = ip / (4 ir); tt < 4 (+rounding) so the quotient is 0 or 1 (ip >= 0)
+    const int64_t four_ir = 4 * ir;
+    if (ip >= four_ir) ip -= (ip >= 2 * four_ir) ? ip / four_ir : 1;
+    const int64_t npix = 12 * nside * nside;
+    return (a.region > 0) ? (2 * ir * (ir - 1) + ip) : (npix - 2 * ir * (ir + 1) + ip);
+}
+
+// Detector polarisation angle alpha; tolerance-class output (weights are compared with
+// rtol), so the device's libm (ocml) sin/cos/atan2 are used here.
+TOAST_HD double stokes_alpha(const double * q) {
+    const double xaxis[3] = {1.0, 0.0, 0.0};
+    const double zaxis[3] = {0.0, 0.0, 1.0};
+    double vd[3], vo[3];
+    quat_rotate(q, zaxis, vd);
+    quat_rotate(q, xaxis, vo);
+    const double ang_xy = atan2(vd[1], vd[0]);
+    const double vm_x = vd[2] * cos(ang_xy);
+    const double vm_y = vd[2] * sin(ang_xy);
+    const double vm_z = -f_sqrt(1.0 - vd[2] * vd[2]);
+    const double alpha_y = (vd[0] * (vm_y * vo[2] - vm_z * vo[1]) - vd[1] * (vm_x * vo[2] - vm_z * vo[0]) +
+                            vd[2] * (vm_x * vo[1] - vm_y * vo[0]));
+    const double alpha_x = (vm_x * vo[0] + vm_y * vo[1] + vm_z * vo[2]);
+    return atan2(alpha_y, alpha_x);
+}
+
+// ------------------------------------------------------------------ division by a run-time constant
+// q = n / d for 0 <= n < 2^63 with one 64x64->high multiply.  mul = floor(2^(63+s)/d) + 1,
+// s = ceil(log2 d): the error term n*e/(d 2^(63+s)) < 1/d, so the floor is exact.
+struct FastDiv {
+    uint64_t mul;
+    int32_t shift;  // s - 1, or -1 for d == 1
+    int64_t d;
+};
+
+inline FastDiv make_fastdiv(int64_t d) {
+    FastDiv f;
+    f.d = d;
+    if (d <= 1) {
+        f.mul = 0;
+        f.shift = -1;
+        return f;
+    }
+    int s = 0;
+    while ((int64_t(1) << s) < d) ++s;
+    const unsigned __int128 num = (unsigned __int128)1 << (63 + s);
+    f.mul = (uint64_t)(num / (unsigned __int128)d) + 1;
+    f.shift = s - 1;
+    return f;
+}
+
+TOAST_HD uint64_t mulhi_u64(uint64_t a, uint64_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (uint64_t)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+
+TOAST_HD int64_t fastdiv(int64_t n, const FastDiv & f) {
+    return (f.shift < 0) ? n : (int64_t)(mulhi_u64((uint64_t)n, f.mul) >> f.shift);
+}
+
+}  // namespace toast_hip
