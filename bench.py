@@ -1,0 +1,314 @@
+#!/usr/bin/env python3
+"""Headline benchmark: detector-samples/s through one PCG (A^T N^-1 A) iteration.
+
+One "step" = one pass of the PCG's pointing-matrix projections over every local
+detector-sample, exactly the sequence of SolverLHS (reference:
+src/toast/ops/mapmaker_solve.py:342-506):
+
+    zmap = 0
+    zmap += A^T N^-1 tod         build_noise_weighted      (41 B / det-sample)
+    [N > 1]  all-reduce(zmap)    RCCL sum over the detector shards
+    zmap  = C zmap               cov_apply_diag            (map sized)
+    tod2 -= A zmap ; tod2 *= w   scan_map(subtract) + fused noise_weight  (48 B / det-sample)
+
+Workload (config.workload = "cfg3"): BASELINE.json configs[2] -- 1024 detectors x 1 h @ 200 Hz
+(720 000 samples) per GPU, Nside 1024 NEST, IQU, synthetic satellite scan (spin 10 min,
+precession 50 min, 30 deg / 65 deg opening angles), white-noise TOD, 0.5 % random detector
+flags, a 1 % shared-flag block.  Pointing (quaternions -> pixels, Stokes weights) is expanded
+on the GPU by the library's own kernels before the timed region; all inputs are resident in
+HBM when timing starts.  With N GPUs every rank holds its own 1024 detectors of a 1024 N
+detector focalplane observing the same scan (weak scaling, detector-sharded like configs[3]).
+
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2]
+        (N > 1 is launched by torch.distributed.run, one rank per GPU)
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (n_det per GPU, n_samp, rate Hz, nside)
+    "cfg3": (1024, 720000, 200.0, 1024),
+    "cfg2": (64, 360000, 100.0, 512),
+    "mini": (16, 50000, 100.0, 256),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_BNW = 41.0       # pixel 8 + weights 24 + tod 8 + det flag 1   
+BYTES_SCAN = 48.0      # pixel 8 + weights 24 + tod read 8 + tod write 8
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-dets", type=int, default=32, help="detectors in the CPU baseline sample")
+    ap.add_argument("--unfused", action="store_true", help="run noise_weight as its own kernel (105 B variant)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    from toast_amd import capi, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    D = capi.dev
+    stream = torch.cuda.current_stream().cuda_stream
+
+    n_det, n_samp, rate, nside = WORKLOADS[args.workload]
+    nnz = 3
+    nps = 3072 if nside >= 16 else 12 * nside * nside
+    n_submap = 12 * nside * nside // nps
+
+    # ------------------------------------------------------------------ synthetic inputs
+    t_setup = time.time()
+    fp_all, gamma_all = synth.hex_focalplane(n_det * world, fov_deg=10.0)
+    fp = np.ascontiguousarray(fp_all[rank * n_det : (rank + 1) * n_det])
+    gamma = np.ascontiguousarray(gamma_all[rank * n_det : (rank + 1) * n_det])
+    bore = synth.satellite_boresight(n_samp, rate, 600.0, 30.0, 3000.0, 65.0)
+    ivl = synth.make_intervals(n_samp, 1, rate)
+    idx = np.arange(n_det, dtype=np.int32)
+    sflags_h = synth.shared_flags_block(n_samp, 0.01, value=1)
+
+    d_bore = torch.from_numpy(bore).to(dev)
+    d_sflags = torch.from_numpy(sflags_h).to(dev)
+    d_quats = torch.empty((n_det, n_samp, 4), dtype=torch.float64, device=dev)
+    d_pixels = torch.empty((n_det, n_samp), dtype=torch.int64, device=dev)
+    d_weights = torch.empty((n_det, n_samp, 3), dtype=torch.float64, device=dev)
+    d_hsub = torch.zeros(n_submap, dtype=torch.uint8, device=dev)
+
+    def timed(fn, reps=1):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    nsamp_tot = float(n_det) * n_samp
+    t_pd = timed(lambda: D.pointing_detector(fp, d_bore.data_ptr(), idx, d_quats.data_ptr(), n_samp, ivl,
+                                             d_sflags.data_ptr(), n_samp, 1, stream))
+    pix_call = lambda: D.pixels_healpix(idx, d_quats.data_ptr(), d_sflags.data_ptr(), n_samp, 1, idx,
+                                        d_pixels.data_ptr(), n_samp, ivl, d_hsub.data_ptr(), n_submap, nps,
+                                        nside, True, stream)
+    pix_call()
+    t_pix = timed(pix_call, 3)
+    sw_call = lambda: D.stokes_weights_IQU(idx, d_quats.data_ptr(), idx, d_weights.data_ptr(), n_samp, 0, 0, ivl,
+                                           np.zeros(n_det), gamma, np.ones(n_det), False, stream)
+    sw_call()
+    t_sw = timed(sw_call, 2)
+    del d_quats
+    torch.cuda.empty_cache()
+
+    # union of hit submaps over ranks -> one global2local for everybody
+    hs = d_hsub.to(torch.int32)
+    if world > 1:
+        dist.all_reduce(hs, op=dist.ReduceOp.MAX)
+    g2l_h, hit = synth.global_to_local(hs.cpu().numpy())
+    n_local = int(hit.size)
+    d_g2l = torch.from_numpy(g2l_h).to(dev)
+    d_zmap = torch.zeros((n_local, nps, nnz), dtype=torch.float64, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(20261001 + rank)
+    sigma = 50.0e-6 * np.sqrt(rate)
+    d_tod = torch.randn((n_det, n_samp), dtype=torch.float64, device=dev, generator=gen) * sigma
+    d_tod2 = torch.randn((n_det, n_samp), dtype=torch.float64, device=dev, generator=gen) * sigma
+    d_dflags = (torch.rand((n_det, n_samp), device=dev, generator=gen) < 0.005).to(torch.uint8)
+    # packed upper-triangle "covariance": diagonally dominant, O(1)
+    d_cov = torch.rand((n_local, nps, 6), dtype=torch.float64, device=dev, generator=gen) * 0.1
+    d_cov[..., 0] += 1.0
+    d_cov[..., 3] += 1.0
+    d_cov[..., 5] += 1.0
+    det_scale = np.full(n_det, 1.0 / (sigma * sigma))
+    det_w = np.linspace(0.5, 0.9, n_det)
+    torch.cuda.synchronize()
+    t_setup = time.time() - t_setup
+
+    # ------------------------------------------------------------------ one step
+    ev = {k: [] for k in ("bnw", "cov", "scan")}
+
+    def step(record):
+        d_zmap.zero_()
+        if record:
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+            e[0].record()
+        D.build_noise_weighted(d_g2l.data_ptr(), d_zmap.data_ptr(), nps, nnz, idx, d_pixels.data_ptr(), idx,
+                               d_weights.data_ptr(), idx, d_tod.data_ptr(), idx, d_dflags.data_ptr(), n_samp,
+                               det_scale, 1, n_samp, ivl, d_sflags.data_ptr(), n_samp, 1, stream)
+        if record:
+            e[1].record()
+        if world > 1:
+            dist.all_reduce(d_zmap)
+        if record:
+            e[2].record()
+        D.cov_apply_diag(n_local, nps, nnz, d_cov.data_ptr(), d_zmap.data_ptr(), stream)
+        if record:
+            e[3].record()
+            e[4].record()
+        if args.unfused:
+            D.scan_map(np.float64, d_g2l.data_ptr(), nps, d_zmap.data_ptr(), nnz, d_tod2.data_ptr(), idx,
+                       d_pixels.data_ptr(), idx, d_weights.data_ptr(), idx, n_samp, ivl, 1.0, False, True, False,
+                       None, stream)
+            D.noise_weight(d_tod2.data_ptr(), n_samp, idx, ivl, det_w, stream)
+        else:
+            D.scan_map(np.float64, d_g2l.data_ptr(), nps, d_zmap.data_ptr(), nnz, d_tod2.data_ptr(), idx,
+                       d_pixels.data_ptr(), idx, d_weights.data_ptr(), idx, n_samp, ivl, 1.0, False, True, False,
+                       det_w, stream)
+        if record:
+            e[5].record()
+            ev["bnw"].append((e[0], e[1]))
+            ev["cov"].append((e[2], e[3]))
+            ev["scan"].append((e[4], e[5]))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
+    value = world * nsamp_tot * args.steps / elapsed
+
+    # dominant kernel -> roofline entry (algorithmic bytes / measured launch duration)
+    scan_bytes = BYTES_SCAN if not args.unfused else BYTES_SCAN  # noise_weight timed inside "scan" if unfused
+    cand = {
+        "build_noise_weighted": (BYTES_BNW * nsamp_tot, ms["bnw"]),
+        "scan_map": ((scan_bytes + (16.0 if args.unfused else 0.0)) * nsamp_tot, ms["scan"]),
+    }
+    dom = max(cand, key=lambda k: cand[k][1])
+    ach = cand[dom][0] / (cand[dom][1] * 1e-3) / 1e9
+    roofline = {
+        "bound": "hbm",
+        "kernel": dom,
+        "achieved": ach,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": ach / HBM_PEAK_GBS,
+        "traffic": None,
+        "per_kernel_GBs": {k: cand[k][0] / (cand[k][1] * 1e-3) / 1e9 for k in cand},
+        "iteration_GBs": (BYTES_BNW + BYTES_SCAN) * nsamp_tot / ((ms["bnw"] + ms["scan"]) * 1e-3) / 1e9,
+    }
+
+    out = {
+        "metric": "detector-samples/sec through one PCG (A^T N^-1 A) iteration",
+        "value": value,
+        "unit": "det-samples/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": args.workload,
+            "detectors_per_gpu": n_det,
+            "samples_per_detector": n_samp,
+            "sample_rate_hz": rate,
+            "nside": nside,
+            "nnz": nnz,
+            "n_local_submap": n_local,
+            "noise_weight": "separate kernel" if args.unfused else "fused into scan_map",
+            "parallelism": "detector-sharded x%d, RCCL all-reduce of zmap per step" % world,
+        },
+        "roofline": roofline,
+        "kernel_ms": ms,
+        "expansion": {
+            "pointing_detector_Gsamp_s": nsamp_tot / t_pd / 1e6,
+            "pixels_healpix_Gsamp_s": nsamp_tot / t_pix / 1e6,
+            "pixels_healpix_GBs": 40.0 * nsamp_tot / t_pix / 1e6,
+            "stokes_weights_IQU_Gsamp_s": nsamp_tot / t_sw / 1e6,
+        },
+        "setup_s": t_setup,
+    }
+
+    # ------------------------------------------------------------------ CPU baseline (rank 0, N=1)
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        import oracle
+
+        nd = min(args.cpu_dets, n_det)
+        sub = slice(0, nd)
+        pix_h = d_pixels[sub].cpu().numpy()
+        w_h = d_weights[sub].cpu().numpy()
+        tod_h = d_tod[sub].cpu().numpy()
+        tod2_h = d_tod2[sub].cpu().numpy()
+        df_h = d_dflags[sub].cpu().numpy()
+        z_h = np.zeros((n_local, nps, nnz))
+        cov_h = d_cov.cpu().numpy()
+        idx_h = np.arange(nd, dtype=np.int32)
+        ds_h = np.ascontiguousarray(det_scale[:nd])
+        dw_h = np.ascontiguousarray(det_w[:nd])
+
+        def cpu_step():
+            z_h[:] = 0.0
+            oracle.build_noise_weighted(g2l_h, z_h, idx_h, pix_h, idx_h, w_h, idx_h, tod_h, idx_h, df_h, ds_h, 1,
+                                        ivl, sflags_h, 1)
+            oracle.scan_map(g2l_h, nps, z_h, tod2_h, idx_h, pix_h, idx_h, w_h, idx_h, ivl, 1.0, False, True, False)
+            oracle.noise_weight(tod2_h, idx_h, ivl, dw_h)
+
+        cpu_step()  # warm (page-touch)
+        t0 = time.perf_counter()
+        reps = 0
+        while True:
+            cpu_step()
+            reps += 1
+            if time.perf_counter() - t0 > 10.0 or reps >= 5:
+                break
+        cpu_t = (time.perf_counter() - t0) / reps
+        out["cpu_baseline"] = {
+            "value": nd * n_samp / cpu_t,
+            "unit": "det-samples/s",
+            "cores": oracle.num_threads(),
+            "kind": "port",
+            "sample": "%d of the %d detectors x %d samples of the same workload; build_noise_weighted + "
+                      "scan_map(subtract) + noise_weight with the reference's host parallelisation "
+                      "(cov_apply_diag excluded: map sized)" % (nd, n_det, n_samp),
+        }
+        del cov_h
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

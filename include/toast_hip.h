@@ -1,0 +1,311 @@
+/* toast_hip.h -- C ABI of the MI355X-native TOAST map-making hot path (libtoast_hip.so).
+ *
+ * This is the drop-in boundary: every entry point replaces one binding of the reference's
+ * pybind11 extension `toast._libtoast` (or one method of its OpenMP-target memory manager)
+ * and is cited below as  [ref: <file>:<line>]  with paths relative to
+ * /root/reference/src/toast/_libtoast/.  Plain pointers and sizes only; no C++ or torch
+ * types.  INTEGRATION.md shows the reference-side binding a TOAST maintainer would add.
+ *
+ * Two levels:
+ *
+ *   toast_hip_<kernel>(..., int use_accel)
+ *       Same arguments, same meaning and same validation rules as the reference binding:
+ *       all pointers are HOST pointers.  With use_accel != 0 the large arrays must have been
+ *       registered with toast_hip_accel_create() + toast_hip_accel_update_device() (exactly
+ *       like OmpManager) and the kernel runs on their device copies, asynchronously on the
+ *       library stream.  With use_accel == 0 the buffers are staged to the GPU, processed
+ *       and copied back before the call returns.  There is no CPU implementation in this
+ *       library: without a usable gfx950 device every call fails (return code != 0).
+ *
+ *   toast_hip_<kernel>_dev(..., void *stream)
+ *       Large arrays are DEVICE pointers (hipMalloc'd by the caller, e.g. torch tensors);
+ *       small per-call arrays (index arrays, intervals, per-detector scalars) remain host
+ *       pointers and are packed into one cached parameter block.  Asynchronous on `stream`
+ *       (a hipStream_t, NULL = default stream).
+ *
+ * "Optional" arrays follow the reference convention: an array whose length differs from
+ * n_samp is treated as absent (ops_pixels_healpix.cpp:1204-1211,
+ * ops_mapmaker_utils.cpp:181-197).
+ *
+ * Error handling: every function returns 0 on success and a nonzero code on failure;
+ * toast_hip_last_error() returns the message (thread local).  The reference throws
+ * std::runtime_error with the same text where one exists.
+ */
+#ifndef TOAST_HIP_H
+#define TOAST_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TOAST_HIP_OK 0
+#define TOAST_HIP_ERR_ARG 1      /* invalid argument / shape */
+#define TOAST_HIP_ERR_DEVICE 2   /* no device, HIP runtime error */
+#define TOAST_HIP_ERR_MEMORY 3   /* memory manager: not present / already present / size */
+
+/* Sample interval, 32 bytes.  The kernels process first <= isamp < last.
+ * [ref: intervals.hpp:10-15; dtype intervals.cpp:11-38] */
+typedef struct toast_hip_interval {
+    double start;
+    double stop;
+    int64_t first;
+    int64_t last;
+} toast_hip_interval;
+
+const char * toast_hip_last_error(void);
+const char * toast_hip_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Device selection and the host-pointer -> device-pointer memory manager
+ * [ref: accelerator.hpp:73-159 (class OmpManager), accelerator.cpp:233-766, Python
+ *  bindings accelerator.cpp:768-1110]
+ * ---------------------------------------------------------------------------------- */
+
+/* Number of usable HIP devices > 0.  [ref: accelerator.cpp:770-779 accel_enabled] */
+int toast_hip_accel_enabled(void);
+
+/* Pick this process's GPU: device = node_rank / ceil(node_procs / n_device).  `disabled`
+ * != 0 refuses all later use_accel work.  Clears previously registered buffers.
+ * [ref: accelerator.cpp:233-306 assign_device] */
+int toast_hip_accel_assign_device(int node_procs, int node_rank, double mem_gb, int disabled);
+
+/* Assigned device id (-1 = disabled).  Error if assign_device was never called.
+ * [ref: accelerator.cpp:308-317 get_device] */
+int toast_hip_accel_get_device(int * device);
+
+/* *present = 1 if `host` is registered.  Error if registered with a different size.
+ * [ref: accelerator.cpp:656-695 present] */
+int toast_hip_accel_present(const void * host, size_t nbytes, int * present);
+
+/* Allocate a device buffer of nbytes keyed by the host base pointer.  Error if the key is
+ * already present.  [ref: accelerator.cpp:327-388 create] */
+int toast_hip_accel_create(const void * host, size_t nbytes, const char * name);
+
+/* Zero the device copy.  [ref: accelerator.cpp:593-654 reset] */
+int toast_hip_accel_reset(const void * host, size_t nbytes, const char * name);
+
+/* Host -> device copy of the whole buffer.  [ref: accelerator.cpp:459-522 update_device] */
+int toast_hip_accel_update_device(const void * host, size_t nbytes, const char * name);
+
+/* Device -> host copy of the whole buffer; returns after the data is on the host.
+ * [ref: accelerator.cpp:524-591 update_host] */
+int toast_hip_accel_update_host(void * host, size_t nbytes, const char * name);
+
+/* Free the device copy.  [ref: accelerator.cpp:390-457 remove] */
+int toast_hip_accel_delete(const void * host, size_t nbytes, const char * name);
+
+/* Device pointer of a registered host buffer (error if absent).
+ * [ref: accelerator.hpp:115-143 device_ptr] */
+int toast_hip_accel_device_ptr(const void * host, void ** device);
+
+/* Print the table of registered buffers.  [ref: accelerator.cpp:697-720 dump] */
+int toast_hip_accel_dump(void);
+
+/* Stream used by the host-pointer level (hipStream_t; NULL = default stream). */
+int toast_hip_set_stream(void * stream);
+/* Block until all work queued by this library on its stream has finished. */
+int toast_hip_synchronize(void);
+
+/* ------------------------------------------------------------------------------------
+ * pointing_detector: quats[q_idx[d], s, :] = (flagged ? identity : boresight[s]) * fp[d]
+ * [ref: ops_pointing_detector.cpp:78-227]
+ *   focalplane f64[n_det,4]; boresight f64[n_samp,4]; quat_index i32[n_det];
+ *   quats f64[*,n_samp,4]; shared_flags u8[n_flags] (used iff n_flags == n_samp)
+ * ---------------------------------------------------------------------------------- */
+int toast_hip_pointing_detector(
+    const double * focalplane, const double * boresight, const int32_t * quat_index,
+    int64_t n_det, double * quats, int64_t n_quat_rows, int64_t n_samp,
+    const toast_hip_interval * intervals, int64_t n_view,
+    const uint8_t * shared_flags, int64_t n_flags, uint8_t shared_flag_mask, int use_accel);
+
+int toast_hip_pointing_detector_dev(
+    const double * focalplane /*host*/, const double * d_boresight, const int32_t * quat_index /*host*/,
+    int64_t n_det, double * d_quats, int64_t n_samp,
+    const toast_hip_interval * intervals /*host*/, int64_t n_view,
+    const uint8_t * d_shared_flags, int64_t n_flags, uint8_t shared_flag_mask, void * stream);
+
+/* ------------------------------------------------------------------------------------
+ * pixels_healpix: detector quaternions -> HEALPix pixel index (NEST or RING); flagged
+ * samples get -1; hit_submaps[pix / n_pix_submap] |= 1 for unflagged samples.
+ * [ref: ops_pixels_healpix.cpp:1153-1417; per-sample math :44-276, :586-666]
+ *   quats f64[*,n_samp,4]; pixels i64[*,n_samp]; hit_submaps u8[n_submap] (host, in/out)
+ * ---------------------------------------------------------------------------------- */
+int toast_hip_pixels_healpix(
+    const int32_t * quat_index, int64_t n_det, const double * quats, int64_t n_quat_rows,
+    const uint8_t * shared_flags, int64_t n_flags, uint8_t shared_flag_mask,
+    const int32_t * pixel_index, int64_t * pixels, int64_t n_pixel_rows, int64_t n_samp,
+    const toast_hip_interval * intervals, int64_t n_view,
+    uint8_t * hit_submaps, int64_t n_submap, int64_t n_pix_submap, int64_t nside, int nest,
+    int use_accel);
+
+/* d_hit_submaps is a device array here (u8[n_submap], OR-ed in place). */
+int toast_hip_pixels_healpix_dev(
+    const int32_t * quat_index /*host*/, int64_t n_det, const double * d_quats,
+    const uint8_t * d_shared_flags, int64_t n_flags, uint8_t shared_flag_mask,
+    const int32_t * pixel_index /*host*/, int64_t * d_pixels, int64_t n_samp,
+    const toast_hip_interval * intervals /*host*/, int64_t n_view,
+    uint8_t * d_hit_submaps, int64_t n_submap, int64_t n_pix_submap, int64_t nside, int nest,
+    void * stream);
+
+/* ------------------------------------------------------------------------------------
+ * stokes_weights_IQU / _I
+ * [ref: ops_stokes_weights.cpp:151-396 (IQU), :398-506 (I); per-sample :50-140]
+ *   weights f64[*,n_samp,3] (IQU) or f64[n_det,n_samp] (I); hwp f64[n_hwp] used iff
+ *   n_hwp == n_samp; epsilon, gamma, cal f64[n_det]
+ * ---------------------------------------------------------------------------------- */
+int toast_hip_stokes_weights_IQU(
+    const int32_t * quat_index, int64_t n_det, const double * quats, int64_t n_quat_rows,
+    const int32_t * weight_index, double * weights, int64_t n_weight_rows, int64_t n_samp,
+    const double * hwp, int64_t n_hwp, const toast_hip_interval * intervals, int64_t n_view,
+    const double * epsilon, const double * gamma, const double * cal, int iau, int use_accel);
+
+int toast_hip_stokes_weights_IQU_dev(
+    const int32_t * quat_index /*host*/, int64_t n_det, const double * d_quats,
+    const int32_t * weight_index /*host*/, double * d_weights, int64_t n_samp,
+    const double * d_hwp, int64_t n_hwp, const toast_hip_interval * intervals /*host*/,
+    int64_t n_view, const double * epsilon /*host*/, const double * gamma /*host*/,
+    const double * cal /*host*/, int iau, void * stream);
+
+int toast_hip_stokes_weights_I(
+    const int32_t * weight_index, int64_t n_det, double * weights, int64_t n_weight_rows,
+    int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view, const double * cal,
+    int use_accel);
+
+int toast_hip_stokes_weights_I_dev(
+    const int32_t * weight_index /*host*/, int64_t n_det, double * d_weights, int64_t n_samp,
+    const toast_hip_interval * intervals /*host*/, int64_t n_view, const double * cal /*host*/,
+    void * stream);
+
+/* ------------------------------------------------------------------------------------
+ * scan_map (the A of A^T N^-1 A):
+ *   tod[d,s] (=0 if should_zero) {+=, -=, *=} data_scale * sum_k w[d,s,k] * map[g2l[p / nps], p % nps, k]
+ * for pixels p >= 0.   map_dtype selects the reference instantiation.
+ * [ref: ops_scan_map.cpp:84-292 (ops_scan_map_float64/float32/int64/int32); per-sample :15-78]
+ * ---------------------------------------------------------------------------------- */
+#define TOAST_HIP_MAP_F64 0
+#define TOAST_HIP_MAP_F32 1
+#define TOAST_HIP_MAP_I64 2
+#define TOAST_HIP_MAP_I32 3
+
+int toast_hip_scan_map(
+    int map_dtype, const int64_t * global2local, int64_t n_submap, int64_t n_pix_submap,
+    const void * mapdata, int64_t n_local_submap, int64_t nnz,
+    double * det_data, int64_t n_data_rows, const int32_t * data_index,
+    const int64_t * pixels, int64_t n_pixel_rows, const int32_t * pixel_index,
+    const double * weights, int64_t n_weight_rows, const int32_t * weight_index,
+    int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
+    double data_scale, int should_zero, int should_subtract, int should_scale, int use_accel);
+
+/* det_weights (host, f64[n_det]) may be NULL; when given, the kernel also applies the
+ * diagonal noise weight  tod *= det_weights[d]  after the scan (fused ScanMap + NoiseWeight,
+ * the PCG's proj_pipe: src/toast/ops/mapmaker_solve.py:470-498). */
+int toast_hip_scan_map_dev(
+    int map_dtype, const int64_t * d_global2local, int64_t n_pix_submap, const void * d_mapdata,
+    int64_t nnz, double * d_det_data, const int32_t * data_index /*host*/,
+    const int64_t * d_pixels, const int32_t * pixel_index /*host*/,
+    const double * d_weights, const int32_t * weight_index /*host*/,
+    int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals /*host*/, int64_t n_view,
+    double data_scale, int should_zero, int should_subtract, int should_scale,
+    const double * det_weights /*host or NULL*/, void * stream);
+
+/* ------------------------------------------------------------------------------------
+ * build_noise_weighted (the A^T N^-1 of A^T N^-1 A):
+ *   zmap[g2l[p / nps], p % nps, k] += tod[d,s] * det_scale[d] * w[d,s,k]
+ * for p >= 0 and unflagged samples.  [ref: ops_mapmaker_utils.cpp:93-380; per-sample :15-86]
+ *   det_flags u8[*,n_flag_samp] used iff n_flag_samp == n_samp; shared_flags likewise.
+ * ---------------------------------------------------------------------------------- */
+int toast_hip_build_noise_weighted(
+    const int64_t * global2local, int64_t n_submap, double * zmap, int64_t n_local_submap,
+    int64_t n_pix_submap, int64_t nnz,
+    const int32_t * pixel_index, const int64_t * pixels, int64_t n_pixel_rows,
+    const int32_t * weight_index, const double * weights, int64_t n_weight_rows,
+    const int32_t * data_index, const double * det_data, int64_t n_data_rows,
+    const int32_t * flag_index, const uint8_t * det_flags, int64_t n_flag_rows, int64_t n_flag_samp,
+    const double * det_scale, uint8_t det_flag_mask,
+    int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
+    const uint8_t * shared_flags, int64_t n_shared_flags, uint8_t shared_flag_mask, int use_accel);
+
+int toast_hip_build_noise_weighted_dev(
+    const int64_t * d_global2local, double * d_zmap, int64_t n_pix_submap, int64_t nnz,
+    const int32_t * pixel_index /*host*/, const int64_t * d_pixels,
+    const int32_t * weight_index /*host*/, const double * d_weights,
+    const int32_t * data_index /*host*/, const double * d_det_data,
+    const int32_t * flag_index /*host*/, const uint8_t * d_det_flags, int64_t n_flag_samp,
+    const double * det_scale /*host*/, uint8_t det_flag_mask,
+    int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals /*host*/, int64_t n_view,
+    const uint8_t * d_shared_flags, int64_t n_shared_flags, uint8_t shared_flag_mask, void * stream);
+
+/* ------------------------------------------------------------------------------------
+ * noise_weight: tod[d_idx[d], s] *= detector_weights[d]   [ref: ops_noise_weight.cpp:11-119]
+ * ---------------------------------------------------------------------------------- */
+int toast_hip_noise_weight(
+    double * det_data, int64_t n_data_rows, int64_t n_samp, const int32_t * data_index, int64_t n_det,
+    const toast_hip_interval * intervals, int64_t n_view, const double * detector_weights,
+    int use_accel);
+
+int toast_hip_noise_weight_dev(
+    double * d_det_data, int64_t n_samp, const int32_t * data_index /*host*/, int64_t n_det,
+    const toast_hip_interval * intervals /*host*/, int64_t n_view,
+    const double * detector_weights /*host*/, void * stream);
+
+/* ------------------------------------------------------------------------------------
+ * cov_apply_diag: per pixel, vec <- Sym(mat) vec with mat the packed upper triangle
+ * (nnz (nnz+1)/2 values).  [ref: /root/reference/src/libtoast/src/toast_map_cov.cpp:471-528,
+ * called by covariance_apply, src/toast/covariance.py:262-306]
+ * ---------------------------------------------------------------------------------- */
+int toast_hip_cov_apply_diag(int64_t n_sub, int64_t subsize, int64_t nnz, const double * mat,
+                             double * vec, int use_accel);
+int toast_hip_cov_apply_diag_dev(int64_t n_sub, int64_t subsize, int64_t nnz, const double * d_mat,
+                                 double * d_vec, void * stream);
+
+/* ------------------------------------------------------------------------------------
+ * Offset template (the M and M^T of every PCG iteration)
+ * [ref: template_offset.cpp:16-147 add_to_signal, :149-332 project_signal,
+ *  :334-408 apply_diag_precond]
+ * ---------------------------------------------------------------------------------- */
+int toast_hip_template_offset_add_to_signal(
+    int64_t step_length, int64_t amp_offset, const int64_t * n_amp_views,
+    const double * amplitudes, const uint8_t * amplitude_flags, int64_t n_amp,
+    int32_t data_index, double * det_data, int64_t n_data_rows, int64_t n_samp,
+    const toast_hip_interval * intervals, int64_t n_view, int use_accel);
+
+int toast_hip_template_offset_add_to_signal_dev(
+    int64_t step_length, int64_t amp_offset, const int64_t * n_amp_views /*host*/,
+    const double * d_amplitudes, const uint8_t * d_amplitude_flags,
+    int32_t data_index, double * d_det_data, int64_t n_samp,
+    const toast_hip_interval * intervals /*host*/, int64_t n_view, void * stream);
+
+int toast_hip_template_offset_project_signal(
+    int32_t data_index, const double * det_data, int64_t n_data_rows,
+    int32_t flag_index, const uint8_t * flag_data, int64_t n_flag_rows, uint8_t flag_mask,
+    int64_t step_length, int64_t amp_offset, const int64_t * n_amp_views,
+    double * amplitudes, const uint8_t * amplitude_flags, int64_t n_amp, int64_t n_samp,
+    const toast_hip_interval * intervals, int64_t n_view, int use_accel);
+
+int toast_hip_template_offset_project_signal_dev(
+    int32_t data_index, const double * d_det_data, int32_t flag_index, const uint8_t * d_flag_data,
+    uint8_t flag_mask, int64_t step_length, int64_t amp_offset, const int64_t * n_amp_views /*host*/,
+    double * d_amplitudes, const uint8_t * d_amplitude_flags, int64_t n_samp,
+    const toast_hip_interval * intervals /*host*/, int64_t n_view, void * stream);
+
+int toast_hip_template_offset_apply_diag_precond(
+    const double * offset_var, const double * amp_in, const uint8_t * amplitude_flags,
+    double * amp_out, int64_t n_amp, int use_accel);
+
+int toast_hip_template_offset_apply_diag_precond_dev(
+    const double * d_offset_var, const double * d_amp_in, const uint8_t * d_amplitude_flags,
+    double * d_amp_out, int64_t n_amp, void * stream);
+
+/* ------------------------------------------------------------------------------------
+ * Test / measurement helpers (device primitives compared per operation with the CPU).
+ * ---------------------------------------------------------------------------------- */
+int toast_hip_test_math_dev(int op /*0 atan2(a,b), 1 sqrt(a), 2 a/b*/, int64_t n, const double * d_a,
+                            const double * d_b, double * d_out, void * stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TOAST_HIP_H */

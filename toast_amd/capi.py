@@ -1,0 +1,487 @@
+"""ctypes view of the C ABI in ``include/toast_hip.h`` (``toast_amd/libtoast_hip.so``).
+
+Two groups of callables:
+
+* ``pixels_healpix(...)``, ``ops_scan_map_float64(...)``, ``build_noise_weighted(...)`` ... take
+  NumPy arrays in exactly the argument order of the reference's ``toast._libtoast`` bindings
+  (including the trailing ``use_accel``) and call the host-pointer level
+  entry points.  Buffer validation mirrors ``extract_buffer``
+  (reference: src/toast/_libtoast/common.hpp:32-124).
+* ``dev.<kernel>(...)`` take raw device pointers (``int``; e.g. ``tensor.data_ptr()``) for the
+  large arrays and NumPy arrays for the small per-call ones.
+
+There is no CPU fallback: if the library is missing or no gfx950 device is usable, calls raise.
+"""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtoast_hip.so")
+
+interval_dtype = np.dtype(
+    {
+        "names": ["start", "stop", "first", "last"],
+        "formats": ["d", "d", "q", "q"],
+        "offsets": [0, 8, 16, 24],
+    }
+)
+
+MAP_F64, MAP_F32, MAP_I64, MAP_I32 = 0, 1, 2, 3
+_MAP_CODES = {
+    np.dtype(np.float64): MAP_F64,
+    np.dtype(np.float32): MAP_F32,
+    np.dtype(np.int64): MAP_I64,
+    np.dtype(np.int32): MAP_I32,
+}
+
+_lib = None
+
+
+def lib():
+    """Load libtoast_hip.so (raises if it has not been built: no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -m toast_amd.build` "
+                "(the HIP library is the only implementation of this path)"
+            )
+        _lib = C.CDLL(LIB_PATH)
+        _lib.toast_hip_last_error.restype = C.c_char_p
+        _lib.toast_hip_version.restype = C.c_char_p
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError(lib().toast_hip_last_error().decode())
+
+
+# --------------------------------------------------------------------------- argument helpers
+def _buf(a, name, dtype, ndim, shape=None):
+    """extract_buffer-style validation; returns the array (common.hpp:50-121)."""
+    if not isinstance(a, np.ndarray):
+        raise RuntimeError(f"Object {name} is not a NumPy array")
+    if a.dtype != dtype:
+        raise RuntimeError(f"Object {name} has dtype {a.dtype}, expected {np.dtype(dtype)}")
+    if a.ndim != ndim:
+        raise RuntimeError(f"Object {name} has {a.ndim} dimensions instead of {ndim}")
+    if not a.flags["C_CONTIGUOUS"]:
+        raise RuntimeError(f"Object {name} is not contiguous.")
+    if shape is not None:
+        for i, (got, want) in enumerate(zip(a.shape, shape)):
+            if want >= 0 and got != want:
+                raise RuntimeError(f"Object {name} dimension {i} has length {got} instead of {want}")
+    return a
+
+
+def _p(a):
+    if a is None:
+        return C.c_void_p(0)
+    if isinstance(a, np.ndarray):
+        return C.c_void_p(a.ctypes.data)
+    return C.c_void_p(int(a))
+
+
+def _i64(x):
+    return C.c_int64(int(x))
+
+
+def _u8(x):
+    return C.c_uint8(int(x))
+
+
+def _int(x):
+    return C.c_int(int(bool(x)))
+
+
+# --------------------------------------------------------------------------- memory manager
+def accel_enabled():
+    return bool(lib().toast_hip_accel_enabled())
+
+
+def accel_assign_device(node_procs, node_rank, mem_gb, disabled):
+    _check(lib().toast_hip_accel_assign_device(int(node_procs), int(node_rank), C.c_double(mem_gb), _int(disabled)))
+
+
+def accel_get_device():
+    d = C.c_int(0)
+    _check(lib().toast_hip_accel_get_device(C.byref(d)))
+    return d.value
+
+
+def _raw(buf):
+    a = np.asarray(buf)
+    if not a.flags["C_CONTIGUOUS"]:
+        raise RuntimeError("accel_* buffers must be contiguous")
+    return a
+
+
+def accel_present(buf, name="NA"):
+    a = _raw(buf)
+    r = C.c_int(0)
+    _check(lib().toast_hip_accel_present(_p(a), C.c_size_t(a.nbytes), C.byref(r)))
+    return bool(r.value)
+
+
+def accel_create(buf, name="NA"):
+    a = _raw(buf)
+    _check(lib().toast_hip_accel_create(_p(a), C.c_size_t(a.nbytes), name.encode()))
+
+
+def accel_reset(buf, name="NA"):
+    a = _raw(buf)
+    _check(lib().toast_hip_accel_reset(_p(a), C.c_size_t(a.nbytes), name.encode()))
+
+
+def accel_update_device(buf, name="NA"):
+    a = _raw(buf)
+    _check(lib().toast_hip_accel_update_device(_p(a), C.c_size_t(a.nbytes), name.encode()))
+
+
+def accel_update_host(buf, name="NA"):
+    a = _raw(buf)
+    _check(lib().toast_hip_accel_update_host(_p(a), C.c_size_t(a.nbytes), name.encode()))
+
+
+def accel_delete(buf, name="NA"):
+    a = _raw(buf)
+    _check(lib().toast_hip_accel_delete(_p(a), C.c_size_t(a.nbytes), name.encode()))
+
+
+def accel_device_ptr(buf):
+    a = _raw(buf)
+    out = C.c_void_p(0)
+    _check(lib().toast_hip_accel_device_ptr(_p(a), C.byref(out)))
+    return out.value
+
+
+def accel_dump():
+    _check(lib().toast_hip_accel_dump())
+
+
+def set_stream(stream):
+    _check(lib().toast_hip_set_stream(C.c_void_p(int(stream))))
+
+
+def synchronize():
+    _check(lib().toast_hip_synchronize())
+
+
+# --------------------------------------------------------------------------- host-pointer level
+def pointing_detector(focalplane, boresight, quat_index, quats, intervals, shared_flags,
+                      shared_flag_mask, use_accel=False):
+    qi = _buf(quat_index, "quat_index", np.int32, 1)
+    n_det = qi.shape[0]
+    fp = _buf(focalplane, "focalplane", np.float64, 2, (n_det, 4))
+    bore = _buf(boresight, "boresight", np.float64, 2, (-1, 4))
+    n_samp = bore.shape[0]
+    q = _buf(quats, "quats", np.float64, 3, (-1, n_samp, 4))
+    iv = _buf(intervals, "intervals", interval_dtype, 1)
+    fl = _buf(shared_flags, "flags", np.uint8, 1)
+    _check(lib().toast_hip_pointing_detector(
+        _p(fp), _p(bore), _p(qi), _i64(n_det), _p(q), _i64(q.shape[0]), _i64(n_samp), _p(iv),
+        _i64(iv.shape[0]), _p(fl), _i64(fl.shape[0]), _u8(shared_flag_mask), _int(use_accel)))
+
+
+def pixels_healpix(quat_index, quats, shared_flags, shared_flag_mask, pixel_index, pixels, intervals,
+                   hit_submaps, n_pix_submap, nside, nest, use_accel=False):
+    qi = _buf(quat_index, "quat_index", np.int32, 1)
+    n_det = qi.shape[0]
+    pi = _buf(pixel_index, "pixel_index", np.int32, 1, (n_det,))
+    px = _buf(pixels, "pixels", np.int64, 2)
+    n_samp = px.shape[1]
+    q = _buf(quats, "quats", np.float64, 3, (-1, n_samp, 4))
+    iv = _buf(intervals, "intervals", interval_dtype, 1)
+    hs = _buf(hit_submaps, "hit_submaps", np.uint8, 1)
+    fl = _buf(shared_flags, "flags", np.uint8, 1)
+    _check(lib().toast_hip_pixels_healpix(
+        _p(qi), _i64(n_det), _p(q), _i64(q.shape[0]), _p(fl), _i64(fl.shape[0]), _u8(shared_flag_mask),
+        _p(pi), _p(px), _i64(px.shape[0]), _i64(n_samp), _p(iv), _i64(iv.shape[0]), _p(hs),
+        _i64(hs.shape[0]), _i64(n_pix_submap), _i64(nside), _int(nest), _int(use_accel)))
+
+
+def stokes_weights_IQU(quat_index, quats, weight_index, weights, hwp, intervals, epsilon, gamma, cal,
+                       IAU, use_accel=False):
+    qi = _buf(quat_index, "quat_index", np.int32, 1)
+    n_det = qi.shape[0]
+    wi = _buf(weight_index, "weight_index", np.int32, 1, (n_det,))
+    w = _buf(weights, "weights", np.float64, 3, (-1, -1, 3))
+    n_samp = w.shape[1]
+    q = _buf(quats, "quats", np.float64, 3, (-1, n_samp, 4))
+    h = _buf(hwp, "hwp", np.float64, 1)
+    iv = _buf(intervals, "intervals", interval_dtype, 1)
+    e = _buf(epsilon, "epsilon", np.float64, 1, (n_det,))
+    cl = _buf(cal, "cal", np.float64, 1, (n_det,))
+    g = _buf(gamma, "gamma", np.float64, 1, (n_det,))
+    _check(lib().toast_hip_stokes_weights_IQU(
+        _p(qi), _i64(n_det), _p(q), _i64(q.shape[0]), _p(wi), _p(w), _i64(w.shape[0]), _i64(n_samp),
+        _p(h), _i64(h.shape[0]), _p(iv), _i64(iv.shape[0]), _p(e), _p(g), _p(cl), _int(IAU),
+        _int(use_accel)))
+
+
+def stokes_weights_I(weight_index, weights, intervals, cal, use_accel=False):
+    wi = _buf(weight_index, "weight_index", np.int32, 1)
+    n_det = wi.shape[0]
+    w = _buf(weights, "weights", np.float64, 2, (n_det, -1))
+    iv = _buf(intervals, "intervals", interval_dtype, 1)
+    cl = _buf(cal, "cal", np.float64, 1, (n_det,))
+    _check(lib().toast_hip_stokes_weights_I(
+        _p(wi), _i64(n_det), _p(w), _i64(w.shape[0]), _i64(w.shape[1]), _p(iv), _i64(iv.shape[0]),
+        _p(cl), _int(use_accel)))
+
+
+def _weights_nnz(weights, n_samp):
+    if not isinstance(weights, np.ndarray):
+        raise RuntimeError("Object weights is not a NumPy array")
+    if weights.ndim == 2:
+        return _buf(weights, "weights", np.float64, 2, (-1, n_samp)), 1
+    w = _buf(weights, "weights", np.float64, 3, (-1, n_samp, -1))
+    return w, w.shape[2]
+
+
+def _scan_map(map_dtype, global2local, n_pix_submap, mapdata, det_data, data_index, pixels, pixel_index,
+              weights, weight_index, intervals, data_scale, should_zero, should_subtract, should_scale,
+              use_accel):
+    pi = _buf(pixel_index, "pixel_index", np.int32, 1)
+    n_det = pi.shape[0]
+    px = _buf(pixels, "pixels", np.int64, 2)
+    n_samp = px.shape[1]
+    wi = _buf(weight_index, "weight_index", np.int32, 1, (n_det,))
+    w, nnz = _weights_nnz(weights, n_samp)
+    di = _buf(data_index, "data_index", np.int32, 1, (n_det,))
+    dd = _buf(det_data, "det_data", np.float64, 2, (-1, n_samp))
+    iv = _buf(intervals, "intervals", interval_dtype, 1)
+    g2l = _buf(global2local, "global2local", np.int64, 1)
+    m = _buf(mapdata, "mapdata", map_dtype, 3, (-1, n_pix_submap, nnz))
+    _check(lib().toast_hip_scan_map(
+        C.c_int(_MAP_CODES[np.dtype(map_dtype)]), _p(g2l), _i64(g2l.shape[0]), _i64(n_pix_submap), _p(m),
+        _i64(m.shape[0]), _i64(nnz), _p(dd), _i64(dd.shape[0]), _p(di), _p(px), _i64(px.shape[0]), _p(pi),
+        _p(w), _i64(w.shape[0]), _p(wi), _i64(n_det), _i64(n_samp), _p(iv), _i64(iv.shape[0]),
+        C.c_double(data_scale), _int(should_zero), _int(should_subtract), _int(should_scale),
+        _int(use_accel)))
+
+
+def ops_scan_map_float64(*args):
+    return _scan_map(np.float64, *args)
+
+
+def ops_scan_map_float32(*args):
+    return _scan_map(np.float32, *args)
+
+
+def ops_scan_map_int64(*args):
+    return _scan_map(np.int64, *args)
+
+
+def ops_scan_map_int32(*args):
+    return _scan_map(np.int32, *args)
+
+
+def build_noise_weighted(global2local, zmap, pixel_index, pixels, weight_index, weights, data_index,
+                         det_data, flag_index, det_flags, det_scale, det_flag_mask, intervals,
+                         shared_flags, shared_flag_mask, use_accel=False):
+    pi = _buf(pixel_index, "pixel_index", np.int32, 1)
+    n_det = pi.shape[0]
+    px = _buf(pixels, "pixels", np.int64, 2)
+    n_samp = px.shape[1]
+    wi = _buf(weight_index, "weight_index", np.int32, 1, (n_det,))
+    w, nnz = _weights_nnz(weights, n_samp)
+    di = _buf(data_index, "data_index", np.int32, 1, (n_det,))
+    dd = _buf(det_data, "det_data", np.float64, 2, (-1, n_samp))
+    fi = _buf(flag_index, "flag_index", np.int32, 1, (n_det,))
+    ds = _buf(det_scale, "det_scale", np.float64, 1, (n_det,))
+    iv = _buf(intervals, "intervals", interval_dtype, 1)
+    g2l = _buf(global2local, "global2local", np.int64, 1)
+    z = _buf(zmap, "zmap", np.float64, 3, (-1, -1, nnz))
+    sf = _buf(shared_flags, "flags", np.uint8, 1)
+    df = _buf(det_flags, "det_flags", np.uint8, 2)
+    _check(lib().toast_hip_build_noise_weighted(
+        _p(g2l), _i64(g2l.shape[0]), _p(z), _i64(z.shape[0]), _i64(z.shape[1]), _i64(nnz), _p(pi), _p(px),
+        _i64(px.shape[0]), _p(wi), _p(w), _i64(w.shape[0]), _p(di), _p(dd), _i64(dd.shape[0]), _p(fi),
+        _p(df), _i64(df.shape[0]), _i64(df.shape[1]), _p(ds), _u8(det_flag_mask), _i64(n_det),
+        _i64(n_samp), _p(iv), _i64(iv.shape[0]), _p(sf), _i64(sf.shape[0]), _u8(shared_flag_mask),
+        _int(use_accel)))
+
+
+def noise_weight(det_data, data_index, intervals, detector_weights, use_accel=False):
+    di = _buf(data_index, "data_index", np.int32, 1)
+    n_det = di.shape[0]
+    dd = _buf(det_data, "det_data", np.float64, 2)
+    iv = _buf(intervals, "intervals", interval_dtype, 1)
+    dw = _buf(detector_weights, "detector_weights", np.float64, 1, (n_det,))
+    _check(lib().toast_hip_noise_weight(
+        _p(dd), _i64(dd.shape[0]), _i64(dd.shape[1]), _p(di), _i64(n_det), _p(iv), _i64(iv.shape[0]),
+        _p(dw), _int(use_accel)))
+
+
+def cov_apply_diag(nsub, subsize, nnz, mat, vec, use_accel=False):
+    m = np.asarray(mat)
+    v = np.asarray(vec)
+    if m.dtype != np.float64 or v.dtype != np.float64:
+        raise RuntimeError("cov_apply_diag needs float64 buffers")
+    _check(lib().toast_hip_cov_apply_diag(_i64(nsub), _i64(subsize), _i64(nnz), _p(m), _p(v), _int(use_accel)))
+
+
+def template_offset_add_to_signal(step_length, amp_offset, n_amp_views, amplitudes, amplitude_flags,
+                                  data_index, det_data, intervals, use_accel=False):
+    a = _buf(amplitudes, "amplitudes", np.float64, 1)
+    af = _buf(amplitude_flags, "amplitude_flags", np.uint8, 1, (a.shape[0],))
+    dd = _buf(det_data, "det_data", np.float64, 2)
+    iv = _buf(intervals, "intervals", interval_dtype, 1)
+    nv = _buf(n_amp_views, "n_amp_views", np.int64, 1, (iv.shape[0],))
+    _check(lib().toast_hip_template_offset_add_to_signal(
+        _i64(step_length), _i64(amp_offset), _p(nv), _p(a), _p(af), _i64(a.shape[0]),
+        C.c_int32(int(data_index)), _p(dd), _i64(dd.shape[0]), _i64(dd.shape[1]), _p(iv),
+        _i64(iv.shape[0]), _int(use_accel)))
+
+
+def template_offset_project_signal(data_index, det_data, flag_index, flag_data, flag_mask, step_length,
+                                   amp_offset, n_amp_views, amplitudes, amplitude_flags, intervals,
+                                   use_accel=False):
+    a = _buf(amplitudes, "amplitudes", np.float64, 1)
+    af = _buf(amplitude_flags, "amplitude_flags", np.uint8, 1, (a.shape[0],))
+    dd = _buf(det_data, "det_data", np.float64, 2)
+    n_samp = dd.shape[1]
+    iv = _buf(intervals, "intervals", interval_dtype, 1)
+    nv = _buf(n_amp_views, "n_amp_views", np.int64, 1, (iv.shape[0],))
+    n_flag_rows = 0
+    fd = None
+    if int(flag_index) >= 0:
+        fd = _buf(flag_data, "flag_data", np.uint8, 2, (-1, n_samp))
+        n_flag_rows = fd.shape[0]
+    _check(lib().toast_hip_template_offset_project_signal(
+        C.c_int32(int(data_index)), _p(dd), _i64(dd.shape[0]), C.c_int32(int(flag_index)), _p(fd),
+        _i64(n_flag_rows), _u8(flag_mask), _i64(step_length), _i64(amp_offset), _p(nv), _p(a), _p(af),
+        _i64(a.shape[0]), _i64(n_samp), _p(iv), _i64(iv.shape[0]), _int(use_accel)))
+
+
+def template_offset_apply_diag_precond(offset_var, amplitudes_in, amplitude_flags, amplitudes_out,
+                                       use_accel=False):
+    ai = _buf(amplitudes_in, "amplitudes_in", np.float64, 1)
+    n = ai.shape[0]
+    ao = _buf(amplitudes_out, "amplitudes_out", np.float64, 1, (n,))
+    ov = _buf(offset_var, "offset_var", np.float64, 1, (n,))
+    af = _buf(amplitude_flags, "amplitude_flags", np.uint8, 1, (n,))
+    _check(lib().toast_hip_template_offset_apply_diag_precond(_p(ov), _p(ai), _p(af), _p(ao), _i64(n),
+                                                              _int(use_accel)))
+
+
+# --------------------------------------------------------------------------- device-pointer level
+class _Dev:
+    """``toast_hip_*_dev``: large arrays are device pointers (ints), small ones NumPy arrays."""
+
+    @staticmethod
+    def _small(a, dtype):
+        return np.ascontiguousarray(a, dtype=dtype)
+
+    def pointing_detector(self, focalplane, d_boresight, quat_index, d_quats, n_samp, intervals,
+                          d_shared_flags=0, n_flags=0, mask=0, stream=0):
+        fp = self._small(focalplane, np.float64)
+        qi = self._small(quat_index, np.int32)
+        iv = self._small(intervals, interval_dtype)
+        _check(lib().toast_hip_pointing_detector_dev(
+            _p(fp), _p(d_boresight), _p(qi), _i64(qi.size), _p(d_quats), _i64(n_samp), _p(iv),
+            _i64(iv.size), _p(d_shared_flags), _i64(n_flags), _u8(mask), _p(stream)))
+
+    def pixels_healpix(self, quat_index, d_quats, d_shared_flags, n_flags, mask, pixel_index, d_pixels,
+                       n_samp, intervals, d_hit_submaps, n_submap, n_pix_submap, nside, nest, stream=0):
+        qi = self._small(quat_index, np.int32)
+        pi = self._small(pixel_index, np.int32)
+        iv = self._small(intervals, interval_dtype)
+        _check(lib().toast_hip_pixels_healpix_dev(
+            _p(qi), _i64(qi.size), _p(d_quats), _p(d_shared_flags), _i64(n_flags), _u8(mask), _p(pi),
+            _p(d_pixels), _i64(n_samp), _p(iv), _i64(iv.size), _p(d_hit_submaps), _i64(n_submap),
+            _i64(n_pix_submap), _i64(nside), _int(nest), _p(stream)))
+
+    def stokes_weights_IQU(self, quat_index, d_quats, weight_index, d_weights, n_samp, d_hwp, n_hwp,
+                           intervals, epsilon, gamma, cal, iau, stream=0):
+        qi = self._small(quat_index, np.int32)
+        wi = self._small(weight_index, np.int32)
+        iv = self._small(intervals, interval_dtype)
+        e = self._small(epsilon, np.float64)
+        g = self._small(gamma, np.float64)
+        cl = self._small(cal, np.float64)
+        _check(lib().toast_hip_stokes_weights_IQU_dev(
+            _p(qi), _i64(qi.size), _p(d_quats), _p(wi), _p(d_weights), _i64(n_samp), _p(d_hwp),
+            _i64(n_hwp), _p(iv), _i64(iv.size), _p(e), _p(g), _p(cl), _int(iau), _p(stream)))
+
+    def stokes_weights_I(self, weight_index, d_weights, n_samp, intervals, cal, stream=0):
+        wi = self._small(weight_index, np.int32)
+        iv = self._small(intervals, interval_dtype)
+        cl = self._small(cal, np.float64)
+        _check(lib().toast_hip_stokes_weights_I_dev(_p(wi), _i64(wi.size), _p(d_weights), _i64(n_samp),
+                                                    _p(iv), _i64(iv.size), _p(cl), _p(stream)))
+
+    def scan_map(self, map_dtype, d_g2l, n_pix_submap, d_mapdata, nnz, d_det_data, data_index, d_pixels,
+                 pixel_index, d_weights, weight_index, n_samp, intervals, data_scale=1.0, should_zero=False,
+                 should_subtract=False, should_scale=False, det_weights=None, stream=0):
+        di = self._small(data_index, np.int32)
+        pi = self._small(pixel_index, np.int32)
+        wi = self._small(weight_index, np.int32)
+        iv = self._small(intervals, interval_dtype)
+        dw = None if det_weights is None else self._small(det_weights, np.float64)
+        _check(lib().toast_hip_scan_map_dev(
+            C.c_int(_MAP_CODES[np.dtype(map_dtype)]), _p(d_g2l), _i64(n_pix_submap), _p(d_mapdata), _i64(nnz),
+            _p(d_det_data), _p(di), _p(d_pixels), _p(pi), _p(d_weights), _p(wi), _i64(di.size),
+            _i64(n_samp), _p(iv), _i64(iv.size), C.c_double(data_scale), _int(should_zero),
+            _int(should_subtract), _int(should_scale), _p(dw), _p(stream)))
+
+    def build_noise_weighted(self, d_g2l, d_zmap, n_pix_submap, nnz, pixel_index, d_pixels, weight_index,
+                             d_weights, data_index, d_det_data, flag_index, d_det_flags, n_flag_samp,
+                             det_scale, det_flag_mask, n_samp, intervals, d_shared_flags, n_shared_flags,
+                             shared_flag_mask, stream=0):
+        pi = self._small(pixel_index, np.int32)
+        wi = self._small(weight_index, np.int32)
+        di = self._small(data_index, np.int32)
+        fi = self._small(flag_index, np.int32)
+        ds = self._small(det_scale, np.float64)
+        iv = self._small(intervals, interval_dtype)
+        _check(lib().toast_hip_build_noise_weighted_dev(
+            _p(d_g2l), _p(d_zmap), _i64(n_pix_submap), _i64(nnz), _p(pi), _p(d_pixels), _p(wi),
+            _p(d_weights), _p(di), _p(d_det_data), _p(fi), _p(d_det_flags), _i64(n_flag_samp), _p(ds),
+            _u8(det_flag_mask), _i64(pi.size), _i64(n_samp), _p(iv), _i64(iv.size), _p(d_shared_flags),
+            _i64(n_shared_flags), _u8(shared_flag_mask), _p(stream)))
+
+    def noise_weight(self, d_det_data, n_samp, data_index, intervals, detector_weights, stream=0):
+        di = self._small(data_index, np.int32)
+        iv = self._small(intervals, interval_dtype)
+        dw = self._small(detector_weights, np.float64)
+        _check(lib().toast_hip_noise_weight_dev(_p(d_det_data), _i64(n_samp), _p(di), _i64(di.size), _p(iv),
+                                                _i64(iv.size), _p(dw), _p(stream)))
+
+    def cov_apply_diag(self, n_sub, subsize, nnz, d_mat, d_vec, stream=0):
+        _check(lib().toast_hip_cov_apply_diag_dev(_i64(n_sub), _i64(subsize), _i64(nnz), _p(d_mat), _p(d_vec),
+                                                  _p(stream)))
+
+    def template_offset_add_to_signal(self, step_length, amp_offset, n_amp_views, d_amplitudes,
+                                      d_amplitude_flags, data_index, d_det_data, n_samp, intervals, stream=0):
+        iv = self._small(intervals, interval_dtype)
+        nv = self._small(n_amp_views, np.int64)
+        _check(lib().toast_hip_template_offset_add_to_signal_dev(
+            _i64(step_length), _i64(amp_offset), _p(nv), _p(d_amplitudes), _p(d_amplitude_flags),
+            C.c_int32(int(data_index)), _p(d_det_data), _i64(n_samp), _p(iv), _i64(iv.size), _p(stream)))
+
+    def template_offset_project_signal(self, data_index, d_det_data, flag_index, d_flag_data, flag_mask,
+                                       step_length, amp_offset, n_amp_views, d_amplitudes,
+                                       d_amplitude_flags, n_samp, intervals, stream=0):
+        iv = self._small(intervals, interval_dtype)
+        nv = self._small(n_amp_views, np.int64)
+        _check(lib().toast_hip_template_offset_project_signal_dev(
+            C.c_int32(int(data_index)), _p(d_det_data), C.c_int32(int(flag_index)), _p(d_flag_data),
+            _u8(flag_mask), _i64(step_length), _i64(amp_offset), _p(nv), _p(d_amplitudes),
+            _p(d_amplitude_flags), _i64(n_samp), _p(iv), _i64(iv.size), _p(stream)))
+
+    def template_offset_apply_diag_precond(self, d_offset_var, d_amp_in, d_amp_flags, d_amp_out, n_amp,
+                                           stream=0):
+        _check(lib().toast_hip_template_offset_apply_diag_precond_dev(
+            _p(d_offset_var), _p(d_amp_in), _p(d_amp_flags), _p(d_amp_out), _i64(n_amp), _p(stream)))
+
+    def test_math(self, op, n, d_a, d_b, d_out, stream=0):
+        _check(lib().toast_hip_test_math_dev(C.c_int(op), _i64(n), _p(d_a), _p(d_b), _p(d_out), _p(stream)))
+
+
+dev = _Dev()

@@ -1,0 +1,878 @@
+// kernels.hip -- hand-written gfx950 kernels of the map-making hot path and their
+// device-pointer level C entry points (toast_hip_*_dev in include/toast_hip.h).
+//
+// Launch shape shared by every per-sample kernel: one workgroup (256 threads = 4 wave64)
+// per (chunk, detector); blockIdx.x = detector is the FAST grid index, so the workgroups
+// resident at any moment cover all detectors over a short time span.  Detectors of one
+// focalplane look at the same few square degrees at the same time, so the map working set
+// of the resident workgroups is a few hundred KB and stays in every XCD's 4 MiB L2
+// (time-major order; a detector-major grid would sweep the whole 300 MB map instead).
+//
+// Compiled with -ffp-contract=off (see build.py): the pixel path must reproduce the
+// reference's separately rounded operations.
+#include <hip/hip_runtime.h>
+
+#include "hpix_math.hpp"
+#include "runtime.hpp"
+
+using namespace toast_hip;
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct alignas(16) Quat {
+    double x, y, z, w;
+};
+
+__device__ __forceinline__ Quat load_quat(const double * p) {
+    const double2 a = *reinterpret_cast<const double2 *>(p);
+    const double2 b = *reinterpret_cast<const double2 *>(p + 2);
+    return Quat{a.x, a.y, b.x, b.y};
+}
+
+__device__ __forceinline__ void store_quat(double * p, const double * r) {
+    *reinterpret_cast<double2 *>(p) = make_double2(r[0], r[1]);
+    *reinterpret_cast<double2 *>(p + 2) = make_double2(r[2], r[3]);
+}
+
+// ------------------------------------------------------------------------------------
+// pointing_detector   [ref: ops_pointing_detector.cpp:33-68]
+// R 32 B boresight (shared by all detectors, L2 resident) + 1 B flag, W 32 B.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_pointing_detector(
+    const Chunk * __restrict__ chunks, int n_chunks, const double * __restrict__ fp,
+    const int32_t * __restrict__ q_idx, const double * __restrict__ bore,
+    double * __restrict__ quats, const uint8_t * __restrict__ flags, uint8_t mask, int use_flags,
+    int64_t n_samp) {
+    const int det = blockIdx.x;
+    const double f[4] = {fp[4 * det], fp[4 * det + 1], fp[4 * det + 2], fp[4 * det + 3]};
+    double * row = quats + (int64_t)q_idx[det] * n_samp * 4;
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        for (int i = threadIdx.x; i < c.count; i += kThreads) {
+            const int64_t s = c.first + i;
+            double p[4] = {0.0, 0.0, 0.0, 1.0};
+            if (!(use_flags && (flags[s] & mask))) {
+                const Quat b = load_quat(bore + 4 * s);
+                p[0] = b.x; p[1] = b.y; p[2] = b.z; p[3] = b.w;
+            }
+            double r[4];
+            quat_mult(p, f, r);
+            store_quat(row + 4 * s, r);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// pixels_healpix   [ref: ops_pixels_healpix.cpp:586-666]
+// R 32 B quaternion + 1 B flag, W 8 B pixel; hit_submaps written once per run of equal
+// submaps inside a wave.
+// ------------------------------------------------------------------------------------
+template <bool NEST>
+__global__ __launch_bounds__(kThreads) void k_pixels_healpix(
+    const Chunk * __restrict__ chunks, int n_chunks, const int32_t * __restrict__ q_idx,
+    const int32_t * __restrict__ p_idx, const double * __restrict__ quats,
+    const uint8_t * __restrict__ flags, uint8_t mask, int use_flags, int64_t * __restrict__ pixels,
+    uint8_t * __restrict__ hsub, FastDiv nps_div, int64_t nside, int factor, int64_t n_samp) {
+    __shared__ double s_tab[2 * TOAST_ATAN_TABLE_N];
+    if (threadIdx.x < 2 * TOAST_ATAN_TABLE_N) s_tab[threadIdx.x] = kAtanTab[threadIdx.x];
+    __syncthreads();
+
+    const int det = blockIdx.x;
+    const double * qrow = quats + (int64_t)q_idx[det] * n_samp * 4;
+    int64_t * prow = pixels + (int64_t)p_idx[det] * n_samp;
+    const int lane = threadIdx.x & 63;
+    const double zaxis[3] = {0.0, 0.0, 1.0};
+
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        for (int base = 0; base < c.count; base += kThreads) {
+            const int i = base + threadIdx.x;
+            const bool active = i < c.count;
+            const int64_t s = c.first + (active ? i : 0);
+            const Quat q = load_quat(qrow + 4 * s);
+            const double qa[4] = {q.x, q.y, q.z, q.w};
+            double dir[3];
+            quat_rotate(qa, zaxis, dir);
+            const ZPhi a = zphi_from_vec(dir, s_tab);
+            int64_t pix = NEST ? zphi_to_nest(nside, factor, a) : zphi_to_ring(nside, factor, a);
+            const bool flagged = use_flags && ((flags[s] & mask) != 0);
+            int64_t sub = -1;
+            if (flagged) {
+                pix = -1;
+            } else {
+                sub = fastdiv(pix, nps_div);
+            }
+            if (!active) sub = -1;
+            const int64_t prev = __shfl_up(sub, 1);
+            if (active) {
+                prow[s] = pix;
+                if (sub >= 0 && (lane == 0 || prev != sub)) hsub[sub] = 1;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// stokes_weights   [ref: ops_stokes_weights.cpp:77-140, :459-505]
+// ------------------------------------------------------------------------------------
+template <bool HWP>
+__global__ __launch_bounds__(kThreads) void k_stokes_iqu(
+    const Chunk * __restrict__ chunks, int n_chunks, const int32_t * __restrict__ q_idx,
+    const int32_t * __restrict__ w_idx, const double * __restrict__ quats,
+    double * __restrict__ weights, const double * __restrict__ hwp,
+    const double * __restrict__ epsilon, const double * __restrict__ gamma,
+    const double * __restrict__ cal, double usign, int64_t n_samp) {
+    const int det = blockIdx.x;
+    const double eps = epsilon[det];
+    const double eta = (1.0 - eps) / (1.0 + eps);
+    const double cd = cal[det];
+    const double gd = gamma[det];
+    const double * qrow = quats + (int64_t)q_idx[det] * n_samp * 4;
+    double * wrow = weights + (int64_t)w_idx[det] * n_samp * 3;
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        for (int i = threadIdx.x; i < c.count; i += kThreads) {
+            const int64_t s = c.first + i;
+            const Quat q = load_quat(qrow + 4 * s);
+            const double qa[4] = {q.x, q.y, q.z, q.w};
+            const double alpha = stokes_alpha(qa);
+            double * w = wrow + 3 * s;
+            if (HWP) {
+                const double ang = 2.0 * (2.0 * (gd - hwp[s]) - alpha);
+                w[0] = cd;
+                w[1] = cos(ang) * eta * cd;
+                w[2] = -sin(ang) * eta * cd * usign;
+            } else {
+                const double ang = alpha * 2.0;
+                w[0] = cd;
+                w[1] = cos(ang) * eta * cd;
+                w[2] = sin(ang) * eta * cd * usign;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_stokes_i(
+    const Chunk * __restrict__ chunks, int n_chunks, const int32_t * __restrict__ w_idx,
+    double * __restrict__ weights, const double * __restrict__ cal, int64_t n_samp) {
+    const int det = blockIdx.x;
+    const double cd = cal[det];
+    double * wrow = weights + (int64_t)w_idx[det] * n_samp;
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        for (int i = threadIdx.x; i < c.count; i += kThreads) wrow[c.first + i] = cd;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// scan_map   [ref: ops_scan_map.cpp:15-78]
+// R 8 B pixel + 8*nnz B weights + 8 B tod (unless zeroing), W 8 B tod; map gather served by
+// L2 (see file header).  `det_w` != nullptr fuses the PCG's diagonal noise weight.
+// ------------------------------------------------------------------------------------
+template <typename T, int NNZ>
+__global__ __launch_bounds__(kThreads) void k_scan_map(
+    const Chunk * __restrict__ chunks, int n_chunks, const int32_t * __restrict__ d_idx,
+    const int32_t * __restrict__ p_idx, const int32_t * __restrict__ w_idx,
+    const int64_t * __restrict__ g2l, const T * __restrict__ map, double * __restrict__ tod,
+    const int64_t * __restrict__ pixels, const double * __restrict__ weights, int nnz_rt,
+    FastDiv nps_div, double scale, int zero, int subtract, int mult,
+    const double * __restrict__ det_w, int64_t n_samp) {
+    const int det = blockIdx.x;
+    const int nnz = (NNZ > 0) ? NNZ : nnz_rt;
+    double * drow = tod + (int64_t)d_idx[det] * n_samp;
+    const int64_t * prow = pixels + (int64_t)p_idx[det] * n_samp;
+    const double * wrow = weights + (int64_t)w_idx[det] * n_samp * nnz;
+    const bool fuse = det_w != nullptr;
+    const double dw = fuse ? det_w[det] : 1.0;
+    const int64_t nps = nps_div.d;
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        for (int i = threadIdx.x; i < c.count; i += kThreads) {
+            const int64_t s = c.first + i;
+            const int64_t p = prow[s];
+            double d = zero ? 0.0 : drow[s];
+            if (p >= 0) {
+                const int64_t gsm = fastdiv(p, nps_div);
+                const int64_t lsm = g2l[gsm];
+                const int64_t sub = p - gsm * nps;
+                const T * m = map + nnz * (lsm * nps + sub);
+                const double * w = wrow + nnz * s;
+                double v = 0.0;
+#pragma unroll
+                for (int k = 0; k < nnz; ++k) v += w[k] * (double)m[k];
+                v *= scale;
+                if (subtract) {
+                    d -= v;
+                } else if (mult) {
+                    d *= v;
+                } else {
+                    d += v;
+                }
+            }
+            if (fuse) d *= dw;
+            drow[s] = d;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Wave-level segmented sum: lanes holding equal, *adjacent* keys form a run; after the
+// call the LAST lane of each run (is_tail) holds the run total in v[].  Six shuffle steps.
+// ------------------------------------------------------------------------------------
+template <int NV>
+__device__ __forceinline__ bool wave_run_reduce(int64_t key, double (&v)[NV]) {
+    const int lane = threadIdx.x & 63;
+    const int64_t prev = __shfl_up(key, 1);
+    const bool head = (lane == 0) || (prev != key);
+    const unsigned long long heads = __ballot(head);
+    // run start = highest head bit at or below my lane
+    const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    const int start = 63 - __clzll(below);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const double o = __shfl_up(v[k], d);
+            if (lane - d >= start) v[k] += o;
+        }
+    }
+    return (lane == 63) || ((heads >> (lane + 1)) & 1ull);
+}
+
+// ------------------------------------------------------------------------------------
+// build_noise_weighted   [ref: ops_mapmaker_utils.cpp:15-86]
+// R 8 B pixel + 8*nnz B weights + 8 B tod + 1 B det flag (+ shared flag); the scatter is
+// reduced per run of equal pixels inside each wave (a satellite scan revisits the same pixel
+// for ~10-20 consecutive samples), leaving one hardware fp64 atomic per run and component.
+// ------------------------------------------------------------------------------------
+template <int NNZ>
+__global__ __launch_bounds__(kThreads) void k_build_noise_weighted(
+    const Chunk * __restrict__ chunks, int n_chunks, const int32_t * __restrict__ p_idx,
+    const int32_t * __restrict__ w_idx, const int32_t * __restrict__ d_idx,
+    const int32_t * __restrict__ f_idx, const double * __restrict__ det_scale,
+    const int64_t * __restrict__ g2l, double * __restrict__ zmap,
+    const int64_t * __restrict__ pixels, const double * __restrict__ weights,
+    const double * __restrict__ tod, const uint8_t * __restrict__ dflags, uint8_t dmask,
+    int use_dflags, const uint8_t * __restrict__ sflags, uint8_t smask, int use_sflags,
+    FastDiv nps_div, int64_t n_samp) {
+    const int det = blockIdx.x;
+    const int64_t * prow = pixels + (int64_t)p_idx[det] * n_samp;
+    const double * wrow = weights + (int64_t)w_idx[det] * n_samp * NNZ;
+    const double * drow = tod + (int64_t)d_idx[det] * n_samp;
+    const uint8_t * frow = use_dflags ? dflags + (int64_t)f_idx[det] * n_samp : nullptr;
+    const double ds = det_scale[det];
+    const int64_t nps = nps_div.d;
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        for (int base = 0; base < c.count; base += kThreads) {
+            const int i = base + threadIdx.x;
+            const bool active = i < c.count;
+            const int64_t s = c.first + (active ? i : 0);
+            int64_t key = -1;
+            double v[NNZ];
+#pragma unroll
+            for (int k = 0; k < NNZ; ++k) v[k] = 0.0;
+            if (active) {
+                const int64_t p = prow[s];
+                bool good = p >= 0;
+                if (use_dflags) good = good && ((frow[s] & dmask) == 0);
+                if (use_sflags) good = good && ((sflags[s] & smask) == 0);
+                if (good) {
+                    const int64_t gsm = fastdiv(p, nps_div);
+                    key = g2l[gsm] * nps + (p - gsm * nps);
+                    const double sd = drow[s] * ds;
+                    const double * w = wrow + NNZ * s;
+#pragma unroll
+                    for (int k = 0; k < NNZ; ++k) v[k] = sd * w[k];
+                }
+            }
+            const bool tail = wave_run_reduce<NNZ>(key, v);
+            if (tail && key >= 0) {
+                double * z = zmap + NNZ * key;
+#pragma unroll
+                for (int k = 0; k < NNZ; ++k) unsafeAtomicAdd(z + k, v[k]);
+            }
+        }
+    }
+}
+
+// generic nnz (rare: nnz not in {1,2,3}): plain per-sample atomics
+__global__ __launch_bounds__(kThreads) void k_build_noise_weighted_any(
+    const Chunk * __restrict__ chunks, int n_chunks, const int32_t * __restrict__ p_idx,
+    const int32_t * __restrict__ w_idx, const int32_t * __restrict__ d_idx,
+    const int32_t * __restrict__ f_idx, const double * __restrict__ det_scale,
+    const int64_t * __restrict__ g2l, double * __restrict__ zmap,
+    const int64_t * __restrict__ pixels, const double * __restrict__ weights,
+    const double * __restrict__ tod, const uint8_t * __restrict__ dflags, uint8_t dmask,
+    int use_dflags, const uint8_t * __restrict__ sflags, uint8_t smask, int use_sflags,
+    FastDiv nps_div, int64_t n_samp, int nnz) {
+    const int det = blockIdx.x;
+    const int64_t * prow = pixels + (int64_t)p_idx[det] * n_samp;
+    const double * wrow = weights + (int64_t)w_idx[det] * n_samp * nnz;
+    const double * drow = tod + (int64_t)d_idx[det] * n_samp;
+    const uint8_t * frow = use_dflags ? dflags + (int64_t)f_idx[det] * n_samp : nullptr;
+    const double ds = det_scale[det];
+    const int64_t nps = nps_div.d;
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        for (int i = threadIdx.x; i < c.count; i += kThreads) {
+            const int64_t s = c.first + i;
+            const int64_t p = prow[s];
+            if (p < 0) continue;
+            if (use_dflags && (frow[s] & dmask)) continue;
+            if (use_sflags && (sflags[s] & smask)) continue;
+            const int64_t gsm = fastdiv(p, nps_div);
+            double * z = zmap + nnz * (g2l[gsm] * nps + (p - gsm * nps));
+            const double sd = drow[s] * ds;
+            const double * w = wrow + nnz * s;
+            for (int k = 0; k < nnz; ++k) unsafeAtomicAdd(z + k, sd * w[k]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// noise_weight   [ref: ops_noise_weight.cpp:71-96]
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_noise_weight(
+    const Chunk * __restrict__ chunks, int n_chunks, const int32_t * __restrict__ d_idx,
+    const double * __restrict__ det_w, double * __restrict__ tod, int64_t n_samp) {
+    const int det = blockIdx.x;
+    const double w = det_w[det];
+    double * drow = tod + (int64_t)d_idx[det] * n_samp;
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        for (int i = threadIdx.x; i < c.count; i += kThreads) drow[c.first + i] *= w;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// cov_apply_diag   [ref: src/libtoast/src/toast_map_cov.cpp:471-528]
+// One thread per pixel; reference accumulation order (row k, then the mirrored term).
+// ------------------------------------------------------------------------------------
+template <int NNZ>
+__global__ __launch_bounds__(kThreads) void k_cov_apply_diag(int64_t n_px, const double * __restrict__ mat,
+                                                             double * __restrict__ vec) {
+    constexpr int BLK = NNZ * (NNZ + 1) / 2;
+    for (int64_t px = (int64_t)blockIdx.x * kThreads + threadIdx.x; px < n_px;
+         px += (int64_t)gridDim.x * kThreads) {
+        const double * m = mat + px * BLK;
+        double * v = vec + px * NNZ;
+        double in[NNZ], t[NNZ];
+#pragma unroll
+        for (int k = 0; k < NNZ; ++k) {
+            in[k] = v[k];
+            t[k] = 0.0;
+        }
+        if (NNZ == 1) {
+            v[0] = in[0] * m[0];
+            continue;
+        }
+        int off = 0;
+#pragma unroll
+        for (int k = 0; k < NNZ; ++k) {
+#pragma unroll
+            for (int j = k; j < NNZ; ++j, ++off) {
+                t[k] += m[off] * in[j];
+                if (j != k) t[j] += m[off] * in[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NNZ; ++k) v[k] = t[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Offset template   [ref: template_offset.cpp:93-120, :243-290, :375-390]
+// view_first / view_aoff: per-interval first sample and amplitude offset (host-built).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_offset_add_to_signal(
+    const Chunk * __restrict__ chunks, int n_chunks, const int64_t * __restrict__ view_first,
+    const int64_t * __restrict__ view_aoff, FastDiv step_div, int64_t amp_offset,
+    const double * __restrict__ amps, const uint8_t * __restrict__ amp_flags,
+    double * __restrict__ drow) {
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        const int64_t vfirst = view_first[c.view];
+        const int64_t abase = amp_offset + view_aoff[c.view];
+        for (int i = threadIdx.x; i < c.count; i += kThreads) {
+            const int64_t s = c.first + i;
+            const int64_t a = abase + fastdiv(s - vfirst, step_div);
+            if (amp_flags[a] == 0) drow[s] += amps[a];
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_offset_project_signal(
+    const Chunk * __restrict__ chunks, int n_chunks, const int64_t * __restrict__ view_first,
+    const int64_t * __restrict__ view_aoff, FastDiv step_div, int64_t amp_offset,
+    double * __restrict__ amps, const uint8_t * __restrict__ amp_flags,
+    const double * __restrict__ drow, const uint8_t * __restrict__ frow, uint8_t fmask,
+    int use_flags) {
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        const int64_t vfirst = view_first[c.view];
+        const int64_t abase = amp_offset + view_aoff[c.view];
+        for (int base = 0; base < c.count; base += kThreads) {
+            const int i = base + threadIdx.x;
+            const bool active = i < c.count;
+            int64_t key = -1;
+            double v[1] = {0.0};
+            if (active) {
+                const int64_t s = c.first + i;
+                const int64_t a = abase + fastdiv(s - vfirst, step_div);
+                if (amp_flags[a] == 0) {
+                    key = a;
+                    const bool bad = use_flags && ((frow[s] & fmask) != 0);
+                    v[0] = bad ? 0.0 : drow[s];
+                }
+            }
+            const bool tail = wave_run_reduce<1>(key, v);
+            if (tail && key >= 0) unsafeAtomicAdd(amps + key, v[0]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_offset_apply_diag_precond(
+    int64_t n_amp, const double * __restrict__ var, const double * __restrict__ in,
+    const uint8_t * __restrict__ flags, double * __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n_amp;
+         i += (int64_t)gridDim.x * kThreads) {
+        out[i] = (flags[i] == 0) ? in[i] * var[i] : 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// per-operation math probe (tests)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_test_math(int op, int64_t n, const double * __restrict__ a,
+                                                        const double * __restrict__ b,
+                                                        double * __restrict__ out) {
+    __shared__ double s_tab[2 * TOAST_ATAN_TABLE_N];
+    if (threadIdx.x < 2 * TOAST_ATAN_TABLE_N) s_tab[threadIdx.x] = kAtanTab[threadIdx.x];
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * kThreads) {
+        double r;
+        if (op == 0) {
+            r = atan2_dd(a[i], b[i], s_tab);
+        } else if (op == 1) {
+            r = f_sqrt(a[i]);
+        } else {
+            r = a[i] / b[i];
+        }
+        out[i] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// host helpers
+// ------------------------------------------------------------------------------------
+inline hipStream_t as_stream(void * s) { return static_cast<hipStream_t>(s); }
+
+inline void check_launch() { TH_HIP(hipGetLastError()); }
+
+inline void need_aligned(const void * p, const char * what) {
+    if ((reinterpret_cast<uintptr_t>(p) & 15) != 0) {
+        fail_arg(std::string(what) + " must be 16-byte aligned");
+    }
+}
+
+inline dim3 chunk_grid(int64_t n_det, size_t n_chunks) {
+    const unsigned gy = (unsigned)((n_chunks < 65535) ? n_chunks : 65535);
+    return dim3((unsigned)n_det, gy ? gy : 1, 1);
+}
+
+inline int log2_exact(int64_t nside) {
+    if (nside <= 0 || (nside & (nside - 1)) != 0) fail_arg("nside must be a positive power of two");
+    int f = 0;
+    while ((int64_t(1) << f) != nside) ++f;
+    return f;
+}
+
+inline dim3 flat_grid(int64_t n) {
+    int64_t b = (n + kThreads - 1) / kThreads;
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return dim3((unsigned)b);
+}
+
+}  // namespace
+
+namespace {
+
+template <typename T>
+void launch_scan_map(dim3 grid, hipStream_t st, const Chunk * ch, int n_ch, const int32_t * di,
+                     const int32_t * pi, const int32_t * wi, const int64_t * g2l, const void * map,
+                     double * tod, const int64_t * pix, const double * w, int nnz, FastDiv dv,
+                     double scale, int zero, int sub, int mult, const double * det_w,
+                     int64_t n_samp) {
+    const T * m = static_cast<const T *>(map);
+    if (nnz == 3) {
+        hipLaunchKernelGGL((k_scan_map<T, 3>), grid, dim3(kThreads), 0, st, ch, n_ch, di, pi, wi, g2l,
+                           m, tod, pix, w, nnz, dv, scale, zero, sub, mult, det_w, n_samp);
+    } else if (nnz == 1) {
+        hipLaunchKernelGGL((k_scan_map<T, 1>), grid, dim3(kThreads), 0, st, ch, n_ch, di, pi, wi, g2l,
+                           m, tod, pix, w, nnz, dv, scale, zero, sub, mult, det_w, n_samp);
+    } else {
+        hipLaunchKernelGGL((k_scan_map<T, 0>), grid, dim3(kThreads), 0, st, ch, n_ch, di, pi, wi, g2l,
+                           m, tod, pix, w, nnz, dv, scale, zero, sub, mult, det_w, n_samp);
+    }
+}
+
+}  // namespace
+
+namespace {
+
+struct OffsetViews {
+    std::vector<int64_t> first;
+    std::vector<int64_t> aoff;
+};
+
+OffsetViews offset_views(const toast_hip_interval * ivl, const int64_t * n_amp_views, int64_t n_view) {
+    OffsetViews v;
+    int64_t run = 0;  // template_offset.cpp:57-63
+    for (int64_t i = 0; i < n_view; ++i) {
+        v.first.push_back(ivl[i].first);
+        v.aoff.push_back(run);
+        run += n_amp_views[i];
+    }
+    return v;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------
+// C ABI, device-pointer level
+// ------------------------------------------------------------------------------------
+extern "C" {
+
+int toast_hip_pointing_detector_dev(const double * focalplane, const double * d_boresight,
+                                    const int32_t * quat_index, int64_t n_det, double * d_quats,
+                                    int64_t n_samp, const toast_hip_interval * intervals,
+                                    int64_t n_view, const uint8_t * d_shared_flags, int64_t n_flags,
+                                    uint8_t mask, void * stream) {
+    return guarded([&] {
+        if (n_det <= 0) return;
+        need_aligned(d_boresight, "boresight");
+        need_aligned(d_quats, "quats");
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        ParamBlock pb;
+        const size_t o_ch = pb.push_vec(chunks);
+        const size_t o_fp = pb.push(focalplane, sizeof(double) * 4 * n_det);
+        const size_t o_qi = pb.push(quat_index, sizeof(int32_t) * n_det);
+        const char * d = pb.commit(as_stream(stream));
+        const int use_flags = (n_flags == n_samp) ? 1 : 0;
+        hipLaunchKernelGGL(k_pointing_detector, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0,
+                           as_stream(stream), (const Chunk *)(d + o_ch), (int)chunks.size(),
+                           (const double *)(d + o_fp), (const int32_t *)(d + o_qi), d_boresight,
+                           d_quats, d_shared_flags, mask, use_flags, n_samp);
+        check_launch();
+    });
+}
+
+int toast_hip_pixels_healpix_dev(const int32_t * quat_index, int64_t n_det, const double * d_quats,
+                                 const uint8_t * d_shared_flags, int64_t n_flags, uint8_t mask,
+                                 const int32_t * pixel_index, int64_t * d_pixels, int64_t n_samp,
+                                 const toast_hip_interval * intervals, int64_t n_view,
+                                 uint8_t * d_hit_submaps, int64_t n_submap, int64_t n_pix_submap,
+                                 int64_t nside, int nest, void * stream) {
+    return guarded([&] {
+        if (n_det <= 0) return;
+        need_aligned(d_quats, "quats");
+        const int factor = log2_exact(nside);
+        if (n_pix_submap <= 0) fail_arg("n_pix_submap must be positive");
+        if (n_submap * n_pix_submap < 12 * nside * nside) {
+            fail_arg("hit_submaps is too short for this nside / n_pix_submap");
+        }
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        ParamBlock pb;
+        const size_t o_ch = pb.push_vec(chunks);
+        const size_t o_qi = pb.push(quat_index, sizeof(int32_t) * n_det);
+        const size_t o_pi = pb.push(pixel_index, sizeof(int32_t) * n_det);
+        const char * d = pb.commit(as_stream(stream));
+        const int use_flags = (n_flags == n_samp) ? 1 : 0;
+        const FastDiv dv = make_fastdiv(n_pix_submap);
+        auto kern = nest ? k_pixels_healpix<true> : k_pixels_healpix<false>;
+        hipLaunchKernelGGL(kern, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0,
+                           as_stream(stream), (const Chunk *)(d + o_ch), (int)chunks.size(),
+                           (const int32_t *)(d + o_qi), (const int32_t *)(d + o_pi), d_quats,
+                           d_shared_flags, mask, use_flags, d_pixels, d_hit_submaps, dv, nside,
+                           factor, n_samp);
+        check_launch();
+    });
+}
+
+int toast_hip_stokes_weights_IQU_dev(const int32_t * quat_index, int64_t n_det, const double * d_quats,
+                                     const int32_t * weight_index, double * d_weights, int64_t n_samp,
+                                     const double * d_hwp, int64_t n_hwp,
+                                     const toast_hip_interval * intervals, int64_t n_view,
+                                     const double * epsilon, const double * gamma, const double * cal,
+                                     int iau, void * stream) {
+    return guarded([&] {
+        if (n_det <= 0) return;
+        need_aligned(d_quats, "quats");
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        ParamBlock pb;
+        const size_t o_ch = pb.push_vec(chunks);
+        const size_t o_qi = pb.push(quat_index, sizeof(int32_t) * n_det);
+        const size_t o_wi = pb.push(weight_index, sizeof(int32_t) * n_det);
+        const size_t o_e = pb.push(epsilon, sizeof(double) * n_det);
+        const size_t o_g = pb.push(gamma, sizeof(double) * n_det);
+        const size_t o_c = pb.push(cal, sizeof(double) * n_det);
+        const char * d = pb.commit(as_stream(stream));
+        const bool use_hwp = (n_hwp == n_samp);
+        const double usign = iau ? -1.0 : 1.0;
+        auto kern = use_hwp ? k_stokes_iqu<true> : k_stokes_iqu<false>;
+        hipLaunchKernelGGL(kern, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0,
+                           as_stream(stream), (const Chunk *)(d + o_ch), (int)chunks.size(),
+                           (const int32_t *)(d + o_qi), (const int32_t *)(d + o_wi), d_quats,
+                           d_weights, d_hwp, (const double *)(d + o_e), (const double *)(d + o_g),
+                           (const double *)(d + o_c), usign, n_samp);
+        check_launch();
+    });
+}
+
+int toast_hip_stokes_weights_I_dev(const int32_t * weight_index, int64_t n_det, double * d_weights,
+                                   int64_t n_samp, const toast_hip_interval * intervals,
+                                   int64_t n_view, const double * cal, void * stream) {
+    return guarded([&] {
+        if (n_det <= 0) return;
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        ParamBlock pb;
+        const size_t o_ch = pb.push_vec(chunks);
+        const size_t o_wi = pb.push(weight_index, sizeof(int32_t) * n_det);
+        const size_t o_c = pb.push(cal, sizeof(double) * n_det);
+        const char * d = pb.commit(as_stream(stream));
+        hipLaunchKernelGGL(k_stokes_i, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0,
+                           as_stream(stream), (const Chunk *)(d + o_ch), (int)chunks.size(),
+                           (const int32_t *)(d + o_wi), d_weights, (const double *)(d + o_c), n_samp);
+        check_launch();
+    });
+}
+
+
+int toast_hip_scan_map_dev(int map_dtype, const int64_t * d_g2l, int64_t n_pix_submap,
+                           const void * d_mapdata, int64_t nnz, double * d_det_data,
+                           const int32_t * data_index, const int64_t * d_pixels,
+                           const int32_t * pixel_index, const double * d_weights,
+                           const int32_t * weight_index, int64_t n_det, int64_t n_samp,
+                           const toast_hip_interval * intervals, int64_t n_view, double data_scale,
+                           int should_zero, int should_subtract, int should_scale,
+                           const double * det_weights, void * stream) {
+    return guarded([&] {
+        if (n_det <= 0) return;
+        if (nnz <= 0) fail_arg("nnz must be positive");
+        if (n_pix_submap <= 0) fail_arg("n_pix_submap must be positive");
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        ParamBlock pb;
+        const size_t o_ch = pb.push_vec(chunks);
+        const size_t o_di = pb.push(data_index, sizeof(int32_t) * n_det);
+        const size_t o_pi = pb.push(pixel_index, sizeof(int32_t) * n_det);
+        const size_t o_wi = pb.push(weight_index, sizeof(int32_t) * n_det);
+        const size_t o_dw = det_weights ? pb.push(det_weights, sizeof(double) * n_det) : 0;
+        const char * d = pb.commit(as_stream(stream));
+        const double * dw = det_weights ? (const double *)(d + o_dw) : nullptr;
+        const FastDiv dv = make_fastdiv(n_pix_submap);
+        const dim3 grid = chunk_grid(n_det, chunks.size());
+        const Chunk * ch = (const Chunk *)(d + o_ch);
+        const int32_t * di = (const int32_t *)(d + o_di);
+        const int32_t * pi = (const int32_t *)(d + o_pi);
+        const int32_t * wi = (const int32_t *)(d + o_wi);
+        const int n_ch = (int)chunks.size();
+        hipStream_t st = as_stream(stream);
+        switch (map_dtype) {
+            case TOAST_HIP_MAP_F64:
+                launch_scan_map<double>(grid, st, ch, n_ch, di, pi, wi, d_g2l, d_mapdata, d_det_data,
+                                        d_pixels, d_weights, (int)nnz, dv, data_scale, should_zero,
+                                        should_subtract, should_scale, dw, n_samp);
+                break;
+            case TOAST_HIP_MAP_F32:
+                launch_scan_map<float>(grid, st, ch, n_ch, di, pi, wi, d_g2l, d_mapdata, d_det_data,
+                                       d_pixels, d_weights, (int)nnz, dv, data_scale, should_zero,
+                                       should_subtract, should_scale, dw, n_samp);
+                break;
+            case TOAST_HIP_MAP_I64:
+                launch_scan_map<int64_t>(grid, st, ch, n_ch, di, pi, wi, d_g2l, d_mapdata, d_det_data,
+                                         d_pixels, d_weights, (int)nnz, dv, data_scale, should_zero,
+                                         should_subtract, should_scale, dw, n_samp);
+                break;
+            case TOAST_HIP_MAP_I32:
+                launch_scan_map<int32_t>(grid, st, ch, n_ch, di, pi, wi, d_g2l, d_mapdata, d_det_data,
+                                         d_pixels, d_weights, (int)nnz, dv, data_scale, should_zero,
+                                         should_subtract, should_scale, dw, n_samp);
+                break;
+            default:
+                fail_arg("unknown map_dtype");
+        }
+        check_launch();
+    });
+}
+
+int toast_hip_build_noise_weighted_dev(
+    const int64_t * d_g2l, double * d_zmap, int64_t n_pix_submap, int64_t nnz,
+    const int32_t * pixel_index, const int64_t * d_pixels, const int32_t * weight_index,
+    const double * d_weights, const int32_t * data_index, const double * d_det_data,
+    const int32_t * flag_index, const uint8_t * d_det_flags, int64_t n_flag_samp,
+    const double * det_scale, uint8_t det_flag_mask, int64_t n_det, int64_t n_samp,
+    const toast_hip_interval * intervals, int64_t n_view, const uint8_t * d_shared_flags,
+    int64_t n_shared_flags, uint8_t shared_flag_mask, void * stream) {
+    return guarded([&] {
+        if (n_det <= 0) return;
+        if (nnz <= 0) fail_arg("nnz must be positive");
+        if (n_pix_submap <= 0) fail_arg("n_pix_submap must be positive");
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        const int use_d = (n_flag_samp == n_samp) ? 1 : 0;
+        const int use_s = (n_shared_flags == n_samp) ? 1 : 0;
+        std::vector<int32_t> fidx(n_det, 0);
+        if (use_d) std::memcpy(fidx.data(), flag_index, sizeof(int32_t) * n_det);
+        ParamBlock pb;
+        const size_t o_ch = pb.push_vec(chunks);
+        const size_t o_pi = pb.push(pixel_index, sizeof(int32_t) * n_det);
+        const size_t o_wi = pb.push(weight_index, sizeof(int32_t) * n_det);
+        const size_t o_di = pb.push(data_index, sizeof(int32_t) * n_det);
+        const size_t o_fi = pb.push_vec(fidx);
+        const size_t o_ds = pb.push(det_scale, sizeof(double) * n_det);
+        const char * d = pb.commit(as_stream(stream));
+        const FastDiv dv = make_fastdiv(n_pix_submap);
+        const dim3 grid = chunk_grid(n_det, chunks.size());
+        hipStream_t st = as_stream(stream);
+#define TH_BNW_ARGS                                                                               \
+    (const Chunk *)(d + o_ch), (int)chunks.size(), (const int32_t *)(d + o_pi),                   \
+        (const int32_t *)(d + o_wi), (const int32_t *)(d + o_di), (const int32_t *)(d + o_fi),    \
+        (const double *)(d + o_ds), d_g2l, d_zmap, d_pixels, d_weights, d_det_data, d_det_flags,  \
+        det_flag_mask, use_d, d_shared_flags, shared_flag_mask, use_s, dv, n_samp
+        if (nnz == 3) {
+            hipLaunchKernelGGL(k_build_noise_weighted<3>, grid, dim3(kThreads), 0, st, TH_BNW_ARGS);
+        } else if (nnz == 1) {
+            hipLaunchKernelGGL(k_build_noise_weighted<1>, grid, dim3(kThreads), 0, st, TH_BNW_ARGS);
+        } else if (nnz == 2) {
+            hipLaunchKernelGGL(k_build_noise_weighted<2>, grid, dim3(kThreads), 0, st, TH_BNW_ARGS);
+        } else {
+            hipLaunchKernelGGL(k_build_noise_weighted_any, grid, dim3(kThreads), 0, st, TH_BNW_ARGS,
+                               (int)nnz);
+        }
+#undef TH_BNW_ARGS
+        check_launch();
+    });
+}
+
+int toast_hip_noise_weight_dev(double * d_det_data, int64_t n_samp, const int32_t * data_index,
+                               int64_t n_det, const toast_hip_interval * intervals, int64_t n_view,
+                               const double * detector_weights, void * stream) {
+    return guarded([&] {
+        if (n_det <= 0) return;
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        ParamBlock pb;
+        const size_t o_ch = pb.push_vec(chunks);
+        const size_t o_di = pb.push(data_index, sizeof(int32_t) * n_det);
+        const size_t o_w = pb.push(detector_weights, sizeof(double) * n_det);
+        const char * d = pb.commit(as_stream(stream));
+        hipLaunchKernelGGL(k_noise_weight, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0,
+                           as_stream(stream), (const Chunk *)(d + o_ch), (int)chunks.size(),
+                           (const int32_t *)(d + o_di), (const double *)(d + o_w), d_det_data, n_samp);
+        check_launch();
+    });
+}
+
+int toast_hip_cov_apply_diag_dev(int64_t n_sub, int64_t subsize, int64_t nnz, const double * d_mat,
+                                 double * d_vec, void * stream) {
+    return guarded([&] {
+        const int64_t n_px = n_sub * subsize;
+        if (n_px <= 0) return;
+        const dim3 grid = flat_grid(n_px);
+        hipStream_t st = as_stream(stream);
+        switch (nnz) {
+            case 1: hipLaunchKernelGGL(k_cov_apply_diag<1>, grid, dim3(kThreads), 0, st, n_px, d_mat, d_vec); break;
+            case 2: hipLaunchKernelGGL(k_cov_apply_diag<2>, grid, dim3(kThreads), 0, st, n_px, d_mat, d_vec); break;
+            case 3: hipLaunchKernelGGL(k_cov_apply_diag<3>, grid, dim3(kThreads), 0, st, n_px, d_mat, d_vec); break;
+            case 4: hipLaunchKernelGGL(k_cov_apply_diag<4>, grid, dim3(kThreads), 0, st, n_px, d_mat, d_vec); break;
+            default: fail_arg("cov_apply_diag: nnz must be 1..4");
+        }
+        check_launch();
+    });
+}
+
+
+int toast_hip_template_offset_add_to_signal_dev(
+    int64_t step_length, int64_t amp_offset, const int64_t * n_amp_views, const double * d_amplitudes,
+    const uint8_t * d_amplitude_flags, int32_t data_index, double * d_det_data, int64_t n_samp,
+    const toast_hip_interval * intervals, int64_t n_view, void * stream) {
+    return guarded([&] {
+        if (step_length <= 0) fail_arg("step_length must be positive");
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        const OffsetViews ov = offset_views(intervals, n_amp_views, n_view);
+        ParamBlock pb;
+        const size_t o_ch = pb.push_vec(chunks);
+        const size_t o_vf = pb.push_vec(ov.first);
+        const size_t o_va = pb.push_vec(ov.aoff);
+        const char * d = pb.commit(as_stream(stream));
+        hipLaunchKernelGGL(k_offset_add_to_signal, chunk_grid(1, chunks.size()), dim3(kThreads), 0,
+                           as_stream(stream), (const Chunk *)(d + o_ch), (int)chunks.size(),
+                           (const int64_t *)(d + o_vf), (const int64_t *)(d + o_va),
+                           make_fastdiv(step_length), amp_offset, d_amplitudes, d_amplitude_flags,
+                           d_det_data + (int64_t)data_index * n_samp);
+        check_launch();
+    });
+}
+
+int toast_hip_template_offset_project_signal_dev(
+    int32_t data_index, const double * d_det_data, int32_t flag_index, const uint8_t * d_flag_data,
+    uint8_t flag_mask, int64_t step_length, int64_t amp_offset, const int64_t * n_amp_views,
+    double * d_amplitudes, const uint8_t * d_amplitude_flags, int64_t n_samp,
+    const toast_hip_interval * intervals, int64_t n_view, void * stream) {
+    return guarded([&] {
+        if (step_length <= 0) fail_arg("step_length must be positive");
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        const OffsetViews ov = offset_views(intervals, n_amp_views, n_view);
+        ParamBlock pb;
+        const size_t o_ch = pb.push_vec(chunks);
+        const size_t o_vf = pb.push_vec(ov.first);
+        const size_t o_va = pb.push_vec(ov.aoff);
+        const char * d = pb.commit(as_stream(stream));
+        const int use_flags = (flag_index >= 0) ? 1 : 0;
+        const uint8_t * frow = use_flags ? d_flag_data + (int64_t)flag_index * n_samp : nullptr;
+        hipLaunchKernelGGL(k_offset_project_signal, chunk_grid(1, chunks.size()), dim3(kThreads), 0,
+                           as_stream(stream), (const Chunk *)(d + o_ch), (int)chunks.size(),
+                           (const int64_t *)(d + o_vf), (const int64_t *)(d + o_va),
+                           make_fastdiv(step_length), amp_offset, d_amplitudes, d_amplitude_flags,
+                           d_det_data + (int64_t)data_index * n_samp, frow, flag_mask, use_flags);
+        check_launch();
+    });
+}
+
+int toast_hip_template_offset_apply_diag_precond_dev(const double * d_offset_var,
+                                                     const double * d_amp_in,
+                                                     const uint8_t * d_amplitude_flags,
+                                                     double * d_amp_out, int64_t n_amp,
+                                                     void * stream) {
+    return guarded([&] {
+        if (n_amp <= 0) return;
+        hipLaunchKernelGGL(k_offset_apply_diag_precond, flat_grid(n_amp), dim3(kThreads), 0,
+                           as_stream(stream), n_amp, d_offset_var, d_amp_in, d_amplitude_flags,
+                           d_amp_out);
+        check_launch();
+    });
+}
+
+int toast_hip_test_math_dev(int op, int64_t n, const double * d_a, const double * d_b, double * d_out,
+                            void * stream) {
+    return guarded([&] {
+        if (n <= 0) return;
+        hipLaunchKernelGGL(k_test_math, flat_grid(n), dim3(kThreads), 0, as_stream(stream), op, n, d_a,
+                           d_b, d_out);
+        check_launch();
+    });
+}
+
+}  // extern "C"

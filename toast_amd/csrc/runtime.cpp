@@ -1,0 +1,360 @@
+// runtime.cpp -- see runtime.hpp.  Reference counterpart of the memory manager:
+// /root/reference/src/toast/_libtoast/accelerator.cpp:233-766 (OmpManager).
+#include "runtime.hpp"
+
+#include <cstdio>
+#include <list>
+#include <mutex>
+
+namespace toast_hip {
+
+namespace {
+thread_local std::string g_last_error;
+}
+
+void set_last_error(const std::string & msg) { g_last_error = msg; }
+
+[[noreturn]] void fail_arg(const std::string & msg) { throw Error(TOAST_HIP_ERR_ARG, msg); }
+
+// ------------------------------------------------------------------ chunks
+std::vector<Chunk> make_chunks(const toast_hip_interval * ivl, int64_t n_view, int64_t n_samp) {
+    std::vector<Chunk> out;
+    for (int64_t v = 0; v < n_view; ++v) {
+        const int64_t first = ivl[v].first;
+        const int64_t last = ivl[v].last;
+        if (first < 0 || last > n_samp) {
+            std::ostringstream o;
+            o << "interval " << v << " = [" << first << ", " << last << ") is outside the "
+              << n_samp << " samples of the buffers";
+            fail_arg(o.str());
+        }
+        for (int64_t s = first; s < last; s += kChunk) {
+            const int64_t n = (last - s < kChunk) ? (last - s) : kChunk;
+            out.push_back(Chunk{s, (int32_t)n, (int32_t)v});
+        }
+    }
+    return out;
+}
+
+// ------------------------------------------------------------------ parameter blocks
+size_t ParamBlock::push(const void * src, size_t bytes) {
+    size_t off = (host_.size() + 15) & ~size_t(15);
+    host_.resize(off + bytes);
+    if (bytes) std::memcpy(host_.data() + off, src, bytes);
+    return off;
+}
+
+namespace {
+
+struct CachedBlock {
+    std::vector<char> host;
+    char * dev;
+    int device;
+};
+
+// Most-recently-used list of uploaded blocks; bounded in bytes.
+std::list<CachedBlock> g_blocks;
+size_t g_block_bytes = 0;
+constexpr size_t kBlockCacheBytes = size_t(256) << 20;
+std::mutex g_block_mutex;
+
+}  // namespace
+
+const char * ParamBlock::commit(hipStream_t stream) {
+    int dev = 0;
+    TH_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_block_mutex);
+    for (auto it = g_blocks.begin(); it != g_blocks.end(); ++it) {
+        if (it->device == dev && it->host.size() == host_.size() &&
+            std::memcmp(it->host.data(), host_.data(), host_.size()) == 0) {
+            g_blocks.splice(g_blocks.begin(), g_blocks, it);
+            return g_blocks.front().dev;
+        }
+    }
+    while (!g_blocks.empty() && g_block_bytes + host_.size() > kBlockCacheBytes) {
+        // Blocks still referenced by queued kernels must outlive them.
+        TH_HIP(hipDeviceSynchronize());
+        CachedBlock & old = g_blocks.back();
+        g_block_bytes -= old.host.size();
+        (void)hipFree(old.dev);
+        g_blocks.pop_back();
+    }
+    CachedBlock blk;
+    blk.device = dev;
+    blk.host = host_;
+    void * p = nullptr;
+    TH_HIP(hipMalloc(&p, host_.size() ? host_.size() : 16));
+    blk.dev = static_cast<char *>(p);
+    // The cached host copy outlives the asynchronous copy.
+    g_blocks.push_front(std::move(blk));
+    g_block_bytes += host_.size();
+    if (!host_.empty()) {
+        TH_HIP(hipMemcpyAsync(g_blocks.front().dev, g_blocks.front().host.data(), host_.size(),
+                              hipMemcpyHostToDevice, stream));
+    }
+    return g_blocks.front().dev;
+}
+
+// ------------------------------------------------------------------ manager
+Manager & Manager::get() {
+    static Manager m;
+    return m;
+}
+
+void Manager::clear() {
+    for (auto & kv : table_) (void)hipFree(kv.second.dev);
+    table_.clear();
+}
+
+void Manager::assign_device(int node_procs, int node_rank, double /*mem_gb*/, bool disabled) {
+    // accelerator.cpp:236-246
+    if (node_procs < 1 || node_rank < 0) {
+        throw Error(TOAST_HIP_ERR_ARG,
+                    "HipManager:  must have at least one process per node with a rank >= 0");
+    }
+    if (node_rank >= node_procs) {
+        throw Error(TOAST_HIP_ERR_ARG, "HipManager:  node rank must be < number of node procs");
+    }
+    clear();
+    int n_dev = 0;
+    if (!disabled) {
+        if (hipGetDeviceCount(&n_dev) != hipSuccess) n_dev = 0;
+    }
+    if (n_dev == 0) {
+        device_ = -1;
+    } else {
+        // accelerator.cpp:276-281: ceil(node_procs / n_dev) processes share a device
+        int per = node_procs / n_dev;
+        if (n_dev * per < node_procs) per += 1;
+        device_ = node_rank / per;
+        TH_HIP(hipSetDevice(device_));
+    }
+    assigned_ = true;
+}
+
+int Manager::device() {
+    if (!assigned_) {
+        throw Error(TOAST_HIP_ERR_DEVICE,
+                    "HipManager:  device not yet assigned, call assign_device() first");
+    }
+    return device_;
+}
+
+void Manager::require_device() {
+    if (device() < 0) {
+        throw Error(TOAST_HIP_ERR_DEVICE,
+                    "HipManager:  no gfx950 device is assigned to this process (disabled or "
+                    "none visible); libtoast_hip has no host implementation");
+    }
+    TH_HIP(hipSetDevice(device_));
+}
+
+Manager::Entry & Manager::lookup(const void * host, size_t nbytes, const char * name,
+                                 const char * what) {
+    auto it = table_.find(host);
+    std::ostringstream o;
+    if (it == table_.end()) {
+        o << "HipManager:  host ptr " << host << " (name='" << (name ? name : "NA")
+          << "') is not present- cannot " << what;
+        throw Error(TOAST_HIP_ERR_MEMORY, o.str());
+    }
+    if (it->second.nbytes != nbytes) {
+        o << "HipManager:  on " << what << ", host ptr " << host << " (name='" << it->second.name
+          << "') has " << it->second.nbytes << " bytes instead of " << nbytes;
+        throw Error(TOAST_HIP_ERR_MEMORY, o.str());
+    }
+    return it->second;
+}
+
+int Manager::present(const void * host, size_t nbytes) {
+    if (device() < 0) return 0;
+    auto it = table_.find(host);
+    if (it == table_.end()) return 0;
+    if (it->second.nbytes != nbytes) {
+        // accelerator.cpp:672-685
+        std::ostringstream o;
+        o << "HipManager:  host ptr " << host << " is present, but has " << it->second.nbytes
+          << " bytes instead of " << nbytes;
+        throw Error(TOAST_HIP_ERR_MEMORY, o.str());
+    }
+    return 1;
+}
+
+void * Manager::create(const void * host, size_t nbytes, const char * name) {
+    require_device();
+    auto it = table_.find(host);
+    if (it != table_.end()) {
+        // accelerator.cpp:339-347
+        std::ostringstream o;
+        o << "HipManager:  on create, host ptr " << host << " with " << nbytes
+          << " bytes (name='" << it->second.name << "') is already present with "
+          << it->second.nbytes << " bytes on device " << device_;
+        throw Error(TOAST_HIP_ERR_MEMORY, o.str());
+    }
+    void * dev = nullptr;
+    hipError_t e = hipMalloc(&dev, nbytes ? nbytes : 16);
+    if (e != hipSuccess || dev == nullptr) {
+        std::ostringstream o;
+        o << "HipManager:  on create, host ptr " << host << " with " << nbytes << " bytes (name='"
+          << (name ? name : "NA") << "') on device " << device_ << ", allocation failed";
+        throw Error(TOAST_HIP_ERR_MEMORY, o.str());
+    }
+    table_[host] = Entry{dev, nbytes, name ? name : "NA"};
+    return dev;
+}
+
+void Manager::reset(const void * host, size_t nbytes, const char * name) {
+    require_device();
+    Entry & e = lookup(host, nbytes, name, "reset data");
+    TH_HIP(hipMemsetAsync(e.dev, 0, nbytes, stream_));
+}
+
+void Manager::update_device(const void * host, size_t nbytes, const char * name) {
+    require_device();
+    Entry & e = lookup(host, nbytes, name, "update device");
+    // Pageable host memory: the call returns once the source has been consumed.
+    TH_HIP(hipMemcpyAsync(e.dev, host, nbytes, hipMemcpyHostToDevice, stream_));
+    TH_HIP(hipStreamSynchronize(stream_));
+}
+
+void Manager::update_host(void * host, size_t nbytes, const char * name) {
+    require_device();
+    Entry & e = lookup(host, nbytes, name, "update host");
+    TH_HIP(hipMemcpyAsync(host, e.dev, nbytes, hipMemcpyDeviceToHost, stream_));
+    TH_HIP(hipStreamSynchronize(stream_));
+}
+
+void Manager::remove(const void * host, size_t nbytes, const char * name) {
+    require_device();
+    Entry & e = lookup(host, nbytes, name, "delete");
+    TH_HIP(hipStreamSynchronize(stream_));
+    TH_HIP(hipFree(e.dev));
+    table_.erase(host);
+}
+
+void * Manager::find(const void * host) {
+    auto it = table_.find(host);
+    return (it == table_.end()) ? nullptr : it->second.dev;
+}
+
+void * Manager::device_ptr(const void * host) {
+    void * p = find(host);
+    if (p == nullptr) {
+        // accelerator.hpp:127-133
+        std::ostringstream o;
+        o << "HipManager:  host ptr " << host << " is not present- cannot get device pointer";
+        throw Error(TOAST_HIP_ERR_MEMORY, o.str());
+    }
+    return p;
+}
+
+void Manager::dump() {
+    std::printf("HipManager: device %d, %zu buffers\n", device_, table_.size());
+    for (auto & kv : table_) {
+        std::printf("  host %p -> dev %p  %zu bytes  '%s'\n", kv.first, kv.second.dev,
+                    kv.second.nbytes, kv.second.name.c_str());
+    }
+    std::fflush(stdout);
+}
+
+// ------------------------------------------------------------------ staging
+void * Staging::resolve(void * host, size_t bytes, bool upload, bool download, bool force_temp) {
+    if (host == nullptr) return nullptr;
+    if (accel_ && !force_temp) return Manager::get().device_ptr(host);
+    void * dev = nullptr;
+    TH_HIP(hipMalloc(&dev, bytes ? bytes : 16));
+    temps_.push_back(Temp{host, dev, bytes, download});
+    if (upload && bytes) {
+        TH_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, stream_));
+    }
+    return dev;
+}
+
+void Staging::finish() {
+    if (finished_) return;
+    finished_ = true;
+    if (temps_.empty()) return;
+    for (auto & t : temps_) {
+        if (t.download && t.bytes) {
+            TH_HIP(hipMemcpyAsync(t.host, t.dev, t.bytes, hipMemcpyDeviceToHost, stream_));
+        }
+    }
+    TH_HIP(hipStreamSynchronize(stream_));
+    for (auto & t : temps_) (void)hipFree(t.dev);
+    temps_.clear();
+}
+
+Staging::~Staging() {
+    if (!finished_) {
+        // error path: make sure nothing queued still uses the temporaries, then free them
+        (void)hipStreamSynchronize(stream_);
+        for (auto & t : temps_) (void)hipFree(t.dev);
+    }
+}
+
+}  // namespace toast_hip
+
+// ------------------------------------------------------------------ C ABI: runtime part
+using namespace toast_hip;
+
+extern "C" {
+
+const char * toast_hip_last_error(void) { return g_last_error.c_str(); }
+
+const char * toast_hip_version(void) { return "toast_hip 0.1 (gfx950)"; }
+
+int toast_hip_accel_enabled(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n > 0 ? 1 : 0;
+}
+
+int toast_hip_accel_assign_device(int node_procs, int node_rank, double mem_gb, int disabled) {
+    return guarded([&] { Manager::get().assign_device(node_procs, node_rank, mem_gb, disabled != 0); });
+}
+
+int toast_hip_accel_get_device(int * device) {
+    return guarded([&] { *device = Manager::get().device(); });
+}
+
+int toast_hip_accel_present(const void * host, size_t nbytes, int * present) {
+    return guarded([&] { *present = Manager::get().present(host, nbytes); });
+}
+
+int toast_hip_accel_create(const void * host, size_t nbytes, const char * name) {
+    return guarded([&] { Manager::get().create(host, nbytes, name); });
+}
+
+int toast_hip_accel_reset(const void * host, size_t nbytes, const char * name) {
+    return guarded([&] { Manager::get().reset(host, nbytes, name); });
+}
+
+int toast_hip_accel_update_device(const void * host, size_t nbytes, const char * name) {
+    return guarded([&] { Manager::get().update_device(host, nbytes, name); });
+}
+
+int toast_hip_accel_update_host(void * host, size_t nbytes, const char * name) {
+    return guarded([&] { Manager::get().update_host(host, nbytes, name); });
+}
+
+int toast_hip_accel_delete(const void * host, size_t nbytes, const char * name) {
+    return guarded([&] { Manager::get().remove(host, nbytes, name); });
+}
+
+int toast_hip_accel_device_ptr(const void * host, void ** device) {
+    return guarded([&] { *device = Manager::get().device_ptr(host); });
+}
+
+int toast_hip_accel_dump(void) {
+    return guarded([&] { Manager::get().dump(); });
+}
+
+int toast_hip_set_stream(void * stream) {
+    return guarded([&] { Manager::get().set_stream(static_cast<hipStream_t>(stream)); });
+}
+
+int toast_hip_synchronize(void) {
+    return guarded([&] { TH_HIP(hipStreamSynchronize(Manager::get().stream())); });
+}
+
+}  // extern "C"

@@ -1,0 +1,167 @@
+// runtime.hpp -- host-side runtime of libtoast_hip: error plumbing, device selection, the
+// host-pointer -> device-pointer memory manager (counterpart of the reference's OmpManager,
+// /root/reference/src/toast/_libtoast/accelerator.hpp:73-159) and the per-call parameter
+// block cache.  HIP only (gfx950); there is no host fallback anywhere in this library.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/toast_hip.h"
+
+namespace toast_hip {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string & m) : std::runtime_error(m), code(c) {}
+};
+
+void set_last_error(const std::string & msg);
+
+#define TH_HIP(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            std::ostringstream o_;                                                            \
+            o_ << "HIP error " << hipGetErrorName(e_) << " (" << hipGetErrorString(e_)        \
+               << ") at " << __FILE__ << ":" << __LINE__ << " in " #expr;                     \
+            throw ::toast_hip::Error(TOAST_HIP_ERR_DEVICE, o_.str());                         \
+        }                                                                                     \
+    } while (0)
+
+// Wrap the body of an extern "C" entry point.
+template <typename F>
+int guarded(F && f) noexcept {
+    try {
+        f();
+        return TOAST_HIP_OK;
+    } catch (const Error & e) {
+        set_last_error(e.what());
+        return e.code;
+    } catch (const std::exception & e) {
+        set_last_error(e.what());
+        return TOAST_HIP_ERR_ARG;
+    } catch (...) {
+        set_last_error("unknown error");
+        return TOAST_HIP_ERR_ARG;
+    }
+}
+
+[[noreturn]] void fail_arg(const std::string & msg);
+
+// ------------------------------------------------------------------ work decomposition
+// A chunk is a run of <= kChunk consecutive samples inside one interval; a workgroup
+// processes one (chunk, detector) pair.  16 bytes.
+constexpr int kChunk = 1024;
+struct Chunk {
+    int64_t first;   // first sample
+    int32_t count;   // number of samples (1..kChunk)
+    int32_t view;    // interval index
+};
+
+// ------------------------------------------------------------------ parameter blocks
+// Small per-call arrays (index arrays, chunk list, per-detector scalars) are packed into
+// one host block, deduplicated against recently used blocks and uploaded at most once:
+// a PCG loop re-issuing the same call pays no host->device traffic after the first pass.
+class ParamBlock {
+public:
+    // Append `bytes` from `src` aligned to 16; returns the byte offset inside the block.
+    size_t push(const void * src, size_t bytes);
+    template <typename T>
+    size_t push_vec(const std::vector<T> & v) {
+        return push(v.data(), v.size() * sizeof(T));
+    }
+    // Upload (or find cached) on `stream`; returns the device base pointer.
+    const char * commit(hipStream_t stream);
+
+private:
+    std::vector<char> host_;
+};
+
+std::vector<Chunk> make_chunks(const toast_hip_interval * ivl, int64_t n_view, int64_t n_samp);
+
+// ------------------------------------------------------------------ memory manager
+class Manager {
+public:
+    static Manager & get();
+
+    void assign_device(int node_procs, int node_rank, double mem_gb, bool disabled);
+    int device();               // throws if not yet assigned; -1 when disabled
+    void require_device();      // throws unless a GPU is assigned and usable; hipSetDevice
+    int present(const void * host, size_t nbytes);
+    void * create(const void * host, size_t nbytes, const char * name);
+    void reset(const void * host, size_t nbytes, const char * name);
+    void update_device(const void * host, size_t nbytes, const char * name);
+    void update_host(void * host, size_t nbytes, const char * name);
+    void remove(const void * host, size_t nbytes, const char * name);
+    void * device_ptr(const void * host);   // throws if absent
+    void * find(const void * host);         // nullptr if absent
+    void dump();
+    void clear();
+
+    hipStream_t stream() const { return stream_; }
+    void set_stream(hipStream_t s) { stream_ = s; }
+
+private:
+    struct Entry {
+        void * dev;
+        size_t nbytes;
+        std::string name;
+    };
+    Entry & lookup(const void * host, size_t nbytes, const char * name, const char * what);
+
+    std::unordered_map<const void *, Entry> table_;
+    bool assigned_ = false;
+    int device_ = -1;
+    hipStream_t stream_ = nullptr;
+};
+
+// Resolve one array of a host-level call.  use_accel: device copy must be registered.
+// Otherwise: stage a temporary device copy (optionally uploading the host contents) that is
+// copied back (if `out`) and released by finish().
+class Staging {
+public:
+    Staging(bool use_accel, hipStream_t stream) : accel_(use_accel), stream_(stream) {}
+    ~Staging();
+    template <typename T>
+    T * in(const T * host, size_t count) {
+        return static_cast<T *>(resolve(const_cast<T *>(host), count * sizeof(T), true, false));
+    }
+    template <typename T>
+    T * inout(T * host, size_t count) {
+        return static_cast<T *>(resolve(host, count * sizeof(T), true, true));
+    }
+    template <typename T>
+    T * out(T * host, size_t count) {
+        // outputs are partially written (intervals only): keep the host contents elsewhere
+        return static_cast<T *>(resolve(host, count * sizeof(T), true, true));
+    }
+    // Always staged (never looked up in the manager), e.g. hit_submaps.
+    template <typename T>
+    T * temp_inout(T * host, size_t count) {
+        return static_cast<T *>(resolve(host, count * sizeof(T), true, true, true));
+    }
+    void finish();  // copy outputs back, free temporaries, synchronise when anything was staged
+
+private:
+    void * resolve(void * host, size_t bytes, bool upload, bool download, bool force_temp = false);
+    struct Temp {
+        void * host;
+        void * dev;
+        size_t bytes;
+        bool download;
+    };
+    bool accel_;
+    hipStream_t stream_;
+    std::vector<Temp> temps_;
+    bool finished_ = false;
+};
+
+}  // namespace toast_hip
