@@ -1,0 +1,73 @@
+"""CPU: the C-ABI library loads, exports every symbol include/toast_hip.h declares, and
+fails loudly (no CPU fallback) when no GPU is usable."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "toast_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(toast_hip_[a-zA-Z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported():
+    from toast_amd import build, capi
+
+    build.build_library(verbose=False)
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 35
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_interval_layout():
+    from toast_amd import capi
+
+    assert capi.interval_dtype.itemsize == 32
+    assert [capi.interval_dtype.fields[k][1] for k in ("start", "stop", "first", "last")] == [0, 8, 16, 24]
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product path must raise, never compute on the host."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from toast_amd import capi
+
+    assert not capi.accel_enabled()
+    capi.accel_assign_device(1, 0, 1.0, False)
+    assert capi.accel_get_device() == -1
+    t = np.ones((1, 8))
+    iv = np.zeros(1, capi.interval_dtype)
+    iv["last"] = 8
+    with pytest.raises(RuntimeError, match="no host implementation"):
+        capi.noise_weight(t, np.zeros(1, np.int32), iv, np.ones(1), False)
+    with pytest.raises(RuntimeError):
+        capi.noise_weight(t, np.zeros(1, np.int32), iv, np.ones(1), True)
+    assert np.all(t == 1.0)
+    with pytest.raises(RuntimeError):
+        capi.accel_create(t, "t")
+    assert not capi.accel_present(t, "t")
+
+
+def test_buffer_validation_messages():
+    """extract_buffer-style checks happen before any device work (common.hpp:50-121)."""
+    from toast_amd import capi
+
+    iv = np.zeros(1, capi.interval_dtype)
+    with pytest.raises(RuntimeError, match="dimensions"):
+        capi.noise_weight(np.ones(8), np.zeros(1, np.int32), iv, np.ones(1), False)
+    with pytest.raises(RuntimeError, match="dtype"):
+        capi.noise_weight(np.ones((1, 8), np.float32), np.zeros(1, np.int32), iv, np.ones(1), False)
+    with pytest.raises(RuntimeError, match="contiguous"):
+        capi.noise_weight(np.ones((2, 16))[:, ::2], np.zeros(1, np.int32), iv, np.ones(1), False)
+    with pytest.raises(RuntimeError, match="length"):
+        capi.noise_weight(np.ones((1, 8)), np.zeros(1, np.int32), iv, np.ones(3), False)

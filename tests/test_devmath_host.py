@@ -1,0 +1,98 @@
+"""CPU: the device pointing math (toast_amd/csrc/hpix_math.hpp) compiled for the host must
+reproduce the oracle's pixel indices bit-for-bit; the run-time-constant divider must equal //."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from toast_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.fixture(scope="module")
+def devmath():
+    src = os.path.join(HERE, "devmath_host.cpp")
+    out = os.path.join(HERE, "libdevmath_host.so")
+    deps = [src, os.path.join(ROOT, "toast_amd", "csrc", "hpix_math.hpp")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off",
+                               "-mfma", src, "-o", out])
+    return C.CDLL(out)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _pixels(lib, q, nside, nest):
+    pix = np.empty(q.shape[0], np.int64)
+    lib.devmath_pixels(C.c_int64(q.shape[0]), _p(q), C.c_int64(nside), C.c_int(nest), _p(pix))
+    return pix
+
+
+def _oracle_pixels(oracle, q, nside, nest):
+    n = q.shape[0]
+    ref = np.empty((1, n), np.int64)
+    iv = np.zeros(1, oracle.interval_dtype)
+    iv["last"] = n
+    nps = 3072 if nside >= 16 else 12 * nside * nside
+    hs = np.zeros(12 * nside * nside // nps + 1, np.uint8)
+    oracle.pixels_healpix(np.zeros(1, np.int32), q.reshape(1, n, 4), np.zeros(1, np.uint8), 0,
+                          np.zeros(1, np.int32), ref, iv, hs, nps, nside, nest)
+    return ref[0]
+
+
+@pytest.mark.parametrize("nside", [1, 2, 64, 1024, 1 << 14, 1 << 20])
+@pytest.mark.parametrize("nest", [1, 0])
+def test_pixels_random(devmath, oracle, nside, nest):
+    rng = np.random.default_rng(nside + nest)
+    q = synth.quat_normalize(rng.standard_normal((1_000_000, 4)))
+    assert np.array_equal(_pixels(devmath, q, nside, nest), _oracle_pixels(oracle, q, nside, nest))
+
+
+def test_pixels_scan_and_special(devmath, oracle):
+    bore = synth.satellite_boresight(1_000_000, 200.0)
+    fp, _ = synth.hex_focalplane(4)
+    for d in range(4):
+        q = np.ascontiguousarray(synth.quat_mult(bore, fp[d]))
+        for nside in (512, 1024, 2048):
+            for nest in (1, 0):
+                assert np.array_equal(_pixels(devmath, q, nside, nest), _oracle_pixels(oracle, q, nside, nest))
+    # axis-aligned and pole directions (zeros, signed zeros in the rotated vector)
+    s = np.sqrt(0.5)
+    q = np.array([[0, 0, 0, 1], [1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [s, 0, 0, s], [0, s, 0, s], [0, 0, s, s],
+                  [-s, 0, 0, s], [0, -s, 0, s], [s, s, 0, 0], [0.5, 0.5, 0.5, 0.5], [-0.5, 0.5, -0.5, 0.5],
+                  [0, 0, 0, -1], [-0.0, 0.0, -0.0, 1.0]], dtype=np.float64)
+    for nside in (1, 8, 1024):
+        for nest in (1, 0):
+            assert np.array_equal(_pixels(devmath, q, nside, nest), _oracle_pixels(oracle, q, nside, nest))
+
+
+def test_atan2_vs_glibc(devmath, oracle):
+    rng = np.random.default_rng(1)
+    n = 2_000_000
+    y = rng.standard_normal(n)
+    x = rng.standard_normal(n)
+    out = np.empty(n)
+    devmath.devmath_atan2(C.c_int64(n), _p(y), _p(x), _p(out))
+    ref = oracle.libm_atan2(y, x)
+    d = np.abs(out.view(np.int64) - ref.view(np.int64))
+    assert d.max() <= 1
+    assert np.count_nonzero(d) < 4e-3 * n  # glibc's own misrounding rate is ~1e-3
+
+
+def test_fastdiv(devmath):
+    rng = np.random.default_rng(2)
+    for d in (1, 2, 3, 7, 12, 48, 3072, 3073, 12 * 4096, (1 << 31) - 1, (1 << 40) + 3):
+        num = np.concatenate([
+            rng.integers(0, 1 << 62, 100000, dtype=np.int64),
+            rng.integers(0, 1 << 30, 100000, dtype=np.int64),
+            np.array([0, 1, d - 1, d, d + 1, 2 * d - 1, 2 * d, (1 << 62), (1 << 63) - 1], dtype=np.int64),
+        ])
+        q = np.empty_like(num)
+        devmath.devmath_fastdiv(C.c_int64(num.size), _p(num), C.c_int64(d), _p(q))
+        assert np.array_equal(q, num // d), d
