@@ -49,6 +49,14 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `python -m toast_amd.build` "
                 "(the HIP library is the only implementation of this path)"
             )
+        # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64.so (SONAME
+        # libamdhip64.so.7) and look it up by file name, so if /opt/rocm's copy were loaded first
+        # torch would load a second runtime and lose the GPU.  Importing torch first makes the
+        # loader resolve our NEEDED libamdhip64.so.7 / librocfft.so.0 to the already loaded ones.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = C.CDLL(LIB_PATH)
         _lib.toast_hip_last_error.restype = C.c_char_p
         _lib.toast_hip_version.restype = C.c_char_p
