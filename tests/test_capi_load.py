@@ -71,3 +71,20 @@ def test_buffer_validation_messages():
         capi.noise_weight(np.ones((2, 16))[:, ::2], np.zeros(1, np.int32), iv, np.ones(1), False)
     with pytest.raises(RuntimeError, match="length"):
         capi.noise_weight(np.ones((1, 8)), np.zeros(1, np.int32), iv, np.ones(3), False)
+
+
+def test_pybind_module_names_match_reference():
+    """Every hot-path name of toast._libtoast exists with that spelling."""
+    import toast_amd
+
+    m = toast_amd.load_native()
+    for name in ("pixels_healpix", "pointing_detector", "stokes_weights_IQU", "stokes_weights_I",
+                 "ops_scan_map_float64", "ops_scan_map_float32", "ops_scan_map_int64", "ops_scan_map_int32",
+                 "build_noise_weighted", "noise_weight", "template_offset_add_to_signal",
+                 "template_offset_project_signal", "template_offset_apply_diag_precond", "cov_apply_diag",
+                 "accel_enabled", "accel_assign_device", "accel_get_device", "accel_present", "accel_create",
+                 "accel_reset", "accel_update_device", "accel_update_host", "accel_delete", "accel_dump", "Interval"):
+        assert hasattr(m, name), name
+    iv = m.Interval()
+    iv.first, iv.last = 3, 9
+    assert iv.astuple()[2:] == (3, 9)

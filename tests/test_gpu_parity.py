@@ -196,3 +196,21 @@ def test_error_paths(hip):
         hip.noise_weight(t.astype(np.float32), c["data_index"], c["intervals"], c["det_scale"], False)
     with pytest.raises(RuntimeError):
         hip.noise_weight(t, c["data_index"].astype(np.int64), c["intervals"], c["det_scale"], False)
+
+
+@pytest.mark.parametrize("name", ["split_gap_extra_hwp", "ragged"])
+def test_pybind_module_matches_oracle(oracle, name):
+    """The pybind11 host layer (toast._libtoast names/signatures) over the same C ABI."""
+    import toast_amd
+
+    m = toast_amd.load_native()
+    assert m.accel_enabled()
+    m.accel_assign_device(1, 0, 1.0, False)
+    c = cases.make_case(**CASES[name])
+    got = cases.run_chain(m, c, nest=True, tail=(False,))
+    want = cases.run_chain(oracle, c, nest=True)
+    compare_chain(got, want)
+    with pytest.raises(RuntimeError, match="dimensions instead of"):
+        m.noise_weight(np.ones(8), c["data_index"], c["intervals"], c["det_scale"], False)
+    with pytest.raises(RuntimeError, match="instead of"):
+        m.noise_weight(np.ones((4, 8), np.float32), c["data_index"], c["intervals"], c["det_scale"], False)

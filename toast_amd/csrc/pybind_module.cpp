@@ -1,0 +1,417 @@
+// pybind_module.cpp -- `toast_amd._libtoast_hip`: the pybind11 host layer over the C ABI.
+//
+// Exposes the map-making hot path under the SAME Python names and argument orders as the
+// reference's `toast._libtoast`, so that a kernels.py wrapper can switch
+// `from ..._libtoast import pixels_healpix` to this module unchanged.  Buffers are validated
+// like the reference's extract_buffer<T> (src/toast/_libtoast/common.hpp:32-124) -- same
+// checks, same messages -- and then handed to libtoast_hip.so as plain pointers + sizes.
+// Built with g++ only (no HIP headers): everything device-side sits behind include/toast_hip.h.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+
+#include <cstdint>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "toast_hip.h"
+
+namespace py = pybind11;
+
+namespace {
+
+using Shape = std::vector<int64_t>;
+
+// numpy int64 may be reported as 'q' or 'l' (common.hpp:57-63)
+std::string norm_format(const std::string & f) {
+    std::string s;
+    for (char ch : f) {
+        if (ch == '@' || ch == '=' || ch == '<' || ch == '>' || ch == '!') continue;
+        s.push_back(ch);
+    }
+    if (s == "l") s = "q";
+    if (s == "L") s = "Q";
+    return s;
+}
+
+template <typename T>
+std::string target_format() {
+    return norm_format(py::format_descriptor<T>::format());
+}
+
+[[noreturn]] void raise(const std::ostringstream & o) { throw std::runtime_error(o.str()); }
+
+// Generic extraction: dtype given by format string + item size so that the Interval struct
+// (a structured dtype) can be checked too.
+void * extract_raw(py::buffer data, const char * name, const std::string & want_format, size_t itemsize,
+                   bool check_format, size_t assert_dims, Shape & shape, const Shape & assert_shape) {
+    auto info = data.request();
+    std::ostringstream o;
+    if (check_format) {
+        const std::string got = norm_format(info.format);
+        if (got != want_format) {
+            o << "Object " << name << " has format \"" << got << "\" instead of \"" << want_format << "\"";
+            raise(o);
+        }
+    }
+    if ((size_t)info.itemsize != itemsize) {
+        o << "Object " << name << " has item size of " << info.itemsize << " instead of " << itemsize;
+        raise(o);
+    }
+    if ((size_t)info.ndim != assert_dims) {
+        o << "Object " << name << " has " << info.ndim << " dimensions instead of " << assert_dims;
+        raise(o);
+    }
+    shape.assign(info.shape.begin(), info.shape.end());
+    py::ssize_t stride = info.itemsize;
+    for (int d = (int)info.ndim - 1; d >= 0; d--) {
+        if (info.strides[d] != stride && info.shape[d] > 1) {
+            o << "Object " << name << ": python buffers must be contiguous in memory.";
+            raise(o);
+        }
+        stride *= info.shape[d];
+    }
+    for (size_t d = 0; d < assert_dims; d++) {
+        if (assert_shape[d] >= 0 && assert_shape[d] != shape[d]) {
+            o << "Object " << name << " dimension " << d << " has length " << shape[d] << " instead of "
+              << assert_shape[d];
+            raise(o);
+        }
+    }
+    return info.ptr;
+}
+
+template <typename T>
+T * extract(py::buffer data, const char * name, size_t dims, Shape & shape, const Shape & assert_shape) {
+    return static_cast<T *>(
+        extract_raw(data, name, target_format<T>(), sizeof(T), true, dims, shape, assert_shape));
+}
+
+toast_hip_interval * extract_intervals(py::buffer data, Shape & shape) {
+    return static_cast<toast_hip_interval *>(
+        extract_raw(data, "intervals", "", sizeof(toast_hip_interval), false, 1, shape, {-1}));
+}
+
+void check(int rc) {
+    if (rc != TOAST_HIP_OK) throw std::runtime_error(toast_hip_last_error());
+}
+
+struct RawBuf {
+    void * ptr;
+    size_t nbytes;
+};
+
+// accel_* take any contiguous buffer; the key is its base pointer and byte size
+// (accelerator.cpp:722-766 extract_accel_buffer)
+RawBuf accel_buf(py::buffer data) {
+    auto info = data.request();
+    size_t n = (size_t)info.itemsize;
+    for (auto s : info.shape) n *= (size_t)s;
+    return RawBuf{info.ptr, n};
+}
+
+template <int DTYPE, typename T>
+void scan_map_binding(py::buffer global2local, int64_t n_pix_submap, py::buffer mapdata, py::buffer det_data,
+                      py::buffer data_index, py::buffer pixels, py::buffer pixel_index, py::buffer weights,
+                      py::buffer weight_index, py::buffer intervals, double data_scale, bool should_zero,
+                      bool should_subtract, bool should_scale, bool use_accel) {
+    Shape s(3);
+    int32_t * p_idx = extract<int32_t>(pixel_index, "pixel_index", 1, s, {-1});
+    const int64_t n_det = s[0];
+    int64_t * pix = extract<int64_t>(pixels, "pixels", 2, s, {-1, -1});
+    const int64_t n_pix_rows = s[0], n_samp = s[1];
+    int32_t * w_idx = extract<int32_t>(weight_index, "weight_index", 1, s, {n_det});
+    // weights may be 2-D (nnz = 1) or 3-D (ops_scan_map.cpp:125-139)
+    double * w;
+    int64_t nnz, n_w_rows;
+    if (weights.request().ndim == 2) {
+        w = extract<double>(weights, "weights", 2, s, {-1, n_samp});
+        nnz = 1;
+        n_w_rows = s[0];
+    } else {
+        w = extract<double>(weights, "weights", 3, s, {-1, n_samp, -1});
+        nnz = s[2];
+        n_w_rows = s[0];
+    }
+    int32_t * d_idx = extract<int32_t>(data_index, "data_index", 1, s, {n_det});
+    double * tod = extract<double>(det_data, "det_data", 2, s, {-1, n_samp});
+    const int64_t n_d_rows = s[0];
+    toast_hip_interval * ivl = extract_intervals(intervals, s);
+    const int64_t n_view = s[0];
+    int64_t * g2l = extract<int64_t>(global2local, "global2local", 1, s, {-1});
+    const int64_t n_submap = s[0];
+    T * map = extract<T>(mapdata, "mapdata", 3, s, {-1, n_pix_submap, nnz});
+    const int64_t n_local = s[0];
+    check(toast_hip_scan_map(DTYPE, g2l, n_submap, n_pix_submap, map, n_local, nnz, tod, n_d_rows, d_idx, pix,
+                             n_pix_rows, p_idx, w, n_w_rows, w_idx, n_det, n_samp, ivl, n_view, data_scale,
+                             should_zero, should_subtract, should_scale, use_accel));
+}
+
+}  // namespace
+
+PYBIND11_MODULE(_libtoast_hip, m) {
+    m.doc() = "MI355X (gfx950) implementation of toast._libtoast's map-making hot path";
+
+    // ---- Interval dtype (intervals.cpp:11-38)
+    PYBIND11_NUMPY_DTYPE(toast_hip_interval, start, stop, first, last);
+    py::class_<toast_hip_interval>(m, "Interval", "Numpy dtype for an interval")
+        .def(py::init([]() { return toast_hip_interval(); }))
+        .def_readwrite("start", &toast_hip_interval::start)
+        .def_readwrite("stop", &toast_hip_interval::stop)
+        .def_readwrite("first", &toast_hip_interval::first)
+        .def_readwrite("last", &toast_hip_interval::last)
+        .def("astuple", [](const toast_hip_interval & s) { return py::make_tuple(s.start, s.stop, s.first, s.last); });
+
+    // ---- accelerator management (accelerator.cpp:768-1110)
+    m.def("accel_enabled", []() { return toast_hip_accel_enabled() != 0; });
+    m.def("accel_assign_device", [](int node_procs, int node_rank, float mem_gb, bool disabled) {
+        check(toast_hip_accel_assign_device(node_procs, node_rank, mem_gb, disabled));
+    });
+    m.def("accel_get_device", []() {
+        int d = -1;
+        check(toast_hip_accel_get_device(&d));
+        return d;
+    });
+    m.def("accel_present", [](py::buffer data, std::string name) {
+        RawBuf b = accel_buf(data);
+        int r = 0;
+        check(toast_hip_accel_present(b.ptr, b.nbytes, &r));
+        return r != 0;
+    }, py::arg("data"), py::arg("name"));
+    m.def("accel_create", [](py::buffer data, std::string name) {
+        RawBuf b = accel_buf(data);
+        check(toast_hip_accel_create(b.ptr, b.nbytes, name.c_str()));
+    }, py::arg("data"), py::arg("name"));
+    m.def("accel_reset", [](py::buffer data, std::string name) {
+        RawBuf b = accel_buf(data);
+        check(toast_hip_accel_reset(b.ptr, b.nbytes, name.c_str()));
+    }, py::arg("data"), py::arg("name"));
+    m.def("accel_update_device", [](py::buffer data, std::string name) {
+        RawBuf b = accel_buf(data);
+        check(toast_hip_accel_update_device(b.ptr, b.nbytes, name.c_str()));
+    }, py::arg("data"), py::arg("name"));
+    m.def("accel_update_host", [](py::buffer data, std::string name) {
+        RawBuf b = accel_buf(data);
+        check(toast_hip_accel_update_host(b.ptr, b.nbytes, name.c_str()));
+    }, py::arg("data"), py::arg("name"));
+    m.def("accel_delete", [](py::buffer data, std::string name) {
+        RawBuf b = accel_buf(data);
+        check(toast_hip_accel_delete(b.ptr, b.nbytes, name.c_str()));
+    }, py::arg("data"), py::arg("name"));
+    m.def("accel_dump", []() { check(toast_hip_accel_dump()); });
+    m.def("accel_synchronize", []() { check(toast_hip_synchronize()); });
+
+    // ---- pointing_detector (ops_pointing_detector.cpp:78-88)
+    m.def("pointing_detector", [](py::buffer focalplane, py::buffer boresight, py::buffer quat_index,
+                                  py::buffer quats, py::buffer intervals, py::buffer shared_flags,
+                                  uint8_t shared_flag_mask, bool use_accel) {
+        Shape s(3);
+        int32_t * q_idx = extract<int32_t>(quat_index, "quat_index", 1, s, {-1});
+        const int64_t n_det = s[0];
+        double * fp = extract<double>(focalplane, "focalplane", 2, s, {n_det, 4});
+        double * bore = extract<double>(boresight, "boresight", 2, s, {-1, 4});
+        const int64_t n_samp = s[0];
+        double * q = extract<double>(quats, "quats", 3, s, {-1, n_samp, 4});
+        const int64_t n_q_rows = s[0];
+        toast_hip_interval * ivl = extract_intervals(intervals, s);
+        const int64_t n_view = s[0];
+        uint8_t * fl = extract<uint8_t>(shared_flags, "flags", 1, s, {-1});
+        check(toast_hip_pointing_detector(fp, bore, q_idx, n_det, q, n_q_rows, n_samp, ivl, n_view, fl, s[0],
+                                          shared_flag_mask, use_accel));
+    });
+
+    // ---- pixels_healpix (ops_pixels_healpix.cpp:1153-1167)
+    m.def("pixels_healpix", [](py::buffer quat_index, py::buffer quats, py::buffer shared_flags,
+                               uint8_t shared_flag_mask, py::buffer pixel_index, py::buffer pixels,
+                               py::buffer intervals, py::buffer hit_submaps, int64_t n_pix_submap, int64_t nside,
+                               bool nest, bool use_accel) {
+        Shape s(3);
+        int32_t * q_idx = extract<int32_t>(quat_index, "quat_index", 1, s, {-1});
+        const int64_t n_det = s[0];
+        int32_t * p_idx = extract<int32_t>(pixel_index, "pixel_index", 1, s, {n_det});
+        int64_t * pix = extract<int64_t>(pixels, "pixels", 2, s, {-1, -1});
+        const int64_t n_p_rows = s[0], n_samp = s[1];
+        double * q = extract<double>(quats, "quats", 3, s, {-1, n_samp, 4});
+        const int64_t n_q_rows = s[0];
+        toast_hip_interval * ivl = extract_intervals(intervals, s);
+        const int64_t n_view = s[0];
+        uint8_t * hs = extract<uint8_t>(hit_submaps, "hit_submaps", 1, s, {-1});
+        const int64_t n_submap = s[0];
+        uint8_t * fl = extract<uint8_t>(shared_flags, "flags", 1, s, {-1});
+        check(toast_hip_pixels_healpix(q_idx, n_det, q, n_q_rows, fl, s[0], shared_flag_mask, p_idx, pix, n_p_rows,
+                                       n_samp, ivl, n_view, hs, n_submap, n_pix_submap, nside, nest, use_accel));
+    });
+
+    // ---- stokes weights (ops_stokes_weights.cpp:151-163, :398-404)
+    m.def("stokes_weights_IQU", [](py::buffer quat_index, py::buffer quats, py::buffer weight_index,
+                                   py::buffer weights, py::buffer hwp, py::buffer intervals, py::buffer epsilon,
+                                   py::buffer gamma, py::buffer cal, bool IAU, bool use_accel) {
+        Shape s(3);
+        int32_t * q_idx = extract<int32_t>(quat_index, "quat_index", 1, s, {-1});
+        const int64_t n_det = s[0];
+        int32_t * w_idx = extract<int32_t>(weight_index, "weight_index", 1, s, {n_det});
+        double * w = extract<double>(weights, "weights", 3, s, {-1, -1, 3});
+        const int64_t n_w_rows = s[0], n_samp = s[1];
+        double * q = extract<double>(quats, "quats", 3, s, {-1, n_samp, 4});
+        const int64_t n_q_rows = s[0];
+        double * h = extract<double>(hwp, "hwp", 1, s, {-1});
+        const int64_t n_hwp = s[0];
+        toast_hip_interval * ivl = extract_intervals(intervals, s);
+        const int64_t n_view = s[0];
+        double * eps = extract<double>(epsilon, "epsilon", 1, s, {n_det});
+        double * cl = extract<double>(cal, "cal", 1, s, {n_det});
+        double * gm = extract<double>(gamma, "gamma", 1, s, {n_det});
+        check(toast_hip_stokes_weights_IQU(q_idx, n_det, q, n_q_rows, w_idx, w, n_w_rows, n_samp, h, n_hwp, ivl,
+                                           n_view, eps, gm, cl, IAU, use_accel));
+    });
+    m.def("stokes_weights_I", [](py::buffer weight_index, py::buffer weights, py::buffer intervals,
+                                 py::buffer cal, bool use_accel) {
+        Shape s(3);
+        int32_t * w_idx = extract<int32_t>(weight_index, "weight_index", 1, s, {-1});
+        const int64_t n_det = s[0];
+        double * w = extract<double>(weights, "weights", 2, s, {n_det, -1});
+        const int64_t n_samp = s[1];
+        toast_hip_interval * ivl = extract_intervals(intervals, s);
+        const int64_t n_view = s[0];
+        double * cl = extract<double>(cal, "cal", 1, s, {n_det});
+        check(toast_hip_stokes_weights_I(w_idx, n_det, w, n_det, n_samp, ivl, n_view, cl, use_accel));
+    });
+
+    // ---- scan_map, four map dtypes (ops_scan_map.cpp:84-102)
+    m.def("ops_scan_map_float64", &scan_map_binding<TOAST_HIP_MAP_F64, double>);
+    m.def("ops_scan_map_float32", &scan_map_binding<TOAST_HIP_MAP_F32, float>);
+    m.def("ops_scan_map_int64", &scan_map_binding<TOAST_HIP_MAP_I64, int64_t>);
+    m.def("ops_scan_map_int32", &scan_map_binding<TOAST_HIP_MAP_I32, int32_t>);
+
+    // ---- build_noise_weighted (ops_mapmaker_utils.cpp:93-111)
+    m.def("build_noise_weighted", [](py::buffer global2local, py::buffer zmap, py::buffer pixel_index,
+                                     py::buffer pixels, py::buffer weight_index, py::buffer weights,
+                                     py::buffer data_index, py::buffer det_data, py::buffer flag_index,
+                                     py::buffer det_flags, py::buffer det_scale, uint8_t det_flag_mask,
+                                     py::buffer intervals, py::buffer shared_flags, uint8_t shared_flag_mask,
+                                     bool use_accel) {
+        Shape s(3);
+        int32_t * p_idx = extract<int32_t>(pixel_index, "pixel_index", 1, s, {-1});
+        const int64_t n_det = s[0];
+        int64_t * pix = extract<int64_t>(pixels, "pixels", 2, s, {-1, -1});
+        const int64_t n_p_rows = s[0], n_samp = s[1];
+        int32_t * w_idx = extract<int32_t>(weight_index, "weight_index", 1, s, {n_det});
+        double * w;
+        int64_t nnz, n_w_rows;
+        if (weights.request().ndim == 2) {
+            w = extract<double>(weights, "weights", 2, s, {-1, n_samp});
+            nnz = 1;
+            n_w_rows = s[0];
+        } else {
+            w = extract<double>(weights, "weights", 3, s, {-1, n_samp, -1});
+            nnz = s[2];
+            n_w_rows = s[0];
+        }
+        int32_t * d_idx = extract<int32_t>(data_index, "data_index", 1, s, {n_det});
+        double * tod = extract<double>(det_data, "det_data", 2, s, {-1, n_samp});
+        const int64_t n_d_rows = s[0];
+        int32_t * f_idx = extract<int32_t>(flag_index, "flag_index", 1, s, {n_det});
+        double * dscale = extract<double>(det_scale, "det_scale", 1, s, {n_det});
+        toast_hip_interval * ivl = extract_intervals(intervals, s);
+        const int64_t n_view = s[0];
+        int64_t * g2l = extract<int64_t>(global2local, "global2local", 1, s, {-1});
+        const int64_t n_submap = s[0];
+        double * z = extract<double>(zmap, "zmap", 3, s, {-1, -1, nnz});
+        const int64_t n_local = s[0], nps = s[1];
+        uint8_t * sf = extract<uint8_t>(shared_flags, "flags", 1, s, {-1});
+        const int64_t n_sf = s[0];
+        uint8_t * df = extract<uint8_t>(det_flags, "det_flags", 2, s, {-1, -1});
+        check(toast_hip_build_noise_weighted(g2l, n_submap, z, n_local, nps, nnz, p_idx, pix, n_p_rows, w_idx, w,
+                                             n_w_rows, d_idx, tod, n_d_rows, f_idx, df, s[0], s[1], dscale,
+                                             det_flag_mask, n_det, n_samp, ivl, n_view, sf, n_sf, shared_flag_mask,
+                                             use_accel));
+    });
+
+    // ---- noise_weight (ops_noise_weight.cpp:12-19)
+    m.def("noise_weight", [](py::buffer det_data, py::buffer data_index, py::buffer intervals,
+                             py::buffer detector_weights, bool use_accel) {
+        Shape s(3);
+        int32_t * d_idx = extract<int32_t>(data_index, "data_index", 1, s, {-1});
+        const int64_t n_det = s[0];
+        double * tod = extract<double>(det_data, "det_data", 2, s, {-1, -1});
+        const int64_t n_rows = s[0], n_samp = s[1];
+        toast_hip_interval * ivl = extract_intervals(intervals, s);
+        const int64_t n_view = s[0];
+        double * dw = extract<double>(detector_weights, "detector_weights", 1, s, {n_det});
+        check(toast_hip_noise_weight(tod, n_rows, n_samp, d_idx, n_det, ivl, n_view, dw, use_accel));
+    });
+
+    // ---- cov_apply_diag (map_cov.cpp:372-401; flat buffers)
+    m.def("cov_apply_diag", [](int64_t nsub, int64_t nsubpix, int64_t nnz, py::buffer mat, py::buffer vec,
+                               bool use_accel) {
+        auto im = mat.request();
+        auto iv = vec.request();
+        if (norm_format(im.format) != "d" || norm_format(iv.format) != "d") {
+            throw std::runtime_error("cov_apply_diag: buffers must be float64");
+        }
+        const int64_t block = nnz * (nnz + 1) / 2;
+        const size_t nb = (size_t)(im.size / block), nv = (size_t)(iv.size / nnz);
+        if (nb != nv) {
+            std::ostringstream o;
+            o << "Buffer sizes are not consistent. npix_matrix = " << nb << ", npix_map = " << nv
+              << ", matrix_size = " << im.size << ", block = " << block << ", nnz = " << nnz;
+            raise(o);
+        }
+        check(toast_hip_cov_apply_diag(nsub, nsubpix, nnz, static_cast<double *>(im.ptr),
+                                       static_cast<double *>(iv.ptr), use_accel));
+    }, py::arg("nsub"), py::arg("nsubpix"), py::arg("nnz"), py::arg("mat"), py::arg("vec"),
+       py::arg("use_accel") = false);
+
+    // ---- offset template (template_offset.cpp:16-25, :149-162, :334-340)
+    m.def("template_offset_add_to_signal", [](int64_t step_length, int64_t amp_offset, py::buffer n_amp_views,
+                                              py::buffer amplitudes, py::buffer amplitude_flags,
+                                              int32_t data_index, py::buffer det_data, py::buffer intervals,
+                                              bool use_accel) {
+        Shape s(3);
+        double * amps = extract<double>(amplitudes, "amplitudes", 1, s, {-1});
+        const int64_t n_amp = s[0];
+        uint8_t * af = extract<uint8_t>(amplitude_flags, "amplitude_flags", 1, s, {n_amp});
+        double * tod = extract<double>(det_data, "det_data", 2, s, {-1, -1});
+        const int64_t n_rows = s[0], n_samp = s[1];
+        toast_hip_interval * ivl = extract_intervals(intervals, s);
+        const int64_t n_view = s[0];
+        int64_t * nav = extract<int64_t>(n_amp_views, "n_amp_views", 1, s, {n_view});
+        check(toast_hip_template_offset_add_to_signal(step_length, amp_offset, nav, amps, af, n_amp, data_index, tod,
+                                                      n_rows, n_samp, ivl, n_view, use_accel));
+    });
+    m.def("template_offset_project_signal", [](int32_t data_index, py::buffer det_data, int32_t flag_index,
+                                               py::buffer flag_data, uint8_t flag_mask, int64_t step_length,
+                                               int64_t amp_offset, py::buffer n_amp_views, py::buffer amplitudes,
+                                               py::buffer amplitude_flags, py::buffer intervals, bool use_accel) {
+        Shape s(3);
+        double * amps = extract<double>(amplitudes, "amplitudes", 1, s, {-1});
+        const int64_t n_amp = s[0];
+        uint8_t * af = extract<uint8_t>(amplitude_flags, "amplitude_flags", 1, s, {n_amp});
+        double * tod = extract<double>(det_data, "det_data", 2, s, {-1, -1});
+        const int64_t n_rows = s[0], n_samp = s[1];
+        toast_hip_interval * ivl = extract_intervals(intervals, s);
+        const int64_t n_view = s[0];
+        int64_t * nav = extract<int64_t>(n_amp_views, "n_amp_views", 1, s, {n_view});
+        uint8_t * fd = nullptr;
+        int64_t n_f_rows = 0;
+        if (flag_index >= 0) {
+            fd = extract<uint8_t>(flag_data, "flag_data", 2, s, {-1, n_samp});
+            n_f_rows = s[0];
+        }
+        check(toast_hip_template_offset_project_signal(data_index, tod, n_rows, flag_index, fd, n_f_rows, flag_mask,
+                                                       step_length, amp_offset, nav, amps, af, n_amp, n_samp, ivl,
+                                                       n_view, use_accel));
+    });
+    m.def("template_offset_apply_diag_precond", [](py::buffer offset_var, py::buffer amplitudes_in,
+                                                   py::buffer amplitude_flags, py::buffer amplitudes_out,
+                                                   bool use_accel) {
+        Shape s(3);
+        double * in = extract<double>(amplitudes_in, "amplitudes_in", 1, s, {-1});
+        const int64_t n_amp = s[0];
+        double * out = extract<double>(amplitudes_out, "amplitudes_out", 1, s, {n_amp});
+        double * var = extract<double>(offset_var, "offset_var", 1, s, {n_amp});
+        uint8_t * af = extract<uint8_t>(amplitude_flags, "amplitude_flags", 1, s, {n_amp});
+        check(toast_hip_template_offset_apply_diag_precond(var, in, af, out, n_amp, use_accel));
+    });
+}
