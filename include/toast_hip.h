@@ -300,6 +300,41 @@ int toast_hip_template_offset_apply_diag_precond_dev(
     double * d_amp_out, int64_t n_amp, void * stream);
 
 /* ------------------------------------------------------------------------------------
+ * FFT noise weighting (rocFFT)
+ *
+ * toast_hip_fft_convolve: in-place convolution (or deconvolution) of each selected timestream
+ * with a Fourier-domain kernel -- toast.fft.convolve(..., algorithm="numpy")
+ * [ref: src/toast/fft.py:163-212, 252-350; caller src/toast/ops/noise_filter.py:130-188].
+ * The kernel is passed the way the reference evaluates it: |K| and arg K as PCHIP piecewise
+ * cubics on the common kernel frequencies (`knots`), as scipy PPoly coefficients
+ * coef[kernel][interval][4] (highest power first); ang_coef may be NULL (real kernel >= 0).
+ * n_kernel is 1 (one kernel for all detectors) or n_det.  `apodize` is the n_reflect-sample
+ * half window of fft.py:163-171.  n_fft = toast_hip_fft_length(n_samp).
+ *
+ * toast_hip_fft_r1d: batched 1-D real transforms in FFTW half-complex layout -- the
+ * FFTPlanReal1D exec of the reference [ref: src/libtoast/include/toast/math_fft.hpp:24-82,
+ * src/libtoast/src/toast_math_fft_fftw.cpp:26-128, cuFFT variant toast_math_fft_cufft.cpp:16-238]:
+ * forward: out = scale * r2hc(in); backward: out = (scale / length) * hc2r(in).
+ * ---------------------------------------------------------------------------------- */
+int64_t toast_hip_fft_length(int64_t n_samp);
+
+int toast_hip_fft_convolve(
+    double * det_data, int64_t n_data_rows, const int32_t * data_index, int64_t n_det, int64_t n_samp,
+    double rate, const double * knots, int64_t n_knot, const double * mag_coef, const double * ang_coef,
+    int64_t n_kernel, int deconvolve, const double * apodize, int64_t n_apodize, int use_accel);
+
+int toast_hip_fft_convolve_dev(
+    double * d_det_data, const int32_t * data_index /*host*/, int64_t n_det, int64_t n_samp, double rate,
+    const double * knots /*host*/, int64_t n_knot, const double * mag_coef /*host*/,
+    const double * ang_coef /*host or NULL*/, int64_t n_kernel, int deconvolve,
+    const double * apodize /*host*/, int64_t n_apodize, int64_t max_batch, void * stream);
+
+int toast_hip_fft_r1d(int forward, int64_t length, int64_t count, const double * in, double * out,
+                      double scale, int use_accel);
+int toast_hip_fft_r1d_dev(int forward, int64_t length, int64_t count, const double * d_in, double * d_out,
+                          double scale, void * stream);
+
+/* ------------------------------------------------------------------------------------
  * Test / measurement helpers (device primitives compared per operation with the CPU).
  * ---------------------------------------------------------------------------------- */
 int toast_hip_test_math_dev(int op /*0 atan2(a,b), 1 sqrt(a), 2 a/b*/, int64_t n, const double * d_a,

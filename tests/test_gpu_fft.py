@@ -1,0 +1,128 @@
+"""GPU: rocFFT noise-weighting pipeline against the NumPy restatement of toast.fft.convolve
+(oracle/fft_oracle.py), tolerance 1e-12 relative to the signal scale, plus the reference's
+own two-tone low-pass criterion and the FFTW half-complex plan semantics."""
+import numpy as np
+import pytest
+
+from test_fft_oracle import butter_kernel, check_lowpass, two_tone
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-12
+
+
+@pytest.fixture(scope="module")
+def pf():
+    from toast_amd import capi, fft
+
+    assert capi.accel_enabled()
+    capi.accel_assign_device(1, 0, 1.0, False)
+    return fft
+
+
+def test_two_tone_lowpass_like_reference(pf):
+    from oracle import fft_oracle as fo
+
+    rate, n_samp = 200.0, 12345
+    times, orig, lowf = two_tone(rate, n_samp)
+    kfreqs = np.fft.rfftfreq(fo.fft_length(n_samp), d=1.0 / rate)
+    kvals, shift = butter_kernel(rate, 4, kfreqs, np.array([5.0]))
+    assert pf.fft_length(n_samp) == fo.fft_length(n_samp) == 32768
+    got = orig.copy()
+    pf.convolve(got, rate, kernel_freq=kfreqs, kernels=kvals)
+    check_lowpass(times, got, lowf, shift[0], rate)  # reference criterion, tests/fft.py:225-237
+    want = orig.copy()
+    fo.convolve(want, rate, kernel_freq=kfreqs, kernels=kvals)
+    assert np.max(np.abs(got - want)) < TOL * np.max(np.abs(want))
+    for algo in ("internal", None):
+        g2 = orig.copy()
+        pf.convolve(g2, rate, kernel_freq=kfreqs, kernels=kvals, algorithm=algo)
+        assert np.array_equal(g2, got)
+
+
+@pytest.mark.parametrize("n_samp", [1000, 4096, 50001])
+def test_noise_filter_kernels_per_detector(pf, n_samp):
+    """NoiseFilter-style real inverse-PSD kernels on a log frequency grid, one per detector,
+    with detector row indirection (reference ops/noise_filter.py:130-188)."""
+    from oracle import fft_oracle as fo
+
+    rng = np.random.default_rng(n_samp)
+    rate, n_det, rows = 100.0, 5, 7
+    freq = np.concatenate([[0.0], np.geomspace(1e-5, rate / 2, 70)])
+    kernels = []
+    for d in range(n_det):
+        net = 1.0 + 0.1 * d
+        fknee = 0.05 * (d + 1)
+        psd = net**2 * (freq + fknee) / np.maximum(freq + 1e-5, 1e-12)
+        kernels.append(fo.noise_filter_kernel(psd, net))
+    kernels = np.array(kernels)
+    buf = rng.standard_normal((rows, n_samp)).cumsum(axis=1) * 0.01 + rng.standard_normal((rows, n_samp))
+    idx = np.array([5, 0, 3, 6, 2], dtype=np.int32)
+    want = buf.copy()
+    sub = np.ascontiguousarray(buf[idx])
+    fo.convolve(sub, rate, kernel_freq=freq, kernels=kernels)
+    want[idx] = sub
+    got = buf.copy()
+    pf.convolve_buffer(got, idx, rate, freq, kernels)
+    assert np.max(np.abs(got - want)) < TOL * np.max(np.abs(want))
+    untouched = [r for r in range(rows) if r not in idx]
+    assert np.array_equal(got[untouched], buf[untouched])
+
+
+def test_deconvolve_and_flags(pf):
+    from oracle import fft_oracle as fo
+
+    rng = np.random.default_rng(4)
+    rate, n_samp, n_tod = 50.0, 6000, 3
+    freq = np.linspace(0, rate / 2, 200)
+    kern = (1.0 / (1.0 + (freq / 5.0) ** 2)) * np.exp(-1j * 0.02 * freq)
+    data = rng.standard_normal((n_tod, n_samp))
+    flags = (rng.random((n_tod, n_samp)) < 0.002).astype(np.uint8)
+    got, gflags = data.copy(), flags.copy()
+    want, wflags = data.copy(), flags.copy()
+    pf.convolve(got, rate, flags=gflags, flag_mask=1, kernel_freq=freq, kernels=kern)
+    fo.convolve(want, rate, flags=wflags, flag_mask=1, kernel_freq=freq, kernels=kern)
+    assert np.max(np.abs(got - want)) < TOL * np.max(np.abs(want))
+    assert np.array_equal(gflags, wflags)
+    g2, w2 = data.copy(), data.copy()
+    pf.convolve(g2, rate, kernel_freq=freq, kernels=kern, deconvolve=True)
+    fo.convolve(w2, rate, kernel_freq=freq, kernels=kern, deconvolve=True)
+    assert np.max(np.abs(g2 - w2)) < 1e-11 * np.max(np.abs(w2))
+
+
+def test_r1d_half_complex_plans(pf):
+    """FFTPlanReal1D semantics: forward unscaled r2hc, backward scaled by 1/length; round trip
+    (reference tests src/toast/tests/fft.py:42-94)."""
+    from oracle import fft_oracle as fo
+
+    rng = np.random.default_rng(2)
+    for n in (64, 1000, 65536):
+        x = rng.standard_normal((4, n))
+        hc = pf.r1d_forward(x)
+        want = fo.r1d_forward(x)
+        assert np.max(np.abs(hc - want)) < 1e-12 * np.max(np.abs(want))
+        back = pf.r1d_backward(hc)
+        assert np.max(np.abs(back - x)) < 1e-12 * np.max(np.abs(x))
+    one = pf.r1d_forward(x[0])
+    assert one.shape == (n,)
+
+
+def test_large_batch_chunking(pf):
+    """More detectors than one work batch: exercises the batch loop and plan cache."""
+    import torch
+    from oracle import fft_oracle as fo
+
+    rng = np.random.default_rng(9)
+    rate, n_samp, n_det = 100.0, 3000, 37
+    freq = np.concatenate([[0.0], np.geomspace(1e-3, 50, 40)])
+    kern = 1.0 / (1.0 + 0.1 / np.maximum(freq, 1e-3))
+    kern[0] = 0
+    data = rng.standard_normal((n_det, n_samp))
+    want = data.copy()
+    fo.convolve(want, rate, kernel_freq=freq, kernels=kern)
+    t = torch.from_numpy(data).cuda()
+    pf.convolve_dev(t.data_ptr(), np.arange(n_det, dtype=np.int32), n_samp, rate, freq, kern, max_batch=8,
+                    stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = t.cpu().numpy()
+    assert np.max(np.abs(got - want)) < TOL * np.max(np.abs(want))

@@ -1,0 +1,391 @@
+// fft_filter.hip -- FFT-based noise weighting of timestreams on gfx950 with rocFFT.
+//
+// Device counterpart of the reference's
+//   * toast.fft.convolve(..., algorithm="numpy")  (src/toast/fft.py:163-212 padding/apodisation,
+//     :190-212 kernel interpolation, :296-350 rfft -> multiply -> irfft -> crop), as driven by
+//     ops.NoiseFilter (src/toast/ops/noise_filter.py:130-188), and
+//   * FFTPlanReal1D (batched r2hc / hc2r in FFTW half-complex layout;
+//     src/libtoast/include/toast/math_fft.hpp:24-82, src/libtoast/src/toast_math_fft_fftw.cpp:26-128).
+//
+// Pipeline per batch of B detectors (B chosen so the work buffers fit a budget):
+//   k_fft_fill     tdata[b, :] = [0 .. | apodised mirror | tod | apodised mirror | .. 0]   (n_fft = 2^(ceil(log2 n)+1))
+//   rocFFT D2Z     batched, out of place, interleaved hermitian output (n_fft/2 + 1 bins)
+//   k_fft_kernel   F *= K (or /= K), K = |K|(f) exp(i arg K(f)) evaluated on the fly from the
+//                  PCHIP piecewise cubics of |K| and arg K; Im F[nyquist] = 0; F[0] = 0
+//   rocFFT Z2D     batched
+//   k_fft_crop     tod[s] = tdata[b, n_buffer + s] / n_fft
+// All stages are HBM streaming passes; the transforms themselves are rocFFT's.
+#include <hip/hip_runtime.h>
+#include <rocfft/rocfft.h>
+
+#include <map>
+#include <mutex>
+#include <tuple>
+
+#include "runtime.hpp"
+
+using namespace toast_hip;
+
+namespace {
+
+constexpr int kThreads = 256;
+
+#define TH_ROCFFT(expr)                                                                   \
+    do {                                                                                  \
+        rocfft_status s_ = (expr);                                                        \
+        if (s_ != rocfft_status_success) {                                                \
+            std::ostringstream o_;                                                        \
+            o_ << "rocFFT error " << (int)s_ << " at " << __FILE__ << ":" << __LINE__     \
+               << " in " #expr;                                                           \
+            throw ::toast_hip::Error(TOAST_HIP_ERR_DEVICE, o_.str());                     \
+        }                                                                                 \
+    } while (0)
+
+struct Plan {
+    rocfft_plan plan = nullptr;
+    rocfft_execution_info info = nullptr;
+    void * work = nullptr;
+    size_t work_bytes = 0;
+};
+
+std::mutex g_mutex;
+bool g_setup = false;
+std::map<std::tuple<int, int64_t, int64_t, int>, Plan> g_plans;  // (device, length, batch, forward)
+
+Plan & get_plan(int64_t length, int64_t batch, bool forward) {
+    int dev = 0;
+    TH_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_mutex);
+    if (!g_setup) {
+        TH_ROCFFT(rocfft_setup());
+        g_setup = true;
+    }
+    auto key = std::make_tuple(dev, length, batch, forward ? 1 : 0);
+    auto it = g_plans.find(key);
+    if (it != g_plans.end()) return it->second;
+    Plan p;
+    rocfft_plan_description desc = nullptr;
+    TH_ROCFFT(rocfft_plan_description_create(&desc));
+    const size_t n_psd = (size_t)(length / 2 + 1);
+    size_t one = 1;
+    if (forward) {
+        TH_ROCFFT(rocfft_plan_description_set_data_layout(desc, rocfft_array_type_real,
+                                                          rocfft_array_type_hermitian_interleaved,
+                                                          nullptr, nullptr, 1, &one, (size_t)length, 1,
+                                                          &one, n_psd));
+    } else {
+        TH_ROCFFT(rocfft_plan_description_set_data_layout(desc, rocfft_array_type_hermitian_interleaved,
+                                                          rocfft_array_type_real, nullptr, nullptr, 1,
+                                                          &one, n_psd, 1, &one, (size_t)length));
+    }
+    const size_t len = (size_t)length;
+    TH_ROCFFT(rocfft_plan_create(&p.plan, rocfft_placement_notinplace,
+                                 forward ? rocfft_transform_type_real_forward
+                                         : rocfft_transform_type_real_inverse,
+                                 rocfft_precision_double, 1, &len, (size_t)batch, desc));
+    TH_ROCFFT(rocfft_plan_description_destroy(desc));
+    TH_ROCFFT(rocfft_execution_info_create(&p.info));
+    TH_ROCFFT(rocfft_plan_get_work_buffer_size(p.plan, &p.work_bytes));
+    if (p.work_bytes) {
+        TH_HIP(hipMalloc(&p.work, p.work_bytes));
+        TH_ROCFFT(rocfft_execution_info_set_work_buffer(p.info, p.work, p.work_bytes));
+    }
+    return g_plans.emplace(key, p).first->second;
+}
+
+void exec_plan(Plan & p, void * in, void * out, hipStream_t stream) {
+    TH_ROCFFT(rocfft_execution_info_set_stream(p.info, stream));
+    void * ib[1] = {in};
+    void * ob[1] = {out};
+    TH_ROCFFT(rocfft_execute(p.plan, ib, ob, p.info));
+}
+
+// Grow-only device scratch (time-domain and Fourier-domain batches).
+struct Scratch {
+    void * ptr = nullptr;
+    size_t bytes = 0;
+    void * get(size_t need) {
+        if (need > bytes) {
+            if (ptr) {
+                TH_HIP(hipDeviceSynchronize());
+                TH_HIP(hipFree(ptr));
+            }
+            TH_HIP(hipMalloc(&ptr, need));
+            bytes = need;
+        }
+        return ptr;
+    }
+};
+Scratch g_tbuf, g_fbuf;
+
+// ------------------------------------------------------------------------------------
+// fill: src/toast/fft.py:163-188 (set_rfft_input)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_fft_fill(const double * __restrict__ tod,
+                                                       const int32_t * __restrict__ d_idx, int det0,
+                                                       double * __restrict__ tdata,
+                                                       const double * __restrict__ apod, int64_t n_samp,
+                                                       int64_t n_fft, int64_t n_buffer, int64_t n_reflect) {
+    const int b = blockIdx.y;
+    const double * row = tod + (int64_t)d_idx[det0 + b] * n_samp;
+    double * out = tdata + (int64_t)b * n_fft;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n_fft;
+         i += (int64_t)gridDim.x * kThreads) {
+        const int64_t s = i - n_buffer;  // sample index relative to the TOD start
+        double v = 0.0;
+        if (s >= 0 && s < n_samp) {
+            v = row[s];
+        } else if (s < 0 && s >= -n_reflect) {
+            // tdata[n_buffer - n_reflect : n_buffer] = tod[n_reflect-1::-1] * apodize
+            const int64_t j = s + n_reflect;  // 0 .. n_reflect-1 within the mirrored block
+            v = row[n_reflect - 1 - j] * apod[j];
+        } else if (s >= n_samp && s < n_samp + n_reflect) {
+            // mirrored tail; the window is applied reversed (largest next to the data)
+            const int64_t j = s - n_samp;  // 0 .. n_reflect-1
+            v = row[n_samp - 1 - j] * apod[n_reflect - 1 - j];
+        }
+        out[i] = v;
+    }
+}
+
+// Piecewise-cubic evaluation p(x) = c0 dx^3 + c1 dx^2 + c2 dx + c3 on the knot interval that
+// contains x (first / last interval outside the knots: extrapolate=True), scipy PPoly order.
+__device__ __forceinline__ double ppoly_eval(const double * __restrict__ knots, int n_knot,
+                                             const double * __restrict__ coef, double x) {
+    int lo = 0, hi = n_knot - 2;  // interval index range
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (knots[mid] <= x) {
+            lo = mid;
+        } else {
+            hi = mid - 1;
+        }
+    }
+    const double * c = coef + 4 * lo;
+    const double dx = x - knots[lo];
+    return ((c[0] * dx + c[1]) * dx + c[2]) * dx + c[3];
+}
+
+// multiply: src/toast/fft.py:190-212 (kernel = mag * exp(1j * ang)), :330-337
+__global__ __launch_bounds__(kThreads) void k_fft_kernel(double2 * __restrict__ fdata, int det0,
+                                                         int64_t n_psd, double fstep,
+                                                         const double * __restrict__ knots, int n_knot,
+                                                         const double * __restrict__ mag_coef,
+                                                         const double * __restrict__ ang_coef,
+                                                         int per_det, int deconvolve) {
+    const int b = blockIdx.y;
+    const int64_t kern = per_det ? (int64_t)(det0 + b) : 0;
+    const double * mc = mag_coef + kern * 4 * (n_knot - 1);
+    const double * ac = ang_coef ? ang_coef + kern * 4 * (n_knot - 1) : nullptr;
+    double2 * f = fdata + (int64_t)b * n_psd;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n_psd;
+         i += (int64_t)gridDim.x * kThreads) {
+        double2 v = f[i];
+        if (i == 0) {
+            v = make_double2(0.0, 0.0);  // remove DC level
+        } else {
+            const double freq = (double)i * fstep;
+            const double mag = ppoly_eval(knots, n_knot, mc, freq);
+            double kr = mag, ki = 0.0;
+            if (ac) {
+                const double ang = ppoly_eval(knots, n_knot, ac, freq);
+                kr = mag * cos(ang);
+                ki = mag * sin(ang);
+            }
+            double2 r;
+            if (deconvolve) {
+                const double den = kr * kr + ki * ki;
+                r.x = (v.x * kr + v.y * ki) / den;
+                r.y = (v.y * kr - v.x * ki) / den;
+            } else {
+                r.x = v.x * kr - v.y * ki;
+                r.y = v.x * ki + v.y * kr;
+            }
+            if (i == n_psd - 1) r.y = 0.0;  // Nyquist bin of a real transform is real
+            v = r;
+        }
+        f[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_fft_crop(const double * __restrict__ tdata,
+                                                       const int32_t * __restrict__ d_idx, int det0,
+                                                       double * __restrict__ tod, int64_t n_samp,
+                                                       int64_t n_fft, int64_t n_buffer, double norm) {
+    const int b = blockIdx.y;
+    double * row = tod + (int64_t)d_idx[det0 + b] * n_samp;
+    const double * in = tdata + (int64_t)b * n_fft + n_buffer;
+    for (int64_t s = (int64_t)blockIdx.x * kThreads + threadIdx.x; s < n_samp;
+         s += (int64_t)gridDim.x * kThreads) {
+        row[s] = in[s] * norm;
+    }
+}
+
+// FFTW half-complex <-> interleaved hermitian (toast_math_fft_cufft.cpp:157-238 does this on
+// the host): hc = r0, r1, .., r_{n/2}, i_{(n+1)/2-1}, .., i_1
+__global__ __launch_bounds__(kThreads) void k_c2hc(const double2 * __restrict__ f, double * __restrict__ hc,
+                                                   int64_t length, double scale) {
+    const int b = blockIdx.y;
+    const int64_t n_psd = length / 2 + 1;
+    const double2 * in = f + (int64_t)b * n_psd;
+    double * out = hc + (int64_t)b * length;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n_psd;
+         i += (int64_t)gridDim.x * kThreads) {
+        const double2 v = in[i];
+        out[i] = v.x * scale;
+        if (i > 0 && 2 * i < length) out[length - i] = v.y * scale;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_hc2c(const double * __restrict__ hc, double2 * __restrict__ f,
+                                                   int64_t length) {
+    const int b = blockIdx.y;
+    const int64_t n_psd = length / 2 + 1;
+    const double * in = hc + (int64_t)b * length;
+    double2 * out = f + (int64_t)b * n_psd;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n_psd;
+         i += (int64_t)gridDim.x * kThreads) {
+        const double im = (i > 0 && 2 * i < length) ? in[length - i] : 0.0;
+        out[i] = make_double2(in[i], im);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_scale(double * __restrict__ x, int64_t n, double s) {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * kThreads) {
+        x[i] *= s;
+    }
+}
+
+inline dim3 grid2(int64_t n, int64_t batch) {
+    int64_t gx = (n + kThreads - 1) / kThreads;
+    if (gx > 4096) gx = 4096;
+    return dim3((unsigned)gx, (unsigned)batch, 1);
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t toast_hip_fft_length(int64_t n_samp) {
+    // src/toast/fft.py:278-280: order = ceil(log2 n_samp); n_fft = 2^(order+1)
+    int64_t order = 0;
+    while ((int64_t(1) << order) < n_samp) ++order;
+    return int64_t(1) << (order + 1);
+}
+
+int toast_hip_fft_convolve_dev(double * d_tod, const int32_t * data_index, int64_t n_det,
+                               int64_t n_samp, double rate, const double * knots, int64_t n_knot,
+                               const double * mag_coef, const double * ang_coef, int64_t n_kernel,
+                               int deconvolve, const double * apodize, int64_t n_apodize,
+                               int64_t max_batch, void * stream) {
+    return guarded([&] {
+        if (n_det <= 0 || n_samp <= 0) return;
+        if (n_knot < 2) fail_arg("fft_convolve: need at least two kernel frequencies");
+        if (n_kernel != 1 && n_kernel != n_det) fail_arg("fft_convolve: n_kernel must be 1 or n_det");
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        const int64_t n_fft = toast_hip_fft_length(n_samp);
+        const int64_t n_psd = n_fft / 2 + 1;
+        const int64_t n_buffer = (n_fft - n_samp) / 2;                          // fft.py:283
+        const int64_t n_reflect = (n_buffer < n_samp) ? n_buffer : n_samp;      // fft.py:284
+        if (n_apodize != n_reflect) fail_arg("fft_convolve: apodize window must have n_reflect entries");
+        // numpy.fft.rfftfreq(n, d): k * (1 / (n d)) with d = 1 / rate
+        const double fstep = 1.0 / ((double)n_fft * (1.0 / rate));
+
+        ParamBlock pb;
+        const size_t o_idx = pb.push(data_index, sizeof(int32_t) * n_det);
+        const size_t o_kn = pb.push(knots, sizeof(double) * n_knot);
+        const size_t o_mc = pb.push(mag_coef, sizeof(double) * n_kernel * 4 * (n_knot - 1));
+        const size_t o_ac = ang_coef ? pb.push(ang_coef, sizeof(double) * n_kernel * 4 * (n_knot - 1)) : 0;
+        const size_t o_ap = pb.push(apodize, sizeof(double) * n_reflect);
+        const char * d = pb.commit(st);
+        const int32_t * d_idx = (const int32_t *)(d + o_idx);
+        const double * d_ac = ang_coef ? (const double *)(d + o_ac) : nullptr;
+
+        int64_t batch = (max_batch > 0) ? max_batch : 64;
+        // keep the two work buffers under ~8 GB
+        const int64_t cap = (int64_t)((size_t(8) << 30) / ((size_t)n_fft * 8 + (size_t)n_psd * 16));
+        if (batch > cap) batch = cap > 0 ? cap : 1;
+        if (batch > n_det) batch = n_det;
+        double * tbuf = (double *)g_tbuf.get((size_t)batch * n_fft * sizeof(double));
+        double2 * fbuf = (double2 *)g_fbuf.get((size_t)batch * n_psd * sizeof(double2));
+
+        for (int64_t det0 = 0; det0 < n_det; det0 += batch) {
+            const int64_t nb = (n_det - det0 < batch) ? (n_det - det0) : batch;
+            Plan & fwd = get_plan(n_fft, nb, true);
+            Plan & inv = get_plan(n_fft, nb, false);
+            hipLaunchKernelGGL(k_fft_fill, grid2(n_fft, nb), dim3(kThreads), 0, st, d_tod, d_idx,
+                               (int)det0, tbuf, (const double *)(d + o_ap), n_samp, n_fft, n_buffer,
+                               n_reflect);
+            exec_plan(fwd, tbuf, fbuf, st);
+            hipLaunchKernelGGL(k_fft_kernel, grid2(n_psd, nb), dim3(kThreads), 0, st, fbuf, (int)det0,
+                               n_psd, fstep, (const double *)(d + o_kn), (int)n_knot,
+                               (const double *)(d + o_mc), d_ac, (n_kernel == n_det && n_det > 1) ? 1 : 0,
+                               deconvolve);
+            exec_plan(inv, fbuf, tbuf, st);
+            hipLaunchKernelGGL(k_fft_crop, grid2(n_samp, nb), dim3(kThreads), 0, st, tbuf, d_idx,
+                               (int)det0, d_tod, n_samp, n_fft, n_buffer, 1.0 / (double)n_fft);
+            TH_HIP(hipGetLastError());
+        }
+    });
+}
+
+int toast_hip_fft_convolve(double * det_data, int64_t n_data_rows, const int32_t * data_index,
+                           int64_t n_det, int64_t n_samp, double rate, const double * knots,
+                           int64_t n_knot, const double * mag_coef, const double * ang_coef,
+                           int64_t n_kernel, int deconvolve, const double * apodize,
+                           int64_t n_apodize, int use_accel) {
+    return guarded([&] {
+        Manager::get().require_device();
+        hipStream_t st = Manager::get().stream();
+        Staging stg(use_accel != 0, st);
+        double * d_tod = stg.inout(det_data, (size_t)(n_data_rows * n_samp));
+        int rc = toast_hip_fft_convolve_dev(d_tod, data_index, n_det, n_samp, rate, knots, n_knot,
+                                            mag_coef, ang_coef, n_kernel, deconvolve, apodize,
+                                            n_apodize, 0, st);
+        if (rc != TOAST_HIP_OK) throw Error(rc, toast_hip_last_error());
+        stg.finish();
+    });
+}
+
+// FFTPlanReal1D counterpart: `count` real transforms of `length`, FFTW half-complex layout.
+// forward: out = scale * r2hc(in);  backward: out = scale / length * hc2r(in)
+int toast_hip_fft_r1d_dev(int forward, int64_t length, int64_t count, const double * d_in,
+                          double * d_out, double scale, void * stream) {
+    return guarded([&] {
+        if (length <= 0 || count <= 0) return;
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        const int64_t n_psd = length / 2 + 1;
+        double2 * fbuf = (double2 *)g_fbuf.get((size_t)count * n_psd * sizeof(double2));
+        if (forward) {
+            double * tbuf = (double *)g_tbuf.get((size_t)count * length * sizeof(double));
+            TH_HIP(hipMemcpyAsync(tbuf, d_in, (size_t)count * length * sizeof(double),
+                                  hipMemcpyDeviceToDevice, st));  // rocFFT may overwrite its input
+            exec_plan(get_plan(length, count, true), tbuf, fbuf, st);
+            hipLaunchKernelGGL(k_c2hc, grid2(n_psd, count), dim3(kThreads), 0, st, fbuf, d_out, length,
+                               scale);
+        } else {
+            hipLaunchKernelGGL(k_hc2c, grid2(n_psd, count), dim3(kThreads), 0, st, d_in, fbuf, length);
+            exec_plan(get_plan(length, count, false), fbuf, d_out, st);
+            hipLaunchKernelGGL(k_scale, grid2(count * length, 1), dim3(kThreads), 0, st, d_out,
+                               count * length, scale / (double)length);
+        }
+        TH_HIP(hipGetLastError());
+    });
+}
+
+int toast_hip_fft_r1d(int forward, int64_t length, int64_t count, const double * in, double * out,
+                      double scale, int use_accel) {
+    return guarded([&] {
+        Manager::get().require_device();
+        hipStream_t st = Manager::get().stream();
+        Staging stg(use_accel != 0, st);
+        const double * d_in = stg.in(in, (size_t)(length * count));
+        double * d_out = stg.inout(out, (size_t)(length * count));
+        int rc = toast_hip_fft_r1d_dev(forward, length, count, d_in, d_out, scale, st);
+        if (rc != TOAST_HIP_OK) throw Error(rc, toast_hip_last_error());
+        stg.finish();
+    });
+}
+
+}  // extern "C"

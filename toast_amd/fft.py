@@ -1,0 +1,185 @@
+"""FFT noise weighting on the GPU: the product-side mirror of ``toast.fft.convolve``
+(reference: src/toast/fft.py:700-945, ``algorithm="numpy"`` semantics, :252-350).
+
+Host logic only prepares small things -- the PCHIP piecewise cubics of |K| and arg K on the
+kernel frequencies (SciPy, as the reference does at fft.py:190-212), the apodisation window
+(fft.py:163-171) and the flag bookkeeping (fft.py:836-872, :935-945); the padding, the
+batched rocFFT transforms, the kernel evaluation/multiply and the crop all run on the GPU
+through ``toast_hip_fft_convolve`` (toast_amd/csrc/fft_filter.hip).
+"""
+
+import ctypes as C
+
+import numpy as np
+from scipy.interpolate import PchipInterpolator
+
+from . import capi
+
+
+def fft_length(n_samp):
+    return int(capi.lib().toast_hip_fft_length(C.c_int64(int(n_samp))))
+
+
+def apodization(n_reflect):
+    """First half of ``general_gaussian(2 n_reflect, p=3, sig=n_reflect // 2)``
+    (reference fft.py:163-171; formula of scipy.signal.windows.general_gaussian)."""
+    m = 2 * n_reflect
+    n = np.arange(0, m) - (m - 1.0) / 2.0
+    sig = n_reflect // 2
+    with np.errstate(divide="ignore", invalid="ignore"):
+        w = np.exp(-0.5 * np.abs(n / sig) ** (2 * 3.0))
+    return np.ascontiguousarray(w[:n_reflect])
+
+
+def _pchip_coef(kernel_freq, values):
+    """scipy PPoly coefficients [n_kernel, n_knot - 1, 4] of the PCHIP interpolant(s)."""
+    values = np.atleast_2d(values)
+    out = np.empty((values.shape[0], kernel_freq.size - 1, 4), dtype=np.float64)
+    for i, v in enumerate(values):
+        out[i] = PchipInterpolator(kernel_freq, v, extrapolate=True).c.T
+    return np.ascontiguousarray(out)
+
+
+def kernel_coefficients(kernel_freq, kernels, deconvolve=False):
+    """|K| and arg K as piecewise cubics (reference fft.py:190-212)."""
+    kernels = np.asarray(kernels)
+    mag = np.absolute(kernels)
+    ang = np.angle(kernels)
+    if deconvolve:
+        m2 = np.atleast_2d(mag).copy()
+        for row in m2:
+            limit = 1.0e-5 * np.max(row)
+            row[row < limit] = limit
+        mag = m2
+    mag_c = _pchip_coef(kernel_freq, mag)
+    ang_c = None if not np.any(ang) else _pchip_coef(kernel_freq, ang)
+    return mag_c, ang_c
+
+
+def _p(a):
+    return C.c_void_p(0) if a is None else C.c_void_p(a.ctypes.data)
+
+
+def convolve_buffer(det_data, data_index, rate, kernel_freq, kernels, deconvolve=False, use_accel=False):
+    """Convolve rows ``data_index`` of the 2-D float64 buffer ``det_data`` in place."""
+    det_data = capi._buf(det_data, "det_data", np.float64, 2)
+    di = capi._buf(np.ascontiguousarray(data_index, dtype=np.int32), "data_index", np.int32, 1)
+    n_det, n_samp = di.size, det_data.shape[1]
+    kernel_freq = np.ascontiguousarray(kernel_freq, dtype=np.float64)
+    kernels = np.asarray(kernels)
+    if kernels.ndim == 2 and kernels.shape[0] != n_det:
+        raise RuntimeError("kernels should have one row per detector")
+    mag_c, ang_c = kernel_coefficients(kernel_freq, kernels, deconvolve)
+    n_fft = fft_length(n_samp)
+    n_buffer = (n_fft - n_samp) // 2
+    n_reflect = min(n_buffer, n_samp)
+    apod = apodization(n_reflect)
+    capi._check(capi.lib().toast_hip_fft_convolve(
+        _p(det_data), C.c_int64(det_data.shape[0]), _p(di), C.c_int64(n_det), C.c_int64(n_samp),
+        C.c_double(rate), _p(kernel_freq), C.c_int64(kernel_freq.size), _p(mag_c), _p(ang_c),
+        C.c_int64(mag_c.shape[0]), C.c_int(bool(deconvolve)), _p(apod), C.c_int64(apod.size),
+        C.c_int(bool(use_accel))))
+
+
+def convolve_dev(d_det_data, data_index, n_samp, rate, kernel_freq, kernels, deconvolve=False, max_batch=0,
+                 stream=0):
+    """Device-pointer variant (``d_det_data`` = device address of a [rows, n_samp] f64 array)."""
+    di = np.ascontiguousarray(data_index, dtype=np.int32)
+    kernel_freq = np.ascontiguousarray(kernel_freq, dtype=np.float64)
+    mag_c, ang_c = kernel_coefficients(kernel_freq, np.asarray(kernels), deconvolve)
+    n_fft = fft_length(n_samp)
+    n_buffer = (n_fft - n_samp) // 2
+    n_reflect = min(n_buffer, n_samp)
+    apod = apodization(n_reflect)
+    capi._check(capi.lib().toast_hip_fft_convolve_dev(
+        C.c_void_p(int(d_det_data)), _p(di), C.c_int64(di.size), C.c_int64(n_samp), C.c_double(rate),
+        _p(kernel_freq), C.c_int64(kernel_freq.size), _p(mag_c), _p(ang_c), C.c_int64(mag_c.shape[0]),
+        C.c_int(bool(deconvolve)), _p(apod), C.c_int64(apod.size), C.c_int64(max_batch),
+        C.c_void_p(int(stream))))
+
+
+def extend_flags(flags, mask, buffer):
+    """Grow every flagged region by ``buffer`` samples on both sides
+    (reference: src/toast/utils.py:1055-1113)."""
+    bad = (flags & mask) != 0
+    if not bad.any():
+        return
+    edges = np.diff(np.concatenate([[0], bad.view(np.int8), [0]]))
+    starts = np.flatnonzero(edges == 1)
+    ends = np.flatnonzero(edges == -1)
+    n = flags.size
+    for start, end in zip(starts, ends):
+        fstart = max(start - buffer, 0)
+        fend = end + buffer
+        if fend >= n:
+            fend = n - 1
+        flags[fstart:fend] = mask
+
+
+def convolve(raw, rate, flags=None, flag_mask=None, kernel_freq=None, kernels=None, kernel_func=None,
+             deconvolve=False, algorithm="numpy", use_accel=False):
+    """Drop-in for ``toast.fft.convolve`` (2-D ``raw`` = one row per timestream, in place).
+
+    ``algorithm`` "numpy"/"internal"/None all map to the rocFFT pipeline (they are the same
+    mathematics in the reference: fft.py:296-350 vs :396-484); "nonuniform" and
+    ``kernel_func`` are not part of the hot path and raise.
+    """
+    if kernel_func is not None:
+        raise NotImplementedError("kernel_func kernels are evaluated on the host in the reference; not supported")
+    if algorithm not in (None, "numpy", "internal"):
+        raise RuntimeError(f"Unknown or unsupported algorithm '{algorithm}'")
+    if kernel_freq is None or kernels is None:
+        raise RuntimeError("Must specify explicit kernel values")
+    if (flags is None) != (flag_mask is None):
+        raise RuntimeError("Both flags and flag_mask must be specified or set to None")
+    raw = np.asarray(raw)
+    one_d = raw.ndim == 1
+    data = raw.reshape(1, -1) if one_d else raw
+    if data.ndim != 2 or data.dtype != np.float64 or not data.flags["C_CONTIGUOUS"]:
+        raise RuntimeError("Only contiguous 1D and 2D float64 arrays are supported as inputs")
+    n_tod, n_samp = data.shape
+    idx = np.arange(n_tod, dtype=np.int32)
+    extend = np.zeros(n_tod, dtype=np.int32)
+    if flags is not None:
+        # impulse response spread (fft.py:836-872), through the same GPU pipeline
+        temp = np.zeros_like(data)
+        temp[:, n_samp // 2] = 100.0
+        convolve_buffer(temp, idx, rate, kernel_freq, kernels, deconvolve)
+        atemp = np.absolute(temp)
+        for itod in range(n_tod):
+            ipeak = int(np.argmax(atemp[itod]))
+            thr = 0.02 * atemp[itod, ipeak]
+            imin = ipeak
+            while imin > 0 and atemp[itod, imin] > thr:
+                imin -= 1
+            imax = ipeak
+            while imax < n_samp and atemp[itod, imax] > thr:
+                imax += 1
+            extend[itod] = imax - imin
+            if extend[itod] == n_samp:
+                raise RuntimeError("Impulse response spreads to all samples")
+    convolve_buffer(data, idx, rate, kernel_freq, kernels, deconvolve, use_accel=use_accel)
+    if flags is not None:
+        for itod in range(n_tod):
+            ext = int(extend[itod])
+            extend_flags(flags[itod], flag_mask, ext)
+            flags[itod][:ext] |= flag_mask
+            flags[itod][-ext:] |= flag_mask
+
+
+def r1d_forward(indata):
+    """Batched real FFT in FFTW half-complex layout (reference fft.py:26-68)."""
+    x = np.ascontiguousarray(np.atleast_2d(indata), dtype=np.float64)
+    out = np.empty_like(x)
+    capi._check(capi.lib().toast_hip_fft_r1d(C.c_int(1), C.c_int64(x.shape[1]), C.c_int64(x.shape[0]), _p(x), _p(out),
+                                             C.c_double(1.0), C.c_int(0)))
+    return out[0] if np.ndim(indata) == 1 else out
+
+
+def r1d_backward(indata):
+    """Inverse of :func:`r1d_forward` (scaled by 1/length; reference fft.py:71-117)."""
+    x = np.ascontiguousarray(np.atleast_2d(indata), dtype=np.float64)
+    out = np.empty_like(x)
+    capi._check(capi.lib().toast_hip_fft_r1d(C.c_int(0), C.c_int64(x.shape[1]), C.c_int64(x.shape[0]), _p(x), _p(out),
+                                             C.c_double(1.0), C.c_int(0)))
+    return out[0] if np.ndim(indata) == 1 else out
