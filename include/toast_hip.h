@@ -101,6 +101,11 @@ int toast_hip_accel_delete(const void * host, size_t nbytes, const char * name);
  * [ref: accelerator.hpp:115-143 device_ptr] */
 int toast_hip_accel_device_ptr(const void * host, void ** device);
 
+/* Register device memory owned by the caller (e.g. a torch tensor) as the device copy of
+ * `host`; toast_hip_accel_delete() then only forgets the mapping.  Extension (no reference
+ * counterpart): lets RCCL collectives run on torch tensors that the kernels also address. */
+int toast_hip_accel_adopt(const void * host, size_t nbytes, void * device, const char * name);
+
 /* Print the table of registered buffers.  [ref: accelerator.cpp:697-720 dump] */
 int toast_hip_accel_dump(void);
 
@@ -260,6 +265,42 @@ int toast_hip_cov_apply_diag(int64_t n_sub, int64_t subsize, int64_t nnz, const 
                              double * vec, int use_accel);
 int toast_hip_cov_apply_diag_dev(int64_t n_sub, int64_t subsize, int64_t nnz, const double * d_mat,
                                  double * d_vec, void * stream);
+
+/* ------------------------------------------------------------------------------------
+ * Pixel-domain noise covariance products (used by BinMap / MapMaker setup)
+ *
+ * toast_hip_build_cov: mode 0 = hit map   hits[pix] += 1            (out: int64[n_loc,nps,1])
+ *                      mode 1 = inverse covariance  invnpp[pix,(j,k>=j)] += w_k (w_j det_scale)
+ *                                                          (out: f64[n_loc,nps,nnz(nnz+1)/2])
+ *   for unflagged samples with pix >= 0 -- the operator-level semantics of BuildHitMap /
+ *   BuildInverseCovariance [ref: src/toast/ops/mapmaker_utils/mapmaker_utils.py:100-210,
+ *   :352-520; per-sample arithmetic src/libtoast/src/toast_map_cov.cpp:66-153].
+ * toast_hip_cov_eigendecompose_diag: per-pixel rcond and (optionally) inverse of the packed
+ *   symmetric blocks [ref: src/libtoast/src/toast_map_cov.cpp:246-396; binding
+ *   src/toast/_libtoast/map_cov.cpp:269-325].  cond may be NULL.
+ * ---------------------------------------------------------------------------------- */
+int toast_hip_build_cov_dev(
+    int mode, const int64_t * d_global2local, void * d_out, int64_t n_pix_submap, int64_t nnz,
+    const int32_t * pixel_index /*host*/, const int64_t * d_pixels,
+    const int32_t * weight_index /*host, mode 1*/, const double * d_weights /*mode 1*/,
+    const int32_t * flag_index /*host*/, const uint8_t * d_det_flags, int64_t n_flag_samp,
+    const double * det_scale /*host, mode 1*/, uint8_t det_flag_mask, int64_t n_det, int64_t n_samp,
+    const toast_hip_interval * intervals /*host*/, int64_t n_view, const uint8_t * d_shared_flags,
+    int64_t n_shared_flags, uint8_t shared_flag_mask, void * stream);
+
+int toast_hip_build_cov(
+    int mode, const int64_t * global2local, int64_t n_submap, void * out, int64_t n_local_submap,
+    int64_t n_pix_submap, int64_t nnz, const int32_t * pixel_index, const int64_t * pixels,
+    int64_t n_pixel_rows, const int32_t * weight_index, const double * weights, int64_t n_weight_rows,
+    const int32_t * flag_index, const uint8_t * det_flags, int64_t n_flag_rows, int64_t n_flag_samp,
+    const double * det_scale, uint8_t det_flag_mask, int64_t n_det, int64_t n_samp,
+    const toast_hip_interval * intervals, int64_t n_view, const uint8_t * shared_flags,
+    int64_t n_shared_flags, uint8_t shared_flag_mask, int use_accel);
+
+int toast_hip_cov_eigendecompose_diag(int64_t n_sub, int64_t subsize, int64_t nnz, double * data,
+                                      double * cond, double threshold, int invert, int use_accel);
+int toast_hip_cov_eigendecompose_diag_dev(int64_t n_sub, int64_t subsize, int64_t nnz, double * d_data,
+                                          double * d_cond, double threshold, int invert, void * stream);
 
 /* ------------------------------------------------------------------------------------
  * Offset template (the M and M^T of every PCG iteration)

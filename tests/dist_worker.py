@@ -1,0 +1,70 @@
+"""Worker for tests/test_dist_gloo.py: run under torch.distributed.run with world_size 2 and
+the gloo backend (CPU).  Exercises every collective of the N>1 path: the union of hit
+submaps, the map all-reduce of PixelData, scalar reductions of amplitude dot products and the
+detector-sharded data layout.  Exits non-zero on any mismatch."""
+import os
+import sys
+
+import numpy as np
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from toast_amd.data import Comm  # noqa: E402
+from toast_amd.pixels import PixelData, PixelDistribution, unify_local_submaps  # noqa: E402
+from toast_amd.sim import create_satellite_data  # noqa: E402
+from toast_amd.templates import Amplitudes  # noqa: E402
+
+
+def main():
+    dist.init_process_group("gloo")
+    comm = Comm()
+    rank, size = comm.world_rank, comm.world_size
+    assert size == 2 and comm.comm_world is not None
+
+    # 1. union of hit submaps -> identical distribution everywhere
+    hits = np.zeros(16, dtype=np.uint8)
+    hits[[1, 4] if rank == 0 else [4, 9, 15]] = 1
+    union = unify_local_submaps(hits, comm)
+    assert list(np.flatnonzero(union)) == [1, 4, 9, 15], union
+    d = PixelDistribution(n_pix=16 * 48, n_submap=16, local_submaps=np.flatnonzero(union), comm=comm)
+
+    # 2. map all-reduce (host path; the device path is the same call on an RCCL tensor)
+    pd = PixelData(d, np.float64, n_value=3)
+    rng = np.random.default_rng(100 + rank)
+    mine = rng.standard_normal(pd.raw.size)
+    pd.raw[:] = mine
+    pd.sync_allreduce()
+    other = np.random.default_rng(100 + (1 - rank)).standard_normal(pd.raw.size)
+    np.testing.assert_allclose(pd.raw, mine + other, rtol=0, atol=1e-15)
+    ph = PixelData(d, np.int64, n_value=1)
+    ph.raw[:] = rank + 1
+    ph.sync_allreduce()
+    assert np.all(ph.raw == 3)
+
+    # 3. amplitude dot products: local dot + scalar all-reduce
+    a = Amplitudes(comm, 10, 5)
+    a.local[:] = np.arange(5) + 5 * rank
+    val = a.dot(a)
+    assert abs(val - float(np.sum(np.arange(10) ** 2))) < 1e-12, val
+    assert comm.allreduce_scalar(rank + 1, op="max") == 2
+    assert comm.allreduce_scalar(3, op="sum") == 6
+
+    # 4. detector sharding: each rank gets its own detectors of one focalplane, same scan
+    data = create_satellite_data(comm=comm, n_det=2, total_det=4, first_det=2 * rank, n_samp=200)
+    names = data.obs[0].local_detectors
+    all_names = [None, None]
+    dist.all_gather_object(all_names, names)
+    assert len(set(all_names[0]) | set(all_names[1])) == 4 and not (set(all_names[0]) & set(all_names[1]))
+    bore = data.obs[0].shared["boresight_radec"].data.copy()
+    comm.allreduce_array_(bore)
+    np.testing.assert_allclose(bore, 2 * data.obs[0].shared["boresight_radec"].data)
+
+    comm.barrier()
+    dist.destroy_process_group()
+    print(f"rank {rank} OK")
+
+
+if __name__ == "__main__":
+    main()

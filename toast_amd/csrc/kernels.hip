@@ -333,6 +333,175 @@ __global__ __launch_bounds__(kThreads) void k_build_noise_weighted_any(
 }
 
 // ------------------------------------------------------------------------------------
+// Hit map and inverse pixel covariance accumulation (BuildHitMap / BuildInverseCovariance,
+// src/toast/ops/mapmaker_utils/mapmaker_utils.py:100-210, :352-520; per-sample arithmetic of
+// cov_accum_diag_hits / cov_accum_diag_invnpp, src/libtoast/src/toast_map_cov.cpp:66-153).
+// Same run-reduced scatter as build_noise_weighted.  MODE 0: hits[pix] += 1 (int64);
+// MODE 1: invnpp[pix, (j,k>=j)] += w_k * (w_j * det_scale).
+// ------------------------------------------------------------------------------------
+template <int NNZ, int MODE>
+__global__ __launch_bounds__(kThreads) void k_build_cov(
+    const Chunk * __restrict__ chunks, int n_chunks, const int32_t * __restrict__ p_idx,
+    const int32_t * __restrict__ w_idx, const int32_t * __restrict__ f_idx,
+    const double * __restrict__ det_scale, const int64_t * __restrict__ g2l,
+    double * __restrict__ invcov, long long * __restrict__ hits, const int64_t * __restrict__ pixels,
+    const double * __restrict__ weights, const uint8_t * __restrict__ dflags, uint8_t dmask,
+    int use_dflags, const uint8_t * __restrict__ sflags, uint8_t smask, int use_sflags,
+    FastDiv nps_div, int64_t n_samp) {
+    constexpr int NV = (MODE == 0) ? 1 : NNZ * (NNZ + 1) / 2;
+    const int det = blockIdx.x;
+    const int64_t * prow = pixels + (int64_t)p_idx[det] * n_samp;
+    const double * wrow = (MODE == 1) ? weights + (int64_t)w_idx[det] * n_samp * NNZ : nullptr;
+    const uint8_t * frow = use_dflags ? dflags + (int64_t)f_idx[det] * n_samp : nullptr;
+    const double ds = (MODE == 1) ? det_scale[det] : 1.0;
+    const int64_t nps = nps_div.d;
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        for (int base = 0; base < c.count; base += kThreads) {
+            const int i = base + threadIdx.x;
+            const bool active = i < c.count;
+            const int64_t s = c.first + (active ? i : 0);
+            int64_t key = -1;
+            double v[NV];
+#pragma unroll
+            for (int k = 0; k < NV; ++k) v[k] = 0.0;
+            if (active) {
+                const int64_t p = prow[s];
+                bool good = p >= 0;
+                if (use_dflags) good = good && ((frow[s] & dmask) == 0);
+                if (use_sflags) good = good && ((sflags[s] & smask) == 0);
+                if (good) {
+                    const int64_t gsm = fastdiv(p, nps_div);
+                    key = g2l[gsm] * nps + (p - gsm * nps);
+                    if (MODE == 0) {
+                        v[0] = 1.0;
+                    } else {
+                        const double * w = wrow + NNZ * s;
+                        int off = 0;
+#pragma unroll
+                        for (int j = 0; j < NNZ; ++j) {
+                            const double sw = w[j] * ds;
+#pragma unroll
+                            for (int k = j; k < NNZ; ++k, ++off) v[off] = w[k] * sw;
+                        }
+                    }
+                }
+            }
+            const bool tail = wave_run_reduce<NV>(key, v);
+            if (tail && key >= 0) {
+                if (MODE == 0) {
+                    atomicAdd(reinterpret_cast<unsigned long long *>(hits + key),
+                              (unsigned long long)(long long)v[0]);
+                } else {
+                    double * z = invcov + NV * key;
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) unsafeAtomicAdd(z + k, v[k]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Per-pixel inversion of the packed symmetric covariance through its eigen-decomposition
+// (cov_eigendecompose_diag, src/libtoast/src/toast_map_cov.cpp:246-396): rcond = emin/emax;
+// if rcond >= threshold the block becomes V diag(1/lambda) V^T, else zero (and rcond 0).
+// Cyclic Jacobi rotations replace LAPACK dsyev (nnz <= 4, one thread per pixel).
+// ------------------------------------------------------------------------------------
+template <int NNZ>
+__global__ __launch_bounds__(kThreads) void k_cov_invert(int64_t n_px, double * __restrict__ data,
+                                                         double * __restrict__ cond, double threshold,
+                                                         int invert) {
+    constexpr int BLK = NNZ * (NNZ + 1) / 2;
+    for (int64_t px = (int64_t)blockIdx.x * kThreads + threadIdx.x; px < n_px;
+         px += (int64_t)gridDim.x * kThreads) {
+        double * d = data + px * BLK;
+        if (NNZ == 1) {
+            if (cond) cond[px] = 1.0;
+            if (invert && d[0] != 0) d[0] = 1.0 / d[0];
+            continue;
+        }
+        double a[NNZ][NNZ], v[NNZ][NNZ];
+        int off = 0;
+#pragma unroll
+        for (int k = 0; k < NNZ; ++k) {
+#pragma unroll
+            for (int m = k; m < NNZ; ++m, ++off) {
+                a[k][m] = d[off];
+                a[m][k] = d[off];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NNZ; ++k) {
+#pragma unroll
+            for (int m = 0; m < NNZ; ++m) v[k][m] = (k == m) ? 1.0 : 0.0;
+        }
+        for (int sweep = 0; sweep < 30; ++sweep) {
+            double offn = 0.0, diag = 0.0;
+#pragma unroll
+            for (int k = 0; k < NNZ; ++k) {
+                diag += a[k][k] * a[k][k];
+#pragma unroll
+                for (int m = k + 1; m < NNZ; ++m) offn += a[k][m] * a[k][m];
+            }
+            if (offn <= 1e-34 * diag || offn == 0.0) break;
+#pragma unroll
+            for (int p = 0; p < NNZ - 1; ++p) {
+#pragma unroll
+                for (int q = p + 1; q < NNZ; ++q) {
+                    const double apq = a[p][q];
+                    if (apq == 0.0) continue;
+                    const double theta = (a[q][q] - a[p][p]) / (2.0 * apq);
+                    const double t = ((theta >= 0) ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    const double cs = 1.0 / sqrt(t * t + 1.0);
+                    const double sn = t * cs;
+#pragma unroll
+                    for (int k = 0; k < NNZ; ++k) {
+                        const double akp = a[k][p], akq = a[k][q];
+                        a[k][p] = cs * akp - sn * akq;
+                        a[k][q] = sn * akp + cs * akq;
+                    }
+#pragma unroll
+                    for (int k = 0; k < NNZ; ++k) {
+                        const double apk = a[p][k], aqk = a[q][k];
+                        a[p][k] = cs * apk - sn * aqk;
+                        a[q][k] = sn * apk + cs * aqk;
+                    }
+#pragma unroll
+                    for (int k = 0; k < NNZ; ++k) {
+                        const double vkp = v[k][p], vkq = v[k][q];
+                        v[k][p] = cs * vkp - sn * vkq;
+                        v[k][q] = sn * vkp + cs * vkq;
+                    }
+                }
+            }
+        }
+        double emin = 1.0e100, emax = 0.0;
+#pragma unroll
+        for (int k = 0; k < NNZ; ++k) {
+            if (a[k][k] < emin) emin = a[k][k];
+            if (a[k][k] > emax) emax = a[k][k];
+        }
+        const double rc = (emax > 0.0) ? (emin / emax) : 0.0;
+        const bool ok = rc >= threshold;
+        if (invert) {
+            off = 0;
+#pragma unroll
+            for (int k = 0; k < NNZ; ++k) {
+#pragma unroll
+                for (int m = k; m < NNZ; ++m, ++off) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int e = 0; e < NNZ; ++e) acc += v[k][e] * v[m][e] / a[e][e];
+                    d[off] = ok ? acc : 0.0;
+                }
+            }
+        }
+        if (cond) cond[px] = ok ? rc : 0.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // noise_weight   [ref: ops_noise_weight.cpp:71-96]
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void k_noise_weight(
@@ -861,6 +1030,75 @@ int toast_hip_template_offset_apply_diag_precond_dev(const double * d_offset_var
         hipLaunchKernelGGL(k_offset_apply_diag_precond, flat_grid(n_amp), dim3(kThreads), 0,
                            as_stream(stream), n_amp, d_offset_var, d_amp_in, d_amplitude_flags,
                            d_amp_out);
+        check_launch();
+    });
+}
+
+int toast_hip_build_cov_dev(
+    int mode /*0 hits, 1 inverse covariance*/, const int64_t * d_g2l, void * d_out, int64_t n_pix_submap,
+    int64_t nnz, const int32_t * pixel_index, const int64_t * d_pixels, const int32_t * weight_index,
+    const double * d_weights, const int32_t * flag_index, const uint8_t * d_det_flags,
+    int64_t n_flag_samp, const double * det_scale, uint8_t det_flag_mask, int64_t n_det, int64_t n_samp,
+    const toast_hip_interval * intervals, int64_t n_view, const uint8_t * d_shared_flags,
+    int64_t n_shared_flags, uint8_t shared_flag_mask, void * stream) {
+    return guarded([&] {
+        if (n_det <= 0) return;
+        if (n_pix_submap <= 0) fail_arg("n_pix_submap must be positive");
+        if (mode == 1 && (nnz < 1 || nnz > 3)) fail_arg("build_inverse_covariance: nnz must be 1..3");
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        const int use_d = (n_flag_samp == n_samp) ? 1 : 0;
+        const int use_s = (n_shared_flags == n_samp) ? 1 : 0;
+        std::vector<int32_t> fidx(n_det, 0), widx(n_det, 0);
+        std::vector<double> dscale(n_det, 1.0);
+        if (use_d) std::memcpy(fidx.data(), flag_index, sizeof(int32_t) * n_det);
+        if (mode == 1) {
+            std::memcpy(widx.data(), weight_index, sizeof(int32_t) * n_det);
+            std::memcpy(dscale.data(), det_scale, sizeof(double) * n_det);
+        }
+        ParamBlock pb;
+        const size_t o_ch = pb.push_vec(chunks);
+        const size_t o_pi = pb.push(pixel_index, sizeof(int32_t) * n_det);
+        const size_t o_wi = pb.push_vec(widx);
+        const size_t o_fi = pb.push_vec(fidx);
+        const size_t o_ds = pb.push_vec(dscale);
+        const char * d = pb.commit(as_stream(stream));
+        const FastDiv dv = make_fastdiv(n_pix_submap);
+        const dim3 grid = chunk_grid(n_det, chunks.size());
+        hipStream_t st = as_stream(stream);
+#define TH_COV_ARGS                                                                              \
+    (const Chunk *)(d + o_ch), (int)chunks.size(), (const int32_t *)(d + o_pi),                  \
+        (const int32_t *)(d + o_wi), (const int32_t *)(d + o_fi), (const double *)(d + o_ds),    \
+        d_g2l, (double *)d_out, (long long *)d_out, d_pixels, d_weights, d_det_flags,            \
+        det_flag_mask, use_d, d_shared_flags, shared_flag_mask, use_s, dv, n_samp
+        if (mode == 0) {
+            hipLaunchKernelGGL((k_build_cov<1, 0>), grid, dim3(kThreads), 0, st, TH_COV_ARGS);
+        } else if (nnz == 3) {
+            hipLaunchKernelGGL((k_build_cov<3, 1>), grid, dim3(kThreads), 0, st, TH_COV_ARGS);
+        } else if (nnz == 2) {
+            hipLaunchKernelGGL((k_build_cov<2, 1>), grid, dim3(kThreads), 0, st, TH_COV_ARGS);
+        } else {
+            hipLaunchKernelGGL((k_build_cov<1, 1>), grid, dim3(kThreads), 0, st, TH_COV_ARGS);
+        }
+#undef TH_COV_ARGS
+        check_launch();
+    });
+}
+
+int toast_hip_cov_eigendecompose_diag_dev(int64_t n_sub, int64_t subsize, int64_t nnz, double * d_data,
+                                          double * d_cond, double threshold, int invert, void * stream) {
+    return guarded([&] {
+        const int64_t n_px = n_sub * subsize;
+        if (n_px <= 0) return;
+        const dim3 grid = flat_grid(n_px);
+        hipStream_t st = as_stream(stream);
+        switch (nnz) {
+            case 1: hipLaunchKernelGGL(k_cov_invert<1>, grid, dim3(kThreads), 0, st, n_px, d_data, d_cond, threshold, invert); break;
+            case 2: hipLaunchKernelGGL(k_cov_invert<2>, grid, dim3(kThreads), 0, st, n_px, d_data, d_cond, threshold, invert); break;
+            case 3: hipLaunchKernelGGL(k_cov_invert<3>, grid, dim3(kThreads), 0, st, n_px, d_data, d_cond, threshold, invert); break;
+            case 4: hipLaunchKernelGGL(k_cov_invert<4>, grid, dim3(kThreads), 0, st, n_px, d_data, d_cond, threshold, invert); break;
+            default: fail_arg("cov_eigendecompose_diag: nnz must be 1..4");
+        }
         check_launch();
     });
 }

@@ -414,4 +414,97 @@ PYBIND11_MODULE(_libtoast_hip, m) {
         uint8_t * af = extract<uint8_t>(amplitude_flags, "amplitude_flags", 1, s, {n_amp});
         check(toast_hip_template_offset_apply_diag_precond(var, in, af, out, n_amp, use_accel));
     });
+    // ---- extensions without a toast._libtoast counterpart
+    m.def("accel_device_ptr", [](py::buffer data) {
+        RawBuf b = accel_buf(data);
+        void * dev = nullptr;
+        check(toast_hip_accel_device_ptr(b.ptr, &dev));
+        return reinterpret_cast<uintptr_t>(dev);
+    });
+    m.def("accel_adopt", [](py::buffer data, uintptr_t device, std::string name) {
+        RawBuf b = accel_buf(data);
+        check(toast_hip_accel_adopt(b.ptr, b.nbytes, reinterpret_cast<void *>(device), name.c_str()));
+    });
+
+    // ---- hit map / inverse covariance accumulation (operator-level kernels of BuildHitMap and
+    //      BuildInverseCovariance, src/toast/ops/mapmaker_utils/mapmaker_utils.py:100-210, :352-520)
+    auto build_cov = [](int mode, py::buffer global2local, py::buffer out, py::buffer pixel_index,
+                        py::buffer pixels, py::buffer weight_index, py::buffer weights, py::buffer flag_index,
+                        py::buffer det_flags, py::buffer det_scale, uint8_t det_flag_mask, py::buffer intervals,
+                        py::buffer shared_flags, uint8_t shared_flag_mask, bool use_accel) {
+        Shape s(3);
+        int32_t * p_idx = extract<int32_t>(pixel_index, "pixel_index", 1, s, {-1});
+        const int64_t n_det = s[0];
+        int64_t * pix = extract<int64_t>(pixels, "pixels", 2, s, {-1, -1});
+        const int64_t n_p_rows = s[0], n_samp = s[1];
+        int32_t * f_idx = extract<int32_t>(flag_index, "flag_index", 1, s, {n_det});
+        toast_hip_interval * ivl = extract_intervals(intervals, s);
+        const int64_t n_view = s[0];
+        int64_t * g2l = extract<int64_t>(global2local, "global2local", 1, s, {-1});
+        const int64_t n_submap = s[0];
+        uint8_t * sf = extract<uint8_t>(shared_flags, "flags", 1, s, {-1});
+        const int64_t n_sf = s[0];
+        uint8_t * df = extract<uint8_t>(det_flags, "det_flags", 2, s, {-1, -1});
+        const int64_t n_f_rows = s[0], n_f_samp = s[1];
+        int32_t * w_idx = nullptr;
+        double * w = nullptr;
+        double * dscale = nullptr;
+        int64_t nnz = 1, n_w_rows = 0, n_local, nps;
+        void * outp;
+        if (mode == 0) {
+            outp = extract<int64_t>(out, "hits", 3, s, {-1, -1, 1});
+            n_local = s[0];
+            nps = s[1];
+        } else {
+            w_idx = extract<int32_t>(weight_index, "weight_index", 1, s, {n_det});
+            if (weights.request().ndim == 2) {
+                w = extract<double>(weights, "weights", 2, s, {-1, n_samp});
+                nnz = 1;
+            } else {
+                w = extract<double>(weights, "weights", 3, s, {-1, n_samp, -1});
+                nnz = s[2];
+            }
+            n_w_rows = s[0];
+            dscale = extract<double>(det_scale, "det_scale", 1, s, {n_det});
+            outp = extract<double>(out, "invcov", 3, s, {-1, -1, nnz * (nnz + 1) / 2});
+            n_local = s[0];
+            nps = s[1];
+        }
+        check(toast_hip_build_cov(mode, g2l, n_submap, outp, n_local, nps, nnz, p_idx, pix, n_p_rows, w_idx, w,
+                                  n_w_rows, f_idx, df, n_f_rows, n_f_samp, dscale, det_flag_mask, n_det, n_samp,
+                                  ivl, n_view, sf, n_sf, shared_flag_mask, use_accel));
+    };
+    m.def("build_hit_map", [build_cov](py::buffer global2local, py::buffer hits, py::buffer pixel_index,
+                                       py::buffer pixels, py::buffer flag_index, py::buffer det_flags,
+                                       uint8_t det_flag_mask, py::buffer intervals, py::buffer shared_flags,
+                                       uint8_t shared_flag_mask, bool use_accel) {
+        build_cov(0, global2local, hits, pixel_index, pixels, pixel_index, pixels, flag_index, det_flags,
+                  pixels, det_flag_mask, intervals, shared_flags, shared_flag_mask, use_accel);
+    });
+    m.def("build_inverse_covariance", [build_cov](py::buffer global2local, py::buffer invcov,
+                                                  py::buffer pixel_index, py::buffer pixels,
+                                                  py::buffer weight_index, py::buffer weights,
+                                                  py::buffer flag_index, py::buffer det_flags,
+                                                  py::buffer det_scale, uint8_t det_flag_mask,
+                                                  py::buffer intervals, py::buffer shared_flags,
+                                                  uint8_t shared_flag_mask, bool use_accel) {
+        build_cov(1, global2local, invcov, pixel_index, pixels, weight_index, weights, flag_index, det_flags,
+                  det_scale, det_flag_mask, intervals, shared_flags, shared_flag_mask, use_accel);
+    });
+    // map_cov.cpp:269-325
+    m.def("cov_eigendecompose_diag", [](int64_t nsub, int64_t nsubpix, int64_t nnz, py::buffer data,
+                                        py::buffer cond, double threshold, bool invert, bool use_accel) {
+        auto id = data.request();
+        auto ic = cond.request();
+        if (norm_format(id.format) != "d" || norm_format(ic.format) != "d") {
+            throw std::runtime_error("cov_eigendecompose_diag: buffers must be float64");
+        }
+        const int64_t block = nnz * (nnz + 1) / 2;
+        if ((int64_t)id.size != nsub * nsubpix * block || (int64_t)ic.size != nsub * nsubpix) {
+            throw std::runtime_error("cov_eigendecompose_diag: buffer sizes are not consistent");
+        }
+        check(toast_hip_cov_eigendecompose_diag(nsub, nsubpix, nnz, static_cast<double *>(id.ptr),
+                                                static_cast<double *>(ic.ptr), threshold, invert, use_accel));
+    }, py::arg("nsub"), py::arg("nsubpix"), py::arg("nnz"), py::arg("data"), py::arg("cond"),
+       py::arg("threshold"), py::arg("invert"), py::arg("use_accel") = false);
 }

@@ -102,7 +102,9 @@ Manager & Manager::get() {
 }
 
 void Manager::clear() {
-    for (auto & kv : table_) (void)hipFree(kv.second.dev);
+    for (auto & kv : table_) {
+        if (kv.second.owned) (void)hipFree(kv.second.dev);
+    }
     table_.clear();
 }
 
@@ -199,8 +201,18 @@ void * Manager::create(const void * host, size_t nbytes, const char * name) {
           << (name ? name : "NA") << "') on device " << device_ << ", allocation failed";
         throw Error(TOAST_HIP_ERR_MEMORY, o.str());
     }
-    table_[host] = Entry{dev, nbytes, name ? name : "NA"};
+    table_[host] = Entry{dev, nbytes, name ? name : "NA", true};
     return dev;
+}
+
+void Manager::adopt(const void * host, size_t nbytes, void * device, const char * name) {
+    require_device();
+    if (table_.count(host)) {
+        std::ostringstream o;
+        o << "HipManager:  on adopt, host ptr " << host << " is already present";
+        throw Error(TOAST_HIP_ERR_MEMORY, o.str());
+    }
+    table_[host] = Entry{device, nbytes, name ? name : "NA", false};
 }
 
 void Manager::reset(const void * host, size_t nbytes, const char * name) {
@@ -228,7 +240,7 @@ void Manager::remove(const void * host, size_t nbytes, const char * name) {
     require_device();
     Entry & e = lookup(host, nbytes, name, "delete");
     TH_HIP(hipStreamSynchronize(stream_));
-    TH_HIP(hipFree(e.dev));
+    if (e.owned) TH_HIP(hipFree(e.dev));
     table_.erase(host);
 }
 
@@ -323,6 +335,10 @@ int toast_hip_accel_present(const void * host, size_t nbytes, int * present) {
 
 int toast_hip_accel_create(const void * host, size_t nbytes, const char * name) {
     return guarded([&] { Manager::get().create(host, nbytes, name); });
+}
+
+int toast_hip_accel_adopt(const void * host, size_t nbytes, void * device, const char * name) {
+    return guarded([&] { Manager::get().adopt(host, nbytes, device, name); });
 }
 
 int toast_hip_accel_reset(const void * host, size_t nbytes, const char * name) {

@@ -97,6 +97,7 @@ public:
     void require_device();      // throws unless a GPU is assigned and usable; hipSetDevice
     int present(const void * host, size_t nbytes);
     void * create(const void * host, size_t nbytes, const char * name);
+    void adopt(const void * host, size_t nbytes, void * device, const char * name);
     void reset(const void * host, size_t nbytes, const char * name);
     void update_device(const void * host, size_t nbytes, const char * name);
     void update_host(void * host, size_t nbytes, const char * name);
@@ -114,6 +115,7 @@ private:
         void * dev;
         size_t nbytes;
         std::string name;
+        bool owned = true;
     };
     Entry & lookup(const void * host, size_t nbytes, const char * name, const char * what);
 

@@ -1,0 +1,552 @@
+"""Minimal data model honouring the reference's buffer layouts -- only what the map-making
+operators touch (SURVEY.md §2.1 marks the full data model out of scope):
+
+* ``DetectorData`` / ``DetDataManager``  src/toast/observation_data.py:25-860
+  (one contiguous ``[n_det, n_samp, ...]`` buffer per key, row lookup with ``indices()``,
+  ``ensure()`` re-using allocations, accel_* staging keyed by the buffer's base pointer)
+* ``SharedData``                         src/toast/observation_data.py:1200-  (per-observation arrays)
+* ``IntervalList``                       src/toast/intervals.py:26-300 (32-byte records)
+* ``Observation`` / ``Data``             src/toast/observation.py, src/toast/data.py
+* ``Comm``                               src/toast/mpi.py:113-275, backed by torch.distributed
+  (RCCL on GPUs, gloo on CPU) instead of mpi4py.
+"""
+
+import types
+from collections.abc import MutableMapping
+
+import numpy as np
+
+from .accel import (
+    AcceleratorObject,
+    accel_data_create,
+    accel_data_delete,
+    accel_data_present,
+    accel_data_reset,
+    accel_data_update_device,
+    accel_data_update_host,
+    accel_enabled,
+)
+from .synth import interval_dtype
+
+#: default names and flag masks (reference: src/toast/observation.py:44-111)
+defaults = types.SimpleNamespace(
+    times="times",
+    shared_flags="flags",
+    det_data="signal",
+    det_flags="flags",
+    hwp_angle="hwp_angle",
+    boresight_radec="boresight_radec",
+    pixels="pixels",
+    weights="weights",
+    quats="quats",
+    noise_model="noise_model",
+    shared_mask_invalid=1,
+    shared_mask_processing=2,
+    shared_mask_unstable_scanrate=4,
+    shared_mask_irregular=8,
+    shared_mask_nonscience=1 | 2 | 4 | 8,
+    det_mask_invalid=1,
+    det_mask_processing=2,
+    det_mask_sso=4,
+    det_mask_nonscience=1 | 2 | 4,
+    det_data_units="K",
+)
+
+
+# ----------------------------------------------------------------------------- communicator
+class Comm:
+    """Process layout.  One process per GPU; ``comm_world`` is None for a single process,
+    else this object (it provides the few collectives the path needs)."""
+
+    def __init__(self, use_dist=None):
+        import torch.distributed as dist
+
+        self._dist = dist if (dist.is_available() and dist.is_initialized()) else None
+        if use_dist is False:
+            self._dist = None
+        self.world_rank = self._dist.get_rank() if self._dist else 0
+        self.world_size = self._dist.get_world_size() if self._dist else 1
+        self.group_rank = self.world_rank
+        self.group_size = self.world_size
+        self.group = 0
+        self.ngroups = 1
+
+    @property
+    def comm_world(self):
+        return self if (self._dist is not None and self.world_size > 1) else None
+
+    comm_group = comm_world
+
+    # -- collectives
+    def allreduce_scalar(self, value, op="sum"):
+        """All-reduce one Python number (``Amplitudes.dot`` / nnz agreement)."""
+        if self.comm_world is None:
+            return value
+        import torch
+
+        ops = {"sum": self._dist.ReduceOp.SUM, "max": self._dist.ReduceOp.MAX, "min": self._dist.ReduceOp.MIN}
+        dev = self._collective_device()
+        t = torch.tensor([value], dtype=torch.float64, device=dev)
+        self._dist.all_reduce(t, op=ops[op])
+        return type(value)(t.item()) if isinstance(value, (int, np.integer)) else float(t.item())
+
+    def _collective_device(self):
+        import torch
+
+        backend = self._dist.get_backend()
+        return torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+
+    def allreduce_tensor_(self, tensor, op="sum"):
+        """In-place all-reduce of a torch tensor (device tensor -> RCCL over xGMI)."""
+        if self.comm_world is None:
+            return tensor
+        ops = {"sum": self._dist.ReduceOp.SUM, "max": self._dist.ReduceOp.MAX}
+        self._dist.all_reduce(tensor, op=ops[op])
+        return tensor
+
+    def allreduce_array_(self, arr, op="sum"):
+        """In-place all-reduce of a host NumPy array."""
+        if self.comm_world is None:
+            return arr
+        import torch
+
+        t = torch.from_numpy(arr)
+        if self._dist.get_backend() == "nccl":
+            d = t.to(self._collective_device())
+            self.allreduce_tensor_(d, op)
+            t.copy_(d.cpu())
+        else:
+            self.allreduce_tensor_(t, op)
+        return arr
+
+    def barrier(self):
+        if self.comm_world is not None:
+            self._dist.barrier()
+
+
+# ----------------------------------------------------------------------------- intervals
+class IntervalList:
+    """Sample spans ``[first, last)`` with their times; ``.data`` is the structured array the
+    kernels consume (reference: src/toast/intervals.py)."""
+
+    def __init__(self, timestamps=None, samplespans=None, data=None):
+        if data is not None:
+            self.data = np.ascontiguousarray(data, dtype=interval_dtype)
+            return
+        spans = [] if samplespans is None else list(samplespans)
+        self.data = np.zeros(len(spans), dtype=interval_dtype)
+        for i, (first, last) in enumerate(spans):
+            self.data[i]["first"] = first
+            self.data[i]["last"] = last
+            if timestamps is not None and len(timestamps) > 0:
+                self.data[i]["start"] = timestamps[first]
+                self.data[i]["stop"] = timestamps[min(last, len(timestamps)) - 1]
+
+    def __len__(self):
+        return len(self.data)
+
+    def __iter__(self):
+        for rec in self.data:
+            yield types.SimpleNamespace(start=float(rec["start"]), stop=float(rec["stop"]),
+                                        first=int(rec["first"]), last=int(rec["last"]))
+
+    def __eq__(self, other):
+        return isinstance(other, IntervalList) and np.array_equal(self.data[["first", "last"]],
+                                                                  other.data[["first", "last"]])
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+
+class IntervalsManager(dict):
+    """``ob.intervals[name]``; the key ``None`` is the whole observation."""
+
+    def __init__(self, n_samp, timestamps=None):
+        super().__init__()
+        self._n_samp = n_samp
+        self._times = timestamps
+        self[None] = IntervalList(timestamps, [(0, n_samp)])
+
+    def create(self, name, samplespans):
+        self[name] = IntervalList(self._times, samplespans)
+
+
+# ----------------------------------------------------------------------------- detector data
+class DetectorData(AcceleratorObject):
+    """One contiguous buffer ``[n_det, n_samp] + sample_shape`` for a list of detectors."""
+
+    def __init__(self, detectors, shape, dtype, units=None):
+        super().__init__("DetectorData")
+        self._set_detectors(detectors)
+        self._sample_shape = tuple(shape[1:])
+        self._n_samp = int(shape[0])
+        self._dtype = np.dtype(dtype)
+        self.units = units
+        full = (len(self._detectors), self._n_samp) + self._sample_shape
+        self._raw = np.zeros(int(np.prod(full)) if len(self._detectors) else 0, dtype=self._dtype)
+        self._capacity = self._raw.size
+        self._data = self._raw[: int(np.prod(full))].reshape(full)
+
+    def _set_detectors(self, detectors):
+        self._detectors = list(detectors)
+        self._name2idx = {d: i for i, d in enumerate(self._detectors)}
+
+    @property
+    def detectors(self):
+        return list(self._detectors)
+
+    keys = detectors.fget
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+    @property
+    def shape(self):
+        return self._data.shape
+
+    @property
+    def detector_shape(self):
+        return self._data.shape[1:]
+
+    @property
+    def data(self):
+        """The full buffer view; its base pointer is the accelerator key."""
+        return self._data
+
+    def indices(self, names):
+        """Rows of the given detectors, int32 (observation_data.py:171-195)."""
+        return np.array([self._name2idx[x] for x in names], dtype=np.int32)
+
+    def change_detectors(self, detectors):
+        """Re-use the allocation for a different detector list when it is not longer, else
+        reallocate (observation_data.py:248-325).  Host (and device) contents are zeroed."""
+        detectors = list(detectors)
+        if detectors == self._detectors:
+            return
+        n_new = len(detectors)
+        need = n_new * self._n_samp * int(np.prod(self._sample_shape, dtype=np.int64))
+        if need > self._capacity:
+            if self.accel_exists():
+                self.accel_delete()
+            self._raw = np.zeros(need, dtype=self._dtype)
+            self._capacity = need
+        elif need == self._data.size:
+            # same footprint (e.g. one-detector buffers recycled by SINGLE pipelines): keep the
+            # host allocation and the device copy, zero both
+            self._raw[:] = 0
+            if self.accel_exists():
+                self.accel_reset()
+        else:
+            # the device copy is keyed by the *view*, whose size changes: drop it
+            if self.accel_exists():
+                self.accel_delete()
+            self._raw[:] = 0
+        self._set_detectors(detectors)
+        self._data = self._raw[:need].reshape((n_new, self._n_samp) + self._sample_shape)
+
+    def reset(self, dets=None):
+        if dets is None:
+            self._data[:] = 0
+            if self.accel_exists():
+                self.accel_reset()
+        elif set(dets) >= set(self._detectors):
+            self.reset(None)
+        else:
+            on_dev = self.accel_in_use()
+            if on_dev:
+                self.accel_update_host()
+            for d in dets:
+                self._data[self._name2idx[d]] = 0
+            if on_dev:
+                self.accel_update_device()
+
+    def _row(self, key):
+        if isinstance(key, (str, np.str_)):
+            return self._name2idx[key]
+        return key
+
+    def __getitem__(self, key):
+        if isinstance(key, tuple):
+            first = key[0]
+            if isinstance(first, (list, tuple)) and first and isinstance(first[0], (str, np.str_)):
+                first = [self._name2idx[x] for x in first]
+            else:
+                first = self._row(first)
+            return self._data[(first,) + tuple(key[1:])]
+        return self._data[self._row(key)]
+
+    def __setitem__(self, key, value):
+        if isinstance(key, tuple):
+            self._data[(self._row(key[0]),) + tuple(key[1:])] = value
+        else:
+            self._data[self._row(key)] = value
+
+    # accelerator protocol
+    def _accel_exists(self):
+        return self._data.size > 0 and accel_data_present(self._data, self._accel_name)
+
+    def _accel_create(self, zero_out=False):
+        accel_data_create(self._data, self._accel_name, zero_out=zero_out)
+
+    def _accel_update_device(self):
+        accel_data_update_device(self._data, self._accel_name)
+
+    def _accel_update_host(self):
+        accel_data_update_host(self._data, self._accel_name)
+
+    def _accel_delete(self):
+        accel_data_delete(self._data, self._accel_name)
+
+    def _accel_reset(self):
+        accel_data_reset(self._data, self._accel_name)
+
+
+class DetDataManager(MutableMapping):
+    """``ob.detdata`` (reference: observation_data.py:620-1190)."""
+
+    def __init__(self, n_samp, local_detectors):
+        self._n_samp = n_samp
+        self._local_detectors = list(local_detectors)
+        self._store = {}
+
+    def create(self, name, sample_shape=(), dtype=np.float64, detectors=None, units=None):
+        if name in self._store:
+            raise RuntimeError(f"detdata '{name}' already exists")
+        dets = self._local_detectors if detectors is None else list(detectors)
+        self._store[name] = DetectorData(dets, (self._n_samp,) + tuple(sample_shape), dtype, units=units)
+        self._store[name]._accel_name = name
+        return self._store[name]
+
+    def ensure(self, name, sample_shape=(), dtype=np.float64, detectors=None, accel=False, create_units=None):
+        """Make sure ``name`` exists with this shape/dtype and holds ``detectors``.
+
+        Returns True when it already held all requested detectors (callers then skip
+        recomputation), False when it was created or its detector list changed
+        (observation_data.py:725-860).  With ``accel=True`` the buffer also exists on the
+        device afterwards and is marked as in use there."""
+        dets = self._local_detectors if detectors is None else list(detectors)
+        existing = True
+        if name not in self._store:
+            self.create(name, sample_shape, dtype, dets, units=create_units)
+            existing = False
+        else:
+            cur = self._store[name]
+            if cur.detector_shape[1:] != tuple(sample_shape) or cur.dtype != np.dtype(dtype):
+                raise RuntimeError(f"detdata '{name}' exists with a different sample shape or dtype")
+            have = set(cur.detectors)
+            if not all(d in have for d in dets):
+                cur.change_detectors(dets)
+                existing = False
+        obj = self._store[name]
+        if accel and accel_enabled():
+            if not obj.accel_exists():
+                obj.accel_create(name, zero_out=not existing)
+                if existing:
+                    obj.accel_update_device()
+            elif not obj.accel_in_use():
+                obj.accel_update_device()
+            obj.accel_used(True)
+        return existing
+
+    def __getitem__(self, name):
+        return self._store[name]
+
+    def __setitem__(self, name, value):
+        self._store[name] = value
+
+    def __delitem__(self, name):
+        obj = self._store.pop(name)
+        if obj.accel_exists():
+            obj.accel_delete()
+
+    def __iter__(self):
+        return iter(self._store)
+
+    def __len__(self):
+        return len(self._store)
+
+
+class SharedData(AcceleratorObject):
+    """A per-observation array shared by all detectors (boresight, flags, HWP angle, times)."""
+
+    def __init__(self, array, name="shared"):
+        super().__init__(name)
+        self.data = np.ascontiguousarray(array)
+
+    def _accel_exists(self):
+        return accel_data_present(self.data, self._accel_name)
+
+    def _accel_create(self, zero_out=False):
+        accel_data_create(self.data, self._accel_name, zero_out=zero_out)
+
+    def _accel_update_device(self):
+        accel_data_update_device(self.data, self._accel_name)
+
+    def _accel_update_host(self):
+        accel_data_update_host(self.data, self._accel_name)
+
+    def _accel_delete(self):
+        accel_data_delete(self.data, self._accel_name)
+
+    def _accel_reset(self):
+        accel_data_reset(self.data, self._accel_name)
+
+
+class SharedDataManager(dict):
+    def create(self, name, array):
+        self[name] = SharedData(array, name)
+        return self[name]
+
+
+# ----------------------------------------------------------------------------- instrument
+class Focalplane:
+    """Detector table: ``detector_data[det]`` has ``quat``, ``gamma``, ``pol_leakage``
+    (epsilon) and ``cal`` (reference: src/toast/instrument.py Focalplane)."""
+
+    def __init__(self, detectors, quats, gamma=None, epsilon=None, cal=None, sample_rate=1.0):
+        self.detectors = list(detectors)
+        n = len(self.detectors)
+        self.sample_rate = float(sample_rate)
+        gamma = np.zeros(n) if gamma is None else np.asarray(gamma, dtype=np.float64)
+        epsilon = np.zeros(n) if epsilon is None else np.asarray(epsilon, dtype=np.float64)
+        cal = np.ones(n) if cal is None else np.asarray(cal, dtype=np.float64)
+        self._table = {
+            d: dict(quat=np.asarray(quats[i], dtype=np.float64), gamma=float(gamma[i]),
+                    pol_leakage=float(epsilon[i]), cal=float(cal[i]))
+            for i, d in enumerate(self.detectors)
+        }
+
+    def __getitem__(self, det):
+        return self._table[det]
+
+
+class Telescope:
+    def __init__(self, name, focalplane):
+        self.name = name
+        self.focalplane = focalplane
+
+
+class Observation(MutableMapping):
+    """One observation: telescope, ``n_local_samples``, ``detdata``, ``shared``, ``intervals``
+    and a dict of metadata (e.g. the noise model)."""
+
+    def __init__(self, comm, telescope, n_samples, name="obs", detectors=None):
+        self.comm = comm
+        self.telescope = telescope
+        self.name = name
+        self.n_local_samples = int(n_samples)
+        self.local_detectors = list(telescope.focalplane.detectors if detectors is None else detectors)
+        self.local_detector_flags = {d: 0 for d in self.local_detectors}
+        times = None
+        self.detdata = DetDataManager(self.n_local_samples, self.local_detectors)
+        self.shared = SharedDataManager()
+        self.intervals = IntervalsManager(self.n_local_samples, times)
+        self._meta = {}
+
+    def set_times(self, times):
+        self.shared.create(defaults.times, np.asarray(times, dtype=np.float64))
+        self.intervals._times = self.shared[defaults.times].data
+        self.intervals[None] = IntervalList(self.intervals._times, [(0, self.n_local_samples)])
+
+    def update_local_detector_flags(self, flags):
+        self.local_detector_flags.update(flags)
+
+    def select_local_detectors(self, selection=None, flagmask=0):
+        """Local detectors restricted to ``selection`` and with ``(flags & flagmask) == 0``
+        (reference: src/toast/observation.py select_local_detectors)."""
+        sel = None if selection is None else set(selection)
+        out = []
+        for d in self.local_detectors:
+            if sel is not None and d not in sel:
+                continue
+            if self.local_detector_flags.get(d, 0) & flagmask:
+                continue
+            out.append(d)
+        return out
+
+    def __getitem__(self, key):
+        return self._meta[key]
+
+    def __setitem__(self, key, value):
+        self._meta[key] = value
+
+    def __delitem__(self, key):
+        del self._meta[key]
+
+    def __iter__(self):
+        return iter(self._meta)
+
+    def __len__(self):
+        return len(self._meta)
+
+
+class Data(MutableMapping):
+    """Observations + global objects (pixel distributions, maps, amplitudes)."""
+
+    def __init__(self, comm=None):
+        self.comm = Comm() if comm is None else comm
+        self.obs = []
+        self._internal = {}
+
+    def all_local_detectors(self, selection=None, flagmask=0):
+        seen, out = set(), []
+        for ob in self.obs:
+            for d in ob.select_local_detectors(selection, flagmask):
+                if d not in seen:
+                    seen.add(d)
+                    out.append(d)
+        return out
+
+    # dict interface for global objects
+    def __getitem__(self, key):
+        return self._internal[key]
+
+    def __setitem__(self, key, value):
+        self._internal[key] = value
+
+    def __delitem__(self, key):
+        obj = self._internal.pop(key)
+        if isinstance(obj, AcceleratorObject) and obj.accel_exists():
+            obj.accel_delete()
+
+    def __iter__(self):
+        return iter(self._internal)
+
+    def __len__(self):
+        return len(self._internal)
+
+    # -- accelerator staging by ``requires()`` / ``provides()`` dictionaries
+    #    (reference: src/toast/data.py accel_create / accel_update_device / ...)
+    def _each(self, names):
+        for key in names.get("global", []):
+            obj = self._internal.get(key)
+            if isinstance(obj, AcceleratorObject):
+                yield key, obj
+        for ob in self.obs:
+            for key in names.get("detdata", []):
+                if key in ob.detdata:
+                    yield key, ob.detdata[key]
+            for key in names.get("shared", []):
+                if key in ob.shared:
+                    yield key, ob.shared[key]
+
+    def accel_create(self, names):
+        for key, obj in self._each(names):
+            if not obj.accel_exists():
+                obj.accel_create(key)
+
+    def accel_update_device(self, names):
+        for key, obj in self._each(names):
+            if obj.accel_exists() and not obj.accel_in_use():
+                obj.accel_update_device()
+
+    def accel_update_host(self, names):
+        for key, obj in self._each(names):
+            if obj.accel_exists() and obj.accel_in_use():
+                obj.accel_update_host()
+
+    def accel_delete(self, names):
+        for key, obj in self._each(names):
+            if obj.accel_exists():
+                obj.accel_delete()

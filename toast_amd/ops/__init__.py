@@ -1,0 +1,20 @@
+"""Operator surface of the map-making hot path, with the reference's class names
+(``toast.ops.*``): drop-in for that path."""
+
+from .mapmaker import ApplyAmplitudes, MapMaker
+from .mapmaker_ops import (
+    BinMap,
+    BuildHitMap,
+    BuildInverseCovariance,
+    BuildNoiseWeighted,
+    Copy,
+    CovarianceAndHits,
+    Delete,
+    NoiseWeight,
+    ScanMap,
+)
+from .mapmaker_solve import SolverLHS, SolverRHS, TemplateMatrix, solve
+from .noise_filter import NoiseFilter
+from .operator import Operator
+from .pipeline import Pipeline
+from .pointing import PixelsHealpix, PointingDetectorSimple, StokesWeights

@@ -1,0 +1,158 @@
+"""MapMaker: solve for template amplitudes (destriping) and bin the cleaned signal.
+
+Reference: src/toast/ops/mapmaker.py:37-790 (MapMaker) and
+src/toast/ops/mapmaker_templates.py:423-1125 (SolveAmplitudes, ApplyAmplitudes).  The
+orchestration is reproduced for the configuration used on the hot path: covariance + hits
+from the same pointing, RHS, PCG on the Offset amplitudes, template subtraction, final BinMap.
+"""
+
+import numpy as np
+
+from ..data import defaults
+from ..pixels import PixelData
+from ..traits import Bool, Float, Instance, Int, Unicode
+from .mapmaker_ops import BinMap, Copy, CovarianceAndHits, Delete
+from .mapmaker_solve import SolverLHS, SolverRHS, TemplateMatrix, solve
+from .operator import Operator
+from .pipeline import Pipeline
+
+
+class ApplyAmplitudes(Operator):
+    """``out = det_data (-|+|*|/) M a`` (mapmaker_templates.py:1128-1320, subtract only)."""
+
+    API = Int(0, help="Internal interface version for this operator")
+    op = Unicode("subtract", help="Operation on the timestreams: 'subtract' or 'add'")
+    amplitudes = Unicode(None, allow_none=True, help="Data key for template amplitudes")
+    template_matrix = Instance(klass=Operator, help="This must be an instance of a template matrix operator")
+    det_data = Unicode(defaults.det_data, help="Observation detdata key for the timestream data")
+    output = Unicode(None, allow_none=True, help="Observation detdata key for output (default: in place)")
+
+    def _exec(self, data, detectors=None, **kwargs):
+        if self.op not in ("subtract", "add"):
+            raise NotImplementedError("only subtract / add are supported")
+        out = self.det_data if self.output is None else self.output
+        temp = "temp_apply_amps"
+        tm = self.template_matrix.duplicate()
+        tm.amplitudes = self.amplitudes
+        tm.transpose = False
+        tm.det_data = temp
+        tm.apply(data, detectors=detectors)
+        for ob in data.obs:
+            if out != self.det_data:
+                Copy(detdata=[(self.det_data, out)]).apply(data, detectors=detectors)
+            dets = ob.select_local_detectors(detectors, flagmask=tm.det_mask)
+            t = ob.detdata[temp]
+            if t.accel_in_use():
+                t.accel_update_host()
+            o = ob.detdata[out]
+            if o.accel_in_use():
+                o.accel_update_host()
+            for d in dets:
+                if self.op == "subtract":
+                    o[d] -= t[d]
+                else:
+                    o[d] += t[d]
+        Delete(detdata=[temp]).apply(data)
+
+    def _finalize(self, data, **kwargs):
+        return
+
+    def _requires(self):
+        return {"global": [self.amplitudes], "detdata": [self.det_data]}
+
+    def _provides(self):
+        return {"detdata": [self.det_data if self.output is None else self.output]}
+
+
+class MapMaker(Operator):
+    """Generalised destriping map-maker.
+
+    Products (``<name>_hits``, ``_cov``, ``_rcond``, ``_map``, ``_amplitudes``) are stored in
+    ``data``.  With no templates this reduces to CovarianceAndHits + BinMap."""
+
+    API = Int(0, help="Internal interface version for this operator")
+    det_data = Unicode(defaults.det_data, help="Observation detdata key for the timestream data")
+    convergence = Float(1.0e-12, help="Relative convergence limit")
+    iter_min = Int(3, help="Minimum number of iterations")
+    iter_max = Int(100, help="Maximum number of iterations")
+    solve_rcond_threshold = Float(1.0e-8, help="When solving, minimum value for inverse pixel condition number cut.")
+    map_rcond_threshold = Float(1.0e-8, help="For final map, minimum value for inverse pixel condition number cut.")
+    binning = Instance(klass=Operator, help="Binning operator used for solving template amplitudes")
+    template_matrix = Instance(klass=Operator, help="This must be an instance of a template matrix operator")
+    map_binning = Instance(klass=Operator, help="Binning operator for final map making (default: solver binning)")
+    keep_solver_products = Bool(False, help="If True, keep the map domain solver products in data")
+    keep_final_products = Bool(True, help="If True, keep the map domain products in data after write")
+    save_cleaned = Bool(False, help="If True, save the template-subtracted detector timestreams")
+    overwrite_cleaned = Bool(False, help="If True and save_cleaned is True, overwrite the input data")
+    reset_pix_dist = Bool(False, help="Clear any existing pixel distribution.")
+
+    def _exec(self, data, detectors=None, **kwargs):
+        for trait in ("binning",):
+            if getattr(self, trait) is None:
+                raise RuntimeError(f"You must set the '{trait}' trait before calling exec()")
+        binning = self.binning
+        map_binning = self.map_binning if self.map_binning is not None else binning
+        self.history = []
+        if self.reset_pix_dist and binning.pixel_dist in data:
+            del data[binning.pixel_dist]
+        hits_name, cov_name, rcond_name = f"{self.name}_hits", f"{self.name}_cov", f"{self.name}_rcond"
+        map_name, amp_name = f"{self.name}_map", f"{self.name}_amplitudes"
+        # covariance + hits with the solver flags
+        cov_op = CovarianceAndHits(
+            pixel_dist=binning.pixel_dist, covariance=cov_name, hits=hits_name, rcond=rcond_name,
+            det_mask=binning.det_mask, det_flags=binning.det_flags, det_flag_mask=binning.det_flag_mask,
+            shared_flags=binning.shared_flags, shared_flag_mask=binning.shared_flag_mask,
+            pixel_pointing=binning.pixel_pointing, stokes_weights=binning.stokes_weights,
+            noise_model=binning.noise_model, rcond_threshold=self.solve_rcond_threshold,
+            sync_type=binning.sync_type, save_pointing=binning.full_pointing)
+        cov_op.apply(data, detectors=detectors)
+        binning.covariance = cov_name
+        map_binning.covariance = cov_name
+        cleaned = self.det_data
+        tm = self.template_matrix
+        if tm is not None and len(tm.templates) > 0:
+            tm.reset()
+            tm.amplitudes = f"{self.name}_rhs"
+            solver_bin = f"{self.name}_solve_bin"
+            binning.binned = solver_bin
+            rhs = SolverRHS(name=f"{self.name}_rhs", det_data=self.det_data, binning=binning, template_matrix=tm)
+            if f"{self.name}_rhs" in data:
+                del data[f"{self.name}_rhs"]
+            rhs.apply(data, detectors=detectors)
+            lhs = SolverLHS(name=f"{self.name}_lhs", binning=binning, template_matrix=tm)
+            if amp_name in data:
+                del data[amp_name]
+            self.history = solve(data, detectors, lhs, f"{self.name}_rhs", amp_name, convergence=self.convergence,
+                                 n_iter_min=self.iter_min, n_iter_max=self.iter_max)
+            for ob in data.obs:
+                if lhs.det_temp in ob.detdata:
+                    del ob.detdata[lhs.det_temp]
+            if not self.keep_solver_products:
+                for key in (solver_bin, f"{self.name}_rhs"):
+                    if key in data:
+                        if hasattr(data[key], "clear"):
+                            data[key].clear()
+                        del data[key]
+            # cleaned timestreams = d - M a
+            if self.save_cleaned and not self.overwrite_cleaned:
+                cleaned = f"{self.name}_cleaned"
+            elif not self.overwrite_cleaned:
+                cleaned = f"{self.name}_temp_cleaned"
+            ApplyAmplitudes(op="subtract", amplitudes=amp_name, template_matrix=tm, det_data=self.det_data,
+                            output=None if cleaned == self.det_data else cleaned).apply(data, detectors=detectors)
+        map_binning.binned = map_name
+        map_binning.det_data = cleaned
+        map_binning.apply(data, detectors=detectors)
+        if cleaned.endswith("_temp_cleaned"):
+            Delete(detdata=[cleaned]).apply(data)
+
+    def _finalize(self, data, **kwargs):
+        return
+
+    def _requires(self):
+        req = self.binning.requires()
+        req["detdata"].append(self.det_data)
+        return req
+
+    def _provides(self):
+        return {"global": [f"{self.name}_map", f"{self.name}_hits", f"{self.name}_cov", f"{self.name}_rcond"]}

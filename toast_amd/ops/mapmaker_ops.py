@@ -1,0 +1,599 @@
+"""Map-domain operators of the hot path: ScanMap, NoiseWeight, BuildNoiseWeighted,
+BuildHitMap, BuildInverseCovariance, CovarianceAndHits, BinMap (+ Copy / Delete / Reset helpers).
+
+Reference: src/toast/ops/scan_map/scan_map.py:22-215, src/toast/ops/noise_weight/noise_weight.py:20-160,
+src/toast/ops/mapmaker_utils/mapmaker_utils.py:34-1271, src/toast/ops/mapmaker_binning.py:27-317,
+src/toast/ops/copy.py, delete.py, reset.py.
+"""
+
+import numpy as np
+
+from ..accel import native
+from ..data import defaults
+from ..pixels import PixelData, covariance_apply, covariance_invert
+from ..traits import Bool, Float, ImplementationType, Instance, Int, List, Unicode
+from .operator import Operator
+from .pipeline import Pipeline
+
+_IMPLS = [ImplementationType.DEFAULT, ImplementationType.COMPILED]
+
+
+def _global_to(obj, name, use_accel, zero_new=False):
+    """Move a global PixelData where the kernel will look for it (mapmaker_utils.py:745-773)."""
+    if use_accel:
+        if not obj.accel_exists():
+            obj.accel_create(name, zero_out=zero_new)
+            if zero_new:
+                obj.accel_used(True)
+            else:
+                obj.accel_update_device()
+        elif not obj.accel_in_use():
+            obj.accel_update_device()
+    elif obj.accel_in_use():
+        obj.accel_update_host()
+
+
+class ScanMap(Operator):
+    """Scan a map into detector timestreams: ``tod (+|-)= sum_k w_k map[pix, k]``."""
+
+    API = Int(0, help="Internal interface version for this operator")
+    det_data = Unicode(defaults.det_data, help="Observation detdata key for accumulating output")
+    det_data_units = Unicode(defaults.det_data_units, allow_none=True, help="Output units if creating detector data")
+    det_mask = Int(defaults.det_mask_invalid, help="Bit mask value for per-detector flagging")
+    det_flag_mask = Int(defaults.det_mask_invalid, help="Bit mask value for detector sample flagging")
+    view = Unicode(None, allow_none=True, help="Use this view of the data in all observations")
+    pixels = Unicode(defaults.pixels, help="Observation detdata key for pixel indices")
+    weights = Unicode(defaults.weights, allow_none=True, help="Observation detdata key for Stokes weights")
+    map_key = Unicode(None, allow_none=True, help="The Data key where the map is located")
+    subtract = Bool(False, help="If True, subtract the map timestream instead of accumulating")
+    zero = Bool(False, help="If True, zero the data before accumulating / subtracting")
+
+    def _exec(self, data, detectors=None, use_accel=None, **kwargs):
+        implementation, use_accel = self.select_kernels(use_accel=use_accel)
+        if self.det_data is None:
+            raise RuntimeError("You must set the det_data trait before calling exec()")
+        if self.map_key is None:
+            raise RuntimeError("You must set the map_key trait before calling exec()")
+        if self.map_key not in data:
+            raise RuntimeError("The map_key '{}' does not exist in the data".format(self.map_key))
+        map_data = data[self.map_key]
+        if not isinstance(map_data, PixelData):
+            raise RuntimeError("The map to scan must be a PixelData instance")
+        if self.weights is None:
+            raise NotImplementedError("ScanMap without Stokes weights is not on the compiled path")
+        map_dist = map_data.distribution
+        _global_to(map_data, self.map_key, use_accel)
+        name = {np.dtype(np.float64): "ops_scan_map_float64", np.dtype(np.float32): "ops_scan_map_float32",
+                np.dtype(np.int64): "ops_scan_map_int64", np.dtype(np.int32): "ops_scan_map_int32"}[map_data.dtype]
+        kernel = getattr(native(), name)
+        for ob in data.obs:
+            dets = ob.select_local_detectors(detectors, flagmask=self.det_mask)
+            check_nnz = 1
+            if len(ob.detdata[self.weights].detector_shape) > 1:
+                check_nnz = ob.detdata[self.weights].detector_shape[-1]
+            if map_data.n_value != check_nnz:
+                raise RuntimeError(f"Detector data '{self.weights}' in observation '{ob.name}' has {check_nnz} nnz "
+                                   f"instead of {map_data.n_value} in the map")
+            ob.detdata.ensure(self.det_data, detectors=dets, create_units=self.det_data_units, accel=use_accel)
+            if len(dets) == 0:
+                continue
+            kernel(map_dist.global_submap_to_local, map_dist.n_pix_submap, map_data.data,
+                   ob.detdata[self.det_data].data, ob.detdata[self.det_data].indices(dets),
+                   ob.detdata[self.pixels].data, ob.detdata[self.pixels].indices(dets),
+                   ob.detdata[self.weights].data, ob.detdata[self.weights].indices(dets),
+                   ob.intervals[self.view].data, 1.0, bool(self.zero), bool(self.subtract), False, use_accel)
+
+    def _finalize(self, data, **kwargs):
+        return
+
+    def _requires(self):
+        req = {"global": [self.map_key], "meta": [], "shared": [], "detdata": [self.pixels, self.det_data],
+               "intervals": []}
+        if self.weights is not None:
+            req["detdata"].append(self.weights)
+        if self.view is not None:
+            req["intervals"].append(self.view)
+        return req
+
+    def _provides(self):
+        return {"detdata": [self.det_data]}
+
+    def _implementations(self):
+        return _IMPLS
+
+    def _supports_accel(self):
+        return True
+
+
+class NoiseWeight(Operator):
+    """Apply diagonal noise weighting ``tod *= detector_weight`` (N^-1 of the PCG)."""
+
+    API = Int(0, help="Internal interface version for this operator")
+    noise_model = Unicode(defaults.noise_model, help="The observation key containing the noise model")
+    view = Unicode(None, allow_none=True, help="Use this view of the data in all observations")
+    det_data = Unicode(defaults.det_data, help="Observation detdata key for the timestream data")
+    det_mask = Int(defaults.det_mask_invalid, help="Bit mask value for per-detector flagging")
+    det_flag_mask = Int(defaults.det_mask_invalid, help="Bit mask value for detector sample flagging")
+    det_data_units = Unicode(defaults.det_data_units, allow_none=True, help="Desired timestream units")
+
+    def _exec(self, data, detectors=None, use_accel=None, **kwargs):
+        implementation, use_accel = self.select_kernels(use_accel=use_accel)
+        for ob in data.obs:
+            if self.det_data not in ob.detdata:
+                continue
+            dets = ob.select_local_detectors(detectors, flagmask=self.det_mask)
+            if len(dets) == 0:
+                continue
+            if self.noise_model not in ob:
+                raise RuntimeError("Noise model {} does not exist in observation {}".format(self.noise_model, ob.name))
+            noise = ob[self.noise_model]
+            detector_weights = np.array([noise.detector_weight(d) for d in dets], dtype=np.float64)
+            dd = ob.detdata[self.det_data]
+            if use_accel and not dd.accel_in_use():
+                if not dd.accel_exists():
+                    dd.accel_create(self.det_data)
+                dd.accel_update_device()
+            native().noise_weight(dd.data, dd.indices(dets), ob.intervals[self.view].data, detector_weights,
+                                  use_accel)
+
+    def _finalize(self, data, **kwargs):
+        return
+
+    def _requires(self):
+        req = {"meta": [self.noise_model], "detdata": [self.det_data], "intervals": []}
+        if self.view is not None:
+            req["intervals"].append(self.view)
+        return req
+
+    def _provides(self):
+        return {"detdata": [self.det_data]}
+
+    def _implementations(self):
+        return _IMPLS
+
+    def _supports_accel(self):
+        return True
+
+
+class _MapBuilder(Operator):
+    """Shared traits / flag plumbing of the accumulate operators."""
+
+    API = Int(0, help="Internal interface version for this operator")
+    pixel_dist = Unicode(None, allow_none=True, help="The Data key containing the submap distribution")
+    view = Unicode(None, allow_none=True, help="Use this view of the data in all observations")
+    pixels = Unicode(defaults.pixels, help="Observation detdata key for pixel indices")
+    det_mask = Int(defaults.det_mask_nonscience, help="Bit mask value for per-detector flagging")
+    det_flags = Unicode(defaults.det_flags, allow_none=True, help="Observation detdata key for flags to use")
+    det_flag_mask = Int(defaults.det_mask_nonscience, help="Bit mask value for detector sample flagging")
+    shared_flags = Unicode(defaults.shared_flags, allow_none=True, help="Observation shared key for telescope flags")
+    shared_flag_mask = Int(defaults.shared_mask_nonscience, help="Bit mask value for optional telescope flagging")
+    sync_type = Unicode("allreduce", help="Communication algorithm: 'allreduce' or 'alltoallv'")
+
+    def _validate_sync_type(self, check):
+        if check not in ("allreduce", "alltoallv"):
+            raise RuntimeError("Invalid communication algorithm")
+        return check
+
+    def _dist(self, data):
+        if self.pixel_dist is None:
+            raise RuntimeError("You must set the 'pixel_dist' trait before calling exec()")
+        if self.pixel_dist not in data:
+            raise RuntimeError("Data does not contain submap distribution '{}'".format(self.pixel_dist))
+        return data[self.pixel_dist]
+
+    def _flag_args(self, ob, dets, use_accel):
+        if self.det_flags is not None:
+            fd = ob.detdata[self.det_flags]
+            if use_accel and not fd.accel_in_use():
+                if not fd.accel_exists():
+                    fd.accel_create(self.det_flags)
+                fd.accel_update_device()
+            flag_indx, flag_data = fd.indices(dets), fd.data
+        else:
+            # reference quirk (mapmaker_utils.py:836-838): [-1]; our binding wants n_det entries
+            flag_indx, flag_data = np.zeros(len(dets), dtype=np.int32), np.zeros((1, 1), dtype=np.uint8)
+        if self.shared_flags is not None:
+            sf = ob.shared[self.shared_flags]
+            if use_accel and not sf.accel_in_use():
+                if not sf.accel_exists():
+                    sf.accel_create(self.shared_flags)
+                sf.accel_update_device()
+            shared = sf.data
+        else:
+            shared = np.zeros(1, dtype=np.uint8)
+        return flag_indx, flag_data, shared
+
+    def _weight_nnz(self, data, detectors):
+        nnz = 0
+        for ob in data.obs:
+            if self.weights not in ob.detdata:
+                raise RuntimeError(f"Stokes weights '{self.weights}' not in obs {ob.name}")
+            shp = ob.detdata[self.weights].detector_shape
+            nnz = 1 if len(shp) == 1 else shp[1]
+        if data.comm.comm_world is not None:
+            nnz = int(data.comm.allreduce_scalar(nnz, op="max"))
+        return nnz
+
+    def _sync(self, pd):
+        # sync_alltoallv and sync_allreduce give identical results (reference test
+        # src/toast/tests/ops_mapmaker_utils.py:211-397); on xGMI one in-place RCCL all-reduce of
+        # the device buffer serves both.
+        pd.sync_allreduce()
+
+    def _implementations(self):
+        return _IMPLS
+
+    def _supports_accel(self):
+        return True
+
+
+class BuildNoiseWeighted(_MapBuilder):
+    """Accumulate the noise weighted map ``zmap += A^T N^-1 d``; finalize sums over processes."""
+
+    zmap = Unicode("zmap", help="The Data key for the output noise weighted map")
+    weights = Unicode(defaults.weights, help="Observation detdata key for Stokes weights")
+    noise_model = Unicode(defaults.noise_model, help="Observation key containing the noise model")
+    det_data = Unicode(defaults.det_data, help="Observation detdata key for the timestream data")
+    det_data_units = Unicode(defaults.det_data_units, allow_none=True, help="Desired timestream units")
+
+    def _exec(self, data, detectors=None, use_accel=None, **kwargs):
+        implementation, use_accel = self.select_kernels(use_accel=use_accel)
+        dist = self._dist(data)
+        if self.det_data is None:
+            raise RuntimeError("You must set the det_data trait before calling exec()")
+        if self.zmap in data:
+            if data[self.zmap].distribution != dist:
+                raise RuntimeError("Existing zmap '{}' has different data distribution".format(self.zmap))
+            zmap = data[self.zmap]
+        else:
+            data[self.zmap] = PixelData(dist, np.float64, n_value=self._weight_nnz(data, detectors))
+            zmap = data[self.zmap]
+        _global_to(zmap, self.zmap, use_accel, zero_new=not zmap.accel_exists() and not np.any(zmap.raw))
+        for ob in data.obs:
+            dets = ob.select_local_detectors(selection=detectors, flagmask=self.det_mask)
+            if self.noise_model not in ob:
+                raise RuntimeError("Noise model {} does not exist in observation {}".format(self.noise_model, ob.name))
+            if len(dets) == 0:
+                continue
+            noise = ob[self.noise_model]
+            detweights = np.array([noise.detector_weight(x) for x in dets], dtype=np.float64)
+            flag_indx, flag_data, shared = self._flag_args(ob, dets, use_accel)
+            native().build_noise_weighted(
+                dist.global_submap_to_local, zmap.data, ob.detdata[self.pixels].indices(dets),
+                ob.detdata[self.pixels].data, ob.detdata[self.weights].indices(dets), ob.detdata[self.weights].data,
+                ob.detdata[self.det_data].indices(dets), ob.detdata[self.det_data].data, flag_indx, flag_data,
+                detweights, self.det_flag_mask, ob.intervals[self.view].data, shared, self.shared_flag_mask,
+                use_accel)
+
+    def _finalize(self, data, use_accel=None, **kwargs):
+        if self.zmap in data:
+            self._sync(data[self.zmap])
+
+    def _requires(self):
+        req = {"global": [self.pixel_dist], "meta": [self.noise_model], "shared": [],
+               "detdata": [self.pixels, self.weights, self.det_data], "intervals": []}
+        if self.shared_flags is not None:
+            req["shared"].append(self.shared_flags)
+        if self.det_flags is not None:
+            req["detdata"].append(self.det_flags)
+        if self.view is not None:
+            req["intervals"].append(self.view)
+        return req
+
+    def _provides(self):
+        return {"global": [self.zmap]}
+
+
+class BuildHitMap(_MapBuilder):
+    """``hits[pix] += 1`` for every unflagged sample (mapmaker_utils.py:34-260)."""
+
+    hits = Unicode("hits", help="The Data key for the output hit map")
+
+    def _exec(self, data, detectors=None, use_accel=None, **kwargs):
+        implementation, use_accel = self.select_kernels(use_accel=use_accel)
+        dist = self._dist(data)
+        if self.hits in data:
+            if data[self.hits].distribution != dist:
+                raise RuntimeError("Existing hits '{}' has different data distribution".format(self.hits))
+            hits = data[self.hits]
+        else:
+            data[self.hits] = PixelData(dist, np.int64, n_value=1)
+            hits = data[self.hits]
+        _global_to(hits, self.hits, use_accel, zero_new=not hits.accel_exists() and not np.any(hits.raw))
+        for ob in data.obs:
+            dets = ob.select_local_detectors(selection=detectors, flagmask=self.det_mask)
+            if len(dets) == 0:
+                continue
+            flag_indx, flag_data, shared = self._flag_args(ob, dets, use_accel)
+            native().build_hit_map(dist.global_submap_to_local, hits.data, ob.detdata[self.pixels].indices(dets),
+                                   ob.detdata[self.pixels].data, flag_indx, flag_data, self.det_flag_mask,
+                                   ob.intervals[self.view].data, shared, self.shared_flag_mask, use_accel)
+
+    def _finalize(self, data, use_accel=None, **kwargs):
+        if self.hits in data:
+            self._sync(data[self.hits])
+
+    def _requires(self):
+        req = {"global": [self.pixel_dist], "meta": [], "shared": [], "detdata": [self.pixels], "intervals": []}
+        if self.shared_flags is not None:
+            req["shared"].append(self.shared_flags)
+        if self.det_flags is not None:
+            req["detdata"].append(self.det_flags)
+        if self.view is not None:
+            req["intervals"].append(self.view)
+        return req
+
+    def _provides(self):
+        return {"global": [self.hits]}
+
+
+class BuildInverseCovariance(_MapBuilder):
+    """``invcov[pix, (j,k>=j)] += w_j w_k detector_weight`` (mapmaker_utils.py:262-560)."""
+
+    inverse_covariance = Unicode("inv_covariance", help="The Data key for the output inverse covariance")
+    weights = Unicode(defaults.weights, help="Observation detdata key for Stokes weights")
+    noise_model = Unicode(defaults.noise_model, help="Observation key containing the noise model")
+    det_data_units = Unicode(defaults.det_data_units, allow_none=True, help="Desired timestream units")
+
+    def _exec(self, data, detectors=None, use_accel=None, **kwargs):
+        implementation, use_accel = self.select_kernels(use_accel=use_accel)
+        dist = self._dist(data)
+        if self.inverse_covariance in data:
+            if data[self.inverse_covariance].distribution != dist:
+                raise RuntimeError("Existing inv cov '{}' has different data distribution".format(
+                    self.inverse_covariance))
+            invcov = data[self.inverse_covariance]
+        else:
+            nnz = self._weight_nnz(data, detectors)
+            data[self.inverse_covariance] = PixelData(dist, np.float64, n_value=nnz * (nnz + 1) // 2)
+            invcov = data[self.inverse_covariance]
+        _global_to(invcov, self.inverse_covariance, use_accel,
+                   zero_new=not invcov.accel_exists() and not np.any(invcov.raw))
+        for ob in data.obs:
+            dets = ob.select_local_detectors(selection=detectors, flagmask=self.det_mask)
+            if self.noise_model not in ob:
+                raise RuntimeError("Noise model {} does not exist in observation {}".format(self.noise_model, ob.name))
+            if len(dets) == 0:
+                continue
+            noise = ob[self.noise_model]
+            detweights = np.array([noise.detector_weight(x) for x in dets], dtype=np.float64)
+            flag_indx, flag_data, shared = self._flag_args(ob, dets, use_accel)
+            native().build_inverse_covariance(
+                dist.global_submap_to_local, invcov.data, ob.detdata[self.pixels].indices(dets),
+                ob.detdata[self.pixels].data, ob.detdata[self.weights].indices(dets), ob.detdata[self.weights].data,
+                flag_indx, flag_data, detweights, self.det_flag_mask, ob.intervals[self.view].data, shared,
+                self.shared_flag_mask, use_accel)
+
+    def _finalize(self, data, use_accel=None, **kwargs):
+        if self.inverse_covariance in data:
+            self._sync(data[self.inverse_covariance])
+
+    def _requires(self):
+        req = {"global": [self.pixel_dist], "meta": [self.noise_model], "shared": [],
+               "detdata": [self.pixels, self.weights], "intervals": []}
+        if self.shared_flags is not None:
+            req["shared"].append(self.shared_flags)
+        if self.det_flags is not None:
+            req["detdata"].append(self.det_flags)
+        if self.view is not None:
+            req["intervals"].append(self.view)
+        return req
+
+    def _provides(self):
+        return {"global": [self.inverse_covariance]}
+
+
+class CovarianceAndHits(Operator):
+    """Hit map + inverse covariance + (inverted) covariance and its rcond in one pass over the
+    pointing (reference: mapmaker_utils.py:927-1271)."""
+
+    API = Int(0, help="Internal interface version for this operator")
+    pixel_dist = Unicode("pixel_dist", help="The Data key where the PixelDistribution object is located")
+    covariance = Unicode("covariance", help="The Data key where the covariance should be stored")
+    inverse_covariance = Unicode(None, allow_none=True, help="The Data key where the inverse covariance is stored")
+    hits = Unicode("hits", help="The Data key where the hits should be stored")
+    rcond = Unicode("rcond", help="The Data key where the inverse condition number should be stored")
+    det_mask = Int(defaults.det_mask_nonscience, help="Bit mask value for per-detector flagging")
+    det_flags = Unicode(defaults.det_flags, allow_none=True, help="Observation detdata key for flags to use")
+    det_flag_mask = Int(defaults.det_mask_nonscience, help="Bit mask value for detector sample flagging")
+    shared_flags = Unicode(defaults.shared_flags, allow_none=True, help="Observation shared key for telescope flags")
+    shared_flag_mask = Int(defaults.shared_mask_nonscience, help="Bit mask value for optional telescope flagging")
+    pixel_pointing = Instance(klass=Operator, help="The pixel pointing operator")
+    stokes_weights = Instance(klass=Operator, help="The Stokes weights operator")
+    noise_model = Unicode(defaults.noise_model, help="Observation key containing the noise model")
+    rcond_threshold = Float(1.0e-8, help="Minimum value for inverse condition number cut.")
+    sync_type = Unicode("allreduce", help="Communication algorithm: 'allreduce' or 'alltoallv'")
+    save_pointing = Bool(False, help="If True, do not clear detector pointing matrices")
+    det_data_units = Unicode(defaults.det_data_units, allow_none=True, help="Desired timestream units")
+
+    def _exec(self, data, detectors=None, **kwargs):
+        for trait in ("pixel_pointing", "stokes_weights"):
+            if getattr(self, trait) is None:
+                raise RuntimeError(f"You must set the '{trait}' trait before calling exec()")
+        for key in (self.hits, self.covariance, self.rcond):
+            if key in data:
+                del data[key]
+        inv_key = self.inverse_covariance if self.inverse_covariance is not None else f"{self.name}_inv_covariance"
+        if inv_key in data:
+            del data[inv_key]
+        if self.pixel_dist not in data:
+            self.pixel_pointing.create_dist = self.pixel_dist
+            pix_dist = Pipeline(detector_sets=["ALL"] if self.save_pointing else ["SINGLE"],
+                                operators=[self.pixel_pointing])
+            pix_dist.apply(data, detectors=detectors)
+            self.pixel_pointing.create_dist = None
+        common = dict(pixel_dist=self.pixel_dist, view=self.pixel_pointing.view, pixels=self.pixel_pointing.pixels,
+                      det_mask=self.det_mask, det_flags=self.det_flags, det_flag_mask=self.det_flag_mask,
+                      shared_flags=self.shared_flags, shared_flag_mask=self.shared_flag_mask,
+                      sync_type=self.sync_type)
+        build_hits = BuildHitMap(hits=self.hits, **common)
+        build_invcov = BuildInverseCovariance(inverse_covariance=inv_key, weights=self.stokes_weights.weights,
+                                              noise_model=self.noise_model, det_data_units=self.det_data_units,
+                                              **common)
+        accum = Pipeline(detector_sets=["ALL"] if self.save_pointing else ["SINGLE"],
+                         operators=[self.pixel_pointing, self.stokes_weights, build_hits, build_invcov])
+        accum.apply(data, detectors=detectors)
+        cov = data[inv_key].duplicate()
+        data[self.covariance] = cov
+        data[self.rcond] = PixelData(data[self.pixel_dist], np.float64, n_value=1)
+        covariance_invert(cov, self.rcond_threshold, rcond=data[self.rcond])
+        if self.inverse_covariance is None:
+            del data[inv_key]
+
+    def _finalize(self, data, **kwargs):
+        return
+
+    def _requires(self):
+        req = self.pixel_pointing.requires()
+        for k, v in self.stokes_weights.requires().items():
+            req.setdefault(k, []).extend(v)
+        req["meta"].append(self.noise_model)
+        return req
+
+    def _provides(self):
+        prov = {"global": [self.pixel_dist, self.hits, self.covariance, self.rcond]}
+        if self.inverse_covariance is not None:
+            prov["global"].append(self.inverse_covariance)
+        return prov
+
+
+class BinMap(Operator):
+    """Binned map ``C A^T N^-1 d``: Pipeline[pre_process, pixel_pointing, stokes_weights,
+    BuildNoiseWeighted] followed by ``covariance_apply`` (mapmaker_binning.py:27-317)."""
+
+    API = Int(0, help="Internal interface version for this operator")
+    pixel_dist = Unicode("pixel_dist", help="The Data key where the PixelDistribution object is located")
+    covariance = Unicode("covariance", help="The Data key containing the noise covariance PixelData instance")
+    binned = Unicode("binned", help="The Data key where the binned map should be stored")
+    noiseweighted = Unicode(None, allow_none=True, help="The Data key where the noiseweighted map should be stored")
+    det_data = Unicode(defaults.det_data, help="Observation detdata key for the timestream data")
+    det_data_units = Unicode(defaults.det_data_units, allow_none=True, help="Desired timestream units")
+    det_mask = Int(defaults.det_mask_nonscience, help="Bit mask value for per-detector flagging")
+    det_flags = Unicode(defaults.det_flags, allow_none=True, help="Observation detdata key for flags to use")
+    det_flag_mask = Int(defaults.det_mask_nonscience, help="Bit mask value for detector sample flagging")
+    shared_flags = Unicode(defaults.shared_flags, allow_none=True, help="Observation shared key for telescope flags")
+    shared_flag_mask = Int(defaults.shared_mask_nonscience, help="Bit mask value for optional telescope flagging")
+    pixel_pointing = Instance(klass=Operator, help="The pixel pointing operator")
+    stokes_weights = Instance(klass=Operator, help="The Stokes weights operator")
+    pre_process = Instance(klass=Operator, help="Optional extra operator to run prior to binning")
+    noise_model = Unicode(defaults.noise_model, help="Observation key containing the noise model")
+    sync_type = Unicode("allreduce", help="Communication algorithm: 'allreduce' or 'alltoallv'")
+    full_pointing = Bool(False, help="If True, expand pointing for all detectors and save")
+
+    def _validate_sync_type(self, check):
+        if check not in ("allreduce", "alltoallv"):
+            raise RuntimeError("Invalid communication algorithm")
+        return check
+
+    def _exec(self, data, detectors=None, use_accel=None, **kwargs):
+        for trait in ("pixel_pointing", "stokes_weights", "det_data"):
+            if getattr(self, trait) is None:
+                raise RuntimeError(f"You must set the '{trait}' trait before calling exec()")
+        if self.covariance not in data:
+            raise RuntimeError(f"Data does not contain noise covariance '{self.covariance}'")
+        cov = data[self.covariance]
+        if self.pixel_dist not in data or cov.distribution != data[self.pixel_dist]:
+            raise RuntimeError(f"Pixel distribution '{self.pixel_dist}' does not match the one used by covariance "
+                               f"'{self.covariance}'")
+        self.pixel_pointing.create_dist = None
+        if self.binned in data:
+            if data[self.binned].distribution != data[self.pixel_dist]:
+                raise RuntimeError(f"Pixel distribution '{self.pixel_dist}' does not match existing binned map "
+                                   f"'{self.binned}'")
+            data[self.binned].reset()
+        self.pixel_pointing.detector_pointing.det_mask = self.det_mask
+        self.pixel_pointing.detector_pointing.det_flag_mask = self.det_flag_mask
+        if self.stokes_weights.has_trait("detector_pointing"):
+            self.stokes_weights.detector_pointing.det_mask = self.det_mask
+            self.stokes_weights.detector_pointing.det_flag_mask = self.det_flag_mask
+        build_zmap = BuildNoiseWeighted(
+            pixel_dist=self.pixel_dist, zmap=self.binned, view=self.pixel_pointing.view,
+            pixels=self.pixel_pointing.pixels, weights=self.stokes_weights.weights, noise_model=self.noise_model,
+            det_data=self.det_data, det_data_units=self.det_data_units, det_mask=self.det_mask,
+            det_flags=self.det_flags, det_flag_mask=self.det_flag_mask, shared_flags=self.shared_flags,
+            shared_flag_mask=self.shared_flag_mask, sync_type=self.sync_type)
+        accum_ops = []
+        if self.pre_process is not None:
+            accum_ops.append(self.pre_process)
+        accum = Pipeline(detector_sets=["ALL"] if self.full_pointing else ["SINGLE"])
+        accum_ops.extend([self.pixel_pointing, self.stokes_weights, build_zmap])
+        accum.operators = accum_ops
+        accum.apply(data, detectors=detectors, use_accel=use_accel)
+        if self.noiseweighted is not None:
+            data[self.noiseweighted] = data[self.binned].duplicate()
+        covariance_apply(cov, data[self.binned], use_alltoallv=(self.sync_type == "alltoallv"))
+
+    def _finalize(self, data, **kwargs):
+        return
+
+    def _requires(self):
+        req = self.pixel_pointing.requires()
+        for k, v in self.stokes_weights.requires().items():
+            req.setdefault(k, []).extend(v)
+        req["global"].extend([self.pixel_dist, self.covariance])
+        req["meta"].append(self.noise_model)
+        req["detdata"].append(self.det_data)
+        if self.shared_flags is not None:
+            req["shared"].append(self.shared_flags)
+        if self.det_flags is not None:
+            req["detdata"].append(self.det_flags)
+        return req
+
+    def _provides(self):
+        return {"global": [self.binned]}
+
+
+class Copy(Operator):
+    """Copy detdata objects ``[(src, dst), ...]`` (reference: src/toast/ops/copy.py)."""
+
+    API = Int(0, help="Internal interface version for this operator")
+    detdata = List([], help="List of tuples of Observation detdata keys to copy")
+
+    def _exec(self, data, detectors=None, use_accel=None, **kwargs):
+        for ob in data.obs:
+            for src, dst in self.detdata:
+                s = ob.detdata[src]
+                if s.accel_in_use():
+                    s.accel_update_host()
+                dets = ob.select_local_detectors(detectors)
+                ob.detdata.ensure(dst, sample_shape=s.detector_shape[1:], dtype=s.dtype, detectors=s.detectors)
+                d = ob.detdata[dst]
+                if d.accel_in_use():
+                    d.accel_update_host()
+                for det in dets:
+                    d[det] = s[det]
+
+    def _finalize(self, data, **kwargs):
+        return
+
+    def _requires(self):
+        return {"detdata": [x[0] for x in self.detdata]}
+
+    def _provides(self):
+        return {"detdata": [x[1] for x in self.detdata]}
+
+
+class Delete(Operator):
+    """Delete detdata / global objects (reference: src/toast/ops/delete.py)."""
+
+    API = Int(0, help="Internal interface version for this operator")
+    detdata = List([], help="List of Observation detdata keys to delete")
+    meta = List([], help="List of Data keys to delete")
+
+    def _exec(self, data, detectors=None, **kwargs):
+        for ob in data.obs:
+            for key in self.detdata:
+                if key in ob.detdata:
+                    del ob.detdata[key]
+        for key in self.meta:
+            if key in data:
+                del data[key]
+
+    def _finalize(self, data, **kwargs):
+        return
+
+    def _requires(self):
+        return {"detdata": list(self.detdata), "global": list(self.meta)}
+
+    def _provides(self):
+        return {}

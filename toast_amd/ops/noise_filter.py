@@ -1,0 +1,137 @@
+"""NoiseFilter: convolve each detector timestream with N_tt'^-1 = NET^2 / PSD(f) using the
+rocFFT pipeline (reference: src/toast/ops/noise_filter.py:20-205 -> toast.fft.convolve)."""
+
+import numpy as np
+
+from .. import fft as hipfft
+from ..data import defaults
+from ..traits import Float, Int, Unicode
+from .operator import Operator
+
+
+def estimate_net(freqs, data):
+    """White-noise level from the high-frequency end of a PSD.  The reference fits a parabola
+    (or line) to the last 20 % of the spectrum with scipy curve_fit and evaluates it at the
+    last frequency (src/toast/ops/noise_model.py:108-170); here the same constrained
+    least-squares fit is done in closed form with numpy.polyfit."""
+    n_psd = len(data)
+    offset = int(0.8 * n_psd)
+    deg = 2
+    if n_psd - offset < 10:
+        deg = 1
+        if n_psd < 10:
+            offset = 0
+    x = np.asarray(freqs[offset:], dtype=np.float64)
+    y = np.asarray(data[offset:], dtype=np.float64)
+    if x.size < deg + 1:
+        return float(np.sqrt(np.mean(y)))
+    coef = np.polyfit(x - x[-1], y, deg)
+    val = float(np.polyval(coef, 0.0))
+    if val <= 0:
+        val = float(np.mean(y))
+    return float(np.sqrt(val))
+
+
+class NoiseFilter(Operator):
+    """Apply the inverse noise covariance to the signal in the Fourier domain."""
+
+    API = Int(0, help="Internal interface version for this operator")
+    det_data = Unicode(defaults.det_data, help="Observation detdata key for the timestream data")
+    det_mask = Int(defaults.det_mask_invalid, help="Bit mask value for per-detector flagging")
+    det_flags = Unicode(None, allow_none=True, help="Observation detdata key for flags to use")
+    det_flag_mask = Int(defaults.det_mask_invalid, help="Bit mask value for detector sample flagging")
+    shared_flags = Unicode(None, allow_none=True, help="Observation shared key for telescope flags to use")
+    shared_flag_mask = Int(defaults.shared_mask_invalid, help="Bit mask value for optional shared flagging")
+    noise_model = Unicode("noise_model", help="Observation key containing the noise model")
+    white_noise_min = Float(None, allow_none=True, help="Minimum frequency of the white noise plateau [Hz]")
+    white_noise_max = Float(None, allow_none=True, help="Maximum frequency of the white noise plateau [Hz]")
+
+    def _exec(self, data, detectors=None, use_accel=None, **kwargs):
+        if self.white_noise_max is not None and self.white_noise_min is None:
+            raise RuntimeError("You must set both of the min / max values or neither of them")
+        for obs in data.obs:
+            dets = obs.select_local_detectors(detectors, flagmask=self.det_mask)
+            if len(dets) == 0:
+                continue
+            rate = obs.telescope.focalplane.sample_rate
+            dd = obs.detdata[self.det_data]
+            on_dev = dd.accel_in_use()
+            flags = None
+            flag_mask = None
+            if self.det_flags is not None:
+                fdata = obs.detdata[self.det_flags]
+                if fdata.accel_in_use():
+                    fdata.accel_update_host()
+                flags = [fdata[d] for d in dets]
+                if self.shared_flags is not None:
+                    shflg = self.det_flag_mask * np.array(
+                        obs.shared[self.shared_flags].data & self.shared_flag_mask != 0, dtype=np.uint8)
+                    for detflag in flags:
+                        detflag |= shflg
+                flag_mask = self.det_flag_mask
+            # N_tt'^-1 kernels (noise_filter.py:130-171)
+            nse = obs[self.noise_model]
+            kernels = []
+            kern_freq = None
+            for d in dets:
+                freq = np.asarray(nse.freq(d), dtype=np.float64)
+                if kern_freq is None:
+                    kern_freq = freq
+                elif not np.allclose(kern_freq, freq):
+                    raise RuntimeError("All detectors in the noise model must have the same frequency binning")
+                psd = np.array(nse.psd(d), dtype=np.float64)
+                if self.white_noise_max is None:
+                    net = estimate_net(freq, psd)
+                else:
+                    plateau = np.logical_and(freq > self.white_noise_min, freq < self.white_noise_max)
+                    net = np.sqrt(np.mean(psd[plateau]))
+                net_sq = net**2
+                psd_limit = 1.0e-3 * net_sq
+                psd[psd < psd_limit] = psd_limit
+                psd[:] = 1 / psd
+                psd *= net_sq
+                psd[0] = 0
+                kernels.append(psd)
+            kernels = np.array(kernels)
+            idx = dd.indices(dets)
+            extend = np.zeros(len(dets), dtype=np.int32)
+            n_samp = dd.data.shape[1]
+            if flags is not None:
+                # impulse response spread (fft.py:836-872) through the same GPU pipeline
+                temp = np.zeros((len(dets), n_samp))
+                temp[:, n_samp // 2] = 100.0
+                hipfft.convolve_buffer(temp, np.arange(len(dets), dtype=np.int32), rate, kern_freq, kernels)
+                atemp = np.absolute(temp)
+                for i in range(len(dets)):
+                    ipeak = int(np.argmax(atemp[i]))
+                    thr = 0.02 * atemp[i, ipeak]
+                    imin = ipeak
+                    while imin > 0 and atemp[i, imin] > thr:
+                        imin -= 1
+                    imax = ipeak
+                    while imax < n_samp and atemp[i, imax] > thr:
+                        imax += 1
+                    extend[i] = imax - imin
+                    if extend[i] == n_samp:
+                        raise RuntimeError("Impulse response spreads to all samples")
+            hipfft.convolve_buffer(dd.data, idx, rate, kern_freq, kernels, use_accel=on_dev)
+            if flags is not None:
+                for i, f in enumerate(flags):
+                    ext = int(extend[i])
+                    hipfft.extend_flags(f, flag_mask, ext)
+                    f[:ext] |= flag_mask
+                    f[-ext:] |= flag_mask
+
+    def _finalize(self, data, **kwargs):
+        return
+
+    def _requires(self):
+        req = {"meta": [self.noise_model], "shared": [], "detdata": [self.det_data], "intervals": []}
+        if self.shared_flags is not None:
+            req["shared"].append(self.shared_flags)
+        if self.det_flags is not None:
+            req["detdata"].append(self.det_flags)
+        return req
+
+    def _provides(self):
+        return {"detdata": [self.det_data]}

@@ -1,0 +1,342 @@
+"""Pointing operators: PointingDetectorSimple, PixelsHealpix, StokesWeights.
+
+Reference: src/toast/ops/pointing_detector/pointing_detector.py:22-330,
+src/toast/ops/pixels_healpix/pixels_healpix.py:18-330,
+src/toast/ops/stokes_weights/stokes_weights.py:20-330.  Same traits, same buffer
+construction, same ``exists -> skip`` logic; the kernels are the HIP library's.
+"""
+
+import numpy as np
+
+from ..accel import native
+from ..data import defaults
+from ..pixels import PixelDistribution, unify_local_submaps
+from ..traits import Bool, ImplementationType, Instance, Int, Unicode
+from .operator import Operator
+
+_IMPLS = [ImplementationType.DEFAULT, ImplementationType.COMPILED]
+
+
+def _shared_to(ob, name, use_accel):
+    """Put a shared object where the kernel will look for it (pointing_detector.py:168-177)."""
+    obj = ob.shared[name]
+    if use_accel:
+        if not obj.accel_in_use():
+            if not obj.accel_exists():
+                obj.accel_create(name)
+            obj.accel_update_device()
+    elif obj.accel_in_use():
+        obj.accel_update_host()
+
+
+class PointingDetectorSimple(Operator):
+    """Boresight pointing x focalplane offsets -> detector quaternions."""
+
+    API = Int(0, help="Internal interface version for this operator")
+    view = Unicode(None, allow_none=True, help="Use this view of the data in all observations")
+    shared_flags = Unicode(defaults.shared_flags, allow_none=True, help="Observation shared key for telescope flags")
+    shared_flag_mask = Int(defaults.shared_mask_invalid, help="Bit mask value for optional flagging")
+    det_mask = Int(defaults.det_mask_invalid, help="Bit mask value for per-detector flagging")
+    det_flag_mask = Int(defaults.det_mask_invalid, help="Bit mask value for detector sample flagging")
+    boresight = Unicode(defaults.boresight_radec, help="Observation shared key for boresight")
+    hwp_angle = Unicode(None, allow_none=True, help="Observation shared key for HWP angle")
+    quats = Unicode(defaults.quats, allow_none=True, help="Observation detdata key for output quaternions")
+    coord_in = Unicode(None, allow_none=True, help="The input boresight coordinate system ('C', 'E', 'G')")
+    coord_out = Unicode(None, allow_none=True, help="The output coordinate system ('C', 'E', 'G')")
+
+    def _validate_shared_flag_mask(self, check):
+        if check < 0:
+            raise RuntimeError("Flag mask should be a positive integer")
+        return check
+
+    def _exec(self, data, detectors=None, use_accel=None, **kwargs):
+        implementation, use_accel = self.select_kernels(use_accel=use_accel)
+        if (self.coord_in is None) != (self.coord_out is None):
+            raise RuntimeError("Input and output coordinate systems should both be None or valid")
+        if self.coord_in is not None and self.coord_in != self.coord_out:
+            raise NotImplementedError("coordinate rotation of the boresight is outside the hot path")
+        for ob in data.obs:
+            _shared_to(ob, self.boresight, use_accel)
+            if self.shared_flags is not None:
+                _shared_to(ob, self.shared_flags, use_accel)
+        for ob in data.obs:
+            dets = ob.select_local_detectors(detectors, flagmask=self.det_mask)
+            exists = ob.detdata.ensure(self.quats, sample_shape=(4,), dtype=np.float64, detectors=dets,
+                                       accel=use_accel)
+            if len(dets) == 0 or exists:
+                continue
+            focalplane = ob.telescope.focalplane
+            fp_quats = np.zeros((len(dets), 4), dtype=np.float64)
+            for idet, d in enumerate(dets):
+                fp_quats[idet, :] = focalplane[d]["quat"]
+            quat_indx = ob.detdata[self.quats].indices(dets)
+            flags = np.zeros(1, dtype=np.uint8) if self.shared_flags is None else ob.shared[self.shared_flags].data
+            native().pointing_detector(fp_quats, ob.shared[self.boresight].data, quat_indx,
+                                       ob.detdata[self.quats].data, ob.intervals[self.view].data, flags,
+                                       self.shared_flag_mask, use_accel)
+
+    def _finalize(self, data, **kwargs):
+        return
+
+    def _requires(self):
+        req = {"meta": [], "shared": [self.boresight], "detdata": [self.quats], "intervals": []}
+        if self.shared_flags is not None:
+            req["shared"].append(self.shared_flags)
+        if self.view is not None:
+            req["intervals"].append(self.view)
+        return req
+
+    def _provides(self):
+        return {"detdata": [self.quats]}
+
+    def _implementations(self):
+        return _IMPLS
+
+    def _supports_accel(self):
+        return True
+
+
+def _check_detector_pointing(op, traits):
+    if op is not None:
+        if not isinstance(op, Operator):
+            raise RuntimeError("detector_pointing should be an Operator instance")
+        for trt in traits:
+            if not op.has_trait(trt):
+                raise RuntimeError(f"detector_pointing operator should have a '{trt}' trait")
+    return op
+
+
+class PixelsHealpix(Operator):
+    """Detector quaternions -> HEALPix pixel numbers (flagged samples -> -1), optionally
+    collecting the hit submaps into a ``PixelDistribution``."""
+
+    API = Int(0, help="Internal interface version for this operator")
+    detector_pointing = Instance(klass=Operator, help="Operator that translates boresight pointing into detector frame")
+    nside = Int(64, help="The NSIDE resolution")
+    nside_submap = Int(16, help="The NSIDE of the submap resolution")
+    nest = Bool(True, help="If True, use NESTED ordering instead of RING")
+    view = Unicode(None, allow_none=True, help="Use this view of the data in all observations")
+    pixels = Unicode(defaults.pixels, help="Observation detdata key for output pixel indices")
+    create_dist = Unicode(None, allow_none=True,
+                          help="Create the submap distribution for all detectors and store in the Data key specified")
+    single_precision = Bool(False, help="If True, use 32bit int in output")
+
+    def _validate_detector_pointing(self, op):
+        return _check_detector_pointing(op, ["view", "boresight", "shared_flags", "shared_flag_mask", "det_mask",
+                                             "quats", "coord_in", "coord_out"])
+
+    def _validate_nside(self, check):
+        if check <= 0 or (check & (check - 1)) != 0:
+            raise RuntimeError("Invalid NSIDE value")
+        if check < self.nside_submap:
+            raise RuntimeError("NSIDE value is less than nside_submap")
+        return check
+
+    def _validate_nside_submap(self, check):
+        if check <= 0 or (check & (check - 1)) != 0:
+            raise RuntimeError("Invalid NSIDE submap value")
+        if check > self.nside:
+            check = 16 if self.nside >= 16 else 1
+        return check
+
+    def _observe_nside(self, change):
+        self._set_hpix(change["new"], self.nside_submap)
+
+    def _observe_nside_submap(self, change):
+        self._set_hpix(self.nside, change["new"])
+
+    def __init__(self, **kwargs):
+        if "nside" in kwargs and "nside_submap" not in kwargs and kwargs["nside"] < 16:
+            kwargs["nside_submap"] = 1
+        # nside_submap must be applied before nside is validated against it
+        sub = kwargs.pop("nside_submap", None)
+        nside = kwargs.pop("nside", None)
+        super().__init__(**kwargs)
+        if nside is not None and sub is not None and sub > nside:
+            sub = 16 if nside >= 16 else 1
+        if sub is not None and sub <= self.nside:
+            self.nside_submap = sub
+        if nside is not None:
+            self.nside = nside
+        if sub is not None:
+            self.nside_submap = sub
+        self._set_hpix(self.nside, self.nside_submap)
+
+    def _set_hpix(self, nside, nside_submap):
+        self._n_pix = 12 * nside**2
+        self._n_pix_submap = 12 * nside_submap**2
+        self._n_submap = (nside // nside_submap) ** 2
+        self._local_submaps = None
+
+    def _exec(self, data, detectors=None, use_accel=None, **kwargs):
+        implementation, use_accel = self.select_kernels(use_accel=use_accel)
+        if self.detector_pointing is None:
+            raise RuntimeError("The detector_pointing trait must be set")
+        if self.single_precision:
+            raise NotImplementedError("the compiled kernel writes int64 pixels (as in the reference, "
+                                      "ops_pixels_healpix.cpp:1184-1186)")
+        if self._local_submaps is None and self.create_dist is not None:
+            self._local_submaps = np.zeros(self._n_submap, dtype=np.uint8)
+        quats_name = self.detector_pointing.quats
+        view = self.view if self.view is not None else self.detector_pointing.view
+        self.detector_pointing.apply(data, detectors=detectors, use_accel=use_accel)
+        for ob in data.obs:
+            dets = ob.select_local_detectors(detectors, flagmask=self.detector_pointing.det_mask)
+            exists = ob.detdata.ensure(self.pixels, sample_shape=(), dtype=np.int64, detectors=dets, accel=use_accel)
+            hit_submaps = self._local_submaps
+            if hit_submaps is None:
+                hit_submaps = np.zeros(self._n_submap, dtype=np.uint8)
+            if exists:
+                if self.create_dist is not None:
+                    # pixels already computed but the caller wants the distribution
+                    # (pixels_healpix.py:215-243): recover it from the host copy
+                    pd = ob.detdata[self.pixels]
+                    restore = False
+                    if pd.accel_in_use():
+                        pd.accel_update_host()
+                        restore = True
+                    for det in dets:
+                        for iv in ob.intervals[view]:
+                            p = pd[det, iv.first:iv.last]
+                            good = p >= 0
+                            self._local_submaps[p[good] // self._n_pix_submap] = 1
+                    if restore:
+                        pd.accel_update_device()
+                continue
+            if len(dets) == 0:
+                continue
+            quat_indx = ob.detdata[quats_name].indices(dets)
+            pix_indx = ob.detdata[self.pixels].indices(dets)
+            if self.detector_pointing.shared_flags is None:
+                flags = np.zeros(1, dtype=np.uint8)
+            else:
+                flags = ob.shared[self.detector_pointing.shared_flags].data
+            native().pixels_healpix(quat_indx, ob.detdata[quats_name].data, flags,
+                                    self.detector_pointing.shared_flag_mask, pix_indx, ob.detdata[self.pixels].data,
+                                    ob.intervals[view].data, hit_submaps, self._n_pix_submap, self.nside,
+                                    bool(self.nest), use_accel)
+            if self._local_submaps is not None:
+                self._local_submaps[:] |= hit_submaps
+
+    def _finalize(self, data, use_accel=None, **kwargs):
+        if self.create_dist is not None:
+            # Every process keeps the union of hit submaps so that map reductions are plain
+            # all-reduces of one contiguous buffer; single process: unchanged.
+            hits = unify_local_submaps(self._local_submaps, data.comm)
+            submaps = np.arange(self._n_submap, dtype=np.int64)[hits == 1]
+            data[self.create_dist] = PixelDistribution(n_pix=self._n_pix, n_submap=self._n_submap,
+                                                       local_submaps=submaps, comm=data.comm)
+            data[self.create_dist].nest = bool(self.nest)
+
+    def _requires(self):
+        req = self.detector_pointing.requires()
+        req.setdefault("detdata", []).append(self.pixels)
+        if self.view is not None:
+            req["intervals"].append(self.view)
+        return req
+
+    def _provides(self):
+        prov = self.detector_pointing.provides()
+        prov["detdata"].append(self.pixels)
+        if self.create_dist is not None:
+            prov.setdefault("global", []).append(self.create_dist)
+        return prov
+
+    def _implementations(self):
+        return _IMPLS
+
+    def _supports_accel(self):
+        return self.detector_pointing is not None and self.detector_pointing.supports_accel()
+
+
+class StokesWeights(Operator):
+    """Detector quaternions (+ HWP angle) -> Stokes I/Q/U pointing weights."""
+
+    API = Int(0, help="Internal interface version for this operator")
+    detector_pointing = Instance(klass=Operator, help="Operator that translates boresight pointing into detector frame")
+    mode = Unicode("I", help="The Stokes weights to generate (I or IQU)")
+    view = Unicode(None, allow_none=True, help="Use this view of the data in all observations")
+    hwp_angle = Unicode(None, allow_none=True, help="Observation shared key for HWP angle")
+    fp_gamma = Unicode("gamma", allow_none=True, help="Focalplane key for detector gamma offset angle")
+    weights = Unicode(defaults.weights, help="Observation detdata key for output weights")
+    cal = Unicode(None, allow_none=True, help="The observation key with a dictionary of pointing weight calibration")
+    single_precision = Bool(False, help="If True, use 32bit float in output")
+    IAU = Bool(False, help="If True, use the IAU convention rather than COSMO")
+
+    def _validate_detector_pointing(self, op):
+        return _check_detector_pointing(op, ["view", "boresight", "shared_flags", "shared_flag_mask", "det_mask",
+                                             "quats", "coord_in", "coord_out"])
+
+    def _validate_mode(self, check):
+        if check not in ("I", "IQU"):
+            raise RuntimeError("Invalid mode (must be 'I' or 'IQU')")
+        return check
+
+    def _exec(self, data, detectors=None, use_accel=None, **kwargs):
+        nnz = len(self.mode)
+        implementation, use_accel = self.select_kernels(use_accel=use_accel)
+        if self.detector_pointing is None:
+            raise RuntimeError("The detector_pointing trait must be set")
+        if self.single_precision:
+            raise NotImplementedError("the compiled kernel writes float64 weights")
+        if ("QU" in self.mode) and self.hwp_angle is not None and self.fp_gamma is None:
+            raise RuntimeError("If using HWP, you must specify the fp_gamma key")
+        quats_name = self.detector_pointing.quats
+        view = self.view if self.view is not None else self.detector_pointing.view
+        self.detector_pointing.apply(data, detectors=detectors, use_accel=use_accel)
+        for ob in data.obs:
+            dets = ob.select_local_detectors(detectors, flagmask=self.detector_pointing.det_mask)
+            exists = ob.detdata.ensure(self.weights, sample_shape=(nnz,), dtype=np.float64, detectors=dets,
+                                       accel=use_accel)
+            if exists or len(dets) == 0:
+                continue
+            quat_indx = ob.detdata[quats_name].indices(dets)
+            weight_indx = ob.detdata[self.weights].indices(dets)
+            focalplane = ob.telescope.focalplane
+            det_epsilon = np.array([focalplane[d]["pol_leakage"] for d in dets], dtype=np.float64)
+            if self.cal is None:
+                cal = np.ones(len(dets), dtype=np.float64)
+            else:
+                cal = np.array([ob[self.cal][x] for x in dets], np.float64)
+            if "QU" in self.mode:
+                det_gamma = np.zeros(len(dets), dtype=np.float64)
+                if self.hwp_angle is None or self.hwp_angle not in ob.shared:
+                    hwp_data = np.zeros(1, dtype=np.float64)
+                else:
+                    _shared_to(ob, self.hwp_angle, use_accel)
+                    hwp_data = ob.shared[self.hwp_angle].data
+                    for idet, d in enumerate(dets):
+                        det_gamma[idet] = focalplane[d][self.fp_gamma]
+                native().stokes_weights_IQU(quat_indx, ob.detdata[quats_name].data, weight_indx,
+                                            ob.detdata[self.weights].data, hwp_data, ob.intervals[view].data,
+                                            det_epsilon, det_gamma, cal, bool(self.IAU), use_accel)
+            else:
+                # the compiled kernel takes a 2-D [n_det, n_samp] buffer (ops_stokes_weights.cpp:417-420)
+                wd = ob.detdata[self.weights].data
+                native().stokes_weights_I(weight_indx, wd.reshape(wd.shape[0], wd.shape[1]),
+                                          ob.intervals[view].data, cal, use_accel)
+
+    def _finalize(self, data, **kwargs):
+        return
+
+    def _requires(self):
+        req = self.detector_pointing.requires()
+        req.setdefault("detdata", []).append(self.weights)
+        if self.cal is not None:
+            req["meta"].append(self.cal)
+        if self.hwp_angle is not None:
+            req["shared"].append(self.hwp_angle)
+        if self.view is not None:
+            req["intervals"].append(self.view)
+        return req
+
+    def _provides(self):
+        prov = self.detector_pointing.provides()
+        prov["detdata"].append(self.weights)
+        return prov
+
+    def _implementations(self):
+        return _IMPLS
+
+    def _supports_accel(self):
+        return self.detector_pointing is not None and self.detector_pointing.supports_accel()

@@ -1,0 +1,223 @@
+"""Distributed pixel-domain containers (reference: src/toast/pixels.py:59-241 PixelDistribution,
+:436-538 PixelData, :710-780 sync_allreduce) and covariance helpers
+(src/toast/covariance.py:20-306).
+
+MI355X-native difference: the map reduction across processes runs **on the device copy**
+with one RCCL all-reduce over xGMI (``torch.distributed`` backend "nccl"), instead of
+device->host copy, chunked host MPI_Allreduce and host->device copy
+(mapmaker_utils.py:885-925 in the reference).  Without a device copy (or with the gloo
+backend in CPU tests) the host buffer is reduced."""
+
+import numpy as np
+
+from .accel import (
+    AcceleratorObject,
+    accel_data_create,
+    accel_data_delete,
+    accel_data_present,
+    accel_data_reset,
+    accel_data_update_device,
+    accel_data_update_host,
+    accel_device_ptr,
+    native,
+)
+
+
+class PixelDistribution:
+    """Which submaps of the ``n_pix`` pixel domain are held locally."""
+
+    def __init__(self, n_pix=None, n_submap=1000, local_submaps=None, comm=None):
+        self._n_pix = int(n_pix)
+        self._n_submap = int(n_submap)
+        if self._n_submap > self._n_pix:
+            raise RuntimeError("Cannot create a PixelDistribution with more submaps than pixels")
+        self._n_pix_submap = self._n_pix // self._n_submap
+        if self._n_pix % self._n_submap != 0:
+            self._n_pix_submap += 1
+        self._comm = comm
+        if local_submaps is None:
+            self._local_submaps = None
+            self._glob2loc = None
+        else:
+            self._local_submaps = np.array(local_submaps, dtype=np.int64)
+            if self._local_submaps.size and np.max(self._local_submaps) > self._n_submap - 1:
+                raise RuntimeError("local submap indices out of range")
+            # pixels.py:216-241
+            self._glob2loc = np.full(self._n_submap, -1, dtype=np.int64)
+            self._glob2loc[self._local_submaps] = np.arange(self._local_submaps.size, dtype=np.int64)
+        self.nest = True
+
+    comm = property(lambda self: self._comm)
+    n_pix = property(lambda self: self._n_pix)
+    n_submap = property(lambda self: self._n_submap)
+    n_pix_submap = property(lambda self: self._n_pix_submap)
+    local_submaps = property(lambda self: self._local_submaps)
+    global_submap_to_local = property(lambda self: self._glob2loc)
+
+    @property
+    def n_local_submap(self):
+        return 0 if self._local_submaps is None else int(self._local_submaps.size)
+
+    def __eq__(self, other):
+        return (
+            isinstance(other, PixelDistribution)
+            and self._n_pix == other._n_pix
+            and self._n_submap == other._n_submap
+            and np.array_equal(self._local_submaps, other._local_submaps)
+        )
+
+    def __ne__(self, other):
+        return not self.__eq__(other)
+
+    def global_pixel_to_submap(self, gl):
+        """pixels.py:130-160: (local submap, pixel within submap); negatives stay negative."""
+        gl = np.asarray(gl, dtype=np.int64)
+        bad = gl < 0
+        sm = gl // self._n_pix_submap
+        pix = gl - sm * self._n_pix_submap
+        lsm = np.where(bad, -1, self._glob2loc[np.where(bad, 0, sm)])
+        return lsm, np.where(bad, -1, pix)
+
+
+def unify_local_submaps(hit_submaps, comm):
+    """Union of hit submaps over all processes (one-off MAX all-reduce): every process then
+    holds the same ``local_submaps`` so that the per-iteration map reduction is a plain
+    all-reduce of one contiguous buffer."""
+    hits = np.asarray(hit_submaps).astype(np.int32)
+    if comm is not None and comm.comm_world is not None:
+        comm.allreduce_array_(hits, op="max")
+    return hits.astype(np.uint8)
+
+
+class PixelData(AcceleratorObject):
+    """``[n_local_submap, n_pix_submap, n_value]`` values of a distributed map."""
+
+    def __init__(self, dist, dtype, n_value=1, units=None):
+        super().__init__("PixelData")
+        self._dist = dist
+        self._n_value = int(n_value)
+        self._dtype = np.dtype(dtype)
+        self.units = units
+        self._shape = (dist.n_local_submap, dist.n_pix_submap, self._n_value)
+        self.raw = np.zeros(int(np.prod(self._shape)), dtype=self._dtype)
+        self.data = self.raw.reshape(self._shape)
+
+    distribution = property(lambda self: self._dist)
+    n_value = property(lambda self: self._n_value)
+    dtype = property(lambda self: self._dtype)
+
+    def update_units(self, units):
+        self.units = units
+
+    def reset(self):
+        self.raw[:] = 0
+        if self.accel_exists():
+            self.accel_reset()
+
+    def duplicate(self):
+        """Host (and device, if in use) copy."""
+        dup = PixelData(self._dist, self._dtype, n_value=self._n_value, units=self.units)
+        if self.accel_in_use():
+            self.accel_update_host()
+            self.accel_used(True)  # device copy is still valid
+        dup.raw[:] = self.raw
+        return dup
+
+    def device_tensor(self):
+        """Zero-copy torch view of the device buffer (for RCCL collectives)."""
+        import torch
+
+        ptr = accel_device_ptr(self.raw)
+
+        class _Iface:
+            pass
+
+        holder = _Iface()
+        typestr = np.dtype(self._dtype).str
+        holder.__cuda_array_interface__ = dict(shape=(self.raw.size,), typestr=typestr, data=(ptr, False), version=3)
+        return torch.as_tensor(holder, device=torch.device("cuda", torch.cuda.current_device()))
+
+    def sync_allreduce(self, comm=None):
+        """Sum the map over all processes; every process ends with the total (all processes
+        must hold the same local submaps).  Device-resident data is reduced in place by RCCL."""
+        comm = self._dist.comm if comm is None else comm
+        if comm is None or comm.comm_world is None:
+            return
+        if self.accel_in_use() and comm._dist.get_backend() == "nccl":
+            native().accel_synchronize()  # kernels run on the library stream
+            comm.allreduce_tensor_(self.device_tensor())
+            import torch
+
+            torch.cuda.current_stream().synchronize()
+        else:
+            restore = False
+            if self.accel_in_use():
+                self.accel_update_host()
+                restore = True
+            comm.allreduce_array_(self.raw)
+            if restore:
+                self.accel_update_device()
+
+    # accelerator protocol
+    def _accel_exists(self):
+        return self.raw.size > 0 and accel_data_present(self.raw, self._accel_name)
+
+    def _accel_create(self, zero_out=False):
+        accel_data_create(self.raw, self._accel_name, zero_out=zero_out)
+
+    def _accel_update_device(self):
+        accel_data_update_device(self.raw, self._accel_name)
+
+    def _accel_update_host(self):
+        accel_data_update_host(self.raw, self._accel_name)
+
+    def _accel_delete(self):
+        accel_data_delete(self.raw, self._accel_name)
+
+    def _accel_reset(self):
+        accel_data_reset(self.raw, self._accel_name)
+
+
+# ----------------------------------------------------------------------------- covariance
+def covariance_apply(npp, m, use_alltoallv=False):
+    """In-place ``m <- npp . m`` per pixel (reference: src/toast/covariance.py:262-306).
+    Runs where the map lives: on the device copies when both are resident there."""
+    mapnnz = int(((np.sqrt(8 * npp.n_value) - 1) / 2) + 0.5)
+    if npp.distribution != m.distribution:
+        raise RuntimeError("covariance matrix and map must have same pixel distribution")
+    if m.n_value != mapnnz:
+        raise RuntimeError("covariance matrix and map have incompatible NNZ values")
+    on_dev = m.accel_in_use()
+    if on_dev and not npp.accel_in_use():
+        if not npp.accel_exists():
+            npp.accel_create("covariance")
+        npp.accel_update_device()
+    if (not on_dev) and npp.accel_in_use():
+        npp.accel_update_host()
+    native().cov_apply_diag(npp.distribution.n_local_submap, npp.distribution.n_pix_submap, mapnnz, npp.raw, m.raw,
+                            on_dev)
+
+
+def covariance_invert(npp, threshold, rcond=None, use_alltoallv=False):
+    """In-place inverse of the per-pixel blocks with an rcond threshold
+    (reference: src/toast/covariance.py:20-110 -> cov_eigendecompose_diag)."""
+    mapnnz = int(((np.sqrt(8 * npp.n_value) - 1) / 2) + 0.5)
+    if rcond is not None and rcond.distribution != npp.distribution:
+        raise RuntimeError("covariance matrix and condition number map must have same pixel distribution")
+    if npp.accel_in_use():
+        npp.accel_update_host()
+    cond = np.zeros(npp.distribution.n_local_submap * npp.distribution.n_pix_submap) if rcond is None else rcond.raw
+    native().cov_eigendecompose_diag(npp.distribution.n_local_submap, npp.distribution.n_pix_submap, mapnnz, npp.raw,
+                                     cond, float(threshold), True, False)
+
+
+def covariance_rcond(npp, use_alltoallv=False):
+    """Condition-number map of a covariance (reference: covariance.py:190-259)."""
+    mapnnz = int(((np.sqrt(8 * npp.n_value) - 1) / 2) + 0.5)
+    rcond = PixelData(npp.distribution, np.float64, n_value=1)
+    if npp.accel_in_use():
+        npp.accel_update_host()
+    work = npp.raw.copy()
+    native().cov_eigendecompose_diag(npp.distribution.n_local_submap, npp.distribution.n_pix_submap, mapnnz, work,
+                                     rcond.raw, 0.0, False, False)
+    return rcond

@@ -1,0 +1,81 @@
+"""Build small synthetic satellite observations in the ``toast_amd.data`` model -- the
+counterpart of the reference's test fixture ``create_satellite_data``
+(src/toast/tests/helpers/space.py:119-228): hexagon-like focalplane with two orthogonal
+detectors per pixel, spinning + precessing boresight, HWP angle, analytic noise model, and
+(optionally) deliberately flagged detectors / samples."""
+
+import numpy as np
+
+from . import synth
+from .data import Comm, Data, Focalplane, Observation, Telescope, defaults
+from .noise import AnalyticNoise
+
+
+def create_satellite_data(
+    comm=None,
+    n_det=4,
+    n_obs=1,
+    n_samp=3000,
+    rate=10.0,
+    spin_period_s=30.0,
+    spin_angle_deg=3.0,
+    prec_period_s=300.0,
+    prec_angle_deg=7.0,
+    hwp_rpm=9.0,
+    net=1.0,
+    fknee=0.05,
+    fmin=1.0e-5,
+    alpha=1.0,
+    flagged_pixels=False,
+    flag_samples=True,
+    n_intervals=1,
+    first_det=0,
+    fov_deg=10.0,
+    total_det=None,
+    seed=0,
+):
+    """Return a ``Data`` with ``n_obs`` observations of ``n_samp`` samples.
+
+    ``first_det`` / ``total_det`` select this process's slice of a larger focalplane (detector
+    sharding across processes: every process sees the same scan with its own detectors)."""
+    comm = Comm() if comm is None else comm
+    data = Data(comm=comm)
+    total = n_det if total_det is None else total_det
+    fp_all, gamma_all = synth.hex_focalplane(total, fov_deg=fov_deg)
+    names_all = ["D%04d%s" % (i // 2, "AB"[i % 2]) for i in range(total)]
+    sl = slice(first_det, first_det + n_det)
+    names = names_all[sl]
+    rng = np.random.default_rng(seed)
+    eps = np.zeros(n_det)
+    fp = Focalplane(names, fp_all[sl], gamma=gamma_all[sl], epsilon=eps, sample_rate=rate)
+    tele = Telescope("sat", fp)
+    for iobs in range(n_obs):
+        ob = Observation(comm, tele, n_samp, name=f"obs_{iobs:03d}")
+        t0 = iobs * n_samp / rate
+        times = t0 + np.arange(n_samp) / rate
+        ob.set_times(times)
+        bore = synth.satellite_boresight(n_samp, rate, spin_period_s, spin_angle_deg, prec_period_s, prec_angle_deg,
+                                         sample_offset=iobs * n_samp)
+        ob.shared.create(defaults.boresight_radec, bore)
+        sflags = np.zeros(n_samp, dtype=np.uint8)
+        if flag_samples:
+            sflags[int(0.37 * n_samp): int(0.37 * n_samp) + max(n_samp // 50, 1)] = defaults.shared_mask_invalid
+        ob.shared.create(defaults.shared_flags, sflags)
+        hwp = 2 * np.pi * ((times * hwp_rpm / 60.0) % 1.0)
+        ob.shared.create(defaults.hwp_angle, hwp)
+        if n_intervals > 1:
+            ivl = synth.make_intervals(n_samp, n_intervals, rate, gap=2)
+            ob.intervals.create("scan", [(int(a["first"]), int(a["last"])) for a in ivl])
+        ob[defaults.noise_model] = AnalyticNoise(
+            rate={d: rate for d in names}, fmin={d: fmin for d in names}, detectors=names,
+            fknee={d: fknee for d in names}, alpha={d: alpha for d in names}, NET={d: net for d in names})
+        ob.detdata.create(defaults.det_data, dtype=np.float64, units=defaults.det_data_units)
+        dflags = ob.detdata.create(defaults.det_flags, dtype=np.uint8)
+        if flag_samples:
+            dflags.data[rng.random(dflags.data.shape) < 0.01] = defaults.det_mask_invalid
+        if flagged_pixels:
+            # flag every other pixel's detectors at the detector level (space.py:200-214)
+            flg = {d: (defaults.det_mask_invalid if (i // 2) % 2 == 1 else 0) for i, d in enumerate(names)}
+            ob.update_local_detector_flags(flg)
+        data.obs.append(ob)
+    return data

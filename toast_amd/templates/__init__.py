@@ -1,0 +1,434 @@
+"""Template amplitudes and the Offset (destriping baseline) template.
+
+Reference: src/toast/templates/amplitudes.py (Amplitudes, AmplitudesMap),
+src/toast/templates/template.py (Template), src/toast/templates/offset/offset.py (Offset,
+kernels src/toast/_libtoast/template_offset.cpp:16-408).  The noise prior of the Offset
+template (offset.py:455-476, 884-1005) is host-only scipy code in the reference
+(``NotImplementedError`` on accelerators) and is out of the hot path: only
+``use_noise_prior=False`` (the reference default) is supported.
+"""
+
+import numpy as np
+
+from ..accel import (
+    AcceleratorObject,
+    accel_data_create,
+    accel_data_delete,
+    accel_data_present,
+    accel_data_reset,
+    accel_data_update_device,
+    accel_data_update_host,
+    native,
+)
+from ..data import defaults
+from ..traits import Any, Bool, Float, ImplementationType, Int, TraitConfig, Unicode
+
+
+class Amplitudes(AcceleratorObject):
+    """Local piece of a distributed amplitude vector with flags.  Offset amplitudes are unique
+    per process (each detector lives on one process), so ``dot`` = local dot + scalar
+    all-reduce (amplitudes.py:523-565)."""
+
+    def __init__(self, comm, n_global, n_local, dtype=np.float64):
+        super().__init__("Amplitudes")
+        self._comm = comm
+        self._n_global = int(n_global)
+        self._n_local = int(n_local)
+        self.local = np.zeros(self._n_local, dtype=dtype)
+        self.local_flags = np.zeros(self._n_local, dtype=np.uint8)
+
+    n_global = property(lambda self: self._n_global)
+    n_local = property(lambda self: self._n_local)
+    comm = property(lambda self: self._comm)
+
+    def _host(self):
+        if self.accel_in_use():
+            self.accel_update_host()
+
+    def duplicate(self):
+        self._host()
+        ret = Amplitudes(self._comm, self._n_global, self._n_local, dtype=self.local.dtype)
+        ret.local[:] = self.local
+        ret.local_flags[:] = self.local_flags
+        return ret
+
+    def reset(self):
+        self.local[:] = 0
+        if self.accel_exists():
+            self.accel_reset()
+
+    def clear(self):
+        if self.accel_exists():
+            self.accel_delete()
+
+    def __iadd__(self, other):
+        self._host()
+        if isinstance(other, Amplitudes):
+            other._host()
+            self.local += other.local
+        else:
+            self.local += other
+        return self
+
+    def __isub__(self, other):
+        self._host()
+        if isinstance(other, Amplitudes):
+            other._host()
+            self.local -= other.local
+        else:
+            self.local -= other
+        return self
+
+    def __imul__(self, other):
+        self._host()
+        if isinstance(other, Amplitudes):
+            other._host()
+            self.local *= other.local
+        else:
+            self.local *= other
+        return self
+
+    def dot(self, other):
+        self._host()
+        other._host()
+        good = np.logical_and(self.local_flags == 0, other.local_flags == 0)
+        val = float(np.dot(self.local[good], other.local[good]))
+        if self._comm is not None and self._comm.comm_world is not None:
+            val = self._comm.allreduce_scalar(val, op="sum")
+        return val
+
+    def sync(self):
+        """Offset amplitudes are process-local: nothing to combine (amplitudes.py:357)."""
+        return
+
+    # accelerator protocol: values and flags are two registered buffers
+    def _accel_exists(self):
+        return self._n_local > 0 and accel_data_present(self.local, self._accel_name)
+
+    def _accel_create(self, zero_out=False):
+        accel_data_create(self.local, self._accel_name, zero_out=zero_out)
+        accel_data_create(self.local_flags, self._accel_name + "_flags")
+        accel_data_update_device(self.local_flags, self._accel_name + "_flags")
+
+    def _accel_update_device(self):
+        accel_data_update_device(self.local, self._accel_name)
+        accel_data_update_device(self.local_flags, self._accel_name + "_flags")
+
+    def _accel_update_host(self):
+        accel_data_update_host(self.local, self._accel_name)
+
+    def _accel_delete(self):
+        accel_data_delete(self.local, self._accel_name)
+        accel_data_delete(self.local_flags, self._accel_name + "_flags")
+
+    def _accel_reset(self):
+        accel_data_reset(self.local, self._accel_name)
+
+
+class AmplitudesMap(dict):
+    """name -> Amplitudes with vector arithmetic (amplitudes.py AmplitudesMap)."""
+
+    def duplicate(self):
+        ret = AmplitudesMap()
+        for k, v in self.items():
+            ret[k] = v.duplicate()
+        return ret
+
+    def reset(self):
+        for v in self.values():
+            v.reset()
+
+    def clear(self):
+        for v in self.values():
+            v.clear()
+        super().clear()
+
+    def dot(self, other):
+        return sum(v.dot(other[k]) for k, v in self.items())
+
+    def _binary(self, other, fn):
+        for k, v in self.items():
+            fn(v, other[k] if isinstance(other, AmplitudesMap) else other)
+        return self
+
+    def __iadd__(self, other):
+        return self._binary(other, lambda a, b: a.__iadd__(b))
+
+    def __isub__(self, other):
+        return self._binary(other, lambda a, b: a.__isub__(b))
+
+    def __imul__(self, other):
+        return self._binary(other, lambda a, b: a.__imul__(b))
+
+    def accel_exists(self):
+        return all(v.accel_exists() for v in self.values()) and len(self) > 0
+
+    def accel_in_use(self):
+        return any(v.accel_in_use() for v in self.values())
+
+    def accel_create(self, name, zero_out=False):
+        for k, v in self.items():
+            if not v.accel_exists():
+                v.accel_create(f"{name}_{k}", zero_out=zero_out)
+
+    def accel_used(self, state):
+        for v in self.values():
+            v.accel_used(state)
+
+    def accel_update_device(self):
+        for v in self.values():
+            if v.accel_exists() and not v.accel_in_use():
+                v.accel_update_device()
+
+    def accel_update_host(self):
+        for v in self.values():
+            if v.accel_in_use():
+                v.accel_update_host()
+
+    def accel_delete(self):
+        for v in self.values():
+            if v.accel_exists():
+                v.accel_delete()
+
+
+class Template(TraitConfig):
+    """Base class of timestream templates (templates/template.py)."""
+
+    data = Any(None, help="This must be an instance of a Data class (or None)")
+    view = Unicode(None, allow_none=True, help="Use this view of the data in all observations")
+    det_data = Unicode(defaults.det_data, allow_none=True, help="Observation detdata key for the timestream data")
+    det_data_units = Unicode(defaults.det_data_units, allow_none=True, help="Desired units of detector data")
+    det_mask = Int(defaults.det_mask_nonscience, help="Bit mask value for solver per-detector flagging")
+    det_flags = Unicode(defaults.det_flags, allow_none=True, help="Observation detdata key for solver flags to use")
+    det_flag_mask = Int(defaults.det_mask_nonscience, help="Bit mask value for solver flags")
+
+    def _observe_data(self, change):
+        if change["new"] is not None:
+            self._initialize(change["new"])
+
+    def initialize(self, new_data):
+        self.data = new_data
+
+    def _check_enabled(self):
+        if self.data is None:
+            raise RuntimeError("You must set the data trait before calling template methods")
+        return self.enabled
+
+    def detectors(self):
+        return self._detectors() if self._check_enabled() else []
+
+    def zeros(self):
+        return self._zeros() if self._check_enabled() else None
+
+    def add_to_signal(self, detector, amplitudes, **kwargs):
+        if self._check_enabled():
+            self._add_to_signal(detector, amplitudes, **kwargs)
+
+    def project_signal(self, detector, amplitudes, **kwargs):
+        if self._check_enabled():
+            self._project_signal(detector, amplitudes, **kwargs)
+
+    def add_prior(self, amplitudes_in, amplitudes_out, **kwargs):
+        if self._check_enabled():
+            self._add_prior(amplitudes_in, amplitudes_out, **kwargs)
+
+    def apply_precond(self, amplitudes_in, amplitudes_out, **kwargs):
+        if self._check_enabled():
+            self._apply_precond(amplitudes_in, amplitudes_out, **kwargs)
+
+
+class Offset(Template):
+    """One amplitude per detector per ``step_time`` of every view (baseline offsets)."""
+
+    step_time = Float(10000.0, help="Time per baseline step [s]")
+    times = Unicode(defaults.times, help="Observation shared key for timestamps")
+    noise_model = Unicode(None, allow_none=True, help="Observation key containing the optional noise model")
+    good_fraction = Float(0.5, help="Fraction of unflagged samples needed to keep a given offset amplitude")
+    use_noise_prior = Bool(False, help="Use detector PSDs to build the noise prior and preconditioner")
+    precond_width = Int(20, help="Preconditioner width in terms of offsets / baselines")
+
+    def _step_length(self, stime, rate):
+        return int(stime * rate + 0.5)
+
+    def _initialize(self, new_data):
+        if self.use_noise_prior:
+            raise NotImplementedError("the Offset noise prior is host-only in the reference and not on the hot path")
+        self._obs_views, self._obs_view_flags, self._obs_rate, self._obs_dets = {}, {}, {}, {}
+        all_dets = {}
+        for iob, ob in enumerate(new_data.obs):
+            rate = ob.telescope.focalplane.sample_rate
+            if self.times in ob.shared and ob.shared[self.times].data.size > 1:
+                t = ob.shared[self.times].data
+                rate = 1.0 / np.median(np.diff(t))  # rate_from_times
+            self._obs_rate[iob] = rate
+            step_length = self._step_length(self.step_time, rate)
+            views = []
+            for vw in ob.intervals[self.view]:
+                view_len = vw.last - vw.first
+                n = view_len // step_length
+                if n * step_length < view_len:
+                    n += 1
+                views.append(n)
+            self._obs_views[iob] = np.array(views, dtype=np.int64)
+            vf = np.ones(ob.n_local_samples, dtype=np.uint8)
+            for vw in ob.intervals[self.view]:
+                vf[vw.first:vw.last] = 0
+            self._obs_view_flags[iob] = vf
+            self._obs_dets[iob] = set()
+            for d in ob.select_local_detectors(flagmask=self.det_mask):
+                if self.det_data in ob.detdata and d not in ob.detdata[self.det_data].detectors:
+                    continue
+                self._obs_dets[iob].add(d)
+                all_dets.setdefault(d, None)
+        self._all_dets = list(all_dets.keys())
+        self._det_start = {}
+        offset = 0
+        for det in self._all_dets:
+            self._det_start[det] = offset
+            for iob, ob in enumerate(new_data.obs):
+                if det in self._obs_dets[iob]:
+                    offset += int(np.sum(self._obs_views[iob]))
+        self._n_local = offset
+        comm = new_data.comm
+        self._n_global = self._n_local
+        if comm.comm_world is not None:
+            self._n_global = int(comm.allreduce_scalar(self._n_local, op="sum"))
+        self._amp_flags = np.zeros(self._n_local, dtype=np.uint8)
+        self._offsetvar = np.zeros(self._n_local, dtype=np.float64)
+        # offset variance / flags: offset.py:262-343
+        offset = 0
+        for det in self._all_dets:
+            for iob, ob in enumerate(new_data.obs):
+                if det not in self._obs_dets[iob]:
+                    continue
+                detnoise = 1.0
+                if self.noise_model is not None:
+                    detnoise = ob[self.noise_model].detector_weight(det)
+                step_length = self._step_length(self.step_time, self._obs_rate[iob])
+                for ivw, vw in enumerate(ob.intervals[self.view]):
+                    n_amp_view = int(self._obs_views[iob][ivw])
+                    view_samples = vw.last - vw.first
+                    if detnoise <= 0:
+                        self._amp_flags[offset:offset + n_amp_view] = 1
+                    else:
+                        flags = np.array(self._obs_view_flags[iob][vw.first:vw.last], dtype=np.uint8)
+                        if self.det_flags is not None:
+                            flags |= ob.detdata[self.det_flags][det, vw.first:vw.last] & self.det_flag_mask
+                        voff = 0
+                        for amp in range(n_amp_view):
+                            amplen = step_length if amp < n_amp_view - 1 else view_samples - voff
+                            n_good = amplen - np.count_nonzero(flags[voff:voff + amplen])
+                            if (n_good / amplen) <= self.good_fraction:
+                                self._amp_flags[offset + amp] = 1
+                            else:
+                                self._offsetvar[offset + amp] = 1.0 / (detnoise * n_good)
+                            voff += step_length
+                    offset += n_amp_view
+        self._flag_cache = {}
+
+    def _detectors(self):
+        return self._all_dets
+
+    def _zeros(self):
+        z = Amplitudes(self.data.comm, self._n_global, self._n_local)
+        z.local_flags[:] = self._amp_flags
+        return z
+
+    def _supports_accel(self):
+        return not self.use_noise_prior
+
+    def supports_accel(self):
+        return self._supports_accel()
+
+    def _implementations(self):
+        return [ImplementationType.DEFAULT, ImplementationType.COMPILED]
+
+    def _amps_to(self, amplitudes, use_accel):
+        if use_accel:
+            if not amplitudes.accel_exists():
+                amplitudes.accel_create(f"{self.name}_amps")
+                amplitudes.accel_update_device()
+            elif not amplitudes.accel_in_use():
+                amplitudes.accel_update_device()
+        elif amplitudes.accel_in_use():
+            amplitudes.accel_update_host()
+
+    def _add_to_signal(self, detector, amplitudes, use_accel=None, **kwargs):
+        if detector not in self._all_dets:
+            return
+        use_accel = bool(use_accel)
+        self._amps_to(amplitudes, use_accel)
+        amp_offset = self._det_start[detector]
+        for iob, ob in enumerate(self.data.obs):
+            if detector not in self._obs_dets[iob]:
+                continue
+            det_indx = ob.detdata[self.det_data].indices([detector])
+            step_length = self._step_length(self.step_time, self._obs_rate[iob])
+            n_amp_views = self._obs_views[iob]
+            native().template_offset_add_to_signal(step_length, amp_offset, n_amp_views, amplitudes.local,
+                                                   amplitudes.local_flags, int(det_indx[0]),
+                                                   ob.detdata[self.det_data].data, ob.intervals[self.view].data,
+                                                   use_accel)
+            amp_offset += int(np.sum(n_amp_views))
+
+    def _solver_flags(self, iob, ob, use_accel):
+        """det_flags | view flags, cached per observation (offset.py:834-843 builds this copy on
+        every call); registered on the device when needed."""
+        key = (iob, use_accel)
+        if key not in self._flag_cache:
+            fd = ob.detdata[self.det_flags]
+            if fd.accel_in_use():
+                fd.accel_update_host()
+                fd.accel_used(True)
+            flag_data = np.copy(fd.data)
+            flag_data |= (self.det_flag_mask * self._obs_view_flags[iob]).astype(np.uint8)
+            if use_accel:
+                accel_data_create(flag_data, f"{self.name}_solver_flags")
+                accel_data_update_device(flag_data, f"{self.name}_solver_flags")
+            self._flag_cache[key] = flag_data
+        return self._flag_cache[key]
+
+    def _project_signal(self, detector, amplitudes, use_accel=None, **kwargs):
+        if detector not in self._all_dets:
+            return
+        use_accel = bool(use_accel)
+        self._amps_to(amplitudes, use_accel)
+        amp_offset = self._det_start[detector]
+        for iob, ob in enumerate(self.data.obs):
+            if detector not in self._obs_dets[iob]:
+                continue
+            det_indx = ob.detdata[self.det_data].indices([detector])
+            if self.det_flags is not None:
+                flag_indx = int(ob.detdata[self.det_flags].indices([detector])[0])
+                flag_data = self._solver_flags(iob, ob, use_accel)
+            else:
+                flag_indx = -1
+                flag_data = np.zeros((1, 1), dtype=np.uint8)
+            step_length = self._step_length(self.step_time, self._obs_rate[iob])
+            n_amp_views = self._obs_views[iob]
+            native().template_offset_project_signal(int(det_indx[0]), ob.detdata[self.det_data].data, flag_indx,
+                                                    flag_data, self.det_flag_mask, step_length, amp_offset,
+                                                    n_amp_views, amplitudes.local, amplitudes.local_flags,
+                                                    ob.intervals[self.view].data, use_accel)
+            amp_offset += int(np.sum(n_amp_views))
+
+    def _add_prior(self, amplitudes_in, amplitudes_out, use_accel=None, **kwargs):
+        # no noise prior: nothing to accumulate (offset.py:884-893)
+        return
+
+    def _apply_precond(self, amplitudes_in, amplitudes_out, use_accel=None, **kwargs):
+        # diagonal preconditioner (offset.py:1007-1028 -> template_offset_apply_diag_precond)
+        if self._n_local == 0:
+            return
+        if amplitudes_in.accel_in_use():
+            amplitudes_in.accel_update_host()
+        if amplitudes_out.accel_in_use():
+            amplitudes_out.accel_update_host()
+        native().template_offset_apply_diag_precond(self._offsetvar, amplitudes_in.local, amplitudes_in.local_flags,
+                                                    amplitudes_out.local, False)
+
+    def clear(self):
+        for (iob, on_dev), buf in self._flag_cache.items():
+            if on_dev:
+                accel_data_delete(buf, f"{self.name}_solver_flags")
+        self._flag_cache = {}
