@@ -60,12 +60,40 @@ def accel_data_present(data, name="None"):
     return bool(native().accel_present(_key(data), name))
 
 
-def accel_data_create(data, name="None", zero_out=False):
-    """reference accel.py:147-176"""
+_finalizers = {}
+
+
+def _release(ptr, nbytes, name):
+    """Finalizer: drop the device copy of a host buffer whose owner was garbage collected.
+    Device copies are keyed by host address (like the reference's OmpManager), so a leaked
+    entry would be mistaken for the next allocation at that address."""
+    import ctypes
+
+    from . import capi
+
+    _finalizers.pop(ptr, None)
+    try:
+        lib = capi.lib()
+        present = ctypes.c_int(0)
+        rc = lib.toast_hip_accel_present(ctypes.c_void_p(ptr), ctypes.c_size_t(nbytes), ctypes.byref(present))
+        if rc == 0 and present.value:
+            lib.toast_hip_accel_delete(ctypes.c_void_p(ptr), ctypes.c_size_t(nbytes), name.encode())
+    except Exception:  # interpreter shutdown
+        pass
+
+
+def accel_data_create(data, name="None", zero_out=False, owner=None):
+    """reference accel.py:147-176.  ``owner``: object whose lifetime bounds the device copy."""
+    import weakref
+
     ensure_assigned()
-    native().accel_create(_key(data), name)
+    arr = _key(data)
+    native().accel_create(arr, name)
     if zero_out:
-        native().accel_reset(_key(data), name)
+        native().accel_reset(arr, name)
+    if owner is not None:
+        ptr = arr.ctypes.data
+        _finalizers[ptr] = weakref.finalize(owner, _release, ptr, arr.nbytes, name)
     return data
 
 
@@ -89,7 +117,11 @@ def accel_data_update_host(data, name="None"):
 
 def accel_data_delete(data, name="None"):
     ensure_assigned()
-    native().accel_delete(_key(data), name)
+    arr = _key(data)
+    fin = _finalizers.pop(arr.ctypes.data, None)
+    if fin is not None:
+        fin.detach()
+    native().accel_delete(arr, name)
     return data
 
 

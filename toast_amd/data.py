@@ -287,7 +287,7 @@ class DetectorData(AcceleratorObject):
         return self._data.size > 0 and accel_data_present(self._data, self._accel_name)
 
     def _accel_create(self, zero_out=False):
-        accel_data_create(self._data, self._accel_name, zero_out=zero_out)
+        accel_data_create(self._data, self._accel_name, zero_out=zero_out, owner=self)
 
     def _accel_update_device(self):
         accel_data_update_device(self._data, self._accel_name)
@@ -378,7 +378,7 @@ class SharedData(AcceleratorObject):
         return accel_data_present(self.data, self._accel_name)
 
     def _accel_create(self, zero_out=False):
-        accel_data_create(self.data, self._accel_name, zero_out=zero_out)
+        accel_data_create(self.data, self._accel_name, zero_out=zero_out, owner=self)
 
     def _accel_update_device(self):
         accel_data_update_device(self.data, self._accel_name)

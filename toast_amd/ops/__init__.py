@@ -12,6 +12,7 @@ from .mapmaker_ops import (
     Delete,
     NoiseWeight,
     ScanMap,
+    ScanMask,
 )
 from .mapmaker_solve import SolverLHS, SolverRHS, TemplateMatrix, solve
 from .noise_filter import NoiseFilter

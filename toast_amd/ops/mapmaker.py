@@ -11,7 +11,7 @@ import numpy as np
 from ..data import defaults
 from ..pixels import PixelData
 from ..traits import Bool, Float, Instance, Int, Unicode
-from .mapmaker_ops import BinMap, Copy, CovarianceAndHits, Delete
+from .mapmaker_ops import BinMap, Copy, CovarianceAndHits, Delete, ScanMask
 from .mapmaker_solve import SolverLHS, SolverRHS, TemplateMatrix, solve
 from .operator import Operator
 from .pipeline import Pipeline
@@ -97,6 +97,37 @@ class MapMaker(Operator):
             del data[binning.pixel_dist]
         hits_name, cov_name, rcond_name = f"{self.name}_hits", f"{self.name}_cov", f"{self.name}_rcond"
         map_name, amp_name = f"{self.name}_map", f"{self.name}_amplitudes"
+        # Solver flags: one uint8 per sample combining detector and shared flags, so that the
+        # binning and the templates cut exactly the same samples while solving
+        # (SolveAmplitudes._prepare_flagging, mapmaker_templates.py:764-810).
+        solver_flags = f"{self.name}_solve_flags"
+        saved = (binning.det_flags, binning.det_flag_mask)
+        tm = self.template_matrix
+        use_templates = tm is not None and len(tm.templates) > 0
+        if use_templates:
+            for ob in data.obs:
+                ob.detdata.ensure(solver_flags, dtype=np.uint8, detectors=ob.local_detectors)
+                sf = ob.detdata[solver_flags]
+                sf.data[:] = 0
+                if binning.det_flags is not None:
+                    src = ob.detdata[binning.det_flags]
+                    if src.accel_in_use():
+                        src.accel_update_host()
+                    for d in ob.local_detectors:
+                        sf[d][(src[d] & binning.det_flag_mask) != 0] = 1
+                if binning.shared_flags is not None:
+                    shared = ob.shared[binning.shared_flags]
+                    if shared.accel_in_use():
+                        shared.accel_update_host()
+                    bad = (shared.data & binning.shared_flag_mask) != 0
+                    sf.data[:, bad] = 1
+                if binning.pixel_pointing.view is not None:
+                    outside = np.ones(ob.n_local_samples, dtype=bool)
+                    for iv in ob.intervals[binning.pixel_pointing.view]:
+                        outside[iv.first:iv.last] = False
+                    sf.data[:, outside] = 1
+            binning.det_flags, binning.det_flag_mask = solver_flags, 1
+            tm.det_flags, tm.det_flag_mask = solver_flags, 1
         # covariance + hits with the solver flags
         cov_op = CovarianceAndHits(
             pixel_dist=binning.pixel_dist, covariance=cov_name, hits=hits_name, rcond=rcond_name,
@@ -108,9 +139,21 @@ class MapMaker(Operator):
         cov_op.apply(data, detectors=detectors)
         binning.covariance = cov_name
         map_binning.covariance = cov_name
+        if use_templates:
+            # samples in pixels that fail the rcond cut must not constrain the templates
+            # (SolveAmplitudes._get_rcond_mask, mapmaker_templates.py:895-939)
+            mask_name = f"{self.name}_rcond_mask"
+            data[mask_name] = PixelData(data[binning.pixel_dist], np.uint8, n_value=1)
+            data[mask_name].data[data[rcond_name].data < self.solve_rcond_threshold] = 1
+            scanner = ScanMask(det_flags=solver_flags, det_flags_value=1, det_mask=binning.det_mask,
+                               pixels=binning.pixel_pointing.pixels, view=binning.pixel_pointing.view,
+                               mask_key=mask_name)
+            scan_pipe = Pipeline(detector_sets=["ALL"] if binning.full_pointing else ["SINGLE"],
+                                 operators=[binning.pixel_pointing, scanner])
+            scan_pipe.apply(data, detectors=detectors)
+            del data[mask_name]
         cleaned = self.det_data
-        tm = self.template_matrix
-        if tm is not None and len(tm.templates) > 0:
+        if use_templates:
             tm.reset()
             tm.amplitudes = f"{self.name}_rhs"
             solver_bin = f"{self.name}_solve_bin"
@@ -140,6 +183,9 @@ class MapMaker(Operator):
                 cleaned = f"{self.name}_temp_cleaned"
             ApplyAmplitudes(op="subtract", amplitudes=amp_name, template_matrix=tm, det_data=self.det_data,
                             output=None if cleaned == self.det_data else cleaned).apply(data, detectors=detectors)
+        if use_templates:
+            binning.det_flags, binning.det_flag_mask = saved
+            Delete(detdata=[solver_flags]).apply(data)
         map_binning.binned = map_name
         map_binning.det_data = cleaned
         map_binning.apply(data, detectors=detectors)

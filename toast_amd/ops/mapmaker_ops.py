@@ -105,6 +105,71 @@ class ScanMap(Operator):
         return True
 
 
+class ScanMask(Operator):
+    """Flag detector samples that fall in masked pixels: ``det_flags |= det_flags_value`` where
+    ``mask[pix] & mask_bits`` is set.  Host-side bookkeeping exactly as in the reference (its
+    ScanMask has ``_supports_accel() == False``: src/toast/ops/scan_map/scan_map.py:218-345);
+    it runs once while preparing the solver flags, never inside the PCG loop."""
+
+    API = Int(0, help="Internal interface version for this operator")
+    det_mask = Int(defaults.det_mask_invalid, help="Bit mask value for per-detector flagging")
+    det_flags = Unicode(defaults.det_flags, allow_none=True, help="Observation detdata key for flags to use")
+    det_flags_value = Int(defaults.det_mask_processing, help="The detector flag value to set where the mask result is non-zero")
+    det_flag_mask = Int(defaults.det_mask_invalid, help="Bit mask value for detector sample flagging")
+    view = Unicode(None, allow_none=True, help="Use this view of the data in all observations")
+    pixels = Unicode(defaults.pixels, help="Observation detdata key for pixel indices")
+    mask_key = Unicode(None, allow_none=True, help="The Data key where the mask is located")
+    mask_bits = Int(255, help="The number to bitwise-and with each mask value to form the result")
+
+    def _exec(self, data, detectors=None, use_accel=None, **kwargs):
+        if self.det_flags is None:
+            raise RuntimeError("You must set the det_flags trait before calling exec()")
+        if self.mask_key is None:
+            raise RuntimeError("You must set the mask_key trait before calling exec()")
+        if self.mask_key not in data:
+            raise RuntimeError("The mask_key '{}' does not exist in the data".format(self.mask_key))
+        mask_data = data[self.mask_key]
+        if not isinstance(mask_data, PixelData):
+            raise RuntimeError("The mask to scan must be a PixelData instance")
+        mask_dist = mask_data.distribution
+        for ob in data.obs:
+            dets = ob.select_local_detectors(detectors, flagmask=self.det_mask)
+            if len(dets) == 0:
+                continue
+            if self.det_flags not in ob.detdata:
+                ob.detdata.create(self.det_flags, dtype=np.uint8, detectors=ob.local_detectors)
+            pd, fd = ob.detdata[self.pixels], ob.detdata[self.det_flags]
+            if pd.accel_in_use():
+                pd.accel_update_host()
+                pd.accel_used(True)
+            if fd.accel_in_use():
+                fd.accel_update_host()
+            for iv in ob.intervals[self.view]:
+                for det in dets:
+                    pix = pd[det, iv.first:iv.last]
+                    local_sm, local_pix = mask_dist.global_pixel_to_submap(pix)
+                    ok = local_sm >= 0
+                    masked = np.zeros(pix.shape, dtype=bool)
+                    masked[ok] = (mask_data.data[local_sm[ok], local_pix[ok], 0] & self.mask_bits) != 0
+                    fd[det, iv.first:iv.last][masked] |= self.det_flags_value
+
+    def _finalize(self, data, **kwargs):
+        return
+
+    def _requires(self):
+        req = {"meta": [], "global": [self.mask_key], "shared": [], "detdata": [self.pixels, self.det_flags],
+               "intervals": []}
+        if self.view is not None:
+            req["intervals"].append(self.view)
+        return req
+
+    def _provides(self):
+        return {"detdata": [self.det_flags]}
+
+    def _supports_accel(self):
+        return False
+
+
 class NoiseWeight(Operator):
     """Apply diagonal noise weighting ``tod *= detector_weight`` (N^-1 of the PCG)."""
 

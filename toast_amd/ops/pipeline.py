@@ -127,7 +127,13 @@ class Pipeline(Operator):
             use_accel_op = bool(pipe_accel and op.supports_accel())
             result.append(op.finalize(data, use_accel=use_accel_op, **kwargs))
         if self._staged_data is not None:
-            provides = _SetDict(self.provides())
+            # The reference copies back only the pruned provides() (pipeline.py:280-295), which
+            # leaves intermediate products that stay allocated on the host (e.g. cached pixels /
+            # weights with full_pointing=True) stale there once the device copies are deleted.
+            # We bring back everything any operator provided.
+            provides = _SetDict()
+            for op in self.operators:
+                provides |= op.provides()
             provides &= self._staged_data
             data.accel_update_host(provides)
             data.accel_delete(self._staged_data)

@@ -163,7 +163,7 @@ class PixelData(AcceleratorObject):
         return self.raw.size > 0 and accel_data_present(self.raw, self._accel_name)
 
     def _accel_create(self, zero_out=False):
-        accel_data_create(self.raw, self._accel_name, zero_out=zero_out)
+        accel_data_create(self.raw, self._accel_name, zero_out=zero_out, owner=self)
 
     def _accel_update_device(self):
         accel_data_update_device(self.raw, self._accel_name)

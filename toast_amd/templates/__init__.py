@@ -106,8 +106,8 @@ class Amplitudes(AcceleratorObject):
         return self._n_local > 0 and accel_data_present(self.local, self._accel_name)
 
     def _accel_create(self, zero_out=False):
-        accel_data_create(self.local, self._accel_name, zero_out=zero_out)
-        accel_data_create(self.local_flags, self._accel_name + "_flags")
+        accel_data_create(self.local, self._accel_name, zero_out=zero_out, owner=self)
+        accel_data_create(self.local_flags, self._accel_name + "_flags", owner=self)
         accel_data_update_device(self.local_flags, self._accel_name + "_flags")
 
     def _accel_update_device(self):
@@ -247,6 +247,10 @@ class Offset(Template):
     use_noise_prior = Bool(False, help="Use detector PSDs to build the noise prior and preconditioner")
     precond_width = Int(20, help="Preconditioner width in terms of offsets / baselines")
 
+    def __init__(self, **kwargs):
+        self._flag_cache = {}
+        super().__init__(**kwargs)
+
     def _step_length(self, stime, rate):
         return int(stime * rate + 0.5)
 
@@ -383,7 +387,7 @@ class Offset(Template):
             flag_data = np.copy(fd.data)
             flag_data |= (self.det_flag_mask * self._obs_view_flags[iob]).astype(np.uint8)
             if use_accel:
-                accel_data_create(flag_data, f"{self.name}_solver_flags")
+                accel_data_create(flag_data, f"{self.name}_solver_flags", owner=self)
                 accel_data_update_device(flag_data, f"{self.name}_solver_flags")
             self._flag_cache[key] = flag_data
         return self._flag_cache[key]
