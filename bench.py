@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-dets", type=int, default=32, help="detectors in the CPU baseline sample")
+    ap.add_argument("--no-arena", action="store_true", help="allocate every buffer separately (placement experiment)")
     ap.add_argument("--unfused", action="store_true", help="run noise_weight as its own kernel (105 B variant)")
     return ap.parse_args()
 
@@ -92,12 +93,50 @@ def main():
     idx = np.arange(n_det, dtype=np.int32)
     sflags_h = synth.shared_flags_block(n_samp, 0.01, value=1)
 
+    # Persistent buffers first, the big temporary (quaternions, 23.6 GB) last: HBM placement
+    # matters (buffers carved out of just-freed memory ran scan_map up to 15 % slower in
+    # tools/exp_scan_placement.py), so nothing long-lived is allocated after a large free.
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(20261001 + rank)
+    sigma = 50.0e-6 * np.sqrt(rate)
     d_bore = torch.from_numpy(bore).to(dev)
     d_sflags = torch.from_numpy(sflags_h).to(dev)
-    d_quats = torch.empty((n_det, n_samp, 4), dtype=torch.float64, device=dev)
-    d_pixels = torch.empty((n_det, n_samp), dtype=torch.int64, device=dev)
-    d_weights = torch.empty((n_det, n_samp, 3), dtype=torch.float64, device=dev)
     d_hsub = torch.zeros(n_submap, dtype=torch.uint8, device=dev)
+
+    # One arena for every persistent TOD-domain buffer, allocated first on the fresh device and
+    # carved at 2 MiB boundaries (the reference's OmpPoolResource idea,
+    # src/toast/_libtoast/accelerator.hpp:33-71): one large early allocation gets the most
+    # contiguous physical backing.
+    def _align(n):
+        return (n + (1 << 21) - 1) & ~((1 << 21) - 1)
+
+    nds = n_det * n_samp
+    sizes = {"pixels": nds * 8, "weights": nds * 24, "tod": nds * 8, "tod2": nds * 8, "dflags": nds}
+    if args.no_arena:
+        arena = None
+    else:
+        arena = torch.empty(sum(_align(v) for v in sizes.values()), dtype=torch.uint8, device=dev)
+    cursor = [0]
+
+    def carve(name, dtype, shape):
+        if arena is None:
+            return torch.empty(shape, dtype=dtype, device=dev)
+        nb = sizes[name]
+        view = arena[cursor[0]:cursor[0] + nb].view(dtype).view(shape)
+        cursor[0] += _align(nb)
+        return view
+
+    d_pixels = carve("pixels", torch.int64, (n_det, n_samp))
+    d_weights = carve("weights", torch.float64, (n_det, n_samp, 3))
+    d_tod = carve("tod", torch.float64, (n_det, n_samp))
+    d_tod2 = carve("tod2", torch.float64, (n_det, n_samp))
+    d_dflags = carve("dflags", torch.uint8, (n_det, n_samp))
+    d_tod.normal_(0.0, sigma, generator=gen)
+    d_tod2.normal_(0.0, sigma, generator=gen)
+    for d0 in range(0, n_det, 128):  # bounded temporaries
+        blk = d_dflags[d0:d0 + 128]
+        blk.copy_((torch.rand(blk.shape, device=dev, generator=gen) < 0.005).to(torch.uint8))
+    d_quats = torch.empty((n_det, n_samp, 4), dtype=torch.float64, device=dev)
 
     def timed(fn, reps=1):
         e0 = torch.cuda.Event(enable_timing=True)
@@ -122,7 +161,6 @@ def main():
     sw_call()
     t_sw = timed(sw_call, 2)
     del d_quats
-    torch.cuda.empty_cache()
 
     # union of hit submaps over ranks -> one global2local for everybody
     hs = d_hsub.to(torch.int32)
@@ -132,12 +170,6 @@ def main():
     n_local = int(hit.size)
     d_g2l = torch.from_numpy(g2l_h).to(dev)
     d_zmap = torch.zeros((n_local, nps, nnz), dtype=torch.float64, device=dev)
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(20261001 + rank)
-    sigma = 50.0e-6 * np.sqrt(rate)
-    d_tod = torch.randn((n_det, n_samp), dtype=torch.float64, device=dev, generator=gen) * sigma
-    d_tod2 = torch.randn((n_det, n_samp), dtype=torch.float64, device=dev, generator=gen) * sigma
-    d_dflags = (torch.rand((n_det, n_samp), device=dev, generator=gen) < 0.005).to(torch.uint8)
     # packed upper-triangle "covariance": diagonally dominant, O(1)
     d_cov = torch.rand((n_local, nps, 6), dtype=torch.float64, device=dev, generator=gen) * 0.1
     d_cov[..., 0] += 1.0

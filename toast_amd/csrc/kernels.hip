@@ -178,8 +178,10 @@ __global__ __launch_bounds__(kThreads) void k_scan_map(
     const int64_t * __restrict__ g2l, const T * __restrict__ map, double * __restrict__ tod,
     const int64_t * __restrict__ pixels, const double * __restrict__ weights, int nnz_rt,
     FastDiv nps_div, double scale, int zero, int subtract, int mult,
-    const double * __restrict__ det_w, int64_t n_samp) {
-    const int det = blockIdx.x;
+    const double * __restrict__ det_w, int64_t n_samp, int det_major) {
+    const int det = det_major ? blockIdx.y : blockIdx.x;
+    const int ci0 = det_major ? blockIdx.x : blockIdx.y;
+    const int cstride = det_major ? gridDim.x : gridDim.y;
     const int nnz = (NNZ > 0) ? NNZ : nnz_rt;
     double * drow = tod + (int64_t)d_idx[det] * n_samp;
     const int64_t * prow = pixels + (int64_t)p_idx[det] * n_samp;
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(kThreads) void k_scan_map(
     const bool fuse = det_w != nullptr;
     const double dw = fuse ? det_w[det] : 1.0;
     const int64_t nps = nps_div.d;
-    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+    for (int ci = ci0; ci < n_chunks; ci += cstride) {
         const Chunk c = chunks[ci];
         for (int i = threadIdx.x; i < c.count; i += kThreads) {
             const int64_t s = c.first + i;
@@ -256,15 +258,17 @@ __global__ __launch_bounds__(kThreads) void k_build_noise_weighted(
     const int64_t * __restrict__ pixels, const double * __restrict__ weights,
     const double * __restrict__ tod, const uint8_t * __restrict__ dflags, uint8_t dmask,
     int use_dflags, const uint8_t * __restrict__ sflags, uint8_t smask, int use_sflags,
-    FastDiv nps_div, int64_t n_samp) {
-    const int det = blockIdx.x;
+    FastDiv nps_div, int64_t n_samp, int det_major) {
+    const int det = det_major ? blockIdx.y : blockIdx.x;
+    const int ci0 = det_major ? blockIdx.x : blockIdx.y;
+    const int cstride = det_major ? gridDim.x : gridDim.y;
     const int64_t * prow = pixels + (int64_t)p_idx[det] * n_samp;
     const double * wrow = weights + (int64_t)w_idx[det] * n_samp * NNZ;
     const double * drow = tod + (int64_t)d_idx[det] * n_samp;
     const uint8_t * frow = use_dflags ? dflags + (int64_t)f_idx[det] * n_samp : nullptr;
     const double ds = det_scale[det];
     const int64_t nps = nps_div.d;
-    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+    for (int ci = ci0; ci < n_chunks; ci += cstride) {
         const Chunk c = chunks[ci];
         for (int base = 0; base < c.count; base += kThreads) {
             const int i = base + threadIdx.x;
@@ -678,15 +682,17 @@ void launch_scan_map(dim3 grid, hipStream_t st, const Chunk * ch, int n_ch, cons
                      double scale, int zero, int sub, int mult, const double * det_w,
                      int64_t n_samp) {
     const T * m = static_cast<const T *>(map);
+    const int dm = det_major_grid() ? 1 : 0;
+    if (dm) grid = dim3(grid.y, grid.x, 1);
     if (nnz == 3) {
         hipLaunchKernelGGL((k_scan_map<T, 3>), grid, dim3(kThreads), 0, st, ch, n_ch, di, pi, wi, g2l,
-                           m, tod, pix, w, nnz, dv, scale, zero, sub, mult, det_w, n_samp);
+                           m, tod, pix, w, nnz, dv, scale, zero, sub, mult, det_w, n_samp, dm);
     } else if (nnz == 1) {
         hipLaunchKernelGGL((k_scan_map<T, 1>), grid, dim3(kThreads), 0, st, ch, n_ch, di, pi, wi, g2l,
-                           m, tod, pix, w, nnz, dv, scale, zero, sub, mult, det_w, n_samp);
+                           m, tod, pix, w, nnz, dv, scale, zero, sub, mult, det_w, n_samp, dm);
     } else {
         hipLaunchKernelGGL((k_scan_map<T, 0>), grid, dim3(kThreads), 0, st, ch, n_ch, di, pi, wi, g2l,
-                           m, tod, pix, w, nnz, dv, scale, zero, sub, mult, det_w, n_samp);
+                           m, tod, pix, w, nnz, dv, scale, zero, sub, mult, det_w, n_samp, dm);
     }
 }
 
@@ -918,12 +924,14 @@ int toast_hip_build_noise_weighted_dev(
         (const int32_t *)(d + o_wi), (const int32_t *)(d + o_di), (const int32_t *)(d + o_fi),    \
         (const double *)(d + o_ds), d_g2l, d_zmap, d_pixels, d_weights, d_det_data, d_det_flags,  \
         det_flag_mask, use_d, d_shared_flags, shared_flag_mask, use_s, dv, n_samp
+        const int dm = det_major_grid() ? 1 : 0;
+        const dim3 g2 = dm ? dim3(grid.y, grid.x, 1) : grid;
         if (nnz == 3) {
-            hipLaunchKernelGGL(k_build_noise_weighted<3>, grid, dim3(kThreads), 0, st, TH_BNW_ARGS);
+            hipLaunchKernelGGL(k_build_noise_weighted<3>, g2, dim3(kThreads), 0, st, TH_BNW_ARGS, dm);
         } else if (nnz == 1) {
-            hipLaunchKernelGGL(k_build_noise_weighted<1>, grid, dim3(kThreads), 0, st, TH_BNW_ARGS);
+            hipLaunchKernelGGL(k_build_noise_weighted<1>, g2, dim3(kThreads), 0, st, TH_BNW_ARGS, dm);
         } else if (nnz == 2) {
-            hipLaunchKernelGGL(k_build_noise_weighted<2>, grid, dim3(kThreads), 0, st, TH_BNW_ARGS);
+            hipLaunchKernelGGL(k_build_noise_weighted<2>, g2, dim3(kThreads), 0, st, TH_BNW_ARGS, dm);
         } else {
             hipLaunchKernelGGL(k_build_noise_weighted_any, grid, dim3(kThreads), 0, st, TH_BNW_ARGS,
                                (int)nnz);

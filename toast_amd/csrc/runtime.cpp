@@ -3,6 +3,7 @@
 #include "runtime.hpp"
 
 #include <cstdio>
+#include <cstdlib>
 #include <list>
 #include <mutex>
 
@@ -17,8 +18,28 @@ void set_last_error(const std::string & msg) { g_last_error = msg; }
 [[noreturn]] void fail_arg(const std::string & msg) { throw Error(TOAST_HIP_ERR_ARG, msg); }
 
 // ------------------------------------------------------------------ chunks
+int chunk_size() {
+    // Tuning knob for experiments (profiles/): samples per workgroup, default kChunk.
+    static const int v = [] {
+        const char * e = std::getenv("TOAST_HIP_CHUNK");
+        const int c = e ? std::atoi(e) : 0;
+        return (c >= 64 && c <= (1 << 20)) ? c : kChunk;
+    }();
+    return v;
+}
+
+bool det_major_grid() {
+    // Experiment switch: detector-major instead of time-major workgroup order.
+    static const bool v = [] {
+        const char * e = std::getenv("TOAST_HIP_DET_MAJOR");
+        return e && e[0] == '1';
+    }();
+    return v;
+}
+
 std::vector<Chunk> make_chunks(const toast_hip_interval * ivl, int64_t n_view, int64_t n_samp) {
     std::vector<Chunk> out;
+    const int64_t kc = chunk_size();
     for (int64_t v = 0; v < n_view; ++v) {
         const int64_t first = ivl[v].first;
         const int64_t last = ivl[v].last;
@@ -28,8 +49,8 @@ std::vector<Chunk> make_chunks(const toast_hip_interval * ivl, int64_t n_view, i
               << n_samp << " samples of the buffers";
             fail_arg(o.str());
         }
-        for (int64_t s = first; s < last; s += kChunk) {
-            const int64_t n = (last - s < kChunk) ? (last - s) : kChunk;
+        for (int64_t s = first; s < last; s += kc) {
+            const int64_t n = (last - s < kc) ? (last - s) : kc;
             out.push_back(Chunk{s, (int32_t)n, (int32_t)v});
         }
     }

@@ -85,6 +85,8 @@ private:
     std::vector<char> host_;
 };
 
+int chunk_size();
+bool det_major_grid();
 std::vector<Chunk> make_chunks(const toast_hip_interval * ivl, int64_t n_view, int64_t n_samp);
 
 // ------------------------------------------------------------------ memory manager
