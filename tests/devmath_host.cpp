@@ -16,11 +16,10 @@ void devmath_atan2(int64_t n, const double * y, const double * x, double * out) 
 void devmath_pixels(int64_t n, const double * quats, int64_t nside, int nest, int64_t * pix) {
     int factor = 0;
     while (nside != (int64_t(1) << factor)) ++factor;
-    const double zaxis[3] = {0.0, 0.0, 1.0};
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) {
         double dir[3];
-        quat_rotate(quats + 4 * i, zaxis, dir);
+        quat_rotate_z(quats + 4 * i, dir);
         const ZPhi a = zphi_from_vec(dir, kAtanTab);
         pix[i] = nest ? zphi_to_nest(nside, factor, a) : zphi_to_ring(nside, factor, a);
     }
@@ -33,6 +32,26 @@ void devmath_vec2pix(int64_t n, const double * vec, int64_t nside, int nest, int
     for (int64_t i = 0; i < n; ++i) {
         const ZPhi a = zphi_from_vec(vec + 3 * i, kAtanTab);
         pix[i] = nest ? zphi_to_nest(nside, factor, a) : zphi_to_ring(nside, factor, a);
+    }
+}
+
+void devmath_stokes(int64_t n, const double * quats, double * c2a, double * s2a) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) stokes_cs2alpha(quats + 4 * i, c2a[i], s2a[i]);
+}
+
+void devmath_recip(int64_t n, const double * b, double * out) {
+    for (int64_t i = 0; i < n; ++i) out[i] = recip_newton(b[i]);
+}
+
+// the correctly rounded phi / (2 pi) used by phi_to_tt, exposed through its effect: returns
+// the intermediate quotient
+void devmath_div_twopi(int64_t n, const double * phi, double * out) {
+    const double period = TOAST_TWOPI;
+    const double inv = 1.0 / TOAST_TWOPI;
+    for (int64_t i = 0; i < n; ++i) {
+        const double q0 = phi[i] * inv;
+        out[i] = (q0 == 0.0) ? q0 : f_fma(f_fma(-q0, period, phi[i]), inv, q0);
     }
 }
 

@@ -96,3 +96,42 @@ def test_fastdiv(devmath):
         q = np.empty_like(num)
         devmath.devmath_fastdiv(C.c_int64(num.size), _p(num), C.c_int64(d), _p(q))
         assert np.array_equal(q, num // d), d
+
+
+def test_recip_and_division_by_two_pi(devmath, oracle):
+    rng = np.random.default_rng(7)
+    n = 4_000_000
+    b = np.concatenate([rng.random(n) + 1e-3, 10.0 ** rng.uniform(-30, 30, n)])
+    out = np.empty_like(b)
+    devmath.devmath_recip(C.c_int64(b.size), _p(b), _p(out))
+    err = np.abs(out * b - 1.0)
+    assert err.max() < 4.5e-16  # ~1 ulp reciprocal
+    # phi / (2 pi): Markstein sequence == IEEE division, bit for bit
+    phi = np.concatenate([(rng.random(n) - 0.5) * 2 * np.pi, rng.standard_normal(n) * 1e-8,
+                          np.array([0.0, -0.0, np.pi, -np.pi, np.pi / 2, 2 * np.pi, 1e-300, 3.0])])
+    q = np.empty_like(phi)
+    devmath.devmath_div_twopi(C.c_int64(phi.size), _p(phi), _p(q))
+    want = oracle.ieee_div(phi, np.full(phi.size, 2 * np.pi))
+    assert np.array_equal(q.view(np.int64), want.view(np.int64))
+
+
+def test_algebraic_stokes_weights_vs_oracle(devmath, oracle):
+    """cos 2a / sin 2a without atan2 / sincos: within 1e-14 of the reference formulation for
+    scan-like and random quaternions (the weights are a tolerance-class output)."""
+    rng = np.random.default_rng(9)
+    n = 2_000_000
+    bore = synth.satellite_boresight(n // 2, 100.0)
+    fp, _ = synth.hex_focalplane(2)
+    q = np.concatenate([synth.quat_normalize(rng.standard_normal((n // 2, 4))), synth.quat_mult(bore, fp[1])])
+    q = np.ascontiguousarray(q)
+    c2a = np.empty(n)
+    s2a = np.empty(n)
+    devmath.devmath_stokes(C.c_int64(n), _p(q), _p(c2a), _p(s2a))
+    w = np.zeros((1, n, 3))
+    iv = np.zeros(1, oracle.interval_dtype)
+    iv["last"] = n
+    z1 = np.zeros(1)
+    oracle.stokes_weights_IQU(np.zeros(1, np.int32), q.reshape(1, n, 4), np.zeros(1, np.int32), w, np.zeros(1), iv,
+                              z1, z1, np.ones(1), False)
+    assert np.max(np.abs(w[0, :, 1] - c2a)) < 1e-14
+    assert np.max(np.abs(w[0, :, 2] - s2a)) < 1e-14

@@ -82,9 +82,35 @@ TOAST_HD dd dd_add(dd a, dd b) {
 
 TOAST_HD dd dd_sub(dd a, dd b) { return dd_add(a, dd{-b.hi, -b.lo}); }
 
-// a / b with one IEEE reciprocal and fma residuals (~2^-100 relative).
+// a + b when |a.hi| >= |b.hi| is known (3 additions fewer).
+TOAST_HD dd dd_add_ordered(dd a, dd b) {
+    dd s = quick_two_sum(a.hi, b.hi);
+    s.lo += a.lo + b.lo;
+    return quick_two_sum(s.hi, s.lo);
+}
+
+// 1/b to ~1 ulp for normal positive b without the IEEE division sequence: integer-seeded
+// Newton iteration.  Only + * fma and an integer subtract, so host and device agree bit for
+// bit.  (An IEEE f64 divide costs ~35 instructions on gfx950, this is 12.)
+TOAST_HD double recip_newton(double b) {
+    union {
+        double d;
+        int64_t i;
+    } u;
+    u.d = b;
+    u.i = 0x7FDE623822FC16E6ll - u.i;  // ~ 1/b within 12 %
+    double r = u.d;
+    r = r * f_fma(-b, r, 2.0);  // error 1.4e-2
+    r = r * f_fma(-b, r, 2.0);  // 2e-4
+    r = r * f_fma(-b, r, 2.0);  // 4e-8
+    r = r * f_fma(-b, r, 2.0);  // 2e-15
+    r = f_fma(r, f_fma(-b, r, 1.0), r);  // ~1 ulp
+    return r;
+}
+
+// a / b with a ~1 ulp reciprocal and fma residuals (~2^-100 relative); b.hi > 0, normal.
 TOAST_HD dd dd_div(dd a, dd b) {
-    const double r = 1.0 / b.hi;
+    const double r = recip_newton(b.hi);
     const double q = a.hi * r;
     const double e = f_fma(-q, b.hi, a.hi);
     const double ql = ((e + a.lo) - q * b.lo) * r;
@@ -114,9 +140,10 @@ TOAST_HD double atan2_dd(double y, double x, const double * tab) {
         if (i != 0) {
             // u = (t - c) / (1 + t c); t.hi - c is exact because |t - c| <= 1/64 <= c/2
             const double c = (double)i * 0.03125;
-            const dd num = two_sum(t.hi - c, t.lo);
+            // |t.hi - c| is 0 or >= ulp(t.hi)/2 >= |t.lo|;  1 >= t c
+            const dd num = quick_two_sum(t.hi - c, t.lo);
             const dd tc = two_prod(t.hi, c);
-            dd den = two_sum(1.0, tc.hi);
+            dd den = quick_two_sum(1.0, tc.hi);
             den.lo += tc.lo + t.lo * c;
             u = dd_div(num, den);
         }
@@ -129,10 +156,12 @@ TOAST_HD double atan2_dd(double y, double x, const double * tab) {
         p = f_fma(p, s, -1.0 / 3.0);
         p = p * s;
         const dd au = quick_two_sum(u.hi, u.lo + u.hi * p);
-        a = dd_add(dd{tab[2 * i], tab[2 * i + 1]}, au);
+        // atan(i/32) >= 1/32 > |au| for i >= 1; the table entry is exactly 0 for i == 0
+        a = (i == 0) ? au : dd_add_ordered(dd{tab[2 * i], tab[2 * i + 1]}, au);
     }
-    if (swap) a = dd_sub(dd{kHalfPi_HI, kHalfPi_LO}, a);
-    if (xneg) a = dd_sub(dd{kPi_HI, kPi_LO}, a);
+    // pi/2 and pi dominate a (a <= pi/4 resp. <= pi/2)
+    if (swap) a = dd_add_ordered(dd{kHalfPi_HI, kHalfPi_LO}, dd{-a.hi, -a.lo});
+    if (xneg) a = dd_add_ordered(dd{kPi_HI, kPi_LO}, dd{-a.hi, -a.lo});
     const double r = a.hi + a.lo;
     return yneg ? -r : r;
 }
@@ -146,6 +175,18 @@ TOAST_HD void quat_rotate(const double * q, const double * v, double * out) {
     out[0] = 2 * ((y2 + z2) * v[0] + (xy - zw) * v[1] + (yw + xz) * v[2]) + v[0];
     out[1] = 2 * ((zw + xy) * v[0] + (x2 + z2) * v[1] + (yz - xw) * v[2]) + v[1];
     out[2] = 2 * ((xz - yw) * v[0] + (xw + yz) * v[1] + (x2 + y2) * v[2]) + v[2];
+}
+
+// quat_rotate(q, (0,0,1)) for finite q, bit-identical to the general form: the reference's
+// `(..) * 0.0` terms only contribute signed zeros, which vanish against a non-zero third term,
+// and `+ 0.0` reproduces the sign of a zero result (x + (+0) == +0 for x == -0).
+TOAST_HD void quat_rotate_z(const double * q, double * out) {
+    const double xw = q[3] * q[0], yw = q[3] * q[1];
+    const double x2 = -q[0] * q[0], xz = q[0] * q[2];
+    const double y2 = -q[1] * q[1], yz = q[1] * q[2];
+    out[0] = 2 * (yw + xz) + 0.0;
+    out[1] = 2 * (yz - xw) + 0.0;
+    out[2] = 2 * (x2 + y2) + 1.0;
 }
 
 // r = p * q (scalar last), reference term order.
@@ -170,7 +211,8 @@ TOAST_HD ZPhi zphi_from_vec(const double * v, const double * atan_tab) {
     const double za = f_abs(o.z);
     const int s = (o.z > 0.0) ? 1 : -1;
     o.region = (za <= TOAST_TWOTHIRDS) ? s : s + s;
-    o.rtz = f_sqrt(3.0 * (1.0 - za));
+    // the reference always evaluates sqrt(3 (1 - |z|)) but reads it only in the polar caps
+    o.rtz = (o.region == 1 || o.region == -1) ? 0.0 : f_sqrt(3.0 * (1.0 - za));
     o.phi = atan2_dd(v[1], v[0], atan_tab);
     return o;
 }
@@ -178,7 +220,14 @@ TOAST_HD ZPhi zphi_from_vec(const double * v, const double * atan_tab) {
 TOAST_HD double phi_to_tt(double phi) {
     const double tol = 10.0 * 2.220446049250313e-16;
     const double period = TOAST_TWOPI;
-    const double div = phi / period;
+    // phi / period, correctly rounded without a divide (Markstein): y = RN(1/period),
+    // q0 = RN(phi y), r = phi - period q0 (exact by fma), q = RN(q0 + r y).  Exact IEEE quotient
+    // for every phi because the significand of period is not all ones; checked against the
+    // hardware / x86 division in tests (test_devmath_host.py, test_gpu_math.py).
+    const double inv = 1.0 / TOAST_TWOPI;
+    const double q0 = phi * inv;
+    // (q0 itself when it is a zero: keeps the sign of -0 / period)
+    const double div = (q0 == 0.0) ? q0 : f_fma(f_fma(-q0, period, phi), inv, q0);
     double pm = period * (div - (double)((int64_t)div));
     if ((pm < tol) && (pm > -tol)) pm = 0.0;
     return (pm >= 0.0) ? pm * TOAST_2_OVER_PI : pm * TOAST_2_OVER_PI + 4.0;
@@ -195,20 +244,45 @@ TOAST_HD uint64_t spread_bits(uint64_t v) {
     return v;
 }
 
-TOAST_HD int64_t zphi_to_nest(int64_t nside, int factor, const ZPhi & a) {
+// 16-bit variant for nside <= 8192 (x, y < 2^13): all-32-bit integer path
+TOAST_HD uint32_t spread_bits16(uint32_t v) {
+    v &= 0xffffu;
+    v = (v | (v << 8)) & 0x00ff00ffu;
+    v = (v | (v << 4)) & 0x0f0f0f0fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+
+template <typename I>
+TOAST_HD I morton_interleave(I x, I y);
+template <>
+TOAST_HD int64_t morton_interleave<int64_t>(int64_t x, int64_t y) {
+    return (int64_t)(spread_bits((uint64_t)x) | (spread_bits((uint64_t)y) << 1));
+}
+template <>
+TOAST_HD int32_t morton_interleave<int32_t>(int32_t x, int32_t y) {
+    return (int32_t)(spread_bits16((uint32_t)x) | (spread_bits16((uint32_t)y) << 1));
+}
+
+// Integer type I = int32_t is exact for nside <= 8192 (12 nside^2 < 2^31, every intermediate
+// below fits); int64_t is the general path.  f64 -> integer conversions truncate like the
+// reference's (int64_t) casts.
+template <typename I>
+TOAST_HD I zphi_to_nest_t(I nside, int factor, const ZPhi & a) {
     const double tt = phi_to_tt(a.phi);
     const double dn = (double)nside;
-    const int64_t nm1 = nside - 1;
-    int64_t x, y, face;
+    const I nm1 = nside - 1;
+    I x, y, face;
     if (a.region == 1 || a.region == -1) {
         const double t1 = 0.5 * dn + dn * tt;
         const double t2 = (0.75 * dn) * a.z;
-        const int64_t jp = (int64_t)(t1 - t2);
-        const int64_t jm = (int64_t)(t1 + t2);
-        const int64_t ifp = jp >> factor;
-        const int64_t ifm = jm >> factor;
+        const I jp = (I)(t1 - t2);
+        const I jm = (I)(t1 + t2);
+        const I ifp = jp >> factor;
+        const I ifm = jm >> factor;
         if (ifp == ifm) {
-            face = (ifp == 4) ? (int64_t)4 : ifp + 4;
+            face = (ifp == 4) ? (I)4 : ifp + 4;
         } else if (ifp < ifm) {
             face = ifp;
         } else {
@@ -217,11 +291,11 @@ TOAST_HD int64_t zphi_to_nest(int64_t nside, int factor, const ZPhi & a) {
         x = jm & nm1;
         y = nm1 - (jp & nm1);
     } else {
-        const int64_t ntt = (int64_t)tt;
+        const I ntt = (I)tt;
         const double tp = tt - (double)ntt;
         const double t1 = dn * a.rtz;
-        int64_t jp = (int64_t)(tp * t1);
-        int64_t jm = (int64_t)((1.0 - tp) * t1);
+        I jp = (I)(tp * t1);
+        I jm = (I)((1.0 - tp) * t1);
         if (jp >= nside) jp = nm1;
         if (jm >= nside) jm = nm1;
         if (a.z >= 0) {
@@ -234,56 +308,93 @@ TOAST_HD int64_t zphi_to_nest(int64_t nside, int factor, const ZPhi & a) {
             y = jm;
         }
     }
-    const int64_t sipf = (int64_t)(spread_bits((uint64_t)x) | (spread_bits((uint64_t)y) << 1));
-    return sipf + (face << (2 * factor));
+    return morton_interleave<I>(x, y) + (face << (2 * factor));
 }
 
-TOAST_HD int64_t zphi_to_ring(int64_t nside, int /*factor*/, const ZPhi & a) {
+template <typename I>
+TOAST_HD I zphi_to_ring_t(I nside, int /*factor*/, const ZPhi & a) {
     const double tt = phi_to_tt(a.phi);
     const double dn = (double)nside;
-    const int64_t n4 = 4 * nside;
+    const I n4 = 4 * nside;
     if (a.region == 1 || a.region == -1) {
-        const int64_t ncap = 2 * (nside * nside - nside);
+        const I ncap = 2 * (nside * nside - nside);
         const double t1 = 0.5 * dn + dn * tt;
         const double t2 = (0.75 * dn) * a.z;
-        const int64_t jp = (int64_t)(t1 - t2);
-        const int64_t jm = (int64_t)(t1 + t2);
-        const int64_t ir = (nside + 1) + jp - jm;
-        const int64_t kshift = 1 - (ir & 1);
-        int64_t ip = (jp + jm - nside + kshift + 1) >> 1;
+        const I jp = (I)(t1 - t2);
+        const I jm = (I)(t1 + t2);
+        const I ir = (nside + 1) + jp - jm;
+        const I kshift = 1 - (ir & 1);
+        I ip = (jp + jm - nside + kshift + 1) >> 1;
         // ip % (4 nside) with C truncation semantics; 4 nside is a power of two
         ip = (ip >= 0) ? (ip & (n4 - 1)) : -((-ip) & (n4 - 1));
         return ncap + ((ir - 1) * n4 + ip);
     }
     const double tp = tt - f_floor(tt);
     const double t1 = dn * a.rtz;
-    const int64_t jp = (int64_t)(tp * t1);
-    const int64_t jm = (int64_t)((1.0 - tp) * t1);
-    const int64_t ir = jp + jm + 1;
-    int64_t ip = (int64_t)(tt * (double)ir);
+    const I jp = (I)(tp * t1);
+    const I jm = (I)((1.0 - tp) * t1);
+    const I ir = jp + jm + 1;
+    I ip = (I)(tt * (double)ir);
     // longpart = ip / (4 ir); tt < 4 (+rounding) so the quotient is 0 or 1 (ip >= 0)
-    const int64_t four_ir = 4 * ir;
+    const I four_ir = 4 * ir;
     if (ip >= four_ir) ip -= (ip >= 2 * four_ir) ? ip / four_ir : 1;
-    const int64_t npix = 12 * nside * nside;
+    const I npix = 12 * nside * nside;
     return (a.region > 0) ? (2 * ir * (ir - 1) + ip) : (npix - 2 * ir * (ir + 1) + ip);
 }
 
-// Detector polarisation angle alpha; tolerance-class output (weights are compared with
-// rtol), so the device's libm (ocml) sin/cos/atan2 are used here.
-TOAST_HD double stokes_alpha(const double * q) {
-    const double xaxis[3] = {1.0, 0.0, 0.0};
-    const double zaxis[3] = {0.0, 0.0, 1.0};
+TOAST_HD int64_t zphi_to_nest(int64_t nside, int factor, const ZPhi & a) {
+    if (nside <= 8192) return (int64_t)zphi_to_nest_t<int32_t>((int32_t)nside, factor, a);
+    return zphi_to_nest_t<int64_t>(nside, factor, a);
+}
+
+TOAST_HD int64_t zphi_to_ring(int64_t nside, int factor, const ZPhi & a) {
+    if (nside <= 8192) return (int64_t)zphi_to_ring_t<int32_t>((int32_t)nside, factor, a);
+    return zphi_to_ring_t<int64_t>(nside, factor, a);
+}
+
+// quat_rotate(q, (1,0,0)) for finite q (same reasoning as quat_rotate_z).
+TOAST_HD void quat_rotate_x(const double * q, double * out) {
+    const double yw = q[3] * q[1], zw = q[3] * q[2];
+    const double xy = q[0] * q[1], xz = q[0] * q[2];
+    const double y2 = -q[1] * q[1], z2 = -q[2] * q[2];
+    out[0] = 2 * (y2 + z2) + 1.0;
+    out[1] = 2 * (zw + xy) + 0.0;
+    out[2] = 2 * (xz - yw) + 0.0;
+}
+
+// cos(2 alpha), sin(2 alpha) of the detector polarisation angle alpha of the reference
+// (ops_stokes_weights.cpp:50-75: alpha = atan2(alpha_y, alpha_x) with the meridian vector
+// built from cos / sin of atan2(vd1, vd0)), evaluated algebraically:
+//   cos(atan2(y, x)) = x / r,  sin(atan2(y, x)) = y / r,
+//   cos 2a = (ax^2 - ay^2) / (ax^2 + ay^2),  sin 2a = 2 ax ay / (ax^2 + ay^2)
+// i.e. one sqrt and two reciprocals instead of two atan2 and two sincos.  Weights are a
+// tolerance-class output (reference tests: assert_allclose), agreement ~1e-15 absolute.
+TOAST_HD void stokes_cs2alpha(const double * q, double & c2a, double & s2a) {
     double vd[3], vo[3];
-    quat_rotate(q, zaxis, vd);
-    quat_rotate(q, xaxis, vo);
-    const double ang_xy = atan2(vd[1], vd[0]);
-    const double vm_x = vd[2] * cos(ang_xy);
-    const double vm_y = vd[2] * sin(ang_xy);
+    quat_rotate_z(q, vd);
+    quat_rotate_x(q, vo);
+    const double r2 = vd[0] * vd[0] + vd[1] * vd[1];
+    double cxy = __builtin_signbit(vd[0]) ? -1.0 : 1.0;  // atan2(+-0, +-0) is 0 or pi
+    double sxy = 0.0;
+    if (r2 > 0.0) {
+        const double rinv = recip_newton(f_sqrt(r2));
+        cxy = vd[0] * rinv;
+        sxy = vd[1] * rinv;
+    }
+    const double vm_x = vd[2] * cxy;
+    const double vm_y = vd[2] * sxy;
     const double vm_z = -f_sqrt(1.0 - vd[2] * vd[2]);
-    const double alpha_y = (vd[0] * (vm_y * vo[2] - vm_z * vo[1]) - vd[1] * (vm_x * vo[2] - vm_z * vo[0]) +
-                            vd[2] * (vm_x * vo[1] - vm_y * vo[0]));
-    const double alpha_x = (vm_x * vo[0] + vm_y * vo[1] + vm_z * vo[2]);
-    return atan2(alpha_y, alpha_x);
+    const double ay = (vd[0] * (vm_y * vo[2] - vm_z * vo[1]) - vd[1] * (vm_x * vo[2] - vm_z * vo[0]) +
+                       vd[2] * (vm_x * vo[1] - vm_y * vo[0]));
+    const double ax = (vm_x * vo[0] + vm_y * vo[1] + vm_z * vo[2]);
+    const double n2 = ax * ax + ay * ay;
+    c2a = 1.0;  // alpha = atan2(0, 0) = 0
+    s2a = 0.0;
+    if (n2 > 0.0) {
+        const double ninv = recip_newton(n2);
+        c2a = (ax * ax - ay * ay) * ninv;
+        s2a = (2.0 * ax * ay) * ninv;
+    }
 }
 
 // ------------------------------------------------------------------ division by a run-time constant

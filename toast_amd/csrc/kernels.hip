@@ -83,7 +83,6 @@ __global__ __launch_bounds__(kThreads) void k_pixels_healpix(
     const double * qrow = quats + (int64_t)q_idx[det] * n_samp * 4;
     int64_t * prow = pixels + (int64_t)p_idx[det] * n_samp;
     const int lane = threadIdx.x & 63;
-    const double zaxis[3] = {0.0, 0.0, 1.0};
 
     for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
         const Chunk c = chunks[ci];
@@ -94,7 +93,7 @@ __global__ __launch_bounds__(kThreads) void k_pixels_healpix(
             const Quat q = load_quat(qrow + 4 * s);
             const double qa[4] = {q.x, q.y, q.z, q.w};
             double dir[3];
-            quat_rotate(qa, zaxis, dir);
+            quat_rotate_z(qa, dir);
             const ZPhi a = zphi_from_vec(dir, s_tab);
             int64_t pix = NEST ? zphi_to_nest(nside, factor, a) : zphi_to_ring(nside, factor, a);
             const bool flagged = use_flags && ((flags[s] & mask) != 0);
@@ -137,18 +136,23 @@ __global__ __launch_bounds__(kThreads) void k_stokes_iqu(
             const int64_t s = c.first + i;
             const Quat q = load_quat(qrow + 4 * s);
             const double qa[4] = {q.x, q.y, q.z, q.w};
-            const double alpha = stokes_alpha(qa);
+            double c2a, s2a;
+            stokes_cs2alpha(qa, c2a, s2a);
             double * w = wrow + 3 * s;
             if (HWP) {
-                const double ang = 2.0 * (2.0 * (gd - hwp[s]) - alpha);
+                // ang = 2 (2 (gamma - hwp) - alpha) = beta - 2 alpha
+                const double beta = 2.0 * (2.0 * (gd - hwp[s]));
+                double sb, cb;
+                sincos(beta, &sb, &cb);
+                const double cang = cb * c2a + sb * s2a;
+                const double sang = sb * c2a - cb * s2a;
                 w[0] = cd;
-                w[1] = cos(ang) * eta * cd;
-                w[2] = -sin(ang) * eta * cd * usign;
+                w[1] = cang * eta * cd;
+                w[2] = -sang * eta * cd * usign;
             } else {
-                const double ang = alpha * 2.0;
                 w[0] = cd;
-                w[1] = cos(ang) * eta * cd;
-                w[2] = sin(ang) * eta * cd * usign;
+                w[1] = c2a * eta * cd;
+                w[2] = s2a * eta * cd * usign;
             }
         }
     }
