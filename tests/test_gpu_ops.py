@@ -329,3 +329,38 @@ def test_noise_filter_operator():
     lo_before = np.abs(np.fft.rfft(sig[0]))[1:20].mean()
     lo_after = np.abs(np.fft.rfft(got[0]))[1:20].mean()
     assert lo_after < 0.1 * lo_before
+
+
+def test_workflow_sim_satellite_simple(oracle):
+    """BASELINE configs[0]: the simple satellite workflow (4 det x 10 min @100 Hz, Nside 64);
+    its hit count must equal the number of unflagged samples and its binned map must equal
+    the oracle's build_noise_weighted + cov_apply_diag on the same pointing."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "workflows",
+                        "sim_satellite_simple.py")
+    spec = importlib.util.spec_from_file_location("wf", path)
+    wf = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(wf)
+    data = wf.main(["--ndet", "4", "--minutes", "10", "--rate", "100", "--nside", "64", "--full-pointing"])
+    ob = data.obs[0]
+    dist = data["pixel_dist"]
+    sf = ob.shared[defaults.shared_flags].data
+    n_good = 0
+    for det in ob.local_detectors:
+        p = ob.detdata[defaults.pixels][det]
+        df = ob.detdata[defaults.det_flags][det]
+        n_good += np.count_nonzero((p >= 0) & ((df & defaults.det_mask_nonscience) == 0)
+                                   & ((sf & defaults.shared_mask_nonscience) == 0))
+    assert int(data["mapmaker_hits"].data.sum()) == n_good
+    idx = np.arange(len(ob.local_detectors), dtype=np.int32)
+    z = np.zeros((dist.n_local_submap, dist.n_pix_submap, 3))
+    detw = np.array([ob[defaults.noise_model].detector_weight(d) for d in ob.local_detectors])
+    oracle.build_noise_weighted(dist.global_submap_to_local, z, idx, ob.detdata[defaults.pixels].data, idx,
+                                ob.detdata[defaults.weights].data, idx, ob.detdata[defaults.det_data].data, idx,
+                                ob.detdata[defaults.det_flags].data, detw, defaults.det_mask_nonscience,
+                                ob.intervals[None].data, sf, defaults.shared_mask_nonscience)
+    oracle.cov_apply_diag(dist.n_local_submap, dist.n_pix_submap, 3, data["mapmaker_cov"].raw, z)
+    got = data["mapmaker_map"].data
+    assert np.max(np.abs(got - z)) < 1e-10 * np.max(np.abs(z))
