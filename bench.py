@@ -245,6 +245,18 @@ def main():
     }
     dom = max(cand, key=lambda k: cand[k][1])
     ach = cand[dom][0] / (cand[dom][1] * 1e-3) / 1e9
+    # HBM traffic per launch of the dominant kernel from the committed PMC profile of this same
+    # command (profiles/traffic_<workload>.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes,
+    # gfx950 FETCH correction calibrated in-run; profiles/README.md); null if not profiled.
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+    kname = {"build_noise_weighted": "k_build_noise_weighted<3>", "scan_map": "k_scan_map<double, 3>"}[dom]
+    if os.path.isfile(tpath) and not args.unfused:
+        try:
+            with open(tpath) as f:
+                traffic = json.load(f)["kernels"][kname]["hbm_bytes"]
+        except (KeyError, ValueError):
+            traffic = None
     roofline = {
         "bound": "hbm",
         "kernel": dom,
@@ -252,7 +264,9 @@ def main():
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": ach / HBM_PEAK_GBS,
-        "traffic": None,
+        "traffic": traffic,
+        "traffic_unit": "bytes per launch (rocprofv3 PMC, committed profile)",
+        "algorithmic_bytes_per_launch": cand[dom][0],
         "per_kernel_GBs": {k: cand[k][0] / (cand[k][1] * 1e-3) / 1e9 for k in cand},
         "iteration_GBs": (BYTES_BNW + BYTES_SCAN) * nsamp_tot / ((ms["bnw"] + ms["scan"]) * 1e-3) / 1e9,
     }

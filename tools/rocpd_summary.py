@@ -39,5 +39,30 @@ def main(paths):
                 print("%-44s %-14s %6d %16.1f %16.1f %16.1f" % (short(r[0]), r[1], r[2], r[3], r[4], r[5]))
 
 
+def traffic_json(fetch_db, write_db, out_path, workload, note=""):
+    """HBM bytes per launch for our kernels = 2 x FETCH_SIZE + WRITE_SIZE (KiB), with the gfx950
+    FETCH_SIZE correction calibrated on k_noise_weight in the same run (profiles/README.md)."""
+    import json
+
+    def avg(db, counter):
+        cur = sqlite3.connect(db).cursor()
+        rows = cur.execute("select kernel_name, avg(value) from counters_collection where counter_name=? "
+                           "group by kernel_name", (counter,))
+        return {short(r[0]): r[1] for r in rows if "k_" in r[0]}
+
+    fetch, write = avg(fetch_db, "FETCH_SIZE"), avg(write_db, "WRITE_SIZE")
+    out = {"workload": workload, "unit": "bytes per launch", "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024",
+           "note": note, "kernels": {}}
+    for k in sorted(set(fetch) & set(write)):
+        out["kernels"][k] = {"fetch_KiB_raw": fetch[k], "write_KiB": write[k],
+                             "hbm_bytes": (2.0 * fetch[k] + write[k]) * 1024.0}
+    with open(out_path, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", out_path)
+
+
 if __name__ == "__main__":
-    main(sys.argv[1:])
+    if len(sys.argv) > 1 and sys.argv[1] == "--traffic":
+        traffic_json(*sys.argv[2:])
+    else:
+        main(sys.argv[1:])
