@@ -332,6 +332,47 @@ int toast_hip_template_offset_project_signal_dev(
     double * d_amplitudes, const uint8_t * d_amplitude_flags, int64_t n_samp,
     const toast_hip_interval * intervals /*host*/, int64_t n_view, void * stream);
 
+/* Batched (all detectors in one launch) forms of the two per-detector offset kernels, and the
+ * fused left-hand side of the PCG for offset templates.  Extensions: the reference calls the
+ * per-detector bindings in a Python loop (src/toast/templates/offset/offset.py:727-881) and runs
+ * add_to_signal / build_noise_weighted / scan_map / noise_weight / project_signal as separate
+ * passes (src/toast/ops/mapmaker_solve.py:342-506).
+ *   offset_accumulate :   zmap += A^T N^-1 (M a)
+ *   offset_scan_project : a_out += M^T [ det_w (M a - A map) ]  over samples with clear flags
+ * amp_offsets[d] = first amplitude of detector d (Offset._det_start).  flag_index / d_flag_data
+ * may be NULL (no sample flags). */
+int toast_hip_template_offset_add_to_signal_multi_dev(
+    int64_t step_length, const int64_t * amp_offsets /*host*/, const int64_t * n_amp_views /*host*/,
+    const double * d_amplitudes, const uint8_t * d_amplitude_flags, const int32_t * data_index /*host*/,
+    int64_t n_det, double * d_det_data, int64_t n_samp, const toast_hip_interval * intervals /*host*/,
+    int64_t n_view, void * stream);
+
+int toast_hip_template_offset_project_signal_multi_dev(
+    const int32_t * data_index /*host*/, const double * d_det_data, const int32_t * flag_index /*host*/,
+    const uint8_t * d_flag_data, uint8_t flag_mask, int64_t step_length, const int64_t * amp_offsets /*host*/,
+    const int64_t * n_amp_views /*host*/, double * d_amplitudes, const uint8_t * d_amplitude_flags,
+    int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals /*host*/, int64_t n_view,
+    void * stream);
+
+int toast_hip_offset_accumulate_dev(
+    int64_t step_length, const int64_t * amp_offsets /*host*/, const int64_t * n_amp_views /*host*/,
+    const double * d_amplitudes, const uint8_t * d_amplitude_flags, const int64_t * d_global2local,
+    double * d_zmap, int64_t n_pix_submap, int64_t nnz, const int32_t * pixel_index /*host*/,
+    const int64_t * d_pixels, const int32_t * weight_index /*host*/, const double * d_weights,
+    const int32_t * flag_index /*host*/, const uint8_t * d_det_flags, int64_t n_flag_samp,
+    const double * det_scale /*host*/, uint8_t det_flag_mask, int64_t n_det, int64_t n_samp,
+    const toast_hip_interval * intervals /*host*/, int64_t n_view, const uint8_t * d_shared_flags,
+    int64_t n_shared_flags, uint8_t shared_flag_mask, void * stream);
+
+int toast_hip_offset_scan_project_dev(
+    int64_t step_length, const int64_t * amp_offsets /*host*/, const int64_t * n_amp_views /*host*/,
+    const double * d_amplitudes_in, double * d_amplitudes_out, const uint8_t * d_amplitude_flags,
+    const int64_t * d_global2local, const double * d_map, int64_t n_pix_submap, int64_t nnz,
+    const int32_t * pixel_index /*host*/, const int64_t * d_pixels, const int32_t * weight_index /*host*/,
+    const double * d_weights, const int32_t * flag_index /*host or NULL*/, const uint8_t * d_flag_data,
+    uint8_t flag_mask, const double * det_weights /*host*/, int64_t n_det, int64_t n_samp,
+    const toast_hip_interval * intervals /*host*/, int64_t n_view, void * stream);
+
 int toast_hip_template_offset_apply_diag_precond(
     const double * offset_var, const double * amp_in, const uint8_t * amplitude_flags,
     double * amp_out, int64_t n_amp, int use_accel);

@@ -364,3 +364,38 @@ def test_workflow_sim_satellite_simple(oracle):
     oracle.cov_apply_diag(dist.n_local_submap, dist.n_pix_submap, 3, data["mapmaker_cov"].raw, z)
     got = data["mapmaker_map"].data
     assert np.max(np.abs(got - z)) < 1e-10 * np.max(np.abs(z))
+
+
+def test_fused_lhs_equals_operator_sequence():
+    """The fused device-resident LHS (offset_accumulate + cov_apply + offset_scan_project, no
+    timestream buffer) must reproduce the reference operator sequence (TemplateMatrix, BinMap,
+    ScanMap, NoiseWeight, TemplateMatrix^T) on the same amplitudes."""
+    from toast_amd.templates import AmplitudesMap
+
+    results = {}
+    for fused in (False, True):
+        data, pix, sw, truth, sky = make_solver_setup(n_det=6, n_samp=9000)
+        ops.CovarianceAndHits(pixel_dist="dist", covariance="cov", pixel_pointing=pix, stokes_weights=sw,
+                              save_pointing=True).apply(data)
+        lhs_bin = ops.BinMap(pixel_dist="dist", covariance="cov", binned="lhs_bin", pixel_pointing=pix,
+                             stokes_weights=sw, full_pointing=True)
+        tmpl = Offset(step_time=7.3, noise_model=defaults.noise_model, name="baselines", good_fraction=0.2)
+        tmatrix = ops.TemplateMatrix(templates=[tmpl], amplitudes="amps_in", det_data="temp_LHS")
+        tmatrix.initialize(data)
+        amps = tmpl.zeros()
+        amps.local[:] = np.random.default_rng(3).standard_normal(amps.n_local)
+        data["amps_in"] = AmplitudesMap(baselines=amps)
+        data["lhs_out"] = data["amps_in"].duplicate()
+        data["lhs_out"].reset()
+        lhs = ops.SolverLHS(binning=lhs_bin, template_matrix=tmatrix, out="lhs_out", fused=fused)
+        assert lhs._can_fuse(data) == fused
+        lhs.apply(data)
+        first = data["lhs_out"]["baselines"].local.copy()
+        lhs.apply(data)  # second application: buffers are reused / reset correctly
+        assert np.array_equal(data["lhs_out"]["baselines"].local, first) or np.allclose(
+            data["lhs_out"]["baselines"].local, first, rtol=1e-12, atol=1e-12 * np.max(np.abs(first)))
+        results[fused] = first
+        assert np.array_equal(data["amps_in"]["baselines"].local, amps.local)  # input untouched
+    a, b = results[False], results[True]
+    assert np.max(np.abs(a)) > 0
+    assert np.max(np.abs(a - b)) < 1e-11 * np.max(np.abs(a))

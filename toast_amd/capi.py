@@ -488,6 +488,62 @@ class _Dev:
         _check(lib().toast_hip_template_offset_apply_diag_precond_dev(
             _p(d_offset_var), _p(d_amp_in), _p(d_amp_flags), _p(d_amp_out), _i64(n_amp), _p(stream)))
 
+    def offset_add_to_signal_multi(self, step_length, amp_offsets, n_amp_views, d_amplitudes, d_amplitude_flags,
+                                   data_index, d_det_data, n_samp, intervals, stream=0):
+        ao = self._small(amp_offsets, np.int64)
+        nv = self._small(n_amp_views, np.int64)
+        di = self._small(data_index, np.int32)
+        iv = self._small(intervals, interval_dtype)
+        _check(lib().toast_hip_template_offset_add_to_signal_multi_dev(
+            _i64(step_length), _p(ao), _p(nv), _p(d_amplitudes), _p(d_amplitude_flags), _p(di), _i64(di.size),
+            _p(d_det_data), _i64(n_samp), _p(iv), _i64(iv.size), _p(stream)))
+
+    def offset_project_signal_multi(self, data_index, d_det_data, flag_index, d_flag_data, flag_mask, step_length,
+                                    amp_offsets, n_amp_views, d_amplitudes, d_amplitude_flags, n_samp, intervals,
+                                    stream=0):
+        ao = self._small(amp_offsets, np.int64)
+        nv = self._small(n_amp_views, np.int64)
+        di = self._small(data_index, np.int32)
+        fi = None if flag_index is None else self._small(flag_index, np.int32)
+        iv = self._small(intervals, interval_dtype)
+        _check(lib().toast_hip_template_offset_project_signal_multi_dev(
+            _p(di), _p(d_det_data), _p(fi), _p(d_flag_data), _u8(flag_mask), _i64(step_length), _p(ao), _p(nv),
+            _p(d_amplitudes), _p(d_amplitude_flags), _i64(di.size), _i64(n_samp), _p(iv), _i64(iv.size),
+            _p(stream)))
+
+    def offset_accumulate(self, step_length, amp_offsets, n_amp_views, d_amplitudes, d_amplitude_flags, d_g2l,
+                          d_zmap, n_pix_submap, nnz, pixel_index, d_pixels, weight_index, d_weights, flag_index,
+                          d_det_flags, n_flag_samp, det_scale, det_flag_mask, n_samp, intervals, d_shared_flags,
+                          n_shared_flags, shared_flag_mask, stream=0):
+        ao = self._small(amp_offsets, np.int64)
+        nv = self._small(n_amp_views, np.int64)
+        pi = self._small(pixel_index, np.int32)
+        wi = self._small(weight_index, np.int32)
+        fi = self._small(flag_index, np.int32)
+        ds = self._small(det_scale, np.float64)
+        iv = self._small(intervals, interval_dtype)
+        _check(lib().toast_hip_offset_accumulate_dev(
+            _i64(step_length), _p(ao), _p(nv), _p(d_amplitudes), _p(d_amplitude_flags), _p(d_g2l), _p(d_zmap),
+            _i64(n_pix_submap), _i64(nnz), _p(pi), _p(d_pixels), _p(wi), _p(d_weights), _p(fi), _p(d_det_flags),
+            _i64(n_flag_samp), _p(ds), _u8(det_flag_mask), _i64(pi.size), _i64(n_samp), _p(iv), _i64(iv.size),
+            _p(d_shared_flags), _i64(n_shared_flags), _u8(shared_flag_mask), _p(stream)))
+
+    def offset_scan_project(self, step_length, amp_offsets, n_amp_views, d_amps_in, d_amps_out, d_amplitude_flags,
+                            d_g2l, d_map, n_pix_submap, nnz, pixel_index, d_pixels, weight_index, d_weights,
+                            flag_index, d_flag_data, flag_mask, det_weights, n_samp, intervals, stream=0):
+        ao = self._small(amp_offsets, np.int64)
+        nv = self._small(n_amp_views, np.int64)
+        pi = self._small(pixel_index, np.int32)
+        wi = self._small(weight_index, np.int32)
+        fi = None if flag_index is None else self._small(flag_index, np.int32)
+        dw = self._small(det_weights, np.float64)
+        iv = self._small(intervals, interval_dtype)
+        _check(lib().toast_hip_offset_scan_project_dev(
+            _i64(step_length), _p(ao), _p(nv), _p(d_amps_in), _p(d_amps_out), _p(d_amplitude_flags), _p(d_g2l),
+            _p(d_map), _i64(n_pix_submap), _i64(nnz), _p(pi), _p(d_pixels), _p(wi), _p(d_weights), _p(fi),
+            _p(d_flag_data), _u8(flag_mask), _p(dw), _i64(pi.size), _i64(n_samp), _p(iv), _i64(iv.size),
+            _p(stream)))
+
     def test_math(self, op, n, d_a, d_b, d_out, stream=0):
         _check(lib().toast_hip_test_math_dev(C.c_int(op), _i64(n), _p(d_a), _p(d_b), _p(d_out), _p(stream)))
 

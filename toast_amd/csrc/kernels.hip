@@ -566,9 +566,12 @@ __global__ __launch_bounds__(kThreads) void k_cov_apply_diag(int64_t n_px, const
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void k_offset_add_to_signal(
     const Chunk * __restrict__ chunks, int n_chunks, const int64_t * __restrict__ view_first,
-    const int64_t * __restrict__ view_aoff, FastDiv step_div, int64_t amp_offset,
-    const double * __restrict__ amps, const uint8_t * __restrict__ amp_flags,
-    double * __restrict__ drow) {
+    const int64_t * __restrict__ view_aoff, FastDiv step_div, const int64_t * __restrict__ amp_offsets,
+    const int32_t * __restrict__ d_idx, const double * __restrict__ amps,
+    const uint8_t * __restrict__ amp_flags, double * __restrict__ tod, int64_t n_samp) {
+    const int det = blockIdx.x;
+    double * drow = tod + (int64_t)d_idx[det] * n_samp;
+    const int64_t amp_offset = amp_offsets[det];
     for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
         const Chunk c = chunks[ci];
         const int64_t vfirst = view_first[c.view];
@@ -583,10 +586,14 @@ __global__ __launch_bounds__(kThreads) void k_offset_add_to_signal(
 
 __global__ __launch_bounds__(kThreads) void k_offset_project_signal(
     const Chunk * __restrict__ chunks, int n_chunks, const int64_t * __restrict__ view_first,
-    const int64_t * __restrict__ view_aoff, FastDiv step_div, int64_t amp_offset,
-    double * __restrict__ amps, const uint8_t * __restrict__ amp_flags,
-    const double * __restrict__ drow, const uint8_t * __restrict__ frow, uint8_t fmask,
-    int use_flags) {
+    const int64_t * __restrict__ view_aoff, FastDiv step_div, const int64_t * __restrict__ amp_offsets,
+    const int32_t * __restrict__ d_idx, const int32_t * __restrict__ f_idx, double * __restrict__ amps,
+    const uint8_t * __restrict__ amp_flags, const double * __restrict__ tod,
+    const uint8_t * __restrict__ flags, uint8_t fmask, int use_flags, int64_t n_samp) {
+    const int det = blockIdx.x;
+    const double * drow = tod + (int64_t)d_idx[det] * n_samp;
+    const uint8_t * frow = use_flags ? flags + (int64_t)f_idx[det] * n_samp : nullptr;
+    const int64_t amp_offset = amp_offsets[det];
     for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
         const Chunk c = chunks[ci];
         const int64_t vfirst = view_first[c.view];
@@ -607,6 +614,131 @@ __global__ __launch_bounds__(kThreads) void k_offset_project_signal(
             }
             const bool tail = wave_run_reduce<1>(key, v);
             if (tail && key >= 0) unsafeAtomicAdd(amps + key, v[0]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Fused PCG left-hand side for offset templates (SolverLHS, src/toast/ops/mapmaker_solve.py:
+// 342-506, with the Offset template kernels template_offset.cpp:93-120 / :243-290):
+//
+//   k_offset_accumulate :  zmap += A^T N^-1 (M a)          == add_to_signal + build_noise_weighted
+//   k_offset_scan_project: a_out += M^T N^-1 (M a - A z)   == add_to_signal + scan_map(subtract)
+//                                                              + noise_weight + project_signal
+//
+// The timestream M a is never materialised: 33 B per det-sample per kernel (pixel 8 + weights
+// 24 + flag 1) instead of 8 + 41 and 8 + 48 + 9 in the reference's operator sequence.  Per
+// sample the arithmetic is the same as in the unfused kernels.
+// ------------------------------------------------------------------------------------
+template <int NNZ>
+__global__ __launch_bounds__(kThreads) void k_offset_accumulate(
+    const Chunk * __restrict__ chunks, int n_chunks, const int64_t * __restrict__ view_first,
+    const int64_t * __restrict__ view_aoff, FastDiv step_div, const int64_t * __restrict__ amp_offsets,
+    const double * __restrict__ amps, const uint8_t * __restrict__ amp_flags,
+    const int32_t * __restrict__ p_idx, const int32_t * __restrict__ w_idx,
+    const int32_t * __restrict__ f_idx, const double * __restrict__ det_scale,
+    const int64_t * __restrict__ g2l, double * __restrict__ zmap, const int64_t * __restrict__ pixels,
+    const double * __restrict__ weights, const uint8_t * __restrict__ dflags, uint8_t dmask,
+    int use_dflags, const uint8_t * __restrict__ sflags, uint8_t smask, int use_sflags,
+    FastDiv nps_div, int64_t n_samp) {
+    const int det = blockIdx.x;
+    const int64_t * prow = pixels + (int64_t)p_idx[det] * n_samp;
+    const double * wrow = weights + (int64_t)w_idx[det] * n_samp * NNZ;
+    const uint8_t * frow = use_dflags ? dflags + (int64_t)f_idx[det] * n_samp : nullptr;
+    const double ds = det_scale[det];
+    const int64_t nps = nps_div.d;
+    const int64_t amp_offset = amp_offsets[det];
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        const int64_t vfirst = view_first[c.view];
+        const int64_t abase = amp_offset + view_aoff[c.view];
+        for (int base = 0; base < c.count; base += kThreads) {
+            const int i = base + threadIdx.x;
+            const bool active = i < c.count;
+            const int64_t s = c.first + (active ? i : 0);
+            int64_t key = -1;
+            double v[NNZ];
+#pragma unroll
+            for (int k = 0; k < NNZ; ++k) v[k] = 0.0;
+            if (active) {
+                const int64_t p = prow[s];
+                bool good = p >= 0;
+                if (use_dflags) good = good && ((frow[s] & dmask) == 0);
+                if (use_sflags) good = good && ((sflags[s] & smask) == 0);
+                if (good) {
+                    const int64_t gsm = fastdiv(p, nps_div);
+                    key = g2l[gsm] * nps + (p - gsm * nps);
+                    const int64_t a = abase + fastdiv(s - vfirst, step_div);
+                    // tod = 0 + amplitude (unflagged amplitudes only), then * det_scale
+                    const double t = (amp_flags[a] == 0) ? (0.0 + amps[a]) : 0.0;
+                    const double sd = t * ds;
+                    const double * w = wrow + NNZ * s;
+#pragma unroll
+                    for (int k = 0; k < NNZ; ++k) v[k] = sd * w[k];
+                }
+            }
+            const bool tail = wave_run_reduce<NNZ>(key, v);
+            if (tail && key >= 0) {
+                double * z = zmap + NNZ * key;
+#pragma unroll
+                for (int k = 0; k < NNZ; ++k) unsafeAtomicAdd(z + k, v[k]);
+            }
+        }
+    }
+}
+
+template <int NNZ>
+__global__ __launch_bounds__(kThreads) void k_offset_scan_project(
+    const Chunk * __restrict__ chunks, int n_chunks, const int64_t * __restrict__ view_first,
+    const int64_t * __restrict__ view_aoff, FastDiv step_div, const int64_t * __restrict__ amp_offsets,
+    const double * __restrict__ amps_in, double * __restrict__ amps_out,
+    const uint8_t * __restrict__ amp_flags, const int32_t * __restrict__ p_idx,
+    const int32_t * __restrict__ w_idx, const int32_t * __restrict__ f_idx,
+    const double * __restrict__ det_w, const int64_t * __restrict__ g2l,
+    const double * __restrict__ map, const int64_t * __restrict__ pixels,
+    const double * __restrict__ weights, const uint8_t * __restrict__ flags, uint8_t fmask,
+    int use_flags, FastDiv nps_div, int64_t n_samp) {
+    const int det = blockIdx.x;
+    const int64_t * prow = pixels + (int64_t)p_idx[det] * n_samp;
+    const double * wrow = weights + (int64_t)w_idx[det] * n_samp * NNZ;
+    const uint8_t * frow = use_flags ? flags + (int64_t)f_idx[det] * n_samp : nullptr;
+    const double dw = det_w[det];
+    const int64_t nps = nps_div.d;
+    const int64_t amp_offset = amp_offsets[det];
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        const int64_t vfirst = view_first[c.view];
+        const int64_t abase = amp_offset + view_aoff[c.view];
+        for (int base = 0; base < c.count; base += kThreads) {
+            const int i = base + threadIdx.x;
+            const bool active = i < c.count;
+            int64_t key = -1;
+            double v[1] = {0.0};
+            if (active) {
+                const int64_t s = c.first + i;
+                const int64_t a = abase + fastdiv(s - vfirst, step_div);
+                if (amp_flags[a] == 0) {
+                    key = a;
+                    const bool bad = use_flags && ((frow[s] & fmask) != 0);
+                    if (!bad) {
+                        double d = 0.0 + amps_in[a];
+                        const int64_t p = prow[s];
+                        if (p >= 0) {
+                            const int64_t gsm = fastdiv(p, nps_div);
+                            const double * m = map + NNZ * (g2l[gsm] * nps + (p - gsm * nps));
+                            const double * w = wrow + NNZ * s;
+                            double sc = 0.0;
+#pragma unroll
+                            for (int k = 0; k < NNZ; ++k) sc += w[k] * m[k];
+                            sc *= 1.0;
+                            d -= sc;
+                        }
+                        v[0] = d * dw;
+                    }
+                }
+            }
+            const bool tail = wave_run_reduce<1>(key, v);
+            if (tail && key >= 0) unsafeAtomicAdd(amps_out + key, v[0]);
         }
     }
 }
@@ -983,11 +1115,13 @@ int toast_hip_cov_apply_diag_dev(int64_t n_sub, int64_t subsize, int64_t nnz, co
 }
 
 
-int toast_hip_template_offset_add_to_signal_dev(
-    int64_t step_length, int64_t amp_offset, const int64_t * n_amp_views, const double * d_amplitudes,
-    const uint8_t * d_amplitude_flags, int32_t data_index, double * d_det_data, int64_t n_samp,
-    const toast_hip_interval * intervals, int64_t n_view, void * stream) {
+int toast_hip_template_offset_add_to_signal_multi_dev(
+    int64_t step_length, const int64_t * amp_offsets, const int64_t * n_amp_views,
+    const double * d_amplitudes, const uint8_t * d_amplitude_flags, const int32_t * data_index,
+    int64_t n_det, double * d_det_data, int64_t n_samp, const toast_hip_interval * intervals,
+    int64_t n_view, void * stream) {
     return guarded([&] {
+        if (n_det <= 0) return;
         if (step_length <= 0) fail_arg("step_length must be positive");
         const auto chunks = make_chunks(intervals, n_view, n_samp);
         if (chunks.empty()) return;
@@ -996,12 +1130,55 @@ int toast_hip_template_offset_add_to_signal_dev(
         const size_t o_ch = pb.push_vec(chunks);
         const size_t o_vf = pb.push_vec(ov.first);
         const size_t o_va = pb.push_vec(ov.aoff);
+        const size_t o_ao = pb.push(amp_offsets, sizeof(int64_t) * n_det);
+        const size_t o_di = pb.push(data_index, sizeof(int32_t) * n_det);
         const char * d = pb.commit(as_stream(stream));
-        hipLaunchKernelGGL(k_offset_add_to_signal, chunk_grid(1, chunks.size()), dim3(kThreads), 0,
+        hipLaunchKernelGGL(k_offset_add_to_signal, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0,
                            as_stream(stream), (const Chunk *)(d + o_ch), (int)chunks.size(),
                            (const int64_t *)(d + o_vf), (const int64_t *)(d + o_va),
-                           make_fastdiv(step_length), amp_offset, d_amplitudes, d_amplitude_flags,
-                           d_det_data + (int64_t)data_index * n_samp);
+                           make_fastdiv(step_length), (const int64_t *)(d + o_ao),
+                           (const int32_t *)(d + o_di), d_amplitudes, d_amplitude_flags, d_det_data, n_samp);
+        check_launch();
+    });
+}
+
+int toast_hip_template_offset_add_to_signal_dev(
+    int64_t step_length, int64_t amp_offset, const int64_t * n_amp_views, const double * d_amplitudes,
+    const uint8_t * d_amplitude_flags, int32_t data_index, double * d_det_data, int64_t n_samp,
+    const toast_hip_interval * intervals, int64_t n_view, void * stream) {
+    return toast_hip_template_offset_add_to_signal_multi_dev(step_length, &amp_offset, n_amp_views,
+                                                             d_amplitudes, d_amplitude_flags, &data_index, 1,
+                                                             d_det_data, n_samp, intervals, n_view, stream);
+}
+
+int toast_hip_template_offset_project_signal_multi_dev(
+    const int32_t * data_index, const double * d_det_data, const int32_t * flag_index,
+    const uint8_t * d_flag_data, uint8_t flag_mask, int64_t step_length, const int64_t * amp_offsets,
+    const int64_t * n_amp_views, double * d_amplitudes, const uint8_t * d_amplitude_flags, int64_t n_det,
+    int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view, void * stream) {
+    return guarded([&] {
+        if (n_det <= 0) return;
+        if (step_length <= 0) fail_arg("step_length must be positive");
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        const OffsetViews ov = offset_views(intervals, n_amp_views, n_view);
+        const int use_flags = (flag_index != nullptr && d_flag_data != nullptr && flag_index[0] >= 0) ? 1 : 0;
+        std::vector<int32_t> fidx(n_det, 0);
+        if (use_flags) std::memcpy(fidx.data(), flag_index, sizeof(int32_t) * n_det);
+        ParamBlock pb;
+        const size_t o_ch = pb.push_vec(chunks);
+        const size_t o_vf = pb.push_vec(ov.first);
+        const size_t o_va = pb.push_vec(ov.aoff);
+        const size_t o_ao = pb.push(amp_offsets, sizeof(int64_t) * n_det);
+        const size_t o_di = pb.push(data_index, sizeof(int32_t) * n_det);
+        const size_t o_fi = pb.push_vec(fidx);
+        const char * d = pb.commit(as_stream(stream));
+        hipLaunchKernelGGL(k_offset_project_signal, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0,
+                           as_stream(stream), (const Chunk *)(d + o_ch), (int)chunks.size(),
+                           (const int64_t *)(d + o_vf), (const int64_t *)(d + o_va),
+                           make_fastdiv(step_length), (const int64_t *)(d + o_ao),
+                           (const int32_t *)(d + o_di), (const int32_t *)(d + o_fi), d_amplitudes,
+                           d_amplitude_flags, d_det_data, d_flag_data, flag_mask, use_flags, n_samp);
         check_launch();
     });
 }
@@ -1011,23 +1188,102 @@ int toast_hip_template_offset_project_signal_dev(
     uint8_t flag_mask, int64_t step_length, int64_t amp_offset, const int64_t * n_amp_views,
     double * d_amplitudes, const uint8_t * d_amplitude_flags, int64_t n_samp,
     const toast_hip_interval * intervals, int64_t n_view, void * stream) {
+    return toast_hip_template_offset_project_signal_multi_dev(
+        &data_index, d_det_data, &flag_index, d_flag_data, flag_mask, step_length, &amp_offset, n_amp_views,
+        d_amplitudes, d_amplitude_flags, 1, n_samp, intervals, n_view, stream);
+}
+
+int toast_hip_offset_accumulate_dev(
+    int64_t step_length, const int64_t * amp_offsets, const int64_t * n_amp_views,
+    const double * d_amplitudes, const uint8_t * d_amplitude_flags, const int64_t * d_g2l, double * d_zmap,
+    int64_t n_pix_submap, int64_t nnz, const int32_t * pixel_index, const int64_t * d_pixels,
+    const int32_t * weight_index, const double * d_weights, const int32_t * flag_index,
+    const uint8_t * d_det_flags, int64_t n_flag_samp, const double * det_scale, uint8_t det_flag_mask,
+    int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
+    const uint8_t * d_shared_flags, int64_t n_shared_flags, uint8_t shared_flag_mask, void * stream) {
     return guarded([&] {
+        if (n_det <= 0) return;
         if (step_length <= 0) fail_arg("step_length must be positive");
+        if (nnz != 1 && nnz != 3) fail_arg("offset_accumulate: nnz must be 1 or 3");
         const auto chunks = make_chunks(intervals, n_view, n_samp);
         if (chunks.empty()) return;
         const OffsetViews ov = offset_views(intervals, n_amp_views, n_view);
+        const int use_d = (n_flag_samp == n_samp) ? 1 : 0;
+        const int use_s = (n_shared_flags == n_samp) ? 1 : 0;
+        std::vector<int32_t> fidx(n_det, 0);
+        if (use_d) std::memcpy(fidx.data(), flag_index, sizeof(int32_t) * n_det);
         ParamBlock pb;
         const size_t o_ch = pb.push_vec(chunks);
         const size_t o_vf = pb.push_vec(ov.first);
         const size_t o_va = pb.push_vec(ov.aoff);
+        const size_t o_ao = pb.push(amp_offsets, sizeof(int64_t) * n_det);
+        const size_t o_pi = pb.push(pixel_index, sizeof(int32_t) * n_det);
+        const size_t o_wi = pb.push(weight_index, sizeof(int32_t) * n_det);
+        const size_t o_fi = pb.push_vec(fidx);
+        const size_t o_ds = pb.push(det_scale, sizeof(double) * n_det);
         const char * d = pb.commit(as_stream(stream));
-        const int use_flags = (flag_index >= 0) ? 1 : 0;
-        const uint8_t * frow = use_flags ? d_flag_data + (int64_t)flag_index * n_samp : nullptr;
-        hipLaunchKernelGGL(k_offset_project_signal, chunk_grid(1, chunks.size()), dim3(kThreads), 0,
-                           as_stream(stream), (const Chunk *)(d + o_ch), (int)chunks.size(),
-                           (const int64_t *)(d + o_vf), (const int64_t *)(d + o_va),
-                           make_fastdiv(step_length), amp_offset, d_amplitudes, d_amplitude_flags,
-                           d_det_data + (int64_t)data_index * n_samp, frow, flag_mask, use_flags);
+        const dim3 grid = chunk_grid(n_det, chunks.size());
+        hipStream_t st = as_stream(stream);
+#define TH_OA_ARGS                                                                                  \
+    (const Chunk *)(d + o_ch), (int)chunks.size(), (const int64_t *)(d + o_vf),                     \
+        (const int64_t *)(d + o_va), make_fastdiv(step_length), (const int64_t *)(d + o_ao),        \
+        d_amplitudes, d_amplitude_flags, (const int32_t *)(d + o_pi), (const int32_t *)(d + o_wi),  \
+        (const int32_t *)(d + o_fi), (const double *)(d + o_ds), d_g2l, d_zmap, d_pixels, d_weights, \
+        d_det_flags, det_flag_mask, use_d, d_shared_flags, shared_flag_mask, use_s,                 \
+        make_fastdiv(n_pix_submap), n_samp
+        if (nnz == 3) {
+            hipLaunchKernelGGL(k_offset_accumulate<3>, grid, dim3(kThreads), 0, st, TH_OA_ARGS);
+        } else {
+            hipLaunchKernelGGL(k_offset_accumulate<1>, grid, dim3(kThreads), 0, st, TH_OA_ARGS);
+        }
+#undef TH_OA_ARGS
+        check_launch();
+    });
+}
+
+int toast_hip_offset_scan_project_dev(
+    int64_t step_length, const int64_t * amp_offsets, const int64_t * n_amp_views,
+    const double * d_amplitudes_in, double * d_amplitudes_out, const uint8_t * d_amplitude_flags,
+    const int64_t * d_g2l, const double * d_map, int64_t n_pix_submap, int64_t nnz,
+    const int32_t * pixel_index, const int64_t * d_pixels, const int32_t * weight_index,
+    const double * d_weights, const int32_t * flag_index, const uint8_t * d_flag_data, uint8_t flag_mask,
+    const double * det_weights, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals,
+    int64_t n_view, void * stream) {
+    return guarded([&] {
+        if (n_det <= 0) return;
+        if (step_length <= 0) fail_arg("step_length must be positive");
+        if (nnz != 1 && nnz != 3) fail_arg("offset_scan_project: nnz must be 1 or 3");
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        const OffsetViews ov = offset_views(intervals, n_amp_views, n_view);
+        const int use_flags = (flag_index != nullptr && d_flag_data != nullptr) ? 1 : 0;
+        std::vector<int32_t> fidx(n_det, 0);
+        if (use_flags) std::memcpy(fidx.data(), flag_index, sizeof(int32_t) * n_det);
+        ParamBlock pb;
+        const size_t o_ch = pb.push_vec(chunks);
+        const size_t o_vf = pb.push_vec(ov.first);
+        const size_t o_va = pb.push_vec(ov.aoff);
+        const size_t o_ao = pb.push(amp_offsets, sizeof(int64_t) * n_det);
+        const size_t o_pi = pb.push(pixel_index, sizeof(int32_t) * n_det);
+        const size_t o_wi = pb.push(weight_index, sizeof(int32_t) * n_det);
+        const size_t o_fi = pb.push_vec(fidx);
+        const size_t o_dw = pb.push(det_weights, sizeof(double) * n_det);
+        const char * d = pb.commit(as_stream(stream));
+        const dim3 grid = chunk_grid(n_det, chunks.size());
+        hipStream_t st = as_stream(stream);
+#define TH_OS_ARGS                                                                                  \
+    (const Chunk *)(d + o_ch), (int)chunks.size(), (const int64_t *)(d + o_vf),                     \
+        (const int64_t *)(d + o_va), make_fastdiv(step_length), (const int64_t *)(d + o_ao),        \
+        d_amplitudes_in, d_amplitudes_out, d_amplitude_flags, (const int32_t *)(d + o_pi),          \
+        (const int32_t *)(d + o_wi), (const int32_t *)(d + o_fi), (const double *)(d + o_dw), d_g2l, \
+        d_map, d_pixels, d_weights, d_flag_data, flag_mask, use_flags, make_fastdiv(n_pix_submap),  \
+        n_samp
+        if (nnz == 3) {
+            hipLaunchKernelGGL(k_offset_scan_project<3>, grid, dim3(kThreads), 0, st, TH_OS_ARGS);
+        } else {
+            hipLaunchKernelGGL(k_offset_scan_project<1>, grid, dim3(kThreads), 0, st, TH_OS_ARGS);
+        }
+#undef TH_OS_ARGS
         check_launch();
     });
 }
