@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-dets", type=int, default=32, help="detectors in the CPU baseline sample")
+    ap.add_argument("--pcg-extra", action="store_true",
+                    help="also time the full PCG LHS with offset templates (operator sequence vs fused kernels)")
     ap.add_argument("--no-arena", action="store_true", help="allocate every buffer separately (placement experiment)")
     ap.add_argument("--unfused", action="store_true", help="run noise_weight as its own kernel (105 B variant)")
     return ap.parse_args()
@@ -305,6 +307,69 @@ def main():
         },
         "setup_s": t_setup,
     }
+
+    # ------------------------------------------------------------------ extra: full PCG LHS with offset templates
+    # (not the headline metric) the complete SolverLHS of configs[2] "full MapMaker PCG":
+    # a' = M^T N^-1 (M a - A C A^T N^-1 M a) with 1 s baselines, as the reference's operator
+    # sequence (8 + 41 + 8 + 48 + 9 B per det-sample, five passes) and fused (33 + 33 B, two passes).
+    if args.pcg_extra:
+        step_len = int(rate)  # 1 s baselines
+        n_amp_det = (n_samp + step_len - 1) // step_len
+        nav = np.array([n_amp_det], dtype=np.int64)
+        amp_off = np.arange(n_det, dtype=np.int64) * n_amp_det
+        n_amp = n_det * n_amp_det
+        d_amp_in = torch.randn(n_amp, dtype=torch.float64, device=dev, generator=gen)
+        d_amp_out = torch.zeros(n_amp, dtype=torch.float64, device=dev)
+        d_amp_flags = torch.zeros(n_amp, dtype=torch.uint8, device=dev)
+
+        def lhs_unfused():
+            d_tod2.zero_()
+            D.offset_add_to_signal_multi(step_len, amp_off, nav, d_amp_in.data_ptr(), d_amp_flags.data_ptr(), idx,
+                                         d_tod2.data_ptr(), n_samp, ivl, stream)
+            d_zmap.zero_()
+            D.build_noise_weighted(d_g2l.data_ptr(), d_zmap.data_ptr(), nps, nnz, idx, d_pixels.data_ptr(), idx,
+                                   d_weights.data_ptr(), idx, d_tod2.data_ptr(), idx, d_dflags.data_ptr(), n_samp,
+                                   det_w, 1, n_samp, ivl, d_sflags.data_ptr(), n_samp, 1, stream)
+            if world > 1:
+                dist.all_reduce(d_zmap)
+            D.cov_apply_diag(n_local, nps, nnz, d_cov.data_ptr(), d_zmap.data_ptr(), stream)
+            D.scan_map(np.float64, d_g2l.data_ptr(), nps, d_zmap.data_ptr(), nnz, d_tod2.data_ptr(), idx,
+                       d_pixels.data_ptr(), idx, d_weights.data_ptr(), idx, n_samp, ivl, 1.0, False, True, False,
+                       det_w, stream)
+            d_amp_out.zero_()
+            D.offset_project_signal_multi(idx, d_tod2.data_ptr(), idx, d_dflags.data_ptr(), 1, step_len, amp_off, nav,
+                                          d_amp_out.data_ptr(), d_amp_flags.data_ptr(), n_samp, ivl, stream)
+
+        def lhs_fused():
+            d_zmap.zero_()
+            D.offset_accumulate(step_len, amp_off, nav, d_amp_in.data_ptr(), d_amp_flags.data_ptr(),
+                                d_g2l.data_ptr(), d_zmap.data_ptr(), nps, nnz, idx, d_pixels.data_ptr(), idx,
+                                d_weights.data_ptr(), idx, d_dflags.data_ptr(), n_samp, det_w, 1, n_samp, ivl,
+                                d_sflags.data_ptr(), n_samp, 1, stream)
+            if world > 1:
+                dist.all_reduce(d_zmap)
+            D.cov_apply_diag(n_local, nps, nnz, d_cov.data_ptr(), d_zmap.data_ptr(), stream)
+            d_amp_out.zero_()
+            D.offset_scan_project(step_len, amp_off, nav, d_amp_in.data_ptr(), d_amp_out.data_ptr(),
+                                  d_amp_flags.data_ptr(), d_g2l.data_ptr(), d_zmap.data_ptr(), nps, nnz, idx,
+                                  d_pixels.data_ptr(), idx, d_weights.data_ptr(), idx, d_dflags.data_ptr(), 1, det_w,
+                                  n_samp, ivl, stream)
+
+        lhs_unfused()
+        ref_out = d_amp_out.clone()
+        t_unf = timed(lhs_unfused, 5)
+        lhs_fused()
+        err = float((d_amp_out - ref_out).abs().max() / ref_out.abs().max())
+        t_fus = timed(lhs_fused, 5)
+        out["pcg_lhs_offset_templates"] = {
+            "baseline_step_samples": step_len,
+            "amplitudes": int(n_amp),
+            "operator_sequence_ms": t_unf,
+            "fused_ms": t_fus,
+            "operator_sequence_Gsamp_s": world * nsamp_tot / t_unf / 1e6,
+            "fused_Gsamp_s": world * nsamp_tot / t_fus / 1e6,
+            "fused_vs_sequence_max_rel_diff": err,
+        }
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1)
     if world == 1 and rank == 0 and not args.no_cpu_baseline:

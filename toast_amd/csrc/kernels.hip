@@ -197,17 +197,27 @@ __global__ __launch_bounds__(kThreads) void k_scan_map(
         const Chunk c = chunks[ci];
         for (int i = threadIdx.x; i < c.count; i += kThreads) {
             const int64_t s = c.first + i;
+            // streaming loads first (one round trip), then the dependent global2local -> map gather
             const int64_t p = prow[s];
             double d = zero ? 0.0 : drow[s];
+            const double * w = wrow + nnz * s;
+            double wk[(NNZ > 0) ? NNZ : 1];
+            if (NNZ > 0) {
+#pragma unroll
+                for (int k = 0; k < NNZ; ++k) wk[k] = w[k];
+            }
             if (p >= 0) {
                 const int64_t gsm = fastdiv(p, nps_div);
                 const int64_t lsm = g2l[gsm];
                 const int64_t sub = p - gsm * nps;
                 const T * m = map + nnz * (lsm * nps + sub);
-                const double * w = wrow + nnz * s;
                 double v = 0.0;
+                if (NNZ > 0) {
 #pragma unroll
-                for (int k = 0; k < nnz; ++k) v += w[k] * (double)m[k];
+                    for (int k = 0; k < NNZ; ++k) v += wk[k] * (double)m[k];
+                } else {
+                    for (int k = 0; k < nnz; ++k) v += w[k] * (double)m[k];
+                }
                 v *= scale;
                 if (subtract) {
                     d -= v;
@@ -283,17 +293,23 @@ __global__ __launch_bounds__(kThreads) void k_build_noise_weighted(
 #pragma unroll
             for (int k = 0; k < NNZ; ++k) v[k] = 0.0;
             if (active) {
+                // every streaming load is issued before the first use: one memory round trip for
+                // pixel / flags / tod / weights, a second one for global2local
                 const int64_t p = prow[s];
-                bool good = p >= 0;
-                if (use_dflags) good = good && ((frow[s] & dmask) == 0);
-                if (use_sflags) good = good && ((sflags[s] & smask) == 0);
+                const uint8_t fd = use_dflags ? frow[s] : (uint8_t)0;
+                const uint8_t fs = use_sflags ? sflags[s] : (uint8_t)0;
+                const double t = drow[s];
+                const double * w = wrow + NNZ * s;
+                double wk[NNZ];
+#pragma unroll
+                for (int k = 0; k < NNZ; ++k) wk[k] = w[k];
+                const bool good = (p >= 0) & ((fd & dmask) == 0) & ((fs & smask) == 0);
                 if (good) {
                     const int64_t gsm = fastdiv(p, nps_div);
                     key = g2l[gsm] * nps + (p - gsm * nps);
-                    const double sd = drow[s] * ds;
-                    const double * w = wrow + NNZ * s;
+                    const double sd = t * ds;
 #pragma unroll
-                    for (int k = 0; k < NNZ; ++k) v[k] = sd * w[k];
+                    for (int k = 0; k < NNZ; ++k) v[k] = sd * wk[k];
                 }
             }
             const bool tail = wave_run_reduce<NNZ>(key, v);
@@ -375,16 +391,20 @@ __global__ __launch_bounds__(kThreads) void k_build_cov(
             for (int k = 0; k < NV; ++k) v[k] = 0.0;
             if (active) {
                 const int64_t p = prow[s];
-                bool good = p >= 0;
-                if (use_dflags) good = good && ((frow[s] & dmask) == 0);
-                if (use_sflags) good = good && ((sflags[s] & smask) == 0);
+                const uint8_t fd = use_dflags ? frow[s] : (uint8_t)0;
+                const uint8_t fs = use_sflags ? sflags[s] : (uint8_t)0;
+                double w[NNZ];
+                if (MODE == 1) {
+#pragma unroll
+                    for (int k = 0; k < NNZ; ++k) w[k] = wrow[NNZ * s + k];
+                }
+                const bool good = (p >= 0) & ((fd & dmask) == 0) & ((fs & smask) == 0);
                 if (good) {
                     const int64_t gsm = fastdiv(p, nps_div);
                     key = g2l[gsm] * nps + (p - gsm * nps);
                     if (MODE == 0) {
                         v[0] = 1.0;
                     } else {
-                        const double * w = wrow + NNZ * s;
                         int off = 0;
 #pragma unroll
                         for (int j = 0; j < NNZ; ++j) {
@@ -662,19 +682,24 @@ __global__ __launch_bounds__(kThreads) void k_offset_accumulate(
             for (int k = 0; k < NNZ; ++k) v[k] = 0.0;
             if (active) {
                 const int64_t p = prow[s];
-                bool good = p >= 0;
-                if (use_dflags) good = good && ((frow[s] & dmask) == 0);
-                if (use_sflags) good = good && ((sflags[s] & smask) == 0);
+                const uint8_t fd = use_dflags ? frow[s] : (uint8_t)0;
+                const uint8_t fs = use_sflags ? sflags[s] : (uint8_t)0;
+                const int64_t a = abase + fastdiv(s - vfirst, step_div);
+                const uint8_t af = amp_flags[a];
+                const double av = amps[a];
+                const double * w = wrow + NNZ * s;
+                double wk[NNZ];
+#pragma unroll
+                for (int k = 0; k < NNZ; ++k) wk[k] = w[k];
+                const bool good = (p >= 0) & ((fd & dmask) == 0) & ((fs & smask) == 0);
                 if (good) {
                     const int64_t gsm = fastdiv(p, nps_div);
                     key = g2l[gsm] * nps + (p - gsm * nps);
-                    const int64_t a = abase + fastdiv(s - vfirst, step_div);
                     // tod = 0 + amplitude (unflagged amplitudes only), then * det_scale
-                    const double t = (amp_flags[a] == 0) ? (0.0 + amps[a]) : 0.0;
+                    const double t = (af == 0) ? (0.0 + av) : 0.0;
                     const double sd = t * ds;
-                    const double * w = wrow + NNZ * s;
 #pragma unroll
-                    for (int k = 0; k < NNZ; ++k) v[k] = sd * w[k];
+                    for (int k = 0; k < NNZ; ++k) v[k] = sd * wk[k];
                 }
             }
             const bool tail = wave_run_reduce<NNZ>(key, v);
@@ -717,19 +742,24 @@ __global__ __launch_bounds__(kThreads) void k_offset_scan_project(
             if (active) {
                 const int64_t s = c.first + i;
                 const int64_t a = abase + fastdiv(s - vfirst, step_div);
-                if (amp_flags[a] == 0) {
+                const uint8_t af = amp_flags[a];
+                const double av = amps_in[a];
+                const uint8_t fl = use_flags ? frow[s] : (uint8_t)0;
+                const int64_t p = prow[s];
+                const double * w = wrow + NNZ * s;
+                double wk[NNZ];
+#pragma unroll
+                for (int k = 0; k < NNZ; ++k) wk[k] = w[k];
+                if (af == 0) {
                     key = a;
-                    const bool bad = use_flags && ((frow[s] & fmask) != 0);
-                    if (!bad) {
-                        double d = 0.0 + amps_in[a];
-                        const int64_t p = prow[s];
+                    if ((fl & fmask) == 0) {
+                        double d = 0.0 + av;
                         if (p >= 0) {
                             const int64_t gsm = fastdiv(p, nps_div);
                             const double * m = map + NNZ * (g2l[gsm] * nps + (p - gsm * nps));
-                            const double * w = wrow + NNZ * s;
                             double sc = 0.0;
 #pragma unroll
-                            for (int k = 0; k < NNZ; ++k) sc += w[k] * m[k];
+                            for (int k = 0; k < NNZ; ++k) sc += wk[k] * m[k];
                             sc *= 1.0;
                             d -= sc;
                         }
