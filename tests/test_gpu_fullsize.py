@@ -1,0 +1,162 @@
+"""GPU: BASELINE.json's full single-GPU configuration (configs[2]: 1024 detectors x 720 000
+samples @ 200 Hz, Nside 1024, IQU), checked through size-independent properties, plus oracle
+parity on a detector subsample:
+
+* pixels: bit-exact vs the CPU oracle for 6 of the 1024 detectors (4.3e6 samples), all indices
+  inside the map, flagged samples -1, kernel idempotent;
+* hit map total == number of unflagged samples (exact, integer);
+* sum over the map of each Stokes component of zmap == the same sum taken over the samples
+  (checksum of checksums, fp64, 1e-10 relative);
+* linearity: A^T N^-1 (2 d) == 2 A^T N^-1 d (1e-12);
+* scanning a map into zeroed TOD and subtracting it again returns exact zeros
+  (reference test src/toast/tests/ops_scan_map.py:99-172).
+
+Set TOAST_AMD_FULLSIZE_DETS to shrink the detector count on small-memory devices."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def full():
+    import torch
+
+    from toast_amd import capi, synth
+
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda", 0)
+    n_det = int(os.environ.get("TOAST_AMD_FULLSIZE_DETS", "1024"))
+    n_samp, rate, nside, nps, nnz = 720000, 200.0, 1024, 3072, 3
+    n_submap = 12 * nside * nside // nps
+    D = capi.dev
+    st = torch.cuda.current_stream().cuda_stream
+    fp, gamma = synth.hex_focalplane(n_det, fov_deg=10.0)
+    bore = synth.satellite_boresight(n_samp, rate, 600.0, 30.0, 3000.0, 65.0)
+    ivl = synth.make_intervals(n_samp, 3, rate, gap=11)
+    idx = np.arange(n_det, dtype=np.int32)
+    sflags_h = synth.shared_flags_block(n_samp, 0.01, value=1)
+    t = dict(n_det=n_det, n_samp=n_samp, nside=nside, nps=nps, nnz=nnz, n_submap=n_submap, ivl=ivl, idx=idx, fp=fp,
+             bore=bore, sflags_h=sflags_h, D=D, st=st, torch=torch, dev=dev)
+    t["bore_d"] = torch.from_numpy(bore).to(dev)
+    t["sflags"] = torch.from_numpy(sflags_h).to(dev)
+    t["pixels"] = torch.full((n_det, n_samp), -7, dtype=torch.int64, device=dev)
+    t["weights"] = torch.zeros((n_det, n_samp, 3), dtype=torch.float64, device=dev)
+    t["hsub"] = torch.zeros(n_submap, dtype=torch.uint8, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    t["tod"] = torch.randn((n_det, n_samp), dtype=torch.float64, device=dev, generator=gen)
+    t["dflags"] = (torch.rand((n_det, n_samp), device=dev, generator=gen) < 0.005).to(torch.uint8)
+    quats = torch.empty((n_det, n_samp, 4), dtype=torch.float64, device=dev)
+    D.pointing_detector(fp, t["bore_d"].data_ptr(), idx, quats.data_ptr(), n_samp, ivl, t["sflags"].data_ptr(), n_samp, 1, st)
+    D.pixels_healpix(idx, quats.data_ptr(), t["sflags"].data_ptr(), n_samp, 1, idx, t["pixels"].data_ptr(), n_samp, ivl,
+                     t["hsub"].data_ptr(), n_submap, nps, nside, True, st)
+    D.stokes_weights_IQU(idx, quats.data_ptr(), idx, t["weights"].data_ptr(), n_samp, 0, 0, ivl, np.zeros(n_det), gamma,
+                         np.ones(n_det), False, st)
+    torch.cuda.synchronize()
+    sub = np.linspace(0, n_det - 1, 6).astype(int)
+    t["sub"] = sub
+    t["quats_sub"] = quats[torch.from_numpy(sub).to(dev)].cpu().numpy()
+    # idempotence: second pass into a fresh buffer
+    pix2 = torch.full_like(t["pixels"], -7)
+    D.pixels_healpix(idx, quats.data_ptr(), t["sflags"].data_ptr(), n_samp, 1, idx, pix2.data_ptr(), n_samp, ivl,
+                     t["hsub"].data_ptr(), n_submap, nps, nside, True, st)
+    torch.cuda.synchronize()
+    t["idempotent"] = bool(torch.equal(pix2, t["pixels"]))
+    del quats, pix2
+    g2l_h, hit = synth.global_to_local(t["hsub"].cpu().numpy())
+    t["g2l_h"], t["hit"] = g2l_h, hit
+    t["g2l"] = torch.from_numpy(g2l_h).to(dev)
+    inside = torch.zeros(n_samp, dtype=torch.bool, device=dev)
+    for iv in ivl:
+        inside[int(iv["first"]):int(iv["last"])] = True
+    t["inside"] = inside
+    return t
+
+
+def test_pixels_fullsize(full, oracle):
+    t = full
+    torch = t["torch"]
+    pix = t["pixels"]
+    inside = t["inside"]
+    assert t["idempotent"]
+    assert bool((pix[:, ~inside] == -7).all())  # samples outside the intervals untouched
+    body = pix[:, inside]
+    flagged = (t["sflags"][inside] != 0)
+    assert bool((body[:, flagged] == -1).all())
+    good = body[:, ~flagged]
+    assert int(good.min()) >= 0 and int(good.max()) < 12 * t["nside"] ** 2
+    # hit submaps == submaps of the good pixels
+    sm = torch.unique(good // t["nps"]).cpu().numpy()
+    assert np.array_equal(sm, t["hit"])
+    # oracle parity on a detector subsample
+    sub = t["sub"]
+    want = np.full((len(sub), t["n_samp"]), -7, dtype=np.int64)
+    hs = np.zeros(t["n_submap"], dtype=np.uint8)
+    idx = np.arange(len(sub), dtype=np.int32)
+    oracle.pixels_healpix(idx, t["quats_sub"], t["sflags_h"], 1, idx, want, t["ivl"], hs, t["nps"], t["nside"], True)
+    got = pix[torch.from_numpy(sub).to(t["dev"])].cpu().numpy()
+    nbad = int(np.count_nonzero(got != want))
+    assert nbad == 0, f"{nbad} pixel mismatches in {want.size} samples"
+
+
+def test_accumulate_checksums_and_linearity(full):
+    t = full
+    torch, D, st = t["torch"], t["D"], t["st"]
+    n_det, n_samp, nps, nnz = t["n_det"], t["n_samp"], t["nps"], t["nnz"]
+    n_local = int(t["hit"].size)
+    det_scale = np.linspace(0.5, 1.5, n_det)
+    zmap = torch.zeros((n_local, nps, nnz), dtype=torch.float64, device=t["dev"])
+
+    def bnw(tod, out):
+        D.build_noise_weighted(t["g2l"].data_ptr(), out.data_ptr(), nps, nnz, t["idx"], t["pixels"].data_ptr(), t["idx"],
+                               t["weights"].data_ptr(), t["idx"], tod.data_ptr(), t["idx"], t["dflags"].data_ptr(), n_samp,
+                               det_scale, 1, n_samp, t["ivl"], t["sflags"].data_ptr(), n_samp, 1, st)
+
+    bnw(t["tod"], zmap)
+    hits = torch.zeros((n_local, nps, 1), dtype=torch.int64, device=t["dev"])
+    from toast_amd import capi
+    import ctypes as C
+
+    capi._check(capi.lib().toast_hip_build_cov_dev(
+        C.c_int(0), C.c_void_p(t["g2l"].data_ptr()), C.c_void_p(hits.data_ptr()), C.c_int64(nps), C.c_int64(1),
+        capi._p(t["idx"]), C.c_void_p(t["pixels"].data_ptr()), capi._p(t["idx"]), C.c_void_p(0), capi._p(t["idx"]),
+        C.c_void_p(t["dflags"].data_ptr()), C.c_int64(n_samp), capi._p(det_scale), C.c_uint8(1), C.c_int64(n_det),
+        C.c_int64(n_samp), capi._p(t["ivl"]), C.c_int64(t["ivl"].size), C.c_void_p(t["sflags"].data_ptr()),
+        C.c_int64(n_samp), C.c_uint8(1), C.c_void_p(st)))
+    torch.cuda.synchronize()
+    good = (t["pixels"] >= 0) & (t["dflags"] == 0) & (t["sflags"] == 0)[None, :] & t["inside"][None, :]
+    assert int(hits.sum()) == int(good.sum())
+    ds = torch.from_numpy(det_scale).to(t["dev"])[:, None]
+    sd = torch.where(good, t["tod"] * ds, torch.zeros((), dtype=torch.float64, device=t["dev"]))
+    for k in range(nnz):
+        lhs = float(zmap[:, :, k].sum())
+        rhs = float((sd * t["weights"][:, :, k]).sum())
+        scale = float((sd * t["weights"][:, :, k]).abs().sum())
+        assert abs(lhs - rhs) < 1e-10 * scale
+    z2 = torch.zeros_like(zmap)
+    bnw(t["tod"] * 2.0, z2)
+    torch.cuda.synchronize()
+    assert float((z2 - 2.0 * zmap).abs().max()) < 1e-12 * float(zmap.abs().max())
+    full["zmap"] = zmap
+
+
+def test_scan_roundtrip_zero(full):
+    t = full
+    torch, D, st = t["torch"], t["D"], t["st"]
+    zmap = t.get("zmap")
+    if zmap is None:
+        pytest.skip("accumulate test did not run")
+    n_samp, nps, nnz = t["n_samp"], t["nps"], t["nnz"]
+    tod = torch.zeros((t["n_det"], n_samp), dtype=torch.float64, device=t["dev"])
+    args = (np.float64, t["g2l"].data_ptr(), nps, zmap.data_ptr(), nnz, tod.data_ptr(), t["idx"], t["pixels"].data_ptr(),
+            t["idx"], t["weights"].data_ptr(), t["idx"], n_samp, t["ivl"], 1.0)
+    D.scan_map(*args, False, False, False, None, st)
+    torch.cuda.synchronize()
+    assert float(tod.abs().max()) > 0
+    assert bool((tod[:, ~t["inside"]] == 0).all())
+    D.scan_map(*args, False, True, False, None, st)
+    torch.cuda.synchronize()
+    assert bool((tod == 0).all())
