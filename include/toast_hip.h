@@ -416,6 +416,18 @@ int toast_hip_fft_r1d(int forward, int64_t length, int64_t count, const double *
 int toast_hip_fft_r1d_dev(int forward, int64_t length, int64_t count, const double * d_in, double * d_out,
                           double scale, void * stream);
 
+/* ScanMask on device copies: det_flags[d,s] |= flag_value where mask[g2l[p/nps], p%nps] &
+ * mask_bits (mask: u8[n_local_submap, n_pix_submap, 1]).  Operator-level semantics of the
+ * reference's host-only ScanMask [ref: src/toast/ops/scan_map/scan_map.py:283-320]. */
+int toast_hip_scan_mask_dev(const int64_t * d_global2local, const uint8_t * d_mask, int64_t n_pix_submap,
+                            uint8_t mask_bits, uint8_t flag_value, const int32_t * pixel_index /*host*/,
+                            const int64_t * d_pixels, const int32_t * flag_index /*host*/,
+                            uint8_t * d_det_flags, int64_t n_det, int64_t n_samp,
+                            const toast_hip_interval * intervals /*host*/, int64_t n_view, void * stream);
+
+/* Device-to-device copy on the stream (Copy operator on resident buffers). */
+int toast_hip_copy_dev(void * d_dst, const void * d_src, size_t nbytes, void * stream);
+
 /* ------------------------------------------------------------------------------------
  * Test / measurement helpers (device primitives compared per operation with the CPU).
  * ---------------------------------------------------------------------------------- */

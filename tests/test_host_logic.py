@@ -32,7 +32,7 @@ def test_traits_and_select_kernels():
     assert pix.select_kernels(use_accel=False) == (ImplementationType.DEFAULT, False)
     assert pix.select_kernels(use_accel=True) == (ImplementationType.COMPILED, True)
     with pytest.raises(RuntimeError):
-        ops.Copy().select_kernels(use_accel=True)
+        ops.Delete().select_kernels(use_accel=True)  # host-only operator
 
 
 def test_pipeline_requires_provides():
@@ -47,7 +47,7 @@ def test_pipeline_requires_provides():
     assert defaults.pixels not in req["detdata"] or True
     assert "z" in prov["global"]
     assert pipe.supports_accel()
-    hybrid = ops.Pipeline(operators=[pix, ops.Copy(detdata=[("a", "b")])])
+    hybrid = ops.Pipeline(operators=[pix, ops.Delete(detdata=["b"])])
     assert not hybrid._supports_accel() and hybrid._supports_accel_partial()
     with pytest.raises(RuntimeError):
         ops.Pipeline(operators=[pix, "notanop"])

@@ -544,6 +544,18 @@ class _Dev:
             _p(d_flag_data), _u8(flag_mask), _p(dw), _i64(pi.size), _i64(n_samp), _p(iv), _i64(iv.size),
             _p(stream)))
 
+    def scan_mask(self, d_g2l, d_mask, n_pix_submap, mask_bits, flag_value, pixel_index, d_pixels, flag_index,
+                  d_det_flags, n_samp, intervals, stream=0):
+        pi = self._small(pixel_index, np.int32)
+        fi = self._small(flag_index, np.int32)
+        iv = self._small(intervals, interval_dtype)
+        _check(lib().toast_hip_scan_mask_dev(
+            _p(d_g2l), _p(d_mask), _i64(n_pix_submap), _u8(mask_bits), _u8(flag_value), _p(pi), _p(d_pixels), _p(fi),
+            _p(d_det_flags), _i64(pi.size), _i64(n_samp), _p(iv), _i64(iv.size), _p(stream)))
+
+    def copy(self, d_dst, d_src, nbytes, stream=0):
+        _check(lib().toast_hip_copy_dev(_p(d_dst), _p(d_src), C.c_size_t(int(nbytes)), _p(stream)))
+
     def test_math(self, op, n, d_a, d_b, d_out, stream=0):
         _check(lib().toast_hip_test_math_dev(C.c_int(op), _i64(n), _p(d_a), _p(d_b), _p(d_out), _p(stream)))
 

@@ -530,6 +530,34 @@ __global__ __launch_bounds__(kThreads) void k_cov_invert(int64_t n_px, double * 
 }
 
 // ------------------------------------------------------------------------------------
+// scan_mask: det_flags[d, s] |= value where mask[g2l[pix / nps], pix % nps] & bits
+// (operator-level semantics of ScanMask, src/toast/ops/scan_map/scan_map.py:283-320 -- host
+// NumPy in the reference; here the same pass on the device copies).
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_scan_mask(
+    const Chunk * __restrict__ chunks, int n_chunks, const int32_t * __restrict__ p_idx,
+    const int32_t * __restrict__ f_idx, const int64_t * __restrict__ g2l,
+    const uint8_t * __restrict__ mask, uint8_t bits, uint8_t value, const int64_t * __restrict__ pixels,
+    uint8_t * __restrict__ flags, FastDiv nps_div, int64_t n_samp) {
+    const int det = blockIdx.x;
+    const int64_t * prow = pixels + (int64_t)p_idx[det] * n_samp;
+    uint8_t * frow = flags + (int64_t)f_idx[det] * n_samp;
+    const int64_t nps = nps_div.d;
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        for (int i = threadIdx.x; i < c.count; i += kThreads) {
+            const int64_t s = c.first + i;
+            const int64_t p = prow[s];
+            if (p < 0) continue;
+            const int64_t gsm = fastdiv(p, nps_div);
+            const int64_t lsm = g2l[gsm];
+            if (lsm < 0) continue;
+            if (mask[lsm * nps + (p - gsm * nps)] & bits) frow[s] |= value;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // noise_weight   [ref: ops_noise_weight.cpp:71-96]
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void k_noise_weight(
@@ -1398,6 +1426,36 @@ int toast_hip_cov_eigendecompose_diag_dev(int64_t n_sub, int64_t subsize, int64_
             default: fail_arg("cov_eigendecompose_diag: nnz must be 1..4");
         }
         check_launch();
+    });
+}
+
+int toast_hip_scan_mask_dev(const int64_t * d_g2l, const uint8_t * d_mask, int64_t n_pix_submap,
+                            uint8_t mask_bits, uint8_t flag_value, const int32_t * pixel_index,
+                            const int64_t * d_pixels, const int32_t * flag_index, uint8_t * d_det_flags,
+                            int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals,
+                            int64_t n_view, void * stream) {
+    return guarded([&] {
+        if (n_det <= 0) return;
+        if (n_pix_submap <= 0) fail_arg("n_pix_submap must be positive");
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        ParamBlock pb;
+        const size_t o_ch = pb.push_vec(chunks);
+        const size_t o_pi = pb.push(pixel_index, sizeof(int32_t) * n_det);
+        const size_t o_fi = pb.push(flag_index, sizeof(int32_t) * n_det);
+        const char * d = pb.commit(as_stream(stream));
+        hipLaunchKernelGGL(k_scan_mask, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0,
+                           as_stream(stream), (const Chunk *)(d + o_ch), (int)chunks.size(),
+                           (const int32_t *)(d + o_pi), (const int32_t *)(d + o_fi), d_g2l, d_mask,
+                           mask_bits, flag_value, d_pixels, d_det_flags, make_fastdiv(n_pix_submap), n_samp);
+        check_launch();
+    });
+}
+
+int toast_hip_copy_dev(void * d_dst, const void * d_src, size_t nbytes, void * stream) {
+    return guarded([&] {
+        if (nbytes == 0) return;
+        TH_HIP(hipMemcpyAsync(d_dst, d_src, nbytes, hipMemcpyDeviceToDevice, as_stream(stream)));
     });
 }
 

@@ -122,8 +122,20 @@ Manager & Manager::get() {
     return m;
 }
 
+size_t pin_threshold() {
+    // TOAST_HIP_PIN_HOST_MB: page-lock host buffers of at least this many MiB when they are
+    // registered (default 16; 0 disables pinning).
+    static const size_t v = [] {
+        const char * e = std::getenv("TOAST_HIP_PIN_HOST_MB");
+        const long mb = e ? std::atol(e) : 16;
+        return (mb <= 0) ? ~size_t(0) : (size_t)mb << 20;
+    }();
+    return v;
+}
+
 void Manager::clear() {
     for (auto & kv : table_) {
+        if (kv.second.host_registered) (void)hipHostUnregister(const_cast<void *>(kv.first));
         if (kv.second.owned) (void)hipFree(kv.second.dev);
     }
     table_.clear();
@@ -222,7 +234,17 @@ void * Manager::create(const void * host, size_t nbytes, const char * name) {
           << (name ? name : "NA") << "') on device " << device_ << ", allocation failed";
         throw Error(TOAST_HIP_ERR_MEMORY, o.str());
     }
-    table_[host] = Entry{dev, nbytes, name ? name : "NA", true};
+    Entry ent{dev, nbytes, name ? name : "NA", true};
+    // Page-lock large host buffers: update_device / update_host then run at PCIe speed instead
+    // of through the driver's bounce buffers (pageable copies measured 5-10x slower).
+    if (nbytes >= pin_threshold()) {
+        if (hipHostRegister(const_cast<void *>(host), nbytes, hipHostRegisterDefault) == hipSuccess) {
+            ent.host_registered = true;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    table_[host] = ent;
     return dev;
 }
 
@@ -233,7 +255,8 @@ void Manager::adopt(const void * host, size_t nbytes, void * device, const char 
         o << "HipManager:  on adopt, host ptr " << host << " is already present";
         throw Error(TOAST_HIP_ERR_MEMORY, o.str());
     }
-    table_[host] = Entry{device, nbytes, name ? name : "NA", false};
+    Entry ent{device, nbytes, name ? name : "NA", false};
+    table_[host] = ent;
 }
 
 void Manager::reset(const void * host, size_t nbytes, const char * name) {
@@ -261,6 +284,7 @@ void Manager::remove(const void * host, size_t nbytes, const char * name) {
     require_device();
     Entry & e = lookup(host, nbytes, name, "delete");
     TH_HIP(hipStreamSynchronize(stream_));
+    if (e.host_registered) (void)hipHostUnregister(const_cast<void *>(host));
     if (e.owned) TH_HIP(hipFree(e.dev));
     table_.erase(host);
 }

@@ -85,6 +85,7 @@ private:
     std::vector<char> host_;
 };
 
+size_t pin_threshold();
 int chunk_size();
 bool det_major_grid();
 std::vector<Chunk> make_chunks(const toast_hip_interval * ivl, int64_t n_view, int64_t n_samp);
@@ -118,6 +119,7 @@ private:
         size_t nbytes;
         std::string name;
         bool owned = true;
+        bool host_registered = false;
     };
     Entry & lookup(const void * host, size_t nbytes, const char * name, const char * what);
 

@@ -488,6 +488,26 @@ class Data(MutableMapping):
         self.comm = Comm() if comm is None else comm
         self.obs = []
         self._internal = {}
+        self._pinned = {k: set() for k in ("global", "detdata", "shared")}
+
+    def accel_pin(self, names):
+        """Keep these objects resident on the device across Pipelines: ``accel_update_host`` and
+        ``accel_delete`` driven by Pipeline staging skip them while they are in use there.  For
+        buffers that are written once and then only read (cached pointing), on a 288 GB device."""
+        for k, v in names.items():
+            self._pinned[k] |= set(v)
+
+    def accel_unpin(self, names=None, update_host=True):
+        """Release pinned objects (all when ``names`` is None): bring the host copies up to date
+        and free the device copies (the state a Pipeline would have left)."""
+        names = {k: set(v) for k, v in self._pinned.items()} if names is None else names
+        for k, v in names.items():
+            self._pinned[k] -= set(v)
+        for key, obj in self._each({k: list(v) for k, v in names.items()}, include_pinned=True):
+            if obj.accel_exists():
+                if update_host and obj.accel_in_use():
+                    obj.accel_update_host()
+                obj.accel_delete()
 
     def all_local_detectors(self, selection=None, flagmask=0):
         seen, out = set(), []
@@ -518,17 +538,17 @@ class Data(MutableMapping):
 
     # -- accelerator staging by ``requires()`` / ``provides()`` dictionaries
     #    (reference: src/toast/data.py accel_create / accel_update_device / ...)
-    def _each(self, names):
+    def _each(self, names, include_pinned=True):
         for key in names.get("global", []):
             obj = self._internal.get(key)
-            if isinstance(obj, AcceleratorObject):
+            if isinstance(obj, AcceleratorObject) and (include_pinned or key not in self._pinned["global"]):
                 yield key, obj
         for ob in self.obs:
             for key in names.get("detdata", []):
-                if key in ob.detdata:
+                if key in ob.detdata and (include_pinned or key not in self._pinned["detdata"]):
                     yield key, ob.detdata[key]
             for key in names.get("shared", []):
-                if key in ob.shared:
+                if key in ob.shared and (include_pinned or key not in self._pinned["shared"]):
                     yield key, ob.shared[key]
 
     def accel_create(self, names):
@@ -542,11 +562,11 @@ class Data(MutableMapping):
                 obj.accel_update_device()
 
     def accel_update_host(self, names):
-        for key, obj in self._each(names):
+        for key, obj in self._each(names, include_pinned=False):
             if obj.accel_exists() and obj.accel_in_use():
                 obj.accel_update_host()
 
     def accel_delete(self, names):
-        for key, obj in self._each(names):
+        for key, obj in self._each(names, include_pinned=False):
             if obj.accel_exists():
                 obj.accel_delete()

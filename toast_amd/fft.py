@@ -62,6 +62,9 @@ def _p(a):
 
 def convolve_buffer(det_data, data_index, rate, kernel_freq, kernels, deconvolve=False, use_accel=False):
     """Convolve rows ``data_index`` of the 2-D float64 buffer ``det_data`` in place."""
+    from .accel import ensure_assigned
+
+    ensure_assigned()
     det_data = capi._buf(det_data, "det_data", np.float64, 2)
     di = capi._buf(np.ascontiguousarray(data_index, dtype=np.int32), "data_index", np.int32, 1)
     n_det, n_samp = di.size, det_data.shape[1]
@@ -169,6 +172,9 @@ def convolve(raw, rate, flags=None, flag_mask=None, kernel_freq=None, kernels=No
 
 def r1d_forward(indata):
     """Batched real FFT in FFTW half-complex layout (reference fft.py:26-68)."""
+    from .accel import ensure_assigned
+
+    ensure_assigned()
     x = np.ascontiguousarray(np.atleast_2d(indata), dtype=np.float64)
     out = np.empty_like(x)
     capi._check(capi.lib().toast_hip_fft_r1d(C.c_int(1), C.c_int64(x.shape[1]), C.c_int64(x.shape[0]), _p(x), _p(out),
@@ -178,6 +184,9 @@ def r1d_forward(indata):
 
 def r1d_backward(indata):
     """Inverse of :func:`r1d_forward` (scaled by 1/length; reference fft.py:71-117)."""
+    from .accel import ensure_assigned
+
+    ensure_assigned()
     x = np.ascontiguousarray(np.atleast_2d(indata), dtype=np.float64)
     out = np.empty_like(x)
     capi._check(capi.lib().toast_hip_fft_r1d(C.c_int(0), C.c_int64(x.shape[1]), C.c_int64(x.shape[0]), _p(x), _p(out),

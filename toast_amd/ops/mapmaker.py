@@ -36,7 +36,9 @@ class ApplyAmplitudes(Operator):
         tm.amplitudes = self.amplitudes
         tm.transpose = False
         tm.det_data = temp
-        tm.apply(data, detectors=detectors)
+        # inside a Pipeline so that the template kernels find device-resident buffers (staged
+        # once) instead of staging the whole timestream buffer per detector
+        Pipeline(operators=[tm]).apply(data, detectors=detectors)
         for ob in data.obs:
             if out != self.det_data:
                 Copy(detdata=[(self.det_data, out)]).apply(data, detectors=detectors)
@@ -90,9 +92,20 @@ class MapMaker(Operator):
         for trait in ("binning",):
             if getattr(self, trait) is None:
                 raise RuntimeError(f"You must set the '{trait}' trait before calling exec()")
+        import time as _time
+
+        from ..accel import native as _native
+
+        def _lap(label, t_start):
+            _native().accel_synchronize()
+            self.timing_log[label] = self.timing_log.get(label, 0.0) + (_time.time() - t_start)
+            return _time.time()
+
         binning = self.binning
         map_binning = self.map_binning if self.map_binning is not None else binning
         self.history = []
+        self.timing_log = {}
+        _t = _time.time()
         if self.reset_pix_dist and binning.pixel_dist in data:
             del data[binning.pixel_dist]
         hits_name, cov_name, rcond_name = f"{self.name}_hits", f"{self.name}_cov", f"{self.name}_rcond"
@@ -128,6 +141,14 @@ class MapMaker(Operator):
                     sf.data[:, outside] = 1
             binning.det_flags, binning.det_flag_mask = solver_flags, 1
             tm.det_flags, tm.det_flag_mask = solver_flags, 1
+        # Cached pointing is written once and read by every later phase: keep it on the device
+        # (288 GB HBM) instead of the copy-back / delete / re-upload of each Pipeline.
+        pinned = None
+        from ..accel import accel_enabled as _accel_enabled
+
+        if binning.full_pointing and _accel_enabled():
+            pinned = {"detdata": [binning.pixel_pointing.pixels, binning.stokes_weights.weights]}
+            data.accel_pin(pinned)
         # covariance + hits with the solver flags
         cov_op = CovarianceAndHits(
             pixel_dist=binning.pixel_dist, covariance=cov_name, hits=hits_name, rcond=rcond_name,
@@ -137,6 +158,7 @@ class MapMaker(Operator):
             noise_model=binning.noise_model, rcond_threshold=self.solve_rcond_threshold,
             sync_type=binning.sync_type, save_pointing=binning.full_pointing)
         cov_op.apply(data, detectors=detectors)
+        _t = _lap("covariance_and_hits", _t)
         binning.covariance = cov_name
         map_binning.covariance = cov_name
         if use_templates:
@@ -162,11 +184,13 @@ class MapMaker(Operator):
             if f"{self.name}_rhs" in data:
                 del data[f"{self.name}_rhs"]
             rhs.apply(data, detectors=detectors)
+            _t = _lap("rhs", _t)
             lhs = SolverLHS(name=f"{self.name}_lhs", binning=binning, template_matrix=tm)
             if amp_name in data:
                 del data[amp_name]
             self.history = solve(data, detectors, lhs, f"{self.name}_rhs", amp_name, convergence=self.convergence,
                                  n_iter_min=self.iter_min, n_iter_max=self.iter_max)
+            _t = _lap("pcg_iterations", _t)
             for ob in data.obs:
                 if lhs.det_temp in ob.detdata:
                     del ob.detdata[lhs.det_temp]
@@ -188,9 +212,14 @@ class MapMaker(Operator):
             Delete(detdata=[solver_flags]).apply(data)
         map_binning.binned = map_name
         map_binning.det_data = cleaned
+        _t = _lap("apply_amplitudes", _t)
         map_binning.apply(data, detectors=detectors)
+        _t = _lap("final_binning", _t)
         if cleaned.endswith("_temp_cleaned"):
             Delete(detdata=[cleaned]).apply(data)
+        if pinned is not None:
+            data.accel_unpin(pinned)
+            _t = _lap("unpin_pointing", _t)
 
     def _finalize(self, data, **kwargs):
         return

@@ -107,9 +107,9 @@ class ScanMap(Operator):
 
 class ScanMask(Operator):
     """Flag detector samples that fall in masked pixels: ``det_flags |= det_flags_value`` where
-    ``mask[pix] & mask_bits`` is set.  Host-side bookkeeping exactly as in the reference (its
-    ScanMask has ``_supports_accel() == False``: src/toast/ops/scan_map/scan_map.py:218-345);
-    it runs once while preparing the solver flags, never inside the PCG loop."""
+    ``mask[pix] & mask_bits`` is set (reference: src/toast/ops/scan_map/scan_map.py:218-345,
+    host NumPy only there).  With ``use_accel`` the same pass runs on the device copies
+    (``toast_hip_scan_mask_dev``); the host branch mirrors the reference's bookkeeping."""
 
     API = Int(0, help="Internal interface version for this operator")
     det_mask = Int(defaults.det_mask_invalid, help="Bit mask value for per-detector flagging")
@@ -122,6 +122,7 @@ class ScanMask(Operator):
     mask_bits = Int(255, help="The number to bitwise-and with each mask value to form the result")
 
     def _exec(self, data, detectors=None, use_accel=None, **kwargs):
+        implementation, use_accel = self.select_kernels(use_accel=use_accel)
         if self.det_flags is None:
             raise RuntimeError("You must set the det_flags trait before calling exec()")
         if self.mask_key is None:
@@ -139,6 +140,30 @@ class ScanMask(Operator):
             if self.det_flags not in ob.detdata:
                 ob.detdata.create(self.det_flags, dtype=np.uint8, detectors=ob.local_detectors)
             pd, fd = ob.detdata[self.pixels], ob.detdata[self.det_flags]
+            if use_accel:
+                # device pass (toast_hip_scan_mask_dev): pixels / flags / mask stay resident
+                from .. import capi
+                from ..accel import accel_device_ptr
+                from ..data import SharedData
+
+                for obj, nm in ((pd, self.pixels), (fd, self.det_flags), (mask_data, self.mask_key)):
+                    if not obj.accel_exists():
+                        obj.accel_create(nm)
+                    if not obj.accel_in_use():
+                        obj.accel_update_device()
+                gkey = "_g2l_" + str(id(mask_dist))
+                if gkey not in data:
+                    data[gkey] = SharedData(mask_dist.global_submap_to_local, "g2l")
+                g2l = data[gkey]
+                if not g2l.accel_exists():
+                    g2l.accel_create("g2l")
+                if not g2l.accel_in_use():
+                    g2l.accel_update_device()
+                capi.dev.scan_mask(accel_device_ptr(g2l.data), accel_device_ptr(mask_data.raw),
+                                   mask_dist.n_pix_submap, self.mask_bits, self.det_flags_value, pd.indices(dets),
+                                   accel_device_ptr(pd.data), fd.indices(dets), accel_device_ptr(fd.data),
+                                   ob.n_local_samples, ob.intervals[self.view].data)
+                continue
             if pd.accel_in_use():
                 pd.accel_update_host()
                 pd.accel_used(True)
@@ -166,8 +191,11 @@ class ScanMask(Operator):
     def _provides(self):
         return {"detdata": [self.det_flags]}
 
+    def _implementations(self):
+        return _IMPLS
+
     def _supports_accel(self):
-        return False
+        return True
 
 
 class NoiseWeight(Operator):
@@ -618,9 +646,20 @@ class Copy(Operator):
         for ob in data.obs:
             for src, dst in self.detdata:
                 s = ob.detdata[src]
+                dets = ob.select_local_detectors(detectors)
+                if use_accel and s.accel_in_use() and set(dets) >= set(s.detectors):
+                    # whole-buffer device-to-device copy, nothing crosses PCIe
+                    from .. import capi
+                    from ..accel import accel_device_ptr
+
+                    ob.detdata.ensure(dst, sample_shape=s.detector_shape[1:], dtype=s.dtype, detectors=s.detectors,
+                                      accel=True)
+                    d = ob.detdata[dst]
+                    capi.dev.copy(accel_device_ptr(d.data), accel_device_ptr(s.data), s.data.nbytes)
+                    d.accel_used(True)
+                    continue
                 if s.accel_in_use():
                     s.accel_update_host()
-                dets = ob.select_local_detectors(detectors)
                 ob.detdata.ensure(dst, sample_shape=s.detector_shape[1:], dtype=s.dtype, detectors=s.detectors)
                 d = ob.detdata[dst]
                 if d.accel_in_use():
@@ -636,6 +675,12 @@ class Copy(Operator):
 
     def _provides(self):
         return {"detdata": [x[1] for x in self.detdata]}
+
+    def _implementations(self):
+        return _IMPLS
+
+    def _supports_accel(self):
+        return True
 
 
 class Delete(Operator):

@@ -99,9 +99,13 @@ class TemplateMatrix(Operator):
                 for tmpl in self.templates:
                     if tmpl.enabled:
                         data[self.amplitudes][tmpl.name] = tmpl.zeros()
-            for d in all_dets:
-                for tmpl in self.templates:
-                    if tmpl.enabled:
+            for tmpl in self.templates:
+                if not tmpl.enabled:
+                    continue
+                if use_accel and hasattr(tmpl, "project_signal_multi"):
+                    tmpl.project_signal_multi(all_dets, data[self.amplitudes][tmpl.name], **kwargs)
+                else:
+                    for d in all_dets:
                         tmpl.project_signal(d, data[self.amplitudes][tmpl.name], use_accel=use_accel, **kwargs)
         else:
             if self.amplitudes not in data:
@@ -112,9 +116,13 @@ class TemplateMatrix(Operator):
                                            create_units=self.det_data_units)
                 if exists:
                     ob.detdata[self.det_data].reset(dets=dets)
-            for d in all_dets:
-                for tmpl in self.templates:
-                    if tmpl.enabled:
+            for tmpl in self.templates:
+                if not tmpl.enabled:
+                    continue
+                if use_accel and hasattr(tmpl, "add_to_signal_multi"):
+                    tmpl.add_to_signal_multi(all_dets, data[self.amplitudes][tmpl.name], **kwargs)
+                else:
+                    for d in all_dets:
                         tmpl.add_to_signal(d, data[self.amplitudes][tmpl.name], use_accel=use_accel, **kwargs)
 
     def _finalize(self, data, use_accel=None, **kwargs):
@@ -300,18 +308,15 @@ class SolverLHS(Operator):
                     if d in tmpl._obs_dets[iob]]
             if len(dets) == 0:
                 continue
-            # amplitude offset of each detector in this observation (offset.py:727-760)
-            amp_offsets = []
-            for d in dets:
-                off = tmpl._det_start[d]
-                for job in range(iob):
-                    if d in tmpl._obs_dets[job]:
-                        off += int(np.sum(tmpl._obs_views[job]))
-                amp_offsets.append(off)
+            amp_offsets = tmpl.det_amp_offsets(iob, dets)
             step_length = tmpl._step_length(tmpl.step_time, tmpl._obs_rate[iob])
             pd, wd = ob.detdata[pixels_op.pixels], ob.detdata[weights_op.weights]
             noise = ob[binning.noise_model]
-            detw = np.array([noise.detector_weight(d) for d in dets], dtype=np.float64)
+            wkey = (id(noise), tuple(dets))
+            wcache = self.__dict__.setdefault("_detw_cache", {})
+            if wkey not in wcache:
+                wcache[wkey] = np.array([noise.detector_weight(d) for d in dets], dtype=np.float64)
+            detw = wcache[wkey]
             n_samp = ob.n_local_samples
             ivl = ob.intervals[pixels_op.view].data
             if binning.det_flags is not None:

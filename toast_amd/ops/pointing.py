@@ -96,6 +96,16 @@ class PointingDetectorSimple(Operator):
         return True
 
 
+def _outputs_exist(data, key, detectors, det_mask):
+    """True when every observation already holds ``key`` for all requested detectors: the
+    operator (and the detector pointing it would trigger) has nothing to do."""
+    for ob in data.obs:
+        dets = ob.select_local_detectors(detectors, flagmask=det_mask)
+        if key not in ob.detdata or not set(dets) <= set(ob.detdata[key].detectors):
+            return False
+    return True
+
+
 def _check_detector_pointing(op, traits):
     if op is not None:
         if not isinstance(op, Operator):
@@ -179,7 +189,10 @@ class PixelsHealpix(Operator):
             self._local_submaps = np.zeros(self._n_submap, dtype=np.uint8)
         quats_name = self.detector_pointing.quats
         view = self.view if self.view is not None else self.detector_pointing.view
-        self.detector_pointing.apply(data, detectors=detectors, use_accel=use_accel)
+        # (the reference expands detector pointing unconditionally, pixels_healpix.py:162; when
+        # the pixels are cached there is nothing to feed and the quaternions may be gone)
+        if not _outputs_exist(data, self.pixels, detectors, self.detector_pointing.det_mask):
+            self.detector_pointing.apply(data, detectors=detectors, use_accel=use_accel)
         for ob in data.obs:
             dets = ob.select_local_detectors(detectors, flagmask=self.detector_pointing.det_mask)
             exists = ob.detdata.ensure(self.pixels, sample_shape=(), dtype=np.int64, detectors=dets, accel=use_accel)
@@ -283,7 +296,8 @@ class StokesWeights(Operator):
             raise RuntimeError("If using HWP, you must specify the fp_gamma key")
         quats_name = self.detector_pointing.quats
         view = self.view if self.view is not None else self.detector_pointing.view
-        self.detector_pointing.apply(data, detectors=detectors, use_accel=use_accel)
+        if not _outputs_exist(data, self.weights, detectors, self.detector_pointing.det_mask):
+            self.detector_pointing.apply(data, detectors=detectors, use_accel=use_accel)
         for ob in data.obs:
             dets = ob.select_local_detectors(detectors, flagmask=self.detector_pointing.det_mask)
             exists = ob.detdata.ensure(self.weights, sample_shape=(nnz,), dtype=np.float64, detectors=dets,

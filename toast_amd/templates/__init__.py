@@ -318,17 +318,21 @@ class Offset(Template):
                         flags = np.array(self._obs_view_flags[iob][vw.first:vw.last], dtype=np.uint8)
                         if self.det_flags is not None:
                             flags |= ob.detdata[self.det_flags][det, vw.first:vw.last] & self.det_flag_mask
-                        voff = 0
-                        for amp in range(n_amp_view):
-                            amplen = step_length if amp < n_amp_view - 1 else view_samples - voff
-                            n_good = amplen - np.count_nonzero(flags[voff:voff + amplen])
-                            if (n_good / amplen) <= self.good_fraction:
-                                self._amp_flags[offset + amp] = 1
-                            else:
-                                self._offsetvar[offset + amp] = 1.0 / (detnoise * n_good)
-                            voff += step_length
+                        # per-baseline count of good samples, vectorised (offset.py:318-343)
+                        starts = np.arange(n_amp_view, dtype=np.int64) * step_length
+                        bad = np.add.reduceat((flags != 0).astype(np.int64), starts)
+                        amplen = np.full(n_amp_view, step_length, dtype=np.int64)
+                        amplen[-1] = view_samples - starts[-1]
+                        n_good = amplen - bad
+                        cut = (n_good / amplen) <= self.good_fraction
+                        sl = slice(offset, offset + n_amp_view)
+                        self._amp_flags[sl][cut] = 1
+                        with np.errstate(divide="ignore"):
+                            var = 1.0 / (detnoise * n_good)
+                        self._offsetvar[sl] = np.where(cut, 0.0, var)
                     offset += n_amp_view
         self._flag_cache = {}
+        self._amp_offset_cache = {}
 
     def _detectors(self):
         return self._all_dets
@@ -356,6 +360,63 @@ class Offset(Template):
                 amplitudes.accel_update_device()
         elif amplitudes.accel_in_use():
             amplitudes.accel_update_host()
+
+    def det_amp_offsets(self, iob, dets):
+        """First amplitude of each detector's block for observation ``iob`` (the running
+        ``amp_offset`` of offset.py:727-760), cached."""
+        key = (iob, tuple(dets))
+        cache = self.__dict__.setdefault("_amp_offset_cache", {})
+        if key not in cache:
+            out = []
+            for d in dets:
+                off = self._det_start[d]
+                for job in range(iob):
+                    if d in self._obs_dets[job]:
+                        off += int(np.sum(self._obs_views[job]))
+                out.append(off)
+            cache[key] = np.array(out, dtype=np.int64)
+        return cache[key]
+
+    def add_to_signal_multi(self, detectors, amplitudes, **kwargs):
+        """All detectors in one launch per observation (device-resident buffers only)."""
+        from .. import capi
+        from ..accel import accel_device_ptr
+
+        if not self._check_enabled():
+            return
+        self._amps_to(amplitudes, True)
+        for iob, ob in enumerate(self.data.obs):
+            dets = [d for d in detectors if d in self._obs_dets[iob]]
+            if len(dets) == 0:
+                continue
+            dd = ob.detdata[self.det_data]
+            capi.dev.offset_add_to_signal_multi(
+                self._step_length(self.step_time, self._obs_rate[iob]), self.det_amp_offsets(iob, dets),
+                self._obs_views[iob], accel_device_ptr(amplitudes.local), accel_device_ptr(amplitudes.local_flags),
+                dd.indices(dets), accel_device_ptr(dd.data), ob.n_local_samples, ob.intervals[self.view].data)
+
+    def project_signal_multi(self, detectors, amplitudes, **kwargs):
+        from .. import capi
+        from ..accel import accel_device_ptr
+
+        if not self._check_enabled():
+            return
+        self._amps_to(amplitudes, True)
+        for iob, ob in enumerate(self.data.obs):
+            dets = [d for d in detectors if d in self._obs_dets[iob]]
+            if len(dets) == 0:
+                continue
+            dd = ob.detdata[self.det_data]
+            if self.det_flags is not None:
+                f_idx = ob.detdata[self.det_flags].indices(dets)
+                f_ptr = accel_device_ptr(self._solver_flags(iob, ob, True))
+            else:
+                f_idx, f_ptr = None, 0
+            capi.dev.offset_project_signal_multi(
+                dd.indices(dets), accel_device_ptr(dd.data), f_idx, f_ptr, self.det_flag_mask,
+                self._step_length(self.step_time, self._obs_rate[iob]), self.det_amp_offsets(iob, dets),
+                self._obs_views[iob], accel_device_ptr(amplitudes.local), accel_device_ptr(amplitudes.local_flags),
+                ob.n_local_samples, ob.intervals[self.view].data)
 
     def _add_to_signal(self, detector, amplitudes, use_accel=None, **kwargs):
         if detector not in self._all_dets:
