@@ -428,6 +428,14 @@ int toast_hip_scan_mask_dev(const int64_t * d_global2local, const uint8_t * d_ma
 /* Device-to-device copy on the stream (Copy operator on resident buffers). */
 int toast_hip_copy_dev(void * d_dst, const void * d_src, size_t nbytes, void * stream);
 
+/* PCG vector algebra on device-resident amplitude vectors
+ * [ref: src/toast/templates/amplitudes.py:400-565]:  y = a x + b y  (b == 0 overwrites), and the
+ * flagged dot product  sum_i x_i y_i over entries with both flags clear (flag pointers may be
+ * NULL); the dot returns its value to the host (synchronises the stream). */
+int toast_hip_vec_axpby_dev(int64_t n, double a, const double * d_x, double b, double * d_y, void * stream);
+int toast_hip_vec_dot_dev(int64_t n, const double * d_x, const double * d_y, const uint8_t * d_flags_x,
+                          const uint8_t * d_flags_y, double * result /*host*/, void * stream);
+
 /* ------------------------------------------------------------------------------------
  * Test / measurement helpers (device primitives compared per operation with the CPU).
  * ---------------------------------------------------------------------------------- */

@@ -556,6 +556,14 @@ class _Dev:
     def copy(self, d_dst, d_src, nbytes, stream=0):
         _check(lib().toast_hip_copy_dev(_p(d_dst), _p(d_src), C.c_size_t(int(nbytes)), _p(stream)))
 
+    def vec_axpby(self, n, a, d_x, b, d_y, stream=0):
+        _check(lib().toast_hip_vec_axpby_dev(_i64(n), C.c_double(a), _p(d_x), C.c_double(b), _p(d_y), _p(stream)))
+
+    def vec_dot(self, n, d_x, d_y, d_fx=0, d_fy=0, stream=0):
+        out = C.c_double(0.0)
+        _check(lib().toast_hip_vec_dot_dev(_i64(n), _p(d_x), _p(d_y), _p(d_fx), _p(d_fy), C.byref(out), _p(stream)))
+        return out.value
+
     def test_math(self, op, n, d_a, d_b, d_out, stream=0):
         _check(lib().toast_hip_test_math_dev(C.c_int(op), _i64(n), _p(d_a), _p(d_b), _p(d_out), _p(stream)))
 

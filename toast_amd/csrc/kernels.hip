@@ -558,6 +558,43 @@ __global__ __launch_bounds__(kThreads) void k_scan_mask(
 }
 
 // ------------------------------------------------------------------------------------
+// Amplitude-vector algebra of the PCG on the device (axpby, flagged dot product): the
+// Amplitudes arithmetic of src/toast/templates/amplitudes.py:400-565 for resident vectors.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_vec_axpby(int64_t n, double a, const double * __restrict__ x,
+                                                        double b, double * __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * kThreads) {
+        // b == 0 overwrites (y may hold anything, including NaN)
+        y[i] = (b == 0.0) ? a * x[i] : a * x[i] + b * y[i];
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_vec_dot(int64_t n, const double * __restrict__ x,
+                                                      const double * __restrict__ y,
+                                                      const uint8_t * __restrict__ fx,
+                                                      const uint8_t * __restrict__ fy,
+                                                      double * __restrict__ result) {
+    __shared__ double s_part[kThreads / 64];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * kThreads) {
+        const bool good = (fx == nullptr || fx[i] == 0) && (fy == nullptr || fy[i] == 0);
+        if (good) acc += x[i] * y[i];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) t += s_part[w];
+        unsafeAtomicAdd(result, t);
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // noise_weight   [ref: ops_noise_weight.cpp:71-96]
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void k_noise_weight(
@@ -1456,6 +1493,32 @@ int toast_hip_copy_dev(void * d_dst, const void * d_src, size_t nbytes, void * s
     return guarded([&] {
         if (nbytes == 0) return;
         TH_HIP(hipMemcpyAsync(d_dst, d_src, nbytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+    });
+}
+
+int toast_hip_vec_axpby_dev(int64_t n, double a, const double * d_x, double b, double * d_y, void * stream) {
+    return guarded([&] {
+        if (n <= 0) return;
+        hipLaunchKernelGGL(k_vec_axpby, flat_grid(n), dim3(kThreads), 0, as_stream(stream), n, a, d_x, b, d_y);
+        check_launch();
+    });
+}
+
+int toast_hip_vec_dot_dev(int64_t n, const double * d_x, const double * d_y, const uint8_t * d_flags_x,
+                          const uint8_t * d_flags_y, double * result, void * stream) {
+    return guarded([&] {
+        static double * d_res = nullptr;
+        if (d_res == nullptr) TH_HIP(hipMalloc((void **)&d_res, sizeof(double)));
+        hipStream_t st = as_stream(stream);
+        TH_HIP(hipMemsetAsync(d_res, 0, sizeof(double), st));
+        if (n > 0) {
+            dim3 grid = flat_grid(n);
+            if (grid.x > 1024) grid.x = 1024;
+            hipLaunchKernelGGL(k_vec_dot, grid, dim3(kThreads), 0, st, n, d_x, d_y, d_flags_x, d_flags_y, d_res);
+            check_launch();
+        }
+        TH_HIP(hipMemcpyAsync(result, d_res, sizeof(double), hipMemcpyDeviceToHost, st));
+        TH_HIP(hipStreamSynchronize(st));
     });
 }
 

@@ -319,7 +319,8 @@ void * Staging::resolve(void * host, size_t bytes, bool upload, bool download, b
     if (host == nullptr) return nullptr;
     if (accel_ && !force_temp) return Manager::get().device_ptr(host);
     void * dev = nullptr;
-    TH_HIP(hipMalloc(&dev, bytes ? bytes : 16));
+    // stream-ordered pool allocation: no device-wide synchronisation per staged call
+    TH_HIP(hipMallocAsync(&dev, bytes ? bytes : 16, stream_));
     temps_.push_back(Temp{host, dev, bytes, download});
     if (upload && bytes) {
         TH_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, stream_));
@@ -336,16 +337,16 @@ void Staging::finish() {
             TH_HIP(hipMemcpyAsync(t.host, t.dev, t.bytes, hipMemcpyDeviceToHost, stream_));
         }
     }
+    for (auto & t : temps_) (void)hipFreeAsync(t.dev, stream_);
     TH_HIP(hipStreamSynchronize(stream_));
-    for (auto & t : temps_) (void)hipFree(t.dev);
     temps_.clear();
 }
 
 Staging::~Staging() {
     if (!finished_) {
         // error path: make sure nothing queued still uses the temporaries, then free them
+        for (auto & t : temps_) (void)hipFreeAsync(t.dev, stream_);
         (void)hipStreamSynchronize(stream_);
-        for (auto & t : temps_) (void)hipFree(t.dev);
     }
 }
 

@@ -351,9 +351,10 @@ class SolverLHS(Operator):
                                   accel_device_ptr(g2l.data), accel_device_ptr(zmap.raw), dist.n_pix_submap, nnz,
                                   common["pi"], common["pp"], common["wi"], common["wp"], pf_idx, pf_ptr,
                                   tmpl.det_flag_mask, common["detw"], common["n_samp"], common["ivl"])
-        native().accel_synchronize()
-        amps_out.accel_update_host()
-        amps_in.accel_used(False)  # host copy is current again (it was never modified on the device)
+        if not getattr(self, "keep_on_device", False):
+            native().accel_synchronize()
+            amps_out.accel_update_host()
+            amps_in.accel_used(False)  # host copy is current again (never modified on the device)
         for t in tm.templates:
             t.det_data = self.det_temp
 
@@ -433,6 +434,18 @@ def solve(data, detectors, lhs_op, rhs_key, result_key, convergence=1.0e-12, n_i
     if not isinstance(result, AmplitudesMap):
         raise RuntimeError("result_key does not point to an AmplitudesMap")
 
+    # With the fused device path every PCG vector stays resident on the GPU: the per-iteration
+    # algebra (3 dots, 3 axpby, the preconditioner) runs in device kernels and only the three
+    # scalars cross PCIe.  Otherwise the vectors live on the host as in the reference.
+    on_device = bool(getattr(lhs_op, "_can_fuse", lambda d: False)(data))
+
+    def place(amps, name):
+        if on_device:
+            amps.accel_resident(name)
+        return amps
+
+    place(rhs, rhs_key)
+    place(result, result_key)
     lhs_out_key = f"{lhs_op.name}_out"
     if lhs_out_key in data:
         data[lhs_out_key].clear()
@@ -446,21 +459,18 @@ def solve(data, detectors, lhs_op, rhs_key, result_key, convergence=1.0e-12, n_i
     data[proposal_key] = rhs.duplicate()
     data[proposal_key].reset()
     proposal = data[proposal_key]
-    temp = rhs.duplicate()
-    temp.reset()
 
     # residual of the starting guess
     lhs_op.template_matrix.amplitudes = result_key
     lhs_op.out = lhs_out_key
+    lhs_op.keep_on_device = on_device
     lhs_op.apply(data, detectors=detectors)
     residual = rhs.duplicate()
     residual -= lhs_out
     precond = rhs.duplicate()
     precond.reset()
     lhs_op.template_matrix.apply_precond(residual, precond)
-    for k, v in proposal.items():
-        v._host()
-        v.local[:] = precond[k].local
+    proposal.copy_from(precond)
     lhs_op.template_matrix.amplitudes = proposal_key
 
     sqsum = rhs.dot(rhs)
@@ -474,16 +484,10 @@ def solve(data, detectors, lhs_op, rhs_key, result_key, convergence=1.0e-12, n_i
             raise RuntimeError("Residual is not finite")
         lhs_op.apply(data, detectors=detectors)
         alpha = delta / proposal.dot(lhs_out)
-        temp.reset()
-        for k, v in temp.items():
-            v.local[:] = proposal[k].local
-        temp *= alpha
-        result += temp
-        temp.reset()
-        for k, v in temp.items():
-            v.local[:] = lhs_out[k].local
-        temp *= alpha
-        residual -= temp
+        # result += alpha * proposal ; residual -= alpha * lhs_out  (mapmaker_solve.py:683-701,
+        # same roundings as the reference's scaled temporary)
+        result.axpby(alpha, proposal)
+        residual.axpby(-alpha, lhs_out)
         sqsum = residual.dot(residual)
         relative = sqsum / sqsum_init if sqsum_init != 0 else 0.0
         history.append(relative)
@@ -500,9 +504,14 @@ def solve(data, detectors, lhs_op, rhs_key, result_key, convergence=1.0e-12, n_i
         delta_last = delta
         delta = precond.dot(residual)
         beta = delta / delta_last
-        proposal *= beta
-        proposal += precond
-    temp.clear()
+        # proposal = beta * proposal + precond
+        proposal.axpby(1.0, precond, beta)
+    lhs_op.keep_on_device = False
+    if on_device:
+        result.accel_update_host()
+        rhs.accel_update_host()
+    for tmp in (residual, precond):
+        tmp.clear()
     proposal.clear()
     del data[proposal_key]
     lhs_out.clear()

@@ -18,6 +18,7 @@ from ..accel import (
     accel_data_reset,
     accel_data_update_device,
     accel_data_update_host,
+    accel_device_ptr,
     native,
 )
 from ..data import defaults
@@ -45,14 +46,48 @@ class Amplitudes(AcceleratorObject):
         if self.accel_in_use():
             self.accel_update_host()
 
+    def accel_resident(self, name=None):
+        """Make the device copy current and keep working there: later arithmetic (``+=``,
+        ``axpby``, ``dot`` ...) runs in device kernels (toast_hip_vec_*_dev) until
+        ``accel_update_host``."""
+        if self._n_local == 0:
+            return self
+        if not self.accel_exists():
+            self.accel_create(name)
+        if not self.accel_in_use():
+            self.accel_update_device()
+        return self
+
+    def _device_pair(self, other):
+        """True when the operation should run on the device: either operand's device copy is
+        the current one (the other is then made resident as well)."""
+        if not isinstance(other, Amplitudes):
+            return self.accel_in_use()
+        if not (self.accel_in_use() or other.accel_in_use()):
+            return False
+        self.accel_resident()
+        other.accel_resident()
+        return True
+
+    def _dptr(self):
+        return accel_device_ptr(self.local)
+
     def duplicate(self):
-        self._host()
         ret = Amplitudes(self._comm, self._n_global, self._n_local, dtype=self.local.dtype)
-        ret.local[:] = self.local
-        ret.local_flags[:] = self.local_flags
+        if self.accel_in_use():
+            ret.local_flags[:] = self.local_flags
+            ret.accel_create(self._accel_name + "_dup")
+            ret.accel_used(True)
+            ret.copy_from(self)
+        else:
+            ret.local[:] = self.local
+            ret.local_flags[:] = self.local_flags
         return ret
 
     def reset(self):
+        if self.accel_in_use():
+            self.accel_reset()
+            return
         self.local[:] = 0
         if self.accel_exists():
             self.accel_reset()
@@ -61,38 +96,69 @@ class Amplitudes(AcceleratorObject):
         if self.accel_exists():
             self.accel_delete()
 
-    def __iadd__(self, other):
-        self._host()
-        if isinstance(other, Amplitudes):
-            other._host()
-            self.local += other.local
+    def axpby(self, a, other, b=1.0):
+        """self = a * other + b * self (the PCG updates without a temporary)."""
+        if self._n_local == 0:
+            return self
+        if self._device_pair(other):
+            from .. import capi
+
+            capi.dev.vec_axpby(self._n_local, float(a), other._dptr(), float(b), self._dptr())
+        elif b == 1.0:
+            self.local += a * other.local
         else:
-            self.local += other
+            self.local *= b
+            self.local += a * other.local
+        return self
+
+    def copy_from(self, other):
+        """self.local[:] = other.local on whichever side is current."""
+        if self._n_local == 0:
+            return self
+        if self._device_pair(other):
+            from .. import capi
+
+            capi.dev.vec_axpby(self._n_local, 1.0, other._dptr(), 0.0, self._dptr())
+        else:
+            self.local[:] = other.local
+        return self
+
+    def __iadd__(self, other):
+        if isinstance(other, Amplitudes):
+            return self.axpby(1.0, other)
+        self._host()
+        self.local += other
         return self
 
     def __isub__(self, other):
-        self._host()
         if isinstance(other, Amplitudes):
-            other._host()
-            self.local -= other.local
-        else:
-            self.local -= other
+            return self.axpby(-1.0, other)
+        self._host()
+        self.local -= other
         return self
 
     def __imul__(self, other):
-        self._host()
         if isinstance(other, Amplitudes):
+            self._host()
             other._host()
             self.local *= other.local
+        elif self.accel_in_use():
+            from .. import capi
+
+            capi.dev.vec_axpby(self._n_local, 0.0, self._dptr(), float(other), self._dptr())
         else:
             self.local *= other
         return self
 
     def dot(self, other):
-        self._host()
-        other._host()
-        good = np.logical_and(self.local_flags == 0, other.local_flags == 0)
-        val = float(np.dot(self.local[good], other.local[good]))
+        if self._n_local > 0 and self._device_pair(other):
+            from .. import capi
+
+            val = capi.dev.vec_dot(self._n_local, self._dptr(), other._dptr(), accel_device_ptr(self.local_flags),
+                                   accel_device_ptr(other.local_flags))
+        else:
+            good = np.logical_and(self.local_flags == 0, other.local_flags == 0)
+            val = float(np.dot(np.where(good, self.local, 0.0), other.local))
         if self._comm is not None and self._comm.comm_world is not None:
             val = self._comm.allreduce_scalar(val, op="sum")
         return val
@@ -159,6 +225,21 @@ class AmplitudesMap(dict):
 
     def __imul__(self, other):
         return self._binary(other, lambda a, b: a.__imul__(b))
+
+    def axpby(self, a, other, b=1.0):
+        for k, v in self.items():
+            v.axpby(a, other[k], b)
+        return self
+
+    def copy_from(self, other):
+        for k, v in self.items():
+            v.copy_from(other[k])
+        return self
+
+    def accel_resident(self, name):
+        for k, v in self.items():
+            v.accel_resident(f"{name}_{k}")
+        return self
 
     def accel_exists(self):
         return all(v.accel_exists() for v in self.values()) and len(self) > 0
@@ -485,14 +566,24 @@ class Offset(Template):
         # diagonal preconditioner (offset.py:1007-1028 -> template_offset_apply_diag_precond)
         if self._n_local == 0:
             return
-        if amplitudes_in.accel_in_use():
-            amplitudes_in.accel_update_host()
-        if amplitudes_out.accel_in_use():
-            amplitudes_out.accel_update_host()
+        if amplitudes_in.accel_in_use() or amplitudes_out.accel_in_use():
+            # device-resident PCG vectors: the variances are uploaded once per template
+            amplitudes_in.accel_resident()
+            amplitudes_out.accel_resident()
+            if not getattr(self, "_offsetvar_on_dev", False):
+                accel_data_create(self._offsetvar, f"{self.name}_offsetvar", owner=self)
+                accel_data_update_device(self._offsetvar, f"{self.name}_offsetvar")
+                self._offsetvar_on_dev = True
+            native().template_offset_apply_diag_precond(self._offsetvar, amplitudes_in.local,
+                                                        amplitudes_in.local_flags, amplitudes_out.local, True)
+            return
         native().template_offset_apply_diag_precond(self._offsetvar, amplitudes_in.local, amplitudes_in.local_flags,
                                                     amplitudes_out.local, False)
 
     def clear(self):
+        if getattr(self, "_offsetvar_on_dev", False):
+            accel_data_delete(self._offsetvar, f"{self.name}_offsetvar")
+            self._offsetvar_on_dev = False
         for (iob, on_dev), buf in self._flag_cache.items():
             if on_dev:
                 accel_data_delete(buf, f"{self.name}_solver_flags")
