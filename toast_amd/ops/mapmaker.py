@@ -87,6 +87,8 @@ class MapMaker(Operator):
     save_cleaned = Bool(False, help="If True, save the template-subtracted detector timestreams")
     overwrite_cleaned = Bool(False, help="If True and save_cleaned is True, overwrite the input data")
     reset_pix_dist = Bool(False, help="Clear any existing pixel distribution.")
+    fused_lhs = Bool(True, help="Let SolverLHS use the fused device-resident kernels when it can "
+                                "(not a reference trait; False = the reference operator sequence)")
 
     def _exec(self, data, detectors=None, **kwargs):
         for trait in ("binning",):
@@ -185,7 +187,7 @@ class MapMaker(Operator):
                 del data[f"{self.name}_rhs"]
             rhs.apply(data, detectors=detectors)
             _t = _lap("rhs", _t)
-            lhs = SolverLHS(name=f"{self.name}_lhs", binning=binning, template_matrix=tm)
+            lhs = SolverLHS(name=f"{self.name}_lhs", binning=binning, template_matrix=tm, fused=self.fused_lhs)
             if amp_name in data:
                 del data[amp_name]
             self.history = solve(data, detectors, lhs, f"{self.name}_rhs", amp_name, convergence=self.convergence,

@@ -507,9 +507,9 @@ def solve(data, detectors, lhs_op, rhs_key, result_key, convergence=1.0e-12, n_i
         # proposal = beta * proposal + precond
         proposal.axpby(1.0, precond, beta)
     lhs_op.keep_on_device = False
-    if on_device:
-        result.accel_update_host()
-        rhs.accel_update_host()
+    # hand the solution back on the host (AmplitudesMap.accel_update_host skips host-current ones)
+    result.accel_update_host()
+    rhs.accel_update_host()
     for tmp in (residual, precond):
         tmp.clear()
     proposal.clear()
