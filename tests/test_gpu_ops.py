@@ -467,3 +467,33 @@ def test_solve_resident_equals_host_algebra():
     np.testing.assert_allclose(hist[True][:5], hist[False][:5], rtol=1e-6)
     scale = np.max(np.abs(amps[False]))
     assert np.max(np.abs(amps[True] - amps[False])) < 1e-6 * scale
+
+
+def test_lazy_host_coherence_and_eviction():
+    """Pipelines leave detector data resident and device-current; the host copy is refreshed on
+    access (DetectorData.data) or by eviction, and equals the eagerly copied result."""
+    from toast_amd.ops.pipeline import Pipeline
+
+    got = {}
+    for lazy in (True, False):
+        data = create_satellite_data(n_det=4, n_samp=3000)
+        data.lazy_host = lazy
+        dp, pix, sw = pointing_ops(nside=64, create_dist=None)
+        Pipeline(operators=[dp, pix, sw]).apply(data)
+        ob = data.obs[0]
+        for key in (defaults.quats, defaults.pixels, defaults.weights):
+            assert ob.detdata[key].accel_in_use() == lazy
+            assert ob.detdata[key].accel_exists() == lazy
+        if lazy:
+            # stale host buffer until somebody looks
+            assert not np.any(ob.detdata[defaults.pixels].buffer)
+            px = ob.detdata[defaults.pixels].data          # copies back
+            assert not ob.detdata[defaults.pixels].accel_in_use()
+            freed = data.accel_evict()                      # quats + weights written back and freed
+            assert freed >= ob.detdata[defaults.quats].buffer.nbytes + ob.detdata[defaults.weights].buffer.nbytes
+            assert not ob.detdata[defaults.weights].accel_exists()
+            assert data.accel_evict() == 0
+        got[lazy] = {k: ob.detdata[k].data.copy() for k in (defaults.quats, defaults.pixels, defaults.weights)}
+    for k in got[True]:
+        assert np.any(got[False][k])
+        assert np.array_equal(got[True][k], got[False][k])

@@ -82,13 +82,32 @@ def _release(ptr, nbytes, name):
         pass
 
 
+_eviction_handlers = []
+
+
+def add_eviction_handler(fn):
+    """Register ``fn() -> bytes_freed``; called when a device allocation fails so that lazily
+    retained buffers can be written back and released before one retry."""
+    _eviction_handlers.append(fn)
+
+
 def accel_data_create(data, name="None", zero_out=False, owner=None):
     """reference accel.py:147-176.  ``owner``: object whose lifetime bounds the device copy."""
     import weakref
 
     ensure_assigned()
     arr = _key(data)
-    native().accel_create(arr, name)
+    try:
+        native().accel_create(arr, name)
+    except RuntimeError as err:
+        if "allocation failed" not in str(err):
+            raise
+        freed = 0
+        for fn in list(_eviction_handlers):
+            freed += int(fn() or 0)
+        if freed == 0:
+            raise
+        native().accel_create(arr, name)
     if zero_out:
         native().accel_reset(arr, name)
     if owner is not None:

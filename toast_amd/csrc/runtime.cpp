@@ -2,6 +2,10 @@
 // /root/reference/src/toast/_libtoast/accelerator.cpp:233-766 (OmpManager).
 #include "runtime.hpp"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
 #include <cstdio>
 #include <cstdlib>
 #include <list>
@@ -226,6 +230,7 @@ void * Manager::create(const void * host, size_t nbytes, const char * name) {
           << it->second.nbytes << " bytes on device " << device_;
         throw Error(TOAST_HIP_ERR_MEMORY, o.str());
     }
+    const double t0 = trace_begin();
     void * dev = nullptr;
     hipError_t e = hipMalloc(&dev, nbytes ? nbytes : 16);
     if (e != hipSuccess || dev == nullptr) {
@@ -235,17 +240,45 @@ void * Manager::create(const void * host, size_t nbytes, const char * name) {
         throw Error(TOAST_HIP_ERR_MEMORY, o.str());
     }
     Entry ent{dev, nbytes, name ? name : "NA", true};
-    // Page-lock large host buffers: update_device / update_host then run at PCIe speed instead
-    // of through the driver's bounce buffers (pageable copies measured 5-10x slower).
-    if (nbytes >= pin_threshold()) {
-        if (hipHostRegister(const_cast<void *>(host), nbytes, hipHostRegisterDefault) == hipSuccess) {
-            ent.host_registered = true;
-        } else {
-            (void)hipGetLastError();
-        }
-    }
     table_[host] = ent;
+    trace("create", ent.name, nbytes, t0);
     return dev;
+}
+
+// Page-lock large host buffers at their first transfer: update_device / update_host then run at
+// PCIe speed instead of through the driver's bounce buffers (pageable copies measured 5-10x
+// slower).  Buffers that are produced and consumed on the device never pay for the pinning
+// (nor for touching their host pages at all).
+void Manager::pin_for_transfer(const void * host, Entry & e) {
+    if (e.host_registered || e.pin_failed || e.nbytes < pin_threshold()) return;
+    if (hipHostRegister(const_cast<void *>(host), e.nbytes, hipHostRegisterDefault) == hipSuccess) {
+        e.host_registered = true;
+    } else {
+        (void)hipGetLastError();
+        e.pin_failed = true;
+    }
+}
+
+static bool trace_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char * s = std::getenv("TOAST_HIP_TRACE");
+        v = (s != nullptr && s[0] != '\0' && s[0] != '0') ? 1 : 0;
+    }
+    return v == 1;
+}
+
+static double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+double Manager::trace_begin() { return trace_enabled() ? now_s() : 0.0; }
+
+void Manager::trace(const char * what, const std::string & name, size_t nbytes, double t0) {
+    if (!trace_enabled()) return;
+    const double dt = now_s() - t0;
+    std::fprintf(stderr, "[toast_hip] %-13s %-28s %10.3f MB %8.2f ms %7.2f GB/s\n", what, name.c_str(),
+                 nbytes / 1.0e6, dt * 1e3, dt > 0 ? nbytes / dt / 1e9 : 0.0);
 }
 
 void Manager::adopt(const void * host, size_t nbytes, void * device, const char * name) {
@@ -268,24 +301,32 @@ void Manager::reset(const void * host, size_t nbytes, const char * name) {
 void Manager::update_device(const void * host, size_t nbytes, const char * name) {
     require_device();
     Entry & e = lookup(host, nbytes, name, "update device");
+    const double t0 = trace_begin();
+    pin_for_transfer(host, e);
     // Pageable host memory: the call returns once the source has been consumed.
     TH_HIP(hipMemcpyAsync(e.dev, host, nbytes, hipMemcpyHostToDevice, stream_));
     TH_HIP(hipStreamSynchronize(stream_));
+    trace("update_device", e.name, nbytes, t0);
 }
 
 void Manager::update_host(void * host, size_t nbytes, const char * name) {
     require_device();
     Entry & e = lookup(host, nbytes, name, "update host");
+    const double t0 = trace_begin();
+    pin_for_transfer(host, e);
     TH_HIP(hipMemcpyAsync(host, e.dev, nbytes, hipMemcpyDeviceToHost, stream_));
     TH_HIP(hipStreamSynchronize(stream_));
+    trace("update_host", e.name, nbytes, t0);
 }
 
 void Manager::remove(const void * host, size_t nbytes, const char * name) {
     require_device();
     Entry & e = lookup(host, nbytes, name, "delete");
+    const double t0 = trace_begin();
     TH_HIP(hipStreamSynchronize(stream_));
     if (e.host_registered) (void)hipHostUnregister(const_cast<void *>(host));
     if (e.owned) TH_HIP(hipFree(e.dev));
+    trace("delete", e.name, nbytes, t0);
     table_.erase(host);
 }
 

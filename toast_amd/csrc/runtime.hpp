@@ -120,7 +120,11 @@ private:
         std::string name;
         bool owned = true;
         bool host_registered = false;
+        bool pin_failed = false;
     };
+    void pin_for_transfer(const void * host, Entry & e);
+    static double trace_begin();
+    static void trace(const char * what, const std::string & name, size_t nbytes, double t0);
     Entry & lookup(const void * host, size_t nbytes, const char * name, const char * what);
 
     std::unordered_map<const void *, Entry> table_;

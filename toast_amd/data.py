@@ -211,8 +211,23 @@ class DetectorData(AcceleratorObject):
 
     @property
     def data(self):
-        """The full buffer view; its base pointer is the accelerator key."""
+        """The full buffer on the HOST.  Lazy coherence: when the device copy is the current
+        one (Pipelines leave their detector-data products resident), it is copied back first and
+        the host becomes the current side again."""
+        if self._accel_used:
+            self.accel_update_host()
         return self._data
+
+    @property
+    def buffer(self):
+        """The same view without synchronisation: its base pointer is the accelerator key.  For
+        device-side code paths only -- the contents may be stale."""
+        return self._data
+
+    def arg(self, use_accel):
+        """Array to hand to a kernel call: the key view when the kernel runs on registered
+        device memory, the (synchronised) host contents when the call is host-staged."""
+        return self._data if use_accel else self.data
 
     def indices(self, names):
         """Rows of the given detectors, int32 (observation_data.py:171-195)."""
@@ -247,6 +262,9 @@ class DetectorData(AcceleratorObject):
 
     def reset(self, dets=None):
         if dets is None:
+            if self._accel_used:
+                self.accel_reset()   # the host side is stale anyway
+                return
             self._data[:] = 0
             if self.accel_exists():
                 self.accel_reset()
@@ -267,6 +285,8 @@ class DetectorData(AcceleratorObject):
         return key
 
     def __getitem__(self, key):
+        if self._accel_used:
+            self.accel_update_host()
         if isinstance(key, tuple):
             first = key[0]
             if isinstance(first, (list, tuple)) and first and isinstance(first[0], (str, np.str_)):
@@ -277,6 +297,8 @@ class DetectorData(AcceleratorObject):
         return self._data[self._row(key)]
 
     def __setitem__(self, key, value):
+        if self._accel_used:
+            self.accel_update_host()
         if isinstance(key, tuple):
             self._data[(self._row(key[0]),) + tuple(key[1:])] = value
         else:
@@ -489,6 +511,17 @@ class Data(MutableMapping):
         self.obs = []
         self._internal = {}
         self._pinned = {k: set() for k in ("global", "detdata", "shared")}
+        # Lazy host coherence (MI355X: 288 GB of HBM): Pipelines leave detector data resident
+        # and device-current at finalize; ``DetectorData.data`` copies back on first host access.
+        # ``_protected``: detdata keys staged by a running Pipeline (never evicted).
+        self.lazy_host = True
+        self._protected = []   # one set per running Pipeline
+        import weakref
+
+        from .accel import add_eviction_handler
+
+        ref = weakref.ref(self)
+        add_eviction_handler(lambda: (ref().accel_evict() if ref() is not None else 0))
 
     def accel_pin(self, names):
         """Keep these objects resident on the device across Pipelines: ``accel_update_host`` and
@@ -505,9 +538,27 @@ class Data(MutableMapping):
             self._pinned[k] -= set(v)
         for key, obj in self._each({k: list(v) for k, v in names.items()}, include_pinned=True):
             if obj.accel_exists():
+                if self.lazy_host and isinstance(obj, DetectorData):
+                    continue  # stays resident; copied back on host access or eviction
                 if update_host and obj.accel_in_use():
                     obj.accel_update_host()
                 obj.accel_delete()
+
+    def accel_evict(self):
+        """Write back and free every resident detector-data buffer that is neither pinned nor
+        staged by a running Pipeline.  Returns the number of bytes released."""
+        freed = 0
+        for ob in self.obs:
+            for key in list(ob.detdata.keys()):
+                obj = ob.detdata[key]
+                if (key in self._pinned["detdata"] or any(key in s for s in self._protected)
+                        or not obj.accel_exists()):
+                    continue
+                if obj.accel_in_use():
+                    obj.accel_update_host()
+                freed += obj.buffer.nbytes
+                obj.accel_delete()
+        return freed
 
     def all_local_detectors(self, selection=None, flagmask=0):
         seen, out = set(), []

@@ -39,16 +39,24 @@ class ApplyAmplitudes(Operator):
         # inside a Pipeline so that the template kernels find device-resident buffers (staged
         # once) instead of staging the whole timestream buffer per detector
         Pipeline(operators=[tm]).apply(data, detectors=detectors)
+        if out != self.det_data:
+            Pipeline(operators=[Copy(detdata=[(self.det_data, out)])]).apply(data, detectors=detectors)
+        sign = -1.0 if self.op == "subtract" else 1.0
         for ob in data.obs:
-            if out != self.det_data:
-                Copy(detdata=[(self.det_data, out)]).apply(data, detectors=detectors)
             dets = ob.select_local_detectors(detectors, flagmask=tm.det_mask)
-            t = ob.detdata[temp]
-            if t.accel_in_use():
-                t.accel_update_host()
-            o = ob.detdata[out]
-            if o.accel_in_use():
-                o.accel_update_host()
+            t, o = ob.detdata[temp], ob.detdata[out]
+            if t.accel_in_use() and t.detectors == o.detectors and t.dtype == np.float64 and o.dtype == np.float64:
+                # whole-buffer device update  out = out +- temp  (rows of unselected detectors
+                # hold zeros in temp); nothing crosses PCIe
+                from .. import capi
+                from ..accel import accel_device_ptr
+
+                if not o.accel_exists():
+                    o.accel_create(out)
+                if not o.accel_in_use():
+                    o.accel_update_device()
+                capi.dev.vec_axpby(t.buffer.size, sign, accel_device_ptr(t.buffer), 1.0, accel_device_ptr(o.buffer))
+                continue
             for d in dets:
                 if self.op == "subtract":
                     o[d] -= t[d]

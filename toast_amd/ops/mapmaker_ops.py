@@ -78,9 +78,9 @@ class ScanMap(Operator):
             if len(dets) == 0:
                 continue
             kernel(map_dist.global_submap_to_local, map_dist.n_pix_submap, map_data.data,
-                   ob.detdata[self.det_data].data, ob.detdata[self.det_data].indices(dets),
-                   ob.detdata[self.pixels].data, ob.detdata[self.pixels].indices(dets),
-                   ob.detdata[self.weights].data, ob.detdata[self.weights].indices(dets),
+                   ob.detdata[self.det_data].arg(use_accel), ob.detdata[self.det_data].indices(dets),
+                   ob.detdata[self.pixels].arg(use_accel), ob.detdata[self.pixels].indices(dets),
+                   ob.detdata[self.weights].arg(use_accel), ob.detdata[self.weights].indices(dets),
                    ob.intervals[self.view].data, 1.0, bool(self.zero), bool(self.subtract), False, use_accel)
 
     def _finalize(self, data, **kwargs):
@@ -161,14 +161,9 @@ class ScanMask(Operator):
                     g2l.accel_update_device()
                 capi.dev.scan_mask(accel_device_ptr(g2l.data), accel_device_ptr(mask_data.raw),
                                    mask_dist.n_pix_submap, self.mask_bits, self.det_flags_value, pd.indices(dets),
-                                   accel_device_ptr(pd.data), fd.indices(dets), accel_device_ptr(fd.data),
+                                   accel_device_ptr(pd.buffer), fd.indices(dets), accel_device_ptr(fd.buffer),
                                    ob.n_local_samples, ob.intervals[self.view].data)
                 continue
-            if pd.accel_in_use():
-                pd.accel_update_host()
-                pd.accel_used(True)
-            if fd.accel_in_use():
-                fd.accel_update_host()
             for iv in ob.intervals[self.view]:
                 for det in dets:
                     pix = pd[det, iv.first:iv.last]
@@ -226,7 +221,7 @@ class NoiseWeight(Operator):
                 if not dd.accel_exists():
                     dd.accel_create(self.det_data)
                 dd.accel_update_device()
-            native().noise_weight(dd.data, dd.indices(dets), ob.intervals[self.view].data, detector_weights,
+            native().noise_weight(dd.arg(use_accel), dd.indices(dets), ob.intervals[self.view].data, detector_weights,
                                   use_accel)
 
     def _finalize(self, data, **kwargs):
@@ -281,7 +276,7 @@ class _MapBuilder(Operator):
                 if not fd.accel_exists():
                     fd.accel_create(self.det_flags)
                 fd.accel_update_device()
-            flag_indx, flag_data = fd.indices(dets), fd.data
+            flag_indx, flag_data = fd.indices(dets), fd.arg(use_accel)
         else:
             # reference quirk (mapmaker_utils.py:836-838): [-1]; our binding wants n_det entries
             flag_indx, flag_data = np.zeros(len(dets), dtype=np.int32), np.zeros((1, 1), dtype=np.uint8)
@@ -353,8 +348,8 @@ class BuildNoiseWeighted(_MapBuilder):
             flag_indx, flag_data, shared = self._flag_args(ob, dets, use_accel)
             native().build_noise_weighted(
                 dist.global_submap_to_local, zmap.data, ob.detdata[self.pixels].indices(dets),
-                ob.detdata[self.pixels].data, ob.detdata[self.weights].indices(dets), ob.detdata[self.weights].data,
-                ob.detdata[self.det_data].indices(dets), ob.detdata[self.det_data].data, flag_indx, flag_data,
+                ob.detdata[self.pixels].arg(use_accel), ob.detdata[self.weights].indices(dets), ob.detdata[self.weights].arg(use_accel),
+                ob.detdata[self.det_data].indices(dets), ob.detdata[self.det_data].arg(use_accel), flag_indx, flag_data,
                 detweights, self.det_flag_mask, ob.intervals[self.view].data, shared, self.shared_flag_mask,
                 use_accel)
 
@@ -399,7 +394,7 @@ class BuildHitMap(_MapBuilder):
                 continue
             flag_indx, flag_data, shared = self._flag_args(ob, dets, use_accel)
             native().build_hit_map(dist.global_submap_to_local, hits.data, ob.detdata[self.pixels].indices(dets),
-                                   ob.detdata[self.pixels].data, flag_indx, flag_data, self.det_flag_mask,
+                                   ob.detdata[self.pixels].arg(use_accel), flag_indx, flag_data, self.det_flag_mask,
                                    ob.intervals[self.view].data, shared, self.shared_flag_mask, use_accel)
 
     def _finalize(self, data, use_accel=None, **kwargs):
@@ -453,7 +448,7 @@ class BuildInverseCovariance(_MapBuilder):
             flag_indx, flag_data, shared = self._flag_args(ob, dets, use_accel)
             native().build_inverse_covariance(
                 dist.global_submap_to_local, invcov.data, ob.detdata[self.pixels].indices(dets),
-                ob.detdata[self.pixels].data, ob.detdata[self.weights].indices(dets), ob.detdata[self.weights].data,
+                ob.detdata[self.pixels].arg(use_accel), ob.detdata[self.weights].indices(dets), ob.detdata[self.weights].arg(use_accel),
                 flag_indx, flag_data, detweights, self.det_flag_mask, ob.intervals[self.view].data, shared,
                 self.shared_flag_mask, use_accel)
 
@@ -655,7 +650,7 @@ class Copy(Operator):
                     ob.detdata.ensure(dst, sample_shape=s.detector_shape[1:], dtype=s.dtype, detectors=s.detectors,
                                       accel=True)
                     d = ob.detdata[dst]
-                    capi.dev.copy(accel_device_ptr(d.data), accel_device_ptr(s.data), s.data.nbytes)
+                    capi.dev.copy(accel_device_ptr(d.buffer), accel_device_ptr(s.buffer), s.buffer.nbytes)
                     d.accel_used(True)
                     continue
                 if s.accel_in_use():

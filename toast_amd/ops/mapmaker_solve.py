@@ -321,7 +321,7 @@ class SolverLHS(Operator):
             ivl = ob.intervals[pixels_op.view].data
             if binning.det_flags is not None:
                 fd = self._resident(ob.detdata[binning.det_flags], binning.det_flags)
-                f_idx, f_ptr, f_ns = fd.indices(dets), accel_device_ptr(fd.data), n_samp
+                f_idx, f_ptr, f_ns = fd.indices(dets), accel_device_ptr(fd.buffer), n_samp
             else:
                 f_idx, f_ptr, f_ns = np.zeros(len(dets), np.int32), 0, 0
             if binning.shared_flags is not None:
@@ -335,8 +335,8 @@ class SolverLHS(Operator):
             else:
                 pf_idx, pf_ptr = None, 0
             common = dict(step=step_length, ao=amp_offsets, nav=tmpl._obs_views[iob],
-                          pi=pd.indices(dets), pp=accel_device_ptr(pd.data), wi=wd.indices(dets),
-                          wp=accel_device_ptr(wd.data), n_samp=n_samp, ivl=ivl, detw=detw)
+                          pi=pd.indices(dets), pp=accel_device_ptr(pd.buffer), wi=wd.indices(dets),
+                          wp=accel_device_ptr(wd.buffer), n_samp=n_samp, ivl=ivl, detw=detw)
             D.offset_accumulate(step_length, amp_offsets, tmpl._obs_views[iob], accel_device_ptr(amps_in.local),
                                 accel_device_ptr(amps_in.local_flags), accel_device_ptr(g2l.data),
                                 accel_device_ptr(zmap.raw), dist.n_pix_submap, nnz, common["pi"], common["pp"],

@@ -95,7 +95,7 @@ class NoiseFilter(Operator):
             kernels = np.array(kernels)
             idx = dd.indices(dets)
             extend = np.zeros(len(dets), dtype=np.int32)
-            n_samp = dd.data.shape[1]
+            n_samp = dd.shape[1]
             if flags is not None:
                 # impulse response spread (fft.py:836-872) through the same GPU pipeline
                 temp = np.zeros((len(dets), n_samp))
@@ -114,7 +114,7 @@ class NoiseFilter(Operator):
                     extend[i] = imax - imin
                     if extend[i] == n_samp:
                         raise RuntimeError("Impulse response spreads to all samples")
-            hipfft.convolve_buffer(dd.data, idx, rate, kern_freq, kernels, use_accel=on_dev)
+            hipfft.convolve_buffer(dd.arg(on_dev), idx, rate, kern_freq, kernels, use_accel=on_dev)
             if flags is not None:
                 for i, f in enumerate(flags):
                     ext = int(extend[i])

@@ -65,6 +65,9 @@ class Pipeline(Operator):
         if pipe_accel:
             self._staged_data = _SetDict()
             self._unstaged_data = _SetDict()
+            self._protect = set()
+            if hasattr(data, "_protected"):
+                data._protected.append(self._protect)
         det_mask = None
         for op in self.operators:
             if op.has_trait("det_mask"):
@@ -105,6 +108,7 @@ class Pipeline(Operator):
             requires = _SetDict(op.requires())
             if run_accel:
                 requires -= self._staged_data
+                self._protect |= requires["detdata"] | set(op.provides().get("detdata", ()))
                 data.accel_create(requires)
                 data.accel_update_device(requires)
                 self._unstaged_data -= requires
@@ -135,6 +139,15 @@ class Pipeline(Operator):
             for op in self.operators:
                 provides |= op.provides()
             provides &= self._staged_data
+            if getattr(data, "lazy_host", False):
+                # detector data (the bulk) stays resident and device-current: the host copy is
+                # refreshed on access (DetectorData.data) or on eviction.  Small objects follow
+                # the reference: outputs copied back, device copies freed.
+                provides["detdata"] = set()
+                self._staged_data["detdata"] = set()
+            if getattr(self, "_protect", None) is not None and hasattr(data, "_protected"):
+                data._protected[:] = [s for s in data._protected if s is not self._protect]
+                self._protect = None
             data.accel_update_host(provides)
             data.accel_delete(self._staged_data)
             self._staged_data = None

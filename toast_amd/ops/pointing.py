@@ -72,7 +72,7 @@ class PointingDetectorSimple(Operator):
             quat_indx = ob.detdata[self.quats].indices(dets)
             flags = np.zeros(1, dtype=np.uint8) if self.shared_flags is None else ob.shared[self.shared_flags].data
             native().pointing_detector(fp_quats, ob.shared[self.boresight].data, quat_indx,
-                                       ob.detdata[self.quats].data, ob.intervals[self.view].data, flags,
+                                       ob.detdata[self.quats].arg(use_accel), ob.intervals[self.view].data, flags,
                                        self.shared_flag_mask, use_accel)
 
     def _finalize(self, data, **kwargs):
@@ -224,8 +224,8 @@ class PixelsHealpix(Operator):
                 flags = np.zeros(1, dtype=np.uint8)
             else:
                 flags = ob.shared[self.detector_pointing.shared_flags].data
-            native().pixels_healpix(quat_indx, ob.detdata[quats_name].data, flags,
-                                    self.detector_pointing.shared_flag_mask, pix_indx, ob.detdata[self.pixels].data,
+            native().pixels_healpix(quat_indx, ob.detdata[quats_name].arg(use_accel), flags,
+                                    self.detector_pointing.shared_flag_mask, pix_indx, ob.detdata[self.pixels].arg(use_accel),
                                     ob.intervals[view].data, hit_submaps, self._n_pix_submap, self.nside,
                                     bool(self.nest), use_accel)
             if self._local_submaps is not None:
@@ -321,12 +321,12 @@ class StokesWeights(Operator):
                     hwp_data = ob.shared[self.hwp_angle].data
                     for idet, d in enumerate(dets):
                         det_gamma[idet] = focalplane[d][self.fp_gamma]
-                native().stokes_weights_IQU(quat_indx, ob.detdata[quats_name].data, weight_indx,
-                                            ob.detdata[self.weights].data, hwp_data, ob.intervals[view].data,
+                native().stokes_weights_IQU(quat_indx, ob.detdata[quats_name].arg(use_accel), weight_indx,
+                                            ob.detdata[self.weights].arg(use_accel), hwp_data, ob.intervals[view].data,
                                             det_epsilon, det_gamma, cal, bool(self.IAU), use_accel)
             else:
                 # the compiled kernel takes a 2-D [n_det, n_samp] buffer (ops_stokes_weights.cpp:417-420)
-                wd = ob.detdata[self.weights].data
+                wd = ob.detdata[self.weights].arg(use_accel)
                 native().stokes_weights_I(weight_indx, wd.reshape(wd.shape[0], wd.shape[1]),
                                           ob.intervals[view].data, cal, use_accel)
 

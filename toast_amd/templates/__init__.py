@@ -474,7 +474,7 @@ class Offset(Template):
             capi.dev.offset_add_to_signal_multi(
                 self._step_length(self.step_time, self._obs_rate[iob]), self.det_amp_offsets(iob, dets),
                 self._obs_views[iob], accel_device_ptr(amplitudes.local), accel_device_ptr(amplitudes.local_flags),
-                dd.indices(dets), accel_device_ptr(dd.data), ob.n_local_samples, ob.intervals[self.view].data)
+                dd.indices(dets), accel_device_ptr(dd.buffer), ob.n_local_samples, ob.intervals[self.view].data)
 
     def project_signal_multi(self, detectors, amplitudes, **kwargs):
         from .. import capi
@@ -494,7 +494,7 @@ class Offset(Template):
             else:
                 f_idx, f_ptr = None, 0
             capi.dev.offset_project_signal_multi(
-                dd.indices(dets), accel_device_ptr(dd.data), f_idx, f_ptr, self.det_flag_mask,
+                dd.indices(dets), accel_device_ptr(dd.buffer), f_idx, f_ptr, self.det_flag_mask,
                 self._step_length(self.step_time, self._obs_rate[iob]), self.det_amp_offsets(iob, dets),
                 self._obs_views[iob], accel_device_ptr(amplitudes.local), accel_device_ptr(amplitudes.local_flags),
                 ob.n_local_samples, ob.intervals[self.view].data)
@@ -513,7 +513,7 @@ class Offset(Template):
             n_amp_views = self._obs_views[iob]
             native().template_offset_add_to_signal(step_length, amp_offset, n_amp_views, amplitudes.local,
                                                    amplitudes.local_flags, int(det_indx[0]),
-                                                   ob.detdata[self.det_data].data, ob.intervals[self.view].data,
+                                                   ob.detdata[self.det_data].arg(use_accel), ob.intervals[self.view].data,
                                                    use_accel)
             amp_offset += int(np.sum(n_amp_views))
 
@@ -552,7 +552,7 @@ class Offset(Template):
                 flag_data = np.zeros((1, 1), dtype=np.uint8)
             step_length = self._step_length(self.step_time, self._obs_rate[iob])
             n_amp_views = self._obs_views[iob]
-            native().template_offset_project_signal(int(det_indx[0]), ob.detdata[self.det_data].data, flag_indx,
+            native().template_offset_project_signal(int(det_indx[0]), ob.detdata[self.det_data].arg(use_accel), flag_indx,
                                                     flag_data, self.det_flag_mask, step_length, amp_offset,
                                                     n_amp_views, amplitudes.local, amplitudes.local_flags,
                                                     ob.intervals[self.view].data, use_accel)
