@@ -4,6 +4,7 @@ rocFFT pipeline (reference: src/toast/ops/noise_filter.py:20-205 -> toast.fft.co
 import numpy as np
 
 from .. import fft as hipfft
+from ..accel import accel_enabled
 from ..data import defaults
 from ..traits import Float, Int, Unicode
 from .operator import Operator
@@ -56,6 +57,14 @@ class NoiseFilter(Operator):
             rate = obs.telescope.focalplane.sample_rate
             dd = obs.detdata[self.det_data]
             on_dev = dd.accel_in_use()
+            made_resident = False
+            if not on_dev and accel_enabled():
+                # one page-locked upload instead of per-call pageable staging; the filtered
+                # timestream stays resident for the map-maker (lazy host coherence)
+                if not dd.accel_exists():
+                    dd.accel_create(self.det_data)
+                dd.accel_update_device()
+                on_dev = made_resident = True
             flags = None
             flag_mask = None
             if self.det_flags is not None:
@@ -115,6 +124,9 @@ class NoiseFilter(Operator):
                     if extend[i] == n_samp:
                         raise RuntimeError("Impulse response spreads to all samples")
             hipfft.convolve_buffer(dd.arg(on_dev), idx, rate, kern_freq, kernels, use_accel=on_dev)
+            if made_resident and not getattr(data, "lazy_host", False):
+                dd.accel_update_host()
+                dd.accel_delete()
             if flags is not None:
                 for i, f in enumerate(flags):
                     ext = int(extend[i])
