@@ -371,6 +371,84 @@ def main():
             "fused_vs_sequence_max_rel_diff": err,
         }
 
+        # pointing on the fly: the same two operators and the same LHS
+        # without the 32 B/det-sample pointing cache -- 9 + 16 B (A^T, A) and ~2 + ~2 B (offset LHS)
+        pt = capi.otf_pointing(d_bore.data_ptr(), fp, nside, True, nnz, d_shared_flags=d_sflags.data_ptr(),
+                               n_shared_flags=n_samp, shared_flag_mask=1, epsilon=np.zeros(n_det), gamma=gamma,
+                               cal=np.ones(n_det))
+
+        def ata_otf():
+            d_zmap.zero_()
+            D.otf_build_noise_weighted(pt, d_g2l.data_ptr(), d_zmap.data_ptr(), nps, idx, d_tod.data_ptr(), idx,
+                                       d_dflags.data_ptr(), n_samp, det_scale, 1, n_samp, ivl, d_sflags.data_ptr(),
+                                       n_samp, 1, stream)
+            if world > 1:
+                dist.all_reduce(d_zmap)
+            D.cov_apply_diag(n_local, nps, nnz, d_cov.data_ptr(), d_zmap.data_ptr(), stream)
+            D.otf_scan_map(pt, d_g2l.data_ptr(), d_zmap.data_ptr(), nps, d_tod2.data_ptr(), idx, n_samp, ivl, 1.0,
+                           False, True, det_w, stream)
+
+        def lhs_otf():
+            d_zmap.zero_()
+            D.otf_offset_accumulate(pt, step_len, amp_off, nav, d_amp_in.data_ptr(), d_amp_flags.data_ptr(),
+                                    d_g2l.data_ptr(), d_zmap.data_ptr(), nps, idx, d_dflags.data_ptr(), n_samp,
+                                    det_w, 1, n_samp, ivl, d_sflags.data_ptr(), n_samp, 1, stream)
+            if world > 1:
+                dist.all_reduce(d_zmap)
+            D.cov_apply_diag(n_local, nps, nnz, d_cov.data_ptr(), d_zmap.data_ptr(), stream)
+            d_amp_out.zero_()
+            D.otf_offset_scan_project(pt, step_len, amp_off, nav, d_amp_in.data_ptr(), d_amp_out.data_ptr(),
+                                      d_amp_flags.data_ptr(), d_g2l.data_ptr(), d_zmap.data_ptr(), nps, idx,
+                                      d_dflags.data_ptr(), n_samp, 1, det_w, n_samp, ivl, stream)
+
+        lhs_otf()
+        err_otf = float((d_amp_out - ref_out).abs().max() / ref_out.abs().max())
+        t_lhs_otf = timed(lhs_otf, 5)
+        ata_otf()
+        t_ata_otf = timed(ata_otf, 5)
+        t_acc = timed(lambda: D.otf_build_noise_weighted(
+            pt, d_g2l.data_ptr(), d_zmap.data_ptr(), nps, idx, d_tod.data_ptr(), idx, d_dflags.data_ptr(), n_samp,
+            det_scale, 1, n_samp, ivl, d_sflags.data_ptr(), n_samp, 1, stream), 3)
+        # compact mode: int32 local pixel index cache (4 B) + weights on the fly
+        d_cpix = torch.empty((n_det, n_samp), dtype=torch.int32, device=dev)
+        D.compact_pixels(d_g2l.data_ptr(), nps, n_local, idx, d_pixels.data_ptr(), idx, d_cpix.data_ptr(), n_samp, ivl,
+                         stream)
+        ptc = capi.otf_pointing(d_bore.data_ptr(), fp, nside, True, nnz, d_shared_flags=d_sflags.data_ptr(),
+                                n_shared_flags=n_samp, shared_flag_mask=1, epsilon=np.zeros(n_det), gamma=gamma,
+                                cal=np.ones(n_det), d_compact_pixels=d_cpix.data_ptr(), compact_index=idx)
+        pt_keep = pt
+        pt = ptc
+        lhs_otf()
+        err_c = float((d_amp_out - ref_out).abs().max() / ref_out.abs().max())
+        t_lhs_c = timed(lhs_otf, 5)
+        ata_otf()
+        t_ata_c = timed(ata_otf, 5)
+        t_acc_c = timed(lambda: D.otf_build_noise_weighted(
+            ptc, d_g2l.data_ptr(), d_zmap.data_ptr(), nps, idx, d_tod.data_ptr(), idx, d_dflags.data_ptr(), n_samp,
+            det_scale, 1, n_samp, ivl, d_sflags.data_ptr(), n_samp, 1, stream), 3)
+        t_scan_c = timed(lambda: D.otf_scan_map(ptc, d_g2l.data_ptr(), d_zmap.data_ptr(), nps, d_tod2.data_ptr(), idx,
+                                                n_samp, ivl, 1.0, False, True, det_w, stream), 3)
+        pt = pt_keep
+        out["compact_pixels_weights_on_the_fly"] = {
+            "bytes_per_det_sample": {"accumulate": 13, "scan": 20, "offset_lhs": 10},
+            "ata_ms": t_ata_c,
+            "ata_Gsamp_s": world * nsamp_tot / t_ata_c / 1e6,
+            "accumulate_ms": t_acc_c,
+            "scan_ms": t_scan_c,
+            "offset_lhs_ms": t_lhs_c,
+            "offset_lhs_Gsamp_s": world * nsamp_tot / t_lhs_c / 1e6,
+            "offset_lhs_vs_sequence_max_rel_diff": err_c,
+        }
+        out["pointing_on_the_fly"] = {
+            "ata_ms": t_ata_otf,
+            "ata_Gsamp_s": world * nsamp_tot / t_ata_otf / 1e6,
+            "otf_build_noise_weighted_ms": t_acc,
+            "offset_lhs_ms": t_lhs_otf,
+            "offset_lhs_Gsamp_s": world * nsamp_tot / t_lhs_otf / 1e6,
+            "offset_lhs_vs_sequence_max_rel_diff": err_otf,
+            "cached_expand_plus_ata_ms": t_pd + t_pix + t_sw + 1e3 * elapsed / args.steps,
+        }
+
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1)
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         import oracle

@@ -428,6 +428,82 @@ int toast_hip_scan_mask_dev(const int64_t * d_global2local, const uint8_t * d_ma
 /* Device-to-device copy on the stream (Copy operator on resident buffers). */
 int toast_hip_copy_dev(void * d_dst, const void * d_src, size_t nbytes, void * stream);
 
+/* ------------------------------------------------------------------------------------
+ * Pointing on the fly: the accumulate / scan kernels evaluate
+ * pointing_detector -> pixels_healpix -> stokes_weights per det-sample in registers instead of
+ * reading cached pixels / weights.  This is the fused form of the reference's
+ * full_pointing=False pipelines [ref: src/toast/ops/mapmaker_binning.py:265-271,
+ * src/toast/ops/mapmaker_solve.py:476-489], which re-run the three pointing operators inside
+ * every pass.  The descriptor collects the arguments of those three operators
+ * [ref: ops_pointing_detector.cpp:78-88, ops_pixels_healpix.cpp:1153-1167,
+ * ops_stokes_weights.cpp:151-163]; d_* members are device pointers, the others host arrays of
+ * n_det entries (row i = detector i of the call).
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+    const double * d_boresight;     /* [n_samp, 4] */
+    const uint8_t * d_shared_flags; /* [n_shared_flags]; used when n_shared_flags == n_samp */
+    int64_t n_shared_flags;
+    uint8_t shared_flag_mask;
+    const double * focalplane;      /* host [n_det, 4] detector quaternions */
+    const double * d_hwp;           /* [n_hwp]; HWP angle used when n_hwp == n_samp (nnz 3 only) */
+    int64_t n_hwp;
+    const double * epsilon;         /* host [n_det] or NULL (= 0) */
+    const double * gamma;           /* host [n_det] or NULL (= 0) */
+    const double * cal;             /* host [n_det] or NULL (= 1) */
+    int IAU;
+    int64_t nside;
+    int nest;
+    int nnz;                        /* 1: intensity weights, 3: IQU */
+    /* Optional compact pixel cache (toast_hip_compact_pixels_dev): when not NULL the kernels read
+     * the int32 LOCAL map index of each det-sample from row compact_index[i] of this [rows, n_samp]
+     * array (4 B/det-sample) and evaluate only the Stokes weights on the fly. */
+    const int32_t * d_compact_pixels;
+    const int32_t * compact_index;  /* host [n_det] */
+} toast_hip_otf_pointing;
+
+/* Compact pixel cache: local map index  global2local[pix / n_pix_submap] * n_pix_submap +
+ * pix % n_pix_submap  as int32 (-1 for pix < 0 or a submap that is not local) for every sample in
+ * the intervals.  n_local_submap * n_pix_submap must fit in int32. */
+int toast_hip_compact_pixels_dev(const int64_t * d_g2l, int64_t n_pix_submap, int64_t n_local_submap,
+                                 const int32_t * pixel_index, const int64_t * d_pixels,
+                                 const int32_t * compact_index, int32_t * d_compact_pixels, int64_t n_det,
+                                 int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
+                                 void * stream);
+
+/* zmap += P^T N^-1 d  with on-the-fly pointing (== pointing chain + build_noise_weighted). */
+int toast_hip_otf_build_noise_weighted_dev(
+    const toast_hip_otf_pointing * pointing, const int64_t * d_g2l, double * d_zmap, int64_t n_pix_submap,
+    const int32_t * data_index, const double * d_det_data, const int32_t * flag_index,
+    const uint8_t * d_det_flags, int64_t n_flag_samp, const double * det_scale, uint8_t det_flag_mask,
+    int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
+    const uint8_t * d_shared_flags, int64_t n_shared_flags, uint8_t shared_flag_mask, void * stream);
+
+/* d = (zero ? 0 : d) -/+ data_scale * P m, optionally followed by d *= det_weights[det]
+ * (== pointing chain + scan_map(float64) [+ noise_weight]); det_weights may be NULL. */
+int toast_hip_otf_scan_map_dev(const toast_hip_otf_pointing * pointing, const int64_t * d_g2l,
+                               const double * d_map, int64_t n_pix_submap, double * d_det_data,
+                               const int32_t * data_index, int64_t n_det, int64_t n_samp,
+                               const toast_hip_interval * intervals, int64_t n_view, double data_scale,
+                               int should_zero, int should_subtract, const double * det_weights,
+                               void * stream);
+
+/* Fused PCG left-hand side halves for Offset templates with on-the-fly pointing (see
+ * toast_hip_offset_accumulate_dev / toast_hip_offset_scan_project_dev). */
+int toast_hip_otf_offset_accumulate_dev(
+    const toast_hip_otf_pointing * pointing, int64_t step_length, const int64_t * amp_offsets,
+    const int64_t * n_amp_views, const double * d_amplitudes, const uint8_t * d_amplitude_flags,
+    const int64_t * d_g2l, double * d_zmap, int64_t n_pix_submap, const int32_t * flag_index,
+    const uint8_t * d_det_flags, int64_t n_flag_samp, const double * det_scale, uint8_t det_flag_mask,
+    int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
+    const uint8_t * d_shared_flags, int64_t n_shared_flags, uint8_t shared_flag_mask, void * stream);
+int toast_hip_otf_offset_scan_project_dev(
+    const toast_hip_otf_pointing * pointing, int64_t step_length, const int64_t * amp_offsets,
+    const int64_t * n_amp_views, const double * d_amplitudes_in, double * d_amplitudes_out,
+    const uint8_t * d_amplitude_flags, const int64_t * d_g2l, const double * d_map, int64_t n_pix_submap,
+    const int32_t * flag_index, const uint8_t * d_det_flags, int64_t n_flag_samp, uint8_t det_flag_mask,
+    const double * det_weights, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals,
+    int64_t n_view, void * stream);
+
 /* PCG vector algebra on device-resident amplitude vectors
  * [ref: src/toast/templates/amplitudes.py:400-565]:  y = a x + b y  (b == 0 overwrites), and the
  * flagged dot product  sum_i x_i y_i over entries with both flags clear (flag pointers may be

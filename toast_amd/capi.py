@@ -379,6 +379,63 @@ def template_offset_apply_diag_precond(offset_var, amplitudes_in, amplitude_flag
 
 
 # --------------------------------------------------------------------------- device-pointer level
+
+class OtfPointing(C.Structure):
+    """``toast_hip_otf_pointing`` (include/toast_hip.h): arguments of the three pointing operators
+    for the on-the-fly kernels.  Build with :func:`otf_pointing`, which keeps the host arrays alive."""
+
+    _fields_ = [
+        ("d_boresight", C.c_void_p),
+        ("d_shared_flags", C.c_void_p),
+        ("n_shared_flags", C.c_int64),
+        ("shared_flag_mask", C.c_uint8),
+        ("focalplane", C.c_void_p),
+        ("d_hwp", C.c_void_p),
+        ("n_hwp", C.c_int64),
+        ("epsilon", C.c_void_p),
+        ("gamma", C.c_void_p),
+        ("cal", C.c_void_p),
+        ("IAU", C.c_int),
+        ("nside", C.c_int64),
+        ("nest", C.c_int),
+        ("nnz", C.c_int),
+        ("d_compact_pixels", C.c_void_p),
+        ("compact_index", C.c_void_p),
+    ]
+
+
+def otf_pointing(d_boresight, focalplane, nside, nest, nnz, d_shared_flags=0, n_shared_flags=0, shared_flag_mask=0,
+                 d_hwp=0, n_hwp=0, epsilon=None, gamma=None, cal=None, IAU=False, d_compact_pixels=0,
+                 compact_index=None):
+    fp = np.ascontiguousarray(focalplane, dtype=np.float64)
+    if fp.ndim != 2 or fp.shape[1] != 4:
+        raise RuntimeError("focalplane should be a [n_det, 4] float64 array")
+    keep = [fp]
+
+    def small(a):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        if a.shape != (fp.shape[0],):
+            raise RuntimeError("epsilon / gamma / cal should have one entry per detector")
+        keep.append(a)
+        return a.ctypes.data
+
+    pt = OtfPointing(int(d_boresight), int(d_shared_flags) or None, int(n_shared_flags), int(shared_flag_mask),
+                     fp.ctypes.data, int(d_hwp) or None, int(n_hwp), small(epsilon), small(gamma), small(cal),
+                     int(bool(IAU)), int(nside), int(bool(nest)), int(nnz), None, None)
+    if d_compact_pixels:
+        ci = np.ascontiguousarray(compact_index, dtype=np.int32)
+        if ci.shape != (fp.shape[0],):
+            raise RuntimeError("compact_index should have one entry per detector")
+        keep.append(ci)
+        pt.d_compact_pixels = int(d_compact_pixels)
+        pt.compact_index = ci.ctypes.data
+    pt._keep = keep
+    pt.n_det = fp.shape[0]
+    return pt
+
+
 class _Dev:
     """``toast_hip_*_dev``: large arrays are device pointers (ints), small ones NumPy arrays."""
 
@@ -543,6 +600,66 @@ class _Dev:
             _p(d_map), _i64(n_pix_submap), _i64(nnz), _p(pi), _p(d_pixels), _p(wi), _p(d_weights), _p(fi),
             _p(d_flag_data), _u8(flag_mask), _p(dw), _i64(pi.size), _i64(n_samp), _p(iv), _i64(iv.size),
             _p(stream)))
+
+    # -- pointing on the fly (otf_kernels.hip)
+    def otf_build_noise_weighted(self, pt, d_g2l, d_zmap, n_pix_submap, data_index, d_det_data, flag_index,
+                                 d_det_flags, n_flag_samp, det_scale, det_flag_mask, n_samp, intervals,
+                                 d_shared_flags=0, n_shared_flags=0, shared_flag_mask=0, stream=0):
+        di = self._small(data_index, np.int32)
+        fi = self._small(flag_index, np.int32)
+        ds = self._small(det_scale, np.float64)
+        iv = self._small(intervals, interval_dtype)
+        _check(lib().toast_hip_otf_build_noise_weighted_dev(
+            C.byref(pt), _p(d_g2l), _p(d_zmap), _i64(n_pix_submap), _p(di), _p(d_det_data), _p(fi),
+            _p(d_det_flags), _i64(n_flag_samp), _p(ds), _u8(det_flag_mask), _i64(di.size), _i64(n_samp), _p(iv),
+            _i64(iv.size), _p(d_shared_flags), _i64(n_shared_flags), _u8(shared_flag_mask), _p(stream)))
+
+    def compact_pixels(self, d_g2l, n_pix_submap, n_local_submap, pixel_index, d_pixels, compact_index,
+                       d_compact_pixels, n_samp, intervals, stream=0):
+        pi = self._small(pixel_index, np.int32)
+        ci = self._small(compact_index, np.int32)
+        iv = self._small(intervals, interval_dtype)
+        _check(lib().toast_hip_compact_pixels_dev(
+            _p(d_g2l), _i64(n_pix_submap), _i64(n_local_submap), _p(pi), _p(d_pixels), _p(ci),
+            _p(d_compact_pixels), _i64(pi.size), _i64(n_samp), _p(iv), _i64(iv.size), _p(stream)))
+
+    def otf_scan_map(self, pt, d_g2l, d_map, n_pix_submap, d_det_data, data_index, n_samp, intervals,
+                     data_scale=1.0, should_zero=False, should_subtract=False, det_weights=None, stream=0):
+        di = self._small(data_index, np.int32)
+        dw = None if det_weights is None else self._small(det_weights, np.float64)
+        iv = self._small(intervals, interval_dtype)
+        _check(lib().toast_hip_otf_scan_map_dev(
+            C.byref(pt), _p(d_g2l), _p(d_map), _i64(n_pix_submap), _p(d_det_data), _p(di), _i64(di.size),
+            _i64(n_samp), _p(iv), _i64(iv.size), C.c_double(data_scale), _int(should_zero), _int(should_subtract),
+            _p(dw), _p(stream)))
+
+    def otf_offset_accumulate(self, pt, step_length, amp_offsets, n_amp_views, d_amplitudes, d_amplitude_flags,
+                              d_g2l, d_zmap, n_pix_submap, flag_index, d_det_flags, n_flag_samp, det_scale,
+                              det_flag_mask, n_samp, intervals, d_shared_flags=0, n_shared_flags=0,
+                              shared_flag_mask=0, stream=0):
+        ao = self._small(amp_offsets, np.int64)
+        nv = self._small(n_amp_views, np.int64)
+        fi = self._small(flag_index, np.int32)
+        ds = self._small(det_scale, np.float64)
+        iv = self._small(intervals, interval_dtype)
+        _check(lib().toast_hip_otf_offset_accumulate_dev(
+            C.byref(pt), _i64(step_length), _p(ao), _p(nv), _p(d_amplitudes), _p(d_amplitude_flags), _p(d_g2l),
+            _p(d_zmap), _i64(n_pix_submap), _p(fi), _p(d_det_flags), _i64(n_flag_samp), _p(ds),
+            _u8(det_flag_mask), _i64(ao.size), _i64(n_samp), _p(iv), _i64(iv.size), _p(d_shared_flags),
+            _i64(n_shared_flags), _u8(shared_flag_mask), _p(stream)))
+
+    def otf_offset_scan_project(self, pt, step_length, amp_offsets, n_amp_views, d_amps_in, d_amps_out,
+                                d_amplitude_flags, d_g2l, d_map, n_pix_submap, flag_index, d_flag_data,
+                                n_flag_samp, flag_mask, det_weights, n_samp, intervals, stream=0):
+        ao = self._small(amp_offsets, np.int64)
+        nv = self._small(n_amp_views, np.int64)
+        fi = None if flag_index is None else self._small(flag_index, np.int32)
+        dw = self._small(det_weights, np.float64)
+        iv = self._small(intervals, interval_dtype)
+        _check(lib().toast_hip_otf_offset_scan_project_dev(
+            C.byref(pt), _i64(step_length), _p(ao), _p(nv), _p(d_amps_in), _p(d_amps_out), _p(d_amplitude_flags),
+            _p(d_g2l), _p(d_map), _i64(n_pix_submap), _p(fi), _p(d_flag_data), _i64(n_flag_samp), _u8(flag_mask),
+            _p(dw), _i64(ao.size), _i64(n_samp), _p(iv), _i64(iv.size), _p(stream)))
 
     def scan_mask(self, d_g2l, d_mask, n_pix_submap, mask_bits, flag_value, pixel_index, d_pixels, flag_index,
                   d_det_flags, n_samp, intervals, stream=0):

@@ -367,26 +367,32 @@ TOAST_HD void quat_rotate_x(const double * q, double * out) {
 // built from cos / sin of atan2(vd1, vd0)), evaluated algebraically:
 //   cos(atan2(y, x)) = x / r,  sin(atan2(y, x)) = y / r,
 //   cos 2a = (ax^2 - ay^2) / (ax^2 + ay^2),  sin 2a = 2 ax ay / (ax^2 + ay^2)
-// i.e. one sqrt and two reciprocals instead of two atan2 and two sincos.  Weights are a
+// i.e. one reciprocal instead of two atan2 and two sincos (see the scaling argument below).  Weights are a
 // tolerance-class output (reference tests: assert_allclose), agreement ~1e-15 absolute.
 TOAST_HD void stokes_cs2alpha(const double * q, double & c2a, double & s2a) {
     double vd[3], vo[3];
     quat_rotate_z(q, vd);
     quat_rotate_x(q, vo);
-    const double r2 = vd[0] * vd[0] + vd[1] * vd[1];
-    double cxy = __builtin_signbit(vd[0]) ? -1.0 : 1.0;  // atan2(+-0, +-0) is 0 or pi
-    double sxy = 0.0;
+    const double r2 = vd[0] * vd[0] + vd[1] * vd[1];   // sin^2(theta)
+    double ax, ay;
     if (r2 > 0.0) {
-        const double rinv = recip_newton(f_sqrt(r2));
-        cxy = vd[0] * rinv;
-        sxy = vd[1] * rinv;
+        // alpha = atan2(ay, ax) only enters through cos 2a / sin 2a, which do not change when
+        // (ax, ay) is scaled by s = sin(theta) > 0.  With s * meridian = (vd2 vd0, vd2 vd1, -s^2)
+        // and s * (vd x meridian) = (-vd1, vd0, 0) for the unit vector vd, the scaled components
+        // need neither the square roots nor the 1/s of the reference formulation:
+        ax = vd[2] * (vd[0] * vo[0] + vd[1] * vo[1]) - r2 * vo[2];
+        ay = vd[0] * vo[1] - vd[1] * vo[0];
+    } else {
+        // on the pole atan2(+-0, +-0) is 0 or pi: the reference's expressions, literally
+        const double cxy = __builtin_signbit(vd[0]) ? -1.0 : 1.0;
+        const double sxy = 0.0;
+        const double vm_x = vd[2] * cxy;
+        const double vm_y = vd[2] * sxy;
+        const double vm_z = -f_sqrt(1.0 - vd[2] * vd[2]);
+        ay = (vd[0] * (vm_y * vo[2] - vm_z * vo[1]) - vd[1] * (vm_x * vo[2] - vm_z * vo[0]) +
+              vd[2] * (vm_x * vo[1] - vm_y * vo[0]));
+        ax = (vm_x * vo[0] + vm_y * vo[1] + vm_z * vo[2]);
     }
-    const double vm_x = vd[2] * cxy;
-    const double vm_y = vd[2] * sxy;
-    const double vm_z = -f_sqrt(1.0 - vd[2] * vd[2]);
-    const double ay = (vd[0] * (vm_y * vo[2] - vm_z * vo[1]) - vd[1] * (vm_x * vo[2] - vm_z * vo[0]) +
-                       vd[2] * (vm_x * vo[1] - vm_y * vo[0]));
-    const double ax = (vm_x * vo[0] + vm_y * vo[1] + vm_z * vo[2]);
     const double n2 = ax * ax + ay * ay;
     c2a = 1.0;  // alpha = atan2(0, 0) = 0
     s2a = 0.0;

@@ -12,29 +12,11 @@
 // reference's separately rounded operations.
 #include <hip/hip_runtime.h>
 
-#include "hpix_math.hpp"
-#include "runtime.hpp"
+#include "kernel_common.hpp"
 
 using namespace toast_hip;
 
 namespace {
-
-constexpr int kThreads = 256;
-
-struct alignas(16) Quat {
-    double x, y, z, w;
-};
-
-__device__ __forceinline__ Quat load_quat(const double * p) {
-    const double2 a = *reinterpret_cast<const double2 *>(p);
-    const double2 b = *reinterpret_cast<const double2 *>(p + 2);
-    return Quat{a.x, a.y, b.x, b.y};
-}
-
-__device__ __forceinline__ void store_quat(double * p, const double * r) {
-    *reinterpret_cast<double2 *>(p) = make_double2(r[0], r[1]);
-    *reinterpret_cast<double2 *>(p + 2) = make_double2(r[2], r[3]);
-}
 
 // ------------------------------------------------------------------------------------
 // pointing_detector   [ref: ops_pointing_detector.cpp:33-68]
@@ -231,30 +213,6 @@ __global__ __launch_bounds__(kThreads) void k_scan_map(
             drow[s] = d;
         }
     }
-}
-
-// ------------------------------------------------------------------------------------
-// Wave-level segmented sum: lanes holding equal, *adjacent* keys form a run; after the
-// call the LAST lane of each run (is_tail) holds the run total in v[].  Six shuffle steps.
-// ------------------------------------------------------------------------------------
-template <int NV>
-__device__ __forceinline__ bool wave_run_reduce(int64_t key, double (&v)[NV]) {
-    const int lane = threadIdx.x & 63;
-    const int64_t prev = __shfl_up(key, 1);
-    const bool head = (lane == 0) || (prev != key);
-    const unsigned long long heads = __ballot(head);
-    // run start = highest head bit at or below my lane
-    const unsigned long long below = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-    const int start = 63 - __clzll(below);
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const double o = __shfl_up(v[k], d);
-            if (lane - d >= start) v[k] += o;
-        }
-    }
-    return (lane == 63) || ((heads >> (lane + 1)) & 1ull);
 }
 
 // ------------------------------------------------------------------------------------
@@ -870,38 +828,6 @@ __global__ __launch_bounds__(kThreads) void k_test_math(int op, int64_t n, const
     }
 }
 
-// ------------------------------------------------------------------------------------
-// host helpers
-// ------------------------------------------------------------------------------------
-inline hipStream_t as_stream(void * s) { return static_cast<hipStream_t>(s); }
-
-inline void check_launch() { TH_HIP(hipGetLastError()); }
-
-inline void need_aligned(const void * p, const char * what) {
-    if ((reinterpret_cast<uintptr_t>(p) & 15) != 0) {
-        fail_arg(std::string(what) + " must be 16-byte aligned");
-    }
-}
-
-inline dim3 chunk_grid(int64_t n_det, size_t n_chunks) {
-    const unsigned gy = (unsigned)((n_chunks < 65535) ? n_chunks : 65535);
-    return dim3((unsigned)n_det, gy ? gy : 1, 1);
-}
-
-inline int log2_exact(int64_t nside) {
-    if (nside <= 0 || (nside & (nside - 1)) != 0) fail_arg("nside must be a positive power of two");
-    int f = 0;
-    while ((int64_t(1) << f) != nside) ++f;
-    return f;
-}
-
-inline dim3 flat_grid(int64_t n) {
-    int64_t b = (n + kThreads - 1) / kThreads;
-    if (b > 256 * 16) b = 256 * 16;
-    if (b < 1) b = 1;
-    return dim3((unsigned)b);
-}
-
 }  // namespace
 
 namespace {
@@ -925,26 +851,6 @@ void launch_scan_map(dim3 grid, hipStream_t st, const Chunk * ch, int n_ch, cons
         hipLaunchKernelGGL((k_scan_map<T, 0>), grid, dim3(kThreads), 0, st, ch, n_ch, di, pi, wi, g2l,
                            m, tod, pix, w, nnz, dv, scale, zero, sub, mult, det_w, n_samp, dm);
     }
-}
-
-}  // namespace
-
-namespace {
-
-struct OffsetViews {
-    std::vector<int64_t> first;
-    std::vector<int64_t> aoff;
-};
-
-OffsetViews offset_views(const toast_hip_interval * ivl, const int64_t * n_amp_views, int64_t n_view) {
-    OffsetViews v;
-    int64_t run = 0;  // template_offset.cpp:57-63
-    for (int64_t i = 0; i < n_view; ++i) {
-        v.first.push_back(ivl[i].first);
-        v.aoff.push_back(run);
-        run += n_amp_views[i];
-    }
-    return v;
 }
 
 }  // namespace

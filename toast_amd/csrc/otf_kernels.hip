@@ -1,0 +1,595 @@
+// otf_kernels.hip -- "pointing on the fly" variants of the map-domain kernels.
+//
+// The reference's memory-saving mode (BinMap.full_pointing = False, src/toast/ops/
+// mapmaker_binning.py:265-271, and SolverLHS, src/toast/ops/mapmaker_solve.py:476-489) runs
+// [PointingDetectorSimple, PixelsHealpix, StokesWeights] again inside every pass over the
+// data, one detector at a time, through 64 B/det-sample of scratch.  Here the same three steps
+// run in registers inside the accumulate / scan kernels:
+//
+//     boresight (32 B per *time* sample, shared by all detectors -> L2)  ->  detector quaternion
+//     [ops_pointing_detector.cpp:33-68]  ->  pixel [ops_pixels_healpix.cpp:586-666]  +  Stokes
+//     weights [ops_stokes_weights.cpp:77-140]  ->  zmap scatter / map gather
+//
+// so a det-sample costs 9 B (A^T: signal + flag) or 16 B (A: signal read + write) of HBM traffic
+// instead of 41 / 48 B, and 0-2 B in the offset-template forms, at the price of ~300 fp64
+// operations.  The per-sample arithmetic is the device functions of hpix_math.hpp that the
+// stand-alone kernels use, so pixels are bit-identical and weights identical to the cached path.
+#include "kernel_common.hpp"
+
+namespace {
+
+// Device view of toast_hip_otf_pointing.
+struct OtfDev {
+    const double * bore;      // [n_samp, 4]
+    const uint8_t * pflags;   // shared flags seen by the pointing operators
+    const double * hwp;       // [n_samp] (MODE 2 only)
+    const double * fp;        // [n_det, 4]
+    const double * eps;       // [n_det]
+    const double * gamma;     // [n_det]
+    const double * cal;       // [n_det]
+    const int64_t * g2l;      // global submap -> local submap
+    const int32_t * cpix;     // PIX 1: cached local pixel index [rows, n_samp] (int32, -1 = none)
+    const int32_t * cpix_idx; // PIX 1: row of each detector in cpix
+    double usign;
+    int64_t nside;
+    FastDiv nps_div;
+    int factor;
+    int use_pflags;
+    uint8_t pmask;
+};
+
+struct DetConst {
+    double f[4];
+    double eta, cd, gd;
+    const int32_t * crow;   // PIX 1: this detector's row of cached local pixel indices
+};
+
+__device__ __forceinline__ DetConst det_const(const OtfDev & P, int det) {
+    DetConst D;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) D.f[k] = P.fp[4 * det + k];
+    const double eps = P.eps[det];
+    D.eta = (1.0 - eps) / (1.0 + eps);
+    D.cd = P.cal[det];
+    D.gd = P.gamma[det];
+    D.crow = nullptr;
+    return D;
+}
+
+// MODE 0: intensity only (nnz 1); 1: IQU without HWP; 2: IQU with HWP.
+template <int MODE>
+struct ModeNnz {
+    static constexpr int value = (MODE == 0) ? 1 : 3;
+};
+
+// LOCAL map index (n_pix_submap * local_submap + pixel-in-submap; -1 when the boresight sample is
+// flagged) and Stokes weights of one det-sample.
+//   PIX 0: the pixel is computed here (pointing_detector -> pixels_healpix -> global2local);
+//   PIX 1: the local index is read from a compact int32 cache (4 B instead of the 8 B global
+//          pixel + global2local lookup) and only the weights are evaluated on the fly.
+template <bool NEST, int MODE, int PIX>
+__device__ __forceinline__ int64_t otf_point(const OtfDev & P, const DetConst & D, int64_t s,
+                                             const double * s_tab, double (&w)[ModeNnz<MODE>::value]) {
+    int64_t lidx = -1;
+    if constexpr (PIX == 1) lidx = D.crow[s];
+    if constexpr (PIX == 1 && MODE == 0) {
+        w[0] = D.cd;
+        return lidx;
+    }
+    const Quat b = load_quat(P.bore + 4 * s);
+    const uint8_t fl = P.use_pflags ? P.pflags[s] : (uint8_t)0;
+    double hw = 0.0;
+    if constexpr (MODE == 2) hw = P.hwp[s];
+    const bool flagged = (fl & P.pmask) != 0;
+    // pointing_detector: a flagged boresight sample is replaced by the identity rotation
+    double p[4] = {0.0, 0.0, 0.0, 1.0};
+    if (!flagged) {
+        p[0] = b.x; p[1] = b.y; p[2] = b.z; p[3] = b.w;
+    }
+    double r[4];
+    quat_mult(p, D.f, r);
+    // stokes_weights (computed for flagged samples too, like the stand-alone kernel)
+    if constexpr (MODE == 0) {
+        w[0] = D.cd;
+    } else {
+        double c2a, s2a;
+        stokes_cs2alpha(r, c2a, s2a);
+        if constexpr (MODE == 2) {
+            const double beta = 2.0 * (2.0 * (D.gd - hw));
+            double sb, cb;
+            sincos(beta, &sb, &cb);
+            const double cang = cb * c2a + sb * s2a;
+            const double sang = sb * c2a - cb * s2a;
+            w[0] = D.cd;
+            w[1] = cang * D.eta * D.cd;
+            w[2] = -sang * D.eta * D.cd * P.usign;
+        } else {
+            w[0] = D.cd;
+            w[1] = c2a * D.eta * D.cd;
+            w[2] = s2a * D.eta * D.cd * P.usign;
+        }
+    }
+    if constexpr (PIX == 1) {
+        return lidx;
+    } else {
+        // pixels_healpix
+        if (flagged) return -1;
+        double dir[3];
+        quat_rotate_z(r, dir);
+        const ZPhi a = zphi_from_vec(dir, s_tab);
+        const int64_t pix = NEST ? zphi_to_nest(P.nside, P.factor, a) : zphi_to_ring(P.nside, P.factor, a);
+        const int64_t gsm = fastdiv(pix, P.nps_div);
+        return P.g2l[gsm] * P.nps_div.d + (pix - gsm * P.nps_div.d);
+    }
+}
+
+// Offset-template addressing (template_offset.cpp:57-63, :93-120)
+struct OffsetDev {
+    const int64_t * view_first;
+    const int64_t * view_aoff;
+    const int64_t * amp_offsets;
+    const double * amps_in;
+    double * amps_out;
+    const uint8_t * amp_flags;
+    FastDiv step_div;
+};
+
+// ------------------------------------------------------------------------------------
+// A^T:  zmap += P^T N^-1 d      SIG 0: d = timestream buffer (build_noise_weighted)
+//                               SIG 1: d = M a, offset amplitudes (k_offset_accumulate)
+// ------------------------------------------------------------------------------------
+template <bool NEST, int MODE, int SIG, int PIX>
+__global__ __launch_bounds__(kThreads) void k_otf_accumulate(
+    const Chunk * __restrict__ chunks, int n_chunks, OtfDev P, OffsetDev O,
+    const int32_t * __restrict__ d_idx, const double * __restrict__ tod,
+    const int32_t * __restrict__ f_idx, const uint8_t * __restrict__ dflags, uint8_t dmask,
+    int use_dflags, const uint8_t * __restrict__ sflags, uint8_t smask, int use_sflags,
+    const double * __restrict__ det_scale, double * __restrict__ zmap, int64_t n_samp) {
+    constexpr int NNZ = ModeNnz<MODE>::value;
+    __shared__ double s_tab[2 * TOAST_ATAN_TABLE_N];
+    if (threadIdx.x < 2 * TOAST_ATAN_TABLE_N) s_tab[threadIdx.x] = kAtanTab[threadIdx.x];
+    __syncthreads();
+
+    const int det = blockIdx.x;
+    DetConst D = det_const(P, det);
+    if (PIX == 1) D.crow = P.cpix + (int64_t)P.cpix_idx[det] * n_samp;
+    const double * drow = (SIG == 0) ? tod + (int64_t)d_idx[det] * n_samp : nullptr;
+    const uint8_t * frow = use_dflags ? dflags + (int64_t)f_idx[det] * n_samp : nullptr;
+    const double ds = det_scale[det];
+    const int64_t amp_offset = (SIG == 1) ? O.amp_offsets[det] : 0;
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        int64_t vfirst = 0, abase = 0;
+        if (SIG == 1) {
+            vfirst = O.view_first[c.view];
+            abase = amp_offset + O.view_aoff[c.view];
+        }
+        for (int base = 0; base < c.count; base += kThreads) {
+            const int i = base + threadIdx.x;
+            const bool active = i < c.count;
+            const int64_t s = c.first + (active ? i : 0);
+            int64_t key = -1;
+            double v[NNZ];
+#pragma unroll
+            for (int k = 0; k < NNZ; ++k) v[k] = 0.0;
+            if (active) {
+                const uint8_t fd = use_dflags ? frow[s] : (uint8_t)0;
+                const uint8_t fs = use_sflags ? sflags[s] : (uint8_t)0;
+                double t;
+                if (SIG == 0) {
+                    t = drow[s];
+                } else {
+                    const int64_t a = abase + fastdiv(s - vfirst, O.step_div);
+                    const uint8_t af = O.amp_flags[a];
+                    const double av = O.amps_in[a];
+                    t = (af == 0) ? (0.0 + av) : 0.0;
+                }
+                double wk[NNZ];
+                const int64_t p = otf_point<NEST, MODE, PIX>(P, D, s, s_tab, wk);
+                const bool good = (p >= 0) & ((fd & dmask) == 0) & ((fs & smask) == 0);
+                if (good) {
+                    key = p;
+                    const double sd = t * ds;
+#pragma unroll
+                    for (int k = 0; k < NNZ; ++k) v[k] = sd * wk[k];
+                }
+            }
+            const bool tail = wave_run_reduce<NNZ>(key, v);
+            if (tail && key >= 0) {
+                double * z = zmap + NNZ * key;
+#pragma unroll
+                for (int k = 0; k < NNZ; ++k) unsafeAtomicAdd(z + k, v[k]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// A:  SIG 0:  d = (zero ? 0 : d) -/+ scale * P m ; d *= det_w     (scan_map [+ noise_weight])
+//     SIG 1:  a_out += M^T N^-1 (M a - P m)                        (k_offset_scan_project)
+// ------------------------------------------------------------------------------------
+template <bool NEST, int MODE, int SIG, int PIX>
+__global__ __launch_bounds__(kThreads) void k_otf_scan(
+    const Chunk * __restrict__ chunks, int n_chunks, OtfDev P, OffsetDev O,
+    const int32_t * __restrict__ d_idx, double * __restrict__ tod, double scale, int zero,
+    int subtract, const int32_t * __restrict__ f_idx, const uint8_t * __restrict__ flags,
+    uint8_t fmask, int use_flags, const double * __restrict__ det_w,
+    const double * __restrict__ map, int64_t n_samp) {
+    constexpr int NNZ = ModeNnz<MODE>::value;
+    __shared__ double s_tab[2 * TOAST_ATAN_TABLE_N];
+    if (threadIdx.x < 2 * TOAST_ATAN_TABLE_N) s_tab[threadIdx.x] = kAtanTab[threadIdx.x];
+    __syncthreads();
+
+    const int det = blockIdx.x;
+    DetConst D = det_const(P, det);
+    if (PIX == 1) D.crow = P.cpix + (int64_t)P.cpix_idx[det] * n_samp;
+    double * drow = (SIG == 0) ? tod + (int64_t)d_idx[det] * n_samp : nullptr;
+    const uint8_t * frow = (SIG == 1 && use_flags) ? flags + (int64_t)f_idx[det] * n_samp : nullptr;
+    const bool fuse = det_w != nullptr;
+    const double dw = fuse ? det_w[det] : 1.0;
+    const int64_t amp_offset = (SIG == 1) ? O.amp_offsets[det] : 0;
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        int64_t vfirst = 0, abase = 0;
+        if (SIG == 1) {
+            vfirst = O.view_first[c.view];
+            abase = amp_offset + O.view_aoff[c.view];
+        }
+        for (int base = 0; base < c.count; base += kThreads) {
+            const int i = base + threadIdx.x;
+            const bool active = i < c.count;
+            const int64_t s = c.first + (active ? i : 0);
+            if (SIG == 0) {
+                if (!active) continue;
+                double d = zero ? 0.0 : drow[s];
+                double wk[NNZ];
+                const int64_t p = otf_point<NEST, MODE, PIX>(P, D, s, s_tab, wk);
+                if (p >= 0) {
+                    const double * m = map + NNZ * p;
+                    double v = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NNZ; ++k) v += wk[k] * m[k];
+                    v *= scale;
+                    if (subtract) {
+                        d -= v;
+                    } else {
+                        d += v;
+                    }
+                }
+                if (fuse) d *= dw;
+                drow[s] = d;
+            } else {
+                int64_t key = -1;
+                double v[1] = {0.0};
+                if (active) {
+                    const int64_t a = abase + fastdiv(s - vfirst, O.step_div);
+                    const uint8_t af = O.amp_flags[a];
+                    const double av = O.amps_in[a];
+                    const uint8_t fl = use_flags ? frow[s] : (uint8_t)0;
+                    if (af == 0) {
+                        key = a;
+                        if ((fl & fmask) == 0) {
+                            double wk[NNZ];
+                            const int64_t p = otf_point<NEST, MODE, PIX>(P, D, s, s_tab, wk);
+                            double d = 0.0 + av;
+                            if (p >= 0) {
+                                const double * m = map + NNZ * p;
+                                double sc = 0.0;
+#pragma unroll
+                                for (int k = 0; k < NNZ; ++k) sc += wk[k] * m[k];
+                                sc *= 1.0;
+                                d -= sc;
+                            }
+                            v[0] = d * dw;
+                        }
+                    }
+                }
+                const bool tail = wave_run_reduce<1>(key, v);
+                if (tail && key >= 0) unsafeAtomicAdd(O.amps_out + key, v[0]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------
+struct OtfHost {
+    OtfDev dev;
+    int mode;
+    bool nest;
+    bool compact;
+    size_t o_fp, o_eps, o_gamma, o_cal, o_ci;
+};
+
+// Validate the descriptor and stage its per-detector arrays in the parameter block.
+OtfHost otf_prepare(const toast_hip_otf_pointing * pt, int64_t n_det, int64_t n_samp, int64_t n_pix_submap,
+                    const int64_t * d_g2l, ParamBlock & pb) {
+    if (pt == nullptr) fail_arg("otf pointing descriptor is NULL");
+    if (pt->nnz != 1 && pt->nnz != 3) fail_arg("otf pointing: nnz must be 1 (I) or 3 (IQU)");
+    if (n_pix_submap <= 0) fail_arg("n_pix_submap must be positive");
+    if (pt->d_boresight == nullptr || pt->focalplane == nullptr) fail_arg("otf pointing: boresight / focalplane missing");
+    need_aligned(pt->d_boresight, "boresight");
+    OtfHost h;
+    h.nest = pt->nest != 0;
+    const bool hwp = (pt->nnz == 3) && (pt->n_hwp == n_samp) && (pt->d_hwp != nullptr);
+    h.mode = (pt->nnz == 1) ? 0 : (hwp ? 2 : 1);
+    std::vector<double> zeros(n_det, 0.0), ones(n_det, 1.0);
+    h.o_fp = pb.push(pt->focalplane, sizeof(double) * 4 * n_det);
+    h.o_eps = pb.push(pt->epsilon ? pt->epsilon : zeros.data(), sizeof(double) * n_det);
+    h.o_gamma = pb.push(pt->gamma ? pt->gamma : zeros.data(), sizeof(double) * n_det);
+    h.o_cal = pb.push(pt->cal ? pt->cal : ones.data(), sizeof(double) * n_det);
+    h.compact = pt->d_compact_pixels != nullptr;
+    h.o_ci = 0;
+    if (h.compact) {
+        if (pt->compact_index == nullptr) fail_arg("otf pointing: compact_index is required with d_compact_pixels");
+        h.o_ci = pb.push(pt->compact_index, sizeof(int32_t) * n_det);
+    }
+    OtfDev & d = h.dev;
+    d.g2l = d_g2l;
+    d.cpix = pt->d_compact_pixels;
+    d.cpix_idx = nullptr;
+    d.bore = pt->d_boresight;
+    d.pflags = pt->d_shared_flags;
+    d.hwp = pt->d_hwp;
+    d.usign = pt->IAU ? -1.0 : 1.0;
+    d.nside = pt->nside;
+    d.nps_div = make_fastdiv(n_pix_submap);
+    d.factor = log2_exact(pt->nside);
+    d.use_pflags = (pt->n_shared_flags == n_samp && pt->d_shared_flags != nullptr) ? 1 : 0;
+    d.pmask = pt->shared_flag_mask;
+    return h;
+}
+
+void otf_bind(OtfHost & h, const char * base) {
+    h.dev.fp = (const double *)(base + h.o_fp);
+    h.dev.eps = (const double *)(base + h.o_eps);
+    h.dev.gamma = (const double *)(base + h.o_gamma);
+    h.dev.cal = (const double *)(base + h.o_cal);
+    if (h.compact) h.dev.cpix_idx = (const int32_t *)(base + h.o_ci);
+}
+
+template <int SIG, int PIX, typename... Args>
+void launch_accumulate_pix(const OtfHost & h, dim3 grid, hipStream_t st, Args... args) {
+#define TH_OTF_CASE(N, M)                                                                        \
+    hipLaunchKernelGGL((k_otf_accumulate<N, M, SIG, PIX>), grid, dim3(kThreads), 0, st, args...)
+    // with cached pixels the ordering scheme plays no role: one instantiation serves both
+    const bool nest = (PIX == 1) ? true : h.nest;
+    if (nest) {
+        if (h.mode == 0) TH_OTF_CASE(true, 0);
+        else if (h.mode == 1) TH_OTF_CASE(true, 1);
+        else TH_OTF_CASE(true, 2);
+    } else if constexpr (PIX == 0) {
+        if (h.mode == 0) TH_OTF_CASE(false, 0);
+        else if (h.mode == 1) TH_OTF_CASE(false, 1);
+        else TH_OTF_CASE(false, 2);
+    }
+#undef TH_OTF_CASE
+}
+
+template <int SIG, typename... Args>
+void launch_accumulate(const OtfHost & h, dim3 grid, hipStream_t st, Args... args) {
+    if (h.compact) {
+        launch_accumulate_pix<SIG, 1>(h, grid, st, args...);
+    } else {
+        launch_accumulate_pix<SIG, 0>(h, grid, st, args...);
+    }
+}
+
+template <int SIG, int PIX, typename... Args>
+void launch_scan_pix(const OtfHost & h, dim3 grid, hipStream_t st, Args... args) {
+#define TH_OTF_CASE(N, M)                                                                        \
+    hipLaunchKernelGGL((k_otf_scan<N, M, SIG, PIX>), grid, dim3(kThreads), 0, st, args...)
+    const bool nest = (PIX == 1) ? true : h.nest;
+    if (nest) {
+        if (h.mode == 0) TH_OTF_CASE(true, 0);
+        else if (h.mode == 1) TH_OTF_CASE(true, 1);
+        else TH_OTF_CASE(true, 2);
+    } else if constexpr (PIX == 0) {
+        if (h.mode == 0) TH_OTF_CASE(false, 0);
+        else if (h.mode == 1) TH_OTF_CASE(false, 1);
+        else TH_OTF_CASE(false, 2);
+    }
+#undef TH_OTF_CASE
+}
+
+template <int SIG, typename... Args>
+void launch_scan(const OtfHost & h, dim3 grid, hipStream_t st, Args... args) {
+    if (h.compact) {
+        launch_scan_pix<SIG, 1>(h, grid, st, args...);
+    } else {
+        launch_scan_pix<SIG, 0>(h, grid, st, args...);
+    }
+}
+
+// int64 global pixels -> int32 local map indices (the compact cache read by PIX 1)
+__global__ __launch_bounds__(kThreads) void k_compact_pixels(
+    const Chunk * __restrict__ chunks, int n_chunks, const int32_t * __restrict__ p_idx,
+    const int32_t * __restrict__ c_idx, const int64_t * __restrict__ pixels,
+    int32_t * __restrict__ cpix, const int64_t * __restrict__ g2l, FastDiv nps_div, int64_t n_samp) {
+    const int det = blockIdx.x;
+    const int64_t * prow = pixels + (int64_t)p_idx[det] * n_samp;
+    int32_t * crow = cpix + (int64_t)c_idx[det] * n_samp;
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        for (int i = threadIdx.x; i < c.count; i += kThreads) {
+            const int64_t s = c.first + i;
+            const int64_t p = prow[s];
+            int64_t l = -1;
+            if (p >= 0) {
+                const int64_t gsm = fastdiv(p, nps_div);
+                const int64_t lsm = g2l[gsm];
+                if (lsm >= 0) l = lsm * nps_div.d + (p - gsm * nps_div.d);
+            }
+            crow[s] = (int32_t)l;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int toast_hip_otf_build_noise_weighted_dev(
+    const toast_hip_otf_pointing * pointing, const int64_t * d_g2l, double * d_zmap, int64_t n_pix_submap,
+    const int32_t * data_index, const double * d_det_data, const int32_t * flag_index,
+    const uint8_t * d_det_flags, int64_t n_flag_samp, const double * det_scale, uint8_t det_flag_mask,
+    int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
+    const uint8_t * d_shared_flags, int64_t n_shared_flags, uint8_t shared_flag_mask, void * stream) {
+    return guarded([&] {
+        if (n_det <= 0) return;
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        ParamBlock pb;
+        OtfHost h = otf_prepare(pointing, n_det, n_samp, n_pix_submap, d_g2l, pb);
+        const int use_d = (n_flag_samp == n_samp) ? 1 : 0;
+        const int use_s = (n_shared_flags == n_samp) ? 1 : 0;
+        std::vector<int32_t> fidx(n_det, 0);
+        if (use_d) std::memcpy(fidx.data(), flag_index, sizeof(int32_t) * n_det);
+        const size_t o_ch = pb.push_vec(chunks);
+        const size_t o_di = pb.push(data_index, sizeof(int32_t) * n_det);
+        const size_t o_fi = pb.push_vec(fidx);
+        const size_t o_ds = pb.push(det_scale, sizeof(double) * n_det);
+        hipStream_t st = as_stream(stream);
+        const char * d = pb.commit(st);
+        otf_bind(h, d);
+        OffsetDev off{};
+        launch_accumulate<0>(h, chunk_grid(n_det, chunks.size()), st, (const Chunk *)(d + o_ch),
+                             (int)chunks.size(), h.dev, off, (const int32_t *)(d + o_di), d_det_data,
+                             (const int32_t *)(d + o_fi), d_det_flags, det_flag_mask, use_d, d_shared_flags,
+                             shared_flag_mask, use_s, (const double *)(d + o_ds), d_zmap, n_samp);
+        check_launch();
+    });
+}
+
+int toast_hip_otf_scan_map_dev(const toast_hip_otf_pointing * pointing, const int64_t * d_g2l,
+                               const double * d_map, int64_t n_pix_submap, double * d_det_data,
+                               const int32_t * data_index, int64_t n_det, int64_t n_samp,
+                               const toast_hip_interval * intervals, int64_t n_view, double data_scale,
+                               int should_zero, int should_subtract, const double * det_weights,
+                               void * stream) {
+    return guarded([&] {
+        if (n_det <= 0) return;
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        ParamBlock pb;
+        OtfHost h = otf_prepare(pointing, n_det, n_samp, n_pix_submap, d_g2l, pb);
+        const size_t o_ch = pb.push_vec(chunks);
+        const size_t o_di = pb.push(data_index, sizeof(int32_t) * n_det);
+        const size_t o_dw = det_weights ? pb.push(det_weights, sizeof(double) * n_det) : 0;
+        hipStream_t st = as_stream(stream);
+        const char * d = pb.commit(st);
+        otf_bind(h, d);
+        OffsetDev off{};
+        launch_scan<0>(h, chunk_grid(n_det, chunks.size()), st, (const Chunk *)(d + o_ch), (int)chunks.size(),
+                       h.dev, off, (const int32_t *)(d + o_di), d_det_data, data_scale, should_zero ? 1 : 0,
+                       should_subtract ? 1 : 0, (const int32_t *)nullptr, (const uint8_t *)nullptr, (uint8_t)0, 0,
+                       det_weights ? (const double *)(d + o_dw) : (const double *)nullptr, d_map, n_samp);
+        check_launch();
+    });
+}
+
+int toast_hip_otf_offset_accumulate_dev(
+    const toast_hip_otf_pointing * pointing, int64_t step_length, const int64_t * amp_offsets,
+    const int64_t * n_amp_views, const double * d_amplitudes, const uint8_t * d_amplitude_flags,
+    const int64_t * d_g2l, double * d_zmap, int64_t n_pix_submap, const int32_t * flag_index,
+    const uint8_t * d_det_flags, int64_t n_flag_samp, const double * det_scale, uint8_t det_flag_mask,
+    int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
+    const uint8_t * d_shared_flags, int64_t n_shared_flags, uint8_t shared_flag_mask, void * stream) {
+    return guarded([&] {
+        if (n_det <= 0) return;
+        if (step_length <= 0) fail_arg("step_length must be positive");
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        const OffsetViews ov = offset_views(intervals, n_amp_views, n_view);
+        ParamBlock pb;
+        OtfHost h = otf_prepare(pointing, n_det, n_samp, n_pix_submap, d_g2l, pb);
+        const int use_d = (n_flag_samp == n_samp) ? 1 : 0;
+        const int use_s = (n_shared_flags == n_samp) ? 1 : 0;
+        std::vector<int32_t> fidx(n_det, 0);
+        if (use_d) std::memcpy(fidx.data(), flag_index, sizeof(int32_t) * n_det);
+        const size_t o_ch = pb.push_vec(chunks);
+        const size_t o_vf = pb.push_vec(ov.first);
+        const size_t o_va = pb.push_vec(ov.aoff);
+        const size_t o_ao = pb.push(amp_offsets, sizeof(int64_t) * n_det);
+        const size_t o_fi = pb.push_vec(fidx);
+        const size_t o_ds = pb.push(det_scale, sizeof(double) * n_det);
+        hipStream_t st = as_stream(stream);
+        const char * d = pb.commit(st);
+        otf_bind(h, d);
+        OffsetDev off{(const int64_t *)(d + o_vf), (const int64_t *)(d + o_va), (const int64_t *)(d + o_ao),
+                      d_amplitudes, nullptr, d_amplitude_flags, make_fastdiv(step_length)};
+        launch_accumulate<1>(h, chunk_grid(n_det, chunks.size()), st, (const Chunk *)(d + o_ch),
+                             (int)chunks.size(), h.dev, off, (const int32_t *)nullptr, (const double *)nullptr,
+                             (const int32_t *)(d + o_fi), d_det_flags, det_flag_mask, use_d, d_shared_flags,
+                             shared_flag_mask, use_s, (const double *)(d + o_ds), d_zmap, n_samp);
+        check_launch();
+    });
+}
+
+int toast_hip_otf_offset_scan_project_dev(
+    const toast_hip_otf_pointing * pointing, int64_t step_length, const int64_t * amp_offsets,
+    const int64_t * n_amp_views, const double * d_amplitudes_in, double * d_amplitudes_out,
+    const uint8_t * d_amplitude_flags, const int64_t * d_g2l, const double * d_map, int64_t n_pix_submap,
+    const int32_t * flag_index, const uint8_t * d_det_flags, int64_t n_flag_samp, uint8_t det_flag_mask,
+    const double * det_weights, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals,
+    int64_t n_view, void * stream) {
+    return guarded([&] {
+        if (n_det <= 0) return;
+        if (step_length <= 0) fail_arg("step_length must be positive");
+        if (det_weights == nullptr) fail_arg("det_weights is required");
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        const OffsetViews ov = offset_views(intervals, n_amp_views, n_view);
+        ParamBlock pb;
+        OtfHost h = otf_prepare(pointing, n_det, n_samp, n_pix_submap, d_g2l, pb);
+        const int use_f = (n_flag_samp == n_samp) ? 1 : 0;
+        std::vector<int32_t> fidx(n_det, 0);
+        if (use_f) std::memcpy(fidx.data(), flag_index, sizeof(int32_t) * n_det);
+        const size_t o_ch = pb.push_vec(chunks);
+        const size_t o_vf = pb.push_vec(ov.first);
+        const size_t o_va = pb.push_vec(ov.aoff);
+        const size_t o_ao = pb.push(amp_offsets, sizeof(int64_t) * n_det);
+        const size_t o_fi = pb.push_vec(fidx);
+        const size_t o_dw = pb.push(det_weights, sizeof(double) * n_det);
+        hipStream_t st = as_stream(stream);
+        const char * d = pb.commit(st);
+        otf_bind(h, d);
+        OffsetDev off{(const int64_t *)(d + o_vf), (const int64_t *)(d + o_va), (const int64_t *)(d + o_ao),
+                      d_amplitudes_in, d_amplitudes_out, d_amplitude_flags, make_fastdiv(step_length)};
+        launch_scan<1>(h, chunk_grid(n_det, chunks.size()), st, (const Chunk *)(d + o_ch), (int)chunks.size(),
+                       h.dev, off, (const int32_t *)nullptr, (double *)nullptr, 1.0, 0, 1,
+                       (const int32_t *)(d + o_fi), d_det_flags, det_flag_mask, use_f,
+                       (const double *)(d + o_dw), d_map, n_samp);
+        check_launch();
+    });
+}
+
+int toast_hip_compact_pixels_dev(const int64_t * d_g2l, int64_t n_pix_submap, int64_t n_local_submap,
+                                 const int32_t * pixel_index, const int64_t * d_pixels,
+                                 const int32_t * compact_index, int32_t * d_compact_pixels, int64_t n_det,
+                                 int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
+                                 void * stream) {
+    return guarded([&] {
+        if (n_det <= 0) return;
+        if (n_pix_submap <= 0) fail_arg("n_pix_submap must be positive");
+        if (n_local_submap * n_pix_submap > (int64_t)INT32_MAX) {
+            fail_arg("compact pixels: the local map has more than 2^31-1 pixels");
+        }
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        ParamBlock pb;
+        const size_t o_ch = pb.push_vec(chunks);
+        const size_t o_pi = pb.push(pixel_index, sizeof(int32_t) * n_det);
+        const size_t o_ci = pb.push(compact_index, sizeof(int32_t) * n_det);
+        hipStream_t st = as_stream(stream);
+        const char * d = pb.commit(st);
+        hipLaunchKernelGGL(k_compact_pixels, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0, st,
+                           (const Chunk *)(d + o_ch), (int)chunks.size(), (const int32_t *)(d + o_pi),
+                           (const int32_t *)(d + o_ci), d_pixels, d_compact_pixels, d_g2l,
+                           make_fastdiv(n_pix_submap), n_samp);
+        check_launch();
+    });
+}
+
+}  // extern "C"
