@@ -109,7 +109,7 @@ def test_build_noise_weighted_vs_python_loop(use_accel):
     assert np.max(np.abs(data["zmap"].data - 2 * want)) < 1e-12 * np.max(np.abs(want))
 
 
-def test_hits_covariance_and_binmap():
+def test_hits_covariance_and_binmap(monkeypatch):
     data = create_satellite_data(n_det=4, n_samp=3000)
     fill_signal(data)
     dp, pix, sw = pointing_ops(nside=32, create_dist=None)
@@ -169,6 +169,14 @@ def test_hits_covariance_and_binmap():
                          stokes_weights=sw, full_pointing=False)
     binner2.apply(data)
     assert np.max(np.abs(data["binned2"].data - data["binned"].data)) < 1e-12 * np.max(np.abs(data["binned"].data))
+    # ... through the pointing-on-the-fly kernel: no pointing buffers at all
+    assert defaults.pixels not in ob.detdata and defaults.weights not in ob.detdata
+    # the reference's own sequence (scratch pointing recomputed per detector pass)
+    monkeypatch.setenv("TOAST_HIP_POINTING_BATCH", "1")
+    binner3 = ops.BinMap(pixel_dist="dist", covariance="cov", binned="binned3", pixel_pointing=pix,
+                         stokes_weights=sw, full_pointing=False, on_the_fly=False)
+    binner3.apply(data)
+    assert np.max(np.abs(data["binned3"].data - data["binned"].data)) < 1e-12 * np.max(np.abs(data["binned"].data))
     assert ob.detdata[defaults.pixels].data.shape[0] == 1  # one-detector buffers were recycled
 
 
@@ -497,3 +505,54 @@ def test_lazy_host_coherence_and_eviction():
     for k in got[True]:
         assert np.any(got[False][k])
         assert np.array_equal(got[True][k], got[False][k])
+
+
+def test_uncached_pointing_matches_full_pointing(monkeypatch):
+    """full_pointing=False (the reference default) runs through the pointing-on-the-fly kernels
+    (BinMap, fused SolverLHS) and batched scratch passes; the products equal the cached-pointing
+    run: maps, hits, covariance, amplitudes."""
+    monkeypatch.setenv("TOAST_HIP_POINTING_BATCH", "4")   # two scratch passes: 4 + 2 detectors
+    out = {}
+    for full in (True, False):
+        data, pix, sw, truth, sky = make_solver_setup(noise_rms=0.1, n_det=6, n_samp=9000)
+        binner = ops.BinMap(pixel_dist="dist", pixel_pointing=pix, stokes_weights=sw, full_pointing=full)
+        tmpl = Offset(step_time=20.0, noise_model=defaults.noise_model, name="baselines", good_fraction=0.2)
+        tmatrix = ops.TemplateMatrix(templates=[tmpl])
+        mapper = ops.MapMaker(name="mm", det_data=defaults.det_data, binning=binner, template_matrix=tmatrix,
+                              iter_max=12, convergence=1e-30, solve_rcond_threshold=1e-3, map_rcond_threshold=1e-3)
+        mapper.apply(data)
+        ob = data.obs[0]
+        if not full:
+            # nothing of the 56 B/det-sample pointing was kept
+            assert defaults.weights not in ob.detdata or ob.detdata[defaults.weights].buffer.shape[0] < 6
+        out[full] = dict(map=data["mm_map"].data.copy(), hits=data["mm_hits"].data.copy(),
+                         cov=data["mm_cov"].data.copy(), amps=data["mm_amplitudes"]["baselines"].local.copy(),
+                         hist=np.array(mapper.history))
+    assert np.array_equal(out[True]["hits"], out[False]["hits"])
+    np.testing.assert_allclose(out[False]["cov"], out[True]["cov"], rtol=1e-10, atol=1e-14 * np.max(np.abs(out[True]["cov"])))
+    np.testing.assert_allclose(out[False]["hist"][:5], out[True]["hist"][:5], rtol=1e-6)
+    scale = np.max(np.abs(out[True]["amps"]))
+    assert np.max(np.abs(out[False]["amps"] - out[True]["amps"])) < 1e-7 * scale
+    mscale = np.max(np.abs(out[True]["map"]))
+    assert np.max(np.abs(out[False]["map"] - out[True]["map"])) < 1e-7 * mscale
+
+
+def test_binmap_on_the_fly_equals_cached():
+    data, pix, sw, truth, sky = make_solver_setup(noise_rms=0.1, n_det=5, n_samp=6000)
+    ops.CovarianceAndHits(pixel_dist="dist", covariance="cov", pixel_pointing=pix, stokes_weights=sw).apply(data)
+    # the scratch pointing of the covariance pass happens to hold every detector here: cached
+    # pointing would be preferred over recomputation, so drop it
+    ops.Delete(detdata=[defaults.pixels, defaults.weights, defaults.quats]).apply(data)
+    got = {}
+    for key, kw in (("otf", dict(full_pointing=False)), ("batch", dict(full_pointing=False, on_the_fly=False)),
+                    ("full", dict(full_pointing=True))):
+        b = ops.BinMap(pixel_dist="dist", covariance="cov", binned=f"bin_{key}", pixel_pointing=pix,
+                       stokes_weights=sw, **kw)
+        if key == "otf":
+            assert b._on_the_fly(data, None, None)
+        b.apply(data)
+        got[key] = data[f"bin_{key}"].data.copy()
+    scale = np.max(np.abs(got["full"]))
+    assert scale > 0
+    assert np.max(np.abs(got["otf"] - got["full"])) < 1e-12 * scale
+    assert np.max(np.abs(got["batch"] - got["full"])) < 1e-12 * scale

@@ -14,7 +14,7 @@ from ..traits import Bool, Float, Instance, Int, Unicode
 from .mapmaker_ops import BinMap, Copy, CovarianceAndHits, Delete, ScanMask
 from .mapmaker_solve import SolverLHS, SolverRHS, TemplateMatrix, solve
 from .operator import Operator
-from .pipeline import Pipeline
+from .pipeline import Pipeline, uncached_detector_sets
 
 
 class ApplyAmplitudes(Operator):
@@ -180,7 +180,7 @@ class MapMaker(Operator):
             scanner = ScanMask(det_flags=solver_flags, det_flags_value=1, det_mask=binning.det_mask,
                                pixels=binning.pixel_pointing.pixels, view=binning.pixel_pointing.view,
                                mask_key=mask_name)
-            scan_pipe = Pipeline(detector_sets=["ALL"] if binning.full_pointing else ["SINGLE"],
+            scan_pipe = Pipeline(detector_sets=["ALL"] if binning.full_pointing else uncached_detector_sets(),
                                  operators=[binning.pixel_pointing, scanner])
             scan_pipe.apply(data, detectors=detectors)
             del data[mask_name]

@@ -13,7 +13,7 @@ from ..data import defaults
 from ..pixels import PixelData, covariance_apply, covariance_invert
 from ..traits import Bool, Float, ImplementationType, Instance, Int, List, Unicode
 from .operator import Operator
-from .pipeline import Pipeline
+from .pipeline import Pipeline, uncached_detector_sets
 
 _IMPLS = [ImplementationType.DEFAULT, ImplementationType.COMPILED]
 
@@ -372,6 +372,79 @@ class BuildNoiseWeighted(_MapBuilder):
         return {"global": [self.zmap]}
 
 
+class BuildNoiseWeightedOnTheFly(BuildNoiseWeighted):
+    """``zmap += A^T N^-1 d`` with the pointing evaluated inside the kernel
+    (toast_hip_otf_build_noise_weighted_dev): the fused form of the reference's
+    ``Pipeline(detector_sets=["SINGLE"], [pixels, weights, build_zmap])``
+    (mapmaker_binning.py:265-271) -- no per-detector pointing scratch, one launch per observation."""
+
+    pixel_pointing = Instance(klass=Operator, help="The pixel pointing operator")
+    stokes_weights = Instance(klass=Operator, help="The Stokes weights operator")
+
+    def _exec(self, data, detectors=None, use_accel=None, **kwargs):
+        from .. import capi
+        from ..accel import accel_device_ptr
+        from ..data import SharedData
+        from .pointing import otf_descriptor
+
+        if not use_accel:
+            raise RuntimeError("BuildNoiseWeightedOnTheFly runs on the accelerator only")
+        dist = self._dist(data)
+        nnz = len(self.stokes_weights.mode)
+        if self.zmap in data:
+            if data[self.zmap].distribution != dist:
+                raise RuntimeError("Existing zmap '{}' has different data distribution".format(self.zmap))
+            zmap = data[self.zmap]
+        else:
+            data[self.zmap] = PixelData(dist, np.float64, n_value=nnz)
+            zmap = data[self.zmap]
+        _global_to(zmap, self.zmap, True, zero_new=not zmap.accel_exists() and not np.any(zmap.raw))
+        gkey = "_g2l_" + self.pixel_dist
+        if gkey not in data:
+            data[gkey] = SharedData(dist.global_submap_to_local, "g2l")
+        g2l = data[gkey]
+        if not g2l.accel_exists():
+            g2l.accel_create("g2l")
+        if not g2l.accel_in_use():
+            g2l.accel_update_device()
+        view = self.pixel_pointing.view
+        for ob in data.obs:
+            dets = ob.select_local_detectors(selection=detectors, flagmask=self.det_mask)
+            if self.noise_model not in ob:
+                raise RuntimeError("Noise model {} does not exist in observation {}".format(self.noise_model, ob.name))
+            if len(dets) == 0:
+                continue
+            noise = ob[self.noise_model]
+            detweights = np.array([noise.detector_weight(x) for x in dets], dtype=np.float64)
+            pt = otf_descriptor(ob, dets, self.pixel_pointing, self.stokes_weights)
+            n_samp = ob.n_local_samples
+            dd = ob.detdata[self.det_data]
+            if not dd.accel_in_use():
+                if not dd.accel_exists():
+                    dd.accel_create(self.det_data)
+                dd.accel_update_device()
+            flag_indx, flag_data, shared = self._flag_args(ob, dets, True)
+            f_ptr, f_n = (accel_device_ptr(flag_data), n_samp) if self.det_flags is not None else (0, 0)
+            s_ptr, s_n = (accel_device_ptr(shared), n_samp) if self.shared_flags is not None else (0, 0)
+            capi.dev.otf_build_noise_weighted(
+                pt, accel_device_ptr(g2l.data), accel_device_ptr(zmap.raw), dist.n_pix_submap, dd.indices(dets),
+                accel_device_ptr(dd.buffer), flag_indx, f_ptr, f_n, detweights, self.det_flag_mask, n_samp,
+                ob.intervals[view].data, s_ptr, s_n, self.shared_flag_mask)
+
+    def _requires(self):
+        dp = self.pixel_pointing.detector_pointing
+        req = {"global": [self.pixel_dist], "meta": [self.noise_model], "shared": [dp.boresight],
+               "detdata": [self.det_data], "intervals": []}
+        for key in (dp.shared_flags, self.shared_flags, self.stokes_weights.hwp_angle):
+            if key is not None and key not in req["shared"]:
+                req["shared"].append(key)
+        if self.det_flags is not None:
+            req["detdata"].append(self.det_flags)
+        if self.pixel_pointing.view is not None:
+            req["intervals"].append(self.pixel_pointing.view)
+        return req
+
+
 class BuildHitMap(_MapBuilder):
     """``hits[pix] += 1`` for every unflagged sample (mapmaker_utils.py:34-260)."""
 
@@ -506,7 +579,7 @@ class CovarianceAndHits(Operator):
             del data[inv_key]
         if self.pixel_dist not in data:
             self.pixel_pointing.create_dist = self.pixel_dist
-            pix_dist = Pipeline(detector_sets=["ALL"] if self.save_pointing else ["SINGLE"],
+            pix_dist = Pipeline(detector_sets=["ALL"] if self.save_pointing else uncached_detector_sets(),
                                 operators=[self.pixel_pointing])
             pix_dist.apply(data, detectors=detectors)
             self.pixel_pointing.create_dist = None
@@ -518,7 +591,7 @@ class CovarianceAndHits(Operator):
         build_invcov = BuildInverseCovariance(inverse_covariance=inv_key, weights=self.stokes_weights.weights,
                                               noise_model=self.noise_model, det_data_units=self.det_data_units,
                                               **common)
-        accum = Pipeline(detector_sets=["ALL"] if self.save_pointing else ["SINGLE"],
+        accum = Pipeline(detector_sets=["ALL"] if self.save_pointing else uncached_detector_sets(),
                          operators=[self.pixel_pointing, self.stokes_weights, build_hits, build_invcov])
         accum.apply(data, detectors=detectors)
         cov = data[inv_key].duplicate()
@@ -567,6 +640,8 @@ class BinMap(Operator):
     noise_model = Unicode(defaults.noise_model, help="Observation key containing the noise model")
     sync_type = Unicode("allreduce", help="Communication algorithm: 'allreduce' or 'alltoallv'")
     full_pointing = Bool(False, help="If True, expand pointing for all detectors and save")
+    on_the_fly = Bool(True, help="With full_pointing=False on the accelerator, evaluate the pointing inside "
+                                 "the accumulate kernel (not a reference trait; False = SINGLE pipelines)")
 
     def _validate_sync_type(self, check):
         if check not in ("allreduce", "alltoallv"):
@@ -603,13 +678,47 @@ class BinMap(Operator):
         accum_ops = []
         if self.pre_process is not None:
             accum_ops.append(self.pre_process)
-        accum = Pipeline(detector_sets=["ALL"] if self.full_pointing else ["SINGLE"])
-        accum_ops.extend([self.pixel_pointing, self.stokes_weights, build_zmap])
-        accum.operators = accum_ops
-        accum.apply(data, detectors=detectors, use_accel=use_accel)
+        if self._on_the_fly(data, detectors, use_accel):
+            # full_pointing=False on the accelerator: the pointing is evaluated inside the
+            # accumulate kernel instead of per-detector SINGLE passes through pointing scratch
+            otf = BuildNoiseWeightedOnTheFly(
+                pixel_dist=self.pixel_dist, zmap=self.binned, view=self.pixel_pointing.view,
+                pixel_pointing=self.pixel_pointing, stokes_weights=self.stokes_weights,
+                noise_model=self.noise_model, det_data=self.det_data, det_data_units=self.det_data_units,
+                det_mask=self.det_mask, det_flags=self.det_flags, det_flag_mask=self.det_flag_mask,
+                shared_flags=self.shared_flags, shared_flag_mask=self.shared_flag_mask, sync_type=self.sync_type)
+            accum = Pipeline(detector_sets=["ALL"], operators=accum_ops + [otf])
+            accum.apply(data, detectors=detectors, use_accel=True)
+        else:
+            accum = Pipeline(detector_sets=["ALL"] if self.full_pointing else uncached_detector_sets())
+            accum_ops.extend([self.pixel_pointing, self.stokes_weights, build_zmap])
+            accum.operators = accum_ops
+            accum.apply(data, detectors=detectors, use_accel=use_accel)
         if self.noiseweighted is not None:
             data[self.noiseweighted] = data[self.binned].duplicate()
         covariance_apply(cov, data[self.binned], use_alltoallv=(self.sync_type == "alltoallv"))
+
+    def _on_the_fly(self, data, detectors, use_accel):
+        """Pointing-on-the-fly applies when the pointing is not cached (``full_pointing=False``
+        and no pixels / weights left over from an earlier full expansion), the accelerator is in
+        use and the pointing operators are the standard trio."""
+        from ..accel import accel_enabled
+        from .pointing import _outputs_exist, otf_supported
+
+        if self.full_pointing or not self.on_the_fly or use_accel is False or not accel_enabled():
+            return False
+        if not otf_supported(self.pixel_pointing, self.stokes_weights):
+            return False
+        if self.pre_process is not None and not self.pre_process.supports_accel():
+            return False
+        for ob in data.obs:
+            if self.det_data in ob.detdata and ob.detdata[self.det_data].dtype != np.float64:
+                return False
+        # cached pointing of all detectors is cheaper to read than to recompute
+        if (_outputs_exist(data, self.pixel_pointing.pixels, detectors, self.det_mask)
+                and _outputs_exist(data, self.stokes_weights.weights, detectors, self.det_mask)):
+            return False
+        return True
 
     def _finalize(self, data, **kwargs):
         return
@@ -642,15 +751,26 @@ class Copy(Operator):
             for src, dst in self.detdata:
                 s = ob.detdata[src]
                 dets = ob.select_local_detectors(detectors)
-                if use_accel and s.accel_in_use() and set(dets) >= set(s.detectors):
-                    # whole-buffer device-to-device copy, nothing crosses PCIe
+                if use_accel and s.accel_in_use():
+                    # device-to-device copy of the selected rows (runs of adjacent rows merged),
+                    # nothing crosses PCIe
                     from .. import capi
                     from ..accel import accel_device_ptr
 
                     ob.detdata.ensure(dst, sample_shape=s.detector_shape[1:], dtype=s.dtype, detectors=s.detectors,
                                       accel=True)
                     d = ob.detdata[dst]
-                    capi.dev.copy(accel_device_ptr(d.buffer), accel_device_ptr(s.buffer), s.buffer.nbytes)
+                    rows = sorted(int(r) for r in s.indices([x for x in dets if x in s.detectors]))
+                    row_bytes = s.buffer[0].nbytes if len(s.detectors) else 0
+                    sp, dp_ = accel_device_ptr(s.buffer), accel_device_ptr(d.buffer)
+                    i = 0
+                    while i < len(rows):
+                        j = i
+                        while j + 1 < len(rows) and rows[j + 1] == rows[j] + 1:
+                            j += 1
+                        off = rows[i] * row_bytes
+                        capi.dev.copy(dp_ + off, sp + off, (j - i + 1) * row_bytes)
+                        i = j + 1
                     d.accel_used(True)
                     continue
                 if s.accel_in_use():

@@ -14,7 +14,7 @@ from ..templates import AmplitudesMap
 from ..traits import Bool, Float, ImplementationType, Instance, Int, List, Unicode
 from .mapmaker_ops import BinMap, Copy, Delete, NoiseWeight, ScanMap
 from .operator import Operator
-from .pipeline import Pipeline
+from .pipeline import Pipeline, uncached_detector_sets
 
 
 class TemplateMatrix(Operator):
@@ -193,7 +193,7 @@ class SolverRHS(Operator):
             proj_pipe = Pipeline(detector_sets=["ALL"], operators=ops)
         else:
             ops = [copy_det, pixels, weights, scan_map, noise_weight, self.template_matrix]
-            proj_pipe = Pipeline(detector_sets=["SINGLE"], operators=ops)
+            proj_pipe = Pipeline(detector_sets=uncached_detector_sets(), operators=ops)
         proj_pipe.apply(data, detectors=detectors)
         Delete(detdata=[det_temp]).apply(data)
 
@@ -227,8 +227,15 @@ class SolverLHS(Operator):
         from ..accel import accel_enabled
         from ..templates import Offset
 
-        if not (self.fused and self.binning.full_pointing and accel_enabled()):
+        if not (self.fused and accel_enabled()):
             return False
+        if not self.binning.full_pointing:
+            # uncached pointing: only through the on-the-fly kernels
+            from .pointing import otf_supported
+
+            if not (getattr(self.binning, "on_the_fly", False)
+                    and otf_supported(self.binning.pixel_pointing, self.binning.stokes_weights)):
+                return False
         tmpls = [t for t in self.template_matrix.templates if t.enabled]
         if len(tmpls) != 1 or not isinstance(tmpls[0], Offset) or tmpls[0].use_noise_prior:
             return False
@@ -252,6 +259,7 @@ class SolverLHS(Operator):
         from .. import capi
         from ..accel import accel_device_ptr, native
         from ..pixels import PixelData, covariance_apply
+        from .pointing import otf_descriptor
 
         D = capi.dev
         binning, tm = self.binning, self.template_matrix
@@ -263,22 +271,25 @@ class SolverLHS(Operator):
         tm.initialize(data)
         amps_in = data[tm.amplitudes][tmpl.name]
         amps_out = data[self.out][tmpl.name]
-        # cached pointing, resident on the device (computed once, reused by every iteration)
+        # full_pointing: cached pointing, resident on the device (computed once, reused by every
+        # iteration); otherwise the kernels evaluate the pointing on the fly from the boresight
         pixels_op.detector_pointing.det_mask = binning.det_mask
-        cached = True
-        for ob in data.obs:
-            dets = ob.select_local_detectors(detectors, flagmask=binning.det_mask)
-            for key in (pixels_op.pixels, weights_op.weights):
-                if key not in ob.detdata or not set(dets) <= set(ob.detdata[key].detectors):
-                    cached = False
-        if cached:
-            # do not drag the detector quaternions (4x the pixel volume) to the device again
+        on_the_fly = not binning.full_pointing
+        if not on_the_fly:
+            cached = True
             for ob in data.obs:
-                self._resident(ob.detdata[pixels_op.pixels], pixels_op.pixels)
-                self._resident(ob.detdata[weights_op.weights], weights_op.weights)
-        else:
-            pixels_op.apply(data, detectors=detectors, use_accel=True)
-            weights_op.apply(data, detectors=detectors, use_accel=True)
+                dets = ob.select_local_detectors(detectors, flagmask=binning.det_mask)
+                for key in (pixels_op.pixels, weights_op.weights):
+                    if key not in ob.detdata or not set(dets) <= set(ob.detdata[key].detectors):
+                        cached = False
+            if cached:
+                # do not drag the detector quaternions (4x the pixel volume) to the device again
+                for ob in data.obs:
+                    self._resident(ob.detdata[pixels_op.pixels], pixels_op.pixels)
+                    self._resident(ob.detdata[weights_op.weights], weights_op.weights)
+            else:
+                pixels_op.apply(data, detectors=detectors, use_accel=True)
+                weights_op.apply(data, detectors=detectors, use_accel=True)
         dist = data[binning.pixel_dist]
         nnz = len(weights_op.mode)
         if binning.binned not in data:
@@ -310,7 +321,6 @@ class SolverLHS(Operator):
                 continue
             amp_offsets = tmpl.det_amp_offsets(iob, dets)
             step_length = tmpl._step_length(tmpl.step_time, tmpl._obs_rate[iob])
-            pd, wd = ob.detdata[pixels_op.pixels], ob.detdata[weights_op.weights]
             noise = ob[binning.noise_model]
             wkey = (id(noise), tuple(dets))
             wcache = self.__dict__.setdefault("_detw_cache", {})
@@ -331,26 +341,53 @@ class SolverLHS(Operator):
                 s_ptr, s_n = 0, 0
             if tmpl.det_flags is not None:
                 pflags = tmpl._solver_flags(iob, ob, True)
-                pf_idx, pf_ptr = ob.detdata[tmpl.det_flags].indices(dets), accel_device_ptr(pflags)
+                pf_idx, pf_ptr, pf_n = ob.detdata[tmpl.det_flags].indices(dets), accel_device_ptr(pflags), n_samp
             else:
-                pf_idx, pf_ptr = None, 0
-            common = dict(step=step_length, ao=amp_offsets, nav=tmpl._obs_views[iob],
-                          pi=pd.indices(dets), pp=accel_device_ptr(pd.buffer), wi=wd.indices(dets),
-                          wp=accel_device_ptr(wd.buffer), n_samp=n_samp, ivl=ivl, detw=detw)
-            D.offset_accumulate(step_length, amp_offsets, tmpl._obs_views[iob], accel_device_ptr(amps_in.local),
-                                accel_device_ptr(amps_in.local_flags), accel_device_ptr(g2l.data),
-                                accel_device_ptr(zmap.raw), dist.n_pix_submap, nnz, common["pi"], common["pp"],
-                                common["wi"], common["wp"], f_idx, f_ptr, f_ns, detw, binning.det_flag_mask, n_samp,
-                                ivl, s_ptr, s_n, binning.shared_flag_mask)
-            passes.append((common, pf_idx, pf_ptr))
+                pf_idx, pf_ptr, pf_n = None, 0, 0
+            common = dict(step=step_length, ao=amp_offsets, nav=tmpl._obs_views[iob], n_samp=n_samp, ivl=ivl,
+                          detw=detw)
+            if on_the_fly:
+                # the descriptor only depends on the detector list and the resident shared data
+                pcache = self.__dict__.setdefault("_otf_cache", {})
+                pkey = (id(ob), tuple(dets), accel_device_ptr(ob.shared[pixels_op.detector_pointing.boresight].data)
+                        if ob.shared[pixels_op.detector_pointing.boresight].accel_exists() else 0)
+                if pkey not in pcache:
+                    pcache.clear()
+                    pt = otf_descriptor(ob, dets, pixels_op, weights_op)
+                    pkey = (id(ob), tuple(dets), int(pt.d_boresight))
+                    pcache[pkey] = pt
+                pt = pcache[pkey]
+                common["pt"] = pt
+                D.otf_offset_accumulate(pt, step_length, amp_offsets, tmpl._obs_views[iob],
+                                        accel_device_ptr(amps_in.local), accel_device_ptr(amps_in.local_flags),
+                                        accel_device_ptr(g2l.data), accel_device_ptr(zmap.raw), dist.n_pix_submap,
+                                        f_idx, f_ptr, f_ns, detw, binning.det_flag_mask, n_samp, ivl, s_ptr, s_n,
+                                        binning.shared_flag_mask)
+            else:
+                pd, wd = ob.detdata[pixels_op.pixels], ob.detdata[weights_op.weights]
+                common.update(pi=pd.indices(dets), pp=accel_device_ptr(pd.buffer), wi=wd.indices(dets),
+                              wp=accel_device_ptr(wd.buffer))
+                D.offset_accumulate(step_length, amp_offsets, tmpl._obs_views[iob], accel_device_ptr(amps_in.local),
+                                    accel_device_ptr(amps_in.local_flags), accel_device_ptr(g2l.data),
+                                    accel_device_ptr(zmap.raw), dist.n_pix_submap, nnz, common["pi"], common["pp"],
+                                    common["wi"], common["wp"], f_idx, f_ptr, f_ns, detw, binning.det_flag_mask,
+                                    n_samp, ivl, s_ptr, s_n, binning.shared_flag_mask)
+            passes.append((common, pf_idx, pf_ptr, pf_n))
         zmap.sync_allreduce()
         covariance_apply(cov, zmap)
-        for common, pf_idx, pf_ptr in passes:
-            D.offset_scan_project(common["step"], common["ao"], common["nav"], accel_device_ptr(amps_in.local),
-                                  accel_device_ptr(amps_out.local), accel_device_ptr(amps_in.local_flags),
-                                  accel_device_ptr(g2l.data), accel_device_ptr(zmap.raw), dist.n_pix_submap, nnz,
-                                  common["pi"], common["pp"], common["wi"], common["wp"], pf_idx, pf_ptr,
-                                  tmpl.det_flag_mask, common["detw"], common["n_samp"], common["ivl"])
+        for common, pf_idx, pf_ptr, pf_n in passes:
+            if on_the_fly:
+                D.otf_offset_scan_project(common["pt"], common["step"], common["ao"], common["nav"],
+                                          accel_device_ptr(amps_in.local), accel_device_ptr(amps_out.local),
+                                          accel_device_ptr(amps_in.local_flags), accel_device_ptr(g2l.data),
+                                          accel_device_ptr(zmap.raw), dist.n_pix_submap, pf_idx, pf_ptr, pf_n,
+                                          tmpl.det_flag_mask, common["detw"], common["n_samp"], common["ivl"])
+            else:
+                D.offset_scan_project(common["step"], common["ao"], common["nav"], accel_device_ptr(amps_in.local),
+                                      accel_device_ptr(amps_out.local), accel_device_ptr(amps_in.local_flags),
+                                      accel_device_ptr(g2l.data), accel_device_ptr(zmap.raw), dist.n_pix_submap, nnz,
+                                      common["pi"], common["pp"], common["wi"], common["wp"], pf_idx, pf_ptr,
+                                      tmpl.det_flag_mask, common["detw"], common["n_samp"], common["ivl"])
         if not getattr(self, "keep_on_device", False):
             native().accel_synchronize()
             amps_out.accel_update_host()
@@ -401,7 +438,7 @@ class SolverLHS(Operator):
             proj_pipe = Pipeline(detector_sets=["ALL"], operators=ops)
         else:
             ops = [self.template_matrix, pixels, weights, scan_map, noise_weight, template_transpose]
-            proj_pipe = Pipeline(detector_sets=["SINGLE"], operators=ops)
+            proj_pipe = Pipeline(detector_sets=uncached_detector_sets(), operators=ops)
         proj_pipe.apply(data, detectors=detectors)
 
     def _finalize(self, data, **kwargs):

@@ -1,8 +1,10 @@
 """Pipeline: run a list of operators over detector sets and stage their data on the
 accelerator (reference: src/toast/ops/pipeline.py:22-389)."""
 
+import os
+
 from ..accel import accel_enabled
-from ..traits import Bool, ImplementationType, List
+from ..traits import Bool, ImplementationType, Int, List
 from .operator import Operator
 
 
@@ -34,6 +36,13 @@ class _SetDict(dict):
         return all(len(v) == 0 for v in self.values())
 
 
+def uncached_detector_sets():
+    """Detector sets for passes that recompute pointing into scratch buffers: the reference's
+    ["SINGLE"] on the host, ["BATCH"] on the accelerator (one-detector launches cannot fill
+    256 CUs)."""
+    return ["BATCH"] if accel_enabled() else ["SINGLE"]
+
+
 class Pipeline(Operator):
     """Chain of operators.  ``detector_sets`` = ["ALL"] (one pass over all detectors),
     ["SINGLE"] (one pass per detector: pointing is recomputed into recycled one-detector
@@ -42,7 +51,8 @@ class Pipeline(Operator):
     operator and outputs are copied back and freed at finalize (pipeline.py:208-303)."""
 
     operators = List([], help="List of Operator instances to run.")
-    detector_sets = List(["ALL"], help="List of detector sets: 'ALL', 'SINGLE' or lists of names")
+    detector_sets = List(["ALL"], help="List of detector sets: 'ALL', 'SINGLE', 'BATCH' or lists of names")
+    batch_size = Int(64, help="Detectors per pass for detector_sets=['BATCH'] (not a reference trait)")
     use_hybrid = Bool(True, help="Should the pipeline be allowed to use the GPU when it has some cpu-only operators.")
 
     def _validate_operators(self, ops):
@@ -90,6 +100,15 @@ class Pipeline(Operator):
                 all_local = [None]
             for det in all_local:
                 dets = [] if det is None else [det]
+                for op in self.operators:
+                    self._exec_operator(op, data, dets, pipe_accel)
+        elif len(sets) == 1 and sets[0] == "BATCH":
+            # SINGLE semantics (scratch pointing buffers recycled between passes) with enough
+            # detectors per pass to fill the GPU: 64 detectors x 64 B/sample of pointing scratch
+            all_local = data.all_local_detectors(selection=detectors, flagmask=det_mask)
+            n = max(1, int(os.environ.get("TOAST_HIP_POINTING_BATCH", self.batch_size)))
+            for i in range(0, max(len(all_local), 1), n):
+                dets = all_local[i:i + n]
                 for op in self.operators:
                     self._exec_operator(op, data, dets, pipe_accel)
         else:

@@ -96,6 +96,60 @@ class PointingDetectorSimple(Operator):
         return True
 
 
+def otf_supported(pixels_op, weights_op):
+    """True when the pointing operator trio is the one the on-the-fly kernels reproduce
+    (PointingDetectorSimple -> PixelsHealpix -> StokesWeights, same detector pointing)."""
+    if not isinstance(pixels_op, PixelsHealpix) or not isinstance(weights_op, StokesWeights):
+        return False
+    dp = pixels_op.detector_pointing
+    if not isinstance(dp, PointingDetectorSimple) or weights_op.detector_pointing is None:
+        return False
+    wp = weights_op.detector_pointing
+    same = all(getattr(dp, t) == getattr(wp, t) for t in ("boresight", "shared_flags", "shared_flag_mask", "view"))
+    if not same or (dp.coord_in is not None and dp.coord_in != dp.coord_out):
+        return False
+    if weights_op.single_precision or weights_op.mode not in ("I", "IQU"):
+        return False
+    view = weights_op.view if weights_op.view is not None else wp.view
+    return view == pixels_op.view
+
+
+def otf_descriptor(ob, dets, pixels_op, weights_op, compact=None):
+    """``toast_hip_otf_pointing`` for these detectors of one observation: the arguments the three
+    pointing operators would pass to their kernels (pointing_detector.py:150-214,
+    pixels_healpix.py:215-277, stokes_weights.py:200-310), with boresight / flags / HWP angle
+    resident on the device.  ``compact`` = (DetectorData of int32 local pixel indices) or None."""
+    from .. import capi
+    from ..accel import accel_device_ptr
+
+    dp = pixels_op.detector_pointing
+    _shared_to(ob, dp.boresight, True)
+    bore = accel_device_ptr(ob.shared[dp.boresight].data)
+    n_samp = ob.n_local_samples
+    d_flags, n_flags = 0, 0
+    if dp.shared_flags is not None:
+        _shared_to(ob, dp.shared_flags, True)
+        d_flags, n_flags = accel_device_ptr(ob.shared[dp.shared_flags].data), n_samp
+    focalplane = ob.telescope.focalplane
+    fp_quats = np.array([focalplane[d]["quat"] for d in dets], dtype=np.float64).reshape(len(dets), 4)
+    nnz = len(weights_op.mode)
+    eps = np.array([focalplane[d]["pol_leakage"] for d in dets], dtype=np.float64)
+    cal = (np.ones(len(dets)) if weights_op.cal is None
+           else np.array([ob[weights_op.cal][x] for x in dets], np.float64))
+    gamma = np.zeros(len(dets), dtype=np.float64)
+    d_hwp, n_hwp = 0, 0
+    if nnz == 3 and weights_op.hwp_angle is not None and weights_op.hwp_angle in ob.shared:
+        _shared_to(ob, weights_op.hwp_angle, True)
+        d_hwp, n_hwp = accel_device_ptr(ob.shared[weights_op.hwp_angle].data), n_samp
+        gamma = np.array([focalplane[d][weights_op.fp_gamma] for d in dets], dtype=np.float64)
+    extra = {}
+    if compact is not None:
+        extra = dict(d_compact_pixels=accel_device_ptr(compact.buffer), compact_index=compact.indices(dets))
+    return capi.otf_pointing(bore, fp_quats, pixels_op.nside, pixels_op.nest, nnz, d_shared_flags=d_flags,
+                             n_shared_flags=n_flags, shared_flag_mask=dp.shared_flag_mask, d_hwp=d_hwp, n_hwp=n_hwp,
+                             epsilon=eps, gamma=gamma, cal=cal, IAU=bool(weights_op.IAU), **extra)
+
+
 def _outputs_exist(data, key, detectors, det_mask):
     """True when every observation already holds ``key`` for all requested detectors: the
     operator (and the detector pointing it would trigger) has nothing to do."""
