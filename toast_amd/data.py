@@ -248,8 +248,10 @@ class DetectorData(AcceleratorObject):
             self._capacity = need
         elif need == self._data.size:
             # same footprint (e.g. one-detector buffers recycled by SINGLE pipelines): keep the
-            # host allocation and the device copy, zero both
-            self._raw[:] = 0
+            # host allocation and the device copy, zero both (the host side only when it is the
+            # current one: a stale host buffer is overwritten by the next update_host anyway)
+            if not self._accel_used:
+                self._raw[:] = 0
             if self.accel_exists():
                 self.accel_reset()
         else:

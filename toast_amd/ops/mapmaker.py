@@ -198,8 +198,10 @@ class MapMaker(Operator):
             lhs = SolverLHS(name=f"{self.name}_lhs", binning=binning, template_matrix=tm, fused=self.fused_lhs)
             if amp_name in data:
                 del data[amp_name]
+            self.iteration_seconds = []
             self.history = solve(data, detectors, lhs, f"{self.name}_rhs", amp_name, convergence=self.convergence,
-                                 n_iter_min=self.iter_min, n_iter_max=self.iter_max)
+                                 n_iter_min=self.iter_min, n_iter_max=self.iter_max,
+                                 iteration_seconds=self.iteration_seconds)
             _t = _lap("pcg_iterations", _t)
             for ob in data.obs:
                 if lhs.det_temp in ob.detdata:

@@ -454,7 +454,7 @@ class SolverLHS(Operator):
 
 
 def solve(data, detectors, lhs_op, rhs_key, result_key, convergence=1.0e-12, n_iter_min=3, n_iter_max=100,
-          log=None):
+          log=None, iteration_seconds=None):
     """Preconditioned conjugate gradient for the template amplitudes
     (mapmaker_solve.py:524-755; same recurrence, same convergence / stall tests).
 
@@ -516,7 +516,13 @@ def solve(data, detectors, lhs_op, rhs_key, result_key, convergence=1.0e-12, n_i
     last_best = sqsum
     delta = proposal.dot(residual)
     history = []
+    import time as _time
+
     for it in range(n_iter_max):
+        if iteration_seconds is not None:
+            # every iteration ends in a dot product (a device synchronisation): wall time per
+            # iteration is the time between those points
+            iteration_seconds.append(_time.perf_counter())
         if not np.isfinite(sqsum):
             raise RuntimeError("Residual is not finite")
         lhs_op.apply(data, detectors=detectors)
@@ -543,6 +549,10 @@ def solve(data, detectors, lhs_op, rhs_key, result_key, convergence=1.0e-12, n_i
         beta = delta / delta_last
         # proposal = beta * proposal + precond
         proposal.axpby(1.0, precond, beta)
+    if iteration_seconds is not None and len(iteration_seconds) > 0:
+        iteration_seconds.append(_time.perf_counter())
+        stamps = list(iteration_seconds)
+        iteration_seconds[:] = [b - a for a, b in zip(stamps[:-1], stamps[1:])]
     lhs_op.keep_on_device = False
     # hand the solution back on the host (AmplitudesMap.accel_update_host skips host-current ones)
     result.accel_update_host()
