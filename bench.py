@@ -39,6 +39,11 @@ WORKLOADS = {
     "cfg3": (1024, 720000, 200.0, 1024),
     "cfg2": (64, 360000, 100.0, 512),
     "mini": (16, 50000, 100.0, 256),
+    # configs[3]: 4096 detectors x 4 h @200 Hz over 8 GPUs = 512 detectors x 2 880 000 samples each
+    "cfg4": (512, 2880000, 200.0, 1024),
+    # configs[4] structure (ground CES: ~100 sweep intervals, flagged turnarounds, Nside 2048;
+    # 2048 detectors over 8 GPUs = 256 each); the atmosphere / ground-template inputs are upstream
+    "cfg5g": (256, 720000, 200.0, 2048),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 BYTES_BNW = 41.0       # pixel 8 + weights 24 + tod 8 + det flag 1   
@@ -90,10 +95,13 @@ def main():
     fp_all, gamma_all = synth.hex_focalplane(n_det * world, fov_deg=10.0)
     fp = np.ascontiguousarray(fp_all[rank * n_det : (rank + 1) * n_det])
     gamma = np.ascontiguousarray(gamma_all[rank * n_det : (rank + 1) * n_det])
-    bore = synth.satellite_boresight(n_samp, rate, 600.0, 30.0, 3000.0, 65.0)
-    ivl = synth.make_intervals(n_samp, 1, rate)
+    if args.workload == "cfg5g":
+        bore, ivl, sflags_h = synth.ground_scan(n_samp, rate)
+    else:
+        bore = synth.satellite_boresight(n_samp, rate, 600.0, 30.0, 3000.0, 65.0)
+        ivl = synth.make_intervals(n_samp, 1, rate)
+        sflags_h = synth.shared_flags_block(n_samp, 0.01, value=1)
     idx = np.arange(n_det, dtype=np.int32)
-    sflags_h = synth.shared_flags_block(n_samp, 0.01, value=1)
 
     # Persistent buffers first, the big temporary (quaternions, 23.6 GB) last: HBM placement
     # matters (buffers carved out of just-freed memory ran scan_map up to 15 % slower in
@@ -150,7 +158,8 @@ def main():
         e1.synchronize()
         return e0.elapsed_time(e1) / reps
 
-    nsamp_tot = float(n_det) * n_samp
+    n_in_view = int(np.sum(ivl["last"] - ivl["first"]))   # samples inside the intervals
+    nsamp_tot = float(n_det) * n_in_view
     t_pd = timed(lambda: D.pointing_detector(fp, d_bore.data_ptr(), idx, d_quats.data_ptr(), n_samp, ivl,
                                              d_sflags.data_ptr(), n_samp, 1, stream))
     pix_call = lambda: D.pixels_healpix(idx, d_quats.data_ptr(), d_sflags.data_ptr(), n_samp, 1, idx,
@@ -314,8 +323,8 @@ def main():
     # sequence (8 + 41 + 8 + 48 + 9 B per det-sample, five passes) and fused (33 + 33 B, two passes).
     if args.pcg_extra:
         step_len = int(rate)  # 1 s baselines
-        n_amp_det = (n_samp + step_len - 1) // step_len
-        nav = np.array([n_amp_det], dtype=np.int64)
+        nav = np.array([(int(v["last"]) - int(v["first"]) + step_len - 1) // step_len for v in ivl], dtype=np.int64)
+        n_amp_det = int(nav.sum())
         amp_off = np.arange(n_det, dtype=np.int64) * n_amp_det
         n_amp = n_det * n_amp_det
         d_amp_in = torch.randn(n_amp, dtype=torch.float64, device=dev, generator=gen)

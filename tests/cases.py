@@ -27,6 +27,8 @@ def make_case(
     prec_angle_deg=7.0,
     nside_submap=16,
     random_pointing=False,
+    ground=False,
+    fp_roll=0,
 ):
     """Inputs of one observation.
 
@@ -38,13 +40,24 @@ def make_case(
     """
     rng = np.random.default_rng(seed)
     fp, gamma = synth.hex_focalplane(n_det, fov_deg=10.0)
-    if random_pointing:
+    if fp_roll:
+        # break the (A, B) same-pixel adjacency of the focalplane: detector pairs (2b, 2b+1) of a
+        # call then look at different sky pixels (fallback path of the pair-merging kernels)
+        fp, gamma = np.roll(fp, fp_roll, axis=0), np.roll(gamma, fp_roll)
+    ground_ivl = ground_flags = None
+    if ground:
+        # constant-elevation ground scan: many sweep intervals, turnarounds flagged and outside
+        # every interval (the structure of BASELINE configs[4] inputs)
+        bore, ground_ivl, ground_flags = synth.ground_scan(n_samp, rate, scan_rate_deg_s=7.0, turnaround_s=1.0)
+    elif random_pointing:
         bore = synth.quat_normalize(rng.standard_normal((n_samp, 4)))
     else:
         bore = synth.satellite_boresight(
             n_samp, rate, spin_period_s, spin_angle_deg, prec_period_s, prec_angle_deg
         )
     ivl = synth.make_intervals(n_samp, n_split=n_split, rate=rate, gap=gap)
+    if ground_ivl is not None:
+        ivl = ground_ivl
     rows = n_det + extra_rows
     perm = rng.permutation(rows)[:n_det].astype(np.int32) if extra_rows else np.arange(n_det, dtype=np.int32)
     case = dict(
@@ -71,6 +84,8 @@ def make_case(
         tod=np.ascontiguousarray(rng.standard_normal((rows, n_samp))),
         det_scale=np.ascontiguousarray(0.5 + rng.random(n_det)),
     )
+    if ground_flags is not None and with_shared_flags:
+        case["shared_flags"] = np.ascontiguousarray(ground_flags * np.uint8(3))
     n_pix = 12 * nside * nside
     case["n_submap"] = (n_pix + case["n_pix_submap"] - 1) // case["n_pix_submap"]
     if not with_det_flags and n_det != 1:

@@ -67,6 +67,7 @@ CASES = {
     "index_rows": dict(n_det=3, n_samp=3000, nside=32, extra_rows=2, with_hwp=True),
     "no_flags": dict(n_det=2, n_samp=2500, nside=1024, with_shared_flags=False, with_det_flags=False),
     "random": dict(n_det=3, n_samp=4000, nside=128, random_pointing=True),
+    "unpaired": dict(n_det=6, n_samp=4000, nside=128, fp_roll=1),
 }
 
 

@@ -31,6 +31,11 @@ CASES = {
     "ragged": dict(n_samp=1029, n_split=4, gap=1, n_det=3, nside=256),
     "tiny": dict(n_samp=3, n_det=2, nside=1, with_det_flags=False, with_shared_flags=False),
     "no_shared_flags": dict(with_shared_flags=False, n_samp=4097, nside=512),
+    # detector pairs of the call do not share a pixel / odd detector count (pair-merge fallbacks)
+    "unpaired_dets": dict(fp_roll=1, n_det=6, n_samp=6000, nside=128),
+    "odd_dets": dict(n_det=5, n_samp=3000, nside=64, fp_roll=1),
+    # ground CES: ~70 sweep intervals, flagged turnarounds, Nside 2048 (configs[4] structure)
+    "ground_nside2048": dict(ground=True, n_samp=72000, rate=100.0, nside=2048, n_det=6, with_hwp=True),
 }
 
 

@@ -102,6 +102,7 @@ LIVE = {
     "nside1024": dict(nside=1024, n_samp=5000, with_det_flags=False, n_det=1),
     "random4096": dict(random_pointing=True, nside=4096, n_samp=20000),
     "ragged": dict(n_samp=1029, n_split=4, gap=1, n_det=3, nside=256),
+    "ground2048": dict(ground=True, n_samp=72000, rate=100.0, nside=2048, n_det=6, with_hwp=True),
 }
 
 

@@ -117,6 +117,38 @@ __device__ __forceinline__ bool wave_run_reduce(int64_t key, double (&v)[NV]) {
     return (lane == 63) || ((heads >> (lane + 1)) & 1ull);
 }
 
+// Scatter the per-lane contributions of E detectors (E = 1, 2) into the map: one run reduction
+// and one set of atomics when the wave's two keys agree lane by lane (or one is invalid), two
+// passes otherwise.
+template <int NNZ, int E>
+__device__ __forceinline__ void scatter_runs(int64_t (&key)[E], double (&v)[E][NNZ], double * __restrict__ zmap) {
+    if constexpr (E == 2) {
+        const bool mergeable = (key[0] == key[1]) | (key[0] < 0) | (key[1] < 0);
+        if (__all(mergeable)) {
+            const int64_t km = (key[0] >= 0) ? key[0] : key[1];
+            double vm[NNZ];
+#pragma unroll
+            for (int k = 0; k < NNZ; ++k) vm[k] = v[0][k] + v[1][k];
+            const bool tail = wave_run_reduce<NNZ>(km, vm);
+            if (tail && km >= 0) {
+                double * z = zmap + NNZ * km;
+#pragma unroll
+                for (int k = 0; k < NNZ; ++k) unsafeAtomicAdd(z + k, vm[k]);
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const bool tail = wave_run_reduce<NNZ>(key[e], v[e]);
+        if (tail && key[e] >= 0) {
+            double * z = zmap + NNZ * key[e];
+#pragma unroll
+            for (int k = 0; k < NNZ; ++k) unsafeAtomicAdd(z + k, v[e][k]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // host helpers
 // ------------------------------------------------------------------------------------

@@ -280,6 +280,79 @@ __global__ __launch_bounds__(kThreads) void k_build_noise_weighted(
     }
 }
 
+// Detector-pair variant.  The fp64 atomic unit, not HBM, bounds the scatter once runs get short
+// (measured ~25 G atomics/s device-wide, independent of which XCD issues them:
+// profiles/r01_b_tuning_experiments.txt §6), and focalplanes carry two orthogonally polarised
+// detectors per pixel that see the same sky pixel at the same instant.  One workgroup therefore
+// processes detectors (2b, 2b+1) of the call together: when every lane of the wave finds the
+// two keys equal (or one of them invalid) the contributions are added *before* the run
+// reduction -- half the scans and half the atomics; any other wave falls back to two passes.
+template <int NNZ>
+__global__ __launch_bounds__(kThreads) void k_build_noise_weighted_pair(
+    const Chunk * __restrict__ chunks, int n_chunks, int n_det, const int32_t * __restrict__ p_idx,
+    const int32_t * __restrict__ w_idx, const int32_t * __restrict__ d_idx,
+    const int32_t * __restrict__ f_idx, const double * __restrict__ det_scale,
+    const int64_t * __restrict__ g2l, double * __restrict__ zmap,
+    const int64_t * __restrict__ pixels, const double * __restrict__ weights,
+    const double * __restrict__ tod, const uint8_t * __restrict__ dflags, uint8_t dmask,
+    int use_dflags, const uint8_t * __restrict__ sflags, uint8_t smask, int use_sflags,
+    FastDiv nps_div, int64_t n_samp) {
+    const int det0 = 2 * blockIdx.x;
+    const bool two = det0 + 1 < n_det;
+    const int det1 = two ? det0 + 1 : det0;
+    const int64_t * prow[2] = {pixels + (int64_t)p_idx[det0] * n_samp, pixels + (int64_t)p_idx[det1] * n_samp};
+    const double * wrow[2] = {weights + (int64_t)w_idx[det0] * n_samp * NNZ,
+                              weights + (int64_t)w_idx[det1] * n_samp * NNZ};
+    const double * drow[2] = {tod + (int64_t)d_idx[det0] * n_samp, tod + (int64_t)d_idx[det1] * n_samp};
+    const uint8_t * frow[2] = {use_dflags ? dflags + (int64_t)f_idx[det0] * n_samp : nullptr,
+                               use_dflags ? dflags + (int64_t)f_idx[det1] * n_samp : nullptr};
+    const double ds[2] = {det_scale[det0], det_scale[det1]};
+    const int64_t nps = nps_div.d;
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        for (int base = 0; base < c.count; base += kThreads) {
+            const int i = base + threadIdx.x;
+            const bool active = i < c.count;
+            const int64_t s = c.first + (active ? i : 0);
+            int64_t key[2] = {-1, -1};
+            double v[2][NNZ];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+#pragma unroll
+                for (int k = 0; k < NNZ; ++k) v[e][k] = 0.0;
+            }
+            if (active) {
+                // all streaming loads of both detectors first
+                int64_t p[2];
+                uint8_t fd[2];
+                double t[2], wk[2][NNZ];
+                const uint8_t fs = use_sflags ? sflags[s] : (uint8_t)0;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    p[e] = prow[e][s];
+                    fd[e] = use_dflags ? frow[e][s] : (uint8_t)0;
+                    t[e] = drow[e][s];
+                    const double * w = wrow[e] + NNZ * s;
+#pragma unroll
+                    for (int k = 0; k < NNZ; ++k) wk[e][k] = w[k];
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const bool good = (p[e] >= 0) & ((fd[e] & dmask) == 0) & ((fs & smask) == 0) & (e == 0 || two);
+                    if (good) {
+                        const int64_t gsm = fastdiv(p[e], nps_div);
+                        key[e] = g2l[gsm] * nps + (p[e] - gsm * nps);
+                        const double sd = t[e] * ds[e];
+#pragma unroll
+                        for (int k = 0; k < NNZ; ++k) v[e][k] = sd * wk[e][k];
+                    }
+                }
+            }
+            scatter_runs<NNZ, 2>(key, v, zmap);
+        }
+    }
+}
+
 // generic nnz (rare: nnz not in {1,2,3}): plain per-sample atomics
 __global__ __launch_bounds__(kThreads) void k_build_noise_weighted_any(
     const Chunk * __restrict__ chunks, int n_chunks, const int32_t * __restrict__ p_idx,
@@ -673,9 +746,11 @@ __global__ __launch_bounds__(kThreads) void k_offset_project_signal(
 // 24 + flag 1) instead of 8 + 41 and 8 + 48 + 9 in the reference's operator sequence.  Per
 // sample the arithmetic is the same as in the unfused kernels.
 // ------------------------------------------------------------------------------------
-template <int NNZ>
+// E = detectors per workgroup: 2 merges the contributions of the detector pair (2b, 2b+1) before
+// the run reduction whenever the whole wave sees equal keys (see k_build_noise_weighted_pair).
+template <int NNZ, int E>
 __global__ __launch_bounds__(kThreads) void k_offset_accumulate(
-    const Chunk * __restrict__ chunks, int n_chunks, const int64_t * __restrict__ view_first,
+    const Chunk * __restrict__ chunks, int n_chunks, int n_det, const int64_t * __restrict__ view_first,
     const int64_t * __restrict__ view_aoff, FastDiv step_div, const int64_t * __restrict__ amp_offsets,
     const double * __restrict__ amps, const uint8_t * __restrict__ amp_flags,
     const int32_t * __restrict__ p_idx, const int32_t * __restrict__ w_idx,
@@ -684,53 +759,72 @@ __global__ __launch_bounds__(kThreads) void k_offset_accumulate(
     const double * __restrict__ weights, const uint8_t * __restrict__ dflags, uint8_t dmask,
     int use_dflags, const uint8_t * __restrict__ sflags, uint8_t smask, int use_sflags,
     FastDiv nps_div, int64_t n_samp) {
-    const int det = blockIdx.x;
-    const int64_t * prow = pixels + (int64_t)p_idx[det] * n_samp;
-    const double * wrow = weights + (int64_t)w_idx[det] * n_samp * NNZ;
-    const uint8_t * frow = use_dflags ? dflags + (int64_t)f_idx[det] * n_samp : nullptr;
-    const double ds = det_scale[det];
+    const int64_t * prow[E];
+    const double * wrow[E];
+    const uint8_t * frow[E];
+    double ds[E];
+    int64_t amp_offset[E];
+    bool valid[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        int det = E * blockIdx.x + e;
+        valid[e] = det < n_det;
+        if (!valid[e]) det = E * blockIdx.x;
+        prow[e] = pixels + (int64_t)p_idx[det] * n_samp;
+        wrow[e] = weights + (int64_t)w_idx[det] * n_samp * NNZ;
+        frow[e] = use_dflags ? dflags + (int64_t)f_idx[det] * n_samp : nullptr;
+        ds[e] = det_scale[det];
+        amp_offset[e] = amp_offsets[det];
+    }
     const int64_t nps = nps_div.d;
-    const int64_t amp_offset = amp_offsets[det];
     for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
         const Chunk c = chunks[ci];
         const int64_t vfirst = view_first[c.view];
-        const int64_t abase = amp_offset + view_aoff[c.view];
+        const int64_t vaoff = view_aoff[c.view];
         for (int base = 0; base < c.count; base += kThreads) {
             const int i = base + threadIdx.x;
             const bool active = i < c.count;
             const int64_t s = c.first + (active ? i : 0);
-            int64_t key = -1;
-            double v[NNZ];
+            int64_t key[E];
+            double v[E][NNZ];
 #pragma unroll
-            for (int k = 0; k < NNZ; ++k) v[k] = 0.0;
+            for (int e = 0; e < E; ++e) {
+                key[e] = -1;
+#pragma unroll
+                for (int k = 0; k < NNZ; ++k) v[e][k] = 0.0;
+            }
             if (active) {
-                const int64_t p = prow[s];
-                const uint8_t fd = use_dflags ? frow[s] : (uint8_t)0;
                 const uint8_t fs = use_sflags ? sflags[s] : (uint8_t)0;
-                const int64_t a = abase + fastdiv(s - vfirst, step_div);
-                const uint8_t af = amp_flags[a];
-                const double av = amps[a];
-                const double * w = wrow + NNZ * s;
-                double wk[NNZ];
+                const int64_t astep = fastdiv(s - vfirst, step_div);
+                int64_t p[E];
+                uint8_t fd[E], af[E];
+                double av[E], wk[E][NNZ];
 #pragma unroll
-                for (int k = 0; k < NNZ; ++k) wk[k] = w[k];
-                const bool good = (p >= 0) & ((fd & dmask) == 0) & ((fs & smask) == 0);
-                if (good) {
-                    const int64_t gsm = fastdiv(p, nps_div);
-                    key = g2l[gsm] * nps + (p - gsm * nps);
-                    // tod = 0 + amplitude (unflagged amplitudes only), then * det_scale
-                    const double t = (af == 0) ? (0.0 + av) : 0.0;
-                    const double sd = t * ds;
+                for (int e = 0; e < E; ++e) {
+                    p[e] = prow[e][s];
+                    fd[e] = use_dflags ? frow[e][s] : (uint8_t)0;
+                    const int64_t a = amp_offset[e] + vaoff + astep;
+                    af[e] = amp_flags[a];
+                    av[e] = amps[a];
+                    const double * w = wrow[e] + NNZ * s;
 #pragma unroll
-                    for (int k = 0; k < NNZ; ++k) v[k] = sd * wk[k];
+                    for (int k = 0; k < NNZ; ++k) wk[e][k] = w[k];
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const bool good = (p[e] >= 0) & ((fd[e] & dmask) == 0) & ((fs & smask) == 0) & valid[e];
+                    if (good) {
+                        const int64_t gsm = fastdiv(p[e], nps_div);
+                        key[e] = g2l[gsm] * nps + (p[e] - gsm * nps);
+                        // tod = 0 + amplitude (unflagged amplitudes only), then * det_scale
+                        const double t = (af[e] == 0) ? (0.0 + av[e]) : 0.0;
+                        const double sd = t * ds[e];
+#pragma unroll
+                        for (int k = 0; k < NNZ; ++k) v[e][k] = sd * wk[e][k];
+                    }
                 }
             }
-            const bool tail = wave_run_reduce<NNZ>(key, v);
-            if (tail && key >= 0) {
-                double * z = zmap + NNZ * key;
-#pragma unroll
-                for (int k = 0; k < NNZ; ++k) unsafeAtomicAdd(z + k, v[k]);
-            }
+            scatter_runs<NNZ, E>(key, v, zmap);
         }
     }
 }
@@ -1063,7 +1157,20 @@ int toast_hip_build_noise_weighted_dev(
         det_flag_mask, use_d, d_shared_flags, shared_flag_mask, use_s, dv, n_samp
         const int dm = det_major_grid() ? 1 : 0;
         const dim3 g2 = dm ? dim3(grid.y, grid.x, 1) : grid;
-        if (nnz == 3) {
+        if (pair_detectors() && !dm && (nnz == 3 || nnz == 1) && n_det >= 2) {
+            const dim3 gp((unsigned)((n_det + 1) / 2), grid.y, 1);
+#define TH_BNW_PAIR_ARGS                                                                          \
+    (const Chunk *)(d + o_ch), (int)chunks.size(), (int)n_det, (const int32_t *)(d + o_pi),       \
+        (const int32_t *)(d + o_wi), (const int32_t *)(d + o_di), (const int32_t *)(d + o_fi),    \
+        (const double *)(d + o_ds), d_g2l, d_zmap, d_pixels, d_weights, d_det_data, d_det_flags,  \
+        det_flag_mask, use_d, d_shared_flags, shared_flag_mask, use_s, dv, n_samp
+            if (nnz == 3) {
+                hipLaunchKernelGGL(k_build_noise_weighted_pair<3>, gp, dim3(kThreads), 0, st, TH_BNW_PAIR_ARGS);
+            } else {
+                hipLaunchKernelGGL(k_build_noise_weighted_pair<1>, gp, dim3(kThreads), 0, st, TH_BNW_PAIR_ARGS);
+            }
+#undef TH_BNW_PAIR_ARGS
+        } else if (nnz == 3) {
             hipLaunchKernelGGL(k_build_noise_weighted<3>, g2, dim3(kThreads), 0, st, TH_BNW_ARGS, dm);
         } else if (nnz == 1) {
             hipLaunchKernelGGL(k_build_noise_weighted<1>, g2, dim3(kThreads), 0, st, TH_BNW_ARGS, dm);
@@ -1226,16 +1333,23 @@ int toast_hip_offset_accumulate_dev(
         const dim3 grid = chunk_grid(n_det, chunks.size());
         hipStream_t st = as_stream(stream);
 #define TH_OA_ARGS                                                                                  \
-    (const Chunk *)(d + o_ch), (int)chunks.size(), (const int64_t *)(d + o_vf),                     \
+    (const Chunk *)(d + o_ch), (int)chunks.size(), (int)n_det, (const int64_t *)(d + o_vf),         \
         (const int64_t *)(d + o_va), make_fastdiv(step_length), (const int64_t *)(d + o_ao),        \
         d_amplitudes, d_amplitude_flags, (const int32_t *)(d + o_pi), (const int32_t *)(d + o_wi),  \
         (const int32_t *)(d + o_fi), (const double *)(d + o_ds), d_g2l, d_zmap, d_pixels, d_weights, \
         d_det_flags, det_flag_mask, use_d, d_shared_flags, shared_flag_mask, use_s,                 \
         make_fastdiv(n_pix_submap), n_samp
-        if (nnz == 3) {
-            hipLaunchKernelGGL(k_offset_accumulate<3>, grid, dim3(kThreads), 0, st, TH_OA_ARGS);
+        if (pair_detectors() && n_det >= 2) {
+            const dim3 gp((unsigned)((n_det + 1) / 2), grid.y, 1);
+            if (nnz == 3) {
+                hipLaunchKernelGGL((k_offset_accumulate<3, 2>), gp, dim3(kThreads), 0, st, TH_OA_ARGS);
+            } else {
+                hipLaunchKernelGGL((k_offset_accumulate<1, 2>), gp, dim3(kThreads), 0, st, TH_OA_ARGS);
+            }
+        } else if (nnz == 3) {
+            hipLaunchKernelGGL((k_offset_accumulate<3, 1>), grid, dim3(kThreads), 0, st, TH_OA_ARGS);
         } else {
-            hipLaunchKernelGGL(k_offset_accumulate<1>, grid, dim3(kThreads), 0, st, TH_OA_ARGS);
+            hipLaunchKernelGGL((k_offset_accumulate<1, 1>), grid, dim3(kThreads), 0, st, TH_OA_ARGS);
         }
 #undef TH_OA_ARGS
         check_launch();

@@ -138,9 +138,9 @@ struct OffsetDev {
 // A^T:  zmap += P^T N^-1 d      SIG 0: d = timestream buffer (build_noise_weighted)
 //                               SIG 1: d = M a, offset amplitudes (k_offset_accumulate)
 // ------------------------------------------------------------------------------------
-template <bool NEST, int MODE, int SIG, int PIX>
+template <bool NEST, int MODE, int SIG, int PIX, int E>
 __global__ __launch_bounds__(kThreads) void k_otf_accumulate(
-    const Chunk * __restrict__ chunks, int n_chunks, OtfDev P, OffsetDev O,
+    const Chunk * __restrict__ chunks, int n_chunks, int n_det, OtfDev P, OffsetDev O,
     const int32_t * __restrict__ d_idx, const double * __restrict__ tod,
     const int32_t * __restrict__ f_idx, const uint8_t * __restrict__ dflags, uint8_t dmask,
     int use_dflags, const uint8_t * __restrict__ sflags, uint8_t smask, int use_sflags,
@@ -150,56 +150,76 @@ __global__ __launch_bounds__(kThreads) void k_otf_accumulate(
     if (threadIdx.x < 2 * TOAST_ATAN_TABLE_N) s_tab[threadIdx.x] = kAtanTab[threadIdx.x];
     __syncthreads();
 
-    const int det = blockIdx.x;
-    DetConst D = det_const(P, det);
-    if (PIX == 1) D.crow = P.cpix + (int64_t)P.cpix_idx[det] * n_samp;
-    const double * drow = (SIG == 0) ? tod + (int64_t)d_idx[det] * n_samp : nullptr;
-    const uint8_t * frow = use_dflags ? dflags + (int64_t)f_idx[det] * n_samp : nullptr;
-    const double ds = det_scale[det];
-    const int64_t amp_offset = (SIG == 1) ? O.amp_offsets[det] : 0;
+    // E detectors per workgroup (pair merging, see k_build_noise_weighted_pair)
+    DetConst D[E];
+    const double * drow[E];
+    const uint8_t * frow[E];
+    double ds[E];
+    int64_t amp_offset[E];
+    bool valid[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        int det = E * blockIdx.x + e;
+        valid[e] = det < n_det;
+        if (!valid[e]) det = E * blockIdx.x;
+        D[e] = det_const(P, det);
+        if (PIX == 1) D[e].crow = P.cpix + (int64_t)P.cpix_idx[det] * n_samp;
+        drow[e] = (SIG == 0) ? tod + (int64_t)d_idx[det] * n_samp : nullptr;
+        frow[e] = use_dflags ? dflags + (int64_t)f_idx[det] * n_samp : nullptr;
+        ds[e] = det_scale[det];
+        amp_offset[e] = (SIG == 1) ? O.amp_offsets[det] : 0;
+    }
     for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
         const Chunk c = chunks[ci];
-        int64_t vfirst = 0, abase = 0;
+        int64_t vfirst = 0, vaoff = 0;
         if (SIG == 1) {
             vfirst = O.view_first[c.view];
-            abase = amp_offset + O.view_aoff[c.view];
+            vaoff = O.view_aoff[c.view];
         }
         for (int base = 0; base < c.count; base += kThreads) {
             const int i = base + threadIdx.x;
             const bool active = i < c.count;
             const int64_t s = c.first + (active ? i : 0);
-            int64_t key = -1;
-            double v[NNZ];
+            int64_t key[E];
+            double v[E][NNZ];
 #pragma unroll
-            for (int k = 0; k < NNZ; ++k) v[k] = 0.0;
+            for (int e = 0; e < E; ++e) {
+                key[e] = -1;
+#pragma unroll
+                for (int k = 0; k < NNZ; ++k) v[e][k] = 0.0;
+            }
             if (active) {
-                const uint8_t fd = use_dflags ? frow[s] : (uint8_t)0;
                 const uint8_t fs = use_sflags ? sflags[s] : (uint8_t)0;
-                double t;
-                if (SIG == 0) {
-                    t = drow[s];
-                } else {
-                    const int64_t a = abase + fastdiv(s - vfirst, O.step_div);
-                    const uint8_t af = O.amp_flags[a];
-                    const double av = O.amps_in[a];
-                    t = (af == 0) ? (0.0 + av) : 0.0;
-                }
-                double wk[NNZ];
-                const int64_t p = otf_point<NEST, MODE, PIX>(P, D, s, s_tab, wk);
-                const bool good = (p >= 0) & ((fd & dmask) == 0) & ((fs & smask) == 0);
-                if (good) {
-                    key = p;
-                    const double sd = t * ds;
+                int64_t astep = 0;
+                if (SIG == 1) astep = fastdiv(s - vfirst, O.step_div);
+                uint8_t fd[E];
+                double t[E];
 #pragma unroll
-                    for (int k = 0; k < NNZ; ++k) v[k] = sd * wk[k];
+                for (int e = 0; e < E; ++e) {
+                    fd[e] = use_dflags ? frow[e][s] : (uint8_t)0;
+                    if (SIG == 0) {
+                        t[e] = drow[e][s];
+                    } else {
+                        const int64_t a = amp_offset[e] + vaoff + astep;
+                        const uint8_t af = O.amp_flags[a];
+                        const double av = O.amps_in[a];
+                        t[e] = (af == 0) ? (0.0 + av) : 0.0;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    double wk[NNZ];
+                    const int64_t p = otf_point<NEST, MODE, PIX>(P, D[e], s, s_tab, wk);
+                    const bool good = (p >= 0) & ((fd[e] & dmask) == 0) & ((fs & smask) == 0) & valid[e];
+                    if (good) {
+                        key[e] = p;
+                        const double sd = t[e] * ds[e];
+#pragma unroll
+                        for (int k = 0; k < NNZ; ++k) v[e][k] = sd * wk[k];
+                    }
                 }
             }
-            const bool tail = wave_run_reduce<NNZ>(key, v);
-            if (tail && key >= 0) {
-                double * z = zmap + NNZ * key;
-#pragma unroll
-                for (int k = 0; k < NNZ; ++k) unsafeAtomicAdd(z + k, v[k]);
-            }
+            scatter_runs<NNZ, E>(key, v, zmap);
         }
     }
 }
@@ -349,10 +369,10 @@ void otf_bind(OtfHost & h, const char * base) {
     if (h.compact) h.dev.cpix_idx = (const int32_t *)(base + h.o_ci);
 }
 
-template <int SIG, int PIX, typename... Args>
+template <int SIG, int PIX, int E, typename... Args>
 void launch_accumulate_pix(const OtfHost & h, dim3 grid, hipStream_t st, Args... args) {
 #define TH_OTF_CASE(N, M)                                                                        \
-    hipLaunchKernelGGL((k_otf_accumulate<N, M, SIG, PIX>), grid, dim3(kThreads), 0, st, args...)
+    hipLaunchKernelGGL((k_otf_accumulate<N, M, SIG, PIX, E>), grid, dim3(kThreads), 0, st, args...)
     // with cached pixels the ordering scheme plays no role: one instantiation serves both
     const bool nest = (PIX == 1) ? true : h.nest;
     if (nest) {
@@ -367,12 +387,17 @@ void launch_accumulate_pix(const OtfHost & h, dim3 grid, hipStream_t st, Args...
 #undef TH_OTF_CASE
 }
 
+// grid.x = detectors of the call; halved here when detector pairs share a workgroup
 template <int SIG, typename... Args>
 void launch_accumulate(const OtfHost & h, dim3 grid, hipStream_t st, Args... args) {
+    const bool pair = pair_detectors() && grid.x >= 2;
+    if (pair) grid.x = (grid.x + 1) / 2;
     if (h.compact) {
-        launch_accumulate_pix<SIG, 1>(h, grid, st, args...);
+        if (pair) launch_accumulate_pix<SIG, 1, 2>(h, grid, st, args...);
+        else launch_accumulate_pix<SIG, 1, 1>(h, grid, st, args...);
     } else {
-        launch_accumulate_pix<SIG, 0>(h, grid, st, args...);
+        if (pair) launch_accumulate_pix<SIG, 0, 2>(h, grid, st, args...);
+        else launch_accumulate_pix<SIG, 0, 1>(h, grid, st, args...);
     }
 }
 
@@ -455,7 +480,7 @@ int toast_hip_otf_build_noise_weighted_dev(
         otf_bind(h, d);
         OffsetDev off{};
         launch_accumulate<0>(h, chunk_grid(n_det, chunks.size()), st, (const Chunk *)(d + o_ch),
-                             (int)chunks.size(), h.dev, off, (const int32_t *)(d + o_di), d_det_data,
+                             (int)chunks.size(), (int)n_det, h.dev, off, (const int32_t *)(d + o_di), d_det_data,
                              (const int32_t *)(d + o_fi), d_det_flags, det_flag_mask, use_d, d_shared_flags,
                              shared_flag_mask, use_s, (const double *)(d + o_ds), d_zmap, n_samp);
         check_launch();
@@ -520,7 +545,7 @@ int toast_hip_otf_offset_accumulate_dev(
         OffsetDev off{(const int64_t *)(d + o_vf), (const int64_t *)(d + o_va), (const int64_t *)(d + o_ao),
                       d_amplitudes, nullptr, d_amplitude_flags, make_fastdiv(step_length)};
         launch_accumulate<1>(h, chunk_grid(n_det, chunks.size()), st, (const Chunk *)(d + o_ch),
-                             (int)chunks.size(), h.dev, off, (const int32_t *)nullptr, (const double *)nullptr,
+                             (int)chunks.size(), (int)n_det, h.dev, off, (const int32_t *)nullptr, (const double *)nullptr,
                              (const int32_t *)(d + o_fi), d_det_flags, det_flag_mask, use_d, d_shared_flags,
                              shared_flag_mask, use_s, (const double *)(d + o_ds), d_zmap, n_samp);
         check_launch();

@@ -41,6 +41,15 @@ bool det_major_grid() {
     return v;
 }
 
+bool pair_detectors() {
+    // TOAST_HIP_PAIR=0 disables the detector-pair accumulate kernels.
+    static const bool v = [] {
+        const char * e = std::getenv("TOAST_HIP_PAIR");
+        return !(e && e[0] == '0');
+    }();
+    return v;
+}
+
 std::vector<Chunk> make_chunks(const toast_hip_interval * ivl, int64_t n_view, int64_t n_samp) {
     std::vector<Chunk> out;
     const int64_t kc = chunk_size();

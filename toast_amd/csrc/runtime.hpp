@@ -88,6 +88,7 @@ private:
 size_t pin_threshold();
 int chunk_size();
 bool det_major_grid();
+bool pair_detectors();
 std::vector<Chunk> make_chunks(const toast_hip_interval * ivl, int64_t n_view, int64_t n_samp);
 
 // ------------------------------------------------------------------ memory manager

@@ -98,6 +98,47 @@ def satellite_boresight(
     return np.ascontiguousarray(quat_normalize(q))
 
 
+def ground_scan(n_samp, rate, az_min_deg=40.0, az_max_deg=110.0, el_deg=50.0, scan_rate_deg_s=1.0,
+                turnaround_s=2.0, site_lat_deg=-22.96, lst0_deg=30.0):
+    """Constant-elevation scan (CES) of a ground telescope: boresight quaternions ``[n_samp, 4]``
+    in equatorial coordinates, the half-open sample intervals of the constant-velocity sweeps and
+    the uint8 shared flags (1 during turnarounds) -- the structure of BASELINE configs[4] inputs
+    (reference: src/toast/ops/sim_ground.py builds az/el from a schedule, flags turnarounds and
+    stores throw intervals; atmosphere and ground templates are outside the hot path).
+
+    The azimuth is a triangle wave at ``scan_rate_deg_s`` with ``turnaround_s`` of flagged samples
+    at every reversal; ``q = Rz(LST) Ry(pi/2 - lat) Rz(-az) Ry(pi/2 - el)``, LST advancing at
+    the sidereal rate.
+    """
+    t = np.arange(n_samp, dtype=np.float64) / rate
+    throw = float(az_max_deg - az_min_deg)
+    sweep_s = throw / scan_rate_deg_s
+    phase = t / sweep_s
+    k = np.floor(phase).astype(np.int64)
+    frac = phase - k
+    az = np.where(k % 2 == 0, az_min_deg + throw * frac, az_max_deg - throw * frac)
+    lst = np.radians(lst0_deg) + 2.0 * np.pi * t / 86164.0905
+    q_lst = quat_rotation(_Z, lst)
+    q_lat = quat_rotation(_Y, np.pi / 2 - np.radians(site_lat_deg))
+    q_az = quat_rotation(_Z, -np.radians(az))
+    q_el = quat_rotation(_Y, np.pi / 2 - np.radians(el_deg))
+    q = quat_mult(q_lst, quat_mult(q_lat, quat_mult(q_az, q_el)))
+    bore = np.ascontiguousarray(quat_normalize(q))
+    # sweeps: samples farther than turnaround/2 from a reversal
+    half = 0.5 * turnaround_s / sweep_s
+    turning = (frac < half) | (frac > 1.0 - half)
+    flags = turning.astype(np.uint8)
+    edges = np.diff(np.concatenate([[1], flags, [1]]).astype(np.int8))
+    first = np.flatnonzero(edges == -1)
+    last = np.flatnonzero(edges == 1)
+    ivl = np.zeros(first.size, dtype=interval_dtype)
+    ivl["first"] = first
+    ivl["last"] = last
+    ivl["start"] = first / rate
+    ivl["stop"] = (last - 1) / rate
+    return bore, ivl, flags
+
+
 def hex_focalplane(n_det, fov_deg=10.0):
     """Detector quaternions ``[n_det, 4]`` plus polarisation angles ``gamma[n_det]``.
 
