@@ -556,3 +556,26 @@ def test_binmap_on_the_fly_equals_cached():
     assert scale > 0
     assert np.max(np.abs(got["otf"] - got["full"])) < 1e-12 * scale
     assert np.max(np.abs(got["batch"] - got["full"])) < 1e-12 * scale
+
+
+@pytest.mark.parametrize("save_pointing", [True, False])
+def test_build_pixel_distribution(save_pointing, monkeypatch):
+    """BuildPixelDistribution (reference ops/pointing.py:18-130): the distribution equals the one
+    PixelsHealpix(create_dist=...) builds in a single pass; scratch passes leave no full pointing."""
+    monkeypatch.setenv("TOAST_HIP_POINTING_BATCH", "2")
+    data = create_satellite_data(n_det=6, n_samp=5000)
+    dp, pix, sw = pointing_ops(nside=128, create_dist=None)
+    ops.BuildPixelDistribution(pixel_dist="dist", pixel_pointing=pix, save_pointing=save_pointing).apply(data)
+    with pytest.raises(RuntimeError, match="already exists"):
+        ops.BuildPixelDistribution(pixel_dist="dist", pixel_pointing=pix).apply(data)
+    ob = data.obs[0]
+    n_dets = len(ob.select_local_detectors(flagmask=dp.det_mask))
+    if save_pointing:
+        assert ob.detdata[defaults.pixels].data.shape[0] == n_dets
+    else:
+        assert ob.detdata[defaults.pixels].data.shape[0] <= 2
+    data2 = create_satellite_data(n_det=6, n_samp=5000)
+    dp2, pix2, sw2 = pointing_ops(nside=128, create_dist="dist")
+    pix2.apply(data2)
+    assert list(data["dist"].local_submaps) == list(data2["dist"].local_submaps)
+    assert data["dist"].n_pix == data2["dist"].n_pix and data["dist"].n_pix_submap == data2["dist"].n_pix_submap

@@ -18,4 +18,4 @@ from .mapmaker_solve import SolverLHS, SolverRHS, TemplateMatrix, solve
 from .noise_filter import NoiseFilter
 from .operator import Operator
 from .pipeline import Pipeline
-from .pointing import PixelsHealpix, PointingDetectorSimple, StokesWeights
+from .pointing import BuildPixelDistribution, PixelsHealpix, PointingDetectorSimple, StokesWeights

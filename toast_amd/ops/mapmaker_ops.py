@@ -578,11 +578,10 @@ class CovarianceAndHits(Operator):
         if inv_key in data:
             del data[inv_key]
         if self.pixel_dist not in data:
-            self.pixel_pointing.create_dist = self.pixel_dist
-            pix_dist = Pipeline(detector_sets=["ALL"] if self.save_pointing else uncached_detector_sets(),
-                                operators=[self.pixel_pointing])
-            pix_dist.apply(data, detectors=detectors)
-            self.pixel_pointing.create_dist = None
+            from .pointing import BuildPixelDistribution
+
+            BuildPixelDistribution(pixel_dist=self.pixel_dist, pixel_pointing=self.pixel_pointing,
+                                   save_pointing=self.save_pointing).apply(data, detectors=detectors)
         common = dict(pixel_dist=self.pixel_dist, view=self.pixel_pointing.view, pixels=self.pixel_pointing.pixels,
                       det_mask=self.det_mask, det_flags=self.det_flags, det_flag_mask=self.det_flag_mask,
                       shared_flags=self.shared_flags, shared_flag_mask=self.shared_flag_mask,

@@ -408,3 +408,51 @@ class StokesWeights(Operator):
 
     def _supports_accel(self):
         return self.detector_pointing is not None and self.detector_pointing.supports_accel()
+
+
+class BuildPixelDistribution(Operator):
+    """Runs the pixel pointing once to build the ``PixelDistribution`` (which submaps are hit
+    locally / by whom) and stores it in ``data[pixel_dist]`` (reference:
+    src/toast/ops/pointing.py:18-130).  One pass over all detectors when ``save_pointing`` is
+    set, otherwise scratch passes (the reference forces this pass to the host, ``use_accel=False``,
+    "a small amount of calculation for a huge data volume"; on the MI355X the pixel kernel runs at
+    >100 G samples/s, so it stays on the device when one is in use)."""
+
+    API = Int(0, help="Internal interface version for this operator")
+    pixel_dist = Unicode("pixel_dist", help="The Data key where the PixelDist object should be stored")
+    pixel_pointing = Instance(klass=Operator, allow_none=True, help="This must be an instance of a pointing operator")
+    save_pointing = Bool(False, help="If True, do not clear detector pointing matrices after use")
+
+    def _validate_pixel_pointing(self, pntg):
+        if pntg is not None:
+            if not isinstance(pntg, Operator):
+                raise RuntimeError("pixel_pointing should be an Operator instance")
+            for trt in ("pixels", "create_dist", "view"):
+                if not pntg.has_trait(trt):
+                    raise RuntimeError(f"pixel_pointing operator should have a '{trt}' trait")
+        return pntg
+
+    def _exec(self, data, detectors=None, **kwargs):
+        from .pipeline import Pipeline, uncached_detector_sets
+
+        if self.pixel_pointing is None:
+            raise RuntimeError("You must set the 'pixel_pointing' trait before calling exec()")
+        if self.pixel_dist in data:
+            raise RuntimeError(f"pixel distribution `{self.pixel_dist}` already exists")
+        self.pixel_pointing.create_dist = self.pixel_dist
+        pipe = Pipeline(detector_sets=["ALL"] if self.save_pointing else uncached_detector_sets(),
+                        operators=[self.pixel_pointing])
+        pipe.apply(data, detectors=detectors)
+        self.pixel_pointing.create_dist = None
+
+    def _finalize(self, data, **kwargs):
+        return
+
+    def _requires(self):
+        return self.pixel_pointing.requires()
+
+    def _provides(self):
+        prov = {"global": [self.pixel_dist]}
+        if self.save_pointing:
+            prov["detdata"] = [self.pixel_pointing.pixels]
+        return prov
