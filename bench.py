@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--pcg-extra", action="store_true",
                     help="also time the full PCG LHS with offset templates (operator sequence vs fused kernels)")
     ap.add_argument("--no-arena", action="store_true", help="allocate every buffer separately (placement experiment)")
+    ap.add_argument("--hwp", action="store_true", help="rotating half-wave plate (88 rpm): Stokes weights with HWP angle")
     ap.add_argument("--unfused", action="store_true", help="run noise_weight as its own kernel (105 B variant)")
     return ap.parse_args()
 
@@ -167,7 +168,12 @@ def main():
                                         nside, True, stream)
     pix_call()
     t_pix = timed(pix_call, 3)
-    sw_call = lambda: D.stokes_weights_IQU(idx, d_quats.data_ptr(), idx, d_weights.data_ptr(), n_samp, 0, 0, ivl,
+    d_hwp = None
+    if args.hwp:
+        hwp_h = np.ascontiguousarray(2 * np.pi * ((np.arange(n_samp) * (88.0 / 60.0) / rate) % 1.0))
+        d_hwp = torch.from_numpy(hwp_h).to(dev)
+    hwp_ptr, hwp_n = (d_hwp.data_ptr(), n_samp) if args.hwp else (0, 0)
+    sw_call = lambda: D.stokes_weights_IQU(idx, d_quats.data_ptr(), idx, d_weights.data_ptr(), n_samp, hwp_ptr, hwp_n, ivl,
                                            np.zeros(n_det), gamma, np.ones(n_det), False, stream)
     sw_call()
     t_sw = timed(sw_call, 2)
@@ -384,7 +390,7 @@ def main():
         # without the 32 B/det-sample pointing cache -- 9 + 16 B (A^T, A) and ~2 + ~2 B (offset LHS)
         pt = capi.otf_pointing(d_bore.data_ptr(), fp, nside, True, nnz, d_shared_flags=d_sflags.data_ptr(),
                                n_shared_flags=n_samp, shared_flag_mask=1, epsilon=np.zeros(n_det), gamma=gamma,
-                               cal=np.ones(n_det))
+                               cal=np.ones(n_det), d_hwp=hwp_ptr, n_hwp=hwp_n)
 
         def ata_otf():
             d_zmap.zero_()
@@ -424,7 +430,8 @@ def main():
                          stream)
         ptc = capi.otf_pointing(d_bore.data_ptr(), fp, nside, True, nnz, d_shared_flags=d_sflags.data_ptr(),
                                 n_shared_flags=n_samp, shared_flag_mask=1, epsilon=np.zeros(n_det), gamma=gamma,
-                                cal=np.ones(n_det), d_compact_pixels=d_cpix.data_ptr(), compact_index=idx)
+                                cal=np.ones(n_det), d_compact_pixels=d_cpix.data_ptr(), compact_index=idx,
+                                d_hwp=hwp_ptr, n_hwp=hwp_n)
         pt_keep = pt
         pt = ptc
         lhs_otf()

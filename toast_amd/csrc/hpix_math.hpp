@@ -403,6 +403,15 @@ TOAST_HD void stokes_cs2alpha(const double * q, double & c2a, double & s2a) {
     }
 }
 
+// cos / sin of the HWP modulation angle  beta = 2 (2 (gamma - hwp)) = 4 gamma - 4 hwp
+// (ops_stokes_weights.cpp:96-99) by the angle-addition formulas, from cos / sin of 4 gamma
+// (per detector) and of 4 hwp (per time sample, shared by all detectors): no transcendental
+// per det-sample.  4 x is exact in binary floating point; agreement with sincos(beta) ~3e-16.
+TOAST_HD void hwp_rotation(double c4g, double s4g, double c4h, double s4h, double & cb, double & sb) {
+    cb = c4g * c4h + s4g * s4h;
+    sb = s4g * c4h - c4g * s4h;
+}
+
 // ------------------------------------------------------------------ division by a run-time constant
 // q = n / d for 0 <= n < 2^63 with one 64x64->high multiply.  mul = floor(2^(63+s)/d) + 1,
 // s = ceil(log2 d): the error term n*e/(d 2^(63+s)) < 1/d, so the floor is exact.

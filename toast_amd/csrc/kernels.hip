@@ -110,6 +110,8 @@ __global__ __launch_bounds__(kThreads) void k_stokes_iqu(
     const double eta = (1.0 - eps) / (1.0 + eps);
     const double cd = cal[det];
     const double gd = gamma[det];
+    double c4g = 1.0, s4g = 0.0;
+    if (HWP) sincos(4.0 * gd, &s4g, &c4g);
     const double * qrow = quats + (int64_t)q_idx[det] * n_samp * 4;
     double * wrow = weights + (int64_t)w_idx[det] * n_samp * 3;
     for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
@@ -122,10 +124,10 @@ __global__ __launch_bounds__(kThreads) void k_stokes_iqu(
             stokes_cs2alpha(qa, c2a, s2a);
             double * w = wrow + 3 * s;
             if (HWP) {
-                // ang = 2 (2 (gamma - hwp) - alpha) = beta - 2 alpha
-                const double beta = 2.0 * (2.0 * (gd - hwp[s]));
-                double sb, cb;
-                sincos(beta, &sb, &cb);
+                // ang = 2 (2 (gamma - hwp) - alpha) = beta - 2 alpha, beta = 4 gamma - 4 hwp
+                double s4h, c4h, sb, cb;
+                sincos(4.0 * hwp[s], &s4h, &c4h);
+                hwp_rotation(c4g, s4g, c4h, s4h, cb, sb);
                 const double cang = cb * c2a + sb * s2a;
                 const double sang = sb * c2a - cb * s2a;
                 w[0] = cd;

@@ -41,6 +41,7 @@ struct OtfDev {
 struct DetConst {
     double f[4];
     double eta, cd, gd;
+    double c4g, s4g;        // cos / sin of 4 gamma (HWP modulation, see hwp_rotation)
     const int32_t * crow;   // PIX 1: this detector's row of cached local pixel indices
 };
 
@@ -52,6 +53,7 @@ __device__ __forceinline__ DetConst det_const(const OtfDev & P, int det) {
     D.eta = (1.0 - eps) / (1.0 + eps);
     D.cd = P.cal[det];
     D.gd = P.gamma[det];
+    sincos(4.0 * D.gd, &D.s4g, &D.c4g);
     D.crow = nullptr;
     return D;
 }
@@ -67,9 +69,12 @@ struct ModeNnz {
 //   PIX 0: the pixel is computed here (pointing_detector -> pixels_healpix -> global2local);
 //   PIX 1: the local index is read from a compact int32 cache (4 B instead of the 8 B global
 //          pixel + global2local lookup) and only the weights are evaluated on the fly.
+// c4h / s4h: cos / sin of four times the HWP angle of this time sample (MODE 2), evaluated once
+// per sample by the caller and shared by the detectors of a workgroup.
 template <bool NEST, int MODE, int PIX>
 __device__ __forceinline__ int64_t otf_point(const OtfDev & P, const DetConst & D, int64_t s,
-                                             const double * s_tab, double (&w)[ModeNnz<MODE>::value]) {
+                                             const double * s_tab, double c4h, double s4h,
+                                             double (&w)[ModeNnz<MODE>::value]) {
     int64_t lidx = -1;
     if constexpr (PIX == 1) lidx = D.crow[s];
     if constexpr (PIX == 1 && MODE == 0) {
@@ -78,8 +83,6 @@ __device__ __forceinline__ int64_t otf_point(const OtfDev & P, const DetConst & 
     }
     const Quat b = load_quat(P.bore + 4 * s);
     const uint8_t fl = P.use_pflags ? P.pflags[s] : (uint8_t)0;
-    double hw = 0.0;
-    if constexpr (MODE == 2) hw = P.hwp[s];
     const bool flagged = (fl & P.pmask) != 0;
     // pointing_detector: a flagged boresight sample is replaced by the identity rotation
     double p[4] = {0.0, 0.0, 0.0, 1.0};
@@ -95,9 +98,8 @@ __device__ __forceinline__ int64_t otf_point(const OtfDev & P, const DetConst & 
         double c2a, s2a;
         stokes_cs2alpha(r, c2a, s2a);
         if constexpr (MODE == 2) {
-            const double beta = 2.0 * (2.0 * (D.gd - hw));
             double sb, cb;
-            sincos(beta, &sb, &cb);
+            hwp_rotation(D.c4g, D.s4g, c4h, s4h, cb, sb);
             const double cang = cb * c2a + sb * s2a;
             const double sang = sb * c2a - cb * s2a;
             w[0] = D.cd;
@@ -192,6 +194,8 @@ __global__ __launch_bounds__(kThreads) void k_otf_accumulate(
                 const uint8_t fs = use_sflags ? sflags[s] : (uint8_t)0;
                 int64_t astep = 0;
                 if (SIG == 1) astep = fastdiv(s - vfirst, O.step_div);
+                double c4h = 1.0, s4h = 0.0;
+                if constexpr (MODE == 2) sincos(4.0 * P.hwp[s], &s4h, &c4h);
                 uint8_t fd[E];
                 double t[E];
 #pragma unroll
@@ -209,7 +213,7 @@ __global__ __launch_bounds__(kThreads) void k_otf_accumulate(
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
                     double wk[NNZ];
-                    const int64_t p = otf_point<NEST, MODE, PIX>(P, D[e], s, s_tab, wk);
+                    const int64_t p = otf_point<NEST, MODE, PIX>(P, D[e], s, s_tab, c4h, s4h, wk);
                     const bool good = (p >= 0) & ((fd[e] & dmask) == 0) & ((fs & smask) == 0) & valid[e];
                     if (good) {
                         key[e] = p;
@@ -262,8 +266,10 @@ __global__ __launch_bounds__(kThreads) void k_otf_scan(
             if (SIG == 0) {
                 if (!active) continue;
                 double d = zero ? 0.0 : drow[s];
+                double c4h = 1.0, s4h = 0.0;
+                if constexpr (MODE == 2) sincos(4.0 * P.hwp[s], &s4h, &c4h);
                 double wk[NNZ];
-                const int64_t p = otf_point<NEST, MODE, PIX>(P, D, s, s_tab, wk);
+                const int64_t p = otf_point<NEST, MODE, PIX>(P, D, s, s_tab, c4h, s4h, wk);
                 if (p >= 0) {
                     const double * m = map + NNZ * p;
                     double v = 0.0;
@@ -289,8 +295,10 @@ __global__ __launch_bounds__(kThreads) void k_otf_scan(
                     if (af == 0) {
                         key = a;
                         if ((fl & fmask) == 0) {
+                            double c4h = 1.0, s4h = 0.0;
+                            if constexpr (MODE == 2) sincos(4.0 * P.hwp[s], &s4h, &c4h);
                             double wk[NNZ];
-                            const int64_t p = otf_point<NEST, MODE, PIX>(P, D, s, s_tab, wk);
+                            const int64_t p = otf_point<NEST, MODE, PIX>(P, D, s, s_tab, c4h, s4h, wk);
                             double d = 0.0 + av;
                             if (p >= 0) {
                                 const double * m = map + NNZ * p;
