@@ -470,6 +470,15 @@ int toast_hip_compact_pixels_dev(const int64_t * d_g2l, int64_t n_pix_submap, in
                                  int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
                                  void * stream);
 
+/* The same cache computed straight from the boresight (pointing_detector -> pixels_healpix ->
+ * global2local in registers): no int64 pixel buffer is needed at all.  `pointing`'s weight
+ * members and d_compact_pixels are ignored. */
+int toast_hip_otf_compact_pixels_dev(const toast_hip_otf_pointing * pointing, const int64_t * d_g2l,
+                                     int64_t n_pix_submap, int64_t n_local_submap,
+                                     const int32_t * compact_index, int32_t * d_compact_pixels, int64_t n_det,
+                                     int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
+                                     void * stream);
+
 /* zmap += P^T N^-1 d  with on-the-fly pointing (== pointing chain + build_noise_weighted). */
 int toast_hip_otf_build_noise_weighted_dev(
     const toast_hip_otf_pointing * pointing, const int64_t * d_g2l, double * d_zmap, int64_t n_pix_submap,

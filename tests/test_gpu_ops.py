@@ -507,7 +507,8 @@ def test_lazy_host_coherence_and_eviction():
         assert np.array_equal(got[True][k], got[False][k])
 
 
-def test_uncached_pointing_matches_full_pointing(monkeypatch):
+@pytest.mark.parametrize("compact", [False, True])
+def test_uncached_pointing_matches_full_pointing(monkeypatch, compact):
     """full_pointing=False (the reference default) runs through the pointing-on-the-fly kernels
     (BinMap, fused SolverLHS) and batched scratch passes; the products equal the cached-pointing
     run: maps, hits, covariance, amplitudes."""
@@ -515,7 +516,8 @@ def test_uncached_pointing_matches_full_pointing(monkeypatch):
     out = {}
     for full in (True, False):
         data, pix, sw, truth, sky = make_solver_setup(noise_rms=0.1, n_det=6, n_samp=9000)
-        binner = ops.BinMap(pixel_dist="dist", pixel_pointing=pix, stokes_weights=sw, full_pointing=full)
+        binner = ops.BinMap(pixel_dist="dist", pixel_pointing=pix, stokes_weights=sw, full_pointing=full,
+                            compact_cache=compact)
         tmpl = Offset(step_time=20.0, noise_model=defaults.noise_model, name="baselines", good_fraction=0.2)
         tmatrix = ops.TemplateMatrix(templates=[tmpl])
         mapper = ops.MapMaker(name="mm", det_data=defaults.det_data, binning=binner, template_matrix=tmatrix,
@@ -525,6 +527,10 @@ def test_uncached_pointing_matches_full_pointing(monkeypatch):
         if not full:
             # nothing of the 56 B/det-sample pointing was kept
             assert defaults.weights not in ob.detdata or ob.detdata[defaults.weights].buffer.shape[0] < 6
+            cname = defaults.pixels + "_compact"
+            assert (cname in ob.detdata) == compact
+            if compact:
+                assert ob.detdata[cname].dtype == np.int32 and ob.detdata[cname].accel_in_use()
         out[full] = dict(map=data["mm_map"].data.copy(), hits=data["mm_hits"].data.copy(),
                          cov=data["mm_cov"].data.copy(), amps=data["mm_amplitudes"]["baselines"].local.copy(),
                          hist=np.array(mapper.history))

@@ -623,6 +623,14 @@ class _Dev:
             _p(d_g2l), _i64(n_pix_submap), _i64(n_local_submap), _p(pi), _p(d_pixels), _p(ci),
             _p(d_compact_pixels), _i64(pi.size), _i64(n_samp), _p(iv), _i64(iv.size), _p(stream)))
 
+    def otf_compact_pixels(self, pt, d_g2l, n_pix_submap, n_local_submap, compact_index, d_compact_pixels, n_samp,
+                           intervals, stream=0):
+        ci = self._small(compact_index, np.int32)
+        iv = self._small(intervals, interval_dtype)
+        _check(lib().toast_hip_otf_compact_pixels_dev(
+            C.byref(pt), _p(d_g2l), _i64(n_pix_submap), _i64(n_local_submap), _p(ci), _p(d_compact_pixels),
+            _i64(ci.size), _i64(n_samp), _p(iv), _i64(iv.size), _p(stream)))
+
     def otf_scan_map(self, pt, d_g2l, d_map, n_pix_submap, d_det_data, data_index, n_samp, intervals,
                      data_scale=1.0, should_zero=False, should_subtract=False, det_weights=None, stream=0):
         di = self._small(data_index, np.int32)

@@ -435,6 +435,29 @@ void launch_scan(const OtfHost & h, dim3 grid, hipStream_t st, Args... args) {
     }
 }
 
+// boresight -> int32 local map indices directly (no int64 pixel buffer at all)
+template <bool NEST>
+__global__ __launch_bounds__(kThreads) void k_otf_compact_pixels(
+    const Chunk * __restrict__ chunks, int n_chunks, OtfDev P, const int32_t * __restrict__ c_idx,
+    int32_t * __restrict__ cpix, int64_t n_samp) {
+    __shared__ double s_tab[2 * TOAST_ATAN_TABLE_N];
+    if (threadIdx.x < 2 * TOAST_ATAN_TABLE_N) s_tab[threadIdx.x] = kAtanTab[threadIdx.x];
+    __syncthreads();
+    const int det = blockIdx.x;
+    const DetConst D = det_const(P, det);
+    int32_t * crow = cpix + (int64_t)c_idx[det] * n_samp;
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        for (int i = threadIdx.x; i < c.count; i += kThreads) {
+            const int64_t s = c.first + i;
+            double w[1];
+            int64_t l = otf_point<NEST, 0, 0>(P, D, s, s_tab, 1.0, 0.0, w);
+            if (l < 0) l = -1;   // flagged sample or pixel in a submap that is not local
+            crow[s] = (int32_t)l;
+        }
+    }
+}
+
 // int64 global pixels -> int32 local map indices (the compact cache read by PIX 1)
 __global__ __launch_bounds__(kThreads) void k_compact_pixels(
     const Chunk * __restrict__ chunks, int n_chunks, const int32_t * __restrict__ p_idx,
@@ -594,6 +617,36 @@ int toast_hip_otf_offset_scan_project_dev(
                        h.dev, off, (const int32_t *)nullptr, (double *)nullptr, 1.0, 0, 1,
                        (const int32_t *)(d + o_fi), d_det_flags, det_flag_mask, use_f,
                        (const double *)(d + o_dw), d_map, n_samp);
+        check_launch();
+    });
+}
+
+int toast_hip_otf_compact_pixels_dev(const toast_hip_otf_pointing * pointing, const int64_t * d_g2l,
+                                     int64_t n_pix_submap, int64_t n_local_submap,
+                                     const int32_t * compact_index, int32_t * d_compact_pixels, int64_t n_det,
+                                     int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
+                                     void * stream) {
+    return guarded([&] {
+        if (n_det <= 0) return;
+        if (n_local_submap * n_pix_submap > (int64_t)INT32_MAX) {
+            fail_arg("compact pixels: the local map has more than 2^31-1 pixels");
+        }
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        ParamBlock pb;
+        toast_hip_otf_pointing pt = *pointing;
+        pt.d_compact_pixels = nullptr;   // the pixels are computed here
+        pt.nnz = 1;
+        OtfHost h = otf_prepare(&pt, n_det, n_samp, n_pix_submap, d_g2l, pb);
+        const size_t o_ch = pb.push_vec(chunks);
+        const size_t o_ci = pb.push(compact_index, sizeof(int32_t) * n_det);
+        hipStream_t st = as_stream(stream);
+        const char * d = pb.commit(st);
+        otf_bind(h, d);
+        auto kern = h.nest ? k_otf_compact_pixels<true> : k_otf_compact_pixels<false>;
+        hipLaunchKernelGGL(kern, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0, st,
+                           (const Chunk *)(d + o_ch), (int)chunks.size(), h.dev, (const int32_t *)(d + o_ci),
+                           d_compact_pixels, n_samp);
         check_launch();
     });
 }

@@ -380,12 +380,14 @@ class BuildNoiseWeightedOnTheFly(BuildNoiseWeighted):
 
     pixel_pointing = Instance(klass=Operator, help="The pixel pointing operator")
     stokes_weights = Instance(klass=Operator, help="The Stokes weights operator")
+    compact_cache = Bool(False, help="Keep an int32 local-pixel cache (4 B/det-sample) instead of recomputing "
+                                     "the pixel in every pass")
 
     def _exec(self, data, detectors=None, use_accel=None, **kwargs):
         from .. import capi
         from ..accel import accel_device_ptr
         from ..data import SharedData
-        from .pointing import otf_descriptor
+        from .pointing import compact_pixel_cache, otf_descriptor
 
         if not use_accel:
             raise RuntimeError("BuildNoiseWeightedOnTheFly runs on the accelerator only")
@@ -416,7 +418,11 @@ class BuildNoiseWeightedOnTheFly(BuildNoiseWeighted):
                 continue
             noise = ob[self.noise_model]
             detweights = np.array([noise.detector_weight(x) for x in dets], dtype=np.float64)
-            pt = otf_descriptor(ob, dets, self.pixel_pointing, self.stokes_weights)
+            compact = None
+            if self.compact_cache:
+                compact = compact_pixel_cache(ob, dets, self.pixel_pointing, self.stokes_weights, dist,
+                                              accel_device_ptr(g2l.data))
+            pt = otf_descriptor(ob, dets, self.pixel_pointing, self.stokes_weights, compact=compact)
             n_samp = ob.n_local_samples
             dd = ob.detdata[self.det_data]
             if not dd.accel_in_use():
@@ -641,6 +647,8 @@ class BinMap(Operator):
     full_pointing = Bool(False, help="If True, expand pointing for all detectors and save")
     on_the_fly = Bool(True, help="With full_pointing=False on the accelerator, evaluate the pointing inside "
                                  "the accumulate kernel (not a reference trait; False = SINGLE pipelines)")
+    compact_cache = Bool(False, help="With on_the_fly: keep an int32 local-pixel cache (4 B/det-sample) and "
+                                     "evaluate only the Stokes weights on the fly (not a reference trait)")
 
     def _validate_sync_type(self, check):
         if check not in ("allreduce", "alltoallv"):
@@ -685,7 +693,8 @@ class BinMap(Operator):
                 pixel_pointing=self.pixel_pointing, stokes_weights=self.stokes_weights,
                 noise_model=self.noise_model, det_data=self.det_data, det_data_units=self.det_data_units,
                 det_mask=self.det_mask, det_flags=self.det_flags, det_flag_mask=self.det_flag_mask,
-                shared_flags=self.shared_flags, shared_flag_mask=self.shared_flag_mask, sync_type=self.sync_type)
+                shared_flags=self.shared_flags, shared_flag_mask=self.shared_flag_mask, sync_type=self.sync_type,
+                compact_cache=self.compact_cache)
             accum = Pipeline(detector_sets=["ALL"], operators=accum_ops + [otf])
             accum.apply(data, detectors=detectors, use_accel=True)
         else:

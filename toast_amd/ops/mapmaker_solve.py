@@ -259,7 +259,7 @@ class SolverLHS(Operator):
         from .. import capi
         from ..accel import accel_device_ptr, native
         from ..pixels import PixelData, covariance_apply
-        from .pointing import otf_descriptor
+        from .pointing import compact_pixel_cache, otf_descriptor
 
         D = capi.dev
         binning, tm = self.binning, self.template_matrix
@@ -349,12 +349,16 @@ class SolverLHS(Operator):
             if on_the_fly:
                 # the descriptor only depends on the detector list and the resident shared data
                 pcache = self.__dict__.setdefault("_otf_cache", {})
-                pkey = (id(ob), tuple(dets), accel_device_ptr(ob.shared[pixels_op.detector_pointing.boresight].data)
-                        if ob.shared[pixels_op.detector_pointing.boresight].accel_exists() else 0)
+                compact = None
+                if getattr(binning, "compact_cache", False):
+                    compact = compact_pixel_cache(ob, dets, pixels_op, weights_op, dist, accel_device_ptr(g2l.data))
+                bore = ob.shared[pixels_op.detector_pointing.boresight]
+                pkey = (id(ob), tuple(dets), accel_device_ptr(bore.data) if bore.accel_exists() else 0,
+                        accel_device_ptr(compact.buffer) if compact is not None else 0)
                 if pkey not in pcache:
                     pcache.clear()
-                    pt = otf_descriptor(ob, dets, pixels_op, weights_op)
-                    pkey = (id(ob), tuple(dets), int(pt.d_boresight))
+                    pt = otf_descriptor(ob, dets, pixels_op, weights_op, compact=compact)
+                    pkey = pkey[:2] + (int(pt.d_boresight),) + pkey[3:]
                     pcache[pkey] = pt
                 pt = pcache[pkey]
                 common["pt"] = pt

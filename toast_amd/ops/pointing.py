@@ -150,6 +150,32 @@ def otf_descriptor(ob, dets, pixels_op, weights_op, compact=None):
                              epsilon=eps, gamma=gamma, cal=cal, IAU=bool(weights_op.IAU), **extra)
 
 
+def compact_pixel_cache(ob, dets, pixels_op, weights_op, dist, d_g2l):
+    """Device-only int32 cache of the LOCAL map index of every det-sample
+    (``toast_hip_otf_compact_pixels_dev``): 4 B/det-sample instead of the 8 + 8 nnz B of cached
+    pixels + weights.  Stored as ``ob.detdata[<pixels>_compact]``; rows are filled on demand and
+    reused until the pixel distribution changes."""
+    from .. import capi
+    from ..accel import accel_device_ptr
+
+    name = pixels_op.pixels + "_compact"
+    ob.detdata.ensure(name, dtype=np.int32, detectors=ob.local_detectors, accel=True)
+    dd = ob.detdata[name]
+    state = dd.__dict__.setdefault("_compact_state", {"dist": None, "filled": set()})
+    sig = (id(dist), pixels_op.nside, pixels_op.nest, pixels_op.view)
+    if state["dist"] != sig:
+        state["dist"], state["filled"] = sig, set()
+    missing = [d for d in dets if d not in state["filled"]]
+    if missing:
+        pt = otf_descriptor(ob, missing, pixels_op, weights_op)
+        capi.dev.otf_compact_pixels(pt, d_g2l, dist.n_pix_submap, dist.n_local_submap, dd.indices(missing),
+                                    accel_device_ptr(dd.buffer), ob.n_local_samples,
+                                    ob.intervals[pixels_op.view].data)
+        state["filled"].update(missing)
+    dd.accel_used(True)
+    return dd
+
+
 def _outputs_exist(data, key, detectors, det_mask):
     """True when every observation already holds ``key`` for all requested detectors: the
     operator (and the detector pointing it would trigger) has nothing to do."""

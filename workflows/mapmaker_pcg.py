@@ -46,6 +46,8 @@ def main(argv=None):
     ap.add_argument("--no-filter", action="store_true")
     ap.add_argument("--uncached", action="store_true",
                     help="full_pointing=False (the reference default): no pointing cache, on-the-fly kernels")
+    ap.add_argument("--compact", action="store_true",
+                    help="with --uncached: keep a 4 B/det-sample int32 pixel cache, weights on the fly")
     args = ap.parse_args(argv)
 
     n_samp = int(args.minutes * 60 * args.rate)
@@ -67,7 +69,7 @@ def main(argv=None):
     pixels = ops.PixelsHealpix(detector_pointing=det_pointing, nside=args.nside, nest=True)
     weights = ops.StokesWeights(detector_pointing=det_pointing, mode="IQU", hwp_angle=defaults.hwp_angle)
     binner = ops.BinMap(pixel_dist="pixel_dist", pixel_pointing=pixels, stokes_weights=weights,
-                        full_pointing=not args.uncached)
+                        full_pointing=not args.uncached, compact_cache=args.compact)
     tmatrix = ops.TemplateMatrix(templates=[Offset(step_time=args.step_time, noise_model=defaults.noise_model,
                                                    name="baselines")])
     mapper = ops.MapMaker(name="mapmaker", det_data=defaults.det_data, binning=binner, template_matrix=tmatrix,
