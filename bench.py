@@ -267,11 +267,16 @@ def main():
     # gfx950 FETCH correction calibrated in-run; profiles/README.md); null if not profiled.
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-    kname = {"build_noise_weighted": "k_build_noise_weighted<3>", "scan_map": "k_scan_map<double, 3>"}[dom]
+    knames = {"build_noise_weighted": ("k_build_noise_weighted_pair<3>", "k_build_noise_weighted<3>"),
+              "scan_map": ("k_scan_map<double, 3>",)}[dom]
     if os.path.isfile(tpath) and not args.unfused:
         try:
             with open(tpath) as f:
-                traffic = json.load(f)["kernels"][kname]["hbm_bytes"]
+                kernels = json.load(f)["kernels"]
+            for kname in knames:
+                if kname in kernels:
+                    traffic = kernels[kname]["hbm_bytes"]
+                    break
         except (KeyError, ValueError):
             traffic = None
     roofline = {
