@@ -293,6 +293,18 @@ def main():
         "iteration_GBs": (BYTES_BNW + BYTES_SCAN) * nsamp_tot / ((ms["bnw"] + ms["scan"]) * 1e-3) / 1e9,
     }
 
+    # measured stream ceiling on this box ("report % of both"): a pure
+    # 8 B read + 8 B write stream (k_noise_weight over the work timestream, scale 1.0)
+    ones = np.ones(n_det)
+    D.noise_weight(d_tod2.data_ptr(), n_samp, idx, ivl, ones, stream)
+    t_rw = timed(lambda: D.noise_weight(d_tod2.data_ptr(), n_samp, idx, ivl, ones, stream), 5)
+    stream_rw = 16.0 * nsamp_tot / t_rw / 1e6
+    roofline["stream_ceiling"] = {
+        "read_write_GBs": stream_rw,
+        "frac_of_read_write_stream": ach / stream_rw,
+        "note": "k_noise_weight, a pure 8 B read + 8 B write per sample stream over the same work buffer",
+    }
+
     out = {
         "metric": "detector-samples/sec through one PCG (A^T N^-1 A) iteration",
         "value": value,
