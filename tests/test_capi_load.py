@@ -88,3 +88,26 @@ def test_pybind_module_names_match_reference():
     iv = m.Interval()
     iv.first, iv.last = 3, 9
     assert iv.astuple()[2:] == (3, 9)
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """The drop-in boundary is a C ABI: include/toast_hip.h compiles as C99 (no C++, no torch
+    types) and a C client links against libtoast_hip.so and can call a non-compute entry point."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "client.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <string.h>\n#include "toast_hip.h"\n'
+        "int main(void) {\n"
+        "    toast_hip_interval iv; toast_hip_otf_pointing pt;\n"
+        "    memset(&iv, 0, sizeof iv); memset(&pt, 0, sizeof pt);\n"
+        '    printf("%d %d %d\\n", (int)sizeof(iv), toast_hip_accel_enabled() >= 0, toast_hip_fft_length(720000) > 0);\n'
+        "    return 0;\n}\n")
+    exe = tmp_path / "client"
+    libdir = os.path.join(root, "toast_amd")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(root, "include"), str(src),
+                    "-L", libdir, "-ltoast_hip", "-Wl,-rpath," + libdir, "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert out[0] == "32" and out[1] == "1" and out[2] == "1"
