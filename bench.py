@@ -173,6 +173,11 @@ def main():
         hwp_h = np.ascontiguousarray(2 * np.pi * ((np.arange(n_samp) * (88.0 / 60.0) / rate) % 1.0))
         d_hwp = torch.from_numpy(hwp_h).to(dev)
     hwp_ptr, hwp_n = (d_hwp.data_ptr(), n_samp) if args.hwp else (0, 0)
+    hwp_tab_ptr = 0
+    if args.hwp:
+        d_hwp_tab = torch.empty((n_samp, 2), dtype=torch.float64, device=dev)
+        D.hwp_table(hwp_ptr, n_samp, d_hwp_tab.data_ptr(), stream)
+        hwp_tab_ptr = d_hwp_tab.data_ptr()
     sw_call = lambda: D.stokes_weights_IQU(idx, d_quats.data_ptr(), idx, d_weights.data_ptr(), n_samp, hwp_ptr, hwp_n, ivl,
                                            np.zeros(n_det), gamma, np.ones(n_det), False, stream)
     sw_call()
@@ -407,7 +412,7 @@ def main():
         # without the 32 B/det-sample pointing cache -- 9 + 16 B (A^T, A) and ~2 + ~2 B (offset LHS)
         pt = capi.otf_pointing(d_bore.data_ptr(), fp, nside, True, nnz, d_shared_flags=d_sflags.data_ptr(),
                                n_shared_flags=n_samp, shared_flag_mask=1, epsilon=np.zeros(n_det), gamma=gamma,
-                               cal=np.ones(n_det), d_hwp=hwp_ptr, n_hwp=hwp_n)
+                               cal=np.ones(n_det), d_hwp=hwp_ptr, n_hwp=hwp_n, d_hwp_table=hwp_tab_ptr)
 
         def ata_otf():
             d_zmap.zero_()
@@ -448,7 +453,7 @@ def main():
         ptc = capi.otf_pointing(d_bore.data_ptr(), fp, nside, True, nnz, d_shared_flags=d_sflags.data_ptr(),
                                 n_shared_flags=n_samp, shared_flag_mask=1, epsilon=np.zeros(n_det), gamma=gamma,
                                 cal=np.ones(n_det), d_compact_pixels=d_cpix.data_ptr(), compact_index=idx,
-                                d_hwp=hwp_ptr, n_hwp=hwp_n)
+                                d_hwp=hwp_ptr, n_hwp=hwp_n, d_hwp_table=hwp_tab_ptr)
         pt_keep = pt
         pt = ptc
         lhs_otf()

@@ -459,6 +459,9 @@ typedef struct {
      * array (4 B/det-sample) and evaluate only the Stokes weights on the fly. */
     const int32_t * d_compact_pixels;
     const int32_t * compact_index;  /* host [n_det] */
+    /* Optional [n_hwp, 2] table (cos 4 hwp, sin 4 hwp) from toast_hip_hwp_table_dev: the kernels
+     * then read 16 B per time sample (shared by all detectors) instead of evaluating sincos. */
+    const double * d_hwp_table;
 } toast_hip_otf_pointing;
 
 /* Compact pixel cache: local map index  global2local[pix / n_pix_submap] * n_pix_submap +
@@ -469,6 +472,11 @@ int toast_hip_compact_pixels_dev(const int64_t * d_g2l, int64_t n_pix_submap, in
                                  const int32_t * compact_index, int32_t * d_compact_pixels, int64_t n_det,
                                  int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
                                  void * stream);
+
+/* table[i] = (cos(4 hwp[i]), sin(4 hwp[i])): the HWP modulation 2 (2 (gamma - hwp)) of
+ * stokes_weights_IQU [ref: ops_stokes_weights.cpp:96-99] by angle addition from per-detector
+ * cos / sin 4 gamma; d_table is 16-byte aligned, 2 n_samp doubles. */
+int toast_hip_hwp_table_dev(const double * d_hwp, int64_t n_samp, double * d_table, void * stream);
 
 /* The same cache computed straight from the boresight (pointing_detector -> pixels_healpix ->
  * global2local in registers): no int64 pixel buffer is needed at all.  `pointing`'s weight

@@ -26,12 +26,20 @@ def _dev(torch, a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-def _descriptor(torch, capi, c, nest, iau, nnz, shared_mask, hold, compact=None):
+def _descriptor(torch, capi, c, nest, iau, nnz, shared_mask, hold, compact=None, hwp_table=False):
     bore = _dev(torch, c["boresight"])
     sfl = _dev(torch, c["shared_flags"])
     hwp = _dev(torch, c["hwp"])
     hold += [bore, sfl, hwp]
     extra = {}
+    if hwp_table and c["hwp"].size == c["n_samp"]:
+        tab = torch.empty((c["n_samp"], 2), dtype=torch.float64, device="cuda")
+        capi.dev.hwp_table(hwp.data_ptr(), c["n_samp"], tab.data_ptr())
+        torch.cuda.synchronize()
+        want = np.stack([np.cos(4.0 * c["hwp"]), np.sin(4.0 * c["hwp"])], axis=1)
+        assert np.max(np.abs(tab.cpu().numpy() - want)) < 1e-15
+        hold.append(tab)
+        extra["d_hwp_table"] = tab.data_ptr()
     if compact is not None:
         extra = dict(d_compact_pixels=compact.data_ptr(), compact_index=c["pixel_index"])
     return capi.otf_pointing(bore.data_ptr(), c["focalplane"], c["nside"], nest, nnz,
@@ -143,7 +151,8 @@ def test_otf_matches_operator_chain(env, oracle, name, nest):
 
     # (iii) compact mode: int32 local pixel cache + weights on the fly
     cp = _compact(torch, capi, c, g2l, pixels, want["zmap"].shape[0])
-    ptc, _ = _descriptor(torch, capi, c, nest, iau, 3, 1, hold, compact=cp)
+    # ... with the per-observation HWP table (identical values: same bits as without)
+    ptc, _ = _descriptor(torch, capi, c, nest, iau, 3, 1, hold, compact=cp, hwp_table=True)
     tod4 = _dev(torch, c["tod"])
     D.otf_scan_map(ptc, g2l.data_ptr(), zin.data_ptr(), c["n_pix_submap"], tod4.data_ptr(), c["data_index"], n_samp,
                    c["intervals"], 1.0, False, True, det_weights=c["det_scale"])

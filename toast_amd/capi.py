@@ -401,12 +401,13 @@ class OtfPointing(C.Structure):
         ("nnz", C.c_int),
         ("d_compact_pixels", C.c_void_p),
         ("compact_index", C.c_void_p),
+        ("d_hwp_table", C.c_void_p),
     ]
 
 
 def otf_pointing(d_boresight, focalplane, nside, nest, nnz, d_shared_flags=0, n_shared_flags=0, shared_flag_mask=0,
                  d_hwp=0, n_hwp=0, epsilon=None, gamma=None, cal=None, IAU=False, d_compact_pixels=0,
-                 compact_index=None):
+                 compact_index=None, d_hwp_table=0):
     fp = np.ascontiguousarray(focalplane, dtype=np.float64)
     if fp.ndim != 2 or fp.shape[1] != 4:
         raise RuntimeError("focalplane should be a [n_det, 4] float64 array")
@@ -423,7 +424,7 @@ def otf_pointing(d_boresight, focalplane, nside, nest, nnz, d_shared_flags=0, n_
 
     pt = OtfPointing(int(d_boresight), int(d_shared_flags) or None, int(n_shared_flags), int(shared_flag_mask),
                      fp.ctypes.data, int(d_hwp) or None, int(n_hwp), small(epsilon), small(gamma), small(cal),
-                     int(bool(IAU)), int(nside), int(bool(nest)), int(nnz), None, None)
+                     int(bool(IAU)), int(nside), int(bool(nest)), int(nnz), None, None, int(d_hwp_table) or None)
     if d_compact_pixels:
         ci = np.ascontiguousarray(compact_index, dtype=np.int32)
         if ci.shape != (fp.shape[0],):
@@ -622,6 +623,9 @@ class _Dev:
         _check(lib().toast_hip_compact_pixels_dev(
             _p(d_g2l), _i64(n_pix_submap), _i64(n_local_submap), _p(pi), _p(d_pixels), _p(ci),
             _p(d_compact_pixels), _i64(pi.size), _i64(n_samp), _p(iv), _i64(iv.size), _p(stream)))
+
+    def hwp_table(self, d_hwp, n_samp, d_table, stream=0):
+        _check(lib().toast_hip_hwp_table_dev(_p(d_hwp), _i64(n_samp), _p(d_table), _p(stream)))
 
     def otf_compact_pixels(self, pt, d_g2l, n_pix_submap, n_local_submap, compact_index, d_compact_pixels, n_samp,
                            intervals, stream=0):

@@ -23,6 +23,7 @@ struct OtfDev {
     const double * bore;      // [n_samp, 4]
     const uint8_t * pflags;   // shared flags seen by the pointing operators
     const double * hwp;       // [n_samp] (MODE 2 only)
+    const double * hwp_tab;   // optional [n_samp, 2] = (cos 4 hwp, sin 4 hwp), see toast_hip_hwp_table_dev
     const double * fp;        // [n_det, 4]
     const double * eps;       // [n_det]
     const double * gamma;     // [n_det]
@@ -63,6 +64,24 @@ template <int MODE>
 struct ModeNnz {
     static constexpr int value = (MODE == 0) ? 1 : 3;
 };
+
+// cos / sin of four times the HWP angle of time sample s: from the per-observation table when
+// the caller provides one (identical values: the table is filled with the same sincos), else
+// evaluated here.
+template <int MODE>
+__device__ __forceinline__ void hwp_cs4(const OtfDev & P, int64_t s, double & c4h, double & s4h) {
+    c4h = 1.0;
+    s4h = 0.0;
+    if constexpr (MODE == 2) {
+        if (P.hwp_tab != nullptr) {
+            const double2 t = *reinterpret_cast<const double2 *>(P.hwp_tab + 2 * s);
+            c4h = t.x;
+            s4h = t.y;
+        } else {
+            sincos(4.0 * P.hwp[s], &s4h, &c4h);
+        }
+    }
+}
 
 // LOCAL map index (n_pix_submap * local_submap + pixel-in-submap; -1 when the boresight sample is
 // flagged) and Stokes weights of one det-sample.
@@ -194,8 +213,8 @@ __global__ __launch_bounds__(kThreads) void k_otf_accumulate(
                 const uint8_t fs = use_sflags ? sflags[s] : (uint8_t)0;
                 int64_t astep = 0;
                 if (SIG == 1) astep = fastdiv(s - vfirst, O.step_div);
-                double c4h = 1.0, s4h = 0.0;
-                if constexpr (MODE == 2) sincos(4.0 * P.hwp[s], &s4h, &c4h);
+                double c4h, s4h;
+                hwp_cs4<MODE>(P, s, c4h, s4h);
                 uint8_t fd[E];
                 double t[E];
 #pragma unroll
@@ -266,8 +285,8 @@ __global__ __launch_bounds__(kThreads) void k_otf_scan(
             if (SIG == 0) {
                 if (!active) continue;
                 double d = zero ? 0.0 : drow[s];
-                double c4h = 1.0, s4h = 0.0;
-                if constexpr (MODE == 2) sincos(4.0 * P.hwp[s], &s4h, &c4h);
+                double c4h, s4h;
+                hwp_cs4<MODE>(P, s, c4h, s4h);
                 double wk[NNZ];
                 const int64_t p = otf_point<NEST, MODE, PIX>(P, D, s, s_tab, c4h, s4h, wk);
                 if (p >= 0) {
@@ -295,8 +314,8 @@ __global__ __launch_bounds__(kThreads) void k_otf_scan(
                     if (af == 0) {
                         key = a;
                         if ((fl & fmask) == 0) {
-                            double c4h = 1.0, s4h = 0.0;
-                            if constexpr (MODE == 2) sincos(4.0 * P.hwp[s], &s4h, &c4h);
+                            double c4h, s4h;
+                            hwp_cs4<MODE>(P, s, c4h, s4h);
                             double wk[NNZ];
                             const int64_t p = otf_point<NEST, MODE, PIX>(P, D, s, s_tab, c4h, s4h, wk);
                             double d = 0.0 + av;
@@ -360,6 +379,8 @@ OtfHost otf_prepare(const toast_hip_otf_pointing * pt, int64_t n_det, int64_t n_
     d.bore = pt->d_boresight;
     d.pflags = pt->d_shared_flags;
     d.hwp = pt->d_hwp;
+    d.hwp_tab = hwp ? pt->d_hwp_table : nullptr;
+    if (d.hwp_tab != nullptr) need_aligned(d.hwp_tab, "hwp table");
     d.usign = pt->IAU ? -1.0 : 1.0;
     d.nside = pt->nside;
     d.nps_div = make_fastdiv(n_pix_submap);
@@ -432,6 +453,15 @@ void launch_scan(const OtfHost & h, dim3 grid, hipStream_t st, Args... args) {
         launch_scan_pix<SIG, 1>(h, grid, st, args...);
     } else {
         launch_scan_pix<SIG, 0>(h, grid, st, args...);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_hwp_table(int64_t n, const double * __restrict__ hwp,
+                                                        double * __restrict__ tab) {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+        double s4h, c4h;
+        sincos(4.0 * hwp[i], &s4h, &c4h);
+        *reinterpret_cast<double2 *>(tab + 2 * i) = make_double2(c4h, s4h);
     }
 }
 
@@ -617,6 +647,16 @@ int toast_hip_otf_offset_scan_project_dev(
                        h.dev, off, (const int32_t *)nullptr, (double *)nullptr, 1.0, 0, 1,
                        (const int32_t *)(d + o_fi), d_det_flags, det_flag_mask, use_f,
                        (const double *)(d + o_dw), d_map, n_samp);
+        check_launch();
+    });
+}
+
+int toast_hip_hwp_table_dev(const double * d_hwp, int64_t n_samp, double * d_table, void * stream) {
+    return guarded([&] {
+        if (n_samp <= 0) return;
+        need_aligned(d_table, "hwp table");
+        hipLaunchKernelGGL(k_hwp_table, flat_grid(n_samp), dim3(kThreads), 0, as_stream(stream), n_samp, d_hwp,
+                           d_table);
         check_launch();
     });
 }

@@ -137,14 +137,32 @@ def otf_descriptor(ob, dets, pixels_op, weights_op, compact=None):
     cal = (np.ones(len(dets)) if weights_op.cal is None
            else np.array([ob[weights_op.cal][x] for x in dets], np.float64))
     gamma = np.zeros(len(dets), dtype=np.float64)
-    d_hwp, n_hwp = 0, 0
+    d_hwp, n_hwp, extra_tab = 0, 0, 0
     if nnz == 3 and weights_op.hwp_angle is not None and weights_op.hwp_angle in ob.shared:
         _shared_to(ob, weights_op.hwp_angle, True)
         d_hwp, n_hwp = accel_device_ptr(ob.shared[weights_op.hwp_angle].data), n_samp
         gamma = np.array([focalplane[d][weights_op.fp_gamma] for d in dets], dtype=np.float64)
+        # (cos 4 hwp, sin 4 hwp) per time sample, built once per observation and shared by all
+        # detectors: the kernels then evaluate no transcendental per det-sample
+        tkey = weights_op.hwp_angle + "_cs4"
+        if tkey not in ob.shared:
+            from ..data import SharedData
+
+            ob.shared[tkey] = SharedData(np.zeros((n_samp, 2), dtype=np.float64), tkey)
+            tab = ob.shared[tkey]
+            tab.accel_create(tkey)
+            capi.dev.hwp_table(d_hwp, n_samp, accel_device_ptr(tab.data))
+            tab.accel_used(True)
+        tab = ob.shared[tkey]
+        if not tab.accel_exists():      # evicted: the values live on the host copy
+            tab.accel_create(tkey)
+            tab.accel_update_device()
+        extra_tab = accel_device_ptr(tab.data)
     extra = {}
     if compact is not None:
         extra = dict(d_compact_pixels=accel_device_ptr(compact.buffer), compact_index=compact.indices(dets))
+    if extra_tab:
+        extra["d_hwp_table"] = extra_tab
     return capi.otf_pointing(bore, fp_quats, pixels_op.nside, pixels_op.nest, nnz, d_shared_flags=d_flags,
                              n_shared_flags=n_flags, shared_flag_mask=dp.shared_flag_mask, d_hwp=d_hwp, n_hwp=n_hwp,
                              epsilon=eps, gamma=gamma, cal=cal, IAU=bool(weights_op.IAU), **extra)
