@@ -521,6 +521,17 @@ int toast_hip_otf_offset_scan_project_dev(
     const double * det_weights, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals,
     int64_t n_view, void * stream);
 
+/* Solver flags [ref: src/toast/ops/mapmaker_templates.py:764-810]: for the samples inside the
+ * intervals  out[out_index[d]][s] = ((det_flags[flag_index[d]][s] & det_flag_mask) != 0) |
+ * ((shared_flags[s] & shared_flag_mask) != 0);  the optional inputs are absent when their length
+ * differs from n_samp.  When outside_value >= 0 the whole [n_out_rows, n_samp] buffer is first
+ * set to it (samples outside every interval keep that value), otherwise it is left untouched. */
+int toast_hip_combine_flags_dev(uint8_t * d_out, const int32_t * out_index, const uint8_t * d_det_flags,
+                                int64_t n_flag_samp, const int32_t * flag_index, uint8_t det_flag_mask,
+                                const uint8_t * d_shared_flags, int64_t n_shared_flags, uint8_t shared_flag_mask,
+                                int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals,
+                                int64_t n_view, int64_t n_out_rows, int outside_value, void * stream);
+
 /* PCG vector algebra on device-resident amplitude vectors
  * [ref: src/toast/templates/amplitudes.py:400-565]:  y = a x + b y  (b == 0 overwrites), and the
  * flagged dot product  sum_i x_i y_i over entries with both flags clear (flag pointers may be

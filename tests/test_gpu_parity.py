@@ -219,3 +219,35 @@ def test_pybind_module_matches_oracle(oracle, name):
         m.noise_weight(np.ones(8), c["data_index"], c["intervals"], c["det_scale"], False)
     with pytest.raises(RuntimeError, match="instead of"):
         m.noise_weight(np.ones((4, 8), np.float32), c["data_index"], c["intervals"], c["det_scale"], False)
+
+
+def test_combine_flags_matches_numpy(hip):
+    """toast_hip_combine_flags_dev (MapMaker solver flags, mapmaker_templates.py:764-810)."""
+    import torch
+
+    c = cases.make_case(n_det=5, n_samp=4001, n_split=3, gap=9, extra_rows=2)
+    n_samp, rows = c["n_samp"], c["rows"]
+    dfl = torch.from_numpy(c["det_flags"]).cuda()
+    sfl = torch.from_numpy(c["shared_flags"]).cuda()
+    for outside in (1, 0, -1):
+        out = torch.full((rows, n_samp), 7, dtype=torch.uint8, device="cuda")
+        hip.dev.combine_flags(out.data_ptr(), c["data_index"], dfl.data_ptr(), n_samp, c["flag_index"], 4,
+                              sfl.data_ptr(), n_samp, 2, n_samp, c["intervals"], n_out_rows=rows,
+                              outside_value=outside)
+        torch.cuda.synchronize()
+        want = np.full((rows, n_samp), 7 if outside < 0 else outside, dtype=np.uint8)
+        for iv in c["intervals"]:
+            sl = slice(int(iv["first"]), int(iv["last"]))
+            for o, f in zip(c["data_index"], c["flag_index"]):
+                want[o, sl] = ((c["det_flags"][f, sl] & 4) != 0) | ((c["shared_flags"][sl] & 2) != 0)
+        assert np.array_equal(out.cpu().numpy(), want)
+    # absent optional inputs
+    out = torch.zeros((rows, n_samp), dtype=torch.uint8, device="cuda")
+    hip.dev.combine_flags(out.data_ptr(), c["data_index"], 0, 0, c["flag_index"], 4, 0, 0, 2, n_samp, c["intervals"],
+                          n_out_rows=rows, outside_value=1)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    inside = np.zeros(n_samp, dtype=bool)
+    for iv in c["intervals"]:
+        inside[int(iv["first"]):int(iv["last"])] = True
+    assert np.all(got[c["data_index"]][:, inside] == 0) and np.all(got[:, ~inside] == 1)

@@ -682,6 +682,16 @@ class _Dev:
             _p(d_g2l), _p(d_mask), _i64(n_pix_submap), _u8(mask_bits), _u8(flag_value), _p(pi), _p(d_pixels), _p(fi),
             _p(d_det_flags), _i64(pi.size), _i64(n_samp), _p(iv), _i64(iv.size), _p(stream)))
 
+    def combine_flags(self, d_out, out_index, d_det_flags, n_flag_samp, flag_index, det_flag_mask, d_shared_flags,
+                      n_shared_flags, shared_flag_mask, n_samp, intervals, n_out_rows=0, outside_value=-1, stream=0):
+        oi = self._small(out_index, np.int32)
+        fi = self._small(flag_index, np.int32)
+        iv = self._small(intervals, interval_dtype)
+        _check(lib().toast_hip_combine_flags_dev(
+            _p(d_out), _p(oi), _p(d_det_flags), _i64(n_flag_samp), _p(fi), _u8(det_flag_mask), _p(d_shared_flags),
+            _i64(n_shared_flags), _u8(shared_flag_mask), _i64(oi.size), _i64(n_samp), _p(iv), _i64(iv.size),
+            _i64(n_out_rows), C.c_int(int(outside_value)), _p(stream)))
+
     def copy(self, d_dst, d_src, nbytes, stream=0):
         _check(lib().toast_hip_copy_dev(_p(d_dst), _p(d_src), C.c_size_t(int(nbytes)), _p(stream)))
 

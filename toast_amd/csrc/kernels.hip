@@ -591,6 +591,31 @@ __global__ __launch_bounds__(kThreads) void k_scan_mask(
 }
 
 // ------------------------------------------------------------------------------------
+// Solver flags: one uint8 per det-sample = detector flag | shared flag (masked), the combined
+// cut MapMaker hands to the binning and the templates while solving
+// [ref: SolveAmplitudes._prepare_flagging, src/toast/ops/mapmaker_templates.py:764-810].
+// Samples outside the intervals are set by the caller (memset) before this kernel.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_combine_flags(
+    const Chunk * __restrict__ chunks, int n_chunks, const int32_t * __restrict__ o_idx,
+    const int32_t * __restrict__ f_idx, uint8_t * __restrict__ out, const uint8_t * __restrict__ dflags,
+    uint8_t dmask, int use_dflags, const uint8_t * __restrict__ sflags, uint8_t smask, int use_sflags,
+    int64_t n_samp) {
+    const int det = blockIdx.x;
+    uint8_t * orow = out + (int64_t)o_idx[det] * n_samp;
+    const uint8_t * frow = use_dflags ? dflags + (int64_t)f_idx[det] * n_samp : nullptr;
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        for (int i = threadIdx.x; i < c.count; i += kThreads) {
+            const int64_t s = c.first + i;
+            const uint8_t fd = use_dflags ? frow[s] : (uint8_t)0;
+            const uint8_t fs = use_sflags ? sflags[s] : (uint8_t)0;
+            orow[s] = (((fd & dmask) != 0) | ((fs & smask) != 0)) ? 1 : 0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // Amplitude-vector algebra of the PCG on the device (axpby, flagged dot product): the
 // Amplitudes arithmetic of src/toast/templates/amplitudes.py:400-565 for resident vectors.
 // ------------------------------------------------------------------------------------
@@ -1507,6 +1532,37 @@ int toast_hip_scan_mask_dev(const int64_t * d_g2l, const uint8_t * d_mask, int64
                            as_stream(stream), (const Chunk *)(d + o_ch), (int)chunks.size(),
                            (const int32_t *)(d + o_pi), (const int32_t *)(d + o_fi), d_g2l, d_mask,
                            mask_bits, flag_value, d_pixels, d_det_flags, make_fastdiv(n_pix_submap), n_samp);
+        check_launch();
+    });
+}
+
+int toast_hip_combine_flags_dev(uint8_t * d_out, const int32_t * out_index, const uint8_t * d_det_flags,
+                                int64_t n_flag_samp, const int32_t * flag_index, uint8_t det_flag_mask,
+                                const uint8_t * d_shared_flags, int64_t n_shared_flags, uint8_t shared_flag_mask,
+                                int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals,
+                                int64_t n_view, int64_t n_out_rows, int outside_value, void * stream) {
+    return guarded([&] {
+        if (n_det <= 0) return;
+        hipStream_t st0 = as_stream(stream);
+        if (outside_value >= 0 && n_out_rows > 0) {
+            TH_HIP(hipMemsetAsync(d_out, outside_value & 0xff, (size_t)(n_out_rows * n_samp), st0));
+        }
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        const int use_d = (n_flag_samp == n_samp) ? 1 : 0;
+        const int use_s = (n_shared_flags == n_samp) ? 1 : 0;
+        std::vector<int32_t> fidx(n_det, 0);
+        if (use_d) std::memcpy(fidx.data(), flag_index, sizeof(int32_t) * n_det);
+        ParamBlock pb;
+        const size_t o_ch = pb.push_vec(chunks);
+        const size_t o_oi = pb.push(out_index, sizeof(int32_t) * n_det);
+        const size_t o_fi = pb.push_vec(fidx);
+        hipStream_t st = as_stream(stream);
+        const char * d = pb.commit(st);
+        hipLaunchKernelGGL(k_combine_flags, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0, st,
+                           (const Chunk *)(d + o_ch), (int)chunks.size(), (const int32_t *)(d + o_oi),
+                           (const int32_t *)(d + o_fi), d_out, d_det_flags, det_flag_mask, use_d, d_shared_flags,
+                           shared_flag_mask, use_s, n_samp);
         check_launch();
     });
 }

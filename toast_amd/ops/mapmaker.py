@@ -128,14 +128,17 @@ class MapMaker(Operator):
         tm = self.template_matrix
         use_templates = tm is not None and len(tm.templates) > 0
         if use_templates:
+            from ..accel import accel_enabled as _acc_on
+
             for ob in data.obs:
+                if _acc_on():
+                    self._solver_flags_device(ob, solver_flags, binning)
+                    continue
                 ob.detdata.ensure(solver_flags, dtype=np.uint8, detectors=ob.local_detectors)
                 sf = ob.detdata[solver_flags]
                 sf.data[:] = 0
                 if binning.det_flags is not None:
                     src = ob.detdata[binning.det_flags]
-                    if src.accel_in_use():
-                        src.accel_update_host()
                     for d in ob.local_detectors:
                         sf[d][(src[d] & binning.det_flag_mask) != 0] = 1
                 if binning.shared_flags is not None:
@@ -232,6 +235,40 @@ class MapMaker(Operator):
         if pinned is not None:
             data.accel_unpin(pinned)
             _t = _lap("unpin_pointing", _t)
+
+    @staticmethod
+    def _solver_flags_device(ob, solver_flags, binning):
+        """The same combination on the device (toast_hip_combine_flags_dev): nothing but the
+        uint8 inputs cross PCIe, and those only if they are not resident yet."""
+        from .. import capi
+        from ..accel import accel_device_ptr
+
+        dets = ob.local_detectors
+        ob.detdata.ensure(solver_flags, dtype=np.uint8, detectors=dets, accel=True)
+        sf = ob.detdata[solver_flags]
+        n_samp = ob.n_local_samples
+        f_ptr, f_n, f_idx = 0, 0, np.zeros(len(dets), np.int32)
+        if binning.det_flags is not None:
+            src = ob.detdata[binning.det_flags]
+            if not src.accel_in_use():
+                if not src.accel_exists():
+                    src.accel_create(binning.det_flags)
+                src.accel_update_device()
+            f_ptr, f_n, f_idx = accel_device_ptr(src.buffer), n_samp, src.indices(dets)
+        s_ptr, s_n = 0, 0
+        if binning.shared_flags is not None:
+            shared = ob.shared[binning.shared_flags]
+            if not shared.accel_in_use():
+                if not shared.accel_exists():
+                    shared.accel_create(binning.shared_flags)
+                shared.accel_update_device()
+            s_ptr, s_n = accel_device_ptr(shared.data), n_samp
+        view = binning.pixel_pointing.view
+        capi.dev.combine_flags(accel_device_ptr(sf.buffer), sf.indices(dets), f_ptr, f_n, f_idx,
+                               binning.det_flag_mask, s_ptr, s_n, binning.shared_flag_mask, n_samp,
+                               ob.intervals[view].data, n_out_rows=len(sf.detectors),
+                               outside_value=1 if view is not None else 0)
+        sf.accel_used(True)
 
     def _finalize(self, data, **kwargs):
         return
