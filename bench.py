@@ -504,31 +504,58 @@ def main():
         ds_h = np.ascontiguousarray(det_scale[:nd])
         dw_h = np.ascontiguousarray(det_w[:nd])
 
-        def cpu_step():
-            z_h[:] = 0.0
-            oracle.build_noise_weighted(g2l_h, z_h, idx_h, pix_h, idx_h, w_h, idx_h, tod_h, idx_h, df_h, ds_h, 1,
-                                        ivl, sflags_h, 1)
-            oracle.scan_map(g2l_h, nps, z_h, tod2_h, idx_h, pix_h, idx_h, w_h, idx_h, ivl, 1.0, False, True, False)
-            oracle.noise_weight(tod2_h, idx_h, ivl, dw_h)
+        def make_step(impl, tail):
+            scan = getattr(impl, "scan_map", None) or getattr(impl, "ops_scan_map_float64")
 
-        cpu_step()  # warm (page-touch)
-        t0 = time.perf_counter()
-        reps = 0
-        while True:
-            cpu_step()
-            reps += 1
-            if time.perf_counter() - t0 > 10.0 or reps >= 5:
-                break
-        cpu_t = (time.perf_counter() - t0) / reps
-        out["cpu_baseline"] = {
-            "value": nd * n_samp / cpu_t,
-            "unit": "det-samples/s",
-            "cores": oracle.num_threads(),
-            "kind": "port",
-            "sample": "%d of the %d detectors x %d samples of the same workload; build_noise_weighted + "
-                      "scan_map(subtract) + noise_weight with the reference's host parallelisation "
-                      "(cov_apply_diag excluded: map sized)" % (nd, n_det, n_samp),
-        }
+            def cpu_step():
+                z_h[:] = 0.0
+                impl.build_noise_weighted(g2l_h, z_h, idx_h, pix_h, idx_h, w_h, idx_h, tod_h, idx_h, df_h, ds_h, 1,
+                                          ivl, sflags_h, 1, *tail)
+                scan(g2l_h, nps, z_h, tod2_h, idx_h, pix_h, idx_h, w_h, idx_h, ivl, 1.0, False, True, False, *tail)
+                impl.noise_weight(tod2_h, idx_h, ivl, dw_h, *tail)
+
+            return cpu_step
+
+        def time_cpu(cpu_step, budget_s):
+            cpu_step()  # warm (page-touch)
+            t0 = time.perf_counter()
+            reps = 0
+            while True:
+                cpu_step()
+                reps += 1
+                if time.perf_counter() - t0 > budget_s or reps >= 5:
+                    break
+            return (time.perf_counter() - t0) / reps
+
+        # the reference's own compiled host path (oracle/_ref, built from /root/reference's sources by
+        # oracle/ref_build.sh and shipped as a prebuilt .so) when present, else our restatement of it
+        ref = None
+        try:
+            ref = oracle.load_ref()
+        except Exception:  # an unloadable .so must not take the bench down
+            ref = None
+        t_port = time_cpu(make_step(oracle, ()), 10.0 if ref is None else 4.0)
+        sample = ("%d of the %d detectors x %d samples of the same workload; build_noise_weighted + "
+                  "scan_map(subtract) + noise_weight on the host path (cov_apply_diag excluded: map sized)"
+                  % (nd, n_det, n_samp))
+        if ref is not None:
+            t_ref = time_cpu(make_step(ref, (False,)), 8.0)
+            out["cpu_baseline"] = {
+                "value": nd * n_samp / t_ref,
+                "unit": "det-samples/s",
+                "cores": oracle.num_threads(),
+                "kind": "reference",
+                "sample": sample + "; libtoast's own kernels compiled from the reference sources (use_accel=False)",
+                "port_value": nd * n_samp / t_port,
+            }
+        else:
+            out["cpu_baseline"] = {
+                "value": nd * n_samp / t_port,
+                "unit": "det-samples/s",
+                "cores": oracle.num_threads(),
+                "kind": "port",
+                "sample": sample + "; our restatement with the reference's host parallelisation",
+            }
         del cov_h
 
     if rank == 0:
