@@ -33,6 +33,14 @@ def accel_assign_device(node_procs, node_rank, mem_gb, disabled=False):
     global _assigned
     native().accel_assign_device(int(node_procs), int(node_rank), float(mem_gb), bool(disabled))
     _assigned = True
+    # one HIP runtime, one current device: torch (device tensors handed to RCCL, the collectives'
+    # scratch tensors) must sit on the GPU the memory manager chose for this process
+    dev = int(native().accel_get_device())
+    if dev >= 0:
+        import torch
+
+        if torch.cuda.is_available() and torch.cuda.current_device() != dev:
+            torch.cuda.set_device(dev)
 
 
 def ensure_assigned():
