@@ -11,8 +11,8 @@ import numpy as np
 from ..data import defaults
 from ..pixels import PixelData
 from ..traits import Bool, Float, Instance, Int, Unicode
-from .mapmaker_ops import BinMap, Copy, CovarianceAndHits, Delete, ScanMask
-from .mapmaker_solve import SolverLHS, SolverRHS, TemplateMatrix, solve
+from .mapmaker_ops import Copy, CovarianceAndHits, Delete, ScanMask
+from .mapmaker_solve import SolverLHS, SolverRHS, solve
 from .operator import Operator
 from .pipeline import Pipeline, uncached_detector_sets
 

@@ -11,8 +11,8 @@ import numpy as np
 
 from ..data import defaults
 from ..templates import AmplitudesMap
-from ..traits import Bool, Float, ImplementationType, Instance, Int, List, Unicode
-from .mapmaker_ops import BinMap, Copy, Delete, NoiseWeight, ScanMap
+from ..traits import Bool, ImplementationType, Instance, Int, List, Unicode
+from .mapmaker_ops import Copy, Delete, NoiseWeight, ScanMap
 from .operator import Operator
 from .pipeline import Pipeline, uncached_detector_sets
 

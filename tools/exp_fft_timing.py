@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 from toast_amd import fft as hipfft
-from toast_amd.accel import ensure_assigned, native
+from toast_amd.accel import ensure_assigned
 
 ensure_assigned()
 n_det, n_samp, rate = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, 720000, 200.0

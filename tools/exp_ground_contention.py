@@ -2,7 +2,7 @@
 detectors?  Same total work, launched (a) once for all detectors into one zmap, (b) as G
 sequential launches over detector groups (fewer concurrent colliders), (c) groups into private
 zmap replicas."""
-import os, sys, time
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch

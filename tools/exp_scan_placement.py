@@ -1,5 +1,5 @@
 """Experiment: is the scan_map bimodality (6.3 vs 7.1 ms) tied to buffer placement?"""
-import os, sys, time
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from toast_amd import capi, synth
