@@ -473,6 +473,19 @@ int toast_hip_compact_pixels_dev(const int64_t * d_g2l, int64_t n_pix_submap, in
                                  int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
                                  void * stream);
 
+/* Quaternion-free pointing expansion: the results of pointing_detector + pixels_healpix
+ * (int64 pixels, -1 for flagged boresight samples, hit_submaps marked on the device) and of
+ * pointing_detector + stokes_weights_IQU / _I ([rows, n_samp, nnz] weights) written straight
+ * from the boresight; same values as the separate kernels. */
+int toast_hip_otf_pixels_healpix_dev(const toast_hip_otf_pointing * pointing, const int32_t * pixel_index,
+                                     int64_t * d_pixels, int64_t n_det, int64_t n_samp,
+                                     const toast_hip_interval * intervals, int64_t n_view,
+                                     uint8_t * d_hit_submaps, int64_t n_submap, int64_t n_pix_submap,
+                                     void * stream);
+int toast_hip_otf_stokes_weights_dev(const toast_hip_otf_pointing * pointing, const int32_t * weight_index,
+                                     double * d_weights, int64_t n_det, int64_t n_samp,
+                                     const toast_hip_interval * intervals, int64_t n_view, void * stream);
+
 /* table[i] = (cos(4 hwp[i]), sin(4 hwp[i])): the HWP modulation 2 (2 (gamma - hwp)) of
  * stokes_weights_IQU [ref: ops_stokes_weights.cpp:96-99] by angle addition from per-detector
  * cos / sin 4 gamma; d_table is 16-byte aligned, 2 n_samp doubles. */

@@ -164,7 +164,8 @@ def test_hits_covariance_and_binmap(monkeypatch):
     assert np.max(np.abs(data["binned"].data - data["zcheck"].data)) < 1e-12 * np.max(np.abs(data["zcheck"].data))
     # full_pointing=False (SINGLE pipeline: pointing recomputed per detector) gives the same map
     for key in (defaults.pixels, defaults.weights, defaults.quats):
-        del ob.detdata[key]
+        if key in ob.detdata:   # no quaternion buffer when the expansion ran on the device
+            del ob.detdata[key]
     binner2 = ops.BinMap(pixel_dist="dist", covariance="cov", binned="binned2", pixel_pointing=pix,
                          stokes_weights=sw, full_pointing=False)
     binner2.apply(data)
@@ -228,7 +229,8 @@ def make_solver_setup(n_det=4, n_samp=6000, step_time=20.0, seed=11, noise_rms=0
         sig += noise_rms * rng.standard_normal(n_samp)
         ob.detdata[defaults.det_data][det] = sig
     for key in (defaults.pixels, defaults.weights, defaults.quats):
-        del ob.detdata[key]
+        if key in ob.detdata:
+            del ob.detdata[key]
     return data, pix, sw, truth, sky
 
 
@@ -585,3 +587,25 @@ def test_build_pixel_distribution(save_pointing, monkeypatch):
     pix2.apply(data2)
     assert list(data["dist"].local_submaps) == list(data2["dist"].local_submaps)
     assert data["dist"].n_pix == data2["dist"].n_pix and data["dist"].n_pix_submap == data2["dist"].n_pix_submap
+
+
+def test_pointing_expansion_without_quaternions():
+    """On the device the pointing operators write pixels / weights straight from the boresight
+    (no [n_det, n_samp, 4] quaternion buffer); the results equal the three-kernel chain's."""
+    from toast_amd.ops.pipeline import Pipeline
+
+    out = {}
+    for skip in (True, False):
+        data = create_satellite_data(n_det=6, n_samp=5000, flagged_pixels=True)
+        dp, pix, sw = pointing_ops(nside=256, create_dist="dist")
+        pix.skip_quaternions = skip
+        sw.skip_quaternions = skip
+        Pipeline(operators=[pix, sw]).apply(data)
+        ob = data.obs[0]
+        assert (defaults.quats in ob.detdata) == (not skip)
+        out[skip] = (ob.detdata[defaults.pixels].data.copy(), ob.detdata[defaults.weights].data.copy(),
+                     list(data["dist"].local_submaps))
+    assert np.array_equal(out[True][0], out[False][0])
+    assert np.array_equal(out[True][1], out[False][1])
+    assert out[True][2] == out[False][2]
+    assert np.any(out[True][0] >= 0)

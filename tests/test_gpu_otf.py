@@ -149,6 +149,19 @@ def test_otf_matches_operator_chain(env, oracle, name, nest):
     torch.cuda.synchronize()
     assert np.max(np.abs(zc.cpu().numpy() - z)) < 1e-13 * scale
 
+    # quaternion-free expansion: same pixels / hit submaps / weights as the three-kernel chain
+    pix_q = torch.full((rows_n, n_samp), -7, dtype=torch.int64, device="cuda")
+    hs_q = torch.zeros(c["n_submap"], dtype=torch.uint8, device="cuda")
+    w_q = torch.zeros((rows_n, n_samp, 3), dtype=torch.float64, device="cuda")
+    pth, _ = _descriptor(torch, capi, c, nest, iau, 3, 1, hold, hwp_table=True)
+    D.otf_pixels_healpix(pth, c["pixel_index"], pix_q.data_ptr(), n_samp, c["intervals"], hs_q.data_ptr(),
+                         c["n_submap"], c["n_pix_submap"])
+    D.otf_stokes_weights(pth, c["weight_index"], w_q.data_ptr(), n_samp, c["intervals"])
+    torch.cuda.synchronize()
+    assert np.array_equal(pix_q.cpu().numpy(), want["pixels"])          # == the CPU oracle, bit for bit
+    assert np.array_equal(hs_q.cpu().numpy(), want["hsub"])
+    assert bool(torch.equal(w_q, weights))                               # == k_stokes_iqu, bit for bit
+
     # (iii) compact mode: int32 local pixel cache + weights on the fly
     cp = _compact(torch, capi, c, g2l, pixels, want["zmap"].shape[0])
     # ... with the per-observation HWP table (identical values: same bits as without)

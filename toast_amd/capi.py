@@ -624,6 +624,20 @@ class _Dev:
             _p(d_g2l), _i64(n_pix_submap), _i64(n_local_submap), _p(pi), _p(d_pixels), _p(ci),
             _p(d_compact_pixels), _i64(pi.size), _i64(n_samp), _p(iv), _i64(iv.size), _p(stream)))
 
+    def otf_pixels_healpix(self, pt, pixel_index, d_pixels, n_samp, intervals, d_hit_submaps, n_submap, n_pix_submap,
+                           stream=0):
+        pi = self._small(pixel_index, np.int32)
+        iv = self._small(intervals, interval_dtype)
+        _check(lib().toast_hip_otf_pixels_healpix_dev(
+            C.byref(pt), _p(pi), _p(d_pixels), _i64(pi.size), _i64(n_samp), _p(iv), _i64(iv.size), _p(d_hit_submaps),
+            _i64(n_submap), _i64(n_pix_submap), _p(stream)))
+
+    def otf_stokes_weights(self, pt, weight_index, d_weights, n_samp, intervals, stream=0):
+        wi = self._small(weight_index, np.int32)
+        iv = self._small(intervals, interval_dtype)
+        _check(lib().toast_hip_otf_stokes_weights_dev(
+            C.byref(pt), _p(wi), _p(d_weights), _i64(wi.size), _i64(n_samp), _p(iv), _i64(iv.size), _p(stream)))
+
     def hwp_table(self, d_hwp, n_samp, d_table, stream=0):
         _check(lib().toast_hip_hwp_table_dev(_p(d_hwp), _i64(n_samp), _p(d_table), _p(stream)))
 

@@ -87,7 +87,9 @@ __device__ __forceinline__ void hwp_cs4(const OtfDev & P, int64_t s, double & c4
 // flagged) and Stokes weights of one det-sample.
 //   PIX 0: the pixel is computed here (pointing_detector -> pixels_healpix -> global2local);
 //   PIX 1: the local index is read from a compact int32 cache (4 B instead of the 8 B global
-//          pixel + global2local lookup) and only the weights are evaluated on the fly.
+//          pixel + global2local lookup) and only the weights are evaluated on the fly;
+//   PIX 2: like 0 but the GLOBAL pixel number is returned (quaternion-free pixels_healpix);
+//   PIX 3: no pixel at all, weights only (quaternion-free stokes_weights).
 // c4h / s4h: cos / sin of four times the HWP angle of this time sample (MODE 2), evaluated once
 // per sample by the caller and shared by the detectors of a workgroup.
 template <bool NEST, int MODE, int PIX>
@@ -132,6 +134,8 @@ __device__ __forceinline__ int64_t otf_point(const OtfDev & P, const DetConst & 
     }
     if constexpr (PIX == 1) {
         return lidx;
+    } else if constexpr (PIX == 3) {
+        return 0;
     } else {
         // pixels_healpix
         if (flagged) return -1;
@@ -139,6 +143,7 @@ __device__ __forceinline__ int64_t otf_point(const OtfDev & P, const DetConst & 
         quat_rotate_z(r, dir);
         const ZPhi a = zphi_from_vec(dir, s_tab);
         const int64_t pix = NEST ? zphi_to_nest(P.nside, P.factor, a) : zphi_to_ring(P.nside, P.factor, a);
+        if constexpr (PIX == 2) return pix;
         const int64_t gsm = fastdiv(pix, P.nps_div);
         return P.g2l[gsm] * P.nps_div.d + (pix - gsm * P.nps_div.d);
     }
@@ -465,6 +470,61 @@ __global__ __launch_bounds__(kThreads) void k_hwp_table(int64_t n, const double 
     }
 }
 
+// ------------------------------------------------------------------------------------
+// Quaternion-free pointing expansion: the outputs of pixels_healpix / stokes_weights written
+// straight from the boresight, without the [n_det, n_samp, 4] detector-quaternion buffer in
+// between (cfg-3: 23.6 GB that is never allocated, written or read twice).
+// ------------------------------------------------------------------------------------
+template <bool NEST>
+__global__ __launch_bounds__(kThreads) void k_otf_pixels(
+    const Chunk * __restrict__ chunks, int n_chunks, OtfDev P, const int32_t * __restrict__ p_idx,
+    int64_t * __restrict__ pixels, uint8_t * __restrict__ hsub, int64_t n_samp) {
+    __shared__ double s_tab[2 * TOAST_ATAN_TABLE_N];
+    if (threadIdx.x < 2 * TOAST_ATAN_TABLE_N) s_tab[threadIdx.x] = kAtanTab[threadIdx.x];
+    __syncthreads();
+    const int det = blockIdx.x;
+    const DetConst D = det_const(P, det);
+    int64_t * prow = pixels + (int64_t)p_idx[det] * n_samp;
+    const int lane = threadIdx.x & 63;
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        for (int base = 0; base < c.count; base += kThreads) {
+            const int i = base + threadIdx.x;
+            const bool active = i < c.count;
+            const int64_t s = c.first + (active ? i : 0);
+            double w[1];
+            const int64_t pix = otf_point<NEST, 0, 2>(P, D, s, s_tab, 1.0, 0.0, w);
+            int64_t sub = (pix >= 0 && active) ? fastdiv(pix, P.nps_div) : -1;
+            const int64_t prev = __shfl_up(sub, 1);
+            if (active) {
+                prow[s] = pix;
+                if (sub >= 0 && (lane == 0 || prev != sub)) hsub[sub] = 1;
+            }
+        }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void k_otf_weights(
+    const Chunk * __restrict__ chunks, int n_chunks, OtfDev P, const int32_t * __restrict__ w_idx,
+    double * __restrict__ weights, int64_t n_samp) {
+    constexpr int NNZ = ModeNnz<MODE>::value;
+    const int det = blockIdx.x;
+    const DetConst D = det_const(P, det);
+    double * wrow = weights + (int64_t)w_idx[det] * n_samp * NNZ;
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        for (int i = threadIdx.x; i < c.count; i += kThreads) {
+            const int64_t s = c.first + i;
+            double c4h, s4h, w[NNZ];
+            hwp_cs4<MODE>(P, s, c4h, s4h);
+            (void)otf_point<true, MODE, 3>(P, D, s, nullptr, c4h, s4h, w);
+#pragma unroll
+            for (int k = 0; k < NNZ; ++k) wrow[NNZ * s + k] = w[k];
+        }
+    }
+}
+
 // boresight -> int32 local map indices directly (no int64 pixel buffer at all)
 template <bool NEST>
 __global__ __launch_bounds__(kThreads) void k_otf_compact_pixels(
@@ -647,6 +707,65 @@ int toast_hip_otf_offset_scan_project_dev(
                        h.dev, off, (const int32_t *)nullptr, (double *)nullptr, 1.0, 0, 1,
                        (const int32_t *)(d + o_fi), d_det_flags, det_flag_mask, use_f,
                        (const double *)(d + o_dw), d_map, n_samp);
+        check_launch();
+    });
+}
+
+int toast_hip_otf_pixels_healpix_dev(const toast_hip_otf_pointing * pointing, const int32_t * pixel_index,
+                                     int64_t * d_pixels, int64_t n_det, int64_t n_samp,
+                                     const toast_hip_interval * intervals, int64_t n_view,
+                                     uint8_t * d_hit_submaps, int64_t n_submap, int64_t n_pix_submap,
+                                     void * stream) {
+    return guarded([&] {
+        if (n_det <= 0) return;
+        if (n_pix_submap <= 0) fail_arg("n_pix_submap must be positive");
+        if (n_submap * n_pix_submap < 12 * pointing->nside * pointing->nside) {
+            fail_arg("hit_submaps is too short for this nside / n_pix_submap");
+        }
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        ParamBlock pb;
+        toast_hip_otf_pointing pt = *pointing;
+        pt.d_compact_pixels = nullptr;
+        pt.nnz = 1;
+        OtfHost h = otf_prepare(&pt, n_det, n_samp, n_pix_submap, nullptr, pb);
+        const size_t o_ch = pb.push_vec(chunks);
+        const size_t o_pi = pb.push(pixel_index, sizeof(int32_t) * n_det);
+        hipStream_t st = as_stream(stream);
+        const char * d = pb.commit(st);
+        otf_bind(h, d);
+        auto kern = h.nest ? k_otf_pixels<true> : k_otf_pixels<false>;
+        hipLaunchKernelGGL(kern, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0, st,
+                           (const Chunk *)(d + o_ch), (int)chunks.size(), h.dev, (const int32_t *)(d + o_pi),
+                           d_pixels, d_hit_submaps, n_samp);
+        check_launch();
+    });
+}
+
+int toast_hip_otf_stokes_weights_dev(const toast_hip_otf_pointing * pointing, const int32_t * weight_index,
+                                     double * d_weights, int64_t n_det, int64_t n_samp,
+                                     const toast_hip_interval * intervals, int64_t n_view, void * stream) {
+    return guarded([&] {
+        if (n_det <= 0) return;
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        ParamBlock pb;
+        toast_hip_otf_pointing pt = *pointing;
+        pt.d_compact_pixels = nullptr;
+        OtfHost h = otf_prepare(&pt, n_det, n_samp, 1, nullptr, pb);
+        const size_t o_ch = pb.push_vec(chunks);
+        const size_t o_wi = pb.push(weight_index, sizeof(int32_t) * n_det);
+        hipStream_t st = as_stream(stream);
+        const char * d = pb.commit(st);
+        otf_bind(h, d);
+        const dim3 grid = chunk_grid(n_det, chunks.size());
+#define TH_OTF_W(M)                                                                               \
+    hipLaunchKernelGGL(k_otf_weights<M>, grid, dim3(kThreads), 0, st, (const Chunk *)(d + o_ch),  \
+                       (int)chunks.size(), h.dev, (const int32_t *)(d + o_wi), d_weights, n_samp)
+        if (h.mode == 0) TH_OTF_W(0);
+        else if (h.mode == 1) TH_OTF_W(1);
+        else TH_OTF_W(2);
+#undef TH_OTF_W
         check_launch();
     });
 }

@@ -122,7 +122,7 @@ def otf_descriptor(ob, dets, pixels_op, weights_op, compact=None):
     from .. import capi
     from ..accel import accel_device_ptr
 
-    dp = pixels_op.detector_pointing
+    dp = (pixels_op if pixels_op is not None else weights_op).detector_pointing
     _shared_to(ob, dp.boresight, True)
     bore = accel_device_ptr(ob.shared[dp.boresight].data)
     n_samp = ob.n_local_samples
@@ -132,9 +132,9 @@ def otf_descriptor(ob, dets, pixels_op, weights_op, compact=None):
         d_flags, n_flags = accel_device_ptr(ob.shared[dp.shared_flags].data), n_samp
     focalplane = ob.telescope.focalplane
     fp_quats = np.array([focalplane[d]["quat"] for d in dets], dtype=np.float64).reshape(len(dets), 4)
-    nnz = len(weights_op.mode)
+    nnz = len(weights_op.mode) if weights_op is not None else 1
     eps = np.array([focalplane[d]["pol_leakage"] for d in dets], dtype=np.float64)
-    cal = (np.ones(len(dets)) if weights_op.cal is None
+    cal = (np.ones(len(dets)) if weights_op is None or weights_op.cal is None
            else np.array([ob[weights_op.cal][x] for x in dets], np.float64))
     gamma = np.zeros(len(dets), dtype=np.float64)
     d_hwp, n_hwp, extra_tab = 0, 0, 0
@@ -163,9 +163,26 @@ def otf_descriptor(ob, dets, pixels_op, weights_op, compact=None):
         extra = dict(d_compact_pixels=accel_device_ptr(compact.buffer), compact_index=compact.indices(dets))
     if extra_tab:
         extra["d_hwp_table"] = extra_tab
-    return capi.otf_pointing(bore, fp_quats, pixels_op.nside, pixels_op.nest, nnz, d_shared_flags=d_flags,
+    nside, nest = (pixels_op.nside, pixels_op.nest) if pixels_op is not None else (1, True)
+    iau = bool(weights_op.IAU) if weights_op is not None else False
+    return capi.otf_pointing(bore, fp_quats, nside, nest, nnz, d_shared_flags=d_flags,
                              n_shared_flags=n_flags, shared_flag_mask=dp.shared_flag_mask, d_hwp=d_hwp, n_hwp=n_hwp,
-                             epsilon=eps, gamma=gamma, cal=cal, IAU=bool(weights_op.IAU), **extra)
+                             epsilon=eps, gamma=gamma, cal=cal, IAU=iau, **extra)
+
+
+def _skip_quaternions(op, data, detectors, use_accel):
+    """True when this pointing operator can write its output straight from the boresight
+    (toast_hip_otf_pixels_healpix_dev / _stokes_weights_dev): device-resident run, the plain
+    detector pointing, and no detector quaternions lying around that we would be expected to use."""
+    dp = op.detector_pointing
+    if not (use_accel and op.skip_quaternions and isinstance(dp, PointingDetectorSimple)):
+        return False
+    if dp.coord_in is not None and dp.coord_in != dp.coord_out:
+        return False
+    for ob in data.obs:
+        if dp.quats in ob.detdata:
+            return False
+    return True
 
 
 def compact_pixel_cache(ob, dets, pixels_op, weights_op, dist, d_g2l):
@@ -228,6 +245,8 @@ class PixelsHealpix(Operator):
     create_dist = Unicode(None, allow_none=True,
                           help="Create the submap distribution for all detectors and store in the Data key specified")
     single_precision = Bool(False, help="If True, use 32bit int in output")
+    skip_quaternions = Bool(True, help="On the accelerator, compute the pixels straight from the boresight "
+                                       "without materialising detector quaternions (not a reference trait)")
 
     def _validate_detector_pointing(self, op):
         return _check_detector_pointing(op, ["view", "boresight", "shared_flags", "shared_flag_mask", "det_mask",
@@ -289,7 +308,8 @@ class PixelsHealpix(Operator):
         view = self.view if self.view is not None else self.detector_pointing.view
         # (the reference expands detector pointing unconditionally, pixels_healpix.py:162; when
         # the pixels are cached there is nothing to feed and the quaternions may be gone)
-        if not _outputs_exist(data, self.pixels, detectors, self.detector_pointing.det_mask):
+        no_quats = _skip_quaternions(self, data, detectors, use_accel)
+        if not no_quats and not _outputs_exist(data, self.pixels, detectors, self.detector_pointing.det_mask):
             self.detector_pointing.apply(data, detectors=detectors, use_accel=use_accel)
         for ob in data.obs:
             dets = ob.select_local_detectors(detectors, flagmask=self.detector_pointing.det_mask)
@@ -316,6 +336,11 @@ class PixelsHealpix(Operator):
                 continue
             if len(dets) == 0:
                 continue
+            if no_quats:
+                self._exec_from_boresight(ob, dets, view, hit_submaps)
+                if self._local_submaps is not None:
+                    self._local_submaps[:] |= hit_submaps
+                continue
             quat_indx = ob.detdata[quats_name].indices(dets)
             pix_indx = ob.detdata[self.pixels].indices(dets)
             if self.detector_pointing.shared_flags is None:
@@ -328,6 +353,29 @@ class PixelsHealpix(Operator):
                                     bool(self.nest), use_accel)
             if self._local_submaps is not None:
                 self._local_submaps[:] |= hit_submaps
+
+    def _exec_from_boresight(self, ob, dets, view, hit_submaps):
+        """pointing_detector + pixels_healpix in one kernel, no quaternion buffer.  ``hit_submaps``
+        is the host in/out array of the reference interface: staged through the memory manager."""
+        from .. import capi
+        from ..accel import (accel_data_create, accel_data_delete, accel_data_update_device, accel_data_update_host,
+                             accel_device_ptr)
+
+        pt = otf_descriptor(ob, dets, self, None)
+        pd = ob.detdata[self.pixels]
+        hs = np.ascontiguousarray(hit_submaps)
+        accel_data_create(hs, "hit_submaps")
+        try:
+            accel_data_update_device(hs, "hit_submaps")
+            capi.dev.otf_pixels_healpix(pt, pd.indices(dets), accel_device_ptr(pd.buffer), ob.n_local_samples,
+                                        ob.intervals[view].data, accel_device_ptr(hs), self._n_submap,
+                                        self._n_pix_submap)
+            accel_data_update_host(hs, "hit_submaps")
+        finally:
+            accel_data_delete(hs, "hit_submaps")
+        if hs is not hit_submaps:
+            hit_submaps[:] = hs
+        pd.accel_used(True)
 
     def _finalize(self, data, use_accel=None, **kwargs):
         if self.create_dist is not None:
@@ -373,6 +421,8 @@ class StokesWeights(Operator):
     cal = Unicode(None, allow_none=True, help="The observation key with a dictionary of pointing weight calibration")
     single_precision = Bool(False, help="If True, use 32bit float in output")
     IAU = Bool(False, help="If True, use the IAU convention rather than COSMO")
+    skip_quaternions = Bool(True, help="On the accelerator, compute the weights straight from the boresight "
+                                       "without materialising detector quaternions (not a reference trait)")
 
     def _validate_detector_pointing(self, op):
         return _check_detector_pointing(op, ["view", "boresight", "shared_flags", "shared_flag_mask", "det_mask",
@@ -394,13 +444,24 @@ class StokesWeights(Operator):
             raise RuntimeError("If using HWP, you must specify the fp_gamma key")
         quats_name = self.detector_pointing.quats
         view = self.view if self.view is not None else self.detector_pointing.view
-        if not _outputs_exist(data, self.weights, detectors, self.detector_pointing.det_mask):
+        no_quats = _skip_quaternions(self, data, detectors, use_accel)
+        if not no_quats and not _outputs_exist(data, self.weights, detectors, self.detector_pointing.det_mask):
             self.detector_pointing.apply(data, detectors=detectors, use_accel=use_accel)
         for ob in data.obs:
             dets = ob.select_local_detectors(detectors, flagmask=self.detector_pointing.det_mask)
             exists = ob.detdata.ensure(self.weights, sample_shape=(nnz,), dtype=np.float64, detectors=dets,
                                        accel=use_accel)
             if exists or len(dets) == 0:
+                continue
+            if no_quats:
+                from .. import capi
+                from ..accel import accel_device_ptr
+
+                pt = otf_descriptor(ob, dets, None, self)
+                wd = ob.detdata[self.weights]
+                capi.dev.otf_stokes_weights(pt, wd.indices(dets), accel_device_ptr(wd.buffer), ob.n_local_samples,
+                                            ob.intervals[view].data)
+                wd.accel_used(True)
                 continue
             quat_indx = ob.detdata[quats_name].indices(dets)
             weight_indx = ob.detdata[self.weights].indices(dets)
