@@ -183,6 +183,13 @@ def main():
     sw_call()
     t_sw = timed(sw_call, 2)
     del d_quats
+    # the same two outputs straight from the boresight (no quaternion buffer)
+    pt_x = capi.otf_pointing(d_bore.data_ptr(), fp, nside, True, nnz, d_shared_flags=d_sflags.data_ptr(),
+                             n_shared_flags=n_samp, shared_flag_mask=1, epsilon=np.zeros(n_det), gamma=gamma,
+                             cal=np.ones(n_det), d_hwp=hwp_ptr, n_hwp=hwp_n, d_hwp_table=hwp_tab_ptr)
+    t_pix_x = timed(lambda: D.otf_pixels_healpix(pt_x, idx, d_pixels.data_ptr(), n_samp, ivl, d_hsub.data_ptr(),
+                                                 n_submap, nps, stream), 2)
+    t_sw_x = timed(lambda: D.otf_stokes_weights(pt_x, idx, d_weights.data_ptr(), n_samp, ivl, stream), 2)
 
     # union of hit submaps over ranks -> one global2local for everybody
     hs = d_hsub.to(torch.int32)
@@ -341,6 +348,9 @@ def main():
             "pixels_healpix_Gsamp_s": nsamp_tot / t_pix / 1e6,
             "pixels_healpix_GBs": 40.0 * nsamp_tot / t_pix / 1e6,
             "stokes_weights_IQU_Gsamp_s": nsamp_tot / t_sw / 1e6,
+            "three_kernel_chain_ms": t_pd + t_pix + t_sw,
+            "from_boresight_pixels_ms": t_pix_x,
+            "from_boresight_weights_ms": t_sw_x,
         },
         "setup_s": t_setup,
     }
