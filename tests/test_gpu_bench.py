@@ -1,0 +1,43 @@
+"""GPU: bench.py honours its output contract (one JSON line with the driver's keys, the roofline
+and cpu_baseline objects) on the small workload."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_contract_small_workload():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                          "--workload", "mini", "--cpu-dets", "4", "--pcg-extra"], capture_output=True, text=True,
+                         timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["dtype"] == "f64"
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["unit"] == "det-samples/s" and d["value"] > 0 and d["ms_per_step"] > 0
+    assert d["config"]["workload"] == "mini"
+    r = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in r, key
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    c = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in c, key
+    assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] >= 1
+    # value == whole-job units / time
+    n = d["config"]["detectors_per_gpu"] * d["config"]["samples_per_detector"]
+    assert abs(d["value"] - n / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    # the fused / on-the-fly variants agree with the operator sequence
+    assert d["pcg_lhs_offset_templates"]["fused_vs_sequence_max_rel_diff"] < 1e-12
+    assert d["pointing_on_the_fly"]["offset_lhs_vs_sequence_max_rel_diff"] < 1e-12
+    assert d["compact_pixels_weights_on_the_fly"]["offset_lhs_vs_sequence_max_rel_diff"] < 1e-12
