@@ -534,6 +534,14 @@ int toast_hip_otf_offset_scan_project_dev(
     const double * det_weights, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals,
     int64_t n_view, void * stream);
 
+/* counts[amplitude] += number of samples under that offset amplitude with (det_flags & flag_mask) != 0
+ * (as doubles; the caller zeroes d_counts): the input of the good-fraction cut and of the
+ * preconditioner variances in Offset initialisation [ref: src/toast/templates/offset/offset.py:262-343]. */
+int toast_hip_offset_count_flagged_dev(int64_t step_length, const int64_t * amp_offsets,
+                                       const int64_t * n_amp_views, double * d_counts, const int32_t * flag_index,
+                                       const uint8_t * d_det_flags, uint8_t flag_mask, int64_t n_det, int64_t n_samp,
+                                       const toast_hip_interval * intervals, int64_t n_view, void * stream);
+
 /* Solver flags [ref: src/toast/ops/mapmaker_templates.py:764-810]: for the samples inside the
  * intervals  out[out_index[d]][s] = ((det_flags[flag_index[d]][s] & det_flag_mask) != 0) |
  * ((shared_flags[s] & shared_flag_mask) != 0);  the optional inputs are absent when their length

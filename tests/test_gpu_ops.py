@@ -609,3 +609,31 @@ def test_pointing_expansion_without_quaternions():
     assert np.array_equal(out[True][1], out[False][1])
     assert out[True][2] == out[False][2]
     assert np.any(out[True][0] >= 0)
+
+
+def test_offset_initialisation_device_equals_host():
+    """Offset amplitude flags / preconditioner variances from the device flag counts
+    (toast_hip_offset_count_flagged_dev) equal the reference's per-detector host loop
+    (offset.py:262-343), for several views, a ragged last baseline and a dead detector."""
+    from toast_amd import synth
+
+    data = create_satellite_data(n_det=6, n_samp=7013, flagged_pixels=True)
+    ob = data.obs[0]
+    from toast_amd.data import IntervalList
+
+    ob.intervals["scan"] = IntervalList(data=synth.make_intervals(7013, n_split=3, rate=10.0, gap=17))
+    rng = np.random.default_rng(5)
+    fl = ob.detdata[defaults.det_flags].data
+    fl[:] = (rng.random(fl.shape) < 0.3).astype(np.uint8) * 5
+    fl[2, 1000:1800] = 1                      # baselines cut by the good fraction
+    tmpl = Offset(step_time=7.3, noise_model=defaults.noise_model, name="baselines", good_fraction=0.6,
+                  view="scan", det_flag_mask=1)
+    tmpl.det_data = defaults.det_data
+    tmpl.data = data                          # initialises on the device (an accelerator is in use)
+    flags_dev, var_dev = tmpl._amp_flags.copy(), tmpl._offsetvar.copy()
+    assert 0 < flags_dev.sum() < flags_dev.size
+    tmpl._amp_flags[:] = 0
+    tmpl._offsetvar[:] = 0
+    tmpl._init_variances_host(data)
+    assert np.array_equal(flags_dev, tmpl._amp_flags)
+    assert np.array_equal(var_dev, tmpl._offsetvar)

@@ -696,6 +696,16 @@ class _Dev:
             _p(d_g2l), _p(d_mask), _i64(n_pix_submap), _u8(mask_bits), _u8(flag_value), _p(pi), _p(d_pixels), _p(fi),
             _p(d_det_flags), _i64(pi.size), _i64(n_samp), _p(iv), _i64(iv.size), _p(stream)))
 
+    def offset_count_flagged(self, step_length, amp_offsets, n_amp_views, d_counts, flag_index, d_det_flags, flag_mask,
+                             n_samp, intervals, stream=0):
+        ao = self._small(amp_offsets, np.int64)
+        nv = self._small(n_amp_views, np.int64)
+        fi = self._small(flag_index, np.int32)
+        iv = self._small(intervals, interval_dtype)
+        _check(lib().toast_hip_offset_count_flagged_dev(
+            _i64(step_length), _p(ao), _p(nv), _p(d_counts), _p(fi), _p(d_det_flags), _u8(flag_mask), _i64(ao.size),
+            _i64(n_samp), _p(iv), _i64(iv.size), _p(stream)))
+
     def combine_flags(self, d_out, out_index, d_det_flags, n_flag_samp, flag_index, det_flag_mask, d_shared_flags,
                       n_shared_flags, shared_flag_mask, n_samp, intervals, n_out_rows=0, outside_value=-1, stream=0):
         oi = self._small(out_index, np.int32)

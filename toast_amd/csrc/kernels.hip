@@ -761,6 +761,35 @@ __global__ __launch_bounds__(kThreads) void k_offset_project_signal(
     }
 }
 
+// Number of flagged samples under every offset amplitude (the good-fraction cut and the
+// preconditioner variances of Offset._initialize, offset.py:262-343), as doubles.
+__global__ __launch_bounds__(kThreads) void k_offset_count_flagged(
+    const Chunk * __restrict__ chunks, int n_chunks, const int64_t * __restrict__ view_first,
+    const int64_t * __restrict__ view_aoff, FastDiv step_div, const int64_t * __restrict__ amp_offsets,
+    const int32_t * __restrict__ f_idx, double * __restrict__ counts, const uint8_t * __restrict__ flags,
+    uint8_t fmask, int64_t n_samp) {
+    const int det = blockIdx.x;
+    const uint8_t * frow = flags + (int64_t)f_idx[det] * n_samp;
+    const int64_t amp_offset = amp_offsets[det];
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        const int64_t vfirst = view_first[c.view];
+        const int64_t abase = amp_offset + view_aoff[c.view];
+        for (int base = 0; base < c.count; base += kThreads) {
+            const int i = base + threadIdx.x;
+            int64_t key = -1;
+            double v[1] = {0.0};
+            if (i < c.count) {
+                const int64_t s = c.first + i;
+                key = abase + fastdiv(s - vfirst, step_div);
+                v[0] = ((frow[s] & fmask) != 0) ? 1.0 : 0.0;
+            }
+            const bool tail = wave_run_reduce<1>(key, v);
+            if (tail && key >= 0 && v[0] != 0.0) unsafeAtomicAdd(counts + key, v[0]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // Fused PCG left-hand side for offset templates (SolverLHS, src/toast/ops/mapmaker_solve.py:
 // 342-506, with the Offset template kernels template_offset.cpp:93-120 / :243-290):
@@ -1532,6 +1561,32 @@ int toast_hip_scan_mask_dev(const int64_t * d_g2l, const uint8_t * d_mask, int64
                            as_stream(stream), (const Chunk *)(d + o_ch), (int)chunks.size(),
                            (const int32_t *)(d + o_pi), (const int32_t *)(d + o_fi), d_g2l, d_mask,
                            mask_bits, flag_value, d_pixels, d_det_flags, make_fastdiv(n_pix_submap), n_samp);
+        check_launch();
+    });
+}
+
+int toast_hip_offset_count_flagged_dev(int64_t step_length, const int64_t * amp_offsets,
+                                       const int64_t * n_amp_views, double * d_counts, const int32_t * flag_index,
+                                       const uint8_t * d_det_flags, uint8_t flag_mask, int64_t n_det, int64_t n_samp,
+                                       const toast_hip_interval * intervals, int64_t n_view, void * stream) {
+    return guarded([&] {
+        if (n_det <= 0) return;
+        if (step_length <= 0) fail_arg("step_length must be positive");
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        const OffsetViews ov = offset_views(intervals, n_amp_views, n_view);
+        ParamBlock pb;
+        const size_t o_ch = pb.push_vec(chunks);
+        const size_t o_vf = pb.push_vec(ov.first);
+        const size_t o_va = pb.push_vec(ov.aoff);
+        const size_t o_ao = pb.push(amp_offsets, sizeof(int64_t) * n_det);
+        const size_t o_fi = pb.push(flag_index, sizeof(int32_t) * n_det);
+        hipStream_t st = as_stream(stream);
+        const char * d = pb.commit(st);
+        hipLaunchKernelGGL(k_offset_count_flagged, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0, st,
+                           (const Chunk *)(d + o_ch), (int)chunks.size(), (const int64_t *)(d + o_vf),
+                           (const int64_t *)(d + o_va), make_fastdiv(step_length), (const int64_t *)(d + o_ao),
+                           (const int32_t *)(d + o_fi), d_counts, d_det_flags, flag_mask, n_samp);
         check_launch();
     });
 }

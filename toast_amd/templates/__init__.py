@@ -380,7 +380,67 @@ class Offset(Template):
             self._n_global = int(comm.allreduce_scalar(self._n_local, op="sum"))
         self._amp_flags = np.zeros(self._n_local, dtype=np.uint8)
         self._offsetvar = np.zeros(self._n_local, dtype=np.float64)
+        self._amp_offset_cache = {}
         # offset variance / flags: offset.py:262-343
+        from ..accel import accel_enabled
+
+        if accel_enabled() and self._n_local > 0:
+            self._init_variances_device(new_data)
+        else:
+            self._init_variances_host(new_data)
+        self._flag_cache = {}
+
+    def _init_variances_device(self, new_data):
+        """Per-amplitude counts of flagged samples from one kernel over the resident flags
+        (toast_hip_offset_count_flagged_dev), the rest vectorised over all amplitudes."""
+        from .. import capi
+
+        bad = Amplitudes(None, self._n_local, self._n_local)
+        bad.accel_create(f"{self.name}_badcount", zero_out=True)
+        bad.accel_used(True)
+        amplen = np.zeros(self._n_local, dtype=np.int64)
+        detnoise = np.ones(self._n_local, dtype=np.float64)
+        for iob, ob in enumerate(new_data.obs):
+            dets = [d for d in self._all_dets if d in self._obs_dets[iob]]
+            if len(dets) == 0:
+                continue
+            step_length = self._step_length(self.step_time, self._obs_rate[iob])
+            # lengths of the baselines of one detector of this observation, view after view
+            lens = []
+            for ivw, vw in enumerate(ob.intervals[self.view]):
+                n_amp_view = int(self._obs_views[iob][ivw])
+                if n_amp_view == 0:
+                    continue
+                a = np.full(n_amp_view, step_length, dtype=np.int64)
+                a[-1] = (vw.last - vw.first) - (n_amp_view - 1) * step_length
+                lens.append(a)
+            lens = np.concatenate(lens) if lens else np.zeros(0, dtype=np.int64)
+            offs = self.det_amp_offsets(iob, dets)
+            idx = (offs[:, None] + np.arange(lens.size, dtype=np.int64)[None, :]).ravel()
+            amplen[idx] = np.tile(lens, len(dets))
+            if self.noise_model is not None:
+                w = np.array([ob[self.noise_model].detector_weight(d) for d in dets], dtype=np.float64)
+                detnoise[idx] = np.repeat(w, lens.size)
+            if self.det_flags is not None:
+                fd = ob.detdata[self.det_flags]
+                if not fd.accel_in_use():
+                    if not fd.accel_exists():
+                        fd.accel_create(self.det_flags)
+                    fd.accel_update_device()
+                capi.dev.offset_count_flagged(step_length, offs, self._obs_views[iob], accel_device_ptr(bad.local),
+                                              fd.indices(dets), accel_device_ptr(fd.buffer), self.det_flag_mask,
+                                              ob.n_local_samples, ob.intervals[self.view].data)
+        bad.accel_update_host()
+        bad.clear()
+        n_good = amplen - np.rint(bad.local).astype(np.int64)
+        dead = detnoise <= 0
+        with np.errstate(divide="ignore", invalid="ignore"):
+            cut = ((n_good / np.maximum(amplen, 1)) <= self.good_fraction) | dead | (amplen == 0)
+            var = 1.0 / (detnoise * n_good)
+        self._amp_flags[cut] = 1
+        self._offsetvar[:] = np.where(cut, 0.0, var)
+
+    def _init_variances_host(self, new_data):
         offset = 0
         for det in self._all_dets:
             for iob, ob in enumerate(new_data.obs):
@@ -412,9 +472,6 @@ class Offset(Template):
                             var = 1.0 / (detnoise * n_good)
                         self._offsetvar[sl] = np.where(cut, 0.0, var)
                     offset += n_amp_view
-        self._flag_cache = {}
-        self._amp_offset_cache = {}
-
     def _detectors(self):
         return self._all_dets
 
