@@ -637,3 +637,31 @@ def test_offset_initialisation_device_equals_host():
     tmpl._init_variances_host(data)
     assert np.array_equal(flags_dev, tmpl._amp_flags)
     assert np.array_equal(var_dev, tmpl._offsetvar)
+
+
+def test_mapmaker_two_observations_fused_equals_operator_sequence():
+    """Two observations of different length (amplitude blocks interleave per detector,
+    offset.py:727-760): the fused device path and the reference operator sequence agree, cached
+    and uncached."""
+    res = {}
+    for key, kw in (("seq", dict(fused_lhs=False, full=True)), ("fused", dict(fused_lhs=True, full=True)),
+                    ("otf", dict(fused_lhs=True, full=False))):
+        data, pix, sw, truth, sky = make_solver_setup(noise_rms=0.1, n_det=4, n_samp=5000, seed=3)
+        data2, _, _, _, _ = make_solver_setup(noise_rms=0.1, n_det=4, n_samp=3100, seed=4)
+        ob2 = data2.obs[0]
+        ob2.name = "second"
+        data.obs.append(ob2)
+        binner = ops.BinMap(pixel_dist="dist", pixel_pointing=pix, stokes_weights=sw, full_pointing=kw["full"])
+        tmpl = Offset(step_time=13.0, noise_model=defaults.noise_model, name="baselines", good_fraction=0.2)
+        mapper = ops.MapMaker(name="mm", det_data=defaults.det_data, binning=binner,
+                              template_matrix=ops.TemplateMatrix(templates=[tmpl]), iter_max=10, convergence=1e-30,
+                              solve_rcond_threshold=1e-3, map_rcond_threshold=1e-3, fused_lhs=kw["fused_lhs"])
+        mapper.apply(data)
+        res[key] = (data["mm_amplitudes"]["baselines"].local.copy(), data["mm_map"].data.copy(),
+                    np.array(mapper.history))
+    n_amp = res["seq"][0].size
+    assert n_amp == 4 * (-(-5000 // 130) + -(-3100 // 130))
+    for key in ("fused", "otf"):
+        np.testing.assert_allclose(res[key][2][:5], res["seq"][2][:5], rtol=1e-6)
+        assert np.max(np.abs(res[key][0] - res["seq"][0])) < 1e-7 * np.max(np.abs(res["seq"][0]))
+        assert np.max(np.abs(res[key][1] - res["seq"][1])) < 1e-7 * np.max(np.abs(res["seq"][1]))
