@@ -91,3 +91,54 @@ def test_data_stage():
         assert not ob.detdata[name].accel_exists() and not ob.shared[name].accel_exists()
     assert not data["test_pix"].accel_exists()
     assert defaults.det_data in ob.detdata   # untouched objects stay where they were
+
+
+_EVICT_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from toast_amd import ops
+from toast_amd.data import defaults
+from toast_amd.ops.pipeline import Pipeline
+from toast_amd.sim import create_satellite_data
+
+data = create_satellite_data(n_det=4, n_samp=100000)
+dp = ops.PointingDetectorSimple()
+pix = ops.PixelsHealpix(detector_pointing=dp, nside=64, skip_quaternions=False)
+sw = ops.StokesWeights(detector_pointing=dp, mode="IQU", skip_quaternions=False)
+Pipeline(operators=[dp, pix, sw]).apply(data)          # quats 12.8 MB + pixels 3.2 MB + weights 9.6 MB stay resident
+ob = data.obs[0]
+resident = [k for k in (defaults.quats, defaults.pixels, defaults.weights) if ob.detdata[k].accel_in_use()]
+Pipeline(operators=[ops.Copy(detdata=[(defaults.det_data, "copy")])]).apply(data)   # + 2 x 3.2 MB
+after = [k for k in (defaults.quats, defaults.pixels, defaults.weights) if ob.detdata[k].accel_exists()]
+chk = [float(np.sum(ob.detdata[k].data.astype(np.float64))) for k in (defaults.quats, defaults.pixels, defaults.weights)]
+same = bool(np.array_equal(ob.detdata["copy"].data, ob.detdata[defaults.det_data].data))
+print("RESULT", len(resident), len(after), same, *chk)
+"""
+
+
+def test_eviction_under_memory_cap(tmp_path):
+    """A failed device allocation evicts lazily retained detector data (written back to the host
+    first) and retries: run once unconstrained and once with the manager capped at 28 MB
+    (TOAST_HIP_MEM_LIMIT_MB), same results."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "evict.py"
+    script.write_text(_EVICT_SCRIPT)
+    out = {}
+    for limit in (None, "28"):
+        env = dict(os.environ)
+        env.pop("TOAST_HIP_MEM_LIMIT_MB", None)
+        if limit:
+            env["TOAST_HIP_MEM_LIMIT_MB"] = limit
+        res = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, env=env, timeout=600)
+        assert res.returncode == 0, res.stderr[-3000:]
+        line = [ln for ln in res.stdout.splitlines() if ln.startswith("RESULT")][0].split()
+        out[limit] = line[1:]
+    free, capped = out[None], out["28"]
+    assert free[0] == "3" and free[1] == "3" and free[2] == "True"          # nothing evicted without a cap
+    assert capped[0] == "3" and int(capped[1]) < 3 and capped[2] == "True"  # something had to go
+    assert free[3:] == capped[3:]                                           # and came back intact

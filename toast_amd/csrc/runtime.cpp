@@ -152,6 +152,7 @@ void Manager::clear() {
         if (kv.second.owned) (void)hipFree(kv.second.dev);
     }
     table_.clear();
+    owned_bytes_ = 0;
 }
 
 void Manager::assign_device(int node_procs, int node_rank, double /*mem_gb*/, bool disabled) {
@@ -241,8 +242,17 @@ void * Manager::create(const void * host, size_t nbytes, const char * name) {
     }
     const double t0 = trace_begin();
     void * dev = nullptr;
-    hipError_t e = hipMalloc(&dev, nbytes ? nbytes : 16);
+    // TOAST_HIP_MEM_LIMIT_MB: cap on the bytes this manager may hold (the role of the reference's
+    // per-process pool size, accelerator.cpp:262-300); exceeding it fails like an exhausted device,
+    // which is what lets callers exercise their eviction paths on a 288 GB part.
+    static const size_t limit = [] {
+        const char * s = std::getenv("TOAST_HIP_MEM_LIMIT_MB");
+        return (s != nullptr && std::atol(s) > 0) ? (size_t)std::atol(s) << 20 : (size_t)0;
+    }();
+    hipError_t e = hipErrorOutOfMemory;
+    if (limit == 0 || owned_bytes_ + nbytes <= limit) e = hipMalloc(&dev, nbytes ? nbytes : 16);
     if (e != hipSuccess || dev == nullptr) {
+        (void)hipGetLastError();
         std::ostringstream o;
         o << "HipManager:  on create, host ptr " << host << " with " << nbytes << " bytes (name='"
           << (name ? name : "NA") << "') on device " << device_ << ", allocation failed";
@@ -250,6 +260,7 @@ void * Manager::create(const void * host, size_t nbytes, const char * name) {
     }
     Entry ent{dev, nbytes, name ? name : "NA", true};
     table_[host] = ent;
+    owned_bytes_ += nbytes;
     trace("create", ent.name, nbytes, t0);
     return dev;
 }
@@ -334,7 +345,10 @@ void Manager::remove(const void * host, size_t nbytes, const char * name) {
     const double t0 = trace_begin();
     TH_HIP(hipStreamSynchronize(stream_));
     if (e.host_registered) (void)hipHostUnregister(const_cast<void *>(host));
-    if (e.owned) TH_HIP(hipFree(e.dev));
+    if (e.owned) {
+        TH_HIP(hipFree(e.dev));
+        owned_bytes_ -= (e.nbytes <= owned_bytes_) ? e.nbytes : owned_bytes_;
+    }
     trace("delete", e.name, nbytes, t0);
     table_.erase(host);
 }

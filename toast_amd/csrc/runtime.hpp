@@ -130,6 +130,7 @@ private:
 
     std::unordered_map<const void *, Entry> table_;
     bool assigned_ = false;
+    size_t owned_bytes_ = 0;
     int device_ = -1;
     hipStream_t stream_ = nullptr;
 };
