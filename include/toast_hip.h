@@ -66,6 +66,10 @@ const char * toast_hip_version(void);
 
 /* Number of usable HIP devices > 0.  [ref: accelerator.cpp:770-779 accel_enabled] */
 int toast_hip_accel_enabled(void);
+/* Counter bumped by every create / adopt / delete / assign_device of the memory manager: while it
+ * is unchanged, device pointers obtained earlier are still the ones the manager would return
+ * (lets a caller replay a prepared launch sequence without looking everything up again). */
+int toast_hip_accel_generation(uint64_t * generation);
 
 /* Pick this process's GPU: device = node_rank / ceil(node_procs / n_device).  `disabled`
  * != 0 refuses all later use_accel work.  Clears previously registered buffers.
@@ -427,6 +431,7 @@ int toast_hip_scan_mask_dev(const int64_t * d_global2local, const uint8_t * d_ma
 
 /* Device-to-device copy on the stream (Copy operator on resident buffers). */
 int toast_hip_copy_dev(void * d_dst, const void * d_src, size_t nbytes, void * stream);
+int toast_hip_memset_dev(void * d_dst, int value, size_t nbytes, void * stream);
 
 /* ------------------------------------------------------------------------------------
  * Pointing on the fly: the accumulate / scan kernels evaluate

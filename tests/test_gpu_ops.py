@@ -665,3 +665,46 @@ def test_mapmaker_two_observations_fused_equals_operator_sequence():
         np.testing.assert_allclose(res[key][2][:5], res["seq"][2][:5], rtol=1e-6)
         assert np.max(np.abs(res[key][0] - res["seq"][0])) < 1e-7 * np.max(np.abs(res["seq"][0]))
         assert np.max(np.abs(res[key][1] - res["seq"][1])) < 1e-7 * np.max(np.abs(res["seq"][1]))
+
+
+def test_fused_lhs_plan_replay_and_invalidation():
+    """The recorded launch plan of the fused LHS is replayed while nothing changed and rebuilt
+    when the memory manager's generation changes (here: cached pointing evicted in between)."""
+    from toast_amd import capi
+    from toast_amd.templates import AmplitudesMap
+
+    data, pix, sw, truth, sky = make_solver_setup(n_det=6, n_samp=9000)
+    ops.CovarianceAndHits(pixel_dist="dist", covariance="cov", pixel_pointing=pix, stokes_weights=sw,
+                          save_pointing=True).apply(data)
+    lhs_bin = ops.BinMap(pixel_dist="dist", covariance="cov", binned="lhs_bin", pixel_pointing=pix, stokes_weights=sw,
+                         full_pointing=True)
+    tmpl = Offset(step_time=7.3, noise_model=defaults.noise_model, name="baselines", good_fraction=0.2)
+    tmatrix = ops.TemplateMatrix(templates=[tmpl], amplitudes="amps_in", det_data="temp_LHS")
+    tmatrix.initialize(data)
+    amps = tmpl.zeros()
+    amps.local[:] = np.random.default_rng(3).standard_normal(amps.n_local)
+    data["amps_in"] = AmplitudesMap(baselines=amps)
+    data["lhs_out"] = data["amps_in"].duplicate()
+    lhs = ops.SolverLHS(binning=lhs_bin, template_matrix=tmatrix, out="lhs_out", fused=True)
+    lhs.keep_on_device = True
+    def result():
+        o = data["lhs_out"]["baselines"]
+        o.accel_update_host()          # no device allocation: the manager's generation is unchanged
+        return o.local.copy()
+
+    outs = []
+    lhs.apply(data)
+    plan0 = lhs._fused_plan
+    outs.append(result())
+    lhs.apply(data)
+    assert lhs._fused_plan is plan0                      # replayed
+    outs.append(result())
+    gen = capi.accel_generation()
+    assert data.accel_evict() > 0                        # pixels / weights leave the device
+    assert capi.accel_generation() != gen
+    lhs.apply(data)
+    assert lhs._fused_plan is not plan0                  # rebuilt with the new device pointers
+    outs.append(result())
+    assert np.max(np.abs(outs[0])) > 0
+    for o in outs[1:]:
+        assert np.max(np.abs(o - outs[0])) < 1e-12 * np.max(np.abs(outs[0]))

@@ -40,9 +40,64 @@ _MAP_CODES = {
 _lib = None
 
 
+class CallPlan:
+    """A recorded sequence of C-ABI calls with their fully converted arguments: the host-side
+    analogue of a captured graph.  ``capture()`` records instead of executing; ``replay()``
+    issues the calls.  The small host arrays the calls point at are kept alive with the plan
+    (the library copies them into its cached parameter blocks at every call)."""
+
+    def __init__(self):
+        self.calls = []
+        self.keep = []
+
+    def replay(self):
+        for fn, args in self.calls:
+            if fn(*args) != 0:
+                raise RuntimeError(_lib.toast_hip_last_error().decode())
+
+
+class _Recorder:
+    def __init__(self, plan):
+        self._plan = plan
+
+    def __getattr__(self, name):
+        real = getattr(_lib, name)
+        plan = self._plan
+
+        def record(*args):
+            plan.calls.append((real, args))
+            return 0
+
+        return record
+
+
+_capture = None
+
+
+class capture:
+    """``with capi.capture() as plan:`` -- every ``capi.dev`` / C-ABI call made inside is
+    recorded into ``plan`` and NOT executed."""
+
+    def __enter__(self):
+        global _capture
+        lib()
+        if _capture is not None:
+            raise RuntimeError("capi.capture() does not nest")
+        self.plan = CallPlan()
+        _capture = _Recorder(self.plan)
+        return self.plan
+
+    def __exit__(self, *exc):
+        global _capture
+        _capture = None
+        return False
+
+
 def lib():
     """Load libtoast_hip.so (raises if it has not been built: no fallback)."""
     global _lib
+    if _capture is not None and _lib is not None:
+        return _capture
     if _lib is None:
         if not os.path.isfile(LIB_PATH):
             raise RuntimeError(
@@ -61,6 +116,15 @@ def lib():
         _lib.toast_hip_last_error.restype = C.c_char_p
         _lib.toast_hip_version.restype = C.c_char_p
     return _lib
+
+
+def accel_generation():
+    """Memory-manager generation counter (toast_hip_accel_generation)."""
+    out = C.c_uint64(0)
+    lib()
+    if _lib.toast_hip_accel_generation(C.byref(out)) != 0:
+        raise RuntimeError(_lib.toast_hip_last_error().decode())
+    return int(out.value)
 
 
 def _check(rc):
@@ -90,6 +154,8 @@ def _p(a):
     if a is None:
         return C.c_void_p(0)
     if isinstance(a, np.ndarray):
+        if _capture is not None:
+            _capture._plan.keep.append(a)
         return C.c_void_p(a.ctypes.data)
     return C.c_void_p(int(a))
 
@@ -715,6 +781,9 @@ class _Dev:
             _p(d_out), _p(oi), _p(d_det_flags), _i64(n_flag_samp), _p(fi), _u8(det_flag_mask), _p(d_shared_flags),
             _i64(n_shared_flags), _u8(shared_flag_mask), _i64(oi.size), _i64(n_samp), _p(iv), _i64(iv.size),
             _i64(n_out_rows), C.c_int(int(outside_value)), _p(stream)))
+
+    def memset(self, d_dst, value, nbytes, stream=0):
+        _check(lib().toast_hip_memset_dev(_p(d_dst), C.c_int(int(value)), C.c_size_t(int(nbytes)), _p(stream)))
 
     def copy(self, d_dst, d_src, nbytes, stream=0):
         _check(lib().toast_hip_copy_dev(_p(d_dst), _p(d_src), C.c_size_t(int(nbytes)), _p(stream)))

@@ -1629,6 +1629,13 @@ int toast_hip_copy_dev(void * d_dst, const void * d_src, size_t nbytes, void * s
     });
 }
 
+int toast_hip_memset_dev(void * d_dst, int value, size_t nbytes, void * stream) {
+    return guarded([&] {
+        if (nbytes == 0) return;
+        TH_HIP(hipMemsetAsync(d_dst, value & 0xff, nbytes, as_stream(stream)));
+    });
+}
+
 int toast_hip_vec_axpby_dev(int64_t n, double a, const double * d_x, double b, double * d_y, void * stream) {
     return guarded([&] {
         if (n <= 0) return;

@@ -153,6 +153,7 @@ void Manager::clear() {
     }
     table_.clear();
     owned_bytes_ = 0;
+    ++generation_;
 }
 
 void Manager::assign_device(int node_procs, int node_rank, double /*mem_gb*/, bool disabled) {
@@ -261,6 +262,7 @@ void * Manager::create(const void * host, size_t nbytes, const char * name) {
     Entry ent{dev, nbytes, name ? name : "NA", true};
     table_[host] = ent;
     owned_bytes_ += nbytes;
+    ++generation_;
     trace("create", ent.name, nbytes, t0);
     return dev;
 }
@@ -310,6 +312,7 @@ void Manager::adopt(const void * host, size_t nbytes, void * device, const char 
     }
     Entry ent{device, nbytes, name ? name : "NA", false};
     table_[host] = ent;
+    ++generation_;
 }
 
 void Manager::reset(const void * host, size_t nbytes, const char * name) {
@@ -351,6 +354,7 @@ void Manager::remove(const void * host, size_t nbytes, const char * name) {
     }
     trace("delete", e.name, nbytes, t0);
     table_.erase(host);
+    ++generation_;
 }
 
 void * Manager::find(const void * host) {
@@ -424,6 +428,10 @@ extern "C" {
 const char * toast_hip_last_error(void) { return g_last_error.c_str(); }
 
 const char * toast_hip_version(void) { return "toast_hip 0.1 (gfx950)"; }
+
+int toast_hip_accel_generation(uint64_t * generation) {
+    return toast_hip::guarded([&] { *generation = toast_hip::Manager::get().generation(); });
+}
 
 int toast_hip_accel_enabled(void) {
     int n = 0;

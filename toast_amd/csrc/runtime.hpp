@@ -111,6 +111,7 @@ public:
     void dump();
     void clear();
 
+    uint64_t generation() const { return generation_; }
     hipStream_t stream() const { return stream_; }
     void set_stream(hipStream_t s) { stream_ = s; }
 
@@ -131,6 +132,7 @@ private:
     std::unordered_map<const void *, Entry> table_;
     bool assigned_ = false;
     size_t owned_bytes_ = 0;
+    uint64_t generation_ = 0;
     int device_ = -1;
     hipStream_t stream_ = nullptr;
 };
