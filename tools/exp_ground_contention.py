@@ -1,7 +1,6 @@
 """Ground-scan accumulate: is the A^T kernel limited by same-address atomic contention between
 detectors?  Same total work, launched (a) once for all detectors into one zmap, (b) as G
-sequential launches over detector groups (fewer concurrent colliders), (c) groups into private
-zmap replicas."""
+sequential launches over detector groups (fewer concurrent colliders)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -72,21 +71,6 @@ for G in (2, 4, 8):
     groups = [np.ascontiguousarray(idx[g * (n_det // G):(g + 1) * (n_det // G)]) for g in range(G)]
     t = timed(lambda: [launch(s, zmaps[0]) for s in groups])
     print(f"{G} sequential launches (contiguous dets),  one zmap: {t:7.3f} ms  {alg / t / 1e6:7.0f} GB/s")
-# XCD-private replicas: every XCD accumulates into its own copy of the map (kernel reads XCC_ID)
-big = torch.zeros((8, n_local, nps, nnz), dtype=torch.float64, device=dev)
-os.environ["TOAST_HIP_ZMAP_REPLICA_STRIDE"] = str(n_local * nps * nnz)
-t = timed(lambda: launch(idx, big))
-print(f"one launch, 8 XCD-private replicas:   {t:7.3f} ms  {alg / t / 1e6:7.0f} GB/s")
-big.zero_()
-launch(idx, big)
-torch.cuda.synchronize()
-per = big.abs().sum(dim=(1, 2, 3)).cpu().numpy()
-print("replica |sum| per XCD:", np.array2string(per / per.sum(), precision=3))
-tot = big.sum(dim=0)
-del os.environ["TOAST_HIP_ZMAP_REPLICA_STRIDE"]
-zmaps[1].zero_()
-launch(idx, zmaps[1])
-torch.cuda.synchronize()
-print("replica sum vs single map: max rel diff", float((tot - zmaps[1]).abs().max() / zmaps[1].abs().max()))
-t = timed(lambda: torch.sum(big, dim=0, out=zmaps[2]))
-print(f"reduce 8 replicas (torch.sum):        {t:7.3f} ms")
+# (The XCD-private replica variant of this experiment -- kernel selecting one of eight map copies by
+# s_getreg HW_REG_XCC_ID -- needed a temporary kernel argument that is no longer in the tree; its
+# result is recorded in profiles/r01_b_tuning_experiments.txt section 6.)
