@@ -76,6 +76,8 @@ CASES = {
     "no_flags": dict(n_det=2, n_samp=2500, nside=1024, with_shared_flags=False, with_det_flags=False),
     "random": dict(n_det=3, n_samp=4000, nside=128, random_pointing=True),
     "unpaired": dict(n_det=6, n_samp=4000, nside=128, fp_roll=1),
+    # 64-bit pixel arithmetic (Nside > 8192)
+    "nside16384": dict(n_det=2, n_samp=3000, nside=16384, random_pointing=True),
 }
 
 
