@@ -23,6 +23,15 @@
  *       pointers and are packed into one cached parameter block.  Asynchronous on `stream`
  *       (a hipStream_t, NULL = default stream).
  *
+ *   Beyond the one-to-one replacements, the _dev level carries the entry points of the solver
+ *   loop that have no single counterpart in `toast._libtoast` (each cites the reference code it
+ *   stands in for): the fused offset-template left-hand side (toast_hip_offset_accumulate_dev /
+ *   _scan_project_dev), pointing evaluated inside the kernels for the reference's uncached
+ *   full_pointing=False mode (toast_hip_otf_* with the toast_hip_otf_pointing descriptor, the
+ *   compact pixel cache, the HWP table), the amplitude-vector algebra of the PCG
+ *   (toast_hip_vec_*), solver flags and Offset-template set-up
+ *   (toast_hip_combine_flags_dev, toast_hip_offset_count_flagged_dev).
+ *
  * "Optional" arrays follow the reference convention: an array whose length differs from
  * n_samp is treated as absent (ops_pixels_healpix.cpp:1204-1211,
  * ops_mapmaker_utils.cpp:181-197).
