@@ -708,3 +708,34 @@ def test_fused_lhs_plan_replay_and_invalidation():
     assert np.max(np.abs(outs[0])) > 0
     for o in outs[1:]:
         assert np.max(np.abs(o - outs[0])) < 1e-12 * np.max(np.abs(outs[0]))
+
+
+@pytest.mark.parametrize("op", ["add", "subtract", "multiply", "divide"])
+@pytest.mark.parametrize("target", ["first", "second", "new"])
+def test_combine_operator(op, target):
+    """ops.Combine (reference src/toast/ops/arithmetic.py): host path and the device path for
+    add / subtract of resident float64 buffers."""
+    for resident in (False, True):
+        data = create_satellite_data(n_det=3, n_samp=1000)
+        ob = data.obs[0]
+        rng = np.random.default_rng(2)
+        a = rng.standard_normal((3, 1000))
+        b = rng.standard_normal((3, 1000)) + 3.0
+        ob.detdata.create("a", dtype=np.float64)
+        ob.detdata.create("b", dtype=np.float64)
+        ob.detdata["a"].data[:] = a
+        ob.detdata["b"].data[:] = b
+        if resident:
+            for k in ("a", "b"):
+                ob.detdata[k].accel_create(k)
+                ob.detdata[k].accel_update_device()
+        res = {"first": "a", "second": "b", "new": "c"}[target]
+        ops.Combine(op=op, first="a", second="b", result=res).apply(data)
+        want = {"add": a + b, "subtract": a - b, "multiply": a * b, "divide": a / b}[op]
+        on_dev = ob.detdata[res].accel_in_use()
+        assert on_dev == (resident and op in ("add", "subtract"))
+        assert np.array_equal(ob.detdata[res].data, want)
+        if target == "new":
+            assert np.array_equal(ob.detdata["a"].data, a) and np.array_equal(ob.detdata["b"].data, b)
+    with pytest.raises(RuntimeError):
+        ops.Combine(op="power")

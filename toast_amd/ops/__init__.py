@@ -1,6 +1,7 @@
 """Operator surface of the map-making hot path, with the reference's class names
 (``toast.ops.*``): drop-in for that path."""
 
+from .arithmetic import Combine
 from .mapmaker import ApplyAmplitudes, MapMaker
 from .mapmaker_ops import (
     BinMap,

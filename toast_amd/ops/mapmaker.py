@@ -11,6 +11,7 @@ import numpy as np
 from ..data import defaults
 from ..pixels import PixelData
 from ..traits import Bool, Float, Instance, Int, Unicode
+from .arithmetic import Combine
 from .mapmaker_ops import Copy, CovarianceAndHits, Delete, ScanMask
 from .mapmaker_solve import SolverLHS, SolverRHS, solve
 from .operator import Operator
@@ -28,40 +29,22 @@ class ApplyAmplitudes(Operator):
     output = Unicode(None, allow_none=True, help="Observation detdata key for output (default: in place)")
 
     def _exec(self, data, detectors=None, **kwargs):
-        if self.op not in ("subtract", "add"):
-            raise NotImplementedError("only subtract / add are supported")
-        out = self.det_data if self.output is None else self.output
-        temp = "temp_apply_amps"
+        if self.op not in ("subtract", "add", "multiply", "divide"):
+            raise RuntimeError("op must be one of 'subtract', 'add', 'multiply', 'divide'")
+        temp = f"{self.name}_temp"
+        if self.output is not None:
+            # the input is copied first, then overwritten (mapmaker_templates.py:1231-1236)
+            Pipeline(operators=[Copy(detdata=[(self.det_data, self.output)])]).apply(data, detectors=detectors)
         tm = self.template_matrix.duplicate()
         tm.amplitudes = self.amplitudes
         tm.transpose = False
         tm.det_data = temp
-        # inside a Pipeline so that the template kernels find device-resident buffers (staged
-        # once) instead of staging the whole timestream buffer per detector
-        Pipeline(operators=[tm]).apply(data, detectors=detectors)
-        if out != self.det_data:
-            Pipeline(operators=[Copy(detdata=[(self.det_data, out)])]).apply(data, detectors=detectors)
-        sign = -1.0 if self.op == "subtract" else 1.0
-        for ob in data.obs:
-            dets = ob.select_local_detectors(detectors, flagmask=tm.det_mask)
-            t, o = ob.detdata[temp], ob.detdata[out]
-            if t.accel_in_use() and t.detectors == o.detectors and t.dtype == np.float64 and o.dtype == np.float64:
-                # whole-buffer device update  out = out +- temp  (rows of unselected detectors
-                # hold zeros in temp); nothing crosses PCIe
-                from .. import capi
-                from ..accel import accel_device_ptr
-
-                if not o.accel_exists():
-                    o.accel_create(out)
-                if not o.accel_in_use():
-                    o.accel_update_device()
-                capi.dev.vec_axpby(t.buffer.size, sign, accel_device_ptr(t.buffer), 1.0, accel_device_ptr(o.buffer))
-                continue
-            for d in dets:
-                if self.op == "subtract":
-                    o[d] -= t[d]
-                else:
-                    o[d] += t[d]
+        combine = Combine(op=self.op, first=self.det_data, second=temp,
+                          result=self.det_data if self.output is None else self.output)
+        # The reference projects and combines one detector at a time (Pipeline SINGLE,
+        # mapmaker_templates.py:1252-1260); here all detectors go through one batched template
+        # kernel and one device Combine, the projected timestreams never leave the GPU.
+        Pipeline(operators=[tm, combine]).apply(data, detectors=detectors)
         Delete(detdata=[temp]).apply(data)
 
     def _finalize(self, data, **kwargs):
