@@ -282,7 +282,7 @@ def test_mapmaker_recovers_offsets_and_sky():
     # stay in the map-making (in the reference too), which would break exact recovery
     tmpl = Offset(step_time=20.0, noise_model=defaults.noise_model, name="baselines", good_fraction=0.2)
     tmatrix = ops.TemplateMatrix(templates=[tmpl])
-    mapper = ops.MapMaker(name="mm", det_data=defaults.det_data, binning=binner, template_matrix=tmatrix,
+    mapper = ops.MapMaker(name="mm", keep_solver_products=True, det_data=defaults.det_data, binning=binner, template_matrix=tmatrix,
                           iter_max=200, convergence=1e-20, solve_rcond_threshold=1e-3, map_rcond_threshold=1e-3)
     mapper.apply(data)
     assert mapper.history[-1] < 1e-12 and len(mapper.history) < 200
@@ -298,7 +298,7 @@ def test_mapmaker_recovers_offsets_and_sky():
     resid[:, 0] -= np.mean(resid[:, 0])
     assert np.max(np.abs(resid)) < 1e-6
     # the baselines themselves, up to the common offset
-    amps = data["mm_amplitudes"]["baselines"]
+    amps = data["mm_solve_amplitudes"]["baselines"]
     off = 0
     errs = []
     for det in data.obs[0].local_detectors:
@@ -466,12 +466,12 @@ def test_solve_resident_equals_host_algebra():
         binner = ops.BinMap(pixel_dist="dist", pixel_pointing=pix, stokes_weights=sw, full_pointing=True)
         tmpl = Offset(step_time=20.0, noise_model=defaults.noise_model, name="baselines", good_fraction=0.2)
         tmatrix = ops.TemplateMatrix(templates=[tmpl])
-        mapper = ops.MapMaker(name="mm", det_data=defaults.det_data, binning=binner, template_matrix=tmatrix,
+        mapper = ops.MapMaker(name="mm", keep_solver_products=True, det_data=defaults.det_data, binning=binner, template_matrix=tmatrix,
                               iter_max=15, convergence=1e-30, solve_rcond_threshold=1e-3, map_rcond_threshold=1e-3,
                               fused_lhs=fused)
         mapper.apply(data)
         hist[fused] = np.array(mapper.history)
-        amps[fused] = data["mm_amplitudes"]["baselines"].local.copy()
+        amps[fused] = data["mm_solve_amplitudes"]["baselines"].local.copy()
     n = min(len(hist[True]), len(hist[False]))
     assert n >= 5
     np.testing.assert_allclose(hist[True][:5], hist[False][:5], rtol=1e-6)
@@ -522,7 +522,7 @@ def test_uncached_pointing_matches_full_pointing(monkeypatch, compact):
                             compact_cache=compact)
         tmpl = Offset(step_time=20.0, noise_model=defaults.noise_model, name="baselines", good_fraction=0.2)
         tmatrix = ops.TemplateMatrix(templates=[tmpl])
-        mapper = ops.MapMaker(name="mm", det_data=defaults.det_data, binning=binner, template_matrix=tmatrix,
+        mapper = ops.MapMaker(name="mm", keep_solver_products=True, det_data=defaults.det_data, binning=binner, template_matrix=tmatrix,
                               iter_max=12, convergence=1e-30, solve_rcond_threshold=1e-3, map_rcond_threshold=1e-3)
         mapper.apply(data)
         ob = data.obs[0]
@@ -534,7 +534,7 @@ def test_uncached_pointing_matches_full_pointing(monkeypatch, compact):
             if compact:
                 assert ob.detdata[cname].dtype == np.int32 and ob.detdata[cname].accel_in_use()
         out[full] = dict(map=data["mm_map"].data.copy(), hits=data["mm_hits"].data.copy(),
-                         cov=data["mm_cov"].data.copy(), amps=data["mm_amplitudes"]["baselines"].local.copy(),
+                         cov=data["mm_cov"].data.copy(), amps=data["mm_solve_amplitudes"]["baselines"].local.copy(),
                          hist=np.array(mapper.history))
     assert np.array_equal(out[True]["hits"], out[False]["hits"])
     np.testing.assert_allclose(out[False]["cov"], out[True]["cov"], rtol=1e-10, atol=1e-14 * np.max(np.abs(out[True]["cov"])))
@@ -653,11 +653,11 @@ def test_mapmaker_two_observations_fused_equals_operator_sequence():
         data.obs.append(ob2)
         binner = ops.BinMap(pixel_dist="dist", pixel_pointing=pix, stokes_weights=sw, full_pointing=kw["full"])
         tmpl = Offset(step_time=13.0, noise_model=defaults.noise_model, name="baselines", good_fraction=0.2)
-        mapper = ops.MapMaker(name="mm", det_data=defaults.det_data, binning=binner,
+        mapper = ops.MapMaker(name="mm", keep_solver_products=True, det_data=defaults.det_data, binning=binner,
                               template_matrix=ops.TemplateMatrix(templates=[tmpl]), iter_max=10, convergence=1e-30,
                               solve_rcond_threshold=1e-3, map_rcond_threshold=1e-3, fused_lhs=kw["fused_lhs"])
         mapper.apply(data)
-        res[key] = (data["mm_amplitudes"]["baselines"].local.copy(), data["mm_map"].data.copy(),
+        res[key] = (data["mm_solve_amplitudes"]["baselines"].local.copy(), data["mm_map"].data.copy(),
                     np.array(mapper.history))
     n_amp = res["seq"][0].size
     assert n_amp == 4 * (-(-5000 // 130) + -(-3100 // 130))
@@ -739,3 +739,50 @@ def test_combine_operator(op, target):
             assert np.array_equal(ob.detdata["a"].data, a) and np.array_equal(ob.detdata["b"].data, b)
     with pytest.raises(RuntimeError):
         ops.Combine(op="power")
+
+
+def test_mapmaker_products_and_solve_mask():
+    """MapMaker products as in the reference (mapmaker.py:304-313): hits / cov / invcov / rcond /
+    map / noiseweighted_map (+ binmap, cleaned on request); solver products only with
+    keep_solver_products; a pixel mask for the solve cuts those samples from the template fit
+    but not from the final map."""
+    data, pix, sw, truth, sky = make_solver_setup(noise_rms=0.1, n_det=4, n_samp=6000)
+    binner = ops.BinMap(pixel_dist="dist", pixel_pointing=pix, stokes_weights=sw, full_pointing=True)
+    tmpl = Offset(step_time=20.0, noise_model=defaults.noise_model, name="baselines", good_fraction=0.2)
+    mapper = ops.MapMaker(name="mm", det_data=defaults.det_data, binning=binner,
+                          template_matrix=ops.TemplateMatrix(templates=[tmpl]), iter_max=10, convergence=1e-30,
+                          solve_rcond_threshold=1e-3, map_rcond_threshold=1e-3, write_binmap=True, save_cleaned=True)
+    mapper.apply(data)
+    for key in ("mm_hits", "mm_cov", "mm_invcov", "mm_rcond", "mm_map", "mm_noiseweighted_map", "mm_binmap"):
+        assert key in data, key
+    for key in ("mm_solve_hits", "mm_solve_cov", "mm_solve_rcond", "mm_solve_rcond_mask", "mm_solve_rhs",
+                "mm_solve_bin", "mm_solve_amplitudes"):
+        assert key not in data, key
+    ob = data.obs[0]
+    assert "mm_cleaned" in ob.detdata and "mm_solve_flags" not in ob.detdata
+    assert not np.array_equal(ob.detdata["mm_cleaned"].data, ob.detdata[defaults.det_data].data)
+    # map = C * noiseweighted map
+    z = data["mm_noiseweighted_map"].duplicate()
+    covariance_apply(data["mm_cov"], z)
+    assert np.max(np.abs(z.data - data["mm_map"].data)) < 1e-12 * np.max(np.abs(data["mm_map"].data))
+    assert np.max(np.abs(data["mm_binmap"].data - data["mm_map"].data)) > 0     # destriping did something
+    hits_all = int(data["mm_hits"].data.sum())
+
+    # second run with half of the hit pixels masked for the solve
+    data2, pix2, sw2, _, _ = make_solver_setup(noise_rms=0.1, n_det=4, n_samp=6000)
+    binner2 = ops.BinMap(pixel_dist="dist", pixel_pointing=pix2, stokes_weights=sw2, full_pointing=True)
+    ops.BuildPixelDistribution(pixel_dist="dist", pixel_pointing=pix2, save_pointing=True).apply(data2)
+    mask = PixelData(data2["dist"], np.uint8, n_value=1)
+    mask.data[::2] = 1
+    data2["solve_mask"] = mask
+    tmpl2 = Offset(step_time=20.0, noise_model=defaults.noise_model, name="baselines", good_fraction=0.2)
+    mapper2 = ops.MapMaker(name="mm", det_data=defaults.det_data, binning=binner2, mask="solve_mask",
+                           template_matrix=ops.TemplateMatrix(templates=[tmpl2]), iter_max=10, convergence=1e-30,
+                           solve_rcond_threshold=1e-3, map_rcond_threshold=1e-3, keep_solver_products=True)
+    mapper2.apply(data2)
+    assert int(data2["mm_hits"].data.sum()) == hits_all                  # final map: all samples
+    assert 0 < int(data2["mm_solve_hits"].data.sum()) < hits_all         # solve: masked samples cut
+    sf = data2.obs[0].detdata["mm_solve_flags"].data
+    assert np.any(sf & 2) and np.any(sf & 1) and not np.any(sf & ~np.uint8(7))
+    amps2 = data2["mm_solve_amplitudes"]["baselines"].local
+    assert np.all(np.isfinite(amps2)) and np.max(np.abs(amps2)) > 0

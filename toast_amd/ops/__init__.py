@@ -2,7 +2,7 @@
 (``toast.ops.*``): drop-in for that path."""
 
 from .arithmetic import Combine
-from .mapmaker import ApplyAmplitudes, MapMaker
+from .mapmaker import ApplyAmplitudes, MapMaker, SolveAmplitudes
 from .mapmaker_ops import (
     BinMap,
     BuildHitMap,

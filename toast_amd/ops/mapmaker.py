@@ -57,11 +57,185 @@ class ApplyAmplitudes(Operator):
         return {"detdata": [self.det_data if self.output is None else self.output]}
 
 
-class MapMaker(Operator):
-    """Generalised destriping map-maker.
+class SolveAmplitudes(Operator):
+    """Solve for template amplitudes (reference: src/toast/ops/mapmaker_templates.py:407-1155):
 
-    Products (``<name>_hits``, ``_cov``, ``_rcond``, ``_map``, ``_amplitudes``) are stored in
-    ``data``.  With no templates this reduces to CovarianceAndHits + BinMap."""
+        a = (M^T N^-1 Z M + M_p)^-1 M^T N^-1 Z d,     Z = I - P (P^T N^-1 P)^-1 P^T N^-1
+
+    Stages, as in the reference: solver flags (bit 1: detector | shared flags, bit 2: pixel
+    mask, bit 4: poorly conditioned pixels), solver covariance / hits / rcond, right-hand side,
+    PCG.  Products ``<name>_solve_{hits,cov,rcond,rcond_mask,rhs,bin,flags}`` are removed at the
+    end unless ``keep_solver_products``; the solution is ``data[self.amplitudes]``
+    (default ``<name>_solve_amplitudes``)."""
+
+    API = Int(0, help="Internal interface version for this operator")
+    det_data = Unicode(defaults.det_data, help="Observation detdata key for the timestream data")
+    amplitudes = Unicode(None, allow_none=True, help="Data key for output amplitudes")
+    convergence = Float(1.0e-12, help="Relative convergence limit")
+    iter_min = Int(3, help="Minimum number of iterations")
+    iter_max = Int(100, help="Maximum number of iterations")
+    solve_rcond_threshold = Float(1.0e-8, help="When solving, minimum value for inverse pixel condition number cut.")
+    mask = Unicode(None, allow_none=True, help="Data key for pixel mask to use in solving.  "
+                                               "First bit of pixel values is tested")
+    binning = Instance(klass=Operator, help="Binning operator used for solving template amplitudes")
+    template_matrix = Instance(klass=Operator, help="This must be an instance of a template matrix operator")
+    keep_solver_products = Bool(False, help="If True, keep the map domain solver products in data")
+    reset_pix_dist = Bool(False, help="Clear any existing pixel distribution.")
+    fused_lhs = Bool(True, help="Let SolverLHS use the fused device-resident kernels when it can "
+                                "(not a reference trait; False = the reference operator sequence)")
+
+    def _names(self):
+        n = self.name
+        return dict(flags=f"{n}_solve_flags", hits=f"{n}_solve_hits", cov=f"{n}_solve_cov", rcond=f"{n}_solve_rcond",
+                    rcond_mask=f"{n}_solve_rcond_mask", rhs=f"{n}_solve_rhs", bin=f"{n}_solve_bin")
+
+    def _exec(self, data, detectors=None, **kwargs):
+        import time as _time
+
+        from ..accel import accel_enabled, native
+
+        for trait in ("binning", "template_matrix"):
+            if getattr(self, trait) is None:
+                raise RuntimeError(f"You must set the '{trait}' trait before calling exec()")
+        binning, tm = self.binning, self.template_matrix
+        if len([t for t in tm.templates if t.enabled]) == 0:
+            raise RuntimeError("No enabled templates: nothing to solve for")
+        self.history, self.iteration_seconds = [], []
+        self.timing_log = {}
+
+        def lap(label, t0):
+            native().accel_synchronize() if accel_enabled() else None
+            self.timing_log[label] = self.timing_log.get(label, 0.0) + (_time.time() - t0)
+            return _time.time()
+
+        t0 = _time.time()
+        nm = self._names()
+        if self.amplitudes is None:
+            self.amplitudes = f"{self.name}_solve_amplitudes"
+        # state of the binning / template operators that the solve borrows (:596-611)
+        saved = dict(det_flags=binning.det_flags, det_flag_mask=binning.det_flag_mask, binned=binning.binned,
+                     covariance=binning.covariance, shared_flags=binning.shared_flags,
+                     shared_flag_mask=binning.shared_flag_mask, tm_flags=tm.det_flags, tm_flag_mask=tm.det_flag_mask,
+                     tm_det_data=tm.det_data, tm_amplitudes=tm.amplitudes)
+        pixels, weights = binning.pixel_pointing, binning.stokes_weights
+        pixels.detector_pointing.det_mask = binning.det_mask
+        if self.reset_pix_dist:
+            for key in (nm["hits"], nm["cov"], nm["rcond_mask"], nm["rcond"], nm["rhs"], nm["bin"], binning.pixel_dist):
+                if key in data:
+                    del data[key]
+            Delete(detdata=[pixels.pixels, weights.weights, pixels.detector_pointing.quats, nm["flags"]]).apply(data)
+        # Cached pointing is written once and read by every later phase: keep it on the device
+        pinned = None
+        if binning.full_pointing and accel_enabled():
+            pinned = {"detdata": [pixels.pixels, weights.weights]}
+            data.accel_pin(pinned)
+        # -- solver flags (:698-810)
+        for ob in data.obs:
+            if accel_enabled():
+                MapMaker._solver_flags_device(ob, nm["flags"], binning, detectors)
+            else:
+                self._solver_flags_host(ob, nm["flags"], binning, detectors)
+        scanner = ScanMask(det_flags=nm["flags"], det_mask=binning.det_mask, pixels=pixels.pixels, view=pixels.view)
+        scan_pipe = Pipeline(detector_sets=["ALL"] if binning.full_pointing else uncached_detector_sets(),
+                             operators=[pixels, scanner])
+        if self.mask is not None:
+            scanner.det_flags_value, scanner.mask_key = 2, self.mask
+            scan_pipe.apply(data, detectors=detectors)
+        # -- solver covariance, hits, condition numbers (:846-900)
+        CovarianceAndHits(
+            pixel_dist=binning.pixel_dist, covariance=nm["cov"], hits=nm["hits"], rcond=nm["rcond"],
+            det_mask=binning.det_mask, det_flags=nm["flags"], det_flag_mask=255, shared_flags=None,
+            pixel_pointing=pixels, stokes_weights=weights, noise_model=binning.noise_model,
+            rcond_threshold=self.solve_rcond_threshold, sync_type=binning.sync_type,
+            save_pointing=binning.full_pointing, det_data_units=binning.det_data_units).apply(data, detectors=detectors)
+        t0 = lap("covariance_and_hits", t0)
+        # -- samples in poorly conditioned pixels must not constrain the templates (:902-939)
+        data[nm["rcond_mask"]] = PixelData(data[binning.pixel_dist], np.uint8, n_value=1)
+        data[nm["rcond_mask"]].data[data[nm["rcond"]].data < self.solve_rcond_threshold] = 1
+        scanner.det_flags_value, scanner.mask_key = 4, nm["rcond_mask"]
+        scan_pipe.apply(data, detectors=detectors)
+        # -- right-hand side (:941-1000): the binning and the templates see the solver flags only
+        binning.det_flags, binning.det_flag_mask = nm["flags"], 255
+        binning.shared_flags = None
+        tm.det_flags, tm.det_flag_mask = nm["flags"], 255
+        binning.covariance, binning.binned = nm["cov"], nm["bin"]
+        try:
+            tm.reset()
+            tm.amplitudes = nm["rhs"]
+            if nm["rhs"] in data:
+                del data[nm["rhs"]]
+            SolverRHS(name=f"{self.name}_rhs", det_data=self.det_data, binning=binning,
+                      template_matrix=tm).apply(data, detectors=detectors)
+            t0 = lap("rhs", t0)
+            # -- PCG (:1002-1060)
+            lhs = SolverLHS(name=f"{self.name}_lhs", binning=binning, template_matrix=tm, fused=self.fused_lhs)
+            if self.amplitudes in data:
+                del data[self.amplitudes]
+            self.history = solve(data, detectors, lhs, nm["rhs"], self.amplitudes, convergence=self.convergence,
+                                 n_iter_min=self.iter_min, n_iter_max=self.iter_max,
+                                 iteration_seconds=self.iteration_seconds)
+            t0 = lap("pcg_iterations", t0)
+            for ob in data.obs:
+                if lhs.det_temp in ob.detdata:
+                    del ob.detdata[lhs.det_temp]
+        finally:
+            # -- restore the borrowed operators (:1062-1100)
+            binning.det_flags, binning.det_flag_mask = saved["det_flags"], saved["det_flag_mask"]
+            binning.shared_flags, binning.shared_flag_mask = saved["shared_flags"], saved["shared_flag_mask"]
+            binning.binned, binning.covariance = saved["binned"], saved["covariance"]
+            tm.det_flags, tm.det_flag_mask = saved["tm_flags"], saved["tm_flag_mask"]
+        if not self.keep_solver_products:
+            for key in (nm["hits"], nm["cov"], nm["rcond"], nm["rcond_mask"], nm["rhs"], nm["bin"]):
+                if key in data:
+                    if hasattr(data[key], "clear") and not isinstance(data[key], PixelData):
+                        data[key].clear()
+                    del data[key]
+            Delete(detdata=[nm["flags"]]).apply(data)
+        if pinned is not None:
+            data.accel_unpin(pinned)
+
+    @staticmethod
+    def _solver_flags_host(ob, solver_flags, binning, detectors=None):
+        dets = ob.select_local_detectors(detectors, flagmask=binning.det_mask)
+        ob.detdata.ensure(solver_flags, dtype=np.uint8, detectors=dets)
+        if len(dets) == 0:
+            return
+        sf = ob.detdata[solver_flags]
+        view = binning.pixel_pointing.view
+        for iv in ob.intervals[view]:
+            start = np.zeros(iv.last - iv.first, dtype=np.uint8)
+            if binning.shared_flags is not None:
+                start[:] = (ob.shared[binning.shared_flags].data[iv.first:iv.last] & binning.shared_flag_mask) != 0
+            for d in dets:
+                sf[d, iv.first:iv.last] = start
+                if binning.det_flags is not None:
+                    sf[d, iv.first:iv.last] |= (
+                        (ob.detdata[binning.det_flags][d, iv.first:iv.last] & binning.det_flag_mask) != 0
+                    ).astype(np.uint8)
+
+    def _finalize(self, data, **kwargs):
+        return
+
+    def _requires(self):
+        req = self.binning.requires()
+        req["detdata"].append(self.det_data)
+        if self.mask is not None:
+            req["global"].append(self.mask)
+        return req
+
+    def _provides(self):
+        return {"global": [self.amplitudes if self.amplitudes is not None else f"{self.name}_solve_amplitudes"]}
+
+
+class MapMaker(Operator):
+    """Generalised destriping map-maker (reference: src/toast/ops/mapmaker.py:27-811):
+    SolveAmplitudes -> final covariance / hits / rcond with the map binning -> template-cleaned
+    timestreams (ApplyAmplitudes) -> binned map.
+
+    Products ``<name>_hits``, ``_cov``, ``_invcov``, ``_rcond``, ``_map``, ``_noiseweighted_map``
+    (and ``_binmap`` with ``write_binmap``, ``_cleaned`` with ``save_cleaned``) stay in ``data``;
+    the solved amplitudes ``<name>_solve_amplitudes`` only with ``keep_solver_products``.  With no
+    templates this reduces to CovarianceAndHits + BinMap."""
 
     API = Int(0, help="Internal interface version for this operator")
     det_data = Unicode(defaults.det_data, help="Observation detdata key for the timestream data")
@@ -70,9 +244,12 @@ class MapMaker(Operator):
     iter_max = Int(100, help="Maximum number of iterations")
     solve_rcond_threshold = Float(1.0e-8, help="When solving, minimum value for inverse pixel condition number cut.")
     map_rcond_threshold = Float(1.0e-8, help="For final map, minimum value for inverse pixel condition number cut.")
+    mask = Unicode(None, allow_none=True, help="Data key for pixel mask to use in solving.  "
+                                               "First bit of pixel values is tested")
     binning = Instance(klass=Operator, help="Binning operator used for solving template amplitudes")
     template_matrix = Instance(klass=Operator, help="This must be an instance of a template matrix operator")
     map_binning = Instance(klass=Operator, help="Binning operator for final map making (default: solver binning)")
+    write_binmap = Bool(False, help="If True, also bin a map of the input (undestriped) signal: <name>_binmap")
     keep_solver_products = Bool(False, help="If True, keep the map domain solver products in data")
     keep_final_products = Bool(True, help="If True, keep the map domain products in data after write")
     save_cleaned = Bool(False, help="If True, save the template-subtracted detector timestreams")
@@ -82,152 +259,106 @@ class MapMaker(Operator):
                                 "(not a reference trait; False = the reference operator sequence)")
 
     def _exec(self, data, detectors=None, **kwargs):
-        for trait in ("binning",):
-            if getattr(self, trait) is None:
-                raise RuntimeError(f"You must set the '{trait}' trait before calling exec()")
         import time as _time
 
-        from ..accel import native as _native
+        from ..accel import accel_enabled, native
+        from .pointing import BuildPixelDistribution
 
-        def _lap(label, t_start):
-            _native().accel_synchronize()
-            self.timing_log[label] = self.timing_log.get(label, 0.0) + (_time.time() - t_start)
+        if self.binning is None:
+            raise RuntimeError("You must set the 'binning' trait before calling exec()")
+        n = self.name
+        hits_name, cov_name, invcov_name, rcond_name = f"{n}_hits", f"{n}_cov", f"{n}_invcov", f"{n}_rcond"
+        clean_name, binmap_name, map_name, nw_name = f"{n}_cleaned", f"{n}_binmap", f"{n}_map", f"{n}_noiseweighted_map"
+        self.history, self.iteration_seconds, self.timing_log = [], [], {}
+
+        def lap(label, t0):
+            native().accel_synchronize() if accel_enabled() else None
+            self.timing_log[label] = self.timing_log.get(label, 0.0) + (_time.time() - t0)
             return _time.time()
 
-        binning = self.binning
-        map_binning = self.map_binning if self.map_binning is not None else binning
-        self.history = []
-        self.timing_log = {}
-        _t = _time.time()
-        if self.reset_pix_dist and binning.pixel_dist in data:
-            del data[binning.pixel_dist]
-        hits_name, cov_name, rcond_name = f"{self.name}_hits", f"{self.name}_cov", f"{self.name}_rcond"
-        map_name, amp_name = f"{self.name}_map", f"{self.name}_amplitudes"
-        # Solver flags: one uint8 per sample combining detector and shared flags, so that the
-        # binning and the templates cut exactly the same samples while solving
-        # (SolveAmplitudes._prepare_flagging, mapmaker_templates.py:764-810).
-        solver_flags = f"{self.name}_solve_flags"
-        saved = (binning.det_flags, binning.det_flag_mask)
+        t0 = _time.time()
         tm = self.template_matrix
-        use_templates = tm is not None and len(tm.templates) > 0
+        use_templates = tm is not None and len([t for t in tm.templates if t.enabled]) > 0
+        # -- fit templates (mapmaker.py:338-379)
+        amplitudes = None
         if use_templates:
-            from ..accel import accel_enabled as _acc_on
-
-            for ob in data.obs:
-                if _acc_on():
-                    self._solver_flags_device(ob, solver_flags, binning)
-                    continue
-                ob.detdata.ensure(solver_flags, dtype=np.uint8, detectors=ob.local_detectors)
-                sf = ob.detdata[solver_flags]
-                sf.data[:] = 0
-                if binning.det_flags is not None:
-                    src = ob.detdata[binning.det_flags]
-                    for d in ob.local_detectors:
-                        sf[d][(src[d] & binning.det_flag_mask) != 0] = 1
-                if binning.shared_flags is not None:
-                    shared = ob.shared[binning.shared_flags]
-                    if shared.accel_in_use():
-                        shared.accel_update_host()
-                    bad = (shared.data & binning.shared_flag_mask) != 0
-                    sf.data[:, bad] = 1
-                if binning.pixel_pointing.view is not None:
-                    outside = np.ones(ob.n_local_samples, dtype=bool)
-                    for iv in ob.intervals[binning.pixel_pointing.view]:
-                        outside[iv.first:iv.last] = False
-                    sf.data[:, outside] = 1
-            binning.det_flags, binning.det_flag_mask = solver_flags, 1
-            tm.det_flags, tm.det_flag_mask = solver_flags, 1
-        # Cached pointing is written once and read by every later phase: keep it on the device
-        # (288 GB HBM) instead of the copy-back / delete / re-upload of each Pipeline.
-        pinned = None
-        from ..accel import accel_enabled as _accel_enabled
-
-        if binning.full_pointing and _accel_enabled():
-            pinned = {"detdata": [binning.pixel_pointing.pixels, binning.stokes_weights.weights]}
-            data.accel_pin(pinned)
-        # covariance + hits with the solver flags
-        cov_op = CovarianceAndHits(
-            pixel_dist=binning.pixel_dist, covariance=cov_name, hits=hits_name, rcond=rcond_name,
-            det_mask=binning.det_mask, det_flags=binning.det_flags, det_flag_mask=binning.det_flag_mask,
-            shared_flags=binning.shared_flags, shared_flag_mask=binning.shared_flag_mask,
-            pixel_pointing=binning.pixel_pointing, stokes_weights=binning.stokes_weights,
-            noise_model=binning.noise_model, rcond_threshold=self.solve_rcond_threshold,
-            sync_type=binning.sync_type, save_pointing=binning.full_pointing)
-        cov_op.apply(data, detectors=detectors)
-        _t = _lap("covariance_and_hits", _t)
-        binning.covariance = cov_name
+            solver = SolveAmplitudes(name=n, det_data=self.det_data, convergence=self.convergence,
+                                     iter_min=self.iter_min, iter_max=self.iter_max,
+                                     solve_rcond_threshold=self.solve_rcond_threshold, mask=self.mask,
+                                     binning=self.binning, template_matrix=tm,
+                                     keep_solver_products=self.keep_solver_products,
+                                     reset_pix_dist=self.reset_pix_dist, fused_lhs=self.fused_lhs)
+            solver.apply(data, detectors=detectors)
+            amplitudes = solver.amplitudes
+            self.history, self.iteration_seconds = solver.history, solver.iteration_seconds
+            self.timing_log.update(solver.timing_log)
+            t0 = _time.time()
+        # -- final binning set-up (:381-436)
+        map_binning = self.map_binning if (self.map_binning is not None and self.map_binning.enabled) else self.binning
+        map_binning.pre_process = None
         map_binning.covariance = cov_name
+        if self.reset_pix_dist:
+            for key in (hits_name, cov_name, invcov_name, rcond_name, binmap_name, map_name, nw_name,
+                        map_binning.pixel_dist):
+                if key is not None and key in data:
+                    del data[key]
+            Delete(detdata=[clean_name]).apply(data)
+        pinned = None
+        if map_binning.full_pointing and accel_enabled():
+            pinned = {"detdata": [map_binning.pixel_pointing.pixels, map_binning.stokes_weights.weights]}
+            data.accel_pin(pinned)
+        if map_binning.pixel_dist not in data:
+            BuildPixelDistribution(pixel_dist=map_binning.pixel_dist, pixel_pointing=map_binning.pixel_pointing,
+                                   save_pointing=map_binning.full_pointing).apply(data, detectors=detectors)
+        # -- final covariance, hits, rcond with the map binning's own flags (:438-479)
+        CovarianceAndHits(
+            pixel_dist=map_binning.pixel_dist, covariance=cov_name, inverse_covariance=invcov_name, hits=hits_name,
+            rcond=rcond_name, det_mask=map_binning.det_mask, det_flags=map_binning.det_flags,
+            det_flag_mask=map_binning.det_flag_mask, det_data_units=map_binning.det_data_units,
+            shared_flags=map_binning.shared_flags, shared_flag_mask=map_binning.shared_flag_mask,
+            pixel_pointing=map_binning.pixel_pointing, stokes_weights=map_binning.stokes_weights,
+            noise_model=map_binning.noise_model, rcond_threshold=self.map_rcond_threshold,
+            sync_type=map_binning.sync_type, save_pointing=map_binning.full_pointing).apply(data, detectors=detectors)
+        t0 = lap("final_covariance", t0)
+        # -- undestriped map (:481-513)
+        if self.write_binmap:
+            map_binning.det_data, map_binning.binned, map_binning.noiseweighted = self.det_data, binmap_name, None
+            map_binning.apply(data, detectors=detectors)
+        # -- template-cleaned timestreams (:515-559)
+        out_cleaned = self.det_data
         if use_templates:
-            # samples in pixels that fail the rcond cut must not constrain the templates
-            # (SolveAmplitudes._get_rcond_mask, mapmaker_templates.py:895-939)
-            mask_name = f"{self.name}_rcond_mask"
-            data[mask_name] = PixelData(data[binning.pixel_dist], np.uint8, n_value=1)
-            data[mask_name].data[data[rcond_name].data < self.solve_rcond_threshold] = 1
-            scanner = ScanMask(det_flags=solver_flags, det_flags_value=1, det_mask=binning.det_mask,
-                               pixels=binning.pixel_pointing.pixels, view=binning.pixel_pointing.view,
-                               mask_key=mask_name)
-            scan_pipe = Pipeline(detector_sets=["ALL"] if binning.full_pointing else uncached_detector_sets(),
-                                 operators=[binning.pixel_pointing, scanner])
-            scan_pipe.apply(data, detectors=detectors)
-            del data[mask_name]
-        cleaned = self.det_data
-        if use_templates:
-            tm.reset()
-            tm.amplitudes = f"{self.name}_rhs"
-            solver_bin = f"{self.name}_solve_bin"
-            binning.binned = solver_bin
-            rhs = SolverRHS(name=f"{self.name}_rhs", det_data=self.det_data, binning=binning, template_matrix=tm)
-            if f"{self.name}_rhs" in data:
-                del data[f"{self.name}_rhs"]
-            rhs.apply(data, detectors=detectors)
-            _t = _lap("rhs", _t)
-            lhs = SolverLHS(name=f"{self.name}_lhs", binning=binning, template_matrix=tm, fused=self.fused_lhs)
-            if amp_name in data:
-                del data[amp_name]
-            self.iteration_seconds = []
-            self.history = solve(data, detectors, lhs, f"{self.name}_rhs", amp_name, convergence=self.convergence,
-                                 n_iter_min=self.iter_min, n_iter_max=self.iter_max,
-                                 iteration_seconds=self.iteration_seconds)
-            _t = _lap("pcg_iterations", _t)
-            for ob in data.obs:
-                if lhs.det_temp in ob.detdata:
-                    del ob.detdata[lhs.det_temp]
+            out_cleaned = clean_name
+            output = clean_name
+            if self.save_cleaned and self.overwrite_cleaned:
+                output, out_cleaned = None, self.det_data
+            ApplyAmplitudes(op="subtract", det_data=self.det_data, amplitudes=amplitudes, template_matrix=tm,
+                            output=output).apply(data, detectors=detectors)
             if not self.keep_solver_products:
-                for key in (solver_bin, f"{self.name}_rhs"):
-                    if key in data:
-                        if hasattr(data[key], "clear"):
-                            data[key].clear()
-                        del data[key]
-            # cleaned timestreams = d - M a
-            if self.save_cleaned and not self.overwrite_cleaned:
-                cleaned = f"{self.name}_cleaned"
-            elif not self.overwrite_cleaned:
-                cleaned = f"{self.name}_temp_cleaned"
-            ApplyAmplitudes(op="subtract", amplitudes=amp_name, template_matrix=tm, det_data=self.det_data,
-                            output=None if cleaned == self.det_data else cleaned).apply(data, detectors=detectors)
-        if use_templates:
-            binning.det_flags, binning.det_flag_mask = saved
-            Delete(detdata=[solver_flags]).apply(data)
+                data[amplitudes].clear()
+                del data[amplitudes]
+            t0 = lap("apply_amplitudes", t0)
+        # -- destriped map (:561-590)
+        map_binning.det_data = out_cleaned
+        map_binning.noiseweighted = nw_name if self.keep_final_products else None
         map_binning.binned = map_name
-        map_binning.det_data = cleaned
-        _t = _lap("apply_amplitudes", _t)
         map_binning.apply(data, detectors=detectors)
-        _t = _lap("final_binning", _t)
-        if cleaned.endswith("_temp_cleaned"):
-            Delete(detdata=[cleaned]).apply(data)
+        t0 = lap("final_binning", t0)
+        if use_templates and not self.save_cleaned and out_cleaned == clean_name:
+            Delete(detdata=[clean_name]).apply(data)
         if pinned is not None:
             data.accel_unpin(pinned)
-            _t = _lap("unpin_pointing", _t)
 
     @staticmethod
-    def _solver_flags_device(ob, solver_flags, binning):
+    def _solver_flags_device(ob, solver_flags, binning, detectors=None):
         """The same combination on the device (toast_hip_combine_flags_dev): nothing but the
         uint8 inputs cross PCIe, and those only if they are not resident yet."""
         from .. import capi
         from ..accel import accel_device_ptr
 
-        dets = ob.local_detectors
+        dets = ob.select_local_detectors(detectors, flagmask=binning.det_mask)
         ob.detdata.ensure(solver_flags, dtype=np.uint8, detectors=dets, accel=True)
+        if len(dets) == 0:
+            return
         sf = ob.detdata[solver_flags]
         n_samp = ob.n_local_samples
         f_ptr, f_n, f_idx = 0, 0, np.zeros(len(dets), np.int32)
@@ -249,8 +380,7 @@ class MapMaker(Operator):
         view = binning.pixel_pointing.view
         capi.dev.combine_flags(accel_device_ptr(sf.buffer), sf.indices(dets), f_ptr, f_n, f_idx,
                                binning.det_flag_mask, s_ptr, s_n, binning.shared_flag_mask, n_samp,
-                               ob.intervals[view].data, n_out_rows=len(sf.detectors),
-                               outside_value=1 if view is not None else 0)
+                               ob.intervals[view].data, n_out_rows=len(sf.detectors), outside_value=0)
         sf.accel_used(True)
 
     def _finalize(self, data, **kwargs):

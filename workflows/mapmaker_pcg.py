@@ -72,7 +72,7 @@ def main(argv=None):
                         full_pointing=not args.uncached, compact_cache=args.compact)
     tmatrix = ops.TemplateMatrix(templates=[Offset(step_time=args.step_time, noise_model=defaults.noise_model,
                                                    name="baselines")])
-    mapper = ops.MapMaker(name="mapmaker", det_data=defaults.det_data, binning=binner, template_matrix=tmatrix,
+    mapper = ops.MapMaker(name="mapmaker", keep_solver_products=True, det_data=defaults.det_data, binning=binner, template_matrix=tmatrix,
                           iter_min=args.iter, iter_max=args.iter, convergence=1e-30)
     t0 = time.time()
     mapper.apply(data)
@@ -82,7 +82,7 @@ def main(argv=None):
     n_it = len(mapper.history)
     nds = args.ndet * n_samp
     print(f"detectors {args.ndet}  samples/det {n_samp}  nside {args.nside}  amplitudes "
-          f"{data['mapmaker_amplitudes']['baselines'].n_local}  PCG iterations {n_it}  "
+          f"{data['mapmaker_solve_amplitudes']['baselines'].n_local}  PCG iterations {n_it}  "
           f"relative residual {mapper.history[-1]:.3e}")
     if hasattr(mapper, "timing_log"):
         for k, v in mapper.timing_log.items():
