@@ -786,3 +786,29 @@ def test_mapmaker_products_and_solve_mask():
     assert np.any(sf & 2) and np.any(sf & 1) and not np.any(sf & ~np.uint8(7))
     amps2 = data2["mm_solve_amplitudes"]["baselines"].local
     assert np.all(np.isfinite(amps2)) and np.max(np.abs(amps2)) > 0
+
+
+def test_mapmaker_mc_mode_reuses_flags_and_covariance():
+    """mc_mode (mapmaker_templates.py:499-501, :702-712, :852-864): realisation k re-uses the solver
+    flags and the covariances of the first pass; only rhs / bin / amplitudes / maps are per index."""
+    data, pix, sw, truth, sky = make_solver_setup(noise_rms=0.1, n_det=4, n_samp=6000)
+    binner = ops.BinMap(pixel_dist="dist", pixel_pointing=pix, stokes_weights=sw, full_pointing=True)
+    tmpl = Offset(step_time=20.0, noise_model=defaults.noise_model, name="baselines", good_fraction=0.2)
+    tm = ops.TemplateMatrix(templates=[tmpl])
+    kw = dict(name="mm", det_data=defaults.det_data, binning=binner, template_matrix=tm, iter_max=8,
+              convergence=1e-30, solve_rcond_threshold=1e-3, map_rcond_threshold=1e-3, keep_solver_products=True)
+    with pytest.raises(RuntimeError, match="MC mode|In MC mode"):
+        ops.MapMaker(mc_mode=True, mc_index=0, **kw).apply(data)      # nothing to re-use yet
+    ops.MapMaker(**kw).apply(data)
+    cov0, scov0, map0 = data["mm_cov"], data["mm_solve_cov"], data["mm_map"].data.copy()
+    flags0 = data.obs[0].detdata["mm_solve_flags"]
+    rng = np.random.default_rng(9)
+    ob = data.obs[0]
+    ob.detdata[defaults.det_data].data[:] += 0.5 * rng.standard_normal(ob.detdata[defaults.det_data].data.shape)
+    ops.MapMaker(mc_mode=True, mc_index=3, **kw).apply(data)
+    assert data["mm_cov"] is cov0 and data["mm_solve_cov"] is scov0          # not rebuilt
+    assert data.obs[0].detdata["mm_solve_flags"] is flags0
+    for key in ("mm_00003_map", "mm_00003_solve_amplitudes", "mm_00003_noiseweighted_map"):
+        assert key in data, key
+    assert np.array_equal(data["mm_map"].data, map0)                        # first realisation untouched
+    assert np.max(np.abs(data["mm_00003_map"].data - map0)) > 0

@@ -80,14 +80,20 @@ class SolveAmplitudes(Operator):
     binning = Instance(klass=Operator, help="Binning operator used for solving template amplitudes")
     template_matrix = Instance(klass=Operator, help="This must be an instance of a template matrix operator")
     keep_solver_products = Bool(False, help="If True, keep the map domain solver products in data")
+    mc_mode = Bool(False, help="If True, re-use solver flags, sparse covariances, etc")
+    mc_index = Int(None, allow_none=True, help="The Monte-Carlo index")
     reset_pix_dist = Bool(False, help="Clear any existing pixel distribution.")
     fused_lhs = Bool(True, help="Let SolverLHS use the fused device-resident kernels when it can "
                                 "(not a reference trait; False = the reference operator sequence)")
 
     def _names(self):
         n = self.name
+        # Monte-Carlo realisations share flags / covariance and get their own rhs / bin /
+        # amplitudes (mapmaker_templates.py:612-626)
+        root = f"{n}_{self.mc_index:05d}" if (self.mc_mode and self.mc_index is not None) else n
         return dict(flags=f"{n}_solve_flags", hits=f"{n}_solve_hits", cov=f"{n}_solve_cov", rcond=f"{n}_solve_rcond",
-                    rcond_mask=f"{n}_solve_rcond_mask", rhs=f"{n}_solve_rhs", bin=f"{n}_solve_bin")
+                    rcond_mask=f"{n}_solve_rcond_mask", rhs=f"{root}_solve_rhs", bin=f"{root}_solve_bin",
+                    amplitudes=f"{root}_solve_amplitudes")
 
     def _exec(self, data, detectors=None, **kwargs):
         import time as _time
@@ -111,7 +117,7 @@ class SolveAmplitudes(Operator):
         t0 = _time.time()
         nm = self._names()
         if self.amplitudes is None:
-            self.amplitudes = f"{self.name}_solve_amplitudes"
+            self.amplitudes = nm["amplitudes"]
         # state of the binning / template operators that the solve borrows (:596-611)
         saved = dict(det_flags=binning.det_flags, det_flag_mask=binning.det_flag_mask, binned=binning.binned,
                      covariance=binning.covariance, shared_flags=binning.shared_flags,
@@ -129,31 +135,42 @@ class SolveAmplitudes(Operator):
         if binning.full_pointing and accel_enabled():
             pinned = {"detdata": [pixels.pixels, weights.weights]}
             data.accel_pin(pinned)
-        # -- solver flags (:698-810)
-        for ob in data.obs:
-            if accel_enabled():
-                MapMaker._solver_flags_device(ob, nm["flags"], binning, detectors)
-            else:
-                self._solver_flags_host(ob, nm["flags"], binning, detectors)
-        scanner = ScanMask(det_flags=nm["flags"], det_mask=binning.det_mask, pixels=pixels.pixels, view=pixels.view)
-        scan_pipe = Pipeline(detector_sets=["ALL"] if binning.full_pointing else uncached_detector_sets(),
-                             operators=[pixels, scanner])
-        if self.mask is not None:
-            scanner.det_flags_value, scanner.mask_key = 2, self.mask
+        if self.mc_mode:
+            # re-use the flags and the covariance of an earlier realisation (:702-712, :852-864)
+            for ob in data.obs:
+                dets = ob.select_local_detectors(detectors, flagmask=binning.det_mask)
+                if nm["flags"] not in ob.detdata or not set(dets) <= set(ob.detdata[nm["flags"]].detectors):
+                    raise RuntimeError(f"In MC mode, solver flags missing for observation {ob.name}")
+            if binning.pixel_dist not in data:
+                raise RuntimeError(f"MC mode, pixel distribution '{binning.pixel_dist}' does not exist")
+            if nm["cov"] not in data:
+                raise RuntimeError(f"MC mode, covariance '{nm['cov']}' does not exist")
+        else:
+            # -- solver flags (:698-810)
+            for ob in data.obs:
+                if accel_enabled():
+                    MapMaker._solver_flags_device(ob, nm["flags"], binning, detectors)
+                else:
+                    self._solver_flags_host(ob, nm["flags"], binning, detectors)
+            scanner = ScanMask(det_flags=nm["flags"], det_mask=binning.det_mask, pixels=pixels.pixels, view=pixels.view)
+            scan_pipe = Pipeline(detector_sets=["ALL"] if binning.full_pointing else uncached_detector_sets(),
+                                 operators=[pixels, scanner])
+            if self.mask is not None:
+                scanner.det_flags_value, scanner.mask_key = 2, self.mask
+                scan_pipe.apply(data, detectors=detectors)
+            # -- solver covariance, hits, condition numbers (:846-900)
+            CovarianceAndHits(
+                pixel_dist=binning.pixel_dist, covariance=nm["cov"], hits=nm["hits"], rcond=nm["rcond"],
+                det_mask=binning.det_mask, det_flags=nm["flags"], det_flag_mask=255, shared_flags=None,
+                pixel_pointing=pixels, stokes_weights=weights, noise_model=binning.noise_model,
+                rcond_threshold=self.solve_rcond_threshold, sync_type=binning.sync_type,
+                save_pointing=binning.full_pointing, det_data_units=binning.det_data_units).apply(data, detectors=detectors)
+            t0 = lap("covariance_and_hits", t0)
+            # -- samples in poorly conditioned pixels must not constrain the templates (:902-939)
+            data[nm["rcond_mask"]] = PixelData(data[binning.pixel_dist], np.uint8, n_value=1)
+            data[nm["rcond_mask"]].data[data[nm["rcond"]].data < self.solve_rcond_threshold] = 1
+            scanner.det_flags_value, scanner.mask_key = 4, nm["rcond_mask"]
             scan_pipe.apply(data, detectors=detectors)
-        # -- solver covariance, hits, condition numbers (:846-900)
-        CovarianceAndHits(
-            pixel_dist=binning.pixel_dist, covariance=nm["cov"], hits=nm["hits"], rcond=nm["rcond"],
-            det_mask=binning.det_mask, det_flags=nm["flags"], det_flag_mask=255, shared_flags=None,
-            pixel_pointing=pixels, stokes_weights=weights, noise_model=binning.noise_model,
-            rcond_threshold=self.solve_rcond_threshold, sync_type=binning.sync_type,
-            save_pointing=binning.full_pointing, det_data_units=binning.det_data_units).apply(data, detectors=detectors)
-        t0 = lap("covariance_and_hits", t0)
-        # -- samples in poorly conditioned pixels must not constrain the templates (:902-939)
-        data[nm["rcond_mask"]] = PixelData(data[binning.pixel_dist], np.uint8, n_value=1)
-        data[nm["rcond_mask"]].data[data[nm["rcond"]].data < self.solve_rcond_threshold] = 1
-        scanner.det_flags_value, scanner.mask_key = 4, nm["rcond_mask"]
-        scan_pipe.apply(data, detectors=detectors)
         # -- right-hand side (:941-1000): the binning and the templates see the solver flags only
         binning.det_flags, binning.det_flag_mask = nm["flags"], 255
         binning.shared_flags = None
@@ -184,7 +201,7 @@ class SolveAmplitudes(Operator):
             binning.shared_flags, binning.shared_flag_mask = saved["shared_flags"], saved["shared_flag_mask"]
             binning.binned, binning.covariance = saved["binned"], saved["covariance"]
             tm.det_flags, tm.det_flag_mask = saved["tm_flags"], saved["tm_flag_mask"]
-        if not self.keep_solver_products:
+        if not self.keep_solver_products and not self.mc_mode:
             for key in (nm["hits"], nm["cov"], nm["rcond"], nm["rcond_mask"], nm["rhs"], nm["bin"]):
                 if key in data:
                     if hasattr(data[key], "clear") and not isinstance(data[key], PixelData):
@@ -250,6 +267,8 @@ class MapMaker(Operator):
     template_matrix = Instance(klass=Operator, help="This must be an instance of a template matrix operator")
     map_binning = Instance(klass=Operator, help="Binning operator for final map making (default: solver binning)")
     write_binmap = Bool(False, help="If True, also bin a map of the input (undestriped) signal: <name>_binmap")
+    mc_mode = Bool(False, help="If True, re-use solver flags, sparse covariances, etc")
+    mc_index = Int(None, allow_none=True, help="The Monte-Carlo index")
     keep_solver_products = Bool(False, help="If True, keep the map domain solver products in data")
     keep_final_products = Bool(True, help="If True, keep the map domain products in data after write")
     save_cleaned = Bool(False, help="If True, save the template-subtracted detector timestreams")
@@ -267,8 +286,11 @@ class MapMaker(Operator):
         if self.binning is None:
             raise RuntimeError("You must set the 'binning' trait before calling exec()")
         n = self.name
+        # per-realisation products carry the Monte-Carlo index (mapmaker.py:296-313)
+        root = f"{n}_{self.mc_index:05d}" if (self.mc_mode and self.mc_index is not None) else n
         hits_name, cov_name, invcov_name, rcond_name = f"{n}_hits", f"{n}_cov", f"{n}_invcov", f"{n}_rcond"
-        clean_name, binmap_name, map_name, nw_name = f"{n}_cleaned", f"{n}_binmap", f"{n}_map", f"{n}_noiseweighted_map"
+        clean_name, binmap_name = f"{n}_cleaned", f"{root}_binmap"
+        map_name, nw_name = f"{root}_map", f"{root}_noiseweighted_map"
         self.history, self.iteration_seconds, self.timing_log = [], [], {}
 
         def lap(label, t0):
@@ -286,8 +308,9 @@ class MapMaker(Operator):
                                      iter_min=self.iter_min, iter_max=self.iter_max,
                                      solve_rcond_threshold=self.solve_rcond_threshold, mask=self.mask,
                                      binning=self.binning, template_matrix=tm,
-                                     keep_solver_products=self.keep_solver_products,
-                                     reset_pix_dist=self.reset_pix_dist, fused_lhs=self.fused_lhs)
+                                     keep_solver_products=self.keep_solver_products, mc_mode=self.mc_mode,
+                                     mc_index=self.mc_index, reset_pix_dist=self.reset_pix_dist,
+                                     fused_lhs=self.fused_lhs)
             solver.apply(data, detectors=detectors)
             amplitudes = solver.amplitudes
             self.history, self.iteration_seconds = solver.history, solver.iteration_seconds
@@ -310,15 +333,17 @@ class MapMaker(Operator):
         if map_binning.pixel_dist not in data:
             BuildPixelDistribution(pixel_dist=map_binning.pixel_dist, pixel_pointing=map_binning.pixel_pointing,
                                    save_pointing=map_binning.full_pointing).apply(data, detectors=detectors)
-        # -- final covariance, hits, rcond with the map binning's own flags (:438-479)
-        CovarianceAndHits(
-            pixel_dist=map_binning.pixel_dist, covariance=cov_name, inverse_covariance=invcov_name, hits=hits_name,
-            rcond=rcond_name, det_mask=map_binning.det_mask, det_flags=map_binning.det_flags,
-            det_flag_mask=map_binning.det_flag_mask, det_data_units=map_binning.det_data_units,
-            shared_flags=map_binning.shared_flags, shared_flag_mask=map_binning.shared_flag_mask,
-            pixel_pointing=map_binning.pixel_pointing, stokes_weights=map_binning.stokes_weights,
-            noise_model=map_binning.noise_model, rcond_threshold=self.map_rcond_threshold,
-            sync_type=map_binning.sync_type, save_pointing=map_binning.full_pointing).apply(data, detectors=detectors)
+        # -- final covariance, hits, rcond with the map binning's own flags (:438-479); an MC
+        #    realisation re-uses the existing one
+        if not (self.mc_mode and cov_name in data):
+            CovarianceAndHits(
+                pixel_dist=map_binning.pixel_dist, covariance=cov_name, inverse_covariance=invcov_name, hits=hits_name,
+                rcond=rcond_name, det_mask=map_binning.det_mask, det_flags=map_binning.det_flags,
+                det_flag_mask=map_binning.det_flag_mask, det_data_units=map_binning.det_data_units,
+                shared_flags=map_binning.shared_flags, shared_flag_mask=map_binning.shared_flag_mask,
+                pixel_pointing=map_binning.pixel_pointing, stokes_weights=map_binning.stokes_weights,
+                noise_model=map_binning.noise_model, rcond_threshold=self.map_rcond_threshold,
+                sync_type=map_binning.sync_type, save_pointing=map_binning.full_pointing).apply(data, detectors=detectors)
         t0 = lap("final_covariance", t0)
         # -- undestriped map (:481-513)
         if self.write_binmap:
