@@ -42,6 +42,11 @@ def main():
     ph.raw[:] = rank + 1
     ph.sync_allreduce()
     assert np.all(ph.raw == 3)
+    # sync_alltoallv: same result (reference tests/ops_mapmaker_utils.py:211-397)
+    pa = PixelData(d, np.float64, n_value=3)
+    pa.raw[:] = mine
+    pa.sync_alltoallv()
+    assert np.array_equal(pa.raw, pd.raw)
 
     # 3. amplitude dot products: local dot + scalar all-reduce
     a = Amplitudes(comm, 10, 5)

@@ -158,6 +158,15 @@ class PixelData(AcceleratorObject):
             if restore:
                 self.accel_update_device()
 
+    def sync_alltoallv(self, comm=None, **kwargs):
+        """Same result as :meth:`sync_allreduce` (the reference test
+        src/toast/tests/ops_mapmaker_utils.py:211-397 asserts the equivalence).  The reference's
+        owner-computes alltoallv (pixels.py:878-970) saves MPI volume for sparse per-process sky
+        coverage; with one process per GPU on xGMI every rank holds the union of the hit submaps
+        (``unify_local_submaps``) and one in-place RCCL all-reduce of the device buffer serves
+        both entry points."""
+        self.sync_allreduce(comm=comm)
+
     # accelerator protocol
     def _accel_exists(self):
         return self.raw.size > 0 and accel_data_present(self.raw, self._accel_name)
