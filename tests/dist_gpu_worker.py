@@ -1,0 +1,72 @@
+"""Worker for tests/test_gpu_dist.py: two processes on ONE GPU (the memory manager maps
+ceil(procs / devices) processes to a device, accelerator.cpp:276-281), collectives over gloo.
+Each rank holds half of the detectors of one focalplane; the full MapMaker (solver covariance,
+RHS, PCG with offset templates, final covariance, cleaned-signal binning) must reproduce the
+single-process run over all detectors: every collective of the N > 1 path -- union of hit
+submaps, zmap / hits / inverse-covariance all-reduce, amplitude dot products -- sits on that path."""
+import os
+import sys
+
+import numpy as np
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from toast_amd import ops  # noqa: E402
+from toast_amd.accel import accel_assign_device  # noqa: E402
+from toast_amd.data import Comm, defaults  # noqa: E402
+from toast_amd.sim import create_satellite_data  # noqa: E402
+from toast_amd.templates import Offset  # noqa: E402
+
+N_SAMP, N_TOTAL, STEP = 6000, 6, 200
+
+
+def build(comm, first, n_det, full_pointing):
+    data = create_satellite_data(comm=comm, n_det=n_det, total_det=N_TOTAL, first_det=first, n_samp=N_SAMP, rate=10.0,
+                                 spin_angle_deg=25.0, prec_angle_deg=35.0)
+    ob = data.obs[0]
+    for i, d in enumerate(ob.local_detectors):   # signal and flags are functions of the GLOBAL detector index
+        rng = np.random.default_rng(1000 + first + i)
+        sig = rng.standard_normal(N_SAMP) + np.repeat(3.0 * rng.standard_normal(N_SAMP // STEP + 1), STEP)[:N_SAMP]
+        ob.detdata[defaults.det_data][d] = sig
+        ob.detdata[defaults.det_flags][d] = (rng.random(N_SAMP) < 0.01).astype(np.uint8) * defaults.det_mask_invalid
+    dp = ops.PointingDetectorSimple()
+    pix = ops.PixelsHealpix(detector_pointing=dp, nside=16, nside_submap=4)
+    sw = ops.StokesWeights(detector_pointing=dp, mode="IQU", hwp_angle=defaults.hwp_angle)
+    binner = ops.BinMap(pixel_dist="dist", pixel_pointing=pix, stokes_weights=sw, full_pointing=full_pointing)
+    tmpl = Offset(step_time=STEP / 10.0, noise_model=defaults.noise_model, name="baselines", good_fraction=0.2)
+    mapper = ops.MapMaker(name="mm", det_data=defaults.det_data, binning=binner,
+                          template_matrix=ops.TemplateMatrix(templates=[tmpl]), iter_max=15, convergence=1e-30,
+                          solve_rcond_threshold=1e-3, map_rcond_threshold=1e-3, keep_solver_products=True)
+    mapper.apply(data)
+    return data, mapper
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, size = dist.get_rank(), dist.get_world_size()
+    assert size == 2
+    accel_assign_device(size, rank, 1.0, False)
+    half = N_TOTAL // size
+    for full_pointing in (True, False):
+        data, mapper = build(Comm(), half * rank, half, full_pointing)
+        serial, smapper = build(Comm(use_dist=False), 0, N_TOTAL, full_pointing)
+        assert list(data["dist"].local_submaps) == list(serial["dist"].local_submaps)
+        assert np.array_equal(data["mm_hits"].data, serial["mm_hits"].data)
+        for key in ("mm_cov", "mm_rcond", "mm_map", "mm_noiseweighted_map"):
+            a, b = data[key].data, serial[key].data
+            assert np.max(np.abs(a - b)) < 1e-9 * np.max(np.abs(b)), (key, float(np.max(np.abs(a - b))))
+        np.testing.assert_allclose(mapper.history[:5], smapper.history[:5], rtol=1e-6)
+        mine = data["mm_solve_amplitudes"]["baselines"]
+        ref = serial["mm_solve_amplitudes"]["baselines"]
+        assert mine.n_local * size == ref.n_local and mine.n_global == ref.n_global
+        want = ref.local[rank * mine.n_local:(rank + 1) * mine.n_local]
+        assert np.max(np.abs(mine.local - want)) < 1e-7 * np.max(np.abs(ref.local))
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"rank {rank} OK")
+
+
+if __name__ == "__main__":
+    main()
