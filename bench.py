@@ -79,10 +79,17 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # TOAST_BENCH_SHARE_GPU=1 (tests only): several ranks on the GPUs that exist, collectives over
+    # gloo -- lets the N > 1 code path run on a single-GPU box.  Numbers from such a run mean nothing.
+    share = os.environ.get("TOAST_BENCH_SHARE_GPU", "0") == "1"
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     D = capi.dev
     stream = torch.cuda.current_stream().cuda_stream
 

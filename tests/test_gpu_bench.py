@@ -41,3 +41,22 @@ def test_bench_contract_small_workload():
     assert d["pcg_lhs_offset_templates"]["fused_vs_sequence_max_rel_diff"] < 1e-12
     assert d["pointing_on_the_fly"]["offset_lhs_vs_sequence_max_rel_diff"] < 1e-12
     assert d["compact_pixels_weights_on_the_fly"]["offset_lhs_vs_sequence_max_rel_diff"] < 1e-12
+
+
+def test_bench_two_ranks_code_path():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one rank per GPU), here
+    with both ranks sharing the one GPU and gloo instead of RCCL (TOAST_BENCH_SHARE_GPU=1): rank 0
+    prints one JSON line, value is the whole-job aggregate, the zmap all-reduce is in the step."""
+    env = dict(os.environ, TOAST_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--workload", "mini"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 3
+    n = d["config"]["detectors_per_gpu"] * d["config"]["samples_per_detector"]
+    assert abs(d["value"] - 2 * n / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert "cpu_baseline" not in d          # rank 0 at N = 1 only
