@@ -645,7 +645,7 @@ def test_mapmaker_two_observations_fused_equals_operator_sequence():
     and uncached."""
     res = {}
     for key, kw in (("seq", dict(fused_lhs=False, full=True)), ("fused", dict(fused_lhs=True, full=True)),
-                    ("otf", dict(fused_lhs=True, full=False))):
+                    ("otf", dict(fused_lhs=True, full=False)), ("seq_uncached", dict(fused_lhs=False, full=False))):
         data, pix, sw, truth, sky = make_solver_setup(noise_rms=0.1, n_det=4, n_samp=5000, seed=3)
         data2, _, _, _, _ = make_solver_setup(noise_rms=0.1, n_det=4, n_samp=3100, seed=4)
         ob2 = data2.obs[0]
@@ -661,7 +661,7 @@ def test_mapmaker_two_observations_fused_equals_operator_sequence():
                     np.array(mapper.history))
     n_amp = res["seq"][0].size
     assert n_amp == 4 * (-(-5000 // 130) + -(-3100 // 130))
-    for key in ("fused", "otf"):
+    for key in ("fused", "otf", "seq_uncached"):
         np.testing.assert_allclose(res[key][2][:5], res["seq"][2][:5], rtol=1e-6)
         assert np.max(np.abs(res[key][0] - res["seq"][0])) < 1e-7 * np.max(np.abs(res["seq"][0]))
         assert np.max(np.abs(res[key][1] - res["seq"][1])) < 1e-7 * np.max(np.abs(res["seq"][1]))
