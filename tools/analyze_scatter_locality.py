@@ -1,5 +1,5 @@
-"""How many global atomics could an LDS-staged accumulator tile save?  (CPU analysis, oracle
-pixels.)  For tiles of 1024 consecutive samples x G detectors, count the distinct pixels (= the
+"""How many global atomics could an LDS-staged accumulator tile save?  (Analysis of the pixel
+streams; the pixels come from the HIP library, so this runs on the GPU box.)  For tiles of 1024 consecutive samples x G detectors, count the distinct pixels (= the
 flushes an ideal LDS image needs) and compare with the atomics the run-reduction kernels issue:
 one per run of equal pixels inside each 64-sample wave, half of that when the A/B detectors of
 a focalplane pixel are merged.  Output per det-sample (multiply by nnz for atomic instructions)."""
@@ -8,9 +8,11 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import torch
 
-import oracle
-from toast_amd import synth
+from toast_amd import capi, synth
+
+D = capi.dev
 
 for label, (nside, rate, scan) in {"cfg3 satellite": (1024, 200.0, "sat"), "cfg5g ground": (2048, 200.0, "ground")}.items():
     n_det, n_samp = 64, 200000
@@ -20,11 +22,13 @@ for label, (nside, rate, scan) in {"cfg3 satellite": (1024, 200.0, "sat"), "cfg5
             else synth.ground_scan(n_samp, rate)[0])
     ivl = synth.make_intervals(n_samp, 1, rate)
     idx = np.arange(n_det, dtype=np.int32)
-    quats = np.zeros((n_det, n_samp, 4))
-    oracle.pointing_detector(fp, bore, idx, quats, ivl, np.zeros(1, np.uint8), 0)
-    pix = np.zeros((n_det, n_samp), dtype=np.int64)
-    hs = np.zeros(12 * nside * nside // 3072, dtype=np.uint8)
-    oracle.pixels_healpix(idx, quats, np.zeros(1, np.uint8), 0, idx, pix, ivl, hs, 3072, nside, True)
+    d_bore = torch.from_numpy(bore).cuda()
+    d_pix = torch.zeros((n_det, n_samp), dtype=torch.int64, device="cuda")
+    d_hs = torch.zeros(12 * nside * nside // 3072, dtype=torch.uint8, device="cuda")
+    pt = capi.otf_pointing(d_bore.data_ptr(), fp, nside, True, 1)
+    D.otf_pixels_healpix(pt, idx, d_pix.data_ptr(), n_samp, ivl, d_hs.data_ptr(), d_hs.numel(), 3072)
+    torch.cuda.synchronize()
+    pix = d_pix.cpu().numpy()
     chunk, stride = 1024, 7
     runs_single = runs_pair = 0
     distinct = {2: 0, 16: 0, 64: 0}
