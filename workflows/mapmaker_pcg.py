@@ -4,7 +4,12 @@ Nside 1024, rocFFT noise weighting (NoiseFilter) followed by the full MapMaker P
 offset (baseline) templates, everything through the reference's Operator names.
 
     python workflows/mapmaker_pcg.py [--ndet 1024] [--minutes 60] [--rate 200] [--nside 1024]
-                                     [--iter 10] [--step-time 1.0] [--no-filter]
+                                     [--iter 10] [--step-time 1.0] [--no-filter] [--uncached [--compact]]
+
+Detector-sharded over several GPUs (configs[3]: --ndet is the number of detectors PER RANK):
+
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 \
+        workflows/mapmaker_pcg.py --ndet 512 --minutes 240
 
 Prints wall time per phase and the PCG iteration rate in det-samples/s.
 """
@@ -25,13 +30,15 @@ from toast_amd.templates import Offset  # noqa: E402
 
 
 class Phase:
-    def __init__(self):
+    def __init__(self, quiet=False):
         self.t = time.time()
+        self.quiet = quiet
 
     def lap(self, name):
         native().accel_synchronize()
         now = time.time()
-        print(f"  {name:34s} {now - self.t:8.2f} s", flush=True)
+        if not self.quiet:
+            print(f"  {name:34s} {now - self.t:8.2f} s", flush=True)
         self.t = now
 
 
@@ -51,12 +58,32 @@ def main(argv=None):
     args = ap.parse_args(argv)
 
     n_samp = int(args.minutes * 60 * args.rate)
-    ph = Phase()
-    data = create_satellite_data(n_det=args.ndet, n_samp=n_samp, rate=args.rate, spin_period_s=600.0,
-                                 spin_angle_deg=30.0, prec_period_s=3000.0, prec_angle_deg=65.0, net=1.0,
-                                 fknee=0.05)
+    # one process per GPU: rank r owns detectors [r * ndet, (r + 1) * ndet) of one focalplane
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    comm = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        from toast_amd.accel import accel_assign_device
+        from toast_amd.data import Comm
+
+        share = os.environ.get("TOAST_BENCH_SHARE_GPU", "0") == "1"   # tests: ranks share the GPUs, gloo
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        nloc = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        accel_assign_device(nloc, local, 1.0, False)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+        comm = Comm()
+    quiet = rank != 0
+    ph = Phase(quiet)
+    data = create_satellite_data(comm=comm, n_det=args.ndet, total_det=args.ndet * world, first_det=args.ndet * rank,
+                                 n_samp=n_samp, rate=args.rate, spin_period_s=600.0, spin_angle_deg=30.0,
+                                 prec_period_s=3000.0, prec_angle_deg=65.0, net=1.0, fknee=0.05)
     ob = data.obs[0]
-    rng = np.random.default_rng(1)
+    rng = np.random.default_rng(1 + rank)
     sig = ob.detdata[defaults.det_data].data
     for d in range(sig.shape[0]):  # white noise + one random-walk-ish drift per detector
         sig[d] = rng.standard_normal(n_samp)
@@ -80,9 +107,17 @@ def main(argv=None):
     total = time.time() - t0
     ph.lap("MapMaker (cov + RHS + PCG + bin)")
     n_it = len(mapper.history)
-    nds = args.ndet * n_samp
-    print(f"detectors {args.ndet}  samples/det {n_samp}  nside {args.nside}  amplitudes "
-          f"{data['mapmaker_solve_amplitudes']['baselines'].n_local}  PCG iterations {n_it}  "
+    nds = args.ndet * world * n_samp
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+    if quiet:
+        if world > 1:
+            dist.destroy_process_group()
+        return data
+    print(f"ranks {world}  detectors {args.ndet * world}  samples/det {n_samp}  nside {args.nside}  amplitudes "
+          f"{data['mapmaker_solve_amplitudes']['baselines'].n_global}  PCG iterations {n_it}  "
           f"relative residual {mapper.history[-1]:.3e}")
     if hasattr(mapper, "timing_log"):
         for k, v in mapper.timing_log.items():
@@ -95,6 +130,8 @@ def main(argv=None):
             med = float(np.median(its))
             print(f"PCG iteration (median wall time): {1e3 * med:.1f} ms  = {nds / med / 1e9:.1f} G det-samples/s")
     print(f"MapMaker total {total:.2f} s")
+    if world > 1:
+        dist.destroy_process_group()
     return data
 
 
