@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--pcg-extra", action="store_true",
                     help="also time the full PCG LHS with offset templates (operator sequence vs fused kernels)")
     ap.add_argument("--no-arena", action="store_true", help="allocate every buffer separately (placement experiment)")
+    ap.add_argument("--no-probe", action="store_true",
+                    help="one arena in allocation order instead of probing HBM regions for the fastest placement")
     ap.add_argument("--hwp", action="store_true", help="rotating half-wave plate (88 rpm): Stokes weights with HWP angle")
     ap.add_argument("--unfused", action="store_true", help="run noise_weight as its own kernel (105 B variant)")
     return ap.parse_args()
@@ -130,10 +132,13 @@ def main():
 
     nds = n_det * n_samp
     sizes = {"pixels": nds * 8, "weights": nds * 24, "tod": nds * 8, "tod2": nds * 8, "dflags": nds}
+    placement = None
     if args.no_arena:
         arena = None
-    else:
+    elif args.no_probe:
         arena = torch.empty(sum(_align(v) for v in sizes.values()), dtype=torch.uint8, device=dev)
+    else:
+        arena = None
     cursor = [0]
 
     def carve(name, dtype, shape):
@@ -143,6 +148,54 @@ def main():
         view = arena[cursor[0]:cursor[0] + nb].view(dtype).view(shape)
         cursor[0] += _align(nb)
         return view
+
+    if arena is None and not args.no_arena:
+        # HBM region probing.  The same kernel runs up to 19 % slower on some multi-GB regions of
+        # HBM than on others (5.05 vs 5.99 TB/s for a pure stream, stable for the lifetime of an
+        # allocation: profiles/r01_b_tuning_experiments.txt section 14).  Allocate more candidate
+        # buffers than needed, time a pure read+write stream on each, keep the fastest ones for
+        # the persistent TOD-domain arrays (the written timestream first) and free the rest.
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        budget = int(0.45 * total_b)
+        one, three = _align(nds * 8), _align(nds * 24)
+        n_tri = 3 if 3 * three + 4 * one <= budget else (2 if 2 * three + 3 * one <= budget else 1)
+        n_one = max(3, min(8, (budget - n_tri * three) // one))
+        singles = [torch.empty(one, dtype=torch.uint8, device=dev) for _ in range(n_one)]
+        triples = [torch.empty(three, dtype=torch.uint8, device=dev) for _ in range(n_tri)]
+        idx_p = np.arange(n_det, dtype=np.int32)
+        ivl_p = synth.make_intervals(n_samp, 1, rate)
+        ones_p = np.ones(n_det)
+
+        def stream_ms(ptr):
+            D.noise_weight(ptr, n_samp, idx_p, ivl_p, ones_p, stream)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                D.noise_weight(ptr, n_samp, idx_p, ivl_p, ones_p, stream)
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) / 3
+
+        for t in singles + triples:
+            t.zero_()
+        t_one = [stream_ms(t.data_ptr()) for t in singles]
+        t_tri = [sum(stream_ms(t.data_ptr() + k * nds * 8) for k in range(3)) for t in triples]
+        order = list(np.argsort(t_one))
+        best_tri = int(np.argmin(t_tri))
+        chosen = {"tod2": singles[order[0]], "tod": singles[order[1]], "pixels": singles[order[2]],
+                  "weights": triples[best_tri]}
+        placement = {
+            "stream_ms_single_candidates": [round(float(x), 3) for x in t_one],
+            "stream_ms_triple_candidates": [round(float(x), 3) for x in t_tri],
+            "chosen": {"tod2": int(order[0]), "tod": int(order[1]), "pixels": int(order[2]), "weights": best_tri},
+        }
+        del singles, triples
+        torch.cuda.empty_cache()
+
+        def carve(name, dtype, shape):  # noqa: F811
+            if name in chosen:
+                return chosen[name][: sizes[name]].view(dtype).view(shape)
+            return torch.empty(shape, dtype=dtype, device=dev)
 
     d_pixels = carve("pixels", torch.int64, (n_det, n_samp))
     d_weights = carve("weights", torch.float64, (n_det, n_samp, 3))
@@ -360,6 +413,7 @@ def main():
             "from_boresight_weights_ms": t_sw_x,
         },
         "setup_s": t_setup,
+        "placement": placement,
     }
 
     # ------------------------------------------------------------------ extra: full PCG LHS with offset templates
