@@ -394,6 +394,39 @@ int toast_hip_template_offset_apply_diag_precond_dev(
     const double * d_offset_var, const double * d_amp_in, const uint8_t * d_amplitude_flags,
     double * d_amp_out, int64_t n_amp, void * stream);
 
+/* Offset template noise prior and its preconditioners on device-resident amplitudes.  The
+ * reference applies them on the host only and refuses use_accel
+ * (src/toast/templates/offset/offset.py:884-960 `_add_prior`, :963-1005 `_apply_precond`); these
+ * two entry points are what a maintainer binds there instead of the NotImplementedError.
+ *
+ * The local amplitudes are a concatenation of n_seg segments, one per (detector, observation,
+ * view) in the template's own order: d_seg_start[n_seg + 1] holds their first amplitudes and the
+ * total.  Every table argument is a device pointer.
+ *
+ * toast_hip_template_offset_convolve_dev: out (+)= scipy.signal.convolve(in, filter, "same") per
+ * segment with the segment's filter (d_filters + d_filt_start[s], d_filt_len[s] taps, odd),
+ * then out = 0 where the amplitude is flagged.  accumulate != 0 is `_add_prior`
+ * (offset.py:918-943), accumulate == 0 the Toeplitz preconditioner of precond_width <= 1
+ * (offset.py:981-989).  in and out must differ.
+ *
+ * toast_hip_template_offset_banded_solve_dev: out = cho_solve_banded((factor, lower=True), in)
+ * per segment (offset.py:990-1001), out = 0 where flagged.  The factor of segment s, band width
+ * w = d_band_width[s] <= max_band_width <= 256, is handed over as two [n_amp_view][w] row-major
+ * tables at d_forward / d_backward + d_band_start[s], with cb[k][j] = L[j + k][j] scipy's lower
+ * banded storage:
+ *   forward[i][0] = backward[i][0] = 1 / cb[0][i]
+ *   forward[i][k]  = cb[k][i - k]  (0 when i - k < 0),   k = 1 .. w-1
+ *   backward[i][k] = cb[k][i]      (0 when i + k >= n),  k = 1 .. w-1 */
+int toast_hip_template_offset_convolve_dev(
+    int64_t n_amp, int64_t n_seg, const int64_t * d_seg_start, const int64_t * d_filt_start,
+    const int64_t * d_filt_len, const double * d_filters, const double * d_amp_in,
+    const uint8_t * d_amplitude_flags, double * d_amp_out, int accumulate, void * stream);
+
+int toast_hip_template_offset_banded_solve_dev(
+    int64_t n_seg, const int64_t * d_seg_start, const int32_t * d_band_width, int32_t max_band_width,
+    const int64_t * d_band_start, const double * d_forward, const double * d_backward,
+    const double * d_amp_in, const uint8_t * d_amplitude_flags, double * d_amp_out, void * stream);
+
 /* ------------------------------------------------------------------------------------
  * FFT noise weighting (rocFFT)
  *

@@ -237,7 +237,11 @@ class SolverLHS(Operator):
                     and otf_supported(self.binning.pixel_pointing, self.binning.stokes_weights)):
                 return False
         tmpls = [t for t in self.template_matrix.templates if t.enabled]
-        if len(tmpls) != 1 or not isinstance(tmpls[0], Offset) or tmpls[0].use_noise_prior:
+        if len(tmpls) != 1 or not isinstance(tmpls[0], Offset):
+            return False
+        if tmpls[0].use_noise_prior and self.binning.pixel_pointing.view is not None:
+            # with a noise prior the baselines ignore the view (offset.py:135-140); the fused
+            # kernels take the baseline boundaries from the pointing view
             return False
         if self.binning.stokes_weights.mode not in ("I", "IQU"):
             return False
@@ -305,7 +309,10 @@ class SolverLHS(Operator):
                    in_ptr=accel_device_ptr(amps_in.local), in_flags_ptr=accel_device_ptr(amps_in.local_flags),
                    out_ptr=accel_device_ptr(amps_out.local), out_bytes=amps_out.local.nbytes,
                    det_flag_mask=binning.det_flag_mask, shared_flag_mask=binning.shared_flag_mask,
-                   tmpl_flag_mask=tmpl.det_flag_mask, passes=[])
+                   tmpl_flag_mask=tmpl.det_flag_mask, passes=[], prior=None)
+        if tmpl.use_noise_prior and tmpl._prior is not None:
+            tmpl._prior.to_device()
+            ctx["prior"] = tmpl._prior
         for iob, ob in enumerate(data.obs):
             dets = [d for d in ob.select_local_detectors(detectors, flagmask=binning.det_mask)
                     if d in tmpl._obs_dets[iob]]
@@ -351,6 +358,9 @@ class SolverLHS(Operator):
         D = capi.dev
         D.memset(c["zmap_ptr"], 0, c["zmap_bytes"])
         D.memset(c["out_ptr"], 0, c["out_bytes"])
+        if c["prior"] is not None:
+            # a_out = C_a^-1 a: the noise prior term of the left-hand side (mapmaker_solve.py:409-411)
+            c["prior"].add_prior(c["amps_in"], c["amps_out"])
         for ps in c["passes"]:
             if c["on_the_fly"]:
                 D.otf_offset_accumulate(ps["pt"], ps["step"], ps["ao"], ps["nav"], c["in_ptr"], c["in_flags_ptr"],
@@ -406,7 +416,8 @@ class SolverLHS(Operator):
                id(data.get(binning.binned)), id(data.get(binning.covariance)), id(data.get(binning.pixel_dist)),
                binning.full_pointing, bool(getattr(binning, "compact_cache", False)), binning.det_flags,
                binning.det_flag_mask, binning.shared_flags, binning.shared_flag_mask, binning.det_mask,
-               tmpl.det_flags, tmpl.det_flag_mask, tmpl.step_time, amps_in.accel_in_use())
+               tmpl.det_flags, tmpl.det_flag_mask, tmpl.step_time, tmpl.use_noise_prior, tmpl.precond_width,
+               amps_in.accel_in_use())
         plan = self.__dict__.get("_fused_plan")
         if plan is None or plan["key"] != key or plan["generation"] != capi.accel_generation():
             ctx = self._fused_prepare(data, detectors)

@@ -4,8 +4,8 @@ Reference: src/toast/templates/amplitudes.py (Amplitudes, AmplitudesMap),
 src/toast/templates/template.py (Template), src/toast/templates/offset/offset.py (Offset,
 kernels src/toast/_libtoast/template_offset.cpp:16-408).  The noise prior of the Offset
 template (offset.py:455-476, 884-1005) is host-only scipy code in the reference
-(``NotImplementedError`` on accelerators) and is out of the hot path: only
-``use_noise_prior=False`` (the reference default) is supported.
+(``NotImplementedError`` on accelerators); here ``use_noise_prior=True`` runs on the device as
+well (templates/offset_prior.py, csrc/offset_prior.hip).
 """
 
 import numpy as np
@@ -336,8 +336,14 @@ class Offset(Template):
         return int(stime * rate + 0.5)
 
     def _initialize(self, new_data):
-        if self.use_noise_prior:
-            raise NotImplementedError("the Offset noise prior is host-only in the reference and not on the hot path")
+        if self.use_noise_prior and self.noise_model is None:
+            raise RuntimeError("cannot use noise prior without specifying noise_model")
+        # with a noise prior the baselines run through the whole observation and the view only
+        # flags samples (offset.py:135-140)
+        self._bounds_view = None if self.use_noise_prior else self.view
+        if getattr(self, "_prior", None) is not None:
+            self._prior.clear()
+        self._prior = None
         self._obs_views, self._obs_view_flags, self._obs_rate, self._obs_dets = {}, {}, {}, {}
         all_dets = {}
         for iob, ob in enumerate(new_data.obs):
@@ -348,7 +354,7 @@ class Offset(Template):
             self._obs_rate[iob] = rate
             step_length = self._step_length(self.step_time, rate)
             views = []
-            for vw in ob.intervals[self.view]:
+            for vw in ob.intervals[self._bounds_view]:
                 view_len = vw.last - vw.first
                 n = view_len // step_length
                 if n * step_length < view_len:
@@ -384,11 +390,45 @@ class Offset(Template):
         # offset variance / flags: offset.py:262-343
         from ..accel import accel_enabled
 
-        if accel_enabled() and self._n_local > 0:
+        if accel_enabled() and self._n_local > 0 and self._bounds_view == self.view:
             self._init_variances_device(new_data)
         else:
+            # (also when the baselines do not follow the view: the samples outside the view count
+            # as flagged, which the host form takes from the view flags)
             self._init_variances_host(new_data)
         self._flag_cache = {}
+        if self.use_noise_prior and self._n_local > 0:
+            self._init_noise_prior(new_data)
+
+    def _init_noise_prior(self, new_data):
+        """Filters and preconditioners of every (detector, observation, view) segment
+        (offset.py:200-223, 345-566), built once on the host; see templates/offset_prior.py."""
+        from .offset_prior import OffsetPrior, prior_frequencies
+
+        freq = {}
+        for iob, ob in enumerate(new_data.obs):
+            t = ob.shared[self.times].data
+            obstime = float(t[-1] - t[0])
+            if obstime / self.step_time < 1.0:
+                # the reference disables the prior for such an observation and then fails on the
+                # missing frequency grid (offset.py:212-218, 365-371)
+                raise RuntimeError(f"obs {ob.name} has only one offset amplitude: cannot use the noise prior")
+            freq[iob] = prior_frequencies(obstime, self.step_time, self._obs_rate[iob])
+        segments = []
+        offset = 0
+        for det in self._all_dets:
+            for iob, ob in enumerate(new_data.obs):
+                if det not in self._obs_dets[iob]:
+                    continue
+                noise = ob[self.noise_model]
+                psdfreq = np.ascontiguousarray(noise.freq(det), dtype=np.float64)
+                psd = np.ascontiguousarray(noise.psd(det), dtype=np.float64)
+                detnoise = float(noise.detector_weight(det))
+                for n_amp_view in self._obs_views[iob]:
+                    segments.append(dict(first=offset, n_amp=int(n_amp_view), freq=freq[iob], psdfreq=psdfreq,
+                                         psd=psd, detnoise=detnoise))
+                    offset += int(n_amp_view)
+        self._prior = OffsetPrior(self.name, self.precond_width).build(segments, self._offsetvar, self.step_time)
 
     def _init_variances_device(self, new_data):
         """Per-amplitude counts of flagged samples from one kernel over the resident flags
@@ -407,7 +447,7 @@ class Offset(Template):
             step_length = self._step_length(self.step_time, self._obs_rate[iob])
             # lengths of the baselines of one detector of this observation, view after view
             lens = []
-            for ivw, vw in enumerate(ob.intervals[self.view]):
+            for ivw, vw in enumerate(ob.intervals[self._bounds_view]):
                 n_amp_view = int(self._obs_views[iob][ivw])
                 if n_amp_view == 0:
                     continue
@@ -429,7 +469,7 @@ class Offset(Template):
                     fd.accel_update_device()
                 capi.dev.offset_count_flagged(step_length, offs, self._obs_views[iob], accel_device_ptr(bad.local),
                                               fd.indices(dets), accel_device_ptr(fd.buffer), self.det_flag_mask,
-                                              ob.n_local_samples, ob.intervals[self.view].data)
+                                              ob.n_local_samples, ob.intervals[self._bounds_view].data)
         bad.accel_update_host()
         bad.clear()
         n_good = amplen - np.rint(bad.local).astype(np.int64)
@@ -450,7 +490,7 @@ class Offset(Template):
                 if self.noise_model is not None:
                     detnoise = ob[self.noise_model].detector_weight(det)
                 step_length = self._step_length(self.step_time, self._obs_rate[iob])
-                for ivw, vw in enumerate(ob.intervals[self.view]):
+                for ivw, vw in enumerate(ob.intervals[self._bounds_view]):
                     n_amp_view = int(self._obs_views[iob][ivw])
                     view_samples = vw.last - vw.first
                     if detnoise <= 0:
@@ -481,7 +521,7 @@ class Offset(Template):
         return z
 
     def _supports_accel(self):
-        return not self.use_noise_prior
+        return True
 
     def supports_accel(self):
         return self._supports_accel()
@@ -531,7 +571,7 @@ class Offset(Template):
             capi.dev.offset_add_to_signal_multi(
                 self._step_length(self.step_time, self._obs_rate[iob]), self.det_amp_offsets(iob, dets),
                 self._obs_views[iob], accel_device_ptr(amplitudes.local), accel_device_ptr(amplitudes.local_flags),
-                dd.indices(dets), accel_device_ptr(dd.buffer), ob.n_local_samples, ob.intervals[self.view].data)
+                dd.indices(dets), accel_device_ptr(dd.buffer), ob.n_local_samples, ob.intervals[self._bounds_view].data)
 
     def project_signal_multi(self, detectors, amplitudes, **kwargs):
         from .. import capi
@@ -554,7 +594,7 @@ class Offset(Template):
                 dd.indices(dets), accel_device_ptr(dd.buffer), f_idx, f_ptr, self.det_flag_mask,
                 self._step_length(self.step_time, self._obs_rate[iob]), self.det_amp_offsets(iob, dets),
                 self._obs_views[iob], accel_device_ptr(amplitudes.local), accel_device_ptr(amplitudes.local_flags),
-                ob.n_local_samples, ob.intervals[self.view].data)
+                ob.n_local_samples, ob.intervals[self._bounds_view].data)
 
     def _add_to_signal(self, detector, amplitudes, use_accel=None, **kwargs):
         if detector not in self._all_dets:
@@ -570,7 +610,7 @@ class Offset(Template):
             n_amp_views = self._obs_views[iob]
             native().template_offset_add_to_signal(step_length, amp_offset, n_amp_views, amplitudes.local,
                                                    amplitudes.local_flags, int(det_indx[0]),
-                                                   ob.detdata[self.det_data].arg(use_accel), ob.intervals[self.view].data,
+                                                   ob.detdata[self.det_data].arg(use_accel), ob.intervals[self._bounds_view].data,
                                                    use_accel)
             amp_offset += int(np.sum(n_amp_views))
 
@@ -612,17 +652,39 @@ class Offset(Template):
             native().template_offset_project_signal(int(det_indx[0]), ob.detdata[self.det_data].arg(use_accel), flag_indx,
                                                     flag_data, self.det_flag_mask, step_length, amp_offset,
                                                     n_amp_views, amplitudes.local, amplitudes.local_flags,
-                                                    ob.intervals[self.view].data, use_accel)
+                                                    ob.intervals[self._bounds_view].data, use_accel)
             amp_offset += int(np.sum(n_amp_views))
 
+    def _on_device(self, amplitudes_in, amplitudes_out, fn):
+        """Run ``fn`` with both vectors resident; hand the result back to the host when the
+        caller's vectors were host-current (the PCG keeps them resident and skips this)."""
+        stay = amplitudes_in.accel_in_use() or amplitudes_out.accel_in_use()
+        in_was = amplitudes_in.accel_in_use()
+        amplitudes_in.accel_resident(f"{self.name}_amps_in")
+        amplitudes_out.accel_resident(f"{self.name}_amps_out")
+        fn()
+        if not stay:
+            native().accel_synchronize()
+            amplitudes_out.accel_update_host()
+        if not in_was:
+            amplitudes_in.accel_used(False)  # never modified on the device
+
     def _add_prior(self, amplitudes_in, amplitudes_out, use_accel=None, **kwargs):
-        # no noise prior: nothing to accumulate (offset.py:884-893)
-        return
+        if not self.use_noise_prior or self._n_local == 0:
+            # no noise prior: nothing to accumulate (offset.py:884-893)
+            return
+        self._on_device(amplitudes_in, amplitudes_out, lambda: self._prior.add_prior(amplitudes_in, amplitudes_out))
 
     def _apply_precond(self, amplitudes_in, amplitudes_out, use_accel=None, **kwargs):
-        # diagonal preconditioner (offset.py:1007-1028 -> template_offset_apply_diag_precond)
         if self._n_local == 0:
             return
+        if self.use_noise_prior:
+            # the left-hand side holds the inverse baseline covariance, so does the preconditioner
+            # (offset.py:963-1005)
+            self._on_device(amplitudes_in, amplitudes_out,
+                            lambda: self._prior.apply_precond(amplitudes_in, amplitudes_out))
+            return
+        # diagonal preconditioner (offset.py:1007-1028 -> template_offset_apply_diag_precond)
         if amplitudes_in.accel_in_use() or amplitudes_out.accel_in_use():
             # device-resident PCG vectors: the variances are uploaded once per template
             amplitudes_in.accel_resident()
@@ -638,6 +700,8 @@ class Offset(Template):
                                                     amplitudes_out.local, False)
 
     def clear(self):
+        if getattr(self, "_prior", None) is not None:
+            self._prior.clear()
         if getattr(self, "_offsetvar_on_dev", False):
             accel_data_delete(self._offsetvar, f"{self.name}_offsetvar")
             self._offsetvar_on_dev = False
