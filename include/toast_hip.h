@@ -415,8 +415,10 @@ int toast_hip_template_offset_apply_diag_precond_dev(
  * tables at d_forward / d_backward + d_band_start[s], with cb[k][j] = L[j + k][j] scipy's lower
  * banded storage:
  *   forward[i][0] = backward[i][0] = 1 / cb[0][i]
- *   forward[i][k]  = cb[k][i - k]  (0 when i - k < 0),   k = 1 .. w-1
- *   backward[i][k] = cb[k][i]      (0 when i + k >= n),  k = 1 .. w-1 */
+ *   forward[i][k]  = cb[k][i]      = L[i + k][i]  (0 when i + k >= n),  k = 1 .. w-1
+ *   backward[i][k] = cb[k][i - k]  = L[i][i - k]  (0 when i - k < 0),   k = 1 .. w-1
+ * i.e. row i of each table couples unknown i to the unknowns solved AFTER it in that sweep (the
+ * column-oriented substitution of LAPACK's dtbsv). */
 int toast_hip_template_offset_convolve_dev(
     int64_t n_amp, int64_t n_seg, const int64_t * d_seg_start, const int64_t * d_filt_start,
     const int64_t * d_filt_len, const double * d_filters, const double * d_amp_in,

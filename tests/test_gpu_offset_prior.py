@@ -80,8 +80,8 @@ def pack_factor(cb):
     b = np.zeros((n, w))
     f[:, 0] = b[:, 0] = 1.0 / cb[0]
     for k in range(1, min(w, n)):
-        f[k:, k] = cb[k, :n - k]
-        b[:n - k, k] = cb[k, :n - k]
+        f[:n - k, k] = cb[k, :n - k]
+        b[k:, k] = cb[k, :n - k]
     return f.ravel(), b.ravel()
 
 

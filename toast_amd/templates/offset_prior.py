@@ -217,8 +217,8 @@ class OffsetPrior:
                 f[:, 0] = rdiag
                 b[:, 0] = rdiag
                 for k in range(1, min(w, n)):
-                    f[k:, k] = cb[k, :n - k]   # L[i][i - k]
-                    b[:n - k, k] = cb[k, :n - k]  # L[i + k][i]
+                    f[:n - k, k] = cb[k, :n - k]  # L[i + k][i]: unknown i feeds i + k going forward
+                    b[k:, k] = cb[k, :n - k]      # L[i][i - k]: unknown i feeds i - k going backward
             self.max_width = int(width.max()) if n_seg else 1
             self._register("band_width", width)
             self._register("band_start", start)

@@ -51,6 +51,9 @@ def main(argv=None):
     ap.add_argument("--iter", type=int, default=10)
     ap.add_argument("--step-time", type=float, default=1.0, help="baseline length [s]")
     ap.add_argument("--no-filter", action="store_true")
+    ap.add_argument("--noise-prior", action="store_true",
+                    help="Offset template with the amplitude-domain noise prior (use_noise_prior=True)")
+    ap.add_argument("--precond-width", type=int, default=20, help="band width of the prior's preconditioner")
     ap.add_argument("--uncached", action="store_true",
                     help="full_pointing=False (the reference default): no pointing cache, on-the-fly kernels")
     ap.add_argument("--compact", action="store_true",
@@ -98,7 +101,8 @@ def main(argv=None):
     binner = ops.BinMap(pixel_dist="pixel_dist", pixel_pointing=pixels, stokes_weights=weights,
                         full_pointing=not args.uncached, compact_cache=args.compact)
     tmatrix = ops.TemplateMatrix(templates=[Offset(step_time=args.step_time, noise_model=defaults.noise_model,
-                                                   name="baselines")])
+                                                   name="baselines", use_noise_prior=args.noise_prior,
+                                                   precond_width=args.precond_width)])
     mapper = ops.MapMaker(name="mapmaker", keep_solver_products=True, det_data=defaults.det_data, binning=binner, template_matrix=tmatrix,
                           iter_min=args.iter, iter_max=args.iter, convergence=1e-30)
     t0 = time.time()
