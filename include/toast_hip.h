@@ -429,6 +429,20 @@ int toast_hip_template_offset_banded_solve_dev(
     const int64_t * d_band_start, const double * d_forward, const double * d_backward,
     const double * d_amp_in, const uint8_t * d_amplitude_flags, double * d_amp_out, void * stream);
 
+/* toast_hip_template_offset_banded_cholesky_dev: factorise, per segment, the preconditioner matrix
+ *   M = diag(d_diag_scale[s] / d_offset_var[i]) + Toeplitz(band of segment s)
+ * (offset.py:522-545; scipy.linalg.cholesky_banded(lower=True) on the host there) and write the
+ * factor directly in the two table layouts described above.  The Toeplitz band of segment s is
+ * d_toeplitz[d_toeplitz_start[s] .. + d_toeplitz_len[s]), zero beyond; an amplitude with
+ * variance 0 (flagged) gets no diagonal term.  d_backward must be zero-filled by the caller
+ * (entries that leave the segment are not written).  d_status[s] != 0: not positive definite at
+ * this band width (the caller widens the band, offset.py:546-566).  Band widths up to 64. */
+int toast_hip_template_offset_banded_cholesky_dev(
+    int64_t n_seg, const int64_t * d_seg_start, const int32_t * d_band_width, int32_t max_band_width,
+    const int64_t * d_band_start, const int64_t * d_toeplitz_start, const int32_t * d_toeplitz_len,
+    const double * d_toeplitz, const double * d_diag_scale, const double * d_offset_var,
+    double * d_forward, double * d_backward, int32_t * d_status, void * stream);
+
 /* ------------------------------------------------------------------------------------
  * FFT noise weighting (rocFFT)
  *

@@ -129,6 +129,61 @@ def test_banded_solve_kernel_vs_scipy(width):
     assert np.all(got[flags != 0] == 0.0)
 
 
+@pytest.mark.parametrize("width", [1, 5, 20, 32, 40, 64])
+def test_banded_cholesky_kernel_vs_scipy(width):
+    """toast_hip_template_offset_banded_cholesky_dev vs scipy.linalg.cholesky_banded, including a
+    flagged amplitude (variance 0), a detector without a diagonal term and a matrix that is not
+    positive definite (status)."""
+    import torch
+
+    from toast_amd import capi
+
+    rng = np.random.default_rng(100 + width)
+    seg_len = [1, 3, 19, 64, 65, 700, 129, 50]
+    n_seg = len(seg_len)
+    seg_start = np.concatenate([[0], np.cumsum(seg_len)]).astype(np.int64)
+    n_amp = int(seg_start[-1])
+    var = 1.0 / (3.0 + 5.0 * rng.random(n_amp))
+    var[seg_start[5] + 11] = 0.0
+    widths = np.array([width if s % 2 == 0 else max(1, width // 2) for s in range(n_seg)], dtype=np.int32)
+    band_a = (0.9 ** np.arange(64)) / 4.0
+    band_a[0] = 2.0                           # positive definite on its own
+    band_b = np.concatenate([[0.1], np.full(63, 0.4)])   # needs the diagonal term
+    band_bad = np.concatenate([[0.1], np.full(63, -3.0)])
+    bands = [band_a, band_b, band_a, band_b, band_a, band_b, band_a, band_bad]
+    dscale = np.array([1.0, 1.0, 0.0, 1.0, 1.0, 1.0, 1.0, 1.0])
+    tlen = np.minimum(widths, [64, 64, 64, 3, 64, 64, 64, 64]).astype(np.int32)   # one band shorter than the width
+    tstart = (np.arange(n_seg) * 64).astype(np.int64)
+    start = np.concatenate([[0], np.cumsum(np.array(seg_len) * widths)[:-1]]).astype(np.int64)
+    total = int(np.sum(np.array(seg_len) * widths))
+    d = dev_arrays(seg_start=seg_start, bw=widths, bs=start, ts=tstart, tl=tlen, toep=np.concatenate(bands),
+                   ds=dscale, var=var, fwd=np.full(total, np.nan), bwd=np.zeros(total),
+                   status=np.full(n_seg, -1, dtype=np.int32))
+    capi.dev.offset_banded_cholesky(n_seg, d["seg_start"].data_ptr(), d["bw"].data_ptr(), int(widths.max()),
+                                    d["bs"].data_ptr(), d["ts"].data_ptr(), d["tl"].data_ptr(), d["toep"].data_ptr(),
+                                    d["ds"].data_ptr(), d["var"].data_ptr(), d["fwd"].data_ptr(), d["bwd"].data_ptr(),
+                                    d["status"].data_ptr())
+    torch.cuda.synchronize()
+    status = d["status"].cpu().numpy()
+    fwd, bwd = d["fwd"].cpu().numpy(), d["bwd"].cpu().numpy()
+    for s, n in enumerate(seg_len):
+        w = int(widths[s])
+        ab = np.zeros((w, n))
+        v = var[seg_start[s]:seg_start[s + 1]]
+        ab[0] = dscale[s] * np.where(v > 0, 1.0 / np.where(v > 0, v, 1.0), 0.0)
+        ab[:tlen[s]] += bands[s][:tlen[s], None]
+        try:
+            cb = scipy.linalg.cholesky_banded(ab, lower=True)
+        except np.linalg.LinAlgError:
+            assert status[s] == 1
+            continue
+        assert status[s] == 0
+        f, b = pack_factor(cb)
+        assert rel(fwd[start[s]:start[s] + n * w], f) < TOL
+        assert rel(bwd[start[s]:start[s] + n * w], b) < TOL
+    assert status[-1] == (1 if width > 1 else 0)
+
+
 def prior_setup(precond_width, n_det=3, n_samp=6000, step_time=5.0, n_intervals=1, view=None):
     data = create_satellite_data(n_det=n_det, n_samp=n_samp, rate=10.0, fknee=0.1, net=2.0, n_intervals=n_intervals,
                                  flag_samples=False)
@@ -167,9 +222,16 @@ def test_template_prior_vs_oracle(oracle, precond_width):
             preconds.append(OP.banded_preconditioner(filt, tmpl._offsetvar[first:first + n_amp_view], precond_width,
                                                      detnoise))
         assert rel(tmpl._prior.filters[idet], filt) < 1e-12
-        got_pre = tmpl._prior.precond[idet]
-        want_pre = preconds[-1] if precond_width <= 1 else preconds[-1][0]
-        assert got_pre.shape == want_pre.shape and rel(got_pre, want_pre) < 1e-12
+        if precond_width <= 1:
+            got_pre, want_pre = tmpl._prior.precond[idet], preconds[-1]
+        else:
+            # factorised on the device (k_offset_banded_cholesky); entries below the last row of the
+            # matrix are unused padding in scipy's layout
+            assert tmpl._prior.factor_on_device
+            got_pre, want_pre = tmpl._prior.banded_factor(idet), preconds[-1][0].copy()
+            for k in range(1, want_pre.shape[0]):
+                want_pre[k, n_amp_view - k:] = 0.0
+        assert got_pre.shape == want_pre.shape and rel(got_pre, want_pre) < TOL
     amps_in = tmpl.zeros()
     rng = np.random.default_rng(5)
     amps_in.local[:] = rng.standard_normal(amps_in.n_local)

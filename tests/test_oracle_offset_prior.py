@@ -84,7 +84,7 @@ def test_product_construction_matches_oracle(gold):
         segs = [dict(first=0, n_amp=n_small, freq=freq, psdfreq=f, psd=p, detnoise=0.1),
                 dict(first=n_small, n_amp=n_small, freq=freq, psdfreq=f, psd=p, detnoise=0.1)]
         for width in (1, 20):
-            prior = OffsetPrior("t", width).build(segs, var, step)
+            prior = OffsetPrior("t", width, factor_on_device=False).build(segs, var, step)
             assert list(prior.seg_start) == [0, n_small, 2 * n_small]
             want = OP.view_filter(freq, gold[f"c{ic}_offset_psd"], n_small, step)
             for filt in prior.filters:

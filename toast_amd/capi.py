@@ -784,6 +784,14 @@ class _Dev:
             _i64(n_seg), _p(d_seg_start), _p(d_band_width), C.c_int32(int(max_band_width)), _p(d_band_start),
             _p(d_forward), _p(d_backward), _p(d_amp_in), _p(d_amp_flags), _p(d_amp_out), _p(stream)))
 
+    def offset_banded_cholesky(self, n_seg, d_seg_start, d_band_width, max_band_width, d_band_start, d_toep_start,
+                               d_toep_len, d_toeplitz, d_diag_scale, d_offset_var, d_forward, d_backward, d_status,
+                               stream=0):
+        _check(lib().toast_hip_template_offset_banded_cholesky_dev(
+            _i64(n_seg), _p(d_seg_start), _p(d_band_width), C.c_int32(int(max_band_width)), _p(d_band_start),
+            _p(d_toep_start), _p(d_toep_len), _p(d_toeplitz), _p(d_diag_scale), _p(d_offset_var), _p(d_forward),
+            _p(d_backward), _p(d_status), _p(stream)))
+
     def combine_flags(self, d_out, out_index, d_det_flags, n_flag_samp, flag_index, det_flag_mask, d_shared_flags,
                       n_shared_flags, shared_flag_mask, n_samp, intervals, n_out_rows=0, outside_value=-1, stream=0):
         oi = self._small(out_index, np.int32)

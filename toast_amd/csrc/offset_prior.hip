@@ -80,21 +80,45 @@ __device__ __forceinline__ double dpp_f64_zero_fill(double x) {   // lanes witho
 
 constexpr int kDppWaveShl1 = 0x130;  // lane i reads lane i + 1 of the wave
 
+__device__ __forceinline__ void lds_sync() {   // LDS writes of this wave visible to its later reads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Geometry of one solve: NR registers per lane (window of 64 NR pending unknowns), tiles of R steps.
+template <int NR, int WMAX>
+struct Banded {
+    static constexpr int kWin = 64 * NR;                 // LDS row stride; slots >= w stay zero
+    static constexpr int R = (NR == 1) ? 64 : 16;        // steps per tile
+    static constexpr int G = (NR >= 4) ? 1 : 4 / NR;     // steps whose operands are read together
+    static constexpr int kRows = R + 2 * G;              // + zero rows read by the pipelined tail
+    static constexpr int kPre = R * WMAX / 64;           // tile doubles per lane (global prefetch)
+    static constexpr int kSide = 2 * kRows;              // rhs / diag per step, solved unknowns
+};
+
 // One direction of the banded solve for one segment.  Row i of `coef` holds the reciprocal of the
 // diagonal in slot 0 and, in slots 1..w-1, the couplings of unknown i to the w-1 unknowns that
 // FOLLOW it in sweep order (zero where the band leaves the segment): column i of L going forward,
-// row i of L going backward.  NR registers per lane: pending unknown m = lane + 64 r steps ahead.
-// The rows of R consecutive steps are contiguous in memory: they are staged through LDS with fully
-// coalesced loads, and the rows of the next steps are read from LDS while the current steps run.
-// `side` is 2 R doubles of LDS: rhs / diagonal per step, and the solved unknowns of the block.
-template <int NR, int R, int WMAX, bool BACKWARD>
+// row i of L going backward.  Lane m (+ 64 r) holds the pending sum of the unknown m steps ahead.
+//
+// A single wave issues roughly one instruction per 9 cycles on this recurrence
+// (tools/ubench_chain.hip), so the step is written for instruction count: the rows of R steps
+// are staged in LDS in sweep order with a stride of 64 NR doubles and zero padding, so that a step
+// needs three unconditional LDS reads (its couplings, and 1 / diag and rhs / diag as broadcasts),
+// two v_readlane, two FMAs, one DPP move and one LDS write; operands are read two groups ahead
+// in alternating register sets.
+template <int NR, int WMAX, bool BACKWARD>
 __device__ __forceinline__ void banded_sweep(int64_t n, int w, const double * __restrict__ coef,
                                              const double * rhs, double * out,
                                              const uint8_t * __restrict__ flags, double * __restrict__ tile,
                                              double * __restrict__ side) {
-    constexpr int kPre = R * WMAX / 64;  // doubles per lane of one tile: R rows x WMAX bands / 64 lanes
+    using B = Banded<NR, WMAX>;
+    constexpr int R = B::R, G = B::G, kWin = B::kWin, kPre = B::kPre;
     const int lane = threadIdx.x & 63;
-    double pend[NR];  // sum of coupling x solved unknown, per pending unknown of the window
+    double * __restrict__ solved = side + B::kRows;
+    const unsigned long long inv_w = (1ull << 32) / (unsigned)w + 1ull;   // q / w == (q * inv_w) >> 32, q < 2^16
+    double pend[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) pend[r] = 0.0;
     // The tile and the right-hand sides of the NEXT block are fetched into registers while the
@@ -115,6 +139,40 @@ __device__ __forceinline__ void banded_sweep(int64_t n, int w, const double * __
         const int64_t mine = BACKWARD ? n - 1 - (blk + lane) : blk + lane;
         b_pre = (lane < steps) ? rhs[mine] : 0.0;
     };
+    struct Operands {
+        double c[G][NR], rd[G], t[G];
+    };
+    auto read_rows = [&](Operands & o, int first_step) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const double * __restrict__ row = tile + (first_step + u) * kWin;
+            o.rd[u] = row[0];                   // same address in every lane: a broadcast
+            o.t[u] = side[first_step + u];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) o.c[u][r] = row[lane + 64 * r];
+        }
+    };
+    auto run_steps = [&](const Operands & o, int first_step) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            // y = (b - sum) / diag, as b / diag - sum / diag in one FMA
+            const double y = __builtin_fma(-lane_value(pend[0], 0), o.rd[u], o.t[u]);
+            if (lane == 0) solved[first_step + u] = y;
+            // every pending sum takes its term of this unknown (lane 0 of register 0 is leaving the
+            // window: what it accumulates is discarded), then the window moves on by one lane
+#pragma unroll
+            for (int r = 0; r < NR; ++r) pend[r] = __builtin_fma(o.c[u][r], y, pend[r]);
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                double moved = dpp_f64_zero_fill<kDppWaveShl1>(pend[r]);
+                if (r + 1 < NR) {
+                    const double carry = lane_value(pend[r + 1], 0);
+                    if (lane == 63) moved = carry;
+                }
+                pend[r] = moved;
+            }
+        }
+    };
     fetch(0);
     for (int64_t blk = 0; blk < n; blk += R) {
         const int steps = (n - blk < R) ? (int)(n - blk) : R;
@@ -123,80 +181,35 @@ __device__ __forceinline__ void banded_sweep(int64_t n, int w, const double * __
 #pragma unroll
         for (int u = 0; u < kPre; ++u) {
             const int q = u * 64 + lane;
-            if (q < total) tile[q] = pre[u];
+            if (q < total) {
+                const int row = (int)(((unsigned long long)q * inv_w) >> 32);
+                const int k = q - row * w;
+                const int st = BACKWARD ? steps - 1 - row : row;   // sweep order
+                tile[st * kWin + k] = pre[u];
+            }
+        }
+        if (steps < R) {   // last block: the rows behind it must read as zero (no-op steps)
+            for (int q = lane; q < (R - steps) * kWin; q += 64) tile[steps * kWin + q] = 0.0;
         }
         // right-hand sides of this block, one per lane, in sweep order
         const int64_t mine = BACKWARD ? n - 1 - (blk + lane) : blk + lane;
         const bool live = lane < steps;
         const double b = b_pre;
         if (blk + R < n) fetch(blk + R);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // rhs / diagonal of every step of the block, read back below as a broadcast
-        {
-            const int my_row = BACKWARD ? steps - 1 - lane : lane;
-            if (lane < R) side[lane] = live ? b * tile[my_row * w] : 0.0;
+        lds_sync();
+        if (lane < R) side[lane] = live ? b * tile[lane * kWin] : 0.0;   // rhs / diagonal
+        lds_sync();
+        Operands oa, ob;
+        read_rows(oa, 0);
+        for (int g = 0; g < steps; g += 2 * G) {
+            read_rows(ob, g + G);
+            run_steps(oa, g);
+            read_rows(oa, g + 2 * G);
+            run_steps(ob, g + G);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // The rows are read from LDS a group of G steps ahead (the step itself is shorter than the
-        // LDS latency); rows past the end of the block read as zero, which makes those steps no-ops.
-        constexpr int G = (NR >= 4) ? 1 : 4 / NR;
-        double c_next[G][NR], rd_next[G], t_next[G];
-        auto read_rows = [&](int first_step) {
-#pragma unroll
-            for (int u = 0; u < G; ++u) {
-                const int st = first_step + u;
-                const bool valid = st < steps;
-                const int row = BACKWARD ? steps - 1 - st : st;
-                rd_next[u] = valid ? tile[row * w] : 0.0;   // same address in every lane: a broadcast
-                t_next[u] = valid ? side[st] : 0.0;
-#pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    const int k = lane + 64 * r;
-                    c_next[u][r] = (valid && k < w) ? tile[row * w + k] : 0.0;
-                }
-            }
-        };
-        read_rows(0);
-        for (int g = 0; g < steps; g += G) {
-            double c[G][NR], rd[G], t[G];
-#pragma unroll
-            for (int u = 0; u < G; ++u) {
-                rd[u] = rd_next[u];
-                t[u] = t_next[u];
-#pragma unroll
-                for (int r = 0; r < NR; ++r) c[u][r] = c_next[u][r];
-            }
-            if (g + G < steps) read_rows(g + G);
-#pragma unroll
-            for (int u = 0; u < G; ++u) {
-                // y = (b - sum) / diag, as b / diag - sum / diag in one FMA
-                const double y = __builtin_fma(-lane_value(pend[0], 0), rd[u], t[u]);
-                if (lane == 0 && g + u < steps) side[R + g + u] = y;
-                // every pending sum takes its term of this unknown (lane 0 of register 0 is leaving
-                // the window: what it accumulates is discarded), then the window moves on by one lane
-#pragma unroll
-                for (int r = 0; r < NR; ++r) pend[r] = __builtin_fma(c[u][r], y, pend[r]);
-#pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    double moved = dpp_f64_zero_fill<kDppWaveShl1>(pend[r]);
-                    if (r + 1 < NR) {
-                        const double carry = lane_value(pend[r + 1], 0);
-                        if (lane == 63) moved = carry;
-                    }
-                    pend[r] = moved;
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const double y_keep = live ? side[R + lane] : 0.0;
+        lds_sync();
         if (live) {
-            double v = y_keep;
+            double v = solved[lane];
             if (BACKWARD && flags[mine] != 0) v = 0.0;
             out[mine] = v;
         }
@@ -210,19 +223,86 @@ __global__ __launch_bounds__(64) void k_offset_banded_solve(
     const int64_t * __restrict__ seg_start, const int32_t * __restrict__ band_width,
     const int64_t * __restrict__ band_start, const double * __restrict__ fwd, const double * __restrict__ bwd,
     const double * __restrict__ in, const uint8_t * __restrict__ flags, double * __restrict__ out) {
+    using B = Banded<NR, WMAX>;
     const int64_t s = blockIdx.x;
     const int64_t first = seg_start[s];
     const int64_t n = seg_start[s + 1] - first;
     const int w = band_width[s];
-    if (n <= 0) return;
+    if (n <= 0 || w < 1) return;
     const double * __restrict__ cf = fwd + band_start[s];
     const double * __restrict__ cb = bwd + band_start[s];
-    constexpr int R = (NR == 1) ? 64 : 16;   // rows per LDS tile: at most R * WMAX doubles = 32 KB
-    __shared__ double tile[R * WMAX];
-    __shared__ double side[2 * R];
-    banded_sweep<NR, R, WMAX, false>(n, w, cf, in + first, out + first, flags + first, tile, side);
+    __shared__ double tile[B::kRows * B::kWin];
+    __shared__ double side[B::kSide];
+    for (int q = threadIdx.x; q < B::kRows * B::kWin; q += 64) tile[q] = 0.0;
+    for (int q = threadIdx.x; q < B::kSide; q += 64) side[q] = 0.0;
+    banded_sweep<NR, WMAX, false>(n, w, cf, in + first, out + first, flags + first, tile, side);
     __threadfence_block();
-    banded_sweep<NR, R, WMAX, true>(n, w, cb, out + first, out + first, flags + first, tile, side);
+    banded_sweep<NR, WMAX, true>(n, w, cb, out + first, out + first, flags + first, tile, side);
+}
+
+// Banded Cholesky factorisation of every segment's preconditioner matrix
+//   M = diag(diag_scale / offset_var) + Toeplitz(band)         (offset.py:522-545)
+// written straight into the two tables k_offset_banded_solve reads.  The reference factorises on
+// the host with scipy.linalg.cholesky_banded, one call per detector and view; at cfg3 that is
+// 1024 LAPACK calls (0.8 - 4 s) plus a 1.2 GB upload of the factors.  Here: one wave per segment,
+// left-looking, column j from the previous w-1 columns kept in an LDS ring:
+//   L[j+m][j] = (M[j+m][j] - sum_k L[j+m][j-k] L[j][j-k]) / L[j][j],   lane m, k = 1 .. w-1-m.
+// status[s] != 0: the matrix of segment s is not positive definite at this band width (the
+// caller widens the band as the reference does, offset.py:546-566).
+template <int WMAX>
+__global__ __launch_bounds__(64) void k_offset_banded_cholesky(
+    const int64_t * __restrict__ seg_start, const int32_t * __restrict__ band_width,
+    const int64_t * __restrict__ band_start, const int64_t * __restrict__ toep_start,
+    const int32_t * __restrict__ toep_len, const double * __restrict__ toeplitz,
+    const double * __restrict__ diag_scale, const double * __restrict__ offset_var, double * __restrict__ fwd,
+    double * __restrict__ bwd, int32_t * __restrict__ status) {
+    const int64_t s = blockIdx.x;
+    const int64_t first = seg_start[s];
+    const int64_t n = seg_start[s + 1] - first;
+    const int w = band_width[s];
+    if (n <= 0 || w < 1) return;
+    const int lane = threadIdx.x & 63;
+    __shared__ double hist[WMAX * WMAX];   // ring of the last WMAX columns, WMAX slots each
+    for (int q = lane; q < WMAX * WMAX; q += 64) hist[q] = 0.0;
+    const double band = (lane < toep_len[s]) ? toeplitz[toep_start[s] + lane] : 0.0;
+    const double dscale = diag_scale[s];
+    const double * __restrict__ var = offset_var + first;
+    double * __restrict__ f = fwd + band_start[s];
+    double * __restrict__ b = bwd + band_start[s];
+    lds_sync();
+    bool ok = true;
+    for (int64_t j = 0; j < n; ++j) {
+        double acc = band;
+        if (lane == 0) {
+            const double v = var[j];
+            // a flagged amplitude (variance 0) keeps the Toeplitz part only: see
+            // templates/offset_prior.py -- the reference divides by zero there
+            if (v > 0.0) acc += dscale / v;
+        }
+        const int kmax = (j < w - 1) ? (int)j : w - 1;
+        for (int k = 1; k <= kmax; ++k) {
+            const double * __restrict__ col = hist + (int)((j - k) & (WMAX - 1)) * WMAX;
+            const double mine = (lane + k < w) ? col[lane + k] : 0.0;
+            acc = __builtin_fma(-mine, col[k], acc);
+        }
+        const double d = lane_value(acc, 0);
+        if (!(d > 0.0)) {
+            ok = false;
+            break;
+        }
+        const double ljj = sqrt(d);
+        double l = (lane == 0) ? ljj : acc / ljj;
+        if (lane >= w || j + lane >= n) l = 0.0;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < WMAX) hist[(int)(j & (WMAX - 1)) * WMAX + lane] = l;
+        if (lane < w) {
+            const double outv = (lane == 0) ? 1.0 / ljj : l;
+            f[j * w + lane] = outv;                               // L[j + m][j]: column j
+            if (j + lane < n) b[(j + lane) * w + lane] = outv;    // L[i][i - m] with i = j + m
+        }
+        lds_sync();
+    }
+    if (lane == 0) status[s] = ok ? 0 : 1;
 }
 
 }  // namespace
@@ -274,6 +354,31 @@ int toast_hip_template_offset_banded_solve_dev(int64_t n_seg, const int64_t * d_
             launch(k_offset_banded_solve<2, 128>);
         } else {
             launch(k_offset_banded_solve<4, 256>);
+        }
+        check_launch();
+    });
+}
+
+int toast_hip_template_offset_banded_cholesky_dev(int64_t n_seg, const int64_t * d_seg_start,
+                                                  const int32_t * d_band_width, int32_t max_band_width,
+                                                  const int64_t * d_band_start, const int64_t * d_toeplitz_start,
+                                                  const int32_t * d_toeplitz_len, const double * d_toeplitz,
+                                                  const double * d_diag_scale, const double * d_offset_var,
+                                                  double * d_forward, double * d_backward, int32_t * d_status,
+                                                  void * stream) {
+    return guarded([&] {
+        if (n_seg <= 0) return;
+        if (max_band_width < 1 || max_band_width > 64) fail_arg("offset banded cholesky: band width must be 1..64");
+        const dim3 grid((unsigned)n_seg);
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, grid, dim3(64), 0, as_stream(stream), d_seg_start, d_band_width, d_band_start,
+                               d_toeplitz_start, d_toeplitz_len, d_toeplitz, d_diag_scale, d_offset_var, d_forward,
+                               d_backward, d_status);
+        };
+        if (max_band_width <= 32) {
+            launch(k_offset_banded_cholesky<32>);
+        } else {
+            launch(k_offset_banded_cholesky<64>);
         }
         check_launch();
     });

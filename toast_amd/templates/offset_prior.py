@@ -88,9 +88,16 @@ def _filter_length(n_amp_view):
 class OffsetPrior:
     """Filters, preconditioners and their device tables for one initialised Offset template."""
 
-    def __init__(self, name, precond_width):
+    def __init__(self, name, precond_width, factor_on_device=None):
+        from ..accel import accel_enabled
+
         self.name = name
         self.precond_width = int(precond_width)
+        # banded preconditioner: factorise on the device (one kernel, the factors never exist on
+        # the host) unless there is no device -- then scipy, as the reference does
+        self.factor_on_device = accel_enabled() if factor_on_device is None else bool(factor_on_device)
+        self.detnoise = []         # per segment
+        self._offsetvar = None
         self.seg_start = None      # int64[n_seg + 1]
         self.filters = []          # per segment (host, for inspection / tests)
         self.precond = []          # per segment: Toeplitz row or lower banded Cholesky factor
@@ -102,6 +109,7 @@ class OffsetPrior:
         """``segments``: list of dicts with keys first, n_amp, freq, psdfreq, psd, detnoise in
         amplitude order.  ``offsetvar``: the template's per-amplitude variances."""
         n_seg = len(segments)
+        self._offsetvar = offsetvar
         self.seg_start = np.zeros(n_seg + 1, dtype=np.int64)
         psd_cache, filt_cache = {}, {}
         for iseg, seg in enumerate(segments):
@@ -122,6 +130,7 @@ class OffsetPrior:
             noisefilter = filt_cache[fkey]
             self.filters.append(noisefilter)
             detnoise = float(seg["detnoise"])
+            self.detnoise.append(detnoise)
             if self.precond_width <= 1:
                 tkey = (pid, flen, "toeplitz")
                 if tkey not in filt_cache:
@@ -131,7 +140,7 @@ class OffsetPrior:
                 if detnoise != 0:
                     pre[pre.size // 2] += 1.0 / detnoise  # offset.py:505-507
                 self.precond.append(pre)
-            else:
+            elif not self.factor_on_device:
                 self.precond.append(self._banded_factor(noisefilter, offsetvar[first:first + n_amp], detnoise))
         return self
 
@@ -200,13 +209,11 @@ class OffsetPrior:
             self._register("pre_start", ps)
             self._register("pre_len", pl)
             self._register("pre_filters", pp)
+        elif self.factor_on_device:
+            self._factor_on_device()
         else:
             width = np.array([cb.shape[0] for cb in self.precond], dtype=np.int32)
-            n_amp = np.diff(self.seg_start)
-            start = np.zeros(n_seg, dtype=np.int64)
-            if n_seg > 1:
-                start[1:] = np.cumsum(n_amp[:-1] * width[:-1])
-            total = int(np.sum(n_amp * width))
+            start, total = self._band_layout(width)
             fwd = np.zeros(max(total, 1), dtype=np.float64)
             bwd = np.zeros(max(total, 1), dtype=np.float64)
             for iseg, cb in enumerate(self.precond):
@@ -225,6 +232,99 @@ class OffsetPrior:
             self._register("forward", fwd)
             self._register("backward", bwd)
         self._on_device = True
+
+    def _band_layout(self, width):
+        n_amp = np.diff(self.seg_start)
+        start = np.zeros(width.size, dtype=np.int64)
+        if width.size > 1:
+            start[1:] = np.cumsum(n_amp[:-1] * width[:-1])
+        return start, int(np.sum(n_amp * width))
+
+    def _create(self, key, arr):
+        """Device buffer keyed by ``arr`` without an upload (``arr`` is never touched)."""
+        self._tables[key] = arr
+        accel_data_create(arr, f"{self.name}_prior_{key}", owner=self)
+
+    def _drop(self, key):
+        accel_data_delete(self._tables.pop(key), f"{self.name}_prior_{key}")
+
+    def _factor_on_device(self):
+        """Banded Cholesky factors of all segments in one launch
+        (toast_hip_template_offset_banded_cholesky_dev), widening the band of the segments that
+        are not positive definite the way the reference does (offset.py:546-566)."""
+        from .. import capi
+        from ..accel import accel_data_update_host, native
+
+        n_seg = self.seg_start.size - 1
+        n_amp = np.diff(self.seg_start)
+        centre = np.array([f.size // 2 for f in self.filters], dtype=np.int64)
+        try_width = np.full(n_seg, self.precond_width, dtype=np.int64)
+        dscale = np.array([1.0 if d != 0 else 0.0 for d in self.detnoise], dtype=np.float64)
+        self._register("diag_scale", dscale)
+        self._register("offset_var", np.ascontiguousarray(self._offsetvar))
+        status = np.zeros(max(n_seg, 1), dtype=np.int32)
+        self._create("status", status)
+        while True:
+            wband = np.minimum(try_width, centre)
+            width = np.maximum(wband, np.minimum(try_width, n_amp)).astype(np.int32)
+            if int(width.max()) > 64:
+                raise RuntimeError(f"{self.name}: banded preconditioner needs a band of {int(width.max())} > 64 "
+                                   "baselines; use precond_width <= 1 (Toeplitz) for this noise model")
+            # Toeplitz bands: filter[centre : centre + wband], stored once per distinct filter
+            tstart = np.zeros(n_seg, dtype=np.int64)
+            pool, seen, cursor = [], {}, 0
+            for i, filt in enumerate(self.filters):
+                k = (id(filt), int(wband[i]))
+                if k not in seen:
+                    seen[k] = cursor
+                    pool.append(filt[centre[i]:centre[i] + wband[i]])
+                    cursor += int(wband[i])
+                tstart[i] = seen[k]
+            start, total = self._band_layout(width)
+            for key, arr in (("toep_start", tstart), ("toep_len", wband.astype(np.int32)),
+                             ("toeplitz", np.concatenate(pool)), ("band_width", width), ("band_start", start)):
+                self._register(key, arr)
+            # the factor tables exist on the device only; the host arrays are untouched keys
+            self._create("forward", np.empty(max(total, 1), dtype=np.float64))
+            self._create("backward", np.empty(max(total, 1), dtype=np.float64))
+            capi.dev.memset(self._ptr("backward"), 0, 8 * max(total, 1))
+            capi.dev.offset_banded_cholesky(n_seg, self._ptr("seg_start"), self._ptr("band_width"), int(width.max()),
+                                            self._ptr("band_start"), self._ptr("toep_start"), self._ptr("toep_len"),
+                                            self._ptr("toeplitz"), self._ptr("diag_scale"), self._ptr("offset_var"),
+                                            self._ptr("forward"), self._ptr("backward"), self._ptr("status"))
+            native().accel_synchronize()
+            accel_data_update_host(status, f"{self.name}_prior_status")
+            failed = np.nonzero(status[:n_seg])[0]
+            if failed.size == 0:
+                break
+            for i in failed:
+                if try_width[i] < centre[i] and try_width[i] < n_amp[i]:
+                    try_width[i] *= 2
+                else:
+                    raise RuntimeError(f"{self.name}: banded preconditioner of segment {i} is not positive "
+                                       f"definite at the maximum width {int(try_width[i])}")
+            for key in ("toep_start", "toep_len", "toeplitz", "band_width", "band_start", "forward", "backward"):
+                self._drop(key)
+        self.max_width = int(width.max())
+        for key in ("toep_start", "toep_len", "toeplitz", "diag_scale", "offset_var", "status"):
+            self._drop(key)
+
+    def banded_factor(self, iseg):
+        """Lower banded factor of one segment in scipy's layout, read back from the device tables
+        (tests / inspection)."""
+        from ..accel import accel_data_update_host
+
+        if not self.factor_on_device:
+            return self.precond[iseg]
+        self.to_device()
+        fwd = self._tables["forward"]
+        accel_data_update_host(fwd, f"{self.name}_prior_forward")
+        w = int(self._tables["band_width"][iseg])
+        n = int(self.seg_start[iseg + 1] - self.seg_start[iseg])
+        s0 = int(self._tables["band_start"][iseg])
+        cb = fwd[s0:s0 + n * w].reshape(n, w).T.copy()
+        cb[0] = 1.0 / cb[0]
+        return cb
 
     def clear(self):
         for key, arr in self._tables.items():
