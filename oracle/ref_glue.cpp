@@ -15,6 +15,8 @@ void init_ops_mapmaker_utils(py::module &);
 void init_ops_noise_weight(py::module &);
 void init_ops_scan_map(py::module &);
 void init_template_offset(py::module &);
+void init_tod_filter(py::module &);   // tod_filter.cpp: legendre_templates, bin_proj, bin_invcov, add_templates
+void init_map_cov(py::module &);      // map_cov.cpp: cov_accum_*, cov_apply_diag (LAPACK-free parts)
 
 PYBIND11_MODULE(_toast_ref, m) {
     m.doc() = "hpc4cmb/toast hot-path bindings compiled in place (parity oracle, tests only)";
@@ -27,4 +29,6 @@ PYBIND11_MODULE(_toast_ref, m) {
     init_ops_noise_weight(m);
     init_ops_scan_map(m);
     init_template_offset(m);
+    init_tod_filter(m);
+    init_map_cov(m);
 }

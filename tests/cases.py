@@ -133,3 +133,30 @@ def run_chain(impl, case, nest=True, iau=False, shared_mask=1, det_mask=1, map_d
          c["weight_index"], c["intervals"], scan_scale, False, True, False, *tail)
     impl.noise_weight(tod2, c["data_index"], c["intervals"], c["det_scale"], *tail)
     return dict(quats=quats, pixels=pixels, hsub=hsub, weights=weights, g2l=g2l, zmap=zmap, tod=tod2)
+
+
+def python_hits_invcov(z, det_mask=1, shared_mask=1):
+    """Hit map and packed inverse pixel covariance of a golden chain (tests/golden/chain_*.npz)
+    by the per-sample definition of BuildHitMap / BuildInverseCovariance
+    (src/toast/ops/mapmaker_utils/mapmaker_utils.py:178-204, 464-513): plain Python loops."""
+    pixels, weights, g2l = z["out_pixels"], z["out_weights"], z["out_g2l"]
+    nps = int(z["meta_n_pix_submap"])
+    n_local = int(g2l.max()) + 1
+    dflags, sflags = z["in_det_flags"], z["in_shared_flags"]
+    use_det = dflags.shape[1] == pixels.shape[1]
+    hits = np.zeros((n_local, nps, 1), dtype=np.int64)
+    invcov = np.zeros((n_local, nps, 6), dtype=np.float64)
+    iu = np.triu_indices(3)
+    for d in range(z["in_pixel_index"].size):
+        prow, wrow, frow = z["in_pixel_index"][d], z["in_weight_index"][d], z["in_flag_index"][d]
+        scale = float(z["in_det_scale"][d])
+        for iv in z["in_intervals"]:
+            for i in range(int(iv["first"]), int(iv["last"])):
+                pix = int(pixels[prow, i])
+                if pix < 0 or (sflags[i] & shared_mask) or (use_det and (dflags[frow, i] & det_mask)):
+                    continue
+                sm, sp = int(g2l[pix // nps]), pix % nps
+                hits[sm, sp, 0] += 1
+                w = weights[wrow, i]
+                invcov[sm, sp] += (np.outer(w * scale, w))[iu]
+    return hits, invcov

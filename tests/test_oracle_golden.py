@@ -1,5 +1,7 @@
 """CPU: the oracle restatement against the reference's own outputs (golden fixtures), the
 reference's known-answer values, and -- when oracle/_ref is present -- the live reference."""
+import os
+
 import numpy as np
 import pytest
 
@@ -76,8 +78,7 @@ def test_oracle_offset_template_fixture(oracle):
 
 
 def test_oracle_cov_apply_diag_semantics(oracle):
-    """toast_map_cov.cpp needs LAPACK and cannot be built here: pin the restatement to the
-    documented semantics (vec <- Sym(packed upper triangle) . vec) with dense numpy."""
+    """vec <- Sym(packed upper triangle) . vec, against dense numpy (toast_map_cov.cpp:471-528)."""
     rng = np.random.default_rng(0)
     for nnz in (1, 2, 3):
         nsub, subsize = 3, 17
@@ -94,6 +95,38 @@ def test_oracle_cov_apply_diag_semantics(oracle):
                 want[i, j] = m @ vec[i, j]
         oracle.cov_apply_diag(nsub, subsize, nnz, mat, vec)
         np.testing.assert_allclose(vec, want, rtol=1e-13, atol=1e-13)
+
+
+def test_oracle_cov_apply_diag_matches_reference_fixture(oracle):
+    """tests/golden/cov_filter.npz: outputs of the reference's own cov_apply_diag (its no-LAPACK
+    configuration builds in place, tests/golden/make_golden_cov.py): bit-exact."""
+    z = np.load(os.path.join(gu.GOLDEN, "cov_filter.npz"))
+    for nnz in (1, 2, 3):
+        mat, vec = z[f"apply{nnz}_mat"], z[f"apply{nnz}_vec"].copy()
+        oracle.cov_apply_diag(mat.shape[0], mat.shape[1], nnz, mat, vec)
+        assert np.array_equal(vec, z[f"apply{nnz}_out"])
+
+
+@pytest.mark.parametrize("name", ["chain_a", "chain_b", "chain_c"])
+def test_hits_and_invcov_fixture_vs_python_loop(name):
+    """The reference's cov_accum_diag_hits / cov_accum_diag_invnpp driven like BuildHitMap /
+    BuildInverseCovariance (fixture) against the plain per-sample definition."""
+    z = np.load(os.path.join(gu.GOLDEN, name + ".npz"))
+    g = np.load(os.path.join(gu.GOLDEN, "cov_filter.npz"))
+    hits, invcov = cases.python_hits_invcov(z)
+    assert np.array_equal(hits, g[name + "_hits"])
+    np.testing.assert_allclose(invcov, g[name + "_invcov"], rtol=1e-13, atol=1e-13 * np.max(np.abs(invcov)))
+
+
+def test_cov_apply_diag_live_reference(oracle, ref):
+    rng = np.random.default_rng(4)
+    for nnz in (1, 2, 3):
+        mat = rng.standard_normal((4, 33, nnz * (nnz + 1) // 2))
+        a = rng.standard_normal((4, 33, nnz))
+        b = a.copy()
+        ref.cov_apply_diag(4, 33, nnz, mat.reshape(-1), a.reshape(-1))
+        oracle.cov_apply_diag(4, 33, nnz, mat, b)
+        assert np.array_equal(a, b)
 
 
 LIVE = {
