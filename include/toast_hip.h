@@ -444,6 +444,48 @@ int toast_hip_template_offset_banded_cholesky_dev(
     double * d_forward, double * d_backward, int32_t * d_status, void * stream);
 
 /* ------------------------------------------------------------------------------------
+ * Template regression for toast.ops.GroundFilter (device-resident buffers; host index arrays)
+ *
+ * The reference fits, per detector, a set of templates shared by all detectors of an observation
+ * (Legendre trend, Legendre / binned functions of azimuth) with four host kernels of
+ * src/libtoast/src/toast_tod_filter.cpp -- `legendre` :269-331, `bin_proj` :160-177, `bin_invcov`
+ * :179-215, `add_templates` :333-355 (bindings src/toast/_libtoast/tod_filter.cpp:100, 213, 254,
+ * 291) -- called in a Python loop over detectors (src/toast/ops/groundfilter.py:443-500).
+ *
+ * toast_hip_legendre_templates_dev: templates[order - start_order][i] = normalised Legendre
+ *   polynomial of d_x[i], orders [start_order, stop_order); same recurrence and rounding.
+ * toast_hip_template_fit_dev: for every detector d (rows signal_index[d] / flag_index[d]),
+ *   good[d][i] = !(shared_flags[i] & shared_flag_mask) && !(det_flags[d][i] & det_flag_mask):
+ *     d_proj[d][r]            = sum_i T[r][i] signal[d][i] good[d][i]              (bin_proj)
+ *     d_gram_common[r][c]     = sum_i T[r][i] T[c][i] over samples with good shared flags
+ *     d_gram_flagged[d][r][c] = the same sum over samples with good shared flags that detector d flags
+ *   so that bin_invcov of detector d is d_gram_common - d_gram_flagged[d].  All three outputs are
+ *   overwritten.  d_det_flags / d_shared_flags may be NULL (no flags of that kind).
+ * toast_hip_template_subtract_dev: signal[d][i] -= sum_{r >= first_template} coeff[d][r] T[r][i]
+ *   for ALL samples, the sum accumulated from zero in template order (add_templates into a zeroed
+ *   buffer, then `ref -= fit`: groundfilter.py:384-393).  d_coeff is [n_det][n_template].
+ * ---------------------------------------------------------------------------------- */
+int toast_hip_legendre_templates_dev(const double * d_x, int64_t n_samp, int64_t start_order,
+                                     int64_t stop_order, double * d_templates, void * stream);
+
+/* out[i] = keep ? (d_src ? d_src[i] : 1.0) : 0.0 with keep = (d_key[i] == value) if keep_equal else
+ * (d_key[i] != value): the split (left / right going scans) and binned-azimuth templates of
+ * groundfilter.py:208-257 from a per-sample key (scan direction, azimuth bin). */
+int toast_hip_template_select_dev(const double * d_src, const int32_t * d_key, int32_t value, int keep_equal,
+                                  int64_t n_samp, double * d_out, void * stream);
+
+int toast_hip_template_fit_dev(
+    const double * d_templates, int64_t n_template, int64_t n_samp, const int32_t * signal_index /*host*/,
+    const double * d_signal, const int32_t * flag_index /*host*/, const uint8_t * d_det_flags,
+    uint8_t det_flag_mask, const uint8_t * d_shared_flags, uint8_t shared_flag_mask, int64_t n_det,
+    double * d_proj, double * d_gram_common, double * d_gram_flagged, void * stream);
+
+int toast_hip_template_subtract_dev(
+    const double * d_templates, int64_t n_template, int64_t first_template, int64_t n_samp,
+    const int32_t * signal_index /*host*/, double * d_signal, const double * d_coeff, int64_t n_det,
+    void * stream);
+
+/* ------------------------------------------------------------------------------------
  * FFT noise weighting (rocFFT)
  *
  * toast_hip_fft_convolve: in-place convolution (or deconvolution) of each selected timestream

@@ -792,6 +792,30 @@ class _Dev:
             _p(d_toep_start), _p(d_toep_len), _p(d_toeplitz), _p(d_diag_scale), _p(d_offset_var), _p(d_forward),
             _p(d_backward), _p(d_status), _p(stream)))
 
+    def legendre_templates(self, d_x, n_samp, start_order, stop_order, d_templates, stream=0):
+        _check(lib().toast_hip_legendre_templates_dev(_p(d_x), _i64(n_samp), _i64(start_order), _i64(stop_order),
+                                                      _p(d_templates), _p(stream)))
+
+    def template_select(self, d_src, d_key, value, keep_equal, n_samp, d_out, stream=0):
+        _check(lib().toast_hip_template_select_dev(_p(d_src), _p(d_key), C.c_int32(int(value)),
+                                                   C.c_int(1 if keep_equal else 0), _i64(n_samp), _p(d_out), _p(stream)))
+
+    def template_fit(self, d_templates, n_template, n_samp, signal_index, d_signal, flag_index, d_det_flags,
+                     det_flag_mask, d_shared_flags, shared_flag_mask, d_proj, d_gram_common, d_gram_flagged, stream=0):
+        si = self._small(signal_index, np.int32)
+        fi = self._small(flag_index if flag_index is not None else np.zeros(si.size), np.int32)
+        _check(lib().toast_hip_template_fit_dev(
+            _p(d_templates), _i64(n_template), _i64(n_samp), _p(si), _p(d_signal), _p(fi), _p(d_det_flags),
+            _u8(det_flag_mask), _p(d_shared_flags), _u8(shared_flag_mask), _i64(si.size), _p(d_proj), _p(d_gram_common),
+            _p(d_gram_flagged), _p(stream)))
+
+    def template_subtract(self, d_templates, n_template, first_template, n_samp, signal_index, d_signal, d_coeff,
+                          stream=0):
+        si = self._small(signal_index, np.int32)
+        _check(lib().toast_hip_template_subtract_dev(
+            _p(d_templates), _i64(n_template), _i64(first_template), _i64(n_samp), _p(si), _p(d_signal), _p(d_coeff),
+            _i64(si.size), _p(stream)))
+
     def combine_flags(self, d_out, out_index, d_det_flags, n_flag_samp, flag_index, det_flag_mask, d_shared_flags,
                       n_shared_flags, shared_flag_mask, n_samp, intervals, n_out_rows=0, outside_value=-1, stream=0):
         oi = self._small(out_index, np.int32)

@@ -36,6 +36,13 @@ defaults = types.SimpleNamespace(
     det_flags="flags",
     hwp_angle="hwp_angle",
     boresight_radec="boresight_radec",
+    boresight_azel="boresight_azel",
+    azimuth="azimuth",
+    elevation="elevation",
+    scanning_interval="scanning",
+    turnaround_interval="turnaround",
+    throw_leftright_interval="throw_leftright",
+    throw_rightleft_interval="throw_rightleft",
     pixels="pixels",
     weights="weights",
     quats="quats",

@@ -16,6 +16,7 @@ from .mapmaker_ops import (
     ScanMask,
 )
 from .mapmaker_solve import SolverLHS, SolverRHS, TemplateMatrix, solve
+from .ground_filter import GroundFilter
 from .noise_filter import NoiseFilter
 from .operator import Operator
 from .pipeline import Pipeline

@@ -79,3 +79,47 @@ def create_satellite_data(
             ob.update_local_detector_flags(flg)
         data.obs.append(ob)
     return data
+
+
+def create_ground_data(comm=None, n_det=4, n_obs=1, n_samp=6000, rate=20.0, net=1.0, fknee=0.05, fmin=1.0e-5,
+                       alpha=1.0, scan_rate_deg_s=1.0, az_min_deg=40.0, az_max_deg=75.0, el_deg=50.0,
+                       turnaround_s=2.0, fov_deg=4.0, flag_samples=True, seed=0):
+    """Constant-elevation scans of a ground telescope (the structure of BASELINE configs[4]; the
+    reference builds these with ops.SimGround from a schedule, src/toast/ops/sim_ground.py): shared
+    ``azimuth``, ``boresight_radec``, flags with the turnarounds marked invalid, and the interval
+    lists ``scanning`` / ``turnaround`` / ``throw_leftright`` / ``throw_rightleft``."""
+    comm = Comm() if comm is None else comm
+    data = Data(comm=comm)
+    fp_q, gamma = synth.hex_focalplane(n_det, fov_deg=fov_deg)
+    names = ["D%04d%s" % (i // 2, "AB"[i % 2]) for i in range(n_det)]
+    fp = Focalplane(names, fp_q, gamma=gamma, epsilon=np.zeros(n_det), sample_rate=rate)
+    tele = Telescope("ground", fp)
+    rng = np.random.default_rng(seed)
+    for iobs in range(n_obs):
+        ob = Observation(comm, tele, n_samp, name=f"ces_{iobs:03d}")
+        times = iobs * n_samp / rate + np.arange(n_samp) / rate
+        ob.set_times(times)
+        bore, ivl, sflags, az, direction = synth.ground_scan(
+            n_samp, rate, az_min_deg=az_min_deg, az_max_deg=az_max_deg, el_deg=el_deg, scan_rate_deg_s=scan_rate_deg_s,
+            turnaround_s=turnaround_s, lst0_deg=30.0 + 15.0 * iobs, with_azimuth=True)
+        ob.shared.create(defaults.boresight_radec, bore)
+        ob.shared.create(defaults.azimuth, az)
+        ob.shared.create(defaults.elevation, np.full(n_samp, np.radians(el_deg)))
+        ob.shared.create(defaults.shared_flags, (sflags * defaults.shared_mask_invalid).astype(np.uint8))
+        ob.shared.create(defaults.hwp_angle, np.zeros(n_samp))
+        spans = [(int(a["first"]), int(a["last"])) for a in ivl]
+        ob.intervals.create(defaults.scanning_interval, spans)
+        ob.intervals.create(defaults.throw_leftright_interval, [s for s, d in zip(spans, direction) if d > 0])
+        ob.intervals.create(defaults.throw_rightleft_interval, [s for s, d in zip(spans, direction) if d < 0])
+        edges = [0] + [x for s in spans for x in s] + [n_samp]
+        ob.intervals.create(defaults.turnaround_interval,
+                            [(a, b) for a, b in zip(edges[0::2], edges[1::2]) if b > a])
+        ob[defaults.noise_model] = AnalyticNoise(
+            rate={d: rate for d in names}, fmin={d: fmin for d in names}, detectors=names,
+            fknee={d: fknee for d in names}, alpha={d: alpha for d in names}, NET={d: net for d in names})
+        ob.detdata.create(defaults.det_data, dtype=np.float64, units=defaults.det_data_units)
+        dflags = ob.detdata.create(defaults.det_flags, dtype=np.uint8)
+        if flag_samples:
+            dflags.data[rng.random(dflags.data.shape) < 0.01] = defaults.det_mask_invalid
+        data.obs.append(ob)
+    return data

@@ -99,7 +99,7 @@ def satellite_boresight(
 
 
 def ground_scan(n_samp, rate, az_min_deg=40.0, az_max_deg=110.0, el_deg=50.0, scan_rate_deg_s=1.0,
-                turnaround_s=2.0, site_lat_deg=-22.96, lst0_deg=30.0):
+                turnaround_s=2.0, site_lat_deg=-22.96, lst0_deg=30.0, with_azimuth=False):
     """Constant-elevation scan (CES) of a ground telescope: boresight quaternions ``[n_samp, 4]``
     in equatorial coordinates, the half-open sample intervals of the constant-velocity sweeps and
     the uint8 shared flags (1 during turnarounds) -- the structure of BASELINE configs[4] inputs
@@ -136,6 +136,9 @@ def ground_scan(n_samp, rate, az_min_deg=40.0, az_max_deg=110.0, el_deg=50.0, sc
     ivl["last"] = last
     ivl["start"] = first / rate
     ivl["stop"] = (last - 1) / rate
+    if with_azimuth:
+        # also: azimuth [rad] and the direction of every sweep (+1 left to right, -1 right to left)
+        return bore, ivl, flags, np.radians(az), np.where(k[first] % 2 == 0, 1, -1)
     return bore, ivl, flags
 
 
