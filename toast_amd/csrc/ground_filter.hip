@@ -103,72 +103,62 @@ __global__ __launch_bounds__(kThreads) void k_template_gram(
     }
 }
 
-// proj[d][r] = sum_i T[r][i] signal[d][i] good[d][i].  Block = (slice of samples, group of DB
-// detectors): each K-tile of the templates is staged in LDS once and serves all DB detectors; the
-// 4 waves of the block take detectors in turn, each lane keeping one accumulator per template row
-// across the whole slice, so the cross-lane reduction happens once per (detector, row, slice).
-template <int NTG>
+// proj[d][r] = sum_i T[r][i] signal[d][i] good[d][i].  One WAVE per (slice of samples, DPW
+// detectors), no LDS and no barriers: a step loads 64 samples of the NTG template rows (coalesced,
+// shared through L2 by the waves working on other detectors) and of the DPW signals -- NTG + 2 DPW
+// independent loads in flight per lane -- and each lane keeps NTG x DPW accumulators across the
+// whole slice, so the cross-lane reduction happens once per (detector, row, slice).
+template <int NTG, int DPW>
 __global__ __launch_bounds__(kThreads) void k_template_project(
     const double * __restrict__ templates, int64_t n_template, int64_t t0, int64_t n_samp, const int32_t * __restrict__ sig_index,
     const double * __restrict__ signal, const int32_t * __restrict__ flag_index, const uint8_t * __restrict__ det_flags,
     uint8_t det_mask, const uint8_t * __restrict__ shared_flags, uint8_t shared_mask, int64_t n_det, int64_t slice,
-    int dets_per_block, double * __restrict__ proj) {
-    __shared__ double tile[NTG * kTile];
+    double * __restrict__ proj) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nt = (n_template - t0 < NTG) ? (int)(n_template - t0) : NTG;
     const int64_t i0 = (int64_t)blockIdx.x * slice;
     const int64_t i1 = (i0 + slice < n_samp) ? i0 + slice : n_samp;
-    const int64_t d0 = (int64_t)blockIdx.y * dets_per_block;
-    // detectors of this wave: d0 + wave, d0 + wave + 4, ...
-    constexpr int kDetPerWave = 4;
-    double acc[kDetPerWave][NTG];
+    const int64_t d0 = ((int64_t)blockIdx.y * 4 + wave) * DPW;
+    if (d0 >= n_det) return;
+    const double * sig[DPW];
+    const uint8_t * df[DPW];
 #pragma unroll
-    for (int dd = 0; dd < kDetPerWave; ++dd) {
+    for (int dd = 0; dd < DPW; ++dd) {
+        const int64_t d = (d0 + dd < n_det) ? d0 + dd : n_det - 1;   // clamped: the duplicate is not written
+        sig[dd] = signal + (int64_t)sig_index[d] * n_samp;
+        df[dd] = (det_flags != nullptr) ? det_flags + (int64_t)flag_index[d] * n_samp : nullptr;
+    }
+    double acc[DPW][NTG];
+#pragma unroll
+    for (int dd = 0; dd < DPW; ++dd) {
 #pragma unroll
         for (int r = 0; r < NTG; ++r) acc[dd][r] = 0.0;
     }
-    for (int64_t base = i0; base < i1; base += kTile) {
-        __syncthreads();
-        for (int q = threadIdx.x; q < nt * kTile; q += kThreads) {
-            const int r = q / kTile, k = q - r * kTile;
-            const int64_t i = base + k;
-            tile[q] = (i < i1) ? templates[(t0 + r) * n_samp + i] : 0.0;
-        }
-        __syncthreads();
+    const double * __restrict__ trow = templates + t0 * n_samp;
+    for (int64_t i = i0 + lane; i < i1; i += 64) {
+        double t[NTG];
 #pragma unroll
-        for (int dd = 0; dd < kDetPerWave; ++dd) {
-            const int64_t d = d0 + wave + 4 * dd;
-            if (d >= n_det || wave + 4 * dd >= dets_per_block) continue;
-            const double * __restrict__ sig = signal + (int64_t)sig_index[d] * n_samp;
-            const uint8_t * __restrict__ df = (det_flags != nullptr) ? det_flags + (int64_t)flag_index[d] * n_samp : nullptr;
+        for (int r = 0; r < NTG; ++r) t[r] = (r < nt) ? trow[r * n_samp + i] : 0.0;
+        const bool cgood = (shared_flags == nullptr) || ((shared_flags[i] & shared_mask) == 0);
 #pragma unroll
-            for (int k = 0; k < kTile / 64; ++k) {
-                const int kk = lane + 64 * k;
-                const int64_t i = base + kk;
-                double s = 0.0;
-                if (i < i1) {
-                    bool good = (shared_flags == nullptr) || ((shared_flags[i] & shared_mask) == 0);
-                    if (df != nullptr && (df[i] & det_mask) != 0) good = false;
-                    if (good) s = sig[i];
-                }
+        for (int dd = 0; dd < DPW; ++dd) {
+            double sv = sig[dd][i];
+            const bool bad = !cgood || (df[dd] != nullptr && (df[dd][i] & det_mask) != 0);
+            if (bad) sv = 0.0;
 #pragma unroll
-                for (int r = 0; r < NTG; ++r) {
-                    if (r < nt) acc[dd][r] += tile[r * kTile + kk] * s;
-                }
-            }
+            for (int r = 0; r < NTG; ++r) acc[dd][r] += t[r] * sv;
         }
     }
 #pragma unroll
-    for (int dd = 0; dd < kDetPerWave; ++dd) {
-        const int64_t d = d0 + wave + 4 * dd;
-        if (d >= n_det || wave + 4 * dd >= dets_per_block) continue;
+    for (int dd = 0; dd < DPW; ++dd) {
+        if (d0 + dd >= n_det) continue;
 #pragma unroll
         for (int r = 0; r < NTG; ++r) {
             if (r >= nt) continue;
             double v = acc[dd][r];
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-            if (lane == 0 && v != 0.0) atomicAdd(&proj[d * n_template + t0 + r], v);
+            if (lane == 0 && v != 0.0) atomicAdd(&proj[(d0 + dd) * n_template + t0 + r], v);
         }
     }
 }
@@ -317,14 +307,25 @@ int toast_hip_template_fit_dev(const double * d_templates, int64_t n_template, i
         hipLaunchKernelGGL(k_template_gram, dim3((unsigned)((n_samp + gslice - 1) / gslice), (unsigned)n_pair), dim3(kThreads),
                            0, st, d_templates, n_template, n_samp, d_shared_flags, shared_flag_mask, gslice, d_gram_common);
         check_launch();
-        const int dets_per_block = 16;
-        const int64_t pslice = 16384;
-        const dim3 pgrid((unsigned)((n_samp + pslice - 1) / pslice), (unsigned)((n_det + dets_per_block - 1) / dets_per_block));
-        for (int64_t t0 = 0; t0 < n_template; t0 += 16) {
-            hipLaunchKernelGGL(k_template_project<16>, pgrid, dim3(kThreads), 0, st, d_templates, n_template, t0, n_samp,
-                               sidx, d_signal, fidx, d_det_flags, det_flag_mask, d_shared_flags, shared_flag_mask,
-                               n_det, pslice, dets_per_block, d_proj);
-            check_launch();
+        // template rows per pass x detectors per wave: 64 accumulators per lane either way
+        const int64_t pslice = 4096;
+        auto project = [&](auto kernel, int ntg, int dpw) {
+            const dim3 pgrid((unsigned)((n_samp + pslice - 1) / pslice), (unsigned)((n_det + 4 * dpw - 1) / (4 * dpw)));
+            for (int64_t t0 = 0; t0 < n_template; t0 += ntg) {
+                hipLaunchKernelGGL(kernel, pgrid, dim3(kThreads), 0, st, d_templates, n_template, t0, n_samp, sidx,
+                                   d_signal, fidx, d_det_flags, det_flag_mask, d_shared_flags, shared_flag_mask, n_det,
+                                   pslice, d_proj);
+                check_launch();
+            }
+        };
+        if (n_template <= 8) {
+            project(k_template_project<8, 8>, 8, 8);
+        } else if (n_template <= 16) {
+            project(k_template_project<16, 4>, 16, 4);
+        } else if (n_template <= 24 || (n_template > 32 && n_template <= 48)) {
+            project(k_template_project<24, 3>, 24, 3);
+        } else {
+            project(k_template_project<32, 2>, 32, 2);
         }
         if (d_det_flags != nullptr) {
             const int64_t fslice = 65536;

@@ -168,16 +168,21 @@ class GroundFilter(Operator):
         invcov = gram_common[None, :, :] - gram_flagged
         coeff = np.zeros_like(proj)
         ok = n_good > 0
-        for d in np.nonzero(ok)[0]:
-            rcond = 1 / np.linalg.cond(invcov[d])
-            self.rcondsum += rcond
-            if rcond > 1e-6:
-                self.ngood += 1
-                cov = np.linalg.inv(invcov[d])
-            else:
-                self.nsingular += 1
+        sel = np.nonzero(ok)[0]
+        if sel.size > 0:
+            # stacked over detectors: the same np.linalg calls as the reference makes one by one
+            with np.errstate(divide="ignore"):
+                rcond = 1 / np.linalg.cond(invcov[sel])
+            self.rcondsum += float(np.sum(rcond))
+            regular = rcond > 1e-6
+            self.ngood += int(np.count_nonzero(regular))
+            self.nsingular += int(np.count_nonzero(~regular))
+            if np.any(regular):
+                cov = np.linalg.inv(invcov[sel[regular]])
+                coeff[sel[regular]] = np.einsum("dij,dj->di", cov, proj[sel[regular]])
+            for d in sel[~regular]:
                 cov = np.linalg.pinv(invcov[d], rcond=1e-12, hermitian=True)
-            coeff[d] = np.dot(cov, proj[d])
+                coeff[d] = np.dot(cov, proj[d])
         return coeff, ok
 
     def _exec(self, data, detectors=None, use_accel=None, **kwargs):
