@@ -325,3 +325,32 @@ def test_mapmaker_with_noise_prior_damps_the_baselines():
     assert np.corrcoef(a, b)[0, 1] > 0.9
     assert np.std(b) < 1.02 * np.std(a)
     assert 0.0 < np.std(a - b) < 0.6 * np.std(a)
+
+
+def test_pattern_select_with_toeplitz_prior():
+    """The reference's test_pattern_select (src/toast/tests/ops_mapmaker.py:668-808): maps of the
+    A and B detectors and of all of them, Offset template with the noise prior and the Toeplitz
+    preconditioner (precond_width=1); the hit maps must add up and the detector flags be restored."""
+    from test_gpu_ops import make_solver_setup
+
+    data, pix, sw, truth, sky = make_solver_setup(n_det=6, n_samp=9000, step_time=3.0, noise_rms=0.05)
+    ob = data.obs[0]
+    flags_before = dict(ob.local_detector_flags)
+    binner = ops.BinMap(pixel_dist="dist", pixel_pointing=pix, stokes_weights=sw, noise_model=defaults.noise_model)
+    tmpl = Offset(times=defaults.times, noise_model=defaults.noise_model, step_time=3.0, use_noise_prior=True,
+                  precond_width=1, name="baselines")
+    mapper = ops.MapMaker(name="mapmaker", det_data=defaults.det_data, binning=binner,
+                          template_matrix=ops.TemplateMatrix(templates=[tmpl]), solve_rcond_threshold=1.0e-1,
+                          map_rcond_threshold=1.0e-1, iter_max=5)
+    hits = {}
+    for name, pattern in (("map_A", ".*A"), ("map_B", ".*B"), ("map_total", None)):
+        mapper.name = name
+        mapper.pattern = pattern
+        mapper.apply(data)
+        hits[name] = data[f"{name}_hits"].data.copy()
+        assert np.all(np.isfinite(data[f"{name}_map"].data))
+        assert ob.local_detector_flags == flags_before
+    good = (hits["map_A"] > 0) & (hits["map_B"] > 0)
+    assert np.count_nonzero(good) > 100
+    assert np.array_equal(hits["map_total"][good], hits["map_A"][good] + hits["map_B"][good])
+    assert hits["map_A"].sum() > 0 and hits["map_A"].sum() + hits["map_B"].sum() == hits["map_total"].sum()

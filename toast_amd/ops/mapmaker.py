@@ -276,8 +276,29 @@ class MapMaker(Operator):
     reset_pix_dist = Bool(False, help="Clear any existing pixel distribution.")
     fused_lhs = Bool(True, help="Let SolverLHS use the fused device-resident kernels when it can "
                                 "(not a reference trait; False = the reference operator sequence)")
+    pattern = Unicode(None, allow_none=True, help="Regex pattern to match against detector names. "
+                                                  "Only these are mapped.")
 
     def _exec(self, data, detectors=None, **kwargs):
+        if self.pattern is None:
+            return self._run(data, detectors=detectors, **kwargs)
+        # Detectors that do not match are flagged invalid for the duration of the run
+        # (mapmaker.py:315-333) and restored afterwards (:658-662).
+        import re
+
+        det_pat = re.compile(self.pattern)
+        saved = []
+        for ob in data.obs:
+            saved.append(dict(ob.local_detector_flags))
+            ob.update_local_detector_flags({d: ob.local_detector_flags.get(d, 0) | defaults.det_mask_invalid
+                                            for d in ob.local_detectors if det_pat.match(d) is None})
+        try:
+            return self._run(data, detectors=detectors, **kwargs)
+        finally:
+            for ob, flags in zip(data.obs, saved):
+                ob.local_detector_flags = flags
+
+    def _run(self, data, detectors=None, **kwargs):
         import time as _time
 
         from ..accel import accel_enabled, native
