@@ -812,3 +812,31 @@ def test_mapmaker_mc_mode_reuses_flags_and_covariance():
         assert key in data, key
     assert np.array_equal(data["mm_map"].data, map0)                        # first realisation untouched
     assert np.max(np.abs(data["mm_00003_map"].data - map0)) > 0
+
+
+def test_template_pattern_restricts_the_amplitudes():
+    """Template.pattern (templates/template.py:45-49, offset.py:226-236): only matching detectors
+    carry baselines; the fused and the operator-sequence left-hand sides agree on them."""
+    from toast_amd.templates import AmplitudesMap
+
+    results = {}
+    for fused in (False, True):
+        data, pix, sw, truth, sky = make_solver_setup(n_det=6, n_samp=6000)
+        ops.CovarianceAndHits(pixel_dist="dist", covariance="cov", pixel_pointing=pix, stokes_weights=sw,
+                              save_pointing=True).apply(data)
+        lhs_bin = ops.BinMap(pixel_dist="dist", covariance="cov", binned="lhs_bin", pixel_pointing=pix,
+                             stokes_weights=sw, full_pointing=True)
+        tmpl = Offset(step_time=10.0, noise_model=defaults.noise_model, name="baselines", pattern=".*A")
+        tmatrix = ops.TemplateMatrix(templates=[tmpl], amplitudes="amps_in", det_data="temp_LHS")
+        tmatrix.initialize(data)
+        assert tmpl.detectors() == [d for d in data.obs[0].local_detectors if d.endswith("A")]
+        amps = tmpl.zeros()
+        assert amps.n_local == 3 * 60
+        amps.local[:] = np.random.default_rng(3).standard_normal(amps.n_local)
+        data["amps_in"] = AmplitudesMap(baselines=amps)
+        data["lhs_out"] = data["amps_in"].duplicate()
+        data["lhs_out"].reset()
+        ops.SolverLHS(binning=lhs_bin, template_matrix=tmatrix, out="lhs_out", fused=fused).apply(data)
+        results[fused] = data["lhs_out"]["baselines"].local.copy()
+    assert np.max(np.abs(results[False])) > 0
+    assert np.max(np.abs(results[False] - results[True])) < 1e-11 * np.max(np.abs(results[False]))

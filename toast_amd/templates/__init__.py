@@ -8,6 +8,8 @@ template (offset.py:455-476, 884-1005) is host-only scipy code in the reference
 well (templates/offset_prior.py, csrc/offset_prior.hip).
 """
 
+import re
+
 import numpy as np
 
 from ..accel import (
@@ -282,6 +284,8 @@ class Template(TraitConfig):
     det_mask = Int(defaults.det_mask_nonscience, help="Bit mask value for solver per-detector flagging")
     det_flags = Unicode(defaults.det_flags, allow_none=True, help="Observation detdata key for solver flags to use")
     det_flag_mask = Int(defaults.det_mask_nonscience, help="Bit mask value for solver flags")
+    pattern = Unicode(None, allow_none=True, help="Regex pattern to match against detector names. "
+                                                  "Only these are projected.")
 
     def _observe_data(self, change):
         if change["new"] is not None:
@@ -366,9 +370,12 @@ class Offset(Template):
                 vf[vw.first:vw.last] = 0
             self._obs_view_flags[iob] = vf
             self._obs_dets[iob] = set()
+            det_pat = re.compile(self.pattern) if self.pattern is not None else None
             for d in ob.select_local_detectors(flagmask=self.det_mask):
                 if self.det_data in ob.detdata and d not in ob.detdata[self.det_data].detectors:
                     continue
+                if det_pat is not None and det_pat.match(d) is None:
+                    continue  # offset.py:226-236
                 self._obs_dets[iob].add(d)
                 all_dets.setdefault(d, None)
         self._all_dets = list(all_dets.keys())
