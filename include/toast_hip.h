@@ -407,7 +407,9 @@ int toast_hip_template_offset_apply_diag_precond_dev(
  * segment with the segment's filter (d_filters + d_filt_start[s], d_filt_len[s] taps, odd),
  * then out = 0 where the amplitude is flagged.  accumulate != 0 is `_add_prior`
  * (offset.py:918-943), accumulate == 0 the Toeplitz preconditioner of precond_width <= 1
- * (offset.py:981-989).  in and out must differ.
+ * (offset.py:981-989).  in and out must differ.  max_segment_len / max_filter_len (host values:
+ * the longest segment and filter) select the launch geometry -- filters longer than 512 taps take
+ * an LDS-tiled kernel.
  *
  * toast_hip_template_offset_banded_solve_dev: out = cho_solve_banded((factor, lower=True), in)
  * per segment (offset.py:990-1001), out = 0 where flagged.  The factor of segment s, band width
@@ -420,9 +422,10 @@ int toast_hip_template_offset_apply_diag_precond_dev(
  * i.e. row i of each table couples unknown i to the unknowns solved AFTER it in that sweep (the
  * column-oriented substitution of LAPACK's dtbsv). */
 int toast_hip_template_offset_convolve_dev(
-    int64_t n_amp, int64_t n_seg, const int64_t * d_seg_start, const int64_t * d_filt_start,
-    const int64_t * d_filt_len, const double * d_filters, const double * d_amp_in,
-    const uint8_t * d_amplitude_flags, double * d_amp_out, int accumulate, void * stream);
+    int64_t n_amp, int64_t n_seg, const int64_t * d_seg_start, int64_t max_segment_len,
+    const int64_t * d_filt_start, const int64_t * d_filt_len, int64_t max_filter_len,
+    const double * d_filters, const double * d_amp_in, const uint8_t * d_amplitude_flags,
+    double * d_amp_out, int accumulate, void * stream);
 
 int toast_hip_template_offset_banded_solve_dev(
     int64_t n_seg, const int64_t * d_seg_start, const int32_t * d_band_width, int32_t max_band_width,

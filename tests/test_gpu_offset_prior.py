@@ -40,14 +40,21 @@ def dev_arrays(**arrs):
 
 
 @pytest.mark.parametrize("accumulate", [False, True])
-def test_convolve_kernel_vs_scipy(accumulate):
+@pytest.mark.parametrize("long_filters", [False, True])
+def test_convolve_kernel_vs_scipy(accumulate, long_filters):
     import torch
 
     from toast_amd import capi
 
     rng = np.random.default_rng(7)
-    seg_len = [1, 2, 5, 63, 64, 65, 300, 1000, 7, 0, 129]
-    filt_len = [3, 9, 15, 87, 1, 131, 87, 2047, 5, 3, 257]  # filters longer than their segment included
+    if long_filters:
+        # > 512 taps: the LDS-tiled kernel (segments longer than one 1024-output tile, filters longer
+        # than their segment, tap counts that are not multiples of the 256-tap window or of 4)
+        seg_len = [1, 5, 1023, 1024, 1025, 3600, 0, 2500, 130]
+        filt_len = [3, 4097, 87, 8191, 1, 2051, 3, 513, 257]
+    else:
+        seg_len = [1, 2, 5, 63, 64, 65, 300, 1000, 7, 0, 129]
+        filt_len = [3, 9, 15, 87, 1, 131, 87, 511, 5, 3, 257]  # filters longer than their segment included
     seg_start = np.concatenate([[0], np.cumsum(seg_len)]).astype(np.int64)
     n_amp = int(seg_start[-1])
     filters = [rng.standard_normal(n) for n in filt_len]
@@ -65,8 +72,8 @@ def test_convolve_kernel_vs_scipy(accumulate):
     expect[flags != 0] = 0.0
     d = dev_arrays(seg_start=seg_start, filt_start=filt_start, filt_len=np.array(filt_len, dtype=np.int64),
                    filters=np.concatenate(filters), amp_in=amp_in, flags=flags, out=prev)
-    capi.dev.offset_convolve(n_amp, len(seg_len), d["seg_start"].data_ptr(), d["filt_start"].data_ptr(),
-                             d["filt_len"].data_ptr(), d["filters"].data_ptr(), d["amp_in"].data_ptr(),
+    capi.dev.offset_convolve(n_amp, len(seg_len), d["seg_start"].data_ptr(), max(seg_len), d["filt_start"].data_ptr(),
+                             d["filt_len"].data_ptr(), max(filt_len), d["filters"].data_ptr(), d["amp_in"].data_ptr(),
                              d["flags"].data_ptr(), d["out"].data_ptr(), accumulate)
     torch.cuda.synchronize()
     got = d["out"].cpu().numpy()

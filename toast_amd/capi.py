@@ -772,11 +772,12 @@ class _Dev:
             _i64(step_length), _p(ao), _p(nv), _p(d_counts), _p(fi), _p(d_det_flags), _u8(flag_mask), _i64(ao.size),
             _i64(n_samp), _p(iv), _i64(iv.size), _p(stream)))
 
-    def offset_convolve(self, n_amp, n_seg, d_seg_start, d_filt_start, d_filt_len, d_filters, d_amp_in, d_amp_flags,
-                        d_amp_out, accumulate, stream=0):
+    def offset_convolve(self, n_amp, n_seg, d_seg_start, max_segment_len, d_filt_start, d_filt_len, max_filter_len,
+                        d_filters, d_amp_in, d_amp_flags, d_amp_out, accumulate, stream=0):
         _check(lib().toast_hip_template_offset_convolve_dev(
-            _i64(n_amp), _i64(n_seg), _p(d_seg_start), _p(d_filt_start), _p(d_filt_len), _p(d_filters), _p(d_amp_in),
-            _p(d_amp_flags), _p(d_amp_out), C.c_int(1 if accumulate else 0), _p(stream)))
+            _i64(n_amp), _i64(n_seg), _p(d_seg_start), _i64(max_segment_len), _p(d_filt_start), _p(d_filt_len),
+            _i64(max_filter_len), _p(d_filters), _p(d_amp_in), _p(d_amp_flags), _p(d_amp_out),
+            C.c_int(1 if accumulate else 0), _p(stream)))
 
     def offset_banded_solve(self, n_seg, d_seg_start, d_band_width, max_band_width, d_band_start, d_forward,
                             d_backward, d_amp_in, d_amp_flags, d_amp_out, stream=0):

@@ -65,6 +65,101 @@ __global__ __launch_bounds__(kThreads) void k_offset_convolve(
     }
 }
 
+// The same convolution for LONG filters (the Toeplitz preconditioner of precond_width <= 1 is not
+// truncated much: 8191 taps for 3600 baselines).  One block per (segment, tile of 1024 outputs);
+// each thread owns 4 consecutive outputs and slides a 4-value window of the input through its
+// registers, so a tap costs one conflict-free LDS read (the window is stored with one pad slot per
+// 32 values) and one scalar load of the tap for 4 FMAs.
+constexpr int kConvOut = 4 * kThreads;    // outputs per block
+constexpr int kConvTaps = 256;            // taps per LDS window
+__device__ __forceinline__ int conv_pad(int k) { return k + (k >> 5); }
+
+template <bool ACCUMULATE>
+__global__ __launch_bounds__(kThreads) void k_offset_convolve_tiled(
+    const int64_t * __restrict__ seg_start, const int64_t * __restrict__ filt_start, const int64_t * __restrict__ filt_len,
+    const double * __restrict__ filters, const double * __restrict__ in, const uint8_t * __restrict__ flags,
+    double * __restrict__ out) {
+    constexpr int kWindow = kConvOut + kConvTaps - 1;
+    __shared__ double win[kWindow + kWindow / 32 + 1];
+    const int64_t s = blockIdx.y;
+    const int64_t first = seg_start[s];
+    const int64_t n = seg_start[s + 1] - first;
+    const int64_t j0 = (int64_t)blockIdx.x * kConvOut;
+    if (j0 >= n) return;
+    const int64_t len = filt_len[s];
+    const int64_t c = (len - 1) >> 1;
+    const double * __restrict__ f = filters + filt_start[s];
+    const double * __restrict__ x = in + first;
+    const int64_t j_hi = (j0 + kConvOut < n) ? j0 + kConvOut : n;   // one past the last output of the tile
+    // taps that reach any input of the segment from any output of the tile
+    int64_t t_lo = j0 + c - (n - 1);
+    if (t_lo < 0) t_lo = 0;
+    int64_t t_hi = j_hi - 1 + c;
+    if (t_hi > len - 1) t_hi = len - 1;
+    const int tid = threadIdx.x;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t t0 = t_lo; t0 <= t_hi; t0 += kConvTaps) {
+        // window: x[wbase + k], k = 0 .. kWindow-1, zero outside the segment
+        const int64_t wbase = j0 + c - (t0 + kConvTaps - 1);
+        __syncthreads();
+        for (int k = tid; k < kWindow; k += kThreads) {
+            const int64_t i = wbase + k;
+            win[conv_pad(k)] = (i >= 0 && i < n) ? x[i] : 0.0;
+        }
+        __syncthreads();
+        // outputs j0 + 4 tid + r at tap t0 + u read window slot 4 tid + r + (kConvTaps - 1) - u
+        const int top = 4 * tid + kConvTaps - 1;
+        double w0 = win[conv_pad(top)], w1 = win[conv_pad(top + 1)], w2 = win[conv_pad(top + 2)],
+               w3 = win[conv_pad(top + 3)];
+        const int64_t taps = (t_hi - t0 + 1 < kConvTaps) ? t_hi - t0 + 1 : kConvTaps;
+        const double * __restrict__ ft = f + t0;
+        int u = 0;
+        for (; u + 4 <= taps; u += 4) {
+            const double f0 = ft[u], f1 = ft[u + 1], f2 = ft[u + 2], f3 = ft[u + 3];
+            acc[0] = __builtin_fma(f0, w0, acc[0]);
+            acc[1] = __builtin_fma(f0, w1, acc[1]);
+            acc[2] = __builtin_fma(f0, w2, acc[2]);
+            acc[3] = __builtin_fma(f0, w3, acc[3]);
+            w3 = win[conv_pad(top - u - 1)];
+            acc[0] = __builtin_fma(f1, w3, acc[0]);
+            acc[1] = __builtin_fma(f1, w0, acc[1]);
+            acc[2] = __builtin_fma(f1, w1, acc[2]);
+            acc[3] = __builtin_fma(f1, w2, acc[3]);
+            w2 = win[conv_pad(top - u - 2)];
+            acc[0] = __builtin_fma(f2, w2, acc[0]);
+            acc[1] = __builtin_fma(f2, w3, acc[1]);
+            acc[2] = __builtin_fma(f2, w0, acc[2]);
+            acc[3] = __builtin_fma(f2, w1, acc[3]);
+            w1 = win[conv_pad(top - u - 3)];
+            acc[0] = __builtin_fma(f3, w1, acc[0]);
+            acc[1] = __builtin_fma(f3, w2, acc[1]);
+            acc[2] = __builtin_fma(f3, w3, acc[2]);
+            acc[3] = __builtin_fma(f3, w0, acc[3]);
+            w0 = win[conv_pad(top - u - 4 >= 0 ? top - u - 4 : 0)];
+            // after four taps the registers are back in order: (w0 .. w3) = slots top-u-4 .. top-u-1
+        }
+        for (; u < taps; ++u) {
+            const double fu = ft[u];
+            acc[0] = __builtin_fma(fu, w0, acc[0]);
+            acc[1] = __builtin_fma(fu, w1, acc[1]);
+            acc[2] = __builtin_fma(fu, w2, acc[2]);
+            acc[3] = __builtin_fma(fu, w3, acc[3]);
+            w3 = w2;
+            w2 = w1;
+            w1 = w0;
+            w0 = win[conv_pad(top - u - 1 >= 0 ? top - u - 1 : 0)];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t j = j0 + 4 * tid + r;
+        if (j < n) {
+            const int64_t i = first + j;
+            out[i] = (flags[i] != 0) ? 0.0 : (ACCUMULATE ? out[i] + acc[r] : acc[r]);
+        }
+    }
+}
+
 __device__ __forceinline__ double lane_value(double v, int lane) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
@@ -310,14 +405,21 @@ __global__ __launch_bounds__(64) void k_offset_banded_cholesky(
 extern "C" {
 
 int toast_hip_template_offset_convolve_dev(int64_t n_amp, int64_t n_seg, const int64_t * d_seg_start,
-                                           const int64_t * d_filt_start, const int64_t * d_filt_len,
+                                           int64_t max_segment_len, const int64_t * d_filt_start,
+                                           const int64_t * d_filt_len, int64_t max_filter_len,
                                            const double * d_filters, const double * d_amp_in,
                                            const uint8_t * d_amplitude_flags, double * d_amp_out, int accumulate,
                                            void * stream) {
     return guarded([&] {
         if (n_amp <= 0 || n_seg <= 0) return;
         if (d_amp_in == d_amp_out) fail_arg("offset convolve: input and output amplitudes must differ");
-        if (accumulate) {
+        if (max_filter_len > 512 && max_segment_len > 0) {
+            // long filters (Toeplitz preconditioner): LDS-tiled, register-blocked kernel
+            const dim3 grid((unsigned)((max_segment_len + kConvOut - 1) / kConvOut), (unsigned)n_seg);
+            auto kern = accumulate ? k_offset_convolve_tiled<true> : k_offset_convolve_tiled<false>;
+            hipLaunchKernelGGL(kern, grid, dim3(kThreads), 0, as_stream(stream), d_seg_start, d_filt_start, d_filt_len,
+                               d_filters, d_amp_in, d_amplitude_flags, d_amp_out);
+        } else if (accumulate) {
             hipLaunchKernelGGL(k_offset_convolve<true>, flat_grid(n_amp), dim3(kThreads), 0, as_stream(stream), n_amp,
                                n_seg, d_seg_start, d_filt_start, d_filt_len, d_filters, d_amp_in, d_amplitude_flags,
                                d_amp_out);

@@ -180,6 +180,10 @@ class OffsetPrior:
     def _ptr(self, key):
         return accel_device_ptr(self._tables[key])
 
+    @property
+    def _max_seg(self):
+        return int(np.max(np.diff(self.seg_start))) if self.seg_start.size > 1 else 0
+
     def to_device(self):
         if self._on_device:
             return
@@ -339,8 +343,9 @@ class OffsetPrior:
 
         self.to_device()
         n_seg = self.seg_start.size - 1
-        capi.dev.offset_convolve(int(self.seg_start[-1]), n_seg, self._ptr("seg_start"), self._ptr("filt_start"),
-                                 self._ptr("filt_len"), self._ptr("filters"), accel_device_ptr(amps_in.local),
+        capi.dev.offset_convolve(int(self.seg_start[-1]), n_seg, self._ptr("seg_start"), self._max_seg,
+                                 self._ptr("filt_start"), self._ptr("filt_len"), max(f.size for f in self.filters),
+                                 self._ptr("filters"), accel_device_ptr(amps_in.local),
                                  accel_device_ptr(amps_in.local_flags), accel_device_ptr(amps_out.local), True)
 
     def apply_precond(self, amps_in, amps_out):
@@ -350,8 +355,9 @@ class OffsetPrior:
         self.to_device()
         n_seg = self.seg_start.size - 1
         if self.precond_width <= 1:
-            capi.dev.offset_convolve(int(self.seg_start[-1]), n_seg, self._ptr("seg_start"), self._ptr("pre_start"),
-                                     self._ptr("pre_len"), self._ptr("pre_filters"), accel_device_ptr(amps_in.local),
+            capi.dev.offset_convolve(int(self.seg_start[-1]), n_seg, self._ptr("seg_start"), self._max_seg,
+                                     self._ptr("pre_start"), self._ptr("pre_len"), max(p.size for p in self.precond),
+                                     self._ptr("pre_filters"), accel_device_ptr(amps_in.local),
                                      accel_device_ptr(amps_in.local_flags), accel_device_ptr(amps_out.local), False)
         else:
             capi.dev.offset_banded_solve(n_seg, self._ptr("seg_start"), self._ptr("band_width"), self.max_width,

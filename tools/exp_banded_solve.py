@@ -47,7 +47,7 @@ def main():
                                      bwd.data_ptr(), x.data_ptr(), flags.data_ptr(), out.data_ptr())
 
     def conv():
-        capi.dev.offset_convolve(n_seg * n, n_seg, seg_start.data_ptr(), fstart.data_ptr(), flen.data_ptr(),
+        capi.dev.offset_convolve(n_seg * n, n_seg, seg_start.data_ptr(), n, fstart.data_ptr(), flen.data_ptr(), taps,
                                  filt.data_ptr(), x.data_ptr(), flags.data_ptr(), out.data_ptr(), False)
 
     for name, fn in (("banded_solve", solve), ("convolve", conv)):
