@@ -462,7 +462,8 @@ int toast_hip_template_offset_banded_cholesky_dev(
  *     d_proj[d][r]            = sum_i T[r][i] signal[d][i] good[d][i]              (bin_proj)
  *     d_gram_common[r][c]     = sum_i T[r][i] T[c][i] over samples with good shared flags
  *     d_gram_flagged[d][r][c] = the same sum over samples with good shared flags that detector d flags
- *   so that bin_invcov of detector d is d_gram_common - d_gram_flagged[d].  All three outputs are
+ *     d_n_flagged[d]          = the number of those samples
+ *   so that bin_invcov of detector d is d_gram_common - d_gram_flagged[d].  All four outputs are
  *   overwritten.  d_det_flags / d_shared_flags may be NULL (no flags of that kind).
  * toast_hip_template_subtract_dev: signal[d][i] -= sum_{r >= first_template} coeff[d][r] T[r][i]
  *   for ALL samples, the sum accumulated from zero in template order (add_templates into a zeroed
@@ -481,7 +482,7 @@ int toast_hip_template_fit_dev(
     const double * d_templates, int64_t n_template, int64_t n_samp, const int32_t * signal_index /*host*/,
     const double * d_signal, const int32_t * flag_index /*host*/, const uint8_t * d_det_flags,
     uint8_t det_flag_mask, const uint8_t * d_shared_flags, uint8_t shared_flag_mask, int64_t n_det,
-    double * d_proj, double * d_gram_common, double * d_gram_flagged, void * stream);
+    double * d_proj, double * d_gram_common, double * d_gram_flagged, int64_t * d_n_flagged, void * stream);
 
 int toast_hip_template_subtract_dev(
     const double * d_templates, int64_t n_template, int64_t first_template, int64_t n_samp,

@@ -62,10 +62,12 @@ def test_fit_and_subtract_kernels_vs_reference_fixture():
     proj = torch.full((2, nt), float("nan"), dtype=torch.float64, device="cuda")
     gram = torch.full((nt, nt), float("nan"), dtype=torch.float64, device="cuda")
     dgram = torch.full((2, nt, nt), float("nan"), dtype=torch.float64, device="cuda")
+    nflag = torch.full((2,), -1, dtype=torch.int64, device="cuda")
     capi.dev.template_fit(d_t.data_ptr(), nt, n, [3, 1], d_s.data_ptr(), [2, 0], d_f.data_ptr(), 2, d_sh.data_ptr(), 1,
-                          proj.data_ptr(), gram.data_ptr(), dgram.data_ptr())
+                          proj.data_ptr(), gram.data_ptr(), dgram.data_ptr(), nflag.data_ptr())
     torch.cuda.synchronize()
     proj, invcov = proj.cpu().numpy(), (gram[None] - dgram).cpu().numpy()
+    assert list(nflag.cpu().numpy()) == [int(np.count_nonzero(dflags[0])), int(np.count_nonzero(dflags[1]))]
     for d in range(2):
         assert np.max(np.abs(proj[d] - g[f"gf_proj{d}"])) < 1e-12 * np.max(np.abs(g[f"gf_proj{d}"]))
         assert np.max(np.abs(invcov[d] - g[f"gf_invcov{d}"])) < 1e-12 * np.max(np.abs(g[f"gf_invcov{d}"]))
@@ -99,11 +101,14 @@ def test_fit_kernel_many_detectors_and_templates_vs_oracle(oracle):
     proj = torch.zeros((n_det, nt), dtype=torch.float64, device="cuda")
     gram = torch.zeros((nt, nt), dtype=torch.float64, device="cuda")
     dgram = torch.zeros((n_det, nt, nt), dtype=torch.float64, device="cuda")
+    nflag = torch.zeros(n_det, dtype=torch.int64, device="cuda")
     idx = np.arange(n_det, dtype=np.int32)
     capi.dev.template_fit(d_t.data_ptr(), nt, n, idx, d_s.data_ptr(), idx, d_f.data_ptr(), 1, d_sh.data_ptr(), 1,
-                          proj.data_ptr(), gram.data_ptr(), dgram.data_ptr())
+                          proj.data_ptr(), gram.data_ptr(), dgram.data_ptr(), nflag.data_ptr())
     torch.cuda.synchronize()
     proj, invcov = proj.cpu().numpy(), (gram[None] - dgram).cpu().numpy()
+    want_n = np.count_nonzero((dflags != 0) & (shared[None, :] == 0), axis=1)
+    assert np.array_equal(nflag.cpu().numpy(), want_n)
     for d in (0, 5, 17, 36):
         good = ((shared == 0) & (dflags[d] == 0)).astype(np.uint8)
         want_p = GF.bin_proj(sig[d], templates, good)
@@ -113,7 +118,7 @@ def test_fit_kernel_many_detectors_and_templates_vs_oracle(oracle):
         assert np.max(np.abs(invcov[d] - want_i)) < 1e-12 * scale
     # no flags at all
     capi.dev.template_fit(d_t.data_ptr(), nt, n, idx, d_s.data_ptr(), None, 0, 1, 0, 1, proj_t := torch.zeros(
-        (n_det, nt), dtype=torch.float64, device="cuda").data_ptr(), gram.data_ptr(), dgram.data_ptr())
+        (n_det, nt), dtype=torch.float64, device="cuda").data_ptr(), gram.data_ptr(), dgram.data_ptr(), nflag.data_ptr())
     torch.cuda.synchronize()
     want = GF.bin_invcov(templates, np.ones(n, dtype=np.uint8))
     assert np.max(np.abs(gram.cpu().numpy() - want)) < 1e-12 * np.max(np.abs(want))

@@ -802,13 +802,14 @@ class _Dev:
                                                    C.c_int(1 if keep_equal else 0), _i64(n_samp), _p(d_out), _p(stream)))
 
     def template_fit(self, d_templates, n_template, n_samp, signal_index, d_signal, flag_index, d_det_flags,
-                     det_flag_mask, d_shared_flags, shared_flag_mask, d_proj, d_gram_common, d_gram_flagged, stream=0):
+                     det_flag_mask, d_shared_flags, shared_flag_mask, d_proj, d_gram_common, d_gram_flagged, d_n_flagged,
+                     stream=0):
         si = self._small(signal_index, np.int32)
         fi = self._small(flag_index if flag_index is not None else np.zeros(si.size), np.int32)
         _check(lib().toast_hip_template_fit_dev(
             _p(d_templates), _i64(n_template), _i64(n_samp), _p(si), _p(d_signal), _p(fi), _p(d_det_flags),
             _u8(det_flag_mask), _p(d_shared_flags), _u8(shared_flag_mask), _i64(si.size), _p(d_proj), _p(d_gram_common),
-            _p(d_gram_flagged), _p(stream)))
+            _p(d_gram_flagged), _p(d_n_flagged), _p(stream)))
 
     def template_subtract(self, d_templates, n_template, first_template, n_samp, signal_index, d_signal, d_coeff,
                           stream=0):

@@ -169,7 +169,7 @@ __global__ __launch_bounds__(kThreads) void k_template_project(
 __global__ __launch_bounds__(kThreads) void k_template_gram_flagged(
     const double * __restrict__ templates, int64_t n_template, int64_t n_samp, const int32_t * __restrict__ flag_index,
     const uint8_t * __restrict__ det_flags, uint8_t det_mask, const uint8_t * __restrict__ shared_flags, uint8_t shared_mask,
-    int64_t slice, double * __restrict__ dgram) {
+    int64_t slice, double * __restrict__ dgram, int64_t * __restrict__ n_flagged) {
     constexpr int kQueue = 1024;
     __shared__ int queue[kQueue];
     __shared__ int n_queued;
@@ -192,6 +192,7 @@ __global__ __launch_bounds__(kThreads) void k_template_gram_flagged(
         __syncthreads();
         const int nq = n_queued;
         if (nq > 0) {
+            if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&n_flagged[d]), (unsigned long long)nq);
             for (int64_t pair = threadIdx.x; pair < n_pair; pair += kThreads) {
                 int64_t r = 0, rem = pair;
                 while (rem >= n_template - r) {
@@ -288,13 +289,15 @@ int toast_hip_template_fit_dev(const double * d_templates, int64_t n_template, i
                                const int32_t * signal_index, const double * d_signal,
                                const int32_t * flag_index, const uint8_t * d_det_flags, uint8_t det_flag_mask,
                                const uint8_t * d_shared_flags, uint8_t shared_flag_mask, int64_t n_det,
-                               double * d_proj, double * d_gram_common, double * d_gram_flagged, void * stream) {
+                               double * d_proj, double * d_gram_common, double * d_gram_flagged,
+                               int64_t * d_n_flagged, void * stream) {
     return guarded([&] {
         if (n_template <= 0 || n_samp <= 0 || n_det <= 0) return;
         hipStream_t st = as_stream(stream);
         TH_HIP(hipMemsetAsync(d_proj, 0, sizeof(double) * n_det * n_template, st));
         TH_HIP(hipMemsetAsync(d_gram_common, 0, sizeof(double) * n_template * n_template, st));
         TH_HIP(hipMemsetAsync(d_gram_flagged, 0, sizeof(double) * n_det * n_template * n_template, st));
+        TH_HIP(hipMemsetAsync(d_n_flagged, 0, sizeof(int64_t) * n_det, st));
         ParamBlock pb;
         const size_t o_si = pb.push(signal_index, sizeof(int32_t) * n_det);
         std::vector<int32_t> no_flags(n_det, 0);
@@ -331,7 +334,7 @@ int toast_hip_template_fit_dev(const double * d_templates, int64_t n_template, i
             const int64_t fslice = 65536;
             hipLaunchKernelGGL(k_template_gram_flagged, dim3((unsigned)((n_samp + fslice - 1) / fslice), (unsigned)n_det),
                                dim3(kThreads), 0, st, d_templates, n_template, n_samp, fidx, d_det_flags, det_flag_mask,
-                               d_shared_flags, shared_flag_mask, fslice, d_gram_flagged);
+                               d_shared_flags, shared_flag_mask, fslice, d_gram_flagged, d_n_flagged);
             check_launch();
         }
     });

@@ -229,26 +229,19 @@ class GroundFilter(Operator):
             proj = np.zeros((n_det, nt))
             gram_common = np.zeros((nt, nt))
             gram_flagged = np.zeros((n_det, nt, nt))
-            outs = {"proj": proj, "gram": gram_common, "dgram": gram_flagged}
+            n_flagged = np.zeros(n_det, dtype=np.int64)
+            outs = {"proj": proj, "gram": gram_common, "dgram": gram_flagged, "nflag": n_flagged}
             for key, arr in outs.items():
                 accel_data_create(arr, f"{self.name}_{key}", owner=self)
             D.template_fit(accel_device_ptr(templates), nt, n, dd.indices(dets), accel_device_ptr(dd.buffer), f_idx, f_ptr,
                            self.det_flag_mask, s_ptr, self.shared_flag_mask, accel_device_ptr(proj),
-                           accel_device_ptr(gram_common), accel_device_ptr(gram_flagged))
+                           accel_device_ptr(gram_common), accel_device_ptr(gram_flagged), accel_device_ptr(n_flagged))
             native().accel_synchronize()
             for key, arr in outs.items():
                 accel_data_update_host(arr, f"{self.name}_{key}")
                 accel_data_delete(arr, f"{self.name}_{key}")
-            # number of good samples per detector = common good minus the detector's own flags
-            # among them: the flagged Gram matrix of the constant-1 "template" is not available, so
-            # count on the host flags (cheap: one byte per det-sample, only when flags exist)
-            n_good = np.full(n_det, int(np.count_nonzero(common_good)), dtype=np.int64)
-            if fd is not None:
-                if fd.accel_in_use():
-                    fd.accel_update_host()
-                    fd.accel_used(True)
-                for i, det in enumerate(dets):
-                    n_good[i] -= int(np.count_nonzero(((fd.data[fd.indices([det])[0]] & self.det_flag_mask) != 0) & common_good))
+            # good samples per detector: the commonly good ones minus those only this detector flags
+            n_good = int(np.count_nonzero(common_good)) - n_flagged
             coeff, ok = self.solve(proj, gram_common, gram_flagged, n_good)
             for i, det in enumerate(dets):
                 if not ok[i]:

@@ -28,6 +28,7 @@ def main():
     proj = torch.zeros((n_det, nt), dtype=torch.float64, device=dev)
     gram = torch.zeros((nt, nt), dtype=torch.float64, device=dev)
     dgram = torch.zeros((n_det, nt, nt), dtype=torch.float64, device=dev)
+    nflag = torch.zeros(n_det, dtype=torch.int64, device=dev)
     coeff = torch.randn((n_det, nt), dtype=torch.float64, device=dev) * 1e-3
     idx = np.arange(n_det, dtype=np.int32)
     D = capi.dev
@@ -37,7 +38,7 @@ def main():
 
     def fit():
         D.template_fit(templates.data_ptr(), nt, n, idx, sig.data_ptr(), idx, dflags.data_ptr(), 1, sflags.data_ptr(), 1,
-                       proj.data_ptr(), gram.data_ptr(), dgram.data_ptr())
+                       proj.data_ptr(), gram.data_ptr(), dgram.data_ptr(), nflag.data_ptr())
 
     def subtract():
         D.template_subtract(templates.data_ptr(), nt, trend, n, idx, sig.data_ptr(), coeff.data_ptr())
