@@ -6,6 +6,9 @@ orchestration is reproduced for the configuration used on the hot path: covarian
 from the same pointing, RHS, PCG on the Offset amplitudes, template subtraction, final BinMap.
 """
 
+import os as _os
+import sys as _sys
+
 import numpy as np
 
 from ..data import defaults
@@ -112,6 +115,8 @@ class SolveAmplitudes(Operator):
         def lap(label, t0):
             native().accel_synchronize() if accel_enabled() else None
             self.timing_log[label] = self.timing_log.get(label, 0.0) + (_time.time() - t0)
+            if _os.environ.get("TOAST_HIP_TRACE", "0") not in ("", "0"):
+                print(f"[toast_hip] phase         {label:30s} {1e3 * (_time.time() - t0):10.2f} ms", file=_sys.stderr, flush=True)
             return _time.time()
 
         t0 = _time.time()
@@ -317,6 +322,8 @@ class MapMaker(Operator):
         def lap(label, t0):
             native().accel_synchronize() if accel_enabled() else None
             self.timing_log[label] = self.timing_log.get(label, 0.0) + (_time.time() - t0)
+            if _os.environ.get("TOAST_HIP_TRACE", "0") not in ("", "0"):
+                print(f"[toast_hip] phase         {label:30s} {1e3 * (_time.time() - t0):10.2f} ms", file=_sys.stderr, flush=True)
             return _time.time()
 
         t0 = _time.time()

@@ -625,8 +625,16 @@ class Offset(Template):
         """det_flags | view flags, cached per observation (offset.py:834-843 builds this copy on
         every call); registered on the device when needed."""
         key = (iob, use_accel)
+        fd = ob.detdata[self.det_flags]
+        if use_accel and not self._obs_view_flags[iob].any():
+            # no sample lies outside the view: the solver flags ARE the detector flags, and they
+            # are used where they live (no 1 B/det-sample round trip through the host)
+            if not fd.accel_in_use():
+                if not fd.accel_exists():
+                    fd.accel_create(self.det_flags)
+                fd.accel_update_device()
+            return fd.buffer
         if key not in self._flag_cache:
-            fd = ob.detdata[self.det_flags]
             if fd.accel_in_use():
                 fd.accel_update_host()
                 fd.accel_used(True)
