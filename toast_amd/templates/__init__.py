@@ -634,6 +634,20 @@ class Offset(Template):
                     fd.accel_create(self.det_flags)
                 fd.accel_update_device()
             return fd.buffer
+        if key not in self._flag_cache and use_accel and (self.det_flag_mask & 1) and fd.accel_in_use():
+            # device-current flags and a view: (flags & mask) != 0 inside the view, 1 outside, built
+            # on the device (toast_hip_combine_flags_dev); equivalent under `& det_flag_mask` to
+            # the reference's det_flags | mask * view_flags as long as bit 0 is in the mask
+            from .. import capi
+
+            buf = fd.buffer
+            rows = np.arange(buf.shape[0], dtype=np.int32)
+            flag_data = np.empty_like(buf)   # host key only: the contents live on the device
+            accel_data_create(flag_data, f"{self.name}_solver_flags", owner=self)
+            capi.dev.combine_flags(accel_device_ptr(flag_data), rows, accel_device_ptr(buf), ob.n_local_samples, rows,
+                                   self.det_flag_mask, 0, 0, 0, ob.n_local_samples, ob.intervals[self.view].data,
+                                   n_out_rows=buf.shape[0], outside_value=1)
+            self._flag_cache[key] = flag_data
         if key not in self._flag_cache:
             if fd.accel_in_use():
                 fd.accel_update_host()
