@@ -22,7 +22,7 @@ from toast_amd.templates import Offset  # noqa: E402
 N_SAMP, N_TOTAL, STEP = 6000, 6, 200
 
 
-def build(comm, first, n_det, full_pointing):
+def build(comm, first, n_det, full_pointing, prior=False):
     data = create_satellite_data(comm=comm, n_det=n_det, total_det=N_TOTAL, first_det=first, n_samp=N_SAMP, rate=10.0,
                                  spin_angle_deg=25.0, prec_angle_deg=35.0)
     ob = data.obs[0]
@@ -35,7 +35,8 @@ def build(comm, first, n_det, full_pointing):
     pix = ops.PixelsHealpix(detector_pointing=dp, nside=16, nside_submap=4)
     sw = ops.StokesWeights(detector_pointing=dp, mode="IQU", hwp_angle=defaults.hwp_angle)
     binner = ops.BinMap(pixel_dist="dist", pixel_pointing=pix, stokes_weights=sw, full_pointing=full_pointing)
-    tmpl = Offset(step_time=STEP / 10.0, noise_model=defaults.noise_model, name="baselines", good_fraction=0.2)
+    tmpl = Offset(step_time=STEP / 10.0, noise_model=defaults.noise_model, name="baselines", good_fraction=0.2,
+                  use_noise_prior=prior, precond_width=20)
     mapper = ops.MapMaker(name="mm", det_data=defaults.det_data, binning=binner,
                           template_matrix=ops.TemplateMatrix(templates=[tmpl]), iter_max=15, convergence=1e-30,
                           solve_rcond_threshold=1e-3, map_rcond_threshold=1e-3, keep_solver_products=True)
@@ -49,9 +50,11 @@ def main():
     assert size == 2
     accel_assign_device(size, rank, 1.0, False)
     half = N_TOTAL // size
-    for full_pointing in (True, False):
-        data, mapper = build(Comm(), half * rank, half, full_pointing)
-        serial, smapper = build(Comm(use_dist=False), 0, N_TOTAL, full_pointing)
+    # cached pointing, pointing on the fly, and the amplitude-domain noise prior (rank-local
+    # filters and banded preconditioner; the dot products of the PCG are all-reduced)
+    for full_pointing, prior in ((True, False), (False, False), (True, True)):
+        data, mapper = build(Comm(), half * rank, half, full_pointing, prior)
+        serial, smapper = build(Comm(use_dist=False), 0, N_TOTAL, full_pointing, prior)
         assert list(data["dist"].local_submaps) == list(serial["dist"].local_submaps)
         assert np.array_equal(data["mm_hits"].data, serial["mm_hits"].data)
         for key in ("mm_cov", "mm_rcond", "mm_map", "mm_noiseweighted_map"):
