@@ -187,6 +187,22 @@ int toast_hip_stokes_weights_IQU_dev(
     int64_t n_view, const double * epsilon /*host*/, const double * gamma /*host*/,
     const double * cal /*host*/, int iau, void * stream);
 
+/* Mode "QU" of StokesWeights: weights f64[*,n_samp,2] = (Q, U) of the IQU triple.  The reference has
+ * no kernel for it: it runs stokes_weights_IQU into a temporary [n_det,n_samp,3] host array and
+ * copies two columns out (src/toast/ops/stokes_weights/stokes_weights.py:251-279). */
+int toast_hip_stokes_weights_QU(
+    const int32_t * quat_index, int64_t n_det, const double * quats, int64_t n_quat_rows,
+    const int32_t * weight_index, double * weights, int64_t n_weight_rows, int64_t n_samp,
+    const double * hwp, int64_t n_hwp, const toast_hip_interval * intervals, int64_t n_view,
+    const double * epsilon, const double * gamma, const double * cal, int iau, int use_accel);
+
+int toast_hip_stokes_weights_QU_dev(
+    const int32_t * quat_index /*host*/, int64_t n_det, const double * d_quats,
+    const int32_t * weight_index /*host*/, double * d_weights, int64_t n_samp,
+    const double * d_hwp, int64_t n_hwp, const toast_hip_interval * intervals /*host*/,
+    int64_t n_view, const double * epsilon /*host*/, const double * gamma /*host*/,
+    const double * cal /*host*/, int iau, void * stream);
+
 int toast_hip_stokes_weights_I(
     const int32_t * weight_index, int64_t n_det, double * weights, int64_t n_weight_rows,
     int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view, const double * cal,

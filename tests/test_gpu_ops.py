@@ -840,3 +840,37 @@ def test_template_pattern_restricts_the_amplitudes():
         results[fused] = data["lhs_out"]["baselines"].local.copy()
     assert np.max(np.abs(results[False])) > 0
     assert np.max(np.abs(results[False] - results[True])) < 1e-11 * np.max(np.abs(results[False]))
+
+
+@pytest.mark.parametrize("hwp", [True, False])
+def test_stokes_weights_qu_mode(hwp):
+    """mode="QU" (stokes_weights.py:251-279: the Q, U columns of the IQU weights), host-staged and
+    accelerator-resident; and a QU-only binned map through nnz = 2 kernels."""
+    got = {}
+    for mode in ("IQU", "QU"):
+        for use_accel in (False, True):
+            data = create_satellite_data(n_det=4, n_samp=3000)
+            dp, pix, sw = pointing_ops(nside=32, mode=mode, hwp=hwp)
+            sw.apply(data, use_accel=use_accel) if use_accel else sw.apply(data)
+            wd = data.obs[0].detdata[defaults.weights]
+            got[(mode, use_accel)] = wd.data.copy()
+            assert wd.data.shape == (4, 3000, len(mode))
+    assert np.array_equal(got[("QU", False)], got[("IQU", False)][:, :, 1:])
+    assert np.array_equal(got[("QU", True)], got[("IQU", False)][:, :, 1:])
+    # QU map-making: covariance has 3 packed elements, the map 2 components
+    data = create_satellite_data(n_det=4, n_samp=6000)
+    dp, pix, sw = pointing_ops(nside=16, mode="QU", hwp=hwp)
+    rng = np.random.default_rng(0)
+    ob = data.obs[0]
+    ops.Pipeline(operators=[pix, sw]).apply(data)
+    q, u = 0.3, -0.2
+    for det in ob.local_detectors:
+        w = ob.detdata[defaults.weights][det]
+        ob.detdata[defaults.det_data][det] = q * w[:, 0] + u * w[:, 1] + 1e-3 * rng.standard_normal(6000)
+    binner = ops.BinMap(pixel_dist="dist", pixel_pointing=pix, stokes_weights=sw, full_pointing=True)
+    ops.MapMaker(name="qu", det_data=defaults.det_data, binning=binner, map_rcond_threshold=1e-2).apply(data)
+    m, rc = data["qu_map"].data, data["qu_rcond"].data[:, :, 0]
+    assert m.shape[-1] == 2 and data["qu_cov"].data.shape[-1] == 3
+    good = rc > 0.1
+    assert np.count_nonzero(good) > 20
+    assert np.max(np.abs(m[good] - np.array([q, u]))) < 5e-3

@@ -297,6 +297,25 @@ def stokes_weights_IQU(quat_index, quats, weight_index, weights, hwp, intervals,
         _int(use_accel)))
 
 
+def stokes_weights_QU(quat_index, quats, weight_index, weights, hwp, intervals, epsilon, gamma, cal,
+                       IAU, use_accel=False):
+    qi = _buf(quat_index, "quat_index", np.int32, 1)
+    n_det = qi.shape[0]
+    wi = _buf(weight_index, "weight_index", np.int32, 1, (n_det,))
+    w = _buf(weights, "weights", np.float64, 3, (-1, -1, 2))
+    n_samp = w.shape[1]
+    q = _buf(quats, "quats", np.float64, 3, (-1, n_samp, 4))
+    h = _buf(hwp, "hwp", np.float64, 1)
+    iv = _buf(intervals, "intervals", interval_dtype, 1)
+    e = _buf(epsilon, "epsilon", np.float64, 1, (n_det,))
+    cl = _buf(cal, "cal", np.float64, 1, (n_det,))
+    g = _buf(gamma, "gamma", np.float64, 1, (n_det,))
+    _check(lib().toast_hip_stokes_weights_QU(
+        _p(qi), _i64(n_det), _p(q), _i64(q.shape[0]), _p(wi), _p(w), _i64(w.shape[0]), _i64(n_samp),
+        _p(h), _i64(h.shape[0]), _p(iv), _i64(iv.shape[0]), _p(e), _p(g), _p(cl), _int(IAU),
+        _int(use_accel)))
+
+
 def stokes_weights_I(weight_index, weights, intervals, cal, use_accel=False):
     wi = _buf(weight_index, "weight_index", np.int32, 1)
     n_det = wi.shape[0]
@@ -538,6 +557,18 @@ class _Dev:
         g = self._small(gamma, np.float64)
         cl = self._small(cal, np.float64)
         _check(lib().toast_hip_stokes_weights_IQU_dev(
+            _p(qi), _i64(qi.size), _p(d_quats), _p(wi), _p(d_weights), _i64(n_samp), _p(d_hwp),
+            _i64(n_hwp), _p(iv), _i64(iv.size), _p(e), _p(g), _p(cl), _int(iau), _p(stream)))
+
+    def stokes_weights_QU(self, quat_index, d_quats, weight_index, d_weights, n_samp, d_hwp, n_hwp,
+                           intervals, epsilon, gamma, cal, iau, stream=0):
+        qi = self._small(quat_index, np.int32)
+        wi = self._small(weight_index, np.int32)
+        iv = self._small(intervals, interval_dtype)
+        e = self._small(epsilon, np.float64)
+        g = self._small(gamma, np.float64)
+        cl = self._small(cal, np.float64)
+        _check(lib().toast_hip_stokes_weights_QU_dev(
             _p(qi), _i64(qi.size), _p(d_quats), _p(wi), _p(d_weights), _i64(n_samp), _p(d_hwp),
             _i64(n_hwp), _p(iv), _i64(iv.size), _p(e), _p(g), _p(cl), _int(iau), _p(stream)))
 

@@ -107,6 +107,24 @@ int toast_hip_stokes_weights_IQU(const int32_t * quat_index, int64_t n_det, cons
     });
 }
 
+int toast_hip_stokes_weights_QU(const int32_t * quat_index, int64_t n_det, const double * quats,
+                                int64_t n_quat_rows, const int32_t * weight_index, double * weights,
+                                int64_t n_weight_rows, int64_t n_samp, const double * hwp,
+                                int64_t n_hwp, const toast_hip_interval * intervals, int64_t n_view,
+                                const double * epsilon, const double * gamma, const double * cal,
+                                int iau, int use_accel) {
+    return guarded([&] {
+        Call c(use_accel);
+        const double * d_quats = c.st.in(quats, (size_t)(n_quat_rows * n_samp * 4));
+        double * d_w = c.st.inout(weights, (size_t)(n_weight_rows * n_samp * 2));
+        const double * d_hwp = optional_in(c.st, hwp, n_hwp, n_samp);
+        c.check(toast_hip_stokes_weights_QU_dev(quat_index, n_det, d_quats, weight_index, d_w, n_samp,
+                                                d_hwp, d_hwp ? n_samp : 0, intervals, n_view, epsilon,
+                                                gamma, cal, iau, c.stream));
+        c.st.finish();
+    });
+}
+
 int toast_hip_stokes_weights_I(const int32_t * weight_index, int64_t n_det, double * weights,
                                int64_t n_weight_rows, int64_t n_samp,
                                const toast_hip_interval * intervals, int64_t n_view,

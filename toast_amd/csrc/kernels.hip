@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kThreads) void k_pixels_healpix(
 // ------------------------------------------------------------------------------------
 // stokes_weights   [ref: ops_stokes_weights.cpp:77-140, :459-505]
 // ------------------------------------------------------------------------------------
-template <bool HWP>
+template <bool HWP, int NOUT>   // NOUT = 3: (I, Q, U); 2: (Q, U) only (StokesWeights mode "QU")
 __global__ __launch_bounds__(kThreads) void k_stokes_iqu(
     const Chunk * __restrict__ chunks, int n_chunks, const int32_t * __restrict__ q_idx,
     const int32_t * __restrict__ w_idx, const double * __restrict__ quats,
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kThreads) void k_stokes_iqu(
     double c4g = 1.0, s4g = 0.0;
     if (HWP) sincos(4.0 * gd, &s4g, &c4g);
     const double * qrow = quats + (int64_t)q_idx[det] * n_samp * 4;
-    double * wrow = weights + (int64_t)w_idx[det] * n_samp * 3;
+    double * wrow = weights + (int64_t)w_idx[det] * n_samp * NOUT;
     for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
         const Chunk c = chunks[ci];
         for (int i = threadIdx.x; i < c.count; i += kThreads) {
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(kThreads) void k_stokes_iqu(
             const double qa[4] = {q.x, q.y, q.z, q.w};
             double c2a, s2a;
             stokes_cs2alpha(qa, c2a, s2a);
-            double * w = wrow + 3 * s;
+            double * w = wrow + NOUT * s - (3 - NOUT);   // w[1], w[2] land in the last two slots
             if (HWP) {
                 // ang = 2 (2 (gamma - hwp) - alpha) = beta - 2 alpha, beta = 4 gamma - 4 hwp
                 double s4h, c4h, sb, cb;
@@ -130,11 +130,11 @@ __global__ __launch_bounds__(kThreads) void k_stokes_iqu(
                 hwp_rotation(c4g, s4g, c4h, s4h, cb, sb);
                 const double cang = cb * c2a + sb * s2a;
                 const double sang = sb * c2a - cb * s2a;
-                w[0] = cd;
+                if (NOUT == 3) w[0] = cd;
                 w[1] = cang * eta * cd;
                 w[2] = -sang * eta * cd * usign;
             } else {
-                w[0] = cd;
+                if (NOUT == 3) w[0] = cd;
                 w[1] = c2a * eta * cd;
                 w[2] = s2a * eta * cd * usign;
             }
@@ -1068,7 +1068,7 @@ int toast_hip_pixels_healpix_dev(const int32_t * quat_index, int64_t n_det, cons
     });
 }
 
-int toast_hip_stokes_weights_IQU_dev(const int32_t * quat_index, int64_t n_det, const double * d_quats,
+static int stokes_weights_pol_dev(int n_out, const int32_t * quat_index, int64_t n_det, const double * d_quats,
                                      const int32_t * weight_index, double * d_weights, int64_t n_samp,
                                      const double * d_hwp, int64_t n_hwp,
                                      const toast_hip_interval * intervals, int64_t n_view,
@@ -1089,7 +1089,8 @@ int toast_hip_stokes_weights_IQU_dev(const int32_t * quat_index, int64_t n_det, 
         const char * d = pb.commit(as_stream(stream));
         const bool use_hwp = (n_hwp == n_samp);
         const double usign = iau ? -1.0 : 1.0;
-        auto kern = use_hwp ? k_stokes_iqu<true> : k_stokes_iqu<false>;
+        auto kern = (n_out == 3) ? (use_hwp ? k_stokes_iqu<true, 3> : k_stokes_iqu<false, 3>)
+                                 : (use_hwp ? k_stokes_iqu<true, 2> : k_stokes_iqu<false, 2>);
         hipLaunchKernelGGL(kern, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0,
                            as_stream(stream), (const Chunk *)(d + o_ch), (int)chunks.size(),
                            (const int32_t *)(d + o_qi), (const int32_t *)(d + o_wi), d_quats,
@@ -1097,6 +1098,26 @@ int toast_hip_stokes_weights_IQU_dev(const int32_t * quat_index, int64_t n_det, 
                            (const double *)(d + o_c), usign, n_samp);
         check_launch();
     });
+}
+
+int toast_hip_stokes_weights_IQU_dev(const int32_t * quat_index, int64_t n_det, const double * d_quats,
+                                     const int32_t * weight_index, double * d_weights, int64_t n_samp,
+                                     const double * d_hwp, int64_t n_hwp,
+                                     const toast_hip_interval * intervals, int64_t n_view,
+                                     const double * epsilon, const double * gamma, const double * cal,
+                                     int iau, void * stream) {
+    return stokes_weights_pol_dev(3, quat_index, n_det, d_quats, weight_index, d_weights, n_samp, d_hwp, n_hwp, intervals,
+                                  n_view, epsilon, gamma, cal, iau, stream);
+}
+
+int toast_hip_stokes_weights_QU_dev(const int32_t * quat_index, int64_t n_det, const double * d_quats,
+                                    const int32_t * weight_index, double * d_weights, int64_t n_samp,
+                                    const double * d_hwp, int64_t n_hwp,
+                                    const toast_hip_interval * intervals, int64_t n_view,
+                                    const double * epsilon, const double * gamma, const double * cal,
+                                    int iau, void * stream) {
+    return stokes_weights_pol_dev(2, quat_index, n_det, d_quats, weight_index, d_weights, n_samp, d_hwp, n_hwp, intervals,
+                                  n_view, epsilon, gamma, cal, iau, stream);
 }
 
 int toast_hip_stokes_weights_I_dev(const int32_t * weight_index, int64_t n_det, double * d_weights,

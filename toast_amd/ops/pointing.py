@@ -413,7 +413,7 @@ class StokesWeights(Operator):
 
     API = Int(0, help="Internal interface version for this operator")
     detector_pointing = Instance(klass=Operator, help="Operator that translates boresight pointing into detector frame")
-    mode = Unicode("I", help="The Stokes weights to generate (I or IQU)")
+    mode = Unicode("I", help="The Stokes weights to generate (I, QU or IQU)")
     view = Unicode(None, allow_none=True, help="Use this view of the data in all observations")
     hwp_angle = Unicode(None, allow_none=True, help="Observation shared key for HWP angle")
     fp_gamma = Unicode("gamma", allow_none=True, help="Focalplane key for detector gamma offset angle")
@@ -429,8 +429,8 @@ class StokesWeights(Operator):
                                              "quats", "coord_in", "coord_out"])
 
     def _validate_mode(self, check):
-        if check not in ("I", "IQU"):
-            raise RuntimeError("Invalid mode (must be 'I' or 'IQU')")
+        if check not in ("I", "QU", "IQU"):
+            raise RuntimeError("Invalid mode (must be 'I', 'QU' or 'IQU')")
         return check
 
     def _exec(self, data, detectors=None, use_accel=None, **kwargs):
@@ -444,7 +444,7 @@ class StokesWeights(Operator):
             raise RuntimeError("If using HWP, you must specify the fp_gamma key")
         quats_name = self.detector_pointing.quats
         view = self.view if self.view is not None else self.detector_pointing.view
-        no_quats = _skip_quaternions(self, data, detectors, use_accel)
+        no_quats = self.mode != "QU" and _skip_quaternions(self, data, detectors, use_accel)
         if not no_quats and not _outputs_exist(data, self.weights, detectors, self.detector_pointing.det_mask):
             self.detector_pointing.apply(data, detectors=detectors, use_accel=use_accel)
         for ob in data.obs:
@@ -480,9 +480,19 @@ class StokesWeights(Operator):
                     hwp_data = ob.shared[self.hwp_angle].data
                     for idet, d in enumerate(dets):
                         det_gamma[idet] = focalplane[d][self.fp_gamma]
-                native().stokes_weights_IQU(quat_indx, ob.detdata[quats_name].arg(use_accel), weight_indx,
-                                            ob.detdata[self.weights].arg(use_accel), hwp_data, ob.intervals[view].data,
-                                            det_epsilon, det_gamma, cal, bool(self.IAU), use_accel)
+                if self.mode == "QU":
+                    # (the reference computes IQU into a temporary and copies Q, U out,
+                    # stokes_weights.py:251-279; here the kernel writes the two columns directly)
+                    from .. import capi
+
+                    capi.stokes_weights_QU(quat_indx, ob.detdata[quats_name].arg(use_accel), weight_indx,
+                                           ob.detdata[self.weights].arg(use_accel), hwp_data, ob.intervals[view].data,
+                                           det_epsilon, det_gamma, cal, bool(self.IAU), use_accel)
+                else:
+                    native().stokes_weights_IQU(quat_indx, ob.detdata[quats_name].arg(use_accel), weight_indx,
+                                                ob.detdata[self.weights].arg(use_accel), hwp_data,
+                                                ob.intervals[view].data, det_epsilon, det_gamma, cal, bool(self.IAU),
+                                                use_accel)
             else:
                 # the compiled kernel takes a 2-D [n_det, n_samp] buffer (ops_stokes_weights.cpp:417-420)
                 wd = ob.detdata[self.weights].arg(use_accel)
