@@ -874,3 +874,32 @@ def test_stokes_weights_qu_mode(hwp):
     good = rc > 0.1
     assert np.count_nonzero(good) > 20
     assert np.max(np.abs(m[good] - np.array([q, u]))) < 5e-3
+
+
+def test_mapmaker_focalplane_key_split():
+    """Split map-making on a focalplane column (mapmaker.py:728-790): one set of products per
+    value, named <name>_<value>; their hit maps add up to the unsplit run's."""
+    data, pix, sw, truth, sky = make_solver_setup(n_det=6, n_samp=6000)
+    fp = data.obs[0].telescope.focalplane
+    for d in fp.detectors:
+        fp[d]["pol"] = d[-1]          # "A" / "B"
+    assert sorted(fp.detector_groups("pol")) == ["A", "B"]
+    groups = data.all_detector_groups(column="pol")
+    assert sorted(groups) == ["A", "B"] and all(len(v) == 3 for v in groups.values())
+    assert list(data.all_detector_groups()) == ["ALL"]
+    binner = ops.BinMap(pixel_dist="dist", pixel_pointing=pix, stokes_weights=sw, full_pointing=True)
+    tmpl = Offset(step_time=20.0, noise_model=defaults.noise_model, name="baselines", good_fraction=0.2)
+    mapper = ops.MapMaker(name="mm", det_data=defaults.det_data, binning=binner,
+                          template_matrix=ops.TemplateMatrix(templates=[tmpl]), iter_max=10,
+                          solve_rcond_threshold=1e-3, map_rcond_threshold=1e-3, focalplane_key="pol")
+    mapper.apply(data)
+    assert mapper.name == "mm" and "mm_hits" not in data
+    hits = {k: data[f"mm_{k}_hits"].data.copy() for k in ("A", "B")}
+    dists = {k: list(data["dist"].local_submaps) for k in ("B",)}
+    mapper.focalplane_key = None
+    mapper.reset_pix_dist = True
+    mapper.apply(data)
+    total = data["mm_hits"].data
+    assert list(data["dist"].local_submaps) == dists["B"] or total.shape[0] >= hits["B"].shape[0]
+    assert int(total.sum()) == int(hits["A"].sum() + hits["B"].sum()) and int(hits["A"].sum()) > 0
+    assert np.all(np.isfinite(data["mm_A_map"].data)) and np.all(np.isfinite(data["mm_B_map"].data))

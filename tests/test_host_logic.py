@@ -177,3 +177,27 @@ def test_noise_models():
     assert f[0] == 1e-9 and f[-1] == 50.0 and np.all(np.diff(f) > 0)
     assert p[-1] == pytest.approx(4.0 * (50 + 0.05) / (50 + 1e-5))
     assert estimate_net(f, p) == pytest.approx(2.0, rel=0.05)
+
+
+def test_copy_and_delete_all_object_kinds():
+    """Copy / Delete of shared, intervals and observation metadata (src/toast/ops/copy.py:83-128,
+    delete.py:45-62) -- host-only bookkeeping, no device needed."""
+    import numpy as np
+
+    from toast_amd import ops
+    from toast_amd.data import defaults
+    from toast_amd.sim import create_satellite_data
+
+    data = create_satellite_data(n_det=2, n_samp=200, n_intervals=2)
+    ob = data.obs[0]
+    ob["calib"] = {"a": 1.5}
+    data["glob"] = 3
+    ops.Copy(meta=[("calib", "calib2")], shared=[(defaults.hwp_angle, "hwp2")], intervals=[("scan", "scan2")],
+             detdata=[(defaults.det_data, "sig2")]).apply(data)
+    assert ob["calib2"] == {"a": 1.5} and ob["calib2"] is not ob["calib"]
+    assert np.array_equal(ob.shared["hwp2"].data, ob.shared[defaults.hwp_angle].data)
+    assert len(ob.intervals["scan2"]) == len(ob.intervals["scan"])
+    assert np.array_equal(ob.detdata["sig2"].data, ob.detdata[defaults.det_data].data)
+    ops.Delete(meta=["calib2"], shared=["hwp2"], intervals=["scan2"], detdata=["sig2"], global_meta=["glob"]).apply(data)
+    assert "calib2" not in ob and "hwp2" not in ob.shared and "scan2" not in ob.intervals
+    assert "sig2" not in ob.detdata and "glob" not in data and "calib" in ob

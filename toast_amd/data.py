@@ -435,7 +435,7 @@ class Focalplane:
     """Detector table: ``detector_data[det]`` has ``quat``, ``gamma``, ``pol_leakage``
     (epsilon) and ``cal`` (reference: src/toast/instrument.py Focalplane)."""
 
-    def __init__(self, detectors, quats, gamma=None, epsilon=None, cal=None, sample_rate=1.0):
+    def __init__(self, detectors, quats, gamma=None, epsilon=None, cal=None, sample_rate=1.0, columns=None):
         self.detectors = list(detectors)
         n = len(self.detectors)
         self.sample_rate = float(sample_rate)
@@ -448,8 +448,23 @@ class Focalplane:
             for i, d in enumerate(self.detectors)
         }
 
+        # extra per-detector columns (wafer, band, pixel ... : the keys of split map-making)
+        for name, values in (columns or {}).items():
+            for d, v in zip(self.detectors, values):
+                self._table[d][name] = v
+
     def __getitem__(self, det):
         return self._table[det]
+
+    def detector_groups(self, column):
+        """Detectors grouped by the value of a focalplane column (instrument.py
+        Focalplane.detector_groups)."""
+        groups = {}
+        for d in self.detectors:
+            if column not in self._table[d]:
+                raise RuntimeError(f"focalplane has no column '{column}'")
+            groups.setdefault(self._table[d][column], []).append(d)
+        return groups
 
 
 class Telescope:
@@ -531,6 +546,33 @@ class Data(MutableMapping):
 
         ref = weakref.ref(self)
         add_eviction_handler(lambda: (ref().accel_evict() if ref() is not None else 0))
+
+    def all_detector_groups(self, column=None, selection=None, flagmask=0):
+        """Valid detectors of all observations (and all processes), split by the value of a
+        focalplane column; ``{"ALL": None}``-style single group without a column
+        (src/toast/data.py:141-230)."""
+        splits = {}
+        for ob in self.obs:
+            groups = {"ALL": ob.local_detectors} if column is None else ob.telescope.focalplane.detector_groups(column)
+            dets = set(ob.select_local_detectors(selection, flagmask=flagmask))
+            for k, v in groups.items():
+                for d in v:
+                    if d in dets and d not in splits.setdefault(k, []):
+                        splits[k].append(d)
+        splits = {k: v for k, v in splits.items() if len(v) > 0}
+        if self.comm.comm_world is not None:
+            import torch.distributed as dist
+
+            gathered = [None] * self.comm.world_size
+            dist.all_gather_object(gathered, splits)
+            merged = {}
+            for part in gathered:
+                for k, v in part.items():
+                    for d in v:
+                        if d not in merged.setdefault(k, []):
+                            merged[k].append(d)
+            splits = {k: merged[k] for k in sorted(merged, key=str)}
+        return splits
 
     def accel_pin(self, names):
         """Keep these objects resident on the device across Pipelines: ``accel_update_host`` and

@@ -284,7 +284,30 @@ class MapMaker(Operator):
     pattern = Unicode(None, allow_none=True, help="Regex pattern to match against detector names. "
                                                   "Only these are mapped.")
 
+    focalplane_key = Unicode(None, allow_none=True, help="Focalplane key for split mapmaking.")
+
     def _exec(self, data, detectors=None, **kwargs):
+        # Split map-making: one complete run per value of a focalplane column, products named
+        # <name>_<value> (mapmaker.py:728-790).
+        map_binning = self.map_binning if self.map_binning is not None and self.map_binning.enabled else self.binning
+        splits = data.all_detector_groups(column=self.focalplane_key, selection=detectors, flagmask=map_binning.det_mask)
+        if len(splits) == 0:
+            return  # no valid detectors, no mapmaking
+        for split_key, split_dets in splits.items():
+            if split_key == "ALL":
+                self._exec_pattern(data, detectors=detectors, **kwargs)
+                continue
+            import re
+
+            saved = (self.name, self.reset_pix_dist)
+            self.name = f"{saved[0]}_" + re.sub(r"\s", "", str(split_key))
+            self.reset_pix_dist = True
+            try:
+                self._exec_pattern(data, detectors=split_dets, **kwargs)
+            finally:
+                self.name, self.reset_pix_dist = saved
+
+    def _exec_pattern(self, data, detectors=None, **kwargs):
         if self.pattern is None:
             return self._run(data, detectors=detectors, **kwargs)
         # Detectors that do not match are flagged invalid for the duration of the run

@@ -753,9 +753,29 @@ class Copy(Operator):
 
     API = Int(0, help="Internal interface version for this operator")
     detdata = List([], help="List of tuples of Observation detdata keys to copy")
+    meta = List([], help="List of tuples of Observation meta keys to copy")
+    shared = List([], help="List of tuples of Observation shared keys to copy")
+    intervals = List([], help="List of tuples of Observation intervals keys to copy")
 
     def _exec(self, data, detectors=None, use_accel=None, **kwargs):
+        import copy as _copy
+
         for ob in data.obs:
+            for src, dst in self.meta:      # copy.py:83-90
+                ob[dst] = _copy.deepcopy(ob[src])
+            for src, dst in self.shared:    # copy.py:92-116
+                obj = ob.shared[src]
+                if obj.accel_in_use():
+                    obj.accel_update_host()
+                    obj.accel_used(True)
+                if dst in ob.shared:
+                    if ob.shared[dst].data.shape != obj.data.shape or ob.shared[dst].data.dtype != obj.data.dtype:
+                        raise RuntimeError(f"Destination shared key {dst} exists with a different shape / dtype")
+                    ob.shared[dst].data[:] = obj.data
+                else:
+                    ob.shared.create(dst, np.array(obj.data))
+            for src, dst in self.intervals:  # copy.py:118-128
+                ob.intervals[dst] = _copy.deepcopy(ob.intervals[src])
             for src, dst in self.detdata:
                 s = ob.detdata[src]
                 dets = ob.select_local_detectors(detectors)
@@ -807,26 +827,43 @@ class Copy(Operator):
 
 
 class Delete(Operator):
-    """Delete detdata / global objects (reference: src/toast/ops/delete.py)."""
+    """Delete observation (detdata, shared, intervals, meta) and global objects
+    (reference: src/toast/ops/delete.py)."""
 
     API = Int(0, help="Internal interface version for this operator")
+    global_meta = List([], help="List of global data dictionary keys to delete")
+    meta = List([], help="List of Observation dictionary keys to delete")
     detdata = List([], help="List of Observation detdata keys to delete")
-    meta = List([], help="List of Data keys to delete")
+    shared = List([], help="List of Observation shared keys to delete")
+    intervals = List([], help="List of tuples of Observation intervals keys to delete")
 
     def _exec(self, data, detectors=None, **kwargs):
+        for key in self.global_meta:
+            if key in data:
+                del data[key]
         for ob in data.obs:
             for key in self.detdata:
                 if key in ob.detdata:
                     del ob.detdata[key]
-        for key in self.meta:
-            if key in data:
-                del data[key]
+            for key in self.shared:
+                if key in ob.shared:
+                    obj = ob.shared[key]
+                    if obj.accel_exists():
+                        obj.accel_delete()
+                    del ob.shared[key]
+            for key in self.intervals:
+                if key in ob.intervals:
+                    del ob.intervals[key]
+            for key in self.meta:
+                if key in ob:
+                    del ob[key]
 
     def _finalize(self, data, **kwargs):
         return
 
     def _requires(self):
-        return {"detdata": list(self.detdata), "global": list(self.meta)}
+        return {"detdata": list(self.detdata), "global": list(self.global_meta), "shared": list(self.shared),
+                "intervals": list(self.intervals), "meta": list(self.meta)}
 
     def _provides(self):
         return {}

@@ -376,6 +376,9 @@ class Offset(Template):
                     continue
                 if det_pat is not None and det_pat.match(d) is None:
                     continue  # offset.py:226-236
+                if self.det_flags is not None and self.det_flags in ob.detdata \
+                        and d not in ob.detdata[self.det_flags].detectors:
+                    continue  # no solver flags for it: not part of this (split) run
                 self._obs_dets[iob].add(d)
                 all_dets.setdefault(d, None)
         self._all_dets = list(all_dets.keys())
