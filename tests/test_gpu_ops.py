@@ -903,3 +903,46 @@ def test_mapmaker_focalplane_key_split():
     assert list(data["dist"].local_submaps) == dists["B"] or total.shape[0] >= hits["B"].shape[0]
     assert int(total.sum()) == int(hits["A"].sum() + hits["B"].sum()) and int(hits["A"].sum()) > 0
     assert np.all(np.isfinite(data["mm_A_map"].data)) and np.all(np.isfinite(data["mm_B_map"].data))
+
+
+@pytest.mark.parametrize("use_accel", [False, True])
+def test_hwp_deflection_of_the_boresight(oracle, use_accel):
+    """hwp_deflection_radius (pointing_detector.py:236-276, host-only in the reference): detector
+    quaternions = focalplane offsets applied to the boresight rotated by `radius` about an axis 90
+    degrees from the HWP fast axis; the cached and the quaternion-free expansions agree."""
+    data = create_satellite_data(n_det=3, n_samp=2000)
+    ob = data.obs[0]
+    radius, offset = np.radians(0.25), 0.3
+    dp = ops.PointingDetectorSimple(hwp_angle=defaults.hwp_angle, hwp_deflection_radius=radius, hwp_angle_offset=offset)
+    dp.apply(data, use_accel=use_accel) if use_accel else dp.apply(data)
+    got = ob.detdata[defaults.quats].data.copy()
+    # independent construction of the deflected boresight
+    ang = ob.shared[defaults.hwp_angle].data + offset + np.pi / 2
+    half = radius / 2
+    defl = np.stack([np.cos(ang) * np.sin(half), np.sin(ang) * np.sin(half), np.zeros_like(ang),
+                     np.full_like(ang, np.cos(half))], axis=1)
+    p, q = ob.shared[defaults.boresight_radec].data, defl
+    bore = np.stack([
+        p[:, 0] * q[:, 3] + p[:, 1] * q[:, 2] - p[:, 2] * q[:, 1] + p[:, 3] * q[:, 0],
+        -p[:, 0] * q[:, 2] + p[:, 1] * q[:, 3] + p[:, 2] * q[:, 0] + p[:, 3] * q[:, 1],
+        p[:, 0] * q[:, 1] - p[:, 1] * q[:, 0] + p[:, 2] * q[:, 3] + p[:, 3] * q[:, 2],
+        -p[:, 0] * q[:, 0] - p[:, 1] * q[:, 1] - p[:, 2] * q[:, 2] + p[:, 3] * q[:, 3]], axis=1)
+    fp = np.array([ob.telescope.focalplane[d]["quat"] for d in ob.local_detectors])
+    want = np.zeros_like(got)
+    ivl = ob.intervals[None].data
+    oracle.pointing_detector(fp, np.ascontiguousarray(bore), np.arange(3, dtype=np.int32), want, ivl,
+                             ob.shared[defaults.shared_flags].data, defaults.shared_mask_invalid)
+    assert np.array_equal(got, want)
+    plain = create_satellite_data(n_det=3, n_samp=2000)
+    ops.PointingDetectorSimple().apply(plain)
+    assert np.max(np.abs(got - plain.obs[0].detdata[defaults.quats].data)) > 1e-4   # it does deflect
+    if use_accel:
+        # quaternion-free pixel expansion reads the same deflected boresight
+        pix_a = ops.PixelsHealpix(detector_pointing=dp, nside=256)
+        pix_a.apply(data, use_accel=True)
+        d2 = create_satellite_data(n_det=3, n_samp=2000)
+        dp2 = ops.PointingDetectorSimple(hwp_angle=defaults.hwp_angle, hwp_deflection_radius=radius,
+                                         hwp_angle_offset=offset)
+        ops.PixelsHealpix(detector_pointing=dp2, nside=256).apply(d2, use_accel=True)   # no cached quats here
+        assert defaults.quats not in d2.obs[0].detdata
+        assert np.array_equal(d2.obs[0].detdata[defaults.pixels].data, ob.detdata[defaults.pixels].data)

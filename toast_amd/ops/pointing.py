@@ -11,7 +11,7 @@ import numpy as np
 from ..accel import native
 from ..data import defaults
 from ..pixels import PixelDistribution, unify_local_submaps
-from ..traits import Bool, ImplementationType, Instance, Int, Unicode
+from ..traits import Bool, Float, ImplementationType, Instance, Int, Unicode
 from .operator import Operator
 
 _IMPLS = [ImplementationType.DEFAULT, ImplementationType.COMPILED]
@@ -40,6 +40,10 @@ class PointingDetectorSimple(Operator):
     det_flag_mask = Int(defaults.det_mask_invalid, help="Bit mask value for detector sample flagging")
     boresight = Unicode(defaults.boresight_radec, help="Observation shared key for boresight")
     hwp_angle = Unicode(None, allow_none=True, help="Observation shared key for HWP angle")
+    hwp_angle_offset = Float(0.0, help="HWP angle offset [rad] to apply when constructing deflection")
+    hwp_deflection_radius = Float(None, allow_none=True,
+                                  help="If non-zero, nominal detector pointing will be deflected in a circular "
+                                       "pattern according to HWP phase [rad].")
     quats = Unicode(defaults.quats, allow_none=True, help="Observation detdata key for output quaternions")
     coord_in = Unicode(None, allow_none=True, help="The input boresight coordinate system ('C', 'E', 'G')")
     coord_out = Unicode(None, allow_none=True, help="The output coordinate system ('C', 'E', 'G')")
@@ -49,6 +53,39 @@ class PointingDetectorSimple(Operator):
             raise RuntimeError("Flag mask should be a positive integer")
         return check
 
+    def effective_boresight(self, ob):
+        """Shared key of the boresight the kernels read: the boresight itself, or -- with
+        ``hwp_deflection_radius`` -- its copy deflected by the HWP wobble.  The reference applies
+        the deflection on the host only (pointing_detector.py:236-276: a rotation of
+        ``hwp_deflection_radius`` about an axis 90 deg from the HWP fast axis, multiplied onto the
+        boresight; ``NotImplementedError`` on accelerators); here the deflected boresight, one
+        quaternion per time sample, is built once and then used like any boresight, resident on
+        the device."""
+        if self.hwp_deflection_radius is None or self.hwp_deflection_radius == 0:
+            return self.boresight
+        if self.hwp_angle is None or self.hwp_angle not in ob.shared:
+            raise RuntimeError("hwp_deflection_radius needs the hwp_angle shared key")
+        from .. import synth
+
+        key = f"{self.boresight}_deflected"
+        hwp = ob.shared[self.hwp_angle]
+        sig = (float(self.hwp_deflection_radius), float(self.hwp_angle_offset), id(hwp.data), id(ob.shared[self.boresight].data))
+        if key in ob.shared and getattr(ob.shared[key], "_deflection_sig", None) == sig:
+            return key
+        orientation = np.array(hwp.data, dtype=np.float64) + self.hwp_angle_offset + np.pi / 2
+        half = 0.5 * float(self.hwp_deflection_radius)
+        deflection = np.zeros((orientation.size, 4), dtype=np.float64)
+        deflection[:, 0] = np.cos(orientation) * np.sin(half)
+        deflection[:, 1] = np.sin(orientation) * np.sin(half)
+        deflection[:, 3] = np.cos(half)
+        if key in ob.shared:
+            if ob.shared[key].accel_exists():
+                ob.shared[key].accel_delete()
+            del ob.shared[key]
+        ob.shared.create(key, np.ascontiguousarray(synth.quat_mult(ob.shared[self.boresight].data, deflection)))
+        ob.shared[key]._deflection_sig = sig
+        return key
+
     def _exec(self, data, detectors=None, use_accel=None, **kwargs):
         implementation, use_accel = self.select_kernels(use_accel=use_accel)
         if (self.coord_in is None) != (self.coord_out is None):
@@ -56,7 +93,7 @@ class PointingDetectorSimple(Operator):
         if self.coord_in is not None and self.coord_in != self.coord_out:
             raise NotImplementedError("coordinate rotation of the boresight is outside the hot path")
         for ob in data.obs:
-            _shared_to(ob, self.boresight, use_accel)
+            _shared_to(ob, self.effective_boresight(ob), use_accel)
             if self.shared_flags is not None:
                 _shared_to(ob, self.shared_flags, use_accel)
         for ob in data.obs:
@@ -71,7 +108,7 @@ class PointingDetectorSimple(Operator):
                 fp_quats[idet, :] = focalplane[d]["quat"]
             quat_indx = ob.detdata[self.quats].indices(dets)
             flags = np.zeros(1, dtype=np.uint8) if self.shared_flags is None else ob.shared[self.shared_flags].data
-            native().pointing_detector(fp_quats, ob.shared[self.boresight].data, quat_indx,
+            native().pointing_detector(fp_quats, ob.shared[self.effective_boresight(ob)].data, quat_indx,
                                        ob.detdata[self.quats].arg(use_accel), ob.intervals[self.view].data, flags,
                                        self.shared_flag_mask, use_accel)
 
@@ -105,7 +142,8 @@ def otf_supported(pixels_op, weights_op):
     if not isinstance(dp, PointingDetectorSimple) or weights_op.detector_pointing is None:
         return False
     wp = weights_op.detector_pointing
-    same = all(getattr(dp, t) == getattr(wp, t) for t in ("boresight", "shared_flags", "shared_flag_mask", "view"))
+    same = all(getattr(dp, t) == getattr(wp, t) for t in ("boresight", "shared_flags", "shared_flag_mask", "view",
+                                                          "hwp_angle", "hwp_angle_offset", "hwp_deflection_radius"))
     if not same or (dp.coord_in is not None and dp.coord_in != dp.coord_out):
         return False
     if weights_op.single_precision or weights_op.mode not in ("I", "IQU"):
@@ -123,8 +161,9 @@ def otf_descriptor(ob, dets, pixels_op, weights_op, compact=None):
     from ..accel import accel_device_ptr
 
     dp = (pixels_op if pixels_op is not None else weights_op).detector_pointing
-    _shared_to(ob, dp.boresight, True)
-    bore = accel_device_ptr(ob.shared[dp.boresight].data)
+    bore_key = dp.effective_boresight(ob)
+    _shared_to(ob, bore_key, True)
+    bore = accel_device_ptr(ob.shared[bore_key].data)
     n_samp = ob.n_local_samples
     d_flags, n_flags = 0, 0
     if dp.shared_flags is not None:
