@@ -29,6 +29,50 @@ def _shared_to(ob, name, use_accel):
         obj.accel_update_host()
 
 
+# J2000 coordinate transforms: the rotation matrices of src/toast/qarray.py:676-768 (equatorial ->
+# galactic, equatorial -> ecliptic, ecliptic -> galactic "as in HEALPix"), converted to quaternions
+# the way libtoast does (toast_math_qarray.cpp:957-991).
+_COORD_MATRICES = {
+    "C2G": (-0.054875539726, -0.873437108010, -0.483834985808, 0.494109453312, -0.444829589425, 0.746982251810,
+            -0.867666135858, -0.198076386122, 0.455983795705),
+    "C2E": (1.0, 0.0, 0.0, 0.0, 0.917482062069182, 0.397777155931914, 0.0, -0.397777155931914, 0.917482062069182),
+    "E2G": (-0.054882486, -0.993821033, -0.096476249, 0.494116468, -0.110993846, 0.862281440, -0.867661702,
+            -0.000346354, 0.497154957),
+}
+
+
+def _quat_from_rotmat(m):
+    tr = m[0] + m[4] + m[8]
+    if tr > 0:
+        s = np.sqrt(tr + 1.0) * 2.0
+        q = [(m[7] - m[5]) / s, (m[2] - m[6]) / s, (m[3] - m[1]) / s, 0.25 * s]
+    elif m[0] > m[4] and m[0] > m[8]:
+        s = np.sqrt(1.0 + m[0] - m[4] - m[8]) * 2.0
+        q = [0.25 * s, (m[1] + m[3]) / s, (m[2] + m[6]) / s, (m[7] - m[5]) / s]
+    elif m[4] > m[8]:
+        s = np.sqrt(1.0 + m[4] - m[0] - m[8]) * 2.0
+        q = [(m[1] + m[3]) / s, 0.25 * s, (m[5] + m[7]) / s, (m[2] - m[6]) / s]
+    else:
+        s = np.sqrt(1.0 + m[8] - m[0] - m[4]) * 2.0
+        q = [(m[2] + m[6]) / s, (m[5] + m[7]) / s, 0.25 * s, (m[3] - m[1]) / s]
+    return np.array(q, dtype=np.float64)
+
+
+def coordinate_rotation(coord_in, coord_out):
+    """(quaternion, suffix) taking a boresight from ``coord_in`` to ``coord_out`` ('C', 'E', 'G'):
+    pointing_detector.py:120-154; (None, "") when there is nothing to do."""
+    if coord_in is None or coord_in == coord_out:
+        return None, ""
+    valid = ("C", "E", "G")
+    if coord_in not in valid or coord_out not in valid:
+        raise RuntimeError("coordinate systems must be one of 'C', 'E', 'G'")
+    key = f"{coord_in}2{coord_out}"
+    if key in _COORD_MATRICES:
+        return _quat_from_rotmat(_COORD_MATRICES[key]), "_" + key
+    inverse = _quat_from_rotmat(_COORD_MATRICES[f"{coord_out}2{coord_in}"])
+    return inverse * np.array([-1.0, -1.0, -1.0, 1.0]), "_" + key   # qa.inv of a unit quaternion
+
+
 class PointingDetectorSimple(Operator):
     """Boresight pointing x focalplane offsets -> detector quaternions."""
 
@@ -61,15 +105,29 @@ class PointingDetectorSimple(Operator):
         boresight; ``NotImplementedError`` on accelerators); here the deflected boresight, one
         quaternion per time sample, is built once and then used like any boresight, resident on
         the device."""
-        if self.hwp_deflection_radius is None or self.hwp_deflection_radius == 0:
-            return self.boresight
-        if self.hwp_angle is None or self.hwp_angle not in ob.shared:
-            raise RuntimeError("hwp_deflection_radius needs the hwp_angle shared key")
         from .. import synth
 
-        key = f"{self.boresight}_deflected"
+        base = self.boresight
+        coord_rot, suffix = coordinate_rotation(self.coord_in, self.coord_out)
+        if coord_rot is not None:
+            # the boresight in the output frame is computed once and kept: it is re-used by every
+            # iteration of the amplitude solver (pointing_detector.py:156-175)
+            base = f"{self.boresight}{suffix}"
+            src = ob.shared[self.boresight].data
+            if base not in ob.shared or getattr(ob.shared[base], "_coord_src", None) != id(src):
+                if base in ob.shared:
+                    if ob.shared[base].accel_exists():
+                        ob.shared[base].accel_delete()
+                    del ob.shared[base]
+                ob.shared.create(base, np.ascontiguousarray(synth.quat_mult(coord_rot, src)))
+                ob.shared[base]._coord_src = id(src)
+        if self.hwp_deflection_radius is None or self.hwp_deflection_radius == 0:
+            return base
+        if self.hwp_angle is None or self.hwp_angle not in ob.shared:
+            raise RuntimeError("hwp_deflection_radius needs the hwp_angle shared key")
+        key = f"{base}_deflected"
         hwp = ob.shared[self.hwp_angle]
-        sig = (float(self.hwp_deflection_radius), float(self.hwp_angle_offset), id(hwp.data), id(ob.shared[self.boresight].data))
+        sig = (float(self.hwp_deflection_radius), float(self.hwp_angle_offset), id(hwp.data), id(ob.shared[base].data))
         if key in ob.shared and getattr(ob.shared[key], "_deflection_sig", None) == sig:
             return key
         orientation = np.array(hwp.data, dtype=np.float64) + self.hwp_angle_offset + np.pi / 2
@@ -82,7 +140,7 @@ class PointingDetectorSimple(Operator):
             if ob.shared[key].accel_exists():
                 ob.shared[key].accel_delete()
             del ob.shared[key]
-        ob.shared.create(key, np.ascontiguousarray(synth.quat_mult(ob.shared[self.boresight].data, deflection)))
+        ob.shared.create(key, np.ascontiguousarray(synth.quat_mult(ob.shared[base].data, deflection)))
         ob.shared[key]._deflection_sig = sig
         return key
 
@@ -90,8 +148,6 @@ class PointingDetectorSimple(Operator):
         implementation, use_accel = self.select_kernels(use_accel=use_accel)
         if (self.coord_in is None) != (self.coord_out is None):
             raise RuntimeError("Input and output coordinate systems should both be None or valid")
-        if self.coord_in is not None and self.coord_in != self.coord_out:
-            raise NotImplementedError("coordinate rotation of the boresight is outside the hot path")
         for ob in data.obs:
             _shared_to(ob, self.effective_boresight(ob), use_accel)
             if self.shared_flags is not None:
@@ -143,8 +199,9 @@ def otf_supported(pixels_op, weights_op):
         return False
     wp = weights_op.detector_pointing
     same = all(getattr(dp, t) == getattr(wp, t) for t in ("boresight", "shared_flags", "shared_flag_mask", "view",
-                                                          "hwp_angle", "hwp_angle_offset", "hwp_deflection_radius"))
-    if not same or (dp.coord_in is not None and dp.coord_in != dp.coord_out):
+                                                          "hwp_angle", "hwp_angle_offset", "hwp_deflection_radius",
+                                                          "coord_in", "coord_out"))
+    if not same:
         return False
     if weights_op.single_precision or weights_op.mode not in ("I", "IQU"):
         return False
@@ -215,8 +272,6 @@ def _skip_quaternions(op, data, detectors, use_accel):
     detector pointing, and no detector quaternions lying around that we would be expected to use."""
     dp = op.detector_pointing
     if not (use_accel and op.skip_quaternions and isinstance(dp, PointingDetectorSimple)):
-        return False
-    if dp.coord_in is not None and dp.coord_in != dp.coord_out:
         return False
     for ob in data.obs:
         if dp.quats in ob.detdata:
