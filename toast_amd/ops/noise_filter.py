@@ -37,6 +37,7 @@ class NoiseFilter(Operator):
     """Apply the inverse noise covariance to the signal in the Fourier domain."""
 
     API = Int(0, help="Internal interface version for this operator")
+    times = Unicode(defaults.times, help="Observation shared key for timestamps")
     det_data = Unicode(defaults.det_data, help="Observation detdata key for the timestream data")
     det_mask = Int(defaults.det_mask_invalid, help="Bit mask value for per-detector flagging")
     det_flags = Unicode(None, allow_none=True, help="Observation detdata key for flags to use")
@@ -46,6 +47,7 @@ class NoiseFilter(Operator):
     noise_model = Unicode("noise_model", help="Observation key containing the noise model")
     white_noise_min = Float(None, allow_none=True, help="Minimum frequency of the white noise plateau [Hz]")
     white_noise_max = Float(None, allow_none=True, help="Maximum frequency of the white noise plateau [Hz]")
+    debug = Unicode(None, allow_none=True, help="Path to directory for generating debug plots (not produced here)")
 
     def _exec(self, data, detectors=None, use_accel=None, **kwargs):
         if self.white_noise_max is not None and self.white_noise_min is None:

@@ -50,6 +50,7 @@ class Pipeline(Operator):
     operators supporting it, required objects are created/updated on the device before each
     operator and outputs are copied back and freed at finalize (pipeline.py:208-303)."""
 
+    API = Int(0, help="Internal interface version for this operator")
     operators = List([], help="List of Operator instances to run.")
     detector_sets = List(["ALL"], help="List of detector sets: 'ALL', 'SINGLE', 'BATCH' or lists of names")
     batch_size = Int(64, help="Detectors per pass for detector_sets=['BATCH'] (not a reference trait)")
