@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <list>
 #include <mutex>
+#include <vector>
 
 namespace toast_hip {
 
@@ -146,7 +147,48 @@ size_t pin_threshold() {
     return v;
 }
 
+// Released blocks of at least 64 MB are kept for the next create of exactly that size instead of
+// going back to the driver: the map-maker allocates and frees the same multi-GB temporaries in
+// every phase (temp_RHS, the ApplyAmplitudes timestream, per-batch quaternions), and hipMalloc costs
+// up to ~27 ms per GB on some boxes (0.3 ms on others).  TOAST_HIP_ALLOC_CACHE_MB caps the bytes
+// held (default 32768, 0 disables); the cache is emptied when an allocation fails and on clear().
+void * Manager::take_cached(size_t nbytes) {
+    for (size_t i = 0; i < free_blocks_.size(); ++i) {
+        if (free_blocks_[i].second == nbytes) {
+            void * p = free_blocks_[i].first;
+            free_blocks_.erase(free_blocks_.begin() + (long)i);
+            cached_bytes_ -= nbytes;
+            return p;
+        }
+    }
+    return nullptr;
+}
+
+bool Manager::keep_cached(void * dev, size_t nbytes) {
+    static const size_t cap = [] {
+        const char * s = std::getenv("TOAST_HIP_ALLOC_CACHE_MB");
+        return (size_t)((s != nullptr) ? std::atol(s) : 32768) << 20;
+    }();
+    if (nbytes < ((size_t)64 << 20) || cap == 0) return false;
+    while (!free_blocks_.empty() && cached_bytes_ + nbytes > cap) {   // oldest first
+        (void)hipFree(free_blocks_.front().first);
+        cached_bytes_ -= free_blocks_.front().second;
+        free_blocks_.erase(free_blocks_.begin());
+    }
+    if (cached_bytes_ + nbytes > cap) return false;
+    free_blocks_.emplace_back(dev, nbytes);
+    cached_bytes_ += nbytes;
+    return true;
+}
+
+void Manager::flush_cached() {
+    for (auto & b : free_blocks_) (void)hipFree(b.first);
+    free_blocks_.clear();
+    cached_bytes_ = 0;
+}
+
 void Manager::clear() {
+    flush_cached();
     for (auto & kv : table_) {
         if (kv.second.host_registered) (void)hipHostUnregister(const_cast<void *>(kv.first));
         if (kv.second.owned) (void)hipFree(kv.second.dev);
@@ -251,7 +293,20 @@ void * Manager::create(const void * host, size_t nbytes, const char * name) {
         return (s != nullptr && std::atol(s) > 0) ? (size_t)std::atol(s) << 20 : (size_t)0;
     }();
     hipError_t e = hipErrorOutOfMemory;
-    if (limit == 0 || owned_bytes_ + nbytes <= limit) e = hipMalloc(&dev, nbytes ? nbytes : 16);
+    if (limit == 0 || owned_bytes_ + nbytes <= limit) {
+        dev = take_cached(nbytes);
+        if (dev != nullptr) {
+            e = hipSuccess;
+        } else {
+            e = hipMalloc(&dev, nbytes ? nbytes : 16);
+            if ((e != hipSuccess || dev == nullptr) && !free_blocks_.empty()) {
+                // the cache of released blocks is holding the memory: give it back and retry
+                (void)hipGetLastError();
+                flush_cached();
+                e = hipMalloc(&dev, nbytes ? nbytes : 16);
+            }
+        }
+    }
     if (e != hipSuccess || dev == nullptr) {
         (void)hipGetLastError();
         std::ostringstream o;
@@ -349,7 +404,7 @@ void Manager::remove(const void * host, size_t nbytes, const char * name) {
     TH_HIP(hipStreamSynchronize(stream_));
     if (e.host_registered) (void)hipHostUnregister(const_cast<void *>(host));
     if (e.owned) {
-        TH_HIP(hipFree(e.dev));
+        if (!keep_cached(e.dev, e.nbytes)) TH_HIP(hipFree(e.dev));
         owned_bytes_ -= (e.nbytes <= owned_bytes_) ? e.nbytes : owned_bytes_;
     }
     trace("delete", e.name, nbytes, t0);

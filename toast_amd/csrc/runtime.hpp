@@ -125,6 +125,11 @@ private:
         bool pin_failed = false;
     };
     void pin_for_transfer(const void * host, Entry & e);
+    void * take_cached(size_t nbytes);
+    bool keep_cached(void * dev, size_t nbytes);
+    void flush_cached();
+    std::vector<std::pair<void *, size_t>> free_blocks_;   // released device blocks kept for reuse
+    size_t cached_bytes_ = 0;
     static double trace_begin();
     static void trace(const char * what, const std::string & name, size_t nbytes, double t0);
     Entry & lookup(const void * host, size_t nbytes, const char * name, const char * what);
