@@ -33,6 +33,27 @@ def estimate_net(freqs, data):
     return float(np.sqrt(val))
 
 
+def estimate_net_stack(freqs, psds):
+    """``estimate_net`` for a stack of PSDs on one frequency grid: one least-squares fit for all
+    detectors (np.polyfit takes the right-hand sides as columns)."""
+    psds = np.asarray(psds, dtype=np.float64)
+    n_psd = psds.shape[1]
+    offset = int(0.8 * n_psd)
+    deg = 2
+    if n_psd - offset < 10:
+        deg = 1
+        if n_psd < 10:
+            offset = 0
+    x = np.asarray(freqs[offset:], dtype=np.float64)
+    y = psds[:, offset:]
+    if x.size < deg + 1:
+        return np.sqrt(np.mean(y, axis=1))
+    coef = np.polyfit(x - x[-1], y.T, deg)
+    val = coef[-1]
+    val = np.where(val <= 0, np.mean(y, axis=1), val)
+    return np.sqrt(val)
+
+
 class NoiseFilter(Operator):
     """Apply the inverse noise covariance to the signal in the Fourier domain."""
 
@@ -80,30 +101,22 @@ class NoiseFilter(Operator):
                     for detflag in flags:
                         detflag |= shflg
                 flag_mask = self.det_flag_mask
-            # N_tt'^-1 kernels (noise_filter.py:130-171)
+            # N_tt'^-1 kernels (noise_filter.py:130-171), all detectors at once
             nse = obs[self.noise_model]
-            kernels = []
-            kern_freq = None
-            for d in dets:
+            kern_freq = np.asarray(nse.freq(dets[0]), dtype=np.float64)
+            for d in dets[1:]:
                 freq = np.asarray(nse.freq(d), dtype=np.float64)
-                if kern_freq is None:
-                    kern_freq = freq
-                elif not np.allclose(kern_freq, freq):
+                if freq.shape != kern_freq.shape or not np.allclose(kern_freq, freq):
                     raise RuntimeError("All detectors in the noise model must have the same frequency binning")
-                psd = np.array(nse.psd(d), dtype=np.float64)
-                if self.white_noise_max is None:
-                    net = estimate_net(freq, psd)
-                else:
-                    plateau = np.logical_and(freq > self.white_noise_min, freq < self.white_noise_max)
-                    net = np.sqrt(np.mean(psd[plateau]))
-                net_sq = net**2
-                psd_limit = 1.0e-3 * net_sq
-                psd[psd < psd_limit] = psd_limit
-                psd[:] = 1 / psd
-                psd *= net_sq
-                psd[0] = 0
-                kernels.append(psd)
-            kernels = np.array(kernels)
+            psds = np.array([np.asarray(nse.psd(d), dtype=np.float64) for d in dets])
+            if self.white_noise_max is None:
+                net = estimate_net_stack(kern_freq, psds)
+            else:
+                plateau = np.logical_and(kern_freq > self.white_noise_min, kern_freq < self.white_noise_max)
+                net = np.sqrt(np.mean(psds[:, plateau], axis=1))
+            net_sq = net**2
+            kernels = net_sq[:, None] / np.maximum(psds, 1.0e-3 * net_sq[:, None])
+            kernels[:, 0] = 0
             idx = dd.indices(dets)
             extend = np.zeros(len(dets), dtype=np.int32)
             n_samp = dd.shape[1]
