@@ -463,6 +463,76 @@ __global__ __launch_bounds__(kThreads) void k_build_cov(
     }
 }
 
+// Inverse covariance with the detector-pair merged scatter (see k_build_noise_weighted_pair): the
+// A / B detectors of a focalplane pixel look at the same sky pixel, so their packed products are
+// summed before the run reduction and share one set of atomics.
+template <int NNZ>
+__global__ __launch_bounds__(kThreads) void k_build_cov_pair(
+    const Chunk * __restrict__ chunks, int n_chunks, int n_det, const int32_t * __restrict__ p_idx,
+    const int32_t * __restrict__ w_idx, const int32_t * __restrict__ f_idx,
+    const double * __restrict__ det_scale, const int64_t * __restrict__ g2l,
+    double * __restrict__ invcov, const int64_t * __restrict__ pixels,
+    const double * __restrict__ weights, const uint8_t * __restrict__ dflags, uint8_t dmask,
+    int use_dflags, const uint8_t * __restrict__ sflags, uint8_t smask, int use_sflags,
+    FastDiv nps_div, int64_t n_samp) {
+    constexpr int NV = NNZ * (NNZ + 1) / 2;
+    const int det0 = 2 * blockIdx.x;
+    const bool two = det0 + 1 < n_det;
+    const int det1 = two ? det0 + 1 : det0;
+    const int64_t * prow[2] = {pixels + (int64_t)p_idx[det0] * n_samp, pixels + (int64_t)p_idx[det1] * n_samp};
+    const double * wrow[2] = {weights + (int64_t)w_idx[det0] * n_samp * NNZ,
+                              weights + (int64_t)w_idx[det1] * n_samp * NNZ};
+    const uint8_t * frow[2] = {use_dflags ? dflags + (int64_t)f_idx[det0] * n_samp : nullptr,
+                               use_dflags ? dflags + (int64_t)f_idx[det1] * n_samp : nullptr};
+    const double ds[2] = {det_scale[det0], det_scale[det1]};
+    const int64_t nps = nps_div.d;
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        for (int base = 0; base < c.count; base += kThreads) {
+            const int i = base + threadIdx.x;
+            const bool active = i < c.count;
+            const int64_t s = c.first + (active ? i : 0);
+            int64_t key[2] = {-1, -1};
+            double v[2][NV];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+#pragma unroll
+                for (int k = 0; k < NV; ++k) v[e][k] = 0.0;
+            }
+            if (active) {
+                int64_t p[2];
+                uint8_t fd[2];
+                double wk[2][NNZ];
+                const uint8_t fs = use_sflags ? sflags[s] : (uint8_t)0;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    p[e] = prow[e][s];
+                    fd[e] = use_dflags ? frow[e][s] : (uint8_t)0;
+                    const double * w = wrow[e] + NNZ * s;
+#pragma unroll
+                    for (int k = 0; k < NNZ; ++k) wk[e][k] = w[k];
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const bool good = (p[e] >= 0) & ((fd[e] & dmask) == 0) & ((fs & smask) == 0) & (e == 0 || two);
+                    if (good) {
+                        const int64_t gsm = fastdiv(p[e], nps_div);
+                        key[e] = g2l[gsm] * nps + (p[e] - gsm * nps);
+                        int off = 0;
+#pragma unroll
+                        for (int j = 0; j < NNZ; ++j) {
+                            const double sw = wk[e][j] * ds[e];
+#pragma unroll
+                            for (int k = j; k < NNZ; ++k, ++off) v[e][off] = wk[e][k] * sw;
+                        }
+                    }
+                }
+            }
+            scatter_runs<NV, 2>(key, v, invcov);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // Per-pixel inversion of the packed symmetric covariance through its eigen-decomposition
 // (cov_eigendecompose_diag, src/libtoast/src/toast_map_cov.cpp:246-396): rcond = emin/emax;
@@ -1533,6 +1603,13 @@ int toast_hip_build_cov_dev(
         det_flag_mask, use_d, d_shared_flags, shared_flag_mask, use_s, dv, n_samp
         if (mode == 0) {
             hipLaunchKernelGGL((k_build_cov<1, 0>), grid, dim3(kThreads), 0, st, TH_COV_ARGS);
+        } else if (nnz == 3 && pair_detectors() && n_det >= 2) {
+            const dim3 gp((unsigned)((n_det + 1) / 2), grid.y, 1);
+            hipLaunchKernelGGL(k_build_cov_pair<3>, gp, dim3(kThreads), 0, st, (const Chunk *)(d + o_ch), (int)chunks.size(),
+                               (int)n_det, (const int32_t *)(d + o_pi), (const int32_t *)(d + o_wi),
+                               (const int32_t *)(d + o_fi), (const double *)(d + o_ds), d_g2l, (double *)d_out, d_pixels,
+                               d_weights, d_det_flags, det_flag_mask, use_d, d_shared_flags, shared_flag_mask, use_s, dv,
+                               n_samp);
         } else if (nnz == 3) {
             hipLaunchKernelGGL((k_build_cov<3, 1>), grid, dim3(kThreads), 0, st, TH_COV_ARGS);
         } else if (nnz == 2) {
