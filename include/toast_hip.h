@@ -424,8 +424,8 @@ int toast_hip_template_offset_apply_diag_precond_dev(
  * then out = 0 where the amplitude is flagged.  accumulate != 0 is `_add_prior`
  * (offset.py:918-943), accumulate == 0 the Toeplitz preconditioner of precond_width <= 1
  * (offset.py:981-989).  in and out must differ.  max_segment_len / max_filter_len (host values:
- * the longest segment and filter) select the launch geometry -- filters longer than 512 taps take
- * an LDS-tiled kernel.
+ * the longest segment and filter) select the launch geometry -- filters longer than 32 taps take
+ * an LDS-tiled, register-blocked kernel.
  *
  * toast_hip_template_offset_banded_solve_dev: out = cho_solve_banded((factor, lower=True), in)
  * per segment (offset.py:990-1001), out = 0 where flagged.  The factor of segment s, band width

@@ -40,7 +40,7 @@ def dev_arrays(**arrs):
 
 
 @pytest.mark.parametrize("accumulate", [False, True])
-@pytest.mark.parametrize("long_filters", [False, True])
+@pytest.mark.parametrize("long_filters", [False, True, None])
 def test_convolve_kernel_vs_scipy(accumulate, long_filters):
     import torch
 
@@ -52,6 +52,10 @@ def test_convolve_kernel_vs_scipy(accumulate, long_filters):
         # than their segment, tap counts that are not multiples of the 256-tap window or of 4)
         seg_len = [1, 5, 1023, 1024, 1025, 3600, 0, 2500, 130]
         filt_len = [3, 4097, 87, 8191, 1, 2051, 3, 513, 257]
+    elif long_filters is None:
+        # at most 32 taps everywhere: the one-thread-per-amplitude kernel
+        seg_len = [1, 2, 5, 63, 64, 65, 300, 1000, 7, 0, 129]
+        filt_len = [3, 9, 15, 31, 1, 27, 5, 32, 5, 3, 17]
     else:
         seg_len = [1, 2, 5, 63, 64, 65, 300, 1000, 7, 0, 129]
         filt_len = [3, 9, 15, 87, 1, 131, 87, 511, 5, 3, 257]  # filters longer than their segment included

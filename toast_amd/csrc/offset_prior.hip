@@ -65,8 +65,8 @@ __global__ __launch_bounds__(kThreads) void k_offset_convolve(
     }
 }
 
-// The same convolution for LONG filters (the Toeplitz preconditioner of precond_width <= 1 is not
-// truncated much: 8191 taps for 3600 baselines).  One block per (segment, tile of 1024 outputs);
+// The same convolution for filters of more than 32 taps (the prior: 87 taps; the Toeplitz
+// preconditioner of precond_width <= 1 is not truncated much: 8191 taps for 3600 baselines).  One block per (segment, tile of 1024 outputs);
 // each thread owns 4 consecutive outputs and slides a 4-value window of the input through its
 // registers, so a tap costs one conflict-free LDS read (the window is stored with one pad slot per
 // 32 values) and one scalar load of the tap for 4 FMAs.
@@ -413,8 +413,8 @@ int toast_hip_template_offset_convolve_dev(int64_t n_amp, int64_t n_seg, const i
     return guarded([&] {
         if (n_amp <= 0 || n_seg <= 0) return;
         if (d_amp_in == d_amp_out) fail_arg("offset convolve: input and output amplitudes must differ");
-        if (max_filter_len > 512 && max_segment_len > 0) {
-            // long filters (Toeplitz preconditioner): LDS-tiled, register-blocked kernel
+        if (max_filter_len > 32 && max_segment_len > 0) {
+            // all but tiny filters: LDS-tiled, register-blocked kernel (87 taps: 0.037 vs 0.32 ms at cfg3)
             const dim3 grid((unsigned)((max_segment_len + kConvOut - 1) / kConvOut), (unsigned)n_seg);
             auto kern = accumulate ? k_offset_convolve_tiled<true> : k_offset_convolve_tiled<false>;
             hipLaunchKernelGGL(kern, grid, dim3(kThreads), 0, as_stream(stream), d_seg_start, d_filt_start, d_filt_len,
