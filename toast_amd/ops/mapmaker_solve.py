@@ -219,8 +219,8 @@ class SolverLHS(Operator):
     binning = Instance(klass=Operator, help="Binning operator for solving")
     template_matrix = Instance(klass=Operator, help="This must be an instance of a template matrix operator")
     out = Unicode(None, allow_none=True, help="Output Data key for resulting amplitudes")
-    fused = Bool(True, help="Use the fused device-resident kernels when every template is an Offset "
-                            "template without prior and the pointing is cached (full_pointing)")
+    fused = Bool(True, help="Use the fused device-resident kernels when the template is an Offset template "
+                            "(pointing cached, compact-cached or evaluated on the fly)")
 
     # -- fused path ---------------------------------------------------------------------------
     def _can_fuse(self, data):
