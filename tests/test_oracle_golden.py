@@ -155,3 +155,27 @@ def test_oracle_scan_map_dtypes_vs_live_reference(oracle, ref, map_dtype):
     a = cases.run_chain(ref, c, map_dtype=map_dtype, scan_scale=0.37, tail=(False,))
     b = cases.run_chain(oracle, c, map_dtype=map_dtype, scan_scale=0.37)
     assert np.array_equal(a["tod"], b["tod"])
+
+
+@pytest.mark.parametrize("nside", [1, 1 << 14, 1 << 20, 1 << 29])
+def test_oracle_pixels_on_boundaries_vs_live_reference(oracle, ref, nside):
+    """The pointings of tests/test_gpu_pixels_adversarial.py (|z| = 2/3, poles, face meridians within
+    0 .. 1e3 ulp) through the reference's own compiled kernel and the oracle: identical indices up
+    to the largest nside."""
+    from test_gpu_pixels_adversarial import boundary_pointings
+
+    q = boundary_pointings(np.random.default_rng(nside % 9973), n_each=1500)
+    n = q.shape[0]
+    quats = np.ascontiguousarray(q.reshape(1, n, 4))
+    iv = np.zeros(1, cases.interval_dtype)
+    iv["last"] = n
+    npix = 12 * nside * nside
+    nps = npix if nside < 16 else npix // 3072
+    idx, flags = np.zeros(1, np.int32), np.zeros(1, np.uint8)
+    for nest in (True, False):
+        a = np.full((1, n), -7, np.int64)
+        b = np.full((1, n), -9, np.int64)
+        ha, hb = np.zeros(npix // nps, np.uint8), np.zeros(npix // nps, np.uint8)
+        ref.pixels_healpix(idx, quats, flags, 0, idx, a, iv, ha, nps, nside, nest, False)
+        oracle.pixels_healpix(idx, quats, flags, 0, idx, b, iv, hb, nps, nside, nest)
+        assert np.array_equal(a, b) and np.array_equal(ha, hb)
