@@ -88,3 +88,34 @@ def test_boundary_pointings_bit_exact(hip, oracle, nside):
         assert nbad == 0, f"nside {nside} nest {nest}: {nbad} of {n} indices differ"
         assert got.min() >= 0 and got.max() < npix
         assert np.array_equal(hs_g, hs_w)
+
+
+@pytest.mark.parametrize("use_hwp", [False, True])
+def test_stokes_weights_on_boundaries(hip, oracle, use_hwp):
+    """Same boundary pointings plus exact and near poles through stokes_weights_IQU.  Wherever the
+    reference formulation is finite the weights agree to 1e-13; at pointings where rounding makes
+    1 - z^2 negative the reference's -sqrt(1 - z^2) is NaN (ops_stokes_weights.cpp:50-75) and so is
+    the oracle -- the device formulation (no square root, hpix_math.hpp stokes_cs2alpha) stays
+    finite there with the correct modulus eta * cal."""
+    rng = np.random.default_rng(3)
+    q = boundary_pointings(rng, n_each=2000)
+    th = np.concatenate([np.zeros(1000), np.full(1000, np.pi), rng.uniform(0, 1e-12, 1000),
+                         np.pi - rng.uniform(0, 1e-12, 1000)])
+    q = np.concatenate([q, quats_pointing_at(th, rng.uniform(0, 2 * np.pi, th.size), rng.uniform(0, 2 * np.pi, th.size))])
+    n = q.shape[0]
+    quats = np.ascontiguousarray(q.reshape(1, n, 4))
+    iv = np.zeros(1, cases.interval_dtype)
+    iv["last"] = n
+    idx = np.zeros(1, np.int32)
+    hwp = rng.uniform(0, 2 * np.pi, n) if use_hwp else np.zeros(1)
+    eps, gamma, cal = np.array([0.1]), np.array([0.3]), np.array([1.7])
+    got, want = np.zeros((1, n, 3)), np.zeros((1, n, 3))
+    hip.stokes_weights_IQU(idx, quats, idx, got, hwp, iv, eps, gamma, cal, False, False)
+    oracle.stokes_weights_IQU(idx, quats, idx, want, hwp, iv, eps, gamma, cal, False)
+    assert not np.any(np.isnan(got))
+    finite = ~np.isnan(want).any(axis=2)[0]
+    assert np.count_nonzero(finite) > 0.9 * n
+    assert np.max(np.abs(got[0][finite] - want[0][finite])) < 1e-13
+    eta = (1 - eps[0]) / (1 + eps[0])
+    assert np.array_equal(got[0, :, 0], np.full(n, cal[0]))
+    assert np.max(np.abs(np.hypot(got[0, :, 1], got[0, :, 2]) - eta * cal[0])) < 1e-13
