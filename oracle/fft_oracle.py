@@ -1,9 +1,13 @@
 """NumPy/SciPy restatement of the reference's FFT noise weighting (TEST INFRASTRUCTURE ONLY).
 
-Parity status: the `toast` Python package cannot be imported here (astropy, traitlets, ... are
-absent) and FFTW is absent, so this restatement is pinned by the reference's own test of the
-path -- the two-tone low-pass of src/toast/tests/fft.py:151-237 (|diff| < 0.2), re-run in
-tests/test_fft_oracle.py -- and follows the reference line by line:
+Parity status: PINNED.  The `toast` package cannot be imported here (astropy, traitlets, the
+compiled _libtoast are absent), but the reference's `AlgorithmBase` / `AlgorithmNumpy` classes
+(src/toast/fft.py:121-350) are pure NumPy / SciPy: tests/golden/make_golden_fft.py compiles exactly
+those class definitions from the reference file in place and runs them; this restatement
+reproduces their outputs bit for bit (tests/golden/fft_convolve.npz,
+tests/test_fft_oracle.py::test_oracle_matches_reference_convolve_fixture).  The reference's own
+test of the path -- the two-tone low-pass of src/toast/tests/fft.py:151-237 (|diff| < 0.2) -- is
+re-run as well.  Line by line:
 
 * convolve / AlgorithmNumpy   src/toast/fft.py:163-212, 252-350, 700-945
 * extend_flags                src/toast/utils.py:1055-1113

@@ -88,3 +88,21 @@ def test_noise_filter_kernel():
     k = fo.noise_filter_kernel(psd, net)
     assert k[0] == 0 and np.all(k[1:] > 0) and np.all(k <= 1000.0 + 1e-9)
     assert abs(k[-1] - 1.0) < 0.01  # white plateau -> unit response
+
+
+def test_oracle_matches_reference_convolve_fixture():
+    """tests/golden/fft_convolve.npz: outputs of the reference's own AlgorithmNumpy.convolve
+    (its class definitions compiled from src/toast/fft.py in place, tests/golden/make_golden_fft.py).
+    Same NumPy / SciPy calls in the same order: bit-identical."""
+    import os
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fft_convolve.npz"))
+    for name in ("a", "b", "c", "d"):
+        data = z[f"{name}_data"].copy()
+        deconv = bool(z[f"{name}_deconvolve"]) if f"{name}_deconvolve" in z.files else False
+        fo.algorithm_numpy(data, float(z[f"{name}_rate"]), z[f"{name}_kernel_freq"], z[f"{name}_kernels"], deconv)
+        assert np.array_equal(data, z[f"{name}_out"]), name
+        if f"{name}_n_fft" in z.files:
+            assert fo.fft_length(data.shape[1]) == int(z[f"{name}_n_fft"])
+            n_buffer = (int(z[f"{name}_n_fft"]) - data.shape[1]) // 2
+            assert np.array_equal(fo.apodization(min(n_buffer, data.shape[1])), z[f"{name}_apodize"])

@@ -126,3 +126,19 @@ def test_large_batch_chunking(pf):
     torch.cuda.synchronize()
     got = t.cpu().numpy()
     assert np.max(np.abs(got - want)) < TOL * np.max(np.abs(want))
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c", "d"])
+def test_rocfft_pipeline_vs_reference_convolve_fixture(pf, name):
+    """The rocFFT pipeline against the outputs of the reference's own AlgorithmNumpy.convolve
+    (tests/golden/fft_convolve.npz): complex per-detector kernels, deconvolution, a common real
+    kernel; 1e-12 of the signal scale."""
+    import os
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fft_convolve.npz"))
+    data = z[f"{name}_data"].copy()
+    deconv = bool(z[f"{name}_deconvolve"]) if f"{name}_deconvolve" in z.files else False
+    pf.convolve(data, float(z[f"{name}_rate"]), kernel_freq=z[f"{name}_kernel_freq"], kernels=z[f"{name}_kernels"],
+                deconvolve=deconv)
+    want = z[f"{name}_out"]
+    assert np.max(np.abs(data - want)) < TOL * np.max(np.abs(want))
