@@ -65,6 +65,31 @@ def main():
     result = data.copy()
     AlgorithmNumpy(2, n_samp, rate, None, None, kfreq, kern, None, False).convolve(result)
     out.update(d_rate=np.array(rate), d_kernel_freq=kfreq, d_kernels=kern, d_data=data, d_out=result)
+    # extend_flags (src/toast/utils.py:1055-1113, pure NumPy): the function definition compiled from
+    # the reference file in place, run on flag patterns covering every branch
+    utils = "/root/reference/src/toast/utils.py"
+    utree = ast.parse(open(utils).read(), utils)
+    fn = [n for n in utree.body if isinstance(n, ast.FunctionDef) and n.name == "extend_flags"]
+    umod = ast.Module(body=fn, type_ignores=[])
+    ast.fix_missing_locations(umod)
+    uns = {"np": np}
+    exec(compile(umod, utils, "exec"), uns)
+    patterns = {
+        "none": np.zeros(40, np.uint8),
+        "middle": np.array([0] * 10 + [1] * 3 + [0] * 12 + [3] * 2 + [0] * 13, np.uint8),
+        "start": np.array([1] * 4 + [0] * 20 + [1] * 2 + [0] * 14, np.uint8),
+        "end": np.array([0] * 25 + [1] * 15, np.uint8),
+        "both": np.array([1] * 3 + [0] * 30 + [1] * 7, np.uint8),
+        "only_start": np.array([1] * 9 + [0] * 31, np.uint8),
+        "other_bits": np.array([2] * 5 + [0] * 10 + [3] * 2 + [0] * 10 + [2] * 13, np.uint8),
+        "random": (rng.random(300) < 0.05).astype(np.uint8),
+    }
+    for pname, flags in patterns.items():
+        for buf in (0, 1, 4, 50):
+            got = flags.copy()
+            uns["extend_flags"](got, 1, buf)
+            out[f"ef_{pname}_{buf}"] = got
+        out[f"ef_{pname}_in"] = flags
     np.savez_compressed(os.path.join(HERE, "fft_convolve.npz"), **out)
     print("wrote fft_convolve.npz", {k: v.shape for k, v in out.items() if k.endswith("_out")})
 

@@ -106,3 +106,23 @@ def test_oracle_matches_reference_convolve_fixture():
             assert fo.fft_length(data.shape[1]) == int(z[f"{name}_n_fft"])
             n_buffer = (int(z[f"{name}_n_fft"]) - data.shape[1]) // 2
             assert np.array_equal(fo.apodization(min(n_buffer, data.shape[1])), z[f"{name}_apodize"])
+
+
+def test_extend_flags_matches_reference_fixture():
+    """extend_flags outputs of the reference's own function (compiled from src/toast/utils.py in
+    place by tests/golden/make_golden_fft.py) for flag patterns covering every branch; the oracle
+    and the product's host helper (toast_amd.fft.extend_flags) both reproduce them exactly."""
+    import os
+
+    from toast_amd import fft as pf
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fft_convolve.npz"))
+    names = sorted({k[3:-3] for k in z.files if k.startswith("ef_") and k.endswith("_in")})
+    assert len(names) == 8
+    for pname in names:
+        for buf in (0, 1, 4, 50):
+            want = z[f"ef_{pname}_{buf}"]
+            for impl in (fo.extend_flags, pf.extend_flags):
+                got = z[f"ef_{pname}_in"].copy()
+                impl(got, 1, buf)
+                assert np.array_equal(got, want), (pname, buf, impl.__module__)
