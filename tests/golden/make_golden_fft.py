@@ -90,6 +90,25 @@ def main():
             uns["extend_flags"](got, 1, buf)
             out[f"ef_{pname}_{buf}"] = got
         out[f"ef_{pname}_in"] = flags
+    # estimate_net (src/toast/ops/noise_model.py:108-170, pure NumPy / SciPy): white-noise level from
+    # the high-frequency end of a PSD -- the normalisation of NoiseFilter's kernels
+    from scipy.optimize import curve_fit
+
+    nm = "/root/reference/src/toast/ops/noise_model.py"
+    ntree = ast.parse(open(nm).read(), nm)
+    fn = [n for n in ntree.body if isinstance(n, ast.FunctionDef) and n.name == "estimate_net"]
+    nmod = ast.Module(body=fn, type_ignores=[])
+    ast.fix_missing_locations(nmod)
+    nns = {"np": np, "curve_fit": curve_fit}
+    exec(compile(nmod, nm, "exec"), nns)
+    for iname, (n_freq, rate, fknee, alpha, net) in enumerate([(77, 200.0, 0.05, 1.0, 50e-6), (60, 10.0, 0.1, 1.5, 1.0),
+                                                             (300, 100.0, 1.0, 2.0, 3e-3), (12, 37.0, 0.5, 1.0, 2.0),
+                                                             (8, 20.0, 0.2, 1.0, 0.7)]):
+        f = np.geomspace(1e-5, rate / 2, n_freq)
+        psd = net ** 2 * (f ** alpha + fknee ** alpha) / (f ** alpha + 1e-5 ** alpha)
+        psd *= np.exp(0.02 * rng.standard_normal(n_freq))     # estimation noise
+        out[f"net{iname}_freq"], out[f"net{iname}_psd"] = f, psd
+        out[f"net{iname}_out"] = np.array(nns["estimate_net"](f, psd))
     np.savez_compressed(os.path.join(HERE, "fft_convolve.npz"), **out)
     print("wrote fft_convolve.npz", {k: v.shape for k, v in out.items() if k.endswith("_out")})
 

@@ -126,3 +126,20 @@ def test_extend_flags_matches_reference_fixture():
                 got = z[f"ef_{pname}_in"].copy()
                 impl(got, 1, buf)
                 assert np.array_equal(got, want), (pname, buf, impl.__module__)
+
+
+def test_estimate_net_matches_reference_fixture():
+    """NoiseFilter's white-noise estimate against outputs of the reference's own estimate_net
+    (src/toast/ops/noise_model.py:108-170, compiled in place by tests/golden/make_golden_fft.py):
+    log-log parabola / line fit to the last 20 % of the PSD.  The reference iterates (curve_fit,
+    tolerance 1.5e-8), the product solves the same least squares in closed form: 1e-6 relative."""
+    import os
+
+    from toast_amd.ops.noise_filter import estimate_net, estimate_net_stack
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fft_convolve.npz"))
+    for i in range(5):
+        f, psd, want = z[f"net{i}_freq"], z[f"net{i}_psd"], float(z[f"net{i}_out"])
+        assert abs(estimate_net(f, psd) / want - 1.0) < 1e-6
+        stack = estimate_net_stack(f, np.stack([psd, 4.0 * psd]))
+        assert abs(stack[0] / want - 1.0) < 1e-6 and abs(stack[1] / (2.0 * want) - 1.0) < 1e-6

@@ -10,48 +10,37 @@ from ..traits import Float, Int, Unicode
 from .operator import Operator
 
 
-def estimate_net(freqs, data):
-    """White-noise level from the high-frequency end of a PSD.  The reference fits a parabola
-    (or line) to the last 20 % of the spectrum with scipy curve_fit and evaluates it at the
-    last frequency (src/toast/ops/noise_model.py:108-170); here the same constrained
-    least-squares fit is done in closed form with numpy.polyfit."""
-    n_psd = len(data)
+def _fit_window(n_psd):
+    """First bin and polynomial degree of the high-frequency fit (noise_model.py:133-143)."""
     offset = int(0.8 * n_psd)
     deg = 2
     if n_psd - offset < 10:
         deg = 1
-        if n_psd < 10:
-            offset = 0
-    x = np.asarray(freqs[offset:], dtype=np.float64)
-    y = np.asarray(data[offset:], dtype=np.float64)
-    if x.size < deg + 1:
-        return float(np.sqrt(np.mean(y)))
-    coef = np.polyfit(x - x[-1], y, deg)
-    val = float(np.polyval(coef, 0.0))
-    if val <= 0:
-        val = float(np.mean(y))
-    return float(np.sqrt(val))
+        offset = 0 if n_psd < 10 else n_psd - 10
+    return offset, deg
 
 
 def estimate_net_stack(freqs, psds):
-    """``estimate_net`` for a stack of PSDs on one frequency grid: one least-squares fit for all
-    detectors (np.polyfit takes the right-hand sides as columns)."""
-    psds = np.asarray(psds, dtype=np.float64)
-    n_psd = psds.shape[1]
-    offset = int(0.8 * n_psd)
-    deg = 2
-    if n_psd - offset < 10:
-        deg = 1
-        if n_psd < 10:
-            offset = 0
-    x = np.asarray(freqs[offset:], dtype=np.float64)
-    y = psds[:, offset:]
+    """White-noise level of a stack of PSDs on one frequency grid: the reference fits, in log-log
+    space, a parabola (a line when fewer than 10 bins are available) to the last 20 % of the
+    spectrum and takes sqrt(exp(fit(last bin))) (src/toast/ops/noise_model.py:108-170, scipy
+    curve_fit).  Here the same least-squares problem is solved in closed form for all detectors at
+    once (np.polyfit with the PSDs as columns): it agrees with the reference's iterative fit to the
+    convergence tolerance of that fit (~1e-8 relative; tests/test_fft_oracle.py pins it against
+    outputs of the reference's own function)."""
+    psds = np.atleast_2d(np.asarray(psds, dtype=np.float64))
+    offset, deg = _fit_window(psds.shape[1])
+    x = np.log(np.asarray(freqs, dtype=np.float64)[offset:])
+    y = np.log(psds[:, offset:])
     if x.size < deg + 1:
-        return np.sqrt(np.mean(y, axis=1))
+        return np.sqrt(np.exp(np.mean(y, axis=1)))
     coef = np.polyfit(x - x[-1], y.T, deg)
-    val = coef[-1]
-    val = np.where(val <= 0, np.mean(y, axis=1), val)
-    return np.sqrt(val)
+    return np.sqrt(np.exp(coef[-1]))
+
+
+def estimate_net(freqs, data):
+    """``estimate_net_stack`` for one PSD."""
+    return float(estimate_net_stack(freqs, np.asarray(data, dtype=np.float64)[None, :])[0])
 
 
 class NoiseFilter(Operator):
