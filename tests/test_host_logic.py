@@ -201,3 +201,33 @@ def test_copy_and_delete_all_object_kinds():
     ops.Delete(meta=["calib2"], shared=["hwp2"], intervals=["scan2"], detdata=["sig2"], global_meta=["glob"]).apply(data)
     assert "calib2" not in ob and "hwp2" not in ob.shared and "scan2" not in ob.intervals
     assert "sig2" not in ob.detdata and "glob" not in data and "calib" in ob
+
+
+def test_noise_models_follow_the_reference():
+    """AnalyticNoise (noise_sim.py:60-143): white spectrum for fknee = 0, fknee < fmin rejected,
+    zero weight for NET = 0; generic Noise.detector_weight (noise.py:216-262): plateau from the top
+    of the band, or from [0.2, 0.4] x rate under a transfer-function roll-off, 0 for an all-zero PSD."""
+    import numpy as np
+    import pytest
+
+    from toast_amd.noise import AnalyticNoise, Noise
+
+    dets = ["a", "b", "c"]
+    an = AnalyticNoise(rate={d: 100.0 for d in dets}, fmin={d: 1e-5 for d in dets}, detectors=dets,
+                       fknee={"a": 0.1, "b": 0.0, "c": 0.1}, alpha={d: 1.0 for d in dets},
+                       NET={"a": 2.0, "b": 3.0, "c": 0.0})
+    assert np.array_equal(an.psd("b"), np.full(an.freq("b").size, 9.0))
+    f = an.freq("a")
+    assert f[0] == 1.0e-9 and f[-1] == 50.0 and np.allclose(f[1:-1] / f[:-2], 1.4)
+    assert np.allclose(an.psd("a"), (f + 0.1) / (f + 1e-5) * 4.0)
+    assert an.detector_weight("a") == 1.0 / 4.0 / 100.0 and an.detector_weight("c") == 0.0
+    with pytest.raises(RuntimeError):
+        AnalyticNoise(rate={"a": 10.0}, fmin={"a": 1e-2}, detectors=["a"], fknee={"a": 1e-3}, alpha={"a": 1.0}, NET={"a": 1.0})
+    freq = np.linspace(0.0, 50.0, 501)
+    flat = np.full(freq.size, 4.0)
+    rolled = flat * np.where(freq > 42.0, 0.1, 1.0)
+    nz = Noise(["flat", "rolled", "dead"], {"flat": freq, "rolled": freq, "dead": freq},
+               {"flat": flat, "rolled": rolled, "dead": np.zeros(freq.size)}, rate=100.0)
+    assert nz.detector_weight("flat") == 1.0 / 4.0 / 100.0
+    assert nz.detector_weight("rolled") == 1.0 / 4.0 / 100.0     # plateau, not the rolled-off end
+    assert nz.detector_weight("dead") == 0.0

@@ -5,8 +5,8 @@ import numpy as np
 
 
 class Noise:
-    """Generic PSD-based model.  ``detector_weight`` = 1 / (white level * rate) with the white
-    level = median PSD over [0.45, 0.5] x rate (reference: src/toast/noise.py:213-277)."""
+    """Generic PSD-based model (reference: src/toast/noise.py; no mixing matrix: one PSD per
+    detector)."""
 
     def __init__(self, detectors, freqs, psds, rate=None):
         self.detectors = list(detectors)
@@ -25,15 +25,29 @@ class Noise:
         return 2.0 * self._freqs[det][-1] if self._rate is None else self._rate
 
     def detector_weight(self, det):
+        """1 / (white-noise variance * rate), the white level measured as the reference does
+        (src/toast/noise.py:216-262): the median PSD over [0.45, 0.5] x rate, or over
+        [0.2, 0.4] x rate when the end of the spectrum lies below half of its middle
+        ([0.225, 0.275] x rate), i.e. a transfer-function roll-off; 0 for a detector whose mid-band
+        PSD is zero (flagged in the noise model)."""
         if det not in self._weights:
             f, p, rate = self._freqs[det], self._psds[det], self.rate(det)
-            first = np.searchsorted(f, rate * 0.45, side="left")
-            last = np.searchsorted(f, rate * 0.50, side="right")
-            if first == last:
-                first = max(0, first - 1)
-                last = min(f.size, last + 1)
-            noisevar = np.median(p[first:last])
-            self._weights[det] = 1.0 / (noisevar * rate)
+
+            def median_between(lo, hi):
+                first = np.searchsorted(f, rate * lo, side="left")
+                last = np.searchsorted(f, rate * hi, side="right")
+                if first == last:
+                    first = max(0, first - 1)
+                    last = min(f.size - 1, last + 1)
+                return np.median(p[first:last])
+
+            noisevar_mid = median_between(0.225, 0.275)
+            if noisevar_mid == 0:
+                self._weights[det] = 0.0
+            else:
+                noisevar_end = median_between(0.45, 0.50)
+                noisevar = median_between(0.2, 0.4) if noisevar_end / noisevar_mid < 0.5 else noisevar_end
+                self._weights[det] = 1.0 / noisevar / rate
         return self._weights[det]
 
 
@@ -57,10 +71,16 @@ class AnalyticNoise(Noise):
             tempfreq.append(nyq)
             f = np.array(tempfreq, dtype=np.float64)
             a = float(alpha[d])
-            ktemp = np.power(float(fknee[d]), a)
-            mtemp = np.power(float(fmin[d]), a)
-            temp = np.power(f, a)
-            psds[d] = (temp + ktemp) / (temp + mtemp) * self._net[d] ** 2
+            fk, fm = float(fknee[d]), float(fmin[d])
+            if fk > 0.0 and fk < fm:
+                raise RuntimeError("If knee frequency is non-zero, it must be greater than f_min")
+            if fk > 0.0:
+                ktemp = np.power(fk, a)
+                mtemp = np.power(fm, a)
+                temp = np.power(f, a)
+                psds[d] = (temp + ktemp) / (temp + mtemp) * self._net[d] ** 2
+            else:
+                psds[d] = np.ones_like(f) * self._net[d] ** 2   # white (noise_sim.py:109-111)
             freqs[d] = f
         super().__init__(detectors, freqs, psds)
 
@@ -71,4 +91,6 @@ class AnalyticNoise(Noise):
         return self._net[det]
 
     def detector_weight(self, det):
-        return 1.0 / (self._net[det] ** 2 * self._rate_d[det])
+        if self._net[det] == 0:
+            return 0.0   # noise_sim.py:138-140
+        return 1.0 / (self._net[det] ** 2) / self._rate_d[det]

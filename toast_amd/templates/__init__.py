@@ -337,7 +337,7 @@ class Offset(Template):
         super().__init__(**kwargs)
 
     def _step_length(self, stime, rate):
-        return int(stime * rate + 0.5)
+        return int(np.rint(stime * rate))   # offset.py:723-724 (round half to even)
 
     def _initialize(self, new_data):
         if self.use_noise_prior and self.noise_model is None:
