@@ -213,3 +213,26 @@ def test_operator_detrend_flags_and_resident_data():
         slope = np.polyfit(t[g], after[i][g], 1)[0]
         assert abs(slope) < 0.2
     assert set(gf.coefficients) == {ob.local_detectors[i] for i in (0, 2, 3)}
+
+
+def test_azimuth_from_boresight_azel():
+    """Without an azimuth key the azimuth comes from the Az/El boresight quaternions:
+    az = 2 pi - phi with phi in [0, 2 pi) (groundfilter.py:285-289, qa.to_iso_angles)."""
+    from toast_amd.synth import quat_mult, quat_rotation
+
+    data = create_ground_data(n_det=2, n_samp=4000, rate=20.0)
+    ob = data.obs[0]
+    az = np.array(ob.shared[defaults.azimuth].data)
+    el = np.radians(50.0)
+    # Az/El boresight: azimuth is measured the other way round from the ISO phi
+    q = quat_mult(quat_rotation(np.array([0.0, 0.0, 1.0]), -az), quat_rotation(np.array([0.0, 1.0, 0.0]), np.pi / 2 - el))
+    ob.shared.create(defaults.boresight_azel, np.ascontiguousarray(q))
+    gf = ops.GroundFilter(azimuth=None, name="gf")
+    got = gf._azimuth(ob)
+    assert np.max(np.abs(got - az)) < 1e-12 and got.min() > 0 and got.max() <= 2 * np.pi
+    # crossing the meridian: azimuths just below 2 pi and just above 0 stay in (0, 2 pi]
+    az2 = np.array([6.2, 6.28, 0.01, 0.1])
+    q2 = quat_mult(quat_rotation(np.array([0.0, 0.0, 1.0]), -az2), quat_rotation(np.array([0.0, 1.0, 0.0]), np.pi / 2 - el))
+    ob2 = create_ground_data(n_det=1, n_samp=4, rate=1.0).obs[0]
+    ob2.shared.create(defaults.boresight_azel, np.ascontiguousarray(q2))
+    assert np.max(np.abs(ops.GroundFilter(azimuth=None, name="g2")._azimuth(ob2) - az2)) < 1e-12

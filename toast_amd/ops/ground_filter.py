@@ -68,7 +68,9 @@ class GroundFilter(Operator):
             x, y, z, w = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
             dx = 2 * (x * z + w * y)
             dy = 2 * (y * z - w * x)
-            return 2 * np.pi - np.arctan2(dy, dx)
+            phi = np.arctan2(dy, dx)
+            phi[phi < 0] += 2 * np.pi        # qa.to_iso_angles: phi in [0, 2 pi) (toast_math_qarray.cpp:1184-1189)
+            return 2 * np.pi - phi
         raise RuntimeError("Failed to get boresight azimuth from TOD.  Perhaps it is not ground TOD?")
 
     def build_templates(self, obs):
