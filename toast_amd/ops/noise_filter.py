@@ -85,8 +85,9 @@ class NoiseFilter(Operator):
                     fdata.accel_update_host()
                 flags = [fdata[d] for d in dets]
                 if self.shared_flags is not None:
-                    shflg = self.det_flag_mask * np.array(
-                        obs.shared[self.shared_flags].data & self.shared_flag_mask != 0, dtype=np.uint8)
+                    # (the flag VALUE times the mask, as the reference writes it: noise_filter.py:121-124)
+                    shflg = (self.det_flag_mask * np.array(
+                        obs.shared[self.shared_flags].data & self.shared_flag_mask, dtype=np.uint8)).astype(np.uint8)
                     for detflag in flags:
                         detflag |= shflg
                 flag_mask = self.det_flag_mask
