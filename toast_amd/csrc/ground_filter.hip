@@ -79,7 +79,7 @@ __global__ __launch_bounds__(kThreads) void k_template_gram(
     const double * __restrict__ templates, int64_t n_template, int64_t n_samp, const uint8_t * __restrict__ shared_flags,
     uint8_t shared_mask, int64_t slice, double * __restrict__ gram) {
     __shared__ double scratch[4];
-    const int64_t pair = blockIdx.y;
+    const int64_t pair = blockIdx.x;   // (pairs can exceed the 65535 limit of grid.y with binned templates)
     // pair -> (r, c), r <= c
     int64_t r = 0, rem = pair;
     while (rem >= n_template - r) {
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kThreads) void k_template_gram(
         ++r;
     }
     const int64_t c = r + rem;
-    const int64_t i0 = (int64_t)blockIdx.x * slice;
+    const int64_t i0 = (int64_t)blockIdx.y * slice;
     const int64_t i1 = (i0 + slice < n_samp) ? i0 + slice : n_samp;
     const double * __restrict__ tr = templates + r * n_samp;
     const double * __restrict__ tc = templates + c * n_samp;
@@ -307,7 +307,7 @@ int toast_hip_template_fit_dev(const double * d_templates, int64_t n_template, i
         const int32_t * fidx = (const int32_t *)(dparam + o_fi);
         const int64_t n_pair = n_template * (n_template + 1) / 2;
         const int64_t gslice = 65536;
-        hipLaunchKernelGGL(k_template_gram, dim3((unsigned)((n_samp + gslice - 1) / gslice), (unsigned)n_pair), dim3(kThreads),
+        hipLaunchKernelGGL(k_template_gram, dim3((unsigned)n_pair, (unsigned)((n_samp + gslice - 1) / gslice)), dim3(kThreads),
                            0, st, d_templates, n_template, n_samp, d_shared_flags, shared_flag_mask, gslice, d_gram_common);
         check_launch();
         // template rows per pass x detectors per wave: 64 accumulators per lane either way
