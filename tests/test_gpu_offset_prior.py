@@ -365,3 +365,48 @@ def test_pattern_select_with_toeplitz_prior():
     assert np.count_nonzero(good) > 100
     assert np.array_equal(hits["map_total"][good], hits["map_A"][good] + hits["map_B"][good])
     assert hits["map_A"].sum() > 0 and hits["map_A"].sum() + hits["map_B"].sum() == hits["map_total"].sum()
+
+
+def test_many_short_segments():
+    """More (detector, observation, view) segments than one grid dimension holds (65535): the
+    tiled convolution, the factorisation and the solve index segments on grid.x."""
+    import torch
+
+    from toast_amd import capi
+
+    rng = np.random.default_rng(1)
+    n_seg, n, w = 70001, 8, 4
+    n_amp = n_seg * n
+    filt = np.exp(-np.abs(np.arange(41) - 20) / 3.0)
+    x = rng.standard_normal(n_amp)
+    seg_start = (np.arange(n_seg + 1) * n).astype(np.int64)
+    d = dev_arrays(seg_start=seg_start, zero=np.zeros(n_seg, dtype=np.int64), flen=np.full(n_seg, filt.size, dtype=np.int64),
+                   filt=filt, x=x, flags=np.zeros(n_amp, dtype=np.uint8), out=np.zeros(n_amp))
+    capi.dev.offset_convolve(n_amp, n_seg, d["seg_start"].data_ptr(), n, d["zero"].data_ptr(), d["flen"].data_ptr(),
+                             filt.size, d["filt"].data_ptr(), d["x"].data_ptr(), d["flags"].data_ptr(),
+                             d["out"].data_ptr(), False)
+    torch.cuda.synchronize()
+    got = d["out"].cpu().numpy().reshape(n_seg, n)
+    for s in (0, 1, 65535, 65536, n_seg - 1):
+        want = scipy.signal.convolve(x[s * n:(s + 1) * n], filt, mode="same", method="direct")
+        assert rel(got[s], want) < TOL
+    band = np.array([2.0, 0.5, 0.2, 0.1])
+    var = 1.0 / (1.0 + rng.random(n_amp))
+    e = dev_arrays(bw=np.full(n_seg, w, dtype=np.int32), bs=(np.arange(n_seg) * n * w).astype(np.int64), band=band,
+                   ones=np.ones(n_seg), var=var, fwd=np.zeros(n_amp * w), bwd=np.zeros(n_amp * w),
+                   status=np.full(n_seg, -1, dtype=np.int32), sol=np.zeros(n_amp))
+    capi.dev.offset_banded_cholesky(n_seg, d["seg_start"].data_ptr(), e["bw"].data_ptr(), w, e["bs"].data_ptr(),
+                                    d["zero"].data_ptr(), e["bw"].data_ptr(), e["band"].data_ptr(), e["ones"].data_ptr(),
+                                    e["var"].data_ptr(), e["fwd"].data_ptr(), e["bwd"].data_ptr(), e["status"].data_ptr())
+    capi.dev.offset_banded_solve(n_seg, d["seg_start"].data_ptr(), e["bw"].data_ptr(), w, e["bs"].data_ptr(),
+                                 e["fwd"].data_ptr(), e["bwd"].data_ptr(), d["x"].data_ptr(), d["flags"].data_ptr(),
+                                 e["sol"].data_ptr())
+    torch.cuda.synchronize()
+    assert int(e["status"].abs().max()) == 0
+    sol = e["sol"].cpu().numpy().reshape(n_seg, n)
+    for s in (0, 65535, 65536, n_seg - 1):
+        ab = np.zeros((w, n))
+        ab[0] = 1.0 / var[s * n:(s + 1) * n]
+        ab += band[:, None]
+        want = scipy.linalg.solveh_banded(ab, x[s * n:(s + 1) * n], lower=True)
+        assert rel(sol[s], want) < TOL

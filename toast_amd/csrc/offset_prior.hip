@@ -81,10 +81,10 @@ __global__ __launch_bounds__(kThreads) void k_offset_convolve_tiled(
     double * __restrict__ out) {
     constexpr int kWindow = kConvOut + kConvTaps - 1;
     __shared__ double win[kWindow + kWindow / 32 + 1];
-    const int64_t s = blockIdx.y;
+    const int64_t s = blockIdx.x;      // segments on grid.x: detectors x observations can exceed 65535
     const int64_t first = seg_start[s];
     const int64_t n = seg_start[s + 1] - first;
-    const int64_t j0 = (int64_t)blockIdx.x * kConvOut;
+    const int64_t j0 = (int64_t)blockIdx.y * kConvOut;
     if (j0 >= n) return;
     const int64_t len = filt_len[s];
     const int64_t c = (len - 1) >> 1;
@@ -415,7 +415,7 @@ int toast_hip_template_offset_convolve_dev(int64_t n_amp, int64_t n_seg, const i
         if (d_amp_in == d_amp_out) fail_arg("offset convolve: input and output amplitudes must differ");
         if (max_filter_len > 32 && max_segment_len > 0) {
             // all but tiny filters: LDS-tiled, register-blocked kernel (87 taps: 0.037 vs 0.32 ms at cfg3)
-            const dim3 grid((unsigned)((max_segment_len + kConvOut - 1) / kConvOut), (unsigned)n_seg);
+            const dim3 grid((unsigned)n_seg, (unsigned)((max_segment_len + kConvOut - 1) / kConvOut));
             auto kern = accumulate ? k_offset_convolve_tiled<true> : k_offset_convolve_tiled<false>;
             hipLaunchKernelGGL(kern, grid, dim3(kThreads), 0, as_stream(stream), d_seg_start, d_filt_start, d_filt_len,
                                d_filters, d_amp_in, d_amplitude_flags, d_amp_out);
