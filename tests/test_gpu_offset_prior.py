@@ -410,3 +410,49 @@ def test_many_short_segments():
         ab += band[:, None]
         want = scipy.linalg.solveh_banded(ab, x[s * n:(s + 1) * n], lower=True)
         assert rel(sol[s], want) < TOL
+
+
+def test_prior_with_two_observations_fused_equals_operator_sequence(oracle):
+    """Two observations: the amplitude blocks are ordered detector -> observation -> view
+    (offset.py:240-251) and so are the prior's segments; fused and operator-sequence LHS agree,
+    and the prior term equals the oracle's per-segment convolution."""
+    from oracle import offset_prior as OP
+
+    results = {}
+    for fused in (False, True):
+        data = create_satellite_data(n_det=4, n_obs=2, n_samp=4000, rate=10.0, fknee=0.1, net=2.0, flag_samples=True)
+        rng = np.random.default_rng(4)
+        for ob in data.obs:
+            ob.detdata[defaults.det_data].data[:] = rng.standard_normal(ob.detdata[defaults.det_data].data.shape)
+        dp = ops.PointingDetectorSimple()
+        pix = ops.PixelsHealpix(detector_pointing=dp, nside=16, nside_submap=4)
+        sw = ops.StokesWeights(detector_pointing=dp, mode="IQU", hwp_angle=defaults.hwp_angle)
+        ops.CovarianceAndHits(pixel_dist="dist", covariance="cov", pixel_pointing=pix, stokes_weights=sw,
+                              save_pointing=True).apply(data)
+        lhs_bin = ops.BinMap(pixel_dist="dist", covariance="cov", binned="lhs_bin", pixel_pointing=pix,
+                             stokes_weights=sw, full_pointing=True)
+        tmpl = Offset(step_time=8.0, noise_model=defaults.noise_model, name="baselines", good_fraction=0.2,
+                      use_noise_prior=True)
+        tmatrix = ops.TemplateMatrix(templates=[tmpl], amplitudes="amps_in", det_data="temp_LHS")
+        tmatrix.initialize(data)
+        n_amp_obs = (4000 + 79) // 80
+        assert tmpl._prior.seg_start.size - 1 == 4 * 2 and int(tmpl._prior.seg_start[-1]) == 8 * n_amp_obs
+        amps = tmpl.zeros()
+        amps.local[:] = np.random.default_rng(3).standard_normal(amps.n_local)
+        data["amps_in"] = AmplitudesMap(baselines=amps)
+        data["lhs_out"] = data["amps_in"].duplicate()
+        data["lhs_out"].reset()
+        lhs = ops.SolverLHS(binning=lhs_bin, template_matrix=tmatrix, out="lhs_out", fused=fused)
+        assert lhs._can_fuse(data) == fused
+        lhs.apply(data)
+        results[fused] = data["lhs_out"]["baselines"].local.copy()
+        if fused:
+            segs = [(int(a), int(b - a)) for a, b in zip(tmpl._prior.seg_start[:-1], tmpl._prior.seg_start[1:])]
+            prior_only = np.zeros(amps.n_local)
+            OP.add_prior(segs, tmpl._prior.filters, amps.local, amps.local_flags, prior_only)
+            got = np.zeros_like(prior_only)
+            out = tmpl.zeros()
+            tmpl.add_prior(amps, out)
+            assert rel(out.local, prior_only) < TOL
+    scale = np.max(np.abs(results[False]))
+    assert scale > 0 and np.max(np.abs(results[False] - results[True])) < TOL * scale
