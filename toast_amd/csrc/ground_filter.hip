@@ -179,6 +179,19 @@ __global__ __launch_bounds__(kThreads) void k_template_gram_flagged(
     const uint8_t * __restrict__ df = det_flags + (int64_t)flag_index[d] * n_samp;
     const int64_t n_pair = n_template * (n_template + 1) / 2;
     double * __restrict__ out = dgram + d * n_template * n_template;
+    // With at most 256 pairs (n_template <= 22) every thread owns one pair for the whole slice and
+    // issues its atomics once; otherwise once per 1024-sample sub-block.
+    const bool one_pair = n_pair <= kThreads;
+    int64_t my_r = 0, my_c = 0;
+    if (one_pair && threadIdx.x < n_pair) {
+        int64_t rem = threadIdx.x;
+        while (rem >= n_template - my_r) {
+            rem -= n_template - my_r;
+            ++my_r;
+        }
+        my_c = my_r + rem;
+    }
+    double slice_acc = 0.0;
     for (int64_t base = i0; base < i1; base += kQueue) {
         if (threadIdx.x == 0) n_queued = 0;
         __syncthreads();
@@ -193,24 +206,36 @@ __global__ __launch_bounds__(kThreads) void k_template_gram_flagged(
         const int nq = n_queued;
         if (nq > 0) {
             if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&n_flagged[d]), (unsigned long long)nq);
-            for (int64_t pair = threadIdx.x; pair < n_pair; pair += kThreads) {
-                int64_t r = 0, rem = pair;
-                while (rem >= n_template - r) {
-                    rem -= n_template - r;
-                    ++r;
+            if (one_pair) {
+                if (threadIdx.x < n_pair) {
+                    const double * __restrict__ tr = templates + my_r * n_samp + base;
+                    const double * __restrict__ tc = templates + my_c * n_samp + base;
+                    for (int q = 0; q < nq; ++q) slice_acc += tr[queue[q]] * tc[queue[q]];
                 }
-                const int64_t c = r + rem;
-                const double * __restrict__ tr = templates + r * n_samp + base;
-                const double * __restrict__ tc = templates + c * n_samp + base;
-                double acc = 0.0;
-                for (int q = 0; q < nq; ++q) acc += tr[queue[q]] * tc[queue[q]];
-                if (acc != 0.0) {
-                    atomicAdd(&out[r * n_template + c], acc);
-                    if (c != r) atomicAdd(&out[c * n_template + r], acc);
+            } else {
+                for (int64_t pair = threadIdx.x; pair < n_pair; pair += kThreads) {
+                    int64_t r = 0, rem = pair;
+                    while (rem >= n_template - r) {
+                        rem -= n_template - r;
+                        ++r;
+                    }
+                    const int64_t c = r + rem;
+                    const double * __restrict__ tr = templates + r * n_samp + base;
+                    const double * __restrict__ tc = templates + c * n_samp + base;
+                    double acc = 0.0;
+                    for (int q = 0; q < nq; ++q) acc += tr[queue[q]] * tc[queue[q]];
+                    if (acc != 0.0) {
+                        atomicAdd(&out[r * n_template + c], acc);
+                        if (c != r) atomicAdd(&out[c * n_template + r], acc);
+                    }
                 }
             }
         }
         __syncthreads();
+    }
+    if (one_pair && threadIdx.x < n_pair && slice_acc != 0.0) {
+        atomicAdd(&out[my_r * n_template + my_c], slice_acc);
+        if (my_c != my_r) atomicAdd(&out[my_c * n_template + my_r], slice_acc);
     }
 }
 
