@@ -116,9 +116,11 @@ __global__ __launch_bounds__(kThreads) void k_template_project(
     double * __restrict__ proj) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nt = (n_template - t0 < NTG) ? (int)(n_template - t0) : NTG;
-    const int64_t i0 = (int64_t)blockIdx.x * slice;
+    // detector groups on the fast grid index: blocks that run together share a slice, i.e. the
+    // same template rows (measured HBM traffic 2.94 -> 2.49 GB, profiles/r01_g_ground_filter_pmc.txt)
+    const int64_t i0 = (int64_t)blockIdx.y * slice;
     const int64_t i1 = (i0 + slice < n_samp) ? i0 + slice : n_samp;
-    const int64_t d0 = ((int64_t)blockIdx.y * 4 + wave) * DPW;
+    const int64_t d0 = ((int64_t)blockIdx.x * 4 + wave) * DPW;
     if (d0 >= n_det) return;
     const double * sig[DPW];
     const uint8_t * df[DPW];
@@ -338,7 +340,7 @@ int toast_hip_template_fit_dev(const double * d_templates, int64_t n_template, i
         // template rows per pass x detectors per wave: 64 accumulators per lane either way
         const int64_t pslice = 4096;
         auto project = [&](auto kernel, int ntg, int dpw) {
-            const dim3 pgrid((unsigned)((n_samp + pslice - 1) / pslice), (unsigned)((n_det + 4 * dpw - 1) / (4 * dpw)));
+            const dim3 pgrid((unsigned)((n_det + 4 * dpw - 1) / (4 * dpw)), (unsigned)((n_samp + pslice - 1) / pslice));
             for (int64_t t0 = 0; t0 < n_template; t0 += ntg) {
                 hipLaunchKernelGGL(kernel, pgrid, dim3(kThreads), 0, st, d_templates, n_template, t0, n_samp, sidx,
                                    d_signal, fidx, d_det_flags, det_flag_mask, d_shared_flags, shared_flag_mask, n_det,
