@@ -60,9 +60,16 @@ def parse():
     ap.add_argument("--cpu-dets", type=int, default=32, help="detectors in the CPU baseline sample")
     ap.add_argument("--pcg-extra", action="store_true",
                     help="also time the full PCG LHS with offset templates (operator sequence vs fused kernels)")
-    ap.add_argument("--no-arena", action="store_true", help="allocate every buffer separately (placement experiment)")
-    ap.add_argument("--no-probe", action="store_true",
-                    help="one arena in allocation order instead of probing HBM regions for the fastest placement")
+    ap.add_argument("--no-arena", action="store_true", help="accepted for compatibility; separate allocations are the default")
+    ap.add_argument("--probe", action="store_true",
+                    help="EXPERIMENT (not what operators get): over-allocate candidate buffers, time a stream on "
+                         "each and keep the fastest HBM regions (profiles/r01_b_tuning_experiments.txt section 14)")
+    ap.add_argument("--arena", action="store_true",
+                    help="EXPERIMENT: one arena carved in allocation order instead of one allocation per buffer")
+    ap.add_argument("--no-probe", action="store_true", help="accepted for compatibility; probing is off by default")
+    ap.add_argument("--no-fft", action="store_true", help="skip the FFT noise-weighting measurement")
+    ap.add_argument("--no-cfg4", action="store_true",
+                    help="with --gpus 8 and the default workload: do not also time the configs[3] shard (cfg4)")
     ap.add_argument("--hwp", action="store_true", help="rotating half-wave plate (88 rpm): Stokes weights with HWP angle")
     ap.add_argument("--unfused", action="store_true", help="run noise_weight as its own kernel (105 B variant)")
     return ap.parse_args()
@@ -72,8 +79,6 @@ def main():
     args = parse()
     import torch
     import torch.distributed as dist
-
-    from toast_amd import capi, synth
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -92,10 +97,33 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    out = run(args, args.workload, world, rank, dev, headline=True)
+    if world == 8 and args.workload == "cfg3" and not args.no_cfg4:
+        # BASELINE configs[3] (4096 detectors x 4 h @ 200 Hz over 8 GPUs): the default line above is the
+        # weak-scaling cfg3 shard (same per-GPU work at every N, which is what a scaling curve needs);
+        # the actual configs[3] shard (512 detectors x 2 880 000 samples per GPU) is timed here as well.
+        torch.cuda.empty_cache()
+        sub = run(args, "cfg4", world, rank, dev, headline=False)
+        if rank == 0:
+            out["configs3_shard"] = {k: sub[k] for k in ("value", "unit", "ms_per_step", "kernel_ms", "config",
+                                                         "allreduce", "roofline")}
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run(args, workload, world, rank, dev, headline=True):
+    """Time one workload; returns the JSON object (complete on rank 0)."""
+    import torch
+    import torch.distributed as dist
+
+    from toast_amd import capi, synth
+
     D = capi.dev
     stream = torch.cuda.current_stream().cuda_stream
 
-    n_det, n_samp, rate, nside = WORKLOADS[args.workload]
+    n_det, n_samp, rate, nside = WORKLOADS[workload]
     nnz = 3
     nps = 3072 if nside >= 16 else 12 * nside * nside
     n_submap = 12 * nside * nside // nps
@@ -105,7 +133,7 @@ def main():
     fp_all, gamma_all = synth.hex_focalplane(n_det * world, fov_deg=10.0)
     fp = np.ascontiguousarray(fp_all[rank * n_det : (rank + 1) * n_det])
     gamma = np.ascontiguousarray(gamma_all[rank * n_det : (rank + 1) * n_det])
-    if args.workload == "cfg5g":
+    if workload == "cfg5g":
         bore, ivl, sflags_h = synth.ground_scan(n_samp, rate)
     else:
         bore = synth.satellite_boresight(n_samp, rate, 600.0, 30.0, 3000.0, 65.0)
@@ -133,12 +161,13 @@ def main():
     nds = n_det * n_samp
     sizes = {"pixels": nds * 8, "weights": nds * 24, "tod": nds * 8, "tod2": nds * 8, "dflags": nds}
     placement = None
-    if args.no_arena:
-        arena = None
-    elif args.no_probe:
+    # Default: one allocation per buffer, which is what the product's memory manager does
+    # (toast_hip::Manager::create -> hipMalloc per registered array); operators get exactly this.
+    allocator = "one hipMalloc per buffer (same policy as toast_hip::Manager)"
+    arena = None
+    if args.arena and not args.probe:
         arena = torch.empty(sum(_align(v) for v in sizes.values()), dtype=torch.uint8, device=dev)
-    else:
-        arena = None
+        allocator = "experiment: one arena carved in allocation order"
     cursor = [0]
 
     def carve(name, dtype, shape):
@@ -149,7 +178,8 @@ def main():
         cursor[0] += _align(nb)
         return view
 
-    if arena is None and not args.no_arena:
+    if args.probe:
+        allocator = "experiment: HBM region probing (fastest of several candidate allocations)"
         # HBM region probing.  The same kernel runs up to 19 % slower on some multi-GB regions of
         # HBM than on others (5.05 vs 5.99 TB/s for a pure stream, stable for the lifetime of an
         # allocation: profiles/r01_b_tuning_experiments.txt section 14).  Allocate more candidate
@@ -270,7 +300,7 @@ def main():
     t_setup = time.time() - t_setup
 
     # ------------------------------------------------------------------ one step
-    ev = {k: [] for k in ("bnw", "cov", "scan")}
+    ev = {k: [] for k in ("bnw", "allreduce", "cov", "scan")}
 
     def step(record):
         d_zmap.zero_()
@@ -302,6 +332,7 @@ def main():
         if record:
             e[5].record()
             ev["bnw"].append((e[0], e[1]))
+            ev["allreduce"].append((e[1], e[2]))
             ev["cov"].append((e[2], e[3]))
             ev["scan"].append((e[4], e[5]))
 
@@ -338,7 +369,7 @@ def main():
     # command (profiles/traffic_<workload>.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes,
     # gfx950 FETCH correction calibrated in-run; profiles/README.md); null if not profiled.
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+    tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
     knames = {"build_noise_weighted": ("k_build_noise_weighted_pair<3>", "k_build_noise_weighted<3>"),
               "scan_map": ("k_scan_map<double, 3>",)}[dom]
     if os.path.isfile(tpath) and not args.unfused:
@@ -391,7 +422,7 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": args.workload,
+            "workload": workload,
             "detectors_per_gpu": n_det,
             "samples_per_detector": n_samp,
             "sample_rate_hz": rate,
@@ -413,8 +444,60 @@ def main():
             "from_boresight_weights_ms": t_sw_x,
         },
         "setup_s": t_setup,
+        "allocator": allocator,
         "placement": placement,
+        # per-step RCCL all-reduce of the device-resident zmap (fp64 sum over the detector shards);
+        # kernel_ms.allreduce is its stream time on this rank (includes waiting for the slowest rank)
+        "allreduce": {
+            "bytes": int(n_local) * nps * nnz * 8 if world > 1 else 0,
+            "ms": ms["allreduce"] if world > 1 else 0.0,
+            "backend": (dist.get_backend() if world > 1 else None),
+            "algorithm_GBs": (2.0 * (world - 1) / world * n_local * nps * nnz * 8 / (ms["allreduce"] * 1e-3) / 1e9
+                              if world > 1 and ms["allreduce"] > 0 else None),
+        },
     }
+
+    # ------------------------------------------------------------------ FFT noise weighting (SURVEY.md section 8d:
+    # "report separately"): ops.NoiseFilter's device call on the same timestream shape -- every detector
+    # row convolved with its own N_tt'^-1 = NET^2 / PSD(f) kernel (reference src/toast/ops/noise_filter.py:130-188
+    # -> toast.fft.convolve, src/toast/fft.py:252-350).  Not part of the PCG step; timed once per run.
+    if not args.no_fft:
+        from toast_amd import fft as hipfft
+        from toast_amd.noise import AnalyticNoise
+
+        nse = AnalyticNoise(rate={"d": rate}, fmin={"d": 1.0e-5}, detectors=["d"], fknee={"d": 0.05},
+                            alpha={"d": 1.0}, NET={"d": 50.0e-6})
+        kfreq = nse.freq("d")
+        psd = nse.psd("d")
+        net_sq = (50.0e-6) ** 2
+        kern = net_sq / np.maximum(psd, 1.0e-3 * net_sq)
+        kern[0] = 0.0
+        kernels = np.tile(kern, (n_det, 1)) * np.linspace(0.9, 1.1, n_det)[:, None]   # one kernel per detector
+        n_fft = hipfft.fft_length(n_samp)
+        fft_call = lambda: hipfft.convolve_dev(d_tod2.data_ptr(), idx, n_samp, rate, kfreq, kernels, stream=stream)
+        t_first = time.perf_counter()
+        fft_call()                      # plans, rocFFT kernel cache, scratch buffers
+        torch.cuda.synchronize()
+        t_first = time.perf_counter() - t_first
+        t_fft = timed(fft_call, 3)
+        tot = float(n_det) * n_samp
+        out["fft_noise_weight"] = {
+            "ms": t_fft,
+            "first_call_ms": 1e3 * t_first,
+            "samples_per_s": tot / (t_fft * 1e-3),
+            "n_fft": int(n_fft),
+            "implementation": hipfft.implementation() if hasattr(hipfft, "implementation") else "rocfft-5pass",
+            # compulsory traffic: read + write each timestream sample once
+            "hbm_GBs": 16.0 * tot / (t_fft * 1e-3) / 1e9,
+            "frac": 16.0 * tot / (t_fft * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            # what the passes of the pipeline move per timestream sample
+            "pipeline_bytes_per_sample": hipfft.pipeline_bytes_per_sample(n_samp)
+            if hasattr(hipfft, "pipeline_bytes_per_sample") else None,
+        }
+        pb = out["fft_noise_weight"]["pipeline_bytes_per_sample"]
+        if pb:
+            out["fft_noise_weight"]["pipeline_GBs"] = pb * tot / (t_fft * 1e-3) / 1e9
+            out["fft_noise_weight"]["pipeline_frac"] = pb * tot / (t_fft * 1e-3) / 1e9 / HBM_PEAK_GBS
 
     # ------------------------------------------------------------------ extra: full PCG LHS with offset templates
     # (not the headline metric) the complete SolverLHS of configs[2] "full MapMaker PCG":
@@ -559,7 +642,7 @@ def main():
         }
 
     # ------------------------------------------------------------------ CPU baseline (rank 0, N=1)
-    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+    if world == 1 and rank == 0 and headline and not args.no_cpu_baseline:
         import oracle
 
         nd = min(args.cpu_dets, n_det)
@@ -605,34 +688,36 @@ def main():
             ref = oracle.load_ref()
         except Exception:  # an unloadable .so must not take the bench down
             ref = None
-        t_port = time_cpu(make_step(oracle, ()), 10.0 if ref is None else 4.0)
         sample = ("%d of the %d detectors x %d samples of the same workload; build_noise_weighted + "
                   "scan_map(subtract) + noise_weight on the host path (cov_apply_diag excluded: map sized)"
                   % (nd, n_det, n_samp))
+        impl, tail, kind = (ref, (False,), "reference") if ref is not None else (oracle, (), "port")
+        n_all = oracle.num_threads()
+        # thread sweep (SURVEY.md section 8d asks for the all-core and the 1-thread number; the reference's
+        # build_noise_weighted host path lets every thread scan all samples -- T-fold redundant reads -- so
+        # more threads are not faster: report the whole curve and the best point)
+        sweep = {}
+        for nt in sorted({1, 8, 32, n_all} & set(range(1, n_all + 1))):
+            oracle.set_num_threads(nt)
+            sweep[nt] = nd * n_samp / time_cpu(make_step(impl, tail), 3.0 if nt > 1 else 6.0)
+        oracle.set_num_threads(n_all)
+        best = max(sweep, key=lambda k: sweep[k])
+        out["cpu_baseline"] = {
+            "value": sweep[n_all],
+            "unit": "det-samples/s",
+            "cores": n_all,
+            "kind": kind,
+            "sample": sample + ("; libtoast's own kernels compiled from the reference sources (use_accel=False)"
+                                if ref is not None else "; our restatement with the reference's host parallelisation"),
+            "one_thread": sweep.get(1),
+            "best_threads": {"threads": int(best), "value": sweep[best]},
+            "thread_sweep": {str(k): v for k, v in sweep.items()},
+        }
         if ref is not None:
-            t_ref = time_cpu(make_step(ref, (False,)), 8.0)
-            out["cpu_baseline"] = {
-                "value": nd * n_samp / t_ref,
-                "unit": "det-samples/s",
-                "cores": oracle.num_threads(),
-                "kind": "reference",
-                "sample": sample + "; libtoast's own kernels compiled from the reference sources (use_accel=False)",
-                "port_value": nd * n_samp / t_port,
-            }
-        else:
-            out["cpu_baseline"] = {
-                "value": nd * n_samp / t_port,
-                "unit": "det-samples/s",
-                "cores": oracle.num_threads(),
-                "kind": "port",
-                "sample": sample + "; our restatement with the reference's host parallelisation",
-            }
+            out["cpu_baseline"]["port_value"] = nd * n_samp / time_cpu(make_step(oracle, ()), 3.0)
         del cov_h
 
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":

@@ -272,6 +272,12 @@ def num_threads():
     return int(lib().oracle_num_threads())
 
 
+def set_num_threads(n):
+    """Set the OpenMP thread count of the restatement AND of oracle/_ref (one libgomp instance
+    per process serves both)."""
+    lib().oracle_set_num_threads(C.c_int(int(n)))
+
+
 def libm_atan2(y, x):
     y = np.ascontiguousarray(y, dtype=np.float64)
     x = np.ascontiguousarray(x, dtype=np.float64)

@@ -700,4 +700,14 @@ int oracle_num_threads(void) {
 #endif
 }
 
+// Thread count of the OpenMP runtime shared by this library and oracle/_ref (both link the same
+// libgomp instance in one process): used by bench.py's cpu_baseline thread sweep.
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 }  // extern "C"

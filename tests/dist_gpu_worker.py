@@ -45,7 +45,15 @@ def build(comm, first, n_det, full_pointing, prior=False):
 
 
 def main():
-    dist.init_process_group("gloo")
+    backend = os.environ.get("TOAST_TEST_BACKEND", "gloo")
+    if backend == "nccl":   # one process per GPU (tests/test_gpu_rccl.py, needs two GPUs)
+        import torch
+
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group("gloo")
     rank, size = dist.get_rank(), dist.get_world_size()
     assert size == 2
     accel_assign_device(size, rank, 1.0, False)

@@ -1,0 +1,162 @@
+"""GPU: the BASELINE.json configurations that the kernel-level full-size tests do not reach,
+at their full per-GPU sizes and through the reference's operator names.
+
+* configs[1]: 64 detectors x 1 h @ 100 Hz satellite scan, Nside 512, ``PixelsHealpix`` + ``BinMap``
+  (reference bars: src/toast/tests/ops_mapmaker_binning.py:27-127, ops_pixels_healpix.py) -- pixel
+  indices bit-exact against the CPU oracle on ALL 64 detectors, hit map == unflagged samples,
+  binned map < 1e-10 of the oracle's build_noise_weighted + cov_apply_diag;
+* configs[4], one GPU's share (256 of 2048 detectors x 720 000 samples of constant-elevation
+  scans, Nside 2048): ``GroundFilter`` -> ``MapMaker`` (baseline offsets, PCG) with hit totals,
+  the checksum of checksums of the noise-weighted map, map == C * noise-weighted map, pixel parity
+  at Nside 2048 on a detector subsample and a decreasing PCG residual.
+
+(configs[0] is tests/test_gpu_ops.py::test_workflow_sim_satellite_simple, configs[2] and the
+configs[3] shard are tests/test_gpu_fullsize.py.)"""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _workflow(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "workflows", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def _good_samples(ob, pixels, det_flags, shared_flags, view=None):
+    from toast_amd.data import defaults
+
+    inside = np.zeros(ob.n_local_samples, dtype=bool)
+    for iv in ob.intervals[view].data:
+        inside[int(iv["first"]):int(iv["last"])] = True
+    good = (pixels >= 0) & ((det_flags & defaults.det_mask_nonscience) == 0)
+    good &= (((shared_flags & defaults.shared_mask_nonscience) == 0) & inside)[None, :]
+    return good
+
+
+def test_configs1_pixels_healpix_and_binmap(oracle):
+    from toast_amd.data import defaults
+
+    wf = _workflow("sim_satellite_simple")
+    data = wf.main(["--ndet", "64", "--minutes", "60", "--rate", "100", "--nside", "512", "--full-pointing"])
+    ob = data.obs[0]
+    dist = data["pixel_dist"]
+    n_det, n_samp = len(ob.local_detectors), ob.n_local_samples
+    assert (n_det, n_samp) == (64, 360000)
+    assert dist.n_pix == 12 * 512 * 512
+    sf = ob.shared[defaults.shared_flags].data
+    ivl = ob.intervals[None].data
+    idx = np.arange(n_det, dtype=np.int32)
+    # -- pixels: every detector, bit for bit (oracle: boresight -> quaternions -> pixels)
+    fp = np.ascontiguousarray(np.array([ob.telescope.focalplane[d]["quat"] for d in ob.local_detectors]))
+    quats = np.zeros((n_det, n_samp, 4))
+    oracle.pointing_detector(fp, ob.shared[defaults.boresight_radec].data, idx, quats, ivl, sf,
+                             defaults.shared_mask_invalid)
+    want = np.full((n_det, n_samp), -7, dtype=np.int64)
+    hsub = np.zeros(dist.n_submap, dtype=np.uint8)
+    oracle.pixels_healpix(idx, quats, sf, defaults.shared_mask_invalid, idx, want, ivl, hsub, dist.n_pix_submap, 512,
+                          True)
+    del quats
+    got = ob.detdata[defaults.pixels].data
+    assert got.shape == want.shape
+    nbad = int(np.count_nonzero(got != want))
+    assert nbad == 0, f"{nbad} pixel mismatches in {want.size} samples"
+    assert np.array_equal(np.flatnonzero(hsub), dist.local_submaps)
+    # -- hits and the binned map
+    good = _good_samples(ob, got, ob.detdata[defaults.det_flags].data, sf)
+    assert int(data["mapmaker_hits"].data.sum()) == int(good.sum())
+    z = np.zeros((dist.n_local_submap, dist.n_pix_submap, 3))
+    detw = np.array([ob[defaults.noise_model].detector_weight(d) for d in ob.local_detectors])
+    oracle.build_noise_weighted(dist.global_submap_to_local, z, idx, got, idx, ob.detdata[defaults.weights].data, idx,
+                                ob.detdata[defaults.det_data].data, idx, ob.detdata[defaults.det_flags].data, detw,
+                                defaults.det_mask_nonscience, ivl, sf, defaults.shared_mask_nonscience)
+    oracle.cov_apply_diag(dist.n_local_submap, dist.n_pix_submap, 3, data["mapmaker_cov"].raw, z)
+    binned = data["mapmaker_map"].data
+    assert np.max(np.abs(binned - z)) < 1e-10 * np.max(np.abs(z))
+
+
+def test_configs4_shard_ground_filter_mapmaker(oracle):
+    from toast_amd import ops
+    from toast_amd.data import defaults
+    from toast_amd.sim import create_ground_data
+    from toast_amd.templates import Offset
+
+    n_det, n_samp, rate, nside = 256, 720000, 200.0, 2048
+    data = create_ground_data(n_det=n_det, n_samp=n_samp, rate=rate, az_min_deg=40.0, az_max_deg=110.0,
+                              scan_rate_deg_s=1.0, fov_deg=8.0)
+    data.lazy_host = True
+    ob = data.obs[0]
+    rng = np.random.default_rng(1)
+    az = ob.shared[defaults.azimuth].data
+    phase = (az - az.min()) / (az.max() - az.min()) * 2 - 1
+    ground = 20.0 * (np.sin(3 * phase) + 0.5 * phase ** 2)
+    sig = ob.detdata[defaults.det_data].data
+    offsets = rng.standard_normal(n_det) * 3.0
+    for d in range(n_det):
+        sig[d] = rng.standard_normal(n_samp) + ground * (1.0 + 0.1 * rng.standard_normal()) + offsets[d]
+    sf = ob.shared[defaults.shared_flags].data
+    science = (sf & 1) == 0
+    rms_before = float(np.std(sig[0][science]))
+    gf = ops.GroundFilter(trend_order=5, filter_order=5, name="groundfilter")
+    gf.apply(data)
+    assert gf.ngood == n_det and gf.nsingular == 0
+    rms_after = float(np.std(ob.detdata[defaults.det_data].data[0][science]))
+    assert rms_before > 5.0 and abs(rms_after - 1.0) < 0.02      # ground signal gone, white noise left
+
+    view = defaults.scanning_interval
+    det_pointing = ops.PointingDetectorSimple()
+    pixels = ops.PixelsHealpix(detector_pointing=det_pointing, nside=nside, nest=True, view=view)
+    weights = ops.StokesWeights(detector_pointing=det_pointing, mode="IQU", view=view)
+    binner = ops.BinMap(pixel_dist="pixel_dist", pixel_pointing=pixels, stokes_weights=weights, full_pointing=True)
+    tmatrix = ops.TemplateMatrix(templates=[Offset(step_time=1.0, noise_model=defaults.noise_model,
+                                                   name="baselines")], view=view)
+    mapper = ops.MapMaker(name="mm", det_data=defaults.det_data, binning=binner, template_matrix=tmatrix,
+                          iter_min=5, iter_max=5, convergence=1e-30, keep_final_products=True, save_cleaned=True)
+    mapper.apply(data)
+    assert len(mapper.history) >= 5 and mapper.history[-1] < 1e-3 * mapper.history[0]
+
+    dist = data["pixel_dist"]
+    assert dist.n_pix == 12 * nside * nside
+    pix = ob.detdata[defaults.pixels].data
+    w = ob.detdata[defaults.weights].data
+    dflags = ob.detdata[defaults.det_flags].data
+    cleaned = ob.detdata["mm_cleaned"].data
+    good = _good_samples(ob, pix, dflags, sf, view=view)
+    # integer hit total == unflagged samples inside the sweeps
+    assert int(data["mm_hits"].data.sum()) == int(good.sum())
+    # checksum of checksums: sum of each Stokes plane of A^T N^-1 d == the same sum over the samples
+    nw = data["mm_noiseweighted_map"].data
+    detw = np.array([ob[defaults.noise_model].detector_weight(d) for d in ob.local_detectors])
+    sd = np.where(good, cleaned * detw[:, None], 0.0)
+    for k in range(3):
+        prod = sd * w[:, :, k]
+        assert abs(float(nw[:, :, k].sum()) - float(prod.sum())) < 1e-10 * float(np.abs(prod).sum())
+    del sd, prod
+    # final map == C * noise-weighted map (the reference's covariance_apply, toast_map_cov.cpp:471-528)
+    z = nw.copy()
+    oracle.cov_apply_diag(dist.n_local_submap, dist.n_pix_submap, 3, data["mm_cov"].raw, z)
+    assert np.max(np.abs(data["mm_map"].data - z)) <= 1e-12 * np.max(np.abs(z))
+    # pixels at Nside 2048, bit for bit, on 8 of the 256 detectors
+    sub = np.unique(np.linspace(0, n_det - 1, 8).astype(int))
+    fp = np.ascontiguousarray(np.array([ob.telescope.focalplane[ob.local_detectors[d]]["quat"] for d in sub]))
+    ivl = ob.intervals[view].data
+    idx = np.arange(len(sub), dtype=np.int32)
+    quats = np.zeros((len(sub), n_samp, 4))
+    oracle.pointing_detector(fp, ob.shared[defaults.boresight_radec].data, idx, quats, ivl, sf,
+                             defaults.shared_mask_invalid)
+    want = np.zeros((len(sub), n_samp), dtype=np.int64)
+    hsub = np.zeros(dist.n_submap, dtype=np.uint8)
+    oracle.pixels_healpix(idx, quats, sf, defaults.shared_mask_invalid, idx, want, ivl, hsub, dist.n_pix_submap, nside,
+                          True)
+    inside = np.zeros(n_samp, dtype=bool)
+    for iv in ivl:
+        inside[int(iv["first"]):int(iv["last"])] = True
+    nbad = int(np.count_nonzero(pix[sub][:, inside] != want[:, inside]))
+    assert nbad == 0, f"{nbad} pixel mismatches"

@@ -1,6 +1,8 @@
 """GPU: BASELINE.json's full single-GPU configuration (configs[2]: 1024 detectors x 720 000
-samples @ 200 Hz, Nside 1024, IQU), checked through size-independent properties, plus oracle
-parity on a detector subsample:
+samples @ 200 Hz, Nside 1024, IQU) AND the per-GPU shard of configs[3] (4096 detectors x 4 h
+@ 200 Hz over 8 GPUs = 512 detectors x 2 880 000 samples, detectors 1024..1535 of the 4096
+detector focalplane, i.e. what rank 2 holds), checked through size-independent properties, plus
+oracle parity on a detector subsample:
 
 * pixels: bit-exact vs the CPU oracle for 32 of the 1024 detectors (2.3e7 samples), all indices
   inside the map, flagged samples -1, kernel idempotent;
@@ -20,26 +22,33 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def full():
+#: name -> (detectors, samples, detectors of the whole focalplane, first detector of this shard)
+SHAPES = {"configs2": (1024, 720000, 1024, 0), "configs3_shard": (512, 2880000, 4096, 1024)}
+
+
+@pytest.fixture(scope="module", params=list(SHAPES))
+def full(request):
     import torch
 
     from toast_amd import capi, synth
 
     assert torch.cuda.is_available()
     dev = torch.device("cuda", 0)
-    n_det = int(os.environ.get("TOAST_AMD_FULLSIZE_DETS", "1024"))
-    n_samp, rate, nside, nps, nnz = 720000, 200.0, 1024, 3072, 3
+    n_det, n_samp, n_total, first = SHAPES[request.param]
+    n_det = int(os.environ.get("TOAST_AMD_FULLSIZE_DETS", str(n_det)))
+    rate, nside, nps, nnz = 200.0, 1024, 3072, 3
     n_submap = 12 * nside * nside // nps
     D = capi.dev
     st = torch.cuda.current_stream().cuda_stream
-    fp, gamma = synth.hex_focalplane(n_det, fov_deg=10.0)
+    fp_all, gamma_all = synth.hex_focalplane(n_total, fov_deg=10.0)
+    fp = np.ascontiguousarray(fp_all[first:first + n_det])
+    gamma = np.ascontiguousarray(gamma_all[first:first + n_det])
     bore = synth.satellite_boresight(n_samp, rate, 600.0, 30.0, 3000.0, 65.0)
     ivl = synth.make_intervals(n_samp, 3, rate, gap=11)
     idx = np.arange(n_det, dtype=np.int32)
     sflags_h = synth.shared_flags_block(n_samp, 0.01, value=1)
     t = dict(n_det=n_det, n_samp=n_samp, nside=nside, nps=nps, nnz=nnz, n_submap=n_submap, ivl=ivl, idx=idx, fp=fp,
-             bore=bore, sflags_h=sflags_h, D=D, st=st, torch=torch, dev=dev)
+             gamma=gamma, bore=bore, sflags_h=sflags_h, D=D, st=st, torch=torch, dev=dev)
     t["bore_d"] = torch.from_numpy(bore).to(dev)
     t["sflags"] = torch.from_numpy(sflags_h).to(dev)
     t["pixels"] = torch.full((n_det, n_samp), -7, dtype=torch.int64, device=dev)
@@ -56,7 +65,8 @@ def full():
     D.stokes_weights_IQU(idx, quats.data_ptr(), idx, t["weights"].data_ptr(), n_samp, 0, 0, ivl, np.zeros(n_det), gamma,
                          np.ones(n_det), False, st)
     torch.cuda.synchronize()
-    sub = np.unique(np.linspace(0, n_det - 1, int(os.environ.get("TOAST_AMD_FULLSIZE_ORACLE_DETS", "32"))).astype(int))
+    n_sub = int(os.environ.get("TOAST_AMD_FULLSIZE_ORACLE_DETS", "32" if n_samp <= 720000 else "16"))
+    sub = np.unique(np.linspace(0, n_det - 1, n_sub).astype(int))
     t["sub"] = sub
     t["quats_sub"] = quats[torch.from_numpy(sub).to(dev)].cpu().numpy()
     # idempotence: second pass into a fresh buffer
@@ -73,7 +83,9 @@ def full():
     for iv in ivl:
         inside[int(iv["first"]):int(iv["last"])] = True
     t["inside"] = inside
-    return t
+    yield t
+    t.clear()
+    torch.cuda.empty_cache()
 
 
 def test_pixels_fullsize(full, oracle):
@@ -176,7 +188,7 @@ def test_on_the_fly_and_compact_fullsize(full):
 
     n_det, n_samp, nps, nnz = t["n_det"], t["n_samp"], t["nps"], t["nnz"]
     n_local = int(t["hit"].size)
-    fp, gamma = synth.hex_focalplane(n_det, fov_deg=10.0)
+    fp, gamma = t["fp"], t["gamma"]
     det_scale = np.linspace(0.5, 1.5, n_det)
     pt = capi.otf_pointing(t["bore_d"].data_ptr(), fp, t["nside"], True, nnz, d_shared_flags=t["sflags"].data_ptr(),
                            n_shared_flags=n_samp, shared_flag_mask=1, epsilon=np.zeros(n_det), gamma=gamma,

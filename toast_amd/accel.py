@@ -81,7 +81,9 @@ def _release(ptr, nbytes, name):
 
     _finalizers.pop(ptr, None)
     try:
-        lib = capi.lib()
+        # the real handle: a garbage collection inside a capi.capture() block must free the device
+        # copy now, not record the call into the plan that is replayed every iteration
+        lib = capi.real_lib()
         present = ctypes.c_int(0)
         rc = lib.toast_hip_accel_present(ctypes.c_void_p(ptr), ctypes.c_size_t(nbytes), ctypes.byref(present))
         if rc == 0 and present.value:

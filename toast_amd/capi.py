@@ -118,6 +118,19 @@ def lib():
     return _lib
 
 
+def real_lib():
+    """The loaded library itself, never the recorder of an active ``capture()`` block (finalizers
+    and other calls that must EXECUTE now, not be recorded into a replayed plan)."""
+    if _lib is None:
+        saved = _capture
+        try:
+            globals()["_capture"] = None
+            lib()
+        finally:
+            globals()["_capture"] = saved
+    return _lib
+
+
 def accel_generation():
     """Memory-manager generation counter (toast_hip_accel_generation)."""
     out = C.c_uint64(0)

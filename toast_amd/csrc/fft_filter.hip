@@ -100,23 +100,13 @@ void exec_plan(Plan & p, void * in, void * out, hipStream_t stream) {
     TH_ROCFFT(rocfft_execute(p.plan, ib, ob, p.info));
 }
 
-// Grow-only device scratch (time-domain and Fourier-domain batches).
+// Time-domain and Fourier-domain batch buffers: grow-only scratch slots of the memory manager
+// (per process / device, failure-safe growth, the manager's block cache is flushed before giving up).
 struct Scratch {
-    void * ptr = nullptr;
-    size_t bytes = 0;
-    void * get(size_t need) {
-        if (need > bytes) {
-            if (ptr) {
-                TH_HIP(hipDeviceSynchronize());
-                TH_HIP(hipFree(ptr));
-            }
-            TH_HIP(hipMalloc(&ptr, need));
-            bytes = need;
-        }
-        return ptr;
-    }
+    int slot;
+    void * get(size_t need) { return Manager::get().scratch(slot, need); }
 };
-Scratch g_tbuf, g_fbuf;
+Scratch g_tbuf{Manager::kScratchFftTime}, g_fbuf{Manager::kScratchFftFreq};
 
 // ------------------------------------------------------------------------------------
 // fill: src/toast/fft.py:163-188 (set_rfft_input)

@@ -1745,8 +1745,7 @@ int toast_hip_vec_axpby_dev(int64_t n, double a, const double * d_x, double b, d
 int toast_hip_vec_dot_dev(int64_t n, const double * d_x, const double * d_y, const uint8_t * d_flags_x,
                           const uint8_t * d_flags_y, double * result, void * stream) {
     return guarded([&] {
-        static double * d_res = nullptr;
-        if (d_res == nullptr) TH_HIP(hipMalloc((void **)&d_res, sizeof(double)));
+        double * d_res = (double *)Manager::get().scratch(Manager::kScratchDot, sizeof(double));
         hipStream_t st = as_stream(stream);
         TH_HIP(hipMemsetAsync(d_res, 0, sizeof(double), st));
         if (n > 0) {

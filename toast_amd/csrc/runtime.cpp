@@ -87,11 +87,49 @@ struct CachedBlock {
     int device;
 };
 
-// Most-recently-used list of uploaded blocks; bounded in bytes.
+// Most-recently-used list of uploaded blocks; bounded in bytes.  Device storage is carved out of
+// 8 MB slabs (bump allocation): committing a new block costs one async copy, never a hipMalloc or
+// a synchronisation on the launch path.  When the cache is full everything is dropped at once
+// (one device synchronisation per ~256 MB of distinct parameter blocks).
 std::list<CachedBlock> g_blocks;
 size_t g_block_bytes = 0;
 constexpr size_t kBlockCacheBytes = size_t(256) << 20;
+constexpr size_t kSlabBytes = size_t(8) << 20;
+struct Slab {
+    char * base;
+    size_t bytes;
+    size_t used;
+    int device;
+};
+std::vector<Slab> g_slabs;
 std::mutex g_block_mutex;
+
+char * slab_alloc(size_t bytes, int device) {
+    const size_t need = (bytes + 255) & ~size_t(255);
+    for (auto & s : g_slabs) {
+        if (s.device == device && s.used + need <= s.bytes) {
+            char * p = s.base + s.used;
+            s.used += need;
+            return p;
+        }
+    }
+    Slab s{nullptr, need > kSlabBytes ? need : kSlabBytes, 0, device};
+    void * p = nullptr;
+    TH_HIP(hipMalloc(&p, s.bytes));
+    s.base = static_cast<char *>(p);
+    s.used = need;
+    g_slabs.push_back(s);
+    return s.base;
+}
+
+void drop_all_blocks() {
+    // Blocks still referenced by queued kernels must outlive them.
+    TH_HIP(hipDeviceSynchronize());
+    for (auto & s : g_slabs) (void)hipFree(s.base);
+    g_slabs.clear();
+    g_blocks.clear();
+    g_block_bytes = 0;
+}
 
 }  // namespace
 
@@ -106,20 +144,11 @@ const char * ParamBlock::commit(hipStream_t stream) {
             return g_blocks.front().dev;
         }
     }
-    while (!g_blocks.empty() && g_block_bytes + host_.size() > kBlockCacheBytes) {
-        // Blocks still referenced by queued kernels must outlive them.
-        TH_HIP(hipDeviceSynchronize());
-        CachedBlock & old = g_blocks.back();
-        g_block_bytes -= old.host.size();
-        (void)hipFree(old.dev);
-        g_blocks.pop_back();
-    }
+    if (!g_blocks.empty() && g_block_bytes + host_.size() > kBlockCacheBytes) drop_all_blocks();
     CachedBlock blk;
     blk.device = dev;
     blk.host = host_;
-    void * p = nullptr;
-    TH_HIP(hipMalloc(&p, host_.size() ? host_.size() : 16));
-    blk.dev = static_cast<char *>(p);
+    blk.dev = slab_alloc(host_.size() ? host_.size() : 16, dev);
     // The cached host copy outlives the asynchronous copy.
     g_blocks.push_front(std::move(blk));
     g_block_bytes += host_.size();
@@ -187,8 +216,48 @@ void Manager::flush_cached() {
     cached_bytes_ = 0;
 }
 
+// Grow-only scratch buffers owned by the manager (so: per process = per device, released by
+// clear()).  A failed growth leaves the slot empty -- never a dangling pointer -- and is retried once
+// after the cache of released blocks has been given back to the driver.
+void * Manager::scratch(int slot, size_t bytes) {
+    // keyed by the CURRENT device: the device-pointer entry points (toast_hip_*_dev) serve callers
+    // that own their device memory and never went through assign_device()
+    int dev = 0;
+    TH_HIP(hipGetDevice(&dev));
+    auto & s = scratch_[std::make_pair(dev, slot)];
+    if (bytes <= s.second && s.first != nullptr) return s.first;
+    if (s.first != nullptr) {
+        TH_HIP(hipDeviceSynchronize());
+        void * old = s.first;
+        s.first = nullptr;
+        s.second = 0;
+        TH_HIP(hipFree(old));
+    }
+    void * p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
+    if ((e != hipSuccess || p == nullptr) && !free_blocks_.empty()) {
+        (void)hipGetLastError();
+        flush_cached();
+        e = hipMalloc(&p, bytes ? bytes : 16);
+    }
+    if (e != hipSuccess || p == nullptr) {
+        (void)hipGetLastError();
+        std::ostringstream o;
+        o << "HipManager:  scratch buffer of " << bytes << " bytes on device " << dev
+          << ", allocation failed";
+        throw Error(TOAST_HIP_ERR_MEMORY, o.str());
+    }
+    s.first = p;
+    s.second = bytes;
+    return p;
+}
+
 void Manager::clear() {
     flush_cached();
+    for (auto & kv : scratch_) {
+        if (kv.second.first) (void)hipFree(kv.second.first);
+    }
+    scratch_.clear();
     for (auto & kv : table_) {
         if (kv.second.host_registered) (void)hipHostUnregister(const_cast<void *>(kv.first));
         if (kv.second.owned) (void)hipFree(kv.second.dev);

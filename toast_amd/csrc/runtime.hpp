@@ -8,6 +8,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <map>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -110,12 +111,18 @@ public:
     void * find(const void * host);         // nullptr if absent
     void dump();
     void clear();
+    // Grow-only device scratch (slot = kScratch*): FFT work buffers, reduction results.
+    void * scratch(int slot, size_t bytes);
+    void release_cached() { flush_cached(); }
 
     uint64_t generation() const { return generation_; }
     hipStream_t stream() const { return stream_; }
     void set_stream(hipStream_t s) { stream_ = s; }
 
+    static constexpr int kScratchFftTime = 0, kScratchFftFreq = 1, kScratchDot = 2, kScratchFftWork = 3;
+
 private:
+    std::map<std::pair<int, int>, std::pair<void *, size_t>> scratch_;   // (device, slot) -> (ptr, bytes)
     struct Entry {
         void * dev;
         size_t nbytes;

@@ -65,12 +65,15 @@ class Comm:
     """Process layout.  One process per GPU; ``comm_world`` is None for a single process,
     else this object (it provides the few collectives the path needs)."""
 
-    def __init__(self, use_dist=None):
+    def __init__(self, use_dist=None, single_rank_collectives=False):
         import torch.distributed as dist
 
         self._dist = dist if (dist.is_available() and dist.is_initialized()) else None
         if use_dist is False:
             self._dist = None
+        # tests only: issue the collectives even in a one-rank process group, so that the RCCL code
+        # path (device tensors, stream ordering) runs on a single-GPU box
+        self._single_rank_collectives = bool(single_rank_collectives)
         self.world_rank = self._dist.get_rank() if self._dist else 0
         self.world_size = self._dist.get_world_size() if self._dist else 1
         self.group_rank = self.world_rank
@@ -80,7 +83,9 @@ class Comm:
 
     @property
     def comm_world(self):
-        return self if (self._dist is not None and self.world_size > 1) else None
+        if self._dist is None:
+            return None
+        return self if (self.world_size > 1 or self._single_rank_collectives) else None
 
     comm_group = comm_world
 
@@ -109,6 +114,37 @@ class Comm:
             return tensor
         ops = {"sum": self._dist.ReduceOp.SUM, "max": self._dist.ReduceOp.MAX}
         self._dist.all_reduce(tensor, op=ops[op])
+        return tensor
+
+    def reduce_scatter_allgather_(self, tensor):
+        """In-place sum over ranks as reduce-scatter + all-gather of a 1-D tensor: every element is
+        reduced by exactly ONE owner rank and the owner's value is what all ranks receive -- the
+        communication pattern of the reference's owner-computes ``sync_alltoallv``
+        (src/toast/pixels.py:878-970), expressed with RCCL's two ring halves.  The shard between the
+        two halves (``owned`` below) is where a per-pixel operation on 1/N of the map can be applied.
+        Falls back to one all-reduce where the backend has no reduce-scatter (gloo)."""
+        if self.comm_world is None:
+            return tensor
+        import torch
+
+        n, size, rank = tensor.numel(), self.world_size, self.world_rank
+        chunk = (n + size - 1) // size
+        try:
+            if chunk * size != n:
+                work = torch.zeros(chunk * size, dtype=tensor.dtype, device=tensor.device)
+                work[:n].copy_(tensor)
+            else:
+                work = tensor
+            owned = torch.empty(chunk, dtype=tensor.dtype, device=tensor.device)
+            self._dist.reduce_scatter_tensor(owned, work, op=self._dist.ReduceOp.SUM)
+            self._dist.all_gather_into_tensor(work, owned)
+            if work is not tensor:
+                tensor.copy_(work[:n])
+        except (RuntimeError, NotImplementedError) as err:
+            if self._dist.get_backend() == "nccl":
+                raise
+            del err
+            self._dist.all_reduce(tensor, op=self._dist.ReduceOp.SUM)
         return tensor
 
     def allreduce_array_(self, arr, op="sum"):

@@ -420,7 +420,19 @@ class SolverLHS(Operator):
                amps_in.accel_in_use())
         plan = self.__dict__.get("_fused_plan")
         if plan is None or plan["key"] != key or plan["generation"] != capi.accel_generation():
-            ctx = self._fused_prepare(data, detectors)
+            # The context holds raw device pointers.  An allocation made while they are being collected
+            # can fail and trigger the eviction handler (Data.accel_evict), which may free a buffer whose
+            # pointer is already in the context.  Every create / delete bumps the manager's generation, so:
+            # collect again until one whole pass ran without any (the second pass normally finds
+            # everything resident and allocates nothing).
+            for _attempt in range(4):
+                gen0 = capi.accel_generation()
+                ctx = self._fused_prepare(data, detectors)
+                if capi.accel_generation() == gen0:
+                    break
+            else:
+                raise RuntimeError("SolverLHS: device buffers keep being evicted while the fused left-hand "
+                                   "side is prepared (device memory too small for its working set)")
             with capi.capture() as first:
                 self._fused_first_half(ctx)
             with capi.capture() as second:

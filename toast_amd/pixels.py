@@ -161,11 +161,34 @@ class PixelData(AcceleratorObject):
     def sync_alltoallv(self, comm=None, **kwargs):
         """Same result as :meth:`sync_allreduce` (the reference test
         src/toast/tests/ops_mapmaker_utils.py:211-397 asserts the equivalence).  The reference's
-        owner-computes alltoallv (pixels.py:878-970) saves MPI volume for sparse per-process sky
-        coverage; with one process per GPU on xGMI every rank holds the union of the hit submaps
-        (``unify_local_submaps``) and one in-place RCCL all-reduce of the device buffer serves
-        both entry points."""
-        self.sync_allreduce(comm=comm)
+        owner-computes alltoallv (pixels.py:878-970) sends every submap to one owner, reduces there
+        and sends the totals back.  With one process per GPU every rank holds the union of the hit
+        submaps (``unify_local_submaps``), so "owner" = the rank that holds slice r of the flat map:
+        RCCL reduce-scatter (owners reduce) + all-gather (totals go back), in place on the device
+        buffer.  Every rank receives the owner's bits, like in the reference."""
+        comm = self._dist.comm if comm is None else comm
+        if comm is None or comm.comm_world is None:
+            return
+        import torch
+
+        if self.accel_in_use() and comm._dist.get_backend() == "nccl":
+            native().accel_synchronize()  # kernels run on the library stream
+            comm.reduce_scatter_allgather_(self.device_tensor())
+            torch.cuda.current_stream().synchronize()
+        else:
+            restore = False
+            if self.accel_in_use():
+                self.accel_update_host()
+                restore = True
+            t = torch.from_numpy(self.raw)
+            if comm._dist.get_backend() == "nccl":
+                d = t.to(comm._collective_device())
+                comm.reduce_scatter_allgather_(d)
+                t.copy_(d.cpu())
+            else:
+                comm.reduce_scatter_allgather_(t)
+            if restore:
+                self.accel_update_device()
 
     # accelerator protocol
     def _accel_exists(self):
