@@ -486,13 +486,12 @@ def run(args, workload, world, rank, dev, headline=True):
             "first_call_ms": 1e3 * t_first,
             "samples_per_s": tot / (t_fft * 1e-3),
             "n_fft": int(n_fft),
-            "implementation": hipfft.implementation() if hasattr(hipfft, "implementation") else "rocfft-5pass",
+            "implementation": hipfft.implementation(n_samp),
             # compulsory traffic: read + write each timestream sample once
             "hbm_GBs": 16.0 * tot / (t_fft * 1e-3) / 1e9,
             "frac": 16.0 * tot / (t_fft * 1e-3) / 1e9 / HBM_PEAK_GBS,
             # what the passes of the pipeline move per timestream sample
-            "pipeline_bytes_per_sample": hipfft.pipeline_bytes_per_sample(n_samp)
-            if hasattr(hipfft, "pipeline_bytes_per_sample") else None,
+            "pipeline_bytes_per_sample": hipfft.pipeline_bytes_per_sample(n_samp),
         }
         pb = out["fft_noise_weight"]["pipeline_bytes_per_sample"]
         if pb:

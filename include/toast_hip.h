@@ -506,7 +506,7 @@ int toast_hip_template_subtract_dev(
     void * stream);
 
 /* ------------------------------------------------------------------------------------
- * FFT noise weighting (rocFFT)
+ * FFT noise weighting
  *
  * toast_hip_fft_convolve: in-place convolution (or deconvolution) of each selected timestream
  * with a Fourier-domain kernel -- toast.fft.convolve(..., algorithm="numpy")
@@ -523,6 +523,18 @@ int toast_hip_template_subtract_dev(
  * forward: out = scale * r2hc(in); backward: out = (scale / length) * hc2r(in).
  * ---------------------------------------------------------------------------------- */
 int64_t toast_hip_fft_length(int64_t n_samp);
+/* Which implementation toast_hip_fft_convolve* uses for this timestream length: 1 = the fused
+ * three-pass kernels (toast_amd/csrc/fft_fused.hip: padding / apodisation, real-FFT packing, the
+ * kernel multiplication and the crop fused into two column passes and one row pass of a four-step
+ * FFT; power-of-two n_fft >= 8192), 0 = the rocFFT pipeline (short transforms, or every length
+ * with TOAST_HIP_FFT=rocfft in the environment).  Both give the same result to ~1e-15 relative. */
+int toast_hip_fft_fused(int64_t n_samp);
+/* Override the choice at run time: rocfft_only != 0 = the rocFFT pipeline for every length,
+ * 0 = automatic (what TOAST_HIP_FFT=rocfft / unset select at start-up). */
+void toast_hip_fft_select(int rocfft_only);
+/* HBM bytes per timestream sample that the passes of that implementation move (accounting for
+ * bench.py / DESIGN.md, not a measurement). */
+double toast_hip_fft_pipeline_bytes(int64_t n_samp);
 
 int toast_hip_fft_convolve(
     double * det_data, int64_t n_data_rows, const int32_t * data_index, int64_t n_det, int64_t n_samp,

@@ -142,3 +142,71 @@ def test_rocfft_pipeline_vs_reference_convolve_fixture(pf, name):
                 deconvolve=deconv)
     want = z[f"{name}_out"]
     assert np.max(np.abs(data - want)) < TOL * np.max(np.abs(want))
+
+
+def _noise_kernels(freq, n_det, complex_phase=False):
+    from oracle import fft_oracle as fo
+
+    kernels = []
+    for d in range(n_det):
+        net = 1.0 + 0.1 * d
+        fknee = 0.05 * (d + 1)
+        psd = net**2 * (freq + fknee) / np.maximum(freq + 1e-5, 1e-12)
+        k = fo.noise_filter_kernel(psd, net)
+        if complex_phase:
+            k = k * np.exp(-1j * 0.03 * (d + 1) * freq)
+        kernels.append(k)
+    return np.array(kernels)
+
+
+@pytest.mark.parametrize("n_samp", [2049, 3000, 8192, 8193, 12345, 50001, 100000, 262145, 300001, 720000, 1100003,
+                                    2200000])
+def test_fused_three_pass_all_column_lengths(pf, n_samp):
+    """The fused three-pass pipeline (fft_fused.hip) for every column length N1 = 2 .. 2048 of its
+    four-step factorisation (n_fft = 2^13 .. 2^23, odd and even buffer offsets), against the NumPy
+    restatement of toast.fft.convolve AND against the rocFFT pipeline: per-detector real kernels with
+    row indirection; rows outside the index stay untouched."""
+    from oracle import fft_oracle as fo
+
+    assert pf.implementation(n_samp) == "fused-3pass"
+    rng = np.random.default_rng(n_samp)
+    rate, n_det, rows = 200.0, 3, 4
+    freq = np.concatenate([[0.0], np.geomspace(1e-5, rate / 2, 70)])
+    kernels = _noise_kernels(freq, n_det)
+    buf = rng.standard_normal((rows, n_samp)).cumsum(axis=1) * 0.01 + rng.standard_normal((rows, n_samp))
+    idx = np.array([3, 0, 2], dtype=np.int32)
+    want = np.ascontiguousarray(buf[idx])
+    fo.convolve(want, rate, kernel_freq=freq, kernels=kernels)
+    got = buf.copy()
+    pf.convolve_buffer(got, idx, rate, freq, kernels)
+    scale = np.max(np.abs(want))
+    assert np.max(np.abs(got[idx] - want)) < TOL * scale
+    assert np.array_equal(got[1], buf[1])
+    pf.select(True)
+    try:
+        assert pf.implementation(n_samp) == "rocfft"
+        lib = buf.copy()
+        pf.convolve_buffer(lib, idx, rate, freq, kernels)
+    finally:
+        pf.select(False)
+    assert np.max(np.abs(got - lib)) < 1e-13 * scale
+
+
+@pytest.mark.parametrize("deconvolve", [False, True])
+def test_fused_complex_kernels_and_common_kernel(pf, deconvolve):
+    """Complex (phase-carrying) kernels, deconvolution and one kernel shared by all detectors
+    through the fused pipeline at a length that uses the register radix-16 stages (N1 = 256)."""
+    from oracle import fft_oracle as fo
+
+    rng = np.random.default_rng(77)
+    rate, n_samp, n_det = 100.0, 270001, 2
+    freq = np.linspace(0, rate / 2, 300)
+    kern = (1.0 / (1.0 + (freq / 5.0) ** 2) + 0.05) * np.exp(-1j * 0.02 * freq)
+    per_det = np.array([kern, kern * np.exp(-1j * 0.01 * freq)])
+    for kernels in (per_det, kern):
+        data = rng.standard_normal((n_det, n_samp))
+        want = data.copy()
+        fo.convolve(want, rate, kernel_freq=freq, kernels=kernels, deconvolve=deconvolve)
+        got = data.copy()
+        pf.convolve(got, rate, kernel_freq=freq, kernels=kernels, deconvolve=deconvolve)
+        assert np.max(np.abs(got - want)) < (1e-11 if deconvolve else TOL) * np.max(np.abs(want))

@@ -18,15 +18,41 @@
 #include <hip/hip_runtime.h>
 #include <rocfft/rocfft.h>
 
+#include <cstdlib>
 #include <map>
 #include <mutex>
+#include <string>
 #include <tuple>
 
 #include "runtime.hpp"
 
 using namespace toast_hip;
 
+namespace toast_hip {
+namespace fused_fft {
+// fft_fused.hip: the three-pass hand-written pipeline (power-of-two lengths >= 8192)
+bool supported(int64_t n_fft);
+double pipeline_bytes_per_sample(int64_t n_samp, int64_t n_fft);
+void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_samp, int64_t n_fft,
+              int64_t n_buffer, int64_t n_reflect, double fstep, const double * d_knots, int64_t n_knot,
+              const double * d_mag, const double * d_ang, int per_det, int deconvolve, const double * d_apod,
+              int64_t max_batch, hipStream_t st);
+}  // namespace fused_fft
+}  // namespace toast_hip
+
 namespace {
+
+// TOAST_HIP_FFT=rocfft selects the rocFFT pipeline below for every length (default: the fused
+// three-pass kernels wherever they apply, rocFFT for short or non power-of-two transforms).
+int g_force_rocfft = -1;   // -1: not decided yet (environment), 0 / 1: set
+
+bool use_fused(int64_t n_fft) {
+    if (g_force_rocfft < 0) {
+        const char * e = std::getenv("TOAST_HIP_FFT");
+        g_force_rocfft = (e != nullptr && std::string(e) == "rocfft") ? 1 : 0;
+    }
+    return g_force_rocfft == 0 && fused_fft::supported(n_fft);
+}
 
 constexpr int kThreads = 256;
 
@@ -264,6 +290,19 @@ int64_t toast_hip_fft_length(int64_t n_samp) {
     return int64_t(1) << (order + 1);
 }
 
+void toast_hip_fft_select(int rocfft_only) { g_force_rocfft = rocfft_only ? 1 : 0; }
+
+int toast_hip_fft_fused(int64_t n_samp) { return use_fused(toast_hip_fft_length(n_samp)) ? 1 : 0; }
+
+double toast_hip_fft_pipeline_bytes(int64_t n_samp) {
+    const int64_t n_fft = toast_hip_fft_length(n_samp);
+    if (use_fused(n_fft)) return fused_fft::pipeline_bytes_per_sample(n_samp, n_fft);
+    // rocFFT pipeline: fill (8 + 8 r), 5 + 5 library passes of 16 r each way... counted from the
+    // kernel trace (profiles/r02_a_fft_rocfft_baseline_rocprofv3.txt): 14 passes over 8 n_fft bytes,
+    // read + write
+    return 14.0 * 16.0 * (double)n_fft / (double)n_samp;
+}
+
 int toast_hip_fft_convolve_dev(double * d_tod, const int32_t * data_index, int64_t n_det,
                                int64_t n_samp, double rate, const double * knots, int64_t n_knot,
                                const double * mag_coef, const double * ang_coef, int64_t n_kernel,
@@ -292,6 +331,13 @@ int toast_hip_fft_convolve_dev(double * d_tod, const int32_t * data_index, int64
         const int32_t * d_idx = (const int32_t *)(d + o_idx);
         const double * d_ac = ang_coef ? (const double *)(d + o_ac) : nullptr;
 
+        if (use_fused(n_fft)) {
+            fused_fft::convolve(d_tod, d_idx, n_det, n_samp, n_fft, n_buffer, n_reflect, fstep,
+                                (const double *)(d + o_kn), n_knot, (const double *)(d + o_mc), d_ac,
+                                (n_kernel == n_det && n_det > 1) ? 1 : 0, deconvolve,
+                                (const double *)(d + o_ap), max_batch, st);
+            return;
+        }
         int64_t batch = (max_batch > 0) ? max_batch : 64;
         // keep the two work buffers under ~8 GB
         const int64_t cap = (int64_t)((size_t(8) << 30) / ((size_t)n_fft * 8 + (size_t)n_psd * 16));

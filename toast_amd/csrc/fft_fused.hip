@@ -1,0 +1,604 @@
+// fft_fused.hip -- FFT noise weighting in three HBM passes (hand-written, gfx950).
+//
+// Same mathematics as the rocFFT pipeline of fft_filter.hip (reference: toast.fft.convolve with
+// algorithm="numpy", src/toast/fft.py:163-212 padding / apodisation, :190-212 kernel
+// interpolation, :296-350 rfft -> multiply -> irfft -> crop), organised so that a timestream
+// crosses HBM three times instead of fourteen (profiles/r02_a_fft_rocfft_baseline_rocprofv3.txt):
+//
+//   The padded real series x[0 .. n_fft) is transformed as ONE complex FFT of length M = n_fft / 2
+//   on z[j] = x[2j] + i x[2j+1], factored M = N1 x N2 (four-step), with the real <-> complex
+//   packing, the kernel multiplication and the inverse packing done where the data already sits in
+//   LDS:
+//
+//   pass 1  k_fft_cols<FWD>   for every group of C adjacent columns j2: read the TIMESTREAM directly
+//                             (mirror + apodisation of set_rfft_input evaluated on the fly: no
+//                             fill pass), FFT of length N1 down the columns, twiddle w_M^(k1 j2),
+//                             write work[k1][j2]
+//   pass 2  k_fft_rows        for every row pair (k1, N1 - k1): FFT of length N2 along both rows
+//                             -> Z[k1 + N1 k2]; bins k and M - k now sit in the same tile:
+//                             X[k] = E + w_N^k O (real-FFT unpacking), Y = K(f) X (or X / K),
+//                             DC removed, Nyquist made real, repacked to Z'[k]; inverse row FFT;
+//                             write work in place
+//   pass 3  k_fft_cols<INV>   twiddle, inverse FFT of length N1 down the columns, crop and scale
+//                             straight into the timestream (no crop pass)
+//
+// Every FFT inside a pass is a Stockham autosort transform on a tile of 4096 complex doubles held
+// by 256 threads x 16 points: radix-16 / 8 / 4 / 2 butterflies in registers, tile exchanges
+// through 64 KB of LDS (XOR-swizzled against bank conflicts), the first and last radix-16 stage
+// go straight from / to global memory.  The inverse transforms reuse the forward code on data with
+// real and imaginary parts swapped (ifft(z) = swap(fft(swap(z)))).
+//
+// Algorithmic HBM bytes per timestream sample: pass 1 reads 8 (+ mirror
+// re-reads served by L2) and writes 8 n_fft / n_samp, pass 2 reads and writes 8 n_fft / n_samp,
+// pass 3 reads 8 n_fft / n_samp and writes 8: 16 + 32 n_fft / n_samp = 109 B at cfg-3.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "runtime.hpp"
+
+namespace toast_hip {
+namespace fused_fft {
+
+constexpr int kLT = 12;             // log2 of the tile (4096 complex doubles = 64 KB of LDS)
+constexpr int kTile = 1 << kLT;
+constexpr int kThreads = kTile / 16;   // 256: every thread holds 16 points
+
+// ------------------------------------------------------------------------------------------
+// complex helpers (explicit fma: the library is built with -ffp-contract=off)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+    return make_double2(__builtin_fma(a.x, b.x, -(a.y * b.y)), __builtin_fma(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 cconj(double2 a) { return make_double2(a.x, -a.y); }
+// a * (-i)
+__device__ __forceinline__ double2 mul_mi(double2 a) { return make_double2(a.y, -a.x); }
+
+// LDS position of tile element i: XOR swizzle of the low four bits with the next four -- the
+// strided writes of a Stockham stage (stride 16 elements = 256 B) then spread over all banks.
+__device__ __forceinline__ int sw(int i) { return i ^ ((i >> 4) & 15); }
+
+// forward DFT of R points in registers, natural order in and out
+template <int R>
+struct DFT;
+template <>
+struct DFT<1> {
+    static __device__ __forceinline__ void run(double2 *) {}
+};
+template <>
+struct DFT<2> {
+    static __device__ __forceinline__ void run(double2 * a) {
+        const double2 t = a[0];
+        a[0] = cadd(t, a[1]);
+        a[1] = csub(t, a[1]);
+    }
+};
+template <int R>
+struct DFT {
+    static __device__ __forceinline__ void run(double2 * a) {
+        constexpr int H = R / 2;
+        double2 e[H], o[H];
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            e[k] = a[2 * k];
+            o[k] = a[2 * k + 1];
+        }
+        DFT<H>::run(e);
+        DFT<H>::run(o);
+        // w_R^k = (cos(2 pi k / R), -sin(2 pi k / R)), k < R / 2
+        constexpr double c16[8] = {1.0, 0.92387953251128673848, 0.70710678118654752440, 0.38268343236508977173,
+                                   0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128673848};
+        constexpr double s16[8] = {0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128673848,
+                                   1.0, 0.92387953251128673848, 0.70710678118654752440, 0.38268343236508977173};
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            constexpr int step = 16 / R;
+            double2 t;
+            if (k == 0) {
+                t = o[0];
+            } else if (2 * k == H) {
+                t = mul_mi(o[k]);
+            } else {
+                t = cmul(o[k], make_double2(c16[k * step], -s16[k * step]));
+            }
+            a[k] = cadd(e[k], t);
+            a[k + H] = csub(e[k], t);
+        }
+    }
+};
+
+template <int R>
+struct Log2;
+template <>
+struct Log2<2> {
+    static constexpr int v = 1;
+};
+template <>
+struct Log2<4> {
+    static constexpr int v = 2;
+};
+template <>
+struct Log2<8> {
+    static constexpr int v = 3;
+};
+template <>
+struct Log2<16> {
+    static constexpr int v = 4;
+};
+
+__device__ __forceinline__ int out_idx(int u, int j, int log_s, int log_r) {
+    return (u & ((1 << log_s) - 1)) | ((u >> log_s) << (log_s + log_r)) | (j << log_s);
+}
+
+// out[j] *= w^(j) for j = 1 .. R-1 with w = base (powers by a product tree of depth <= 4)
+template <int R>
+__device__ __forceinline__ void apply_powers(double2 * a, double2 w1) {
+    if (R >= 2) a[1] = cmul(a[1], w1);
+    if (R >= 4) {
+        const double2 w2 = cmul(w1, w1);
+        const double2 w3 = cmul(w2, w1);
+        a[2] = cmul(a[2], w2);
+        a[3] = cmul(a[3], w3);
+        if (R >= 8) {
+            const double2 w4 = cmul(w2, w2);
+            const double2 w5 = cmul(w4, w1);
+            const double2 w6 = cmul(w3, w3);
+            const double2 w7 = cmul(w4, w3);
+            a[4] = cmul(a[4], w4);
+            a[5] = cmul(a[5], w5);
+            a[6] = cmul(a[6], w6);
+            a[7] = cmul(a[7], w7);
+            if (R >= 16) {
+                const double2 w8 = cmul(w4, w4);
+                a[8] = cmul(a[8], w8);
+                a[9] = cmul(a[9], cmul(w8, w1));
+                a[10] = cmul(a[10], cmul(w5, w5));
+                a[11] = cmul(a[11], cmul(w8, w3));
+                a[12] = cmul(a[12], cmul(w6, w6));
+                a[13] = cmul(a[13], cmul(w8, w5));
+                a[14] = cmul(a[14], cmul(w7, w7));
+                a[15] = cmul(a[15], cmul(w8, w7));
+            }
+        }
+    }
+}
+
+// One Stockham stage of radix R on the whole tile, LDS -> LDS.  Remaining transform length is
+// (kTile >> log_s); the stage twiddle w_n^(j p) = wtile[(p << log_s) * j] is built from wtile[u & ~(s-1)].
+template <int R>
+__device__ __forceinline__ void stage_lds(double2 * sm, int tid, int log_s, bool last,
+                                          const double2 * __restrict__ wtile) {
+    constexpr int B = 16 / R;
+    constexpr int Q = kTile / R;
+    constexpr int LR = Log2<R>::v;
+    double2 v[B][R];
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        const int u = tid + kThreads * b;
+#pragma unroll
+        for (int k = 0; k < R; ++k) v[b][k] = sm[sw(u + k * Q)];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        const int u = tid + kThreads * b;
+        DFT<R>::run(v[b]);
+        if (!last) apply_powers<R>(v[b], wtile[(u >> log_s) << log_s]);
+#pragma unroll
+        for (int j = 0; j < R; ++j) sm[sw(out_idx(u, j, log_s, LR))] = v[b][j];
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void stage_lds_any(int r, double2 * sm, int tid, int log_s, bool last,
+                                              const double2 * __restrict__ wtile) {
+    switch (r) {
+        case 16: stage_lds<16>(sm, tid, log_s, last, wtile); break;
+        case 8: stage_lds<8>(sm, tid, log_s, last, wtile); break;
+        case 4: stage_lds<4>(sm, tid, log_s, last, wtile); break;
+        default: stage_lds<2>(sm, tid, log_s, last, wtile); break;
+    }
+}
+
+// Forward FFTs of length n = 2^log_n along the slow axis of the tile (kTile / n interleaved
+// transforms).  In and out: v[k] = tile element tid + k * kThreads.
+__device__ __forceinline__ void tile_fft(double2 (&v)[16], double2 * sm, int tid, int log_n,
+                                         const double2 * __restrict__ wtile) {
+    const int log_s0 = kLT - log_n;
+    if (log_n >= 8) {
+        // plan [16, mid, 16], mid = n / 256: the radix-16 ends work straight on the registers
+        const int log_mid = log_n - 8;
+        DFT<16>::run(v);
+        apply_powers<16>(v, wtile[(tid >> log_s0) << log_s0]);
+        __syncthreads();   // earlier readers of the tile are done
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sm[sw(out_idx(tid, j, log_s0, 4))] = v[j];
+        __syncthreads();
+        if (log_mid > 0) stage_lds_any(1 << log_mid, sm, tid, log_s0 + 4, false, wtile);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = sm[sw(tid + k * kThreads)];
+        DFT<16>::run(v);
+        return;
+    }
+    // short transforms (only small problems get here): every stage through LDS
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sm[sw(tid + k * kThreads)] = v[k];
+    __syncthreads();
+    int log_rem = log_n, log_s = log_s0;
+    while (log_rem > 0) {
+        const int lr = log_rem >= 4 ? 4 : log_rem;
+        stage_lds_any(1 << lr, sm, tid, log_s, log_rem == lr, wtile);
+        log_s += lr;
+        log_rem -= lr;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = sm[sw(tid + k * kThreads)];
+}
+
+// ------------------------------------------------------------------------------------------
+// tables: wtile[e] = w_tile^e (e < kTile); three-level w_N^e = t2[e >> 14] t1[(e >> 7) & 127] t0[e & 127]
+// ------------------------------------------------------------------------------------------
+struct Tables {
+    const double2 * wtile;
+    const double2 * t0;
+    const double2 * t1;
+    const double2 * t2;
+};
+
+__device__ __forceinline__ double2 tw_big(const Tables & tb, int64_t e) {
+    const double2 a = tb.t2[e >> 14];
+    const double2 b = tb.t1[(e >> 7) & 127];
+    const double2 c = tb.t0[e & 127];
+    return cmul(cmul(a, b), c);
+}
+
+struct Params {
+    double * tod;                 // [rows, n_samp]
+    const int32_t * d_idx;        // row of detector b
+    int det0;
+    double2 * work;               // [batch, M]
+    const double * apod;          // n_reflect
+    int64_t n_samp, n_fft, n_buffer, n_reflect;
+    int log_n1, log_n2;           // M = N1 N2
+    Tables tb;
+    // kernel K(f)
+    const double * knots;
+    int n_knot;
+    const double * mag_coef;
+    const double * ang_coef;      // nullptr: real kernel
+    const int32_t * knot_hint;    // interval index at the first bin of every block of 256 bins
+    int per_det, deconvolve;
+    double fstep, scale;
+};
+
+// set_rfft_input evaluated for one element of the padded series (src/toast/fft.py:163-188)
+__device__ __forceinline__ double padded(const double * __restrict__ row, const double * __restrict__ apod,
+                                         int64_t i, int64_t n_samp, int64_t n_buffer, int64_t n_reflect) {
+    const int64_t s = i - n_buffer;
+    if (s >= 0 && s < n_samp) return row[s];
+    if (s < 0 && s >= -n_reflect) {
+        const int64_t j = s + n_reflect;
+        return row[n_reflect - 1 - j] * apod[j];
+    }
+    if (s >= n_samp && s < n_samp + n_reflect) {
+        const int64_t j = s - n_samp;
+        return row[n_samp - 1 - j] * apod[n_reflect - 1 - j];
+    }
+    return 0.0;
+}
+
+// pass 1 (INV = false) and pass 3 (INV = true): transforms of length N1 down the columns
+template <bool INV>
+__global__ __launch_bounds__(kThreads, 2) void k_fft_cols(const Params p) {
+    extern __shared__ double2 sm[];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int log_c = kLT - p.log_n1;                 // columns per tile
+    const int64_t n2 = int64_t(1) << p.log_n2;
+    const int64_t c0 = (int64_t)blockIdx.x << log_c;
+    const int64_t m = int64_t(1) << (p.log_n1 + p.log_n2);
+    double2 * __restrict__ work = p.work + (int64_t)b * m;
+    double * __restrict__ row = p.tod + (int64_t)p.d_idx[p.det0 + b] * p.n_samp;
+    double2 v[16];
+    if (!INV) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int e = tid + k * kThreads;
+            const int64_t j = ((int64_t)(e >> log_c) << p.log_n2) + c0 + (e & ((1 << log_c) - 1));
+            v[k].x = padded(row, p.apod, 2 * j, p.n_samp, p.n_buffer, p.n_reflect);
+            v[k].y = padded(row, p.apod, 2 * j + 1, p.n_samp, p.n_buffer, p.n_reflect);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int e = tid + k * kThreads;
+            const int64_t k1 = e >> log_c;
+            const int64_t j2 = c0 + (e & ((1 << log_c) - 1));
+            v[k] = cmul(work[(k1 << p.log_n2) + j2], tw_big(p.tb, 2 * k1 * j2));
+        }
+    }
+    tile_fft(v, sm, tid, p.log_n1, p.tb.wtile);
+    if (!INV) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int e = tid + k * kThreads;
+            const int64_t k1 = e >> log_c;
+            const int64_t j2 = c0 + (e & ((1 << log_c) - 1));
+            work[(k1 << p.log_n2) + j2] = cmul(v[k], tw_big(p.tb, 2 * k1 * j2));
+        }
+    } else {
+        // the transform ran on swapped data: Re z' = v.y, Im z' = v.x; crop + scale (fft.py:341-350)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int e = tid + k * kThreads;
+            const int64_t j = ((int64_t)(e >> log_c) << p.log_n2) + c0 + (e & ((1 << log_c) - 1));
+            const int64_t s = 2 * j - p.n_buffer;
+            if (s >= 0 && s < p.n_samp) row[s] = v[k].y * p.scale;
+            if (s + 1 >= 0 && s + 1 < p.n_samp) row[s + 1] = v[k].x * p.scale;
+        }
+    }
+    (void)n2;
+}
+
+// K(f) at bin k (src/toast/fft.py:190-212): PCHIP piecewise cubics of |K| and arg K
+__device__ __forceinline__ double ppoly_at(const double * __restrict__ knots, int n_knot,
+                                           const double * __restrict__ coef, int lo, double x) {
+    const double * c = coef + 4 * lo;
+    const double dx = x - knots[lo];
+    return ((c[0] * dx + c[1]) * dx + c[2]) * dx + c[3];
+}
+
+__device__ __forceinline__ double2 kernel_at(const Params & p, const double * __restrict__ mc,
+                                             const double * __restrict__ ac, int64_t k) {
+    const double x = (double)k * p.fstep;
+    // interval: start from the hint of this block of 256 bins, walk forward (the knots are sorted;
+    // a block holds more than a few knots only near f = 0)
+    int lo = p.knot_hint[k >> 8];
+    while (lo < p.n_knot - 2 && p.knots[lo + 1] <= x) ++lo;
+    const double mag = ppoly_at(p.knots, p.n_knot, mc, lo, x);
+    if (ac == nullptr) return make_double2(mag, 0.0);
+    const double ang = ppoly_at(p.knots, p.n_knot, ac, lo, x);
+    return make_double2(mag * cos(ang), mag * sin(ang));
+}
+
+__device__ __forceinline__ double2 apply_kernel(double2 v, double2 kk, int deconvolve) {
+    if (deconvolve) {
+        const double den = kk.x * kk.x + kk.y * kk.y;
+        return make_double2((v.x * kk.x + v.y * kk.y) / den, (v.y * kk.x - v.x * kk.y) / den);
+    }
+    return make_double2(v.x * kk.x - v.y * kk.y, v.x * kk.y + v.y * kk.x);
+}
+
+// pass 2: rows (k1, N1 - k1) [block 0: rows 0 and N1 / 2]
+__global__ __launch_bounds__(kThreads, 2) void k_fft_rows(const Params p) {
+    extern __shared__ double2 sm[];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int g = blockIdx.x;
+    const int64_t n1 = int64_t(1) << p.log_n1;
+    const int n2 = 1 << p.log_n2;            // = kTile / 2
+    const int64_t m = n1 << p.log_n2;
+    double2 * __restrict__ work = p.work + (int64_t)b * m;
+    const int64_t r0 = (g == 0) ? 0 : g;
+    const int64_t r1 = (g == 0) ? (n1 >> 1) : (n1 - g);
+    double2 v[16];
+    // tile element e = 2 k2 + r
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int e = tid + k * kThreads;
+        const int64_t rr = (e & 1) ? r1 : r0;
+        v[k] = work[(rr << p.log_n2) + (e >> 1)];
+    }
+    tile_fft(v, sm, tid, p.log_n2, p.tb.wtile);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sm[sw(tid + k * kThreads)] = v[k];
+    __syncthreads();
+
+    const int64_t kern = p.per_det ? (int64_t)(p.det0 + b) : 0;
+    const double * __restrict__ mc = p.mag_coef + kern * 4 * (p.n_knot - 1);
+    const double * __restrict__ ac = p.ang_coef ? p.ang_coef + kern * 4 * (p.n_knot - 1) : nullptr;
+    // bins k and M - k: real-FFT unpacking, kernel, repacking (all factors 1/2 are in p.scale)
+    for (int i = 0; i < n2 / kThreads; ++i) {
+        const int q = tid + kThreads * i;
+        int ea, eb;
+        int64_t k;
+        if (g != 0) {
+            ea = 2 * q;
+            eb = 2 * (n2 - 1 - q) + 1;
+            k = g + n1 * q;
+        } else if (q < n2 / 2) {
+            ea = 2 * q + 1;
+            eb = 2 * (n2 - 1 - q) + 1;
+            k = (n1 >> 1) + n1 * q;
+        } else {
+            const int qq = q - n2 / 2;
+            if (qq == 0) {
+                // DC and Nyquist share element 0: Z[0] = a + i b, X[0] = a + b, X[M] = a - b
+                const double2 z0 = sm[sw(0)];
+                const double2 km = kernel_at(p, mc, ac, m);
+                double2 ym = apply_kernel(make_double2(2.0 * (z0.x - z0.y), 0.0), km, p.deconvolve);
+                ym.y = 0.0;                                  // Nyquist bin of a real transform is real
+                // Y[0] = 0 (DC removed): Z'[0] = (Y[M], -Y[M]); stored swapped
+                sm[sw(0)] = make_double2(-ym.x, ym.x);
+                ea = eb = n2;                                // bin M / 2 pairs with itself (row 0, k2 = N2 / 2)
+                k = m >> 1;
+            } else {
+                ea = 2 * qq;
+                eb = 2 * (n2 - qq);
+                k = n1 * qq;
+            }
+        }
+        const double2 za = sm[sw(ea)];
+        const double2 zb = sm[sw(eb)];
+        const double2 cb = cconj(zb);
+        const double2 ee = cadd(za, cb);
+        const double2 oo = mul_mi(csub(za, cb));
+        const double2 wk = tw_big(p.tb, k);
+        const double2 t = cmul(wk, oo);
+        const double2 xa = cadd(ee, t);
+        const double2 xb = cconj(csub(ee, t));
+        const double2 ya = apply_kernel(xa, kernel_at(p, mc, ac, k), p.deconvolve);
+        const double2 yb = apply_kernel(xb, kernel_at(p, mc, ac, m - k), p.deconvolve);
+        const double2 cyb = cconj(yb);
+        const double2 ye = cadd(ya, cyb);
+        const double2 yo = cmul(cconj(wk), csub(ya, cyb));
+        // Z'[k] = Ye + i Yo, Z'[M-k] = conj(Ye) + i conj(Yo); stored with re / im swapped
+        sm[sw(ea)] = make_double2(ye.y + yo.x, ye.x - yo.y);
+        if (eb != ea) sm[sw(eb)] = make_double2(yo.x - ye.y, ye.x + yo.y);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = sm[sw(tid + k * kThreads)];
+    tile_fft(v, sm, tid, p.log_n2, p.tb.wtile);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int e = tid + k * kThreads;
+        const int64_t rr = (e & 1) ? r1 : r0;
+        work[(rr << p.log_n2) + (e >> 1)] = v[k];
+    }
+}
+
+// per-block start interval of the kernel's piecewise cubics (bins 256 i: frequency 256 i fstep)
+__global__ void k_knot_hint(const double * __restrict__ knots, int n_knot, double fstep, int64_t n_block,
+                            int32_t * __restrict__ hint) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_block) return;
+    const double x = (double)(i << 8) * fstep;
+    int lo = 0, hi = n_knot - 2;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (knots[mid] <= x) {
+            lo = mid;
+        } else {
+            hi = mid - 1;
+        }
+    }
+    hint[i] = lo;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+struct Plan {
+    double2 * tables = nullptr;   // wtile | t0 | t1 | t2
+    int64_t n2_entries = 0;
+};
+
+std::mutex g_mutex;
+std::map<std::pair<int, int64_t>, Plan> g_plans;
+
+static void fill_twiddle(std::vector<double2> & out, size_t at, int64_t e, int64_t n) {
+    // w_n^e = exp(-2 pi i e / n) in extended precision, rounded once
+    const long double a = 2.0L * 3.14159265358979323846264338327950288L * (long double)e / (long double)n;
+    out[at] = make_double2((double)cosl(a), (double)(-sinl(a)));
+}
+
+static Plan & get_plan(int64_t n_fft, hipStream_t st) {
+    int dev = 0;
+    TH_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_mutex);
+    auto key = std::make_pair(dev, n_fft);
+    auto it = g_plans.find(key);
+    if (it != g_plans.end()) return it->second;
+    Plan pl;
+    pl.n2_entries = (n_fft >> 14) > 0 ? (n_fft >> 14) : 1;
+    std::vector<double2> h((size_t)kTile + 256 + (size_t)pl.n2_entries);
+    for (int64_t e = 0; e < kTile; ++e) fill_twiddle(h, (size_t)e, e, kTile);
+    for (int64_t e = 0; e < 128; ++e) fill_twiddle(h, (size_t)kTile + e, e, n_fft);
+    for (int64_t e = 0; e < 128; ++e) fill_twiddle(h, (size_t)kTile + 128 + e, (e << 7) % n_fft, n_fft);
+    for (int64_t e = 0; e < pl.n2_entries; ++e) fill_twiddle(h, (size_t)kTile + 256 + e, (e << 14) % n_fft, n_fft);
+    void * d = nullptr;
+    TH_HIP(hipMalloc(&d, h.size() * sizeof(double2)));
+    TH_HIP(hipMemcpyAsync(d, h.data(), h.size() * sizeof(double2), hipMemcpyHostToDevice, st));
+    TH_HIP(hipStreamSynchronize(st));
+    pl.tables = static_cast<double2 *>(d);
+    static bool attr_set = false;
+    if (!attr_set) {
+        TH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_cols<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kTile * sizeof(double2)));
+        TH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_cols<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kTile * sizeof(double2)));
+        TH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_rows),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, kTile * sizeof(double2)));
+        attr_set = true;
+    }
+    return g_plans.emplace(key, pl).first->second;
+}
+
+bool supported(int64_t n_fft) {
+    // M = n_fft / 2 = N1 N2 with N2 = kTile / 2 and N1 >= 2
+    return n_fft >= 2 * kTile && n_fft <= (int64_t(1) << 24);
+}
+
+// Bytes the three passes move per timestream sample (bench / DESIGN accounting).
+double pipeline_bytes_per_sample(int64_t n_samp, int64_t n_fft) {
+    return 16.0 + 32.0 * (double)n_fft / (double)n_samp;
+}
+
+void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_samp, int64_t n_fft,
+              int64_t n_buffer, int64_t n_reflect, double fstep, const double * d_knots, int64_t n_knot,
+              const double * d_mag, const double * d_ang, int per_det, int deconvolve, const double * d_apod,
+              int64_t max_batch, hipStream_t st) {
+    Plan & pl = get_plan(n_fft, st);
+    const int64_t m = n_fft / 2;
+    int log_m = 0;
+    while ((int64_t(1) << log_m) < m) ++log_m;
+    Params p;
+    p.tod = d_tod;
+    p.d_idx = d_idx;
+    p.apod = d_apod;
+    p.n_samp = n_samp;
+    p.n_fft = n_fft;
+    p.n_buffer = n_buffer;
+    p.n_reflect = n_reflect;
+    p.log_n2 = kLT - 1;
+    p.log_n1 = log_m - p.log_n2;
+    p.tb.wtile = pl.tables;
+    p.tb.t0 = pl.tables + kTile;
+    p.tb.t1 = pl.tables + kTile + 128;
+    p.tb.t2 = pl.tables + kTile + 256;
+    p.knots = d_knots;
+    p.n_knot = (int)n_knot;
+    p.mag_coef = d_mag;
+    p.ang_coef = d_ang;
+    p.per_det = per_det;
+    p.deconvolve = deconvolve;
+    p.fstep = fstep;
+    // unnormalised inverse of length M on un-halved packing factors: 1 / (4 M), a power of two
+    p.scale = 1.0 / (4.0 * (double)m);
+
+    int64_t batch = (max_batch > 0) ? max_batch : 512;
+    const int64_t cap = (int64_t)((size_t(8) << 30) / ((size_t)m * sizeof(double2)));
+    if (batch > cap) batch = cap > 0 ? cap : 1;
+    if (batch > n_det) batch = n_det;
+    const int64_t n_hint = (m >> 8) + 1;
+    const size_t hint_bytes = ((size_t)n_hint * sizeof(int32_t) + 255) & ~size_t(255);
+    char * scratch = (char *)Manager::get().scratch(Manager::kScratchFftWork,
+                                                    hint_bytes + (size_t)batch * m * sizeof(double2));
+    int32_t * d_hint = (int32_t *)scratch;
+    p.knot_hint = d_hint;
+    p.work = (double2 *)(scratch + hint_bytes);
+    hipLaunchKernelGGL(k_knot_hint, dim3((unsigned)((n_hint + 255) / 256)), dim3(256), 0, st, d_knots,
+                       (int)n_knot, fstep, n_hint, d_hint);
+    const size_t lds = kTile * sizeof(double2);
+    const unsigned n_col_tiles = (unsigned)(int64_t(1) << (p.log_n2 - (kLT - p.log_n1)));   // N2 / C
+    const unsigned n_row_tiles = (unsigned)((int64_t(1) << p.log_n1) / 2);                 // N1 / 2
+    for (int64_t det0 = 0; det0 < n_det; det0 += batch) {
+        const int64_t nb = (n_det - det0 < batch) ? (n_det - det0) : batch;
+        p.det0 = (int)det0;
+        hipLaunchKernelGGL(k_fft_cols<false>, dim3(n_col_tiles, (unsigned)nb), dim3(kThreads), lds, st, p);
+        hipLaunchKernelGGL(k_fft_rows, dim3(n_row_tiles, (unsigned)nb), dim3(kThreads), lds, st, p);
+        hipLaunchKernelGGL(k_fft_cols<true>, dim3(n_col_tiles, (unsigned)nb), dim3(kThreads), lds, st, p);
+        TH_HIP(hipGetLastError());
+    }
+}
+
+}  // namespace fused_fft
+}  // namespace toast_hip

@@ -20,6 +20,23 @@ def fft_length(n_samp):
     return int(capi.lib().toast_hip_fft_length(C.c_int64(int(n_samp))))
 
 
+def implementation(n_samp=720000):
+    """"fused-3pass" (toast_amd/csrc/fft_fused.hip) or "rocfft" for a timestream of this length."""
+    return "fused-3pass" if capi.lib().toast_hip_fft_fused(C.c_int64(int(n_samp))) else "rocfft"
+
+
+def select(rocfft_only):
+    """Force the rocFFT pipeline for every length (True) or return to the automatic choice (False)."""
+    capi.lib().toast_hip_fft_select(C.c_int(1 if rocfft_only else 0))
+
+
+def pipeline_bytes_per_sample(n_samp):
+    """HBM bytes per timestream sample moved by the passes of the implementation in use."""
+    fn = capi.lib().toast_hip_fft_pipeline_bytes
+    fn.restype = C.c_double
+    return float(fn(C.c_int64(int(n_samp))))
+
+
 def apodization(n_reflect):
     """First half of ``general_gaussian(2 n_reflect, p=3, sig=n_reflect // 2)``
     (reference fft.py:163-171; formula of scipy.signal.windows.general_gaussian)."""
