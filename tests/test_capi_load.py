@@ -83,11 +83,47 @@ def test_pybind_module_names_match_reference():
                  "build_noise_weighted", "noise_weight", "template_offset_add_to_signal",
                  "template_offset_project_signal", "template_offset_apply_diag_precond", "cov_apply_diag",
                  "accel_enabled", "accel_assign_device", "accel_get_device", "accel_present", "accel_create",
-                 "accel_reset", "accel_update_device", "accel_update_host", "accel_delete", "accel_dump", "Interval"):
+                 "accel_reset", "accel_update_device", "accel_update_host", "accel_delete", "accel_dump", "Interval",
+                 "FFTPlanReal1D", "FFTPlanReal1DStore", "FFTPlanType", "FFTDirection"):
         assert hasattr(m, name), name
     iv = m.Interval()
     iv.first, iv.last = 3, 9
     assert iv.astuple()[2:] == (3, 9)
+
+
+def test_fft_plan_classes_follow_the_reference_binding():
+    """FFTPlanReal1D / FFTPlanReal1DStore (reference src/toast/_libtoast/math_fft.cpp:10-175): create /
+    length / count / tdata / fdata (NumPy views INTO plan-owned, zero-initialised memory: time buffers
+    first, Fourier buffers behind them) and the plan store singleton (cache / forward / backward /
+    clear, one plan per (length, n) and direction).  No compute call without a GPU."""
+    import toast_amd
+
+    m = toast_amd.load_native()
+    assert [e for e in ("fast", "best") if hasattr(m.FFTPlanType, e)] == ["fast", "best"]
+    assert [e for e in ("forward", "backward") if hasattr(m.FFTDirection, e)] == ["forward", "backward"]
+    p = m.FFTPlanReal1D.create(length=12, n=3, type=m.FFTPlanType.fast, dir=m.FFTDirection.forward, scale=2.0)
+    assert (p.length(), p.count()) == (12, 3)
+    t1, f0 = p.tdata(1), p.fdata(0)
+    assert t1.shape == (12,) and t1.dtype == np.float64 and not t1.flags["OWNDATA"]
+    assert not f0.any() and not t1.any()
+    t1[:] = np.arange(12)
+    assert np.array_equal(p.tdata(1), np.arange(12))          # a view, not a copy
+    base = p.tdata(0).ctypes.data
+    assert p.tdata(2).ctypes.data == base + 2 * 12 * 8 and p.fdata(0).ctypes.data == base + 3 * 12 * 8
+    with pytest.raises(IndexError):
+        p.fdata(3)
+    with pytest.raises(RuntimeError):
+        m.FFTPlanReal1D.create(0, 1, m.FFTPlanType.fast, m.FFTDirection.forward, 1.0)
+    store = m.FFTPlanReal1DStore.get()
+    store.clear()
+    store.cache(16, 2)
+    a, b = store.forward(16, 2), store.backward(16, 2)
+    assert a is store.forward(16, 2) and b is store.backward(16, 2) and a is not b
+    assert store.forward(16, 1) is not a
+    assert m.FFTPlanReal1DStore.get().forward(16, 2) is a     # one process-wide store
+    store.clear()
+    assert store.forward(16, 2) is not a
+    store.clear()
 
 
 def test_header_is_plain_c_and_links(tmp_path):

@@ -107,6 +107,39 @@ def test_r1d_half_complex_plans(pf):
     assert one.shape == (n,)
 
 
+def test_fft_plan_classes_exec(pf):
+    """FFTPlanReal1D.exec through the class surface of the reference binding (math_fft.cpp:19-130):
+    forward = scale * r2hc, backward = scale / length * hc2r, buffers are views into the plan;
+    the reference's round-trip test (src/toast/tests/fft.py:42-94) through the plan store."""
+    import toast_amd
+    from oracle import fft_oracle as fo
+
+    m = toast_amd.load_native()
+    rng = np.random.default_rng(5)
+    for length, n, scale in ((65536, 3, 1.0), (1000, 2, 0.25), (15, 1, 3.0)):
+        x = rng.standard_normal((n, length))
+        fwd = m.FFTPlanReal1D.create(length, n, m.FFTPlanType.fast, m.FFTDirection.forward, scale)
+        for i in range(n):
+            fwd.tdata(i)[:] = x[i]
+        fwd.exec()
+        hc = np.array([fwd.fdata(i) for i in range(n)])
+        want = scale * fo.r1d_forward(x)
+        assert np.max(np.abs(hc - want)) < 1e-12 * np.max(np.abs(want))
+        bwd = m.FFTPlanReal1D.create(length, n, m.FFTPlanType.best, m.FFTDirection.backward, 1.0 / scale)
+        for i in range(n):
+            bwd.fdata(i)[:] = hc[i]
+        bwd.exec()
+        back = np.array([bwd.tdata(i) for i in range(n)])
+        assert np.max(np.abs(back - x)) < 1e-12 * np.max(np.abs(x))
+    store = m.FFTPlanReal1DStore.get()
+    store.clear()
+    y = rng.standard_normal((4, 2048))
+    np.testing.assert_array_almost_equal(pf.r1d_backward(pf.r1d_forward(y)), y)
+    np.testing.assert_array_almost_equal(pf.r1d_backward(pf.r1d_forward(y[0])), y[0])
+    assert store.forward(2048, 4).count() == 4
+    store.clear()
+
+
 def test_large_batch_chunking(pf):
     """More detectors than one work batch: exercises the batch loop and plan cache."""
     import torch

@@ -10,6 +10,8 @@
 #include <pybind11/pybind11.h>
 
 #include <cstdint>
+#include <map>
+#include <memory>
 #include <sstream>
 #include <stdexcept>
 #include <string>
@@ -149,6 +151,82 @@ void scan_map_binding(py::buffer global2local, int64_t n_pix_submap, py::buffer 
 }
 
 }  // namespace
+
+// ------------------------------------------------------------------------------------------
+// FFTPlanReal1D / FFTPlanReal1DStore: the reference's batched 1-D real FFT plans
+// (src/toast/_libtoast/math_fft.cpp:10-175, src/libtoast/include/toast/math_fft.hpp:24-82, FFTW
+// implementation src/libtoast/src/toast_math_fft_fftw.cpp:26-128): `n` transforms of `length`,
+// one host slab of 2 n length doubles (time-domain buffers first, Fourier-domain buffers after
+// them, zero-initialised), FFTW half-complex layout, forward result * scale, backward result *
+// scale / length.  exec() runs on the GPU (toast_hip_fft_r1d: staged through device memory).
+// ------------------------------------------------------------------------------------------
+enum class FFTPlanType { fast = 0, best = 1 };
+enum class FFTDirection { forward = 0, backward = 1 };
+
+class HipFFTPlanReal1D : public std::enable_shared_from_this<HipFFTPlanReal1D> {
+public:
+    typedef std::shared_ptr<HipFFTPlanReal1D> pshr;
+    static pshr create(int64_t length, int64_t n, FFTPlanType type, FFTDirection dir, double scale) {
+        if (length < 1 || n < 1) throw std::runtime_error("FFTPlanReal1D: length and n must be positive");
+        return pshr(new HipFFTPlanReal1D(length, n, type, dir, scale));
+    }
+    void exec() {
+        double * traw = data_.data();
+        double * fraw = data_.data() + n_ * length_;
+        if (dir_ == FFTDirection::forward) {
+            check(toast_hip_fft_r1d(1, length_, n_, traw, fraw, scale_, 0));
+        } else {
+            check(toast_hip_fft_r1d(0, length_, n_, fraw, traw, scale_, 0));
+        }
+    }
+    double * tdata(int64_t indx) { return data_.data() + checked(indx) * length_; }
+    double * fdata(int64_t indx) { return data_.data() + (n_ + checked(indx)) * length_; }
+    int64_t length() const { return length_; }
+    int64_t count() const { return n_; }
+
+private:
+    HipFFTPlanReal1D(int64_t length, int64_t n, FFTPlanType type, FFTDirection dir, double scale)
+        : length_(length), n_(n), scale_(scale), type_(type), dir_(dir), data_((size_t)(2 * n * length), 0.0) {}
+    int64_t checked(int64_t indx) const {
+        if (indx < 0 || indx >= n_) throw py::index_error("FFTPlanReal1D: buffer index out of range");
+        return indx;
+    }
+    int64_t length_, n_;
+    double scale_;
+    FFTPlanType type_;
+    FFTDirection dir_;
+    std::vector<double> data_;
+};
+
+class HipFFTPlanReal1DStore {
+public:
+    static HipFFTPlanReal1DStore & get() {
+        static HipFFTPlanReal1DStore instance;
+        return instance;
+    }
+    void clear() {
+        fplans_.clear();
+        rplans_.clear();
+    }
+    void cache(int64_t len, int64_t n) {
+        forward(len, n);
+        backward(len, n);
+    }
+    HipFFTPlanReal1D::pshr forward(int64_t len, int64_t n) { return fetch(fplans_, len, n, FFTDirection::forward); }
+    HipFFTPlanReal1D::pshr backward(int64_t len, int64_t n) { return fetch(rplans_, len, n, FFTDirection::backward); }
+
+private:
+    typedef std::map<std::pair<int64_t, int64_t>, HipFFTPlanReal1D::pshr> plan_map;
+    static HipFFTPlanReal1D::pshr fetch(plan_map & plans, int64_t len, int64_t n, FFTDirection dir) {
+        auto key = std::make_pair(len, n);
+        auto it = plans.find(key);
+        if (it == plans.end()) {
+            it = plans.emplace(key, HipFFTPlanReal1D::create(len, n, FFTPlanType::fast, dir, 1.0)).first;
+        }
+        return it->second;
+    }
+    plan_map fplans_, rplans_;
+};
 
 PYBIND11_MODULE(_libtoast_hip, m) {
     m.doc() = "MI355X (gfx950) implementation of toast._libtoast's map-making hot path";
@@ -507,4 +585,32 @@ PYBIND11_MODULE(_libtoast_hip, m) {
                                                 static_cast<double *>(ic.ptr), threshold, invert, use_accel));
     }, py::arg("nsub"), py::arg("nsubpix"), py::arg("nnz"), py::arg("data"), py::arg("cond"),
        py::arg("threshold"), py::arg("invert"), py::arg("use_accel") = false);
+
+    // math_fft.cpp:8-175
+    py::enum_<FFTPlanType>(m, "FFTPlanType", "FFT Plan Type")
+        .value("fast", FFTPlanType::fast)
+        .value("best", FFTPlanType::best);
+    py::enum_<FFTDirection>(m, "FFTDirection", "FFT Direction")
+        .value("forward", FFTDirection::forward)
+        .value("backward", FFTDirection::backward);
+    py::class_<HipFFTPlanReal1D, HipFFTPlanReal1D::pshr>(m, "FFTPlanReal1D")
+        .def_static("create", &HipFFTPlanReal1D::create, py::arg("length"), py::arg("n"), py::arg("type"),
+                    py::arg("dir"), py::arg("scale"))
+        .def("exec", &HipFFTPlanReal1D::exec)
+        .def("length", &HipFFTPlanReal1D::length)
+        .def("count", &HipFFTPlanReal1D::count)
+        .def("tdata", [](HipFFTPlanReal1D & self, int64_t indx) {
+            return py::array_t<double>({self.length()}, {sizeof(double)}, self.tdata(indx), py::cast(self));
+        }, py::return_value_policy::reference_internal)
+        .def("fdata", [](HipFFTPlanReal1D & self, int64_t indx) {
+            return py::array_t<double>({self.length()}, {sizeof(double)}, self.fdata(indx), py::cast(self));
+        }, py::return_value_policy::reference_internal);
+    py::class_<HipFFTPlanReal1DStore, std::unique_ptr<HipFFTPlanReal1DStore, py::nodelete>>(m, "FFTPlanReal1DStore")
+        .def("get", []() {
+            return std::unique_ptr<HipFFTPlanReal1DStore, py::nodelete>(&HipFFTPlanReal1DStore::get());
+        })
+        .def("clear", &HipFFTPlanReal1DStore::clear)
+        .def("cache", &HipFFTPlanReal1DStore::cache, py::arg("length"), py::arg("n"))
+        .def("forward", &HipFFTPlanReal1DStore::forward, py::arg("length"), py::arg("n"))
+        .def("backward", &HipFFTPlanReal1DStore::backward, py::arg("length"), py::arg("n"));
 }

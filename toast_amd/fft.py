@@ -186,25 +186,40 @@ def convolve(raw, rate, flags=None, flag_mask=None, kernel_freq=None, kernels=No
             flags[itod][-ext:] |= flag_mask
 
 
-def r1d_forward(indata):
-    """Batched real FFT in FFTW half-complex layout (reference fft.py:26-68)."""
+def _r1d(indata, direction):
+    """The reference's r1d_forward / r1d_backward (src/toast/fft.py:26-117) on the plan store of
+    the native module: copy into the plan's buffers, exec, copy out."""
+    import toast_amd
+
     from .accel import ensure_assigned
 
     ensure_assigned()
-    x = np.ascontiguousarray(np.atleast_2d(indata), dtype=np.float64)
-    out = np.empty_like(x)
-    capi._check(capi.lib().toast_hip_fft_r1d(C.c_int(1), C.c_int64(x.shape[1]), C.c_int64(x.shape[0]), _p(x), _p(out),
-                                             C.c_double(1.0), C.c_int(0)))
-    return out[0] if np.ndim(indata) == 1 else out
+    m = toast_amd.load_native()
+    x = np.asarray(indata, dtype=np.float64)
+    one = x.ndim == 1
+    count, length = (1, x.shape[0]) if one else x.shape
+    store = m.FFTPlanReal1DStore.get()
+    plan = store.forward(length, count) if direction == "forward" else store.backward(length, count)
+    src, dst = (plan.tdata, plan.fdata) if direction == "forward" else (plan.fdata, plan.tdata)
+    if one:
+        src(0)[:] = x
+    else:
+        for i in range(count):
+            src(i)[:] = x[i]
+    plan.exec()
+    if one:
+        return np.array(dst(0))
+    out = np.zeros_like(x)
+    for i in range(count):
+        out[i] = dst(i)
+    return out
+
+
+def r1d_forward(indata):
+    """Batched real FFT in FFTW half-complex layout (reference fft.py:26-68)."""
+    return _r1d(indata, "forward")
 
 
 def r1d_backward(indata):
     """Inverse of :func:`r1d_forward` (scaled by 1/length; reference fft.py:71-117)."""
-    from .accel import ensure_assigned
-
-    ensure_assigned()
-    x = np.ascontiguousarray(np.atleast_2d(indata), dtype=np.float64)
-    out = np.empty_like(x)
-    capi._check(capi.lib().toast_hip_fft_r1d(C.c_int(0), C.c_int64(x.shape[1]), C.c_int64(x.shape[0]), _p(x), _p(out),
-                                             C.c_double(1.0), C.c_int(0)))
-    return out[0] if np.ndim(indata) == 1 else out
+    return _r1d(indata, "backward")
