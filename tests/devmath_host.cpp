@@ -1,6 +1,7 @@
 // Host build of toast_amd/csrc/hpix_math.hpp (the device pointing math) so that its
 // bit-parity with the oracle can be measured on a CPU: tests/test_devmath_host.py.
 // Test harness only -- the product never runs this code on the host.
+#include <cmath>
 #include <cstdint>
 #include "../toast_amd/csrc/hpix_math.hpp"
 
@@ -33,6 +34,95 @@ void devmath_vec2pix(int64_t n, const double * vec, int64_t nside, int nest, int
         const ZPhi a = zphi_from_vec(vec + 3 * i, kAtanTab);
         pix[i] = nest ? zphi_to_nest(nside, factor, a) : zphi_to_ring(nside, factor, a);
     }
+}
+
+// the shipped pixel path (Ziv-style: plain-double atan2, double-double only when not provably equal)
+void devmath_pixels_fast(int64_t n, const double * quats, int64_t nside, int nest, int64_t * pix) {
+    int factor = 0;
+    while (nside != (int64_t(1) << factor)) ++factor;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        double dir[3];
+        quat_rotate_z(quats + 4 * i, dir);
+        pix[i] = nest ? vec_to_pixel<true>(dir, nside, factor, kAtanTab) : vec_to_pixel<false>(dir, nside, factor, kAtanTab);
+    }
+}
+
+void devmath_vec2pix_fast(int64_t n, const double * vec, int64_t nside, int nest, int64_t * pix) {
+    int factor = 0;
+    while (nside != (int64_t(1) << factor)) ++factor;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        pix[i] = nest ? vec_to_pixel<true>(vec + 3 * i, nside, factor, kAtanTab)
+                      : vec_to_pixel<false>(vec + 3 * i, nside, factor, kAtanTab);
+    }
+}
+
+void devmath_atan2_fast(int64_t n, const double * y, const double * x, double * out) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) out[i] = atan2_fast(y[i], x[i]);
+}
+
+// Self-contained sweep: n pseudo-random unit vectors (splitmix64 from `seed`; every 8th one pushed
+// onto a decision boundary |z| = 2/3, a face meridian or a pole within a few ulp), pixel by the
+// fast path vs the double-double path.  Returns the number of mismatches; *n_fallback counts the
+// samples the fast path handed to the slow one (*n_fallback_random: among the 7/8 of purely
+// random directions), *max_err the largest |atan2_fast - atan2_dd|.
+int64_t devmath_sweep(int64_t n, uint64_t seed, int64_t nside, int nest, int64_t * n_fallback,
+                      int64_t * n_fallback_random, double * max_err) {
+    int factor = 0;
+    while (nside != (int64_t(1) << factor)) ++factor;
+    int64_t bad = 0, fb = 0, fbr = 0;
+    double worst = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : bad, fb, fbr) reduction(max : worst)
+    for (int64_t i = 0; i < n; ++i) {
+        uint64_t st = seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1);
+        auto next = [&st]() {
+            uint64_t z = (st += 0x9E3779B97F4A7C15ull);
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            return z ^ (z >> 31);
+        };
+        auto unif = [&next]() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); };
+        double z = 2.0 * unif() - 1.0;
+        double phi = TOAST_TWOPI * unif() - 3.14159265358979323846;
+        const uint64_t kind = next() & 63;
+        if (kind == 0) z = (next() & 1) ? TOAST_TWOTHIRDS : -TOAST_TWOTHIRDS;
+        if (kind == 1) phi = 1.5707963267948966 * (double)((int64_t)(next() % 5) - 2);
+        if (kind == 2) z = (next() & 1) ? 1.0 : -1.0;
+        if (kind == 3) phi = 0.0;
+        if (kind < 8) {   // nudge by up to +-4 ulp
+            const int64_t k = (int64_t)(next() % 9) - 4;
+            union { double d; int64_t i; } w;
+            w.d = (kind & 1) ? phi : z;
+            w.i += k;
+            if (kind & 1) phi = w.d; else z = w.d;
+        }
+        const double rxy = f_sqrt((1.0 - z) * (1.0 + z) > 0 ? (1.0 - z) * (1.0 + z) : 0.0);
+        const double v[3] = {rxy * std::cos(phi), rxy * std::sin(phi), z};
+        ZPhi a = zphi_from_vec(v, kAtanTab);
+        const int64_t want = nest ? zphi_to_nest(nside, factor, a) : zphi_to_ring(nside, factor, a);
+        const int64_t got = nest ? vec_to_pixel<true>(v, nside, factor, kAtanTab) : vec_to_pixel<false>(v, nside, factor, kAtanTab);
+        bad += (got != want);
+        ZPhi b = zphi_head(v);
+        b.phi = atan2_fast(v[1], v[0]);
+        bool safe;
+        if (nside <= 8192) {
+            (void)(nest ? pixel_checked<int32_t, true>((int32_t)nside, factor, b, TOAST_ATAN2_FAST_ERR, safe)
+                        : pixel_checked<int32_t, false>((int32_t)nside, factor, b, TOAST_ATAN2_FAST_ERR, safe));
+        } else {
+            (void)(nest ? pixel_checked<int64_t, true>(nside, factor, b, TOAST_ATAN2_FAST_ERR, safe)
+                        : pixel_checked<int64_t, false>(nside, factor, b, TOAST_ATAN2_FAST_ERR, safe));
+        }
+        fb += !safe;
+        fbr += (!safe && kind >= 8);
+        const double e = f_abs(b.phi - a.phi);
+        if (e == e && e > worst) worst = e;
+    }
+    *n_fallback = fb;
+    *n_fallback_random = fbr;
+    *max_err = worst;
+    return bad;
 }
 
 void devmath_stokes(int64_t n, const double * quats, double * c2a, double * s2a) {

@@ -19,7 +19,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtoast_hip.so")
+# TOAST_HIP_LIBRARY: load another build of the same library (kernel experiments, profiles/)
+LIB_PATH = os.environ.get("TOAST_HIP_LIBRARY") or os.path.join(_HERE, "libtoast_hip.so")
 
 interval_dtype = np.dtype(
     {

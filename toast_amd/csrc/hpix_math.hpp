@@ -166,6 +166,55 @@ TOAST_HD double atan2_dd(double y, double x, const double * tab) {
     return yneg ? -r : r;
 }
 
+// atan2 in plain double precision, for the Ziv-style fast path of the pixel computation
+// (vec_to_pixel below): absolute error < 2^-46 = 1.4e-14 for finite arguments with a normal
+// |larger| component, anything else comes out as NaN or as a value the caller's safety check
+// rejects.  t = small / big with a 4-step Newton reciprocal (2e-15 relative), atan(t) = t P(t^2)
+// with the 17-term Chebyshev fit of atan(sqrt(s)) / sqrt(s) on [0, 1] (7.6e-15 absolute,
+// mpmath.chebyfit at 60 digits), octant fix-ups like atan2_dd.  ~55 FP64 instructions against
+// ~220 for the double-double evaluation.
+#if defined(__HIPCC__)
+# define TOAST_CONST_TABLE static __constant__ const
+#else
+# define TOAST_CONST_TABLE static const
+#endif
+TOAST_CONST_TABLE double kAtanFastPoly[17] = {
+    7.06314263588804606e-05,  -6.77410539964507603e-04, 3.06599570281080062e-03,  -8.79243554221763486e-03,
+    1.81985704853957868e-02,  -2.95890121943443718e-02, 4.05177897712506591e-02,  -4.97799667595504730e-02,
+    5.79419231688184516e-02,  -6.64614579022125423e-02, 7.68881166240129449e-02,  -9.09048964779903268e-02,
+    1.11110775849717722e-01,  -1.42857126460503997e-01, 1.99999999574818260e-01,  -3.33333333328939774e-01,
+    9.99999999999992450e-01};
+#define TOAST_ATAN2_FAST_ERR 1.1368683772161603e-13   /* 2^-43: bound used by the caller, 8x the budget */
+TOAST_HD double atan2_fast(double y, double x) {
+    const double ax = f_abs(x);
+    const double ay = f_abs(y);
+    const bool swap = ay > ax;
+    const double big = swap ? ay : ax;
+    const double small = swap ? ax : ay;
+    union {
+        double d;
+        int64_t i;
+    } u;
+    u.d = big;
+    u.i = 0x7FDE623822FC16E6ll - u.i;
+    double r = u.d;
+    r = r * f_fma(-big, r, 2.0);
+    r = r * f_fma(-big, r, 2.0);
+    r = r * f_fma(-big, r, 2.0);
+    r = r * f_fma(-big, r, 2.0);
+    const double t = small * r;
+    const double s = t * t;
+    // coefficients through the scalar unit (constant address space -> s_load -> SGPR operands): as
+    // literals the compiler parks all seventeen in VGPRs for the lifetime of the sample loop
+    double p = kAtanFastPoly[0];
+#pragma unroll
+    for (int k = 1; k < 17; ++k) p = f_fma(p, s, kAtanFastPoly[k]);
+    double a = t * p;
+    if (swap) a = kHalfPi_HI - a;
+    if (__builtin_signbit(x)) a = kPi_HI - a;
+    return __builtin_signbit(y) ? -a : a;
+}
+
 // ------------------------------------------------------------------ quaternions
 // Rotate v by unit quaternion q = [x, y, z, w]; literal operation order of the reference.
 TOAST_HD void quat_rotate(const double * q, const double * v, double * out) {
@@ -205,7 +254,8 @@ struct ZPhi {
     int region;  // sign(z) * (1 if |z| <= 2/3 else 2)
 };
 
-TOAST_HD ZPhi zphi_from_vec(const double * v, const double * atan_tab) {
+// everything of hpix_vec2zphi that does not need phi
+TOAST_HD ZPhi zphi_head(const double * v) {
     ZPhi o;
     o.z = v[2];
     const double za = f_abs(o.z);
@@ -213,6 +263,12 @@ TOAST_HD ZPhi zphi_from_vec(const double * v, const double * atan_tab) {
     o.region = (za <= TOAST_TWOTHIRDS) ? s : s + s;
     // the reference always evaluates sqrt(3 (1 - |z|)) but reads it only in the polar caps
     o.rtz = (o.region == 1 || o.region == -1) ? 0.0 : f_sqrt(3.0 * (1.0 - za));
+    o.phi = 0.0;
+    return o;
+}
+
+TOAST_HD ZPhi zphi_from_vec(const double * v, const double * atan_tab) {
+    ZPhi o = zphi_head(v);
     o.phi = atan2_dd(v[1], v[0], atan_tab);
     return o;
 }
@@ -350,6 +406,143 @@ TOAST_HD int64_t zphi_to_nest(int64_t nside, int factor, const ZPhi & a) {
 TOAST_HD int64_t zphi_to_ring(int64_t nside, int factor, const ZPhi & a) {
     if (nside <= 8192) return (int64_t)zphi_to_ring_t<int32_t>((int32_t)nside, factor, a);
     return zphi_to_ring_t<int64_t>(nside, factor, a);
+}
+
+// ------------------------------------------------------------------ Ziv-style fast path
+// The pixel index is a piecewise-constant function of phi.  pixel_checked evaluates the SAME
+// arithmetic as phi_to_tt + zphi_to_nest_t / zphi_to_ring_t on an approximate phi (atan2_fast,
+// |phi~ - phi| <= delta) and reports `safe` only if no decision of that arithmetic can come out
+// differently for ANY phi' with |phi' - phi~| <= delta: every operand of a float -> integer
+// truncation must be farther than `bound` from an integer and the zero-snap / sign test of
+// phi_to_tt farther than delta from its thresholds.  Error propagation (every operation is
+// monotone; dn = nside, a power of two, so dn * tt is exact):
+//   |d tt| <= (2 / pi) delta + 3 ulp(4)            <= delta          (delta = 2^-43 >> 1e-15)
+//   equatorial  t1 -+ t2:   dn |d tt| + 2 ulp(5 dn)  <= 1.03 dn delta
+//   polar  tp t1, (1 - tp) t1 (t1 = dn rtz <= dn):    <= 1.01 dn delta;   tt itself: delta
+//   ring polar  tt ir (ir < 2 dn):                    <= 2.01 dn delta
+// bound = 4 dn delta (and 4 delta for tt) covers all of them with a factor >= 2 to spare.  NaNs
+// fail every comparison, so non-finite input is never "safe".  When safe, the returned index is
+// by construction the one the double-double path produces; otherwise the caller recomputes with
+// atan2_dd.  At nside 1024 a sample is unsafe with probability ~3e-9.
+template <typename I, bool NEST>
+TOAST_HD I pixel_checked(I nside, int factor, const ZPhi & a, double delta, bool & safe) {
+    const double dn = (double)nside;
+    const double bound = 4.0 * dn * delta;
+    const double hi = 1.0 - bound;
+    // phi_to_tt, with the distance of pm to the snap interval checked
+    const double tol = 10.0 * 2.220446049250313e-16;
+    const double period = TOAST_TWOPI;
+    const double inv = 1.0 / TOAST_TWOPI;
+    const double q0 = a.phi * inv;
+    const double div = (q0 == 0.0) ? q0 : f_fma(f_fma(-q0, period, a.phi), inv, q0);
+    double pm = period * (div - (double)((int64_t)div));
+    bool ok = f_abs(pm) > tol + 2.0 * delta;
+    if ((pm < tol) && (pm > -tol)) pm = 0.0;
+    const double tt = (pm >= 0.0) ? pm * TOAST_2_OVER_PI : pm * TOAST_2_OVER_PI + 4.0;
+    const I nm1 = nside - 1;
+    I result;
+    if (a.region == 1 || a.region == -1) {
+        const double t1 = 0.5 * dn + dn * tt;
+        const double t2 = (0.75 * dn) * a.z;
+        const double wp = t1 - t2, wm = t1 + t2;
+        const I jp = (I)wp;
+        const I jm = (I)wm;
+        const double fp = wp - (double)jp, fm = wm - (double)jm;
+        ok = ok && (fp > bound) && (fp < hi) && (fm > bound) && (fm < hi);
+        if (NEST) {
+            const I ifp = jp >> factor;
+            const I ifm = jm >> factor;
+            I face;
+            if (ifp == ifm) {
+                face = (ifp == 4) ? (I)4 : ifp + 4;
+            } else if (ifp < ifm) {
+                face = ifp;
+            } else {
+                face = ifm + 8;
+            }
+            const I x = jm & nm1;
+            const I y = nm1 - (jp & nm1);
+            result = morton_interleave<I>(x, y) + (face << (2 * factor));
+        } else {
+            const I n4 = 4 * nside;
+            const I ncap = 2 * (nside * nside - nside);
+            const I ir = (nside + 1) + jp - jm;
+            const I kshift = 1 - (ir & 1);
+            I ip = (jp + jm - nside + kshift + 1) >> 1;
+            ip = (ip >= 0) ? (ip & (n4 - 1)) : -((-ip) & (n4 - 1));
+            result = ncap + ((ir - 1) * n4 + ip);
+        }
+    } else {
+        const I ntt = (I)tt;
+        const double tp = tt - (double)ntt;      // == tt - floor(tt) for tt >= 0
+        const double tb = 4.0 * delta;
+        ok = ok && (tp > tb) && (tp < 1.0 - tb);
+        const double t1 = dn * a.rtz;
+        const double wp = tp * t1, wm = (1.0 - tp) * t1;
+        I jp = (I)wp;
+        I jm = (I)wm;
+        const double fp = wp - (double)jp, fm = wm - (double)jm;
+        ok = ok && (fp > bound) && (fp < hi) && (fm > bound) && (fm < hi);
+        if (NEST) {
+            if (jp >= nside) jp = nm1;
+            if (jm >= nside) jm = nm1;
+            I x, y, face;
+            if (a.z >= 0) {
+                face = ntt;
+                x = nm1 - jm;
+                y = nm1 - jp;
+            } else {
+                face = ntt + 8;
+                x = jp;
+                y = jm;
+            }
+            result = morton_interleave<I>(x, y) + (face << (2 * factor));
+        } else {
+            const I ir = jp + jm + 1;
+            const double wi = tt * (double)ir;
+            I ip = (I)wi;
+            const double fi = wi - (double)ip;
+            ok = ok && (fi > bound) && (fi < hi);
+            const I four_ir = 4 * ir;
+            if (ip >= four_ir) ip -= (ip >= 2 * four_ir) ? ip / four_ir : 1;
+            const I npix = 12 * nside * nside;
+            result = (a.region > 0) ? (2 * ir * (ir - 1) + ip) : (npix - 2 * ir * (ir + 1) + ip);
+        }
+    }
+    safe = ok;
+    return result;
+}
+
+// The double-double path, kept out of line: it runs for ~1e-9 of the samples and must not set the
+// register allocation of the kernels that inline vec_to_pixel.
+#if defined(TOAST_PIXEL_SLOW_INLINE)   /* experiment switch, profiles/r02_c */
+# define TOAST_NOINLINE TOAST_HD
+#elif defined(__HIPCC__)
+# define TOAST_NOINLINE __host__ __device__ __attribute__((noinline))
+#else
+# define TOAST_NOINLINE __attribute__((noinline))
+#endif
+template <bool NEST>
+TOAST_NOINLINE int64_t vec_to_pixel_slow(const double * v, int64_t nside, int factor, const double * atan_tab) {
+    const ZPhi a = zphi_from_vec(v, atan_tab);
+    return NEST ? zphi_to_nest(nside, factor, a) : zphi_to_ring(nside, factor, a);
+}
+
+// Pixel of a direction vector: fast path first, double-double atan2 only where the fast result
+// is not provably the same.  Bit-identical to zphi_from_vec + zphi_to_nest / zphi_to_ring.
+template <bool NEST>
+TOAST_HD int64_t vec_to_pixel(const double * v, int64_t nside, int factor, const double * atan_tab) {
+    ZPhi a = zphi_head(v);
+    a.phi = atan2_fast(v[1], v[0]);
+    bool safe;
+    int64_t pix;
+    if (nside <= 8192) {
+        pix = (int64_t)pixel_checked<int32_t, NEST>((int32_t)nside, factor, a, TOAST_ATAN2_FAST_ERR, safe);
+    } else {
+        pix = pixel_checked<int64_t, NEST>(nside, factor, a, TOAST_ATAN2_FAST_ERR, safe);
+    }
+    if (__builtin_expect(!safe, 0)) pix = vec_to_pixel_slow<NEST>(v, nside, factor, atan_tab);
+    return pix;
 }
 
 // quat_rotate(q, (1,0,0)) for finite q (same reasoning as quat_rotate_z).

@@ -76,8 +76,7 @@ __global__ __launch_bounds__(kThreads) void k_pixels_healpix(
             const double qa[4] = {q.x, q.y, q.z, q.w};
             double dir[3];
             quat_rotate_z(qa, dir);
-            const ZPhi a = zphi_from_vec(dir, s_tab);
-            int64_t pix = NEST ? zphi_to_nest(nside, factor, a) : zphi_to_ring(nside, factor, a);
+            int64_t pix = vec_to_pixel<NEST>(dir, nside, factor, s_tab);
             const bool flagged = use_flags && ((flags[s] & mask) != 0);
             int64_t sub = -1;
             if (flagged) {

@@ -141,8 +141,7 @@ __device__ __forceinline__ int64_t otf_point(const OtfDev & P, const DetConst & 
         if (flagged) return -1;
         double dir[3];
         quat_rotate_z(r, dir);
-        const ZPhi a = zphi_from_vec(dir, s_tab);
-        const int64_t pix = NEST ? zphi_to_nest(P.nside, P.factor, a) : zphi_to_ring(P.nside, P.factor, a);
+        const int64_t pix = vec_to_pixel<NEST>(dir, P.nside, P.factor, s_tab);
         if constexpr (PIX == 2) return pix;
         const int64_t gsm = fastdiv(pix, P.nps_div);
         return P.g2l[gsm] * P.nps_div.d + (pix - gsm * P.nps_div.d);
