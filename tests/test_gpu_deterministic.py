@@ -1,0 +1,167 @@
+"""GPU: the two "identical to the reference, not only close to it" switches.
+
+* Deterministic debug mode (TOAST_HIP_DETERMINISTIC=1 / capi.set_deterministic): build_noise_weighted
+  and build_inverse_covariance sum every pixel in (detector, interval, sample) order like the
+  reference's host path (ops_mapmaker_utils.cpp:294-378, toast_map_cov.cpp:96-153) -- the result is
+  BIT-identical to the reference's own outputs (tests/golden/chain_*.npz, cov_filter.npz), to the
+  oracle, and from run to run; the default atomic kernels agree with it to 1e-12.
+* toast_hip_set_stokes_reference_nan: NaN Q / U weights exactly where the reference produces them."""
+import numpy as np
+import pytest
+
+import cases
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def hip():
+    from toast_amd import capi
+
+    assert capi.accel_enabled()
+    capi.accel_assign_device(1, 0, 1.0, False)
+    capi.set_deterministic(True)
+    yield capi
+    capi.set_deterministic(False)
+    capi.set_stokes_reference_nan(False)
+
+
+def _bnw(impl, c, g2l, zmap, pixels, weights, tail=()):
+    impl.build_noise_weighted(g2l, zmap, c["pixel_index"], pixels, c["weight_index"], weights, c["data_index"],
+                              c["tod"], c["flag_index"], c["det_flags"], c["det_scale"], 1, c["intervals"],
+                              c["shared_flags"], 1, *tail)
+
+
+@pytest.mark.parametrize("name", gu.CHAINS)
+def test_deterministic_zmap_and_invcov_equal_reference_outputs_bit_for_bit(hip, name):
+    import toast_amd
+
+    assert hip.get_deterministic()
+    case, want, nest, iau = gu.load_chain(name)
+    pixels, weights, g2l = want["pixels"], want["weights"], want["g2l"]
+    runs = []
+    for _ in range(2):
+        zmap = np.zeros_like(want["zmap"])
+        _bnw(hip, case, g2l, zmap, pixels, weights, tail=(False,))
+        runs.append(zmap)
+    assert np.array_equal(runs[0], runs[1])                       # run to run
+    assert np.array_equal(runs[0], want["zmap"])                  # == the reference's own host path
+    # the default kernels (atomics) stay within the parity bar of the same numbers
+    hip.set_deterministic(False)
+    zmap = np.zeros_like(want["zmap"])
+    _bnw(hip, case, g2l, zmap, pixels, weights, tail=(False,))
+    hip.set_deterministic(True)
+    assert np.max(np.abs(zmap - want["zmap"])) <= 1e-12 * np.max(np.abs(want["zmap"]))
+    # inverse covariance against the reference's cov_accum_diag_invnpp outputs
+    m = toast_amd.load_native()
+    g = gu.load("cov_filter")
+    want_invcov = g[name + "_invcov"]
+    invcov = np.zeros_like(want_invcov)
+    m.build_inverse_covariance(np.ascontiguousarray(g2l), invcov, case["pixel_index"], np.ascontiguousarray(pixels),
+                               case["weight_index"], np.ascontiguousarray(weights), case["flag_index"],
+                               case["det_flags"], case["det_scale"], 1, case["intervals"], case["shared_flags"], 1, False)
+    assert np.array_equal(invcov, want_invcov)
+
+
+CASES = {
+    "default": dict(),
+    "split_gap_extra": dict(n_split=3, gap=5, extra_rows=2),
+    "ragged": dict(n_samp=1029, n_split=4, gap=1, n_det=3, nside=256),
+    "no_flags": dict(with_det_flags=False, with_shared_flags=False, n_samp=4097, nside=512),
+    "ground_nside2048": dict(ground=True, n_samp=72000, rate=100.0, nside=2048, n_det=6),
+    "many_hits": dict(n_det=16, n_samp=60000, nside=16, nside_submap=4),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_deterministic_accumulate_equals_oracle_bit_for_bit(hip, oracle, name):
+    """Same pointing into both: the oracle's chain provides pixels / weights, then A^T N^-1 d is
+    accumulated ON TOP of existing map content in two calls (the reference accumulates across
+    observations, mapmaker_utils.py:706-773) -- resident buffers (use_accel=True path)."""
+    import torch
+
+    c = cases.make_case(**CASES[name])
+    ref = cases.run_chain(oracle, c)
+    rng = np.random.default_rng(5)
+    start = rng.standard_normal(ref["zmap"].shape)
+    want = start.copy()
+    _bnw(oracle, c, ref["g2l"], want, ref["pixels"], ref["weights"])
+    c2 = dict(c)
+    c2["tod"] = np.ascontiguousarray(c["tod"][:, ::-1])
+    _bnw(oracle, c2, ref["g2l"], want, ref["pixels"], ref["weights"])
+    dev = torch.device("cuda")
+    D = hip.dev
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in
+         dict(g2l=ref["g2l"], z=start, pix=ref["pixels"], w=ref["weights"], tod=c["tod"], tod2=c2["tod"],
+              df=c["det_flags"], sf=c["shared_flags"]).items()}
+    n_samp = c["n_samp"]
+    nf = n_samp if c["det_flags"].shape[1] == n_samp else 0
+    ns = n_samp if c["shared_flags"].size == n_samp else 0
+    for tod in (t["tod"], t["tod2"]):
+        D.build_noise_weighted(t["g2l"].data_ptr(), t["z"].data_ptr(), c["n_pix_submap"], 3, c["pixel_index"],
+                               t["pix"].data_ptr(), c["weight_index"], t["w"].data_ptr(), c["data_index"],
+                               tod.data_ptr(), c["flag_index"], t["df"].data_ptr(), nf, c["det_scale"], 1, n_samp,
+                               c["intervals"], t["sf"].data_ptr(), ns, 1)
+    torch.cuda.synchronize()
+    assert np.array_equal(t["z"].cpu().numpy(), want)
+
+
+def test_operators_are_reproducible_in_deterministic_mode(hip):
+    """BinMap (hits, inverse covariance, noise-weighted map, binned map) twice from scratch, cached and
+    uncached pointing: every product bit-identical between the runs."""
+    from toast_amd import ops
+    from toast_amd.data import defaults
+    from toast_amd.sim import create_satellite_data
+
+    outs = []
+    for full_pointing in (True, False, True, False):
+        data = create_satellite_data(n_det=8, n_samp=40000, rate=50.0, spin_angle_deg=30.0, prec_angle_deg=60.0)
+        rng = np.random.default_rng(2)
+        data.obs[0].detdata[defaults.det_data].data[:] = rng.standard_normal((8, 40000))
+        dp = ops.PointingDetectorSimple()
+        pix = ops.PixelsHealpix(detector_pointing=dp, nside=64)
+        sw = ops.StokesWeights(detector_pointing=dp, mode="IQU", hwp_angle=defaults.hwp_angle)
+        binner = ops.BinMap(pixel_dist="dist", pixel_pointing=pix, stokes_weights=sw, full_pointing=full_pointing)
+        ops.MapMaker(name="mm", binning=binner, template_matrix=None, keep_final_products=True).apply(data)
+        outs.append({k: data[k].data.copy() for k in ("mm_hits", "mm_cov", "mm_noiseweighted_map", "mm_map")})
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[2][k]), k       # cached pointing, run to run
+        assert np.array_equal(outs[1][k], outs[3][k]), k       # uncached pointing, run to run
+    assert np.array_equal(outs[0]["mm_hits"], outs[1]["mm_hits"])
+
+
+@pytest.mark.parametrize("use_hwp", [False, True])
+def test_stokes_reference_nan_switch(hip, oracle, use_hwp):
+    """With the switch on, the Q / U weights are NaN at exactly the samples where the reference's
+    -sqrt(1 - z^2) is (ops_stokes_weights.cpp:66-75), finite and equal to 1e-13 everywhere else;
+    with it off (default) everything is finite."""
+    from test_gpu_pixels_adversarial import boundary_pointings, quats_pointing_at
+
+    rng = np.random.default_rng(3)
+    q = boundary_pointings(rng, n_each=2000)
+    th = np.concatenate([np.zeros(1000), np.full(1000, np.pi), rng.uniform(0, 1e-12, 1000),
+                         np.pi - rng.uniform(0, 1e-12, 1000), rng.uniform(0, 3e-8, 4000)])
+    q = np.concatenate([q, quats_pointing_at(th, rng.uniform(0, 2 * np.pi, th.size), rng.uniform(0, 2 * np.pi, th.size))])
+    n = q.shape[0]
+    quats = np.ascontiguousarray(q.reshape(1, n, 4))
+    iv = np.zeros(1, cases.interval_dtype)
+    iv["last"] = n
+    idx = np.zeros(1, np.int32)
+    hwp = rng.uniform(0, 2 * np.pi, n) if use_hwp else np.zeros(1)
+    eps, gamma, cal = np.array([0.1]), np.array([0.3]), np.array([1.7])
+    want = np.zeros((1, n, 3))
+    oracle.stokes_weights_IQU(idx, quats, idx, want, hwp, iv, eps, gamma, cal, False)
+    want_nan = np.isnan(want[0, :, 1])
+    assert want_nan.any() and np.array_equal(want_nan, np.isnan(want[0, :, 2]))
+    hip.set_stokes_reference_nan(True)
+    got = np.zeros((1, n, 3))
+    hip.stokes_weights_IQU(idx, quats, idx, got, hwp, iv, eps, gamma, cal, False, False)
+    assert np.array_equal(np.isnan(got[0, :, 1]), want_nan) and np.array_equal(np.isnan(got[0, :, 2]), want_nan)
+    assert not np.isnan(got[0, :, 0]).any()
+    ok = ~want_nan
+    assert np.max(np.abs(got[0][ok] - want[0][ok])) < 1e-13
+    hip.set_stokes_reference_nan(False)
+    got2 = np.zeros((1, n, 3))
+    hip.stokes_weights_IQU(idx, quats, idx, got2, hwp, iv, eps, gamma, cal, False, False)
+    assert not np.isnan(got2).any()

@@ -132,6 +132,20 @@ def real_lib():
     return _lib
 
 
+def set_deterministic(on):
+    """Order-deterministic A^T scatter (toast_hip_set_deterministic; also TOAST_HIP_DETERMINISTIC=1)."""
+    real_lib().toast_hip_set_deterministic(C.c_int(1 if on else 0))
+
+
+def get_deterministic():
+    return bool(real_lib().toast_hip_get_deterministic())
+
+
+def set_stokes_reference_nan(on):
+    """NaN Q / U weights where the reference's formulation produces them (poles within rounding)."""
+    real_lib().toast_hip_set_stokes_reference_nan(C.c_int(1 if on else 0))
+
+
 def accel_generation():
     """Memory-manager generation counter (toast_hip_accel_generation)."""
     out = C.c_uint64(0)

@@ -562,10 +562,18 @@ TOAST_HD void quat_rotate_x(const double * q, double * out) {
 //   cos 2a = (ax^2 - ay^2) / (ax^2 + ay^2),  sin 2a = 2 ax ay / (ax^2 + ay^2)
 // i.e. one reciprocal instead of two atan2 and two sincos (see the scaling argument below).  Weights are a
 // tolerance-class output (reference tests: assert_allclose), agreement ~1e-15 absolute.
-TOAST_HD void stokes_cs2alpha(const double * q, double & c2a, double & s2a) {
+// `reference_nan`: reproduce the one place where the reference formulation is NOT finite -- within
+// rounding of a pole vd2 * vd2 can exceed 1, its -sqrt(1 - vd2 * vd2) is NaN and so are alpha and
+// the Q / U weights (ops_stokes_weights.cpp:66-75).  Off by default (finite weights of modulus
+// eta * cal there); TOAST_HIP_STOKES_REFERENCE_NAN=1 / toast_hip_set_stokes_reference_nan(1).
+TOAST_HD void stokes_cs2alpha(const double * q, double & c2a, double & s2a, bool reference_nan = false) {
     double vd[3], vo[3];
     quat_rotate_z(q, vd);
     quat_rotate_x(q, vo);
+    if (reference_nan && (1.0 - vd[2] * vd[2] < 0.0)) {
+        c2a = s2a = __builtin_nan("");
+        return;
+    }
     const double r2 = vd[0] * vd[0] + vd[1] * vd[1];   // sin^2(theta)
     double ax, ay;
     if (r2 > 0.0) {

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(kThreads) void k_stokes_iqu(
     const int32_t * __restrict__ w_idx, const double * __restrict__ quats,
     double * __restrict__ weights, const double * __restrict__ hwp,
     const double * __restrict__ epsilon, const double * __restrict__ gamma,
-    const double * __restrict__ cal, double usign, int64_t n_samp) {
+    const double * __restrict__ cal, double usign, int64_t n_samp, int ref_nan) {
     const int det = blockIdx.x;
     const double eps = epsilon[det];
     const double eta = (1.0 - eps) / (1.0 + eps);
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(kThreads) void k_stokes_iqu(
             const Quat q = load_quat(qrow + 4 * s);
             const double qa[4] = {q.x, q.y, q.z, q.w};
             double c2a, s2a;
-            stokes_cs2alpha(qa, c2a, s2a);
+            stokes_cs2alpha(qa, c2a, s2a, ref_nan != 0);
             double * w = wrow + NOUT * s - (3 - NOUT);   // w[1], w[2] land in the last two slots
             if (HWP) {
                 // ang = 2 (2 (gamma - hwp) - alpha) = beta - 2 alpha, beta = 4 gamma - 4 hwp
@@ -1164,7 +1164,7 @@ static int stokes_weights_pol_dev(int n_out, const int32_t * quat_index, int64_t
                            as_stream(stream), (const Chunk *)(d + o_ch), (int)chunks.size(),
                            (const int32_t *)(d + o_qi), (const int32_t *)(d + o_wi), d_quats,
                            d_weights, d_hwp, (const double *)(d + o_e), (const double *)(d + o_g),
-                           (const double *)(d + o_c), usign, n_samp);
+                           (const double *)(d + o_c), usign, n_samp, stokes_reference_nan() ? 1 : 0);
         check_launch();
     });
 }
@@ -1283,6 +1283,14 @@ int toast_hip_build_noise_weighted_dev(
         if (chunks.empty()) return;
         const int use_d = (n_flag_samp == n_samp) ? 1 : 0;
         const int use_s = (n_shared_flags == n_samp) ? 1 : 0;
+        if (deterministic_mode()) {
+            // debug mode: the reference host path's summation order, bit for bit (deterministic.hip)
+            deterministic_scatter(0, d_g2l, d_zmap, n_pix_submap, nnz, pixel_index, d_pixels, weight_index,
+                                  d_weights, data_index, d_det_data, flag_index, d_det_flags, use_d, det_scale,
+                                  det_flag_mask, n_det, n_samp, intervals, n_view, d_shared_flags, use_s,
+                                  shared_flag_mask, as_stream(stream));
+            return;
+        }
         std::vector<int32_t> fidx(n_det, 0);
         if (use_d) std::memcpy(fidx.data(), flag_index, sizeof(int32_t) * n_det);
         ParamBlock pb;
@@ -1584,6 +1592,14 @@ int toast_hip_build_cov_dev(
         if (mode == 1) {
             std::memcpy(widx.data(), weight_index, sizeof(int32_t) * n_det);
             std::memcpy(dscale.data(), det_scale, sizeof(double) * n_det);
+        }
+        if (mode == 1 && deterministic_mode()) {
+            // (the hit map is integer: its atomic accumulation is order-independent already)
+            deterministic_scatter(1, d_g2l, (double *)d_out, n_pix_submap, nnz, pixel_index, d_pixels, widx.data(),
+                                  d_weights, nullptr, nullptr, fidx.data(), d_det_flags, use_d, dscale.data(),
+                                  det_flag_mask, n_det, n_samp, intervals, n_view, d_shared_flags, use_s,
+                                  shared_flag_mask, as_stream(stream));
+            return;
         }
         ParamBlock pb;
         const size_t o_ch = pb.push_vec(chunks);

@@ -37,6 +37,7 @@ struct OtfDev {
     int factor;
     int use_pflags;
     uint8_t pmask;
+    int ref_nan;              // reproduce the reference's NaN Q / U weights at the poles
 };
 
 struct DetConst {
@@ -117,7 +118,7 @@ __device__ __forceinline__ int64_t otf_point(const OtfDev & P, const DetConst & 
         w[0] = D.cd;
     } else {
         double c2a, s2a;
-        stokes_cs2alpha(r, c2a, s2a);
+        stokes_cs2alpha(r, c2a, s2a, P.ref_nan != 0);
         if constexpr (MODE == 2) {
             double sb, cb;
             hwp_rotation(D.c4g, D.s4g, c4h, s4h, cb, sb);
@@ -386,6 +387,7 @@ OtfHost otf_prepare(const toast_hip_otf_pointing * pt, int64_t n_det, int64_t n_
     d.hwp_tab = hwp ? pt->d_hwp_table : nullptr;
     if (d.hwp_tab != nullptr) need_aligned(d.hwp_tab, "hwp table");
     d.usign = pt->IAU ? -1.0 : 1.0;
+    d.ref_nan = stokes_reference_nan() ? 1 : 0;
     d.nside = pt->nside;
     d.nps_div = make_fastdiv(n_pix_submap);
     d.factor = log2_exact(pt->nside);

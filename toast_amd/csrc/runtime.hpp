@@ -90,6 +90,19 @@ size_t pin_threshold();
 int chunk_size();
 bool det_major_grid();
 bool pair_detectors();
+// TOAST_HIP_STOKES_REFERENCE_NAN=1 / toast_hip_set_stokes_reference_nan(): NaN Q / U weights where the
+// reference's formulation produces them (hpix_math.hpp: stokes_cs2alpha).
+bool stokes_reference_nan();
+// TOAST_HIP_DETERMINISTIC=1 / toast_hip_set_deterministic(): order-deterministic A^T scatter
+// (deterministic.hip) instead of the atomic kernels.
+bool deterministic_mode();
+void deterministic_scatter(int mode, const int64_t * d_g2l, double * d_out, int64_t n_pix_submap, int64_t nnz,
+                           const int32_t * pixel_index, const int64_t * d_pixels, const int32_t * weight_index,
+                           const double * d_weights, const int32_t * data_index, const double * d_det_data,
+                           const int32_t * flag_index, const uint8_t * d_det_flags, int use_d,
+                           const double * det_scale, uint8_t det_flag_mask, int64_t n_det, int64_t n_samp,
+                           const toast_hip_interval * intervals, int64_t n_view, const uint8_t * d_shared_flags,
+                           int use_s, uint8_t shared_flag_mask, hipStream_t st);
 std::vector<Chunk> make_chunks(const toast_hip_interval * ivl, int64_t n_view, int64_t n_samp);
 
 // ------------------------------------------------------------------ memory manager
@@ -119,7 +132,8 @@ public:
     hipStream_t stream() const { return stream_; }
     void set_stream(hipStream_t s) { stream_ = s; }
 
-    static constexpr int kScratchFftTime = 0, kScratchFftFreq = 1, kScratchDot = 2, kScratchFftWork = 3;
+    static constexpr int kScratchFftTime = 0, kScratchFftFreq = 1, kScratchDot = 2, kScratchFftWork = 3,
+                         kScratchSort = 4;
 
 private:
     std::map<std::pair<int, int>, std::pair<void *, size_t>> scratch_;   // (device, slot) -> (ptr, bytes)

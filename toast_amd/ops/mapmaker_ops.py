@@ -715,6 +715,10 @@ class BinMap(Operator):
 
         if self.full_pointing or not self.on_the_fly or use_accel is False or not accel_enabled():
             return False
+        from .. import capi
+
+        if capi.get_deterministic():
+            return False      # the on-the-fly accumulate kernels have no order-deterministic form
         if not otf_supported(self.pixel_pointing, self.stokes_weights):
             return False
         if self.pre_process is not None and not self.pre_process.supports_accel():

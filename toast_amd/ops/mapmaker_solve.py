@@ -229,6 +229,11 @@ class SolverLHS(Operator):
 
         if not (self.fused and accel_enabled()):
             return False
+        from .. import capi
+
+        if capi.get_deterministic():
+            # debug mode: only build_noise_weighted has an order-deterministic form (deterministic.hip)
+            return False
         if not self.binning.full_pointing:
             # uncached pointing: only through the on-the-fly kernels
             from .pointing import otf_supported
