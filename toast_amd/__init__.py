@@ -21,39 +21,12 @@ except ImportError:  # pragma: no cover
 __version__ = "0.1.0"
 
 
-def _seed_rocfft_cache():
-    """rocFFT compiles its kernels at run time (~1.9 s for the first 2^21-point plan on a fresh
-    machine).  Ship the compiled-kernel cache of the BASELINE transform lengths
-    (tools/make_rocfft_cache.py) and seed the user's cache file with it, unless the user already
-    points ROCFFT_RTC_CACHE_PATH somewhere.  A stale or unusable cache only means rocFFT compiles."""
-    import os
-    import shutil
-
-    if "ROCFFT_RTC_CACHE_PATH" in os.environ:
-        return
-    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rocfft_rtc_cache_gfx950.db")
-    if not os.path.isfile(src):
-        return
-    # working copy (rocFFT appends to it): next to the package when that is writable, else in
-    # the user's cache directory
-    here = os.path.dirname(os.path.abspath(__file__))
-    user = os.path.join(os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache"),
-                        "toast_amd")
-    for dst_dir in (os.path.join(here, ".rocfft_cache"), user):
-        try:
-            os.makedirs(dst_dir, exist_ok=True)
-            dst = os.path.join(dst_dir, "rocfft_rtc_cache_gfx950.db")
-            if not os.path.isfile(dst):
-                tmp = dst + ".%d.tmp" % os.getpid()
-                shutil.copyfile(src, tmp)
-                os.replace(tmp, dst)
-            os.environ["ROCFFT_RTC_CACHE_PATH"] = dst
-            return
-        except OSError:
-            continue
-
-
-_seed_rocfft_cache()
+# No import-time side effects: the rocFFT kernel-cache seeding of round 1 (a 0.5 MB binary copied
+# into the user's cache directory and ROCFFT_RTC_CACHE_PATH set at import) is gone.  The noise
+# weighting of map-making-sized timestreams runs on the hand-written kernels of csrc/fft_fused.hip
+# (nothing to compile at run time); rocFFT serves only short transforms and the FFTPlanReal1D
+# plans, where its one-off run-time compilation is its own documented behaviour
+# (tools/make_rocfft_cache.py builds a cache file for users who want to pre-seed it themselves).
 
 
 def load_native():

@@ -1,7 +1,9 @@
 """Populate a rocFFT runtime-compilation cache for the transform lengths of the BASELINE
-configurations (run on an MI355X with ROCFFT_RTC_CACHE_PATH pointing at the output file); the
-result is shipped as toast_amd/rocfft_rtc_cache_gfx950.db and seeded into the user's cache
-directory at import, which removes the ~1.9 s kernel build of the first NoiseFilter call."""
+configurations with the rocFFT pipeline forced (run on an MI355X with ROCFFT_RTC_CACHE_PATH pointing
+at the output file).  Nothing is shipped or seeded automatically any more: the default noise
+weighting runs on the fused kernels (csrc/fft_fused.hip), which need no run-time compilation; users
+of TOAST_HIP_FFT=rocfft who want to skip rocFFT's ~1.9 s first-plan build point
+ROCFFT_RTC_CACHE_PATH at the file this script writes."""
 import os
 import sys
 import time
@@ -15,6 +17,7 @@ from toast_amd import fft as hipfft
 from toast_amd.accel import ensure_assigned
 
 ensure_assigned()
+hipfft.select(True)   # the rocFFT pipeline for every length
 rate = 200.0
 freq = np.linspace(0, rate / 2, 64)
 kern = 1.0 / (1.0 + (0.05 / np.maximum(freq, 1e-4)))
