@@ -160,3 +160,25 @@ def test_configs4_shard_ground_filter_mapmaker(oracle):
         inside[int(iv["first"]):int(iv["last"])] = True
     nbad = int(np.count_nonzero(pix[sub][:, inside] != want[:, inside]))
     assert nbad == 0, f"{nbad} pixel mismatches"
+
+
+def test_scheduled_ground_observations_through_filter_and_mapmaker():
+    """configs[4] inputs from a schedule: ops.SimGround (two constant-elevation scans with
+    finite-acceleration turnarounds, one observation each) -> GroundFilter -> MapMaker; the ground
+    signal is removed in both observations and the hit map counts every unflagged sweep sample."""
+    from toast_amd.data import defaults
+
+    wf = _workflow("ground_filter_mapmaker")
+    data = wf.main(["--ndet", "8", "--minutes", "6", "--rate", "50", "--nside", "256", "--scheduled", "2", "--iter", "3"])
+    assert len(data.obs) == 2
+    n_good = 0
+    for ob in data.obs:
+        sf = ob.shared[defaults.shared_flags].data
+        science = (sf & defaults.shared_mask_nonscience) == 0
+        assert 0.5 < science.mean() < 0.98                     # turnarounds flagged, sweeps not
+        sig = ob.detdata[defaults.det_data].data
+        assert abs(np.std(sig[0][science]) - 1.0) < 0.05       # a 16 sigma ground signal is gone
+        pix = ob.detdata[defaults.pixels].data
+        good = _good_samples(ob, pix, ob.detdata[defaults.det_flags].data, sf, view=defaults.scanning_interval)
+        n_good += int(good.sum())
+    assert int(data["mapmaker_hits"].data.sum()) == n_good

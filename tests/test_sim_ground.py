@@ -1,0 +1,174 @@
+"""CPU: ops.SimGround (schedule-driven constant-elevation scans).
+
+* ``simulate_ces_scan`` against the outputs of the reference's own function
+  (tests/golden/sim_ground.npz, produced by tests/golden/make_golden_sim_ground.py): azimuth
+  profile, time stamps and all six interval lists bit for bit, including the randomised phase,
+  cosecant modulation, wrap across north and the stare short-circuit;
+* the schedule text formats (versions 4 / 3 / 2 / 1 of src/toast/schedule.py:386-520) and
+  ``file_split``;
+* the operator: observations per scan, interval lists from time spans with the reference's
+  half-open convention (intervals.py:150-175), turnaround bits in the shared flags, the horizontal
+  and equatorial boresight (geometry checks: elevation, azimuth, declination bound, rotation rate)."""
+import os
+
+import numpy as np
+import pytest
+
+from toast_amd import schedule as sch
+from toast_amd.data import Comm, Data, Focalplane, Telescope, defaults
+from toast_amd.ops import sim_ground as sg
+from toast_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sim_ground.npz")
+CASES = ("ces_basic", "ces_mount_rate", "ces_wrap", "ces_random_phase", "ces_cosecant", "ces_cosecant_setting", "stare",
+         "configs4_one_hour")
+NAMES = ("times", "az", "el", "min_az", "max_az", "scan_leftright", "turn_leftright", "scan_rightleft",
+         "turn_rightleft", "throw_leftright", "throw_rightleft")
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_simulate_ces_scan_equals_reference_outputs(name):
+    z = np.load(GOLDEN)
+    t0, t1, rate, el, azmin, azmax, azrate, fix, accel, cosec, rand = z[name + "_args"]
+    got = sg.simulate_ces_scan(t0, t1, rate, el, azmin, azmax, azmin, azrate, bool(fix), accel, azmin, azmax,
+                               cosecant_modulation=bool(cosec), randomize_phase=bool(rand))
+    for key, val in zip(NAMES, got):
+        want = z[f"{name}_{key}"]
+        arr = np.asarray(val, dtype=np.float64)
+        if key in ("times", "el"):
+            assert arr[0] == want[0] and arr[-1] == want[1] and arr.size == int(want[2])
+            if key == "times":
+                assert np.array_equal(arr, t0 + np.arange(arr.size) / rate)
+            else:
+                assert np.all(arr == arr[0])
+            continue
+        if key == "az" and arr.size > 8000:
+            arr = arr[::53]
+        if key.endswith(("leftright", "rightleft")):
+            arr = arr.reshape(-1, 2)
+        assert arr.shape == want.shape, key
+        assert np.array_equal(arr, want), key
+
+
+def _write(tmp_path, text, name="sched.txt"):
+    p = tmp_path / name
+    p.write_text(text)
+    return str(p)
+
+
+def test_schedule_text_formats(tmp_path):
+    head = "#Site | Telescope | Lat | Lon | Alt\nATACAMA | LAT | -22.958 | -67.786 | 5200.0\n#Start ...\n"
+    v4 = head + ("2027-01-01 00:00:00 | 2027-01-01 00:30:00 | 0.00 | patch_A | 40.00 | 75.00 | 50.00 | 0 | 0\n"
+                 "2027-01-01 00:31:00 | 2027-01-01 01:01:00 | 10.00 | patch_A | 285.00 | 320.00 | 50.00 | 0 | 1\n"
+                 "2027-01-01 01:02:00 | 2027-01-01 01:32:00 | 0.00 | patch_A | 40.00 | 75.00 | 52.00 | 1 | 0\n")
+    s = sch.GroundSchedule()
+    s.read(_write(tmp_path, v4))
+    assert (s.site_name, s.telescope_name, s.site_lat, s.site_lon, s.site_alt) == ("ATACAMA", "LAT", -22.958, -67.786, 5200.0)
+    assert len(s.scans) == 3 and s.scans[1].boresight_angle == 10.0 and s.scans[0].rising and not s.scans[1].rising
+    assert (s.scans[0].stop - s.scans[0].start).total_seconds() == 1800.0
+    assert s.scans[0].start.timestamp() == 1798761600.0     # UTC
+    # version 3: date and time in separate whitespace fields
+    v3 = head + "2027-01-01 00:00:00 2027-01-01 00:30:00 0.00 patch_B 40.00 75.00 50.00 0 0\n"
+    s3 = sch.GroundSchedule()
+    s3.read(_write(tmp_path, v3, "v3.txt"))
+    assert len(s3.scans) == 1 and s3.scans[0].name == "patch_B" and s3.scans[0].start == s.scans[0].start
+    # version 2: 22 verbose fields
+    v2 = head + ("2027-01-01 00:00:00 | 2027-01-01 00:30:00 | 61406.0 | 61406.02 | 5.0 | patch_C | 40.0 | 75.0 | 50.0 | R | "
+                 "1 | 2 | 3 | 4 | 5 | 6 | 7 | 8 | 0.5 | 3 | 1 | 0.1\n")
+    s2 = sch.GroundSchedule()
+    s2.read(_write(tmp_path, v2, "v2.txt"))
+    assert s2.scans[0].name == "patch_C" and s2.scans[0].boresight_angle == 5.0 and s2.scans[0].el == 50.0
+    # file_split: every second rising pass of a patch; the choice is made when the patch name changes and
+    # holds for its sub-scans (schedule.py:601-622)
+    alt = v4.replace("10.00 | patch_A", "10.00 | patch_B")
+    half = sch.GroundSchedule()
+    half.read(_write(tmp_path, alt, "again.txt"), file_split=(0, 2))
+    assert [(x.name, x.el) for x in half.scans] == [("patch_A", 50.0), ("patch_B", 50.0)]
+    other = sch.GroundSchedule()
+    other.read(_write(tmp_path, alt, "again.txt"), file_split=(1, 2))
+    assert [(x.name, x.el) for x in other.scans] == [("patch_A", 52.0)]
+    with pytest.raises(RuntimeError):
+        sch.GroundSchedule().read(_write(tmp_path, head + "not a schedule line\n", "bad.txt"))
+    # round trip through the writer
+    out = str(tmp_path / "out.txt")
+    s.write(out)
+    back = sch.GroundSchedule()
+    back.read(out)
+    assert [(x.name, x.az_min, x.az_max, x.el, x.start) for x in back.scans] == \
+           [(x.name, x.az_min, x.az_max, x.el, x.start) for x in s.scans]
+
+
+def test_sim_ground_operator():
+    rate, n_det = 20.0, 4
+    schedule = sch.make_ces_schedule(3, scan_seconds=600.0, gap_seconds=30.0, az_min=40.0, az_max=75.0, el=50.0)
+    fp_q, gamma = synth.hex_focalplane(n_det, fov_deg=4.0)
+    names = ["D%04d%s" % (i // 2, "AB"[i % 2]) for i in range(n_det)]
+    tele = Telescope("ground", Focalplane(names, fp_q, gamma=gamma, epsilon=np.zeros(n_det), sample_rate=rate))
+    data = Data(comm=Comm(use_dist=False))
+    op = sg.SimGround(telescope=tele, schedule=schedule, scan_rate_az=1.0, scan_accel_az=0.5, fix_rate_on_sky=False,
+                      hwp_angle=defaults.hwp_angle, hwp_rpm=60.0)
+    op.apply(data)
+    assert len(data.obs) == 3
+    for iob, ob in enumerate(data.obs):
+        n = ob.n_local_samples
+        assert n == int(600.0 * rate)      # 1 + int(rate * duration) samples requested, stop = start + (n - 1) / rate
+        times = ob.shared[defaults.times].data
+        az, el = ob.shared[defaults.azimuth].data, ob.shared[defaults.elevation].data
+        assert np.allclose(np.diff(times), 1.0 / rate) and np.all(el == np.radians(50.0))
+        lo, hi = (40.0, 75.0) if iob % 2 == 0 else (285.0, 320.0)
+        assert az.min() >= np.radians(lo) - 0.03 and az.max() <= np.radians(hi) + 0.03   # turnaround overshoot a^2 / (2 accel)
+        scanning = ob.intervals[defaults.scanning_interval].data
+        turn = ob.intervals[defaults.turnaround_interval].data
+        assert len(scanning) >= 2 * int(600.0 / (2 * 35.0 + 2 * 4.0)) and len(turn) >= len(scanning) - 1
+        flags = ob.shared[defaults.shared_flags].data
+        inside_turn = np.zeros(n, bool)
+        for iv in turn:
+            inside_turn[iv["first"]:iv["last"]] = True
+        assert np.array_equal(flags != 0, inside_turn) and set(np.unique(flags)) <= {0, defaults.shared_mask_unstable_scanrate}
+        # constant scan rate inside the sweeps, sign by direction
+        rate_az = np.diff(az) * rate
+        for name, sign in ((op.scan_leftright_interval, +1.0), (op.scan_rightleft_interval, -1.0)):
+            for iv in ob.intervals[name].data:
+                seg = rate_az[iv["first"] + 1:iv["last"] - 2]
+                assert np.allclose(seg, sign * np.radians(1.0), rtol=1e-4)   # time stamps ~1.8e9 s resolve 2.4e-7 s
+        # throws = scan + half of the turnarounds on either side; scanning + turnaround tile the observation
+        assert len(ob.intervals[op.throw_interval].data) >= 1
+        covered = inside_turn.copy()
+        for iv in scanning:
+            assert not covered[iv["first"]:iv["last"]].any()
+            covered[iv["first"]:iv["last"]] = True
+        assert covered[:-1].all()
+        # horizontal boresight: direction = (lon -az, lat el); focalplane X towards decreasing elevation
+        q = ob.shared[defaults.boresight_azel].data
+        z = np.array([synth_rotate(qi, np.array([0.0, 0.0, 1.0])) for qi in q[::97]])
+        assert np.allclose(np.arcsin(z[:, 2]), el[::97]) and np.allclose(np.arctan2(z[:, 1], z[:, 0]), -az[::97] % (2 * np.pi) - 2 * np.pi * (-az[::97] % (2 * np.pi) > np.pi))
+        x = np.array([synth_rotate(qi, np.array([1.0, 0.0, 0.0])) for qi in q[::97]])
+        assert np.all(x[:, 2] < 0)
+        # equatorial boresight: unit quaternions, declination within [lat - (90 - el), lat + (90 - el)],
+        # the frame turns at the sidereal rate
+        qr = ob.shared[defaults.boresight_radec].data
+        assert np.allclose(np.sum(qr * qr, axis=1), 1.0)
+        zr = np.array([synth_rotate(qi, np.array([0.0, 0.0, 1.0])) for qi in qr[::97]])
+        dec = np.degrees(np.arcsin(zr[:, 2]))
+        assert dec.min() >= -22.958 - 40.0 - 1e-6 and dec.max() <= -22.958 + 40.0 + 1e-6
+        hwp = ob.shared[defaults.hwp_angle].data
+        assert hwp[0] == 0.0 and np.isclose(hwp[int(rate)], 0.0, atol=1e-9) or np.isclose(hwp[int(rate)], 2 * np.pi, atol=1e-9)
+        assert ob.detdata[defaults.det_data].data.shape == (n_det, n) and ob.detdata[defaults.det_flags].data.dtype == np.uint8
+    era = sg.earth_rotation_angle(np.array([946728000.0, 946728000.0 + 86164.0905]))    # J2000.0 epoch, one sidereal day
+    assert abs(era[0] - 2 * np.pi * 0.7790572732640) < 1e-9 and abs((era[1] - era[0] + np.pi) % (2 * np.pi) - np.pi) < 1e-6
+
+
+def synth_rotate(q, v):
+    x, y, z, w = q
+    r = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    return r @ v
+
+
+def test_interval_conversion_conventions():
+    times = 100.0 + np.arange(50) / 10.0
+    spans = sg.timespans_to_samples(times, [(99.0, 100.35), (101.0, 102.0), (104.0, 104.9), (200.0, 300.0)])
+    # start <= t < stop; a span ending on the last stamp includes the last sample; spans outside are dropped
+    assert spans == [(0, 4), (10, 20), (40, 50)]
+    assert sg.union_spans(50, [(0, 4), (10, 20)], [(4, 7), (30, 31)]) == [(0, 7), (10, 20), (30, 31)]

@@ -21,3 +21,4 @@ from .noise_filter import NoiseFilter
 from .operator import Operator
 from .pipeline import Pipeline
 from .pointing import BuildPixelDistribution, PixelsHealpix, PointingDetectorSimple, StokesWeights
+from .sim_ground import SimGround

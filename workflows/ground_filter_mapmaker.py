@@ -35,6 +35,10 @@ def main(argv=None):
     ap.add_argument("--trend-order", type=int, default=5)
     ap.add_argument("--filter-order", type=int, default=5)
     ap.add_argument("--split", action="store_true", help="separate templates for left- and right-going sweeps")
+    ap.add_argument("--scheduled", type=int, default=0, metavar="N",
+                    help="build the observations with ops.SimGround from a schedule of N constant-elevation scans of "
+                         "--minutes each (finite-acceleration turnarounds, one observation per scan) instead of "
+                         "the synthetic single-observation generator")
     args = ap.parse_args(argv)
     n_samp = int(args.minutes * 60 * args.rate)
     t = time.time()
@@ -46,17 +50,30 @@ def main(argv=None):
         print(f"  {name:40s} {now - t:8.2f} s", flush=True)
         t = now
 
-    data = create_ground_data(n_det=args.ndet, n_samp=n_samp, rate=args.rate, az_min_deg=40.0, az_max_deg=110.0,
-                              scan_rate_deg_s=1.0, fov_deg=8.0)
+    if args.scheduled > 0:
+        from toast_amd.ops.sim_ground import create_ground_data_from_schedule
+        from toast_amd.schedule import make_ces_schedule
+
+        schedule = make_ces_schedule(args.scheduled, scan_seconds=args.minutes * 60.0, az_min=40.0, az_max=110.0, el=50.0)
+        data = create_ground_data_from_schedule(schedule, n_det=args.ndet, rate=args.rate, fov_deg=8.0,
+                                                scan_rate_az=1.0, scan_accel_az=1.0, fix_rate_on_sky=False)
+        for ob in data.obs:     # the map-maker skips samples with any non-science bit: raise "invalid" too
+            ob.shared[defaults.shared_flags].data[ob.shared[defaults.shared_flags].data != 0] |= defaults.shared_mask_invalid
+    else:
+        data = create_ground_data(n_det=args.ndet, n_samp=n_samp, rate=args.rate, az_min_deg=40.0, az_max_deg=110.0,
+                                  scan_rate_deg_s=1.0, fov_deg=8.0)
     data.lazy_host = True
-    ob = data.obs[0]
     rng = np.random.default_rng(1)
-    az = ob.shared[defaults.azimuth].data
-    phase = (az - az.min()) / (az.max() - az.min()) * 2 - 1
-    ground = 20.0 * (np.sin(3 * phase) + 0.5 * phase ** 2)
+    for ob in data.obs:
+        az = ob.shared[defaults.azimuth].data
+        phase = (az - az.min()) / (az.max() - az.min()) * 2 - 1
+        ground = 20.0 * (np.sin(3 * phase) + 0.5 * phase ** 2)
+        sig = ob.detdata[defaults.det_data].data
+        for d in range(sig.shape[0]):
+            sig[d] = rng.standard_normal(sig.shape[1]) + ground * (1.0 + 0.1 * rng.standard_normal())
+    ob = data.obs[0]
     sig = ob.detdata[defaults.det_data].data
-    for d in range(sig.shape[0]):
-        sig[d] = rng.standard_normal(n_samp) + ground * (1.0 + 0.1 * rng.standard_normal())
+    n_samp = ob.n_local_samples
     lap("simulate (host)")
     good = (ob.shared[defaults.shared_flags].data & 1) == 0
     rms_before = float(np.std(sig[0][good]))
@@ -77,7 +94,7 @@ def main(argv=None):
                           iter_min=args.iter, iter_max=args.iter, convergence=1e-30, keep_solver_products=True)
     mapper.apply(data)
     lap("MapMaker (cov + RHS + PCG + bin)")
-    nds = args.ndet * n_samp
+    nds = args.ndet * sum(o.n_local_samples for o in data.obs)
     n_views = len(ob.intervals[defaults.scanning_interval])
     print(f"detectors {args.ndet}  samples/det {n_samp}  sweeps {n_views}  nside {args.nside}  templates "
           f"{len(next(iter(gf.coefficients.values())))}  rcond mean {gf.rcondsum / max(gf.ngood + gf.nsingular, 1):.2e}")
