@@ -274,6 +274,7 @@ struct Params {
     const double * ang_coef;      // nullptr: real kernel
     const int32_t * knot_hint;    // interval index at the first bin of every block of 256 bins
     int per_det, deconvolve;
+    int aligned;                  // pass 1 may use padded_pair
     double fstep, scale;
 };
 
@@ -293,6 +294,51 @@ __device__ __forceinline__ double padded(const double * __restrict__ row, const 
     return 0.0;
 }
 
+// v[k] *= w_M^(k1 j2) for the thread's sixteen tile elements e = tid + 256 k.  When the tile has at most
+// 256 columns all sixteen share the column j2 and their rows are k1 = k1_0 + k (256 >> log_c): the
+// factors are w^(e0) (w^d)^k -- two table look-ups and a product tree instead of sixteen look-ups.
+__device__ __forceinline__ void col_twiddles(double2 (&v)[16], const Params & p, int tid, int log_c, int64_t c0) {
+    if (log_c <= 8) {
+        const int64_t j2 = c0 + (tid & ((1 << log_c) - 1));
+        const int64_t k10 = tid >> log_c;
+        const int64_t dk = kThreads >> log_c;
+        const double2 w0 = tw_big(p.tb, 2 * k10 * j2);
+        const double2 wd = tw_big(p.tb, 2 * dk * j2);
+        v[0] = cmul(v[0], w0);
+        apply_powers<16>(v, wd);
+#pragma unroll
+        for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], w0);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int e = tid + k * kThreads;
+            const int64_t k1 = e >> log_c;
+            const int64_t j2 = c0 + (e & ((1 << log_c) - 1));
+            v[k] = cmul(v[k], tw_big(p.tb, 2 * k1 * j2));
+        }
+    }
+}
+
+// the same for the pair (x[s + n_buffer], x[s + n_buffer + 1]), s even, when n_samp and n_reflect are even
+// and the row is 16-byte aligned: identical values (one product per element), half the loads
+__device__ __forceinline__ double2 padded_pair(const double * __restrict__ row, const double * __restrict__ apod,
+                                               int64_t s, int64_t n_samp, int64_t n_reflect) {
+    if (s >= 0 && s < n_samp) return *reinterpret_cast<const double2 *>(row + s);
+    if (s < 0 && s >= -n_reflect) {
+        const int64_t j = s + n_reflect;
+        const double2 r = *reinterpret_cast<const double2 *>(row + (n_reflect - 2 - j));
+        const double2 a = *reinterpret_cast<const double2 *>(apod + j);
+        return make_double2(r.y * a.x, r.x * a.y);
+    }
+    if (s >= n_samp && s < n_samp + n_reflect) {
+        const int64_t j = s - n_samp;
+        const double2 r = *reinterpret_cast<const double2 *>(row + (n_samp - 2 - j));
+        const double2 a = *reinterpret_cast<const double2 *>(apod + (n_reflect - 2 - j));
+        return make_double2(r.y * a.y, r.x * a.x);
+    }
+    return make_double2(0.0, 0.0);
+}
+
 // pass 1 (INV = false) and pass 3 (INV = true): transforms of length N1 down the columns
 template <bool INV>
 __global__ __launch_bounds__(kThreads, 2) void k_fft_cols(const Params p) {
@@ -307,12 +353,23 @@ __global__ __launch_bounds__(kThreads, 2) void k_fft_cols(const Params p) {
     double * __restrict__ row = p.tod + (int64_t)p.d_idx[p.det0 + b] * p.n_samp;
     double2 v[16];
     if (!INV) {
+        if (p.aligned) {
+            // n_buffer, n_samp, n_reflect even and 16-byte aligned rows: (x[2j], x[2j+1]) is one aligned
+            // pair of the timestream (reversed in the mirrored parts), one 16-byte load per point
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int e = tid + k * kThreads;
-            const int64_t j = ((int64_t)(e >> log_c) << p.log_n2) + c0 + (e & ((1 << log_c) - 1));
-            v[k].x = padded(row, p.apod, 2 * j, p.n_samp, p.n_buffer, p.n_reflect);
-            v[k].y = padded(row, p.apod, 2 * j + 1, p.n_samp, p.n_buffer, p.n_reflect);
+            for (int k = 0; k < 16; ++k) {
+                const int e = tid + k * kThreads;
+                const int64_t j = ((int64_t)(e >> log_c) << p.log_n2) + c0 + (e & ((1 << log_c) - 1));
+                v[k] = padded_pair(row, p.apod, 2 * j - p.n_buffer, p.n_samp, p.n_reflect);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int e = tid + k * kThreads;
+                const int64_t j = ((int64_t)(e >> log_c) << p.log_n2) + c0 + (e & ((1 << log_c) - 1));
+                v[k].x = padded(row, p.apod, 2 * j, p.n_samp, p.n_buffer, p.n_reflect);
+                v[k].y = padded(row, p.apod, 2 * j + 1, p.n_samp, p.n_buffer, p.n_reflect);
+            }
         }
     } else {
 #pragma unroll
@@ -320,17 +377,19 @@ __global__ __launch_bounds__(kThreads, 2) void k_fft_cols(const Params p) {
             const int e = tid + k * kThreads;
             const int64_t k1 = e >> log_c;
             const int64_t j2 = c0 + (e & ((1 << log_c) - 1));
-            v[k] = cmul(work[(k1 << p.log_n2) + j2], tw_big(p.tb, 2 * k1 * j2));
+            v[k] = work[(k1 << p.log_n2) + j2];
         }
+        col_twiddles(v, p, tid, log_c, c0);
     }
     tile_fft(v, sm, tid, p.log_n1, p.tb.wtile);
     if (!INV) {
+        col_twiddles(v, p, tid, log_c, c0);
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int e = tid + k * kThreads;
             const int64_t k1 = e >> log_c;
             const int64_t j2 = c0 + (e & ((1 << log_c) - 1));
-            work[(k1 << p.log_n2) + j2] = cmul(v[k], tw_big(p.tb, 2 * k1 * j2));
+            work[(k1 << p.log_n2) + j2] = v[k];
         }
     } else {
         // the transform ran on swapped data: Re z' = v.y, Im z' = v.x; crop + scale (fft.py:341-350)
@@ -571,6 +630,9 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
     p.per_det = per_det;
     p.deconvolve = deconvolve;
     p.fstep = fstep;
+    p.aligned = ((n_buffer % 2) == 0 && (n_samp % 2) == 0 && (n_reflect % 2) == 0 &&
+                 (reinterpret_cast<uintptr_t>(d_tod) % 16) == 0 && (reinterpret_cast<uintptr_t>(d_apod) % 16) == 0)
+                    ? 1 : 0;
     // unnormalised inverse of length M on un-halved packing factors: 1 / (4 M), a power of two
     p.scale = 1.0 / (4.0 * (double)m);
 

@@ -9,6 +9,7 @@ through ``toast_hip_fft_convolve`` (toast_amd/csrc/fft_filter.hip).
 """
 
 import ctypes as C
+import functools
 
 import numpy as np
 from scipy.interpolate import PchipInterpolator
@@ -37,15 +38,19 @@ def pipeline_bytes_per_sample(n_samp):
     return float(fn(C.c_int64(int(n_samp))))
 
 
+@functools.lru_cache(maxsize=8)
 def apodization(n_reflect):
     """First half of ``general_gaussian(2 n_reflect, p=3, sig=n_reflect // 2)``
-    (reference fft.py:163-171; formula of scipy.signal.windows.general_gaussian)."""
+    (reference fft.py:163-171; formula of scipy.signal.windows.general_gaussian).  Cached per length
+    (read-only array): the window of a cfg-3 timestream has 688 576 entries, 15 - 30 ms of exp()."""
     m = 2 * n_reflect
     n = np.arange(0, m) - (m - 1.0) / 2.0
     sig = n_reflect // 2
     with np.errstate(divide="ignore", invalid="ignore"):
         w = np.exp(-0.5 * np.abs(n / sig) ** (2 * 3.0))
-    return np.ascontiguousarray(w[:n_reflect])
+    out = np.ascontiguousarray(w[:n_reflect])
+    out.setflags(write=False)
+    return out
 
 
 def _pchip_coef(kernel_freq, values):
