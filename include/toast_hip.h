@@ -79,6 +79,14 @@ int toast_hip_accel_enabled(void);
  * is unchanged, device pointers obtained earlier are still the ones the manager would return
  * (lets a caller replay a prepared launch sequence without looking everything up again). */
 int toast_hip_accel_generation(uint64_t * generation);
+/* Raw device memory with the memory manager's allocation policy (flags = -1), a plain hipMalloc (0)
+ * or explicit hipExtMallocWithFlags flags (4 = physically contiguous): what bench.py and the
+ * placement experiments use so that they see the allocations the operators get. */
+int toast_hip_device_malloc(size_t nbytes, int flags, void ** out);
+int toast_hip_device_free(void * p);
+/* Experiment switches at run time (tools/exp_*.py): key "det_major" = 0 / 1 (workgroup order of the
+ * accumulate / scan kernels; the environment variable TOAST_HIP_DET_MAJOR sets the start-up value). */
+int toast_hip_set_tuning(const char * key, int value);
 
 /* Pick this process's GPU: device = node_rank / ceil(node_procs / n_device).  `disabled`
  * != 0 refuses all later use_accel work.  Clears previously registered buffers.

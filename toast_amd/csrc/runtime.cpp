@@ -33,14 +33,20 @@ int chunk_size() {
     return v;
 }
 
+namespace {
+int g_det_major = -1;   // -1: environment
+}
+
 bool det_major_grid() {
     // Experiment switch: detector-major instead of time-major workgroup order.
-    static const bool v = [] {
+    if (g_det_major < 0) {
         const char * e = std::getenv("TOAST_HIP_DET_MAJOR");
-        return e && e[0] == '1';
-    }();
-    return v;
+        g_det_major = (e && e[0] == '1') ? 1 : 0;
+    }
+    return g_det_major == 1;
 }
+
+void set_det_major_grid(int on) { g_det_major = on ? 1 : 0; }
 
 bool pair_detectors() {
     // TOAST_HIP_PAIR=0 disables the detector-pair accumulate kernels.
@@ -341,6 +347,27 @@ int Manager::present(const void * host, size_t nbytes) {
     return 1;
 }
 
+// One allocation function for everything large the manager owns.  TOAST_HIP_ALLOC=contiguous asks the
+// driver for physically contiguous backing (hipDeviceMallocContiguous) for blocks >= 256 MB, falling
+// back to a plain hipMalloc when that fails; default = plain hipMalloc.  Returns nullptr on failure.
+void * Manager::device_alloc(size_t nbytes) {
+    static const bool contiguous = [] {
+        const char * e = std::getenv("TOAST_HIP_ALLOC");
+        return e != nullptr && std::string(e) == "contiguous";
+    }();
+    void * p = nullptr;
+    if (contiguous && nbytes >= (size_t(256) << 20)) {
+        if (hipExtMallocWithFlags(&p, nbytes, hipDeviceMallocContiguous) == hipSuccess && p != nullptr) return p;
+        (void)hipGetLastError();
+        p = nullptr;
+    }
+    if (hipMalloc(&p, nbytes ? nbytes : 16) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
 void * Manager::create(const void * host, size_t nbytes, const char * name) {
     require_device();
     auto it = table_.find(host);
@@ -367,12 +394,13 @@ void * Manager::create(const void * host, size_t nbytes, const char * name) {
         if (dev != nullptr) {
             e = hipSuccess;
         } else {
-            e = hipMalloc(&dev, nbytes ? nbytes : 16);
-            if ((e != hipSuccess || dev == nullptr) && !free_blocks_.empty()) {
+            dev = device_alloc(nbytes);
+            e = (dev != nullptr) ? hipSuccess : hipErrorOutOfMemory;
+            if (dev == nullptr && !free_blocks_.empty()) {
                 // the cache of released blocks is holding the memory: give it back and retry
-                (void)hipGetLastError();
                 flush_cached();
-                e = hipMalloc(&dev, nbytes ? nbytes : 16);
+                dev = device_alloc(nbytes);
+                e = (dev != nullptr) ? hipSuccess : hipErrorOutOfMemory;
             }
         }
     }
@@ -552,6 +580,37 @@ extern "C" {
 const char * toast_hip_last_error(void) { return g_last_error.c_str(); }
 
 const char * toast_hip_version(void) { return "toast_hip 0.1 (gfx950)"; }
+
+// Raw device allocations with the manager's policy (experiments, bench.py): flags as in
+// hipExtMallocWithFlags (0 default, 4 hipDeviceMallocContiguous), -1 = the manager's own policy.
+int toast_hip_device_malloc(size_t nbytes, int flags, void ** out) {
+    return guarded([&] {
+        void * p = nullptr;
+        if (flags < 0) {
+            p = Manager::get().device_alloc(nbytes);
+        } else if (flags == 0) {
+            TH_HIP(hipMalloc(&p, nbytes));
+        } else {
+            TH_HIP(hipExtMallocWithFlags(&p, nbytes, (unsigned)flags));
+        }
+        *out = p;
+    });
+}
+
+// Run-time tuning switches for experiments (tools/): "det_major" = 0 / 1.
+int toast_hip_set_tuning(const char * key, int value) {
+    return guarded([&] {
+        if (std::string(key) == "det_major") {
+            set_det_major_grid(value);
+        } else {
+            fail_arg(std::string("unknown tuning key ") + key);
+        }
+    });
+}
+
+int toast_hip_device_free(void * p) {
+    return guarded([&] { TH_HIP(hipFree(p)); });
+}
 
 int toast_hip_accel_generation(uint64_t * generation) {
     return toast_hip::guarded([&] { *generation = toast_hip::Manager::get().generation(); });

@@ -89,6 +89,7 @@ private:
 size_t pin_threshold();
 int chunk_size();
 bool det_major_grid();
+void set_det_major_grid(int on);
 bool pair_detectors();
 // TOAST_HIP_STOKES_REFERENCE_NAN=1 / toast_hip_set_stokes_reference_nan(): NaN Q / U weights where the
 // reference's formulation produces them (hpix_math.hpp: stokes_cs2alpha).
@@ -126,6 +127,7 @@ public:
     void clear();
     // Grow-only device scratch (slot = kScratch*): FFT work buffers, reduction results.
     void * scratch(int slot, size_t bytes);
+    void * device_alloc(size_t nbytes);   // allocation policy of the manager (nullptr on failure)
     void release_cached() { flush_cached(); }
 
     uint64_t generation() const { return generation_; }
