@@ -84,6 +84,9 @@ int toast_hip_accel_generation(uint64_t * generation);
  * placement experiments use so that they see the allocations the operators get. */
 int toast_hip_device_malloc(size_t nbytes, int flags, void ** out);
 int toast_hip_device_free(void * p);
+/* Experiment: virtual range backed by chunk_mb-sized physical allocations mapped in order / shuffled
+ * (tools/exp_alloc_flags.py, profiles/r02_d_placement_experiments.txt).  The range is never released. */
+int toast_hip_device_malloc_vmm(size_t nbytes, int chunk_mb, int shuffled, void ** out);
 /* Experiment switches at run time (tools/exp_*.py): key "det_major" = 0 / 1 (workgroup order of the
  * accumulate / scan kernels; the environment variable TOAST_HIP_DET_MAJOR sets the start-up value). */
 int toast_hip_set_tuning(const char * key, int value);

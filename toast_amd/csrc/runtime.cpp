@@ -608,6 +608,48 @@ int toast_hip_set_tuning(const char * key, int value) {
     });
 }
 
+// EXPERIMENT (tools/exp_alloc_flags.py): a virtual range backed by `chunk_mb`-sized physical allocations
+// mapped in a shuffled order (flags: 100 = in order, 101 = shuffled).  Never freed.
+int toast_hip_device_malloc_vmm(size_t nbytes, int chunk_mb, int shuffled, void ** out) {
+    return guarded([&] {
+        int dev = 0;
+        TH_HIP(hipGetDevice(&dev));
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = dev;
+        size_t gran = 0;
+        TH_HIP(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+        size_t chunk = (size_t)chunk_mb << 20;
+        if (chunk < gran) chunk = gran;
+        chunk = (chunk + gran - 1) / gran * gran;
+        const size_t n = (nbytes + chunk - 1) / chunk;
+        void * va = nullptr;
+        TH_HIP(hipMemAddressReserve(&va, n * chunk, 0, nullptr, 0));
+        std::vector<hipMemGenericAllocationHandle_t> h(n);
+        for (size_t i = 0; i < n; ++i) TH_HIP(hipMemCreate(&h[i], chunk, &prop, 0));
+        std::vector<size_t> perm(n);
+        for (size_t i = 0; i < n; ++i) perm[i] = i;
+        if (shuffled) {
+            uint64_t st = 0x9E3779B97F4A7C15ull;
+            for (size_t i = n - 1; i > 0; --i) {
+                st = st * 6364136223846793005ull + 1442695040888963407ull;
+                const size_t j = (size_t)((st >> 33) % (i + 1));
+                std::swap(perm[i], perm[j]);
+            }
+        }
+        for (size_t i = 0; i < n; ++i) {
+            TH_HIP(hipMemMap((char *)va + i * chunk, chunk, 0, h[perm[i]], 0));
+        }
+        hipMemAccessDesc acc = {};
+        acc.location.type = hipMemLocationTypeDevice;
+        acc.location.id = dev;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        TH_HIP(hipMemSetAccess(va, n * chunk, &acc, 1));
+        *out = va;
+    });
+}
+
 int toast_hip_device_free(void * p) {
     return guarded([&] { TH_HIP(hipFree(p)); });
 }

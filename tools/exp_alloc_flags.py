@@ -45,6 +45,17 @@ for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 12):
 for flags, p in bufs:
     t = stream_ms(p.value)
     print("flags %d  ptr %#x  stream %.3f ms = %.2f TB/s" % (flags, p.value, t, 2 * nbytes / t / 1e9), flush=True)
+# virtual-memory ranges backed by separately created physical chunks, mapped in order / shuffled
+for chunk_mb, shuffled in ((2, 0), (2, 1), (64, 0), (64, 1), (1024, 0), (1024, 1), (2, 1), (64, 1)):
+    p = C.c_void_p(0)
+    rc = lib.toast_hip_device_malloc_vmm(C.c_size_t(nbytes), C.c_int(chunk_mb), C.c_int(shuffled), C.byref(p))
+    if rc != 0:
+        print("vmm alloc failed", chunk_mb, shuffled, lib.toast_hip_last_error().decode())
+        continue
+    lib.toast_hip_memset_dev(p, C.c_int(0), C.c_size_t(nbytes), C.c_void_p(st))
+    t = stream_ms(p.value)
+    print("vmm chunk %4d MB %s  ptr %#x  stream %.3f ms = %.2f TB/s" % (chunk_mb, "shuffled" if shuffled else "in order",
+                                                                         p.value, t, 2 * nbytes / t / 1e9), flush=True)
 # free every other one, allocate again (fragmented pool)
 for flags, p in bufs[::3]:
     lib.toast_hip_device_free(p)
