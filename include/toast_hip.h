@@ -543,6 +543,11 @@ int toast_hip_fft_fused(int64_t n_samp);
 /* Override the choice at run time: rocfft_only != 0 = the rocFFT pipeline for every length,
  * 0 = automatic (what TOAST_HIP_FFT=rocfft / unset select at start-up). */
 void toast_hip_fft_select(int rocfft_only);
+/* Points per thread (16 or 8; anything else = default) of the row pass, the forward and the inverse
+ * column pass of the fused kernels: 16 = 256-thread workgroups with radix-16 stages, 8 = 512-thread
+ * workgroups with radix-8 stages and twice the waves per SIMD.  Defaults 8 / 8 / 16; start-up value
+ * from TOAST_HIP_FFT_POINTS="rows,cols_fwd,cols_inv". */
+void toast_hip_fft_points(int rows, int cols_fwd, int cols_inv);
 /* HBM bytes per timestream sample that the passes of that implementation move (accounting for
  * bench.py / DESIGN.md, not a measurement). */
 double toast_hip_fft_pipeline_bytes(int64_t n_samp);

@@ -192,9 +192,10 @@ def _noise_kernels(freq, n_det, complex_phase=False):
     return np.array(kernels)
 
 
+@pytest.mark.parametrize("points", [(16, 16, 16), (8, 8, 8)])
 @pytest.mark.parametrize("n_samp", [2049, 3000, 8192, 8193, 12345, 50001, 100000, 262145, 300001, 720000, 1100003,
                                     2200000])
-def test_fused_three_pass_all_column_lengths(pf, n_samp):
+def test_fused_three_pass_all_column_lengths(pf, n_samp, points):
     """The fused three-pass pipeline (fft_fused.hip) for every column length N1 = 2 .. 2048 of its
     four-step factorisation (n_fft = 2^13 .. 2^23, odd and even buffer offsets), against the NumPy
     restatement of toast.fft.convolve AND against the rocFFT pipeline: per-detector real kernels with
@@ -202,6 +203,7 @@ def test_fused_three_pass_all_column_lengths(pf, n_samp):
     from oracle import fft_oracle as fo
 
     assert pf.implementation(n_samp) == "fused-3pass"
+    pf.set_points(*points)      # 256-thread radix-16 and 512-thread radix-8 variants of the three kernels
     rng = np.random.default_rng(n_samp)
     rate, n_det, rows = 200.0, 3, 4
     freq = np.concatenate([[0.0], np.geomspace(1e-5, rate / 2, 70)])
@@ -223,6 +225,7 @@ def test_fused_three_pass_all_column_lengths(pf, n_samp):
     finally:
         pf.select(False)
     assert np.max(np.abs(got - lib)) < 1e-13 * scale
+    pf.set_points()             # back to the defaults
 
 
 @pytest.mark.parametrize("deconvolve", [False, True])

@@ -34,6 +34,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -45,7 +47,9 @@ namespace fused_fft {
 
 constexpr int kLT = 12;             // log2 of the tile (4096 complex doubles = 64 KB of LDS)
 constexpr int kTile = 1 << kLT;
-constexpr int kThreads = kTile / 16;   // 256: every thread holds 16 points
+// Every kernel is a template on P = points per thread (kTile / P threads per workgroup):
+//   P = 16: 256 threads, radix-16 ends, one LDS round trip fewer per transform, ~250 VGPRs -> 2 waves / SIMD
+//   P = 8:  512 threads, radix-8 stages, ~100 VGPRs -> 4 waves / SIMD (two workgroups per CU either way: LDS)
 
 // ------------------------------------------------------------------------------------------
 // complex helpers (explicit fma: the library is built with -ffp-contract=off)
@@ -170,23 +174,24 @@ __device__ __forceinline__ void apply_powers(double2 * a, double2 w1) {
 
 // One Stockham stage of radix R on the whole tile, LDS -> LDS.  Remaining transform length is
 // (kTile >> log_s); the stage twiddle w_n^(j p) = wtile[(p << log_s) * j] is built from wtile[u & ~(s-1)].
-template <int R>
+template <int P, int R>
 __device__ __forceinline__ void stage_lds(double2 * sm, int tid, int log_s, bool last,
                                           const double2 * __restrict__ wtile) {
-    constexpr int B = 16 / R;
+    constexpr int T = kTile / P;
+    constexpr int B = P / R;
     constexpr int Q = kTile / R;
     constexpr int LR = Log2<R>::v;
     double2 v[B][R];
 #pragma unroll
     for (int b = 0; b < B; ++b) {
-        const int u = tid + kThreads * b;
+        const int u = tid + T * b;
 #pragma unroll
         for (int k = 0; k < R; ++k) v[b][k] = sm[sw(u + k * Q)];
     }
     __syncthreads();
 #pragma unroll
     for (int b = 0; b < B; ++b) {
-        const int u = tid + kThreads * b;
+        const int u = tid + T * b;
         DFT<R>::run(v[b]);
         if (!last) apply_powers<R>(v[b], wtile[(u >> log_s) << log_s]);
 #pragma unroll
@@ -195,50 +200,62 @@ __device__ __forceinline__ void stage_lds(double2 * sm, int tid, int log_s, bool
     __syncthreads();
 }
 
+template <int P>
 __device__ __forceinline__ void stage_lds_any(int r, double2 * sm, int tid, int log_s, bool last,
                                               const double2 * __restrict__ wtile) {
-    switch (r) {
-        case 16: stage_lds<16>(sm, tid, log_s, last, wtile); break;
-        case 8: stage_lds<8>(sm, tid, log_s, last, wtile); break;
-        case 4: stage_lds<4>(sm, tid, log_s, last, wtile); break;
-        default: stage_lds<2>(sm, tid, log_s, last, wtile); break;
+    if (P >= 16 && r == 16) {
+        stage_lds<P, (P >= 16 ? 16 : P)>(sm, tid, log_s, last, wtile);
+    } else if (r == 8) {
+        stage_lds<P, 8>(sm, tid, log_s, last, wtile);
+    } else if (r == 4) {
+        stage_lds<P, 4>(sm, tid, log_s, last, wtile);
+    } else {
+        stage_lds<P, 2>(sm, tid, log_s, last, wtile);
     }
 }
 
 // Forward FFTs of length n = 2^log_n along the slow axis of the tile (kTile / n interleaved
-// transforms).  In and out: v[k] = tile element tid + k * kThreads.
-__device__ __forceinline__ void tile_fft(double2 (&v)[16], double2 * sm, int tid, int log_n,
+// transforms).  In and out: v[k] = tile element tid + k * T, T = kTile / P threads.
+template <int P>
+__device__ __forceinline__ void tile_fft(double2 (&v)[P], double2 * sm, int tid, int log_n,
                                          const double2 * __restrict__ wtile) {
+    constexpr int T = kTile / P;
+    constexpr int LP = Log2<P>::v;
     const int log_s0 = kLT - log_n;
-    if (log_n >= 8) {
-        // plan [16, mid, 16], mid = n / 256: the radix-16 ends work straight on the registers
-        const int log_mid = log_n - 8;
-        DFT<16>::run(v);
-        apply_powers<16>(v, wtile[(tid >> log_s0) << log_s0]);
+    if (log_n >= 2 * LP) {
+        // plan [P, middle stages, P]: the radix-P ends work straight on the registers
+        DFT<P>::run(v);
+        apply_powers<P>(v, wtile[(tid >> log_s0) << log_s0]);
         __syncthreads();   // earlier readers of the tile are done
 #pragma unroll
-        for (int j = 0; j < 16; ++j) sm[sw(out_idx(tid, j, log_s0, 4))] = v[j];
+        for (int j = 0; j < P; ++j) sm[sw(out_idx(tid, j, log_s0, LP))] = v[j];
         __syncthreads();
-        if (log_mid > 0) stage_lds_any(1 << log_mid, sm, tid, log_s0 + 4, false, wtile);
+        int log_mid = log_n - 2 * LP, log_s = log_s0 + LP;
+        while (log_mid > 0) {
+            const int lr = log_mid >= LP ? LP : log_mid;
+            stage_lds_any<P>(1 << lr, sm, tid, log_s, false, wtile);
+            log_s += lr;
+            log_mid -= lr;
+        }
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = sm[sw(tid + k * kThreads)];
-        DFT<16>::run(v);
+        for (int k = 0; k < P; ++k) v[k] = sm[sw(tid + k * T)];
+        DFT<P>::run(v);
         return;
     }
     // short transforms (only small problems get here): every stage through LDS
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) sm[sw(tid + k * kThreads)] = v[k];
+    for (int k = 0; k < P; ++k) sm[sw(tid + k * T)] = v[k];
     __syncthreads();
     int log_rem = log_n, log_s = log_s0;
     while (log_rem > 0) {
-        const int lr = log_rem >= 4 ? 4 : log_rem;
-        stage_lds_any(1 << lr, sm, tid, log_s, log_rem == lr, wtile);
+        const int lr = log_rem >= LP ? LP : log_rem;
+        stage_lds_any<P>(1 << lr, sm, tid, log_s, log_rem == lr, wtile);
         log_s += lr;
         log_rem -= lr;
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = sm[sw(tid + k * kThreads)];
+    for (int k = 0; k < P; ++k) v[k] = sm[sw(tid + k * T)];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -294,24 +311,26 @@ __device__ __forceinline__ double padded(const double * __restrict__ row, const 
     return 0.0;
 }
 
-// v[k] *= w_M^(k1 j2) for the thread's sixteen tile elements e = tid + 256 k.  When the tile has at most
-// 256 columns all sixteen share the column j2 and their rows are k1 = k1_0 + k (256 >> log_c): the
-// factors are w^(e0) (w^d)^k -- two table look-ups and a product tree instead of sixteen look-ups.
-__device__ __forceinline__ void col_twiddles(double2 (&v)[16], const Params & p, int tid, int log_c, int64_t c0) {
-    if (log_c <= 8) {
+// v[k] *= w_M^(k1 j2) for the thread's P tile elements e = tid + T k.  When the tile has at most T columns
+// all of them share the column j2 and their rows are k1 = k1_0 + k (T >> log_c): the factors are
+// w^(e0) (w^d)^k -- two table look-ups and a product tree instead of P look-ups.
+template <int P>
+__device__ __forceinline__ void col_twiddles(double2 (&v)[P], const Params & p, int tid, int log_c, int64_t c0) {
+    constexpr int T = kTile / P;
+    if ((1 << log_c) <= T) {
         const int64_t j2 = c0 + (tid & ((1 << log_c) - 1));
         const int64_t k10 = tid >> log_c;
-        const int64_t dk = kThreads >> log_c;
+        const int64_t dk = T >> log_c;
         const double2 w0 = tw_big(p.tb, 2 * k10 * j2);
         const double2 wd = tw_big(p.tb, 2 * dk * j2);
         v[0] = cmul(v[0], w0);
-        apply_powers<16>(v, wd);
+        apply_powers<P>(v, wd);
 #pragma unroll
-        for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], w0);
+        for (int k = 1; k < P; ++k) v[k] = cmul(v[k], w0);
     } else {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int e = tid + k * kThreads;
+        for (int k = 0; k < P; ++k) {
+            const int e = tid + k * T;
             const int64_t k1 = e >> log_c;
             const int64_t j2 = c0 + (e & ((1 << log_c) - 1));
             v[k] = cmul(v[k], tw_big(p.tb, 2 * k1 * j2));
@@ -340,8 +359,9 @@ __device__ __forceinline__ double2 padded_pair(const double * __restrict__ row, 
 }
 
 // pass 1 (INV = false) and pass 3 (INV = true): transforms of length N1 down the columns
-template <bool INV>
-__global__ __launch_bounds__(kThreads, 2) void k_fft_cols(const Params p) {
+template <int P, bool INV>
+__global__ __launch_bounds__(kTile / P, (P == 16 ? 2 : 4)) void k_fft_cols(const Params p) {
+    constexpr int T = kTile / P;
     extern __shared__ double2 sm[];
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
@@ -351,21 +371,21 @@ __global__ __launch_bounds__(kThreads, 2) void k_fft_cols(const Params p) {
     const int64_t m = int64_t(1) << (p.log_n1 + p.log_n2);
     double2 * __restrict__ work = p.work + (int64_t)b * m;
     double * __restrict__ row = p.tod + (int64_t)p.d_idx[p.det0 + b] * p.n_samp;
-    double2 v[16];
+    double2 v[P];
     if (!INV) {
         if (p.aligned) {
             // n_buffer, n_samp, n_reflect even and 16-byte aligned rows: (x[2j], x[2j+1]) is one aligned
             // pair of the timestream (reversed in the mirrored parts), one 16-byte load per point
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int e = tid + k * kThreads;
+            for (int k = 0; k < P; ++k) {
+                const int e = tid + k * T;
                 const int64_t j = ((int64_t)(e >> log_c) << p.log_n2) + c0 + (e & ((1 << log_c) - 1));
                 v[k] = padded_pair(row, p.apod, 2 * j - p.n_buffer, p.n_samp, p.n_reflect);
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int e = tid + k * kThreads;
+            for (int k = 0; k < P; ++k) {
+                const int e = tid + k * T;
                 const int64_t j = ((int64_t)(e >> log_c) << p.log_n2) + c0 + (e & ((1 << log_c) - 1));
                 v[k].x = padded(row, p.apod, 2 * j, p.n_samp, p.n_buffer, p.n_reflect);
                 v[k].y = padded(row, p.apod, 2 * j + 1, p.n_samp, p.n_buffer, p.n_reflect);
@@ -373,20 +393,20 @@ __global__ __launch_bounds__(kThreads, 2) void k_fft_cols(const Params p) {
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int e = tid + k * kThreads;
+        for (int k = 0; k < P; ++k) {
+            const int e = tid + k * T;
             const int64_t k1 = e >> log_c;
             const int64_t j2 = c0 + (e & ((1 << log_c) - 1));
             v[k] = work[(k1 << p.log_n2) + j2];
         }
-        col_twiddles(v, p, tid, log_c, c0);
+        col_twiddles<P>(v, p, tid, log_c, c0);
     }
-    tile_fft(v, sm, tid, p.log_n1, p.tb.wtile);
+    tile_fft<P>(v, sm, tid, p.log_n1, p.tb.wtile);
     if (!INV) {
-        col_twiddles(v, p, tid, log_c, c0);
+        col_twiddles<P>(v, p, tid, log_c, c0);
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int e = tid + k * kThreads;
+        for (int k = 0; k < P; ++k) {
+            const int e = tid + k * T;
             const int64_t k1 = e >> log_c;
             const int64_t j2 = c0 + (e & ((1 << log_c) - 1));
             work[(k1 << p.log_n2) + j2] = v[k];
@@ -394,8 +414,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_fft_cols(const Params p) {
     } else {
         // the transform ran on swapped data: Re z' = v.y, Im z' = v.x; crop + scale (fft.py:341-350)
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int e = tid + k * kThreads;
+        for (int k = 0; k < P; ++k) {
+            const int e = tid + k * T;
             const int64_t j = ((int64_t)(e >> log_c) << p.log_n2) + c0 + (e & ((1 << log_c) - 1));
             const int64_t s = 2 * j - p.n_buffer;
             if (s >= 0 && s < p.n_samp) row[s] = v[k].y * p.scale;
@@ -435,7 +455,9 @@ __device__ __forceinline__ double2 apply_kernel(double2 v, double2 kk, int decon
 }
 
 // pass 2: rows (k1, N1 - k1) [block 0: rows 0 and N1 / 2]
-__global__ __launch_bounds__(kThreads, 2) void k_fft_rows(const Params p) {
+template <int P>
+__global__ __launch_bounds__(kTile / P, (P == 16 ? 2 : 4)) void k_fft_rows(const Params p) {
+    constexpr int T = kTile / P;
     extern __shared__ double2 sm[];
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
@@ -446,26 +468,26 @@ __global__ __launch_bounds__(kThreads, 2) void k_fft_rows(const Params p) {
     double2 * __restrict__ work = p.work + (int64_t)b * m;
     const int64_t r0 = (g == 0) ? 0 : g;
     const int64_t r1 = (g == 0) ? (n1 >> 1) : (n1 - g);
-    double2 v[16];
+    double2 v[P];
     // tile element e = 2 k2 + r
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int e = tid + k * kThreads;
+    for (int k = 0; k < P; ++k) {
+        const int e = tid + k * T;
         const int64_t rr = (e & 1) ? r1 : r0;
         v[k] = work[(rr << p.log_n2) + (e >> 1)];
     }
-    tile_fft(v, sm, tid, p.log_n2, p.tb.wtile);
+    tile_fft<P>(v, sm, tid, p.log_n2, p.tb.wtile);
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) sm[sw(tid + k * kThreads)] = v[k];
+    for (int k = 0; k < P; ++k) sm[sw(tid + k * T)] = v[k];
     __syncthreads();
 
     const int64_t kern = p.per_det ? (int64_t)(p.det0 + b) : 0;
     const double * __restrict__ mc = p.mag_coef + kern * 4 * (p.n_knot - 1);
     const double * __restrict__ ac = p.ang_coef ? p.ang_coef + kern * 4 * (p.n_knot - 1) : nullptr;
     // bins k and M - k: real-FFT unpacking, kernel, repacking (all factors 1/2 are in p.scale)
-    for (int i = 0; i < n2 / kThreads; ++i) {
-        const int q = tid + kThreads * i;
+    for (int i = 0; i < n2 / T; ++i) {
+        const int q = tid + T * i;
         int ea, eb;
         int64_t k;
         if (g != 0) {
@@ -514,11 +536,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_fft_rows(const Params p) {
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = sm[sw(tid + k * kThreads)];
-    tile_fft(v, sm, tid, p.log_n2, p.tb.wtile);
+    for (int k = 0; k < P; ++k) v[k] = sm[sw(tid + k * T)];
+    tile_fft<P>(v, sm, tid, p.log_n2, p.tb.wtile);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int e = tid + k * kThreads;
+    for (int k = 0; k < P; ++k) {
+        const int e = tid + k * T;
         const int64_t rr = (e & 1) ? r1 : r0;
         work[(rr << p.log_n2) + (e >> 1)] = v[k];
     }
@@ -580,15 +602,54 @@ static Plan & get_plan(int64_t n_fft, hipStream_t st) {
     pl.tables = static_cast<double2 *>(d);
     static bool attr_set = false;
     if (!attr_set) {
-        TH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_cols<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, kTile * sizeof(double2)));
-        TH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_cols<true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, kTile * sizeof(double2)));
-        TH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_rows),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, kTile * sizeof(double2)));
+        const int lds = kTile * sizeof(double2);
+        TH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_cols<16, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        TH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_cols<16, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        TH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_rows<16>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        TH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_cols<8, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        TH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_cols<8, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        TH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_rows<8>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
     return g_plans.emplace(key, pl).first->second;
+}
+
+namespace {
+// points per thread of (row pass, forward column pass, inverse column pass); measured best at cfg-3:
+// 8 / 8 / 16 (profiles/r02_f_fft_points.txt)
+int g_points[3] = {0, 0, 0};
+void read_points() {
+    if (g_points[0] != 0) return;
+    g_points[0] = 8;
+    g_points[1] = 8;
+    g_points[2] = 16;
+    const char * e = std::getenv("TOAST_HIP_FFT_POINTS");
+    if (e != nullptr) {
+        int a = 0, b = 0, c = 0;
+        if (std::sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) {
+            g_points[0] = (a == 16) ? 16 : 8;
+            g_points[1] = (b == 16) ? 16 : 8;
+            g_points[2] = (c == 8) ? 8 : 16;
+        }
+    }
+}
+}  // namespace
+int points_of(int pass) {
+    read_points();
+    return g_points[pass];
+}
+void set_points(int rows, int cols_fwd, int cols_inv) {
+    g_points[0] = 0;
+    read_points();       // defaults
+    if (rows == 8 || rows == 16) g_points[0] = rows;
+    if (cols_fwd == 8 || cols_fwd == 16) g_points[1] = cols_fwd;
+    if (cols_inv == 8 || cols_inv == 16) g_points[2] = cols_inv;
 }
 
 bool supported(int64_t n_fft) {
@@ -655,9 +716,22 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
     for (int64_t det0 = 0; det0 < n_det; det0 += batch) {
         const int64_t nb = (n_det - det0 < batch) ? (n_det - det0) : batch;
         p.det0 = (int)det0;
-        hipLaunchKernelGGL(k_fft_cols<false>, dim3(n_col_tiles, (unsigned)nb), dim3(kThreads), lds, st, p);
-        hipLaunchKernelGGL(k_fft_rows, dim3(n_row_tiles, (unsigned)nb), dim3(kThreads), lds, st, p);
-        hipLaunchKernelGGL(k_fft_cols<true>, dim3(n_col_tiles, (unsigned)nb), dim3(kThreads), lds, st, p);
+        // points per thread of each pass: TOAST_HIP_FFT_POINTS="rows,cols_fwd,cols_inv" / toast_hip_fft_points
+        if (points_of(1) == 8) {
+            hipLaunchKernelGGL((k_fft_cols<8, false>), dim3(n_col_tiles, (unsigned)nb), dim3(kTile / 8), lds, st, p);
+        } else {
+            hipLaunchKernelGGL((k_fft_cols<16, false>), dim3(n_col_tiles, (unsigned)nb), dim3(kTile / 16), lds, st, p);
+        }
+        if (points_of(0) == 8) {
+            hipLaunchKernelGGL(k_fft_rows<8>, dim3(n_row_tiles, (unsigned)nb), dim3(kTile / 8), lds, st, p);
+        } else {
+            hipLaunchKernelGGL(k_fft_rows<16>, dim3(n_row_tiles, (unsigned)nb), dim3(kTile / 16), lds, st, p);
+        }
+        if (points_of(2) == 8) {
+            hipLaunchKernelGGL((k_fft_cols<8, true>), dim3(n_col_tiles, (unsigned)nb), dim3(kTile / 8), lds, st, p);
+        } else {
+            hipLaunchKernelGGL((k_fft_cols<16, true>), dim3(n_col_tiles, (unsigned)nb), dim3(kTile / 16), lds, st, p);
+        }
         TH_HIP(hipGetLastError());
     }
 }

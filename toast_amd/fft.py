@@ -31,6 +31,12 @@ def select(rocfft_only):
     capi.lib().toast_hip_fft_select(C.c_int(1 if rocfft_only else 0))
 
 
+def set_points(rows=0, cols_fwd=0, cols_inv=0):
+    """Points per thread (16 or 8, 0 = default) of the row pass / forward / inverse column pass of the
+    fused kernels."""
+    capi.lib().toast_hip_fft_points(C.c_int(int(rows)), C.c_int(int(cols_fwd)), C.c_int(int(cols_inv)))
+
+
 def pipeline_bytes_per_sample(n_samp):
     """HBM bytes per timestream sample moved by the passes of the implementation in use."""
     fn = capi.lib().toast_hip_fft_pipeline_bytes

@@ -13,6 +13,8 @@ freq = np.linspace(0, rate / 2, 400)
 kern = 1.0 / (1.0 + (0.05 / np.maximum(freq, 1e-4)) ** 1.0)
 kernels = np.tile(kern, (n_det, 1))
 idx = np.arange(n_det, dtype=np.int32)
+if len(sys.argv) > 4:
+    hipfft.set_points(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
 for it in range(4):
     torch.cuda.synchronize()
     t0 = time.time()
