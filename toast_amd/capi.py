@@ -887,6 +887,11 @@ class _Dev:
             _i64(n_shared_flags), _u8(shared_flag_mask), _i64(oi.size), _i64(n_samp), _p(iv), _i64(iv.size),
             _i64(n_out_rows), C.c_int(int(outside_value)), _p(stream)))
 
+    def cov_eigendecompose_diag(self, n_sub, subsize, nnz, d_data, d_cond, threshold, invert, stream=0):
+        _check(lib().toast_hip_cov_eigendecompose_diag_dev(_i64(n_sub), _i64(subsize), _i64(nnz), _p(d_data), _p(d_cond),
+                                                           C.c_double(float(threshold)), C.c_int(1 if invert else 0),
+                                                           _p(stream)))
+
     def memset(self, d_dst, value, nbytes, stream=0):
         _check(lib().toast_hip_memset_dev(_p(d_dst), C.c_int(int(value)), C.c_size_t(int(nbytes)), _p(stream)))
 

@@ -599,10 +599,24 @@ class CovarianceAndHits(Operator):
         accum = Pipeline(detector_sets=["ALL"] if self.save_pointing else uncached_detector_sets(),
                          operators=[self.pixel_pointing, self.stokes_weights, build_hits, build_invcov])
         accum.apply(data, detectors=detectors)
-        cov = data[inv_key].duplicate()
-        data[self.covariance] = cov
+        invcov = data[inv_key]
         data[self.rcond] = PixelData(data[self.pixel_dist], np.float64, n_value=1)
-        covariance_invert(cov, self.rcond_threshold, rcond=data[self.rcond])
+        if invcov.accel_in_use():
+            # accumulated on the device: copy, invert and keep it there (the binning applies it there);
+            # the host sides are brought up to date once, the device copies stay the current ones
+            cov = invcov.duplicate_on_device()
+            data[self.covariance] = cov
+            covariance_invert(cov, self.rcond_threshold, rcond=data[self.rcond])
+            for obj in (cov, data[self.rcond]):
+                obj.accel_update_host()
+                obj.accel_used(True)
+            if self.inverse_covariance is not None:
+                invcov.accel_update_host()
+                invcov.accel_used(True)
+        else:
+            cov = invcov.duplicate()
+            data[self.covariance] = cov
+            covariance_invert(cov, self.rcond_threshold, rcond=data[self.rcond])
         if self.inverse_covariance is None:
             del data[inv_key]
 

@@ -123,6 +123,20 @@ class PixelData(AcceleratorObject):
         dup.raw[:] = self.raw
         return dup
 
+    def duplicate_on_device(self):
+        """Copy whose DEVICE side is filled by a device-to-device copy (the source must be in use on the
+        device); the host side of the copy stays zero until ``accel_update_host``.  Spares the D2H + H2D
+        round trip of ``duplicate`` for intermediates that are consumed on the device."""
+        from . import capi
+
+        if not self.accel_in_use():
+            raise RuntimeError("duplicate_on_device: the data is not in use on the device")
+        dup = PixelData(self._dist, self._dtype, n_value=self._n_value, units=self.units)
+        dup.accel_create(self._accel_name + "_copy")
+        capi.dev.copy(accel_device_ptr(dup.raw), accel_device_ptr(self.raw), self.raw.nbytes)
+        dup.accel_used(True)
+        return dup
+
     def device_tensor(self):
         """Zero-copy torch view of the device buffer (for RCCL collectives)."""
         import torch
@@ -232,15 +246,29 @@ def covariance_apply(npp, m, use_alltoallv=False):
 
 def covariance_invert(npp, threshold, rcond=None, use_alltoallv=False):
     """In-place inverse of the per-pixel blocks with an rcond threshold
-    (reference: src/toast/covariance.py:20-110 -> cov_eigendecompose_diag)."""
+    (reference: src/toast/covariance.py:20-110 -> cov_eigendecompose_diag).  Runs where the matrix
+    lives: a device-resident covariance is inverted there and stays there (its condition-number map
+    too); host data is staged through the GPU by the host-level entry point."""
     mapnnz = int(((np.sqrt(8 * npp.n_value) - 1) / 2) + 0.5)
     if rcond is not None and rcond.distribution != npp.distribution:
         raise RuntimeError("covariance matrix and condition number map must have same pixel distribution")
+    dist = npp.distribution
     if npp.accel_in_use():
-        npp.accel_update_host()
-    cond = np.zeros(npp.distribution.n_local_submap * npp.distribution.n_pix_submap) if rcond is None else rcond.raw
-    native().cov_eigendecompose_diag(npp.distribution.n_local_submap, npp.distribution.n_pix_submap, mapnnz, npp.raw,
-                                     cond, float(threshold), True, False)
+        from . import capi
+
+        cond = PixelData(dist, np.float64, n_value=1) if rcond is None else rcond
+        if not cond.accel_exists():
+            cond.accel_create("rcond", zero_out=True)
+        capi.dev.cov_eigendecompose_diag(dist.n_local_submap, dist.n_pix_submap, mapnnz, accel_device_ptr(npp.raw),
+                                         accel_device_ptr(cond.raw), float(threshold), True)
+        cond.accel_used(True)
+        if rcond is None:
+            native().accel_synchronize()
+            cond.accel_delete()
+        return
+    cond = np.zeros(dist.n_local_submap * dist.n_pix_submap) if rcond is None else rcond.raw
+    native().cov_eigendecompose_diag(dist.n_local_submap, dist.n_pix_submap, mapnnz, npp.raw, cond, float(threshold),
+                                     True, False)
 
 
 def covariance_rcond(npp, use_alltoallv=False):
