@@ -70,6 +70,9 @@ def parse():
     ap.add_argument("--no-fft", action="store_true", help="skip the FFT noise-weighting measurement")
     ap.add_argument("--no-cfg4", action="store_true",
                     help="with --gpus 8 and the default workload: do not also time the configs[3] shard (cfg4)")
+    ap.add_argument("--shard-workload", default=None, choices=sorted(WORKLOADS),
+                    help="also time this workload after the headline one and attach it as `configs3_shard` "
+                         "(default: cfg4 when --gpus 8 runs the default workload)")
     ap.add_argument("--hwp", action="store_true", help="rotating half-wave plate (88 rpm): Stokes weights with HWP angle")
     ap.add_argument("--unfused", action="store_true", help="run noise_weight as its own kernel (105 B variant)")
     return ap.parse_args()
@@ -98,12 +101,15 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
     out = run(args, args.workload, world, rank, dev, headline=True)
-    if world == 8 and args.workload == "cfg3" and not args.no_cfg4:
+    shard = args.shard_workload
+    if shard is None and world == 8 and args.workload == "cfg3" and not args.no_cfg4:
+        shard = "cfg4"
+    if shard is not None:
         # BASELINE configs[3] (4096 detectors x 4 h @ 200 Hz over 8 GPUs): the default line above is the
         # weak-scaling cfg3 shard (same per-GPU work at every N, which is what a scaling curve needs);
         # the actual configs[3] shard (512 detectors x 2 880 000 samples per GPU) is timed here as well.
         torch.cuda.empty_cache()
-        sub = run(args, "cfg4", world, rank, dev, headline=False)
+        sub = run(args, shard, world, rank, dev, headline=False)
         if rank == 0:
             out["configs3_shard"] = {k: sub[k] for k in ("value", "unit", "ms_per_step", "kernel_ms", "config",
                                                          "allreduce", "roofline")}

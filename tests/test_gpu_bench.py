@@ -34,6 +34,14 @@ def test_bench_contract_small_workload():
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key
     assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] >= 1
+    assert c["one_thread"] > 0 and c["best_threads"]["value"] >= max(c["thread_sweep"].values()) * (1 - 1e-12)
+    assert "1" in c["thread_sweep"] and str(c["cores"]) in c["thread_sweep"]
+    # the buffers are allocated like the operators allocate them; the FFT noise weighting is reported separately
+    assert "hipMalloc per buffer" in d["allocator"] and d["placement"] is None
+    f = d["fft_noise_weight"]
+    assert f["ms"] > 0 and f["samples_per_s"] > 0 and f["n_fft"] == 131072 and f["implementation"] == "fused-3pass"
+    assert abs(f["pipeline_bytes_per_sample"] - (16 + 32 * 131072 / 50000)) < 1e-9
+    assert d["allreduce"]["bytes"] == 0 and d["kernel_ms"]["allreduce"] >= 0
     # value == whole-job units / time
     n = d["config"]["detectors_per_gpu"] * d["config"]["samples_per_detector"]
     assert abs(d["value"] - n / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
@@ -49,8 +57,8 @@ def test_bench_two_ranks_code_path():
     prints one JSON line, value is the whole-job aggregate, the zmap all-reduce is in the step."""
     env = dict(os.environ, TOAST_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "1", "--workload", "mini"]
+           "127.0.0.1", "--master-port", "29549", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--workload", "mini", "--shard-workload", "cfg2", "--no-fft"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -60,3 +68,8 @@ def test_bench_two_ranks_code_path():
     n = d["config"]["detectors_per_gpu"] * d["config"]["samples_per_detector"]
     assert abs(d["value"] - 2 * n / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert "cpu_baseline" not in d          # rank 0 at N = 1 only
+    # the all-reduce of the zmap is timed and sized; the extra shard workload (what --gpus 8 does with cfg4) is attached
+    assert d["allreduce"]["bytes"] == d["config"]["n_local_submap"] * 3072 * 3 * 8 and d["allreduce"]["ms"] > 0
+    assert d["kernel_ms"]["allreduce"] > 0 and d["allreduce"]["backend"] == "gloo"
+    sh = d["configs3_shard"]
+    assert sh["config"]["workload"] == "cfg2" and sh["value"] > 0 and sh["allreduce"]["bytes"] > 0

@@ -165,3 +165,47 @@ def test_stokes_reference_nan_switch(hip, oracle, use_hwp):
     got2 = np.zeros((1, n, 3))
     hip.stokes_weights_IQU(idx, quats, idx, got2, hwp, iv, eps, gamma, cal, False, False)
     assert not np.isnan(got2).any()
+
+
+def test_deterministic_detector_groups_at_shard_size(hip, oracle):
+    """256 detectors x 720 000 samples (the configs[4] shard; 1.8e8 det-samples = two detector groups of
+    the sorted reduction, which is bounded to 2^27 entries): zmap bit-identical to the oracle's host-path
+    order, i.e. splitting into groups does not change any sum."""
+    import torch
+
+    from toast_amd import capi, synth
+
+    n_det, n_samp, rate, nside, nps, nnz = 256, 720000, 200.0, 512, 3072, 3
+    dev = torch.device("cuda")
+    D = capi.dev
+    st = torch.cuda.current_stream().cuda_stream
+    fp, gamma = synth.hex_focalplane(n_det, fov_deg=10.0)
+    bore = synth.satellite_boresight(n_samp, rate, 600.0, 30.0, 3000.0, 65.0)
+    ivl = synth.make_intervals(n_samp, 3, rate, gap=7)
+    idx = np.arange(n_det, dtype=np.int32)
+    n_submap = 12 * nside * nside // nps
+    sflags_h = synth.shared_flags_block(n_samp, 0.01, value=1)
+    d_bore, d_sf = torch.from_numpy(bore).to(dev), torch.from_numpy(sflags_h).to(dev)
+    d_hsub = torch.zeros(n_submap, dtype=torch.uint8, device=dev)
+    d_pix = torch.full((n_det, n_samp), -1, dtype=torch.int64, device=dev)
+    d_w = torch.zeros((n_det, n_samp, 3), dtype=torch.float64, device=dev)
+    pt = capi.otf_pointing(d_bore.data_ptr(), fp, nside, True, nnz, d_shared_flags=d_sf.data_ptr(), n_shared_flags=n_samp,
+                           shared_flag_mask=1, epsilon=np.zeros(n_det), gamma=gamma, cal=np.ones(n_det))
+    D.otf_pixels_healpix(pt, idx, d_pix.data_ptr(), n_samp, ivl, d_hsub.data_ptr(), n_submap, nps, st)
+    D.otf_stokes_weights(pt, idx, d_w.data_ptr(), n_samp, ivl, st)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(3)
+    d_tod = torch.randn((n_det, n_samp), dtype=torch.float64, device=dev, generator=gen)
+    d_df = (torch.rand((n_det, n_samp), device=dev, generator=gen) < 0.005).to(torch.uint8)
+    g2l_h, hit = synth.global_to_local(d_hsub.cpu().numpy())
+    d_g2l = torch.from_numpy(g2l_h).to(dev)
+    det_scale = np.linspace(0.5, 1.5, n_det)
+    d_z = torch.zeros((hit.size, nps, nnz), dtype=torch.float64, device=dev)
+    assert hip.get_deterministic()
+    D.build_noise_weighted(d_g2l.data_ptr(), d_z.data_ptr(), nps, nnz, idx, d_pix.data_ptr(), idx, d_w.data_ptr(), idx,
+                           d_tod.data_ptr(), idx, d_df.data_ptr(), n_samp, det_scale, 1, n_samp, ivl, d_sf.data_ptr(), n_samp, 1, st)
+    torch.cuda.synchronize()
+    want = np.zeros((hit.size, nps, nnz))
+    oracle.build_noise_weighted(g2l_h, want, idx, d_pix.cpu().numpy(), idx, d_w.cpu().numpy(), idx, d_tod.cpu().numpy(), idx,
+                                d_df.cpu().numpy(), det_scale, 1, ivl, sflags_h, 1)
+    assert np.array_equal(d_z.cpu().numpy(), want)
