@@ -577,8 +577,10 @@ int toast_hip_fft_r1d_dev(int forward, int64_t length, int64_t count, const doub
  * [ref: src/toast/_libtoast/ops_mapmaker_utils.cpp:294-378, src/libtoast/src/toast_map_cov.cpp:96-153]
  * -- by a stable sort of (pixel, det-sample) pairs and a sequential segmented sum
  * (toast_amd/csrc/deterministic.hip): bit-identical between runs and to the reference's host
- * result.  ~20x slower than the atomic kernels; the fused / on-the-fly accumulate kernels are
- * not covered (the operators avoid them while the mode is on).
+ * result.  ~20x slower than the atomic kernels.  Also switched: toast_hip_template_offset_project_signal*
+ * (one thread per amplitude, samples in increasing order) and toast_hip_vec_dot_dev (block partials
+ * summed in block order).  The fused / on-the-fly accumulate kernels are not covered (the operators
+ * avoid them while the mode is on).
  * ---------------------------------------------------------------------------------- */
 int toast_hip_set_deterministic(int on);
 int toast_hip_get_deterministic(void);

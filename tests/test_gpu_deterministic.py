@@ -209,3 +209,67 @@ def test_deterministic_detector_groups_at_shard_size(hip, oracle):
     oracle.build_noise_weighted(g2l_h, want, idx, d_pix.cpu().numpy(), idx, d_w.cpu().numpy(), idx, d_tod.cpu().numpy(), idx,
                                 d_df.cpu().numpy(), det_scale, 1, ivl, sflags_h, 1)
     assert np.array_equal(d_z.cpu().numpy(), want)
+
+
+def test_deterministic_project_signal_and_dot(hip, oracle):
+    """M^T in deterministic mode: every amplitude adds its samples in increasing order like the
+    reference's host loop (template_offset.cpp:243-290) -- bit-identical to the oracle; the amplitude
+    dot product (block partials summed in block order) is reproducible to the bit."""
+    import torch
+
+    rng = np.random.default_rng(8)
+    for kw in (dict(n_split=3, gap=5, n_samp=7001), dict(n_samp=4096), dict(n_samp=131, n_split=2, gap=1)):
+        c = cases.make_case(**kw)
+        ivl = c["intervals"]
+        for step in (1, 37, 1000):
+            n_amp_views = np.array([(iv["last"] - iv["first"] + step - 1) // step for iv in ivl], dtype=np.int64)
+            amp_offset = 5
+            n_amp = int(amp_offset + n_amp_views.sum() + 3)
+            amps = rng.standard_normal(n_amp)
+            aflags = (rng.random(n_amp) < 0.1).astype(np.uint8)
+            for fidx in (-1, 2):
+                a_h, a_o = amps.copy(), amps.copy()
+                hip.template_offset_project_signal(1, c["tod"], fidx, c["det_flags"], 1, step, amp_offset, n_amp_views,
+                                                   a_h, aflags, ivl, False)
+                oracle.template_offset_project_signal(1, c["tod"], fidx, c["det_flags"], 1, step, amp_offset,
+                                                      n_amp_views, a_o, aflags, ivl)
+                assert np.array_equal(a_h, a_o), (kw, step, fidx)
+    dev = torch.device("cuda")
+    x = torch.randn(3_000_001, dtype=torch.float64, device=dev)
+    y = torch.randn(3_000_001, dtype=torch.float64, device=dev)
+    f = (torch.rand(3_000_001, device=dev) < 0.01).to(torch.uint8)
+    vals = {hip.dev.vec_dot(x.numel(), x.data_ptr(), y.data_ptr(), f.data_ptr(), 0) for _ in range(20)}
+    assert len(vals) == 1
+    want = float((x * y * (f == 0)).sum())
+    assert abs(vals.pop() - want) < 1e-9 * abs(want) + 1e-6
+
+
+def test_mapmaker_with_templates_is_reproducible_in_deterministic_mode(hip):
+    """The complete destriping MapMaker (solver covariance, RHS, PCG with offset templates, final binning)
+    twice from scratch: amplitudes, residual history and every map bit-identical between the runs."""
+    from toast_amd import ops
+    from toast_amd.data import defaults
+    from toast_amd.sim import create_satellite_data
+    from toast_amd.templates import Offset
+
+    outs = []
+    for _ in range(2):
+        data = create_satellite_data(n_det=8, n_samp=40000, rate=50.0, spin_angle_deg=30.0, prec_angle_deg=60.0)
+        rng = np.random.default_rng(2)
+        sig = rng.standard_normal((8, 40000)) + np.repeat(3.0 * rng.standard_normal((8, 40)), 1000, axis=1)
+        data.obs[0].detdata[defaults.det_data].data[:] = sig
+        dp = ops.PointingDetectorSimple()
+        pix = ops.PixelsHealpix(detector_pointing=dp, nside=64)
+        sw = ops.StokesWeights(detector_pointing=dp, mode="IQU", hwp_angle=defaults.hwp_angle)
+        binner = ops.BinMap(pixel_dist="dist", pixel_pointing=pix, stokes_weights=sw, full_pointing=True)
+        tm = ops.TemplateMatrix(templates=[Offset(step_time=20.0, noise_model=defaults.noise_model, name="baselines")])
+        mm = ops.MapMaker(name="mm", binning=binner, template_matrix=tm, iter_min=8, iter_max=8, convergence=1e-30,
+                          keep_solver_products=True, keep_final_products=True)
+        mm.apply(data)
+        out = {k: data[k].data.copy() for k in ("mm_hits", "mm_cov", "mm_noiseweighted_map", "mm_map")}
+        out["amps"] = data["mm_solve_amplitudes"]["baselines"].local.copy()
+        out["history"] = np.array(mm.history)
+        outs.append(out)
+    assert len(outs[0]["history"]) >= 8 and outs[0]["history"][-1] < outs[0]["history"][0]
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k

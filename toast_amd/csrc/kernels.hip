@@ -697,11 +697,23 @@ __global__ __launch_bounds__(kThreads) void k_vec_axpby(int64_t n, double a, con
     }
 }
 
+// `partials` != nullptr (deterministic mode): every block stores its sum, k_vec_dot_final adds them in block
+// order -- the result no longer depends on the order in which the blocks retire.
+__global__ __launch_bounds__(kThreads) void k_vec_dot_final(int n_block, const double * __restrict__ partials,
+                                                            double * __restrict__ result) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double t = 0.0;
+        for (int b = 0; b < n_block; ++b) t += partials[b];
+        *result = t;
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void k_vec_dot(int64_t n, const double * __restrict__ x,
                                                       const double * __restrict__ y,
                                                       const uint8_t * __restrict__ fx,
                                                       const uint8_t * __restrict__ fy,
-                                                      double * __restrict__ result) {
+                                                      double * __restrict__ result,
+                                                      double * __restrict__ partials) {
     __shared__ double s_part[kThreads / 64];
     double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n;
@@ -717,7 +729,11 @@ __global__ __launch_bounds__(kThreads) void k_vec_dot(int64_t n, const double * 
         double t = 0.0;
 #pragma unroll
         for (int w = 0; w < kThreads / 64; ++w) t += s_part[w];
-        unsafeAtomicAdd(result, t);
+        if (partials != nullptr) {
+            partials[blockIdx.x] = t;
+        } else {
+            unsafeAtomicAdd(result, t);
+        }
     }
 }
 
@@ -828,6 +844,39 @@ __global__ __launch_bounds__(kThreads) void k_offset_project_signal(
             if (tail && key >= 0) unsafeAtomicAdd(amps + key, v[0]);
         }
     }
+}
+
+// Deterministic form of k_offset_project_signal (TOAST_HIP_DETERMINISTIC): one thread per amplitude adds its
+// samples in increasing order onto the value already there -- the order of the reference's host loop
+// (template_offset.cpp:243-290), so the projected amplitudes are bit-identical to it and from run to run.
+__global__ __launch_bounds__(kThreads) void k_offset_project_signal_det(
+    int n_view, const int64_t * __restrict__ view_first, const int64_t * __restrict__ view_last,
+    const int64_t * __restrict__ view_aoff, const int64_t * __restrict__ view_namp, int64_t n_amp_det, int64_t step,
+    const int64_t * __restrict__ amp_offsets, const int32_t * __restrict__ d_idx, const int32_t * __restrict__ f_idx,
+    double * __restrict__ amps, const uint8_t * __restrict__ amp_flags, const double * __restrict__ tod,
+    const uint8_t * __restrict__ flags, uint8_t fmask, int use_flags, int64_t n_samp) {
+    const int det = blockIdx.y;
+    int64_t b = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (b >= n_amp_det) return;
+    int v = 0;
+    while (v < n_view - 1 && b >= view_namp[v]) {
+        b -= view_namp[v];
+        ++v;
+    }
+    if (b >= view_namp[v]) return;
+    const int64_t a = amp_offsets[det] + view_aoff[v] + b;
+    if (amp_flags[a] != 0) return;
+    const double * drow = tod + (int64_t)d_idx[det] * n_samp;
+    const uint8_t * frow = use_flags ? flags + (int64_t)f_idx[det] * n_samp : nullptr;
+    const int64_t s0 = view_first[v] + b * step;
+    int64_t s1 = s0 + step;
+    if (s1 > view_last[v]) s1 = view_last[v];
+    double acc = amps[a];
+    for (int64_t s = s0; s < s1; ++s) {
+        const bool bad = use_flags && ((frow[s] & fmask) != 0);
+        acc += bad ? 0.0 : drow[s];
+    }
+    amps[a] = acc;
 }
 
 // Number of flagged samples under every offset amplitude (the good-fraction cut and the
@@ -1434,6 +1483,29 @@ int toast_hip_template_offset_project_signal_multi_dev(
         const size_t o_ao = pb.push(amp_offsets, sizeof(int64_t) * n_det);
         const size_t o_di = pb.push(data_index, sizeof(int32_t) * n_det);
         const size_t o_fi = pb.push_vec(fidx);
+        if (deterministic_mode()) {
+            std::vector<int64_t> vlast(n_view), vnamp(n_view);
+            int64_t n_amp_det = 0;
+            for (int64_t v = 0; v < n_view; ++v) {
+                vlast[v] = intervals[v].last;
+                vnamp[v] = n_amp_views[v];
+                n_amp_det += n_amp_views[v];
+            }
+            const size_t o_vl = pb.push_vec(vlast);
+            const size_t o_vn = pb.push_vec(vnamp);
+            const char * dd = pb.commit(as_stream(stream));
+            if (n_amp_det > 0) {
+                hipLaunchKernelGGL(k_offset_project_signal_det,
+                                   dim3((unsigned)((n_amp_det + kThreads - 1) / kThreads), (unsigned)n_det), dim3(kThreads),
+                                   0, as_stream(stream), (int)n_view, (const int64_t *)(dd + o_vf),
+                                   (const int64_t *)(dd + o_vl), (const int64_t *)(dd + o_va), (const int64_t *)(dd + o_vn),
+                                   n_amp_det, step_length, (const int64_t *)(dd + o_ao), (const int32_t *)(dd + o_di),
+                                   (const int32_t *)(dd + o_fi), d_amplitudes, d_amplitude_flags, d_det_data, d_flag_data,
+                                   flag_mask, use_flags, n_samp);
+                check_launch();
+            }
+            return;
+        }
         const char * d = pb.commit(as_stream(stream));
         hipLaunchKernelGGL(k_offset_project_signal, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0,
                            as_stream(stream), (const Chunk *)(d + o_ch), (int)chunks.size(),
@@ -1760,13 +1832,17 @@ int toast_hip_vec_axpby_dev(int64_t n, double a, const double * d_x, double b, d
 int toast_hip_vec_dot_dev(int64_t n, const double * d_x, const double * d_y, const uint8_t * d_flags_x,
                           const uint8_t * d_flags_y, double * result, void * stream) {
     return guarded([&] {
-        double * d_res = (double *)Manager::get().scratch(Manager::kScratchDot, sizeof(double));
+        double * d_res = (double *)Manager::get().scratch(Manager::kScratchDot, sizeof(double) * 1032);
         hipStream_t st = as_stream(stream);
         TH_HIP(hipMemsetAsync(d_res, 0, sizeof(double), st));
         if (n > 0) {
             dim3 grid = flat_grid(n);
             if (grid.x > 1024) grid.x = 1024;
-            hipLaunchKernelGGL(k_vec_dot, grid, dim3(kThreads), 0, st, n, d_x, d_y, d_flags_x, d_flags_y, d_res);
+            double * d_part = deterministic_mode() ? d_res + 8 : nullptr;
+            hipLaunchKernelGGL(k_vec_dot, grid, dim3(kThreads), 0, st, n, d_x, d_y, d_flags_x, d_flags_y, d_res, d_part);
+            if (d_part != nullptr) {
+                hipLaunchKernelGGL(k_vec_dot_final, dim3(1), dim3(kThreads), 0, st, (int)grid.x, d_part, d_res);
+            }
             check_launch();
         }
         TH_HIP(hipMemcpyAsync(result, d_res, sizeof(double), hipMemcpyDeviceToHost, st));
