@@ -194,10 +194,10 @@ def _noise_kernels(freq, n_det, complex_phase=False):
 
 @pytest.mark.parametrize("points", [(16, 16, 16), (8, 8, 8)])
 @pytest.mark.parametrize("n_samp", [2049, 3000, 8192, 8193, 12345, 50001, 100000, 262145, 300001, 720000, 1100003,
-                                    2200000])
+                                    2200000, 4200001])
 def test_fused_three_pass_all_column_lengths(pf, n_samp, points):
-    """The fused three-pass pipeline (fft_fused.hip) for every column length N1 = 2 .. 2048 of its
-    four-step factorisation (n_fft = 2^13 .. 2^23, odd and even buffer offsets), against the NumPy
+    """The fused three-pass pipeline (fft_fused.hip) for every column length N1 = 2 .. 4096 of its
+    four-step factorisation (n_fft = 2^13 .. 2^24, N1 up to 4096, odd and even buffer offsets), against the NumPy
     restatement of toast.fft.convolve AND against the rocFFT pipeline: per-detector real kernels with
     row indirection; rows outside the index stay untouched."""
     from oracle import fft_oracle as fo
