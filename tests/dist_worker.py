@@ -48,6 +48,18 @@ def main():
     pa.sync_alltoallv()
     assert np.array_equal(pa.raw, pd.raw)
 
+    # ... also when the flat map does not divide by the number of ranks (padded shards of the reduce-scatter)
+    d_odd = PixelDistribution(n_pix=16 * 45, n_submap=16, local_submaps=np.array([1, 4, 9]), comm=comm)
+    po = PixelData(d_odd, np.float64, n_value=1)
+    assert po.raw.size % size == 1
+    mine_o = np.random.default_rng(300 + rank).standard_normal(po.raw.size)
+    po.raw[:] = mine_o
+    po.sync_alltoallv()
+    other_o = np.random.default_rng(300 + (1 - rank)).standard_normal(po.raw.size)
+    np.testing.assert_allclose(po.raw, mine_o + other_o, rtol=0, atol=1e-15)
+    t = comm.reduce_scatter_allgather_(__import__("torch").arange(7, dtype=__import__("torch").float64) * (rank + 1))
+    assert t.tolist() == [0.0, 3.0, 6.0, 9.0, 12.0, 15.0, 18.0]
+
     # 3. amplitude dot products: local dot + scalar all-reduce
     a = Amplitudes(comm, 10, 5)
     a.local[:] = np.arange(5) + 5 * rank
