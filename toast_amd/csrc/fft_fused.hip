@@ -454,6 +454,28 @@ __device__ __forceinline__ double2 apply_kernel(double2 v, double2 kk, int decon
     return make_double2(v.x * kk.x - v.y * kk.y, v.x * kk.y + v.y * kk.x);
 }
 
+// Bins k (tile element ea) and M - k (element eb) of the packed transform: real-FFT unpacking X = E + w^k O,
+// Y = K X, repacking Z'[k] = Ye + i Yo, Z'[M - k] = conj(Ye) + i conj(Yo), stored with re / im swapped for the
+// inverse transform.  ea == eb: the bin that pairs with itself (k = M / 2).
+__device__ __forceinline__ void pair_update(double2 * sm, int ea, int eb, double2 wk, double2 ka, double2 kb,
+                                            int deconvolve) {
+    const double2 za = sm[sw(ea)];
+    const double2 zb = sm[sw(eb)];
+    const double2 cb = cconj(zb);
+    const double2 ee = cadd(za, cb);
+    const double2 oo = mul_mi(csub(za, cb));
+    const double2 t = cmul(wk, oo);
+    const double2 xa = cadd(ee, t);
+    const double2 xb = cconj(csub(ee, t));
+    const double2 ya = apply_kernel(xa, ka, deconvolve);
+    const double2 yb = apply_kernel(xb, kb, deconvolve);
+    const double2 cyb = cconj(yb);
+    const double2 ye = cadd(ya, cyb);
+    const double2 yo = cmul(cconj(wk), csub(ya, cyb));
+    sm[sw(ea)] = make_double2(ye.y + yo.x, ye.x - yo.y);
+    if (eb != ea) sm[sw(eb)] = make_double2(yo.x - ye.y, ye.x + yo.y);
+}
+
 // pass 2: rows (k1, N1 - k1) [block 0: rows 0 and N1 / 2]
 template <int P>
 __global__ __launch_bounds__(kTile / P, (P == 16 ? 2 : 4)) void k_fft_rows(const Params p) {
@@ -486,53 +508,55 @@ __global__ __launch_bounds__(kTile / P, (P == 16 ? 2 : 4)) void k_fft_rows(const
     const double * __restrict__ mc = p.mag_coef + kern * 4 * (p.n_knot - 1);
     const double * __restrict__ ac = p.ang_coef ? p.ang_coef + kern * 4 * (p.n_knot - 1) : nullptr;
     // bins k and M - k: real-FFT unpacking, kernel, repacking (all factors 1/2 are in p.scale)
-    for (int i = 0; i < n2 / T; ++i) {
-        const int q = tid + T * i;
-        int ea, eb;
-        int64_t k;
-        if (g != 0) {
-            ea = 2 * q;
-            eb = 2 * (n2 - 1 - q) + 1;
-            k = g + n1 * q;
-        } else if (q < n2 / 2) {
-            ea = 2 * q + 1;
-            eb = 2 * (n2 - 1 - q) + 1;
-            k = (n1 >> 1) + n1 * q;
-        } else {
-            const int qq = q - n2 / 2;
-            if (qq == 0) {
-                // DC and Nyquist share element 0: Z[0] = a + i b, X[0] = a + b, X[M] = a - b
-                const double2 z0 = sm[sw(0)];
-                const double2 km = kernel_at(p, mc, ac, m);
-                double2 ym = apply_kernel(make_double2(2.0 * (z0.x - z0.y), 0.0), km, p.deconvolve);
-                ym.y = 0.0;                                  // Nyquist bin of a real transform is real
-                // Y[0] = 0 (DC removed): Z'[0] = (Y[M], -Y[M]); stored swapped
-                sm[sw(0)] = make_double2(-ym.x, ym.x);
-                ea = eb = n2;                                // bin M / 2 pairs with itself (row 0, k2 = N2 / 2)
-                k = m >> 1;
-            } else {
-                ea = 2 * qq;
-                eb = 2 * (n2 - qq);
-                k = n1 * qq;
-            }
+    if (g != 0) {
+        // every workgroup but the first: pair q = (row k1, element q) with (row N1 - k1, element N2 - 1 - q), bin
+        // k = g + N1 q.  A thread's pairs q = tid + T i have bins N1 T = N / P apart, so their unpacking twiddles are
+        // w_N^k0 times the CONSTANTS w_P^i: one table look-up per thread, and the loop unrolls completely (the
+        // kernel-interval look-ups of all pairs are in flight together).
+        constexpr int NP = kTile / 2 / T;
+        constexpr double c16[8] = {1.0, 0.92387953251128673848, 0.70710678118654752440, 0.38268343236508977173,
+                                   0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128673848};
+        constexpr double s16[8] = {0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128673848,
+                                   1.0, 0.92387953251128673848, 0.70710678118654752440, 0.38268343236508977173};
+        const int64_t k0 = g + n1 * tid;
+        const double2 w0 = tw_big(p.tb, k0);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const int q = tid + T * i;
+            const int64_t k = k0 + n1 * (int64_t)(T * i);
+            const double2 wk = (i == 0) ? w0 : cmul(w0, make_double2(c16[i * (16 / P)], -s16[i * (16 / P)]));
+            pair_update(sm, 2 * q, 2 * (n2 - 1 - q) + 1, wk, kernel_at(p, mc, ac, k), kernel_at(p, mc, ac, m - k),
+                        p.deconvolve);
         }
-        const double2 za = sm[sw(ea)];
-        const double2 zb = sm[sw(eb)];
-        const double2 cb = cconj(zb);
-        const double2 ee = cadd(za, cb);
-        const double2 oo = mul_mi(csub(za, cb));
-        const double2 wk = tw_big(p.tb, k);
-        const double2 t = cmul(wk, oo);
-        const double2 xa = cadd(ee, t);
-        const double2 xb = cconj(csub(ee, t));
-        const double2 ya = apply_kernel(xa, kernel_at(p, mc, ac, k), p.deconvolve);
-        const double2 yb = apply_kernel(xb, kernel_at(p, mc, ac, m - k), p.deconvolve);
-        const double2 cyb = cconj(yb);
-        const double2 ye = cadd(ya, cyb);
-        const double2 yo = cmul(cconj(wk), csub(ya, cyb));
-        // Z'[k] = Ye + i Yo, Z'[M-k] = conj(Ye) + i conj(Yo); stored with re / im swapped
-        sm[sw(ea)] = make_double2(ye.y + yo.x, ye.x - yo.y);
-        if (eb != ea) sm[sw(eb)] = make_double2(yo.x - ye.y, ye.x + yo.y);
+    } else {
+        for (int i = 0; i < n2 / T; ++i) {
+            const int q = tid + T * i;
+            int ea, eb;
+            int64_t k;
+            if (q < n2 / 2) {
+                ea = 2 * q + 1;
+                eb = 2 * (n2 - 1 - q) + 1;
+                k = (n1 >> 1) + n1 * q;
+            } else {
+                const int qq = q - n2 / 2;
+                if (qq == 0) {
+                    // DC and Nyquist share element 0: Z[0] = a + i b, X[0] = a + b, X[M] = a - b
+                    const double2 z0 = sm[sw(0)];
+                    const double2 km = kernel_at(p, mc, ac, m);
+                    double2 ym = apply_kernel(make_double2(2.0 * (z0.x - z0.y), 0.0), km, p.deconvolve);
+                    ym.y = 0.0;                                  // Nyquist bin of a real transform is real
+                    // Y[0] = 0 (DC removed): Z'[0] = (Y[M], -Y[M]); stored swapped
+                    sm[sw(0)] = make_double2(-ym.x, ym.x);
+                    ea = eb = n2;                                // bin M / 2 pairs with itself (row 0, k2 = N2 / 2)
+                    k = m >> 1;
+                } else {
+                    ea = 2 * qq;
+                    eb = 2 * (n2 - qq);
+                    k = n1 * qq;
+                }
+            }
+            pair_update(sm, ea, eb, tw_big(p.tb, k), kernel_at(p, mc, ac, k), kernel_at(p, mc, ac, m - k), p.deconvolve);
+        }
     }
     __syncthreads();
 #pragma unroll
