@@ -548,6 +548,11 @@ void toast_hip_fft_select(int rocfft_only);
  * workgroups with radix-8 stages and twice the waves per SIMD.  Defaults 8 / 8 / 16; start-up value
  * from TOAST_HIP_FFT_POINTS="rows,cols_fwd,cols_inv". */
 void toast_hip_fft_points(int rows, int cols_fwd, int cols_inv);
+/* Row pass of the fused kernels: split != 0 (default) = one row of N2 = 2048 bins per 32 KB LDS tile, the two rows
+ * of a pair (k1, N1 - k1) one after the other with the first row's spectrum kept in registers (four workgroups per
+ * CU); 0 = both rows interleaved in one 64 KB tile (two workgroups per CU).  Start-up value from
+ * TOAST_HIP_FFT_ROWS=split|pair.  Same results to rounding. */
+void toast_hip_fft_rows_split(int split);
 /* HBM bytes per timestream sample that the passes of that implementation move (accounting for
  * bench.py / DESIGN.md, not a measurement). */
 double toast_hip_fft_pipeline_bytes(int64_t n_samp);

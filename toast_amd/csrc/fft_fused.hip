@@ -38,6 +38,7 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "runtime.hpp"
@@ -47,6 +48,8 @@ namespace fused_fft {
 
 constexpr int kLT = 12;             // log2 of the tile (4096 complex doubles = 64 KB of LDS)
 constexpr int kTile = 1 << kLT;
+// LDS budget of the row pass for the kernel tables (two 64 KB tiles + tables per CU: 2 x (64 + 15) KB <= 160 KB)
+constexpr int kTabLdsMax = 15 * 1024;
 // Every kernel is a template on P = points per thread (kTile / P threads per workgroup):
 //   P = 16: 256 threads, radix-16 ends, one LDS round trip fewer per transform, ~250 VGPRs -> 2 waves / SIMD
 //   P = 8:  512 threads, radix-8 stages, ~100 VGPRs -> 4 waves / SIMD (two workgroups per CU either way: LDS)
@@ -172,14 +175,15 @@ __device__ __forceinline__ void apply_powers(double2 * a, double2 w1) {
     }
 }
 
-// One Stockham stage of radix R on the whole tile, LDS -> LDS.  Remaining transform length is
-// (kTile >> log_s); the stage twiddle w_n^(j p) = wtile[(p << log_s) * j] is built from wtile[u & ~(s-1)].
-template <int P, int R>
+// One Stockham stage of radix R on the whole tile of 2^LT elements, LDS -> LDS.  Remaining transform length is
+// (tile >> log_s); the stage twiddle w_n^(j p) = w_tile^((p << log_s) * j) is built from w_tile^(u & ~(s-1)), and
+// w_tile^e = wtile[e << (kLT - LT)] (the table holds the 4096th roots).
+template <int LT, int P, int R>
 __device__ __forceinline__ void stage_lds(double2 * sm, int tid, int log_s, bool last,
                                           const double2 * __restrict__ wtile) {
-    constexpr int T = kTile / P;
+    constexpr int T = (1 << LT) / P;
     constexpr int B = P / R;
-    constexpr int Q = kTile / R;
+    constexpr int Q = (1 << LT) / R;
     constexpr int LR = Log2<R>::v;
     double2 v[B][R];
 #pragma unroll
@@ -193,69 +197,77 @@ __device__ __forceinline__ void stage_lds(double2 * sm, int tid, int log_s, bool
     for (int b = 0; b < B; ++b) {
         const int u = tid + T * b;
         DFT<R>::run(v[b]);
-        if (!last) apply_powers<R>(v[b], wtile[(u >> log_s) << log_s]);
+        if (!last) apply_powers<R>(v[b], wtile[((u >> log_s) << log_s) << (kLT - LT)]);
 #pragma unroll
         for (int j = 0; j < R; ++j) sm[sw(out_idx(u, j, log_s, LR))] = v[b][j];
     }
     __syncthreads();
 }
 
-template <int P>
+template <int LT, int P>
 __device__ __forceinline__ void stage_lds_any(int r, double2 * sm, int tid, int log_s, bool last,
                                               const double2 * __restrict__ wtile) {
     if (P >= 16 && r == 16) {
-        stage_lds<P, (P >= 16 ? 16 : P)>(sm, tid, log_s, last, wtile);
+        stage_lds<LT, P, (P >= 16 ? 16 : P)>(sm, tid, log_s, last, wtile);
     } else if (r == 8) {
-        stage_lds<P, 8>(sm, tid, log_s, last, wtile);
+        stage_lds<LT, P, 8>(sm, tid, log_s, last, wtile);
     } else if (r == 4) {
-        stage_lds<P, 4>(sm, tid, log_s, last, wtile);
+        stage_lds<LT, P, 4>(sm, tid, log_s, last, wtile);
     } else {
-        stage_lds<P, 2>(sm, tid, log_s, last, wtile);
+        stage_lds<LT, P, 2>(sm, tid, log_s, last, wtile);
     }
 }
 
-// Forward FFTs of length n = 2^log_n along the slow axis of the tile (kTile / n interleaved
-// transforms).  In and out: v[k] = tile element tid + k * T, T = kTile / P threads.
-template <int P>
-__device__ __forceinline__ void tile_fft(double2 (&v)[P], double2 * sm, int tid, int log_n,
-                                         const double2 * __restrict__ wtile) {
-    constexpr int T = kTile / P;
+// Forward FFTs of length n = 2^log_n along the slow axis of the tile of 2^LT elements (tile / n interleaved
+// transforms).  In: v[k] = tile element u_in + k * T, out: v[k] = element u_out + k * T, T = tile / P threads;
+// u_in / u_out are any permutation of the thread index (u = tid: natural order; the row pass mirrors one of them).
+template <int LT, int P>
+__device__ __forceinline__ void tile_fft_t(double2 (&v)[P], double2 * sm, int tid, int log_n,
+                                           const double2 * __restrict__ wtile, int u_in, int u_out) {
+    constexpr int T = (1 << LT) / P;
     constexpr int LP = Log2<P>::v;
-    const int log_s0 = kLT - log_n;
+    const int log_s0 = LT - log_n;
     if (log_n >= 2 * LP) {
         // plan [P, middle stages, P]: the radix-P ends work straight on the registers
         DFT<P>::run(v);
-        apply_powers<P>(v, wtile[(tid >> log_s0) << log_s0]);
+        apply_powers<P>(v, wtile[((u_in >> log_s0) << log_s0) << (kLT - LT)]);
         __syncthreads();   // earlier readers of the tile are done
 #pragma unroll
-        for (int j = 0; j < P; ++j) sm[sw(out_idx(tid, j, log_s0, LP))] = v[j];
+        for (int j = 0; j < P; ++j) sm[sw(out_idx(u_in, j, log_s0, LP))] = v[j];
         __syncthreads();
         int log_mid = log_n - 2 * LP, log_s = log_s0 + LP;
         while (log_mid > 0) {
             const int lr = log_mid >= LP ? LP : log_mid;
-            stage_lds_any<P>(1 << lr, sm, tid, log_s, false, wtile);
+            stage_lds_any<LT, P>(1 << lr, sm, tid, log_s, false, wtile);
             log_s += lr;
             log_mid -= lr;
         }
 #pragma unroll
-        for (int k = 0; k < P; ++k) v[k] = sm[sw(tid + k * T)];
+        for (int k = 0; k < P; ++k) v[k] = sm[sw(u_out + k * T)];
         DFT<P>::run(v);
         return;
     }
     // short transforms (only small problems get here): every stage through LDS
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < P; ++k) sm[sw(tid + k * T)] = v[k];
+    for (int k = 0; k < P; ++k) sm[sw(u_in + k * T)] = v[k];
     __syncthreads();
     int log_rem = log_n, log_s = log_s0;
     while (log_rem > 0) {
         const int lr = log_rem >= LP ? LP : log_rem;
-        stage_lds_any<P>(1 << lr, sm, tid, log_s, log_rem == lr, wtile);
+        stage_lds_any<LT, P>(1 << lr, sm, tid, log_s, log_rem == lr, wtile);
         log_s += lr;
         log_rem -= lr;
     }
 #pragma unroll
-    for (int k = 0; k < P; ++k) v[k] = sm[sw(tid + k * T)];
+    for (int k = 0; k < P; ++k) v[k] = sm[sw(u_out + k * T)];
+}
+
+// the 4096-element tile in natural order (column passes, self-paired rows)
+template <int P>
+__device__ __forceinline__ void tile_fft(double2 (&v)[P], double2 * sm, int tid, int log_n,
+                                         const double2 * __restrict__ wtile) {
+    tile_fft_t<kLT, P>(v, sm, tid, log_n, wtile, tid, tid);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -289,7 +301,8 @@ struct Params {
     int n_knot;
     const double * mag_coef;
     const double * ang_coef;      // nullptr: real kernel
-    const int32_t * knot_hint;    // interval index at the first bin of every block of 256 bins
+    const int32_t * knot_hint;    // interval index at bin q N1, q = 0 .. N2 + 1
+    const uint16_t * knot_hint16; // the same in 16 bits (n_knot < 65536), for the LDS copy
     int per_det, deconvolve;
     int aligned;                  // pass 1 may use padded_pair
     double fstep, scale;
@@ -315,18 +328,34 @@ __device__ __forceinline__ double padded(const double * __restrict__ row, const 
 // all of them share the column j2 and their rows are k1 = k1_0 + k (T >> log_c): the factors are
 // w^(e0) (w^d)^k -- two table look-ups and a product tree instead of P look-ups.
 template <int P>
-__device__ __forceinline__ void col_twiddles(double2 (&v)[P], const Params & p, int tid, int log_c, int64_t c0) {
+struct ColTw {
+    double2 w0, wd;
+};
+// the table look-ups (independent of the data: issued before the transform whose barriers they could not cross)
+template <int P>
+__device__ __forceinline__ ColTw<P> col_twiddles_prepare(const Params & p, int tid, int log_c, int64_t c0) {
     constexpr int T = kTile / P;
+    ColTw<P> tw;
+    tw.w0 = make_double2(1.0, 0.0);
+    tw.wd = tw.w0;
     if ((1 << log_c) <= T) {
         const int64_t j2 = c0 + (tid & ((1 << log_c) - 1));
         const int64_t k10 = tid >> log_c;
         const int64_t dk = T >> log_c;
-        const double2 w0 = tw_big(p.tb, 2 * k10 * j2);
-        const double2 wd = tw_big(p.tb, 2 * dk * j2);
-        v[0] = cmul(v[0], w0);
-        apply_powers<P>(v, wd);
+        tw.w0 = tw_big(p.tb, 2 * k10 * j2);
+        tw.wd = tw_big(p.tb, 2 * dk * j2);
+    }
+    return tw;
+}
+template <int P>
+__device__ __forceinline__ void col_twiddles(double2 (&v)[P], const Params & p, int tid, int log_c, int64_t c0,
+                                             const ColTw<P> & tw) {
+    constexpr int T = kTile / P;
+    if ((1 << log_c) <= T) {
+        v[0] = cmul(v[0], tw.w0);
+        apply_powers<P>(v, tw.wd);
 #pragma unroll
-        for (int k = 1; k < P; ++k) v[k] = cmul(v[k], w0);
+        for (int k = 1; k < P; ++k) v[k] = cmul(v[k], tw.w0);
     } else {
 #pragma unroll
         for (int k = 0; k < P; ++k) {
@@ -399,11 +428,11 @@ __global__ __launch_bounds__(kTile / P, (P == 16 ? 2 : 4)) void k_fft_cols(const
             const int64_t j2 = c0 + (e & ((1 << log_c) - 1));
             v[k] = work[(k1 << p.log_n2) + j2];
         }
-        col_twiddles<P>(v, p, tid, log_c, c0);
+        col_twiddles<P>(v, p, tid, log_c, c0, col_twiddles_prepare<P>(p, tid, log_c, c0));
     }
     tile_fft<P>(v, sm, tid, p.log_n1, p.tb.wtile);
     if (!INV) {
-        col_twiddles<P>(v, p, tid, log_c, c0);
+        col_twiddles<P>(v, p, tid, log_c, c0, col_twiddles_prepare<P>(p, tid, log_c, c0));
 #pragma unroll
         for (int k = 0; k < P; ++k) {
             const int e = tid + k * T;
@@ -433,18 +462,98 @@ __device__ __forceinline__ double ppoly_at(const double * __restrict__ knots, in
     return ((c[0] * dx + c[1]) * dx + c[2]) * dx + c[3];
 }
 
-__device__ __forceinline__ double2 kernel_at(const Params & p, const double * __restrict__ mc,
-                                             const double * __restrict__ ac, int64_t k) {
-    const double x = (double)k * p.fstep;
-    // interval: start from the hint of this block of 256 bins, walk forward (the knots are sorted;
-    // a block holds more than a few knots only near f = 0)
-    int lo = p.knot_hint[k >> 8];
-    while (lo < p.n_knot - 2 && p.knots[lo + 1] <= x) ++lo;
-    const double mag = ppoly_at(p.knots, p.n_knot, mc, lo, x);
-    if (ac == nullptr) return make_double2(mag, 0.0);
-    const double ang = ppoly_at(p.knots, p.n_knot, ac, lo, x);
+// The kernel tables as the row pass sees them: in global memory, or (TLDS) a copy behind the tile in the workgroup's
+// LDS.  Measured with phase clocks (tools/exp_fft_phases.py): with the tables in global memory the unpack / multiply /
+// repack phase took 42 % of the row pass -- three DEPENDENT cache round trips per bin (hint -> knot -> coefficients)
+// at the latency of a memory system that is busy streaming the tiles.
+template <typename H>
+struct KTab {
+    const H * hint;            // interval at bin q N1, q = 0 .. N2 + 1
+    const double * knots;
+    const double * mc;         // |K| cubics of this workgroup's detector
+    const double * ac;         // arg K cubics, nullptr: real kernel
+    int log_n1;
+    double fstep;
+};
+
+// Interval of bin k in the knot vector.  hint[q] is the interval at bin q N1 (the first bin of element q of every
+// row), so the answer lies in [hint[q], hint[q + 1]]: no search at all where no knot falls into the block (most of
+// them: the noise kernels' frequencies are log spaced), a walk only below that (the first block holds most knots of
+// a log-spaced vector).
+template <typename H>
+__device__ __forceinline__ int kernel_interval(const KTab<H> & t, int k) {
+    const double x = (double)k * t.fstep;
+    const int q = k >> t.log_n1;
+    const int h0 = (int)t.hint[q];
+    const int h1 = (int)t.hint[q + 1];
+    int lo = h0;
+    if (h1 > h0) {
+        if (t.knots[h0 + 1] <= x) {
+            ++lo;
+            while (lo < h1 && t.knots[lo + 1] <= x) ++lo;
+        }
+    }
+    return lo;
+}
+
+template <typename H>
+__device__ __forceinline__ double2 kernel_eval(const KTab<H> & t, int lo, int k) {
+    const double x = (double)k * t.fstep;
+    const double mag = ppoly_at(t.knots, 0, t.mc, lo, x);
+    if (t.ac == nullptr) return make_double2(mag, 0.0);
+    const double ang = ppoly_at(t.knots, 0, t.ac, lo, x);
     return make_double2(mag * cos(ang), mag * sin(ang));
 }
+
+template <typename H>
+__device__ __forceinline__ double2 kernel_at(const KTab<H> & t, int64_t k) {
+    return kernel_eval(t, kernel_interval(t, (int)k), (int)k);
+}
+
+// Tables of the row pass: global (TLDS = false, 32-bit hints) or copied into LDS at `tab` (16-bit hints; the host
+// checks that they fit, Params::tab_lds_bytes).  The copy is visible after the next __syncthreads().
+template <bool TLDS>
+struct KTabSel {
+    using H = int32_t;
+    static __device__ __forceinline__ KTab<H> make(const Params & p, int64_t kern, char *, int, int) {
+        KTab<H> t;
+        t.hint = p.knot_hint;
+        t.knots = p.knots;
+        t.mc = p.mag_coef + kern * 4 * (p.n_knot - 1);
+        t.ac = p.ang_coef ? p.ang_coef + kern * 4 * (p.n_knot - 1) : nullptr;
+        t.log_n1 = p.log_n1;
+        t.fstep = p.fstep;
+        return t;
+    }
+};
+template <>
+struct KTabSel<true> {
+    using H = uint16_t;
+    static __device__ __forceinline__ KTab<H> make(const Params & p, int64_t kern, char * tab, int tid, int nthread) {
+        const int n_hint = (kTile / 2) + 2;
+        const int n_coef = 4 * (p.n_knot - 1);
+        double * s_knots = reinterpret_cast<double *>(tab);
+        double * s_mc = s_knots + p.n_knot;
+        double * s_ac = s_mc + n_coef;
+        H * s_hint = reinterpret_cast<H *>(s_ac + (p.ang_coef ? n_coef : 0));
+        const double * __restrict__ g_mc = p.mag_coef + kern * n_coef;
+        for (int i = tid; i < p.n_knot; i += nthread) s_knots[i] = p.knots[i];
+        for (int i = tid; i < n_coef; i += nthread) s_mc[i] = g_mc[i];
+        if (p.ang_coef) {
+            const double * __restrict__ g_ac = p.ang_coef + kern * n_coef;
+            for (int i = tid; i < n_coef; i += nthread) s_ac[i] = g_ac[i];
+        }
+        for (int i = tid; i < n_hint; i += nthread) s_hint[i] = p.knot_hint16[i];
+        KTab<H> t;
+        t.hint = s_hint;
+        t.knots = s_knots;
+        t.mc = s_mc;
+        t.ac = p.ang_coef ? s_ac : nullptr;
+        t.log_n1 = p.log_n1;
+        t.fstep = p.fstep;
+        return t;
+    }
+};
 
 __device__ __forceinline__ double2 apply_kernel(double2 v, double2 kk, int deconvolve) {
     if (deconvolve) {
@@ -457,10 +566,8 @@ __device__ __forceinline__ double2 apply_kernel(double2 v, double2 kk, int decon
 // Bins k (tile element ea) and M - k (element eb) of the packed transform: real-FFT unpacking X = E + w^k O,
 // Y = K X, repacking Z'[k] = Ye + i Yo, Z'[M - k] = conj(Ye) + i conj(Yo), stored with re / im swapped for the
 // inverse transform.  ea == eb: the bin that pairs with itself (k = M / 2).
-__device__ __forceinline__ void pair_update(double2 * sm, int ea, int eb, double2 wk, double2 ka, double2 kb,
-                                            int deconvolve) {
-    const double2 za = sm[sw(ea)];
-    const double2 zb = sm[sw(eb)];
+__device__ __forceinline__ void pair_update_reg(double2 & za, double2 & zb, bool same, double2 wk, double2 ka,
+                                                double2 kb, int deconvolve) {
     const double2 cb = cconj(zb);
     const double2 ee = cadd(za, cb);
     const double2 oo = mul_mi(csub(za, cb));
@@ -472,12 +579,39 @@ __device__ __forceinline__ void pair_update(double2 * sm, int ea, int eb, double
     const double2 cyb = cconj(yb);
     const double2 ye = cadd(ya, cyb);
     const double2 yo = cmul(cconj(wk), csub(ya, cyb));
-    sm[sw(ea)] = make_double2(ye.y + yo.x, ye.x - yo.y);
-    if (eb != ea) sm[sw(eb)] = make_double2(yo.x - ye.y, ye.x + yo.y);
+    za = make_double2(ye.y + yo.x, ye.x - yo.y);
+    if (!same) zb = make_double2(yo.x - ye.y, ye.x + yo.y);
 }
 
+__device__ __forceinline__ void pair_update(double2 * sm, int ea, int eb, double2 wk, double2 ka, double2 kb,
+                                            int deconvolve) {
+    double2 za = sm[sw(ea)];
+    double2 zb = sm[sw(eb)];
+    pair_update_reg(za, zb, ea == eb, wk, ka, kb, deconvolve);
+    sm[sw(ea)] = za;
+    if (eb != ea) sm[sw(eb)] = zb;
+}
+
+// Experimental build (-DTOAST_FFT_PHASE_CLOCK, tools/exp_fft_phases.py): thread 0 of every workgroup of the row pass
+// adds the 100 MHz wall-clock ticks between phase boundaries to g_phase_ticks.
+#if defined(TOAST_FFT_PHASE_CLOCK)
+__device__ unsigned long long g_phase_ticks[16];
+# define PHASE_DECL unsigned long long ph_t = wall_clock64()
+# define PHASE_WAIT_LOADS asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+# define PHASE_MARK(i)                                                        \
+    do {                                                                      \
+        const unsigned long long ph_n = wall_clock64();                       \
+        if (threadIdx.x == 0) atomicAdd(&g_phase_ticks[i], ph_n - ph_t);      \
+        ph_t = ph_n;                                                          \
+    } while (0)
+#else
+# define PHASE_DECL
+# define PHASE_WAIT_LOADS
+# define PHASE_MARK(i)
+#endif
+
 // pass 2: rows (k1, N1 - k1) [block 0: rows 0 and N1 / 2]
-template <int P>
+template <int P, bool TLDS>
 __global__ __launch_bounds__(kTile / P, (P == 16 ? 2 : 4)) void k_fft_rows(const Params p) {
     constexpr int T = kTile / P;
     extern __shared__ double2 sm[];
@@ -498,15 +632,18 @@ __global__ __launch_bounds__(kTile / P, (P == 16 ? 2 : 4)) void k_fft_rows(const
         const int64_t rr = (e & 1) ? r1 : r0;
         v[k] = work[(rr << p.log_n2) + (e >> 1)];
     }
+    const auto kt = KTabSel<TLDS>::make(p, p.per_det ? (int64_t)(p.det0 + b) : 0, reinterpret_cast<char *>(sm + kTile),
+                                        tid, T);
+    PHASE_DECL;
+    PHASE_WAIT_LOADS;
+    PHASE_MARK(0);
     tile_fft<P>(v, sm, tid, p.log_n2, p.tb.wtile);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < P; ++k) sm[sw(tid + k * T)] = v[k];
     __syncthreads();
+    PHASE_MARK(1);
 
-    const int64_t kern = p.per_det ? (int64_t)(p.det0 + b) : 0;
-    const double * __restrict__ mc = p.mag_coef + kern * 4 * (p.n_knot - 1);
-    const double * __restrict__ ac = p.ang_coef ? p.ang_coef + kern * 4 * (p.n_knot - 1) : nullptr;
     // bins k and M - k: real-FFT unpacking, kernel, repacking (all factors 1/2 are in p.scale)
     if (g != 0) {
         // every workgroup but the first: pair q = (row k1, element q) with (row N1 - k1, element N2 - 1 - q), bin
@@ -518,15 +655,22 @@ __global__ __launch_bounds__(kTile / P, (P == 16 ? 2 : 4)) void k_fft_rows(const
                                    0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128673848};
         constexpr double s16[8] = {0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128673848,
                                    1.0, 0.92387953251128673848, 0.70710678118654752440, 0.38268343236508977173};
-        const int64_t k0 = g + n1 * tid;
+        const int k0 = g + ((int)n1) * tid;
+        const int dk = ((int)n1) * T;
         const double2 w0 = tw_big(p.tb, k0);
+        int lo_a[NP], lo_b[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            lo_a[i] = kernel_interval(kt, k0 + dk * i);
+            lo_b[i] = kernel_interval(kt, (int)m - (k0 + dk * i));
+        }
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int q = tid + T * i;
-            const int64_t k = k0 + n1 * (int64_t)(T * i);
+            const int k = k0 + dk * i;
             const double2 wk = (i == 0) ? w0 : cmul(w0, make_double2(c16[i * (16 / P)], -s16[i * (16 / P)]));
-            pair_update(sm, 2 * q, 2 * (n2 - 1 - q) + 1, wk, kernel_at(p, mc, ac, k), kernel_at(p, mc, ac, m - k),
-                        p.deconvolve);
+            pair_update(sm, 2 * q, 2 * (n2 - 1 - q) + 1, wk, kernel_eval(kt, lo_a[i], k),
+                        kernel_eval(kt, lo_b[i], (int)m - k), p.deconvolve);
         }
     } else {
         for (int i = 0; i < n2 / T; ++i) {
@@ -542,7 +686,7 @@ __global__ __launch_bounds__(kTile / P, (P == 16 ? 2 : 4)) void k_fft_rows(const
                 if (qq == 0) {
                     // DC and Nyquist share element 0: Z[0] = a + i b, X[0] = a + b, X[M] = a - b
                     const double2 z0 = sm[sw(0)];
-                    const double2 km = kernel_at(p, mc, ac, m);
+                    const double2 km = kernel_at(kt, m);
                     double2 ym = apply_kernel(make_double2(2.0 * (z0.x - z0.y), 0.0), km, p.deconvolve);
                     ym.y = 0.0;                                  // Nyquist bin of a real transform is real
                     // Y[0] = 0 (DC removed): Z'[0] = (Y[M], -Y[M]); stored swapped
@@ -555,27 +699,92 @@ __global__ __launch_bounds__(kTile / P, (P == 16 ? 2 : 4)) void k_fft_rows(const
                     k = n1 * qq;
                 }
             }
-            pair_update(sm, ea, eb, tw_big(p.tb, k), kernel_at(p, mc, ac, k), kernel_at(p, mc, ac, m - k), p.deconvolve);
+            pair_update(sm, ea, eb, tw_big(p.tb, k), kernel_at(kt, k), kernel_at(kt, m - k), p.deconvolve);
         }
     }
     __syncthreads();
+    PHASE_MARK(2);
 #pragma unroll
     for (int k = 0; k < P; ++k) v[k] = sm[sw(tid + k * T)];
     tile_fft<P>(v, sm, tid, p.log_n2, p.tb.wtile);
+    PHASE_MARK(3);
 #pragma unroll
     for (int k = 0; k < P; ++k) {
         const int e = tid + k * T;
         const int64_t rr = (e & 1) ? r1 : r0;
         work[(rr << p.log_n2) + (e >> 1)] = v[k];
     }
+    PHASE_WAIT_LOADS;
+    PHASE_MARK(4);
 }
 
-// per-block start interval of the kernel's piecewise cubics (bins 256 i: frequency 256 i fstep)
-__global__ void k_knot_hint(const double * __restrict__ knots, int n_knot, double fstep, int64_t n_block,
-                            int32_t * __restrict__ hint) {
+// pass 2, row pairs (k1, N1 - k1) with 0 < k1 < N1 / 2: ONE row (N2 = 2048 elements, 32 KB of LDS) in the tile at
+// a time, so that four or five workgroups share a CU instead of two (the passes are latency bound:
+// profiles/r02_c_pmc_hot_kernels.txt).  Bin k of row k1 pairs with bin M - k = element N2 - 1 - q of row N1 - k1.  The
+// last radix-P butterfly of the second row's transform is computed by the MIRRORED thread (u = T - 1 - tid), which
+// leaves both members of each of the thread's P pairs in its own registers: unpacking, kernel and repacking need no
+// LDS round trip, and the first butterfly of that row's inverse transform starts from the same registers.
+template <int P, int WPE, bool TLDS>
+__global__ __launch_bounds__((kTile / 2) / P, WPE) void k_fft_rows_split(const Params p) {
+    constexpr int LT = kLT - 1;
+    constexpr int T = (1 << LT) / P;
+    extern __shared__ double2 sm[];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int g = blockIdx.x + 1;
+    const int64_t n1 = int64_t(1) << p.log_n1;
+    const int64_t m = n1 << LT;
+    double2 * __restrict__ row_a = p.work + (int64_t)b * m + ((int64_t)g << LT);
+    double2 * __restrict__ row_b = p.work + (int64_t)b * m + ((n1 - g) << LT);
+    double2 va[P], vb[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) va[k] = row_a[tid + k * T];
+#pragma unroll
+    for (int k = 0; k < P; ++k) vb[k] = row_b[tid + k * T];
+    const int um = T - 1 - tid;
+    const auto kt = KTabSel<TLDS>::make(p, p.per_det ? (int64_t)(p.det0 + b) : 0,
+                                        reinterpret_cast<char *>(sm + (kTile / 2)), tid, T);
+    tile_fft_t<LT, P>(va, sm, tid, LT, p.tb.wtile, tid, tid);      // va[j] = Z[g + N1 (tid + j T)]
+    tile_fft_t<LT, P>(vb, sm, tid, LT, p.tb.wtile, tid, um);       // vb[j] = Z[M - (g + N1 (tid + (P-1-j) T))]
+
+    {
+        // a thread's bins k = k0 + N1 T j are N / (2 P) apart: unpacking twiddles w_N^k0 times the constants w_2P^j
+        constexpr double c16[8] = {1.0, 0.92387953251128673848, 0.70710678118654752440, 0.38268343236508977173,
+                                   0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128673848};
+        constexpr double s16[8] = {0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128673848,
+                                   1.0, 0.92387953251128673848, 0.70710678118654752440, 0.38268343236508977173};
+        static_assert(P == 8 || P == 4, "k_fft_rows_split: 4 or 8 points per thread");
+        const int k0 = g + ((int)n1) * tid;
+        const int dk = ((int)n1) * T;
+        const double2 w0 = tw_big(p.tb, k0);
+        int lo_a[P], lo_b[P];
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            lo_a[j] = kernel_interval(kt, k0 + dk * j);
+            lo_b[j] = kernel_interval(kt, (int)m - (k0 + dk * j));
+        }
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int k = k0 + dk * j;
+            const double2 wk = (j == 0) ? w0 : cmul(w0, make_double2(c16[j * (8 / P)], -s16[j * (8 / P)]));
+            pair_update_reg(va[j], vb[P - 1 - j], false, wk, kernel_eval(kt, lo_a[j], k),
+                            kernel_eval(kt, lo_b[j], (int)m - k), p.deconvolve);
+        }
+    }
+    tile_fft_t<LT, P>(vb, sm, tid, LT, p.tb.wtile, um, tid);
+#pragma unroll
+    for (int k = 0; k < P; ++k) row_b[tid + k * T] = vb[k];
+    tile_fft_t<LT, P>(va, sm, tid, LT, p.tb.wtile, tid, tid);
+#pragma unroll
+    for (int k = 0; k < P; ++k) row_a[tid + k * T] = va[k];
+}
+
+// interval of the kernel's piecewise cubics at bin q N1 (frequency q N1 fstep), q = 0 .. N2 + 1
+__global__ void k_knot_hint(const double * __restrict__ knots, int n_knot, double fstep, int log_n1, int64_t n_block,
+                            int32_t * __restrict__ hint, uint16_t * __restrict__ hint16) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_block) return;
-    const double x = (double)(i << 8) * fstep;
+    const double x = (double)(i << log_n1) * fstep;
     int lo = 0, hi = n_knot - 2;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -586,6 +795,7 @@ __global__ void k_knot_hint(const double * __restrict__ knots, int n_knot, doubl
         }
     }
     hint[i] = lo;
+    hint16[i] = (uint16_t)(lo < 65535 ? lo : 65535);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -627,18 +837,18 @@ static Plan & get_plan(int64_t n_fft, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
         const int lds = kTile * sizeof(double2);
-        TH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_cols<16, false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        TH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_cols<16, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        TH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_rows<16>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        TH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_cols<8, false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        TH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_cols<8, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        TH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_rows<8>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        const int lds_tab = lds + kTabLdsMax;     // the row pass keeps the kernel tables behind the tile
+        auto set = [](const void * fn, int bytes) {
+            TH_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+        };
+        set(reinterpret_cast<const void *>(&k_fft_cols<16, false>), lds);
+        set(reinterpret_cast<const void *>(&k_fft_cols<16, true>), lds);
+        set(reinterpret_cast<const void *>(&k_fft_cols<8, false>), lds);
+        set(reinterpret_cast<const void *>(&k_fft_cols<8, true>), lds);
+        set(reinterpret_cast<const void *>(&k_fft_rows<16, false>), lds);
+        set(reinterpret_cast<const void *>(&k_fft_rows<8, false>), lds);
+        set(reinterpret_cast<const void *>(&k_fft_rows<16, true>), lds_tab);
+        set(reinterpret_cast<const void *>(&k_fft_rows<8, true>), lds_tab);
         attr_set = true;
     }
     return g_plans.emplace(key, pl).first->second;
@@ -668,6 +878,19 @@ int points_of(int pass) {
     read_points();
     return g_points[pass];
 }
+// row pass: 0 = row pair per 64 KB tile (k_fft_rows, default), 1 = one row per 32 KB tile (k_fft_rows_split:
+// experiment; needs more registers than four workgroups per CU leave)
+namespace {
+int g_rows_split = -1;
+}
+int rows_split() {
+    if (g_rows_split < 0) {
+        const char * e = std::getenv("TOAST_HIP_FFT_ROWS");
+        g_rows_split = (e != nullptr && std::string(e) == "split") ? 1 : 0;
+    }
+    return g_rows_split;
+}
+void set_rows_split(int split) { g_rows_split = split ? 1 : 0; }
 void set_points(int rows, int cols_fwd, int cols_inv) {
     g_points[0] = 0;
     read_points();       // defaults
@@ -725,16 +948,29 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
     const int64_t cap = (int64_t)((size_t(8) << 30) / ((size_t)m * sizeof(double2)));
     if (batch > cap) batch = cap > 0 ? cap : 1;
     if (batch > n_det) batch = n_det;
-    const int64_t n_hint = (m >> 8) + 1;
-    const size_t hint_bytes = ((size_t)n_hint * sizeof(int32_t) + 255) & ~size_t(255);
+    const int64_t n_hint = (kTile / 2) + 2;       // bins q N1, q = 0 .. N2 + 1
+    const size_t hint_bytes = ((size_t)n_hint * (sizeof(int32_t) + sizeof(uint16_t)) + 255) & ~size_t(255);
     char * scratch = (char *)Manager::get().scratch(Manager::kScratchFftWork,
                                                     hint_bytes + (size_t)batch * m * sizeof(double2));
     int32_t * d_hint = (int32_t *)scratch;
+    uint16_t * d_hint16 = (uint16_t *)(d_hint + n_hint);
     p.knot_hint = d_hint;
+    p.knot_hint16 = d_hint16;
     p.work = (double2 *)(scratch + hint_bytes);
     hipLaunchKernelGGL(k_knot_hint, dim3((unsigned)((n_hint + 255) / 256)), dim3(256), 0, st, d_knots,
-                       (int)n_knot, fstep, n_hint, d_hint);
+                       (int)n_knot, fstep, p.log_n1, n_hint, d_hint, d_hint16);
+    // row pass: knots, this detector's cubics and 16-bit hints in LDS when they fit (layout: KTabSel<true>::make)
+    const size_t tab_bytes = (((size_t)n_knot + (size_t)4 * (n_knot - 1) * (d_ang ? 2 : 1)) * sizeof(double) +
+                              (size_t)n_hint * sizeof(uint16_t) + 15) & ~size_t(15);
+    static int tab_lds_env = -1;
+    if (tab_lds_env < 0) {
+        const char * e = std::getenv("TOAST_HIP_FFT_TABLES");      // "global": experiment switch
+        tab_lds_env = (e != nullptr && std::string(e) == "global") ? 0 : 1;
+    }
+    const bool tab_lds = tab_lds_env && n_knot < 65535 && tab_bytes <= (size_t)kTabLdsMax;
     const size_t lds = kTile * sizeof(double2);
+    const size_t lds_rows = lds + (tab_lds ? tab_bytes : 0);
+    const size_t lds_split = lds / 2 + (tab_lds ? tab_bytes : 0);
     const unsigned n_col_tiles = (unsigned)(int64_t(1) << (p.log_n2 - (kLT - p.log_n1)));   // N2 / C
     const unsigned n_row_tiles = (unsigned)((int64_t(1) << p.log_n1) / 2);                 // N1 / 2
     for (int64_t det0 = 0; det0 < n_det; det0 += batch) {
@@ -746,10 +982,37 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
         } else {
             hipLaunchKernelGGL((k_fft_cols<16, false>), dim3(n_col_tiles, (unsigned)nb), dim3(kTile / 16), lds, st, p);
         }
-        if (points_of(0) == 8) {
-            hipLaunchKernelGGL(k_fft_rows<8>, dim3(n_row_tiles, (unsigned)nb), dim3(kTile / 8), lds, st, p);
+        const bool split = rows_split() != 0;
+        const dim3 g_pair(split ? 1 : n_row_tiles, (unsigned)nb);   // split: rows 0 and N1 / 2 only (self-paired)
+        if (split || points_of(0) == 8) {
+            if (tab_lds) {
+                hipLaunchKernelGGL((k_fft_rows<8, true>), g_pair, dim3(kTile / 8), lds_rows, st, p);
+            } else {
+                hipLaunchKernelGGL((k_fft_rows<8, false>), g_pair, dim3(kTile / 8), lds_rows, st, p);
+            }
+        } else if (tab_lds) {
+            hipLaunchKernelGGL((k_fft_rows<16, true>), g_pair, dim3(kTile / 16), lds_rows, st, p);
         } else {
-            hipLaunchKernelGGL(k_fft_rows<16>, dim3(n_row_tiles, (unsigned)nb), dim3(kTile / 16), lds, st, p);
+            hipLaunchKernelGGL((k_fft_rows<16, false>), g_pair, dim3(kTile / 16), lds_rows, st, p);
+        }
+        if (split && n_row_tiles > 1) {
+            static int wpe = -1;
+            if (wpe < 0) {
+                const char * e = std::getenv("TOAST_HIP_FFT_ROWS_WPE");
+                wpe = e ? std::atoi(e) : 4;
+            }
+            const dim3 gr(n_row_tiles - 1, (unsigned)nb), bl(kTile / 16);
+            if (tab_lds) {
+                if (wpe == 2) {
+                    hipLaunchKernelGGL((k_fft_rows_split<8, 2, true>), gr, bl, lds_split, st, p);
+                } else if (wpe == 3) {
+                    hipLaunchKernelGGL((k_fft_rows_split<8, 3, true>), gr, bl, lds_split, st, p);
+                } else {
+                    hipLaunchKernelGGL((k_fft_rows_split<8, 4, true>), gr, bl, lds_split, st, p);
+                }
+            } else {
+                hipLaunchKernelGGL((k_fft_rows_split<8, 2, false>), gr, bl, lds_split, st, p);
+            }
         }
         if (points_of(2) == 8) {
             hipLaunchKernelGGL((k_fft_cols<8, true>), dim3(n_col_tiles, (unsigned)nb), dim3(kTile / 8), lds, st, p);
@@ -760,5 +1023,22 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
     }
 }
 
+#if defined(TOAST_FFT_PHASE_CLOCK)
+void phase_ticks(unsigned long long * out, int reset) {
+    TH_HIP(hipDeviceSynchronize());
+    TH_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase_ticks), 16 * sizeof(unsigned long long)));
+    if (reset) {
+        unsigned long long z[16] = {0};
+        TH_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_phase_ticks), z, sizeof(z)));
+    }
+}
+#endif
+
 }  // namespace fused_fft
 }  // namespace toast_hip
+
+#if defined(TOAST_FFT_PHASE_CLOCK)
+extern "C" void toast_hip_fft_phase_ticks(unsigned long long * out, int reset) {
+    toast_hip::fused_fft::phase_ticks(out, reset);
+}
+#endif

@@ -37,6 +37,11 @@ def set_points(rows=0, cols_fwd=0, cols_inv=0):
     capi.lib().toast_hip_fft_points(C.c_int(int(rows)), C.c_int(int(cols_fwd)), C.c_int(int(cols_inv)))
 
 
+def set_rows_split(split=True):
+    """Row pass of the fused kernels: one row per 32 KB tile (default) or the row pair in one 64 KB tile."""
+    capi.lib().toast_hip_fft_rows_split(C.c_int(1 if split else 0))
+
+
 def pipeline_bytes_per_sample(n_samp):
     """HBM bytes per timestream sample moved by the passes of the implementation in use."""
     fn = capi.lib().toast_hip_fft_pipeline_bytes

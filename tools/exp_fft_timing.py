@@ -9,7 +9,7 @@ from toast_amd.accel import ensure_assigned
 ensure_assigned()
 n_det, n_samp, rate = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, 720000, 200.0
 x = torch.randn(n_det, n_samp, dtype=torch.float64, device="cuda")
-freq = np.linspace(0, rate / 2, 400)
+freq = np.linspace(0, rate / 2, 70)      # NoiseFilter kernels have ~70 knots
 kern = 1.0 / (1.0 + (0.05 / np.maximum(freq, 1e-4)) ** 1.0)
 kernels = np.tile(kern, (n_det, 1))
 idx = np.arange(n_det, dtype=np.int32)
