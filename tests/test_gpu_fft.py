@@ -246,3 +246,41 @@ def test_fused_complex_kernels_and_common_kernel(pf, deconvolve):
         got = data.copy()
         pf.convolve(got, rate, kernel_freq=freq, kernels=kernels, deconvolve=deconvolve)
         assert np.max(np.abs(got - want)) < (1e-11 if deconvolve else TOL) * np.max(np.abs(want))
+
+
+@pytest.mark.parametrize("rows", ["pair", "split"])
+@pytest.mark.parametrize("tables", ["lds-complex", "lds-dense", "global-dense", "global-complex"])
+def test_fused_kernel_table_paths(pf, rows, tables):
+    """Row pass of the fused pipeline: kernel tables in LDS (few knots) or in global memory (many), interval search
+    with several knots inside one block of N1 bins (dense knot vectors: the walk from the per-row-element hint), real
+    and complex kernels; both tile layouts of the row pass (row pair per 64 KB tile / one row per 32 KB tile with the
+    mirrored last butterfly)."""
+    from oracle import fft_oracle as fo
+
+    rate, n_det = 200.0, 3
+    if tables == "lds-complex":
+        freq = np.concatenate([[0.0], np.geomspace(1e-4, rate / 2, 90)])
+        phase = True
+    elif tables == "lds-dense":
+        # knot spacing 0.0134 Hz below 2 Hz: 3 - 4 knots per block of N1 bins (rate / 4096 = 0.049 Hz)
+        freq = np.concatenate([np.linspace(0.0, 2.0, 150), np.geomspace(2.1, rate / 2, 50)])
+        phase = False
+    elif tables == "global-dense":
+        freq = np.linspace(0.0, rate / 2, 5000)
+        phase = False
+    else:
+        freq = np.linspace(0.0, rate / 2, 400)
+        phase = True
+    kernels = _noise_kernels(freq, n_det, complex_phase=phase)
+    pf.set_rows_split(rows == "split")
+    try:
+        for n_samp in (9000, 100001, 720000):
+            rng = np.random.default_rng(n_samp)
+            data = rng.standard_normal((n_det, n_samp)).cumsum(axis=1) * 0.01 + rng.standard_normal((n_det, n_samp))
+            want = data.copy()
+            fo.convolve(want, rate, kernel_freq=freq, kernels=kernels)
+            got = data.copy()
+            pf.convolve(got, rate, kernel_freq=freq, kernels=kernels)
+            assert np.max(np.abs(got - want)) < TOL * np.max(np.abs(want)), (n_samp, tables, rows)
+    finally:
+        pf.set_rows_split(False)

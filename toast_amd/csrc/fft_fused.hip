@@ -305,6 +305,7 @@ struct Params {
     const uint16_t * knot_hint16; // the same in 16 bits (n_knot < 65536), for the LDS copy
     int per_det, deconvolve;
     int aligned;                  // pass 1 may use padded_pair
+    int xcd_order;                // column passes: contiguous column ranges per XCD
     double fstep, scale;
 };
 
@@ -387,6 +388,24 @@ __device__ __forceinline__ double2 padded_pair(const double * __restrict__ row, 
     return make_double2(0.0, 0.0);
 }
 
+// Experimental build (-DTOAST_FFT_PHASE_CLOCK, tools/exp_fft_phases.py): thread 0 of every workgroup
+// adds the 100 MHz wall-clock ticks between phase boundaries to g_phase_ticks.
+#if defined(TOAST_FFT_PHASE_CLOCK)
+__device__ unsigned long long g_phase_ticks[16];
+# define PHASE_DECL unsigned long long ph_t = wall_clock64()
+# define PHASE_WAIT_LOADS asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+# define PHASE_MARK(i)                                                        \
+    do {                                                                      \
+        const unsigned long long ph_n = wall_clock64();                       \
+        if (threadIdx.x == 0) atomicAdd(&g_phase_ticks[i], ph_n - ph_t);      \
+        ph_t = ph_n;                                                          \
+    } while (0)
+#else
+# define PHASE_DECL
+# define PHASE_WAIT_LOADS
+# define PHASE_MARK(i)
+#endif
+
 // pass 1 (INV = false) and pass 3 (INV = true): transforms of length N1 down the columns
 template <int P, bool INV>
 __global__ __launch_bounds__(kTile / P, (P == 16 ? 2 : 4)) void k_fft_cols(const Params p) {
@@ -396,7 +415,11 @@ __global__ __launch_bounds__(kTile / P, (P == 16 ? 2 : 4)) void k_fft_cols(const
     const int b = blockIdx.y;
     const int log_c = kLT - p.log_n1;                 // columns per tile
     const int64_t n2 = int64_t(1) << p.log_n2;
-    const int64_t c0 = (int64_t)blockIdx.x << log_c;
+    // XCD-aware tile order: workgroups go round-robin to the 8 XCDs, so with tile = blockIdx.x every XCD's L2 would
+    // hold every 8th 128-byte piece of a row of the work array; this way XCD x owns a contiguous eighth of the columns
+    unsigned bx = blockIdx.x;
+    if (p.xcd_order && (gridDim.x & 7u) == 0u) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);
+    const int64_t c0 = (int64_t)bx << log_c;
     const int64_t m = int64_t(1) << (p.log_n1 + p.log_n2);
     double2 * __restrict__ work = p.work + (int64_t)b * m;
     double * __restrict__ row = p.tod + (int64_t)p.d_idx[p.det0 + b] * p.n_samp;
@@ -430,7 +453,11 @@ __global__ __launch_bounds__(kTile / P, (P == 16 ? 2 : 4)) void k_fft_cols(const
         }
         col_twiddles<P>(v, p, tid, log_c, c0, col_twiddles_prepare<P>(p, tid, log_c, c0));
     }
+    PHASE_DECL;
+    PHASE_WAIT_LOADS;
+    PHASE_MARK(INV ? 10 : 5);
     tile_fft<P>(v, sm, tid, p.log_n1, p.tb.wtile);
+    PHASE_MARK(INV ? 11 : 6);
     if (!INV) {
         col_twiddles<P>(v, p, tid, log_c, c0, col_twiddles_prepare<P>(p, tid, log_c, c0));
 #pragma unroll
@@ -451,6 +478,9 @@ __global__ __launch_bounds__(kTile / P, (P == 16 ? 2 : 4)) void k_fft_cols(const
             if (s + 1 >= 0 && s + 1 < p.n_samp) row[s + 1] = v[k].x * p.scale;
         }
     }
+    PHASE_MARK(INV ? 12 : 7);
+    PHASE_WAIT_LOADS;
+    PHASE_MARK(INV ? 13 : 8);
     (void)n2;
 }
 
@@ -591,24 +621,6 @@ __device__ __forceinline__ void pair_update(double2 * sm, int ea, int eb, double
     sm[sw(ea)] = za;
     if (eb != ea) sm[sw(eb)] = zb;
 }
-
-// Experimental build (-DTOAST_FFT_PHASE_CLOCK, tools/exp_fft_phases.py): thread 0 of every workgroup of the row pass
-// adds the 100 MHz wall-clock ticks between phase boundaries to g_phase_ticks.
-#if defined(TOAST_FFT_PHASE_CLOCK)
-__device__ unsigned long long g_phase_ticks[16];
-# define PHASE_DECL unsigned long long ph_t = wall_clock64()
-# define PHASE_WAIT_LOADS asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-# define PHASE_MARK(i)                                                        \
-    do {                                                                      \
-        const unsigned long long ph_n = wall_clock64();                       \
-        if (threadIdx.x == 0) atomicAdd(&g_phase_ticks[i], ph_n - ph_t);      \
-        ph_t = ph_n;                                                          \
-    } while (0)
-#else
-# define PHASE_DECL
-# define PHASE_WAIT_LOADS
-# define PHASE_MARK(i)
-#endif
 
 // pass 2: rows (k1, N1 - k1) [block 0: rows 0 and N1 / 2]
 template <int P, bool TLDS>
@@ -941,6 +953,14 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
     p.aligned = ((n_buffer % 2) == 0 && (n_samp % 2) == 0 && (n_reflect % 2) == 0 &&
                  (reinterpret_cast<uintptr_t>(d_tod) % 16) == 0 && (reinterpret_cast<uintptr_t>(d_apod) % 16) == 0)
                     ? 1 : 0;
+    {
+        static int xo = -1;
+        if (xo < 0) {
+            const char * e = std::getenv("TOAST_HIP_FFT_XCD");
+            xo = (e != nullptr && e[0] == '0') ? 0 : 1;
+        }
+        p.xcd_order = xo;
+    }
     // unnormalised inverse of length M on un-halved packing factors: 1 / (4 M), a power of two
     p.scale = 1.0 / (4.0 * (double)m);
 
@@ -996,20 +1016,9 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
             hipLaunchKernelGGL((k_fft_rows<16, false>), g_pair, dim3(kTile / 16), lds_rows, st, p);
         }
         if (split && n_row_tiles > 1) {
-            static int wpe = -1;
-            if (wpe < 0) {
-                const char * e = std::getenv("TOAST_HIP_FFT_ROWS_WPE");
-                wpe = e ? std::atoi(e) : 4;
-            }
             const dim3 gr(n_row_tiles - 1, (unsigned)nb), bl(kTile / 16);
             if (tab_lds) {
-                if (wpe == 2) {
-                    hipLaunchKernelGGL((k_fft_rows_split<8, 2, true>), gr, bl, lds_split, st, p);
-                } else if (wpe == 3) {
-                    hipLaunchKernelGGL((k_fft_rows_split<8, 3, true>), gr, bl, lds_split, st, p);
-                } else {
-                    hipLaunchKernelGGL((k_fft_rows_split<8, 4, true>), gr, bl, lds_split, st, p);
-                }
+                hipLaunchKernelGGL((k_fft_rows_split<8, 2, true>), gr, bl, lds_split, st, p);
             } else {
                 hipLaunchKernelGGL((k_fft_rows_split<8, 2, false>), gr, bl, lds_split, st, p);
             }

@@ -15,9 +15,9 @@ freq = np.linspace(0, rate / 2, 70)
 kern = 1.0 / (1.0 + (0.05 / np.maximum(freq, 1e-4)) ** 1.0)
 kernels = np.tile(kern, (n_det, 1)) * np.linspace(0.9, 1.1, n_det)[:, None]
 idx = np.arange(n_det, dtype=np.int32)
-names = sys.argv[1].split(",") if len(sys.argv) > 1 else ["load", "fft", "pair", "ifft", "store"]
+names = sys.argv[1].split(",") if len(sys.argv) > 1 else ["r:load", "r:fft", "r:pair", "r:ifft", "r:store", "cf:load", "cf:fft", "cf:tw+st", "cf:drain", "", "ci:ld+tw", "ci:fft", "ci:store", "ci:drain"]
 ticks = (C.c_ulonglong * 16)()
-for split in (0, 1):
+for split in (0,):
     hipfft.set_rows_split(split)
     hipfft.convolve_dev(x.data_ptr(), idx, n_samp, rate, freq, kernels)
     capi.lib().toast_hip_fft_phase_ticks(ticks, C.c_int(1))
