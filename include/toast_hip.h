@@ -545,7 +545,7 @@ int toast_hip_fft_fused(int64_t n_samp);
 void toast_hip_fft_select(int rocfft_only);
 /* Points per thread (16 or 8; anything else = default) of the row pass, the forward and the inverse
  * column pass of the fused kernels: 16 = 256-thread workgroups with radix-16 stages, 8 = 512-thread
- * workgroups with radix-8 stages and twice the waves per SIMD.  Defaults 8 / 8 / 16; start-up value
+ * workgroups with radix-8 stages and twice the waves per SIMD.  Defaults 8 / 8 / 8; start-up value
  * from TOAST_HIP_FFT_POINTS="rows,cols_fwd,cols_inv". */
 void toast_hip_fft_points(int rows, int cols_fwd, int cols_inv);
 /* Row pass of the fused kernels: split != 0 (default) = one row of N2 = 2048 bins per 32 KB LDS tile, the two rows

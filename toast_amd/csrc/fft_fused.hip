@@ -333,9 +333,9 @@ struct ColTw {
     double2 w0, wd;
 };
 // the table look-ups (independent of the data: issued before the transform whose barriers they could not cross)
-template <int P>
+template <int LT, int P>
 __device__ __forceinline__ ColTw<P> col_twiddles_prepare(const Params & p, int tid, int log_c, int64_t c0) {
-    constexpr int T = kTile / P;
+    constexpr int T = (1 << LT) / P;
     ColTw<P> tw;
     tw.w0 = make_double2(1.0, 0.0);
     tw.wd = tw.w0;
@@ -348,10 +348,10 @@ __device__ __forceinline__ ColTw<P> col_twiddles_prepare(const Params & p, int t
     }
     return tw;
 }
-template <int P>
+template <int LT, int P>
 __device__ __forceinline__ void col_twiddles(double2 (&v)[P], const Params & p, int tid, int log_c, int64_t c0,
                                              const ColTw<P> & tw) {
-    constexpr int T = kTile / P;
+    constexpr int T = (1 << LT) / P;
     if ((1 << log_c) <= T) {
         v[0] = cmul(v[0], tw.w0);
         apply_powers<P>(v, tw.wd);
@@ -407,13 +407,13 @@ __device__ unsigned long long g_phase_ticks[16];
 #endif
 
 // pass 1 (INV = false) and pass 3 (INV = true): transforms of length N1 down the columns
-template <int P, bool INV>
-__global__ __launch_bounds__(kTile / P, (P == 16 ? 2 : 4)) void k_fft_cols(const Params p) {
-    constexpr int T = kTile / P;
+template <int LT, int P, bool INV>
+__global__ __launch_bounds__((1 << LT) / P, (P == 16 ? 2 : 4)) void k_fft_cols(const Params p) {
+    constexpr int T = (1 << LT) / P;
     extern __shared__ double2 sm[];
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
-    const int log_c = kLT - p.log_n1;                 // columns per tile
+    const int log_c = LT - p.log_n1;                  // columns per tile
     const int64_t n2 = int64_t(1) << p.log_n2;
     // XCD-aware tile order: workgroups go round-robin to the 8 XCDs, so with tile = blockIdx.x every XCD's L2 would
     // hold every 8th 128-byte piece of a row of the work array; this way XCD x owns a contiguous eighth of the columns
@@ -451,15 +451,15 @@ __global__ __launch_bounds__(kTile / P, (P == 16 ? 2 : 4)) void k_fft_cols(const
             const int64_t j2 = c0 + (e & ((1 << log_c) - 1));
             v[k] = work[(k1 << p.log_n2) + j2];
         }
-        col_twiddles<P>(v, p, tid, log_c, c0, col_twiddles_prepare<P>(p, tid, log_c, c0));
+        col_twiddles<LT, P>(v, p, tid, log_c, c0, col_twiddles_prepare<LT, P>(p, tid, log_c, c0));
     }
     PHASE_DECL;
     PHASE_WAIT_LOADS;
     PHASE_MARK(INV ? 10 : 5);
-    tile_fft<P>(v, sm, tid, p.log_n1, p.tb.wtile);
+    tile_fft_t<LT, P>(v, sm, tid, p.log_n1, p.tb.wtile, tid, tid);
     PHASE_MARK(INV ? 11 : 6);
     if (!INV) {
-        col_twiddles<P>(v, p, tid, log_c, c0, col_twiddles_prepare<P>(p, tid, log_c, c0));
+        col_twiddles<LT, P>(v, p, tid, log_c, c0, col_twiddles_prepare<LT, P>(p, tid, log_c, c0));
 #pragma unroll
         for (int k = 0; k < P; ++k) {
             const int e = tid + k * T;
@@ -853,10 +853,10 @@ static Plan & get_plan(int64_t n_fft, hipStream_t st) {
         auto set = [](const void * fn, int bytes) {
             TH_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
         };
-        set(reinterpret_cast<const void *>(&k_fft_cols<16, false>), lds);
-        set(reinterpret_cast<const void *>(&k_fft_cols<16, true>), lds);
-        set(reinterpret_cast<const void *>(&k_fft_cols<8, false>), lds);
-        set(reinterpret_cast<const void *>(&k_fft_cols<8, true>), lds);
+        set(reinterpret_cast<const void *>(&k_fft_cols<kLT, 16, false>), lds);
+        set(reinterpret_cast<const void *>(&k_fft_cols<kLT, 16, true>), lds);
+        set(reinterpret_cast<const void *>(&k_fft_cols<kLT, 8, false>), lds);
+        set(reinterpret_cast<const void *>(&k_fft_cols<kLT, 8, true>), lds);
         set(reinterpret_cast<const void *>(&k_fft_rows<16, false>), lds);
         set(reinterpret_cast<const void *>(&k_fft_rows<8, false>), lds);
         set(reinterpret_cast<const void *>(&k_fft_rows<16, true>), lds_tab);
@@ -868,20 +868,20 @@ static Plan & get_plan(int64_t n_fft, hipStream_t st) {
 
 namespace {
 // points per thread of (row pass, forward column pass, inverse column pass); measured best at cfg-3:
-// 8 / 8 / 16 (profiles/r02_f_fft_points.txt)
+// 8 / 8 / 8 (profiles/r02_f_fft_points.txt; the inverse column pass moved from 16 to 8 with the XCD-aware tile order)
 int g_points[3] = {0, 0, 0};
 void read_points() {
     if (g_points[0] != 0) return;
     g_points[0] = 8;
     g_points[1] = 8;
-    g_points[2] = 16;
+    g_points[2] = 8;
     const char * e = std::getenv("TOAST_HIP_FFT_POINTS");
     if (e != nullptr) {
         int a = 0, b = 0, c = 0;
         if (std::sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) {
             g_points[0] = (a == 16) ? 16 : 8;
             g_points[1] = (b == 16) ? 16 : 8;
-            g_points[2] = (c == 8) ? 8 : 16;
+            g_points[2] = (c == 16) ? 16 : 8;
         }
     }
 }
@@ -992,15 +992,14 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
     const size_t lds_rows = lds + (tab_lds ? tab_bytes : 0);
     const size_t lds_split = lds / 2 + (tab_lds ? tab_bytes : 0);
     const unsigned n_col_tiles = (unsigned)(int64_t(1) << (p.log_n2 - (kLT - p.log_n1)));   // N2 / C
-    const unsigned n_row_tiles = (unsigned)((int64_t(1) << p.log_n1) / 2);                 // N1 / 2
     for (int64_t det0 = 0; det0 < n_det; det0 += batch) {
         const int64_t nb = (n_det - det0 < batch) ? (n_det - det0) : batch;
         p.det0 = (int)det0;
         // points per thread of each pass: TOAST_HIP_FFT_POINTS="rows,cols_fwd,cols_inv" / toast_hip_fft_points
         if (points_of(1) == 8) {
-            hipLaunchKernelGGL((k_fft_cols<8, false>), dim3(n_col_tiles, (unsigned)nb), dim3(kTile / 8), lds, st, p);
+            hipLaunchKernelGGL((k_fft_cols<kLT, 8, false>), dim3(n_col_tiles, (unsigned)nb), dim3(kTile / 8), lds, st, p);
         } else {
-            hipLaunchKernelGGL((k_fft_cols<16, false>), dim3(n_col_tiles, (unsigned)nb), dim3(kTile / 16), lds, st, p);
+            hipLaunchKernelGGL((k_fft_cols<kLT, 16, false>), dim3(n_col_tiles, (unsigned)nb), dim3(kTile / 16), lds, st, p);
         }
         const bool split = rows_split() != 0;
         const dim3 g_pair(split ? 1 : n_row_tiles, (unsigned)nb);   // split: rows 0 and N1 / 2 only (self-paired)
@@ -1024,9 +1023,9 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
             }
         }
         if (points_of(2) == 8) {
-            hipLaunchKernelGGL((k_fft_cols<8, true>), dim3(n_col_tiles, (unsigned)nb), dim3(kTile / 8), lds, st, p);
+            hipLaunchKernelGGL((k_fft_cols<kLT, 8, true>), dim3(n_col_tiles, (unsigned)nb), dim3(kTile / 8), lds, st, p);
         } else {
-            hipLaunchKernelGGL((k_fft_cols<16, true>), dim3(n_col_tiles, (unsigned)nb), dim3(kTile / 16), lds, st, p);
+            hipLaunchKernelGGL((k_fft_cols<kLT, 16, true>), dim3(n_col_tiles, (unsigned)nb), dim3(kTile / 16), lds, st, p);
         }
         TH_HIP(hipGetLastError());
     }

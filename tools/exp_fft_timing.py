@@ -7,7 +7,9 @@ from toast_amd import fft as hipfft
 from toast_amd.accel import ensure_assigned
 
 ensure_assigned()
-n_det, n_samp, rate = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, 720000, 200.0
+n_det = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+n_samp = int(os.environ.get("FFT_N_SAMP", "720000"))
+rate = 200.0
 x = torch.randn(n_det, n_samp, dtype=torch.float64, device="cuda")
 freq = np.linspace(0, rate / 2, 70)      # NoiseFilter kernels have ~70 knots
 kern = 1.0 / (1.0 + (0.05 / np.maximum(freq, 1e-4)) ** 1.0)
