@@ -992,6 +992,7 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
     const size_t lds_rows = lds + (tab_lds ? tab_bytes : 0);
     const size_t lds_split = lds / 2 + (tab_lds ? tab_bytes : 0);
     const unsigned n_col_tiles = (unsigned)(int64_t(1) << (p.log_n2 - (kLT - p.log_n1)));   // N2 / C
+    const unsigned n_row_tiles = (unsigned)((int64_t(1) << p.log_n1) / 2);                 // N1 / 2
     for (int64_t det0 = 0; det0 < n_det; det0 += batch) {
         const int64_t nb = (n_det - det0 < batch) ? (n_det - det0) : batch;
         p.det0 = (int)det0;
