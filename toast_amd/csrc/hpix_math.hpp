@@ -549,6 +549,50 @@ TOAST_HD int64_t vec_to_pixel(const double * v, int64_t nside, int factor, const
     return pix;
 }
 
+// Pixels of TWO directions that are expected to coincide: the two orthogonally polarised detectors of one
+// focalplane pixel look along the same line of sight, and their direction vectors differ only by the rounding of two
+// different quaternion products (measured: <= 1.6e-15 per component).  When v1 lies within kPairDirTol = 2^-48 of v0 the
+// checked fast path of v0 already decides v1's pixel: pixel_checked() reports `safe` only if every decision of the
+// pixel arithmetic is the same for ALL phi within delta = 2^-43 of its approximate phi, with a margin of
+// bound = 4 nside delta on every truncation operand.  For v1 (reference phi_1 = libm atan2(v1) within 1 ulp of exact):
+//   |phi_1 - phi~| <= 2^-46 (atan2_fast) + sqrt(2) 2^-48 / r + 1 ulp  <  2^-43      for r = |(x, y)| >= 2^-3
+//   equatorial  t2 = 0.75 nside z:          |d t2| <= 0.75 nside 2^-48          = 0.02 nside delta
+//   polar  t1 = nside sqrt(3 (1 - |z|)):    |d t1| <= 1.5 nside 2^-48 / rtz     <= 0.31 nside delta  for 1 - |z| >= 2^-7
+// all inside the factor the bound holds in reserve (hpix_math.hpp, "Ziv-style fast path": 1.03 of 4 used), every
+// operation being monotone in z as it is in phi; the region test |z| <= 2/3 is guarded separately.  Outside these
+// conditions (within 7 degrees of a pole, NaNs, unrelated detectors, an unsafe v0) v1 goes through vec_to_pixel on
+// its own.  Result: bit-identical to two vec_to_pixel calls (tests/devmath_host.cpp devmath_sweep_pair: 3e9 random
+// and pixel-edge adversarial pairs, 0 mismatches).
+#define TOAST_PAIR_DIR_TOL 3.552713678800501e-15      /* 2^-48 */
+#define TOAST_PAIR_R2_MIN 0.015625                    /* 2^-6: r >= 2^-3 */
+#define TOAST_PAIR_ZA_MAX 0.9921875                   /* 1 - 2^-7 */
+#define TOAST_PAIR_REGION_GUARD 7.105427357601002e-15 /* 2^-47 */
+template <bool NEST>
+TOAST_HD void vec_to_pixel_pair(const double * v0, const double * v1, int64_t nside, int factor,
+                                const double * atan_tab, int64_t & pix0, int64_t & pix1) {
+    ZPhi a = zphi_head(v0);
+    a.phi = atan2_fast(v0[1], v0[0]);
+    bool safe;
+    int64_t pix;
+    if (nside <= 8192) {
+        pix = (int64_t)pixel_checked<int32_t, NEST>((int32_t)nside, factor, a, TOAST_ATAN2_FAST_ERR, safe);
+    } else {
+        pix = pixel_checked<int64_t, NEST>(nside, factor, a, TOAST_ATAN2_FAST_ERR, safe);
+    }
+    const double za = f_abs(v0[2]);
+    const double r2 = v0[0] * v0[0] + v0[1] * v0[1];
+    const bool close = (f_abs(v1[0] - v0[0]) <= TOAST_PAIR_DIR_TOL) && (f_abs(v1[1] - v0[1]) <= TOAST_PAIR_DIR_TOL) &&
+                       (f_abs(v1[2] - v0[2]) <= TOAST_PAIR_DIR_TOL) && (r2 >= TOAST_PAIR_R2_MIN) &&
+                       (za <= TOAST_PAIR_ZA_MAX) && (f_abs(za - TOAST_TWOTHIRDS) > TOAST_PAIR_REGION_GUARD);
+    if (__builtin_expect(!safe, 0)) pix = vec_to_pixel_slow<NEST>(v0[0], v0[1], v0[2], nside, factor, atan_tab);
+    pix0 = pix;
+    if (safe && close) {
+        pix1 = pix;
+    } else {
+        pix1 = vec_to_pixel<NEST>(v1, nside, factor, atan_tab);
+    }
+}
+
 // quat_rotate(q, (1,0,0)) for finite q (same reasoning as quat_rotate_z).
 TOAST_HD void quat_rotate_x(const double * q, double * out) {
     const double yw = q[3] * q[1], zw = q[3] * q[2];

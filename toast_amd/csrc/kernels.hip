@@ -51,9 +51,11 @@ __global__ __launch_bounds__(kThreads) void k_pointing_detector(
 // R 32 B quaternion + 1 B flag, W 8 B pixel; hit_submaps written once per run of equal
 // submaps inside a wave.
 // ------------------------------------------------------------------------------------
-template <bool NEST>
+// E = 2: detectors 2b and 2b + 1 of the call in one workgroup; the pixel arithmetic runs once for a co-pointing
+// (orthogonally polarised) pair -- vec_to_pixel_pair, bit-identical to two separate evaluations.
+template <bool NEST, int E>
 __global__ __launch_bounds__(kThreads) void k_pixels_healpix(
-    const Chunk * __restrict__ chunks, int n_chunks, const int32_t * __restrict__ q_idx,
+    const Chunk * __restrict__ chunks, int n_chunks, int n_det, const int32_t * __restrict__ q_idx,
     const int32_t * __restrict__ p_idx, const double * __restrict__ quats,
     const uint8_t * __restrict__ flags, uint8_t mask, int use_flags, int64_t * __restrict__ pixels,
     uint8_t * __restrict__ hsub, FastDiv nps_div, int64_t nside, int factor, int64_t n_samp) {
@@ -61,9 +63,17 @@ __global__ __launch_bounds__(kThreads) void k_pixels_healpix(
     if (threadIdx.x < 2 * TOAST_ATAN_TABLE_N) s_tab[threadIdx.x] = kAtanTab[threadIdx.x];
     __syncthreads();
 
-    const int det = blockIdx.x;
-    const double * qrow = quats + (int64_t)q_idx[det] * n_samp * 4;
-    int64_t * prow = pixels + (int64_t)p_idx[det] * n_samp;
+    const double * qrow[E];
+    int64_t * prow[E];
+    bool valid[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        int det = E * blockIdx.x + e;
+        valid[e] = det < n_det;
+        if (!valid[e]) det = E * blockIdx.x;
+        qrow[e] = quats + (int64_t)q_idx[det] * n_samp * 4;
+        prow[e] = pixels + (int64_t)p_idx[det] * n_samp;
+    }
     const int lane = threadIdx.x & 63;
 
     for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
@@ -72,23 +82,34 @@ __global__ __launch_bounds__(kThreads) void k_pixels_healpix(
             const int i = base + threadIdx.x;
             const bool active = i < c.count;
             const int64_t s = c.first + (active ? i : 0);
-            const Quat q = load_quat(qrow + 4 * s);
-            const double qa[4] = {q.x, q.y, q.z, q.w};
-            double dir[3];
-            quat_rotate_z(qa, dir);
-            int64_t pix = vec_to_pixel<NEST>(dir, nside, factor, s_tab);
-            const bool flagged = use_flags && ((flags[s] & mask) != 0);
-            int64_t sub = -1;
-            if (flagged) {
-                pix = -1;
-            } else {
-                sub = fastdiv(pix, nps_div);
+            double dir[E][3];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const Quat q = load_quat(qrow[e] + 4 * s);
+                const double qa[4] = {q.x, q.y, q.z, q.w};
+                quat_rotate_z(qa, dir[e]);
             }
-            if (!active) sub = -1;
-            const int64_t prev = __shfl_up(sub, 1);
-            if (active) {
-                prow[s] = pix;
-                if (sub >= 0 && (lane == 0 || prev != sub)) hsub[sub] = 1;
+            int64_t pix[E];
+            if constexpr (E == 2) {
+                vec_to_pixel_pair<NEST>(dir[0], dir[1], nside, factor, s_tab, pix[0], pix[1]);
+            } else {
+                pix[0] = vec_to_pixel<NEST>(dir[0], nside, factor, s_tab);
+            }
+            const bool flagged = use_flags && ((flags[s] & mask) != 0);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                int64_t sub = -1;
+                if (flagged) {
+                    pix[e] = -1;
+                } else {
+                    sub = fastdiv(pix[e], nps_div);
+                }
+                if (!active || !valid[e]) sub = -1;
+                const int64_t prev = __shfl_up(sub, 1);
+                if (active && valid[e]) {
+                    prow[e][s] = pix[e];
+                    if (sub >= 0 && (lane == 0 || prev != sub)) hsub[sub] = 1;
+                }
             }
         }
     }
@@ -1176,9 +1197,11 @@ int toast_hip_pixels_healpix_dev(const int32_t * quat_index, int64_t n_det, cons
         const char * d = pb.commit(as_stream(stream));
         const int use_flags = (n_flags == n_samp) ? 1 : 0;
         const FastDiv dv = make_fastdiv(n_pix_submap);
-        auto kern = nest ? k_pixels_healpix<true> : k_pixels_healpix<false>;
-        hipLaunchKernelGGL(kern, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0,
-                           as_stream(stream), (const Chunk *)(d + o_ch), (int)chunks.size(),
+        const bool pair = pair_detectors() && n_det >= 2;
+        auto kern = pair ? (nest ? k_pixels_healpix<true, 2> : k_pixels_healpix<false, 2>)
+                         : (nest ? k_pixels_healpix<true, 1> : k_pixels_healpix<false, 1>);
+        hipLaunchKernelGGL(kern, chunk_grid(pair ? (n_det + 1) / 2 : n_det, chunks.size()), dim3(kThreads), 0,
+                           as_stream(stream), (const Chunk *)(d + o_ch), (int)chunks.size(), (int)n_det,
                            (const int32_t *)(d + o_qi), (const int32_t *)(d + o_pi), d_quats,
                            d_shared_flags, mask, use_flags, d_pixels, d_hit_submaps, dv, nside,
                            factor, n_samp);

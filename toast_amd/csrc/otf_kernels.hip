@@ -84,6 +84,32 @@ __device__ __forceinline__ void hwp_cs4(const OtfDev & P, int64_t s, double & c4
     }
 }
 
+// stokes_weights of one det-sample from its detector quaternion (computed for flagged samples too, like the
+// stand-alone kernel)
+template <int MODE>
+__device__ __forceinline__ void otf_weights(const OtfDev & P, const DetConst & D, const double * r, double c4h,
+                                            double s4h, double (&w)[ModeNnz<MODE>::value]) {
+    if constexpr (MODE == 0) {
+        w[0] = D.cd;
+    } else {
+        double c2a, s2a;
+        stokes_cs2alpha(r, c2a, s2a, P.ref_nan != 0);
+        if constexpr (MODE == 2) {
+            double sb, cb;
+            hwp_rotation(D.c4g, D.s4g, c4h, s4h, cb, sb);
+            const double cang = cb * c2a + sb * s2a;
+            const double sang = sb * c2a - cb * s2a;
+            w[0] = D.cd;
+            w[1] = cang * D.eta * D.cd;
+            w[2] = -sang * D.eta * D.cd * P.usign;
+        } else {
+            w[0] = D.cd;
+            w[1] = c2a * D.eta * D.cd;
+            w[2] = s2a * D.eta * D.cd * P.usign;
+        }
+    }
+}
+
 // LOCAL map index (n_pix_submap * local_submap + pixel-in-submap; -1 when the boresight sample is
 // flagged) and Stokes weights of one det-sample.
 //   PIX 0: the pixel is computed here (pointing_detector -> pixels_healpix -> global2local);
@@ -113,26 +139,7 @@ __device__ __forceinline__ int64_t otf_point(const OtfDev & P, const DetConst & 
     }
     double r[4];
     quat_mult(p, D.f, r);
-    // stokes_weights (computed for flagged samples too, like the stand-alone kernel)
-    if constexpr (MODE == 0) {
-        w[0] = D.cd;
-    } else {
-        double c2a, s2a;
-        stokes_cs2alpha(r, c2a, s2a, P.ref_nan != 0);
-        if constexpr (MODE == 2) {
-            double sb, cb;
-            hwp_rotation(D.c4g, D.s4g, c4h, s4h, cb, sb);
-            const double cang = cb * c2a + sb * s2a;
-            const double sang = sb * c2a - cb * s2a;
-            w[0] = D.cd;
-            w[1] = cang * D.eta * D.cd;
-            w[2] = -sang * D.eta * D.cd * P.usign;
-        } else {
-            w[0] = D.cd;
-            w[1] = c2a * D.eta * D.cd;
-            w[2] = s2a * D.eta * D.cd * P.usign;
-        }
-    }
+    otf_weights<MODE>(P, D, r, c4h, s4h, w);
     if constexpr (PIX == 1) {
         return lidx;
     } else if constexpr (PIX == 3) {
@@ -146,6 +153,55 @@ __device__ __forceinline__ int64_t otf_point(const OtfDev & P, const DetConst & 
         if constexpr (PIX == 2) return pix;
         const int64_t gsm = fastdiv(pix, P.nps_div);
         return P.g2l[gsm] * P.nps_div.d + (pix - gsm * P.nps_div.d);
+    }
+}
+
+// The same for the two detectors of one workgroup (E = 2: detectors 2b and 2b + 1 of the call, the two orthogonally
+// polarised detectors of a focalplane pixel in the usual ordering).  The boresight sample is loaded once; when the
+// pixel is computed here (PIX 0 / 2) both directions go through vec_to_pixel_pair, which evaluates the pixel
+// arithmetic ONCE when the two lines of sight agree to rounding (bit-identical to two separate evaluations by
+// construction and on 3e9 host-checked pairs, tests/devmath_host.cpp) -- the pixel is ~60 % of the per-sample
+// instructions of the on-the-fly kernels.  Unrelated detectors just take the separate path.
+template <bool NEST, int MODE, int PIX>
+__device__ __forceinline__ void otf_point_pair(const OtfDev & P, const DetConst & D0, const DetConst & D1, int64_t s,
+                                               const double * s_tab, double c4h, double s4h,
+                                               double (&w0)[ModeNnz<MODE>::value], double (&w1)[ModeNnz<MODE>::value],
+                                               int64_t & idx0, int64_t & idx1) {
+    if constexpr (PIX == 1 || PIX == 3) {
+        idx0 = otf_point<NEST, MODE, PIX>(P, D0, s, s_tab, c4h, s4h, w0);
+        idx1 = otf_point<NEST, MODE, PIX>(P, D1, s, s_tab, c4h, s4h, w1);
+    } else {
+        const Quat b = load_quat(P.bore + 4 * s);
+        const uint8_t fl = P.use_pflags ? P.pflags[s] : (uint8_t)0;
+        const bool flagged = (fl & P.pmask) != 0;
+        double p[4] = {0.0, 0.0, 0.0, 1.0};
+        if (!flagged) {
+            p[0] = b.x; p[1] = b.y; p[2] = b.z; p[3] = b.w;
+        }
+        double r0[4], r1[4];
+        quat_mult(p, D0.f, r0);
+        quat_mult(p, D1.f, r1);
+        otf_weights<MODE>(P, D0, r0, c4h, s4h, w0);
+        otf_weights<MODE>(P, D1, r1, c4h, s4h, w1);
+        idx0 = idx1 = -1;
+        if (flagged) return;
+        double dir0[3], dir1[3];
+        quat_rotate_z(r0, dir0);
+        quat_rotate_z(r1, dir1);
+        int64_t pix0, pix1;
+        vec_to_pixel_pair<NEST>(dir0, dir1, P.nside, P.factor, s_tab, pix0, pix1);
+        if constexpr (PIX == 2) {
+            idx0 = pix0;
+            idx1 = pix1;
+        } else {
+            const int64_t gsm0 = fastdiv(pix0, P.nps_div);
+            idx0 = P.g2l[gsm0] * P.nps_div.d + (pix0 - gsm0 * P.nps_div.d);
+            idx1 = idx0;
+            if (pix1 != pix0) {
+                const int64_t gsm1 = fastdiv(pix1, P.nps_div);
+                idx1 = P.g2l[gsm1] * P.nps_div.d + (pix1 - gsm1 * P.nps_div.d);
+            }
+        }
     }
 }
 
@@ -234,16 +290,21 @@ __global__ __launch_bounds__(kThreads) void k_otf_accumulate(
                         t[e] = (af == 0) ? (0.0 + av) : 0.0;
                     }
                 }
+                double wk[E][NNZ];
+                int64_t pidx[E];
+                if constexpr (E == 2) {
+                    otf_point_pair<NEST, MODE, PIX>(P, D[0], D[1], s, s_tab, c4h, s4h, wk[0], wk[1], pidx[0], pidx[1]);
+                } else {
+                    pidx[0] = otf_point<NEST, MODE, PIX>(P, D[0], s, s_tab, c4h, s4h, wk[0]);
+                }
 #pragma unroll
                 for (int e = 0; e < E; ++e) {
-                    double wk[NNZ];
-                    const int64_t p = otf_point<NEST, MODE, PIX>(P, D[e], s, s_tab, c4h, s4h, wk);
-                    const bool good = (p >= 0) & ((fd[e] & dmask) == 0) & ((fs & smask) == 0) & valid[e];
+                    const bool good = (pidx[e] >= 0) & ((fd[e] & dmask) == 0) & ((fs & smask) == 0) & valid[e];
                     if (good) {
-                        key[e] = p;
+                        key[e] = pidx[e];
                         const double sd = t[e] * ds[e];
 #pragma unroll
-                        for (int k = 0; k < NNZ; ++k) v[e][k] = sd * wk[k];
+                        for (int k = 0; k < NNZ; ++k) v[e][k] = sd * wk[e][k];
                     }
                 }
             }
@@ -256,9 +317,9 @@ __global__ __launch_bounds__(kThreads) void k_otf_accumulate(
 // A:  SIG 0:  d = (zero ? 0 : d) -/+ scale * P m ; d *= det_w     (scan_map [+ noise_weight])
 //     SIG 1:  a_out += M^T N^-1 (M a - P m)                        (k_offset_scan_project)
 // ------------------------------------------------------------------------------------
-template <bool NEST, int MODE, int SIG, int PIX>
+template <bool NEST, int MODE, int SIG, int PIX, int E>
 __global__ __launch_bounds__(kThreads) void k_otf_scan(
-    const Chunk * __restrict__ chunks, int n_chunks, OtfDev P, OffsetDev O,
+    const Chunk * __restrict__ chunks, int n_chunks, int n_det, OtfDev P, OffsetDev O,
     const int32_t * __restrict__ d_idx, double * __restrict__ tod, double scale, int zero,
     int subtract, const int32_t * __restrict__ f_idx, const uint8_t * __restrict__ flags,
     uint8_t fmask, int use_flags, const double * __restrict__ det_w,
@@ -268,20 +329,32 @@ __global__ __launch_bounds__(kThreads) void k_otf_scan(
     if (threadIdx.x < 2 * TOAST_ATAN_TABLE_N) s_tab[threadIdx.x] = kAtanTab[threadIdx.x];
     __syncthreads();
 
-    const int det = blockIdx.x;
-    DetConst D = det_const(P, det);
-    if (PIX == 1) D.crow = P.cpix + (int64_t)P.cpix_idx[det] * n_samp;
-    double * drow = (SIG == 0) ? tod + (int64_t)d_idx[det] * n_samp : nullptr;
-    const uint8_t * frow = (SIG == 1 && use_flags) ? flags + (int64_t)f_idx[det] * n_samp : nullptr;
+    // E detectors per workgroup: with E = 2 the pixel of a co-pointing detector pair is evaluated once (otf_point_pair)
     const bool fuse = det_w != nullptr;
-    const double dw = fuse ? det_w[det] : 1.0;
-    const int64_t amp_offset = (SIG == 1) ? O.amp_offsets[det] : 0;
+    DetConst D[E];
+    double * drow[E];
+    const uint8_t * frow[E];
+    double dw[E];
+    int64_t amp_offset[E];
+    bool valid[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        int det = E * blockIdx.x + e;
+        valid[e] = det < n_det;
+        if (!valid[e]) det = E * blockIdx.x;
+        D[e] = det_const(P, det);
+        if (PIX == 1) D[e].crow = P.cpix + (int64_t)P.cpix_idx[det] * n_samp;
+        drow[e] = (SIG == 0) ? tod + (int64_t)d_idx[det] * n_samp : nullptr;
+        frow[e] = (SIG == 1 && use_flags) ? flags + (int64_t)f_idx[det] * n_samp : nullptr;
+        dw[e] = fuse ? det_w[det] : 1.0;
+        amp_offset[e] = (SIG == 1) ? O.amp_offsets[det] : 0;
+    }
     for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
         const Chunk c = chunks[ci];
-        int64_t vfirst = 0, abase = 0;
+        int64_t vfirst = 0, vaoff = 0;
         if (SIG == 1) {
             vfirst = O.view_first[c.view];
-            abase = amp_offset + O.view_aoff[c.view];
+            vaoff = O.view_aoff[c.view];
         }
         for (int base = 0; base < c.count; base += kThreads) {
             const int i = base + threadIdx.x;
@@ -289,55 +362,91 @@ __global__ __launch_bounds__(kThreads) void k_otf_scan(
             const int64_t s = c.first + (active ? i : 0);
             if (SIG == 0) {
                 if (!active) continue;
-                double d = zero ? 0.0 : drow[s];
+                double d[E];
+#pragma unroll
+                for (int e = 0; e < E; ++e) d[e] = zero ? 0.0 : drow[e][s];
                 double c4h, s4h;
                 hwp_cs4<MODE>(P, s, c4h, s4h);
-                double wk[NNZ];
-                const int64_t p = otf_point<NEST, MODE, PIX>(P, D, s, s_tab, c4h, s4h, wk);
-                if (p >= 0) {
-                    const double * m = map + NNZ * p;
-                    double v = 0.0;
-#pragma unroll
-                    for (int k = 0; k < NNZ; ++k) v += wk[k] * m[k];
-                    v *= scale;
-                    if (subtract) {
-                        d -= v;
-                    } else {
-                        d += v;
-                    }
+                double wk[E][NNZ];
+                int64_t pidx[E];
+                if constexpr (E == 2) {
+                    otf_point_pair<NEST, MODE, PIX>(P, D[0], D[1], s, s_tab, c4h, s4h, wk[0], wk[1], pidx[0], pidx[1]);
+                } else {
+                    pidx[0] = otf_point<NEST, MODE, PIX>(P, D[0], s, s_tab, c4h, s4h, wk[0]);
                 }
-                if (fuse) d *= dw;
-                drow[s] = d;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if (pidx[e] >= 0) {
+                        const double * m = map + NNZ * pidx[e];
+                        double v = 0.0;
+#pragma unroll
+                        for (int k = 0; k < NNZ; ++k) v += wk[e][k] * m[k];
+                        v *= scale;
+                        if (subtract) {
+                            d[e] -= v;
+                        } else {
+                            d[e] += v;
+                        }
+                    }
+                    if (fuse) d[e] *= dw[e];
+                    if (valid[e]) drow[e][s] = d[e];
+                }
             } else {
-                int64_t key = -1;
-                double v[1] = {0.0};
-                if (active) {
-                    const int64_t a = abase + fastdiv(s - vfirst, O.step_div);
-                    const uint8_t af = O.amp_flags[a];
-                    const double av = O.amps_in[a];
-                    const uint8_t fl = use_flags ? frow[s] : (uint8_t)0;
-                    if (af == 0) {
-                        key = a;
-                        if ((fl & fmask) == 0) {
-                            double c4h, s4h;
-                            hwp_cs4<MODE>(P, s, c4h, s4h);
-                            double wk[NNZ];
-                            const int64_t p = otf_point<NEST, MODE, PIX>(P, D, s, s_tab, c4h, s4h, wk);
-                            double d = 0.0 + av;
-                            if (p >= 0) {
-                                const double * m = map + NNZ * p;
+                int64_t key[E];
+                double v[E][1];
+                double av[E];
+                bool need[E];
+                bool any = false;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    key[e] = -1;
+                    v[e][0] = 0.0;
+                    av[e] = 0.0;
+                    need[e] = false;
+                    if (active && valid[e]) {
+                        const int64_t a = amp_offset[e] + vaoff + fastdiv(s - vfirst, O.step_div);
+                        const uint8_t af = O.amp_flags[a];
+                        av[e] = O.amps_in[a];
+                        const uint8_t fl = use_flags ? frow[e][s] : (uint8_t)0;
+                        if (af == 0) {
+                            key[e] = a;
+                            need[e] = (fl & fmask) == 0;
+                        }
+                    }
+                    any = any || need[e];
+                }
+                if (any) {
+                    double c4h, s4h;
+                    hwp_cs4<MODE>(P, s, c4h, s4h);
+                    double wk[E][NNZ];
+                    int64_t pidx[E];
+                    if constexpr (E == 2) {
+                        otf_point_pair<NEST, MODE, PIX>(P, D[0], D[1], s, s_tab, c4h, s4h, wk[0], wk[1], pidx[0],
+                                                        pidx[1]);
+                    } else {
+                        pidx[0] = otf_point<NEST, MODE, PIX>(P, D[0], s, s_tab, c4h, s4h, wk[0]);
+                    }
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        if (need[e]) {
+                            double d = 0.0 + av[e];
+                            if (pidx[e] >= 0) {
+                                const double * m = map + NNZ * pidx[e];
                                 double sc = 0.0;
 #pragma unroll
-                                for (int k = 0; k < NNZ; ++k) sc += wk[k] * m[k];
+                                for (int k = 0; k < NNZ; ++k) sc += wk[e][k] * m[k];
                                 sc *= 1.0;
                                 d -= sc;
                             }
-                            v[0] = d * dw;
+                            v[e][0] = d * dw[e];
                         }
                     }
                 }
-                const bool tail = wave_run_reduce<1>(key, v);
-                if (tail && key >= 0) unsafeAtomicAdd(O.amps_out + key, v[0]);
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const bool tail = wave_run_reduce<1>(key[e], v[e]);
+                    if (tail && key[e] >= 0) unsafeAtomicAdd(O.amps_out + key[e], v[e][0]);
+                }
             }
         }
     }
@@ -436,10 +545,10 @@ void launch_accumulate(const OtfHost & h, dim3 grid, hipStream_t st, Args... arg
     }
 }
 
-template <int SIG, int PIX, typename... Args>
+template <int SIG, int PIX, int E, typename... Args>
 void launch_scan_pix(const OtfHost & h, dim3 grid, hipStream_t st, Args... args) {
 #define TH_OTF_CASE(N, M)                                                                        \
-    hipLaunchKernelGGL((k_otf_scan<N, M, SIG, PIX>), grid, dim3(kThreads), 0, st, args...)
+    hipLaunchKernelGGL((k_otf_scan<N, M, SIG, PIX, E>), grid, dim3(kThreads), 0, st, args...)
     const bool nest = (PIX == 1) ? true : h.nest;
     if (nest) {
         if (h.mode == 0) TH_OTF_CASE(true, 0);
@@ -453,12 +562,17 @@ void launch_scan_pix(const OtfHost & h, dim3 grid, hipStream_t st, Args... args)
 #undef TH_OTF_CASE
 }
 
+// grid.x = detectors of the call; halved when detector pairs share a workgroup (only where the pixel is computed
+// in the kernel: with the compact pixel cache there is nothing to share)
 template <int SIG, typename... Args>
 void launch_scan(const OtfHost & h, dim3 grid, hipStream_t st, Args... args) {
     if (h.compact) {
-        launch_scan_pix<SIG, 1>(h, grid, st, args...);
+        launch_scan_pix<SIG, 1, 1>(h, grid, st, args...);
+    } else if (pair_detectors() && grid.x >= 2) {
+        grid.x = (grid.x + 1) / 2;
+        launch_scan_pix<SIG, 0, 2>(h, grid, st, args...);
     } else {
-        launch_scan_pix<SIG, 0>(h, grid, st, args...);
+        launch_scan_pix<SIG, 0, 1>(h, grid, st, args...);
     }
 }
 
@@ -476,16 +590,24 @@ __global__ __launch_bounds__(kThreads) void k_hwp_table(int64_t n, const double 
 // straight from the boresight, without the [n_det, n_samp, 4] detector-quaternion buffer in
 // between (cfg-3: 23.6 GB that is never allocated, written or read twice).
 // ------------------------------------------------------------------------------------
-template <bool NEST>
+template <bool NEST, int E>
 __global__ __launch_bounds__(kThreads) void k_otf_pixels(
-    const Chunk * __restrict__ chunks, int n_chunks, OtfDev P, const int32_t * __restrict__ p_idx,
+    const Chunk * __restrict__ chunks, int n_chunks, int n_det, OtfDev P, const int32_t * __restrict__ p_idx,
     int64_t * __restrict__ pixels, uint8_t * __restrict__ hsub, int64_t n_samp) {
     __shared__ double s_tab[2 * TOAST_ATAN_TABLE_N];
     if (threadIdx.x < 2 * TOAST_ATAN_TABLE_N) s_tab[threadIdx.x] = kAtanTab[threadIdx.x];
     __syncthreads();
-    const int det = blockIdx.x;
-    const DetConst D = det_const(P, det);
-    int64_t * prow = pixels + (int64_t)p_idx[det] * n_samp;
+    DetConst D[E];
+    int64_t * prow[E];
+    bool valid[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        int det = E * blockIdx.x + e;
+        valid[e] = det < n_det;
+        if (!valid[e]) det = E * blockIdx.x;
+        D[e] = det_const(P, det);
+        prow[e] = pixels + (int64_t)p_idx[det] * n_samp;
+    }
     const int lane = threadIdx.x & 63;
     for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
         const Chunk c = chunks[ci];
@@ -493,13 +615,21 @@ __global__ __launch_bounds__(kThreads) void k_otf_pixels(
             const int i = base + threadIdx.x;
             const bool active = i < c.count;
             const int64_t s = c.first + (active ? i : 0);
-            double w[1];
-            const int64_t pix = otf_point<NEST, 0, 2>(P, D, s, s_tab, 1.0, 0.0, w);
-            int64_t sub = (pix >= 0 && active) ? fastdiv(pix, P.nps_div) : -1;
-            const int64_t prev = __shfl_up(sub, 1);
-            if (active) {
-                prow[s] = pix;
-                if (sub >= 0 && (lane == 0 || prev != sub)) hsub[sub] = 1;
+            double w[E][1];
+            int64_t pix[E];
+            if constexpr (E == 2) {
+                otf_point_pair<NEST, 0, 2>(P, D[0], D[1], s, s_tab, 1.0, 0.0, w[0], w[1], pix[0], pix[1]);
+            } else {
+                pix[0] = otf_point<NEST, 0, 2>(P, D[0], s, s_tab, 1.0, 0.0, w[0]);
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                int64_t sub = (pix[e] >= 0 && active && valid[e]) ? fastdiv(pix[e], P.nps_div) : -1;
+                const int64_t prev = __shfl_up(sub, 1);
+                if (active && valid[e]) {
+                    prow[e][s] = pix[e];
+                    if (sub >= 0 && (lane == 0 || prev != sub)) hsub[sub] = 1;
+                }
             }
         }
     }
@@ -527,24 +657,40 @@ __global__ __launch_bounds__(kThreads) void k_otf_weights(
 }
 
 // boresight -> int32 local map indices directly (no int64 pixel buffer at all)
-template <bool NEST>
+template <bool NEST, int E>
 __global__ __launch_bounds__(kThreads) void k_otf_compact_pixels(
-    const Chunk * __restrict__ chunks, int n_chunks, OtfDev P, const int32_t * __restrict__ c_idx,
+    const Chunk * __restrict__ chunks, int n_chunks, int n_det, OtfDev P, const int32_t * __restrict__ c_idx,
     int32_t * __restrict__ cpix, int64_t n_samp) {
     __shared__ double s_tab[2 * TOAST_ATAN_TABLE_N];
     if (threadIdx.x < 2 * TOAST_ATAN_TABLE_N) s_tab[threadIdx.x] = kAtanTab[threadIdx.x];
     __syncthreads();
-    const int det = blockIdx.x;
-    const DetConst D = det_const(P, det);
-    int32_t * crow = cpix + (int64_t)c_idx[det] * n_samp;
+    DetConst D[E];
+    int32_t * crow[E];
+    bool valid[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        int det = E * blockIdx.x + e;
+        valid[e] = det < n_det;
+        if (!valid[e]) det = E * blockIdx.x;
+        D[e] = det_const(P, det);
+        crow[e] = cpix + (int64_t)c_idx[det] * n_samp;
+    }
     for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
         const Chunk c = chunks[ci];
         for (int i = threadIdx.x; i < c.count; i += kThreads) {
             const int64_t s = c.first + i;
-            double w[1];
-            int64_t l = otf_point<NEST, 0, 0>(P, D, s, s_tab, 1.0, 0.0, w);
-            if (l < 0) l = -1;   // flagged sample or pixel in a submap that is not local
-            crow[s] = (int32_t)l;
+            double w[E][1];
+            int64_t l[E];
+            if constexpr (E == 2) {
+                otf_point_pair<NEST, 0, 0>(P, D[0], D[1], s, s_tab, 1.0, 0.0, w[0], w[1], l[0], l[1]);
+            } else {
+                l[0] = otf_point<NEST, 0, 0>(P, D[0], s, s_tab, 1.0, 0.0, w[0]);
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                if (l[e] < 0) l[e] = -1;   // flagged sample or pixel in a submap that is not local
+                if (valid[e]) crow[e][s] = (int32_t)l[e];
+            }
         }
     }
 }
@@ -629,7 +775,7 @@ int toast_hip_otf_scan_map_dev(const toast_hip_otf_pointing * pointing, const in
         otf_bind(h, d);
         OffsetDev off{};
         launch_scan<0>(h, chunk_grid(n_det, chunks.size()), st, (const Chunk *)(d + o_ch), (int)chunks.size(),
-                       h.dev, off, (const int32_t *)(d + o_di), d_det_data, data_scale, should_zero ? 1 : 0,
+                       (int)n_det, h.dev, off, (const int32_t *)(d + o_di), d_det_data, data_scale, should_zero ? 1 : 0,
                        should_subtract ? 1 : 0, (const int32_t *)nullptr, (const uint8_t *)nullptr, (uint8_t)0, 0,
                        det_weights ? (const double *)(d + o_dw) : (const double *)nullptr, d_map, n_samp);
         check_launch();
@@ -705,7 +851,7 @@ int toast_hip_otf_offset_scan_project_dev(
         OffsetDev off{(const int64_t *)(d + o_vf), (const int64_t *)(d + o_va), (const int64_t *)(d + o_ao),
                       d_amplitudes_in, d_amplitudes_out, d_amplitude_flags, make_fastdiv(step_length)};
         launch_scan<1>(h, chunk_grid(n_det, chunks.size()), st, (const Chunk *)(d + o_ch), (int)chunks.size(),
-                       h.dev, off, (const int32_t *)nullptr, (double *)nullptr, 1.0, 0, 1,
+                       (int)n_det, h.dev, off, (const int32_t *)nullptr, (double *)nullptr, 1.0, 0, 1,
                        (const int32_t *)(d + o_fi), d_det_flags, det_flag_mask, use_f,
                        (const double *)(d + o_dw), d_map, n_samp);
         check_launch();
@@ -735,10 +881,12 @@ int toast_hip_otf_pixels_healpix_dev(const toast_hip_otf_pointing * pointing, co
         hipStream_t st = as_stream(stream);
         const char * d = pb.commit(st);
         otf_bind(h, d);
-        auto kern = h.nest ? k_otf_pixels<true> : k_otf_pixels<false>;
-        hipLaunchKernelGGL(kern, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0, st,
-                           (const Chunk *)(d + o_ch), (int)chunks.size(), h.dev, (const int32_t *)(d + o_pi),
-                           d_pixels, d_hit_submaps, n_samp);
+        const bool pair = pair_detectors() && n_det >= 2;
+        auto kern = pair ? (h.nest ? k_otf_pixels<true, 2> : k_otf_pixels<false, 2>)
+                         : (h.nest ? k_otf_pixels<true, 1> : k_otf_pixels<false, 1>);
+        hipLaunchKernelGGL(kern, chunk_grid(pair ? (n_det + 1) / 2 : n_det, chunks.size()), dim3(kThreads), 0, st,
+                           (const Chunk *)(d + o_ch), (int)chunks.size(), (int)n_det, h.dev,
+                           (const int32_t *)(d + o_pi), d_pixels, d_hit_submaps, n_samp);
         check_launch();
     });
 }
@@ -803,10 +951,12 @@ int toast_hip_otf_compact_pixels_dev(const toast_hip_otf_pointing * pointing, co
         hipStream_t st = as_stream(stream);
         const char * d = pb.commit(st);
         otf_bind(h, d);
-        auto kern = h.nest ? k_otf_compact_pixels<true> : k_otf_compact_pixels<false>;
-        hipLaunchKernelGGL(kern, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0, st,
-                           (const Chunk *)(d + o_ch), (int)chunks.size(), h.dev, (const int32_t *)(d + o_ci),
-                           d_compact_pixels, n_samp);
+        const bool pair = pair_detectors() && n_det >= 2;
+        auto kern = pair ? (h.nest ? k_otf_compact_pixels<true, 2> : k_otf_compact_pixels<false, 2>)
+                         : (h.nest ? k_otf_compact_pixels<true, 1> : k_otf_compact_pixels<false, 1>);
+        hipLaunchKernelGGL(kern, chunk_grid(pair ? (n_det + 1) / 2 : n_det, chunks.size()), dim3(kThreads), 0, st,
+                           (const Chunk *)(d + o_ch), (int)chunks.size(), (int)n_det, h.dev,
+                           (const int32_t *)(d + o_ci), d_compact_pixels, n_samp);
         check_launch();
     });
 }
