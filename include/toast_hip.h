@@ -87,8 +87,10 @@ int toast_hip_device_free(void * p);
 /* Experiment: virtual range backed by chunk_mb-sized physical allocations mapped in order / shuffled
  * (tools/exp_alloc_flags.py, profiles/r02_d_placement_experiments.txt).  The range is never released. */
 int toast_hip_device_malloc_vmm(size_t nbytes, int chunk_mb, int shuffled, void ** out);
-/* Experiment switches at run time (tools/exp_*.py): key "det_major" = 0 / 1 (workgroup order of the
- * accumulate / scan kernels; the environment variable TOAST_HIP_DET_MAJOR sets the start-up value). */
+/* Switches at run time (tools/exp_*.py, tests): key "det_major" = 0 / 1 (workgroup order of the
+ * accumulate / scan kernels; the environment variable TOAST_HIP_DET_MAJOR sets the start-up value);
+ * key "pair" = 0 / 1 (two detectors per workgroup in the scatter and pixel kernels: merged atomics and one
+ * pixel evaluation for a co-pointing pair; start-up value from TOAST_HIP_PAIR, default 1). */
 int toast_hip_set_tuning(const char * key, int value);
 
 /* Pick this process's GPU: device = node_rank / ceil(node_procs / n_device).  `disabled`

@@ -181,3 +181,36 @@ def test_pair_pixel_sharing_is_bit_identical(devmath, nside, nest):
     assert shared.value > 0.5 * n        # three of the four perturbation amplitudes are inside the tolerance
     if nside >= 64:
         assert differ.value > 0          # the adversarial families do produce pairs in different pixels
+
+
+def test_pixel_edge_samples_where_glibc_misrounds(devmath, oracle):
+    """Directions built to sit on pixel edges (tests/test_gpu_pair_pixels.py): here a 1-ulp difference in phi flips the
+    pixel, and the device path and the glibc-based oracle do differ on ~1e-5 of such samples.  Every one of them is a
+    case where glibc's atan2 is not correctly rounded and the device's double-double atan2 is (mpmath, 50 digits) --
+    the documented residual of DESIGN.md section 2, made visible by construction; on ordinary directions the
+    probability of sitting within an ulp of an edge is ~1e-13 per sample."""
+    import mpmath
+
+    from test_gpu_pair_pixels import _edge_directions, _quat_to
+
+    rng = np.random.default_rng(99)
+    nside, n = 1024, 400_000
+    q = np.ascontiguousarray(_quat_to(_edge_directions(rng, n, nside)))
+    roll = synth.quat_rotation([0.0, 0.0, 1.0], rng.random(n) * 2 * np.pi)
+    q = np.ascontiguousarray(synth.quat_normalize(synth.quat_mult(q, roll)))
+    got = _pixels(devmath, q, nside, 1)
+    want = _oracle_pixels(oracle, q, nside, True)
+    diff = np.flatnonzero(got != want)
+    assert diff.size < 1e-3 * n
+    # direction vectors of the differing samples, as the kernels compute them
+    x, y, z, w = (q[diff, k] for k in range(4))
+    vx = 2 * (w * y + x * z) + 0.0
+    vy = 2 * (y * z - w * x) + 0.0
+    dd = np.empty(diff.size)
+    devmath.devmath_atan2(C.c_int64(diff.size), _p(np.ascontiguousarray(vy)), _p(np.ascontiguousarray(vx)), _p(dd))
+    libm = oracle.libm_atan2(np.ascontiguousarray(vy), np.ascontiguousarray(vx))
+    mpmath.mp.dps = 50
+    exact = np.array([float(mpmath.atan2(mpmath.mpf(float(a)), mpmath.mpf(float(b)))) for a, b in zip(vy, vx)])
+    assert np.array_equal(dd, exact)              # the device's atan2 is the correctly rounded one ...
+    assert np.all(libm != exact)                  # ... and glibc's is 1 ulp off on exactly these samples
+    print("edge samples:", n, "differing:", diff.size)

@@ -137,6 +137,11 @@ def set_deterministic(on):
     real_lib().toast_hip_set_deterministic(C.c_int(1 if on else 0))
 
 
+def set_tuning(key, value):
+    """Run-time switches of the library (toast_hip_set_tuning): "pair" = 0 / 1, "det_major" = 0 / 1."""
+    _check(real_lib().toast_hip_set_tuning(key.encode(), C.c_int(int(value))))
+
+
 def get_deterministic():
     return bool(real_lib().toast_hip_get_deterministic())
 

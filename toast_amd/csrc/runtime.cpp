@@ -48,14 +48,18 @@ bool det_major_grid() {
 
 void set_det_major_grid(int on) { g_det_major = on ? 1 : 0; }
 
-bool pair_detectors() {
-    // TOAST_HIP_PAIR=0 disables the detector-pair accumulate kernels.
-    static const bool v = [] {
-        const char * e = std::getenv("TOAST_HIP_PAIR");
-        return !(e && e[0] == '0');
-    }();
-    return v;
+namespace {
+int g_pair = -1;   // -1: not read yet
 }
+bool pair_detectors() {
+    // TOAST_HIP_PAIR=0 disables the detector-pair kernels; toast_hip_set_tuning("pair", v) at run time.
+    if (g_pair < 0) {
+        const char * e = std::getenv("TOAST_HIP_PAIR");
+        g_pair = (e && e[0] == '0') ? 0 : 1;
+    }
+    return g_pair != 0;
+}
+void set_pair_detectors(int on) { g_pair = on ? 1 : 0; }
 
 std::vector<Chunk> make_chunks(const toast_hip_interval * ivl, int64_t n_view, int64_t n_samp) {
     std::vector<Chunk> out;
@@ -597,11 +601,13 @@ int toast_hip_device_malloc(size_t nbytes, int flags, void ** out) {
     });
 }
 
-// Run-time tuning switches for experiments (tools/): "det_major" = 0 / 1.
+// Run-time tuning switches for experiments and tests: "det_major" = 0 / 1, "pair" = 0 / 1.
 int toast_hip_set_tuning(const char * key, int value) {
     return guarded([&] {
         if (std::string(key) == "det_major") {
             set_det_major_grid(value);
+        } else if (std::string(key) == "pair") {
+            set_pair_detectors(value);
         } else {
             fail_arg(std::string("unknown tuning key ") + key);
         }
