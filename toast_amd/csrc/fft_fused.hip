@@ -369,23 +369,29 @@ __device__ __forceinline__ void col_twiddles(double2 (&v)[P], const Params & p, 
 }
 
 // the same for the pair (x[s + n_buffer], x[s + n_buffer + 1]), s even, when n_samp and n_reflect are even
-// and the row is 16-byte aligned: identical values (one product per element), half the loads
+// and the row is 16-byte aligned: identical values (one product per element), half the loads.
+// BRANCH-FREE: source and window positions are selected arithmetically and both 16-byte loads are issued for every
+// point, so that all 2 P loads of a thread are in flight together.  (With one branch per region the compiler waited
+// for each mirrored point's two loads before the next point: two thirds of the padded series are mirrored, i.e.
+// five or six serialised memory round trips per thread -- the largest part of the forward column pass,
+// profiles/r02_g_fft_phase_clocks.txt section 7.)
 __device__ __forceinline__ double2 padded_pair(const double * __restrict__ row, const double * __restrict__ apod,
                                                int64_t s, int64_t n_samp, int64_t n_reflect) {
-    if (s >= 0 && s < n_samp) return *reinterpret_cast<const double2 *>(row + s);
-    if (s < 0 && s >= -n_reflect) {
-        const int64_t j = s + n_reflect;
-        const double2 r = *reinterpret_cast<const double2 *>(row + (n_reflect - 2 - j));
-        const double2 a = *reinterpret_cast<const double2 *>(apod + j);
-        return make_double2(r.y * a.x, r.x * a.y);
-    }
-    if (s >= n_samp && s < n_samp + n_reflect) {
-        const int64_t j = s - n_samp;
-        const double2 r = *reinterpret_cast<const double2 *>(row + (n_samp - 2 - j));
-        const double2 a = *reinterpret_cast<const double2 *>(apod + (n_reflect - 2 - j));
-        return make_double2(r.y * a.y, r.x * a.x);
-    }
-    return make_double2(0.0, 0.0);
+    const bool direct = (s >= 0) & (s < n_samp);
+    const bool left = (s < 0) & (s >= -n_reflect);
+    const bool right = (s >= n_samp) & (s < n_samp + n_reflect);
+    const int64_t jl = s + n_reflect;             // left mirror: window index j, source n_reflect - 2 - j
+    const int64_t jr = s - n_samp;                // right mirror: window index n_reflect - 2 - j, source n_samp - 2 - j
+    int64_t src = direct ? s : (left ? n_reflect - 2 - jl : n_samp - 2 - jr);
+    int64_t win = left ? jl : n_reflect - 2 - jr;
+    if (!(direct | left | right)) src = 0;
+    if (!(left | right)) win = 0;
+    const double2 r = *reinterpret_cast<const double2 *>(row + src);
+    const double2 a = *reinterpret_cast<const double2 *>(apod + win);
+    const double2 m = left ? make_double2(r.y * a.x, r.x * a.y) : make_double2(r.y * a.y, r.x * a.x);
+    double2 out = direct ? r : m;
+    if (!(direct | left | right)) out = make_double2(0.0, 0.0);
+    return out;
 }
 
 // Experimental build (-DTOAST_FFT_PHASE_CLOCK, tools/exp_fft_phases.py): thread 0 of every workgroup
@@ -474,8 +480,15 @@ __global__ __launch_bounds__((1 << LT) / P, (P == 16 ? 2 : 4)) void k_fft_cols(c
             const int e = tid + k * T;
             const int64_t j = ((int64_t)(e >> log_c) << p.log_n2) + c0 + (e & ((1 << log_c) - 1));
             const int64_t s = 2 * j - p.n_buffer;
-            if (s >= 0 && s < p.n_samp) row[s] = v[k].y * p.scale;
-            if (s + 1 >= 0 && s + 1 < p.n_samp) row[s + 1] = v[k].x * p.scale;
+            if (p.aligned) {
+                // s and n_samp even, row 16-byte aligned: both samples of the pair are inside or outside together
+                if (s >= 0 && s < p.n_samp) {
+                    *reinterpret_cast<double2 *>(row + s) = make_double2(v[k].y * p.scale, v[k].x * p.scale);
+                }
+            } else {
+                if (s >= 0 && s < p.n_samp) row[s] = v[k].y * p.scale;
+                if (s + 1 >= 0 && s + 1 < p.n_samp) row[s + 1] = v[k].x * p.scale;
+            }
         }
     }
     PHASE_MARK(INV ? 12 : 7);
