@@ -150,8 +150,11 @@ def test_hits_covariance_and_binmap(monkeypatch):
         r = ev[0] / ev[-1] if ev[-1] > 0 else 0.0
         if r >= 1e-6:
             n_good += 1
-            np.testing.assert_allclose(cov[i], np.linalg.inv(m)[iu], rtol=1e-8, atol=1e-12 * abs(cov[i]).max())
-            assert rc[i] == pytest.approx(r, rel=1e-8)
+            # conditioning-aware bound: the inverse of a matrix with reciprocal condition number r is defined to
+            # ~eps / r (LAPACK is absent from the reference build here -- it throws --, NumPy is the yardstick)
+            want = np.linalg.inv(m)[iu]
+            assert np.max(np.abs(cov[i] - want)) <= (64 * 2.2e-16 / r) * np.max(np.abs(want))
+            assert rc[i] == pytest.approx(r, rel=64 * 2.2e-16 / r)
         else:
             assert np.all(cov[i] == 0) and rc[i] == 0
     assert n_good > 100
