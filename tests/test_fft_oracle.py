@@ -150,3 +150,34 @@ def test_estimate_net_matches_reference_fixture():
         assert abs(closed[0] / want - 1.0) < 1e-6 and abs(closed[1] / (2.0 * want) - 1.0) < 1e-6
         worst = max(worst, abs(closed[0] / want - 1.0))
     assert worst < 1e-7
+
+
+def test_impulse_extent_equals_the_reference_loops():
+    """toast_amd.fft.impulse_extent (windowed vectorised search) against the reference's sample-by-sample walk from the
+    peak of the impulse response (src/toast/fft.py:846-866), incl. responses that never fall below the threshold."""
+    from toast_amd.fft import impulse_extent
+
+    def loops(a):
+        n = a.size
+        ipeak = int(np.argmax(a))
+        thr = 0.02 * a[ipeak]
+        imin = ipeak
+        while imin > 0 and a[imin] > thr:
+            imin -= 1
+        imax = ipeak
+        while imax < n and a[imax] > thr:
+            imax += 1
+        return imax - imin
+
+    rng = np.random.default_rng(0)
+    for t in range(300):
+        n = int(rng.integers(5, 9000))
+        c = int(rng.integers(0, n))
+        w = 10 ** rng.uniform(0, 3.5)
+        a = np.exp(-np.abs(np.arange(n) - c) / w) * (1 + 0.3 * rng.random(n))
+        if t % 7 == 0:
+            a[:] = 1.0
+            a[c] = 2.0
+        if t % 11 == 0:
+            a = np.abs(rng.standard_normal(n))
+        assert impulse_extent(a) == loops(a)

@@ -166,15 +166,7 @@ class NoiseFilter(Operator):
                 hipfft.convolve_buffer(temp, np.arange(len(dets), dtype=np.int32), rate, kern_freq, kernels)
                 atemp = np.absolute(temp)
                 for i in range(len(dets)):
-                    ipeak = int(np.argmax(atemp[i]))
-                    thr = 0.02 * atemp[i, ipeak]
-                    imin = ipeak
-                    while imin > 0 and atemp[i, imin] > thr:
-                        imin -= 1
-                    imax = ipeak
-                    while imax < n_samp and atemp[i, imax] > thr:
-                        imax += 1
-                    extend[i] = imax - imin
+                    extend[i] = hipfft.impulse_extent(atemp[i])
                     if extend[i] == n_samp:
                         raise RuntimeError("Impulse response spreads to all samples")
             hipfft.convolve_buffer(dd.arg(on_dev), idx, rate, kern_freq, kernels, use_accel=on_dev)
