@@ -545,6 +545,22 @@ int toast_hip_fft_fused(int64_t n_samp);
 /* Override the choice at run time: rocfft_only != 0 = the rocFFT pipeline for every length,
  * 0 = automatic (what TOAST_HIP_FFT=rocfft / unset select at start-up). */
 void toast_hip_fft_select(int rocfft_only);
+/* Widths of the kernels' impulse responses, as toast.fft.convolve measures them before growing the flagged regions
+ * (src/toast/fft.py:836-872: an impulse of 100 at sample n_samp / 2 of an empty timestream through the same
+ * convolution; from the peak of |response| walk both ways while it exceeds 2 % of the peak): extents[d] = imax - imin
+ * for d < n_det (n_kernel == 1: one common response).  Kernel arguments as toast_hip_fft_convolve; everything runs on
+ * the device, `extents` is a host array.  stream NULL = the manager's stream. */
+int toast_hip_fft_impulse_extents(int64_t n_det, int64_t n_samp, double rate, const double * knots, int64_t n_knot,
+                                  const double * mag_coef, const double * ang_coef, int64_t n_kernel,
+                                  int deconvolve, const double * apodize, int64_t n_apodize, int32_t * extents,
+                                  void * stream);
+/* Flag bookkeeping of toast.fft.convolve / NoiseFilter on the device: for detector d (row flag_index[d] of the uint8
+ * [n_flag_rows, n_samp] buffer) grow every run of samples with (flag & mask) != 0 by extents[d] samples on both sides
+ * exactly as the reference's extend_flags does (src/toast/utils.py:1055-1113: the mask is ASSIGNED, the last sample is
+ * never assigned), and with edges != 0 OR the mask into the first and last extents[d] samples
+ * (src/toast/fft.py:935-945).  Host buffer, or its registered device copy with use_accel != 0. */
+int toast_hip_fft_extend_flags(uint8_t * flags, int64_t n_flag_rows, const int32_t * flag_index, int64_t n_det,
+                               int64_t n_samp, uint8_t mask, const int32_t * extents, int edges, int use_accel);
 /* Points per thread (16 or 8; anything else = default) of the row pass, the forward and the inverse
  * column pass of the fused kernels: 16 = 256-thread workgroups with radix-16 stages, 8 = 512-thread
  * workgroups with radix-8 stages and twice the waves per SIMD.  Defaults 8 / 8 / 8; start-up value

@@ -284,3 +284,65 @@ def test_fused_kernel_table_paths(pf, rows, tables):
             assert np.max(np.abs(got - want)) < TOL * np.max(np.abs(want)), (n_samp, tables, rows)
     finally:
         pf.set_rows_split(False)
+
+
+@pytest.mark.parametrize("n_samp", [6000, 50001, 300000])
+def test_impulse_extents_on_device(pf, n_samp):
+    """toast_hip_fft_impulse_extents (impulses made, convolved and measured in HBM) against the reference procedure
+    on the host: convolve temp[:, n_samp // 2] = 100 and walk from the peak (src/toast/fft.py:836-872)."""
+    from oracle import fft_oracle as fo
+
+    rate, n_det = 100.0, 5
+    freq = np.concatenate([[0.0], np.geomspace(1e-4, rate / 2, 60)])
+    for kernels in (_noise_kernels(freq, n_det), _noise_kernels(freq, n_det, complex_phase=True),
+                    _noise_kernels(freq, 1)[0]):
+        got = pf.impulse_extents(n_det, n_samp, rate, freq, kernels)
+        temp = np.zeros((n_det, n_samp))
+        temp[:, n_samp // 2] = 100.0
+        pf.convolve_buffer(temp, np.arange(n_det, dtype=np.int32), rate, freq, kernels)
+        want = np.array([pf.impulse_extent(np.absolute(temp[i])) for i in range(n_det)], dtype=np.int32)
+        assert np.array_equal(got, want)
+        # and the oracle's own impulse response gives the same widths
+        ref = np.zeros((n_det, n_samp))
+        ref[:, n_samp // 2] = 100.0
+        fo.convolve(ref, rate, kernel_freq=freq, kernels=kernels)
+        assert np.array_equal(want, [pf.impulse_extent(np.absolute(ref[i])) for i in range(n_det)])
+
+
+def test_extend_flags_on_device(pf):
+    """toast_hip_fft_extend_flags against the host restatement of the reference's extend_flags (pinned to the
+    reference function's outputs in tests/test_fft_oracle.py) followed by the first / last samples of
+    toast.fft.convolve: random flags, other flag bits that an assignment must clear, runs touching both ends,
+    extents from 0 (Python's f[-0:] flags everything) to longer than the timestream, row indirection."""
+    rng = np.random.default_rng(3)
+    n_samp, rows = 50001, 9
+    flags = np.zeros((rows, n_samp), dtype=np.uint8)
+    flags[0] = (rng.random(n_samp) < 0.002) * 1
+    flags[1] = (rng.random(n_samp) < 0.01) * 1 + (rng.random(n_samp) < 0.3) * 4
+    flags[2, :3] = 1
+    flags[2, -1] = 1
+    flags[3, -2] = 1
+    flags[3, 1000:1010] = 3
+    flags[4] = (rng.random(n_samp) < 0.0005) * 1
+    flags[5] = 4                      # nothing flagged under the mask
+    flags[6, 25000] = 1
+    flags[7] = (rng.random(n_samp) < 0.05) * 1
+    flags[8, n_samp - 1] = 5
+    idx = np.array([7, 0, 2, 3, 1, 5, 6, 4, 8], dtype=np.int32)
+    extents = np.array([3, 250, 1, 17, 1000, 40, 60000, 0, 5], dtype=np.int32)
+    want = flags.copy()
+    for row, ext in zip(idx, extents):
+        ext = int(ext)
+        pf.extend_flags(want[row], 1, ext)
+        want[row][:ext] |= 1
+        want[row][-ext:] |= 1
+    got = flags.copy()
+    pf.extend_flags_buffer(got, idx, 1, extents)
+    assert np.array_equal(got, want)
+    # without the edges: extend_flags alone
+    want2 = flags.copy()
+    for row, ext in zip(idx, extents):
+        pf.extend_flags(want2[row], 1, int(ext))
+    got2 = flags.copy()
+    pf.extend_flags_buffer(got2, idx, 1, extents, edges=False)
+    assert np.array_equal(got2, want2)

@@ -275,6 +275,130 @@ __global__ __launch_bounds__(kThreads) void k_scale(double * __restrict__ x, int
     }
 }
 
+// impulse of `value` at sample `pos` of every row
+__global__ void k_impulse_set(double * __restrict__ rows, int64_t n_row, int64_t n_samp, int64_t pos, double value) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_row) rows[r * n_samp + pos] = value;
+}
+
+// One workgroup per row: ipeak = first index of max |x| (numpy.argmax), thr = 0.02 |x[ipeak]|,
+// imin = max({j <= ipeak : |x_j| <= thr} u {0}), imax = min({j >= ipeak : |x_j| <= thr} u {n}), extent = imax - imin
+// (the reference's two while loops, src/toast/fft.py:846-866).
+__global__ __launch_bounds__(256) void k_impulse_extent(const double * __restrict__ rows, int64_t n_samp,
+                                                        int32_t * __restrict__ extent) {
+    const double * __restrict__ x = rows + (int64_t)blockIdx.x * n_samp;
+    __shared__ double s_val[256];
+    __shared__ int64_t s_idx[256];
+    const int tid = threadIdx.x;
+    double best = -1.0;
+    int64_t bi = 0;
+    for (int64_t j = tid; j < n_samp; j += 256) {
+        const double a = fabs(x[j]);
+        if (a > best) {        // strictly greater: the first occurrence wins inside a thread
+            best = a;
+            bi = j;
+        }
+    }
+    s_val[tid] = best;
+    s_idx[tid] = bi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            const double ov = s_val[tid + s];
+            const int64_t oi = s_idx[tid + s];
+            if (ov > s_val[tid] || (ov == s_val[tid] && oi < s_idx[tid])) {
+                s_val[tid] = ov;
+                s_idx[tid] = oi;
+            }
+        }
+        __syncthreads();
+    }
+    const int64_t ipeak = s_idx[0];
+    const double thr = 0.02 * s_val[0];
+    __syncthreads();
+    int64_t lo = 0, hi = n_samp;
+    for (int64_t j = tid; j < n_samp; j += 256) {
+        const bool below = fabs(x[j]) <= thr;
+        if (below && j <= ipeak && j > lo) lo = j;
+        if (below && j >= ipeak && j < hi) hi = j;
+    }
+    s_idx[tid] = lo;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s && s_idx[tid + s] > s_idx[tid]) s_idx[tid] = s_idx[tid + s];
+        __syncthreads();
+    }
+    const int64_t imin = s_idx[0];
+    __syncthreads();
+    s_idx[tid] = hi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s && s_idx[tid + s] < s_idx[tid]) s_idx[tid] = s_idx[tid + s];
+        __syncthreads();
+    }
+    if (tid == 0) extent[blockIdx.x] = (int32_t)(s_idx[0] - imin);
+}
+
+// Flag extension of toast.fft.convolve / NoiseFilter (reference src/toast/utils.py:1055-1113 extend_flags, then
+// src/toast/fft.py:935-945): every flagged run [s, e) ASSIGNS the mask to [max(s - b, 0), e + b) -- the end clipped to
+// n - 1 when it reaches n, so the last sample is never assigned --, then the first and last b samples get the mask
+// OR-ed in.  Sample j <= n - 2 is assigned iff a flagged sample lies in [j - b, j + b]: a window count from the prefix
+// sum of the flagged samples.  One workgroup per detector row; the prefix sums of the row live in `prefix`.
+__global__ __launch_bounds__(256) void k_extend_flags(uint8_t * __restrict__ flags, const int32_t * __restrict__ f_idx,
+                                                      int row0, int64_t n_samp, uint8_t mask,
+                                                      const int32_t * __restrict__ extent,
+                                                      int32_t * __restrict__ prefix, int edges) {
+    const int r = row0 + blockIdx.x;
+    uint8_t * __restrict__ f = flags + (int64_t)f_idx[r] * n_samp;
+    int32_t * __restrict__ pre = prefix + (int64_t)blockIdx.x * n_samp;
+    const int64_t b = extent[r];
+    __shared__ int32_t s_cnt[256];
+    __shared__ int32_t s_carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    constexpr int PER = 8;
+    for (int64_t base = 0; base < n_samp; base += 256 * PER) {
+        const int64_t j0 = base + (int64_t)tid * PER;
+        int32_t loc[PER];
+        int32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int64_t j = j0 + k;
+            run += (j < n_samp && (f[j] & mask) != 0) ? 1 : 0;
+            loc[k] = run;
+        }
+        s_cnt[tid] = run;
+        __syncthreads();
+        // inclusive scan of the 256 thread totals (Hillis-Steele)
+        for (int d = 1; d < 256; d <<= 1) {
+            const int32_t o = (tid >= d) ? s_cnt[tid - d] : 0;
+            __syncthreads();
+            s_cnt[tid] += o;
+            __syncthreads();
+        }
+        const int32_t before = s_carry + ((tid > 0) ? s_cnt[tid - 1] : 0);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int64_t j = j0 + k;
+            if (j < n_samp) pre[j] = before + loc[k];
+        }
+        __syncthreads();
+        if (tid == 255) s_carry += s_cnt[255];
+        __syncthreads();
+    }
+    for (int64_t j = tid; j < n_samp; j += 256) {
+        const int64_t lo = (j - b > 0) ? j - b : 0;
+        const int64_t hi = (j + b < n_samp - 1) ? j + b : n_samp - 1;
+        const int32_t cnt = pre[hi] - ((lo > 0) ? pre[lo - 1] : 0);
+        uint8_t v = f[j];
+        if (cnt > 0 && j <= n_samp - 2) v = mask;
+        // f[:b] |= mask; f[-b:] |= mask  (Python semantics: b == 0 makes the second slice the whole array)
+        if (edges && (b == 0 || j < b || j >= n_samp - b)) v |= mask;
+        f[j] = v;
+    }
+}
+
 inline dim3 grid2(int64_t n, int64_t batch) {
     int64_t gx = (n + kThreads - 1) / kThreads;
     if (gx > 4096) gx = 4096;
@@ -388,6 +512,84 @@ int toast_hip_fft_convolve(double * det_data, int64_t n_data_rows, const int32_t
                                             mag_coef, ang_coef, n_kernel, deconvolve, apodize,
                                             n_apodize, 0, st);
         if (rc != TOAST_HIP_OK) throw Error(rc, toast_hip_last_error());
+        stg.finish();
+    });
+}
+
+// Width of every kernel's impulse response (reference src/toast/fft.py:836-872: an impulse of 100 in the middle of
+// an empty timestream goes through the same convolution; walk left and right from the peak of |response| while it
+// exceeds 2 % of the peak).  The reference does this on the host, one detector at a time; here the impulses are made,
+// convolved and measured on the device in batches of rows of a scratch buffer and only the widths come back.
+int toast_hip_fft_impulse_extents(int64_t n_det, int64_t n_samp, double rate, const double * knots, int64_t n_knot,
+                                  const double * mag_coef, const double * ang_coef, int64_t n_kernel,
+                                  int deconvolve, const double * apodize, int64_t n_apodize, int32_t * extents,
+                                  void * stream) {
+    return guarded([&] {
+        if (n_det <= 0 || n_samp <= 0) return;
+        if (n_kernel != 1 && n_kernel != n_det) fail_arg("fft_impulse_extents: n_kernel must be 1 or n_det");
+        Manager::get().require_device();
+        hipStream_t st = stream ? static_cast<hipStream_t>(stream) : Manager::get().stream();
+        // a common kernel has one impulse response
+        const int64_t n_resp = (n_kernel == 1) ? 1 : n_det;
+        int64_t batch = (int64_t)((size_t(1) << 30) / ((size_t)n_samp * sizeof(double)));   // <= 1 GB of rows
+        if (batch < 1) batch = 1;
+        if (batch > 256) batch = 256;
+        if (batch > n_resp) batch = n_resp;
+        const size_t row_bytes = (((size_t)n_samp * sizeof(double)) + 255) & ~size_t(255);
+        char * scratch = (char *)Manager::get().scratch(Manager::kScratchFftImpulse,
+                                                        (size_t)batch * row_bytes + 256 + sizeof(int32_t) * batch);
+        // rows must be contiguous [nb, n_samp] for the convolution: no padding between them
+        double * d_rows = (double *)scratch;
+        int32_t * d_ext = (int32_t *)(scratch + (((size_t)batch * n_samp * sizeof(double) + 255) & ~size_t(255)));
+        std::vector<int32_t> idx((size_t)batch);
+        for (int64_t i = 0; i < batch; ++i) idx[(size_t)i] = (int32_t)i;
+        const int64_t n_coef = 4 * (n_knot - 1);
+        for (int64_t r0 = 0; r0 < n_resp; r0 += batch) {
+            const int64_t nb = (n_resp - r0 < batch) ? (n_resp - r0) : batch;
+            TH_HIP(hipMemsetAsync(d_rows, 0, (size_t)nb * n_samp * sizeof(double), st));
+            hipLaunchKernelGGL(k_impulse_set, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, d_rows, nb, n_samp,
+                               n_samp / 2, 100.0);
+            const int64_t nk = (n_kernel == 1) ? 1 : nb;
+            int rc = toast_hip_fft_convolve_dev(d_rows, idx.data(), nb, n_samp, rate, knots, n_knot,
+                                                mag_coef + ((n_kernel == 1) ? 0 : r0 * n_coef),
+                                                ang_coef ? ang_coef + ((n_kernel == 1) ? 0 : r0 * n_coef) : nullptr, nk,
+                                                deconvolve, apodize, n_apodize, 0, st);
+            if (rc != TOAST_HIP_OK) throw Error(rc, toast_hip_last_error());
+            hipLaunchKernelGGL(k_impulse_extent, dim3((unsigned)nb), dim3(256), 0, st, d_rows, n_samp, d_ext);
+            TH_HIP(hipGetLastError());
+            TH_HIP(hipMemcpyAsync(extents + r0, d_ext, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, st));
+            TH_HIP(hipStreamSynchronize(st));
+        }
+        if (n_kernel == 1) {
+            for (int64_t i = 1; i < n_det; ++i) extents[i] = extents[0];
+        }
+    });
+}
+
+int toast_hip_fft_extend_flags(uint8_t * flags, int64_t n_flag_rows, const int32_t * flag_index, int64_t n_det,
+                               int64_t n_samp, uint8_t mask, const int32_t * extents, int edges, int use_accel) {
+    return guarded([&] {
+        if (n_det <= 0 || n_samp <= 0) return;
+        Manager::get().require_device();
+        hipStream_t st = Manager::get().stream();
+        Staging stg(use_accel != 0, st);
+        uint8_t * d_flags = stg.inout(flags, (size_t)(n_flag_rows * n_samp));
+        ParamBlock pb;
+        const size_t o_fi = pb.push(flag_index, sizeof(int32_t) * n_det);
+        const size_t o_ex = pb.push(extents, sizeof(int32_t) * n_det);
+        const char * d = pb.commit(st);
+        int64_t batch = (int64_t)((size_t(512) << 20) / ((size_t)n_samp * sizeof(int32_t)));
+        if (batch < 1) batch = 1;
+        if (batch > n_det) batch = n_det;
+        int32_t * d_pre = (int32_t *)Manager::get().scratch(Manager::kScratchFftImpulse,
+                                                           (size_t)batch * n_samp * sizeof(int32_t));
+        for (int64_t r0 = 0; r0 < n_det; r0 += batch) {
+            const int64_t nb = (n_det - r0 < batch) ? (n_det - r0) : batch;
+            hipLaunchKernelGGL(k_extend_flags, dim3((unsigned)nb), dim3(256), 0, st, d_flags,
+                               (const int32_t *)(d + o_fi), (int)r0, n_samp, mask, (const int32_t *)(d + o_ex), d_pre,
+                               edges ? 1 : 0);
+        }
+        TH_HIP(hipGetLastError());
         stg.finish();
     });
 }

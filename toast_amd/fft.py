@@ -135,7 +135,9 @@ def convolve_dev(d_det_data, data_index, n_samp, rate, kernel_freq, kernels, dec
 
 def extend_flags(flags, mask, buffer):
     """Grow every flagged region by ``buffer`` samples on both sides
-    (reference: src/toast/utils.py:1055-1113)."""
+    (reference: src/toast/utils.py:1055-1113).  The reference loops over the regions and ASSIGNS the mask to
+    [start - buffer, end + buffer) (end clipped to n - 1 when it reaches n); here the union of those ranges is
+    built with a difference array, same result for any number of regions."""
     bad = (flags & mask) != 0
     if not bad.any():
         return
@@ -143,12 +145,32 @@ def extend_flags(flags, mask, buffer):
     starts = np.flatnonzero(edges == 1)
     ends = np.flatnonzero(edges == -1)
     n = flags.size
-    for start, end in zip(starts, ends):
-        fstart = max(start - buffer, 0)
-        fend = end + buffer
-        if fend >= n:
-            fend = n - 1
-        flags[fstart:fend] = mask
+    fstart = np.maximum(starts - buffer, 0)
+    fend = ends + buffer
+    fend = np.where(fend >= n, n - 1, fend)
+    keep = fend > fstart                      # an empty slice assigns nothing
+    delta = np.zeros(n + 1, dtype=np.int32)
+    np.add.at(delta, fstart[keep], 1)
+    np.add.at(delta, fend[keep], -1)
+    flags[np.cumsum(delta[:n]) > 0] = mask
+
+
+def extend_flags_buffer(flags, flag_index, mask, extents, edges=True, use_accel=False):
+    """``extend_flags`` (and, with ``edges``, the flagging of the first and last ``extent`` samples that
+    toast.fft.convolve does afterwards) for rows ``flag_index`` of the 2-D uint8 buffer ``flags``, each with its
+    own extent, on the device (``toast_hip_fft_extend_flags``).  ``use_accel``: the buffer's registered device copy
+    is updated instead of the host array."""
+    from .accel import ensure_assigned
+
+    ensure_assigned()
+    fl = capi._buf(flags, "flags", np.uint8, 2)
+    fi = capi._buf(np.ascontiguousarray(flag_index, dtype=np.int32), "flag_index", np.int32, 1)
+    ex = np.ascontiguousarray(extents, dtype=np.int32)
+    if ex.shape != fi.shape:
+        raise RuntimeError("extents should have one entry per flag row")
+    capi._check(capi.lib().toast_hip_fft_extend_flags(
+        _p(fl), C.c_int64(fl.shape[0]), _p(fi), C.c_int64(fi.size), C.c_int64(fl.shape[1]), C.c_uint8(int(mask)),
+        _p(ex), C.c_int(bool(edges)), C.c_int(bool(use_accel))))
 
 
 def impulse_extent(atemp):
@@ -179,6 +201,29 @@ def impulse_extent(atemp):
     return imax - imin
 
 
+def impulse_extents(n_tod, n_samp, rate, kernel_freq, kernels, deconvolve=False):
+    """Width of every kernel's impulse response (reference src/toast/fft.py:836-872), measured on the device
+    (``toast_hip_fft_impulse_extents``): impulses made, convolved and searched in HBM, only ``n_tod`` integers come
+    back.  Same numbers as convolving ``temp[:, n_samp // 2] = 100`` on the host and ``impulse_extent`` per row."""
+    from .accel import ensure_assigned
+
+    ensure_assigned()
+    kernel_freq = np.ascontiguousarray(kernel_freq, dtype=np.float64)
+    kernels = np.asarray(kernels)
+    if kernels.ndim == 2 and kernels.shape[0] != n_tod:
+        raise RuntimeError("kernels should have one row per detector")
+    mag_c, ang_c = kernel_coefficients(kernel_freq, kernels, deconvolve)
+    n_fft = fft_length(n_samp)
+    n_reflect = min((n_fft - n_samp) // 2, n_samp)
+    apod = apodization(n_reflect)
+    out = np.zeros(n_tod, dtype=np.int32)
+    capi._check(capi.lib().toast_hip_fft_impulse_extents(
+        C.c_int64(n_tod), C.c_int64(n_samp), C.c_double(rate), _p(kernel_freq), C.c_int64(kernel_freq.size), _p(mag_c),
+        _p(ang_c), C.c_int64(mag_c.shape[0]), C.c_int(bool(deconvolve)), _p(apod), C.c_int64(apod.size), _p(out),
+        C.c_void_p(0)))
+    return out
+
+
 def convolve(raw, rate, flags=None, flag_mask=None, kernel_freq=None, kernels=None, kernel_func=None,
              deconvolve=False, algorithm="numpy", use_accel=False):
     """Drop-in for ``toast.fft.convolve`` (2-D ``raw`` = one row per timestream, in place).
@@ -204,22 +249,20 @@ def convolve(raw, rate, flags=None, flag_mask=None, kernel_freq=None, kernels=No
     idx = np.arange(n_tod, dtype=np.int32)
     extend = np.zeros(n_tod, dtype=np.int32)
     if flags is not None:
-        # impulse response spread (fft.py:836-872), through the same GPU pipeline
-        temp = np.zeros_like(data)
-        temp[:, n_samp // 2] = 100.0
-        convolve_buffer(temp, idx, rate, kernel_freq, kernels, deconvolve)
-        atemp = np.absolute(temp)
-        for itod in range(n_tod):
-            extend[itod] = impulse_extent(atemp[itod])
-            if extend[itod] == n_samp:
-                raise RuntimeError("Impulse response spreads to all samples")
+        # impulse response spread (fft.py:836-872), through the same GPU pipeline, measured on the device
+        extend[:] = impulse_extents(n_tod, n_samp, rate, kernel_freq, kernels, deconvolve)
+        if np.any(extend == n_samp):
+            raise RuntimeError("Impulse response spreads to all samples")
     convolve_buffer(data, idx, rate, kernel_freq, kernels, deconvolve, use_accel=use_accel)
     if flags is not None:
-        for itod in range(n_tod):
-            ext = int(extend[itod])
-            extend_flags(flags[itod], flag_mask, ext)
-            flags[itod][:ext] |= flag_mask
-            flags[itod][-ext:] |= flag_mask
+        if isinstance(flags, np.ndarray) and flags.ndim == 2 and flags.dtype == np.uint8 and flags.flags["C_CONTIGUOUS"]:
+            extend_flags_buffer(flags, idx, flag_mask, extend)
+        else:
+            for itod in range(n_tod):
+                ext = int(extend[itod])
+                extend_flags(flags[itod], flag_mask, ext)
+                flags[itod][:ext] |= flag_mask
+                flags[itod][-ext:] |= flag_mask
 
 
 def _r1d(indata, direction):

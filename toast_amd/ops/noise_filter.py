@@ -96,11 +96,11 @@ class NoiseFilter(Operator):
     times = Unicode(defaults.times, help="Observation shared key for timestamps")
     det_data = Unicode(defaults.det_data, help="Observation detdata key for the timestream data")
     det_mask = Int(defaults.det_mask_invalid, help="Bit mask value for per-detector flagging")
-    det_flags = Unicode(None, allow_none=True, help="Observation detdata key for flags to use")
+    det_flags = Unicode(defaults.det_flags, allow_none=True, help="Observation detdata key for flags to use")
     det_flag_mask = Int(defaults.det_mask_invalid, help="Bit mask value for detector sample flagging")
-    shared_flags = Unicode(None, allow_none=True, help="Observation shared key for telescope flags to use")
+    shared_flags = Unicode(defaults.shared_flags, allow_none=True, help="Observation shared key for telescope flags to use")
     shared_flag_mask = Int(defaults.shared_mask_invalid, help="Bit mask value for optional shared flagging")
-    noise_model = Unicode("noise_model", help="Observation key containing the noise model")
+    noise_model = Unicode(defaults.noise_model, help="Observation key containing the noise model")
     white_noise_min = Float(None, allow_none=True, help="Minimum frequency of the white noise plateau [Hz]")
     white_noise_max = Float(None, allow_none=True, help="Maximum frequency of the white noise plateau [Hz]")
     debug = Unicode(None, allow_none=True, help="Path to directory for generating debug plots (not produced here)")
@@ -160,25 +160,18 @@ class NoiseFilter(Operator):
             extend = np.zeros(len(dets), dtype=np.int32)
             n_samp = dd.shape[1]
             if flags is not None:
-                # impulse response spread (fft.py:836-872) through the same GPU pipeline
-                temp = np.zeros((len(dets), n_samp))
-                temp[:, n_samp // 2] = 100.0
-                hipfft.convolve_buffer(temp, np.arange(len(dets), dtype=np.int32), rate, kern_freq, kernels)
-                atemp = np.absolute(temp)
-                for i in range(len(dets)):
-                    extend[i] = hipfft.impulse_extent(atemp[i])
-                    if extend[i] == n_samp:
-                        raise RuntimeError("Impulse response spreads to all samples")
+                # impulse response spread (fft.py:836-872) through the same GPU pipeline, measured on the device
+                extend[:] = hipfft.impulse_extents(len(dets), n_samp, rate, kern_freq, kernels)
+                if np.any(extend == n_samp):
+                    raise RuntimeError("Impulse response spreads to all samples")
             hipfft.convolve_buffer(dd.arg(on_dev), idx, rate, kern_freq, kernels, use_accel=on_dev)
             if made_resident and not getattr(data, "lazy_host", False):
                 dd.accel_update_host()
                 dd.accel_delete()
             if flags is not None:
-                for i, f in enumerate(flags):
-                    ext = int(extend[i])
-                    hipfft.extend_flags(f, flag_mask, ext)
-                    f[:ext] |= flag_mask
-                    f[-ext:] |= flag_mask
+                # extend_flags + first / last samples (fft.py:935-945) for all detectors in one device pass
+                fdata = obs.detdata[self.det_flags]
+                hipfft.extend_flags_buffer(fdata.data, fdata.indices(dets), flag_mask, extend)
 
     def _finalize(self, data, **kwargs):
         return
