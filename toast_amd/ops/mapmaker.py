@@ -78,6 +78,8 @@ class SolveAmplitudes(Operator):
     iter_min = Int(3, help="Minimum number of iterations")
     iter_max = Int(100, help="Maximum number of iterations")
     solve_rcond_threshold = Float(1.0e-8, help="When solving, minimum value for inverse pixel condition number cut.")
+    map_rcond_threshold = Float(1.0e-8, help="For final map, minimum value for inverse pixel condition number cut "
+                                "(declared like the reference's; SolveAmplitudes itself does not bin a final map).")
     mask = Unicode(None, allow_none=True, help="Data key for pixel mask to use in solving.  "
                                                "First bit of pixel values is tested")
     binning = Instance(klass=Operator, help="Binning operator used for solving template amplitudes")

@@ -199,7 +199,7 @@ class NoiseWeight(Operator):
     API = Int(0, help="Internal interface version for this operator")
     noise_model = Unicode(defaults.noise_model, help="The observation key containing the noise model")
     view = Unicode(None, allow_none=True, help="Use this view of the data in all observations")
-    det_data = Unicode(defaults.det_data, help="Observation detdata key for the timestream data")
+    det_data = Unicode(None, allow_none=True, help="Observation detdata key for the timestream data")
     det_mask = Int(defaults.det_mask_invalid, help="Bit mask value for per-detector flagging")
     det_flag_mask = Int(defaults.det_mask_invalid, help="Bit mask value for detector sample flagging")
     det_data_units = Unicode(defaults.det_data_units, allow_none=True, help="Desired timestream units")
@@ -255,7 +255,7 @@ class _MapBuilder(Operator):
     det_flag_mask = Int(defaults.det_mask_nonscience, help="Bit mask value for detector sample flagging")
     shared_flags = Unicode(defaults.shared_flags, allow_none=True, help="Observation shared key for telescope flags")
     shared_flag_mask = Int(defaults.shared_mask_nonscience, help="Bit mask value for optional telescope flagging")
-    sync_type = Unicode("allreduce", help="Communication algorithm: 'allreduce' or 'alltoallv'")
+    sync_type = Unicode("alltoallv", help="Communication algorithm: 'allreduce' or 'alltoallv'")
 
     def _validate_sync_type(self, check):
         if check not in ("allreduce", "alltoallv"):
@@ -569,7 +569,7 @@ class CovarianceAndHits(Operator):
     stokes_weights = Instance(klass=Operator, help="The Stokes weights operator")
     noise_model = Unicode(defaults.noise_model, help="Observation key containing the noise model")
     rcond_threshold = Float(1.0e-8, help="Minimum value for inverse condition number cut.")
-    sync_type = Unicode("allreduce", help="Communication algorithm: 'allreduce' or 'alltoallv'")
+    sync_type = Unicode("alltoallv", help="Communication algorithm: 'allreduce' or 'alltoallv'")
     save_pointing = Bool(False, help="If True, do not clear detector pointing matrices")
     det_data_units = Unicode(defaults.det_data_units, allow_none=True, help="Desired timestream units")
 
@@ -657,7 +657,7 @@ class BinMap(Operator):
     stokes_weights = Instance(klass=Operator, help="The Stokes weights operator")
     pre_process = Instance(klass=Operator, help="Optional extra operator to run prior to binning")
     noise_model = Unicode(defaults.noise_model, help="Observation key containing the noise model")
-    sync_type = Unicode("allreduce", help="Communication algorithm: 'allreduce' or 'alltoallv'")
+    sync_type = Unicode("alltoallv", help="Communication algorithm: 'allreduce' or 'alltoallv'")
     full_pointing = Bool(False, help="If True, expand pointing for all detectors and save")
     on_the_fly = Bool(True, help="With full_pointing=False on the accelerator, evaluate the pointing inside "
                                  "the accumulate kernel (not a reference trait; False = SINGLE pipelines)")

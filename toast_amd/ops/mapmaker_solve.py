@@ -163,7 +163,7 @@ class SolverRHS(Operator):
     """Right-hand side ``b = M^T N^-1 Z d`` (mapmaker_solve.py:27-229)."""
 
     API = Int(0, help="Internal interface version for this operator")
-    det_data = Unicode(defaults.det_data, help="Observation detdata key for the timestream data")
+    det_data = Unicode(None, allow_none=True, help="Observation detdata key for the timestream data")
     det_data_units = Unicode(defaults.det_data_units, allow_none=True, help="Desired units of detector data")
     binning = Instance(klass=Operator, help="Binning operator for solving")
     template_matrix = Instance(klass=Operator, help="This must be an instance of a template matrix operator")

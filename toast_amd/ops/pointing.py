@@ -83,7 +83,7 @@ class PointingDetectorSimple(Operator):
     det_mask = Int(defaults.det_mask_invalid, help="Bit mask value for per-detector flagging")
     det_flag_mask = Int(defaults.det_mask_invalid, help="Bit mask value for detector sample flagging")
     boresight = Unicode(defaults.boresight_radec, help="Observation shared key for boresight")
-    hwp_angle = Unicode(None, allow_none=True, help="Observation shared key for HWP angle")
+    hwp_angle = Unicode(defaults.hwp_angle, allow_none=True, help="Observation shared key for HWP angle")
     hwp_angle_offset = Float(0.0, help="HWP angle offset [rad] to apply when constructing deflection")
     hwp_deflection_radius = Float(None, allow_none=True,
                                   help="If non-zero, nominal detector pointing will be deflected in a circular "

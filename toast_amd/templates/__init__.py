@@ -281,7 +281,7 @@ class Template(TraitConfig):
     view = Unicode(None, allow_none=True, help="Use this view of the data in all observations")
     det_data = Unicode(defaults.det_data, allow_none=True, help="Observation detdata key for the timestream data")
     det_data_units = Unicode(defaults.det_data_units, allow_none=True, help="Desired units of detector data")
-    det_mask = Int(defaults.det_mask_nonscience, help="Bit mask value for solver per-detector flagging")
+    det_mask = Int(defaults.det_mask_invalid, help="Bit mask value for per-detector flagging")
     det_flags = Unicode(defaults.det_flags, allow_none=True, help="Observation detdata key for solver flags to use")
     det_flag_mask = Int(defaults.det_mask_nonscience, help="Bit mask value for solver flags")
     pattern = Unicode(None, allow_none=True, help="Regex pattern to match against detector names. "
