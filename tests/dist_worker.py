@@ -60,6 +60,39 @@ def main():
     t = comm.reduce_scatter_allgather_(__import__("torch").arange(7, dtype=__import__("torch").float64) * (rank + 1))
     assert t.tolist() == [0.0, 3.0, 6.0, 9.0, 12.0, 15.0, 18.0]
 
+    # 2b. ownership, statistics and broadcast of a distribution whose ranks hold DIFFERENT submaps
+    # (reference src/toast/pixels.py:176-315, :972-1184)
+    mine_sm = np.array([1, 4, 9] if rank == 0 else [4, 9, 12, 15])
+    dd = PixelDistribution(n_pix=16 * 48 - 5, n_submap=16, local_submaps=mine_sm, comm=comm)
+    assert list(dd.all_hit_submaps) == [1, 4, 9, 12, 15]
+    owners = dd.submap_owners
+    assert list(owners[[1, 4, 9, 12, 15]]) == [0, 0, 0, 1, 1] and np.all(owners[[0, 2, 3, 5]] == -1)
+    assert list(dd.owned_submaps) == ([1, 4, 9] if rank == 0 else [12, 15])
+    full = [np.arange(dd.n_pix, dtype=np.float64) * (k + 1) for k in range(2)]
+    pm = PixelData(dd, np.float64, n_value=2)
+    pm.broadcast_map(full if rank == 0 else None, comm_bytes=3 * 48 * 2 * 8)
+    for loc, sm in enumerate(mine_sm):
+        want = np.zeros((48, 2))
+        n_in = min(48, dd.n_pix - sm * 48)
+        for k in range(2):
+            want[:n_in, k] = full[k][sm * 48:sm * 48 + n_in]
+        assert np.array_equal(pm.data[loc], want), (rank, sm)
+    st = pm.stats()
+    # every hit submap counted once; the reference divides by ALL n_submap * n_pix_submap pixels
+    ref = np.zeros((16, 48, 2))
+    for sm in (1, 4, 9, 12, 15):
+        n_in = min(48, dd.n_pix - sm * 48)
+        for k in range(2):
+            ref[sm, :n_in, k] = full[k][sm * 48:sm * 48 + n_in]
+    if rank == 0:
+        for k in range(2):
+            assert abs(st["sum"][k] - ref[:, :, k].sum()) < 1e-9 * abs(ref[:, :, k].sum())
+            assert abs(st["mean"][k] - ref[:, :, k].mean()) < 1e-12 * abs(ref[:, :, k].mean())
+            assert abs(st["rms"][k] - np.std(ref[:, :, k], ddof=1)) < 1e-12 * np.std(ref[:, :, k])
+    else:
+        assert st is None
+    assert list(dd.global_pixel_to_local(np.array([48, 4 * 48 + 7]))) == ([0, 48 + 7] if rank == 0 else [-48, 7])
+
     # 3. amplitude dot products: local dot + scalar all-reduce
     a = Amplitudes(comm, 10, 5)
     a.local[:] = np.arange(5) + 5 * rank

@@ -112,7 +112,7 @@ class Comm:
         """In-place all-reduce of a torch tensor (device tensor -> RCCL over xGMI)."""
         if self.comm_world is None:
             return tensor
-        ops = {"sum": self._dist.ReduceOp.SUM, "max": self._dist.ReduceOp.MAX}
+        ops = {"sum": self._dist.ReduceOp.SUM, "max": self._dist.ReduceOp.MAX, "min": self._dist.ReduceOp.MIN}
         self._dist.all_reduce(tensor, op=ops[op])
         return tensor
 
@@ -160,6 +160,21 @@ class Comm:
             t.copy_(d.cpu())
         else:
             self.allreduce_tensor_(t, op)
+        return arr
+
+    def bcast_array_(self, arr, root=0):
+        """In-place broadcast of a host NumPy array from ``root``."""
+        if self.comm_world is None:
+            return arr
+        import torch
+
+        t = torch.from_numpy(arr)
+        if self._dist.get_backend() == "nccl":
+            d = t.to(self._collective_device())
+            self._dist.broadcast(d, src=root)
+            t.copy_(d.cpu())
+        else:
+            self._dist.broadcast(t, src=root)
         return arr
 
     def barrier(self):

@@ -70,13 +70,84 @@ class PixelDistribution:
         return not self.__eq__(other)
 
     def global_pixel_to_submap(self, gl):
-        """pixels.py:130-160: (local submap, pixel within submap); negatives stay negative."""
+        """pixels.py:193-211: (local submap, pixel within submap); negatives stay negative."""
         gl = np.asarray(gl, dtype=np.int64)
+        if gl.size == 0:
+            return (np.zeros_like(gl), np.zeros_like(gl))
+        if np.max(gl) >= self._n_pix:
+            raise RuntimeError("Global pixel indices exceed the maximum for the pixelization")
         bad = gl < 0
         sm = gl // self._n_pix_submap
         pix = gl - sm * self._n_pix_submap
         lsm = np.where(bad, -1, self._glob2loc[np.where(bad, 0, sm)])
         return lsm, np.where(bad, -1, pix)
+
+    def global_pixel_to_local(self, gl):
+        """pixels.py:214-236: index into the flat local buffer, local_submap * n_pix_submap + pixel in submap."""
+        gl = np.asarray(gl, dtype=np.int64)
+        if gl.size == 0:
+            return np.zeros_like(gl)
+        local_sm, pixels = self.global_pixel_to_submap(gl)
+        return pixels + local_sm * self._n_pix_submap
+
+    def clear(self):
+        """pixels.py:130-141: drop the global -> local table (the object must not be used afterwards)."""
+        self._glob2loc = None
+
+    def __repr__(self):
+        return "<PixelDistribution {} pixels, {} submaps, submap size = {}>".format(
+            self._n_pix, self._n_submap, self._n_pix_submap)
+
+    def _world(self):
+        c = self._comm
+        return None if (c is None or c.comm_world is None) else c
+
+    @property
+    def all_hit_submaps(self):
+        """Submaps local to at least one process (pixels.py:176-185)."""
+        if getattr(self, "_all_hit_submaps", None) is None:
+            hits = np.zeros(self._n_submap, dtype=np.int64)
+            if self._local_submaps is not None:
+                hits[self._local_submaps] += 1
+            if self._world() is not None:
+                self._world().allreduce_array_(hits)
+            self._all_hit_submaps = np.flatnonzero(hits != 0)
+        return self._all_hit_submaps
+
+    @property
+    def submap_owners(self):
+        """Owning process of every hit submap, -1 elsewhere (pixels.py:244-297): the hit submaps are dealt out in
+        rank order, uniformly (the reference's distribute_uniform: the first `total % size` processes get one more)."""
+        if getattr(self, "_submap_owners", None) is not None:
+            return self._submap_owners
+        owners = np.full(self._n_submap, -1, dtype=np.int32)
+        w = self._world()
+        if w is None:
+            if self._local_submaps is not None and len(self._local_submaps) > 0:
+                owners[self._local_submaps] = 0
+        else:
+            hit = self.all_hit_submaps
+            size = w.world_size
+            base, extra = divmod(hit.size, size)
+            target = [base + (1 if r < extra else 0) for r in range(size)]
+            proc = proc_offset = 0
+            for sm in hit:
+                owners[sm] = proc
+                proc_offset += 1
+                if proc_offset >= target[proc]:
+                    proc += 1
+                    proc_offset = 0
+        self._submap_owners = owners
+        return owners
+
+    @property
+    def owned_submaps(self):
+        """Submaps owned by this process (pixels.py:299-315)."""
+        if getattr(self, "_owned_submaps", None) is None:
+            w = self._world()
+            rank = 0 if w is None else w.world_rank
+            self._owned_submaps = np.flatnonzero(self.submap_owners == rank).astype(np.int32)
+        return self._owned_submaps
 
 
 def unify_local_submaps(hit_submaps, comm):
@@ -105,6 +176,113 @@ class PixelData(AcceleratorObject):
     distribution = property(lambda self: self._dist)
     n_value = property(lambda self: self._n_value)
     dtype = property(lambda self: self._dtype)
+
+    # array access to the local submaps (pixels.py:613-627)
+    def __getitem__(self, key):
+        return np.array(self.data[key], dtype=self._dtype, copy=False)
+
+    def __setitem__(self, key, value):
+        self.data[key] = value
+
+    def __delitem__(self, key):
+        raise NotImplementedError("Cannot delete individual memory elements")
+
+    def __iter__(self):
+        return iter(self.data)
+
+    def __len__(self):
+        return len(self.data)
+
+    def __repr__(self):
+        return "<PixelData {} values per pixel, dtype = {}, units= {}, dist = {}>".format(
+            self._n_value, self._dtype.name, self.units, self._dist)
+
+    def clear(self):
+        """pixels.py:540-578: release the device copy and the host buffer."""
+        if self.accel_exists():
+            self.accel_delete()
+        self.data = None
+        self.raw = None
+
+    def comm_nsubmap(self, bytes):
+        """Number of submaps to move per message of about `bytes` bytes (pixels.py:665-683)."""
+        dbytes = self._dtype.itemsize
+        nsub = int(bytes / (dbytes * self._n_value * self._dist.n_pix_submap))
+        if nsub == 0:
+            nsub = 1
+        allsub = int(self._dist.n_pix / self._dist.n_pix_submap)
+        return min(nsub, allsub)
+
+    def _no_device_comm(self):
+        if self.accel_in_use():
+            raise RuntimeError(f"PixelData {self._accel_name} currently on accelerator cannot do MPI communication")
+
+    def stats(self, comm_bytes=10000000):
+        """Sum / mean / rms of every value over all pixels of the hit submaps, on rank zero (None elsewhere); the map
+        must already be consistent across processes (pixels.py:972-1093: every submap counted once, contributed by
+        the lowest rank holding it; sample variance over all pixels of the hit submaps)."""
+        self._no_device_comm()
+        dist = self._dist
+        w = dist._world()
+        if w is None:
+            return {
+                "sum": [np.sum(self.data[:, :, x]) for x in range(self._n_value)],
+                "mean": [np.mean(self.data[:, :, x]) for x in range(self._n_value)],
+                "rms": [np.std(self.data[:, :, x]) for x in range(self._n_value)],
+            }
+        nsub = dist.n_submap
+        lowest = np.full(nsub, w.world_size, dtype=np.int64)
+        if dist.local_submaps is not None:
+            lowest[dist.local_submaps] = w.world_rank
+        w.allreduce_array_(lowest, op="min")
+        mine = np.flatnonzero(lowest == w.world_rank)
+        loc = dist.global_submap_to_local[mine]
+        # the reference counts n_pix_submap pixels for EVERY submap index (hit or not: unhit ones contribute zeros)
+        count = float(nsub) * dist.n_pix_submap
+        part = np.array([np.sum(self.data[loc, :, v], dtype=np.float64) for v in range(self._n_value)])
+        w.allreduce_array_(part)
+        mean = part / count
+        n_unhit = nsub - np.count_nonzero(lowest < w.world_size)
+        var = np.array([np.sum((self.data[loc, :, v].astype(np.float64) - mean[v]) ** 2)
+                        for v in range(self._n_value)])
+        w.allreduce_array_(var)
+        var += n_unhit * dist.n_pix_submap * mean**2
+        if w.world_rank != 0:
+            return None
+        return {
+            "sum": [float(x) for x in part],
+            "mean": [float(x) for x in mean],
+            "rms": [float(np.sqrt(x / (count - 1))) for x in var],
+        }
+
+    def broadcast_map(self, fdata, comm_bytes=10000000):
+        """Distribute a full map held by process zero: `fdata` = one array of n_pix values per map value (or a single
+        array when n_value == 1), significant on process zero only; every process keeps its local submaps
+        (pixels.py:1095-1184: chunks of submaps are broadcast; pixels past n_pix in the last submap are zero)."""
+        self._no_device_comm()
+        dist = self._dist
+        w = dist._world()
+        rank = 0 if w is None else w.world_rank
+        nps = dist.n_pix_submap
+        if rank == 0 and self._n_value == 1 and not isinstance(fdata, (tuple, list)):
+            fdata = (fdata,)
+        comm_submap = self.comm_nsubmap(comm_bytes)
+        buf = np.zeros((comm_submap, nps, self._n_value), dtype=self._dtype)
+        for sm0 in range(0, dist.n_submap, comm_submap):
+            nsm = min(comm_submap, dist.n_submap - sm0)
+            buf[:] = 0
+            if rank == 0:
+                p0 = sm0 * nps
+                p1 = min((sm0 + nsm) * nps, dist.n_pix)
+                flat = buf.reshape(-1, self._n_value)
+                for col in range(self._n_value):
+                    flat[: p1 - p0, col] = np.asarray(fdata[col])[p0:p1]
+            if w is not None:
+                w.bcast_array_(buf, root=0)
+            for sm in range(sm0, sm0 + nsm):
+                loc = dist.global_submap_to_local[sm]
+                if loc >= 0:
+                    self.data[loc, :, :] = buf[sm - sm0, :, :]
 
     def update_units(self, units):
         self.units = units
