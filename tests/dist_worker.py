@@ -98,6 +98,24 @@ def main():
     a.local[:] = np.arange(5) + 5 * rank
     val = a.dot(a)
     assert abs(val - float(np.sum(np.arange(10) ** 2))) < 1e-12, val
+    # full copies on every process (n_local == n_global): the dot product is not reduced, sync() sums the copies
+    # with flagged values contributing zero (reference templates/amplitudes.py:357-470, :545-554)
+    f = Amplitudes(comm, 6, 6)
+    g = Amplitudes(comm, 6, 6)
+    f.local[:] = np.arange(6) + 1.0
+    g.local[:] = 2.0
+    f.local_flags[1] = 1
+    assert abs(f.dot(g) - 2.0 * (21.0 - 2.0)) < 1e-12
+    assert f.n_local_flagged == 1
+    f.sync()
+    assert np.allclose(f.local, [2.0, 0.0, 6.0, 8.0, 10.0, 12.0])
+    f.reset_flags()
+    assert f.n_local_flagged == 0 and f.use_group is False and f.local_indices is None
+    try:
+        Amplitudes(comm, 10, 4)
+        raise SystemExit("inconsistent n_local was accepted")
+    except RuntimeError:
+        pass
     assert comm.allreduce_scalar(rank + 1, op="max") == 2
     assert comm.allreduce_scalar(3, op="sum") == 6
 

@@ -32,17 +32,62 @@ class Amplitudes(AcceleratorObject):
     per process (each detector lives on one process), so ``dot`` = local dot + scalar
     all-reduce (amplitudes.py:523-565)."""
 
-    def __init__(self, comm, n_global, n_local, dtype=np.float64):
+    def __init__(self, comm, n_global, n_local, local_indices=None, local_ranges=None, dtype=np.float64,
+                 use_group=False, _full=None):
+        """Constructor of the reference (src/toast/templates/amplitudes.py:77-140).  Supported distributions: every
+        process holds a full copy (n_local == n_global everywhere: dot products and sync as in the reference) or
+        disjoint pieces (the Offset template's case: the sum of n_local equals n_global).  Amplitudes shared between
+        some processes through ``local_ranges`` / ``local_indices`` are not part of the offset-template path and
+        raise."""
         super().__init__("Amplitudes")
         self._comm = comm
         self._n_global = int(n_global)
         self._n_local = int(n_local)
+        if local_indices is not None or local_ranges is not None:
+            raise NotImplementedError("Amplitudes with local_ranges / local_indices (values shared between some "
+                                      "processes) are not supported: only full copies and disjoint pieces")
+        self._local_indices = None
+        self._local_ranges = None
+        self._use_group = bool(use_group)
+        world = None if comm is None else (comm.comm_group if use_group else comm.comm_world)
+        self._full = False
+        if _full is not None:
+            self._full = bool(_full)      # copy of an existing distribution: no collective
+        elif world is not None:
+            total = comm.allreduce_scalar(self._n_local, op="sum")
+            size = comm.group_size if use_group else comm.world_size
+            if total == size * self._n_global:
+                self._full = True
+            elif total != self._n_global:
+                raise RuntimeError("Total amplitudes on all processes does not equal n_global")
+        elif self._n_local != self._n_global:
+            raise RuntimeError("Total amplitudes on all processes does not equal n_global")
         self.local = np.zeros(self._n_local, dtype=dtype)
         self.local_flags = np.zeros(self._n_local, dtype=np.uint8)
 
     n_global = property(lambda self: self._n_global)
     n_local = property(lambda self: self._n_local)
     comm = property(lambda self: self._comm)
+    local_indices = property(lambda self: self._local_indices)
+    local_ranges = property(lambda self: self._local_ranges)
+    use_group = property(lambda self: self._use_group)
+
+    @property
+    def n_local_flagged(self):
+        """Number of flagged local amplitudes (amplitudes.py:335-341)."""
+        if self._n_local == 0:
+            return 0
+        if self.accel_in_use():
+            accel_data_update_host(self.local_flags, self._accel_name + "_flags")
+        return int(np.count_nonzero(self.local_flags))
+
+    def reset_flags(self):
+        """Clear all flags, on the host and on the device copy (amplitudes.py:283-290)."""
+        if self._n_local == 0:
+            return
+        self.local_flags[:] = 0
+        if self.accel_exists():
+            accel_data_update_device(self.local_flags, self._accel_name + "_flags")
 
     def _host(self):
         if self.accel_in_use():
@@ -75,7 +120,8 @@ class Amplitudes(AcceleratorObject):
         return accel_device_ptr(self.local)
 
     def duplicate(self):
-        ret = Amplitudes(self._comm, self._n_global, self._n_local, dtype=self.local.dtype)
+        ret = Amplitudes(self._comm, self._n_global, self._n_local, dtype=self.local.dtype, use_group=self._use_group,
+                         _full=self._full)
         if self.accel_in_use():
             ret.local_flags[:] = self.local_flags
             ret.accel_create(self._accel_name + "_dup")
@@ -161,13 +207,22 @@ class Amplitudes(AcceleratorObject):
         else:
             good = np.logical_and(self.local_flags == 0, other.local_flags == 0)
             val = float(np.dot(np.where(good, self.local, 0.0), other.local))
-        if self._comm is not None and self._comm.comm_world is not None:
+        # every process holds the full set: no reduction (amplitudes.py:545-554); disjoint pieces: sum of the local dots
+        if self._comm is not None and self._comm.comm_world is not None and not self._full:
             val = self._comm.allreduce_scalar(val, op="sum")
         return val
 
-    def sync(self):
-        """Offset amplitudes are process-local: nothing to combine (amplitudes.py:357)."""
-        return
+    def sync(self, comm_bytes=10000000):
+        """Sum over processes where amplitudes are replicated (amplitudes.py:357-470): full copies are all-reduced
+        with flagged values contributing zero; disjoint pieces (the Offset template) need no communication."""
+        if self._comm is None or self._comm.comm_world is None or self._n_global == 0 or not self._full:
+            return
+        self._host()
+        send = np.where(self.local_flags != 0, 0, self.local)
+        self._comm.allreduce_array_(send)
+        self.local[:] = send
+        if self.accel_exists():
+            self.accel_update_device()
 
     # accelerator protocol: values and flags are two registered buffers
     def _accel_exists(self):
@@ -205,6 +260,10 @@ class AmplitudesMap(dict):
     def reset(self):
         for v in self.values():
             v.reset()
+
+    def reset_flags(self):
+        for v in self.values():
+            v.reset_flags()
 
     def clear(self):
         for v in self.values():
