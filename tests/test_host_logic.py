@@ -231,3 +231,29 @@ def test_noise_models_follow_the_reference():
     assert nz.detector_weight("flat") == 1.0 / 4.0 / 100.0
     assert nz.detector_weight("rolled") == 1.0 / 4.0 / 100.0     # plateau, not the rolled-off end
     assert nz.detector_weight("dead") == 0.0
+    # mixing matrix: a detector's weight is the mixmatrix-weighted sum of the PSDs' inverse variances
+    # (src/toast/noise.py:217-265); keys, indices and accessors as in the reference
+    mix = {"d0": {"flat": 1.0, "rolled": 0.5}, "d1": {"rolled": 2.0, "dead": 1.0, "flat": 0.0}}
+    nm = Noise(["d1", "d0"], {"flat": freq, "rolled": freq, "dead": freq},
+               {"flat": flat, "rolled": rolled, "dead": np.zeros(freq.size)}, mixmatrix=mix)
+    assert nm.detectors == ["d0", "d1"] and nm.keys == ["dead", "flat", "rolled"]
+    inv = 1.0 / 4.0 / (2.0 * freq[-1])
+    assert nm.detector_weight("d0") == pytest.approx(1.5 * inv, rel=1e-15)
+    assert nm.detector_weight("d1") == pytest.approx(2.0 * inv, rel=1e-15)
+    # the reference returns the LAST detector's weight from the call that fills the table (its loop variable shadows
+    # the argument, src/toast/noise.py:262-265): reproduced only on request
+    Noise.reference_first_call_quirk = True
+    try:
+        nq = Noise(["d1", "d0"], {"flat": freq, "rolled": freq, "dead": freq},
+                   {"flat": flat, "rolled": rolled, "dead": np.zeros(freq.size)}, mixmatrix=mix)
+        assert nq.detector_weight("d0") == pytest.approx(2.0 * inv, rel=1e-15)      # d1's weight
+        assert nq.detector_weight("d0") == pytest.approx(1.5 * inv, rel=1e-15)      # every later call is right
+    finally:
+        Noise.reference_first_call_quirk = False
+    assert nm.weight("d0", "dead") == 0 and nm.weight("d1", "rolled") == 2.0
+    assert nm.all_keys_for_dets(["d1"]) == ["dead", "rolled"]          # zero weights do not count
+    from toast_amd.noise import name_UID
+
+    assert nm.index("flat") == name_UID("flat") and int(name_UID("flat")) < 2**31
+    assert Noise(["a"], {"a": freq}, {"a": flat}, detweights={"a": 7.0}).detector_weight("a") == 7.0
+    assert an.fknee("a") == pytest.approx(an.fknee("a")) and an.alpha(dets[0]) >= 0
