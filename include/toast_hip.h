@@ -308,6 +308,15 @@ int toast_hip_cov_apply_diag(int64_t n_sub, int64_t subsize, int64_t nnz, const 
 int toast_hip_cov_apply_diag_dev(int64_t n_sub, int64_t subsize, int64_t nnz, const double * d_mat,
                                  double * d_vec, void * stream);
 
+/* cov_mult_diag: per pixel, data1 <- packed upper triangle of Sym(data1) Sym(data2), entry (k, m >= k) taken from
+ * row m, column k of the product as the reference's column-major dsymm call leaves it.
+ * [ref: /root/reference/src/libtoast/src/toast_map_cov.cpp:398-469, called by covariance_multiply,
+ * src/toast/covariance.py:179-221] */
+int toast_hip_cov_mult_diag(int64_t n_sub, int64_t subsize, int64_t nnz, double * data1, const double * data2,
+                            int use_accel);
+int toast_hip_cov_mult_diag_dev(int64_t n_sub, int64_t subsize, int64_t nnz, double * d_data1, const double * d_data2,
+                                void * stream);
+
 /* ------------------------------------------------------------------------------------
  * Pixel-domain noise covariance products (used by BinMap / MapMaker setup)
  *

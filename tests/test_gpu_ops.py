@@ -999,3 +999,45 @@ def test_boresight_coordinate_rotation():
     plain = create_satellite_data(n_det=3, n_samp=2500)
     ops.PixelsHealpix(detector_pointing=ops.PointingDetectorSimple(), nside=128).apply(plain)
     assert np.count_nonzero(plain.obs[0].detdata[defaults.pixels].data != results[0]) > 2000
+
+
+def test_covariance_multiply_inverse_is_identity():
+    """covariance_multiply (cov_mult_diag, reference src/libtoast/src/toast_map_cov.cpp:398-469: packed upper triangle
+    of the product of two symmetric blocks): against NumPy (the reference build here has no BLAS and throws), and
+    C C^-1 = 1 as in the reference's covariance test (src/toast/tests/cov.py)."""
+    from toast_amd.pixels import PixelData, PixelDistribution, covariance_invert, covariance_multiply
+
+    rng = np.random.default_rng(11)
+    for nnz in (1, 2, 3):
+        blk = nnz * (nnz + 1) // 2
+        dist = PixelDistribution(n_pix=8 * 50, n_submap=8, local_submaps=[1, 4, 6])
+        a = PixelData(dist, np.float64, n_value=blk)
+        b = PixelData(dist, np.float64, n_value=blk)
+        iu = np.triu_indices(nnz)
+        full_a = np.zeros((3 * 50, nnz, nnz))
+        full_b = np.zeros_like(full_a)
+        for full, pd in ((full_a, a), (full_b, b)):
+            g = rng.standard_normal((3 * 50, nnz, nnz))
+            full[:] = g @ np.swapaxes(g, 1, 2) + nnz * np.eye(nnz)
+            pd.data.reshape(-1, blk)[:] = full[:, iu[0], iu[1]]
+        want = np.einsum("pmj,pjk->pmk", full_a, full_b)      # entry (k, m >= k) <- product[m, k]
+        for on_dev in (False, True):
+            x = a.duplicate()
+            y = b.duplicate()
+            if on_dev:
+                for v, nm in ((x, "cm_x"), (y, "cm_y")):
+                    v.accel_create(nm)
+                    v.accel_update_device()
+            covariance_multiply(x, y)
+            if on_dev:
+                x.accel_update_host()
+                x.accel_delete()
+                y.accel_delete()
+            got = x.data.reshape(-1, blk)
+            assert np.max(np.abs(got - want[:, iu[1], iu[0]])) < 1e-13 * np.max(np.abs(want)), (nnz, on_dev)
+        inv = a.duplicate()
+        covariance_invert(inv, 1.0e-8)
+        prod = a.duplicate()
+        covariance_multiply(prod, inv)
+        eye = np.eye(nnz)[iu]
+        assert np.max(np.abs(prod.data.reshape(-1, blk) - eye)) < 1e-10

@@ -452,6 +452,16 @@ def cov_apply_diag(nsub, subsize, nnz, mat, vec, use_accel=False):
     _check(lib().toast_hip_cov_apply_diag(_i64(nsub), _i64(subsize), _i64(nnz), _p(m), _p(v), _int(use_accel)))
 
 
+def cov_mult_diag(nsub, subsize, nnz, data1, data2, use_accel=False):
+    a = np.asarray(data1)
+    b = np.asarray(data2)
+    if a.dtype != np.float64 or b.dtype != np.float64:
+        raise RuntimeError("cov_mult_diag needs float64 buffers")
+    if a.size != b.size:
+        raise RuntimeError("Buffer sizes are not consistent.")
+    _check(lib().toast_hip_cov_mult_diag(_i64(nsub), _i64(subsize), _i64(nnz), _p(a), _p(b), _int(use_accel)))
+
+
 def template_offset_add_to_signal(step_length, amp_offset, n_amp_views, amplitudes, amplitude_flags,
                                   data_index, det_data, intervals, use_accel=False):
     a = _buf(amplitudes, "amplitudes", np.float64, 1)

@@ -215,6 +215,19 @@ int toast_hip_cov_apply_diag(int64_t n_sub, int64_t subsize, int64_t nnz, const 
     });
 }
 
+int toast_hip_cov_mult_diag(int64_t n_sub, int64_t subsize, int64_t nnz, double * data1, const double * data2,
+                            int use_accel) {
+    return guarded([&] {
+        Call c(use_accel);
+        const int64_t n_px = n_sub * subsize;
+        const size_t n = (size_t)(n_px * nnz * (nnz + 1) / 2);
+        double * d_1 = c.st.inout(data1, n);
+        const double * d_2 = c.st.in(data2, n);
+        c.check(toast_hip_cov_mult_diag_dev(n_sub, subsize, nnz, d_1, d_2, c.stream));
+        c.st.finish();
+    });
+}
+
 int toast_hip_build_cov(int mode, const int64_t * global2local, int64_t n_submap, void * out,
                         int64_t n_local_submap, int64_t n_pix_submap, int64_t nnz,
                         const int32_t * pixel_index, const int64_t * pixels, int64_t n_pixel_rows,

@@ -774,6 +774,49 @@ __global__ __launch_bounds__(kThreads) void k_noise_weight(
 }
 
 // ------------------------------------------------------------------------------------
+// cov_mult_diag   [ref: src/libtoast/src/toast_map_cov.cpp:398-469]
+// Per pixel, data1 <- packed upper triangle of the product of the two symmetric blocks: the reference expands both
+// to full matrices, calls the batched dsymm (C = S1 S2 in column-major storage) and packs entry (k, m >= k) from
+// C(m, k) = sum_j S1(m, j) S2(j, k).  LAPACK / BLAS are absent from the reference build here (it throws); the
+// summation runs over j = 0 .. nnz-1 in order.
+// ------------------------------------------------------------------------------------
+template <int NNZ>
+__global__ __launch_bounds__(kThreads) void k_cov_mult_diag(int64_t n_px, double * __restrict__ data1,
+                                                            const double * __restrict__ data2) {
+    constexpr int BLK = NNZ * (NNZ + 1) / 2;
+    for (int64_t px = (int64_t)blockIdx.x * kThreads + threadIdx.x; px < n_px;
+         px += (int64_t)gridDim.x * kThreads) {
+        double * a = data1 + px * BLK;
+        const double * b = data2 + px * BLK;
+        if (NNZ == 1) {
+            a[0] *= b[0];
+            continue;
+        }
+        double s1[NNZ][NNZ], s2[NNZ][NNZ];
+        int off = 0;
+#pragma unroll
+        for (int k = 0; k < NNZ; ++k) {
+#pragma unroll
+            for (int m = k; m < NNZ; ++m, ++off) {
+                s1[k][m] = s1[m][k] = a[off];
+                s2[k][m] = s2[m][k] = b[off];
+            }
+        }
+        off = 0;
+#pragma unroll
+        for (int k = 0; k < NNZ; ++k) {
+#pragma unroll
+            for (int m = k; m < NNZ; ++m, ++off) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < NNZ; ++j) acc += s1[m][j] * s2[j][k];
+                a[off] = acc;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // cov_apply_diag   [ref: src/libtoast/src/toast_map_cov.cpp:471-528]
 // One thread per pixel; reference accumulation order (row k, then the mirrored term).
 // ------------------------------------------------------------------------------------
@@ -1426,6 +1469,24 @@ int toast_hip_noise_weight_dev(double * d_det_data, int64_t n_samp, const int32_
         hipLaunchKernelGGL(k_noise_weight, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0,
                            as_stream(stream), (const Chunk *)(d + o_ch), (int)chunks.size(),
                            (const int32_t *)(d + o_di), (const double *)(d + o_w), d_det_data, n_samp);
+        check_launch();
+    });
+}
+
+int toast_hip_cov_mult_diag_dev(int64_t n_sub, int64_t subsize, int64_t nnz, double * d_data1, const double * d_data2,
+                               void * stream) {
+    return guarded([&] {
+        const int64_t n_px = n_sub * subsize;
+        if (n_px <= 0) return;
+        const dim3 grid = flat_grid(n_px);
+        hipStream_t st = as_stream(stream);
+        switch (nnz) {
+            case 1: hipLaunchKernelGGL(k_cov_mult_diag<1>, grid, dim3(kThreads), 0, st, n_px, d_data1, d_data2); break;
+            case 2: hipLaunchKernelGGL(k_cov_mult_diag<2>, grid, dim3(kThreads), 0, st, n_px, d_data1, d_data2); break;
+            case 3: hipLaunchKernelGGL(k_cov_mult_diag<3>, grid, dim3(kThreads), 0, st, n_px, d_data1, d_data2); break;
+            case 4: hipLaunchKernelGGL(k_cov_mult_diag<4>, grid, dim3(kThreads), 0, st, n_px, d_data1, d_data2); break;
+            default: fail_arg("cov_mult_diag: nnz must be 1..4");
+        }
         check_launch();
     });
 }

@@ -441,6 +441,21 @@ PYBIND11_MODULE(_libtoast_hip, m) {
     }, py::arg("nsub"), py::arg("nsubpix"), py::arg("nnz"), py::arg("mat"), py::arg("vec"),
        py::arg("use_accel") = false);
 
+    m.def("cov_mult_diag", [](int64_t nsub, int64_t nsubpix, int64_t nnz, py::buffer data1, py::buffer data2,
+                              bool use_accel) {
+        auto i1 = data1.request();
+        auto i2 = data2.request();
+        if (norm_format(i1.format) != "d" || norm_format(i2.format) != "d") {
+            throw std::runtime_error("cov_mult_diag: buffers must be float64");
+        }
+        if (i1.size != i2.size) {
+            throw std::runtime_error("Buffer sizes are not consistent.");
+        }
+        check(toast_hip_cov_mult_diag(nsub, nsubpix, nnz, static_cast<double *>(i1.ptr),
+                                      static_cast<double *>(i2.ptr), use_accel));
+    }, py::arg("nsub"), py::arg("nsubpix"), py::arg("nnz"), py::arg("data1"), py::arg("data2"),
+       py::arg("use_accel") = false);
+
     // ---- offset template (template_offset.cpp:16-25, :149-162, :334-340)
     m.def("template_offset_add_to_signal", [](int64_t step_length, int64_t amp_offset, py::buffer n_amp_views,
                                               py::buffer amplitudes, py::buffer amplitude_flags,

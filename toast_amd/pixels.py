@@ -422,6 +422,30 @@ def covariance_apply(npp, m, use_alltoallv=False):
                             on_dev)
 
 
+def covariance_multiply(npp1, npp2, use_alltoallv=False):
+    """In-place per-pixel product of two block-diagonal covariances, ``npp1 <- npp1 npp2`` (reference:
+    src/toast/covariance.py:179-221 -> cov_mult_diag).  Runs where ``npp1`` lives."""
+    mapnnz = int(((np.sqrt(8 * npp1.n_value) - 1) / 2) + 0.5)
+    if npp1.distribution != npp2.distribution:
+        raise RuntimeError("covariance matrices must have same pixel distribution")
+    if npp1.n_value != npp2.n_value:
+        raise RuntimeError("covariance matrices must have same n_values")
+    on_dev = npp1.accel_in_use()
+    if on_dev and not npp2.accel_in_use():
+        if not npp2.accel_exists():
+            npp2.accel_create("covariance2")
+        npp2.accel_update_device()
+    if (not on_dev) and npp2.accel_in_use():
+        npp2.accel_update_host()
+    native().cov_mult_diag(npp1.distribution.n_local_submap, npp1.distribution.n_pix_submap, mapnnz, npp1.raw,
+                           npp2.raw, on_dev)
+    if npp1.units is not None and npp2.units is not None:
+        try:
+            npp1.update_units(npp1.units * npp2.units)
+        except TypeError:
+            pass
+
+
 def covariance_invert(npp, threshold, rcond=None, use_alltoallv=False):
     """In-place inverse of the per-pixel blocks with an rcond threshold
     (reference: src/toast/covariance.py:20-110 -> cov_eigendecompose_diag).  Runs where the matrix
