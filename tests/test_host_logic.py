@@ -100,10 +100,10 @@ def test_pixel_distribution_and_data():
 
 def test_intervals():
     t = np.arange(100) / 10.0
-    iv = IntervalList(t, [(0, 10), (20, 100)])
+    iv = IntervalList(t, samplespans=[(0, 10), (20, 100)])
     assert len(iv) == 2 and iv.data.dtype.itemsize == 32
     assert [x.first for x in iv] == [0, 20] and iv.data["stop"][1] == t[99]
-    assert iv == IntervalList(t, [(0, 10), (20, 100)]) and iv != IntervalList(t, [(0, 10)])
+    assert iv == IntervalList(t, samplespans=[(0, 10), (20, 100)]) and iv != IntervalList(t, samplespans=[(0, 10)])
 
 
 def test_amplitude_algebra():

@@ -183,37 +183,220 @@ class Comm:
 
 
 # ----------------------------------------------------------------------------- intervals
-class IntervalList:
-    """Sample spans ``[first, last)`` with their times; ``.data`` is the structured array the
-    kernels consume (reference: src/toast/intervals.py)."""
+def build_interval_dtype():
+    """The Interval record (reference src/toast/intervals.py:26-45; same layout as ``synth.interval_dtype``)."""
+    return interval_dtype
 
-    def __init__(self, timestamps=None, samplespans=None, data=None):
+
+def regular_intervals(n, start, first, rate, duration, gap):
+    """``n`` intervals of ``duration`` seconds separated by ``gap`` seconds, as a raw record array (reference
+    src/toast/intervals.py:449-520): both lengths are rounded down to whole samples, except that a span that is an
+    exact multiple of the sampling excludes its final sample."""
+    invrate = 1.0 / rate
+
+    def whole(span):
+        lower = int(span * rate)
+        return lower + 1 if np.absolute(lower * invrate - span) > 1.0e-12 else lower
+
+    totsamples = whole(duration + gap)
+    dursamples = whole(duration)
+    out = np.zeros(n, dtype=interval_dtype).view(np.recarray)
+    for i in range(n):
+        out[i].first = first + i * totsamples
+        out[i].last = out[i].first + dursamples
+        out[i].start = start + i * (totsamples * invrate)
+        out[i].stop = out[i].start + (dursamples * invrate)
+    return out
+
+
+class IntervalList:
+    """Sorted, disjoint sample spans ``[first, last)`` with their times, valid inside the local ``timestamps``; ``.data``
+    is the record array the kernels consume.  Construction from an existing list (``intervals``), from time spans or
+    from sample spans, set algebra (``~ & |``) and ``simplify`` follow the reference (src/toast/intervals.py:48-403);
+    ``data=`` adopts a ready record array (used by the synthetic inputs)."""
+
+    def __init__(self, timestamps=None, intervals=None, timespans=None, samplespans=None, data=None):
+        self.timestamps = timestamps
+        empty = np.zeros(0, dtype=interval_dtype).view(np.recarray)
         if data is not None:
-            self.data = np.ascontiguousarray(data, dtype=interval_dtype)
-            return
-        spans = [] if samplespans is None else list(samplespans)
-        self.data = np.zeros(len(spans), dtype=interval_dtype)
-        for i, (first, last) in enumerate(spans):
-            self.data[i]["first"] = first
-            self.data[i]["last"] = last
-            if timestamps is not None and len(timestamps) > 0:
-                self.data[i]["start"] = timestamps[first]
-                self.data[i]["stop"] = timestamps[min(last, len(timestamps)) - 1]
+            self.data = np.ascontiguousarray(data, dtype=interval_dtype).view(np.recarray)
+        elif intervals is not None:
+            if timespans is not None or samplespans is not None:
+                raise RuntimeError("If constructing from intervals, other spans should be None")
+            if len(intervals) == 0:
+                self.data = empty
+            else:
+                self.data = self._from_timespans([(x.start, x.stop) for x in intervals])
+        elif timespans is not None:
+            if samplespans is not None:
+                raise RuntimeError("Cannot construct from both time and sample spans")
+            if len(timespans) == 0:
+                self.data = empty
+            else:
+                spans = np.vstack(timespans).astype(np.float64)
+                for k in range(len(spans) - 1):
+                    if np.isclose(spans[k][1], spans[k + 1][0], rtol=1e-12):
+                        spans[k][1] = spans[k + 1][0]      # nearly equal times are made equal
+                    if spans[k][1] > spans[k + 1][0]:
+                        raise RuntimeError("Timespans must be sorted and disjoint")
+                self.data = self._from_timespans(spans)
+        elif samplespans is not None:
+            spans = list(samplespans)
+            for k in range(len(spans) - 1):
+                if spans[k][1] > spans[k + 1][0]:
+                    raise RuntimeError("Sample spans must be sorted and disjoint")
+            if timestamps is None or len(timestamps) == 0:
+                # no time axis (kernel-level callers): sample spans only
+                self.data = np.zeros(len(spans), dtype=interval_dtype).view(np.recarray)
+                for k, (first, last) in enumerate(spans):
+                    self.data[k].first, self.data[k].last = first, last
+            else:
+                rows = []
+                n = len(timestamps)
+                for first, last in spans:
+                    if last < 0 or first >= n:
+                        continue
+                    first = max(first, 0)
+                    last = min(last, n)
+                    rows.append((self._sample_time(first), self._sample_time(last), first, last))
+                self.data = np.array(rows, dtype=interval_dtype).view(np.recarray) if rows else empty
+        else:
+            self.data = empty
+
+    def _sample_time(self, sample):
+        n = len(self.timestamps)
+        if sample < 0 or sample > n:
+            raise RuntimeError(f"Invalid sample index: {sample} not in [0, {n}]")
+        return self.timestamps[sample - 1] if sample == n else self.timestamps[sample]
+
+    def _from_timespans(self, timespans):
+        """start <= t < stop, the last timestamp included when an interval stops exactly there (intervals.py:150-175);
+        spans outside the local timestamps are dropped."""
+        t = self.timestamps
+        start, stop = np.vstack(timespans).T
+        good = np.logical_and(start < t[-1], stop > t[0])
+        start, stop = start[good], stop[good]
+        first = np.searchsorted(t, start, side="left")
+        last = np.searchsorted(t, stop, side="left")
+        last[last == len(t) - 1] = len(t)
+        out = np.zeros(len(start), dtype=interval_dtype).view(np.recarray)
+        out.start, out.stop, out.first, out.last = start, stop, first, last
+        return out
+
+    def __getitem__(self, key):
+        return self.data[key]
+
+    def __delitem__(self, key):
+        raise RuntimeError("Cannot delete individual elements from an IntervalList")
+
+    def __contains__(self, item):
+        return any(ival == item for ival in self.data)
 
     def __len__(self):
         return len(self.data)
 
     def __iter__(self):
-        for rec in self.data:
-            yield types.SimpleNamespace(start=float(rec["start"]), stop=float(rec["stop"]),
-                                        first=int(rec["first"]), last=int(rec["last"]))
+        return iter(self.data)
+
+    def __repr__(self):
+        s = "<IntervalList [\n"
+        for ival in self.data:
+            s += f" {ival.start:15.3f} - {ival.stop:15.3f} ({ival.first:9} - {ival.last:9}),\n"
+        return s + "]>"
+
+    def _same_times(self, other):
+        a, b = self.timestamps, other.timestamps
+        if a is None or b is None:
+            return a is None and b is None
+        return (len(a) == len(b) and bool(np.isclose(a[0], b[0], rtol=1e-12))
+                and bool(np.isclose(a[-1], b[-1], rtol=1e-12)))
 
     def __eq__(self, other):
-        return isinstance(other, IntervalList) and np.array_equal(self.data[["first", "last"]],
-                                                                  other.data[["first", "last"]])
+        if not isinstance(other, IntervalList) or len(self.data) != len(other) or not self._same_times(other):
+            return False
+        return np.array_equal(self.data.first, other.data.first) and np.array_equal(self.data.last, other.data.last)
 
     def __ne__(self, other):
         return not self.__eq__(other)
+
+    def simplify(self):
+        """Merge intervals that touch (intervals.py:225-252)."""
+        if len(self.data) == 0:
+            return
+        rows = [list(self.data[0].tolist())]
+        for cur in self.data[1:]:
+            if cur.first == rows[-1][3]:
+                rows[-1][1], rows[-1][3] = cur.stop, cur.last
+            else:
+                rows.append(list(cur.tolist()))
+        if len(rows) < len(self.data):
+            self.data = np.array([tuple(r) for r in rows], dtype=interval_dtype).view(np.recarray)
+
+    def __invert__(self):
+        """The gaps, including the ranges before the first and after the last interval (intervals.py:254-283)."""
+        if len(self.data) == 0:
+            return
+        t, d = self.timestamps, self.data
+        neg = []
+        if not np.isclose(t[0], d[0].start, rtol=1e-12):
+            neg.append((t[0], d[0].start, 0, d[0].first))
+        for k in range(len(d) - 1):
+            if d[k + 1].first != d[k].last + 1:
+                neg.append((d[k].stop, d[k + 1].start, d[k].last, d[k + 1].first))
+        if not np.isclose(t[-1], d[-1].stop, rtol=1e-12):
+            neg.append((d[-1].stop, t[-1], d[-1].last, len(t)))
+        return IntervalList(t, intervals=np.array(neg, dtype=interval_dtype).view(np.recarray))
+
+    def _check_times(self, other, what):
+        if not self._same_times(other):
+            raise RuntimeError(f"Cannot do {what} operation on intervals with different timestamps")
+
+    def __and__(self, other):
+        """Intersection (intervals.py:285-318)."""
+        self._check_times(other, "AND")
+        if len(self.data) == 0 or len(other) == 0:
+            return IntervalList(self.timestamps)
+        result = []
+        a = b = 0
+        while a < len(self.data) and b < len(other):
+            x, y = self.data[a], other[b]
+            start, stop = max(x.start, y.start), min(x.stop, y.stop)
+            if start < stop:
+                result.append((start, stop, max(x.first, y.first), min(x.last, y.last)))
+            if x.stop < y.stop:
+                a += 1
+            else:
+                b += 1
+        return IntervalList(self.timestamps, intervals=np.array(result, dtype=interval_dtype).view(np.recarray))
+
+    def __or__(self, other):
+        """Union; intervals that merely touch stay separate, ``simplify`` joins them (intervals.py:320-402)."""
+        self._check_times(other, "OR")
+        if len(self.data) == 0:
+            return IntervalList(self.timestamps, intervals=other.data)
+        if len(other) == 0:
+            return IntervalList(self.timestamps, intervals=self.data)
+        # merge the two sorted sequences by first sample (ties: the other list first, like the reference's walk)
+        a = b = 0
+        merged = []
+        while a < len(self.data) or b < len(other):
+            if b >= len(other) or (a < len(self.data) and self.data[a].first < other[b].first):
+                merged.append(self.data[a])
+                a += 1
+            else:
+                merged.append(other[b])
+                b += 1
+        result = []
+        cur = list(merged[0].tolist())
+        for nxt in merged[1:]:
+            if nxt.first < cur[3]:
+                if nxt.last > cur[3]:
+                    cur[1], cur[3] = nxt.stop, nxt.last
+            else:
+                result.append(tuple(cur))
+                cur = list(nxt.tolist())
+        result.append(tuple(cur))
+        return IntervalList(self.timestamps, intervals=np.array(result, dtype=interval_dtype).view(np.recarray))
 
 
 class IntervalsManager(dict):
@@ -223,10 +406,10 @@ class IntervalsManager(dict):
         super().__init__()
         self._n_samp = n_samp
         self._times = timestamps
-        self[None] = IntervalList(timestamps, [(0, n_samp)])
+        self[None] = IntervalList(timestamps, samplespans=[(0, n_samp)])
 
     def create(self, name, samplespans):
-        self[name] = IntervalList(self._times, samplespans)
+        self[name] = IntervalList(self._times, samplespans=samplespans)
 
 
 # ----------------------------------------------------------------------------- detector data
@@ -544,7 +727,7 @@ class Observation(MutableMapping):
     def set_times(self, times):
         self.shared.create(defaults.times, np.asarray(times, dtype=np.float64))
         self.intervals._times = self.shared[defaults.times].data
-        self.intervals[None] = IntervalList(self.intervals._times, [(0, self.n_local_samples)])
+        self.intervals[None] = IntervalList(self.intervals._times, samplespans=[(0, self.n_local_samples)])
 
     def update_local_detector_flags(self, flags):
         self.local_detector_flags.update(flags)

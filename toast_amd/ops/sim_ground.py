@@ -339,16 +339,16 @@ class SimGround(Operator):
                      dict(scan_lr=scan_lr, turn_lr=turn_lr, scan_rl=scan_rl, turn_rl=turn_rl, throw_lr=throw_lr,
                           throw_rl=throw_rl).items()}
             n = len(times)
-            ob.intervals[self.throw_leftright_interval] = IntervalList(times, spans["throw_lr"])
-            ob.intervals[self.throw_rightleft_interval] = IntervalList(times, spans["throw_rl"])
-            ob.intervals[self.throw_interval] = IntervalList(times, union_spans(n, spans["throw_lr"], spans["throw_rl"]))
-            ob.intervals[self.scan_leftright_interval] = IntervalList(times, spans["scan_lr"])
-            ob.intervals[self.turn_leftright_interval] = IntervalList(times, spans["turn_lr"])
-            ob.intervals[self.scan_rightleft_interval] = IntervalList(times, spans["scan_rl"])
-            ob.intervals[self.turn_rightleft_interval] = IntervalList(times, spans["turn_rl"])
-            ob.intervals[self.scanning_interval] = IntervalList(times, union_spans(n, spans["scan_lr"], spans["scan_rl"]))
+            ob.intervals[self.throw_leftright_interval] = IntervalList(times, samplespans=spans["throw_lr"])
+            ob.intervals[self.throw_rightleft_interval] = IntervalList(times, samplespans=spans["throw_rl"])
+            ob.intervals[self.throw_interval] = IntervalList(times, samplespans=union_spans(n, spans["throw_lr"], spans["throw_rl"]))
+            ob.intervals[self.scan_leftright_interval] = IntervalList(times, samplespans=spans["scan_lr"])
+            ob.intervals[self.turn_leftright_interval] = IntervalList(times, samplespans=spans["turn_lr"])
+            ob.intervals[self.scan_rightleft_interval] = IntervalList(times, samplespans=spans["scan_rl"])
+            ob.intervals[self.turn_rightleft_interval] = IntervalList(times, samplespans=spans["turn_rl"])
+            ob.intervals[self.scanning_interval] = IntervalList(times, samplespans=union_spans(n, spans["scan_lr"], spans["scan_rl"]))
             turn = union_spans(n, spans["turn_lr"], spans["turn_rl"])
-            ob.intervals[self.turnaround_interval] = IntervalList(times, turn)
+            ob.intervals[self.turnaround_interval] = IntervalList(times, samplespans=turn)
             if self.shared_flags is not None:
                 flags = np.zeros(n, dtype=np.uint8)
                 for a, b in turn:      # FlagIntervals(view_mask=[(turnaround, turnaround_mask)])
