@@ -547,6 +547,46 @@ class DetectorData(AcceleratorObject):
         else:
             self._data[self._row(key)] = value
 
+    # small accessors of the reference class (src/toast/observation_data.py:181-246, :462-500)
+    def keys(self):
+        return list(self._detectors)
+
+    @property
+    def sample_shape(self):
+        return tuple(self._sample_shape)
+
+    @property
+    def flatdata(self):
+        """1-D view of the buffer holding the current detectors."""
+        if self._accel_used:
+            self.accel_update_host()
+        return self._data.reshape(-1)
+
+    def memory_use(self):
+        return int(self._raw.nbytes)
+
+    def update_units(self, new_units):
+        self.units = new_units
+
+    def view(self, key):
+        """Array view for a detector name, index, slice or list of names (no copy for the first three)."""
+        return self[key]
+
+    def __delitem__(self, key):
+        raise NotImplementedError("Cannot delete individual elements")
+
+    def __iter__(self):
+        return iter(self._detectors)
+
+    def __len__(self):
+        return len(self._detectors)
+
+    def clear(self):
+        """Release the device copy and the host buffer."""
+        if self.accel_exists():
+            self.accel_delete()
+        self._data = self._raw = None
+
     # accelerator protocol
     def _accel_exists(self):
         return self._data.size > 0 and accel_data_present(self._data, self._accel_name)
@@ -567,7 +607,48 @@ class DetectorData(AcceleratorObject):
         accel_data_reset(self._data, self._accel_name)
 
 
-class DetDataManager(MutableMapping):
+class _KeyAccel:
+    """Key-wise accelerator calls of the reference's DetDataManager / SharedDataManager
+    (src/toast/observation_data.py:881-1039): thin wrappers around the objects' own methods."""
+
+    def _obj(self, key):
+        return self[key]
+
+    def accel_exists(self, key):
+        return self._obj(key).accel_exists()
+
+    def accel_in_use(self, key):
+        return self._obj(key).accel_in_use()
+
+    def accel_used(self, key, state):
+        self._obj(key).accel_used(state)
+
+    def accel_create(self, key, zero_out=False):
+        self._obj(key).accel_create(key, zero_out=zero_out)
+
+    def accel_update_device(self, key):
+        self._obj(key).accel_update_device()
+
+    def accel_update_host(self, key):
+        self._obj(key).accel_update_host()
+
+    def accel_delete(self, key):
+        self._obj(key).accel_delete()
+
+    def accel_reset(self, key):
+        self._obj(key).accel_reset()
+
+    def accel_clear(self):
+        for key in list(self.keys()):
+            if self._obj(key).accel_exists():
+                self._obj(key).accel_delete()
+
+    def memory_use(self):
+        return sum(int(getattr(self._obj(k), "_raw", getattr(self._obj(k), "data", np.zeros(0))).nbytes)
+                   for k in self.keys())
+
+
+class DetDataManager(_KeyAccel, MutableMapping):
     """``ob.detdata`` (reference: observation_data.py:620-1190)."""
 
     def __init__(self, n_samp, local_detectors):
@@ -614,6 +695,12 @@ class DetDataManager(MutableMapping):
             obj.accel_used(True)
         return existing
 
+    def rename(self, original, new_name):
+        """Move the object stored under ``original`` to ``new_name`` (observation_data.py:861-879)."""
+        if new_name in self._store:
+            raise RuntimeError(f"detdata key '{new_name}' already exists")
+        self._store[new_name] = self._store.pop(original)
+
     def __getitem__(self, name):
         return self._store[name]
 
@@ -658,7 +745,7 @@ class SharedData(AcceleratorObject):
         accel_data_reset(self.data, self._accel_name)
 
 
-class SharedDataManager(dict):
+class SharedDataManager(_KeyAccel, dict):
     def create(self, name, array):
         self[name] = SharedData(array, name)
         return self[name]
