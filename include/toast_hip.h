@@ -308,6 +308,22 @@ int toast_hip_cov_apply_diag(int64_t n_sub, int64_t subsize, int64_t nnz, const 
 int toast_hip_cov_apply_diag_dev(int64_t n_sub, int64_t subsize, int64_t nnz, const double * d_mat,
                                  double * d_vec, void * stream);
 
+/* cov_accum_diag_hits / cov_accum_diag_invnpp: the reference's kernels behind BuildHitMap / BuildInverseCovariance at
+ * the FFI level -- one stream of n_samp samples with a (local submap, pixel in submap) pair per sample (negative =
+ * skipped): hits[submap * subsize + pixel] += 1;  invnpp[.. * nnz (nnz+1)/2 + (j, k >= j)] += (scale w_j) w_k.
+ * [ref: /root/reference/src/toast/_libtoast/map_cov.cpp:87-197 -> src/libtoast/src/toast_map_cov.cpp:66-153; called by
+ * src/toast/ops/mapmaker_utils/kernels.py:31-41].  The batched operator path is toast_hip_build_cov below. */
+int toast_hip_cov_accum_diag_hits(int64_t n_sub, int64_t subsize, int64_t nnz, int64_t n_samp, const int64_t * submap,
+                                 const int64_t * subpix, int64_t * hits, int use_accel);
+int toast_hip_cov_accum_diag_hits_dev(int64_t n_sub, int64_t subsize, int64_t n_samp, const int64_t * d_submap,
+                                     const int64_t * d_subpix, int64_t * d_hits, void * stream);
+int toast_hip_cov_accum_diag_invnpp(int64_t n_sub, int64_t subsize, int64_t nnz, int64_t n_samp,
+                                   const int64_t * submap, const int64_t * subpix, const double * weights,
+                                   double scale, double * invnpp, int use_accel);
+int toast_hip_cov_accum_diag_invnpp_dev(int64_t n_sub, int64_t subsize, int64_t nnz, int64_t n_samp,
+                                       const int64_t * d_submap, const int64_t * d_subpix, const double * d_weights,
+                                       double scale, double * d_invnpp, void * stream);
+
 /* cov_mult_diag: per pixel, data1 <- packed upper triangle of Sym(data1) Sym(data2), entry (k, m >= k) taken from
  * row m, column k of the product as the reference's column-major dsymm call leaves it.
  * [ref: /root/reference/src/libtoast/src/toast_map_cov.cpp:398-469, called by covariance_multiply,

@@ -1041,3 +1041,40 @@ def test_covariance_multiply_inverse_is_identity():
         covariance_multiply(prod, inv)
         eye = np.eye(nnz)[iu]
         assert np.max(np.abs(prod.data.reshape(-1, blk) - eye)) < 1e-10
+
+
+def test_cov_accum_ffi_kernels():
+    """cov_accum_diag_hits / cov_accum_diag_invnpp, the reference's FFI-level kernels behind BuildHitMap and
+    BuildInverseCovariance (src/toast/_libtoast/map_cov.cpp:87-197): one stream of (local submap, pixel) pairs,
+    negative = skipped; against a NumPy scatter of the same definition."""
+    import toast_amd
+
+    m = toast_amd.load_native()
+    rng = np.random.default_rng(21)
+    nsub, nsubpix, n = 5, 64, 40000
+    # scanning-like stream: runs of equal pixels, some skipped samples
+    pix = np.repeat(rng.integers(0, nsub * nsubpix, n // 8), 8)[:n]
+    submap = (pix // nsubpix).astype(np.int64)
+    subpix = (pix % nsubpix).astype(np.int64)
+    skip = rng.random(n) < 0.05
+    submap[skip & (rng.random(n) < 0.5)] = -1
+    subpix[skip & (submap >= 0)] = -1
+    good = (submap >= 0) & (subpix >= 0)
+    hits = np.zeros(nsub * nsubpix, dtype=np.int64)
+    hits[7] = 3          # accumulates into what is there
+    m.cov_accum_diag_hits(nsub, nsubpix, 3, submap, subpix, hits, False)
+    want = np.zeros_like(hits)
+    want[7] = 3
+    np.add.at(want, (submap * nsubpix + subpix)[good], 1)
+    assert np.array_equal(hits, want)
+    for nnz in (1, 3):
+        w = rng.standard_normal((n, nnz))
+        blk = nnz * (nnz + 1) // 2
+        inv = np.zeros(nsub * nsubpix * blk)
+        m.cov_accum_diag_invnpp(nsub, nsubpix, nnz, submap, subpix, np.ascontiguousarray(w.reshape(-1)), 2.5, inv, False)
+        iu = np.triu_indices(nnz)
+        wanti = np.zeros((nsub * nsubpix, blk))
+        np.add.at(wanti, (submap * nsubpix + subpix)[good], (2.5 * w[good][:, iu[0]]) * w[good][:, iu[1]])
+        assert np.max(np.abs(inv.reshape(-1, blk) - wanti)) < 1e-12 * np.max(np.abs(wanti))
+    with pytest.raises(RuntimeError):
+        m.cov_accum_diag_hits(nsub, nsubpix, 3, submap, subpix[:-1], hits, False)

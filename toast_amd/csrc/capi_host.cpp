@@ -215,6 +215,34 @@ int toast_hip_cov_apply_diag(int64_t n_sub, int64_t subsize, int64_t nnz, const 
     });
 }
 
+int toast_hip_cov_accum_diag_hits(int64_t n_sub, int64_t subsize, int64_t nnz, int64_t n_samp, const int64_t * submap,
+                                 const int64_t * subpix, int64_t * hits, int use_accel) {
+    (void)nnz;
+    return guarded([&] {
+        Call c(use_accel);
+        const int64_t * d_sm = c.st.in(submap, (size_t)n_samp);
+        const int64_t * d_px = c.st.in(subpix, (size_t)n_samp);
+        int64_t * d_h = c.st.inout(hits, (size_t)(n_sub * subsize));
+        c.check(toast_hip_cov_accum_diag_hits_dev(n_sub, subsize, n_samp, d_sm, d_px, d_h, c.stream));
+        c.st.finish();
+    });
+}
+
+int toast_hip_cov_accum_diag_invnpp(int64_t n_sub, int64_t subsize, int64_t nnz, int64_t n_samp,
+                                   const int64_t * submap, const int64_t * subpix, const double * weights,
+                                   double scale, double * invnpp, int use_accel) {
+    return guarded([&] {
+        Call c(use_accel);
+        const int64_t * d_sm = c.st.in(submap, (size_t)n_samp);
+        const int64_t * d_px = c.st.in(subpix, (size_t)n_samp);
+        const double * d_w = c.st.in(weights, (size_t)(n_samp * nnz));
+        double * d_c = c.st.inout(invnpp, (size_t)(n_sub * subsize * nnz * (nnz + 1) / 2));
+        c.check(toast_hip_cov_accum_diag_invnpp_dev(n_sub, subsize, nnz, n_samp, d_sm, d_px, d_w, scale, d_c,
+                                                    c.stream));
+        c.st.finish();
+    });
+}
+
 int toast_hip_cov_mult_diag(int64_t n_sub, int64_t subsize, int64_t nnz, double * data1, const double * data2,
                             int use_accel) {
     return guarded([&] {

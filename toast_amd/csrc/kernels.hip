@@ -774,6 +774,56 @@ __global__ __launch_bounds__(kThreads) void k_noise_weight(
 }
 
 // ------------------------------------------------------------------------------------
+// cov_accum_diag_hits / cov_accum_diag_invnpp   [ref: src/libtoast/src/toast_map_cov.cpp:66-153]
+// The reference's kernels behind BuildHitMap / BuildInverseCovariance at the FFI level: one stream of samples with its
+// (local submap, pixel in submap) index pair per sample (negative = skip); hits[hpx] += 1, invnpp[hpx] += upper
+// triangle of (scale w) w^T.  Same run reduction + one atomic per run as k_build_cov.
+// ------------------------------------------------------------------------------------
+template <int NNZ, int MODE>
+__global__ __launch_bounds__(kThreads) void k_cov_accum(int64_t n_samp, const int64_t * __restrict__ submap,
+                                                       const int64_t * __restrict__ subpix, int64_t subsize,
+                                                       const double * __restrict__ weights, double scale,
+                                                       double * __restrict__ invnpp, long long * __restrict__ hits) {
+    constexpr int NV = (MODE == 0) ? 1 : NNZ * (NNZ + 1) / 2;
+    const int64_t n_round = (n_samp + kThreads - 1) / kThreads;
+    for (int64_t r = blockIdx.x; r < n_round; r += gridDim.x) {
+        const int64_t i = r * kThreads + threadIdx.x;
+        int64_t key = -1;
+        double v[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[k] = 0.0;
+        if (i < n_samp) {
+            const int64_t sm = submap[i], px = subpix[i];
+            // (the reference tests isubmap = submap * subsize < 0, i.e. submap < 0)
+            if (sm >= 0 && px >= 0) {
+                key = sm * subsize + px;
+                if (MODE == 0) {
+                    v[0] = 1.0;
+                } else {
+                    int off = 0;
+#pragma unroll
+                    for (int j = 0; j < NNZ; ++j) {
+                        const double sw = weights[i * NNZ + j] * scale;
+#pragma unroll
+                        for (int k = j; k < NNZ; ++k, ++off) v[off] = weights[i * NNZ + k] * sw;
+                    }
+                }
+            }
+        }
+        const bool tail = wave_run_reduce<NV>(key, v);
+        if (tail && key >= 0) {
+            if (MODE == 0) {
+                atomicAdd(reinterpret_cast<unsigned long long *>(hits + key), (unsigned long long)(long long)v[0]);
+            } else {
+                double * z = invnpp + NV * key;
+#pragma unroll
+                for (int k = 0; k < NV; ++k) unsafeAtomicAdd(z + k, v[k]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // cov_mult_diag   [ref: src/libtoast/src/toast_map_cov.cpp:398-469]
 // Per pixel, data1 <- packed upper triangle of the product of the two symmetric blocks: the reference expands both
 // to full matrices, calls the batched dsymm (C = S1 S2 in column-major storage) and packs entry (k, m >= k) from
@@ -1469,6 +1519,39 @@ int toast_hip_noise_weight_dev(double * d_det_data, int64_t n_samp, const int32_
         hipLaunchKernelGGL(k_noise_weight, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0,
                            as_stream(stream), (const Chunk *)(d + o_ch), (int)chunks.size(),
                            (const int32_t *)(d + o_di), (const double *)(d + o_w), d_det_data, n_samp);
+        check_launch();
+    });
+}
+
+int toast_hip_cov_accum_diag_hits_dev(int64_t n_sub, int64_t subsize, int64_t n_samp, const int64_t * d_submap,
+                                     const int64_t * d_subpix, int64_t * d_hits, void * stream) {
+    return guarded([&] {
+        if (n_sub < 1 || n_samp <= 0) return;
+        hipLaunchKernelGGL((k_cov_accum<1, 0>), flat_grid(n_samp), dim3(kThreads), 0, as_stream(stream), n_samp, d_submap,
+                           d_subpix, subsize, (const double *)nullptr, 1.0, (double *)nullptr,
+                           reinterpret_cast<long long *>(d_hits));
+        check_launch();
+    });
+}
+
+int toast_hip_cov_accum_diag_invnpp_dev(int64_t n_sub, int64_t subsize, int64_t nnz, int64_t n_samp,
+                                       const int64_t * d_submap, const int64_t * d_subpix, const double * d_weights,
+                                       double scale, double * d_invnpp, void * stream) {
+    return guarded([&] {
+        if (n_sub < 1 || n_samp <= 0) return;
+        const dim3 grid = flat_grid(n_samp);
+        hipStream_t st = as_stream(stream);
+#define TH_ACC(N)                                                                                              \
+    hipLaunchKernelGGL((k_cov_accum<N, 1>), grid, dim3(kThreads), 0, st, n_samp, d_submap, d_subpix, subsize, \
+                       d_weights, scale, d_invnpp, (long long *)nullptr)
+        switch (nnz) {
+            case 1: TH_ACC(1); break;
+            case 2: TH_ACC(2); break;
+            case 3: TH_ACC(3); break;
+            case 4: TH_ACC(4); break;
+            default: fail_arg("cov_accum_diag_invnpp: nnz must be 1..4");
+        }
+#undef TH_ACC
         check_launch();
     });
 }

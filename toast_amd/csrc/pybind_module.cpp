@@ -441,6 +441,42 @@ PYBIND11_MODULE(_libtoast_hip, m) {
     }, py::arg("nsub"), py::arg("nsubpix"), py::arg("nnz"), py::arg("mat"), py::arg("vec"),
        py::arg("use_accel") = false);
 
+    m.def("cov_accum_diag_hits", [](int64_t nsub, int64_t nsubpix, int64_t nnz, py::buffer submap, py::buffer subpix,
+                                    py::buffer hits, bool use_accel) {
+        auto ism = submap.request();
+        auto ipx = subpix.request();
+        auto ih = hits.request();
+        if (!(norm_format(ism.format) == "q") || !(norm_format(ipx.format) == "q") || !(norm_format(ih.format) == "q")) {
+            throw std::runtime_error("cov_accum_diag_hits: buffers must be int64");
+        }
+        if (ipx.size != ism.size) throw std::runtime_error("Buffer sizes are not consistent.");
+        check(toast_hip_cov_accum_diag_hits(nsub, nsubpix, nnz, (int64_t)ism.size, static_cast<int64_t *>(ism.ptr),
+                                            static_cast<int64_t *>(ipx.ptr), static_cast<int64_t *>(ih.ptr),
+                                            use_accel));
+    }, py::arg("nsub"), py::arg("nsubpix"), py::arg("nnz"), py::arg("submap"), py::arg("subpix"), py::arg("hits"),
+       py::arg("use_accel") = false);
+
+    m.def("cov_accum_diag_invnpp", [](int64_t nsub, int64_t nsubpix, int64_t nnz, py::buffer submap, py::buffer subpix,
+                                      py::buffer weights, double scale, py::buffer invnpp, bool use_accel) {
+        auto ism = submap.request();
+        auto ipx = subpix.request();
+        auto iw = weights.request();
+        auto ic = invnpp.request();
+        if (!(norm_format(ism.format) == "q") || !(norm_format(ipx.format) == "q")) {
+            throw std::runtime_error("cov_accum_diag_invnpp: index buffers must be int64");
+        }
+        if (norm_format(iw.format) != "d" || norm_format(ic.format) != "d") {
+            throw std::runtime_error("cov_accum_diag_invnpp: weights / invnpp must be float64");
+        }
+        if (ipx.size != ism.size || (size_t)(iw.size / nnz) != (size_t)ism.size) {
+            throw std::runtime_error("Buffer sizes are not consistent.");
+        }
+        check(toast_hip_cov_accum_diag_invnpp(nsub, nsubpix, nnz, (int64_t)ism.size, static_cast<int64_t *>(ism.ptr),
+                                              static_cast<int64_t *>(ipx.ptr), static_cast<double *>(iw.ptr), scale,
+                                              static_cast<double *>(ic.ptr), use_accel));
+    }, py::arg("nsub"), py::arg("nsubpix"), py::arg("nnz"), py::arg("submap"), py::arg("subpix"), py::arg("weights"),
+       py::arg("scale"), py::arg("invnpp"), py::arg("use_accel") = false);
+
     m.def("cov_mult_diag", [](int64_t nsub, int64_t nsubpix, int64_t nnz, py::buffer data1, py::buffer data2,
                               bool use_accel) {
         auto i1 = data1.request();
