@@ -308,6 +308,13 @@ int toast_hip_cov_apply_diag(int64_t n_sub, int64_t subsize, int64_t nnz, const 
 int toast_hip_cov_apply_diag_dev(int64_t n_sub, int64_t subsize, int64_t nnz, const double * d_mat,
                                  double * d_vec, void * stream);
 
+/* healpix_vec2nest / healpix_vec2ring: HEALPix pixel of n direction vectors [n, 3] (the arithmetic of the pointing
+ * kernels: bit-identical to the reference).  [ref: /root/reference/src/toast/_libtoast/ops_pixels_healpix.cpp:816-893
+ * -> hpix_vec2nest / hpix_vec2ring :351-381; used by src/toast/healpix.py] */
+int toast_hip_healpix_vec2pix(int64_t nside, int nest, int64_t n, const double * vec, int64_t * pix, int use_accel);
+int toast_hip_healpix_vec2pix_dev(int64_t nside, int nest, int64_t n, const double * d_vec, int64_t * d_pix,
+                                 void * stream);
+
 /* cov_accum_diag_hits / cov_accum_diag_invnpp: the reference's kernels behind BuildHitMap / BuildInverseCovariance at
  * the FFI level -- one stream of n_samp samples with a (local submap, pixel in submap) pair per sample (negative =
  * skipped): hits[submap * subsize + pixel] += 1;  invnpp[.. * nnz (nnz+1)/2 + (j, k >= j)] += (scale w_j) w_k.

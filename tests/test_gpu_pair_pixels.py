@@ -186,3 +186,30 @@ def test_pair_pixels_from_boresight(env, kind):
     quarter = n_samp - 3 * (n_samp // 4)
     assert not diff[:, : n_samp - quarter].any()
     assert diff.sum() <= 2e-3 * diff.size
+
+
+@pytest.mark.parametrize("nest", [True, False])
+def test_healpix_vec2pix_binding(env, nest):
+    """healpix_vec2nest / healpix_vec2ring of the native module (names of toast._libtoast) against the oracle, incl. the
+    known-answer direction of the reference's pixel test (src/toast/tests/ops_pixels_healpix.py:35-42)."""
+    import toast_amd
+
+    capi, oracle = env
+    m = toast_amd.load_native()
+    rng = np.random.default_rng(4)
+    v = rng.standard_normal((20000, 3))
+    v /= np.linalg.norm(v, axis=1)[:, None]
+    v[:6] = [[0, 0, 1], [0, 0, -1], [1, 0, 0], [0, 1, 0], [-1, 0, 0], [0.6, 0.0, 2.0 / 3.0]]
+    for nside in (1, 64, 4096, 1 << 20):
+        got = np.full(v.shape[0], -5, dtype=np.int64)
+        (m.healpix_vec2nest if nest else m.healpix_vec2ring)(nside, np.ascontiguousarray(v), got)
+        want = oracle.healpix_vec2pix(nside, np.ascontiguousarray(v), nest=nest)
+        assert np.array_equal(got, want), nside
+    q = np.array([-0.51308546259679089, 0.81748419984459697, -0.13909683464480427, 0.22161895602152878])
+    x, y, z, w = q
+    d = np.array([[2 * (w * y + x * z), 2 * (y * z - w * x), 2 * (-x * x - y * y) + 1.0]])
+    out = np.zeros(1, dtype=np.int64)
+    (m.healpix_vec2nest if nest else m.healpix_vec2ring)(4096, d, out)
+    assert out[0] == (143138818 if nest else 187529588)
+    with pytest.raises(RuntimeError):
+        m.healpix_vec2nest(64, np.zeros((5, 2)), np.zeros(5, dtype=np.int64))

@@ -215,6 +215,16 @@ int toast_hip_cov_apply_diag(int64_t n_sub, int64_t subsize, int64_t nnz, const 
     });
 }
 
+int toast_hip_healpix_vec2pix(int64_t nside, int nest, int64_t n, const double * vec, int64_t * pix, int use_accel) {
+    return guarded([&] {
+        Call c(use_accel);
+        const double * d_v = c.st.in(vec, (size_t)(3 * n));
+        int64_t * d_p = c.st.out(pix, (size_t)n);
+        c.check(toast_hip_healpix_vec2pix_dev(nside, nest, n, d_v, d_p, c.stream));
+        c.st.finish();
+    });
+}
+
 int toast_hip_cov_accum_diag_hits(int64_t n_sub, int64_t subsize, int64_t nnz, int64_t n_samp, const int64_t * submap,
                                  const int64_t * subpix, int64_t * hits, int use_accel) {
     (void)nnz;

@@ -116,6 +116,22 @@ __global__ __launch_bounds__(kThreads) void k_pixels_healpix(
 }
 
 // ------------------------------------------------------------------------------------
+// healpix_vec2nest / healpix_vec2ring   [ref: ops_pixels_healpix.cpp:351-381, bindings :816-893]
+// Pixel of n direction vectors: the device functions of the pointing kernels (vec_to_pixel).
+// ------------------------------------------------------------------------------------
+template <bool NEST>
+__global__ __launch_bounds__(kThreads) void k_healpix_vec2pix(int64_t n, const double * __restrict__ vec,
+                                                             int64_t * __restrict__ pix, int64_t nside, int factor) {
+    __shared__ double s_tab[2 * TOAST_ATAN_TABLE_N];
+    if (threadIdx.x < 2 * TOAST_ATAN_TABLE_N) s_tab[threadIdx.x] = kAtanTab[threadIdx.x];
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+        const double v[3] = {vec[3 * i], vec[3 * i + 1], vec[3 * i + 2]};
+        pix[i] = vec_to_pixel<NEST>(v, nside, factor, s_tab);
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // stokes_weights   [ref: ops_stokes_weights.cpp:77-140, :459-505]
 // ------------------------------------------------------------------------------------
 template <bool HWP, int NOUT>   // NOUT = 3: (I, Q, U); 2: (Q, U) only (StokesWeights mode "QU")
@@ -1519,6 +1535,22 @@ int toast_hip_noise_weight_dev(double * d_det_data, int64_t n_samp, const int32_
         hipLaunchKernelGGL(k_noise_weight, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0,
                            as_stream(stream), (const Chunk *)(d + o_ch), (int)chunks.size(),
                            (const int32_t *)(d + o_di), (const double *)(d + o_w), d_det_data, n_samp);
+        check_launch();
+    });
+}
+
+int toast_hip_healpix_vec2pix_dev(int64_t nside, int nest, int64_t n, const double * d_vec, int64_t * d_pix,
+                                 void * stream) {
+    return guarded([&] {
+        if (n <= 0) return;
+        const int factor = log2_exact(nside);
+        if (nest) {
+            hipLaunchKernelGGL(k_healpix_vec2pix<true>, flat_grid(n), dim3(kThreads), 0, as_stream(stream), n, d_vec,
+                               d_pix, nside, factor);
+        } else {
+            hipLaunchKernelGGL(k_healpix_vec2pix<false>, flat_grid(n), dim3(kThreads), 0, as_stream(stream), n, d_vec,
+                               d_pix, nside, factor);
+        }
         check_launch();
     });
 }

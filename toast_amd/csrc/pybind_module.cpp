@@ -441,6 +441,16 @@ PYBIND11_MODULE(_libtoast_hip, m) {
     }, py::arg("nsub"), py::arg("nsubpix"), py::arg("nnz"), py::arg("mat"), py::arg("vec"),
        py::arg("use_accel") = false);
 
+    for (int nest = 1; nest >= 0; --nest) {
+        m.def(nest ? "healpix_vec2nest" : "healpix_vec2ring", [nest](int64_t nside, py::buffer vec, py::buffer pix) {
+            Shape shape;
+            double * raw_vec = extract<double>(vec, "vec", 2, shape, {-1, 3});
+            const int64_t n_samp = shape[0];
+            int64_t * raw_pix = extract<int64_t>(pix, "pix", 1, shape, {n_samp});
+            check(toast_hip_healpix_vec2pix(nside, nest, n_samp, raw_vec, raw_pix, 0));
+        }, py::arg("nside"), py::arg("vec"), py::arg("pix"));
+    }
+
     m.def("cov_accum_diag_hits", [](int64_t nsub, int64_t nsubpix, int64_t nnz, py::buffer submap, py::buffer subpix,
                                     py::buffer hits, bool use_accel) {
         auto ism = submap.request();
