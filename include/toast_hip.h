@@ -308,6 +308,14 @@ int toast_hip_cov_apply_diag(int64_t n_sub, int64_t subsize, int64_t nnz, const 
 int toast_hip_cov_apply_diag_dev(int64_t n_sub, int64_t subsize, int64_t nnz, const double * d_mat,
                                  double * d_vec, void * stream);
 
+/* healpix_ring2nest (op 0), healpix_nest2ring (1), healpix_degrade_nest (2) / upgrade_nest (3) / degrade_ring (4) /
+ * upgrade_ring (5) by `levels` powers of two, for n pixel numbers at resolution nside.
+ * [ref: /root/reference/src/toast/_libtoast/ops_pixels_healpix.cpp:383-580, bindings :893-1150] */
+int toast_hip_healpix_convert(int op, int64_t nside, int64_t levels, int64_t n, const int64_t * in, int64_t * out,
+                              int use_accel);
+int toast_hip_healpix_convert_dev(int op, int64_t nside, int64_t levels, int64_t n, const int64_t * d_in,
+                                  int64_t * d_out, void * stream);
+
 /* healpix_vec2nest / healpix_vec2ring: HEALPix pixel of n direction vectors [n, 3] (the arithmetic of the pointing
  * kernels: bit-identical to the reference).  [ref: /root/reference/src/toast/_libtoast/ops_pixels_healpix.cpp:816-893
  * -> hpix_vec2nest / hpix_vec2ring :351-381; used by src/toast/healpix.py] */

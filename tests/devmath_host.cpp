@@ -223,6 +223,20 @@ int64_t devmath_sweep_pair(int64_t n, uint64_t seed, int64_t nside, int nest, in
     return bad;
 }
 
+void devmath_ring2nest(int64_t n, int64_t nside, const int64_t * in, int64_t * out) {
+    int factor = 0;
+    while (nside != (int64_t(1) << factor)) ++factor;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) out[i] = ring_to_nest(nside, factor, in[i]);
+}
+
+void devmath_nest2ring(int64_t n, int64_t nside, const int64_t * in, int64_t * out) {
+    int factor = 0;
+    while (nside != (int64_t(1) << factor)) ++factor;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) out[i] = nest_to_ring(nside, factor, in[i]);
+}
+
 void devmath_stokes(int64_t n, const double * quats, double * c2a, double * s2a) {
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) stokes_cs2alpha(quats + 4 * i, c2a[i], s2a[i]);

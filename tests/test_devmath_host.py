@@ -214,3 +214,31 @@ def test_pixel_edge_samples_where_glibc_misrounds(devmath, oracle):
     assert np.array_equal(dd, exact)              # the device's atan2 is the correctly rounded one ...
     assert np.all(libm != exact)                  # ... and glibc's is 1 ulp off on exactly these samples
     print("edge samples:", n, "differing:", diff.size)
+
+
+@pytest.mark.parametrize("nside", [1, 2, 16, 1024, 8192, 1 << 20, 1 << 29])
+def test_ring_nest_conversions(devmath, oracle, nside):
+    """ring_to_nest / nest_to_ring of hpix_math.hpp (host build of the device functions) against the oracle's
+    restatement of the reference (ops_pixels_healpix.cpp:383-520): every pixel at small nside, random and boundary pixels
+    at large nside; the two are inverse to each other."""
+    npix = 12 * nside * nside
+    rng = np.random.default_rng(nside % 1000)
+    if npix <= 50000:
+        pix = np.arange(npix, dtype=np.int64)
+    else:
+        ncap = 2 * (nside * nside - nside)
+        edges = np.array([0, 1, 3, 4, ncap - 1, ncap, ncap + 1, npix - ncap - 1, npix - ncap, npix - 2, npix - 1])
+        pix = np.concatenate([rng.integers(0, npix, 300000), edges, edges[edges + 4 * nside < npix] + 4 * nside])
+        pix = np.ascontiguousarray(pix.astype(np.int64))
+    nest = np.empty_like(pix)
+    devmath.devmath_ring2nest(C.c_int64(pix.size), C.c_int64(nside), _p(pix), _p(nest))
+    assert np.array_equal(nest, oracle.healpix_ring2nest(nside, pix))
+    back = np.empty_like(pix)
+    devmath.devmath_nest2ring(C.c_int64(pix.size), C.c_int64(nside), _p(nest), _p(back))
+    if nside <= 1 << 24:
+        # (beyond that 2 * n_pix exceeds 2^53 and the reference's own sqrt-based ring number is off by one for some
+        # polar-cap pixels: ring -> nest is then not invertible in the reference either)
+        assert np.array_equal(back, pix)
+    ring = np.empty_like(pix)
+    devmath.devmath_nest2ring(C.c_int64(pix.size), C.c_int64(nside), _p(pix), _p(ring))
+    assert np.array_equal(ring, oracle.healpix_nest2ring(nside, pix))

@@ -215,6 +215,17 @@ int toast_hip_cov_apply_diag(int64_t n_sub, int64_t subsize, int64_t nnz, const 
     });
 }
 
+int toast_hip_healpix_convert(int op, int64_t nside, int64_t levels, int64_t n, const int64_t * in, int64_t * out,
+                              int use_accel) {
+    return guarded([&] {
+        Call c(use_accel);
+        const int64_t * d_i = c.st.in(in, (size_t)n);
+        int64_t * d_o = c.st.out(out, (size_t)n);
+        c.check(toast_hip_healpix_convert_dev(op, nside, levels, n, d_i, d_o, c.stream));
+        c.st.finish();
+    });
+}
+
 int toast_hip_healpix_vec2pix(int64_t nside, int nest, int64_t n, const double * vec, int64_t * pix, int use_accel) {
     return guarded([&] {
         Call c(use_accel);

@@ -661,6 +661,111 @@ TOAST_HD void hwp_rotation(double c4g, double s4g, double c4h, double s4h, doubl
     sb = s4g * c4h - c4g * s4h;
 }
 
+// ------------------------------------------------------------------ RING <-> NEST
+// bit 2k of v -> bit k (the inverse of spread_bits; == the reference's ctab composition hpix_pix2xy, :87-102)
+TOAST_HD uint64_t compress_bits(uint64_t v) {
+    v &= 0x5555555555555555ull;
+    v = (v | (v >> 1)) & 0x3333333333333333ull;
+    v = (v | (v >> 2)) & 0x0f0f0f0f0f0f0f0full;
+    v = (v | (v >> 4)) & 0x00ff00ff00ff00ffull;
+    v = (v | (v >> 8)) & 0x0000ffff0000ffffull;
+    v = (v | (v >> 16)) & 0x00000000ffffffffull;
+    return v;
+}
+
+// ops_pixels_healpix.cpp:383-473 (pixel numbers only: integer arithmetic and two exactly rounded square roots)
+TOAST_HD int64_t ring_to_nest(int64_t nside, int factor, int64_t ringpix) {
+    const int64_t npix = 12 * nside * nside;
+    const int64_t ncap = 2 * (nside * nside - nside);
+    const int64_t jr_tab[12] = {2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4};
+    const int64_t jp_tab[12] = {1, 3, 5, 7, 0, 2, 4, 6, 1, 3, 5, 7};
+    int64_t fc, nr, kshift, iring, iphi;
+    if (ringpix < ncap) {
+        iring = (int64_t)(0.5 * (1.0 + f_sqrt((double)(1 + 2 * ringpix))));
+        iphi = (ringpix + 1) - 2 * iring * (iring - 1);
+        kshift = 0;
+        nr = iring;
+        fc = 0;
+        int64_t tmp = iphi - 1;
+        if (tmp >= 2 * iring) {
+            fc = 2;
+            tmp -= 2 * iring;
+        }
+        if (tmp >= iring) ++fc;
+    } else if (ringpix < npix - ncap) {
+        const int64_t ip = ringpix - ncap;
+        iring = (ip >> (factor + 2)) + nside;
+        iphi = (ip & (4 * nside - 1)) + 1;
+        kshift = (iring + nside) & 1;
+        nr = nside;
+        const int64_t ire = iring - nside + 1;
+        const int64_t irm = 2 * nside + 2 - ire;
+        const int64_t ifm = (iphi - (ire / 2) + nside - 1) >> factor;
+        const int64_t ifp = (iphi - (irm / 2) + nside - 1) >> factor;
+        if (ifp == ifm) {
+            fc = (ifp == 4) ? 4 : ifp + 4;
+        } else if (ifp < ifm) {
+            fc = ifp;
+        } else {
+            fc = ifm + 8;
+        }
+    } else {
+        const int64_t ip = npix - ringpix;
+        iring = (int64_t)(0.5 * (1.0 + f_sqrt((double)(2 * ip - 1))));
+        iphi = 4 * iring + 1 - (ip - 2 * iring * (iring - 1));
+        kshift = 0;
+        nr = iring;
+        iring = 4 * nside - iring;
+        fc = 8;
+        int64_t tmp = iphi - 1;
+        if (tmp >= 2 * nr) {
+            fc = 10;
+            tmp -= 2 * nr;
+        }
+        if (tmp >= nr) ++fc;
+    }
+    const int64_t irt = iring - jr_tab[fc] * nside + 1;
+    int64_t ipt = 2 * iphi - jp_tab[fc] * nr - kshift - 1;
+    if (ipt >= 2 * nside) ipt -= 8 * nside;
+    const int64_t x = (ipt - irt) >> 1;
+    const int64_t y = (-(ipt + irt)) >> 1;
+    return morton_interleave<int64_t>(x, y) + (fc << (2 * factor));
+}
+
+// ops_pixels_healpix.cpp:475-520
+TOAST_HD int64_t nest_to_ring(int64_t nside, int factor, int64_t nestpix) {
+    const int64_t npix = 12 * nside * nside;
+    const int64_t ncap = 2 * (nside * nside - nside);
+    const int64_t jr_tab[12] = {2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4};
+    const int64_t jp_tab[12] = {1, 3, 5, 7, 0, 2, 4, 6, 1, 3, 5, 7};
+    const int64_t fc = nestpix >> (2 * factor);
+    const uint64_t in_face = (uint64_t)(nestpix & (nside * nside - 1));
+    const int64_t x = (int64_t)compress_bits(in_face);
+    const int64_t y = (int64_t)compress_bits(in_face >> 1);
+    const int64_t jr = jr_tab[fc] * nside - x - y - 1;
+    int64_t nr, n_before, kshift;
+    if (jr < nside) {
+        nr = jr;
+        n_before = 2 * nr * (nr - 1);
+        kshift = 0;
+    } else if (jr > 3 * nside) {
+        nr = 4 * nside - jr;
+        n_before = npix - 2 * (nr + 1) * nr;
+        kshift = 0;
+    } else {
+        nr = nside;
+        n_before = ncap + (jr - nside) * 4 * nside;
+        kshift = (jr - nside) & 1;
+    }
+    int64_t jp = (jp_tab[fc] * nr + x - y + 1 + kshift) / 2;
+    if (jp > 4 * nside) {
+        jp -= 4 * nside;
+    } else if (jp < 1) {
+        jp += 4 * nside;
+    }
+    return n_before + jp - 1;
+}
+
 // ------------------------------------------------------------------ division by a run-time constant
 // q = n / d for 0 <= n < 2^63 with one 64x64->high multiply.  mul = floor(2^(63+s)/d) + 1,
 // s = ceil(log2 d): the error term n*e/(d 2^(63+s)) < 1/d, so the floor is exact.

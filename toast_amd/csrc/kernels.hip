@@ -132,6 +132,37 @@ __global__ __launch_bounds__(kThreads) void k_healpix_vec2pix(int64_t n, const d
 }
 
 // ------------------------------------------------------------------------------------
+// healpix_ring2nest / nest2ring / degrade_* / upgrade_*   [ref: ops_pixels_healpix.cpp:383-580, bindings :893-1150]
+// op 0: ring -> nest, 1: nest -> ring, 2: nest >> 2 levels (degrade), 3: nest << 2 levels (upgrade),
+// 4 / 5: the RING forms of 2 / 3 (through NEST at the input resolution and back at the output resolution)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_healpix_convert(int op, int64_t n, const int64_t * __restrict__ in,
+                                                             int64_t * __restrict__ out, int64_t nside, int factor,
+                                                             int64_t levels) {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+        const int64_t p = in[i];
+        int64_t r;
+        if (op == 0) {
+            r = ring_to_nest(nside, factor, p);
+        } else if (op == 1) {
+            r = nest_to_ring(nside, factor, p);
+        } else if (op == 2) {
+            r = p >> (2 * levels);
+        } else if (op == 3) {
+            r = p << (2 * levels);
+        } else {
+            const int64_t nest = ring_to_nest(nside, factor, p);
+            if (op == 4) {
+                r = nest_to_ring(nside >> levels, factor - (int)levels, nest >> (2 * levels));
+            } else {
+                r = nest_to_ring(nside << levels, factor + (int)levels, nest << (2 * levels));
+            }
+        }
+        out[i] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // stokes_weights   [ref: ops_stokes_weights.cpp:77-140, :459-505]
 // ------------------------------------------------------------------------------------
 template <bool HWP, int NOUT>   // NOUT = 3: (I, Q, U); 2: (Q, U) only (StokesWeights mode "QU")
@@ -1535,6 +1566,21 @@ int toast_hip_noise_weight_dev(double * d_det_data, int64_t n_samp, const int32_
         hipLaunchKernelGGL(k_noise_weight, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0,
                            as_stream(stream), (const Chunk *)(d + o_ch), (int)chunks.size(),
                            (const int32_t *)(d + o_di), (const double *)(d + o_w), d_det_data, n_samp);
+        check_launch();
+    });
+}
+
+int toast_hip_healpix_convert_dev(int op, int64_t nside, int64_t levels, int64_t n, const int64_t * d_in,
+                                 int64_t * d_out, void * stream) {
+    return guarded([&] {
+        if (n <= 0) return;
+        if (op < 0 || op > 5) fail_arg("healpix_convert: op must be 0..5");
+        const int factor = log2_exact(nside);
+        if (levels < 0 || ((op == 2 || op == 4) && levels > factor) || ((op == 3 || op == 5) && factor + levels > 29)) {
+            fail_arg("healpix_convert: resolution change out of range");
+        }
+        hipLaunchKernelGGL(k_healpix_convert, flat_grid(n), dim3(kThreads), 0, as_stream(stream), op, n, d_in, d_out,
+                           nside, factor, levels);
         check_launch();
     });
 }

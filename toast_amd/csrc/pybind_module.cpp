@@ -441,6 +441,34 @@ PYBIND11_MODULE(_libtoast_hip, m) {
     }, py::arg("nsub"), py::arg("nsubpix"), py::arg("nnz"), py::arg("mat"), py::arg("vec"),
        py::arg("use_accel") = false);
 
+    {
+        struct Conv { const char * name; int op; const char * in; const char * out; };
+        static const Conv two[] = {{"healpix_ring2nest", 0, "ring_pix", "nest_pix"},
+                                   {"healpix_nest2ring", 1, "nest_pix", "ring_pix"}};
+        for (const Conv & cv : two) {
+            m.def(cv.name, [cv](int64_t nside, py::buffer in_pix, py::buffer out_pix) {
+                Shape shape;
+                int64_t * raw_in = extract<int64_t>(in_pix, cv.in, 1, shape, {-1});
+                const int64_t n = shape[0];
+                int64_t * raw_out = extract<int64_t>(out_pix, cv.out, 1, shape, {n});
+                check(toast_hip_healpix_convert(cv.op, nside, 0, n, raw_in, raw_out, 0));
+            });
+        }
+        static const Conv four[] = {{"healpix_degrade_nest", 2, "in_pix", "out_pix"},
+                                    {"healpix_upgrade_nest", 3, "in_pix", "out_pix"},
+                                    {"healpix_degrade_ring", 4, "in_pix", "out_pix"},
+                                    {"healpix_upgrade_ring", 5, "in_pix", "out_pix"}};
+        for (const Conv & cv : four) {
+            m.def(cv.name, [cv](int64_t in_nside, int64_t factor, py::buffer in_pix, py::buffer out_pix) {
+                Shape shape;
+                int64_t * raw_in = extract<int64_t>(in_pix, cv.in, 1, shape, {-1});
+                const int64_t n = shape[0];
+                int64_t * raw_out = extract<int64_t>(out_pix, cv.out, 1, shape, {n});
+                check(toast_hip_healpix_convert(cv.op, in_nside, factor, n, raw_in, raw_out, 0));
+            });
+        }
+    }
+
     for (int nest = 1; nest >= 0; --nest) {
         m.def(nest ? "healpix_vec2nest" : "healpix_vec2ring", [nest](int64_t nside, py::buffer vec, py::buffer pix) {
             Shape shape;
