@@ -308,6 +308,19 @@ int toast_hip_cov_apply_diag(int64_t n_sub, int64_t subsize, int64_t nnz, const 
 int toast_hip_cov_apply_diag_dev(int64_t n_sub, int64_t subsize, int64_t nnz, const double * d_mat,
                                  double * d_vec, void * stream);
 
+/* healpix_ang2vec / vec2ang / ang2nest / ang2ring for n angles (theta, phi) or vectors [n, 3].  sin / cos / acos /
+ * atan2 come from the device math library: vectors and angles agree with the reference to rounding (tolerance class),
+ * pixel numbers except for angles within an ulp of a pixel or region boundary.
+ * [ref: /root/reference/src/toast/_libtoast/ops_pixels_healpix.cpp:278-349, bindings :668-815] */
+int toast_hip_healpix_ang2vec(int64_t n, const double * theta, const double * phi, double * vec, int use_accel);
+int toast_hip_healpix_ang2vec_dev(int64_t n, const double * d_theta, const double * d_phi, double * d_vec, void * stream);
+int toast_hip_healpix_vec2ang(int64_t n, const double * vec, double * theta, double * phi, int use_accel);
+int toast_hip_healpix_vec2ang_dev(int64_t n, const double * d_vec, double * d_theta, double * d_phi, void * stream);
+int toast_hip_healpix_ang2pix(int64_t nside, int nest, int64_t n, const double * theta, const double * phi,
+                              int64_t * pix, int use_accel);
+int toast_hip_healpix_ang2pix_dev(int64_t nside, int nest, int64_t n, const double * d_theta, const double * d_phi,
+                                  int64_t * d_pix, void * stream);
+
 /* healpix_ring2nest (op 0), healpix_nest2ring (1), healpix_degrade_nest (2) / upgrade_nest (3) / degrade_ring (4) /
  * upgrade_ring (5) by `levels` powers of two, for n pixel numbers at resolution nside.
  * [ref: /root/reference/src/toast/_libtoast/ops_pixels_healpix.cpp:383-580, bindings :893-1150] */

@@ -215,6 +215,40 @@ int toast_hip_cov_apply_diag(int64_t n_sub, int64_t subsize, int64_t nnz, const 
     });
 }
 
+int toast_hip_healpix_ang2vec(int64_t n, const double * theta, const double * phi, double * vec, int use_accel) {
+    return guarded([&] {
+        Call c(use_accel);
+        const double * d_t = c.st.in(theta, (size_t)n);
+        const double * d_p = c.st.in(phi, (size_t)n);
+        double * d_v = c.st.out(vec, (size_t)(3 * n));
+        c.check(toast_hip_healpix_ang2vec_dev(n, d_t, d_p, d_v, c.stream));
+        c.st.finish();
+    });
+}
+
+int toast_hip_healpix_vec2ang(int64_t n, const double * vec, double * theta, double * phi, int use_accel) {
+    return guarded([&] {
+        Call c(use_accel);
+        const double * d_v = c.st.in(vec, (size_t)(3 * n));
+        double * d_t = c.st.out(theta, (size_t)n);
+        double * d_p = c.st.out(phi, (size_t)n);
+        c.check(toast_hip_healpix_vec2ang_dev(n, d_v, d_t, d_p, c.stream));
+        c.st.finish();
+    });
+}
+
+int toast_hip_healpix_ang2pix(int64_t nside, int nest, int64_t n, const double * theta, const double * phi,
+                              int64_t * pix, int use_accel) {
+    return guarded([&] {
+        Call c(use_accel);
+        const double * d_t = c.st.in(theta, (size_t)n);
+        const double * d_p = c.st.in(phi, (size_t)n);
+        int64_t * d_x = c.st.out(pix, (size_t)n);
+        c.check(toast_hip_healpix_ang2pix_dev(nside, nest, n, d_t, d_p, d_x, c.stream));
+        c.st.finish();
+    });
+}
+
 int toast_hip_healpix_convert(int op, int64_t nside, int64_t levels, int64_t n, const int64_t * in, int64_t * out,
                               int use_accel) {
     return guarded([&] {

@@ -132,6 +132,58 @@ __global__ __launch_bounds__(kThreads) void k_healpix_vec2pix(int64_t n, const d
 }
 
 // ------------------------------------------------------------------------------------
+// healpix_ang2vec / vec2ang / ang2nest / ang2ring   [ref: ops_pixels_healpix.cpp:278-349, bindings :668-815]
+// These go through sin / cos / acos / atan2 of the device math library; glibc's and the device's versions agree to
+// an ulp, not bit for bit: vectors and angles are tolerance-class outputs, a pixel number can differ only for an angle
+// within an ulp of a pixel or region boundary.  (The pointing kernels do not use them: their only transcendental is the
+// double-double atan2 of hpix_math.hpp.)
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_healpix_ang2vec(int64_t n, const double * __restrict__ theta,
+                                                             const double * __restrict__ phi,
+                                                             double * __restrict__ vec) {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+        const double st = sin(theta[i]);
+        vec[3 * i] = st * cos(phi[i]);
+        vec[3 * i + 1] = st * sin(phi[i]);
+        vec[3 * i + 2] = cos(theta[i]);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_healpix_vec2ang(int64_t n, const double * __restrict__ vec,
+                                                             double * __restrict__ theta, double * __restrict__ phi) {
+    const double eps = 2.220446049250313e-16;
+    const double pi = 3.14159265358979323846;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+        const double x = vec[3 * i], y = vec[3 * i + 1], z = vec[3 * i + 2];
+        const double norm = 1.0 / sqrt(x * x + y * y + z * z);
+        const double th = acos(z * norm);
+        const bool edge = (fabs(th) <= eps) || (fabs(pi - th) <= eps);
+        const double pt = atan2(y, x);
+        double ph = (pt < 0) ? pt + 2 * pi : pt;
+        if (edge) ph = 0.0;
+        theta[i] = th;
+        phi[i] = ph;
+    }
+}
+
+template <bool NEST>
+__global__ __launch_bounds__(kThreads) void k_healpix_ang2pix(int64_t n, const double * __restrict__ theta,
+                                                             const double * __restrict__ phi,
+                                                             int64_t * __restrict__ pix, int64_t nside, int factor) {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+        // hpix_theta2z (:304-317): the square root is evaluated in both regions there, read only in the caps
+        ZPhi a;
+        a.z = cos(theta[i]);
+        const double za = fabs(a.z);
+        const int s = (a.z > 0.0) ? 1 : -1;
+        a.region = (za <= TOAST_TWOTHIRDS) ? s : s + s;
+        a.rtz = sqrt(3.0 * (1.0 - za));
+        a.phi = phi[i];
+        pix[i] = NEST ? zphi_to_nest(nside, factor, a) : zphi_to_ring(nside, factor, a);
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // healpix_ring2nest / nest2ring / degrade_* / upgrade_*   [ref: ops_pixels_healpix.cpp:383-580, bindings :893-1150]
 // op 0: ring -> nest, 1: nest -> ring, 2: nest >> 2 levels (degrade), 3: nest << 2 levels (upgrade),
 // 4 / 5: the RING forms of 2 / 3 (through NEST at the input resolution and back at the output resolution)
@@ -1566,6 +1618,38 @@ int toast_hip_noise_weight_dev(double * d_det_data, int64_t n_samp, const int32_
         hipLaunchKernelGGL(k_noise_weight, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0,
                            as_stream(stream), (const Chunk *)(d + o_ch), (int)chunks.size(),
                            (const int32_t *)(d + o_di), (const double *)(d + o_w), d_det_data, n_samp);
+        check_launch();
+    });
+}
+
+int toast_hip_healpix_ang2vec_dev(int64_t n, const double * d_theta, const double * d_phi, double * d_vec, void * stream) {
+    return guarded([&] {
+        if (n <= 0) return;
+        hipLaunchKernelGGL(k_healpix_ang2vec, flat_grid(n), dim3(kThreads), 0, as_stream(stream), n, d_theta, d_phi, d_vec);
+        check_launch();
+    });
+}
+
+int toast_hip_healpix_vec2ang_dev(int64_t n, const double * d_vec, double * d_theta, double * d_phi, void * stream) {
+    return guarded([&] {
+        if (n <= 0) return;
+        hipLaunchKernelGGL(k_healpix_vec2ang, flat_grid(n), dim3(kThreads), 0, as_stream(stream), n, d_vec, d_theta, d_phi);
+        check_launch();
+    });
+}
+
+int toast_hip_healpix_ang2pix_dev(int64_t nside, int nest, int64_t n, const double * d_theta, const double * d_phi,
+                                 int64_t * d_pix, void * stream) {
+    return guarded([&] {
+        if (n <= 0) return;
+        const int factor = log2_exact(nside);
+        if (nest) {
+            hipLaunchKernelGGL(k_healpix_ang2pix<true>, flat_grid(n), dim3(kThreads), 0, as_stream(stream), n, d_theta,
+                               d_phi, d_pix, nside, factor);
+        } else {
+            hipLaunchKernelGGL(k_healpix_ang2pix<false>, flat_grid(n), dim3(kThreads), 0, as_stream(stream), n, d_theta,
+                               d_phi, d_pix, nside, factor);
+        }
         check_launch();
     });
 }

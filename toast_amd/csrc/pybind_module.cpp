@@ -441,6 +441,34 @@ PYBIND11_MODULE(_libtoast_hip, m) {
     }, py::arg("nsub"), py::arg("nsubpix"), py::arg("nnz"), py::arg("mat"), py::arg("vec"),
        py::arg("use_accel") = false);
 
+    m.def("healpix_ang2vec", [](py::buffer theta, py::buffer phi, py::buffer vec) {
+        Shape shape;
+        double * raw_theta = extract<double>(theta, "theta", 1, shape, {-1});
+        const int64_t n = shape[0];
+        double * raw_phi = extract<double>(phi, "phi", 1, shape, {n});
+        double * raw_vec = extract<double>(vec, "vec", 2, shape, {n, 3});
+        check(toast_hip_healpix_ang2vec(n, raw_theta, raw_phi, raw_vec, 0));
+    });
+    m.def("healpix_vec2ang", [](py::buffer vec, py::buffer theta, py::buffer phi) {
+        Shape shape;
+        double * raw_vec = extract<double>(vec, "vec", 2, shape, {-1, 3});
+        const int64_t n = shape[0];
+        double * raw_theta = extract<double>(theta, "theta", 1, shape, {n});
+        double * raw_phi = extract<double>(phi, "phi", 1, shape, {n});
+        check(toast_hip_healpix_vec2ang(n, raw_vec, raw_theta, raw_phi, 0));
+    });
+    for (int nest = 1; nest >= 0; --nest) {
+        m.def(nest ? "healpix_ang2nest" : "healpix_ang2ring", [nest](int64_t nside, py::buffer theta, py::buffer phi,
+                                                                     py::buffer pix) {
+            Shape shape;
+            double * raw_theta = extract<double>(theta, "theta", 1, shape, {-1});
+            const int64_t n = shape[0];
+            double * raw_phi = extract<double>(phi, "phi", 1, shape, {n});
+            int64_t * raw_pix = extract<int64_t>(pix, "pix", 1, shape, {n});
+            check(toast_hip_healpix_ang2pix(nside, nest, n, raw_theta, raw_phi, raw_pix, 0));
+        });
+    }
+
     {
         struct Conv { const char * name; int op; const char * in; const char * out; };
         static const Conv two[] = {{"healpix_ring2nest", 0, "ring_pix", "nest_pix"},
