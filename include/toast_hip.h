@@ -352,6 +352,23 @@ int toast_hip_cov_accum_diag_invnpp_dev(int64_t n_sub, int64_t subsize, int64_t 
                                        const int64_t * d_submap, const int64_t * d_subpix, const double * d_weights,
                                        double scale, double * d_invnpp, void * stream);
 
+/* cov_accum_zmap: zmap[(submap * subsize + pixel) * nnz + k] += (scale * tod) * w_k for one sample stream.
+ * [ref: /root/reference/src/toast/_libtoast/map_cov.cpp:199-250 -> src/libtoast/src/toast_map_cov.cpp:204-244].
+ * (cov_accum_diag = hits + invnpp + zmap of the same stream: the three calls in a row.) */
+int toast_hip_cov_accum_zmap(int64_t n_sub, int64_t subsize, int64_t nnz, int64_t n_samp, const int64_t * submap,
+                            const int64_t * subpix, const double * weights, double scale, const double * tod,
+                            double * zmap, int use_accel);
+int toast_hip_cov_accum_zmap_dev(int64_t n_sub, int64_t subsize, int64_t nnz, int64_t n_samp, const int64_t * d_submap,
+                                const int64_t * d_subpix, const double * d_weights, double scale, const double * d_tod,
+                                double * d_zmap, void * stream);
+/* global_to_local: (local submap, pixel in submap) of n global pixel numbers; negative pixels give (-1, -1).
+ * [ref: /root/reference/src/toast/_libtoast/pixels.cpp:9-66 -> src/libtoast/include/toast/map_pixels.hpp:11-41] */
+int toast_hip_global_to_local(int64_t n, const int64_t * global_pixels, int64_t n_pix_submap, const int64_t * global2local,
+                              int64_t n_submap, int64_t * local_submaps, int64_t * local_pixels, int use_accel);
+int toast_hip_global_to_local_dev(int64_t n, const int64_t * d_global_pixels, int64_t n_pix_submap,
+                                 const int64_t * d_global2local, int64_t * d_local_submaps, int64_t * d_local_pixels,
+                                 void * stream);
+
 /* cov_mult_diag: per pixel, data1 <- packed upper triangle of Sym(data1) Sym(data2), entry (k, m >= k) taken from
  * row m, column k of the product as the reference's column-major dsymm call leaves it.
  * [ref: /root/reference/src/libtoast/src/toast_map_cov.cpp:398-469, called by covariance_multiply,

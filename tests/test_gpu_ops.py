@@ -1078,3 +1078,46 @@ def test_cov_accum_ffi_kernels():
         assert np.max(np.abs(inv.reshape(-1, blk) - wanti)) < 1e-12 * np.max(np.abs(wanti))
     with pytest.raises(RuntimeError):
         m.cov_accum_diag_hits(nsub, nsubpix, 3, submap, subpix[:-1], hits, False)
+
+
+def test_cov_accum_zmap_diag_and_global_to_local():
+    """cov_accum_zmap, the all-in-one cov_accum_diag and global_to_local of the native module (names and argument
+    order of toast._libtoast: map_cov.cpp:10-86, :199-250, pixels.cpp:9-66) against NumPy."""
+    import toast_amd
+
+    m = toast_amd.load_native()
+    rng = np.random.default_rng(31)
+    n_submap, nsubpix, n, nnz = 9, 48, 30000, 3
+    local = np.array([1, 4, 7])
+    g2l = np.full(n_submap, -1, dtype=np.int64)
+    g2l[local] = np.arange(local.size)
+    gl = rng.integers(0, n_submap * nsubpix, n).astype(np.int64)
+    gl[rng.random(n) < 0.03] = -1
+    lsm, lpx = m.global_to_local(gl, nsubpix, g2l)
+    want_sm = np.where(gl < 0, -1, g2l[np.maximum(gl, 0) // nsubpix])
+    want_px = np.where(gl < 0, -1, gl % nsubpix)
+    assert np.array_equal(lsm, want_sm) and np.array_equal(lpx, want_px) and lsm.dtype == np.int64
+    assert m.global_to_local(np.zeros(0, dtype=np.int64), nsubpix, g2l)[0].size == 0
+    nsub = local.size
+    w = rng.standard_normal((n, nnz))
+    tod = rng.standard_normal(n)
+    good = (lsm >= 0) & (lpx >= 0)
+    hpx = (lsm * nsubpix + lpx)[good]
+    zmap = np.zeros(nsub * nsubpix * nnz)
+    m.cov_accum_zmap(nsub, nsubpix, nnz, lsm, lpx, np.ascontiguousarray(w.reshape(-1)), 0.5, tod, zmap)
+    wantz = np.zeros((nsub * nsubpix, nnz))
+    np.add.at(wantz, hpx, (0.5 * tod[good])[:, None] * w[good])
+    assert np.max(np.abs(zmap.reshape(-1, nnz) - wantz)) < 1e-12 * np.max(np.abs(wantz))
+    blk = nnz * (nnz + 1) // 2
+    inv = np.zeros(nsub * nsubpix * blk)
+    hits = np.zeros(nsub * nsubpix, dtype=np.int64)
+    z2 = np.zeros_like(zmap)
+    m.cov_accum_diag(nsub, nsubpix, nnz, lsm, lpx, np.ascontiguousarray(w.reshape(-1)), 0.5, tod, inv, hits, z2)
+    assert np.max(np.abs(z2 - zmap)) < 1e-12 * np.max(np.abs(zmap))
+    iu = np.triu_indices(nnz)
+    wanti = np.zeros((nsub * nsubpix, blk))
+    np.add.at(wanti, hpx, (0.5 * w[good][:, iu[0]]) * w[good][:, iu[1]])
+    assert np.max(np.abs(inv.reshape(-1, blk) - wanti)) < 1e-12 * np.max(np.abs(wanti))
+    wanth = np.zeros_like(hits)
+    np.add.at(wanth, hpx, 1)
+    assert np.array_equal(hits, wanth)

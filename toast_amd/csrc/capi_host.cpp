@@ -298,6 +298,34 @@ int toast_hip_cov_accum_diag_invnpp(int64_t n_sub, int64_t subsize, int64_t nnz,
     });
 }
 
+int toast_hip_cov_accum_zmap(int64_t n_sub, int64_t subsize, int64_t nnz, int64_t n_samp, const int64_t * submap,
+                            const int64_t * subpix, const double * weights, double scale, const double * tod,
+                            double * zmap, int use_accel) {
+    return guarded([&] {
+        Call c(use_accel);
+        const int64_t * d_sm = c.st.in(submap, (size_t)n_samp);
+        const int64_t * d_px = c.st.in(subpix, (size_t)n_samp);
+        const double * d_w = c.st.in(weights, (size_t)(n_samp * nnz));
+        const double * d_t = c.st.in(tod, (size_t)n_samp);
+        double * d_z = c.st.inout(zmap, (size_t)(n_sub * subsize * nnz));
+        c.check(toast_hip_cov_accum_zmap_dev(n_sub, subsize, nnz, n_samp, d_sm, d_px, d_w, scale, d_t, d_z, c.stream));
+        c.st.finish();
+    });
+}
+
+int toast_hip_global_to_local(int64_t n, const int64_t * global_pixels, int64_t n_pix_submap, const int64_t * global2local,
+                              int64_t n_submap, int64_t * local_submaps, int64_t * local_pixels, int use_accel) {
+    return guarded([&] {
+        Call c(use_accel);
+        const int64_t * d_g = c.st.in(global_pixels, (size_t)n);
+        const int64_t * d_t = c.st.in(global2local, (size_t)n_submap);
+        int64_t * d_s = c.st.out(local_submaps, (size_t)n);
+        int64_t * d_p = c.st.out(local_pixels, (size_t)n);
+        c.check(toast_hip_global_to_local_dev(n, d_g, n_pix_submap, d_t, d_s, d_p, c.stream));
+        c.st.finish();
+    });
+}
+
 int toast_hip_cov_mult_diag(int64_t n_sub, int64_t subsize, int64_t nnz, double * data1, const double * data2,
                             int use_accel) {
     return guarded([&] {

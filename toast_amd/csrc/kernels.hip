@@ -878,12 +878,14 @@ __global__ __launch_bounds__(kThreads) void k_noise_weight(
 // (local submap, pixel in submap) index pair per sample (negative = skip); hits[hpx] += 1, invnpp[hpx] += upper
 // triangle of (scale w) w^T.  Same run reduction + one atomic per run as k_build_cov.
 // ------------------------------------------------------------------------------------
+// MODE 0: hits, 1: inverse covariance (invnpp), 2: noise-weighted map (invnpp = zmap, `tod` = the signal)
 template <int NNZ, int MODE>
 __global__ __launch_bounds__(kThreads) void k_cov_accum(int64_t n_samp, const int64_t * __restrict__ submap,
                                                        const int64_t * __restrict__ subpix, int64_t subsize,
                                                        const double * __restrict__ weights, double scale,
-                                                       double * __restrict__ invnpp, long long * __restrict__ hits) {
-    constexpr int NV = (MODE == 0) ? 1 : NNZ * (NNZ + 1) / 2;
+                                                       double * __restrict__ invnpp, long long * __restrict__ hits,
+                                                       const double * __restrict__ tod) {
+    constexpr int NV = (MODE == 0) ? 1 : ((MODE == 2) ? NNZ : NNZ * (NNZ + 1) / 2);
     const int64_t n_round = (n_samp + kThreads - 1) / kThreads;
     for (int64_t r = blockIdx.x; r < n_round; r += gridDim.x) {
         const int64_t i = r * kThreads + threadIdx.x;
@@ -898,6 +900,10 @@ __global__ __launch_bounds__(kThreads) void k_cov_accum(int64_t n_samp, const in
                 key = sm * subsize + px;
                 if (MODE == 0) {
                     v[0] = 1.0;
+                } else if (MODE == 2) {
+                    const double ss = scale * tod[i];
+#pragma unroll
+                    for (int k = 0; k < NNZ; ++k) v[k] = weights[i * NNZ + k] * ss;
                 } else {
                     int off = 0;
 #pragma unroll
@@ -1691,7 +1697,7 @@ int toast_hip_cov_accum_diag_hits_dev(int64_t n_sub, int64_t subsize, int64_t n_
         if (n_sub < 1 || n_samp <= 0) return;
         hipLaunchKernelGGL((k_cov_accum<1, 0>), flat_grid(n_samp), dim3(kThreads), 0, as_stream(stream), n_samp, d_submap,
                            d_subpix, subsize, (const double *)nullptr, 1.0, (double *)nullptr,
-                           reinterpret_cast<long long *>(d_hits));
+                           reinterpret_cast<long long *>(d_hits), (const double *)nullptr);
         check_launch();
     });
 }
@@ -1705,7 +1711,7 @@ int toast_hip_cov_accum_diag_invnpp_dev(int64_t n_sub, int64_t subsize, int64_t 
         hipStream_t st = as_stream(stream);
 #define TH_ACC(N)                                                                                              \
     hipLaunchKernelGGL((k_cov_accum<N, 1>), grid, dim3(kThreads), 0, st, n_samp, d_submap, d_subpix, subsize, \
-                       d_weights, scale, d_invnpp, (long long *)nullptr)
+                       d_weights, scale, d_invnpp, (long long *)nullptr, (const double *)nullptr)
         switch (nnz) {
             case 1: TH_ACC(1); break;
             case 2: TH_ACC(2); break;
@@ -1714,6 +1720,57 @@ int toast_hip_cov_accum_diag_invnpp_dev(int64_t n_sub, int64_t subsize, int64_t 
             default: fail_arg("cov_accum_diag_invnpp: nnz must be 1..4");
         }
 #undef TH_ACC
+        check_launch();
+    });
+}
+
+int toast_hip_cov_accum_zmap_dev(int64_t n_sub, int64_t subsize, int64_t nnz, int64_t n_samp, const int64_t * d_submap,
+                                const int64_t * d_subpix, const double * d_weights, double scale, const double * d_tod,
+                                double * d_zmap, void * stream) {
+    return guarded([&] {
+        if (n_sub < 1 || n_samp <= 0) return;
+        const dim3 grid = flat_grid(n_samp);
+        hipStream_t st = as_stream(stream);
+#define TH_ACC(N)                                                                                              \
+    hipLaunchKernelGGL((k_cov_accum<N, 2>), grid, dim3(kThreads), 0, st, n_samp, d_submap, d_subpix, subsize, \
+                       d_weights, scale, d_zmap, (long long *)nullptr, d_tod)
+        switch (nnz) {
+            case 1: TH_ACC(1); break;
+            case 2: TH_ACC(2); break;
+            case 3: TH_ACC(3); break;
+            case 4: TH_ACC(4); break;
+            default: fail_arg("cov_accum_zmap: nnz must be 1..4");
+        }
+#undef TH_ACC
+        check_launch();
+    });
+}
+
+// global pixel -> (local submap, pixel in submap)   [ref: src/libtoast/include/toast/map_pixels.hpp:11-41]
+__global__ __launch_bounds__(kThreads) void k_global_to_local(int64_t n, const int64_t * __restrict__ gl,
+                                                             FastDiv nps_div, const int64_t * __restrict__ g2l,
+                                                             int64_t * __restrict__ lsm, int64_t * __restrict__ lpx) {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+        const int64_t p = gl[i];
+        int64_t sm = -1, px = -1;
+        if (p >= 0) {
+            const int64_t gsm = fastdiv(p, nps_div);
+            px = p - gsm * nps_div.d;
+            sm = g2l[gsm];
+        }
+        lsm[i] = sm;
+        lpx[i] = px;
+    }
+}
+
+int toast_hip_global_to_local_dev(int64_t n, const int64_t * d_global_pixels, int64_t n_pix_submap,
+                                 const int64_t * d_global2local, int64_t * d_local_submaps, int64_t * d_local_pixels,
+                                 void * stream) {
+    return guarded([&] {
+        if (n <= 0) return;
+        if (n_pix_submap <= 0) fail_arg("n_pix_submap must be positive");
+        hipLaunchKernelGGL(k_global_to_local, flat_grid(n), dim3(kThreads), 0, as_stream(stream), n, d_global_pixels,
+                           make_fastdiv(n_pix_submap), d_global2local, d_local_submaps, d_local_pixels);
         check_launch();
     });
 }

@@ -543,6 +543,71 @@ PYBIND11_MODULE(_libtoast_hip, m) {
     }, py::arg("nsub"), py::arg("nsubpix"), py::arg("nnz"), py::arg("submap"), py::arg("subpix"), py::arg("weights"),
        py::arg("scale"), py::arg("invnpp"), py::arg("use_accel") = false);
 
+    // cov_accum_zmap and the all-in-one cov_accum_diag (map_cov.cpp:10-86, :199-250)
+    auto accum_zmap = [](int64_t nsub, int64_t nsubpix, int64_t nnz, py::buffer submap, py::buffer subpix,
+                         py::buffer weights, double scale, py::buffer tod, py::buffer zmap) {
+        auto ism = submap.request();
+        auto ipx = subpix.request();
+        auto iw = weights.request();
+        auto it = tod.request();
+        auto iz = zmap.request();
+        if (norm_format(ism.format) != "q" || norm_format(ipx.format) != "q") {
+            throw std::runtime_error("cov_accum_zmap: index buffers must be int64");
+        }
+        if (norm_format(iw.format) != "d" || norm_format(it.format) != "d" || norm_format(iz.format) != "d") {
+            throw std::runtime_error("cov_accum_zmap: weights / tod / zmap must be float64");
+        }
+        if (ipx.size != ism.size || it.size != ism.size || (size_t)(iw.size / nnz) != (size_t)ism.size) {
+            throw std::runtime_error("Buffer sizes are not consistent.");
+        }
+        check(toast_hip_cov_accum_zmap(nsub, nsubpix, nnz, (int64_t)ism.size, static_cast<int64_t *>(ism.ptr),
+                                       static_cast<int64_t *>(ipx.ptr), static_cast<double *>(iw.ptr), scale,
+                                       static_cast<double *>(it.ptr), static_cast<double *>(iz.ptr), 0));
+    };
+    m.def("cov_accum_zmap", accum_zmap, py::arg("nsub"), py::arg("nsubpix"), py::arg("nnz"), py::arg("submap"),
+          py::arg("subpix"), py::arg("weights"), py::arg("scale"), py::arg("tod"), py::arg("zmap"));
+    m.def("cov_accum_diag", [accum_zmap](int64_t nsub, int64_t nsubpix, int64_t nnz, py::buffer submap, py::buffer subpix,
+                                         py::buffer weights, double scale, py::buffer tod, py::buffer invnpp,
+                                         py::buffer hits, py::buffer zmap) {
+        auto ism = submap.request();
+        auto ipx = subpix.request();
+        auto iw = weights.request();
+        auto ic = invnpp.request();
+        auto ih = hits.request();
+        if (norm_format(ism.format) != "q" || norm_format(ipx.format) != "q" || norm_format(ih.format) != "q") {
+            throw std::runtime_error("cov_accum_diag: index / hit buffers must be int64");
+        }
+        if (norm_format(iw.format) != "d" || norm_format(ic.format) != "d") {
+            throw std::runtime_error("cov_accum_diag: weights / invnpp must be float64");
+        }
+        if (ipx.size != ism.size || (size_t)(iw.size / nnz) != (size_t)ism.size) {
+            throw std::runtime_error("Buffer sizes are not consistent.");
+        }
+        accum_zmap(nsub, nsubpix, nnz, submap, subpix, weights, scale, tod, zmap);
+        check(toast_hip_cov_accum_diag_invnpp(nsub, nsubpix, nnz, (int64_t)ism.size, static_cast<int64_t *>(ism.ptr),
+                                              static_cast<int64_t *>(ipx.ptr), static_cast<double *>(iw.ptr), scale,
+                                              static_cast<double *>(ic.ptr), 0));
+        check(toast_hip_cov_accum_diag_hits(nsub, nsubpix, nnz, (int64_t)ism.size, static_cast<int64_t *>(ism.ptr),
+                                            static_cast<int64_t *>(ipx.ptr), static_cast<int64_t *>(ih.ptr), 0));
+    }, py::arg("nsub"), py::arg("nsubpix"), py::arg("nnz"), py::arg("submap"), py::arg("subpix"), py::arg("weights"),
+       py::arg("scale"), py::arg("tod"), py::arg("invnpp"), py::arg("hits"), py::arg("zmap"));
+
+    m.def("global_to_local", [](py::array_t<int64_t, py::array::c_style | py::array::forcecast> global_pixels,
+                                size_t npix_submap,
+                                py::array_t<int64_t, py::array::c_style | py::array::forcecast> global2local) {
+        auto ig = global_pixels.request();
+        auto it = global2local.request();
+        const int64_t n = (int64_t)ig.size;
+        py::array_t<int64_t> local_submaps(n), local_pixels(n);
+        if (n > 0) {
+            check(toast_hip_global_to_local(n, static_cast<int64_t *>(ig.ptr), (int64_t)npix_submap,
+                                            static_cast<int64_t *>(it.ptr), (int64_t)it.size,
+                                            static_cast<int64_t *>(local_submaps.request().ptr),
+                                            static_cast<int64_t *>(local_pixels.request().ptr), 0));
+        }
+        return py::make_tuple(local_submaps, local_pixels);
+    }, py::arg("global_pixels"), py::arg("npix_submap"), py::arg("global2local"));
+
     m.def("cov_mult_diag", [](int64_t nsub, int64_t nsubpix, int64_t nnz, py::buffer data1, py::buffer data2,
                               bool use_accel) {
         auto i1 = data1.request();
