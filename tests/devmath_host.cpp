@@ -126,8 +126,8 @@ int64_t devmath_sweep(int64_t n, uint64_t seed, int64_t nside, int nest, int64_t
 }
 
 // Detector pairs (vec_to_pixel_pair): direction v0 as in devmath_sweep plus a family sitting on PIXEL EDGES (an
-// equatorial jp / jm boundary or a polar-cap jp boundary reconstructed from integer targets, then nudged by a few
-// ulp), partner v1 = v0 + per-component noise of amplitude 2^-53 .. 2^-47 (the last one beyond the sharing
+// equatorial jp / jm boundary, a polar-cap jp or jm boundary or an in-ring index boundary of the RING scheme,
+// reconstructed from integer targets, then nudged by a few ulp), partner v1 = v0 + per-component noise of amplitude 2^-53 .. 2^-47 (the last one beyond the sharing
 // tolerance).  Both pixels must equal the double-double path evaluated on each direction separately.  Returns the
 // number of mismatches; *n_shared = pairs whose second pixel was taken from the first.
 int64_t devmath_sweep_pair(int64_t n, uint64_t seed, int64_t nside, int nest, int64_t * n_shared, int64_t * n_differ) {
@@ -172,7 +172,28 @@ int64_t devmath_sweep_pair(int64_t n, uint64_t seed, int64_t nside, int nest, in
             phi = tt * 1.5707963267948966;
             if (phi > 3.14159265358979323846) phi -= TOAST_TWOPI;
         }
-        if (kind < 6) {   // nudge by up to +-4 ulp
+        if (kind == 6 || kind == 7) {
+            // polar cap, the OTHER truncations: (1 - tp) t1 = integer J (jm edge), or tt (jp + jm + 1) = integer (the
+            // ring scheme's in-ring index)
+            const double za = TOAST_TWOTHIRDS + unif() * (1.0 - TOAST_TWOTHIRDS) * 0.999;
+            z = (next() & 1) ? za : -za;
+            const double t1 = dn * f_sqrt(3.0 * (1.0 - za));
+            double tp = unif();
+            const double ntt = (double)(next() & 3);
+            if (kind == 6) {
+                const double J = std::floor(unif() * t1);
+                tp = (t1 > 0.0) ? 1.0 - J / t1 : 0.0;
+                if (tp >= 1.0) tp = 0.0;
+            } else {
+                const double ir = std::floor(tp * t1) + std::floor((1.0 - tp) * t1) + 1.0;
+                const double K = std::floor((ntt + tp) * ir);
+                const double tp2 = K / ir - ntt;
+                if (tp2 >= 0.0 && tp2 < 1.0) tp = tp2;
+            }
+            phi = (ntt + tp) * 1.5707963267948966;
+            if (phi > 3.14159265358979323846) phi -= TOAST_TWOPI;
+        }
+        if (kind < 8) {   // nudge by up to +-4 ulp
             const int64_t k = (int64_t)(next() % 9) - 4;
             union { double d; int64_t i; } w;
             const bool on_phi = (kind == 1) || (kind >= 3);

@@ -167,7 +167,7 @@ def test_fast_pixel_path_is_bit_identical(devmath, nside, nest):
                                         (1 << 29, 0)])
 def test_pair_pixel_sharing_is_bit_identical(devmath, nside, nest):
     """vec_to_pixel_pair (hpix_math.hpp): the pixel of the second detector of an orthogonally polarised pair is
-    taken from the first one's checked fast path when the directions agree to 2^-48 -- 2e7 pairs per case, 3/8 of
+    taken from the first one's checked fast path when the directions agree to 2^-48 -- 2e7 pairs per case, half of
     them sitting on |z| = 2/3, the face meridians, the poles or on PIXEL EDGES within +-4 ulp, partners perturbed by
     2^-53 .. 2^-47 per component: both pixels equal the double-double path evaluated on each direction separately
     (some pairs straddle an edge: `differ` > 0), and most pairs share.  The same sweep with 1e9 pairs at nside 1024
@@ -178,7 +178,7 @@ def test_pair_pixel_sharing_is_bit_identical(devmath, nside, nest):
     bad = devmath.devmath_sweep_pair(C.c_int64(n), C.c_uint64(777 + nside), C.c_int64(nside), C.c_int(nest),
                                      C.byref(shared), C.byref(differ))
     assert bad == 0
-    assert shared.value > 0.5 * n        # three of the four perturbation amplitudes are inside the tolerance
+    assert shared.value > 0.35 * n       # three of the four perturbation amplitudes are inside the tolerance
     if nside >= 64:
         assert differ.value > 0          # the adversarial families do produce pairs in different pixels
 
