@@ -75,6 +75,24 @@ def full(request):
                      t["hsub"].data_ptr(), n_submap, nps, nside, True, st)
     torch.cuda.synchronize()
     t["idempotent"] = bool(torch.equal(pix2, t["pixels"]))
+    # the detector-pair kernels (one pixel evaluation per co-pointing pair) against one detector per workgroup, on
+    # EVERY sample of the configuration, for the cached-quaternion kernel and the quaternion-free one
+    capi.set_tuning("pair", 0)
+    try:
+        pix2.fill_(-7)
+        D.pixels_healpix(idx, quats.data_ptr(), t["sflags"].data_ptr(), n_samp, 1, idx, pix2.data_ptr(), n_samp, ivl,
+                         t["hsub"].data_ptr(), n_submap, nps, nside, True, st)
+        torch.cuda.synchronize()
+        t["pair_equals_single"] = bool(torch.equal(pix2, t["pixels"]))
+    finally:
+        capi.set_tuning("pair", 1)
+    pt = capi.otf_pointing(t["bore_d"].data_ptr(), fp, nside, True, 1, d_shared_flags=t["sflags"].data_ptr(),
+                           n_shared_flags=n_samp, shared_flag_mask=1)
+    pix2.fill_(-7)
+    hs2 = torch.zeros_like(t["hsub"])
+    D.otf_pixels_healpix(pt, idx, pix2.data_ptr(), n_samp, ivl, hs2.data_ptr(), n_submap, nps, st)
+    torch.cuda.synchronize()
+    t["from_boresight_equals_cached"] = bool(torch.equal(pix2, t["pixels"])) and bool(torch.equal(hs2, t["hsub"]))
     del quats, pix2
     g2l_h, hit = synth.global_to_local(t["hsub"].cpu().numpy())
     t["g2l_h"], t["hit"] = g2l_h, hit
@@ -94,6 +112,8 @@ def test_pixels_fullsize(full, oracle):
     pix = t["pixels"]
     inside = t["inside"]
     assert t["idempotent"]
+    assert t["pair_equals_single"]              # 7.4e8 (1.5e9) pixels: pair kernel == one-detector kernel
+    assert t["from_boresight_equals_cached"]    # and the quaternion-free pair kernel gives the same pixels
     assert bool((pix[:, ~inside] == -7).all())  # samples outside the intervals untouched
     body = pix[:, inside]
     flagged = (t["sflags"][inside] != 0)
