@@ -75,7 +75,7 @@ def test_data_stage():
     for name in names["detdata"]:
         ob.detdata[name].buffer[:] = 0
         ob.shared[name].data[:] = 0
-    data["test_pix"].raw[:] = 0
+    data["test_pix"].buffer[:] = 0
     for name in names["detdata"]:
         assert ob.detdata[name].accel_in_use() and ob.shared[name].accel_in_use()
     data.accel_update_host(names)

@@ -557,8 +557,7 @@ int toast_hip_fft_impulse_extents(int64_t n_det, int64_t n_samp, double rate, co
             if (rc != TOAST_HIP_OK) throw Error(rc, toast_hip_last_error());
             hipLaunchKernelGGL(k_impulse_extent, dim3((unsigned)nb), dim3(256), 0, st, d_rows, n_samp, d_ext);
             TH_HIP(hipGetLastError());
-            TH_HIP(hipMemcpyAsync(extents + r0, d_ext, sizeof(int32_t) * nb, hipMemcpyDeviceToHost, st));
-            TH_HIP(hipStreamSynchronize(st));
+            copy_to_host(extents + r0, d_ext, sizeof(int32_t) * nb, st);
         }
         if (n_kernel == 1) {
             for (int64_t i = 1; i < n_det; ++i) extents[i] = extents[0];

@@ -856,8 +856,7 @@ static Plan & get_plan(int64_t n_fft, hipStream_t st) {
     for (int64_t e = 0; e < pl.n2_entries; ++e) fill_twiddle(h, (size_t)kTile + 256 + e, (e << 14) % n_fft, n_fft);
     void * d = nullptr;
     TH_HIP(hipMalloc(&d, h.size() * sizeof(double2)));
-    TH_HIP(hipMemcpyAsync(d, h.data(), h.size() * sizeof(double2), hipMemcpyHostToDevice, st));
-    TH_HIP(hipStreamSynchronize(st));
+    copy_to_device(d, h.data(), h.size() * sizeof(double2), st);
     pl.tables = static_cast<double2 *>(d);
     static bool attr_set = false;
     if (!attr_set) {

@@ -2231,8 +2231,7 @@ int toast_hip_vec_dot_dev(int64_t n, const double * d_x, const double * d_y, con
             }
             check_launch();
         }
-        TH_HIP(hipMemcpyAsync(result, d_res, sizeof(double), hipMemcpyDeviceToHost, st));
-        TH_HIP(hipStreamSynchronize(st));
+        copy_to_host(result, d_res, sizeof(double), st);
     });
 }
 

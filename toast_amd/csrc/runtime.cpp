@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include <cstdio>
 #include <cstdlib>
@@ -162,11 +163,128 @@ const char * ParamBlock::commit(hipStream_t stream) {
     // The cached host copy outlives the asynchronous copy.
     g_blocks.push_front(std::move(blk));
     g_block_bytes += host_.size();
-    if (!host_.empty()) {
-        TH_HIP(hipMemcpyAsync(g_blocks.front().dev, g_blocks.front().host.data(), host_.size(),
-                              hipMemcpyHostToDevice, stream));
-    }
+    if (!host_.empty()) copy_to_device(g_blocks.front().dev, g_blocks.front().host.data(), host_.size(), stream);
     return g_blocks.front().dev;
+}
+
+// ------------------------------------------------------------------ bounce ring
+namespace {
+
+struct BounceRing {
+    static constexpr int kSlots = 2;
+    static constexpr size_t kSlotBytes = size_t(4) << 20;
+    char * slot[kSlots] = {nullptr, nullptr};
+    hipEvent_t done[kSlots] = {nullptr, nullptr};
+    bool busy[kSlots] = {false, false};
+    int device = -1;
+    int next = 0;
+    std::mutex mutex;
+
+    void prepare() {
+        int dev = 0;
+        TH_HIP(hipGetDevice(&dev));
+        if (slot[0] != nullptr && dev == device) return;
+        release();
+        for (int k = 0; k < kSlots; ++k) {
+            void * p = nullptr;
+            TH_HIP(hipHostMalloc(&p, kSlotBytes, hipHostMallocDefault));
+            slot[k] = static_cast<char *>(p);
+            TH_HIP(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
+            busy[k] = false;
+        }
+        device = dev;
+        next = 0;
+    }
+    void release() {
+        for (int k = 0; k < kSlots; ++k) {
+            if (done[k] != nullptr) {
+                if (busy[k]) (void)hipEventSynchronize(done[k]);
+                (void)hipEventDestroy(done[k]);
+            }
+            if (slot[k] != nullptr) (void)hipHostFree(slot[k]);
+            slot[k] = nullptr;
+            done[k] = nullptr;
+            busy[k] = false;
+        }
+    }
+    // wait until the device has finished with slot k
+    void wait(int k) {
+        if (busy[k]) {
+            TH_HIP(hipEventSynchronize(done[k]));
+            busy[k] = false;
+        }
+    }
+};
+
+BounceRing g_bounce;
+
+bool bounce_enabled() {
+    static const bool v = [] {
+        const char * e = std::getenv("TOAST_HIP_BOUNCE");
+        return !(e != nullptr && e[0] == '0');
+    }();
+    return v;
+}
+
+}  // namespace
+
+void copy_to_device(void * dev, const void * host, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return;
+    if (!bounce_enabled()) {
+        TH_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, stream));
+        TH_HIP(hipStreamSynchronize(stream));
+        return;
+    }
+    std::lock_guard<std::mutex> lock(g_bounce.mutex);
+    g_bounce.prepare();
+    const char * src = static_cast<const char *>(host);
+    char * dst = static_cast<char *>(dev);
+    for (size_t off = 0; off < bytes; off += BounceRing::kSlotBytes) {
+        const size_t n = (bytes - off < BounceRing::kSlotBytes) ? bytes - off : BounceRing::kSlotBytes;
+        const int k = g_bounce.next;
+        g_bounce.next = (k + 1) % BounceRing::kSlots;
+        g_bounce.wait(k);
+        std::memcpy(g_bounce.slot[k], src + off, n);
+        TH_HIP(hipMemcpyAsync(dst + off, g_bounce.slot[k], n, hipMemcpyHostToDevice, stream));
+        TH_HIP(hipEventRecord(g_bounce.done[k], stream));
+        g_bounce.busy[k] = true;
+    }
+}
+
+void copy_to_host(void * host, const void * dev, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return;
+    if (!bounce_enabled()) {
+        TH_HIP(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, stream));
+        TH_HIP(hipStreamSynchronize(stream));
+        return;
+    }
+    std::lock_guard<std::mutex> lock(g_bounce.mutex);
+    g_bounce.prepare();
+    char * dst = static_cast<char *>(host);
+    const char * src = static_cast<const char *>(dev);
+    const size_t nchunk = (bytes + BounceRing::kSlotBytes - 1) / BounceRing::kSlotBytes;
+    auto chunk_bytes = [&](size_t c) {
+        const size_t off = c * BounceRing::kSlotBytes;
+        return (bytes - off < BounceRing::kSlotBytes) ? bytes - off : BounceRing::kSlotBytes;
+    };
+    // slot of chunk c = (first + c) % kSlots; chunk c + 1 is in flight while chunk c is copied out
+    const int first = g_bounce.next;
+    auto issue = [&](size_t c) {
+        const int k = (first + (int)(c % BounceRing::kSlots)) % BounceRing::kSlots;
+        g_bounce.wait(k);
+        TH_HIP(hipMemcpyAsync(g_bounce.slot[k], src + c * BounceRing::kSlotBytes, chunk_bytes(c), hipMemcpyDeviceToHost,
+                              stream));
+        TH_HIP(hipEventRecord(g_bounce.done[k], stream));
+        g_bounce.busy[k] = true;
+    };
+    issue(0);
+    for (size_t c = 0; c < nchunk; ++c) {
+        const int k = (first + (int)(c % BounceRing::kSlots)) % BounceRing::kSlots;
+        if (c + 1 < nchunk) issue(c + 1);
+        g_bounce.wait(k);
+        std::memcpy(dst + c * BounceRing::kSlotBytes, g_bounce.slot[k], chunk_bytes(c));
+    }
+    g_bounce.next = (first + (int)(nchunk % BounceRing::kSlots)) % BounceRing::kSlots;
 }
 
 // ------------------------------------------------------------------ manager
@@ -452,6 +570,26 @@ static double now_s() {
 
 double Manager::trace_begin() { return trace_enabled() ? now_s() : 0.0; }
 
+static bool call_trace_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char * s = std::getenv("TOAST_HIP_TRACE");
+        v = (s != nullptr && std::atoi(s) >= 2) ? 1 : 0;
+    }
+    return v == 1;
+}
+
+double call_trace_begin() noexcept { return call_trace_enabled() ? now_s() : -1.0; }
+
+void call_trace_end(const char * fn, double t0) noexcept {
+    static double origin = t0;
+    const double tb = now_s();
+    (void)hipDeviceSynchronize();
+    const double t1 = now_s();
+    std::fprintf(stderr, "[toast_hip] call %10.2f ms  +%9.3f ms  %s (host %.3f ms)\n", (t0 - origin) * 1e3,
+                 (t1 - t0) * 1e3, fn, (tb - t0) * 1e3);
+}
+
 void Manager::trace(const char * what, const std::string & name, size_t nbytes, double t0) {
     if (!trace_enabled()) return;
     const double dt = now_s() - t0;
@@ -482,9 +620,13 @@ void Manager::update_device(const void * host, size_t nbytes, const char * name)
     Entry & e = lookup(host, nbytes, name, "update device");
     const double t0 = trace_begin();
     pin_for_transfer(host, e);
-    // Pageable host memory: the call returns once the source has been consumed.
-    TH_HIP(hipMemcpyAsync(e.dev, host, nbytes, hipMemcpyHostToDevice, stream_));
-    TH_HIP(hipStreamSynchronize(stream_));
+    if (e.host_registered) {
+        // page-locked source: direct DMA; the call returns once the source has been consumed
+        TH_HIP(hipMemcpyAsync(e.dev, host, nbytes, hipMemcpyHostToDevice, stream_));
+        TH_HIP(hipStreamSynchronize(stream_));
+    } else {
+        copy_to_device(e.dev, host, nbytes, stream_);
+    }
     trace("update_device", e.name, nbytes, t0);
 }
 
@@ -493,8 +635,12 @@ void Manager::update_host(void * host, size_t nbytes, const char * name) {
     Entry & e = lookup(host, nbytes, name, "update host");
     const double t0 = trace_begin();
     pin_for_transfer(host, e);
-    TH_HIP(hipMemcpyAsync(host, e.dev, nbytes, hipMemcpyDeviceToHost, stream_));
-    TH_HIP(hipStreamSynchronize(stream_));
+    if (e.host_registered) {
+        TH_HIP(hipMemcpyAsync(host, e.dev, nbytes, hipMemcpyDeviceToHost, stream_));
+        TH_HIP(hipStreamSynchronize(stream_));
+    } else {
+        copy_to_host(host, e.dev, nbytes, stream_);
+    }
     trace("update_host", e.name, nbytes, t0);
 }
 
@@ -546,9 +692,7 @@ void * Staging::resolve(void * host, size_t bytes, bool upload, bool download, b
     // stream-ordered pool allocation: no device-wide synchronisation per staged call
     TH_HIP(hipMallocAsync(&dev, bytes ? bytes : 16, stream_));
     temps_.push_back(Temp{host, dev, bytes, download});
-    if (upload && bytes) {
-        TH_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, stream_));
-    }
+    if (upload && bytes) copy_to_device(dev, host, bytes, stream_);
     return dev;
 }
 
@@ -557,9 +701,7 @@ void Staging::finish() {
     finished_ = true;
     if (temps_.empty()) return;
     for (auto & t : temps_) {
-        if (t.download && t.bytes) {
-            TH_HIP(hipMemcpyAsync(t.host, t.dev, t.bytes, hipMemcpyDeviceToHost, stream_));
-        }
+        if (t.download && t.bytes) copy_to_host(t.host, t.dev, t.bytes, stream_);
     }
     for (auto & t : temps_) (void)hipFreeAsync(t.dev, stream_);
     TH_HIP(hipStreamSynchronize(stream_));

@@ -37,11 +37,18 @@ void set_last_error(const std::string & msg);
         }                                                                                     \
     } while (0)
 
+// TOAST_HIP_TRACE=2: every entry point is followed by a device synchronisation and logged with its wall time and its
+// start time (stderr), i.e. a serialised timeline of the calls.  call_trace_begin() returns < 0 when this is off.
+double call_trace_begin() noexcept;
+void call_trace_end(const char * fn, double t0) noexcept;
+
 // Wrap the body of an extern "C" entry point.
 template <typename F>
-int guarded(F && f) noexcept {
+int guarded(F && f, const char * fn = __builtin_FUNCTION()) noexcept {
     try {
+        const double t0 = call_trace_begin();
         f();
+        if (t0 >= 0) call_trace_end(fn, t0);
         return TOAST_HIP_OK;
     } catch (const Error & e) {
         set_last_error(e.what());
@@ -87,6 +94,16 @@ private:
 };
 
 size_t pin_threshold();
+
+// Transfers between pageable application memory and the device, through a page-locked bounce ring owned by the library
+// (two 4 MB slots, copy of slot k overlapped with the host memcpy of slot k+1).  The HIP runtime never sees pageable
+// application memory: handing it such a pointer makes the driver register the range for device access for the duration
+// of the copy, and a later change of that mapping by the allocator (free, heap growth) stalls the NEXT device operation
+// of the process by 20-30 ms (profiles/r02_j).  TOAST_HIP_BOUNCE=0 restores direct hipMemcpyAsync calls.
+//   copy_to_device: returns when the source has been consumed (the device copy is stream-ordered).
+//   copy_to_host:   returns when the destination holds the data.
+void copy_to_device(void * dev, const void * host, size_t bytes, hipStream_t stream);
+void copy_to_host(void * host, const void * dev, size_t bytes, hipStream_t stream);
 int chunk_size();
 bool det_major_grid();
 void set_det_major_grid(int on);

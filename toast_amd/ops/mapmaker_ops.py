@@ -77,7 +77,7 @@ class ScanMap(Operator):
             ob.detdata.ensure(self.det_data, detectors=dets, create_units=self.det_data_units, accel=use_accel)
             if len(dets) == 0:
                 continue
-            kernel(map_dist.global_submap_to_local, map_dist.n_pix_submap, map_data.data,
+            kernel(map_dist.global_submap_to_local, map_dist.n_pix_submap, map_data.arg(use_accel),
                    ob.detdata[self.det_data].arg(use_accel), ob.detdata[self.det_data].indices(dets),
                    ob.detdata[self.pixels].arg(use_accel), ob.detdata[self.pixels].indices(dets),
                    ob.detdata[self.weights].arg(use_accel), ob.detdata[self.weights].indices(dets),
@@ -159,7 +159,7 @@ class ScanMask(Operator):
                     g2l.accel_create("g2l")
                 if not g2l.accel_in_use():
                     g2l.accel_update_device()
-                capi.dev.scan_mask(accel_device_ptr(g2l.data), accel_device_ptr(mask_data.raw),
+                capi.dev.scan_mask(accel_device_ptr(g2l.data), accel_device_ptr(mask_data.buffer),
                                    mask_dist.n_pix_submap, self.mask_bits, self.det_flags_value, pd.indices(dets),
                                    accel_device_ptr(pd.buffer), fd.indices(dets), accel_device_ptr(fd.buffer),
                                    ob.n_local_samples, ob.intervals[self.view].data)
@@ -336,7 +336,7 @@ class BuildNoiseWeighted(_MapBuilder):
         else:
             data[self.zmap] = PixelData(dist, np.float64, n_value=self._weight_nnz(data, detectors))
             zmap = data[self.zmap]
-        _global_to(zmap, self.zmap, use_accel, zero_new=not zmap.accel_exists() and not np.any(zmap.raw))
+        _global_to(zmap, self.zmap, use_accel, zero_new=not zmap.accel_exists() and zmap.host_is_zero())
         for ob in data.obs:
             dets = ob.select_local_detectors(selection=detectors, flagmask=self.det_mask)
             if self.noise_model not in ob:
@@ -347,7 +347,7 @@ class BuildNoiseWeighted(_MapBuilder):
             detweights = np.array([noise.detector_weight(x) for x in dets], dtype=np.float64)
             flag_indx, flag_data, shared = self._flag_args(ob, dets, use_accel)
             native().build_noise_weighted(
-                dist.global_submap_to_local, zmap.data, ob.detdata[self.pixels].indices(dets),
+                dist.global_submap_to_local, zmap.arg(use_accel), ob.detdata[self.pixels].indices(dets),
                 ob.detdata[self.pixels].arg(use_accel), ob.detdata[self.weights].indices(dets), ob.detdata[self.weights].arg(use_accel),
                 ob.detdata[self.det_data].indices(dets), ob.detdata[self.det_data].arg(use_accel), flag_indx, flag_data,
                 detweights, self.det_flag_mask, ob.intervals[self.view].data, shared, self.shared_flag_mask,
@@ -400,7 +400,7 @@ class BuildNoiseWeightedOnTheFly(BuildNoiseWeighted):
         else:
             data[self.zmap] = PixelData(dist, np.float64, n_value=nnz)
             zmap = data[self.zmap]
-        _global_to(zmap, self.zmap, True, zero_new=not zmap.accel_exists() and not np.any(zmap.raw))
+        _global_to(zmap, self.zmap, True, zero_new=not zmap.accel_exists() and zmap.host_is_zero())
         gkey = "_g2l_" + self.pixel_dist
         if gkey not in data:
             data[gkey] = SharedData(dist.global_submap_to_local, "g2l")
@@ -433,7 +433,7 @@ class BuildNoiseWeightedOnTheFly(BuildNoiseWeighted):
             f_ptr, f_n = (accel_device_ptr(flag_data), n_samp) if self.det_flags is not None else (0, 0)
             s_ptr, s_n = (accel_device_ptr(shared), n_samp) if self.shared_flags is not None else (0, 0)
             capi.dev.otf_build_noise_weighted(
-                pt, accel_device_ptr(g2l.data), accel_device_ptr(zmap.raw), dist.n_pix_submap, dd.indices(dets),
+                pt, accel_device_ptr(g2l.data), accel_device_ptr(zmap.buffer), dist.n_pix_submap, dd.indices(dets),
                 accel_device_ptr(dd.buffer), flag_indx, f_ptr, f_n, detweights, self.det_flag_mask, n_samp,
                 ob.intervals[view].data, s_ptr, s_n, self.shared_flag_mask)
 
@@ -466,13 +466,13 @@ class BuildHitMap(_MapBuilder):
         else:
             data[self.hits] = PixelData(dist, np.int64, n_value=1)
             hits = data[self.hits]
-        _global_to(hits, self.hits, use_accel, zero_new=not hits.accel_exists() and not np.any(hits.raw))
+        _global_to(hits, self.hits, use_accel, zero_new=not hits.accel_exists() and hits.host_is_zero())
         for ob in data.obs:
             dets = ob.select_local_detectors(selection=detectors, flagmask=self.det_mask)
             if len(dets) == 0:
                 continue
             flag_indx, flag_data, shared = self._flag_args(ob, dets, use_accel)
-            native().build_hit_map(dist.global_submap_to_local, hits.data, ob.detdata[self.pixels].indices(dets),
+            native().build_hit_map(dist.global_submap_to_local, hits.arg(use_accel), ob.detdata[self.pixels].indices(dets),
                                    ob.detdata[self.pixels].arg(use_accel), flag_indx, flag_data, self.det_flag_mask,
                                    ob.intervals[self.view].data, shared, self.shared_flag_mask, use_accel)
 
@@ -515,7 +515,7 @@ class BuildInverseCovariance(_MapBuilder):
             data[self.inverse_covariance] = PixelData(dist, np.float64, n_value=nnz * (nnz + 1) // 2)
             invcov = data[self.inverse_covariance]
         _global_to(invcov, self.inverse_covariance, use_accel,
-                   zero_new=not invcov.accel_exists() and not np.any(invcov.raw))
+                   zero_new=not invcov.accel_exists() and invcov.host_is_zero())
         for ob in data.obs:
             dets = ob.select_local_detectors(selection=detectors, flagmask=self.det_mask)
             if self.noise_model not in ob:
@@ -526,7 +526,7 @@ class BuildInverseCovariance(_MapBuilder):
             detweights = np.array([noise.detector_weight(x) for x in dets], dtype=np.float64)
             flag_indx, flag_data, shared = self._flag_args(ob, dets, use_accel)
             native().build_inverse_covariance(
-                dist.global_submap_to_local, invcov.data, ob.detdata[self.pixels].indices(dets),
+                dist.global_submap_to_local, invcov.arg(use_accel), ob.detdata[self.pixels].indices(dets),
                 ob.detdata[self.pixels].arg(use_accel), ob.detdata[self.weights].indices(dets), ob.detdata[self.weights].arg(use_accel),
                 flag_indx, flag_data, detweights, self.det_flag_mask, ob.intervals[self.view].data, shared,
                 self.shared_flag_mask, use_accel)
@@ -602,17 +602,11 @@ class CovarianceAndHits(Operator):
         invcov = data[inv_key]
         data[self.rcond] = PixelData(data[self.pixel_dist], np.float64, n_value=1)
         if invcov.accel_in_use():
-            # accumulated on the device: copy, invert and keep it there (the binning applies it there);
-            # the host sides are brought up to date once, the device copies stay the current ones
+            # accumulated on the device: copy, invert and keep it there (the binning applies it there); the host
+            # sides are refreshed when somebody reads them (PixelData.data)
             cov = invcov.duplicate_on_device()
             data[self.covariance] = cov
             covariance_invert(cov, self.rcond_threshold, rcond=data[self.rcond])
-            for obj in (cov, data[self.rcond]):
-                obj.accel_update_host()
-                obj.accel_used(True)
-            if self.inverse_covariance is not None:
-                invcov.accel_update_host()
-                invcov.accel_used(True)
         else:
             cov = invcov.duplicate()
             data[self.covariance] = cov

@@ -309,8 +309,8 @@ class SolverLHS(Operator):
         if not amps_out.accel_exists():
             amps_out.accel_create(f"{tmpl.name}_out", zero_out=True)
         ctx = dict(on_the_fly=on_the_fly, nnz=nnz, nps=dist.n_pix_submap, n_local=dist.n_local_submap,
-                   zmap=zmap, amps_in=amps_in, amps_out=amps_out, zmap_ptr=accel_device_ptr(zmap.raw),
-                   zmap_bytes=zmap.raw.nbytes, cov_ptr=accel_device_ptr(cov.raw), g2l_ptr=accel_device_ptr(g2l.data),
+                   zmap=zmap, amps_in=amps_in, amps_out=amps_out, zmap_ptr=accel_device_ptr(zmap.buffer),
+                   zmap_bytes=zmap.buffer.nbytes, cov_ptr=accel_device_ptr(cov.buffer), g2l_ptr=accel_device_ptr(g2l.data),
                    in_ptr=accel_device_ptr(amps_in.local), in_flags_ptr=accel_device_ptr(amps_in.local_flags),
                    out_ptr=accel_device_ptr(amps_out.local), out_bytes=amps_out.local.nbytes,
                    det_flag_mask=binning.det_flag_mask, shared_flag_mask=binning.shared_flag_mask,

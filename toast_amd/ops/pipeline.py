@@ -165,6 +165,15 @@ class Pipeline(Operator):
                 # the reference: outputs copied back, device copies freed.
                 provides["detdata"] = set()
                 self._staged_data["detdata"] = set()
+                # maps too (PixelData.data / .raw copy back on access): the next operator of the map-making chain
+                # (covariance inversion, covariance_apply, the solver) finds them where the kernels left them
+                from ..pixels import PixelData
+
+                lazy = {k for k in self._staged_data.get("global", ()) if isinstance(data._internal.get(k), PixelData)}
+                if "global" in provides:
+                    provides["global"] = set(provides["global"]) - lazy
+                if "global" in self._staged_data:
+                    self._staged_data["global"] = set(self._staged_data["global"]) - lazy
             if getattr(self, "_protect", None) is not None and hasattr(data, "_protected"):
                 data._protected[:] = [s for s in data._protected if s is not self._protect]
                 self._protect = None

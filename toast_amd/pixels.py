@@ -170,12 +170,47 @@ class PixelData(AcceleratorObject):
         self._dtype = np.dtype(dtype)
         self.units = units
         self._shape = (dist.n_local_submap, dist.n_pix_submap, self._n_value)
-        self.raw = np.zeros(int(np.prod(self._shape)), dtype=self._dtype)
-        self.data = self.raw.reshape(self._shape)
+        self._raw = np.zeros(int(np.prod(self._shape)), dtype=self._dtype)
+        self._data = self._raw.reshape(self._shape)
+        self._pristine = True   # host side still all zero and never handed out
 
     distribution = property(lambda self: self._dist)
     n_value = property(lambda self: self._n_value)
     dtype = property(lambda self: self._dtype)
+
+    # Lazy host coherence (like DetectorData.data): Pipelines leave maps resident and device-current (288 GB of HBM);
+    # the first HOST access copies the map back and makes the host the current side again.
+    def _host(self):
+        if self._raw is not None and self._accel_used:
+            self.accel_update_host()
+        self._pristine = False
+
+    @property
+    def raw(self):
+        """Flat host buffer (pixels.py:560-563)."""
+        self._host()
+        return self._raw
+
+    @property
+    def data(self):
+        """Host view [n_local_submap, n_pix_submap, n_value] (pixels.py:556-558)."""
+        self._host()
+        return self._data
+
+    @property
+    def buffer(self):
+        """The flat buffer WITHOUT synchronisation: its address is the accelerator key and its contents may be stale.
+        For device-side code paths only."""
+        return self._raw
+
+    def arg(self, use_accel):
+        """Array to hand to a kernel call: the key view when the kernel runs on the registered device memory, the
+        synchronised host contents when the call is host-staged."""
+        return self._data if use_accel else self.data
+
+    def host_is_zero(self):
+        """True when the host side holds only zeros (without reading it when it was never handed out)."""
+        return self._pristine or not np.any(self._raw)
 
     # array access to the local submaps (pixels.py:613-627)
     def __getitem__(self, key):
@@ -201,8 +236,8 @@ class PixelData(AcceleratorObject):
         """pixels.py:540-578: release the device copy and the host buffer."""
         if self.accel_exists():
             self.accel_delete()
-        self.data = None
-        self.raw = None
+        self._data = None
+        self._raw = None
 
     def comm_nsubmap(self, bytes):
         """Number of submaps to move per message of about `bytes` bytes (pixels.py:665-683)."""
@@ -288,17 +323,24 @@ class PixelData(AcceleratorObject):
         self.units = units
 
     def reset(self):
-        self.raw[:] = 0
+        if self.accel_in_use():
+            self.accel_reset()   # the device copy is the current one; the host side is refreshed on access
+            return
+        if not self._pristine:
+            self._raw[:] = 0
+            self._pristine = True
         if self.accel_exists():
             self.accel_reset()
 
     def duplicate(self):
-        """Host (and device, if in use) copy."""
-        dup = PixelData(self._dist, self._dtype, n_value=self._n_value, units=self.units)
+        """Copy of the current side: device-to-device when the map is in use there (the host side of the copy is
+        refreshed on access), host-to-host otherwise."""
         if self.accel_in_use():
-            self.accel_update_host()
-            self.accel_used(True)  # device copy is still valid
-        dup.raw[:] = self.raw
+            return self.duplicate_on_device()
+        dup = PixelData(self._dist, self._dtype, n_value=self._n_value, units=self.units)
+        if not self._pristine:
+            dup._raw[:] = self._raw
+            dup._pristine = False
         return dup
 
     def duplicate_on_device(self):
@@ -311,7 +353,7 @@ class PixelData(AcceleratorObject):
             raise RuntimeError("duplicate_on_device: the data is not in use on the device")
         dup = PixelData(self._dist, self._dtype, n_value=self._n_value, units=self.units)
         dup.accel_create(self._accel_name + "_copy")
-        capi.dev.copy(accel_device_ptr(dup.raw), accel_device_ptr(self.raw), self.raw.nbytes)
+        capi.dev.copy(accel_device_ptr(dup._raw), accel_device_ptr(self._raw), self._raw.nbytes)
         dup.accel_used(True)
         return dup
 
@@ -319,14 +361,14 @@ class PixelData(AcceleratorObject):
         """Zero-copy torch view of the device buffer (for RCCL collectives)."""
         import torch
 
-        ptr = accel_device_ptr(self.raw)
+        ptr = accel_device_ptr(self._raw)
 
         class _Iface:
             pass
 
         holder = _Iface()
         typestr = np.dtype(self._dtype).str
-        holder.__cuda_array_interface__ = dict(shape=(self.raw.size,), typestr=typestr, data=(ptr, False), version=3)
+        holder.__cuda_array_interface__ = dict(shape=(self._raw.size,), typestr=typestr, data=(ptr, False), version=3)
         return torch.as_tensor(holder, device=torch.device("cuda", torch.cuda.current_device()))
 
     def sync_allreduce(self, comm=None):
@@ -346,7 +388,8 @@ class PixelData(AcceleratorObject):
             if self.accel_in_use():
                 self.accel_update_host()
                 restore = True
-            comm.allreduce_array_(self.raw)
+            self._pristine = False
+            comm.allreduce_array_(self._raw)
             if restore:
                 self.accel_update_device()
 
@@ -372,7 +415,8 @@ class PixelData(AcceleratorObject):
             if self.accel_in_use():
                 self.accel_update_host()
                 restore = True
-            t = torch.from_numpy(self.raw)
+            self._pristine = False
+            t = torch.from_numpy(self._raw)
             if comm._dist.get_backend() == "nccl":
                 d = t.to(comm._collective_device())
                 comm.reduce_scatter_allgather_(d)
@@ -384,22 +428,23 @@ class PixelData(AcceleratorObject):
 
     # accelerator protocol
     def _accel_exists(self):
-        return self.raw.size > 0 and accel_data_present(self.raw, self._accel_name)
+        return self._raw is not None and self._raw.size > 0 and accel_data_present(self._raw, self._accel_name)
 
     def _accel_create(self, zero_out=False):
-        accel_data_create(self.raw, self._accel_name, zero_out=zero_out, owner=self)
+        accel_data_create(self._raw, self._accel_name, zero_out=zero_out, owner=self)
 
     def _accel_update_device(self):
-        accel_data_update_device(self.raw, self._accel_name)
+        accel_data_update_device(self._raw, self._accel_name)
 
     def _accel_update_host(self):
-        accel_data_update_host(self.raw, self._accel_name)
+        accel_data_update_host(self._raw, self._accel_name)
+        self._pristine = False
 
     def _accel_delete(self):
-        accel_data_delete(self.raw, self._accel_name)
+        accel_data_delete(self._raw, self._accel_name)
 
     def _accel_reset(self):
-        accel_data_reset(self.raw, self._accel_name)
+        accel_data_reset(self._raw, self._accel_name)
 
 
 # ----------------------------------------------------------------------------- covariance
@@ -418,8 +463,8 @@ def covariance_apply(npp, m, use_alltoallv=False):
         npp.accel_update_device()
     if (not on_dev) and npp.accel_in_use():
         npp.accel_update_host()
-    native().cov_apply_diag(npp.distribution.n_local_submap, npp.distribution.n_pix_submap, mapnnz, npp.raw, m.raw,
-                            on_dev)
+    native().cov_apply_diag(npp.distribution.n_local_submap, npp.distribution.n_pix_submap, mapnnz,
+                            npp.buffer if on_dev else npp.raw, m.buffer if on_dev else m.raw, on_dev)
 
 
 def covariance_multiply(npp1, npp2, use_alltoallv=False):
@@ -437,8 +482,8 @@ def covariance_multiply(npp1, npp2, use_alltoallv=False):
         npp2.accel_update_device()
     if (not on_dev) and npp2.accel_in_use():
         npp2.accel_update_host()
-    native().cov_mult_diag(npp1.distribution.n_local_submap, npp1.distribution.n_pix_submap, mapnnz, npp1.raw,
-                           npp2.raw, on_dev)
+    native().cov_mult_diag(npp1.distribution.n_local_submap, npp1.distribution.n_pix_submap, mapnnz,
+                           npp1.buffer if on_dev else npp1.raw, npp2.buffer if on_dev else npp2.raw, on_dev)
     if npp1.units is not None and npp2.units is not None:
         try:
             npp1.update_units(npp1.units * npp2.units)
@@ -461,8 +506,8 @@ def covariance_invert(npp, threshold, rcond=None, use_alltoallv=False):
         cond = PixelData(dist, np.float64, n_value=1) if rcond is None else rcond
         if not cond.accel_exists():
             cond.accel_create("rcond", zero_out=True)
-        capi.dev.cov_eigendecompose_diag(dist.n_local_submap, dist.n_pix_submap, mapnnz, accel_device_ptr(npp.raw),
-                                         accel_device_ptr(cond.raw), float(threshold), True)
+        capi.dev.cov_eigendecompose_diag(dist.n_local_submap, dist.n_pix_submap, mapnnz, accel_device_ptr(npp.buffer),
+                                         accel_device_ptr(cond.buffer), float(threshold), True)
         cond.accel_used(True)
         if rcond is None:
             native().accel_synchronize()

@@ -58,6 +58,7 @@ def main(argv=None):
                     help="full_pointing=False (the reference default): no pointing cache, on-the-fly kernels")
     ap.add_argument("--compact", action="store_true",
                     help="with --uncached: keep a 4 B/det-sample int32 pixel cache, weights on the fly")
+    ap.add_argument("--profile", action="store_true", help="cProfile of the MapMaker call (top functions by own time)")
     args = ap.parse_args(argv)
 
     n_samp = int(args.minutes * 60 * args.rate)
@@ -106,7 +107,16 @@ def main(argv=None):
     mapper = ops.MapMaker(name="mapmaker", keep_solver_products=True, det_data=defaults.det_data, binning=binner, template_matrix=tmatrix,
                           iter_min=args.iter, iter_max=args.iter, convergence=1e-30)
     t0 = time.time()
-    mapper.apply(data)
+    if args.profile:
+        import cProfile
+        import pstats
+
+        prof = cProfile.Profile()
+        prof.runcall(mapper.apply, data)
+        if not quiet:
+            pstats.Stats(prof).sort_stats("tottime").print_stats(45)
+    else:
+        mapper.apply(data)
     native().accel_synchronize()
     total = time.time() - t0
     ph.lap("MapMaker (cov + RHS + PCG + bin)")
