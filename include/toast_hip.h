@@ -628,9 +628,12 @@ int toast_hip_fft_impulse_extents(int64_t n_det, int64_t n_samp, double rate, co
  * [n_flag_rows, n_samp] buffer) grow every run of samples with (flag & mask) != 0 by extents[d] samples on both sides
  * exactly as the reference's extend_flags does (src/toast/utils.py:1055-1113: the mask is ASSIGNED, the last sample is
  * never assigned), and with edges != 0 OR the mask into the first and last extents[d] samples
- * (src/toast/fft.py:935-945).  Host buffer, or its registered device copy with use_accel != 0. */
+ * (src/toast/fft.py:935-945).  or_row (host array [n_samp], may be NULL) is OR-ed into every selected row first: the
+ * shared flags NoiseFilter merges into the detector flags before the convolution (src/toast/ops/noise_filter.py:118-126).
+ * Host buffer, or its registered device copy with use_accel != 0. */
 int toast_hip_fft_extend_flags(uint8_t * flags, int64_t n_flag_rows, const int32_t * flag_index, int64_t n_det,
-                               int64_t n_samp, uint8_t mask, const int32_t * extents, int edges, int use_accel);
+                               int64_t n_samp, uint8_t mask, const int32_t * extents, int edges,
+                               const uint8_t * or_row, int use_accel);
 /* Points per thread (16 or 8; anything else = default) of the row pass, the forward and the inverse
  * column pass of the fused kernels: 16 = 256-thread workgroups with radix-16 stages, 8 = 512-thread
  * workgroups with radix-8 stages and twice the waves per SIMD.  Defaults 8 / 8 / 8; start-up value

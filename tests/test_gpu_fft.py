@@ -346,3 +346,27 @@ def test_extend_flags_on_device(pf):
     got2 = flags.copy()
     pf.extend_flags_buffer(got2, idx, 1, extents, edges=False)
     assert np.array_equal(got2, want2)
+    # a common row OR-ed in first (the shared flags NoiseFilter merges into the detector flags: value 3 has a bit under
+    # the mask and one outside), only into the selected rows; host buffer and registered device copy
+    from toast_amd import accel
+
+    common = ((rng.random(n_samp) < 0.001) * 3).astype(np.uint8)
+    sel = idx[:6]
+    want3 = flags.copy()
+    for row, ext in zip(sel, extents[:6]):
+        ext = int(ext)
+        want3[row] |= common
+        pf.extend_flags(want3[row], 1, ext)
+        want3[row][:ext] |= 1
+        want3[row][-ext:] |= 1
+    got3 = flags.copy()
+    pf.extend_flags_buffer(got3, sel, 1, extents[:6], or_row=common)
+    assert np.array_equal(got3, want3)
+    got4 = flags.copy()
+    accel.accel_data_create(got4, "flags")
+    accel.accel_data_update_device(got4, "flags")
+    pf.extend_flags_buffer(got4, sel, 1, extents[:6], or_row=common, use_accel=True)
+    assert np.array_equal(got4, flags)            # host side untouched
+    accel.accel_data_update_host(got4, "flags")
+    accel.accel_data_delete(got4, "flags")
+    assert np.array_equal(got4, want3)

@@ -335,10 +335,23 @@ def test_noise_filter_operator():
 
     for d in ob.local_detectors:
         kernels.append(fo.noise_filter_kernel(nse.psd(d), estimate_net(nse.freq(d), nse.psd(d))))
-    fo.convolve(want, 20.0, kernel_freq=nse.freq(ob.local_detectors[0]), kernels=np.array(kernels))
+    # detector flags (a bit under the mask, one outside) and shared flags: the operator ORs mask * (shared & mask) into
+    # the detector flags and extends them by the width of the impulse response (noise_filter.py:118-126, fft.py:935-945)
+    dflags = ((rng.random((3, 20000)) < 0.001) * 1 + (rng.random((3, 20000)) < 0.01) * 2).astype(np.uint8)
+    shared = ((rng.random(20000) < 0.0005) * 1).astype(np.uint8)
+    ob.detdata[defaults.det_flags].data[:] = dflags
+    ob.shared[defaults.shared_flags].data[:] = shared
+    want_flags = dflags.copy()
+    shflg = (defaults.det_mask_invalid * (shared & defaults.shared_mask_invalid)).astype(np.uint8)
+    for row in want_flags:
+        row |= shflg
+    fo.convolve(want, 20.0, flags=list(want_flags), flag_mask=defaults.det_mask_invalid,
+                kernel_freq=nse.freq(ob.local_detectors[0]), kernels=np.array(kernels))
     ops.NoiseFilter(noise_model=defaults.noise_model).apply(data)
     got = ob.detdata[defaults.det_data].data
     assert np.max(np.abs(got - want)) < 1e-11 * np.max(np.abs(want))
+    assert np.array_equal(ob.detdata[defaults.det_flags].data, want_flags)
+    assert np.count_nonzero(want_flags != dflags) > 100
     lo_before = np.abs(np.fft.rfft(sig[0]))[1:20].mean()
     lo_after = np.abs(np.fft.rfft(got[0]))[1:20].mean()
     assert lo_after < 0.1 * lo_before

@@ -347,7 +347,8 @@ __global__ __launch_bounds__(256) void k_impulse_extent(const double * __restric
 __global__ __launch_bounds__(256) void k_extend_flags(uint8_t * __restrict__ flags, const int32_t * __restrict__ f_idx,
                                                       int row0, int64_t n_samp, uint8_t mask,
                                                       const int32_t * __restrict__ extent,
-                                                      int32_t * __restrict__ prefix, int edges) {
+                                                      int32_t * __restrict__ prefix, int edges,
+                                                      const uint8_t * __restrict__ or_row) {
     const int r = row0 + blockIdx.x;
     uint8_t * __restrict__ f = flags + (int64_t)f_idx[r] * n_samp;
     int32_t * __restrict__ pre = prefix + (int64_t)blockIdx.x * n_samp;
@@ -365,7 +366,8 @@ __global__ __launch_bounds__(256) void k_extend_flags(uint8_t * __restrict__ fla
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
             const int64_t j = j0 + k;
-            run += (j < n_samp && (f[j] & mask) != 0) ? 1 : 0;
+            const uint8_t extra = (or_row != nullptr && j < n_samp) ? or_row[j] : (uint8_t)0;
+            run += (j < n_samp && ((f[j] | extra) & mask) != 0) ? 1 : 0;
             loc[k] = run;
         }
         s_cnt[tid] = run;
@@ -392,6 +394,7 @@ __global__ __launch_bounds__(256) void k_extend_flags(uint8_t * __restrict__ fla
         const int64_t hi = (j + b < n_samp - 1) ? j + b : n_samp - 1;
         const int32_t cnt = pre[hi] - ((lo > 0) ? pre[lo - 1] : 0);
         uint8_t v = f[j];
+        if (or_row != nullptr) v |= or_row[j];
         if (cnt > 0 && j <= n_samp - 2) v = mask;
         // f[:b] |= mask; f[-b:] |= mask  (Python semantics: b == 0 makes the second slice the whole array)
         if (edges && (b == 0 || j < b || j >= n_samp - b)) v |= mask;
@@ -566,13 +569,16 @@ int toast_hip_fft_impulse_extents(int64_t n_det, int64_t n_samp, double rate, co
 }
 
 int toast_hip_fft_extend_flags(uint8_t * flags, int64_t n_flag_rows, const int32_t * flag_index, int64_t n_det,
-                               int64_t n_samp, uint8_t mask, const int32_t * extents, int edges, int use_accel) {
+                               int64_t n_samp, uint8_t mask, const int32_t * extents, int edges,
+                               const uint8_t * or_row, int use_accel) {
     return guarded([&] {
         if (n_det <= 0 || n_samp <= 0) return;
         Manager::get().require_device();
         hipStream_t st = Manager::get().stream();
         Staging stg(use_accel != 0, st);
         uint8_t * d_flags = stg.inout(flags, (size_t)(n_flag_rows * n_samp));
+        // the common row is a small per-call host array either way
+        const uint8_t * d_or = (or_row != nullptr) ? stg.temp_in(or_row, (size_t)n_samp) : nullptr;
         ParamBlock pb;
         const size_t o_fi = pb.push(flag_index, sizeof(int32_t) * n_det);
         const size_t o_ex = pb.push(extents, sizeof(int32_t) * n_det);
@@ -586,7 +592,7 @@ int toast_hip_fft_extend_flags(uint8_t * flags, int64_t n_flag_rows, const int32
             const int64_t nb = (n_det - r0 < batch) ? (n_det - r0) : batch;
             hipLaunchKernelGGL(k_extend_flags, dim3((unsigned)nb), dim3(256), 0, st, d_flags,
                                (const int32_t *)(d + o_fi), (int)r0, n_samp, mask, (const int32_t *)(d + o_ex), d_pre,
-                               edges ? 1 : 0);
+                               edges ? 1 : 0, d_or);
         }
         TH_HIP(hipGetLastError());
         stg.finish();

@@ -691,8 +691,24 @@ void * Staging::resolve(void * host, size_t bytes, bool upload, bool download, b
     void * dev = nullptr;
     // stream-ordered pool allocation: no device-wide synchronisation per staged call
     TH_HIP(hipMallocAsync(&dev, bytes ? bytes : 16, stream_));
-    temps_.push_back(Temp{host, dev, bytes, download});
-    if (upload && bytes) copy_to_device(dev, host, bytes, stream_);
+    // Large buffers: page-lock the host range for the call (DMA at PCIe speed; the bounce ring is bound by the host
+    // memcpy, ~10 GB/s) and release it in finish(), before the caller can free the memory.
+    bool registered = false;
+    if (bytes >= pin_threshold() && (upload || download)) {
+        if (hipHostRegister(host, bytes, hipHostRegisterDefault) == hipSuccess) {
+            registered = true;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    temps_.push_back(Temp{host, dev, bytes, download, registered});
+    if (upload && bytes) {
+        if (registered) {
+            TH_HIP(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, stream_));
+        } else {
+            copy_to_device(dev, host, bytes, stream_);
+        }
+    }
     return dev;
 }
 
@@ -701,10 +717,19 @@ void Staging::finish() {
     finished_ = true;
     if (temps_.empty()) return;
     for (auto & t : temps_) {
-        if (t.download && t.bytes) copy_to_host(t.host, t.dev, t.bytes, stream_);
+        if (t.download && t.bytes) {
+            if (t.registered) {
+                TH_HIP(hipMemcpyAsync(t.host, t.dev, t.bytes, hipMemcpyDeviceToHost, stream_));
+            } else {
+                copy_to_host(t.host, t.dev, t.bytes, stream_);
+            }
+        }
     }
     for (auto & t : temps_) (void)hipFreeAsync(t.dev, stream_);
     TH_HIP(hipStreamSynchronize(stream_));
+    for (auto & t : temps_) {
+        if (t.registered) (void)hipHostUnregister(t.host);
+    }
     temps_.clear();
 }
 
@@ -713,6 +738,9 @@ Staging::~Staging() {
         // error path: make sure nothing queued still uses the temporaries, then free them
         for (auto & t : temps_) (void)hipFreeAsync(t.dev, stream_);
         (void)hipStreamSynchronize(stream_);
+        for (auto & t : temps_) {
+            if (t.registered) (void)hipHostUnregister(t.host);
+        }
     }
 }
 

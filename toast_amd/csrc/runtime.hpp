@@ -208,6 +208,12 @@ public:
     T * temp_inout(T * host, size_t count) {
         return static_cast<T *>(resolve(host, count * sizeof(T), true, true, true));
     }
+    // a small per-call host array that is never part of the registered data (uploaded to a temporary even with
+    // use_accel)
+    template <typename T>
+    const T * temp_in(const T * host, size_t count) {
+        return static_cast<const T *>(resolve(const_cast<T *>(host), count * sizeof(T), true, false, true));
+    }
     void finish();  // copy outputs back, free temporaries, synchronise when anything was staged
 
 private:
@@ -217,6 +223,7 @@ private:
         void * dev;
         size_t bytes;
         bool download;
+        bool registered;   // host range page-locked for the duration of the call (large buffers)
     };
     bool accel_;
     hipStream_t stream_;

@@ -155,11 +155,11 @@ def extend_flags(flags, mask, buffer):
     flags[np.cumsum(delta[:n]) > 0] = mask
 
 
-def extend_flags_buffer(flags, flag_index, mask, extents, edges=True, use_accel=False):
+def extend_flags_buffer(flags, flag_index, mask, extents, edges=True, use_accel=False, or_row=None):
     """``extend_flags`` (and, with ``edges``, the flagging of the first and last ``extent`` samples that
     toast.fft.convolve does afterwards) for rows ``flag_index`` of the 2-D uint8 buffer ``flags``, each with its
     own extent, on the device (``toast_hip_fft_extend_flags``).  ``use_accel``: the buffer's registered device copy
-    is updated instead of the host array."""
+    is updated instead of the host array.  ``or_row`` (uint8 [n_samp]) is OR-ed into every selected row first."""
     from .accel import ensure_assigned
 
     ensure_assigned()
@@ -168,9 +168,14 @@ def extend_flags_buffer(flags, flag_index, mask, extents, edges=True, use_accel=
     ex = np.ascontiguousarray(extents, dtype=np.int32)
     if ex.shape != fi.shape:
         raise RuntimeError("extents should have one entry per flag row")
+    orr = None
+    if or_row is not None:
+        orr = np.ascontiguousarray(or_row, dtype=np.uint8)
+        if orr.shape != (fl.shape[1],):
+            raise RuntimeError("or_row should have one entry per sample")
     capi._check(capi.lib().toast_hip_fft_extend_flags(
         _p(fl), C.c_int64(fl.shape[0]), _p(fi), C.c_int64(fi.size), C.c_int64(fl.shape[1]), C.c_uint8(int(mask)),
-        _p(ex), C.c_int(bool(edges)), C.c_int(bool(use_accel))))
+        _p(ex), C.c_int(bool(edges)), _p(orr) if orr is not None else None, C.c_int(bool(use_accel))))
 
 
 def impulse_extent(atemp):
@@ -212,6 +217,11 @@ def impulse_extents(n_tod, n_samp, rate, kernel_freq, kernels, deconvolve=False)
     kernels = np.asarray(kernels)
     if kernels.ndim == 2 and kernels.shape[0] != n_tod:
         raise RuntimeError("kernels should have one row per detector")
+    if kernels.ndim == 2 and n_tod > 1:
+        # the width is a function of the kernel alone: detectors sharing a noise model share one measurement
+        uniq, inverse = np.unique(kernels, axis=0, return_inverse=True)
+        if uniq.shape[0] < n_tod:
+            return impulse_extents(uniq.shape[0], n_samp, rate, kernel_freq, uniq, deconvolve)[np.ravel(inverse)]
     mag_c, ang_c = kernel_coefficients(kernel_freq, kernels, deconvolve)
     n_fft = fft_length(n_samp)
     n_reflect = min((n_fft - n_samp) // 2, n_samp)

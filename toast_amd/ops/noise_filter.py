@@ -128,17 +128,14 @@ class NoiseFilter(Operator):
                 on_dev = made_resident = True
             flags = None
             flag_mask = None
+            shflg = None
             if self.det_flags is not None:
-                fdata = obs.detdata[self.det_flags]
-                if fdata.accel_in_use():
-                    fdata.accel_update_host()
-                flags = [fdata[d] for d in dets]
+                flags = obs.detdata[self.det_flags]
                 if self.shared_flags is not None:
-                    # (the flag VALUE times the mask, as the reference writes it: noise_filter.py:121-124)
+                    # (the flag VALUE times the mask, as the reference writes it: noise_filter.py:121-124); OR-ed into
+                    # the detector flags by the same device pass that extends them (nothing reads them in between)
                     shflg = (self.det_flag_mask * np.array(
                         obs.shared[self.shared_flags].data & self.shared_flag_mask, dtype=np.uint8)).astype(np.uint8)
-                    for detflag in flags:
-                        detflag |= shflg
                 flag_mask = self.det_flag_mask
             # N_tt'^-1 kernels (noise_filter.py:130-171), all detectors at once
             nse = obs[self.noise_model]
@@ -169,9 +166,21 @@ class NoiseFilter(Operator):
                 dd.accel_update_host()
                 dd.accel_delete()
             if flags is not None:
-                # extend_flags + first / last samples (fft.py:935-945) for all detectors in one device pass
-                fdata = obs.detdata[self.det_flags]
-                hipfft.extend_flags_buffer(fdata.data, fdata.indices(dets), flag_mask, extend)
+                # shared flags + extend_flags + first / last samples (fft.py:935-945) for all detectors in one device
+                # pass over the resident detector flags (uploaded once; the map-maker reads them there)
+                fdata = flags
+                if accel_enabled():
+                    if not fdata.accel_in_use():
+                        if not fdata.accel_exists():
+                            fdata.accel_create(self.det_flags)
+                        fdata.accel_update_device()
+                    hipfft.extend_flags_buffer(fdata.buffer, fdata.indices(dets), flag_mask, extend, or_row=shflg,
+                                               use_accel=True)
+                    if not getattr(data, "lazy_host", False):
+                        fdata.accel_update_host()
+                        fdata.accel_delete()
+                else:
+                    hipfft.extend_flags_buffer(fdata.data, fdata.indices(dets), flag_mask, extend, or_row=shflg)
 
     def _finalize(self, data, **kwargs):
         return

@@ -525,11 +525,24 @@ class Offset(Template):
                 lens.append(a)
             lens = np.concatenate(lens) if lens else np.zeros(0, dtype=np.int64)
             offs = self.det_amp_offsets(iob, dets)
-            idx = (offs[:, None] + np.arange(lens.size, dtype=np.int64)[None, :]).ravel()
-            amplen[idx] = np.tile(lens, len(dets))
+            w = None
             if self.noise_model is not None:
                 w = np.array([ob[self.noise_model].detector_weight(d) for d in dets], dtype=np.float64)
-                detnoise[idx] = np.repeat(w, lens.size)
+            stride = int(offs[1] - offs[0]) if len(dets) > 1 else lens.size
+            if lens.size > 0 and stride >= lens.size and np.all(np.diff(offs) == stride):
+                # the detectors' amplitude blocks are equally spaced (always, with one observation): broadcast
+                # writes through a [detector, baseline] view instead of 8 B of index per amplitude
+                def rows(arr):
+                    return np.lib.stride_tricks.as_strided(arr[int(offs[0]):], shape=(len(dets), lens.size),
+                                                           strides=(stride * arr.itemsize, arr.itemsize))
+                rows(amplen)[:] = lens[None, :]
+                if w is not None:
+                    rows(detnoise)[:] = w[:, None]
+            else:
+                idx = (offs[:, None] + np.arange(lens.size, dtype=np.int64)[None, :]).ravel()
+                amplen[idx] = np.tile(lens, len(dets))
+                if w is not None:
+                    detnoise[idx] = np.repeat(w, lens.size)
             if self.det_flags is not None:
                 fd = ob.detdata[self.det_flags]
                 if not fd.accel_in_use():
@@ -541,13 +554,19 @@ class Offset(Template):
                                               ob.n_local_samples, ob.intervals[self._bounds_view].data)
         bad.accel_update_host()
         bad.clear()
-        n_good = amplen - np.rint(bad.local).astype(np.int64)
-        dead = detnoise <= 0
+        # counts are whole numbers far below 2^53: float64 arithmetic is exact
+        n_good = amplen.astype(np.float64)
+        n_good -= np.rint(bad.local)
         with np.errstate(divide="ignore", invalid="ignore"):
-            cut = ((n_good / np.maximum(amplen, 1)) <= self.good_fraction) | dead | (amplen == 0)
-            var = 1.0 / (detnoise * n_good)
+            cut = (n_good / np.maximum(amplen, 1)) <= self.good_fraction
+            cut |= detnoise <= 0
+            cut |= amplen == 0
+            var = detnoise
+            var *= n_good
+            np.divide(1.0, var, out=var)
+        var[cut] = 0.0
         self._amp_flags[cut] = 1
-        self._offsetvar[:] = np.where(cut, 0.0, var)
+        self._offsetvar[:] = var
 
     def _init_variances_host(self, new_data):
         offset = 0

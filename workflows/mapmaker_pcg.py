@@ -95,7 +95,7 @@ def main(argv=None):
     ph.lap("simulate (host)")
     if not args.no_filter:
         ops.NoiseFilter(noise_model=defaults.noise_model).apply(data)
-        ph.lap("NoiseFilter (rocFFT)")
+        ph.lap("NoiseFilter")
     det_pointing = ops.PointingDetectorSimple()
     pixels = ops.PixelsHealpix(detector_pointing=det_pointing, nside=args.nside, nest=True)
     weights = ops.StokesWeights(detector_pointing=det_pointing, mode="IQU", hwp_angle=defaults.hwp_angle)
