@@ -387,7 +387,7 @@ void Manager::clear() {
     }
     scratch_.clear();
     for (auto & kv : table_) {
-        if (kv.second.host_registered) (void)hipHostUnregister(const_cast<void *>(kv.first));
+        unpin(kv.first, kv.second);
         if (kv.second.owned) (void)hipFree(kv.second.dev);
     }
     table_.clear();
@@ -555,6 +555,12 @@ void Manager::pin_for_transfer(const void * host, Entry & e) {
     }
 }
 
+void Manager::unpin(const void * host, Entry & e) {
+    if (!e.host_registered) return;
+    (void)hipHostUnregister(const_cast<void *>(host));
+    e.host_registered = false;
+}
+
 static bool trace_enabled() {
     static int v = -1;
     if (v < 0) {
@@ -649,7 +655,7 @@ void Manager::remove(const void * host, size_t nbytes, const char * name) {
     Entry & e = lookup(host, nbytes, name, "delete");
     const double t0 = trace_begin();
     TH_HIP(hipStreamSynchronize(stream_));
-    if (e.host_registered) (void)hipHostUnregister(const_cast<void *>(host));
+    unpin(host, e);
     if (e.owned) {
         if (!keep_cached(e.dev, e.nbytes)) TH_HIP(hipFree(e.dev));
         owned_bytes_ -= (e.nbytes <= owned_bytes_) ? e.nbytes : owned_bytes_;

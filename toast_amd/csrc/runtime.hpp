@@ -166,6 +166,7 @@ private:
         bool pin_failed = false;
     };
     void pin_for_transfer(const void * host, Entry & e);
+    static void unpin(const void * host, Entry & e);
     void * take_cached(size_t nbytes);
     bool keep_cached(void * dev, size_t nbytes);
     void flush_cached();
