@@ -142,3 +142,91 @@ def test_eviction_under_memory_cap(tmp_path):
     assert free[0] == "3" and free[1] == "3" and free[2] == "True"          # nothing evicted without a cap
     assert capped[0] == "3" and int(capped[1]) < 3 and capped[2] == "True"  # something had to go
     assert free[3:] == capped[3:]                                           # and came back intact
+
+
+def test_transfer_sizes_through_the_bounce_ring():
+    """Round trips of pageable buffers at every size class of the transfer paths (runtime.cpp: copy_to_device /
+    copy_to_host through the 2 x 4 MiB page-locked ring, page-locked in place from 16 MiB): below, at and just past
+    the slot size and its multiples, odd byte counts, and the first registered size."""
+    rng = np.random.default_rng(5)
+    slot = 4 << 20
+    sizes = [1, 7, 4096, slot - 1, slot, slot + 1, 2 * slot, 2 * slot + 3, 3 * slot - 5, 3 * slot + 1, (16 << 20) - 1,
+             16 << 20, (16 << 20) + 9]
+    for n in sizes:
+        want = rng.integers(0, 256, size=n, dtype=np.uint8)
+        buf = want.copy()
+        accel.accel_data_create(buf, "t")
+        accel.accel_data_update_device(buf, "t")
+        buf[:] = 0
+        accel.accel_data_update_host(buf, "t")
+        assert np.array_equal(buf, want), n
+        # a second, different upload into the same device buffer (slots are reused in a different phase)
+        want2 = (want ^ 0x5A).astype(np.uint8)
+        buf[:] = want2
+        accel.accel_data_update_device(buf, "t")
+        buf[:] = 1
+        accel.accel_data_update_host(buf, "t")
+        assert np.array_equal(buf, want2), n
+        accel.accel_data_delete(buf, "t")
+
+
+def test_host_staged_call_with_a_large_argument():
+    """A host-level entry point whose array argument is past the pinning threshold (page-locked for the call, released
+    before it returns): cov_apply_diag on 2^21 pixels x 6 covariance values (100 MB) against NumPy."""
+    rng = np.random.default_rng(6)
+    n_sub, n_pix = 512, 4096
+    cov = rng.standard_normal((n_sub * n_pix, 6))
+    m = rng.standard_normal((n_sub * n_pix, 3))
+    want = np.empty_like(m)
+    tri = [(0, 0, 0), (0, 1, 1), (0, 2, 2), (1, 1, 3), (1, 2, 4), (2, 2, 5)]
+    full = np.zeros((n_sub * n_pix, 3, 3))
+    for i, j, k in tri:
+        full[:, i, j] = cov[:, k]
+        full[:, j, i] = cov[:, k]
+    want = np.einsum("pij,pj->pi", full, m)
+    got = m.copy()
+    accel.native().cov_apply_diag(n_sub, n_pix, 3, cov.reshape(-1), got.reshape(-1), False)
+    assert np.max(np.abs(got - want)) < 1e-13 * np.max(np.abs(want))
+    # the arrays can be released and their addresses reused right away
+    del cov, got
+    again = np.ones(n_sub * n_pix * 6)
+    accel.accel_data_create(again, "again")
+    accel.accel_data_update_device(again, "again")
+    accel.accel_data_delete(again, "again")
+
+
+def test_pixel_data_lazy_host_coherence():
+    """PixelData copies back on the first host access only: device-side work goes through .buffer / .arg(True), a
+    device-current map is duplicated and reset on the device, a map that was never handed out is known to be zero."""
+    from toast_amd import capi
+    from toast_amd.accel import accel_device_ptr
+
+    dist = PixelDistribution(n_pix=4000, n_submap=10, local_submaps=[1, 3, 4])
+    pd = PixelData(dist, np.float64, n_value=3)
+    assert pd.host_is_zero()
+    pd.accel_create("lazy", zero_out=True)
+    pd.accel_used(True)
+    n = pd.buffer.size
+    ones = np.ones(n)
+    accel.accel_data_create(ones, "ones")
+    accel.accel_data_update_device(ones, "ones")
+    capi.dev.vec_axpby(n, 2.5, accel_device_ptr(ones), 0.0, accel_device_ptr(pd.buffer))   # pd = 2.5 on the device
+    assert pd.accel_in_use()
+    assert not np.any(pd.buffer)                      # the key view is not synchronised
+    assert pd.arg(True).ctypes.data == pd.buffer.ctypes.data
+    dup = pd.duplicate()                              # device-to-device
+    assert dup.accel_in_use() and pd.accel_in_use() and not np.any(dup.buffer)
+    assert np.all(pd.data == 2.5)                     # first host access copies back ...
+    assert not pd.accel_in_use() and pd.accel_exists()
+    assert np.all(dup.raw == 2.5) and not dup.accel_in_use()
+    assert not pd.host_is_zero()
+    pd.data[:] = 7.0                                  # ... and the host is the current side again
+    pd.accel_update_device()
+    pd.reset()                                        # device-current: cleared there, host refreshed on access
+    assert pd.accel_in_use() and np.all(pd.buffer == 7.0)
+    assert not np.any(pd.data)
+    host_dup = pd.duplicate()                         # host-current now: a host copy
+    assert not host_dup.accel_exists() and not np.any(host_dup.data)
+    accel.accel_data_delete(ones, "ones")
+    for obj in (pd, dup):
+        obj.accel_delete()
