@@ -41,6 +41,24 @@ class ApplyAmplitudes(Operator):
         tm = self.template_matrix.duplicate()
         tm.amplitudes = self.amplitudes
         tm.transpose = False
+        result = self.det_data if self.output is None else self.output
+        n_enabled = len([t for t in tm.templates if t.enabled])
+        if self.op in ("subtract", "add") and n_enabled == 1 and self.amplitudes in data:
+            # One template: det -/+ M a = det + M (-/+ a) exactly (the projection is linear and a sign change is exact),
+            # so the template is added straight into the result with signed amplitudes -- no second buffer the size of
+            # the timestreams (5.9 GB at cfg-3: an allocation the driver may have to clear first, 120 ms) and no
+            # separate combine pass.  Several templates keep the reference's order of operations below.
+            signed = f"{self.name}_signed_amplitudes"
+            data[signed] = data[self.amplitudes].duplicate()
+            try:
+                if self.op == "subtract":
+                    data[signed] *= -1.0
+                tm.amplitudes, tm.det_data, tm.accumulate = signed, result, True
+                Pipeline(operators=[tm]).apply(data, detectors=detectors)
+            finally:
+                data[signed].clear()
+                del data[signed]
+            return
         tm.det_data = temp
         combine = Combine(op=self.op, first=self.det_data, second=temp,
                           result=self.det_data if self.output is None else self.output)

@@ -25,6 +25,8 @@ class TemplateMatrix(Operator):
     templates = List([], help="This should be a list of Template-derived objects")
     amplitudes = Unicode(None, allow_none=True, help="Data key for template amplitudes")
     transpose = Bool(False, help="If True, apply the transpose.")
+    accumulate = Bool(False, help="transpose=False: add M a to the existing timestreams instead of zeroing them first "
+                      "(not a reference trait; lets ApplyAmplitudes work without a second timestream buffer)")
     view = Unicode(None, allow_none=True, help="Use this view of the data in all observations")
     det_data = Unicode(None, allow_none=True, help="Observation detdata key for the timestream data")
     det_data_units = Unicode(defaults.det_data_units, allow_none=True, help="Desired units of detector data")
@@ -114,7 +116,7 @@ class TemplateMatrix(Operator):
                 dets = ob.select_local_detectors(selection=detectors, flagmask=self.det_mask)
                 exists = ob.detdata.ensure(self.det_data, detectors=dets, accel=use_accel,
                                            create_units=self.det_data_units)
-                if exists:
+                if exists and not self.accumulate:
                     ob.detdata[self.det_data].reset(dets=dets)
             for tmpl in self.templates:
                 if not tmpl.enabled:
