@@ -132,6 +132,7 @@ def test_eviction_under_memory_cap(tmp_path):
     for limit in (None, "28"):
         env = dict(os.environ)
         env.pop("TOAST_HIP_MEM_LIMIT_MB", None)
+        env["TOAST_HIP_LAZY_HOST"] = "1"   # this is a test of the lazily retained buffers
         if limit:
             env["TOAST_HIP_MEM_LIMIT_MB"] = limit
         res = subprocess.run([sys.executable, str(script), root], capture_output=True, text=True, env=env, timeout=600)

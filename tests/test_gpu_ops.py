@@ -276,6 +276,39 @@ def test_lhs_equals_rhs_of_projected_amplitudes(full_pointing):
     np.testing.assert_allclose(b, a, rtol=1e-9, atol=1e-10 * np.max(np.abs(a)))
 
 
+def test_mapmaker_eager_and_lazy_host_coherence_agree():
+    """Data.lazy_host = False (the reference's copy-back / delete at the end of every Pipeline; also
+    TOAST_HIP_LAZY_HOST=0) must give the products of the default lazy mode: solver flags, covariances, right-hand
+    side, amplitudes, cleaned timestreams and maps agree to rounding."""
+    def run(lazy):
+        data, pix, sw, truth, sky = make_solver_setup(noise_rms=0.0)
+        data.lazy_host = lazy
+        binner = ops.BinMap(pixel_dist="dist", pixel_pointing=pix, stokes_weights=sw, full_pointing=True)
+        tmpl = Offset(step_time=20.0, noise_model=defaults.noise_model, name="baselines", good_fraction=0.2)
+        mapper = ops.MapMaker(name="mm", keep_solver_products=True, det_data=defaults.det_data, binning=binner,
+                              template_matrix=ops.TemplateMatrix(templates=[tmpl]), iter_max=200, convergence=1e-20,
+                              solve_rcond_threshold=1e-3, map_rcond_threshold=1e-3, save_cleaned=True)
+        mapper.apply(data)
+        out = {k: np.array(data[k].raw, dtype=np.float64)
+               for k in ("mm_solve_hits", "mm_solve_cov", "mm_solve_rcond_mask", "mm_solve_bin", "mm_hits", "mm_cov",
+                         "mm_map", "mm_rcond")}
+        out["amps"] = np.array(data["mm_solve_amplitudes"]["baselines"].local)
+        out["rhs"] = np.array(data["mm_solve_rhs"]["baselines"].local)
+        ob = data.obs[0]
+        for k in ("mm_solve_flags", "mm_cleaned", defaults.det_data):
+            out["dd_" + k] = np.array(ob.detdata[k].data, dtype=np.float64)
+        return out
+
+    lazy, eager = run(True), run(False)
+    for k, a in lazy.items():
+        b = eager[k]
+        assert a.shape == b.shape, k
+        scale = max(np.max(np.abs(a)), 1e-30)
+        assert np.max(np.abs(a - b)) <= 1e-12 * scale + 1e-15, k
+    assert np.array_equal(lazy["dd_mm_solve_flags"], eager["dd_mm_solve_flags"])
+    assert np.array_equal(lazy["mm_hits"], eager["mm_hits"])
+
+
 def test_mapmaker_recovers_offsets_and_sky():
     """End to end (configs[0] shape: 4 detectors x 10 min @10 Hz, Nside 16): destriping removes
     the injected baselines; the binned map equals the input sky on well-conditioned pixels."""

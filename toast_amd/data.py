@@ -11,6 +11,7 @@ operators touch (SURVEY.md §2.1 marks the full data model out of scope):
   (RCCL on GPUs, gloo on CPU) instead of mpi4py.
 """
 
+import os
 import types
 from collections.abc import MutableMapping
 
@@ -859,7 +860,8 @@ class Data(MutableMapping):
         # Lazy host coherence (MI355X: 288 GB of HBM): Pipelines leave detector data resident
         # and device-current at finalize; ``DetectorData.data`` copies back on first host access.
         # ``_protected``: detdata keys staged by a running Pipeline (never evicted).
-        self.lazy_host = True
+        # (TOAST_HIP_LAZY_HOST=0: the reference's eager copy-back / delete at the end of every Pipeline)
+        self.lazy_host = os.environ.get("TOAST_HIP_LAZY_HOST", "1") != "0"
         self._protected = []   # one set per running Pipeline
         import weakref
 

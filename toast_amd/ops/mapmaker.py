@@ -173,7 +173,9 @@ class SolveAmplitudes(Operator):
         else:
             # -- solver flags (:698-810)
             for ob in data.obs:
-                if accel_enabled():
+                if accel_enabled() and getattr(data, "lazy_host", False):
+                    # built on the device and left there; with eager copies (lazy_host False: Pipelines free the
+                    # device copies of their inputs without copying them back) the flags are built on the host
                     MapMaker._solver_flags_device(ob, nm["flags"], binning, detectors)
                 else:
                     self._solver_flags_host(ob, nm["flags"], binning, detectors)

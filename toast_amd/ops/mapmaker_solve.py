@@ -144,6 +144,8 @@ class TemplateMatrix(Operator):
                 req["detdata"].append(self.det_flags)
         else:
             req["global"].append(self.amplitudes)
+            if self.accumulate:
+                req["detdata"].append(self.det_data)   # added to, not overwritten
         return req
 
     def _provides(self):
