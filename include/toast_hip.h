@@ -813,6 +813,14 @@ int toast_hip_offset_count_flagged_dev(int64_t step_length, const int64_t * amp_
                                        const int64_t * n_amp_views, double * d_counts, const int32_t * flag_index,
                                        const uint8_t * d_det_flags, uint8_t flag_mask, int64_t n_det, int64_t n_samp,
                                        const toast_hip_interval * intervals, int64_t n_view, void * stream);
+/* Offset template set-up, second half (src/toast/templates/offset.py:300-343): flag and variance of every baseline from
+ * the flagged-sample counts of toast_hip_offset_count_flagged_dev.  Detector d owns amplitudes amp_offsets[d] + j,
+ * j < n_len, with amp_len[j] samples each and noise weight det_weight[d] (host arrays).  Cut (flag 1, variance 0) when
+ * n_good / amp_len <= good_fraction, det_weight <= 0 or amp_len == 0; otherwise variance = 1 / (det_weight * n_good).
+ * d_n_bad, d_amp_flags, d_variance: device arrays over all amplitudes. */
+int toast_hip_offset_variance_dev(int64_t n_det, int64_t n_len, const int64_t * amp_offsets, const double * det_weight,
+                                  const int64_t * amp_len, const double * d_n_bad, double good_fraction,
+                                  uint8_t * d_amp_flags, double * d_variance, void * stream);
 
 /* Solver flags [ref: src/toast/ops/mapmaker_templates.py:764-810]: for the samples inside the
  * intervals  out[out_index[d]][s] = ((det_flags[flag_index[d]][s] & det_flag_mask) != 0) |

@@ -846,6 +846,15 @@ class _Dev:
             _i64(step_length), _p(ao), _p(nv), _p(d_counts), _p(fi), _p(d_det_flags), _u8(flag_mask), _i64(ao.size),
             _i64(n_samp), _p(iv), _i64(iv.size), _p(stream)))
 
+    def offset_variance(self, amp_offsets, det_weight, amp_len, d_n_bad, good_fraction, d_amp_flags, d_variance,
+                        stream=0):
+        ao = self._small(amp_offsets, np.int64)
+        dw = self._small(det_weight, np.float64)
+        al = self._small(amp_len, np.int64)
+        _check(lib().toast_hip_offset_variance_dev(
+            _i64(ao.size), _i64(al.size), _p(ao), _p(dw), _p(al), _p(d_n_bad), C.c_double(float(good_fraction)),
+            _p(d_amp_flags), _p(d_variance), _p(stream)))
+
     def offset_convolve(self, n_amp, n_seg, d_seg_start, max_segment_len, d_filt_start, d_filt_len, max_filter_len,
                         d_filters, d_amp_in, d_amp_flags, d_amp_out, accumulate, stream=0):
         _check(lib().toast_hip_template_offset_convolve_dev(

@@ -583,7 +583,7 @@ int toast_hip_fft_extend_flags(uint8_t * flags, int64_t n_flag_rows, const int32
         const size_t o_fi = pb.push(flag_index, sizeof(int32_t) * n_det);
         const size_t o_ex = pb.push(extents, sizeof(int32_t) * n_det);
         const char * d = pb.commit(st);
-        int64_t batch = (int64_t)((size_t(512) << 20) / ((size_t)n_samp * sizeof(int32_t)));
+        int64_t batch = (int64_t)((size_t(4) << 30) / ((size_t)n_samp * sizeof(int32_t)));   // prefix sums: <= 4 GB of scratch
         if (batch < 1) batch = 1;
         if (batch > n_det) batch = n_det;
         int32_t * d_pre = (int32_t *)Manager::get().scratch(Manager::kScratchFftImpulse,

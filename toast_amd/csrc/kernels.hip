@@ -2162,6 +2162,50 @@ int toast_hip_offset_count_flagged_dev(int64_t step_length, const int64_t * amp_
     });
 }
 
+// Offset template set-up (reference src/toast/templates/offset.py:262-343): from the number of flagged samples under every
+// baseline to its flag and its variance.  Detector d of the call owns amplitudes amp_offsets[d] + j, j < n_len, of
+// lengths amp_len[j] samples; its noise weight is det_weight[d].  An amplitude is cut (flag 1, variance 0) when the
+// fraction of good samples is <= good_fraction, the detector has no weight or the baseline is empty; else
+// variance = 1 / (det_weight * n_good).
+__global__ __launch_bounds__(kThreads) void k_offset_variance(int64_t n_det, int64_t n_len,
+                                                               const int64_t * __restrict__ amp_offsets,
+                                                               const double * __restrict__ det_weight,
+                                                               const int64_t * __restrict__ amp_len,
+                                                               const double * __restrict__ n_bad, double good_fraction,
+                                                               uint8_t * __restrict__ flags, double * __restrict__ var) {
+    const int64_t d = blockIdx.y;
+    const int64_t base = amp_offsets[d];
+    const double w = det_weight[d];
+    for (int64_t j = (int64_t)blockIdx.x * kThreads + threadIdx.x; j < n_len; j += (int64_t)gridDim.x * kThreads) {
+        const int64_t a = base + j;
+        const int64_t len = amp_len[j];
+        const double n_good = (double)len - rint(n_bad[a]);
+        const bool cut = (n_good / (double)(len > 1 ? len : 1) <= good_fraction) || (w <= 0.0) || (len == 0);
+        flags[a] = cut ? (uint8_t)1 : (uint8_t)0;
+        var[a] = cut ? 0.0 : 1.0 / (w * n_good);
+    }
+}
+
+int toast_hip_offset_variance_dev(int64_t n_det, int64_t n_len, const int64_t * amp_offsets, const double * det_weight,
+                                  const int64_t * amp_len, const double * d_n_bad, double good_fraction,
+                                  uint8_t * d_amp_flags, double * d_variance, void * stream) {
+    return guarded([&] {
+        if (n_det <= 0 || n_len <= 0) return;
+        ParamBlock pb;
+        const size_t o_ao = pb.push(amp_offsets, sizeof(int64_t) * n_det);
+        const size_t o_dw = pb.push(det_weight, sizeof(double) * n_det);
+        const size_t o_al = pb.push(amp_len, sizeof(int64_t) * n_len);
+        hipStream_t st = as_stream(stream);
+        const char * d = pb.commit(st);
+        int64_t gx = (n_len + kThreads - 1) / kThreads;
+        if (gx > 1024) gx = 1024;
+        hipLaunchKernelGGL(k_offset_variance, dim3((unsigned)gx, (unsigned)n_det), dim3(kThreads), 0, st, n_det, n_len,
+                           (const int64_t *)(d + o_ao), (const double *)(d + o_dw), (const int64_t *)(d + o_al), d_n_bad,
+                           good_fraction, d_amp_flags, d_variance);
+        check_launch();
+    });
+}
+
 int toast_hip_combine_flags_dev(uint8_t * d_out, const int32_t * out_index, const uint8_t * d_det_flags,
                                 int64_t n_flag_samp, const int32_t * flag_index, uint8_t det_flag_mask,
                                 const uint8_t * d_shared_flags, int64_t n_shared_flags, uint8_t shared_flag_mask,

@@ -501,72 +501,57 @@ class Offset(Template):
 
     def _init_variances_device(self, new_data):
         """Per-amplitude counts of flagged samples from one kernel over the resident flags
-        (toast_hip_offset_count_flagged_dev), the rest vectorised over all amplitudes."""
+        (toast_hip_offset_count_flagged_dev), flags and variances of all amplitudes from a second one
+        (toast_hip_offset_variance_dev); only the two finished vectors come back to the host."""
         from .. import capi
+        from ..accel import accel_data_create, accel_data_delete, accel_data_update_device, accel_data_update_host
 
         bad = Amplitudes(None, self._n_local, self._n_local)
         bad.accel_create(f"{self.name}_badcount", zero_out=True)
         bad.accel_used(True)
-        amplen = np.zeros(self._n_local, dtype=np.int64)
-        detnoise = np.ones(self._n_local, dtype=np.float64)
-        for iob, ob in enumerate(new_data.obs):
-            dets = [d for d in self._all_dets if d in self._obs_dets[iob]]
-            if len(dets) == 0:
-                continue
-            step_length = self._step_length(self.step_time, self._obs_rate[iob])
-            # lengths of the baselines of one detector of this observation, view after view
-            lens = []
-            for ivw, vw in enumerate(ob.intervals[self._bounds_view]):
-                n_amp_view = int(self._obs_views[iob][ivw])
-                if n_amp_view == 0:
+        # an amplitude that no (detector, observation) block claims stays cut, like a baseline without samples
+        self._amp_flags[:] = 1
+        flag_name, var_name = f"{self.name}_init_flags", f"{self.name}_init_variance"
+        accel_data_create(self._amp_flags, flag_name)
+        accel_data_update_device(self._amp_flags, flag_name)
+        accel_data_create(self._offsetvar, var_name, zero_out=True)
+        try:
+            for iob, ob in enumerate(new_data.obs):
+                dets = [d for d in self._all_dets if d in self._obs_dets[iob]]
+                if len(dets) == 0:
                     continue
-                a = np.full(n_amp_view, step_length, dtype=np.int64)
-                a[-1] = (vw.last - vw.first) - (n_amp_view - 1) * step_length
-                lens.append(a)
-            lens = np.concatenate(lens) if lens else np.zeros(0, dtype=np.int64)
-            offs = self.det_amp_offsets(iob, dets)
-            w = None
-            if self.noise_model is not None:
-                w = np.array([ob[self.noise_model].detector_weight(d) for d in dets], dtype=np.float64)
-            stride = int(offs[1] - offs[0]) if len(dets) > 1 else lens.size
-            if lens.size > 0 and stride >= lens.size and np.all(np.diff(offs) == stride):
-                # the detectors' amplitude blocks are equally spaced (always, with one observation): broadcast
-                # writes through a [detector, baseline] view instead of 8 B of index per amplitude
-                def rows(arr):
-                    return np.lib.stride_tricks.as_strided(arr[int(offs[0]):], shape=(len(dets), lens.size),
-                                                           strides=(stride * arr.itemsize, arr.itemsize))
-                rows(amplen)[:] = lens[None, :]
-                if w is not None:
-                    rows(detnoise)[:] = w[:, None]
-            else:
-                idx = (offs[:, None] + np.arange(lens.size, dtype=np.int64)[None, :]).ravel()
-                amplen[idx] = np.tile(lens, len(dets))
-                if w is not None:
-                    detnoise[idx] = np.repeat(w, lens.size)
-            if self.det_flags is not None:
-                fd = ob.detdata[self.det_flags]
-                if not fd.accel_in_use():
-                    if not fd.accel_exists():
-                        fd.accel_create(self.det_flags)
-                    fd.accel_update_device()
-                capi.dev.offset_count_flagged(step_length, offs, self._obs_views[iob], accel_device_ptr(bad.local),
-                                              fd.indices(dets), accel_device_ptr(fd.buffer), self.det_flag_mask,
-                                              ob.n_local_samples, ob.intervals[self._bounds_view].data)
-        bad.accel_update_host()
-        bad.clear()
-        # counts are whole numbers far below 2^53: float64 arithmetic is exact
-        n_good = amplen.astype(np.float64)
-        n_good -= np.rint(bad.local)
-        with np.errstate(divide="ignore", invalid="ignore"):
-            cut = (n_good / np.maximum(amplen, 1)) <= self.good_fraction
-            cut |= detnoise <= 0
-            cut |= amplen == 0
-            var = detnoise
-            var *= n_good
-            np.divide(1.0, var, out=var)
-        var[cut] = 0.0
-        self._amp_flags[cut] = 1
-        self._offsetvar[:] = var
+                step_length = self._step_length(self.step_time, self._obs_rate[iob])
+                # lengths of the baselines of one detector of this observation, view after view
+                lens = []
+                for ivw, vw in enumerate(ob.intervals[self._bounds_view]):
+                    n_amp_view = int(self._obs_views[iob][ivw])
+                    if n_amp_view == 0:
+                        continue
+                    a = np.full(n_amp_view, step_length, dtype=np.int64)
+                    a[-1] = (vw.last - vw.first) - (n_amp_view - 1) * step_length
+                    lens.append(a)
+                lens = np.concatenate(lens) if lens else np.zeros(0, dtype=np.int64)
+                offs = self.det_amp_offsets(iob, dets)
+                w = np.ones(len(dets), dtype=np.float64)
+                if self.noise_model is not None:
+                    w = np.array([ob[self.noise_model].detector_weight(d) for d in dets], dtype=np.float64)
+                if self.det_flags is not None:
+                    fd = ob.detdata[self.det_flags]
+                    if not fd.accel_in_use():
+                        if not fd.accel_exists():
+                            fd.accel_create(self.det_flags)
+                        fd.accel_update_device()
+                    capi.dev.offset_count_flagged(step_length, offs, self._obs_views[iob], accel_device_ptr(bad.local),
+                                                  fd.indices(dets), accel_device_ptr(fd.buffer), self.det_flag_mask,
+                                                  ob.n_local_samples, ob.intervals[self._bounds_view].data)
+                capi.dev.offset_variance(offs, w, lens, accel_device_ptr(bad.local), self.good_fraction,
+                                         accel_device_ptr(self._amp_flags), accel_device_ptr(self._offsetvar))
+            accel_data_update_host(self._amp_flags, flag_name)
+            accel_data_update_host(self._offsetvar, var_name)
+        finally:
+            accel_data_delete(self._amp_flags, flag_name)
+            accel_data_delete(self._offsetvar, var_name)
+            bad.clear()
 
     def _init_variances_host(self, new_data):
         offset = 0
