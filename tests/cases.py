@@ -29,6 +29,8 @@ def make_case(
     random_pointing=False,
     ground=False,
     fp_roll=0,
+    empty_intervals=False,
+    all_flagged=False,
 ):
     """Inputs of one observation.
 
@@ -86,6 +88,10 @@ def make_case(
     )
     if ground_flags is not None and with_shared_flags:
         case["shared_flags"] = np.ascontiguousarray(ground_flags * np.uint8(3))
+    if empty_intervals:
+        case["intervals"] = np.zeros(0, dtype=interval_dtype)      # a view without any interval: nothing is touched
+    if all_flagged:
+        case["shared_flags"] = np.full(n_samp, 1, dtype=np.uint8)   # every sample cut by the shared flags
     n_pix = 12 * nside * nside
     case["n_submap"] = (n_pix + case["n_pix_submap"] - 1) // case["n_pix_submap"]
     if not with_det_flags and n_det != 1:

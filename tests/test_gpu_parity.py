@@ -34,6 +34,10 @@ CASES = {
     # detector pairs of the call do not share a pixel / odd detector count (pair-merge fallbacks)
     "unpaired_dets": dict(fp_roll=1, n_det=6, n_samp=6000, nside=128),
     "odd_dets": dict(n_det=5, n_samp=3000, nside=64, fp_roll=1),
+    # degenerate inputs: a view without intervals, every sample flagged, one-sample intervals
+    "no_intervals": dict(empty_intervals=True, n_samp=500, nside=32),
+    "all_flagged": dict(all_flagged=True, n_samp=700, nside=32),
+    "one_sample_intervals": dict(n_samp=24, n_split=24, n_det=2, nside=8),
     # ground CES: ~70 sweep intervals, flagged turnarounds, Nside 2048 (configs[4] structure)
     "ground_nside2048": dict(ground=True, n_samp=72000, rate=100.0, nside=2048, n_det=6, with_hwp=True),
 }

@@ -136,6 +136,12 @@ LIVE = {
     "random4096": dict(random_pointing=True, nside=4096, n_samp=20000),
     "ragged": dict(n_samp=1029, n_split=4, gap=1, n_det=3, nside=256),
     "ground2048": dict(ground=True, n_samp=72000, rate=100.0, nside=2048, n_det=6, with_hwp=True),
+    # degenerate inputs: a view without intervals, every sample flagged, one-sample intervals, odd / unpaired detectors
+    "no_intervals": dict(empty_intervals=True, n_samp=500, nside=32),
+    "all_flagged": dict(all_flagged=True, n_samp=700, nside=32),
+    "one_sample_intervals": dict(n_samp=24, n_split=24, n_det=2, nside=8),
+    "odd_dets": dict(n_det=5, n_samp=3000, nside=64, fp_roll=1),
+    "tiny": dict(n_samp=3, n_det=2, nside=1, with_det_flags=False, with_shared_flags=False),
 }
 
 
