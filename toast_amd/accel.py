@@ -65,7 +65,10 @@ def accel_data_present(data, name="None"):
     if data is None:
         return False
     ensure_assigned()
-    return bool(native().accel_present(_key(data), name))
+    arr = _key(data)
+    if arr.size == 0:
+        return False   # empty buffers (an observation without valid detectors) are never registered
+    return bool(native().accel_present(arr, name))
 
 
 _finalizers = {}
@@ -107,6 +110,8 @@ def accel_data_create(data, name="None", zero_out=False, owner=None):
 
     ensure_assigned()
     arr = _key(data)
+    if arr.size == 0:
+        return data
     try:
         native().accel_create(arr, name)
     except RuntimeError as err:
@@ -128,25 +133,30 @@ def accel_data_create(data, name="None", zero_out=False, owner=None):
 
 def accel_data_reset(data, name="None"):
     ensure_assigned()
-    native().accel_reset(_key(data), name)
+    if _key(data).size > 0:
+        native().accel_reset(_key(data), name)
     return data
 
 
 def accel_data_update_device(data, name="None"):
     ensure_assigned()
-    native().accel_update_device(_key(data), name)
+    if _key(data).size > 0:
+        native().accel_update_device(_key(data), name)
     return data
 
 
 def accel_data_update_host(data, name="None"):
     ensure_assigned()
-    native().accel_update_host(_key(data), name)
+    if _key(data).size > 0:
+        native().accel_update_host(_key(data), name)
     return data
 
 
 def accel_data_delete(data, name="None"):
     ensure_assigned()
     arr = _key(data)
+    if arr.size == 0:
+        return data
     fin = _finalizers.pop(arr.ctypes.data, None)
     if fin is not None:
         fin.detach()
@@ -156,6 +166,8 @@ def accel_data_delete(data, name="None"):
 
 def accel_device_ptr(data):
     ensure_assigned()
+    if _key(data).size == 0:
+        return 0
     return int(native().accel_device_ptr(_key(data)))
 
 

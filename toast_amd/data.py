@@ -686,7 +686,7 @@ class DetDataManager(_KeyAccel, MutableMapping):
                 cur.change_detectors(dets)
                 existing = False
         obj = self._store[name]
-        if accel and accel_enabled():
+        if accel and accel_enabled() and obj.buffer.size > 0:   # (no detectors: nothing to hold on the device)
             if not obj.accel_exists():
                 obj.accel_create(name, zero_out=not existing)
                 if existing:

@@ -259,6 +259,8 @@ class SolverLHS(Operator):
     @staticmethod
     def _resident(obj, name):
         """Make the device copy of an AcceleratorObject current and leave it there."""
+        if getattr(obj, "buffer", None) is not None and obj.buffer.size == 0:
+            return obj   # an observation without valid detectors: nothing to hold
         if not obj.accel_exists():
             obj.accel_create(name)
         if not obj.accel_in_use():
