@@ -397,6 +397,45 @@ def test_mapmaker_with_an_empty_view(full_pointing):
     assert np.max(np.abs(both["mm_map"] - alone["mm_map"])) < 1e-9 * np.max(np.abs(alone["mm_map"]))
 
 
+def test_repeated_runs_reuse_existing_products():
+    """Operators applied a second time to the same Data (existing pixel distribution, covariances, maps, resident
+    buffers) reproduce the first run; a binned map that the host scribbled over in between is reset, not accumulated
+    into."""
+    data, pix, sw, truth, sky = make_solver_setup(n_det=4, noise_rms=0.3)
+    binner = ops.BinMap(pixel_dist="dist", pixel_pointing=pix, stokes_weights=sw, full_pointing=True)
+    tmpl = Offset(step_time=20.0, noise_model=defaults.noise_model, name="baselines", good_fraction=0.2)
+    mapper = ops.MapMaker(name="mm", det_data=defaults.det_data, binning=binner, keep_solver_products=True,
+                          template_matrix=ops.TemplateMatrix(templates=[tmpl]), iter_max=100, convergence=1e-18)
+    mapper.apply(data)
+    first = {k: np.array(data[k].data) for k in ("mm_hits", "mm_cov", "mm_map", "mm_rcond")}
+    amps1 = np.array(data["mm_solve_amplitudes"]["baselines"].local)
+    mapper.apply(data)
+    for k, v in first.items():
+        got = np.array(data[k].data)
+        if k == "mm_hits":
+            assert np.array_equal(got, v)
+        else:
+            assert np.max(np.abs(got - v)) <= 1e-10 * np.max(np.abs(v)), k
+    assert np.max(np.abs(np.array(data["mm_solve_amplitudes"]["baselines"].local) - amps1)) < 1e-8 * np.max(np.abs(amps1))
+    # BinMap alone, three ways to find its output: resident and device-current, host-current after a host write,
+    # freshly deleted device copy
+    bm = ops.BinMap(pixel_dist="dist", covariance="mm_cov", binned="again", pixel_pointing=pix, stokes_weights=sw,
+                    det_data=defaults.det_data, full_pointing=True)
+    bm.apply(data)
+    want = np.array(data["again"].data)
+    assert np.max(np.abs(want)) > 0
+    bm.apply(data)
+    assert np.max(np.abs(np.array(data["again"].data) - want)) <= 1e-12 * np.max(np.abs(want))
+    data["again"].data[:] = 1.0e6                      # host becomes the current side, full of garbage
+    bm.apply(data)
+    assert np.max(np.abs(np.array(data["again"].data) - want)) <= 1e-12 * np.max(np.abs(want))
+    data["again"].data[:] = -3.0
+    if data["again"].accel_exists():
+        data["again"].accel_delete()
+    bm.apply(data)
+    assert np.max(np.abs(np.array(data["again"].data) - want)) <= 1e-12 * np.max(np.abs(want))
+
+
 def test_mapmaker_recovers_offsets_and_sky():
     """End to end (configs[0] shape: 4 detectors x 10 min @10 Hz, Nside 16): destriping removes
     the injected baselines; the binned map equals the input sky on well-conditioned pixels."""
