@@ -813,6 +813,10 @@ int toast_hip_offset_count_flagged_dev(int64_t step_length, const int64_t * amp_
                                        const int64_t * n_amp_views, double * d_counts, const int32_t * flag_index,
                                        const uint8_t * d_det_flags, uint8_t flag_mask, int64_t n_det, int64_t n_samp,
                                        const toast_hip_interval * intervals, int64_t n_view, void * stream);
+/* d_mask[i] |= bit where d_value[i] < threshold (device arrays of n entries): the pixels whose inverse condition
+ * number is below the solver's cut, SolveAmplitudes' rcond mask (src/toast/ops/mapmaker_templates.py:902-939). */
+int toast_hip_threshold_mask_dev(int64_t n, const double * d_value, double threshold, uint8_t bit, uint8_t * d_mask,
+                                 void * stream);
 /* Offset template set-up, second half (src/toast/templates/offset.py:300-343): flag and variance of every baseline from
  * the flagged-sample counts of toast_hip_offset_count_flagged_dev.  Detector d owns amplitudes amp_offsets[d] + j,
  * j < n_len, with amp_len[j] samples each and noise weight det_weight[d] (host arrays).  Cut (flag 1, variance 0) when

@@ -846,6 +846,10 @@ class _Dev:
             _i64(step_length), _p(ao), _p(nv), _p(d_counts), _p(fi), _p(d_det_flags), _u8(flag_mask), _i64(ao.size),
             _i64(n_samp), _p(iv), _i64(iv.size), _p(stream)))
 
+    def threshold_mask(self, n, d_value, threshold, bit, d_mask, stream=0):
+        _check(lib().toast_hip_threshold_mask_dev(_i64(n), _p(d_value), C.c_double(float(threshold)), _u8(bit),
+                                                  _p(d_mask), _p(stream)))
+
     def offset_variance(self, amp_offsets, det_weight, amp_len, d_n_bad, good_fraction, d_amp_flags, d_variance,
                         stream=0):
         ao = self._small(amp_offsets, np.int64)

@@ -2162,6 +2162,26 @@ int toast_hip_offset_count_flagged_dev(int64_t step_length, const int64_t * amp_
     });
 }
 
+// mask[i] |= bit where value[i] < threshold: the pixels with a poor condition number that SolveAmplitudes turns into
+// sample flags (src/toast/ops/mapmaker_templates.py:902-939: rcond_mask[rcond < threshold] = 1), without a host pass.
+__global__ __launch_bounds__(kThreads) void k_threshold_mask(int64_t n, const double * __restrict__ value,
+                                                              double threshold, uint8_t bit,
+                                                              uint8_t * __restrict__ mask) {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+        if (value[i] < threshold) mask[i] |= bit;
+    }
+}
+
+int toast_hip_threshold_mask_dev(int64_t n, const double * d_value, double threshold, uint8_t bit, uint8_t * d_mask,
+                                 void * stream) {
+    return guarded([&] {
+        if (n <= 0) return;
+        hipLaunchKernelGGL(k_threshold_mask, flat_grid(n), dim3(kThreads), 0, as_stream(stream), n, d_value, threshold,
+                           bit, d_mask);
+        check_launch();
+    });
+}
+
 // Offset template set-up (reference src/toast/templates/offset.py:262-343): from the number of flagged samples under every
 // baseline to its flag and its variance.  Detector d of the call owns amplitudes amp_offsets[d] + j, j < n_len, of
 // lengths amp_len[j] samples; its noise weight is det_weight[d].  An amplitude is cut (flag 1, variance 0) when the

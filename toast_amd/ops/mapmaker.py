@@ -195,7 +195,18 @@ class SolveAmplitudes(Operator):
             t0 = lap("covariance_and_hits", t0)
             # -- samples in poorly conditioned pixels must not constrain the templates (:902-939)
             data[nm["rcond_mask"]] = PixelData(data[binning.pixel_dist], np.uint8, n_value=1)
-            data[nm["rcond_mask"]].data[data[nm["rcond"]].data < self.solve_rcond_threshold] = 1
+            rc, mask = data[nm["rcond"]], data[nm["rcond_mask"]]
+            if rc.accel_in_use():
+                # the condition numbers were computed on the device: threshold them there
+                from .. import capi
+                from ..accel import accel_device_ptr
+
+                mask.accel_create(nm["rcond_mask"], zero_out=True)
+                mask.accel_used(True)
+                capi.dev.threshold_mask(rc.buffer.size, accel_device_ptr(rc.buffer), self.solve_rcond_threshold, 1,
+                                        accel_device_ptr(mask.buffer))
+            else:
+                mask.data[rc.data < self.solve_rcond_threshold] = 1
             scanner.det_flags_value, scanner.mask_key = 4, nm["rcond_mask"]
             scan_pipe.apply(data, detectors=detectors)
         # -- right-hand side (:941-1000): the binning and the templates see the solver flags only

@@ -413,7 +413,13 @@ class Offset(Template):
             rate = ob.telescope.focalplane.sample_rate
             if self.times in ob.shared and ob.shared[self.times].data.size > 1:
                 t = ob.shared[self.times].data
-                rate = 1.0 / np.median(np.diff(t))  # rate_from_times
+                # rate_from_times; a median over all time stamps (8 ms per 720 000), remembered per time-stamp buffer
+                memo = ob.__dict__.setdefault("_rate_from_times", {})
+                key = (t.ctypes.data, t.size, float(t[0]), float(t[-1]))
+                if key not in memo:
+                    memo.clear()
+                    memo[key] = 1.0 / np.median(np.diff(t))
+                rate = memo[key]
             self._obs_rate[iob] = rate
             step_length = self._step_length(self.step_time, rate)
             views = []
@@ -442,12 +448,13 @@ class Offset(Template):
                 all_dets.setdefault(d, None)
         self._all_dets = list(all_dets.keys())
         self._det_start = {}
+        view_totals = {iob: int(np.sum(v)) for iob, v in self._obs_views.items()}
         offset = 0
         for det in self._all_dets:
             self._det_start[det] = offset
             for iob, ob in enumerate(new_data.obs):
                 if det in self._obs_dets[iob]:
-                    offset += int(np.sum(self._obs_views[iob]))
+                    offset += view_totals[iob]
         self._n_local = offset
         comm = new_data.comm
         self._n_global = self._n_local
