@@ -769,12 +769,17 @@ __global__ __launch_bounds__(kThreads) void k_scan_mask(
         const Chunk c = chunks[ci];
         for (int i = threadIdx.x; i < c.count; i += kThreads) {
             const int64_t s = c.first + i;
+            // straight-line loads (pixel and flag together, then global2local, then the mask byte): as nested tests
+            // every sample waits for four memory round trips in a row
             const int64_t p = prow[s];
-            if (p < 0) continue;
-            const int64_t gsm = fastdiv(p, nps_div);
+            const uint8_t f = frow[s];
+            const bool hit = p >= 0;
+            const int64_t pp = hit ? p : 0;
+            const int64_t gsm = fastdiv(pp, nps_div);
             const int64_t lsm = g2l[gsm];
-            if (lsm < 0) continue;
-            if (mask[lsm * nps + (p - gsm * nps)] & bits) frow[s] |= value;
+            const bool local = hit && lsm >= 0;
+            const uint8_t mk = mask[(local ? lsm : 0) * nps + (pp - gsm * nps)];
+            if (local && (mk & bits)) frow[s] = f | value;
         }
     }
 }
@@ -1053,11 +1058,12 @@ __global__ __launch_bounds__(kThreads) void k_offset_project_signal(
             if (active) {
                 const int64_t s = c.first + i;
                 const int64_t a = abase + fastdiv(s - vfirst, step_div);
-                if (amp_flags[a] == 0) {
-                    key = a;
-                    const bool bad = use_flags && ((frow[s] & fmask) != 0);
-                    v[0] = bad ? 0.0 : drow[s];
-                }
+                // the three loads together (as nested tests: three memory round trips in a row)
+                const uint8_t af = amp_flags[a];
+                const uint8_t fl = use_flags ? frow[s] : (uint8_t)0;
+                const double dv = drow[s];
+                key = (af == 0) ? a : (int64_t)-1;
+                v[0] = (af == 0 && (fl & fmask) == 0) ? dv : 0.0;
             }
             const bool tail = wave_run_reduce<1>(key, v);
             if (tail && key >= 0) unsafeAtomicAdd(amps + key, v[0]);
@@ -1250,6 +1256,11 @@ __global__ __launch_bounds__(kThreads) void k_offset_scan_project(
             int64_t key = -1;
             double v[1] = {0.0};
             if (active) {
+                // Straight-line form: with the flag and pixel tests as branches the compiler sinks the pixel, weight
+                // and map loads into them and every sample waits for five memory round trips in a row (amplitude
+                // flag -> sample flag -> pixel -> weights + global2local -> map); here everything that does not depend
+                // on a loaded value is issued at once (three round trips: streams, global2local, map) and the tests
+                // select values.  Flagged samples and samples without a pixel read map element 0 and discard it.
                 const int64_t s = c.first + i;
                 const int64_t a = abase + fastdiv(s - vfirst, step_div);
                 const uint8_t af = amp_flags[a];
@@ -1260,22 +1271,21 @@ __global__ __launch_bounds__(kThreads) void k_offset_scan_project(
                 double wk[NNZ];
 #pragma unroll
                 for (int k = 0; k < NNZ; ++k) wk[k] = w[k];
-                if (af == 0) {
-                    key = a;
-                    if ((fl & fmask) == 0) {
-                        double d = 0.0 + av;
-                        if (p >= 0) {
-                            const int64_t gsm = fastdiv(p, nps_div);
-                            const double * m = map + NNZ * (g2l[gsm] * nps + (p - gsm * nps));
-                            double sc = 0.0;
+                const bool hit = p >= 0;
+                const int64_t pp = hit ? p : 0;
+                const int64_t gsm = fastdiv(pp, nps_div);
+                int64_t lsm = g2l[gsm];
+                lsm = (lsm < 0) ? 0 : lsm;
+                const double * m = map + NNZ * (lsm * nps + (pp - gsm * nps));
+                double sc = 0.0;
 #pragma unroll
-                            for (int k = 0; k < NNZ; ++k) sc += wk[k] * m[k];
-                            sc *= 1.0;
-                            d -= sc;
-                        }
-                        v[0] = d * dw;
-                    }
-                }
+                for (int k = 0; k < NNZ; ++k) sc += wk[k] * m[k];
+                sc *= 1.0;
+                double d = 0.0 + av;
+                d = hit ? d - sc : d;
+                const bool good = (fl & fmask) == 0;
+                key = (af == 0) ? a : (int64_t)-1;
+                v[0] = (af == 0 && good) ? d * dw : 0.0;
             }
             const bool tail = wave_run_reduce<1>(key, v);
             if (tail && key >= 0) unsafeAtomicAdd(amps_out + key, v[0]);
