@@ -895,6 +895,91 @@ def test_mapmaker_two_observations_fused_equals_operator_sequence():
         assert np.max(np.abs(res[key][1] - res["seq"][1])) < 1e-7 * np.max(np.abs(res["seq"][1]))
 
 
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("TOAST_TEST_FUZZ_SEEDS", "16")))))
+def test_mapmaker_random_configurations(seed):
+    """Randomly drawn inputs -- 1 to 3 observations of different lengths, a view with gaps (or none), random sample
+    flags, a detector cut in one observation, odd baseline lengths, I or IQU, NEST or RING, with or without HWP, compact
+    pixel cache, Offset noise prior -- through the complete MapMaker: the fused
+    device left-hand side (cached and on-the-fly pointing) and the reference's operator sequence agree on hits,
+    amplitudes and maps."""
+    from toast_amd import synth
+    from toast_amd.data import IntervalList
+
+    rng = np.random.default_rng(100 + seed)
+    n_obs = int(rng.integers(1, 4))
+    n_det = int(rng.choice([2, 3, 4, 6]))
+    lengths = [int(rng.integers(2500, 6000)) for _ in range(n_obs)]
+    step_time = float(rng.choice([7.3, 13.0, 20.0, 31.7]))
+    use_view = bool(rng.integers(0, 2))
+    mode = str(rng.choice(["I", "IQU"]))
+    cut = (int(rng.integers(0, n_obs)), int(rng.integers(0, n_det))) if n_det > 2 and rng.integers(0, 2) else None
+    flag_frac = float(rng.choice([0.0, 0.02, 0.2]))
+    splits = [int(rng.integers(1, 5)) for _ in range(n_obs)]
+    gaps = [int(rng.integers(0, 40)) for _ in range(n_obs)]
+    flag_seeds = [int(rng.integers(0, 2**31)) for _ in range(n_obs)]
+    nest, hwp, compact = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    prior = (not use_view) and bool(rng.integers(0, 2))
+
+    def build():
+        data = None
+        for iob, n_samp in enumerate(lengths):
+            d, pix, sw, _, _ = make_solver_setup(noise_rms=0.2, n_det=n_det, n_samp=n_samp, seed=10 * seed + iob)
+            ob = d.obs[0]
+            ob.name = f"obs{iob}"
+            if use_view:
+                ob.intervals["scan"] = IntervalList(data=synth.make_intervals(n_samp, n_split=splits[iob], rate=10.0,
+                                                                               gap=gaps[iob]))
+            if flag_frac > 0:
+                fl = ob.detdata[defaults.det_flags].data
+                fl[:] = (np.random.default_rng(flag_seeds[iob]).random(fl.shape) < flag_frac).astype(np.uint8)
+            if cut is not None and cut[0] == iob:
+                ob.update_local_detector_flags({ob.local_detectors[cut[1]]: 1})
+            if data is None:
+                data, pix0, sw0 = d, pix, sw
+            else:
+                data.obs.append(ob)
+        sw0.mode = mode
+        pix0.nest = nest
+        if not hwp:
+            sw0.hwp_angle = None
+        if use_view:
+            pix0.view = "scan"
+            sw0.view = "scan"
+            pix0.detector_pointing.view = "scan"
+        return data, pix0, sw0
+
+    res = {}
+    for key, kw in (("seq", dict(fused=False, full=True)), ("fused", dict(fused=True, full=True)),
+                    ("otf", dict(fused=True, full=False))):
+        data, pix, sw = build()
+        binner = ops.BinMap(pixel_dist="dist", pixel_pointing=pix, stokes_weights=sw, full_pointing=kw["full"],
+                            compact_cache=compact and not kw["full"])
+        tmpl = Offset(step_time=step_time, noise_model=defaults.noise_model, name="baselines", good_fraction=0.3,
+                      view="scan" if use_view else None, use_noise_prior=prior, precond_width=5)
+        mapper = ops.MapMaker(name="mm", keep_solver_products=True, det_data=defaults.det_data, binning=binner,
+                              template_matrix=ops.TemplateMatrix(templates=[tmpl], view="scan" if use_view else None),
+                              iter_max=8, convergence=1e-30, solve_rcond_threshold=1e-3, map_rcond_threshold=1e-3,
+                              fused_lhs=kw["fused"])
+        mapper.apply(data)
+        dist = data["dist"]
+        full = {}
+        for name in ("mm_hits", "mm_map"):
+            m = np.zeros((dist.n_submap, dist.n_pix_submap, data[name].n_value))
+            m[dist.local_submaps] = data[name].data
+            full[name] = m
+        res[key] = (np.array(data["mm_solve_amplitudes"]["baselines"].local), full, np.array(mapper.history),
+                    np.array(data["mm_solve_amplitudes"]["baselines"].local_flags))
+    ref = res["seq"]
+    assert ref[1]["mm_hits"].sum() > 0 and np.max(np.abs(ref[0])) > 0
+    for key in ("fused", "otf"):
+        got = res[key]
+        assert np.array_equal(got[1]["mm_hits"], ref[1]["mm_hits"]), key
+        assert np.array_equal(got[3], ref[3]), key
+        np.testing.assert_allclose(got[2][:4], ref[2][:4], rtol=1e-6, err_msg=key)
+        assert np.max(np.abs(got[0] - ref[0])) < 1e-7 * np.max(np.abs(ref[0])), key
+        assert np.max(np.abs(got[1]["mm_map"] - ref[1]["mm_map"])) < 1e-7 * np.max(np.abs(ref[1]["mm_map"])), key
+
+
 def test_fused_lhs_plan_replay_and_invalidation():
     """The recorded launch plan of the fused LHS is replayed while nothing changed and rebuilt
     when the memory manager's generation changes (here: cached pointing evicted in between)."""
