@@ -66,6 +66,36 @@ def test_chain_staged(hip, oracle, name, nest):
     compare_chain(got, want)
 
 
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("TOAST_TEST_FUZZ_SEEDS", "16")))))
+def test_chain_random_cases(hip, oracle, seed):
+    """Randomly drawn shapes and options of the whole chain (detector count incl. odd, ragged interval splits with gaps,
+    Nside 1 .. 8192, NEST / RING, HWP, flags on / off, row indirection, broken detector pairs, random pointing, IAU)
+    against the oracle: pixels bit-exact, the rest within the chain's tolerances."""
+    rng = np.random.default_rng(5000 + seed)
+    n_samp = int(rng.integers(1, 3000))
+    kw = dict(
+        n_det=int(rng.integers(1, 8)),
+        n_samp=n_samp,
+        nside=int(2 ** rng.integers(0, 14)),
+        n_split=int(rng.integers(1, min(6, n_samp) + 1)),
+        gap=int(rng.integers(0, 4)),
+        with_shared_flags=bool(rng.integers(0, 2)),
+        with_det_flags=bool(rng.integers(0, 2)),
+        with_hwp=bool(rng.integers(0, 2)),
+        extra_rows=int(rng.integers(0, 3)),
+        seed=int(rng.integers(0, 1000)),
+        random_pointing=bool(rng.integers(0, 2)),
+        fp_roll=int(rng.integers(0, 2)),
+    )
+    if kw["n_det"] == 1:
+        kw["extra_rows"] = 0
+    nest, iau = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    c = cases.make_case(**kw)
+    got = cases.run_chain(hip, c, nest=nest, iau=iau, tail=(False,))
+    want = cases.run_chain(oracle, c, nest=nest, iau=iau)
+    compare_chain(got, want)
+
+
 @pytest.mark.parametrize("map_dtype", [np.float32, np.int64, np.int32])
 def test_scan_map_dtypes(hip, oracle, map_dtype):
     c = cases.make_case(n_samp=3000, nside=128, n_split=2)

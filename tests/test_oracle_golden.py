@@ -185,3 +185,33 @@ def test_oracle_pixels_on_boundaries_vs_live_reference(oracle, ref, nside):
         ref.pixels_healpix(idx, quats, flags, 0, idx, a, iv, ha, nps, nside, nest, False)
         oracle.pixels_healpix(idx, quats, flags, 0, idx, b, iv, hb, nps, nside, nest)
         assert np.array_equal(a, b) and np.array_equal(ha, hb)
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_oracle_vs_live_reference_random(oracle, ref, seed):
+    """The same randomly drawn chain cases as tests/test_gpu_parity.py::test_chain_random_cases: the oracle and the
+    reference's own compiled kernels agree bit for bit on every product."""
+    rng = np.random.default_rng(5000 + seed)
+    n_samp = int(rng.integers(1, 3000))
+    kw = dict(
+        n_det=int(rng.integers(1, 8)),
+        n_samp=n_samp,
+        nside=int(2 ** rng.integers(0, 14)),
+        n_split=int(rng.integers(1, min(6, n_samp) + 1)),
+        gap=int(rng.integers(0, 4)),
+        with_shared_flags=bool(rng.integers(0, 2)),
+        with_det_flags=bool(rng.integers(0, 2)),
+        with_hwp=bool(rng.integers(0, 2)),
+        extra_rows=int(rng.integers(0, 3)),
+        seed=int(rng.integers(0, 1000)),
+        random_pointing=bool(rng.integers(0, 2)),
+        fp_roll=int(rng.integers(0, 2)),
+    )
+    if kw["n_det"] == 1:
+        kw["extra_rows"] = 0
+    nest, iau = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    c = cases.make_case(**kw)
+    a = cases.run_chain(ref, c, nest=nest, iau=iau, tail=(False,))
+    b = cases.run_chain(oracle, c, nest=nest, iau=iau)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
