@@ -69,6 +69,42 @@ def test_noise_filter_kernels_per_detector(pf, n_samp):
     assert np.array_equal(got[untouched], buf[untouched])
 
 
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("TOAST_TEST_FUZZ_SEEDS", "12")))))
+def test_convolve_random_cases(pf, seed):
+    """Randomly drawn timestream lengths (1 .. 150 000: both the rocFFT pipeline and the fused three-pass kernels and
+    every padding / reflection regime of toast.fft.convolve), detector counts, row indirection, knot counts, real or
+    complex kernels, one kernel per detector or a common one, deconvolution -- against the oracle, 1e-12."""
+    from oracle import fft_oracle as fo
+
+    rng = np.random.default_rng(7000 + seed)
+    n_samp = int(rng.choice([rng.integers(2, 200), rng.integers(200, 5000), rng.integers(5000, 150000)]))
+    n_det = int(rng.integers(1, 7))
+    rows = n_det + int(rng.integers(0, 3))
+    rate = float(rng.choice([10.0, 37.5, 200.0]))
+    n_knot = int(rng.integers(4, 90))
+    freq = np.concatenate([[0.0], np.geomspace(1e-4, rate / 2, n_knot - 1)])
+    common = bool(rng.integers(0, 2))
+    cplx = bool(rng.integers(0, 2))
+    deconvolve = bool(rng.integers(0, 2))
+    nk = 1 if common else n_det
+    mag = 0.2 + rng.random((nk, n_knot))
+    kernels = mag * np.exp(1j * rng.uniform(-0.5, 0.5, (nk, n_knot))) if cplx else mag
+    if cplx:
+        kernels[:, 0] = kernels[:, 0].real
+    kern = kernels[0] if common else kernels
+    buf = rng.standard_normal((rows, n_samp)) + 0.01 * rng.standard_normal((rows, n_samp)).cumsum(axis=1)
+    idx = rng.permutation(rows)[:n_det].astype(np.int32)
+    want = buf.copy()
+    sub = np.ascontiguousarray(buf[idx])
+    fo.convolve(sub, rate, kernel_freq=freq, kernels=kern, deconvolve=deconvolve)
+    want[idx] = sub
+    got = buf.copy()
+    pf.convolve_buffer(got, idx, rate, freq, kern, deconvolve=deconvolve)
+    assert np.max(np.abs(got - want)) < TOL * np.max(np.abs(want)), (n_samp, n_det, common, cplx, deconvolve)
+    untouched = [r for r in range(rows) if r not in idx]
+    assert np.array_equal(got[untouched], buf[untouched])
+
+
 def test_deconvolve_and_flags(pf):
     from oracle import fft_oracle as fo
 
