@@ -186,6 +186,54 @@ def test_operator_vs_oracle_and_rms(oracle, split, bin_width, orders):
                 assert new_rms < old_rms
 
 
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("TOAST_TEST_FUZZ_SEEDS", "10")))))
+def test_operator_random_configurations(oracle, seed):
+    """Randomly drawn GroundFilter set-ups (detector and observation counts, lengths, scan rates, polynomial orders,
+    split templates, detrending, random sample flags, a cut detector) against the oracle restatement of
+    groundfilter.py."""
+    from oracle import ground_filter as GF
+
+    rng = np.random.default_rng(9000 + seed)
+    n_det = int(rng.integers(1, 8))
+    n_obs = int(rng.integers(1, 3))
+    n_samp = int(rng.integers(6000, 30000))
+    trend_order = [None, 0, 2, 5][int(rng.integers(0, 4))]
+    filter_order = int(rng.integers(1, 9))
+    split = bool(rng.integers(0, 2))
+    data = create_ground_data(n_det=n_det, n_samp=n_samp, rate=float(rng.choice([20.0, 50.0])), n_obs=n_obs,
+                              scan_rate_deg_s=float(rng.choice([1.0, 2.5])), seed=seed)
+    inject_ground(data, rng)
+    for ob in data.obs:
+        fl = ob.detdata[defaults.det_flags].data
+        fl |= (rng.random(fl.shape) < float(rng.choice([0.0, 0.01, 0.1]))).astype(np.uint8)
+    cut = None
+    if n_det > 1 and rng.integers(0, 2):
+        cut = data.obs[0].local_detectors[int(rng.integers(0, n_det))]
+        data.obs[0].update_local_detector_flags({cut: 1})
+    before = {ob.name: ob.detdata[defaults.det_data].data.copy() for ob in data.obs}
+    gf = ops.GroundFilter(trend_order=trend_order, filter_order=filter_order, split_template=split,
+                          detrend=trend_order is None, name="gf")
+    gf.apply(data)
+    for iob, ob in enumerate(data.obs):
+        n = ob.n_local_samples
+        lr = np.zeros(n, dtype=bool)
+        rl = np.zeros(n, dtype=bool)
+        for iv in ob.intervals[defaults.throw_leftright_interval]:
+            lr[iv.first:iv.last] = True
+        for iv in ob.intervals[defaults.throw_rightleft_interval]:
+            rl[iv.first:iv.last] = True
+        templates = GF.build_templates(n, ob.shared[defaults.azimuth].data, trend_order, filter_order, bin_width=None,
+                                       split=split, lr_mask=lr, rl_mask=rl)
+        rows = [i for i, d in enumerate(ob.local_detectors) if not (iob == 0 and d == cut)]
+        want = before[ob.name].copy()
+        sub = np.ascontiguousarray(want[rows])
+        GF.apply(sub, np.ascontiguousarray(ob.detdata[defaults.det_flags].data[rows]), 1,
+                 ob.shared[defaults.shared_flags].data, 1, templates, trend_order, trend_order is None)
+        want[rows] = sub
+        got = ob.detdata[defaults.det_data].data
+        assert np.max(np.abs(got - want)) < 1e-9 * np.max(np.abs(before[ob.name])), (seed, ob.name)
+
+
 def test_operator_detrend_flags_and_resident_data():
     rng = np.random.default_rng(5)
     data = create_ground_data(n_det=4, n_samp=12000, rate=20.0)
