@@ -484,6 +484,18 @@ int toast_hip_offset_scan_project_dev(
     const double * d_weights, const int32_t * flag_index /*host or NULL*/, const uint8_t * d_flag_data,
     uint8_t flag_mask, const double * det_weights /*host*/, int64_t n_det, int64_t n_samp,
     const toast_hip_interval * intervals /*host*/, int64_t n_view, void * stream);
+/* The solver's right-hand side tail in one pass: a_out += M^T N^-1 (d - A z) for the timestreams d (row signal_index[d]
+ * of the device buffer d_signal, which is only read) -- the reference's Copy, ScanMap(subtract), NoiseWeight and
+ * TemplateMatrix(transpose) of SolverRHS (src/toast/ops/mapmaker_solve.py:140-229) with the per-sample arithmetic of
+ * scan_map (ops_scan_map.cpp:15-78), noise_weight (ops_noise_weight.cpp:14-40) and offset project_signal
+ * (template_offset.cpp:149-331).  Other arguments as toast_hip_offset_scan_project_dev. */
+int toast_hip_offset_scan_project_signal_dev(
+    int64_t step_length, const int64_t * amp_offsets, const int64_t * n_amp_views, const int32_t * signal_index,
+    const double * d_signal, double * d_amplitudes_out, const uint8_t * d_amplitude_flags, const int64_t * d_g2l,
+    const double * d_map, int64_t n_pix_submap, int64_t nnz, const int32_t * pixel_index, const int64_t * d_pixels,
+    const int32_t * weight_index, const double * d_weights, const int32_t * flag_index, const uint8_t * d_flag_data,
+    uint8_t flag_mask, const double * det_weights, int64_t n_det, int64_t n_samp,
+    const toast_hip_interval * intervals, int64_t n_view, void * stream);
 
 int toast_hip_template_offset_apply_diag_precond(
     const double * offset_var, const double * amp_in, const uint8_t * amplitude_flags,

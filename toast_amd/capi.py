@@ -742,6 +742,24 @@ class _Dev:
             _p(d_flag_data), _u8(flag_mask), _p(dw), _i64(pi.size), _i64(n_samp), _p(iv), _i64(iv.size),
             _p(stream)))
 
+    def offset_scan_project_signal(self, step_length, amp_offsets, n_amp_views, signal_index, d_signal, d_amps_out,
+                                   d_amplitude_flags, d_g2l, d_map, n_pix_submap, nnz, pixel_index, d_pixels,
+                                   weight_index, d_weights, flag_index, d_flag_data, flag_mask, det_weights, n_samp,
+                                   intervals, stream=0):
+        ao = self._small(amp_offsets, np.int64)
+        nv = self._small(n_amp_views, np.int64)
+        si = self._small(signal_index, np.int32)
+        pi = self._small(pixel_index, np.int32)
+        wi = self._small(weight_index, np.int32)
+        fi = None if flag_index is None else self._small(flag_index, np.int32)
+        dw = self._small(det_weights, np.float64)
+        iv = self._small(intervals, interval_dtype)
+        _check(lib().toast_hip_offset_scan_project_signal_dev(
+            _i64(step_length), _p(ao), _p(nv), _p(si), _p(d_signal), _p(d_amps_out), _p(d_amplitude_flags), _p(d_g2l),
+            _p(d_map), _i64(n_pix_submap), _i64(nnz), _p(pi), _p(d_pixels), _p(wi), _p(d_weights), _p(fi),
+            _p(d_flag_data), _u8(flag_mask), _p(dw), _i64(pi.size), _i64(n_samp), _p(iv), _i64(iv.size),
+            _p(stream)))
+
     # -- pointing on the fly (otf_kernels.hip)
     def otf_build_noise_weighted(self, pt, d_g2l, d_zmap, n_pix_submap, data_index, d_det_data, flag_index,
                                  d_det_flags, n_flag_samp, det_scale, det_flag_mask, n_samp, intervals,

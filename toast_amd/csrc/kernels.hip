@@ -1228,7 +1228,9 @@ __global__ __launch_bounds__(kThreads) void k_offset_accumulate(
     }
 }
 
-template <int NNZ>
+// SIGBUF: the signal is a timestream buffer instead of M a -- a_out += M^T N^-1 (d - A z), the right-hand side of the
+// solver (SolverRHS: copy, scan_map(subtract), noise_weight and project_signal in one pass that leaves d untouched).
+template <int NNZ, bool SIGBUF>
 __global__ __launch_bounds__(kThreads) void k_offset_scan_project(
     const Chunk * __restrict__ chunks, int n_chunks, const int64_t * __restrict__ view_first,
     const int64_t * __restrict__ view_aoff, FastDiv step_div, const int64_t * __restrict__ amp_offsets,
@@ -1238,8 +1240,10 @@ __global__ __launch_bounds__(kThreads) void k_offset_scan_project(
     const double * __restrict__ det_w, const int64_t * __restrict__ g2l,
     const double * __restrict__ map, const int64_t * __restrict__ pixels,
     const double * __restrict__ weights, const uint8_t * __restrict__ flags, uint8_t fmask,
-    int use_flags, FastDiv nps_div, int64_t n_samp) {
+    int use_flags, FastDiv nps_div, int64_t n_samp, const int32_t * __restrict__ s_idx,
+    const double * __restrict__ signal) {
     const int det = blockIdx.x;
+    const double * srow = SIGBUF ? signal + (int64_t)s_idx[det] * n_samp : nullptr;
     const int64_t * prow = pixels + (int64_t)p_idx[det] * n_samp;
     const double * wrow = weights + (int64_t)w_idx[det] * n_samp * NNZ;
     const uint8_t * frow = use_flags ? flags + (int64_t)f_idx[det] * n_samp : nullptr;
@@ -1264,7 +1268,7 @@ __global__ __launch_bounds__(kThreads) void k_offset_scan_project(
                 const int64_t s = c.first + i;
                 const int64_t a = abase + fastdiv(s - vfirst, step_div);
                 const uint8_t af = amp_flags[a];
-                const double av = amps_in[a];
+                const double av = SIGBUF ? srow[s] : amps_in[a];
                 const uint8_t fl = use_flags ? frow[s] : (uint8_t)0;
                 const int64_t p = prow[s];
                 const double * w = wrow + NNZ * s;
@@ -1281,7 +1285,7 @@ __global__ __launch_bounds__(kThreads) void k_offset_scan_project(
 #pragma unroll
                 for (int k = 0; k < NNZ; ++k) sc += wk[k] * m[k];
                 sc *= 1.0;
-                double d = 0.0 + av;
+                double d = SIGBUF ? av : 0.0 + av;
                 d = hit ? d - sc : d;
                 const bool good = (fl & fmask) == 0;
                 key = (af == 0) ? a : (int64_t)-1;
@@ -1978,16 +1982,19 @@ int toast_hip_offset_accumulate_dev(
     });
 }
 
-int toast_hip_offset_scan_project_dev(
+static int offset_scan_project_launch(
     int64_t step_length, const int64_t * amp_offsets, const int64_t * n_amp_views,
     const double * d_amplitudes_in, double * d_amplitudes_out, const uint8_t * d_amplitude_flags,
     const int64_t * d_g2l, const double * d_map, int64_t n_pix_submap, int64_t nnz,
     const int32_t * pixel_index, const int64_t * d_pixels, const int32_t * weight_index,
     const double * d_weights, const int32_t * flag_index, const uint8_t * d_flag_data, uint8_t flag_mask,
     const double * det_weights, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals,
-    int64_t n_view, void * stream) {
+    int64_t n_view, const int32_t * signal_index, const double * d_signal, void * stream,
+    const char * fn = __builtin_FUNCTION()) {
     return guarded([&] {
         if (n_det <= 0) return;
+        const bool sigbuf = d_signal != nullptr;
+        if (sigbuf && signal_index == nullptr) fail_arg("offset_scan_project: signal_index is NULL");
         if (step_length <= 0) fail_arg("step_length must be positive");
         if (nnz != 1 && nnz != 3) fail_arg("offset_scan_project: nnz must be 1 or 3");
         const auto chunks = make_chunks(intervals, n_view, n_samp);
@@ -2005,6 +2012,9 @@ int toast_hip_offset_scan_project_dev(
         const size_t o_wi = pb.push(weight_index, sizeof(int32_t) * n_det);
         const size_t o_fi = pb.push_vec(fidx);
         const size_t o_dw = pb.push(det_weights, sizeof(double) * n_det);
+        std::vector<int32_t> sidx(n_det, 0);
+        if (sigbuf) std::memcpy(sidx.data(), signal_index, sizeof(int32_t) * n_det);
+        const size_t o_si = pb.push_vec(sidx);
         const char * d = pb.commit(as_stream(stream));
         const dim3 grid = chunk_grid(n_det, chunks.size());
         hipStream_t st = as_stream(stream);
@@ -2014,15 +2024,52 @@ int toast_hip_offset_scan_project_dev(
         d_amplitudes_in, d_amplitudes_out, d_amplitude_flags, (const int32_t *)(d + o_pi),          \
         (const int32_t *)(d + o_wi), (const int32_t *)(d + o_fi), (const double *)(d + o_dw), d_g2l, \
         d_map, d_pixels, d_weights, d_flag_data, flag_mask, use_flags, make_fastdiv(n_pix_submap),  \
-        n_samp
-        if (nnz == 3) {
-            hipLaunchKernelGGL(k_offset_scan_project<3>, grid, dim3(kThreads), 0, st, TH_OS_ARGS);
+        n_samp, (const int32_t *)(d + o_si), d_signal
+        if (sigbuf) {
+            if (nnz == 3) {
+                hipLaunchKernelGGL((k_offset_scan_project<3, true>), grid, dim3(kThreads), 0, st, TH_OS_ARGS);
+            } else {
+                hipLaunchKernelGGL((k_offset_scan_project<1, true>), grid, dim3(kThreads), 0, st, TH_OS_ARGS);
+            }
+        } else if (nnz == 3) {
+            hipLaunchKernelGGL((k_offset_scan_project<3, false>), grid, dim3(kThreads), 0, st, TH_OS_ARGS);
         } else {
-            hipLaunchKernelGGL(k_offset_scan_project<1>, grid, dim3(kThreads), 0, st, TH_OS_ARGS);
+            hipLaunchKernelGGL((k_offset_scan_project<1, false>), grid, dim3(kThreads), 0, st, TH_OS_ARGS);
         }
 #undef TH_OS_ARGS
         check_launch();
-    });
+    }, fn);
+}
+
+int toast_hip_offset_scan_project_dev(
+    int64_t step_length, const int64_t * amp_offsets, const int64_t * n_amp_views,
+    const double * d_amplitudes_in, double * d_amplitudes_out, const uint8_t * d_amplitude_flags,
+    const int64_t * d_g2l, const double * d_map, int64_t n_pix_submap, int64_t nnz,
+    const int32_t * pixel_index, const int64_t * d_pixels, const int32_t * weight_index,
+    const double * d_weights, const int32_t * flag_index, const uint8_t * d_flag_data, uint8_t flag_mask,
+    const double * det_weights, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals,
+    int64_t n_view, void * stream) {
+    return offset_scan_project_launch(step_length, amp_offsets, n_amp_views, d_amplitudes_in, d_amplitudes_out,
+                                      d_amplitude_flags, d_g2l, d_map, n_pix_submap, nnz, pixel_index, d_pixels,
+                                      weight_index, d_weights, flag_index, d_flag_data, flag_mask, det_weights, n_det,
+                                      n_samp, intervals, n_view, nullptr, nullptr, stream);
+}
+
+int toast_hip_offset_scan_project_signal_dev(
+    int64_t step_length, const int64_t * amp_offsets, const int64_t * n_amp_views, const int32_t * signal_index,
+    const double * d_signal, double * d_amplitudes_out, const uint8_t * d_amplitude_flags, const int64_t * d_g2l,
+    const double * d_map, int64_t n_pix_submap, int64_t nnz, const int32_t * pixel_index, const int64_t * d_pixels,
+    const int32_t * weight_index, const double * d_weights, const int32_t * flag_index, const uint8_t * d_flag_data,
+    uint8_t flag_mask, const double * det_weights, int64_t n_det, int64_t n_samp,
+    const toast_hip_interval * intervals, int64_t n_view, void * stream) {
+    if (d_signal == nullptr) {
+        set_last_error("offset_scan_project_signal: d_signal is NULL");
+        return TOAST_HIP_ERR_ARG;
+    }
+    return offset_scan_project_launch(step_length, amp_offsets, n_amp_views, nullptr, d_amplitudes_out,
+                                      d_amplitude_flags, d_g2l, d_map, n_pix_submap, nnz, pixel_index, d_pixels,
+                                      weight_index, d_weights, flag_index, d_flag_data, flag_mask, det_weights, n_det,
+                                      n_samp, intervals, n_view, signal_index, d_signal, stream);
 }
 
 int toast_hip_template_offset_apply_diag_precond_dev(const double * d_offset_var,

@@ -220,7 +220,7 @@ class SolveAmplitudes(Operator):
             if nm["rhs"] in data:
                 del data[nm["rhs"]]
             SolverRHS(name=f"{self.name}_rhs", det_data=self.det_data, binning=binning,
-                      template_matrix=tm).apply(data, detectors=detectors)
+                      template_matrix=tm, fused=self.fused_lhs).apply(data, detectors=detectors)
             t0 = lap("rhs", t0)
             # -- PCG (:1002-1060)
             lhs = SolverLHS(name=f"{self.name}_lhs", binning=binning, template_matrix=tm, fused=self.fused_lhs)

@@ -171,6 +171,60 @@ class SolverRHS(Operator):
     det_data_units = Unicode(defaults.det_data_units, allow_none=True, help="Desired units of detector data")
     binning = Instance(klass=Operator, help="Binning operator for solving")
     template_matrix = Instance(klass=Operator, help="This must be an instance of a template matrix operator")
+    fused = Bool(True, help="With cached pointing and one Offset template on the accelerator: project the timestreams in "
+                            "one pass that leaves them untouched instead of copy / scan / weight / project "
+                            "(not a reference trait; False = the reference operator sequence)")
+
+    def _fused_lhs(self, data):
+        """The SolverLHS whose launch context the fused tail borrows, or None when the sequence has to run."""
+        if not (self.fused and self.binning.full_pointing):
+            return None
+        lhs = SolverLHS(name=f"{self.name}_ctx", binning=self.binning, template_matrix=self.template_matrix,
+                        out=self.template_matrix.amplitudes, fused=True)
+        if not lhs._can_fuse(data):
+            return None
+        tmpl = [t for t in self.template_matrix.templates if t.enabled][0]
+        if tmpl.use_noise_prior:
+            return None     # (the prior's baselines ignore the view; keep the reference sequence there)
+        for ob in data.obs:
+            if self.det_data in ob.detdata and ob.detdata[self.det_data].dtype != np.float64:
+                return None
+        return lhs
+
+    def _exec_fused(self, data, detectors, lhs):
+        """b = M^T N^-1 (d - A C A^T N^-1 d): the binning pass, then ONE pass over the cached pointing that reads d
+        (toast_hip_offset_scan_project_signal_dev) -- no copy of the timestreams, no scan_map / noise_weight /
+        project_signal passes over it."""
+        from .. import capi
+        from ..accel import accel_device_ptr
+        from ..templates import AmplitudesMap
+
+        tm = self.template_matrix
+        tm.transpose = True
+        tm.det_data = self.det_data
+        tm.det_data_units = self.det_data_units
+        for t in tm.templates:
+            t.det_data = self.det_data
+        tm.initialize(data)
+        tmpl = [t for t in tm.templates if t.enabled][0]
+        if tm.amplitudes not in data:
+            data[tm.amplitudes] = AmplitudesMap()
+            data[tm.amplitudes][tmpl.name] = tmpl.zeros()
+        # the binned map of the pass above is an INPUT here (the left-hand side only uses that buffer as scratch)
+        SolverLHS._resident(data[self.binning.binned], self.binning.binned)
+        ctx = lhs._fused_prepare(data, detectors)
+        D = capi.dev
+        D.memset(ctx["out_ptr"], 0, ctx["out_bytes"])
+        for ps in ctx["passes"]:
+            ob = data.obs[ps["iob"]]
+            dd = SolverLHS._resident(ob.detdata[self.det_data], self.det_data)
+            D.offset_scan_project_signal(ps["step"], ps["ao"], ps["nav"], dd.indices(ps["dets"]),
+                                         accel_device_ptr(dd.buffer), ctx["out_ptr"], ctx["in_flags_ptr"],
+                                         ctx["g2l_ptr"], ctx["zmap_ptr"], ctx["nps"], ctx["nnz"], ps["pi"], ps["pp"],
+                                         ps["wi"], ps["wp"], ps["pf_idx"], ps["pf_ptr"], ctx["tmpl_flag_mask"],
+                                         ps["detw"], ps["n_samp"], ps["ivl"])
+        ctx["amps_out"].accel_used(True)
+        tm._finalize(data)
 
     def _exec(self, data, detectors=None, **kwargs):
         for trait in ("det_data", "binning", "template_matrix"):
@@ -179,6 +233,10 @@ class SolverRHS(Operator):
         self.binning.det_data = self.det_data
         self.binning.det_data_units = self.det_data_units
         self.binning.apply(data, detectors=detectors)
+        lhs = self._fused_lhs(data)
+        if lhs is not None:
+            self._exec_fused(data, detectors, lhs)
+            return
         det_temp = "temp_RHS"
         pixels = self.binning.pixel_pointing
         weights = self.binning.stokes_weights
@@ -331,7 +389,8 @@ class SolverLHS(Operator):
                 continue
             noise = ob[binning.noise_model]
             n_samp = ob.n_local_samples
-            ps = dict(step=tmpl._step_length(tmpl.step_time, tmpl._obs_rate[iob]), ao=tmpl.det_amp_offsets(iob, dets),
+            ps = dict(iob=iob, dets=dets, step=tmpl._step_length(tmpl.step_time, tmpl._obs_rate[iob]),
+                      ao=tmpl.det_amp_offsets(iob, dets),
                       nav=tmpl._obs_views[iob], n_samp=n_samp, ivl=ob.intervals[pixels_op.view].data,
                       detw=np.array([noise.detector_weight(d) for d in dets], dtype=np.float64))
             if binning.det_flags is not None:
