@@ -665,13 +665,15 @@ class DetDataManager(_KeyAccel, MutableMapping):
         self._store[name]._accel_name = name
         return self._store[name]
 
-    def ensure(self, name, sample_shape=(), dtype=np.float64, detectors=None, accel=False, create_units=None):
+    def ensure(self, name, sample_shape=(), dtype=np.float64, detectors=None, accel=False, create_units=None,
+               zero_new=True):
         """Make sure ``name`` exists with this shape/dtype and holds ``detectors``.
 
         Returns True when it already held all requested detectors (callers then skip
         recomputation), False when it was created or its detector list changed
         (observation_data.py:725-860).  With ``accel=True`` the buffer also exists on the
-        device afterwards and is marked as in use there."""
+        device afterwards and is marked as in use there.  ``zero_new=False``: the caller is about to write every
+        sample of every row, a new device buffer need not be cleared first (17.7 GB of Stokes weights: 3 ms)."""
         dets = self._local_detectors if detectors is None else list(detectors)
         existing = True
         if name not in self._store:
@@ -688,7 +690,7 @@ class DetDataManager(_KeyAccel, MutableMapping):
         obj = self._store[name]
         if accel and accel_enabled() and obj.buffer.size > 0:   # (no detectors: nothing to hold on the device)
             if not obj.accel_exists():
-                obj.accel_create(name, zero_out=not existing)
+                obj.accel_create(name, zero_out=(not existing) and zero_new)
                 if existing:
                     obj.accel_update_device()
             elif not obj.accel_in_use():

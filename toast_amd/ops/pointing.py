@@ -266,6 +266,23 @@ def otf_descriptor(ob, dets, pixels_op, weights_op, compact=None):
                              epsilon=eps, gamma=gamma, cal=cal, IAU=iau, **extra)
 
 
+def _view_covers_all(ob, view):
+    """True when the intervals of ``view`` cover every sample of the observation (then a kernel over the view writes
+    every sample of its output rows)."""
+    ivl = ob.intervals[view].data
+    if len(ivl) == 0:
+        return ob.n_local_samples == 0
+    first = np.asarray(ivl["first"], dtype=np.int64)
+    last = np.asarray(ivl["last"], dtype=np.int64)
+    order = np.argsort(first, kind="stable")
+    reach = 0
+    for f, l in zip(first[order], last[order]):
+        if f > reach:
+            return False
+        reach = max(reach, int(l))
+    return reach >= ob.n_local_samples
+
+
 def _skip_quaternions(op, data, detectors, use_accel):
     """True when this pointing operator can write its output straight from the boresight
     (toast_hip_otf_pixels_healpix_dev / _stokes_weights_dev): device-resident run, the plain
@@ -407,7 +424,8 @@ class PixelsHealpix(Operator):
             self.detector_pointing.apply(data, detectors=detectors, use_accel=use_accel)
         for ob in data.obs:
             dets = ob.select_local_detectors(detectors, flagmask=self.detector_pointing.det_mask)
-            exists = ob.detdata.ensure(self.pixels, sample_shape=(), dtype=np.int64, detectors=dets, accel=use_accel)
+            exists = ob.detdata.ensure(self.pixels, sample_shape=(), dtype=np.int64, detectors=dets, accel=use_accel,
+                                       zero_new=not _view_covers_all(ob, view))
             hit_submaps = self._local_submaps
             if hit_submaps is None:
                 hit_submaps = np.zeros(self._n_submap, dtype=np.uint8)
@@ -544,7 +562,7 @@ class StokesWeights(Operator):
         for ob in data.obs:
             dets = ob.select_local_detectors(detectors, flagmask=self.detector_pointing.det_mask)
             exists = ob.detdata.ensure(self.weights, sample_shape=(nnz,), dtype=np.float64, detectors=dets,
-                                       accel=use_accel)
+                                       accel=use_accel, zero_new=not _view_covers_all(ob, view))
             if exists or len(dets) == 0:
                 continue
             if no_quats:
