@@ -406,3 +406,33 @@ def test_extend_flags_on_device(pf):
     accel.accel_data_update_host(got4, "flags")
     accel.accel_data_delete(got4, "flags")
     assert np.array_equal(got4, want3)
+
+
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("TOAST_TEST_FUZZ_SEEDS", "12")))))
+def test_extend_flags_random_cases(pf, seed):
+    """Randomly drawn flag buffers (lengths 1 .. 20 000, densities, masks with other bits set, extents 0 .. beyond the
+    length, row subsets, with / without the edges and the common OR-ed row) against the host restatement of the
+    reference's extend_flags."""
+    rng = np.random.default_rng(13000 + seed)
+    n_samp = int(rng.choice([rng.integers(1, 40), rng.integers(40, 20000)]))
+    rows = int(rng.integers(1, 9))
+    mask = int(rng.choice([1, 2, 3, 129]))
+    flags = ((rng.random((rows, n_samp)) < rng.choice([0.0, 0.001, 0.05, 0.5])) * mask
+             + (rng.random((rows, n_samp)) < 0.1) * 64).astype(np.uint8)
+    n_sel = int(rng.integers(1, rows + 1))
+    idx = rng.permutation(rows)[:n_sel].astype(np.int32)
+    extents = rng.choice([0, 1, 2, 7, 100, n_samp // 2, n_samp, n_samp + 5], size=n_sel).astype(np.int32)
+    edges = bool(rng.integers(0, 2))
+    common = ((rng.random(n_samp) < 0.01) * int(rng.choice([mask, 3, 64]))).astype(np.uint8) if rng.integers(0, 2) else None
+    want = flags.copy()
+    for row, ext in zip(idx, extents):
+        ext = int(ext)
+        if common is not None:
+            want[row] |= common
+        pf.extend_flags(want[row], mask, ext)
+        if edges:
+            want[row][:ext] |= mask
+            want[row][-ext:] |= mask
+    got = flags.copy()
+    pf.extend_flags_buffer(got, idx, mask, extents, edges=edges, or_row=common)
+    assert np.array_equal(got, want), (n_samp, rows, mask, list(extents), edges, common is not None)
