@@ -436,6 +436,35 @@ def test_repeated_runs_reuse_existing_products():
     assert np.max(np.abs(np.array(data["again"].data) - want)) <= 1e-12 * np.max(np.abs(want))
 
 
+def test_solver_rhs_fused_equals_sequence_and_accumulates():
+    """SolverRHS with the one-pass tail (toast_hip_offset_scan_project_signal_dev) against the reference's operator
+    sequence: same amplitudes to rounding, the timestreams untouched, and -- like TemplateMatrix(transpose) -- a second
+    application adds to the existing amplitudes."""
+    out = {}
+    for fused in (False, True):
+        data, pix, sw, truth, sky = make_solver_setup(n_det=4, noise_rms=0.3)
+        ops.CovarianceAndHits(pixel_dist="dist", covariance="cov", pixel_pointing=pix, stokes_weights=sw,
+                              save_pointing=True).apply(data)
+        binner = ops.BinMap(pixel_dist="dist", covariance="cov", binned="bin", pixel_pointing=pix, stokes_weights=sw,
+                            full_pointing=True)
+        tmpl = Offset(step_time=13.0, noise_model=defaults.noise_model, name="baselines", good_fraction=0.2)
+        tm = ops.TemplateMatrix(templates=[tmpl], amplitudes="rhs")
+        before = data.obs[0].detdata[defaults.det_data].data.copy()
+        rhs = ops.SolverRHS(det_data=defaults.det_data, binning=binner, template_matrix=tm, fused=fused)
+        rhs.apply(data)
+        once = np.array(data["rhs"]["baselines"].local)
+        rhs.apply(data)
+        twice = np.array(data["rhs"]["baselines"].local)
+        assert np.array_equal(data.obs[0].detdata[defaults.det_data].data, before)
+        out[fused] = (once, twice)
+    seq, fus = out[False], out[True]
+    scale = np.max(np.abs(seq[0]))
+    assert scale > 0
+    assert np.max(np.abs(fus[0] - seq[0])) < 1e-12 * scale
+    assert np.max(np.abs(seq[1] - 2 * seq[0])) < 1e-12 * scale
+    assert np.max(np.abs(fus[1] - 2 * fus[0])) < 1e-12 * scale
+
+
 def test_mapmaker_recovers_offsets_and_sky():
     """End to end (configs[0] shape: 4 detectors x 10 min @10 Hz, Nside 16): destriping removes
     the injected baselines; the binned map equals the input sky on well-conditioned pixels."""

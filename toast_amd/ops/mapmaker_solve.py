@@ -214,7 +214,7 @@ class SolverRHS(Operator):
         SolverLHS._resident(data[self.binning.binned], self.binning.binned)
         ctx = lhs._fused_prepare(data, detectors)
         D = capi.dev
-        D.memset(ctx["out_ptr"], 0, ctx["out_bytes"])
+        # (like TemplateMatrix(transpose): amplitudes that already exist are added to, not reset)
         for ps in ctx["passes"]:
             ob = data.obs[ps["iob"]]
             dd = SolverLHS._resident(ob.detdata[self.det_data], self.det_data)
