@@ -210,14 +210,26 @@ class SolverRHS(Operator):
         if tm.amplitudes not in data:
             data[tm.amplitudes] = AmplitudesMap()
             data[tm.amplitudes][tmpl.name] = tmpl.zeros()
-        # the binned map of the pass above is an INPUT here (the left-hand side only uses that buffer as scratch)
-        SolverLHS._resident(data[self.binning.binned], self.binning.binned)
-        ctx = lhs._fused_prepare(data, detectors)
+        # The context holds raw device pointers: collect until one whole pass made no allocation (an allocation that
+        # fails evicts lazily retained buffers, possibly one whose pointer was already taken; see SolverLHS).
+        for _attempt in range(4):
+            gen0 = capi.accel_generation()
+            # the binned map of the pass above is an INPUT here (the left-hand side only uses that buffer as scratch)
+            SolverLHS._resident(data[self.binning.binned], self.binning.binned)
+            for ob in data.obs:
+                if self.det_data in ob.detdata:
+                    SolverLHS._resident(ob.detdata[self.det_data], self.det_data)
+            ctx = lhs._fused_prepare(data, detectors)
+            if capi.accel_generation() == gen0:
+                break
+        else:
+            raise RuntimeError("SolverRHS: device buffers keep being evicted while the right-hand side is prepared "
+                               "(device memory too small for its working set)")
         D = capi.dev
         # (like TemplateMatrix(transpose): amplitudes that already exist are added to, not reset)
         for ps in ctx["passes"]:
             ob = data.obs[ps["iob"]]
-            dd = SolverLHS._resident(ob.detdata[self.det_data], self.det_data)
+            dd = ob.detdata[self.det_data]
             D.offset_scan_project_signal(ps["step"], ps["ao"], ps["nav"], dd.indices(ps["dets"]),
                                          accel_device_ptr(dd.buffer), ctx["out_ptr"], ctx["in_flags_ptr"],
                                          ctx["g2l_ptr"], ctx["zmap_ptr"], ctx["nps"], ctx["nnz"], ps["pi"], ps["pp"],
