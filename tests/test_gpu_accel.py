@@ -231,3 +231,60 @@ def test_pixel_data_lazy_host_coherence():
     accel.accel_data_delete(ones, "ones")
     for obj in (pd, dup):
         obj.accel_delete()
+
+
+_CAP_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from toast_amd import ops
+from toast_amd.data import defaults
+from toast_amd.sim import create_satellite_data
+from toast_amd.templates import Offset
+
+data = create_satellite_data(n_det=4, n_samp=200000, rate=20.0)
+rng = np.random.default_rng(1)
+ob = data.obs[0]
+ob.detdata[defaults.det_data].data[:] = rng.standard_normal((4, 200000))
+dp = ops.PointingDetectorSimple()
+pix = ops.PixelsHealpix(detector_pointing=dp, nside=256, nest=True)
+sw = ops.StokesWeights(detector_pointing=dp, mode="IQU", hwp_angle=defaults.hwp_angle)
+binner = ops.BinMap(pixel_dist="dist", pixel_pointing=pix, stokes_weights=sw, full_pointing=sys.argv[2] == "full")
+tm = ops.TemplateMatrix(templates=[Offset(step_time=10.0, noise_model=defaults.noise_model, name="baselines")])
+mm = ops.MapMaker(name="mm", det_data=defaults.det_data, binning=binner, template_matrix=tm, iter_max=5,
+                  convergence=1e-30, keep_solver_products=True)
+mm.apply(data)
+maps = [float(np.sum(np.abs(data[k].data))) for k in ("mm_hits", "mm_map", "mm_cov", "mm_solve_cov")]
+print("RESULT", int(data.accel_evict() >= 0), *maps, float(np.sum(np.abs(data["mm_solve_amplitudes"]["baselines"].local))))
+"""
+
+
+@pytest.mark.parametrize("pointing", ["full", "uncached"])
+def test_mapmaker_under_memory_cap(tmp_path, pointing):
+    """A complete MapMaker run with the manager capped at 52 MB, below what it keeps resident without a cap (timestreams
+    6.4 MB, cached pointing 25.6 MB, a dozen maps; tools: TOAST_HIP_TRACE=1 shows 84 - 90 write-backs / releases instead
+    of 78): allocations fail, lazily retained timestreams AND maps are written back and released, the collection of
+    device pointers for the fused solver passes is repeated -- same products as without a cap."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "cap.py"
+    script.write_text(_CAP_SCRIPT)
+    out = {}
+    for limit in (None, "52"):
+        env = dict(os.environ)
+        env.pop("TOAST_HIP_MEM_LIMIT_MB", None)
+        env["TOAST_HIP_LAZY_HOST"] = "1"
+        env["TOAST_HIP_ALLOC_CACHE_MB"] = "0"
+        if limit:
+            env["TOAST_HIP_MEM_LIMIT_MB"] = limit
+        res = subprocess.run([sys.executable, str(script), root, pointing], capture_output=True, text=True, env=env,
+                             timeout=600)
+        assert res.returncode == 0, res.stderr[-3000:]
+        out[limit] = [float(x) for x in [ln for ln in res.stdout.splitlines() if ln.startswith("RESULT")][0].split()[1:]]
+    free, capped = np.array(out[None]), np.array(out["52"])
+    assert free[1] > 0 and free[2] > 0
+    assert free[1] == capped[1]                                 # hits
+    assert np.all(np.abs(free[2:] - capped[2:]) <= 1e-9 * np.abs(free[2:]))

@@ -921,8 +921,8 @@ class Data(MutableMapping):
                 obj.accel_delete()
 
     def accel_evict(self):
-        """Write back and free every resident detector-data buffer that is neither pinned nor
-        staged by a running Pipeline.  Returns the number of bytes released."""
+        """Write back and free every resident detector-data buffer and every lazily retained map that is neither
+        pinned nor staged by a running Pipeline.  Returns the number of bytes released."""
         freed = 0
         for ob in self.obs:
             for key in list(ob.detdata.keys()):
@@ -934,6 +934,17 @@ class Data(MutableMapping):
                     obj.accel_update_host()
                 freed += obj.buffer.nbytes
                 obj.accel_delete()
+        # lazily retained maps (PixelData): the same treatment
+        from .pixels import PixelData
+
+        for key, obj in list(self._internal.items()):
+            if (not isinstance(obj, PixelData) or key in self._pinned["global"]
+                    or any(("global:" + key) in s for s in self._protected) or not obj.accel_exists()):
+                continue
+            if obj.accel_in_use():
+                obj.accel_update_host()
+            freed += obj.buffer.nbytes
+            obj.accel_delete()
         return freed
 
     def all_local_detectors(self, selection=None, flagmask=0):

@@ -129,6 +129,7 @@ class Pipeline(Operator):
             if run_accel:
                 requires -= self._staged_data
                 self._protect |= requires["detdata"] | set(op.provides().get("detdata", ()))
+                self._protect |= {"global:" + k for k in set(requires["global"]) | set(op.provides().get("global", ()))}
                 data.accel_create(requires)
                 data.accel_update_device(requires)
                 self._unstaged_data -= requires
