@@ -29,6 +29,10 @@ from toast_amd.sim import create_satellite_data  # noqa: E402
 from toast_amd.templates import Offset  # noqa: E402
 
 
+#: timings of the last main() call of this process (bench.py reports them as its "operator_level" entry)
+LAST_STATS = {}
+
+
 class Phase:
     def __init__(self, quiet=False):
         self.t = time.time()
@@ -39,6 +43,7 @@ class Phase:
         now = time.time()
         if not self.quiet:
             print(f"  {name:34s} {now - self.t:8.2f} s", flush=True)
+        LAST_STATS.setdefault("laps", {})[name] = now - self.t
         self.t = now
 
 
@@ -82,6 +87,7 @@ def main(argv=None):
             dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
         comm = Comm()
     quiet = rank != 0
+    LAST_STATS.clear()
     ph = Phase(quiet)
     data = create_satellite_data(comm=comm, n_det=args.ndet, total_det=args.ndet * world, first_det=args.ndet * rank,
                                  n_samp=n_samp, rate=args.rate, spin_period_s=600.0, spin_angle_deg=30.0,
@@ -122,6 +128,12 @@ def main(argv=None):
     ph.lap("MapMaker (cov + RHS + PCG + bin)")
     n_it = len(mapper.history)
     nds = args.ndet * world * n_samp
+    its = getattr(mapper, "iteration_seconds", None)
+    LAST_STATS.update(mapmaker_s=total, iterations=n_it, relative_residual=float(mapper.history[-1]) if n_it else None,
+                      phases_s=dict(getattr(mapper, "timing_log", {})),
+                      pcg_iteration_ms=1e3 * float(np.median(its)) if its else None,
+                      pcg_Gsamp_s=nds / float(np.median(its)) / 1e9 if its else None,
+                      detectors=args.ndet * world, samples_per_detector=n_samp, nside=args.nside)
     if world > 1:
         import torch.distributed as dist
 
