@@ -399,6 +399,27 @@ int toast_hip_build_cov_dev(
     const double * det_scale /*host, mode 1*/, uint8_t det_flag_mask, int64_t n_det, int64_t n_samp,
     const toast_hip_interval * intervals /*host*/, int64_t n_view, const uint8_t * d_shared_flags,
     int64_t n_shared_flags, uint8_t shared_flag_mask, void * stream);
+/* BuildInverseCovariance and BuildHitMap of one CovarianceAndHits pass (src/toast/ops/mapmaker_utils.py:927-1271 runs
+ * them one after the other over the same pixels and flags) in one kernel where the detector-pair merged
+ * inverse-covariance kernel applies (IQU, pairing on), as two passes otherwise; same accumulation as mode 1 / mode 0 of
+ * toast_hip_build_cov_dev into d_invcov [n_local_pix, nnz (nnz + 1) / 2] and d_hits [n_local_pix] (int64). */
+int toast_hip_build_cov_hits_dev(
+    const int64_t * d_g2l, double * d_invcov, int64_t * d_hits, int64_t n_pix_submap, int64_t nnz,
+    const int32_t * pixel_index, const int64_t * d_pixels, const int32_t * weight_index, const double * d_weights,
+    const int32_t * flag_index, const uint8_t * d_det_flags, int64_t n_flag_samp, const double * det_scale,
+    uint8_t det_flag_mask, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
+    const uint8_t * d_shared_flags, int64_t n_shared_flags, uint8_t shared_flag_mask, void * stream);
+/* Host-array level of the same call (arrays resolved like toast_hip_build_cov: registered device copies with use_accel,
+ * staged temporaries otherwise). */
+int toast_hip_build_cov_hits(const int64_t * global2local, int64_t n_submap, double * invcov, int64_t * hits,
+                             int64_t n_local_submap, int64_t n_pix_submap, int64_t nnz,
+                             const int32_t * pixel_index, const int64_t * pixels, int64_t n_pixel_rows,
+                             const int32_t * weight_index, const double * weights, int64_t n_weight_rows,
+                             const int32_t * flag_index, const uint8_t * det_flags, int64_t n_flag_rows,
+                             int64_t n_flag_samp, const double * det_scale, uint8_t det_flag_mask,
+                             int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals,
+                             int64_t n_view, const uint8_t * shared_flags, int64_t n_shared_flags,
+                             uint8_t shared_flag_mask, int use_accel);
 
 int toast_hip_build_cov(
     int mode, const int64_t * global2local, int64_t n_submap, void * out, int64_t n_local_submap,

@@ -176,6 +176,67 @@ def test_chain_accel_resident(hip, oracle):
         hip.noise_weight(tod, c["data_index"], c["intervals"], c["det_scale"], True)  # not present
 
 
+@pytest.mark.parametrize("seed", list(range(int(__import__("os").environ.get("TOAST_TEST_FUZZ_SEEDS", "10")))))
+def test_inverse_covariance_and_hits_in_one_call(hip, oracle, seed):  # noqa: C901
+    """build_inverse_covariance_and_hits (hit map carried by the pair-merged inverse-covariance kernel, or two kernels
+    behind the same call for I-only weights / a single detector / broken pairs) against the two separate calls and a
+    NumPy statement of the accumulation: hits exactly, inverse covariance to rounding; it adds to existing contents."""
+    rng = np.random.default_rng(17000 + seed)
+    kw = dict(n_det=int(rng.integers(1, 8)), n_samp=int(rng.integers(50, 4000)), nside=int(2 ** rng.integers(2, 9)),
+              n_split=int(rng.integers(1, 4)), gap=int(rng.integers(0, 5)), with_shared_flags=bool(rng.integers(0, 2)),
+              with_det_flags=bool(rng.integers(0, 2)), fp_roll=int(rng.integers(0, 2)), seed=int(rng.integers(0, 99)))
+    c = cases.make_case(**kw)
+    ch = cases.run_chain(oracle, c, nest=True)
+    pixels, g2l = ch["pixels"], ch["g2l"]
+    n_local = max(int(np.count_nonzero(ch["hsub"])), 1)
+    nnz = int(rng.choice([1, 3]))
+    weights = ch["weights"] if nnz == 3 else np.ascontiguousarray(ch["weights"][:, :, 0])
+    blk = nnz * (nnz + 1) // 2
+    shape = (n_local, c["n_pix_submap"])
+    args = (c["flag_index"], c["det_flags"], c["det_scale"], 1, c["intervals"], c["shared_flags"], 1)
+    want_hits = np.zeros(shape + (1,), dtype=np.int64)
+    want_cov = np.zeros(shape + (blk,))
+    # NumPy statement of cov_accum_diag_hits / cov_accum_diag_invnpp over the intervals (toast_map_cov.cpp:66-153; the
+    # kernels themselves are pinned to the reference's outputs in tests/test_gpu_golden.py)
+    nps = c["n_pix_submap"]
+    use_d, use_s = c["det_flags"].shape[1] == c["n_samp"], c["shared_flags"].size == c["n_samp"]
+    for d in range(c["n_det"]):
+        prow, wrow = pixels[c["pixel_index"][d]], weights[c["weight_index"][d]]
+        for iv in c["intervals"]:
+            sl = slice(int(iv["first"]), int(iv["last"]))
+            p = prow[sl]
+            good = p >= 0
+            if use_d:
+                good &= (c["det_flags"][c["flag_index"][d], sl] & 1) == 0
+            if use_s:
+                good &= (c["shared_flags"][sl] & 1) == 0
+            pg = p[good]
+            loc = g2l[pg // nps] * nps + pg % nps
+            np.add.at(want_hits.reshape(-1), loc, 1)
+            wg = wrow[sl][good].reshape(pg.size, nnz)
+            off = 0
+            for j in range(nnz):
+                for k in range(j, nnz):
+                    np.add.at(want_cov.reshape(-1, blk)[:, off], loc, wg[:, j] * wg[:, k] * c["det_scale"][d])
+                    off += 1
+    from toast_amd.accel import native
+
+    sep_hits = np.zeros_like(want_hits)
+    sep_cov = np.zeros_like(want_cov)
+    hip = native()   # the pybind11 module carries these bindings
+    hip.build_hit_map(g2l, sep_hits, c["pixel_index"], pixels, args[0], args[1], 1, args[4], args[5], 1, False)
+    hip.build_inverse_covariance(g2l, sep_cov, c["pixel_index"], pixels, c["weight_index"], weights, *args, False)
+    got_hits = np.full_like(want_hits, 5)                     # accumulates onto what is there
+    got_cov = np.full_like(want_cov, 0.25)
+    hip.build_inverse_covariance_and_hits(g2l, got_cov, got_hits, c["pixel_index"], pixels, c["weight_index"], weights,
+                                          *args, False)
+    assert np.array_equal(sep_hits, want_hits)
+    assert np.array_equal(got_hits - 5, want_hits)
+    scale = max(np.max(np.abs(want_cov)), 1e-300)
+    assert np.max(np.abs(sep_cov - want_cov)) < 1e-12 * scale
+    assert np.max(np.abs((got_cov - 0.25) - want_cov)) < 1e-12 * max(scale, 0.25)
+
+
 def test_stokes_I_and_cov_and_offsets(hip, oracle):
     rng = np.random.default_rng(3)
     c = cases.make_case(n_det=3, n_samp=5000, n_split=3, gap=7)

@@ -365,6 +365,33 @@ int toast_hip_build_cov(int mode, const int64_t * global2local, int64_t n_submap
     });
 }
 
+int toast_hip_build_cov_hits(const int64_t * global2local, int64_t n_submap, double * invcov, int64_t * hits,
+                             int64_t n_local_submap, int64_t n_pix_submap, int64_t nnz,
+                             const int32_t * pixel_index, const int64_t * pixels, int64_t n_pixel_rows,
+                             const int32_t * weight_index, const double * weights, int64_t n_weight_rows,
+                             const int32_t * flag_index, const uint8_t * det_flags, int64_t n_flag_rows,
+                             int64_t n_flag_samp, const double * det_scale, uint8_t det_flag_mask,
+                             int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals,
+                             int64_t n_view, const uint8_t * shared_flags, int64_t n_shared_flags,
+                             uint8_t shared_flag_mask, int use_accel) {
+    return guarded([&] {
+        Call c(use_accel);
+        const int64_t * d_g2l = resolve_g2l(c.st, global2local, n_submap, use_accel != 0);
+        const int64_t nv = nnz * (nnz + 1) / 2;
+        double * d_cov = c.st.inout(invcov, (size_t)(n_local_submap * n_pix_submap * nv));
+        int64_t * d_hits = c.st.inout(hits, (size_t)(n_local_submap * n_pix_submap));
+        const int64_t * d_pix = c.st.in(pixels, (size_t)(n_pixel_rows * n_samp));
+        const double * d_w = c.st.in(weights, (size_t)(n_weight_rows * n_samp * nnz));
+        const uint8_t * d_df = optional_in(c.st, det_flags, n_flag_samp, n_samp, n_flag_rows);
+        const uint8_t * d_sf = optional_in(c.st, shared_flags, n_shared_flags, n_samp);
+        c.check(toast_hip_build_cov_hits_dev(d_g2l, d_cov, d_hits, n_pix_submap, nnz, pixel_index, d_pix, weight_index,
+                                             d_w, flag_index, d_df, d_df ? n_samp : 0, det_scale, det_flag_mask,
+                                             n_det, n_samp, intervals, n_view, d_sf, d_sf ? n_samp : 0,
+                                             shared_flag_mask, c.stream));
+        c.st.finish();
+    });
+}
+
 int toast_hip_cov_eigendecompose_diag(int64_t n_sub, int64_t subsize, int64_t nnz, double * data,
                                       double * cond, double threshold, int invert, int use_accel) {
     return guarded([&] {

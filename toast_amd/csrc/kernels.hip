@@ -585,7 +585,9 @@ __global__ __launch_bounds__(kThreads) void k_build_cov(
 // Inverse covariance with the detector-pair merged scatter (see k_build_noise_weighted_pair): the
 // A / B detectors of a focalplane pixel look at the same sky pixel, so their packed products are
 // summed before the run reduction and share one set of atomics.
-template <int NNZ>
+// HITS: the hit map rides along as one more reduced value (a count, exact in fp64) and leaves as one integer atomic per
+// run -- BuildHitMap's separate pass over pixels and flags (9 B per det-sample at 280 G samples/s) disappears.
+template <int NNZ, bool HITS>
 __global__ __launch_bounds__(kThreads) void k_build_cov_pair(
     const Chunk * __restrict__ chunks, int n_chunks, int n_det, const int32_t * __restrict__ p_idx,
     const int32_t * __restrict__ w_idx, const int32_t * __restrict__ f_idx,
@@ -593,8 +595,9 @@ __global__ __launch_bounds__(kThreads) void k_build_cov_pair(
     double * __restrict__ invcov, const int64_t * __restrict__ pixels,
     const double * __restrict__ weights, const uint8_t * __restrict__ dflags, uint8_t dmask,
     int use_dflags, const uint8_t * __restrict__ sflags, uint8_t smask, int use_sflags,
-    FastDiv nps_div, int64_t n_samp) {
-    constexpr int NV = NNZ * (NNZ + 1) / 2;
+    FastDiv nps_div, int64_t n_samp, long long * __restrict__ hits) {
+    constexpr int NC = NNZ * (NNZ + 1) / 2;
+    constexpr int NV = NC + (HITS ? 1 : 0);
     const int det0 = 2 * blockIdx.x;
     const bool two = det0 + 1 < n_det;
     const int det1 = two ? det0 + 1 : det0;
@@ -644,10 +647,41 @@ __global__ __launch_bounds__(kThreads) void k_build_cov_pair(
 #pragma unroll
                             for (int k = j; k < NNZ; ++k, ++off) v[e][off] = wk[e][k] * sw;
                         }
+                        if (HITS) v[e][NC] = 1.0;
                     }
                 }
             }
-            scatter_runs<NV, 2>(key, v, invcov);
+            if (!HITS) {
+                scatter_runs<NV, 2>(key, v, invcov);
+            } else {
+                // as scatter_runs, with the last value going to the integer hit map
+                const bool mergeable = (key[0] == key[1]) | (key[0] < 0) | (key[1] < 0);
+                if (__all(mergeable)) {
+                    const int64_t km = (key[0] >= 0) ? key[0] : key[1];
+                    double vm[NV];
+#pragma unroll
+                    for (int k = 0; k < NV; ++k) vm[k] = v[0][k] + v[1][k];
+                    const bool tail = wave_run_reduce<NV>(km, vm);
+                    if (tail && km >= 0) {
+                        double * z = invcov + NC * km;
+#pragma unroll
+                        for (int k = 0; k < NC; ++k) unsafeAtomicAdd(z + k, vm[k]);
+                        atomicAdd((unsigned long long *)(hits + km), (unsigned long long)__double2ll_rn(vm[NC]));
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const bool tail = wave_run_reduce<NV>(key[e], v[e]);
+                        if (tail && key[e] >= 0) {
+                            double * z = invcov + NC * key[e];
+#pragma unroll
+                            for (int k = 0; k < NC; ++k) unsafeAtomicAdd(z + k, v[e][k]);
+                            atomicAdd((unsigned long long *)(hits + key[e]),
+                                      (unsigned long long)__double2ll_rn(v[e][NC]));
+                        }
+                    }
+                }
+            }
         }
     }
 }
@@ -2086,14 +2120,20 @@ int toast_hip_template_offset_apply_diag_precond_dev(const double * d_offset_var
     });
 }
 
-int toast_hip_build_cov_dev(
+// d_hits != nullptr (mode 1 only): the hit map is accumulated by the same kernel when the pair-merged kernel applies;
+// *hits_done tells the caller whether it was.
+static int build_cov_launch(
     int mode /*0 hits, 1 inverse covariance*/, const int64_t * d_g2l, void * d_out, int64_t n_pix_submap,
     int64_t nnz, const int32_t * pixel_index, const int64_t * d_pixels, const int32_t * weight_index,
     const double * d_weights, const int32_t * flag_index, const uint8_t * d_det_flags,
     int64_t n_flag_samp, const double * det_scale, uint8_t det_flag_mask, int64_t n_det, int64_t n_samp,
     const toast_hip_interval * intervals, int64_t n_view, const uint8_t * d_shared_flags,
-    int64_t n_shared_flags, uint8_t shared_flag_mask, void * stream) {
+    int64_t n_shared_flags, uint8_t shared_flag_mask, void * stream, int64_t * d_hits_in, bool * hits_done,
+    const char * fn = __builtin_FUNCTION()) {
+    if (hits_done != nullptr) *hits_done = false;
     return guarded([&] {
+        int64_t * d_hits = d_hits_in;
+        if (!(mode == 1 && nnz == 3 && pair_detectors() && n_det >= 2 && !deterministic_mode())) d_hits = nullptr;
         if (n_det <= 0) return;
         if (n_pix_submap <= 0) fail_arg("n_pix_submap must be positive");
         if (mode == 1 && (nnz < 1 || nnz > 3)) fail_arg("build_inverse_covariance: nnz must be 1..3");
@@ -2135,11 +2175,19 @@ int toast_hip_build_cov_dev(
             hipLaunchKernelGGL((k_build_cov<1, 0>), grid, dim3(kThreads), 0, st, TH_COV_ARGS);
         } else if (nnz == 3 && pair_detectors() && n_det >= 2) {
             const dim3 gp((unsigned)((n_det + 1) / 2), grid.y, 1);
-            hipLaunchKernelGGL(k_build_cov_pair<3>, gp, dim3(kThreads), 0, st, (const Chunk *)(d + o_ch), (int)chunks.size(),
-                               (int)n_det, (const int32_t *)(d + o_pi), (const int32_t *)(d + o_wi),
-                               (const int32_t *)(d + o_fi), (const double *)(d + o_ds), d_g2l, (double *)d_out, d_pixels,
-                               d_weights, d_det_flags, det_flag_mask, use_d, d_shared_flags, shared_flag_mask, use_s, dv,
-                               n_samp);
+            if (d_hits != nullptr) {
+                hipLaunchKernelGGL((k_build_cov_pair<3, true>), gp, dim3(kThreads), 0, st, (const Chunk *)(d + o_ch),
+                                   (int)chunks.size(), (int)n_det, (const int32_t *)(d + o_pi),
+                                   (const int32_t *)(d + o_wi), (const int32_t *)(d + o_fi), (const double *)(d + o_ds),
+                                   d_g2l, (double *)d_out, d_pixels, d_weights, d_det_flags, det_flag_mask, use_d,
+                                   d_shared_flags, shared_flag_mask, use_s, dv, n_samp, (long long *)d_hits);
+            } else {
+                hipLaunchKernelGGL((k_build_cov_pair<3, false>), gp, dim3(kThreads), 0, st, (const Chunk *)(d + o_ch),
+                                   (int)chunks.size(), (int)n_det, (const int32_t *)(d + o_pi),
+                                   (const int32_t *)(d + o_wi), (const int32_t *)(d + o_fi), (const double *)(d + o_ds),
+                                   d_g2l, (double *)d_out, d_pixels, d_weights, d_det_flags, det_flag_mask, use_d,
+                                   d_shared_flags, shared_flag_mask, use_s, dv, n_samp, (long long *)nullptr);
+            }
         } else if (nnz == 3) {
             hipLaunchKernelGGL((k_build_cov<3, 1>), grid, dim3(kThreads), 0, st, TH_COV_ARGS);
         } else if (nnz == 2) {
@@ -2149,7 +2197,38 @@ int toast_hip_build_cov_dev(
         }
 #undef TH_COV_ARGS
         check_launch();
-    });
+        if (hits_done != nullptr) *hits_done = d_hits != nullptr;
+    }, fn);
+}
+
+int toast_hip_build_cov_dev(
+    int mode /*0 hits, 1 inverse covariance*/, const int64_t * d_g2l, void * d_out, int64_t n_pix_submap,
+    int64_t nnz, const int32_t * pixel_index, const int64_t * d_pixels, const int32_t * weight_index,
+    const double * d_weights, const int32_t * flag_index, const uint8_t * d_det_flags,
+    int64_t n_flag_samp, const double * det_scale, uint8_t det_flag_mask, int64_t n_det, int64_t n_samp,
+    const toast_hip_interval * intervals, int64_t n_view, const uint8_t * d_shared_flags,
+    int64_t n_shared_flags, uint8_t shared_flag_mask, void * stream) {
+    return build_cov_launch(mode, d_g2l, d_out, n_pix_submap, nnz, pixel_index, d_pixels, weight_index, d_weights,
+                            flag_index, d_det_flags, n_flag_samp, det_scale, det_flag_mask, n_det, n_samp, intervals,
+                            n_view, d_shared_flags, n_shared_flags, shared_flag_mask, stream, nullptr, nullptr);
+}
+
+int toast_hip_build_cov_hits_dev(
+    const int64_t * d_g2l, double * d_invcov, int64_t * d_hits, int64_t n_pix_submap, int64_t nnz,
+    const int32_t * pixel_index, const int64_t * d_pixels, const int32_t * weight_index, const double * d_weights,
+    const int32_t * flag_index, const uint8_t * d_det_flags, int64_t n_flag_samp, const double * det_scale,
+    uint8_t det_flag_mask, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
+    const uint8_t * d_shared_flags, int64_t n_shared_flags, uint8_t shared_flag_mask, void * stream) {
+    bool hits_done = false;
+    int rc = build_cov_launch(1, d_g2l, d_invcov, n_pix_submap, nnz, pixel_index, d_pixels, weight_index, d_weights,
+                              flag_index, d_det_flags, n_flag_samp, det_scale, det_flag_mask, n_det, n_samp, intervals,
+                              n_view, d_shared_flags, n_shared_flags, shared_flag_mask, stream, d_hits, &hits_done);
+    if (rc != TOAST_HIP_OK || hits_done || n_det <= 0) return rc;
+    // no pair-merged kernel for this call (nnz != 3, a single detector, pairing off, deterministic mode): the hit
+    // map in its own pass
+    return build_cov_launch(0, d_g2l, d_hits, n_pix_submap, nnz, pixel_index, d_pixels, weight_index, d_weights,
+                            flag_index, d_det_flags, n_flag_samp, det_scale, det_flag_mask, n_det, n_samp, intervals,
+                            n_view, d_shared_flags, n_shared_flags, shared_flag_mask, stream, nullptr, nullptr);
 }
 
 int toast_hip_cov_eigendecompose_diag_dev(int64_t n_sub, int64_t subsize, int64_t nnz, double * d_data,

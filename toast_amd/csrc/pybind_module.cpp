@@ -751,6 +751,46 @@ PYBIND11_MODULE(_libtoast_hip, m) {
         build_cov(1, global2local, invcov, pixel_index, pixels, weight_index, weights, flag_index, det_flags,
                   det_scale, det_flag_mask, intervals, shared_flags, shared_flag_mask, use_accel);
     });
+    // (not a reference binding) BuildInverseCovariance and BuildHitMap of one CovarianceAndHits pass in one call
+    m.def("build_inverse_covariance_and_hits", [](py::buffer global2local, py::buffer invcov, py::buffer hits,
+                                                  py::buffer pixel_index, py::buffer pixels,
+                                                  py::buffer weight_index, py::buffer weights,
+                                                  py::buffer flag_index, py::buffer det_flags,
+                                                  py::buffer det_scale, uint8_t det_flag_mask,
+                                                  py::buffer intervals, py::buffer shared_flags,
+                                                  uint8_t shared_flag_mask, bool use_accel) {
+        Shape s(3);
+        int32_t * p_idx = extract<int32_t>(pixel_index, "pixel_index", 1, s, {-1});
+        const int64_t n_det = s[0];
+        int64_t * pix = extract<int64_t>(pixels, "pixels", 2, s, {-1, -1});
+        const int64_t n_p_rows = s[0], n_samp = s[1];
+        int32_t * f_idx = extract<int32_t>(flag_index, "flag_index", 1, s, {n_det});
+        toast_hip_interval * ivl = extract_intervals(intervals, s);
+        const int64_t n_view = s[0];
+        int64_t * g2l = extract<int64_t>(global2local, "global2local", 1, s, {-1});
+        const int64_t n_submap = s[0];
+        uint8_t * sf = extract<uint8_t>(shared_flags, "flags", 1, s, {-1});
+        const int64_t n_sf = s[0];
+        uint8_t * df = extract<uint8_t>(det_flags, "det_flags", 2, s, {-1, -1});
+        const int64_t n_f_rows = s[0], n_f_samp = s[1];
+        int32_t * w_idx = extract<int32_t>(weight_index, "weight_index", 1, s, {n_det});
+        double * w;
+        int64_t nnz = 1;
+        if (weights.request().ndim == 2) {
+            w = extract<double>(weights, "weights", 2, s, {-1, n_samp});
+        } else {
+            w = extract<double>(weights, "weights", 3, s, {-1, n_samp, -1});
+            nnz = s[2];
+        }
+        const int64_t n_w_rows = s[0];
+        double * dscale = extract<double>(det_scale, "det_scale", 1, s, {n_det});
+        double * cov = extract<double>(invcov, "invcov", 3, s, {-1, -1, nnz * (nnz + 1) / 2});
+        const int64_t n_local = s[0], nps = s[1];
+        int64_t * hp = extract<int64_t>(hits, "hits", 3, s, {n_local, nps, 1});
+        check(toast_hip_build_cov_hits(g2l, n_submap, cov, hp, n_local, nps, nnz, p_idx, pix, n_p_rows, w_idx, w,
+                                       n_w_rows, f_idx, df, n_f_rows, n_f_samp, dscale, det_flag_mask, n_det, n_samp,
+                                       ivl, n_view, sf, n_sf, shared_flag_mask, use_accel));
+    });
     // map_cov.cpp:269-325
     m.def("cov_eigendecompose_diag", [](int64_t nsub, int64_t nsubpix, int64_t nnz, py::buffer data,
                                         py::buffer cond, double threshold, bool invert, bool use_accel) {

@@ -501,10 +501,21 @@ class BuildInverseCovariance(_MapBuilder):
     weights = Unicode(defaults.weights, help="Observation detdata key for Stokes weights")
     noise_model = Unicode(defaults.noise_model, help="Observation key containing the noise model")
     det_data_units = Unicode(defaults.det_data_units, allow_none=True, help="Desired timestream units")
+    hits = Unicode(None, allow_none=True, help="Also accumulate the hit map under this Data key in the same pass over "
+                   "the pointing (not a reference trait: CovarianceAndHits uses it instead of a separate BuildHitMap)")
 
     def _exec(self, data, detectors=None, use_accel=None, **kwargs):
         implementation, use_accel = self.select_kernels(use_accel=use_accel)
         dist = self._dist(data)
+        hits = None
+        if self.hits is not None:
+            if self.hits in data:
+                if data[self.hits].distribution != dist:
+                    raise RuntimeError("Existing hits '{}' has different data distribution".format(self.hits))
+            else:
+                data[self.hits] = PixelData(dist, np.int64, n_value=1)
+            hits = data[self.hits]
+            _global_to(hits, self.hits, use_accel, zero_new=not hits.accel_exists() and hits.host_is_zero())
         if self.inverse_covariance in data:
             if data[self.inverse_covariance].distribution != dist:
                 raise RuntimeError("Existing inv cov '{}' has different data distribution".format(
@@ -525,6 +536,14 @@ class BuildInverseCovariance(_MapBuilder):
             noise = ob[self.noise_model]
             detweights = np.array([noise.detector_weight(x) for x in dets], dtype=np.float64)
             flag_indx, flag_data, shared = self._flag_args(ob, dets, use_accel)
+            if hits is not None:
+                native().build_inverse_covariance_and_hits(
+                    dist.global_submap_to_local, invcov.arg(use_accel), hits.arg(use_accel),
+                    ob.detdata[self.pixels].indices(dets), ob.detdata[self.pixels].arg(use_accel),
+                    ob.detdata[self.weights].indices(dets), ob.detdata[self.weights].arg(use_accel), flag_indx,
+                    flag_data, detweights, self.det_flag_mask, ob.intervals[self.view].data, shared,
+                    self.shared_flag_mask, use_accel)
+                continue
             native().build_inverse_covariance(
                 dist.global_submap_to_local, invcov.arg(use_accel), ob.detdata[self.pixels].indices(dets),
                 ob.detdata[self.pixels].arg(use_accel), ob.detdata[self.weights].indices(dets), ob.detdata[self.weights].arg(use_accel),
@@ -534,6 +553,8 @@ class BuildInverseCovariance(_MapBuilder):
     def _finalize(self, data, use_accel=None, **kwargs):
         if self.inverse_covariance in data:
             self._sync(data[self.inverse_covariance])
+        if self.hits is not None and self.hits in data:
+            self._sync(data[self.hits])
 
     def _requires(self):
         req = {"global": [self.pixel_dist], "meta": [self.noise_model], "shared": [],
@@ -547,7 +568,10 @@ class BuildInverseCovariance(_MapBuilder):
         return req
 
     def _provides(self):
-        return {"global": [self.inverse_covariance]}
+        prov = {"global": [self.inverse_covariance]}
+        if self.hits is not None:
+            prov["global"].append(self.hits)
+        return prov
 
 
 class CovarianceAndHits(Operator):
@@ -592,12 +616,13 @@ class CovarianceAndHits(Operator):
                       det_mask=self.det_mask, det_flags=self.det_flags, det_flag_mask=self.det_flag_mask,
                       shared_flags=self.shared_flags, shared_flag_mask=self.shared_flag_mask,
                       sync_type=self.sync_type)
-        build_hits = BuildHitMap(hits=self.hits, **common)
+        # hit map and inverse covariance read the same pixels and flags: one pass (the pair-merged kernel carries the
+        # count along; other shapes run the two kernels behind the same call)
         build_invcov = BuildInverseCovariance(inverse_covariance=inv_key, weights=self.stokes_weights.weights,
                                               noise_model=self.noise_model, det_data_units=self.det_data_units,
-                                              **common)
+                                              hits=self.hits, **common)
         accum = Pipeline(detector_sets=["ALL"] if self.save_pointing else uncached_detector_sets(),
-                         operators=[self.pixel_pointing, self.stokes_weights, build_hits, build_invcov])
+                         operators=[self.pixel_pointing, self.stokes_weights, build_invcov])
         accum.apply(data, detectors=detectors)
         invcov = data[inv_key]
         data[self.rcond] = PixelData(data[self.pixel_dist], np.float64, n_value=1)
