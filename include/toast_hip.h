@@ -838,6 +838,15 @@ int toast_hip_otf_offset_scan_project_dev(
     const int32_t * flag_index, const uint8_t * d_det_flags, int64_t n_flag_samp, uint8_t det_flag_mask,
     const double * det_weights, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals,
     int64_t n_view, void * stream);
+/* The same with the timestreams as the signal (row signal_index[d] of d_signal, only read): the tail of SolverRHS for
+ * uncached pointing, see toast_hip_offset_scan_project_signal_dev. */
+int toast_hip_otf_offset_scan_project_signal_dev(
+    const toast_hip_otf_pointing * pointing, int64_t step_length, const int64_t * amp_offsets,
+    const int64_t * n_amp_views, const int32_t * signal_index, const double * d_signal, double * d_amplitudes_out,
+    const uint8_t * d_amplitude_flags, const int64_t * d_g2l, const double * d_map, int64_t n_pix_submap,
+    const int32_t * flag_index, const uint8_t * d_det_flags, int64_t n_flag_samp, uint8_t det_flag_mask,
+    const double * det_weights, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals,
+    int64_t n_view, void * stream);
 
 /* counts[amplitude] += number of samples under that offset amplitude with (det_flags & flag_mask) != 0
  * (as doubles; the caller zeroes d_counts): the input of the good-fraction cut and of the

@@ -845,6 +845,21 @@ class _Dev:
             _p(d_g2l), _p(d_map), _i64(n_pix_submap), _p(fi), _p(d_flag_data), _i64(n_flag_samp), _u8(flag_mask),
             _p(dw), _i64(ao.size), _i64(n_samp), _p(iv), _i64(iv.size), _p(stream)))
 
+    def otf_offset_scan_project_signal(self, pt, step_length, amp_offsets, n_amp_views, signal_index, d_signal,
+                                       d_amps_out, d_amplitude_flags, d_g2l, d_map, n_pix_submap, flag_index,
+                                       d_flag_data, n_flag_samp, flag_mask, det_weights, n_samp, intervals, stream=0):
+        ao = self._small(amp_offsets, np.int64)
+        nv = self._small(n_amp_views, np.int64)
+        si = self._small(signal_index, np.int32)
+        fi = None if flag_index is None else self._small(flag_index, np.int32)
+        dw = self._small(det_weights, np.float64)
+        iv = self._small(intervals, interval_dtype)
+        _check(lib().toast_hip_otf_offset_scan_project_signal_dev(
+            C.byref(pt), _i64(step_length), _p(ao), _p(nv), _p(si), _p(d_signal), _p(d_amps_out),
+            _p(d_amplitude_flags), _p(d_g2l), _p(d_map), _i64(n_pix_submap), _p(fi), _p(d_flag_data),
+            _i64(n_flag_samp), _u8(flag_mask), _p(dw), _i64(ao.size), _i64(n_samp), _p(iv), _i64(iv.size),
+            _p(stream)))
+
     def scan_mask(self, d_g2l, d_mask, n_pix_submap, mask_bits, flag_value, pixel_index, d_pixels, flag_index,
                   d_det_flags, n_samp, intervals, stream=0):
         pi = self._small(pixel_index, np.int32)

@@ -316,6 +316,7 @@ __global__ __launch_bounds__(kThreads) void k_otf_accumulate(
 // ------------------------------------------------------------------------------------
 // A:  SIG 0:  d = (zero ? 0 : d) -/+ scale * P m ; d *= det_w     (scan_map [+ noise_weight])
 //     SIG 1:  a_out += M^T N^-1 (M a - P m)                        (k_offset_scan_project)
+//     SIG 2:  a_out += M^T N^-1 (d - P m), d only read             (the tail of SolverRHS in one pass)
 // ------------------------------------------------------------------------------------
 template <bool NEST, int MODE, int SIG, int PIX, int E>
 __global__ __launch_bounds__(kThreads) void k_otf_scan(
@@ -344,15 +345,15 @@ __global__ __launch_bounds__(kThreads) void k_otf_scan(
         if (!valid[e]) det = E * blockIdx.x;
         D[e] = det_const(P, det);
         if (PIX == 1) D[e].crow = P.cpix + (int64_t)P.cpix_idx[det] * n_samp;
-        drow[e] = (SIG == 0) ? tod + (int64_t)d_idx[det] * n_samp : nullptr;
-        frow[e] = (SIG == 1 && use_flags) ? flags + (int64_t)f_idx[det] * n_samp : nullptr;
+        drow[e] = (SIG != 1) ? tod + (int64_t)d_idx[det] * n_samp : nullptr;   // SIG 2: read only
+        frow[e] = (SIG != 0 && use_flags) ? flags + (int64_t)f_idx[det] * n_samp : nullptr;
         dw[e] = fuse ? det_w[det] : 1.0;
-        amp_offset[e] = (SIG == 1) ? O.amp_offsets[det] : 0;
+        amp_offset[e] = (SIG != 0) ? O.amp_offsets[det] : 0;
     }
     for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
         const Chunk c = chunks[ci];
         int64_t vfirst = 0, vaoff = 0;
-        if (SIG == 1) {
+        if (SIG != 0) {
             vfirst = O.view_first[c.view];
             vaoff = O.view_aoff[c.view];
         }
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(kThreads) void k_otf_scan(
                     if (active && valid[e]) {
                         const int64_t a = amp_offset[e] + vaoff + fastdiv(s - vfirst, O.step_div);
                         const uint8_t af = O.amp_flags[a];
-                        av[e] = O.amps_in[a];
+                        av[e] = (SIG == 2) ? drow[e][s] : O.amps_in[a];
                         const uint8_t fl = use_flags ? frow[e][s] : (uint8_t)0;
                         if (af == 0) {
                             key[e] = a;
@@ -429,7 +430,7 @@ __global__ __launch_bounds__(kThreads) void k_otf_scan(
 #pragma unroll
                     for (int e = 0; e < E; ++e) {
                         if (need[e]) {
-                            double d = 0.0 + av[e];
+                            double d = (SIG == 2) ? av[e] : 0.0 + av[e];
                             if (pidx[e] >= 0) {
                                 const double * m = map + NNZ * pidx[e];
                                 double sc = 0.0;
@@ -852,6 +853,46 @@ int toast_hip_otf_offset_scan_project_dev(
                       d_amplitudes_in, d_amplitudes_out, d_amplitude_flags, make_fastdiv(step_length)};
         launch_scan<1>(h, chunk_grid(n_det, chunks.size()), st, (const Chunk *)(d + o_ch), (int)chunks.size(),
                        (int)n_det, h.dev, off, (const int32_t *)nullptr, (double *)nullptr, 1.0, 0, 1,
+                       (const int32_t *)(d + o_fi), d_det_flags, det_flag_mask, use_f,
+                       (const double *)(d + o_dw), d_map, n_samp);
+        check_launch();
+    });
+}
+
+int toast_hip_otf_offset_scan_project_signal_dev(
+    const toast_hip_otf_pointing * pointing, int64_t step_length, const int64_t * amp_offsets,
+    const int64_t * n_amp_views, const int32_t * signal_index, const double * d_signal, double * d_amplitudes_out,
+    const uint8_t * d_amplitude_flags, const int64_t * d_g2l, const double * d_map, int64_t n_pix_submap,
+    const int32_t * flag_index, const uint8_t * d_det_flags, int64_t n_flag_samp, uint8_t det_flag_mask,
+    const double * det_weights, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals,
+    int64_t n_view, void * stream) {
+    return guarded([&] {
+        if (n_det <= 0) return;
+        if (step_length <= 0) fail_arg("step_length must be positive");
+        if (det_weights == nullptr) fail_arg("det_weights is required");
+        if (d_signal == nullptr || signal_index == nullptr) fail_arg("signal and signal_index are required");
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        const OffsetViews ov = offset_views(intervals, n_amp_views, n_view);
+        ParamBlock pb;
+        OtfHost h = otf_prepare(pointing, n_det, n_samp, n_pix_submap, d_g2l, pb);
+        const int use_f = (n_flag_samp == n_samp) ? 1 : 0;
+        std::vector<int32_t> fidx(n_det, 0);
+        if (use_f) std::memcpy(fidx.data(), flag_index, sizeof(int32_t) * n_det);
+        const size_t o_ch = pb.push_vec(chunks);
+        const size_t o_vf = pb.push_vec(ov.first);
+        const size_t o_va = pb.push_vec(ov.aoff);
+        const size_t o_ao = pb.push(amp_offsets, sizeof(int64_t) * n_det);
+        const size_t o_fi = pb.push_vec(fidx);
+        const size_t o_dw = pb.push(det_weights, sizeof(double) * n_det);
+        const size_t o_si = pb.push(signal_index, sizeof(int32_t) * n_det);
+        hipStream_t st = as_stream(stream);
+        const char * d = pb.commit(st);
+        otf_bind(h, d);
+        OffsetDev off{(const int64_t *)(d + o_vf), (const int64_t *)(d + o_va), (const int64_t *)(d + o_ao),
+                      nullptr, d_amplitudes_out, d_amplitude_flags, make_fastdiv(step_length)};
+        launch_scan<2>(h, chunk_grid(n_det, chunks.size()), st, (const Chunk *)(d + o_ch), (int)chunks.size(),
+                       (int)n_det, h.dev, off, (const int32_t *)(d + o_si), const_cast<double *>(d_signal), 1.0, 0, 1,
                        (const int32_t *)(d + o_fi), d_det_flags, det_flag_mask, use_f,
                        (const double *)(d + o_dw), d_map, n_samp);
         check_launch();

@@ -171,13 +171,14 @@ class SolverRHS(Operator):
     det_data_units = Unicode(defaults.det_data_units, allow_none=True, help="Desired units of detector data")
     binning = Instance(klass=Operator, help="Binning operator for solving")
     template_matrix = Instance(klass=Operator, help="This must be an instance of a template matrix operator")
-    fused = Bool(True, help="With cached pointing and one Offset template on the accelerator: project the timestreams in "
-                            "one pass that leaves them untouched instead of copy / scan / weight / project "
+    fused = Bool(True, help="With one Offset template on the accelerator (pointing cached, compact-cached or on the fly): "
+                            "project the timestreams in one pass that leaves them untouched instead of copy / scan / "
+                            "weight / project "
                             "(not a reference trait; False = the reference operator sequence)")
 
     def _fused_lhs(self, data):
         """The SolverLHS whose launch context the fused tail borrows, or None when the sequence has to run."""
-        if not (self.fused and self.binning.full_pointing):
+        if not self.fused:
             return None
         lhs = SolverLHS(name=f"{self.name}_ctx", binning=self.binning, template_matrix=self.template_matrix,
                         out=self.template_matrix.amplitudes, fused=True)
@@ -230,6 +231,13 @@ class SolverRHS(Operator):
         for ps in ctx["passes"]:
             ob = data.obs[ps["iob"]]
             dd = ob.detdata[self.det_data]
+            if ctx["on_the_fly"]:
+                D.otf_offset_scan_project_signal(ps["pt"], ps["step"], ps["ao"], ps["nav"], dd.indices(ps["dets"]),
+                                                 accel_device_ptr(dd.buffer), ctx["out_ptr"], ctx["in_flags_ptr"],
+                                                 ctx["g2l_ptr"], ctx["zmap_ptr"], ctx["nps"], ps["pf_idx"],
+                                                 ps["pf_ptr"], ps["pf_n"], ctx["tmpl_flag_mask"], ps["detw"],
+                                                 ps["n_samp"], ps["ivl"])
+                continue
             D.offset_scan_project_signal(ps["step"], ps["ao"], ps["nav"], dd.indices(ps["dets"]),
                                          accel_device_ptr(dd.buffer), ctx["out_ptr"], ctx["in_flags_ptr"],
                                          ctx["g2l_ptr"], ctx["zmap_ptr"], ctx["nps"], ctx["nnz"], ps["pi"], ps["pp"],
