@@ -618,7 +618,9 @@ void Manager::adopt(const void * host, size_t nbytes, void * device, const char 
 void Manager::reset(const void * host, size_t nbytes, const char * name) {
     require_device();
     Entry & e = lookup(host, nbytes, name, "reset data");
+    const double t0 = trace_begin();
     TH_HIP(hipMemsetAsync(e.dev, 0, nbytes, stream_));
+    trace("reset", e.name, nbytes, t0);   // (enqueue time only: the fill itself is asynchronous)
 }
 
 void Manager::update_device(const void * host, size_t nbytes, const char * name) {

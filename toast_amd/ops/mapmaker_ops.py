@@ -822,10 +822,11 @@ class Copy(Operator):
                     from .. import capi
                     from ..accel import accel_device_ptr
 
-                    ob.detdata.ensure(dst, sample_shape=s.detector_shape[1:], dtype=s.dtype, detectors=s.detectors,
-                                      accel=True)
-                    d = ob.detdata[dst]
                     rows = sorted(int(r) for r in s.indices([x for x in dets if x in s.detectors]))
+                    # (a new destination whose every row is about to be overwritten need not be cleared first)
+                    ob.detdata.ensure(dst, sample_shape=s.detector_shape[1:], dtype=s.dtype, detectors=s.detectors,
+                                      accel=True, zero_new=len(rows) < len(s.detectors))
+                    d = ob.detdata[dst]
                     row_bytes = s.buffer[0].nbytes if len(s.detectors) else 0
                     sp, dp_ = accel_device_ptr(s.buffer), accel_device_ptr(d.buffer)
                     i = 0
