@@ -2446,3 +2446,45 @@ int toast_hip_test_math_dev(int op, int64_t n, const double * d_a, const double 
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------
+namespace {
+
+// Placement probe of the memory manager (TOAST_HIP_ALLOC=probe, runtime.cpp): one read + write pass over a new block
+// with the access pattern of the timestream kernels (1024 rows in flight, 1024-sample chunks per workgroup); returns
+// the time in ms.  The block holds nothing yet.
+__global__ __launch_bounds__(kThreads) void k_probe_stream(double * __restrict__ p, int64_t row_len, double one) {
+    double * row = p + (int64_t)blockIdx.x * row_len;
+    for (int64_t c0 = (int64_t)blockIdx.y * 1024; c0 < row_len; c0 += (int64_t)gridDim.y * 1024) {
+        for (int i = threadIdx.x; i < 1024 && c0 + i < row_len; i += kThreads) row[c0 + i] = row[c0 + i] * one;
+    }
+}
+
+}  // namespace
+
+namespace toast_hip {
+double probe_stream_ms(void * block, size_t bytes, hipStream_t st) {
+    const int64_t rows = 1024;
+    const int64_t row_len = (int64_t)(bytes / sizeof(double)) / rows;
+    if (row_len < 1024) return 0.0;
+    hipEvent_t e0, e1;
+    TH_HIP(hipEventCreate(&e0));
+    TH_HIP(hipEventCreate(&e1));
+    int64_t gy = (row_len + 1023) / 1024;
+    if (gy > 65535) gy = 65535;
+    float best = 1e30f;
+    for (int rep = 0; rep < 2; ++rep) {   // the first pass also pays the first touch of the block
+        TH_HIP(hipEventRecord(e0, st));
+        hipLaunchKernelGGL(k_probe_stream, dim3((unsigned)rows, (unsigned)gy), dim3(kThreads), 0, st,
+                           static_cast<double *>(block), row_len, 1.0);
+        TH_HIP(hipEventRecord(e1, st));
+        TH_HIP(hipEventSynchronize(e1));
+        float ms = 0.0f;
+        TH_HIP(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return (double)best;
+}
+}  // namespace toast_hip

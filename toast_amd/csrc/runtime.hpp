@@ -94,6 +94,8 @@ private:
 };
 
 size_t pin_threshold();
+// kernels.hip: time of a read + write pass over a new device block with the timestream kernels' access pattern
+double probe_stream_ms(void * block, size_t bytes, hipStream_t stream);
 
 // Transfers between pageable application memory and the device, through a page-locked bounce ring owned by the library
 // (two 4 MB slots, copy of slot k overlapped with the host memcpy of slot k+1).  The HIP runtime never sees pageable
