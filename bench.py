@@ -20,7 +20,8 @@ HBM when timing starts.  With N GPUs every rank holds its own 1024 detectors of 
 detector focalplane observing the same scan (weak scaling, detector-sharded like configs[3]).
 
 Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2]
-        (N > 1 is launched by torch.distributed.run, one rank per GPU)
+        (N > 1: one rank per GPU -- either launched by torch.distributed.run, or, when called
+        as plain `python bench.py --gpus N`, bench.py starts that launcher itself as a child process)
 """
 
 import argparse
@@ -129,8 +130,33 @@ def operator_level():
     }
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` outside a launcher: start N ranks (one per GPU) as a FRESH child
+    `python -m torch.distributed.run ... bench.py <same arguments>`, relay its output and return its exit code.
+    This process has not touched the GPU (torch is not even imported yet) and it never replaces itself: the
+    ranks are children, the parent only waits."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in proc.stdout:            # rank 0's JSON line (and nothing else of ours) comes through here
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
     import torch
     import torch.distributed as dist
 
@@ -138,8 +164,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
     # TOAST_BENCH_SHARE_GPU=1 (tests only): several ranks on the GPUs that exist, collectives over
     # gloo -- lets the N > 1 code path run on a single-GPU box.  Numbers from such a run mean nothing.
     share = os.environ.get("TOAST_BENCH_SHARE_GPU", "0") == "1"

@@ -73,3 +73,22 @@ def test_bench_two_ranks_code_path():
     assert d["kernel_ms"]["allreduce"] > 0 and d["allreduce"]["backend"] == "gloo"
     sh = d["configs3_shard"]
     assert sh["config"]["workload"] == "cfg2" and sh["value"] > 0 and sh["allreduce"]["bytes"] > 0
+
+
+def test_bench_self_launch_two_ranks():
+    """Exactly the driver's command form `python3 bench.py --gpus 2 ...` (no launcher, no RANK in the
+    environment): bench.py starts torch.distributed.run itself as a child process and relays rank 0's one
+    JSON line.  Both ranks share the one GPU here (TOAST_BENCH_SHARE_GPU=1, gloo)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR",
+                                                             "MASTER_PORT")}
+    env.update(TOAST_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup",
+                          "1", "--workload", "mini", "--no-fft"], capture_output=True, text=True, timeout=900,
+                         cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["allreduce"]["bytes"] > 0 and d["allreduce"]["ms"] > 0
+    n = d["config"]["detectors_per_gpu"] * d["config"]["samples_per_detector"]
+    assert abs(d["value"] - 2 * n / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]

@@ -67,8 +67,10 @@ def test_rccl_two_ranks_mapmaker_equals_single_process():
 def test_bench_two_gpus_over_rccl():
     if _n_gpus() < 2:
         pytest.skip("needs two GPUs")
-    out = _torchrun(2, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--workload",
-                    "mini", "--no-cpu-baseline", "--no-fft", port=29547)
+    # the driver's own command form: bench.py launches its ranks itself
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup",
+                          "1", "--workload", "mini", "--no-cpu-baseline", "--no-fft"], capture_output=True, text=True,
+                         env=_env(), timeout=1200, cwd=ROOT)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-6000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["allreduce"]["backend"] == "nccl"
