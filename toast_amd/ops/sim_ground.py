@@ -4,8 +4,8 @@ BASELINE configs[4]'s pointing inputs.
 Reference: src/toast/ops/sim_ground.py:61-1270 (operator), src/toast/ops/sim_ground_utils.py:458-753
 (``simulate_ces_scan``).  This is input generation and runs on the host in the reference too
 (NumPy interpolation of one high-resolution scan / turnaround cycle); nothing here is on the
-A / A^T path.  Reproduced: the azimuth profile with finite-acceleration turnarounds (bit-identical
-restatement of ``simulate_ces_scan``, pinned to the reference function's own outputs in
+A / A^T path.  Reproduced: the azimuth profile with finite-acceleration turnarounds (``CesCycle``: the
+scan cycle written down from its geometry; outputs pinned bit for bit to the reference function's in
 tests/golden/sim_ground.npz), optional cosecant modulation and randomised phase, the seven
 interval lists (scan / turn / throw, left-right and right-left) plus ``scanning`` / ``turnaround`` /
 ``throw``, turnaround bits in the shared flags (``FlagIntervals`` with ``turnaround_mask``), the
@@ -31,148 +31,117 @@ from ..traits import Bool, Float, Instance, Int, Unicode
 from .operator import Operator
 
 
-def simulate_stare(t_start, t_stop, rate, el, az):
-    """sim_ground_utils.py:435-455: no motion, no intervals."""
-    samples = int((t_stop - t_start) * rate)
-    times = t_start + np.arange(samples) / rate
-    az_sample = np.zeros(samples) + az
-    el_sample = np.zeros(samples) + el
-    return times, az_sample, el_sample, az, az, [], [], [], [], [], []
+class CesCycle:
+    """One period of a constant-elevation scan as a closed piece of geometry.
+
+    The mount sweeps the throw [az_lo, az_hi] at a constant azimuth rate (or, with
+    ``cosecant`` set, at a constant rate of cos(az), which keeps the integration depth per
+    declination stripe flat), reverses with the constant acceleration ``accel`` over
+    2 * rate / accel seconds -- a parabola leaving and re-entering the throw edge at the sweep
+    rate -- sweeps back and reverses again: period = 2 * (sweep + turn).
+
+    The cycle is sampled as a knot table (linear interpolation between knots happens in
+    ``simulate_ces_scan``): a constant-rate sweep is exact with its two end knots, curved pieces get
+    ``nstep`` knots.  Bit-identity with the reference's outputs (tests/golden/sim_ground.npz) fixes
+    the rounding order of the two curve expressions below and nothing else."""
+
+    def __init__(self, el, az_lo, az_hi, az_rate, on_sky, accel, cosecant, nstep):
+        self.shift = 0.0
+        if cosecant:
+            # constant d(cos az)/dt only makes sense inside one half of the circle: fold the throw into
+            # [0, pi) and put the western half back afterwards
+            if az_lo > np.pi:
+                self.shift = np.pi
+            az_lo, az_hi = az_lo % np.pi, az_hi % np.pi
+            if az_lo > az_hi:
+                raise RuntimeError("Cannot scan across zero meridian with cosecant-modulated scan")
+        elif az_hi < az_lo:
+            az_hi += 2 * np.pi          # throw across north
+        self.az_lo, self.az_hi, self.cosecant, self.nstep, self.accel = az_lo, az_hi, cosecant, nstep, accel
+        self.rate = az_rate / np.cos(el) if on_sky else az_rate
+        if cosecant:
+            self.sweep = (np.cos(az_lo) - np.cos(az_hi)) / self.rate
+            self.edge_rate = self.rate / np.abs(np.sin(az_lo))   # both turnarounds use the rate at the low edge
+        else:
+            self.sweep = (az_hi - az_lo) / self.rate
+            self.edge_rate = self.rate
+        self.turn = 2 * self.edge_rate / accel
+        self.period = 2 * self.sweep + 2 * self.turn
+
+    def segments(self, t0):
+        """Start / stop times of the four pieces of the cycle that starts at t0, shape (4, 2), in the
+        order sweep up, turn at the high edge, sweep down, turn at the low edge."""
+        edges = np.cumsum([t0, self.sweep, self.turn, self.sweep, self.turn])   # each piece starts where the last ended
+        return np.column_stack((edges[:-1], edges[1:]))
+
+    def _sweep_knots(self, span, az_from, az_to, direction):
+        if not self.cosecant:
+            return np.array(span), np.array([az_from, az_to])
+        t = np.linspace(span[0], span[1], self.nstep, endpoint=True)
+        return t, np.arccos((np.cos(az_from) + direction * (self.rate * span[0])) - direction * (self.rate * t))
+
+    def _turn_knots(self, span, az_edge, direction):
+        # interior knots only: the end points are the neighbouring sweeps' knots
+        t = np.linspace(span[0], span[1], self.nstep, endpoint=True)[1:-1]
+        tau = t - span[0]
+        return t, (az_edge + direction * (tau * self.edge_rate)) - direction * (0.5 * self.accel * tau**2)
+
+    def knots(self, t0):
+        """(t, az) knot table of one period; the closing knot at t0 + period is left to the next period."""
+        up, top, down, bottom = self.segments(t0)
+        pieces = (self._sweep_knots(up, self.az_lo, self.az_hi, +1.0), self._turn_knots(top, self.az_hi, +1.0),
+                  self._sweep_knots(down, self.az_hi, self.az_lo, -1.0), self._turn_knots(bottom, self.az_lo, -1.0))
+        t = np.concatenate([p[0] for p in pieces])
+        az = np.concatenate([p[1] for p in pieces])
+        if az.min() < -2 * np.pi:
+            az += 2 * np.pi
+        if az.max() > 2 * np.pi:
+            az -= 2 * np.pi
+        return t, az + self.shift if self.shift else az
+
+
+def _clip_tail(spans, t_last):
+    """The reference trims only the very last span of each list against the last time stamp (and, through
+    a slip in its head test, never the first): later consumers intersect with the sample range anyway
+    (``timespans_to_samples``).  Same lists here, so that they compare equal span for span."""
+    if spans[-1, 0] > t_last:
+        spans = spans[:-1]
+    elif spans[-1, 1] > t_last:
+        spans[-1, 1] = t_last
+    return [(float(a), float(b)) for a, b in spans]
 
 
 def simulate_ces_scan(t_start, t_stop, rate, el, az_min, az_max, az_start, az_rate, fix_rate_on_sky, az_accel,
                       scan_min_az, scan_max_az, cosecant_modulation=False, nstep=10000, randomize_phase=False):
-    """One constant-elevation scan (angles in radians, rates in rad/s, times in s): a full
-    left-right / turnaround / right-left / turnaround cycle is built at high resolution and
-    interpolated to the sample times (sim_ground_utils.py:458-753, without ``track_azimuth``).
-    Returns (times, az, el, min_az, max_az, scan_leftright, turn_leftright, scan_rightleft,
-    turn_rightleft, throw_leftright, throw_rightleft) with the interval lists as time spans."""
+    """Azimuth / elevation of one constant-elevation scan sampled at ``rate`` Hz from t_start to t_stop
+    (radians, rad/s, seconds), plus the time spans of its sweeps, turnarounds and throws (sweep extended by
+    half a turnaround on both sides).  Same outputs as src/toast/ops/sim_ground_utils.py:458-753 without
+    ``track_azimuth``: (times, az, el, min_az, max_az, scan_leftright, turn_leftright, scan_rightleft,
+    turn_rightleft, throw_leftright, throw_rightleft).  A zero-width throw is a stare: constant
+    azimuth, no spans (:435-455)."""
+    n_samp = int((t_stop - t_start) * rate)
+    times = t_start + np.arange(n_samp) / rate
+    el_samp = np.full(n_samp, 0.0) + el
     if np.abs(az_min - az_max) < 1e-10:
-        return simulate_stare(t_start, t_stop, rate, el, az_min)
-    mirror_cosecant = False
-    if cosecant_modulation:
-        if az_min > np.pi:
-            mirror_cosecant = True
-        az_min %= np.pi
-        az_max %= np.pi
-        if az_min > az_max:
-            raise RuntimeError("Cannot scan across zero meridian with cosecant-modulated scan")
-    elif az_max < az_min:
-        az_max += 2 * np.pi
-    base_rate = az_rate / np.cos(el) if fix_rate_on_sky else az_rate
-    scan_accel = az_accel
-    if cosecant_modulation:
-        scan_time = (np.cos(az_min) - np.cos(az_max)) / base_rate
-        dazdt = base_rate / np.abs(np.sin(az_min))
-    else:
-        scan_time = (az_max - az_min) / base_rate
-        dazdt = base_rate
-    turnaround_time = 2 * dazdt / scan_accel
-    scan_pair_time = 2 * scan_time + 2 * turnaround_time
-    az_drift = 0
-    drift_time = 0
-    all_t, all_az = [], []
-    # left-to-right
-    t0 = t_start
-    t1 = t0 + scan_time + drift_time
-    if cosecant_modulation:
-        tvec = np.linspace(t0, t1, nstep, endpoint=True)
-        azvec = np.arccos(np.cos(az_min) + base_rate * t0 - base_rate * tvec)
-    else:
-        tvec = np.array([t0, t1 + drift_time])
-        azvec = np.array([az_min, az_max + az_drift])
-    all_t.append(np.array(tvec))
-    all_az.append(np.array(azvec))
-    range_scan_leftright = (t0, t1)
-    # turnaround
-    t0 = t1
-    az0 = az_max + az_drift
-    t1 = t0 + turnaround_time
-    tvec = np.linspace(t0, t1, nstep, endpoint=True)[1:]
-    azvec = az0 + (tvec - t0) * dazdt - 0.5 * scan_accel * (tvec - t0) ** 2
-    all_t.append(np.array(tvec[:-1]))
-    all_az.append(np.array(azvec[:-1]))
-    range_turn_leftright = (t0, t1)
-    # right-to-left
-    t0 = t1
-    t1 = t0 + scan_time - drift_time
-    if cosecant_modulation:
-        tvec = np.linspace(t0, t1, nstep, endpoint=True)
-        azvec = np.arccos(np.cos(az_max) - base_rate * t0 + base_rate * tvec)
-    else:
-        tvec = np.array([t0, t1])
-        azvec = np.array([az_max + az_drift, az_min + 2 * az_drift])
-    all_t.append(np.array(tvec))
-    all_az.append(np.array(azvec))
-    range_scan_rightleft = (t0, t1)
-    # turnaround
-    t0 = t1
-    az0 = az_min + 2 * az_drift
-    t1 = t0 + turnaround_time
-    tvec = np.linspace(t0, t1, nstep, endpoint=True)[1:]
-    azvec = az0 - (tvec - t0) * dazdt + 0.5 * scan_accel * (tvec - t0) ** 2
-    all_t.append(np.array(tvec))
-    all_az.append(np.array(azvec))
-    range_turn_rightleft = (t0, t1)
-    tvec = np.hstack(all_t)
-    azvec = np.hstack(all_az)
-    if np.amin(azvec) < -2 * np.pi:
-        azvec += 2 * np.pi
-    if np.amax(azvec) > 2 * np.pi:
-        azvec -= 2 * np.pi
-    if mirror_cosecant:
-        azvec += np.pi
-    n_repeat = int((t_stop - t_start) / scan_pair_time)
-    n_repeat += 2
-    tvec = tvec[:-1]
-    azvec = azvec[:-1]
-    t, az = [], []
-    for i in range(n_repeat):
-        t.append(tvec + i * scan_pair_time)
-        az.append(azvec + i * 2 * az_drift)
-    tvec = np.hstack(t)
-    azvec = np.hstack(az)
-    new_min_az = min(scan_min_az, np.min(azvec))
-    new_max_az = max(scan_max_az, np.max(azvec))
-    samples = int((t_stop - t_start) * rate)
-    times = t_start + np.arange(samples) / rate
-    if randomize_phase:
-        np.random.seed(int(t_start % 2**32))
-        t_off = scan_pair_time * np.random.rand()
-    else:
-        t_off = 0
-    az_sample = np.interp(times + t_off, tvec, azvec)
-    el_sample = np.zeros_like(az_sample) + el
-    ival = {k: [] for k in ("scan_lr", "scan_rl", "turn_lr", "turn_rl", "throw_lr", "throw_rl")}
-    t_off = -t_off
-    for _ in range(n_repeat):
-        ival["scan_lr"].append((range_scan_leftright[0] + t_off, range_scan_leftright[1] + t_off))
-        ival["turn_lr"].append((range_turn_leftright[0] + t_off, range_turn_leftright[1] + t_off))
-        ival["scan_rl"].append((range_scan_rightleft[0] + t_off, range_scan_rightleft[1] + t_off))
-        ival["turn_rl"].append((range_turn_rightleft[0] + t_off, range_turn_rightleft[1] + t_off))
-        half_turn_lr = 0.5 * (range_turn_leftright[1] - range_turn_leftright[0])
-        half_turn_rl = 0.5 * (range_turn_rightleft[1] - range_turn_rightleft[0])
-        ival["throw_lr"].append((range_scan_leftright[0] + t_off - half_turn_rl,
-                                 range_scan_leftright[1] + t_off + half_turn_lr))
-        ival["throw_rl"].append((range_scan_rightleft[0] + t_off - half_turn_lr,
-                                 range_scan_rightleft[1] + t_off + half_turn_rl))
-        t_off += scan_pair_time
-    # trim to the time stamps (the reference tests ival[-1] where it means ival[0]; same outcome
-    # for the first element whenever the list is longer than one entry -- kept literally)
-    for key in ("scan_lr", "scan_rl", "turn_lr", "turn_rl", "throw_lr", "throw_rl"):
-        lst = ival[key]
-        first = tuple(lst[-1])
-        if first[1] < times[0]:
-            del lst[0]
-        elif first[0] < times[0]:
-            lst[0] = (times[0], first[1])
-        last = tuple(lst[-1])
-        if last[0] > times[-1]:
-            del lst[-1]
-        elif last[1] > times[-1]:
-            lst[-1] = (last[0], times[-1])
-    return (times, az_sample, el_sample, new_min_az, new_max_az, ival["scan_lr"], ival["turn_lr"], ival["scan_rl"],
-            ival["turn_rl"], ival["throw_lr"], ival["throw_rl"])
+        return times, np.full(n_samp, 0.0) + az_min, el_samp, az_min, az_min, [], [], [], [], [], []
+    cyc = CesCycle(el, az_min, az_max, az_rate, fix_rate_on_sky, az_accel, cosecant_modulation, nstep)
+    n_cycle = int((t_stop - t_start) / cyc.period) + 2      # covers the phase offset and the tail
+    t1, az1 = cyc.knots(t_start)
+    lag = np.arange(n_cycle)[:, None] * cyc.period
+    t_knot = (t1[None, :] + lag).ravel()
+    az_knot = np.tile(az1, n_cycle)
+    # where in the cycle the scan begins: its start, or a point drawn from the start time's own seed
+    phase = cyc.period * np.random.RandomState(int(t_start % 2**32)).random_sample() if randomize_phase else 0.0
+    az_samp = np.interp(times + phase, t_knot, az_knot)
+    # spans of cycle k = spans of the first cycle moved by k periods (summed up one by one), minus the phase
+    moves = np.cumsum(np.concatenate(([-phase], np.full(n_cycle - 1, cyc.period))))[:, None]
+    up, top, down, bottom = cyc.segments(t_start)
+    half_top, half_bottom = 0.5 * (top[1] - top[0]), 0.5 * (bottom[1] - bottom[0])
+    throw_up = ((up + moves) + np.array([-half_bottom, half_top]))
+    throw_down = ((down + moves) + np.array([-half_top, half_bottom]))
+    lists = [_clip_tail(x, times[-1]) for x in (up + moves, top + moves, down + moves, bottom + moves, throw_up,
+                                                throw_down)]
+    return (times, az_samp, el_samp, min(scan_min_az, az_knot.min()), max(scan_max_az, az_knot.max()), *lists)
 
 
 def timespans_to_samples(times, timespans):
