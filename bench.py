@@ -496,8 +496,31 @@ def run(args, workload, world, rank, dev, headline=True):
     roofline["stream_ceiling"] = {
         "read_write_GBs": stream_rw,
         "frac_of_read_write_stream": ach / stream_rw,
-        "note": "k_noise_weight, a pure 8 B read + 8 B write per sample stream over the same work buffer",
+        "note": "k_noise_weight_v2, a pure read + write stream (16 B per lane and access) over the same work buffer",
     }
+    # the same three kernels with one sample per lane (8-byte lane accesses) and two consecutive samples per lane
+    # (16-byte lane accesses; the default), same buffers, same process
+    if headline:
+        lanes = {}
+        bnw_only = lambda: D.build_noise_weighted(d_g2l.data_ptr(), d_zmap.data_ptr(), nps, nnz, idx, d_pixels.data_ptr(),
+                                                  idx, d_weights.data_ptr(), idx, d_tod.data_ptr(), idx,
+                                                  d_dflags.data_ptr(), n_samp, det_scale, 1, n_samp, ivl,
+                                                  d_sflags.data_ptr(), n_samp, 1, stream)
+        scan_only = lambda: D.scan_map(np.float64, d_g2l.data_ptr(), nps, d_zmap.data_ptr(), nnz, d_tod2.data_ptr(), idx,
+                                       d_pixels.data_ptr(), idx, d_weights.data_ptr(), idx, n_samp, ivl, 1.0, False, True,
+                                       False, det_w, stream)
+        rw_only = lambda: D.noise_weight(d_tod2.data_ptr(), n_samp, idx, ivl, ones, stream)
+        for v2, name in ((0, "one_sample_per_lane"), (1, "two_samples_per_lane")):
+            capi.set_tuning("vec2", v2)
+            for fn in (bnw_only, scan_only, rw_only):
+                fn()
+            t_b, t_s, t_r = timed(bnw_only, 3), timed(scan_only, 3), timed(rw_only, 3)
+            lanes[name] = {"build_noise_weighted_ms": t_b, "scan_map_ms": t_s, "read_write_stream_ms": t_r,
+                           "build_noise_weighted_GBs": BYTES_BNW * nsamp_tot / t_b / 1e6,
+                           "scan_map_GBs": BYTES_SCAN * nsamp_tot / t_s / 1e6,
+                           "read_write_stream_GBs": 16.0 * nsamp_tot / t_r / 1e6}
+        capi.set_tuning("vec2", 1)
+        roofline["lane_width"] = lanes
 
     out = {
         "metric": "detector-samples/sec through one PCG (A^T N^-1 A) iteration",

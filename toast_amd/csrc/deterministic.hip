@@ -103,7 +103,8 @@ __global__ __launch_bounds__(kDetThreads) void k_det_keys(const DetArgs a, uint6
             uint64_t key = sentinel;
             if ((p >= 0) && ((fd & a.dmask) == 0) && ((fs & a.smask) == 0)) {
                 const int64_t gsm = fastdiv(p, a.nps_div);
-                key = (uint64_t)(a.g2l[gsm] * nps + (p - gsm * nps));
+                const int64_t lsm = a.g2l[gsm];
+                if (lsm >= 0) key = (uint64_t)(lsm * nps + (p - gsm * nps));   // non-local submap: sentinel
             }
             keys[base + i] = key;
             vals[base + i] = (uint32_t)((int64_t)det_local * a.n_samp + s);

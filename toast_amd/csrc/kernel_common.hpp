@@ -149,6 +149,41 @@ __device__ __forceinline__ void scatter_runs(int64_t (&key)[E], double (&v)[E][N
     }
 }
 
+// Two CONSECUTIVE samples per lane (A before B): a wave then reduces runs over 128 samples with one segmented scan.
+// A joins B inside the lane when their keys agree; otherwise A ends the run of the previous lanes and is handed to the
+// previous lane (DPP wave_shl:1) when that lane's B carries the same key, or -- a run of one sample, or lane 0 --
+// goes to the map by itself.  The scan then runs over the B keys.
+constexpr int kDppWaveShl1 = 0x130;    // lane i reads lane i + 1 of the wave
+
+template <int NNZ>
+__device__ __forceinline__ void scatter_runs2(int64_t ka, double (&va)[NNZ], int64_t kb, double (&vb)[NNZ],
+                                              double * __restrict__ zmap) {
+    const int lane = threadIdx.x & 63;
+    const bool same = ka == kb;
+    const bool apart = !same & (ka >= 0);
+    if (same) {
+#pragma unroll
+        for (int k = 0; k < NNZ; ++k) vb[k] += va[k];
+    }
+    if (__any(apart)) {
+        const int64_t prev_b = dpp_i64<kDppWaveShr1>(kb);
+        const bool give = apart & (lane > 0) & (prev_b == ka);
+#pragma unroll
+        for (int k = 0; k < NNZ; ++k) vb[k] += dpp_f64<kDppWaveShl1>(give ? va[k] : 0.0);
+        if (apart & !give) {
+            double * z = zmap + NNZ * ka;
+#pragma unroll
+            for (int k = 0; k < NNZ; ++k) unsafeAtomicAdd(z + k, va[k]);
+        }
+    }
+    const bool tail = wave_run_reduce<NNZ>(kb, vb);
+    if (tail && kb >= 0) {
+        double * z = zmap + NNZ * kb;
+#pragma unroll
+        for (int k = 0; k < NNZ; ++k) unsafeAtomicAdd(z + k, vb[k]);
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // host helpers
 // ------------------------------------------------------------------------------------

@@ -309,9 +309,10 @@ __global__ __launch_bounds__(kThreads) void k_scan_map(
 #pragma unroll
                 for (int k = 0; k < NNZ; ++k) wk[k] = w[k];
             }
-            if (p >= 0) {
-                const int64_t gsm = fastdiv(p, nps_div);
-                const int64_t lsm = g2l[gsm];
+            // (a pixel in a submap that is not local leaves the sample alone; the reference reads in front of the map)
+            const int64_t gsm = fastdiv(p >= 0 ? p : 0, nps_div);
+            const int64_t lsm = g2l[gsm];
+            if ((p >= 0) & (lsm >= 0)) {
                 const int64_t sub = p - gsm * nps;
                 const T * m = map + nnz * (lsm * nps + sub);
                 double v = 0.0;
@@ -330,6 +331,98 @@ __global__ __launch_bounds__(kThreads) void k_scan_map(
                     d += v;
                 }
             }
+            if (fuse) d *= dw;
+            drow[s] = d;
+        }
+    }
+}
+
+// Two consecutive samples per lane: the pixel pair and the timestream pair are one 16-byte lane access each, the two
+// weight triples three of them over 48 contiguous bytes, the result one 16-byte store (a wave covers 1 KiB / 3 KiB
+// contiguous per load instruction instead of 512 B / three interleaved 24-byte strides).  Needs every row to start on a
+// 16-byte boundary (even n_samp, checked by the launcher); a chunk that starts on an odd sample peels it, an odd tail is
+// handled by one lane.  Per-sample arithmetic identical to k_scan_map (same expression, same order).
+// One sample of scan_map in three straight-line stages, so that a lane holding several samples issues all their
+// gathers of one stage together (a test on a loaded value must not guard the next load): a sample without
+// a pixel (or whose submap is not local) gathers map element 0 and discards it.
+struct ScanGather {
+    int64_t off;   // element offset of the pixel's first map value
+    bool hit;
+};
+
+__device__ __forceinline__ int64_t scan_submap(int64_t p, const FastDiv & nps_div) {
+    return fastdiv(p >= 0 ? p : 0, nps_div);
+}
+
+__device__ __forceinline__ ScanGather scan_locate(int64_t p, int64_t gsm, int64_t lsm, const FastDiv & nps_div) {
+    ScanGather g;
+    g.hit = (p >= 0) & (lsm >= 0);
+    g.off = g.hit ? 3 * (lsm * nps_div.d + (p - gsm * nps_div.d)) : 0;
+    return g;
+}
+
+__device__ __forceinline__ double scan_combine(bool hit, double d, double w0, double w1, double w2, double m0, double m1,
+                                               double m2, double scale, int subtract, int mult) {
+    double v = 0.0;
+    v += w0 * m0;
+    v += w1 * m1;
+    v += w2 * m2;
+    v *= scale;
+    const double r = subtract ? d - v : (mult ? d * v : d + v);
+    return hit ? r : d;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void k_scan_map_v2(
+    const Chunk * __restrict__ chunks, int n_chunks, const int32_t * __restrict__ d_idx,
+    const int32_t * __restrict__ p_idx, const int32_t * __restrict__ w_idx,
+    const int64_t * __restrict__ g2l, const T * __restrict__ map, double * __restrict__ tod,
+    const int64_t * __restrict__ pixels, const double * __restrict__ weights,
+    FastDiv nps_div, double scale, int zero, int subtract, int mult,
+    const double * __restrict__ det_w, int64_t n_samp) {
+    const int det = blockIdx.x;
+    double * drow = tod + (int64_t)d_idx[det] * n_samp;
+    const int64_t * prow = pixels + (int64_t)p_idx[det] * n_samp;
+    const double * wrow = weights + (int64_t)w_idx[det] * n_samp * 3;
+    const bool fuse = det_w != nullptr;
+    const double dw = fuse ? det_w[det] : 1.0;
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        const int head = (int)(c.first & 1);
+        const int64_t s0 = c.first + head;          // even
+        const int n_pair = (c.count - head) >> 1;
+        for (int j = threadIdx.x; j < n_pair; j += kThreads) {
+            const int64_t s = s0 + 2 * (int64_t)j;
+            const longlong2 pp = *reinterpret_cast<const longlong2 *>(prow + s);
+            double2 dd = make_double2(0.0, 0.0);
+            if (!zero) dd = *reinterpret_cast<const double2 *>(drow + s);
+            const double2 * wv = reinterpret_cast<const double2 *>(wrow + 3 * s);
+            const double2 wa = wv[0], wb = wv[1], wc = wv[2];
+            const int64_t ga = scan_submap(pp.x, nps_div), gb = scan_submap(pp.y, nps_div);
+            const int64_t la = g2l[ga], lb = g2l[gb];
+            const ScanGather qa = scan_locate(pp.x, ga, la, nps_div), qb = scan_locate(pp.y, gb, lb, nps_div);
+            const T * ma = map + qa.off;
+            const T * mb = map + qb.off;
+            const T a0 = ma[0], a1 = ma[1], a2 = ma[2], b0 = mb[0], b1 = mb[1], b2 = mb[2];
+            dd.x = scan_combine(qa.hit, dd.x, wa.x, wa.y, wb.x, (double)a0, (double)a1, (double)a2, scale, subtract, mult);
+            dd.y = scan_combine(qb.hit, dd.y, wb.y, wc.x, wc.y, (double)b0, (double)b1, (double)b2, scale, subtract, mult);
+            if (fuse) {
+                dd.x *= dw;
+                dd.y *= dw;
+            }
+            *reinterpret_cast<double2 *>(drow + s) = dd;
+        }
+        // the peeled first sample and the odd last one: lanes 0 and 1 of the workgroup
+        const int tail = (c.count - head) & 1;
+        if ((threadIdx.x == 0 && head) || (threadIdx.x == 1 && tail)) {
+            const int64_t s = (threadIdx.x == 0) ? c.first : c.first + c.count - 1;
+            const double * w = wrow + 3 * s;
+            const int64_t p = prow[s];
+            const int64_t gs = scan_submap(p, nps_div);
+            const ScanGather q = scan_locate(p, gs, g2l[gs], nps_div);
+            const T * m = map + q.off;
+            double d = scan_combine(q.hit, zero ? 0.0 : drow[s], w[0], w[1], w[2], (double)m[0], (double)m[1], (double)m[2],
+                                    scale, subtract, mult);
             if (fuse) d *= dw;
             drow[s] = d;
         }
@@ -470,6 +563,133 @@ __global__ __launch_bounds__(kThreads) void k_build_noise_weighted_pair(
                 }
             }
             scatter_runs<NNZ, 2>(key, v, zmap);
+        }
+    }
+}
+
+// Two consecutive samples per lane and E = 1 or 2 detectors per workgroup (nnz = 3): 16-byte lane accesses for pixels
+// and timestream, 3 x 16 bytes for the two weight triples, 2 bytes for the two flags; one segmented scan per 128
+// samples (scatter_runs2).  Rows start on 16-byte boundaries (even n_samp, checked by the launcher); the odd first /
+// last sample of a chunk is added by one lane with plain atomics.
+template <int E>
+__global__ __launch_bounds__(kThreads) void k_build_noise_weighted_v2(
+    const Chunk * __restrict__ chunks, int n_chunks, int n_det, const int32_t * __restrict__ p_idx,
+    const int32_t * __restrict__ w_idx, const int32_t * __restrict__ d_idx,
+    const int32_t * __restrict__ f_idx, const double * __restrict__ det_scale,
+    const int64_t * __restrict__ g2l, double * __restrict__ zmap,
+    const int64_t * __restrict__ pixels, const double * __restrict__ weights,
+    const double * __restrict__ tod, const uint8_t * __restrict__ dflags, uint8_t dmask,
+    int use_dflags, const uint8_t * __restrict__ sflags, uint8_t smask, int use_sflags,
+    FastDiv nps_div, int64_t n_samp) {
+    constexpr int NNZ = 3;
+    const int det0 = E * blockIdx.x;
+    int dets[E];
+    bool on[E];
+    const int64_t * prow[E];
+    const double * wrow[E];
+    const double * drow[E];
+    const uint8_t * frow[E];
+    double ds[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        on[e] = det0 + e < n_det;
+        dets[e] = on[e] ? det0 + e : det0;
+        prow[e] = pixels + (int64_t)p_idx[dets[e]] * n_samp;
+        wrow[e] = weights + (int64_t)w_idx[dets[e]] * n_samp * NNZ;
+        drow[e] = tod + (int64_t)d_idx[dets[e]] * n_samp;
+        frow[e] = use_dflags ? dflags + (int64_t)f_idx[dets[e]] * n_samp : nullptr;
+        ds[e] = det_scale[dets[e]];
+    }
+    const int64_t nps = nps_div.d;
+    const uint16_t dmask2 = (uint16_t)(dmask | (dmask << 8));
+    const uint16_t smask2 = (uint16_t)(smask | (smask << 8));
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        const int head = (int)(c.first & 1);
+        const int64_t s0 = c.first + head;          // even
+        const int n_pair = (c.count - head) >> 1;
+        for (int base = 0; base < n_pair; base += kThreads) {
+            const int j = base + threadIdx.x;
+            const bool active = j < n_pair;
+            const int64_t s = s0 + 2 * (int64_t)(active ? j : 0);
+            int64_t ka[E], kb[E];
+            double va[E][NNZ], vb[E][NNZ];
+            // all streaming loads of both samples of all detectors first (inactive lanes re-read pair 0: same lines)
+            longlong2 pp[E];
+            double2 tt[E], w0[E], w1[E], w2[E];
+            uint16_t fd[E];
+            const uint16_t fs = use_sflags ? *reinterpret_cast<const uint16_t *>(sflags + s) : (uint16_t)0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                pp[e] = *reinterpret_cast<const longlong2 *>(prow[e] + s);
+                fd[e] = use_dflags ? *reinterpret_cast<const uint16_t *>(frow[e] + s) : (uint16_t)0;
+                tt[e] = *reinterpret_cast<const double2 *>(drow[e] + s);
+                const double2 * wv = reinterpret_cast<const double2 *>(wrow[e] + NNZ * s);
+                w0[e] = wv[0];
+                w1[e] = wv[1];
+                w2[e] = wv[2];
+            }
+            // global2local of every sample in one round trip (sample without a pixel: submap 0, discarded)
+            int64_t ga[E], gb[E], la[E], lb[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                ga[e] = fastdiv(pp[e].x >= 0 ? pp[e].x : 0, nps_div);
+                gb[e] = fastdiv(pp[e].y >= 0 ? pp[e].y : 0, nps_div);
+                la[e] = g2l[ga[e]];
+                lb[e] = g2l[gb[e]];
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const uint16_t bad = (uint16_t)((fd[e] & dmask2) | (fs & smask2));
+                const bool good_a = active & on[e] & (pp[e].x >= 0) & ((bad & 0x00ff) == 0);
+                const bool good_b = active & on[e] & (pp[e].y >= 0) & ((bad & 0xff00) == 0);
+                ka[e] = good_a ? la[e] * nps + (pp[e].x - ga[e] * nps) : -1;
+                kb[e] = good_b ? lb[e] * nps + (pp[e].y - gb[e] * nps) : -1;
+                const double sa = tt[e].x * ds[e], sb = tt[e].y * ds[e];
+                va[e][0] = good_a ? sa * w0[e].x : 0.0;
+                va[e][1] = good_a ? sa * w0[e].y : 0.0;
+                va[e][2] = good_a ? sa * w1[e].x : 0.0;
+                vb[e][0] = good_b ? sb * w1[e].y : 0.0;
+                vb[e][1] = good_b ? sb * w2[e].x : 0.0;
+                vb[e][2] = good_b ? sb * w2[e].y : 0.0;
+            }
+            if constexpr (E == 2) {
+                const bool mergeable = ((ka[0] == ka[1]) | (ka[0] < 0) | (ka[1] < 0)) &
+                                       ((kb[0] == kb[1]) | (kb[0] < 0) | (kb[1] < 0));
+                if (__all(mergeable)) {
+                    const int64_t kam = (ka[0] >= 0) ? ka[0] : ka[1];
+                    const int64_t kbm = (kb[0] >= 0) ? kb[0] : kb[1];
+                    double vam[NNZ], vbm[NNZ];
+#pragma unroll
+                    for (int k = 0; k < NNZ; ++k) {
+                        vam[k] = va[0][k] + va[1][k];
+                        vbm[k] = vb[0][k] + vb[1][k];
+                    }
+                    scatter_runs2<NNZ>(kam, vam, kbm, vbm, zmap);
+                    continue;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) scatter_runs2<NNZ>(ka[e], va[e], kb[e], vb[e], zmap);
+        }
+        // the peeled first sample (lane 0) and the odd last one (lane 1)
+        const int tail = (c.count - head) & 1;
+        if ((threadIdx.x == 0 && head) || (threadIdx.x == 1 && tail)) {
+            const int64_t s = (threadIdx.x == 0) ? c.first : c.first + c.count - 1;
+            const uint8_t fs = use_sflags ? sflags[s] : (uint8_t)0;
+            for (int e = 0; e < E; ++e) {
+                if (!on[e]) continue;
+                const int64_t p = prow[e][s];
+                const uint8_t fd = use_dflags ? frow[e][s] : (uint8_t)0;
+                if ((p < 0) | ((fd & dmask) != 0) | ((fs & smask) != 0)) continue;
+                const int64_t gsm = fastdiv(p, nps_div);
+                const int64_t key = g2l[gsm] * nps + (p - gsm * nps);
+                if (key < 0) continue;
+                const double sd = drow[e][s] * ds[e];
+                const double * w = wrow[e] + NNZ * s;
+                double * z = zmap + NNZ * key;
+                for (int k = 0; k < NNZ; ++k) unsafeAtomicAdd(z + k, sd * w[k]);
+            }
         }
     }
 }
@@ -911,6 +1131,29 @@ __global__ __launch_bounds__(kThreads) void k_noise_weight(
     }
 }
 
+// two samples (16 bytes) per lane; rows start on 16-byte boundaries (even n_samp, checked by the launcher)
+__global__ __launch_bounds__(kThreads) void k_noise_weight_v2(
+    const Chunk * __restrict__ chunks, int n_chunks, const int32_t * __restrict__ d_idx,
+    const double * __restrict__ det_w, double * __restrict__ tod, int64_t n_samp) {
+    const int det = blockIdx.x;
+    const double w = det_w[det];
+    double * drow = tod + (int64_t)d_idx[det] * n_samp;
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        const int head = (int)(c.first & 1);
+        double2 * row2 = reinterpret_cast<double2 *>(drow + c.first + head);
+        const int n_pair = (c.count - head) >> 1;
+        for (int j = threadIdx.x; j < n_pair; j += kThreads) {
+            double2 v = row2[j];
+            v.x *= w;
+            v.y *= w;
+            row2[j] = v;
+        }
+        if (threadIdx.x == 0 && head) drow[c.first] *= w;
+        if (threadIdx.x == 1 && ((c.count - head) & 1)) drow[c.first + c.count - 1] *= w;
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // cov_accum_diag_hits / cov_accum_diag_invnpp   [ref: src/libtoast/src/toast_map_cov.cpp:66-153]
 // The reference's kernels behind BuildHitMap / BuildInverseCovariance at the FFI level: one stream of samples with its
@@ -1309,10 +1552,10 @@ __global__ __launch_bounds__(kThreads) void k_offset_scan_project(
                 double wk[NNZ];
 #pragma unroll
                 for (int k = 0; k < NNZ; ++k) wk[k] = w[k];
-                const bool hit = p >= 0;
-                const int64_t pp = hit ? p : 0;
+                const int64_t pp = (p >= 0) ? p : 0;
                 const int64_t gsm = fastdiv(pp, nps_div);
                 int64_t lsm = g2l[gsm];
+                const bool hit = (p >= 0) & (lsm >= 0);   // a pixel in a non-local submap scans nothing
                 lsm = (lsm < 0) ? 0 : lsm;
                 const double * m = map + NNZ * (lsm * nps + (pp - gsm * nps));
                 double sc = 0.0;
@@ -1367,6 +1610,8 @@ __global__ __launch_bounds__(kThreads) void k_test_math(int op, int64_t n, const
 
 namespace {
 
+inline bool rows_16b(const void * p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 template <typename T>
 void launch_scan_map(dim3 grid, hipStream_t st, const Chunk * ch, int n_ch, const int32_t * di,
                      const int32_t * pi, const int32_t * wi, const int64_t * g2l, const void * map,
@@ -1375,6 +1620,11 @@ void launch_scan_map(dim3 grid, hipStream_t st, const Chunk * ch, int n_ch, cons
                      int64_t n_samp) {
     const T * m = static_cast<const T *>(map);
     const int dm = det_major_grid() ? 1 : 0;
+    if (nnz == 3 && !dm && vec2_lanes() && (n_samp & 1) == 0 && rows_16b(tod) && rows_16b(pix) && rows_16b(w)) {
+        hipLaunchKernelGGL((k_scan_map_v2<T>), grid, dim3(kThreads), 0, st, ch, n_ch, di, pi, wi, g2l, m, tod, pix, w,
+                           dv, scale, zero, sub, mult, det_w, n_samp);
+        return;
+    }
     if (dm) grid = dim3(grid.y, grid.x, 1);
     if (nnz == 3) {
         hipLaunchKernelGGL((k_scan_map<T, 3>), grid, dim3(kThreads), 0, st, ch, n_ch, di, pi, wi, g2l,
@@ -1629,7 +1879,18 @@ int toast_hip_build_noise_weighted_dev(
         det_flag_mask, use_d, d_shared_flags, shared_flag_mask, use_s, dv, n_samp
         const int dm = det_major_grid() ? 1 : 0;
         const dim3 g2 = dm ? dim3(grid.y, grid.x, 1) : grid;
-        if (pair_detectors() && !dm && (nnz == 3 || nnz == 1) && n_det >= 2) {
+        const bool v2 = vec2_lanes() && nnz == 3 && !dm && (n_samp & 1) == 0 && rows_16b(d_pixels) &&
+                        rows_16b(d_weights) && rows_16b(d_det_data) && (!use_d || rows_16b(d_det_flags)) &&
+                        (!use_s || rows_16b(d_shared_flags));
+        if (v2) {
+            const bool pr = pair_detectors() && n_det >= 2;
+            const dim3 gp((unsigned)(pr ? (n_det + 1) / 2 : n_det), grid.y, 1);
+            hipLaunchKernelGGL(pr ? k_build_noise_weighted_v2<2> : k_build_noise_weighted_v2<1>, gp, dim3(kThreads), 0, st,
+                               (const Chunk *)(d + o_ch), (int)chunks.size(), (int)n_det, (const int32_t *)(d + o_pi),
+                               (const int32_t *)(d + o_wi), (const int32_t *)(d + o_di), (const int32_t *)(d + o_fi),
+                               (const double *)(d + o_ds), d_g2l, d_zmap, d_pixels, d_weights, d_det_data, d_det_flags,
+                               det_flag_mask, use_d, d_shared_flags, shared_flag_mask, use_s, dv, n_samp);
+        } else if (pair_detectors() && !dm && (nnz == 3 || nnz == 1) && n_det >= 2) {
             const dim3 gp((unsigned)((n_det + 1) / 2), grid.y, 1);
 #define TH_BNW_PAIR_ARGS                                                                          \
     (const Chunk *)(d + o_ch), (int)chunks.size(), (int)n_det, (const int32_t *)(d + o_pi),       \
@@ -1669,7 +1930,8 @@ int toast_hip_noise_weight_dev(double * d_det_data, int64_t n_samp, const int32_
         const size_t o_di = pb.push(data_index, sizeof(int32_t) * n_det);
         const size_t o_w = pb.push(detector_weights, sizeof(double) * n_det);
         const char * d = pb.commit(as_stream(stream));
-        hipLaunchKernelGGL(k_noise_weight, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0,
+        const bool v2 = vec2_lanes() && (n_samp & 1) == 0 && rows_16b(d_det_data);
+        hipLaunchKernelGGL(v2 ? k_noise_weight_v2 : k_noise_weight, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0,
                            as_stream(stream), (const Chunk *)(d + o_ch), (int)chunks.size(),
                            (const int32_t *)(d + o_di), (const double *)(d + o_w), d_det_data, n_samp);
         check_launch();

@@ -173,7 +173,6 @@ __device__ __forceinline__ double dpp_f64_zero_fill(double x) {   // lanes witho
     return __hiloint2double(hi, lo);
 }
 
-constexpr int kDppWaveShl1 = 0x130;  // lane i reads lane i + 1 of the wave
 
 __device__ __forceinline__ void lds_sync() {   // LDS writes of this wave visible to its later reads
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

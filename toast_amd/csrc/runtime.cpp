@@ -62,6 +62,21 @@ bool pair_detectors() {
 }
 void set_pair_detectors(int on) { g_pair = on ? 1 : 0; }
 
+namespace {
+int g_vec2 = -1;   // -1: not read yet
+}
+bool vec2_lanes() {
+    // Two consecutive samples per lane (16-byte lane accesses) in scan_map / build_noise_weighted / noise_weight
+    // (DESIGN.md §4 "16 bytes per lane"); TOAST_HIP_VEC2=0 selects the one-sample-per-lane kernels;
+    // toast_hip_set_tuning("vec2", v) at run time.
+    if (g_vec2 < 0) {
+        const char * e = std::getenv("TOAST_HIP_VEC2");
+        g_vec2 = (e && e[0] == '0') ? 0 : 1;
+    }
+    return g_vec2 != 0;
+}
+void set_vec2_lanes(int on) { g_vec2 = on ? 1 : 0; }
+
 std::vector<Chunk> make_chunks(const toast_hip_interval * ivl, int64_t n_view, int64_t n_samp) {
     std::vector<Chunk> out;
     const int64_t kc = chunk_size();
@@ -827,6 +842,8 @@ int toast_hip_set_tuning(const char * key, int value) {
             set_det_major_grid(value);
         } else if (std::string(key) == "pair") {
             set_pair_detectors(value);
+        } else if (std::string(key) == "vec2") {
+            set_vec2_lanes(value);
         } else {
             fail_arg(std::string("unknown tuning key ") + key);
         }

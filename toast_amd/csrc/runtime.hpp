@@ -111,6 +111,8 @@ bool det_major_grid();
 void set_det_major_grid(int on);
 bool pair_detectors();
 void set_pair_detectors(int on);
+bool vec2_lanes();
+void set_vec2_lanes(int on);
 // TOAST_HIP_STOKES_REFERENCE_NAN=1 / toast_hip_set_stokes_reference_nan(): NaN Q / U weights where the
 // reference's formulation produces them (hpix_math.hpp: stokes_cs2alpha).
 bool stokes_reference_nan();
