@@ -213,6 +213,7 @@ def run(args, workload, world, rank, dev, headline=True):
 
     D = capi.dev
     stream = torch.cuda.current_stream().cuda_stream
+    share = os.environ.get("TOAST_BENCH_SHARE_GPU", "0") == "1"
 
     n_det, n_samp, rate, nside = WORKLOADS[workload]
     nnz = 3
@@ -390,6 +391,51 @@ def run(args, workload, world, rank, dev, headline=True):
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
+    # ------------------------------------------------------------------ the sum over the detector shards
+    # N > 1: the library's own RCCL communicator (toast_hip_comm_*: the collective is enqueued on the kernels' stream,
+    # which is what the operators do) after a check of its results against torch.distributed on this very job; any
+    # failure on any rank makes every rank use torch.distributed's all-reduce instead, and the JSON line says which.
+    comm_impl, comm_note = None, None
+    if world > 1:
+        comm_impl, ok = "torch.distributed", 0
+        if not share and os.environ.get("TOAST_BENCH_COMM", "") != "torch":
+            try:
+                n_r, r_r, _ = D.comm_info()
+                if n_r == 0:
+                    uid = torch.zeros(128, dtype=torch.uint8)
+                    if rank == 0:
+                        uid = torch.frombuffer(bytearray(D.comm_unique_id()), dtype=torch.uint8).clone()
+                    uid = uid.to(dev)
+                    dist.broadcast(uid, src=0)
+                    D.comm_init(bytes(uid.cpu().numpy().tobytes()), world, rank)
+                chk = torch.arange(3 * 4096, dtype=torch.float64, device=dev) * (rank + 1.0)
+                ref_chk = chk.clone()
+                dist.all_reduce(ref_chk)
+                torch.cuda.synchronize()
+                a = chk.clone()
+                D.comm_allreduce(a.data_ptr(), a.numel(), np.float64, "sum", stream)
+                b = chk.clone()
+                D.comm_map_reduce_apply(4096, 3, 0, b.data_ptr(), True, stream)
+                torch.cuda.synchronize()
+                ok = int(torch.equal(a, ref_chk) and torch.allclose(b, ref_chk, rtol=1e-14, atol=0.0))
+                if not ok:
+                    comm_note = "toast_hip_comm results differ from torch.distributed"
+            except Exception as err:    # noqa: BLE001 -- the benchmark must still run
+                comm_note = repr(err)[:300]
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev if not share else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            comm_impl = "toast_hip_comm (RCCL on the kernels' stream)"
+    zmap_count = n_local * nps * nnz
+
+    def allreduce_zmap():
+        if comm_impl is None:
+            return
+        if comm_impl.startswith("toast_hip_comm"):
+            D.comm_allreduce(d_zmap.data_ptr(), zmap_count, np.float64, "sum", stream)
+        else:
+            dist.all_reduce(d_zmap)
+
     # ------------------------------------------------------------------ one step
     ev = {k: [] for k in ("bnw", "allreduce", "cov", "scan")}
 
@@ -403,8 +449,7 @@ def run(args, workload, world, rank, dev, headline=True):
                                det_scale, 1, n_samp, ivl, d_sflags.data_ptr(), n_samp, 1, stream)
         if record:
             e[1].record()
-        if world > 1:
-            dist.all_reduce(d_zmap)
+        allreduce_zmap()
         if record:
             e[2].record()
         D.cov_apply_diag(n_local, nps, nnz, d_cov.data_ptr(), d_zmap.data_ptr(), stream)
@@ -487,6 +532,14 @@ def run(args, workload, world, rank, dev, headline=True):
         "iteration_GBs": (BYTES_BNW + BYTES_SCAN) * nsamp_tot / ((ms["bnw"] + ms["scan"]) * 1e-3) / 1e9,
     }
 
+    owner_ms = None
+    if comm_impl is not None and comm_impl.startswith("toast_hip_comm"):
+        # the same sum + covariance as ONE owner-computes pass (reduce-scatter, cov_apply_diag on the owned pixel
+        # shard, all-gather): what ops.BinMap / the fused SolverLHS do with sync_type = "alltoallv"
+        oc = lambda: D.comm_map_reduce_apply(n_local * nps, nnz, d_cov.data_ptr(), d_zmap.data_ptr(), True, stream)
+        oc()
+        owner_ms = timed(oc, 5)
+
     # measured stream ceiling on this box ("report % of both"): a pure
     # 8 B read + 8 B write stream (k_noise_weight over the work timestream, scale 1.0)
     ones = np.ones(n_det)
@@ -566,6 +619,9 @@ def run(args, workload, world, rank, dev, headline=True):
             "bytes": int(n_local) * nps * nnz * 8 if world > 1 else 0,
             "ms": ms["allreduce"] if world > 1 else 0.0,
             "backend": (dist.get_backend() if world > 1 else None),
+            "implementation": comm_impl,
+            "owner_computes_reduce_apply_ms": owner_ms,
+            "note": comm_note,
             "algorithm_GBs": (2.0 * (world - 1) / world * n_local * nps * nnz * 8 / (ms["allreduce"] * 1e-3) / 1e9
                               if world > 1 and ms["allreduce"] > 0 else None),
         },
@@ -634,8 +690,7 @@ def run(args, workload, world, rank, dev, headline=True):
             D.build_noise_weighted(d_g2l.data_ptr(), d_zmap.data_ptr(), nps, nnz, idx, d_pixels.data_ptr(), idx,
                                    d_weights.data_ptr(), idx, d_tod2.data_ptr(), idx, d_dflags.data_ptr(), n_samp,
                                    det_w, 1, n_samp, ivl, d_sflags.data_ptr(), n_samp, 1, stream)
-            if world > 1:
-                dist.all_reduce(d_zmap)
+            allreduce_zmap()
             D.cov_apply_diag(n_local, nps, nnz, d_cov.data_ptr(), d_zmap.data_ptr(), stream)
             D.scan_map(np.float64, d_g2l.data_ptr(), nps, d_zmap.data_ptr(), nnz, d_tod2.data_ptr(), idx,
                        d_pixels.data_ptr(), idx, d_weights.data_ptr(), idx, n_samp, ivl, 1.0, False, True, False,
@@ -650,8 +705,7 @@ def run(args, workload, world, rank, dev, headline=True):
                                 d_g2l.data_ptr(), d_zmap.data_ptr(), nps, nnz, idx, d_pixels.data_ptr(), idx,
                                 d_weights.data_ptr(), idx, d_dflags.data_ptr(), n_samp, det_w, 1, n_samp, ivl,
                                 d_sflags.data_ptr(), n_samp, 1, stream)
-            if world > 1:
-                dist.all_reduce(d_zmap)
+            allreduce_zmap()
             D.cov_apply_diag(n_local, nps, nnz, d_cov.data_ptr(), d_zmap.data_ptr(), stream)
             d_amp_out.zero_()
             D.offset_scan_project(step_len, amp_off, nav, d_amp_in.data_ptr(), d_amp_out.data_ptr(),
@@ -686,8 +740,7 @@ def run(args, workload, world, rank, dev, headline=True):
             D.otf_build_noise_weighted(pt, d_g2l.data_ptr(), d_zmap.data_ptr(), nps, idx, d_tod.data_ptr(), idx,
                                        d_dflags.data_ptr(), n_samp, det_scale, 1, n_samp, ivl, d_sflags.data_ptr(),
                                        n_samp, 1, stream)
-            if world > 1:
-                dist.all_reduce(d_zmap)
+            allreduce_zmap()
             D.cov_apply_diag(n_local, nps, nnz, d_cov.data_ptr(), d_zmap.data_ptr(), stream)
             D.otf_scan_map(pt, d_g2l.data_ptr(), d_zmap.data_ptr(), nps, d_tod2.data_ptr(), idx, n_samp, ivl, 1.0,
                            False, True, det_w, stream)
@@ -697,8 +750,7 @@ def run(args, workload, world, rank, dev, headline=True):
             D.otf_offset_accumulate(pt, step_len, amp_off, nav, d_amp_in.data_ptr(), d_amp_flags.data_ptr(),
                                     d_g2l.data_ptr(), d_zmap.data_ptr(), nps, idx, d_dflags.data_ptr(), n_samp,
                                     det_w, 1, n_samp, ivl, d_sflags.data_ptr(), n_samp, 1, stream)
-            if world > 1:
-                dist.all_reduce(d_zmap)
+            allreduce_zmap()
             D.cov_apply_diag(n_local, nps, nnz, d_cov.data_ptr(), d_zmap.data_ptr(), stream)
             d_amp_out.zero_()
             D.otf_offset_scan_project(pt, step_len, amp_off, nav, d_amp_in.data_ptr(), d_amp_out.data_ptr(),

@@ -90,7 +90,9 @@ int toast_hip_device_malloc_vmm(size_t nbytes, int chunk_mb, int shuffled, void 
 /* Switches at run time (tools/exp_*.py, tests): key "det_major" = 0 / 1 (workgroup order of the
  * accumulate / scan kernels; the environment variable TOAST_HIP_DET_MAJOR sets the start-up value);
  * key "pair" = 0 / 1 (two detectors per workgroup in the scatter and pixel kernels: merged atomics and one
- * pixel evaluation for a co-pointing pair; start-up value from TOAST_HIP_PAIR, default 1). */
+ * pixel evaluation for a co-pointing pair; start-up value from TOAST_HIP_PAIR, default 1);
+ * key "vec2" = 0 / 1 (two consecutive samples per lane -- 16-byte lane accesses -- in scan_map,
+ * build_noise_weighted and noise_weight when n_samp is even; start-up value from TOAST_HIP_VEC2, default 1). */
 int toast_hip_set_tuning(const char * key, int value);
 
 /* Pick this process's GPU: device = node_rank / ceil(node_procs / n_device).  `disabled`
@@ -886,6 +888,47 @@ int toast_hip_combine_flags_dev(uint8_t * d_out, const int32_t * out_index, cons
 int toast_hip_vec_axpby_dev(int64_t n, double a, const double * d_x, double b, double * d_y, void * stream);
 int toast_hip_vec_dot_dev(int64_t n, const double * d_x, const double * d_y, const uint8_t * d_flags_x,
                           const uint8_t * d_flags_y, double * result /*host*/, void * stream);
+
+/* ------------------------------------------------------------------------------------
+ * Multi-GPU: the process' RCCL communicator (one process per GPU), collectives enqueued on the
+ * caller's stream -- kernel -> collective -> kernel is stream order, no host synchronisation.
+ * Replaces the reference's host-side MPI reductions of the pixel-domain objects:
+ *   PixelData.sync_allreduce  [ref: src/toast/pixels.py:710-780]  (D2H, MPI Allreduce in 10 MB pieces, H2D:
+ *                              src/toast/ops/mapmaker_utils/mapmaker_utils.py:885-925)
+ *   PixelData.sync_alltoallv(local_func)  [ref: src/toast/pixels.py:942-967] and its users
+ *   covariance_invert / _multiply / _apply(use_alltoallv=True)  [ref: src/toast/covariance.py:34-131, 134-221, 224-306]
+ * librccl is opened at run time by the first call (a single-GPU process does not need it).
+ * The 128-byte unique id is created on one rank and handed to the others by the host side's own
+ * transport (MPI bcast in TOAST, torch.distributed here) before toast_hip_comm_init.
+ * ---------------------------------------------------------------------------------- */
+#define TOAST_HIP_COMM_ID_BYTES 128
+enum { TOAST_HIP_COMM_F64 = 0, TOAST_HIP_COMM_F32 = 1, TOAST_HIP_COMM_I64 = 2, TOAST_HIP_COMM_I32 = 3, TOAST_HIP_COMM_U8 = 4 };
+enum { TOAST_HIP_COMM_SUM = 0, TOAST_HIP_COMM_MAX = 1, TOAST_HIP_COMM_MIN = 2 };
+int toast_hip_comm_unique_id(void * id128);
+int toast_hip_comm_init(const void * id128, int n_ranks, int rank);
+/* n_ranks = 0 / rank = -1 when there is no communicator; rccl_version as ncclGetVersion reports it */
+int toast_hip_comm_info(int * n_ranks, int * rank, int * rccl_version);
+int toast_hip_comm_destroy(void);
+/* in place on d_buf: every rank ends with the reduction over all ranks */
+int toast_hip_comm_allreduce_dev(void * d_buf, int64_t count, int dtype, int op, void * stream);
+int toast_hip_comm_broadcast_dev(void * d_buf, int64_t count, int dtype, int root, void * stream);
+/* d_send holds n_ranks * recv_count elements; rank r receives the reduction of piece r */
+int toast_hip_comm_reduce_scatter_dev(const void * d_send, void * d_recv, int64_t recv_count, int dtype, int op,
+                                      void * stream);
+/* d_recv holds n_ranks * send_count elements; piece r = rank r's d_send */
+int toast_hip_comm_all_gather_dev(const void * d_send, void * d_recv, int64_t send_count, int dtype, void * stream);
+/* Owner-computes on pixel-domain objects that every rank holds with the same local submaps: rank r owns the pixels
+ * [r * per, (r + 1) * per) of the n_px local pixels, per = ceil(n_px / n_ranks) (toast_hip_comm_pixel_shard).
+ *   map_reduce_apply: map <- [cov .] (reduce ? sum over ranks of map : map) -- reduce-scatter (owners receive the sum),
+ *       cov_apply_diag on the owned shard (skipped when d_cov is NULL), all-gather (results go back).  With d_cov = NULL
+ *       and reduce = 1 this is sync_alltoallv() with the default local_func (sum).
+ *   cov_invert / cov_mult: every rank works on its shard of the replicated matrices, the shards are gathered. */
+int toast_hip_comm_pixel_shard(int64_t n_px, int64_t * first, int64_t * count);
+int toast_hip_comm_map_reduce_apply_dev(int64_t n_px, int64_t nnz, const double * d_cov, double * d_map, int reduce,
+                                        void * stream);
+int toast_hip_comm_cov_invert_dev(int64_t n_px, int64_t nnz, double * d_cov, double * d_rcond, double threshold,
+                                  int invert, void * stream);
+int toast_hip_comm_cov_mult_dev(int64_t n_px, int64_t nnz, double * d_cov1, const double * d_cov2, void * stream);
 
 /* ------------------------------------------------------------------------------------
  * Test / measurement helpers (device primitives compared per operation with the CPU).

@@ -44,6 +44,58 @@ def build(comm, first, n_det, full_pointing, prior=False):
     return data, mapper
 
 
+def covariance_owner_computes(comm):
+    """Covariance operations with every process working on the submaps it owns (use_alltoallv=True) against the
+    all-local form (reference covariance.py:78-131, 179-221, 262-306), for a replicated distribution and for one
+    whose ranks hold different submaps; host-resident and device-resident operands."""
+    from toast_amd.pixels import (PixelData, PixelDistribution, covariance_apply, covariance_invert,
+                                  covariance_multiply)
+
+    rank = comm.world_rank
+    d = PixelDistribution(n_pix=16 * 48, n_submap=16, local_submaps=np.array([1, 4, 9, 15]), comm=comm)
+    dd = PixelDistribution(n_pix=16 * 48 - 5, n_submap=16,
+                           local_submaps=np.array([1, 4, 9] if rank == 0 else [4, 9, 12, 15]), comm=comm)
+    for dist_x in (d, dd):
+        n_loc = dist_x.n_local_submap
+        crng = np.random.default_rng(77)          # same matrices on every rank (they are replicated per submap)
+        tri = {}
+        for sm in range(16):
+            a_ = crng.standard_normal((48, 3, 3))
+            spd = a_ @ a_.transpose(0, 2, 1) + 0.5 * np.eye(3)
+            tri[sm] = spd[:, [0, 0, 0, 1, 1, 2], [0, 1, 2, 1, 2, 2]]
+        mvals = {sm: crng.standard_normal((48, 3)) for sm in range(16)}
+
+        def fill(n_value, table, on_device):
+            out = PixelData(dist_x, np.float64, n_value=n_value)
+            for loc, sm in enumerate(dist_x.local_submaps):
+                out.data[loc] = table[int(sm)]
+            if on_device:
+                out.accel_create("t")
+                out.accel_update_device()
+            return out
+
+        for on_device in (False, True):
+            for alltoallv in (False, True):
+                cov, m = fill(6, tri, on_device), fill(3, mvals, on_device)
+                covariance_apply(cov, m, use_alltoallv=alltoallv)
+                if not alltoallv:
+                    want_apply = m.data.copy()
+                else:
+                    np.testing.assert_allclose(m.data, want_apply, rtol=1e-14, atol=1e-14)
+                inv, rc_map = fill(6, tri, on_device), PixelData(dist_x, np.float64, n_value=1)
+                covariance_invert(inv, 1.0e-6, rcond=rc_map, use_alltoallv=alltoallv)
+                if not alltoallv:
+                    want_inv, want_rc = inv.data.copy(), rc_map.data.copy()
+                    assert np.all(want_rc > 0)
+                else:
+                    np.testing.assert_allclose(inv.data, want_inv, rtol=1e-12, atol=1e-14)
+                    np.testing.assert_allclose(rc_map.data, want_rc, rtol=1e-12, atol=1e-14)
+                prod = fill(6, tri, on_device)
+                covariance_multiply(prod, inv, use_alltoallv=alltoallv)       # C . C^-1 = 1
+                ident = np.tile(np.array([1.0, 0, 0, 1.0, 0, 1.0]), (n_loc, 48, 1))
+                np.testing.assert_allclose(prod.data, ident, rtol=0, atol=1e-9)
+
+
 def main():
     backend = os.environ.get("TOAST_TEST_BACKEND", "gloo")
     if backend == "nccl":   # one process per GPU (tests/test_gpu_rccl.py, needs two GPUs)
@@ -57,6 +109,7 @@ def main():
     rank, size = dist.get_rank(), dist.get_world_size()
     assert size == 2
     accel_assign_device(size, rank, 1.0, False)
+    covariance_owner_computes(Comm())
     half = N_TOTAL // size
     # cached pointing, pointing on the fly, and the amplitude-domain noise prior (rank-local
     # filters and banded preconditioner; the dot products of the PCG are all-reduced)

@@ -93,6 +93,43 @@ def main():
         assert st is None
     assert list(dd.global_pixel_to_local(np.array([48, 4 * 48 + 7]))) == ([0, 48 + 7] if rank == 0 else [-48, 7])
 
+    # 2c. owner-computes exchange with DIFFERENT local submaps per rank (reference pixels.py:317-414, 780-967)
+    sc, sd, rc, rd, rloc = dd.alltoallv_info
+    if rank == 0:       # holds 1, 4, 9 (all owned by rank 0); owns 1, 4, 9, of which rank 1 holds 4 and 9
+        assert list(sc) == [3, 0] and list(sd) == [0, 3] and list(rc) == [3, 2] and list(rd) == [0, 3]
+        assert {k: list(v) for k, v in rloc.items()} == {1: [0], 4: [1, 3], 9: [2, 4]}
+    else:               # holds 4, 9 (owner 0) and 12, 15 (its own)
+        assert list(sc) == [2, 2] and list(sd) == [0, 2] and list(rc) == [0, 2] and list(rd) == [0, 0]
+        assert {k: list(v) for k, v in rloc.items()} == {12: [0], 15: [1]}
+    assert not dd.replicated and d.replicated
+    pv = PixelData(dd, np.float64, n_value=2)
+    for loc, sm in enumerate(mine_sm):
+        pv.data[loc] = 100.0 * sm + (rank + 1)
+    pv.sync_alltoallv()                               # default local_func: every submap = sum of its copies
+    for loc, sm in enumerate(mine_sm):
+        holders = [r for r, sms in enumerate(([1, 4, 9], [4, 9, 12, 15])) if sm in sms]
+        assert np.all(pv.data[loc] == sum(100.0 * sm + (r + 1) for r in holders)), (rank, sm)
+    seen = {}
+
+    def negate_first_copy(n_submap_value, receive_locations, receive, reduce_buf):
+        # the reference's calling convention: every owned submap with the offsets of its copies in `receive`
+        for sm, locs in receive_locations.items():
+            seen[sm] = len(locs)
+            reduce_buf[:] = -receive[locs[0]:locs[0] + n_submap_value]
+            for lc in locs:
+                receive[lc:lc + n_submap_value] = reduce_buf
+
+    before = pv.data.copy()
+    pv.sync_alltoallv(local_func=negate_first_copy)
+    assert np.array_equal(pv.data, -before)
+    assert seen == ({1: 1, 4: 2, 9: 2} if rank == 0 else {12: 1, 15: 1})
+
+    try:
+        pv.sync_alltoallv(bogus=1)
+        raise SystemExit("unknown keyword was accepted")
+    except TypeError:
+        pass
+
     # 3. amplitude dot products: local dot + scalar all-reduce
     a = Amplitudes(comm, 10, 5)
     a.local[:] = np.arange(5) + 5 * rank

@@ -70,6 +70,97 @@ def main():
     if size <= 2:
         # two addends (or one): the sum does not depend on the reduction order
         assert np.array_equal(results["sync_allreduce"], results["sync_alltoallv"])
+    # the collectives above went through the library's own communicator (toast_hip_comm_*), created on first use
+    from toast_amd import capi
+
+    # ... enqueued on the kernels' stream: no host synchronisation on the way (kernel -> collective -> kernel)
+    nat = native()
+    real_sync, calls = nat.accel_synchronize, []
+    nat.accel_synchronize = lambda: (calls.append(1), real_sync())[1]
+    real_tsync = torch.cuda.Stream.synchronize
+    torch.cuda.Stream.synchronize = lambda self: (calls.append(2), real_tsync(self))[1]
+    try:
+        pd = PixelData(d, np.float64, n_value=3)
+        pd.raw[:] = parts[rank]
+        pd.accel_create("zmap")
+        pd.accel_update_device()
+        covariance_apply(ident, pd)
+        pd.sync_allreduce()
+        covariance_apply(ident, pd)
+        pd.sync_alltoallv()
+        covariance_apply(ident, pd, use_alltoallv=True)
+        assert calls == [], calls
+    finally:
+        nat.accel_synchronize = real_sync
+        torch.cuda.Stream.synchronize = real_tsync
+    pd.accel_update_host()
+    np.testing.assert_allclose(pd.raw, 8.0 * size * total, rtol=0, atol=1e-12 * size * np.max(np.abs(total)))
+    pd.accel_delete()
+
+    assert comm.device_comm() and capi.dev.comm_info()[:2] == (size, rank) and capi.dev.comm_info()[2] > 0
+    first, count = capi.dev.comm_pixel_shard(37 * 48)
+    per = -(-37 * 48 // size)
+    assert first == min(rank * per, 37 * 48) and count == max(0, min(37 * 48, (rank + 1) * per) - first)
+    # raw collectives of the C ABI on torch tensors (library stream = the default stream)
+    t = torch.arange(size * 5, dtype=torch.float64, device="cuda") * (rank + 1)
+    mine = torch.empty(5, dtype=torch.float64, device="cuda")
+    capi.dev.comm_reduce_scatter(t.data_ptr(), mine.data_ptr(), 5, np.float64)
+    tri = size * (size + 1) // 2
+    assert torch.equal(mine.cpu(), torch.arange(rank * 5, rank * 5 + 5, dtype=torch.float64) * tri)
+    back = torch.empty(size * 5, dtype=torch.float64, device="cuda")
+    capi.dev.comm_all_gather(mine.data_ptr(), back.data_ptr(), 5, np.float64)
+    assert torch.equal(back.cpu(), torch.arange(size * 5, dtype=torch.float64) * tri)
+    b = torch.full((7,), float(rank + 3), dtype=torch.float64, device="cuda")
+    capi.dev.comm_broadcast(b.data_ptr(), 7, np.float64, root=size - 1)
+    assert torch.all(b.cpu() == size + 2)
+    u = torch.tensor([rank, 5, 250 - rank], dtype=torch.uint8, device="cuda")
+    capi.dev.comm_allreduce(u.data_ptr(), 3, np.uint8, "max")
+    assert u.cpu().tolist() == [size - 1, 5, 250]
+
+    # owner-computes covariance operations on device-resident operands (reduce-scatter / kernel on the owned pixel
+    # shard / all-gather) against the all-local kernels: covariance.py:78-131, 179-221, 262-306
+    from toast_amd.pixels import covariance_invert, covariance_multiply, map_reduce_apply
+
+    crng = np.random.default_rng(41)
+    a_ = crng.standard_normal((37 * 48, 3, 3))
+    spd = (a_ @ a_.transpose(0, 2, 1) + 0.5 * np.eye(3))[:, [0, 0, 0, 1, 1, 2], [0, 1, 2, 1, 2, 2]]
+
+    def dev_map(values, n_value, name):
+        out = PixelData(d, np.float64, n_value=n_value)
+        out.raw[:] = np.asarray(values).reshape(-1)
+        out.accel_create(name)
+        out.accel_update_device()
+        return out
+
+    mvals = crng.standard_normal((37 * 48, 3))
+    want = {}
+    for alltoallv in (False, True):
+        cv, mp = dev_map(spd, 6, "cov"), dev_map(mvals, 3, "map")
+        covariance_apply(cv, mp, use_alltoallv=alltoallv)
+        inv, rc = dev_map(spd, 6, "inv"), PixelData(d, np.float64, n_value=1)
+        covariance_invert(inv, 1e-6, rcond=rc, use_alltoallv=alltoallv)
+        assert inv.accel_in_use() and rc.accel_in_use()
+        prod = dev_map(spd, 6, "prod")
+        covariance_multiply(prod, inv, use_alltoallv=alltoallv)
+        got = dict(apply=mp.data.copy(), inv=inv.data.copy(), rc=rc.data.copy(), prod=prod.data.copy())
+        if not alltoallv:
+            want = got
+        else:
+            for key in got:
+                np.testing.assert_allclose(got[key], want[key], rtol=1e-13, atol=1e-15, err_msg=key)
+        for obj in (cv, mp, inv, rc, prod):
+            obj.accel_delete()
+    np.testing.assert_allclose(want["prod"].reshape(-1, 6), np.tile([1.0, 0, 0, 1.0, 0, 1.0], (37 * 48, 1)), atol=1e-9)
+    # the middle of a PCG iteration in one pass: zmap <- C . sum over ranks (zmap)
+    for sync_type in ("alltoallv", "allreduce"):
+        cv, z = dev_map(spd, 6, "cov"), dev_map(parts[rank], 3, "zmap")
+        map_reduce_apply(cv, z, sync_type=sync_type)
+        ref = PixelData(d, np.float64, n_value=3)
+        ref.raw[:] = total
+        covariance_apply(dev_map(spd, 6, "cov2"), ref)       # host map: staged through the same kernel
+        np.testing.assert_allclose(z.data, ref.data, rtol=1e-13, atol=1e-13 * np.max(np.abs(total)))
+        cv.accel_delete()
+        z.accel_delete()
     # host-resident data with the nccl backend (staged through the device)
     ph = PixelData(d, np.int64, n_value=1)
     ph.raw[:] = rank + 1

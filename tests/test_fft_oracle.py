@@ -78,6 +78,14 @@ def test_product_host_helpers_match_oracle():
         pf.extend_flags(f1, 1, 4)
         fo.extend_flags(f2, 1, 4)
         assert np.array_equal(f1, f2), seed
+    # a completely flagged array (no edge) keeps its other bits; one good sample anywhere and the mask is assigned
+    for n_good in (0, 1):
+        f1 = np.full(50, 7, dtype=np.uint8)
+        f1[10:10 + n_good] = 6
+        f2 = f1.copy()
+        pf.extend_flags(f1, 1, 3)
+        fo.extend_flags(f2, 1, 3)
+        assert np.array_equal(f1, f2) and (n_good == 1 or np.all(f1 == 7))
 
 
 def test_noise_filter_kernel():

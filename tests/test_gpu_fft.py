@@ -419,17 +419,21 @@ def test_extend_flags_random_cases(pf, seed):
     mask = int(rng.choice([1, 2, 3, 129]))
     flags = ((rng.random((rows, n_samp)) < rng.choice([0.0, 0.001, 0.05, 0.5])) * mask
              + (rng.random((rows, n_samp)) < 0.1) * 64).astype(np.uint8)
+    # one completely flagged row carrying bits outside the mask: no edge, the reference leaves it alone
+    flags[int(rng.integers(0, rows))] = (mask | 64 | 16)
     n_sel = int(rng.integers(1, rows + 1))
     idx = rng.permutation(rows)[:n_sel].astype(np.int32)
     extents = rng.choice([0, 1, 2, 7, 100, n_samp // 2, n_samp, n_samp + 5], size=n_sel).astype(np.int32)
     edges = bool(rng.integers(0, 2))
     common = ((rng.random(n_samp) < 0.01) * int(rng.choice([mask, 3, 64]))).astype(np.uint8) if rng.integers(0, 2) else None
+    import oracle.fft_oracle as fo
+
     want = flags.copy()
     for row, ext in zip(idx, extents):
         ext = int(ext)
         if common is not None:
             want[row] |= common
-        pf.extend_flags(want[row], mask, ext)
+        fo.extend_flags(want[row], mask, ext)     # the literal restatement of the reference (region loop)
         if edges:
             want[row][:ext] |= mask
             want[row][-ext:] |= mask

@@ -257,3 +257,22 @@ def test_noise_models_follow_the_reference():
     assert nm.index("flat") == name_UID("flat") and int(name_UID("flat")) < 2**31
     assert Noise(["a"], {"a": freq}, {"a": flat}, detweights={"a": 7.0}).detector_weight("a") == 7.0
     assert an.fknee("a") == pytest.approx(an.fknee("a")) and an.alpha(dets[0]) >= 0
+
+
+def test_pixel_data_reset_after_the_buffer_was_handed_out():
+    """A caller holding a view of the host buffer may write after reset(): the map must not be taken for zero
+    (the 'never handed out' shortcut of host_is_zero / duplicate is one way)."""
+    d = PixelDistribution(n_pix=12 * 4 * 4, n_submap=12, local_submaps=np.arange(12))
+    pd = PixelData(d, np.float64, n_value=3)
+    assert pd.host_is_zero()                      # fresh: known zero without looking
+    view = pd.data
+    view[2, 5, 1] = 4.0
+    assert not pd.host_is_zero()
+    pd.reset()
+    assert pd.host_is_zero() and not np.any(pd.raw)
+    view[3, 1, 0] = -2.5                          # written through the old view, after the reset
+    assert not pd.host_is_zero()
+    dup = pd.duplicate()
+    assert dup.data[3, 1, 0] == -2.5 and np.count_nonzero(dup.raw) == 1
+    pd.reset()
+    assert not np.any(view) and pd.host_is_zero()

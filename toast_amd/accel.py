@@ -171,6 +171,26 @@ def accel_device_ptr(data):
     return int(native().accel_device_ptr(_key(data)))
 
 
+class accel_hold:
+    """``with accel_hold(a, b): ...`` -- the device copies of ``a`` and ``b`` are not evicted inside the block
+    (``Data.accel_evict`` skips held objects).  For code outside a Pipeline that allocates device memory while it
+    holds another object's device state: a failed allocation triggers eviction, and writing back / freeing the very
+    operand the code is about to read would leave it with a stale device pointer."""
+
+    def __init__(self, *objs):
+        self._objs = [o for o in objs if o is not None]
+
+    def __enter__(self):
+        for o in self._objs:
+            o._accel_hold = getattr(o, "_accel_hold", 0) + 1
+        return self
+
+    def __exit__(self, *exc):
+        for o in self._objs:
+            o._accel_hold -= 1
+        return False
+
+
 class AcceleratorObject:
     """Mix-in for objects with a device copy (reference: accel.py:308-520).
 

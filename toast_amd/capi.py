@@ -138,7 +138,7 @@ def set_deterministic(on):
 
 
 def set_tuning(key, value):
-    """Run-time switches of the library (toast_hip_set_tuning): "pair" = 0 / 1, "det_major" = 0 / 1."""
+    """Run-time switches of the library (toast_hip_set_tuning): "pair" = 0 / 1, "det_major" = 0 / 1, "vec2" = 0 / 1."""
     _check(real_lib().toast_hip_set_tuning(key.encode(), C.c_int(int(value))))
 
 
@@ -966,6 +966,63 @@ class _Dev:
         out = C.c_double(0.0)
         _check(lib().toast_hip_vec_dot_dev(_i64(n), _p(d_x), _p(d_y), _p(d_fx), _p(d_fy), C.byref(out), _p(stream)))
         return out.value
+
+    # ---- the process' RCCL communicator (toast_hip_comm_*): collectives on the kernels' stream
+    COMM_DTYPES = {np.dtype(np.float64): 0, np.dtype(np.float32): 1, np.dtype(np.int64): 2, np.dtype(np.int32): 3,
+                   np.dtype(np.uint8): 4}
+    COMM_OPS = {"sum": 0, "max": 1, "min": 2}
+
+    def comm_unique_id(self):
+        buf = (C.c_ubyte * 128)()
+        _check(real_lib().toast_hip_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, n_ranks, rank):
+        if len(unique_id) != 128:
+            raise ValueError("the RCCL unique id has 128 bytes")
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        _check(real_lib().toast_hip_comm_init(buf, C.c_int(int(n_ranks)), C.c_int(int(rank))))
+
+    def comm_info(self):
+        n, r, v = C.c_int(0), C.c_int(-1), C.c_int(0)
+        _check(real_lib().toast_hip_comm_info(C.byref(n), C.byref(r), C.byref(v)))
+        return int(n.value), int(r.value), int(v.value)
+
+    def comm_destroy(self):
+        _check(real_lib().toast_hip_comm_destroy())
+
+    def comm_allreduce(self, d_buf, count, dtype, op="sum", stream=0):
+        _check(lib().toast_hip_comm_allreduce_dev(_p(d_buf), _i64(count), C.c_int(self.COMM_DTYPES[np.dtype(dtype)]),
+                                                  C.c_int(self.COMM_OPS[op]), _p(stream)))
+
+    def comm_broadcast(self, d_buf, count, dtype, root=0, stream=0):
+        _check(lib().toast_hip_comm_broadcast_dev(_p(d_buf), _i64(count), C.c_int(self.COMM_DTYPES[np.dtype(dtype)]),
+                                                  C.c_int(int(root)), _p(stream)))
+
+    def comm_reduce_scatter(self, d_send, d_recv, recv_count, dtype, op="sum", stream=0):
+        _check(lib().toast_hip_comm_reduce_scatter_dev(_p(d_send), _p(d_recv), _i64(recv_count),
+                                                       C.c_int(self.COMM_DTYPES[np.dtype(dtype)]),
+                                                       C.c_int(self.COMM_OPS[op]), _p(stream)))
+
+    def comm_all_gather(self, d_send, d_recv, send_count, dtype, stream=0):
+        _check(lib().toast_hip_comm_all_gather_dev(_p(d_send), _p(d_recv), _i64(send_count),
+                                                   C.c_int(self.COMM_DTYPES[np.dtype(dtype)]), _p(stream)))
+
+    def comm_pixel_shard(self, n_px):
+        first, count = C.c_int64(0), C.c_int64(0)
+        _check(real_lib().toast_hip_comm_pixel_shard(_i64(n_px), C.byref(first), C.byref(count)))
+        return int(first.value), int(count.value)
+
+    def comm_map_reduce_apply(self, n_px, nnz, d_cov, d_map, reduce=True, stream=0):
+        _check(lib().toast_hip_comm_map_reduce_apply_dev(_i64(n_px), _i64(nnz), _p(d_cov), _p(d_map),
+                                                         C.c_int(1 if reduce else 0), _p(stream)))
+
+    def comm_cov_invert(self, n_px, nnz, d_cov, d_rcond, threshold, invert=True, stream=0):
+        _check(lib().toast_hip_comm_cov_invert_dev(_i64(n_px), _i64(nnz), _p(d_cov), _p(d_rcond),
+                                                   C.c_double(float(threshold)), C.c_int(1 if invert else 0), _p(stream)))
+
+    def comm_cov_mult(self, n_px, nnz, d_cov1, d_cov2, stream=0):
+        _check(lib().toast_hip_comm_cov_mult_dev(_i64(n_px), _i64(nnz), _p(d_cov1), _p(d_cov2), _p(stream)))
 
     def test_math(self, op, n, d_a, d_b, d_out, stream=0):
         _check(lib().toast_hip_test_math_dev(C.c_int(op), _i64(n), _p(d_a), _p(d_b), _p(d_out), _p(stream)))

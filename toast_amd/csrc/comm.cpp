@@ -1,0 +1,329 @@
+// comm.cpp -- the process' RCCL communicator behind the C ABI.
+//
+// One process per GPU.  The collectives of the map-making path (sum of the noise-weighted map over the detector
+// shards, the scalar sums of the PCG, the union of the hit submaps) are enqueued on the stream the kernels run on, so a
+// PCG iteration needs no host synchronisation around them: kernel -> collective -> kernel is plain stream order.
+//
+// Reference semantics: PixelData.sync_allreduce (src/toast/pixels.py:710-780: every process ends with the sum) and
+// PixelData.sync_alltoallv (src/toast/pixels.py:942-967: every submap goes to ONE owner, the owner runs `local_func`
+// on it, the result goes back to every holder).  With one process per GPU all ranks hold the same local submaps
+// (the union of the hit submaps), so "owner of a pixel" = the rank whose contiguous pixel shard contains it:
+// reduce-scatter (owners receive the sum) -> per-pixel kernel on the owned shard -> all-gather (results go back).
+//
+// librccl is opened at run time (dlopen) the first time a communicator is asked for: a single-GPU process needs no
+// RCCL at all, and a process that already carries an RCCL (PyTorch-ROCm bundles one) keeps using that one copy.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <sstream>
+#include <string>
+
+#include "../../include/toast_hip.h"
+#include "runtime.hpp"
+
+namespace {
+
+using namespace toast_hip;
+
+struct Rccl {
+    void * handle = nullptr;
+    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclAllReduce) all_reduce = nullptr;
+    decltype(&ncclReduceScatter) reduce_scatter = nullptr;
+    decltype(&ncclAllGather) all_gather = nullptr;
+    decltype(&ncclBroadcast) broadcast = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+    decltype(&ncclGetVersion) get_version = nullptr;
+};
+
+template <typename F>
+void resolve(void * h, const char * name, F & fn) {
+    fn = reinterpret_cast<F>(dlsym(h, name));
+    if (fn == nullptr) throw Error(TOAST_HIP_ERR_DEVICE, std::string("HipComm:  librccl has no symbol ") + name);
+}
+
+Rccl & rccl() {
+    static Rccl r;
+    if (r.handle != nullptr) return r;
+    // the copy this process already carries first (RTLD_NOLOAD), then the loader's search path, then ROCm's
+    const char * loaded[] = {"librccl.so", "librccl.so.1"};
+    for (const char * n : loaded) {
+        if (r.handle == nullptr) r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    }
+    const char * names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char * n : names) {
+        if (r.handle == nullptr) r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    }
+    if (r.handle == nullptr) {
+        const char * e = dlerror();
+        throw Error(TOAST_HIP_ERR_DEVICE, std::string("HipComm:  cannot open librccl (") + (e ? e : "?") + ")");
+    }
+    resolve(r.handle, "ncclGetUniqueId", r.get_unique_id);
+    resolve(r.handle, "ncclCommInitRank", r.comm_init_rank);
+    resolve(r.handle, "ncclCommDestroy", r.comm_destroy);
+    resolve(r.handle, "ncclAllReduce", r.all_reduce);
+    resolve(r.handle, "ncclReduceScatter", r.reduce_scatter);
+    resolve(r.handle, "ncclAllGather", r.all_gather);
+    resolve(r.handle, "ncclBroadcast", r.broadcast);
+    resolve(r.handle, "ncclGetErrorString", r.error_string);
+    resolve(r.handle, "ncclGetVersion", r.get_version);
+    return r;
+}
+
+void check(ncclResult_t rc, const char * what) {
+    if (rc == ncclSuccess) return;
+    std::ostringstream o;
+    o << "HipComm:  " << what << " failed: " << rccl().error_string(rc);
+    throw Error(TOAST_HIP_ERR_DEVICE, o.str());
+}
+
+ncclComm_t g_comm = nullptr;
+int g_size = 0;
+int g_rank = -1;
+
+ncclComm_t comm() {
+    if (g_comm == nullptr) {
+        throw Error(TOAST_HIP_ERR_DEVICE, "HipComm:  no communicator, call toast_hip_comm_init() first");
+    }
+    return g_comm;
+}
+
+struct DType {
+    ncclDataType_t nccl;
+    size_t bytes;
+};
+
+DType dtype_of(int code) {
+    switch (code) {
+        case TOAST_HIP_COMM_F64: return {ncclFloat64, 8};
+        case TOAST_HIP_COMM_F32: return {ncclFloat32, 4};
+        case TOAST_HIP_COMM_I64: return {ncclInt64, 8};
+        case TOAST_HIP_COMM_I32: return {ncclInt32, 4};
+        case TOAST_HIP_COMM_U8: return {ncclUint8, 1};
+        default: fail_arg("HipComm:  unknown data type code");
+    }
+}
+
+ncclRedOp_t op_of(int code) {
+    switch (code) {
+        case TOAST_HIP_COMM_SUM: return ncclSum;
+        case TOAST_HIP_COMM_MAX: return ncclMax;
+        case TOAST_HIP_COMM_MIN: return ncclMin;
+        default: fail_arg("HipComm:  unknown reduction code");
+    }
+}
+
+inline hipStream_t as_stream(void * s) { return static_cast<hipStream_t>(s); }
+
+// Pixel shards: rank r owns pixels [r * per, min((r + 1) * per, n_px)), per = ceil(n_px / size).
+struct Shard {
+    int64_t per;     // pixels per rank (the last ranks may own fewer, or none)
+    int64_t first;   // first owned pixel
+    int64_t count;   // owned pixels (>= 0)
+    bool even;       // n_px == per * size: the collectives run in place on the map
+};
+
+Shard shard_of(int64_t n_px) {
+    Shard s;
+    s.per = (n_px + g_size - 1) / g_size;
+    s.first = (int64_t)g_rank * s.per;
+    const int64_t last = (s.first + s.per < n_px) ? s.first + s.per : n_px;
+    s.count = (last > s.first) ? last - s.first : 0;
+    if (s.first > n_px) s.first = n_px;
+    s.even = (s.per * g_size == n_px);
+    return s;
+}
+
+// `work` = the buffer the two ring halves run on: the map itself when the pixels divide evenly, else a zero-padded
+// scratch copy of per * size pixels (kScratchCommA / B of the manager's grow-only scratch buffers).
+double * padded_copy(const double * d_map, int64_t n_px, int64_t nv, const Shard & s, int slot, hipStream_t st) {
+    const size_t bytes = (size_t)s.per * g_size * nv * sizeof(double);
+    double * w = static_cast<double *>(Manager::get().scratch(slot, bytes));
+    TH_HIP(hipMemcpyAsync(w, d_map, (size_t)n_px * nv * sizeof(double), hipMemcpyDeviceToDevice, st));
+    const size_t pad = bytes - (size_t)n_px * nv * sizeof(double);
+    if (pad > 0) TH_HIP(hipMemsetAsync(w + n_px * nv, 0, pad, st));
+    return w;
+}
+
+void all_gather_pixels(double * d_data, int64_t n_px, int64_t nv, const Shard & s, int slot, hipStream_t st) {
+    if (s.even) {
+        check(rccl().all_gather(d_data + s.first * nv, d_data, (size_t)(s.per * nv), ncclFloat64, comm(), st),
+              "ncclAllGather");
+        return;
+    }
+    double * w = padded_copy(d_data, n_px, nv, s, slot, st);
+    check(rccl().all_gather(w + (int64_t)g_rank * s.per * nv, w, (size_t)(s.per * nv), ncclFloat64, comm(), st),
+          "ncclAllGather");
+    TH_HIP(hipMemcpyAsync(d_data, w, (size_t)n_px * nv * sizeof(double), hipMemcpyDeviceToDevice, st));
+}
+
+}  // namespace
+
+extern "C" {
+
+int toast_hip_comm_unique_id(void * id128) {
+    return guarded([&] {
+        if (id128 == nullptr) fail_arg("HipComm:  unique id buffer is null");
+        static_assert(sizeof(ncclUniqueId) == TOAST_HIP_COMM_ID_BYTES, "unique id size");
+        ncclUniqueId id;
+        check(rccl().get_unique_id(&id), "ncclGetUniqueId");
+        std::memcpy(id128, &id, sizeof(id));
+    });
+}
+
+int toast_hip_comm_init(const void * id128, int n_ranks, int rank) {
+    return guarded([&] {
+        if (id128 == nullptr) fail_arg("HipComm:  unique id buffer is null");
+        if (n_ranks < 1 || rank < 0 || rank >= n_ranks) fail_arg("HipComm:  need 0 <= rank < n_ranks");
+        if (g_comm != nullptr) {
+            throw Error(TOAST_HIP_ERR_DEVICE, "HipComm:  a communicator already exists, call toast_hip_comm_destroy() first");
+        }
+        ncclUniqueId id;
+        std::memcpy(&id, id128, sizeof(id));
+        ncclComm_t c = nullptr;
+        check(rccl().comm_init_rank(&c, n_ranks, id, rank), "ncclCommInitRank");
+        g_comm = c;
+        g_size = n_ranks;
+        g_rank = rank;
+    });
+}
+
+int toast_hip_comm_info(int * n_ranks, int * rank, int * rccl_version) {
+    return guarded([&] {
+        if (n_ranks) *n_ranks = g_comm ? g_size : 0;
+        if (rank) *rank = g_comm ? g_rank : -1;
+        if (rccl_version) {
+            *rccl_version = 0;
+            if (g_comm) check(rccl().get_version(rccl_version), "ncclGetVersion");
+        }
+    });
+}
+
+int toast_hip_comm_destroy(void) {
+    return guarded([&] {
+        if (g_comm == nullptr) return;
+        ncclComm_t c = g_comm;
+        g_comm = nullptr;
+        g_size = 0;
+        g_rank = -1;
+        check(rccl().comm_destroy(c), "ncclCommDestroy");
+    });
+}
+
+int toast_hip_comm_allreduce_dev(void * d_buf, int64_t count, int dtype, int op, void * stream) {
+    return guarded([&] {
+        if (count <= 0) return;
+        const DType t = dtype_of(dtype);
+        check(rccl().all_reduce(d_buf, d_buf, (size_t)count, t.nccl, op_of(op), comm(), as_stream(stream)), "ncclAllReduce");
+    });
+}
+
+int toast_hip_comm_broadcast_dev(void * d_buf, int64_t count, int dtype, int root, void * stream) {
+    return guarded([&] {
+        if (count <= 0) return;
+        const DType t = dtype_of(dtype);
+        check(rccl().broadcast(d_buf, d_buf, (size_t)count, t.nccl, root, comm(), as_stream(stream)), "ncclBroadcast");
+    });
+}
+
+int toast_hip_comm_reduce_scatter_dev(const void * d_send, void * d_recv, int64_t recv_count, int dtype, int op,
+                                      void * stream) {
+    return guarded([&] {
+        if (recv_count <= 0) return;
+        const DType t = dtype_of(dtype);
+        check(rccl().reduce_scatter(d_send, d_recv, (size_t)recv_count, t.nccl, op_of(op), comm(), as_stream(stream)),
+              "ncclReduceScatter");
+    });
+}
+
+int toast_hip_comm_all_gather_dev(const void * d_send, void * d_recv, int64_t send_count, int dtype, void * stream) {
+    return guarded([&] {
+        if (send_count <= 0) return;
+        const DType t = dtype_of(dtype);
+        check(rccl().all_gather(d_send, d_recv, (size_t)send_count, t.nccl, comm(), as_stream(stream)), "ncclAllGather");
+    });
+}
+
+int toast_hip_comm_pixel_shard(int64_t n_px, int64_t * first, int64_t * count) {
+    return guarded([&] {
+        (void)comm();
+        const Shard s = shard_of(n_px);
+        if (first) *first = s.first;
+        if (count) *count = s.count;
+    });
+}
+
+// map <- [C .] sum over ranks (map), owner computes:  reduce-scatter of the pixel shards, cov_apply_diag on the owned
+// shard (skipped when d_cov is null), all-gather.  reduce = 0: the map is already the same on all ranks (the
+// reference's covariance_apply(use_alltoallv=True), covariance.py:224-306): owners apply, results are gathered.
+int toast_hip_comm_map_reduce_apply_dev(int64_t n_px, int64_t nnz, const double * d_cov, double * d_map, int reduce,
+                                        void * stream) {
+    return guarded([&] {
+        if (n_px <= 0) return;
+        if (nnz <= 0) fail_arg("nnz must be positive");
+        (void)comm();
+        hipStream_t st = as_stream(stream);
+        const Shard s = shard_of(n_px);
+        const int64_t ncov = nnz * (nnz + 1) / 2;
+        double * work = d_map;
+        if (!s.even) work = padded_copy(d_map, n_px, nnz, s, Manager::kScratchCommA, st);
+        double * mine = work + (int64_t)g_rank * s.per * nnz;
+        if (reduce) {
+            check(rccl().reduce_scatter(work, mine, (size_t)(s.per * nnz), ncclFloat64, ncclSum, comm(), st),
+                  "ncclReduceScatter");
+        }
+        if (d_cov != nullptr && s.count > 0) {
+            const int rc = toast_hip_cov_apply_diag_dev(1, s.count, nnz, d_cov + s.first * ncov, mine, stream);
+            if (rc != 0) throw Error(rc, toast_hip_last_error());
+        }
+        check(rccl().all_gather(mine, work, (size_t)(s.per * nnz), ncclFloat64, comm(), st), "ncclAllGather");
+        if (work != d_map) {
+            TH_HIP(hipMemcpyAsync(d_map, work, (size_t)n_px * nnz * sizeof(double), hipMemcpyDeviceToDevice, st));
+        }
+    });
+}
+
+// In-place inverse of the per-pixel blocks, owner computes (covariance_invert(use_alltoallv=True), covariance.py:34-131):
+// every rank decomposes its pixel shard of the (replicated) matrix, then the shards are gathered; same for the
+// condition-number map when given.
+int toast_hip_comm_cov_invert_dev(int64_t n_px, int64_t nnz, double * d_cov, double * d_rcond, double threshold,
+                                  int invert, void * stream) {
+    return guarded([&] {
+        if (n_px <= 0) return;
+        (void)comm();
+        hipStream_t st = as_stream(stream);
+        const Shard s = shard_of(n_px);
+        const int64_t ncov = nnz * (nnz + 1) / 2;
+        if (s.count > 0) {
+            const int rc = toast_hip_cov_eigendecompose_diag_dev(1, s.count, nnz, d_cov + s.first * ncov,
+                                                                 d_rcond ? d_rcond + s.first : nullptr, threshold, invert,
+                                                                 stream);
+            if (rc != 0) throw Error(rc, toast_hip_last_error());
+        }
+        if (invert) all_gather_pixels(d_cov, n_px, ncov, s, Manager::kScratchCommA, st);
+        if (d_rcond != nullptr) all_gather_pixels(d_rcond, n_px, 1, s, Manager::kScratchCommB, st);
+    });
+}
+
+// cov1 <- cov1 . cov2 per pixel, owner computes (covariance_multiply(use_alltoallv=True), covariance.py:134-221).
+int toast_hip_comm_cov_mult_dev(int64_t n_px, int64_t nnz, double * d_cov1, const double * d_cov2, void * stream) {
+    return guarded([&] {
+        if (n_px <= 0) return;
+        (void)comm();
+        hipStream_t st = as_stream(stream);
+        const Shard s = shard_of(n_px);
+        const int64_t ncov = nnz * (nnz + 1) / 2;
+        if (s.count > 0) {
+            const int rc = toast_hip_cov_mult_diag_dev(1, s.count, nnz, d_cov1 + s.first * ncov, d_cov2 + s.first * ncov,
+                                                       stream);
+            if (rc != 0) throw Error(rc, toast_hip_last_error());
+        }
+        all_gather_pixels(d_cov1, n_px, ncov, s, Manager::kScratchCommA, st);
+    });
+}
+
+}  // extern "C"

@@ -389,13 +389,16 @@ __global__ __launch_bounds__(256) void k_extend_flags(uint8_t * __restrict__ fla
         if (tid == 255) s_carry += s_cnt[255];
         __syncthreads();
     }
+    // a completely flagged row has no rising or falling edge: the reference returns without touching it, so the bits
+    // outside the mask survive (utils.py:1078-1083)
+    const bool extend = s_carry != (int32_t)n_samp;
     for (int64_t j = tid; j < n_samp; j += 256) {
         const int64_t lo = (j - b > 0) ? j - b : 0;
         const int64_t hi = (j + b < n_samp - 1) ? j + b : n_samp - 1;
         const int32_t cnt = pre[hi] - ((lo > 0) ? pre[lo - 1] : 0);
         uint8_t v = f[j];
         if (or_row != nullptr) v |= or_row[j];
-        if (cnt > 0 && j <= n_samp - 2) v = mask;
+        if (extend && cnt > 0 && j <= n_samp - 2) v = mask;
         // f[:b] |= mask; f[-b:] |= mask  (Python semantics: b == 0 makes the second slice the whole array)
         if (edges && (b == 0 || j < b || j >= n_samp - b)) v |= mask;
         f[j] = v;

@@ -157,7 +157,7 @@ public:
     void set_stream(hipStream_t s) { stream_ = s; }
 
     static constexpr int kScratchFftTime = 0, kScratchFftFreq = 1, kScratchDot = 2, kScratchFftWork = 3,
-                         kScratchSort = 4, kScratchFftImpulse = 5;
+                         kScratchSort = 4, kScratchFftImpulse = 5, kScratchCommA = 6, kScratchCommB = 7;
 
 private:
     std::map<std::pair<int, int>, std::pair<void *, size_t>> scratch_;   // (device, slot) -> (ptr, bytes)

@@ -178,6 +178,64 @@ class Comm:
             self._dist.broadcast(t, src=root)
         return arr
 
+    def allgather_array(self, arr):
+        """Host NumPy array of the same shape on every rank -> array [world_size, ...] of all of them."""
+        if self.comm_world is None:
+            return np.asarray(arr)[None]
+        import torch
+
+        dev = self._collective_device()
+        t = torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
+        out = [torch.empty_like(t) for _ in range(self.world_size)]
+        self._dist.all_gather(out, t)
+        return np.stack([o.cpu().numpy() for o in out])
+
+    def alltoallv_array(self, send, send_counts, send_displ, recv, recv_counts, recv_displ):
+        """MPI Alltoallv on host NumPy arrays (element counts / displacements per rank); the pieces of ``send`` and of
+        ``recv`` must lie in rank order without gaps, which is how PixelDistribution.alltoallv_info builds them."""
+        import torch
+
+        for cnt, dsp in ((send_counts, send_displ), (recv_counts, recv_displ)):
+            if not np.array_equal(np.cumsum(cnt) - cnt, dsp):
+                raise RuntimeError("alltoallv_array: pieces must be contiguous and in rank order")
+        n_send, n_recv = int(np.sum(send_counts)), int(np.sum(recv_counts))
+        dev = self._collective_device()
+        s = torch.from_numpy(send[:n_send]).to(dev)
+        r = torch.empty(n_recv, dtype=s.dtype, device=dev)
+        self._dist.all_to_all_single(r, s, [int(c) for c in recv_counts], [int(c) for c in send_counts])
+        recv[:n_recv] = r.cpu().numpy()
+        return recv
+
+    def device_comm(self):
+        """True when the collectives of device-resident data go through the library's own RCCL communicator
+        (``toast_hip_comm_*``: enqueued on the kernels' stream, no host synchronisation).  That is the case when the
+        process group says one GPU per rank (backend "nccl"; ``TOAST_HIP_COMM=rccl`` forces it, ``=torch`` turns it
+        off).  The communicator is created on first use: rank 0 draws the RCCL unique id, the process group carries it
+        to the other ranks."""
+        if self.comm_world is None:
+            return False
+        state = getattr(self, "_device_comm", None)
+        if state is not None:
+            return state
+        import os
+
+        from . import capi
+        from .accel import accel_enabled
+
+        want = os.environ.get("TOAST_HIP_COMM", "")
+        ok = accel_enabled() and want != "torch" and (self._dist.get_backend() == "nccl" or want == "rccl")
+        if ok:
+            n, r, _ = capi.dev.comm_info()
+            if n == 0:
+                uid = np.frombuffer(capi.dev.comm_unique_id() if self.world_rank == 0 else bytes(128), dtype=np.uint8).copy()
+                self.bcast_array_(uid, root=0)
+                capi.dev.comm_init(uid.tobytes(), self.world_size, self.world_rank)
+            elif (n, r) != (self.world_size, self.world_rank):
+                raise RuntimeError(f"the library's communicator is rank {r} of {n}, the process group says "
+                                   f"{self.world_rank} of {self.world_size}")
+        self._device_comm = ok
+        return ok
+
     def barrier(self):
         if self.comm_world is not None:
             self._dist.barrier()
@@ -645,8 +703,17 @@ class _KeyAccel:
                 self._obj(key).accel_delete()
 
     def memory_use(self):
-        return sum(int(getattr(self._obj(k), "_raw", getattr(self._obj(k), "data", np.zeros(0))).nbytes)
-                   for k in self.keys())
+        """Bytes held on the host.  A size query: it must not go through ``.data`` (the lazy-coherence property would
+        copy every device-resident buffer back and make the host the current side)."""
+        total = 0
+        for k in self.keys():
+            obj = self._obj(k)
+            if hasattr(obj, "memory_use"):
+                total += int(obj.memory_use())
+            else:
+                raw = getattr(obj, "_raw", None)
+                total += int(raw.nbytes) if raw is not None else 0
+        return total
 
 
 class DetDataManager(_KeyAccel, MutableMapping):
@@ -928,7 +995,7 @@ class Data(MutableMapping):
             for key in list(ob.detdata.keys()):
                 obj = ob.detdata[key]
                 if (key in self._pinned["detdata"] or any(key in s for s in self._protected)
-                        or not obj.accel_exists()):
+                        or getattr(obj, "_accel_hold", 0) > 0 or not obj.accel_exists()):
                     continue
                 if obj.accel_in_use():
                     obj.accel_update_host()
@@ -939,7 +1006,8 @@ class Data(MutableMapping):
 
         for key, obj in list(self._internal.items()):
             if (not isinstance(obj, PixelData) or key in self._pinned["global"]
-                    or any(("global:" + key) in s for s in self._protected) or not obj.accel_exists()):
+                    or any(("global:" + key) in s for s in self._protected) or getattr(obj, "_accel_hold", 0) > 0
+                    or not obj.accel_exists()):
                 continue
             if obj.accel_in_use():
                 obj.accel_update_host()

@@ -139,8 +139,8 @@ def extend_flags(flags, mask, buffer):
     [start - buffer, end + buffer) (end clipped to n - 1 when it reaches n); here the union of those ranges is
     built with a difference array, same result for any number of regions."""
     bad = (flags & mask) != 0
-    if not bad.any():
-        return
+    if not bad.any() or bad.all():
+        return        # a completely flagged array has no edge: the reference leaves it (and its other bits) alone
     edges = np.diff(np.concatenate([[0], bad.view(np.int8), [0]]))
     starts = np.flatnonzero(edges == 1)
     ends = np.flatnonzero(edges == -1)

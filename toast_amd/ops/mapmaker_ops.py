@@ -10,7 +10,7 @@ import numpy as np
 
 from ..accel import native
 from ..data import defaults
-from ..pixels import PixelData, covariance_apply, covariance_invert
+from ..pixels import PixelData, covariance_apply, covariance_invert, map_reduce_apply
 from ..traits import Bool, Float, ImplementationType, Instance, Int, List, Unicode
 from .operator import Operator
 from .pipeline import Pipeline, uncached_detector_sets
@@ -303,10 +303,15 @@ class _MapBuilder(Operator):
         return nnz
 
     def _sync(self, pd):
-        # sync_alltoallv and sync_allreduce give identical results (reference test
-        # src/toast/tests/ops_mapmaker_utils.py:211-397); on xGMI one in-place RCCL all-reduce of
-        # the device buffer serves both.
-        pd.sync_allreduce()
+        # sync_alltoallv (every submap summed by its owner) and sync_allreduce give the same sums (reference test
+        # src/toast/tests/ops_mapmaker_utils.py:211-397); device-resident maps: RCCL reduce-scatter + all-gather, or
+        # one all-reduce, on the kernels' stream (pixels.py)
+        if getattr(self, "_defer_sync", False):
+            return          # the caller reduces and applies the covariance in one owner-computes pass
+        if self.sync_type == "alltoallv":
+            pd.sync_alltoallv()
+        else:
+            pd.sync_allreduce()
 
     def _implementations(self):
         return _IMPLS
@@ -631,11 +636,13 @@ class CovarianceAndHits(Operator):
             # sides are refreshed when somebody reads them (PixelData.data)
             cov = invcov.duplicate_on_device()
             data[self.covariance] = cov
-            covariance_invert(cov, self.rcond_threshold, rcond=data[self.rcond])
+            covariance_invert(cov, self.rcond_threshold, rcond=data[self.rcond],
+                              use_alltoallv=(self.sync_type == "alltoallv"))
         else:
             cov = invcov.duplicate()
             data[self.covariance] = cov
-            covariance_invert(cov, self.rcond_threshold, rcond=data[self.rcond])
+            covariance_invert(cov, self.rcond_threshold, rcond=data[self.rcond],
+                              use_alltoallv=(self.sync_type == "alltoallv"))
         if self.inverse_covariance is None:
             del data[inv_key]
 
@@ -715,6 +722,11 @@ class BinMap(Operator):
             det_data=self.det_data, det_data_units=self.det_data_units, det_mask=self.det_mask,
             det_flags=self.det_flags, det_flag_mask=self.det_flag_mask, shared_flags=self.shared_flags,
             shared_flag_mask=self.shared_flag_mask, sync_type=self.sync_type)
+        # Nobody needs the summed noise-weighted map itself: leave the sum over processes to the owner-computes pass
+        # that also applies the covariance (one reduce-scatter + all-gather instead of all-reduce + full-map multiply)
+        fuse_sync = (self.noiseweighted is None and self.sync_type == "alltoallv"
+                     and data.comm.comm_world is not None)
+        build_zmap._defer_sync = fuse_sync
         accum_ops = []
         if self.pre_process is not None:
             accum_ops.append(self.pre_process)
@@ -728,6 +740,7 @@ class BinMap(Operator):
                 det_mask=self.det_mask, det_flags=self.det_flags, det_flag_mask=self.det_flag_mask,
                 shared_flags=self.shared_flags, shared_flag_mask=self.shared_flag_mask, sync_type=self.sync_type,
                 compact_cache=self.compact_cache)
+            otf._defer_sync = fuse_sync
             accum = Pipeline(detector_sets=["ALL"], operators=accum_ops + [otf])
             accum.apply(data, detectors=detectors, use_accel=True)
         else:
@@ -737,7 +750,11 @@ class BinMap(Operator):
             accum.apply(data, detectors=detectors, use_accel=use_accel)
         if self.noiseweighted is not None:
             data[self.noiseweighted] = data[self.binned].duplicate()
-        covariance_apply(cov, data[self.binned], use_alltoallv=(self.sync_type == "alltoallv"))
+        if fuse_sync:
+            # binned = C . (sum over processes of zmap): reduce-scatter, covariance on the owned pixels, all-gather
+            map_reduce_apply(cov, data[self.binned], sync_type=self.sync_type)
+        else:
+            covariance_apply(cov, data[self.binned], use_alltoallv=(self.sync_type == "alltoallv"))
 
     def _on_the_fly(self, data, detectors, use_accel):
         """Pointing-on-the-fly applies when the pointing is not cached (``full_pointing=False``

@@ -399,6 +399,10 @@ class SolverLHS(Operator):
                    out_ptr=accel_device_ptr(amps_out.local), out_bytes=amps_out.local.nbytes,
                    det_flag_mask=binning.det_flag_mask, shared_flag_mask=binning.shared_flag_mask,
                    tmpl_flag_mask=tmpl.det_flag_mask, passes=[], prior=None)
+        world = dist._world()
+        # several processes, one GPU each: sum over processes and covariance in one owner-computes pass on the stream
+        ctx["owner_computes"] = bool(world is not None and binning.sync_type == "alltoallv" and world.device_comm()
+                                     and dist.replicated)
         if tmpl.use_noise_prior and tmpl._prior is not None:
             tmpl._prior.to_device()
             ctx["prior"] = tmpl._prior
@@ -469,7 +473,12 @@ class SolverLHS(Operator):
         from .. import capi
 
         D = capi.dev
-        D.cov_apply_diag(c["n_local"], c["nps"], c["nnz"], c["cov_ptr"], c["zmap_ptr"])
+        if c.get("owner_computes"):
+            # zmap = C . (sum over processes of zmap) in one owner-computes pass on this stream: RCCL reduce-scatter,
+            # covariance on the owned pixel shard, all-gather (toast_hip_comm_map_reduce_apply_dev)
+            D.comm_map_reduce_apply(c["n_local"] * c["nps"], c["nnz"], c["cov_ptr"], c["zmap_ptr"], reduce=True)
+        else:
+            D.cov_apply_diag(c["n_local"], c["nps"], c["nnz"], c["cov_ptr"], c["zmap_ptr"])
         for ps in c["passes"]:
             if c["on_the_fly"]:
                 D.otf_offset_scan_project(ps["pt"], ps["step"], ps["ao"], ps["nav"], c["in_ptr"], c["out_ptr"],
@@ -535,7 +544,8 @@ class SolverLHS(Operator):
         zmap.accel_used(True)
         amps_out.accel_used(True)
         plan["first"].replay()
-        zmap.sync_allreduce()
+        if not ctx.get("owner_computes"):
+            zmap.sync_allreduce()      # (device-resident: an RCCL all-reduce on the same stream; no-op for one process)
         plan["second"].replay()
         if not getattr(self, "keep_on_device", False):
             native().accel_synchronize()

@@ -19,6 +19,7 @@ from .accel import (
     accel_data_update_device,
     accel_data_update_host,
     accel_device_ptr,
+    accel_hold,
     native,
 )
 
@@ -150,6 +151,63 @@ class PixelDistribution:
         return self._owned_submaps
 
 
+
+    @property
+    def replicated(self):
+        """True when every process holds the same local submaps (the layout of one process per GPU after
+        ``unify_local_submaps``): the owner-computes collectives can then run as reduce-scatter / all-gather over
+        contiguous pixel shards of the one buffer all ranks share the shape of."""
+        if getattr(self, "_replicated", None) is None:
+            w = self._world()
+            if w is None:
+                self._replicated = True
+            else:
+                mine = np.zeros(self._n_submap, dtype=np.int64)
+                if self._local_submaps is not None:
+                    mine[self._local_submaps] = 1
+                lo, hi = mine.copy(), mine.copy()
+                w.allreduce_array_(lo, op="min")
+                w.allreduce_array_(hi, op="max")
+                self._replicated = bool(np.array_equal(lo, hi))
+        return self._replicated
+
+    @property
+    def alltoallv_info(self):
+        """(send_counts, send_displ, recv_counts, recv_displ, recv_locations) of the submap exchange with the owners, in
+        units of submaps (reference pixels.py:317-414).  A process sends each of its local submaps to that submap's
+        owner; an owner receives, process by process in rank order, the submaps it owns that the sender holds, each
+        in increasing submap order.  ``recv_locations[sm]`` lists the slots of the copies of owned submap ``sm`` in the
+        receive buffer.  Local submaps must be sorted (owners then appear in rank order along the local buffer)."""
+        if getattr(self, "_alltoallv_info", None) is not None:
+            return self._alltoallv_info
+        w = self._world()
+        local = np.zeros(0, dtype=np.int64) if self._local_submaps is None else self._local_submaps
+        if w is None:
+            one = np.array([local.size], dtype=np.int32)
+            zero = np.zeros(1, dtype=np.int32)
+            self._alltoallv_info = (one, zero, one.copy(), zero.copy(),
+                                    {int(sm): np.array([k], dtype=np.int32) for k, sm in enumerate(local)})
+            return self._alltoallv_info
+        if np.any(np.diff(local) <= 0):
+            raise RuntimeError("alltoallv needs the local submaps in increasing order")
+        size, rank = w.world_size, w.world_rank
+        owners = self.submap_owners
+        holds = np.zeros(self._n_submap, dtype=np.uint8)
+        holds[local] = 1
+        holds = w.allgather_array(holds).astype(bool)            # [size, n_submap]
+        send_counts = np.bincount(owners[local], minlength=size).astype(np.int32)
+        send_displ = (np.cumsum(send_counts) - send_counts).astype(np.int32)
+        owned = np.flatnonzero(owners == rank)
+        copies = holds[:, owned]                                  # [sender, owned submap]
+        recv_counts = copies.sum(axis=1).astype(np.int32)
+        recv_displ = (np.cumsum(recv_counts) - recv_counts).astype(np.int32)
+        slot = (np.cumsum(copies.ravel()) - 1).reshape(copies.shape)
+        recv_locations = {int(sm): slot[copies[:, j], j].astype(np.int32) for j, sm in enumerate(owned)
+                          if copies[:, j].any()}
+        self._alltoallv_info = (send_counts, send_displ, recv_counts, recv_displ, recv_locations)
+        return self._alltoallv_info
+
+
 def unify_local_submaps(hit_submaps, comm):
     """Union of hit submaps over all processes (one-off MAX all-reduce): every process then
     holds the same ``local_submaps`` so that the per-iteration map reduction is a plain
@@ -172,7 +230,7 @@ class PixelData(AcceleratorObject):
         self._shape = (dist.n_local_submap, dist.n_pix_submap, self._n_value)
         self._raw = np.zeros(int(np.prod(self._shape)), dtype=self._dtype)
         self._data = self._raw.reshape(self._shape)
-        self._pristine = True   # host side still all zero and never handed out
+        self._pristine = True   # host side still all zero and never handed out (one way: never set back to True)
 
     distribution = property(lambda self: self._dist)
     n_value = property(lambda self: self._n_value)
@@ -327,8 +385,9 @@ class PixelData(AcceleratorObject):
             self.accel_reset()   # the device copy is the current one; the host side is refreshed on access
             return
         if not self._pristine:
+            # the buffer has been handed out (.raw / .data / a view): a caller may still hold it and write after this
+            # reset, so the "known zero" shortcut is gone for good -- host_is_zero() looks at the contents from now on
             self._raw[:] = 0
-            self._pristine = True
         if self.accel_exists():
             self.accel_reset()
 
@@ -352,7 +411,8 @@ class PixelData(AcceleratorObject):
         if not self.accel_in_use():
             raise RuntimeError("duplicate_on_device: the data is not in use on the device")
         dup = PixelData(self._dist, self._dtype, n_value=self._n_value, units=self.units)
-        dup.accel_create(self._accel_name + "_copy")
+        with accel_hold(self):      # a failed allocation must not evict the source of the copy
+            dup.accel_create(self._accel_name + "_copy")
         capi.dev.copy(accel_device_ptr(dup._raw), accel_device_ptr(self._raw), self._raw.nbytes)
         dup.accel_used(True)
         return dup
@@ -371,60 +431,123 @@ class PixelData(AcceleratorObject):
         holder.__cuda_array_interface__ = dict(shape=(self._raw.size,), typestr=typestr, data=(ptr, False), version=3)
         return torch.as_tensor(holder, device=torch.device("cuda", torch.cuda.current_device()))
 
-    def sync_allreduce(self, comm=None):
-        """Sum the map over all processes; every process ends with the total (all processes
-        must hold the same local submaps).  Device-resident data is reduced in place by RCCL."""
+    def _device_collectives(self, comm):
+        """Device-resident data reduced in place through the library's RCCL communicator on the kernels' stream."""
+        from . import capi
+
+        return (self.accel_in_use() and comm.device_comm() and self._dtype in capi.dev.COMM_DTYPES
+                and self._dist.replicated)
+
+    def sync_allreduce(self, comm=None, comm_bytes=10000000):
+        """Sum the map over all processes; every process ends with the total (reference pixels.py:710-780; all
+        processes must hold the same local submaps).  Device-resident data: one in-place RCCL all-reduce enqueued on
+        the kernels' stream -- no host synchronisation before or after, the next kernel simply follows in stream
+        order.  ``comm_bytes`` (the reference's message size on the host) has no meaning here."""
+        del comm_bytes
         comm = self._dist.comm if comm is None else comm
         if comm is None or comm.comm_world is None:
             return
-        if self.accel_in_use() and comm._dist.get_backend() == "nccl":
-            native().accel_synchronize()  # kernels run on the library stream
-            comm.allreduce_tensor_(self.device_tensor())
-            import torch
+        if self._device_collectives(comm):
+            from . import capi
 
-            torch.cuda.current_stream().synchronize()
-        else:
-            restore = False
-            if self.accel_in_use():
-                self.accel_update_host()
-                restore = True
-            self._pristine = False
-            comm.allreduce_array_(self._raw)
-            if restore:
-                self.accel_update_device()
-
-    def sync_alltoallv(self, comm=None, **kwargs):
-        """Same result as :meth:`sync_allreduce` (the reference test
-        src/toast/tests/ops_mapmaker_utils.py:211-397 asserts the equivalence).  The reference's
-        owner-computes alltoallv (pixels.py:878-970) sends every submap to one owner, reduces there
-        and sends the totals back.  With one process per GPU every rank holds the union of the hit
-        submaps (``unify_local_submaps``), so "owner" = the rank that holds slice r of the flat map:
-        RCCL reduce-scatter (owners reduce) + all-gather (totals go back), in place on the device
-        buffer.  Every rank receives the owner's bits, like in the reference."""
-        comm = self._dist.comm if comm is None else comm
-        if comm is None or comm.comm_world is None:
+            capi.dev.comm_allreduce(accel_device_ptr(self._raw), self._raw.size, self._dtype, "sum")
             return
-        import torch
+        restore = False
+        if self.accel_in_use():
+            self.accel_update_host()
+            restore = True
+        self._pristine = False
+        comm.allreduce_array_(self._raw)
+        if restore:
+            self.accel_update_device()
 
-        if self.accel_in_use() and comm._dist.get_backend() == "nccl":
-            native().accel_synchronize()  # kernels run on the library stream
-            comm.reduce_scatter_allgather_(self.device_tensor())
-            torch.cuda.current_stream().synchronize()
+    # ---- owner-computes exchange (reference pixels.py:780-967)
+    @property
+    def _n_submap_value(self):
+        return self._dist.n_pix_submap * self._n_value
+
+    @staticmethod
+    def local_reduction(n_submap_value, receive_locations, receive, reduce_buf):
+        """Default ``local_func``: every owned submap becomes the sum of its copies (pixels.py:780-789)."""
+        for locs in receive_locations.values():
+            reduce_buf[:] = 0
+            for lc in locs:
+                reduce_buf += receive[lc:lc + n_submap_value]
+            for lc in locs:
+                receive[lc:lc + n_submap_value] = reduce_buf
+
+    def setup_alltoallv(self):
+        """Counts, displacements and the persistent receive / reduce buffers of the exchange (pixels.py:791-876)."""
+        if getattr(self, "_send_counts", None) is not None:
+            return
+        send_counts, send_displ, recv_counts, recv_displ, recv_locations = self._dist.alltoallv_info
+        scale = self._n_submap_value
+        self._send_counts = scale * np.asarray(send_counts, dtype=np.int64)
+        self._send_displ = scale * np.asarray(send_displ, dtype=np.int64)
+        self._recv_counts = scale * np.asarray(recv_counts, dtype=np.int64)
+        self._recv_displ = scale * np.asarray(recv_displ, dtype=np.int64)
+        self._recv_locations = {sm: scale * np.asarray(locs, dtype=np.int64) for sm, locs in recv_locations.items()}
+        self.reduce_buf = np.zeros(scale, dtype=self._dtype)
+        if self._dist._world() is None:
+            self.receive = self.raw          # serial: owned submaps are the local ones, in place
         else:
-            restore = False
-            if self.accel_in_use():
-                self.accel_update_host()
-                restore = True
-            self._pristine = False
-            t = torch.from_numpy(self._raw)
-            if comm._dist.get_backend() == "nccl":
-                d = t.to(comm._collective_device())
-                comm.reduce_scatter_allgather_(d)
-                t.copy_(d.cpu())
+            self.receive = np.zeros(int(self._recv_displ[-1] + self._recv_counts[-1]), dtype=self._dtype)
+
+    def forward_alltoallv(self):
+        """Send every local submap to its owner (pixels.py:878-909).  Host data."""
+        if self.accel_in_use():
+            self.accel_update_host()
+        self.setup_alltoallv()
+        w = self._dist._world()
+        if w is None:
+            return
+        w.alltoallv_array(self.raw, self._send_counts, self._send_displ, self.receive, self._recv_counts,
+                          self._recv_displ)
+
+    def reverse_alltoallv(self):
+        """Send the owners' copies back to every holder (pixels.py:911-939)."""
+        w = self._dist._world()
+        if w is None:
+            return
+        if getattr(self, "_send_counts", None) is None:
+            raise RuntimeError("Cannot do reverse alltoallv before buffers have been setup")
+        w.alltoallv_array(self.receive, self._recv_counts, self._recv_displ, self.raw, self._send_counts,
+                          self._send_displ)
+
+    def sync_alltoallv(self, local_func=None, comm=None):
+        """Owner-computes exchange (reference pixels.py:942-967): every submap goes to its owner, ``local_func(
+        n_submap_value, receive_locations, receive, reduce_buf)`` works on the owned submaps there (default: sum of the
+        copies), the results go back to every holder.
+
+        Device-resident data held with the same local submaps on every rank runs as RCCL reduce-scatter -> per-pixel
+        kernel on the owned pixel shard -> all-gather on the kernels' stream, when ``local_func`` is the default or
+        one of the covariance functors of this module (``create_local_apply / _invert / _multiply``: they carry the
+        device form of their operation).  Any other ``local_func`` runs on the host with the reference's buffers."""
+        if comm is not None and comm is not self._dist.comm:
+            raise RuntimeError("sync_alltoallv works on the communicator of the pixel distribution")
+        w = self._dist._world()
+        device_form = local_func is None or hasattr(local_func, "on_device")
+        if w is not None and device_form and self._device_collectives(w):
+            if local_func is None:
+                from . import capi
+
+                if self._dtype == np.float64:
+                    capi.dev.comm_map_reduce_apply(self._raw.size // self._n_value, self._n_value, 0,
+                                                   accel_device_ptr(self._raw), reduce=True)
+                else:   # integer / single precision maps: the plain all-reduce gives the same sums
+                    capi.dev.comm_allreduce(accel_device_ptr(self._raw), self._raw.size, self._dtype, "sum")
             else:
-                comm.reduce_scatter_allgather_(t)
-            if restore:
-                self.accel_update_device()
+                local_func.on_device(self)
+            return
+        restore = self.accel_in_use()
+        self.forward_alltoallv()
+        self._pristine = False
+        if local_func is None:
+            local_func = self.local_reduction
+        local_func(self._n_submap_value, self._recv_locations, self.receive, self.reduce_buf)
+        self.reverse_alltoallv()
+        if restore:
+            self.accel_update_device()
 
     # accelerator protocol
     def _accel_exists(self):
@@ -448,42 +571,190 @@ class PixelData(AcceleratorObject):
 
 
 # ----------------------------------------------------------------------------- covariance
+def _mapnnz(npp):
+    return int(((np.sqrt(8 * npp.n_value) - 1) / 2) + 0.5)
+
+
+def _ensure_on_device(obj, name):
+    if not obj.accel_in_use():
+        if not obj.accel_exists():
+            obj.accel_create(name)
+        obj.accel_update_device()
+
+
+def _owner_computes_on_device(pd):
+    w = pd.distribution._world()
+    return w is not None and pd._device_collectives(w)
+
+
+class _LocalFunc:
+    """A ``local_func`` of ``PixelData.sync_alltoallv`` (signature ``(n_submap_value, receive_locations, receive,
+    reduce_buf)``, reference covariance.py:34-75, 134-177, 224-259) that also knows its device form ``on_device(pd)``:
+    the per-pixel kernel on this rank's pixel shard followed by the all-gather."""
+
+
+class create_local_apply(_LocalFunc):
+    """m <- cov . m on the owned submaps; the copies of a submap are taken to be equal (the map was reduced before),
+    the first one is multiplied and written to every location (covariance.py:224-259).  ``cov`` must have gone
+    through ``forward_alltoallv`` for the host form."""
+
+    def __init__(self, n_pix_submap, mapnnz, cov):
+        self.n_pix_submap, self.mapnnz, self.cov = n_pix_submap, mapnnz, cov
+
+    def __call__(self, n_submap_value, receive_locations, receive, reduce_buf):
+        cov = self.cov
+        n_cov = self.n_pix_submap * cov.n_value
+        for sm, locs in receive_locations.items():
+            c0 = cov._recv_locations[sm][0]
+            reduce_buf[:] = receive[locs[0]:locs[0] + n_submap_value]
+            cov.reduce_buf[:] = cov.receive[c0:c0 + n_cov]
+            native().cov_apply_diag(1, self.n_pix_submap, self.mapnnz, cov.reduce_buf, reduce_buf, False)
+            for lc in locs:
+                receive[lc:lc + n_submap_value] = reduce_buf
+
+    def on_device(self, m, reduce=False):
+        from . import capi
+
+        with accel_hold(m):
+            _ensure_on_device(self.cov, "covariance")
+        capi.dev.comm_map_reduce_apply(m.buffer.size // m.n_value, self.mapnnz, accel_device_ptr(self.cov.buffer),
+                                       accel_device_ptr(m.buffer), reduce=reduce)
+
+
+class create_local_invert(_LocalFunc):
+    """Eigendecomposition / inverse of the owned submaps' blocks with the condition-number threshold
+    (covariance.py:34-75): the first copy is processed and written to every location; ``rcond`` (optional PixelData,
+    ``setup_alltoallv`` done) receives the inverse condition numbers."""
+
+    def __init__(self, n_pix_submap, mapnnz, threshold, rcond, invert=False):
+        self.n_pix_submap, self.mapnnz, self.threshold, self.rcond, self.invert = (n_pix_submap, mapnnz, threshold,
+                                                                                   rcond, invert)
+
+    def __call__(self, n_submap_value, receive_locations, receive, reduce_buf):
+        rcond = self.rcond
+        for sm, locs in receive_locations.items():
+            reduce_buf[:] = receive[locs[0]:locs[0] + n_submap_value]
+            if rcond is None:
+                rdata = np.zeros(self.n_pix_submap)
+            else:
+                rcond.reduce_buf[:] = 0.0
+                rdata = rcond.reduce_buf
+            native().cov_eigendecompose_diag(1, self.n_pix_submap, self.mapnnz, reduce_buf, rdata, float(self.threshold),
+                                             bool(self.invert), False)
+            for lc in locs:
+                receive[lc:lc + n_submap_value] = reduce_buf
+            if rcond is not None:
+                for lc in rcond._recv_locations[sm]:
+                    rcond.receive[lc:lc + self.n_pix_submap] = rcond.reduce_buf
+
+    def on_device(self, npp):
+        from . import capi
+
+        rcond = self.rcond
+        d_rc = 0
+        if rcond is not None:
+            with accel_hold(npp):
+                if not rcond.accel_exists():
+                    rcond.accel_create("rcond", zero_out=True)
+            d_rc = accel_device_ptr(rcond.buffer)
+        capi.dev.comm_cov_invert(npp.buffer.size // npp.n_value, self.mapnnz, accel_device_ptr(npp.buffer), d_rc,
+                                 float(self.threshold), invert=self.invert)
+        if rcond is not None:
+            rcond.accel_used(True)
+
+
+class create_local_multiply(_LocalFunc):
+    """npp1 <- npp1 . npp2 on the owned submaps (covariance.py:134-177); ``other`` must have gone through
+    ``forward_alltoallv`` for the host form."""
+
+    def __init__(self, n_pix_submap, mapnnz, other):
+        self.n_pix_submap, self.mapnnz, self.other = n_pix_submap, mapnnz, other
+
+    def __call__(self, n_submap_value, receive_locations, receive, reduce_buf):
+        other = self.other
+        for sm, locs in receive_locations.items():
+            o0 = other._recv_locations[sm][0]
+            reduce_buf[:] = receive[locs[0]:locs[0] + n_submap_value]
+            other.reduce_buf[:] = other.receive[o0:o0 + n_submap_value]
+            native().cov_mult_diag(1, self.n_pix_submap, self.mapnnz, reduce_buf, other.reduce_buf, False)
+            for lc in locs:
+                receive[lc:lc + n_submap_value] = reduce_buf
+
+    def on_device(self, npp1):
+        from . import capi
+
+        with accel_hold(npp1):
+            _ensure_on_device(self.other, "covariance2")
+        capi.dev.comm_cov_mult(npp1.buffer.size // npp1.n_value, self.mapnnz, accel_device_ptr(npp1.buffer),
+                               accel_device_ptr(self.other.buffer))
+
+
 def covariance_apply(npp, m, use_alltoallv=False):
-    """In-place ``m <- npp . m`` per pixel (reference: src/toast/covariance.py:262-306).
-    Runs where the map lives: on the device copies when both are resident there."""
-    mapnnz = int(((np.sqrt(8 * npp.n_value) - 1) / 2) + 0.5)
+    """In-place ``m <- npp . m`` per pixel (reference: src/toast/covariance.py:262-306).  Runs where the map lives: on
+    the device copies when the map is resident there.  ``use_alltoallv``: every process multiplies only the submaps
+    it owns and the results are exchanged (on the device: its pixel shard, then an all-gather)."""
+    mapnnz = _mapnnz(npp)
     if npp.distribution != m.distribution:
         raise RuntimeError("covariance matrix and map must have same pixel distribution")
     if m.n_value != mapnnz:
         raise RuntimeError("covariance matrix and map have incompatible NNZ values")
+    if use_alltoallv and m.distribution._world() is not None:
+        lapply = create_local_apply(npp.distribution.n_pix_submap, mapnnz, npp)
+        if _owner_computes_on_device(m):
+            lapply.on_device(m)
+        else:
+            npp.forward_alltoallv()
+            m.sync_alltoallv(local_func=lapply)
+        return
     on_dev = m.accel_in_use()
-    if on_dev and not npp.accel_in_use():
-        if not npp.accel_exists():
-            npp.accel_create("covariance")
-        npp.accel_update_device()
-    if (not on_dev) and npp.accel_in_use():
+    if on_dev:
+        with accel_hold(m):
+            _ensure_on_device(npp, "covariance")
+    elif npp.accel_in_use():
         npp.accel_update_host()
     native().cov_apply_diag(npp.distribution.n_local_submap, npp.distribution.n_pix_submap, mapnnz,
                             npp.buffer if on_dev else npp.raw, m.buffer if on_dev else m.raw, on_dev)
 
 
+def map_reduce_apply(npp, m, sync_type="alltoallv"):
+    """``m <- npp . (sum over processes of m)``: the finalisation of a binned map and the middle of every PCG
+    iteration.  With device-resident data and ``sync_type="alltoallv"`` one owner-computes pass -- reduce-scatter,
+    ``cov_apply_diag`` on the owned pixel shard, all-gather -- instead of an all-reduce followed by every process
+    multiplying the whole map; otherwise ``sync_allreduce`` / ``sync_alltoallv`` followed by ``covariance_apply``."""
+    if sync_type == "alltoallv" and _owner_computes_on_device(m):
+        create_local_apply(npp.distribution.n_pix_submap, _mapnnz(npp), npp).on_device(m, reduce=True)
+        return
+    if sync_type == "alltoallv":
+        m.sync_alltoallv()
+    else:
+        m.sync_allreduce()
+    covariance_apply(npp, m, use_alltoallv=(sync_type == "alltoallv"))
+
+
 def covariance_multiply(npp1, npp2, use_alltoallv=False):
     """In-place per-pixel product of two block-diagonal covariances, ``npp1 <- npp1 npp2`` (reference:
     src/toast/covariance.py:179-221 -> cov_mult_diag).  Runs where ``npp1`` lives."""
-    mapnnz = int(((np.sqrt(8 * npp1.n_value) - 1) / 2) + 0.5)
+    mapnnz = _mapnnz(npp1)
     if npp1.distribution != npp2.distribution:
         raise RuntimeError("covariance matrices must have same pixel distribution")
     if npp1.n_value != npp2.n_value:
         raise RuntimeError("covariance matrices must have same n_values")
-    on_dev = npp1.accel_in_use()
-    if on_dev and not npp2.accel_in_use():
-        if not npp2.accel_exists():
-            npp2.accel_create("covariance2")
-        npp2.accel_update_device()
-    if (not on_dev) and npp2.accel_in_use():
-        npp2.accel_update_host()
-    native().cov_mult_diag(npp1.distribution.n_local_submap, npp1.distribution.n_pix_submap, mapnnz,
-                           npp1.buffer if on_dev else npp1.raw, npp2.buffer if on_dev else npp2.raw, on_dev)
+    if use_alltoallv and npp1.distribution._world() is not None:
+        lmult = create_local_multiply(npp1.distribution.n_pix_submap, mapnnz, npp2)
+        if _owner_computes_on_device(npp1):
+            lmult.on_device(npp1)
+        else:
+            npp2.forward_alltoallv()
+            npp1.sync_alltoallv(local_func=lmult)
+    else:
+        on_dev = npp1.accel_in_use()
+        if on_dev:
+            with accel_hold(npp1):
+                _ensure_on_device(npp2, "covariance2")
+        elif npp2.accel_in_use():
+            npp2.accel_update_host()
+        native().cov_mult_diag(npp1.distribution.n_local_submap, npp1.distribution.n_pix_submap, mapnnz,
+                               npp1.buffer if on_dev else npp1.raw, npp2.buffer if on_dev else npp2.raw, on_dev)
     if npp1.units is not None and npp2.units is not None:
         try:
             npp1.update_units(npp1.units * npp2.units)
@@ -493,19 +764,40 @@ def covariance_multiply(npp1, npp2, use_alltoallv=False):
 
 def covariance_invert(npp, threshold, rcond=None, use_alltoallv=False):
     """In-place inverse of the per-pixel blocks with an rcond threshold
-    (reference: src/toast/covariance.py:20-110 -> cov_eigendecompose_diag).  Runs where the matrix
+    (reference: src/toast/covariance.py:78-131 -> cov_eigendecompose_diag).  Runs where the matrix
     lives: a device-resident covariance is inverted there and stays there (its condition-number map
-    too); host data is staged through the GPU by the host-level entry point."""
-    mapnnz = int(((np.sqrt(8 * npp.n_value) - 1) / 2) + 0.5)
-    if rcond is not None and rcond.distribution != npp.distribution:
-        raise RuntimeError("covariance matrix and condition number map must have same pixel distribution")
+    too); host data is staged through the GPU by the host-level entry point.  ``use_alltoallv``: every process
+    inverts only the submaps it owns (on the device: its pixel shard) and the results are exchanged."""
+    mapnnz = _mapnnz(npp)
+    if npp.n_value <= 0:
+        raise RuntimeError(f"NNZ = {npp.n_value}. It is an error to invert a pixel matrix with non-positive dimensions.")
+    if rcond is not None:
+        if rcond.distribution != npp.distribution:
+            raise RuntimeError("covariance matrix and condition number map must have same pixel distribution")
+        if rcond.n_value != 1:
+            raise RuntimeError("condition number map should have n_value = 1")
     dist = npp.distribution
+    if use_alltoallv and dist._world() is not None:
+        linvert = create_local_invert(dist.n_pix_submap, mapnnz, threshold, rcond, invert=True)
+        if _owner_computes_on_device(npp):
+            linvert.on_device(npp)
+            return
+        if rcond is not None:
+            if rcond.accel_in_use():
+                rcond.accel_update_host()
+            rcond.setup_alltoallv()
+        npp.sync_alltoallv(local_func=linvert)
+        if rcond is not None:
+            rcond._pristine = False
+            rcond.reverse_alltoallv()
+        return
     if npp.accel_in_use():
         from . import capi
 
         cond = PixelData(dist, np.float64, n_value=1) if rcond is None else rcond
-        if not cond.accel_exists():
-            cond.accel_create("rcond", zero_out=True)
+        with accel_hold(npp):
+            if not cond.accel_exists():
+                cond.accel_create("rcond", zero_out=True)
         capi.dev.cov_eigendecompose_diag(dist.n_local_submap, dist.n_pix_submap, mapnnz, accel_device_ptr(npp.buffer),
                                          accel_device_ptr(cond.buffer), float(threshold), True)
         cond.accel_used(True)
