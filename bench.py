@@ -64,13 +64,8 @@ def parse():
                          "about 10 s, most of it the host-side simulation of its inputs)")
     ap.add_argument("--pcg-extra", action="store_true",
                     help="also time the full PCG LHS with offset templates (operator sequence vs fused kernels)")
-    ap.add_argument("--no-arena", action="store_true", help="accepted for compatibility; separate allocations are the default")
-    ap.add_argument("--probe", action="store_true",
-                    help="EXPERIMENT (not what operators get): over-allocate candidate buffers, time a stream on "
-                         "each and keep the fastest HBM regions (profiles/r01_b_tuning_experiments.txt section 14)")
-    ap.add_argument("--arena", action="store_true",
-                    help="EXPERIMENT: one arena carved in allocation order instead of one allocation per buffer")
-    ap.add_argument("--no-probe", action="store_true", help="accepted for compatibility; probing is off by default")
+    ap.add_argument("--torch-alloc", action="store_true",
+                    help="EXPERIMENT: allocate the TOD-domain buffers with torch instead of the library's memory manager")
     ap.add_argument("--no-fft", action="store_true", help="skip the FFT noise-weighting measurement")
     ap.add_argument("--no-cfg4", action="store_true",
                     help="with --gpus 8 and the default workload: do not also time the configs[3] shard (cfg4)")
@@ -243,81 +238,35 @@ def run(args, workload, world, rank, dev, headline=True):
     d_sflags = torch.from_numpy(sflags_h).to(dev)
     d_hsub = torch.zeros(n_submap, dtype=torch.uint8, device=dev)
 
-    # One arena for every persistent TOD-domain buffer, allocated first on the fresh device and
-    # carved at 2 MiB boundaries (the reference's OmpPoolResource idea,
-    # src/toast/_libtoast/accelerator.hpp:33-71): one large early allocation gets the most
-    # contiguous physical backing.
-    def _align(n):
-        return (n + (1 << 21) - 1) & ~((1 << 21) - 1)
-
     nds = n_det * n_samp
     sizes = {"pixels": nds * 8, "weights": nds * 24, "tod": nds * 8, "tod2": nds * 8, "dflags": nds}
     placement = None
     # Default: one allocation per buffer, which is what the product's memory manager does
     # (toast_hip::Manager::create -> hipMalloc per registered array); operators get exactly this.
-    allocator = "one hipMalloc per buffer (same policy as toast_hip::Manager)"
-    arena = None
-    if args.arena and not args.probe:
-        arena = torch.empty(sum(_align(v) for v in sizes.values()), dtype=torch.uint8, device=dev)
-        allocator = "experiment: one arena carved in allocation order"
-    cursor = [0]
+    allocator = ("toast_hip::Manager (one block per buffer through toast_hip_device_malloc: the operators' allocation "
+                 "and placement policy)")
+    if args.torch_alloc:
+        allocator = "experiment: torch caching allocator (one hipMalloc per buffer, no placement policy)"
+    managed = []     # device blocks from the library's memory manager (released at the end of run())
+
+    def manager_tensor(nbytes, dtype, shape):
+        """A torch view of a block allocated by toast_hip::Manager::device_alloc -- the allocation AND placement
+        policy every operator's buffers get (toast_hip_device_malloc(flags = -1))."""
+        ptr = capi.device_malloc(nbytes, -1)
+        managed.append(ptr)
+
+        class _Block:
+            pass
+
+        blk = _Block()
+        typestr = {torch.int64: "<i8", torch.float64: "<f8", torch.uint8: "|u1"}[dtype]
+        blk.__cuda_array_interface__ = dict(shape=tuple(shape), typestr=typestr, data=(ptr, False), version=3)
+        return torch.as_tensor(blk, device=dev)
 
     def carve(name, dtype, shape):
-        if arena is None:
+        if args.torch_alloc:
             return torch.empty(shape, dtype=dtype, device=dev)
-        nb = sizes[name]
-        view = arena[cursor[0]:cursor[0] + nb].view(dtype).view(shape)
-        cursor[0] += _align(nb)
-        return view
-
-    if args.probe:
-        allocator = "experiment: HBM region probing (fastest of several candidate allocations)"
-        # HBM region probing.  The same kernel runs up to 19 % slower on some multi-GB regions of
-        # HBM than on others (5.05 vs 5.99 TB/s for a pure stream, stable for the lifetime of an
-        # allocation: profiles/r01_b_tuning_experiments.txt section 14).  Allocate more candidate
-        # buffers than needed, time a pure read+write stream on each, keep the fastest ones for
-        # the persistent TOD-domain arrays (the written timestream first) and free the rest.
-        free_b, total_b = torch.cuda.mem_get_info(dev)
-        budget = int(0.45 * total_b)
-        one, three = _align(nds * 8), _align(nds * 24)
-        n_tri = 3 if 3 * three + 4 * one <= budget else (2 if 2 * three + 3 * one <= budget else 1)
-        n_one = max(3, min(8, (budget - n_tri * three) // one))
-        singles = [torch.empty(one, dtype=torch.uint8, device=dev) for _ in range(n_one)]
-        triples = [torch.empty(three, dtype=torch.uint8, device=dev) for _ in range(n_tri)]
-        idx_p = np.arange(n_det, dtype=np.int32)
-        ivl_p = synth.make_intervals(n_samp, 1, rate)
-        ones_p = np.ones(n_det)
-
-        def stream_ms(ptr):
-            D.noise_weight(ptr, n_samp, idx_p, ivl_p, ones_p, stream)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(3):
-                D.noise_weight(ptr, n_samp, idx_p, ivl_p, ones_p, stream)
-            e1.record()
-            e1.synchronize()
-            return e0.elapsed_time(e1) / 3
-
-        for t in singles + triples:
-            t.zero_()
-        t_one = [stream_ms(t.data_ptr()) for t in singles]
-        t_tri = [sum(stream_ms(t.data_ptr() + k * nds * 8) for k in range(3)) for t in triples]
-        order = list(np.argsort(t_one))
-        best_tri = int(np.argmin(t_tri))
-        chosen = {"tod2": singles[order[0]], "tod": singles[order[1]], "pixels": singles[order[2]],
-                  "weights": triples[best_tri]}
-        placement = {
-            "stream_ms_single_candidates": [round(float(x), 3) for x in t_one],
-            "stream_ms_triple_candidates": [round(float(x), 3) for x in t_tri],
-            "chosen": {"tod2": int(order[0]), "tod": int(order[1]), "pixels": int(order[2]), "weights": best_tri},
-        }
-        del singles, triples
-        torch.cuda.empty_cache()
-
-        def carve(name, dtype, shape):  # noqa: F811
-            if name in chosen:
-                return chosen[name][: sizes[name]].view(dtype).view(shape)
-            return torch.empty(shape, dtype=dtype, device=dev)
+        return manager_tensor(sizes[name], dtype, shape)
 
     d_pixels = carve("pixels", torch.int64, (n_det, n_samp))
     d_weights = carve("weights", torch.float64, (n_det, n_samp, 3))
@@ -613,6 +562,8 @@ def run(args, workload, world, rank, dev, headline=True):
         "setup_s": t_setup,
         "allocator": allocator,
         "placement": placement,
+        # what the manager's placement policy did for this process (blocks of 1-8 GB chosen among probed candidates)
+        "allocator_stats": capi.alloc_stats(),
         # per-step RCCL all-reduce of the device-resident zmap (fp64 sum over the detector shards);
         # kernel_ms.allreduce is its stream time on this rank (includes waiting for the slowest rank)
         "allreduce": {
@@ -882,6 +833,11 @@ def run(args, workload, world, rank, dev, headline=True):
             out["cpu_baseline"]["port_value"] = nd * n_samp / time_cpu(make_step(oracle, ()), 3.0)
         del cov_h
 
+    # hand the manager's blocks back (the views above die with this frame; nothing is running any more)
+    torch.cuda.synchronize()
+    del d_pixels, d_weights, d_tod, d_tod2, d_dflags
+    for ptr in managed:
+        capi.device_free(ptr)
     return out
 
 

@@ -79,10 +79,16 @@ int toast_hip_accel_enabled(void);
  * is unchanged, device pointers obtained earlier are still the ones the manager would return
  * (lets a caller replay a prepared launch sequence without looking everything up again). */
 int toast_hip_accel_generation(uint64_t * generation);
-/* Raw device memory with the memory manager's allocation policy (flags = -1), a plain hipMalloc (0)
+/* Raw device memory with the memory manager's allocation and placement policy (flags = -1), a plain hipMalloc (0)
  * or explicit hipExtMallocWithFlags flags (4 = physically contiguous): what bench.py and the
  * placement experiments use so that they see the allocations the operators get. */
 int toast_hip_device_malloc(size_t nbytes, int flags, void ** out);
+/* What the placement policy has done so far in this process (blocks of 1 .. 8 GB are chosen among up to K probed
+ * candidate allocations, TOAST_HIP_ALLOC=probe[:K] | plain | contiguous; runtime.cpp Manager::device_alloc):
+ * blocks chosen by probing, how many of them stream at the fast level, candidates probed, time spent probing,
+ * stream rate (TB/s, read + write) of the last kept block.  Any pointer may be NULL. */
+int toast_hip_alloc_stats(int64_t * probed_blocks, int64_t * fast_blocks, int64_t * candidates, double * probe_ms,
+                          double * last_tbs);
 int toast_hip_device_free(void * p);
 /* Experiment: virtual range backed by chunk_mb-sized physical allocations mapped in order / shuffled
  * (tools/exp_alloc_flags.py, profiles/r02_d_placement_experiments.txt).  The range is never released. */

@@ -2,6 +2,8 @@
 ``test_memory`` (:131-184: create / update_device / update_host / delete round trip for every
 dtype) and ``test_data_stage`` (:186-351: Data.accel_create / update_device / update_host /
 delete by requires()-style dictionaries over detdata, shared and global objects)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -288,3 +290,50 @@ def test_mapmaker_under_memory_cap(tmp_path, pointing):
     assert free[1] > 0 and free[2] > 0
     assert free[1] == capped[1]                                 # hits
     assert np.all(np.abs(free[2:] - capped[2:]) <= 1e-9 * np.abs(free[2:]))
+
+
+def test_placement_policy_of_the_memory_manager():
+    """Blocks of 1 .. 8 GB are chosen among probed candidate allocations (Manager::device_alloc, DESIGN.md section 3):
+    the policy runs for raw blocks (what bench.py allocates) and for registered arrays alike, counts what it did, and
+    ``TOAST_HIP_ALLOC=plain`` turns it off."""
+    import subprocess
+    import sys
+    import textwrap
+
+    code = textwrap.dedent("""
+        import numpy as np
+        from toast_amd import capi
+        from toast_amd.accel import accel_assign_device, accel_data_create, accel_data_delete, accel_data_update_device, accel_data_update_host
+        accel_assign_device(1, 0, 1.0, False)
+        s0 = capi.alloc_stats()
+        small = capi.device_malloc(64 << 20)                  # below the probed size class
+        assert capi.alloc_stats()["probed_blocks"] == s0["probed_blocks"]
+        big = [capi.device_malloc(3 << 29) for _ in range(3)]  # 1.5 GB each
+        s1 = capi.alloc_stats()
+        for p in big + [small]:
+            capi.device_free(p)
+        host = np.arange((5 << 28) // 8, dtype=np.float64)     # 1.25 GB registered array: same policy
+        accel_data_create(host, "big")
+        accel_data_update_device(host, "big")
+        host2 = host.copy(); host[:] = 0
+        accel_data_update_host(host, "big")
+        assert np.array_equal(host, host2)                     # the probe pass ran before the upload, not after
+        accel_data_delete(host, "big")
+        s2 = capi.alloc_stats()
+        print("STATS", s1["probed_blocks"] - s0["probed_blocks"], s1["candidates"] - s0["candidates"],
+              s2["probed_blocks"] - s1["probed_blocks"], s1["last_TBs"], s1["probe_ms"])
+    """)
+    env = dict(os.environ)
+    env.pop("TOAST_HIP_ALLOC", None)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    f = [ln for ln in out.stdout.splitlines() if ln.startswith("STATS")][0].split()
+    blocks, cands, blocks_reg, tbs, ms = int(f[1]), int(f[2]), int(f[3]), float(f[4]), float(f[5])
+    assert blocks == 3 and 3 <= cands <= 12 and blocks_reg == 1 and 2.0 < tbs < 8.0 and 0.0 < ms < 500.0
+    env["TOAST_HIP_ALLOC"] = "plain"
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    f = [ln for ln in out.stdout.splitlines() if ln.startswith("STATS")][0].split()
+    assert int(f[1]) == 0 and int(f[2]) == 0 and int(f[3]) == 0

@@ -254,6 +254,27 @@ def accel_update_host(buf, name="NA"):
     _check(lib().toast_hip_accel_update_host(_p(a), C.c_size_t(a.nbytes), name.encode()))
 
 
+def device_malloc(nbytes, flags=-1):
+    """Raw device memory: flags = -1 with the memory manager's allocation / placement policy (what operators get),
+    0 a plain hipMalloc, otherwise hipExtMallocWithFlags flags.  Returns the device address."""
+    out = C.c_void_p(0)
+    _check(real_lib().toast_hip_device_malloc(C.c_size_t(int(nbytes)), C.c_int(int(flags)), C.byref(out)))
+    return int(out.value or 0)
+
+
+def device_free(ptr):
+    _check(real_lib().toast_hip_device_free(C.c_void_p(int(ptr))))
+
+
+def alloc_stats():
+    """Placement policy counters of this process (toast_hip_alloc_stats)."""
+    pb, fb, cd = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    ms, tbs = C.c_double(0.0), C.c_double(0.0)
+    _check(real_lib().toast_hip_alloc_stats(C.byref(pb), C.byref(fb), C.byref(cd), C.byref(ms), C.byref(tbs)))
+    return dict(probed_blocks=int(pb.value), fast_blocks=int(fb.value), candidates=int(cd.value),
+                probe_ms=float(ms.value), last_TBs=float(tbs.value))
+
+
 def accel_delete(buf, name="NA"):
     a = _raw(buf)
     _check(lib().toast_hip_accel_delete(_p(a), C.c_size_t(a.nbytes), name.encode()))

@@ -486,45 +486,85 @@ int Manager::present(const void * host, size_t nbytes) {
     return 1;
 }
 
-// One allocation function for everything large the manager owns.  TOAST_HIP_ALLOC=contiguous asks the
-// driver for physically contiguous backing (hipDeviceMallocContiguous) for blocks >= 256 MB, falling
-// back to a plain hipMalloc when that fails; default = plain hipMalloc.  Returns nullptr on failure.
+// One allocation function for everything large the manager owns.
+//
+// Placement policy.  The time-major kernels stream one piece of each of ~1000 detector rows at a time, and how fast an
+// allocation streams under that pattern depends on where the driver placed it: 5.05 or 5.99 TB/s, for the lifetime of
+// the allocation (profiles/r02_d_placement_experiments.txt); the headline moves by 12 % with it.
+// Only measuring an allocation tells.  So blocks of the size class that shows the two levels (1 GB .. 8 GB: the
+// timestreams and the pixel numbers; the 17.7 GB weight buffers show a 2.5 % spread and are not probed) are chosen
+// among up to K candidates: each candidate gets one row-parallel read + write pass with the kernels' own access
+// pattern (k_probe_stream, after a first-touch pass); the first one that streams at the fast level is taken, otherwise
+// the fastest of the K.  Candidates are held until the choice is made (a freed slow region would simply be handed out
+// again) and the losers are then released.  Cost: one ~5 ms probe per block on a box that hands out fast memory, K of
+// them on one that does not.
+//   TOAST_HIP_ALLOC=probe[:K]   the policy with K candidates (default: probe:4)
+//   TOAST_HIP_ALLOC=plain       one hipMalloc per block, no probing
+//   TOAST_HIP_ALLOC=contiguous  hipDeviceMallocContiguous for blocks >= 256 MB (experiment: always the slow level)
+// Returns nullptr on failure.
+namespace {
+struct AllocPolicy {
+    bool contiguous = false;
+    int probe_k = 4;
+    double accept_tbs = 5.65;   // read + write bytes / probe time: between the two levels (5.05-5.4 and 5.9-6.0)
+};
+const AllocPolicy & alloc_policy() {
+    static const AllocPolicy pol = [] {
+        AllocPolicy a;
+        const char * e = std::getenv("TOAST_HIP_ALLOC");
+        if (e != nullptr) {
+            const std::string v(e);
+            if (v == "contiguous") {
+                a.contiguous = true;
+                a.probe_k = 0;
+            } else if (v == "plain") {
+                a.probe_k = 0;
+            } else if (v.rfind("probe", 0) == 0) {
+                const char * c = std::strchr(e, ':');
+                const int k = c ? std::atoi(c + 1) : 4;
+                a.probe_k = k < 2 ? 2 : (k > 8 ? 8 : k);
+            }
+        }
+        const char * t = std::getenv("TOAST_HIP_ALLOC_ACCEPT_TBS");
+        if (t != nullptr && std::atof(t) > 0.0) a.accept_tbs = std::atof(t);
+        return a;
+    }();
+    return pol;
+}
+AllocStats g_alloc_stats;
+}  // namespace
+
+const AllocStats & alloc_stats() { return g_alloc_stats; }
+
 void * Manager::device_alloc(size_t nbytes) {
-    static const bool contiguous = [] {
-        const char * e = std::getenv("TOAST_HIP_ALLOC");
-        return e != nullptr && std::string(e) == "contiguous";
-    }();
-    // EXPERIMENT, TOAST_HIP_ALLOC=probe[:K]: blocks >= 1 GB are chosen among K (default 3) candidate allocations by a
-    // row-parallel read + write pass over each (kernels.hip: probe_stream_ms); the same kernels run up to 19 % faster
-    // on some allocations than on others for as long as the allocation lives.
-    static const int probe_k = [] {
-        const char * e = std::getenv("TOAST_HIP_ALLOC");
-        if (e == nullptr || std::string(e).rfind("probe", 0) != 0) return 0;
-        const char * c = std::strchr(e, ':');
-        const int k = c ? std::atoi(c + 1) : 3;
-        return k < 2 ? 2 : (k > 8 ? 8 : k);
-    }();
-    if (probe_k > 0 && nbytes >= (size_t(1) << 30)) {
+    const AllocPolicy & pol = alloc_policy();
+    const size_t lo = size_t(1) << 30, hi = size_t(8) << 30;
+    if (pol.probe_k > 0 && nbytes >= lo && nbytes <= hi) {
         std::vector<void *> cand;
-        std::vector<double> ms;
-        for (int k = 0; k < probe_k; ++k) {
+        std::vector<double> tbs;
+        size_t best = 0;
+        for (int k = 0; k < pol.probe_k; ++k) {
             void * c = nullptr;
             if (hipMalloc(&c, nbytes) != hipSuccess) {
                 (void)hipGetLastError();
-                break;
+                break;   // memory is short: make do with the candidates so far
             }
+            const double ms = probe_stream_ms(c, nbytes, stream_);
             cand.push_back(c);
-            ms.push_back(probe_stream_ms(c, nbytes, stream_));
+            tbs.push_back(ms > 0.0 ? 2.0 * (double)nbytes / ms / 1.0e9 : 0.0);
+            g_alloc_stats.probe_ms += ms;
+            ++g_alloc_stats.candidates;
+            if (tbs.back() > tbs[best]) best = cand.size() - 1;
+            if (tbs.back() >= pol.accept_tbs) break;
         }
         if (!cand.empty()) {
-            size_t best = 0;
-            for (size_t k = 1; k < cand.size(); ++k) {
-                if (ms[k] < ms[best]) best = k;
-            }
+            ++g_alloc_stats.probed_blocks;
+            if (tbs[best] >= pol.accept_tbs) ++g_alloc_stats.fast_blocks;
+            g_alloc_stats.last_tbs = tbs[best];
             if (trace_enabled()) {
                 std::string line;
-                for (size_t k = 0; k < cand.size(); ++k) line += (k ? " " : "") + std::to_string(ms[k]);
-                std::fprintf(stderr, "[toast_hip] probe         %.1f MB: %s ms, kept #%zu\n", nbytes / 1.0e6, line.c_str(),
+                for (size_t k = 0; k < cand.size(); ++k) line += (k ? " " : "") + std::to_string(tbs[k]);
+                std::fprintf(stderr, "[toast_hip] probe         %.1f MB: %s TB/s, kept #%zu\n", nbytes / 1.0e6, line.c_str(),
                              best);
             }
             for (size_t k = 0; k < cand.size(); ++k) {
@@ -534,7 +574,7 @@ void * Manager::device_alloc(size_t nbytes) {
         }
     }
     void * p = nullptr;
-    if (contiguous && nbytes >= (size_t(256) << 20)) {
+    if (pol.contiguous && nbytes >= (size_t(256) << 20)) {
         if (hipExtMallocWithFlags(&p, nbytes, hipDeviceMallocContiguous) == hipSuccess && p != nullptr) return p;
         (void)hipGetLastError();
         p = nullptr;
@@ -821,11 +861,24 @@ const char * toast_hip_version(void) { return "toast_hip 0.1 (gfx950)"; }
 
 // Raw device allocations with the manager's policy (experiments, bench.py): flags as in
 // hipExtMallocWithFlags (0 default, 4 hipDeviceMallocContiguous), -1 = the manager's own policy.
+int toast_hip_alloc_stats(int64_t * probed_blocks, int64_t * fast_blocks, int64_t * candidates, double * probe_ms,
+                          double * last_tbs) {
+    return guarded([&] {
+        const AllocStats & a = alloc_stats();
+        if (probed_blocks) *probed_blocks = a.probed_blocks;
+        if (fast_blocks) *fast_blocks = a.fast_blocks;
+        if (candidates) *candidates = a.candidates;
+        if (probe_ms) *probe_ms = a.probe_ms;
+        if (last_tbs) *last_tbs = a.last_tbs;
+    });
+}
+
 int toast_hip_device_malloc(size_t nbytes, int flags, void ** out) {
     return guarded([&] {
         void * p = nullptr;
         if (flags < 0) {
             p = Manager::get().device_alloc(nbytes);
+            if (p == nullptr) throw Error(TOAST_HIP_ERR_MEMORY, "HipManager:  device_malloc, allocation failed");
         } else if (flags == 0) {
             TH_HIP(hipMalloc(&p, nbytes));
         } else {

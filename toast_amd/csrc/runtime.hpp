@@ -96,6 +96,15 @@ private:
 size_t pin_threshold();
 // kernels.hip: time of a read + write pass over a new device block with the timestream kernels' access pattern
 double probe_stream_ms(void * block, size_t bytes, hipStream_t stream);
+// what the placement policy of Manager::device_alloc has done so far in this process
+struct AllocStats {
+    int64_t probed_blocks = 0;   // blocks chosen by probing
+    int64_t fast_blocks = 0;     // ... of which the kept candidate streams at the fast level
+    int64_t candidates = 0;      // candidate allocations probed in total
+    double probe_ms = 0.0;       // time spent in the probe passes
+    double last_tbs = 0.0;       // stream rate of the last kept candidate
+};
+const AllocStats & alloc_stats();
 
 // Transfers between pageable application memory and the device, through a page-locked bounce ring owned by the library
 // (two 4 MB slots, copy of slot k overlapped with the host memcpy of slot k+1).  The HIP runtime never sees pageable
