@@ -896,6 +896,46 @@ int toast_hip_vec_dot_dev(int64_t n, const double * d_x, const double * d_y, con
                           const uint8_t * d_flags_y, double * result /*host*/, void * stream);
 
 /* ------------------------------------------------------------------------------------
+ * PCG with its scalars on the device [ref: src/toast/ops/mapmaker_solve.py:524-755, the recurrence and its
+ * convergence (relative < convergence or sqsum < 1e-30), stall (every 10 iterations: last_best < 2 sqsum_best) and
+ * iteration-limit tests].  The state (alpha, beta, delta, the residual norms, iteration counter, history of relative
+ * residuals) lives in a device block of toast_hip_pcg_state_bytes(); dot products reduce into it, one-thread stage
+ * kernels do the scalar arithmetic, the vector updates read alpha / beta from it: the host only enqueues and reads the
+ * status `lag` iterations late.  After the solver has finished (done != 0) further stages / updates change nothing.
+ *   one iteration:  lhs_out = A proposal;  dot(proposal, lhs_out); stage 1;  result += alpha proposal (axpby ALPHA, ONE);
+ *       residual -= alpha lhs_out (NEG_ALPHA, ONE);  dot(residual, residual); stage 2;  precond = M^-1 residual;
+ *       dot(precond, residual); stage 3;  proposal = live precond + beta proposal (LIVE, BETA).
+ * `allreduce` != 0 sums the dot product over the ranks of toast_hip_comm before the stage reads it.
+ * ---------------------------------------------------------------------------------- */
+enum { TOAST_HIP_PCG_RUNNING = 0, TOAST_HIP_PCG_CONVERGED = 1, TOAST_HIP_PCG_STALLED = 2, TOAST_HIP_PCG_NOT_FINITE = 3,
+       TOAST_HIP_PCG_MAX_ITER = 4 };
+enum { TOAST_HIP_PCG_ONE = 0, TOAST_HIP_PCG_ALPHA = 1, TOAST_HIP_PCG_NEG_ALPHA = 2, TOAST_HIP_PCG_BETA = 3,
+       TOAST_HIP_PCG_LIVE = 4 };
+typedef struct toast_hip_pcg_status {
+    int64_t iteration;   /* iterations completed */
+    int64_t done;        /* TOAST_HIP_PCG_* */
+    int64_t n_history;   /* relative residuals recorded */
+    double relative;     /* the last of them */
+    double sqsum;        /* the last residual norm squared */
+} toast_hip_pcg_status;
+int toast_hip_pcg_state_bytes(int64_t n_iter_max, size_t * bytes);
+int toast_hip_pcg_init_dev(void * d_state, double sqsum_init, double delta, double convergence, int64_t n_iter_min,
+                           int64_t n_iter_max, void * stream);
+/* state.tmp (+)= sum_i x_i y_i over entries with both flags clear (flag pointers may be NULL) */
+int toast_hip_pcg_dot_dev(void * d_state, int64_t n, const double * d_x, const double * d_y, const uint8_t * d_flags_x,
+                          const uint8_t * d_flags_y, int accumulate, void * stream);
+int toast_hip_pcg_stage_dev(void * d_state, int stage, int allreduce, void * stream);
+/* y = S[a_sel] x + S[b_sel] y with S = the state's scalars (TOAST_HIP_PCG_ONE ... _LIVE) */
+int toast_hip_pcg_axpby_dev(const void * d_state, int64_t n, int a_sel, const double * d_x, int b_sel, double * d_y,
+                            void * stream);
+/* Enqueue an asynchronous copy of the status and return the one enqueued `lag` calls ago (0 = this one: waits for the
+ * stream; 1 = the host runs one iteration ahead of the device); zeros while fewer than `lag` calls have been made. */
+int toast_hip_pcg_status_dev(void * d_state, int lag, toast_hip_pcg_status * out, void * stream);
+/* Waits for the stream; copies min(n_history, capacity) relative residuals and the final status to the host. */
+int toast_hip_pcg_history_dev(void * d_state, double * history, int64_t capacity, toast_hip_pcg_status * final_status,
+                              void * stream);
+
+/* ------------------------------------------------------------------------------------
  * Multi-GPU: the process' RCCL communicator (one process per GPU), collectives enqueued on the
  * caller's stream -- kernel -> collective -> kernel is stream order, no host synchronisation.
  * Replaces the reference's host-side MPI reductions of the pixel-domain objects:

@@ -787,6 +787,49 @@ def test_solve_resident_equals_host_algebra():
     assert np.max(np.abs(amps[True] - amps[False])) < 1e-6 * scale
 
 
+@pytest.mark.parametrize("case", ["converges", "iteration_limit", "stalls", "noise_prior"])
+def test_pcg_scalars_on_the_device_follow_the_host_loop(monkeypatch, case):
+    """solve() with alpha / beta / residual norms and the convergence logic on the device (csrc/pcg.hip: the host
+    enqueues one iteration ahead and reads the status one iteration late) against the same solve with the scalars
+    on the host (TOAST_HIP_PCG_SCALARS=host, the reference's loop structure): the same number of iterations, the same
+    history and the same amplitudes -- whichever of the reference's exits ends the loop (convergence, the iteration
+    limit, the stall test), i.e. the speculative iteration enqueued after the end changes nothing."""
+    kw = dict(converges=dict(iter_max=60, convergence=1e-10), iteration_limit=dict(iter_max=7, convergence=1e-30),
+              stalls=dict(iter_max=100, convergence=1e-30, iter_min=3), noise_prior=dict(iter_max=25, convergence=1e-12))[case]
+    hist, amps, n_sync = {}, {}, {}
+    from toast_amd.accel import native
+
+    for mode in ("host", "device"):
+        monkeypatch.setenv("TOAST_HIP_PCG_SCALARS", mode)
+        data, pix, sw, truth, sky = make_solver_setup(noise_rms=0.1)
+        binner = ops.BinMap(pixel_dist="dist", pixel_pointing=pix, stokes_weights=sw, full_pointing=True)
+        tmpl = Offset(step_time=20.0, noise_model=defaults.noise_model, name="baselines", good_fraction=0.2,
+                      use_noise_prior=(case == "noise_prior"), precond_width=10)
+        mapper = ops.MapMaker(name="mm", keep_solver_products=True, det_data=defaults.det_data, binning=binner,
+                              template_matrix=ops.TemplateMatrix(templates=[tmpl]), solve_rcond_threshold=1e-3,
+                              map_rcond_threshold=1e-3, **kw)
+        mapper.apply(data)
+        hist[mode] = np.array(mapper.history)
+        amps[mode] = data["mm_solve_amplitudes"]["baselines"].local.copy()
+        assert len(mapper.iteration_seconds) == len(mapper.history)
+    # (the two loops add the dot products in different orders: the trajectories agree to rounding amplified by the
+    # iteration, and an exit test sitting on its threshold may fall one iteration apart)
+    n_dev, n_host = len(hist["device"]), len(hist["host"])
+    assert n_host >= 3 and abs(n_dev - n_host) <= (0 if case == "iteration_limit" else 1), (n_dev, n_host)
+    if case == "iteration_limit":
+        assert n_host == 7
+    if case == "converges":
+        assert hist["host"][-1] < 1e-10 and hist["device"][-1] < 1e-10 and n_host < 60
+    if case == "stalls":
+        assert n_host < 100 and n_dev < 100
+    n = min(n_dev, n_host)
+    above = hist["host"][:n] > 1e-18         # (below that the residual is rounding noise of the two summation orders)
+    np.testing.assert_allclose(hist["device"][:n][above], hist["host"][:n][above], rtol=1e-5, atol=0)
+    assert np.all(hist["device"][:n][~above] < 1e-15)
+    scale = np.max(np.abs(amps["host"]))
+    assert np.max(np.abs(amps["device"] - amps["host"])) < 1e-6 * scale
+
+
 def test_lazy_host_coherence_and_eviction():
     """Pipelines leave detector data resident and device-current; the host copy is refreshed on
     access (DetectorData.data) or by eviction, and equals the eagerly copied result."""

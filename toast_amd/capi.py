@@ -988,6 +988,47 @@ class _Dev:
         _check(lib().toast_hip_vec_dot_dev(_i64(n), _p(d_x), _p(d_y), _p(d_fx), _p(d_fy), C.byref(out), _p(stream)))
         return out.value
 
+    # ---- PCG with device-side scalars (toast_hip_pcg_*)
+    PCG_ONE, PCG_ALPHA, PCG_NEG_ALPHA, PCG_BETA, PCG_LIVE = 0, 1, 2, 3, 4
+    PCG_DONE = {0: "running", 1: "converged", 2: "stalled", 3: "not finite", 4: "iteration limit"}
+
+    class PcgStatus(C.Structure):
+        _fields_ = [("iteration", C.c_int64), ("done", C.c_int64), ("n_history", C.c_int64), ("relative", C.c_double),
+                    ("sqsum", C.c_double)]
+
+    def pcg_state_bytes(self, n_iter_max):
+        out = C.c_size_t(0)
+        _check(real_lib().toast_hip_pcg_state_bytes(_i64(n_iter_max), C.byref(out)))
+        return int(out.value)
+
+    def pcg_init(self, d_state, sqsum_init, delta, convergence, n_iter_min, n_iter_max, stream=0):
+        _check(lib().toast_hip_pcg_init_dev(_p(d_state), C.c_double(float(sqsum_init)), C.c_double(float(delta)),
+                                            C.c_double(float(convergence)), _i64(n_iter_min), _i64(n_iter_max),
+                                            _p(stream)))
+
+    def pcg_dot(self, d_state, n, d_x, d_y, d_fx=0, d_fy=0, accumulate=False, stream=0):
+        _check(lib().toast_hip_pcg_dot_dev(_p(d_state), _i64(n), _p(d_x), _p(d_y), _p(d_fx), _p(d_fy),
+                                           C.c_int(1 if accumulate else 0), _p(stream)))
+
+    def pcg_stage(self, d_state, stage, allreduce=False, stream=0):
+        _check(lib().toast_hip_pcg_stage_dev(_p(d_state), C.c_int(int(stage)), C.c_int(1 if allreduce else 0),
+                                             _p(stream)))
+
+    def pcg_axpby(self, d_state, n, a_sel, d_x, b_sel, d_y, stream=0):
+        _check(lib().toast_hip_pcg_axpby_dev(_p(d_state), _i64(n), C.c_int(int(a_sel)), _p(d_x), C.c_int(int(b_sel)),
+                                             _p(d_y), _p(stream)))
+
+    def pcg_status(self, d_state, lag=1, stream=0):
+        st = self.PcgStatus()
+        _check(real_lib().toast_hip_pcg_status_dev(_p(d_state), C.c_int(int(lag)), C.byref(st), _p(stream)))
+        return st
+
+    def pcg_history(self, d_state, capacity, stream=0):
+        hist = np.zeros(max(int(capacity), 1), dtype=np.float64)
+        st = self.PcgStatus()
+        _check(real_lib().toast_hip_pcg_history_dev(_p(d_state), _p(hist), _i64(capacity), C.byref(st), _p(stream)))
+        return hist[:min(int(st.n_history), int(capacity))].copy(), st
+
     # ---- the process' RCCL communicator (toast_hip_comm_*): collectives on the kernels' stream
     COMM_DTYPES = {np.dtype(np.float64): 0, np.dtype(np.float32): 1, np.dtype(np.int64): 2, np.dtype(np.int32): 3,
                    np.dtype(np.uint8): 4}

@@ -1,0 +1,290 @@
+// pcg.hip -- the scalars of the preconditioned conjugate gradient kept on the device.
+//
+// The reference's solver (src/toast/ops/mapmaker_solve.py:524-755) computes three dot products per iteration on the
+// host -- p.Ap for the step length, r.r for the convergence test, z.r for the direction update -- and each of them is a
+// device -> host round trip when the amplitude vectors live on the GPU: the host cannot enqueue the next kernel before
+// the previous scalar has arrived, ~30 % of an iteration at configs[1] size.  Here the recurrence's scalars and its
+// control flow (convergence test, the stall test every 10 iterations, the iteration limit) live in one small device
+// structure; the dot products reduce into it, one-thread "stage" kernels do the scalar arithmetic in the reference's
+// order, and the vector updates read alpha / beta from it.  The host only enqueues; it learns about convergence from
+// an asynchronous copy of the status that it reads ONE ITERATION LATE, so the GPU never waits for it.  An iteration
+// enqueued after the solver finished is a no-op for the solution: alpha = 0 leaves result and residual bit for bit as
+// they were (x + 0 * p == x), the direction update is skipped.
+//
+// Several processes: the local dot product is summed over the ranks by the library's communicator on the same stream
+// (toast_hip_comm, comm.cpp) before the stage kernel reads it.
+#include "kernel_common.hpp"
+
+#include "../../include/toast_hip.h"
+
+namespace {
+
+struct PcgState {
+    double delta, p_ap, alpha, neg_alpha, sqsum, sqsum_init, sqsum_best, last_best, beta, live, tmp, convergence,
+        relative;
+    int64_t it, n_iter_min, n_iter_max, done, n_history;
+    toast_hip_pcg_status stat;   // filled by k_pcg_status for the asynchronous copy to the host
+    double history[1];           // n_iter_max entries follow
+};
+
+constexpr int kDotBlocks = 1024;
+
+// block partial sums of the flagged dot product, in block order (the result does not depend on scheduling)
+__global__ __launch_bounds__(kThreads) void k_pcg_dot_partials(int64_t n, const double * __restrict__ x,
+                                                               const double * __restrict__ y,
+                                                               const uint8_t * __restrict__ fx,
+                                                               const uint8_t * __restrict__ fy,
+                                                               double * __restrict__ partials) {
+    __shared__ double s_part[kThreads / 64];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+        const bool good = (fx == nullptr || fx[i] == 0) && (fy == nullptr || fy[i] == 0);
+        if (good) acc += x[i] * y[i];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) t += s_part[w];
+        partials[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_pcg_dot_final(int n_block, const double * __restrict__ partials,
+                                                      PcgState * __restrict__ s, int accumulate) {
+    // one wave: lane l adds partials l, l + 64, ... in order, then the lanes are added in order
+    double t = 0.0;
+    for (int b = threadIdx.x; b < n_block; b += 64) t += partials[b];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) t += __shfl_down(t, d);
+    if (threadIdx.x == 0) s->tmp = (accumulate ? s->tmp : 0.0) + t;
+}
+
+__global__ void k_pcg_init(PcgState * __restrict__ s, double sqsum_init, double delta, double convergence,
+                           int64_t n_iter_min, int64_t n_iter_max) {
+    s->delta = delta;
+    s->p_ap = 0.0;
+    s->alpha = 0.0;
+    s->neg_alpha = 0.0;
+    s->sqsum = sqsum_init;
+    s->sqsum_init = sqsum_init;
+    s->sqsum_best = sqsum_init;
+    s->last_best = sqsum_init;
+    s->beta = 1.0;
+    s->live = (n_iter_max > 0) ? 1.0 : 0.0;
+    s->tmp = 0.0;
+    s->convergence = convergence;
+    s->relative = 0.0;
+    s->it = 0;
+    s->n_iter_min = n_iter_min;
+    s->n_iter_max = n_iter_max;
+    s->done = (n_iter_max > 0) ? 0 : TOAST_HIP_PCG_MAX_ITER;
+    s->n_history = 0;
+}
+
+// The scalar part of one third of an iteration (reference mapmaker_solve.py:672-745), `tmp` = the dot product that was
+// just reduced:  stage 1  alpha = delta / (p . A p);   stage 2  sqsum = r . r, history, convergence and stall tests;
+// stage 3  beta = (z . r) / delta, delta = z . r, next iteration.
+__global__ void k_pcg_stage(PcgState * __restrict__ s, int stage) {
+    if (s->done != 0) {
+        s->alpha = 0.0;
+        s->neg_alpha = 0.0;
+        s->beta = 1.0;
+        s->live = 0.0;
+        return;
+    }
+    if (stage == 1) {
+        s->p_ap = s->tmp;
+        s->alpha = s->delta / s->p_ap;
+        s->neg_alpha = -s->alpha;
+    } else if (stage == 2) {
+        const double sqsum = s->tmp;
+        s->sqsum = sqsum;
+        const double relative = (s->sqsum_init != 0.0) ? sqsum / s->sqsum_init : 0.0;
+        s->relative = relative;
+        s->history[s->it] = relative;
+        s->n_history = s->it + 1;
+        if (!isfinite(sqsum)) {
+            s->done = TOAST_HIP_PCG_NOT_FINITE;
+        } else if (relative < s->convergence || sqsum < 1.0e-30) {
+            s->done = TOAST_HIP_PCG_CONVERGED;
+        } else {
+            s->sqsum_best = (sqsum < s->sqsum_best) ? sqsum : s->sqsum_best;
+            if (s->it % 10 == 0 && s->it >= s->n_iter_min) {
+                if (s->last_best < s->sqsum_best * 2.0) {
+                    s->done = TOAST_HIP_PCG_STALLED;
+                } else {
+                    s->last_best = s->sqsum_best;
+                }
+            }
+        }
+        if (s->done != 0) s->live = 0.0;
+    } else {
+        const double delta_last = s->delta;
+        s->delta = s->tmp;
+        s->beta = s->delta / delta_last;
+        s->it += 1;
+        if (s->it >= s->n_iter_max) s->done = TOAST_HIP_PCG_MAX_ITER;   // (this iteration's direction update still runs)
+    }
+}
+
+__device__ __forceinline__ double pcg_scalar(const PcgState * s, int sel) {
+    switch (sel) {
+        case TOAST_HIP_PCG_ALPHA: return s->alpha;
+        case TOAST_HIP_PCG_NEG_ALPHA: return s->neg_alpha;
+        case TOAST_HIP_PCG_BETA: return s->beta;
+        case TOAST_HIP_PCG_LIVE: return s->live;
+        default: return 1.0;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void k_pcg_axpby(const PcgState * __restrict__ s, int64_t n, int a_sel,
+                                                        const double * __restrict__ x, int b_sel,
+                                                        double * __restrict__ y) {
+    const double a = pcg_scalar(s, a_sel), b = pcg_scalar(s, b_sel);
+    if (a == 0.0 && b == 1.0) return;    // the solver has finished: y stays bit for bit
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+        y[i] = (b == 1.0) ? y[i] + a * x[i] : a * x[i] + b * y[i];
+    }
+}
+
+struct StatusRing {
+    static constexpr int kSlots = 4;
+    toast_hip_pcg_status * host = nullptr;   // page-locked
+    hipEvent_t ev[kSlots];
+    bool pending[kSlots] = {false, false, false, false};
+    int64_t next = 0;
+};
+
+StatusRing & ring() {
+    static StatusRing r;
+    if (r.host == nullptr) {
+        TH_HIP(hipHostMalloc(reinterpret_cast<void **>(&r.host), sizeof(toast_hip_pcg_status) * StatusRing::kSlots,
+                             hipHostMallocDefault));
+        for (int i = 0; i < StatusRing::kSlots; ++i) TH_HIP(hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming));
+    }
+    return r;
+}
+
+__global__ void k_pcg_status(PcgState * __restrict__ s) {
+    toast_hip_pcg_status * out = &s->stat;
+    out->iteration = s->it;
+    out->done = s->done;
+    out->n_history = s->n_history;
+    out->relative = s->relative;
+    out->sqsum = s->sqsum;
+}
+
+}  // namespace
+
+extern "C" {
+
+int toast_hip_pcg_state_bytes(int64_t n_iter_max, size_t * bytes) {
+    return guarded([&] {
+        if (n_iter_max < 0) fail_arg("n_iter_max must not be negative");
+        *bytes = sizeof(PcgState) + sizeof(double) * (size_t)n_iter_max;
+    });
+}
+
+int toast_hip_pcg_init_dev(void * d_state, double sqsum_init, double delta, double convergence, int64_t n_iter_min,
+                           int64_t n_iter_max, void * stream) {
+    return guarded([&] {
+        hipLaunchKernelGGL(k_pcg_init, dim3(1), dim3(1), 0, as_stream(stream), static_cast<PcgState *>(d_state),
+                           sqsum_init, delta, convergence, n_iter_min, n_iter_max);
+        check_launch();
+        StatusRing & r = ring();
+        for (int i = 0; i < StatusRing::kSlots; ++i) r.pending[i] = false;
+        r.next = 0;
+    });
+}
+
+int toast_hip_pcg_dot_dev(void * d_state, int64_t n, const double * d_x, const double * d_y, const uint8_t * d_flags_x,
+                          const uint8_t * d_flags_y, int accumulate, void * stream) {
+    return guarded([&] {
+        double * d_part = (double *)Manager::get().scratch(Manager::kScratchDot, sizeof(double) * 1032) + 8;
+        hipStream_t st = as_stream(stream);
+        dim3 grid = flat_grid(n > 0 ? n : 1);
+        if (grid.x > kDotBlocks) grid.x = kDotBlocks;
+        hipLaunchKernelGGL(k_pcg_dot_partials, grid, dim3(kThreads), 0, st, n, d_x, d_y, d_flags_x, d_flags_y, d_part);
+        hipLaunchKernelGGL(k_pcg_dot_final, dim3(1), dim3(64), 0, st, (int)grid.x, d_part, static_cast<PcgState *>(d_state),
+                           accumulate);
+        check_launch();
+    });
+}
+
+int toast_hip_pcg_stage_dev(void * d_state, int stage, int allreduce, void * stream) {
+    return guarded([&] {
+        if (stage < 1 || stage > 3) fail_arg("pcg stage must be 1, 2 or 3");
+        PcgState * s = static_cast<PcgState *>(d_state);
+        if (allreduce) {
+            const int rc = toast_hip_comm_allreduce_dev(&s->tmp, 1, TOAST_HIP_COMM_F64, TOAST_HIP_COMM_SUM, stream);
+            if (rc != 0) throw Error(rc, toast_hip_last_error());
+        }
+        hipLaunchKernelGGL(k_pcg_stage, dim3(1), dim3(1), 0, as_stream(stream), s, stage);
+        check_launch();
+    });
+}
+
+int toast_hip_pcg_axpby_dev(const void * d_state, int64_t n, int a_sel, const double * d_x, int b_sel, double * d_y,
+                            void * stream) {
+    return guarded([&] {
+        if (n <= 0) return;
+        hipLaunchKernelGGL(k_pcg_axpby, flat_grid(n), dim3(kThreads), 0, as_stream(stream),
+                           static_cast<const PcgState *>(d_state), n, a_sel, d_x, b_sel, d_y);
+        check_launch();
+    });
+}
+
+int toast_hip_pcg_status_dev(void * d_state, int lag, toast_hip_pcg_status * out, void * stream) {
+    return guarded([&] {
+        if (lag < 0 || lag >= StatusRing::kSlots) fail_arg("pcg status lag must be 0 .. 3");
+        StatusRing & r = ring();
+        hipStream_t st = as_stream(stream);
+        PcgState * s = static_cast<PcgState *>(d_state);
+        const int slot = (int)(r.next % StatusRing::kSlots);
+        hipLaunchKernelGGL(k_pcg_status, dim3(1), dim3(1), 0, st, s);
+        check_launch();
+        TH_HIP(hipMemcpyAsync(&r.host[slot], &s->stat, sizeof(toast_hip_pcg_status), hipMemcpyDeviceToHost, st));
+        TH_HIP(hipEventRecord(r.ev[slot], st));
+        r.pending[slot] = true;
+        const int64_t want = r.next - lag;
+        r.next += 1;
+        if (want < 0) {
+            out->iteration = 0;
+            out->done = 0;
+            out->n_history = 0;
+            out->relative = 0.0;
+            out->sqsum = 0.0;
+            return;
+        }
+        const int ws = (int)(want % StatusRing::kSlots);
+        TH_HIP(hipEventSynchronize(r.ev[ws]));
+        *out = r.host[ws];
+    });
+}
+
+int toast_hip_pcg_history_dev(void * d_state, double * history, int64_t capacity, toast_hip_pcg_status * final_status,
+                              void * stream) {
+    return guarded([&] {
+        hipStream_t st = as_stream(stream);
+        PcgState * s = static_cast<PcgState *>(d_state);
+        PcgState head;
+        copy_to_host(&head, s, sizeof(PcgState), st);      // (through the page-locked bounce ring; synchronises)
+        if (final_status != nullptr) {
+            final_status->iteration = head.it;
+            final_status->done = head.done;
+            final_status->n_history = head.n_history;
+            final_status->relative = head.relative;
+            final_status->sqsum = head.sqsum;
+        }
+        const int64_t n = (head.n_history < capacity) ? head.n_history : capacity;
+        if (n > 0 && history != nullptr) {
+            copy_to_host(history, reinterpret_cast<const char *>(s) + offsetof(PcgState, history), sizeof(double) * n, st);
+        }
+    });
+}
+
+}  // extern "C"

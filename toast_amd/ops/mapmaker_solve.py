@@ -612,6 +612,89 @@ class SolverLHS(Operator):
         return {"global": [self.out]}
 
 
+def _device_scalars(rhs, vectors):
+    """The PCG can keep its scalars on the device when every amplitude vector is in use there and the dot products can
+    be summed over the processes on the stream (one process, or the library's own communicator)."""
+    import os
+
+    if os.environ.get("TOAST_HIP_PCG_SCALARS", "device") == "host":
+        return False
+    for amps in (rhs,) + tuple(vectors):
+        for v in amps.values():
+            if v.n_local == 0 or not v.accel_in_use():
+                return False
+    comm = next(iter(rhs.values()))._comm
+    if comm is not None and comm.comm_world is not None:
+        return bool(comm.device_comm())
+    return True
+
+
+def _pcg_device_scalars(data, detectors, lhs_op, result, residual, precond, proposal, lhs_out, sqsum_init, delta,
+                        convergence, n_iter_min, n_iter_max, log, iteration_seconds):
+    """The PCG loop of ``solve`` with alpha, beta, delta and the residual norms on the device (toast_hip_pcg_*,
+    csrc/pcg.hip): same recurrence, same convergence / stall / iteration-limit tests as the reference
+    (mapmaker_solve.py:660-755), evaluated by one-thread kernels between the vector kernels.  The host enqueues
+    iteration k + 1 while the device works on iteration k and reads the status one iteration late; an iteration
+    enqueued after the end is a no-op for the solution (alpha = 0)."""
+    import time as _time
+
+    from .. import capi
+    from ..accel import accel_device_ptr
+
+    D = capi.dev
+    state_host = np.zeros(D.pcg_state_bytes(n_iter_max), dtype=np.uint8)
+    accel_data = __import__("toast_amd.accel", fromlist=["accel_data_create"])
+    accel_data.accel_data_create(state_host, "pcg_state")
+    try:
+        d_state = accel_device_ptr(state_host)
+        D.pcg_init(d_state, sqsum_init, delta, convergence, n_iter_min, n_iter_max)
+        names = list(result.keys())
+        first = result[names[0]]
+        comm = first._comm
+        reduce_dots = bool(comm is not None and comm.comm_world is not None and not first._full)
+
+        def dot(a, b, stage):
+            for i, k in enumerate(names):
+                x, y = a[k], b[k]
+                D.pcg_dot(d_state, x.n_local, x._dptr(), y._dptr(), accel_device_ptr(x.local_flags),
+                          accel_device_ptr(y.local_flags), accumulate=(i > 0))
+            D.pcg_stage(d_state, stage, allreduce=reduce_dots)
+
+        def axpby(y, a_sel, x, b_sel):
+            for k in names:
+                D.pcg_axpby(d_state, y[k].n_local, a_sel, x[k]._dptr(), b_sel, y[k]._dptr())
+
+        seen = 0       # relative residuals reported so far (the log lags one iteration behind the device)
+        for it in range(n_iter_max + 1):
+            if iteration_seconds is not None:
+                iteration_seconds.append(_time.perf_counter())
+            lhs_op.apply(data, detectors=detectors)
+            dot(proposal, lhs_out, 1)
+            axpby(result, D.PCG_ALPHA, proposal, D.PCG_ONE)          # result += alpha * proposal
+            axpby(residual, D.PCG_NEG_ALPHA, lhs_out, D.PCG_ONE)     # residual -= alpha * lhs_out
+            dot(residual, residual, 2)
+            lhs_op.template_matrix.apply_precond(residual, precond)
+            dot(precond, residual, 3)
+            axpby(proposal, D.PCG_LIVE, precond, D.PCG_BETA)         # proposal = precond + beta * proposal
+            st = D.pcg_status(d_state, lag=1)                        # the status after the PREVIOUS iteration
+            if log is not None and st.n_history > seen:
+                log(f"MapMaker iteration {st.n_history - 1:4d}, relative residual = {st.relative:0.6e}")
+            seen = int(st.n_history)
+            if st.done != 0:
+                break
+        history, final = D.pcg_history(d_state, n_iter_max)
+        if final.done == 3:
+            raise RuntimeError("Residual is not finite")
+        if log is not None:
+            log(f"MapMaker PCG finished after {len(history)} iterations ({D.PCG_DONE.get(int(final.done), '?')}), "
+                f"relative residual = {final.relative:0.6e}")
+        if iteration_seconds is not None and len(iteration_seconds) > len(history):
+            del iteration_seconds[len(history):]     # the speculative iteration after the end
+        return [float(x) for x in history]
+    finally:
+        accel_data.accel_data_delete(state_host, "pcg_state")
+
+
 def solve(data, detectors, lhs_op, rhs_key, result_key, convergence=1.0e-12, n_iter_min=3, n_iter_max=100,
           log=None, iteration_seconds=None):
     """Preconditioned conjugate gradient for the template amplitudes
@@ -676,6 +759,13 @@ def solve(data, detectors, lhs_op, rhs_key, result_key, convergence=1.0e-12, n_i
     delta = proposal.dot(residual)
     history = []
     import time as _time
+
+    if on_device and _device_scalars(rhs, (result, residual, precond, proposal, lhs_out)):
+        if not np.isfinite(sqsum):
+            raise RuntimeError("Residual is not finite")
+        history = _pcg_device_scalars(data, detectors, lhs_op, result, residual, precond, proposal, lhs_out, sqsum_init,
+                                      delta, convergence, n_iter_min, n_iter_max, log, iteration_seconds)
+        n_iter_max = 0       # the host-scalar loop below does not run
 
     for it in range(n_iter_max):
         if iteration_seconds is not None:
