@@ -921,10 +921,15 @@ typedef struct toast_hip_pcg_status {
 int toast_hip_pcg_state_bytes(int64_t n_iter_max, size_t * bytes);
 int toast_hip_pcg_init_dev(void * d_state, double sqsum_init, double delta, double convergence, int64_t n_iter_min,
                            int64_t n_iter_max, void * stream);
-/* state.tmp (+)= sum_i x_i y_i over entries with both flags clear (flag pointers may be NULL) */
+/* state.tmp (+)= sum_i x_i y_i over entries with both flags clear (flag pointers may be NULL); stage != 0 runs that
+ * stage right behind the reduction in the same launch (one process), stage = 0 leaves it to toast_hip_pcg_stage_dev
+ * (several processes: the sum over the ranks comes in between). */
 int toast_hip_pcg_dot_dev(void * d_state, int64_t n, const double * d_x, const double * d_y, const uint8_t * d_flags_x,
-                          const uint8_t * d_flags_y, int accumulate, void * stream);
+                          const uint8_t * d_flags_y, int accumulate, int stage, void * stream);
 int toast_hip_pcg_stage_dev(void * d_state, int stage, int allreduce, void * stream);
+/* result += alpha proposal;  residual -= alpha lhs_out  (one launch) */
+int toast_hip_pcg_step_dev(const void * d_state, int64_t n, const double * d_proposal, double * d_result,
+                           const double * d_lhs_out, double * d_residual, void * stream);
 /* y = S[a_sel] x + S[b_sel] y with S = the state's scalars (TOAST_HIP_PCG_ONE ... _LIVE) */
 int toast_hip_pcg_axpby_dev(const void * d_state, int64_t n, int a_sel, const double * d_x, int b_sel, double * d_y,
                             void * stream);

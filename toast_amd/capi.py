@@ -1006,9 +1006,13 @@ class _Dev:
                                             C.c_double(float(convergence)), _i64(n_iter_min), _i64(n_iter_max),
                                             _p(stream)))
 
-    def pcg_dot(self, d_state, n, d_x, d_y, d_fx=0, d_fy=0, accumulate=False, stream=0):
+    def pcg_dot(self, d_state, n, d_x, d_y, d_fx=0, d_fy=0, accumulate=False, stage=0, stream=0):
         _check(lib().toast_hip_pcg_dot_dev(_p(d_state), _i64(n), _p(d_x), _p(d_y), _p(d_fx), _p(d_fy),
-                                           C.c_int(1 if accumulate else 0), _p(stream)))
+                                           C.c_int(1 if accumulate else 0), C.c_int(int(stage)), _p(stream)))
+
+    def pcg_step(self, d_state, n, d_proposal, d_result, d_lhs_out, d_residual, stream=0):
+        _check(lib().toast_hip_pcg_step_dev(_p(d_state), _i64(n), _p(d_proposal), _p(d_result), _p(d_lhs_out),
+                                            _p(d_residual), _p(stream)))
 
     def pcg_stage(self, d_state, stage, allreduce=False, stream=0):
         _check(lib().toast_hip_pcg_stage_dev(_p(d_state), C.c_int(int(stage)), C.c_int(1 if allreduce else 0),

@@ -23,45 +23,12 @@ struct PcgState {
     double delta, p_ap, alpha, neg_alpha, sqsum, sqsum_init, sqsum_best, last_best, beta, live, tmp, convergence,
         relative;
     int64_t it, n_iter_min, n_iter_max, done, n_history;
-    toast_hip_pcg_status stat;   // filled by k_pcg_status for the asynchronous copy to the host
+    unsigned int ticket, pad;    // blocks of the running dot product that have stored their partial sum
+    toast_hip_pcg_status stat;   // refreshed by every stage for the asynchronous copy to the host
     double history[1];           // n_iter_max entries follow
 };
 
-constexpr int kDotBlocks = 1024;
-
-// block partial sums of the flagged dot product, in block order (the result does not depend on scheduling)
-__global__ __launch_bounds__(kThreads) void k_pcg_dot_partials(int64_t n, const double * __restrict__ x,
-                                                               const double * __restrict__ y,
-                                                               const uint8_t * __restrict__ fx,
-                                                               const uint8_t * __restrict__ fy,
-                                                               double * __restrict__ partials) {
-    __shared__ double s_part[kThreads / 64];
-    double acc = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
-        const bool good = (fx == nullptr || fx[i] == 0) && (fy == nullptr || fy[i] == 0);
-        if (good) acc += x[i] * y[i];
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d);
-    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-#pragma unroll
-        for (int w = 0; w < kThreads / 64; ++w) t += s_part[w];
-        partials[blockIdx.x] = t;
-    }
-}
-
-__global__ __launch_bounds__(64) void k_pcg_dot_final(int n_block, const double * __restrict__ partials,
-                                                      PcgState * __restrict__ s, int accumulate) {
-    // one wave: lane l adds partials l, l + 64, ... in order, then the lanes are added in order
-    double t = 0.0;
-    for (int b = threadIdx.x; b < n_block; b += 64) t += partials[b];
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) t += __shfl_down(t, d);
-    if (threadIdx.x == 0) s->tmp = (accumulate ? s->tmp : 0.0) + t;
-}
+constexpr int kDotBlocks = 256;
 
 __global__ void k_pcg_init(PcgState * __restrict__ s, double sqsum_init, double delta, double convergence,
                            int64_t n_iter_min, int64_t n_iter_max) {
@@ -83,20 +50,25 @@ __global__ void k_pcg_init(PcgState * __restrict__ s, double sqsum_init, double 
     s->n_iter_max = n_iter_max;
     s->done = (n_iter_max > 0) ? 0 : TOAST_HIP_PCG_MAX_ITER;
     s->n_history = 0;
+    s->ticket = 0;
+    s->pad = 0;
+    s->stat.iteration = 0;
+    s->stat.done = s->done;
+    s->stat.n_history = 0;
+    s->stat.relative = 0.0;
+    s->stat.sqsum = sqsum_init;
 }
 
 // The scalar part of one third of an iteration (reference mapmaker_solve.py:672-745), `tmp` = the dot product that was
 // just reduced:  stage 1  alpha = delta / (p . A p);   stage 2  sqsum = r . r, history, convergence and stall tests;
-// stage 3  beta = (z . r) / delta, delta = z . r, next iteration.
-__global__ void k_pcg_stage(PcgState * __restrict__ s, int stage) {
+// stage 3  beta = (z . r) / delta, delta = z . r, next iteration.  One thread.
+__device__ void pcg_stage(PcgState * __restrict__ s, int stage) {
     if (s->done != 0) {
         s->alpha = 0.0;
         s->neg_alpha = 0.0;
         s->beta = 1.0;
         s->live = 0.0;
-        return;
-    }
-    if (stage == 1) {
+    } else if (stage == 1) {
         s->p_ap = s->tmp;
         s->alpha = s->delta / s->p_ap;
         s->neg_alpha = -s->alpha;
@@ -129,6 +101,60 @@ __global__ void k_pcg_stage(PcgState * __restrict__ s, int stage) {
         s->it += 1;
         if (s->it >= s->n_iter_max) s->done = TOAST_HIP_PCG_MAX_ITER;   // (this iteration's direction update still runs)
     }
+    s->stat.iteration = s->it;
+    s->stat.done = s->done;
+    s->stat.n_history = s->n_history;
+    s->stat.relative = s->relative;
+    s->stat.sqsum = s->sqsum;
+}
+
+__global__ void k_pcg_stage(PcgState * __restrict__ s, int stage) { pcg_stage(s, stage); }
+
+// Dot product, reduction and stage in ONE launch (a launch costs ~5 us of device time, an iteration at configs[1] size
+// 400): every block stores its partial sum and takes a ticket; the block that draws the last ticket adds the partials
+// in block order (the result does not depend on which block that is) and runs the stage.
+__global__ __launch_bounds__(kThreads) void k_pcg_dot_stage(int64_t n, const double * __restrict__ x,
+                                                            const double * __restrict__ y,
+                                                            const uint8_t * __restrict__ fx,
+                                                            const uint8_t * __restrict__ fy,
+                                                            double * __restrict__ partials, PcgState * __restrict__ s,
+                                                            int accumulate, int stage) {
+    __shared__ double s_part[kThreads / 64];
+    __shared__ bool s_last;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+        const bool good = (fx == nullptr || fx[i] == 0) && (fy == nullptr || fy[i] == 0);
+        if (good) acc += x[i] * y[i];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_down(acc, d);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) t += s_part[w];
+        __hip_atomic_store(&partials[blockIdx.x], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        const unsigned int ticket = atomicAdd(&s->ticket, 1u);
+        s_last = (ticket == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (threadIdx.x < 64) {
+        double t = 0.0;
+        for (int b = threadIdx.x; b < (int)gridDim.x; b += 64) {
+            t += __hip_atomic_load(&partials[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) t += __shfl_down(t, d);
+        if (threadIdx.x == 0) {
+            s->tmp = (accumulate ? s->tmp : 0.0) + t;
+            s->ticket = 0;
+            if (stage != 0) pcg_stage(s, stage);
+        }
+    }
 }
 
 __device__ __forceinline__ double pcg_scalar(const PcgState * s, int sel) {
@@ -151,6 +177,18 @@ __global__ __launch_bounds__(kThreads) void k_pcg_axpby(const PcgState * __restr
     }
 }
 
+// result += alpha proposal and residual -= alpha lhs_out in one launch
+__global__ __launch_bounds__(kThreads) void k_pcg_step(const PcgState * __restrict__ s, int64_t n,
+                                                       const double * __restrict__ p, double * __restrict__ result,
+                                                       const double * __restrict__ ap, double * __restrict__ residual) {
+    const double a = s->alpha, na = s->neg_alpha;
+    if (a == 0.0) return;    // the solver has finished: both vectors stay bit for bit
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+        result[i] = result[i] + a * p[i];
+        residual[i] = residual[i] + na * ap[i];
+    }
+}
+
 struct StatusRing {
     static constexpr int kSlots = 4;
     toast_hip_pcg_status * host = nullptr;   // page-locked
@@ -167,15 +205,6 @@ StatusRing & ring() {
         for (int i = 0; i < StatusRing::kSlots; ++i) TH_HIP(hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming));
     }
     return r;
-}
-
-__global__ void k_pcg_status(PcgState * __restrict__ s) {
-    toast_hip_pcg_status * out = &s->stat;
-    out->iteration = s->it;
-    out->done = s->done;
-    out->n_history = s->n_history;
-    out->relative = s->relative;
-    out->sqsum = s->sqsum;
 }
 
 }  // namespace
@@ -202,15 +231,29 @@ int toast_hip_pcg_init_dev(void * d_state, double sqsum_init, double delta, doub
 }
 
 int toast_hip_pcg_dot_dev(void * d_state, int64_t n, const double * d_x, const double * d_y, const uint8_t * d_flags_x,
-                          const uint8_t * d_flags_y, int accumulate, void * stream) {
+                          const uint8_t * d_flags_y, int accumulate, int stage, void * stream) {
     return guarded([&] {
+        if (stage < 0 || stage > 3) fail_arg("pcg stage must be 0 (none), 1, 2 or 3");
         double * d_part = (double *)Manager::get().scratch(Manager::kScratchDot, sizeof(double) * 1032) + 8;
         hipStream_t st = as_stream(stream);
-        dim3 grid = flat_grid(n > 0 ? n : 1);
-        if (grid.x > kDotBlocks) grid.x = kDotBlocks;
-        hipLaunchKernelGGL(k_pcg_dot_partials, grid, dim3(kThreads), 0, st, n, d_x, d_y, d_flags_x, d_flags_y, d_part);
-        hipLaunchKernelGGL(k_pcg_dot_final, dim3(1), dim3(64), 0, st, (int)grid.x, d_part, static_cast<PcgState *>(d_state),
-                           accumulate);
+        // few blocks: every block ends in one atomic on the same ticket, and the last one adds all partial sums
+        // (900 blocks: 26 us per dot product at configs[1] size; 8 elements per thread and at most one block per CU: 6 us)
+        int64_t nb = (n + (int64_t)kThreads * 8 - 1) / ((int64_t)kThreads * 8);
+        if (nb < 1) nb = 1;
+        if (nb > kDotBlocks) nb = kDotBlocks;
+        const dim3 grid((unsigned)nb);
+        hipLaunchKernelGGL(k_pcg_dot_stage, grid, dim3(kThreads), 0, st, n, d_x, d_y, d_flags_x, d_flags_y, d_part,
+                           static_cast<PcgState *>(d_state), accumulate, stage);
+        check_launch();
+    });
+}
+
+int toast_hip_pcg_step_dev(const void * d_state, int64_t n, const double * d_proposal, double * d_result,
+                           const double * d_lhs_out, double * d_residual, void * stream) {
+    return guarded([&] {
+        if (n <= 0) return;
+        hipLaunchKernelGGL(k_pcg_step, flat_grid(n), dim3(kThreads), 0, as_stream(stream),
+                           static_cast<const PcgState *>(d_state), n, d_proposal, d_result, d_lhs_out, d_residual);
         check_launch();
     });
 }
@@ -245,8 +288,6 @@ int toast_hip_pcg_status_dev(void * d_state, int lag, toast_hip_pcg_status * out
         hipStream_t st = as_stream(stream);
         PcgState * s = static_cast<PcgState *>(d_state);
         const int slot = (int)(r.next % StatusRing::kSlots);
-        hipLaunchKernelGGL(k_pcg_status, dim3(1), dim3(1), 0, st, s);
-        check_launch();
         TH_HIP(hipMemcpyAsync(&r.host[slot], &s->stat, sizeof(toast_hip_pcg_status), hipMemcpyDeviceToHost, st));
         TH_HIP(hipEventRecord(r.ev[slot], st));
         r.pending[slot] = true;

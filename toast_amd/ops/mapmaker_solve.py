@@ -656,9 +656,12 @@ def _pcg_device_scalars(data, detectors, lhs_op, result, residual, precond, prop
         def dot(a, b, stage):
             for i, k in enumerate(names):
                 x, y = a[k], b[k]
+                # one process: the stage runs in the same launch, right behind the last template's reduction
+                inline = stage if (i == len(names) - 1 and not reduce_dots) else 0
                 D.pcg_dot(d_state, x.n_local, x._dptr(), y._dptr(), accel_device_ptr(x.local_flags),
-                          accel_device_ptr(y.local_flags), accumulate=(i > 0))
-            D.pcg_stage(d_state, stage, allreduce=reduce_dots)
+                          accel_device_ptr(y.local_flags), accumulate=(i > 0), stage=inline)
+            if reduce_dots:
+                D.pcg_stage(d_state, stage, allreduce=True)     # sum over the ranks on the stream, then the stage
 
         def axpby(y, a_sel, x, b_sel):
             for k in names:
@@ -670,8 +673,9 @@ def _pcg_device_scalars(data, detectors, lhs_op, result, residual, precond, prop
                 iteration_seconds.append(_time.perf_counter())
             lhs_op.apply(data, detectors=detectors)
             dot(proposal, lhs_out, 1)
-            axpby(result, D.PCG_ALPHA, proposal, D.PCG_ONE)          # result += alpha * proposal
-            axpby(residual, D.PCG_NEG_ALPHA, lhs_out, D.PCG_ONE)     # residual -= alpha * lhs_out
+            for k in names:       # result += alpha * proposal;  residual -= alpha * lhs_out
+                D.pcg_step(d_state, result[k].n_local, proposal[k]._dptr(), result[k]._dptr(), lhs_out[k]._dptr(),
+                           residual[k]._dptr())
             dot(residual, residual, 2)
             lhs_op.template_matrix.apply_precond(residual, precond)
             dot(precond, residual, 3)

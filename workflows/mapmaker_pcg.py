@@ -150,11 +150,11 @@ def main(argv=None):
             print(f"  {k:34s} {v:8.2f} s")
         it = mapper.timing_log.get("pcg_iterations", None)
         if it:
-            print(f"PCG phase / iterations: {1e3 * it / n_it:.1f} ms (includes the start-up LHS and vector set-up)")
+            print(f"PCG phase / iterations: {1e3 * it / n_it:.3f} ms (includes the start-up LHS and vector set-up)")
         its = getattr(mapper, "iteration_seconds", None)
         if its:
             med = float(np.median(its))
-            print(f"PCG iteration (median wall time): {1e3 * med:.1f} ms  = {nds / med / 1e9:.1f} G det-samples/s")
+            print(f"PCG iteration (median wall time): {1e3 * med:.3f} ms  = {nds / med / 1e9:.1f} G det-samples/s")
     print(f"MapMaker total {total:.2f} s")
     if world > 1:
         dist.destroy_process_group()
