@@ -597,6 +597,40 @@ def test_noise_filter_random_configurations(seed):
     assert np.array_equal(ob.detdata[defaults.det_flags].data, want_flags if use_det_flags else dflags)
 
 
+def test_noise_filter_pipelined_upload():
+    """A host-resident timestream buffer of 256 MB or more is uploaded in row blocks on the library's upload stream
+    while the transform of the blocks that have arrived runs (toast_hip_accel_update_device_parts / _wait / _finish):
+    same bits as one blocking upload followed by one transform, the oracle's numbers on sampled rows, and the
+    detector subset / row order handled per block."""
+    from oracle import fft_oracle as fo
+    from toast_amd.ops.noise_filter import estimate_net
+
+    n_det, n_samp, rate = 36, 1000000, 50.0           # 288 MB of timestreams
+    out = {}
+    for parts in (1, 5):
+        data = create_satellite_data(n_det=n_det, n_samp=n_samp, rate=rate, fknee=0.2, flag_samples=False)
+        ob = data.obs[0]
+        rng = np.random.default_rng(77)
+        sig = rng.standard_normal((n_det, n_samp))
+        sig[:, ::1000] += 5.0
+        ob.detdata[defaults.det_data].data[:] = sig
+        dets = ob.local_detectors
+        op = ops.NoiseFilter(noise_model=defaults.noise_model, det_flags=None, shared_flags=None, upload_parts=parts)
+        op.apply(data, detectors=[d for i, d in enumerate(dets) if i % 7 != 3])    # a subset: some rows stay untouched
+        assert ob.detdata[defaults.det_data].accel_in_use()                         # left resident for the map-maker
+        out[parts] = ob.detdata[defaults.det_data].data.copy()
+    assert np.array_equal(out[1], out[5])
+    for i in (3, 10, 17):                                                           # rows outside the subset
+        assert np.array_equal(out[5][i], sig[i])
+    nse = ob[defaults.noise_model]
+    rows = [0, 18, 35]
+    kernels = np.array([fo.noise_filter_kernel(nse.psd(dets[i]), estimate_net(nse.freq(dets[i]), nse.psd(dets[i])))
+                        for i in rows])
+    want = sig[rows].copy()
+    fo.convolve(want, rate, kernel_freq=nse.freq(dets[0]), kernels=kernels)
+    assert np.max(np.abs(out[5][rows] - want)) < 1e-11 * np.max(np.abs(want))
+
+
 def test_filters_skip_cut_detectors():
     """NoiseFilter and GroundFilter leave the timestreams and flags of detectors cut by their per-detector flags
     untouched and treat the others exactly as a run restricted to them with ``detectors=``; an observation without any

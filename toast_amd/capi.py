@@ -275,6 +275,25 @@ def alloc_stats():
                 probe_ms=float(ms.value), last_TBs=float(tbs.value))
 
 
+def accel_update_device_parts(buf, part_end, name="NA"):
+    """Start the upload of a registered buffer in parts (byte offsets ``part_end``, the last one = its size) on the
+    library's upload stream; returns once the copies are enqueued."""
+    a = _raw(buf)
+    pe = np.ascontiguousarray(part_end, dtype=np.uint64)
+    _check(real_lib().toast_hip_accel_update_device_parts(_p(a), C.c_size_t(a.nbytes), name.encode(), _p(pe),
+                                                          C.c_int(pe.size)))
+
+
+def accel_update_device_wait(buf, part, stream=0):
+    """Later work on ``stream`` waits for part ``part`` of the upload (the host does not)."""
+    _check(real_lib().toast_hip_accel_update_device_wait(_p(_raw(buf)), C.c_int(int(part)), _p(stream)))
+
+
+def accel_update_device_finish(buf):
+    """Block until every part of the upload has arrived."""
+    _check(real_lib().toast_hip_accel_update_device_finish(_p(_raw(buf))))
+
+
 def accel_delete(buf, name="NA"):
     a = _raw(buf)
     _check(lib().toast_hip_accel_delete(_p(a), C.c_size_t(a.nbytes), name.encode()))

@@ -412,6 +412,19 @@ __device__ unsigned long long g_phase_ticks[16];
 # define PHASE_MARK(i)
 #endif
 
+// The element offsets of a thread's loads are needed again for its stores at the end of the kernel.  Left alone, the
+// compiler keeps the 64-bit offsets alive across the whole transform and, at the 128-VGPR budget of the P = 8 kernels,
+// spills one or two of them to scratch.  Re-deriving them from an opaque copy of the shift costs a few integer
+// instructions at the end and keeps the kernels free of scratch.
+__device__ __forceinline__ int opaque_sgpr(int x) {
+    asm volatile("" : "+s"(x));
+    return x;
+}
+__device__ __forceinline__ int opaque_vgpr(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
 // pass 1 (INV = false) and pass 3 (INV = true): transforms of length N1 down the columns
 template <int LT, int P, bool INV>
 __global__ __launch_bounds__((1 << LT) / P, (P == 16 ? 2 : 4)) void k_fft_cols(const Params p) {
@@ -466,19 +479,22 @@ __global__ __launch_bounds__((1 << LT) / P, (P == 16 ? 2 : 4)) void k_fft_cols(c
     PHASE_MARK(INV ? 11 : 6);
     if (!INV) {
         col_twiddles<LT, P>(v, p, tid, log_c, c0, col_twiddles_prepare<LT, P>(p, tid, log_c, c0));
+        const int tid_tail = opaque_vgpr(tid);
 #pragma unroll
         for (int k = 0; k < P; ++k) {
-            const int e = tid + k * T;
+            const int e = tid_tail + k * T;
             const int64_t k1 = e >> log_c;
             const int64_t j2 = c0 + (e & ((1 << log_c) - 1));
             work[(k1 << p.log_n2) + j2] = v[k];
         }
     } else {
         // the transform ran on swapped data: Re z' = v.y, Im z' = v.x; crop + scale (fft.py:341-350)
+        const int log_n2_tail = opaque_sgpr(p.log_n2);
+        const int tid_tail = opaque_vgpr(tid);
 #pragma unroll
         for (int k = 0; k < P; ++k) {
-            const int e = tid + k * T;
-            const int64_t j = ((int64_t)(e >> log_c) << p.log_n2) + c0 + (e & ((1 << log_c) - 1));
+            const int e = tid_tail + k * T;
+            const int64_t j = ((int64_t)(e >> log_c) << log_n2_tail) + c0 + (e & ((1 << log_c) - 1));
             const int64_t s = 2 * j - p.n_buffer;
             if (p.aligned) {
                 // s and n_samp even, row 16-byte aligned: both samples of the pair are inside or outside together
@@ -733,11 +749,13 @@ __global__ __launch_bounds__(kTile / P, (P == 16 ? 2 : 4)) void k_fft_rows(const
     for (int k = 0; k < P; ++k) v[k] = sm[sw(tid + k * T)];
     tile_fft<P>(v, sm, tid, p.log_n2, p.tb.wtile);
     PHASE_MARK(3);
+    const int log_n2_tail = opaque_sgpr(p.log_n2);
+    const int tid_tail = opaque_vgpr(tid);
 #pragma unroll
     for (int k = 0; k < P; ++k) {
-        const int e = tid + k * T;
+        const int e = tid_tail + k * T;
         const int64_t rr = (e & 1) ? r1 : r0;
-        work[(rr << p.log_n2) + (e >> 1)] = v[k];
+        work[(rr << log_n2_tail) + (e >> 1)] = v[k];
     }
     PHASE_WAIT_LOADS;
     PHASE_MARK(4);

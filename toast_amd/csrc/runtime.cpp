@@ -403,7 +403,10 @@ void Manager::clear() {
         if (kv.second.first) (void)hipFree(kv.second.first);
     }
     scratch_.clear();
+    if (upload_stream_ != nullptr) (void)hipStreamSynchronize(upload_stream_);
     for (auto & kv : table_) {
+        for (hipEvent_t ev : kv.second.part_done) (void)hipEventDestroy(ev);
+        kv.second.part_done.clear();
         unpin(kv.first, kv.second);
         if (kv.second.owned) (void)hipFree(kv.second.dev);
     }
@@ -734,6 +737,65 @@ void Manager::update_device(const void * host, size_t nbytes, const char * name)
     trace("update_device", e.name, nbytes, t0);
 }
 
+void Manager::update_device_parts(const void * host, size_t nbytes, const char * name, const size_t * part_end,
+                                  int n_parts) {
+    require_device();
+    Entry & e = lookup(host, nbytes, name, "update device");
+    if (n_parts < 1 || part_end == nullptr || part_end[n_parts - 1] != nbytes) {
+        fail_arg("update_device_parts: the last part must end at the size of the buffer");
+    }
+    if (!e.part_done.empty()) fail_arg("update_device_parts: an upload of this buffer is still in flight");
+    const double t0 = trace_begin();
+    pin_for_transfer(host, e);
+    if (!e.host_registered) {
+        // pageable source (small buffer, or page-locking failed): the synchronous path through the bounce ring
+        copy_to_device(e.dev, host, nbytes, stream_);
+        trace("update_device", e.name, nbytes, t0);
+        return;
+    }
+    if (upload_stream_ == nullptr) TH_HIP(hipStreamCreateWithFlags(&upload_stream_, hipStreamNonBlocking));
+    // the device block may still be in use by earlier work of the default stream (a reset, a probe pass)
+    hipEvent_t before;
+    TH_HIP(hipEventCreateWithFlags(&before, hipEventDisableTiming));
+    TH_HIP(hipEventRecord(before, stream_));
+    TH_HIP(hipStreamWaitEvent(upload_stream_, before, 0));
+    (void)hipEventDestroy(before);
+    size_t off = 0;
+    for (int k = 0; k < n_parts; ++k) {
+        if (part_end[k] < off || part_end[k] > nbytes) fail_arg("update_device_parts: part ends must increase");
+        const size_t len = part_end[k] - off;
+        if (len > 0) {
+            TH_HIP(hipMemcpyAsync(static_cast<char *>(e.dev) + off, static_cast<const char *>(host) + off, len,
+                                  hipMemcpyHostToDevice, upload_stream_));
+        }
+        hipEvent_t ev;
+        TH_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        TH_HIP(hipEventRecord(ev, upload_stream_));
+        e.part_done.push_back(ev);
+        off = part_end[k];
+    }
+    trace("upload_parts", e.name, nbytes, t0);   // (enqueue time: page-locking + launches; the copies run on)
+}
+
+void Manager::update_device_wait(const void * host, int part, hipStream_t stream) {
+    auto it = table_.find(host);
+    if (it == table_.end()) fail_arg("update_device_wait: host pointer is not registered");
+    Entry & e = it->second;
+    if (e.part_done.empty()) return;   // the upload took the synchronous path: everything is there
+    if (part < 0 || part >= (int)e.part_done.size()) fail_arg("update_device_wait: no such part");
+    TH_HIP(hipStreamWaitEvent(stream, e.part_done[(size_t)part], 0));
+}
+
+void Manager::update_device_finish(const void * host) {
+    auto it = table_.find(host);
+    if (it == table_.end()) fail_arg("update_device_finish: host pointer is not registered");
+    Entry & e = it->second;
+    if (e.part_done.empty()) return;
+    TH_HIP(hipStreamSynchronize(upload_stream_));
+    for (hipEvent_t ev : e.part_done) (void)hipEventDestroy(ev);
+    e.part_done.clear();
+}
+
 void Manager::update_host(void * host, size_t nbytes, const char * name) {
     require_device();
     Entry & e = lookup(host, nbytes, name, "update host");
@@ -752,6 +814,7 @@ void Manager::remove(const void * host, size_t nbytes, const char * name) {
     require_device();
     Entry & e = lookup(host, nbytes, name, "delete");
     const double t0 = trace_begin();
+    if (!e.part_done.empty()) update_device_finish(host);   // an upload in parts that nobody waited for
     TH_HIP(hipStreamSynchronize(stream_));
     unpin(host, e);
     if (e.owned) {
@@ -985,6 +1048,19 @@ int toast_hip_accel_reset(const void * host, size_t nbytes, const char * name) {
 
 int toast_hip_accel_update_device(const void * host, size_t nbytes, const char * name) {
     return guarded([&] { Manager::get().update_device(host, nbytes, name); });
+}
+
+int toast_hip_accel_update_device_parts(const void * host, size_t nbytes, const char * name, const size_t * part_end,
+                                        int n_parts) {
+    return guarded([&] { Manager::get().update_device_parts(host, nbytes, name, part_end, n_parts); });
+}
+
+int toast_hip_accel_update_device_wait(const void * host, int part, void * stream) {
+    return guarded([&] { Manager::get().update_device_wait(host, part, static_cast<hipStream_t>(stream)); });
+}
+
+int toast_hip_accel_update_device_finish(const void * host) {
+    return guarded([&] { Manager::get().update_device_finish(host); });
 }
 
 int toast_hip_accel_update_host(void * host, size_t nbytes, const char * name) {

@@ -150,6 +150,12 @@ public:
     void adopt(const void * host, size_t nbytes, void * device, const char * name);
     void reset(const void * host, size_t nbytes, const char * name);
     void update_device(const void * host, size_t nbytes, const char * name);
+    // Upload in parts on a stream of its own: returns once the copies are ENQUEUED (part k ends at byte part_end[k]);
+    // update_device_wait makes `stream` wait for part k (no host blocking), update_device_finish waits for all of
+    // them.  Lets kernels work on the first rows while the later ones are still crossing PCIe.
+    void update_device_parts(const void * host, size_t nbytes, const char * name, const size_t * part_end, int n_parts);
+    void update_device_wait(const void * host, int part, hipStream_t stream);
+    void update_device_finish(const void * host);
     void update_host(void * host, size_t nbytes, const char * name);
     void remove(const void * host, size_t nbytes, const char * name);
     void * device_ptr(const void * host);   // throws if absent
@@ -177,7 +183,9 @@ private:
         bool owned = true;
         bool host_registered = false;
         bool pin_failed = false;
+        std::vector<hipEvent_t> part_done;   // update_device_parts: one event per enqueued part
     };
+    hipStream_t upload_stream_ = nullptr;   // non-blocking: does not synchronise with the default stream
     void pin_for_transfer(const void * host, Entry & e);
     static void unpin(const void * host, Entry & e);
     void * take_cached(size_t nbytes);

@@ -104,6 +104,8 @@ class NoiseFilter(Operator):
     white_noise_min = Float(None, allow_none=True, help="Minimum frequency of the white noise plateau [Hz]")
     white_noise_max = Float(None, allow_none=True, help="Maximum frequency of the white noise plateau [Hz]")
     debug = Unicode(None, allow_none=True, help="Path to directory for generating debug plots (not produced here)")
+    upload_parts = Int(4, help="Row blocks in which a host-resident timestream buffer of 256 MB or more is uploaded, "
+                       "the transform of one block overlapping the upload of the next (1: one blocking upload)")
     net_fit = Unicode("reference", help="White-noise estimate when no plateau range is given: 'reference' = the "
                       "reference's iterative curve_fit per detector (its exact numbers), 'closed_form' = the same least "
                       "squares solved exactly for all detectors at once (agrees to ~1e-8, 1000x faster)")
@@ -119,12 +121,25 @@ class NoiseFilter(Operator):
             dd = obs.detdata[self.det_data]
             on_dev = dd.accel_in_use()
             made_resident = False
+            upload_bounds = None
             if not on_dev and accel_enabled():
                 # one page-locked upload instead of per-call pageable staging; the filtered
                 # timestream stays resident for the map-maker (lazy host coherence)
                 if not dd.accel_exists():
                     dd.accel_create(self.det_data)
-                dd.accel_update_device()
+                rows = dd.buffer.shape[0]
+                n_parts = min(self.upload_parts, rows) if dd.buffer.nbytes >= (256 << 20) else 1
+                if n_parts > 1:
+                    # Large buffer: the upload is enqueued in row blocks on the library's upload stream and this
+                    # thread moves on -- the kernels below are built while the data crosses PCIe, and the transform
+                    # of block k runs while block k + 1 is still on its way (toast_hip_accel_update_device_parts).
+                    from .. import capi
+
+                    upload_bounds = np.linspace(0, rows, n_parts + 1).astype(np.int64)
+                    capi.accel_update_device_parts(dd.buffer, upload_bounds[1:] * dd.buffer.shape[1] * 8, self.det_data)
+                    dd.accel_used(True)
+                else:
+                    dd.accel_update_device()
                 on_dev = made_resident = True
             flags = None
             flag_mask = None
@@ -161,7 +176,18 @@ class NoiseFilter(Operator):
                 extend[:] = hipfft.impulse_extents(len(dets), n_samp, rate, kern_freq, kernels)
                 if np.any(extend == n_samp):
                     raise RuntimeError("Impulse response spreads to all samples")
-            hipfft.convolve_buffer(dd.arg(on_dev), idx, rate, kern_freq, kernels, use_accel=on_dev)
+            if upload_bounds is not None:
+                from .. import capi
+
+                for part in range(len(upload_bounds) - 1):
+                    sel = np.flatnonzero((idx >= upload_bounds[part]) & (idx < upload_bounds[part + 1]))
+                    if sel.size == 0:
+                        continue
+                    capi.accel_update_device_wait(dd.buffer, part)      # the stream waits, the host does not
+                    hipfft.convolve_buffer(dd.arg(True), idx[sel], rate, kern_freq, kernels[sel], use_accel=True)
+                capi.accel_update_device_finish(dd.buffer)
+            else:
+                hipfft.convolve_buffer(dd.arg(on_dev), idx, rate, kern_freq, kernels, use_accel=on_dev)
             if made_resident and not getattr(data, "lazy_host", False):
                 dd.accel_update_host()
                 dd.accel_delete()
