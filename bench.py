@@ -455,8 +455,9 @@ def run(args, workload, world, rank, dev, headline=True):
     # gfx950 FETCH correction calibrated in-run; profiles/README.md); null if not profiled.
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
-    knames = {"build_noise_weighted": ("k_build_noise_weighted_pair<3>", "k_build_noise_weighted<3>"),
-              "scan_map": ("k_scan_map<double, 3>",)}[dom]
+    knames = {"build_noise_weighted": ("k_build_noise_weighted_v2<2>", "k_build_noise_weighted_pair<3>",
+                                       "k_build_noise_weighted<3>"),
+              "scan_map": ("k_scan_map_v2<double>", "k_scan_map<double, 3>")}[dom]
     if os.path.isfile(tpath) and not args.unfused:
         try:
             with open(tpath) as f:

@@ -8,7 +8,7 @@ import sys
 
 
 def short(name):
-    m = re.search(r"(k_[a-z_]+(?:<[^>]*>)?)", name)
+    m = re.search(r"(k_[a-z_0-9]+(?:<[^>]*>)?)", name)
     if m:
         return m.group(1)
     name = re.sub(r"\(.*", "", name)
