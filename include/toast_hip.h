@@ -984,6 +984,8 @@ int toast_hip_comm_all_gather_dev(const void * d_send, void * d_recv, int64_t se
  *       and reduce = 1 this is sync_alltoallv() with the default local_func (sum).
  *   cov_invert / cov_mult: every rank works on its shard of the replicated matrices, the shards are gathered. */
 int toast_hip_comm_pixel_shard(int64_t n_px, int64_t * first, int64_t * count);
+/* the same rule for any (n_ranks, rank), no communicator needed: pixels [first, first + count), per_rank = ceil(n_px / n_ranks) */
+int toast_hip_comm_shard_of(int64_t n_px, int n_ranks, int rank, int64_t * first, int64_t * count, int64_t * per_rank);
 int toast_hip_comm_map_reduce_apply_dev(int64_t n_px, int64_t nnz, const double * d_cov, double * d_map, int reduce,
                                         void * stream);
 int toast_hip_comm_cov_invert_dev(int64_t n_px, int64_t nnz, double * d_cov, double * d_rcond, double threshold,

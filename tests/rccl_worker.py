@@ -117,6 +117,18 @@ def main():
     capi.dev.comm_allreduce(u.data_ptr(), 3, np.uint8, "max")
     assert u.cpu().tolist() == [size - 1, 5, 250]
 
+    # the pybind front end of the same calls (what a maintainer binds in PixelData)
+    assert nat.comm_info()[:2] == (size, rank)
+    pz = PixelData(d, np.float64, n_value=3)
+    pz.raw[:] = parts[rank]
+    pz.accel_create("zmap")
+    pz.accel_update_device()
+    nat.comm_allreduce(pz.buffer, "sum")
+    nat.comm_map_reduce_apply(None, pz.buffer, 3, True)          # sums the (already equal) copies again
+    pz.accel_update_host()
+    np.testing.assert_allclose(pz.raw, size * total, rtol=0, atol=1e-13 * size * np.max(np.abs(total)))
+    pz.accel_delete()
+
     # owner-computes covariance operations on device-resident operands (reduce-scatter / kernel on the owned pixel
     # shard / all-gather) against the all-local kernels: covariance.py:78-131, 179-221, 262-306
     from toast_amd.pixels import covariance_invert, covariance_multiply, map_reduce_apply

@@ -147,3 +147,32 @@ def test_header_is_plain_c_and_links(tmp_path):
                     "-L", libdir, "-ltoast_hip", "-Wl,-rpath," + libdir, "-o", str(exe)], check=True)
     out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
     assert out[0] == "32" and out[1] == "1" and out[2] == "1"
+
+
+def test_comm_pixel_shards_partition_the_map():
+    """The owner-computes collectives give rank r the pixels [r * per, (r + 1) * per), per = ceil(n_px / n_ranks)
+    (toast_hip_comm_shard_of; comm.cpp): for any size the shards are disjoint, in rank order, and cover the map; the
+    reduce-scatter / all-gather buffers of per * n_ranks pixels hold every shard."""
+    import ctypes as C
+
+    from toast_amd import capi
+
+    lib = capi.real_lib()
+    rng = np.random.default_rng(3)
+    sizes = [0, 1, 2, 7, 8, 9, 3072, 3072 * 37, 12 * 1024 * 1024] + [int(x) for x in rng.integers(1, 10**7, 20)]
+    for n_px in sizes:
+        for n_ranks in (1, 2, 3, 4, 5, 7, 8, 16):
+            nxt = 0
+            for rank in range(n_ranks):
+                first, count, per = C.c_int64(-1), C.c_int64(-1), C.c_int64(-1)
+                rc = lib.toast_hip_comm_shard_of(C.c_int64(n_px), C.c_int(n_ranks), C.c_int(rank), C.byref(first),
+                                                 C.byref(count), C.byref(per))
+                assert rc == 0
+                assert per.value == -(-n_px // n_ranks) and 0 <= count.value <= per.value
+                assert first.value == min(nxt, n_px) == min(rank * per.value, n_px)
+                nxt = first.value + count.value
+            assert nxt == n_px and per.value * n_ranks >= n_px
+    assert lib.toast_hip_comm_shard_of(C.c_int64(10), C.c_int(2), C.c_int(2), None, None, None) != 0
+    # without a communicator the collectives fail loudly
+    assert lib.toast_hip_comm_allreduce_dev(None, C.c_int64(4), C.c_int(0), C.c_int(0), None) != 0
+    assert b"toast_hip_comm_init" in lib.toast_hip_last_error()

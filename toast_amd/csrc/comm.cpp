@@ -127,16 +127,18 @@ struct Shard {
     bool even;       // n_px == per * size: the collectives run in place on the map
 };
 
-Shard shard_of(int64_t n_px) {
+Shard shard_of(int64_t n_px, int size, int rank) {
     Shard s;
-    s.per = (n_px + g_size - 1) / g_size;
-    s.first = (int64_t)g_rank * s.per;
+    s.per = (n_px + size - 1) / size;
+    s.first = (int64_t)rank * s.per;
     const int64_t last = (s.first + s.per < n_px) ? s.first + s.per : n_px;
     s.count = (last > s.first) ? last - s.first : 0;
     if (s.first > n_px) s.first = n_px;
-    s.even = (s.per * g_size == n_px);
+    s.even = (s.per * size == n_px);
     return s;
 }
+
+Shard shard_of(int64_t n_px) { return shard_of(n_px, g_size, g_rank); }
 
 // `work` = the buffer the two ring halves run on: the map itself when the pixels divide evenly, else a zero-padded
 // scratch copy of per * size pixels (kScratchCommA / B of the manager's grow-only scratch buffers).
@@ -245,6 +247,16 @@ int toast_hip_comm_all_gather_dev(const void * d_send, void * d_recv, int64_t se
         if (send_count <= 0) return;
         const DType t = dtype_of(dtype);
         check(rccl().all_gather(d_send, d_recv, (size_t)send_count, t.nccl, comm(), as_stream(stream)), "ncclAllGather");
+    });
+}
+
+int toast_hip_comm_shard_of(int64_t n_px, int n_ranks, int rank, int64_t * first, int64_t * count, int64_t * per_rank) {
+    return guarded([&] {
+        if (n_px < 0 || n_ranks < 1 || rank < 0 || rank >= n_ranks) fail_arg("HipComm:  need n_px >= 0 and 0 <= rank < n_ranks");
+        const Shard s = shard_of(n_px, n_ranks, rank);
+        if (first) *first = s.first;
+        if (count) *count = s.count;
+        if (per_rank) *per_rank = s.per;
     });
 }
 

@@ -681,6 +681,59 @@ PYBIND11_MODULE(_libtoast_hip, m) {
         check(toast_hip_accel_device_ptr(b.ptr, &dev));
         return reinterpret_cast<uintptr_t>(dev);
     });
+    // ---- the process' RCCL communicator on registered (device-resident) buffers: what PixelData.sync_allreduce /
+    //      sync_alltoallv and covariance_*(use_alltoallv=True) call when their data is on the accelerator
+    //      (INTEGRATION.md "Map reductions over several GPUs")
+    m.def("comm_unique_id", []() {
+        char id[TOAST_HIP_COMM_ID_BYTES];
+        check(toast_hip_comm_unique_id(id));
+        return py::bytes(id, sizeof(id));
+    });
+    m.def("comm_init", [](py::bytes id, int n_ranks, int rank) {
+        const std::string s = id;
+        if (s.size() != TOAST_HIP_COMM_ID_BYTES) throw std::runtime_error("comm_init: the RCCL unique id has 128 bytes");
+        check(toast_hip_comm_init(s.data(), n_ranks, rank));
+    });
+    m.def("comm_destroy", []() { check(toast_hip_comm_destroy()); });
+    m.def("comm_info", []() {
+        int n = 0, r = -1, v = 0;
+        check(toast_hip_comm_info(&n, &r, &v));
+        return py::make_tuple(n, r, v);
+    });
+    m.def("comm_allreduce", [](py::buffer data, std::string op) {
+        auto info = data.request();
+        const std::string f = norm_format(info.format);
+        int dt = -1;
+        if (f == "d") dt = TOAST_HIP_COMM_F64;
+        else if (f == "f") dt = TOAST_HIP_COMM_F32;
+        else if (f == "q") dt = TOAST_HIP_COMM_I64;
+        else if (f == "i") dt = TOAST_HIP_COMM_I32;
+        else if (f == "B") dt = TOAST_HIP_COMM_U8;
+        else throw std::runtime_error("comm_allreduce: unsupported element type " + info.format);
+        const int o = (op == "sum") ? TOAST_HIP_COMM_SUM : (op == "max") ? TOAST_HIP_COMM_MAX
+                      : (op == "min") ? TOAST_HIP_COMM_MIN : -1;
+        if (o < 0) throw std::runtime_error("comm_allreduce: op must be sum, max or min");
+        void * dev = nullptr;
+        check(toast_hip_accel_device_ptr(info.ptr, &dev));
+        check(toast_hip_comm_allreduce_dev(dev, (int64_t)info.size, dt, o, nullptr));
+    }, py::arg("data"), py::arg("op") = "sum");
+    m.def("comm_map_reduce_apply", [](py::object cov, py::buffer map, int64_t nnz, bool reduce) {
+        auto im = map.request();
+        if (norm_format(im.format) != "d") throw std::runtime_error("comm_map_reduce_apply: the map must be float64");
+        void * d_map = nullptr;
+        void * d_cov = nullptr;
+        check(toast_hip_accel_device_ptr(im.ptr, &d_map));
+        if (!cov.is_none()) {
+            auto ic = cov.cast<py::buffer>().request();
+            if (norm_format(ic.format) != "d" || ic.size / (nnz * (nnz + 1) / 2) != im.size / nnz) {
+                throw std::runtime_error("comm_map_reduce_apply: covariance and map sizes are not consistent");
+            }
+            check(toast_hip_accel_device_ptr(ic.ptr, &d_cov));
+        }
+        check(toast_hip_comm_map_reduce_apply_dev((int64_t)(im.size / nnz), nnz, static_cast<const double *>(d_cov),
+                                                  static_cast<double *>(d_map), reduce ? 1 : 0, nullptr));
+    }, py::arg("cov"), py::arg("map"), py::arg("nnz"), py::arg("reduce") = true);
+
     m.def("accel_adopt", [](py::buffer data, uintptr_t device, std::string name) {
         RawBuf b = accel_buf(data);
         check(toast_hip_accel_adopt(b.ptr, b.nbytes, reinterpret_cast<void *>(device), name.c_str()));
