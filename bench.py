@@ -166,6 +166,13 @@ def main():
     dev_index = local_rank % max(torch.cuda.device_count(), 1) if share else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    # TOAST_BENCH_SINGLE_RANK_COMM=1 (tests only): run the N > 1 code path -- process group, the library's RCCL
+    # communicator with its self-check, the per-step collective -- with ONE rank, which a single-GPU box can do.
+    single = world == 1 and os.environ.get("TOAST_BENCH_SINGLE_RANK_COMM", "0") == "1"
+    if single:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29561")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     if world > 1:
         if share:
             dist.init_process_group("gloo")
@@ -195,7 +202,7 @@ def main():
         out["operator_level"] = op_level
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or single:
         dist.destroy_process_group()
 
 
@@ -209,6 +216,8 @@ def run(args, workload, world, rank, dev, headline=True):
     D = capi.dev
     stream = torch.cuda.current_stream().cuda_stream
     share = os.environ.get("TOAST_BENCH_SHARE_GPU", "0") == "1"
+    # the collectives of the N > 1 path run (also with one rank when the single-rank test mode built a process group)
+    multi = world > 1 or (dist.is_available() and dist.is_initialized())
 
     n_det, n_samp, rate, nside = WORKLOADS[workload]
     nnz = 3
@@ -345,18 +354,41 @@ def run(args, workload, world, rank, dev, headline=True):
     # which is what the operators do) after a check of its results against torch.distributed on this very job; any
     # failure on any rank makes every rank use torch.distributed's all-reduce instead, and the JSON line says which.
     comm_impl, comm_note = None, None
-    if world > 1:
+    if multi:
         comm_impl, ok = "torch.distributed", 0
         if not share and os.environ.get("TOAST_BENCH_COMM", "") != "torch":
+            # Every step below that is collective is entered by ALL ranks or by none: first agree that every rank can
+            # load RCCL, then rank 0's id (with a validity byte) goes round, then the collective initialisation.
+            n_r, r_r, _ = D.comm_info()
+            ready = n_r == world and r_r == rank
+            if n_r == 0:
+                able = torch.tensor([1 if D.comm_available() else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(able, op=dist.ReduceOp.MIN)
+                uid = torch.zeros(129, dtype=torch.uint8)
+                if int(able.item()) == 1 and rank == 0:
+                    try:
+                        uid[:128] = torch.frombuffer(bytearray(D.comm_unique_id()), dtype=torch.uint8)
+                        uid[128] = 1
+                    except RuntimeError as err:
+                        comm_note = repr(err)[:300]
+                uid = uid.to(dev)
+                dist.broadcast(uid, src=0)
+                uid = uid.cpu()
+                if int(uid[128]) == 1:
+                    try:
+                        D.comm_init(bytes(uid[:128].numpy().tobytes()), world, rank)   # collective
+                        ready = True
+                    except RuntimeError as err:
+                        comm_note = repr(err)[:300]
+                elif comm_note is None:
+                    comm_note = "librccl could not be loaded on every rank"
+            # ... and the communicator is used only if EVERY rank has one
+            every = torch.tensor([1 if ready else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(every, op=dist.ReduceOp.MIN)
+            ready = int(every.item()) == 1
             try:
-                n_r, r_r, _ = D.comm_info()
-                if n_r == 0:
-                    uid = torch.zeros(128, dtype=torch.uint8)
-                    if rank == 0:
-                        uid = torch.frombuffer(bytearray(D.comm_unique_id()), dtype=torch.uint8).clone()
-                    uid = uid.to(dev)
-                    dist.broadcast(uid, src=0)
-                    D.comm_init(bytes(uid.cpu().numpy().tobytes()), world, rank)
+                if not ready:
+                    raise RuntimeError(comm_note or "no communicator on some rank")
                 chk = torch.arange(3 * 4096, dtype=torch.float64, device=dev) * (rank + 1.0)
                 ref_chk = chk.clone()
                 dist.all_reduce(ref_chk)
@@ -568,14 +600,14 @@ def run(args, workload, world, rank, dev, headline=True):
         # per-step RCCL all-reduce of the device-resident zmap (fp64 sum over the detector shards);
         # kernel_ms.allreduce is its stream time on this rank (includes waiting for the slowest rank)
         "allreduce": {
-            "bytes": int(n_local) * nps * nnz * 8 if world > 1 else 0,
-            "ms": ms["allreduce"] if world > 1 else 0.0,
-            "backend": (dist.get_backend() if world > 1 else None),
+            "bytes": int(n_local) * nps * nnz * 8 if multi else 0,
+            "ms": ms["allreduce"] if multi else 0.0,
+            "backend": (dist.get_backend() if multi else None),
             "implementation": comm_impl,
             "owner_computes_reduce_apply_ms": owner_ms,
             "note": comm_note,
             "algorithm_GBs": (2.0 * (world - 1) / world * n_local * nps * nnz * 8 / (ms["allreduce"] * 1e-3) / 1e9
-                              if world > 1 and ms["allreduce"] > 0 else None),
+                              if multi and world > 1 and ms["allreduce"] > 0 else None),
         },
     }
 

@@ -964,6 +964,9 @@ int toast_hip_pcg_history_dev(void * d_state, double * history, int64_t capacity
 #define TOAST_HIP_COMM_ID_BYTES 128
 enum { TOAST_HIP_COMM_F64 = 0, TOAST_HIP_COMM_F32 = 1, TOAST_HIP_COMM_I64 = 2, TOAST_HIP_COMM_I32 = 3, TOAST_HIP_COMM_U8 = 4 };
 enum { TOAST_HIP_COMM_SUM = 0, TOAST_HIP_COMM_MAX = 1, TOAST_HIP_COMM_MIN = 2 };
+/* 1 when librccl can be opened with every entry point needed (no communicator is created): lets the ranks agree
+ * before the collective toast_hip_comm_init -- a rank that cannot load RCCL would leave the others waiting in it. */
+int toast_hip_comm_available(void);
 int toast_hip_comm_unique_id(void * id128);
 int toast_hip_comm_init(const void * id128, int n_ranks, int rank);
 /* n_ranks = 0 / rank = -1 when there is no communicator; rccl_version as ncclGetVersion reports it */

@@ -93,3 +93,23 @@ def test_bench_self_launch_two_ranks():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["allreduce"]["bytes"] > 0 and d["allreduce"]["ms"] > 0
     n = d["config"]["detectors_per_gpu"] * d["config"]["samples_per_detector"]
     assert abs(d["value"] - 2 * n / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+def test_bench_collective_path_with_one_rank():
+    """The N > 1 code path of bench.py on a single-GPU box (TOAST_BENCH_SINGLE_RANK_COMM=1: a one-rank `nccl` process
+    group): the ranks agree that RCCL can be loaded, the library's communicator is created from the id that the process
+    group carries, its all-reduce and owner-computes pass are checked against torch.distributed, and the timed step
+    reduces the map through it on the kernels' stream."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(TOAST_BENCH_SINGLE_RANK_COMM="1", OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--workload",
+                          "mini", "--no-fft", "--no-cpu-baseline", "--shard-workload", "cfg2"], capture_output=True,
+                         text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    a = d["allreduce"]
+    assert d["n_gpus"] == 1 and a["backend"] == "nccl" and a["note"] is None, a
+    assert a["implementation"].startswith("toast_hip_comm") and a["bytes"] > 0 and a["ms"] > 0
+    assert a["owner_computes_reduce_apply_ms"] > 0
+    sh = d["configs3_shard"]["allreduce"]           # a second workload in the same process reuses the communicator
+    assert sh["implementation"].startswith("toast_hip_comm") and sh["note"] is None

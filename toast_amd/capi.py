@@ -1057,6 +1057,9 @@ class _Dev:
                    np.dtype(np.uint8): 4}
     COMM_OPS = {"sum": 0, "max": 1, "min": 2}
 
+    def comm_available(self):
+        return bool(real_lib().toast_hip_comm_available())
+
     def comm_unique_id(self):
         buf = (C.c_ubyte * 128)()
         _check(real_lib().toast_hip_comm_unique_id(buf))

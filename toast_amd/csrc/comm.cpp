@@ -167,6 +167,18 @@ void all_gather_pixels(double * d_data, int64_t n_px, int64_t nv, const Shard & 
 
 extern "C" {
 
+int toast_hip_comm_available(void) {
+    // 1 when librccl can be opened and has every entry point this file uses; never throws, creates nothing.  Lets all
+    // ranks agree BEFORE the collective toast_hip_comm_init (a rank that cannot load RCCL would leave the others
+    // waiting inside ncclCommInitRank).
+    try {
+        (void)rccl();
+        return 1;
+    } catch (...) {
+        return 0;
+    }
+}
+
 int toast_hip_comm_unique_id(void * id128) {
     return guarded([&] {
         if (id128 == nullptr) fail_arg("HipComm:  unique id buffer is null");

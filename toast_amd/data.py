@@ -227,9 +227,28 @@ class Comm:
         if ok:
             n, r, _ = capi.dev.comm_info()
             if n == 0:
-                uid = np.frombuffer(capi.dev.comm_unique_id() if self.world_rank == 0 else bytes(128), dtype=np.uint8).copy()
+                # every rank must be able to load RCCL before anybody enters the collective initialisation
+                able = int(self.allreduce_scalar(1 if capi.dev.comm_available() else 0, op="min"))
+                uid = np.zeros(129, dtype=np.uint8)
+                if able and self.world_rank == 0:
+                    try:
+                        uid[:128] = np.frombuffer(capi.dev.comm_unique_id(), dtype=np.uint8)
+                        uid[128] = 1
+                    except RuntimeError:
+                        pass
                 self.bcast_array_(uid, root=0)
-                capi.dev.comm_init(uid.tobytes(), self.world_size, self.world_rank)
+                mine = 0
+                if uid[128] == 1:
+                    try:
+                        capi.dev.comm_init(uid[:128].tobytes(), self.world_size, self.world_rank)
+                        mine = 1
+                    except RuntimeError:
+                        mine = 0
+                # used only if EVERY rank has a communicator; otherwise the collectives of device-resident data go
+                # through the process group (host staging for gloo, torch's own RCCL for nccl)
+                ok = bool(int(self.allreduce_scalar(mine, op="min")))
+                if not ok and mine:
+                    capi.dev.comm_destroy()
             elif (n, r) != (self.world_size, self.world_rank):
                 raise RuntimeError(f"the library's communicator is rank {r} of {n}, the process group says "
                                    f"{self.world_rank} of {self.world_size}")
