@@ -510,6 +510,7 @@ struct AllocPolicy {
     bool contiguous = false;
     int probe_k = 4;
     double accept_tbs = 5.65;   // read + write bytes / probe time: between the two levels (5.05-5.4 and 5.9-6.0)
+    size_t max_bytes = size_t(8) << 30;   // TOAST_HIP_ALLOC_PROBE_MAX_GB
 };
 const AllocPolicy & alloc_policy() {
     static const AllocPolicy pol = [] {
@@ -530,6 +531,8 @@ const AllocPolicy & alloc_policy() {
         }
         const char * t = std::getenv("TOAST_HIP_ALLOC_ACCEPT_TBS");
         if (t != nullptr && std::atof(t) > 0.0) a.accept_tbs = std::atof(t);
+        const char * m = std::getenv("TOAST_HIP_ALLOC_PROBE_MAX_GB");
+        if (m != nullptr && std::atol(m) > 0) a.max_bytes = (size_t)std::atol(m) << 30;
         return a;
     }();
     return pol;
@@ -541,7 +544,7 @@ const AllocStats & alloc_stats() { return g_alloc_stats; }
 
 void * Manager::device_alloc(size_t nbytes) {
     const AllocPolicy & pol = alloc_policy();
-    const size_t lo = size_t(1) << 30, hi = size_t(8) << 30;
+    const size_t lo = size_t(1) << 30, hi = pol.max_bytes;
     if (pol.probe_k > 0 && nbytes >= lo && nbytes <= hi) {
         std::vector<void *> cand;
         std::vector<double> tbs;
