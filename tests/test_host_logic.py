@@ -276,3 +276,32 @@ def test_pixel_data_reset_after_the_buffer_was_handed_out():
     assert dup.data[3, 1, 0] == -2.5 and np.count_nonzero(dup.raw) == 1
     pd.reset()
     assert not np.any(view) and pd.host_is_zero()
+
+
+def test_sync_alltoallv_single_process():
+    """One process: the default exchange has nothing to do (and must not touch the buffers -- a device-resident map
+    would be dragged to the host and back); a user local_func sees every local submap as its single owned copy, in
+    place (reference pixels.py:852-858)."""
+    d = PixelDistribution(n_pix=12 * 4 * 4, n_submap=12, local_submaps=np.array([2, 5, 7]))
+    pd = PixelData(d, np.float64, n_value=2)
+    pd.data[:] = np.arange(pd.raw.size).reshape(pd.data.shape)
+    before = pd.data.copy()
+    pd.sync_alltoallv()
+    pd.sync_allreduce()
+    assert np.array_equal(pd.data, before) and not hasattr(pd, "receive")
+    calls = []
+
+    def double_it(n_submap_value, receive_locations, receive, reduce_buf):
+        assert n_submap_value == 16 * 2 and reduce_buf.size == n_submap_value
+        for sm, locs in receive_locations.items():
+            calls.append((sm, list(locs)))
+            for lc in locs:
+                receive[lc:lc + n_submap_value] *= 2.0
+
+    pd.sync_alltoallv(local_func=double_it)
+    assert calls == [(2, [0]), (5, [32]), (7, [64])]
+    assert np.array_equal(pd.data, 2.0 * before)
+    sc, sd, rc, rd, rloc = d.alltoallv_info
+    assert list(sc) == [3] and list(sd) == [0] and list(rc) == [3] and list(rd) == [0]
+    with pytest.raises(TypeError):
+        pd.sync_alltoallv(bogus=True)

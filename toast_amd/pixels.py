@@ -526,6 +526,8 @@ class PixelData(AcceleratorObject):
         if comm is not None and comm is not self._dist.comm:
             raise RuntimeError("sync_alltoallv works on the communicator of the pixel distribution")
         w = self._dist._world()
+        if w is None and local_func is None:
+            return      # one process: every submap is its own and only copy
         device_form = local_func is None or hasattr(local_func, "on_device")
         if w is not None and device_form and self._device_collectives(w):
             if local_func is None:
