@@ -694,6 +694,10 @@ void toast_hip_fft_points(int rows, int cols_fwd, int cols_inv);
  * CU); 0 = both rows interleaved in one 64 KB tile (two workgroups per CU).  Start-up value from
  * TOAST_HIP_FFT_ROWS=split|pair.  Same results to rounding. */
 void toast_hip_fft_rows_split(int split);
+/* Row length of the four-step factorisation M = N1 x N2 of the fused kernels: 2048 (64 KB row-pair tiles, two
+ * workgroups per CU in the row pass, 128-byte pieces in the column passes) or 1024 (32 KB tiles, four workgroups per
+ * CU, 64-byte pieces; only for M <= 2^20).  Start-up value from TOAST_HIP_FFT_N2.  Same results to rounding. */
+void toast_hip_fft_rows_n2(int n2);
 /* HBM bytes per timestream sample that the passes of that implementation move (accounting for
  * bench.py / DESIGN.md, not a measurement). */
 double toast_hip_fft_pipeline_bytes(int64_t n_samp);

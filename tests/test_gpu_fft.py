@@ -322,6 +322,39 @@ def test_fused_kernel_table_paths(pf, rows, tables):
         pf.set_rows_split(False)
 
 
+@pytest.mark.parametrize("tables", ["lds-real", "lds-complex", "global-dense"])
+def test_fused_rows_of_1024(pf, tables):
+    """The fused kernels with rows of N2 = 1024 (32 KB row-pair tiles, four workgroups per CU in the row pass; 64-byte
+    pieces in the column passes) against the oracle and against the N2 = 2048 factorisation, for every N1 that the
+    half-size rows allow (n_fft 2^13 .. 2^21) plus a length that falls back to N2 = 2048 (n_fft 2^22)."""
+    from oracle import fft_oracle as fo
+
+    rate, n_det = 200.0, 3
+    if tables == "global-dense":
+        freq, phase = np.linspace(0.0, rate / 2, 5000), False
+    elif tables == "lds-complex":
+        freq, phase = np.concatenate([[0.0], np.geomspace(1e-4, rate / 2, 90)]), True
+    else:
+        freq, phase = np.concatenate([[0.0], np.geomspace(1e-4, rate / 2, 70)]), False
+    kernels = _noise_kernels(freq, n_det, complex_phase=phase)
+    try:
+        for n_samp in (2100, 9000, 33000, 100001, 400000, 720000, 1100000):
+            rng = np.random.default_rng(n_samp)
+            data = rng.standard_normal((n_det, n_samp)).cumsum(axis=1) * 0.01 + rng.standard_normal((n_det, n_samp))
+            want = data.copy()
+            fo.convolve(want, rate, kernel_freq=freq, kernels=kernels)
+            out = {}
+            for n2 in (2048, 1024):
+                pf.set_rows_n2(n2)
+                got = data.copy()
+                pf.convolve(got, rate, kernel_freq=freq, kernels=kernels)
+                assert np.max(np.abs(got - want)) < TOL * np.max(np.abs(want)), (n_samp, tables, n2)
+                out[n2] = got
+            assert np.max(np.abs(out[1024] - out[2048])) < 1e-13 * np.max(np.abs(want))
+    finally:
+        pf.set_rows_n2(2048)
+
+
 @pytest.mark.parametrize("n_samp", [6000, 50001, 300000])
 def test_impulse_extents_on_device(pf, n_samp):
     """toast_hip_fft_impulse_extents (impulses made, convolved and measured in HBM) against the reference procedure

@@ -34,6 +34,7 @@ namespace fused_fft {
 bool supported(int64_t n_fft);
 void set_points(int rows, int cols_fwd, int cols_inv);
 void set_rows_split(int split);
+void set_rows_n2(int n2);
 double pipeline_bytes_per_sample(int64_t n_samp, int64_t n_fft);
 void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_samp, int64_t n_fft,
               int64_t n_buffer, int64_t n_reflect, double fstep, const double * d_knots, int64_t n_knot,
@@ -425,6 +426,7 @@ int64_t toast_hip_fft_length(int64_t n_samp) {
 void toast_hip_fft_select(int rocfft_only) { g_force_rocfft = rocfft_only ? 1 : 0; }
 
 void toast_hip_fft_rows_split(int split) { toast_hip::fused_fft::set_rows_split(split); }
+void toast_hip_fft_rows_n2(int n2) { toast_hip::fused_fft::set_rows_n2(n2); }
 
 void toast_hip_fft_points(int rows, int cols_fwd, int cols_inv) {
     toast_hip::fused_fft::set_points(rows, cols_fwd, cols_inv);

@@ -50,6 +50,8 @@ constexpr int kLT = 12;             // log2 of the tile (4096 complex doubles = 
 constexpr int kTile = 1 << kLT;
 // LDS budget of the row pass for the kernel tables (two 64 KB tiles + tables per CU: 2 x (64 + 15) KB <= 160 KB)
 constexpr int kTabLdsMax = 15 * 1024;
+// ... and with 32 KB tiles (N2 = 1024): four workgroups per CU, 4 x (32 + 7.5) KB <= 160 KB
+constexpr int kTabLdsHalf = 7 * 1024 + 512;
 // Every kernel is a template on P = points per thread (kTile / P threads per workgroup):
 //   P = 16: 256 threads, radix-16 ends, one LDS round trip fewer per transform, ~250 VGPRs -> 2 waves / SIMD
 //   P = 8:  512 threads, radix-8 stages, ~100 VGPRs -> 4 waves / SIMD (two workgroups per CU either way: LDS)
@@ -589,7 +591,7 @@ template <>
 struct KTabSel<true> {
     using H = uint16_t;
     static __device__ __forceinline__ KTab<H> make(const Params & p, int64_t kern, char * tab, int tid, int nthread) {
-        const int n_hint = (kTile / 2) + 2;
+        const int n_hint = (1 << p.log_n2) + 2;
         const int n_coef = 4 * (p.n_knot - 1);
         double * s_knots = reinterpret_cast<double *>(tab);
         double * s_mc = s_knots + p.n_knot;
@@ -652,15 +654,17 @@ __device__ __forceinline__ void pair_update(double2 * sm, int ea, int eb, double
 }
 
 // pass 2: rows (k1, N1 - k1) [block 0: rows 0 and N1 / 2]
-template <int P, bool TLDS>
-__global__ __launch_bounds__(kTile / P, (P == 16 ? 2 : 4)) void k_fft_rows(const Params p) {
-    constexpr int T = kTile / P;
+// LT = log2 of the tile = 2 N2: 12 (N2 = 2048, 64 KB, two workgroups per CU) or 11 (N2 = 1024, 32 KB, four per CU)
+template <int LT, int P, bool TLDS>
+__global__ __launch_bounds__((1 << LT) / P, (P == 16 ? 2 : 4)) void k_fft_rows(const Params p) {
+    constexpr int kRowTile = 1 << LT;
+    constexpr int T = kRowTile / P;
     extern __shared__ double2 sm[];
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const int g = blockIdx.x;
     const int64_t n1 = int64_t(1) << p.log_n1;
-    const int n2 = 1 << p.log_n2;            // = kTile / 2
+    const int n2 = 1 << p.log_n2;            // = tile / 2
     const int64_t m = n1 << p.log_n2;
     double2 * __restrict__ work = p.work + (int64_t)b * m;
     const int64_t r0 = (g == 0) ? 0 : g;
@@ -673,12 +677,12 @@ __global__ __launch_bounds__(kTile / P, (P == 16 ? 2 : 4)) void k_fft_rows(const
         const int64_t rr = (e & 1) ? r1 : r0;
         v[k] = work[(rr << p.log_n2) + (e >> 1)];
     }
-    const auto kt = KTabSel<TLDS>::make(p, p.per_det ? (int64_t)(p.det0 + b) : 0, reinterpret_cast<char *>(sm + kTile),
+    const auto kt = KTabSel<TLDS>::make(p, p.per_det ? (int64_t)(p.det0 + b) : 0, reinterpret_cast<char *>(sm + kRowTile),
                                         tid, T);
     PHASE_DECL;
     PHASE_WAIT_LOADS;
     PHASE_MARK(0);
-    tile_fft<P>(v, sm, tid, p.log_n2, p.tb.wtile);
+    tile_fft_t<LT, P>(v, sm, tid, p.log_n2, p.tb.wtile, tid, tid);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < P; ++k) sm[sw(tid + k * T)] = v[k];
@@ -691,7 +695,7 @@ __global__ __launch_bounds__(kTile / P, (P == 16 ? 2 : 4)) void k_fft_rows(const
         // k = g + N1 q.  A thread's pairs q = tid + T i have bins N1 T = N / P apart, so their unpacking twiddles are
         // w_N^k0 times the CONSTANTS w_P^i: one table look-up per thread, and the loop unrolls completely (the
         // kernel-interval look-ups of all pairs are in flight together).
-        constexpr int NP = kTile / 2 / T;
+        constexpr int NP = kRowTile / 2 / T;
         constexpr double c16[8] = {1.0, 0.92387953251128673848, 0.70710678118654752440, 0.38268343236508977173,
                                    0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128673848};
         constexpr double s16[8] = {0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128673848,
@@ -747,7 +751,7 @@ __global__ __launch_bounds__(kTile / P, (P == 16 ? 2 : 4)) void k_fft_rows(const
     PHASE_MARK(2);
 #pragma unroll
     for (int k = 0; k < P; ++k) v[k] = sm[sw(tid + k * T)];
-    tile_fft<P>(v, sm, tid, p.log_n2, p.tb.wtile);
+    tile_fft_t<LT, P>(v, sm, tid, p.log_n2, p.tb.wtile, tid, tid);
     PHASE_MARK(3);
     const int log_n2_tail = opaque_sgpr(p.log_n2);
     const int tid_tail = opaque_vgpr(tid);
@@ -887,10 +891,12 @@ static Plan & get_plan(int64_t n_fft, hipStream_t st) {
         set(reinterpret_cast<const void *>(&k_fft_cols<kLT, 16, true>), lds);
         set(reinterpret_cast<const void *>(&k_fft_cols<kLT, 8, false>), lds);
         set(reinterpret_cast<const void *>(&k_fft_cols<kLT, 8, true>), lds);
-        set(reinterpret_cast<const void *>(&k_fft_rows<16, false>), lds);
-        set(reinterpret_cast<const void *>(&k_fft_rows<8, false>), lds);
-        set(reinterpret_cast<const void *>(&k_fft_rows<16, true>), lds_tab);
-        set(reinterpret_cast<const void *>(&k_fft_rows<8, true>), lds_tab);
+        set(reinterpret_cast<const void *>(&k_fft_rows<kLT, 16, false>), lds);
+        set(reinterpret_cast<const void *>(&k_fft_rows<kLT, 8, false>), lds);
+        set(reinterpret_cast<const void *>(&k_fft_rows<kLT, 16, true>), lds_tab);
+        set(reinterpret_cast<const void *>(&k_fft_rows<kLT, 8, true>), lds_tab);
+        set(reinterpret_cast<const void *>(&k_fft_rows<kLT - 1, 8, false>), lds / 2);
+        set(reinterpret_cast<const void *>(&k_fft_rows<kLT - 1, 8, true>), lds / 2 + kTabLdsHalf);
         attr_set = true;
     }
     return g_plans.emplace(key, pl).first->second;
@@ -933,6 +939,17 @@ int rows_split() {
     return g_rows_split;
 }
 void set_rows_split(int split) { g_rows_split = split ? 1 : 0; }
+namespace {
+int g_rows_n2 = -1;
+}
+int rows_n2() {
+    if (g_rows_n2 < 0) {
+        const char * e = std::getenv("TOAST_HIP_FFT_N2");
+        g_rows_n2 = (e != nullptr && std::atoi(e) == 1024) ? 1024 : 2048;
+    }
+    return g_rows_n2;
+}
+void set_rows_n2(int n2) { g_rows_n2 = (n2 == 1024) ? 1024 : 2048; }
 void set_points(int rows, int cols_fwd, int cols_inv) {
     g_points[0] = 0;
     read_points();       // defaults
@@ -967,7 +984,10 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
     p.n_fft = n_fft;
     p.n_buffer = n_buffer;
     p.n_reflect = n_reflect;
+    // Rows of N2 = 2048 (64 KB pair tiles) or, for M <= 2^20, of N2 = 1024 (32 KB pair tiles: four workgroups per CU in
+    // the row pass; the column passes then move 64-byte instead of 128-byte pieces).  TOAST_HIP_FFT_N2=1024|2048.
     p.log_n2 = kLT - 1;
+    if (rows_n2() == 1024 && log_m >= 11 && log_m <= 20) p.log_n2 = kLT - 2;
     p.log_n1 = log_m - p.log_n2;
     p.tb.wtile = pl.tables;
     p.tb.t0 = pl.tables + kTile;
@@ -998,7 +1018,7 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
     const int64_t cap = (int64_t)((size_t(8) << 30) / ((size_t)m * sizeof(double2)));
     if (batch > cap) batch = cap > 0 ? cap : 1;
     if (batch > n_det) batch = n_det;
-    const int64_t n_hint = (kTile / 2) + 2;       // bins q N1, q = 0 .. N2 + 1
+    const int64_t n_hint = (int64_t(1) << p.log_n2) + 2;       // bins q N1, q = 0 .. N2 + 1
     const size_t hint_bytes = ((size_t)n_hint * (sizeof(int32_t) + sizeof(uint16_t)) + 255) & ~size_t(255);
     char * scratch = (char *)Manager::get().scratch(Manager::kScratchFftWork,
                                                     hint_bytes + (size_t)batch * m * sizeof(double2));
@@ -1017,7 +1037,8 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
         const char * e = std::getenv("TOAST_HIP_FFT_TABLES");      // "global": experiment switch
         tab_lds_env = (e != nullptr && std::string(e) == "global") ? 0 : 1;
     }
-    const bool tab_lds = tab_lds_env && n_knot < 65535 && tab_bytes <= (size_t)kTabLdsMax;
+    const bool half_rows = p.log_n2 == kLT - 2;
+    const bool tab_lds = tab_lds_env && n_knot < 65535 && tab_bytes <= (size_t)(half_rows ? kTabLdsHalf : kTabLdsMax);
     const size_t lds = kTile * sizeof(double2);
     const size_t lds_rows = lds + (tab_lds ? tab_bytes : 0);
     const size_t lds_split = lds / 2 + (tab_lds ? tab_bytes : 0);
@@ -1032,18 +1053,25 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
         } else {
             hipLaunchKernelGGL((k_fft_cols<kLT, 16, false>), dim3(n_col_tiles, (unsigned)nb), dim3(kTile / 16), lds, st, p);
         }
-        const bool split = rows_split() != 0;
+        const bool split = rows_split() != 0 && !half_rows;
         const dim3 g_pair(split ? 1 : n_row_tiles, (unsigned)nb);   // split: rows 0 and N1 / 2 only (self-paired)
-        if (split || points_of(0) == 8) {
+        if (half_rows) {
+            const size_t lds_half = lds / 2 + (tab_lds ? tab_bytes : 0);
             if (tab_lds) {
-                hipLaunchKernelGGL((k_fft_rows<8, true>), g_pair, dim3(kTile / 8), lds_rows, st, p);
+                hipLaunchKernelGGL((k_fft_rows<kLT - 1, 8, true>), g_pair, dim3(kTile / 16), lds_half, st, p);
             } else {
-                hipLaunchKernelGGL((k_fft_rows<8, false>), g_pair, dim3(kTile / 8), lds_rows, st, p);
+                hipLaunchKernelGGL((k_fft_rows<kLT - 1, 8, false>), g_pair, dim3(kTile / 16), lds_half, st, p);
+            }
+        } else if (split || points_of(0) == 8) {
+            if (tab_lds) {
+                hipLaunchKernelGGL((k_fft_rows<kLT, 8, true>), g_pair, dim3(kTile / 8), lds_rows, st, p);
+            } else {
+                hipLaunchKernelGGL((k_fft_rows<kLT, 8, false>), g_pair, dim3(kTile / 8), lds_rows, st, p);
             }
         } else if (tab_lds) {
-            hipLaunchKernelGGL((k_fft_rows<16, true>), g_pair, dim3(kTile / 16), lds_rows, st, p);
+            hipLaunchKernelGGL((k_fft_rows<kLT, 16, true>), g_pair, dim3(kTile / 16), lds_rows, st, p);
         } else {
-            hipLaunchKernelGGL((k_fft_rows<16, false>), g_pair, dim3(kTile / 16), lds_rows, st, p);
+            hipLaunchKernelGGL((k_fft_rows<kLT, 16, false>), g_pair, dim3(kTile / 16), lds_rows, st, p);
         }
         if (split && n_row_tiles > 1) {
             const dim3 gr(n_row_tiles - 1, (unsigned)nb), bl(kTile / 16);

@@ -42,6 +42,11 @@ def set_rows_split(split=True):
     capi.lib().toast_hip_fft_rows_split(C.c_int(1 if split else 0))
 
 
+def set_rows_n2(n2=2048):
+    """Row length N2 of the four-step factorisation of the fused kernels: 2048 or 1024 (toast_hip_fft_rows_n2)."""
+    capi.lib().toast_hip_fft_rows_n2(C.c_int(int(n2)))
+
+
 def pipeline_bytes_per_sample(n_samp):
     """HBM bytes per timestream sample moved by the passes of the implementation in use."""
     fn = capi.lib().toast_hip_fft_pipeline_bytes
