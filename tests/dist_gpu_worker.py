@@ -96,6 +96,56 @@ def covariance_owner_computes(comm):
                 np.testing.assert_allclose(prod.data, ident, rtol=0, atol=1e-9)
 
 
+def single_rank_device_comm():
+    """One rank, backend nccl, collectives issued anyway (Comm(single_rank_collectives=True)): the complete MapMaker
+    with every multi-process branch taken on the device -- hit / covariance / map sums and the owner-computes
+    covariance inversion through the library's RCCL communicator, the fused left-hand side with the reduction +
+    covariance as one owner-computes pass inside its recorded plan, the PCG's dot products summed over the ranks on the
+    stream before each stage -- against the plain single-process run.  What a one-GPU box can exercise of the N > 1
+    operator path before a multi-GPU machine does."""
+    from toast_amd import capi
+
+    for full_pointing, prior in ((True, False), (False, False), (True, True)):
+        comm = Comm(single_rank_collectives=True)
+        assert comm.comm_world is not None and comm.device_comm() and capi.dev.comm_info()[:2] == (1, 0)
+        # count what went through the communicator (the wrappers run at least once per call site: the recorded plan of
+        # the fused left-hand side replays the C call itself afterwards)
+        D, seen = capi.dev, {}
+        originals = {name: getattr(type(D), name) for name in ("comm_map_reduce_apply", "comm_cov_invert",
+                                                               "comm_allreduce", "pcg_stage", "pcg_dot")}
+
+        def counting(name):
+            def wrapper(self, *args, **kwargs):
+                key = name + ("+allreduce" if kwargs.get("allreduce") else "")
+                seen[key] = seen.get(key, 0) + 1
+                return originals[name](self, *args, **kwargs)
+            return wrapper
+
+        for name in originals:
+            setattr(type(D), name, counting(name))
+        try:
+            data, mapper = build(comm, 0, N_TOTAL, full_pointing, prior)
+        finally:
+            for name, fn in originals.items():
+                setattr(type(D), name, fn)
+        # BinMap / fused LHS reduce + apply, covariance inversion on the owned shard, hit / inverse covariance sums, the
+        # PCG with its scalars on the device (with one rank the Offset amplitudes are "full" copies, whose dot products
+        # the reference does not reduce either, amplitudes.py:545-554: the stage's sum over the ranks needs two ranks)
+        assert seen.get("comm_map_reduce_apply", 0) >= 3 and seen.get("comm_cov_invert", 0) >= 2, seen
+        assert seen.get("comm_allreduce", 0) >= 2 and seen.get("pcg_dot", 0) >= 3 * len(mapper.history), seen
+        serial, smapper = build(Comm(use_dist=False), 0, N_TOTAL, full_pointing, prior)
+        assert list(data["dist"].local_submaps) == list(serial["dist"].local_submaps) and data["dist"].replicated
+        assert np.array_equal(data["mm_hits"].data, serial["mm_hits"].data)
+        for key in ("mm_cov", "mm_rcond", "mm_map", "mm_noiseweighted_map"):
+            a, b = data[key].data, serial[key].data
+            assert np.max(np.abs(a - b)) < 1e-11 * np.max(np.abs(b)), (key, float(np.max(np.abs(a - b))))
+        assert len(mapper.history) == len(smapper.history)
+        np.testing.assert_allclose(mapper.history[:8], smapper.history[:8], rtol=1e-7)
+        mine = data["mm_solve_amplitudes"]["baselines"].local
+        ref = serial["mm_solve_amplitudes"]["baselines"].local
+        assert np.max(np.abs(mine - ref)) < 1e-8 * np.max(np.abs(ref))
+
+
 def main():
     backend = os.environ.get("TOAST_TEST_BACKEND", "gloo")
     if backend == "nccl":   # one process per GPU (tests/test_gpu_rccl.py, needs two GPUs)
@@ -107,8 +157,14 @@ def main():
     else:
         dist.init_process_group("gloo")
     rank, size = dist.get_rank(), dist.get_world_size()
-    assert size == 2
     accel_assign_device(size, rank, 1.0, False)
+    if size == 1:
+        single_rank_device_comm()
+        dist.barrier()
+        dist.destroy_process_group()
+        print(f"rank {rank} OK")
+        return
+    assert size == 2
     covariance_owner_computes(Comm())
     half = N_TOTAL // size
     # cached pointing, pointing on the fly, and the amplitude-domain noise prior (rank-local

@@ -129,6 +129,34 @@ def main():
     np.testing.assert_allclose(pz.raw, size * total, rtol=0, atol=1e-13 * size * np.max(np.abs(total)))
     pz.accel_delete()
 
+    # the PCG's dot product summed over the ranks on the stream before the stage reads it (toast_hip_pcg_stage_dev with
+    # allreduce = 1) against the single-launch form of one process: p . Ap -> alpha = delta / (size * local dot)
+    n_amp = 10007
+    xs = torch.from_numpy(np.random.default_rng(900 + rank).standard_normal(n_amp)).cuda()
+    ys = torch.from_numpy(np.random.default_rng(950 + rank).standard_normal(n_amp)).cuda()
+    local_dot = float(torch.dot(xs, ys).item())
+    tot = torch.tensor([local_dot], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tot)
+    state = torch.zeros(capi.dev.pcg_state_bytes(5) // 8 + 1, dtype=torch.float64, device="cuda")
+    capi.dev.pcg_init(state.data_ptr(), 4.0, 3.0, 1e-12, 3, 5)
+    capi.dev.pcg_dot(state.data_ptr(), n_amp, xs.data_ptr(), ys.data_ptr(), 0, 0, accumulate=False, stage=0)
+    capi.dev.pcg_stage(state.data_ptr(), 1, allreduce=True)
+    res = torch.zeros(n_amp, dtype=torch.float64, device="cuda")
+    resid = torch.zeros(n_amp, dtype=torch.float64, device="cuda")
+    capi.dev.pcg_step(state.data_ptr(), n_amp, xs.data_ptr(), res.data_ptr(), ys.data_ptr(), resid.data_ptr())
+    torch.cuda.synchronize()
+    alpha = 3.0 / float(tot.item())
+    assert torch.allclose(res, alpha * xs, rtol=1e-12, atol=0) and torch.allclose(resid, -alpha * ys, rtol=1e-12, atol=0)
+    if size == 1:
+        state2 = torch.zeros_like(state)
+        capi.dev.pcg_init(state2.data_ptr(), 4.0, 3.0, 1e-12, 3, 5)
+        capi.dev.pcg_dot(state2.data_ptr(), n_amp, xs.data_ptr(), ys.data_ptr(), 0, 0, accumulate=False, stage=1)
+        res2 = torch.zeros_like(res)
+        resid2 = torch.zeros_like(res)
+        capi.dev.pcg_step(state2.data_ptr(), n_amp, xs.data_ptr(), res2.data_ptr(), ys.data_ptr(), resid2.data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(res, res2) and torch.equal(resid, resid2)
+
     # owner-computes covariance operations on device-resident operands (reduce-scatter / kernel on the owned pixel
     # shard / all-gather) against the all-local kernels: covariance.py:78-131, 179-221, 262-306
     from toast_amd.pixels import covariance_invert, covariance_multiply, map_reduce_apply

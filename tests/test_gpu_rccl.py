@@ -36,6 +36,19 @@ def test_rccl_single_rank_process_group():
     assert "rank 0 of 1 OK" in out.stdout
 
 
+def test_rccl_single_rank_mapmaker_through_the_device_communicator():
+    """tests/dist_gpu_worker.py with ONE rank over `nccl`: the complete MapMaker with every multi-process branch taken
+    on the device (owner-computes reductions in BinMap / CovarianceAndHits / the fused left-hand side, PCG dot products
+    summed on the stream) equals the plain single-process run."""
+    env = _env()
+    env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29551",
+               TOAST_TEST_BACKEND="nccl")
+    out = subprocess.run([sys.executable, os.path.join(HERE, "dist_gpu_worker.py")], capture_output=True, text=True,
+                         env=env, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-6000:]
+    assert "rank 0 OK" in out.stdout
+
+
 def _torchrun(n, script, *args, port=29543, timeout=1200):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), script, *args]
