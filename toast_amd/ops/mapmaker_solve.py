@@ -639,12 +639,11 @@ def _pcg_device_scalars(data, detectors, lhs_op, result, residual, precond, prop
     import time as _time
 
     from .. import capi
-    from ..accel import accel_device_ptr
+    from ..accel import accel_data_create, accel_data_delete, accel_device_ptr
 
     D = capi.dev
-    state_host = np.zeros(D.pcg_state_bytes(n_iter_max), dtype=np.uint8)
-    accel_data = __import__("toast_amd.accel", fromlist=["accel_data_create"])
-    accel_data.accel_data_create(state_host, "pcg_state")
+    state_host = np.zeros(D.pcg_state_bytes(n_iter_max), dtype=np.uint8)   # host key of the device-side state block
+    accel_data_create(state_host, "pcg_state")
     try:
         d_state = accel_device_ptr(state_host)
         D.pcg_init(d_state, sqsum_init, delta, convergence, n_iter_min, n_iter_max)
@@ -696,7 +695,7 @@ def _pcg_device_scalars(data, detectors, lhs_op, result, residual, precond, prop
             del iteration_seconds[len(history):]     # the speculative iteration after the end
         return [float(x) for x in history]
     finally:
-        accel_data.accel_data_delete(state_host, "pcg_state")
+        accel_data_delete(state_host, "pcg_state")
 
 
 def solve(data, detectors, lhs_op, rhs_key, result_key, convergence=1.0e-12, n_iter_min=3, n_iter_max=100,
