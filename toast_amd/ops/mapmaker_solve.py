@@ -564,8 +564,8 @@ class SolverLHS(Operator):
             if getattr(self, trait) is None:
                 raise RuntimeError(f"You must set the '{trait}' trait before calling exec()")
         if self._can_fuse(data):
-            if self.out in data:
-                data[self.out].reset()
+            if self.out in data and not data[self.out].accel_in_use():
+                data[self.out].reset()      # (device-current output: the first fused pass zeroes it itself)
             self._exec_fused(data, detectors)
             return
         self._zero_temp(data)
