@@ -619,14 +619,12 @@ def _device_scalars(rhs, vectors):
 
     if os.environ.get("TOAST_HIP_PCG_SCALARS", "device") == "host":
         return False
-    for amps in (rhs,) + tuple(vectors):
-        for v in amps.values():
-            if v.n_local == 0 or not v.accel_in_use():
-                return False
+    mine = all(v.n_local > 0 and v.accel_in_use() for amps in (rhs,) + tuple(vectors) for v in amps.values())
     comm = next(iter(rhs.values()))._comm
     if comm is not None and comm.comm_world is not None:
-        return bool(comm.device_comm())
-    return True
+        # a collective decision (the communicator is created collectively, and every rank must take the same loop)
+        return bool(comm.device_comm()) and bool(int(comm.allreduce_scalar(1 if mine else 0, op="min")))
+    return mine
 
 
 def _pcg_device_scalars(data, detectors, lhs_op, result, residual, precond, proposal, lhs_out, sqsum_init, delta,

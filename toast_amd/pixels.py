@@ -435,8 +435,10 @@ class PixelData(AcceleratorObject):
         """Device-resident data reduced in place through the library's RCCL communicator on the kernels' stream."""
         from . import capi
 
-        return (self.accel_in_use() and comm.device_comm() and self._dtype in capi.dev.COMM_DTYPES
-                and self._dist.replicated)
+        # (the two collective questions first, so that every rank asks them -- the communicator is created by the
+        # first one; the ranks are assumed to hold a map on the same side, as the operators leave it)
+        return bool(comm.device_comm() and self._dist.replicated and self.accel_in_use()
+                    and self._dtype in capi.dev.COMM_DTYPES)
 
     def sync_allreduce(self, comm=None, comm_bytes=10000000):
         """Sum the map over all processes; every process ends with the total (reference pixels.py:710-780; all
