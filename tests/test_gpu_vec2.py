@@ -96,3 +96,59 @@ def test_non_local_submap_is_skipped(hip):
     assert np.array_equal(outs[0], outs[1])
     hit_victim = (base["pixels"] // c["n_pix_submap"]) == victim
     assert hit_victim.any() and np.array_equal(outs[1][hit_victim], c["tod"][hit_victim])
+
+
+@pytest.mark.parametrize("pair", [1, 0])
+def test_run_reduction_on_adversarial_pixel_streams(hip, pair):
+    """build_noise_weighted fed hand-made pixel streams that stress the two-samples-per-lane run reduction
+    (scatter_runs2): runs that start on the second sample of a lane, runs of one and two samples, alternating pixels,
+    every other sample flagged or without a pixel, one run over the whole chunk, runs crossing the 128-sample wave and
+    the 1024-sample chunk boundaries -- against a plain NumPy scatter-add."""
+    rng = np.random.default_rng(4242)
+    n_samp, n_det, nps, n_sub = 4096, 4, 48, 40
+    n_pix = nps * n_sub
+    streams = []
+    base = np.arange(n_samp)
+    streams.append(np.full(n_samp, 77))                                  # one run
+    streams.append((base // 2) % n_pix)                                  # runs of two, aligned with the lanes
+    streams.append(((base + 1) // 2) % n_pix)                            # runs of two, straddling lanes
+    streams.append(((base + 1) // 3) % n_pix)                            # runs of three
+    streams.append(np.where(base % 2 == 0, 5, 9))                        # alternating
+    streams.append(rng.integers(0, n_pix, n_samp))                       # runs of one
+    streams.append(np.repeat(rng.integers(0, n_pix, n_samp // 127 + 1), 127)[:n_samp])   # runs across wave boundaries
+    streams.append(np.repeat(rng.integers(0, n_pix, 5), 1000)[:n_samp])  # runs across chunk boundaries
+    lengths = rng.integers(1, 9, n_samp)
+    streams.append(np.repeat(rng.integers(0, n_pix, n_samp), lengths)[:n_samp])          # random short runs
+    hip.set_tuning("pair", pair)
+    hip.set_tuning("vec2", 1)
+    g2l = np.arange(n_sub, dtype=np.int64)
+    idx = np.arange(n_det, dtype=np.int32)
+    for k, stream in enumerate(streams):
+        for holes in (None, "no_pixel", "flagged"):
+            pixels = np.tile(stream.astype(np.int64), (n_det, 1))
+            pixels[1::2] = np.roll(pixels[1::2], 1, axis=1) if k % 2 else pixels[1::2]   # pair partner in or out of step
+            dflags = np.zeros((n_det, n_samp), dtype=np.uint8)
+            if holes == "no_pixel":
+                pixels[:, rng.random(n_samp) < 0.3] = -1
+                pixels[0, ::2] = -1
+            elif holes == "flagged":
+                dflags[:, 1::2] = 1
+                dflags[2] = (rng.random(n_samp) < 0.5)
+            weights = rng.standard_normal((n_det, n_samp, 3))
+            tod = rng.standard_normal((n_det, n_samp))
+            scale = rng.random(n_det) + 0.5
+            sflags = (rng.random(n_samp) < 0.02).astype(np.uint8)
+            ivl = np.zeros(3, dtype=cases.interval_dtype)
+            for j, (a, b) in enumerate(((1, 1500), (1501, 1502), (1511, n_samp))):    # odd starts, a one-sample interval
+                ivl[j]["first"], ivl[j]["last"] = a, b
+            zmap = np.zeros((n_sub, nps, 3))
+            hip.build_noise_weighted(g2l, zmap, idx, pixels, idx, weights, idx, tod, idx, dflags, scale, 1, ivl, sflags, 1,
+                                     False)
+            want = np.zeros((n_pix, 3))
+            for d in range(n_det):
+                for iv in ivl:
+                    sl = slice(int(iv["first"]), int(iv["last"]))
+                    good = (pixels[d, sl] >= 0) & (dflags[d, sl] == 0) & (sflags[sl] == 0)
+                    np.add.at(want, pixels[d, sl][good], (tod[d, sl][good] * scale[d])[:, None] * weights[d, sl][good])
+            err = np.max(np.abs(zmap.reshape(-1, 3) - want)) / max(np.max(np.abs(want)), 1e-300)
+            assert err < 1e-12, (k, holes, pair, err)
