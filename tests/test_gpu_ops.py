@@ -857,9 +857,13 @@ def test_pcg_scalars_on_the_device_follow_the_host_loop(monkeypatch, case):
     if case == "stalls":
         assert n_host < 100 and n_dev < 100
     n = min(n_dev, n_host)
-    above = hist["host"][:n] > 1e-18         # (below that the residual is rounding noise of the two summation orders)
-    np.testing.assert_allclose(hist["device"][:n][above], hist["host"][:n][above], rtol=1e-5, atol=0)
-    assert np.all(hist["device"][:n][~above] < 1e-15)
+    # (towards the rounding floor the two summation orders drift apart: tight above 1e-12, a factor of two down to
+    # 1e-18, below that only "small")
+    h_dev, h_host = hist["device"][:n], hist["host"][:n]
+    tight, loose = h_host > 1e-12, (h_host <= 1e-12) & (h_host > 1e-18)
+    np.testing.assert_allclose(h_dev[tight], h_host[tight], rtol=1e-5, atol=0)
+    assert np.all(h_dev[loose] < 2.0 * h_host[loose]) and np.all(h_dev[loose] > 0.5 * h_host[loose])
+    assert np.all(h_dev[h_host <= 1e-18] < 1e-15)
     scale = np.max(np.abs(amps["host"]))
     assert np.max(np.abs(amps["device"] - amps["host"])) < 1e-6 * scale
 
