@@ -1574,6 +1574,232 @@ __global__ __launch_bounds__(kThreads) void k_offset_scan_project(
     }
 }
 
+// k_offset_accumulate with two consecutive samples per lane (nnz = 3): k_build_noise_weighted_v2 with the timestream
+// replaced by the amplitude of each sample's baseline (two look-ups per lane, equal except at a baseline boundary).
+template <int E>
+__global__ __launch_bounds__(kThreads) void k_offset_accumulate_v2(
+    const Chunk * __restrict__ chunks, int n_chunks, int n_det, const int64_t * __restrict__ view_first,
+    const int64_t * __restrict__ view_aoff, FastDiv step_div, const int64_t * __restrict__ amp_offsets,
+    const double * __restrict__ amps, const uint8_t * __restrict__ amp_flags,
+    const int32_t * __restrict__ p_idx, const int32_t * __restrict__ w_idx,
+    const int32_t * __restrict__ f_idx, const double * __restrict__ det_scale,
+    const int64_t * __restrict__ g2l, double * __restrict__ zmap, const int64_t * __restrict__ pixels,
+    const double * __restrict__ weights, const uint8_t * __restrict__ dflags, uint8_t dmask,
+    int use_dflags, const uint8_t * __restrict__ sflags, uint8_t smask, int use_sflags,
+    FastDiv nps_div, int64_t n_samp) {
+    constexpr int NNZ = 3;
+    const int det0 = E * blockIdx.x;
+    bool on[E];
+    const int64_t * prow[E];
+    const double * wrow[E];
+    const uint8_t * frow[E];
+    double ds[E];
+    int64_t amp_offset[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        on[e] = det0 + e < n_det;
+        const int det = on[e] ? det0 + e : det0;
+        prow[e] = pixels + (int64_t)p_idx[det] * n_samp;
+        wrow[e] = weights + (int64_t)w_idx[det] * n_samp * NNZ;
+        frow[e] = use_dflags ? dflags + (int64_t)f_idx[det] * n_samp : nullptr;
+        ds[e] = det_scale[det];
+        amp_offset[e] = amp_offsets[det];
+    }
+    const int64_t nps = nps_div.d;
+    const uint16_t dmask2 = (uint16_t)(dmask | (dmask << 8));
+    const uint16_t smask2 = (uint16_t)(smask | (smask << 8));
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        const int64_t vfirst = view_first[c.view];
+        const int64_t vaoff = view_aoff[c.view];
+        const int head = (int)(c.first & 1);
+        const int64_t s0 = c.first + head;          // even
+        const int n_pair = (c.count - head) >> 1;
+        for (int base = 0; base < n_pair; base += kThreads) {
+            const int j = base + threadIdx.x;
+            const bool active = j < n_pair;
+            const int64_t s = s0 + 2 * (int64_t)(active ? j : 0);
+            const int64_t step_a = fastdiv(s - vfirst, step_div), step_b = fastdiv(s + 1 - vfirst, step_div);
+            int64_t ka[E], kb[E];
+            double va[E][NNZ], vb[E][NNZ];
+            longlong2 pp[E];
+            double2 w0[E], w1[E], w2[E], av[E];
+            uint16_t fd[E];
+            uint8_t afa[E], afb[E];
+            const uint16_t fs = use_sflags ? *reinterpret_cast<const uint16_t *>(sflags + s) : (uint16_t)0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                pp[e] = *reinterpret_cast<const longlong2 *>(prow[e] + s);
+                fd[e] = use_dflags ? *reinterpret_cast<const uint16_t *>(frow[e] + s) : (uint16_t)0;
+                const int64_t aa = amp_offset[e] + vaoff + step_a, ab = amp_offset[e] + vaoff + step_b;
+                afa[e] = amp_flags[aa];
+                afb[e] = amp_flags[ab];
+                av[e] = make_double2(amps[aa], amps[ab]);
+                const double2 * wv = reinterpret_cast<const double2 *>(wrow[e] + NNZ * s);
+                w0[e] = wv[0];
+                w1[e] = wv[1];
+                w2[e] = wv[2];
+            }
+            int64_t ga[E], gb[E], la[E], lb[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                ga[e] = fastdiv(pp[e].x >= 0 ? pp[e].x : 0, nps_div);
+                gb[e] = fastdiv(pp[e].y >= 0 ? pp[e].y : 0, nps_div);
+                la[e] = g2l[ga[e]];
+                lb[e] = g2l[gb[e]];
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const uint16_t bad = (uint16_t)((fd[e] & dmask2) | (fs & smask2));
+                const bool good_a = active & on[e] & (pp[e].x >= 0) & ((bad & 0x00ff) == 0);
+                const bool good_b = active & on[e] & (pp[e].y >= 0) & ((bad & 0xff00) == 0);
+                ka[e] = good_a ? la[e] * nps + (pp[e].x - ga[e] * nps) : -1;
+                kb[e] = good_b ? lb[e] * nps + (pp[e].y - gb[e] * nps) : -1;
+                // tod = 0 + amplitude (unflagged amplitudes only), then * det_scale
+                const double ta = (afa[e] == 0) ? (0.0 + av[e].x) : 0.0, tb = (afb[e] == 0) ? (0.0 + av[e].y) : 0.0;
+                const double sa = ta * ds[e], sb = tb * ds[e];
+                va[e][0] = good_a ? sa * w0[e].x : 0.0;
+                va[e][1] = good_a ? sa * w0[e].y : 0.0;
+                va[e][2] = good_a ? sa * w1[e].x : 0.0;
+                vb[e][0] = good_b ? sb * w1[e].y : 0.0;
+                vb[e][1] = good_b ? sb * w2[e].x : 0.0;
+                vb[e][2] = good_b ? sb * w2[e].y : 0.0;
+            }
+            if constexpr (E == 2) {
+                const bool mergeable = ((ka[0] == ka[1]) | (ka[0] < 0) | (ka[1] < 0)) &
+                                       ((kb[0] == kb[1]) | (kb[0] < 0) | (kb[1] < 0));
+                if (__all(mergeable)) {
+                    const int64_t kam = (ka[0] >= 0) ? ka[0] : ka[1];
+                    const int64_t kbm = (kb[0] >= 0) ? kb[0] : kb[1];
+                    double vam[NNZ], vbm[NNZ];
+#pragma unroll
+                    for (int k = 0; k < NNZ; ++k) {
+                        vam[k] = va[0][k] + va[1][k];
+                        vbm[k] = vb[0][k] + vb[1][k];
+                    }
+                    scatter_runs2<NNZ>(kam, vam, kbm, vbm, zmap);
+                    continue;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) scatter_runs2<NNZ>(ka[e], va[e], kb[e], vb[e], zmap);
+        }
+        const int tail = (c.count - head) & 1;
+        if ((threadIdx.x == 0 && head) || (threadIdx.x == 1 && tail)) {
+            const int64_t s = (threadIdx.x == 0) ? c.first : c.first + c.count - 1;
+            const uint8_t fs = use_sflags ? sflags[s] : (uint8_t)0;
+            const int64_t astep = fastdiv(s - vfirst, step_div);
+            for (int e = 0; e < E; ++e) {
+                if (!on[e]) continue;
+                const int64_t p = prow[e][s];
+                const uint8_t fd = use_dflags ? frow[e][s] : (uint8_t)0;
+                if ((p < 0) | ((fd & dmask) != 0) | ((fs & smask) != 0)) continue;
+                const int64_t gsm = fastdiv(p, nps_div);
+                const int64_t key = g2l[gsm] * nps + (p - gsm * nps);
+                if (key < 0) continue;
+                const int64_t a = amp_offset[e] + vaoff + astep;
+                const double t = (amp_flags[a] == 0) ? (0.0 + amps[a]) : 0.0;
+                const double sd = t * ds[e];
+                const double * w = wrow[e] + NNZ * s;
+                double * z = zmap + NNZ * key;
+                for (int k = 0; k < NNZ; ++k) unsafeAtomicAdd(z + k, sd * w[k]);
+            }
+        }
+    }
+}
+
+// Two consecutive samples per lane (nnz = 3; see k_scan_map_v2 / k_build_noise_weighted_v2): 16-byte lane accesses for
+// pixels, weights (3 x) and -- SIGBUF -- the signal, the two flags as one 2-byte load; the global2local and map gathers
+// of both samples go out together; the amplitude keys of the pair (equal except at a baseline boundary) are reduced over
+// 128 samples per wave by one segmented scan (scatter_runs2).  Per-sample arithmetic as in k_offset_scan_project.
+template <bool SIGBUF>
+__global__ __launch_bounds__(kThreads) void k_offset_scan_project_v2(
+    const Chunk * __restrict__ chunks, int n_chunks, const int64_t * __restrict__ view_first,
+    const int64_t * __restrict__ view_aoff, FastDiv step_div, const int64_t * __restrict__ amp_offsets,
+    const double * __restrict__ amps_in, double * __restrict__ amps_out,
+    const uint8_t * __restrict__ amp_flags, const int32_t * __restrict__ p_idx,
+    const int32_t * __restrict__ w_idx, const int32_t * __restrict__ f_idx,
+    const double * __restrict__ det_w, const int64_t * __restrict__ g2l,
+    const double * __restrict__ map, const int64_t * __restrict__ pixels,
+    const double * __restrict__ weights, const uint8_t * __restrict__ flags, uint8_t fmask,
+    int use_flags, FastDiv nps_div, int64_t n_samp, const int32_t * __restrict__ s_idx,
+    const double * __restrict__ signal) {
+    const int det = blockIdx.x;
+    const double * srow = SIGBUF ? signal + (int64_t)s_idx[det] * n_samp : nullptr;
+    const int64_t * prow = pixels + (int64_t)p_idx[det] * n_samp;
+    const double * wrow = weights + (int64_t)w_idx[det] * n_samp * 3;
+    const uint8_t * frow = use_flags ? flags + (int64_t)f_idx[det] * n_samp : nullptr;
+    const double dw = det_w[det];
+    const int64_t amp_offset = amp_offsets[det];
+    const uint16_t fmask2 = (uint16_t)(fmask | (fmask << 8));
+    // one sample: everything after the stream loads (global2local and the map value are gathered by the caller)
+    auto finish = [&](bool hit, double av, double w0, double w1, double w2, double m0, double m1, double m2) {
+        double sc = 0.0;
+        sc += w0 * m0;
+        sc += w1 * m1;
+        sc += w2 * m2;
+        sc *= 1.0;
+        const double d = SIGBUF ? av : 0.0 + av;
+        return hit ? d - sc : d;
+    };
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        const int64_t vfirst = view_first[c.view];
+        const int64_t abase = amp_offset + view_aoff[c.view];
+        const int head = (int)(c.first & 1);
+        const int64_t s0 = c.first + head;          // even
+        const int n_pair = (c.count - head) >> 1;
+        for (int base = 0; base < n_pair; base += kThreads) {
+            const int j = base + threadIdx.x;
+            const bool active = j < n_pair;
+            const int64_t s = s0 + 2 * (int64_t)(active ? j : 0);
+            // streams (inactive lanes re-read pair 0: same lines) and the amplitude look-ups
+            const int64_t aa = abase + fastdiv(s - vfirst, step_div);
+            const int64_t ab = abase + fastdiv(s + 1 - vfirst, step_div);
+            const uint8_t afa = amp_flags[aa], afb = amp_flags[ab];
+            double2 av;
+            if (SIGBUF) {
+                av = *reinterpret_cast<const double2 *>(srow + s);
+            } else {
+                av = make_double2(amps_in[aa], amps_in[ab]);
+            }
+            const uint16_t fl = use_flags ? *reinterpret_cast<const uint16_t *>(frow + s) : (uint16_t)0;
+            const longlong2 pp = *reinterpret_cast<const longlong2 *>(prow + s);
+            const double2 * wv = reinterpret_cast<const double2 *>(wrow + 3 * s);
+            const double2 wa = wv[0], wb = wv[1], wc = wv[2];
+            const int64_t ga = scan_submap(pp.x, nps_div), gb = scan_submap(pp.y, nps_div);
+            const int64_t la = g2l[ga], lb = g2l[gb];
+            const ScanGather qa = scan_locate(pp.x, ga, la, nps_div), qb = scan_locate(pp.y, gb, lb, nps_div);
+            const double * ma = map + qa.off;
+            const double * mb = map + qb.off;
+            const double a0 = ma[0], a1 = ma[1], a2 = ma[2], b0 = mb[0], b1 = mb[1], b2 = mb[2];
+            const double da = finish(qa.hit, av.x, wa.x, wa.y, wb.x, a0, a1, a2);
+            const double db = finish(qb.hit, av.y, wb.y, wc.x, wc.y, b0, b1, b2);
+            const uint16_t bad = (uint16_t)(fl & fmask2);
+            int64_t ka = (active && afa == 0) ? aa : (int64_t)-1;
+            int64_t kb = (active && afb == 0) ? ab : (int64_t)-1;
+            double va[1] = {(ka >= 0 && (bad & 0x00ff) == 0) ? da * dw : 0.0};
+            double vb[1] = {(kb >= 0 && (bad & 0xff00) == 0) ? db * dw : 0.0};
+            scatter_runs2<1>(ka, va, kb, vb, amps_out);
+        }
+        // the peeled first sample (lane 0) and the odd last one (lane 1)
+        const int tail = (c.count - head) & 1;
+        if ((threadIdx.x == 0 && head) || (threadIdx.x == 1 && tail)) {
+            const int64_t s = (threadIdx.x == 0) ? c.first : c.first + c.count - 1;
+            const int64_t a = abase + fastdiv(s - vfirst, step_div);
+            if (amp_flags[a] == 0 && !(use_flags && (frow[s] & fmask))) {
+                const int64_t p = prow[s];
+                const int64_t gs = scan_submap(p, nps_div);
+                const ScanGather q = scan_locate(p, gs, g2l[gs], nps_div);
+                const double * m = map + q.off;
+                const double * w = wrow + 3 * s;
+                const double d = finish(q.hit, SIGBUF ? srow[s] : amps_in[a], w[0], w[1], w[2], m[0], m[1], m[2]);
+                unsafeAtomicAdd(amps_out + a, d * dw);
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(kThreads) void k_offset_apply_diag_precond(
     int64_t n_amp, const double * __restrict__ var, const double * __restrict__ in,
     const uint8_t * __restrict__ flags, double * __restrict__ out) {
@@ -2261,7 +2487,17 @@ int toast_hip_offset_accumulate_dev(
         (const int32_t *)(d + o_fi), (const double *)(d + o_ds), d_g2l, d_zmap, d_pixels, d_weights, \
         d_det_flags, det_flag_mask, use_d, d_shared_flags, shared_flag_mask, use_s,                 \
         make_fastdiv(n_pix_submap), n_samp
-        if (pair_detectors() && n_det >= 2) {
+        const bool v2 = vec2_lanes() && nnz == 3 && (n_samp & 1) == 0 && rows_16b(d_pixels) && rows_16b(d_weights) &&
+                        (!use_d || rows_16b(d_det_flags)) && (!use_s || rows_16b(d_shared_flags));
+        if (v2) {
+            const bool pr = pair_detectors() && n_det >= 2;
+            const dim3 gp((unsigned)(pr ? (n_det + 1) / 2 : n_det), grid.y, 1);
+            if (pr) {
+                hipLaunchKernelGGL((k_offset_accumulate_v2<2>), gp, dim3(kThreads), 0, st, TH_OA_ARGS);
+            } else {
+                hipLaunchKernelGGL((k_offset_accumulate_v2<1>), gp, dim3(kThreads), 0, st, TH_OA_ARGS);
+            }
+        } else if (pair_detectors() && n_det >= 2) {
             const dim3 gp((unsigned)((n_det + 1) / 2), grid.y, 1);
             if (nnz == 3) {
                 hipLaunchKernelGGL((k_offset_accumulate<3, 2>), gp, dim3(kThreads), 0, st, TH_OA_ARGS);
@@ -2321,7 +2557,15 @@ static int offset_scan_project_launch(
         (const int32_t *)(d + o_wi), (const int32_t *)(d + o_fi), (const double *)(d + o_dw), d_g2l, \
         d_map, d_pixels, d_weights, d_flag_data, flag_mask, use_flags, make_fastdiv(n_pix_submap),  \
         n_samp, (const int32_t *)(d + o_si), d_signal
-        if (sigbuf) {
+        const bool v2 = vec2_lanes() && nnz == 3 && (n_samp & 1) == 0 && rows_16b(d_pixels) && rows_16b(d_weights) &&
+                        (!use_flags || rows_16b(d_flag_data)) && (!sigbuf || rows_16b(d_signal));
+        if (v2) {
+            if (sigbuf) {
+                hipLaunchKernelGGL((k_offset_scan_project_v2<true>), grid, dim3(kThreads), 0, st, TH_OS_ARGS);
+            } else {
+                hipLaunchKernelGGL((k_offset_scan_project_v2<false>), grid, dim3(kThreads), 0, st, TH_OS_ARGS);
+            }
+        } else if (sigbuf) {
             if (nnz == 3) {
                 hipLaunchKernelGGL((k_offset_scan_project<3, true>), grid, dim3(kThreads), 0, st, TH_OS_ARGS);
             } else {
