@@ -501,14 +501,15 @@ int Manager::present(const void * host, size_t nbytes) {
 // the fastest of the K.  Candidates are held until the choice is made (a freed slow region would simply be handed out
 // again) and the losers are then released.  Cost: one ~5 ms probe per block on a box that hands out fast memory, K of
 // them on one that does not.
-//   TOAST_HIP_ALLOC=probe[:K]   the policy with K candidates (default: probe:4)
+//   TOAST_HIP_ALLOC=probe[:K]   the policy with K candidates (default: probe:8; a candidate costs ~2 ms, and with ~40 %
+//                               of them at the fast level four were not enough in one process out of ten)
 //   TOAST_HIP_ALLOC=plain       one hipMalloc per block, no probing
 //   TOAST_HIP_ALLOC=contiguous  hipDeviceMallocContiguous for blocks >= 256 MB (experiment: always the slow level)
 // Returns nullptr on failure.
 namespace {
 struct AllocPolicy {
     bool contiguous = false;
-    int probe_k = 4;
+    int probe_k = 8;
     double accept_tbs = 5.65;   // read + write bytes / probe time: between the two levels (5.05-5.4 and 5.9-6.0)
     size_t max_bytes = size_t(8) << 30;   // TOAST_HIP_ALLOC_PROBE_MAX_GB
 };
@@ -525,7 +526,7 @@ const AllocPolicy & alloc_policy() {
                 a.probe_k = 0;
             } else if (v.rfind("probe", 0) == 0) {
                 const char * c = std::strchr(e, ':');
-                const int k = c ? std::atoi(c + 1) : 4;
+                const int k = c ? std::atoi(c + 1) : 8;
                 a.probe_k = k < 2 ? 2 : (k > 8 ? 8 : k);
             }
         }

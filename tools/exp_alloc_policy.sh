@@ -1,6 +1,6 @@
 #!/bin/bash
 # Placement policy of the memory manager at the bench level: alternating fresh processes with the policy
-# (default, TOAST_HIP_ALLOC unset = probe:4) and without (TOAST_HIP_ALLOC=plain) on one box; prints value, step time,
+# (default, TOAST_HIP_ALLOC unset = probe:8) and without (TOAST_HIP_ALLOC=plain) on one box; prints value, step time,
 # the two kernels, set-up time and what the policy did (profiles/r03_b).  Run on the GPU box.
 out=${1:-gpurun_out/r03b/alloc_policy.txt}
 n=${2:-3}
