@@ -330,7 +330,7 @@ def test_placement_policy_of_the_memory_manager():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     f = [ln for ln in out.stdout.splitlines() if ln.startswith("STATS")][0].split()
     blocks, cands, blocks_reg, tbs, ms = int(f[1]), int(f[2]), int(f[3]), float(f[4]), float(f[5])
-    assert blocks == 3 and 3 <= cands <= 12 and blocks_reg == 1 and 2.0 < tbs < 8.0 and 0.0 < ms < 500.0
+    assert blocks == 3 and 3 <= cands <= 3 * 8 and blocks_reg == 1 and 2.0 < tbs < 8.0 and 0.0 < ms < 1000.0
     env["TOAST_HIP_ALLOC"] = "plain"
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600,
                          cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
