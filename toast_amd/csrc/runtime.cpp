@@ -512,6 +512,7 @@ struct AllocPolicy {
     int probe_k = 8;
     double accept_tbs = 5.65;   // read + write bytes / probe time: between the two levels (5.05-5.4 and 5.9-6.0)
     size_t max_bytes = size_t(8) << 30;   // TOAST_HIP_ALLOC_PROBE_MAX_GB
+    double budget_ms = 60.0;              // TOAST_HIP_ALLOC_BUDGET_MS: no further candidate once a block has cost this much
 };
 const AllocPolicy & alloc_policy() {
     static const AllocPolicy pol = [] {
@@ -532,6 +533,8 @@ const AllocPolicy & alloc_policy() {
         }
         const char * t = std::getenv("TOAST_HIP_ALLOC_ACCEPT_TBS");
         if (t != nullptr && std::atof(t) > 0.0) a.accept_tbs = std::atof(t);
+        const char * b = std::getenv("TOAST_HIP_ALLOC_BUDGET_MS");
+        if (b != nullptr && std::atof(b) > 0.0) a.budget_ms = std::atof(b);
         const char * m = std::getenv("TOAST_HIP_ALLOC_PROBE_MAX_GB");
         if (m != nullptr && std::atol(m) > 0) a.max_bytes = (size_t)std::atol(m) << 30;
         return a;
@@ -550,7 +553,15 @@ void * Manager::device_alloc(size_t nbytes) {
         std::vector<void *> cand;
         std::vector<double> tbs;
         size_t best = 0;
+        // A candidate normally costs ~5 ms (hipMalloc, first-touch pass, timed pass), but on a box whose memory is still
+        // being cleared after another process hipMalloc alone takes ~200 ms per 5.9 GB: the search stops once the block
+        // has cost `budget_ms` (the first candidate is needed in any case).
+        const auto t_start = std::chrono::steady_clock::now();
         for (int k = 0; k < pol.probe_k; ++k) {
+            if (k > 0) {
+                const double spent = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+                if (spent > pol.budget_ms) break;
+            }
             void * c = nullptr;
             if (hipMalloc(&c, nbytes) != hipSuccess) {
                 (void)hipGetLastError();
