@@ -615,11 +615,16 @@ def test_noise_filter_pipelined_upload():
         sig[:, ::1000] += 5.0
         ob.detdata[defaults.det_data].data[:] = sig
         dets = ob.local_detectors
-        op = ops.NoiseFilter(noise_model=defaults.noise_model, det_flags=None, shared_flags=None, upload_parts=parts)
+        frng = np.random.default_rng(78)
+        ob.detdata[defaults.det_flags].data[:] = (frng.random((n_det, n_samp)) < 1e-5).astype(np.uint8)
+        ob.shared[defaults.shared_flags].data[:] = (frng.random(n_samp) < 1e-5).astype(np.uint8)
+        op = ops.NoiseFilter(noise_model=defaults.noise_model, upload_parts=parts)   # flags on, as by default
         op.apply(data, detectors=[d for i, d in enumerate(dets) if i % 7 != 3])    # a subset: some rows stay untouched
         assert ob.detdata[defaults.det_data].accel_in_use()                         # left resident for the map-maker
         out[parts] = ob.detdata[defaults.det_data].data.copy()
-    assert np.array_equal(out[1], out[5])
+        out[("flags", parts)] = ob.detdata[defaults.det_flags].data.copy()
+    assert np.array_equal(out[1], out[5]) and np.array_equal(out[("flags", 1)], out[("flags", 5)])
+    assert np.count_nonzero(out[("flags", 5)]) > 10 * n_det
     for i in (3, 10, 17):                                                           # rows outside the subset
         assert np.array_equal(out[5][i], sig[i])
     nse = ob[defaults.noise_model]
