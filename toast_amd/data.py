@@ -117,37 +117,6 @@ class Comm:
         self._dist.all_reduce(tensor, op=ops[op])
         return tensor
 
-    def reduce_scatter_allgather_(self, tensor):
-        """In-place sum over ranks as reduce-scatter + all-gather of a 1-D tensor: every element is
-        reduced by exactly ONE owner rank and the owner's value is what all ranks receive -- the
-        communication pattern of the reference's owner-computes ``sync_alltoallv``
-        (src/toast/pixels.py:878-970), expressed with RCCL's two ring halves.  The shard between the
-        two halves (``owned`` below) is where a per-pixel operation on 1/N of the map can be applied.
-        Falls back to one all-reduce where the backend has no reduce-scatter (gloo)."""
-        if self.comm_world is None:
-            return tensor
-        import torch
-
-        n, size, rank = tensor.numel(), self.world_size, self.world_rank
-        chunk = (n + size - 1) // size
-        try:
-            if chunk * size != n:
-                work = torch.zeros(chunk * size, dtype=tensor.dtype, device=tensor.device)
-                work[:n].copy_(tensor)
-            else:
-                work = tensor
-            owned = torch.empty(chunk, dtype=tensor.dtype, device=tensor.device)
-            self._dist.reduce_scatter_tensor(owned, work, op=self._dist.ReduceOp.SUM)
-            self._dist.all_gather_into_tensor(work, owned)
-            if work is not tensor:
-                tensor.copy_(work[:n])
-        except (RuntimeError, NotImplementedError) as err:
-            if self._dist.get_backend() == "nccl":
-                raise
-            del err
-            self._dist.all_reduce(tensor, op=self._dist.ReduceOp.SUM)
-        return tensor
-
     def allreduce_array_(self, arr, op="sum"):
         """In-place all-reduce of a host NumPy array."""
         if self.comm_world is None:

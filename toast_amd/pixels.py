@@ -417,20 +417,6 @@ class PixelData(AcceleratorObject):
         dup.accel_used(True)
         return dup
 
-    def device_tensor(self):
-        """Zero-copy torch view of the device buffer (for RCCL collectives)."""
-        import torch
-
-        ptr = accel_device_ptr(self._raw)
-
-        class _Iface:
-            pass
-
-        holder = _Iface()
-        typestr = np.dtype(self._dtype).str
-        holder.__cuda_array_interface__ = dict(shape=(self._raw.size,), typestr=typestr, data=(ptr, False), version=3)
-        return torch.as_tensor(holder, device=torch.device("cuda", torch.cuda.current_device()))
-
     def _device_collectives(self, comm):
         """Device-resident data reduced in place through the library's RCCL communicator on the kernels' stream."""
         from . import capi
