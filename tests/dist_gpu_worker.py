@@ -96,6 +96,43 @@ def covariance_owner_computes(comm):
                 np.testing.assert_allclose(prod.data, ident, rtol=0, atol=1e-9)
 
 
+def binmap_sync_types(comm, first, n_det):
+    """BinMap(sync_type="allreduce") == BinMap(sync_type="alltoallv") == BuildNoiseWeighted + covariance_apply by hand
+    (the reference's own test: src/toast/tests/ops_mapmaker_binning.py:27-127), detector-sharded."""
+    from toast_amd.pixels import covariance_apply
+
+    maps = {}
+    for sync_type in ("allreduce", "alltoallv", "manual"):
+        data = create_satellite_data(comm=comm, n_det=n_det, total_det=N_TOTAL, first_det=first, n_samp=N_SAMP, rate=10.0,
+                                     spin_angle_deg=25.0, prec_angle_deg=35.0)
+        ob = data.obs[0]
+        for i, d in enumerate(ob.local_detectors):
+            ob.detdata[defaults.det_data][d] = np.random.default_rng(2000 + first + i).standard_normal(N_SAMP)
+        dp = ops.PointingDetectorSimple()
+        pix = ops.PixelsHealpix(detector_pointing=dp, nside=16, nside_submap=4, create_dist="dist")
+        sw = ops.StokesWeights(detector_pointing=dp, mode="IQU", hwp_angle=defaults.hwp_angle)
+        st = "alltoallv" if sync_type == "manual" else sync_type
+        ops.CovarianceAndHits(pixel_dist="dist", pixel_pointing=pix, stokes_weights=sw, covariance="cov", hits="hits",
+                              rcond="rcond", sync_type=st, rcond_threshold=1e-3).apply(data)
+        if sync_type == "manual":
+            from toast_amd.ops.pipeline import Pipeline
+
+            build = ops.BuildNoiseWeighted(pixel_dist="dist", zmap="zmap", view=pix.view, pixels=pix.pixels,
+                                           weights=sw.weights, noise_model=defaults.noise_model,
+                                           det_data=defaults.det_data, sync_type="allreduce")
+            Pipeline(operators=[pix, sw, build]).apply(data)
+            covariance_apply(data["cov"], data["zmap"])
+            maps[sync_type] = data["zmap"].data.copy()
+        else:
+            ops.BinMap(pixel_dist="dist", covariance="cov", binned="binned", pixel_pointing=pix, stokes_weights=sw,
+                       sync_type=sync_type, full_pointing=True).apply(data)
+            maps[sync_type] = data["binned"].data.copy()
+    scale = np.max(np.abs(maps["manual"]))
+    assert scale > 0
+    for key in ("allreduce", "alltoallv"):
+        assert np.max(np.abs(maps[key] - maps["manual"])) < 1e-12 * scale, key
+
+
 def single_rank_device_comm():
     """One rank, backend nccl, collectives issued anyway (Comm(single_rank_collectives=True)): the complete MapMaker
     with every multi-process branch taken on the device -- hit / covariance / map sums and the owner-computes
@@ -105,6 +142,7 @@ def single_rank_device_comm():
     operator path before a multi-GPU machine does."""
     from toast_amd import capi
 
+    binmap_sync_types(Comm(single_rank_collectives=True), 0, N_TOTAL)
     for full_pointing, prior in ((True, False), (False, False), (True, True)):
         comm = Comm(single_rank_collectives=True)
         assert comm.comm_world is not None and comm.device_comm() and capi.dev.comm_info()[:2] == (1, 0)
@@ -167,6 +205,7 @@ def main():
     assert size == 2
     covariance_owner_computes(Comm())
     half = N_TOTAL // size
+    binmap_sync_types(Comm(), half * rank, half)
     # cached pointing, pointing on the fly, and the amplitude-domain noise prior (rank-local
     # filters and banded preconditioner; the dot products of the PCG are all-reduced)
     for full_pointing, prior in ((True, False), (False, False), (True, True)):
