@@ -7,7 +7,9 @@ src/toast/ops/mapmaker_solve.py:342-506):
 
     zmap = 0
     zmap += A^T N^-1 tod         build_noise_weighted      (41 B / det-sample)
-    [N > 1]  all-reduce(zmap)    RCCL sum over the detector shards
+    [N > 1]  all-reduce(zmap)    RCCL sum over the detector shards, enqueued on the kernels' stream by the library's
+                                 own communicator (toast_hip_comm_*) once its results have been checked against
+                                 torch.distributed on the job itself; else torch.distributed's all-reduce
     zmap  = C zmap               cov_apply_diag            (map sized)
     tod2 -= A zmap ; tod2 *= w   scan_map(subtract) + fused noise_weight  (48 B / det-sample)
 
