@@ -144,9 +144,12 @@ def launch_ranks(n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
-    for line in proc.stdout:            # rank 0's JSON line (and nothing else of ours) comes through here
-        sys.stdout.write(line)
-        sys.stdout.flush()
+    for line in proc.stdout:
+        # rank 0's JSON line goes to stdout; anything else the ranks print there (RCCL's version banner, launcher
+        # notices) is passed on to stderr, so that stdout carries exactly the one line the contract asks for
+        out = sys.stdout if line.lstrip().startswith("{") else sys.stderr
+        out.write(line)
+        out.flush()
     return proc.wait()
 
 
