@@ -157,6 +157,12 @@ def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus))
+    # stdout carries exactly ONE line, the JSON: while the benchmark runs, file descriptor 1 points at stderr, so that
+    # whatever a library prints there (RCCL's version banner at communicator set-up) cannot end up next to it
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -205,6 +211,15 @@ def main():
                                                          "allreduce", "roofline")}
     if op_level is not None:
         out["operator_level"] = op_level
+    sys.stdout.flush()
+    try:
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)      # the banner sits in the C library's buffer until somebody flushes it
+    except OSError:
+        pass
+    os.dup2(real_stdout, 1)
+    os.close(real_stdout)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1 or single:

@@ -106,7 +106,8 @@ def test_bench_collective_path_with_one_rank():
                           "mini", "--no-fft", "--no-cpu-baseline", "--shard-workload", "cfg2"], capture_output=True,
                          text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
-    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert len(out.stdout.strip().splitlines()) == 1, out.stdout[:600]     # nothing but the JSON line on stdout
+    d = json.loads(out.stdout.strip())
     a = d["allreduce"]
     assert d["n_gpus"] == 1 and a["backend"] == "nccl" and a["note"] is None, a
     assert a["implementation"].startswith("toast_hip_comm") and a["bytes"] > 0 and a["ms"] > 0
