@@ -961,7 +961,8 @@ int toast_hip_pcg_history_dev(void * d_state, double * history, int64_t capacity
  *                              src/toast/ops/mapmaker_utils/mapmaker_utils.py:885-925)
  *   PixelData.sync_alltoallv(local_func)  [ref: src/toast/pixels.py:942-967] and its users
  *   covariance_invert / _multiply / _apply(use_alltoallv=True)  [ref: src/toast/covariance.py:34-131, 134-221, 224-306]
- * librccl is opened at run time by the first call (a single-GPU process does not need it).
+ * librccl is opened at run time by the first call (a single-GPU process does not need it);
+ * TOAST_HIP_RCCL_LIB=<path> names the library to open instead of searching for one.
  * The 128-byte unique id is created on one rank and handed to the others by the host side's own
  * transport (MPI bcast in TOAST, torch.distributed here) before toast_hip_comm_init.
  * ---------------------------------------------------------------------------------- */

@@ -202,7 +202,7 @@ def main():
         dist.destroy_process_group()
         print(f"rank {rank} OK")
         return
-    assert size == 2
+    assert size in (2, 3)
     covariance_owner_computes(Comm())
     half = N_TOTAL // size
     binmap_sync_types(Comm(), half * rank, half)
@@ -222,6 +222,12 @@ def main():
         assert mine.n_local * size == ref.n_local and mine.n_global == ref.n_global
         want = ref.local[rank * mine.n_local:(rank + 1) * mine.n_local]
         assert np.max(np.abs(mine.local - want)) < 1e-7 * np.max(np.abs(ref.local))
+    if os.environ.get("TOAST_HIP_COMM") == "rccl":
+        # (tests/test_gpu_rccl_mock.py) the device-resident collectives above went through toast_hip_comm_*
+        from toast_amd import capi
+
+        n, r, version = capi.dev.comm_info()
+        assert (n, r) == (size, rank) and Comm().device_comm(), (n, r, version)
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank} OK")

@@ -29,11 +29,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29541")
-    torch.cuda.set_device(local)
-    dist.init_process_group("nccl", rank=rank, world_size=size, device_id=torch.device("cuda", local))
+    # "nccl": one process per GPU.  "gloo" (with TOAST_HIP_COMM=rccl and TOAST_HIP_RCCL_LIB = tests/librccl_mock.so):
+    # several ranks on ONE GPU, the library's communicator over the shared-memory stand-in -- same code in comm.cpp
+    backend = os.environ.get("TOAST_TEST_BACKEND", "nccl")
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=size, device_id=torch.device("cuda", local))
+    else:
+        assert os.environ.get("TOAST_HIP_COMM") == "rccl" and os.environ.get("TOAST_HIP_RCCL_LIB")
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=size)
+    check_dev = "cuda" if backend == "nccl" else "cpu"     # where the test's own cross-checks are reduced
     accel_assign_device(size, rank, 1.0, False)
     comm = Comm(single_rank_collectives=True)
-    assert comm.comm_world is not None and comm._dist.get_backend() == "nccl"
+    assert comm.comm_world is not None and comm._dist.get_backend() == backend
 
     # 37 submaps x 48 pixels x 3: 5328 doubles, not divisible by 5 / 7 / 8 ranks -> padded shards
     d = PixelDistribution(n_pix=64 * 48, n_submap=64, local_submaps=np.arange(3, 40), comm=comm)
@@ -61,7 +70,7 @@ def main():
         np.testing.assert_allclose(pd.raw, 4.0 * total, rtol=0, atol=1e-13 * np.max(np.abs(total)))
         results[entry] = pd.raw.copy()
         # every rank holds the same bits
-        t = torch.from_numpy(pd.raw.copy()).cuda()
+        t = torch.from_numpy(pd.raw.copy()).to(check_dev)
         lo, hi = t.clone(), t.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
@@ -135,7 +144,7 @@ def main():
     xs = torch.from_numpy(np.random.default_rng(900 + rank).standard_normal(n_amp)).cuda()
     ys = torch.from_numpy(np.random.default_rng(950 + rank).standard_normal(n_amp)).cuda()
     local_dot = float(torch.dot(xs, ys).item())
-    tot = torch.tensor([local_dot], dtype=torch.float64, device="cuda")
+    tot = torch.tensor([local_dot], dtype=torch.float64, device=check_dev)
     dist.all_reduce(tot)
     state = torch.zeros(capi.dev.pcg_state_bytes(5) // 8 + 1, dtype=torch.float64, device="cuda")
     capi.dev.pcg_init(state.data_ptr(), 4.0, 3.0, 1e-12, 3, 5)

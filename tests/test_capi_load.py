@@ -3,6 +3,8 @@ fails loudly (no CPU fallback) when no GPU is usable."""
 import ctypes
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -176,3 +178,20 @@ def test_comm_pixel_shards_partition_the_map():
     # without a communicator the collectives fail loudly
     assert lib.toast_hip_comm_allreduce_dev(None, C.c_int64(4), C.c_int(0), C.c_int(0), None) != 0
     assert b"toast_hip_comm_init" in lib.toast_hip_last_error()
+
+
+def test_unopenable_library_is_reported_not_replaced():
+    """TOAST_HIP_RCCL_LIB that cannot be opened: toast_hip_comm_available() says 0 (no silent fall back to another
+    librccl), and the error names the variable."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from toast_amd import capi\n"
+            "assert capi.dev.comm_available() == 0\n"
+            "try:\n"
+            "    capi.dev.comm_unique_id()\n"
+            "except RuntimeError as e:\n"
+            "    assert 'TOAST_HIP_RCCL_LIB' in str(e), e\n"
+            "    print('reported')\n" % ROOT)
+    env = dict(os.environ)
+    env["TOAST_HIP_RCCL_LIB"] = "/nonexistent/librccl.so"
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0 and "reported" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <sstream>
 #include <string>
@@ -49,6 +50,16 @@ void resolve(void * h, const char * name, F & fn) {
 Rccl & rccl() {
     static Rccl r;
     if (r.handle != nullptr) return r;
+    // TOAST_HIP_RCCL_LIB names the library outright (a site's own RCCL build; the tests' shared-memory stand-in that
+    // lets several ranks share one GPU, tests/rccl_mock.cpp): no search, and a failure to open it is an error
+    if (const char * forced = std::getenv("TOAST_HIP_RCCL_LIB"); forced != nullptr && forced[0] != '\0') {
+        r.handle = dlopen(forced, RTLD_NOW | RTLD_LOCAL);
+        if (r.handle == nullptr) {
+            const char * e = dlerror();
+            throw Error(TOAST_HIP_ERR_DEVICE,
+                        std::string("HipComm:  cannot open TOAST_HIP_RCCL_LIB=") + forced + " (" + (e ? e : "?") + ")");
+        }
+    }
     // the copy this process already carries first (RTLD_NOLOAD), then the loader's search path, then ROCm's
     const char * loaded[] = {"librccl.so", "librccl.so.1"};
     for (const char * n : loaded) {
