@@ -378,13 +378,16 @@ def run(args, workload, world, rank, dev, headline=True):
     comm_impl, comm_note = None, None
     if multi:
         comm_impl, ok = "torch.distributed", 0
-        if not share and os.environ.get("TOAST_BENCH_COMM", "") != "torch":
+        # (share mode = several test ranks on one GPU over gloo: RCCL would refuse them, so the communicator is tried
+        # there only when TOAST_HIP_RCCL_LIB points the library at the tests' shared-memory stand-in for librccl)
+        cdev = "cpu" if share else dev       # where the protocol's own small tensors live (gloo: host)
+        if (not share or os.environ.get("TOAST_HIP_RCCL_LIB")) and os.environ.get("TOAST_BENCH_COMM", "") != "torch":
             # Every step below that is collective is entered by ALL ranks or by none: first agree that every rank can
             # load RCCL, then rank 0's id (with a validity byte) goes round, then the collective initialisation.
             n_r, r_r, _ = D.comm_info()
             ready = n_r == world and r_r == rank
             if n_r == 0:
-                able = torch.tensor([1 if D.comm_available() else 0], dtype=torch.int32, device=dev)
+                able = torch.tensor([1 if D.comm_available() else 0], dtype=torch.int32, device=cdev)
                 dist.all_reduce(able, op=dist.ReduceOp.MIN)
                 uid = torch.zeros(129, dtype=torch.uint8)
                 if int(able.item()) == 1 and rank == 0:
@@ -393,7 +396,7 @@ def run(args, workload, world, rank, dev, headline=True):
                         uid[128] = 1
                     except RuntimeError as err:
                         comm_note = repr(err)[:300]
-                uid = uid.to(dev)
+                uid = uid.to(cdev)
                 dist.broadcast(uid, src=0)
                 uid = uid.cpu()
                 if int(uid[128]) == 1:
@@ -405,15 +408,16 @@ def run(args, workload, world, rank, dev, headline=True):
                 elif comm_note is None:
                     comm_note = "librccl could not be loaded on every rank"
             # ... and the communicator is used only if EVERY rank has one
-            every = torch.tensor([1 if ready else 0], dtype=torch.int32, device=dev)
+            every = torch.tensor([1 if ready else 0], dtype=torch.int32, device=cdev)
             dist.all_reduce(every, op=dist.ReduceOp.MIN)
             ready = int(every.item()) == 1
             try:
                 if not ready:
                     raise RuntimeError(comm_note or "no communicator on some rank")
                 chk = torch.arange(3 * 4096, dtype=torch.float64, device=dev) * (rank + 1.0)
-                ref_chk = chk.clone()
+                ref_chk = chk.to(cdev)
                 dist.all_reduce(ref_chk)
+                ref_chk = ref_chk.to(dev)
                 torch.cuda.synchronize()
                 a = chk.clone()
                 D.comm_allreduce(a.data_ptr(), a.numel(), np.float64, "sum", stream)
@@ -425,7 +429,7 @@ def run(args, workload, world, rank, dev, headline=True):
                     comm_note = "toast_hip_comm results differ from torch.distributed"
             except Exception as err:    # noqa: BLE001 -- the benchmark must still run
                 comm_note = repr(err)[:300]
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev if not share else "cpu")
+        flag = torch.tensor([ok], dtype=torch.int32, device=cdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
             comm_impl = "toast_hip_comm (RCCL on the kernels' stream)"
