@@ -943,6 +943,20 @@ int toast_hip_pcg_stage_dev(void * d_state, int stage, int allreduce, void * str
 /* result += alpha proposal;  residual -= alpha lhs_out  (one launch) */
 int toast_hip_pcg_step_dev(const void * d_state, int64_t n, const double * d_proposal, double * d_result,
                            const double * d_lhs_out, double * d_residual, void * stream);
+/* The two vector updates whose OUTPUT a dot product of the recurrence reads, fused with that dot product (same
+ * accumulate / stage arguments as toast_hip_pcg_dot_dev; same bits as the separate calls -- the element -> thread
+ * assignment and the summation order are shared):
+ *   step_dot:          result += alpha proposal;  residual -= alpha lhs_out;  state.tmp (+)= residual . residual
+ *                      [ref: src/toast/ops/mapmaker_solve.py:679-690]
+ *   precond_diag_dot:  out = residual * var where the residual's flag is clear, else 0 (template_offset_apply_diag_precond
+ *                      [ref: src/toast/_libtoast/template_offset.cpp:334-396]);  state.tmp (+)= out . residual
+ *                      [ref: src/toast/ops/mapmaker_solve.py:726-737] */
+int toast_hip_pcg_step_dot_dev(void * d_state, int64_t n, const double * d_proposal, double * d_result,
+                               const double * d_lhs_out, double * d_residual, const uint8_t * d_flags, int accumulate,
+                               int stage, void * stream);
+int toast_hip_pcg_precond_diag_dot_dev(void * d_state, int64_t n, const double * d_var, const double * d_residual,
+                                       const uint8_t * d_flags_residual, double * d_out, const uint8_t * d_flags_out,
+                                       int accumulate, int stage, void * stream);
 /* y = S[a_sel] x + S[b_sel] y with S = the state's scalars (TOAST_HIP_PCG_ONE ... _LIVE) */
 int toast_hip_pcg_axpby_dev(const void * d_state, int64_t n, int a_sel, const double * d_x, int b_sel, double * d_y,
                             void * stream);

@@ -874,6 +874,124 @@ def test_pcg_scalars_on_the_device_follow_the_host_loop(monkeypatch, case):
     assert np.max(np.abs(amps["device"] - amps["host"])) < (1e-6 if n_dev == n_host else 1e-4) * scale
 
 
+@pytest.mark.parametrize("prior", [False, True])
+def test_pcg_fused_updates_give_the_bits_of_the_separate_launches(monkeypatch, prior):
+    """The device-scalar loop with the result / residual update inside the r . r launch and the diagonal preconditioner
+    inside the z . r launch (toast_hip_pcg_step_dot_dev, _precond_diag_dot_dev) against the same loop with separate
+    launches (TOAST_HIP_PCG_FUSE=0): the same history and amplitudes to the run-to-run rounding of the left-hand side's
+    atomic scatter (the fused kernels themselves give the bits of the separate launches:
+    test_pcg_fused_kernels_against_numpy).  With the noise prior the preconditioner is banded: only the step is
+    fused."""
+    from toast_amd import capi
+
+    hist, amps, calls = {}, {}, {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("TOAST_HIP_PCG_FUSE", fuse)
+        seen = {}
+        for name in ("pcg_step_dot", "pcg_precond_diag_dot", "pcg_step", "pcg_dot"):
+            real = getattr(capi.dev, name)
+
+            def counted(*a, _real=real, _name=name, **k):
+                seen[_name] = seen.get(_name, 0) + 1
+                return _real(*a, **k)
+
+            monkeypatch.setattr(capi.dev, name, counted)
+        data, pix, sw, truth, sky = make_solver_setup(noise_rms=0.1)
+        binner = ops.BinMap(pixel_dist="dist", pixel_pointing=pix, stokes_weights=sw, full_pointing=True)
+        tmpl = Offset(step_time=20.0, noise_model=defaults.noise_model, name="baselines", good_fraction=0.2,
+                      use_noise_prior=prior, precond_width=10)
+        mapper = ops.MapMaker(name="mm", keep_solver_products=True, det_data=defaults.det_data, binning=binner,
+                              template_matrix=ops.TemplateMatrix(templates=[tmpl]), solve_rcond_threshold=1e-3,
+                              map_rcond_threshold=1e-3, iter_max=12, convergence=1e-30)
+        mapper.apply(data)
+        hist[fuse] = np.array(mapper.history)
+        amps[fuse] = data["mm_solve_amplitudes"]["baselines"].local.copy()
+        calls[fuse] = seen
+        monkeypatch.undo()
+    n = len(hist["1"])
+    assert calls["1"].get("pcg_step_dot", 0) >= n and calls["1"].get("pcg_step", 0) == 0, calls
+    assert (calls["1"].get("pcg_precond_diag_dot", 0) >= n) == (not prior), calls
+    assert calls["0"].get("pcg_step_dot", 0) == 0 and calls["0"].get("pcg_step", 0) >= n, calls
+    assert len(hist["0"]) == n
+    np.testing.assert_allclose(hist["1"], hist["0"], rtol=1e-7)
+    assert np.max(np.abs(amps["1"] - amps["0"])) < 1e-9 * np.max(np.abs(amps["0"]))
+
+
+def test_pcg_fused_kernels_against_numpy():
+    """toast_hip_pcg_step_dot_dev / _precond_diag_dot_dev on vectors of awkward lengths (one element, a partial last
+    pass, more than kDotBlocks x 2048 elements): the updated vectors are exact, the sums agree with NumPy to rounding,
+    flagged amplitudes are left out of the sums, alpha = 0 (solver finished) leaves result and residual untouched."""
+    import torch
+
+    from toast_amd import capi
+
+    D = capi.dev
+    rng = np.random.default_rng(77)
+    for n in (1, 2047, 230400, 1024 * 2048 + 12345):
+        p, res, ap, r, var = (rng.standard_normal(n) for _ in range(5))
+        var = np.abs(var) + 0.1            # variances: z . r is a sum of positive terms
+        flags = (rng.random(n) < 0.05).astype(np.uint8)
+        dp, dres, dap, dr, dvar = (torch.from_numpy(x.copy()).cuda() for x in (p, res, ap, r, var))
+        dfl = torch.from_numpy(flags).cuda()
+        dz = torch.full((n,), 7.0, dtype=torch.float64, device="cuda")
+        state = torch.zeros(D.pcg_state_bytes(4) // 8 + 1, dtype=torch.float64, device="cuda")
+        delta, p_ap = 3.0, float(np.dot(p, ap))
+        D.pcg_init(state.data_ptr(), 10.0, delta, 1e-30, 3, 4)      # (n_iter_min = 3: no stall test in iteration 0)
+        D.pcg_dot(state.data_ptr(), n, dp.data_ptr(), dap.data_ptr(), 0, 0, accumulate=False, stage=1)
+        # alpha as the device computed it (delta / (p . Ap) with ITS summation order): 0 + alpha * 1
+        y0 = torch.zeros(1, dtype=torch.float64, device="cuda")
+        one1 = torch.ones(1, dtype=torch.float64, device="cuda")
+        D.pcg_axpby(state.data_ptr(), 1, D.PCG_ALPHA, one1.data_ptr(), D.PCG_ONE, y0.data_ptr())
+        D.pcg_step_dot(state.data_ptr(), n, dp.data_ptr(), dres.data_ptr(), dap.data_ptr(), dr.data_ptr(),
+                       dfl.data_ptr(), accumulate=False, stage=2)
+        torch.cuda.synchronize()
+        hist, st = D.pcg_history(state.data_ptr(), 4)
+        alpha = float(y0.item())
+        assert abs(alpha - delta / p_ap) < 1e-10 * abs(alpha)
+        assert np.array_equal(dres.cpu().numpy(), res + alpha * p)
+        r_new = r + (-alpha) * ap
+        assert np.array_equal(dr.cpu().numpy(), r_new)
+        want = float(np.sum(r_new[flags == 0] ** 2))
+        assert abs(st.sqsum - want) <= 1e-12 * want + 1e-300, (n, st.sqsum, want)
+        D.pcg_precond_diag_dot(state.data_ptr(), n, dvar.data_ptr(), dr.data_ptr(), dfl.data_ptr(), dz.data_ptr(),
+                               dfl.data_ptr(), accumulate=False, stage=3)
+        torch.cuda.synchronize()
+        z = np.where(flags == 0, r_new * var, 0.0)
+        assert np.array_equal(dz.cpu().numpy(), z)
+        # the separate launches on copies of the same inputs: the same bits in every vector and every scalar
+        sres, sr = torch.from_numpy(res.copy()).cuda(), torch.from_numpy(r.copy()).cuda()
+        sz = torch.full((n,), 7.0, dtype=torch.float64, device="cuda")
+        state2 = torch.zeros_like(state)
+        D.pcg_init(state2.data_ptr(), 10.0, delta, 1e-30, 3, 4)
+        D.pcg_dot(state2.data_ptr(), n, dp.data_ptr(), dap.data_ptr(), 0, 0, accumulate=False, stage=1)
+        D.pcg_step(state2.data_ptr(), n, dp.data_ptr(), sres.data_ptr(), dap.data_ptr(), sr.data_ptr())
+        D.pcg_dot(state2.data_ptr(), n, sr.data_ptr(), sr.data_ptr(), dfl.data_ptr(), dfl.data_ptr(), accumulate=False,
+                  stage=2)
+        D.template_offset_apply_diag_precond(dvar.data_ptr(), sr.data_ptr(), dfl.data_ptr(), sz.data_ptr(), n)
+        D.pcg_dot(state2.data_ptr(), n, sz.data_ptr(), sr.data_ptr(), dfl.data_ptr(), dfl.data_ptr(), accumulate=False,
+                  stage=3)
+        torch.cuda.synchronize()
+        assert torch.equal(sres, dres) and torch.equal(sr, dr) and torch.equal(sz, dz)
+        assert torch.equal(state2, state), n       # alpha, sqsum, delta, beta, history: the whole state block
+        # stage 3: delta <- z . r; read it back through beta = delta_new / delta_old on the next axpby
+        y = torch.zeros(n, dtype=torch.float64, device="cuda")
+        one = torch.ones(n, dtype=torch.float64, device="cuda")
+        D.pcg_axpby(state.data_ptr(), n, D.PCG_BETA, one.data_ptr(), D.PCG_ONE, y.data_ptr())
+        torch.cuda.synchronize()
+        beta = float(y[0].item())
+        want_beta = float(np.dot(z[flags == 0], r_new[flags == 0])) / delta
+        assert abs(beta - want_beta) <= 1e-12 * abs(want_beta) + 1e-300
+    # a finished solver: alpha = 0, nothing is written
+    state = torch.zeros(D.pcg_state_bytes(0) // 8 + 2, dtype=torch.float64, device="cuda")
+    D.pcg_init(state.data_ptr(), 10.0, 3.0, 1e-30, 0, 0)            # n_iter_max = 0: done from the start
+    before = dres.clone(), dr.clone()
+    D.pcg_dot(state.data_ptr(), n, dp.data_ptr(), dap.data_ptr(), 0, 0, accumulate=False, stage=1)
+    D.pcg_step_dot(state.data_ptr(), n, dp.data_ptr(), dres.data_ptr(), dap.data_ptr(), dr.data_ptr(), dfl.data_ptr(),
+                   accumulate=False, stage=2)
+    torch.cuda.synchronize()
+    assert torch.equal(dres, before[0]) and torch.equal(dr, before[1])
+
+
 def test_lazy_host_coherence_and_eviction():
     """Pipelines leave detector data resident and device-current; the host copy is refreshed on
     access (DetectorData.data) or by eviction, and equals the eagerly copied result."""

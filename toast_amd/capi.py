@@ -1033,6 +1033,19 @@ class _Dev:
         _check(lib().toast_hip_pcg_step_dev(_p(d_state), _i64(n), _p(d_proposal), _p(d_result), _p(d_lhs_out),
                                             _p(d_residual), _p(stream)))
 
+    def pcg_step_dot(self, d_state, n, d_proposal, d_result, d_lhs_out, d_residual, d_flags=0, accumulate=False,
+                     stage=0, stream=0):
+        _check(lib().toast_hip_pcg_step_dot_dev(_p(d_state), _i64(n), _p(d_proposal), _p(d_result), _p(d_lhs_out),
+                                                _p(d_residual), _p(d_flags), C.c_int(1 if accumulate else 0),
+                                                C.c_int(int(stage)), _p(stream)))
+
+    def pcg_precond_diag_dot(self, d_state, n, d_var, d_residual, d_flags_residual, d_out, d_flags_out=0,
+                             accumulate=False, stage=0, stream=0):
+        _check(lib().toast_hip_pcg_precond_diag_dot_dev(_p(d_state), _i64(n), _p(d_var), _p(d_residual),
+                                                        _p(d_flags_residual), _p(d_out), _p(d_flags_out),
+                                                        C.c_int(1 if accumulate else 0), C.c_int(int(stage)),
+                                                        _p(stream)))
+
     def pcg_stage(self, d_state, stage, allreduce=False, stream=0):
         _check(lib().toast_hip_pcg_stage_dev(_p(d_state), C.c_int(int(stage)), C.c_int(1 if allreduce else 0),
                                              _p(stream)))

@@ -28,7 +28,18 @@ struct PcgState {
     double history[1];           // n_iter_max entries follow
 };
 
-constexpr int kDotBlocks = 256;
+constexpr int kDotBlocks = 1024;    // partial sums per dot product (the scratch block holds that many)
+constexpr int kDotPer = 8;          // elements per thread and pass
+
+// what a dot-product launch does to the vectors on its way (the sum is always over the values it leaves behind):
+enum { kDotPlain = 0, kDotStep = 1, kDotPrecond = 2 };
+
+struct DotFused {
+    const double * p;        // kDotStep: proposal
+    double * result;         //           result += alpha p
+    const double * ap;       //           x (= residual) += -alpha ap, then x . x
+    const double * var;      // kDotPrecond: x (= z) = y (= residual) * var where y is unflagged, else 0, then x . y
+};
 
 __global__ void k_pcg_init(PcgState * __restrict__ s, double sqsum_init, double delta, double convergence,
                            int64_t n_iter_min, int64_t n_iter_max) {
@@ -113,29 +124,75 @@ __global__ void k_pcg_stage(PcgState * __restrict__ s, int stage) { pcg_stage(s,
 // Dot product, reduction and stage in ONE launch (a launch costs ~5 us of device time, an iteration at configs[1] size
 // 400): every block stores its partial sum and takes a ticket; the block that draws the last ticket adds the partials
 // in block order (the result does not depend on which block that is) and runs the stage.
-__global__ __launch_bounds__(kThreads) void k_pcg_dot_stage(int64_t n, const double * __restrict__ x,
+// MODE kDotStep / kDotPrecond: the vector update whose OUTPUT the dot product reads runs in the same pass (result and
+// residual update before r . r; diagonal preconditioner before z . r) -- two launches and one sweep over the vectors
+// less per iteration each.  Element -> thread assignment and summation order are the same in all modes, so the fused
+// forms give the bits of update kernel + plain dot product.
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void k_pcg_dot_stage(int64_t n, double * __restrict__ x,
                                                             const double * __restrict__ y,
                                                             const uint8_t * __restrict__ fx,
-                                                            const uint8_t * __restrict__ fy,
+                                                            const uint8_t * __restrict__ fy, DotFused f,
                                                             double * __restrict__ partials, PcgState * __restrict__ s,
                                                             int accumulate, int stage) {
     __shared__ double s_part[kThreads / 64];
     __shared__ bool s_last;
     // eight elements per thread and pass, all loads of a pass issued together (a plain grid-stride loop waits for one
     // element after the other: 34 us for 230 k amplitudes at 32 per thread)
-    constexpr int kPer = 8;
+    constexpr int kPer = kDotPer;
+    const double a = (MODE == kDotStep) ? s->alpha : 0.0, na = (MODE == kDotStep) ? s->neg_alpha : 0.0;
     double acc = 0.0;
     for (int64_t base = (int64_t)blockIdx.x * kThreads * kPer; base < n; base += (int64_t)gridDim.x * kThreads * kPer) {
         double xv[kPer], yv[kPer];
         bool good[kPer];
+        if constexpr (MODE == kDotStep) {
+            double pv[kPer], rv[kPer], av[kPer];
 #pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-            const int64_t i = base + threadIdx.x + (int64_t)k * kThreads;
-            const bool in = i < n;
-            const int64_t j = in ? i : 0;
-            xv[k] = x[j];
-            yv[k] = y[j];
-            good[k] = in && (fx == nullptr || fx[j] == 0) && (fy == nullptr || fy[j] == 0);
+            for (int k = 0; k < kPer; ++k) {
+                const int64_t i = base + threadIdx.x + (int64_t)k * kThreads;
+                const int64_t j = (i < n) ? i : 0;
+                xv[k] = x[j];
+                av[k] = f.ap[j];
+                pv[k] = f.p[j];
+                rv[k] = f.result[j];
+                good[k] = (i < n) && (fx == nullptr || fx[j] == 0);
+            }
+            if (a != 0.0) {      // (alpha = 0: the solver has finished, both vectors stay bit for bit)
+#pragma unroll
+                for (int k = 0; k < kPer; ++k) {
+                    const int64_t i = base + threadIdx.x + (int64_t)k * kThreads;
+                    xv[k] = xv[k] + na * av[k];
+                    if (i < n) {
+                        f.result[i] = rv[k] + a * pv[k];
+                        x[i] = xv[k];
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < kPer; ++k) yv[k] = xv[k];
+        } else if constexpr (MODE == kDotPrecond) {
+            double vv[kPer];
+#pragma unroll
+            for (int k = 0; k < kPer; ++k) {
+                const int64_t i = base + threadIdx.x + (int64_t)k * kThreads;
+                const int64_t j = (i < n) ? i : 0;
+                yv[k] = y[j];
+                vv[k] = f.var[j];
+                const bool unflagged = (fy[j] == 0);
+                good[k] = (i < n) && unflagged && (fx == nullptr || fx[j] == 0);
+                xv[k] = unflagged ? yv[k] * vv[k] : 0.0;
+                if (i < n) x[i] = xv[k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kPer; ++k) {
+                const int64_t i = base + threadIdx.x + (int64_t)k * kThreads;
+                const bool in = i < n;
+                const int64_t j = in ? i : 0;
+                xv[k] = x[j];
+                yv[k] = y[j];
+                good[k] = in && (fx == nullptr || fx[j] == 0) && (fy == nullptr || fy[j] == 0);
+            }
         }
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
@@ -246,21 +303,62 @@ int toast_hip_pcg_init_dev(void * d_state, double sqsum_init, double delta, doub
     });
 }
 
+static void dot_launch(int mode, void * d_state, int64_t n, double * d_x, const double * d_y, const uint8_t * d_fx,
+                       const uint8_t * d_fy, const DotFused & f, int accumulate, int stage, void * stream) {
+    if (stage < 0 || stage > 3) fail_arg("pcg stage must be 0 (none), 1, 2 or 3");
+    double * d_part = (double *)Manager::get().scratch(Manager::kScratchDot, sizeof(double) * 1032) + 8;
+    hipStream_t st = as_stream(stream);
+    // few blocks: every block ends in one atomic on the same ticket, and the last one adds all partial sums
+    // (one element per thread, 900 blocks: 26 us per dot product at configs[1] size).  Eight elements per thread and
+    // pass; long vectors get up to kDotBlocks blocks (3.7 M amplitudes with 256 blocks = 7 passes of one 4-wave block
+    // per CU: 67 us for 59 MB)
+    int64_t nb = (n + (int64_t)kThreads * kDotPer - 1) / ((int64_t)kThreads * kDotPer);
+    if (nb < 1) nb = 1;
+    if (nb > kDotBlocks) nb = kDotBlocks;
+    const dim3 grid((unsigned)nb);
+    PcgState * s = static_cast<PcgState *>(d_state);
+    if (mode == kDotStep) {
+        hipLaunchKernelGGL(k_pcg_dot_stage<kDotStep>, grid, dim3(kThreads), 0, st, n, d_x, d_y, d_fx, d_fy, f, d_part, s,
+                           accumulate, stage);
+    } else if (mode == kDotPrecond) {
+        hipLaunchKernelGGL(k_pcg_dot_stage<kDotPrecond>, grid, dim3(kThreads), 0, st, n, d_x, d_y, d_fx, d_fy, f, d_part,
+                           s, accumulate, stage);
+    } else {
+        hipLaunchKernelGGL(k_pcg_dot_stage<kDotPlain>, grid, dim3(kThreads), 0, st, n, d_x, d_y, d_fx, d_fy, f, d_part, s,
+                           accumulate, stage);
+    }
+    check_launch();
+}
+
 int toast_hip_pcg_dot_dev(void * d_state, int64_t n, const double * d_x, const double * d_y, const uint8_t * d_flags_x,
                           const uint8_t * d_flags_y, int accumulate, int stage, void * stream) {
     return guarded([&] {
-        if (stage < 0 || stage > 3) fail_arg("pcg stage must be 0 (none), 1, 2 or 3");
-        double * d_part = (double *)Manager::get().scratch(Manager::kScratchDot, sizeof(double) * 1032) + 8;
-        hipStream_t st = as_stream(stream);
-        // few blocks: every block ends in one atomic on the same ticket, and the last one adds all partial sums
-        // (900 blocks: 26 us per dot product at configs[1] size; 8 elements per thread and at most one block per CU)
-        int64_t nb = (n + (int64_t)kThreads * 8 - 1) / ((int64_t)kThreads * 8);
-        if (nb < 1) nb = 1;
-        if (nb > kDotBlocks) nb = kDotBlocks;
-        const dim3 grid((unsigned)nb);
-        hipLaunchKernelGGL(k_pcg_dot_stage, grid, dim3(kThreads), 0, st, n, d_x, d_y, d_flags_x, d_flags_y, d_part,
-                           static_cast<PcgState *>(d_state), accumulate, stage);
-        check_launch();
+        dot_launch(kDotPlain, d_state, n, const_cast<double *>(d_x), d_y, d_flags_x, d_flags_y, DotFused{}, accumulate,
+                   stage, stream);
+    });
+}
+
+int toast_hip_pcg_step_dot_dev(void * d_state, int64_t n, const double * d_proposal, double * d_result,
+                               const double * d_lhs_out, double * d_residual, const uint8_t * d_flags, int accumulate,
+                               int stage, void * stream) {
+    return guarded([&] {
+        DotFused f{};
+        f.p = d_proposal;
+        f.result = d_result;
+        f.ap = d_lhs_out;
+        dot_launch(kDotStep, d_state, n, d_residual, d_residual, d_flags, d_flags, f, accumulate, stage, stream);
+    });
+}
+
+int toast_hip_pcg_precond_diag_dot_dev(void * d_state, int64_t n, const double * d_var, const double * d_residual,
+                                       const uint8_t * d_flags_residual, double * d_out, const uint8_t * d_flags_out,
+                                       int accumulate, int stage, void * stream) {
+    return guarded([&] {
+        if (d_flags_residual == nullptr) fail_arg("the diagonal preconditioner needs the amplitude flags");
+        DotFused f{};
+        f.var = d_var;
+        dot_launch(kDotPrecond, d_state, n, d_out, d_residual, d_flags_out, d_flags_residual, f, accumulate, stage,
+                   stream);
     });
 }
 

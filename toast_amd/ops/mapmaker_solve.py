@@ -664,18 +664,59 @@ def _pcg_device_scalars(data, detectors, lhs_op, result, residual, precond, prop
             for k in names:
                 D.pcg_axpby(d_state, y[k].n_local, a_sel, x[k]._dptr(), b_sel, y[k]._dptr())
 
+        # The two updates whose output a dot product reads run inside that dot product's launch (same bits as the
+        # separate launches; TOAST_HIP_PCG_FUSE=0 keeps them apart): result / residual update + r . r, and -- for
+        # templates whose preconditioner is a diagonal -- z = M^-1 r + z . r.
+        import os
+
+        fuse = os.environ.get("TOAST_HIP_PCG_FUSE", "1") != "0"
+        templates = {t.name: t for t in lhs_op.template_matrix.templates if t.enabled}
+
+        def step_and_norm():
+            if not fuse:
+                for k in names:       # result += alpha * proposal;  residual -= alpha * lhs_out
+                    D.pcg_step(d_state, result[k].n_local, proposal[k]._dptr(), result[k]._dptr(),
+                               lhs_out[k]._dptr(), residual[k]._dptr())
+                dot(residual, residual, 2)
+                return
+            for i, k in enumerate(names):
+                inline = 2 if (i == len(names) - 1 and not reduce_dots) else 0
+                D.pcg_step_dot(d_state, result[k].n_local, proposal[k]._dptr(), result[k]._dptr(), lhs_out[k]._dptr(),
+                               residual[k]._dptr(), accel_device_ptr(residual[k].local_flags), accumulate=(i > 0),
+                               stage=inline)
+            if reduce_dots:
+                D.pcg_stage(d_state, 2, allreduce=True)
+
+        def precondition_and_project():
+            diag = {k: (templates[k].precond_diag_device() if (fuse and k in templates and
+                                                                hasattr(templates[k], "precond_diag_device")) else None)
+                    for k in names}
+            if not any(v is not None for v in diag.values()):
+                lhs_op.template_matrix.apply_precond(residual, precond)
+                dot(precond, residual, 3)
+                return
+            for i, k in enumerate(names):
+                inline = 3 if (i == len(names) - 1 and not reduce_dots) else 0
+                r, z = residual[k], precond[k]
+                if diag[k] is not None:
+                    D.pcg_precond_diag_dot(d_state, r.n_local, diag[k], r._dptr(), accel_device_ptr(r.local_flags),
+                                           z._dptr(), accel_device_ptr(z.local_flags), accumulate=(i > 0), stage=inline)
+                else:
+                    if k in templates:
+                        templates[k].apply_precond(r, z)
+                    D.pcg_dot(d_state, z.n_local, z._dptr(), r._dptr(), accel_device_ptr(z.local_flags),
+                              accel_device_ptr(r.local_flags), accumulate=(i > 0), stage=inline)
+            if reduce_dots:
+                D.pcg_stage(d_state, 3, allreduce=True)
+
         seen = 0       # relative residuals reported so far (the log lags one iteration behind the device)
         for it in range(n_iter_max + 1):
             if iteration_seconds is not None:
                 iteration_seconds.append(_time.perf_counter())
             lhs_op.apply(data, detectors=detectors)
             dot(proposal, lhs_out, 1)
-            for k in names:       # result += alpha * proposal;  residual -= alpha * lhs_out
-                D.pcg_step(d_state, result[k].n_local, proposal[k]._dptr(), result[k]._dptr(), lhs_out[k]._dptr(),
-                           residual[k]._dptr())
-            dot(residual, residual, 2)
-            lhs_op.template_matrix.apply_precond(residual, precond)
-            dot(precond, residual, 3)
+            step_and_norm()
+            precondition_and_project()
             axpby(proposal, D.PCG_LIVE, precond, D.PCG_BETA)         # proposal = precond + beta * proposal
             st = D.pcg_status(d_state, lag=1)                        # the status after the PREVIOUS iteration
             if log is not None and st.n_history > seen:

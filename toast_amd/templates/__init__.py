@@ -801,6 +801,20 @@ class Offset(Template):
         native().template_offset_apply_diag_precond(self._offsetvar, amplitudes_in.local, amplitudes_in.local_flags,
                                                     amplitudes_out.local, False)
 
+    def precond_diag_device(self):
+        """Device pointer of the diagonal preconditioner (the offset variances), or None when this template's
+        preconditioner is not a diagonal (noise prior: banded).  Lets the solver fuse ``apply_precond`` with the dot
+        product that reads its output (toast_hip_pcg_precond_diag_dot_dev)."""
+        if self.use_noise_prior or not self._check_enabled() or self._n_local == 0:
+            return None
+        if not getattr(self, "_offsetvar_on_dev", False):
+            accel_data_create(self._offsetvar, f"{self.name}_offsetvar", owner=self)
+            accel_data_update_device(self._offsetvar, f"{self.name}_offsetvar")
+            self._offsetvar_on_dev = True
+        from ..accel import accel_device_ptr
+
+        return accel_device_ptr(self._offsetvar)
+
     def clear(self):
         if getattr(self, "_prior", None) is not None:
             self._prior.clear()

@@ -1,9 +1,11 @@
 #!/bin/bash
 # Kernel trace of the configs[1]-size MapMaker (30 PCG iterations) with the PCG scalars on the device: how much of an
 # iteration is kernel time (profiles/r03_c).  Run on the GPU box.
-out=$GRAFT_REPO_ROOT/gpurun_out/r03c
+# usage: gpu_pcg_trace.sh [out-dir-name]   (TOAST_HIP_PCG_FUSE / TOAST_HIP_PCG_SCALARS from the environment)
+out=$GRAFT_REPO_ROOT/gpurun_out/${1:-r03c}
 mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
+rm -rf /tmp/pcgprof
 rocprofv3 --kernel-trace --stats -d /tmp/pcgprof -o pcg -- python3 $GRAFT_REPO_ROOT/workflows/mapmaker_pcg.py --ndet 64 --minutes 60 --rate 100 --nside 512 --iter 30 --no-filter > $out/pcg_trace_stdout.txt 2>/tmp/pcgprof.err
 python3 - <<'PY' > $out/pcg_trace.txt
 import sqlite3, glob, re
