@@ -150,7 +150,8 @@ def single_rank_device_comm():
         # the fused left-hand side replays the C call itself afterwards)
         D, seen = capi.dev, {}
         originals = {name: getattr(type(D), name) for name in ("comm_map_reduce_apply", "comm_cov_invert",
-                                                               "comm_allreduce", "pcg_stage", "pcg_dot")}
+                                                               "comm_allreduce", "pcg_stage", "pcg_dot",
+                                                               "pcg_step_dot", "pcg_precond_diag_dot")}
 
         def counting(name):
             def wrapper(self, *args, **kwargs):
@@ -170,7 +171,8 @@ def single_rank_device_comm():
         # PCG with its scalars on the device (with one rank the Offset amplitudes are "full" copies, whose dot products
         # the reference does not reduce either, amplitudes.py:545-554: the stage's sum over the ranks needs two ranks)
         assert seen.get("comm_map_reduce_apply", 0) >= 3 and seen.get("comm_cov_invert", 0) >= 2, seen
-        assert seen.get("comm_allreduce", 0) >= 2 and seen.get("pcg_dot", 0) >= 3 * len(mapper.history), seen
+        dots = seen.get("pcg_dot", 0) + seen.get("pcg_step_dot", 0) + seen.get("pcg_precond_diag_dot", 0)
+        assert seen.get("comm_allreduce", 0) >= 2 and dots >= 3 * len(mapper.history), seen
         serial, smapper = build(Comm(use_dist=False), 0, N_TOTAL, full_pointing, prior)
         assert list(data["dist"].local_submaps) == list(serial["dist"].local_submaps) and data["dist"].replicated
         assert np.array_equal(data["mm_hits"].data, serial["mm_hits"].data)

@@ -48,8 +48,9 @@ void resolve(void * h, const char * name, F & fn) {
 }
 
 Rccl & rccl() {
-    static Rccl r;
-    if (r.handle != nullptr) return r;
+    static Rccl ready;
+    if (ready.handle != nullptr) return ready;
+    Rccl r;      // published only when every entry point has been found (a later call must not see half a table)
     // TOAST_HIP_RCCL_LIB names the library outright (a site's own RCCL build; the tests' shared-memory stand-in that
     // lets several ranks share one GPU, tests/rccl_mock.cpp): no search, and a failure to open it is an error
     if (const char * forced = std::getenv("TOAST_HIP_RCCL_LIB"); forced != nullptr && forced[0] != '\0') {
@@ -82,7 +83,8 @@ Rccl & rccl() {
     resolve(r.handle, "ncclBroadcast", r.broadcast);
     resolve(r.handle, "ncclGetErrorString", r.error_string);
     resolve(r.handle, "ncclGetVersion", r.get_version);
-    return r;
+    ready = r;
+    return ready;
 }
 
 void check(ncclResult_t rc, const char * what) {
