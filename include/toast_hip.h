@@ -961,7 +961,9 @@ int toast_hip_pcg_precond_diag_dot_dev(void * d_state, int64_t n, const double *
 int toast_hip_pcg_axpby_dev(const void * d_state, int64_t n, int a_sel, const double * d_x, int b_sel, double * d_y,
                             void * stream);
 /* Enqueue an asynchronous copy of the status and return the one enqueued `lag` calls ago (0 = this one: waits for the
- * stream; 1 = the host runs one iteration ahead of the device); zeros while fewer than `lag` calls have been made. */
+ * stream; 1 = the host runs one iteration ahead of the device); zeros while fewer than `lag` calls have been made.
+ * The lagged copies go through one ring of page-locked slots per process, owned by the state initialised last; a call
+ * for any other state block waits for the stream and returns that block's current status. */
 int toast_hip_pcg_status_dev(void * d_state, int lag, toast_hip_pcg_status * out, void * stream);
 /* Waits for the stream; copies min(n_history, capacity) relative residuals and the final status to the host. */
 int toast_hip_pcg_history_dev(void * d_state, double * history, int64_t capacity, toast_hip_pcg_status * final_status,

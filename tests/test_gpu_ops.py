@@ -992,6 +992,30 @@ def test_pcg_fused_kernels_against_numpy():
     assert torch.equal(dres, before[0]) and torch.equal(dr, before[1])
 
 
+def test_pcg_status_of_a_second_state_block_is_read_synchronously():
+    """The lagged status ring belongs to the state initialised last; another state block polled in between gets its own
+    current status (not a slot of the other solver)."""
+    import torch
+
+    from toast_amd import capi
+
+    D = capi.dev
+    x = torch.ones(1000, dtype=torch.float64, device="cuda")
+    a = torch.zeros(D.pcg_state_bytes(5) // 8 + 1, dtype=torch.float64, device="cuda")
+    b = torch.zeros_like(a)
+    D.pcg_init(a.data_ptr(), 100.0, 1.0, 1e-30, 3, 5)
+    D.pcg_init(b.data_ptr(), 200.0, 1.0, 1e-30, 3, 5)          # b owns the ring
+    for state, scale in ((a, 1.0), (b, 2.0)):
+        y = x * scale
+        D.pcg_dot(state.data_ptr(), 1000, y.data_ptr(), y.data_ptr(), 0, 0, accumulate=False, stage=2)
+    sa = D.pcg_status(a.data_ptr(), lag=1)                      # not the owner: current, whatever the lag
+    assert sa.n_history == 1 and sa.sqsum == 1000.0 and sa.relative == 10.0
+    sb0 = D.pcg_status(b.data_ptr(), lag=1)                     # the owner's first lagged read: nothing yet
+    assert sb0.n_history == 0
+    sb1 = D.pcg_status(b.data_ptr(), lag=1)
+    assert sb1.n_history == 1 and sb1.sqsum == 4000.0 and sb1.relative == 20.0
+
+
 def test_lazy_host_coherence_and_eviction():
     """Pipelines leave detector data resident and device-current; the host copy is refreshed on
     access (DetectorData.data) or by eviction, and equals the eagerly copied result."""

@@ -268,6 +268,7 @@ struct StatusRing {
     hipEvent_t ev[kSlots];
     bool pending[kSlots] = {false, false, false, false};
     int64_t next = 0;
+    const void * owner = nullptr;            // the state block whose solver runs ahead through this ring
 };
 
 StatusRing & ring() {
@@ -300,6 +301,7 @@ int toast_hip_pcg_init_dev(void * d_state, double sqsum_init, double delta, doub
         StatusRing & r = ring();
         for (int i = 0; i < StatusRing::kSlots; ++i) r.pending[i] = false;
         r.next = 0;
+        r.owner = d_state;      // (the solver initialised last; any other state block reads its status synchronously)
     });
 }
 
@@ -401,6 +403,11 @@ int toast_hip_pcg_status_dev(void * d_state, int lag, toast_hip_pcg_status * out
         StatusRing & r = ring();
         hipStream_t st = as_stream(stream);
         PcgState * s = static_cast<PcgState *>(d_state);
+        if (r.owner != d_state) {
+            // one ring per process: a second solver interleaved with the one that owns it gets the current status
+            copy_to_host(out, &s->stat, sizeof(toast_hip_pcg_status), st);
+            return;
+        }
         const int slot = (int)(r.next % StatusRing::kSlots);
         TH_HIP(hipMemcpyAsync(&r.host[slot], &s->stat, sizeof(toast_hip_pcg_status), hipMemcpyDeviceToHost, st));
         TH_HIP(hipEventRecord(r.ev[slot], st));
