@@ -72,3 +72,36 @@ def test_bench_two_ranks_through_the_library_communicator(mock_lib):
     assert d["n_gpus"] == 2 and d["allreduce"]["implementation"].startswith("toast_hip_comm"), d["allreduce"]
     assert d["allreduce"]["note"] is None and d["allreduce"]["owner_computes_reduce_apply_ms"] > 0
     assert d["configs3_shard"]["allreduce"]["implementation"].startswith("toast_hip_comm")
+
+
+def test_workflow_two_ranks_equals_one_process(mock_lib):
+    """`workflows/mapmaker_pcg.py` under torch.distributed.run with two ranks (README's multi-GPU command, here on one
+    GPU through the stand-in): 2 x 32 detectors detector-sharded against one process with all 64 -- the same PCG
+    trajectory (the workflow prints the last relative residual) and the same number of amplitudes."""
+    import re
+
+    args = ["--minutes", "5", "--rate", "100", "--nside", "256", "--iter", "8", "--no-filter", "--step-time", "10"]
+    env = dict(os.environ)
+    env.update(OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "workflows", "mapmaker_pcg.py"), "--ndet", "64", *args],
+                         capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-4000:]
+    env.update(TOAST_BENCH_SHARE_GPU="1", TOAST_HIP_COMM="rccl", TOAST_HIP_RCCL_LIB=mock_lib, TOAST_HIP_TRACE="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", "29581", os.path.join(ROOT, "workflows", "mapmaker_pcg.py"), "--ndet", "32",
+           *args]
+    two = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-4000:]
+
+    def summary(text):
+        m = re.search(r"ranks (\d+)\s+detectors (\d+).*amplitudes (\d+)\s+PCG iterations (\d+)\s+relative residual (\S+)",
+                      text)
+        assert m, text[-1500:]
+        return int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4)), float(m.group(5))
+
+    r1, r2 = summary(one.stdout), summary(two.stdout)
+    assert r1[0] == 1 and r2[0] == 2 and r1[1:4] == r2[1:4] == (64, r1[2], 8)
+    assert abs(r2[4] - r1[4]) < 1e-6 * r1[4], (r1, r2)
+    # the collectives of the two-rank run went through the library's communicator, on the device
+    log = two.stderr + two.stdout
+    assert "toast_hip_comm_map_reduce_apply_dev" in log and "toast_hip_comm_allreduce_dev" in log

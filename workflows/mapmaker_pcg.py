@@ -93,11 +93,13 @@ def main(argv=None):
                                  n_samp=n_samp, rate=args.rate, spin_period_s=600.0, spin_angle_deg=30.0,
                                  prec_period_s=3000.0, prec_angle_deg=65.0, net=1.0, fknee=0.05)
     ob = data.obs[0]
-    rng = np.random.default_rng(1 + rank)
     sig = ob.detdata[defaults.det_data].data
     for d in range(sig.shape[0]):  # white noise + one random-walk-ish drift per detector
+        # (seeded by the detector's index in the whole focalplane: the same problem however it is sharded)
+        rng = np.random.default_rng(1 + args.ndet * rank + d)
         sig[d] = rng.standard_normal(n_samp)
         sig[d] += np.repeat(rng.standard_normal((n_samp + 1999) // 2000), 2000)[:n_samp]
+        ob.detdata[defaults.det_flags].data[d] = (rng.random(n_samp) < 0.01).astype(np.uint8) * defaults.det_mask_invalid
     ph.lap("simulate (host)")
     if not args.no_filter:
         ops.NoiseFilter(noise_model=defaults.noise_model).apply(data)
