@@ -897,6 +897,7 @@ def run(args, workload, world, rank, dev, headline=True):
     del d_pixels, d_weights, d_tod, d_tod2, d_dflags
     for ptr in managed:
         capi.device_free(ptr)
+    capi.accel_release_cached()      # (and the candidates the placement policy still holds)
     return out
 
 

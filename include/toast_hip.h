@@ -89,6 +89,14 @@ int toast_hip_device_malloc(size_t nbytes, int flags, void ** out);
  * stream rate (TB/s, read + write) of the last kept block.  Any pointer may be NULL. */
 int toast_hip_alloc_stats(int64_t * probed_blocks, int64_t * fast_blocks, int64_t * candidates, double * probe_ms,
                           double * last_tbs);
+/* More of the same: time spent in hipMalloc for candidates and the longest single call (ms), searches ended by the
+ * time budget, blocks taken from the slow candidates that earlier searches left allocated, and the bytes of such
+ * candidates held right now (they live in the cache of released blocks: TOAST_HIP_ALLOC_HOLD_GB, default 24, bounds
+ * them; an allocation failure or toast_hip_accel_release_cached gives them back).  Any pointer may be NULL. */
+int toast_hip_alloc_stats_ex(double * malloc_ms, double * max_malloc_ms, int64_t * budget_stops, int64_t * held_reused,
+                             int64_t * held_bytes);
+/* Give the cache of released device blocks (TOAST_HIP_ALLOC_CACHE_MB) and the held candidates back to the driver. */
+int toast_hip_accel_release_cached(void);
 int toast_hip_device_free(void * p);
 /* Experiment: virtual range backed by chunk_mb-sized physical allocations mapped in order / shuffled
  * (tools/exp_alloc_flags.py, profiles/r02_d_placement_experiments.txt).  The range is never released. */

@@ -337,3 +337,49 @@ def test_placement_policy_of_the_memory_manager():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     f = [ln for ln in out.stdout.splitlines() if ln.startswith("STATS")][0].split()
     assert int(f[1]) == 0 and int(f[2]) == 0 and int(f[3]) == 0
+
+
+def test_placement_policy_holds_slow_candidates_between_searches():
+    """Candidates that a search measured and passed over stay allocated (in the cache of released blocks, marked with
+    their rate) so that the driver cannot hand the same ranges to the next search; they are a last resort for later
+    blocks of the size, never what ``create`` takes from the cache, bounded by TOAST_HIP_ALLOC_HOLD_GB, and given back by
+    toast_hip_accel_release_cached.  TOAST_HIP_ALLOC_ACCEPT_TBS=100 makes every candidate "slow"."""
+    import subprocess
+    import sys
+    import textwrap
+
+    code = textwrap.dedent("""
+        import numpy as np
+        from toast_amd import capi
+        from toast_amd.accel import accel_assign_device, accel_data_create, accel_data_delete
+        accel_assign_device(1, 0, 1.0, False)
+        n = 3 << 29                                            # 1.5 GB
+        a = capi.device_malloc(n)
+        s1 = capi.alloc_stats()
+        b = capi.device_malloc(n)
+        s2 = capi.alloc_stats()
+        host = np.zeros(n // 8)                                # a registered array of the size: not a held candidate
+        accel_data_create(host, "x")
+        s3 = capi.alloc_stats()
+        accel_data_delete(host, "x")
+        capi.accel_release_cached()
+        s4 = capi.alloc_stats()
+        print("HELD", s1["candidates"], s1["held_GB"], s2["candidates"], s2["held_GB"], s3["probed_blocks"],
+              s4["held_GB"], s2["fast_blocks"])
+    """)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("TOAST_HIP_ALLOC", None)
+    env.update(TOAST_HIP_ALLOC_ACCEPT_TBS="100", TOAST_HIP_ALLOC_BUDGET_MS="100000")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    f = [ln for ln in out.stdout.splitlines() if ln.startswith("HELD")][0].split()
+    c1, h1, c2, h2, blocks3, h4, fast = int(f[1]), float(f[2]), int(f[3]), float(f[4]), int(f[5]), float(f[6]), int(f[7])
+    assert c1 == 8 and abs(h1 - 7 * 1.5) < 1e-6          # eight candidates, one kept, seven held
+    assert c2 == 16 and 7 * 1.5 - 1e-6 <= h2 <= 24.0      # the second search: eight new ones, best of all fifteen
+    assert blocks3 == 3 and h4 == 0.0 and fast == 0       # create() searched as well (a held block is not a cached one)
+    env["TOAST_HIP_ALLOC_HOLD_GB"] = "0"
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    f = [ln for ln in out.stdout.splitlines() if ln.startswith("HELD")][0].split()
+    assert float(f[2]) == 0.0 and float(f[4]) == 0.0

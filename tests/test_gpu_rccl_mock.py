@@ -52,8 +52,9 @@ def test_mapmaker_equals_single_process(mock_lib, n):
     assert out.stdout.count("OK") == n
 
 
-def test_bench_two_ranks_through_the_library_communicator(mock_lib):
-    """`python3 bench.py --gpus 2` (self-launched) with both ranks on the one GPU: the N > 1 protocol of the benchmark
+@pytest.mark.parametrize("n", [2, 3])
+def test_bench_ranks_through_the_library_communicator(mock_lib, n):
+    """`python3 bench.py --gpus N` (self-launched) with all ranks on the one GPU (N = 3: shards that do not divide): the N > 1 protocol of the benchmark
     -- every rank agrees that the library can be loaded, rank 0's id goes round, collective initialisation, the
     self-check of all-reduce and owner-computes pass against torch.distributed, the agreement to use it -- with two
     REAL ranks; the timed step then reduces the map through toast_hip_comm_allreduce_dev."""
@@ -62,14 +63,14 @@ def test_bench_two_ranks_through_the_library_communicator(mock_lib):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR",
                                                              "MASTER_PORT")}
     env.update(TOAST_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="1", TOAST_HIP_RCCL_LIB=mock_lib)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup",
                           "1", "--workload", "mini", "--no-fft", "--shard-workload", "cfg2"], capture_output=True,
                          text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["allreduce"]["implementation"].startswith("toast_hip_comm"), d["allreduce"]
+    assert d["n_gpus"] == n and d["allreduce"]["implementation"].startswith("toast_hip_comm"), d["allreduce"]
     assert d["allreduce"]["note"] is None and d["allreduce"]["owner_computes_reduce_apply_ms"] > 0
     assert d["configs3_shard"]["allreduce"]["implementation"].startswith("toast_hip_comm")
 

@@ -266,13 +266,23 @@ def device_free(ptr):
     _check(real_lib().toast_hip_device_free(C.c_void_p(int(ptr))))
 
 
+def accel_release_cached():
+    """Released device blocks kept for reuse, and slow candidates held by the placement policy, go back to the driver."""
+    _check(real_lib().toast_hip_accel_release_cached())
+
+
 def alloc_stats():
     """Placement policy counters of this process (toast_hip_alloc_stats)."""
     pb, fb, cd = C.c_int64(0), C.c_int64(0), C.c_int64(0)
     ms, tbs = C.c_double(0.0), C.c_double(0.0)
     _check(real_lib().toast_hip_alloc_stats(C.byref(pb), C.byref(fb), C.byref(cd), C.byref(ms), C.byref(tbs)))
+    mm, mx = C.c_double(0.0), C.c_double(0.0)
+    bs, hr, hb = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    _check(real_lib().toast_hip_alloc_stats_ex(C.byref(mm), C.byref(mx), C.byref(bs), C.byref(hr), C.byref(hb)))
     return dict(probed_blocks=int(pb.value), fast_blocks=int(fb.value), candidates=int(cd.value),
-                probe_ms=float(ms.value), last_TBs=float(tbs.value))
+                probe_ms=float(ms.value), last_TBs=float(tbs.value), malloc_ms=float(mm.value),
+                max_malloc_ms=float(mx.value), budget_stops=int(bs.value), held_reused=int(hr.value),
+                held_GB=float(hb.value) / 2.0 ** 30)
 
 
 def accel_update_device_parts(buf, part_end, name="NA"):

@@ -328,7 +328,8 @@ size_t pin_threshold() {
 // held (default 32768, 0 disables); the cache is emptied when an allocation fails and on clear().
 void * Manager::take_cached(size_t nbytes) {
     for (size_t i = 0; i < free_blocks_.size(); ++i) {
-        if (free_blocks_[i].second == nbytes) {
+        // (candidates that the placement policy measured as slow are only handed out by device_alloc, as a last resort)
+        if (free_blocks_[i].second == nbytes && free_blocks_[i].slow_tbs <= 0.0) {
             void * p = free_blocks_[i].first;
             free_blocks_.erase(free_blocks_.begin() + (long)i);
             cached_bytes_ -= nbytes;
@@ -338,7 +339,7 @@ void * Manager::take_cached(size_t nbytes) {
     return nullptr;
 }
 
-bool Manager::keep_cached(void * dev, size_t nbytes) {
+bool Manager::keep_cached(void * dev, size_t nbytes, double slow_tbs) {
     static const size_t cap = [] {
         const char * s = std::getenv("TOAST_HIP_ALLOC_CACHE_MB");
         return (size_t)((s != nullptr) ? std::atol(s) : 32768) << 20;
@@ -350,7 +351,7 @@ bool Manager::keep_cached(void * dev, size_t nbytes) {
         free_blocks_.erase(free_blocks_.begin());
     }
     if (cached_bytes_ + nbytes > cap) return false;
-    free_blocks_.emplace_back(dev, nbytes);
+    free_blocks_.push_back(FreeBlock{dev, nbytes, slow_tbs});
     cached_bytes_ += nbytes;
     return true;
 }
@@ -512,7 +513,8 @@ struct AllocPolicy {
     int probe_k = 8;
     double accept_tbs = 5.65;   // read + write bytes / probe time: between the two levels (5.05-5.4 and 5.9-6.0)
     size_t max_bytes = size_t(8) << 30;   // TOAST_HIP_ALLOC_PROBE_MAX_GB
-    double budget_ms = 60.0;              // TOAST_HIP_ALLOC_BUDGET_MS: no further candidate once a block has cost this much
+    double budget_ms = 60.0;              // TOAST_HIP_ALLOC_BUDGET_MS: what a candidate may cost (two dearer ones in a row end the search)
+    size_t hold_bytes = size_t(24) << 30;  // TOAST_HIP_ALLOC_HOLD_GB: slow candidates kept allocated between searches
 };
 const AllocPolicy & alloc_policy() {
     static const AllocPolicy pol = [] {
@@ -535,6 +537,8 @@ const AllocPolicy & alloc_policy() {
         if (t != nullptr && std::atof(t) > 0.0) a.accept_tbs = std::atof(t);
         const char * b = std::getenv("TOAST_HIP_ALLOC_BUDGET_MS");
         if (b != nullptr && std::atof(b) > 0.0) a.budget_ms = std::atof(b);
+        const char * h = std::getenv("TOAST_HIP_ALLOC_HOLD_GB");
+        if (h != nullptr && std::atol(h) >= 0) a.hold_bytes = (size_t)std::atol(h) << 30;
         const char * m = std::getenv("TOAST_HIP_ALLOC_PROBE_MAX_GB");
         if (m != nullptr && std::atol(m) > 0) a.max_bytes = (size_t)std::atol(m) << 30;
         return a;
@@ -553,27 +557,52 @@ void * Manager::device_alloc(size_t nbytes) {
         std::vector<void *> cand;
         std::vector<double> tbs;
         size_t best = 0;
-        // A candidate normally costs ~5 ms (hipMalloc, first-touch pass, timed pass), but on a box whose memory is still
-        // being cleared after another process hipMalloc alone takes ~200 ms per 5.9 GB: the search stops once the block
-        // has cost `budget_ms` (the first candidate is needed in any case).
+        // A candidate normally costs ~5 ms (hipMalloc, first-touch pass, timed pass).  On a box whose memory is still
+        // being cleared after another process hipMalloc can take ~200 ms per 5.9 GB, candidate after candidate: the
+        // search stops when two candidates in a row have each cost more than `budget_ms`.  (One slow call says little:
+        // the driver also stalls a SINGLE hipMalloc for seconds when it runs out of cleared memory, and the next ones
+        // are quick again -- counting that against the block would leave it with the one candidate.)  A cap on the
+        // whole search bounds the worst case.
         const auto t_start = std::chrono::steady_clock::now();
+        auto ms_since = [](std::chrono::steady_clock::time_point t) {
+            return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+        };
+        int slow_in_a_row = 0;
         for (int k = 0; k < pol.probe_k; ++k) {
-            if (k > 0) {
-                const double spent = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
-                if (spent > pol.budget_ms) break;
+            if (k > 0 && (slow_in_a_row >= 2 || ms_since(t_start) > 40.0 * pol.budget_ms)) {
+                ++g_alloc_stats.budget_stops;
+                break;
             }
+            const auto t_cand = std::chrono::steady_clock::now();
             void * c = nullptr;
             if (hipMalloc(&c, nbytes) != hipSuccess) {
                 (void)hipGetLastError();
                 break;   // memory is short: make do with the candidates so far
             }
+            const double malloc_ms = ms_since(t_cand);
+            g_alloc_stats.malloc_ms += malloc_ms;
+            if (malloc_ms > g_alloc_stats.max_malloc_ms) g_alloc_stats.max_malloc_ms = malloc_ms;
             const double ms = probe_stream_ms(c, nbytes, stream_);
             cand.push_back(c);
             tbs.push_back(ms > 0.0 ? 2.0 * (double)nbytes / ms / 1.0e9 : 0.0);
             g_alloc_stats.probe_ms += ms;
             ++g_alloc_stats.candidates;
+            slow_in_a_row = (ms_since(t_cand) > pol.budget_ms) ? slow_in_a_row + 1 : 0;
             if (tbs.back() > tbs[best]) best = cand.size() - 1;
             if (tbs.back() >= pol.accept_tbs) break;
+        }
+        // Slow candidates of EARLIER searches for this size are still allocated (below: they sit in the cache of
+        // released blocks, which keeps the driver from handing the same ranges out again): if none of the new ones is
+        // fast either, the best of all of them is taken.
+        const size_t n_new = cand.size();
+        if (cand.empty() || tbs[best] < pol.accept_tbs) {
+            for (const FreeBlock & b : free_blocks_) {
+                if (b.second == nbytes && b.slow_tbs > 0.0) {
+                    cand.push_back(b.first);
+                    tbs.push_back(b.slow_tbs);
+                    if (tbs.back() > tbs[best]) best = cand.size() - 1;
+                }
+            }
         }
         if (!cand.empty()) {
             ++g_alloc_stats.probed_blocks;
@@ -581,14 +610,38 @@ void * Manager::device_alloc(size_t nbytes) {
             g_alloc_stats.last_tbs = tbs[best];
             if (trace_enabled()) {
                 std::string line;
-                for (size_t k = 0; k < cand.size(); ++k) line += (k ? " " : "") + std::to_string(tbs[k]);
+                for (size_t k = 0; k < cand.size(); ++k) {
+                    line += (k ? " " : "") + std::to_string(tbs[k]) + (k >= n_new ? "(held)" : "");
+                }
                 std::fprintf(stderr, "[toast_hip] probe         %.1f MB: %s TB/s, kept #%zu\n", nbytes / 1.0e6, line.c_str(),
                              best);
             }
-            for (size_t k = 0; k < cand.size(); ++k) {
-                if (k != best) (void)hipFree(cand[k]);
+            void * chosen = cand[best];
+            if (best >= n_new) {
+                // a held one: out of the cache
+                for (size_t i = 0; i < free_blocks_.size(); ++i) {
+                    if (free_blocks_[i].first == chosen) {
+                        free_blocks_.erase(free_blocks_.begin() + (long)i);
+                        cached_bytes_ -= nbytes;
+                        break;
+                    }
+                }
+                ++g_alloc_stats.held_reused;
             }
-            return cand[best];
+            // The losers stay allocated in the cache of released blocks, marked with their rate (a rate of 0 would make
+            // them ordinary released blocks): at most `hold_bytes` of them, inside that cache's own cap, and given back
+            // with the rest of the cache when memory runs short.
+            size_t held = 0;
+            for (const FreeBlock & b : free_blocks_) held += (b.slow_tbs > 0.0) ? b.second : 0;
+            for (size_t k = 0; k < n_new; ++k) {
+                if (k == best) continue;
+                if (held + nbytes <= pol.hold_bytes && keep_cached(cand[k], nbytes, tbs[k] > 0.0 ? tbs[k] : 1.0e-3)) {
+                    held += nbytes;
+                } else {
+                    (void)hipFree(cand[k]);
+                }
+            }
+            return chosen;
         }
     }
     void * p = nullptr;
@@ -948,6 +1001,22 @@ int toast_hip_alloc_stats(int64_t * probed_blocks, int64_t * fast_blocks, int64_
         if (candidates) *candidates = a.candidates;
         if (probe_ms) *probe_ms = a.probe_ms;
         if (last_tbs) *last_tbs = a.last_tbs;
+    });
+}
+
+int toast_hip_accel_release_cached(void) {
+    return guarded([&] { Manager::get().release_cached(); });
+}
+
+int toast_hip_alloc_stats_ex(double * malloc_ms, double * max_malloc_ms, int64_t * budget_stops, int64_t * held_reused,
+                             int64_t * held_bytes) {
+    return guarded([&] {
+        const AllocStats & a = alloc_stats();
+        if (malloc_ms) *malloc_ms = a.malloc_ms;
+        if (max_malloc_ms) *max_malloc_ms = a.max_malloc_ms;
+        if (budget_stops) *budget_stops = a.budget_stops;
+        if (held_reused) *held_reused = a.held_reused;
+        if (held_bytes) *held_bytes = (int64_t)Manager::get().held_slow_bytes();
     });
 }
 

@@ -103,6 +103,10 @@ struct AllocStats {
     int64_t candidates = 0;      // candidate allocations probed in total
     double probe_ms = 0.0;       // time spent in the probe passes
     double last_tbs = 0.0;       // stream rate of the last kept candidate
+    double malloc_ms = 0.0;      // time spent in hipMalloc for candidates
+    double max_malloc_ms = 0.0;  // ... the longest single call (a driver still clearing memory stalls one for seconds)
+    int64_t budget_stops = 0;    // searches ended by the time budget
+    int64_t held_reused = 0;     // blocks taken from the slow candidates kept from earlier searches
 };
 const AllocStats & alloc_stats();
 
@@ -166,6 +170,11 @@ public:
     void * scratch(int slot, size_t bytes);
     void * device_alloc(size_t nbytes);   // allocation policy of the manager (nullptr on failure)
     void release_cached() { flush_cached(); }
+    size_t held_slow_bytes() const {
+        size_t n = 0;
+        for (const FreeBlock & b : free_blocks_) n += (b.slow_tbs > 0.0) ? b.second : 0;
+        return n;
+    }
 
     uint64_t generation() const { return generation_; }
     hipStream_t stream() const { return stream_; }
@@ -189,9 +198,14 @@ private:
     void pin_for_transfer(const void * host, Entry & e);
     static void unpin(const void * host, Entry & e);
     void * take_cached(size_t nbytes);
-    bool keep_cached(void * dev, size_t nbytes);
+    bool keep_cached(void * dev, size_t nbytes, double slow_tbs = 0.0);
     void flush_cached();
-    std::vector<std::pair<void *, size_t>> free_blocks_;   // released device blocks kept for reuse
+    struct FreeBlock {
+        void * first;       // device pointer
+        size_t second;      // bytes
+        double slow_tbs;    // > 0: a candidate the placement policy measured and passed over (its stream rate, TB/s)
+    };
+    std::vector<FreeBlock> free_blocks_;   // released device blocks kept for reuse
     size_t cached_bytes_ = 0;
     static double trace_begin();
     static void trace(const char * what, const std::string & name, size_t nbytes, double t0);
