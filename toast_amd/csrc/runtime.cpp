@@ -515,6 +515,7 @@ struct AllocPolicy {
     size_t max_bytes = size_t(8) << 30;   // TOAST_HIP_ALLOC_PROBE_MAX_GB
     double budget_ms = 60.0;              // TOAST_HIP_ALLOC_BUDGET_MS: what a candidate may cost (two dearer ones in a row end the search)
     size_t hold_bytes = size_t(24) << 30;  // TOAST_HIP_ALLOC_HOLD_GB: slow candidates kept allocated between searches
+    size_t min_bytes = size_t(1) << 30;    // TOAST_HIP_ALLOC_PROBE_MIN_MB
 };
 const AllocPolicy & alloc_policy() {
     static const AllocPolicy pol = [] {
@@ -539,6 +540,8 @@ const AllocPolicy & alloc_policy() {
         if (b != nullptr && std::atof(b) > 0.0) a.budget_ms = std::atof(b);
         const char * h = std::getenv("TOAST_HIP_ALLOC_HOLD_GB");
         if (h != nullptr && std::atol(h) >= 0) a.hold_bytes = (size_t)std::atol(h) << 30;
+        const char * n = std::getenv("TOAST_HIP_ALLOC_PROBE_MIN_MB");
+        if (n != nullptr && std::atol(n) >= 16) a.min_bytes = (size_t)std::atol(n) << 20;
         const char * m = std::getenv("TOAST_HIP_ALLOC_PROBE_MAX_GB");
         if (m != nullptr && std::atol(m) > 0) a.max_bytes = (size_t)std::atol(m) << 30;
         return a;
@@ -552,7 +555,7 @@ const AllocStats & alloc_stats() { return g_alloc_stats; }
 
 void * Manager::device_alloc(size_t nbytes) {
     const AllocPolicy & pol = alloc_policy();
-    const size_t lo = size_t(1) << 30, hi = pol.max_bytes;
+    const size_t lo = pol.min_bytes, hi = pol.max_bytes;
     if (pol.probe_k > 0 && nbytes >= lo && nbytes <= hi) {
         std::vector<void *> cand;
         std::vector<double> tbs;
