@@ -531,7 +531,7 @@ const AllocPolicy & alloc_policy() {
             } else if (v.rfind("probe", 0) == 0) {
                 const char * c = std::strchr(e, ':');
                 const int k = c ? std::atoi(c + 1) : 8;
-                a.probe_k = k < 2 ? 2 : (k > 8 ? 8 : k);
+                a.probe_k = k < 2 ? 2 : (k > 32 ? 32 : k);
             }
         }
         const char * t = std::getenv("TOAST_HIP_ALLOC_ACCEPT_TBS");
