@@ -369,7 +369,9 @@ def test_placement_policy_holds_slow_candidates_between_searches():
     """)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
-    env.pop("TOAST_HIP_ALLOC", None)
+    for key in ("TOAST_HIP_ALLOC", "TOAST_HIP_ALLOC_CACHE_MB", "TOAST_HIP_ALLOC_HOLD_GB", "TOAST_HIP_ALLOC_PROBE_MIN_MB",
+                "TOAST_HIP_ALLOC_PROBE_MAX_GB"):
+        env.pop(key, None)
     env.update(TOAST_HIP_ALLOC_ACCEPT_TBS="100", TOAST_HIP_ALLOC_BUDGET_MS="100000")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]

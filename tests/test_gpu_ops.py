@@ -887,6 +887,7 @@ def test_pcg_fused_updates_give_the_bits_of_the_separate_launches(monkeypatch, p
     hist, amps, calls = {}, {}, {}
     for fuse in ("1", "0"):
         monkeypatch.setenv("TOAST_HIP_PCG_FUSE", fuse)
+        monkeypatch.setenv("TOAST_HIP_PCG_SCALARS", "device")
         seen = {}
         for name in ("pcg_step_dot", "pcg_precond_diag_dot", "pcg_step", "pcg_dot"):
             real = getattr(capi.dev, name)
