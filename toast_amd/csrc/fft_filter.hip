@@ -343,66 +343,184 @@ __global__ __launch_bounds__(256) void k_impulse_extent(const double * __restric
 // Flag extension of toast.fft.convolve / NoiseFilter (reference src/toast/utils.py:1055-1113 extend_flags, then
 // src/toast/fft.py:935-945): every flagged run [s, e) ASSIGNS the mask to [max(s - b, 0), e + b) -- the end clipped to
 // n - 1 when it reaches n, so the last sample is never assigned --, then the first and last b samples get the mask
-// OR-ed in.  Sample j <= n - 2 is assigned iff a flagged sample lies in [j - b, j + b]: a window count from the prefix
-// sum of the flagged samples.  One workgroup per detector row; the prefix sums of the row live in `prefix`.
+// OR-ed in.  Sample j <= n - 2 is assigned iff a flagged sample lies in [j - b, j + b], i.e. iff the nearest flagged
+// sample at or before j, or the nearest at or after j, is within b.  Two launches over (row, chunk of 2048 samples):
+// the first leaves every chunk's first / last flagged sample and count in a small table, the second finds the nearest
+// flagged samples outside its chunk from that table and inside it with a scan, and rewrites the chunk.  (The first
+// version kept a prefix sum of the whole row in HBM -- 2.9 GB for cfg-3 -- and walked a row with one workgroup:
+// 4.4 ms; this one reads the flags twice and writes them once.)
+constexpr int kFlagChunk = 2048;      // 256 threads x 8 consecutive samples
+constexpr int kFlagPer = kFlagChunk / 256;
+
+// the thread's kFlagPer consecutive flags (OR-ed with the common row), bytes past the end of the row = 0: one 8-byte
+// load per array when the piece is whole and aligned (rows of a multiple of 8 samples), byte loads otherwise
+__device__ __forceinline__ void load_flags8(const uint8_t * __restrict__ f, const uint8_t * __restrict__ or_row,
+                                            int64_t j0, int64_t n_samp, uint8_t (&val)[kFlagPer]) {
+    static_assert(kFlagPer == 8, "one 64-bit word per thread");
+    const bool whole = j0 + kFlagPer <= n_samp;
+    uint64_t w = 0;
+    if (whole && (reinterpret_cast<uintptr_t>(f + j0) & 7u) == 0) {
+        w = *reinterpret_cast<const uint64_t *>(f + j0);
+    } else {
+#pragma unroll
+        for (int k = 0; k < kFlagPer; ++k) {
+            if (j0 + k < n_samp) w |= (uint64_t)f[j0 + k] << (8 * k);
+        }
+    }
+    if (or_row != nullptr) {
+        if (whole && (reinterpret_cast<uintptr_t>(or_row + j0) & 7u) == 0) {
+            w |= *reinterpret_cast<const uint64_t *>(or_row + j0);
+        } else {
+#pragma unroll
+            for (int k = 0; k < kFlagPer; ++k) {
+                if (j0 + k < n_samp) w |= (uint64_t)or_row[j0 + k] << (8 * k);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kFlagPer; ++k) val[k] = (uint8_t)(w >> (8 * k));
+}
+
+__global__ __launch_bounds__(256) void k_flag_chunk_summary(const uint8_t * __restrict__ flags,
+                                                            const int32_t * __restrict__ f_idx, int row0, int64_t n_samp,
+                                                            uint8_t mask, const uint8_t * __restrict__ or_row,
+                                                            int32_t * __restrict__ summary, int n_chunk) {
+    const int r = row0 + blockIdx.y;
+    const uint8_t * __restrict__ f = flags + (int64_t)f_idx[r] * n_samp;
+    const int tid = threadIdx.x;
+    const int64_t j0 = (int64_t)blockIdx.x * kFlagChunk + (int64_t)tid * kFlagPer;
+    int32_t first = INT32_MAX, last = -1, cnt = 0;
+    uint8_t val[kFlagPer];
+    load_flags8(f, or_row, j0, n_samp, val);
+#pragma unroll
+    for (int k = 0; k < kFlagPer; ++k) {
+        const int64_t j = j0 + k;
+        if (j < n_samp && (val[k] & mask) != 0) {
+            if (first == INT32_MAX) first = (int32_t)j;
+            last = (int32_t)j;
+            ++cnt;
+        }
+    }
+    __shared__ int32_t s_first[256], s_last[256], s_cnt[256];
+    s_first[tid] = first;
+    s_last[tid] = last;
+    s_cnt[tid] = cnt;
+    __syncthreads();
+    for (int s2 = 128; s2 > 0; s2 >>= 1) {
+        if (tid < s2) {
+            s_first[tid] = min(s_first[tid], s_first[tid + s2]);
+            s_last[tid] = max(s_last[tid], s_last[tid + s2]);
+            s_cnt[tid] += s_cnt[tid + s2];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int32_t * o = summary + ((int64_t)blockIdx.y * n_chunk + blockIdx.x) * 3;
+        o[0] = s_first[0];
+        o[1] = s_last[0];
+        o[2] = s_cnt[0];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_extend_flags(uint8_t * __restrict__ flags, const int32_t * __restrict__ f_idx,
                                                       int row0, int64_t n_samp, uint8_t mask,
                                                       const int32_t * __restrict__ extent,
-                                                      int32_t * __restrict__ prefix, int edges,
+                                                      const int32_t * __restrict__ summary, int n_chunk, int edges,
                                                       const uint8_t * __restrict__ or_row) {
-    const int r = row0 + blockIdx.x;
+    const int r = row0 + blockIdx.y;
     uint8_t * __restrict__ f = flags + (int64_t)f_idx[r] * n_samp;
-    int32_t * __restrict__ pre = prefix + (int64_t)blockIdx.x * n_samp;
     const int64_t b = extent[r];
-    __shared__ int32_t s_cnt[256];
-    __shared__ int32_t s_carry;
     const int tid = threadIdx.x;
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    constexpr int PER = 8;
-    for (int64_t base = 0; base < n_samp; base += 256 * PER) {
-        const int64_t j0 = base + (int64_t)tid * PER;
-        int32_t loc[PER];
-        int32_t run = 0;
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int64_t j = j0 + k;
-            const uint8_t extra = (or_row != nullptr && j < n_samp) ? or_row[j] : (uint8_t)0;
-            run += (j < n_samp && ((f[j] | extra) & mask) != 0) ? 1 : 0;
-            loc[k] = run;
+    const int c = blockIdx.x;
+    __shared__ int32_t s_a[256], s_b[256];
+    __shared__ int64_t s_tot[256];
+    // nearest flagged sample before / after this chunk, and the row's count, from the table of the first launch
+    {
+        const int32_t * __restrict__ row = summary + (int64_t)blockIdx.y * n_chunk * 3;
+        int32_t before = -1, after = INT32_MAX;
+        int64_t tot = 0;
+        for (int i = tid; i < n_chunk; i += 256) {
+            const int32_t fi = row[3 * i], la = row[3 * i + 1];
+            tot += row[3 * i + 2];
+            if (i < c && la > before) before = la;
+            if (i > c && fi < after) after = fi;
         }
-        s_cnt[tid] = run;
+        s_a[tid] = before;
+        s_b[tid] = after;
+        s_tot[tid] = tot;
         __syncthreads();
-        // inclusive scan of the 256 thread totals (Hillis-Steele)
-        for (int d = 1; d < 256; d <<= 1) {
-            const int32_t o = (tid >= d) ? s_cnt[tid - d] : 0;
+        for (int s2 = 128; s2 > 0; s2 >>= 1) {
+            if (tid < s2) {
+                s_a[tid] = max(s_a[tid], s_a[tid + s2]);
+                s_b[tid] = min(s_b[tid], s_b[tid + s2]);
+                s_tot[tid] += s_tot[tid + s2];
+            }
             __syncthreads();
-            s_cnt[tid] += o;
-            __syncthreads();
         }
-        const int32_t before = s_carry + ((tid > 0) ? s_cnt[tid - 1] : 0);
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int64_t j = j0 + k;
-            if (j < n_samp) pre[j] = before + loc[k];
-        }
-        __syncthreads();
-        if (tid == 255) s_carry += s_cnt[255];
-        __syncthreads();
     }
+    const int32_t prev_out = s_a[0], next_out = s_b[0];
     // a completely flagged row has no rising or falling edge: the reference returns without touching it, so the bits
     // outside the mask survive (utils.py:1078-1083)
-    const bool extend = s_carry != (int32_t)n_samp;
-    for (int64_t j = tid; j < n_samp; j += 256) {
-        const int64_t lo = (j - b > 0) ? j - b : 0;
-        const int64_t hi = (j + b < n_samp - 1) ? j + b : n_samp - 1;
-        const int32_t cnt = pre[hi] - ((lo > 0) ? pre[lo - 1] : 0);
-        uint8_t v = f[j];
-        if (or_row != nullptr) v |= or_row[j];
-        if (extend && cnt > 0 && j <= n_samp - 2) v = mask;
+    const bool extend = s_tot[0] != n_samp;
+    __syncthreads();
+    const int64_t j0 = (int64_t)c * kFlagChunk + (int64_t)tid * kFlagPer;
+    uint8_t val[kFlagPer];
+    bool set[kFlagPer];
+    int32_t my_first = INT32_MAX, my_last = -1;
+    load_flags8(f, or_row, j0, n_samp, val);
+#pragma unroll
+    for (int k = 0; k < kFlagPer; ++k) {
+        const int64_t j = j0 + k;
+        set[k] = j < n_samp && (val[k] & mask) != 0;
+        if (set[k]) {
+            if (my_first == INT32_MAX) my_first = (int32_t)j;
+            my_last = (int32_t)j;
+        }
+    }
+    // last flagged sample of the threads before this one, first flagged sample of the threads after it
+    s_a[tid] = my_last;
+    s_b[tid] = my_first;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const int32_t oa = (tid >= d) ? s_a[tid - d] : -1;
+        const int32_t ob = (tid + d < 256) ? s_b[tid + d] : INT32_MAX;
+        __syncthreads();
+        s_a[tid] = max(s_a[tid], oa);
+        s_b[tid] = min(s_b[tid], ob);
+        __syncthreads();
+    }
+    int32_t prev = max(prev_out, (tid > 0) ? s_a[tid - 1] : -1);
+    const int32_t next_right = min(next_out, (tid < 255) ? s_b[tid + 1] : INT32_MAX);
+    // nearest flagged sample at or after j inside the thread: from the right
+    int32_t next_in[kFlagPer];
+    {
+        int32_t nx = next_right;
+#pragma unroll
+        for (int k = kFlagPer - 1; k >= 0; --k) {
+            if (set[k]) nx = (int32_t)(j0 + k);
+            next_in[k] = nx;
+        }
+    }
+    uint64_t w = 0;
+#pragma unroll
+    for (int k = 0; k < kFlagPer; ++k) {
+        const int64_t j = j0 + k;
+        if (set[k]) prev = (int32_t)j;
+        const bool near = (prev >= 0 && j - prev <= b) || (next_in[k] != INT32_MAX && (int64_t)next_in[k] - j <= b);
+        uint8_t v = val[k];
+        if (extend && near && j <= n_samp - 2) v = mask;
         // f[:b] |= mask; f[-b:] |= mask  (Python semantics: b == 0 makes the second slice the whole array)
         if (edges && (b == 0 || j < b || j >= n_samp - b)) v |= mask;
-        f[j] = v;
+        val[k] = v;
+        w |= (uint64_t)v << (8 * k);
+    }
+    if (j0 + kFlagPer <= n_samp && (reinterpret_cast<uintptr_t>(f + j0) & 7u) == 0) {
+        *reinterpret_cast<uint64_t *>(f + j0) = w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < kFlagPer; ++k) {
+            if (j0 + k < n_samp) f[j0 + k] = val[k];
+        }
     }
 }
 
@@ -588,16 +706,18 @@ int toast_hip_fft_extend_flags(uint8_t * flags, int64_t n_flag_rows, const int32
         const size_t o_fi = pb.push(flag_index, sizeof(int32_t) * n_det);
         const size_t o_ex = pb.push(extents, sizeof(int32_t) * n_det);
         const char * d = pb.commit(st);
-        int64_t batch = (int64_t)((size_t(4) << 30) / ((size_t)n_samp * sizeof(int32_t)));   // prefix sums: <= 4 GB of scratch
-        if (batch < 1) batch = 1;
+        const int64_t n_chunk = (n_samp + kFlagChunk - 1) / kFlagChunk;
+        int64_t batch = 65535;     // rows per launch (grid y)
         if (batch > n_det) batch = n_det;
-        int32_t * d_pre = (int32_t *)Manager::get().scratch(Manager::kScratchFftImpulse,
-                                                           (size_t)batch * n_samp * sizeof(int32_t));
+        int32_t * d_sum = (int32_t *)Manager::get().scratch(Manager::kScratchFftImpulse,
+                                                           (size_t)batch * n_chunk * 3 * sizeof(int32_t));
         for (int64_t r0 = 0; r0 < n_det; r0 += batch) {
             const int64_t nb = (n_det - r0 < batch) ? (n_det - r0) : batch;
-            hipLaunchKernelGGL(k_extend_flags, dim3((unsigned)nb), dim3(256), 0, st, d_flags,
-                               (const int32_t *)(d + o_fi), (int)r0, n_samp, mask, (const int32_t *)(d + o_ex), d_pre,
-                               edges ? 1 : 0, d_or);
+            const dim3 grid((unsigned)n_chunk, (unsigned)nb);
+            hipLaunchKernelGGL(k_flag_chunk_summary, grid, dim3(256), 0, st, d_flags, (const int32_t *)(d + o_fi), (int)r0,
+                               n_samp, mask, d_or, d_sum, (int)n_chunk);
+            hipLaunchKernelGGL(k_extend_flags, grid, dim3(256), 0, st, d_flags, (const int32_t *)(d + o_fi), (int)r0, n_samp,
+                               mask, (const int32_t *)(d + o_ex), d_sum, (int)n_chunk, edges ? 1 : 0, d_or);
         }
         TH_HIP(hipGetLastError());
         stg.finish();
