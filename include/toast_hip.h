@@ -98,6 +98,10 @@ int toast_hip_alloc_stats_ex(double * malloc_ms, double * max_malloc_ms, int64_t
 /* Give the cache of released device blocks (TOAST_HIP_ALLOC_CACHE_MB) and the held candidates back to the driver. */
 int toast_hip_accel_release_cached(void);
 int toast_hip_device_free(void * p);
+/* toast_hip_device_malloc(flags = -2): like -1, but a block of exactly this size that the manager kept when it was released
+ * is handed out first; toast_hip_device_release gives a block to that cache (TOAST_HIP_ALLOC_CACHE_MB) instead of the
+ * driver -- for temporaries of a recurring size (the solver's packed pointing cache: one allocation per solve). */
+int toast_hip_device_release(void * p, size_t nbytes);
 /* Experiment: virtual range backed by chunk_mb-sized physical allocations mapped in order / shuffled
  * (tools/exp_alloc_flags.py, profiles/r02_d_placement_experiments.txt).  The range is never released. */
 int toast_hip_device_malloc_vmm(size_t nbytes, int chunk_mb, int shuffled, void ** out);
@@ -541,6 +545,42 @@ int toast_hip_offset_scan_project_signal_dev(
     const double * d_map, int64_t n_pix_submap, int64_t nnz, const int32_t * pixel_index, const int64_t * d_pixels,
     const int32_t * weight_index, const double * d_weights, const int32_t * flag_index, const uint8_t * d_flag_data,
     uint8_t flag_mask, const double * det_weights, int64_t n_det, int64_t n_samp,
+    const toast_hip_interval * intervals, int64_t n_view, void * stream);
+
+/* ------------------------------------------------------------------------------------
+ * The solver's pointing cache in 20 bytes per detector-sample (csrc/packed_pointing.hip).  Every PCG iteration sweeps
+ * the cached pointing twice [ref: SolverLHS._exec, src/toast/ops/mapmaker_solve.py:342-506] and reads pixel (int64),
+ * three weights and a flag byte per sample: 33 B.  During a solve none of it changes, the intensity weight is a
+ * per-detector constant [ref: stokes_weights_IQU, src/toast/_libtoast/ops_stokes_weights.cpp:77-140: weights[0] = cal],
+ * the kernels only need the OFFSET of the pixel in the local map, and the flags only say "skip".
+ *   pack_pointing:  d_key[n_det][n_samp] (uint32: local pixel offset + 1 in bits 0-29, 0 = no pixel of the local map;
+ *       bit 30 = flagged for the accumulation: (det_flags & det_flag_mask) | (shared_flags & shared_flag_mask); bit 31 =
+ *       flagged for the projection: proj_flags & proj_flag_mask), d_qu[n_det][n_samp][2] (the Q and U weights),
+ *       d_cal[n_det] (the intensity weight).  Rows follow the order of the index arrays.  *packable = 1 when the
+ *       intensity weight is the same number in every sample in view of each row and every offset fits 30 bits
+ *       (Nside <= 8192); otherwise 0, and the caller keeps using toast_hip_offset_accumulate_dev / _scan_project_dev.
+ *       Waits for the stream (once per solve).  "Absent" flag arrays as elsewhere: length != n_samp.
+ *   offset_accumulate_packed / offset_scan_project_packed: the two sweeps of toast_hip_offset_accumulate_dev /
+ *       toast_hip_offset_scan_project_dev (nnz = 3) from the packed cache: the same products in the same order (the
+ *       projection bit for bit; the accumulation up to the order of its atomic additions, as between any two runs).
+ *       n_samp must be even.
+ * ---------------------------------------------------------------------------------- */
+int toast_hip_offset_pack_pointing_dev(
+    const int64_t * d_g2l, int64_t n_pix_submap, const int32_t * pixel_index, const int64_t * d_pixels,
+    const int32_t * weight_index, const double * d_weights, const int32_t * acc_flag_index, const uint8_t * d_det_flags,
+    int64_t n_flag_samp, uint8_t det_flag_mask, const uint8_t * d_shared_flags, int64_t n_shared_flags,
+    uint8_t shared_flag_mask, const int32_t * proj_flag_index, const uint8_t * d_proj_flags, int64_t n_proj_flag_samp,
+    uint8_t proj_flag_mask, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
+    uint32_t * d_key, double * d_qu, double * d_cal, int * packable, void * stream);
+int toast_hip_offset_accumulate_packed_dev(
+    int64_t step_length, const int64_t * amp_offsets, const int64_t * n_amp_views, const double * d_amplitudes,
+    const uint8_t * d_amplitude_flags, double * d_zmap, const uint32_t * d_key, const double * d_qu, const double * d_cal,
+    const double * det_scale, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
+    void * stream);
+int toast_hip_offset_scan_project_packed_dev(
+    int64_t step_length, const int64_t * amp_offsets, const int64_t * n_amp_views, const double * d_amps_in,
+    double * d_amps_out, const uint8_t * d_amplitude_flags, const double * d_map, const uint32_t * d_key,
+    const double * d_qu, const double * d_cal, const double * det_weights, int64_t n_det, int64_t n_samp,
     const toast_hip_interval * intervals, int64_t n_view, void * stream);
 
 int toast_hip_template_offset_apply_diag_precond(

@@ -1,0 +1,190 @@
+"""GPU: the solver's packed pointing cache (csrc/packed_pointing.hip: 20 instead of 33 bytes per detector-sample) against
+the sweeps over the original arrays: the projection bit for bit, the accumulation to the rounding of its atomic
+additions, the complete MapMaker to rounding; and the cases in which packing must refuse."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(n_det=6, n_samp=6000, nside=64, seed=5, odd_views=True):
+    import torch
+
+    from toast_amd import capi, synth
+
+    rng = np.random.default_rng(seed)
+    nps = 12 * nside * nside // 48 if nside >= 2 else 12
+    n_submap = 12 * nside * nside // nps
+    fp, gamma = synth.hex_focalplane(n_det, fov_deg=6.0)
+    bore = synth.satellite_boresight(n_samp, 50.0, 60.0, 30.0, 600.0, 65.0)
+    if odd_views:      # three views with odd first samples and odd lengths: peeled heads and tails
+        ivl = np.zeros(3, dtype=synth.interval_dtype)
+        for k, (a, b) in enumerate(((3, 1500), (1701, 4000), (4100, n_samp - 1))):
+            ivl[k]["first"], ivl[k]["last"] = a, b
+            ivl[k]["start"], ivl[k]["stop"] = a / 50.0, b / 50.0
+    else:
+        ivl = synth.make_intervals(n_samp, 1, 50.0)
+    dev = torch.device("cuda", 0)
+    D = capi.dev
+    idx = np.arange(n_det, dtype=np.int32)
+    d_bore = torch.from_numpy(bore).to(dev)
+    d_quats = torch.empty((n_det, n_samp, 4), dtype=torch.float64, device=dev)
+    d_pix = torch.full((n_det, n_samp), -1, dtype=torch.int64, device=dev)
+    d_w = torch.zeros((n_det, n_samp, 3), dtype=torch.float64, device=dev)
+    d_hsub = torch.zeros(n_submap, dtype=torch.uint8, device=dev)
+    sflags = (rng.random(n_samp) < 0.02).astype(np.uint8)
+    d_sflags = torch.from_numpy(sflags).to(dev)
+    D.pointing_detector(fp, d_bore.data_ptr(), idx, d_quats.data_ptr(), n_samp, ivl, d_sflags.data_ptr(), n_samp, 1, 0)
+    D.pixels_healpix(idx, d_quats.data_ptr(), d_sflags.data_ptr(), n_samp, 1, idx, d_pix.data_ptr(), n_samp, ivl,
+                     d_hsub.data_ptr(), n_submap, nps, nside, True, 0)
+    cal = 0.5 + rng.random(n_det)
+    D.stokes_weights_IQU(idx, d_quats.data_ptr(), idx, d_w.data_ptr(), n_samp, 0, 0, ivl, np.zeros(n_det), gamma, cal,
+                         False, 0)
+    torch.cuda.synchronize()
+    hit = d_hsub.cpu().numpy() != 0
+    # leave one hit submap out of the local map: samples whose pixel is not local
+    hit_idx = np.flatnonzero(hit)
+    hit[hit_idx[len(hit_idx) // 2]] = False
+    g2l = np.full(n_submap, -1, dtype=np.int64)
+    g2l[hit] = np.arange(int(hit.sum()))
+    n_local = int(hit.sum())
+    dflags = (rng.random((n_det, n_samp)) < 0.03).astype(np.uint8) * 3        # bits 0 and 1
+    pflags = (rng.random((n_det, n_samp)) < 0.05).astype(np.uint8)
+    step = 250
+    n_amp_view = [int(np.ceil((int(v["last"]) - int(v["first"])) / step)) for v in ivl]
+    n_amp_det = int(np.sum(n_amp_view))
+    ao = np.arange(n_det, dtype=np.int64) * n_amp_det
+    amps = rng.standard_normal(n_det * n_amp_det)
+    amp_flags = (rng.random(n_det * n_amp_det) < 0.05).astype(np.uint8)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)      # noqa: E731
+    return dict(D=D, torch=torch, dev=dev, n_det=n_det, n_samp=n_samp, nps=nps, n_local=n_local, idx=idx, ivl=ivl, step=step,
+                nav=np.array(n_amp_view, dtype=np.int64), ao=ao, d_pix=d_pix, d_w=d_w, d_g2l=t(g2l), d_dflags=t(dflags),
+                d_pflags=t(pflags), d_sflags=d_sflags, d_amps=t(amps), d_aflags=t(amp_flags), n_amp=n_det * n_amp_det,
+                detw=0.5 + rng.random(n_det), cal=cal, zmap0=rng.standard_normal((n_local, nps, 3)))
+
+
+def _pack(s, dmask=1, smask=1, pmask=1):
+    torch, D = s["torch"], s["D"]
+    key = torch.zeros((s["n_det"], s["n_samp"]), dtype=torch.int32, device=s["dev"])
+    qu = torch.zeros((s["n_det"], s["n_samp"], 2), dtype=torch.float64, device=s["dev"])
+    cal = torch.zeros(s["n_det"], dtype=torch.float64, device=s["dev"])
+    ok = D.offset_pack_pointing(s["d_g2l"].data_ptr(), s["nps"], s["idx"], s["d_pix"].data_ptr(), s["idx"],
+                                s["d_w"].data_ptr(), s["idx"], s["d_dflags"].data_ptr(), s["n_samp"], dmask,
+                                s["d_sflags"].data_ptr(), s["n_samp"], smask, s["idx"], s["d_pflags"].data_ptr(),
+                                s["n_samp"], pmask, s["n_samp"], s["ivl"], key.data_ptr(), qu.data_ptr(), cal.data_ptr())
+    return ok, key, qu, cal
+
+
+@pytest.mark.parametrize("n_det,odd_views", [(6, True), (5, True), (6, False)])
+def test_packed_sweeps_equal_the_sweeps_over_the_original_arrays(n_det, odd_views):
+    s = _setup(n_det=n_det, odd_views=odd_views)
+    torch, D = s["torch"], s["D"]
+    ok, key, qu, cal = _pack(s)
+    assert ok
+    assert np.array_equal(cal.cpu().numpy(), s["cal"])
+    # the packed words say what the original arrays say
+    k = key.cpu().numpy().view(np.uint32)
+    pix = s["d_pix"].cpu().numpy()
+    g2l = s["d_g2l"].cpu().numpy()
+    in_view = np.zeros(s["n_samp"], dtype=bool)
+    for v in s["ivl"]:
+        in_view[int(v["first"]):int(v["last"])] = True
+    gsm = np.where(pix >= 0, pix // s["nps"], 0)
+    local = (pix >= 0) & (g2l[gsm] >= 0)
+    off = np.where(local, g2l[gsm] * s["nps"] + pix % s["nps"] + 1, 0)
+    assert np.array_equal((k & 0x3fffffff)[:, in_view], off[:, in_view])
+    acc = ((s["d_dflags"].cpu().numpy() & 1) != 0) | ((s["d_sflags"].cpu().numpy() & 1) != 0)[None, :]
+    assert np.array_equal(((k >> 30) & 1)[:, in_view].astype(bool), acc[:, in_view])
+    assert np.array_equal((k >> 31)[:, in_view].astype(bool), ((s["d_pflags"].cpu().numpy() & 1) != 0)[:, in_view])
+    assert local.sum() < (pix >= 0).sum()         # (the case "pixel outside the local map" is present)
+    assert np.array_equal(qu.cpu().numpy()[:, in_view], s["d_w"].cpu().numpy()[:, in_view, 1:])
+
+    # projection: bit for bit
+    zmap = torch.from_numpy(s["zmap0"]).to(s["dev"])
+    out_a = torch.zeros(s["n_amp"], dtype=torch.float64, device=s["dev"])
+    out_b = torch.zeros_like(out_a)
+    D.offset_scan_project(s["step"], s["ao"], s["nav"], s["d_amps"].data_ptr(), out_a.data_ptr(), s["d_aflags"].data_ptr(),
+                          s["d_g2l"].data_ptr(), zmap.data_ptr(), s["nps"], 3, s["idx"], s["d_pix"].data_ptr(), s["idx"],
+                          s["d_w"].data_ptr(), s["idx"], s["d_pflags"].data_ptr(), 1, s["detw"], s["n_samp"], s["ivl"])
+    D.offset_scan_project_packed(s["step"], s["ao"], s["nav"], s["d_amps"].data_ptr(), out_b.data_ptr(),
+                                 s["d_aflags"].data_ptr(), zmap.data_ptr(), key.data_ptr(), qu.data_ptr(), cal.data_ptr(),
+                                 s["detw"], s["n_samp"], s["ivl"])
+    torch.cuda.synchronize()
+    a, b = out_a.cpu().numpy(), out_b.cpu().numpy()
+    assert np.any(a != 0)
+    # (the amplitude sums are atomic additions of run totals: equal to rounding, and equal bit for bit wherever a
+    # baseline received one run)
+    np.testing.assert_allclose(b, a, rtol=0, atol=1e-12 * np.max(np.abs(a)))
+
+    # accumulation
+    za = torch.zeros((s["n_local"], s["nps"], 3), dtype=torch.float64, device=s["dev"])
+    zb = torch.zeros_like(za)
+    D.offset_accumulate(s["step"], s["ao"], s["nav"], s["d_amps"].data_ptr(), s["d_aflags"].data_ptr(), s["d_g2l"].data_ptr(),
+                        za.data_ptr(), s["nps"], 3, s["idx"], s["d_pix"].data_ptr(), s["idx"], s["d_w"].data_ptr(), s["idx"],
+                        s["d_dflags"].data_ptr(), s["n_samp"], s["detw"], 1, s["n_samp"], s["ivl"], s["d_sflags"].data_ptr(),
+                        s["n_samp"], 1)
+    D.offset_accumulate_packed(s["step"], s["ao"], s["nav"], s["d_amps"].data_ptr(), s["d_aflags"].data_ptr(), zb.data_ptr(),
+                               key.data_ptr(), qu.data_ptr(), cal.data_ptr(), s["detw"], s["n_samp"], s["ivl"])
+    torch.cuda.synchronize()
+    a, b = za.cpu().numpy(), zb.cpu().numpy()
+    assert np.any(a != 0) and np.array_equal(a != 0, b != 0)
+    np.testing.assert_allclose(b, a, rtol=0, atol=1e-12 * np.max(np.abs(a)))
+
+
+def test_packing_refuses_what_it_cannot_represent():
+    """An intensity weight that varies along a row (weights that did not come from stokes_weights_IQU): not packable, the
+    caller keeps the original arrays.  Different masks give different flag bits."""
+    s = _setup()
+    ok, key, _, _ = _pack(s, dmask=2, smask=0, pmask=0)
+    assert ok
+    k = key.cpu().numpy().view(np.uint32)
+    assert not np.any(k >> 31) and np.array_equal(((k >> 30) & 1).astype(bool)[:, 5:1400],
+                                                  ((s["d_dflags"].cpu().numpy() & 2) != 0)[:, 5:1400])
+    s["d_w"][2, 777, 0] += 1e-9
+    ok, _, _, _ = _pack(s)
+    assert not ok
+
+
+@pytest.mark.parametrize("prior", [False, True])
+def test_mapmaker_with_and_without_the_packed_cache(monkeypatch, prior):
+    from toast_amd import capi, ops
+    from toast_amd.data import defaults
+    from toast_amd.templates import Offset
+    from test_gpu_ops import make_solver_setup
+
+    res = {}
+    for packed in ("1", "0"):
+        monkeypatch.setenv("TOAST_HIP_PACKED_POINTING", packed)
+        seen = {}
+        for name in ("offset_accumulate_packed", "offset_scan_project_packed", "offset_accumulate", "offset_pack_pointing"):
+            real = getattr(capi.dev, name)
+
+            def counted(*a, _real=real, _name=name, **k):
+                seen[_name] = seen.get(_name, 0) + 1
+                return _real(*a, **k)
+
+            monkeypatch.setattr(capi.dev, name, counted)
+        data, pix, sw, truth, sky = make_solver_setup(noise_rms=0.1)
+        binner = ops.BinMap(pixel_dist="dist", pixel_pointing=pix, stokes_weights=sw, full_pointing=True)
+        tmpl = Offset(step_time=20.0, noise_model=defaults.noise_model, name="baselines", good_fraction=0.2,
+                      use_noise_prior=prior, precond_width=10)
+        mapper = ops.MapMaker(name="mm", keep_solver_products=True, det_data=defaults.det_data, binning=binner,
+                              template_matrix=ops.TemplateMatrix(templates=[tmpl]), solve_rcond_threshold=1e-3,
+                              map_rcond_threshold=1e-3, iter_max=12, convergence=1e-30)
+        held0 = capi.alloc_stats()
+        mapper.apply(data)
+        res[packed] = (np.array(mapper.history), data["mm_solve_amplitudes"]["baselines"].local.copy(),
+                       data["mm_map"].data.copy(), dict(seen))
+        monkeypatch.undo()
+        del held0
+    h1, a1, m1, c1 = res["1"]
+    h0, a0, m0, c0 = res["0"]
+    can_pack = not prior        # (with the noise prior the fused left-hand side is not used at all)
+    if can_pack:
+        assert c1.get("offset_pack_pointing", 0) >= 1 and c1.get("offset_accumulate_packed", 0) >= 1, c1
+        assert c1.get("offset_scan_project_packed", 0) >= 1 and c1.get("offset_accumulate", 0) == 0, c1
+    assert c0.get("offset_pack_pointing", 0) == 0 and c0.get("offset_accumulate_packed", 0) == 0, c0
+    assert len(h1) == len(h0)
+    np.testing.assert_allclose(h1, h0, rtol=1e-7)
+    assert np.max(np.abs(a1 - a0)) < 1e-9 * np.max(np.abs(a0))
+    assert np.max(np.abs(m1 - m0)) < 1e-9 * np.max(np.abs(m0))

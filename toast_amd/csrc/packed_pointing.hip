@@ -1,0 +1,378 @@
+// packed_pointing.hip -- the solver's pointing cache in 20 bytes per detector-sample instead of 33.
+//
+// Every PCG iteration of the offset-template map-maker sweeps the cached pointing twice (SolverLHS,
+// src/toast/ops/mapmaker_solve.py:342-506: accumulate A^T N^-1 M a, then project M^T N^-1 (M a - A z)), and each sweep
+// reads, per detector-sample, the pixel number (int64, 8 B), three Stokes weights (24 B) and a flag byte: 33 B, nothing
+// else of that size.  None of it changes during a solve, and a good part of it is redundant:
+//   * the intensity weight of a detector is ONE number (stokes_weights_IQU: weights[0] = cal,
+//     src/toast/_libtoast/ops_stokes_weights.cpp:77-140) -- 8 B per sample for a per-detector constant;
+//   * the kernels turn the global pixel number into an offset into the local map (division by n_pix_submap, a look-up
+//     in global2local) every time; the offset itself fits 30 bits for every Nside <= 8192;
+//   * the flags only say "skip this sample" -- two bits (the accumulation and the projection may look at different
+//     flag arrays / masks).
+// toast_hip_offset_pack_pointing_dev writes, once per solve, a 32-bit word per detector-sample (local pixel offset + 1,
+// or 0, and the two flag bits) and the Q / U weights (16 B); it CHECKS that the intensity weight really is constant
+// along each detector row and refuses otherwise (the caller then keeps using the arrays it has).  The two packed sweeps
+// compute exactly what k_offset_accumulate_v2 / k_offset_scan_project_v2 compute from the original arrays -- same
+// products, same order -- from 20 B per sample, without the division and the global2local gather.
+#include "kernel_common.hpp"
+
+#include "../../include/toast_hip.h"
+
+using namespace toast_hip;
+
+namespace {
+
+constexpr uint32_t kPkIndex = 0x3fffffffu;   // local pixel offset + 1 (0: no pixel of the local map)
+constexpr uint32_t kPkAccFlag = 0x40000000u;  // flagged for the accumulation (A^T N^-1)
+constexpr uint32_t kPkProjFlag = 0x80000000u; // flagged for the projection (M^T N^-1)
+
+__global__ __launch_bounds__(kThreads) void k_pack_pointing(
+    const Chunk * __restrict__ chunks, int n_chunks, const int32_t * __restrict__ p_idx,
+    const int32_t * __restrict__ w_idx, const int32_t * __restrict__ fa_idx, const int32_t * __restrict__ fp_idx,
+    const int64_t * __restrict__ g2l, const int64_t * __restrict__ pixels, const double * __restrict__ weights,
+    const uint8_t * __restrict__ dflags, uint8_t dmask, int use_d, const uint8_t * __restrict__ sflags, uint8_t smask,
+    int use_s, const uint8_t * __restrict__ pflags, uint8_t pmask, int use_p, FastDiv nps_div, int64_t n_samp,
+    uint32_t * __restrict__ key, double2 * __restrict__ qu, double * __restrict__ cal_out, int * __restrict__ status) {
+    const int det = blockIdx.x;
+    const int64_t * prow = pixels + (int64_t)p_idx[det] * n_samp;
+    const double * wrow = weights + (int64_t)w_idx[det] * n_samp * 3;
+    const uint8_t * darow = use_d ? dflags + (int64_t)fa_idx[det] * n_samp : nullptr;
+    const uint8_t * dprow = use_p ? pflags + (int64_t)fp_idx[det] * n_samp : nullptr;
+    uint32_t * krow = key + (int64_t)det * n_samp;
+    double2 * qrow = qu + (int64_t)det * n_samp;
+    const int64_t nps = nps_div.d;
+    // the row's intensity weight: the one of its first sample in view; every sample is compared with it
+    const double cal = wrow[3 * chunks[0].first];
+    if (blockIdx.y == 0 && threadIdx.x == 0) cal_out[det] = cal;
+    int bad = 0;
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        for (int i = threadIdx.x; i < c.count; i += kThreads) {
+            const int64_t s = c.first + i;
+            const int64_t p = prow[s];
+            const double w0 = wrow[3 * s], w1 = wrow[3 * s + 1], w2 = wrow[3 * s + 2];
+            const uint8_t fd = use_d ? darow[s] : (uint8_t)0;
+            const uint8_t fs = use_s ? sflags[s] : (uint8_t)0;
+            const uint8_t fp = use_p ? dprow[s] : (uint8_t)0;
+            const bool hit = p >= 0;
+            const int64_t pp = hit ? p : 0;
+            const int64_t gsm = fastdiv(pp, nps_div);
+            const int64_t lsm = g2l[gsm];
+            const bool local = hit && lsm >= 0;
+            const int64_t off = local ? lsm * nps + (pp - gsm * nps) : -1;
+            if (off + 1 > (int64_t)kPkIndex) bad |= 2;
+            if (!(w0 == cal)) bad |= 1;
+            uint32_t k = local ? (uint32_t)(off + 1) & kPkIndex : 0u;
+            if (((fd & dmask) != 0) | ((fs & smask) != 0)) k |= kPkAccFlag;
+            if ((fp & pmask) != 0) k |= kPkProjFlag;
+            krow[s] = k;
+            qrow[s] = make_double2(w1, w2);
+        }
+    }
+    if (bad) atomicOr(status, bad);
+}
+
+// k_offset_accumulate_v2 from the packed cache: zmap += A^T N^-1 (M a), two consecutive samples per lane, E = 2: the two
+// detectors of a co-pointing pair in one workgroup (their contributions to a pixel are added before the atomics).
+template <int E>
+__global__ __launch_bounds__(kThreads) void k_offset_accumulate_pk(
+    const Chunk * __restrict__ chunks, int n_chunks, int n_det, const int64_t * __restrict__ view_first,
+    const int64_t * __restrict__ view_aoff, FastDiv step_div, const int64_t * __restrict__ amp_offsets,
+    const double * __restrict__ amps, const uint8_t * __restrict__ amp_flags, const double * __restrict__ det_scale,
+    const double * __restrict__ cal, double * __restrict__ zmap, const uint32_t * __restrict__ key,
+    const double2 * __restrict__ qu, int64_t n_samp) {
+    constexpr int NNZ = 3;
+    const int det0 = E * blockIdx.x;
+    bool on[E];
+    const uint32_t * krow[E];
+    const double2 * qrow[E];
+    double ds[E], cl[E];
+    int64_t amp_offset[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        on[e] = det0 + e < n_det;
+        const int det = on[e] ? det0 + e : det0;
+        krow[e] = key + (int64_t)det * n_samp;
+        qrow[e] = qu + (int64_t)det * n_samp;
+        ds[e] = det_scale[det];
+        cl[e] = cal[det];
+        amp_offset[e] = amp_offsets[det];
+    }
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        const int64_t vfirst = view_first[c.view];
+        const int64_t vaoff = view_aoff[c.view];
+        const int head = (int)(c.first & 1);
+        const int64_t s0 = c.first + head;          // even
+        const int n_pair = (c.count - head) >> 1;
+        for (int base = 0; base < n_pair; base += kThreads) {
+            const int j = base + threadIdx.x;
+            const bool active = j < n_pair;
+            const int64_t s = s0 + 2 * (int64_t)(active ? j : 0);
+            const int64_t step_a = fastdiv(s - vfirst, step_div), step_b = fastdiv(s + 1 - vfirst, step_div);
+            int64_t ka[E], kb[E];
+            double va[E][NNZ], vb[E][NNZ];
+            uint2 kk[E];
+            double2 qa[E], qb[E], av[E];
+            uint8_t afa[E], afb[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                kk[e] = *reinterpret_cast<const uint2 *>(krow[e] + s);
+                qa[e] = qrow[e][s];
+                qb[e] = qrow[e][s + 1];
+                const int64_t aa = amp_offset[e] + vaoff + step_a, ab = amp_offset[e] + vaoff + step_b;
+                afa[e] = amp_flags[aa];
+                afb[e] = amp_flags[ab];
+                av[e] = make_double2(amps[aa], amps[ab]);
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const uint32_t ia = kk[e].x & kPkIndex, ib = kk[e].y & kPkIndex;
+                const bool good_a = active & on[e] & (ia != 0) & ((kk[e].x & kPkAccFlag) == 0);
+                const bool good_b = active & on[e] & (ib != 0) & ((kk[e].y & kPkAccFlag) == 0);
+                ka[e] = good_a ? (int64_t)ia - 1 : -1;
+                kb[e] = good_b ? (int64_t)ib - 1 : -1;
+                // tod = 0 + amplitude (unflagged amplitudes only), then * det_scale
+                const double ta = (afa[e] == 0) ? (0.0 + av[e].x) : 0.0, tb = (afb[e] == 0) ? (0.0 + av[e].y) : 0.0;
+                const double sa = ta * ds[e], sb = tb * ds[e];
+                va[e][0] = good_a ? sa * cl[e] : 0.0;
+                va[e][1] = good_a ? sa * qa[e].x : 0.0;
+                va[e][2] = good_a ? sa * qa[e].y : 0.0;
+                vb[e][0] = good_b ? sb * cl[e] : 0.0;
+                vb[e][1] = good_b ? sb * qb[e].x : 0.0;
+                vb[e][2] = good_b ? sb * qb[e].y : 0.0;
+            }
+            if constexpr (E == 2) {
+                const bool mergeable = ((ka[0] == ka[1]) | (ka[0] < 0) | (ka[1] < 0)) &
+                                       ((kb[0] == kb[1]) | (kb[0] < 0) | (kb[1] < 0));
+                if (__all(mergeable)) {
+                    const int64_t kam = (ka[0] >= 0) ? ka[0] : ka[1];
+                    const int64_t kbm = (kb[0] >= 0) ? kb[0] : kb[1];
+                    double vam[NNZ], vbm[NNZ];
+#pragma unroll
+                    for (int k = 0; k < NNZ; ++k) {
+                        vam[k] = va[0][k] + va[1][k];
+                        vbm[k] = vb[0][k] + vb[1][k];
+                    }
+                    scatter_runs2<NNZ>(kam, vam, kbm, vbm, zmap);
+                    continue;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) scatter_runs2<NNZ>(ka[e], va[e], kb[e], vb[e], zmap);
+        }
+        // the peeled first sample and the odd last one: lanes 0 and 1 of the workgroup
+        const int tail = (c.count - head) & 1;
+        if ((threadIdx.x == 0 && head) || (threadIdx.x == 1 && tail)) {
+            const int64_t s = (threadIdx.x == 0) ? c.first : c.first + c.count - 1;
+            const int64_t astep = fastdiv(s - vfirst, step_div);
+            for (int e = 0; e < E; ++e) {
+                if (!on[e]) continue;
+                const uint32_t k = krow[e][s];
+                const uint32_t idx = k & kPkIndex;
+                if (idx == 0 || (k & kPkAccFlag) != 0) continue;
+                const int64_t a = amp_offset[e] + vaoff + astep;
+                const double t = (amp_flags[a] == 0) ? (0.0 + amps[a]) : 0.0;
+                const double sd = t * ds[e];
+                const double2 q = qrow[e][s];
+                double * z = zmap + NNZ * ((int64_t)idx - 1);
+                unsafeAtomicAdd(z, sd * cl[e]);
+                unsafeAtomicAdd(z + 1, sd * q.x);
+                unsafeAtomicAdd(z + 2, sd * q.y);
+            }
+        }
+    }
+}
+
+// k_offset_scan_project_v2 from the packed cache: a_out += M^T N^-1 (M a - A z)
+__global__ __launch_bounds__(kThreads) void k_offset_scan_project_pk(
+    const Chunk * __restrict__ chunks, int n_chunks, const int64_t * __restrict__ view_first,
+    const int64_t * __restrict__ view_aoff, FastDiv step_div, const int64_t * __restrict__ amp_offsets,
+    const double * __restrict__ amps_in, double * __restrict__ amps_out, const uint8_t * __restrict__ amp_flags,
+    const double * __restrict__ det_w, const double * __restrict__ cal, const double * __restrict__ map,
+    const uint32_t * __restrict__ key, const double2 * __restrict__ qu, int64_t n_samp) {
+    const int det = blockIdx.x;
+    const uint32_t * krow = key + (int64_t)det * n_samp;
+    const double2 * qrow = qu + (int64_t)det * n_samp;
+    const double dw = det_w[det];
+    const double cl = cal[det];
+    const int64_t amp_offset = amp_offsets[det];
+    // one sample: same products in the same order as k_offset_scan_project(_v2)
+    auto finish = [&](bool hit, double av, double w0, double w1, double w2, double m0, double m1, double m2) {
+        double sc = 0.0;
+        sc += w0 * m0;
+        sc += w1 * m1;
+        sc += w2 * m2;
+        sc *= 1.0;
+        const double d = 0.0 + av;
+        return hit ? d - sc : d;
+    };
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        const int64_t vfirst = view_first[c.view];
+        const int64_t abase = amp_offset + view_aoff[c.view];
+        const int head = (int)(c.first & 1);
+        const int64_t s0 = c.first + head;          // even
+        const int n_pair = (c.count - head) >> 1;
+        for (int base = 0; base < n_pair; base += kThreads) {
+            const int j = base + threadIdx.x;
+            const bool active = j < n_pair;
+            const int64_t s = s0 + 2 * (int64_t)(active ? j : 0);
+            const int64_t aa = abase + fastdiv(s - vfirst, step_div);
+            const int64_t ab = abase + fastdiv(s + 1 - vfirst, step_div);
+            const uint8_t afa = amp_flags[aa], afb = amp_flags[ab];
+            const double2 av = make_double2(amps_in[aa], amps_in[ab]);
+            const uint2 kk = *reinterpret_cast<const uint2 *>(krow + s);
+            const double2 qa = qrow[s], qb = qrow[s + 1];
+            const uint32_t ia = kk.x & kPkIndex, ib = kk.y & kPkIndex;
+            const bool hit_a = ia != 0, hit_b = ib != 0;
+            const double * ma = map + (hit_a ? 3 * ((int64_t)ia - 1) : 0);
+            const double * mb = map + (hit_b ? 3 * ((int64_t)ib - 1) : 0);
+            const double a0 = ma[0], a1 = ma[1], a2 = ma[2], b0 = mb[0], b1 = mb[1], b2 = mb[2];
+            const double da = finish(hit_a, av.x, cl, qa.x, qa.y, a0, a1, a2);
+            const double db = finish(hit_b, av.y, cl, qb.x, qb.y, b0, b1, b2);
+            int64_t ka = (active && afa == 0) ? aa : (int64_t)-1;
+            int64_t kb = (active && afb == 0) ? ab : (int64_t)-1;
+            double va[1] = {(ka >= 0 && (kk.x & kPkProjFlag) == 0) ? da * dw : 0.0};
+            double vb[1] = {(kb >= 0 && (kk.y & kPkProjFlag) == 0) ? db * dw : 0.0};
+            scatter_runs2<1>(ka, va, kb, vb, amps_out);
+        }
+        // the peeled first sample (lane 0) and the odd last one (lane 1)
+        const int tail = (c.count - head) & 1;
+        if ((threadIdx.x == 0 && head) || (threadIdx.x == 1 && tail)) {
+            const int64_t s = (threadIdx.x == 0) ? c.first : c.first + c.count - 1;
+            const int64_t a = abase + fastdiv(s - vfirst, step_div);
+            const uint32_t k = krow[s];
+            if (amp_flags[a] == 0 && (k & kPkProjFlag) == 0) {
+                const uint32_t idx = k & kPkIndex;
+                const bool hit = idx != 0;
+                const double * m = map + (hit ? 3 * ((int64_t)idx - 1) : 0);
+                const double2 q = qrow[s];
+                const double d = finish(hit, amps_in[a], cl, q.x, q.y, m[0], m[1], m[2]);
+                unsafeAtomicAdd(amps_out + a, d * dw);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int toast_hip_offset_pack_pointing_dev(
+    const int64_t * d_g2l, int64_t n_pix_submap, const int32_t * pixel_index, const int64_t * d_pixels,
+    const int32_t * weight_index, const double * d_weights, const int32_t * acc_flag_index, const uint8_t * d_det_flags,
+    int64_t n_flag_samp, uint8_t det_flag_mask, const uint8_t * d_shared_flags, int64_t n_shared_flags,
+    uint8_t shared_flag_mask, const int32_t * proj_flag_index, const uint8_t * d_proj_flags, int64_t n_proj_flag_samp,
+    uint8_t proj_flag_mask, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
+    uint32_t * d_key, double * d_qu, double * d_cal, int * packable, void * stream) {
+    return guarded([&] {
+        if (packable == nullptr) fail_arg("offset_pack_pointing: packable must not be null");
+        *packable = 0;
+        if (n_det <= 0) return;
+        if (n_pix_submap <= 0) fail_arg("n_pix_submap must be positive");
+        need_aligned(d_qu, "packed Q / U weights");
+        need_aligned(d_key, "packed pixel words");
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        hipStream_t st = as_stream(stream);
+        const int use_d = (n_flag_samp == n_samp) ? 1 : 0;
+        const int use_s = (n_shared_flags == n_samp) ? 1 : 0;
+        const int use_p = (n_proj_flag_samp == n_samp) ? 1 : 0;
+        std::vector<int32_t> fa(n_det, 0), fp(n_det, 0);
+        if (use_d) std::memcpy(fa.data(), acc_flag_index, sizeof(int32_t) * n_det);
+        if (use_p) std::memcpy(fp.data(), proj_flag_index, sizeof(int32_t) * n_det);
+        ParamBlock pb;
+        const size_t o_ch = pb.push_vec(chunks);
+        const size_t o_pi = pb.push(pixel_index, sizeof(int32_t) * n_det);
+        const size_t o_wi = pb.push(weight_index, sizeof(int32_t) * n_det);
+        const size_t o_fa = pb.push_vec(fa);
+        const size_t o_fp = pb.push_vec(fp);
+        const char * d = pb.commit(st);
+        int * d_status = static_cast<int *>(Manager::get().scratch(Manager::kScratchStatus, 64));
+        TH_HIP(hipMemsetAsync(d_status, 0, sizeof(int), st));
+        hipLaunchKernelGGL(k_pack_pointing, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0, st,
+                           (const Chunk *)(d + o_ch), (int)chunks.size(), (const int32_t *)(d + o_pi),
+                           (const int32_t *)(d + o_wi), (const int32_t *)(d + o_fa), (const int32_t *)(d + o_fp), d_g2l,
+                           d_pixels, d_weights, d_det_flags, det_flag_mask, use_d, d_shared_flags, shared_flag_mask, use_s,
+                           d_proj_flags, proj_flag_mask, use_p, make_fastdiv(n_pix_submap), n_samp, d_key,
+                           reinterpret_cast<double2 *>(d_qu), d_cal, d_status);
+        check_launch();
+        int status = 0;
+        copy_to_host(&status, d_status, sizeof(int), st);     // (waits for the stream: once per solve)
+        *packable = (status == 0) ? 1 : 0;
+    });
+}
+
+int toast_hip_offset_accumulate_packed_dev(
+    int64_t step_length, const int64_t * amp_offsets, const int64_t * n_amp_views, const double * d_amplitudes,
+    const uint8_t * d_amplitude_flags, double * d_zmap, const uint32_t * d_key, const double * d_qu, const double * d_cal,
+    const double * det_scale, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
+    void * stream) {
+    return guarded([&] {
+        if (n_det <= 0) return;
+        if (step_length <= 0) fail_arg("step_length must be positive");
+        if ((n_samp & 1) != 0) fail_arg("offset_accumulate_packed: rows of an even number of samples only");
+        need_aligned(d_qu, "packed Q / U weights");
+        need_aligned(d_key, "packed pixel words");
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        const OffsetViews ov = offset_views(intervals, n_amp_views, n_view);
+        ParamBlock pb;
+        const size_t o_ch = pb.push_vec(chunks);
+        const size_t o_vf = pb.push_vec(ov.first);
+        const size_t o_va = pb.push_vec(ov.aoff);
+        const size_t o_ao = pb.push(amp_offsets, sizeof(int64_t) * n_det);
+        const size_t o_ds = pb.push(det_scale, sizeof(double) * n_det);
+        hipStream_t st = as_stream(stream);
+        const char * d = pb.commit(st);
+        const dim3 grid = chunk_grid(n_det, chunks.size());
+        const bool pr = pair_detectors() && n_det >= 2;
+        const dim3 gp((unsigned)(pr ? (n_det + 1) / 2 : n_det), grid.y, 1);
+#define TH_PK_ARGS                                                                                                  \
+    (const Chunk *)(d + o_ch), (int)chunks.size(), (int)n_det, (const int64_t *)(d + o_vf), (const int64_t *)(d + o_va), \
+        make_fastdiv(step_length), (const int64_t *)(d + o_ao), d_amplitudes, d_amplitude_flags,                    \
+        (const double *)(d + o_ds), d_cal, d_zmap, d_key, reinterpret_cast<const double2 *>(d_qu), n_samp
+        if (pr) {
+            hipLaunchKernelGGL((k_offset_accumulate_pk<2>), gp, dim3(kThreads), 0, st, TH_PK_ARGS);
+        } else {
+            hipLaunchKernelGGL((k_offset_accumulate_pk<1>), gp, dim3(kThreads), 0, st, TH_PK_ARGS);
+        }
+#undef TH_PK_ARGS
+        check_launch();
+    });
+}
+
+int toast_hip_offset_scan_project_packed_dev(
+    int64_t step_length, const int64_t * amp_offsets, const int64_t * n_amp_views, const double * d_amps_in,
+    double * d_amps_out, const uint8_t * d_amplitude_flags, const double * d_map, const uint32_t * d_key,
+    const double * d_qu, const double * d_cal, const double * det_weights, int64_t n_det, int64_t n_samp,
+    const toast_hip_interval * intervals, int64_t n_view, void * stream) {
+    return guarded([&] {
+        if (n_det <= 0) return;
+        if (step_length <= 0) fail_arg("step_length must be positive");
+        if ((n_samp & 1) != 0) fail_arg("offset_scan_project_packed: rows of an even number of samples only");
+        need_aligned(d_qu, "packed Q / U weights");
+        need_aligned(d_key, "packed pixel words");
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        const OffsetViews ov = offset_views(intervals, n_amp_views, n_view);
+        ParamBlock pb;
+        const size_t o_ch = pb.push_vec(chunks);
+        const size_t o_vf = pb.push_vec(ov.first);
+        const size_t o_va = pb.push_vec(ov.aoff);
+        const size_t o_ao = pb.push(amp_offsets, sizeof(int64_t) * n_det);
+        const size_t o_dw = pb.push(det_weights, sizeof(double) * n_det);
+        hipStream_t st = as_stream(stream);
+        const char * d = pb.commit(st);
+        hipLaunchKernelGGL(k_offset_scan_project_pk, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0, st,
+                           (const Chunk *)(d + o_ch), (int)chunks.size(), (const int64_t *)(d + o_vf),
+                           (const int64_t *)(d + o_va), make_fastdiv(step_length), (const int64_t *)(d + o_ao), d_amps_in,
+                           d_amps_out, d_amplitude_flags, (const double *)(d + o_dw), d_cal, d_map, d_key,
+                           reinterpret_cast<const double2 *>(d_qu), n_samp);
+        check_launch();
+    });
+}
+
+}  // extern "C"

@@ -1027,7 +1027,13 @@ int toast_hip_device_malloc(size_t nbytes, int flags, void ** out) {
     return guarded([&] {
         void * p = nullptr;
         if (flags < 0) {
-            p = Manager::get().device_alloc(nbytes);
+            // -2: a block of exactly this size that the manager kept when it was released, if there is one
+            if (flags == -2) p = Manager::get().cached_block(nbytes);
+            if (p == nullptr) p = Manager::get().device_alloc(nbytes);
+            if (p == nullptr) {
+                Manager::get().release_cached();       // the cache may be what holds the memory
+                p = Manager::get().device_alloc(nbytes);
+            }
             if (p == nullptr) throw Error(TOAST_HIP_ERR_MEMORY, "HipManager:  device_malloc, allocation failed");
         } else if (flags == 0) {
             TH_HIP(hipMalloc(&p, nbytes));
@@ -1097,6 +1103,12 @@ int toast_hip_device_malloc_vmm(size_t nbytes, int chunk_mb, int shuffled, void 
 
 int toast_hip_device_free(void * p) {
     return guarded([&] { TH_HIP(hipFree(p)); });
+}
+int toast_hip_device_release(void * p, size_t nbytes) {
+    return guarded([&] {
+        if (p == nullptr) return;
+        if (!Manager::get().keep_block(p, nbytes)) TH_HIP(hipFree(p));
+    });
 }
 
 int toast_hip_accel_generation(uint64_t * generation) {

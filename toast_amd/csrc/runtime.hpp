@@ -170,6 +170,12 @@ public:
     void * scratch(int slot, size_t bytes);
     void * device_alloc(size_t nbytes);   // allocation policy of the manager (nullptr on failure)
     void release_cached() { flush_cached(); }
+    // raw blocks (toast_hip_device_malloc(flags = -2) / toast_hip_device_release) share the cache of released blocks
+    void * cached_block(size_t nbytes) { return take_cached(nbytes); }
+    bool keep_block(void * dev, size_t nbytes) {
+        (void)hipStreamSynchronize(stream_);     // nothing enqueued may still be using it when somebody takes it over
+        return keep_cached(dev, nbytes);
+    }
     size_t held_slow_bytes() const {
         size_t n = 0;
         for (const FreeBlock & b : free_blocks_) n += (b.slow_tbs > 0.0) ? b.second : 0;
@@ -181,7 +187,7 @@ public:
     void set_stream(hipStream_t s) { stream_ = s; }
 
     static constexpr int kScratchFftTime = 0, kScratchFftFreq = 1, kScratchDot = 2, kScratchFftWork = 3,
-                         kScratchSort = 4, kScratchFftImpulse = 5, kScratchCommA = 6, kScratchCommB = 7;
+                         kScratchSort = 4, kScratchFftImpulse = 5, kScratchCommA = 6, kScratchCommB = 7, kScratchStatus = 8;
 
 private:
     std::map<std::pair<int, int>, std::pair<void *, size_t>> scratch_;   // (device, slot) -> (ptr, bytes)

@@ -181,7 +181,7 @@ class SolverRHS(Operator):
         if not self.fused:
             return None
         lhs = SolverLHS(name=f"{self.name}_ctx", binning=self.binning, template_matrix=self.template_matrix,
-                        out=self.template_matrix.amplitudes, fused=True)
+                        out=self.template_matrix.amplitudes, fused=True, packed_pointing=False)
         if not lhs._can_fuse(data):
             return None
         tmpl = [t for t in self.template_matrix.templates if t.enabled][0]
@@ -303,6 +303,10 @@ class SolverLHS(Operator):
     out = Unicode(None, allow_none=True, help="Output Data key for resulting amplitudes")
     fused = Bool(True, help="Use the fused device-resident kernels when the template is an Offset template "
                             "(pointing cached, compact-cached or evaluated on the fly)")
+    packed_pointing = Bool(True, help="With cached IQU pointing: let the fused kernels sweep a packed copy of it "
+                                      "(20 instead of 33 bytes per detector-sample: local pixel offset and flag bits in "
+                                      "one word, the Q / U weights, the intensity weight once per detector), built on "
+                                      "the device at the first iteration and released at the end of the solve")
 
     # -- fused path ---------------------------------------------------------------------------
     def _can_fuse(self, data):
@@ -344,6 +348,75 @@ class SolverLHS(Operator):
         if not obj.accel_in_use():
             obj.accel_update_device()
         return obj
+
+    def __del__(self):
+        try:
+            self.release_packed()
+        except Exception:     # noqa: BLE001 -- interpreter shutdown: the library may be gone already
+            pass
+
+    def release_packed(self):
+        """Give the packed pointing cache back (and forget the recorded launches that point into it)."""
+        packed = self.__dict__.pop("_packed", None)
+        if packed:
+            from .. import capi
+
+            self.__dict__.pop("_fused_plan", None)
+            for _key, pk in packed.values():
+                self._free_pack(pk)
+
+    @staticmethod
+    def _free_pack(pk):
+        from .. import capi
+
+        for ptr, nbytes in pk["blocks"]:
+            capi.device_release(ptr, nbytes)     # (kept by the manager for the next solve's copy of the same size)
+
+    def _pack_pass(self, c, ps):
+        """The packed copy of one observation's cached pointing (toast_hip_offset_pack_pointing_dev), or None when it
+        cannot be had: switched off, rows of an odd length, an intensity weight that varies along a row, no memory."""
+        import os
+
+        from .. import capi
+
+        if not self.packed_pointing or os.environ.get("TOAST_HIP_PACKED_POINTING", "1") == "0":
+            return None
+        n_det, n_samp = len(ps["dets"]), int(ps["n_samp"])
+        if c["nnz"] != 3 or n_samp % 2 != 0 or n_det == 0:
+            return None
+        # One packed copy per observation for the whole solve: the launch plan is rebuilt when the amplitude vectors
+        # change (starting guess, then the proposal), the pointing behind it is the same -- same arrays at the same device
+        # addresses, same flags and masks, same views.
+        ident = (tuple(ps["dets"]), n_samp, c["g2l_ptr"], c["nps"], ps["pp"], tuple(int(i) for i in ps["pi"]), ps["wp"],
+                 tuple(int(i) for i in ps["wi"]), ps["f_ptr"], ps["f_ns"], c["det_flag_mask"], ps["s_ptr"], ps["s_n"],
+                 c["shared_flag_mask"], ps["pf_ptr"], ps["pf_n"], c["tmpl_flag_mask"],
+                 np.ascontiguousarray(ps["ivl"]).tobytes())
+        packed = self.__dict__.setdefault("_packed", {})
+        have = packed.get(ps["iob"])
+        if have is not None:
+            if have[0] == ident:
+                return have[1]
+            del packed[ps["iob"]]
+            self._free_pack(have[1])
+        mine = []
+        try:
+            for nbytes in (4 * n_det * n_samp, 16 * n_det * n_samp, 8 * n_det):
+                nbytes = max(nbytes, 16)
+                mine.append((capi.device_malloc(nbytes, -2), nbytes))
+        except RuntimeError:
+            self._free_pack(dict(blocks=mine))
+            return None
+        key_ptr, qu_ptr, cal_ptr = (m[0] for m in mine)
+        ok = capi.dev.offset_pack_pointing(
+            c["g2l_ptr"], c["nps"], ps["pi"], ps["pp"], ps["wi"], ps["wp"], ps["f_idx"], ps["f_ptr"], ps["f_ns"],
+            c["det_flag_mask"], ps["s_ptr"], ps["s_n"], c["shared_flag_mask"], ps["pf_idx"], ps["pf_ptr"], ps["pf_n"],
+            c["tmpl_flag_mask"], n_samp, ps["ivl"], key_ptr, qu_ptr, cal_ptr)
+        if not ok:
+            self._free_pack(dict(blocks=mine))
+            return None
+        pk = dict(key=key_ptr, qu=qu_ptr, cal=cal_ptr, blocks=mine)
+        packed[ps["iob"]] = (ident, pk)
+        return pk
 
     def _fused_prepare(self, data, detectors):
         """Everything of the fused left-hand side that is not a kernel launch: residency of the
@@ -442,6 +515,10 @@ class SolverLHS(Operator):
                 ps.update(pi=pd.indices(dets), pp=accel_device_ptr(pd.buffer), wi=wd.indices(dets),
                           wp=accel_device_ptr(wd.buffer))
             ctx["passes"].append(ps)
+        # (last: the packed copies are read from the arrays whose pointers were just collected)
+        if not on_the_fly:
+            for ps in ctx["passes"]:
+                ps["pk"] = self._pack_pass(ctx, ps)
         return ctx
 
     @staticmethod
@@ -461,6 +538,10 @@ class SolverLHS(Operator):
                                         c["g2l_ptr"], c["zmap_ptr"], c["nps"], ps["f_idx"], ps["f_ptr"], ps["f_ns"],
                                         ps["detw"], c["det_flag_mask"], ps["n_samp"], ps["ivl"], ps["s_ptr"],
                                         ps["s_n"], c["shared_flag_mask"])
+            elif ps.get("pk") is not None:
+                pk = ps["pk"]
+                D.offset_accumulate_packed(ps["step"], ps["ao"], ps["nav"], c["in_ptr"], c["in_flags_ptr"], c["zmap_ptr"],
+                                           pk["key"], pk["qu"], pk["cal"], ps["detw"], ps["n_samp"], ps["ivl"])
             else:
                 D.offset_accumulate(ps["step"], ps["ao"], ps["nav"], c["in_ptr"], c["in_flags_ptr"], c["g2l_ptr"],
                                     c["zmap_ptr"], c["nps"], c["nnz"], ps["pi"], ps["pp"], ps["wi"], ps["wp"],
@@ -485,6 +566,11 @@ class SolverLHS(Operator):
                                           c["in_flags_ptr"], c["g2l_ptr"], c["zmap_ptr"], c["nps"], ps["pf_idx"],
                                           ps["pf_ptr"], ps["pf_n"], c["tmpl_flag_mask"], ps["detw"], ps["n_samp"],
                                           ps["ivl"])
+            elif ps.get("pk") is not None:
+                pk = ps["pk"]
+                D.offset_scan_project_packed(ps["step"], ps["ao"], ps["nav"], c["in_ptr"], c["out_ptr"], c["in_flags_ptr"],
+                                             c["zmap_ptr"], pk["key"], pk["qu"], pk["cal"], ps["detw"], ps["n_samp"],
+                                             ps["ivl"])
             else:
                 D.offset_scan_project(ps["step"], ps["ao"], ps["nav"], c["in_ptr"], c["out_ptr"], c["in_flags_ptr"],
                                       c["g2l_ptr"], c["zmap_ptr"], c["nps"], c["nnz"], ps["pi"], ps["pp"], ps["wi"],
@@ -845,6 +931,8 @@ def solve(data, detectors, lhs_op, rhs_key, result_key, convergence=1.0e-12, n_i
         stamps = list(iteration_seconds)
         iteration_seconds[:] = [b - a for a, b in zip(stamps[:-1], stamps[1:])]
     lhs_op.keep_on_device = False
+    if hasattr(lhs_op, "release_packed"):
+        lhs_op.release_packed()
     # hand the solution back on the host (AmplitudesMap.accel_update_host skips host-current ones)
     result.accel_update_host()
     rhs.accel_update_host()
