@@ -564,6 +564,12 @@ int toast_hip_offset_scan_project_signal_dev(
  *       toast_hip_offset_scan_project_dev (nnz = 3) from the packed cache: the same products in the same order (the
  *       projection bit for bit; the accumulation up to the order of its atomic additions, as between any two runs).
  *       n_samp must be even.
+ *   pair words (pair_words != NULL in pack_pointing, returned 1): the two detectors of a co-pointing pair -- rows 2b and
+ *       2b + 1 -- see the same pixel in every sample, so when every pair of the call agrees on its offsets (checked) and
+ *       they fit 28 bits, row 2b of d_key is rewritten as ONE word per pair-sample (offset + 1 in bits 0-27,
+ *       accumulation / projection flag of member e in bits 28 + 2 e / 29 + 2 e; row 2b + 1 is then unused) and the
+ *       sweeps, told so by their pair_words argument, read 4 + 2 x 16 B per pair-sample = 18 B per detector-sample, with
+ *       one map gather per pair-sample in the projection.
  * ---------------------------------------------------------------------------------- */
 int toast_hip_offset_pack_pointing_dev(
     const int64_t * d_g2l, int64_t n_pix_submap, const int32_t * pixel_index, const int64_t * d_pixels,
@@ -571,16 +577,16 @@ int toast_hip_offset_pack_pointing_dev(
     int64_t n_flag_samp, uint8_t det_flag_mask, const uint8_t * d_shared_flags, int64_t n_shared_flags,
     uint8_t shared_flag_mask, const int32_t * proj_flag_index, const uint8_t * d_proj_flags, int64_t n_proj_flag_samp,
     uint8_t proj_flag_mask, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
-    uint32_t * d_key, double * d_qu, double * d_cal, int * packable, void * stream);
+    uint32_t * d_key, double * d_qu, double * d_cal, int * packable, int * pair_words, void * stream);
 int toast_hip_offset_accumulate_packed_dev(
     int64_t step_length, const int64_t * amp_offsets, const int64_t * n_amp_views, const double * d_amplitudes,
     const uint8_t * d_amplitude_flags, double * d_zmap, const uint32_t * d_key, const double * d_qu, const double * d_cal,
-    const double * det_scale, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
-    void * stream);
+    const double * det_scale, int pair_words, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals,
+    int64_t n_view, void * stream);
 int toast_hip_offset_scan_project_packed_dev(
     int64_t step_length, const int64_t * amp_offsets, const int64_t * n_amp_views, const double * d_amps_in,
     double * d_amps_out, const uint8_t * d_amplitude_flags, const double * d_map, const uint32_t * d_key,
-    const double * d_qu, const double * d_cal, const double * det_weights, int64_t n_det, int64_t n_samp,
+    const double * d_qu, const double * d_cal, const double * det_weights, int pair_words, int64_t n_det, int64_t n_samp,
     const toast_hip_interval * intervals, int64_t n_view, void * stream);
 
 int toast_hip_template_offset_apply_diag_precond(

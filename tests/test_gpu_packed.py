@@ -63,7 +63,7 @@ def _setup(n_det=6, n_samp=6000, nside=64, seed=5, odd_views=True):
                 detw=0.5 + rng.random(n_det), cal=cal, zmap0=rng.standard_normal((n_local, nps, 3)))
 
 
-def _pack(s, dmask=1, smask=1, pmask=1):
+def _pack(s, dmask=1, smask=1, pmask=1, pair_words=False):
     torch, D = s["torch"], s["D"]
     key = torch.zeros((s["n_det"], s["n_samp"]), dtype=torch.int32, device=s["dev"])
     qu = torch.zeros((s["n_det"], s["n_samp"], 2), dtype=torch.float64, device=s["dev"])
@@ -71,8 +71,12 @@ def _pack(s, dmask=1, smask=1, pmask=1):
     ok = D.offset_pack_pointing(s["d_g2l"].data_ptr(), s["nps"], s["idx"], s["d_pix"].data_ptr(), s["idx"],
                                 s["d_w"].data_ptr(), s["idx"], s["d_dflags"].data_ptr(), s["n_samp"], dmask,
                                 s["d_sflags"].data_ptr(), s["n_samp"], smask, s["idx"], s["d_pflags"].data_ptr(),
-                                s["n_samp"], pmask, s["n_samp"], s["ivl"], key.data_ptr(), qu.data_ptr(), cal.data_ptr())
-    return ok, key, qu, cal
+                                s["n_samp"], pmask, s["n_samp"], s["ivl"], key.data_ptr(), qu.data_ptr(), cal.data_ptr(),
+                                pair_words=pair_words)
+    if pair_words:
+        return ok, key, qu, cal
+    assert ok[1] is False
+    return ok[0], key, qu, cal
 
 
 @pytest.mark.parametrize("n_det,odd_views", [(6, True), (5, True), (6, False)])
@@ -129,6 +133,73 @@ def test_packed_sweeps_equal_the_sweeps_over_the_original_arrays(n_det, odd_view
     a, b = za.cpu().numpy(), zb.cpu().numpy()
     assert np.any(a != 0) and np.array_equal(a != 0, b != 0)
     np.testing.assert_allclose(b, a, rtol=0, atol=1e-12 * np.max(np.abs(a)))
+
+
+def _sweeps(s, key=None, qu=None, cal=None, pair=False):
+    """(amplitudes out, zmap) of the projection and the accumulation: from the original arrays, or from a packed cache."""
+    torch, D = s["torch"], s["D"]
+    zmap = torch.from_numpy(s["zmap0"]).to(s["dev"])
+    out = torch.zeros(s["n_amp"], dtype=torch.float64, device=s["dev"])
+    z = torch.zeros((s["n_local"], s["nps"], 3), dtype=torch.float64, device=s["dev"])
+    if key is None:
+        D.offset_scan_project(s["step"], s["ao"], s["nav"], s["d_amps"].data_ptr(), out.data_ptr(), s["d_aflags"].data_ptr(),
+                              s["d_g2l"].data_ptr(), zmap.data_ptr(), s["nps"], 3, s["idx"], s["d_pix"].data_ptr(),
+                              s["idx"], s["d_w"].data_ptr(), s["idx"], s["d_pflags"].data_ptr(), 1, s["detw"], s["n_samp"],
+                              s["ivl"])
+        D.offset_accumulate(s["step"], s["ao"], s["nav"], s["d_amps"].data_ptr(), s["d_aflags"].data_ptr(),
+                            s["d_g2l"].data_ptr(), z.data_ptr(), s["nps"], 3, s["idx"], s["d_pix"].data_ptr(), s["idx"],
+                            s["d_w"].data_ptr(), s["idx"], s["d_dflags"].data_ptr(), s["n_samp"], s["detw"], 1, s["n_samp"],
+                            s["ivl"], s["d_sflags"].data_ptr(), s["n_samp"], 1)
+    else:
+        D.offset_scan_project_packed(s["step"], s["ao"], s["nav"], s["d_amps"].data_ptr(), out.data_ptr(),
+                                     s["d_aflags"].data_ptr(), zmap.data_ptr(), key.data_ptr(), qu.data_ptr(),
+                                     cal.data_ptr(), s["detw"], s["n_samp"], s["ivl"], pair_words=pair)
+        D.offset_accumulate_packed(s["step"], s["ao"], s["nav"], s["d_amps"].data_ptr(), s["d_aflags"].data_ptr(),
+                                   z.data_ptr(), key.data_ptr(), qu.data_ptr(), cal.data_ptr(), s["detw"], s["n_samp"],
+                                   s["ivl"], pair_words=pair)
+    torch.cuda.synchronize()
+    return out.cpu().numpy(), z.cpu().numpy()
+
+
+@pytest.mark.parametrize("n_det,odd_views", [(6, True), (5, True), (8, False)])
+def test_pair_words(n_det, odd_views):
+    """Co-pointing pairs share their pixels: one word per pair-sample (18 B per detector-sample), a lone last detector,
+    and the sweeps that read them against the sweeps over the original arrays."""
+    s = _setup(n_det=n_det, odd_views=odd_views)
+    (ok, pair), key, qu, cal = _pack(s, pair_words=True)
+    assert ok and pair
+    k = key.cpu().numpy().view(np.uint32)
+    ok_d, key_d, _, _ = _pack(s)                       # the per-detector words of the same rows
+    kd = key_d.cpu().numpy().view(np.uint32)
+    in_view = np.zeros(s["n_samp"], dtype=bool)
+    for v in s["ivl"]:
+        in_view[int(v["first"]):int(v["last"])] = True
+    for b in range((n_det + 1) // 2):
+        a_row, b_row = kd[2 * b], (kd[2 * b + 1] if 2 * b + 1 < n_det else None)
+        w = k[2 * b]
+        assert np.array_equal((w & 0x0fffffff)[in_view], (a_row & 0x3fffffff)[in_view])
+        assert np.array_equal(((w >> 28) & 3)[in_view], (a_row >> 30)[in_view])
+        if b_row is not None:
+            assert np.array_equal((b_row & 0x3fffffff)[in_view], (a_row & 0x3fffffff)[in_view])
+            assert np.array_equal(((w >> 30) & 3)[in_view], (b_row >> 30)[in_view])
+        else:
+            assert np.all(((w >> 30) & 3)[in_view] == 3)
+    ref_out, ref_z = _sweeps(s)
+    out, z = _sweeps(s, key, qu, cal, pair=True)
+    assert np.any(ref_out != 0) and np.any(ref_z != 0)
+    np.testing.assert_allclose(out, ref_out, rtol=0, atol=1e-12 * np.max(np.abs(ref_out)))
+    assert np.array_equal(z != 0, ref_z != 0)
+    np.testing.assert_allclose(z, ref_z, rtol=0, atol=1e-12 * np.max(np.abs(ref_z)))
+    # a pair that does not agree on a pixel: no pair words, the per-detector words still pack
+    first = int(s["ivl"][0]["first"])
+    s["d_pix"][1, first + 10] = s["d_pix"][1, first + 400]
+    assert int(s["d_pix"][1, first + 10]) != int(s["d_pix"][0, first + 10])
+    (ok, pair), key, qu, cal = _pack(s, pair_words=True)
+    assert ok and not pair
+    ref_out, ref_z = _sweeps(s)
+    out, z = _sweeps(s, key, qu, cal, pair=False)
+    np.testing.assert_allclose(out, ref_out, rtol=0, atol=1e-12 * np.max(np.abs(ref_out)))
+    np.testing.assert_allclose(z, ref_z, rtol=0, atol=1e-12 * np.max(np.abs(ref_z)))
 
 
 def test_packing_refuses_what_it_cannot_represent():

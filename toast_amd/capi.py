@@ -800,41 +800,44 @@ class _Dev:
     def offset_pack_pointing(self, d_g2l, n_pix_submap, pixel_index, d_pixels, weight_index, d_weights, acc_flag_index,
                              d_det_flags, n_flag_samp, det_flag_mask, d_shared_flags, n_shared_flags, shared_flag_mask,
                              proj_flag_index, d_proj_flags, n_proj_flag_samp, proj_flag_mask, n_samp, intervals, d_key,
-                             d_qu, d_cal, stream=0):
-        """True when the rows could be packed (toast_hip_offset_pack_pointing_dev); waits for the stream."""
+                             d_qu, d_cal, pair_words=True, stream=0):
+        """(packable, pair_words) of toast_hip_offset_pack_pointing_dev; waits for the stream."""
         pi = self._small(pixel_index, np.int32)
         wi = self._small(weight_index, np.int32)
         fa = self._small(acc_flag_index if acc_flag_index is not None else np.zeros(pi.size), np.int32)
         fp = self._small(proj_flag_index if proj_flag_index is not None else np.zeros(pi.size), np.int32)
         iv = self._small(intervals, interval_dtype)
-        ok = C.c_int(0)
+        ok, pair = C.c_int(0), C.c_int(0)
         _check(real_lib().toast_hip_offset_pack_pointing_dev(
             _p(d_g2l), _i64(n_pix_submap), _p(pi), _p(d_pixels), _p(wi), _p(d_weights), _p(fa), _p(d_det_flags),
             _i64(n_flag_samp), _u8(det_flag_mask), _p(d_shared_flags), _i64(n_shared_flags), _u8(shared_flag_mask),
             _p(fp), _p(d_proj_flags), _i64(n_proj_flag_samp), _u8(proj_flag_mask), _i64(pi.size), _i64(n_samp), _p(iv),
-            _i64(iv.size), _p(d_key), _p(d_qu), _p(d_cal), C.byref(ok), _p(stream)))
-        return bool(ok.value)
+            _i64(iv.size), _p(d_key), _p(d_qu), _p(d_cal), C.byref(ok), C.byref(pair) if pair_words else None,
+            _p(stream)))
+        return bool(ok.value), bool(pair.value)
 
     def offset_accumulate_packed(self, step_length, amp_offsets, n_amp_views, d_amplitudes, d_amplitude_flags, d_zmap,
-                                 d_key, d_qu, d_cal, det_scale, n_samp, intervals, stream=0):
+                                 d_key, d_qu, d_cal, det_scale, n_samp, intervals, pair_words=False, stream=0):
         ao = self._small(amp_offsets, np.int64)
         nv = self._small(n_amp_views, np.int64)
         ds = self._small(det_scale, np.float64)
         iv = self._small(intervals, interval_dtype)
         _check(lib().toast_hip_offset_accumulate_packed_dev(
             _i64(step_length), _p(ao), _p(nv), _p(d_amplitudes), _p(d_amplitude_flags), _p(d_zmap), _p(d_key), _p(d_qu),
-            _p(d_cal), _p(ds), _i64(ao.size), _i64(n_samp), _p(iv), _i64(iv.size), _p(stream)))
+            _p(d_cal), _p(ds), C.c_int(1 if pair_words else 0), _i64(ao.size), _i64(n_samp), _p(iv), _i64(iv.size),
+            _p(stream)))
 
     def offset_scan_project_packed(self, step_length, amp_offsets, n_amp_views, d_amps_in, d_amps_out,
                                    d_amplitude_flags, d_map, d_key, d_qu, d_cal, det_weights, n_samp, intervals,
-                                   stream=0):
+                                   pair_words=False, stream=0):
         ao = self._small(amp_offsets, np.int64)
         nv = self._small(n_amp_views, np.int64)
         dw = self._small(det_weights, np.float64)
         iv = self._small(intervals, interval_dtype)
         _check(lib().toast_hip_offset_scan_project_packed_dev(
             _i64(step_length), _p(ao), _p(nv), _p(d_amps_in), _p(d_amps_out), _p(d_amplitude_flags), _p(d_map), _p(d_key),
-            _p(d_qu), _p(d_cal), _p(dw), _i64(ao.size), _i64(n_samp), _p(iv), _i64(iv.size), _p(stream)))
+            _p(d_qu), _p(d_cal), _p(dw), C.c_int(1 if pair_words else 0), _i64(ao.size), _i64(n_samp), _p(iv),
+            _i64(iv.size), _p(stream)))
 
     def offset_scan_project_signal(self, step_length, amp_offsets, n_amp_views, signal_index, d_signal, d_amps_out,
                                    d_amplitude_flags, d_g2l, d_map, n_pix_submap, nnz, pixel_index, d_pixels,

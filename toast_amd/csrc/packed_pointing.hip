@@ -73,6 +73,241 @@ __global__ __launch_bounds__(kThreads) void k_pack_pointing(
     if (bad) atomicOr(status, bad);
 }
 
+// Pair words.  The two detectors of a co-pointing pair (rows 2b and 2b + 1 of a call) see the same pixel in every sample
+// -- the pixel kernels evaluate it once for both -- so their words differ in the flag bits only.  When that holds for
+// every sample in view of every pair (k_pair_check) and the offsets fit 28 bits (Nside <= 4096 full sky), row 2b is
+// rewritten as ONE word per sample for both detectors (k_pair_merge: offset + 1 in bits 0-27, accumulation / projection
+// flag of detector e in bits 28 + 2 e / 29 + 2 e) and the sweeps read 4 + 2 x 16 B per pair-sample = 18 B per
+// detector-sample.  A last detector without a partner becomes a pair whose second member is flagged throughout.
+constexpr uint32_t kPrIndex = 0x0fffffffu;
+__device__ __forceinline__ uint32_t pr_acc_flag(int e) { return 1u << (28 + 2 * e); }
+__device__ __forceinline__ uint32_t pr_proj_flag(int e) { return 1u << (29 + 2 * e); }
+
+__global__ __launch_bounds__(kThreads) void k_pair_check(const Chunk * __restrict__ chunks, int n_chunks, int n_det,
+                                                         const uint32_t * __restrict__ key, int64_t n_samp,
+                                                         int * __restrict__ status) {
+    const int d0 = 2 * blockIdx.x;
+    const bool lone = d0 + 1 >= n_det;
+    const uint32_t * ra = key + (int64_t)d0 * n_samp;
+    const uint32_t * rb = key + (int64_t)(lone ? d0 : d0 + 1) * n_samp;
+    int bad = 0;
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        for (int i = threadIdx.x; i < c.count; i += kThreads) {
+            const int64_t s = c.first + i;
+            const uint32_t oa = ra[s] & kPkIndex, ob = rb[s] & kPkIndex;
+            if (oa != ob || oa > kPrIndex) bad = 4;
+        }
+    }
+    if (bad) atomicOr(status, bad);
+}
+
+__global__ __launch_bounds__(kThreads) void k_pair_merge(const Chunk * __restrict__ chunks, int n_chunks, int n_det,
+                                                         uint32_t * __restrict__ key, int64_t n_samp) {
+    const int d0 = 2 * blockIdx.x;
+    const bool lone = d0 + 1 >= n_det;
+    uint32_t * ra = key + (int64_t)d0 * n_samp;
+    const uint32_t * rb = key + (int64_t)(lone ? d0 : d0 + 1) * n_samp;
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        for (int i = threadIdx.x; i < c.count; i += kThreads) {
+            const int64_t s = c.first + i;
+            const uint32_t ka = ra[s], kb = lone ? (kPkAccFlag | kPkProjFlag) : rb[s];
+            uint32_t w = ka & kPkIndex;
+            if (ka & kPkAccFlag) w |= pr_acc_flag(0);
+            if (ka & kPkProjFlag) w |= pr_proj_flag(0);
+            if (kb & kPkAccFlag) w |= pr_acc_flag(1);
+            if (kb & kPkProjFlag) w |= pr_proj_flag(1);
+            ra[s] = w;
+        }
+    }
+}
+
+// The accumulation from pair words: both detectors of a pair share the pixel, so their contributions are added before
+// the run reduction (what k_offset_accumulate_pk<2> does when it finds the keys equal, without the second key stream).
+__global__ __launch_bounds__(kThreads) void k_offset_accumulate_pr(
+    const Chunk * __restrict__ chunks, int n_chunks, int n_det, const int64_t * __restrict__ view_first,
+    const int64_t * __restrict__ view_aoff, FastDiv step_div, const int64_t * __restrict__ amp_offsets,
+    const double * __restrict__ amps, const uint8_t * __restrict__ amp_flags, const double * __restrict__ det_scale,
+    const double * __restrict__ cal, double * __restrict__ zmap, const uint32_t * __restrict__ key,
+    const double2 * __restrict__ qu, int64_t n_samp) {
+    constexpr int NNZ = 3, E = 2;
+    const int det0 = E * blockIdx.x;
+    const uint32_t * krow = key + (int64_t)det0 * n_samp;
+    bool on[E];
+    const double2 * qrow[E];
+    double ds[E], cl[E];
+    int64_t amp_offset[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        on[e] = det0 + e < n_det;
+        const int det = on[e] ? det0 + e : det0;
+        qrow[e] = qu + (int64_t)det * n_samp;
+        ds[e] = det_scale[det];
+        cl[e] = cal[det];
+        amp_offset[e] = amp_offsets[det];
+    }
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        const int64_t vfirst = view_first[c.view];
+        const int64_t vaoff = view_aoff[c.view];
+        const int head = (int)(c.first & 1);
+        const int64_t s0 = c.first + head;          // even
+        const int n_pair = (c.count - head) >> 1;
+        for (int base = 0; base < n_pair; base += kThreads) {
+            const int j = base + threadIdx.x;
+            const bool active = j < n_pair;
+            const int64_t s = s0 + 2 * (int64_t)(active ? j : 0);
+            const int64_t step_a = fastdiv(s - vfirst, step_div), step_b = fastdiv(s + 1 - vfirst, step_div);
+            const uint2 kk = *reinterpret_cast<const uint2 *>(krow + s);
+            double2 qa[E], qb[E], av[E];
+            uint8_t afa[E], afb[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                qa[e] = qrow[e][s];
+                qb[e] = qrow[e][s + 1];
+                const int64_t aa = amp_offset[e] + vaoff + step_a, ab = amp_offset[e] + vaoff + step_b;
+                afa[e] = amp_flags[aa];
+                afb[e] = amp_flags[ab];
+                av[e] = make_double2(amps[aa], amps[ab]);
+            }
+            const uint32_t ia = kk.x & kPrIndex, ib = kk.y & kPrIndex;
+            double va[E][NNZ], vb[E][NNZ];
+            bool any_a = false, any_b = false;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const bool good_a = active & on[e] & (ia != 0) & ((kk.x & pr_acc_flag(e)) == 0);
+                const bool good_b = active & on[e] & (ib != 0) & ((kk.y & pr_acc_flag(e)) == 0);
+                any_a |= good_a;
+                any_b |= good_b;
+                // tod = 0 + amplitude (unflagged amplitudes only), then * det_scale
+                const double ta = (afa[e] == 0) ? (0.0 + av[e].x) : 0.0, tb = (afb[e] == 0) ? (0.0 + av[e].y) : 0.0;
+                const double sa = ta * ds[e], sb = tb * ds[e];
+                va[e][0] = good_a ? sa * cl[e] : 0.0;
+                va[e][1] = good_a ? sa * qa[e].x : 0.0;
+                va[e][2] = good_a ? sa * qa[e].y : 0.0;
+                vb[e][0] = good_b ? sb * cl[e] : 0.0;
+                vb[e][1] = good_b ? sb * qb[e].x : 0.0;
+                vb[e][2] = good_b ? sb * qb[e].y : 0.0;
+            }
+            const int64_t kam = any_a ? (int64_t)ia - 1 : -1;
+            const int64_t kbm = any_b ? (int64_t)ib - 1 : -1;
+            double vam[NNZ], vbm[NNZ];
+#pragma unroll
+            for (int k = 0; k < NNZ; ++k) {
+                vam[k] = va[0][k] + va[1][k];
+                vbm[k] = vb[0][k] + vb[1][k];
+            }
+            scatter_runs2<NNZ>(kam, vam, kbm, vbm, zmap);
+        }
+        // the peeled first sample and the odd last one: lanes 0 and 1 of the workgroup
+        const int tail = (c.count - head) & 1;
+        if ((threadIdx.x == 0 && head) || (threadIdx.x == 1 && tail)) {
+            const int64_t s = (threadIdx.x == 0) ? c.first : c.first + c.count - 1;
+            const int64_t astep = fastdiv(s - vfirst, step_div);
+            const uint32_t k = krow[s];
+            const uint32_t idx = k & kPrIndex;
+            for (int e = 0; e < E; ++e) {
+                if (!on[e] || idx == 0 || (k & pr_acc_flag(e)) != 0) continue;
+                const int64_t a = amp_offset[e] + vaoff + astep;
+                const double t = (amp_flags[a] == 0) ? (0.0 + amps[a]) : 0.0;
+                const double sd = t * ds[e];
+                const double2 q = qrow[e][s];
+                double * z = zmap + NNZ * ((int64_t)idx - 1);
+                unsafeAtomicAdd(z, sd * cl[e]);
+                unsafeAtomicAdd(z + 1, sd * q.x);
+                unsafeAtomicAdd(z + 2, sd * q.y);
+            }
+        }
+    }
+}
+
+// The projection from pair words: one key stream and ONE map gather per pair-sample.
+__global__ __launch_bounds__(kThreads) void k_offset_scan_project_pr(
+    const Chunk * __restrict__ chunks, int n_chunks, int n_det, const int64_t * __restrict__ view_first,
+    const int64_t * __restrict__ view_aoff, FastDiv step_div, const int64_t * __restrict__ amp_offsets,
+    const double * __restrict__ amps_in, double * __restrict__ amps_out, const uint8_t * __restrict__ amp_flags,
+    const double * __restrict__ det_w, const double * __restrict__ cal, const double * __restrict__ map,
+    const uint32_t * __restrict__ key, const double2 * __restrict__ qu, int64_t n_samp) {
+    constexpr int E = 2;
+    const int det0 = E * blockIdx.x;
+    const uint32_t * krow = key + (int64_t)det0 * n_samp;
+    bool on[E];
+    const double2 * qrow[E];
+    double dw[E], cl[E];
+    int64_t amp_offset[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        on[e] = det0 + e < n_det;
+        const int det = on[e] ? det0 + e : det0;
+        qrow[e] = qu + (int64_t)det * n_samp;
+        dw[e] = det_w[det];
+        cl[e] = cal[det];
+        amp_offset[e] = amp_offsets[det];
+    }
+    auto finish = [&](bool hit, double av, double w0, double w1, double w2, double m0, double m1, double m2) {
+        double sc = 0.0;
+        sc += w0 * m0;
+        sc += w1 * m1;
+        sc += w2 * m2;
+        sc *= 1.0;
+        const double d = 0.0 + av;
+        return hit ? d - sc : d;
+    };
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        const int64_t vfirst = view_first[c.view];
+        const int64_t vaoff = view_aoff[c.view];
+        const int head = (int)(c.first & 1);
+        const int64_t s0 = c.first + head;          // even
+        const int n_pair = (c.count - head) >> 1;
+        for (int base = 0; base < n_pair; base += kThreads) {
+            const int j = base + threadIdx.x;
+            const bool active = j < n_pair;
+            const int64_t s = s0 + 2 * (int64_t)(active ? j : 0);
+            const int64_t step_a = fastdiv(s - vfirst, step_div), step_b = fastdiv(s + 1 - vfirst, step_div);
+            const uint2 kk = *reinterpret_cast<const uint2 *>(krow + s);
+            const uint32_t ia = kk.x & kPrIndex, ib = kk.y & kPrIndex;
+            const bool hit_a = ia != 0, hit_b = ib != 0;
+            const double * ma = map + (hit_a ? 3 * ((int64_t)ia - 1) : 0);
+            const double * mb = map + (hit_b ? 3 * ((int64_t)ib - 1) : 0);
+            const double a0 = ma[0], a1 = ma[1], a2 = ma[2], b0 = mb[0], b1 = mb[1], b2 = mb[2];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int64_t aa = amp_offset[e] + vaoff + step_a, ab = amp_offset[e] + vaoff + step_b;
+                const uint8_t afa = amp_flags[aa], afb = amp_flags[ab];
+                const double2 av = make_double2(amps_in[aa], amps_in[ab]);
+                const double2 qa = qrow[e][s], qb = qrow[e][s + 1];
+                const double da = finish(hit_a, av.x, cl[e], qa.x, qa.y, a0, a1, a2);
+                const double db = finish(hit_b, av.y, cl[e], qb.x, qb.y, b0, b1, b2);
+                int64_t ka = (active && on[e] && afa == 0) ? aa : (int64_t)-1;
+                int64_t kb = (active && on[e] && afb == 0) ? ab : (int64_t)-1;
+                double va[1] = {(ka >= 0 && (kk.x & pr_proj_flag(e)) == 0) ? da * dw[e] : 0.0};
+                double vb[1] = {(kb >= 0 && (kk.y & pr_proj_flag(e)) == 0) ? db * dw[e] : 0.0};
+                scatter_runs2<1>(ka, va, kb, vb, amps_out);
+            }
+        }
+        // the peeled first sample (lane 0) and the odd last one (lane 1)
+        const int tail = (c.count - head) & 1;
+        if ((threadIdx.x == 0 && head) || (threadIdx.x == 1 && tail)) {
+            const int64_t s = (threadIdx.x == 0) ? c.first : c.first + c.count - 1;
+            const int64_t astep = fastdiv(s - vfirst, step_div);
+            const uint32_t k = krow[s];
+            const uint32_t idx = k & kPrIndex;
+            const bool hit = idx != 0;
+            const double * m = map + (hit ? 3 * ((int64_t)idx - 1) : 0);
+            for (int e = 0; e < E; ++e) {
+                if (!on[e]) continue;
+                const int64_t a = amp_offset[e] + vaoff + astep;
+                if (amp_flags[a] != 0 || (k & pr_proj_flag(e)) != 0) continue;
+                const double2 q = qrow[e][s];
+                const double d = finish(hit, amps_in[a], cl[e], q.x, q.y, m[0], m[1], m[2]);
+                unsafeAtomicAdd(amps_out + a, d * dw[e]);
+            }
+        }
+    }
+}
+
 // k_offset_accumulate_v2 from the packed cache: zmap += A^T N^-1 (M a), two consecutive samples per lane, E = 2: the two
 // detectors of a co-pointing pair in one workgroup (their contributions to a pixel are added before the atomics).
 template <int E>
@@ -266,10 +501,11 @@ int toast_hip_offset_pack_pointing_dev(
     int64_t n_flag_samp, uint8_t det_flag_mask, const uint8_t * d_shared_flags, int64_t n_shared_flags,
     uint8_t shared_flag_mask, const int32_t * proj_flag_index, const uint8_t * d_proj_flags, int64_t n_proj_flag_samp,
     uint8_t proj_flag_mask, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
-    uint32_t * d_key, double * d_qu, double * d_cal, int * packable, void * stream) {
+    uint32_t * d_key, double * d_qu, double * d_cal, int * packable, int * pair_words, void * stream) {
     return guarded([&] {
         if (packable == nullptr) fail_arg("offset_pack_pointing: packable must not be null");
         *packable = 0;
+        if (pair_words != nullptr) *pair_words = 0;
         if (n_det <= 0) return;
         if (n_pix_submap <= 0) fail_arg("n_pix_submap must be positive");
         need_aligned(d_qu, "packed Q / U weights");
@@ -302,14 +538,26 @@ int toast_hip_offset_pack_pointing_dev(
         int status = 0;
         copy_to_host(&status, d_status, sizeof(int), st);     // (waits for the stream: once per solve)
         *packable = (status == 0) ? 1 : 0;
+        if (status != 0 || pair_words == nullptr || !pair_detectors()) return;
+        // co-pointing pairs: one word per pair-sample when every pair agrees on its pixels
+        const dim3 gp((unsigned)((n_det + 1) / 2), chunk_grid(n_det, chunks.size()).y, 1);
+        hipLaunchKernelGGL(k_pair_check, gp, dim3(kThreads), 0, st, (const Chunk *)(d + o_ch), (int)chunks.size(), (int)n_det,
+                           d_key, n_samp, d_status);
+        check_launch();
+        copy_to_host(&status, d_status, sizeof(int), st);
+        if (status != 0) return;
+        hipLaunchKernelGGL(k_pair_merge, gp, dim3(kThreads), 0, st, (const Chunk *)(d + o_ch), (int)chunks.size(), (int)n_det,
+                           d_key, n_samp);
+        check_launch();
+        *pair_words = 1;
     });
 }
 
 int toast_hip_offset_accumulate_packed_dev(
     int64_t step_length, const int64_t * amp_offsets, const int64_t * n_amp_views, const double * d_amplitudes,
     const uint8_t * d_amplitude_flags, double * d_zmap, const uint32_t * d_key, const double * d_qu, const double * d_cal,
-    const double * det_scale, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
-    void * stream) {
+    const double * det_scale, int pair_words, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals,
+    int64_t n_view, void * stream) {
     return guarded([&] {
         if (n_det <= 0) return;
         if (step_length <= 0) fail_arg("step_length must be positive");
@@ -328,13 +576,15 @@ int toast_hip_offset_accumulate_packed_dev(
         hipStream_t st = as_stream(stream);
         const char * d = pb.commit(st);
         const dim3 grid = chunk_grid(n_det, chunks.size());
-        const bool pr = pair_detectors() && n_det >= 2;
+        const bool pr = pair_words != 0 || (pair_detectors() && n_det >= 2);
         const dim3 gp((unsigned)(pr ? (n_det + 1) / 2 : n_det), grid.y, 1);
 #define TH_PK_ARGS                                                                                                  \
     (const Chunk *)(d + o_ch), (int)chunks.size(), (int)n_det, (const int64_t *)(d + o_vf), (const int64_t *)(d + o_va), \
         make_fastdiv(step_length), (const int64_t *)(d + o_ao), d_amplitudes, d_amplitude_flags,                    \
         (const double *)(d + o_ds), d_cal, d_zmap, d_key, reinterpret_cast<const double2 *>(d_qu), n_samp
-        if (pr) {
+        if (pair_words) {
+            hipLaunchKernelGGL(k_offset_accumulate_pr, gp, dim3(kThreads), 0, st, TH_PK_ARGS);
+        } else if (pr) {
             hipLaunchKernelGGL((k_offset_accumulate_pk<2>), gp, dim3(kThreads), 0, st, TH_PK_ARGS);
         } else {
             hipLaunchKernelGGL((k_offset_accumulate_pk<1>), gp, dim3(kThreads), 0, st, TH_PK_ARGS);
@@ -347,7 +597,7 @@ int toast_hip_offset_accumulate_packed_dev(
 int toast_hip_offset_scan_project_packed_dev(
     int64_t step_length, const int64_t * amp_offsets, const int64_t * n_amp_views, const double * d_amps_in,
     double * d_amps_out, const uint8_t * d_amplitude_flags, const double * d_map, const uint32_t * d_key,
-    const double * d_qu, const double * d_cal, const double * det_weights, int64_t n_det, int64_t n_samp,
+    const double * d_qu, const double * d_cal, const double * det_weights, int pair_words, int64_t n_det, int64_t n_samp,
     const toast_hip_interval * intervals, int64_t n_view, void * stream) {
     return guarded([&] {
         if (n_det <= 0) return;
@@ -366,6 +616,16 @@ int toast_hip_offset_scan_project_packed_dev(
         const size_t o_dw = pb.push(det_weights, sizeof(double) * n_det);
         hipStream_t st = as_stream(stream);
         const char * d = pb.commit(st);
+        if (pair_words) {
+            const dim3 gp((unsigned)((n_det + 1) / 2), chunk_grid(n_det, chunks.size()).y, 1);
+            hipLaunchKernelGGL(k_offset_scan_project_pr, gp, dim3(kThreads), 0, st, (const Chunk *)(d + o_ch),
+                               (int)chunks.size(), (int)n_det, (const int64_t *)(d + o_vf), (const int64_t *)(d + o_va),
+                               make_fastdiv(step_length), (const int64_t *)(d + o_ao), d_amps_in, d_amps_out,
+                               d_amplitude_flags, (const double *)(d + o_dw), d_cal, d_map, d_key,
+                               reinterpret_cast<const double2 *>(d_qu), n_samp);
+            check_launch();
+            return;
+        }
         hipLaunchKernelGGL(k_offset_scan_project_pk, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0, st,
                            (const Chunk *)(d + o_ch), (int)chunks.size(), (const int64_t *)(d + o_vf),
                            (const int64_t *)(d + o_va), make_fastdiv(step_length), (const int64_t *)(d + o_ao), d_amps_in,

@@ -407,14 +407,14 @@ class SolverLHS(Operator):
             self._free_pack(dict(blocks=mine))
             return None
         key_ptr, qu_ptr, cal_ptr = (m[0] for m in mine)
-        ok = capi.dev.offset_pack_pointing(
+        ok, pair = capi.dev.offset_pack_pointing(
             c["g2l_ptr"], c["nps"], ps["pi"], ps["pp"], ps["wi"], ps["wp"], ps["f_idx"], ps["f_ptr"], ps["f_ns"],
             c["det_flag_mask"], ps["s_ptr"], ps["s_n"], c["shared_flag_mask"], ps["pf_idx"], ps["pf_ptr"], ps["pf_n"],
             c["tmpl_flag_mask"], n_samp, ps["ivl"], key_ptr, qu_ptr, cal_ptr)
         if not ok:
             self._free_pack(dict(blocks=mine))
             return None
-        pk = dict(key=key_ptr, qu=qu_ptr, cal=cal_ptr, blocks=mine)
+        pk = dict(key=key_ptr, qu=qu_ptr, cal=cal_ptr, pair=pair, blocks=mine)
         packed[ps["iob"]] = (ident, pk)
         return pk
 
@@ -541,7 +541,8 @@ class SolverLHS(Operator):
             elif ps.get("pk") is not None:
                 pk = ps["pk"]
                 D.offset_accumulate_packed(ps["step"], ps["ao"], ps["nav"], c["in_ptr"], c["in_flags_ptr"], c["zmap_ptr"],
-                                           pk["key"], pk["qu"], pk["cal"], ps["detw"], ps["n_samp"], ps["ivl"])
+                                           pk["key"], pk["qu"], pk["cal"], ps["detw"], ps["n_samp"], ps["ivl"],
+                                           pair_words=pk["pair"])
             else:
                 D.offset_accumulate(ps["step"], ps["ao"], ps["nav"], c["in_ptr"], c["in_flags_ptr"], c["g2l_ptr"],
                                     c["zmap_ptr"], c["nps"], c["nnz"], ps["pi"], ps["pp"], ps["wi"], ps["wp"],
@@ -570,7 +571,7 @@ class SolverLHS(Operator):
                 pk = ps["pk"]
                 D.offset_scan_project_packed(ps["step"], ps["ao"], ps["nav"], c["in_ptr"], c["out_ptr"], c["in_flags_ptr"],
                                              c["zmap_ptr"], pk["key"], pk["qu"], pk["cal"], ps["detw"], ps["n_samp"],
-                                             ps["ivl"])
+                                             ps["ivl"], pair_words=pk["pair"])
             else:
                 D.offset_scan_project(ps["step"], ps["ao"], ps["nav"], c["in_ptr"], c["out_ptr"], c["in_flags_ptr"],
                                       c["g2l_ptr"], c["zmap_ptr"], c["nps"], c["nnz"], ps["pi"], ps["pp"], ps["wi"],
