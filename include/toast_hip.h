@@ -569,7 +569,8 @@ int toast_hip_offset_scan_project_signal_dev(
  *       they fit 28 bits, row 2b of d_key is rewritten as ONE word per pair-sample (offset + 1 in bits 0-27,
  *       accumulation / projection flag of member e in bits 28 + 2 e / 29 + 2 e; row 2b + 1 is then unused) and the
  *       sweeps, told so by their pair_words argument, read 4 + 2 x 16 B per pair-sample = 18 B per detector-sample, with
- *       one map gather per pair-sample in the projection.
+ *       one map gather per pair-sample in the projection.  toast_hip_offset_pack_pairs_dev is that step on its own, for
+ *       callers that pack their rows in several calls (pair_words = NULL there) and merge at the end.
  * ---------------------------------------------------------------------------------- */
 int toast_hip_offset_pack_pointing_dev(
     const int64_t * d_g2l, int64_t n_pix_submap, const int32_t * pixel_index, const int64_t * d_pixels,
@@ -578,6 +579,8 @@ int toast_hip_offset_pack_pointing_dev(
     uint8_t shared_flag_mask, const int32_t * proj_flag_index, const uint8_t * d_proj_flags, int64_t n_proj_flag_samp,
     uint8_t proj_flag_mask, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
     uint32_t * d_key, double * d_qu, double * d_cal, int * packable, int * pair_words, void * stream);
+int toast_hip_offset_pack_pairs_dev(uint32_t * d_key, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals,
+                                    int64_t n_view, int * pair_words, void * stream);
 int toast_hip_offset_accumulate_packed_dev(
     int64_t step_length, const int64_t * amp_offsets, const int64_t * n_amp_views, const double * d_amplitudes,
     const uint8_t * d_amplitude_flags, double * d_zmap, const uint32_t * d_key, const double * d_qu, const double * d_cal,

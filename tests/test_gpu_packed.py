@@ -259,3 +259,48 @@ def test_mapmaker_with_and_without_the_packed_cache(monkeypatch, prior):
     np.testing.assert_allclose(h1, h0, rtol=1e-7)
     assert np.max(np.abs(a1 - a0)) < 1e-9 * np.max(np.abs(a0))
     assert np.max(np.abs(m1 - m0)) < 1e-9 * np.max(np.abs(m0))
+
+
+def test_uncached_pointing_with_the_packed_cache(monkeypatch):
+    """full_pointing=False: the solver's packed cache expanded from the boresight in batches (BinMap.packed_cache) against
+    the sweeps that evaluate the pointing on the fly, and against cached pointing: the same solve."""
+    from toast_amd import capi, ops
+    from toast_amd.data import defaults
+    from toast_amd.templates import Offset
+    from test_gpu_ops import make_solver_setup
+
+    res = {}
+    for mode in ("otf", "otf_packed", "cached"):
+        seen = {}
+        for name in ("offset_accumulate_packed", "otf_offset_accumulate", "offset_pack_pointing", "offset_pack_pairs",
+                     "otf_pixels_healpix"):
+            real = getattr(capi.dev, name)
+
+            def counted(*a, _real=real, _name=name, **k):
+                seen[_name] = seen.get(_name, 0) + 1
+                return _real(*a, **k)
+
+            monkeypatch.setattr(capi.dev, name, counted)
+        data, pix, sw, truth, sky = make_solver_setup(n_det=6, noise_rms=0.1)
+        binner = ops.BinMap(pixel_dist="dist", pixel_pointing=pix, stokes_weights=sw, full_pointing=(mode == "cached"),
+                            packed_cache=(mode == "otf_packed"))
+        tmpl = Offset(step_time=20.0, noise_model=defaults.noise_model, name="baselines", good_fraction=0.2)
+        mapper = ops.MapMaker(name="mm", keep_solver_products=True, det_data=defaults.det_data, binning=binner,
+                              template_matrix=ops.TemplateMatrix(templates=[tmpl]), solve_rcond_threshold=1e-3,
+                              map_rcond_threshold=1e-3, iter_max=12, convergence=1e-30)
+        mapper.apply(data)
+        res[mode] = (np.array(mapper.history), data["mm_solve_amplitudes"]["baselines"].local.copy(),
+                     data["mm_map"].data.copy(), dict(seen))
+        monkeypatch.undo()
+    c = res["otf_packed"][3]
+    assert c.get("offset_pack_pointing", 0) >= 1 and c.get("offset_pack_pairs", 0) == 1, c
+    assert c.get("offset_accumulate_packed", 0) >= 1 and c.get("otf_offset_accumulate", 0) == 0, c
+    assert res["otf"][3].get("otf_offset_accumulate", 0) >= 1 and res["otf"][3].get("offset_pack_pointing", 0) == 0
+    for other in ("otf", "cached"):
+        h1, a1, m1, _ = res["otf_packed"]
+        h0, a0, m0, _ = res[other]
+        assert len(h1) == len(h0)
+        np.testing.assert_allclose(h1, h0, rtol=1e-7)
+        assert np.max(np.abs(a1 - a0)) < 1e-9 * np.max(np.abs(a0))
+        assert np.max(np.abs(m1 - m0)) < 1e-9 * np.max(np.abs(m0))
+

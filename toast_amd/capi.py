@@ -816,6 +816,14 @@ class _Dev:
             _p(stream)))
         return bool(ok.value), bool(pair.value)
 
+    def offset_pack_pairs(self, d_key, n_det, n_samp, intervals, stream=0):
+        """True when row 2b now holds one word per pair-sample (toast_hip_offset_pack_pairs_dev); waits for the stream."""
+        iv = self._small(intervals, interval_dtype)
+        pair = C.c_int(0)
+        _check(real_lib().toast_hip_offset_pack_pairs_dev(_p(d_key), _i64(n_det), _i64(n_samp), _p(iv), _i64(iv.size),
+                                                          C.byref(pair), _p(stream)))
+        return bool(pair.value)
+
     def offset_accumulate_packed(self, step_length, amp_offsets, n_amp_views, d_amplitudes, d_amplitude_flags, d_zmap,
                                  d_key, d_qu, d_cal, det_scale, n_samp, intervals, pair_words=False, stream=0):
         ao = self._small(amp_offsets, np.int64)

@@ -538,12 +538,34 @@ int toast_hip_offset_pack_pointing_dev(
         int status = 0;
         copy_to_host(&status, d_status, sizeof(int), st);     // (waits for the stream: once per solve)
         *packable = (status == 0) ? 1 : 0;
-        if (status != 0 || pair_words == nullptr || !pair_detectors()) return;
-        // co-pointing pairs: one word per pair-sample when every pair agrees on its pixels
+        if (status != 0 || pair_words == nullptr) return;
+        const int rc = toast_hip_offset_pack_pairs_dev(d_key, n_det, n_samp, intervals, n_view, pair_words, stream);
+        if (rc != 0) throw Error(rc, toast_hip_last_error());
+    });
+}
+
+// Co-pointing pairs: one word per pair-sample when every pair agrees on its pixels (see k_pair_check / k_pair_merge).
+// Separate from the packing so that a caller can pack its rows in several calls (batches of detectors expanded from the
+// boresight, never all in memory at once) and merge at the end.
+int toast_hip_offset_pack_pairs_dev(uint32_t * d_key, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals,
+                                    int64_t n_view, int * pair_words, void * stream) {
+    return guarded([&] {
+        if (pair_words == nullptr) fail_arg("offset_pack_pairs: pair_words must not be null");
+        *pair_words = 0;
+        if (n_det <= 0 || !pair_detectors()) return;
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        hipStream_t st = as_stream(stream);
+        ParamBlock pb;
+        const size_t o_ch = pb.push_vec(chunks);
+        const char * d = pb.commit(st);
+        int * d_status = static_cast<int *>(Manager::get().scratch(Manager::kScratchStatus, 64));
+        TH_HIP(hipMemsetAsync(d_status, 0, sizeof(int), st));
         const dim3 gp((unsigned)((n_det + 1) / 2), chunk_grid(n_det, chunks.size()).y, 1);
         hipLaunchKernelGGL(k_pair_check, gp, dim3(kThreads), 0, st, (const Chunk *)(d + o_ch), (int)chunks.size(), (int)n_det,
                            d_key, n_samp, d_status);
         check_launch();
+        int status = 0;
         copy_to_host(&status, d_status, sizeof(int), st);
         if (status != 0) return;
         hipLaunchKernelGGL(k_pair_merge, gp, dim3(kThreads), 0, st, (const Chunk *)(d + o_ch), (int)chunks.size(), (int)n_det,

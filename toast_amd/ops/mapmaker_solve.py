@@ -418,6 +418,74 @@ class SolverLHS(Operator):
         packed[ps["iob"]] = (ident, pk)
         return pk
 
+    def _pack_pass_otf(self, c, ps, ob, pixels_op, weights_op, n_submap):
+        """The packed cache of an observation whose pointing is NOT cached (full_pointing=False, packed_cache=True):
+        pixels and weights of a batch of detectors are expanded from the boresight into a bounded temporary
+        (toast_hip_otf_pixels_healpix_dev / _stokes_weights_dev), packed into the batch's rows, and the temporary goes to
+        the next batch; co-pointing pairs are merged at the end.  None when it cannot be had (see _pack_pass)."""
+        import os
+
+        from .. import capi
+        from .pointing import otf_descriptor
+
+        if os.environ.get("TOAST_HIP_PACKED_POINTING", "1") == "0":
+            return None
+        dets = ps["dets"]
+        n_det, n_samp = len(dets), int(ps["n_samp"])
+        if c["nnz"] != 3 or n_samp % 2 != 0 or n_det == 0:
+            return None
+        ident = ("otf", tuple(dets), n_samp, c["g2l_ptr"], c["nps"], id(ob), pixels_op.nside, pixels_op.nest,
+                 ps["f_ptr"], ps["f_ns"], c["det_flag_mask"], ps["s_ptr"], ps["s_n"], c["shared_flag_mask"],
+                 ps["pf_ptr"], ps["pf_n"], c["tmpl_flag_mask"], np.ascontiguousarray(ps["ivl"]).tobytes())
+        packed = self.__dict__.setdefault("_packed", {})
+        have = packed.get(ps["iob"])
+        if have is not None:
+            if have[0] == ident:
+                return have[1]
+            del packed[ps["iob"]]
+            self._free_pack(have[1])
+        D = capi.dev
+        batch = max(2, int((4 << 30) // (32 * n_samp)) // 2 * 2)       # <= 4 GB of expanded pointing at a time, whole pairs
+        batch = min(batch, n_det + (n_det & 1))
+        mine, temps = [], []
+        try:
+            for nbytes in (4 * n_det * n_samp, 16 * n_det * n_samp, 8 * n_det):
+                nbytes = max(nbytes, 16)
+                mine.append((capi.device_malloc(nbytes, -2), nbytes))
+            for nbytes in (8 * batch * n_samp, 24 * batch * n_samp, max(int(n_submap), 16)):
+                temps.append((capi.device_malloc(nbytes, -2), nbytes))
+        except RuntimeError:
+            self._free_pack(dict(blocks=mine + temps))
+            return None
+        (key_ptr, _), (qu_ptr, _), (cal_ptr, _) = mine
+        (pix_ptr, _), (w_ptr, _), (hsub_ptr, _) = temps
+        ok = True
+        try:
+            for b0 in range(0, n_det, batch):
+                bd = dets[b0:b0 + batch]
+                rows = np.arange(len(bd), dtype=np.int32)
+                pt = otf_descriptor(ob, bd, pixels_op, weights_op)
+                D.otf_pixels_healpix(pt, rows, pix_ptr, n_samp, ps["ivl"], hsub_ptr, n_submap, c["nps"])
+                D.otf_stokes_weights(pt, rows, w_ptr, n_samp, ps["ivl"])
+                pf_idx = None if ps["pf_idx"] is None else ps["pf_idx"][b0:b0 + batch]
+                good, _ = D.offset_pack_pointing(
+                    c["g2l_ptr"], c["nps"], rows, pix_ptr, rows, w_ptr, ps["f_idx"][b0:b0 + batch], ps["f_ptr"], ps["f_ns"],
+                    c["det_flag_mask"], ps["s_ptr"], ps["s_n"], c["shared_flag_mask"], pf_idx, ps["pf_ptr"], ps["pf_n"],
+                    c["tmpl_flag_mask"], n_samp, ps["ivl"], key_ptr + 4 * b0 * n_samp, qu_ptr + 16 * b0 * n_samp,
+                    cal_ptr + 8 * b0, pair_words=False)
+                if not good:
+                    ok = False
+                    break
+            pair = bool(ok and D.offset_pack_pairs(key_ptr, n_det, n_samp, ps["ivl"]))
+        finally:
+            self._free_pack(dict(blocks=temps))
+        if not ok:
+            self._free_pack(dict(blocks=mine))
+            return None
+        pk = dict(key=key_ptr, qu=qu_ptr, cal=cal_ptr, pair=pair, blocks=mine)
+        packed[ps["iob"]] = (ident, pk)
+        return pk
+
     def _fused_prepare(self, data, detectors):
         """Everything of the fused left-hand side that is not a kernel launch: residency of the
         operands, device pointers, per-observation index arrays.  Returns the launch context."""
@@ -519,6 +587,9 @@ class SolverLHS(Operator):
         if not on_the_fly:
             for ps in ctx["passes"]:
                 ps["pk"] = self._pack_pass(ctx, ps)
+        elif getattr(binning, "packed_cache", False) and self.packed_pointing:
+            for ps in ctx["passes"]:
+                ps["pk"] = self._pack_pass_otf(ctx, ps, data.obs[ps["iob"]], pixels_op, weights_op, dist.n_submap)
         return ctx
 
     @staticmethod
@@ -533,16 +604,16 @@ class SolverLHS(Operator):
             # a_out = C_a^-1 a: the noise prior term of the left-hand side (mapmaker_solve.py:409-411)
             c["prior"].add_prior(c["amps_in"], c["amps_out"])
         for ps in c["passes"]:
-            if c["on_the_fly"]:
-                D.otf_offset_accumulate(ps["pt"], ps["step"], ps["ao"], ps["nav"], c["in_ptr"], c["in_flags_ptr"],
-                                        c["g2l_ptr"], c["zmap_ptr"], c["nps"], ps["f_idx"], ps["f_ptr"], ps["f_ns"],
-                                        ps["detw"], c["det_flag_mask"], ps["n_samp"], ps["ivl"], ps["s_ptr"],
-                                        ps["s_n"], c["shared_flag_mask"])
-            elif ps.get("pk") is not None:
+            if ps.get("pk") is not None:
                 pk = ps["pk"]
                 D.offset_accumulate_packed(ps["step"], ps["ao"], ps["nav"], c["in_ptr"], c["in_flags_ptr"], c["zmap_ptr"],
                                            pk["key"], pk["qu"], pk["cal"], ps["detw"], ps["n_samp"], ps["ivl"],
                                            pair_words=pk["pair"])
+            elif c["on_the_fly"]:
+                D.otf_offset_accumulate(ps["pt"], ps["step"], ps["ao"], ps["nav"], c["in_ptr"], c["in_flags_ptr"],
+                                        c["g2l_ptr"], c["zmap_ptr"], c["nps"], ps["f_idx"], ps["f_ptr"], ps["f_ns"],
+                                        ps["detw"], c["det_flag_mask"], ps["n_samp"], ps["ivl"], ps["s_ptr"],
+                                        ps["s_n"], c["shared_flag_mask"])
             else:
                 D.offset_accumulate(ps["step"], ps["ao"], ps["nav"], c["in_ptr"], c["in_flags_ptr"], c["g2l_ptr"],
                                     c["zmap_ptr"], c["nps"], c["nnz"], ps["pi"], ps["pp"], ps["wi"], ps["wp"],
@@ -562,16 +633,16 @@ class SolverLHS(Operator):
         else:
             D.cov_apply_diag(c["n_local"], c["nps"], c["nnz"], c["cov_ptr"], c["zmap_ptr"])
         for ps in c["passes"]:
-            if c["on_the_fly"]:
-                D.otf_offset_scan_project(ps["pt"], ps["step"], ps["ao"], ps["nav"], c["in_ptr"], c["out_ptr"],
-                                          c["in_flags_ptr"], c["g2l_ptr"], c["zmap_ptr"], c["nps"], ps["pf_idx"],
-                                          ps["pf_ptr"], ps["pf_n"], c["tmpl_flag_mask"], ps["detw"], ps["n_samp"],
-                                          ps["ivl"])
-            elif ps.get("pk") is not None:
+            if ps.get("pk") is not None:
                 pk = ps["pk"]
                 D.offset_scan_project_packed(ps["step"], ps["ao"], ps["nav"], c["in_ptr"], c["out_ptr"], c["in_flags_ptr"],
                                              c["zmap_ptr"], pk["key"], pk["qu"], pk["cal"], ps["detw"], ps["n_samp"],
                                              ps["ivl"], pair_words=pk["pair"])
+            elif c["on_the_fly"]:
+                D.otf_offset_scan_project(ps["pt"], ps["step"], ps["ao"], ps["nav"], c["in_ptr"], c["out_ptr"],
+                                          c["in_flags_ptr"], c["g2l_ptr"], c["zmap_ptr"], c["nps"], ps["pf_idx"],
+                                          ps["pf_ptr"], ps["pf_n"], c["tmpl_flag_mask"], ps["detw"], ps["n_samp"],
+                                          ps["ivl"])
             else:
                 D.offset_scan_project(ps["step"], ps["ao"], ps["nav"], c["in_ptr"], c["out_ptr"], c["in_flags_ptr"],
                                       c["g2l_ptr"], c["zmap_ptr"], c["nps"], c["nnz"], ps["pi"], ps["pp"], ps["wi"],
@@ -600,7 +671,8 @@ class SolverLHS(Operator):
         amps_out = data[self.out][tmpl.name]
         key = (id(data), None if detectors is None else tuple(detectors), id(amps_in), id(amps_out),
                id(data.get(binning.binned)), id(data.get(binning.covariance)), id(data.get(binning.pixel_dist)),
-               binning.full_pointing, bool(getattr(binning, "compact_cache", False)), binning.det_flags,
+               binning.full_pointing, bool(getattr(binning, "compact_cache", False)),
+               bool(getattr(binning, "packed_cache", False)), binning.det_flags,
                binning.det_flag_mask, binning.shared_flags, binning.shared_flag_mask, binning.det_mask,
                tmpl.det_flags, tmpl.det_flag_mask, tmpl.step_time, tmpl.use_noise_prior, tmpl.precond_width,
                amps_in.accel_in_use())
