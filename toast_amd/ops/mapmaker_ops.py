@@ -689,10 +689,12 @@ class BinMap(Operator):
                                  "the accumulate kernel (not a reference trait; False = SINGLE pipelines)")
     compact_cache = Bool(False, help="With on_the_fly: keep an int32 local-pixel cache (4 B/det-sample) and "
                                      "evaluate only the Stokes weights on the fly (not a reference trait)")
-    packed_cache = Bool(False, help="With on_the_fly (IQU): let the solver keep its packed pointing cache "
+    packed_cache = Bool(True, help="With on_the_fly (IQU): let the solver keep its packed pointing cache "
                                     "(18-20 B/det-sample: local pixel offset + flag bits, Q / U weights) for the "
                                     "duration of the solve, expanded from the boresight in batches of detectors, "
-                                    "instead of evaluating the pointing in every sweep (not a reference trait)")
+                                    "instead of evaluating the pointing in every sweep; falls back to the on-the-fly "
+                                    "sweeps when the cache cannot be had (memory, nnz, odd row length); ignored with "
+                                    "compact_cache (not a reference trait)")
 
     def _validate_sync_type(self, check):
         if check not in ("allreduce", "alltoallv"):

@@ -587,7 +587,8 @@ class SolverLHS(Operator):
         if not on_the_fly:
             for ps in ctx["passes"]:
                 ps["pk"] = self._pack_pass(ctx, ps)
-        elif getattr(binning, "packed_cache", False) and self.packed_pointing:
+        elif (getattr(binning, "packed_cache", False) and self.packed_pointing
+              and not getattr(binning, "compact_cache", False)):
             for ps in ctx["passes"]:
                 ps["pk"] = self._pack_pass_otf(ctx, ps, data.obs[ps["iob"]], pixels_op, weights_op, dist.n_submap)
         return ctx

@@ -4,7 +4,7 @@ Nside 1024, rocFFT noise weighting (NoiseFilter) followed by the full MapMaker P
 offset (baseline) templates, everything through the reference's Operator names.
 
     python workflows/mapmaker_pcg.py [--ndet 1024] [--minutes 60] [--rate 200] [--nside 1024]
-                                     [--iter 10] [--step-time 1.0] [--no-filter] [--uncached [--compact | --packed]]
+                                     [--iter 10] [--step-time 1.0] [--no-filter] [--uncached [--compact | --no-packed]]
 
 Detector-sharded over several GPUs (configs[3]: --ndet is the number of detectors PER RANK):
 
@@ -63,9 +63,10 @@ def main(argv=None):
                     help="full_pointing=False (the reference default): no pointing cache, on-the-fly kernels")
     ap.add_argument("--compact", action="store_true",
                     help="with --uncached: keep a 4 B/det-sample int32 pixel cache, weights on the fly")
-    ap.add_argument("--packed", action="store_true",
-                    help="with --uncached: the solver keeps its packed pointing cache (18-20 B/det-sample), expanded "
-                         "from the boresight in batches of detectors, for the duration of the solve")
+    ap.add_argument("--no-packed", action="store_true",
+                    help="with --uncached: evaluate the pointing in both sweeps of every iteration instead of letting "
+                         "the solver keep its packed pointing cache (18-20 B/det-sample, expanded from the boresight in "
+                         "batches of detectors) for the duration of the solve")
     ap.add_argument("--profile", action="store_true", help="cProfile of the MapMaker call (top functions by own time)")
     args = ap.parse_args(argv)
 
@@ -111,7 +112,7 @@ def main(argv=None):
     pixels = ops.PixelsHealpix(detector_pointing=det_pointing, nside=args.nside, nest=True)
     weights = ops.StokesWeights(detector_pointing=det_pointing, mode="IQU", hwp_angle=defaults.hwp_angle)
     binner = ops.BinMap(pixel_dist="pixel_dist", pixel_pointing=pixels, stokes_weights=weights,
-                        full_pointing=not args.uncached, compact_cache=args.compact, packed_cache=args.packed)
+                        full_pointing=not args.uncached, compact_cache=args.compact, packed_cache=not args.no_packed)
     tmatrix = ops.TemplateMatrix(templates=[Offset(step_time=args.step_time, noise_model=defaults.noise_model,
                                                    name="baselines", use_noise_prior=args.noise_prior,
                                                    precond_width=args.precond_width)])
