@@ -95,6 +95,9 @@ int toast_hip_alloc_stats(int64_t * probed_blocks, int64_t * fast_blocks, int64_
  * them; an allocation failure or toast_hip_accel_release_cached gives them back).  Any pointer may be NULL. */
 int toast_hip_alloc_stats_ex(double * malloc_ms, double * max_malloc_ms, int64_t * budget_stops, int64_t * held_reused,
                              int64_t * held_bytes);
+/* Free and total device memory of this process' GPU (hipMemGetInfo; blocks held in the manager's cache of released
+ * blocks count as free). */
+int toast_hip_accel_mem_info(size_t * free_bytes, size_t * total_bytes);
 /* Give the cache of released device blocks (TOAST_HIP_ALLOC_CACHE_MB) and the held candidates back to the driver. */
 int toast_hip_accel_release_cached(void);
 int toast_hip_device_free(void * p);

@@ -304,3 +304,34 @@ def test_uncached_pointing_with_the_packed_cache(monkeypatch):
         assert np.max(np.abs(a1 - a0)) < 1e-9 * np.max(np.abs(a0))
         assert np.max(np.abs(m1 - m0)) < 1e-9 * np.max(np.abs(m0))
 
+
+
+def test_no_packed_cache_without_room(monkeypatch):
+    """The packed cache is built only while a fifth of the device stays free afterwards; otherwise the sweeps over the
+    original arrays run (same result)."""
+    from toast_amd import capi, ops
+    from toast_amd.data import defaults
+    from toast_amd.templates import Offset
+    from test_gpu_ops import make_solver_setup
+
+    free, total = capi.accel_mem_info()
+    assert 0 < free <= total
+    monkeypatch.setattr(capi, "accel_mem_info", lambda: (total // 5 + 1000, total))
+    seen = {}
+    for name in ("offset_pack_pointing", "offset_accumulate", "offset_accumulate_packed"):
+        real = getattr(capi.dev, name)
+
+        def counted(*a, _real=real, _name=name, **k):
+            seen[_name] = seen.get(_name, 0) + 1
+            return _real(*a, **k)
+
+        monkeypatch.setattr(capi.dev, name, counted)
+    data, pix, sw, truth, sky = make_solver_setup(noise_rms=0.1)
+    binner = ops.BinMap(pixel_dist="dist", pixel_pointing=pix, stokes_weights=sw, full_pointing=True)
+    tmpl = Offset(step_time=20.0, noise_model=defaults.noise_model, name="baselines", good_fraction=0.2)
+    mapper = ops.MapMaker(name="mm", det_data=defaults.det_data, binning=binner,
+                          template_matrix=ops.TemplateMatrix(templates=[tmpl]), solve_rcond_threshold=1e-3,
+                          map_rcond_threshold=1e-3, iter_max=5, convergence=1e-30)
+    mapper.apply(data)
+    assert seen.get("offset_pack_pointing", 0) == 0 and seen.get("offset_accumulate_packed", 0) == 0, seen
+    assert seen.get("offset_accumulate", 0) >= 1 and len(mapper.history) == 5

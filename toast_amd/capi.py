@@ -271,6 +271,13 @@ def device_release(ptr, nbytes):
     _check(real_lib().toast_hip_device_release(C.c_void_p(int(ptr)), C.c_size_t(int(nbytes))))
 
 
+def accel_mem_info():
+    """(free, total) bytes of device memory (toast_hip_accel_mem_info)."""
+    f, t = C.c_size_t(0), C.c_size_t(0)
+    _check(real_lib().toast_hip_accel_mem_info(C.byref(f), C.byref(t)))
+    return int(f.value), int(t.value)
+
+
 def accel_release_cached():
     """Released device blocks kept for reuse, and slow candidates held by the placement policy, go back to the driver."""
     _check(real_lib().toast_hip_accel_release_cached())

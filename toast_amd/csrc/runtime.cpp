@@ -1007,6 +1007,16 @@ int toast_hip_alloc_stats(int64_t * probed_blocks, int64_t * fast_blocks, int64_
     });
 }
 
+int toast_hip_accel_mem_info(size_t * free_bytes, size_t * total_bytes) {
+    return guarded([&] {
+        Manager::get().require_device();
+        size_t f = 0, t = 0;
+        TH_HIP(hipMemGetInfo(&f, &t));
+        if (free_bytes) *free_bytes = f + Manager::get().cached_bytes();    // (what the cache holds can be had back)
+        if (total_bytes) *total_bytes = t;
+    });
+}
+
 int toast_hip_accel_release_cached(void) {
     return guarded([&] { Manager::get().release_cached(); });
 }

@@ -170,6 +170,7 @@ public:
     void * scratch(int slot, size_t bytes);
     void * device_alloc(size_t nbytes);   // allocation policy of the manager (nullptr on failure)
     void release_cached() { flush_cached(); }
+    size_t cached_bytes() const { return cached_bytes_; }
     // raw blocks (toast_hip_device_malloc(flags = -2) / toast_hip_device_release) share the cache of released blocks
     void * cached_block(size_t nbytes) { return take_cached(nbytes); }
     bool keep_block(void * dev, size_t nbytes) {

@@ -366,6 +366,15 @@ class SolverLHS(Operator):
                 self._free_pack(pk)
 
     @staticmethod
+    def _room_for_pack(nbytes):
+        """The packed cache is an extra: it is built only while at least a fifth of the device stays free afterwards (a
+        data set of many observations keeps the on-the-fly / unpacked sweeps for those that do not fit)."""
+        from .. import capi
+
+        free, total = capi.accel_mem_info()
+        return free - nbytes >= total // 5
+
+    @staticmethod
     def _free_pack(pk):
         from .. import capi
 
@@ -398,6 +407,8 @@ class SolverLHS(Operator):
                 return have[1]
             del packed[ps["iob"]]
             self._free_pack(have[1])
+        if not self._room_for_pack(20 * n_det * n_samp):
+            return None
         mine = []
         try:
             for nbytes in (4 * n_det * n_samp, 16 * n_det * n_samp, 8 * n_det):
@@ -447,6 +458,8 @@ class SolverLHS(Operator):
         D = capi.dev
         batch = max(2, int((4 << 30) // (32 * n_samp)) // 2 * 2)       # <= 4 GB of expanded pointing at a time, whole pairs
         batch = min(batch, n_det + (n_det & 1))
+        if not self._room_for_pack(20 * n_det * n_samp + 32 * batch * n_samp):
+            return None
         mine, temps = [], []
         try:
             for nbytes in (4 * n_det * n_samp, 16 * n_det * n_samp, 8 * n_det):
