@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--no-operator-level", action="store_true",
                     help="skip the operator-level entry (NoiseFilter + MapMaker of workflows/mapmaker_pcg.py at cfg3; "
                          "about 10 s, most of it the host-side simulation of its inputs)")
+    ap.add_argument("--no-lhs", action="store_true",
+                    help="skip the offset-template left-hand side (operator sequence / fused / packed) on the bench buffers")
     ap.add_argument("--pcg-extra", action="store_true",
                     help="also time the full PCG LHS with offset templates (operator sequence vs fused kernels)")
     ap.add_argument("--torch-alloc", action="store_true",
@@ -682,7 +684,9 @@ def run(args, workload, world, rank, dev, headline=True):
     # (not the headline metric) the complete SolverLHS of configs[2] "full MapMaker PCG":
     # a' = M^T N^-1 (M a - A C A^T N^-1 M a) with 1 s baselines, as the reference's operator
     # sequence (8 + 41 + 8 + 48 + 9 B per det-sample, five passes) and fused (33 + 33 B, two passes).
-    if args.pcg_extra:
+    # The complete left-hand side with one Offset template on the same buffers (operator sequence, fused sweeps, fused
+    # sweeps from the packed pointing cache): part of every run; the on-the-fly / compact variants only with --pcg-extra.
+    if args.pcg_extra or not args.no_lhs:
         step_len = int(rate)  # 1 s baselines
         nav = np.array([(int(v["last"]) - int(v["first"]) + step_len - 1) // step_len for v in ivl], dtype=np.int64)
         n_amp_det = int(nav.sum())
@@ -739,6 +743,45 @@ def run(args, workload, world, rank, dev, headline=True):
             "fused_vs_sequence_max_rel_diff": err,
         }
 
+        # the same left-hand side from the solver's packed pointing cache (csrc/packed_pointing.hip: 18-20 B per
+        # det-sample instead of 33; what ops.SolverLHS sweeps after its first application)
+        pk_key = torch.empty((n_det, n_samp), dtype=torch.int32, device=dev)
+        pk_qu = torch.empty((n_det, n_samp, 2), dtype=torch.float64, device=dev)
+        pk_cal = torch.empty(n_det, dtype=torch.float64, device=dev)
+        t0 = time.time()
+        packable, pair_words = D.offset_pack_pointing(
+            d_g2l.data_ptr(), nps, idx, d_pixels.data_ptr(), idx, d_weights.data_ptr(), idx, d_dflags.data_ptr(), n_samp,
+            1, d_sflags.data_ptr(), n_samp, 1, idx, d_dflags.data_ptr(), n_samp, 1, n_samp, ivl, pk_key.data_ptr(),
+            pk_qu.data_ptr(), pk_cal.data_ptr(), stream=stream)
+        t_pack = 1e3 * (time.time() - t0)
+        if packable:
+            def lhs_packed():
+                d_zmap.zero_()
+                D.offset_accumulate_packed(step_len, amp_off, nav, d_amp_in.data_ptr(), d_amp_flags.data_ptr(),
+                                           d_zmap.data_ptr(), pk_key.data_ptr(), pk_qu.data_ptr(), pk_cal.data_ptr(),
+                                           det_w, n_samp, ivl, pair_words=pair_words, stream=stream)
+                allreduce_zmap()
+                D.cov_apply_diag(n_local, nps, nnz, d_cov.data_ptr(), d_zmap.data_ptr(), stream)
+                d_amp_out.zero_()
+                D.offset_scan_project_packed(step_len, amp_off, nav, d_amp_in.data_ptr(), d_amp_out.data_ptr(),
+                                             d_amp_flags.data_ptr(), d_zmap.data_ptr(), pk_key.data_ptr(),
+                                             pk_qu.data_ptr(), pk_cal.data_ptr(), det_w, n_samp, ivl,
+                                             pair_words=pair_words, stream=stream)
+
+            lhs_packed()
+            err_pk = float((d_amp_out - ref_out).abs().max() / ref_out.abs().max())
+            t_pk = timed(lhs_packed, 5)
+            out["pcg_lhs_offset_templates"].update({
+                "packed_ms": t_pk,
+                "packed_Gsamp_s": world * nsamp_tot / t_pk / 1e6,
+                "packed_bytes_per_det_sample_and_sweep": 18 if pair_words else 20,
+                "packed_pair_words": bool(pair_words),
+                "packed_vs_sequence_max_rel_diff": err_pk,
+                "pack_once_ms": t_pack,
+            })
+        del pk_key, pk_qu, pk_cal
+
+    if args.pcg_extra:
         # pointing on the fly: the same two operators and the same LHS
         # without the 32 B/det-sample pointing cache -- 9 + 16 B (A^T, A) and ~2 + ~2 B (offset LHS)
         pt = capi.otf_pointing(d_bore.data_ptr(), fp, nside, True, nnz, d_shared_flags=d_sflags.data_ptr(),

@@ -49,6 +49,8 @@ def test_bench_contract_small_workload():
     assert abs(d["value"] - n / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     # the fused / on-the-fly variants agree with the operator sequence
     assert d["pcg_lhs_offset_templates"]["fused_vs_sequence_max_rel_diff"] < 1e-12
+    assert d["pcg_lhs_offset_templates"]["packed_vs_sequence_max_rel_diff"] < 1e-12
+    assert d["pcg_lhs_offset_templates"]["packed_bytes_per_det_sample_and_sweep"] in (18, 20)
     assert d["pointing_on_the_fly"]["offset_lhs_vs_sequence_max_rel_diff"] < 1e-12
     assert d["compact_pixels_weights_on_the_fly"]["offset_lhs_vs_sequence_max_rel_diff"] < 1e-12
 
