@@ -165,6 +165,10 @@ def _sweeps(s, key=None, qu=None, cal=None, pair=False):
 def test_pair_words(n_det, odd_views):
     """Co-pointing pairs share their pixels: one word per pair-sample (18 B per detector-sample), a lone last detector,
     and the sweeps that read them against the sweeps over the original arrays."""
+    import os
+
+    if os.environ.get("TOAST_HIP_PAIR", "1") == "0":
+        pytest.skip("detector-pair kernels switched off")
     s = _setup(n_det=n_det, odd_views=odd_views)
     (ok, pair), key, qu, cal = _pack(s, pair_words=True)
     assert ok and pair
@@ -270,7 +274,9 @@ def test_uncached_pointing_with_the_packed_cache(monkeypatch):
     from test_gpu_ops import make_solver_setup
 
     res = {}
+    monkeypatch.setenv("TOAST_HIP_PACKED_POINTING", "1")
     for mode in ("otf", "otf_packed", "cached"):
+        monkeypatch.setenv("TOAST_HIP_PACKED_POINTING", "1")
         seen = {}
         for name in ("offset_accumulate_packed", "otf_offset_accumulate", "offset_pack_pointing", "offset_pack_pairs",
                      "otf_pixels_healpix"):
