@@ -110,7 +110,7 @@ def operator_level():
         wf = None
         gc.collect()
         try:
-            accel_assign_device(1, 0, 1.0, False)
+            accel_assign_device(1, 0, 0.0, False)     # (registered arrays go back to the arena; its slabs stay)
         except Exception:
             pass
     if "error" in st:
@@ -248,6 +248,15 @@ def run(args, workload, world, rank, dev, headline=True):
 
     # ------------------------------------------------------------------ synthetic inputs
     t_setup = time.time()
+    if not args.torch_alloc:
+        # The pool: pixels 8 + weights 24 + two timestreams 16 + flags 1 + quaternions 32 B per det-sample (the packed
+        # cache later takes the quaternions' place), taken from the driver in one piece -- the reference's mem_gb
+        # (accelerator.cpp:292-303).  A process that already holds that much (the operator-level run before this one)
+        # takes nothing.
+        capi.arena_reserve(int(74.0 * n_det * n_samp) + (1 << 30))
+        # ... and the one timestream that the step reads AND writes (scan_map's tod2) in a slab whose 1 GB chunks
+        # alternate between two HBM zones (csrc/vmm_slab.cpp): what ops' timestreams get (DetectorData, 2-D float64)
+        capi.arena_reserve(int(8.0 * n_det * n_samp) + (1 << 30), streamed=True)
     fp_all, gamma_all = synth.hex_focalplane(n_det * world, fov_deg=10.0)
     fp = np.ascontiguousarray(fp_all[rank * n_det : (rank + 1) * n_det])
     gamma = np.ascontiguousarray(gamma_all[rank * n_det : (rank + 1) * n_det])
@@ -274,30 +283,47 @@ def run(args, workload, world, rank, dev, headline=True):
     placement = None
     # Default: one allocation per buffer, which is what the product's memory manager does
     # (toast_hip::Manager::create -> hipMalloc per registered array); operators get exactly this.
-    allocator = ("toast_hip::Manager (one block per buffer through toast_hip_device_malloc: the operators' allocation "
-                 "and placement policy)")
+    allocator = ("toast_hip::Manager arena (every TOD-domain buffer is a block from toast_hip_device_malloc, i.e. a range of "
+                 "the slabs the operators' arrays live in; csrc/arena.cpp)")
     if args.torch_alloc:
         allocator = "experiment: torch caching allocator (one hipMalloc per buffer, no placement policy)"
     managed = []     # device blocks from the library's memory manager (released at the end of run())
 
-    def manager_tensor(nbytes, dtype, shape):
-        """A torch view of a block allocated by toast_hip::Manager::device_alloc -- the allocation AND placement
-        policy every operator's buffers get (toast_hip_device_malloc(flags = -1))."""
-        ptr = capi.device_malloc(nbytes, -1)
+    def manager_tensor(nbytes, dtype, shape, streamed=False):
+        """A torch view of a block from toast_hip::Manager::device_alloc -- the arena every operator's buffers come
+        from (toast_hip_device_malloc(flags = -1))."""
+        ptr = capi.device_malloc(nbytes, -3 if streamed else -1)
         managed.append(ptr)
 
         class _Block:
             pass
 
         blk = _Block()
-        typestr = {torch.int64: "<i8", torch.float64: "<f8", torch.uint8: "|u1"}[dtype]
+        typestr = {torch.int64: "<i8", torch.float64: "<f8", torch.uint8: "|u1", torch.int32: "<i4"}[dtype]
         blk.__cuda_array_interface__ = dict(shape=tuple(shape), typestr=typestr, data=(ptr, False), version=3)
         return torch.as_tensor(blk, device=dev)
+
+    def manager_release(t):
+        """Give the block behind a manager_tensor back to the arena (the caller drops its view)."""
+        ptr = t.data_ptr()
+        managed.remove(ptr)
+        torch.cuda.synchronize()
+        capi.device_free(ptr)
 
     def carve(name, dtype, shape):
         if args.torch_alloc:
             return torch.empty(shape, dtype=dtype, device=dev)
-        return manager_tensor(sizes[name], dtype, shape)
+        return manager_tensor(sizes[name], dtype, shape, streamed=(name == "tod2"))
+
+    def temp(dtype, shape):
+        """A large temporary (quaternions, the packed cache): from the arena as well, released with drop()."""
+        if args.torch_alloc:
+            return torch.empty(shape, dtype=dtype, device=dev)
+        return manager_tensor(int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size(), dtype, shape)
+
+    def drop(t):
+        if not args.torch_alloc:
+            manager_release(t)
 
     d_pixels = carve("pixels", torch.int64, (n_det, n_samp))
     d_weights = carve("weights", torch.float64, (n_det, n_samp, 3))
@@ -309,7 +335,7 @@ def run(args, workload, world, rank, dev, headline=True):
     for d0 in range(0, n_det, 128):  # bounded temporaries
         blk = d_dflags[d0:d0 + 128]
         blk.copy_((torch.rand(blk.shape, device=dev, generator=gen) < 0.005).to(torch.uint8))
-    d_quats = torch.empty((n_det, n_samp, 4), dtype=torch.float64, device=dev)
+    d_quats = temp(torch.float64, (n_det, n_samp, 4))
 
     def timed(fn, reps=1):
         e0 = torch.cuda.Event(enable_timing=True)
@@ -346,6 +372,7 @@ def run(args, workload, world, rank, dev, headline=True):
                                            np.zeros(n_det), gamma, np.ones(n_det), False, stream)
     sw_call()
     t_sw = timed(sw_call, 2)
+    drop(d_quats)
     del d_quats
     # the same two outputs straight from the boresight (no quaternion buffer)
     pt_x = capi.otf_pointing(d_bore.data_ptr(), fp, nside, True, nnz, d_shared_flags=d_sflags.data_ptr(),
@@ -623,7 +650,7 @@ def run(args, workload, world, rank, dev, headline=True):
         "setup_s": t_setup,
         "allocator": allocator,
         "placement": placement,
-        # what the manager's placement policy did for this process (blocks of 1-8 GB chosen among probed candidates)
+        # the arena's counters for this process so far: slabs taken from the driver, wall time inside hipMalloc
         "allocator_stats": capi.alloc_stats(),
         # per-step RCCL all-reduce of the device-resident zmap (fp64 sum over the detector shards);
         # kernel_ms.allreduce is its stream time on this rank (includes waiting for the slowest rank)
@@ -745,8 +772,8 @@ def run(args, workload, world, rank, dev, headline=True):
 
         # the same left-hand side from the solver's packed pointing cache (csrc/packed_pointing.hip: 18-20 B per
         # det-sample instead of 33; what ops.SolverLHS sweeps after its first application)
-        pk_key = torch.empty((n_det, n_samp), dtype=torch.int32, device=dev)
-        pk_qu = torch.empty((n_det, n_samp, 2), dtype=torch.float64, device=dev)
+        pk_key = temp(torch.int32, (n_det, n_samp))
+        pk_qu = temp(torch.float64, (n_det, n_samp, 2))
         pk_cal = torch.empty(n_det, dtype=torch.float64, device=dev)
         t0 = time.time()
         packable, pair_words = D.offset_pack_pointing(
@@ -779,6 +806,8 @@ def run(args, workload, world, rank, dev, headline=True):
                 "packed_vs_sequence_max_rel_diff": err_pk,
                 "pack_once_ms": t_pack,
             })
+        drop(pk_key)
+        drop(pk_qu)
         del pk_key, pk_qu, pk_cal
 
     if args.pcg_extra:
@@ -940,7 +969,7 @@ def run(args, workload, world, rank, dev, headline=True):
     del d_pixels, d_weights, d_tod, d_tod2, d_dflags
     for ptr in managed:
         capi.device_free(ptr)
-    capi.accel_release_cached()      # (and the candidates the placement policy still holds)
+    # (the slabs stay with the arena: a second workload of this process -- the configs[3] shard -- is carved from them)
     return out
 
 

@@ -79,31 +79,63 @@ int toast_hip_accel_enabled(void);
  * is unchanged, device pointers obtained earlier are still the ones the manager would return
  * (lets a caller replay a prepared launch sequence without looking everything up again). */
 int toast_hip_accel_generation(uint64_t * generation);
-/* Raw device memory with the memory manager's allocation and placement policy (flags = -1), a plain hipMalloc (0)
- * or explicit hipExtMallocWithFlags flags (4 = physically contiguous): what bench.py and the
- * placement experiments use so that they see the allocations the operators get. */
+/* The device memory arena [ref: OmpPoolResource, accelerator.cpp:13-230; the pool of `mem_gb` taken at assign_device,
+ * accelerator.cpp:292-303 (dormant upstream)].  Every device block of the library -- registered arrays, temporaries,
+ * the solver's packed pointing cache, FFT work space -- is a range of a slab that was taken from the driver with one
+ * hipMalloc and touched once; released blocks go back to the arena, not to the driver, so that after set-up no operator
+ * calls hipMalloc or hipFree.  TOAST_HIP_ALLOC=plain restores one hipMalloc per block; TOAST_HIP_ARENA_SLAB_GB (16) is
+ * the size of a slab taken on demand; TOAST_HIP_ARENA_RESERVE_GB overrides assign_device's mem_gb. */
+typedef struct toast_hip_arena_stats_t {
+    int64_t slabs;            /* slabs held now */
+    uint64_t slab_bytes;      /* ... their bytes */
+    uint64_t used_bytes;      /* bytes in live blocks */
+    uint64_t peak_used_bytes;
+    int64_t slab_mallocs;     /* hipMalloc calls for slabs so far */
+    int64_t slab_frees;       /* slabs given back to the driver */
+    double malloc_ms;         /* wall time inside hipMalloc (slabs, and direct blocks with TOAST_HIP_ALLOC=plain) */
+    double max_malloc_ms;     /* ... the longest single call */
+    double touch_ms;          /* host time enqueueing the first-touch fills of new slabs */
+    int64_t allocs;           /* blocks handed out */
+    int64_t releases;
+    int64_t direct_mallocs;   /* blocks that went straight to hipMalloc */
+    int64_t failed;           /* requests that could not be served */
+    /* slabs of 8 GB and more are built from 1 GB physical chunks of two different HBM zones mapped alternately
+     * (csrc/vmm_slab.cpp; TOAST_HIP_ARENA_INTERLEAVE=0 turns that off): */
+    int64_t interleaved_slabs;  /* such slabs alive */
+    int64_t chunks;             /* chunks mapped into them so far */
+    int64_t chunks_other_zone;  /* ... of which from a zone other than the slab's first chunk (ideal: half) */
+    int64_t chunks_created;     /* chunks created while searching for the second zone (the surplus is released) */
+    double interleave_ms;       /* wall time building them (part of malloc_ms) */
+    double same_zone_tbs;       /* reference rate of the zone measurement (TB/s) */
+} toast_hip_arena_stats_t;
+int toast_hip_arena_stats(toast_hip_arena_stats_t * out);
+/* Make the arena hold at least `bytes` (one more slab for the difference, at most 90 % of what the device has free). */
+int toast_hip_arena_reserve(size_t bytes);
+/* The same for the part of the arena that serves streamed blocks (below). */
+int toast_hip_arena_reserve_streamed(size_t bytes);
+/* The sub-allocation logic exercised on HOST memory (no device needed): n_ops random allocations / releases with the
+ * bookkeeping and the contents of every live block checked after each step.  0 = sound. */
+int toast_hip_arena_selftest(uint64_t seed, int n_ops, size_t granule, size_t slab_bytes, size_t max_block);
+/* Raw device memory from the arena (flags = -1, also -2; -3 = a STREAMED block: a timestream that sweeps read and write,
+ * placed in a slab whose 1 GB chunks alternate between two HBM zones -- such sweeps run at 6.1 instead of 5.1 TB/s
+ * there, read-only sweeps 5 % slower, csrc/vmm_slab.cpp), a plain hipMalloc (0) or explicit hipExtMallocWithFlags
+ * flags (4 = physically contiguous): what bench.py and the solver's packed cache use, so that they get the blocks the
+ * operators get.  Blocks from flags < 0 are released with toast_hip_device_free / toast_hip_device_release. */
 int toast_hip_device_malloc(size_t nbytes, int flags, void ** out);
-/* What the placement policy has done so far in this process (blocks of 1 .. 8 GB are chosen among up to K probed
- * candidate allocations, TOAST_HIP_ALLOC=probe[:K] | plain | contiguous; runtime.cpp Manager::device_alloc):
- * blocks chosen by probing, how many of them stream at the fast level, candidates probed, time spent probing,
- * stream rate (TB/s, read + write) of the last kept block.  Any pointer may be NULL. */
-int toast_hip_alloc_stats(int64_t * probed_blocks, int64_t * fast_blocks, int64_t * candidates, double * probe_ms,
-                          double * last_tbs);
-/* More of the same: time spent in hipMalloc for candidates and the longest single call (ms), searches ended by the
- * time budget, blocks taken from the slow candidates that earlier searches left allocated, and the bytes of such
- * candidates held right now (they live in the cache of released blocks: TOAST_HIP_ALLOC_HOLD_GB, default 24, bounds
- * them; an allocation failure or toast_hip_accel_release_cached gives them back).  Any pointer may be NULL. */
-int toast_hip_alloc_stats_ex(double * malloc_ms, double * max_malloc_ms, int64_t * budget_stops, int64_t * held_reused,
-                             int64_t * held_bytes);
-/* Free and total device memory of this process' GPU (hipMemGetInfo; blocks held in the manager's cache of released
- * blocks count as free). */
+/* Time (ms) of a read + write pass over [p, p + bytes) with the timestream kernels' access pattern (1024 rows in
+ * flight): placement experiments on ranges of arena blocks. */
+int toast_hip_probe_stream(void * p, size_t bytes, double * ms);
+/* Experiment (csrc/vmm_slab.cpp vmm_pair_matrix): rate of a pass over two 1 GB ranges for every (physical chunk,
+ * virtual slot) combination; out[n_phys * n_slots] in TB/s. */
+int toast_hip_exp_vmm_pair_matrix(int n_phys, int n_slots, double * out);
+/* The same pass with the 1024 rows dealt round-robin to nb <= 4 separate ranges of bytes_each. */
+int toast_hip_probe_stream_split(void * const * bases, int nb, size_t bytes_each, double * ms);
+/* Free and total device memory of this process' GPU (hipMemGetInfo; free ranges of the arena's slabs count as free). */
 int toast_hip_accel_mem_info(size_t * free_bytes, size_t * total_bytes);
-/* Give the cache of released device blocks (TOAST_HIP_ALLOC_CACHE_MB) and the held candidates back to the driver. */
+/* Give the arena's slabs that hold no live block back to the driver. */
 int toast_hip_accel_release_cached(void);
+/* Give a block back: to the arena when it came from it (after the manager's stream has drained), else hipFree. */
 int toast_hip_device_free(void * p);
-/* toast_hip_device_malloc(flags = -2): like -1, but a block of exactly this size that the manager kept when it was released
- * is handed out first; toast_hip_device_release gives a block to that cache (TOAST_HIP_ALLOC_CACHE_MB) instead of the
- * driver -- for temporaries of a recurring size (the solver's packed pointing cache: one allocation per solve). */
 int toast_hip_device_release(void * p, size_t nbytes);
 /* Experiment: virtual range backed by chunk_mb-sized physical allocations mapped in order / shuffled
  * (tools/exp_alloc_flags.py, profiles/r02_d_placement_experiments.txt).  The range is never released. */
@@ -132,6 +164,9 @@ int toast_hip_accel_present(const void * host, size_t nbytes, int * present);
 /* Allocate a device buffer of nbytes keyed by the host base pointer.  Error if the key is
  * already present.  [ref: accelerator.cpp:327-388 create] */
 int toast_hip_accel_create(const void * host, size_t nbytes, const char * name);
+/* The same for an array that sweeps read AND write (a detector timestream): a streamed block of the arena (see
+ * toast_hip_device_malloc, flags = -3). */
+int toast_hip_accel_create_streamed(const void * host, size_t nbytes, const char * name);
 
 /* Zero the device copy.  [ref: accelerator.cpp:593-654 reset] */
 int toast_hip_accel_reset(const void * host, size_t nbytes, const char * name);

@@ -195,3 +195,18 @@ def test_unopenable_library_is_reported_not_replaced():
     env["TOAST_HIP_RCCL_LIB"] = "/nonexistent/librccl.so"
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0 and "reported" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_arena_suballocation_on_host_memory():
+    """The device arena's bookkeeping (csrc/arena.cpp: best fit over address-ordered free ranges, split, merge with both
+    neighbours, slabs of the default size or of the request) exercised on host memory through the C ABI: random
+    allocations and releases with the ranges checked after every step, live blocks checked for overlap by content, and
+    everything back in one free range per slab at the end.  Reference pool: accelerator.cpp:13-230 (OmpPoolResource)."""
+    from toast_amd import capi
+
+    for seed in range(4):
+        capi.arena_selftest(seed, 1500, 512, 1 << 20, 300000)        # the small arena's shape, blocks up to 0.3 slab
+    capi.arena_selftest(11, 600, 4096, 1 << 20, 3 << 20)             # requests above the slab size: slabs of their own
+    capi.arena_selftest(12, 400, 2 << 20, 16 << 20, 12 << 20)        # the large arena's granule
+    with pytest.raises(RuntimeError):
+        capi.arena_selftest(1, 10, 0, 1 << 20, 100)

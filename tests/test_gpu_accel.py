@@ -292,10 +292,11 @@ def test_mapmaker_under_memory_cap(tmp_path, pointing):
     assert np.all(np.abs(free[2:] - capped[2:]) <= 1e-9 * np.abs(free[2:]))
 
 
-def test_placement_policy_of_the_memory_manager():
-    """Blocks of 1 .. 8 GB are chosen among probed candidate allocations (Manager::device_alloc, DESIGN.md section 3):
-    the policy runs for raw blocks (what bench.py allocates) and for registered arrays alike, counts what it did, and
-    ``TOAST_HIP_ALLOC=plain`` turns it off."""
+def test_arena_serves_every_block_without_the_driver():
+    """The device arena (csrc/arena.cpp; reference: OmpPoolResource, accelerator.cpp:13-230): raw blocks (what bench.py
+    and the packed cache allocate) and registered arrays are ranges of slabs; releasing and allocating again does not
+    call hipMalloc; contents survive the neighbours; ``release_cached`` gives empty slabs back; ``TOAST_HIP_ALLOC=plain``
+    turns it off."""
     import subprocess
     import sys
     import textwrap
@@ -304,84 +305,92 @@ def test_placement_policy_of_the_memory_manager():
         import numpy as np
         from toast_amd import capi
         from toast_amd.accel import accel_assign_device, accel_data_create, accel_data_delete, accel_data_update_device, accel_data_update_host
-        accel_assign_device(1, 0, 1.0, False)
+        accel_assign_device(1, 0, 2.0, False)                  # mem_gb = 2: the reservation
         s0 = capi.alloc_stats()
-        small = capi.device_malloc(64 << 20)                  # below the probed size class
-        assert capi.alloc_stats()["probed_blocks"] == s0["probed_blocks"]
-        big = [capi.device_malloc(3 << 29) for _ in range(3)]  # 1.5 GB each
+        small = capi.device_malloc(64 << 20)
+        big = [capi.device_malloc(3 << 28) for _ in range(2)]  # 0.75 GB each: inside the 2 GB
         s1 = capi.alloc_stats()
-        for p in big + [small]:
-            capi.device_free(p)
-        host = np.arange((5 << 28) // 8, dtype=np.float64)     # 1.25 GB registered array: same policy
+        host = np.arange((1 << 28) // 8, dtype=np.float64)     # 256 MB registered array
         accel_data_create(host, "big")
         accel_data_update_device(host, "big")
+        tiny = np.arange(100, dtype=np.int32)                  # below 1 MB: the small arena
+        accel_data_create(tiny, "tiny")
+        accel_data_update_device(tiny, "tiny")
+        for p in big + [small]:
+            capi.device_free(p)
+        again = [capi.device_malloc(3 << 28) for _ in range(2)]
+        s2 = capi.alloc_stats()
         host2 = host.copy(); host[:] = 0
         accel_data_update_host(host, "big")
-        assert np.array_equal(host, host2)                     # the probe pass ran before the upload, not after
+        assert np.array_equal(host, host2)
+        tiny2 = tiny.copy(); tiny[:] = 0
+        accel_data_update_host(tiny, "tiny")
+        assert np.array_equal(tiny, tiny2)
         accel_data_delete(host, "big")
-        s2 = capi.alloc_stats()
-        print("STATS", s1["probed_blocks"] - s0["probed_blocks"], s1["candidates"] - s0["candidates"],
-              s2["probed_blocks"] - s1["probed_blocks"], s1["last_TBs"], s1["probe_ms"])
+        accel_data_delete(tiny, "tiny")
+        for p in again:
+            capi.device_free(p)
+        s3 = capi.alloc_stats()
+        accel_assign_device(1, 0, 2.0, False)                  # clear(): the slabs stay
+        s4 = capi.alloc_stats()
+        capi.accel_release_cached()
+        s5 = capi.alloc_stats()
+        print("STATS", s0["slab_mallocs"], s0["slab_GB"], s1["slab_mallocs"], s2["slab_mallocs"], s3["used_GB"],
+              s4["slab_mallocs"], s4["slabs"], s5["slabs"], s2["direct_mallocs"])
     """)
     env = dict(os.environ)
-    env.pop("TOAST_HIP_ALLOC", None)
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600,
-                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    for key in ("TOAST_HIP_ALLOC", "TOAST_HIP_ARENA_RESERVE_GB", "TOAST_HIP_ARENA_SLAB_GB"):
+        env.pop(key, None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     f = [ln for ln in out.stdout.splitlines() if ln.startswith("STATS")][0].split()
-    blocks, cands, blocks_reg, tbs, ms = int(f[1]), int(f[2]), int(f[3]), float(f[4]), float(f[5])
-    assert blocks == 3 and 3 <= cands <= 3 * 8 and blocks_reg == 1 and 2.0 < tbs < 8.0 and 0.0 < ms < 1000.0
+    m0, gb0, m1, m2, used3, m4, slabs4, slabs5, direct = (int(f[1]), float(f[2]), int(f[3]), int(f[4]), float(f[5]),
+                                                          int(f[6]), int(f[7]), int(f[8]), int(f[9]))
+    assert m0 == 1 and abs(gb0 - 2.0) < 0.01        # the reservation: one slab of mem_gb
+    assert m1 == 1                                  # 64 MB + 2 x 0.75 GB fit into it
+    assert m2 == 2                                  # + one 64 MB slab of the small arena for `tiny`; none for the second round
+    assert used3 == 0.0 and m4 == 2 and slabs4 == 2 and slabs5 == 0 and direct == 0
     env["TOAST_HIP_ALLOC"] = "plain"
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600,
-                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     f = [ln for ln in out.stdout.splitlines() if ln.startswith("STATS")][0].split()
-    assert int(f[1]) == 0 and int(f[2]) == 0 and int(f[3]) == 0
+    assert int(f[3]) == 0 and int(f[4]) == 0 and int(f[9]) >= 7
 
 
-def test_placement_policy_holds_slow_candidates_between_searches():
-    """Candidates that a search measured and passed over stay allocated (in the cache of released blocks, marked with
-    their rate) so that the driver cannot hand the same ranges to the next search; they are a last resort for later
-    blocks of the size, never what ``create`` takes from the cache, bounded by TOAST_HIP_ALLOC_HOLD_GB, and given back by
-    toast_hip_accel_release_cached.  TOAST_HIP_ALLOC_ACCEPT_TBS=100 makes every candidate "slow"."""
+def test_arena_grows_by_slabs():
+    """A request that no free range holds takes a new slab (TOAST_HIP_ARENA_SLAB_GB, or the request when that is larger);
+    slabs that still hold a block stay when the empty ones are given back."""
     import subprocess
     import sys
     import textwrap
 
     code = textwrap.dedent("""
-        import numpy as np
         from toast_amd import capi
-        from toast_amd.accel import accel_assign_device, accel_data_create, accel_data_delete
-        accel_assign_device(1, 0, 1.0, False)
-        n = 3 << 29                                            # 1.5 GB
-        a = capi.device_malloc(n)
+        from toast_amd.accel import accel_assign_device
+        accel_assign_device(1, 0, 0.0, False)
+        a = capi.device_malloc(1 << 28)                        # 256 MB -> a 1 GB slab (the default size here)
         s1 = capi.alloc_stats()
-        b = capi.device_malloc(n)
+        b = capi.device_malloc(3 << 30)                        # 3 GB -> a slab of its own size
         s2 = capi.alloc_stats()
-        host = np.zeros(n // 8)                                # a registered array of the size: not a held candidate
-        accel_data_create(host, "x")
+        c = capi.device_malloc(1 << 29)                        # 512 MB: fits the first slab
         s3 = capi.alloc_stats()
-        accel_data_delete(host, "x")
-        capi.accel_release_cached()
+        capi.device_free(b)
+        capi.accel_release_cached()                            # the 3 GB slab is empty, the first one is not
         s4 = capi.alloc_stats()
-        print("HELD", s1["candidates"], s1["held_GB"], s2["candidates"], s2["held_GB"], s3["probed_blocks"],
-              s4["held_GB"], s2["fast_blocks"])
+        capi.device_free(a); capi.device_free(c)
+        print("STATS", s1["slabs"], s1["slab_GB"], s2["slabs"], s2["slab_GB"], s3["slabs"], s4["slabs"], s4["slab_frees"])
     """)
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
-    for key in ("TOAST_HIP_ALLOC", "TOAST_HIP_ALLOC_CACHE_MB", "TOAST_HIP_ALLOC_HOLD_GB", "TOAST_HIP_ALLOC_PROBE_MIN_MB",
-                "TOAST_HIP_ALLOC_PROBE_MAX_GB"):
+    for key in ("TOAST_HIP_ALLOC", "TOAST_HIP_ARENA_RESERVE_GB"):
         env.pop(key, None)
-    env.update(TOAST_HIP_ALLOC_ACCEPT_TBS="100", TOAST_HIP_ALLOC_BUDGET_MS="100000")
+    env["TOAST_HIP_ARENA_SLAB_GB"] = "1"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
-    f = [ln for ln in out.stdout.splitlines() if ln.startswith("HELD")][0].split()
-    c1, h1, c2, h2, blocks3, h4, fast = int(f[1]), float(f[2]), int(f[3]), float(f[4]), int(f[5]), float(f[6]), int(f[7])
-    assert c1 == 8 and abs(h1 - 7 * 1.5) < 1e-6          # eight candidates, one kept, seven held
-    assert c2 == 16 and 7 * 1.5 - 1e-6 <= h2 <= 24.0      # the second search: eight new ones, best of all fifteen
-    assert blocks3 == 3 and h4 == 0.0 and fast == 0       # create() searched as well (a held block is not a cached one)
-    env["TOAST_HIP_ALLOC_HOLD_GB"] = "0"
-    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600, cwd=root)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
-    f = [ln for ln in out.stdout.splitlines() if ln.startswith("HELD")][0].split()
-    assert float(f[2]) == 0.0 and float(f[4]) == 0.0
+    f = [ln for ln in out.stdout.splitlines() if ln.startswith("STATS")][0].split()
+    assert int(f[1]) == 1 and abs(float(f[2]) - 1.0) < 1e-6
+    assert int(f[3]) == 2 and abs(float(f[4]) - 4.0) < 1e-6 and int(f[5]) == 2
+    assert int(f[6]) == 1 and int(f[7]) == 1
+
+

@@ -48,7 +48,8 @@ def ensure_assigned():
     if not _assigned:
         nproc = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
         rank = int(os.environ.get("LOCAL_RANK", "0"))
-        accel_assign_device(max(nproc, 1), rank, 1.0, False)
+        # the reference's default pool size and its knob (src/toast/mpi.py:60-63)
+        accel_assign_device(max(nproc, 1), rank, float(os.environ.get("TOAST_GPU_MEM_GB", "2.0")), False)
 
 
 def accel_get_device():
@@ -104,8 +105,9 @@ def add_eviction_handler(fn):
     _eviction_handlers.append(fn)
 
 
-def accel_data_create(data, name="None", zero_out=False, owner=None):
-    """reference accel.py:147-176.  ``owner``: object whose lifetime bounds the device copy."""
+def accel_data_create(data, name="None", zero_out=False, owner=None, streamed=False):
+    """reference accel.py:147-176.  ``owner``: object whose lifetime bounds the device copy.  ``streamed``: the array is a
+    timestream that kernels read and write in their sweeps (toast_hip_accel_create_streamed)."""
     import weakref
 
     ensure_assigned()
@@ -113,7 +115,7 @@ def accel_data_create(data, name="None", zero_out=False, owner=None):
     if arr.size == 0:
         return data
     try:
-        native().accel_create(arr, name)
+        native().accel_create(arr, name, bool(streamed))
     except RuntimeError as err:
         if "allocation failed" not in str(err):
             raise
@@ -122,7 +124,7 @@ def accel_data_create(data, name="None", zero_out=False, owner=None):
             freed += int(fn() or 0)
         if freed == 0:
             raise
-        native().accel_create(arr, name)
+        native().accel_create(arr, name, bool(streamed))
     if zero_out:
         native().accel_reset(arr, name)
     if owner is not None:

@@ -267,8 +267,24 @@ def device_free(ptr):
 
 
 def device_release(ptr, nbytes):
-    """Give a block from ``device_malloc(nbytes, -2)`` to the manager's cache of released blocks (or to the driver)."""
+    """Give a block from ``device_malloc`` back to the arena (same as ``device_free``)."""
     _check(real_lib().toast_hip_device_release(C.c_void_p(int(ptr)), C.c_size_t(int(nbytes))))
+
+
+def device_malloc_vmm(nbytes, chunk_mb, shuffled=False):
+    """EXPERIMENT: a virtual range backed by separately created physical chunks (toast_hip_device_malloc_vmm)."""
+    out = C.c_void_p(0)
+    _check(real_lib().toast_hip_device_malloc_vmm(C.c_size_t(int(nbytes)), C.c_int(int(chunk_mb)), _int(shuffled),
+                                                  C.byref(out)))
+    return int(out.value or 0)
+
+
+def probe_stream_split(ptrs, nbytes_each):
+    """ms of the probe pass with its rows dealt round-robin to the ranges ``ptrs`` (toast_hip_probe_stream_split)."""
+    ms = C.c_double(0.0)
+    arr = (C.c_void_p * len(ptrs))(*[int(p) for p in ptrs])
+    _check(real_lib().toast_hip_probe_stream_split(arr, C.c_int(len(ptrs)), C.c_size_t(int(nbytes_each)), C.byref(ms)))
+    return float(ms.value)
 
 
 def accel_mem_info():
@@ -283,18 +299,44 @@ def accel_release_cached():
     _check(real_lib().toast_hip_accel_release_cached())
 
 
+class _ArenaStats(C.Structure):
+    _fields_ = [("slabs", C.c_int64), ("slab_bytes", C.c_uint64), ("used_bytes", C.c_uint64),
+                ("peak_used_bytes", C.c_uint64), ("slab_mallocs", C.c_int64), ("slab_frees", C.c_int64),
+                ("malloc_ms", C.c_double), ("max_malloc_ms", C.c_double), ("touch_ms", C.c_double),
+                ("allocs", C.c_int64), ("releases", C.c_int64), ("direct_mallocs", C.c_int64), ("failed", C.c_int64),
+                ("interleaved_slabs", C.c_int64), ("chunks", C.c_int64), ("chunks_other_zone", C.c_int64),
+                ("chunks_created", C.c_int64), ("interleave_ms", C.c_double), ("same_zone_TBs", C.c_double)]
+
+
 def alloc_stats():
-    """Placement policy counters of this process (toast_hip_alloc_stats)."""
-    pb, fb, cd = C.c_int64(0), C.c_int64(0), C.c_int64(0)
-    ms, tbs = C.c_double(0.0), C.c_double(0.0)
-    _check(real_lib().toast_hip_alloc_stats(C.byref(pb), C.byref(fb), C.byref(cd), C.byref(ms), C.byref(tbs)))
-    mm, mx = C.c_double(0.0), C.c_double(0.0)
-    bs, hr, hb = C.c_int64(0), C.c_int64(0), C.c_int64(0)
-    _check(real_lib().toast_hip_alloc_stats_ex(C.byref(mm), C.byref(mx), C.byref(bs), C.byref(hr), C.byref(hb)))
-    return dict(probed_blocks=int(pb.value), fast_blocks=int(fb.value), candidates=int(cd.value),
-                probe_ms=float(ms.value), last_TBs=float(tbs.value), malloc_ms=float(mm.value),
-                max_malloc_ms=float(mx.value), budget_stops=int(bs.value), held_reused=int(hr.value),
-                held_GB=float(hb.value) / 2.0 ** 30)
+    """Counters of the device memory arena of this process (toast_hip_arena_stats): slabs held, bytes in live blocks,
+    hipMalloc calls and the wall time inside them."""
+    st = _ArenaStats()
+    _check(real_lib().toast_hip_arena_stats(C.byref(st)))
+    out = {name: getattr(st, name) for name, _ in _ArenaStats._fields_}
+    out["slab_GB"] = out.pop("slab_bytes") / 2.0 ** 30
+    out["used_GB"] = out.pop("used_bytes") / 2.0 ** 30
+    out["peak_used_GB"] = out.pop("peak_used_bytes") / 2.0 ** 30
+    return out
+
+
+def arena_reserve(nbytes, streamed=False):
+    """Make the arena (or its part for streamed blocks) hold at least ``nbytes`` (toast_hip_arena_reserve[_streamed])."""
+    fn = real_lib().toast_hip_arena_reserve_streamed if streamed else real_lib().toast_hip_arena_reserve
+    _check(fn(C.c_size_t(int(nbytes))))
+
+
+def arena_selftest(seed, n_ops, granule, slab_bytes, max_block):
+    """The arena's sub-allocation logic on host memory (toast_hip_arena_selftest); raises on an inconsistency."""
+    _check(real_lib().toast_hip_arena_selftest(C.c_uint64(int(seed)), C.c_int(int(n_ops)), C.c_size_t(int(granule)),
+                                               C.c_size_t(int(slab_bytes)), C.c_size_t(int(max_block))))
+
+
+def probe_stream(ptr, nbytes):
+    """ms of one read + write pass over a device range with 1024 rows in flight (toast_hip_probe_stream)."""
+    ms = C.c_double(0.0)
+    _check(real_lib().toast_hip_probe_stream(C.c_void_p(int(ptr)), C.c_size_t(int(nbytes)), C.byref(ms)))
+    return float(ms.value)
 
 
 def accel_update_device_parts(buf, part_end, name="NA"):

@@ -1,0 +1,107 @@
+// arena.hpp -- the device memory arena of libtoast_hip.
+//
+// Reference counterpart: OmpPoolResource, /root/reference/src/toast/_libtoast/accelerator.cpp:13-230 (one pool of
+// `mem_gb` per process taken at assign_device, :233-306 -- dormant upstream: the constructor call is commented out).
+// Same role, different shape: the pool here is a set of SLABS taken from the driver with one hipMalloc each, touched
+// once, and never given back while the process computes; every device block the library hands out -- registered
+// arrays, temporaries, the packed pointing cache, FFT work space, parameter-block storage, scratch -- is a range of a
+// slab.  After set-up no operator phase calls hipMalloc or hipFree: on this driver a hipMalloc costs 0.3 .. 300 ms
+// per GB depending on how much freed memory it still has to clear, a first touch 12 .. 17 ms per GB, and a hipFree
+// synchronises the device.
+//
+// Sub-allocation: address-ordered free ranges per slab, best fit over all slabs (smallest range that holds the request;
+// ties: lowest address), split on allocation, merged with both neighbours on release.  Two instances with different
+// granules keep the kilobyte-sized blocks (interval lists, per-detector scalars) out of the ranges the gigabyte-sized
+// ones need: Manager::device_alloc sends requests below 1 MB to the small arena.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace toast_hip {
+
+struct ArenaStats {
+    int64_t slabs = 0;            // slabs currently held
+    size_t slab_bytes = 0;        // ... their bytes
+    size_t used_bytes = 0;        // bytes in live blocks (granule-rounded)
+    size_t peak_used_bytes = 0;
+    int64_t slab_mallocs = 0;     // hipMalloc calls so far (slabs ever taken)
+    int64_t slab_frees = 0;       // slabs given back (trim / destroy)
+    double malloc_ms = 0.0;       // wall time inside those hipMalloc calls
+    double max_malloc_ms = 0.0;   // ... the longest one
+    double touch_ms = 0.0;        // host time spent enqueueing the first-touch fills (the fills themselves are asynchronous)
+    int64_t allocs = 0;           // blocks handed out
+    int64_t releases = 0;
+    int64_t failed = 0;           // requests that could not be served
+};
+
+// Where slabs come from.  The product uses hip_backend(); host_backend() (plain malloc, no fill) exists so that the
+// sub-allocation logic can be exercised without a GPU (toast_hip_arena_selftest, tests/test_capi_load.py).
+struct ArenaBackend {
+    void * (*take)(size_t bytes, hipStream_t st);             // nullptr on failure (st: where measuring passes run)
+    void (*give)(void * p);
+    void (*touch)(void * p, size_t bytes, hipStream_t st);    // first-touch fill, enqueued on st (may be a no-op)
+};
+const ArenaBackend & hip_backend();          // hipMalloc
+const ArenaBackend & hip_interleaved_backend();   // rank-interleaved slabs (vmm_slab.cpp) when they can be had, else hipMalloc
+const ArenaBackend & host_backend();
+
+class Arena {
+public:
+    // granule: every block is a multiple of it and aligned to it; slab_default: size of a slab taken on demand when
+    // the request is smaller (requests above it get a slab of their own size)
+    // slab_round: slab sizes are multiples of it (the large arena: 1 GB, the chunk size of rank-interleaved slabs)
+    Arena(size_t granule, size_t slab_default, const ArenaBackend & backend = hip_backend(), size_t slab_round = 0)
+        : granule_(granule), slab_default_(slab_default), slab_round_(slab_round ? slab_round : granule), be_(backend) {}
+    ~Arena() = default;   // (process exit: the driver reclaims the slabs; nothing may call HIP from a static destructor)
+
+    // nullptr when neither a free range nor a new slab can hold the request.  `stream`: where the first-touch fill
+    // of a new slab is enqueued (work that uses the block must be ordered after it: same stream, or an event).
+    // grow = false: only from the free ranges of the slabs already held
+    void * alloc(size_t nbytes, hipStream_t stream, bool grow = true);
+    // false when p is not a live block of this arena
+    bool release(void * p);
+    bool owns(const void * p) const;
+    // make the capacity (free + used) at least `bytes` by taking ONE more slab for the difference; false if the
+    // driver refuses
+    bool reserve(size_t bytes, hipStream_t stream);
+    // give slabs without live blocks back to the driver; returns the bytes released
+    size_t trim();
+    // forget everything (all slabs are freed, live blocks included): device change / tests
+    void destroy();
+    size_t free_bytes() const;
+    size_t capacity() const;
+    size_t largest_free() const;
+    ArenaStats stats() const;
+    // consistency of the bookkeeping (ranges tile every slab, free ranges are merged, counters add up); "" if sound
+    std::string check() const;
+    void set_slab_default(size_t b) { slab_default_ = b; }
+    size_t slab_default() const { return slab_default_; }
+
+private:
+    struct Slab {
+        char * base = nullptr;
+        size_t bytes = 0;
+        std::map<size_t, size_t> free;   // offset -> length of the free ranges (address order, never adjacent)
+        std::map<size_t, size_t> live;   // offset -> length of the blocks handed out
+    };
+    Slab * new_slab(size_t bytes, hipStream_t stream);
+    size_t round_up(size_t n) const { return (n + granule_ - 1) / granule_ * granule_; }
+    size_t round_slab(size_t n) const { return (n + slab_round_ - 1) / slab_round_ * slab_round_; }
+
+    size_t granule_;
+    size_t slab_default_;
+    size_t slab_round_;
+    ArenaBackend be_;
+    std::vector<Slab> slabs_;
+    ArenaStats st_;
+    mutable std::mutex mutex_;
+};
+
+}  // namespace toast_hip

@@ -2966,9 +2966,51 @@ __global__ __launch_bounds__(kThreads) void k_probe_stream(double * __restrict__
     }
 }
 
+// The same pass over rows that are dealt round-robin to up to four separate ranges (row r lives in range r % nb):
+// placement experiments -- does it matter where in HBM the rows that are in flight together sit?
+struct ProbeBases {
+    double * p[4];
+};
+__global__ __launch_bounds__(kThreads) void k_probe_stream_split(ProbeBases b, int nb, int64_t row_len, double one) {
+    const int r = blockIdx.x;
+    double * row = b.p[r % nb] + (int64_t)(r / nb) * row_len;
+    for (int64_t c0 = (int64_t)blockIdx.y * 1024; c0 < row_len; c0 += (int64_t)gridDim.y * 1024) {
+        for (int i = threadIdx.x; i < 1024 && c0 + i < row_len; i += kThreads) row[c0 + i] = row[c0 + i] * one;
+    }
+}
+
 }  // namespace
 
 namespace toast_hip {
+double probe_stream_split_ms(void * const * bases, int nb, size_t bytes_each, hipStream_t st) {
+    if (nb < 1 || nb > 4) fail_arg("probe_stream_split: 1 .. 4 ranges");
+    const int64_t rows = 1024;
+    const int64_t rows_each = rows / nb;
+    const int64_t row_len = (int64_t)(bytes_each / sizeof(double)) / rows_each;
+    if (row_len < 1024) return 0.0;
+    ProbeBases b;
+    for (int k = 0; k < 4; ++k) b.p[k] = static_cast<double *>(bases[k < nb ? k : 0]);
+    hipEvent_t e0, e1;
+    TH_HIP(hipEventCreate(&e0));
+    TH_HIP(hipEventCreate(&e1));
+    int64_t gy = (row_len + 1023) / 1024;
+    if (gy > 65535) gy = 65535;
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        TH_HIP(hipEventRecord(e0, st));
+        hipLaunchKernelGGL(k_probe_stream_split, dim3((unsigned)(rows_each * nb), (unsigned)gy), dim3(kThreads), 0, st, b, nb,
+                           row_len, 1.0);
+        TH_HIP(hipEventRecord(e1, st));
+        TH_HIP(hipEventSynchronize(e1));
+        float ms = 0.0f;
+        TH_HIP(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return (double)best;
+}
+
 double probe_stream_ms(void * block, size_t bytes, hipStream_t st) {
     const int64_t rows = 1024;
     const int64_t row_len = (int64_t)(bytes / sizeof(double)) / rows;

@@ -114,8 +114,8 @@ struct CachedBlock {
 };
 
 // Most-recently-used list of uploaded blocks; bounded in bytes.  Device storage is carved out of
-// 8 MB slabs (bump allocation): committing a new block costs one async copy, never a hipMalloc or
-// a synchronisation on the launch path.  When the cache is full everything is dropped at once
+// 8 MB slabs from the manager's arena (bump allocation): committing a new block costs one async copy, never a
+// hipMalloc or a synchronisation on the launch path.  When the cache is full everything is dropped at once
 // (one device synchronisation per ~256 MB of distinct parameter blocks).
 std::list<CachedBlock> g_blocks;
 size_t g_block_bytes = 0;
@@ -140,8 +140,8 @@ char * slab_alloc(size_t bytes, int device) {
         }
     }
     Slab s{nullptr, need > kSlabBytes ? need : kSlabBytes, 0, device};
-    void * p = nullptr;
-    TH_HIP(hipMalloc(&p, s.bytes));
+    void * p = Manager::get().device_alloc(s.bytes);
+    if (p == nullptr) throw Error(TOAST_HIP_ERR_MEMORY, "HipManager:  parameter block storage, allocation failed");
     s.base = static_cast<char *>(p);
     s.used = need;
     g_slabs.push_back(s);
@@ -150,14 +150,19 @@ char * slab_alloc(size_t bytes, int device) {
 
 void drop_all_blocks() {
     // Blocks still referenced by queued kernels must outlive them.
-    TH_HIP(hipDeviceSynchronize());
-    for (auto & s : g_slabs) (void)hipFree(s.base);
+    (void)hipDeviceSynchronize();
+    for (auto & s : g_slabs) Manager::get().device_free(s.base);
     g_slabs.clear();
     g_blocks.clear();
     g_block_bytes = 0;
 }
 
 }  // namespace
+
+void drop_param_blocks() {
+    std::lock_guard<std::mutex> lock(g_block_mutex);
+    drop_all_blocks();
+}
 
 const char * ParamBlock::commit(hipStream_t stream) {
     int dev = 0;
@@ -321,50 +326,8 @@ size_t pin_threshold() {
     return v;
 }
 
-// Released blocks of at least 64 MB are kept for the next create of exactly that size instead of
-// going back to the driver: the map-maker allocates and frees the same multi-GB temporaries in
-// every phase (temp_RHS, the ApplyAmplitudes timestream, per-batch quaternions), and hipMalloc costs
-// up to ~27 ms per GB on some boxes (0.3 ms on others).  TOAST_HIP_ALLOC_CACHE_MB caps the bytes
-// held (default 32768, 0 disables); the cache is emptied when an allocation fails and on clear().
-void * Manager::take_cached(size_t nbytes) {
-    for (size_t i = 0; i < free_blocks_.size(); ++i) {
-        // (candidates that the placement policy measured as slow are only handed out by device_alloc, as a last resort)
-        if (free_blocks_[i].second == nbytes && free_blocks_[i].slow_tbs <= 0.0) {
-            void * p = free_blocks_[i].first;
-            free_blocks_.erase(free_blocks_.begin() + (long)i);
-            cached_bytes_ -= nbytes;
-            return p;
-        }
-    }
-    return nullptr;
-}
-
-bool Manager::keep_cached(void * dev, size_t nbytes, double slow_tbs) {
-    static const size_t cap = [] {
-        const char * s = std::getenv("TOAST_HIP_ALLOC_CACHE_MB");
-        return (size_t)((s != nullptr) ? std::atol(s) : 32768) << 20;
-    }();
-    if (nbytes < ((size_t)64 << 20) || cap == 0) return false;
-    while (!free_blocks_.empty() && cached_bytes_ + nbytes > cap) {   // oldest first
-        (void)hipFree(free_blocks_.front().first);
-        cached_bytes_ -= free_blocks_.front().second;
-        free_blocks_.erase(free_blocks_.begin());
-    }
-    if (cached_bytes_ + nbytes > cap) return false;
-    free_blocks_.push_back(FreeBlock{dev, nbytes, slow_tbs});
-    cached_bytes_ += nbytes;
-    return true;
-}
-
-void Manager::flush_cached() {
-    for (auto & b : free_blocks_) (void)hipFree(b.first);
-    free_blocks_.clear();
-    cached_bytes_ = 0;
-}
-
 // Grow-only scratch buffers owned by the manager (so: per process = per device, released by
-// clear()).  A failed growth leaves the slot empty -- never a dangling pointer -- and is retried once
-// after the cache of released blocks has been given back to the driver.
+// clear()): blocks of the arena.  A failed growth leaves the slot empty -- never a dangling pointer.
 void * Manager::scratch(int slot, size_t bytes) {
     // keyed by the CURRENT device: the device-pointer entry points (toast_hip_*_dev) serve callers
     // that own their device memory and never went through assign_device()
@@ -377,17 +340,10 @@ void * Manager::scratch(int slot, size_t bytes) {
         void * old = s.first;
         s.first = nullptr;
         s.second = 0;
-        TH_HIP(hipFree(old));
+        device_free(old);
     }
-    void * p = nullptr;
-    hipError_t e = hipMalloc(&p, bytes ? bytes : 16);
-    if ((e != hipSuccess || p == nullptr) && !free_blocks_.empty()) {
-        (void)hipGetLastError();
-        flush_cached();
-        e = hipMalloc(&p, bytes ? bytes : 16);
-    }
-    if (e != hipSuccess || p == nullptr) {
-        (void)hipGetLastError();
+    void * p = device_alloc(bytes ? bytes : 16);
+    if (p == nullptr) {
         std::ostringstream o;
         o << "HipManager:  scratch buffer of " << bytes << " bytes on device " << dev
           << ", allocation failed";
@@ -399,9 +355,11 @@ void * Manager::scratch(int slot, size_t bytes) {
 }
 
 void Manager::clear() {
-    flush_cached();
+    // Everything goes back to the ARENA, nothing to the driver: the next phase, solve or benchmark of this process
+    // finds its memory where the last one left it (toast_hip_accel_release_cached returns the slabs).
+    if (!table_.empty() || !scratch_.empty()) (void)hipDeviceSynchronize();
     for (auto & kv : scratch_) {
-        if (kv.second.first) (void)hipFree(kv.second.first);
+        if (kv.second.first) device_free(kv.second.first);
     }
     scratch_.clear();
     if (upload_stream_ != nullptr) (void)hipStreamSynchronize(upload_stream_);
@@ -409,14 +367,14 @@ void Manager::clear() {
         for (hipEvent_t ev : kv.second.part_done) (void)hipEventDestroy(ev);
         kv.second.part_done.clear();
         unpin(kv.first, kv.second);
-        if (kv.second.owned) (void)hipFree(kv.second.dev);
+        if (kv.second.owned) device_free(kv.second.dev);
     }
     table_.clear();
     owned_bytes_ = 0;
     ++generation_;
 }
 
-void Manager::assign_device(int node_procs, int node_rank, double /*mem_gb*/, bool disabled) {
+void Manager::assign_device(int node_procs, int node_rank, double mem_gb, bool disabled) {
     // accelerator.cpp:236-246
     if (node_procs < 1 || node_rank < 0) {
         throw Error(TOAST_HIP_ERR_ARG,
@@ -431,13 +389,26 @@ void Manager::assign_device(int node_procs, int node_rank, double /*mem_gb*/, bo
         if (hipGetDeviceCount(&n_dev) != hipSuccess) n_dev = 0;
     }
     if (n_dev == 0) {
+        if (device_ >= 0) drop_arenas();
         device_ = -1;
     } else {
         // accelerator.cpp:276-281: ceil(node_procs / n_dev) processes share a device
         int per = node_procs / n_dev;
         if (n_dev * per < node_procs) per += 1;
-        device_ = node_rank / per;
+        const int dev = node_rank / per;
+        if (dev != device_) drop_arenas();    // (slabs belong to the device they were taken on)
+        device_ = dev;
         TH_HIP(hipSetDevice(device_));
+        // accelerator.cpp:296-300 (dormant upstream): this process' share of `mem_gb` becomes the pool.  Here the
+        // pool can grow past it (a slab per request that does not fit), so the number is a reservation, not a limit:
+        // what it covers is taken from the driver -- and touched -- now instead of inside the first operators.
+        // TOAST_HIP_ARENA_RESERVE_GB overrides the argument (0 = reserve nothing).
+        double gb = mem_gb / (double)per;
+        if (const char * e = std::getenv("TOAST_HIP_ARENA_RESERVE_GB")) gb = std::atof(e);
+        if (gb > 0.0) reserve((size_t)(gb * 1073741824.0));
+        if (const char * e = std::getenv("TOAST_HIP_ARENA_STREAM_GB")) {
+            if (std::atof(e) > 0.0) reserve((size_t)(std::atof(e) * 1073741824.0), true);
+        }
     }
     assigned_ = true;
 }
@@ -490,177 +461,157 @@ int Manager::present(const void * host, size_t nbytes) {
     return 1;
 }
 
-// One allocation function for everything large the manager owns.
-//
-// Placement policy.  The time-major kernels stream one piece of each of ~1000 detector rows at a time, and how fast an
-// allocation streams under that pattern depends on where the driver placed it: 5.05 or 5.99 TB/s, for the lifetime of
-// the allocation (profiles/r02_d_placement_experiments.txt); the headline moves by 12 % with it.
-// Only measuring an allocation tells.  So blocks of the size class that shows the two levels (1 GB .. 8 GB: the
-// timestreams and the pixel numbers; the 17.7 GB weight buffers show a 2.5 % spread and are not probed) are chosen
-// among up to K candidates: each candidate gets one row-parallel read + write pass with the kernels' own access
-// pattern (k_probe_stream, after a first-touch pass); the first one that streams at the fast level is taken, otherwise
-// the fastest of the K.  Candidates are held until the choice is made (a freed slow region would simply be handed out
-// again) and the losers are then released.  Cost: one ~5 ms probe per block on a box that hands out fast memory, K of
-// them on one that does not.
-//   TOAST_HIP_ALLOC=probe[:K]   the policy with K candidates (default: probe:8; a candidate costs ~2 ms, and with ~40 %
-//                               of them at the fast level four were not enough in one process out of ten)
-//   TOAST_HIP_ALLOC=plain       one hipMalloc per block, no probing
-//   TOAST_HIP_ALLOC=contiguous  hipDeviceMallocContiguous for blocks >= 256 MB (experiment: always the slow level)
-// Returns nullptr on failure.
+// One allocation function for everything the library keeps on the device.
+//   TOAST_HIP_ALLOC=arena        (default) ranges of slabs taken once from the driver (arena.hpp)
+//   TOAST_HIP_ALLOC=plain        one hipMalloc / hipFree per block (experiments; what rounds 1-2 did)
+//   TOAST_HIP_ARENA_SLAB_GB      size of a slab taken on demand (default 16; a larger request gets a slab of its own size)
+//   TOAST_HIP_ARENA_RESERVE_GB   taken at assign_device (default: its mem_gb argument / processes per device)
+// Blocks below 1 MB live in an arena of their own (64 MB slabs, 512-byte granule) so that they cannot split the
+// ranges the timestream-sized blocks need; the large arena works in 2 MB granules (the driver's large-fragment size).
 namespace {
 struct AllocPolicy {
-    bool contiguous = false;
-    int probe_k = 8;
-    double accept_tbs = 5.65;   // read + write bytes / probe time: between the two levels (5.05-5.4 and 5.9-6.0)
-    size_t max_bytes = size_t(8) << 30;   // TOAST_HIP_ALLOC_PROBE_MAX_GB
-    double budget_ms = 60.0;              // TOAST_HIP_ALLOC_BUDGET_MS: what a candidate may cost (two dearer ones in a row end the search)
-    size_t hold_bytes = size_t(24) << 30;  // TOAST_HIP_ALLOC_HOLD_GB: slow candidates kept allocated between searches
-    size_t min_bytes = size_t(1) << 30;    // TOAST_HIP_ALLOC_PROBE_MIN_MB
+    bool plain = false;
+    size_t slab_bytes = size_t(16) << 30;
 };
 const AllocPolicy & alloc_policy() {
     static const AllocPolicy pol = [] {
         AllocPolicy a;
         const char * e = std::getenv("TOAST_HIP_ALLOC");
-        if (e != nullptr) {
-            const std::string v(e);
-            if (v == "contiguous") {
-                a.contiguous = true;
-                a.probe_k = 0;
-            } else if (v == "plain") {
-                a.probe_k = 0;
-            } else if (v.rfind("probe", 0) == 0) {
-                const char * c = std::strchr(e, ':');
-                const int k = c ? std::atoi(c + 1) : 8;
-                a.probe_k = k < 2 ? 2 : (k > 32 ? 32 : k);
-            }
-        }
-        const char * t = std::getenv("TOAST_HIP_ALLOC_ACCEPT_TBS");
-        if (t != nullptr && std::atof(t) > 0.0) a.accept_tbs = std::atof(t);
-        const char * b = std::getenv("TOAST_HIP_ALLOC_BUDGET_MS");
-        if (b != nullptr && std::atof(b) > 0.0) a.budget_ms = std::atof(b);
-        const char * h = std::getenv("TOAST_HIP_ALLOC_HOLD_GB");
-        if (h != nullptr && std::atol(h) >= 0) a.hold_bytes = (size_t)std::atol(h) << 30;
-        const char * n = std::getenv("TOAST_HIP_ALLOC_PROBE_MIN_MB");
-        if (n != nullptr && std::atol(n) >= 16) a.min_bytes = (size_t)std::atol(n) << 20;
-        const char * m = std::getenv("TOAST_HIP_ALLOC_PROBE_MAX_GB");
-        if (m != nullptr && std::atol(m) > 0) a.max_bytes = (size_t)std::atol(m) << 30;
+        if (e != nullptr && std::string(e) == "plain") a.plain = true;
+        const char * g = std::getenv("TOAST_HIP_ARENA_SLAB_GB");
+        if (g != nullptr && std::atof(g) > 0.0) a.slab_bytes = (size_t)(std::atof(g) * 1073741824.0);
         return a;
     }();
     return pol;
 }
-AllocStats g_alloc_stats;
+constexpr size_t kSmallBlock = size_t(1) << 20;
+Arena & big_arena() {
+    static Arena a(size_t(2) << 20, alloc_policy().slab_bytes, hip_backend(), size_t(1) << 30);
+    return a;
+}
+// written timestreams (device_alloc(streamed = true)): slabs of 8 GB built from 1 GB chunks of two HBM zones
+constexpr size_t kStreamBlock = size_t(1) << 30;
+Arena & stream_arena() {
+    static Arena a(size_t(2) << 20, size_t(8) << 30, hip_interleaved_backend(), size_t(1) << 30);
+    return a;
+}
+bool stream_arena_enabled() {
+    static const bool on = [] {
+        const char * e = std::getenv("TOAST_HIP_ARENA_INTERLEAVE");
+        return !(e != nullptr && e[0] == '0');
+    }();
+    return on;
+}
+Arena & small_arena() {
+    static Arena a(512, size_t(64) << 20);
+    return a;
+}
+struct DirectStats {
+    int64_t mallocs = 0;
+    double malloc_ms = 0.0, max_malloc_ms = 0.0;
+} g_direct;
 }  // namespace
 
-const AllocStats & alloc_stats() { return g_alloc_stats; }
+AllocStats alloc_stats() {
+    AllocStats o;
+    for (Arena * a : {&big_arena(), &small_arena(), &stream_arena()}) {
+        const ArenaStats s = a->stats();
+        o.slabs += s.slabs;
+        o.slab_bytes += s.slab_bytes;
+        o.used_bytes += s.used_bytes;
+        o.peak_used_bytes += s.peak_used_bytes;
+        o.slab_mallocs += s.slab_mallocs;
+        o.slab_frees += s.slab_frees;
+        o.malloc_ms += s.malloc_ms;
+        o.max_malloc_ms = s.max_malloc_ms > o.max_malloc_ms ? s.max_malloc_ms : o.max_malloc_ms;
+        o.touch_ms += s.touch_ms;
+        o.allocs += s.allocs;
+        o.releases += s.releases;
+        o.failed += s.failed;
+    }
+    o.direct_mallocs = g_direct.mallocs;
+    o.malloc_ms += g_direct.malloc_ms;
+    o.max_malloc_ms = g_direct.max_malloc_ms > o.max_malloc_ms ? g_direct.max_malloc_ms : o.max_malloc_ms;
+    return o;
+}
 
-void * Manager::device_alloc(size_t nbytes) {
-    const AllocPolicy & pol = alloc_policy();
-    const size_t lo = pol.min_bytes, hi = pol.max_bytes;
-    if (pol.probe_k > 0 && nbytes >= lo && nbytes <= hi) {
-        std::vector<void *> cand;
-        std::vector<double> tbs;
-        size_t best = 0;
-        // A candidate normally costs ~5 ms (hipMalloc, first-touch pass, timed pass).  On a box whose memory is still
-        // being cleared after another process hipMalloc can take ~200 ms per 5.9 GB, candidate after candidate: the
-        // search stops when two candidates in a row have each cost more than `budget_ms`.  (One slow call says little:
-        // the driver also stalls a SINGLE hipMalloc for seconds when it runs out of cleared memory, and the next ones
-        // are quick again -- counting that against the block would leave it with the one candidate.)  A cap on the
-        // whole search bounds the worst case.
-        const auto t_start = std::chrono::steady_clock::now();
-        auto ms_since = [](std::chrono::steady_clock::time_point t) {
-            return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
-        };
-        int slow_in_a_row = 0;
-        for (int k = 0; k < pol.probe_k; ++k) {
-            if (k > 0 && (slow_in_a_row >= 2 || ms_since(t_start) > 40.0 * pol.budget_ms)) {
-                ++g_alloc_stats.budget_stops;
-                break;
-            }
-            const auto t_cand = std::chrono::steady_clock::now();
-            void * c = nullptr;
-            if (hipMalloc(&c, nbytes) != hipSuccess) {
-                (void)hipGetLastError();
-                break;   // memory is short: make do with the candidates so far
-            }
-            const double malloc_ms = ms_since(t_cand);
-            g_alloc_stats.malloc_ms += malloc_ms;
-            if (malloc_ms > g_alloc_stats.max_malloc_ms) g_alloc_stats.max_malloc_ms = malloc_ms;
-            const double ms = probe_stream_ms(c, nbytes, stream_);
-            cand.push_back(c);
-            tbs.push_back(ms > 0.0 ? 2.0 * (double)nbytes / ms / 1.0e9 : 0.0);
-            g_alloc_stats.probe_ms += ms;
-            ++g_alloc_stats.candidates;
-            slow_in_a_row = (ms_since(t_cand) > pol.budget_ms) ? slow_in_a_row + 1 : 0;
-            if (tbs.back() > tbs[best]) best = cand.size() - 1;
-            if (tbs.back() >= pol.accept_tbs) break;
+void * Manager::device_alloc(size_t nbytes, bool streamed) {
+    if (nbytes == 0) nbytes = 16;
+    if (alloc_policy().plain) {
+        void * p = nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        const hipError_t e = hipMalloc(&p, nbytes);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return nullptr;
         }
-        // Slow candidates of EARLIER searches for this size are still allocated (below: they sit in the cache of
-        // released blocks, which keeps the driver from handing the same ranges out again): if none of the new ones is
-        // fast either, the best of all of them is taken.
-        const size_t n_new = cand.size();
-        if (cand.empty() || tbs[best] < pol.accept_tbs) {
-            for (const FreeBlock & b : free_blocks_) {
-                if (b.second == nbytes && b.slow_tbs > 0.0) {
-                    cand.push_back(b.first);
-                    tbs.push_back(b.slow_tbs);
-                    if (tbs.back() > tbs[best]) best = cand.size() - 1;
-                }
-            }
-        }
-        if (!cand.empty()) {
-            ++g_alloc_stats.probed_blocks;
-            if (tbs[best] >= pol.accept_tbs) ++g_alloc_stats.fast_blocks;
-            g_alloc_stats.last_tbs = tbs[best];
-            if (trace_enabled()) {
-                std::string line;
-                for (size_t k = 0; k < cand.size(); ++k) {
-                    line += (k ? " " : "") + std::to_string(tbs[k]) + (k >= n_new ? "(held)" : "");
-                }
-                std::fprintf(stderr, "[toast_hip] probe         %.1f MB: %s TB/s, kept #%zu\n", nbytes / 1.0e6, line.c_str(),
-                             best);
-            }
-            void * chosen = cand[best];
-            if (best >= n_new) {
-                // a held one: out of the cache
-                for (size_t i = 0; i < free_blocks_.size(); ++i) {
-                    if (free_blocks_[i].first == chosen) {
-                        free_blocks_.erase(free_blocks_.begin() + (long)i);
-                        cached_bytes_ -= nbytes;
-                        break;
-                    }
-                }
-                ++g_alloc_stats.held_reused;
-            }
-            // The losers stay allocated in the cache of released blocks, marked with their rate (a rate of 0 would make
-            // them ordinary released blocks): at most `hold_bytes` of them, inside that cache's own cap, and given back
-            // with the rest of the cache when memory runs short.
-            size_t held = 0;
-            for (const FreeBlock & b : free_blocks_) held += (b.slow_tbs > 0.0) ? b.second : 0;
-            for (size_t k = 0; k < n_new; ++k) {
-                if (k == best) continue;
-                if (held + nbytes <= pol.hold_bytes && keep_cached(cand[k], nbytes, tbs[k] > 0.0 ? tbs[k] : 1.0e-3)) {
-                    held += nbytes;
-                } else {
-                    (void)hipFree(cand[k]);
-                }
-            }
-            return chosen;
-        }
+        ++g_direct.mallocs;
+        g_direct.malloc_ms += ms;
+        if (ms > g_direct.max_malloc_ms) g_direct.max_malloc_ms = ms;
+        return p;
     }
-    void * p = nullptr;
-    if (pol.contiguous && nbytes >= (size_t(256) << 20)) {
-        if (hipExtMallocWithFlags(&p, nbytes, hipDeviceMallocContiguous) == hipSuccess && p != nullptr) return p;
-        (void)hipGetLastError();
-        p = nullptr;
+    if (streamed && nbytes >= kStreamBlock && stream_arena_enabled()) {
+        // Streamed blocks come from what has been RESERVED for them (toast_hip_arena_reserve_streamed,
+        // TOAST_HIP_ARENA_STREAM_GB at assign_device): building an interleaved slab takes 0.3 s and more, which is set-up
+        // work -- never something an operator pays for in passing.  Without a reservation they are ordinary blocks.
+        void * p = stream_arena().alloc(nbytes, stream_, false);
+        if (p != nullptr) return p;
     }
-    if (hipMalloc(&p, nbytes ? nbytes : 16) != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;
+    Arena & a = nbytes < kSmallBlock ? small_arena() : big_arena();
+    void * p = a.alloc(nbytes, stream_);
+    if (p == nullptr) {
+        // the driver refused a slab: slabs that hold nothing may be what is in the way (a 16 GB default slab with one
+        // block in it does not move, but empty ones do); then exactly what is asked for
+        if (big_arena().trim() + small_arena().trim() + stream_arena().trim() > 0) p = a.alloc(nbytes, stream_);
+    }
+    if (p != nullptr && trace_enabled() && nbytes >= kSmallBlock) {
+        const ArenaStats s = a.stats();
+        std::fprintf(stderr, "[toast_hip] arena alloc   %10.3f MB -> %p  (%lld slabs, %.1f of %.1f GB in use)\n", nbytes / 1.0e6, p,
+                     (long long)s.slabs, s.used_bytes / 1.0e9, s.slab_bytes / 1.0e9);
     }
     return p;
 }
 
-void * Manager::create(const void * host, size_t nbytes, const char * name) {
+void Manager::device_free(void * p) {
+    if (p == nullptr) return;
+    if (big_arena().release(p) || small_arena().release(p) || stream_arena().release(p)) return;
+    (void)hipFree(p);
+}
+
+size_t Manager::release_cached() {
+    (void)hipDeviceSynchronize();
+    return big_arena().trim() + small_arena().trim() + stream_arena().trim();
+}
+
+size_t Manager::cached_bytes() const {
+    return big_arena().free_bytes() + small_arena().free_bytes() + stream_arena().free_bytes();
+}
+
+void Manager::reserve(size_t bytes, bool streamed) {
+    if (alloc_policy().plain || bytes == 0) return;
+    if (streamed && !stream_arena_enabled()) return;
+    Arena & arena = streamed ? stream_arena() : big_arena();
+    // never more than 90 % of what the device has free right now: a reservation is a hint, not worth a failure
+    size_t f = 0, t = 0;
+    if (hipMemGetInfo(&f, &t) != hipSuccess) return;
+    const size_t have = arena.capacity();
+    if (bytes <= have) return;
+    size_t want = bytes - have;
+    if (want > f / 10 * 9) want = f / 10 * 9;
+    if (want < (size_t(64) << 20)) return;
+    (void)arena.reserve(have + want, stream_);
+}
+
+void Manager::drop_arenas() {
+    (void)hipDeviceSynchronize();
+    drop_param_blocks();
+    big_arena().destroy();
+    small_arena().destroy();
+    stream_arena().destroy();
+}
+
+void * Manager::create(const void * host, size_t nbytes, const char * name, bool streamed) {
     require_device();
     auto it = table_.find(host);
     if (it != table_.end()) {
@@ -682,19 +633,8 @@ void * Manager::create(const void * host, size_t nbytes, const char * name) {
     }();
     hipError_t e = hipErrorOutOfMemory;
     if (limit == 0 || owned_bytes_ + nbytes <= limit) {
-        dev = take_cached(nbytes);
-        if (dev != nullptr) {
-            e = hipSuccess;
-        } else {
-            dev = device_alloc(nbytes);
-            e = (dev != nullptr) ? hipSuccess : hipErrorOutOfMemory;
-            if (dev == nullptr && !free_blocks_.empty()) {
-                // the cache of released blocks is holding the memory: give it back and retry
-                flush_cached();
-                dev = device_alloc(nbytes);
-                e = (dev != nullptr) ? hipSuccess : hipErrorOutOfMemory;
-            }
-        }
+        dev = device_alloc(nbytes, streamed);
+        e = (dev != nullptr) ? hipSuccess : hipErrorOutOfMemory;
     }
     if (e != hipSuccess || dev == nullptr) {
         (void)hipGetLastError();
@@ -889,7 +829,7 @@ void Manager::remove(const void * host, size_t nbytes, const char * name) {
     TH_HIP(hipStreamSynchronize(stream_));
     unpin(host, e);
     if (e.owned) {
-        if (!keep_cached(e.dev, e.nbytes)) TH_HIP(hipFree(e.dev));
+        device_free(e.dev);
         owned_bytes_ -= (e.nbytes <= owned_bytes_) ? e.nbytes : owned_bytes_;
     }
     trace("delete", e.name, nbytes, t0);
@@ -993,18 +933,118 @@ const char * toast_hip_last_error(void) { return g_last_error.c_str(); }
 
 const char * toast_hip_version(void) { return "toast_hip 0.1 (gfx950)"; }
 
-// Raw device allocations with the manager's policy (experiments, bench.py): flags as in
-// hipExtMallocWithFlags (0 default, 4 hipDeviceMallocContiguous), -1 = the manager's own policy.
-int toast_hip_alloc_stats(int64_t * probed_blocks, int64_t * fast_blocks, int64_t * candidates, double * probe_ms,
-                          double * last_tbs) {
+// Raw device blocks from the manager's arena (bench.py, the solver's packed pointing cache, experiments): flags -1
+// (and the older -2) = Manager::device_alloc; 0 = a plain hipMalloc; > 0 = hipExtMallocWithFlags flags.
+int toast_hip_arena_stats(toast_hip_arena_stats_t * out) {
     return guarded([&] {
-        const AllocStats & a = alloc_stats();
-        if (probed_blocks) *probed_blocks = a.probed_blocks;
-        if (fast_blocks) *fast_blocks = a.fast_blocks;
-        if (candidates) *candidates = a.candidates;
-        if (probe_ms) *probe_ms = a.probe_ms;
-        if (last_tbs) *last_tbs = a.last_tbs;
+        if (out == nullptr) fail_arg("toast_hip_arena_stats: out is NULL");
+        const AllocStats a = alloc_stats();
+        out->slabs = a.slabs;
+        out->slab_bytes = a.slab_bytes;
+        out->used_bytes = a.used_bytes;
+        out->peak_used_bytes = a.peak_used_bytes;
+        out->slab_mallocs = a.slab_mallocs;
+        out->slab_frees = a.slab_frees;
+        out->malloc_ms = a.malloc_ms;
+        out->max_malloc_ms = a.max_malloc_ms;
+        out->touch_ms = a.touch_ms;
+        out->allocs = a.allocs;
+        out->releases = a.releases;
+        out->direct_mallocs = a.direct_mallocs;
+        out->failed = a.failed;
+        const VmmSlabStats v = vmm_slab_stats();
+        out->interleaved_slabs = v.slabs;
+        out->chunks = v.chunks;
+        out->chunks_other_zone = v.chunks_other_zone;
+        out->chunks_created = v.created;
+        out->interleave_ms = v.build_ms;
+        out->same_zone_tbs = v.same_zone_tbs;
     });
+}
+
+int toast_hip_arena_reserve(size_t bytes) {
+    // (on the CURRENT device: the device-pointer entry points serve callers that never went through assign_device)
+    return guarded([&] { Manager::get().reserve(bytes); });
+}
+
+int toast_hip_arena_reserve_streamed(size_t bytes) {
+    return guarded([&] { Manager::get().reserve(bytes, true); });
+}
+
+// The sub-allocation logic on host memory (no device needed): `n_ops` random allocations / releases of 1 .. max_block
+// bytes against an arena with the given granule and slab size; after every step the bookkeeping is checked, live blocks
+// are checked for overlap through a byte pattern, and at the end everything is released and every slab must be one
+// free range again.  0 = sound; otherwise the first inconsistency is in toast_hip_last_error().
+int toast_hip_arena_selftest(uint64_t seed, int n_ops, size_t granule, size_t slab_bytes, size_t max_block) {
+    return guarded([&] {
+        if (granule == 0 || slab_bytes < granule || max_block == 0) fail_arg("toast_hip_arena_selftest: bad sizes");
+        Arena a(granule, slab_bytes, host_backend());
+        struct Live { unsigned char * p; size_t n; unsigned char tag; };
+        std::vector<Live> live;
+        uint64_t st = seed * 6364136223846793005ull + 1442695040888963407ull;
+        auto rnd = [&] {
+            st = st * 6364136223846793005ull + 1442695040888963407ull;
+            return (uint64_t)(st >> 24);
+        };
+        auto verify = [&](const Live & b) {
+            for (size_t i = 0; i < b.n; i += (b.n > 4096 ? b.n / 64 : 1)) {
+                if (b.p[i] != b.tag) throw Error(TOAST_HIP_ERR_MEMORY, "arena selftest: a live block was overwritten (overlap)");
+            }
+            if (b.p[b.n - 1] != b.tag) throw Error(TOAST_HIP_ERR_MEMORY, "arena selftest: a live block was overwritten (overlap)");
+        };
+        for (int op = 0; op < n_ops; ++op) {
+            const bool do_alloc = live.empty() || (rnd() % 100) < 55;
+            if (do_alloc) {
+                // a mix of sizes: mostly small, some close to a slab, a few above the slab size
+                const uint64_t r = rnd() % 100;
+                size_t n = 1 + (size_t)(rnd() % max_block);
+                if (r < 50) n = 1 + n % (max_block / 16 + 1);
+                unsigned char * p = static_cast<unsigned char *>(a.alloc(n, nullptr));
+                if (p == nullptr) throw Error(TOAST_HIP_ERR_MEMORY, "arena selftest: host allocation failed");
+                const unsigned char tag = (unsigned char)(1 + rnd() % 255);
+                std::memset(p, tag, n);
+                live.push_back(Live{p, n, tag});
+            } else {
+                const size_t k = (size_t)(rnd() % live.size());
+                verify(live[k]);
+                if (!a.release(live[k].p)) throw Error(TOAST_HIP_ERR_MEMORY, "arena selftest: release refused a live block");
+                if (a.release(live[k].p)) throw Error(TOAST_HIP_ERR_MEMORY, "arena selftest: a block was released twice");
+                live[k] = live.back();
+                live.pop_back();
+            }
+            const std::string bad = a.check();
+            if (!bad.empty()) throw Error(TOAST_HIP_ERR_MEMORY, "arena selftest: " + bad);
+        }
+        for (const Live & b : live) {
+            verify(b);
+            if (!a.release(b.p)) throw Error(TOAST_HIP_ERR_MEMORY, "arena selftest: release refused a live block");
+        }
+        const std::string bad = a.check();
+        if (!bad.empty()) throw Error(TOAST_HIP_ERR_MEMORY, "arena selftest: " + bad);
+        if (a.free_bytes() != a.capacity()) throw Error(TOAST_HIP_ERR_MEMORY, "arena selftest: bytes still in use after the last release");
+        const ArenaStats s = a.stats();
+        if (a.largest_free() * (size_t)s.slabs < a.capacity() && s.slabs == 1) {
+            throw Error(TOAST_HIP_ERR_MEMORY, "arena selftest: free ranges were not merged");
+        }
+        const size_t held = a.capacity();
+        if (a.trim() != held || a.capacity() != 0) throw Error(TOAST_HIP_ERR_MEMORY, "arena selftest: trim left slabs behind");
+    });
+}
+
+// Time (ms) of one read + write pass over [p, p + bytes) with the timestream kernels' access pattern (1024 rows in
+// flight); the better of two passes.  For placement experiments on ranges of arena blocks (tools/exp_arena_regions.py).
+int toast_hip_probe_stream(void * p, size_t bytes, double * ms) {
+    return guarded([&] {
+        *ms = probe_stream_ms(p, bytes, Manager::get().stream());
+    });
+}
+
+int toast_hip_exp_vmm_pair_matrix(int n_phys, int n_slots, double * out) {
+    return guarded([&] { vmm_pair_matrix(n_phys, n_slots, out, Manager::get().stream()); });
+}
+
+int toast_hip_probe_stream_split(void * const * bases, int nb, size_t bytes_each, double * ms) {
+    return guarded([&] { *ms = probe_stream_split_ms(bases, nb, bytes_each, Manager::get().stream()); });
 }
 
 int toast_hip_accel_mem_info(size_t * free_bytes, size_t * total_bytes) {
@@ -1012,7 +1052,7 @@ int toast_hip_accel_mem_info(size_t * free_bytes, size_t * total_bytes) {
         Manager::get().require_device();
         size_t f = 0, t = 0;
         TH_HIP(hipMemGetInfo(&f, &t));
-        if (free_bytes) *free_bytes = f + Manager::get().cached_bytes();    // (what the cache holds can be had back)
+        if (free_bytes) *free_bytes = f + Manager::get().cached_bytes();    // (free ranges of the slabs can be had at once)
         if (total_bytes) *total_bytes = t;
     });
 }
@@ -1021,29 +1061,11 @@ int toast_hip_accel_release_cached(void) {
     return guarded([&] { Manager::get().release_cached(); });
 }
 
-int toast_hip_alloc_stats_ex(double * malloc_ms, double * max_malloc_ms, int64_t * budget_stops, int64_t * held_reused,
-                             int64_t * held_bytes) {
-    return guarded([&] {
-        const AllocStats & a = alloc_stats();
-        if (malloc_ms) *malloc_ms = a.malloc_ms;
-        if (max_malloc_ms) *max_malloc_ms = a.max_malloc_ms;
-        if (budget_stops) *budget_stops = a.budget_stops;
-        if (held_reused) *held_reused = a.held_reused;
-        if (held_bytes) *held_bytes = (int64_t)Manager::get().held_slow_bytes();
-    });
-}
-
 int toast_hip_device_malloc(size_t nbytes, int flags, void ** out) {
     return guarded([&] {
         void * p = nullptr;
         if (flags < 0) {
-            // -2: a block of exactly this size that the manager kept when it was released, if there is one
-            if (flags == -2) p = Manager::get().cached_block(nbytes);
-            if (p == nullptr) p = Manager::get().device_alloc(nbytes);
-            if (p == nullptr) {
-                Manager::get().release_cached();       // the cache may be what holds the memory
-                p = Manager::get().device_alloc(nbytes);
-            }
+            p = Manager::get().device_alloc(nbytes, flags == -3);
             if (p == nullptr) throw Error(TOAST_HIP_ERR_MEMORY, "HipManager:  device_malloc, allocation failed");
         } else if (flags == 0) {
             TH_HIP(hipMalloc(&p, nbytes));
@@ -1112,14 +1134,14 @@ int toast_hip_device_malloc_vmm(size_t nbytes, int chunk_mb, int shuffled, void 
 }
 
 int toast_hip_device_free(void * p) {
-    return guarded([&] { TH_HIP(hipFree(p)); });
-}
-int toast_hip_device_release(void * p, size_t nbytes) {
     return guarded([&] {
         if (p == nullptr) return;
-        if (!Manager::get().keep_block(p, nbytes)) TH_HIP(hipFree(p));
+        // nothing enqueued may still be using the range when somebody else takes it over
+        TH_HIP(hipStreamSynchronize(Manager::get().stream()));
+        Manager::get().device_free(p);
     });
 }
+int toast_hip_device_release(void * p, size_t /*nbytes*/) { return toast_hip_device_free(p); }
 
 int toast_hip_accel_generation(uint64_t * generation) {
     return toast_hip::guarded([&] { *generation = toast_hip::Manager::get().generation(); });
@@ -1145,6 +1167,10 @@ int toast_hip_accel_present(const void * host, size_t nbytes, int * present) {
 
 int toast_hip_accel_create(const void * host, size_t nbytes, const char * name) {
     return guarded([&] { Manager::get().create(host, nbytes, name); });
+}
+
+int toast_hip_accel_create_streamed(const void * host, size_t nbytes, const char * name) {
+    return guarded([&] { Manager::get().create(host, nbytes, name, true); });
 }
 
 int toast_hip_accel_adopt(const void * host, size_t nbytes, void * device, const char * name) {

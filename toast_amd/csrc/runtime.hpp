@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/toast_hip.h"
+#include "arena.hpp"
 
 namespace toast_hip {
 
@@ -94,21 +95,43 @@ private:
 };
 
 size_t pin_threshold();
+void drop_param_blocks();   // forget the cached parameter blocks (their storage is about to go away)
 // kernels.hip: time of a read + write pass over a new device block with the timestream kernels' access pattern
 double probe_stream_ms(void * block, size_t bytes, hipStream_t stream);
-// what the placement policy of Manager::device_alloc has done so far in this process
+// ... with the 1024 rows dealt round-robin to nb <= 4 separate ranges of bytes_each (placement experiments)
+double probe_stream_split_ms(void * const * bases, int nb, size_t bytes_each, hipStream_t stream);
+// Counters of Manager::device_alloc: both arenas (arena.hpp) together, plus what went around them.
 struct AllocStats {
-    int64_t probed_blocks = 0;   // blocks chosen by probing
-    int64_t fast_blocks = 0;     // ... of which the kept candidate streams at the fast level
-    int64_t candidates = 0;      // candidate allocations probed in total
-    double probe_ms = 0.0;       // time spent in the probe passes
-    double last_tbs = 0.0;       // stream rate of the last kept candidate
-    double malloc_ms = 0.0;      // time spent in hipMalloc for candidates
-    double max_malloc_ms = 0.0;  // ... the longest single call (a driver still clearing memory stalls one for seconds)
-    int64_t budget_stops = 0;    // searches ended by the time budget
-    int64_t held_reused = 0;     // blocks taken from the slow candidates kept from earlier searches
+    int64_t slabs = 0;             // slabs held now
+    size_t slab_bytes = 0;
+    size_t used_bytes = 0;         // bytes in live blocks
+    size_t peak_used_bytes = 0;
+    int64_t slab_mallocs = 0;      // hipMalloc calls for slabs so far
+    int64_t slab_frees = 0;
+    double malloc_ms = 0.0;        // wall time inside hipMalloc (slabs and direct blocks)
+    double max_malloc_ms = 0.0;    // ... the longest single call (a driver still clearing memory stalls one for seconds)
+    double touch_ms = 0.0;
+    int64_t allocs = 0;            // blocks handed out
+    int64_t releases = 0;
+    int64_t direct_mallocs = 0;    // blocks that went straight to hipMalloc (TOAST_HIP_ALLOC=plain)
+    int64_t failed = 0;
 };
-const AllocStats & alloc_stats();
+AllocStats alloc_stats();
+
+// Rank-interleaved slabs (vmm_slab.cpp): nullptr when switched off, too small, or the driver refuses.
+void * vmm_slab_take(size_t bytes, hipStream_t stream);
+bool vmm_slab_give(void * p);       // false: not one of them
+struct VmmSlabStats {
+    int64_t slabs = 0;               // interleaved slabs alive
+    int64_t chunks = 0;              // chunks mapped into slabs so far
+    int64_t chunks_other_zone = 0;   // ... of which in a zone other than their slab's first chunk
+    int64_t created = 0;             // chunks created (the surplus was released)
+    int64_t probes = 0;
+    double build_ms = 0.0;
+    double same_zone_tbs = 0.0;      // the last slab's reference rate (two halves of one chunk)
+};
+VmmSlabStats vmm_slab_stats();
+void vmm_pair_matrix(int n_phys, int n_slots, double * out, hipStream_t st);   // experiment, vmm_slab.cpp
 
 // Transfers between pageable application memory and the device, through a page-locked bounce ring owned by the library
 // (two 4 MB slots, copy of slot k overlapped with the host memcpy of slot k+1).  The HIP runtime never sees pageable
@@ -150,7 +173,8 @@ public:
     int device();               // throws if not yet assigned; -1 when disabled
     void require_device();      // throws unless a GPU is assigned and usable; hipSetDevice
     int present(const void * host, size_t nbytes);
-    void * create(const void * host, size_t nbytes, const char * name);
+    // streamed: a timestream that kernels read AND write in their sweeps (device_alloc)
+    void * create(const void * host, size_t nbytes, const char * name, bool streamed = false);
     void adopt(const void * host, size_t nbytes, void * device, const char * name);
     void reset(const void * host, size_t nbytes, const char * name);
     void update_device(const void * host, size_t nbytes, const char * name);
@@ -168,20 +192,23 @@ public:
     void clear();
     // Grow-only device scratch (slot = kScratch*): FFT work buffers, reduction results.
     void * scratch(int slot, size_t bytes);
-    void * device_alloc(size_t nbytes);   // allocation policy of the manager (nullptr on failure)
-    void release_cached() { flush_cached(); }
-    size_t cached_bytes() const { return cached_bytes_; }
-    // raw blocks (toast_hip_device_malloc(flags = -2) / toast_hip_device_release) share the cache of released blocks
-    void * cached_block(size_t nbytes) { return take_cached(nbytes); }
-    bool keep_block(void * dev, size_t nbytes) {
-        (void)hipStreamSynchronize(stream_);     // nothing enqueued may still be using it when somebody takes it over
-        return keep_cached(dev, nbytes);
-    }
-    size_t held_slow_bytes() const {
-        size_t n = 0;
-        for (const FreeBlock & b : free_blocks_) n += (b.slow_tbs > 0.0) ? b.second : 0;
-        return n;
-    }
+    // Every device block of the library comes from here and goes back through device_free: a range of an arena slab
+    // (arena.hpp), or -- TOAST_HIP_ALLOC=plain -- one hipMalloc / hipFree per block.  nullptr on failure.
+    // streamed = true asks for memory whose rows are spread over two HBM zones (rank-interleaved slabs, vmm_slab.cpp): a
+    // sweep that reads and writes ~1000 rows of one array at once runs 20 % faster there (scan_map, noise_weight, the
+    // FFT passes); read-only sweeps (build_noise_weighted, the packed left-hand side) are 5 % faster on plain slabs, which
+    // is what everything else gets.  Blocks below 1 GB are never interleaved.
+    void * device_alloc(size_t nbytes, bool streamed = false);
+    // p from device_alloc (anything else is handed to hipFree).  The caller guarantees that nothing still queued uses it
+    // on a stream other than stream(): the next owner's work is ordered after it on that stream.
+    void device_free(void * p);
+    // slabs without live blocks go back to the driver; returns the bytes
+    size_t release_cached();
+    // free bytes inside the slabs (what device_alloc can serve without the driver)
+    size_t cached_bytes() const;
+    // take `bytes` for the arena now (one slab, touched once): assign_device(mem_gb), TOAST_HIP_ARENA_RESERVE_GB
+    void reserve(size_t bytes, bool streamed = false);
+    void drop_arenas();   // device change: every slab goes back to the driver
 
     uint64_t generation() const { return generation_; }
     hipStream_t stream() const { return stream_; }
@@ -204,16 +231,6 @@ private:
     hipStream_t upload_stream_ = nullptr;   // non-blocking: does not synchronise with the default stream
     void pin_for_transfer(const void * host, Entry & e);
     static void unpin(const void * host, Entry & e);
-    void * take_cached(size_t nbytes);
-    bool keep_cached(void * dev, size_t nbytes, double slow_tbs = 0.0);
-    void flush_cached();
-    struct FreeBlock {
-        void * first;       // device pointer
-        size_t second;      // bytes
-        double slow_tbs;    // > 0: a candidate the placement policy measured and passed over (its stream rate, TB/s)
-    };
-    std::vector<FreeBlock> free_blocks_;   // released device blocks kept for reuse
-    size_t cached_bytes_ = 0;
     static double trace_begin();
     static void trace(const char * what, const std::string & name, size_t nbytes, double t0);
     Entry & lookup(const void * host, size_t nbytes, const char * name, const char * what);

@@ -639,7 +639,10 @@ class DetectorData(AcceleratorObject):
         return self._data.size > 0 and accel_data_present(self._data, self._accel_name)
 
     def _accel_create(self, zero_out=False):
-        accel_data_create(self._data, self._accel_name, zero_out=zero_out, owner=self)
+        # a two-dimensional float64 array per detector is a timestream: scan_map, noise_weight, the FFT passes and the
+        # template projections read and write it in one sweep -- the arena keeps such blocks in rank-interleaved slabs
+        streamed = self._data.ndim == 2 and self._data.dtype == np.float64
+        accel_data_create(self._data, self._accel_name, zero_out=zero_out, owner=self, streamed=streamed)
 
     def _accel_update_device(self):
         accel_data_update_device(self._data, self._accel_name)

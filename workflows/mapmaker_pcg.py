@@ -68,9 +68,16 @@ def main(argv=None):
                          "the solver keep its packed pointing cache (18-20 B/det-sample, expanded from the boresight in "
                          "batches of detectors) for the duration of the solve")
     ap.add_argument("--profile", action="store_true", help="cProfile of the MapMaker call (top functions by own time)")
+    ap.add_argument("--mem-gb", type=float, default=None,
+                    help="device memory the arena takes at accel_assign_device (the reference's TOAST_GPU_MEM_GB); default: "
+                         "76 B per local detector-sample + 2 GB -- cached pointing, timestreams, the solver's packed cache "
+                         "and one timestream-sized temporary")
     args = ap.parse_args(argv)
 
     n_samp = int(args.minutes * 60 * args.rate)
+    mem_gb = args.mem_gb
+    if mem_gb is None:
+        mem_gb = float(os.environ.get("TOAST_GPU_MEM_GB", 76.0 * args.ndet * n_samp / 2.0 ** 30 + 2.0))
     # one process per GPU: rank r owns detectors [r * ndet, (r + 1) * ndet) of one focalplane
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     comm = None
@@ -84,12 +91,23 @@ def main(argv=None):
         share = os.environ.get("TOAST_BENCH_SHARE_GPU", "0") == "1"   # tests: ranks share the GPUs, gloo
         local = int(os.environ.get("LOCAL_RANK", "0"))
         nloc = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-        accel_assign_device(nloc, local, 1.0, False)
+        accel_assign_device(nloc, local, mem_gb, False)
         if share:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
         comm = Comm()
+    else:
+        # The pool is taken from the driver now (one hipMalloc, first touch enqueued) and is ready long before the host
+        # has simulated its inputs; no operator below calls hipMalloc.
+        from toast_amd.accel import accel_assign_device
+
+        accel_assign_device(1, 0, mem_gb, False)
+    # the timestreams (signal and the solver's timestream-sized temporaries) are swept read + write: their part of the
+    # arena is built from chunks of two HBM zones (toast_hip_arena_reserve_streamed)
+    from toast_amd import capi
+
+    capi.arena_reserve(int(16.0 * args.ndet * n_samp) + (2 << 30), streamed=True)
     quiet = rank != 0
     LAST_STATS.clear()
     ph = Phase(quiet)
