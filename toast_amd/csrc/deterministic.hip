@@ -51,8 +51,9 @@ int g_stokes_nan = -1;
 
 bool stokes_reference_nan() {
     if (g_stokes_nan < 0) {
+        // default: the reference's result, NaN included; TOAST_HIP_STOKES_REFERENCE_NAN=0 selects the finite form
         const char * e = std::getenv("TOAST_HIP_STOKES_REFERENCE_NAN");
-        g_stokes_nan = (e != nullptr && e[0] != '\0' && e[0] != '0') ? 1 : 0;
+        g_stokes_nan = (e != nullptr && e[0] == '0') ? 0 : 1;
     }
     return g_stokes_nan == 1;
 }

@@ -612,8 +612,9 @@ TOAST_HD void quat_rotate_x(const double * q, double * out) {
 // tolerance-class output (reference tests: assert_allclose), agreement ~1e-15 absolute.
 // `reference_nan`: reproduce the one place where the reference formulation is NOT finite -- within
 // rounding of a pole vd2 * vd2 can exceed 1, its -sqrt(1 - vd2 * vd2) is NaN and so are alpha and
-// the Q / U weights (ops_stokes_weights.cpp:66-75).  Off by default (finite weights of modulus
-// eta * cal there); TOAST_HIP_STOKES_REFERENCE_NAN=1 / toast_hip_set_stokes_reference_nan(1).
+// the Q / U weights (ops_stokes_weights.cpp:66-75).  The library's default since round 4 (results identical to the
+// reference's on the same inputs); TOAST_HIP_STOKES_REFERENCE_NAN=0 / toast_hip_set_stokes_reference_nan(0) selects
+// finite weights of modulus eta * cal there instead.
 TOAST_HD void stokes_cs2alpha(const double * q, double & c2a, double & s2a, bool reference_nan = false) {
     double vd[3], vo[3];
     quat_rotate_z(q, vd);

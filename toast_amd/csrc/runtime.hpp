@@ -149,8 +149,8 @@ bool pair_detectors();
 void set_pair_detectors(int on);
 bool vec2_lanes();
 void set_vec2_lanes(int on);
-// TOAST_HIP_STOKES_REFERENCE_NAN=1 / toast_hip_set_stokes_reference_nan(): NaN Q / U weights where the
-// reference's formulation produces them (hpix_math.hpp: stokes_cs2alpha).
+// NaN Q / U weights where the reference's formulation produces them (hpix_math.hpp: stokes_cs2alpha): the default;
+// TOAST_HIP_STOKES_REFERENCE_NAN=0 / toast_hip_set_stokes_reference_nan(0) selects the finite form.
 bool stokes_reference_nan();
 // TOAST_HIP_DETERMINISTIC=1 / toast_hip_set_deterministic(): order-deterministic A^T scatter
 // (deterministic.hip) instead of the atomic kernels.

@@ -229,6 +229,8 @@ class SolveAmplitudes(Operator):
             self.history = solve(data, detectors, lhs, nm["rhs"], self.amplitudes, convergence=self.convergence,
                                  n_iter_min=self.iter_min, n_iter_max=self.iter_max,
                                  iteration_seconds=self.iteration_seconds)
+            # how the left-hand side was applied, per observation: "packed" | "fused" | "fused-otf", or ("sequence",)
+            self.lhs_route = tuple(getattr(lhs, "last_route", ()))
             t0 = lap("pcg_iterations", t0)
             for ob in data.obs:
                 if lhs.det_temp in ob.detdata:
@@ -398,6 +400,7 @@ class MapMaker(Operator):
             solver.apply(data, detectors=detectors)
             amplitudes = solver.amplitudes
             self.history, self.iteration_seconds = solver.history, solver.iteration_seconds
+            self.lhs_route = getattr(solver, "lhs_route", ())
             self.timing_log.update(solver.timing_log)
             t0 = _time.time()
         # -- final binning set-up (:381-436)

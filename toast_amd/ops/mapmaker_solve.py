@@ -712,6 +712,10 @@ class SolverLHS(Operator):
             key = key[:4] + (id(data.get(binning.binned)),) + key[5:-1] + (True,)
             plan = dict(key=key, generation=capi.accel_generation(), ctx=ctx, first=first, second=second)
             self._fused_plan = plan
+            # which sweeps the plan holds, one entry per observation: "packed" (the solver's packed pointing cache),
+            # "fused" (the cached pixels / weights as they are), "fused-otf" (pointing evaluated in the kernels)
+            self.last_route = tuple("packed" if ps.get("pk") is not None else ("fused-otf" if ctx["on_the_fly"] else "fused")
+                                    for ps in ctx["passes"])
         ctx = plan["ctx"]
         zmap = ctx["zmap"]
         zmap.accel_used(True)
@@ -741,6 +745,7 @@ class SolverLHS(Operator):
                 data[self.out].reset()      # (device-current output: the first fused pass zeroes it itself)
             self._exec_fused(data, detectors)
             return
+        self.last_route = ("sequence",)
         self._zero_temp(data)
         pixels = self.binning.pixel_pointing
         weights = self.binning.stokes_weights
@@ -954,72 +959,77 @@ def solve(data, detectors, lhs_op, rhs_key, result_key, convergence=1.0e-12, n_i
     data[proposal_key].reset()
     proposal = data[proposal_key]
 
-    # residual of the starting guess
-    lhs_op.template_matrix.amplitudes = result_key
-    lhs_op.out = lhs_out_key
-    lhs_op.keep_on_device = on_device
-    lhs_op.apply(data, detectors=detectors)
-    residual = rhs.duplicate()
-    residual -= lhs_out
-    precond = rhs.duplicate()
-    precond.reset()
-    lhs_op.template_matrix.apply_precond(residual, precond)
-    proposal.copy_from(precond)
-    lhs_op.template_matrix.amplitudes = proposal_key
-
-    sqsum = rhs.dot(rhs)
-    sqsum_init = sqsum
-    sqsum_best = sqsum
-    last_best = sqsum
-    delta = proposal.dot(residual)
-    history = []
-    import time as _time
-
-    if on_device and _device_scalars(rhs, (result, residual, precond, proposal, lhs_out)):
-        if not np.isfinite(sqsum):
-            raise RuntimeError("Residual is not finite")
-        history = _pcg_device_scalars(data, detectors, lhs_op, result, residual, precond, proposal, lhs_out, sqsum_init,
-                                      delta, convergence, n_iter_min, n_iter_max, log, iteration_seconds)
-        n_iter_max = 0       # the host-scalar loop below does not run
-
-    for it in range(n_iter_max):
-        if iteration_seconds is not None:
-            # every iteration ends in a dot product (a device synchronisation): wall time per
-            # iteration is the time between those points
-            iteration_seconds.append(_time.perf_counter())
-        if not np.isfinite(sqsum):
-            raise RuntimeError("Residual is not finite")
+    try:
+        # residual of the starting guess
+        lhs_op.template_matrix.amplitudes = result_key
+        lhs_op.out = lhs_out_key
+        lhs_op.keep_on_device = on_device
         lhs_op.apply(data, detectors=detectors)
-        alpha = delta / proposal.dot(lhs_out)
-        # result += alpha * proposal ; residual -= alpha * lhs_out  (mapmaker_solve.py:683-701,
-        # same roundings as the reference's scaled temporary)
-        result.axpby(alpha, proposal)
-        residual.axpby(-alpha, lhs_out)
-        sqsum = residual.dot(residual)
-        relative = sqsum / sqsum_init if sqsum_init != 0 else 0.0
-        history.append(relative)
-        if log is not None:
-            log(f"MapMaker iteration {it:4d}, relative residual = {relative:0.6e}")
-        if relative < convergence or sqsum < 1e-30:
-            break
-        sqsum_best = min(sqsum, sqsum_best)
-        if it % 10 == 0 and it >= n_iter_min:
-            if last_best < sqsum_best * 2:
-                break
-            last_best = sqsum_best
+        residual = rhs.duplicate()
+        residual -= lhs_out
+        precond = rhs.duplicate()
+        precond.reset()
         lhs_op.template_matrix.apply_precond(residual, precond)
-        delta_last = delta
-        delta = precond.dot(residual)
-        beta = delta / delta_last
-        # proposal = beta * proposal + precond
-        proposal.axpby(1.0, precond, beta)
-    if iteration_seconds is not None and len(iteration_seconds) > 0:
-        iteration_seconds.append(_time.perf_counter())
-        stamps = list(iteration_seconds)
-        iteration_seconds[:] = [b - a for a, b in zip(stamps[:-1], stamps[1:])]
-    lhs_op.keep_on_device = False
-    if hasattr(lhs_op, "release_packed"):
-        lhs_op.release_packed()
+        proposal.copy_from(precond)
+        lhs_op.template_matrix.amplitudes = proposal_key
+
+        sqsum = rhs.dot(rhs)
+        sqsum_init = sqsum
+        sqsum_best = sqsum
+        last_best = sqsum
+        delta = proposal.dot(residual)
+        history = []
+        import time as _time
+
+        if on_device and _device_scalars(rhs, (result, residual, precond, proposal, lhs_out)):
+            if not np.isfinite(sqsum):
+                raise RuntimeError("Residual is not finite")
+            history = _pcg_device_scalars(data, detectors, lhs_op, result, residual, precond, proposal, lhs_out, sqsum_init,
+                                          delta, convergence, n_iter_min, n_iter_max, log, iteration_seconds)
+            n_iter_max = 0       # the host-scalar loop below does not run
+
+        for it in range(n_iter_max):
+            if iteration_seconds is not None:
+                # every iteration ends in a dot product (a device synchronisation): wall time per
+                # iteration is the time between those points
+                iteration_seconds.append(_time.perf_counter())
+            if not np.isfinite(sqsum):
+                raise RuntimeError("Residual is not finite")
+            lhs_op.apply(data, detectors=detectors)
+            alpha = delta / proposal.dot(lhs_out)
+            # result += alpha * proposal ; residual -= alpha * lhs_out  (mapmaker_solve.py:683-701,
+            # same roundings as the reference's scaled temporary)
+            result.axpby(alpha, proposal)
+            residual.axpby(-alpha, lhs_out)
+            sqsum = residual.dot(residual)
+            relative = sqsum / sqsum_init if sqsum_init != 0 else 0.0
+            history.append(relative)
+            if log is not None:
+                log(f"MapMaker iteration {it:4d}, relative residual = {relative:0.6e}")
+            if relative < convergence or sqsum < 1e-30:
+                break
+            sqsum_best = min(sqsum, sqsum_best)
+            if it % 10 == 0 and it >= n_iter_min:
+                if last_best < sqsum_best * 2:
+                    break
+                last_best = sqsum_best
+            lhs_op.template_matrix.apply_precond(residual, precond)
+            delta_last = delta
+            delta = precond.dot(residual)
+            beta = delta / delta_last
+            # proposal = beta * proposal + precond
+            proposal.axpby(1.0, precond, beta)
+        if iteration_seconds is not None and len(iteration_seconds) > 0:
+            iteration_seconds.append(_time.perf_counter())
+            stamps = list(iteration_seconds)
+            iteration_seconds[:] = [b - a for a, b in zip(stamps[:-1], stamps[1:])]
+    finally:
+        # The packed pointing cache is a snapshot of pixels, weights and flags that belongs to THIS solve: whatever ends
+        # it -- convergence, the iteration limit, a non-finite residual, an error in a kernel -- gives it back, so that a
+        # later use of the operator packs the arrays as they are then.
+        lhs_op.keep_on_device = False
+        if hasattr(lhs_op, "release_packed"):
+            lhs_op.release_packed()
     # hand the solution back on the host (AmplitudesMap.accel_update_host skips host-current ones)
     result.accel_update_host()
     rhs.accel_update_host()

@@ -157,7 +157,8 @@ def main(argv=None):
                       phases_s=dict(getattr(mapper, "timing_log", {})),
                       pcg_iteration_ms=1e3 * float(np.median(its)) if its else None,
                       pcg_Gsamp_s=nds / float(np.median(its)) / 1e9 if its else None,
-                      detectors=args.ndet * world, samples_per_detector=n_samp, nside=args.nside)
+                      detectors=args.ndet * world, samples_per_detector=n_samp, nside=args.nside,
+                      lhs_route=list(getattr(mapper, "lhs_route", ())))
     if world > 1:
         import torch.distributed as dist
 
