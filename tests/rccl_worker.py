@@ -210,6 +210,54 @@ def main():
         np.testing.assert_allclose(z.data, ref.data, rtol=1e-13, atol=1e-13 * np.max(np.abs(total)))
         cv.accel_delete()
         z.accel_delete()
+    # MIXED residency: rank 0 has "evicted" its map -- it holds it on the host -- while the others hold
+    # theirs on the device.  The route does not depend on where a rank's copy lives, so every rank enters the same
+    # collective on the same communicator: no hang, the right sums, and each copy ends where it started.
+    for entry in ("sync_allreduce", "sync_alltoallv", "map_reduce_apply", "covariance_apply", "covariance_invert"):
+        z = PixelData(d, np.float64, n_value=3)
+        z.raw[:] = parts[rank]
+        cvm = dev_map(spd, 6, "cov_mixed")
+        on_device = rank != 0
+        if on_device:
+            z.accel_create("zmap_mixed")
+            z.accel_update_device()
+        if entry in ("sync_allreduce", "sync_alltoallv"):
+            getattr(z, entry)()
+            expect = total
+        elif entry == "map_reduce_apply":
+            map_reduce_apply(cvm, z, sync_type="alltoallv")
+            ref = PixelData(d, np.float64, n_value=3)
+            ref.raw[:] = total
+            covariance_apply(dev_map(spd, 6, "cov_mixed_ref"), ref)
+            expect = ref.raw
+        elif entry == "covariance_apply":
+            z.raw[:] = total
+            if on_device:
+                z.accel_update_device()
+            covariance_apply(cvm, z, use_alltoallv=True)
+            ref = PixelData(d, np.float64, n_value=3)
+            ref.raw[:] = total
+            covariance_apply(dev_map(spd, 6, "cov_mixed_ref"), ref)
+            expect = ref.raw
+        else:
+            inv = PixelData(d, np.float64, n_value=6)
+            inv.raw[:] = np.asarray(spd).reshape(-1)
+            if on_device:
+                inv.accel_create("inv_mixed")
+                inv.accel_update_device()
+            covariance_invert(inv, 1e-6, use_alltoallv=True)
+            assert inv.accel_in_use() == on_device, entry
+            np.testing.assert_allclose(inv.data, want["inv"], rtol=1e-13, atol=1e-15, err_msg=entry)
+            if on_device:
+                inv.accel_delete()
+            cvm.accel_delete()
+            continue
+        assert z.accel_in_use() == on_device, entry
+        np.testing.assert_allclose(z.data.reshape(-1), np.asarray(expect).reshape(-1), rtol=1e-13,
+                                   atol=1e-13 * np.max(np.abs(total)), err_msg=entry)
+        if on_device:
+            z.accel_delete()
+        cvm.accel_delete()
     # host-resident data with the nccl backend (staged through the device)
     ph = PixelData(d, np.int64, n_value=1)
     ph.raw[:] = rank + 1

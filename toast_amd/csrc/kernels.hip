@@ -641,8 +641,9 @@ __global__ __launch_bounds__(kThreads) void k_build_noise_weighted_v2(
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const uint16_t bad = (uint16_t)((fd[e] & dmask2) | (fs & smask2));
-                const bool good_a = active & on[e] & (pp[e].x >= 0) & ((bad & 0x00ff) == 0);
-                const bool good_b = active & on[e] & (pp[e].y >= 0) & ((bad & 0xff00) == 0);
+                // (la / lb < 0: the pixel lies in a submap that is not local -- no contribution, also not through the pair merge)
+                const bool good_a = active & on[e] & (pp[e].x >= 0) & (la[e] >= 0) & ((bad & 0x00ff) == 0);
+                const bool good_b = active & on[e] & (pp[e].y >= 0) & (lb[e] >= 0) & ((bad & 0xff00) == 0);
                 ka[e] = good_a ? la[e] * nps + (pp[e].x - ga[e] * nps) : -1;
                 kb[e] = good_b ? lb[e] * nps + (pp[e].y - gb[e] * nps) : -1;
                 const double sa = tt[e].x * ds[e], sb = tt[e].y * ds[e];
@@ -1651,8 +1652,9 @@ __global__ __launch_bounds__(kThreads) void k_offset_accumulate_v2(
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const uint16_t bad = (uint16_t)((fd[e] & dmask2) | (fs & smask2));
-                const bool good_a = active & on[e] & (pp[e].x >= 0) & ((bad & 0x00ff) == 0);
-                const bool good_b = active & on[e] & (pp[e].y >= 0) & ((bad & 0xff00) == 0);
+                // (la / lb < 0: the pixel lies in a submap that is not local -- no contribution, also not through the pair merge)
+                const bool good_a = active & on[e] & (pp[e].x >= 0) & (la[e] >= 0) & ((bad & 0x00ff) == 0);
+                const bool good_b = active & on[e] & (pp[e].y >= 0) & (lb[e] >= 0) & ((bad & 0xff00) == 0);
                 ka[e] = good_a ? la[e] * nps + (pp[e].x - ga[e] * nps) : -1;
                 kb[e] = good_b ? lb[e] * nps + (pp[e].y - gb[e] * nps) : -1;
                 // tod = 0 + amplitude (unflagged amplitudes only), then * det_scale

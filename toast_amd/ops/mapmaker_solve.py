@@ -390,6 +390,11 @@ class SolverLHS(Operator):
 
         if not self.packed_pointing or os.environ.get("TOAST_HIP_PACKED_POINTING", "1") == "0":
             return None
+        if not getattr(self, "keep_on_device", False):
+            # The pack is a SNAPSHOT of pixels, weights and flags, keyed by their device addresses: it lives inside a
+            # solve (solve() sets keep_on_device and gives the pack back in its finally block).  A stand-alone apply()
+            # sweeps the live arrays -- an in-place edit followed by accel_update_device keeps the address.
+            return None
         n_det, n_samp = len(ps["dets"]), int(ps["n_samp"])
         if c["nnz"] != 3 or n_samp % 2 != 0 or n_det == 0:
             return None
@@ -439,8 +444,8 @@ class SolverLHS(Operator):
         from .. import capi
         from .pointing import otf_descriptor
 
-        if os.environ.get("TOAST_HIP_PACKED_POINTING", "1") == "0":
-            return None
+        if os.environ.get("TOAST_HIP_PACKED_POINTING", "1") == "0" or not getattr(self, "keep_on_device", False):
+            return None            # (outside a solve: see _pack_pass)
         dets = ps["dets"]
         n_det, n_samp = len(dets), int(ps["n_samp"])
         if c["nnz"] != 3 or n_samp % 2 != 0 or n_det == 0:

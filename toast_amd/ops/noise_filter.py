@@ -136,7 +136,7 @@ class NoiseFilter(Operator):
                     from .. import capi
 
                     upload_bounds = np.linspace(0, rows, n_parts + 1).astype(np.int64)
-                    capi.accel_update_device_parts(dd.buffer, upload_bounds[1:] * dd.buffer.shape[1] * 8, self.det_data)
+                    capi.accel_update_device_parts(dd.buffer, upload_bounds[1:] * (dd.buffer.nbytes // rows), self.det_data)
                     dd.accel_used(True)
                 else:
                     dd.accel_update_device()

@@ -418,13 +418,41 @@ class PixelData(AcceleratorObject):
         return dup
 
     def _device_collectives(self, comm):
-        """Device-resident data reduced in place through the library's RCCL communicator on the kernels' stream."""
+        """True when this map's collectives go through the library's RCCL communicator on the kernels' stream.
+
+        The answer depends only on things that are the same on every rank -- the communicator, the distribution, the
+        dtype -- never on where THIS rank's copy of the map happens to live: a rank that has evicted its map
+        (Data.accel_evict under memory pressure, uneven detector shards) must enter the same collective on the same
+        communicator as the others, or the job hangs.  A host-resident copy is uploaded for the collective and
+        brought back afterwards (``_device_side``)."""
         from . import capi
 
-        # (the two collective questions first, so that every rank asks them -- the communicator is created by the
-        # first one; the ranks are assumed to hold a map on the same side, as the operators leave it)
-        return bool(comm.device_comm() and self._dist.replicated and self.accel_in_use()
-                    and self._dtype in capi.dev.COMM_DTYPES)
+        return bool(comm.device_comm() and self._dist.replicated and self._dtype in capi.dev.COMM_DTYPES
+                    and self._raw is not None and self._raw.size > 0)
+
+    def _device_side(self):
+        """Context manager: inside, the device copy is the current one; a copy that lived on the host is uploaded on
+        entry, downloaded on exit, and a device buffer created for the purpose is released again."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            moved = not self.accel_in_use()
+            created = False
+            if moved:
+                if not self.accel_exists():
+                    self.accel_create(self._accel_name)
+                    created = True
+                self.accel_update_device()
+            try:
+                yield
+            finally:
+                if moved:
+                    self.accel_update_host()
+                    if created:
+                        self.accel_delete()
+
+        return ctx()
 
     def sync_allreduce(self, comm=None, comm_bytes=10000000):
         """Sum the map over all processes; every process ends with the total (reference pixels.py:710-780; all
@@ -438,7 +466,8 @@ class PixelData(AcceleratorObject):
         if self._device_collectives(comm):
             from . import capi
 
-            capi.dev.comm_allreduce(accel_device_ptr(self._raw), self._raw.size, self._dtype, "sum")
+            with self._device_side():
+                capi.dev.comm_allreduce(accel_device_ptr(self._raw), self._raw.size, self._dtype, "sum")
             return
         restore = False
         if self.accel_in_use():
@@ -518,16 +547,17 @@ class PixelData(AcceleratorObject):
             return      # one process: every submap is its own and only copy
         device_form = local_func is None or hasattr(local_func, "on_device")
         if w is not None and device_form and self._device_collectives(w):
-            if local_func is None:
-                from . import capi
+            with self._device_side():
+                if local_func is None:
+                    from . import capi
 
-                if self._dtype == np.float64:
-                    capi.dev.comm_map_reduce_apply(self._raw.size // self._n_value, self._n_value, 0,
-                                                   accel_device_ptr(self._raw), reduce=True)
-                else:   # integer / single precision maps: the plain all-reduce gives the same sums
-                    capi.dev.comm_allreduce(accel_device_ptr(self._raw), self._raw.size, self._dtype, "sum")
-            else:
-                local_func.on_device(self)
+                    if self._dtype == np.float64:
+                        capi.dev.comm_map_reduce_apply(self._raw.size // self._n_value, self._n_value, 0,
+                                                       accel_device_ptr(self._raw), reduce=True)
+                    else:   # integer / single precision maps: the plain all-reduce gives the same sums
+                        capi.dev.comm_allreduce(accel_device_ptr(self._raw), self._raw.size, self._dtype, "sum")
+                else:
+                    local_func.on_device(self)
             return
         restore = self.accel_in_use()
         self.forward_alltoallv()
@@ -691,7 +721,8 @@ def covariance_apply(npp, m, use_alltoallv=False):
     if use_alltoallv and m.distribution._world() is not None:
         lapply = create_local_apply(npp.distribution.n_pix_submap, mapnnz, npp)
         if _owner_computes_on_device(m):
-            lapply.on_device(m)
+            with m._device_side():
+                lapply.on_device(m)
         else:
             npp.forward_alltoallv()
             m.sync_alltoallv(local_func=lapply)
@@ -712,7 +743,8 @@ def map_reduce_apply(npp, m, sync_type="alltoallv"):
     ``cov_apply_diag`` on the owned pixel shard, all-gather -- instead of an all-reduce followed by every process
     multiplying the whole map; otherwise ``sync_allreduce`` / ``sync_alltoallv`` followed by ``covariance_apply``."""
     if sync_type == "alltoallv" and _owner_computes_on_device(m):
-        create_local_apply(npp.distribution.n_pix_submap, _mapnnz(npp), npp).on_device(m, reduce=True)
+        with m._device_side():
+            create_local_apply(npp.distribution.n_pix_submap, _mapnnz(npp), npp).on_device(m, reduce=True)
         return
     if sync_type == "alltoallv":
         m.sync_alltoallv()
@@ -732,7 +764,8 @@ def covariance_multiply(npp1, npp2, use_alltoallv=False):
     if use_alltoallv and npp1.distribution._world() is not None:
         lmult = create_local_multiply(npp1.distribution.n_pix_submap, mapnnz, npp2)
         if _owner_computes_on_device(npp1):
-            lmult.on_device(npp1)
+            with npp1._device_side():
+                lmult.on_device(npp1)
         else:
             npp2.forward_alltoallv()
             npp1.sync_alltoallv(local_func=lmult)
@@ -770,7 +803,10 @@ def covariance_invert(npp, threshold, rcond=None, use_alltoallv=False):
     if use_alltoallv and dist._world() is not None:
         linvert = create_local_invert(dist.n_pix_submap, mapnnz, threshold, rcond, invert=True)
         if _owner_computes_on_device(npp):
-            linvert.on_device(npp)
+            with npp._device_side():
+                linvert.on_device(npp)
+            if rcond is not None and not npp.accel_in_use() and rcond.accel_in_use():
+                rcond.accel_update_host()      # (the matrix was only on the device for the collective: so is its rcond)
             return
         if rcond is not None:
             if rcond.accel_in_use():
