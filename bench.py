@@ -256,7 +256,7 @@ def run(args, workload, world, rank, dev, headline=True):
         capi.arena_reserve(int(74.0 * n_det * n_samp) + (1 << 30))
         # ... and the one timestream that the step reads AND writes (scan_map's tod2) in a slab whose 1 GB chunks
         # alternate between two HBM zones (csrc/vmm_slab.cpp): what ops' timestreams get (DetectorData, 2-D float64)
-        capi.arena_reserve(int(8.0 * n_det * n_samp) + (1 << 30), streamed=True)
+        capi.arena_reserve(int(8.0 * n_det * n_samp) + (2 << 30), streamed=True)
     fp_all, gamma_all = synth.hex_focalplane(n_det * world, fov_deg=10.0)
     fp = np.ascontiguousarray(fp_all[rank * n_det : (rank + 1) * n_det])
     gamma = np.ascontiguousarray(gamma_all[rank * n_det : (rank + 1) * n_det])
@@ -289,10 +289,10 @@ def run(args, workload, world, rank, dev, headline=True):
         allocator = "experiment: torch caching allocator (one hipMalloc per buffer, no placement policy)"
     managed = []     # device blocks from the library's memory manager (released at the end of run())
 
-    def manager_tensor(nbytes, dtype, shape, streamed=False):
+    def manager_tensor(nbytes, dtype, shape, streamed=False, scatter=False):
         """A torch view of a block from toast_hip::Manager::device_alloc -- the arena every operator's buffers come
         from (toast_hip_device_malloc(flags = -1))."""
-        ptr = capi.device_malloc(nbytes, -3 if streamed else -1)
+        ptr = capi.device_malloc(nbytes, -3 if streamed else (-4 if scatter else -1))
         managed.append(ptr)
 
         class _Block:
@@ -389,7 +389,12 @@ def run(args, workload, world, rank, dev, headline=True):
     g2l_h, hit = synth.global_to_local(hs.cpu().numpy())
     n_local = int(hit.size)
     d_g2l = torch.from_numpy(g2l_h).to(dev)
-    d_zmap = torch.zeros((n_local, nps, nnz), dtype=torch.float64, device=dev)
+    # the map: the target of build_noise_weighted's atomics -- a scatter block of the arena, like every ops.PixelData
+    if args.torch_alloc:
+        d_zmap = torch.zeros((n_local, nps, nnz), dtype=torch.float64, device=dev)
+    else:
+        d_zmap = manager_tensor(n_local * nps * nnz * 8, torch.float64, (n_local, nps, nnz), scatter=True)
+        d_zmap.zero_()
     # packed upper-triangle "covariance": diagonally dominant, O(1)
     d_cov = torch.rand((n_local, nps, 6), dtype=torch.float64, device=dev, generator=gen) * 0.1
     d_cov[..., 0] += 1.0
@@ -720,7 +725,11 @@ def run(args, workload, world, rank, dev, headline=True):
         amp_off = np.arange(n_det, dtype=np.int64) * n_amp_det
         n_amp = n_det * n_amp_det
         d_amp_in = torch.randn(n_amp, dtype=torch.float64, device=dev, generator=gen)
-        d_amp_out = torch.zeros(n_amp, dtype=torch.float64, device=dev)
+        if args.torch_alloc:
+            d_amp_out = torch.zeros(n_amp, dtype=torch.float64, device=dev)
+        else:     # (what the projections scatter into: a scatter block, like ops' Amplitudes)
+            d_amp_out = manager_tensor(n_amp * 8, torch.float64, (n_amp,), scatter=True)
+            d_amp_out.zero_()
         d_amp_flags = torch.zeros(n_amp, dtype=torch.uint8, device=dev)
 
         def lhs_unfused():

@@ -116,10 +116,12 @@ int toast_hip_arena_reserve_streamed(size_t bytes);
 /* The sub-allocation logic exercised on HOST memory (no device needed): n_ops random allocations / releases with the
  * bookkeeping and the contents of every live block checked after each step.  0 = sound. */
 int toast_hip_arena_selftest(uint64_t seed, int n_ops, size_t granule, size_t slab_bytes, size_t max_block);
-/* Raw device memory from the arena (flags = -1, also -2; -3 = a STREAMED block: a timestream that sweeps read and write,
- * placed in a slab whose 1 GB chunks alternate between two HBM zones -- such sweeps run at 6.1 instead of 5.1 TB/s
- * there, read-only sweeps 5 % slower, csrc/vmm_slab.cpp), a plain hipMalloc (0) or explicit hipExtMallocWithFlags
- * flags (4 = physically contiguous): what bench.py and the solver's packed cache use, so that they get the blocks the
+/* Raw device memory from the arena (flags = -1, also -2: a read-mostly block; -3 = a STREAMED block: a timestream that
+ * sweeps read and write, placed in a slab whose 1 GB chunks alternate between two HBM zones -- such sweeps run at 6.1
+ * instead of 5.1 TB/s there; -4 = a SCATTER TARGET: a map or amplitude vector that kernels add to with atomics, placed
+ * inside one chunk of the zone the read-mostly blocks are NOT in -- build_noise_weighted 5.2 instead of 5.8 ms;
+ * csrc/vmm_slab.cpp, profiles/r04_a.  -3 / -4 need toast_hip_arena_reserve_streamed and are read-mostly blocks
+ * without it), a plain hipMalloc (0) or explicit hipExtMallocWithFlags flags (4 = physically contiguous): what bench.py and the solver's packed cache use, so that they get the blocks the
  * operators get.  Blocks from flags < 0 are released with toast_hip_device_free / toast_hip_device_release. */
 int toast_hip_device_malloc(size_t nbytes, int flags, void ** out);
 /* Time (ms) of a read + write pass over [p, p + bytes) with the timestream kernels' access pattern (1024 rows in
@@ -164,9 +166,10 @@ int toast_hip_accel_present(const void * host, size_t nbytes, int * present);
 /* Allocate a device buffer of nbytes keyed by the host base pointer.  Error if the key is
  * already present.  [ref: accelerator.cpp:327-388 create] */
 int toast_hip_accel_create(const void * host, size_t nbytes, const char * name);
-/* The same for an array that sweeps read AND write (a detector timestream): a streamed block of the arena (see
- * toast_hip_device_malloc, flags = -3). */
-int toast_hip_accel_create_streamed(const void * host, size_t nbytes, const char * name);
+/* The same with a statement of what the array is to the kernels, which decides where in HBM the arena puts it (see
+ * toast_hip_device_malloc): kind 0 = read-mostly (what toast_hip_accel_create does), 1 = a timestream that sweeps read
+ * AND write (flags = -3 there), 2 = the target of a scatter with atomics: a map, an amplitude vector (flags = -4). */
+int toast_hip_accel_create_kind(const void * host, size_t nbytes, const char * name, int kind);
 
 /* Zero the device copy.  [ref: accelerator.cpp:593-654 reset] */
 int toast_hip_accel_reset(const void * host, size_t nbytes, const char * name);

@@ -105,9 +105,14 @@ def add_eviction_handler(fn):
     _eviction_handlers.append(fn)
 
 
-def accel_data_create(data, name="None", zero_out=False, owner=None, streamed=False):
-    """reference accel.py:147-176.  ``owner``: object whose lifetime bounds the device copy.  ``streamed``: the array is a
-    timestream that kernels read and write in their sweeps (toast_hip_accel_create_streamed)."""
+#: what an array is to the kernels (toast_hip_accel_create_kind): decides where in HBM the arena puts its device copy
+KIND_DEFAULT, KIND_STREAMED, KIND_SCATTER = 0, 1, 2
+
+
+def accel_data_create(data, name="None", zero_out=False, owner=None, kind=KIND_DEFAULT):
+    """reference accel.py:147-176.  ``owner``: object whose lifetime bounds the device copy.  ``kind``: KIND_STREAMED for
+    a timestream that kernels read and write in their sweeps, KIND_SCATTER for the target of a scatter with atomics (a
+    map, an amplitude vector); toast_hip_accel_create_kind."""
     import weakref
 
     ensure_assigned()
@@ -115,7 +120,7 @@ def accel_data_create(data, name="None", zero_out=False, owner=None, streamed=Fa
     if arr.size == 0:
         return data
     try:
-        native().accel_create(arr, name, bool(streamed))
+        native().accel_create(arr, name, int(kind))
     except RuntimeError as err:
         if "allocation failed" not in str(err):
             raise
@@ -124,7 +129,7 @@ def accel_data_create(data, name="None", zero_out=False, owner=None, streamed=Fa
             freed += int(fn() or 0)
         if freed == 0:
             raise
-        native().accel_create(arr, name, bool(streamed))
+        native().accel_create(arr, name, int(kind))
     if zero_out:
         native().accel_reset(arr, name)
     if owner is not None:

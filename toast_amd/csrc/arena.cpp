@@ -2,6 +2,7 @@
 #include "arena.hpp"
 #include "runtime.hpp"
 
+#include <algorithm>
 #include <chrono>
 #include <cstdlib>
 #include <sstream>
@@ -124,6 +125,32 @@ void * Arena::alloc(size_t nbytes, hipStream_t stream, bool grow) {
     return best_slab->base + off;
 }
 
+void * Arena::alloc_striped(size_t nbytes, size_t stripe, int parity) {
+    const size_t need = round_up(nbytes ? nbytes : 1);
+    if (stripe == 0 || need > stripe) return nullptr;
+    std::lock_guard<std::mutex> lock(mutex_);
+    for (Slab & s : slabs_) {
+        for (auto it = s.free.begin(); it != s.free.end(); ++it) {
+            const size_t off = it->first, len = it->second;
+            // stripes of the wanted parity that overlap [off, off + len)
+            for (size_t k = off / stripe; k * stripe < off + len; ++k) {
+                if ((int)(k & 1) != (parity & 1)) continue;
+                const size_t lo = std::max(off, k * stripe), hi = std::min(off + len, (k + 1) * stripe);
+                if (hi < lo + need) continue;
+                s.free.erase(it);
+                if (lo > off) s.free[off] = lo - off;
+                if (off + len > lo + need) s.free[lo + need] = off + len - (lo + need);
+                s.live[lo] = need;
+                st_.used_bytes += need;
+                if (st_.used_bytes > st_.peak_used_bytes) st_.peak_used_bytes = st_.used_bytes;
+                ++st_.allocs;
+                return s.base + lo;
+            }
+        }
+    }
+    return nullptr;
+}
+
 bool Arena::release(void * p) {
     std::lock_guard<std::mutex> lock(mutex_);
     const char * c = static_cast<const char *>(p);
@@ -161,6 +188,18 @@ bool Arena::owns(const void * p) const {
     const char * c = static_cast<const char *>(p);
     for (const Slab & s : slabs_) {
         if (c >= s.base && c < s.base + s.bytes) return s.live.count((size_t)(c - s.base)) != 0;
+    }
+    return false;
+}
+
+bool Arena::slab_offset(const void * p, size_t * off) const {
+    std::lock_guard<std::mutex> lock(mutex_);
+    const char * c = static_cast<const char *>(p);
+    for (const Slab & s : slabs_) {
+        if (c >= s.base && c < s.base + s.bytes) {
+            *off = (size_t)(c - s.base);
+            return true;
+        }
     }
     return false;
 }

@@ -65,9 +65,16 @@ public:
     // of a new slab is enqueued (work that uses the block must be ordered after it: same stream, or an event).
     // grow = false: only from the free ranges of the slabs already held
     void * alloc(size_t nbytes, hipStream_t stream, bool grow = true);
+    // A block that lies inside ONE stripe of width `stripe` whose index (offset / stripe within its slab) has the given
+    // parity: the slabs of the stream arena alternate between two HBM zones chunk by chunk (vmm_slab.cpp), and a map
+    // -- the target of a scatter -- belongs into the zone the read-only arrays are NOT in.  Never grows the arena;
+    // nullptr when no such range is free.
+    void * alloc_striped(size_t nbytes, size_t stripe, int parity);
     // false when p is not a live block of this arena
     bool release(void * p);
     bool owns(const void * p) const;
+    // offset of an address inside its slab; false when it lies in none
+    bool slab_offset(const void * p, size_t * off) const;
     // make the capacity (free + used) at least `bytes` by taking ONE more slab for the difference; false if the
     // driver refuses
     bool reserve(size_t bytes, hipStream_t stream);

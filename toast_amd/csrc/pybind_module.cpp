@@ -257,11 +257,11 @@ PYBIND11_MODULE(_libtoast_hip, m) {
         check(toast_hip_accel_present(b.ptr, b.nbytes, &r));
         return r != 0;
     }, py::arg("data"), py::arg("name"));
-    m.def("accel_create", [](py::buffer data, std::string name, bool streamed) {
+    m.def("accel_create", [](py::buffer data, std::string name, int kind) {
         RawBuf b = accel_buf(data);
-        check(streamed ? toast_hip_accel_create_streamed(b.ptr, b.nbytes, name.c_str())
-                       : toast_hip_accel_create(b.ptr, b.nbytes, name.c_str()));
-    }, py::arg("data"), py::arg("name"), py::arg("streamed") = false);
+        check(kind != 0 ? toast_hip_accel_create_kind(b.ptr, b.nbytes, name.c_str(), kind)
+                        : toast_hip_accel_create(b.ptr, b.nbytes, name.c_str()));
+    }, py::arg("data"), py::arg("name"), py::arg("kind") = 0);
     m.def("accel_reset", [](py::buffer data, std::string name) {
         RawBuf b = accel_buf(data);
         check(toast_hip_accel_reset(b.ptr, b.nbytes, name.c_str()));

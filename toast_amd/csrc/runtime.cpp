@@ -535,7 +535,7 @@ AllocStats alloc_stats() {
     return o;
 }
 
-void * Manager::device_alloc(size_t nbytes, bool streamed) {
+void * Manager::device_alloc(size_t nbytes, int kind) {
     if (nbytes == 0) nbytes = 16;
     if (alloc_policy().plain) {
         void * p = nullptr;
@@ -551,11 +551,14 @@ void * Manager::device_alloc(size_t nbytes, bool streamed) {
         if (ms > g_direct.max_malloc_ms) g_direct.max_malloc_ms = ms;
         return p;
     }
-    if (streamed && nbytes >= kStreamBlock && stream_arena_enabled()) {
-        // Streamed blocks come from what has been RESERVED for them (toast_hip_arena_reserve_streamed,
+    if (kind != kBlockDefault && stream_arena_enabled() && stream_arena().capacity() > 0) {
+        // Streamed and scatter blocks come from what has been RESERVED for them (toast_hip_arena_reserve_streamed,
         // TOAST_HIP_ARENA_STREAM_GB at assign_device): building an interleaved slab takes 0.3 s and more, which is set-up
         // work -- never something an operator pays for in passing.  Without a reservation they are ordinary blocks.
-        void * p = stream_arena().alloc(nbytes, stream_, false);
+        void * p = nullptr;
+        if (kind == kBlockStreamed && nbytes >= kStreamBlock) p = stream_arena().alloc(nbytes, stream_, false);
+        // (odd chunks are the ones NOT in the zone of the read-mostly arrays)
+        if (kind == kBlockScatter && nbytes >= kSmallBlock) p = stream_arena().alloc_striped(nbytes, kStreamBlock, 1);
         if (p != nullptr) return p;
     }
     Arena & a = nbytes < kSmallBlock ? small_arena() : big_arena();
@@ -603,6 +606,16 @@ void Manager::reserve(size_t bytes, bool streamed) {
     (void)arena.reserve(have + want, stream_);
 }
 
+void * zone_reference_take(size_t bytes) {
+    // from the slabs the read-mostly arrays live in -- only if they exist already (no new slab for this)
+    if (alloc_policy().plain || big_arena().capacity() == 0) return nullptr;
+    return big_arena().alloc(bytes, Manager::get().stream(), false);
+}
+
+void zone_reference_release(void * p) {
+    if (p != nullptr) (void)big_arena().release(p);
+}
+
 void Manager::drop_arenas() {
     (void)hipDeviceSynchronize();
     drop_param_blocks();
@@ -611,7 +624,7 @@ void Manager::drop_arenas() {
     stream_arena().destroy();
 }
 
-void * Manager::create(const void * host, size_t nbytes, const char * name, bool streamed) {
+void * Manager::create(const void * host, size_t nbytes, const char * name, int kind) {
     require_device();
     auto it = table_.find(host);
     if (it != table_.end()) {
@@ -633,7 +646,7 @@ void * Manager::create(const void * host, size_t nbytes, const char * name, bool
     }();
     hipError_t e = hipErrorOutOfMemory;
     if (limit == 0 || owned_bytes_ + nbytes <= limit) {
-        dev = device_alloc(nbytes, streamed);
+        dev = device_alloc(nbytes, kind);
         e = (dev != nullptr) ? hipSuccess : hipErrorOutOfMemory;
     }
     if (e != hipSuccess || dev == nullptr) {
@@ -999,7 +1012,20 @@ int toast_hip_arena_selftest(uint64_t seed, int n_ops, size_t granule, size_t sl
                 const uint64_t r = rnd() % 100;
                 size_t n = 1 + (size_t)(rnd() % max_block);
                 if (r < 50) n = 1 + n % (max_block / 16 + 1);
-                unsigned char * p = static_cast<unsigned char *>(a.alloc(n, nullptr));
+                unsigned char * p = nullptr;
+                const size_t stripe = 8 * granule;
+                if (r >= 90 && n <= stripe) {
+                    // a striped block: inside one stripe of the wanted parity, or refused (never a new slab)
+                    const int parity = (int)(rnd() & 1);
+                    p = static_cast<unsigned char *>(a.alloc_striped(n, stripe, parity));
+                    if (p == nullptr) continue;
+                    size_t off = 0;
+                    if (!a.slab_offset(p, &off) || off / stripe != (off + n - 1) / stripe || (int)((off / stripe) & 1) != parity) {
+                        throw Error(TOAST_HIP_ERR_MEMORY, "arena selftest: a striped block crosses its stripe or has the wrong parity");
+                    }
+                } else {
+                    p = static_cast<unsigned char *>(a.alloc(n, nullptr));
+                }
                 if (p == nullptr) throw Error(TOAST_HIP_ERR_MEMORY, "arena selftest: host allocation failed");
                 const unsigned char tag = (unsigned char)(1 + rnd() % 255);
                 std::memset(p, tag, n);
@@ -1065,7 +1091,8 @@ int toast_hip_device_malloc(size_t nbytes, int flags, void ** out) {
     return guarded([&] {
         void * p = nullptr;
         if (flags < 0) {
-            p = Manager::get().device_alloc(nbytes, flags == -3);
+            p = Manager::get().device_alloc(nbytes, flags == -3 ? Manager::kBlockStreamed
+                                                    : flags == -4 ? Manager::kBlockScatter : Manager::kBlockDefault);
             if (p == nullptr) throw Error(TOAST_HIP_ERR_MEMORY, "HipManager:  device_malloc, allocation failed");
         } else if (flags == 0) {
             TH_HIP(hipMalloc(&p, nbytes));
@@ -1169,8 +1196,11 @@ int toast_hip_accel_create(const void * host, size_t nbytes, const char * name) 
     return guarded([&] { Manager::get().create(host, nbytes, name); });
 }
 
-int toast_hip_accel_create_streamed(const void * host, size_t nbytes, const char * name) {
-    return guarded([&] { Manager::get().create(host, nbytes, name, true); });
+int toast_hip_accel_create_kind(const void * host, size_t nbytes, const char * name, int kind) {
+    return guarded([&] {
+        if (kind < 0 || kind > 2) fail_arg("toast_hip_accel_create_kind: kind must be 0 (default), 1 (streamed) or 2 (scatter target)");
+        Manager::get().create(host, nbytes, name, kind);
+    });
 }
 
 int toast_hip_accel_adopt(const void * host, size_t nbytes, void * device, const char * name) {

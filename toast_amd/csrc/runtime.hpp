@@ -120,6 +120,10 @@ AllocStats alloc_stats();
 
 // Rank-interleaved slabs (vmm_slab.cpp): nullptr when switched off, too small, or the driver refuses.
 void * vmm_slab_take(size_t bytes, hipStream_t stream);
+// a 1 GB device range in the zone of the read-mostly arrays, for the slab builder to measure chunks against (runtime.cpp;
+// nullptr: none to be had -- the slab's first chunk is the reference then); released with zone_reference_release
+void * zone_reference_take(size_t bytes);
+void zone_reference_release(void * p);
 bool vmm_slab_give(void * p);       // false: not one of them
 struct VmmSlabStats {
     int64_t slabs = 0;               // interleaved slabs alive
@@ -173,8 +177,8 @@ public:
     int device();               // throws if not yet assigned; -1 when disabled
     void require_device();      // throws unless a GPU is assigned and usable; hipSetDevice
     int present(const void * host, size_t nbytes);
-    // streamed: a timestream that kernels read AND write in their sweeps (device_alloc)
-    void * create(const void * host, size_t nbytes, const char * name, bool streamed = false);
+    // kind: what the array is to the kernels (device_alloc)
+    void * create(const void * host, size_t nbytes, const char * name, int kind = 0);
     void adopt(const void * host, size_t nbytes, void * device, const char * name);
     void reset(const void * host, size_t nbytes, const char * name);
     void update_device(const void * host, size_t nbytes, const char * name);
@@ -194,11 +198,18 @@ public:
     void * scratch(int slot, size_t bytes);
     // Every device block of the library comes from here and goes back through device_free: a range of an arena slab
     // (arena.hpp), or -- TOAST_HIP_ALLOC=plain -- one hipMalloc / hipFree per block.  nullptr on failure.
-    // streamed = true asks for memory whose rows are spread over two HBM zones (rank-interleaved slabs, vmm_slab.cpp): a
-    // sweep that reads and writes ~1000 rows of one array at once runs 20 % faster there (scan_map, noise_weight, the
-    // FFT passes); read-only sweeps (build_noise_weighted, the packed left-hand side) are 5 % faster on plain slabs, which
-    // is what everything else gets.  Blocks below 1 GB are never interleaved.
-    void * device_alloc(size_t nbytes, bool streamed = false);
+    // `kind` says what the block is to the kernels, which decides WHERE in HBM it should live (vmm_slab.cpp: the 288 GB
+    // behave as three zones; reads and writes that meet in one zone slow each other down):
+    //   kBlockDefault  read-mostly arrays (pixels, weights, flags, the packed cache): plain slabs -- one zone, "P"
+    //   kBlockStreamed a timestream that sweeps read AND write (scan_map, noise_weight, template projections): a slab
+    //                  whose 1 GB chunks alternate between zone P and another zone, so that its ~1000 rows in flight are
+    //                  spread over two zones (6.1 instead of 5.1 TB/s for such sweeps)
+    //   kBlockScatter  the target of a scatter with atomics (maps, amplitude vectors): inside ONE chunk of the other
+    //                  zone, away from the streams that feed the scatter (build_noise_weighted 5.2 instead of 5.8 ms)
+    // Streamed / scatter blocks come from what has been reserved for them (reserve(bytes, true)); without a
+    // reservation, and below 1 GB for streamed blocks, they are default blocks.
+    static constexpr int kBlockDefault = 0, kBlockStreamed = 1, kBlockScatter = 2;
+    void * device_alloc(size_t nbytes, int kind = 0);
     // p from device_alloc (anything else is handed to hipFree).  The caller guarantees that nothing still queued uses it
     // on a stream other than stream(): the next owner's work is ordered after it on that stream.
     void device_free(void * p);

@@ -143,11 +143,17 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
         hipMemGenericAllocationHandle_t h;
         double rate;
     };
+    // What the chunks are measured against: a range in the zone of the read-mostly arrays when the arena has one (the
+    // even slots then hold chunks of THAT zone, the odd slots chunks of another: scatter targets go into odd chunks,
+    // Manager::device_alloc), else the slab's own first chunk.
+    char * ext_ref = static_cast<char *>(zone_reference_take(chunk));
+    const bool external = ext_ref != nullptr;
     std::vector<Cand> cand;
     hipMemGenericAllocationHandle_t first;
     bool have_first = false, failed = false;
     size_t probes = 0;
-    const size_t want_b = n / 2, want_a = n - want_b - 1;     // (chunk 0 is of class A by definition)
+    // (without an external reference chunk 0 is of class A by definition and sits in slot 0 from the start)
+    const size_t want_b = n / 2, want_a = n - want_b - (external ? 0 : 1);
     const size_t max_create = n + pol.search / chunk;
     double thr = 1.0e300;
     auto classify = [&] {
@@ -178,7 +184,7 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
             (void)hipGetLastError();
             break;   // the device is full: make do with what has been created
         }
-        if (!have_first) {
+        if (!have_first && !external) {
             if (!map_chunk(base, chunk, h, dev)) {
                 (void)hipMemRelease(h);
                 failed = true;
@@ -194,7 +200,7 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
             failed = true;
             break;
         }
-        void * two[2] = {base, where};
+        void * two[2] = {external ? ext_ref : base, where};
         const double ms = probe_stream_split_ms(two, 2, chunk, st);     // (best of three passes: the first one touches the chunk)
         ++probes;
         (void)hipMemUnmap(where, chunk);
@@ -204,6 +210,7 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
         counts(na, nb);
         if (na >= want_a && nb >= want_b) break;
     }
+    zone_reference_release(ext_ref);
     const size_t created = cand.size() + (have_first ? 1 : 0);
     size_t have_a = 0, have_b = 0;
     std::vector<hipMemGenericAllocationHandle_t> slot(n);
@@ -213,7 +220,7 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
         filled[0] = 1;
         have_a = 1;
     }
-    if (!failed && (!have_first || created < n)) failed = true;      // not enough memory for the slab at all
+    if (!failed && ((!have_first && !external) || created < n)) failed = true;   // not enough memory for the slab
     if (!failed) {
         // even slots: class A, odd slots: the others; what one class cannot fill, the other does -- the LAST created
         // first: the driver hands out one zone after the other, so a late chunk is the most likely to differ from chunk 0
@@ -227,8 +234,9 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
         for (size_t j = ib.size(); j > take_b && even.size() < want_a; --j) even.push_back(ib[j - 1]);
         std::vector<char> used(cand.size(), 0);
         if (even.size() < want_a || odd.size() < want_b) failed = true;
-        for (size_t k = 1; k < n && !failed; ++k) {
-            const size_t pick = (k % 2 == 1) ? odd[k / 2] : even[k / 2 - 1];
+        const size_t shift = have_first ? 1 : 0;      // even[] starts at slot 2 when chunk 0 already sits in slot 0
+        for (size_t k = shift; k < n && !failed; ++k) {
+            const size_t pick = (k % 2 == 1) ? odd[k / 2] : even[k / 2 - shift];
             used[pick] = 1;
             if (!map_chunk(base + k * chunk, chunk, cand[pick].h, dev)) {
                 failed = true;

@@ -642,7 +642,7 @@ class DetectorData(AcceleratorObject):
         # a two-dimensional float64 array per detector is a timestream: scan_map, noise_weight, the FFT passes and the
         # template projections read and write it in one sweep -- the arena keeps such blocks in rank-interleaved slabs
         streamed = self._data.ndim == 2 and self._data.dtype == np.float64
-        accel_data_create(self._data, self._accel_name, zero_out=zero_out, owner=self, streamed=streamed)
+        accel_data_create(self._data, self._accel_name, zero_out=zero_out, owner=self, kind=1 if streamed else 0)
 
     def _accel_update_device(self):
         accel_data_update_device(self._data, self._accel_name)

@@ -574,7 +574,9 @@ class PixelData(AcceleratorObject):
         return self._raw is not None and self._raw.size > 0 and accel_data_present(self._raw, self._accel_name)
 
     def _accel_create(self, zero_out=False):
-        accel_data_create(self._raw, self._accel_name, zero_out=zero_out, owner=self)
+        # a map is what the A^T kernels scatter into with atomics: the arena keeps it away from the zone of the arrays
+        # that feed the scatter (KIND_SCATTER; a covariance or hit map is only written once -- same place, no harm)
+        accel_data_create(self._raw, self._accel_name, zero_out=zero_out, owner=self, kind=2)
 
     def _accel_update_device(self):
         accel_data_update_device(self._raw, self._accel_name)

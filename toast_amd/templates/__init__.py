@@ -229,7 +229,8 @@ class Amplitudes(AcceleratorObject):
         return self._n_local > 0 and accel_data_present(self.local, self._accel_name)
 
     def _accel_create(self, zero_out=False):
-        accel_data_create(self.local, self._accel_name, zero_out=zero_out, owner=self)
+        # (amplitudes are what the M^T kernels scatter into: KIND_SCATTER)
+        accel_data_create(self.local, self._accel_name, zero_out=zero_out, owner=self, kind=2)
         accel_data_create(self.local_flags, self._accel_name + "_flags", owner=self)
         accel_data_update_device(self.local_flags, self._accel_name + "_flags")
 

@@ -86,8 +86,8 @@ def main():
 
     g2l_cache = {}
 
-    def run(name, off):
-        """off: array -> offset in GB (float) from the base"""
+    def run(name, off, zmap_off=None):
+        """off: array -> offset in GB (float) from the base; zmap_off: the map's offset (default: torch's own block)"""
         p = {k: base + int(v * GB) // 4096 * 4096 for k, v in off.items()}
         for k in p:
             assert p[k] + sizes[k] <= base + n, (k, off[k])
@@ -107,6 +107,9 @@ def main():
             g2l_cache["n_local"] = int(hit.size)
             g2l_cache["zmap"] = torch.zeros((int(hit.size), nps, nnz), dtype=torch.float64, device=dev)
         d_g2l, d_zmap = g2l_cache["g2l"], g2l_cache["zmap"]
+        if zmap_off is not None:
+            d_zmap = view(base + int(zmap_off * GB) // 4096 * 4096, torch.float64, (g2l_cache["n_local"], nps, nnz))
+            d_zmap.zero_()
         det_scale = np.full(n_det, 1.0 / (sigma * sigma))
         det_w = np.linspace(0.5, 0.9, n_det)
         bnw = lambda: D.build_noise_weighted(d_g2l.data_ptr(), d_zmap.data_ptr(), nps, nnz, idx, p["pixels"], idx,
@@ -144,6 +147,14 @@ def main():
     lay = seq(B + 4, ["pixels", "weights", "tod", "dflags"])
     lay["tod2"] = b1 - s_t / 2
     run("tod2 astride A|B, the rest in B", lay)
+    # where the MAP lives (the target of build_noise_weighted's atomics), streams in zone A
+    layA = seq(A, ["pixels", "weights", "tod", "tod2", "dflags"])
+    endA = max(layA[k] + sizes[k] * g for k in layA) + 0.1
+    run("all arrays in A, map in A right behind them", layA, zmap_off=endA)
+    run("all arrays in A, map in B", layA, zmap_off=B + 40.0 if B + 41 < args.gb else B + 1)
+    if b2:
+        run("all arrays in A, map in C", layA, zmap_off=C + 30.0 if C + 31 < args.gb else C + 1)
+    run("all arrays in A, map astride A|B", layA, zmap_off=b1 - 0.05)
     if b2:
         lay = seq(A, ["pixels", "tod", "dflags"])
         lay["weights"] = b1 - s_w / 2
