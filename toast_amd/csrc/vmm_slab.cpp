@@ -1,21 +1,29 @@
-// vmm_slab.cpp -- rank-interleaved slabs for the device arena (arena.hpp).
+// vmm_slab.cpp -- zone-interleaved slabs for the device arena (arena.hpp).
 //
-// Measured on MI355X (profiles/r04_a_arena_and_hbm_ranks.txt): the 288 GB of HBM3E behave as THREE zones of 96 GB
-// (12-high stacks = three ranks of four dies behind every channel).  A kernel that streams ~1000 timestream rows at once
-// -- every TOD-domain kernel of this library -- runs at 5.05 TB/s when all rows lie in one zone and at 6.1-6.2 TB/s when
-// they are spread over two: more banks behind each channel to keep the rows' DRAM pages open.  A plain hipMalloc is
-// physically contiguous more often than not, so a timestream-sized block usually sits inside one zone (the "slow
-// allocations" of rounds 1-3; the round-3 placement policy could only pick the lucky ones).
+// Measured on MI355X (profiles/r04_a_arena_and_hbm_zones.txt): the 288 GB of HBM3E behave as THREE zones of 96 GB
+// (12-high stacks = three ranks of four dies behind every channel).  Writes and reads that meet in one zone slow each
+// other down: a sweep that reads AND writes ~1000 rows of a timestream at once -- scan_map, noise_weight, the template
+// projections -- runs at 5.05 TB/s when the timestream lies inside one zone and at 6.1-6.2 TB/s when its rows are spread
+// over two; a scatter (build_noise_weighted) takes 5.84 ms when the map it adds to lies in the zone of the arrays it
+// streams and 5.22 ms when it lies in another.  Read-only sweeps do not care.  A plain hipMalloc is physically contiguous,
+// so a timestream-sized block sits inside one zone unless it happens to straddle a boundary: the "slow allocations" of
+// rounds 1-3, which the round-3 placement policy could only pick among.
 //
 // Here a slab is a virtual range built from separately created 1 GB physical chunks (hipMemCreate / hipMemMap), mapped
-// so that chunks of two different zones ALTERNATE along the range: any block of 2 GB or more then has its rows in both
-// zones wherever the arena puts it -- caller-visible layouts (the reference's [detector][sample] arrays) stay as they
-// are.  The zone of a chunk cannot be asked for, so it is measured: each new chunk gets one read + write pass together
-// with the slab's first chunk, rows dealt alternately to the two (probe_stream_split_ms, ~1 ms); the pass runs at the
-// slow level when both lie in the same zone.  Chunks are created until both classes have filled their half of the
-// slots (the driver hands out one zone after the other, so this can mean creating up to ~96 chunks more than the slab
-// needs; the surplus is released before the function returns), or until `TOAST_HIP_ARENA_SEARCH_GB` (default 128) of
-// surplus have been looked at -- then the remaining slots take what there is.
+// so that chunks of two zones ALTERNATE along the range -- even slots: the zone of the arena's read-mostly slabs ("P"),
+// odd slots: another zone.  A streamed block of 2 GB or more then has its rows in both zones wherever the arena puts it
+// (caller-visible layouts, the reference's [detector][sample] arrays, stay as they are), and a scatter target is
+// placed inside one odd chunk (Arena::alloc_striped).  Only those two kinds of block live here: read-only sweeps are
+// ~5 % slower on chunk-mapped memory than on a plain slab, for any chunk size (r04_a section 6).
+//
+// The zone of a chunk cannot be asked for, so it is measured: each new chunk gets one read + write pass together with a
+// reference range (1 GB borrowed from the read-mostly slabs; the slab's own first chunk when there are none yet), rows
+// dealt alternately to the two (probe_stream_split_ms, ~1 ms); the pass runs at the slow level when both lie in one
+// zone.  Every chunk is measured at an address of its own (section 5: a chunk mapped where another one sat a moment
+// before shows the earlier chunk's level).  Chunks are created until both classes have filled their half of the slots
+// (the driver hands out one zone after the other, so this can mean creating many more chunks than the slab needs; the
+// surplus is released before the function returns), or until `TOAST_HIP_ARENA_SEARCH_GB` (default 128) of surplus
+// have been looked at -- then the remaining slots take what there is.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
