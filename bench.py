@@ -574,13 +574,25 @@ def run(args, workload, world, rank, dev, headline=True):
         "iteration_GBs": (BYTES_BNW + BYTES_SCAN) * nsamp_tot / ((ms["bnw"] + ms["scan"]) * 1e-3) / 1e9,
     }
 
-    owner_ms = None
+    owner_ms, mode_ms = None, None
     if comm_impl is not None and comm_impl.startswith("toast_hip_comm"):
         # the same sum + covariance as ONE owner-computes pass (reduce-scatter, cov_apply_diag on the owned pixel
         # shard, all-gather): what ops.BinMap / the fused SolverLHS do with sync_type = "alltoallv"
         oc = lambda: D.comm_map_reduce_apply(n_local * nps, nnz, d_cov.data_ptr(), d_zmap.data_ptr(), True, stream)
         oc()
         owner_ms = timed(oc, 5)
+        # ... and the other two ways the library can do that pass (toast_hip_comm_set_mode), for an A/B on this very job:
+        # pixel slices on two side streams (reduce-scatter of slice k + 1 under multiplication + all-gather of slice k),
+        # and one all-reduce followed by every rank multiplying the whole map
+        mode_ms = {"owner": owner_ms}
+        for mode in ("sliced:2", "sliced:4", "sliced:8", "allreduce"):
+            try:
+                D.comm_set_mode(mode)
+                oc()
+                mode_ms[mode] = timed(oc, 5)
+            except RuntimeError as err:      # noqa: PERF203 -- the headline must not depend on this extra
+                mode_ms[mode] = repr(err)[:200]
+        D.comm_set_mode("owner")
 
     # measured stream ceiling on this box ("report % of both"): a pure
     # 8 B read + 8 B write stream (k_noise_weight over the work timestream, scale 1.0)
@@ -665,6 +677,8 @@ def run(args, workload, world, rank, dev, headline=True):
             "backend": (dist.get_backend() if multi else None),
             "implementation": comm_impl,
             "owner_computes_reduce_apply_ms": owner_ms,
+            # the same pass per implementation (TOAST_HIP_COMM_MODE): {"owner", "sliced:2", "sliced:4", "sliced:8", "allreduce"}
+            "reduce_apply_ms_by_mode": mode_ms,
             "note": comm_note,
             "algorithm_GBs": (2.0 * (world - 1) / world * n_local * nps * nnz * 8 / (ms["allreduce"] * 1e-3) / 1e9
                               if multi and world > 1 and ms["allreduce"] > 0 else None),

@@ -1111,6 +1111,14 @@ int toast_hip_comm_pixel_shard(int64_t n_px, int64_t * first, int64_t * count);
 int toast_hip_comm_shard_of(int64_t n_px, int n_ranks, int rank, int64_t * first, int64_t * count, int64_t * per_rank);
 int toast_hip_comm_map_reduce_apply_dev(int64_t n_px, int64_t nnz, const double * d_cov, double * d_map, int reduce,
                                         void * stream);
+/* How toast_hip_comm_map_reduce_apply_dev does its work (TOAST_HIP_COMM_MODE sets the start-up value): "owner" (default:
+ * reduce-scatter, multiplication on the owned shard, all-gather on the caller's stream), "sliced:S" (the same in S pixel
+ * slices dealt to two side streams, so that the reduce-scatter of slice k + 1 overlaps multiplication and all-gather of
+ * slice k), "allreduce" (one all-reduce, every rank multiplies the whole map: the reference's sync_allreduce +
+ * covariance_apply, pixels.py:710-780).  Same results in every mode (to the rounding of the sums' order).  Collective:
+ * every rank must use the same mode. */
+int toast_hip_comm_set_mode(const char * mode);
+int toast_hip_comm_get_mode(char * mode, size_t len);
 int toast_hip_comm_cov_invert_dev(int64_t n_px, int64_t nnz, double * d_cov, double * d_rcond, double threshold,
                                   int invert, void * stream);
 int toast_hip_comm_cov_mult_dev(int64_t n_px, int64_t nnz, double * d_cov1, const double * d_cov2, void * stream);

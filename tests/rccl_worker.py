@@ -18,7 +18,7 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from toast_amd.accel import accel_assign_device, native  # noqa: E402
+from toast_amd.accel import accel_assign_device, accel_device_ptr, native  # noqa: E402
 from toast_amd.data import Comm  # noqa: E402
 from toast_amd.pixels import PixelData, PixelDistribution, covariance_apply  # noqa: E402
 
@@ -210,6 +210,29 @@ def main():
         np.testing.assert_allclose(z.data, ref.data, rtol=1e-13, atol=1e-13 * np.max(np.abs(total)))
         cv.accel_delete()
         z.accel_delete()
+    # the three implementations of the owner-computes pass (toast_hip_comm_set_mode): same sums, same product
+    for mode in ("owner", "sliced:2", "sliced:4", "allreduce", "owner"):
+        capi.dev.comm_set_mode(mode)
+        assert capi.dev.comm_get_mode() == mode
+        for reduce in (True, False):
+            cv, z = dev_map(spd, 6, "cov"), dev_map(parts[rank] if reduce else total, 3, "zmap")
+            capi.dev.comm_map_reduce_apply(37 * 48, 3, accel_device_ptr(cv.buffer), accel_device_ptr(z.buffer), reduce=reduce)
+            z.accel_used(True)
+            ref = PixelData(d, np.float64, n_value=3)
+            ref.raw[:] = total
+            covariance_apply(dev_map(spd, 6, "cov2"), ref)
+            np.testing.assert_allclose(z.data, ref.data, rtol=1e-13, atol=1e-13 * np.max(np.abs(total)), err_msg=mode)
+            cv.accel_delete()
+            z.accel_delete()
+        # a map large enough for the slices to be used (>= S * ranks * 64 pixels): 40 000 pixels, one value
+        big = np.random.default_rng(77 + rank).standard_normal(40000)
+        tot = np.zeros(40000)
+        for r in range(size):
+            tot += np.random.default_rng(77 + r).standard_normal(40000)
+        t = torch.from_numpy(big).cuda()
+        capi.dev.comm_map_reduce_apply(40000, 1, 0, t.data_ptr(), reduce=True)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(t.cpu().numpy(), tot, rtol=0, atol=1e-13 * np.max(np.abs(tot)), err_msg=mode)
     # MIXED residency: rank 0 has "evicted" its map -- it holds it on the host -- while the others hold
     # theirs on the device.  The route does not depend on where a rank's copy lives, so every rank enters the same
     # collective on the same communicator: no hang, the right sums, and each copy ends where it started.

@@ -72,6 +72,12 @@ def test_bench_ranks_through_the_library_communicator(mock_lib, n):
     d = json.loads(lines[0])
     assert d["n_gpus"] == n and d["allreduce"]["implementation"].startswith("toast_hip_comm"), d["allreduce"]
     assert d["allreduce"]["note"] is None and d["allreduce"]["owner_computes_reduce_apply_ms"] > 0
+    # every implementation of the owner-computes pass was timed on this job (A/B material for the first 8-GPU lease),
+    # and the packed left-hand side with the reduction inside is part of the same line
+    modes = d["allreduce"]["reduce_apply_ms_by_mode"]
+    assert set(modes) == {"owner", "sliced:2", "sliced:4", "sliced:8", "allreduce"}
+    assert all(isinstance(v, float) and v > 0 for v in modes.values()), modes
+    assert d["pcg_lhs_offset_templates"]["packed_ms"] > 0
     assert d["configs3_shard"]["allreduce"]["implementation"].startswith("toast_hip_comm")
 
 

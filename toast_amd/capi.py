@@ -1232,6 +1232,16 @@ class _Dev:
         _check(lib().toast_hip_comm_map_reduce_apply_dev(_i64(n_px), _i64(nnz), _p(d_cov), _p(d_map),
                                                          C.c_int(1 if reduce else 0), _p(stream)))
 
+    def comm_set_mode(self, mode):
+        """'owner' | 'sliced:S' | 'allreduce': how comm_map_reduce_apply works (toast_hip_comm_set_mode; collective:
+        every rank the same)."""
+        _check(real_lib().toast_hip_comm_set_mode(str(mode).encode()))
+
+    def comm_get_mode(self):
+        buf = C.create_string_buffer(32)
+        _check(real_lib().toast_hip_comm_get_mode(buf, C.c_size_t(32)))
+        return buf.value.decode()
+
     def comm_cov_invert(self, n_px, nnz, d_cov, d_rcond, threshold, invert=True, stream=0):
         _check(lib().toast_hip_comm_cov_invert_dev(_i64(n_px), _i64(nnz), _p(d_cov), _p(d_rcond),
                                                    C.c_double(float(threshold)), C.c_int(1 if invert else 0), _p(stream)))

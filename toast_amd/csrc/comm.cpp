@@ -294,9 +294,110 @@ int toast_hip_comm_pixel_shard(int64_t n_px, int64_t * first, int64_t * count) {
     });
 }
 
-// map <- [C .] sum over ranks (map), owner computes:  reduce-scatter of the pixel shards, cov_apply_diag on the owned
-// shard (skipped when d_cov is null), all-gather.  reduce = 0: the map is already the same on all ranks (the
-// reference's covariance_apply(use_alltoallv=True), covariance.py:224-306): owners apply, results are gathered.
+// ------------------------------------------------------------------------------------
+// map <- [C .] sum over ranks (map): the middle of every PCG iteration and the finalisation of a binned map.
+// Three ways to do it, switchable at run time so that a multi-GPU run can compare them on its own data
+// (TOAST_HIP_COMM_MODE / toast_hip_comm_set_mode; bench.py reports all of them per N):
+//   owner      (default) reduce-scatter of the pixel shards, cov_apply_diag on the owned shard, all-gather -- all on the
+//              caller's stream.  2 (N-1)/N map volumes over the links, the multiplication done once per pixel.
+//   sliced:S   the same in S pixel slices dealt alternately to two side streams: the reduce-scatter of slice k + 1 runs
+//              while the owners multiply slice k and gather it.  The caller's stream waits for both at the end.
+//   allreduce  one all-reduce of the whole map, then every rank multiplies the whole map (what sync_allreduce +
+//              covariance_apply do; the reference's default, pixels.py:710-780).
+// reduce = 0: the map is already the same on all ranks (the reference's covariance_apply(use_alltoallv=True),
+// covariance.py:224-306): owners apply, results are gathered (allreduce mode: every rank applies, no communication).
+}  // extern "C"
+
+namespace {
+
+struct CommMode {
+    int kind = 0;      // 0 owner, 1 sliced, 2 allreduce
+    int slices = 4;
+};
+CommMode g_mode;
+bool g_mode_read = false;
+
+CommMode parse_mode(const char * text) {
+    CommMode m;
+    const std::string v(text ? text : "");
+    if (v.empty() || v == "owner") return m;
+    if (v == "allreduce") {
+        m.kind = 2;
+        return m;
+    }
+    if (v.rfind("sliced", 0) == 0) {
+        m.kind = 1;
+        const size_t c = v.find(':');
+        if (c != std::string::npos) m.slices = std::atoi(v.c_str() + c + 1);
+        if (m.slices < 2 || m.slices > 64) fail_arg("HipComm:  sliced:S needs 2 <= S <= 64");
+        return m;
+    }
+    fail_arg("HipComm:  unknown mode '" + v + "' (owner | sliced[:S] | allreduce)");
+}
+
+const CommMode & mode() {
+    if (!g_mode_read) {
+        g_mode = parse_mode(std::getenv("TOAST_HIP_COMM_MODE"));
+        g_mode_read = true;
+    }
+    return g_mode;
+}
+
+struct SideStreams {
+    hipStream_t st[2] = {nullptr, nullptr};
+    hipEvent_t start = nullptr, done[2] = {nullptr, nullptr};
+    void prepare() {
+        if (st[0] != nullptr) return;
+        for (int k = 0; k < 2; ++k) {
+            TH_HIP(hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking));
+            TH_HIP(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
+        }
+        TH_HIP(hipEventCreateWithFlags(&start, hipEventDisableTiming));
+    }
+};
+SideStreams g_side;
+
+// owner-computes pass over the pixels [px0, px0 + n) of the map, on `st`
+void reduce_apply_range(int64_t px0, int64_t n, int64_t nnz, const double * d_cov, double * d_map, int reduce, int slot,
+                        hipStream_t st) {
+    if (n <= 0) return;
+    const Shard s = shard_of(n);
+    const int64_t ncov = nnz * (nnz + 1) / 2;
+    double * part = d_map + px0 * nnz;
+    double * work = part;
+    if (!s.even) work = padded_copy(part, n, nnz, s, slot, st);
+    double * mine = work + (int64_t)g_rank * s.per * nnz;
+    if (reduce) {
+        check(rccl().reduce_scatter(work, mine, (size_t)(s.per * nnz), ncclFloat64, ncclSum, comm(), st), "ncclReduceScatter");
+    }
+    if (d_cov != nullptr && s.count > 0) {
+        const int rc = toast_hip_cov_apply_diag_dev(1, s.count, nnz, d_cov + (px0 + s.first) * ncov, mine, st);
+        if (rc != 0) throw Error(rc, toast_hip_last_error());
+    }
+    check(rccl().all_gather(mine, work, (size_t)(s.per * nnz), ncclFloat64, comm(), st), "ncclAllGather");
+    if (work != part) TH_HIP(hipMemcpyAsync(part, work, (size_t)n * nnz * sizeof(double), hipMemcpyDeviceToDevice, st));
+}
+
+}  // namespace
+
+extern "C" {
+
+int toast_hip_comm_set_mode(const char * text) {
+    return guarded([&] {
+        g_mode = parse_mode(text);
+        g_mode_read = true;
+    });
+}
+
+int toast_hip_comm_get_mode(char * text, size_t len) {
+    return guarded([&] {
+        const CommMode & m = mode();
+        const std::string v = m.kind == 0 ? "owner" : m.kind == 2 ? "allreduce" : "sliced:" + std::to_string(m.slices);
+        if (text == nullptr || len < v.size() + 1) fail_arg("HipComm:  mode buffer too small");
+        std::memcpy(text, v.c_str(), v.size() + 1);
+    });
+}
+
 int toast_hip_comm_map_reduce_apply_dev(int64_t n_px, int64_t nnz, const double * d_cov, double * d_map, int reduce,
                                         void * stream) {
     return guarded([&] {
@@ -304,23 +405,36 @@ int toast_hip_comm_map_reduce_apply_dev(int64_t n_px, int64_t nnz, const double 
         if (nnz <= 0) fail_arg("nnz must be positive");
         (void)comm();
         hipStream_t st = as_stream(stream);
-        const Shard s = shard_of(n_px);
-        const int64_t ncov = nnz * (nnz + 1) / 2;
-        double * work = d_map;
-        if (!s.even) work = padded_copy(d_map, n_px, nnz, s, Manager::kScratchCommA, st);
-        double * mine = work + (int64_t)g_rank * s.per * nnz;
-        if (reduce) {
-            check(rccl().reduce_scatter(work, mine, (size_t)(s.per * nnz), ncclFloat64, ncclSum, comm(), st),
-                  "ncclReduceScatter");
+        const CommMode & m = mode();
+        if (m.kind == 2) {
+            if (reduce) {
+                check(rccl().all_reduce(d_map, d_map, (size_t)(n_px * nnz), ncclFloat64, ncclSum, comm(), st), "ncclAllReduce");
+            }
+            if (d_cov != nullptr) {
+                const int rc = toast_hip_cov_apply_diag_dev(1, n_px, nnz, d_cov, d_map, stream);
+                if (rc != 0) throw Error(rc, toast_hip_last_error());
+            }
+            return;
         }
-        if (d_cov != nullptr && s.count > 0) {
-            const int rc = toast_hip_cov_apply_diag_dev(1, s.count, nnz, d_cov + s.first * ncov, mine, stream);
-            if (rc != 0) throw Error(rc, toast_hip_last_error());
+        if (m.kind == 1 && n_px >= (int64_t)m.slices * g_size * 64) {
+            // slices of a whole number of pixels per rank (no padding), the remainder goes to the last one
+            const int64_t per_slice = n_px / m.slices / g_size * g_size;
+            g_side.prepare();
+            TH_HIP(hipEventRecord(g_side.start, st));
+            for (int k = 0; k < 2; ++k) TH_HIP(hipStreamWaitEvent(g_side.st[k], g_side.start, 0));
+            for (int k = 0; k < m.slices; ++k) {
+                const int64_t px0 = (int64_t)k * per_slice;
+                const int64_t n = (k == m.slices - 1) ? n_px - px0 : per_slice;
+                // (only the last slice can be uneven: one user of the padded scratch copy)
+                reduce_apply_range(px0, n, nnz, d_cov, d_map, reduce, Manager::kScratchCommA, g_side.st[k & 1]);
+            }
+            for (int k = 0; k < 2; ++k) {
+                TH_HIP(hipEventRecord(g_side.done[k], g_side.st[k]));
+                TH_HIP(hipStreamWaitEvent(st, g_side.done[k], 0));
+            }
+            return;
         }
-        check(rccl().all_gather(mine, work, (size_t)(s.per * nnz), ncclFloat64, comm(), st), "ncclAllGather");
-        if (work != d_map) {
-            TH_HIP(hipMemcpyAsync(d_map, work, (size_t)n_px * nnz * sizeof(double), hipMemcpyDeviceToDevice, st));
-        }
+        reduce_apply_range(0, n_px, nnz, d_cov, d_map, reduce, Manager::kScratchCommA, st);
     });
 }
 
