@@ -58,7 +58,8 @@ def build_library(force=False, verbose=True):
     for s in srcs:
         o = os.path.join(HERE, "build", os.path.basename(s) + ".o")
         objs.append(o)
-        cmd = [_hipcc(), "-x", "hip", "-c", s, "-o", o] + HIPCC_FLAGS
+        # TOAST_HIP_EXTRA_FLAGS: experimental builds (e.g. -DTOAST_FFT_PHASE_CLOCK, tools/exp_fft_phases.py)
+        cmd = [_hipcc(), "-x", "hip", "-c", s, "-o", o] + HIPCC_FLAGS + os.environ.get("TOAST_HIP_EXTRA_FLAGS", "").split()
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((cmd, subprocess.Popen(cmd)))

@@ -396,11 +396,13 @@ __device__ __forceinline__ double2 padded_pair(const double * __restrict__ row, 
     return out;
 }
 
-// Experimental build (-DTOAST_FFT_PHASE_CLOCK, tools/exp_fft_phases.py): thread 0 of every workgroup
-// adds the 100 MHz wall-clock ticks between phase boundaries to g_phase_ticks.
+// Experimental build (TOAST_HIP_EXTRA_FLAGS=-DTOAST_FFT_PHASE_CLOCK python -m toast_amd.build --force; tools/exp_fft_phases.py):
+// thread 0 of every workgroup adds the 100 MHz wall-clock ticks between phase boundaries to g_phase_ticks.
 #if defined(TOAST_FFT_PHASE_CLOCK)
 __device__ unsigned long long g_phase_ticks[16];
+# define PHASE_ENTRY const unsigned long long ph_e = wall_clock64()
 # define PHASE_DECL unsigned long long ph_t = wall_clock64()
+# define PHASE_SINCE_ENTRY(i) if (threadIdx.x == 0) atomicAdd(&g_phase_ticks[i], wall_clock64() - ph_e)
 # define PHASE_WAIT_LOADS asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 # define PHASE_MARK(i)                                                        \
     do {                                                                      \
@@ -409,7 +411,9 @@ __device__ unsigned long long g_phase_ticks[16];
         ph_t = ph_n;                                                          \
     } while (0)
 #else
+# define PHASE_ENTRY
 # define PHASE_DECL
+# define PHASE_SINCE_ENTRY(i)
 # define PHASE_WAIT_LOADS
 # define PHASE_MARK(i)
 #endif
@@ -669,6 +673,7 @@ __global__ __launch_bounds__((1 << LT) / P, (P == 16 ? 2 : 4)) void k_fft_rows(c
     double2 * __restrict__ work = p.work + (int64_t)b * m;
     const int64_t r0 = (g == 0) ? 0 : g;
     const int64_t r1 = (g == 0) ? (n1 >> 1) : (n1 - g);
+    PHASE_ENTRY;
     double2 v[P];
     // tile element e = 2 k2 + r
 #pragma unroll
@@ -679,8 +684,9 @@ __global__ __launch_bounds__((1 << LT) / P, (P == 16 ? 2 : 4)) void k_fft_rows(c
     }
     const auto kt = KTabSel<TLDS>::make(p, p.per_det ? (int64_t)(p.det0 + b) : 0, reinterpret_cast<char *>(sm + kRowTile),
                                         tid, T);
-    PHASE_DECL;
     PHASE_WAIT_LOADS;
+    PHASE_SINCE_ENTRY(14);      // kernel entry -> tile and kernel tables landed
+    PHASE_DECL;
     PHASE_MARK(0);
     tile_fft_t<LT, P>(v, sm, tid, p.log_n2, p.tb.wtile, tid, tid);
     __syncthreads();
@@ -763,6 +769,7 @@ __global__ __launch_bounds__((1 << LT) / P, (P == 16 ? 2 : 4)) void k_fft_rows(c
     }
     PHASE_WAIT_LOADS;
     PHASE_MARK(4);
+    PHASE_SINCE_ENTRY(15);      // the workgroup's whole life
 }
 
 // pass 2, row pairs (k1, N1 - k1) with 0 < k1 < N1 / 2: ONE row (N2 = 2048 elements, 32 KB of LDS) in the tile at
