@@ -305,6 +305,7 @@ struct Params {
     const double * ang_coef;      // nullptr: real kernel
     const int32_t * knot_hint;    // interval index at bin q N1, q = 0 .. N2 + 1
     const uint16_t * knot_hint16; // the same in 16 bits (n_knot < 65536), for the LDS copy
+    const int32_t * knot_hint0;   // interval index at every bin j of the FIRST block, j = 0 .. N1 - 1
     int per_det, deconvolve;
     int aligned;                  // pass 1 may use padded_pair
     int xcd_order;                // column passes: contiguous column ranges per XCD
@@ -534,6 +535,7 @@ __device__ __forceinline__ double ppoly_at(const double * __restrict__ knots, in
 template <typename H>
 struct KTab {
     const H * hint;            // interval at bin q N1, q = 0 .. N2 + 1
+    const int32_t * hint0;     // interval at every bin of the first block (global memory: one lane per workgroup asks)
     const double * knots;
     const double * mc;         // |K| cubics of this workgroup's detector
     const double * ac;         // arg K cubics, nullptr: real kernel
@@ -543,12 +545,15 @@ struct KTab {
 
 // Interval of bin k in the knot vector.  hint[q] is the interval at bin q N1 (the first bin of element q of every
 // row), so the answer lies in [hint[q], hint[q + 1]]: no search at all where no knot falls into the block (most of
-// them: the noise kernels' frequencies are log spaced), a walk only below that (the first block holds most knots of
-// a log-spaced vector).
+// them: the noise kernels' frequencies are log spaced), a short walk otherwise.  The FIRST block holds most knots of a
+// log-spaced vector (cfg-3: 53 of 77 below bin N1): its bins are looked up directly in hint0 -- the one lane per
+// workgroup that owns such a bin used to walk ~45 knots, LDS round trip by round trip, while the other 511 threads
+// waited for it at the barrier (profiles/r04_c: 5.5 of a workgroup's 25 us).
 template <typename H>
 __device__ __forceinline__ int kernel_interval(const KTab<H> & t, int k) {
     const double x = (double)k * t.fstep;
     const int q = k >> t.log_n1;
+    if (q == 0) return t.hint0[k];
     const int h0 = (int)t.hint[q];
     const int h1 = (int)t.hint[q + 1];
     int lo = h0;
@@ -583,6 +588,7 @@ struct KTabSel {
     static __device__ __forceinline__ KTab<H> make(const Params & p, int64_t kern, char *, int, int) {
         KTab<H> t;
         t.hint = p.knot_hint;
+        t.hint0 = p.knot_hint0;
         t.knots = p.knots;
         t.mc = p.mag_coef + kern * 4 * (p.n_knot - 1);
         t.ac = p.ang_coef ? p.ang_coef + kern * 4 * (p.n_knot - 1) : nullptr;
@@ -611,6 +617,7 @@ struct KTabSel<true> {
         for (int i = tid; i < n_hint; i += nthread) s_hint[i] = p.knot_hint16[i];
         KTab<H> t;
         t.hint = s_hint;
+        t.hint0 = p.knot_hint0;
         t.knots = s_knots;
         t.mc = s_mc;
         t.ac = p.ang_coef ? s_ac : nullptr;
@@ -708,13 +715,19 @@ __global__ __launch_bounds__((1 << LT) / P, (P == 16 ? 2 : 4)) void k_fft_rows(c
                                    1.0, 0.92387953251128673848, 0.70710678118654752440, 0.38268343236508977173};
         const int k0 = g + ((int)n1) * tid;
         const int dk = ((int)n1) * T;
-        const double2 w0 = tw_big(p.tb, k0);
+        // w_N^k0 = w_N^g w_N^(N1 tid) = w_N^g w_(2 N2)^tid: one factor that is the same for the whole workgroup and one
+        // entry of the tile table at a lane-contiguous index, instead of three gathers from the three-level table
+        const double2 w0 = cmul(tw_big(p.tb, g), p.tb.wtile[tid << (kLT - LT)]);
         int lo_a[NP], lo_b[NP];
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             lo_a[i] = kernel_interval(kt, k0 + dk * i);
             lo_b[i] = kernel_interval(kt, (int)m - (k0 + dk * i));
         }
+#if defined(TOAST_FFT_PHASE_CLOCK)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::"v"(w0.x), "v"(lo_a[NP - 1]), "v"(lo_b[NP - 1]) : "memory");
+        PHASE_MARK(9);      // twiddle + interval look-ups
+#endif
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             const int q = tid + T * i;
@@ -753,6 +766,10 @@ __global__ __launch_bounds__((1 << LT) / P, (P == 16 ? 2 : 4)) void k_fft_rows(c
             pair_update(sm, ea, eb, tw_big(p.tb, k), kernel_at(kt, k), kernel_at(kt, m - k), p.deconvolve);
         }
     }
+#if defined(TOAST_FFT_PHASE_CLOCK)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    PHASE_MARK(10);         // evaluation + pair updates (this thread's)
+#endif
     __syncthreads();
     PHASE_MARK(2);
 #pragma unroll
@@ -834,11 +851,14 @@ __global__ __launch_bounds__((kTile / 2) / P, WPE) void k_fft_rows_split(const P
 }
 
 // interval of the kernel's piecewise cubics at bin q N1 (frequency q N1 fstep), q = 0 .. N2 + 1
+// (threads n_block .. n_block + N1 - 1: the interval at every bin of the first block, hint0)
 __global__ void k_knot_hint(const double * __restrict__ knots, int n_knot, double fstep, int log_n1, int64_t n_block,
-                            int32_t * __restrict__ hint, uint16_t * __restrict__ hint16) {
+                            int32_t * __restrict__ hint, uint16_t * __restrict__ hint16, int32_t * __restrict__ hint0) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_block) return;
-    const double x = (double)(i << log_n1) * fstep;
+    const int64_t n1 = int64_t(1) << log_n1;
+    if (i >= n_block + n1) return;
+    const bool first = i >= n_block;
+    const double x = (double)(first ? (i - n_block) : (i << log_n1)) * fstep;
     int lo = 0, hi = n_knot - 2;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -847,6 +867,10 @@ __global__ void k_knot_hint(const double * __restrict__ knots, int n_knot, doubl
         } else {
             hi = mid - 1;
         }
+    }
+    if (first) {
+        hint0[i - n_block] = lo;
+        return;
     }
     hint[i] = lo;
     hint16[i] = (uint16_t)(lo < 65535 ? lo : 65535);
@@ -1026,16 +1050,20 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
     if (batch > cap) batch = cap > 0 ? cap : 1;
     if (batch > n_det) batch = n_det;
     const int64_t n_hint = (int64_t(1) << p.log_n2) + 2;       // bins q N1, q = 0 .. N2 + 1
-    const size_t hint_bytes = ((size_t)n_hint * (sizeof(int32_t) + sizeof(uint16_t)) + 255) & ~size_t(255);
+    const int64_t n_hint0 = int64_t(1) << p.log_n1;             // every bin of the first block
+    const size_t hint_bytes = ((size_t)n_hint * (sizeof(int32_t) + sizeof(uint16_t)) + (size_t)n_hint0 * sizeof(int32_t) +
+                               255 + 8) & ~size_t(255);
     char * scratch = (char *)Manager::get().scratch(Manager::kScratchFftWork,
                                                     hint_bytes + (size_t)batch * m * sizeof(double2));
     int32_t * d_hint = (int32_t *)scratch;
-    uint16_t * d_hint16 = (uint16_t *)(d_hint + n_hint);
+    int32_t * d_hint0 = d_hint + n_hint;
+    uint16_t * d_hint16 = (uint16_t *)(d_hint0 + n_hint0);
     p.knot_hint = d_hint;
     p.knot_hint16 = d_hint16;
+    p.knot_hint0 = d_hint0;
     p.work = (double2 *)(scratch + hint_bytes);
-    hipLaunchKernelGGL(k_knot_hint, dim3((unsigned)((n_hint + 255) / 256)), dim3(256), 0, st, d_knots,
-                       (int)n_knot, fstep, p.log_n1, n_hint, d_hint, d_hint16);
+    hipLaunchKernelGGL(k_knot_hint, dim3((unsigned)((n_hint + n_hint0 + 255) / 256)), dim3(256), 0, st, d_knots,
+                       (int)n_knot, fstep, p.log_n1, n_hint, d_hint, d_hint16, d_hint0);
     // row pass: knots, this detector's cubics and 16-bit hints in LDS when they fit (layout: KTabSel<true>::make)
     const size_t tab_bytes = (((size_t)n_knot + (size_t)4 * (n_knot - 1) * (d_ang ? 2 : 1)) * sizeof(double) +
                               (size_t)n_hint * sizeof(uint16_t) + 15) & ~size_t(15);

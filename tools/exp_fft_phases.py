@@ -36,9 +36,10 @@ lib.toast_hip_fft_phase_ticks(ticks, 1)
 call()
 lib.toast_hip_fft_phase_ticks(ticks, 1)
 n_wg = n_det * 256        # row pairs per detector at n_fft = 2^21: N1 / 2
-names = {14: "entry -> tile + tables landed", 1: "forward FFT", 2: "unpack / kernel / repack", 3: "inverse FFT",
+names = {14: "entry -> tile + tables landed", 1: "forward FFT", 9: "  pair: twiddle + interval look-ups",
+         10: "  pair: evaluation + updates", 2: "  pair: wait at the barrier", 3: "inverse FFT",
          4: "store issue + drain", 15: "whole workgroup"}
-for k in (14, 1, 2, 3, 4, 15):
+for k in (14, 1, 9, 10, 2, 3, 4, 15):
     print("  phase %2d %-32s %8.2f us per workgroup" % (k, names[k], ticks[k] / n_wg / 100.0))
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
