@@ -299,7 +299,7 @@ def run(args, workload, world, rank, dev, headline=True):
             pass
 
         blk = _Block()
-        typestr = {torch.int64: "<i8", torch.float64: "<f8", torch.uint8: "|u1", torch.int32: "<i4"}[dtype]
+        typestr = {torch.int64: "<i8", torch.float64: "<f8", torch.uint8: "|u1", torch.int32: "<i4", torch.float32: "<f4"}[dtype]
         blk.__cuda_array_interface__ = dict(shape=tuple(shape), typestr=typestr, data=(ptr, False), version=3)
         return torch.as_tensor(blk, device=dev)
 
@@ -804,19 +804,27 @@ def run(args, workload, world, rank, dev, headline=True):
             1, d_sflags.data_ptr(), n_samp, 1, idx, d_dflags.data_ptr(), n_samp, 1, n_samp, ivl, pk_key.data_ptr(),
             pk_qu.data_ptr(), pk_cal.data_ptr(), stream=stream)
         t_pack = 1e3 * (time.time() - t0)
+        # pair weights: the partner's Q / U as exact float sums (14 instead of 18 B per det-sample); refused unless exact
+        pk_corr, corr_ptr = None, 0
+        if packable and pair_words:
+            pk_corr = temp(torch.float32, ((n_det + 1) // 2, n_samp, 2))
+            if D.offset_pack_pair_weights(pk_qu.data_ptr(), pk_corr.data_ptr(), n_det, n_samp, ivl, stream=stream):
+                corr_ptr = pk_corr.data_ptr()
         if packable:
+            use_corr = [0]
+
             def lhs_packed():
                 d_zmap.zero_()
                 D.offset_accumulate_packed(step_len, amp_off, nav, d_amp_in.data_ptr(), d_amp_flags.data_ptr(),
                                            d_zmap.data_ptr(), pk_key.data_ptr(), pk_qu.data_ptr(), pk_cal.data_ptr(),
-                                           det_w, n_samp, ivl, pair_words=pair_words, stream=stream)
+                                           det_w, n_samp, ivl, pair_words=pair_words, pair_corr=use_corr[0], stream=stream)
                 allreduce_zmap()
                 D.cov_apply_diag(n_local, nps, nnz, d_cov.data_ptr(), d_zmap.data_ptr(), stream)
                 d_amp_out.zero_()
                 D.offset_scan_project_packed(step_len, amp_off, nav, d_amp_in.data_ptr(), d_amp_out.data_ptr(),
                                              d_amp_flags.data_ptr(), d_zmap.data_ptr(), pk_key.data_ptr(),
                                              pk_qu.data_ptr(), pk_cal.data_ptr(), det_w, n_samp, ivl,
-                                             pair_words=pair_words, stream=stream)
+                                             pair_words=pair_words, pair_corr=use_corr[0], stream=stream)
 
             lhs_packed()
             err_pk = float((d_amp_out - ref_out).abs().max() / ref_out.abs().max())
@@ -829,6 +837,21 @@ def run(args, workload, world, rank, dev, headline=True):
                 "packed_vs_sequence_max_rel_diff": err_pk,
                 "pack_once_ms": t_pack,
             })
+            if corr_ptr:
+                # the same sweeps with the partner's weights rebuilt from the pair sums: what ops.SolverLHS runs when the
+                # pairs allow it (packed_ms above is then the 18-byte form, kept for comparison)
+                use_corr[0] = corr_ptr
+                lhs_packed()
+                err_pw = float((d_amp_out - ref_out).abs().max() / ref_out.abs().max())
+                t_pw = timed(lhs_packed, 5)
+                out["pcg_lhs_offset_templates"].update({
+                    "packed_pair_weights_ms": t_pw,
+                    "packed_pair_weights_Gsamp_s": world * nsamp_tot / t_pw / 1e6,
+                    "packed_pair_weights_bytes_per_det_sample_and_sweep": 14,
+                    "packed_pair_weights_vs_sequence_max_rel_diff": err_pw,
+                })
+        if pk_corr is not None:
+            drop(pk_corr)
         drop(pk_key)
         drop(pk_qu)
         del pk_key, pk_qu, pk_cal

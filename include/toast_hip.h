@@ -622,16 +622,25 @@ int toast_hip_offset_pack_pointing_dev(
     uint32_t * d_key, double * d_qu, double * d_cal, int * packable, int * pair_words, void * stream);
 int toast_hip_offset_pack_pairs_dev(uint32_t * d_key, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals,
                                     int64_t n_view, int * pair_words, void * stream);
+/* Pair weights (with pair words): the Q / U weights of an orthogonal pair are negatives of each other up to a few ulps,
+ * so q_a + q_b is exact, fits a float exactly and gives q_b = (q_a + q_b) - q_a back exactly.  Checked per sample in view
+ * and per component; where it does not hold (weights that are rounding noise around zero, NaN at a pole) the component
+ * gets a NaN marker and the sweeps read that partner weight from d_qu's partner row, which stays in place: lossless for
+ * every input.  *ok = 0 when more than one component in a hundred is marked (pairs of different calibration).
+ * d_corr[(n_det + 1) / 2][n_samp][2] float.  The sweeps then read 14 instead of 18 B per detector-sample: pass d_corr as
+ * d_pair_corr below (NULL: both rows of d_qu are read). */
+int toast_hip_offset_pack_pair_weights_dev(const double * d_qu, float * d_corr, int64_t n_det, int64_t n_samp,
+                                           const toast_hip_interval * intervals, int64_t n_view, int * ok, void * stream);
 int toast_hip_offset_accumulate_packed_dev(
     int64_t step_length, const int64_t * amp_offsets, const int64_t * n_amp_views, const double * d_amplitudes,
     const uint8_t * d_amplitude_flags, double * d_zmap, const uint32_t * d_key, const double * d_qu, const double * d_cal,
-    const double * det_scale, int pair_words, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals,
-    int64_t n_view, void * stream);
+    const double * det_scale, int pair_words, const float * d_pair_corr, int64_t n_det, int64_t n_samp,
+    const toast_hip_interval * intervals, int64_t n_view, void * stream);
 int toast_hip_offset_scan_project_packed_dev(
     int64_t step_length, const int64_t * amp_offsets, const int64_t * n_amp_views, const double * d_amps_in,
     double * d_amps_out, const uint8_t * d_amplitude_flags, const double * d_map, const uint32_t * d_key,
-    const double * d_qu, const double * d_cal, const double * det_weights, int pair_words, int64_t n_det, int64_t n_samp,
-    const toast_hip_interval * intervals, int64_t n_view, void * stream);
+    const double * d_qu, const double * d_cal, const double * det_weights, int pair_words, const float * d_pair_corr,
+    int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view, void * stream);
 
 int toast_hip_template_offset_apply_diag_precond(
     const double * offset_var, const double * amp_in, const uint8_t * amplitude_flags,

@@ -209,6 +209,10 @@ def test_configs2_mapmaker_packed_route_against_unpacked_sweeps():
             data = wf.main(["--iter", "4"])
             res[run] = (data["mapmaker_solve_amplitudes"]["baselines"].local.copy(), data["mapmaker_map"].data.copy(),
                         list(wf.LAST_STATS["lhs_route"]), float(wf.LAST_STATS["relative_residual"]))
+            if packed == "1":
+                # ... in its densest form: co-pointing orthogonal pairs of equal calibration share the key word and the
+                # partner's weights are rebuilt from exact float sums (14 B per detector-sample and sweep)
+                assert list(wf.LAST_STATS["lhs_pack_bytes"]) == [14], wf.LAST_STATS["lhs_pack_bytes"]
             del data
     finally:
         if old is None:

@@ -7,7 +7,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _setup(n_det=6, n_samp=6000, nside=64, seed=5, odd_views=True):
+def _setup(n_det=6, n_samp=6000, nside=64, seed=5, odd_views=True, pair_cal=False):
     import torch
 
     from toast_amd import capi, synth
@@ -38,6 +38,8 @@ def _setup(n_det=6, n_samp=6000, nside=64, seed=5, odd_views=True):
     D.pixels_healpix(idx, d_quats.data_ptr(), d_sflags.data_ptr(), n_samp, 1, idx, d_pix.data_ptr(), n_samp, ivl,
                      d_hsub.data_ptr(), n_submap, nps, nside, True, 0)
     cal = 0.5 + rng.random(n_det)
+    if pair_cal:       # both detectors of a pair with the same calibration (and efficiency): Q / U weights of opposite sign
+        cal = np.repeat(cal[: (n_det + 1) // 2], 2)[:n_det].copy()
     D.stokes_weights_IQU(idx, d_quats.data_ptr(), idx, d_w.data_ptr(), n_samp, 0, 0, ivl, np.zeros(n_det), gamma, cal,
                          False, 0)
     torch.cuda.synchronize()
@@ -204,6 +206,80 @@ def test_pair_words(n_det, odd_views):
     out, z = _sweeps(s, key, qu, cal, pair=False)
     np.testing.assert_allclose(out, ref_out, rtol=0, atol=1e-12 * np.max(np.abs(ref_out)))
     np.testing.assert_allclose(z, ref_z, rtol=0, atol=1e-12 * np.max(np.abs(ref_z)))
+
+
+@pytest.mark.parametrize("n_det,odd_views", [(6, True), (5, True), (8, False)])
+def test_pair_weight_sums(n_det, odd_views):
+    """Orthogonal pairs of equal calibration: q_a + q_b and u_a + u_b are exact and fit a float, the partner's weights come
+    back EXACTLY as (sum) - q_a (checked here on the host, sample by sample), and the sweeps that read 4 + 16 + 8 B per
+    pair-sample (14 B per detector-sample) give what the sweeps over the original arrays give.  Pairs whose calibrations
+    differ are refused and keep their 18-byte form."""
+    import os
+
+    if os.environ.get("TOAST_HIP_PAIR", "1") == "0":
+        pytest.skip("detector-pair kernels switched off")
+    s = _setup(n_det=n_det, odd_views=odd_views, pair_cal=True)
+    torch, D = s["torch"], s["D"]
+    (ok, pair), key, qu, cal = _pack(s, pair_words=True)
+    assert ok and pair
+    n_pairs = (n_det + 1) // 2
+    corr = torch.full((n_pairs, s["n_samp"], 2), 7.0, dtype=torch.float32, device=s["dev"])
+    assert D.offset_pack_pair_weights(qu.data_ptr(), corr.data_ptr(), n_det, s["n_samp"], s["ivl"])
+    in_view = np.zeros(s["n_samp"], dtype=bool)
+    for v in s["ivl"]:
+        in_view[int(v["first"]):int(v["last"])] = True
+    q, c = qu.cpu().numpy(), corr.cpu().numpy()
+    n_marked = 0
+    for b in range(n_det // 2):
+        # a NaN marker: the sum does not fit a float exactly (weights that are rounding noise around zero): the sweeps read
+        # the partner's own row there.  Everywhere else the partner's weight comes back bit for bit.
+        marker = np.isnan(c[b])
+        n_marked += int(marker[in_view].sum())
+        rebuilt = c[b].astype(np.float64) - q[2 * b]
+        good = in_view[:, None] & ~marker
+        assert np.array_equal(rebuilt[good], q[2 * b + 1][good])                # bit for bit
+        assert np.max(np.abs(c[b][good])) < 1e-12                               # a few ulps of weights of order one
+        assert np.all(np.abs(q[2 * b + 1][in_view[:, None] & marker]) < 1e-14)  # markers only where the weight is noise
+    assert n_marked <= 1e-2 * 2 * in_view.sum() * (n_det // 2)
+    assert np.all(c[:, ~in_view] == 7.0)                                        # samples outside the views are not touched
+    ref_out, ref_z = _sweeps(s)
+    zmap = torch.from_numpy(s["zmap0"]).to(s["dev"])
+    out = torch.zeros(s["n_amp"], dtype=torch.float64, device=s["dev"])
+    z = torch.zeros((s["n_local"], s["nps"], 3), dtype=torch.float64, device=s["dev"])
+    # the partner rows of the Q / U array are NOT read any more, except behind a marker: poison the rest
+    qu_poison = qu.clone()
+    keep = torch.isnan(corr[: n_det // 2])
+    part = qu_poison[1::2]
+    part[~keep] = float("nan")
+    qu_poison[1::2] = part
+    D.offset_scan_project_packed(s["step"], s["ao"], s["nav"], s["d_amps"].data_ptr(), out.data_ptr(),
+                                 s["d_aflags"].data_ptr(), zmap.data_ptr(), key.data_ptr(), qu_poison.data_ptr(),
+                                 cal.data_ptr(), s["detw"], s["n_samp"], s["ivl"], pair_words=True,
+                                 pair_corr=corr.data_ptr())
+    D.offset_accumulate_packed(s["step"], s["ao"], s["nav"], s["d_amps"].data_ptr(), s["d_aflags"].data_ptr(),
+                               z.data_ptr(), key.data_ptr(), qu_poison.data_ptr(), cal.data_ptr(), s["detw"], s["n_samp"],
+                               s["ivl"], pair_words=True, pair_corr=corr.data_ptr())
+    torch.cuda.synchronize()
+    out, z = out.cpu().numpy(), z.cpu().numpy()
+    assert np.any(ref_out != 0) and np.any(ref_z != 0)
+    np.testing.assert_allclose(out, ref_out, rtol=0, atol=1e-12 * np.max(np.abs(ref_out)))
+    assert np.array_equal(z != 0, ref_z != 0)
+    np.testing.assert_allclose(z, ref_z, rtol=0, atol=1e-12 * np.max(np.abs(ref_z)))
+    # pair sums without pair words make no sense
+    with pytest.raises(RuntimeError):
+        D.offset_accumulate_packed(s["step"], s["ao"], s["nav"], s["d_amps"].data_ptr(), s["d_aflags"].data_ptr(),
+                                   z_dummy(s).data_ptr(), key.data_ptr(), qu.data_ptr(), cal.data_ptr(), s["detw"],
+                                   s["n_samp"], s["ivl"], pair_words=False, pair_corr=corr.data_ptr())
+    # different calibrations inside a pair: the sums are of the size of the weights themselves -> refused
+    s2 = _setup(n_det=n_det, odd_views=odd_views, pair_cal=False)
+    (ok2, pair2), key2, qu2, cal2 = _pack(s2, pair_words=True)
+    assert ok2 and pair2
+    if n_det >= 2:
+        assert not D.offset_pack_pair_weights(qu2.data_ptr(), corr.data_ptr(), n_det, s2["n_samp"], s2["ivl"])
+
+
+def z_dummy(s):
+    return s["torch"].zeros((s["n_local"], s["nps"], 3), dtype=s["torch"].float64, device=s["dev"])
 
 
 def test_packing_refuses_what_it_cannot_represent():

@@ -873,28 +873,38 @@ class _Dev:
                                                           C.byref(pair), _p(stream)))
         return bool(pair.value)
 
+    def offset_pack_pair_weights(self, d_qu, d_corr, n_det, n_samp, intervals, stream=0):
+        """True when d_corr now holds the pair sums q_a + q_b, u_a + u_b (float2 per pair-sample) from which the sweeps
+        rebuild the partner's weights exactly (toast_hip_offset_pack_pair_weights_dev); waits for the stream."""
+        iv = self._small(intervals, interval_dtype)
+        ok = C.c_int(0)
+        _check(real_lib().toast_hip_offset_pack_pair_weights_dev(_p(d_qu), _p(d_corr), _i64(n_det), _i64(n_samp), _p(iv),
+                                                                 _i64(iv.size), C.byref(ok), _p(stream)))
+        return bool(ok.value)
+
     def offset_accumulate_packed(self, step_length, amp_offsets, n_amp_views, d_amplitudes, d_amplitude_flags, d_zmap,
-                                 d_key, d_qu, d_cal, det_scale, n_samp, intervals, pair_words=False, stream=0):
+                                 d_key, d_qu, d_cal, det_scale, n_samp, intervals, pair_words=False, pair_corr=0,
+                                 stream=0):
         ao = self._small(amp_offsets, np.int64)
         nv = self._small(n_amp_views, np.int64)
         ds = self._small(det_scale, np.float64)
         iv = self._small(intervals, interval_dtype)
         _check(lib().toast_hip_offset_accumulate_packed_dev(
             _i64(step_length), _p(ao), _p(nv), _p(d_amplitudes), _p(d_amplitude_flags), _p(d_zmap), _p(d_key), _p(d_qu),
-            _p(d_cal), _p(ds), C.c_int(1 if pair_words else 0), _i64(ao.size), _i64(n_samp), _p(iv), _i64(iv.size),
-            _p(stream)))
+            _p(d_cal), _p(ds), C.c_int(1 if pair_words else 0), _p(pair_corr), _i64(ao.size), _i64(n_samp), _p(iv),
+            _i64(iv.size), _p(stream)))
 
     def offset_scan_project_packed(self, step_length, amp_offsets, n_amp_views, d_amps_in, d_amps_out,
                                    d_amplitude_flags, d_map, d_key, d_qu, d_cal, det_weights, n_samp, intervals,
-                                   pair_words=False, stream=0):
+                                   pair_words=False, pair_corr=0, stream=0):
         ao = self._small(amp_offsets, np.int64)
         nv = self._small(n_amp_views, np.int64)
         dw = self._small(det_weights, np.float64)
         iv = self._small(intervals, interval_dtype)
         _check(lib().toast_hip_offset_scan_project_packed_dev(
             _i64(step_length), _p(ao), _p(nv), _p(d_amps_in), _p(d_amps_out), _p(d_amplitude_flags), _p(d_map), _p(d_key),
-            _p(d_qu), _p(d_cal), _p(dw), C.c_int(1 if pair_words else 0), _i64(ao.size), _i64(n_samp), _p(iv),
-            _i64(iv.size), _p(stream)))
+            _p(d_qu), _p(d_cal), _p(dw), C.c_int(1 if pair_words else 0), _p(pair_corr), _i64(ao.size), _i64(n_samp),
+            _p(iv), _i64(iv.size), _p(stream)))
 
     def offset_scan_project_signal(self, step_length, amp_offsets, n_amp_views, signal_index, d_signal, d_amps_out,
                                    d_amplitude_flags, d_g2l, d_map, n_pix_submap, nnz, pixel_index, d_pixels,

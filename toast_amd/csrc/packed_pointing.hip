@@ -123,17 +123,67 @@ __global__ __launch_bounds__(kThreads) void k_pair_merge(const Chunk * __restric
     }
 }
 
+// Pair weights.  The two detectors of an orthogonal pair have Q / U weights that are negatives of each other up to a few
+// units in the last place when they carry the same calibration and polarisation efficiency (stokes_weights_IQU:
+// eta cal cos / sin of an angle that differs by pi).  q_a + q_b is then exact in double precision (Sterbenz) and a small
+// multiple of one ulp: it fits a FLOAT exactly, and q_b = (q_a + q_b) - q_a exactly.  k_pair_weights checks that per
+// sample in view and per component and writes the sums as float2: the sweeps then read 4 (key) + 16 (q_a, u_a) + 8
+// (sums) B per pair-sample = 14 B per detector-sample instead of 18.  Where it does not hold -- a weight that is pure
+// rounding noise around zero (1e-32: its sum with the partner's noise needs all 53 bits), the reference's NaN at a pole --
+// the component gets a NaN MARKER and the sweep reads that sample's partner weight from the partner's own row, which
+// stays where it was: lossless for every input.  The markers are counted; more than one component in a hundred (pairs of
+// different calibration: every sample) and the call reports that the sums are not worth using.
+__global__ __launch_bounds__(kThreads) void k_pair_weights(const Chunk * __restrict__ chunks, int n_chunks, int n_det,
+                                                           const double2 * __restrict__ qu, int64_t n_samp,
+                                                           float2 * __restrict__ corr, unsigned long long * __restrict__ n_marked) {
+    const int d0 = 2 * blockIdx.x;
+    const bool lone = d0 + 1 >= n_det;
+    const double2 * ra = qu + (int64_t)d0 * n_samp;
+    const double2 * rb = qu + (int64_t)(lone ? d0 : d0 + 1) * n_samp;
+    float2 * cr = corr + (int64_t)blockIdx.x * n_samp;
+    auto sum_or_marker = [](double a, double b, int & marked) {
+        const double d = a + b;
+        const float f = (float)d;
+        if ((double)f == d && (double)f - a == b) return f;
+        ++marked;
+        return __builtin_nanf("");
+    };
+    int marked = 0;
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        for (int i = threadIdx.x; i < c.count; i += kThreads) {
+            const int64_t s = c.first + i;
+            float2 f = make_float2(0.0f, 0.0f);
+            if (!lone) {
+                const double2 a = ra[s], b = rb[s];
+                f.x = sum_or_marker(a.x, b.x, marked);
+                f.y = sum_or_marker(a.y, b.y, marked);
+            }
+            cr[s] = f;
+        }
+    }
+    if (marked) atomicAdd(n_marked, (unsigned long long)marked);
+}
+
+// the partner's weight of one component: from the pair sum, or -- marker -- from the partner's own row
+__device__ __forceinline__ double pair_partner(float sum, double mine, const double * __restrict__ partner_row_value) {
+    return (sum == sum) ? (double)sum - mine : *partner_row_value;
+}
+
 // The accumulation from pair words: both detectors of a pair share the pixel, so their contributions are added before
 // the run reduction (what k_offset_accumulate_pk<2> does when it finds the keys equal, without the second key stream).
+// CORR: the partner's Q / U weights come from the pair sums (k_pair_weights) instead of its own row.
+template <bool CORR>
 __global__ __launch_bounds__(kThreads) void k_offset_accumulate_pr(
     const Chunk * __restrict__ chunks, int n_chunks, int n_det, const int64_t * __restrict__ view_first,
     const int64_t * __restrict__ view_aoff, FastDiv step_div, const int64_t * __restrict__ amp_offsets,
     const double * __restrict__ amps, const uint8_t * __restrict__ amp_flags, const double * __restrict__ det_scale,
     const double * __restrict__ cal, double * __restrict__ zmap, const uint32_t * __restrict__ key,
-    const double2 * __restrict__ qu, int64_t n_samp) {
+    const double2 * __restrict__ qu, int64_t n_samp, const float2 * __restrict__ corr) {
     constexpr int NNZ = 3, E = 2;
     const int det0 = E * blockIdx.x;
     const uint32_t * krow = key + (int64_t)det0 * n_samp;
+    const float2 * crow = CORR ? corr + (int64_t)blockIdx.x * n_samp : nullptr;
     bool on[E];
     const double2 * qrow[E];
     double ds[E], cl[E];
@@ -162,14 +212,23 @@ __global__ __launch_bounds__(kThreads) void k_offset_accumulate_pr(
             const uint2 kk = *reinterpret_cast<const uint2 *>(krow + s);
             double2 qa[E], qb[E], av[E];
             uint8_t afa[E], afb[E];
+            float4 cc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if constexpr (CORR) cc = *reinterpret_cast<const float4 *>(crow + s);
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                qa[e] = qrow[e][s];
-                qb[e] = qrow[e][s + 1];
+                if (!(CORR && e == 1)) {
+                    qa[e] = qrow[e][s];
+                    qb[e] = qrow[e][s + 1];
+                }
                 const int64_t aa = amp_offset[e] + vaoff + step_a, ab = amp_offset[e] + vaoff + step_b;
                 afa[e] = amp_flags[aa];
                 afb[e] = amp_flags[ab];
                 av[e] = make_double2(amps[aa], amps[ab]);
+            }
+            if constexpr (CORR) {
+                const double * pa = reinterpret_cast<const double *>(qrow[1] + s);      // (read only behind a marker)
+                qa[1] = make_double2(pair_partner(cc.x, qa[0].x, pa), pair_partner(cc.y, qa[0].y, pa + 1));
+                qb[1] = make_double2(pair_partner(cc.z, qb[0].x, pa + 2), pair_partner(cc.w, qb[0].y, pa + 3));
             }
             const uint32_t ia = kk.x & kPrIndex, ib = kk.y & kPrIndex;
             double va[E][NNZ], vb[E][NNZ];
@@ -212,7 +271,12 @@ __global__ __launch_bounds__(kThreads) void k_offset_accumulate_pr(
                 const int64_t a = amp_offset[e] + vaoff + astep;
                 const double t = (amp_flags[a] == 0) ? (0.0 + amps[a]) : 0.0;
                 const double sd = t * ds[e];
-                const double2 q = qrow[e][s];
+                double2 q = qrow[CORR ? 0 : e][s];
+                if (CORR && e == 1) {
+                    const float2 f = crow[s];
+                    const double * pa = reinterpret_cast<const double *>(qrow[1] + s);
+                    q = make_double2(pair_partner(f.x, q.x, pa), pair_partner(f.y, q.y, pa + 1));
+                }
                 double * z = zmap + NNZ * ((int64_t)idx - 1);
                 unsafeAtomicAdd(z, sd * cl[e]);
                 unsafeAtomicAdd(z + 1, sd * q.x);
@@ -223,15 +287,17 @@ __global__ __launch_bounds__(kThreads) void k_offset_accumulate_pr(
 }
 
 // The projection from pair words: one key stream and ONE map gather per pair-sample.
+template <bool CORR>
 __global__ __launch_bounds__(kThreads) void k_offset_scan_project_pr(
     const Chunk * __restrict__ chunks, int n_chunks, int n_det, const int64_t * __restrict__ view_first,
     const int64_t * __restrict__ view_aoff, FastDiv step_div, const int64_t * __restrict__ amp_offsets,
     const double * __restrict__ amps_in, double * __restrict__ amps_out, const uint8_t * __restrict__ amp_flags,
     const double * __restrict__ det_w, const double * __restrict__ cal, const double * __restrict__ map,
-    const uint32_t * __restrict__ key, const double2 * __restrict__ qu, int64_t n_samp) {
+    const uint32_t * __restrict__ key, const double2 * __restrict__ qu, int64_t n_samp, const float2 * __restrict__ corr) {
     constexpr int E = 2;
     const int det0 = E * blockIdx.x;
     const uint32_t * krow = key + (int64_t)det0 * n_samp;
+    const float2 * crow = CORR ? corr + (int64_t)blockIdx.x * n_samp : nullptr;
     bool on[E];
     const double2 * qrow[E];
     double dw[E], cl[E];
@@ -272,12 +338,25 @@ __global__ __launch_bounds__(kThreads) void k_offset_scan_project_pr(
             const double * ma = map + (hit_a ? 3 * ((int64_t)ia - 1) : 0);
             const double * mb = map + (hit_b ? 3 * ((int64_t)ib - 1) : 0);
             const double a0 = ma[0], a1 = ma[1], a2 = ma[2], b0 = mb[0], b1 = mb[1], b2 = mb[2];
+            float4 cc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if constexpr (CORR) cc = *reinterpret_cast<const float4 *>(crow + s);
+            const double2 qa0 = qrow[0][s], qb0 = qrow[0][s + 1];
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 const int64_t aa = amp_offset[e] + vaoff + step_a, ab = amp_offset[e] + vaoff + step_b;
                 const uint8_t afa = amp_flags[aa], afb = amp_flags[ab];
                 const double2 av = make_double2(amps_in[aa], amps_in[ab]);
-                const double2 qa = qrow[e][s], qb = qrow[e][s + 1];
+                double2 qa = qa0, qb = qb0;
+                if (e == 1) {
+                    if constexpr (CORR) {
+                        const double * pa = reinterpret_cast<const double *>(qrow[1] + s);
+                        qa = make_double2(pair_partner(cc.x, qa0.x, pa), pair_partner(cc.y, qa0.y, pa + 1));
+                        qb = make_double2(pair_partner(cc.z, qb0.x, pa + 2), pair_partner(cc.w, qb0.y, pa + 3));
+                    } else {
+                        qa = qrow[1][s];
+                        qb = qrow[1][s + 1];
+                    }
+                }
                 const double da = finish(hit_a, av.x, cl[e], qa.x, qa.y, a0, a1, a2);
                 const double db = finish(hit_b, av.y, cl[e], qb.x, qb.y, b0, b1, b2);
                 int64_t ka = (active && on[e] && afa == 0) ? aa : (int64_t)-1;
@@ -300,7 +379,12 @@ __global__ __launch_bounds__(kThreads) void k_offset_scan_project_pr(
                 if (!on[e]) continue;
                 const int64_t a = amp_offset[e] + vaoff + astep;
                 if (amp_flags[a] != 0 || (k & pr_proj_flag(e)) != 0) continue;
-                const double2 q = qrow[e][s];
+                double2 q = qrow[CORR ? 0 : e][s];
+                if (CORR && e == 1) {
+                    const float2 f = crow[s];
+                    const double * pa = reinterpret_cast<const double *>(qrow[1] + s);
+                    q = make_double2(pair_partner(f.x, q.x, pa), pair_partner(f.y, q.y, pa + 1));
+                }
                 const double d = finish(hit, amps_in[a], cl[e], q.x, q.y, m[0], m[1], m[2]);
                 unsafeAtomicAdd(amps_out + a, d * dw[e]);
             }
@@ -575,12 +659,51 @@ int toast_hip_offset_pack_pairs_dev(uint32_t * d_key, int64_t n_det, int64_t n_s
     });
 }
 
+// Pair weights: d_corr[(n_det + 1) / 2][n_samp] float2 = q_a + q_b, u_a + u_b of every pair-sample in view where that fits a
+// float exactly and gives the partner's weight back exactly, a NaN marker where not (see k_pair_weights); *ok = 0 when more
+// than one component in a hundred is marked (the sweeps then read both rows of d_qu as before).  d_qu stays as it is: the
+// sweeps read the partner's row behind a marker.
+int toast_hip_offset_pack_pair_weights_dev(const double * d_qu, float * d_corr, int64_t n_det, int64_t n_samp,
+                                           const toast_hip_interval * intervals, int64_t n_view, int * ok, void * stream) {
+    return guarded([&] {
+        if (ok == nullptr) fail_arg("offset_pack_pair_weights: ok must not be null");
+        *ok = 0;
+        if (n_det <= 0 || !pair_detectors()) return;
+        if ((n_samp & 1) != 0) fail_arg("offset_pack_pair_weights: rows of an even number of samples only");
+        need_aligned(d_qu, "packed Q / U weights");
+        need_aligned(d_corr, "pair weight sums");
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        hipStream_t st = as_stream(stream);
+        ParamBlock pb;
+        const size_t o_ch = pb.push_vec(chunks);
+        const char * d = pb.commit(st);
+        unsigned long long * d_marked =
+            reinterpret_cast<unsigned long long *>(static_cast<char *>(Manager::get().scratch(Manager::kScratchStatus, 64)) + 8);
+        TH_HIP(hipMemsetAsync(d_marked, 0, sizeof(unsigned long long), st));
+        const dim3 gp((unsigned)((n_det + 1) / 2), chunk_grid(n_det, chunks.size()).y, 1);
+        hipLaunchKernelGGL(k_pair_weights, gp, dim3(kThreads), 0, st, (const Chunk *)(d + o_ch), (int)chunks.size(), (int)n_det,
+                           reinterpret_cast<const double2 *>(d_qu), n_samp, reinterpret_cast<float2 *>(d_corr), d_marked);
+        check_launch();
+        unsigned long long marked = 0;
+        copy_to_host(&marked, d_marked, sizeof(marked), st);
+        // components in view: 2 per pair-sample; worth using while at most one in a hundred needs the partner's row (a
+        // marked sample costs up to a 128-byte line of that row: 1 % of them ~1.3 B per sample against the 4 B saved)
+        unsigned long long in_view = 0;
+        for (const Chunk & c : chunks) in_view += (unsigned long long)c.count;
+        const unsigned long long total = 2ull * in_view * (unsigned long long)(n_det / 2);
+        const int status = (marked * 100ull > total) ? 1 : 0;
+        *ok = (status == 0) ? 1 : 0;
+    });
+}
+
 int toast_hip_offset_accumulate_packed_dev(
     int64_t step_length, const int64_t * amp_offsets, const int64_t * n_amp_views, const double * d_amplitudes,
     const uint8_t * d_amplitude_flags, double * d_zmap, const uint32_t * d_key, const double * d_qu, const double * d_cal,
-    const double * det_scale, int pair_words, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals,
-    int64_t n_view, void * stream) {
+    const double * det_scale, int pair_words, const float * d_pair_corr, int64_t n_det, int64_t n_samp,
+    const toast_hip_interval * intervals, int64_t n_view, void * stream) {
     return guarded([&] {
+        if (d_pair_corr != nullptr && !pair_words) fail_arg("offset_accumulate_packed: pair weight sums need pair words");
         if (n_det <= 0) return;
         if (step_length <= 0) fail_arg("step_length must be positive");
         if ((n_samp & 1) != 0) fail_arg("offset_accumulate_packed: rows of an even number of samples only");
@@ -604,8 +727,12 @@ int toast_hip_offset_accumulate_packed_dev(
     (const Chunk *)(d + o_ch), (int)chunks.size(), (int)n_det, (const int64_t *)(d + o_vf), (const int64_t *)(d + o_va), \
         make_fastdiv(step_length), (const int64_t *)(d + o_ao), d_amplitudes, d_amplitude_flags,                    \
         (const double *)(d + o_ds), d_cal, d_zmap, d_key, reinterpret_cast<const double2 *>(d_qu), n_samp
-        if (pair_words) {
-            hipLaunchKernelGGL(k_offset_accumulate_pr, gp, dim3(kThreads), 0, st, TH_PK_ARGS);
+        if (pair_words && d_pair_corr != nullptr) {
+            need_aligned(d_pair_corr, "pair weight sums");
+            hipLaunchKernelGGL(k_offset_accumulate_pr<true>, gp, dim3(kThreads), 0, st, TH_PK_ARGS,
+                               reinterpret_cast<const float2 *>(d_pair_corr));
+        } else if (pair_words) {
+            hipLaunchKernelGGL(k_offset_accumulate_pr<false>, gp, dim3(kThreads), 0, st, TH_PK_ARGS, (const float2 *)nullptr);
         } else if (pr) {
             hipLaunchKernelGGL((k_offset_accumulate_pk<2>), gp, dim3(kThreads), 0, st, TH_PK_ARGS);
         } else {
@@ -619,10 +746,11 @@ int toast_hip_offset_accumulate_packed_dev(
 int toast_hip_offset_scan_project_packed_dev(
     int64_t step_length, const int64_t * amp_offsets, const int64_t * n_amp_views, const double * d_amps_in,
     double * d_amps_out, const uint8_t * d_amplitude_flags, const double * d_map, const uint32_t * d_key,
-    const double * d_qu, const double * d_cal, const double * det_weights, int pair_words, int64_t n_det, int64_t n_samp,
-    const toast_hip_interval * intervals, int64_t n_view, void * stream) {
+    const double * d_qu, const double * d_cal, const double * det_weights, int pair_words, const float * d_pair_corr,
+    int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view, void * stream) {
     return guarded([&] {
         if (n_det <= 0) return;
+        if (d_pair_corr != nullptr && !pair_words) fail_arg("offset_scan_project_packed: pair weight sums need pair words");
         if (step_length <= 0) fail_arg("step_length must be positive");
         if ((n_samp & 1) != 0) fail_arg("offset_scan_project_packed: rows of an even number of samples only");
         need_aligned(d_qu, "packed Q / U weights");
@@ -640,11 +768,19 @@ int toast_hip_offset_scan_project_packed_dev(
         const char * d = pb.commit(st);
         if (pair_words) {
             const dim3 gp((unsigned)((n_det + 1) / 2), chunk_grid(n_det, chunks.size()).y, 1);
-            hipLaunchKernelGGL(k_offset_scan_project_pr, gp, dim3(kThreads), 0, st, (const Chunk *)(d + o_ch),
-                               (int)chunks.size(), (int)n_det, (const int64_t *)(d + o_vf), (const int64_t *)(d + o_va),
-                               make_fastdiv(step_length), (const int64_t *)(d + o_ao), d_amps_in, d_amps_out,
-                               d_amplitude_flags, (const double *)(d + o_dw), d_cal, d_map, d_key,
-                               reinterpret_cast<const double2 *>(d_qu), n_samp);
+#define TH_PR_ARGS                                                                                                   \
+    (const Chunk *)(d + o_ch), (int)chunks.size(), (int)n_det, (const int64_t *)(d + o_vf), (const int64_t *)(d + o_va),  \
+        make_fastdiv(step_length), (const int64_t *)(d + o_ao), d_amps_in, d_amps_out, d_amplitude_flags,            \
+        (const double *)(d + o_dw), d_cal, d_map, d_key, reinterpret_cast<const double2 *>(d_qu), n_samp
+            if (d_pair_corr != nullptr) {
+                need_aligned(d_pair_corr, "pair weight sums");
+                hipLaunchKernelGGL(k_offset_scan_project_pr<true>, gp, dim3(kThreads), 0, st, TH_PR_ARGS,
+                                   reinterpret_cast<const float2 *>(d_pair_corr));
+            } else {
+                hipLaunchKernelGGL(k_offset_scan_project_pr<false>, gp, dim3(kThreads), 0, st, TH_PR_ARGS,
+                                   (const float2 *)nullptr);
+            }
+#undef TH_PR_ARGS
             check_launch();
             return;
         }

@@ -231,6 +231,7 @@ class SolveAmplitudes(Operator):
                                  iteration_seconds=self.iteration_seconds)
             # how the left-hand side was applied, per observation: "packed" | "fused" | "fused-otf", or ("sequence",)
             self.lhs_route = tuple(getattr(lhs, "last_route", ()))
+            self.lhs_pack_bytes = tuple(getattr(lhs, "last_pack_bytes", ()))
             t0 = lap("pcg_iterations", t0)
             for ob in data.obs:
                 if lhs.det_temp in ob.detdata:
@@ -401,6 +402,7 @@ class MapMaker(Operator):
             amplitudes = solver.amplitudes
             self.history, self.iteration_seconds = solver.history, solver.iteration_seconds
             self.lhs_route = getattr(solver, "lhs_route", ())
+            self.lhs_pack_bytes = getattr(solver, "lhs_pack_bytes", ())
             self.timing_log.update(solver.timing_log)
             t0 = _time.time()
         # -- final binning set-up (:381-436)

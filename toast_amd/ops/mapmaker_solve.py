@@ -430,9 +430,32 @@ class SolverLHS(Operator):
         if not ok:
             self._free_pack(dict(blocks=mine))
             return None
-        pk = dict(key=key_ptr, qu=qu_ptr, cal=cal_ptr, pair=pair, blocks=mine)
+        pk = dict(key=key_ptr, qu=qu_ptr, cal=cal_ptr, pair=pair, corr=0, blocks=mine)
+        self._pack_pair_weights(pk, n_det, n_samp, ps["ivl"])
         packed[ps["iob"]] = (ident, pk)
         return pk
+
+    @staticmethod
+    def _pack_pair_weights(pk, n_det, n_samp, ivl):
+        """With pair words: the partner's Q / U weights as float sums q_a + q_b, u_a + u_b when that is exact for every
+        sample in view (orthogonal pairs of equal calibration and efficiency; toast_hip_offset_pack_pair_weights_dev) --
+        14 instead of 18 B per detector-sample in both sweeps.  Anything else leaves the pack as it is."""
+        import os
+
+        from .. import capi
+
+        if not pk["pair"] or os.environ.get("TOAST_HIP_PACKED_PAIR_WEIGHTS", "1") == "0":
+            return
+        nbytes = max(8 * ((n_det + 1) // 2) * n_samp, 16)
+        try:
+            ptr = capi.device_malloc(nbytes, -2)
+        except RuntimeError:
+            return
+        if capi.dev.offset_pack_pair_weights(pk["qu"], ptr, n_det, n_samp, ivl):
+            pk["corr"] = ptr
+            pk["blocks"] = list(pk["blocks"]) + [(ptr, nbytes)]
+        else:
+            capi.device_release(ptr, nbytes)
 
     def _pack_pass_otf(self, c, ps, ob, pixels_op, weights_op, n_submap):
         """The packed cache of an observation whose pointing is NOT cached (full_pointing=False, packed_cache=True):
@@ -500,7 +523,8 @@ class SolverLHS(Operator):
         if not ok:
             self._free_pack(dict(blocks=mine))
             return None
-        pk = dict(key=key_ptr, qu=qu_ptr, cal=cal_ptr, pair=pair, blocks=mine)
+        pk = dict(key=key_ptr, qu=qu_ptr, cal=cal_ptr, pair=pair, corr=0, blocks=mine)
+        self._pack_pair_weights(pk, n_det, n_samp, ps["ivl"])
         packed[ps["iob"]] = (ident, pk)
         return pk
 
@@ -627,7 +651,7 @@ class SolverLHS(Operator):
                 pk = ps["pk"]
                 D.offset_accumulate_packed(ps["step"], ps["ao"], ps["nav"], c["in_ptr"], c["in_flags_ptr"], c["zmap_ptr"],
                                            pk["key"], pk["qu"], pk["cal"], ps["detw"], ps["n_samp"], ps["ivl"],
-                                           pair_words=pk["pair"])
+                                           pair_words=pk["pair"], pair_corr=pk.get("corr", 0))
             elif c["on_the_fly"]:
                 D.otf_offset_accumulate(ps["pt"], ps["step"], ps["ao"], ps["nav"], c["in_ptr"], c["in_flags_ptr"],
                                         c["g2l_ptr"], c["zmap_ptr"], c["nps"], ps["f_idx"], ps["f_ptr"], ps["f_ns"],
@@ -656,7 +680,7 @@ class SolverLHS(Operator):
                 pk = ps["pk"]
                 D.offset_scan_project_packed(ps["step"], ps["ao"], ps["nav"], c["in_ptr"], c["out_ptr"], c["in_flags_ptr"],
                                              c["zmap_ptr"], pk["key"], pk["qu"], pk["cal"], ps["detw"], ps["n_samp"],
-                                             ps["ivl"], pair_words=pk["pair"])
+                                             ps["ivl"], pair_words=pk["pair"], pair_corr=pk.get("corr", 0))
             elif c["on_the_fly"]:
                 D.otf_offset_scan_project(ps["pt"], ps["step"], ps["ao"], ps["nav"], c["in_ptr"], c["out_ptr"],
                                           c["in_flags_ptr"], c["g2l_ptr"], c["zmap_ptr"], c["nps"], ps["pf_idx"],
@@ -721,6 +745,9 @@ class SolverLHS(Operator):
             # "fused" (the cached pixels / weights as they are), "fused-otf" (pointing evaluated in the kernels)
             self.last_route = tuple("packed" if ps.get("pk") is not None else ("fused-otf" if ctx["on_the_fly"] else "fused")
                                     for ps in ctx["passes"])
+            # bytes per detector-sample and sweep of each packed observation: 20, 18 (pair words) or 14 (+ pair weights)
+            self.last_pack_bytes = tuple((14 if ps["pk"].get("corr") else (18 if ps["pk"]["pair"] else 20))
+                                         if ps.get("pk") is not None else None for ps in ctx["passes"])
         ctx = plan["ctx"]
         zmap = ctx["zmap"]
         zmap.accel_used(True)

@@ -158,7 +158,8 @@ def main(argv=None):
                       pcg_iteration_ms=1e3 * float(np.median(its)) if its else None,
                       pcg_Gsamp_s=nds / float(np.median(its)) / 1e9 if its else None,
                       detectors=args.ndet * world, samples_per_detector=n_samp, nside=args.nside,
-                      lhs_route=list(getattr(mapper, "lhs_route", ())))
+                      lhs_route=list(getattr(mapper, "lhs_route", ())),
+                      lhs_pack_bytes=list(getattr(mapper, "lhs_pack_bytes", ())))
     if world > 1:
         import torch.distributed as dist
 
@@ -180,6 +181,8 @@ def main(argv=None):
         if its:
             med = float(np.median(its))
             print(f"PCG iteration (median wall time): {1e3 * med:.3f} ms  = {nds / med / 1e9:.1f} G det-samples/s")
+    print(f"left-hand side route {list(getattr(mapper, 'lhs_route', ()))}, packed bytes per det-sample "
+          f"{list(getattr(mapper, 'lhs_pack_bytes', ()))}")
     print(f"MapMaker total {total:.2f} s")
     if world > 1:
         dist.destroy_process_group()
