@@ -111,7 +111,8 @@ typedef struct toast_hip_arena_stats_t {
 int toast_hip_arena_stats(toast_hip_arena_stats_t * out);
 /* Make the arena hold at least `bytes` (one more slab for the difference, at most 90 % of what the device has free). */
 int toast_hip_arena_reserve(size_t bytes);
-/* The same for the part of the arena that serves streamed blocks (below). */
+/* The part of the arena that serves streamed blocks and scatter targets (below): make it hold a FREE RANGE of at least
+ * `bytes` (a new zone-interleaved slab of that size when it has none). */
 int toast_hip_arena_reserve_streamed(size_t bytes);
 /* The sub-allocation logic exercised on HOST memory (no device needed): n_ops random allocations / releases with the
  * bookkeeping and the contents of every live block checked after each step.  0 = sound. */

@@ -204,8 +204,16 @@ bool Arena::slab_offset(const void * p, size_t * off) const {
     return false;
 }
 
-bool Arena::reserve(size_t bytes, hipStream_t stream) {
+bool Arena::reserve(size_t bytes, hipStream_t stream, bool contiguous) {
     std::lock_guard<std::mutex> lock(mutex_);
+    if (contiguous) {
+        for (const Slab & s : slabs_) {
+            for (const auto & kv : s.free) {
+                if (kv.second >= bytes) return true;
+            }
+        }
+        return new_slab(round_up(bytes), stream) != nullptr;
+    }
     if (st_.slab_bytes >= bytes) return true;
     return new_slab(round_up(bytes - st_.slab_bytes), stream) != nullptr;
 }

@@ -76,8 +76,9 @@ public:
     // offset of an address inside its slab; false when it lies in none
     bool slab_offset(const void * p, size_t * off) const;
     // make the capacity (free + used) at least `bytes` by taking ONE more slab for the difference; false if the
-    // driver refuses
-    bool reserve(size_t bytes, hipStream_t stream);
+    // driver refuses.  contiguous: make the LARGEST FREE RANGE at least `bytes` instead (a slab of that size when no
+    // range is) -- for arenas that serve a few large blocks each of which has to fit one range
+    bool reserve(size_t bytes, hipStream_t stream, bool contiguous = false);
     // give slabs without live blocks back to the driver; returns the bytes released
     size_t trim();
     // forget everything (all slabs are freed, live blocks included): device change / tests

@@ -594,10 +594,16 @@ size_t Manager::cached_bytes() const {
 void Manager::reserve(size_t bytes, bool streamed) {
     if (alloc_policy().plain || bytes == 0) return;
     if (streamed && !stream_arena_enabled()) return;
-    Arena & arena = streamed ? stream_arena() : big_arena();
     // never more than 90 % of what the device has free right now: a reservation is a hint, not worth a failure
     size_t f = 0, t = 0;
     if (hipMemGetInfo(&f, &t) != hipSuccess) return;
+    if (streamed) {
+        // streamed blocks are few and large and each has to fit ONE range: the reservation is "a free range of `bytes`"
+        if (bytes > f / 10 * 9) return;
+        (void)stream_arena().reserve(bytes, stream_, true);
+        return;
+    }
+    Arena & arena = big_arena();
     const size_t have = arena.capacity();
     if (bytes <= have) return;
     size_t want = bytes - have;
