@@ -56,6 +56,7 @@ struct VmmPolicy {
     size_t min_slab = size_t(4) << 30;
     size_t search = size_t(128) << 30;
     double gap = 0.035;      // two rates this far apart (relative) belong to different levels
+    double search_ms = 500.0;   // TOAST_HIP_ARENA_SEARCH_MS: what the candidate search may cost
 };
 const VmmPolicy & policy() {
     static const VmmPolicy p = [] {
@@ -69,6 +70,9 @@ const VmmPolicy & policy() {
         }
         if (const char * e = std::getenv("TOAST_HIP_ARENA_SEARCH_GB")) {
             if (std::atof(e) >= 0.0) v.search = (size_t)(std::atof(e) * 1073741824.0);
+        }
+        if (const char * e = std::getenv("TOAST_HIP_ARENA_SEARCH_MS")) {
+            if (std::atof(e) >= 0.0) v.search_ms = std::atof(e);
         }
         if (const char * e = std::getenv("TOAST_HIP_ARENA_ZONE_GAP")) {
             if (std::atof(e) > 0.0) v.gap = std::atof(e);
@@ -105,6 +109,37 @@ VmmSlabStats vmm_slab_stats() {
     std::lock_guard<std::mutex> lock(g_vmm_mutex);
     return g_vmm_stats;
 }
+
+namespace {
+
+void register_slab(char * base, size_t n, size_t chunk, const std::vector<hipMemGenericAllocationHandle_t> & slot,
+                   size_t other, size_t created, size_t probes, double level, std::chrono::steady_clock::time_point t_start,
+                   const char * how) {
+    VmmSlab s;
+    s.base = base;
+    s.bytes = n * chunk;
+    s.chunk = chunk;
+    s.handles = slot;
+    {
+        std::lock_guard<std::mutex> lock(g_vmm_mutex);
+        g_vmm[base] = s;
+        ++g_vmm_stats.slabs;
+        g_vmm_stats.chunks += (int64_t)n;
+        g_vmm_stats.chunks_other_zone += (int64_t)other;
+        g_vmm_stats.created += (int64_t)created;
+        g_vmm_stats.probes += (int64_t)probes;
+        g_vmm_stats.build_ms += ms_since(t_start);
+        g_vmm_stats.same_zone_tbs = level / 1.0e9;
+    }
+    if (const char * e = std::getenv("TOAST_HIP_TRACE")) {
+        if (e[0] != '\0' && e[0] != '0') {
+            std::fprintf(stderr, "[toast_hip] vmm slab      %zu chunks of %zu MB at %p (%s): %zu in the other zone, %zu created, %.1f ms\n",
+                         n, chunk >> 20, (void *)base, how, other, created, ms_since(t_start));
+        }
+    }
+}
+
+}  // namespace
 
 void * vmm_slab_take(size_t bytes, hipStream_t st) {
     const VmmPolicy & pol = policy();
@@ -186,7 +221,11 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
         na = nb = 0;
         for (const Cand & c : cand) (c.rate > thr ? nb : na) += 1;
     };
+    const auto t_search = std::chrono::steady_clock::now();
     while (1 + cand.size() < max_create) {
+        // the search for a second zone is worth half a second, not more: on a box whose memory the driver is still
+        // clearing every chunk costs 20-30 ms, and the slab is built from what there is by then
+        if (1 + cand.size() >= n && ms_since(t_search) > pol.search_ms) break;
         hipMemGenericAllocationHandle_t h;
         if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) {
             (void)hipGetLastError();
@@ -279,22 +318,6 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
     }
     (void)hipMemAddressFree(own_va, own_n * chunk);
     const double self_rate = thr < 1.0e299 ? thr : 0.0;     // (reported: the level that separates the classes)
-    VmmSlab s;
-    s.base = base;
-    s.bytes = n * chunk;
-    s.chunk = chunk;
-    s.handles = slot;
-    {
-        std::lock_guard<std::mutex> lock(g_vmm_mutex);
-        g_vmm[base] = s;
-        ++g_vmm_stats.slabs;
-        g_vmm_stats.chunks += (int64_t)n;
-        g_vmm_stats.chunks_other_zone += (int64_t)have_b;
-        g_vmm_stats.created += (int64_t)created;
-        g_vmm_stats.probes += (int64_t)probes;
-        g_vmm_stats.build_ms += ms_since(t_start);
-        g_vmm_stats.same_zone_tbs = self_rate / 1.0e9;
-    }
     if (const char * e = std::getenv("TOAST_HIP_TRACE")) {
         if (e[0] != '\0' && e[0] != '0') {
             std::string line;
@@ -303,11 +326,11 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
                 std::snprintf(buf, sizeof buf, " %.2f", c.rate / 1.0e9);
                 line += buf;
             }
-            std::fprintf(stderr, "[toast_hip] vmm rates (TB/s, creation order; threshold %.2f):%s\n", thr / 1.0e9, line.c_str());
-            std::fprintf(stderr, "[toast_hip] vmm slab      %zu chunks of %zu MB at %p: %zu + %zu from two zones, %zu created, %.1f ms\n",
-                         n, chunk >> 20, (void *)base, have_a, have_b, created, ms_since(t_start));
+            std::fprintf(stderr, "[toast_hip] vmm rates (TB/s, creation order; threshold %.2f):%s\n", thr < 1.0e299 ? thr / 1.0e9 : 0.0,
+                         line.c_str());
         }
     }
+    register_slab(base, n, chunk, slot, have_b, created, probes, self_rate, t_start, "chunk-by-chunk search");
     return base;
 }
 
