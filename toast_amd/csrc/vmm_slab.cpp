@@ -248,7 +248,16 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
             break;
         }
         void * two[2] = {external ? ext_ref : base, where};
-        const double ms = probe_stream_split_ms(two, 2, chunk, st);     // (best of three passes: the first one touches the chunk)
+        double ms = 0.0;
+        try {
+            ms = probe_stream_split_ms(two, 2, chunk, st);     // (best of three passes: the first one touches the chunk)
+        } catch (const Error &) {
+            // a failed launch or event: nothing may leak -- this chunk, and everything collected so far below
+            (void)hipMemUnmap(where, chunk);
+            (void)hipMemRelease(h);
+            failed = true;
+            break;
+        }
         ++probes;
         (void)hipMemUnmap(where, chunk);
         cand.push_back(Cand{h, ms > 0.0 ? 4.0 * (double)chunk / ms : 0.0});
