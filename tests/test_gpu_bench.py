@@ -36,6 +36,9 @@ def test_bench_contract_small_workload():
     assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] >= 1
     assert c["one_thread"] > 0 and c["best_threads"]["value"] >= max(c["thread_sweep"].values()) * (1 - 1e-12)
     assert "1" in c["thread_sweep"] and str(c["cores"]) in c["thread_sweep"]
+    # the reported value is the best point of the sweep with the threads it used; the all-core point is kept beside it
+    assert c["value"] == c["best_threads"]["value"] and c["cores"] == c["best_threads"]["threads"]
+    assert str(c["all_cores"]["threads"]) in c["thread_sweep"]
     # the buffers are allocated like the operators allocate them; the FFT noise weighting is reported separately
     assert "toast_hip::Manager" in d["allocator"] and d["placement"] is None
     assert {"slabs", "slab_mallocs", "malloc_ms", "max_malloc_ms", "slab_GB", "peak_used_GB", "direct_mallocs",
