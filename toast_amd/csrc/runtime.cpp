@@ -612,14 +612,29 @@ void Manager::reserve(size_t bytes, bool streamed) {
     (void)arena.reserve(have + want, stream_);
 }
 
-void * zone_reference_take(size_t bytes) {
-    // from the slabs the read-mostly arrays live in -- only if they exist already (no new slab for this)
-    if (alloc_policy().plain || big_arena().capacity() == 0) return nullptr;
-    return big_arena().alloc(bytes, Manager::get().stream(), false);
+ZoneRefs zone_references_take(size_t bytes) {
+    // From the slabs the read-mostly arrays live in -- only if they exist already (no new slab for this): the first
+    // block the arena hands out, and the one at the end of its largest free range (a filler block in between, given back
+    // at once).  At the time a streamed slab is built -- right after the read-mostly reservation -- that is the first and
+    // the last GB of the slab.
+    ZoneRefs r;
+    if (alloc_policy().plain || big_arena().capacity() == 0) return r;
+    hipStream_t st = Manager::get().stream();
+    r.first = big_arena().alloc(bytes, st, false);
+    const size_t room = big_arena().largest_free();
+    void * filler = nullptr;
+    if (room > bytes + (size_t(64) << 20)) filler = big_arena().alloc(room - bytes - (size_t(4) << 20), st, false);
+    r.last = big_arena().alloc(bytes, st, false);
+    if (filler != nullptr) (void)big_arena().release(filler);
+    if (r.last == nullptr) {
+        r.last = r.first;       // room for one reference only
+    }
+    return r;
 }
 
-void zone_reference_release(void * p) {
-    if (p != nullptr) (void)big_arena().release(p);
+void zone_references_release(const ZoneRefs & r) {
+    if (r.first != nullptr) (void)big_arena().release(r.first);
+    if (r.last != nullptr && r.last != r.first) (void)big_arena().release(r.last);
 }
 
 void Manager::drop_arenas() {

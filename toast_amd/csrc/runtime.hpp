@@ -120,10 +120,15 @@ AllocStats alloc_stats();
 
 // Rank-interleaved slabs (vmm_slab.cpp): nullptr when switched off, too small, or the driver refuses.
 void * vmm_slab_take(size_t bytes, hipStream_t stream);
-// a 1 GB device range in the zone of the read-mostly arrays, for the slab builder to measure chunks against (runtime.cpp;
-// nullptr: none to be had -- the slab's first chunk is the reference then); released with zone_reference_release
-void * zone_reference_take(size_t bytes);
-void zone_reference_release(void * p);
+// Device ranges of `bytes` at the START and at the END of the read-mostly slabs' free space, for the slab builder to
+// measure chunks against (runtime.cpp; nullptr: none to be had -- the slab's first chunk is the reference then);
+// borrowed from the arena, given back with zone_references_release.
+struct ZoneRefs {
+    void * first = nullptr;
+    void * last = nullptr;
+};
+ZoneRefs zone_references_take(size_t bytes);
+void zone_references_release(const ZoneRefs & r);
 bool vmm_slab_give(void * p);       // false: not one of them
 struct VmmSlabStats {
     int64_t slabs = 0;               // interleaved slabs alive

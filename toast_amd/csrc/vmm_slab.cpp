@@ -17,13 +17,16 @@
 // ~5 % slower on chunk-mapped memory than on a plain slab, for any chunk size (r04_a section 6).
 //
 // The zone of a chunk cannot be asked for, so it is measured: each new chunk gets one read + write pass together with a
-// reference range (1 GB borrowed from the read-mostly slabs; the slab's own first chunk when there are none yet), rows
-// dealt alternately to the two (probe_stream_split_ms, ~1 ms); the pass runs at the slow level when both lie in one
-// zone.  Every chunk is measured at an address of its own (section 5: a chunk mapped where another one sat a moment
-// before shows the earlier chunk's level).  Chunks are created until both classes have filled their half of the slots
-// (the driver hands out one zone after the other, so this can mean creating many more chunks than the slab needs; the
-// surplus is released before the function returns), or until `TOAST_HIP_ARENA_SEARCH_GB` (default 128) of surplus
-// have been looked at -- then the remaining slots take what there is.
+// reference range, rows dealt alternately to the two (probe_stream_split_ms, ~2 ms); the pass runs at the slow level when
+// both lie in one zone.  The references are the FIRST and the LAST GB of the read-mostly slab (borrowed from the arena;
+// the slab's own first chunk when there is none yet): a plain slab of ~50 GB straddles a zone boundary more often than
+// not, and the odd slots take chunks that are clear of BOTH ends -- with three zones there is one that holds neither.
+// (Against the first GB alone the maps shared their zone with the slab's upper part in two processes of three, against
+// the last GB alone with its lower part: profiles/r04_a section 8.)  Every chunk is measured at an address of its own
+// (section 5: a chunk mapped where another one sat a moment before shows the earlier chunk's level).  Chunks are created
+// until both classes have filled their half of the slots (the surplus is released before the function returns), within
+// `TOAST_HIP_ARENA_SEARCH_GB` (default 128) of surplus and `TOAST_HIP_ARENA_SEARCH_MS` (default 500) -- then the remaining
+// slots take what there is, late chunks first.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -159,56 +162,50 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
     const size_t chunk = (pol.chunk + gran - 1) / gran * gran;
     const size_t n = (bytes + chunk - 1) / chunk;
     if (n < 4) return nullptr;
-    // the final range
-    void * va = nullptr;
-    if (hipMemAddressReserve(&va, n * chunk, chunk, nullptr, 0) != hipSuccess) {
-        (void)hipGetLastError();
-        return nullptr;
-    }
-    char * base = static_cast<char *>(va);
     // Every candidate is measured at an address of its own: a pass over a chunk mapped where ANOTHER chunk sat a moment
     // ago showed the level of the earlier chunk (profiles/r04_a section 5) -- addresses are never reused here.
-    char * own_va = nullptr;
     const size_t own_n = n + pol.search / chunk + 1;
-    {
-        void * t = nullptr;
-        if (hipMemAddressReserve(&t, own_n * chunk, chunk, nullptr, 0) == hipSuccess) own_va = static_cast<char *>(t);
-    }
-    if (own_va == nullptr) {
+    void * own_res = nullptr;
+    if (hipMemAddressReserve(&own_res, own_n * chunk, chunk, nullptr, 0) != hipSuccess) {
         (void)hipGetLastError();
-        (void)hipMemAddressFree(va, n * chunk);
         return nullptr;
     }
-    // Candidates: every chunk created, with the rate of its pass together with chunk 0 (which sits in slot 0 from the
-    // start).  The classes are decided on the whole set, not chunk by chunk: the levels move a few per cent from box to
-    // box and with the clocks, their ratio (~1.13 for 1 GB ranges) does not.
+    char * own_va = static_cast<char *>(own_res);
+
+    // What the chunks are measured against.  With read-mostly slabs in place: their FIRST and their LAST GB -- a plain slab
+    // of ~50 GB straddles a boundary of the 96 GB zones more often than not, and the scatter targets (odd slots) belong
+    // into a zone that holds NEITHER end of it (three zones: there is one).  Measured against the first GB alone, the maps
+    // shared their zone with the slab's upper part (the packed cache: 5.5 instead of 5.1 ms for its sweeps in two processes
+    // of three); against the last GB alone, with its lower part (build_noise_weighted 5.9 instead of 5.1 ms).  Without such
+    // slabs: the slab's own first chunk.
+    ZoneRefs ext = zone_references_take(chunk);
+    const int n_ref = ext.last != nullptr ? (ext.first != nullptr && ext.first != ext.last ? 2 : 1) : 0;
     struct Cand {
         hipMemGenericAllocationHandle_t h;
-        double rate;
+        char * at;              // where it is mapped during the search
+        double r[2];            // rate of its pass with reference 0 (the slab's last GB / chunk 0) and 1 (the first GB); < 0: not measured
     };
-    // What the chunks are measured against: a range in the zone of the read-mostly arrays when the arena has one (the
-    // even slots then hold chunks of THAT zone, the odd slots chunks of another: scatter targets go into odd chunks,
-    // Manager::device_alloc), else the slab's own first chunk.
-    char * ext_ref = static_cast<char *>(zone_reference_take(chunk));
-    const bool external = ext_ref != nullptr;
     std::vector<Cand> cand;
-    hipMemGenericAllocationHandle_t first;
-    bool have_first = false, failed = false;
+    bool failed = false;
     size_t probes = 0;
-    // (without an external reference chunk 0 is of class A by definition and sits in slot 0 from the start)
-    const size_t want_b = n / 2, want_a = n - want_b - (external ? 0 : 1);
-    const size_t max_create = n + pol.search / chunk;
-    double thr = 1.0e300;
-    auto classify = [&] {
-        // Two levels ~13 % apart, each a few per cent wide: the threshold is the middle of the largest gap between
-        // neighbouring rates, once that gap is wider than anything a single level shows (3.5 %).  (A quantile does not
-        // work: either class can be the small one.)
-        thr = 1.0e300;
-        if (cand.size() < 4) return;
+    auto pass = [&](void * x, void * y, size_t each) {
+        void * two[2] = {x, y};
+        const double ms = probe_stream_split_ms(two, 2, each, st);     // (best of three passes: the first one touches the chunk)
+        ++probes;
+        return ms > 0.0 ? 4.0 * (double)each / ms : 0.0;
+    };
+    // threshold between "same zone as the reference" and "another zone": the middle of the largest gap between
+    // neighbouring rates once that gap is wider than anything one level shows (the two levels are ~13 % apart, each a few per
+    // cent wide; a quantile does not work: either class can be the small one); with one level only, that level against
+    // the rate of a pass over the two halves of the reference itself
+    auto threshold = [&](int k, double level) {
         std::vector<double> r;
-        for (const Cand & c : cand) r.push_back(c.rate);
+        for (const Cand & c : cand) {
+            if (c.r[k] >= 0.0) r.push_back(c.r[k]);
+        }
+        if (r.empty()) return 1.0e300;
         std::sort(r.begin(), r.end());
-        double best = 0.0;
+        double best = 0.0, thr = -1.0;
         for (size_t i = 1; i < r.size(); ++i) {
             const double gap = (r[i] - r[i - 1]) / r[i];
             if (gap > best && gap >= pol.gap) {
@@ -216,130 +213,127 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
                 thr = 0.5 * (r[i] + r[i - 1]);
             }
         }
+        if (thr > 0.0) return thr;
+        return (r[r.size() / 2] > (1.0 + 1.7 * pol.gap) * level) ? 0.0 : 1.0e300;     // all "other" : all "same"
     };
-    auto counts = [&](size_t & na, size_t & nb) {
-        na = nb = 0;
-        for (const Cand & c : cand) (c.rate > thr ? nb : na) += 1;
-    };
-    const auto t_search = std::chrono::steady_clock::now();
-    while (1 + cand.size() < max_create) {
-        // the search for a second zone is worth half a second, not more: on a box whose memory the driver is still
-        // clearing every chunk costs 20-30 ms, and the slab is built from what there is by then
-        if (1 + cand.size() >= n && ms_since(t_search) > pol.search_ms) break;
-        hipMemGenericAllocationHandle_t h;
-        if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) {
-            (void)hipGetLastError();
-            break;   // the device is full: make do with what has been created
+    const size_t want_odd = n / 2, want_even = n - want_odd;
+    const size_t max_create = n + pol.search / chunk;
+    char * ref[2] = {nullptr, nullptr};
+    double level[2] = {0.0, 0.0}, thr[2] = {1.0e300, 1.0e300};
+    std::vector<size_t> cls_odd, cls_even;       // candidates for the odd slots (other than every reference) and the rest
+    try {
+        if (n_ref >= 1) {
+            ref[0] = static_cast<char *>(ext.last);
+            if (n_ref == 2) ref[1] = static_cast<char *>(ext.first);
+            for (int k = 0; k < n_ref; ++k) level[k] = pass(ref[k], ref[k] + chunk / 2, chunk / 2);
         }
-        if (!have_first && !external) {
-            if (!map_chunk(base, chunk, h, dev)) {
+        const auto t_search = std::chrono::steady_clock::now();
+        while (cand.size() < max_create) {
+            // the search for the other zone is worth half a second, not more: on a box whose memory the driver is still
+            // clearing every chunk costs 20-30 ms, and the slab is built from what there is by then
+            if (cand.size() >= n && ms_since(t_search) > pol.search_ms) break;
+            hipMemGenericAllocationHandle_t h;
+            if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                break;   // the device is full: make do with what has been created
+            }
+            char * where = own_va + cand.size() * chunk;
+            if (!map_chunk(where, chunk, h, dev)) {
                 (void)hipMemRelease(h);
                 failed = true;
                 break;
             }
-            first = h;
-            have_first = true;
-            continue;
-        }
-        char * where = own_va + cand.size() * chunk;
-        if (!map_chunk(where, chunk, h, dev)) {
-            (void)hipMemRelease(h);
-            failed = true;
-            break;
-        }
-        void * two[2] = {external ? ext_ref : base, where};
-        double ms = 0.0;
-        try {
-            ms = probe_stream_split_ms(two, 2, chunk, st);     // (best of three passes: the first one touches the chunk)
-        } catch (const Error &) {
-            // a failed launch or event: nothing may leak -- this chunk, and everything collected so far below
-            (void)hipMemUnmap(where, chunk);
-            (void)hipMemRelease(h);
-            failed = true;
-            break;
-        }
-        ++probes;
-        (void)hipMemUnmap(where, chunk);
-        cand.push_back(Cand{h, ms > 0.0 ? 4.0 * (double)chunk / ms : 0.0});
-        classify();
-        size_t na, nb;
-        counts(na, nb);
-        if (na >= want_a && nb >= want_b) break;
-    }
-    zone_reference_release(ext_ref);
-    const size_t created = cand.size() + (have_first ? 1 : 0);
-    size_t have_a = 0, have_b = 0;
-    std::vector<hipMemGenericAllocationHandle_t> slot(n);
-    std::vector<char> filled(n, 0);
-    if (have_first) {
-        slot[0] = first;
-        filled[0] = 1;
-        have_a = 1;
-    }
-    if (!failed && ((!have_first && !external) || created < n)) failed = true;   // not enough memory for the slab
-    if (!failed) {
-        // even slots: class A, odd slots: the others; what one class cannot fill, the other does -- the LAST created
-        // first: the driver hands out one zone after the other, so a late chunk is the most likely to differ from chunk 0
-        std::vector<size_t> ia, ib;
-        for (size_t k = 0; k < cand.size(); ++k) (cand[k].rate > thr ? ib : ia).push_back(k);
-        std::vector<size_t> even, odd;      // candidates for the even slots 2, 4, ... and the odd slots 1, 3, ...
-        const size_t take_a = std::min(ia.size(), want_a), take_b = std::min(ib.size(), want_b);
-        even.assign(ia.begin(), ia.begin() + (long)take_a);
-        odd.assign(ib.begin(), ib.begin() + (long)take_b);
-        for (size_t j = ia.size(); j > take_a && odd.size() < want_b; --j) odd.push_back(ia[j - 1]);
-        for (size_t j = ib.size(); j > take_b && even.size() < want_a; --j) even.push_back(ib[j - 1]);
-        std::vector<char> used(cand.size(), 0);
-        if (even.size() < want_a || odd.size() < want_b) failed = true;
-        const size_t shift = have_first ? 1 : 0;      // even[] starts at slot 2 when chunk 0 already sits in slot 0
-        for (size_t k = shift; k < n && !failed; ++k) {
-            const size_t pick = (k % 2 == 1) ? odd[k / 2] : even[k / 2 - shift];
-            used[pick] = 1;
-            if (!map_chunk(base + k * chunk, chunk, cand[pick].h, dev)) {
-                failed = true;
-                break;
+            cand.push_back(Cand{h, where, {-1.0, -1.0}});
+            Cand & c = cand.back();
+            if (n_ref == 0 && cand.size() == 1) {
+                // no read-mostly slab yet: this chunk is the reference (and of the reference's class by definition)
+                ref[0] = where;
+                level[0] = pass(where, where + chunk / 2, chunk / 2);
+                continue;       // (r[0] stays "not measured": never clear of itself, not part of the threshold)
             }
-            slot[k] = cand[pick].h;
-            filled[k] = 1;
-            (cand[pick].rate > thr ? have_b : have_a) += 1;
-        }
-        if (failed) {
-            for (size_t k = 0; k < n; ++k) {
-                if (filled[k]) (void)hipMemUnmap(base + k * chunk, chunk);
+            c.r[0] = pass(ref[0], where, chunk);
+            thr[0] = threshold(0, level[0]);
+            if (n_ref == 2) {
+                // the second reference only for chunks that are clear of the first (the others are "same" already)
+                for (Cand & d : cand) {
+                    if (d.r[1] < 0.0 && d.r[0] > thr[0]) d.r[1] = pass(ref[1], d.at, chunk);
+                }
+                thr[1] = threshold(1, level[1]);
             }
-            for (const Cand & c : cand) (void)hipMemRelease(c.h);
-            if (have_first) (void)hipMemRelease(first);
-            (void)hipMemAddressFree(va, n * chunk);
-            (void)hipMemAddressFree(own_va, own_n * chunk);
-            return nullptr;
+            cls_odd.clear();
+            cls_even.clear();
+            for (size_t i = 0; i < cand.size(); ++i) {
+                const bool clear0 = cand[i].r[0] >= 0.0 && cand[i].r[0] > thr[0];
+                const bool clear1 = n_ref < 2 || (cand[i].r[1] >= 0.0 && cand[i].r[1] > thr[1]);
+                ((clear0 && clear1) ? cls_odd : cls_even).push_back(i);
+            }
+            if (cls_odd.size() >= want_odd && cls_even.size() >= want_even) break;
         }
-        for (size_t j = 0; j < cand.size(); ++j) {
-            if (!used[j]) (void)hipMemRelease(cand[j].h);
-        }
-    } else {
-        if (have_first) {
-            (void)hipMemUnmap(base, chunk);
-            (void)hipMemRelease(first);
-        }
+    } catch (const Error &) {
+        failed = true;       // a failed launch or event: nothing may leak
+    }
+    zone_references_release(ext);
+    for (const Cand & c : cand) (void)hipMemUnmap(c.at, chunk);
+    (void)hipMemAddressFree(own_res, own_n * chunk);
+    const size_t created = cand.size();
+    if (failed || created < n) {
         for (const Cand & c : cand) (void)hipMemRelease(c.h);
-        (void)hipMemAddressFree(va, n * chunk);
-        (void)hipMemAddressFree(own_va, own_n * chunk);
+        return nullptr;      // (the caller falls back to a plain hipMalloc)
+    }
+    // Odd slots: the class that is clear of every reference; even slots: the rest.  What one class cannot fill, the other
+    // does -- the LAST created first: the driver tends to hand out one zone after the other, so a late chunk is the most
+    // likely to differ from the early ones.
+    std::vector<size_t> odd, even;
+    const size_t take_o = std::min(cls_odd.size(), want_odd), take_e = std::min(cls_even.size(), want_even);
+    odd.assign(cls_odd.begin(), cls_odd.begin() + (long)take_o);
+    even.assign(cls_even.begin(), cls_even.begin() + (long)take_e);
+    for (size_t j = cls_even.size(); j > take_e && odd.size() < want_odd; --j) odd.push_back(cls_even[j - 1]);
+    for (size_t j = cls_odd.size(); j > take_o && even.size() < want_even; --j) even.push_back(cls_odd[j - 1]);
+    void * va = nullptr;
+    if (odd.size() < want_odd || even.size() < want_even ||
+        hipMemAddressReserve(&va, n * chunk, chunk, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        for (const Cand & c : cand) (void)hipMemRelease(c.h);
         return nullptr;
     }
-    (void)hipMemAddressFree(own_va, own_n * chunk);
-    const double self_rate = thr < 1.0e299 ? thr : 0.0;     // (reported: the level that separates the classes)
+    char * base = static_cast<char *>(va);
+    std::vector<hipMemGenericAllocationHandle_t> slot(n);
+    std::vector<char> used(cand.size(), 0);
+    for (size_t k = 0; k < n && !failed; ++k) {
+        const size_t pick = (k & 1) ? odd[k / 2] : even[k / 2];
+        used[pick] = 1;
+        slot[k] = cand[pick].h;
+        if (!map_chunk(base + k * chunk, chunk, slot[k], dev)) {
+            for (size_t j = 0; j < k; ++j) (void)hipMemUnmap(base + j * chunk, chunk);
+            failed = true;
+        }
+    }
+    if (failed) {
+        (void)hipMemAddressFree(va, n * chunk);
+        for (const Cand & c : cand) (void)hipMemRelease(c.h);
+        return nullptr;
+    }
+    for (size_t j = 0; j < cand.size(); ++j) {
+        if (!used[j]) (void)hipMemRelease(cand[j].h);
+    }
     if (const char * e = std::getenv("TOAST_HIP_TRACE")) {
         if (e[0] != '\0' && e[0] != '0') {
             std::string line;
             for (const Cand & c : cand) {
-                char buf[32];
-                std::snprintf(buf, sizeof buf, " %.2f", c.rate / 1.0e9);
+                char buf[48];
+                if (n_ref == 2) {
+                    std::snprintf(buf, sizeof buf, " %.2f/%.2f", c.r[0] / 1.0e9, c.r[1] < 0.0 ? 0.0 : c.r[1] / 1.0e9);
+                } else {
+                    std::snprintf(buf, sizeof buf, " %.2f", c.r[0] / 1.0e9);
+                }
                 line += buf;
             }
-            std::fprintf(stderr, "[toast_hip] vmm rates (TB/s, creation order; threshold %.2f):%s\n", thr < 1.0e299 ? thr / 1.0e9 : 0.0,
-                         line.c_str());
+            std::fprintf(stderr, "[toast_hip] vmm rates vs %d reference(s) (TB/s, creation order; thresholds %.2f %.2f):%s\n", n_ref,
+                         thr[0] < 1.0e299 ? thr[0] / 1.0e9 : 0.0, thr[1] < 1.0e299 ? thr[1] / 1.0e9 : 0.0, line.c_str());
         }
     }
-    register_slab(base, n, chunk, slot, have_b, created, probes, self_rate, t_start, "chunk-by-chunk search");
+    register_slab(base, n, chunk, slot, take_o, created, probes, level[0], t_start,
+                  n_ref == 2 ? "against both ends of the read-mostly slab" : (n_ref == 1 ? "against the read-mostly slab" : "against its first chunk"));
     return base;
 }
 
