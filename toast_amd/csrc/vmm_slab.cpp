@@ -287,7 +287,22 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
     const size_t take_o = std::min(cls_odd.size(), want_odd), take_e = std::min(cls_even.size(), want_even);
     odd.assign(cls_odd.begin(), cls_odd.begin() + (long)take_o);
     even.assign(cls_even.begin(), cls_even.begin() + (long)take_e);
-    for (size_t j = cls_even.size(); j > take_e && odd.size() < want_odd; --j) odd.push_back(cls_even[j - 1]);
+    if (odd.size() < want_odd) {
+        // not enough chunks clear of both ends (the search ran out of time): second best for the scatter targets is the
+        // zone of the slab's END -- the arrays that feed the A^T scatter are created first and sit at its start
+        std::vector<char> taken(cand.size(), 0);
+        for (size_t i : odd) taken[i] = 1;
+        for (size_t i : even) taken[i] = 1;
+        for (int round = 0; round < 2 && odd.size() < want_odd; ++round) {
+            for (size_t j = cls_even.size(); j > take_e && odd.size() < want_odd; --j) {
+                const size_t i = cls_even[j - 1];
+                const bool at_end = !(cand[i].r[0] >= 0.0 && cand[i].r[0] > thr[0]);
+                if (taken[i] || (round == 0 && !at_end)) continue;
+                odd.push_back(i);
+                taken[i] = 1;
+            }
+        }
+    }
     for (size_t j = cls_odd.size(); j > take_o && even.size() < want_even; --j) even.push_back(cls_odd[j - 1]);
     void * va = nullptr;
     if (odd.size() < want_odd || even.size() < want_even ||
