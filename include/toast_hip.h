@@ -862,6 +862,11 @@ int toast_hip_scan_mask_dev(const int64_t * d_global2local, const uint8_t * d_ma
 /* Device-to-device copy on the stream (Copy operator on resident buffers). */
 int toast_hip_copy_dev(void * d_dst, const void * d_src, size_t nbytes, void * stream);
 int toast_hip_memset_dev(void * d_dst, int value, size_t nbytes, void * stream);
+/* n_block blocks of block_bytes: block dst_index[i] of d_dst <- block src_index[i] of d_src (host index arrays).  The
+ * device form of PixelData.sync_alltoallv for ranks that hold DIFFERENT local submaps moves the local submaps into the
+ * union of all ranks' submaps with it, and back [ref: src/toast/pixels.py:792-967]. */
+int toast_hip_block_move_dev(void * d_dst, const void * d_src, int64_t n_block, int64_t block_bytes,
+                             const int64_t * dst_index /*host*/, const int64_t * src_index /*host*/, void * stream);
 
 /* ------------------------------------------------------------------------------------
  * Pointing on the fly: the accumulate / scan kernels evaluate

@@ -233,6 +233,36 @@ def main():
         capi.dev.comm_map_reduce_apply(40000, 1, 0, t.data_ptr(), reduce=True)
         torch.cuda.synchronize()
         np.testing.assert_allclose(t.cpu().numpy(), tot, rtol=0, atol=1e-13 * np.max(np.abs(tot)), err_msg=mode)
+    # ranks that hold DIFFERENT local submaps (the reference's general case): the default exchange on the device through
+    # the union of all ranks' submaps, against the sums computed by hand; rank 0 also tries it with its copy on the host
+    for dtype, n_value in ((np.float64, 3), (np.int64, 1)):
+        mine = np.arange(2 + 3 * rank, 2 + 3 * rank + 7) % 64          # 7 submaps, shifted by 3 per rank: neighbours overlap
+        mine = np.unique(mine)
+        d2 = PixelDistribution(n_pix=64 * 48, n_submap=64, local_submaps=mine, comm=comm)
+        assert not d2.replicated or size == 1
+        vals = {r: (np.random.default_rng(900 + r).standard_normal((7, 48, n_value)) * 100).astype(dtype) for r in range(size)}
+        subs = {r: np.unique(np.arange(2 + 3 * r, 2 + 3 * r + 7) % 64) for r in range(size)}
+        want_u = np.zeros((mine.size, 48, n_value), dtype=dtype)
+        for i, sm in enumerate(mine):
+            for r in range(size):
+                hit = np.flatnonzero(subs[r] == sm)
+                if hit.size:
+                    want_u[i] += vals[r][hit[0]]
+        for on_device in (True, False):
+            pd2 = PixelData(d2, dtype, n_value=n_value)
+            pd2.raw[:] = vals[rank][: mine.size].reshape(-1)
+            if on_device or rank != 0:
+                pd2.accel_create("different_submaps")
+                pd2.accel_update_device()
+            was = pd2.accel_in_use()
+            pd2.sync_alltoallv()
+            assert pd2.accel_in_use() == was
+            if dtype == np.float64:
+                np.testing.assert_allclose(pd2.data, want_u, rtol=1e-13, atol=1e-11)
+            else:
+                assert np.array_equal(pd2.data, want_u)
+            if pd2.accel_exists():
+                pd2.accel_delete()
     # MIXED residency: rank 0 has "evicted" its map -- it holds it on the host -- while the others hold
     # theirs on the device.  The route does not depend on where a rank's copy lives, so every rank enters the same
     # collective on the same communicator: no hang, the right sums, and each copy ends where it started.

@@ -1120,6 +1120,15 @@ class _Dev:
     def memset(self, d_dst, value, nbytes, stream=0):
         _check(lib().toast_hip_memset_dev(_p(d_dst), C.c_int(int(value)), C.c_size_t(int(nbytes)), _p(stream)))
 
+    def block_move(self, d_dst, d_src, block_bytes, dst_index, src_index, stream=0):
+        """Blocks of ``block_bytes``: block ``dst_index[i]`` of ``d_dst`` <- block ``src_index[i]`` of ``d_src``."""
+        di = self._small(dst_index, np.int64)
+        si = self._small(src_index, np.int64)
+        if di.size != si.size:
+            raise RuntimeError("block_move: one source block per destination block")
+        _check(lib().toast_hip_block_move_dev(_p(d_dst), _p(d_src), _i64(di.size), _i64(block_bytes), _p(di), _p(si),
+                                              _p(stream)))
+
     def copy(self, d_dst, d_src, nbytes, stream=0):
         _check(lib().toast_hip_copy_dev(_p(d_dst), _p(d_src), C.c_size_t(int(nbytes)), _p(stream)))
 

@@ -2901,6 +2901,53 @@ int toast_hip_combine_flags_dev(uint8_t * d_out, const int32_t * out_index, cons
     });
 }
 
+}  // extern "C"
+
+namespace {
+// n_block blocks of block_bytes: dst block dst_index[i] <- src block src_index[i] (one workgroup column per block)
+__global__ __launch_bounds__(kThreads) void k_block_move(char * __restrict__ dst, const char * __restrict__ src,
+                                                         const int64_t * __restrict__ dst_index,
+                                                         const int64_t * __restrict__ src_index, int64_t block_bytes) {
+    const int64_t i = blockIdx.x;
+    char * d = dst + dst_index[i] * block_bytes;
+    const char * s = src + src_index[i] * block_bytes;
+    if ((block_bytes & 15) == 0) {
+        const int64_t n16 = block_bytes >> 4;
+        for (int64_t k = (int64_t)blockIdx.y * kThreads + threadIdx.x; k < n16; k += (int64_t)gridDim.y * kThreads) {
+            reinterpret_cast<uint4 *>(d)[k] = reinterpret_cast<const uint4 *>(s)[k];
+        }
+    } else {
+        for (int64_t k = (int64_t)blockIdx.y * kThreads + threadIdx.x; k < block_bytes; k += (int64_t)gridDim.y * kThreads) d[k] = s[k];
+    }
+}
+}  // namespace
+
+extern "C" {
+
+// Submaps from one layout into another: local submaps of a map into their places in the union of all ranks' submaps and
+// back (PixelData.sync_alltoallv on the device for ranks that hold DIFFERENT local submaps, toast_amd/pixels.py).
+int toast_hip_block_move_dev(void * d_dst, const void * d_src, int64_t n_block, int64_t block_bytes,
+                             const int64_t * dst_index, const int64_t * src_index, void * stream) {
+    return guarded([&] {
+        if (n_block <= 0 || block_bytes <= 0) return;
+        if (((block_bytes & 15) == 0) && ((reinterpret_cast<uintptr_t>(d_dst) | reinterpret_cast<uintptr_t>(d_src)) & 15) != 0) {
+            fail_arg("block_move: blocks of a multiple of 16 bytes need 16-byte aligned buffers");
+        }
+        hipStream_t st = as_stream(stream);
+        ParamBlock pb;
+        const size_t o_d = pb.push(dst_index, sizeof(int64_t) * (size_t)n_block);
+        const size_t o_s = pb.push(src_index, sizeof(int64_t) * (size_t)n_block);
+        const char * d = pb.commit(st);
+        int64_t per = (block_bytes / 16 + kThreads - 1) / kThreads;
+        if (per < 1) per = 1;
+        if (per > 64) per = 64;
+        hipLaunchKernelGGL(k_block_move, dim3((unsigned)n_block, (unsigned)per), dim3(kThreads), 0, st,
+                           static_cast<char *>(d_dst), static_cast<const char *>(d_src), (const int64_t *)(d + o_d),
+                           (const int64_t *)(d + o_s), block_bytes);
+        check_launch();
+    });
+}
+
 int toast_hip_copy_dev(void * d_dst, const void * d_src, size_t nbytes, void * stream) {
     return guarded([&] {
         if (nbytes == 0) return;

@@ -430,6 +430,54 @@ class PixelData(AcceleratorObject):
         return bool(comm.device_comm() and self._dist.replicated and self._dtype in capi.dev.COMM_DTYPES
                     and self._raw is not None and self._raw.size > 0)
 
+    def _union_on_device(self, comm):
+        """Ranks that hold DIFFERENT local submaps (the reference's general case, pixels.py:792-940): the default exchange
+        -- every submap becomes the sum of its copies -- runs on the device through the UNION of all ranks' submaps.
+        Like _device_collectives, the answer is the same on every rank (``replicated`` is a collective property)."""
+        from . import capi
+
+        return bool(comm.device_comm() and self._dtype in capi.dev.COMM_DTYPES and not self._dist.replicated)
+
+    def _union_exchange(self):
+        """sync_alltoallv() with the default local_func for a distribution whose ranks hold different submaps: the local
+        submaps are moved into their places in a zeroed scratch map over the union of all ranks' submaps
+        (toast_hip_block_move_dev), that map is summed over the ranks like a replicated one (owner computes /
+        all-reduce, on the kernels' stream), and the local submaps are read back.  A submap nobody else holds comes
+        back as it was; a rank without local submaps takes part with zeros."""
+        from . import capi
+
+        D = capi.dev
+        dist = self._dist
+        union = dist.all_hit_submaps
+        if union.size == 0:
+            return
+        local = np.asarray(dist.local_submaps if dist.local_submaps is not None else [], dtype=np.int64)
+        pos = np.searchsorted(union, local).astype(np.int64)
+        here = np.arange(local.size, dtype=np.int64)
+        block = self._n_submap_value * self._raw.itemsize
+        nbytes = int(union.size) * block
+        scratch = capi.device_malloc(nbytes, -4 if nbytes < (1 << 30) else -1)
+        try:
+            D.memset(scratch, 0, nbytes)
+
+            def reduce():
+                if self._dtype == np.float64:
+                    D.comm_map_reduce_apply(int(union.size) * self._dist.n_pix_submap, self._n_value, 0, scratch,
+                                            reduce=True)
+                else:
+                    D.comm_allreduce(scratch, int(union.size) * self._n_submap_value, self._dtype, "sum")
+
+            if local.size > 0:
+                with self._device_side():
+                    D.block_move(scratch, accel_device_ptr(self._raw), block, pos, here)
+                    reduce()
+                    D.block_move(accel_device_ptr(self._raw), scratch, block, here, pos)
+            else:
+                reduce()
+        finally:
+            capi.device_free(scratch)      # (waits for the stream)
+        self._pristine = False
+
     def _device_side(self):
         """Context manager: inside, the device copy is the current one; a copy that lived on the host is uploaded on
         entry, downloaded on exit, and a device buffer created for the purpose is released again."""
@@ -546,6 +594,9 @@ class PixelData(AcceleratorObject):
         if w is None and local_func is None:
             return      # one process: every submap is its own and only copy
         device_form = local_func is None or hasattr(local_func, "on_device")
+        if w is not None and local_func is None and self._union_on_device(w):
+            self._union_exchange()
+            return
         if w is not None and device_form and self._device_collectives(w):
             with self._device_side():
                 if local_func is None:
