@@ -129,6 +129,42 @@ def operator_level():
     }
 
 
+# Multi-rank runs only: the line as it stands once the timed steps are over, and a timer that prints it if what follows
+# (the A/B repetitions of the communicator's modes, the extra sections) does not come back -- a collective that hangs
+# cannot be caught as an exception, and the headline must not be lost to an extra.
+_LIFELINE = {"fd": None, "line": None, "timer": None}
+
+
+def _lifeline_arm(out, rank):
+    import threading
+
+    if _LIFELINE["timer"] is not None:
+        return
+    limit = float(os.environ.get("TOAST_BENCH_EXTRAS_TIMEOUT_S", "900"))
+    if rank == 0:
+        short = dict(out)
+        short["truncated"] = "the sections after the timed steps did not finish within %.0f s" % limit
+        _LIFELINE["line"] = json.dumps(short)
+
+    def expire():
+        if rank == 0 and _LIFELINE["line"] is not None and _LIFELINE["fd"] is not None:
+            os.write(_LIFELINE["fd"], (_LIFELINE["line"] + "\n").encode())
+        else:
+            time.sleep(2.0)
+        os._exit(0)
+
+    t = threading.Timer(limit, expire)
+    t.daemon = True
+    t.start()
+    _LIFELINE["timer"] = t
+
+
+def _lifeline_disarm():
+    if _LIFELINE["timer"] is not None:
+        _LIFELINE["timer"].cancel()
+        _LIFELINE["timer"] = None
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` outside a launcher: start N ranks (one per GPU) as a FRESH child
     `python -m torch.distributed.run ... bench.py <same arguments>`, relay its output and return its exit code.
@@ -164,6 +200,7 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    _LIFELINE["fd"] = real_stdout
 
     import torch
     import torch.distributed as dist
@@ -220,6 +257,8 @@ def main():
         ctypes.CDLL(None).fflush(None)      # the banner sits in the C library's buffer until somebody flushes it
     except OSError:
         pass
+    _lifeline_disarm()
+    _LIFELINE["fd"] = None
     os.dup2(real_stdout, 1)
     os.close(real_stdout)
     if rank == 0:
@@ -574,26 +613,6 @@ def run(args, workload, world, rank, dev, headline=True):
         "iteration_GBs": (BYTES_BNW + BYTES_SCAN) * nsamp_tot / ((ms["bnw"] + ms["scan"]) * 1e-3) / 1e9,
     }
 
-    owner_ms, mode_ms = None, None
-    if comm_impl is not None and comm_impl.startswith("toast_hip_comm"):
-        # the same sum + covariance as ONE owner-computes pass (reduce-scatter, cov_apply_diag on the owned pixel
-        # shard, all-gather): what ops.BinMap / the fused SolverLHS do with sync_type = "alltoallv"
-        oc = lambda: D.comm_map_reduce_apply(n_local * nps, nnz, d_cov.data_ptr(), d_zmap.data_ptr(), True, stream)
-        oc()
-        owner_ms = timed(oc, 5)
-        # ... and the other two ways the library can do that pass (toast_hip_comm_set_mode), for an A/B on this very job:
-        # pixel slices on two side streams (reduce-scatter of slice k + 1 under multiplication + all-gather of slice k),
-        # and one all-reduce followed by every rank multiplying the whole map
-        mode_ms = {"owner": owner_ms}
-        for mode in ("sliced:2", "sliced:4", "sliced:8", "allreduce"):
-            try:
-                D.comm_set_mode(mode)
-                oc()
-                mode_ms[mode] = timed(oc, 5)
-            except RuntimeError as err:      # noqa: PERF203 -- the headline must not depend on this extra
-                mode_ms[mode] = repr(err)[:200]
-        D.comm_set_mode("owner")
-
     # measured stream ceiling on this box ("report % of both"): a pure
     # 8 B read + 8 B write stream (k_noise_weight over the work timestream, scale 1.0)
     ones = np.ones(n_det)
@@ -676,14 +695,37 @@ def run(args, workload, world, rank, dev, headline=True):
             "ms": ms["allreduce"] if multi else 0.0,
             "backend": (dist.get_backend() if multi else None),
             "implementation": comm_impl,
-            "owner_computes_reduce_apply_ms": owner_ms,
+            "owner_computes_reduce_apply_ms": None,
             # the same pass per implementation (TOAST_HIP_COMM_MODE): {"owner", "sliced:2", "sliced:4", "sliced:8", "allreduce"}
-            "reduce_apply_ms_by_mode": mode_ms,
+            "reduce_apply_ms_by_mode": None,
             "note": comm_note,
             "algorithm_GBs": (2.0 * (world - 1) / world * n_local * nps * nnz * 8 / (ms["allreduce"] * 1e-3) / 1e9
                               if multi and world > 1 and ms["allreduce"] > 0 else None),
         },
     }
+
+    if headline and world > 1:
+        _lifeline_arm(out, rank)
+    if comm_impl is not None and comm_impl.startswith("toast_hip_comm"):
+        # the same sum + covariance as ONE owner-computes pass (reduce-scatter, cov_apply_diag on the owned pixel
+        # shard, all-gather): what ops.BinMap / the fused SolverLHS do with sync_type = "alltoallv"
+        oc = lambda: D.comm_map_reduce_apply(n_local * nps, nnz, d_cov.data_ptr(), d_zmap.data_ptr(), True, stream)
+        oc()
+        owner_ms = timed(oc, 5)
+        # ... and the other two ways the library can do that pass (toast_hip_comm_set_mode), for an A/B on this very job:
+        # pixel slices on two side streams (reduce-scatter of slice k + 1 under multiplication + all-gather of slice k),
+        # and one all-reduce followed by every rank multiplying the whole map
+        mode_ms = {"owner": owner_ms}
+        for mode in ("sliced:2", "sliced:4", "sliced:8", "allreduce"):
+            try:
+                D.comm_set_mode(mode)
+                oc()
+                mode_ms[mode] = timed(oc, 5)
+            except RuntimeError as err:      # noqa: PERF203 -- the headline must not depend on this extra
+                mode_ms[mode] = repr(err)[:200]
+        D.comm_set_mode("owner")
+        out["allreduce"]["owner_computes_reduce_apply_ms"] = owner_ms
+        out["allreduce"]["reduce_apply_ms_by_mode"] = mode_ms
 
     # ------------------------------------------------------------------ FFT noise weighting (SURVEY.md section 8d:
     # "report separately"): ops.NoiseFilter's device call on the same timestream shape -- every detector

@@ -338,3 +338,30 @@ def test_sync_alltoallv_single_process():
     assert list(sc) == [3] and list(sd) == [0] and list(rc) == [3] and list(rd) == [0]
     with pytest.raises(TypeError):
         pd.sync_alltoallv(bogus=True)
+
+
+def test_bench_lifeline_prints_the_headline_when_the_extras_hang():
+    """bench.py, ranks > 1: once the timed steps are over every rank arms a timer; if the sections after them never come
+    back (a collective that hangs cannot be caught), rank 0 prints the line as it stood and every rank leaves with 0."""
+    import json
+    import subprocess
+    import sys
+
+    code = r'''
+import os, sys, time
+sys.path.insert(0, %r)
+import bench
+bench._LIFELINE["fd"] = 1
+bench._lifeline_arm({"metric": "m", "value": 2.5, "n_gpus": 2}, int(sys.argv[1]))
+time.sleep(30)
+print("not reached")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TOAST_BENCH_EXTRAS_TIMEOUT_S="0.5")
+    for rank, lines in ((0, 1), (1, 0)):
+        p = subprocess.run([sys.executable, "-c", code, str(rank)], capture_output=True, text=True, env=env, timeout=60)
+        assert p.returncode == 0, p.stderr
+        got = [ln for ln in p.stdout.splitlines() if ln.strip()]
+        assert len(got) == lines, p.stdout
+        if rank == 0:
+            line = json.loads(got[0])
+            assert line["value"] == 2.5 and line["n_gpus"] == 2 and "truncated" in line
