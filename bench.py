@@ -696,7 +696,7 @@ def run(args, workload, world, rank, dev, headline=True):
             "backend": (dist.get_backend() if multi else None),
             "implementation": comm_impl,
             "owner_computes_reduce_apply_ms": None,
-            # the same pass per implementation (TOAST_HIP_COMM_MODE): {"owner", "sliced:2", "sliced:4", "sliced:8", "allreduce"}
+            # the same pass per implementation (TOAST_HIP_COMM_MODE): {"owner", "sliced:2", "sliced:4", "sliced:8", "allreduce", "peer"}
             "reduce_apply_ms_by_mode": None,
             "note": comm_note,
             "algorithm_GBs": (2.0 * (world - 1) / world * n_local * nps * nnz * 8 / (ms["allreduce"] * 1e-3) / 1e9
@@ -714,9 +714,10 @@ def run(args, workload, world, rank, dev, headline=True):
         owner_ms = timed(oc, 5)
         # ... and the other two ways the library can do that pass (toast_hip_comm_set_mode), for an A/B on this very job:
         # pixel slices on two side streams (reduce-scatter of slice k + 1 under multiplication + all-gather of slice k),
-        # and one all-reduce followed by every rank multiplying the whole map
+        # one all-reduce followed by every rank multiplying the whole map, and the exchange over hipIpc-opened buffers
+        # ("peer": every link of the xGMI mesh at once, RCCL only for the two barriers)
         mode_ms = {"owner": owner_ms}
-        for mode in ("sliced:2", "sliced:4", "sliced:8", "allreduce"):
+        for mode in ("sliced:2", "sliced:4", "sliced:8", "allreduce", "peer"):
             try:
                 D.comm_set_mode(mode)
                 oc()

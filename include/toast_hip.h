@@ -1130,9 +1130,15 @@ int toast_hip_comm_map_reduce_apply_dev(int64_t n_px, int64_t nnz, const double 
  * reduce-scatter, multiplication on the owned shard, all-gather on the caller's stream), "sliced:S" (the same in S pixel
  * slices dealt to two side streams, so that the reduce-scatter of slice k + 1 overlaps multiplication and all-gather of
  * slice k), "allreduce" (one all-reduce, every rank multiplies the whole map: the reference's sync_allreduce +
- * covariance_apply, pixels.py:710-780).  Same results in every mode (to the rounding of the sums' order).  Collective:
- * every rank must use the same mode. */
+ * covariance_apply, pixels.py:710-780), "peer" (at most 16 ranks of one node: no RCCL on the data path -- every rank writes
+ * the foreign slices of its map into their owners' exchange buffers, opened through hipIpc handles, owners add them in rank
+ * order and multiply, every rank reads the finished slices back; all xGMI links of the mesh carry 1/N of the map at once,
+ * RCCL provides the two barriers; fails with TOAST_HIP_ERR_DEVICE on every rank if the buffers cannot be opened).  Same
+ * results in every mode (to the rounding of the sums' order).  Collective: every rank must use the same mode. */
 int toast_hip_comm_set_mode(const char * mode);
+/* mode "peer": reductions done through the exchange buffers, times the buffers were (re-)established (collective hipIpc
+ * exchange; grows with the largest map), bytes of this rank's exchange buffer now */
+int toast_hip_comm_peer_stats(int64_t * reductions, int64_t * establishments, int64_t * exchange_bytes);
 int toast_hip_comm_get_mode(char * mode, size_t len);
 int toast_hip_comm_cov_invert_dev(int64_t n_px, int64_t nnz, double * d_cov, double * d_rcond, double threshold,
                                   int invert, void * stream);

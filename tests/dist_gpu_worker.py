@@ -230,6 +230,10 @@ def main():
 
         n, r, version = capi.dev.comm_info()
         assert (n, r) == (size, rank) and Comm().device_comm(), (n, r, version)
+        if os.environ.get("TOAST_TEST_EXPECT_PEER") == "1":
+            # TOAST_HIP_COMM_MODE=peer: the map reductions of the runs above went through the hipIpc exchange buffers
+            n_red, n_est, n_bytes = capi.dev.comm_peer_stats()
+            assert capi.dev.comm_get_mode() == "peer" and n_red >= 9 and n_est >= 1 and n_bytes > 0, (n_red, n_est, n_bytes)
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank} OK")

@@ -211,7 +211,9 @@ def main():
         cv.accel_delete()
         z.accel_delete()
     # the three implementations of the owner-computes pass (toast_hip_comm_set_mode): same sums, same product
-    for mode in ("owner", "sliced:2", "sliced:4", "allreduce", "owner"):
+    # ("peer": no RCCL on the data path -- slices written into / read from the owners' hipIpc-opened exchange buffers;
+    # between processes that share this GPU here, between GPUs over xGMI on a node)
+    for mode in ("owner", "sliced:2", "sliced:4", "allreduce", "peer", "owner"):
         capi.dev.comm_set_mode(mode)
         assert capi.dev.comm_get_mode() == mode
         for reduce in (True, False):
@@ -233,6 +235,33 @@ def main():
         capi.dev.comm_map_reduce_apply(40000, 1, 0, t.data_ptr(), reduce=True)
         torch.cuda.synchronize()
         np.testing.assert_allclose(t.cpu().numpy(), tot, rtol=0, atol=1e-13 * np.max(np.abs(tot)), err_msg=mode)
+        if mode == "peer":
+            # an odd number of values (8-byte lane accesses, a short last slice), then twice in a row on a smaller map
+            # (the exchange buffers are reused: the second reduction must not see anything of the first)
+            for n_odd in (40101, 997, 997):
+                vals = {r: np.random.default_rng(500 + r + n_odd).standard_normal(n_odd) for r in range(size)}
+                t = torch.from_numpy(vals[rank]).cuda()
+                capi.dev.comm_map_reduce_apply(n_odd, 1, 0, t.data_ptr(), reduce=True)
+                capi.dev.comm_map_reduce_apply(n_odd, 1, 0, t.data_ptr(), reduce=True)     # sum of sums: x size
+                torch.cuda.synchronize()
+                tot = np.zeros(n_odd)
+                for r in range(size):
+                    tot += vals[r]
+                np.testing.assert_allclose(t.cpu().numpy(), size * tot, rtol=0, atol=1e-12 * np.max(np.abs(tot)), err_msg=mode)
+            # bit-identical on every rank, whatever the rank order of arrival: only the owner adds, in rank order
+            got = t.cpu().numpy().copy()
+            ref_bits = torch.from_numpy(got).cuda()
+            capi.dev.comm_broadcast(ref_bits.data_ptr(), got.size, np.float64, 0)
+            torch.cuda.synchronize()
+            assert np.array_equal(ref_bits.cpu().numpy(), got), "peer mode: ranks disagree in the last bit"
+            n_red, n_est, n_bytes = capi.dev.comm_peer_stats()
+            if size > 1:
+                # 2 small maps + 1 of 40 000 + 3 x 2 odd ones went through the exchange buffers, which grew twice
+                # (1776 x 3 values -> 40 000 -> 40 101) and hold (1 + size) slots of ceil(40 101 / size) values
+                assert n_red == 9 and n_est == 3, (n_red, n_est)
+                assert n_bytes >= (1 + size) * 8 * (40101 // size), n_bytes
+            else:
+                assert n_red == 0 and n_est == 0 and n_bytes == 0
     # ranks that hold DIFFERENT local submaps (the reference's general case): the default exchange on the device through
     # the union of all ranks' submaps, against the sums computed by hand; rank 0 also tries it with its copy on the host
     for dtype, n_value in ((np.float64, 3), (np.int64, 1)):

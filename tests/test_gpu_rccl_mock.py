@@ -27,10 +27,11 @@ def mock_lib():
     return MOCK
 
 
-def _run(n, script, port, mock, timeout=1500):
+def _run(n, script, port, mock, timeout=1500, **extra):
     env = dict(os.environ)
     env.update(OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", TOAST_TEST_BACKEND="gloo", TOAST_HIP_COMM="rccl",
                TOAST_HIP_RCCL_LIB=mock)
+    env.update(extra)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(HERE, script)]
     return subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
@@ -50,6 +51,14 @@ def test_mapmaker_equals_single_process(mock_lib, n):
     out = _run(n, "dist_gpu_worker.py", 29571 + n, mock_lib)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-6000:]
     assert out.stdout.count("OK") == n
+
+
+def test_mapmaker_equals_single_process_in_peer_mode(mock_lib):
+    """The same map-maker run with every map reduction of the solve going through the hipIpc exchange buffers
+    (TOAST_HIP_COMM_MODE=peer): three processes writing into and reading from each other's device memory."""
+    out = _run(3, "dist_gpu_worker.py", 29579, mock_lib, TOAST_HIP_COMM_MODE="peer", TOAST_TEST_EXPECT_PEER="1")
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-6000:]
+    assert out.stdout.count("OK") == 3
 
 
 @pytest.mark.parametrize("n", [2, 3])
@@ -75,7 +84,7 @@ def test_bench_ranks_through_the_library_communicator(mock_lib, n):
     # every implementation of the owner-computes pass was timed on this job (A/B material for the first 8-GPU lease),
     # and the packed left-hand side with the reduction inside is part of the same line
     modes = d["allreduce"]["reduce_apply_ms_by_mode"]
-    assert set(modes) == {"owner", "sliced:2", "sliced:4", "sliced:8", "allreduce"}
+    assert set(modes) == {"owner", "sliced:2", "sliced:4", "sliced:8", "allreduce", "peer"}
     assert all(isinstance(v, float) and v > 0 for v in modes.values()), modes
     assert d["pcg_lhs_offset_templates"]["packed_ms"] > 0
     assert d["configs3_shard"]["allreduce"]["implementation"].startswith("toast_hip_comm")

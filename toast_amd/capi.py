@@ -1252,9 +1252,15 @@ class _Dev:
                                                          C.c_int(1 if reduce else 0), _p(stream)))
 
     def comm_set_mode(self, mode):
-        """'owner' | 'sliced:S' | 'allreduce': how comm_map_reduce_apply works (toast_hip_comm_set_mode; collective:
+        """'owner' | 'sliced:S' | 'allreduce' | 'peer': how comm_map_reduce_apply works (toast_hip_comm_set_mode; collective:
         every rank the same)."""
         _check(real_lib().toast_hip_comm_set_mode(str(mode).encode()))
+
+    def comm_peer_stats(self):
+        """(reductions, establishments, exchange_bytes) of mode 'peer' (toast_hip_comm_peer_stats)."""
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        _check(real_lib().toast_hip_comm_peer_stats(C.byref(a), C.byref(b), C.byref(c)))
+        return int(a.value), int(b.value), int(c.value)
 
     def comm_get_mode(self):
         buf = C.create_string_buffer(32)

@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <sstream>
@@ -153,6 +155,8 @@ Shard shard_of(int64_t n_px, int size, int rank) {
 
 Shard shard_of(int64_t n_px) { return shard_of(n_px, g_size, g_rank); }
 
+void peer_release();      // (mode "peer", below: its exchange buffers go before the communicator does)
+
 // `work` = the buffer the two ring halves run on: the map itself when the pixels divide evenly, else a zero-padded
 // scratch copy of per * size pixels (kScratchCommA / B of the manager's grow-only scratch buffers).
 double * padded_copy(const double * d_map, int64_t n_px, int64_t nv, const Shard & s, int slot, hipStream_t st) {
@@ -233,6 +237,7 @@ int toast_hip_comm_info(int * n_ranks, int * rank, int * rccl_version) {
 int toast_hip_comm_destroy(void) {
     return guarded([&] {
         if (g_comm == nullptr) return;
+        peer_release();
         ncclComm_t c = g_comm;
         g_comm = nullptr;
         g_size = 0;
@@ -304,6 +309,12 @@ int toast_hip_comm_pixel_shard(int64_t n_px, int64_t * first, int64_t * count) {
 //              while the owners multiply slice k and gather it.  The caller's stream waits for both at the end.
 //   allreduce  one all-reduce of the whole map, then every rank multiplies the whole map (what sync_allreduce +
 //              covariance_apply do; the reference's default, pixels.py:710-780).
+//   peer       no RCCL on the data path: xGMI is a full mesh of point-to-point links, so every rank WRITES the seven
+//              foreign slices of its map straight into their owners' inboxes (memory opened through hipIpc handles, all
+//              links busy at once), owners add the inboxes in rank order, multiply, and every rank READS the seven
+//              finished slices from their owners.  (N-1)/N map volumes per direction and rank, each link carrying 1/N of
+//              the map per phase instead of a ring's N-1 steps over one link; the sum has a fixed order.  RCCL only
+//              provides the two barriers (a one-word all-reduce each) and the exchange of the handles.
 // reduce = 0: the map is already the same on all ranks (the reference's covariance_apply(use_alltoallv=True),
 // covariance.py:224-306): owners apply, results are gathered (allreduce mode: every rank applies, no communication).
 }  // extern "C"
@@ -311,7 +322,7 @@ int toast_hip_comm_pixel_shard(int64_t n_px, int64_t * first, int64_t * count) {
 namespace {
 
 struct CommMode {
-    int kind = 0;      // 0 owner, 1 sliced, 2 allreduce
+    int kind = 0;      // 0 owner, 1 sliced, 2 allreduce, 3 peer
     int slices = 4;
 };
 CommMode g_mode;
@@ -325,6 +336,10 @@ CommMode parse_mode(const char * text) {
         m.kind = 2;
         return m;
     }
+    if (v == "peer") {
+        m.kind = 3;
+        return m;
+    }
     if (v.rfind("sliced", 0) == 0) {
         m.kind = 1;
         const size_t c = v.find(':');
@@ -332,7 +347,7 @@ CommMode parse_mode(const char * text) {
         if (m.slices < 2 || m.slices > 64) fail_arg("HipComm:  sliced:S needs 2 <= S <= 64");
         return m;
     }
-    fail_arg("HipComm:  unknown mode '" + v + "' (owner | sliced[:S] | allreduce)");
+    fail_arg("HipComm:  unknown mode '" + v + "' (owner | sliced[:S] | allreduce | peer)");
 }
 
 const CommMode & mode() {
@@ -378,6 +393,207 @@ void reduce_apply_range(int64_t px0, int64_t n, int64_t nnz, const double * d_co
     if (work != part) TH_HIP(hipMemcpyAsync(part, work, (size_t)n * nnz * sizeof(double), hipMemcpyDeviceToDevice, st));
 }
 
+
+// ------------------------------------------------------------------------------------ mode "peer"
+// Every rank owns one driver allocation [out | inbox]: `out` holds the finished slice this rank owns (cap_v doubles),
+// `inbox` one slot per rank for their contributions to that slice.  All ranks open all allocations (hipIpc), so a kernel
+// can address any of them.  One reduction, everything on the caller's stream:
+//   push     slice s (s != me) of my map -> inbox of rank s, slot me            (remote writes over all links at once)
+//   barrier  (every contribution has landed: kernel boundaries + a one-word all-reduce)
+//   sum      my slice <- rank 0's + rank 1's + ... in that order (mine read from the map), then C . slice, copy to `out`
+//   barrier  (every owner's `out` is complete)
+//   pull     slice s (s != me) of my map <- out of rank s                        (remote reads over all links at once)
+// Nothing of reduction e + 1 can overtake reduction e: a peer writes my inbox again only after its pull, which follows the
+// second barrier, which I enter after my sum; and I rewrite `out` only after the first barrier of e + 1, which every
+// peer enters after its pull of e.
+constexpr int kPeerMax = 16;
+
+struct PeerTable {
+    double * p[kPeerMax];
+};
+
+// Everything another agent writes or reads goes through system-scope accesses (sc0 sc1: past the caches that are not
+// coherent between agents), on top of the kernel boundaries and barriers between the phases: every value is used once,
+// so there is nothing for a cache to give.
+__device__ inline double peer_load(const double * p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ inline void peer_store(double * p, double v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void __launch_bounds__(256) k_peer_push(const double * __restrict__ map, PeerTable inbox, int rank, int64_t per_v,
+                                                   int64_t n_v) {
+    const int s = blockIdx.y;          // owner of the slice
+    if (s == rank) return;
+    const int64_t first = (int64_t)s * per_v;
+    int64_t cnt = n_v - first;
+    if (cnt <= 0) return;
+    if (cnt > per_v) cnt = per_v;
+    const double * src = map + first;
+    double * dst = inbox.p[s] + (int64_t)rank * per_v;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) peer_store(dst + i, src[i]);
+}
+
+__global__ void __launch_bounds__(256) k_peer_sum(double * __restrict__ mine, const double * inbox, int size, int rank,
+                                                  int64_t per_v, int64_t cnt) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) {
+        double acc = (rank == 0) ? mine[i] : peer_load(inbox + i);
+        for (int p = 1; p < size; ++p) acc += (p == rank) ? mine[i] : peer_load(inbox + (int64_t)p * per_v + i);
+        mine[i] = acc;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_peer_pull(double * __restrict__ map, PeerTable out, int rank, int64_t per_v,
+                                                   int64_t n_v) {
+    const int s = blockIdx.y;
+    if (s == rank) return;
+    const int64_t first = (int64_t)s * per_v;
+    int64_t cnt = n_v - first;
+    if (cnt <= 0) return;
+    if (cnt > per_v) cnt = per_v;
+    const double * src = out.p[s];
+    double * dst = map + first;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) dst[i] = peer_load(src + i);
+}
+
+struct PeerExchange {
+    int64_t cap_v = 0;                 // doubles per slot
+    char * base = nullptr;             // my allocation
+    char * peer[kPeerMax] = {};        // everybody's (peer[g_rank] == base)
+    unsigned char * d_words = nullptr; // device words: [0, 64 * kPeerMax) the handles, then the barrier / agreement word
+    int64_t reductions = 0, establishments = 0;
+    size_t out_bytes() const { return ((size_t)cap_v * sizeof(double) + 255) & ~(size_t)255; }
+    double * out_of(int r) const { return reinterpret_cast<double *>(peer[r]); }
+    double * inbox_of(int r) const { return reinterpret_cast<double *>(peer[r] + out_bytes()); }
+};
+PeerExchange g_peer;
+
+void peer_barrier(hipStream_t st) {
+    int * word = reinterpret_cast<int *>(g_peer.d_words + 64 * kPeerMax);
+    check(rccl().all_reduce(word, word, 1, ncclInt32, ncclMax, comm(), st), "ncclAllReduce (barrier)");
+}
+
+// all ranks: does everybody say yes?  (a rank that failed to open a handle must not leave the others inside a barrier)
+bool peer_agree(bool ok, hipStream_t st) {
+    int * word = reinterpret_cast<int *>(g_peer.d_words + 64 * kPeerMax) + 1;
+    int v = ok ? 1 : 0;
+    TH_HIP(hipMemcpyAsync(word, &v, sizeof(int), hipMemcpyHostToDevice, st));
+    check(rccl().all_reduce(word, word, 1, ncclInt32, ncclMin, comm(), st), "ncclAllReduce (agreement)");
+    TH_HIP(hipMemcpyAsync(&v, word, sizeof(int), hipMemcpyDeviceToHost, st));
+    TH_HIP(hipStreamSynchronize(st));
+    return v == 1;
+}
+
+// collective: close what is open, free what is mine
+void peer_teardown(hipStream_t st) {
+    if (g_peer.base == nullptr) return;
+    TH_HIP(hipStreamSynchronize(st));
+    for (int r = 0; r < g_size; ++r) {
+        if (r != g_rank && g_peer.peer[r] != nullptr) (void)hipIpcCloseMemHandle(g_peer.peer[r]);
+        g_peer.peer[r] = nullptr;
+    }
+    if (g_comm != nullptr && g_peer.d_words != nullptr) {
+        peer_barrier(st);              // nobody frees what somebody still has open
+        TH_HIP(hipStreamSynchronize(st));
+    }
+    (void)hipFree(g_peer.base);
+    g_peer.base = nullptr;
+    g_peer.cap_v = 0;
+}
+
+// collective: every rank arrives with the same need_v (the map is replicated)
+void peer_establish(int64_t need_v, hipStream_t st) {
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
+    if (g_peer.d_words == nullptr) {
+        TH_HIP(hipMalloc(reinterpret_cast<void **>(&g_peer.d_words), 64 * kPeerMax + 64));
+        TH_HIP(hipMemsetAsync(g_peer.d_words, 0, 64 * kPeerMax + 64, st));
+    }
+    peer_teardown(st);
+    g_peer.cap_v = (need_v + 31) / 32 * 32;
+    const size_t bytes = g_peer.out_bytes() * (size_t)(1 + g_size);
+    hipIpcMemHandle_t all[kPeerMax];
+    bool ok = hipMalloc(reinterpret_cast<void **>(&g_peer.base), bytes) == hipSuccess;
+    if (!ok) g_peer.base = nullptr;
+    std::memset(all, 0, sizeof(all));
+    if (ok) ok = hipIpcGetMemHandle(&all[g_rank], g_peer.base) == hipSuccess;
+    (void)hipGetLastError();
+    TH_HIP(hipMemcpyAsync(g_peer.d_words + 64 * g_rank, &all[g_rank], 64, hipMemcpyHostToDevice, st));
+    check(rccl().all_gather(g_peer.d_words + 64 * g_rank, g_peer.d_words, 64, ncclUint8, comm(), st), "ncclAllGather (handles)");
+    TH_HIP(hipMemcpyAsync(all, g_peer.d_words, 64 * (size_t)g_size, hipMemcpyDeviceToHost, st));
+    TH_HIP(hipStreamSynchronize(st));
+    ok = peer_agree(ok, st);           // everybody has an allocation and a handle
+    if (ok) {
+        g_peer.peer[g_rank] = g_peer.base;
+        for (int r = 0; r < g_size && ok; ++r) {
+            if (r == g_rank) continue;
+            void * p = nullptr;
+            ok = hipIpcOpenMemHandle(&p, all[r], hipIpcMemLazyEnablePeerAccess) == hipSuccess;
+            g_peer.peer[r] = ok ? static_cast<char *>(p) : nullptr;
+        }
+        (void)hipGetLastError();
+        ok = peer_agree(ok, st);
+    }
+    if (!ok) {
+        peer_teardown(st);
+        throw Error(TOAST_HIP_ERR_DEVICE,
+                    "HipComm:  mode 'peer': the ranks could not open each other's exchange buffers (hipIpc); use "
+                    "TOAST_HIP_COMM_MODE=owner");
+    }
+    ++g_peer.establishments;
+}
+
+void peer_release() {
+    peer_teardown(nullptr);
+    if (g_peer.d_words != nullptr) (void)hipFree(g_peer.d_words);
+    g_peer.d_words = nullptr;
+}
+
+void peer_reduce_apply(int64_t n_px, int64_t nnz, const double * d_cov, double * d_map, int reduce, hipStream_t st) {
+    if (g_size > kPeerMax) fail_arg("HipComm:  mode 'peer' serves at most 16 ranks");
+    const Shard s = shard_of(n_px);
+    const int64_t ncov = nnz * (nnz + 1) / 2;
+    const int64_t per_v = s.per * nnz, n_v = n_px * nnz, cnt_v = s.count * nnz;
+    double * mine = d_map + s.first * nnz;
+    if (g_size == 1) {
+        if (d_cov != nullptr) {
+            const int rc = toast_hip_cov_apply_diag_dev(1, n_px, nnz, d_cov, d_map, st);
+            if (rc != 0) throw Error(rc, toast_hip_last_error());
+        }
+        return;
+    }
+    if (per_v > g_peer.cap_v || g_peer.base == nullptr) peer_establish(per_v, st);
+    const unsigned gx = (unsigned)std::min<int64_t>((per_v + 255) / 256, 4096);
+    const dim3 grid(gx > 0 ? gx : 1, (unsigned)g_size);
+    PeerTable tab;
+    if (reduce) {
+        for (int r = 0; r < kPeerMax; ++r) tab.p[r] = r < g_size ? g_peer.inbox_of(r) : nullptr;
+        hipLaunchKernelGGL(k_peer_push, grid, dim3(256), 0, st, d_map, tab, g_rank, per_v, n_v);
+        TH_HIP(hipGetLastError());
+        peer_barrier(st);
+        if (cnt_v > 0) {
+            const unsigned gs = (unsigned)std::min<int64_t>((cnt_v + 255) / 256, 8192);
+            hipLaunchKernelGGL(k_peer_sum, dim3(gs), dim3(256), 0, st, mine, g_peer.inbox_of(g_rank), g_size, g_rank, per_v, cnt_v);
+            TH_HIP(hipGetLastError());
+        }
+    }
+    if (cnt_v > 0) {
+        if (d_cov != nullptr) {
+            const int rc = toast_hip_cov_apply_diag_dev(1, s.count, nnz, d_cov + s.first * ncov, mine, st);
+            if (rc != 0) throw Error(rc, toast_hip_last_error());
+        }
+        TH_HIP(hipMemcpyAsync(g_peer.out_of(g_rank), mine, (size_t)cnt_v * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    peer_barrier(st);
+    for (int r = 0; r < kPeerMax; ++r) tab.p[r] = r < g_size ? g_peer.out_of(r) : nullptr;
+    hipLaunchKernelGGL(k_peer_pull, grid, dim3(256), 0, st, d_map, tab, g_rank, per_v, n_v);
+    TH_HIP(hipGetLastError());
+    ++g_peer.reductions;
+}
+
 }  // namespace
 
 extern "C" {
@@ -389,10 +605,21 @@ int toast_hip_comm_set_mode(const char * text) {
     });
 }
 
+int toast_hip_comm_peer_stats(int64_t * reductions, int64_t * establishments, int64_t * exchange_bytes) {
+    return guarded([&] {
+        if (reductions) *reductions = g_peer.reductions;
+        if (establishments) *establishments = g_peer.establishments;
+        if (exchange_bytes) *exchange_bytes = g_peer.base ? (int64_t)(g_peer.out_bytes() * (size_t)(1 + g_size)) : 0;
+    });
+}
+
 int toast_hip_comm_get_mode(char * text, size_t len) {
     return guarded([&] {
         const CommMode & m = mode();
-        const std::string v = m.kind == 0 ? "owner" : m.kind == 2 ? "allreduce" : "sliced:" + std::to_string(m.slices);
+        const std::string v = m.kind == 0   ? "owner"
+                              : m.kind == 2 ? "allreduce"
+                              : m.kind == 3 ? "peer"
+                                            : "sliced:" + std::to_string(m.slices);
         if (text == nullptr || len < v.size() + 1) fail_arg("HipComm:  mode buffer too small");
         std::memcpy(text, v.c_str(), v.size() + 1);
     });
@@ -414,6 +641,10 @@ int toast_hip_comm_map_reduce_apply_dev(int64_t n_px, int64_t nnz, const double 
                 const int rc = toast_hip_cov_apply_diag_dev(1, n_px, nnz, d_cov, d_map, stream);
                 if (rc != 0) throw Error(rc, toast_hip_last_error());
             }
+            return;
+        }
+        if (m.kind == 3) {
+            peer_reduce_apply(n_px, nnz, d_cov, d_map, reduce, st);
             return;
         }
         if (m.kind == 1 && n_px >= (int64_t)m.slices * g_size * 64) {
