@@ -696,7 +696,7 @@ def run(args, workload, world, rank, dev, headline=True):
             "backend": (dist.get_backend() if multi else None),
             "implementation": comm_impl,
             "owner_computes_reduce_apply_ms": None,
-            # the same pass per implementation (TOAST_HIP_COMM_MODE): {"owner", "sliced:2", "sliced:4", "sliced:8", "allreduce", "peer"}
+            # the same pass per implementation (TOAST_HIP_COMM_MODE): {"owner", "sliced:2", "sliced:4", "sliced:8", "allreduce", "peer", "peer:flags"}
             "reduce_apply_ms_by_mode": None,
             "note": comm_note,
             "algorithm_GBs": (2.0 * (world - 1) / world * n_local * nps * nnz * 8 / (ms["allreduce"] * 1e-3) / 1e9
@@ -717,7 +717,7 @@ def run(args, workload, world, rank, dev, headline=True):
         # one all-reduce followed by every rank multiplying the whole map, and the exchange over hipIpc-opened buffers
         # ("peer": every link of the xGMI mesh at once, RCCL only for the two barriers)
         mode_ms = {"owner": owner_ms}
-        for mode in ("sliced:2", "sliced:4", "sliced:8", "allreduce", "peer"):
+        for mode in ("sliced:2", "sliced:4", "sliced:8", "allreduce", "peer", "peer:flags"):
             try:
                 D.comm_set_mode(mode)
                 oc()

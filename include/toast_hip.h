@@ -1133,7 +1133,9 @@ int toast_hip_comm_map_reduce_apply_dev(int64_t n_px, int64_t nnz, const double 
  * covariance_apply, pixels.py:710-780), "peer" (at most 16 ranks of one node: no RCCL on the data path -- every rank writes
  * the foreign slices of its map into their owners' exchange buffers, opened through hipIpc handles, owners add them in rank
  * order and multiply, every rank reads the finished slices back; all xGMI links of the mesh carry 1/N of the map at once,
- * RCCL provides the two barriers; fails with TOAST_HIP_ERR_DEVICE on every rank if the buffers cannot be opened).  Same
+ * RCCL provides the two barriers; fails with TOAST_HIP_ERR_DEVICE on every rank if the buffers cannot be opened),
+ * "peer:flags" (the same with the barriers done by device flags in each other's uncached memory: no library call per
+ * reduction; a wait gives up after TOAST_HIP_COMM_PEER_TIMEOUT_MS and the rank's next call fails).  Same
  * results in every mode (to the rounding of the sums' order).  Collective: every rank must use the same mode. */
 int toast_hip_comm_set_mode(const char * mode);
 /* mode "peer": reductions done through the exchange buffers, times the buffers were (re-)established (collective hipIpc

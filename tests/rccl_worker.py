@@ -213,8 +213,10 @@ def main():
     # the three implementations of the owner-computes pass (toast_hip_comm_set_mode): same sums, same product
     # ("peer": no RCCL on the data path -- slices written into / read from the owners' hipIpc-opened exchange buffers;
     # between processes that share this GPU here, between GPUs over xGMI on a node)
-    for mode in ("owner", "sliced:2", "sliced:4", "allreduce", "peer", "owner"):
+    # ("peer:flags": the same with the two barriers of a reduction done by device flags in each other's memory)
+    for mode in ("owner", "sliced:2", "sliced:4", "allreduce", "peer", "peer:flags", "owner"):
         capi.dev.comm_set_mode(mode)
+        peer_before = capi.dev.comm_peer_stats()
         assert capi.dev.comm_get_mode() == mode
         for reduce in (True, False):
             cv, z = dev_map(spd, 6, "cov"), dev_map(parts[rank] if reduce else total, 3, "zmap")
@@ -235,7 +237,7 @@ def main():
         capi.dev.comm_map_reduce_apply(40000, 1, 0, t.data_ptr(), reduce=True)
         torch.cuda.synchronize()
         np.testing.assert_allclose(t.cpu().numpy(), tot, rtol=0, atol=1e-13 * np.max(np.abs(tot)), err_msg=mode)
-        if mode == "peer":
+        if mode.startswith("peer"):
             # an odd number of values (8-byte lane accesses, a short last slice), then twice in a row on a smaller map
             # (the exchange buffers are reused: the second reduction must not see anything of the first)
             for n_odd in (40101, 997, 997):
@@ -255,10 +257,12 @@ def main():
             torch.cuda.synchronize()
             assert np.array_equal(ref_bits.cpu().numpy(), got), "peer mode: ranks disagree in the last bit"
             n_red, n_est, n_bytes = capi.dev.comm_peer_stats()
+            n_red, n_est = n_red - peer_before[0], n_est - peer_before[1]
             if size > 1:
                 # 2 small maps + 1 of 40 000 + 3 x 2 odd ones went through the exchange buffers, which grew twice
-                # (1776 x 3 values -> 40 000 -> 40 101) and hold (1 + size) slots of ceil(40 101 / size) values
-                assert n_red == 9 and n_est == 3, (n_red, n_est)
+                # (1776 x 3 values -> 40 000 -> 40 101; the second mode finds them large enough) and hold (1 + size)
+                # slots of ceil(40 101 / size) values
+                assert n_red == 9 and n_est == (3 if mode == "peer" else 0), (mode, n_red, n_est)
                 assert n_bytes >= (1 + size) * 8 * (40101 // size), n_bytes
             else:
                 assert n_red == 0 and n_est == 0 and n_bytes == 0

@@ -61,6 +61,12 @@ def test_mapmaker_equals_single_process_in_peer_mode(mock_lib):
     assert out.stdout.count("OK") == 3
 
 
+def test_peer_flags_give_up_loudly_when_a_rank_does_not_arrive(mock_lib):
+    out = _run(2, "peer_timeout_worker.py", 29581, mock_lib, timeout=300, TOAST_HIP_COMM_PEER_TIMEOUT_MS="300")
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-6000:]
+    assert out.stdout.count("OK") == 2
+
+
 @pytest.mark.parametrize("n", [2, 3])
 def test_bench_ranks_through_the_library_communicator(mock_lib, n):
     """`python3 bench.py --gpus N` (self-launched) with all ranks on the one GPU (N = 3: shards that do not divide): the N > 1 protocol of the benchmark
@@ -84,7 +90,7 @@ def test_bench_ranks_through_the_library_communicator(mock_lib, n):
     # every implementation of the owner-computes pass was timed on this job (A/B material for the first 8-GPU lease),
     # and the packed left-hand side with the reduction inside is part of the same line
     modes = d["allreduce"]["reduce_apply_ms_by_mode"]
-    assert set(modes) == {"owner", "sliced:2", "sliced:4", "sliced:8", "allreduce", "peer"}
+    assert set(modes) == {"owner", "sliced:2", "sliced:4", "sliced:8", "allreduce", "peer", "peer:flags"}
     assert all(isinstance(v, float) and v > 0 for v in modes.values()), modes
     assert d["pcg_lhs_offset_templates"]["packed_ms"] > 0
     assert d["configs3_shard"]["allreduce"]["implementation"].startswith("toast_hip_comm")

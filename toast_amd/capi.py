@@ -1252,7 +1252,7 @@ class _Dev:
                                                          C.c_int(1 if reduce else 0), _p(stream)))
 
     def comm_set_mode(self, mode):
-        """'owner' | 'sliced:S' | 'allreduce' | 'peer': how comm_map_reduce_apply works (toast_hip_comm_set_mode; collective:
+        """'owner' | 'sliced:S' | 'allreduce' | 'peer' | 'peer:flags': how comm_map_reduce_apply works (toast_hip_comm_set_mode; collective:
         every rank the same)."""
         _check(real_lib().toast_hip_comm_set_mode(str(mode).encode()))
 

@@ -315,6 +315,9 @@ int toast_hip_comm_pixel_shard(int64_t n_px, int64_t * first, int64_t * count) {
 //              finished slices from their owners.  (N-1)/N map volumes per direction and rank, each link carrying 1/N of
 //              the map per phase instead of a ring's N-1 steps over one link; the sum has a fixed order.  RCCL only
 //              provides the two barriers (a one-word all-reduce each) and the exchange of the handles.
+//   peer:flags the same with the barriers done by the ranks themselves: after its phase every rank stores the number of
+//              the reduction into a word of every peer's (uncached, hipIpc-opened) flag block, and a one-workgroup kernel
+//              on the stream waits until all peers' words have arrived.  No library call per reduction at all.
 // reduce = 0: the map is already the same on all ranks (the reference's covariance_apply(use_alltoallv=True),
 // covariance.py:224-306): owners apply, results are gathered (allreduce mode: every rank applies, no communication).
 }  // extern "C"
@@ -336,8 +339,9 @@ CommMode parse_mode(const char * text) {
         m.kind = 2;
         return m;
     }
-    if (v == "peer") {
+    if (v == "peer" || v == "peer:flags") {
         m.kind = 3;
+        m.slices = (v == "peer") ? 0 : 1;      // 1: the two barriers are device flags, not RCCL calls
         return m;
     }
     if (v.rfind("sliced", 0) == 0) {
@@ -347,7 +351,7 @@ CommMode parse_mode(const char * text) {
         if (m.slices < 2 || m.slices > 64) fail_arg("HipComm:  sliced:S needs 2 <= S <= 64");
         return m;
     }
-    fail_arg("HipComm:  unknown mode '" + v + "' (owner | sliced[:S] | allreduce | peer)");
+    fail_arg("HipComm:  unknown mode '" + v + "' (owner | sliced[:S] | allreduce | peer[:flags])");
 }
 
 const CommMode & mode() {
@@ -460,7 +464,41 @@ __global__ void __launch_bounds__(256) k_peer_pull(double * __restrict__ map, Pe
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) dst[i] = peer_load(src + i);
 }
 
+struct FlagTable {
+    unsigned long long * p[kPeerMax];
+};
+
+// flag block of a rank: word [slot][source rank], slot 0 = "my contributions have landed", slot 1 = "my slice is finished"
+__global__ void k_peer_signal(FlagTable f, int size, int rank, int slot, unsigned long long epoch) {
+    const int p = threadIdx.x;
+    if (p >= size || p == rank) return;
+    __threadfence_system();
+    __hip_atomic_store(f.p[p] + slot * kPeerMax + rank, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// one lane per peer; gives up after `limit` ticks of the 100 MHz clock (a rank that never arrives must not park a kernel
+// on the GPU for ever): the host sees *error != 0 at its next call and raises
+__global__ void k_peer_wait(const unsigned long long * mine, int size, int rank, int slot, unsigned long long epoch,
+                            long long limit, int * error) {
+    const int p = threadIdx.x;
+    if (p < size && p != rank) {
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(mine + slot * kPeerMax + p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+            __builtin_amdgcn_s_sleep(32);
+            if (wall_clock64() - t0 > limit) {
+                __hip_atomic_store(error, 1 + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+        }
+    }
+    __threadfence_system();
+}
+
 struct PeerExchange {
+    unsigned long long * flags[kPeerMax] = {};   // everybody's flag block (uncached memory), flags[g_rank] is mine
+    unsigned long long epoch = 0;                // number of the last barrier pair handed out
+    int * h_error = nullptr;                     // host-mapped word the waiting kernel writes on a time-out
+    long long wait_ticks = 0;
     int64_t cap_v = 0;                 // doubles per slot
     char * base = nullptr;             // my allocation
     char * peer[kPeerMax] = {};        // everybody's (peer[g_rank] == base)
@@ -475,6 +513,89 @@ PeerExchange g_peer;
 void peer_barrier(hipStream_t st) {
     int * word = reinterpret_cast<int *>(g_peer.d_words + 64 * kPeerMax);
     check(rccl().all_reduce(word, word, 1, ncclInt32, ncclMax, comm(), st), "ncclAllReduce (barrier)");
+}
+
+bool peer_agree(bool ok, hipStream_t st);
+
+// barrier `slot` of reduction `epoch` by flags: tell every peer, wait for every peer
+void peer_flag_barrier(int slot, unsigned long long epoch, hipStream_t st) {
+    FlagTable f;
+    for (int r = 0; r < kPeerMax; ++r) f.p[r] = r < g_size ? g_peer.flags[r] : nullptr;
+    hipLaunchKernelGGL(k_peer_signal, dim3(1), dim3(64), 0, st, f, g_size, g_rank, slot, epoch);
+    hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, st, g_peer.flags[g_rank], g_size, g_rank, slot, epoch,
+                       g_peer.wait_ticks, g_peer.h_error);
+    TH_HIP(hipGetLastError());
+}
+
+void peer_check_error() {
+    if (g_peer.h_error != nullptr && *g_peer.h_error != 0) {
+        const int who = *g_peer.h_error - 1;
+        *g_peer.h_error = 0;
+        throw Error(TOAST_HIP_ERR_DEVICE, "HipComm:  mode 'peer:flags': rank " + std::to_string(g_rank) +
+                                              " waited in vain for the flag of rank " + std::to_string(who) +
+                                              " (TOAST_HIP_COMM_PEER_TIMEOUT_MS); the maps of this reduction are not valid");
+    }
+}
+
+// collective, once per communicator: every rank's flag block, opened by everybody
+void peer_establish_flags(hipStream_t st) {
+    if (g_peer.flags[g_rank] != nullptr) return;
+    const char * t = std::getenv("TOAST_HIP_COMM_PEER_TIMEOUT_MS");
+    const double ms = (t != nullptr && t[0] != '\0') ? std::atof(t) : 60000.0;
+    g_peer.wait_ticks = (long long)(ms * 1.0e5);          // 100 MHz
+    hipIpcMemHandle_t all[kPeerMax];
+    std::memset(all, 0, sizeof(all));
+    void * mine = nullptr;
+    bool ok = hipExtMallocWithFlags(&mine, 4096, hipDeviceMallocUncached) == hipSuccess;
+    if (ok) ok = hipMemsetAsync(mine, 0, 4096, st) == hipSuccess;
+    if (ok) ok = hipIpcGetMemHandle(&all[g_rank], mine) == hipSuccess;
+    if (ok && g_peer.h_error == nullptr) {
+        ok = hipHostMalloc(reinterpret_cast<void **>(&g_peer.h_error), sizeof(int), hipHostMallocMapped) == hipSuccess;
+        if (ok) *g_peer.h_error = 0;
+    }
+    (void)hipGetLastError();
+    TH_HIP(hipMemcpyAsync(g_peer.d_words + 64 * g_rank, &all[g_rank], 64, hipMemcpyHostToDevice, st));
+    check(rccl().all_gather(g_peer.d_words + 64 * g_rank, g_peer.d_words, 64, ncclUint8, comm(), st), "ncclAllGather (handles)");
+    TH_HIP(hipMemcpyAsync(all, g_peer.d_words, 64 * (size_t)g_size, hipMemcpyDeviceToHost, st));
+    TH_HIP(hipStreamSynchronize(st));
+    ok = peer_agree(ok, st);
+    if (ok) {
+        g_peer.flags[g_rank] = static_cast<unsigned long long *>(mine);
+        for (int r = 0; r < g_size && ok; ++r) {
+            if (r == g_rank) continue;
+            void * p = nullptr;
+            ok = hipIpcOpenMemHandle(&p, all[r], hipIpcMemLazyEnablePeerAccess) == hipSuccess;
+            g_peer.flags[r] = ok ? static_cast<unsigned long long *>(p) : nullptr;
+        }
+        (void)hipGetLastError();
+        ok = peer_agree(ok, st);
+    }
+    if (!ok) {
+        for (int r = 0; r < g_size; ++r) {
+            if (r != g_rank && g_peer.flags[r] != nullptr) (void)hipIpcCloseMemHandle(g_peer.flags[r]);
+            g_peer.flags[r] = nullptr;
+        }
+        peer_barrier(st);
+        TH_HIP(hipStreamSynchronize(st));
+        if (mine != nullptr) (void)hipFree(mine);
+        throw Error(TOAST_HIP_ERR_DEVICE,
+                    "HipComm:  mode 'peer:flags': the ranks could not open each other's flag blocks (uncached memory over "
+                    "hipIpc); use TOAST_HIP_COMM_MODE=peer or owner");
+    }
+}
+
+void peer_release_flags() {
+    if (g_peer.flags[g_rank < 0 ? 0 : g_rank] == nullptr) return;
+    (void)hipDeviceSynchronize();
+    for (int r = 0; r < g_size; ++r) {
+        if (r != g_rank && g_peer.flags[r] != nullptr) (void)hipIpcCloseMemHandle(g_peer.flags[r]);
+    }
+    if (g_comm != nullptr && g_peer.d_words != nullptr) {
+        peer_barrier(nullptr);
+        (void)hipStreamSynchronize(nullptr);
+    }
+    (void)hipFree(g_peer.flags[g_rank]);
+    for (int r = 0; r < kPeerMax; ++r) g_peer.flags[r] = nullptr;
 }
 
 // all ranks: does everybody say yes?  (a rank that failed to open a handle must not leave the others inside a barrier)
@@ -547,13 +668,16 @@ void peer_establish(int64_t need_v, hipStream_t st) {
 }
 
 void peer_release() {
+    peer_release_flags();
     peer_teardown(nullptr);
     if (g_peer.d_words != nullptr) (void)hipFree(g_peer.d_words);
     g_peer.d_words = nullptr;
 }
 
-void peer_reduce_apply(int64_t n_px, int64_t nnz, const double * d_cov, double * d_map, int reduce, hipStream_t st) {
+void peer_reduce_apply(int64_t n_px, int64_t nnz, const double * d_cov, double * d_map, int reduce, bool flags,
+                       hipStream_t st) {
     if (g_size > kPeerMax) fail_arg("HipComm:  mode 'peer' serves at most 16 ranks");
+    peer_check_error();
     const Shard s = shard_of(n_px);
     const int64_t ncov = nnz * (nnz + 1) / 2;
     const int64_t per_v = s.per * nnz, n_v = n_px * nnz, cnt_v = s.count * nnz;
@@ -566,6 +690,8 @@ void peer_reduce_apply(int64_t n_px, int64_t nnz, const double * d_cov, double *
         return;
     }
     if (per_v > g_peer.cap_v || g_peer.base == nullptr) peer_establish(per_v, st);
+    if (flags) peer_establish_flags(st);
+    const unsigned long long epoch = ++g_peer.epoch;
     const unsigned gx = (unsigned)std::min<int64_t>((per_v + 255) / 256, 4096);
     const dim3 grid(gx > 0 ? gx : 1, (unsigned)g_size);
     PeerTable tab;
@@ -573,7 +699,8 @@ void peer_reduce_apply(int64_t n_px, int64_t nnz, const double * d_cov, double *
         for (int r = 0; r < kPeerMax; ++r) tab.p[r] = r < g_size ? g_peer.inbox_of(r) : nullptr;
         hipLaunchKernelGGL(k_peer_push, grid, dim3(256), 0, st, d_map, tab, g_rank, per_v, n_v);
         TH_HIP(hipGetLastError());
-        peer_barrier(st);
+        if (flags) peer_flag_barrier(0, epoch, st);
+        else peer_barrier(st);
         if (cnt_v > 0) {
             const unsigned gs = (unsigned)std::min<int64_t>((cnt_v + 255) / 256, 8192);
             hipLaunchKernelGGL(k_peer_sum, dim3(gs), dim3(256), 0, st, mine, g_peer.inbox_of(g_rank), g_size, g_rank, per_v, cnt_v);
@@ -587,7 +714,8 @@ void peer_reduce_apply(int64_t n_px, int64_t nnz, const double * d_cov, double *
         }
         TH_HIP(hipMemcpyAsync(g_peer.out_of(g_rank), mine, (size_t)cnt_v * sizeof(double), hipMemcpyDeviceToDevice, st));
     }
-    peer_barrier(st);
+    if (flags) peer_flag_barrier(1, epoch, st);
+    else peer_barrier(st);
     for (int r = 0; r < kPeerMax; ++r) tab.p[r] = r < g_size ? g_peer.out_of(r) : nullptr;
     hipLaunchKernelGGL(k_peer_pull, grid, dim3(256), 0, st, d_map, tab, g_rank, per_v, n_v);
     TH_HIP(hipGetLastError());
@@ -618,7 +746,7 @@ int toast_hip_comm_get_mode(char * text, size_t len) {
         const CommMode & m = mode();
         const std::string v = m.kind == 0   ? "owner"
                               : m.kind == 2 ? "allreduce"
-                              : m.kind == 3 ? "peer"
+                              : m.kind == 3 ? (m.slices ? "peer:flags" : "peer")
                                             : "sliced:" + std::to_string(m.slices);
         if (text == nullptr || len < v.size() + 1) fail_arg("HipComm:  mode buffer too small");
         std::memcpy(text, v.c_str(), v.size() + 1);
@@ -644,7 +772,7 @@ int toast_hip_comm_map_reduce_apply_dev(int64_t n_px, int64_t nnz, const double 
             return;
         }
         if (m.kind == 3) {
-            peer_reduce_apply(n_px, nnz, d_cov, d_map, reduce, st);
+            peer_reduce_apply(n_px, nnz, d_cov, d_map, reduce, m.slices != 0, st);
             return;
         }
         if (m.kind == 1 && n_px >= (int64_t)m.slices * g_size * 64) {

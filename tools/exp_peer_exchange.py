@@ -48,7 +48,7 @@ def rank_main():
         return 1e3 * (time.perf_counter() - t0) / reps
 
     out = {}
-    for mode in ("peer",):      # ("owner" would need the whole map in one 96 MB slot of the stand-in)
+    for mode in ("peer", "peer:flags"):      # ("owner" would need the whole map in one 96 MB slot of the stand-in)
         capi.dev.comm_set_mode(mode)
         z.fill_(float(rank + 1))
         capi.dev.comm_map_reduce_apply(n_px, nnz, 0, z.data_ptr(), reduce=True)
@@ -59,8 +59,8 @@ def rank_main():
     out["one_word_allreduce"] = timed(lambda: capi.dev.comm_allreduce(word.data_ptr(), 1, np.int32, "max"), 20)
     if rank == 0:
         print("ranks %d  map %.0f MB   peer %.3f ms per reduction (of which 2 barriers of the stand-in: %.3f ms)   "
-              "exchange buffer %.0f MB per rank"
-              % (size, n_px * nnz * 8 / 1e6, out["peer"], 2 * out["one_word_allreduce"],
+              "peer:flags %.3f ms   exchange buffer %.0f MB per rank"
+              % (size, n_px * nnz * 8 / 1e6, out["peer"], 2 * out["one_word_allreduce"], out["peer:flags"],
                  capi.dev.comm_peer_stats()[2] / 1e6), flush=True)
     dist.barrier()
     dist.destroy_process_group()
