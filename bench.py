@@ -129,10 +129,43 @@ def operator_level():
     }
 
 
-# Multi-rank runs only: the line as it stands once the timed steps are over, and a timer that prints it if what follows
-# (the A/B repetitions of the communicator's modes, the extra sections) does not come back -- a collective that hangs
-# cannot be caught as an exception, and the headline must not be lost to an extra.
-_LIFELINE = {"fd": None, "line": None, "timer": None}
+# Multi-rank runs only.  The sections after the timed steps try things that have never run on more than one GPU (the A/B
+# repetitions of the communicator's modes); a collective that hangs cannot be caught as an exception and a memory fault
+# ends the process -- the headline must not be lost to an extra.  So rank 0 keeps a small child process (started before
+# anything touches the GPU) that owns the real stdout: it is sent the line as it stands once the timed steps are over,
+# later the complete line, and prints the LAST one it received when rank 0's end of the pipe closes -- however rank 0
+# ended.  A timer on every rank turns a hang into an exit.
+_GUARDIAN_SRC = (
+    "import sys\n"
+    "last = None\n"
+    "for line in sys.stdin:\n"
+    "    if line.strip():\n"
+    "        last = line.rstrip('\\n')\n"
+    "if last is not None:\n"
+    "    sys.stdout.write(last + '\\n')\n"
+    "    sys.stdout.flush()\n"
+)
+_LIFELINE = {"guardian": None, "timer": None}
+
+
+def _guardian_start(stdout_fd):
+    import subprocess
+
+    _LIFELINE["guardian"] = subprocess.Popen([sys.executable, "-c", _GUARDIAN_SRC], stdin=subprocess.PIPE, stdout=stdout_fd,
+                                             text=True, start_new_session=True)
+
+
+def _guardian_send(line):
+    g = _LIFELINE["guardian"]
+    g.stdin.write(line + "\n")
+    g.stdin.flush()
+
+
+def _guardian_finish():
+    g = _LIFELINE["guardian"]
+    _LIFELINE["guardian"] = None
+    g.stdin.close()
+    g.wait()
 
 
 def _lifeline_arm(out, rank):
@@ -141,17 +174,16 @@ def _lifeline_arm(out, rank):
     if _LIFELINE["timer"] is not None:
         return
     limit = float(os.environ.get("TOAST_BENCH_EXTRAS_TIMEOUT_S", "900"))
-    if rank == 0:
+    if rank == 0 and _LIFELINE["guardian"] is not None:
         short = dict(out)
-        short["truncated"] = "the sections after the timed steps did not finish within %.0f s" % limit
-        _LIFELINE["line"] = json.dumps(short)
+        short["truncated"] = ("the sections after the timed steps did not finish (time limit %.0f s, or the process ended "
+                              "in one of them)" % limit)
+        _guardian_send(json.dumps(short))
 
     def expire():
-        if rank == 0 and _LIFELINE["line"] is not None and _LIFELINE["fd"] is not None:
-            os.write(_LIFELINE["fd"], (_LIFELINE["line"] + "\n").encode())
-        else:
+        if rank != 0:
             time.sleep(2.0)
-        os._exit(0)
+        os._exit(0)          # (rank 0: the guardian prints what it was sent)
 
     t = threading.Timer(limit, expire)
     t.daemon = True
@@ -200,7 +232,8 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    _LIFELINE["fd"] = real_stdout
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and int(os.environ.get("RANK", "0")) == 0:
+        _guardian_start(real_stdout)         # (before torch is imported: nothing has touched the GPU yet)
 
     import torch
     import torch.distributed as dist
@@ -258,10 +291,12 @@ def main():
     except OSError:
         pass
     _lifeline_disarm()
-    _LIFELINE["fd"] = None
     os.dup2(real_stdout, 1)
     os.close(real_stdout)
-    if rank == 0:
+    if rank == 0 and _LIFELINE["guardian"] is not None:
+        _guardian_send(json.dumps(out))
+        _guardian_finish()
+    elif rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1 or single:
         dist.destroy_process_group()

@@ -340,9 +340,11 @@ def test_sync_alltoallv_single_process():
         pd.sync_alltoallv(bogus=True)
 
 
-def test_bench_lifeline_prints_the_headline_when_the_extras_hang():
-    """bench.py, ranks > 1: once the timed steps are over every rank arms a timer; if the sections after them never come
-    back (a collective that hangs cannot be caught), rank 0 prints the line as it stood and every rank leaves with 0."""
+def test_bench_guardian_keeps_the_headline_whatever_happens_to_the_extras():
+    """bench.py, ranks > 1: rank 0 hands the line to a child process that owns stdout -- first as it stands after the timed
+    steps, then complete -- and the child prints the last one it got when rank 0 is gone.  Three endings: the extras
+    finish (the complete line, once), they hang (every rank's timer ends the process; the provisional line with a
+    `truncated` key), rank 0 dies in them (SIGABRT, as after a GPU memory fault: the provisional line all the same)."""
     import json
     import subprocess
     import sys
@@ -351,17 +353,28 @@ def test_bench_lifeline_prints_the_headline_when_the_extras_hang():
 import os, sys, time
 sys.path.insert(0, %r)
 import bench
-bench._LIFELINE["fd"] = 1
-bench._lifeline_arm({"metric": "m", "value": 2.5, "n_gpus": 2}, int(sys.argv[1]))
+how, rank = sys.argv[1], int(sys.argv[2])
+if rank == 0:
+    bench._guardian_start(1)
+bench._lifeline_arm({"metric": "m", "value": 2.5, "n_gpus": 2}, rank)
+if how == "finish":
+    bench._lifeline_disarm()
+    if rank == 0:
+        bench._guardian_send('{"metric": "m", "value": 2.5, "n_gpus": 2, "extras": 1}')
+        bench._guardian_finish()
+    sys.exit(0)
+if how == "abort":
+    os.abort()
 time.sleep(30)
 print("not reached")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, TOAST_BENCH_EXTRAS_TIMEOUT_S="0.5")
-    for rank, lines in ((0, 1), (1, 0)):
-        p = subprocess.run([sys.executable, "-c", code, str(rank)], capture_output=True, text=True, env=env, timeout=60)
-        assert p.returncode == 0, p.stderr
+    for how, rank, rc_zero, lines in (("finish", 0, True, 1), ("hang", 0, True, 1), ("hang", 1, True, 0), ("abort", 0, False, 1)):
+        p = subprocess.run([sys.executable, "-c", code, how, str(rank)], capture_output=True, text=True, env=env, timeout=60)
+        assert (p.returncode == 0) == rc_zero, (how, p.returncode, p.stderr)
         got = [ln for ln in p.stdout.splitlines() if ln.strip()]
-        assert len(got) == lines, p.stdout
-        if rank == 0:
+        assert len(got) == lines, (how, rank, p.stdout)
+        if lines:
             line = json.loads(got[0])
-            assert line["value"] == 2.5 and line["n_gpus"] == 2 and "truncated" in line
+            assert line["value"] == 2.5 and line["n_gpus"] == 2
+            assert ("extras" in line) == (how == "finish") and ("truncated" in line) == (how != "finish"), line
