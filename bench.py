@@ -634,6 +634,19 @@ def run(args, workload, world, rank, dev, headline=True):
                     break
         except (KeyError, ValueError):
             traffic = None
+    # the same from the counters that count fixed 32-byte units (profiles/r04_e: exact on known byte counts, no correction)
+    traffic_exact = None
+    xpath = os.path.join(ROOT, "profiles", "traffic_exact_%s.json" % workload)
+    if os.path.isfile(xpath) and not args.unfused:
+        try:
+            with open(xpath) as f:
+                kernels = json.load(f)["kernels"]
+            for kname in knames:
+                if kname in kernels:
+                    traffic_exact = kernels[kname]["hbm_bytes"]
+                    break
+        except (KeyError, ValueError):
+            traffic_exact = None
     roofline = {
         "bound": "hbm",
         "kernel": dom,
@@ -642,6 +655,7 @@ def run(args, workload, world, rank, dev, headline=True):
         "unit": "GB/s",
         "frac": ach / HBM_PEAK_GBS,
         "traffic": traffic,
+        "traffic_exact": traffic_exact,
         "traffic_unit": "bytes per launch (rocprofv3 PMC, committed profile)",
         "algorithmic_bytes_per_launch": cand[dom][0],
         "per_kernel_GBs": {k: cand[k][0] / (cand[k][1] * 1e-3) / 1e9 for k in cand},

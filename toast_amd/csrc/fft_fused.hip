@@ -36,6 +36,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <array>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -59,6 +62,18 @@ constexpr int kTabLdsHalf = 7 * 1024 + 512;
 // ------------------------------------------------------------------------------------------
 // complex helpers (explicit fma: the library is built with -ffp-contract=off)
 // ------------------------------------------------------------------------------------------
+typedef double nt_double2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 load_nt(const double2 * p) {
+    const nt_double2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_double2 *>(p));
+    return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ void store_nt(double2 * p, double2 v) {
+    nt_double2 w;
+    w.x = v.x;
+    w.y = v.y;
+    __builtin_nontemporal_store(w, reinterpret_cast<nt_double2 *>(p));
+}
+
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
     return make_double2(__builtin_fma(a.x, b.x, -(a.y * b.y)), __builtin_fma(a.x, b.y, a.y * b.x));
 }
@@ -309,6 +324,10 @@ struct Params {
     int per_det, deconvolve;
     int aligned;                  // pass 1 may use padded_pair
     int xcd_order;                // column passes: contiguous column ranges per XCD
+    const int32_t * tile_order;   // pass 1: column tile of workgroup blockIdx.x (mirror partners on one XCD), or nullptr
+    int stream_hint;              // bit 0: pass 1 writes the work array with non-temporal stores, bit 1: reads the
+                                  // timestream with non-temporal loads (so that the window table stays in L2), bit 2 / 3:
+                                  // the same for pass 3's loads / stores, bit 4 / 5: the row pass' loads / stores
     double fstep, scale;
 };
 
@@ -379,7 +398,7 @@ __device__ __forceinline__ void col_twiddles(double2 (&v)[P], const Params & p, 
 // five or six serialised memory round trips per thread -- the largest part of the forward column pass,
 // profiles/r02_g_fft_phase_clocks.txt section 7.)
 __device__ __forceinline__ double2 padded_pair(const double * __restrict__ row, const double * __restrict__ apod,
-                                               int64_t s, int64_t n_samp, int64_t n_reflect) {
+                                               int64_t s, int64_t n_samp, int64_t n_reflect, bool nt = false) {
     const bool direct = (s >= 0) & (s < n_samp);
     const bool left = (s < 0) & (s >= -n_reflect);
     const bool right = (s >= n_samp) & (s < n_samp + n_reflect);
@@ -389,7 +408,8 @@ __device__ __forceinline__ double2 padded_pair(const double * __restrict__ row, 
     int64_t win = left ? jl : n_reflect - 2 - jr;
     if (!(direct | left | right)) src = 0;
     if (!(left | right)) win = 0;
-    const double2 r = *reinterpret_cast<const double2 *>(row + src);
+    const double2 r = nt ? load_nt(reinterpret_cast<const double2 *>(row + src))
+                         : *reinterpret_cast<const double2 *>(row + src);
     const double2 a = *reinterpret_cast<const double2 *>(apod + win);
     const double2 m = left ? make_double2(r.y * a.x, r.x * a.y) : make_double2(r.y * a.y, r.x * a.x);
     double2 out = direct ? r : m;
@@ -444,7 +464,8 @@ __global__ __launch_bounds__((1 << LT) / P, (P == 16 ? 2 : 4)) void k_fft_cols(c
     // XCD-aware tile order: workgroups go round-robin to the 8 XCDs, so with tile = blockIdx.x every XCD's L2 would
     // hold every 8th 128-byte piece of a row of the work array; this way XCD x owns a contiguous eighth of the columns
     unsigned bx = blockIdx.x;
-    if (p.xcd_order && (gridDim.x & 7u) == 0u) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);
+    if (!INV && p.tile_order != nullptr) bx = (unsigned)p.tile_order[bx];
+    else if (p.xcd_order && (gridDim.x & 7u) == 0u) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);
     const int64_t c0 = (int64_t)bx << log_c;
     const int64_t m = int64_t(1) << (p.log_n1 + p.log_n2);
     double2 * __restrict__ work = p.work + (int64_t)b * m;
@@ -458,7 +479,7 @@ __global__ __launch_bounds__((1 << LT) / P, (P == 16 ? 2 : 4)) void k_fft_cols(c
             for (int k = 0; k < P; ++k) {
                 const int e = tid + k * T;
                 const int64_t j = ((int64_t)(e >> log_c) << p.log_n2) + c0 + (e & ((1 << log_c) - 1));
-                v[k] = padded_pair(row, p.apod, 2 * j - p.n_buffer, p.n_samp, p.n_reflect);
+                v[k] = padded_pair(row, p.apod, 2 * j - p.n_buffer, p.n_samp, p.n_reflect, (p.stream_hint & 2) != 0);
             }
         } else {
 #pragma unroll
@@ -475,7 +496,7 @@ __global__ __launch_bounds__((1 << LT) / P, (P == 16 ? 2 : 4)) void k_fft_cols(c
             const int e = tid + k * T;
             const int64_t k1 = e >> log_c;
             const int64_t j2 = c0 + (e & ((1 << log_c) - 1));
-            v[k] = work[(k1 << p.log_n2) + j2];
+            v[k] = (p.stream_hint & 4) ? load_nt(work + (k1 << p.log_n2) + j2) : work[(k1 << p.log_n2) + j2];
         }
         col_twiddles<LT, P>(v, p, tid, log_c, c0, col_twiddles_prepare<LT, P>(p, tid, log_c, c0));
     }
@@ -492,7 +513,8 @@ __global__ __launch_bounds__((1 << LT) / P, (P == 16 ? 2 : 4)) void k_fft_cols(c
             const int e = tid_tail + k * T;
             const int64_t k1 = e >> log_c;
             const int64_t j2 = c0 + (e & ((1 << log_c) - 1));
-            work[(k1 << p.log_n2) + j2] = v[k];
+            if (p.stream_hint & 1) store_nt(work + (k1 << p.log_n2) + j2, v[k]);
+            else work[(k1 << p.log_n2) + j2] = v[k];
         }
     } else {
         // the transform ran on swapped data: Re z' = v.y, Im z' = v.x; crop + scale (fft.py:341-350)
@@ -506,7 +528,9 @@ __global__ __launch_bounds__((1 << LT) / P, (P == 16 ? 2 : 4)) void k_fft_cols(c
             if (p.aligned) {
                 // s and n_samp even, row 16-byte aligned: both samples of the pair are inside or outside together
                 if (s >= 0 && s < p.n_samp) {
-                    *reinterpret_cast<double2 *>(row + s) = make_double2(v[k].y * p.scale, v[k].x * p.scale);
+                    const double2 o = make_double2(v[k].y * p.scale, v[k].x * p.scale);
+                    if (p.stream_hint & 8) store_nt(reinterpret_cast<double2 *>(row + s), o);
+                    else *reinterpret_cast<double2 *>(row + s) = o;
                 }
             } else {
                 if (s >= 0 && s < p.n_samp) row[s] = v[k].y * p.scale;
@@ -687,7 +711,7 @@ __global__ __launch_bounds__((1 << LT) / P, (P == 16 ? 2 : 4)) void k_fft_rows(c
     for (int k = 0; k < P; ++k) {
         const int e = tid + k * T;
         const int64_t rr = (e & 1) ? r1 : r0;
-        v[k] = work[(rr << p.log_n2) + (e >> 1)];
+        v[k] = (p.stream_hint & 16) ? load_nt(work + (rr << p.log_n2) + (e >> 1)) : work[(rr << p.log_n2) + (e >> 1)];
     }
     const auto kt = KTabSel<TLDS>::make(p, p.per_det ? (int64_t)(p.det0 + b) : 0, reinterpret_cast<char *>(sm + kRowTile),
                                         tid, T);
@@ -782,7 +806,8 @@ __global__ __launch_bounds__((1 << LT) / P, (P == 16 ? 2 : 4)) void k_fft_rows(c
     for (int k = 0; k < P; ++k) {
         const int e = tid_tail + k * T;
         const int64_t rr = (e & 1) ? r1 : r0;
-        work[(rr << log_n2_tail) + (e >> 1)] = v[k];
+        if (p.stream_hint & 32) store_nt(work + (rr << log_n2_tail) + (e >> 1), v[k]);
+        else work[(rr << log_n2_tail) + (e >> 1)] = v[k];
     }
     PHASE_WAIT_LOADS;
     PHASE_MARK(4);
@@ -882,6 +907,8 @@ __global__ void k_knot_hint(const double * __restrict__ knots, int n_knot, doubl
 struct Plan {
     double2 * tables = nullptr;   // wtile | t0 | t1 | t2
     int64_t n2_entries = 0;
+    // pass 1 tile orders per (n_samp, n_buffer, n_reflect, tiles, columns per tile): device table or nullptr (none found)
+    std::map<std::array<int64_t, 5>, int32_t *> orders;
 };
 
 std::mutex g_mutex;
@@ -931,6 +958,89 @@ static Plan & get_plan(int64_t n_fft, hipStream_t st) {
         attr_set = true;
     }
     return g_plans.emplace(key, pl).first->second;
+}
+
+
+// Pass 1 reads every timestream line up to three times: directly, and as the left and the right mirror image of the
+// padded series (set_rfft_input, src/toast/fft.py:163-188) -- by three DIFFERENT column tiles.  Which tiles share lines
+// is fixed by n_buffer and n_samp modulo the row length: the tiles fall into classes (cfg-3: 8 classes of 32 of the 256
+// tiles).  If the classes can be dealt to the 8 XCDs evenly, every class runs on one XCD (workgroup -> XCD is round robin
+// over the linear workgroup index) and the second and third read of a line can hit that XCD's L2 -- provided the tile's
+// own output does not sweep it out first (non-temporal stores, Params::stream_hint bit 0).
+static std::vector<int32_t> mirror_tile_order(int64_t n_samp, int64_t n_buffer, int64_t n_reflect, int64_t n_tiles,
+                                              int64_t cols_per_tile) {
+    std::vector<int32_t> none;
+    if (n_reflect <= 0 || n_tiles < 8 || (n_tiles % 8) != 0) return none;
+    const int64_t piece = 2 * cols_per_tile;             // reals of one row in a tile
+    const int64_t row = piece * n_tiles;                 // reals per row of the padded series
+    if (row % 16 != 0) return none;
+    const int64_t n_line = row / 16;                     // 128-byte line columns
+    auto fdiv = [](int64_t a, int64_t b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); };
+    auto col = [&](int64_t src) { return ((fdiv(src, 16) % n_line) + n_line) % n_line; };
+    // union-find over tiles (0 .. n_tiles) and line columns (n_tiles .. n_tiles + n_line)
+    std::vector<int32_t> parent((size_t)(n_tiles + n_line));
+    for (size_t i = 0; i < parent.size(); ++i) parent[i] = (int32_t)i;
+    std::function<int32_t(int32_t)> find = [&](int32_t x) {
+        while (parent[x] != x) {
+            parent[x] = parent[parent[x]];
+            x = parent[x];
+        }
+        return x;
+    };
+    auto unite = [&](int64_t a, int64_t b) { parent[find((int32_t)a)] = find((int32_t)b); };
+    std::vector<std::vector<int32_t>> lines_of((size_t)n_tiles);
+    for (int64_t c = 0; c < n_tiles; ++c) {
+        for (int64_t x : {c * piece, c * piece + piece - 1}) {          // first and last real of the piece
+            const int64_t s = x - n_buffer;                               // (row offsets are multiples of `row`: same column)
+            for (int64_t src : {s, -1 - s, 2 * n_samp - 1 - s}) {
+                const int64_t l = col(src);
+                unite(c, n_tiles + l);
+                lines_of[(size_t)c].push_back((int32_t)l);
+            }
+        }
+    }
+    std::map<int32_t, std::vector<int32_t>> classes;
+    for (int64_t c = 0; c < n_tiles; ++c) classes[find((int32_t)c)].push_back((int32_t)c);
+    if (classes.size() < 8) return none;
+    // largest class first into the emptiest of the 8 bins; every bin must end with n_tiles / 8 tiles
+    std::vector<std::vector<int32_t>> cls;
+    for (auto & kv : classes) cls.push_back(kv.second);
+    std::stable_sort(cls.begin(), cls.end(), [](const std::vector<int32_t> & a, const std::vector<int32_t> & b) { return a.size() > b.size(); });
+    std::vector<std::vector<int32_t>> bins(8);
+    for (auto & c : cls) {
+        size_t best = 0;
+        for (size_t b = 1; b < 8; ++b) {
+            if (bins[b].size() < bins[best].size()) best = b;
+        }
+        // inside a class: tiles that share a line next to each other (sorted by their smallest line column)
+        std::stable_sort(c.begin(), c.end(), [&](int32_t a, int32_t b) {
+            return *std::min_element(lines_of[(size_t)a].begin(), lines_of[(size_t)a].end()) <
+                   *std::min_element(lines_of[(size_t)b].begin(), lines_of[(size_t)b].end());
+        });
+        bins[best].insert(bins[best].end(), c.begin(), c.end());
+    }
+    for (auto & b : bins) {
+        if ((int64_t)b.size() != n_tiles / 8) return none;
+    }
+    std::vector<int32_t> order((size_t)n_tiles);
+    for (int64_t b = 0; b < n_tiles; ++b) order[(size_t)b] = bins[(size_t)(b & 7)][(size_t)(b >> 3)];
+    return order;
+}
+
+static const int32_t * tile_order_for(Plan & pl, int64_t n_samp, int64_t n_buffer, int64_t n_reflect, int64_t n_tiles,
+                                      int64_t cols_per_tile, hipStream_t st) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    const std::array<int64_t, 5> key = {n_samp, n_buffer, n_reflect, n_tiles, cols_per_tile};
+    auto it = pl.orders.find(key);
+    if (it != pl.orders.end()) return it->second;
+    const std::vector<int32_t> order = mirror_tile_order(n_samp, n_buffer, n_reflect, n_tiles, cols_per_tile);
+    int32_t * d = nullptr;
+    if (!order.empty()) {
+        TH_HIP(hipMalloc(reinterpret_cast<void **>(&d), order.size() * sizeof(int32_t)));
+        copy_to_device(d, order.data(), order.size() * sizeof(int32_t), st);
+    }
+    pl.orders[key] = d;
+    return d;
 }
 
 namespace {
@@ -1038,9 +1148,19 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
         static int xo = -1;
         if (xo < 0) {
             const char * e = std::getenv("TOAST_HIP_FFT_XCD");
-            xo = (e != nullptr && e[0] == '0') ? 0 : 1;
+            // 0: tiles in launch order; 1: a contiguous eighth of the columns per XCD; 2 (default): pass 1 with the mirror
+            // partners of a tile on one XCD where the geometry allows it (else as 1), passes 3 as 1
+            xo = (e != nullptr && e[0] == '0') ? 0 : (e != nullptr && e[0] == '1') ? 1 : 2;
         }
         p.xcd_order = xo;
+        static int sh = -1;
+        if (sh < 0) {
+            const char * e = std::getenv("TOAST_HIP_FFT_STREAM_HINT");
+            // default 1: pass 1 writes the work array with non-temporal stores (profiles/r04_c section 5: the window table
+            // and the mirrored re-reads of the timestream then stay in L2; every other bit measured neutral or worse)
+            sh = (e != nullptr && e[0] != '\0') ? std::atoi(e) : 1;
+        }
+        p.stream_hint = sh;
     }
     // unnormalised inverse of length M on un-halved packing factors: 1 / (4 M), a power of two
     p.scale = 1.0 / (4.0 * (double)m);
@@ -1078,6 +1198,11 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
     const size_t lds_rows = lds + (tab_lds ? tab_bytes : 0);
     const size_t lds_split = lds / 2 + (tab_lds ? tab_bytes : 0);
     const unsigned n_col_tiles = (unsigned)(int64_t(1) << (p.log_n2 - (kLT - p.log_n1)));   // N2 / C
+    p.tile_order = nullptr;
+    if (p.xcd_order == 2 && p.aligned) {
+        p.tile_order = tile_order_for(pl, n_samp, n_buffer, n_reflect, (int64_t)n_col_tiles,
+                                      int64_t(1) << (kLT - p.log_n1), st);
+    }
     const unsigned n_row_tiles = (unsigned)((int64_t(1) << p.log_n1) / 2);                 // N1 / 2
     for (int64_t det0 = 0; det0 < n_det; det0 += batch) {
         const int64_t nb = (n_det - det0 < batch) ? (n_det - det0) : batch;

@@ -44,5 +44,6 @@ for _ in range(3):
 work.copy_(tod)
 call()
 torch.cuda.synchronize()
-print("prefetch=%s  ms per call: %s   checksum %.17g" % (os.environ.get("TOAST_HIP_FFT_PREFETCH", "0"),
+print("prefetch=%s stream_hint=%s  ms per call: %s   checksum %.17g" % (os.environ.get("TOAST_HIP_FFT_PREFETCH", "0"),
+                                                        os.environ.get("TOAST_HIP_FFT_STREAM_HINT", "0"),
                                                         " ".join("%.3f" % t for t in ts), float(work.double().sum())))
