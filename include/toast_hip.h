@@ -797,15 +797,23 @@ int toast_hip_fft_extend_flags(uint8_t * flags, int64_t n_flag_rows, const int32
  * workgroups with radix-8 stages and twice the waves per SIMD.  Defaults 8 / 8 / 8; start-up value
  * from TOAST_HIP_FFT_POINTS="rows,cols_fwd,cols_inv". */
 void toast_hip_fft_points(int rows, int cols_fwd, int cols_inv);
-/* Row pass of the fused kernels: split != 0 (default) = one row of N2 = 2048 bins per 32 KB LDS tile, the two rows
- * of a pair (k1, N1 - k1) one after the other with the first row's spectrum kept in registers (four workgroups per
- * CU); 0 = both rows interleaved in one 64 KB tile (two workgroups per CU).  Start-up value from
+/* Row pass of the fused kernels: split != 0 = one row of N2 = 2048 bins per 32 KB LDS tile, the two rows of a pair
+ * (k1, N1 - k1) one after the other with the first row's spectrum kept in registers (experiment: register bound, slower);
+ * 0 (default) = both rows interleaved in one 64 KB tile (two workgroups per CU).  Start-up value from
  * TOAST_HIP_FFT_ROWS=split|pair.  Same results to rounding. */
 void toast_hip_fft_rows_split(int split);
 /* Row length of the four-step factorisation M = N1 x N2 of the fused kernels: 2048 (64 KB row-pair tiles, two
  * workgroups per CU in the row pass, 128-byte pieces in the column passes) or 1024 (32 KB tiles, four workgroups per
  * CU, 64-byte pieces; only for M <= 2^20).  Start-up value from TOAST_HIP_FFT_N2.  Same results to rounding. */
 void toast_hip_fft_rows_n2(int n2);
+/* Host only, no device needed: the order in which the forward column pass of the fused kernels takes its n_tiles column
+ * tiles (cols_per_tile complex columns each) so that the tiles reading the same 128-byte lines of the timestream -- directly
+ * and as the two mirror images of the padded series, set_rfft_input, src/toast/fft.py:163-188 -- run on one XCD (workgroup
+ * b runs on XCD b mod 8 and takes tile order[b]).  Returns n_tiles and fills order[0 .. n_tiles), or 0 when the geometry
+ * (n_samp, n_buffer, n_reflect) does not split into classes that fill the 8 XCDs evenly: the pass then keeps contiguous
+ * column ranges per XCD.  TOAST_HIP_FFT_XCD=0|1 switches it off. */
+int toast_hip_fft_mirror_tile_order(int64_t n_samp, int64_t n_buffer, int64_t n_reflect, int64_t n_tiles,
+                                    int64_t cols_per_tile, int32_t * order);
 /* HBM bytes per timestream sample that the passes of that implementation move (accounting for
  * bench.py / DESIGN.md, not a measurement). */
 double toast_hip_fft_pipeline_bytes(int64_t n_samp);

@@ -210,3 +210,54 @@ def test_arena_suballocation_on_host_memory():
     capi.arena_selftest(12, 400, 2 << 20, 16 << 20, 12 << 20)        # the large arena's granule
     with pytest.raises(RuntimeError):
         capi.arena_selftest(1, 10, 0, 1 << 20, 100)
+
+
+def test_fft_mirror_tile_order_is_a_permutation_that_keeps_partners_on_one_xcd():
+    """toast_hip_fft_mirror_tile_order (host only): the forward column pass' tile order.  Restated here from the definition
+    of the padded series (reference src/toast/fft.py:163-188: sample i of the padded series is the timestream at i - n_buffer,
+    or its mirror image about the first / last sample): two tiles that touch a common 128-byte line of the timestream must
+    get workgroup indices that are equal modulo 8 (one XCD)."""
+    from toast_amd import capi
+
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    fn = lib.toast_hip_fft_mirror_tile_order
+    fn.restype = ctypes.c_int
+    fn.argtypes = [ctypes.c_int64] * 5 + [ctypes.c_void_p]
+
+    def lines_of(c, cols, n_tiles, n_samp, n_buffer, n_reflect):
+        row = 2 * cols * n_tiles
+        out = set()
+        for x in range(2 * cols * c, 2 * cols * (c + 1)):
+            s = x - n_buffer
+            for src in (s, -1 - s, 2 * n_samp - 1 - s):
+                out.add((src // 16) % (row // 16))
+        return out
+
+    found = 0
+    for n_samp in (720000, 2880000, 90000, 123456, 99991, 65536):
+        order_bits = int(np.ceil(np.log2(n_samp)))
+        n_fft = 1 << (order_bits + 1)
+        n_buffer = (n_fft - n_samp) // 2
+        n_reflect = min(n_buffer, n_samp)
+        log_m = order_bits                       # M = n_fft / 2 complex points = N1 x 2048
+        n_tiles, cols = 256, 8
+        if log_m - 11 < 9:                       # short series: N1 < 512, more columns per 4096-element tile
+            cols = 4096 >> (log_m - 11)
+            n_tiles = 2048 // cols
+        order = np.full(n_tiles, -1, dtype=np.int32)
+        n = fn(n_samp, n_buffer, n_reflect, n_tiles, cols, order.ctypes.data)
+        assert n in (0, n_tiles)
+        if n == 0:
+            continue
+        found += 1
+        assert sorted(order.tolist()) == list(range(n_tiles))
+        xcd_of_tile = np.empty(n_tiles, dtype=np.int64)
+        xcd_of_tile[order] = np.arange(n_tiles) % 8
+        owner = {}
+        for c in range(n_tiles):
+            for ln in lines_of(c, cols, n_tiles, n_samp, n_buffer, n_reflect):
+                assert owner.setdefault(ln, xcd_of_tile[c]) == xcd_of_tile[c], (n_samp, c, ln)
+        assert np.all(np.bincount(xcd_of_tile, minlength=8) == n_tiles // 8)
+    assert found >= 2          # cfg-3 (720 000) and the configs[3] shard (2 880 000) have such an order
+    # no mirror images, too few tiles: no order
+    assert fn(720000, 688576, 0, 256, 8, None) == 0 and fn(720000, 688576, 688576, 4, 8, None) == 0

@@ -35,6 +35,8 @@ bool supported(int64_t n_fft);
 void set_points(int rows, int cols_fwd, int cols_inv);
 void set_rows_split(int split);
 void set_rows_n2(int n2);
+int mirror_tile_order_host(int64_t n_samp, int64_t n_buffer, int64_t n_reflect, int64_t n_tiles, int64_t cols_per_tile,
+                           int32_t * order);
 double pipeline_bytes_per_sample(int64_t n_samp, int64_t n_fft);
 void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_samp, int64_t n_fft,
               int64_t n_buffer, int64_t n_reflect, double fstep, const double * d_knots, int64_t n_knot,
@@ -545,6 +547,11 @@ void toast_hip_fft_select(int rocfft_only) { g_force_rocfft = rocfft_only ? 1 : 
 
 void toast_hip_fft_rows_split(int split) { toast_hip::fused_fft::set_rows_split(split); }
 void toast_hip_fft_rows_n2(int n2) { toast_hip::fused_fft::set_rows_n2(n2); }
+
+int toast_hip_fft_mirror_tile_order(int64_t n_samp, int64_t n_buffer, int64_t n_reflect, int64_t n_tiles,
+                                    int64_t cols_per_tile, int32_t * order) {
+    return toast_hip::fused_fft::mirror_tile_order_host(n_samp, n_buffer, n_reflect, n_tiles, cols_per_tile, order);
+}
 
 void toast_hip_fft_points(int rows, int cols_fwd, int cols_inv) {
     toast_hip::fused_fft::set_points(rows, cols_fwd, cols_inv);

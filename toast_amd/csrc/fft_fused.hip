@@ -1027,6 +1027,15 @@ static std::vector<int32_t> mirror_tile_order(int64_t n_samp, int64_t n_buffer, 
     return order;
 }
 
+int mirror_tile_order_host(int64_t n_samp, int64_t n_buffer, int64_t n_reflect, int64_t n_tiles, int64_t cols_per_tile,
+                           int32_t * order) {
+    const std::vector<int32_t> o = mirror_tile_order(n_samp, n_buffer, n_reflect, n_tiles, cols_per_tile);
+    if (order != nullptr) {
+        for (size_t i = 0; i < o.size(); ++i) order[i] = o[i];
+    }
+    return (int)o.size();
+}
+
 static const int32_t * tile_order_for(Plan & pl, int64_t n_samp, int64_t n_buffer, int64_t n_reflect, int64_t n_tiles,
                                       int64_t cols_per_tile, hipStream_t st) {
     std::lock_guard<std::mutex> lock(g_mutex);
