@@ -181,13 +181,15 @@ int toast_hip_accel_update_device(const void * host, size_t nbytes, const char *
 /* Device -> host copy of the whole buffer; returns after the data is on the host.
  * [ref: accelerator.cpp:524-591 update_host] */
 /* Upload in parts on a stream of its own (beyond the reference: its accel_update_device is one blocking copy).
- * _parts page-locks the source and returns once the copies are ENQUEUED, part k = bytes [part_end[k-1], part_end[k]);
- * _wait makes `stream` wait for part k without blocking the host; _finish blocks until all parts have arrived (call it
- * before the source may change).  Kernels can then work on the first rows of a timestream buffer while the later
+ * _parts page-locks the source (a buffer not locked yet: range by range, each right before its part is enqueued, so that
+ * locking part k + 1 runs while part k crosses PCIe) and returns once the copies are ENQUEUED, part k = bytes
+ * [part_end[k-1], part_end[k]); _wait makes `stream` wait for part k without blocking the host; _arrived says whether part
+ * k is there (no waiting); _finish blocks until all parts have arrived (call it before the source may change).  Kernels can then work on the first rows of a timestream buffer while the later
  * rows are still crossing PCIe (ops.NoiseFilter).  A pageable source falls back to the blocking copy. */
 int toast_hip_accel_update_device_parts(const void * host, size_t nbytes, const char * name, const size_t * part_end,
                                         int n_parts);
 int toast_hip_accel_update_device_wait(const void * host, int part, void * stream);
+int toast_hip_accel_update_device_arrived(const void * host, int part, int * arrived);
 int toast_hip_accel_update_device_finish(const void * host);
 int toast_hip_accel_update_host(void * host, size_t nbytes, const char * name);
 

@@ -173,6 +173,43 @@ def test_transfer_sizes_through_the_bounce_ring():
         accel.accel_data_delete(buf, "t")
 
 
+def test_upload_in_parts_page_locks_range_by_range():
+    """toast_hip_accel_update_device_parts on a buffer that is not page-locked yet locks it one range per part (each right
+    before its part is enqueued, ending on a 4 KB boundary past the part): parts that end anywhere, a buffer that starts
+    anywhere in a page, then a blocking upload, a download and the release over the same ranges -- always the same bytes."""
+    from toast_amd import capi
+
+    rng = np.random.default_rng(11)
+    n = (48 << 20) + 12345
+    for shift, ends in ((0, [5000001, 17 << 20, (17 << 20) + 1, 40000003, n]), (777, [n // 3, 2 * (n // 3) + 5, n]),
+                        (8, [4096, 8192, n]), (1, [n])):
+        raw = np.zeros(n + 4096, dtype=np.uint8)
+        buf = raw[shift:shift + n]
+        want = rng.integers(0, 256, size=n, dtype=np.uint8)
+        buf[:] = want
+        accel.accel_data_create(buf, "parts")
+        capi.accel_update_device_parts(buf, np.array(ends), "parts")
+        for k in range(len(ends)):
+            capi.accel_update_device_wait(buf, k)
+        capi.accel_update_device_finish(buf)
+        buf[:] = 0
+        accel.accel_data_update_host(buf, "parts")          # one download across all ranges
+        assert np.array_equal(buf, want), (shift, ends)
+        want2 = (want ^ 0xA5).astype(np.uint8)
+        buf[:] = want2
+        accel.accel_data_update_device(buf, "parts")        # one blocking upload across all ranges
+        buf[:] = 3
+        accel.accel_data_update_host(buf, "parts")
+        assert np.array_equal(buf, want2), (shift, ends)
+        capi.accel_update_device_parts(buf, np.array(ends), "parts")     # already locked: straight to the copies
+        capi.accel_update_device_finish(buf)
+        accel.accel_data_delete(buf, "parts")               # unlocks every range
+        # the memory can be locked again afterwards (nothing was left registered)
+        accel.accel_data_create(buf, "parts")
+        accel.accel_data_update_device(buf, "parts")
+        accel.accel_data_delete(buf, "parts")
+
+
 def test_host_staged_call_with_a_large_argument():
     """A host-level entry point whose array argument is past the pinning threshold (page-locked for the call, released
     before it returns): cov_apply_diag on 2^21 pixels x 6 covariance values (100 MB) against NumPy."""

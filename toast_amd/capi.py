@@ -353,6 +353,13 @@ def accel_update_device_wait(buf, part, stream=0):
     _check(real_lib().toast_hip_accel_update_device_wait(_p(_raw(buf)), C.c_int(int(part)), _p(stream)))
 
 
+def accel_update_device_arrived(buf, part):
+    """True once part ``part`` of the upload is on the device (does not wait)."""
+    out = C.c_int(0)
+    _check(real_lib().toast_hip_accel_update_device_arrived(_p(_raw(buf)), C.c_int(int(part)), C.byref(out)))
+    return bool(out.value)
+
+
 def accel_update_device_finish(buf):
     """Block until every part of the upload has arrived."""
     _check(real_lib().toast_hip_accel_update_device_finish(_p(_raw(buf))))

@@ -16,6 +16,8 @@
 //   k_fft_crop     tod[s] = tdata[b, n_buffer + s] / n_fft
 // All stages are HBM streaming passes; the transforms themselves are rocFFT's.
 #include <hip/hip_runtime.h>
+
+#include <chrono>
 #include <rocfft/rocfft.h>
 
 #include <cstdlib>
@@ -586,13 +588,23 @@ int toast_hip_fft_convolve_dev(double * d_tod, const int32_t * data_index, int64
         // numpy.fft.rfftfreq(n, d): k * (1 / (n d)) with d = 1 / rate
         const double fstep = 1.0 / ((double)n_fft * (1.0 / rate));
 
+        static const bool host_timing = std::getenv("TOAST_HIP_FFT_HOST_TIMING") != nullptr;
+        const auto ht0 = std::chrono::steady_clock::now();
+        auto ht = [&](const char * what) {
+            if (host_timing) {
+                std::fprintf(stderr, "[toast_hip] fft_convolve_dev %-22s +%8.3f ms\n", what,
+                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ht0).count());
+            }
+        };
         ParamBlock pb;
         const size_t o_idx = pb.push(data_index, sizeof(int32_t) * n_det);
         const size_t o_kn = pb.push(knots, sizeof(double) * n_knot);
         const size_t o_mc = pb.push(mag_coef, sizeof(double) * n_kernel * 4 * (n_knot - 1));
         const size_t o_ac = ang_coef ? pb.push(ang_coef, sizeof(double) * n_kernel * 4 * (n_knot - 1)) : 0;
         const size_t o_ap = pb.push(apodize, sizeof(double) * n_reflect);
+        ht("pushed");
         const char * d = pb.commit(st);
+        ht("committed");
         const int32_t * d_idx = (const int32_t *)(d + o_idx);
         const double * d_ac = ang_coef ? (const double *)(d + o_ac) : nullptr;
 
@@ -601,6 +613,7 @@ int toast_hip_fft_convolve_dev(double * d_tod, const int32_t * data_index, int64
                                 (const double *)(d + o_kn), n_knot, (const double *)(d + o_mc), d_ac,
                                 (n_kernel == n_det && n_det > 1) ? 1 : 0, deconvolve,
                                 (const double *)(d + o_ap), max_batch, st);
+            ht("launched");
             return;
         }
         int64_t batch = (max_batch > 0) ? max_batch : 64;
@@ -670,7 +683,7 @@ int toast_hip_fft_impulse_extents(int64_t n_det, int64_t n_samp, double rate, co
         if (batch > n_resp) batch = n_resp;
         const size_t row_bytes = (((size_t)n_samp * sizeof(double)) + 255) & ~size_t(255);
         char * scratch = (char *)Manager::get().scratch(Manager::kScratchFftImpulse,
-                                                        (size_t)batch * row_bytes + 256 + sizeof(int32_t) * batch);
+                                                        (size_t)batch * row_bytes + 256 + sizeof(int32_t) * batch, st);
         // rows must be contiguous [nb, n_samp] for the convolution: no padding between them
         double * d_rows = (double *)scratch;
         int32_t * d_ext = (int32_t *)(scratch + (((size_t)batch * n_samp * sizeof(double) + 255) & ~size_t(255)));
@@ -717,7 +730,7 @@ int toast_hip_fft_extend_flags(uint8_t * flags, int64_t n_flag_rows, const int32
         int64_t batch = 65535;     // rows per launch (grid y)
         if (batch > n_det) batch = n_det;
         int32_t * d_sum = (int32_t *)Manager::get().scratch(Manager::kScratchFftImpulse,
-                                                           (size_t)batch * n_chunk * 3 * sizeof(int32_t));
+                                                           (size_t)batch * n_chunk * 3 * sizeof(int32_t), st);
         for (int64_t r0 = 0; r0 < n_det; r0 += batch) {
             const int64_t nb = (n_det - r0 < batch) ? (n_det - r0) : batch;
             const dim3 grid((unsigned)n_chunk, (unsigned)nb);

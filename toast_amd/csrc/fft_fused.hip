@@ -1183,7 +1183,7 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
     const size_t hint_bytes = ((size_t)n_hint * (sizeof(int32_t) + sizeof(uint16_t)) + (size_t)n_hint0 * sizeof(int32_t) +
                                255 + 8) & ~size_t(255);
     char * scratch = (char *)Manager::get().scratch(Manager::kScratchFftWork,
-                                                    hint_bytes + (size_t)batch * m * sizeof(double2));
+                                                    hint_bytes + (size_t)batch * m * sizeof(double2), st);
     int32_t * d_hint = (int32_t *)scratch;
     int32_t * d_hint0 = d_hint + n_hint;
     uint16_t * d_hint16 = (uint16_t *)(d_hint0 + n_hint0);

@@ -238,6 +238,32 @@ struct BounceRing {
 
 BounceRing g_bounce;
 
+// Host -> device for the ring's slots by a KERNEL that reads the page-locked slot over PCIe, instead of a DMA command: the
+// DMA engine serves its queue in order, so a few KB of kernel parameters enqueued behind an upload of gigabytes (the
+// timestream parts of ops.NoiseFilter on the upload stream) would reach the device -- and release the kernels that wait
+// for them -- only after the whole upload (profiles/r04_f).  A kernel's loads share the link with the DMA packet by packet.
+__global__ void __launch_bounds__(256) k_slot_to_device(char * __restrict__ dst, const char * __restrict__ src, size_t n) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0) {
+        const size_t n16 = n >> 4;
+        const uint4 * s = reinterpret_cast<const uint4 *>(src);
+        uint4 * d = reinterpret_cast<uint4 *>(dst);
+        for (size_t i = i0; i < n16; i += stride) d[i] = s[i];
+        for (size_t i = (n16 << 4) + i0; i < n; i += stride) dst[i] = src[i];
+    } else {
+        for (size_t i = i0; i < n; i += stride) dst[i] = src[i];
+    }
+}
+
+bool bounce_by_kernel() {
+    static const bool v = [] {
+        const char * e = std::getenv("TOAST_HIP_BOUNCE_KERNEL");
+        return !(e != nullptr && e[0] == '0');
+    }();
+    return v;
+}
+
 bool bounce_enabled() {
     static const bool v = [] {
         const char * e = std::getenv("TOAST_HIP_BOUNCE");
@@ -265,7 +291,13 @@ void copy_to_device(void * dev, const void * host, size_t bytes, hipStream_t str
         g_bounce.next = (k + 1) % BounceRing::kSlots;
         g_bounce.wait(k);
         std::memcpy(g_bounce.slot[k], src + off, n);
-        TH_HIP(hipMemcpyAsync(dst + off, g_bounce.slot[k], n, hipMemcpyHostToDevice, stream));
+        if (bounce_by_kernel()) {
+            const unsigned blocks = (unsigned)std::min<size_t>((n / 16 + 255) / 256 + 1, 1024);
+            hipLaunchKernelGGL(k_slot_to_device, dim3(blocks), dim3(256), 0, stream, dst + off, g_bounce.slot[k], n);
+            TH_HIP(hipGetLastError());
+        } else {
+            TH_HIP(hipMemcpyAsync(dst + off, g_bounce.slot[k], n, hipMemcpyHostToDevice, stream));
+        }
         TH_HIP(hipEventRecord(g_bounce.done[k], stream));
         g_bounce.busy[k] = true;
     }
@@ -328,15 +360,32 @@ size_t pin_threshold() {
 
 // Grow-only scratch buffers owned by the manager (so: per process = per device, released by
 // clear()): blocks of the arena.  A failed growth leaves the slot empty -- never a dangling pointer.
-void * Manager::scratch(int slot, size_t bytes) {
+void * Manager::scratch(int slot, size_t bytes) { return scratch_impl(slot, bytes, false, nullptr); }
+
+void * Manager::scratch(int slot, size_t bytes, hipStream_t user) { return scratch_impl(slot, bytes, true, user); }
+
+void * Manager::scratch_impl(int slot, size_t bytes, bool named, hipStream_t user) {
     // keyed by the CURRENT device: the device-pointer entry points (toast_hip_*_dev) serve callers
     // that own their device memory and never went through assign_device()
     int dev = 0;
     TH_HIP(hipGetDevice(&dev));
-    auto & s = scratch_[std::make_pair(dev, slot)];
-    if (bytes <= s.second && s.first != nullptr) return s.first;
+    const auto key = std::make_pair(dev, slot);
+    auto & s = scratch_[key];
+    auto known = scratch_user_.find(key);
+    const bool all_named = (known == scratch_user_.end()) ? true : known->second.first;
+    const hipStream_t last = (known == scratch_user_.end()) ? nullptr : known->second.second;
+    scratch_user_[key] = std::make_pair(all_named && named, user);
+    if (bytes <= s.second && s.first != nullptr) {
+        // a different stream takes the buffer over: its kernels must come after the previous user's
+        if (named && all_named && known != scratch_user_.end() && last != user) TH_HIP(hipStreamSynchronize(last));
+        return s.first;
+    }
     if (s.first != nullptr) {
-        TH_HIP(hipDeviceSynchronize());
+        if (all_named && known != scratch_user_.end()) {
+            TH_HIP(hipStreamSynchronize(last));
+        } else {
+            TH_HIP(hipDeviceSynchronize());
+        }
         void * old = s.first;
         s.first = nullptr;
         s.second = 0;
@@ -362,6 +411,7 @@ void Manager::clear() {
         if (kv.second.first) device_free(kv.second.first);
     }
     scratch_.clear();
+    scratch_user_.clear();
     if (upload_stream_ != nullptr) (void)hipStreamSynchronize(upload_stream_);
     for (auto & kv : table_) {
         for (hipEvent_t ev : kv.second.part_done) (void)hipEventDestroy(ev);
@@ -701,8 +751,36 @@ void Manager::pin_for_transfer(const void * host, Entry & e) {
 
 void Manager::unpin(const void * host, Entry & e) {
     if (!e.host_registered) return;
-    (void)hipHostUnregister(const_cast<void *>(host));
+    if (e.pin_ends.empty()) {
+        (void)hipHostUnregister(const_cast<void *>(host));
+    } else {
+        size_t off = 0;
+        for (size_t end : e.pin_ends) {
+            if (end > off) (void)hipHostUnregister(const_cast<char *>(static_cast<const char *>(host)) + off);
+            off = end;
+        }
+        e.pin_ends.clear();
+    }
     e.host_registered = false;
+}
+
+void Manager::copy_pinned(const Entry & e, void * dev, void * host, size_t off, size_t len, bool to_device, hipStream_t st) {
+    auto piece = [&](size_t a, size_t b) {
+        if (b <= a) return;
+        char * h = static_cast<char *>(host) + a;
+        char * d = static_cast<char *>(dev) + a;
+        if (to_device) TH_HIP(hipMemcpyAsync(d, h, b - a, hipMemcpyHostToDevice, st));
+        else TH_HIP(hipMemcpyAsync(h, d, b - a, hipMemcpyDeviceToHost, st));
+    };
+    const size_t stop = off + len;
+    size_t at = off;
+    for (size_t end : e.pin_ends) {
+        if (end <= at) continue;
+        if (at >= stop) break;
+        piece(at, end < stop ? end : stop);
+        at = end < stop ? end : stop;
+    }
+    piece(at, stop);
 }
 
 static bool trace_enabled() {
@@ -774,7 +852,7 @@ void Manager::update_device(const void * host, size_t nbytes, const char * name)
     pin_for_transfer(host, e);
     if (e.host_registered) {
         // page-locked source: direct DMA; the call returns once the source has been consumed
-        TH_HIP(hipMemcpyAsync(e.dev, host, nbytes, hipMemcpyHostToDevice, stream_));
+        copy_pinned(e, e.dev, const_cast<void *>(host), 0, nbytes, true, stream_);
         TH_HIP(hipStreamSynchronize(stream_));
     } else {
         copy_to_device(e.dev, host, nbytes, stream_);
@@ -791,8 +869,13 @@ void Manager::update_device_parts(const void * host, size_t nbytes, const char *
     }
     if (!e.part_done.empty()) fail_arg("update_device_parts: an upload of this buffer is still in flight");
     const double t0 = trace_begin();
-    pin_for_transfer(host, e);
-    if (!e.host_registered) {
+    // Page-locking costs ~3.5 ms per GB of host time.  A buffer that is not page-locked yet is locked RANGE BY RANGE, each
+    // right before its part is enqueued, so that locking part k + 1 runs while part k crosses PCIe.  Ranges end on 4 KB
+    // boundaries past their part's end (two registrations never share a page); copies are split where ranges meet.
+    const bool lock_in_parts = !e.host_registered && !e.pin_failed && n_parts > 1 && nbytes >= pin_threshold() &&
+                               std::getenv("TOAST_HIP_PIN_IN_PARTS_OFF") == nullptr;
+    if (!lock_in_parts) pin_for_transfer(host, e);
+    if (!lock_in_parts && !e.host_registered) {
         // pageable source (small buffer, or page-locking failed): the synchronous path through the bounce ring
         copy_to_device(e.dev, host, nbytes, stream_);
         trace("update_device", e.name, nbytes, t0);
@@ -805,20 +888,42 @@ void Manager::update_device_parts(const void * host, size_t nbytes, const char *
     TH_HIP(hipEventRecord(before, stream_));
     TH_HIP(hipStreamWaitEvent(upload_stream_, before, 0));
     (void)hipEventDestroy(before);
-    size_t off = 0;
+    char * hbytes = const_cast<char *>(static_cast<const char *>(host));
+    size_t off = 0, locked_to = 0;
     for (int k = 0; k < n_parts; ++k) {
         if (part_end[k] < off || part_end[k] > nbytes) fail_arg("update_device_parts: part ends must increase");
-        const size_t len = part_end[k] - off;
-        if (len > 0) {
-            TH_HIP(hipMemcpyAsync(static_cast<char *>(e.dev) + off, static_cast<const char *>(host) + off, len,
-                                  hipMemcpyHostToDevice, upload_stream_));
+        if (lock_in_parts && part_end[k] > locked_to) {
+            size_t end = part_end[k];
+            if (k < n_parts - 1) {
+                const uintptr_t a = (reinterpret_cast<uintptr_t>(hbytes) + end + 4095) & ~uintptr_t(4095);
+                end = (size_t)(a - reinterpret_cast<uintptr_t>(hbytes));
+            }
+            if (end > nbytes || k == n_parts - 1) end = nbytes;
+            if (hipHostRegister(hbytes + locked_to, end - locked_to, hipHostRegisterDefault) != hipSuccess) {
+                // give the ranges back and finish through the bounce ring
+                (void)hipGetLastError();
+                TH_HIP(hipStreamSynchronize(upload_stream_));
+                e.host_registered = !e.pin_ends.empty();
+                unpin(host, e);
+                e.pin_failed = true;
+                for (hipEvent_t ev : e.part_done) (void)hipEventDestroy(ev);
+                e.part_done.clear();
+                if (nbytes > off) copy_to_device(static_cast<char *>(e.dev) + off, hbytes + off, nbytes - off, stream_);
+                trace("update_device", e.name, nbytes, t0);
+                return;
+            }
+            e.pin_ends.push_back(end);
+            locked_to = end;
         }
+        const size_t len = part_end[k] - off;
+        if (len > 0) copy_pinned(e, e.dev, hbytes, off, len, true, upload_stream_);
         hipEvent_t ev;
         TH_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         TH_HIP(hipEventRecord(ev, upload_stream_));
         e.part_done.push_back(ev);
         off = part_end[k];
     }
+    if (lock_in_parts) e.host_registered = true;
     trace("upload_parts", e.name, nbytes, t0);   // (enqueue time: page-locking + launches; the copies run on)
 }
 
@@ -829,6 +934,18 @@ void Manager::update_device_wait(const void * host, int part, hipStream_t stream
     if (e.part_done.empty()) return;   // the upload took the synchronous path: everything is there
     if (part < 0 || part >= (int)e.part_done.size()) fail_arg("update_device_wait: no such part");
     TH_HIP(hipStreamWaitEvent(stream, e.part_done[(size_t)part], 0));
+}
+
+int Manager::update_device_arrived(const void * host, int part) {
+    auto it = table_.find(host);
+    if (it == table_.end()) fail_arg("update_device_arrived: host pointer is not registered");
+    Entry & e = it->second;
+    if (e.part_done.empty()) return 1;
+    if (part < 0 || part >= (int)e.part_done.size()) fail_arg("update_device_arrived: no such part");
+    const hipError_t rc = hipEventQuery(e.part_done[(size_t)part]);
+    if (rc == hipSuccess) return 1;
+    (void)hipGetLastError();
+    return 0;
 }
 
 void Manager::update_device_finish(const void * host) {
@@ -847,7 +964,7 @@ void Manager::update_host(void * host, size_t nbytes, const char * name) {
     const double t0 = trace_begin();
     pin_for_transfer(host, e);
     if (e.host_registered) {
-        TH_HIP(hipMemcpyAsync(host, e.dev, nbytes, hipMemcpyDeviceToHost, stream_));
+        copy_pinned(e, e.dev, host, 0, nbytes, false, stream_);
         TH_HIP(hipStreamSynchronize(stream_));
     } else {
         copy_to_host(host, e.dev, nbytes, stream_);
@@ -1243,6 +1360,13 @@ int toast_hip_accel_update_device_parts(const void * host, size_t nbytes, const 
 
 int toast_hip_accel_update_device_wait(const void * host, int part, void * stream) {
     return guarded([&] { Manager::get().update_device_wait(host, part, static_cast<hipStream_t>(stream)); });
+}
+
+int toast_hip_accel_update_device_arrived(const void * host, int part, int * arrived) {
+    return guarded([&] {
+        const int a = Manager::get().update_device_arrived(host, part);
+        if (arrived) *arrived = a;
+    });
 }
 
 int toast_hip_accel_update_device_finish(const void * host) {

@@ -192,6 +192,7 @@ public:
     // them.  Lets kernels work on the first rows while the later ones are still crossing PCIe.
     void update_device_parts(const void * host, size_t nbytes, const char * name, const size_t * part_end, int n_parts);
     void update_device_wait(const void * host, int part, hipStream_t stream);
+    int update_device_arrived(const void * host, int part);
     void update_device_finish(const void * host);
     void update_host(void * host, size_t nbytes, const char * name);
     void remove(const void * host, size_t nbytes, const char * name);
@@ -200,7 +201,11 @@ public:
     void dump();
     void clear();
     // Grow-only device scratch (slot = kScratch*): FFT work buffers, reduction results.
+    // `user`: the stream the caller's kernels on this buffer run on.  When every use of a slot has named its stream, growing
+    // the slot waits for that stream only -- not for the whole device, which would also wait for an upload of gigabytes
+    // that is crossing PCIe on the upload stream (ops.NoiseFilter; profiles/r04_f).
     void * scratch(int slot, size_t bytes);
+    void * scratch(int slot, size_t bytes, hipStream_t user);
     // Every device block of the library comes from here and goes back through device_free: a range of an arena slab
     // (arena.hpp), or -- TOAST_HIP_ALLOC=plain -- one hipMalloc / hipFree per block.  nullptr on failure.
     // `kind` says what the block is to the kernels, which decides WHERE in HBM it should live (vmm_slab.cpp: the 288 GB
@@ -235,6 +240,9 @@ public:
 
 private:
     std::map<std::pair<int, int>, std::pair<void *, size_t>> scratch_;   // (device, slot) -> (ptr, bytes)
+    // (device, slot) -> (every use so far named its stream, the last one named)
+    std::map<std::pair<int, int>, std::pair<bool, hipStream_t>> scratch_user_;
+    void * scratch_impl(int slot, size_t bytes, bool named, hipStream_t user);
     struct Entry {
         void * dev;
         size_t nbytes;
@@ -242,10 +250,13 @@ private:
         bool owned = true;
         bool host_registered = false;
         bool pin_failed = false;
+        std::vector<size_t> pin_ends;        // page-locked in several ranges (upload in parts): their end offsets; empty = one range
         std::vector<hipEvent_t> part_done;   // update_device_parts: one event per enqueued part
     };
     hipStream_t upload_stream_ = nullptr;   // non-blocking: does not synchronise with the default stream
     void pin_for_transfer(const void * host, Entry & e);
+    // hipMemcpyAsync of [off, off + len) of a page-locked entry, split where its page-locked ranges meet
+    static void copy_pinned(const Entry & e, void * dev, void * host, size_t off, size_t len, bool to_device, hipStream_t st);
     static void unpin(const void * host, Entry & e);
     static double trace_begin();
     static void trace(const char * what, const std::string & name, size_t nbytes, double t0);

@@ -144,8 +144,19 @@ class NoiseFilter(Operator):
             flags = None
             flag_mask = None
             shflg = None
+            flags_in_flight = False
             if self.det_flags is not None:
                 flags = obs.detdata[self.det_flags]
+                if upload_bounds is not None and not flags.accel_in_use() and flags.buffer.nbytes >= (16 << 20):
+                    # the detector flags follow the timestream on the upload stream: they cross PCIe while the
+                    # transforms run, instead of queueing behind them on the compute stream
+                    from .. import capi
+
+                    if not flags.accel_exists():
+                        flags.accel_create(self.det_flags)
+                    capi.accel_update_device_parts(flags.buffer, np.array([flags.buffer.nbytes]), self.det_flags)
+                    flags.accel_used(True)
+                    flags_in_flight = True
                 if self.shared_flags is not None:
                     # (the flag VALUE times the mask, as the reference writes it: noise_filter.py:121-124); OR-ed into
                     # the detector flags by the same device pass that extends them (nothing reads them in between)
@@ -196,12 +207,18 @@ class NoiseFilter(Operator):
                 # pass over the resident detector flags (uploaded once; the map-maker reads them there)
                 fdata = flags
                 if accel_enabled():
-                    if not fdata.accel_in_use():
+                    if flags_in_flight:
+                        from .. import capi
+
+                        capi.accel_update_device_wait(fdata.buffer, 0)       # the stream waits, the host does not
+                    elif not fdata.accel_in_use():
                         if not fdata.accel_exists():
                             fdata.accel_create(self.det_flags)
                         fdata.accel_update_device()
                     hipfft.extend_flags_buffer(fdata.buffer, fdata.indices(dets), flag_mask, extend, or_row=shflg,
                                                use_accel=True)
+                    if flags_in_flight:
+                        capi.accel_update_device_finish(fdata.buffer)
                     if not getattr(data, "lazy_host", False):
                         fdata.accel_update_host()
                         fdata.accel_delete()
