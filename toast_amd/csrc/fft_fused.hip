@@ -1170,6 +1170,11 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
             sh = (e != nullptr && e[0] != '\0') ? std::atoi(e) : 1;
         }
         p.stream_hint = sh;
+        // ... but not with two columns per tile (N1 = 2048, n_fft 2^23): a non-temporal store sends every 32-byte piece to
+        // memory on its own, 61 -> 90 ms per call; with four columns (64-byte pieces, 2^22) it still gains 1.5 %
+        // (profiles/r04_c section 6)
+        static const bool forced = std::getenv("TOAST_HIP_FFT_STREAM_HINT") != nullptr;
+        if (!forced && (kLT - p.log_n1) < 2) p.stream_hint &= ~1;
     }
     // unnormalised inverse of length M on un-halved packing factors: 1 / (4 M), a power of two
     p.scale = 1.0 / (4.0 * (double)m);
