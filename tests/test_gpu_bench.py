@@ -27,8 +27,9 @@ def test_bench_contract_small_workload():
     assert d["unit"] == "det-samples/s" and d["value"] > 0 and d["ms_per_step"] > 0
     assert d["config"]["workload"] == "mini"
     r = d["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_exact"):
         assert key in r, key
+    assert r["traffic"] is None and r["traffic_exact"] is None       # (no committed PMC profile of the mini workload)
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):

@@ -378,3 +378,19 @@ print("not reached")
             line = json.loads(got[0])
             assert line["value"] == 2.5 and line["n_gpus"] == 2
             assert ("extras" in line) == (how == "finish") and ("truncated" in line) == (how != "finish"), line
+
+
+def test_committed_traffic_profiles_agree():
+    """profiles/traffic_cfg3.json (2 x FETCH_SIZE + WRITE_SIZE, the guide's prescription) and profiles/traffic_exact_cfg3.json
+    (32-byte-unit DRAM request counters) are two measurements of the same launches: the dominant kernels must agree to 1 %,
+    and both must sit within a few per cent of the algorithmic bytes bench.py divides by."""
+    import json
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    a = json.load(open(os.path.join(root, "profiles", "traffic_cfg3.json")))["kernels"]
+    b = json.load(open(os.path.join(root, "profiles", "traffic_exact_cfg3.json")))["kernels"]
+    n = 1024 * 720000
+    for name, per_sample in (("k_scan_map_v2<double>", 48.0), ("k_build_noise_weighted_v2<2>", 41.0)):
+        ta, tb = a[name]["hbm_bytes"], b[name]["hbm_bytes"]
+        assert abs(ta - tb) < 0.01 * tb, (name, ta, tb)
+        assert 1.0 <= tb / (per_sample * n) < 1.08, (name, tb / (per_sample * n))
