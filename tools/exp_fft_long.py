@@ -31,7 +31,8 @@ kern[0] = 0.0
 kernels = np.tile(kern, (n_det, 1)) * np.linspace(0.9, 1.1, n_det)[:, None]
 idx = np.arange(n_det, dtype=np.int32)
 stream = torch.cuda.current_stream().cuda_stream
-call = lambda: hipfft.convolve_dev(work.data_ptr(), idx, n_samp, rate, kfreq, kernels, stream=stream)
+max_batch = int(os.environ.get("EXP_FFT_BATCH", "0"))     # detectors per work batch (0: the library's default)
+call = lambda: hipfft.convolve_dev(work.data_ptr(), idx, n_samp, rate, kfreq, kernels, max_batch=max_batch, stream=stream)
 call()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -46,6 +47,6 @@ for _ in range(3):
 work.copy_(tod)
 call()
 torch.cuda.synchronize()
-print("%d x %d  n_fft %d  env %s  ms per call: %s   checksum %.17g" % (
-    n_det, n_samp, hipfft.fft_length(n_samp), {k: v for k, v in os.environ.items() if k.startswith("TOAST_HIP_FFT")},
+print("batch %d  %d x %d  n_fft %d  env %s  ms per call: %s   checksum %.17g" % (
+    max_batch, n_det, n_samp, hipfft.fft_length(n_samp), {k: v for k, v in os.environ.items() if k.startswith("TOAST_HIP_FFT")},
     " ".join("%.3f" % t for t in ts), float(work.double().sum())))
