@@ -71,6 +71,7 @@ def parse():
     ap.add_argument("--torch-alloc", action="store_true",
                     help="EXPERIMENT: allocate the TOD-domain buffers with torch instead of the library's memory manager")
     ap.add_argument("--no-fft", action="store_true", help="skip the FFT noise-weighting measurement")
+    ap.add_argument("--no-fft-long", action="store_true", help="skip the FFT measurement at the configs[3] shard's length")
     ap.add_argument("--no-cfg4", action="store_true",
                     help="with --gpus 8 and the default workload: do not also time the configs[3] shard (cfg4)")
     ap.add_argument("--shard-workload", default=None, choices=sorted(WORKLOADS),
@@ -820,6 +821,28 @@ def run(args, workload, world, rank, dev, headline=True):
         if pb:
             out["fft_noise_weight"]["pipeline_GBs"] = pb * tot / (t_fft * 1e-3) / 1e9
             out["fft_noise_weight"]["pipeline_frac"] = pb * tot / (t_fft * 1e-3) / 1e9 / HBM_PEAK_GBS
+        # ... and at the timestream length of the configs[3] shard (512 detectors x 2 880 000 samples, n_fft 2^23: column
+        # transforms of 2048 points, where the passes' pieces are narrowest), on a buffer of its own
+        if workload == "cfg3" and headline and world == 1 and not args.no_fft_long:
+            ld, ls = 512, 2880000
+            try:
+                d_long = torch.empty((ld, ls), dtype=torch.float64, device=dev).normal_(0.0, 1.0)
+                lidx = np.arange(ld, dtype=np.int32)
+                lkern = np.tile(kern, (ld, 1)) * np.linspace(0.9, 1.1, ld)[:, None]
+                long_call = lambda: hipfft.convolve_dev(d_long.data_ptr(), lidx, ls, rate, kfreq, lkern, stream=stream)
+                long_call()
+                torch.cuda.synchronize()
+                t_long = timed(long_call, 3)
+                lpb = hipfft.pipeline_bytes_per_sample(ls)
+                out["fft_noise_weight"]["long"] = {
+                    "n_det": ld, "n_samp": ls, "n_fft": int(hipfft.fft_length(ls)), "ms": t_long,
+                    "samples_per_s": float(ld) * ls / (t_long * 1e-3),
+                    "pipeline_bytes_per_sample": lpb,
+                    "pipeline_frac": (lpb * float(ld) * ls / (t_long * 1e-3) / 1e9 / HBM_PEAK_GBS) if lpb else None,
+                }
+                del d_long
+            except RuntimeError as err:      # noqa: PERF203 -- an extra: the headline must not depend on it
+                out["fft_noise_weight"]["long"] = {"error": repr(err)[:200]}
 
     # ------------------------------------------------------------------ extra: full PCG LHS with offset templates
     # (not the headline metric) the complete SolverLHS of configs[2] "full MapMaker PCG":

@@ -799,11 +799,16 @@ int toast_hip_fft_extend_flags(uint8_t * flags, int64_t n_flag_rows, const int32
  * workgroups with radix-8 stages and twice the waves per SIMD.  Defaults 8 / 8 / 8; start-up value
  * from TOAST_HIP_FFT_POINTS="rows,cols_fwd,cols_inv". */
 void toast_hip_fft_points(int rows, int cols_fwd, int cols_inv);
-/* Row pass of the fused kernels: split != 0 = one row of N2 = 2048 bins per 32 KB LDS tile, the two rows of a pair
- * (k1, N1 - k1) one after the other with the first row's spectrum kept in registers (experiment: register bound, slower);
- * 0 (default) = both rows interleaved in one 64 KB tile (two workgroups per CU).  Start-up value from
- * TOAST_HIP_FFT_ROWS=split|pair.  Same results to rounding. */
+/* Row pass of the fused kernels: 2 (default) = one row of N2 = 2048 bins per WAVE, the tile in registers and the LDS
+ * only an exchange buffer (csrc/fft_reg.hip); 0 = both rows of a pair (k1, N1 - k1) interleaved in one 64 KB LDS tile;
+ * 1 = one row per 32 KB LDS tile (experiment: register bound, slower).  Start-up value from
+ * TOAST_HIP_FFT_ROWS=reg|lds|split.  Same results to rounding. */
 void toast_hip_fft_rows_split(int split);
+/* Column passes of the fused kernels: 1 (default) = the tile in registers (csrc/fft_reg.hip) for n_fft 2^22 and 2^23
+ * (N2 = 2048, even n_samp / padding: 128- and 64-byte pieces where the LDS tile gives 64 and 32), 2 = for n_fft 2^21 too,
+ * 0 = the tile in LDS (k_fft_cols) at every length.  Start-up value from TOAST_HIP_FFT_COLS=reg|reg9|lds.  Same results
+ * to rounding. */
+void toast_hip_fft_cols_reg(int on);
 /* Row length of the four-step factorisation M = N1 x N2 of the fused kernels: 2048 (64 KB row-pair tiles, two
  * workgroups per CU in the row pass, 128-byte pieces in the column passes) or 1024 (32 KB tiles, four workgroups per
  * CU, 64-byte pieces; only for M <= 2^20).  Start-up value from TOAST_HIP_FFT_N2.  Same results to rounding. */

@@ -284,13 +284,13 @@ def test_fused_complex_kernels_and_common_kernel(pf, deconvolve):
         assert np.max(np.abs(got - want)) < (1e-11 if deconvolve else TOL) * np.max(np.abs(want))
 
 
-@pytest.mark.parametrize("rows", ["pair", "split"])
+@pytest.mark.parametrize("rows", ["reg", "pair", "split"])
 @pytest.mark.parametrize("tables", ["lds-complex", "lds-dense", "global-dense", "global-complex"])
 def test_fused_kernel_table_paths(pf, rows, tables):
     """Row pass of the fused pipeline: kernel tables in LDS (few knots) or in global memory (many), interval search
     with several knots inside one block of N1 bins (dense knot vectors: the walk from the per-row-element hint), real
-    and complex kernels; both tile layouts of the row pass (row pair per 64 KB tile / one row per 32 KB tile with the
-    mirrored last butterfly)."""
+    and complex kernels; the three layouts of the row pass (one row per wave in registers / row pair per 64 KB LDS tile /
+    one row per 32 KB LDS tile with the mirrored last butterfly)."""
     from oracle import fft_oracle as fo
 
     rate, n_det = 200.0, 3
@@ -308,7 +308,7 @@ def test_fused_kernel_table_paths(pf, rows, tables):
         freq = np.linspace(0.0, rate / 2, 400)
         phase = True
     kernels = _noise_kernels(freq, n_det, complex_phase=phase)
-    pf.set_rows_split(rows == "split")
+    pf.set_rows_mode(rows)
     try:
         for n_samp in (9000, 100001, 720000):
             rng = np.random.default_rng(n_samp)
@@ -319,7 +319,40 @@ def test_fused_kernel_table_paths(pf, rows, tables):
             pf.convolve(got, rate, kernel_freq=freq, kernels=kernels)
             assert np.max(np.abs(got - want)) < TOL * np.max(np.abs(want)), (n_samp, tables, rows)
     finally:
-        pf.set_rows_split(False)
+        pf.set_rows_mode("reg")
+
+
+@pytest.mark.parametrize("n_samp", [720000, 1100000, 1440000, 2200000, 2880000])
+def test_register_tile_passes_against_lds_tile_passes(pf, n_samp):
+    """csrc/fft_reg.hip (round 5): the row pass with one row per wave and the column passes with the tile in registers
+    (n_fft 2^21 / 2^22 / 2^23: column tiles of 512 x 8, 1024 x 8, 2048 x 4) against the oracle and against the LDS-tile
+    kernels of fft_fused.hip, per-detector kernels, rows through an index."""
+    from oracle import fft_oracle as fo
+
+    rng = np.random.default_rng(n_samp + 5)
+    rate, n_det, rows = 200.0, 3, 4
+    freq = np.concatenate([[0.0], np.geomspace(1e-5, rate / 2, 70)])
+    kernels = _noise_kernels(freq, n_det)
+    buf = rng.standard_normal((rows, n_samp)).cumsum(axis=1) * 0.01 + rng.standard_normal((rows, n_samp))
+    idx = np.array([3, 0, 2], dtype=np.int32)
+    want = np.ascontiguousarray(buf[idx])
+    fo.convolve(want, rate, kernel_freq=freq, kernels=kernels)
+    scale = np.max(np.abs(want))
+    out = {}
+    try:
+        for cols, rowmode in (("reg9", "reg"), ("lds", "pair"), ("reg9", "pair"), ("lds", "reg")):
+            pf.set_cols_mode(cols)
+            pf.set_rows_mode(rowmode)
+            got = buf.copy()
+            pf.convolve_buffer(got, idx, rate, freq, kernels)
+            assert np.max(np.abs(got[idx] - want)) < TOL * scale, (cols, rowmode)
+            assert np.array_equal(got[1], buf[1])
+            out[(cols, rowmode)] = got
+    finally:
+        pf.set_cols_mode("reg")
+        pf.set_rows_mode("reg")
+    for key, got in out.items():
+        assert np.max(np.abs(got - out[("lds", "pair")])) < 1e-13 * scale, key
 
 
 @pytest.mark.parametrize("tables", ["lds-real", "lds-complex", "global-dense"])

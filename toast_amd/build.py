@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtoast_hip.so")
 
-HIP_SOURCES = ["runtime.cpp", "arena.cpp", "vmm_slab.cpp", "kernels.hip", "otf_kernels.hip", "offset_prior.hip", "ground_filter.hip", "capi_host.cpp", "comm.cpp", "fft_filter.hip", "fft_fused.hip", "deterministic.hip", "pcg.hip", "packed_pointing.hip"]
+HIP_SOURCES = ["runtime.cpp", "arena.cpp", "vmm_slab.cpp", "kernels.hip", "otf_kernels.hip", "offset_prior.hip", "ground_filter.hip", "capi_host.cpp", "comm.cpp", "fft_filter.hip", "fft_fused.hip", "fft_reg.hip", "deterministic.hip", "pcg.hip", "packed_pointing.hip"]
 HIPCC_FLAGS = [
     "--offload-arch=gfx950",
     "-O3",

@@ -36,6 +36,7 @@ namespace fused_fft {
 bool supported(int64_t n_fft);
 void set_points(int rows, int cols_fwd, int cols_inv);
 void set_rows_split(int split);
+void set_cols_reg(int on);
 void set_rows_n2(int n2);
 int mirror_tile_order_host(int64_t n_samp, int64_t n_buffer, int64_t n_reflect, int64_t n_tiles, int64_t cols_per_tile,
                            int32_t * order);
@@ -549,6 +550,7 @@ void toast_hip_fft_select(int rocfft_only) { g_force_rocfft = rocfft_only ? 1 : 
 
 void toast_hip_fft_rows_split(int split) { toast_hip::fused_fft::set_rows_split(split); }
 void toast_hip_fft_rows_n2(int n2) { toast_hip::fused_fft::set_rows_n2(n2); }
+void toast_hip_fft_cols_reg(int on) { toast_hip::fused_fft::set_cols_reg(on); }
 
 int toast_hip_fft_mirror_tile_order(int64_t n_samp, int64_t n_buffer, int64_t n_reflect, int64_t n_tiles,
                                     int64_t cols_per_tile, int32_t * order) {

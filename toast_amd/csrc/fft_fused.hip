@@ -45,412 +45,35 @@
 #include <vector>
 
 #include "runtime.hpp"
+#include "runtime.hpp"
+#include "fft_device.hpp"
 
 namespace toast_hip {
 namespace fused_fft {
 
-constexpr int kLT = 12;             // log2 of the tile (4096 complex doubles = 64 KB of LDS)
-constexpr int kTile = 1 << kLT;
-// LDS budget of the row pass for the kernel tables (two 64 KB tiles + tables per CU: 2 x (64 + 15) KB <= 160 KB)
-constexpr int kTabLdsMax = 15 * 1024;
-// ... and with 32 KB tiles (N2 = 1024): four workgroups per CU, 4 x (32 + 7.5) KB <= 160 KB
-constexpr int kTabLdsHalf = 7 * 1024 + 512;
-// Every kernel is a template on P = points per thread (kTile / P threads per workgroup):
-//   P = 16: 256 threads, radix-16 ends, one LDS round trip fewer per transform, ~250 VGPRs -> 2 waves / SIMD
-//   P = 8:  512 threads, radix-8 stages, ~100 VGPRs -> 4 waves / SIMD (two workgroups per CU either way: LDS)
-
-// ------------------------------------------------------------------------------------------
-// complex helpers (explicit fma: the library is built with -ffp-contract=off)
-// ------------------------------------------------------------------------------------------
-typedef double nt_double2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ double2 load_nt(const double2 * p) {
-    const nt_double2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_double2 *>(p));
-    return make_double2(v.x, v.y);
+// fft_reg.hip
+bool rows_reg_supported(const Params & p);
+void launch_rows_reg(const Params & p, unsigned n_det, bool tab_lds, size_t tab_bytes, hipStream_t st);
+void pack_tables(const Params & p, char * blob, int64_t n_kern, hipStream_t st);
+bool cols_reg_supported(const Params & p, int min_log_n1);
+int cols_reg_log_c(int log_n1);
+int cols_reg_twiddles(int log_n1, int * out);
+void launch_cols_reg(const Params & p, bool inv, unsigned n_det, hipStream_t st);
+// column passes: 1 (default) = tile in registers where fft_reg.hip has a kernel for the length (n_fft 2^21 .. 2^23,
+// aligned timestreams), 0 = tile in LDS (k_fft_cols).  TOAST_HIP_FFT_COLS=reg|lds
+namespace {
+int g_cols_mode = -1;      // 0: LDS tiles, 1: register tiles for N1 >= 1024 (default), 2: register tiles for N1 >= 512 too
 }
-__device__ __forceinline__ void store_nt(double2 * p, double2 v) {
-    nt_double2 w;
-    w.x = v.x;
-    w.y = v.y;
-    __builtin_nontemporal_store(w, reinterpret_cast<nt_double2 *>(p));
-}
-
-__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
-    return make_double2(__builtin_fma(a.x, b.x, -(a.y * b.y)), __builtin_fma(a.x, b.y, a.y * b.x));
-}
-__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ double2 cconj(double2 a) { return make_double2(a.x, -a.y); }
-// a * (-i)
-__device__ __forceinline__ double2 mul_mi(double2 a) { return make_double2(a.y, -a.x); }
-
-// LDS position of tile element i: XOR swizzle of the low four bits with the next four -- the
-// strided writes of a Stockham stage (stride 16 elements = 256 B) then spread over all banks.
-__device__ __forceinline__ int sw(int i) { return i ^ ((i >> 4) & 15); }
-
-// forward DFT of R points in registers, natural order in and out
-template <int R>
-struct DFT;
-template <>
-struct DFT<1> {
-    static __device__ __forceinline__ void run(double2 *) {}
-};
-template <>
-struct DFT<2> {
-    static __device__ __forceinline__ void run(double2 * a) {
-        const double2 t = a[0];
-        a[0] = cadd(t, a[1]);
-        a[1] = csub(t, a[1]);
+static int cols_mode() {
+    if (g_cols_mode < 0) {
+        const char * e = std::getenv("TOAST_HIP_FFT_COLS");
+        const std::string v = (e != nullptr) ? std::string(e) : std::string();
+        g_cols_mode = (v == "lds") ? 0 : (v == "reg9") ? 2 : 1;
     }
-};
-template <int R>
-struct DFT {
-    static __device__ __forceinline__ void run(double2 * a) {
-        constexpr int H = R / 2;
-        double2 e[H], o[H];
-#pragma unroll
-        for (int k = 0; k < H; ++k) {
-            e[k] = a[2 * k];
-            o[k] = a[2 * k + 1];
-        }
-        DFT<H>::run(e);
-        DFT<H>::run(o);
-        // w_R^k = (cos(2 pi k / R), -sin(2 pi k / R)), k < R / 2
-        constexpr double c16[8] = {1.0, 0.92387953251128673848, 0.70710678118654752440, 0.38268343236508977173,
-                                   0.0, -0.38268343236508977173, -0.70710678118654752440, -0.92387953251128673848};
-        constexpr double s16[8] = {0.0, 0.38268343236508977173, 0.70710678118654752440, 0.92387953251128673848,
-                                   1.0, 0.92387953251128673848, 0.70710678118654752440, 0.38268343236508977173};
-#pragma unroll
-        for (int k = 0; k < H; ++k) {
-            constexpr int step = 16 / R;
-            double2 t;
-            if (k == 0) {
-                t = o[0];
-            } else if (2 * k == H) {
-                t = mul_mi(o[k]);
-            } else {
-                t = cmul(o[k], make_double2(c16[k * step], -s16[k * step]));
-            }
-            a[k] = cadd(e[k], t);
-            a[k + H] = csub(e[k], t);
-        }
-    }
-};
-
-template <int R>
-struct Log2;
-template <>
-struct Log2<2> {
-    static constexpr int v = 1;
-};
-template <>
-struct Log2<4> {
-    static constexpr int v = 2;
-};
-template <>
-struct Log2<8> {
-    static constexpr int v = 3;
-};
-template <>
-struct Log2<16> {
-    static constexpr int v = 4;
-};
-
-__device__ __forceinline__ int out_idx(int u, int j, int log_s, int log_r) {
-    return (u & ((1 << log_s) - 1)) | ((u >> log_s) << (log_s + log_r)) | (j << log_s);
+    return g_cols_mode;
 }
-
-// out[j] *= w^(j) for j = 1 .. R-1 with w = base (powers by a product tree of depth <= 4)
-template <int R>
-__device__ __forceinline__ void apply_powers(double2 * a, double2 w1) {
-    if (R >= 2) a[1] = cmul(a[1], w1);
-    if (R >= 4) {
-        const double2 w2 = cmul(w1, w1);
-        const double2 w3 = cmul(w2, w1);
-        a[2] = cmul(a[2], w2);
-        a[3] = cmul(a[3], w3);
-        if (R >= 8) {
-            const double2 w4 = cmul(w2, w2);
-            const double2 w5 = cmul(w4, w1);
-            const double2 w6 = cmul(w3, w3);
-            const double2 w7 = cmul(w4, w3);
-            a[4] = cmul(a[4], w4);
-            a[5] = cmul(a[5], w5);
-            a[6] = cmul(a[6], w6);
-            a[7] = cmul(a[7], w7);
-            if (R >= 16) {
-                const double2 w8 = cmul(w4, w4);
-                a[8] = cmul(a[8], w8);
-                a[9] = cmul(a[9], cmul(w8, w1));
-                a[10] = cmul(a[10], cmul(w5, w5));
-                a[11] = cmul(a[11], cmul(w8, w3));
-                a[12] = cmul(a[12], cmul(w6, w6));
-                a[13] = cmul(a[13], cmul(w8, w5));
-                a[14] = cmul(a[14], cmul(w7, w7));
-                a[15] = cmul(a[15], cmul(w8, w7));
-            }
-        }
-    }
-}
-
-// One Stockham stage of radix R on the whole tile of 2^LT elements, LDS -> LDS.  Remaining transform length is
-// (tile >> log_s); the stage twiddle w_n^(j p) = w_tile^((p << log_s) * j) is built from w_tile^(u & ~(s-1)), and
-// w_tile^e = wtile[e << (kLT - LT)] (the table holds the 4096th roots).
-template <int LT, int P, int R>
-__device__ __forceinline__ void stage_lds(double2 * sm, int tid, int log_s, bool last,
-                                          const double2 * __restrict__ wtile) {
-    constexpr int T = (1 << LT) / P;
-    constexpr int B = P / R;
-    constexpr int Q = (1 << LT) / R;
-    constexpr int LR = Log2<R>::v;
-    double2 v[B][R];
-#pragma unroll
-    for (int b = 0; b < B; ++b) {
-        const int u = tid + T * b;
-#pragma unroll
-        for (int k = 0; k < R; ++k) v[b][k] = sm[sw(u + k * Q)];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int b = 0; b < B; ++b) {
-        const int u = tid + T * b;
-        DFT<R>::run(v[b]);
-        if (!last) apply_powers<R>(v[b], wtile[((u >> log_s) << log_s) << (kLT - LT)]);
-#pragma unroll
-        for (int j = 0; j < R; ++j) sm[sw(out_idx(u, j, log_s, LR))] = v[b][j];
-    }
-    __syncthreads();
-}
-
-template <int LT, int P>
-__device__ __forceinline__ void stage_lds_any(int r, double2 * sm, int tid, int log_s, bool last,
-                                              const double2 * __restrict__ wtile) {
-    if (P >= 16 && r == 16) {
-        stage_lds<LT, P, (P >= 16 ? 16 : P)>(sm, tid, log_s, last, wtile);
-    } else if (r == 8) {
-        stage_lds<LT, P, 8>(sm, tid, log_s, last, wtile);
-    } else if (r == 4) {
-        stage_lds<LT, P, 4>(sm, tid, log_s, last, wtile);
-    } else {
-        stage_lds<LT, P, 2>(sm, tid, log_s, last, wtile);
-    }
-}
-
-// Forward FFTs of length n = 2^log_n along the slow axis of the tile of 2^LT elements (tile / n interleaved
-// transforms).  In: v[k] = tile element u_in + k * T, out: v[k] = element u_out + k * T, T = tile / P threads;
-// u_in / u_out are any permutation of the thread index (u = tid: natural order; the row pass mirrors one of them).
-template <int LT, int P>
-__device__ __forceinline__ void tile_fft_t(double2 (&v)[P], double2 * sm, int tid, int log_n,
-                                           const double2 * __restrict__ wtile, int u_in, int u_out) {
-    constexpr int T = (1 << LT) / P;
-    constexpr int LP = Log2<P>::v;
-    const int log_s0 = LT - log_n;
-    if (log_n >= 2 * LP) {
-        // plan [P, middle stages, P]: the radix-P ends work straight on the registers
-        DFT<P>::run(v);
-        apply_powers<P>(v, wtile[((u_in >> log_s0) << log_s0) << (kLT - LT)]);
-        __syncthreads();   // earlier readers of the tile are done
-#pragma unroll
-        for (int j = 0; j < P; ++j) sm[sw(out_idx(u_in, j, log_s0, LP))] = v[j];
-        __syncthreads();
-        int log_mid = log_n - 2 * LP, log_s = log_s0 + LP;
-        while (log_mid > 0) {
-            const int lr = log_mid >= LP ? LP : log_mid;
-            stage_lds_any<LT, P>(1 << lr, sm, tid, log_s, false, wtile);
-            log_s += lr;
-            log_mid -= lr;
-        }
-#pragma unroll
-        for (int k = 0; k < P; ++k) v[k] = sm[sw(u_out + k * T)];
-        DFT<P>::run(v);
-        return;
-    }
-    // short transforms (only small problems get here): every stage through LDS
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < P; ++k) sm[sw(u_in + k * T)] = v[k];
-    __syncthreads();
-    int log_rem = log_n, log_s = log_s0;
-    while (log_rem > 0) {
-        const int lr = log_rem >= LP ? LP : log_rem;
-        stage_lds_any<LT, P>(1 << lr, sm, tid, log_s, log_rem == lr, wtile);
-        log_s += lr;
-        log_rem -= lr;
-    }
-#pragma unroll
-    for (int k = 0; k < P; ++k) v[k] = sm[sw(u_out + k * T)];
-}
-
-// the 4096-element tile in natural order (column passes, self-paired rows)
-template <int P>
-__device__ __forceinline__ void tile_fft(double2 (&v)[P], double2 * sm, int tid, int log_n,
-                                         const double2 * __restrict__ wtile) {
-    tile_fft_t<kLT, P>(v, sm, tid, log_n, wtile, tid, tid);
-}
-
-// ------------------------------------------------------------------------------------------
-// tables: wtile[e] = w_tile^e (e < kTile); three-level w_N^e = t2[e >> 14] t1[(e >> 7) & 127] t0[e & 127]
-// ------------------------------------------------------------------------------------------
-struct Tables {
-    const double2 * wtile;
-    const double2 * t0;
-    const double2 * t1;
-    const double2 * t2;
-};
-
-__device__ __forceinline__ double2 tw_big(const Tables & tb, int64_t e) {
-    const double2 a = tb.t2[e >> 14];
-    const double2 b = tb.t1[(e >> 7) & 127];
-    const double2 c = tb.t0[e & 127];
-    return cmul(cmul(a, b), c);
-}
-
-struct Params {
-    double * tod;                 // [rows, n_samp]
-    const int32_t * d_idx;        // row of detector b
-    int det0;
-    double2 * work;               // [batch, M]
-    const double * apod;          // n_reflect
-    int64_t n_samp, n_fft, n_buffer, n_reflect;
-    int log_n1, log_n2;           // M = N1 N2
-    Tables tb;
-    // kernel K(f)
-    const double * knots;
-    int n_knot;
-    const double * mag_coef;
-    const double * ang_coef;      // nullptr: real kernel
-    const int32_t * knot_hint;    // interval index at bin q N1, q = 0 .. N2 + 1
-    const uint16_t * knot_hint16; // the same in 16 bits (n_knot < 65536), for the LDS copy
-    const int32_t * knot_hint0;   // interval index at every bin j of the FIRST block, j = 0 .. N1 - 1
-    int per_det, deconvolve;
-    int aligned;                  // pass 1 may use padded_pair
-    int xcd_order;                // column passes: contiguous column ranges per XCD
-    const int32_t * tile_order;   // pass 1: column tile of workgroup blockIdx.x (mirror partners on one XCD), or nullptr
-    int stream_hint;              // bit 0: pass 1 writes the work array with non-temporal stores, bit 1: reads the
-                                  // timestream with non-temporal loads (so that the window table stays in L2), bit 2 / 3:
-                                  // the same for pass 3's loads / stores, bit 4 / 5: the row pass' loads / stores
-    double fstep, scale;
-};
-
-// set_rfft_input evaluated for one element of the padded series (src/toast/fft.py:163-188)
-__device__ __forceinline__ double padded(const double * __restrict__ row, const double * __restrict__ apod,
-                                         int64_t i, int64_t n_samp, int64_t n_buffer, int64_t n_reflect) {
-    const int64_t s = i - n_buffer;
-    if (s >= 0 && s < n_samp) return row[s];
-    if (s < 0 && s >= -n_reflect) {
-        const int64_t j = s + n_reflect;
-        return row[n_reflect - 1 - j] * apod[j];
-    }
-    if (s >= n_samp && s < n_samp + n_reflect) {
-        const int64_t j = s - n_samp;
-        return row[n_samp - 1 - j] * apod[n_reflect - 1 - j];
-    }
-    return 0.0;
-}
-
-// v[k] *= w_M^(k1 j2) for the thread's P tile elements e = tid + T k.  When the tile has at most T columns
-// all of them share the column j2 and their rows are k1 = k1_0 + k (T >> log_c): the factors are
-// w^(e0) (w^d)^k -- two table look-ups and a product tree instead of P look-ups.
-template <int P>
-struct ColTw {
-    double2 w0, wd;
-};
-// the table look-ups (independent of the data: issued before the transform whose barriers they could not cross)
-template <int LT, int P>
-__device__ __forceinline__ ColTw<P> col_twiddles_prepare(const Params & p, int tid, int log_c, int64_t c0) {
-    constexpr int T = (1 << LT) / P;
-    ColTw<P> tw;
-    tw.w0 = make_double2(1.0, 0.0);
-    tw.wd = tw.w0;
-    if ((1 << log_c) <= T) {
-        const int64_t j2 = c0 + (tid & ((1 << log_c) - 1));
-        const int64_t k10 = tid >> log_c;
-        const int64_t dk = T >> log_c;
-        tw.w0 = tw_big(p.tb, 2 * k10 * j2);
-        tw.wd = tw_big(p.tb, 2 * dk * j2);
-    }
-    return tw;
-}
-template <int LT, int P>
-__device__ __forceinline__ void col_twiddles(double2 (&v)[P], const Params & p, int tid, int log_c, int64_t c0,
-                                             const ColTw<P> & tw) {
-    constexpr int T = (1 << LT) / P;
-    if ((1 << log_c) <= T) {
-        v[0] = cmul(v[0], tw.w0);
-        apply_powers<P>(v, tw.wd);
-#pragma unroll
-        for (int k = 1; k < P; ++k) v[k] = cmul(v[k], tw.w0);
-    } else {
-#pragma unroll
-        for (int k = 0; k < P; ++k) {
-            const int e = tid + k * T;
-            const int64_t k1 = e >> log_c;
-            const int64_t j2 = c0 + (e & ((1 << log_c) - 1));
-            v[k] = cmul(v[k], tw_big(p.tb, 2 * k1 * j2));
-        }
-    }
-}
-
-// the same for the pair (x[s + n_buffer], x[s + n_buffer + 1]), s even, when n_samp and n_reflect are even
-// and the row is 16-byte aligned: identical values (one product per element), half the loads.
-// BRANCH-FREE: source and window positions are selected arithmetically and both 16-byte loads are issued for every
-// point, so that all 2 P loads of a thread are in flight together.  (With one branch per region the compiler waited
-// for each mirrored point's two loads before the next point: two thirds of the padded series are mirrored, i.e.
-// five or six serialised memory round trips per thread -- the largest part of the forward column pass,
-// profiles/r02_g_fft_phase_clocks.txt section 7.)
-__device__ __forceinline__ double2 padded_pair(const double * __restrict__ row, const double * __restrict__ apod,
-                                               int64_t s, int64_t n_samp, int64_t n_reflect, bool nt = false) {
-    const bool direct = (s >= 0) & (s < n_samp);
-    const bool left = (s < 0) & (s >= -n_reflect);
-    const bool right = (s >= n_samp) & (s < n_samp + n_reflect);
-    const int64_t jl = s + n_reflect;             // left mirror: window index j, source n_reflect - 2 - j
-    const int64_t jr = s - n_samp;                // right mirror: window index n_reflect - 2 - j, source n_samp - 2 - j
-    int64_t src = direct ? s : (left ? n_reflect - 2 - jl : n_samp - 2 - jr);
-    int64_t win = left ? jl : n_reflect - 2 - jr;
-    if (!(direct | left | right)) src = 0;
-    if (!(left | right)) win = 0;
-    const double2 r = nt ? load_nt(reinterpret_cast<const double2 *>(row + src))
-                         : *reinterpret_cast<const double2 *>(row + src);
-    const double2 a = *reinterpret_cast<const double2 *>(apod + win);
-    const double2 m = left ? make_double2(r.y * a.x, r.x * a.y) : make_double2(r.y * a.y, r.x * a.x);
-    double2 out = direct ? r : m;
-    if (!(direct | left | right)) out = make_double2(0.0, 0.0);
-    return out;
-}
-
-// Experimental build (TOAST_HIP_EXTRA_FLAGS=-DTOAST_FFT_PHASE_CLOCK python -m toast_amd.build --force; tools/exp_fft_phases.py):
-// thread 0 of every workgroup adds the 100 MHz wall-clock ticks between phase boundaries to g_phase_ticks.
-#if defined(TOAST_FFT_PHASE_CLOCK)
-__device__ unsigned long long g_phase_ticks[16];
-# define PHASE_ENTRY const unsigned long long ph_e = wall_clock64()
-# define PHASE_DECL unsigned long long ph_t = wall_clock64()
-# define PHASE_SINCE_ENTRY(i) if (threadIdx.x == 0) atomicAdd(&g_phase_ticks[i], wall_clock64() - ph_e)
-# define PHASE_WAIT_LOADS asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-# define PHASE_MARK(i)                                                        \
-    do {                                                                      \
-        const unsigned long long ph_n = wall_clock64();                       \
-        if (threadIdx.x == 0) atomicAdd(&g_phase_ticks[i], ph_n - ph_t);      \
-        ph_t = ph_n;                                                          \
-    } while (0)
-#else
-# define PHASE_ENTRY
-# define PHASE_DECL
-# define PHASE_SINCE_ENTRY(i)
-# define PHASE_WAIT_LOADS
-# define PHASE_MARK(i)
-#endif
-
-// The element offsets of a thread's loads are needed again for its stores at the end of the kernel.  Left alone, the
-// compiler keeps the 64-bit offsets alive across the whole transform and, at the 128-VGPR budget of the P = 8 kernels,
-// spills one or two of them to scratch.  Re-deriving them from an opaque copy of the shift costs a few integer
-// instructions at the end and keeps the kernels free of scratch.
-__device__ __forceinline__ int opaque_sgpr(int x) {
-    asm volatile("" : "+s"(x));
-    return x;
-}
-__device__ __forceinline__ int opaque_vgpr(int x) {
-    asm volatile("" : "+v"(x));
-    return x;
-}
+static bool cols_reg_for(const Params & p) { return cols_mode() != 0 && cols_reg_supported(p, cols_mode() == 2 ? 9 : 10); }
+void set_cols_reg(int on) { g_cols_mode = (on == 2) ? 2 : (on ? 1 : 0); }
 
 // pass 1 (INV = false) and pass 3 (INV = true): transforms of length N1 down the columns
 template <int LT, int P, bool INV>
@@ -544,149 +167,6 @@ __global__ __launch_bounds__((1 << LT) / P, (P == 16 ? 2 : 4)) void k_fft_cols(c
     (void)n2;
 }
 
-// K(f) at bin k (src/toast/fft.py:190-212): PCHIP piecewise cubics of |K| and arg K
-__device__ __forceinline__ double ppoly_at(const double * __restrict__ knots, int n_knot,
-                                           const double * __restrict__ coef, int lo, double x) {
-    const double * c = coef + 4 * lo;
-    const double dx = x - knots[lo];
-    return ((c[0] * dx + c[1]) * dx + c[2]) * dx + c[3];
-}
-
-// The kernel tables as the row pass sees them: in global memory, or (TLDS) a copy behind the tile in the workgroup's
-// LDS.  Measured with phase clocks (tools/exp_fft_phases.py): with the tables in global memory the unpack / multiply /
-// repack phase took 42 % of the row pass -- three DEPENDENT cache round trips per bin (hint -> knot -> coefficients)
-// at the latency of a memory system that is busy streaming the tiles.
-template <typename H>
-struct KTab {
-    const H * hint;            // interval at bin q N1, q = 0 .. N2 + 1
-    const int32_t * hint0;     // interval at every bin of the first block (global memory: one lane per workgroup asks)
-    const double * knots;
-    const double * mc;         // |K| cubics of this workgroup's detector
-    const double * ac;         // arg K cubics, nullptr: real kernel
-    int log_n1;
-    double fstep;
-};
-
-// Interval of bin k in the knot vector.  hint[q] is the interval at bin q N1 (the first bin of element q of every
-// row), so the answer lies in [hint[q], hint[q + 1]]: no search at all where no knot falls into the block (most of
-// them: the noise kernels' frequencies are log spaced), a short walk otherwise.  The FIRST block holds most knots of a
-// log-spaced vector (cfg-3: 53 of 77 below bin N1): its bins are looked up directly in hint0 -- the one lane per
-// workgroup that owns such a bin used to walk ~45 knots, LDS round trip by round trip, while the other 511 threads
-// waited for it at the barrier (profiles/r04_c: 5.5 of a workgroup's 25 us).
-template <typename H>
-__device__ __forceinline__ int kernel_interval(const KTab<H> & t, int k) {
-    const double x = (double)k * t.fstep;
-    const int q = k >> t.log_n1;
-    if (q == 0) return t.hint0[k];
-    const int h0 = (int)t.hint[q];
-    const int h1 = (int)t.hint[q + 1];
-    int lo = h0;
-    if (h1 > h0) {
-        if (t.knots[h0 + 1] <= x) {
-            ++lo;
-            while (lo < h1 && t.knots[lo + 1] <= x) ++lo;
-        }
-    }
-    return lo;
-}
-
-template <typename H>
-__device__ __forceinline__ double2 kernel_eval(const KTab<H> & t, int lo, int k) {
-    const double x = (double)k * t.fstep;
-    const double mag = ppoly_at(t.knots, 0, t.mc, lo, x);
-    if (t.ac == nullptr) return make_double2(mag, 0.0);
-    const double ang = ppoly_at(t.knots, 0, t.ac, lo, x);
-    return make_double2(mag * cos(ang), mag * sin(ang));
-}
-
-template <typename H>
-__device__ __forceinline__ double2 kernel_at(const KTab<H> & t, int64_t k) {
-    return kernel_eval(t, kernel_interval(t, (int)k), (int)k);
-}
-
-// Tables of the row pass: global (TLDS = false, 32-bit hints) or copied into LDS at `tab` (16-bit hints; the host
-// checks that they fit, Params::tab_lds_bytes).  The copy is visible after the next __syncthreads().
-template <bool TLDS>
-struct KTabSel {
-    using H = int32_t;
-    static __device__ __forceinline__ KTab<H> make(const Params & p, int64_t kern, char *, int, int) {
-        KTab<H> t;
-        t.hint = p.knot_hint;
-        t.hint0 = p.knot_hint0;
-        t.knots = p.knots;
-        t.mc = p.mag_coef + kern * 4 * (p.n_knot - 1);
-        t.ac = p.ang_coef ? p.ang_coef + kern * 4 * (p.n_knot - 1) : nullptr;
-        t.log_n1 = p.log_n1;
-        t.fstep = p.fstep;
-        return t;
-    }
-};
-template <>
-struct KTabSel<true> {
-    using H = uint16_t;
-    static __device__ __forceinline__ KTab<H> make(const Params & p, int64_t kern, char * tab, int tid, int nthread) {
-        const int n_hint = (1 << p.log_n2) + 2;
-        const int n_coef = 4 * (p.n_knot - 1);
-        double * s_knots = reinterpret_cast<double *>(tab);
-        double * s_mc = s_knots + p.n_knot;
-        double * s_ac = s_mc + n_coef;
-        H * s_hint = reinterpret_cast<H *>(s_ac + (p.ang_coef ? n_coef : 0));
-        const double * __restrict__ g_mc = p.mag_coef + kern * n_coef;
-        for (int i = tid; i < p.n_knot; i += nthread) s_knots[i] = p.knots[i];
-        for (int i = tid; i < n_coef; i += nthread) s_mc[i] = g_mc[i];
-        if (p.ang_coef) {
-            const double * __restrict__ g_ac = p.ang_coef + kern * n_coef;
-            for (int i = tid; i < n_coef; i += nthread) s_ac[i] = g_ac[i];
-        }
-        for (int i = tid; i < n_hint; i += nthread) s_hint[i] = p.knot_hint16[i];
-        KTab<H> t;
-        t.hint = s_hint;
-        t.hint0 = p.knot_hint0;
-        t.knots = s_knots;
-        t.mc = s_mc;
-        t.ac = p.ang_coef ? s_ac : nullptr;
-        t.log_n1 = p.log_n1;
-        t.fstep = p.fstep;
-        return t;
-    }
-};
-
-__device__ __forceinline__ double2 apply_kernel(double2 v, double2 kk, int deconvolve) {
-    if (deconvolve) {
-        const double den = kk.x * kk.x + kk.y * kk.y;
-        return make_double2((v.x * kk.x + v.y * kk.y) / den, (v.y * kk.x - v.x * kk.y) / den);
-    }
-    return make_double2(v.x * kk.x - v.y * kk.y, v.x * kk.y + v.y * kk.x);
-}
-
-// Bins k (tile element ea) and M - k (element eb) of the packed transform: real-FFT unpacking X = E + w^k O,
-// Y = K X, repacking Z'[k] = Ye + i Yo, Z'[M - k] = conj(Ye) + i conj(Yo), stored with re / im swapped for the
-// inverse transform.  ea == eb: the bin that pairs with itself (k = M / 2).
-__device__ __forceinline__ void pair_update_reg(double2 & za, double2 & zb, bool same, double2 wk, double2 ka,
-                                                double2 kb, int deconvolve) {
-    const double2 cb = cconj(zb);
-    const double2 ee = cadd(za, cb);
-    const double2 oo = mul_mi(csub(za, cb));
-    const double2 t = cmul(wk, oo);
-    const double2 xa = cadd(ee, t);
-    const double2 xb = cconj(csub(ee, t));
-    const double2 ya = apply_kernel(xa, ka, deconvolve);
-    const double2 yb = apply_kernel(xb, kb, deconvolve);
-    const double2 cyb = cconj(yb);
-    const double2 ye = cadd(ya, cyb);
-    const double2 yo = cmul(cconj(wk), csub(ya, cyb));
-    za = make_double2(ye.y + yo.x, ye.x - yo.y);
-    if (!same) zb = make_double2(yo.x - ye.y, ye.x + yo.y);
-}
-
-__device__ __forceinline__ void pair_update(double2 * sm, int ea, int eb, double2 wk, double2 ka, double2 kb,
-                                            int deconvolve) {
-    double2 za = sm[sw(ea)];
-    double2 zb = sm[sw(eb)];
-    pair_update_reg(za, zb, ea == eb, wk, ka, kb, deconvolve);
-    sm[sw(ea)] = za;
-    if (eb != ea) sm[sw(eb)] = zb;
-}
 
 // pass 2: rows (k1, N1 - k1) [block 0: rows 0 and N1 / 2]
 // LT = log2 of the tile = 2 N2: 12 (N2 = 2048, 64 KB, two workgroups per CU) or 11 (N2 = 1024, 32 KB, four per CU)
@@ -909,6 +389,7 @@ struct Plan {
     int64_t n2_entries = 0;
     // pass 1 tile orders per (n_samp, n_buffer, n_reflect, tiles, columns per tile): device table or nullptr (none found)
     std::map<std::array<int64_t, 5>, int32_t *> orders;
+    std::map<std::array<int64_t, 5>, int32_t *> chains;    // pass 1 of fft_reg.hip: chain_tile_order
 };
 
 std::mutex g_mutex;
@@ -929,11 +410,26 @@ static Plan & get_plan(int64_t n_fft, hipStream_t st) {
     if (it != g_plans.end()) return it->second;
     Plan pl;
     pl.n2_entries = (n_fft >> 14) > 0 ? (n_fft >> 14) : 1;
-    std::vector<double2> h((size_t)kTile + 256 + (size_t)pl.n2_entries);
+    std::vector<double2> h((size_t)kTile + 256 + (size_t)pl.n2_entries + 144 + 144);
     for (int64_t e = 0; e < kTile; ++e) fill_twiddle(h, (size_t)e, e, kTile);
     for (int64_t e = 0; e < 128; ++e) fill_twiddle(h, (size_t)kTile + e, e, n_fft);
     for (int64_t e = 0; e < 128; ++e) fill_twiddle(h, (size_t)kTile + 128 + e, (e << 7) % n_fft, n_fft);
     for (int64_t e = 0; e < pl.n2_entries; ++e) fill_twiddle(h, (size_t)kTile + 256 + e, (e << 14) % n_fft, n_fft);
+    // fft_reg.hip, row transform 2048 = 16 x 8 x 16: w_2048^u (u < 128) after the first stage, w_2048^(16 h) (h < 16) after
+    // the second -- the entries of the tile table those stages would gather, packed for a copy into LDS
+    for (int64_t e = 0; e < 128; ++e) h[(size_t)kTile + 256 + (size_t)pl.n2_entries + e] = h[(size_t)(2 * e)];
+    for (int64_t e = 0; e < 16; ++e) h[(size_t)kTile + 256 + (size_t)pl.n2_entries + 128 + e] = h[(size_t)(32 * e)];
+    // fft_reg.hip, column transform of length N1 = M / 2048 when that is 512, 1024 or 2048
+    {
+        int log_m = 0;
+        while ((int64_t(1) << log_m) < n_fft / 2) ++log_m;
+        const int log_n1 = log_m - (kLT - 1);
+        if (log_n1 >= 9 && log_n1 <= 11) {
+            int ex[144];
+            const int n = cols_reg_twiddles(log_n1, ex);
+            for (int i = 0; i < n; ++i) h[(size_t)kTile + 256 + (size_t)pl.n2_entries + 144 + i] = h[(size_t)ex[i] << (kLT - log_n1)];
+        }
+    }
     void * d = nullptr;
     TH_HIP(hipMalloc(&d, h.size() * sizeof(double2)));
     copy_to_device(d, h.data(), h.size() * sizeof(double2), st);
@@ -1027,6 +523,79 @@ static std::vector<int32_t> mirror_tile_order(int64_t n_samp, int64_t n_buffer, 
     return order;
 }
 
+// Pass 1 of the register kernels: the order in which an XCD takes its column tiles.  Every 128-byte line of the
+// timestream is read by three tiles (directly and as the two mirror images of the padded series) and the window table by
+// the same tile of every detector; lines written by a tile narrower than 128 bytes are shared with its neighbours.  The
+// tiles are grouped into "supers" (the tiles of one 128-byte line column), the supers are chained so that neighbours in
+// the chain read the same timestream lines, and the chain is cut into 8 pieces, one per XCD (convolve() then runs each
+// piece in segments of a few tiles x a few detectors: the segment's timestream lines and window entries stay in that
+// XCD's L2 while they are re-read).  Empty when the geometry does not divide.
+static std::vector<int32_t> chain_tile_order(int64_t n_samp, int64_t n_buffer, int64_t n_reflect, int64_t n_tiles,
+                                             int64_t cols_per_tile) {
+    std::vector<int32_t> none;
+    const int64_t piece = 2 * cols_per_tile;             // reals of one row in a tile
+    const int64_t tps = (piece >= 16) ? 1 : 16 / piece;  // tiles per super
+    if (n_reflect <= 0 || n_tiles % (8 * tps) != 0) return none;
+    const int64_t n_super = n_tiles / tps;
+    const int64_t span = piece * tps;                    // reals of one row in a super
+    const int64_t row = span * n_super;
+    if (row % 16 != 0) return none;
+    const int64_t n_line = row / 16;
+    auto fdiv = [](int64_t a, int64_t b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); };
+    auto col = [&](int64_t src) { return ((fdiv(src, 16) % n_line) + n_line) % n_line; };
+    std::vector<std::vector<int32_t>> cols_of((size_t)n_super);
+    std::vector<std::vector<int32_t>> supers_of((size_t)n_line);
+    for (int64_t s = 0; s < n_super; ++s) {
+        for (int64_t x : {s * span, s * span + span - 1}) {
+            const int64_t rel = x - n_buffer;
+            for (int64_t src : {rel, -1 - rel, 2 * n_samp - 1 - rel}) {
+                const int32_t c = (int32_t)col(src);
+                if (std::find(cols_of[(size_t)s].begin(), cols_of[(size_t)s].end(), c) == cols_of[(size_t)s].end()) {
+                    cols_of[(size_t)s].push_back(c);
+                    supers_of[(size_t)c].push_back((int32_t)s);
+                }
+            }
+        }
+    }
+    std::vector<char> seen((size_t)n_super, 0);
+    std::vector<int32_t> chain;
+    chain.reserve((size_t)n_super);
+    int64_t next_free = 0;
+    auto neighbour = [&](int32_t s) -> int32_t {
+        for (int32_t c : cols_of[(size_t)s]) {
+            for (int32_t t : supers_of[(size_t)c]) {
+                if (!seen[(size_t)t]) return t;
+            }
+        }
+        return -1;
+    };
+    while ((int64_t)chain.size() < n_super) {
+        int32_t cur = -1;
+        for (size_t back = 0; back < 3 && back < chain.size() && cur < 0; ++back) cur = neighbour(chain[chain.size() - 1 - back]);
+        if (cur < 0) {
+            while (seen[(size_t)next_free]) ++next_free;
+            cur = (int32_t)next_free;
+        }
+        seen[(size_t)cur] = 1;
+        chain.push_back(cur);
+    }
+    std::vector<int32_t> order;
+    order.reserve((size_t)n_tiles);
+    for (int32_t s : chain) {
+        for (int64_t t = 0; t < tps; ++t) order.push_back((int32_t)(s * tps + t));
+    }
+    return order;
+}
+
+int chain_tile_order_host(int64_t n_samp, int64_t n_buffer, int64_t n_reflect, int64_t n_tiles, int64_t cols_per_tile,
+                          int32_t * order) {
+    const std::vector<int32_t> o = chain_tile_order(n_samp, n_buffer, n_reflect, n_tiles, cols_per_tile);
+    if (order != nullptr) {
+        for (size_t i = 0; i < o.size(); ++i) order[i] = o[i];
+    }
+    return (int)o.size();
+}
+
 int mirror_tile_order_host(int64_t n_samp, int64_t n_buffer, int64_t n_reflect, int64_t n_tiles, int64_t cols_per_tile,
                            int32_t * order) {
     const std::vector<int32_t> o = mirror_tile_order(n_samp, n_buffer, n_reflect, n_tiles, cols_per_tile);
@@ -1049,6 +618,22 @@ static const int32_t * tile_order_for(Plan & pl, int64_t n_samp, int64_t n_buffe
         copy_to_device(d, order.data(), order.size() * sizeof(int32_t), st);
     }
     pl.orders[key] = d;
+    return d;
+}
+
+static const int32_t * chain_order_for(Plan & pl, int64_t n_samp, int64_t n_buffer, int64_t n_reflect, int64_t n_tiles,
+                                       int64_t cols_per_tile, hipStream_t st) {
+    std::lock_guard<std::mutex> lock(g_mutex);
+    const std::array<int64_t, 5> key = {n_samp, n_buffer, n_reflect, n_tiles, cols_per_tile};
+    auto it = pl.chains.find(key);
+    if (it != pl.chains.end()) return it->second;
+    const std::vector<int32_t> order = chain_tile_order(n_samp, n_buffer, n_reflect, n_tiles, cols_per_tile);
+    int32_t * d = nullptr;
+    if (!order.empty()) {
+        TH_HIP(hipMalloc(reinterpret_cast<void **>(&d), order.size() * sizeof(int32_t)));
+        copy_to_device(d, order.data(), order.size() * sizeof(int32_t), st);
+    }
+    pl.chains[key] = d;
     return d;
 }
 
@@ -1076,19 +661,21 @@ int points_of(int pass) {
     read_points();
     return g_points[pass];
 }
-// row pass: 0 = row pair per 64 KB tile (k_fft_rows, default), 1 = one row per 32 KB tile (k_fft_rows_split:
-// experiment; needs more registers than four workgroups per CU leave)
+// row pass: 2 (default) = one row per wave, tile in registers (k_fft_rows_reg, fft_reg.hip); 0 = row pair per 64 KB LDS
+// tile (k_fft_rows); 1 = one row per 32 KB tile (k_fft_rows_split: experiment; needs more registers than four
+// workgroups per CU leave).  TOAST_HIP_FFT_ROWS=reg|lds|split / toast_hip_fft_rows_split(mode)
 namespace {
 int g_rows_split = -1;
 }
 int rows_split() {
     if (g_rows_split < 0) {
         const char * e = std::getenv("TOAST_HIP_FFT_ROWS");
-        g_rows_split = (e != nullptr && std::string(e) == "split") ? 1 : 0;
+        const std::string v = (e != nullptr) ? std::string(e) : std::string();
+        g_rows_split = (v == "split") ? 1 : (v == "lds") ? 0 : 2;
     }
     return g_rows_split;
 }
-void set_rows_split(int split) { g_rows_split = split ? 1 : 0; }
+void set_rows_split(int split) { g_rows_split = (split == 1 || split == 2) ? split : 0; }
 namespace {
 int g_rows_n2 = -1;
 }
@@ -1143,6 +730,8 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
     p.tb.t0 = pl.tables + kTile;
     p.tb.t1 = pl.tables + kTile + 128;
     p.tb.t2 = pl.tables + kTile + 256;
+    p.wrow = pl.tables + kTile + 256 + pl.n2_entries;
+    p.wcol = p.wrow + 144;
     p.knots = d_knots;
     p.n_knot = (int)n_knot;
     p.mag_coef = d_mag;
@@ -1174,7 +763,9 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
         // memory on its own, 61 -> 90 ms per call; with four columns (64-byte pieces, 2^22) it still gains 1.5 %
         // (profiles/r04_c section 6)
         static const bool forced = std::getenv("TOAST_HIP_FFT_STREAM_HINT") != nullptr;
-        if (!forced && (kLT - p.log_n1) < 2) p.stream_hint &= ~1;
+        // (pass 1 of the register kernels: plain stores at every length -- 49.4 against 51.6 ms per call at 2^23, 44.5
+        // against 47.2 at 2^22, profiles/r05_a)
+        if (!forced && (cols_reg_for(p) || (kLT - p.log_n1) < 2)) p.stream_hint &= ~1;
     }
     // unnormalised inverse of length M on un-halved packing factors: 1 / (4 M), a power of two
     p.scale = 1.0 / (4.0 * (double)m);
@@ -1187,20 +778,26 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
     const int64_t n_hint0 = int64_t(1) << p.log_n1;             // every bin of the first block
     const size_t hint_bytes = ((size_t)n_hint * (sizeof(int32_t) + sizeof(uint16_t)) + (size_t)n_hint0 * sizeof(int32_t) +
                                255 + 8) & ~size_t(255);
+    // row pass: knots, this detector's cubics and 16-bit hints in LDS when they fit (layout: KTabSel<true>::make)
+    const size_t tab_bytes = (((size_t)n_knot + (size_t)4 * (n_knot - 1) * (d_ang ? 2 : 1)) * sizeof(double) +
+                              (size_t)n_hint * sizeof(uint16_t) + 15) & ~size_t(15);
+    // ... which the register row pass copies from one packed block per kernel (k_pack_tables)
+    const int64_t n_kern = per_det ? n_det : 1;
+    const size_t blob_bytes = (tab_bytes <= (size_t)kTabLdsMax) ? (((size_t)n_kern * tab_bytes + 255) & ~size_t(255)) : 0;
     char * scratch = (char *)Manager::get().scratch(Manager::kScratchFftWork,
-                                                    hint_bytes + (size_t)batch * m * sizeof(double2), st);
+                                                    hint_bytes + blob_bytes + (size_t)batch * m * sizeof(double2), st);
     int32_t * d_hint = (int32_t *)scratch;
     int32_t * d_hint0 = d_hint + n_hint;
     uint16_t * d_hint16 = (uint16_t *)(d_hint0 + n_hint0);
     p.knot_hint = d_hint;
     p.knot_hint16 = d_hint16;
     p.knot_hint0 = d_hint0;
-    p.work = (double2 *)(scratch + hint_bytes);
+    p.tab_blob = blob_bytes ? scratch + hint_bytes : nullptr;
+    p.tab_bytes = blob_bytes ? (int)tab_bytes : 0;
+    p.work = (double2 *)(scratch + hint_bytes + blob_bytes);
     hipLaunchKernelGGL(k_knot_hint, dim3((unsigned)((n_hint + n_hint0 + 255) / 256)), dim3(256), 0, st, d_knots,
                        (int)n_knot, fstep, p.log_n1, n_hint, d_hint, d_hint16, d_hint0);
-    // row pass: knots, this detector's cubics and 16-bit hints in LDS when they fit (layout: KTabSel<true>::make)
-    const size_t tab_bytes = (((size_t)n_knot + (size_t)4 * (n_knot - 1) * (d_ang ? 2 : 1)) * sizeof(double) +
-                              (size_t)n_hint * sizeof(uint16_t) + 15) & ~size_t(15);
+    if (blob_bytes && rows_split() == 2) pack_tables(p, scratch + hint_bytes, n_kern, st);
     static int tab_lds_env = -1;
     if (tab_lds_env < 0) {
         const char * e = std::getenv("TOAST_HIP_FFT_TABLES");      // "global": experiment switch
@@ -1211,24 +808,59 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
     const size_t lds = kTile * sizeof(double2);
     const size_t lds_rows = lds + (tab_lds ? tab_bytes : 0);
     const size_t lds_split = lds / 2 + (tab_lds ? tab_bytes : 0);
-    const unsigned n_col_tiles = (unsigned)(int64_t(1) << (p.log_n2 - (kLT - p.log_n1)));   // N2 / C
+    const bool cols_reg = cols_reg_for(p);
+    const int log_c = cols_reg ? cols_reg_log_c(p.log_n1) : (kLT - p.log_n1);               // columns per tile
+    const unsigned n_col_tiles = (unsigned)(int64_t(1) << (p.log_n2 - log_c));               // N2 / C
     p.tile_order = nullptr;
     if (p.xcd_order == 2 && p.aligned) {
-        p.tile_order = tile_order_for(pl, n_samp, n_buffer, n_reflect, (int64_t)n_col_tiles,
-                                      int64_t(1) << (kLT - p.log_n1), st);
+        p.tile_order = tile_order_for(pl, n_samp, n_buffer, n_reflect, (int64_t)n_col_tiles, int64_t(1) << log_c, st);
+    }
+    // pass 1 of the register kernels: segments of the tile chain x groups of detectors per XCD (TOAST_HIP_FFT_FWD_SEG="k,g",
+    // "0": the two-dimensional grid with tile_order)
+    p.fwd_seq = nullptr;
+    p.fwd_k = p.fwd_g = p.fwd_tiles = p.fwd_dets = 0;
+    if (cols_reg) {
+        static int seg_k = -1, seg_g = -1;
+        if (seg_k < 0) {
+            seg_k = 4;          // four tiles (two 128-byte line columns at N1 = 2048) x all detectors of the batch: the tiles
+            seg_g = 1 << 20;    // that run side by side on an XCD read the same window entries and share written lines
+            const char * e = std::getenv("TOAST_HIP_FFT_FWD_SEG");
+            if (e != nullptr) {
+                int a = 0, b = 0;
+                const int n = std::sscanf(e, "%d,%d", &a, &b);
+                if (n == 2 && a > 0 && b > 0) {
+                    seg_k = a;
+                    seg_g = b;
+                } else if (n >= 1 && a == 0) {
+                    seg_k = 0;
+                }
+            }
+        }
+        const int64_t tpx = (int64_t)n_col_tiles / 8;
+        if (seg_k > 0 && (n_col_tiles % 8u) == 0u && tpx % seg_k == 0) {
+            p.fwd_seq = chain_order_for(pl, n_samp, n_buffer, n_reflect, (int64_t)n_col_tiles, int64_t(1) << log_c, st);
+            p.fwd_k = seg_k;
+            p.fwd_g = seg_g;
+            p.fwd_tiles = (int)n_col_tiles;
+        }
     }
     const unsigned n_row_tiles = (unsigned)((int64_t(1) << p.log_n1) / 2);                 // N1 / 2
     for (int64_t det0 = 0; det0 < n_det; det0 += batch) {
         const int64_t nb = (n_det - det0 < batch) ? (n_det - det0) : batch;
         p.det0 = (int)det0;
         // points per thread of each pass: TOAST_HIP_FFT_POINTS="rows,cols_fwd,cols_inv" / toast_hip_fft_points
-        if (points_of(1) == 8) {
+        if (cols_reg) {
+            p.fwd_dets = (int)nb;
+            launch_cols_reg(p, false, (unsigned)nb, st);
+        } else if (points_of(1) == 8) {
             hipLaunchKernelGGL((k_fft_cols<kLT, 8, false>), dim3(n_col_tiles, (unsigned)nb), dim3(kTile / 8), lds, st, p);
         } else {
             hipLaunchKernelGGL((k_fft_cols<kLT, 16, false>), dim3(n_col_tiles, (unsigned)nb), dim3(kTile / 16), lds, st, p);
         }
-        const bool split = rows_split() != 0 && !half_rows;
-        const dim3 g_pair(split ? 1 : n_row_tiles, (unsigned)nb);   // split: rows 0 and N1 / 2 only (self-paired)
+        const bool reg_rows = rows_split() == 2 && !half_rows && rows_reg_supported(p);
+        const bool split = rows_split() == 1 && !half_rows;
+        // split / registers: rows 0 and N1 / 2 only (self-paired)
+        const dim3 g_pair((split || reg_rows) ? 1 : n_row_tiles, (unsigned)nb);
         if (half_rows) {
             const size_t lds_half = lds / 2 + (tab_lds ? tab_bytes : 0);
             if (tab_lds) {
@@ -1247,6 +879,7 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
         } else {
             hipLaunchKernelGGL((k_fft_rows<kLT, 16, false>), g_pair, dim3(kTile / 16), lds_rows, st, p);
         }
+        if (reg_rows) launch_rows_reg(p, (unsigned)nb, tab_lds, tab_bytes, st);
         if (split && n_row_tiles > 1) {
             const dim3 gr(n_row_tiles - 1, (unsigned)nb), bl(kTile / 16);
             if (tab_lds) {
@@ -1255,7 +888,9 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
                 hipLaunchKernelGGL((k_fft_rows_split<8, 2, false>), gr, bl, lds_split, st, p);
             }
         }
-        if (points_of(2) == 8) {
+        if (cols_reg) {
+            launch_cols_reg(p, true, (unsigned)nb, st);
+        } else if (points_of(2) == 8) {
             hipLaunchKernelGGL((k_fft_cols<kLT, 8, true>), dim3(n_col_tiles, (unsigned)nb), dim3(kTile / 8), lds, st, p);
         } else {
             hipLaunchKernelGGL((k_fft_cols<kLT, 16, true>), dim3(n_col_tiles, (unsigned)nb), dim3(kTile / 16), lds, st, p);

@@ -37,9 +37,21 @@ def set_points(rows=0, cols_fwd=0, cols_inv=0):
     capi.lib().toast_hip_fft_points(C.c_int(int(rows)), C.c_int(int(cols_fwd)), C.c_int(int(cols_inv)))
 
 
+def set_rows_mode(mode="reg"):
+    """Row pass of the fused kernels: "reg" (default: one row per wave, tile in registers, fft_reg.hip), "pair" (row pair
+    in one 64 KB LDS tile) or "split" (one row per 32 KB LDS tile; experiment)."""
+    capi.lib().toast_hip_fft_rows_split(C.c_int({"pair": 0, "lds": 0, "split": 1, "reg": 2}[mode]))
+
+
+def set_cols_mode(mode="reg"):
+    """Column passes of the fused kernels: "reg" (default: tile in registers for n_fft 2^22 and 2^23), "reg9" (for 2^21
+    too) or "lds" (csrc/fft_fused.hip for every length)."""
+    capi.lib().toast_hip_fft_cols_reg(C.c_int({"lds": 0, "reg": 1, "reg9": 2}[mode]))
+
+
 def set_rows_split(split=True):
-    """Row pass of the fused kernels: one row per 32 KB tile (default) or the row pair in one 64 KB tile."""
-    capi.lib().toast_hip_fft_rows_split(C.c_int(1 if split else 0))
+    """Older spelling: the "split" row pass (True) or the default one (False)."""
+    set_rows_mode("split" if split else "reg")
 
 
 def set_rows_n2(n2=2048):
