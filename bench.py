@@ -184,7 +184,9 @@ def _lifeline_arm(out, rank):
     def expire():
         if rank != 0:
             time.sleep(2.0)
-        os._exit(0)          # (rank 0: the guardian prints what it was sent)
+        # non-zero: a hung collective or a wedged process is not a success; the guardian still prints the headline it was
+        # sent, with its `truncated` key, and the driver decides from both
+        os._exit(3)
 
     t = threading.Timer(limit, expire)
     t.daemon = True
@@ -282,6 +284,9 @@ def main():
         if rank == 0:
             out["configs3_shard"] = {k: sub[k] for k in ("value", "unit", "ms_per_step", "kernel_ms", "config",
                                                          "allreduce", "roofline")}
+            if "pcg_lhs_offset_templates" in sub:
+                out["configs3_shard"]["pcg_lhs_offset_templates"] = {
+                    k: v for k, v in sub["pcg_lhs_offset_templates"].items() if k.startswith("packed")}
     if op_level is not None:
         out["operator_level"] = op_level
     sys.stdout.flush()
@@ -749,7 +754,9 @@ def run(args, workload, world, rank, dev, headline=True):
             "backend": (dist.get_backend() if multi else None),
             "implementation": comm_impl,
             "owner_computes_reduce_apply_ms": None,
-            # the same pass per implementation (TOAST_HIP_COMM_MODE): {"owner", "sliced:2", "sliced:4", "sliced:8", "allreduce", "peer", "peer:flags"}
+            # the same pass per implementation (TOAST_HIP_COMM_MODE; "@16": TOAST_HIP_COMM_PEER_WIDTH=16): {"owner", "allreduce",
+            # "peer", "peer:flags", "peer@16", "peer:flags@16"} and, for the peer modes, the plain all-reduce of the timed
+            # step through the same exchange ("allreduce_via_<mode>")
             "reduce_apply_ms_by_mode": None,
             "note": comm_note,
             "algorithm_GBs": (2.0 * (world - 1) / world * n_local * nps * nnz * 8 / (ms["allreduce"] * 1e-3) / 1e9
@@ -765,18 +772,28 @@ def run(args, workload, world, rank, dev, headline=True):
         oc = lambda: D.comm_map_reduce_apply(n_local * nps, nnz, d_cov.data_ptr(), d_zmap.data_ptr(), True, stream)
         oc()
         owner_ms = timed(oc, 5)
-        # ... and the other two ways the library can do that pass (toast_hip_comm_set_mode), for an A/B on this very job:
-        # pixel slices on two side streams (reduce-scatter of slice k + 1 under multiplication + all-gather of slice k),
-        # one all-reduce followed by every rank multiplying the whole map, and the exchange over hipIpc-opened buffers
-        # ("peer": every link of the xGMI mesh at once, RCCL only for the two barriers)
+        # ... and the other ways the library can do that pass (toast_hip_comm_set_mode), for an A/B on this very job: one
+        # all-reduce followed by every rank multiplying the whole map, and the exchange over hipIpc-opened buffers ("peer":
+        # every link of the xGMI mesh at once, RCCL only for the two barriers; "peer:flags": device flags instead), the
+        # latter with 8- and 16-byte lane accesses
         mode_ms = {"owner": owner_ms}
-        for mode in ("sliced:2", "sliced:4", "sliced:8", "allreduce", "peer", "peer:flags"):
+        for mode, width in (("allreduce", 0), ("peer", 8), ("peer:flags", 8), ("peer", 16), ("peer:flags", 16)):
+            key = mode if width in (0, 8) else "%s@%d" % (mode, width)
             try:
+                if width:
+                    D.comm_set_peer_width(width)
                 D.comm_set_mode(mode)
                 oc()
-                mode_ms[mode] = timed(oc, 5)
+                mode_ms[key] = timed(oc, 5)
+                if mode.startswith("peer"):
+                    # the timed step's own all-reduce through the same exchange (toast_hip_comm_allreduce_dev in a peer mode)
+                    D.comm_allreduce(d_zmap.data_ptr(), d_zmap.numel(), np.float64, "sum", stream)
+                    mode_ms["allreduce_via_" + key] = timed(
+                        lambda: D.comm_allreduce(d_zmap.data_ptr(), d_zmap.numel(), np.float64, "sum", stream), 5)
+                    D.comm_check(stream)
             except RuntimeError as err:      # noqa: PERF203 -- the headline must not depend on this extra
-                mode_ms[mode] = repr(err)[:200]
+                mode_ms[key] = repr(err)[:200]
+        D.comm_set_peer_width(8)
         D.comm_set_mode("owner")
         out["allreduce"]["owner_computes_reduce_apply_ms"] = owner_ms
         out["allreduce"]["reduce_apply_ms_by_mode"] = mode_ms
@@ -955,6 +972,37 @@ def run(args, workload, world, rank, dev, headline=True):
                 "packed_vs_sequence_max_rel_diff": err_pk,
                 "pack_once_ms": t_pack,
             })
+            if comm_impl is not None and comm_impl.startswith("toast_hip_comm"):
+                # the packed left-hand side with the owner-computes pass in the middle (what the fused SolverLHS runs with
+                # sync_type = "alltoallv"), per implementation of that pass
+                def lhs_packed_oc():
+                    d_zmap.zero_()
+                    D.offset_accumulate_packed(step_len, amp_off, nav, d_amp_in.data_ptr(), d_amp_flags.data_ptr(),
+                                               d_zmap.data_ptr(), pk_key.data_ptr(), pk_qu.data_ptr(), pk_cal.data_ptr(),
+                                               det_w, n_samp, ivl, pair_words=pair_words, pair_corr=corr_ptr, stream=stream)
+                    D.comm_map_reduce_apply(n_local * nps, nnz, d_cov.data_ptr(), d_zmap.data_ptr(), True, stream)
+                    d_amp_out.zero_()
+                    D.offset_scan_project_packed(step_len, amp_off, nav, d_amp_in.data_ptr(), d_amp_out.data_ptr(),
+                                                 d_amp_flags.data_ptr(), d_zmap.data_ptr(), pk_key.data_ptr(),
+                                                 pk_qu.data_ptr(), pk_cal.data_ptr(), det_w, n_samp, ivl,
+                                                 pair_words=pair_words, pair_corr=corr_ptr, stream=stream)
+
+                by_mode = {}
+                for mode, width in (("owner", 0), ("allreduce", 0), ("peer", 8), ("peer:flags", 8), ("peer", 16),
+                                    ("peer:flags", 16)):
+                    key = mode if width in (0, 8) else "%s@%d" % (mode, width)
+                    try:
+                        if width:
+                            D.comm_set_peer_width(width)
+                        D.comm_set_mode(mode)
+                        lhs_packed_oc()
+                        by_mode[key] = timed(lhs_packed_oc, 5)
+                        D.comm_check(stream)
+                    except RuntimeError as err:      # noqa: PERF203
+                        by_mode[key] = repr(err)[:200]
+                D.comm_set_peer_width(8)
+                D.comm_set_mode("owner")
+                out["pcg_lhs_offset_templates"]["packed_ms_by_mode"] = by_mode
             if corr_ptr:
                 # the same sweeps with the partner's weights rebuilt from the pair sums: what ops.SolverLHS runs when the
                 # pairs allow it (packed_ms above is then the 18-byte form, kept for comparison)

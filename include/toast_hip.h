@@ -1142,17 +1142,25 @@ int toast_hip_comm_shard_of(int64_t n_px, int n_ranks, int rank, int64_t * first
 int toast_hip_comm_map_reduce_apply_dev(int64_t n_px, int64_t nnz, const double * d_cov, double * d_map, int reduce,
                                         void * stream);
 /* How toast_hip_comm_map_reduce_apply_dev does its work (TOAST_HIP_COMM_MODE sets the start-up value): "owner" (default:
- * reduce-scatter, multiplication on the owned shard, all-gather on the caller's stream), "sliced:S" (the same in S pixel
- * slices dealt to two side streams, so that the reduce-scatter of slice k + 1 overlaps multiplication and all-gather of
- * slice k), "allreduce" (one all-reduce, every rank multiplies the whole map: the reference's sync_allreduce +
- * covariance_apply, pixels.py:710-780), "peer" (at most 16 ranks of one node: no RCCL on the data path -- every rank writes
- * the foreign slices of its map into their owners' exchange buffers, opened through hipIpc handles, owners add them in rank
- * order and multiply, every rank reads the finished slices back; all xGMI links of the mesh carry 1/N of the map at once,
- * RCCL provides the two barriers; fails with TOAST_HIP_ERR_DEVICE on every rank if the buffers cannot be opened),
- * "peer:flags" (the same with the barriers done by device flags in each other's uncached memory: no library call per
- * reduction; a wait gives up after TOAST_HIP_COMM_PEER_TIMEOUT_MS and the rank's next call fails).  Same
- * results in every mode (to the rounding of the sums' order).  Collective: every rank must use the same mode. */
+ * reduce-scatter, multiplication on the owned shard, all-gather on the caller's stream), "allreduce" (one all-reduce, every
+ * rank multiplies the whole map: the reference's sync_allreduce + covariance_apply, pixels.py:710-780), "peer" (at most 16
+ * ranks of one node: no RCCL on the data path -- every rank writes the foreign slices of its map into their owners' exchange
+ * buffers, opened through hipIpc handles, owners add them in rank order and multiply, every rank reads the finished slices
+ * back; all xGMI links of the mesh carry 1/N of the map at once, RCCL provides the two barriers; fails with
+ * TOAST_HIP_ERR_DEVICE on every rank if the buffers cannot be opened), "peer:flags" (the same with the barriers done by
+ * device flags in each other's uncached memory: no library call per reduction; a wait gives up after
+ * TOAST_HIP_COMM_PEER_TIMEOUT_MS, the map of that reduction starts with NaN, and the error is raised by the rank's next
+ * reduction, toast_hip_comm_check, toast_hip_comm_set_mode or toast_hip_comm_destroy, whichever comes first).  In the
+ * "peer" modes toast_hip_comm_allreduce_dev sums maps of doubles (>= 4096 values per rank) through the exchange buffers
+ * too.  Same results in every mode (to the rounding of the sums' order).  Collective: every rank must use the same mode.
+ * (Round 4's "sliced:S" is gone: two streams of one communicator do not overlap its collectives.) */
 int toast_hip_comm_set_mode(const char * mode);
+/* Bytes per lane and access of the "peer" exchange kernels: 8 (default: system-scope atomic loads / stores of one double)
+ * or 16 (ordinary non-temporal 16-byte accesses; used when the slices are even and the map 16-byte aligned).  Start-up
+ * value from TOAST_HIP_COMM_PEER_WIDTH.  Same values either way. */
+int toast_hip_comm_set_peer_width(int bytes);
+/* Synchronises the stream and raises a pending "peer:flags" time-out (0: nothing pending). */
+int toast_hip_comm_check(void * stream);
 /* mode "peer": reductions done through the exchange buffers, times the buffers were (re-)established (collective hipIpc
  * exchange; grows with the largest map), bytes of this rank's exchange buffer now */
 int toast_hip_comm_peer_stats(int64_t * reductions, int64_t * establishments, int64_t * exchange_bytes);

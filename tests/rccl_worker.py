@@ -214,7 +214,11 @@ def main():
     # ("peer": no RCCL on the data path -- slices written into / read from the owners' hipIpc-opened exchange buffers;
     # between processes that share this GPU here, between GPUs over xGMI on a node)
     # ("peer:flags": the same with the two barriers of a reduction done by device flags in each other's memory)
-    for mode in ("owner", "sliced:2", "sliced:4", "allreduce", "peer", "peer:flags", "owner"):
+    # (both lane widths of the exchange kernels: 8-byte system-scope atomics and ordinary 16-byte accesses)
+    first_peer = True
+    for mode, width in (("owner", 8), ("allreduce", 8), ("peer", 8), ("peer:flags", 8), ("peer", 16), ("peer:flags", 16),
+                        ("owner", 8)):
+        capi.dev.comm_set_peer_width(width)
         capi.dev.comm_set_mode(mode)
         peer_before = capi.dev.comm_peer_stats()
         assert capi.dev.comm_get_mode() == mode
@@ -262,10 +266,40 @@ def main():
                 # 2 small maps + 1 of 40 000 + 3 x 2 odd ones went through the exchange buffers, which grew twice
                 # (1776 x 3 values -> 40 000 -> 40 101; the second mode finds them large enough) and hold (1 + size)
                 # slots of ceil(40 101 / size) values
-                assert n_red == 9 and n_est == (3 if mode == "peer" else 0), (mode, n_red, n_est)
+                assert n_red == 9 and n_est == (3 if first_peer else 0), (mode, width, n_red, n_est)
                 assert n_bytes >= (1 + size) * 8 * (40101 // size), n_bytes
             else:
                 assert n_red == 0 and n_est == 0 and n_bytes == 0
+            first_peer = False
+            # a call that sums nothing (reduce = 0: covariance_apply(use_alltoallv=True)) right behind
+            # another call.  Without the first barrier in the reduce = 0 call a fast rank rewrites the slice it owns while a
+            # slower peer still reads the previous result from it.  The last rank is made slow (a long kernel queue on its
+            # stream before every pair of calls); every rank checks BOTH results, five rounds, on a map large enough for
+            # the pull to take a while.
+            n_big = 1 << 20
+            for rnd in range(5):
+                vals = {r: np.random.default_rng(7000 + 10 * rnd + r).standard_normal(n_big) for r in range(size)}
+                same = np.random.default_rng(7900 + rnd).standard_normal(n_big)
+                ta, tb = torch.from_numpy(vals[rank]).cuda(), torch.from_numpy(same).cuda()
+                if rank == size - 1:
+                    busy = torch.ones(1 << 22, device="cuda")
+                    for _ in range(40):
+                        busy = busy * 1.0000001
+                capi.dev.comm_map_reduce_apply(n_big, 1, 0, ta.data_ptr(), reduce=True)
+                capi.dev.comm_map_reduce_apply(n_big, 1, 0, tb.data_ptr(), reduce=False)
+                capi.dev.comm_check(0)
+                tot = np.zeros(n_big)
+                for r in range(size):
+                    tot += vals[r]
+                np.testing.assert_allclose(ta.cpu().numpy(), tot, rtol=0, atol=1e-12 * np.max(np.abs(tot)), err_msg=mode)
+                assert np.array_equal(tb.cpu().numpy(), same), (mode, width, rnd)
+            # the plain all-reduce of a map of doubles takes the same exchange in these modes (bench.py's timed step)
+            before = capi.dev.comm_peer_stats()[0]
+            t = torch.from_numpy(vals[rank]).cuda()
+            capi.dev.comm_allreduce(t.data_ptr(), n_big, np.float64, "sum")
+            torch.cuda.synchronize()
+            np.testing.assert_allclose(t.cpu().numpy(), tot, rtol=0, atol=1e-12 * np.max(np.abs(tot)), err_msg=mode)
+            assert capi.dev.comm_peer_stats()[0] == before + (1 if size > 1 else 0)
     # ranks that hold DIFFERENT local submaps (the reference's general case): the default exchange on the device through
     # the union of all ranks' submaps, against the sums computed by hand; rank 0 also tries it with its copy on the host
     for dtype, n_value in ((np.float64, 3), (np.int64, 1)):

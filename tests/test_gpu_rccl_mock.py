@@ -90,9 +90,14 @@ def test_bench_ranks_through_the_library_communicator(mock_lib, n):
     # every implementation of the owner-computes pass was timed on this job (A/B material for the first 8-GPU lease),
     # and the packed left-hand side with the reduction inside is part of the same line
     modes = d["allreduce"]["reduce_apply_ms_by_mode"]
-    assert set(modes) == {"owner", "sliced:2", "sliced:4", "sliced:8", "allreduce", "peer", "peer:flags"}
+    assert set(modes) == {"owner", "allreduce", "peer", "peer:flags", "peer@16", "peer:flags@16", "allreduce_via_peer",
+                          "allreduce_via_peer:flags", "allreduce_via_peer@16", "allreduce_via_peer:flags@16"}
     assert all(isinstance(v, float) and v > 0 for v in modes.values()), modes
     assert d["pcg_lhs_offset_templates"]["packed_ms"] > 0
+    by_mode = d["pcg_lhs_offset_templates"]["packed_ms_by_mode"]
+    assert set(by_mode) == {"owner", "allreduce", "peer", "peer:flags", "peer@16", "peer:flags@16"}
+    assert all(isinstance(v, float) and v > 0 for v in by_mode.values()), by_mode
+    assert set(d["configs3_shard"]["pcg_lhs_offset_templates"]["packed_ms_by_mode"]) == set(by_mode)
     assert d["configs3_shard"]["allreduce"]["implementation"].startswith("toast_hip_comm")
 
 

@@ -1259,9 +1259,17 @@ class _Dev:
                                                          C.c_int(1 if reduce else 0), _p(stream)))
 
     def comm_set_mode(self, mode):
-        """'owner' | 'sliced:S' | 'allreduce' | 'peer' | 'peer:flags': how comm_map_reduce_apply works (toast_hip_comm_set_mode; collective:
+        """'owner' | 'allreduce' | 'peer' | 'peer:flags': how comm_map_reduce_apply works (toast_hip_comm_set_mode; collective:
         every rank the same)."""
         _check(real_lib().toast_hip_comm_set_mode(str(mode).encode()))
+
+    def comm_set_peer_width(self, nbytes):
+        """8 or 16 bytes per lane and access in the 'peer' exchange kernels (toast_hip_comm_set_peer_width)."""
+        _check(real_lib().toast_hip_comm_set_peer_width(C.c_int(int(nbytes))))
+
+    def comm_check(self, stream=0):
+        """Synchronise the stream and raise a pending 'peer:flags' time-out (toast_hip_comm_check)."""
+        _check(real_lib().toast_hip_comm_check(_p(stream)))
 
     def comm_peer_stats(self):
         """(reductions, establishments, exchange_bytes) of mode 'peer' (toast_hip_comm_peer_stats)."""

@@ -28,9 +28,11 @@ void hip_give(void * p) { (void)hipFree(p); }
 
 void hip_touch(void * p, size_t bytes, hipStream_t st) {
     // One write of every page: what the first kernel to use a fresh block would otherwise pay inside an operator
-    // (12 .. 17 ms per GB on this driver against 0.2 ms per GB for a fill of touched memory).  Asynchronous: the host
-    // goes on while the device works through it.
-    (void)hipMemsetAsync(p, 0, bytes, st);
+    // (12 .. 17 ms per GB on this driver against 0.2 ms per GB for a fill of touched memory).  The host WAITS for it
+    // (ADVICE round 4): blocks of the slab are handed to callers that work on other streams -- torch's, the upload and
+    // communication streams of the library, any hipStreamNonBlocking one -- and a fill still in flight on this stream could
+    // zero a parameter block or a scratch range after its owner wrote it.  Taking a slab is set-up work either way.
+    if (hipMemsetAsync(p, 0, bytes, st) == hipSuccess) (void)hipStreamSynchronize(st);
 }
 
 void * host_take(size_t bytes, hipStream_t) { return std::malloc(bytes); }

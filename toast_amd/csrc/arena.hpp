@@ -35,7 +35,7 @@ struct ArenaStats {
     int64_t slab_frees = 0;       // slabs given back (trim / destroy)
     double malloc_ms = 0.0;       // wall time inside those hipMalloc calls
     double max_malloc_ms = 0.0;   // ... the longest one
-    double touch_ms = 0.0;        // host time spent enqueueing the first-touch fills (the fills themselves are asynchronous)
+    double touch_ms = 0.0;        // host time spent in the first-touch fills (waited for: blocks go to callers on any stream)
     int64_t allocs = 0;           // blocks handed out
     int64_t releases = 0;
     int64_t failed = 0;           // requests that could not be served
@@ -46,7 +46,7 @@ struct ArenaStats {
 struct ArenaBackend {
     void * (*take)(size_t bytes, hipStream_t st);             // nullptr on failure (st: where measuring passes run)
     void (*give)(void * p);
-    void (*touch)(void * p, size_t bytes, hipStream_t st);    // first-touch fill, enqueued on st (may be a no-op)
+    void (*touch)(void * p, size_t bytes, hipStream_t st);    // first-touch fill on st, complete on return (may be a no-op)
 };
 const ArenaBackend & hip_backend();          // hipMalloc
 const ArenaBackend & hip_interleaved_backend();   // rank-interleaved slabs (vmm_slab.cpp) when they can be had, else hipMalloc
@@ -62,7 +62,7 @@ public:
     ~Arena() = default;   // (process exit: the driver reclaims the slabs; nothing may call HIP from a static destructor)
 
     // nullptr when neither a free range nor a new slab can hold the request.  `stream`: where the first-touch fill
-    // of a new slab is enqueued (work that uses the block must be ordered after it: same stream, or an event).
+    // of a new slab runs (waited for before the block is handed out: its user may work on any stream).
     // grow = false: only from the free ranges of the slabs already held
     void * alloc(size_t nbytes, hipStream_t stream, bool grow = true);
     // A block that lies inside ONE stripe of width `stripe` whose index (offset / stripe within its slab) has the given

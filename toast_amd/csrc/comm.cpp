@@ -156,6 +156,10 @@ Shard shard_of(int64_t n_px, int size, int rank) {
 Shard shard_of(int64_t n_px) { return shard_of(n_px, g_size, g_rank); }
 
 void peer_release();      // (mode "peer", below: its exchange buffers go before the communicator does)
+bool peer_error_pending();
+// mode "peer*": a sum of doubles goes through the exchange buffers like the maps do (so that the headline step of
+// bench.py A/Bs the exchange, not only the owner-computes pass); anything else: false, the caller uses RCCL
+bool peer_allreduce(void * d_buf, int64_t count, int dtype, int op, hipStream_t st);
 
 // `work` = the buffer the two ring halves run on: the map itself when the pixels divide evenly, else a zero-padded
 // scratch copy of per * size pixels (kScratchCommA / B of the manager's grow-only scratch buffers).
@@ -237,12 +241,17 @@ int toast_hip_comm_info(int * n_ranks, int * rank, int * rccl_version) {
 int toast_hip_comm_destroy(void) {
     return guarded([&] {
         if (g_comm == nullptr) return;
+        const bool gave_up = peer_error_pending();
         peer_release();
         ncclComm_t c = g_comm;
         g_comm = nullptr;
         g_size = 0;
         g_rank = -1;
         check(rccl().comm_destroy(c), "ncclCommDestroy");
+        if (gave_up) {
+            throw Error(TOAST_HIP_ERR_DEVICE, "HipComm:  mode 'peer:flags': a wait for a peer's flag gave up in the last reduction "
+                                              "before the communicator was destroyed; its maps were not valid");
+        }
     });
 }
 
@@ -250,6 +259,7 @@ int toast_hip_comm_allreduce_dev(void * d_buf, int64_t count, int dtype, int op,
     return guarded([&] {
         if (count <= 0) return;
         const DType t = dtype_of(dtype);
+        if (peer_allreduce(d_buf, count, dtype, op, as_stream(stream))) return;
         check(rccl().all_reduce(d_buf, d_buf, (size_t)count, t.nccl, op_of(op), comm(), as_stream(stream)), "ncclAllReduce");
     });
 }
@@ -301,12 +311,13 @@ int toast_hip_comm_pixel_shard(int64_t n_px, int64_t * first, int64_t * count) {
 
 // ------------------------------------------------------------------------------------
 // map <- [C .] sum over ranks (map): the middle of every PCG iteration and the finalisation of a binned map.
-// Three ways to do it, switchable at run time so that a multi-GPU run can compare them on its own data
+// Four ways to do it, switchable at run time so that a multi-GPU run can compare them on its own data
 // (TOAST_HIP_COMM_MODE / toast_hip_comm_set_mode; bench.py reports all of them per N):
 //   owner      (default) reduce-scatter of the pixel shards, cov_apply_diag on the owned shard, all-gather -- all on the
 //              caller's stream.  2 (N-1)/N map volumes over the links, the multiplication done once per pixel.
-//   sliced:S   the same in S pixel slices dealt alternately to two side streams: the reduce-scatter of slice k + 1 runs
-//              while the owners multiply slice k and gather it.  The caller's stream waits for both at the end.
+//              (Round 4 also had "sliced:S", the same in S pixel slices on two side streams of this ONE communicator.  RCCL
+//              orders the operations of a communicator, so the reduce-scatter of slice k + 1 never ran under the all-gather
+//              of slice k, and two ring phases on the same links would not gain from it anyway: removed.)
 //   allreduce  one all-reduce of the whole map, then every rank multiplies the whole map (what sync_allreduce +
 //              covariance_apply do; the reference's default, pixels.py:710-780).
 //   peer       no RCCL on the data path: xGMI is a full mesh of point-to-point links, so every rank WRITES the seven
@@ -325,8 +336,8 @@ int toast_hip_comm_pixel_shard(int64_t n_px, int64_t * first, int64_t * count) {
 namespace {
 
 struct CommMode {
-    int kind = 0;      // 0 owner, 1 sliced, 2 allreduce, 3 peer
-    int slices = 4;
+    int kind = 0;      // 0 owner, 2 allreduce, 3 peer
+    int slices = 0;    // peer: 1 = the barriers are device flags
 };
 CommMode g_mode;
 bool g_mode_read = false;
@@ -344,14 +355,7 @@ CommMode parse_mode(const char * text) {
         m.slices = (v == "peer") ? 0 : 1;      // 1: the two barriers are device flags, not RCCL calls
         return m;
     }
-    if (v.rfind("sliced", 0) == 0) {
-        m.kind = 1;
-        const size_t c = v.find(':');
-        if (c != std::string::npos) m.slices = std::atoi(v.c_str() + c + 1);
-        if (m.slices < 2 || m.slices > 64) fail_arg("HipComm:  sliced:S needs 2 <= S <= 64");
-        return m;
-    }
-    fail_arg("HipComm:  unknown mode '" + v + "' (owner | sliced[:S] | allreduce | peer[:flags])");
+    fail_arg("HipComm:  unknown mode '" + v + "' (owner | allreduce | peer[:flags])");
 }
 
 const CommMode & mode() {
@@ -362,19 +366,6 @@ const CommMode & mode() {
     return g_mode;
 }
 
-struct SideStreams {
-    hipStream_t st[2] = {nullptr, nullptr};
-    hipEvent_t start = nullptr, done[2] = {nullptr, nullptr};
-    void prepare() {
-        if (st[0] != nullptr) return;
-        for (int k = 0; k < 2; ++k) {
-            TH_HIP(hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking));
-            TH_HIP(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
-        }
-        TH_HIP(hipEventCreateWithFlags(&start, hipEventDisableTiming));
-    }
-};
-SideStreams g_side;
 
 // owner-computes pass over the pixels [px0, px0 + n) of the map, on `st`
 void reduce_apply_range(int64_t px0, int64_t n, int64_t nnz, const double * d_cov, double * d_map, int reduce, int slot,
@@ -426,42 +417,100 @@ __device__ inline void peer_store(double * p, double v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// W = 8: one double per lane and access, system-scope atomic loads / stores (above).  W = 16 (TOAST_HIP_COMM_PEER_WIDTH=16 /
+// toast_hip_comm_set_peer_width): two doubles per lane as ONE ordinary 16-byte access (non-temporal: streamed past the
+// caches) -- the request width every other kernel of the library uses; what orders it against the other agents are the
+// kernel boundaries and the barriers between the phases.  Needs even slices (per_v % 2 == 0) and 16-byte aligned maps;
+// anything else takes W = 8.  Same values either way (plain copies; the sum keeps its rank order).
+typedef double peer_d2 __attribute__((ext_vector_type(2)));
+template <int W>
+struct PeerAccess;
+template <>
+struct PeerAccess<8> {
+    typedef double T;
+    static __device__ inline T load_remote(const T * p) { return peer_load(p); }
+    static __device__ inline void store_remote(T * p, T v) { peer_store(p, v); }
+};
+template <>
+struct PeerAccess<16> {
+    typedef peer_d2 T;
+    static __device__ inline T load_remote(const T * p) { return __builtin_nontemporal_load(p); }
+    static __device__ inline void store_remote(T * p, T v) { __builtin_nontemporal_store(v, p); }
+};
+
+template <int W>
 __global__ void __launch_bounds__(256) k_peer_push(const double * __restrict__ map, PeerTable inbox, int rank, int64_t per_v,
                                                    int64_t n_v) {
+    typedef typename PeerAccess<W>::T T;
+    constexpr int E = W / 8;
     const int s = blockIdx.y;          // owner of the slice
     if (s == rank) return;
     const int64_t first = (int64_t)s * per_v;
     int64_t cnt = n_v - first;
     if (cnt <= 0) return;
     if (cnt > per_v) cnt = per_v;
-    const double * src = map + first;
-    double * dst = inbox.p[s] + (int64_t)rank * per_v;
+    const T * src = reinterpret_cast<const T *>(map + first);
+    T * dst = reinterpret_cast<T *>(inbox.p[s] + (int64_t)rank * per_v);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) peer_store(dst + i, src[i]);
+    const int64_t whole = cnt / E;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < whole; i += stride) {
+        PeerAccess<W>::store_remote(dst + i, src[i]);
+    }
+    if (E > 1 && (cnt % E) != 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+        peer_store(inbox.p[s] + (int64_t)rank * per_v + cnt - 1, map[first + cnt - 1]);
+    }
 }
 
+template <int W>
 __global__ void __launch_bounds__(256) k_peer_sum(double * __restrict__ mine, const double * inbox, int size, int rank,
                                                   int64_t per_v, int64_t cnt) {
+    typedef typename PeerAccess<W>::T T;
+    constexpr int E = W / 8;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) {
+    const int64_t whole = cnt / E;
+    T * m = reinterpret_cast<T *>(mine);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < whole; i += stride) {
+        T acc = (rank == 0) ? m[i] : PeerAccess<W>::load_remote(reinterpret_cast<const T *>(inbox) + i);
+        for (int p = 1; p < size; ++p) {
+            acc += (p == rank) ? m[i] : PeerAccess<W>::load_remote(reinterpret_cast<const T *>(inbox + (int64_t)p * per_v) + i);
+        }
+        m[i] = acc;
+    }
+    if (E > 1 && (cnt % E) != 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = cnt - 1;
         double acc = (rank == 0) ? mine[i] : peer_load(inbox + i);
         for (int p = 1; p < size; ++p) acc += (p == rank) ? mine[i] : peer_load(inbox + (int64_t)p * per_v + i);
         mine[i] = acc;
     }
 }
 
+template <int W>
 __global__ void __launch_bounds__(256) k_peer_pull(double * __restrict__ map, PeerTable out, int rank, int64_t per_v,
                                                    int64_t n_v) {
+    typedef typename PeerAccess<W>::T T;
+    constexpr int E = W / 8;
     const int s = blockIdx.y;
     if (s == rank) return;
     const int64_t first = (int64_t)s * per_v;
     int64_t cnt = n_v - first;
     if (cnt <= 0) return;
     if (cnt > per_v) cnt = per_v;
-    const double * src = out.p[s];
-    double * dst = map + first;
+    const T * src = reinterpret_cast<const T *>(out.p[s]);
+    T * dst = reinterpret_cast<T *>(map + first);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += stride) dst[i] = peer_load(src + i);
+    const int64_t whole = cnt / E;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < whole; i += stride) {
+        dst[i] = PeerAccess<W>::load_remote(src + i);
+    }
+    if (E > 1 && (cnt % E) != 0 && blockIdx.x == 0 && threadIdx.x == 0) map[first + cnt - 1] = peer_load(out.p[s] + cnt - 1);
+}
+
+// a wait that gave up (k_peer_wait) leaves garbage in the map: make it unmistakable -- NaN in the first values -- for
+// whoever uses the result before the host has seen the error word
+__global__ void k_peer_poison(double * __restrict__ map, int64_t n_v, const int * error) {
+    if (__hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) return;
+    const int64_t i = threadIdx.x;
+    if (i < n_v) map[i] = __builtin_nan("");
 }
 
 struct FlagTable {
@@ -504,6 +553,7 @@ struct PeerExchange {
     char * peer[kPeerMax] = {};        // everybody's (peer[g_rank] == base)
     unsigned char * d_words = nullptr; // device words: [0, 64 * kPeerMax) the handles, then the barrier / agreement word
     int64_t reductions = 0, establishments = 0;
+    int width = 0;                     // bytes per lane and access of push / sum / pull: 8 or 16 (0: not read yet)
     size_t out_bytes() const { return ((size_t)cap_v * sizeof(double) + 255) & ~(size_t)255; }
     double * out_of(int r) const { return reinterpret_cast<double *>(peer[r]); }
     double * inbox_of(int r) const { return reinterpret_cast<double *>(peer[r] + out_bytes()); }
@@ -667,6 +717,14 @@ void peer_establish(int64_t need_v, hipStream_t st) {
     ++g_peer.establishments;
 }
 
+bool peer_error_pending() {
+    if (g_peer.h_error == nullptr) return false;
+    (void)hipDeviceSynchronize();
+    const bool e = *g_peer.h_error != 0;
+    *g_peer.h_error = 0;
+    return e;
+}
+
 void peer_release() {
     peer_release_flags();
     peer_teardown(nullptr);
@@ -694,18 +752,31 @@ void peer_reduce_apply(int64_t n_px, int64_t nnz, const double * d_cov, double *
     const unsigned long long epoch = ++g_peer.epoch;
     const unsigned gx = (unsigned)std::min<int64_t>((per_v + 255) / 256, 4096);
     const dim3 grid(gx > 0 ? gx : 1, (unsigned)g_size);
+    if (g_peer.width == 0) {
+        const char * e = std::getenv("TOAST_HIP_COMM_PEER_WIDTH");
+        g_peer.width = (e != nullptr && std::atoi(e) == 16) ? 16 : 8;
+    }
+    const bool wide = g_peer.width == 16 && (per_v % 2) == 0 && (reinterpret_cast<uintptr_t>(d_map) % 16) == 0;
     PeerTable tab;
     if (reduce) {
         for (int r = 0; r < kPeerMax; ++r) tab.p[r] = r < g_size ? g_peer.inbox_of(r) : nullptr;
-        hipLaunchKernelGGL(k_peer_push, grid, dim3(256), 0, st, d_map, tab, g_rank, per_v, n_v);
+        if (wide) hipLaunchKernelGGL(k_peer_push<16>, grid, dim3(256), 0, st, d_map, tab, g_rank, per_v, n_v);
+        else hipLaunchKernelGGL(k_peer_push<8>, grid, dim3(256), 0, st, d_map, tab, g_rank, per_v, n_v);
         TH_HIP(hipGetLastError());
-        if (flags) peer_flag_barrier(0, epoch, st);
-        else peer_barrier(st);
-        if (cnt_v > 0) {
-            const unsigned gs = (unsigned)std::min<int64_t>((cnt_v + 255) / 256, 8192);
-            hipLaunchKernelGGL(k_peer_sum, dim3(gs), dim3(256), 0, st, mine, g_peer.inbox_of(g_rank), g_size, g_rank, per_v, cnt_v);
-            TH_HIP(hipGetLastError());
+    }
+    // The first barrier is passed in EVERY call, also when nothing is summed (reduce = 0): it is what keeps a fast rank
+    // from rewriting its `out` below while a slower peer still pulls the previous call's result from it (ADVICE round 4:
+    // without it a reduce = 0 call after any other call could hand that peer slices of two different maps).
+    if (flags) peer_flag_barrier(0, epoch, st);
+    else peer_barrier(st);
+    if (reduce && cnt_v > 0) {
+        const unsigned gs = (unsigned)std::min<int64_t>((cnt_v + 255) / 256, 8192);
+        if (wide) {
+            hipLaunchKernelGGL(k_peer_sum<16>, dim3(gs), dim3(256), 0, st, mine, g_peer.inbox_of(g_rank), g_size, g_rank, per_v, cnt_v);
+        } else {
+            hipLaunchKernelGGL(k_peer_sum<8>, dim3(gs), dim3(256), 0, st, mine, g_peer.inbox_of(g_rank), g_size, g_rank, per_v, cnt_v);
         }
+        TH_HIP(hipGetLastError());
     }
     if (cnt_v > 0) {
         if (d_cov != nullptr) {
@@ -717,9 +788,24 @@ void peer_reduce_apply(int64_t n_px, int64_t nnz, const double * d_cov, double *
     if (flags) peer_flag_barrier(1, epoch, st);
     else peer_barrier(st);
     for (int r = 0; r < kPeerMax; ++r) tab.p[r] = r < g_size ? g_peer.out_of(r) : nullptr;
-    hipLaunchKernelGGL(k_peer_pull, grid, dim3(256), 0, st, d_map, tab, g_rank, per_v, n_v);
+    if (wide) hipLaunchKernelGGL(k_peer_pull<16>, grid, dim3(256), 0, st, d_map, tab, g_rank, per_v, n_v);
+    else hipLaunchKernelGGL(k_peer_pull<8>, grid, dim3(256), 0, st, d_map, tab, g_rank, per_v, n_v);
+    if (flags && g_peer.h_error != nullptr) {
+        hipLaunchKernelGGL(k_peer_poison, dim3(1), dim3(64), 0, st, d_map, n_v, g_peer.h_error);
+    }
     TH_HIP(hipGetLastError());
     ++g_peer.reductions;
+}
+
+bool peer_allreduce(void * d_buf, int64_t count, int dtype, int op, hipStream_t st) {
+    const CommMode & m = mode();
+    // (maps, not the PCG's scalar sums: those stay one small RCCL call)
+    if (m.kind != 3 || dtype != TOAST_HIP_COMM_F64 || op != TOAST_HIP_COMM_SUM || g_size < 2 || g_size > kPeerMax ||
+        count < (int64_t)4096 * g_size) {
+        return false;
+    }
+    peer_reduce_apply(count, 1, nullptr, static_cast<double *>(d_buf), 1, m.slices != 0, st);
+    return true;
 }
 
 }  // namespace
@@ -728,8 +814,28 @@ extern "C" {
 
 int toast_hip_comm_set_mode(const char * text) {
     return guarded([&] {
-        g_mode = parse_mode(text);
+        const CommMode m = parse_mode(text);
+        g_mode = m;
         g_mode_read = true;
+        peer_check_error();     // a wait of the mode that is being left may have given up in its last reduction
+    });
+}
+
+int toast_hip_comm_set_peer_width(int bytes) {
+    return guarded([&] {
+        if (bytes != 8 && bytes != 16) fail_arg("HipComm:  the peer exchange moves 8 or 16 bytes per lane");
+        g_peer.width = bytes;
+    });
+}
+
+// The error word of mode "peer:flags" (a wait that gave up), raised where the host next synchronises with the stream the
+// reduction ran on -- not only at the start of the next reduction, which may never come (the last binned map, the last
+// PCG iteration): toast_hip_comm_check(), toast_hip_comm_set_mode(), toast_hip_comm_destroy().
+int toast_hip_comm_check(void * stream) {
+    return guarded([&] {
+        if (g_peer.h_error == nullptr) return;
+        TH_HIP(hipStreamSynchronize(as_stream(stream)));
+        peer_check_error();
     });
 }
 
@@ -746,8 +852,7 @@ int toast_hip_comm_get_mode(char * text, size_t len) {
         const CommMode & m = mode();
         const std::string v = m.kind == 0   ? "owner"
                               : m.kind == 2 ? "allreduce"
-                              : m.kind == 3 ? (m.slices ? "peer:flags" : "peer")
-                                            : "sliced:" + std::to_string(m.slices);
+                                            : (m.slices ? "peer:flags" : "peer");
         if (text == nullptr || len < v.size() + 1) fail_arg("HipComm:  mode buffer too small");
         std::memcpy(text, v.c_str(), v.size() + 1);
     });
@@ -773,24 +878,6 @@ int toast_hip_comm_map_reduce_apply_dev(int64_t n_px, int64_t nnz, const double 
         }
         if (m.kind == 3) {
             peer_reduce_apply(n_px, nnz, d_cov, d_map, reduce, m.slices != 0, st);
-            return;
-        }
-        if (m.kind == 1 && n_px >= (int64_t)m.slices * g_size * 64) {
-            // slices of a whole number of pixels per rank (no padding), the remainder goes to the last one
-            const int64_t per_slice = n_px / m.slices / g_size * g_size;
-            g_side.prepare();
-            TH_HIP(hipEventRecord(g_side.start, st));
-            for (int k = 0; k < 2; ++k) TH_HIP(hipStreamWaitEvent(g_side.st[k], g_side.start, 0));
-            for (int k = 0; k < m.slices; ++k) {
-                const int64_t px0 = (int64_t)k * per_slice;
-                const int64_t n = (k == m.slices - 1) ? n_px - px0 : per_slice;
-                // (only the last slice can be uneven: one user of the padded scratch copy)
-                reduce_apply_range(px0, n, nnz, d_cov, d_map, reduce, Manager::kScratchCommA, g_side.st[k & 1]);
-            }
-            for (int k = 0; k < 2; ++k) {
-                TH_HIP(hipEventRecord(g_side.done[k], g_side.st[k]));
-                TH_HIP(hipStreamWaitEvent(st, g_side.done[k], 0));
-            }
             return;
         }
         reduce_apply_range(0, n_px, nnz, d_cov, d_map, reduce, Manager::kScratchCommA, st);
