@@ -114,16 +114,23 @@ int toast_hip_arena_reserve(size_t bytes);
 /* The part of the arena that serves streamed blocks and scatter targets (below): make it hold a FREE RANGE of at least
  * `bytes` (a new zone-interleaved slab of that size when it has none). */
 int toast_hip_arena_reserve_streamed(size_t bytes);
+/* Where [device_ptr, device_ptr + bytes) lies: interleaved = 1 when inside a zone-interleaved slab, and then how many of
+ * the 1 GB chunks it touches are of the read-mostly slabs' zone / of the other zone (csrc/vmm_slab.cpp: pattern
+ * P Q Q P ...).  Waits for a slab that toast_hip_accel_assign_device is still building. */
+int toast_hip_arena_block_zone(const void * device_ptr, size_t bytes, int * interleaved, int * chunks_own_zone,
+                               int * chunks_other_zone);
 /* The sub-allocation logic exercised on HOST memory (no device needed): n_ops random allocations / releases with the
  * bookkeeping and the contents of every live block checked after each step.  0 = sound. */
 int toast_hip_arena_selftest(uint64_t seed, int n_ops, size_t granule, size_t slab_bytes, size_t max_block);
 /* Raw device memory from the arena (flags = -1, also -2: a read-mostly block; -3 = a STREAMED block: a timestream that
- * sweeps read and write, placed in a slab whose 1 GB chunks alternate between two HBM zones -- such sweeps run at 6.1
- * instead of 5.1 TB/s there; -4 = a SCATTER TARGET: a map or amplitude vector that kernels add to with atomics, placed
- * inside one chunk of the zone the read-mostly blocks are NOT in -- build_noise_weighted 5.2 instead of 5.8 ms;
- * csrc/vmm_slab.cpp, profiles/r04_a.  -3 / -4 need toast_hip_arena_reserve_streamed and are read-mostly blocks
- * without it), a plain hipMalloc (0) or explicit hipExtMallocWithFlags flags (4 = physically contiguous): what bench.py and the solver's packed cache use, so that they get the blocks the
- * operators get.  Blocks from flags < 0 are released with toast_hip_device_free / toast_hip_device_release. */
+ * sweeps read and write, placed in a slab whose 1 GB chunks come from two HBM zones in the pattern P Q Q P ... so that its
+ * rows are spread over both -- such sweeps run at 6.1 instead of 5.1 TB/s there; -4 = a SCATTER TARGET: a map or amplitude
+ * vector that kernels add to with atomics, placed inside one Q Q run (up to 2 GB in the zone the read-mostly blocks are NOT
+ * in) -- build_noise_weighted 5.2 instead of 5.8 ms; csrc/vmm_slab.cpp, profiles/r04_a.  The slab for -3 / -4 is reserved
+ * by toast_hip_accel_assign_device (TOAST_HIP_ARENA_STREAM_GB) or toast_hip_arena_reserve_streamed; blocks that do not
+ * fit it are read-mostly blocks), a plain hipMalloc (0) or explicit hipExtMallocWithFlags flags (4 = physically
+ * contiguous): what bench.py and the solver's packed cache use, so that they get the blocks the operators get.  Blocks
+ * from flags < 0 are released with toast_hip_device_free / toast_hip_device_release. */
 int toast_hip_device_malloc(size_t nbytes, int flags, void ** out);
 /* Time (ms) of a read + write pass over [p, p + bytes) with the timestream kernels' access pattern (1024 rows in
  * flight): placement experiments on ranges of arena blocks. */

@@ -378,6 +378,7 @@ def test_arena_serves_every_block_without_the_driver():
     env = dict(os.environ)
     for key in ("TOAST_HIP_ALLOC", "TOAST_HIP_ARENA_RESERVE_GB", "TOAST_HIP_ARENA_SLAB_GB"):
         env.pop(key, None)
+    env["TOAST_HIP_ARENA_STREAM_GB"] = "0"        # (the slab counts below are those of the plain arenas)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
@@ -422,6 +423,7 @@ def test_arena_grows_by_slabs():
     for key in ("TOAST_HIP_ALLOC", "TOAST_HIP_ARENA_RESERVE_GB"):
         env.pop(key, None)
     env["TOAST_HIP_ARENA_SLAB_GB"] = "1"
+    env["TOAST_HIP_ARENA_STREAM_GB"] = "0"        # (the slab counts below are those of the plain arenas)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
@@ -463,6 +465,7 @@ def test_second_workflow_run_allocates_nothing_from_the_driver():
     env = dict(os.environ)
     for key in ("TOAST_HIP_ALLOC", "TOAST_HIP_ARENA_RESERVE_GB", "TOAST_HIP_ARENA_SLAB_GB"):
         env.pop(key, None)
+    env["TOAST_HIP_ARENA_STREAM_GB"] = "0"        # (the slab counts below are those of the plain arenas)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900, cwd=root)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
@@ -472,3 +475,52 @@ def test_second_workflow_run_allocates_nothing_from_the_driver():
     assert int(f[5]) == 0 and int(f[6]) == 0                  # and nothing went around the arena
     assert int(f[7]) > 20                                     # (the second run did allocate its blocks -- from the slabs)
     assert f[8] == "True"
+
+
+def test_reference_call_sequence_gets_the_zone_placement():
+    """a caller that only speaks the reference's accel_* API -- accel_assign_device with the
+    reference's token mem_gb, accel_create(array, name), kernels -- gets the zone placement: assign_device reserves the
+    interleaved slab itself (on a thread of its own; whoever needs it waits), a [detector][sample] float64 array lands in
+    it with chunks of both zones under it, and a map created as a scatter target lies inside ONE run of chunks of the
+    other zone, also when it is larger than a chunk (the 1.2 GB map of Nside 2048 IQU)."""
+    import subprocess
+    import sys
+    import textwrap
+
+    code = textwrap.dedent("""
+        import ctypes as C, numpy as np
+        from toast_amd import _libtoast_hip as m, capi
+        m.accel_assign_device(1, 0, 1.0, False)
+        tod = np.zeros((200, 1500000), dtype=np.float64)          # 2.4 GB
+        small = np.zeros((64, 3000000), dtype=np.float64)          # 1.5 GB: too small to cover both zones wherever it lies
+        zmap = np.zeros((16384, 3072, 3), dtype=np.float64)       # 1.2 GB: the Nside 2048 IQU map
+        pix = np.zeros((200, 1500000), dtype=np.int64)
+        m.accel_create(tod, "signal")
+        m.accel_create(small, "signal2")
+        m.accel_create(pix, "pixels")
+        m.accel_create(zmap, "zmap", 2)
+        st = capi.alloc_stats()
+        where = {}
+        for name, arr in (("tod", tod), ("small", small), ("zmap", zmap), ("pix", pix)):
+            p = C.c_void_p(0)
+            assert capi.real_lib().toast_hip_accel_device_ptr(C.c_void_p(arr.ctypes.data), C.byref(p)) == 0
+            where[name] = capi.arena_block_zone(p.value, arr.nbytes)
+        print("ZONES", st["interleaved_slabs"], st["chunks"], st["chunks_other_zone"], where)
+        for arr, name in ((tod, "signal"), (small, "signal2"), (pix, "pixels"), (zmap, "zmap")):
+            m.accel_delete(arr, name)
+    """)
+    env = dict(os.environ)
+    for key in ("TOAST_HIP_ALLOC", "TOAST_HIP_ARENA_RESERVE_GB", "TOAST_HIP_ARENA_STREAM_GB", "TOAST_HIP_ARENA_INTERLEAVE",
+                "TOAST_HIP_ARENA_BUILDER"):
+        env.pop(key, None)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("ZONES")][0]
+    f = line.split(None, 4)
+    assert int(f[1]) >= 1 and int(f[2]) >= 8, line
+    where = eval(f[4])
+    assert where["tod"][0] and where["tod"][1] >= 1 and where["tod"][2] >= 1, line       # in the slab, rows in both zones
+    assert where["small"][0] and where["small"][1] >= 1 and where["small"][2] >= 1, line
+    assert where["zmap"][0] and where["zmap"][1] == 0 and where["zmap"][2] in (1, 2), line  # one run of the other zone
+    assert not where["pix"][0], line                                                         # read-mostly: a plain slab

@@ -326,6 +326,15 @@ def arena_reserve(nbytes, streamed=False):
     _check(fn(C.c_size_t(int(nbytes))))
 
 
+def arena_block_zone(device_ptr, nbytes):
+    """(inside a zone-interleaved slab, chunks of the read-mostly zone it touches, chunks of the other zone)
+    (toast_hip_arena_block_zone)."""
+    a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+    _check(real_lib().toast_hip_arena_block_zone(C.c_void_p(int(device_ptr)), C.c_size_t(int(nbytes)), C.byref(a), C.byref(b),
+                                                 C.byref(c)))
+    return bool(a.value), int(b.value), int(c.value)
+
+
 def arena_selftest(seed, n_ops, granule, slab_bytes, max_block):
     """The arena's sub-allocation logic on host memory (toast_hip_arena_selftest); raises on an inconsistency."""
     _check(real_lib().toast_hip_arena_selftest(C.c_uint64(int(seed)), C.c_int(int(n_ops)), C.c_size_t(int(granule)),

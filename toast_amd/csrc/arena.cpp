@@ -153,6 +153,31 @@ void * Arena::alloc_striped(size_t nbytes, size_t stripe, int parity) {
     return nullptr;
 }
 
+void * Arena::alloc_placed(size_t nbytes,
+                           const std::function<size_t(const char * base, size_t lo, size_t hi, size_t need)> & place) {
+    const size_t need = round_up(nbytes ? nbytes : 1);
+    std::lock_guard<std::mutex> lock(mutex_);
+    for (Slab & s : slabs_) {
+        for (auto it = s.free.begin(); it != s.free.end(); ++it) {
+            const size_t off = it->first, len = it->second;
+            if (len < need) continue;
+            size_t lo = place(s.base, off, off + len, need);
+            if (lo == SIZE_MAX) continue;
+            lo = (lo + granule_ - 1) / granule_ * granule_;
+            if (lo < off || lo + need > off + len) continue;
+            s.free.erase(it);
+            if (lo > off) s.free[off] = lo - off;
+            if (off + len > lo + need) s.free[lo + need] = off + len - (lo + need);
+            s.live[lo] = need;
+            st_.used_bytes += need;
+            if (st_.used_bytes > st_.peak_used_bytes) st_.peak_used_bytes = st_.used_bytes;
+            ++st_.allocs;
+            return s.base + lo;
+        }
+    }
+    return nullptr;
+}
+
 bool Arena::release(void * p) {
     std::lock_guard<std::mutex> lock(mutex_);
     const char * c = static_cast<const char *>(p);
@@ -253,6 +278,13 @@ void Arena::destroy() {
 size_t Arena::free_bytes() const {
     std::lock_guard<std::mutex> lock(mutex_);
     return st_.slab_bytes - st_.used_bytes;
+}
+
+std::vector<const char *> Arena::slab_bases() const {
+    std::lock_guard<std::mutex> lock(mutex_);
+    std::vector<const char *> out;
+    for (const Slab & s : slabs_) out.push_back(s.base);
+    return out;
 }
 
 size_t Arena::capacity() const {

@@ -19,6 +19,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <string>
@@ -70,6 +71,11 @@ public:
     // -- the target of a scatter -- belongs into the zone the read-only arrays are NOT in.  Never grows the arena;
     // nullptr when no such range is free.
     void * alloc_striped(size_t nbytes, size_t stripe, int parity);
+    // A block whose position inside a free range the caller chooses: place(slab base, lo, hi, need) returns the offset
+    // (lo <= offset, offset + need <= hi; offsets are relative to the slab) or SIZE_MAX when [lo, hi) has no place for
+    // it.  Used for blocks that belong into particular chunks of a zone-interleaved slab (runtime.cpp: scatter targets
+    // inside a run of chunks of the other zone, small streamed blocks astride a zone boundary).  Never grows the arena.
+    void * alloc_placed(size_t nbytes, const std::function<size_t(const char * base, size_t lo, size_t hi, size_t need)> & place);
     // false when p is not a live block of this arena
     bool release(void * p);
     bool owns(const void * p) const;
@@ -85,6 +91,7 @@ public:
     void destroy();
     size_t free_bytes() const;
     size_t capacity() const;
+    std::vector<const char *> slab_bases() const;
     size_t largest_free() const;
     ArenaStats stats() const;
     // consistency of the bookkeeping (ranges tile every slab, free ranges are merged, counters add up); "" if sound

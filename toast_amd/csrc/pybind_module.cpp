@@ -257,11 +257,19 @@ PYBIND11_MODULE(_libtoast_hip, m) {
         check(toast_hip_accel_present(b.ptr, b.nbytes, &r));
         return r != 0;
     }, py::arg("data"), py::arg("name"));
+    // kind (an extension of the reference's signature, accelerator.cpp:349-377): what the array is to the kernels, which
+    // decides where in HBM the library puts it (include/toast_hip.h, toast_hip_accel_create_kind): 0 read-mostly, 1 a
+    // timestream that sweeps read and write, 2 the target of a scatter.  Left out (-1), a two-dimensional float64 array
+    // -- [detector][sample] -- counts as a timestream, everything else as read-mostly.
     m.def("accel_create", [](py::buffer data, std::string name, int kind) {
+        if (kind < 0) {
+            const py::buffer_info info = data.request();
+            kind = (info.ndim == 2 && info.format == py::format_descriptor<double>::format()) ? 1 : 0;
+        }
         RawBuf b = accel_buf(data);
         check(kind != 0 ? toast_hip_accel_create_kind(b.ptr, b.nbytes, name.c_str(), kind)
                         : toast_hip_accel_create(b.ptr, b.nbytes, name.c_str()));
-    }, py::arg("data"), py::arg("name"), py::arg("kind") = 0);
+    }, py::arg("data"), py::arg("name"), py::arg("kind") = -1);
     m.def("accel_reset", [](py::buffer data, std::string name) {
         RawBuf b = accel_buf(data);
         check(toast_hip_accel_reset(b.ptr, b.nbytes, name.c_str()));

@@ -3,6 +3,8 @@
 #include "runtime.hpp"
 
 #include <chrono>
+#include <condition_variable>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -424,45 +426,6 @@ void Manager::clear() {
     ++generation_;
 }
 
-void Manager::assign_device(int node_procs, int node_rank, double mem_gb, bool disabled) {
-    // accelerator.cpp:236-246
-    if (node_procs < 1 || node_rank < 0) {
-        throw Error(TOAST_HIP_ERR_ARG,
-                    "HipManager:  must have at least one process per node with a rank >= 0");
-    }
-    if (node_rank >= node_procs) {
-        throw Error(TOAST_HIP_ERR_ARG, "HipManager:  node rank must be < number of node procs");
-    }
-    clear();
-    int n_dev = 0;
-    if (!disabled) {
-        if (hipGetDeviceCount(&n_dev) != hipSuccess) n_dev = 0;
-    }
-    if (n_dev == 0) {
-        if (device_ >= 0) drop_arenas();
-        device_ = -1;
-    } else {
-        // accelerator.cpp:276-281: ceil(node_procs / n_dev) processes share a device
-        int per = node_procs / n_dev;
-        if (n_dev * per < node_procs) per += 1;
-        const int dev = node_rank / per;
-        if (dev != device_) drop_arenas();    // (slabs belong to the device they were taken on)
-        device_ = dev;
-        TH_HIP(hipSetDevice(device_));
-        // accelerator.cpp:296-300 (dormant upstream): this process' share of `mem_gb` becomes the pool.  Here the
-        // pool can grow past it (a slab per request that does not fit), so the number is a reservation, not a limit:
-        // what it covers is taken from the driver -- and touched -- now instead of inside the first operators.
-        // TOAST_HIP_ARENA_RESERVE_GB overrides the argument (0 = reserve nothing).
-        double gb = mem_gb / (double)per;
-        if (const char * e = std::getenv("TOAST_HIP_ARENA_RESERVE_GB")) gb = std::atof(e);
-        if (gb > 0.0) reserve((size_t)(gb * 1073741824.0));
-        if (const char * e = std::getenv("TOAST_HIP_ARENA_STREAM_GB")) {
-            if (std::atof(e) > 0.0) reserve((size_t)(std::atof(e) * 1073741824.0), true);
-        }
-    }
-    assigned_ = true;
-}
-
 int Manager::device() {
     if (!assigned_) {
         throw Error(TOAST_HIP_ERR_DEVICE,
@@ -562,7 +525,144 @@ struct DirectStats {
 } g_direct;
 }  // namespace
 
+// The streamed slab is built where the process has time for it: on a thread of its own, started by assign_device
+// (a caller that only speaks the reference's accel_* API gets the zone placement, and no operator
+// waits for the search).  Whoever needs the slab -- a streamed / scatter block, statistics, a trim -- waits for it.
+struct Builder {
+    std::mutex m;
+    std::condition_variable cv;
+    bool running = false;
+    bool at_exit = false;
+} g_builder;
+
+void builder_wait() {
+    std::unique_lock<std::mutex> lock(g_builder.m);
+    g_builder.cv.wait(lock, [] { return !g_builder.running; });
+}
+
+void builder_start(size_t bytes, int dev) {
+    builder_wait();
+    {
+        std::lock_guard<std::mutex> lock(g_builder.m);
+        g_builder.running = true;
+        if (!g_builder.at_exit) {
+            g_builder.at_exit = true;
+            std::atexit([] { builder_wait(); });       // nothing of it may run into the runtime's own exit
+        }
+    }
+    std::thread([bytes, dev] {
+        hipStream_t st = nullptr;
+        if (hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess) {
+            try {
+                (void)stream_arena().reserve(bytes, st, true);
+            } catch (...) {
+            }
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamDestroy(st);
+        }
+        (void)hipGetLastError();
+        {
+            std::lock_guard<std::mutex> lock(g_builder.m);
+            g_builder.running = false;
+        }
+        g_builder.cv.notify_all();
+    }).detach();
+}
+
+// Where blocks go inside an interleaved slab (pattern P Q Q P ..., vmm_slot_other):
+// a scatter target inside ONE run of chunks of one class (other = the Q chunks) ...
+size_t place_in_class(const char * base, size_t lo, size_t hi, size_t need, bool other) {
+    size_t chunk = 0;
+    if (!vmm_slab_layout(base, &chunk) || chunk == 0) return SIZE_MAX;       // (a slab that fell back to a plain hipMalloc)
+    for (size_t k = lo / chunk; k * chunk < hi; ++k) {
+        if (vmm_slot_other(k) != other) continue;
+        size_t run_end = k;
+        while (vmm_slot_other(run_end) == other) ++run_end;
+        const size_t a = std::max(lo, k * chunk), b = std::min(hi, run_end * chunk);
+        if (b >= a + need) return a;
+        k = run_end - 1;
+    }
+    return SIZE_MAX;
+}
+
+// Which class of a slab's chunks the scatter targets belong into.  A slab built against the ends of the read-mostly
+// slab (vmm_slab.cpp, n_ref > 0): the Q chunks, by construction.  A slab that assign_device built before any array
+// existed knows two classes but not which of them the arrays will share a zone with: decided when the first scatter
+// target is asked for -- half a chunk of either class (free memory: the pass rewrites what it reads) against the first
+// and the last GB of the read-mostly slab; the class that runs slower with a reference lies in its zone.  Preferred: the
+// class that is clear of both ends; second: clear of the START (the arrays that feed the A^T scatter are created first).
+std::map<const void *, int> g_scatter_class;      // slab base -> 1 (Q) / 0 (P)
+
+int scatter_class_of(const char * base, hipStream_t st) {
+    auto it = g_scatter_class.find(base);
+    if (it != g_scatter_class.end()) return it->second;
+    size_t chunk = 0;
+    int n_ref = 0;
+    if (!vmm_slab_layout(base, &chunk, &n_ref)) return 1;
+    if (n_ref > 0) return g_scatter_class[base] = 1;
+    const size_t half = chunk / 2;
+    ZoneRefs refs = zone_references_take(half);
+    if (refs.last == nullptr) return 1;            // no read-mostly arrays yet: nothing to keep away from (not cached)
+    void * cand[2] = {stream_arena().alloc_placed(half, [](const char * b, size_t lo, size_t hi, size_t need) {
+                          return place_in_class(b, lo, hi, need, false);
+                      }),
+                      stream_arena().alloc_placed(half, [](const char * b, size_t lo, size_t hi, size_t need) {
+                          return place_in_class(b, lo, hi, need, true);
+                      })};
+    int pick = 1;
+    if (cand[0] != nullptr && cand[1] != nullptr) {
+        void * ref[2] = {refs.first, refs.last};
+        const int nr = (refs.first != nullptr && refs.first != refs.last) ? 2 : 1;
+        if (nr == 1) ref[0] = refs.last;
+        bool same[2][2] = {{false, false}, {false, false}};      // [class][reference]
+        try {
+            for (int k = 0; k < nr; ++k) {
+                double rate[2];
+                for (int c = 0; c < 2; ++c) {
+                    void * two[2] = {ref[k], cand[c]};
+                    const double ms = probe_stream_split_ms(two, 2, half, st);
+                    rate[c] = ms > 0.0 ? 1.0 / ms : 0.0;
+                }
+                if (rate[0] < rate[1] * (1.0 - 0.035)) same[0][k] = true;
+                if (rate[1] < rate[0] * (1.0 - 0.035)) same[1][k] = true;
+            }
+            const bool clear0 = !same[0][0] && !same[0][1], clear1 = !same[1][0] && !same[1][1];
+            if (clear1) pick = 1;
+            else if (clear0) pick = 0;
+            else pick = same[1][0] ? 0 : 1;          // neither is clear of both ends: away from the start (reference 0 = first GB)
+        } catch (const Error &) {
+            pick = 1;
+        }
+        g_scatter_class[base] = pick;
+        if (trace_enabled()) {
+            std::fprintf(stderr, "[toast_hip] scatter targets of the slab at %p go to its %s chunks (P same zone as start/end: %d/%d, Q: %d/%d)\n",
+                         (const void *)base, pick ? "Q" : "P", (int)same[0][0], (int)same[0][1], (int)same[1][0], (int)same[1][1]);
+        }
+    }
+    for (void * c : cand) {
+        if (c != nullptr) (void)stream_arena().release(c);
+    }
+    zone_references_release(refs);
+    return pick;
+}
+
+// ... and a streamed block that is too small to cover both zones wherever it lies (<= 2 chunks): astride a P | Q boundary
+size_t place_astride(const char * base, size_t lo, size_t hi, size_t need) {
+    size_t chunk = 0;
+    if (!vmm_slab_layout(base, &chunk) || chunk == 0) return SIZE_MAX;
+    for (size_t k = lo / chunk + 1; k * chunk < hi; ++k) {
+        if (vmm_slot_other(k) == vmm_slot_other(k - 1)) continue;          // boundary between slots k - 1 and k
+        const size_t edge = k * chunk, half = need / 2;
+        size_t a = edge > half ? edge - half : 0;
+        if (a < lo) a = lo;
+        if (a + need > hi) a = hi > need ? hi - need : SIZE_MAX;
+        if (a != SIZE_MAX && a >= lo && a < edge && a + need > edge) return a;
+    }
+    return SIZE_MAX;
+}
+
 AllocStats alloc_stats() {
+    builder_wait();
     AllocStats o;
     for (Arena * a : {&big_arena(), &small_arena(), &stream_arena()}) {
         const ArenaStats s = a->stats();
@@ -585,9 +685,70 @@ AllocStats alloc_stats() {
     return o;
 }
 
+void Manager::assign_device(int node_procs, int node_rank, double mem_gb, bool disabled) {
+    // accelerator.cpp:236-246
+    if (node_procs < 1 || node_rank < 0) {
+        throw Error(TOAST_HIP_ERR_ARG,
+                    "HipManager:  must have at least one process per node with a rank >= 0");
+    }
+    if (node_rank >= node_procs) {
+        throw Error(TOAST_HIP_ERR_ARG, "HipManager:  node rank must be < number of node procs");
+    }
+    clear();
+    int n_dev = 0;
+    if (!disabled) {
+        if (hipGetDeviceCount(&n_dev) != hipSuccess) n_dev = 0;
+    }
+    if (n_dev == 0) {
+        if (device_ >= 0) drop_arenas();
+        device_ = -1;
+    } else {
+        // accelerator.cpp:276-281: ceil(node_procs / n_dev) processes share a device
+        int per = node_procs / n_dev;
+        if (n_dev * per < node_procs) per += 1;
+        const int dev = node_rank / per;
+        if (dev != device_) drop_arenas();    // (slabs belong to the device they were taken on)
+        device_ = dev;
+        TH_HIP(hipSetDevice(device_));
+        // accelerator.cpp:296-300 (dormant upstream): this process' share of `mem_gb` becomes the pool.  Here the
+        // pool can grow past it (a slab per request that does not fit), so the number is a reservation, not a limit:
+        // what it covers is taken from the driver -- and touched -- now instead of inside the first operators.
+        // TOAST_HIP_ARENA_RESERVE_GB overrides the argument (0 = reserve nothing).
+        double gb = mem_gb / (double)per;
+        if (const char * e = std::getenv("TOAST_HIP_ARENA_RESERVE_GB")) gb = std::atof(e);
+        if (gb > 0.0) reserve((size_t)(gb * 1073741824.0));
+        // ... and the slab for the blocks that sweeps read AND write (timestreams) or scatter into (maps, amplitudes),
+        // built from chunks of two HBM zones (vmm_slab.cpp): a quarter of a real reservation + 2 GB -- 16 of the ~76 B per
+        // detector-sample that a map-making run holds are timestreams that get written (workflows/mapmaker_pcg.py) --, a
+        // sixteenth of the free memory with the reference's token mem_gb; between 8 and 48 GB.
+        // TOAST_HIP_ARENA_STREAM_GB overrides (0: none).  Built on a thread of its own unless TOAST_HIP_ARENA_BUILDER=0:
+        // device_alloc waits for it when it needs it.
+        double sgb = -1.0;
+        if (const char * e = std::getenv("TOAST_HIP_ARENA_STREAM_GB")) sgb = std::atof(e);
+        if (sgb < 0.0 && stream_arena_enabled() && !alloc_policy().plain) {
+            size_t f = 0, t = 0;
+            if (hipMemGetInfo(&f, &t) != hipSuccess) f = 0;
+            sgb = (gb >= 24.0) ? gb / 4.0 + 2.0 : (double)f / 1073741824.0 / 16.0 / (double)per;
+            if (sgb < 8.0) sgb = 8.0;
+            if (sgb > 48.0) sgb = 48.0;
+            if (sgb * 1073741824.0 > (double)f * 0.5) sgb = 0.0;     // a device that is nearly full: nothing
+        }
+        if (sgb > 0.0 && stream_arena_enabled() && !alloc_policy().plain && stream_arena().largest_free() < (size_t)(sgb * 1073741824.0)) {
+            const char * b = std::getenv("TOAST_HIP_ARENA_BUILDER");
+            if (b != nullptr && b[0] == '0') reserve((size_t)(sgb * 1073741824.0), true);
+            else builder_start((size_t)(sgb * 1073741824.0), device_);
+        }
+    }
+    assigned_ = true;
+}
+
 void * Manager::device_alloc(size_t nbytes, int kind) {
     if (nbytes == 0) nbytes = 16;
-    if (alloc_policy().plain) {
+    // The slabs belong to the device they were taken on (assign_device drops them on a change).  A caller of the *_dev
+    // entry points that switches devices on its own gets driver blocks of the device that is current.
+    int cur = device_;
+    if (device_ >= 0 && hipGetDevice(&cur) != hipSuccess) cur = device_;
+    if (alloc_policy().plain || (device_ >= 0 && cur != device_)) {
         void * p = nullptr;
         const auto t0 = std::chrono::steady_clock::now();
         const hipError_t e = hipMalloc(&p, nbytes);
@@ -601,14 +762,26 @@ void * Manager::device_alloc(size_t nbytes, int kind) {
         if (ms > g_direct.max_malloc_ms) g_direct.max_malloc_ms = ms;
         return p;
     }
+    if (kind != kBlockDefault && stream_arena_enabled()) builder_wait();
     if (kind != kBlockDefault && stream_arena_enabled() && stream_arena().capacity() > 0) {
-        // Streamed and scatter blocks come from what has been RESERVED for them (toast_hip_arena_reserve_streamed,
-        // TOAST_HIP_ARENA_STREAM_GB at assign_device): building an interleaved slab takes 0.3 s and more, which is set-up
-        // work -- never something an operator pays for in passing.  Without a reservation they are ordinary blocks.
+        // Streamed and scatter blocks come from what has been RESERVED for them (assign_device does, by default;
+        // toast_hip_arena_reserve_streamed, TOAST_HIP_ARENA_STREAM_GB): building an interleaved slab takes 0.3 s and more,
+        // which is set-up work -- never something an operator pays for in passing.  Without a reservation they are
+        // ordinary blocks.
         void * p = nullptr;
-        if (kind == kBlockStreamed && nbytes >= kStreamBlock) p = stream_arena().alloc(nbytes, stream_, false);
-        // (odd chunks are the ones NOT in the zone of the read-mostly arrays)
-        if (kind == kBlockScatter && nbytes >= kSmallBlock) p = stream_arena().alloc_striped(nbytes, kStreamBlock, 1);
+        if (kind == kBlockStreamed && nbytes >= kStreamBlock) {
+            // more than two chunks: in both zones wherever it lies; up to two: astride a boundary
+            if (nbytes <= 2 * kStreamBlock) p = stream_arena().alloc_placed(nbytes, place_astride);
+            if (p == nullptr) p = stream_arena().alloc(nbytes, stream_, false);
+        }
+        if (kind == kBlockScatter && nbytes >= kSmallBlock) {
+            // (the class of every slab is settled first: scatter_class_of allocates from the arena itself)
+            for (const char * b : stream_arena().slab_bases()) (void)scatter_class_of(b, stream_);
+            p = stream_arena().alloc_placed(nbytes, [](const char * b, size_t lo, size_t hi, size_t need) {
+                auto it = g_scatter_class.find(b);
+                return place_in_class(b, lo, hi, need, it == g_scatter_class.end() || it->second != 0);
+            });
+        }
         if (p != nullptr) return p;
     }
     Arena & a = nbytes < kSmallBlock ? small_arena() : big_arena();
@@ -632,7 +805,10 @@ void Manager::device_free(void * p) {
     (void)hipFree(p);
 }
 
+void Manager::wait_for_builder() { builder_wait(); }
+
 size_t Manager::release_cached() {
+    builder_wait();
     (void)hipDeviceSynchronize();
     return big_arena().trim() + small_arena().trim() + stream_arena().trim();
 }
@@ -648,6 +824,7 @@ void Manager::reserve(size_t bytes, bool streamed) {
     size_t f = 0, t = 0;
     if (hipMemGetInfo(&f, &t) != hipSuccess) return;
     if (streamed) {
+        builder_wait();
         // streamed blocks are few and large and each has to fit ONE range: the reservation is "a free range of `bytes`"
         if (bytes > f / 10 * 9) return;
         (void)stream_arena().reserve(bytes, stream_, true);
@@ -668,7 +845,8 @@ ZoneRefs zone_references_take(size_t bytes) {
     // at once).  At the time a streamed slab is built -- right after the read-mostly reservation -- that is the first and
     // the last GB of the slab.
     ZoneRefs r;
-    if (alloc_policy().plain || big_arena().capacity() == 0) return r;
+    // (a token reservation -- the reference's mem_gb = 1 -- says nothing about where the arrays will live)
+    if (alloc_policy().plain || big_arena().capacity() < (size_t(8) << 30)) return r;
     hipStream_t st = Manager::get().stream();
     r.first = big_arena().alloc(bytes, st, false);
     const size_t room = big_arena().largest_free();
@@ -688,6 +866,8 @@ void zone_references_release(const ZoneRefs & r) {
 }
 
 void Manager::drop_arenas() {
+    builder_wait();
+    g_scatter_class.clear();
     (void)hipDeviceSynchronize();
     drop_param_blocks();
     big_arena().destroy();
@@ -1120,6 +1300,24 @@ int toast_hip_arena_reserve(size_t bytes) {
 
 int toast_hip_arena_reserve_streamed(size_t bytes) {
     return guarded([&] { Manager::get().reserve(bytes, true); });
+}
+
+int toast_hip_arena_block_zone(const void * device_ptr, size_t bytes, int * interleaved, int * chunks_own_zone,
+                               int * chunks_other_zone) {
+    return guarded([&] {
+        Manager::wait_for_builder();
+        int in = 0, own = 0, other = 0;
+        size_t off = 0, chunk = 0;
+        if (stream_arena().slab_offset(device_ptr, &off) &&
+            vmm_slab_layout(static_cast<const char *>(device_ptr) - off, &chunk) && chunk > 0) {
+            in = 1;
+            const size_t last = off + (bytes ? bytes - 1 : 0);
+            for (size_t k = off / chunk; k <= last / chunk; ++k) (vmm_slot_other(k) ? other : own) += 1;
+        }
+        if (interleaved) *interleaved = in;
+        if (chunks_own_zone) *chunks_own_zone = own;
+        if (chunks_other_zone) *chunks_other_zone = other;
+    });
 }
 
 // The sub-allocation logic on host memory (no device needed): `n_ops` random allocations / releases of 1 .. max_block

@@ -140,6 +140,11 @@ struct VmmSlabStats {
     double same_zone_tbs = 0.0;      // the last slab's reference rate (two halves of one chunk)
 };
 VmmSlabStats vmm_slab_stats();
+// slot k of an interleaved slab holds a chunk of the OTHER zone (pattern P Q Q P P Q Q P ...)
+inline bool vmm_slot_other(size_t k) { return (((k + 1) >> 1) & 1) != 0; }
+// is `base` the start of an interleaved slab?  its chunk size
+// n_ref: 0 when the slab's classes are relative to its own first chunk (built before any read-mostly slab existed)
+bool vmm_slab_layout(const void * base, size_t * chunk, int * n_ref = nullptr);
 void vmm_pair_matrix(int n_phys, int n_slots, double * out, hipStream_t st);   // experiment, vmm_slab.cpp
 
 // Transfers between pageable application memory and the device, through a page-locked bounce ring owned by the library
@@ -230,6 +235,8 @@ public:
     // take `bytes` for the arena now (one slab, touched once): assign_device(mem_gb), TOAST_HIP_ARENA_RESERVE_GB
     void reserve(size_t bytes, bool streamed = false);
     void drop_arenas();   // device change: every slab goes back to the driver
+    // the streamed slab that assign_device started building on a thread of its own is complete (no-op otherwise)
+    static void wait_for_builder();
 
     uint64_t generation() const { return generation_; }
     hipStream_t stream() const { return stream_; }

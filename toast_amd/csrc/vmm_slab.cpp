@@ -10,10 +10,11 @@
 // rounds 1-3, which the round-3 placement policy could only pick among.
 //
 // Here a slab is a virtual range built from separately created 1 GB physical chunks (hipMemCreate / hipMemMap), mapped
-// so that chunks of two zones ALTERNATE along the range -- even slots: the zone of the arena's read-mostly slabs ("P"),
-// odd slots: another zone.  A streamed block of 2 GB or more then has its rows in both zones wherever the arena puts it
-// (caller-visible layouts, the reference's [detector][sample] arrays, stay as they are), and a scatter target is
-// placed inside one odd chunk (Arena::alloc_striped).  Only those two kinds of block live here: read-only sweeps are
+// in the pattern P Q Q P P Q Q P ... along the range -- "P": the zone of the arena's read-mostly slabs, "Q": another zone
+// (vmm_slot_other: slots 1, 2, 5, 6, ...).  A streamed block of more than 2 GB then has its rows in both zones wherever
+// the arena puts it (caller-visible layouts, the reference's [detector][sample] arrays, stay as they are), a smaller one
+// is laid astride a P | Q boundary, and a scatter target of up to 2 GB is placed inside one Q Q run (round 4 alternated
+// single chunks: the 1.2 GB map of Nside 2048 IQU straddled two zones; Manager::device_alloc).  Only those two kinds of block live here: read-only sweeps are
 // ~5 % slower on chunk-mapped memory than on a plain slab, for any chunk size (r04_a section 6).
 //
 // The zone of a chunk cannot be asked for, so it is measured: each new chunk gets one read + write pass together with a
@@ -47,6 +48,7 @@ struct VmmSlab {
     size_t bytes = 0;
     size_t chunk = 0;
     std::vector<hipMemGenericAllocationHandle_t> handles;   // in mapping order
+    int n_ref = 0;      // 0: the classes are relative to the slab's own first chunk (no read-mostly slab existed), else to it
 };
 
 std::map<void *, VmmSlab> g_vmm;
@@ -117,12 +119,13 @@ namespace {
 
 void register_slab(char * base, size_t n, size_t chunk, const std::vector<hipMemGenericAllocationHandle_t> & slot,
                    size_t other, size_t created, size_t probes, double level, std::chrono::steady_clock::time_point t_start,
-                   const char * how) {
+                   const char * how, int n_ref) {
     VmmSlab s;
     s.base = base;
     s.bytes = n * chunk;
     s.chunk = chunk;
     s.handles = slot;
+    s.n_ref = n_ref;
     {
         std::lock_guard<std::mutex> lock(g_vmm_mutex);
         g_vmm[base] = s;
@@ -216,7 +219,9 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
         if (thr > 0.0) return thr;
         return (r[r.size() / 2] > (1.0 + 1.7 * pol.gap) * level) ? 0.0 : 1.0e300;     // all "other" : all "same"
     };
-    const size_t want_odd = n / 2, want_even = n - want_odd;
+    size_t want_odd = 0;                         // slots of the other zone ("odd": round 4's name for them)
+    for (size_t k = 0; k < n; ++k) want_odd += vmm_slot_other(k) ? 1 : 0;
+    const size_t want_even = n - want_odd;
     const size_t max_create = n + pol.search / chunk;
     char * ref[2] = {nullptr, nullptr};
     double level[2] = {0.0, 0.0}, thr[2] = {1.0e300, 1.0e300};
@@ -314,8 +319,9 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
     char * base = static_cast<char *>(va);
     std::vector<hipMemGenericAllocationHandle_t> slot(n);
     std::vector<char> used(cand.size(), 0);
+    size_t next_odd = 0, next_even = 0;
     for (size_t k = 0; k < n && !failed; ++k) {
-        const size_t pick = (k & 1) ? odd[k / 2] : even[k / 2];
+        const size_t pick = vmm_slot_other(k) ? odd[next_odd++] : even[next_even++];
         used[pick] = 1;
         slot[k] = cand[pick].h;
         if (!map_chunk(base + k * chunk, chunk, slot[k], dev)) {
@@ -348,7 +354,8 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
         }
     }
     register_slab(base, n, chunk, slot, take_o, created, probes, level[0], t_start,
-                  n_ref == 2 ? "against both ends of the read-mostly slab" : (n_ref == 1 ? "against the read-mostly slab" : "against its first chunk"));
+                  n_ref == 2 ? "against both ends of the read-mostly slab" : (n_ref == 1 ? "against the read-mostly slab" : "against its first chunk"),
+                  n_ref);
     return base;
 }
 
@@ -384,6 +391,15 @@ void vmm_pair_matrix(int n_phys, int n_slots, double * out, hipStream_t st) {
     for (auto hh : h) (void)hipMemRelease(hh);
     (void)hipMemAddressFree(va, (size_t)n_slots * chunk);
     std::fprintf(stderr, "[toast_hip] vmm_pair_matrix: range at %p\n", va);
+}
+
+bool vmm_slab_layout(const void * base, size_t * chunk, int * n_ref) {
+    std::lock_guard<std::mutex> lock(g_vmm_mutex);
+    auto it = g_vmm.find(const_cast<void *>(base));
+    if (it == g_vmm.end()) return false;
+    if (chunk != nullptr) *chunk = it->second.chunk;
+    if (n_ref != nullptr) *n_ref = it->second.n_ref;
+    return true;
 }
 
 size_t vmm_slab_size(void * p) {
