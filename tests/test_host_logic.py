@@ -343,8 +343,8 @@ def test_sync_alltoallv_single_process():
 def test_bench_guardian_keeps_the_headline_whatever_happens_to_the_extras():
     """bench.py, ranks > 1: rank 0 hands the line to a child process that owns stdout -- first as it stands after the timed
     steps, then complete -- and the child prints the last one it got when rank 0 is gone.  Three endings: the extras
-    finish (the complete line, once), they hang (every rank's timer ends the process; the provisional line with a
-    `truncated` key), rank 0 dies in them (SIGABRT, as after a GPU memory fault: the provisional line all the same)."""
+    finish (the complete line, once), they hang (every rank's timer ends the process WITH A NON-ZERO EXIT CODE -- a hung
+    collective is not a success --; the provisional line with a `truncated` key), rank 0 dies in them (SIGABRT, as after a GPU memory fault: the provisional line all the same)."""
     import json
     import subprocess
     import sys
@@ -369,7 +369,7 @@ time.sleep(30)
 print("not reached")
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, TOAST_BENCH_EXTRAS_TIMEOUT_S="0.5")
-    for how, rank, rc_zero, lines in (("finish", 0, True, 1), ("hang", 0, True, 1), ("hang", 1, True, 0), ("abort", 0, False, 1)):
+    for how, rank, rc_zero, lines in (("finish", 0, True, 1), ("hang", 0, False, 1), ("hang", 1, False, 0), ("abort", 0, False, 1)):
         p = subprocess.run([sys.executable, "-c", code, how, str(rank)], capture_output=True, text=True, env=env, timeout=60)
         assert (p.returncode == 0) == rc_zero, (how, p.returncode, p.stderr)
         got = [ln for ln in p.stdout.splitlines() if ln.strip()]

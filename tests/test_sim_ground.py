@@ -172,3 +172,131 @@ def test_interval_conversion_conventions():
     # start <= t < stop; a span ending on the last stamp includes the last sample; spans outside are dropped
     assert spans == [(0, 4), (10, 20), (40, 50)]
     assert sg.union_spans(50, [(0, 4), (10, 20)], [(4, 7), (30, 31)]) == [(0, 7), (10, 20), (30, 31)]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# elevation motions (toast_amd/ops/sim_ground_el.py) against outputs of the reference's own functions
+# (tests/golden/make_golden_sim_ground_el.py -> sim_ground_el.npz), bit for bit
+GOLDEN_EL = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sim_ground_el.npz")
+
+
+def _el_cases(prefix):
+    g = np.load(GOLDEN_EL)
+    return g, sorted({k[len(prefix):].rsplit("_", 1)[0] for k in g.files if k.startswith(prefix) and k.endswith("_args")})
+
+
+def _scan_of(g, index):
+    name = ("scan_a", "scan_b")[int(index)]
+    t0, t1, rate, el, azmin, azmax, azrate, fix, accel = g[name + "_args"]
+    return sg.simulate_ces_scan(t0, t1, rate, el, azmin, azmax, azmin, azrate, bool(fix), accel, azmin, azmax)
+
+
+def test_scan_between_and_scan_time_bit_for_bit():
+    from toast_amd.ops import sim_ground_el as se
+
+    g, names = _el_cases("between_")
+    assert len(names) == 3
+    for name in names:
+        a = g[f"between_{name}_args"]
+        t, az, el = se.scan_between(*a)
+        assert np.array_equal(t[::97], g[f"between_{name}_t"]) and np.array_equal(az[::97], g[f"between_{name}_az"])
+        assert np.array_equal(el[::97], g[f"between_{name}_el"]), name
+        assert se.scan_time(a[1], a[3], a[5], a[6]) == g[f"between_{name}_times"][0]
+        assert se.scan_time(a[2], a[4], a[7], a[8]) == g[f"between_{name}_times"][1]
+
+
+def test_simulate_elnod_bit_for_bit():
+    from toast_amd.ops import sim_ground_el as se
+
+    g, names = _el_cases("elnod_")
+    assert len(names) == 3
+    for name in names:
+        t0, rate, az0, el0, azr, aza, elr, ela = g[f"elnod_{name}_args"]
+        elnod_el = np.array([el0 + np.radians(x) for x in g[f"elnod_{name}_offsets"]])
+        elnod_az = np.zeros_like(elnod_el) + az0
+        res = se.simulate_elnod(t0, rate, az0, el0, azr, aza, elr, ela, elnod_el, elnod_az, az0 - 0.1, az0 + 0.3, el0, el0)
+        for got, key in zip(res[:3], ("t", "az", "el")):
+            assert np.array_equal(got, g[f"elnod_{name}_{key}"]), (name, key)
+        assert np.array_equal(np.array(res[3:], dtype=np.float64), g[f"elnod_{name}_range"]), name
+        assert res[0].size > 50 and np.ptp(res[2]) > 0.0
+
+
+def test_oscillate_el_bit_for_bit():
+    from toast_amd.ops import sim_ground_el as se
+
+    g, names = _el_cases("oscillate_")
+    assert len(names) == 5
+    for name in names:
+        elr, ela, amp, hz, sine, phase = g[f"oscillate_{name}_args"]
+        scan = _scan_of(g, g[f"oscillate_{name}_scan"][0])
+        el = scan[2].copy()
+        state = np.random.get_state()[1].copy()
+        rng = se.oscillate_el(scan[0], el, elr, ela, float(scan[2][0]), float(scan[2][0]), amp, hz, scan[5], scan[7],
+                              el_mod_sine=bool(sine), el_mod_sine_phase=None if np.isnan(phase) else float(phase))
+        assert np.array_equal(np.random.get_state()[1], state)            # (the global generator is left alone)
+        assert np.array_equal(el, g[f"oscillate_{name}_el"]), name
+        assert np.array_equal(np.array(rng, dtype=np.float64), g[f"oscillate_{name}_range"]), name
+        assert np.ptp(el) > 0.9 * amp
+    # what the mount cannot do is refused, like in the reference
+    scan = _scan_of(g, 0)
+    with pytest.raises(RuntimeError, match="oscillation"):
+        se.oscillate_el(scan[0], scan[2].copy(), np.radians(1.0), np.radians(0.001), 0.0, 0.0, np.radians(1.0), 0.5, scan[5],
+                        scan[7])
+    with pytest.raises(RuntimeError, match="mount only allows"):
+        se.oscillate_el(scan[0], scan[2].copy(), np.radians(0.01), np.radians(1.0), 0.0, 0.0, np.radians(1.0), 0.5, scan[5],
+                        scan[7], el_mod_sine=True)
+
+
+def test_step_el_bit_for_bit():
+    from toast_amd.ops import sim_ground_el as se
+
+    g, names = _el_cases("step_")
+    assert len(names) == 2
+    for name in names:
+        elr, ela, step = g[f"step_{name}_args"]
+        scan = _scan_of(g, g[f"step_{name}_scan"][0])
+        el = scan[2].copy()
+        rng = se.step_el(scan[0], scan[1], el, elr, ela, float(scan[2][0]), float(scan[2][0]), step)
+        assert np.array_equal(el, g[f"step_{name}_el"]), name
+        assert np.array_equal(np.array(rng, dtype=np.float64), g[f"step_{name}_range"]), name
+        assert abs(abs(el[-1] - el[0]) / abs(step) - round(abs(el[-1] - el[0]) / abs(step))) < 1e-6      # whole steps
+
+
+def test_sim_ground_operator_with_elnods_and_elevation_modulation():
+    """SimGround with el-nods before and after the scan, a triangle-wave elevation modulation and elevation steps
+    (sim_ground.py:905-1130): one continuous time axis, the el-nods as intervals and flag bits, the stations visited,
+    the modulation inside the mount's limits."""
+    rate, n_det = 20.0, 2
+    schedule = sch.make_ces_schedule(1, scan_seconds=600.0, gap_seconds=30.0, az_min=40.0, az_max=75.0, el=50.0)
+    fp_q, gamma = synth.hex_focalplane(n_det, fov_deg=4.0)
+    tele = Telescope("ground", Focalplane(["D0A", "D0B"], fp_q, gamma=gamma, epsilon=np.zeros(n_det), sample_rate=rate))
+    plain = Data(comm=Comm(use_dist=False))
+    sg.SimGround(telescope=tele, schedule=schedule, scan_rate_az=1.0, scan_accel_az=0.5, fix_rate_on_sky=False).apply(plain)
+    data = Data(comm=Comm(use_dist=False))
+    op = sg.SimGround(telescope=tele, schedule=schedule, scan_rate_az=1.0, scan_accel_az=0.5, fix_rate_on_sky=False,
+                      elnod_start=True, elnod_end=True, elnods=[1.0, -1.0, 0.0], scan_rate_el=1.0, scan_accel_el=1.0,
+                      el_mod_rate=0.02, el_mod_amplitude=0.5, el_mod_step=0.1)
+    op.apply(data)
+    ob, ob0 = data.obs[0], plain.obs[0]
+    times, el, az = ob.shared[defaults.times].data, ob.shared[defaults.elevation].data, ob.shared[defaults.azimuth].data
+    n0 = ob0.n_local_samples
+    nods = ob.intervals[op.elnod_interval].data
+    assert len(nods) == 2 and nods[0]["first"] == 0 and nods[1]["last"] == ob.n_local_samples
+    n_before = int(np.searchsorted(times, ob0.shared[defaults.times].data[0]))     # (spans are half open: the el-nod's last sample is not in its interval)
+    assert n_before == int(nods[0]["last"]) + 1
+    assert ob.n_local_samples > n0 + 2 * 40 and np.allclose(np.diff(times), 1.0 / rate, atol=1e-6)   # one time axis
+    assert np.array_equal(times[n_before:n_before + n0], ob0.shared[defaults.times].data)      # the scan itself: unchanged
+    # the el-nod visits +1 and -1 degree around the scan elevation and the azimuth stays at the throw's edge
+    before = slice(0, n_before)
+    assert el[before].max() > np.radians(50.9) and el[before].min() < np.radians(49.1)
+    assert np.allclose(az[before], np.radians(40.0))
+    flags = ob.shared[defaults.shared_flags].data
+    assert np.all(flags[:n_before - 1] & defaults.shared_mask_irregular) and not np.any(flags[n_before + 5:n_before + n0 - 5] & defaults.shared_mask_irregular)
+    # during the scan: the wave (peak to peak 1 degree) plus whole steps of 0.1 degree
+    scan_el = el[n_before:n_before + n0]
+    assert np.ptp(scan_el) > np.radians(0.9)
+    assert np.max(np.abs(np.diff(scan_el))) * rate <= np.radians(1.0) * 1.001          # the mount's elevation rate
+    # (the upper end of the recorded range is what the reference's simulate_elnod leaves of it: it takes a minimum there)
+    assert ob["scan_min_el"] <= min(scan_el.min(), el.min()) + 1e-12 and ob["scan_max_el"] <= el.max()
+    with pytest.raises(RuntimeError, match="list of offsets"):
+        sg.SimGround(telescope=tele, schedule=schedule, elnod_start=True).apply(Data(comm=Comm(use_dist=False)))

@@ -44,6 +44,7 @@ defaults = types.SimpleNamespace(
     turnaround_interval="turnaround",
     throw_leftright_interval="throw_leftright",
     throw_rightleft_interval="throw_rightleft",
+    elnod_interval="elnod",
     pixels="pixels",
     weights="weights",
     quats="quats",

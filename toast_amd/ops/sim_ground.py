@@ -12,9 +12,14 @@ interval lists (scan / turn / throw, left-right and right-left) plus ``scanning`
 horizontal boresight ``qa.from_lonlat_angles(-az, el, 0) * Rz(boresight_angle)``, HWP angle,
 detector data / flag buffers.
 
+El-nods before / after the scan, the periodic elevation modulation and the elevation steps after every scan pair
+(``elnod_start`` / ``elnod_end`` / ``elnods``, ``el_mod_rate`` / ``el_mod_amplitude`` / ``el_mod_sine``, ``el_mod_step``;
+sim_ground.py:905-1130) are in ``sim_ground_el.py``, pinned bit for bit to the reference's functions as well
+(tests/golden/sim_ground_el.npz).
+
 Not reproduced (their dependencies -- astropy, ephem, qpoint -- are absent, and none of it changes
-the structure of the map-making inputs): el-nods and el modulation, Sun intervals, weather,
-``track_azimuth``, site position / velocity, and the astrometric part of horizontal -> equatorial.
+the structure of the map-making inputs): Sun intervals, weather, ``track_azimuth`` (its drift rate comes from
+ephem, sim_ground_utils.py:522-548), site position / velocity, and the astrometric part of horizontal -> equatorial.
 The equatorial boresight is the rigid rotation
 ``Rz(ERA(t) + lon) Ry(pi/2 - lat) Rz(pi) q_azel`` with the Earth rotation angle of the UTC stamp
 (no precession, nutation, aberration or refraction: arcminute-level differences from the
@@ -27,7 +32,8 @@ import numpy as np
 from .. import synth
 from ..data import Data, IntervalList, Observation, Telescope, defaults
 from ..schedule import GroundSchedule
-from ..traits import Bool, Float, Instance, Int, Unicode
+from ..traits import Bool, Float, Instance, Int, List, Unicode
+from .sim_ground_el import oscillate_el, simulate_elnod, step_el
 from .operator import Operator
 
 
@@ -217,6 +223,18 @@ class SimGround(Operator):
                                       "mount azimuthal rate.")
     scan_accel_az = Float(1.0, help="Mount scanning rate acceleration for turnarounds [deg / s^2]")
     scan_cosecant_modulation = Bool(False, help="Modulate the scan rate according to 1/sin(az) for uniform depth")
+    scan_rate_el = Float(1.0, allow_none=True, help="The sky elevation scanning rate [deg / s]")
+    scan_accel_el = Float(1.0, allow_none=True, help="Mount elevation rate acceleration [deg / s^2]")
+    el_mod_step = Float(0.0, help="Amount to step elevation after each left-right scan pair [deg]")
+    el_mod_rate = Float(0.0, help="Modulate elevation continuously at this rate [Hz]")
+    el_mod_amplitude = Float(1.0, help="Range of elevation modulation [deg]")
+    el_mod_sine = Bool(False, help="Modulate elevation with a sine wave instead of a triangle wave")
+    el_mod_sine_phase = Float(0.0, allow_none=True, help="Add a per subscan extra phase to the sine modulation [deg]. "
+                                                         "If negative adds random phase.")
+    elnod_start = Bool(False, help="Perform an el-nod before the scan")
+    elnod_end = Bool(False, help="Perform an el-nod after the scan")
+    elnods = List([], help="List of relative el_nods [deg]")
+    elnod_every_scan = Bool(False, help="Perform el nods every scan")
     detset_key = Unicode(None, allow_none=True, help="If specified, use this column of the focalplane detector_data "
                                                      "to group detectors")
     times = Unicode(defaults.times, help="Observation shared key for timestamps")
@@ -242,6 +260,8 @@ class SimGround(Operator):
     scan_rightleft_interval = Unicode("scan_rightleft", help="Interval name for right to left scans")
     turn_rightleft_interval = Unicode("turn_rightleft", help="Interval name for turnarounds after right to left scans")
     turnaround_mask = Int(defaults.shared_mask_unstable_scanrate, help="Bit mask to raise turnaround flags with")
+    elnod_interval = Unicode(defaults.elnod_interval, help="Interval name for elnods")
+    elnod_mask = Int(defaults.shared_mask_irregular, help="Bit mask to raise elevation nod flags with")
 
     def _exec(self, data, detectors=None, **kwargs):
         if self.schedule is None and self.schedule_file is not None:
@@ -256,6 +276,8 @@ class SimGround(Operator):
             raise NotImplementedError("track_azimuth needs the ephem package (sim_ground_utils.py:524-548)")
         if self.hwp_angle is not None and self.hwp_rpm is None:
             raise RuntimeError("Cannot simulate HWP without parameters")
+        if (self.elnod_start or self.elnod_end) and len(self.elnods) == 0:
+            raise RuntimeError("If simulating elnods, you must specify the list of offsets")
         focalplane = self.telescope.focalplane
         rate = focalplane.sample_rate
         lat, lon = np.radians(self.schedule.site_lat), np.radians(self.schedule.site_lon)
@@ -280,14 +302,50 @@ class SimGround(Operator):
                 continue
             stop_time = t_start + float(n_samples - 1) / rate        # sim_ground.py:920-921
             az_min, az_max, el = np.radians(scan.az_min), np.radians(scan.az_max), np.radians(scan.el)
+            # sim_ground.py:905-1130 (_simulate_scanning): el-nod, the scan with its elevation modulations, el-nod
+            rate_az, accel_az = np.radians(self.scan_rate_az), np.radians(self.scan_accel_az)
+            min_el = max_el = el
+            min_az, max_az = az_min, az_max
+            parts, ival_elnod = [], []
+            nod_el = nod_az = None
+            if len(self.elnods) > 0:
+                nod_el = np.array([el + np.radians(x) for x in self.elnods])
+                nod_az = np.zeros_like(nod_el) + az_min
+            nod_rates = (rate_az, accel_az, np.radians(self.scan_rate_el or 0.0), np.radians(self.scan_accel_el or 0.0))
+            if self.elnod_start:
+                nt, na, ne, min_az, max_az, min_el, max_el = simulate_elnod(t_start, rate, az_min, el, *nod_rates, nod_el,
+                                                                            nod_az, min_az, max_az, min_el, max_el)
+                if len(nt) > 0:
+                    nt -= (nt[-1] - nt[0]) + incr       # ends one sample before the scan starts
+                    parts.append((nt, na, ne))
+                    ival_elnod.append((nt[0], nt[-1]))
             (times, az, elv, min_az, max_az, scan_lr, turn_lr, scan_rl, turn_rl, throw_lr, throw_rl) = simulate_ces_scan(
-                t_start, stop_time, rate, el, az_min, az_max, az_min, np.radians(self.scan_rate_az),
-                self.fix_rate_on_sky, np.radians(self.scan_accel_az), az_min, az_max,
+                t_start, stop_time, rate, el, az_min, az_max, az_min, rate_az, self.fix_rate_on_sky, accel_az, min_az, max_az,
                 cosecant_modulation=self.scan_cosecant_modulation, randomize_phase=self.randomize_phase)
+            if self.el_mod_rate > 0:
+                min_el, max_el = oscillate_el(times, elv, nod_rates[2], nod_rates[3], min_el, max_el,
+                                              np.radians(self.el_mod_amplitude), self.el_mod_rate, scan_lr, scan_rl,
+                                              el_mod_sine=self.el_mod_sine,
+                                              el_mod_sine_phase=None if self.el_mod_sine_phase is None
+                                              else np.radians(self.el_mod_sine_phase))
+            if np.radians(self.el_mod_step) > 0:
+                min_el, max_el = step_el(times, az, elv, nod_rates[2], nod_rates[3], min_el, max_el,
+                                         np.radians(self.el_mod_step))
+            parts.append((times, az, elv))
+            if self.elnod_end:
+                nt, na, ne, min_az, max_az, min_el, max_el = simulate_elnod(times[-1] + incr, rate, az[-1], elv[-1],
+                                                                            *nod_rates, nod_el, nod_az, min_az, max_az,
+                                                                            min_el, max_el)
+                if len(nt) > 0:
+                    parts.append((nt, na, ne))
+                    ival_elnod.append((nt[0], nt[-1]))
+            if len(parts) > 1:
+                times, az, elv = (np.hstack([p[k] for p in parts]) for k in range(3))
             name = f"{scan.name}-{scan.scan_indx}-{scan.subscan_indx}"
             ob = Observation(comm, Telescope(self.telescope.name, focalplane), len(times), name=name)
             ob["scan_el"] = scan.el
             ob["scan_min_az"], ob["scan_max_az"] = float(min_az), float(max_az)
+            ob["scan_min_el"], ob["scan_max_el"] = float(min_el), float(max_el)
             ob["site"] = dict(name=self.schedule.site_name, lat=self.schedule.site_lat, lon=self.schedule.site_lon,
                               alt=self.schedule.site_alt)
             ob.set_times(times)
@@ -318,10 +376,14 @@ class SimGround(Operator):
             ob.intervals[self.scanning_interval] = IntervalList(times, samplespans=union_spans(n, spans["scan_lr"], spans["scan_rl"]))
             turn = union_spans(n, spans["turn_lr"], spans["turn_rl"])
             ob.intervals[self.turnaround_interval] = IntervalList(times, samplespans=turn)
+            nod = timespans_to_samples(times, ival_elnod)
+            ob.intervals[self.elnod_interval] = IntervalList(times, samplespans=nod)
             if self.shared_flags is not None:
                 flags = np.zeros(n, dtype=np.uint8)
-                for a, b in turn:      # FlagIntervals(view_mask=[(turnaround, turnaround_mask)])
+                for a, b in turn:      # FlagIntervals(view_mask=[(turnaround, turnaround_mask), (elnod, elnod_mask)])
                     flags[a:b] |= np.uint8(self.turnaround_mask)
+                for a, b in nod:
+                    flags[a:b] |= np.uint8(self.elnod_mask)
                 ob.shared.create(self.shared_flags, flags)
             if self.det_data is not None:
                 ob.detdata.create(self.det_data, dtype=np.float64, units=self.det_data_units)
@@ -338,7 +400,8 @@ class SimGround(Operator):
     def _provides(self):
         prov = {"shared": [self.times, self.azimuth, self.elevation, self.boresight_azel, self.boresight_radec],
                 "detdata": [], "intervals": [self.scanning_interval, self.turnaround_interval,
-                                             self.throw_leftright_interval, self.throw_rightleft_interval]}
+                                             self.throw_leftright_interval, self.throw_rightleft_interval,
+                                             self.elnod_interval]}
         if self.shared_flags is not None:
             prov["shared"].append(self.shared_flags)
         if self.det_data is not None:

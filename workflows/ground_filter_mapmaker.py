@@ -39,6 +39,10 @@ def main(argv=None):
                     help="build the observations with ops.SimGround from a schedule of N constant-elevation scans of "
                          "--minutes each (finite-acceleration turnarounds, one observation per scan) instead of "
                          "the synthetic single-observation generator")
+    ap.add_argument("--elnods", action="store_true",
+                    help="with --scheduled: an el-nod (+1, -1, 0 degrees) before and after every scan and elevation steps of "
+                         "0.05 degrees after every scan pair (ops.SimGround elnod_start / elnod_end / el_mod_step); the "
+                         "el-nod samples carry the `irregular` flag bit and stay out of the maps")
     args = ap.parse_args(argv)
     n_samp = int(args.minutes * 60 * args.rate)
     t = time.time()
@@ -55,8 +59,10 @@ def main(argv=None):
         from toast_amd.schedule import make_ces_schedule
 
         schedule = make_ces_schedule(args.scheduled, scan_seconds=args.minutes * 60.0, az_min=40.0, az_max=110.0, el=50.0)
+        el_motion = dict(elnod_start=True, elnod_end=True, elnods=[1.0, -1.0, 0.0], scan_rate_el=1.0, scan_accel_el=1.0,
+                         el_mod_step=0.05) if args.elnods else {}
         data = create_ground_data_from_schedule(schedule, n_det=args.ndet, rate=args.rate, fov_deg=8.0,
-                                                scan_rate_az=1.0, scan_accel_az=1.0, fix_rate_on_sky=False)
+                                                scan_rate_az=1.0, scan_accel_az=1.0, fix_rate_on_sky=False, **el_motion)
         for ob in data.obs:     # the map-maker skips samples with any non-science bit: raise "invalid" too
             ob.shared[defaults.shared_flags].data[ob.shared[defaults.shared_flags].data != 0] |= defaults.shared_mask_invalid
     else:
