@@ -133,7 +133,12 @@ class SolveAmplitudes(Operator):
         self.timing_log = {}
 
         def lap(label, t0):
-            native().accel_synchronize() if accel_enabled() else None
+            # (a phase boundary is a host-side mark: the device is waited for only when somebody wants to READ the phase
+            # times -- TOAST_HIP_TRACE / TOAST_HIP_PHASE_SYNC=1 --, otherwise the host goes on into the next phase's own
+            # work, e.g. the templates' bookkeeping, while the device is still busy with this one)
+            if accel_enabled() and (_os.environ.get("TOAST_HIP_PHASE_SYNC", "0") == "1"
+                                    or _os.environ.get("TOAST_HIP_TRACE", "0") not in ("", "0")):
+                native().accel_synchronize()
             self.timing_log[label] = self.timing_log.get(label, 0.0) + (_time.time() - t0)
             if _os.environ.get("TOAST_HIP_TRACE", "0") not in ("", "0"):
                 print(f"[toast_hip] phase         {label:30s} {1e3 * (_time.time() - t0):10.2f} ms", file=_sys.stderr, flush=True)
@@ -379,7 +384,12 @@ class MapMaker(Operator):
         self.history, self.iteration_seconds, self.timing_log = [], [], {}
 
         def lap(label, t0):
-            native().accel_synchronize() if accel_enabled() else None
+            # (a phase boundary is a host-side mark: the device is waited for only when somebody wants to READ the phase
+            # times -- TOAST_HIP_TRACE / TOAST_HIP_PHASE_SYNC=1 --, otherwise the host goes on into the next phase's own
+            # work, e.g. the templates' bookkeeping, while the device is still busy with this one)
+            if accel_enabled() and (_os.environ.get("TOAST_HIP_PHASE_SYNC", "0") == "1"
+                                    or _os.environ.get("TOAST_HIP_TRACE", "0") not in ("", "0")):
+                native().accel_synchronize()
             self.timing_log[label] = self.timing_log.get(label, 0.0) + (_time.time() - t0)
             if _os.environ.get("TOAST_HIP_TRACE", "0") not in ("", "0"):
                 print(f"[toast_hip] phase         {label:30s} {1e3 * (_time.time() - t0):10.2f} ms", file=_sys.stderr, flush=True)
