@@ -1770,12 +1770,14 @@ class _DenseDeviceLHS(ops.Operator):
     def _host_op(a_in, a_out, fn):
         from toast_amd.accel import accel_data_update_device, accel_data_update_host
 
+        # (``buffer``: the host arrays without the lazy coherence of ``local`` -- this stand-in moves the data itself and
+        # leaves both vectors device-current, as a device operator would)
         assert a_in.accel_in_use()
-        accel_data_update_host(a_in.local, a_in._accel_name)
+        accel_data_update_host(a_in.buffer, a_in._accel_name)
         if not a_out.accel_exists():
             a_out.accel_create(a_out._accel_name)
-        a_out.local[:] = fn(a_in.local)
-        accel_data_update_device(a_out.local, a_out._accel_name)
+        a_out.buffer[:] = fn(a_in.buffer)
+        accel_data_update_device(a_out.buffer, a_out._accel_name)
         a_out.accel_used(True)
 
     def _can_fuse(self, data):

@@ -21,6 +21,37 @@ from .operator import Operator
 from .pipeline import Pipeline, uncached_detector_sets
 
 
+def _pin_for_mapmaking(data, binning):
+    """Keep what every Pipeline of a map-making run reads on the device between them: the cached pointing (written once,
+    read by every later phase) and the shared inputs of the pointing operators (boresight, shared flags, HWP angle: a few
+    tens of MB that each Pipeline would otherwise upload again and free).  Only names that nobody holds yet are taken, so
+    that nested calls (MapMaker -> SolveAmplitudes) release what they took and nothing else.  Returns the dict to hand to
+    ``_unpin_for_mapmaking``."""
+    from ..accel import accel_enabled
+
+    if not accel_enabled():
+        return None
+    pixels, weights = binning.pixel_pointing, binning.stokes_weights
+    want = {"detdata": [], "shared": []}
+    if binning.full_pointing:
+        want["detdata"] = [pixels.pixels, weights.weights]
+    for op, trait in ((pixels.detector_pointing, "boresight"), (pixels.detector_pointing, "shared_flags"),
+                      (weights, "hwp_angle"), (binning, "shared_flags")):
+        key = getattr(op, trait, None)
+        if key is not None and key not in want["shared"]:
+            want["shared"].append(key)
+    taken = {k: [n for n in v if n not in data._pinned[k]] for k, v in want.items()}
+    data.accel_pin(taken)
+    return taken
+
+
+def _unpin_for_mapmaking(data, taken):
+    if taken is None:
+        return
+    data.accel_unpin({"detdata": taken["detdata"]})
+    data.accel_unpin({"shared": taken["shared"]}, update_host=False)   # inputs: never modified on the device
+
+
 class ApplyAmplitudes(Operator):
     """``out = det_data (-|+|*|/) M a`` (mapmaker_templates.py:1128-1320, subtract only)."""
 
@@ -161,10 +192,7 @@ class SolveAmplitudes(Operator):
                     del data[key]
             Delete(detdata=[pixels.pixels, weights.weights, pixels.detector_pointing.quats, nm["flags"]]).apply(data)
         # Cached pointing is written once and read by every later phase: keep it on the device
-        pinned = None
-        if binning.full_pointing and accel_enabled():
-            pinned = {"detdata": [pixels.pixels, weights.weights]}
-            data.accel_pin(pinned)
+        pinned = _pin_for_mapmaking(data, binning)
         if self.mc_mode:
             # re-use the flags and the covariance of an earlier realisation (:702-712, :852-864)
             for ob in data.obs:
@@ -254,8 +282,7 @@ class SolveAmplitudes(Operator):
                         data[key].clear()
                     del data[key]
             Delete(detdata=[nm["flags"]]).apply(data)
-        if pinned is not None:
-            data.accel_unpin(pinned)
+        _unpin_for_mapmaking(data, pinned)
 
     @staticmethod
     def _solver_flags_host(ob, solver_flags, binning, detectors=None):
@@ -398,6 +425,8 @@ class MapMaker(Operator):
         t0 = _time.time()
         tm = self.template_matrix
         use_templates = tm is not None and len([t for t in tm.templates if t.enabled]) > 0
+        final_binning = self.map_binning if (self.map_binning is not None and self.map_binning.enabled) else self.binning
+        pinned = _pin_for_mapmaking(data, final_binning)
         # -- fit templates (mapmaker.py:338-379)
         amplitudes = None
         if use_templates:
@@ -425,10 +454,6 @@ class MapMaker(Operator):
                 if key is not None and key in data:
                     del data[key]
             Delete(detdata=[clean_name]).apply(data)
-        pinned = None
-        if map_binning.full_pointing and accel_enabled():
-            pinned = {"detdata": [map_binning.pixel_pointing.pixels, map_binning.stokes_weights.weights]}
-            data.accel_pin(pinned)
         if map_binning.pixel_dist not in data:
             BuildPixelDistribution(pixel_dist=map_binning.pixel_dist, pixel_pointing=map_binning.pixel_pointing,
                                    save_pointing=map_binning.full_pointing).apply(data, detectors=detectors)
@@ -469,8 +494,7 @@ class MapMaker(Operator):
         t0 = lap("final_binning", t0)
         if use_templates and not self.save_cleaned and out_cleaned == clean_name:
             Delete(detdata=[clean_name]).apply(data)
-        if pinned is not None:
-            data.accel_unpin(pinned)
+        _unpin_for_mapmaking(data, pinned)
 
     @staticmethod
     def _solver_flags_device(ob, solver_flags, binning, detectors=None):

@@ -129,8 +129,10 @@ class TemplateMatrix(Operator):
 
     def _finalize(self, data, use_accel=None, **kwargs):
         if self.transpose and self.amplitudes in data:
-            # make the accumulated amplitudes current on the host for the PCG algebra
-            data[self.amplitudes].accel_update_host()
+            # make the accumulated amplitudes current on the host for the PCG algebra -- unless the host side is brought up
+            # to date on access anyway (Data.lazy_host; Amplitudes.local): the solver's algebra runs on the device
+            if not getattr(data, "lazy_host", False):
+                data[self.amplitudes].accel_update_host()
             for v in data[self.amplitudes].values():
                 v.sync()
 
@@ -578,8 +580,8 @@ class SolverLHS(Operator):
         ctx = dict(on_the_fly=on_the_fly, nnz=nnz, nps=dist.n_pix_submap, n_local=dist.n_local_submap,
                    zmap=zmap, amps_in=amps_in, amps_out=amps_out, zmap_ptr=accel_device_ptr(zmap.buffer),
                    zmap_bytes=zmap.buffer.nbytes, cov_ptr=accel_device_ptr(cov.buffer), g2l_ptr=accel_device_ptr(g2l.data),
-                   in_ptr=accel_device_ptr(amps_in.local), in_flags_ptr=accel_device_ptr(amps_in.local_flags),
-                   out_ptr=accel_device_ptr(amps_out.local), out_bytes=amps_out.local.nbytes,
+                   in_ptr=accel_device_ptr(amps_in.buffer), in_flags_ptr=accel_device_ptr(amps_in.local_flags),
+                   out_ptr=accel_device_ptr(amps_out.buffer), out_bytes=amps_out.buffer.nbytes,
                    det_flag_mask=binning.det_flag_mask, shared_flag_mask=binning.shared_flag_mask,
                    tmpl_flag_mask=tmpl.det_flag_mask, passes=[], prior=None)
         world = dist._world()
@@ -1062,9 +1064,12 @@ def solve(data, detectors, lhs_op, rhs_key, result_key, convergence=1.0e-12, n_i
         lhs_op.keep_on_device = False
         if hasattr(lhs_op, "release_packed"):
             lhs_op.release_packed()
-    # hand the solution back on the host (AmplitudesMap.accel_update_host skips host-current ones)
-    result.accel_update_host()
-    rhs.accel_update_host()
+    # hand the solution back on the host (AmplitudesMap.accel_update_host skips host-current ones); with lazy host
+    # coherence the vectors stay device-current -- ApplyAmplitudes reads them there -- and ``Amplitudes.local`` copies back
+    # when the host asks
+    if not getattr(data, "lazy_host", False):
+        result.accel_update_host()
+        rhs.accel_update_host()
     for tmp in (residual, precond):
         tmp.clear()
     proposal.clear()

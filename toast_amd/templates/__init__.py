@@ -62,8 +62,32 @@ class Amplitudes(AcceleratorObject):
                 raise RuntimeError("Total amplitudes on all processes does not equal n_global")
         elif self._n_local != self._n_global:
             raise RuntimeError("Total amplitudes on all processes does not equal n_global")
-        self.local = np.zeros(self._n_local, dtype=dtype)
+        self._local = np.zeros(self._n_local, dtype=dtype)
         self.local_flags = np.zeros(self._n_local, dtype=np.uint8)
+
+    # Lazy host coherence (like PixelData.data): the solver leaves its vectors resident and device-current; the first HOST
+    # access of ``local`` copies the values back and makes the host the current side again.
+    @property
+    def local(self):
+        """The local amplitudes on the host (amplitudes.py:291-300), brought up to date first."""
+        if self._accel_used:
+            self.accel_update_host()
+        return self._local
+
+    @local.setter
+    def local(self, value):
+        self._local = value
+
+    @property
+    def buffer(self):
+        """The host array WITHOUT synchronisation: its address is the accelerator key and its contents may be stale.
+        For device-side code paths only."""
+        return self._local
+
+    def arg(self, use_accel):
+        """Array to hand to a kernel call: the key array when the kernel runs on the registered device memory, the
+        synchronised host contents when the call is host-staged."""
+        return self._local if use_accel else self.local
 
     n_global = property(lambda self: self._n_global)
     n_local = property(lambda self: self._n_local)
@@ -117,10 +141,10 @@ class Amplitudes(AcceleratorObject):
         return True
 
     def _dptr(self):
-        return accel_device_ptr(self.local)
+        return accel_device_ptr(self._local)
 
     def duplicate(self):
-        ret = Amplitudes(self._comm, self._n_global, self._n_local, dtype=self.local.dtype, use_group=self._use_group,
+        ret = Amplitudes(self._comm, self._n_global, self._n_local, dtype=self._local.dtype, use_group=self._use_group,
                          _full=self._full)
         if self.accel_in_use():
             ret.local_flags[:] = self.local_flags
@@ -136,7 +160,7 @@ class Amplitudes(AcceleratorObject):
         if self.accel_in_use():
             self.accel_reset()
             return
-        self.local[:] = 0
+        self._local[:] = 0
         if self.accel_exists():
             self.accel_reset()
 
@@ -226,27 +250,27 @@ class Amplitudes(AcceleratorObject):
 
     # accelerator protocol: values and flags are two registered buffers
     def _accel_exists(self):
-        return self._n_local > 0 and accel_data_present(self.local, self._accel_name)
+        return self._n_local > 0 and accel_data_present(self._local, self._accel_name)
 
     def _accel_create(self, zero_out=False):
         # (amplitudes are what the M^T kernels scatter into: KIND_SCATTER)
-        accel_data_create(self.local, self._accel_name, zero_out=zero_out, owner=self, kind=2)
+        accel_data_create(self._local, self._accel_name, zero_out=zero_out, owner=self, kind=2)
         accel_data_create(self.local_flags, self._accel_name + "_flags", owner=self)
         accel_data_update_device(self.local_flags, self._accel_name + "_flags")
 
     def _accel_update_device(self):
-        accel_data_update_device(self.local, self._accel_name)
+        accel_data_update_device(self._local, self._accel_name)
         accel_data_update_device(self.local_flags, self._accel_name + "_flags")
 
     def _accel_update_host(self):
-        accel_data_update_host(self.local, self._accel_name)
+        accel_data_update_host(self._local, self._accel_name)
 
     def _accel_delete(self):
-        accel_data_delete(self.local, self._accel_name)
+        accel_data_delete(self._local, self._accel_name)
         accel_data_delete(self.local_flags, self._accel_name + "_flags")
 
     def _accel_reset(self):
-        accel_data_reset(self.local, self._accel_name)
+        accel_data_reset(self._local, self._accel_name)
 
 
 class AmplitudesMap(dict):
@@ -396,6 +420,27 @@ class Offset(Template):
         self._flag_cache = {}
         super().__init__(**kwargs)
 
+    # The offset variances are computed on the device (``_init_variances_device``) and read there by the preconditioner:
+    # the host copy is fetched when somebody asks for it.
+    @property
+    def _offsetvar(self):
+        if getattr(self, "_offsetvar_stale", False):
+            self._offsetvar_stale = False
+            accel_data_update_host(self._offsetvar_buf, f"{self.name}_offsetvar")
+        return self._offsetvar_buf
+
+    @_offsetvar.setter
+    def _offsetvar(self, value):
+        self._drop_offsetvar_device()
+        self._offsetvar_buf = value
+        self._offsetvar_stale = False
+
+    def _drop_offsetvar_device(self):
+        if getattr(self, "_offsetvar_on_dev", False):
+            accel_data_delete(self._offsetvar_buf, f"{self.name}_offsetvar")
+        self._offsetvar_on_dev = False
+        self._offsetvar_stale = False
+
     def _step_length(self, stime, rate):
         return int(np.rint(stime * rate))   # offset.py:723-724 (round half to even)
 
@@ -437,13 +482,16 @@ class Offset(Template):
             self._obs_view_flags[iob] = vf
             self._obs_dets[iob] = set()
             det_pat = re.compile(self.pattern) if self.pattern is not None else None
+            # (sets: `d in list` over 1024 detectors twice per detector was 5 ms of this function)
+            have_data = set(ob.detdata[self.det_data].detectors) if self.det_data in ob.detdata else None
+            have_flags = set(ob.detdata[self.det_flags].detectors) \
+                if (self.det_flags is not None and self.det_flags in ob.detdata) else None
             for d in ob.select_local_detectors(flagmask=self.det_mask):
-                if self.det_data in ob.detdata and d not in ob.detdata[self.det_data].detectors:
+                if have_data is not None and d not in have_data:
                     continue
                 if det_pat is not None and det_pat.match(d) is None:
                     continue  # offset.py:226-236
-                if self.det_flags is not None and self.det_flags in ob.detdata \
-                        and d not in ob.detdata[self.det_flags].detectors:
+                if have_flags is not None and d not in have_flags:
                     continue  # no solver flags for it: not part of this (split) run
                 self._obs_dets[iob].add(d)
                 all_dets.setdefault(d, None)
@@ -475,6 +523,9 @@ class Offset(Template):
             self._init_variances_host(new_data)
         self._flag_cache = {}
         if self.use_noise_prior and self._n_local > 0:
+            # the prior builds its filters from the variances on the host and registers the array under its own name
+            _ = self._offsetvar
+            self._drop_offsetvar_device()
             self._init_noise_prior(new_data)
 
     def _init_noise_prior(self, new_data):
@@ -514,15 +565,18 @@ class Offset(Template):
         from .. import capi
         from ..accel import accel_data_create, accel_data_delete, accel_data_update_device, accel_data_update_host
 
-        bad = Amplitudes(None, self._n_local, self._n_local)
-        bad.accel_create(f"{self.name}_badcount", zero_out=True)
-        bad.accel_used(True)
+        # per-amplitude counts of flagged samples: device scratch, never on the host
+        bad_bytes = 8 * self._n_local
+        bad_ptr = capi.device_malloc(bad_bytes)
+        capi.dev.memset(bad_ptr, 0, bad_bytes)
         # an amplitude that no (detector, observation) block claims stays cut, like a baseline without samples
         self._amp_flags[:] = 1
-        flag_name, var_name = f"{self.name}_init_flags", f"{self.name}_init_variance"
+        flag_name, var_name = f"{self.name}_init_flags", f"{self.name}_offsetvar"
         accel_data_create(self._amp_flags, flag_name)
         accel_data_update_device(self._amp_flags, flag_name)
-        accel_data_create(self._offsetvar, var_name, zero_out=True)
+        # (the variances stay on the device under the name the preconditioner looks for; host copy on demand)
+        accel_data_create(self._offsetvar_buf, var_name, zero_out=True, owner=self)
+        self._offsetvar_on_dev = True
         try:
             for iob, ob in enumerate(new_data.obs):
                 dets = [d for d in self._all_dets if d in self._obs_dets[iob]]
@@ -549,17 +603,19 @@ class Offset(Template):
                         if not fd.accel_exists():
                             fd.accel_create(self.det_flags)
                         fd.accel_update_device()
-                    capi.dev.offset_count_flagged(step_length, offs, self._obs_views[iob], accel_device_ptr(bad.local),
+                    capi.dev.offset_count_flagged(step_length, offs, self._obs_views[iob], bad_ptr,
                                                   fd.indices(dets), accel_device_ptr(fd.buffer), self.det_flag_mask,
                                                   ob.n_local_samples, ob.intervals[self._bounds_view].data)
-                capi.dev.offset_variance(offs, w, lens, accel_device_ptr(bad.local), self.good_fraction,
-                                         accel_device_ptr(self._amp_flags), accel_device_ptr(self._offsetvar))
+                capi.dev.offset_variance(offs, w, lens, bad_ptr, self.good_fraction,
+                                         accel_device_ptr(self._amp_flags), accel_device_ptr(self._offsetvar_buf))
             accel_data_update_host(self._amp_flags, flag_name)
-            accel_data_update_host(self._offsetvar, var_name)
+            self._offsetvar_stale = True
+        except BaseException:
+            self._drop_offsetvar_device()
+            raise
         finally:
             accel_data_delete(self._amp_flags, flag_name)
-            accel_data_delete(self._offsetvar, var_name)
-            bad.clear()
+            capi.device_release(bad_ptr, bad_bytes)
 
     def _init_variances_host(self, new_data):
         offset = 0
@@ -651,7 +707,7 @@ class Offset(Template):
             dd = ob.detdata[self.det_data]
             capi.dev.offset_add_to_signal_multi(
                 self._step_length(self.step_time, self._obs_rate[iob]), self.det_amp_offsets(iob, dets),
-                self._obs_views[iob], accel_device_ptr(amplitudes.local), accel_device_ptr(amplitudes.local_flags),
+                self._obs_views[iob], accel_device_ptr(amplitudes.buffer), accel_device_ptr(amplitudes.local_flags),
                 dd.indices(dets), accel_device_ptr(dd.buffer), ob.n_local_samples, ob.intervals[self._bounds_view].data)
 
     def project_signal_multi(self, detectors, amplitudes, **kwargs):
@@ -674,7 +730,7 @@ class Offset(Template):
             capi.dev.offset_project_signal_multi(
                 dd.indices(dets), accel_device_ptr(dd.buffer), f_idx, f_ptr, self.det_flag_mask,
                 self._step_length(self.step_time, self._obs_rate[iob]), self.det_amp_offsets(iob, dets),
-                self._obs_views[iob], accel_device_ptr(amplitudes.local), accel_device_ptr(amplitudes.local_flags),
+                self._obs_views[iob], accel_device_ptr(amplitudes.buffer), accel_device_ptr(amplitudes.local_flags),
                 ob.n_local_samples, ob.intervals[self._bounds_view].data)
 
     def _add_to_signal(self, detector, amplitudes, use_accel=None, **kwargs):
@@ -689,7 +745,7 @@ class Offset(Template):
             det_indx = ob.detdata[self.det_data].indices([detector])
             step_length = self._step_length(self.step_time, self._obs_rate[iob])
             n_amp_views = self._obs_views[iob]
-            native().template_offset_add_to_signal(step_length, amp_offset, n_amp_views, amplitudes.local,
+            native().template_offset_add_to_signal(step_length, amp_offset, n_amp_views, amplitudes.arg(use_accel),
                                                    amplitudes.local_flags, int(det_indx[0]),
                                                    ob.detdata[self.det_data].arg(use_accel), ob.intervals[self._bounds_view].data,
                                                    use_accel)
@@ -754,7 +810,7 @@ class Offset(Template):
             n_amp_views = self._obs_views[iob]
             native().template_offset_project_signal(int(det_indx[0]), ob.detdata[self.det_data].arg(use_accel), flag_indx,
                                                     flag_data, self.det_flag_mask, step_length, amp_offset,
-                                                    n_amp_views, amplitudes.local, amplitudes.local_flags,
+                                                    n_amp_views, amplitudes.arg(use_accel), amplitudes.local_flags,
                                                     ob.intervals[self._bounds_view].data, use_accel)
             amp_offset += int(np.sum(n_amp_views))
 
@@ -792,12 +848,9 @@ class Offset(Template):
             # device-resident PCG vectors: the variances are uploaded once per template
             amplitudes_in.accel_resident()
             amplitudes_out.accel_resident()
-            if not getattr(self, "_offsetvar_on_dev", False):
-                accel_data_create(self._offsetvar, f"{self.name}_offsetvar", owner=self)
-                accel_data_update_device(self._offsetvar, f"{self.name}_offsetvar")
-                self._offsetvar_on_dev = True
-            native().template_offset_apply_diag_precond(self._offsetvar, amplitudes_in.local,
-                                                        amplitudes_in.local_flags, amplitudes_out.local, True)
+            self._offsetvar_to_device()
+            native().template_offset_apply_diag_precond(self._offsetvar_buf, amplitudes_in.buffer,
+                                                        amplitudes_in.local_flags, amplitudes_out.buffer, True)
             return
         native().template_offset_apply_diag_precond(self._offsetvar, amplitudes_in.local, amplitudes_in.local_flags,
                                                     amplitudes_out.local, False)
@@ -808,20 +861,23 @@ class Offset(Template):
         product that reads its output (toast_hip_pcg_precond_diag_dot_dev)."""
         if self.use_noise_prior or not self._check_enabled() or self._n_local == 0:
             return None
-        if not getattr(self, "_offsetvar_on_dev", False):
-            accel_data_create(self._offsetvar, f"{self.name}_offsetvar", owner=self)
-            accel_data_update_device(self._offsetvar, f"{self.name}_offsetvar")
-            self._offsetvar_on_dev = True
+        self._offsetvar_to_device()
         from ..accel import accel_device_ptr
 
-        return accel_device_ptr(self._offsetvar)
+        return accel_device_ptr(self._offsetvar_buf)
+
+    def _offsetvar_to_device(self):
+        if not getattr(self, "_offsetvar_on_dev", False):
+            accel_data_create(self._offsetvar_buf, f"{self.name}_offsetvar", owner=self)
+            accel_data_update_device(self._offsetvar_buf, f"{self.name}_offsetvar")
+            self._offsetvar_on_dev = True
 
     def clear(self):
         if getattr(self, "_prior", None) is not None:
             self._prior.clear()
-        if getattr(self, "_offsetvar_on_dev", False):
-            accel_data_delete(self._offsetvar, f"{self.name}_offsetvar")
-            self._offsetvar_on_dev = False
+        if getattr(self, "_offsetvar_buf", None) is not None:
+            _ = self._offsetvar          # (somebody may still read the variances on the host)
+            self._drop_offsetvar_device()
         for (iob, on_dev), buf in self._flag_cache.items():
             if on_dev:
                 accel_data_delete(buf, f"{self.name}_solver_flags")

@@ -345,8 +345,8 @@ class OffsetPrior:
         n_seg = self.seg_start.size - 1
         capi.dev.offset_convolve(int(self.seg_start[-1]), n_seg, self._ptr("seg_start"), self._max_seg,
                                  self._ptr("filt_start"), self._ptr("filt_len"), max(f.size for f in self.filters),
-                                 self._ptr("filters"), accel_device_ptr(amps_in.local),
-                                 accel_device_ptr(amps_in.local_flags), accel_device_ptr(amps_out.local), True)
+                                 self._ptr("filters"), accel_device_ptr(amps_in.buffer),
+                                 accel_device_ptr(amps_in.local_flags), accel_device_ptr(amps_out.buffer), True)
 
     def apply_precond(self, amps_in, amps_out):
         """offset.py:963-1005: Toeplitz convolution (width <= 1) or banded Cholesky solve."""
@@ -357,10 +357,10 @@ class OffsetPrior:
         if self.precond_width <= 1:
             capi.dev.offset_convolve(int(self.seg_start[-1]), n_seg, self._ptr("seg_start"), self._max_seg,
                                      self._ptr("pre_start"), self._ptr("pre_len"), max(p.size for p in self.precond),
-                                     self._ptr("pre_filters"), accel_device_ptr(amps_in.local),
-                                     accel_device_ptr(amps_in.local_flags), accel_device_ptr(amps_out.local), False)
+                                     self._ptr("pre_filters"), accel_device_ptr(amps_in.buffer),
+                                     accel_device_ptr(amps_in.local_flags), accel_device_ptr(amps_out.buffer), False)
         else:
             capi.dev.offset_banded_solve(n_seg, self._ptr("seg_start"), self._ptr("band_width"), self.max_width,
                                          self._ptr("band_start"), self._ptr("forward"), self._ptr("backward"),
-                                         accel_device_ptr(amps_in.local), accel_device_ptr(amps_in.local_flags),
-                                         accel_device_ptr(amps_out.local))
+                                         accel_device_ptr(amps_in.buffer), accel_device_ptr(amps_in.local_flags),
+                                         accel_device_ptr(amps_out.buffer))
