@@ -471,7 +471,10 @@ __device__ __forceinline__ double2 pad_combine(double2 r, double2 a, int s, int 
 
 // pass 1 (INV = false) and pass 3 (INV = true), N2 = 2048, aligned timestreams (Params::aligned)
 template <int LOGN, bool INV>
-__global__ __launch_bounds__((1 << ColPlan<LOGN>::LT) / 32, 2) void k_fft_cols_reg(const Params p) {
+#if !defined(TOAST_FFT_FWD_MINWG)
+#define TOAST_FFT_FWD_MINWG 2
+#endif
+__global__ __launch_bounds__((1 << ColPlan<LOGN>::LT) / 32, (INV ? 2 : TOAST_FFT_FWD_MINWG)) void k_fft_cols_reg(const Params p) {
     constexpr int LT = ColPlan<LOGN>::LT;
     constexpr int T = (1 << LT) / 32;
     constexpr int LOGC = LT - LOGN;
