@@ -471,6 +471,9 @@ __device__ __forceinline__ double2 pad_combine(double2 r, double2 a, int s, int 
 
 // pass 1 (INV = false) and pass 3 (INV = true), N2 = 2048, aligned timestreams (Params::aligned)
 template <int LOGN, bool INV>
+#if !defined(TOAST_FFT_WIN_ROUNDS)
+#define TOAST_FFT_WIN_ROUNDS 1
+#endif
 #if !defined(TOAST_FFT_FWD_MINWG)
 #define TOAST_FFT_FWD_MINWG 2
 #endif
@@ -529,9 +532,54 @@ __global__ __launch_bounds__((1 << ColPlan<LOGN>::LT) / 32, (INV ? 2 : TOAST_FFT
         for (int i = 0; i < 32; ++i) {
             const int si = opaque_vgpr(s0 + i * (DK << 12));
             v[i] = *reinterpret_cast<const double2 *>(row + (uint32_t)pad_source(si, n_samp, n_reflect));
+            // one address at a time: hoisted together, the 32 (and the 32 of the window) take the registers the loaded
+            // values need, and the allocator answers with load - wait - spill - load (nine round trips instead of one)
+            __builtin_amdgcn_sched_barrier(0);
         }
+        // ONE memory round trip for the padding: the first 16 window pairs land in registers (64 are free beside the tile),
+        // the other 16 in this wave's 16 KB of the idle exchange buffer (global_load_lds_dwordx4, lane-linear 1 KB per
+        // instruction).  TOAST_FFT_WIN_ROUNDS=4 restores the four double-buffered LDS rounds (three round trips).
         char * stage = reinterpret_cast<char *>(smd) + __builtin_amdgcn_readfirstlane(tid >> 6) * 16384;
         const double2 * staged = reinterpret_cast<const double2 *>(stage) + (tid & 63);
+#if TOAST_FFT_WIN_ROUNDS == 1
+        double2 wr[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int si = opaque_vgpr(s0 + i * (DK << 12));
+            wr[i] = *reinterpret_cast<const double2 *>(p.apod + (uint32_t)pad_window(si, n_samp, n_reflect));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int si = opaque_vgpr(s0 + (16 + i) * (DK << 12));
+            const double * g = p.apod + (uint32_t)pad_window(si, n_samp, n_reflect);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                             (__attribute__((address_space(3))) void *)(stage + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        {
+            const int sb = opaque_vgpr(s0);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                v[k] = pad_combine(v[k], wr[k], sb + k * (DK << 12), n_samp, n_reflect);
+                asm volatile("" : "+v"(v[k].x), "+v"(v[k].y));      // formed HERE (see below)
+            }
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                double2 b4[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) b4[i] = staged[(4 * h + i) * 64];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = 16 + 4 * h + i;
+                    v[k] = pad_combine(v[k], b4[i], sb + k * (DK << 12), n_samp, n_reflect);
+                    asm volatile("" : "+v"(v[k].x), "+v"(v[k].y));
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
         auto issue = [&](int r) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -539,6 +587,7 @@ __global__ __launch_bounds__((1 << ColPlan<LOGN>::LT) / 32, (INV ? 2 : TOAST_FFT
                 const double * g = p.apod + (uint32_t)pad_window(si, n_samp, n_reflect);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                                  (__attribute__((address_space(3))) void *)(stage + ((r & 1) * 8 + i) * 1024), 16, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         };
         auto take = [&](int r) {
@@ -552,6 +601,11 @@ __global__ __launch_bounds__((1 << ColPlan<LOGN>::LT) / 32, (INV ? 2 : TOAST_FFT
                 for (int i = 0; i < 4; ++i) {
                     const int k = 8 * r + 4 * h + i;
                     v[k] = pad_combine(v[k], b4[i], sb + k * (DK << 12), n_samp, n_reflect);
+                    // the product is formed HERE: left alone, the compiler sinks it to its use -- the second butterfly of the
+                    // first stage for every other point --, keeps 16 window pairs alive until then and spills as many
+                    // timestream pairs straight from their loads (load, wait, spill, eight times over: 34 registers of
+                    // scratch, 2.3 GB each way per launch at 2^23, and nine memory round trips where one was meant)
+                    asm volatile("" : "+v"(v[k].x), "+v"(v[k].y));
                 }
             }
         };
@@ -567,6 +621,7 @@ __global__ __launch_bounds__((1 << ColPlan<LOGN>::LT) / 32, (INV ? 2 : TOAST_FFT
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         take(2);
         take(3);
+#endif
         __builtin_amdgcn_sched_barrier(0);      // the padding is finished before the first butterfly starts
     } else {
         const double2 * __restrict__ src = work + ((int64_t)k10 << 11) + j2;
@@ -589,6 +644,7 @@ __global__ __launch_bounds__((1 << ColPlan<LOGN>::LT) / 32, (INV ? 2 : TOAST_FFT
         for (int i = 1; i < 32; ++i) {
             w = cmul(w, wd);
             v[i] = cmul(v[i], w);
+            asm volatile("" : "+v"(v[i].x), "+v"(v[i].y));      // (formed here, not sunk into the butterflies: see pass 1)
         }
     }
     col_fft<LOGN>(v, smd, tid, s_w);
