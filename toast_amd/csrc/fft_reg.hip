@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void k_fft_rows_reg(const Params p) {
 // e mod T, register e / T, so a lane owns ONE column (c = tid mod C) and a load / store instruction of a wave covers
 // 64 / C consecutive rows of C adjacent columns: pieces of 16 C bytes.
 //   n_fft 2^21:  N1 =  512, C = 8 (128-byte pieces), LT = 12, 128 threads, 512 = 16 x 32  (fft_fused.hip: C = 8)
-//   n_fft 2^22:  N1 = 1024, C = 8 (128-byte pieces), LT = 13, 256 threads, 1024 = 32 x 32 (fft_fused.hip: C = 4)
+//   n_fft 2^22:  N1 = 1024, C = 8 (128-byte pieces), LT = 13, 256 threads, 1024 = 16 x 4 x 16 (fft_fused.hip: C = 4)
 //   n_fft 2^23:  N1 = 2048, C = 4 ( 64-byte pieces), LT = 13, 256 threads, 2048 = 16 x 8 x 16 (fft_fused.hip: C = 2:
 //                every 128-byte line is shared by four tiles and crosses HBM 2.3 times, profiles/r04_c section 6)
 template <int LOGN>
@@ -396,7 +396,7 @@ struct ColPlan<9> {
 };
 template <>
 struct ColPlan<10> {
-    static constexpr int LT = 13, R0 = 32, R1 = 32, R2 = 1;
+    static constexpr int LT = 13, R0 = 16, R1 = 4, R2 = 16;     // (32 x 32: the inverse pass spilled 16 registers in its radix-32 butterflies)
 };
 template <>
 struct ColPlan<11> {
@@ -730,14 +730,15 @@ int cols_reg_log_c(int log_n1) { return (log_n1 == 9 ? 12 : 13) - log_n1; }
 // e of w_n^e, n = 2^log_n1); returns their number
 int cols_reg_twiddles(int log_n1, int * out) {
     const int lt = (log_n1 == 9) ? 12 : 13;
-    const int r0 = (log_n1 == 10) ? 32 : 16;
+    const int r0 = 16;
     const int s0 = lt - log_n1;
     int n = 0;
     const int q0 = (1 << lt) / r0;
     for (int h = 0; h < (q0 >> s0); ++h) out[n++] = h;
-    if (log_n1 == 11) {
+    if (log_n1 >= 10) {
+        const int r1 = (log_n1 == 10) ? 4 : 8;
         const int s1 = s0 + 4;
-        const int q1 = (1 << lt) / 8;
+        const int q1 = (1 << lt) / r1;
         for (int h = 0; h < (q1 >> s1); ++h) out[n++] = h << (s1 - s0);
     }
     return n;
