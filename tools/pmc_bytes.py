@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Per kernel: bytes per launch = 32 x (sum over all TCC instances of a *_32B counter), from rocprofv3 --pmc databases.
 
-    pmc_bytes.py <directory prefix> <title> [<prefix> <title> ...]     (directories <prefix><COUNTER>/**/*.db)
+    pmc_bytes.py [--json OUT.json WORKLOAD] <directory prefix> <title> [<prefix> <title> ...]
+                                                                       (directories <prefix><COUNTER>/**/*.db)
+    --json: the LAST prefix' kernels also as profiles/traffic_exact_<workload>.json (what bench.py's roofline.traffic_exact reads)
 """
 import glob
 import sqlite3
@@ -39,6 +41,10 @@ def per_launch(db, counter):
 
 def main():
     args = sys.argv[1:]
+    json_out = workload = None
+    if args and args[0] == "--json":
+        json_out, workload, args = args[1], args[2], args[3:]
+    res = {}
     for prefix, title in zip(args[0::2], args[1::2]):
         print("==", title)
         res = {}
@@ -52,6 +58,20 @@ def main():
             n = max(v[1] for v in d.values())
             print("  %-44s %8d %12.3f %12.3f %12.3f %14.3f" % (name[:44], n, g(COUNTERS[0], 32), g(COUNTERS[1], 32),
                                                              g(COUNTERS[2], 32), g(COUNTERS[3], 128)))
+    if json_out:
+        import json
+
+        kernels = {}
+        for name, d in sorted(res.items()):
+            b = lambda c: float(d.get(c, (0.0, 0))[0] * 32)
+            kernels[name] = {"launches": max(v[1] for v in d.values()), "read_bytes": b(COUNTERS[0]), "written_bytes": b(COUNTERS[1]),
+                             "atomic_bytes": b(COUNTERS[2]), "hbm_bytes": b(COUNTERS[0]) + b(COUNTERS[1]) + b(COUNTERS[2])}
+        with open(json_out, "w") as f:
+            json.dump({"workload": workload, "unit": "bytes per launch",
+                       "counters": "32 B x TCC_EA0_RDREQ_DRAM_32B / TCC_EA0_WRREQ_WRITE_DRAM_32B / TCC_EA0_WRREQ_WRITE_ATOMIC_32B summed over "
+                                   "all TCC instances, one rocprofv3 --pmc pass per counter (tools/gpu_final_profile.sh); exact on known "
+                                   "byte counts (profiles/r04_e)",
+                       "kernels": kernels}, f, indent=1)
 
 
 if __name__ == "__main__":
