@@ -272,6 +272,91 @@ def test_pixel_data_lazy_host_coherence():
         obj.accel_delete()
 
 
+
+def test_amplitudes_lazy_host_coherence():
+    """Amplitudes.local copies back on the first host access only (the solver leaves its vectors device-current under
+    Data.lazy_host); device-side code goes through .buffer / .arg(True); duplicates, scalings and dot products of a
+    device-current vector stay on the device."""
+    from toast_amd import capi
+    from toast_amd.accel import accel_device_ptr
+    from toast_amd.templates import Amplitudes
+
+    n = 5000
+    a = Amplitudes(None, n, n)
+    a.local[:] = np.arange(n, dtype=np.float64)
+    a.local_flags[7] = 1
+    a.accel_resident("lazy_amps")
+    assert a.accel_in_use()
+    capi.dev.vec_axpby(n, 2.0, accel_device_ptr(a.buffer), 0.0, accel_device_ptr(a.buffer))     # a *= 2 on the device
+    assert a.accel_in_use() and a.buffer[3] == 3.0            # the key array is not synchronised
+    assert a.arg(True).ctypes.data == a.buffer.ctypes.data
+    b = a.duplicate()                                          # device-to-device, flags included
+    b *= -1.0
+    assert a.accel_in_use() and b.accel_in_use() and b.buffer[3] == 0.0
+    want = 2.0 * np.arange(n, dtype=np.float64)
+    keep = np.ones(n, dtype=bool)
+    keep[7] = False
+    assert np.isclose(a.dot(b), -np.sum(want[keep] ** 2), rtol=1e-13)
+    assert a.accel_in_use() and b.accel_in_use()
+    assert np.array_equal(b.local, -want)                      # first host access copies back ...
+    assert not b.accel_in_use() and b.accel_exists()
+    assert np.array_equal(a.arg(False), want) and not a.accel_in_use()
+    a.local[0] = 5.0                                           # ... and the host is the current side again
+    a.accel_resident()
+    a.axpby(1.0, b)                                            # either operand device-current: both go there
+    assert a.accel_in_use() and b.accel_in_use()
+    got = a.local
+    assert got[0] == 5.0 and not np.any(got[1:])
+    for v in (a, b):
+        v.clear()
+
+
+def test_mapmaker_leaves_solution_and_offset_variances_on_the_device():
+    """With lazy host coherence (the default) ops.MapMaker hands its solution back device-current -- ApplyAmplitudes read it
+    there -- and the Offset template's variances were never on the host until somebody asked: both equal what the eager
+    mode and the host-side initialisation produce."""
+    from toast_amd import ops
+    from toast_amd.templates import Offset
+    from test_gpu_ops import make_solver_setup
+
+    def run(lazy):
+        data, pix, sw, truth, sky = make_solver_setup(noise_rms=0.2)
+        data.lazy_host = lazy
+        binner = ops.BinMap(pixel_dist="dist", pixel_pointing=pix, stokes_weights=sw, full_pointing=True)
+        tmpl = Offset(step_time=20.0, noise_model=defaults.noise_model, name="baselines", good_fraction=0.2)
+        mapper = ops.MapMaker(name="mm", keep_solver_products=True, det_data=defaults.det_data, binning=binner,
+                              template_matrix=ops.TemplateMatrix(templates=[tmpl]), iter_max=30, convergence=1e-20,
+                              solve_rcond_threshold=1e-3, map_rcond_threshold=1e-3)
+        mapper.apply(data)
+        return data, tmpl
+
+    data, tmpl = run(True)
+    amps = data["mm_solve_amplitudes"]["baselines"]
+    assert amps.accel_in_use()                                 # not copied back by the solver
+    assert getattr(tmpl, "_offsetvar_stale", False)            # computed on the device, host copy pending
+    var_dev = np.array(tmpl._offsetvar)                        # fetched now
+    assert not tmpl._offsetvar_stale
+    # the host-side form of the same initialisation on the same data (keep_solver_products: the solver flags are still there)
+    host = Offset(step_time=20.0, noise_model=defaults.noise_model, name="host_side", good_fraction=0.2)
+    for trait in ("view", "det_data", "det_flags", "det_flag_mask", "det_mask"):
+        setattr(host, trait, getattr(tmpl, trait))
+    for ob in data.obs:
+        _ = ob.detdata[tmpl.det_flags].data                    # (host-current before the accelerator is "switched off")
+    saved = accel.accel_enabled
+    try:
+        accel.accel_enabled = lambda: False
+        host._initialize(data)
+    finally:
+        accel.accel_enabled = saved
+    assert np.array_equal(host._amp_flags, tmpl._amp_flags)
+    assert np.allclose(var_dev, host._offsetvar, rtol=1e-14, atol=0.0)
+    sol_lazy = np.array(amps.local)
+    assert not amps.accel_in_use()
+    data_e, _ = run(False)
+    sol_eager = np.array(data_e["mm_solve_amplitudes"]["baselines"].local)
+    assert np.max(np.abs(sol_lazy - sol_eager)) <= 1e-12 * np.max(np.abs(sol_eager))
+
+
 _CAP_SCRIPT = r"""
 import sys
 import numpy as np
