@@ -907,6 +907,163 @@ __global__ __launch_bounds__(kThreads) void k_build_cov_pair(
     }
 }
 
+// Inverse covariance (+ hits) with TWO consecutive samples per lane and the detector pair of a focalplane pixel per
+// workgroup, like k_build_noise_weighted_v2<2>: one segmented scan per 128 samples instead of one per 64 -- the scan of
+// the six packed products and the hit count is what the kernel spends its vector issue on (counters, round 5:
+// k_build_cov_pair<3, true> 251 vector instructions per detector-sample, 74 % of the issue cycles, 3.8 TB/s).
+// The hit count rides along as value NC and leaves as one integer atomic per run.
+template <int NV, int NC, bool HITS>
+__device__ __forceinline__ void cov_emit(int64_t key, const double (&v)[NV], double * __restrict__ invcov,
+                                         long long * __restrict__ hits) {
+    double * z = invcov + NC * key;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) unsafeAtomicAdd(z + k, v[k]);
+    if constexpr (HITS) atomicAdd((unsigned long long *)(hits + key), (unsigned long long)__double2ll_rn(v[NC]));
+}
+
+// scatter_runs2 (kernel_common.hpp) for the covariance values: A before B in every lane
+template <int NV, int NC, bool HITS>
+__device__ __forceinline__ void cov_scatter_runs2(int64_t ka, double (&va)[NV], int64_t kb, double (&vb)[NV],
+                                                  double * __restrict__ invcov, long long * __restrict__ hits) {
+    const int lane = threadIdx.x & 63;
+    const bool same = ka == kb;
+    const bool apart = !same & (ka >= 0);
+    if (same) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) vb[k] += va[k];
+    }
+    if (__any(apart)) {
+        const int64_t prev_b = dpp_i64<kDppWaveShr1>(kb);
+        const bool give = apart & (lane > 0) & (prev_b == ka);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) vb[k] += dpp_f64<kDppWaveShl1>(give ? va[k] : 0.0);
+        if (apart & !give) cov_emit<NV, NC, HITS>(ka, va, invcov, hits);
+    }
+    const bool tail = wave_run_reduce<NV>(kb, vb);
+    if (tail && kb >= 0) cov_emit<NV, NC, HITS>(kb, vb, invcov, hits);
+}
+
+template <bool HITS>
+__global__ __launch_bounds__(kThreads) void k_build_cov_pair_v2(
+    const Chunk * __restrict__ chunks, int n_chunks, int n_det, const int32_t * __restrict__ p_idx,
+    const int32_t * __restrict__ w_idx, const int32_t * __restrict__ f_idx,
+    const double * __restrict__ det_scale, const int64_t * __restrict__ g2l,
+    double * __restrict__ invcov, const int64_t * __restrict__ pixels,
+    const double * __restrict__ weights, const uint8_t * __restrict__ dflags, uint8_t dmask,
+    int use_dflags, const uint8_t * __restrict__ sflags, uint8_t smask, int use_sflags,
+    FastDiv nps_div, int64_t n_samp, long long * __restrict__ hits) {
+    constexpr int NNZ = 3, NC = 6, NV = NC + (HITS ? 1 : 0), E = 2;
+    const int det0 = E * blockIdx.x;
+    bool on[E];
+    const int64_t * prow[E];
+    const double * wrow[E];
+    const uint8_t * frow[E];
+    double ds[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        on[e] = det0 + e < n_det;
+        const int det = on[e] ? det0 + e : det0;
+        prow[e] = pixels + (int64_t)p_idx[det] * n_samp;
+        wrow[e] = weights + (int64_t)w_idx[det] * n_samp * NNZ;
+        frow[e] = use_dflags ? dflags + (int64_t)f_idx[det] * n_samp : nullptr;
+        ds[e] = det_scale[det];
+    }
+    const int64_t nps = nps_div.d;
+    const uint16_t dmask2 = (uint16_t)(dmask | (dmask << 8));
+    const uint16_t smask2 = (uint16_t)(smask | (smask << 8));
+    // packed upper triangle of (scale w) w^T, the operation order of k_build_cov_pair
+    auto products = [](double (&v)[NV], double wa, double wb, double wc, double scale, bool good) {
+        const double sa = wa * scale, sb = wb * scale, sc = wc * scale;
+        v[0] = good ? wa * sa : 0.0;
+        v[1] = good ? wb * sa : 0.0;
+        v[2] = good ? wc * sa : 0.0;
+        v[3] = good ? wb * sb : 0.0;
+        v[4] = good ? wc * sb : 0.0;
+        v[5] = good ? wc * sc : 0.0;
+        if constexpr (HITS) v[NC] = good ? 1.0 : 0.0;
+    };
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        const int head = (int)(c.first & 1);
+        const int64_t s0 = c.first + head;          // even
+        const int n_pair = (c.count - head) >> 1;
+        for (int base = 0; base < n_pair; base += kThreads) {
+            const int j = base + threadIdx.x;
+            const bool active = j < n_pair;
+            const int64_t s = s0 + 2 * (int64_t)(active ? j : 0);
+            // all streaming loads of both samples of both detectors first (inactive lanes re-read pair 0: same lines)
+            longlong2 pp[E];
+            double2 w0[E], w1[E], w2[E];
+            uint16_t fd[E];
+            const uint16_t fs = use_sflags ? *reinterpret_cast<const uint16_t *>(sflags + s) : (uint16_t)0;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                pp[e] = *reinterpret_cast<const longlong2 *>(prow[e] + s);
+                fd[e] = use_dflags ? *reinterpret_cast<const uint16_t *>(frow[e] + s) : (uint16_t)0;
+                const double2 * wv = reinterpret_cast<const double2 *>(wrow[e] + NNZ * s);
+                w0[e] = wv[0];
+                w1[e] = wv[1];
+                w2[e] = wv[2];
+            }
+            int64_t ga[E], gb[E], la[E], lb[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                ga[e] = fastdiv(pp[e].x >= 0 ? pp[e].x : 0, nps_div);
+                gb[e] = fastdiv(pp[e].y >= 0 ? pp[e].y : 0, nps_div);
+                la[e] = g2l[ga[e]];
+                lb[e] = g2l[gb[e]];
+            }
+            int64_t ka[E], kb[E];
+            double va[E][NV], vb[E][NV];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const uint16_t bad = (uint16_t)((fd[e] & dmask2) | (fs & smask2));
+                const bool good_a = active & on[e] & (pp[e].x >= 0) & (la[e] >= 0) & ((bad & 0x00ff) == 0);
+                const bool good_b = active & on[e] & (pp[e].y >= 0) & (lb[e] >= 0) & ((bad & 0xff00) == 0);
+                ka[e] = good_a ? la[e] * nps + (pp[e].x - ga[e] * nps) : -1;
+                kb[e] = good_b ? lb[e] * nps + (pp[e].y - gb[e] * nps) : -1;
+                products(va[e], w0[e].x, w0[e].y, w1[e].x, ds[e], good_a);
+                products(vb[e], w1[e].y, w2[e].x, w2[e].y, ds[e], good_b);
+            }
+            const bool mergeable = ((ka[0] == ka[1]) | (ka[0] < 0) | (ka[1] < 0)) &
+                                   ((kb[0] == kb[1]) | (kb[0] < 0) | (kb[1] < 0));
+            if (__all(mergeable)) {
+                const int64_t kam = (ka[0] >= 0) ? ka[0] : ka[1];
+                const int64_t kbm = (kb[0] >= 0) ? kb[0] : kb[1];
+                double vam[NV], vbm[NV];
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    vam[k] = va[0][k] + va[1][k];
+                    vbm[k] = vb[0][k] + vb[1][k];
+                }
+                cov_scatter_runs2<NV, NC, HITS>(kam, vam, kbm, vbm, invcov, hits);
+                continue;
+            }
+#pragma unroll
+            for (int e = 0; e < E; ++e) cov_scatter_runs2<NV, NC, HITS>(ka[e], va[e], kb[e], vb[e], invcov, hits);
+        }
+        // the peeled first sample (lane 0) and the odd last one (lane 1)
+        const int tail = (c.count - head) & 1;
+        if ((threadIdx.x == 0 && head) || (threadIdx.x == 1 && tail)) {
+            const int64_t s = (threadIdx.x == 0) ? c.first : c.first + c.count - 1;
+            const uint8_t fs = use_sflags ? sflags[s] : (uint8_t)0;
+            for (int e = 0; e < E; ++e) {
+                if (!on[e]) continue;
+                const int64_t px = prow[e][s];
+                const uint8_t fd = use_dflags ? frow[e][s] : (uint8_t)0;
+                if ((px < 0) | ((fd & dmask) != 0) | ((fs & smask) != 0)) continue;
+                const int64_t gsm = fastdiv(px, nps_div);
+                const int64_t key = g2l[gsm] * nps + (px - gsm * nps);
+                if (key < 0) continue;
+                const double * w = wrow[e] + NNZ * s;
+                double v[NV];
+                products(v, w[0], w[1], w[2], ds[e], true);
+                cov_emit<NV, NC, HITS>(key, v, invcov, hits);
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // Per-pixel inversion of the packed symmetric covariance through its eigen-decomposition
 // (cov_eigendecompose_diag, src/libtoast/src/toast_map_cov.cpp:246-396): rcond = emin/emax;
@@ -2683,7 +2840,17 @@ static int build_cov_launch(
             hipLaunchKernelGGL((k_build_cov<1, 0>), grid, dim3(kThreads), 0, st, TH_COV_ARGS);
         } else if (nnz == 3 && pair_detectors() && n_det >= 2) {
             const dim3 gp((unsigned)((n_det + 1) / 2), grid.y, 1);
-            if (d_hits != nullptr) {
+            // two samples per lane when every row starts on a 16-byte boundary (TOAST_HIP_VEC2=0: one sample per lane)
+            const bool v2 = vec2_lanes() && (n_samp & 1) == 0 && rows_16b(d_pixels) && rows_16b(d_weights) &&
+                            (!use_d || rows_16b(d_det_flags)) && (!use_s || rows_16b(d_shared_flags));
+            if (v2) {
+                hipLaunchKernelGGL(d_hits != nullptr ? k_build_cov_pair_v2<true> : k_build_cov_pair_v2<false>, gp,
+                                   dim3(kThreads), 0, st, (const Chunk *)(d + o_ch), (int)chunks.size(), (int)n_det,
+                                   (const int32_t *)(d + o_pi), (const int32_t *)(d + o_wi), (const int32_t *)(d + o_fi),
+                                   (const double *)(d + o_ds), d_g2l, (double *)d_out, d_pixels, d_weights, d_det_flags,
+                                   det_flag_mask, use_d, d_shared_flags, shared_flag_mask, use_s, dv, n_samp,
+                                   (long long *)d_hits);
+            } else if (d_hits != nullptr) {
                 hipLaunchKernelGGL((k_build_cov_pair<3, true>), gp, dim3(kThreads), 0, st, (const Chunk *)(d + o_ch),
                                    (int)chunks.size(), (int)n_det, (const int32_t *)(d + o_pi),
                                    (const int32_t *)(d + o_wi), (const int32_t *)(d + o_fi), (const double *)(d + o_ds),
