@@ -806,10 +806,11 @@ int toast_hip_fft_extend_flags(uint8_t * flags, int64_t n_flag_rows, const int32
  * workgroups with radix-8 stages and twice the waves per SIMD.  Defaults 8 / 8 / 8; start-up value
  * from TOAST_HIP_FFT_POINTS="rows,cols_fwd,cols_inv". */
 void toast_hip_fft_points(int rows, int cols_fwd, int cols_inv);
-/* Row pass of the fused kernels: 2 (default) = one row of N2 = 2048 bins per WAVE, the tile in registers and the LDS
- * only an exchange buffer (csrc/fft_reg.hip); 0 = both rows of a pair (k1, N1 - k1) interleaved in one 64 KB LDS tile;
- * 1 = one row per 32 KB LDS tile (experiment: register bound, slower).  Start-up value from
- * TOAST_HIP_FFT_ROWS=reg|lds|split.  Same results to rounding. */
+/* Row pass of the fused kernels: 2 (default) = the tile in registers and the LDS only an exchange buffer, 16 points per
+ * lane: a row of N2 = 2048 bins in two waves, the row pair (k1, N1 - k1) in one workgroup, three workgroups per CU
+ * (csrc/fft_reg.hip); 3 = 32 points per lane, one row per wave, two workgroups per CU; 0 = both rows of a pair interleaved
+ * in one 64 KB LDS tile; 1 = one row per 32 KB LDS tile (experiment: register bound, slower).  Start-up value from
+ * TOAST_HIP_FFT_ROWS=reg|reg32|lds|split.  Same results to rounding. */
 void toast_hip_fft_rows_split(int split);
 /* Column passes of the fused kernels: 1 (default) = the tile in registers (csrc/fft_reg.hip) for n_fft 2^22 and 2^23
  * (N2 = 2048, even n_samp / padding: 128- and 64-byte pieces where the LDS tile gives 64 and 32), 2 = for n_fft 2^21 too,

@@ -284,7 +284,7 @@ def test_fused_complex_kernels_and_common_kernel(pf, deconvolve):
         assert np.max(np.abs(got - want)) < (1e-11 if deconvolve else TOL) * np.max(np.abs(want))
 
 
-@pytest.mark.parametrize("rows", ["reg", "pair", "split"])
+@pytest.mark.parametrize("rows", ["reg", "reg32", "pair", "split"])
 @pytest.mark.parametrize("tables", ["lds-complex", "lds-dense", "global-dense", "global-complex"])
 def test_fused_kernel_table_paths(pf, rows, tables):
     """Row pass of the fused pipeline: kernel tables in LDS (few knots) or in global memory (many), interval search
@@ -324,7 +324,7 @@ def test_fused_kernel_table_paths(pf, rows, tables):
 
 @pytest.mark.parametrize("n_samp", [720000, 1100000, 1440000, 2200000, 2880000])
 def test_register_tile_passes_against_lds_tile_passes(pf, n_samp):
-    """csrc/fft_reg.hip (round 5): the row pass with one row per wave and the column passes with the tile in registers
+    """csrc/fft_reg.hip (round 5): the row pass with the tile in registers (16 points per lane: "reg"; 32: "reg32") and the column passes with the tile in registers
     (n_fft 2^21 / 2^22 / 2^23: column tiles of 512 x 8, 1024 x 8, 2048 x 4) against the oracle and against the LDS-tile
     kernels of fft_fused.hip, per-detector kernels, rows through an index."""
     from oracle import fft_oracle as fo
@@ -340,7 +340,7 @@ def test_register_tile_passes_against_lds_tile_passes(pf, n_samp):
     scale = np.max(np.abs(want))
     out = {}
     try:
-        for cols, rowmode in (("reg9", "reg"), ("lds", "pair"), ("reg9", "pair"), ("lds", "reg")):
+        for cols, rowmode in (("reg9", "reg"), ("lds", "pair"), ("reg9", "pair"), ("lds", "reg"), ("reg9", "reg32")):
             pf.set_cols_mode(cols)
             pf.set_rows_mode(rowmode)
             got = buf.copy()

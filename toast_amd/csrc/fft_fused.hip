@@ -54,6 +54,7 @@ namespace fused_fft {
 // fft_reg.hip
 bool rows_reg_supported(const Params & p);
 void launch_rows_reg(const Params & p, unsigned n_det, bool tab_lds, size_t tab_bytes, hipStream_t st);
+void launch_rows_reg16(const Params & p, unsigned n_det, bool tab_lds, size_t tab_bytes, hipStream_t st);
 void pack_tables(const Params & p, char * blob, int64_t n_kern, hipStream_t st);
 bool cols_reg_supported(const Params & p, int min_log_n1);
 int cols_reg_log_c(int log_n1);
@@ -661,9 +662,10 @@ int points_of(int pass) {
     read_points();
     return g_points[pass];
 }
-// row pass: 2 (default) = one row per wave, tile in registers (k_fft_rows_reg, fft_reg.hip); 0 = row pair per 64 KB LDS
+// row pass: 2 (default) = tile in registers, 16 points per lane: a row in two waves, three workgroups per CU
+// (k_fft_rows_reg16, fft_reg.hip); 3 = 32 points per lane, one row per wave (k_fft_rows_reg); 0 = row pair per 64 KB LDS
 // tile (k_fft_rows); 1 = one row per 32 KB tile (k_fft_rows_split: experiment; needs more registers than four
-// workgroups per CU leave).  TOAST_HIP_FFT_ROWS=reg|lds|split / toast_hip_fft_rows_split(mode)
+// workgroups per CU leave).  TOAST_HIP_FFT_ROWS=reg|reg32|lds|split / toast_hip_fft_rows_split(mode)
 namespace {
 int g_rows_split = -1;
 }
@@ -671,11 +673,11 @@ int rows_split() {
     if (g_rows_split < 0) {
         const char * e = std::getenv("TOAST_HIP_FFT_ROWS");
         const std::string v = (e != nullptr) ? std::string(e) : std::string();
-        g_rows_split = (v == "split") ? 1 : (v == "lds") ? 0 : 2;
+        g_rows_split = (v == "split") ? 1 : (v == "lds") ? 0 : (v == "reg32") ? 3 : 2;
     }
     return g_rows_split;
 }
-void set_rows_split(int split) { g_rows_split = (split == 1 || split == 2) ? split : 0; }
+void set_rows_split(int split) { g_rows_split = (split >= 1 && split <= 3) ? split : 0; }
 namespace {
 int g_rows_n2 = -1;
 }
@@ -797,7 +799,7 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
     p.work = (double2 *)(scratch + hint_bytes + blob_bytes);
     hipLaunchKernelGGL(k_knot_hint, dim3((unsigned)((n_hint + n_hint0 + 255) / 256)), dim3(256), 0, st, d_knots,
                        (int)n_knot, fstep, p.log_n1, n_hint, d_hint, d_hint16, d_hint0);
-    if (blob_bytes && rows_split() == 2) pack_tables(p, scratch + hint_bytes, n_kern, st);
+    if (blob_bytes && rows_split() >= 2) pack_tables(p, scratch + hint_bytes, n_kern, st);
     static int tab_lds_env = -1;
     if (tab_lds_env < 0) {
         const char * e = std::getenv("TOAST_HIP_FFT_TABLES");      // "global": experiment switch
@@ -858,7 +860,7 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
         } else {
             hipLaunchKernelGGL((k_fft_cols<kLT, 16, false>), dim3(n_col_tiles, (unsigned)nb), dim3(kTile / 16), lds, st, p);
         }
-        const bool reg_rows = rows_split() == 2 && !half_rows && rows_reg_supported(p);
+        const bool reg_rows = rows_split() >= 2 && !half_rows && rows_reg_supported(p);
         const bool split = rows_split() == 1 && !half_rows;
         // split / registers: rows 0 and N1 / 2 only (self-paired)
         const dim3 g_pair((split || reg_rows) ? 1 : n_row_tiles, (unsigned)nb);
@@ -880,7 +882,10 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
         } else {
             hipLaunchKernelGGL((k_fft_rows<kLT, 16, false>), g_pair, dim3(kTile / 16), lds_rows, st, p);
         }
-        if (reg_rows) launch_rows_reg(p, (unsigned)nb, tab_lds, tab_bytes, st);
+        if (reg_rows) {
+            if (rows_split() == 2) launch_rows_reg16(p, (unsigned)nb, tab_lds, tab_bytes, st);
+            else launch_rows_reg(p, (unsigned)nb, tab_lds, tab_bytes, st);
+        }
         if (split && n_row_tiles > 1) {
             const dim3 gr(n_row_tiles - 1, (unsigned)nb), bl(kTile / 16);
             if (tab_lds) {

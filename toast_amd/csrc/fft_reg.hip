@@ -378,6 +378,113 @@ __global__ __launch_bounds__(256, 2) void k_fft_rows_reg(const Params p) {
     RCLK_MARK(6);       // stores
 }
 
+// The same pass with SIXTEEN points per lane: a row of 2048 in two waves, the row pair (g, N1 - g) in one workgroup of 256
+// threads.  Half the registers (64 of data), 35 KB of exchange buffers per workgroup instead of 70: three workgroups per CU
+// = three waves per SIMD where k_fft_rows_reg has two -- the pass is bound by how badly two waves per SIMD overlap their
+// waits (profiles/r05_a section 3), not by instructions or bytes.  Element q = l + 128 i of a row sits in lane l (0 .. 127 of
+// the row's half of the workgroup), register i; the mirrored last stage of the second row leaves element 127 - l + 128 j in
+// register j, so bin q of row g meets bin 2047 - q of row N1 - g in the same lane, register 15 - i.  The exchanges
+// synchronise with workgroup barriers (both rows run the same sequence).
+__device__ __forceinline__ void row_fft_2048_p16(double2 (&v)[16], double * smd, int l, bool mirror_in, bool mirror_out,
+                                                 const double2 * __restrict__ s_w) {
+    reg_butterflies<11, 16, 16>(v, l, mirror_in, 0, s_w);
+    reg_exchange<11, 16, 16, 8, 0>(v, smd, l, mirror_in, false);
+    reg_butterflies<11, 16, 8>(v, l, false, 4, s_w + 128);
+    reg_exchange<11, 16, 8, 16, 4>(v, smd, l, false, mirror_out);
+    reg_butterflies<11, 16, 16>(v, l, mirror_out, 7, nullptr);
+}
+
+template <bool TLDS, bool CPLX>
+__global__ __launch_bounds__(256, 3) void k_fft_rows_reg16(const Params p) {
+    extern __shared__ double2 sm[];           // 2 x 17 KB exchange buffers (one per row), stage twiddles, kernel tables
+    const int tid = threadIdx.x;
+    const int l = tid & 127;
+    const int side = __builtin_amdgcn_readfirstlane(tid >> 7);      // 0: row g, 1: row N1 - g
+    const int b = blockIdx.y;
+    const int n1 = 1 << p.log_n1;
+    const int64_t m = (int64_t)n1 << 11;
+    const int g = 1 + (int)blockIdx.x;
+    const int64_t row = side ? (n1 - g) : g;
+    const int64_t kern = p.per_det ? (int64_t)(p.det0 + b) : 0;
+    double2 * s_w = sm + 2 * (kPadRow / 2);                        // 144 stage twiddles
+    char * s_tab = reinterpret_cast<char *>(s_w + 144);           // the kernel tables
+    uint4 tc[3];
+    const int n_chunk = TLDS ? (p.tab_bytes >> 4) : 0;            // <= 768 (launch_rows_reg16)
+    if (TLDS) {
+        const uint4 * __restrict__ g_tab = reinterpret_cast<const uint4 *>(p.tab_blob + kern * (int64_t)p.tab_bytes);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) tc[j] = (tid + 256 * j < n_chunk) ? g_tab[tid + 256 * j] : make_uint4(0, 0, 0, 0);
+    }
+    const double2 tws = (tid < 144) ? p.wrow[tid] : make_double2(0.0, 0.0);
+    int lo_g = __builtin_amdgcn_readfirstlane(p.knot_hint0[g]);
+    int lo_ng = __builtin_amdgcn_readfirstlane(p.knot_hint0[n1 - g]);
+    // w_N^k = w_N^g w_4096^q = (w_N^g w_4096^l) w_32^r for bin k = g + N1 q, q = l + 128 r
+    double2 w0 = cmul(tw_big(p.tb, g), p.tb.wtile[l]);
+    const double2 * __restrict__ rowp = p.work + (int64_t)b * m + (row << 11) + l;
+    double2 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = rowp[128 * i];
+    if (TLDS) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            if (tid + 256 * j < n_chunk) reinterpret_cast<uint4 *>(s_tab)[tid + 256 * j] = tc[j];
+        }
+    }
+    if (tid < 144) s_w[tid] = tws;
+    asm volatile("" : "+v"(w0.x), "+v"(w0.y), "+s"(lo_g), "+s"(lo_ng));   // here, not where they are first used
+    __syncthreads();
+    KTab<typename KTabSel<TLDS>::H> kt;
+    if constexpr (TLDS) {
+        const int n_coef = 4 * (p.n_knot - 1);
+        const double * s_knots = reinterpret_cast<const double *>(s_tab);
+        kt.knots = s_knots;
+        kt.mc = s_knots + p.n_knot;
+        kt.ac = CPLX ? kt.mc + n_coef : nullptr;
+        kt.hint = reinterpret_cast<const typename KTabSel<TLDS>::H *>(kt.mc + n_coef * (CPLX ? 2 : 1));
+        kt.hint0 = p.knot_hint0;
+        kt.log_n1 = p.log_n1;
+        kt.fstep = p.fstep;
+    } else {
+        kt = KTabSel<false>::make(p, kern, nullptr, tid, 256);
+        if (!CPLX) kt.ac = nullptr;
+    }
+    double2 * own = sm + side * (kPadRow / 2);
+    double2 * oth = sm + (side ^ 1) * (kPadRow / 2);
+    double * smd = reinterpret_cast<double *>(own);
+
+    row_fft_2048_p16(v, smd, l, false, side != 0, s_w);
+    // each half works on ITS registers 0 .. 7 and hands registers 8 .. 15 to its partner through its own buffer: own
+    // register i meets the partner's register 15 - i = 8 + jj, jj = 7 - i, on both sides
+    __syncthreads();            // (the last exchange's reads of this buffer are done)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) own[j * 128 + l] = v[8 + j];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int jj = 7 - i;
+        const int r = side ? (8 + jj) : i;             // register of row g = the element's high bits
+        const int k = g + n1 * (l + 128 * r);
+        const double2 part = oth[jj * 128 + l];
+        const double2 mine = v[i];
+        double2 za = make_double2(side ? part.x : mine.x, side ? part.y : mine.y);
+        double2 zb = make_double2(side ? mine.x : part.x, side ? mine.y : part.y);
+        const double2 w32 = make_double2(side ? kC64[2 * (8 + jj)] : kC64[2 * i], side ? -kS64[2 * (8 + jj)] : -kS64[2 * i]);
+        const double2 wk = cmul(w0, w32);
+        pair_update_reg(za, zb, false, wk, kernel_eval(kt, kernel_interval_pre(kt, k, g, lo_g, lo_ng), k),
+                        kernel_eval(kt, kernel_interval_pre(kt, (int)m - k, g, lo_g, lo_ng), (int)m - k), p.deconvolve);
+        v[i] = make_double2(side ? zb.x : za.x, side ? zb.y : za.y);
+        oth[jj * 128 + l] = make_double2(side ? za.x : zb.x, side ? za.y : zb.y);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[8 + j] = own[j * 128 + l];
+    // (the next exchange starts with a barrier: taken back before the buffer is written again)
+    row_fft_2048_p16(v, smd, l, side != 0, false, s_w);
+    double2 * __restrict__ outp = p.work + (int64_t)b * m + (row << 11) + opaque_vgpr(l);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) outp[128 * i] = v[i];
+}
+
 // ------------------------------------------------------------------------------------------
 // column passes with the tile in registers
 // ------------------------------------------------------------------------------------------
@@ -715,6 +822,33 @@ void launch_rows_reg(const Params & p, unsigned n_det, bool tab_lds, size_t tab_
     } else {
         if (cplx) hipLaunchKernelGGL((k_fft_rows_reg<false, true>), grid, dim3(256), rows_reg_lds(0), st, p);
         else hipLaunchKernelGGL((k_fft_rows_reg<false, false>), grid, dim3(256), rows_reg_lds(0), st, p);
+    }
+}
+
+// k_fft_rows_reg16: one row pair per workgroup; LDS = two row buffers + twiddles + tables (<= 12 KB: three 16-byte chunks per thread)
+size_t rows_reg16_lds(size_t tab_bytes) { return 2 * kPadRow * sizeof(double) + 144 * sizeof(double2) + tab_bytes; }
+
+void launch_rows_reg16(const Params & p, unsigned n_det, bool tab_lds, size_t tab_bytes, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        const int most = (int)rows_reg16_lds(kTabLdsReg);
+        auto set = [&](const void * fn) { TH_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, most)); };
+        set(reinterpret_cast<const void *>(&k_fft_rows_reg16<true, false>));
+        set(reinterpret_cast<const void *>(&k_fft_rows_reg16<true, true>));
+        set(reinterpret_cast<const void *>(&k_fft_rows_reg16<false, false>));
+        set(reinterpret_cast<const void *>(&k_fft_rows_reg16<false, true>));
+        attr_set = true;
+    }
+    const int n_pair = (1 << p.log_n1) / 2 - 1;                  // row pairs g = 1 .. N1 / 2 - 1
+    if (n_pair <= 0) return;
+    const dim3 grid((unsigned)n_pair, n_det);
+    const bool cplx = p.ang_coef != nullptr;
+    if (tab_lds && p.tab_blob != nullptr && tab_bytes <= kTabLdsReg) {
+        if (cplx) hipLaunchKernelGGL((k_fft_rows_reg16<true, true>), grid, dim3(256), rows_reg16_lds(tab_bytes), st, p);
+        else hipLaunchKernelGGL((k_fft_rows_reg16<true, false>), grid, dim3(256), rows_reg16_lds(tab_bytes), st, p);
+    } else {
+        if (cplx) hipLaunchKernelGGL((k_fft_rows_reg16<false, true>), grid, dim3(256), rows_reg16_lds(0), st, p);
+        else hipLaunchKernelGGL((k_fft_rows_reg16<false, false>), grid, dim3(256), rows_reg16_lds(0), st, p);
     }
 }
 

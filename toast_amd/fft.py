@@ -38,9 +38,10 @@ def set_points(rows=0, cols_fwd=0, cols_inv=0):
 
 
 def set_rows_mode(mode="reg"):
-    """Row pass of the fused kernels: "reg" (default: one row per wave, tile in registers, fft_reg.hip), "pair" (row pair
-    in one 64 KB LDS tile) or "split" (one row per 32 KB LDS tile; experiment)."""
-    capi.lib().toast_hip_fft_rows_split(C.c_int({"pair": 0, "lds": 0, "split": 1, "reg": 2}[mode]))
+    """Row pass of the fused kernels: "reg" (default: tile in registers, 16 points per lane = a row in two waves, three
+    workgroups per CU; fft_reg.hip), "reg32" (32 points per lane, one row per wave), "pair" (row pair in one 64 KB LDS tile)
+    or "split" (one row per 32 KB LDS tile; experiment)."""
+    capi.lib().toast_hip_fft_rows_split(C.c_int({"pair": 0, "lds": 0, "split": 1, "reg": 2, "reg32": 3}[mode]))
 
 
 def set_cols_mode(mode="reg"):
