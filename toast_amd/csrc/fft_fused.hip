@@ -74,6 +74,10 @@ static int cols_mode() {
     return g_cols_mode;
 }
 static bool cols_reg_for(const Params & p) { return cols_mode() != 0 && cols_reg_supported(p, cols_mode() == 2 ? 9 : 10); }
+// pass 3 at N1 = 512 (n_fft 2^21) runs in registers unless the LDS tile is asked for at every length (mode 0): there the
+// forward LDS-tile kernel and the register kernel are a tie (2.75-3.07 against 2.94-2.97 ms from box to box), the inverse
+// register kernel with 16 points per lane is 10 % ahead (same tile geometry: 8 columns)
+static bool cols_inv_reg_for(const Params & p) { return cols_mode() != 0 && cols_reg_supported(p, 9); }
 void set_cols_reg(int on) { g_cols_mode = (on == 2) ? 2 : (on ? 1 : 0); }
 
 // pass 1 (INV = false) and pass 3 (INV = true): transforms of length N1 down the columns
@@ -894,7 +898,7 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
                 hipLaunchKernelGGL((k_fft_rows_split<8, 2, false>), gr, bl, lds_split, st, p);
             }
         }
-        if (cols_reg) {
+        if (cols_reg || cols_inv_reg_for(p)) {
             launch_cols_reg(p, true, (unsigned)nb, st);
         } else if (points_of(2) == 8) {
             hipLaunchKernelGGL((k_fft_cols<kLT, 8, true>), dim3(n_col_tiles, (unsigned)nb), dim3(kTile / 8), lds, st, p);

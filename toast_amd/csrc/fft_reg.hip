@@ -491,7 +491,8 @@ __global__ __launch_bounds__(256, 3) void k_fft_rows_reg16(const Params p) {
 // Tile = N1 rows x C columns = 2^LT points, 32 per lane, T = 2^LT / 32 threads; element e = k1 C + c sits in thread
 // e mod T, register e / T, so a lane owns ONE column (c = tid mod C) and a load / store instruction of a wave covers
 // 64 / C consecutive rows of C adjacent columns: pieces of 16 C bytes.
-//   n_fft 2^21:  N1 =  512, C = 8 (128-byte pieces), LT = 12, 128 threads, 512 = 16 x 32  (fft_fused.hip: C = 8)
+//   n_fft 2^21:  N1 =  512, C = 8 (128-byte pieces), LT = 12, 128 threads, 512 = 16 x 4 x 8 (fft_fused.hip: C = 8);
+//                pass 3: 256 threads of 16 points (k_fft_cols_inv16)
 //   n_fft 2^22:  N1 = 1024, C = 8 (128-byte pieces), LT = 13, 256 threads, 1024 = 16 x 4 x 16 (fft_fused.hip: C = 4)
 //   n_fft 2^23:  N1 = 2048, C = 4 ( 64-byte pieces), LT = 13, 256 threads, 2048 = 16 x 8 x 16 (fft_fused.hip: C = 2:
 //                every 128-byte line is shared by four tiles and crosses HBM 2.3 times, profiles/r04_c section 6)
@@ -499,7 +500,7 @@ template <int LOGN>
 struct ColPlan;
 template <>
 struct ColPlan<9> {
-    static constexpr int LT = 12, R0 = 16, R1 = 32, R2 = 1;
+    static constexpr int LT = 12, R0 = 16, R1 = 4, R2 = 8;
 };
 template <>
 struct ColPlan<10> {
@@ -526,22 +527,23 @@ constexpr int col_tw_count() {
     return n;
 }
 
-template <int LOGN>
-__device__ __forceinline__ void col_fft(double2 (&v)[32], double * smd, int tid, const double2 * __restrict__ s_w) {
+template <int LOGN, int P>
+__device__ __forceinline__ void col_fft(double2 (&v)[P], double * smd, int tid, const double2 * __restrict__ s_w) {
     using PL = ColPlan<LOGN>;
     constexpr int LT = PL::LT;
     constexpr int s0 = LT - LOGN;
     constexpr int s1 = s0 + Log2<PL::R0>::v;
-    reg_butterflies<LT, 32, PL::R0>(v, tid, false, s0, s_w);
-    reg_exchange<LT, 32, PL::R0, PL::R1, s0>(v, smd, tid, false, false);
+    static_assert(PL::R0 <= P && PL::R1 <= P && PL::R2 <= P, "col_fft: a butterfly does not fit a lane");
+    reg_butterflies<LT, P, PL::R0>(v, tid, false, s0, s_w);
+    reg_exchange<LT, P, PL::R0, PL::R1, s0>(v, smd, tid, false, false);
     if constexpr (PL::R2 > 1) {
         constexpr int s2 = s1 + Log2<PL::R1>::v;
         constexpr int n0 = ((1 << LT) / PL::R0) >> s0;
-        reg_butterflies<LT, 32, PL::R1>(v, tid, false, s1, s_w + n0);
-        reg_exchange<LT, 32, PL::R1, PL::R2, s1>(v, smd, tid, false, false);
-        reg_butterflies<LT, 32, PL::R2>(v, tid, false, s2, nullptr);
+        reg_butterflies<LT, P, PL::R1>(v, tid, false, s1, s_w + n0);
+        reg_exchange<LT, P, PL::R1, PL::R2, s1>(v, smd, tid, false, false);
+        reg_butterflies<LT, P, PL::R2>(v, tid, false, s2, nullptr);
     } else {
-        reg_butterflies<LT, 32, PL::R1>(v, tid, false, s1, nullptr);
+        reg_butterflies<LT, P, PL::R1>(v, tid, false, s1, nullptr);
     }
 }
 
@@ -754,7 +756,7 @@ __global__ __launch_bounds__((1 << ColPlan<LOGN>::LT) / 32, (INV ? 2 : TOAST_FFT
             asm volatile("" : "+v"(v[i].x), "+v"(v[i].y));      // (formed here, not sunk into the butterflies: see pass 1)
         }
     }
-    col_fft<LOGN>(v, smd, tid, s_w);
+    col_fft<LOGN, 32>(v, smd, tid, s_w);
     const int tid_tail = opaque_vgpr(tid);
     const int64_t j2t = ((int64_t)bx << LOGC) + (tid_tail & ((1 << LOGC) - 1));
     const int k10t = tid_tail >> LOGC;
@@ -787,6 +789,65 @@ __global__ __launch_bounds__((1 << ColPlan<LOGN>::LT) / 32, (INV ? 2 : TOAST_FFT
             if ((unsigned)sidx < (unsigned)n_samp) {
                 *reinterpret_cast<double2 *>(row + sidx) = make_double2(v[i].y * p.scale, v[i].x * p.scale);
             }
+        }
+    }
+}
+
+// Pass 3 with SIXTEEN points per lane, for N1 = 512 (n_fft 2^21): the 4096-point tile in 256 threads, 120 registers, 35 KB
+// of LDS: four workgroups = four waves per SIMD, where k_fft_cols_reg<9, true> has two (2024 against 2204 us per 512
+// detectors; the LDS-tile kernel: 2252).  At N1 = 1024 / 2048 the tile's exchange buffer (70 KB) allows two workgroups
+// either way and 16 points per lane lose (3175 against 2500 us at 2^23: profiles/r05_a section 10).
+template <int LOGN>
+__global__ __launch_bounds__((1 << ColPlan<LOGN>::LT) / 16, 4) void k_fft_cols_inv16(const Params p) {
+    constexpr int P = 16;
+    constexpr int LT = ColPlan<LOGN>::LT;
+    constexpr int T = (1 << LT) / P;
+    constexpr int LOGC = LT - LOGN;
+    constexpr int DK = T >> LOGC;                      // rows between two registers of a lane
+    constexpr int NTW = col_tw_count<LOGN>();
+    static_assert(NTW <= T, "one stage twiddle per thread");
+    extern __shared__ double smd[];                    // exchange buffer, then the stage twiddles
+    double2 * s_w = reinterpret_cast<double2 *>(smd + (1 << LT) + (1 << (LT - 4)));
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    unsigned bx = blockIdx.x;
+    if (p.xcd_order && (gridDim.x & 7u) == 0u) bx = (bx & 7u) * (gridDim.x >> 3) + (bx >> 3);
+    const int64_t j2 = ((int64_t)bx << LOGC) + (tid & ((1 << LOGC) - 1));      // this lane's column
+    const int k10 = tid >> LOGC;                                                 // its first row
+    const int64_t m = int64_t(1) << (LOGN + 11);
+    double2 * __restrict__ work = p.work + (int64_t)b * m;
+    double * __restrict__ row = p.tod + (int64_t)p.d_idx[p.det0 + b] * p.n_samp;
+    const double2 tws = (tid < NTW) ? p.wcol[tid] : make_double2(0.0, 0.0);
+    double2 w0 = tw_big(p.tb, 2 * (int64_t)k10 * j2);
+    double2 wd = tw_big(p.tb, 2 * (int64_t)DK * j2);
+    double2 v[P];
+    const double2 * __restrict__ src = work + ((int64_t)k10 << 11) + j2;
+#pragma unroll
+    for (int i = 0; i < P; ++i) v[i] = src[(int64_t)(DK * i) << 11];
+    if (tid < NTW) s_w[tid] = tws;
+    asm volatile("" : "+v"(w0.x), "+v"(w0.y), "+v"(wd.x), "+v"(wd.y));
+    __syncthreads();
+    {
+        double2 w = w0;
+        v[0] = cmul(v[0], w);
+#pragma unroll
+        for (int i = 1; i < P; ++i) {
+            w = cmul(w, wd);
+            v[i] = cmul(v[i], w);
+            asm volatile("" : "+v"(v[i].x), "+v"(v[i].y));
+        }
+    }
+    col_fft<LOGN, P>(v, smd, tid, s_w);
+    const int tid_tail = opaque_vgpr(tid);
+    const int64_t j2t = ((int64_t)bx << LOGC) + (tid_tail & ((1 << LOGC) - 1));
+    const int k10t = tid_tail >> LOGC;
+    const int s0 = 2 * ((k10t << 11) + (int)j2t) - (int)p.n_buffer;
+    const int n_samp = (int)p.n_samp;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int sidx = s0 + i * (DK << 12);
+        if ((unsigned)sidx < (unsigned)n_samp) {
+            *reinterpret_cast<double2 *>(row + sidx) = make_double2(v[i].y * p.scale, v[i].x * p.scale);
         }
     }
 }
@@ -869,8 +930,8 @@ int cols_reg_twiddles(int log_n1, int * out) {
     int n = 0;
     const int q0 = (1 << lt) / r0;
     for (int h = 0; h < (q0 >> s0); ++h) out[n++] = h;
-    if (log_n1 >= 10) {
-        const int r1 = (log_n1 == 10) ? 4 : 8;
+    {
+        const int r1 = (log_n1 == 11) ? 8 : 4;
         const int s1 = s0 + 4;
         const int q1 = (1 << lt) / r1;
         for (int h = 0; h < (q1 >> s1); ++h) out[n++] = h << (s1 - s0);
@@ -893,6 +954,20 @@ static void launch_cols_reg_n(const Params & p, bool inv, unsigned n_det, hipStr
         attr_set = true;
     }
     const unsigned n_tiles = (unsigned)(2048 >> (LT - LOGN));
+    if constexpr (LOGN == 9) {
+        if (inv) {
+            const size_t lds16 = ((size_t)(1 << LT) + (size_t)(1 << (LT - 4))) * sizeof(double) +
+                                 (size_t)col_tw_count<LOGN>() * sizeof(double2);
+            static bool attr16 = false;
+            if (!attr16) {
+                TH_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fft_cols_inv16<LOGN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16));
+                attr16 = true;
+            }
+            hipLaunchKernelGGL((k_fft_cols_inv16<LOGN>), dim3(n_tiles, n_det), dim3((1 << LT) / 16), lds16, st, p);
+            return;
+        }
+    }
     if (inv) {
         hipLaunchKernelGGL((k_fft_cols_reg<LOGN, true>), dim3(n_tiles, n_det), dim3(T), lds, st, p);
     } else if (p.fwd_seq != nullptr) {
