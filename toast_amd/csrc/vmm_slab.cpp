@@ -62,6 +62,7 @@ struct VmmPolicy {
     size_t search = size_t(128) << 30;
     double gap = 0.035;      // two rates this far apart (relative) belong to different levels
     double search_ms = 500.0;   // TOAST_HIP_ARENA_SEARCH_MS: what the candidate search may cost
+    size_t spacer = size_t(8) << 30;   // TOAST_HIP_ARENA_SPACER_GB: plain block that steps over a run of useless chunks (0: none)
 };
 const VmmPolicy & policy() {
     static const VmmPolicy p = [] {
@@ -78,6 +79,9 @@ const VmmPolicy & policy() {
         }
         if (const char * e = std::getenv("TOAST_HIP_ARENA_SEARCH_MS")) {
             if (std::atof(e) >= 0.0) v.search_ms = std::atof(e);
+        }
+        if (const char * e = std::getenv("TOAST_HIP_ARENA_SPACER_GB")) {
+            if (std::atof(e) >= 0.0) v.spacer = (size_t)(std::atof(e) * 1073741824.0);
         }
         if (const char * e = std::getenv("TOAST_HIP_ARENA_ZONE_GAP")) {
             if (std::atof(e) > 0.0) v.gap = std::atof(e);
@@ -189,6 +193,8 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
         double r[2];            // rate of its pass with reference 0 (the slab's last GB / chunk 0) and 1 (the first GB); < 0: not measured
     };
     std::vector<Cand> cand;
+    std::vector<void *> spacers;
+    size_t spacer_bytes = 0;
     bool failed = false;
     size_t probes = 0;
     auto pass = [&](void * x, void * y, size_t each) {
@@ -233,10 +239,28 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
             for (int k = 0; k < n_ref; ++k) level[k] = pass(ref[k], ref[k] + chunk / 2, chunk / 2);
         }
         const auto t_search = std::chrono::steady_clock::now();
+        size_t streak = 0, last_odd = 0, last_even = 0;
         while (cand.size() < max_create) {
             // the search for the other zone is worth half a second, not more: on a box whose memory the driver is still
             // clearing every chunk costs 20-30 ms, and the slab is built from what there is by then
             if (cand.size() >= n && ms_since(t_search) > pol.search_ms) break;
+            // The driver hands out one zone after the other in runs of 4-12 GB, and a class that is still short may lie
+            // 30 GB further on: that far in chunks of 1 GB is most of a second on a box that is still clearing its memory.
+            // A plain hipMalloc is not (~1.5 ms per GB): when the last three chunks brought nothing that is still needed,
+            // 8 GB of spacer step over the run (released below with the surplus chunks).
+            if (pol.spacer > 0 && cand.size() >= n && streak >= 3 && spacer_bytes + pol.spacer <= pol.search) {
+                size_t free_b = 0, total_b = 0;
+                void * sp = nullptr;
+                if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > pol.spacer + (size_t(16) << 30) &&
+                    hipMalloc(&sp, pol.spacer) == hipSuccess) {
+                    spacers.push_back(sp);
+                    spacer_bytes += pol.spacer;
+                    streak = 0;
+                    continue;
+                }
+                (void)hipGetLastError();
+                streak = 0;      // (no room: go on chunk by chunk)
+            }
             hipMemGenericAllocationHandle_t h;
             if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) {
                 (void)hipGetLastError();
@@ -273,10 +297,17 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
                 ((clear0 && clear1) ? cls_odd : cls_even).push_back(i);
             }
             if (cls_odd.size() >= want_odd && cls_even.size() >= want_even) break;
+            // did this chunk add to a class that is still short?
+            const bool useful = (cls_odd.size() > last_odd && last_odd < want_odd) ||
+                                (cls_even.size() > last_even && last_even < want_even);
+            streak = useful ? 0 : streak + 1;
+            last_odd = cls_odd.size();
+            last_even = cls_even.size();
         }
     } catch (const Error &) {
         failed = true;       // a failed launch or event: nothing may leak
     }
+    for (void * sp : spacers) (void)hipFree(sp);
     zone_references_release(ext);
     for (const Cand & c : cand) (void)hipMemUnmap(c.at, chunk);
     (void)hipMemAddressFree(own_res, own_n * chunk);
@@ -349,8 +380,8 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
                 }
                 line += buf;
             }
-            std::fprintf(stderr, "[toast_hip] vmm rates vs %d reference(s) (TB/s, creation order; thresholds %.2f %.2f):%s\n", n_ref,
-                         thr[0] < 1.0e299 ? thr[0] / 1.0e9 : 0.0, thr[1] < 1.0e299 ? thr[1] / 1.0e9 : 0.0, line.c_str());
+            std::fprintf(stderr, "[toast_hip] vmm rates vs %d reference(s) (TB/s, creation order; thresholds %.2f %.2f; %zu spacer(s) of %zu GB):%s\n", n_ref,
+                         thr[0] < 1.0e299 ? thr[0] / 1.0e9 : 0.0, thr[1] < 1.0e299 ? thr[1] / 1.0e9 : 0.0, spacers.size(), pol.spacer >> 30, line.c_str());
         }
     }
     register_slab(base, n, chunk, slot, take_o, created, probes, level[0], t_start,
