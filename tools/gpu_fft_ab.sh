@@ -20,7 +20,7 @@ for m in ${FFT_AB_PROF:-lds:lds reg:reg}; do
   export TOAST_HIP_FFT_ROWS=$rows TOAST_HIP_FFT_COLS=$cols
   for shape in "1024 720000" "512 2880000"; do
     tag=${rows}_${cols}_${shape##* }
-    rocprofv3 --kernel-trace --stats -d $out/prof_$tag -o p -- python3 tools/exp_fft_long.py $shape > $out/prof_$tag.log 2>&1
+    timeout -k 5 900 rocprofv3 --kernel-trace --stats -d $out/prof_$tag -o p -- python3 tools/exp_fft_long.py $shape > $out/prof_$tag.log 2>&1
     echo "== rocprofv3 rows=$rows cols=$cols shape=$shape" | tee -a $out/ab.txt
     python3 tools/rocpd_summary.py $(ls $out/prof_$tag/p_results.db $out/prof_$tag/*/p_results.db 2>/dev/null | head -1) | grep "k_fft\|kernel " | tee -a $out/ab.txt
   done

@@ -22,7 +22,7 @@ for m in $modes; do
   i=0
   for g in "${groups[@]}"; do
     [ -n "$FFT_PMC_GROUPS" ] && ! echo " $FFT_PMC_GROUPS " | grep -q " $i " && { i=$((i+1)); continue; }
-    rocprofv3 --pmc $g -d $out/${rows}_$cols/g$i -o p -- python3 tools/exp_fft_long.py $shape > $out/${rows}_${cols}_g$i.log 2>&1
+    timeout -k 5 900 rocprofv3 --pmc $g -d $out/${rows}_$cols/g$i -o p -- python3 tools/exp_fft_long.py $shape > $out/${rows}_${cols}_g$i.log 2>&1
     i=$((i+1))
   done
   echo "#### rows=$rows cols=$cols shape=$shape" >> $out/pmc.txt

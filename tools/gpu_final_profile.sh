@@ -6,12 +6,12 @@ out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 python bench.py > $out/bench.json 2> $out/bench.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $out/trace -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/trace.json 2> $out/trace.err
-rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --unfused > $out/fetch.json 2> /dev/null
-rocprofv3 --pmc WRITE_SIZE -d $out/write -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --unfused > $out/write.json 2> /dev/null
+timeout -k 5 900 rocprofv3 --kernel-trace --stats -d $out/trace -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/trace.json 2> $out/trace.err
+timeout -k 5 900 rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --unfused > $out/fetch.json 2> /dev/null
+timeout -k 5 900 rocprofv3 --pmc WRITE_SIZE -d $out/write -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --unfused > $out/write.json 2> /dev/null
 # the same kernels through the 32-byte-unit DRAM request counters (exact on known byte counts, profiles/r04_e)
 for c in TCC_EA0_RDREQ_DRAM_32B TCC_EA0_WRREQ_WRITE_DRAM_32B TCC_EA0_WRREQ_WRITE_ATOMIC_32B; do
-  rocprofv3 --pmc $c -d /tmp/fp_$c -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+  timeout -k 5 900 rocprofv3 --pmc $c -d /tmp/fp_$c -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 done
 python3 $GRAFT_REPO_ROOT/tools/pmc_bytes.py --json $out/traffic_exact_cfg3.json cfg3 /tmp/fp_ "bench.py cfg3 (1024 x 720 000 samples)" > $out/exact_bytes.txt
 cd $GRAFT_REPO_ROOT

@@ -18,10 +18,10 @@ groups=(
 )
 i=0
 for g in "${groups[@]}"; do
-  rocprofv3 --pmc $g -d $out/g$i -o p -- python3 bench.py --no-cpu-baseline --no-operator-level --no-fft --steps 3 --warmup 1 > $out/g$i.log 2>&1
+  timeout -k 5 900 rocprofv3 --pmc $g -d $out/g$i -o p -- python3 bench.py --no-cpu-baseline --no-operator-level --no-fft --steps 3 --warmup 1 > $out/g$i.log 2>&1
   i=$((i+1))
 done
-rocprofv3 --kernel-trace --stats -d $out/trace -o p -- python3 bench.py --no-cpu-baseline --no-operator-level --no-fft --steps 3 --warmup 1 > $out/trace.log 2>&1
+timeout -k 5 900 rocprofv3 --kernel-trace --stats -d $out/trace -o p -- python3 bench.py --no-cpu-baseline --no-operator-level --no-fft --steps 3 --warmup 1 > $out/trace.log 2>&1
 python3 tools/pmc_table.py $out "k_offset" > $out/pmc.txt
 python3 tools/rocpd_summary.py $(ls $out/trace/p_results.db $out/trace/*/p_results.db 2>/dev/null | head -1) | grep "k_offset\|kernel " >> $out/pmc.txt
 find $out -name '*.db' -delete      # (gpurun brings back at most 64 MiB)

@@ -6,7 +6,7 @@ out=$GRAFT_REPO_ROOT/gpurun_out/${1:-r03c}
 mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/pcgprof
-rocprofv3 --kernel-trace --stats -d /tmp/pcgprof -o pcg -- python3 $GRAFT_REPO_ROOT/workflows/mapmaker_pcg.py --ndet 64 --minutes 60 --rate 100 --nside 512 --iter 30 --no-filter > $out/pcg_trace_stdout.txt 2>/tmp/pcgprof.err
+timeout -k 5 900 rocprofv3 --kernel-trace --stats -d /tmp/pcgprof -o pcg -- python3 $GRAFT_REPO_ROOT/workflows/mapmaker_pcg.py --ndet 64 --minutes 60 --rate 100 --nside 512 --iter 30 --no-filter > $out/pcg_trace_stdout.txt 2>/tmp/pcgprof.err
 python3 - <<'PY' > $out/pcg_trace.txt
 import sqlite3, glob, re
 db = glob.glob('/tmp/pcgprof/*.db')[0]

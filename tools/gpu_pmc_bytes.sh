@@ -10,9 +10,9 @@ out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
 for c in TCC_EA0_RDREQ_DRAM_32B TCC_EA0_WRREQ_WRITE_DRAM_32B TCC_EA0_WRREQ_WRITE_ATOMIC_32B TCC_BUBBLE; do
-  rocprofv3 --pmc $c -d /tmp/pb_sc_$c -o sc -- $GRAFT_REPO_ROOT/tools/ubench/strided_copy > /dev/null 2>&1
-  rocprofv3 --pmc $c -d /tmp/pb_st_$c -o st -- $GRAFT_REPO_ROOT/tools/ubench/stream_ceiling > /dev/null 2>&1
-  rocprofv3 --pmc $c -d /tmp/pb_bench_$c -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/bench_$c.err
+  timeout -k 5 900 rocprofv3 --pmc $c -d /tmp/pb_sc_$c -o sc -- $GRAFT_REPO_ROOT/tools/ubench/strided_copy > /dev/null 2>&1
+  timeout -k 5 900 rocprofv3 --pmc $c -d /tmp/pb_st_$c -o st -- $GRAFT_REPO_ROOT/tools/ubench/stream_ceiling > /dev/null 2>&1
+  timeout -k 5 900 rocprofv3 --pmc $c -d /tmp/pb_bench_$c -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/bench_$c.err
 done
 python3 $GRAFT_REPO_ROOT/tools/pmc_bytes.py /tmp/pb_sc_ "strided_copy: 4 294 967 296 B read and written per launch" \
     /tmp/pb_st_ "stream_ceiling: arrays of 5 898 240 000 B (x3 for the weights)" \

@@ -6,8 +6,8 @@ out=$GRAFT_REPO_ROOT/gpurun_out/r03d
 mkdir -p $out
 cd /tmp; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c -d /tmp/cal_$c -o sc -- $GRAFT_REPO_ROOT/tools/ubench/strided_copy > /dev/null 2>&1
-  rocprofv3 --pmc $c -d /tmp/cal2_$c -o st -- $GRAFT_REPO_ROOT/tools/ubench/stream_ceiling > /dev/null 2>&1
+  timeout -k 5 900 rocprofv3 --pmc $c -d /tmp/cal_$c -o sc -- $GRAFT_REPO_ROOT/tools/ubench/strided_copy > /dev/null 2>&1
+  timeout -k 5 900 rocprofv3 --pmc $c -d /tmp/cal2_$c -o st -- $GRAFT_REPO_ROOT/tools/ubench/stream_ceiling > /dev/null 2>&1
 done
 python3 - <<'PY' > $out/pmc_calibration.txt
 import sqlite3, glob

@@ -6,7 +6,7 @@ mkdir -p $out
 cd /root/repo
 python workflows/mapmaker_pcg.py > $out/plain.log 2>&1
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $out/prof -o wf -- python3 workflows/mapmaker_pcg.py > $out/prof.log 2>&1
+timeout -k 5 900 rocprofv3 --kernel-trace --stats -d $out/prof -o wf -- python3 workflows/mapmaker_pcg.py > $out/prof.log 2>&1
 db=$(ls $out/prof/wf_results.db 2>/dev/null || ls $out/prof/*/wf_results.db | head -1)
 python tools/rocpd_summary.py $db > $out/kernels.txt
 python tools/rocpd_gaps.py $db --min 0.25 > $out/gaps_all.txt

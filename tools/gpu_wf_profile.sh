@@ -8,7 +8,7 @@ python workflows/mapmaker_pcg.py > $out/plain.log 2>&1
 TOAST_HIP_TRACE=2 python workflows/mapmaker_pcg.py > $out/trace2.log 2>&1
 python tools/trace_timeline.py $out/trace2.log > $out/timeline.txt
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $out/prof -o wf -- python3 $GRAFT_REPO_ROOT/workflows/mapmaker_pcg.py > $out/prof.log 2>&1
+timeout -k 5 900 rocprofv3 --kernel-trace --stats -d $out/prof -o wf -- python3 $GRAFT_REPO_ROOT/workflows/mapmaker_pcg.py > $out/prof.log 2>&1
 cd $GRAFT_REPO_ROOT
 db=$(ls $out/prof/wf_results.db 2>/dev/null || ls $out/prof/*/wf_results.db | head -1)
 python tools/rocpd_summary.py $db > $out/kernels.txt
