@@ -51,6 +51,9 @@ def test_bench_contract_small_workload():
     f = d["fft_noise_weight"]
     assert f["ms"] > 0 and f["samples_per_s"] > 0 and f["n_fft"] == 131072 and f["implementation"] == "fused-3pass"
     assert abs(f["pipeline_bytes_per_sample"] - (16 + 32 * 131072 / 50000)) < 1e-9
+    # "ms": calls back to back behind an un-timed call; the idle-queue number of rounds 2-4 and the host preparation beside it
+    assert f["timing"].startswith("3 calls back to back") and f["ms_from_idle_queue"] > 0 and f["host_prep_ms"] > 0
+    assert "long" not in f                                    # (the 512 x 2 880 000 shape rides along with cfg3 only)
     assert d["allreduce"]["bytes"] == 0 and d["kernel_ms"]["allreduce"] >= 0
     # value == whole-job units / time
     n = d["config"]["detectors_per_gpu"] * d["config"]["samples_per_detector"]
