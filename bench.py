@@ -802,6 +802,33 @@ def run(args, workload, world, rank, dev, headline=True):
         out["allreduce"]["owner_computes_reduce_apply_ms"] = owner_ms
         out["allreduce"]["reduce_apply_ms_by_mode"] = mode_ms
 
+    if os.environ.get("TOAST_BENCH_MAP_RUNS", "") != "" and not args.torch_alloc:
+        # EXPERIMENT (profiles/r05_d): build_noise_weighted with its map in block after block of the scatter class, in ONE
+        # process -- is the two-level behaviour of the kernel a property of where in the slab the map lies?
+        runs = []
+        fillers = []
+        for k in range(int(os.environ["TOAST_BENCH_MAP_RUNS"])):
+            zm = manager_tensor(n_local * nps * nnz * 8, torch.float64, (n_local, nps, nnz), scatter=True)
+            zm.zero_()
+            zone = capi.arena_block_zone(zm.data_ptr(), zm.numel() * 8)
+            call = lambda: D.build_noise_weighted(d_g2l.data_ptr(), zm.data_ptr(), nps, nnz, idx, d_pixels.data_ptr(),
+                                                  idx, d_weights.data_ptr(), idx, d_tod.data_ptr(), idx,
+                                                  d_dflags.data_ptr(), n_samp, det_scale, 1, n_samp, ivl,
+                                                  d_sflags.data_ptr(), n_samp, 1, stream)
+            call()
+            runs.append({"address": hex(zm.data_ptr()), "offset_GB_from_first": (zm.data_ptr() - d_zmap.data_ptr()) / 2.0 ** 30,
+                         "zone": zone, "bnw_ms": timed(call, 5)})
+            fillers.append(zm)
+            # what is left of this 2 GB run is taken, so that the next map lands in the next run
+            for pad in (int(1.0 * 2 ** 30), int(0.5 * 2 ** 30), int(0.25 * 2 ** 30)):
+                blk = manager_tensor(pad, torch.uint8, (pad,), scatter=True)
+                if abs(blk.data_ptr() - zm.data_ptr()) < 2 ** 31:
+                    fillers.append(blk)
+                else:
+                    manager_release(blk)
+        out["map_runs_experiment"] = runs
+        del fillers
+
     # ------------------------------------------------------------------ FFT noise weighting (SURVEY.md section 8d:
     # "report separately"): ops.NoiseFilter's device call on the same timestream shape -- every detector
     # row convolved with its own N_tt'^-1 = NET^2 / PSD(f) kernel (reference src/toast/ops/noise_filter.py:130-188
