@@ -405,6 +405,10 @@ def run(args, workload, world, rank, dev, headline=True):
         if not args.torch_alloc:
             manager_release(t)
 
+    if os.environ.get("TOAST_BENCH_POOL_FILLER_GB", "") != "" and not args.torch_alloc:
+        # EXPERIMENT (profiles/r05_d): a read-mostly block in front of the arrays moves them along their slab, i.e.
+        # relative to the zone boundary inside it
+        _filler = manager_tensor(int(float(os.environ["TOAST_BENCH_POOL_FILLER_GB"]) * 2 ** 30), torch.uint8, (1,))
     d_pixels = carve("pixels", torch.int64, (n_det, n_samp))
     d_weights = carve("weights", torch.float64, (n_det, n_samp, 3))
     d_tod = carve("tod", torch.float64, (n_det, n_samp))
