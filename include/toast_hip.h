@@ -107,8 +107,27 @@ typedef struct toast_hip_arena_stats_t {
     int64_t chunks_created;     /* chunks created while searching for the second zone (the surplus is released) */
     double interleave_ms;       /* wall time building them (part of malloc_ms) */
     double same_zone_tbs;       /* reference rate of the zone measurement (TB/s) */
+    /* how the searches for chunks of the other zone ended (budget counted in measuring passes and candidate bytes:
+     * TOAST_HIP_ARENA_SEARCH_PROBES, TOAST_HIP_ARENA_SEARCH_GB; TOAST_HIP_ARENA_SEARCH_MS is a hard cap only): */
+    int64_t chunks_other_wanted;  /* slots that the pattern P Q Q P gives to the other zone (placement ok: chunks_other_zone equals it) */
+    int64_t searches;             /* slabs whose chunks were searched for */
+    int64_t searches_exhausted;   /* ... that ran out of a budget before both classes were full */
+    int64_t searches_capped_ms;   /* ... of which by the hard cap in wall time */
+    int64_t probes;               /* measuring passes (three kernel launches each) */
+    int64_t probes_by_clock;      /* ... timed by the device's constant-rate clock inside the kernel (the rest: HIP events) */
+    double create_ms_per_chunk;   /* last search: average hipMemCreate time (0.1 ms on clean memory, 20-50 while the driver clears) */
+    double search_ms;             /* wall time of the searches (part of interleave_ms) */
 } toast_hip_arena_stats_t;
 int toast_hip_arena_stats(toast_hip_arena_stats_t * out);
+/* Did the zone placement work out?  placement_ok = 1: an interleaved slab stands and every slot meant for the other HBM
+ * zone holds a chunk that measured clear of the read-mostly slabs; search_exhausted = 1: some search ran out of its budget
+ * first (the slab was built from what there was: written timestreams and maps may share a zone with what the kernels
+ * stream, worth 5-12 % of scan_map / build_noise_weighted).  A caller that cares can release the cached slabs
+ * (toast_hip_accel_release_cached) and reserve again (toast_hip_arena_reserve_streamed) when the device is quiet.  Waits
+ * for a slab that toast_hip_accel_assign_device is still building.  Any out pointer may be NULL.
+ * [the pool of accelerator.cpp:292-303 has no such notion: one hipMalloc, wherever the driver puts it] */
+int toast_hip_arena_placement_status(int * placement_ok, int * search_exhausted, int64_t * chunks_other_zone,
+                                     int64_t * chunks_other_wanted);
 /* Make the arena hold at least `bytes` (one more slab for the difference, at most 90 % of what the device has free). */
 int toast_hip_arena_reserve(size_t bytes);
 /* The part of the arena that serves streamed blocks and scatter targets (below): make it hold a FREE RANGE of at least
@@ -116,7 +135,10 @@ int toast_hip_arena_reserve(size_t bytes);
 int toast_hip_arena_reserve_streamed(size_t bytes);
 /* Where [device_ptr, device_ptr + bytes) lies: interleaved = 1 when inside a zone-interleaved slab, and then how many of
  * the 1 GB chunks it touches are of the read-mostly slabs' zone / of the other zone (csrc/vmm_slab.cpp: pattern
- * P Q Q P ...).  Waits for a slab that toast_hip_accel_assign_device is still building. */
+ * P Q Q P ...).  For a slab that was built before any read-mostly array existed the two classes are relative to the
+ * slab's FIRST chunk ("own" = the first chunk's class, "other" = the second class), and scatter targets go to whichever
+ * of the two measured clear of the arrays when the first one was asked for -- one run of ONE class either way.
+ * Waits for a slab that toast_hip_accel_assign_device is still building. */
 int toast_hip_arena_block_zone(const void * device_ptr, size_t bytes, int * interleaved, int * chunks_own_zone,
                                int * chunks_other_zone);
 /* The sub-allocation logic exercised on HOST memory (no device needed): n_ops random allocations / releases with the

@@ -215,3 +215,28 @@ def test_oracle_vs_live_reference_random(oracle, ref, seed):
     b = cases.run_chain(oracle, c, nest=nest, iau=iau)
     for k in a:
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_mapmaker_e2e_fixture_is_what_the_reference_chain_produces_now():
+    """tests/golden/mapmaker_e2e.npz (the destriping map-maker end to end, tests/golden/make_golden_mapmaker.py) is not
+    stale: the small case regenerated here -- oracle/_ref kernels in the reference's operator order, the reference's own
+    solve() compiled from its syntax tree -- equals the committed arrays bit for bit.  Build container only."""
+    import importlib.util
+
+    if not os.path.exists("/root/reference/src/toast/ops/mapmaker_solve.py"):
+        pytest.skip("no /root/reference on this machine")
+    import oracle as o
+
+    if o.load_ref() is None:
+        pytest.skip("oracle/_ref not built")
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_golden_mapmaker", os.path.join(here, "golden", "make_golden_mapmaker.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    blob = gen.run_case("small", gen.load_reference_solve())
+    z = np.load(os.path.join(here, "golden", "mapmaker_e2e.npz"))
+    for k, v in blob.items():
+        assert np.array_equal(np.asarray(v), z[k]), k
+    # the solve did what the fixture says: iters + 1 applications of the left-hand side, a falling residual
+    assert int(z["small_lhs_calls"]) == len(z["small_history"]) + 1
+    assert z["small_history"][-1] < 1e-2 * z["small_history"][0]

@@ -305,7 +305,10 @@ class _ArenaStats(C.Structure):
                 ("malloc_ms", C.c_double), ("max_malloc_ms", C.c_double), ("touch_ms", C.c_double),
                 ("allocs", C.c_int64), ("releases", C.c_int64), ("direct_mallocs", C.c_int64), ("failed", C.c_int64),
                 ("interleaved_slabs", C.c_int64), ("chunks", C.c_int64), ("chunks_other_zone", C.c_int64),
-                ("chunks_created", C.c_int64), ("interleave_ms", C.c_double), ("same_zone_TBs", C.c_double)]
+                ("chunks_created", C.c_int64), ("interleave_ms", C.c_double), ("same_zone_TBs", C.c_double),
+                ("chunks_other_wanted", C.c_int64), ("searches", C.c_int64), ("searches_exhausted", C.c_int64),
+                ("searches_capped_ms", C.c_int64), ("probes", C.c_int64), ("probes_by_clock", C.c_int64),
+                ("create_ms_per_chunk", C.c_double), ("search_ms", C.c_double)]
 
 
 def alloc_stats():
@@ -317,7 +320,20 @@ def alloc_stats():
     out["slab_GB"] = out.pop("slab_bytes") / 2.0 ** 30
     out["used_GB"] = out.pop("used_bytes") / 2.0 ** 30
     out["peak_used_GB"] = out.pop("peak_used_bytes") / 2.0 ** 30
+    # the verdict of toast_hip_arena_placement_status, from the same counters
+    out["placement_ok"] = bool(out["interleaved_slabs"] > 0 and out["chunks_other_zone"] >= out["chunks_other_wanted"])
+    out["search_exhausted"] = bool(out["searches_exhausted"] > 0)
     return out
+
+
+def arena_placement_status():
+    """(placement_ok, search_exhausted, chunks_other_zone, chunks_other_wanted) of the zone-interleaved slabs
+    (toast_hip_arena_placement_status): ok = every slot meant for the other HBM zone holds a chunk that measured clear of
+    the read-mostly slabs."""
+    ok, ex = C.c_int(0), C.c_int(0)
+    a, b = C.c_int64(0), C.c_int64(0)
+    _check(real_lib().toast_hip_arena_placement_status(C.byref(ok), C.byref(ex), C.byref(a), C.byref(b)))
+    return bool(ok.value), bool(ex.value), int(a.value), int(b.value)
 
 
 def arena_reserve(nbytes, streamed=False):

@@ -66,18 +66,21 @@ const ArenaBackend & host_backend() {
     return b;
 }
 
-Arena::Slab * Arena::new_slab(size_t bytes, hipStream_t stream) {
+bool Arena::grow_by(size_t bytes, hipStream_t stream) {
+    // (grow_mutex_ held by the caller, mutex_ NOT)
     bytes = round_slab(bytes);
     const auto t0 = std::chrono::steady_clock::now();
     void * p = be_.take(bytes, stream);
     const double ms = ms_since(t0);
-    if (p == nullptr) return nullptr;
+    if (p == nullptr) return false;
+    const auto t1 = std::chrono::steady_clock::now();
+    be_.touch(p, bytes, stream);
+    const double touch_ms = ms_since(t1);
+    std::lock_guard<std::mutex> lock(mutex_);
     st_.malloc_ms += ms;
     if (ms > st_.max_malloc_ms) st_.max_malloc_ms = ms;
     ++st_.slab_mallocs;
-    const auto t1 = std::chrono::steady_clock::now();
-    be_.touch(p, bytes, stream);
-    st_.touch_ms += ms_since(t1);
+    st_.touch_ms += touch_ms;
     Slab s;
     s.base = static_cast<char *>(p);
     s.bytes = bytes;
@@ -85,12 +88,10 @@ Arena::Slab * Arena::new_slab(size_t bytes, hipStream_t stream) {
     slabs_.push_back(std::move(s));
     ++st_.slabs;
     st_.slab_bytes += bytes;
-    return &slabs_.back();
+    return true;
 }
 
-void * Arena::alloc(size_t nbytes, hipStream_t stream, bool grow) {
-    const size_t need = round_up(nbytes ? nbytes : 1);
-    std::lock_guard<std::mutex> lock(mutex_);
+void * Arena::carve_best(size_t need) {
     // best fit over all slabs
     Slab * best_slab = nullptr;
     std::map<size_t, size_t>::iterator best;
@@ -105,18 +106,7 @@ void * Arena::alloc(size_t nbytes, hipStream_t stream, bool grow) {
         }
         if (best_slab != nullptr && best->second == need) break;
     }
-    if (best_slab == nullptr && !grow) return nullptr;
-    if (best_slab == nullptr) {
-        // a new slab: the default size when the request is smaller; when the driver refuses that, what is asked for
-        size_t want = need > slab_default_ ? need : round_up(slab_default_);
-        best_slab = new_slab(want, stream);
-        if (best_slab == nullptr && want > need) best_slab = new_slab(need, stream);
-        if (best_slab == nullptr) {
-            ++st_.failed;
-            return nullptr;
-        }
-        best = best_slab->free.begin();
-    }
+    if (best_slab == nullptr) return nullptr;
     const size_t off = best->first, len = best->second;
     best_slab->free.erase(best);
     if (len > need) best_slab->free[off + need] = len - need;
@@ -125,6 +115,54 @@ void * Arena::alloc(size_t nbytes, hipStream_t stream, bool grow) {
     if (st_.used_bytes > st_.peak_used_bytes) st_.peak_used_bytes = st_.used_bytes;
     ++st_.allocs;
     return best_slab->base + off;
+}
+
+void * Arena::alloc(size_t nbytes, hipStream_t stream, bool grow) {
+    const size_t need = round_up(nbytes ? nbytes : 1);
+    // (a range that another thread's release or slab opened up between the rounds is taken; a range that another
+    //  thread's alloc took between "adopted" and "carved" costs one more round)
+    for (int round = 0; round < 4; ++round) {
+        {
+            std::lock_guard<std::mutex> lock(mutex_);
+            if (void * p = carve_best(need)) return p;
+            if (!grow) return nullptr;
+        }
+        std::lock_guard<std::mutex> growing(grow_mutex_);
+        {
+            std::lock_guard<std::mutex> lock(mutex_);
+            if (void * p = carve_best(need)) return p;      // somebody else's slab arrived while this thread waited
+        }
+        // a new slab: the default size when the request is smaller; when the driver refuses that, what is asked for
+        const size_t want = need > slab_default_ ? need : round_up(slab_default_);
+        if (!grow_by(want, stream) && !(want > need && grow_by(need, stream))) break;
+    }
+    std::lock_guard<std::mutex> lock(mutex_);
+    ++st_.failed;
+    return nullptr;
+}
+
+void * Arena::alloc_at_end(size_t nbytes) {
+    const size_t need = round_up(nbytes ? nbytes : 1);
+    std::lock_guard<std::mutex> lock(mutex_);
+    Slab * at = nullptr;
+    std::map<size_t, size_t>::iterator big;
+    for (Slab & s : slabs_) {
+        for (auto it = s.free.begin(); it != s.free.end(); ++it) {
+            if (it->second >= need && (at == nullptr || it->second > big->second)) {
+                at = &s;
+                big = it;
+            }
+        }
+    }
+    if (at == nullptr) return nullptr;
+    const size_t off = big->first, len = big->second;
+    if (len == need) at->free.erase(big);
+    else big->second = len - need;
+    at->live[off + len - need] = need;
+    st_.used_bytes += need;
+    if (st_.used_bytes > st_.peak_used_bytes) st_.peak_used_bytes = st_.used_bytes;
+    ++st_.allocs;
+    return at->base + off + len - need;
 }
 
 void * Arena::alloc_striped(size_t nbytes, size_t stripe, int parity) {
@@ -232,17 +270,29 @@ bool Arena::slab_offset(const void * p, size_t * off) const {
 }
 
 bool Arena::reserve(size_t bytes, hipStream_t stream, bool contiguous) {
-    std::lock_guard<std::mutex> lock(mutex_);
-    if (contiguous) {
-        for (const Slab & s : slabs_) {
-            for (const auto & kv : s.free) {
-                if (kv.second >= bytes) return true;
+    auto enough = [&] {     // (mutex_ held) 0: no; else: nothing to do
+        if (contiguous) {
+            for (const Slab & s : slabs_) {
+                for (const auto & kv : s.free) {
+                    if (kv.second >= bytes) return true;
+                }
             }
+            return false;
         }
-        return new_slab(round_up(bytes), stream) != nullptr;
+        return st_.slab_bytes >= bytes;
+    };
+    size_t want = 0;
+    {
+        std::lock_guard<std::mutex> lock(mutex_);
+        if (enough()) return true;
     }
-    if (st_.slab_bytes >= bytes) return true;
-    return new_slab(round_up(bytes - st_.slab_bytes), stream) != nullptr;
+    std::lock_guard<std::mutex> growing(grow_mutex_);
+    {
+        std::lock_guard<std::mutex> lock(mutex_);
+        if (enough()) return true;
+        want = contiguous ? round_up(bytes) : round_up(bytes - st_.slab_bytes);
+    }
+    return grow_by(want, stream);
 }
 
 size_t Arena::trim() {

@@ -76,6 +76,9 @@ public:
     // it.  Used for blocks that belong into particular chunks of a zone-interleaved slab (runtime.cpp: scatter targets
     // inside a run of chunks of the other zone, small streamed blocks astride a zone boundary).  Never grows the arena.
     void * alloc_placed(size_t nbytes, const std::function<size_t(const char * base, size_t lo, size_t hi, size_t need)> & place);
+    // A block at the END of the largest free range (never grows the arena; nullptr when no range holds it): the far
+    // reference of the zone measurement (runtime.cpp zone_references_take), without a filler block in between.
+    void * alloc_at_end(size_t nbytes);
     // false when p is not a live block of this arena
     bool release(void * p);
     bool owns(const void * p) const;
@@ -106,7 +109,11 @@ private:
         std::map<size_t, size_t> free;   // offset -> length of the free ranges (address order, never adjacent)
         std::map<size_t, size_t> live;   // offset -> length of the blocks handed out
     };
-    Slab * new_slab(size_t bytes, hipStream_t stream);
+    // A new slab is taken from the driver -- and touched, and for an interleaved slab measured chunk by chunk: 0.05 .. 8 s --
+    // with only grow_mutex_ held, then adopted under mutex_: release / owns / free_bytes / alloc from existing ranges on
+    // other threads do not wait for it.
+    bool grow_by(size_t bytes, hipStream_t stream);
+    void * carve_best(size_t need);       // best fit over the free ranges (mutex_ held); nullptr when none holds `need`
     size_t round_up(size_t n) const { return (n + granule_ - 1) / granule_ * granule_; }
     size_t round_slab(size_t n) const { return (n + slab_round_ - 1) / slab_round_ * slab_round_; }
 
@@ -117,6 +124,7 @@ private:
     std::vector<Slab> slabs_;
     ArenaStats st_;
     mutable std::mutex mutex_;
+    std::mutex grow_mutex_;      // one slab at a time is being taken (never held together with a wait for mutex_'s holder)
 };
 
 }  // namespace toast_hip

@@ -3187,18 +3187,40 @@ __global__ __launch_bounds__(kThreads) void k_probe_stream(double * __restrict__
 struct ProbeBases {
     double * p[4];
 };
-__global__ __launch_bounds__(kThreads) void k_probe_stream_split(ProbeBases b, int nb, int64_t row_len, double one) {
+__global__ __launch_bounds__(kThreads) void k_probe_stream_split(ProbeBases b, int nb, int64_t row_len, double one,
+                                                                 unsigned long long * __restrict__ clk) {
+    // clk[0] / clk[1]: earliest start and latest end of any workgroup in ticks of the device's constant-rate clock
+    // (hipDeviceAttributeWallClockRate, 100 MHz): the pass is timed where it runs -- host-side event handling, a
+    // profiler's interception of the dispatch or a busy host thread do not enter the rate
+    unsigned long long t0 = 0;
+    if (clk != nullptr && threadIdx.x == 0) t0 = (unsigned long long)wall_clock64();
     const int r = blockIdx.x;
     double * row = b.p[r % nb] + (int64_t)(r / nb) * row_len;
     for (int64_t c0 = (int64_t)blockIdx.y * 1024; c0 < row_len; c0 += (int64_t)gridDim.y * 1024) {
         for (int i = threadIdx.x; i < 1024 && c0 + i < row_len; i += kThreads) row[c0 + i] = row[c0 + i] * one;
     }
+    if (clk != nullptr) {
+        __builtin_amdgcn_s_waitcnt(0);       // the stores of this lane have been acknowledged
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicMin(clk, t0);
+            atomicMax(clk + 1, (unsigned long long)wall_clock64());
+        }
+    }
+}
+
+__global__ void k_probe_clock_reset(unsigned long long * clk) {
+    clk[0] = ~0ull;
+    clk[1] = 0ull;
 }
 
 }  // namespace
 
 namespace toast_hip {
-double probe_stream_split_ms(void * const * bases, int nb, size_t bytes_each, hipStream_t st) {
+// One read + write pass over up to four ranges, rows dealt round-robin; the best of three passes in ms.  Timed by the
+// device's constant-rate clock inside the kernel (first workgroup in, last workgroup out); HIP events only when the
+// clock's rate cannot be asked for.  *used_clock (optional): which of the two it was.
+double probe_stream_split_ms(void * const * bases, int nb, size_t bytes_each, hipStream_t st, bool * used_clock) {
     if (nb < 1 || nb > 4) fail_arg("probe_stream_split: 1 .. 4 ranges");
     const int64_t rows = 1024;
     const int64_t rows_each = rows / nb;
@@ -3206,25 +3228,67 @@ double probe_stream_split_ms(void * const * bases, int nb, size_t bytes_each, hi
     if (row_len < 1024) return 0.0;
     ProbeBases b;
     for (int k = 0; k < 4; ++k) b.p[k] = static_cast<double *>(bases[k < nb ? k : 0]);
-    hipEvent_t e0, e1;
-    TH_HIP(hipEventCreate(&e0));
-    TH_HIP(hipEventCreate(&e1));
     int64_t gy = (row_len + 1023) / 1024;
     if (gy > 65535) gy = 65535;
-    float best = 1e30f;
-    for (int rep = 0; rep < 3; ++rep) {
-        TH_HIP(hipEventRecord(e0, st));
-        hipLaunchKernelGGL(k_probe_stream_split, dim3((unsigned)(rows_each * nb), (unsigned)gy), dim3(kThreads), 0, st, b, nb,
-                           row_len, 1.0);
-        TH_HIP(hipEventRecord(e1, st));
-        TH_HIP(hipEventSynchronize(e1));
-        float ms = 0.0f;
-        TH_HIP(hipEventElapsedTime(&ms, e0, e1));
-        if (ms < best) best = ms;
+    // the clock words: 16 bytes of device memory per process and device, never freed (probes run at set-up, from the
+    // slab builder's thread and from the caller's: one at a time)
+    static std::mutex mu;
+    static std::map<int, unsigned long long *> words;
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0, khz = 0;
+    TH_HIP(hipGetDevice(&dev));
+    unsigned long long * clk = nullptr;
+    static const bool events_only = [] {
+        const char * e = std::getenv("TOAST_HIP_PROBE_CLOCK");
+        return e != nullptr && e[0] == '0';
+    }();
+    if (!events_only && hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0) {
+        auto it = words.find(dev);
+        if (it == words.end()) {
+            void * w = nullptr;
+            if (hipMalloc(&w, 2 * sizeof(unsigned long long)) == hipSuccess) {
+                it = words.emplace(dev, static_cast<unsigned long long *>(w)).first;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+        if (it != words.end()) clk = it->second;
+    } else {
+        (void)hipGetLastError();
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    return (double)best;
+    if (used_clock != nullptr) *used_clock = clk != nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (clk == nullptr) {
+        TH_HIP(hipEventCreate(&e0));
+        TH_HIP(hipEventCreate(&e1));
+    }
+    double best = 1e30;
+    for (int rep = 0; rep < 3; ++rep) {
+        if (clk != nullptr) {
+            hipLaunchKernelGGL(k_probe_clock_reset, dim3(1), dim3(1), 0, st, clk);
+        } else {
+            TH_HIP(hipEventRecord(e0, st));
+        }
+        hipLaunchKernelGGL(k_probe_stream_split, dim3((unsigned)(rows_each * nb), (unsigned)gy), dim3(kThreads), 0, st, b, nb,
+                           row_len, 1.0, clk);
+        double ms = 0.0;
+        if (clk != nullptr) {
+            unsigned long long t[2] = {0, 0};
+            TH_HIP(hipMemcpyAsync(t, clk, sizeof t, hipMemcpyDeviceToHost, st));
+            TH_HIP(hipStreamSynchronize(st));
+            ms = t[1] > t[0] ? (double)(t[1] - t[0]) / (double)khz : 0.0;
+        } else {
+            TH_HIP(hipEventRecord(e1, st));
+            TH_HIP(hipEventSynchronize(e1));
+            float f = 0.0f;
+            TH_HIP(hipEventElapsedTime(&f, e0, e1));
+            ms = (double)f;
+        }
+        if (ms > 0.0 && ms < best) best = ms;
+    }
+    if (e0 != nullptr) (void)hipEventDestroy(e0);
+    if (e1 != nullptr) (void)hipEventDestroy(e1);
+    return best < 1e29 ? best : 0.0;
 }
 
 double probe_stream_ms(void * block, size_t bytes, hipStream_t st) {

@@ -591,15 +591,18 @@ size_t place_in_class(const char * base, size_t lo, size_t hi, size_t need, bool
 // target is asked for -- half a chunk of either class (free memory: the pass rewrites what it reads) against the first
 // and the last GB of the read-mostly slab; the class that runs slower with a reference lies in its zone.  Preferred: the
 // class that is clear of both ends; second: clear of the START (the arrays that feed the A^T scatter are created first).
-std::map<const void *, int> g_scatter_class;      // slab base -> 1 (Q) / 0 (P)
-
+// The decision lives in the slab's own record (vmm_slab.cpp: vmm_slab_scatter_class, under its mutex, forgotten when
+// the slab is given back -- a later slab at the same address starts undecided).
 int scatter_class_of(const char * base, hipStream_t st) {
-    auto it = g_scatter_class.find(base);
-    if (it != g_scatter_class.end()) return it->second;
+    const int known = vmm_slab_scatter_class(base);
+    if (known >= 0) return known;
     size_t chunk = 0;
     int n_ref = 0;
     if (!vmm_slab_layout(base, &chunk, &n_ref)) return 1;
-    if (n_ref > 0) return g_scatter_class[base] = 1;
+    if (n_ref > 0) {
+        vmm_slab_set_scatter_class(base, 1);
+        return 1;
+    }
     const size_t half = chunk / 2;
     ZoneRefs refs = zone_references_take(half);
     if (refs.last == nullptr) return 1;            // no read-mostly arrays yet: nothing to keep away from (not cached)
@@ -633,7 +636,7 @@ int scatter_class_of(const char * base, hipStream_t st) {
         } catch (const Error &) {
             pick = 1;
         }
-        g_scatter_class[base] = pick;
+        vmm_slab_set_scatter_class(base, pick);
         if (trace_enabled()) {
             std::fprintf(stderr, "[toast_hip] scatter targets of the slab at %p go to its %s chunks (P same zone as start/end: %d/%d, Q: %d/%d)\n",
                          (const void *)base, pick ? "Q" : "P", (int)same[0][0], (int)same[0][1], (int)same[1][0], (int)same[1][1]);
@@ -710,6 +713,7 @@ void Manager::assign_device(int node_procs, int node_rank, double mem_gb, bool d
         if (dev != device_) drop_arenas();    // (slabs belong to the device they were taken on)
         device_ = dev;
         TH_HIP(hipSetDevice(device_));
+        vmm_set_device_share(per);
         // accelerator.cpp:296-300 (dormant upstream): this process' share of `mem_gb` becomes the pool.  Here the
         // pool can grow past it (a slab per request that does not fit), so the number is a reservation, not a limit:
         // what it covers is taken from the driver -- and touched -- now instead of inside the first operators.
@@ -725,6 +729,12 @@ void Manager::assign_device(int node_procs, int node_rank, double mem_gb, bool d
         // device_alloc waits for it when it needs it.
         double sgb = -1.0;
         if (const char * e = std::getenv("TOAST_HIP_ARENA_STREAM_GB")) sgb = std::atof(e);
+        if (sgb < 0.0 && per > 1) {
+            // processes that share a device get no slab by default: the search creates chunks beyond the slab itself for a
+            // moment, and several of them side by side are what makes a neighbour's hipMalloc fail;
+            // TOAST_HIP_ARENA_STREAM_GB / toast_hip_arena_reserve_streamed still build one
+            sgb = 0.0;
+        }
         if (sgb < 0.0 && stream_arena_enabled() && !alloc_policy().plain) {
             size_t f = 0, t = 0;
             if (hipMemGetInfo(&f, &t) != hipSuccess) f = 0;
@@ -778,8 +788,7 @@ void * Manager::device_alloc(size_t nbytes, int kind) {
             // (the class of every slab is settled first: scatter_class_of allocates from the arena itself)
             for (const char * b : stream_arena().slab_bases()) (void)scatter_class_of(b, stream_);
             p = stream_arena().alloc_placed(nbytes, [](const char * b, size_t lo, size_t hi, size_t need) {
-                auto it = g_scatter_class.find(b);
-                return place_in_class(b, lo, hi, need, it == g_scatter_class.end() || it->second != 0);
+                return place_in_class(b, lo, hi, need, vmm_slab_scatter_class(b) != 0);
             });
         }
         if (p != nullptr) return p;
@@ -848,12 +857,10 @@ ZoneRefs zone_references_take(size_t bytes) {
     // (a token reservation -- the reference's mem_gb = 1 -- says nothing about where the arrays will live)
     if (alloc_policy().plain || big_arena().capacity() < (size_t(8) << 30)) return r;
     hipStream_t st = Manager::get().stream();
+    // (the far one straight from the END of the largest free range: round 5 reached it with a filler block that took
+    //  nearly the whole range for a moment -- an allocation racing with it on another thread could end up in a NEW slab)
     r.first = big_arena().alloc(bytes, st, false);
-    const size_t room = big_arena().largest_free();
-    void * filler = nullptr;
-    if (room > bytes + (size_t(64) << 20)) filler = big_arena().alloc(room - bytes - (size_t(4) << 20), st, false);
-    r.last = big_arena().alloc(bytes, st, false);
-    if (filler != nullptr) (void)big_arena().release(filler);
+    r.last = big_arena().alloc_at_end(bytes);
     if (r.last == nullptr) {
         r.last = r.first;       // room for one reference only
     }
@@ -867,7 +874,6 @@ void zone_references_release(const ZoneRefs & r) {
 
 void Manager::drop_arenas() {
     builder_wait();
-    g_scatter_class.clear();
     (void)hipDeviceSynchronize();
     drop_param_blocks();
     big_arena().destroy();
@@ -1290,6 +1296,28 @@ int toast_hip_arena_stats(toast_hip_arena_stats_t * out) {
         out->chunks_created = v.created;
         out->interleave_ms = v.build_ms;
         out->same_zone_tbs = v.same_zone_tbs;
+        out->chunks_other_wanted = v.chunks_other_wanted;
+        out->searches = v.searches;
+        out->searches_exhausted = v.searches_exhausted;
+        out->searches_capped_ms = v.searches_capped_ms;
+        out->probes = v.probes;
+        out->probes_by_clock = v.probes_by_clock;
+        out->create_ms_per_chunk = v.create_ms_per_chunk;
+        out->search_ms = v.search_ms;
+    });
+}
+
+int toast_hip_arena_placement_status(int * placement_ok, int * search_exhausted, int64_t * chunks_other_zone,
+                                     int64_t * chunks_other_wanted) {
+    return guarded([&] {
+        Manager::wait_for_builder();
+        const VmmSlabStats v = vmm_slab_stats();
+        // ok: at least one interleaved slab stands and every slot that the pattern gives to the other zone holds a chunk
+        // that measured clear of the read-mostly slabs
+        if (placement_ok) *placement_ok = (v.slabs > 0 && v.chunks_other_zone >= v.chunks_other_wanted) ? 1 : 0;
+        if (search_exhausted) *search_exhausted = v.searches_exhausted > 0 ? 1 : 0;
+        if (chunks_other_zone) *chunks_other_zone = v.chunks_other_zone;
+        if (chunks_other_wanted) *chunks_other_wanted = v.chunks_other_wanted;
     });
 }
 

@@ -99,7 +99,8 @@ void drop_param_blocks();   // forget the cached parameter blocks (their storage
 // kernels.hip: time of a read + write pass over a new device block with the timestream kernels' access pattern
 double probe_stream_ms(void * block, size_t bytes, hipStream_t stream);
 // ... with the 1024 rows dealt round-robin to nb <= 4 separate ranges of bytes_each (placement experiments)
-double probe_stream_split_ms(void * const * bases, int nb, size_t bytes_each, hipStream_t stream);
+// (timed by the device's constant-rate clock inside the kernel; *used_clock = false: HIP events had to do)
+double probe_stream_split_ms(void * const * bases, int nb, size_t bytes_each, hipStream_t stream, bool * used_clock = nullptr);
 // Counters of Manager::device_alloc: both arenas (arena.hpp) together, plus what went around them.
 struct AllocStats {
     int64_t slabs = 0;             // slabs held now
@@ -134,10 +135,21 @@ struct VmmSlabStats {
     int64_t slabs = 0;               // interleaved slabs alive
     int64_t chunks = 0;              // chunks mapped into slabs so far
     int64_t chunks_other_zone = 0;   // ... of which in a zone other than their slab's first chunk
+    int64_t chunks_other_wanted = 0; // ... of which the pattern P Q Q P asks for (half of `chunks`)
     int64_t created = 0;             // chunks created (the surplus was released)
     int64_t probes = 0;
     double build_ms = 0.0;
     double same_zone_tbs = 0.0;      // the last slab's reference rate (two halves of one chunk)
+    // how the candidate searches ended: the search is budgeted in PROBES
+    // (TOAST_HIP_ARENA_SEARCH_PROBES) and candidate bytes (TOAST_HIP_ARENA_SEARCH_GB, at most half of the free memory of
+    // this process' share of the device); TOAST_HIP_ARENA_SEARCH_MS is a hard cap only
+    int64_t searches = 0;            // slabs whose chunks were searched for
+    int64_t searches_exhausted = 0;  // ... that ran out of a budget before both classes were full
+    int64_t searches_capped_ms = 0;  // ... that hit the hard cap in ms (a subset of the exhausted ones)
+    int64_t probes_by_clock = 0;     // probes timed by the device clock (the rest: HIP events)
+    double create_ms_per_chunk = 0.0;   // the last search's average hipMemCreate time per chunk (0.1: clean memory; 20-50: the
+                                        // driver is still clearing what another process returned)
+    double search_ms = 0.0;          // wall time of the searches (part of build_ms)
 };
 VmmSlabStats vmm_slab_stats();
 // slot k of an interleaved slab holds a chunk of the OTHER zone (pattern P Q Q P P Q Q P ...)
@@ -145,6 +157,11 @@ inline bool vmm_slot_other(size_t k) { return (((k + 1) >> 1) & 1) != 0; }
 // is `base` the start of an interleaved slab?  its chunk size
 // n_ref: 0 when the slab's classes are relative to its own first chunk (built before any read-mostly slab existed)
 bool vmm_slab_layout(const void * base, size_t * chunk, int * n_ref = nullptr);
+// which class of a slab's chunks its scatter targets go to: -1 not decided yet, 0 = P (even slots), 1 = Q; forgotten with the slab
+int vmm_slab_scatter_class(const void * base);
+void vmm_slab_set_scatter_class(const void * base, int cls);
+// processes that share this device (assign_device): the transient candidate search is capped by this process' share
+void vmm_set_device_share(int per);
 void vmm_pair_matrix(int n_phys, int n_slots, double * out, hipStream_t st);   // experiment, vmm_slab.cpp
 
 // Transfers between pageable application memory and the device, through a page-locked bounce ring owned by the library

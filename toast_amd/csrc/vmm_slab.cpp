@@ -26,8 +26,15 @@
 // the last GB alone with its lower part: profiles/r04_a section 8.)  Every chunk is measured at an address of its own
 // (section 5: a chunk mapped where another one sat a moment before shows the earlier chunk's level).  Chunks are created
 // until both classes have filled their half of the slots (the surplus is released before the function returns), within
-// `TOAST_HIP_ARENA_SEARCH_GB` (default 128) of surplus and `TOAST_HIP_ARENA_SEARCH_MS` (default 500) -- then the remaining
-// slots take what there is, late chunks first.
+// a budget counted in PROBES (`TOAST_HIP_ARENA_SEARCH_PROBES`, default 320) and surplus bytes (`TOAST_HIP_ARENA_SEARCH_GB`,
+// default 128, at most half of the free memory of this process' share of the device) -- then the remaining slots take what
+// there is, late chunks first.  Rounds 4-5 boxed the search into 500 ms of WALL time: a process that started while the
+// driver was still clearing its predecessor's memory (25-50 ms per hipMemCreate instead of 0.1), or under a profiler,
+// ran out of the box with 1 chunk of the other zone and lost 12 % of scan_map (profiles/r05_f section 2 against the
+// un-profiled line).  Now nothing that the host's clock sees decides the placement: the passes are timed by the device's
+// own constant-rate clock inside the probe kernel, classes are gaps between the rates of ONE search, the budget counts
+// probes, and `TOAST_HIP_ARENA_SEARCH_MS` (default 8000) is only a hard cap whose use is reported
+// (toast_hip_arena_placement_status, toast_hip_arena_stats_t.searches_capped_ms).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -35,6 +42,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "runtime.hpp"
@@ -49,6 +57,7 @@ struct VmmSlab {
     size_t chunk = 0;
     std::vector<hipMemGenericAllocationHandle_t> handles;   // in mapping order
     int n_ref = 0;      // 0: the classes are relative to the slab's own first chunk (no read-mostly slab existed), else to it
+    int scatter_class = -1;   // which class its scatter targets go to (runtime.cpp scatter_class_of): -1 not decided, 0 P, 1 Q
 };
 
 std::map<void *, VmmSlab> g_vmm;
@@ -61,7 +70,8 @@ struct VmmPolicy {
     size_t min_slab = size_t(4) << 30;
     size_t search = size_t(128) << 30;
     double gap = 0.035;      // two rates this far apart (relative) belong to different levels
-    double search_ms = 500.0;   // TOAST_HIP_ARENA_SEARCH_MS: what the candidate search may cost
+    double search_ms = 8000.0;  // TOAST_HIP_ARENA_SEARCH_MS: hard cap on the candidate search (reported when it is hit)
+    long search_probes = 320;   // TOAST_HIP_ARENA_SEARCH_PROBES: the search's budget, counted in measuring passes
     size_t spacer = size_t(8) << 30;   // TOAST_HIP_ARENA_SPACER_GB: plain block that steps over a run of useless chunks (0: none)
 };
 const VmmPolicy & policy() {
@@ -80,6 +90,9 @@ const VmmPolicy & policy() {
         if (const char * e = std::getenv("TOAST_HIP_ARENA_SEARCH_MS")) {
             if (std::atof(e) >= 0.0) v.search_ms = std::atof(e);
         }
+        if (const char * e = std::getenv("TOAST_HIP_ARENA_SEARCH_PROBES")) {
+            if (std::atol(e) >= 0) v.search_probes = std::atol(e);
+        }
         if (const char * e = std::getenv("TOAST_HIP_ARENA_SPACER_GB")) {
             if (std::atof(e) >= 0.0) v.spacer = (size_t)(std::atof(e) * 1073741824.0);
         }
@@ -93,6 +106,20 @@ const VmmPolicy & policy() {
 
 double ms_since(std::chrono::steady_clock::time_point t) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count();
+}
+
+// processes sharing this device (Manager::assign_device): the transient search may use half of the free memory of ONE share
+int g_share = 1;
+
+// TEST HOOK (tests/test_gpu_accel.py): TOAST_HIP_ARENA_TEST_SLOW_MS = host milliseconds added to every chunk creation and
+// every measuring pass of a search -- a box whose driver is still clearing memory, a profiler, a loaded host.  The
+// placement must come out the same (read at every search, not once: the test sets it per slab).
+double test_slow_ms() {
+    const char * e = std::getenv("TOAST_HIP_ARENA_TEST_SLOW_MS");
+    return (e != nullptr && std::atof(e) > 0.0) ? std::atof(e) : 0.0;
+}
+void test_slow(double ms) {
+    if (ms > 0.0) std::this_thread::sleep_for(std::chrono::microseconds((long long)(ms * 1000.0)));
 }
 
 bool map_chunk(char * va, size_t chunk, hipMemGenericAllocationHandle_t h, int dev) {
@@ -121,9 +148,16 @@ VmmSlabStats vmm_slab_stats() {
 
 namespace {
 
+struct SearchOutcome {
+    size_t want_other = 0;
+    size_t probes_clock = 0;
+    bool exhausted = false, capped = false;
+    double create_ms = 0.0, search_ms = 0.0;
+};
+
 void register_slab(char * base, size_t n, size_t chunk, const std::vector<hipMemGenericAllocationHandle_t> & slot,
                    size_t other, size_t created, size_t probes, double level, std::chrono::steady_clock::time_point t_start,
-                   const char * how, int n_ref) {
+                   const char * how, int n_ref, const SearchOutcome & so) {
     VmmSlab s;
     s.base = base;
     s.bytes = n * chunk;
@@ -140,11 +174,20 @@ void register_slab(char * base, size_t n, size_t chunk, const std::vector<hipMem
         g_vmm_stats.probes += (int64_t)probes;
         g_vmm_stats.build_ms += ms_since(t_start);
         g_vmm_stats.same_zone_tbs = level / 1.0e9;
+        g_vmm_stats.chunks_other_wanted += (int64_t)so.want_other;
+        ++g_vmm_stats.searches;
+        g_vmm_stats.searches_exhausted += so.exhausted ? 1 : 0;
+        g_vmm_stats.searches_capped_ms += so.capped ? 1 : 0;
+        g_vmm_stats.probes_by_clock += (int64_t)so.probes_clock;
+        g_vmm_stats.create_ms_per_chunk = created > 0 ? so.create_ms / (double)created : 0.0;
+        g_vmm_stats.search_ms += so.search_ms;
     }
     if (const char * e = std::getenv("TOAST_HIP_TRACE")) {
         if (e[0] != '\0' && e[0] != '0') {
-            std::fprintf(stderr, "[toast_hip] vmm slab      %zu chunks of %zu MB at %p (%s): %zu in the other zone, %zu created, %.1f ms\n",
-                         n, chunk >> 20, (void *)base, how, other, created, ms_since(t_start));
+            std::fprintf(stderr, "[toast_hip] vmm slab      %zu chunks of %zu MB at %p (%s): %zu of %zu wanted in the other zone, %zu created "
+                                 "(%.2f ms each), %zu probes (%zu by the device clock), %.1f ms%s%s\n",
+                         n, chunk >> 20, (void *)base, how, other, so.want_other, created, created ? so.create_ms / (double)created : 0.0, probes,
+                         so.probes_clock, ms_since(t_start), so.exhausted ? ", search budget exhausted" : "", so.capped ? " (hard cap in ms)" : "");
         }
     }
 }
@@ -171,7 +214,23 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
     if (n < 4) return nullptr;
     // Every candidate is measured at an address of its own: a pass over a chunk mapped where ANOTHER chunk sat a moment
     // ago showed the level of the earlier chunk (profiles/r04_a section 5) -- addresses are never reused here.
-    const size_t own_n = n + pol.search / chunk + 1;
+    // surplus candidates: TOAST_HIP_ARENA_SEARCH_GB, but never more than half of what this process' share of the device has
+    // free beyond the slab itself (the transient chunks of one process' search must not make the
+    // allocations of torch or of the processes it shares the device with fail)
+    size_t search_bytes = pol.search;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t mine = free_b / (size_t)(g_share > 0 ? g_share : 1);
+            const size_t room = mine > n * chunk ? (mine - n * chunk) / 2 : 0;
+            if (search_bytes > room) search_bytes = room;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    const size_t own_n = n + search_bytes / chunk + 1;
+    const double slow_ms = test_slow_ms();
+    SearchOutcome so;
     void * own_res = nullptr;
     if (hipMemAddressReserve(&own_res, own_n * chunk, chunk, nullptr, 0) != hipSuccess) {
         (void)hipGetLastError();
@@ -199,8 +258,11 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
     size_t probes = 0;
     auto pass = [&](void * x, void * y, size_t each) {
         void * two[2] = {x, y};
-        const double ms = probe_stream_split_ms(two, 2, each, st);     // (best of three passes: the first one touches the chunk)
+        bool by_clock = false;
+        test_slow(slow_ms);
+        const double ms = probe_stream_split_ms(two, 2, each, st, &by_clock);     // (best of three passes: the first one touches the chunk)
         ++probes;
+        so.probes_clock += by_clock ? 1 : 0;
         return ms > 0.0 ? 4.0 * (double)each / ms : 0.0;
     };
     // threshold between "same zone as the reference" and "another zone": the middle of the largest gap between
@@ -228,7 +290,9 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
     size_t want_odd = 0;                         // slots of the other zone ("odd": round 4's name for them)
     for (size_t k = 0; k < n; ++k) want_odd += vmm_slot_other(k) ? 1 : 0;
     const size_t want_even = n - want_odd;
-    const size_t max_create = n + pol.search / chunk;
+    const size_t max_create = n + search_bytes / chunk;
+    so.want_other = want_odd;
+    bool full = false;
     char * ref[2] = {nullptr, nullptr};
     double level[2] = {0.0, 0.0}, thr[2] = {1.0e300, 1.0e300};
     std::vector<size_t> cls_odd, cls_even;       // candidates for the odd slots (other than every reference) and the rest
@@ -241,14 +305,19 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
         const auto t_search = std::chrono::steady_clock::now();
         size_t streak = 0, last_odd = 0, last_even = 0;
         while (cand.size() < max_create) {
-            // the search for the other zone is worth half a second, not more: on a box whose memory the driver is still
-            // clearing every chunk costs 20-30 ms, and the slab is built from what there is by then
-            if (cand.size() >= n && ms_since(t_search) > pol.search_ms) break;
+            // the budget is counted in measuring passes; wall time is a hard cap only (and reported): on a box whose memory the
+            // driver is still clearing every chunk costs 20-50 ms instead of 0.1, and a search boxed into wall time gave up
+            // there with the written timestreams in one zone
+            if (cand.size() >= n && (long)probes >= pol.search_probes) break;
+            if (cand.size() >= n && ms_since(t_search) > pol.search_ms) {
+                so.capped = true;
+                break;
+            }
             // The driver hands out one zone after the other in runs of 4-12 GB, and a class that is still short may lie
             // 30 GB further on: that far in chunks of 1 GB is most of a second on a box that is still clearing its memory.
             // A plain hipMalloc is not (~1.5 ms per GB): when the last three chunks brought nothing that is still needed,
             // 8 GB of spacer step over the run (released below with the surplus chunks).
-            if (pol.spacer > 0 && cand.size() >= n && streak >= 3 && spacer_bytes + pol.spacer <= pol.search) {
+            if (pol.spacer > 0 && cand.size() >= n && streak >= 3 && spacer_bytes + pol.spacer <= search_bytes) {
                 size_t free_b = 0, total_b = 0;
                 void * sp = nullptr;
                 if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > pol.spacer + (size_t(16) << 30) &&
@@ -262,10 +331,13 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
                 streak = 0;      // (no room: go on chunk by chunk)
             }
             hipMemGenericAllocationHandle_t h;
+            const auto t_create = std::chrono::steady_clock::now();
+            test_slow(slow_ms);
             if (hipMemCreate(&h, chunk, &prop, 0) != hipSuccess) {
                 (void)hipGetLastError();
                 break;   // the device is full: make do with what has been created
             }
+            so.create_ms += ms_since(t_create);
             char * where = own_va + cand.size() * chunk;
             if (!map_chunk(where, chunk, h, dev)) {
                 (void)hipMemRelease(h);
@@ -296,7 +368,10 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
                 const bool clear1 = n_ref < 2 || (cand[i].r[1] >= 0.0 && cand[i].r[1] > thr[1]);
                 ((clear0 && clear1) ? cls_odd : cls_even).push_back(i);
             }
-            if (cls_odd.size() >= want_odd && cls_even.size() >= want_even) break;
+            if (cls_odd.size() >= want_odd && cls_even.size() >= want_even) {
+                full = true;
+                break;
+            }
             // did this chunk add to a class that is still short?
             const bool useful = (cls_odd.size() > last_odd && last_odd < want_odd) ||
                                 (cls_even.size() > last_even && last_even < want_even);
@@ -304,9 +379,11 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
             last_odd = cls_odd.size();
             last_even = cls_even.size();
         }
+        so.search_ms = ms_since(t_search);
     } catch (const Error &) {
         failed = true;       // a failed launch or event: nothing may leak
     }
+    so.exhausted = !full;
     for (void * sp : spacers) (void)hipFree(sp);
     zone_references_release(ext);
     for (const Cand & c : cand) (void)hipMemUnmap(c.at, chunk);
@@ -386,7 +463,7 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
     }
     register_slab(base, n, chunk, slot, take_o, created, probes, level[0], t_start,
                   n_ref == 2 ? "against both ends of the read-mostly slab" : (n_ref == 1 ? "against the read-mostly slab" : "against its first chunk"),
-                  n_ref);
+                  n_ref, so);
     return base;
 }
 
@@ -431,6 +508,23 @@ bool vmm_slab_layout(const void * base, size_t * chunk, int * n_ref) {
     if (chunk != nullptr) *chunk = it->second.chunk;
     if (n_ref != nullptr) *n_ref = it->second.n_ref;
     return true;
+}
+
+int vmm_slab_scatter_class(const void * base) {
+    std::lock_guard<std::mutex> lock(g_vmm_mutex);
+    auto it = g_vmm.find(const_cast<void *>(base));
+    return it == g_vmm.end() ? -1 : it->second.scatter_class;
+}
+
+void vmm_slab_set_scatter_class(const void * base, int cls) {
+    std::lock_guard<std::mutex> lock(g_vmm_mutex);
+    auto it = g_vmm.find(const_cast<void *>(base));
+    if (it != g_vmm.end()) it->second.scatter_class = cls;
+}
+
+void vmm_set_device_share(int per) {
+    std::lock_guard<std::mutex> lock(g_vmm_mutex);
+    g_share = per > 0 ? per : 1;
 }
 
 size_t vmm_slab_size(void * p) {

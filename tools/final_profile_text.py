@@ -12,6 +12,9 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import bench_line  # noqa: E402
 
 d, header = sys.argv[1], sys.argv[2]
+if os.path.exists(os.path.join(d, "PLACEMENT_FAILED")):
+    sys.exit("final_profile_text: %s/PLACEMENT_FAILED exists -- the traced process' zone placement did not work out, "
+             "its kernel durations are not those of the bench line" % d)
 print("# " + header.replace("\n", "\n# "))
 print("# tools/gpu_final_profile.sh: the default bench.py line, then the same command under rocprofv3 (kernel trace; FETCH_SIZE / WRITE_SIZE")
 print("# with --unfused; the exact 32-byte-unit DRAM counters, one pass each).  profiles/traffic_cfg3.json and traffic_exact_cfg3.json are")
@@ -26,6 +29,14 @@ for k in ("roofline", "cpu_baseline", "fft_noise_weight"):
     print("  %s: %s" % (k, json.dumps(b.get(k))))
 print("  pcg_lhs_offset_templates: %s" % json.dumps({k: v for k, v in (b.get("pcg_lhs_offset_templates") or {}).items() if not isinstance(v, dict)}))
 print("\n== 2  rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline ==")
+t = json.loads(open(os.path.join(d, "trace.json")).read().strip().splitlines()[-1])
+ta, tk = t["allocator_stats"], t["kernel_ms"]
+print("  traced process: placement_ok %s, search_exhausted %s, chunks_other_zone %d of %d wanted (%d chunks, %d created, %.1f ms per "
+      "hipMemCreate, %d probes of which %d by the device clock)" % (
+          ta["placement_ok"], ta["search_exhausted"], ta["chunks_other_zone"], ta["chunks_other_wanted"], ta["chunks"], ta["chunks_created"],
+          ta["create_ms_per_chunk"], ta["probes"], ta["probes_by_clock"]))
+print("  its own HIP-event kernel_ms: bnw %.3f  scan %.3f   (un-profiled line above: bnw %.3f  scan %.3f)" % (
+    tk["bnw"], tk["scan"], b["kernel_ms"]["bnw"], b["kernel_ms"]["scan"]))
 print(open(os.path.join(d, "trace.txt")).read().rstrip())
 print("\n== 3  FETCH_SIZE / WRITE_SIZE passes (--unfused) ==")
 for f in ("fetch.txt", "write.txt"):
