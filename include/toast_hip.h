@@ -1194,6 +1194,11 @@ int toast_hip_comm_check(void * stream);
 /* mode "peer": reductions done through the exchange buffers, times the buffers were (re-)established (collective hipIpc
  * exchange; grows with the largest map), bytes of this rank's exchange buffer now */
 int toast_hip_comm_peer_stats(int64_t * reductions, int64_t * establishments, int64_t * exchange_bytes);
+/* mode "peer": is the exchange buffer fine-grained memory?  TOAST_HIP_COMM_PEER_MEM=fine (hipDeviceMallocFinegrained:
+ * coherent between the GPUs by construction) | coarse (default: an ordinary hipMalloc; visibility rests on the kernels'
+ * system-scope accesses / fences and the kernel boundaries around the barriers) -- read when the buffers are established.
+ * [the reference has no device-to-device path: its sync_allreduce goes through host MPI, pixels.py:710-780] */
+int toast_hip_comm_peer_mem(int * fine_grained);
 int toast_hip_comm_get_mode(char * mode, size_t len);
 int toast_hip_comm_cov_invert_dev(int64_t n_px, int64_t nnz, double * d_cov, double * d_rcond, double threshold,
                                   int invert, void * stream);

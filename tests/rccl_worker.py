@@ -268,6 +268,9 @@ def main():
                 # slots of ceil(40 101 / size) values
                 assert n_red == 9 and n_est == (3 if first_peer else 0), (mode, width, n_red, n_est)
                 assert n_bytes >= (1 + size) * 8 * (40101 // size), n_bytes
+                # the memory kind of the exchange buffers is the one asked for (TOAST_HIP_COMM_PEER_MEM; default coarse)
+                want_mem = "fine" if os.environ.get("TOAST_HIP_COMM_PEER_MEM", "coarse") == "fine" else "coarse"
+                assert capi.dev.comm_peer_mem() == want_mem, (capi.dev.comm_peer_mem(), want_mem)
             else:
                 assert n_red == 0 and n_est == 0 and n_bytes == 0
             first_peer = False

@@ -9,7 +9,9 @@ Reference bars: src/toast/tests/ops_mapmaker.py (final products of the complete 
   history to 1e-12, amplitudes and maps below 1e-10 of the fixture, hit counts exact;
 * default mode, all three routes of the solver's left-hand side -- sweeps over the packed pointing cache, the fused
   sweeps over the cached pixels / weights, pointing on the fly (``full_pointing=False``) --: within 10 x the run-to-run
-  floor of the atomic scatter measured here (printed), never worse than 1e-8.
+  floor of the atomic scatter measured here (printed) or 1e-11, whichever is larger (the sums are taken in another ORDER
+  than the reference's, which two runs of one route do not show: 1.3e-12 after ten iterations on the first box), and
+  always below the north star's 1e-10.
 """
 import os
 
@@ -110,8 +112,8 @@ def test_mapmaker_default_routes_within_the_scatter_floor(case):
     floor = max(_rel(a["amplitudes"], b["amplitudes"]), _rel(a["map"], b["map"]),
                 float(np.max(np.abs(a["history"] - b["history"]) / b["history"])), 1e-13)
     print(f"E2E {case}: run-to-run floor of the default route {floor:.2e} (route {a['route']})")
-    assert floor < 1e-9, floor
-    tol = min(10.0 * floor, 1e-8)
+    assert floor < 1e-10, floor
+    tol = min(max(10.0 * floor, 1e-11), 1e-10)
     routes = {}
     routes["default " + "/".join(a["route"])] = a
     routes["fused (TOAST_HIP_PACKED_POINTING=0)"] = _run(case, packed=False)

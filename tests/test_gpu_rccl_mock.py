@@ -46,6 +46,16 @@ def test_map_reductions_and_owner_computes(mock_lib, n):
     assert out.stdout.count("OK") == n
 
 
+@pytest.mark.parametrize("n", [2, 5])
+def test_map_reductions_with_fine_grained_exchange_buffers(mock_lib, n):
+    """The same worker with TOAST_HIP_COMM_PEER_MEM=fine: the peer modes' exchange buffers in fine-grained device memory
+    (hipDeviceMallocFinegrained), both access widths, opened over hipIpc by the other ranks -- the A/B switch for the first
+    run on several GPUs (VERDICT round 5, item 7 a); same results bit for bit, and the library reports the kind it took."""
+    out = _run(n, "rccl_worker.py", 29591 + n, mock_lib, TOAST_HIP_COMM_PEER_MEM="fine")
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-6000:]
+    assert out.stdout.count("OK") == n
+
+
 @pytest.mark.parametrize("n", [2, 3])
 def test_mapmaker_equals_single_process(mock_lib, n):
     out = _run(n, "dist_gpu_worker.py", 29571 + n, mock_lib)

@@ -1302,6 +1302,12 @@ class _Dev:
         _check(real_lib().toast_hip_comm_peer_stats(C.byref(a), C.byref(b), C.byref(c)))
         return int(a.value), int(b.value), int(c.value)
 
+    def comm_peer_mem(self):
+        """'fine' / 'coarse': the memory kind of the 'peer' exchange buffer (toast_hip_comm_peer_mem)."""
+        a = C.c_int(0)
+        _check(real_lib().toast_hip_comm_peer_mem(C.byref(a)))
+        return "fine" if a.value else "coarse"
+
     def comm_get_mode(self):
         buf = C.create_string_buffer(32)
         _check(real_lib().toast_hip_comm_get_mode(buf, C.c_size_t(32)))

@@ -459,6 +459,9 @@ __global__ void __launch_bounds__(256) k_peer_push(const double * __restrict__ m
     if (E > 1 && (cnt % E) != 0 && blockIdx.x == 0 && threadIdx.x == 0) {
         peer_store(inbox.p[s] + (int64_t)rank * per_v + cnt - 1, map[first + cnt - 1]);
     }
+    // W = 16: ordinary stores -- a system-scope release pushes them past this agent's L2 before the kernel ends and the
+    // barrier tells the owner (the 8-byte form does that per access)
+    if (W == 16) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
 }
 
 template <int W>
@@ -469,6 +472,9 @@ __global__ void __launch_bounds__(256) k_peer_sum(double * __restrict__ mine, co
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t whole = cnt / E;
     T * m = reinterpret_cast<T *>(mine);
+    // W = 16: ordinary loads of an inbox that OTHER agents wrote -- a system-scope acquire drops whatever line of it this
+    // agent's caches still hold from the previous reduction (nothing may rest on the buffer staying uncached)
+    if (W == 16) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < whole; i += stride) {
         T acc = (rank == 0) ? m[i] : PeerAccess<W>::load_remote(reinterpret_cast<const T *>(inbox) + i);
         for (int p = 1; p < size; ++p) {
@@ -499,6 +505,7 @@ __global__ void __launch_bounds__(256) k_peer_pull(double * __restrict__ map, Pe
     T * dst = reinterpret_cast<T *>(map + first);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const int64_t whole = cnt / E;
+    if (W == 16) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");      // (as in k_peer_sum: the owners' `out` is foreign memory)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < whole; i += stride) {
         dst[i] = PeerAccess<W>::load_remote(src + i);
     }
@@ -553,6 +560,7 @@ struct PeerExchange {
     char * peer[kPeerMax] = {};        // everybody's (peer[g_rank] == base)
     unsigned char * d_words = nullptr; // device words: [0, 64 * kPeerMax) the handles, then the barrier / agreement word
     int64_t reductions = 0, establishments = 0;
+    bool fine = false;                 // the exchange buffer is fine-grained memory (TOAST_HIP_COMM_PEER_MEM=fine)
     int width = 0;                     // bytes per lane and access of push / sum / pull: 8 or 16 (0: not read yet)
     size_t out_bytes() const { return ((size_t)cap_v * sizeof(double) + 255) & ~(size_t)255; }
     double * out_of(int r) const { return reinterpret_cast<double *>(peer[r]); }
@@ -687,7 +695,15 @@ void peer_establish(int64_t need_v, hipStream_t st) {
     g_peer.cap_v = (need_v + 31) / 32 * 32;
     const size_t bytes = g_peer.out_bytes() * (size_t)(1 + g_size);
     hipIpcMemHandle_t all[kPeerMax];
-    bool ok = hipMalloc(reinterpret_cast<void **>(&g_peer.base), bytes) == hipSuccess;
+    // TOAST_HIP_COMM_PEER_MEM = coarse (default: an ordinary hipMalloc; visibility between the agents rests on the
+    // system-scope accesses / fences of the kernels and on the kernel boundaries around the barriers) | fine
+    // (hipDeviceMallocFinegrained: coherent between agents by construction, slower for the owner's own passes) -- so that
+    // the first run on several GPUs can A/B the memory kind instead of debugging it (VERDICT round 5, item 7 a)
+    g_peer.fine = false;
+    if (const char * e = std::getenv("TOAST_HIP_COMM_PEER_MEM")) g_peer.fine = std::strcmp(e, "fine") == 0;
+    bool ok = g_peer.fine
+                  ? hipExtMallocWithFlags(reinterpret_cast<void **>(&g_peer.base), bytes, hipDeviceMallocFinegrained) == hipSuccess
+                  : hipMalloc(reinterpret_cast<void **>(&g_peer.base), bytes) == hipSuccess;
     if (!ok) g_peer.base = nullptr;
     std::memset(all, 0, sizeof(all));
     if (ok) ok = hipIpcGetMemHandle(&all[g_rank], g_peer.base) == hipSuccess;
@@ -844,6 +860,12 @@ int toast_hip_comm_peer_stats(int64_t * reductions, int64_t * establishments, in
         if (reductions) *reductions = g_peer.reductions;
         if (establishments) *establishments = g_peer.establishments;
         if (exchange_bytes) *exchange_bytes = g_peer.base ? (int64_t)(g_peer.out_bytes() * (size_t)(1 + g_size)) : 0;
+    });
+}
+
+int toast_hip_comm_peer_mem(int * fine_grained) {
+    return guarded([&] {
+        if (fine_grained) *fine_grained = (g_peer.base != nullptr && g_peer.fine) ? 1 : 0;
     });
 }
 

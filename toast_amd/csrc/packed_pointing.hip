@@ -170,10 +170,44 @@ __device__ __forceinline__ double pair_partner(float sum, double mine, const dou
     return (sum == sum) ? (double)sum - mine : *partner_row_value;
 }
 
+// Wave-uniform amplitude look-up (UNI kernels, baselines of at least 128 samples): the 128 consecutive samples a wave
+// handles in one trip (two per lane) lie in at most TWO baselines, so the amplitude values and flags are two scalars per
+// detector -- fetched with scalar loads from wave-uniform addresses and chosen per lane by one compare -- instead of two
+// 64-bit reciprocal divisions, four 64-bit index sums and eight gathers per lane (8 of the 12 vector memory instructions
+// of a trip; profiles/r05_b: vector issue 87 % / 73 % busy).  Same values, same order of operations.
+struct WaveSteps {
+    int64_t step0;     // baseline (within its view) of the wave's first sample
+    bool two;          // a second baseline starts inside the chunk after it ...
+    int split;         // ... at this many samples from the wave's first one (4096: none within reach)
+};
+
+__device__ __forceinline__ WaveSteps wave_steps(int64_t s0, int base, int n_pair, int64_t vfirst, int64_t chunk_end,
+                                                const FastDiv & step_div) {
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int jw = base + 64 * wv;
+    if (jw > n_pair - 1) jw = n_pair - 1;       // (a wave past the chunk's end: all lanes idle, any valid address will do)
+    const int64_t w0 = s0 + 2 * (int64_t)jw;
+    WaveSteps w;
+    w.step0 = fastdiv(w0 - vfirst, step_div);
+    const int64_t next = vfirst + (w.step0 + 1) * step_div.d;
+    w.two = next < chunk_end;
+    const int64_t gap = next - w0;
+    w.split = (w.two && gap < 4096) ? (int)gap : 4096;
+    return w;
+}
+
+// byte p[0] through an aligned dword load (scalar when p is wave-uniform; the dword that holds a valid byte lies inside
+// the allocation)
+__device__ __forceinline__ uint32_t flag_byte_uniform(const uint8_t * p) {
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint32_t w = *reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
+    return (w >> ((unsigned)(a & 3) * 8u)) & 0xffu;
+}
+
 // The accumulation from pair words: both detectors of a pair share the pixel, so their contributions are added before
 // the run reduction (what k_offset_accumulate_pk<2> does when it finds the keys equal, without the second key stream).
 // CORR: the partner's Q / U weights come from the pair sums (k_pair_weights) instead of its own row.
-template <bool CORR>
+template <bool CORR, bool UNI>
 __global__ __launch_bounds__(kThreads) void k_offset_accumulate_pr(
     const Chunk * __restrict__ chunks, int n_chunks, int n_det, const int64_t * __restrict__ view_first,
     const int64_t * __restrict__ view_aoff, FastDiv step_div, const int64_t * __restrict__ amp_offsets,
@@ -208,7 +242,6 @@ __global__ __launch_bounds__(kThreads) void k_offset_accumulate_pr(
             const int j = base + threadIdx.x;
             const bool active = j < n_pair;
             const int64_t s = s0 + 2 * (int64_t)(active ? j : 0);
-            const int64_t step_a = fastdiv(s - vfirst, step_div), step_b = fastdiv(s + 1 - vfirst, step_div);
             const uint2 kk = *reinterpret_cast<const uint2 *>(krow + s);
             double2 qa[E], qb[E], av[E];
             uint8_t afa[E], afb[E];
@@ -220,10 +253,29 @@ __global__ __launch_bounds__(kThreads) void k_offset_accumulate_pr(
                     qa[e] = qrow[e][s];
                     qb[e] = qrow[e][s + 1];
                 }
-                const int64_t aa = amp_offset[e] + vaoff + step_a, ab = amp_offset[e] + vaoff + step_b;
-                afa[e] = amp_flags[aa];
-                afb[e] = amp_flags[ab];
-                av[e] = make_double2(amps[aa], amps[ab]);
+            }
+            if constexpr (UNI) {
+                const WaveSteps w = wave_steps(s0, base, n_pair, vfirst, c.first + c.count, step_div);
+                const int rel = 2 * (int)(threadIdx.x & 63);
+                const bool up_a = rel >= w.split, up_b = rel + 1 >= w.split;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int64_t i0 = amp_offset[e] + vaoff + w.step0, i1 = w.two ? i0 + 1 : i0;
+                    const double a0 = amps[i0], a1 = amps[i1];
+                    const uint32_t f0 = flag_byte_uniform(amp_flags + i0), f1 = flag_byte_uniform(amp_flags + i1);
+                    av[e] = make_double2(up_a ? a1 : a0, up_b ? a1 : a0);
+                    afa[e] = (uint8_t)(up_a ? f1 : f0);
+                    afb[e] = (uint8_t)(up_b ? f1 : f0);
+                }
+            } else {
+                const int64_t step_a = fastdiv(s - vfirst, step_div), step_b = fastdiv(s + 1 - vfirst, step_div);
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int64_t aa = amp_offset[e] + vaoff + step_a, ab = amp_offset[e] + vaoff + step_b;
+                    afa[e] = amp_flags[aa];
+                    afb[e] = amp_flags[ab];
+                    av[e] = make_double2(amps[aa], amps[ab]);
+                }
             }
             if constexpr (CORR) {
                 const double * pa = reinterpret_cast<const double *>(qrow[1] + s);      // (read only behind a marker)
@@ -287,7 +339,7 @@ __global__ __launch_bounds__(kThreads) void k_offset_accumulate_pr(
 }
 
 // The projection from pair words: one key stream and ONE map gather per pair-sample.
-template <bool CORR>
+template <bool CORR, bool UNI>
 __global__ __launch_bounds__(kThreads) void k_offset_scan_project_pr(
     const Chunk * __restrict__ chunks, int n_chunks, int n_det, const int64_t * __restrict__ view_first,
     const int64_t * __restrict__ view_aoff, FastDiv step_div, const int64_t * __restrict__ amp_offsets,
@@ -331,7 +383,6 @@ __global__ __launch_bounds__(kThreads) void k_offset_scan_project_pr(
             const int j = base + threadIdx.x;
             const bool active = j < n_pair;
             const int64_t s = s0 + 2 * (int64_t)(active ? j : 0);
-            const int64_t step_a = fastdiv(s - vfirst, step_div), step_b = fastdiv(s + 1 - vfirst, step_div);
             const uint2 kk = *reinterpret_cast<const uint2 *>(krow + s);
             const uint32_t ia = kk.x & kPrIndex, ib = kk.y & kPrIndex;
             const bool hit_a = ia != 0, hit_b = ib != 0;
@@ -341,11 +392,39 @@ __global__ __launch_bounds__(kThreads) void k_offset_scan_project_pr(
             float4 cc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if constexpr (CORR) cc = *reinterpret_cast<const float4 *>(crow + s);
             const double2 qa0 = qrow[0][s], qb0 = qrow[0][s + 1];
+            WaveSteps w = {0, false, 4096};
+            int64_t step_a = 0, step_b = 0;
+            bool up_a = false, up_b = false;
+            if constexpr (UNI) {
+                w = wave_steps(s0, base, n_pair, vfirst, c.first + c.count, step_div);
+                const int rel = 2 * (int)(threadIdx.x & 63);
+                up_a = rel >= w.split;
+                up_b = rel + 1 >= w.split;
+            } else {
+                step_a = fastdiv(s - vfirst, step_div);
+                step_b = fastdiv(s + 1 - vfirst, step_div);
+            }
 #pragma unroll
             for (int e = 0; e < E; ++e) {
-                const int64_t aa = amp_offset[e] + vaoff + step_a, ab = amp_offset[e] + vaoff + step_b;
-                const uint8_t afa = amp_flags[aa], afb = amp_flags[ab];
-                const double2 av = make_double2(amps_in[aa], amps_in[ab]);
+                int64_t aa, ab;
+                uint8_t afa, afb;
+                double2 av;
+                if constexpr (UNI) {
+                    const int64_t i0 = amp_offset[e] + vaoff + w.step0, i1 = w.two ? i0 + 1 : i0;
+                    const double v0 = amps_in[i0], v1 = amps_in[i1];
+                    const uint32_t f0 = flag_byte_uniform(amp_flags + i0), f1 = flag_byte_uniform(amp_flags + i1);
+                    aa = up_a ? i1 : i0;
+                    ab = up_b ? i1 : i0;
+                    afa = (uint8_t)(up_a ? f1 : f0);
+                    afb = (uint8_t)(up_b ? f1 : f0);
+                    av = make_double2(up_a ? v1 : v0, up_b ? v1 : v0);
+                } else {
+                    aa = amp_offset[e] + vaoff + step_a;
+                    ab = amp_offset[e] + vaoff + step_b;
+                    afa = amp_flags[aa];
+                    afb = amp_flags[ab];
+                    av = make_double2(amps_in[aa], amps_in[ab]);
+                }
                 double2 qa = qa0, qb = qb0;
                 if (e == 1) {
                     if constexpr (CORR) {
@@ -697,6 +776,16 @@ int toast_hip_offset_pack_pair_weights_dev(const double * d_qu, float * d_corr, 
     });
 }
 
+namespace {
+// The wave-uniform amplitude look-up of the pair-word sweeps needs baselines of at least a wave's 128 samples
+// (TOAST_HIP_PACKED_UNIFORM_AMPS=0 keeps the per-lane look-up: A/B runs, tests).
+bool uniform_amplitudes(int64_t step_length) {
+    const char * e = std::getenv("TOAST_HIP_PACKED_UNIFORM_AMPS");
+    if (e != nullptr && e[0] == '0') return false;
+    return step_length >= 128;
+}
+}  // namespace
+
 int toast_hip_offset_accumulate_packed_dev(
     int64_t step_length, const int64_t * amp_offsets, const int64_t * n_amp_views, const double * d_amplitudes,
     const uint8_t * d_amplitude_flags, double * d_zmap, const uint32_t * d_key, const double * d_qu, const double * d_cal,
@@ -723,16 +812,20 @@ int toast_hip_offset_accumulate_packed_dev(
         const dim3 grid = chunk_grid(n_det, chunks.size());
         const bool pr = pair_words != 0 || (pair_detectors() && n_det >= 2);
         const dim3 gp((unsigned)(pr ? (n_det + 1) / 2 : n_det), grid.y, 1);
+        const bool uni = uniform_amplitudes(step_length);
 #define TH_PK_ARGS                                                                                                  \
     (const Chunk *)(d + o_ch), (int)chunks.size(), (int)n_det, (const int64_t *)(d + o_vf), (const int64_t *)(d + o_va), \
         make_fastdiv(step_length), (const int64_t *)(d + o_ao), d_amplitudes, d_amplitude_flags,                    \
         (const double *)(d + o_ds), d_cal, d_zmap, d_key, reinterpret_cast<const double2 *>(d_qu), n_samp
         if (pair_words && d_pair_corr != nullptr) {
             need_aligned(d_pair_corr, "pair weight sums");
-            hipLaunchKernelGGL(k_offset_accumulate_pr<true>, gp, dim3(kThreads), 0, st, TH_PK_ARGS,
-                               reinterpret_cast<const float2 *>(d_pair_corr));
+            const float2 * pc = reinterpret_cast<const float2 *>(d_pair_corr);
+            if (uni) hipLaunchKernelGGL((k_offset_accumulate_pr<true, true>), gp, dim3(kThreads), 0, st, TH_PK_ARGS, pc);
+            else hipLaunchKernelGGL((k_offset_accumulate_pr<true, false>), gp, dim3(kThreads), 0, st, TH_PK_ARGS, pc);
         } else if (pair_words) {
-            hipLaunchKernelGGL(k_offset_accumulate_pr<false>, gp, dim3(kThreads), 0, st, TH_PK_ARGS, (const float2 *)nullptr);
+            const float2 * pc = nullptr;
+            if (uni) hipLaunchKernelGGL((k_offset_accumulate_pr<false, true>), gp, dim3(kThreads), 0, st, TH_PK_ARGS, pc);
+            else hipLaunchKernelGGL((k_offset_accumulate_pr<false, false>), gp, dim3(kThreads), 0, st, TH_PK_ARGS, pc);
         } else if (pr) {
             hipLaunchKernelGGL((k_offset_accumulate_pk<2>), gp, dim3(kThreads), 0, st, TH_PK_ARGS);
         } else {
@@ -772,13 +865,16 @@ int toast_hip_offset_scan_project_packed_dev(
     (const Chunk *)(d + o_ch), (int)chunks.size(), (int)n_det, (const int64_t *)(d + o_vf), (const int64_t *)(d + o_va),  \
         make_fastdiv(step_length), (const int64_t *)(d + o_ao), d_amps_in, d_amps_out, d_amplitude_flags,            \
         (const double *)(d + o_dw), d_cal, d_map, d_key, reinterpret_cast<const double2 *>(d_qu), n_samp
+            const bool uni = uniform_amplitudes(step_length);
             if (d_pair_corr != nullptr) {
                 need_aligned(d_pair_corr, "pair weight sums");
-                hipLaunchKernelGGL(k_offset_scan_project_pr<true>, gp, dim3(kThreads), 0, st, TH_PR_ARGS,
-                                   reinterpret_cast<const float2 *>(d_pair_corr));
+                const float2 * pc = reinterpret_cast<const float2 *>(d_pair_corr);
+                if (uni) hipLaunchKernelGGL((k_offset_scan_project_pr<true, true>), gp, dim3(kThreads), 0, st, TH_PR_ARGS, pc);
+                else hipLaunchKernelGGL((k_offset_scan_project_pr<true, false>), gp, dim3(kThreads), 0, st, TH_PR_ARGS, pc);
             } else {
-                hipLaunchKernelGGL(k_offset_scan_project_pr<false>, gp, dim3(kThreads), 0, st, TH_PR_ARGS,
-                                   (const float2 *)nullptr);
+                const float2 * pc = nullptr;
+                if (uni) hipLaunchKernelGGL((k_offset_scan_project_pr<false, true>), gp, dim3(kThreads), 0, st, TH_PR_ARGS, pc);
+                else hipLaunchKernelGGL((k_offset_scan_project_pr<false, false>), gp, dim3(kThreads), 0, st, TH_PR_ARGS, pc);
             }
 #undef TH_PR_ARGS
             check_launch();

@@ -181,21 +181,23 @@ def step_el(times, az, el, el_rate, el_accel, scan_min_el, scan_max_el, el_mod_s
     """Step ``el`` IN PLACE by ``el_mod_step`` after every scan pair -- at every second reversal of the azimuth --,
     each step a move from rest to rest centred on the reversal (sim_ground_utils.py:360-432).  Returns the new
     (min, max) of el."""
-    sign = np.sign(el_mod_step)
-    el_step = np.abs(el_mod_step)
-    t_accel = el_rate / el_accel
-    el_step_accel = 0.5 * el_accel * t_accel**2
-    if el_step > 2 * el_step_accel:
-        t_scan = (el_step - 2 * el_step_accel) / el_rate
+    direction = np.sign(el_mod_step)
+    height = np.abs(el_mod_step)
+    # rest -> full rate -> rest: a ramp of `ramp_s` seconds covers `ramp_rise`; a step lower than two ramps never reaches
+    # the full rate and has no coasting piece (the operation order is the reference's: the knots are compared bit for bit)
+    ramp_s = el_rate / el_accel
+    ramp_rise = 0.5 * el_accel * ramp_s**2
+    if height > 2 * ramp_rise:
+        coast_s = (height - 2 * ramp_rise) / el_rate
     else:
-        el_step_accel = np.abs(el_mod_step) / 2
-        t_accel = np.sqrt(2 * el_step_accel / el_accel)
-        t_scan = 0
-    rate_reached = el_accel * t_accel
-    pieces = [(t_accel, lambda t, e0: 0.5 * el_accel * t**2)]
-    if t_scan > 0:
-        pieces.append((t_scan, lambda t, e0: e0 + t * el_rate))
-    pieces.append((t_accel, lambda t, e0: e0 + rate_reached * t - 0.5 * el_accel * t**2))
+        ramp_rise = np.abs(el_mod_step) / 2
+        ramp_s = np.sqrt(2 * ramp_rise / el_accel)
+        coast_s = 0
+    rate_reached = el_accel * ramp_s
+    pieces = [(ramp_s, lambda t, e0: 0.5 * el_accel * t**2)]
+    if coast_s > 0:
+        pieces.append((coast_s, lambda t, e0: e0 + t * el_rate))
+    pieces.append((ramp_s, lambda t, e0: e0 + rate_reached * t - 0.5 * el_accel * t**2))
     t_knot, el_knot = [], []
     t_last, el_last = 0.0, 0.0
     for k, (duration, shape) in enumerate(pieces):
@@ -205,7 +207,7 @@ def step_el(times, az, el, el_rate, el_accel, scan_min_el, scan_max_el, el_mod_s
         t_last, el_last = t_knot[-1][-1], el_knot[-1][-1]
     t_knot = np.hstack(t_knot)
     t_knot -= t_knot[t_knot.size // 2]
-    el_knot = sign * np.hstack(el_knot)
+    el_knot = direction * np.hstack(el_knot)
     daz = np.diff(az)
     reversals = np.where(daz[1:] * daz[:-1] < 0)[0] + 1
     for istep in reversals[1::2]:
