@@ -224,6 +224,9 @@ class SolveAmplitudes(Operator):
                 det_mask=binning.det_mask, det_flags=nm["flags"], det_flag_mask=255, shared_flags=None,
                 pixel_pointing=pixels, stokes_weights=weights, noise_model=binning.noise_model,
                 rcond_threshold=self.solve_rcond_threshold, sync_type=binning.sync_type,
+                # (MapMaker asks for the inverse covariance too when the final binning's products are going to be these
+                #  very arrays: _share_with_final below)
+                inverse_covariance=getattr(self, "_share_invcov", None),
                 save_pointing=binning.full_pointing, det_data_units=binning.det_data_units).apply(data, detectors=detectors)
             t0 = lap("covariance_and_hits", t0)
             # -- samples in poorly conditioned pixels must not constrain the templates (:902-939)
@@ -277,6 +280,8 @@ class SolveAmplitudes(Operator):
             tm.det_flags, tm.det_flag_mask = saved["tm_flags"], saved["tm_flag_mask"]
         if not self.keep_solver_products and not self.mc_mode:
             for key in (nm["hits"], nm["cov"], nm["rcond"], nm["rcond_mask"], nm["rhs"], nm["bin"]):
+                if key in getattr(self, "_share_keep", ()):
+                    continue          # MapMaker takes it over as a final product
                 if key in data:
                     if hasattr(data[key], "clear") and not isinstance(data[key], PixelData):
                         data[key].clear()
@@ -437,6 +442,19 @@ class MapMaker(Operator):
                                      keep_solver_products=self.keep_solver_products, mc_mode=self.mc_mode,
                                      mc_index=self.mc_index, reset_pix_dist=self.reset_pix_dist,
                                      fused_lhs=self.fused_lhs)
+            # The final binning's hits / covariance / rcond are the SOLVER's when both are built from the same samples: the
+            # solver flags' first bit is exactly the final binning's own flag test (same operator, its flags and masks
+            # restored after the solve), no pixel mask adds a second bit before the solver covariance is accumulated, and
+            # the two condition-number cuts agree.  The reference accumulates them twice (mapmaker_templates.py:843-893,
+            # mapmaker.py:438-494); here the second sweep over the pointing (33 B per detector-sample, 6.4 ms at cfg-3)
+            # is skipped and the arrays change their names.  TOAST_HIP_SHARE_SOLVER_COV=0: accumulate twice.
+            share = (not self.mc_mode and self.mask is None and final_binning is self.binning
+                     and self.map_rcond_threshold == self.solve_rcond_threshold and not self.reset_pix_dist
+                     and _os.environ.get("TOAST_HIP_SHARE_SOLVER_COV", "1") != "0")
+            snm = solver._names()
+            if share:
+                solver._share_invcov = f"{n}_solve_invcov"
+                solver._share_keep = (snm["hits"], snm["cov"], snm["rcond"])
             solver.apply(data, detectors=detectors)
             amplitudes = solver.amplitudes
             self.history, self.iteration_seconds = solver.history, solver.iteration_seconds
@@ -459,7 +477,18 @@ class MapMaker(Operator):
                                    save_pointing=map_binning.full_pointing).apply(data, detectors=detectors)
         # -- final covariance, hits, rcond with the map binning's own flags (:438-479); an MC
         #    realisation re-uses the existing one
-        if not (self.mc_mode and cov_name in data):
+        shared = False
+        if use_templates and share and all(k in data for k in (snm["hits"], snm["cov"], snm["rcond"], f"{n}_solve_invcov")):
+            for key in (hits_name, cov_name, invcov_name, rcond_name):
+                if key in data:
+                    del data[key]
+            # (moved, not deleted: Data.__delitem__ would drop the device copy with the name)
+            take = (lambda k: data[k].duplicate()) if self.keep_solver_products else (lambda k: data._internal.pop(k))
+            data[hits_name], data[cov_name], data[rcond_name] = take(snm["hits"]), take(snm["cov"]), take(snm["rcond"])
+            data[invcov_name] = data._internal.pop(f"{n}_solve_invcov")
+            shared = True
+        self.shared_solver_covariance = shared
+        if not shared and not (self.mc_mode and cov_name in data):
             CovarianceAndHits(
                 pixel_dist=map_binning.pixel_dist, covariance=cov_name, inverse_covariance=invcov_name, hits=hits_name,
                 rcond=rcond_name, det_mask=map_binning.det_mask, det_flags=map_binning.det_flags,
