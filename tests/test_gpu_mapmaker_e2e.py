@@ -26,7 +26,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 FIXTURE = os.path.join(HERE, "golden", "mapmaker_e2e.npz")
 
 
-def _run(case, full_pointing=True, packed=True, deterministic=False):
+def _run(case, full_pointing=True, packed=True, deterministic=False, share=True):
     from toast_amd import capi, ops
     from toast_amd.data import defaults
     from toast_amd.templates import Offset
@@ -34,6 +34,7 @@ def _run(case, full_pointing=True, packed=True, deterministic=False):
     data, cfg = mapmaker_case.build(case)
     old = os.environ.get("TOAST_HIP_PACKED_POINTING")
     os.environ["TOAST_HIP_PACKED_POINTING"] = "1" if packed else "0"
+    os.environ["TOAST_HIP_SHARE_SOLVER_COV"] = "1" if share else "0"
     was = capi.get_deterministic()
     capi.set_deterministic(deterministic)
     try:
@@ -48,6 +49,7 @@ def _run(case, full_pointing=True, packed=True, deterministic=False):
         mm.apply(data)
     finally:
         capi.set_deterministic(was)
+        os.environ.pop("TOAST_HIP_SHARE_SOLVER_COV", None)
         if old is None:
             os.environ.pop("TOAST_HIP_PACKED_POINTING", None)
         else:
@@ -58,7 +60,7 @@ def _run(case, full_pointing=True, packed=True, deterministic=False):
                binmap=data["mm_binmap"].data.reshape(-1, 3).copy(),
                noiseweighted=data["mm_noiseweighted_map"].data.reshape(-1, 3).copy(),
                cov=data["mm_cov"].data.reshape(-1, 6).copy(), local_submaps=np.array(dist.local_submaps),
-               route=tuple(getattr(mm, "lhs_route", ())))
+               route=tuple(getattr(mm, "lhs_route", ())), shared=bool(getattr(mm, "shared_solver_covariance", False)))
     return out
 
 
@@ -100,6 +102,15 @@ def test_mapmaker_deterministic_mode_equals_reference_chain(case):
     want = _fixture(case)
     got = _run(case, deterministic=True)
     _compare(got, want, 1e-12, 1e-10, f"{case} deterministic")
+    # the final hits / covariance / rcond were the solver's own arrays (same samples, same cut: accumulated once) ...
+    assert got["shared"]
+    if case == "small":
+        # ... and accumulating them a second time, as the reference does, gives the same products bit for bit
+        twice = _run(case, deterministic=True, share=False)
+        assert not twice["shared"]
+        _compare(twice, want, 1e-12, 1e-10, f"{case} deterministic, covariance accumulated twice")
+        for k in ("hits", "cov", "map", "binmap", "noiseweighted", "amplitudes"):
+            assert np.array_equal(twice[k], got[k]), k
 
 
 @pytest.mark.parametrize("case", ["small", "cfg3cut"])

@@ -196,12 +196,12 @@ __device__ __forceinline__ WaveSteps wave_steps(int64_t s0, int base, int n_pair
     return w;
 }
 
-// byte p[0] through an aligned dword load (scalar when p is wave-uniform; the dword that holds a valid byte lies inside
-// the allocation)
-__device__ __forceinline__ uint32_t flag_byte_uniform(const uint8_t * p) {
-    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
-    const uint32_t w = *reinterpret_cast<const uint32_t *>(a & ~(uintptr_t)3);
-    return (w >> ((unsigned)(a & 3) * 8u)) & 0xffu;
+// byte flags[i] through the aligned dword that holds it: a SCALAR load when i is wave-uniform (a byte load is a vector
+// instruction even then; a pointer rebuilt from an integer would be a flat one).  `flags` is 4-byte aligned (checked on the
+// host: uniform_amplitudes), so the dword lies inside the allocation.
+__device__ __forceinline__ uint32_t flag_byte_uniform(const uint8_t * __restrict__ flags, int64_t i) {
+    const uint32_t w = reinterpret_cast<const uint32_t *>(flags)[i >> 2];
+    return (w >> ((unsigned)(i & 3) * 8u)) & 0xffu;
 }
 
 // The accumulation from pair words: both detectors of a pair share the pixel, so their contributions are added before
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(kThreads) void k_offset_accumulate_pr(
                 for (int e = 0; e < E; ++e) {
                     const int64_t i0 = amp_offset[e] + vaoff + w.step0, i1 = w.two ? i0 + 1 : i0;
                     const double a0 = amps[i0], a1 = amps[i1];
-                    const uint32_t f0 = flag_byte_uniform(amp_flags + i0), f1 = flag_byte_uniform(amp_flags + i1);
+                    const uint32_t f0 = flag_byte_uniform(amp_flags, i0), f1 = flag_byte_uniform(amp_flags, i1);
                     av[e] = make_double2(up_a ? a1 : a0, up_b ? a1 : a0);
                     afa[e] = (uint8_t)(up_a ? f1 : f0);
                     afb[e] = (uint8_t)(up_b ? f1 : f0);
@@ -338,6 +338,11 @@ __global__ __launch_bounds__(kThreads) void k_offset_accumulate_pr(
     }
 }
 
+// two doubles at an 8-byte aligned address (global loads need dword alignment only)
+struct __attribute__((packed, aligned(8))) MapPair {
+    double x, y;
+};
+
 // The projection from pair words: one key stream and ONE map gather per pair-sample.
 template <bool CORR, bool UNI>
 __global__ __launch_bounds__(kThreads) void k_offset_scan_project_pr(
@@ -388,7 +393,9 @@ __global__ __launch_bounds__(kThreads) void k_offset_scan_project_pr(
             const bool hit_a = ia != 0, hit_b = ib != 0;
             const double * ma = map + (hit_a ? 3 * ((int64_t)ia - 1) : 0);
             const double * mb = map + (hit_b ? 3 * ((int64_t)ib - 1) : 0);
-            const double a0 = ma[0], a1 = ma[1], a2 = ma[2], b0 = mb[0], b1 = mb[1], b2 = mb[2];
+            // (a map value is 24 bytes at an 8-byte aligned address: one 16-byte and one 8-byte request instead of three)
+            const MapPair ha = *reinterpret_cast<const MapPair *>(ma), hb = *reinterpret_cast<const MapPair *>(mb);
+            const double a0 = ha.x, a1 = ha.y, a2 = ma[2], b0 = hb.x, b1 = hb.y, b2 = mb[2];
             float4 cc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             if constexpr (CORR) cc = *reinterpret_cast<const float4 *>(crow + s);
             const double2 qa0 = qrow[0][s], qb0 = qrow[0][s + 1];
@@ -412,7 +419,7 @@ __global__ __launch_bounds__(kThreads) void k_offset_scan_project_pr(
                 if constexpr (UNI) {
                     const int64_t i0 = amp_offset[e] + vaoff + w.step0, i1 = w.two ? i0 + 1 : i0;
                     const double v0 = amps_in[i0], v1 = amps_in[i1];
-                    const uint32_t f0 = flag_byte_uniform(amp_flags + i0), f1 = flag_byte_uniform(amp_flags + i1);
+                    const uint32_t f0 = flag_byte_uniform(amp_flags, i0), f1 = flag_byte_uniform(amp_flags, i1);
                     aa = up_a ? i1 : i0;
                     ab = up_b ? i1 : i0;
                     afa = (uint8_t)(up_a ? f1 : f0);
@@ -779,10 +786,11 @@ int toast_hip_offset_pack_pair_weights_dev(const double * d_qu, float * d_corr, 
 namespace {
 // The wave-uniform amplitude look-up of the pair-word sweeps needs baselines of at least a wave's 128 samples
 // (TOAST_HIP_PACKED_UNIFORM_AMPS=0 keeps the per-lane look-up: A/B runs, tests).
-bool uniform_amplitudes(int64_t step_length) {
+bool uniform_amplitudes(int64_t step_length, const uint8_t * d_amplitude_flags) {
     const char * e = std::getenv("TOAST_HIP_PACKED_UNIFORM_AMPS");
     if (e != nullptr && e[0] == '0') return false;
-    return step_length >= 128;
+    // (the flags are read as aligned dwords: an interior pointer that is not 4-byte aligned keeps the per-lane look-up)
+    return step_length >= 128 && (reinterpret_cast<uintptr_t>(d_amplitude_flags) & 3u) == 0;
 }
 }  // namespace
 
@@ -812,7 +820,7 @@ int toast_hip_offset_accumulate_packed_dev(
         const dim3 grid = chunk_grid(n_det, chunks.size());
         const bool pr = pair_words != 0 || (pair_detectors() && n_det >= 2);
         const dim3 gp((unsigned)(pr ? (n_det + 1) / 2 : n_det), grid.y, 1);
-        const bool uni = uniform_amplitudes(step_length);
+        const bool uni = uniform_amplitudes(step_length, d_amplitude_flags);
 #define TH_PK_ARGS                                                                                                  \
     (const Chunk *)(d + o_ch), (int)chunks.size(), (int)n_det, (const int64_t *)(d + o_vf), (const int64_t *)(d + o_va), \
         make_fastdiv(step_length), (const int64_t *)(d + o_ao), d_amplitudes, d_amplitude_flags,                    \
@@ -865,7 +873,7 @@ int toast_hip_offset_scan_project_packed_dev(
     (const Chunk *)(d + o_ch), (int)chunks.size(), (int)n_det, (const int64_t *)(d + o_vf), (const int64_t *)(d + o_va),  \
         make_fastdiv(step_length), (const int64_t *)(d + o_ao), d_amps_in, d_amps_out, d_amplitude_flags,            \
         (const double *)(d + o_dw), d_cal, d_map, d_key, reinterpret_cast<const double2 *>(d_qu), n_samp
-            const bool uni = uniform_amplitudes(step_length);
+            const bool uni = uniform_amplitudes(step_length, d_amplitude_flags);
             if (d_pair_corr != nullptr) {
                 need_aligned(d_pair_corr, "pair weight sums");
                 const float2 * pc = reinterpret_cast<const float2 *>(d_pair_corr);
