@@ -599,6 +599,23 @@ int toast_hip_offset_accumulate_dev(
     const toast_hip_interval * intervals /*host*/, int64_t n_view, const uint8_t * d_shared_flags,
     int64_t n_shared_flags, uint8_t shared_flag_mask, void * stream);
 
+/* The map-maker's last two steps in one pass: zmap += A^T N^-1 (d - M a) -- the template-cleaned signal binned without
+ * being written -- the reference's ApplyAmplitudes(op = "subtract") and the accumulation of the final BinMap
+ * (src/toast/ops/mapmaker.py:531-608, mapmaker_templates.py:1205-1261) with the per-sample arithmetic of offset
+ * add_to_signal (template_offset.cpp:16-122: the template value is 0 + a for an unflagged amplitude, 0 otherwise), the
+ * subtraction d - template, and build_noise_weighted (ops_mapmaker_utils.cpp:15-86).  d = row data_index[k] of d_signal
+ * (only read).  nnz = 3, an even number of samples per row and 16-byte aligned rows (what cached IQU pointing has); other
+ * shapes are refused and the caller runs the two operators.  Other arguments as toast_hip_offset_accumulate_dev. */
+int toast_hip_offset_clean_accumulate_dev(
+    int64_t step_length, const int64_t * amp_offsets /*host*/, const int64_t * n_amp_views /*host*/,
+    const double * d_amplitudes, const uint8_t * d_amplitude_flags, const int64_t * d_global2local,
+    double * d_zmap, int64_t n_pix_submap, int64_t nnz, const int32_t * pixel_index /*host*/,
+    const int64_t * d_pixels, const int32_t * weight_index /*host*/, const double * d_weights,
+    const int32_t * data_index /*host*/, const double * d_signal, const int32_t * flag_index /*host*/,
+    const uint8_t * d_det_flags, int64_t n_flag_samp, const double * det_scale /*host*/, uint8_t det_flag_mask,
+    int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals /*host*/, int64_t n_view,
+    const uint8_t * d_shared_flags, int64_t n_shared_flags, uint8_t shared_flag_mask, void * stream);
+
 int toast_hip_offset_scan_project_dev(
     int64_t step_length, const int64_t * amp_offsets /*host*/, const int64_t * n_amp_views /*host*/,
     const double * d_amplitudes_in, double * d_amplitudes_out, const uint8_t * d_amplitude_flags,
@@ -652,6 +669,21 @@ int toast_hip_offset_pack_pointing_dev(
     uint8_t shared_flag_mask, const int32_t * proj_flag_index, const uint8_t * d_proj_flags, int64_t n_proj_flag_samp,
     uint8_t proj_flag_mask, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
     uint32_t * d_key, double * d_qu, double * d_cal, int * packable, int * pair_words, void * stream);
+/* The three calls above in ONE sweep over the cached pointing when the rows come in co-pointing pairs: pair words, both rows
+ * of Q / U weights and the float2 pair weight sums d_corr[(n_det + 1) / 2][n_samp] straight from the pixels, weights and
+ * flags (33 B read, 22 B written per detector-sample instead of four passes).  *pair_weights = 1: d_corr is usable (at most
+ * one marked component in a hundred).  Pairs that do not share their pixels in every sample, an odd n_samp or d_corr == NULL:
+ * the separate passes run instead (*pair_weights = 0).  Same outputs bit for bit, except that row 2 b + 1 of d_key -- which
+ * the pair-word sweeps never read -- is not written.  TOAST_HIP_PACK_ONEPASS=0: always the separate passes.
+ * [ref: what is packed is the pointing SolverLHS._exec sweeps, src/toast/ops/mapmaker_solve.py:342-506] */
+int toast_hip_offset_pack_pointing_onepass_dev(
+    const int64_t * d_g2l, int64_t n_pix_submap, const int32_t * pixel_index /*host*/, const int64_t * d_pixels,
+    const int32_t * weight_index /*host*/, const double * d_weights, const int32_t * acc_flag_index /*host*/,
+    const uint8_t * d_det_flags, int64_t n_flag_samp, uint8_t det_flag_mask, const uint8_t * d_shared_flags,
+    int64_t n_shared_flags, uint8_t shared_flag_mask, const int32_t * proj_flag_index /*host*/,
+    const uint8_t * d_proj_flags, int64_t n_proj_flag_samp, uint8_t proj_flag_mask, int64_t n_det, int64_t n_samp,
+    const toast_hip_interval * intervals /*host*/, int64_t n_view, uint32_t * d_key, double * d_qu, double * d_cal,
+    float * d_corr, int * packable, int * pair_words, int * pair_weights, void * stream);
 int toast_hip_offset_pack_pairs_dev(uint32_t * d_key, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals,
                                     int64_t n_view, int * pair_words, void * stream);
 /* Pair weights (with pair words): the Q / U weights of an orthogonal pair are negatives of each other up to a few ulps,

@@ -26,7 +26,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 FIXTURE = os.path.join(HERE, "golden", "mapmaker_e2e.npz")
 
 
-def _run(case, full_pointing=True, packed=True, deterministic=False, share=True):
+def _run(case, full_pointing=True, packed=True, deterministic=False, share=True, fused_final=True):
     from toast_amd import capi, ops
     from toast_amd.data import defaults
     from toast_amd.templates import Offset
@@ -35,6 +35,7 @@ def _run(case, full_pointing=True, packed=True, deterministic=False, share=True)
     old = os.environ.get("TOAST_HIP_PACKED_POINTING")
     os.environ["TOAST_HIP_PACKED_POINTING"] = "1" if packed else "0"
     os.environ["TOAST_HIP_SHARE_SOLVER_COV"] = "1" if share else "0"
+    os.environ["TOAST_HIP_FUSED_FINAL"] = "1" if fused_final else "0"
     was = capi.get_deterministic()
     capi.set_deterministic(deterministic)
     try:
@@ -50,6 +51,7 @@ def _run(case, full_pointing=True, packed=True, deterministic=False, share=True)
     finally:
         capi.set_deterministic(was)
         os.environ.pop("TOAST_HIP_SHARE_SOLVER_COV", None)
+        os.environ.pop("TOAST_HIP_FUSED_FINAL", None)
         if old is None:
             os.environ.pop("TOAST_HIP_PACKED_POINTING", None)
         else:
@@ -60,7 +62,8 @@ def _run(case, full_pointing=True, packed=True, deterministic=False, share=True)
                binmap=data["mm_binmap"].data.reshape(-1, 3).copy(),
                noiseweighted=data["mm_noiseweighted_map"].data.reshape(-1, 3).copy(),
                cov=data["mm_cov"].data.reshape(-1, 6).copy(), local_submaps=np.array(dist.local_submaps),
-               route=tuple(getattr(mm, "lhs_route", ())), shared=bool(getattr(mm, "shared_solver_covariance", False)))
+               route=tuple(getattr(mm, "lhs_route", ())), shared=bool(getattr(mm, "shared_solver_covariance", False)),
+               fused_final=bool(getattr(mm, "fused_final_binning", False)))
     return out
 
 
@@ -129,6 +132,11 @@ def test_mapmaker_default_routes_within_the_scatter_floor(case):
     routes["default " + "/".join(a["route"])] = a
     routes["fused (TOAST_HIP_PACKED_POINTING=0)"] = _run(case, packed=False)
     routes["full_pointing=False"] = _run(case, full_pointing=False)
+    # the last two steps (subtract the templates, bin) as one sweep -- the default with cached pointing -- and as the
+    # reference's two operators
+    assert a["fused_final"] and not routes["full_pointing=False"]["fused_final"]
+    routes["two-operator final binning (TOAST_HIP_FUSED_FINAL=0)"] = _run(case, fused_final=False)
+    assert not routes["two-operator final binning (TOAST_HIP_FUSED_FINAL=0)"]["fused_final"]
     seen = set()
     for label, got in routes.items():
         seen.add(got["route"])

@@ -278,6 +278,57 @@ def test_pair_weight_sums(n_det, odd_views):
         assert not D.offset_pack_pair_weights(qu2.data_ptr(), corr.data_ptr(), n_det, s2["n_samp"], s2["ivl"])
 
 
+@pytest.mark.parametrize("n_det,odd_views,pair_cal", [(6, True, True), (5, True, True), (8, False, True), (6, True, False)])
+def test_pack_in_one_sweep_equals_the_separate_passes(n_det, odd_views, pair_cal):
+    """Round 6: toast_hip_offset_pack_pointing_onepass_dev writes the pair words, both rows of Q / U weights, the intensity
+    weights and the pair weight sums in ONE sweep over pixels / weights / flags; the outputs are those of pack -> pair
+    check -> pair merge -> pair weights bit for bit (row 2 b + 1 of the key array, which the pair-word sweeps never read,
+    is left alone), including the NaN markers, the untouched samples outside the views and the verdict on the sums."""
+    import os
+
+    if os.environ.get("TOAST_HIP_PAIR", "1") == "0":
+        pytest.skip("detector-pair kernels switched off")
+    s = _setup(n_det=n_det, odd_views=odd_views, pair_cal=pair_cal)
+    torch, D = s["torch"], s["D"]
+    (ok, pair), key, qu, cal = _pack(s, pair_words=True)
+    assert ok and pair
+    n_pairs = (n_det + 1) // 2
+    corr = torch.full((n_pairs, s["n_samp"], 2), 7.0, dtype=torch.float32, device=s["dev"])
+    sums_ok = D.offset_pack_pair_weights(qu.data_ptr(), corr.data_ptr(), n_det, s["n_samp"], s["ivl"])
+    assert sums_ok == (pair_cal or n_det < 2)
+    key1 = torch.full((s["n_det"], s["n_samp"]), -3, dtype=torch.int32, device=s["dev"])
+    qu1 = torch.zeros((s["n_det"], s["n_samp"], 2), dtype=torch.float64, device=s["dev"])
+    cal1 = torch.zeros(s["n_det"], dtype=torch.float64, device=s["dev"])
+    corr1 = torch.full((n_pairs, s["n_samp"], 2), 7.0, dtype=torch.float32, device=s["dev"])
+    ok1, pair1, sums1 = D.offset_pack_pointing_onepass(
+        s["d_g2l"].data_ptr(), s["nps"], s["idx"], s["d_pix"].data_ptr(), s["idx"], s["d_w"].data_ptr(), s["idx"],
+        s["d_dflags"].data_ptr(), s["n_samp"], 1, s["d_sflags"].data_ptr(), s["n_samp"], 1, s["idx"], s["d_pflags"].data_ptr(),
+        s["n_samp"], 1, s["n_samp"], s["ivl"], key1.data_ptr(), qu1.data_ptr(), cal1.data_ptr(), corr1.data_ptr())
+    assert (ok1, pair1, sums1) == (True, True, sums_ok)
+    in_view = np.zeros(s["n_samp"], dtype=bool)
+    for v in s["ivl"]:
+        in_view[int(v["first"]):int(v["last"])] = True
+    k0, k1 = key.cpu().numpy(), key1.cpu().numpy()
+    assert np.array_equal(k1[0::2][:, in_view], k0[0::2][:, in_view])          # the pair words
+    assert np.all(k1[1::2] == -3) and np.all(k1[:, ~in_view] == -3)            # nothing else is written
+    q0, q1 = qu.cpu().numpy(), qu1.cpu().numpy()
+    assert np.array_equal(q1[:, in_view].view(np.uint64), q0[:, in_view].view(np.uint64))
+    assert np.all(q1[:, ~in_view] == 0.0)
+    assert np.array_equal(cal1.cpu().numpy(), cal.cpu().numpy())
+    c0, c1 = corr.cpu().numpy(), corr1.cpu().numpy()
+    assert np.array_equal(c1.view(np.uint32), c0.view(np.uint32))              # sums, NaN markers and the untouched 7.0s
+    # pairs that do not see the same pixels: the separate passes run behind the same call and say so
+    s3 = _setup(n_det=4, odd_views=odd_views, pair_cal=True)
+    pix = s3["d_pix"].clone()
+    pix[1] = torch.roll(pix[1], 7)
+    ok3, pair3, sums3 = D.offset_pack_pointing_onepass(
+        s3["d_g2l"].data_ptr(), s3["nps"], s3["idx"], pix.data_ptr(), s3["idx"], s3["d_w"].data_ptr(), s3["idx"],
+        s3["d_dflags"].data_ptr(), s3["n_samp"], 1, s3["d_sflags"].data_ptr(), s3["n_samp"], 1, s3["idx"],
+        s3["d_pflags"].data_ptr(), s3["n_samp"], 1, s3["n_samp"], s3["ivl"], key1[:4].data_ptr(), qu1[:4].data_ptr(),
+        cal1[:4].data_ptr(), corr1[:2].data_ptr())
+    assert (ok3, pair3, sums3) == (True, False, False)
+
+
 def z_dummy(s):
     return s["torch"].zeros((s["n_local"], s["nps"], 3), dtype=s["torch"].float64, device=s["dev"])
 

@@ -862,6 +862,25 @@ class _Dev:
             _i64(n_flag_samp), _p(ds), _u8(det_flag_mask), _i64(pi.size), _i64(n_samp), _p(iv), _i64(iv.size),
             _p(d_shared_flags), _i64(n_shared_flags), _u8(shared_flag_mask), _p(stream)))
 
+    def offset_clean_accumulate(self, step_length, amp_offsets, n_amp_views, d_amplitudes, d_amplitude_flags, d_g2l,
+                                d_zmap, n_pix_submap, nnz, pixel_index, d_pixels, weight_index, d_weights, data_index,
+                                d_signal, flag_index, d_det_flags, n_flag_samp, det_scale, det_flag_mask, n_samp,
+                                intervals, d_shared_flags, n_shared_flags, shared_flag_mask, stream=0):
+        """zmap += A^T N^-1 (d - M a): the cleaned signal binned in one pass (toast_hip_offset_clean_accumulate_dev)."""
+        ao = self._small(amp_offsets, np.int64)
+        nv = self._small(n_amp_views, np.int64)
+        pi = self._small(pixel_index, np.int32)
+        wi = self._small(weight_index, np.int32)
+        di = self._small(data_index, np.int32)
+        fi = self._small(flag_index, np.int32)
+        ds = self._small(det_scale, np.float64)
+        iv = self._small(intervals, interval_dtype)
+        _check(lib().toast_hip_offset_clean_accumulate_dev(
+            _i64(step_length), _p(ao), _p(nv), _p(d_amplitudes), _p(d_amplitude_flags), _p(d_g2l), _p(d_zmap),
+            _i64(n_pix_submap), _i64(nnz), _p(pi), _p(d_pixels), _p(wi), _p(d_weights), _p(di), _p(d_signal), _p(fi),
+            _p(d_det_flags), _i64(n_flag_samp), _p(ds), _u8(det_flag_mask), _i64(pi.size), _i64(n_samp), _p(iv),
+            _i64(iv.size), _p(d_shared_flags), _i64(n_shared_flags), _u8(shared_flag_mask), _p(stream)))
+
     def offset_scan_project(self, step_length, amp_offsets, n_amp_views, d_amps_in, d_amps_out, d_amplitude_flags,
                             d_g2l, d_map, n_pix_submap, nnz, pixel_index, d_pixels, weight_index, d_weights,
                             flag_index, d_flag_data, flag_mask, det_weights, n_samp, intervals, stream=0):
@@ -896,6 +915,26 @@ class _Dev:
             _i64(iv.size), _p(d_key), _p(d_qu), _p(d_cal), C.byref(ok), C.byref(pair) if pair_words else None,
             _p(stream)))
         return bool(ok.value), bool(pair.value)
+
+    def offset_pack_pointing_onepass(self, d_g2l, n_pix_submap, pixel_index, d_pixels, weight_index, d_weights,
+                                     acc_flag_index, d_det_flags, n_flag_samp, det_flag_mask, d_shared_flags,
+                                     n_shared_flags, shared_flag_mask, proj_flag_index, d_proj_flags, n_proj_flag_samp,
+                                     proj_flag_mask, n_samp, intervals, d_key, d_qu, d_cal, d_corr, stream=0):
+        """(packable, pair_words, pair_weights) of toast_hip_offset_pack_pointing_onepass_dev: the pack, the pair words
+        and the pair weight sums in one sweep; waits for the stream."""
+        pi = self._small(pixel_index, np.int32)
+        wi = self._small(weight_index, np.int32)
+        fa = self._small(acc_flag_index if acc_flag_index is not None else np.zeros(pi.size), np.int32)
+        fp = self._small(proj_flag_index if proj_flag_index is not None else np.zeros(pi.size), np.int32)
+        iv = self._small(intervals, interval_dtype)
+        ok, pair, pw = C.c_int(0), C.c_int(0), C.c_int(0)
+        _check(real_lib().toast_hip_offset_pack_pointing_onepass_dev(
+            _p(d_g2l), _i64(n_pix_submap), _p(pi), _p(d_pixels), _p(wi), _p(d_weights), _p(fa), _p(d_det_flags),
+            _i64(n_flag_samp), _u8(det_flag_mask), _p(d_shared_flags), _i64(n_shared_flags), _u8(shared_flag_mask),
+            _p(fp), _p(d_proj_flags), _i64(n_proj_flag_samp), _u8(proj_flag_mask), _i64(pi.size), _i64(n_samp), _p(iv),
+            _i64(iv.size), _p(d_key), _p(d_qu), _p(d_cal), _p(d_corr), C.byref(ok), C.byref(pair), C.byref(pw),
+            _p(stream)))
+        return bool(ok.value), bool(pair.value), bool(pw.value)
 
     def offset_pack_pairs(self, d_key, n_det, n_samp, intervals, stream=0):
         """True when row 2b now holds one word per pair-sample (toast_hip_offset_pack_pairs_dev); waits for the stream."""

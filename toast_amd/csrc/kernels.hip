@@ -1734,7 +1734,10 @@ __global__ __launch_bounds__(kThreads) void k_offset_scan_project(
 
 // k_offset_accumulate with two consecutive samples per lane (nnz = 3): k_build_noise_weighted_v2 with the timestream
 // replaced by the amplitude of each sample's baseline (two look-ups per lane, equal except at a baseline boundary).
-template <int E>
+// SIG: the timestream is there too and the amplitude is SUBTRACTED from it -- zmap += A^T N^-1 (d - M a), the final binning
+// of the template-cleaned signal (ApplyAmplitudes + BinMap, src/toast/ops/mapmaker.py:531-608) without writing the cleaned
+// timestream: d - (0 + a) per sample, then the products of build_noise_weighted, in the reference's order.
+template <int E, bool SIG>
 __global__ __launch_bounds__(kThreads) void k_offset_accumulate_v2(
     const Chunk * __restrict__ chunks, int n_chunks, int n_det, const int64_t * __restrict__ view_first,
     const int64_t * __restrict__ view_aoff, FastDiv step_div, const int64_t * __restrict__ amp_offsets,
@@ -1744,13 +1747,14 @@ __global__ __launch_bounds__(kThreads) void k_offset_accumulate_v2(
     const int64_t * __restrict__ g2l, double * __restrict__ zmap, const int64_t * __restrict__ pixels,
     const double * __restrict__ weights, const uint8_t * __restrict__ dflags, uint8_t dmask,
     int use_dflags, const uint8_t * __restrict__ sflags, uint8_t smask, int use_sflags,
-    FastDiv nps_div, int64_t n_samp) {
+    FastDiv nps_div, int64_t n_samp, const int32_t * __restrict__ d_idx, const double * __restrict__ signal) {
     constexpr int NNZ = 3;
     const int det0 = E * blockIdx.x;
     bool on[E];
     const int64_t * prow[E];
     const double * wrow[E];
     const uint8_t * frow[E];
+    const double * srow[E];
     double ds[E];
     int64_t amp_offset[E];
 #pragma unroll
@@ -1760,6 +1764,7 @@ __global__ __launch_bounds__(kThreads) void k_offset_accumulate_v2(
         prow[e] = pixels + (int64_t)p_idx[det] * n_samp;
         wrow[e] = weights + (int64_t)w_idx[det] * n_samp * NNZ;
         frow[e] = use_dflags ? dflags + (int64_t)f_idx[det] * n_samp : nullptr;
+        srow[e] = SIG ? signal + (int64_t)d_idx[det] * n_samp : nullptr;
         ds[e] = det_scale[det];
         amp_offset[e] = amp_offsets[det];
     }
@@ -1781,13 +1786,14 @@ __global__ __launch_bounds__(kThreads) void k_offset_accumulate_v2(
             int64_t ka[E], kb[E];
             double va[E][NNZ], vb[E][NNZ];
             longlong2 pp[E];
-            double2 w0[E], w1[E], w2[E], av[E];
+            double2 w0[E], w1[E], w2[E], av[E], sg[E];
             uint16_t fd[E];
             uint8_t afa[E], afb[E];
             const uint16_t fs = use_sflags ? *reinterpret_cast<const uint16_t *>(sflags + s) : (uint16_t)0;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 pp[e] = *reinterpret_cast<const longlong2 *>(prow[e] + s);
+                if constexpr (SIG) sg[e] = *reinterpret_cast<const double2 *>(srow[e] + s);
                 fd[e] = use_dflags ? *reinterpret_cast<const uint16_t *>(frow[e] + s) : (uint16_t)0;
                 const int64_t aa = amp_offset[e] + vaoff + step_a, ab = amp_offset[e] + vaoff + step_b;
                 afa[e] = amp_flags[aa];
@@ -1815,7 +1821,11 @@ __global__ __launch_bounds__(kThreads) void k_offset_accumulate_v2(
                 ka[e] = good_a ? la[e] * nps + (pp[e].x - ga[e] * nps) : -1;
                 kb[e] = good_b ? lb[e] * nps + (pp[e].y - gb[e] * nps) : -1;
                 // tod = 0 + amplitude (unflagged amplitudes only), then * det_scale
-                const double ta = (afa[e] == 0) ? (0.0 + av[e].x) : 0.0, tb = (afb[e] == 0) ? (0.0 + av[e].y) : 0.0;
+                double ta = (afa[e] == 0) ? (0.0 + av[e].x) : 0.0, tb = (afb[e] == 0) ? (0.0 + av[e].y) : 0.0;
+                if constexpr (SIG) {
+                    ta = sg[e].x - ta;
+                    tb = sg[e].y - tb;
+                }
                 const double sa = ta * ds[e], sb = tb * ds[e];
                 va[e][0] = good_a ? sa * w0[e].x : 0.0;
                 va[e][1] = good_a ? sa * w0[e].y : 0.0;
@@ -1857,7 +1867,8 @@ __global__ __launch_bounds__(kThreads) void k_offset_accumulate_v2(
                 const int64_t key = g2l[gsm] * nps + (p - gsm * nps);
                 if (key < 0) continue;
                 const int64_t a = amp_offset[e] + vaoff + astep;
-                const double t = (amp_flags[a] == 0) ? (0.0 + amps[a]) : 0.0;
+                double t = (amp_flags[a] == 0) ? (0.0 + amps[a]) : 0.0;
+                if constexpr (SIG) t = srow[e][s] - t;
                 const double sd = t * ds[e];
                 const double * w = wrow[e] + NNZ * s;
                 double * z = zmap + NNZ * key;
@@ -2608,14 +2619,17 @@ int toast_hip_template_offset_project_signal_dev(
         d_amplitudes, d_amplitude_flags, 1, n_samp, intervals, n_view, stream);
 }
 
-int toast_hip_offset_accumulate_dev(
+namespace {
+// zmap += A^T N^-1 (M a), or -- d_signal != nullptr -- zmap += A^T N^-1 (d - M a)
+int offset_accumulate_impl(
     int64_t step_length, const int64_t * amp_offsets, const int64_t * n_amp_views,
     const double * d_amplitudes, const uint8_t * d_amplitude_flags, const int64_t * d_g2l, double * d_zmap,
     int64_t n_pix_submap, int64_t nnz, const int32_t * pixel_index, const int64_t * d_pixels,
     const int32_t * weight_index, const double * d_weights, const int32_t * flag_index,
     const uint8_t * d_det_flags, int64_t n_flag_samp, const double * det_scale, uint8_t det_flag_mask,
     int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
-    const uint8_t * d_shared_flags, int64_t n_shared_flags, uint8_t shared_flag_mask, void * stream) {
+    const uint8_t * d_shared_flags, int64_t n_shared_flags, uint8_t shared_flag_mask, const int32_t * data_index,
+    const double * d_signal, void * stream) {
     return guarded([&] {
         if (n_det <= 0) return;
         if (step_length <= 0) fail_arg("step_length must be positive");
@@ -2636,6 +2650,7 @@ int toast_hip_offset_accumulate_dev(
         const size_t o_wi = pb.push(weight_index, sizeof(int32_t) * n_det);
         const size_t o_fi = pb.push_vec(fidx);
         const size_t o_ds = pb.push(det_scale, sizeof(double) * n_det);
+        const size_t o_di = d_signal != nullptr ? pb.push(data_index, sizeof(int32_t) * n_det) : o_pi;
         const char * d = pb.commit(as_stream(stream));
         const dim3 grid = chunk_grid(n_det, chunks.size());
         hipStream_t st = as_stream(stream);
@@ -2646,15 +2661,28 @@ int toast_hip_offset_accumulate_dev(
         (const int32_t *)(d + o_fi), (const double *)(d + o_ds), d_g2l, d_zmap, d_pixels, d_weights, \
         d_det_flags, det_flag_mask, use_d, d_shared_flags, shared_flag_mask, use_s,                 \
         make_fastdiv(n_pix_submap), n_samp
+#define TH_OA_ARGS2 TH_OA_ARGS, (const int32_t *)(d + o_di), d_signal
         const bool v2 = vec2_lanes() && nnz == 3 && (n_samp & 1) == 0 && rows_16b(d_pixels) && rows_16b(d_weights) &&
                         (!use_d || rows_16b(d_det_flags)) && (!use_s || rows_16b(d_shared_flags));
-        if (v2) {
+        if (d_signal != nullptr) {
+            // the cleaned-signal form exists for the two-samples-per-lane kernel only (what cached IQU pointing gets)
+            if (!(v2 && rows_16b(d_signal))) {
+                fail_arg("offset_clean_accumulate: needs nnz = 3, an even number of samples per row and 16-byte aligned rows");
+            }
             const bool pr = pair_detectors() && n_det >= 2;
             const dim3 gp((unsigned)(pr ? (n_det + 1) / 2 : n_det), grid.y, 1);
             if (pr) {
-                hipLaunchKernelGGL((k_offset_accumulate_v2<2>), gp, dim3(kThreads), 0, st, TH_OA_ARGS);
+                hipLaunchKernelGGL((k_offset_accumulate_v2<2, true>), gp, dim3(kThreads), 0, st, TH_OA_ARGS2);
             } else {
-                hipLaunchKernelGGL((k_offset_accumulate_v2<1>), gp, dim3(kThreads), 0, st, TH_OA_ARGS);
+                hipLaunchKernelGGL((k_offset_accumulate_v2<1, true>), gp, dim3(kThreads), 0, st, TH_OA_ARGS2);
+            }
+        } else if (v2) {
+            const bool pr = pair_detectors() && n_det >= 2;
+            const dim3 gp((unsigned)(pr ? (n_det + 1) / 2 : n_det), grid.y, 1);
+            if (pr) {
+                hipLaunchKernelGGL((k_offset_accumulate_v2<2, false>), gp, dim3(kThreads), 0, st, TH_OA_ARGS2);
+            } else {
+                hipLaunchKernelGGL((k_offset_accumulate_v2<1, false>), gp, dim3(kThreads), 0, st, TH_OA_ARGS2);
             }
         } else if (pair_detectors() && n_det >= 2) {
             const dim3 gp((unsigned)((n_det + 1) / 2), grid.y, 1);
@@ -2668,9 +2696,42 @@ int toast_hip_offset_accumulate_dev(
         } else {
             hipLaunchKernelGGL((k_offset_accumulate<1, 1>), grid, dim3(kThreads), 0, st, TH_OA_ARGS);
         }
+#undef TH_OA_ARGS2
 #undef TH_OA_ARGS
         check_launch();
     });
+}
+}  // namespace
+
+int toast_hip_offset_accumulate_dev(
+    int64_t step_length, const int64_t * amp_offsets, const int64_t * n_amp_views,
+    const double * d_amplitudes, const uint8_t * d_amplitude_flags, const int64_t * d_g2l, double * d_zmap,
+    int64_t n_pix_submap, int64_t nnz, const int32_t * pixel_index, const int64_t * d_pixels,
+    const int32_t * weight_index, const double * d_weights, const int32_t * flag_index,
+    const uint8_t * d_det_flags, int64_t n_flag_samp, const double * det_scale, uint8_t det_flag_mask,
+    int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
+    const uint8_t * d_shared_flags, int64_t n_shared_flags, uint8_t shared_flag_mask, void * stream) {
+    return offset_accumulate_impl(step_length, amp_offsets, n_amp_views, d_amplitudes, d_amplitude_flags, d_g2l, d_zmap,
+                                  n_pix_submap, nnz, pixel_index, d_pixels, weight_index, d_weights, flag_index, d_det_flags,
+                                  n_flag_samp, det_scale, det_flag_mask, n_det, n_samp, intervals, n_view, d_shared_flags,
+                                  n_shared_flags, shared_flag_mask, nullptr, nullptr, stream);
+}
+
+int toast_hip_offset_clean_accumulate_dev(
+    int64_t step_length, const int64_t * amp_offsets, const int64_t * n_amp_views,
+    const double * d_amplitudes, const uint8_t * d_amplitude_flags, const int64_t * d_g2l, double * d_zmap,
+    int64_t n_pix_submap, int64_t nnz, const int32_t * pixel_index, const int64_t * d_pixels,
+    const int32_t * weight_index, const double * d_weights, const int32_t * data_index, const double * d_signal,
+    const int32_t * flag_index, const uint8_t * d_det_flags, int64_t n_flag_samp, const double * det_scale,
+    uint8_t det_flag_mask, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
+    const uint8_t * d_shared_flags, int64_t n_shared_flags, uint8_t shared_flag_mask, void * stream) {
+    if (d_signal == nullptr || data_index == nullptr) {
+        return guarded([&] { fail_arg("offset_clean_accumulate: the signal and its row indices must not be null"); });
+    }
+    return offset_accumulate_impl(step_length, amp_offsets, n_amp_views, d_amplitudes, d_amplitude_flags, d_g2l, d_zmap,
+                                  n_pix_submap, nnz, pixel_index, d_pixels, weight_index, d_weights, flag_index, d_det_flags,
+                                  n_flag_samp, det_scale, det_flag_mask, n_det, n_samp, intervals, n_view, d_shared_flags,
+                                  n_shared_flags, shared_flag_mask, data_index, d_signal, stream);
 }
 
 static int offset_scan_project_launch(

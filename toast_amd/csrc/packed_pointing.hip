@@ -165,6 +165,101 @@ __global__ __launch_bounds__(kThreads) void k_pair_weights(const Chunk * __restr
     if (marked) atomicAdd(n_marked, (unsigned long long)marked);
 }
 
+// The whole pack in ONE sweep over the cached pointing (round 6): both detectors of a pair per workgroup, the pair word
+// (k_pair_merge's format), both rows of Q / U weights and the pair weight sums (k_pair_weights' float2 or NaN marker)
+// written straight from the pixels, weights and flags -- 33 B read and 22 B written per detector-sample instead of the four
+// passes pack -> check -> merge -> weights (53 + 8 + 12 + 40 / 2 B).  status: bit 0 / 1 as k_pack_pointing (intensity weight
+// not constant along a row, offset beyond 30 bits), bit 2 as k_pair_check (the pair does not see the same pixel in some
+// sample, or the offset needs more than 28 bits): the caller then packs the old way.  Row 2b + 1 of `key` is not written.
+__global__ __launch_bounds__(kThreads) void k_pack_pairs(
+    const Chunk * __restrict__ chunks, int n_chunks, int n_det, const int32_t * __restrict__ p_idx,
+    const int32_t * __restrict__ w_idx, const int32_t * __restrict__ fa_idx, const int32_t * __restrict__ fp_idx,
+    const int64_t * __restrict__ g2l, const int64_t * __restrict__ pixels, const double * __restrict__ weights,
+    const uint8_t * __restrict__ dflags, uint8_t dmask, int use_d, const uint8_t * __restrict__ sflags, uint8_t smask,
+    int use_s, const uint8_t * __restrict__ pflags, uint8_t pmask, int use_p, FastDiv nps_div, int64_t n_samp,
+    uint32_t * __restrict__ key, double2 * __restrict__ qu, double * __restrict__ cal_out, float2 * __restrict__ corr,
+    int * __restrict__ status, unsigned long long * __restrict__ n_marked) {
+    constexpr int E = 2;
+    const int d0 = E * blockIdx.x;
+    const bool lone = d0 + 1 >= n_det;
+    const int64_t * prow[E];
+    const double * wrow[E];
+    const uint8_t * darow[E];
+    const uint8_t * dprow[E];
+    double2 * qrow[E];
+    double cal[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int det = (lone && e == 1) ? d0 : d0 + e;
+        prow[e] = pixels + (int64_t)p_idx[det] * n_samp;
+        wrow[e] = weights + (int64_t)w_idx[det] * n_samp * 3;
+        darow[e] = use_d ? dflags + (int64_t)fa_idx[det] * n_samp : nullptr;
+        dprow[e] = use_p ? pflags + (int64_t)fp_idx[det] * n_samp : nullptr;
+        qrow[e] = qu + (int64_t)det * n_samp;
+        cal[e] = wrow[e][3 * chunks[0].first];
+        if (blockIdx.y == 0 && threadIdx.x == 0 && !(lone && e == 1)) cal_out[det] = cal[e];
+    }
+    uint32_t * krow = key + (int64_t)d0 * n_samp;
+    float2 * crow = corr + (int64_t)blockIdx.x * n_samp;
+    const int64_t nps = nps_div.d;
+    auto sum_or_marker = [](double a, double b, int & marked) {
+        const double d = a + b;
+        const float f = (float)d;
+        if ((double)f == d && (double)f - a == b) return f;
+        ++marked;
+        return __builtin_nanf("");
+    };
+    int bad = 0, marked = 0;
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        for (int i = threadIdx.x; i < c.count; i += kThreads) {
+            const int64_t s = c.first + i;
+            const uint8_t fs = use_s ? sflags[s] : (uint8_t)0;
+            uint32_t k[E];
+            double w1[E], w2[E];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int64_t p = prow[e][s];
+                const double w0 = wrow[e][3 * s];
+                w1[e] = wrow[e][3 * s + 1];
+                w2[e] = wrow[e][3 * s + 2];
+                const uint8_t fd = use_d ? darow[e][s] : (uint8_t)0;
+                const uint8_t fp = use_p ? dprow[e][s] : (uint8_t)0;
+                const bool hit = p >= 0;
+                const int64_t pp = hit ? p : 0;
+                const int64_t gsm = fastdiv(pp, nps_div);
+                const int64_t lsm = g2l[gsm];
+                const bool local = hit && lsm >= 0;
+                const int64_t off = local ? lsm * nps + (pp - gsm * nps) : -1;
+                if (off + 1 > (int64_t)kPkIndex) bad |= 2;
+                if (!(w0 == cal[e])) bad |= 1;
+                k[e] = local ? (uint32_t)(off + 1) & kPkIndex : 0u;
+                if (((fd & dmask) != 0) | ((fs & smask) != 0)) k[e] |= kPkAccFlag;
+                if ((fp & pmask) != 0) k[e] |= kPkProjFlag;
+            }
+            if (lone) k[1] = (k[0] & kPkIndex) | kPkAccFlag | kPkProjFlag;
+            const uint32_t oa = k[0] & kPkIndex, ob = k[1] & kPkIndex;
+            if (oa != ob || oa > kPrIndex) bad |= 4;
+            uint32_t w = oa & kPrIndex;
+            if (k[0] & kPkAccFlag) w |= pr_acc_flag(0);
+            if (k[0] & kPkProjFlag) w |= pr_proj_flag(0);
+            if (k[1] & kPkAccFlag) w |= pr_acc_flag(1);
+            if (k[1] & kPkProjFlag) w |= pr_proj_flag(1);
+            krow[s] = w;
+            qrow[0][s] = make_double2(w1[0], w2[0]);
+            float2 f = make_float2(0.0f, 0.0f);
+            if (!lone) {
+                qrow[1][s] = make_double2(w1[1], w2[1]);
+                f.x = sum_or_marker(w1[0], w1[1], marked);
+                f.y = sum_or_marker(w2[0], w2[1], marked);
+            }
+            crow[s] = f;
+        }
+    }
+    if (bad) atomicOr(status, bad);
+    if (marked) atomicAdd(n_marked, (unsigned long long)marked);
+}
+
 // the partner's weight of one component: from the pair sum, or -- marker -- from the partner's own row
 __device__ __forceinline__ double pair_partner(float sum, double mine, const double * __restrict__ partner_row_value) {
     return (sum == sum) ? (double)sum - mine : *partner_row_value;
@@ -712,6 +807,86 @@ int toast_hip_offset_pack_pointing_dev(
         const int rc = toast_hip_offset_pack_pairs_dev(d_key, n_det, n_samp, intervals, n_view, pair_words, stream);
         if (rc != 0) throw Error(rc, toast_hip_last_error());
     });
+}
+
+// Pack, pair words and pair weight sums in ONE sweep (k_pack_pairs) when the rows come in co-pointing pairs; the outputs
+// are those of toast_hip_offset_pack_pointing_dev + toast_hip_offset_pack_pair_weights_dev, bit for bit (row 2b + 1 of
+// d_key, which the pair-word sweeps never read, is left unwritten).  Pairs that do not share their pixels, rows of an odd
+// length or d_corr == NULL: the separate passes as before (*pair_weights = 0, d_corr untouched).
+int toast_hip_offset_pack_pointing_onepass_dev(
+    const int64_t * d_g2l, int64_t n_pix_submap, const int32_t * pixel_index, const int64_t * d_pixels,
+    const int32_t * weight_index, const double * d_weights, const int32_t * acc_flag_index, const uint8_t * d_det_flags,
+    int64_t n_flag_samp, uint8_t det_flag_mask, const uint8_t * d_shared_flags, int64_t n_shared_flags,
+    uint8_t shared_flag_mask, const int32_t * proj_flag_index, const uint8_t * d_proj_flags, int64_t n_proj_flag_samp,
+    uint8_t proj_flag_mask, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
+    uint32_t * d_key, double * d_qu, double * d_cal, float * d_corr, int * packable, int * pair_words, int * pair_weights,
+    void * stream) {
+    auto separate = [&] {
+        return toast_hip_offset_pack_pointing_dev(d_g2l, n_pix_submap, pixel_index, d_pixels, weight_index, d_weights,
+                                                  acc_flag_index, d_det_flags, n_flag_samp, det_flag_mask, d_shared_flags,
+                                                  n_shared_flags, shared_flag_mask, proj_flag_index, d_proj_flags,
+                                                  n_proj_flag_samp, proj_flag_mask, n_det, n_samp, intervals, n_view, d_key,
+                                                  d_qu, d_cal, packable, pair_words, stream);
+    };
+    if (packable == nullptr || pair_words == nullptr || pair_weights == nullptr) {
+        return guarded([&] { fail_arg("offset_pack_pointing_onepass: the three result words must not be null"); });
+    }
+    *pair_weights = 0;
+    static const bool off = [] {
+        const char * e = std::getenv("TOAST_HIP_PACK_ONEPASS");
+        return e != nullptr && e[0] == '0';
+    }();
+    if (off || d_corr == nullptr || !pair_detectors() || n_det <= 0 || (n_samp & 1) != 0) return separate();
+    int status = 0;
+    const int rc = guarded([&] {
+        *packable = 0;
+        *pair_words = 0;
+        if (n_pix_submap <= 0) fail_arg("n_pix_submap must be positive");
+        need_aligned(d_qu, "packed Q / U weights");
+        need_aligned(d_key, "packed pixel words");
+        need_aligned(d_corr, "pair weight sums");
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        hipStream_t st = as_stream(stream);
+        const int use_d = (n_flag_samp == n_samp) ? 1 : 0;
+        const int use_s = (n_shared_flags == n_samp) ? 1 : 0;
+        const int use_p = (n_proj_flag_samp == n_samp) ? 1 : 0;
+        std::vector<int32_t> fa(n_det, 0), fp(n_det, 0);
+        if (use_d) std::memcpy(fa.data(), acc_flag_index, sizeof(int32_t) * n_det);
+        if (use_p) std::memcpy(fp.data(), proj_flag_index, sizeof(int32_t) * n_det);
+        ParamBlock pb;
+        const size_t o_ch = pb.push_vec(chunks);
+        const size_t o_pi = pb.push(pixel_index, sizeof(int32_t) * n_det);
+        const size_t o_wi = pb.push(weight_index, sizeof(int32_t) * n_det);
+        const size_t o_fa = pb.push_vec(fa);
+        const size_t o_fp = pb.push_vec(fp);
+        const char * d = pb.commit(st);
+        char * scratch = static_cast<char *>(Manager::get().scratch(Manager::kScratchStatus, 64));
+        TH_HIP(hipMemsetAsync(scratch, 0, 16, st));
+        const dim3 gp((unsigned)((n_det + 1) / 2), chunk_grid(n_det, chunks.size()).y, 1);
+        hipLaunchKernelGGL(k_pack_pairs, gp, dim3(kThreads), 0, st, (const Chunk *)(d + o_ch), (int)chunks.size(), (int)n_det,
+                           (const int32_t *)(d + o_pi), (const int32_t *)(d + o_wi), (const int32_t *)(d + o_fa),
+                           (const int32_t *)(d + o_fp), d_g2l, d_pixels, d_weights, d_det_flags, det_flag_mask, use_d,
+                           d_shared_flags, shared_flag_mask, use_s, d_proj_flags, proj_flag_mask, use_p,
+                           make_fastdiv(n_pix_submap), n_samp, d_key, reinterpret_cast<double2 *>(d_qu), d_cal,
+                           reinterpret_cast<float2 *>(d_corr), reinterpret_cast<int *>(scratch),
+                           reinterpret_cast<unsigned long long *>(scratch + 8));
+        check_launch();
+        unsigned long long words[2] = {0, 0};
+        copy_to_host(words, scratch, sizeof(words), st);     // (waits for the stream: once per solve)
+        status = (int)(words[0] & 0xffffffffull);
+        if (status != 0) return;
+        *packable = 1;
+        *pair_words = 1;
+        unsigned long long in_view = 0;
+        for (const Chunk & c : chunks) in_view += (unsigned long long)c.count;
+        const unsigned long long total = 2ull * in_view * (unsigned long long)(n_det / 2);
+        *pair_weights = (words[1] * 100ull > total) ? 0 : 1;      // (as toast_hip_offset_pack_pair_weights_dev)
+    });
+    if (rc != 0) return rc;
+    if ((status & 3) != 0) return 0;               // not packable at all (*packable = 0)
+    if ((status & 4) != 0) return separate();      // the pairs do not co-point: plain words, every row on its own
+    return 0;
 }
 
 // Co-pointing pairs: one word per pair-sample when every pair agrees on its pixels (see k_pair_check / k_pair_merge).

@@ -504,7 +504,15 @@ class MapMaker(Operator):
             map_binning.apply(data, detectors=detectors)
         # -- template-cleaned timestreams (:515-559)
         out_cleaned = self.det_data
-        if use_templates:
+        fused_final = use_templates and self._fused_final_binning(data, detectors, map_binning, tm, amplitudes)
+        self.fused_final_binning = bool(fused_final)
+        if fused_final:
+            # nobody asked for the cleaned timestreams: d - M a is formed inside the accumulate kernel (41 B per
+            # detector-sample instead of copy + add_to_signal + build_noise_weighted = 73 B)
+            map_binning._clean = fused_final
+            if not self.keep_solver_products:
+                self._drop_amplitudes_after = amplitudes
+        elif use_templates:
             out_cleaned = clean_name
             output = clean_name
             if self.save_cleaned and self.overwrite_cleaned:
@@ -519,11 +527,55 @@ class MapMaker(Operator):
         map_binning.det_data = out_cleaned
         map_binning.noiseweighted = nw_name if self.keep_final_products else None
         map_binning.binned = map_name
-        map_binning.apply(data, detectors=detectors)
+        try:
+            map_binning.apply(data, detectors=detectors)
+        finally:
+            map_binning._clean = None
+        if getattr(self, "_drop_amplitudes_after", None) is not None:
+            key, self._drop_amplitudes_after = self._drop_amplitudes_after, None
+            if key in data:
+                data[key].clear()
+                del data[key]
         t0 = lap("final_binning", t0)
         if use_templates and not self.save_cleaned and out_cleaned == clean_name:
             Delete(detdata=[clean_name]).apply(data)
         _unpin_for_mapmaking(data, pinned)
+
+    def _fused_final_binning(self, data, detectors, map_binning, tm, amplitudes):
+        """(template, its amplitudes) when the last two steps -- subtract the templates, bin the result -- can run as ONE
+        sweep (toast_hip_offset_clean_accumulate_dev), else None: a single Offset template, the cleaned timestreams not
+        asked for, cached IQU pointing on the device, every observation of a shape the kernel takes.
+        TOAST_HIP_FUSED_FINAL=0 keeps the two operators."""
+        from ..accel import accel_enabled
+        from ..templates import Offset
+
+        if self.save_cleaned or not accel_enabled() or _os.environ.get("TOAST_HIP_FUSED_FINAL", "1") == "0":
+            return None
+        from .. import capi
+
+        if capi.get_deterministic() or not map_binning.full_pointing or amplitudes not in data:
+            return None
+        tmpls = [t for t in tm.templates if t.enabled]
+        if len(tmpls) != 1 or not isinstance(tmpls[0], Offset):
+            return None
+        tmpl = tmpls[0]
+        pixels_op, weights_op = map_binning.pixel_pointing, map_binning.stokes_weights
+        if weights_op.mode != "IQU" or tmpl.name not in data[amplitudes]:
+            return None
+        if tmpl.use_noise_prior and pixels_op.view is not None:
+            return None          # (with a noise prior the baselines ignore the view, offset.py:135-140)
+        for iob, ob in enumerate(data.obs):
+            dets = ob.select_local_detectors(detectors, flagmask=map_binning.det_mask)
+            if len(dets) == 0:
+                continue
+            if ob.n_local_samples % 2 != 0 or not set(dets) <= set(tmpl._obs_dets.get(iob, ())):
+                return None
+            for key in (pixels_op.pixels, weights_op.weights, self.det_data):
+                if key not in ob.detdata or not set(dets) <= set(ob.detdata[key].detectors):
+                    return None
+            if ob.detdata[self.det_data].dtype != np.float64:
+                return None
+        return (tmpl, data[amplitudes][tmpl.name])
 
     @staticmethod
     def _solver_flags_device(ob, solver_flags, binning, detectors=None):

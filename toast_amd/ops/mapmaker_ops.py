@@ -351,12 +351,50 @@ class BuildNoiseWeighted(_MapBuilder):
             noise = ob[self.noise_model]
             detweights = np.array([noise.detector_weight(x) for x in dets], dtype=np.float64)
             flag_indx, flag_data, shared = self._flag_args(ob, dets, use_accel)
+            clean = getattr(self, "_clean", None)
+            if clean is not None:
+                # zmap += A^T N^-1 (d - M a) in one pass: the cleaned timestream is formed in registers
+                # (MapMaker._fused_final_binning decided that every observation qualifies)
+                self._clean_accumulate(data, ob, dets, clean, dist, zmap, detweights, flag_indx, shared)
+                continue
             native().build_noise_weighted(
                 dist.global_submap_to_local, zmap.arg(use_accel), ob.detdata[self.pixels].indices(dets),
                 ob.detdata[self.pixels].arg(use_accel), ob.detdata[self.weights].indices(dets), ob.detdata[self.weights].arg(use_accel),
                 ob.detdata[self.det_data].indices(dets), ob.detdata[self.det_data].arg(use_accel), flag_indx, flag_data,
                 detweights, self.det_flag_mask, ob.intervals[self.view].data, shared, self.shared_flag_mask,
                 use_accel)
+
+    def _clean_accumulate(self, data, ob, dets, clean, dist, zmap, detweights, flag_indx, shared):
+        """One observation of the fused final binning (toast_hip_offset_clean_accumulate_dev): everything is on the
+        device already -- the Pipeline staged this operator's inputs, the amplitudes are made resident here."""
+        from .. import capi
+        from ..accel import accel_device_ptr
+        from ..data import SharedData
+        from .mapmaker_solve import SolverLHS
+
+        tmpl, amps = clean
+        iob = data.obs.index(ob)
+        SolverLHS._resident(amps, f"{tmpl.name}_amplitudes")
+        if "_g2l_" + self.pixel_dist not in data:
+            data["_g2l_" + self.pixel_dist] = SharedData(dist.global_submap_to_local, "g2l")
+        g2l = SolverLHS._resident(data["_g2l_" + self.pixel_dist], "g2l")
+        n_samp = ob.n_local_samples
+        pd, wd, sd = ob.detdata[self.pixels], ob.detdata[self.weights], ob.detdata[self.det_data]
+        if self.det_flags is not None:
+            fd = ob.detdata[self.det_flags]
+            f_ptr, f_ns = accel_device_ptr(fd.buffer), n_samp
+        else:
+            f_ptr, f_ns = 0, 0
+        if self.shared_flags is not None:
+            s_ptr, s_n = accel_device_ptr(ob.shared[self.shared_flags].data), n_samp
+        else:
+            s_ptr, s_n = 0, 0
+        capi.dev.offset_clean_accumulate(
+            tmpl._step_length(tmpl.step_time, tmpl._obs_rate[iob]), tmpl.det_amp_offsets(iob, dets), tmpl._obs_views[iob],
+            accel_device_ptr(amps.buffer), accel_device_ptr(amps.local_flags), accel_device_ptr(g2l.data),
+            accel_device_ptr(zmap.buffer), dist.n_pix_submap, 3, pd.indices(dets), accel_device_ptr(pd.buffer),
+            wd.indices(dets), accel_device_ptr(wd.buffer), sd.indices(dets), accel_device_ptr(sd.buffer), flag_indx, f_ptr,
+            f_ns, detweights, self.det_flag_mask, n_samp, ob.intervals[self.view].data, s_ptr, s_n, self.shared_flag_mask)
 
     def _finalize(self, data, use_accel=None, **kwargs):
         if self.zmap in data:
@@ -733,6 +771,7 @@ class BinMap(Operator):
         fuse_sync = (self.noiseweighted is None and self.sync_type == "alltoallv"
                      and data.comm.comm_world is not None)
         build_zmap._defer_sync = fuse_sync
+        build_zmap._clean = getattr(self, "_clean", None)      # (MapMaker: bin det_data - M a without writing it)
         accum_ops = []
         if self.pre_process is not None:
             accum_ops.append(self.pre_process)

@@ -425,15 +425,36 @@ class SolverLHS(Operator):
             self._free_pack(dict(blocks=mine))
             return None
         key_ptr, qu_ptr, cal_ptr = (m[0] for m in mine)
-        ok, pair = capi.dev.offset_pack_pointing(
-            c["g2l_ptr"], c["nps"], ps["pi"], ps["pp"], ps["wi"], ps["wp"], ps["f_idx"], ps["f_ptr"], ps["f_ns"],
-            c["det_flag_mask"], ps["s_ptr"], ps["s_n"], c["shared_flag_mask"], ps["pf_idx"], ps["pf_ptr"], ps["pf_n"],
-            c["tmpl_flag_mask"], n_samp, ps["ivl"], key_ptr, qu_ptr, cal_ptr)
+        # the pair weight sums are written by the same sweep (toast_hip_offset_pack_pointing_onepass_dev): their block
+        # is taken first and given back when the pairs turn out not to qualify
+        corr_ptr, corr_bytes = 0, max(8 * ((n_det + 1) // 2) * n_samp, 16)
+        if os.environ.get("TOAST_HIP_PACKED_PAIR_WEIGHTS", "1") != "0" and os.environ.get("TOAST_HIP_PACK_ONEPASS", "1") != "0":
+            try:
+                corr_ptr = capi.device_malloc(corr_bytes, -2)
+            except RuntimeError:
+                corr_ptr = 0
+        tried_onepass = bool(corr_ptr)
+        if corr_ptr:
+            ok, pair, pair_weights = capi.dev.offset_pack_pointing_onepass(
+                c["g2l_ptr"], c["nps"], ps["pi"], ps["pp"], ps["wi"], ps["wp"], ps["f_idx"], ps["f_ptr"], ps["f_ns"],
+                c["det_flag_mask"], ps["s_ptr"], ps["s_n"], c["shared_flag_mask"], ps["pf_idx"], ps["pf_ptr"], ps["pf_n"],
+                c["tmpl_flag_mask"], n_samp, ps["ivl"], key_ptr, qu_ptr, cal_ptr, corr_ptr)
+            if ok and pair_weights:
+                mine.append((corr_ptr, corr_bytes))
+            else:
+                capi.device_release(corr_ptr, corr_bytes)
+                corr_ptr = 0
+        else:
+            ok, pair = capi.dev.offset_pack_pointing(
+                c["g2l_ptr"], c["nps"], ps["pi"], ps["pp"], ps["wi"], ps["wp"], ps["f_idx"], ps["f_ptr"], ps["f_ns"],
+                c["det_flag_mask"], ps["s_ptr"], ps["s_n"], c["shared_flag_mask"], ps["pf_idx"], ps["pf_ptr"], ps["pf_n"],
+                c["tmpl_flag_mask"], n_samp, ps["ivl"], key_ptr, qu_ptr, cal_ptr)
         if not ok:
             self._free_pack(dict(blocks=mine))
             return None
-        pk = dict(key=key_ptr, qu=qu_ptr, cal=cal_ptr, pair=pair, corr=0, blocks=mine)
-        self._pack_pair_weights(pk, n_det, n_samp, ps["ivl"])
+        pk = dict(key=key_ptr, qu=qu_ptr, cal=cal_ptr, pair=pair, corr=corr_ptr, blocks=mine)
+        if not tried_onepass:
+            self._pack_pair_weights(pk, n_det, n_samp, ps["ivl"])
         packed[ps["iob"]] = (ident, pk)
         return pk
 

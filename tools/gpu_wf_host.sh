@@ -7,7 +7,6 @@ mkdir -p $out
 cd /root/repo
 if [ -n "$2" ]; then python -m pytest $2 -x -q 2>&1 | tail -8 | tee $out/tests.txt; fi
 for i in 1 2 3; do python workflows/mapmaker_pcg.py > $out/plain$i.log 2>&1; grep "MapMaker (cov\|NoiseFilter  " $out/plain$i.log; done
-python tools/exp_mapmaker_wall.py 2>&1 | tail -1
 python workflows/mapmaker_pcg.py --profile > $out/cprofile.log 2>&1
 TOAST_HIP_TRACE=2 python workflows/mapmaker_pcg.py > $out/trace_stdout.log 2> $out/trace.log
 python tools/trace_timeline.py $out/trace.log > $out/timeline.txt 2>&1
