@@ -992,18 +992,18 @@ def run(args, workload, world, rank, dev, headline=True):
         pk_key = temp(torch.int32, (n_det, n_samp))
         pk_qu = temp(torch.float64, (n_det, n_samp, 2))
         pk_cal = torch.empty(n_det, dtype=torch.float64, device=dev)
+        # the whole pack in one sweep (round 6: pair words, Q / U rows and the pair weight sums -- the partner's Q / U as exact
+        # float sums, 14 instead of 18 B per det-sample, refused unless exact -- straight from pixels / weights / flags);
+        # pack_once_ms is the complete pack now (round 5: pack + pair check + merge, the sums in a fourth pass not counted)
+        pk_corr = temp(torch.float32, ((n_det + 1) // 2, n_samp, 2))
+        torch.cuda.synchronize()
         t0 = time.time()
-        packable, pair_words = D.offset_pack_pointing(
+        packable, pair_words, pair_sums = D.offset_pack_pointing_onepass(
             d_g2l.data_ptr(), nps, idx, d_pixels.data_ptr(), idx, d_weights.data_ptr(), idx, d_dflags.data_ptr(), n_samp,
             1, d_sflags.data_ptr(), n_samp, 1, idx, d_dflags.data_ptr(), n_samp, 1, n_samp, ivl, pk_key.data_ptr(),
-            pk_qu.data_ptr(), pk_cal.data_ptr(), stream=stream)
+            pk_qu.data_ptr(), pk_cal.data_ptr(), pk_corr.data_ptr(), stream=stream)
         t_pack = 1e3 * (time.time() - t0)
-        # pair weights: the partner's Q / U as exact float sums (14 instead of 18 B per det-sample); refused unless exact
-        pk_corr, corr_ptr = None, 0
-        if packable and pair_words:
-            pk_corr = temp(torch.float32, ((n_det + 1) // 2, n_samp, 2))
-            if D.offset_pack_pair_weights(pk_qu.data_ptr(), pk_corr.data_ptr(), n_det, n_samp, ivl, stream=stream):
-                corr_ptr = pk_corr.data_ptr()
+        corr_ptr = pk_corr.data_ptr() if (packable and pair_words and pair_sums) else 0
         if packable:
             use_corr = [0]
 

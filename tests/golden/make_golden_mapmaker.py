@@ -339,6 +339,9 @@ def run_case(name, solve):
            "dots": dots, "history": history, "lhs_calls": np.array(LHS.calls), "n_local_submap": np.array(n_local),
            "local_submaps": hit.astype(np.int64), "solver_hits_total": np.array(int(s_hits.sum())),
            "solver_flag_counts": np.array([int(np.count_nonzero(solver_flags & b)) for b in (1, 4)]),
+           # ... and over the samples that have a pixel (for the others the reference's ScanMask reads mask[-1, -1]: the
+           # samples are flagged through bit 1 either way)
+           "solver_flag_counts_with_pixel": np.array([int(np.count_nonzero((solver_flags & b) != 0) - np.count_nonzero(((solver_flags & b) != 0) & (pixels < 0))) for b in (1, 4)]),
            "hits_total": np.array(int(f_hits.sum())),
            "map_sums": np.array([destriped[..., k].sum() for k in range(3)] + [np.abs(destriped).sum()]),
            "binmap_sums": np.array([binmap[..., k].sum() for k in range(3)] + [np.abs(binmap).sum()]),

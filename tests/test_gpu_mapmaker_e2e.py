@@ -57,7 +57,12 @@ def _run(case, full_pointing=True, packed=True, deterministic=False, share=True,
         else:
             os.environ["TOAST_HIP_PACKED_POINTING"] = old
     dist = data["pixel_dist"]
-    out = dict(amplitudes=data["mm_solve_amplitudes"]["baselines"].local.copy(), history=np.array(mm.history),
+    ob = data.obs[0]
+    sflags, pix = ob.detdata["mm_solve_flags"].data, ob.detdata[defaults.pixels].data if defaults.pixels in ob.detdata else None
+    flag_counts = None
+    if pix is not None and pix.shape == sflags.shape:
+        flag_counts = [int(np.count_nonzero(((sflags & b) != 0) & (pix >= 0))) for b in (1, 4)]
+    out = dict(flag_counts=flag_counts, amplitudes=data["mm_solve_amplitudes"]["baselines"].local.copy(), history=np.array(mm.history),
                hits=data["mm_hits"].data.reshape(-1).copy(), map=data["mm_map"].data.reshape(-1, 3).copy(),
                binmap=data["mm_binmap"].data.reshape(-1, 3).copy(),
                noiseweighted=data["mm_noiseweighted_map"].data.reshape(-1, 3).copy(),
@@ -105,6 +110,9 @@ def test_mapmaker_deterministic_mode_equals_reference_chain(case):
     want = _fixture(case)
     got = _run(case, deterministic=True)
     _compare(got, want, 1e-12, 1e-10, f"{case} deterministic")
+    # the solver's flags -- bit 1 the binning's own cut, bit 4 the samples in poorly conditioned pixels (ScanMask of the
+    # rcond mask) -- are the reference's, sample for sample in number
+    assert got["flag_counts"] == [int(x) for x in want["solver_flag_counts_with_pixel"]], (got["flag_counts"], want["solver_flag_counts_with_pixel"])
     # the final hits / covariance / rcond were the solver's own arrays (same samples, same cut: accumulated once) ...
     assert got["shared"]
     if case == "small":

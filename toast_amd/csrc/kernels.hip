@@ -1196,6 +1196,47 @@ __global__ __launch_bounds__(kThreads) void k_scan_mask(
     }
 }
 
+// two consecutive samples per lane: one 16-byte pixel load, the two flag bytes as one 2-byte load / store, both
+// global2local look-ups and both mask bytes in flight together (rows of an even length at 16-byte aligned addresses)
+__global__ __launch_bounds__(kThreads) void k_scan_mask_v2(
+    const Chunk * __restrict__ chunks, int n_chunks, const int32_t * __restrict__ p_idx,
+    const int32_t * __restrict__ f_idx, const int64_t * __restrict__ g2l,
+    const uint8_t * __restrict__ mask, uint8_t bits, uint8_t value, const int64_t * __restrict__ pixels,
+    uint8_t * __restrict__ flags, FastDiv nps_div, int64_t n_samp) {
+    const int det = blockIdx.x;
+    const int64_t * prow = pixels + (int64_t)p_idx[det] * n_samp;
+    uint8_t * frow = flags + (int64_t)f_idx[det] * n_samp;
+    const int64_t nps = nps_div.d;
+    auto masked = [&](int64_t p) {
+        const bool hit = p >= 0;
+        const int64_t pp = hit ? p : 0;
+        const int64_t gsm = fastdiv(pp, nps_div);
+        const int64_t lsm = g2l[gsm];
+        const bool local = hit && lsm >= 0;
+        const uint8_t mk = mask[(local ? lsm : 0) * nps + (pp - gsm * nps)];
+        return local && (mk & bits);
+    };
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        const int head = (int)(c.first & 1);
+        const int64_t s0 = c.first + head;          // even
+        const int n_pair = (c.count - head) >> 1;
+        for (int j = threadIdx.x; j < n_pair; j += kThreads) {
+            const int64_t s = s0 + 2 * (int64_t)j;
+            const longlong2 p = *reinterpret_cast<const longlong2 *>(prow + s);
+            const uint16_t f = *reinterpret_cast<const uint16_t *>(frow + s);
+            const bool ma = masked(p.x), mb = masked(p.y);
+            const uint16_t g = (uint16_t)(f | (ma ? (uint16_t)value : (uint16_t)0) | (mb ? (uint16_t)((uint16_t)value << 8) : (uint16_t)0));
+            if (g != f) *reinterpret_cast<uint16_t *>(frow + s) = g;
+        }
+        const int tail = (c.count - head) & 1;
+        if ((threadIdx.x == 0 && head) || (threadIdx.x == 1 && tail)) {
+            const int64_t s = (threadIdx.x == 0) ? c.first : c.first + c.count - 1;
+            if (masked(prow[s])) frow[s] |= value;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // Solver flags: one uint8 per det-sample = detector flag | shared flag (masked), the combined
 // cut MapMaker hands to the binning and the templates while solving
@@ -1564,6 +1605,54 @@ __global__ __launch_bounds__(kThreads) void k_offset_count_flagged(
             }
             const bool tail = wave_run_reduce<1>(key, v);
             if (tail && key >= 0 && v[0] != 0.0) unsafeAtomicAdd(counts + key, v[0]);
+        }
+    }
+}
+
+// The same count with SIXTEEN flag bytes per lane (one 16-byte load; baselines of at least 16 samples, so that a lane's
+// samples lie in at most two of them): the one-byte-per-lane form spends a 64-bit reciprocal division and a segmented
+// wave reduction on every byte -- 1.6 ms for the 0.74 GB of flags of cfg-3 (round 6: 0.3 ms).
+struct __attribute__((packed, aligned(1))) FlagBytes16 {
+    uint32_t w[4];
+};
+__global__ __launch_bounds__(kThreads) void k_offset_count_flagged16(
+    const Chunk * __restrict__ chunks, int n_chunks, const int64_t * __restrict__ view_first,
+    const int64_t * __restrict__ view_aoff, FastDiv step_div, const int64_t * __restrict__ amp_offsets,
+    const int32_t * __restrict__ f_idx, double * __restrict__ counts, const uint8_t * __restrict__ flags,
+    uint8_t fmask, int64_t n_samp) {
+    const int det = blockIdx.x;
+    const uint8_t * frow = flags + (int64_t)f_idx[det] * n_samp;
+    const int64_t amp_offset = amp_offsets[det];
+    const uint32_t m4 = 0x01010101u * (uint32_t)fmask;
+    for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
+        const Chunk c = chunks[ci];
+        const int64_t vfirst = view_first[c.view];
+        const int64_t abase = amp_offset + view_aoff[c.view];
+        for (int base = 0; base < c.count; base += 16 * kThreads) {
+            const int i = base + 16 * threadIdx.x;
+            if (i >= c.count) continue;
+            const int64_t s = c.first + i;
+            const int n = (c.count - i < 16) ? (c.count - i) : 16;
+            uint32_t w[4] = {0u, 0u, 0u, 0u};
+            if (n == 16) {
+                const FlagBytes16 v = *reinterpret_cast<const FlagBytes16 *>(frow + s);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w[k] = v.w[k];
+            } else {
+                for (int k = 0; k < n; ++k) w[k >> 2] |= (uint32_t)frow[s + k] << (8 * (k & 3));
+            }
+            const int64_t st = fastdiv(s - vfirst, step_div);
+            const int64_t next = vfirst + (st + 1) * step_div.d - s;     // samples of this lane that belong to baseline st
+            const int split = next < n ? (int)next : n;
+            int lo = 0, hi = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int f = ((w[k >> 2] & m4) >> (8 * (k & 3))) & 0xff ? 1 : 0;      // (bytes past n are zero)
+                lo += (k < split) ? f : 0;
+                hi += (k < split) ? 0 : f;
+            }
+            if (lo) unsafeAtomicAdd(counts + abase + st, (double)lo);
+            if (hi) unsafeAtomicAdd(counts + abase + st + 1, (double)hi);
         }
     }
 }
@@ -3000,7 +3089,9 @@ int toast_hip_scan_mask_dev(const int64_t * d_g2l, const uint8_t * d_mask, int64
         const size_t o_pi = pb.push(pixel_index, sizeof(int32_t) * n_det);
         const size_t o_fi = pb.push(flag_index, sizeof(int32_t) * n_det);
         const char * d = pb.commit(as_stream(stream));
-        hipLaunchKernelGGL(k_scan_mask, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0,
+        const bool v2 = vec2_lanes() && (n_samp & 1) == 0 && rows_16b(d_pixels) &&
+                        (reinterpret_cast<uintptr_t>(d_det_flags) & 1) == 0;
+        hipLaunchKernelGGL(v2 ? k_scan_mask_v2 : k_scan_mask, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0,
                            as_stream(stream), (const Chunk *)(d + o_ch), (int)chunks.size(),
                            (const int32_t *)(d + o_pi), (const int32_t *)(d + o_fi), d_g2l, d_mask,
                            mask_bits, flag_value, d_pixels, d_det_flags, make_fastdiv(n_pix_submap), n_samp);
@@ -3026,7 +3117,13 @@ int toast_hip_offset_count_flagged_dev(int64_t step_length, const int64_t * amp_
         const size_t o_fi = pb.push(flag_index, sizeof(int32_t) * n_det);
         hipStream_t st = as_stream(stream);
         const char * d = pb.commit(st);
-        hipLaunchKernelGGL(k_offset_count_flagged, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0, st,
+        // (counts are whole numbers added as doubles: the order of the additions does not matter)
+        static const bool wide = [] {
+            const char * e = std::getenv("TOAST_HIP_COUNT_FLAGGED16");
+            return !(e != nullptr && e[0] == '0');
+        }();
+        auto kern = (wide && step_length >= 16) ? k_offset_count_flagged16 : k_offset_count_flagged;
+        hipLaunchKernelGGL(kern, chunk_grid(n_det, chunks.size()), dim3(kThreads), 0, st,
                            (const Chunk *)(d + o_ch), (int)chunks.size(), (const int64_t *)(d + o_vf),
                            (const int64_t *)(d + o_va), make_fastdiv(step_length), (const int64_t *)(d + o_ao),
                            (const int32_t *)(d + o_fi), d_counts, d_det_flags, flag_mask, n_samp);
