@@ -127,6 +127,12 @@ def operator_level():
         "pcg_Gsamp_s": st.get("pcg_Gsamp_s"),
         "relative_residual": st.get("relative_residual"),
         "phases_s": st.get("phases_s"),
+        #  a phase boundary is a host-side mark: the device is not waited for there, so a phase's device work
+        # is booked under whichever later phase first waits (TOAST_HIP_PHASE_SYNC=1 synchronises at the boundaries);
+        # mapmaker_s and noise_filter_s are synchronised wall times
+        "phases_s_are": "host enqueue time per phase (not synchronised)",
+        "lhs_route": st.get("lhs_route"),
+        "lhs_pack_bytes": st.get("lhs_pack_bytes"),
     }
 
 

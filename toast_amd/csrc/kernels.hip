@@ -372,6 +372,10 @@ __device__ __forceinline__ double scan_combine(bool hit, double d, double w0, do
     return hit ? r : d;
 }
 
+// (round 6, tried and taken out: the global2local look-up of a wave's 128 samples as ONE scalar load when they all lie in the
+//  same submap -- 6.19-6.23 against 6.08-6.14 ms in alternating processes, profiles/r06_b section 5: unlike the eight
+//  amplitude gathers of the packed sweeps, these two sit at the head of the dependent chain pixel -> submap -> map value,
+//  and the wave-wide agreement test adds a scalar round trip to it)
 template <typename T>
 __global__ __launch_bounds__(kThreads) void k_scan_map_v2(
     const Chunk * __restrict__ chunks, int n_chunks, const int32_t * __restrict__ d_idx,

@@ -172,6 +172,9 @@ def main(argv=None):
           f"{data['mapmaker_solve_amplitudes']['baselines'].n_global}  PCG iterations {n_it}  "
           f"relative residual {mapper.history[-1]:.3e}")
     if hasattr(mapper, "timing_log"):
+        # (host enqueue time per phase: the device is not waited for at a phase boundary unless TOAST_HIP_PHASE_SYNC=1;
+        #  "MapMaker total" and the PCG iteration's median are synchronised wall times)
+        print("phases (host side, not synchronised):")
         for k, v in mapper.timing_log.items():
             print(f"  {k:34s} {v:8.2f} s")
         it = mapper.timing_log.get("pcg_iterations", None)
