@@ -82,6 +82,31 @@ def parse():
     return ap.parse_args()
 
 
+def _map_residual_vs_reference():
+    """ops.MapMaker on the small end-to-end case (4 detectors x 60 000 samples, Nside 64, 12 PCG iterations; inputs from seeds:
+    tests/mapmaker_case.py) against the committed fixture tests/golden/mapmaker_e2e.npz -- amplitudes and destriped map
+    produced in the build container by the reference's own compiled kernels driven through the reference's own solve()
+    (tests/golden/make_golden_mapmaker.py).  max |ours - reference| / max |reference| in the default (atomic) mode: the
+    north star's "map residual < 1e-10 vs reference" on the final product, measured in this very process."""
+    try:
+        tests = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests")
+        if tests not in sys.path:
+            sys.path.insert(0, tests)
+        import test_gpu_mapmaker_e2e as e2e
+
+        got, want = e2e._run("small"), e2e._fixture("small")
+        sel = want["pix_index"]
+        rel = lambda a, b: float(np.max(np.abs(a - b)) / np.max(np.abs(b)))      # noqa: E731
+        return {
+            "map_residual_vs_reference": rel(got["map"][sel], want["map"]),
+            "amplitude_residual_vs_reference": rel(got["amplitudes"], want["amplitudes"]),
+            "residual_history_vs_reference": float(np.max(np.abs(got["history"] - want["history"]) / want["history"])),
+            "residual_case": "tests/golden/mapmaker_e2e.npz 'small' (reference kernels + reference solve()), route %s" % "/".join(got["route"]),
+        }
+    except Exception as err:   # noqa: BLE001 -- an extra of the line
+        return {"map_residual_vs_reference": None, "residual_error": repr(err)[:200]}
+
+
 def operator_level():
     """The same configuration through the operators a user calls (NoiseFilter, then MapMaker with offset templates and
     10 PCG iterations: workflows/mapmaker_pcg.py with its defaults = cfg3), timed by the workflow itself.  Not the
@@ -118,6 +143,7 @@ def operator_level():
         return st
     laps = st.pop("laps", {})
     return {
+        **_map_residual_vs_reference(),
         "workload": "cfg3 through ops.NoiseFilter + ops.MapMaker (workflows/mapmaker_pcg.py: host-resident inputs, "
                     "uploads included, 3.7 M offset amplitudes, full_pointing=True)",
         "noise_filter_s": laps.get("NoiseFilter"),

@@ -43,7 +43,11 @@ def test_bench_contract_small_workload():
     # the buffers are allocated like the operators allocate them; the FFT noise weighting is reported separately
     assert "toast_hip::Manager" in d["allocator"] and d["placement"] is None
     assert {"slabs", "slab_mallocs", "malloc_ms", "max_malloc_ms", "slab_GB", "peak_used_GB", "direct_mallocs",
-            "interleaved_slabs", "chunks", "chunks_other_zone"} <= set(d["allocator_stats"])
+            "interleaved_slabs", "chunks", "chunks_other_zone", "chunks_other_wanted", "placement_ok", "search_exhausted",
+            "probes", "probes_by_clock", "searches", "searches_capped_ms"} <= set(d["allocator_stats"])
+    # the zone search's passes are timed on the device, and the line says whether the placement worked out
+    assert d["allocator_stats"]["probes_by_clock"] == d["allocator_stats"]["probes"]
+    assert isinstance(d["allocator_stats"]["placement_ok"], bool) and d["allocator_stats"]["searches_capped_ms"] == 0
     if os.environ.get("TOAST_HIP_ALLOC", "") == "plain":        # (the switch that turns the arena off)
         assert d["allocator_stats"]["direct_mallocs"] > 0 and d["allocator_stats"]["slab_mallocs"] == 0
     else:
