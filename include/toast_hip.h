@@ -1043,6 +1043,17 @@ int toast_hip_otf_offset_accumulate_dev(
     const uint8_t * d_det_flags, int64_t n_flag_samp, const double * det_scale, uint8_t det_flag_mask,
     int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
     const uint8_t * d_shared_flags, int64_t n_shared_flags, uint8_t shared_flag_mask, void * stream);
+/* zmap += P^T N^-1 (d - M a) with on-the-fly pointing: ApplyAmplitudes(op = "subtract") + the accumulation of the final
+ * BinMap [ref: src/toast/ops/mapmaker.py:531-608] in one pass, the cleaned timestream never written (the cached-pointing
+ * form: toast_hip_offset_clean_accumulate_dev).  d = row data_index[k] of d_signal (only read). */
+int toast_hip_otf_offset_clean_accumulate_dev(
+    const toast_hip_otf_pointing * pointing, int64_t step_length, const int64_t * amp_offsets /*host*/,
+    const int64_t * n_amp_views /*host*/, const double * d_amplitudes, const uint8_t * d_amplitude_flags,
+    const int64_t * d_g2l, double * d_zmap, int64_t n_pix_submap, const int32_t * data_index /*host*/,
+    const double * d_signal, const int32_t * flag_index /*host*/, const uint8_t * d_det_flags, int64_t n_flag_samp,
+    const double * det_scale /*host*/, uint8_t det_flag_mask, int64_t n_det, int64_t n_samp,
+    const toast_hip_interval * intervals /*host*/, int64_t n_view, const uint8_t * d_shared_flags,
+    int64_t n_shared_flags, uint8_t shared_flag_mask, void * stream);
 int toast_hip_otf_offset_scan_project_dev(
     const toast_hip_otf_pointing * pointing, int64_t step_length, const int64_t * amp_offsets,
     const int64_t * n_amp_views, const double * d_amplitudes_in, double * d_amplitudes_out,

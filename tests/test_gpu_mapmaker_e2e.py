@@ -142,9 +142,12 @@ def test_mapmaker_default_routes_within_the_scatter_floor(case):
     routes["full_pointing=False"] = _run(case, full_pointing=False)
     # the last two steps (subtract the templates, bin) as one sweep -- the default with cached pointing -- and as the
     # reference's two operators
-    assert a["fused_final"] and not routes["full_pointing=False"]["fused_final"]
+    # (cached pointing: k_offset_accumulate_v2<E, true>; full_pointing=False: k_otf_accumulate<.., SIG = 2, ..>)
+    assert a["fused_final"] and routes["full_pointing=False"]["fused_final"]
     routes["two-operator final binning (TOAST_HIP_FUSED_FINAL=0)"] = _run(case, fused_final=False)
-    assert not routes["two-operator final binning (TOAST_HIP_FUSED_FINAL=0)"]["fused_final"]
+    routes["full_pointing=False, two-operator final binning"] = _run(case, full_pointing=False, fused_final=False)
+    for key in ("two-operator final binning (TOAST_HIP_FUSED_FINAL=0)", "full_pointing=False, two-operator final binning"):
+        assert not routes[key]["fused_final"]
     seen = set()
     for label, got in routes.items():
         seen.add(got["route"])

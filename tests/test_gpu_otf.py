@@ -284,6 +284,70 @@ def test_otf_offset_lhs_matches_cached(env, oracle, with_hwp):
     assert np.max(np.abs(out_k.cpu().numpy() - oo)) < 1e-13 * np.max(np.abs(oc))
 
 
+@pytest.mark.parametrize("with_hwp", [False, True])
+def test_otf_clean_accumulate_matches_subtract_then_bin(env, oracle, with_hwp):
+    """Round 6: zmap += P^T N^-1 (d - M a) with the pointing evaluated in the kernel
+    (toast_hip_otf_offset_clean_accumulate_dev, k_otf_accumulate<.., SIG = 2, ..>; also from the compact pixel cache)
+    against the steps it stands in for: the offset template added into a zeroed buffer, d - template on the device,
+    otf_build_noise_weighted of the result -- the same kernel family, so the map values agree to the rounding of the
+    atomic additions and the same pixels are touched; and against the cached-pointing form on the oracle's pointing."""
+    torch, capi = env
+    D = capi.dev
+    c = make_case(n_det=4, n_samp=6000, nside=64, with_hwp=with_hwp, n_split=3, gap=7)
+    n_samp, n_det = c["n_samp"], c["n_det"]
+    want = run_chain(oracle, c, nest=True)
+    hold = []
+    pt, sfl = _descriptor(torch, capi, c, True, False, 3, 1, hold)
+    step = 37
+    ivl = c["intervals"]
+    n_amp_views = np.array([-(-(int(v["last"]) - int(v["first"])) // step) for v in ivl], dtype=np.int64)
+    per_det = int(n_amp_views.sum())
+    amp_offsets = np.arange(n_det, dtype=np.int64) * per_det
+    rng = np.random.default_rng(6)
+    amps = rng.standard_normal(n_det * per_det)
+    aflags = (rng.random(amps.size) < 0.05).astype(np.uint8)
+    d_amps, d_afl = _dev(torch, amps), _dev(torch, aflags)
+    g2l = _dev(torch, want["g2l"])
+    dfl = _dev(torch, c["det_flags"])
+    sig = _dev(torch, c["tod"])
+    rows = c["data_index"]
+    tmpl = torch.zeros_like(sig)
+    D.offset_add_to_signal_multi(step, amp_offsets, n_amp_views, d_amps.data_ptr(), d_afl.data_ptr(), rows, tmpl.data_ptr(),
+                                 n_samp, ivl)
+    cleaned = sig - tmpl
+    z_ref = torch.zeros(want["zmap"].shape, dtype=torch.float64, device="cuda")
+    D.otf_build_noise_weighted(pt, g2l.data_ptr(), z_ref.data_ptr(), c["n_pix_submap"], rows, cleaned.data_ptr(),
+                               c["flag_index"], dfl.data_ptr(), n_samp, c["det_scale"], 1, n_samp, ivl, sfl.data_ptr(),
+                               c["shared_flags"].size, 1)
+    z = torch.zeros_like(z_ref)
+    D.otf_offset_clean_accumulate(pt, step, amp_offsets, n_amp_views, d_amps.data_ptr(), d_afl.data_ptr(), g2l.data_ptr(),
+                                  z.data_ptr(), c["n_pix_submap"], rows, sig.data_ptr(), c["flag_index"], dfl.data_ptr(),
+                                  n_samp, c["det_scale"], 1, n_samp, ivl, sfl.data_ptr(), c["shared_flags"].size, 1)
+    torch.cuda.synchronize()
+    zr, zo = z_ref.cpu().numpy(), z.cpu().numpy()
+    assert np.max(np.abs(zr)) > 0 and np.array_equal(zr != 0, zo != 0)
+    assert np.max(np.abs(zr - zo)) < 1e-12 * np.max(np.abs(zr))
+    # the cached-pointing form on the oracle's pixels / weights (weights agree to 1e-12: tolerance)
+    if n_samp % 2 == 0:
+        pix, wts = _dev(torch, want["pixels"]), _dev(torch, want["weights"])
+        z_c = torch.zeros_like(z_ref)
+        D.offset_clean_accumulate(step, amp_offsets, n_amp_views, d_amps.data_ptr(), d_afl.data_ptr(), g2l.data_ptr(),
+                                  z_c.data_ptr(), c["n_pix_submap"], 3, c["pixel_index"], pix.data_ptr(), c["weight_index"],
+                                  wts.data_ptr(), rows, sig.data_ptr(), c["flag_index"], dfl.data_ptr(), n_samp,
+                                  c["det_scale"], 1, n_samp, ivl, sfl.data_ptr(), c["shared_flags"].size, 1)
+        torch.cuda.synchronize()
+        assert np.max(np.abs(z_c.cpu().numpy() - zo)) < 1e-11 * np.max(np.abs(zr))
+    # from the compact pixel cache
+    cp = _compact(torch, capi, c, g2l, _dev(torch, want["pixels"]), want["zmap"].shape[0])
+    ptc, _ = _descriptor(torch, capi, c, True, False, 3, 1, hold, compact=cp)
+    z_k = torch.zeros_like(z_ref)
+    D.otf_offset_clean_accumulate(ptc, step, amp_offsets, n_amp_views, d_amps.data_ptr(), d_afl.data_ptr(), g2l.data_ptr(),
+                                  z_k.data_ptr(), c["n_pix_submap"], rows, sig.data_ptr(), c["flag_index"], dfl.data_ptr(),
+                                  n_samp, c["det_scale"], 1, n_samp, ivl, sfl.data_ptr(), c["shared_flags"].size, 1)
+    torch.cuda.synchronize()
+    assert np.max(np.abs(z_k.cpu().numpy() - zr)) < 1e-12 * np.max(np.abs(zr))
+
+
 def test_otf_argument_errors(env):
     torch, capi = env
     c = make_case(n_det=2, n_samp=100, nside=16)

@@ -1067,6 +1067,23 @@ class _Dev:
             _u8(det_flag_mask), _i64(ao.size), _i64(n_samp), _p(iv), _i64(iv.size), _p(d_shared_flags),
             _i64(n_shared_flags), _u8(shared_flag_mask), _p(stream)))
 
+    def otf_offset_clean_accumulate(self, pt, step_length, amp_offsets, n_amp_views, d_amplitudes, d_amplitude_flags,
+                                    d_g2l, d_zmap, n_pix_submap, data_index, d_signal, flag_index, d_det_flags,
+                                    n_flag_samp, det_scale, det_flag_mask, n_samp, intervals, d_shared_flags=0,
+                                    n_shared_flags=0, shared_flag_mask=0, stream=0):
+        """zmap += P^T N^-1 (d - M a) with on-the-fly pointing (toast_hip_otf_offset_clean_accumulate_dev)."""
+        ao = self._small(amp_offsets, np.int64)
+        nv = self._small(n_amp_views, np.int64)
+        di = self._small(data_index, np.int32)
+        fi = self._small(flag_index, np.int32)
+        ds = self._small(det_scale, np.float64)
+        iv = self._small(intervals, interval_dtype)
+        _check(lib().toast_hip_otf_offset_clean_accumulate_dev(
+            C.byref(pt), _i64(step_length), _p(ao), _p(nv), _p(d_amplitudes), _p(d_amplitude_flags), _p(d_g2l),
+            _p(d_zmap), _i64(n_pix_submap), _p(di), _p(d_signal), _p(fi), _p(d_det_flags), _i64(n_flag_samp), _p(ds),
+            _u8(det_flag_mask), _i64(ao.size), _i64(n_samp), _p(iv), _i64(iv.size), _p(d_shared_flags),
+            _i64(n_shared_flags), _u8(shared_flag_mask), _p(stream)))
+
     def otf_offset_scan_project(self, pt, step_length, amp_offsets, n_amp_views, d_amps_in, d_amps_out,
                                 d_amplitude_flags, d_g2l, d_map, n_pix_submap, flag_index, d_flag_data,
                                 n_flag_samp, flag_mask, det_weights, n_samp, intervals, stream=0):

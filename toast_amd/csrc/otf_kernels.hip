@@ -219,6 +219,7 @@ struct OffsetDev {
 // ------------------------------------------------------------------------------------
 // A^T:  zmap += P^T N^-1 d      SIG 0: d = timestream buffer (build_noise_weighted)
 //                               SIG 1: d = M a, offset amplitudes (k_offset_accumulate)
+//                               SIG 2: d = timestream - M a (ApplyAmplitudes + the final BinMap in one pass, round 6)
 // ------------------------------------------------------------------------------------
 template <bool NEST, int MODE, int SIG, int PIX, int E>
 __global__ __launch_bounds__(kThreads) void k_otf_accumulate(
@@ -246,15 +247,15 @@ __global__ __launch_bounds__(kThreads) void k_otf_accumulate(
         if (!valid[e]) det = E * blockIdx.x;
         D[e] = det_const(P, det);
         if (PIX == 1) D[e].crow = P.cpix + (int64_t)P.cpix_idx[det] * n_samp;
-        drow[e] = (SIG == 0) ? tod + (int64_t)d_idx[det] * n_samp : nullptr;
+        drow[e] = (SIG != 1) ? tod + (int64_t)d_idx[det] * n_samp : nullptr;
         frow[e] = use_dflags ? dflags + (int64_t)f_idx[det] * n_samp : nullptr;
         ds[e] = det_scale[det];
-        amp_offset[e] = (SIG == 1) ? O.amp_offsets[det] : 0;
+        amp_offset[e] = (SIG != 0) ? O.amp_offsets[det] : 0;
     }
     for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
         const Chunk c = chunks[ci];
         int64_t vfirst = 0, vaoff = 0;
-        if (SIG == 1) {
+        if (SIG != 0) {
             vfirst = O.view_first[c.view];
             vaoff = O.view_aoff[c.view];
         }
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(kThreads) void k_otf_accumulate(
             if (active) {
                 const uint8_t fs = use_sflags ? sflags[s] : (uint8_t)0;
                 int64_t astep = 0;
-                if (SIG == 1) astep = fastdiv(s - vfirst, O.step_div);
+                if (SIG != 0) astep = fastdiv(s - vfirst, O.step_div);
                 double c4h, s4h;
                 hwp_cs4<MODE>(P, s, c4h, s4h);
                 uint8_t fd[E];
@@ -288,6 +289,7 @@ __global__ __launch_bounds__(kThreads) void k_otf_accumulate(
                         const uint8_t af = O.amp_flags[a];
                         const double av = O.amps_in[a];
                         t[e] = (af == 0) ? (0.0 + av) : 0.0;
+                        if (SIG == 2) t[e] = drow[e][s] - t[e];      // d - (0 + a): the template-cleaned sample
                     }
                 }
                 double wk[E][NNZ];
@@ -815,6 +817,46 @@ int toast_hip_otf_offset_accumulate_dev(
                       d_amplitudes, nullptr, d_amplitude_flags, make_fastdiv(step_length)};
         launch_accumulate<1>(h, chunk_grid(n_det, chunks.size()), st, (const Chunk *)(d + o_ch),
                              (int)chunks.size(), (int)n_det, h.dev, off, (const int32_t *)nullptr, (const double *)nullptr,
+                             (const int32_t *)(d + o_fi), d_det_flags, det_flag_mask, use_d, d_shared_flags,
+                             shared_flag_mask, use_s, (const double *)(d + o_ds), d_zmap, n_samp);
+        check_launch();
+    });
+}
+
+int toast_hip_otf_offset_clean_accumulate_dev(
+    const toast_hip_otf_pointing * pointing, int64_t step_length, const int64_t * amp_offsets,
+    const int64_t * n_amp_views, const double * d_amplitudes, const uint8_t * d_amplitude_flags,
+    const int64_t * d_g2l, double * d_zmap, int64_t n_pix_submap, const int32_t * data_index, const double * d_signal,
+    const int32_t * flag_index, const uint8_t * d_det_flags, int64_t n_flag_samp, const double * det_scale,
+    uint8_t det_flag_mask, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
+    const uint8_t * d_shared_flags, int64_t n_shared_flags, uint8_t shared_flag_mask, void * stream) {
+    return guarded([&] {
+        if (n_det <= 0) return;
+        if (step_length <= 0) fail_arg("step_length must be positive");
+        if (d_signal == nullptr || data_index == nullptr) fail_arg("otf_offset_clean_accumulate: the signal and its row indices must not be null");
+        const auto chunks = make_chunks(intervals, n_view, n_samp);
+        if (chunks.empty()) return;
+        const OffsetViews ov = offset_views(intervals, n_amp_views, n_view);
+        ParamBlock pb;
+        OtfHost h = otf_prepare(pointing, n_det, n_samp, n_pix_submap, d_g2l, pb);
+        const int use_d = (n_flag_samp == n_samp) ? 1 : 0;
+        const int use_s = (n_shared_flags == n_samp) ? 1 : 0;
+        std::vector<int32_t> fidx(n_det, 0);
+        if (use_d) std::memcpy(fidx.data(), flag_index, sizeof(int32_t) * n_det);
+        const size_t o_ch = pb.push_vec(chunks);
+        const size_t o_vf = pb.push_vec(ov.first);
+        const size_t o_va = pb.push_vec(ov.aoff);
+        const size_t o_ao = pb.push(amp_offsets, sizeof(int64_t) * n_det);
+        const size_t o_di = pb.push(data_index, sizeof(int32_t) * n_det);
+        const size_t o_fi = pb.push_vec(fidx);
+        const size_t o_ds = pb.push(det_scale, sizeof(double) * n_det);
+        hipStream_t st = as_stream(stream);
+        const char * d = pb.commit(st);
+        otf_bind(h, d);
+        OffsetDev off{(const int64_t *)(d + o_vf), (const int64_t *)(d + o_va), (const int64_t *)(d + o_ao),
+                      d_amplitudes, nullptr, d_amplitude_flags, make_fastdiv(step_length)};
+        launch_accumulate<2>(h, chunk_grid(n_det, chunks.size()), st, (const Chunk *)(d + o_ch),
+                             (int)chunks.size(), (int)n_det, h.dev, off, (const int32_t *)(d + o_di), d_signal,
                              (const int32_t *)(d + o_fi), d_det_flags, det_flag_mask, use_d, d_shared_flags,
                              shared_flag_mask, use_s, (const double *)(d + o_ds), d_zmap, n_samp);
         check_launch();

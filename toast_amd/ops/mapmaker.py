@@ -553,14 +553,19 @@ class MapMaker(Operator):
             return None
         from .. import capi
 
-        if capi.get_deterministic() or not map_binning.full_pointing or amplitudes not in data:
+        if capi.get_deterministic() or amplitudes not in data:
             return None
+        map_binning.det_data = self.det_data           # (what the one-sweep form reads; _on_the_fly looks at its dtype)
+        # BinMap either evaluates the pointing inside the accumulate kernel (full_pointing=False, nothing cached) or runs
+        # its Pipeline [pixels, weights, accumulate] over cached / freshly expanded pointing, all detectors or group by
+        # group: both accumulate operators have the one-sweep form (k_otf_accumulate<.., SIG = 2, ..> / k_offset_accumulate_v2<E, true>)
+        cached = not ((not map_binning.full_pointing) and map_binning._on_the_fly(data, detectors, True))
         tmpls = [t for t in tm.templates if t.enabled]
         if len(tmpls) != 1 or not isinstance(tmpls[0], Offset):
             return None
         tmpl = tmpls[0]
         pixels_op, weights_op = map_binning.pixel_pointing, map_binning.stokes_weights
-        if weights_op.mode != "IQU" or tmpl.name not in data[amplitudes]:
+        if weights_op.mode not in (("IQU",) if cached else ("I", "IQU")) or tmpl.name not in data[amplitudes]:
             return None
         if tmpl.use_noise_prior and pixels_op.view is not None:
             return None          # (with a noise prior the baselines ignore the view, offset.py:135-140)
@@ -568,11 +573,12 @@ class MapMaker(Operator):
             dets = ob.select_local_detectors(detectors, flagmask=map_binning.det_mask)
             if len(dets) == 0:
                 continue
-            if ob.n_local_samples % 2 != 0 or not set(dets) <= set(tmpl._obs_dets.get(iob, ())):
+            if not set(dets) <= set(tmpl._obs_dets.get(iob, ())):
                 return None
-            for key in (pixels_op.pixels, weights_op.weights, self.det_data):
-                if key not in ob.detdata or not set(dets) <= set(ob.detdata[key].detectors):
-                    return None
+            if cached and ob.n_local_samples % 2 != 0:
+                return None      # (the two-samples-per-lane kernel)
+            if self.det_data not in ob.detdata or not set(dets) <= set(ob.detdata[self.det_data].detectors):
+                return None
             if ob.detdata[self.det_data].dtype != np.float64:
                 return None
         return (tmpl, data[amplitudes][tmpl.name])

@@ -475,6 +475,22 @@ class BuildNoiseWeightedOnTheFly(BuildNoiseWeighted):
             flag_indx, flag_data, shared = self._flag_args(ob, dets, True)
             f_ptr, f_n = (accel_device_ptr(flag_data), n_samp) if self.det_flags is not None else (0, 0)
             s_ptr, s_n = (accel_device_ptr(shared), n_samp) if self.shared_flags is not None else (0, 0)
+            clean = getattr(self, "_clean", None)
+            if clean is not None:
+                # zmap += A^T N^-1 (d - M a): the template subtraction inside the accumulate kernel (MapMaker's fused
+                # final binning, here with the pointing evaluated on the fly)
+                from .mapmaker_solve import SolverLHS
+
+                tmpl, amps = clean
+                iob = data.obs.index(ob)
+                SolverLHS._resident(amps, f"{tmpl.name}_amplitudes")
+                capi.dev.otf_offset_clean_accumulate(
+                    pt, tmpl._step_length(tmpl.step_time, tmpl._obs_rate[iob]), tmpl.det_amp_offsets(iob, dets),
+                    tmpl._obs_views[iob], accel_device_ptr(amps.buffer), accel_device_ptr(amps.local_flags),
+                    accel_device_ptr(g2l.data), accel_device_ptr(zmap.buffer), dist.n_pix_submap, dd.indices(dets),
+                    accel_device_ptr(dd.buffer), flag_indx, f_ptr, f_n, detweights, self.det_flag_mask, n_samp,
+                    ob.intervals[view].data, s_ptr, s_n, self.shared_flag_mask)
+                continue
             capi.dev.otf_build_noise_weighted(
                 pt, accel_device_ptr(g2l.data), accel_device_ptr(zmap.buffer), dist.n_pix_submap, dd.indices(dets),
                 accel_device_ptr(dd.buffer), flag_indx, f_ptr, f_n, detweights, self.det_flag_mask, n_samp,
@@ -786,6 +802,7 @@ class BinMap(Operator):
                 shared_flags=self.shared_flags, shared_flag_mask=self.shared_flag_mask, sync_type=self.sync_type,
                 compact_cache=self.compact_cache)
             otf._defer_sync = fuse_sync
+            otf._clean = getattr(self, "_clean", None)
             accum = Pipeline(detector_sets=["ALL"], operators=accum_ops + [otf])
             accum.apply(data, detectors=detectors, use_accel=True)
         else:

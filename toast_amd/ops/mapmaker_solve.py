@@ -523,8 +523,20 @@ class SolverLHS(Operator):
             return None
         (key_ptr, _), (qu_ptr, _), (cal_ptr, _) = mine
         (pix_ptr, _), (w_ptr, _), (hsub_ptr, _) = temps
-        ok = True
-        try:
+        # the pair words and the pair weight sums straight from each batch's expanded pointing (one sweep per batch,
+        # toast_hip_offset_pack_pointing_onepass_dev; batches are whole pairs) -- or, when a batch's pairs do not share their
+        # pixels, everything again the old way: plain words per batch, then pair check / merge / weights over all rows
+        corr_ptr, corr_bytes = 0, max(8 * ((n_det + 1) // 2) * n_samp, 16)
+        if (os.environ.get("TOAST_HIP_PACKED_PAIR_WEIGHTS", "1") != "0" and os.environ.get("TOAST_HIP_PACK_ONEPASS", "1") != "0"
+                and self._room_for_pack(20 * n_det * n_samp + 32 * batch * n_samp + corr_bytes)):
+            try:
+                corr_ptr = capi.device_malloc(corr_bytes, -2)
+            except RuntimeError:
+                corr_ptr = 0
+
+        def sweep(onepass):
+            """-> (ok, every batch in pair words, every batch's sums usable)"""
+            pairs, sums = True, True
             for b0 in range(0, n_det, batch):
                 bd = dets[b0:b0 + batch]
                 rows = np.arange(len(bd), dtype=np.int32)
@@ -532,22 +544,44 @@ class SolverLHS(Operator):
                 D.otf_pixels_healpix(pt, rows, pix_ptr, n_samp, ps["ivl"], hsub_ptr, n_submap, c["nps"])
                 D.otf_stokes_weights(pt, rows, w_ptr, n_samp, ps["ivl"])
                 pf_idx = None if ps["pf_idx"] is None else ps["pf_idx"][b0:b0 + batch]
-                good, _ = D.offset_pack_pointing(
-                    c["g2l_ptr"], c["nps"], rows, pix_ptr, rows, w_ptr, ps["f_idx"][b0:b0 + batch], ps["f_ptr"], ps["f_ns"],
-                    c["det_flag_mask"], ps["s_ptr"], ps["s_n"], c["shared_flag_mask"], pf_idx, ps["pf_ptr"], ps["pf_n"],
-                    c["tmpl_flag_mask"], n_samp, ps["ivl"], key_ptr + 4 * b0 * n_samp, qu_ptr + 16 * b0 * n_samp,
-                    cal_ptr + 8 * b0, pair_words=False)
+                args = (c["g2l_ptr"], c["nps"], rows, pix_ptr, rows, w_ptr, ps["f_idx"][b0:b0 + batch], ps["f_ptr"], ps["f_ns"],
+                        c["det_flag_mask"], ps["s_ptr"], ps["s_n"], c["shared_flag_mask"], pf_idx, ps["pf_ptr"], ps["pf_n"],
+                        c["tmpl_flag_mask"], n_samp, ps["ivl"], key_ptr + 4 * b0 * n_samp, qu_ptr + 16 * b0 * n_samp,
+                        cal_ptr + 8 * b0)
+                if onepass:
+                    good, pair_b, sums_b = D.offset_pack_pointing_onepass(*args, corr_ptr + 8 * (b0 // 2) * n_samp)
+                    pairs, sums = pairs and pair_b, sums and sums_b
+                    if good and not pair_b:
+                        return True, False, False
+                else:
+                    good, _ = D.offset_pack_pointing(*args, pair_words=False)
                 if not good:
-                    ok = False
-                    break
-            pair = bool(ok and D.offset_pack_pairs(key_ptr, n_det, n_samp, ps["ivl"]))
+                    return False, False, False
+            return True, pairs, sums
+
+        ok, tried_onepass = True, False
+        try:
+            pair, sums = False, False
+            if corr_ptr:
+                tried_onepass = True
+                ok, pair, sums = sweep(True)
+            if ok and not pair:
+                tried_onepass = False
+                ok, _, _ = sweep(False)
+                pair = bool(ok and D.offset_pack_pairs(key_ptr, n_det, n_samp, ps["ivl"]))
         finally:
             self._free_pack(dict(blocks=temps))
+        if corr_ptr and not (ok and tried_onepass and sums):
+            capi.device_release(corr_ptr, corr_bytes)
+            corr_ptr = 0
         if not ok:
             self._free_pack(dict(blocks=mine))
             return None
-        pk = dict(key=key_ptr, qu=qu_ptr, cal=cal_ptr, pair=pair, corr=0, blocks=mine)
-        self._pack_pair_weights(pk, n_det, n_samp, ps["ivl"])
+        if corr_ptr:
+            mine.append((corr_ptr, corr_bytes))
+        pk = dict(key=key_ptr, qu=qu_ptr, cal=cal_ptr, pair=pair, corr=corr_ptr, blocks=mine)
+        if not tried_onepass:
+            self._pack_pair_weights(pk, n_det, n_samp, ps["ivl"])
         packed[ps["iob"]] = (ident, pk)
         return pk
 
