@@ -369,6 +369,55 @@ def test_clean_accumulate_equals_subtract_then_bin(n_det, odd_views):
                                   s["n_samp"], s["detw"], 1, s["n_samp"], s["ivl"], s["d_sflags"].data_ptr(), s["n_samp"], 1)
 
 
+@pytest.mark.parametrize("step", [128, 129, 200, 1024, 1500, 5000])
+def test_wave_uniform_amplitude_lookup_equals_the_per_lane_one(step, monkeypatch):
+    """Round 6: the packed pair-word sweeps look the amplitudes of a wave's 128 samples up ONCE (two scalars per detector,
+    picked per lane by the position of the next baseline boundary) when a baseline has at least 128 samples.  Baseline
+    lengths at the limit (128), just above, around a workgroup's 1024 samples and longer than a view, three views with
+    odd first samples: the projection and the accumulation equal the per-lane look-up (TOAST_HIP_PACKED_UNIFORM_AMPS=0)
+    to the rounding of the atomic additions -- the same runs are reduced in the same lanes -- with pair sums and without."""
+    import os
+
+    if os.environ.get("TOAST_HIP_PAIR", "1") == "0":
+        pytest.skip("detector-pair kernels switched off")
+    s = _setup(n_det=6, odd_views=True, pair_cal=True)
+    torch, D = s["torch"], s["D"]
+    rng = np.random.default_rng(step)
+    nav = np.array([-(-(int(v["last"]) - int(v["first"])) // step) for v in s["ivl"]], dtype=np.int64)
+    n_amp_det = int(nav.sum())
+    ao = np.arange(s["n_det"], dtype=np.int64) * n_amp_det
+    n_amp = s["n_det"] * n_amp_det
+    d_amps = torch.from_numpy(rng.standard_normal(n_amp)).to(s["dev"])
+    d_afl = torch.from_numpy((rng.random(n_amp) < 0.2).astype(np.uint8)).to(s["dev"])
+    (ok, pair), key, qu, cal = _pack(s, pair_words=True)
+    assert ok and pair
+    corr = torch.zeros(((s["n_det"] + 1) // 2, s["n_samp"], 2), dtype=torch.float32, device=s["dev"])
+    assert D.offset_pack_pair_weights(qu.data_ptr(), corr.data_ptr(), s["n_det"], s["n_samp"], s["ivl"])
+    res = {}
+    for uni in ("1", "0"):
+        monkeypatch.setenv("TOAST_HIP_PACKED_UNIFORM_AMPS", uni)
+        for cp in (0, corr.data_ptr()):
+            zmap = torch.from_numpy(s["zmap0"]).to(s["dev"])
+            out = torch.zeros(n_amp, dtype=torch.float64, device=s["dev"])
+            z = torch.zeros((s["n_local"], s["nps"], 3), dtype=torch.float64, device=s["dev"])
+            D.offset_scan_project_packed(step, ao, nav, d_amps.data_ptr(), out.data_ptr(), d_afl.data_ptr(), zmap.data_ptr(),
+                                         key.data_ptr(), qu.data_ptr(), cal.data_ptr(), s["detw"], s["n_samp"], s["ivl"],
+                                         pair_words=True, pair_corr=cp)
+            D.offset_accumulate_packed(step, ao, nav, d_amps.data_ptr(), d_afl.data_ptr(), z.data_ptr(), key.data_ptr(),
+                                       qu.data_ptr(), cal.data_ptr(), s["detw"], s["n_samp"], s["ivl"], pair_words=True,
+                                       pair_corr=cp)
+            torch.cuda.synchronize()
+            res[(uni, bool(cp))] = (out.cpu().numpy(), z.cpu().numpy())
+    for with_sums in (False, True):
+        (o1, z1), (o0, z0) = res[("1", with_sums)], res[("0", with_sums)]
+        assert np.any(o0 != 0) and np.any(z0 != 0)
+        assert np.array_equal(o1 != 0, o0 != 0) and np.array_equal(z1 != 0, z0 != 0)
+        assert np.max(np.abs(o1 - o0)) <= 1e-13 * np.max(np.abs(o0))
+        assert np.max(np.abs(z1 - z0)) <= 1e-13 * np.max(np.abs(z0))
+        # flagged amplitudes receive nothing, in either form
+        assert not np.any(o1[d_afl.cpu().numpy() != 0])
+
+
 def z_dummy(s):
     return s["torch"].zeros((s["n_local"], s["nps"], 3), dtype=s["torch"].float64, device=s["dev"])
 
