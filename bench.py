@@ -658,6 +658,66 @@ def run(args, workload, world, rank, dev, headline=True):
 
     ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
     value = world * nsamp_tot * args.steps / elapsed
+    zone_diag = None
+    if os.environ.get("TOAST_BENCH_ZONE_DIAG", "") in ("1", "2") and not args.torch_alloc:
+        # EXPERIMENT (profiles/r06_e): which of the streams that scan_map / build_noise_weighted read share an HBM zone
+        # with the two chunk classes of the written timestream?  One read + write pass (x * 1.0: the data stays bit for
+        # bit) over a 1 GB range of a read stream and a 1 GB chunk of tod2, rows dealt alternately: TB/s (slow = same zone).
+        gb = 1 << 30
+        cls = {}
+        for k in range(int(d_tod2.numel() * 8 // gb)):
+            _, own, other = capi.arena_block_zone(d_tod2.data_ptr() + k * gb, 1)
+            name = "P" if own else ("Q" if other else None)
+            if name is not None:
+                cls.setdefault(name, d_tod2.data_ptr() + k * gb)
+        zone_diag = {"tod2_first_chunk_of_class_offsets_GB": {k: (v - d_tod2.data_ptr()) / gb for k, v in cls.items()}}
+        wb = d_weights.numel() * 8
+        ranges = {"weights@%d%%" % pct: d_weights.data_ptr() + int((wb - gb) * pct / 100) // 4096 * 4096 for pct in (0, 25, 50, 75, 100)}
+        ranges["tod@0%"] = d_tod.data_ptr()
+        ranges["tod@100%"] = d_tod.data_ptr() + (d_tod.numel() * 8 - gb) // 4096 * 4096
+        for rname, rptr in ranges.items():
+            for cname, cptr in cls.items():
+                # (the chunk may start inside tod2: 1 GB from there stays inside the block when it is not its last GB)
+                n_each = min(gb, d_tod2.data_ptr() + d_tod2.numel() * 8 - cptr) // (1 << 20) * (1 << 20)
+                t = capi.probe_stream_split([rptr, cptr], n_each)
+                zone_diag["%s vs tod2:%s" % (rname, cname)] = round(4.0 * n_each / (t * 1e-3) / 1e12, 3)
+        if len(cls) == 2:
+            n_each = min(gb, d_tod2.data_ptr() + d_tod2.numel() * 8 - max(cls.values())) // (1 << 20) * (1 << 20)
+            t = capi.probe_stream_split([cls["P"], cls["Q"]], n_each)
+            zone_diag["tod2:P vs tod2:Q"] = round(4.0 * n_each / (t * 1e-3) / 1e12, 3)
+        zb = d_zmap.numel() * 8 // (1 << 20) * (1 << 20)
+        for rname, rptr in list(ranges.items()) + list(("tod2:" + k, v) for k, v in cls.items()):
+            t = capi.probe_stream_split([rptr, d_zmap.data_ptr()], zb)
+            zone_diag["%s vs zmap" % rname] = round(4.0 * zb / (t * 1e-3) / 1e12, 3)
+        ranges["pixels@0%"] = d_pixels.data_ptr()
+        for rname in ("pixels@0%",):
+            for cname, cptr in list(cls.items()) + [("zmap", d_zmap.data_ptr())]:
+                nb = zb if cname == "zmap" else gb
+                t = capi.probe_stream_split([ranges[rname], cptr], nb)
+                zone_diag["%s vs %s" % (rname, cname if cname == "zmap" else "tod2:" + cname)] = round(4.0 * nb / (t * 1e-3) / 1e12, 3)
+        zone_diag["slabs_third_zone"] = capi.alloc_stats().get("slabs_third_zone")
+        if os.environ["TOAST_BENCH_ZONE_DIAG"] == "2":
+            # does the level of build_noise_weighted follow the place of ITS MAP?  The same launch into maps at other places
+            # of the arena (kept alive: every next one lies elsewhere): scatter blocks, streamed blocks, the read-mostly slab
+            sweep, keep = [], []
+            for kind in ("scatter", "scatter", "scatter", "scatter", "streamed", "streamed", "plain", "plain"):
+                try:
+                    z = manager_tensor(d_zmap.numel() * 8, torch.float64, tuple(d_zmap.shape), streamed=(kind == "streamed"),
+                                       scatter=(kind == "scatter"))
+                except Exception:
+                    break
+                keep.append(z)
+                z.zero_()
+                bnw_z = lambda: D.build_noise_weighted(d_g2l.data_ptr(), z.data_ptr(), nps, nnz, idx, d_pixels.data_ptr(), idx,
+                                                       d_weights.data_ptr(), idx, d_tod.data_ptr(), idx, d_dflags.data_ptr(),
+                                                       n_samp, det_scale, 1, n_samp, ivl, d_sflags.data_ptr(), n_samp, 1, stream)
+                bnw_z()
+                inside, own, other = capi.arena_block_zone(z.data_ptr(), z.numel() * 8)
+                sweep.append([kind, round(timed(bnw_z, 5), 3), "P" if own and not other else ("Q" if other and not own else "PQ"),
+                              round((z.data_ptr() - d_zmap.data_ptr()) / gb, 2)])
+            zone_diag["bnw_ms_by_map_place"] = sweep
+            for z in keep:
+                manager_release(z)
 
     # dominant kernel -> roofline entry (algorithmic bytes / measured launch duration)
     scan_bytes = BYTES_SCAN if not args.unfused else BYTES_SCAN  # noise_weight timed inside "scan" if unfused
@@ -774,6 +834,7 @@ def run(args, workload, world, rank, dev, headline=True):
         },
         "roofline": roofline,
         "kernel_ms": ms,
+        "zone_diag": zone_diag,
         "expansion": {
             "pointing_detector_Gsamp_s": nsamp_tot / t_pd / 1e6,
             "pixels_healpix_Gsamp_s": nsamp_tot / t_pix / 1e6,

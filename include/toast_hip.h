@@ -117,6 +117,8 @@ typedef struct toast_hip_arena_stats_t {
     int64_t probes_by_clock;      /* ... timed by the device's constant-rate clock inside the kernel (the rest: HIP events) */
     double create_ms_per_chunk;   /* last search: average hipMemCreate time (0.1 ms on clean memory, 20-50 while the driver clears) */
     double search_ms;             /* wall time of the searches (part of interleave_ms) */
+    int64_t slabs_third_zone;     /* slabs whose BOTH chunk classes are clear of the read-mostly slab: a written timestream there
+                                   * shares an HBM zone with none of the streams the sweeps read (csrc/vmm_slab.cpp) */
 } toast_hip_arena_stats_t;
 int toast_hip_arena_stats(toast_hip_arena_stats_t * out);
 /* Did the zone placement work out?  placement_ok = 1: an interleaved slab stands and every slot meant for the other HBM

@@ -664,3 +664,69 @@ def test_zone_search_survives_a_slow_box():
     line2, status2, f2 = run({"TOAST_HIP_ARENA_SEARCH_PROBES": "4"})
     assert status2[0] or status2[1], line2                           # too small a budget: either lucky or reported
     assert int(f2[3]) <= 4 + 2 * 12 + 4, line2                       # the budget binds once the slab's own chunks exist
+
+
+def test_written_timestreams_avoid_the_zone_of_the_read_mostly_slab():
+    """Round 6 (profiles/r06_e): when both ends of the read-mostly slab lie in ONE HBM zone, the interleaved slab takes BOTH of
+    its chunk classes from the two other zones -- a written timestream then shares a zone with none of the streams the sweeps
+    read (scan_map 6.13 instead of 6.31 ms in every process).  Checked by measurement from outside the library: one read +
+    write pass over 1 GB of either end of a read-mostly block together with a chunk of either class runs at the level of two
+    different zones, not at the level a chunk shows with itself.  ``TOAST_HIP_ARENA_THIRD_ZONE=0`` keeps the two-class slab
+    of rounds 4-5 (even slots: whatever is not clear of the read-mostly slab)."""
+    import subprocess
+    import sys
+    import textwrap
+
+    code = textwrap.dedent("""
+        from toast_amd import capi
+        capi.accel_assign_device(1, 0, 1.0, False)
+        gb = 1 << 30
+        capi.arena_reserve(40 * gb)                 # ONE read-mostly slab (TOAST_HIP_ARENA_RESERVE_GB=0: none at assign_device):
+        capi.arena_reserve(8 * gb, streamed=True)   # the chunks are measured against its first and its last GB
+        before = capi.alloc_stats()["slab_mallocs"]
+        rd = capi.device_malloc(40 * gb, -1)        # ... which are the first and the last GB of this block
+        wr = capi.device_malloc(7 * gb, -3)
+        assert capi.alloc_stats()["slab_mallocs"] == before     # (both from the slabs that exist)
+        cls = {}
+        for k in range(6):
+            inside, own, other = capi.arena_block_zone(wr + k * gb, 1)
+            assert inside
+            cls.setdefault("P" if own else "Q", wr + k * gb)
+        rate = lambda a, b, n: 4.0 * n / (min(capi.probe_stream_split([a, b], n) for _ in range(3)) * 1e-3) / 1e12
+        same = rate(cls["P"], cls["P"] + gb // 4, gb // 4)
+        same1 = rate(cls["P"], cls["P"] + gb // 4, gb // 4)
+        cross = {"%s-%s" % (rn, cn): rate(rp, cp, gb // 2) for rn, rp in (("start", rd), ("end", rd + 39 * gb + gb // 2)) for cn, cp in cls.items()}
+        cross["P-Q"] = rate(cls["P"], cls["Q"], gb // 2)
+        st = capi.alloc_stats()
+        print("THIRD", st["slabs_third_zone"], st["placement_ok"], st["search_exhausted"], round(max(same, same1), 3), cross)
+    """)
+    env = dict(os.environ)
+    for key in ("TOAST_HIP_ALLOC", "TOAST_HIP_ARENA_RESERVE_GB", "TOAST_HIP_ARENA_INTERLEAVE", "TOAST_HIP_ARENA_BUILDER",
+                "TOAST_HIP_ARENA_SEARCH_MS", "TOAST_HIP_ARENA_SEARCH_PROBES", "TOAST_HIP_PROBE_CLOCK", "TOAST_HIP_ARENA_THIRD_ZONE"):
+        env.pop(key, None)
+    env["TOAST_HIP_ARENA_STREAM_GB"] = "0"
+    env["TOAST_HIP_ARENA_RESERVE_GB"] = "0"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(extra):
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, **extra), timeout=900,
+                             cwd=root)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("THIRD")][0]
+        f = line.split(None, 5)
+        return line, int(f[1]), f[2] == "True", f[3] == "True", float(f[4]), eval(f[5])
+
+    line, third, ok, exhausted, same, cross = run({})
+    print(line)
+    assert ok or exhausted, line
+    assert third in (0, 1), line
+    if third:
+        # every pair (end of the read-mostly block, chunk class) and the two classes among themselves: different zones
+        for k, v in cross.items():
+            assert v > 1.05 * same, (k, line)
+    line0, third0, ok0, exhausted0, same0, cross0 = run({"TOAST_HIP_ARENA_THIRD_ZONE": "0"})
+    print(line0)
+    assert third0 == 0 and (ok0 or exhausted0), line0
+    # the chunks of the odd slots are clear of both ends in either form
+    if ok0:
+        assert cross0["start-Q"] > 1.05 * same0 and cross0["end-Q"] > 1.05 * same0, line0

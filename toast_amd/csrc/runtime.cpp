@@ -1304,6 +1304,7 @@ int toast_hip_arena_stats(toast_hip_arena_stats_t * out) {
         out->probes_by_clock = v.probes_by_clock;
         out->create_ms_per_chunk = v.create_ms_per_chunk;
         out->search_ms = v.search_ms;
+        out->slabs_third_zone = v.slabs_third_zone;
     });
 }
 

@@ -147,6 +147,7 @@ struct VmmSlabStats {
     int64_t searches_exhausted = 0;  // ... that ran out of a budget before both classes were full
     int64_t searches_capped_ms = 0;  // ... that hit the hard cap in ms (a subset of the exhausted ones)
     int64_t probes_by_clock = 0;     // probes timed by the device clock (the rest: HIP events)
+    int64_t slabs_third_zone = 0;    // slabs whose BOTH chunk classes are clear of the read-mostly slab (two other zones)
     double create_ms_per_chunk = 0.0;   // the last search's average hipMemCreate time per chunk (0.1: clean memory; 20-50: the
                                         // driver is still clearing what another process returned)
     double search_ms = 0.0;          // wall time of the searches (part of build_ms)

@@ -72,6 +72,7 @@ struct VmmPolicy {
     double gap = 0.035;      // two rates this far apart (relative) belong to different levels
     double search_ms = 8000.0;  // TOAST_HIP_ARENA_SEARCH_MS: hard cap on the candidate search (reported when it is hit)
     long search_probes = 320;   // TOAST_HIP_ARENA_SEARCH_PROBES: the search's budget, counted in measuring passes
+    bool third = true;          // TOAST_HIP_ARENA_THIRD_ZONE=0 turns off: both chunk classes from zones that hold NEITHER end of the read-mostly slab
     size_t spacer = size_t(8) << 30;   // TOAST_HIP_ARENA_SPACER_GB: plain block that steps over a run of useless chunks (0: none)
 };
 const VmmPolicy & policy() {
@@ -93,6 +94,7 @@ const VmmPolicy & policy() {
         if (const char * e = std::getenv("TOAST_HIP_ARENA_SEARCH_PROBES")) {
             if (std::atol(e) >= 0) v.search_probes = std::atol(e);
         }
+        if (const char * e = std::getenv("TOAST_HIP_ARENA_THIRD_ZONE")) v.third = (e[0] != '0');
         if (const char * e = std::getenv("TOAST_HIP_ARENA_SPACER_GB")) {
             if (std::atof(e) >= 0.0) v.spacer = (size_t)(std::atof(e) * 1073741824.0);
         }
@@ -120,6 +122,24 @@ double test_slow_ms() {
 }
 void test_slow(double ms) {
     if (ms > 0.0) std::this_thread::sleep_for(std::chrono::microseconds((long long)(ms * 1000.0)));
+}
+
+// threshold between "same zone" and "another zone" over a set of measured rates: the middle of the largest relative gap
+// between neighbours once that gap is wider than anything one level shows; with one level only, that level against `level`
+// (the rate of a pass over the two halves of the reference itself): 0 = all "other", 1e300 = all "same"
+double gap_threshold(std::vector<double> r, double level, double min_gap) {
+    if (r.empty()) return 1.0e300;
+    std::sort(r.begin(), r.end());
+    double best = 0.0, thr = -1.0;
+    for (size_t i = 1; i < r.size(); ++i) {
+        const double gap = (r[i] - r[i - 1]) / r[i];
+        if (gap > best && gap >= min_gap) {
+            best = gap;
+            thr = 0.5 * (r[i] + r[i - 1]);
+        }
+    }
+    if (thr > 0.0) return thr;
+    return (r[r.size() / 2] > (1.0 + 1.7 * min_gap) * level) ? 0.0 : 1.0e300;
 }
 
 bool map_chunk(char * va, size_t chunk, hipMemGenericAllocationHandle_t h, int dev) {
@@ -151,7 +171,7 @@ namespace {
 struct SearchOutcome {
     size_t want_other = 0;
     size_t probes_clock = 0;
-    bool exhausted = false, capped = false;
+    bool exhausted = false, capped = false, third = false;
     double create_ms = 0.0, search_ms = 0.0;
 };
 
@@ -178,6 +198,7 @@ void register_slab(char * base, size_t n, size_t chunk, const std::vector<hipMem
         ++g_vmm_stats.searches;
         g_vmm_stats.searches_exhausted += so.exhausted ? 1 : 0;
         g_vmm_stats.searches_capped_ms += so.capped ? 1 : 0;
+        g_vmm_stats.slabs_third_zone += so.third ? 1 : 0;
         g_vmm_stats.probes_by_clock += (int64_t)so.probes_clock;
         g_vmm_stats.create_ms_per_chunk = created > 0 ? so.create_ms / (double)created : 0.0;
         g_vmm_stats.search_ms += so.search_ms;
@@ -250,6 +271,7 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
         hipMemGenericAllocationHandle_t h;
         char * at;              // where it is mapped during the search
         double r[2];            // rate of its pass with reference 0 (the slab's last GB / chunk 0) and 1 (the first GB); < 0: not measured
+        double r2;              // rate of its pass with the ANCHOR, the first chunk that is clear of both references (third-zone split)
     };
     std::vector<Cand> cand;
     std::vector<void *> spacers;
@@ -296,6 +318,8 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
     char * ref[2] = {nullptr, nullptr};
     double level[2] = {0.0, 0.0}, thr[2] = {1.0e300, 1.0e300};
     std::vector<size_t> cls_odd, cls_even;       // candidates for the odd slots (other than every reference) and the rest
+    std::vector<size_t> grp_a, grp_b;            // third-zone split of cls_odd: same zone as the anchor / the other one
+    bool third_done = false;
     try {
         if (n_ref >= 1) {
             ref[0] = static_cast<char *>(ext.last);
@@ -304,6 +328,13 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
         }
         const auto t_search = std::chrono::steady_clock::now();
         size_t streak = 0, last_odd = 0, last_even = 0;
+        // Third-zone split (default; TOAST_HIP_ARENA_THIRD_ZONE=0 turns it off; profiles/r06_e).  When the read-mostly slab lies inside ONE zone X
+        // -- both of its ends slow against the same chunks -- the chunks that are clear of it belong to the two OTHER zones,
+        // and a written timestream whose rows are spread over THOSE two shares a zone with none of the streams the sweeps
+        // read (P = X puts half of its rows next to pixels, weights and the read timestream: scan_map 6.33 instead of 6.08 ms).
+        // The clear chunks are told apart by one more pass each against the first of them (the anchor).
+        size_t anchor = SIZE_MAX, last_a = 0, last_b = 0;
+        double level2 = 0.0;
         while (cand.size() < max_create) {
             // the budget is counted in measuring passes; wall time is a hard cap only (and reported): on a box whose memory the
             // driver is still clearing every chunk costs 20-50 ms instead of 0.1, and a search boxed into wall time gave up
@@ -344,7 +375,7 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
                 failed = true;
                 break;
             }
-            cand.push_back(Cand{h, where, {-1.0, -1.0}});
+            cand.push_back(Cand{h, where, {-1.0, -1.0}, -1.0});
             Cand & c = cand.back();
             if (n_ref == 0 && cand.size() == 1) {
                 // no read-mostly slab yet: this chunk is the reference (and of the reference's class by definition)
@@ -368,17 +399,59 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
                 const bool clear1 = n_ref < 2 || (cand[i].r[1] >= 0.0 && cand[i].r[1] > thr[1]);
                 ((clear0 && clear1) ? cls_odd : cls_even).push_back(i);
             }
-            if (cls_odd.size() >= want_odd && cls_even.size() >= want_even) {
+            bool third_open = false;
+            if (pol.third && n_ref == 2 && (long)probes < pol.search_probes / 2 && cand.size() < n + 96) {
+                // a chunk that is clear of the slab's end but not of its start: the slab straddles two zones, the chunks
+                // that are clear of both belong to ONE zone -- nothing to split
+                bool straddles = false;
+                for (const Cand & d : cand) straddles |= (d.r[0] > thr[0] && d.r[1] >= 0.0 && !(d.r[1] > thr[1]));
+                if (!straddles) {
+                    third_open = true;
+                    if (anchor == SIZE_MAX && !cls_odd.empty()) {
+                        anchor = cls_odd[0];
+                        level2 = pass(cand[anchor].at, cand[anchor].at + chunk / 2, chunk / 2);
+                    }
+                    if (anchor != SIZE_MAX) {
+                        for (size_t i : cls_odd) {
+                            if (i != anchor && cand[i].r2 < 0.0) cand[i].r2 = pass(cand[anchor].at, cand[i].at, chunk);
+                        }
+                        std::vector<double> r2;
+                        for (size_t i : cls_odd) {
+                            if (i != anchor && cand[i].r2 >= 0.0) r2.push_back(cand[i].r2);
+                        }
+                        const double thr2 = gap_threshold(r2, level2, pol.gap);
+                        grp_a.assign(1, anchor);
+                        grp_b.clear();
+                        for (size_t i : cls_odd) {
+                            if (i == anchor || cand[i].r2 < 0.0) continue;
+                            (cand[i].r2 > thr2 ? grp_b : grp_a).push_back(i);
+                        }
+                        if ((grp_a.size() >= want_even && grp_b.size() >= want_odd) ||
+                            (grp_b.size() >= want_even && grp_a.size() >= want_odd)) {
+                            third_done = true;
+                            full = true;
+                            break;
+                        }
+                    }
+                }
+            }
+            if (!third_open && cls_odd.size() >= want_odd && cls_even.size() >= want_even) {
                 full = true;
                 break;
             }
             // did this chunk add to a class that is still short?
-            const bool useful = (cls_odd.size() > last_odd && last_odd < want_odd) ||
-                                (cls_even.size() > last_even && last_even < want_even);
+            bool useful = (cls_odd.size() > last_odd && last_odd < want_odd) ||
+                          (cls_even.size() > last_even && last_even < want_even);
+            if (third_open) {
+                useful = (grp_a.size() > last_a) || (grp_b.size() > last_b) || cls_odd.size() > last_odd;
+                last_a = grp_a.size();
+                last_b = grp_b.size();
+            }
             streak = useful ? 0 : streak + 1;
             last_odd = cls_odd.size();
             last_even = cls_even.size();
         }
+        if (!full) full = cls_odd.size() >= want_odd && cls_even.size() >= want_even;   // (the third-zone attempt ran out: the two-class slab)
         so.search_ms = ms_since(t_search);
     } catch (const Error &) {
         failed = true;       // a failed launch or event: nothing may leak
@@ -397,9 +470,22 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
     // does -- the LAST created first: the driver tends to hand out one zone after the other, so a late chunk is the most
     // likely to differ from the early ones.
     std::vector<size_t> odd, even;
-    const size_t take_o = std::min(cls_odd.size(), want_odd), take_e = std::min(cls_even.size(), want_even);
-    odd.assign(cls_odd.begin(), cls_odd.begin() + (long)take_o);
-    even.assign(cls_even.begin(), cls_even.begin() + (long)take_e);
+    size_t take_o = std::min(cls_odd.size(), want_odd), take_e = std::min(cls_even.size(), want_even);
+    if (third_done) {
+        // both classes from zones that hold neither end of the read-mostly slab (the larger group serves the even slots)
+        const bool a_even = grp_a.size() >= want_even && grp_b.size() >= want_odd;
+        const std::vector<size_t> & ge = a_even ? grp_a : grp_b;
+        const std::vector<size_t> & go = a_even ? grp_b : grp_a;
+        even.assign(ge.begin(), ge.begin() + (long)want_even);
+        odd.assign(go.begin(), go.begin() + (long)want_odd);
+        take_o = want_odd;
+        take_e = want_even;
+        cls_even = ge;       // (nothing is topped up below: both lists are full)
+        cls_odd = go;
+    } else {
+        odd.assign(cls_odd.begin(), cls_odd.begin() + (long)take_o);
+        even.assign(cls_even.begin(), cls_even.begin() + (long)take_e);
+    }
     if (odd.size() < want_odd) {
         // not enough chunks clear of both ends (the search ran out of time): second best for the scatter targets is the
         // zone of the slab's END -- the arrays that feed the A^T scatter are created first and sit at its start
@@ -461,8 +547,11 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
                          thr[0] < 1.0e299 ? thr[0] / 1.0e9 : 0.0, thr[1] < 1.0e299 ? thr[1] / 1.0e9 : 0.0, spacers.size(), pol.spacer >> 30, line.c_str());
         }
     }
+    so.third = third_done;
     register_slab(base, n, chunk, slot, take_o, created, probes, level[0], t_start,
-                  n_ref == 2 ? "against both ends of the read-mostly slab" : (n_ref == 1 ? "against the read-mostly slab" : "against its first chunk"),
+                  third_done ? "both classes clear of the read-mostly slab: two other zones"
+                             : (n_ref == 2 ? "against both ends of the read-mostly slab"
+                                           : (n_ref == 1 ? "against the read-mostly slab" : "against its first chunk")),
                   n_ref, so);
     return base;
 }
