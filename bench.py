@@ -1019,6 +1019,39 @@ def run(args, workload, world, rank, dev, headline=True):
     # sequence (8 + 41 + 8 + 48 + 9 B per det-sample, five passes) and fused (33 + 33 B, two passes).
     # The complete left-hand side with one Offset template on the same buffers (operator sequence, fused sweeps, fused
     # sweeps from the packed pointing cache): part of every run; the on-the-fly / compact variants only with --pcg-extra.
+    if not args.no_lhs and nnz == 3 and not args.torch_alloc:
+        # the two set-up sweeps of a destriping run that read the same pixels / weights / flags -- solver covariance + hits,
+        # then the right-hand side's A^T N^-1 d -- apart and as ONE sweep (toast_hip_build_cov_hits_signal_dev)
+        d_invcov = manager_tensor(n_local * nps * 6 * 8, torch.float64, (n_local, nps, 6), scatter=True)
+        d_hits = manager_tensor(n_local * nps * 8, torch.int64, (n_local, nps, 1), scatter=True)
+        cov_args = lambda: (nps, nnz, idx, d_pixels.data_ptr(), idx, d_weights.data_ptr(), idx, d_tod.data_ptr(), idx,    # noqa: E731
+                            d_dflags.data_ptr(), n_samp, det_scale, det_scale, 1, n_samp, ivl, d_sflags.data_ptr(), n_samp, 1,
+                            stream)
+        fused_flag = [False]
+
+        def cov_only():
+            d_invcov.zero_(); d_hits.zero_()
+            D.build_cov_hits_signal(d_g2l.data_ptr(), d_invcov.data_ptr(), d_hits.data_ptr(), 0, *cov_args())
+
+        def cov_and_signal():
+            d_invcov.zero_(); d_hits.zero_(); d_zmap.zero_()
+            fused_flag[0] = D.build_cov_hits_signal(d_g2l.data_ptr(), d_invcov.data_ptr(), d_hits.data_ptr(),
+                                                    d_zmap.data_ptr(), *cov_args())
+
+        cov_only()
+        ref_cov = d_invcov.clone()
+        cov_and_signal()
+        out["mapmaker_setup_sweeps"] = {
+            "cov_hits_ms": timed(cov_only, 3), "signal_map_ms": ms["bnw"], "cov_hits_signal_ms": timed(cov_and_signal, 3),
+            "one_kernel": bool(fused_flag[0]),
+            "cov_max_rel_diff": float((d_invcov - ref_cov).abs().max() / ref_cov.abs().max()),
+            "note": "inverse covariance + hits (33 B per det-sample) and the right-hand side's noise-weighted map (41 B) as "
+                    "two sweeps and as one (42 B)",
+        }
+        del ref_cov
+        manager_release(d_invcov)
+        manager_release(d_hits)
+        del d_invcov, d_hits
     if args.pcg_extra or not args.no_lhs:
         step_len = int(rate)  # 1 s baselines
         nav = np.array([(int(v["last"]) - int(v["first"]) + step_len - 1) // step_len for v in ivl], dtype=np.int64)

@@ -513,6 +513,22 @@ int toast_hip_build_cov_hits_dev(
     const int32_t * flag_index, const uint8_t * d_det_flags, int64_t n_flag_samp, const double * det_scale,
     uint8_t det_flag_mask, int64_t n_det, int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view,
     const uint8_t * d_shared_flags, int64_t n_shared_flags, uint8_t shared_flag_mask, void * stream);
+/* ... and the noise-weighted map of a timestream, zmap += A^T N^-1 d (toast_hip_build_noise_weighted_dev with `data_scale`
+ * as its det_scale), from the SAME sweep: what SolveAmplitudes runs back to back over the same pixels, weights and flags --
+ * CovarianceAndHits, then the right-hand side's BuildNoiseWeighted (src/toast/ops/mapmaker.py:846-900, 941-1000;
+ * mapmaker_utils.py:927-1271, ops_mapmaker_utils.cpp:93-111).  Values are formed in the operation order of the separate
+ * kernels; 42 instead of 33 + 41 bytes per detector-sample.  *fused = 1 when one kernel did all three (IQU, detector pairs,
+ * two samples per lane: 16-byte rows, even n_samp), 0 when the call fell back to the separate sweeps (same results).
+ * The flags the right-hand side would see in the reference's order -- the solver flags WITH the condition-number cut that is
+ * only known after this pass -- differ from the ones seen here exactly in samples of pixels whose inverse covariance is
+ * zeroed by the cut: the binned map cov x zmap is zero there either way. */
+int toast_hip_build_cov_hits_signal_dev(
+    const int64_t * d_g2l, double * d_invcov, int64_t * d_hits, double * d_zmap, int64_t n_pix_submap, int64_t nnz,
+    const int32_t * pixel_index, const int64_t * d_pixels, const int32_t * weight_index, const double * d_weights,
+    const int32_t * data_index, const double * d_det_data, const int32_t * flag_index, const uint8_t * d_det_flags,
+    int64_t n_flag_samp, const double * det_scale, const double * data_scale, uint8_t det_flag_mask, int64_t n_det,
+    int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view, const uint8_t * d_shared_flags,
+    int64_t n_shared_flags, uint8_t shared_flag_mask, int * fused, void * stream);
 /* Host-array level of the same call (arrays resolved like toast_hip_build_cov: registered device copies with use_accel,
  * staged temporaries otherwise). */
 int toast_hip_build_cov_hits(const int64_t * global2local, int64_t n_submap, double * invcov, int64_t * hits,

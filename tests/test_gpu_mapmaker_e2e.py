@@ -26,7 +26,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 FIXTURE = os.path.join(HERE, "golden", "mapmaker_e2e.npz")
 
 
-def _run(case, full_pointing=True, packed=True, deterministic=False, share=True, fused_final=True):
+def _run(case, full_pointing=True, packed=True, deterministic=False, share=True, fused_final=True, cov_rhs=True):
     from toast_amd import capi, ops
     from toast_amd.data import defaults
     from toast_amd.templates import Offset
@@ -36,6 +36,7 @@ def _run(case, full_pointing=True, packed=True, deterministic=False, share=True,
     os.environ["TOAST_HIP_PACKED_POINTING"] = "1" if packed else "0"
     os.environ["TOAST_HIP_SHARE_SOLVER_COV"] = "1" if share else "0"
     os.environ["TOAST_HIP_FUSED_FINAL"] = "1" if fused_final else "0"
+    os.environ["TOAST_HIP_FUSED_COV_RHS"] = "1" if cov_rhs else "0"
     was = capi.get_deterministic()
     capi.set_deterministic(deterministic)
     try:
@@ -52,6 +53,7 @@ def _run(case, full_pointing=True, packed=True, deterministic=False, share=True,
         capi.set_deterministic(was)
         os.environ.pop("TOAST_HIP_SHARE_SOLVER_COV", None)
         os.environ.pop("TOAST_HIP_FUSED_FINAL", None)
+        os.environ.pop("TOAST_HIP_FUSED_COV_RHS", None)
         if old is None:
             os.environ.pop("TOAST_HIP_PACKED_POINTING", None)
         else:
@@ -68,7 +70,8 @@ def _run(case, full_pointing=True, packed=True, deterministic=False, share=True,
                noiseweighted=data["mm_noiseweighted_map"].data.reshape(-1, 3).copy(),
                cov=data["mm_cov"].data.reshape(-1, 6).copy(), local_submaps=np.array(dist.local_submaps),
                route=tuple(getattr(mm, "lhs_route", ())), shared=bool(getattr(mm, "shared_solver_covariance", False)),
-               fused_final=bool(getattr(mm, "fused_final_binning", False)))
+               fused_final=bool(getattr(mm, "fused_final_binning", False)),
+               rhs_with_cov=getattr(mm, "rhs_map_with_covariance", None))
     return out
 
 
@@ -115,6 +118,9 @@ def test_mapmaker_deterministic_mode_equals_reference_chain(case):
     assert got["flag_counts"] == [int(x) for x in want["solver_flag_counts_with_pixel"]], (got["flag_counts"], want["solver_flag_counts_with_pixel"])
     # the final hits / covariance / rcond were the solver's own arrays (same samples, same cut: accumulated once) ...
     assert got["shared"]
+    # the right-hand side's noise-weighted map was asked of the covariance pass; in this mode the library runs the separate
+    # order-exact sweeps behind that call (False per observation) -- and the results are the ones of the reference's order
+    assert got["rhs_with_cov"] == (False,), got["rhs_with_cov"]
     if case == "small":
         # ... and accumulating them a second time, as the reference does, gives the same products bit for bit
         twice = _run(case, deterministic=True, share=False)
@@ -144,6 +150,11 @@ def test_mapmaker_default_routes_within_the_scatter_floor(case):
     # reference's two operators
     # (cached pointing: k_offset_accumulate_v2<E, true>; full_pointing=False: k_otf_accumulate<.., SIG = 2, ..>)
     assert a["fused_final"] and routes["full_pointing=False"]["fused_final"]
+    # the right-hand side's A^T N^-1 d in the covariance pass's sweep (the default with cached pointing:
+    # k_build_cov_pair_v2<true, true>) and as the reference's separate operator; on the fly the right-hand side bins itself
+    assert a["rhs_with_cov"] == (True,) and routes["full_pointing=False"]["rhs_with_cov"] is None
+    routes["right-hand side binned on its own (TOAST_HIP_FUSED_COV_RHS=0)"] = _run(case, cov_rhs=False)
+    assert routes["right-hand side binned on its own (TOAST_HIP_FUSED_COV_RHS=0)"]["rhs_with_cov"] is None
     routes["two-operator final binning (TOAST_HIP_FUSED_FINAL=0)"] = _run(case, fused_final=False)
     routes["full_pointing=False, two-operator final binning"] = _run(case, full_pointing=False, fused_final=False)
     for key in ("two-operator final binning (TOAST_HIP_FUSED_FINAL=0)", "full_pointing=False, two-operator final binning"):

@@ -565,3 +565,50 @@ def test_no_packed_cache_without_room(monkeypatch):
     mapper.apply(data)
     assert seen.get("offset_pack_pointing", 0) == 0 and seen.get("offset_accumulate_packed", 0) == 0, seen
     assert seen.get("offset_accumulate", 0) >= 1 and len(mapper.history) == 5
+
+
+@pytest.mark.parametrize("n_det,odd_views,n_samp", [(6, True, 6000), (5, True, 6000), (6, False, 6000), (4, True, 5999)])
+def test_covariance_hits_and_signal_map_in_one_sweep(n_det, odd_views, n_samp):
+    """Round 6: toast_hip_build_cov_hits_signal_dev -- inverse covariance, hits and zmap += A^T N^-1 d from ONE sweep over the
+    pointing (k_build_cov_pair_v2<true, true>) -- against the calls it stands in for on the SAME device arrays: the
+    inverse covariance + hits call (the same entry without a map) and build_noise_weighted with the signal's own row
+    selection and scale.  Hits exactly, covariance and map to the rounding of the atomic additions, the same set of touched
+    pixels; everything accumulates onto what is there; an odd row length (no 16-byte rows) falls back to the separate
+    sweeps behind the same call and says so."""
+    s = _setup(n_det=n_det, odd_views=odd_views, n_samp=n_samp, pair_cal=True)
+    torch, D = s["torch"], s["D"]
+    gen = torch.Generator(device=s["dev"])
+    gen.manual_seed(11)
+    sig = torch.empty((n_det, s["n_samp"]), dtype=torch.float64, device=s["dev"]).normal_(0.0, 1.0, generator=gen)
+    perm = np.roll(np.arange(n_det, dtype=np.int32), 1)
+    sig_scale = 0.25 + np.arange(n_det) * 0.125                     # (not the covariance's scale: both are honoured)
+    shape = (s["n_local"], s["nps"])
+    zeros = lambda k, dt=torch.float64: torch.zeros(shape + (k,), dtype=dt, device=s["dev"])       # noqa: E731
+    common = lambda: (s["nps"], 3, s["idx"], s["d_pix"].data_ptr(), s["idx"], s["d_w"].data_ptr(), perm, sig.data_ptr(),    # noqa: E731
+                      s["idx"], s["d_dflags"].data_ptr(), s["n_samp"], s["detw"], sig_scale, 1, s["n_samp"], s["ivl"],
+                      s["d_sflags"].data_ptr(), s["n_samp"], 1)
+    cov_ref, hits_ref, z_ref = zeros(6), zeros(1, torch.int64), zeros(3)
+    assert D.build_cov_hits_signal(s["d_g2l"].data_ptr(), cov_ref.data_ptr(), hits_ref.data_ptr(), 0, *common()) is False
+    D.build_noise_weighted(s["d_g2l"].data_ptr(), z_ref.data_ptr(), s["nps"], 3, s["idx"], s["d_pix"].data_ptr(), s["idx"],
+                           s["d_w"].data_ptr(), perm, sig.data_ptr(), s["idx"], s["d_dflags"].data_ptr(), s["n_samp"],
+                           sig_scale, 1, s["n_samp"], s["ivl"], s["d_sflags"].data_ptr(), s["n_samp"], 1)
+    cov, hits, z = zeros(6) + 0.25, zeros(1, torch.int64) + 5, zeros(3) - 1.5
+    fused = D.build_cov_hits_signal(s["d_g2l"].data_ptr(), cov.data_ptr(), hits.data_ptr(), z.data_ptr(), *common())
+    torch.cuda.synchronize()
+    import os
+
+    expect_fused = (n_samp % 2 == 0) and n_det >= 2 and os.environ.get("TOAST_HIP_PAIR", "1") != "0" \
+        and os.environ.get("TOAST_HIP_VEC2", "1") != "0" and not capi_deterministic()
+    assert fused == expect_fused
+    cov, hits, z = cov.cpu().numpy() - 0.25, hits.cpu().numpy() - 5, z.cpu().numpy() + 1.5
+    cov_ref, hits_ref, z_ref = cov_ref.cpu().numpy(), hits_ref.cpu().numpy(), z_ref.cpu().numpy()
+    assert hits_ref.sum() > 0 and np.array_equal(hits, hits_ref)
+    np.testing.assert_allclose(cov, cov_ref, rtol=0, atol=1e-12 * max(np.max(np.abs(cov_ref)), 0.25))
+    np.testing.assert_allclose(z, z_ref, rtol=0, atol=1e-12 * max(np.max(np.abs(z_ref)), 1.5))
+    assert np.array_equal(np.abs(z) > 1e-9, np.abs(z_ref) > 1e-9) and np.any(z_ref != 0)
+
+
+def capi_deterministic():
+    from toast_amd import capi
+
+    return bool(capi.get_deterministic())

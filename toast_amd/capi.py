@@ -788,6 +788,27 @@ class _Dev:
             _u8(det_flag_mask), _i64(pi.size), _i64(n_samp), _p(iv), _i64(iv.size), _p(d_shared_flags),
             _i64(n_shared_flags), _u8(shared_flag_mask), _p(stream)))
 
+    def build_cov_hits_signal(self, d_g2l, d_invcov, d_hits, d_zmap, n_pix_submap, nnz, pixel_index, d_pixels,
+                              weight_index, d_weights, data_index, d_det_data, flag_index, d_det_flags, n_flag_samp,
+                              det_scale, data_scale, det_flag_mask, n_samp, intervals, d_shared_flags, n_shared_flags,
+                              shared_flag_mask, stream=0):
+        """Inverse covariance, hits and zmap += A^T N^-1 d in one sweep (toast_hip_build_cov_hits_signal_dev).  Returns True
+        when one kernel did all three, False when the library ran the separate sweeps (same results)."""
+        pi = self._small(pixel_index, np.int32)
+        wi = self._small(weight_index, np.int32)
+        di = self._small(data_index, np.int32)
+        fi = self._small(flag_index, np.int32)
+        ds = self._small(det_scale, np.float64)
+        ss = self._small(data_scale, np.float64)
+        iv = self._small(intervals, interval_dtype)
+        fused = C.c_int(0)
+        _check(lib().toast_hip_build_cov_hits_signal_dev(
+            _p(d_g2l), _p(d_invcov), _p(d_hits), _p(d_zmap), _i64(n_pix_submap), _i64(nnz), _p(pi), _p(d_pixels), _p(wi),
+            _p(d_weights), _p(di), _p(d_det_data), _p(fi), _p(d_det_flags), _i64(n_flag_samp), _p(ds), _p(ss),
+            _u8(det_flag_mask), _i64(pi.size), _i64(n_samp), _p(iv), _i64(iv.size), _p(d_shared_flags),
+            _i64(n_shared_flags), _u8(shared_flag_mask), C.byref(fused), _p(stream)))
+        return bool(fused.value)
+
     def noise_weight(self, d_det_data, n_samp, data_index, intervals, detector_weights, stream=0):
         di = self._small(data_index, np.int32)
         iv = self._small(intervals, interval_dtype)

@@ -916,19 +916,29 @@ __global__ __launch_bounds__(kThreads) void k_build_cov_pair(
 // the six packed products and the hit count is what the kernel spends its vector issue on (counters, round 5:
 // k_build_cov_pair<3, true> 251 vector instructions per detector-sample, 74 % of the issue cycles, 3.8 TB/s).
 // The hit count rides along as value NC and leaves as one integer atomic per run.
-template <int NV, int NC, bool HITS>
+// SIG: three more values ride along -- the noise-weighted signal of the sample, (tod x scale) x w, as k_build_noise_weighted_v2
+// forms it -- and leave as atomics into a second map (k_build_cov_pair_v2<HITS, true>: inverse covariance, hits and the
+// right-hand side's A^T N^-1 d in ONE sweep over the pointing).
+template <int NV, int NC, bool HITS, bool SIG>
 __device__ __forceinline__ void cov_emit(int64_t key, const double (&v)[NV], double * __restrict__ invcov,
-                                         long long * __restrict__ hits) {
+                                         long long * __restrict__ hits, double * __restrict__ zmap) {
     double * z = invcov + NC * key;
 #pragma unroll
     for (int k = 0; k < NC; ++k) unsafeAtomicAdd(z + k, v[k]);
     if constexpr (HITS) atomicAdd((unsigned long long *)(hits + key), (unsigned long long)__double2ll_rn(v[NC]));
+    if constexpr (SIG) {
+        constexpr int ZO = NC + (HITS ? 1 : 0);
+        double * m = zmap + 3 * key;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) unsafeAtomicAdd(m + k, v[ZO + k]);
+    }
 }
 
 // scatter_runs2 (kernel_common.hpp) for the covariance values: A before B in every lane
-template <int NV, int NC, bool HITS>
+template <int NV, int NC, bool HITS, bool SIG>
 __device__ __forceinline__ void cov_scatter_runs2(int64_t ka, double (&va)[NV], int64_t kb, double (&vb)[NV],
-                                                  double * __restrict__ invcov, long long * __restrict__ hits) {
+                                                  double * __restrict__ invcov, long long * __restrict__ hits,
+                                                  double * __restrict__ zmap) {
     const int lane = threadIdx.x & 63;
     const bool same = ka == kb;
     const bool apart = !same & (ka >= 0);
@@ -941,13 +951,13 @@ __device__ __forceinline__ void cov_scatter_runs2(int64_t ka, double (&va)[NV], 
         const bool give = apart & (lane > 0) & (prev_b == ka);
 #pragma unroll
         for (int k = 0; k < NV; ++k) vb[k] += dpp_f64<kDppWaveShl1>(give ? va[k] : 0.0);
-        if (apart & !give) cov_emit<NV, NC, HITS>(ka, va, invcov, hits);
+        if (apart & !give) cov_emit<NV, NC, HITS, SIG>(ka, va, invcov, hits, zmap);
     }
     const bool tail = wave_run_reduce<NV>(kb, vb);
-    if (tail && kb >= 0) cov_emit<NV, NC, HITS>(kb, vb, invcov, hits);
+    if (tail && kb >= 0) cov_emit<NV, NC, HITS, SIG>(kb, vb, invcov, hits, zmap);
 }
 
-template <bool HITS>
+template <bool HITS, bool SIG = false>
 __global__ __launch_bounds__(kThreads) void k_build_cov_pair_v2(
     const Chunk * __restrict__ chunks, int n_chunks, int n_det, const int32_t * __restrict__ p_idx,
     const int32_t * __restrict__ w_idx, const int32_t * __restrict__ f_idx,
@@ -955,14 +965,17 @@ __global__ __launch_bounds__(kThreads) void k_build_cov_pair_v2(
     double * __restrict__ invcov, const int64_t * __restrict__ pixels,
     const double * __restrict__ weights, const uint8_t * __restrict__ dflags, uint8_t dmask,
     int use_dflags, const uint8_t * __restrict__ sflags, uint8_t smask, int use_sflags,
-    FastDiv nps_div, int64_t n_samp, long long * __restrict__ hits) {
-    constexpr int NNZ = 3, NC = 6, NV = NC + (HITS ? 1 : 0), E = 2;
+    FastDiv nps_div, int64_t n_samp, long long * __restrict__ hits,
+    const int32_t * __restrict__ d_idx = nullptr, const double * __restrict__ tod = nullptr,
+    const double * __restrict__ sig_scale = nullptr, double * __restrict__ zmap = nullptr) {
+    constexpr int NNZ = 3, NC = 6, ZO = NC + (HITS ? 1 : 0), NV = ZO + (SIG ? 3 : 0), E = 2;
     const int det0 = E * blockIdx.x;
     bool on[E];
     const int64_t * prow[E];
     const double * wrow[E];
+    const double * drow[E];
     const uint8_t * frow[E];
-    double ds[E];
+    double ds[E], ss[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         on[e] = det0 + e < n_det;
@@ -971,12 +984,15 @@ __global__ __launch_bounds__(kThreads) void k_build_cov_pair_v2(
         wrow[e] = weights + (int64_t)w_idx[det] * n_samp * NNZ;
         frow[e] = use_dflags ? dflags + (int64_t)f_idx[det] * n_samp : nullptr;
         ds[e] = det_scale[det];
+        drow[e] = SIG ? tod + (int64_t)d_idx[det] * n_samp : nullptr;
+        ss[e] = SIG ? sig_scale[det] : 0.0;
     }
     const int64_t nps = nps_div.d;
     const uint16_t dmask2 = (uint16_t)(dmask | (dmask << 8));
     const uint16_t smask2 = (uint16_t)(smask | (smask << 8));
-    // packed upper triangle of (scale w) w^T, the operation order of k_build_cov_pair
-    auto products = [](double (&v)[NV], double wa, double wb, double wc, double scale, bool good) {
+    // packed upper triangle of (scale w) w^T, the operation order of k_build_cov_pair; the signal values in the operation
+    // order of k_build_noise_weighted_v2 ((tod x scale) x w)
+    auto products = [](double (&v)[NV], double wa, double wb, double wc, double scale, bool good, double t, double tscale) {
         const double sa = wa * scale, sb = wb * scale, sc = wc * scale;
         v[0] = good ? wa * sa : 0.0;
         v[1] = good ? wb * sa : 0.0;
@@ -985,6 +1001,12 @@ __global__ __launch_bounds__(kThreads) void k_build_cov_pair_v2(
         v[4] = good ? wc * sb : 0.0;
         v[5] = good ? wc * sc : 0.0;
         if constexpr (HITS) v[NC] = good ? 1.0 : 0.0;
+        if constexpr (SIG) {
+            const double st = t * tscale;
+            v[ZO + 0] = good ? st * wa : 0.0;
+            v[ZO + 1] = good ? st * wb : 0.0;
+            v[ZO + 2] = good ? st * wc : 0.0;
+        }
     };
     for (int ci = blockIdx.y; ci < n_chunks; ci += gridDim.y) {
         const Chunk c = chunks[ci];
@@ -997,13 +1019,15 @@ __global__ __launch_bounds__(kThreads) void k_build_cov_pair_v2(
             const int64_t s = s0 + 2 * (int64_t)(active ? j : 0);
             // all streaming loads of both samples of both detectors first (inactive lanes re-read pair 0: same lines)
             longlong2 pp[E];
-            double2 w0[E], w1[E], w2[E];
+            double2 w0[E], w1[E], w2[E], tt[E];
             uint16_t fd[E];
             const uint16_t fs = use_sflags ? *reinterpret_cast<const uint16_t *>(sflags + s) : (uint16_t)0;
 #pragma unroll
             for (int e = 0; e < E; ++e) {
                 pp[e] = *reinterpret_cast<const longlong2 *>(prow[e] + s);
                 fd[e] = use_dflags ? *reinterpret_cast<const uint16_t *>(frow[e] + s) : (uint16_t)0;
+                if constexpr (SIG) tt[e] = *reinterpret_cast<const double2 *>(drow[e] + s);
+                else tt[e] = make_double2(0.0, 0.0);
                 const double2 * wv = reinterpret_cast<const double2 *>(wrow[e] + NNZ * s);
                 w0[e] = wv[0];
                 w1[e] = wv[1];
@@ -1026,8 +1050,8 @@ __global__ __launch_bounds__(kThreads) void k_build_cov_pair_v2(
                 const bool good_b = active & on[e] & (pp[e].y >= 0) & (lb[e] >= 0) & ((bad & 0xff00) == 0);
                 ka[e] = good_a ? la[e] * nps + (pp[e].x - ga[e] * nps) : -1;
                 kb[e] = good_b ? lb[e] * nps + (pp[e].y - gb[e] * nps) : -1;
-                products(va[e], w0[e].x, w0[e].y, w1[e].x, ds[e], good_a);
-                products(vb[e], w1[e].y, w2[e].x, w2[e].y, ds[e], good_b);
+                products(va[e], w0[e].x, w0[e].y, w1[e].x, ds[e], good_a, tt[e].x, ss[e]);
+                products(vb[e], w1[e].y, w2[e].x, w2[e].y, ds[e], good_b, tt[e].y, ss[e]);
             }
             const bool mergeable = ((ka[0] == ka[1]) | (ka[0] < 0) | (ka[1] < 0)) &
                                    ((kb[0] == kb[1]) | (kb[0] < 0) | (kb[1] < 0));
@@ -1040,11 +1064,11 @@ __global__ __launch_bounds__(kThreads) void k_build_cov_pair_v2(
                     vam[k] = va[0][k] + va[1][k];
                     vbm[k] = vb[0][k] + vb[1][k];
                 }
-                cov_scatter_runs2<NV, NC, HITS>(kam, vam, kbm, vbm, invcov, hits);
+                cov_scatter_runs2<NV, NC, HITS, SIG>(kam, vam, kbm, vbm, invcov, hits, zmap);
                 continue;
             }
 #pragma unroll
-            for (int e = 0; e < E; ++e) cov_scatter_runs2<NV, NC, HITS>(ka[e], va[e], kb[e], vb[e], invcov, hits);
+            for (int e = 0; e < E; ++e) cov_scatter_runs2<NV, NC, HITS, SIG>(ka[e], va[e], kb[e], vb[e], invcov, hits, zmap);
         }
         // the peeled first sample (lane 0) and the odd last one (lane 1)
         const int tail = (c.count - head) & 1;
@@ -1061,8 +1085,8 @@ __global__ __launch_bounds__(kThreads) void k_build_cov_pair_v2(
                 if (key < 0) continue;
                 const double * w = wrow[e] + NNZ * s;
                 double v[NV];
-                products(v, w[0], w[1], w[2], ds[e], true);
-                cov_emit<NV, NC, HITS>(key, v, invcov, hits);
+                products(v, w[0], w[1], w[2], ds[e], true, SIG ? drow[e][s] : 0.0, ss[e]);
+                cov_emit<NV, NC, HITS, SIG>(key, v, invcov, hits, zmap);
             }
         }
     }
@@ -2939,8 +2963,17 @@ int toast_hip_template_offset_apply_diag_precond_dev(const double * d_offset_var
     });
 }
 
+// the noise-weighted signal that may ride along with the inverse covariance (toast_hip_build_cov_hits_signal_dev)
+struct CovSignal {
+    const int32_t * index;      // host: row of every detector in d_signal
+    const double * d_signal;    // [rows, n_samp]
+    const double * scale;       // host: per detector (build_noise_weighted's det_scale)
+    double * d_zmap;            // [n_local_pix, 3]
+};
+
 // d_hits != nullptr (mode 1 only): the hit map is accumulated by the same kernel when the pair-merged kernel applies;
-// *hits_done tells the caller whether it was.
+// *hits_done tells the caller whether it was.  sig != nullptr: the same for A^T N^-1 d into sig->d_zmap (two samples per
+// lane, hits in the same launch), *signal_done.
 static int build_cov_launch(
     int mode /*0 hits, 1 inverse covariance*/, const int64_t * d_g2l, void * d_out, int64_t n_pix_submap,
     int64_t nnz, const int32_t * pixel_index, const int64_t * d_pixels, const int32_t * weight_index,
@@ -2948,8 +2981,9 @@ static int build_cov_launch(
     int64_t n_flag_samp, const double * det_scale, uint8_t det_flag_mask, int64_t n_det, int64_t n_samp,
     const toast_hip_interval * intervals, int64_t n_view, const uint8_t * d_shared_flags,
     int64_t n_shared_flags, uint8_t shared_flag_mask, void * stream, int64_t * d_hits_in, bool * hits_done,
-    const char * fn = __builtin_FUNCTION()) {
+    const CovSignal * sig = nullptr, bool * signal_done = nullptr, const char * fn = __builtin_FUNCTION()) {
     if (hits_done != nullptr) *hits_done = false;
+    if (signal_done != nullptr) *signal_done = false;
     return guarded([&] {
         int64_t * d_hits = d_hits_in;
         if (!(mode == 1 && nnz == 3 && pair_detectors() && n_det >= 2 && !deterministic_mode())) d_hits = nullptr;
@@ -2981,6 +3015,8 @@ static int build_cov_launch(
         const size_t o_wi = pb.push_vec(widx);
         const size_t o_fi = pb.push_vec(fidx);
         const size_t o_ds = pb.push_vec(dscale);
+        const size_t o_di = (sig != nullptr && mode == 1) ? pb.push(sig->index, sizeof(int32_t) * n_det) : 0;
+        const size_t o_ss = (sig != nullptr && mode == 1) ? pb.push(sig->scale, sizeof(double) * n_det) : 0;
         const char * d = pb.commit(as_stream(stream));
         const FastDiv dv = make_fastdiv(n_pix_submap);
         const dim3 grid = chunk_grid(n_det, chunks.size());
@@ -2997,13 +3033,23 @@ static int build_cov_launch(
             // two samples per lane when every row starts on a 16-byte boundary (TOAST_HIP_VEC2=0: one sample per lane)
             const bool v2 = vec2_lanes() && (n_samp & 1) == 0 && rows_16b(d_pixels) && rows_16b(d_weights) &&
                             (!use_d || rows_16b(d_det_flags)) && (!use_s || rows_16b(d_shared_flags));
-            if (v2) {
+            if (v2 && d_hits != nullptr && sig != nullptr && rows_16b(sig->d_signal)) {
+                const char * d2 = d;
+                hipLaunchKernelGGL((k_build_cov_pair_v2<true, true>), gp, dim3(kThreads), 0, st,
+                                   (const Chunk *)(d2 + o_ch), (int)chunks.size(), (int)n_det, (const int32_t *)(d2 + o_pi),
+                                   (const int32_t *)(d2 + o_wi), (const int32_t *)(d2 + o_fi), (const double *)(d2 + o_ds),
+                                   d_g2l, (double *)d_out, d_pixels, d_weights, d_det_flags, det_flag_mask, use_d,
+                                   d_shared_flags, shared_flag_mask, use_s, dv, n_samp, (long long *)d_hits,
+                                   (const int32_t *)(d2 + o_di), sig->d_signal, (const double *)(d2 + o_ss), sig->d_zmap);
+                if (signal_done != nullptr) *signal_done = true;
+            } else if (v2) {
                 hipLaunchKernelGGL(d_hits != nullptr ? k_build_cov_pair_v2<true> : k_build_cov_pair_v2<false>, gp,
                                    dim3(kThreads), 0, st, (const Chunk *)(d + o_ch), (int)chunks.size(), (int)n_det,
                                    (const int32_t *)(d + o_pi), (const int32_t *)(d + o_wi), (const int32_t *)(d + o_fi),
                                    (const double *)(d + o_ds), d_g2l, (double *)d_out, d_pixels, d_weights, d_det_flags,
                                    det_flag_mask, use_d, d_shared_flags, shared_flag_mask, use_s, dv, n_samp,
-                                   (long long *)d_hits);
+                                   (long long *)d_hits, (const int32_t *)nullptr, (const double *)nullptr,
+                                   (const double *)nullptr, (double *)nullptr);
             } else if (d_hits != nullptr) {
                 hipLaunchKernelGGL((k_build_cov_pair<3, true>), gp, dim3(kThreads), 0, st, (const Chunk *)(d + o_ch),
                                    (int)chunks.size(), (int)n_det, (const int32_t *)(d + o_pi),
@@ -3058,6 +3104,36 @@ int toast_hip_build_cov_hits_dev(
     return build_cov_launch(0, d_g2l, d_hits, n_pix_submap, nnz, pixel_index, d_pixels, weight_index, d_weights,
                             flag_index, d_det_flags, n_flag_samp, det_scale, det_flag_mask, n_det, n_samp, intervals,
                             n_view, d_shared_flags, n_shared_flags, shared_flag_mask, stream, nullptr, nullptr);
+}
+
+int toast_hip_build_cov_hits_signal_dev(
+    const int64_t * d_g2l, double * d_invcov, int64_t * d_hits, double * d_zmap, int64_t n_pix_submap, int64_t nnz,
+    const int32_t * pixel_index, const int64_t * d_pixels, const int32_t * weight_index, const double * d_weights,
+    const int32_t * data_index, const double * d_det_data, const int32_t * flag_index, const uint8_t * d_det_flags,
+    int64_t n_flag_samp, const double * det_scale, const double * data_scale, uint8_t det_flag_mask, int64_t n_det,
+    int64_t n_samp, const toast_hip_interval * intervals, int64_t n_view, const uint8_t * d_shared_flags,
+    int64_t n_shared_flags, uint8_t shared_flag_mask, int * fused, void * stream) {
+    if (fused != nullptr) *fused = 0;
+    const CovSignal sig{data_index, d_det_data, data_scale, d_zmap};
+    bool hits_done = false, signal_done = false;
+    int rc = build_cov_launch(1, d_g2l, d_invcov, n_pix_submap, nnz, pixel_index, d_pixels, weight_index, d_weights,
+                              flag_index, d_det_flags, n_flag_samp, det_scale, det_flag_mask, n_det, n_samp, intervals,
+                              n_view, d_shared_flags, n_shared_flags, shared_flag_mask, stream, d_hits, &hits_done,
+                              (d_zmap != nullptr && d_det_data != nullptr) ? &sig : nullptr, &signal_done);
+    if (rc != TOAST_HIP_OK || n_det <= 0) return rc;
+    if (!hits_done) {
+        rc = build_cov_launch(0, d_g2l, d_hits, n_pix_submap, nnz, pixel_index, d_pixels, weight_index, d_weights,
+                              flag_index, d_det_flags, n_flag_samp, det_scale, det_flag_mask, n_det, n_samp, intervals,
+                              n_view, d_shared_flags, n_shared_flags, shared_flag_mask, stream, nullptr, nullptr);
+        if (rc != TOAST_HIP_OK) return rc;
+    }
+    if (fused != nullptr) *fused = signal_done ? 1 : 0;
+    if (signal_done || d_zmap == nullptr || d_det_data == nullptr) return rc;
+    // no fused kernel for this call: the map of the signal in its own sweep
+    return toast_hip_build_noise_weighted_dev(d_g2l, d_zmap, n_pix_submap, nnz, pixel_index, d_pixels, weight_index, d_weights,
+                                              data_index, d_det_data, flag_index, d_det_flags, n_flag_samp, data_scale,
+                                              det_flag_mask, n_det, n_samp, intervals, n_view, d_shared_flags,
+                                              n_shared_flags, shared_flag_mask, stream);
 }
 
 int toast_hip_cov_eigendecompose_diag_dev(int64_t n_sub, int64_t subsize, int64_t nnz, double * d_data,

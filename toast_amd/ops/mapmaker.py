@@ -193,6 +193,8 @@ class SolveAmplitudes(Operator):
             Delete(detdata=[pixels.pixels, weights.weights, pixels.detector_pointing.quats, nm["flags"]]).apply(data)
         # Cached pointing is written once and read by every later phase: keep it on the device
         pinned = _pin_for_mapmaking(data, binning)
+        rhs_map_ready = False
+        self.rhs_map_with_covariance = None
         if self.mc_mode:
             # re-use the flags and the covariance of an earlier realisation (:702-712, :852-864)
             for ob in data.obs:
@@ -219,7 +221,15 @@ class SolveAmplitudes(Operator):
                 scanner.det_flags_value, scanner.mask_key = 2, self.mask
                 scan_pipe.apply(data, detectors=detectors)
             # -- solver covariance, hits, condition numbers (:846-900)
-            CovarianceAndHits(
+            # The right-hand side's first step, A^T N^-1 d (:941-1000), reads the same pixels, weights and flags: with
+            # cached pointing on the accelerator it rides along with the covariance (one sweep of 42 B per
+            # detector-sample instead of 33 + 41; TOAST_HIP_FUSED_COV_RHS=0 keeps the two apart).  The right-hand side
+            # would see the solver flags WITH the condition-number cut, which is only known after this pass: the two
+            # differ in samples of pixels whose covariance the cut zeroes -- the binned map is zero there either way.
+            rhs_rides = self._rhs_map_rides_along(data, binning, detectors)
+            if rhs_rides and nm["bin"] in data:
+                del data[nm["bin"]]
+            cah = CovarianceAndHits(
                 pixel_dist=binning.pixel_dist, covariance=nm["cov"], hits=nm["hits"], rcond=nm["rcond"],
                 det_mask=binning.det_mask, det_flags=nm["flags"], det_flag_mask=255, shared_flags=None,
                 pixel_pointing=pixels, stokes_weights=weights, noise_model=binning.noise_model,
@@ -227,7 +237,13 @@ class SolveAmplitudes(Operator):
                 # (MapMaker asks for the inverse covariance too when the final binning's products are going to be these
                 #  very arrays: _share_with_final below)
                 inverse_covariance=getattr(self, "_share_invcov", None),
-                save_pointing=binning.full_pointing, det_data_units=binning.det_data_units).apply(data, detectors=detectors)
+                signal=self.det_data if rhs_rides else None, signal_map=nm["bin"] if rhs_rides else None,
+                save_pointing=binning.full_pointing, det_data_units=binning.det_data_units)
+            cah.apply(data, detectors=detectors)
+            rhs_map_ready = bool(rhs_rides and cah.signal_in_one_sweep is not None and nm["bin"] in data)
+            # how the right-hand side's map was accumulated: None = by the right-hand side itself; a tuple = with the
+            # covariance, per observation True when one kernel did it, False when the library ran the separate sweeps
+            self.rhs_map_with_covariance = cah.signal_in_one_sweep if rhs_map_ready else None
             t0 = lap("covariance_and_hits", t0)
             # -- samples in poorly conditioned pixels must not constrain the templates (:902-939)
             data[nm["rcond_mask"]] = PixelData(data[binning.pixel_dist], np.uint8, n_value=1)
@@ -255,8 +271,11 @@ class SolveAmplitudes(Operator):
             tm.amplitudes = nm["rhs"]
             if nm["rhs"] in data:
                 del data[nm["rhs"]]
+            if not self.mc_mode and rhs_map_ready:
+                binning._zmap_is_accumulated = True      # (BinMap consumes the mark in its next call)
             SolverRHS(name=f"{self.name}_rhs", det_data=self.det_data, binning=binning,
                       template_matrix=tm, fused=self.fused_lhs).apply(data, detectors=detectors)
+            binning.__dict__.pop("_zmap_is_accumulated", None)
             t0 = lap("rhs", t0)
             # -- PCG (:1002-1060)
             lhs = SolverLHS(name=f"{self.name}_lhs", binning=binning, template_matrix=tm, fused=self.fused_lhs)
@@ -288,6 +307,30 @@ class SolveAmplitudes(Operator):
                     del data[key]
             Delete(detdata=[nm["flags"]]).apply(data)
         _unpin_for_mapmaking(data, pinned)
+
+    def _rhs_map_rides_along(self, data, binning, detectors):
+        """May the covariance pass accumulate the right-hand side's noise-weighted map as well?  Cached pointing on the
+        accelerator, float64 timestreams of the same detectors, nothing between the timestream and the binning, nobody
+        who wants the noise-weighted map itself (it differs in the pixels the condition-number cut removes)."""
+        from ..accel import accel_enabled
+
+        if _os.environ.get("TOAST_HIP_FUSED_COV_RHS", "1") == "0" or self.mc_mode:
+            return False
+        if not (accel_enabled() and getattr(data, "lazy_host", False) and binning.full_pointing):
+            return False
+        if binning.pre_process is not None or binning.noiseweighted is not None or self.det_data is None:
+            return False
+        if not (binning.stokes_weights.supports_accel() and binning.pixel_pointing.supports_accel()):
+            return False
+        for ob in data.obs:
+            dets = ob.select_local_detectors(detectors, flagmask=binning.det_mask)
+            if len(dets) == 0:
+                continue
+            if self.det_data not in ob.detdata or ob.detdata[self.det_data].dtype != np.float64:
+                return False
+            if not set(dets) <= set(ob.detdata[self.det_data].detectors):
+                return False
+        return True
 
     @staticmethod
     def _solver_flags_host(ob, solver_flags, binning, detectors=None):
@@ -459,6 +502,7 @@ class MapMaker(Operator):
             amplitudes = solver.amplitudes
             self.history, self.iteration_seconds = solver.history, solver.iteration_seconds
             self.lhs_route = getattr(solver, "lhs_route", ())
+            self.rhs_map_with_covariance = getattr(solver, "rhs_map_with_covariance", None)
             self.lhs_pack_bytes = getattr(solver, "lhs_pack_bytes", ())
             self.timing_log.update(solver.timing_log)
             t0 = _time.time()

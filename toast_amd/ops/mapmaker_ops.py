@@ -562,6 +562,13 @@ class BuildInverseCovariance(_MapBuilder):
     det_data_units = Unicode(defaults.det_data_units, allow_none=True, help="Desired timestream units")
     hits = Unicode(None, allow_none=True, help="Also accumulate the hit map under this Data key in the same pass over "
                    "the pointing (not a reference trait: CovarianceAndHits uses it instead of a separate BuildHitMap)")
+    signal = Unicode(None, allow_none=True, help="With hits on the accelerator: also accumulate the noise-weighted map "
+                     "A^T N^-1 d of this detdata key in the same pass (not a reference trait: SolveAmplitudes' covariance "
+                     "pass and the right-hand side's BuildNoiseWeighted read the same pixels, weights and flags)")
+    signal_map = Unicode(None, allow_none=True, help="The Data key of that noise-weighted map")
+
+    def _signal_rides_along(self, use_accel):
+        return bool(use_accel and self.hits is not None and self.signal is not None and self.signal_map is not None)
 
     def _exec(self, data, detectors=None, use_accel=None, **kwargs):
         implementation, use_accel = self.select_kernels(use_accel=use_accel)
@@ -586,6 +593,15 @@ class BuildInverseCovariance(_MapBuilder):
             invcov = data[self.inverse_covariance]
         _global_to(invcov, self.inverse_covariance, use_accel,
                    zero_new=not invcov.accel_exists() and invcov.host_is_zero())
+        zmap = None
+        if self._signal_rides_along(use_accel):
+            if self.signal_map not in data:
+                data[self.signal_map] = PixelData(dist, np.float64, n_value=self._weight_nnz(data, detectors))
+            zmap = data[self.signal_map]
+            if zmap.distribution != dist:
+                raise RuntimeError("Existing map '{}' has different data distribution".format(self.signal_map))
+            _global_to(zmap, self.signal_map, True, zero_new=not zmap.accel_exists() and zmap.host_is_zero())
+        self.signal_in_one_sweep = []
         for ob in data.obs:
             dets = ob.select_local_detectors(selection=detectors, flagmask=self.det_mask)
             if self.noise_model not in ob:
@@ -595,6 +611,10 @@ class BuildInverseCovariance(_MapBuilder):
             noise = ob[self.noise_model]
             detweights = np.array([noise.detector_weight(x) for x in dets], dtype=np.float64)
             flag_indx, flag_data, shared = self._flag_args(ob, dets, use_accel)
+            if zmap is not None:
+                self.signal_in_one_sweep.append(
+                    self._with_signal(data, ob, dets, dist, invcov, hits, zmap, detweights, flag_indx))
+                continue
             if hits is not None:
                 native().build_inverse_covariance_and_hits(
                     dist.global_submap_to_local, invcov.arg(use_accel), hits.arg(use_accel),
@@ -609,11 +629,44 @@ class BuildInverseCovariance(_MapBuilder):
                 flag_indx, flag_data, detweights, self.det_flag_mask, ob.intervals[self.view].data, shared,
                 self.shared_flag_mask, use_accel)
 
+    def _with_signal(self, data, ob, dets, dist, invcov, hits, zmap, detweights, flag_indx):
+        """One observation of the covariance pass with the signal's map riding along
+        (toast_hip_build_cov_hits_signal_dev); everything is on the device already (the Pipeline staged the inputs).
+        Returns whether ONE kernel did all three."""
+        from .. import capi
+        from ..accel import accel_device_ptr
+        from ..data import SharedData
+        from .mapmaker_solve import SolverLHS
+
+        if "_g2l_" + self.pixel_dist not in data:
+            data["_g2l_" + self.pixel_dist] = SharedData(dist.global_submap_to_local, "g2l")
+        g2l = SolverLHS._resident(data["_g2l_" + self.pixel_dist], "g2l")
+        n_samp = ob.n_local_samples
+        pd, wd, sd = ob.detdata[self.pixels], ob.detdata[self.weights], ob.detdata[self.signal]
+        if sd.dtype != np.float64:
+            raise RuntimeError(f"BuildInverseCovariance: signal '{self.signal}' must be float64")
+        nnz = 1 if len(wd.detector_shape) == 1 else wd.detector_shape[1]
+        if self.det_flags is not None:
+            f_ptr, f_ns = accel_device_ptr(ob.detdata[self.det_flags].buffer), n_samp
+        else:
+            f_ptr, f_ns = 0, 0
+        if self.shared_flags is not None:
+            s_ptr, s_n = accel_device_ptr(ob.shared[self.shared_flags].data), n_samp
+        else:
+            s_ptr, s_n = 0, 0
+        return capi.dev.build_cov_hits_signal(
+            accel_device_ptr(g2l.data), accel_device_ptr(invcov.buffer), accel_device_ptr(hits.buffer),
+            accel_device_ptr(zmap.buffer), dist.n_pix_submap, nnz, pd.indices(dets), accel_device_ptr(pd.buffer),
+            wd.indices(dets), accel_device_ptr(wd.buffer), sd.indices(dets), accel_device_ptr(sd.buffer), flag_indx, f_ptr,
+            f_ns, detweights, detweights, self.det_flag_mask, n_samp, ob.intervals[self.view].data, s_ptr, s_n,
+            self.shared_flag_mask)
+
     def _finalize(self, data, use_accel=None, **kwargs):
         if self.inverse_covariance in data:
             self._sync(data[self.inverse_covariance])
         if self.hits is not None and self.hits in data:
             self._sync(data[self.hits])
+        # (the signal's map is summed over the processes by whoever applies the covariance to it: BinMap)
 
     def _requires(self):
         req = {"global": [self.pixel_dist], "meta": [self.noise_model], "shared": [],
@@ -622,6 +675,8 @@ class BuildInverseCovariance(_MapBuilder):
             req["shared"].append(self.shared_flags)
         if self.det_flags is not None:
             req["detdata"].append(self.det_flags)
+        if self.signal is not None and self.signal_map is not None and self.hits is not None:
+            req["detdata"].append(self.signal)
         if self.view is not None:
             req["intervals"].append(self.view)
         return req
@@ -630,6 +685,8 @@ class BuildInverseCovariance(_MapBuilder):
         prov = {"global": [self.inverse_covariance]}
         if self.hits is not None:
             prov["global"].append(self.hits)
+            if self.signal is not None and self.signal_map is not None:
+                prov["global"].append(self.signal_map)
         return prov
 
 
@@ -655,6 +712,9 @@ class CovarianceAndHits(Operator):
     sync_type = Unicode("alltoallv", help="Communication algorithm: 'allreduce' or 'alltoallv'")
     save_pointing = Bool(False, help="If True, do not clear detector pointing matrices")
     det_data_units = Unicode(defaults.det_data_units, allow_none=True, help="Desired timestream units")
+    signal = Unicode(None, allow_none=True, help="On the accelerator: also accumulate the noise-weighted map of this "
+                     "detdata key in the same pass over the pointing (not a reference trait; see BuildInverseCovariance)")
+    signal_map = Unicode(None, allow_none=True, help="The Data key of that noise-weighted map")
 
     def _exec(self, data, detectors=None, **kwargs):
         for trait in ("pixel_pointing", "stokes_weights"):
@@ -679,10 +739,14 @@ class CovarianceAndHits(Operator):
         # count along; other shapes run the two kernels behind the same call)
         build_invcov = BuildInverseCovariance(inverse_covariance=inv_key, weights=self.stokes_weights.weights,
                                               noise_model=self.noise_model, det_data_units=self.det_data_units,
-                                              hits=self.hits, **common)
+                                              hits=self.hits, signal=self.signal, signal_map=self.signal_map, **common)
         accum = Pipeline(detector_sets=["ALL"] if self.save_pointing else uncached_detector_sets(),
                          operators=[self.pixel_pointing, self.stokes_weights, build_invcov])
         accum.apply(data, detectors=detectors)
+        # per observation: did ONE kernel accumulate covariance, hits and the signal's map (None: the map was not asked for
+        # or the pass ran on the host)
+        self.signal_in_one_sweep = tuple(getattr(build_invcov, "signal_in_one_sweep", ())) \
+            if (self.signal is not None and self.signal_map in data) else None
         invcov = data[inv_key]
         data[self.rcond] = PixelData(data[self.pixel_dist], np.float64, n_value=1)
         if invcov.accel_in_use():
@@ -766,6 +830,22 @@ class BinMap(Operator):
             raise RuntimeError(f"Pixel distribution '{self.pixel_dist}' does not match the one used by covariance "
                                f"'{self.covariance}'")
         self.pixel_pointing.create_dist = None
+        # SolveAmplitudes: the noise-weighted map of this call's timestream was accumulated by the covariance pass already
+        # (same pixels, weights, flags: BuildInverseCovariance.signal) -- ONE call skips the accumulation
+        ready = bool(self.__dict__.pop("_zmap_is_accumulated", False)) and self.binned in data
+        if ready:
+            fuse_sync = (self.noiseweighted is None and self.sync_type == "alltoallv" and data.comm.comm_world is not None)
+            if fuse_sync:
+                map_reduce_apply(cov, data[self.binned], sync_type=self.sync_type)
+                return
+            if self.sync_type == "alltoallv":
+                data[self.binned].sync_alltoallv()
+            else:
+                data[self.binned].sync_allreduce()
+            if self.noiseweighted is not None:
+                data[self.noiseweighted] = data[self.binned].duplicate()
+            covariance_apply(cov, data[self.binned], use_alltoallv=(self.sync_type == "alltoallv"))
+            return
         if self.binned in data:
             if data[self.binned].distribution != data[self.pixel_dist]:
                 raise RuntimeError(f"Pixel distribution '{self.pixel_dist}' does not match existing binned map "
