@@ -411,6 +411,17 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
                         anchor = cls_odd[0];
                         level2 = pass(cand[anchor].at, cand[anchor].at + chunk / 2, chunk / 2);
                     }
+                    if (anchor != SIZE_MAX && std::find(cls_odd.begin(), cls_odd.end(), anchor) == cls_odd.end()) {
+                        // the thresholds moved and the anchor is no longer clear of the slab: start over with another one
+                        anchor = SIZE_MAX;
+                        for (Cand & d : cand) d.r2 = -1.0;
+                        grp_a.clear();
+                        grp_b.clear();
+                        if (!cls_odd.empty()) {
+                            anchor = cls_odd[0];
+                            level2 = pass(cand[anchor].at, cand[anchor].at + chunk / 2, chunk / 2);
+                        }
+                    }
                     if (anchor != SIZE_MAX) {
                         for (size_t i : cls_odd) {
                             if (i != anchor && cand[i].r2 < 0.0) cand[i].r2 = pass(cand[anchor].at, cand[i].at, chunk);
