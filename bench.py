@@ -784,6 +784,20 @@ def run(args, workload, world, rank, dev, headline=True):
         "frac_of_read_write_stream": ach / stream_rw,
         "note": "k_noise_weight_v2, a pure read + write stream (16 B per lane and access) over the same work buffer",
     }
+    if nnz == 3 and n_samp % 2 == 0 and hasattr(capi.real_lib(), "toast_hip_probe_byte_mix_dev"):
+        # ... and the two kernels' OWN byte mixes as plain streams over the very arrays they read and write, in their launch
+        # shape (no gather, no scan, no atomics; flags left out): what the places of these arrays in HBM let such a kernel reach
+        mix_scan = lambda: capi.probe_byte_mix(d_pixels.data_ptr(), d_weights.data_ptr(), d_tod.data_ptr(), d_tod2.data_ptr(),    # noqa: E731
+                                               n_det, n_samp, stream)
+        mix_bnw = lambda: capi.probe_byte_mix(d_pixels.data_ptr(), d_weights.data_ptr(), d_tod.data_ptr(), 0, n_det, n_samp, stream)    # noqa: E731
+        mix_scan(); mix_bnw()
+        t_ms, t_mb = timed(mix_scan, 5), timed(mix_bnw, 5)
+        roofline["stream_ceiling"].update({
+            "scan_map_byte_mix_ms": t_ms, "scan_map_byte_mix_GBs": 48.0 * nsamp_tot / t_ms / 1e6,
+            "build_noise_weighted_byte_mix_ms": t_mb, "build_noise_weighted_byte_mix_GBs": 40.0 * nsamp_tot / t_mb / 1e6,
+            "scan_map_frac_of_its_mix": t_ms / ms["scan"], "build_noise_weighted_frac_of_its_mix": t_mb / ms["bnw"],
+            "byte_mix_note": "k_probe_byte_mix: 40 B read (+ 8 B written) per det-sample from / to the arrays of the timed kernels",
+        })
     # the same three kernels with one sample per lane (8-byte lane accesses) and two consecutive samples per lane
     # (16-byte lane accesses; the default), same buffers, same process
     if headline:

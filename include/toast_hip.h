@@ -164,6 +164,12 @@ int toast_hip_probe_stream(void * p, size_t bytes, double * ms);
 int toast_hip_exp_vmm_pair_matrix(int n_phys, int n_slots, double * out);
 /* The same pass with the 1024 rows dealt round-robin to nb <= 4 separate ranges of bytes_each. */
 int toast_hip_probe_stream_split(void * const * bases, int nb, size_t bytes_each, double * ms);
+/* Measurement aid (bench.py roofline.stream_ceiling): the byte mix of scan_map -- 8 B of pixels, 24 B of weights and 8 B of a
+ * timestream read, 8 B written per detector-sample -- or, with d_out = NULL, of build_noise_weighted (40 B read) as plain
+ * streams in the launch shape of the two kernels, no gather, no scan, no atomics: what the arrays' places in HBM let a
+ * kernel of this mix reach.  [n_det, n_samp] rows, n_samp even, rows 16-byte aligned; asynchronous on `stream`. */
+int toast_hip_probe_byte_mix_dev(const int64_t * d_pixels, const double * d_weights, const double * d_tod, double * d_out,
+                                 int64_t n_det, int64_t n_samp, void * stream);
 /* Free and total device memory of this process' GPU (hipMemGetInfo; free ranges of the arena's slabs count as free). */
 int toast_hip_accel_mem_info(size_t * free_bytes, size_t * total_bytes);
 /* Give the arena's slabs that hold no live block back to the driver. */

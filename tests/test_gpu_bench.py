@@ -31,6 +31,10 @@ def test_bench_contract_small_workload():
         assert key in r, key
     assert r["traffic"] is None and r["traffic_exact"] is None       # (no committed PMC profile of the mini workload)
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # the two kernels' own byte mixes as plain streams over the same arrays (k_probe_byte_mix) ride along with the line
+    sc = r["stream_ceiling"]
+    for key in ("read_write_GBs", "scan_map_byte_mix_ms", "build_noise_weighted_byte_mix_ms", "scan_map_frac_of_its_mix"):
+        assert sc[key] > 0, key
     c = d["cpu_baseline"]
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert key in c, key

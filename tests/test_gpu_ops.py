@@ -1852,3 +1852,29 @@ def test_pcg_device_scalars_against_the_reference_solve(monkeypatch, case):
     ratio = hist[:m][floor] / want[:m][floor]
     assert np.all(ratio < 50.0) and np.all(ratio > 0.02)
     assert np.max(np.abs(got - sol)) <= 1e-6 * np.max(np.abs(sol))
+
+
+def test_byte_mix_probe_reads_what_it_says_and_leaves_the_inputs_alone():
+    """toast_hip_probe_byte_mix_dev (bench.py's roofline.stream_ceiling): the streams of scan_map / build_noise_weighted with no
+    gather -- its output is a fixed function of the three inputs (so every byte was read), the inputs are unchanged, and
+    without an output array nothing is written at all."""
+    import torch
+
+    from toast_amd import capi
+
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(3)
+    n_det, n_samp = 5, 4098
+    pix = torch.from_numpy(rng.integers(-1, 1000, (n_det, n_samp))).to(dev)
+    w = torch.from_numpy(rng.standard_normal((n_det, n_samp, 3))).to(dev)
+    tod = torch.from_numpy(rng.standard_normal((n_det, n_samp))).to(dev)
+    out = torch.full((n_det, n_samp), -7.0, dtype=torch.float64, device=dev)
+    before = (pix.clone(), w.clone(), tod.clone())
+    capi.probe_byte_mix(pix.data_ptr(), w.data_ptr(), tod.data_ptr(), out.data_ptr(), n_det, n_samp)
+    capi.probe_byte_mix(pix.data_ptr(), w.data_ptr(), tod.data_ptr(), 0, n_det, n_samp)
+    torch.cuda.synchronize()
+    want = tod * w.sum(dim=2) + (pix & 1).to(torch.float64)
+    assert torch.allclose(out, want, rtol=0, atol=1e-12)
+    assert torch.equal(pix, before[0]) and torch.equal(w, before[1]) and torch.equal(tod, before[2])
+    with pytest.raises(RuntimeError):
+        capi.probe_byte_mix(pix.data_ptr(), w.data_ptr(), tod.data_ptr(), 0, n_det, n_samp - 1)      # odd rows

@@ -287,6 +287,14 @@ def probe_stream_split(ptrs, nbytes_each):
     return float(ms.value)
 
 
+def probe_byte_mix(d_pixels, d_weights, d_tod, d_out, n_det, n_samp, stream=0):
+    """The byte mix of scan_map (d_out given) / build_noise_weighted (d_out = 0) as plain streams
+    (toast_hip_probe_byte_mix_dev); asynchronous on ``stream``."""
+    _check(real_lib().toast_hip_probe_byte_mix_dev(C.c_void_p(int(d_pixels)), C.c_void_p(int(d_weights)), C.c_void_p(int(d_tod)),
+                                                   C.c_void_p(int(d_out)) if d_out else None, C.c_int64(int(n_det)),
+                                                   C.c_int64(int(n_samp)), C.c_void_p(int(stream)) if stream else None))
+
+
 def accel_mem_info():
     """(free, total) bytes of device memory (toast_hip_accel_mem_info)."""
     f, t = C.c_size_t(0), C.c_size_t(0)

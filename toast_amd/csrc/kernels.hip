@@ -3449,6 +3449,31 @@ __global__ __launch_bounds__(kThreads) void k_probe_stream_split(ProbeBases b, i
     }
 }
 
+// The byte mix of scan_map / build_noise_weighted WITHOUT their gathers, scans and atomics, in the launch shape of the
+// *_v2 kernels (detector = blockIdx.x, 1024-sample chunks along y, two samples per lane): 16 B of pixels, 48 B of weights and
+// 16 B of a timestream read per lane and trip; 16 B written when `out` is given.  What the arrays' places in HBM let a
+// kernel of this byte mix reach (bench.py: roofline.stream_ceiling).
+__global__ __launch_bounds__(kThreads) void k_probe_byte_mix(const int64_t * __restrict__ pixels,
+                                                             const double * __restrict__ weights,
+                                                             const double * __restrict__ tod, double * __restrict__ out,
+                                                             double * __restrict__ sink, int64_t n_samp) {
+    const int64_t row = (int64_t)blockIdx.x * n_samp;
+    double acc = 0.0;
+    for (int64_t c0 = (int64_t)blockIdx.y * 1024; c0 < n_samp; c0 += (int64_t)gridDim.y * 1024) {
+        for (int64_t s = c0 + 2 * (int64_t)threadIdx.x; s < c0 + 1024 && s + 1 < n_samp; s += 2 * kThreads) {
+            const longlong2 pp = *reinterpret_cast<const longlong2 *>(pixels + row + s);
+            const double2 tt = *reinterpret_cast<const double2 *>(tod + row + s);
+            const double2 * wv = reinterpret_cast<const double2 *>(weights + 3 * (row + s));
+            const double2 w0 = wv[0], w1 = wv[1], w2 = wv[2];
+            const double a = tt.x * (w0.x + w0.y + w1.x) + (double)(pp.x & 1);
+            const double b = tt.y * (w1.y + w2.x + w2.y) + (double)(pp.y & 1);
+            if (out != nullptr) *reinterpret_cast<double2 *>(out + row + s) = make_double2(a, b);
+            else acc += a + b;
+        }
+    }
+    if (out == nullptr && acc == 1.2345e301) *sink = acc;      // (never: keeps the loads alive)
+}
+
 __global__ void k_probe_clock_reset(unsigned long long * clk) {
     clk[0] = ~0ull;
     clk[1] = 0ull;
@@ -3529,6 +3554,19 @@ double probe_stream_split_ms(void * const * bases, int nb, size_t bytes_each, hi
     if (e0 != nullptr) (void)hipEventDestroy(e0);
     if (e1 != nullptr) (void)hipEventDestroy(e1);
     return best < 1e29 ? best : 0.0;
+}
+
+void probe_byte_mix(const int64_t * pixels, const double * weights, const double * tod, double * out, int64_t n_det,
+                    int64_t n_samp, hipStream_t st) {
+    if (n_det <= 0 || n_samp < 2) return;
+    if ((n_samp & 1) != 0) fail_arg("probe_byte_mix: even row length");
+    int64_t gy = (n_samp + 1023) / 1024;
+    if (gy > 65535) gy = 65535;
+    static double * sink = nullptr;
+    if (sink == nullptr) TH_HIP(hipMalloc(reinterpret_cast<void **>(&sink), sizeof(double)));
+    hipLaunchKernelGGL(k_probe_byte_mix, dim3((unsigned)n_det, (unsigned)gy), dim3(kThreads), 0, st, pixels, weights, tod, out,
+                       sink, n_samp);
+    check_launch();
 }
 
 double probe_stream_ms(void * block, size_t bytes, hipStream_t st) {

@@ -1438,6 +1438,13 @@ int toast_hip_probe_stream_split(void * const * bases, int nb, size_t bytes_each
     return guarded([&] { *ms = probe_stream_split_ms(bases, nb, bytes_each, Manager::get().stream()); });
 }
 
+int toast_hip_probe_byte_mix_dev(const int64_t * d_pixels, const double * d_weights, const double * d_tod, double * d_out,
+                                 int64_t n_det, int64_t n_samp, void * stream) {
+    return guarded([&] {
+        probe_byte_mix(d_pixels, d_weights, d_tod, d_out, n_det, n_samp, static_cast<hipStream_t>(stream));
+    });
+}
+
 int toast_hip_accel_mem_info(size_t * free_bytes, size_t * total_bytes) {
     return guarded([&] {
         Manager::get().require_device();

@@ -100,6 +100,10 @@ void drop_param_blocks();   // forget the cached parameter blocks (their storage
 double probe_stream_ms(void * block, size_t bytes, hipStream_t stream);
 // ... with the 1024 rows dealt round-robin to nb <= 4 separate ranges of bytes_each (placement experiments)
 // (timed by the device's constant-rate clock inside the kernel; *used_clock = false: HIP events had to do)
+// the byte mix of scan_map (out != nullptr) / build_noise_weighted (out == nullptr) as plain streams in the launch shape of the
+// *_v2 kernels (kernels.hip k_probe_byte_mix); asynchronous on st
+void probe_byte_mix(const int64_t * pixels, const double * weights, const double * tod, double * out, int64_t n_det,
+                    int64_t n_samp, hipStream_t st);
 double probe_stream_split_ms(void * const * bases, int nb, size_t bytes_each, hipStream_t stream, bool * used_clock = nullptr);
 // Counters of Manager::device_alloc: both arenas (arena.hpp) together, plus what went around them.
 struct AllocStats {
