@@ -659,7 +659,7 @@ def run(args, workload, world, rank, dev, headline=True):
     ms = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in ev.items()}
     value = world * nsamp_tot * args.steps / elapsed
     zone_diag = None
-    if os.environ.get("TOAST_BENCH_ZONE_DIAG", "") in ("1", "2") and not args.torch_alloc:
+    if os.environ.get("TOAST_BENCH_ZONE_DIAG", "") in ("1", "2", "3") and not args.torch_alloc:
         # EXPERIMENT (profiles/r06_e): which of the streams that scan_map / build_noise_weighted read share an HBM zone
         # with the two chunk classes of the written timestream?  One read + write pass (x * 1.0: the data stays bit for
         # bit) over a 1 GB range of a read stream and a 1 GB chunk of tod2, rows dealt alternately: TB/s (slow = same zone).
@@ -696,7 +696,27 @@ def run(args, workload, world, rank, dev, headline=True):
                 t = capi.probe_stream_split([ranges[rname], cptr], nb)
                 zone_diag["%s vs %s" % (rname, cname if cname == "zmap" else "tod2:" + cname)] = round(4.0 * nb / (t * 1e-3) / 1e12, 3)
         zone_diag["slabs_third_zone"] = capi.alloc_stats().get("slabs_third_zone")
-        if os.environ["TOAST_BENCH_ZONE_DIAG"] == "2":
+        if os.environ["TOAST_BENCH_ZONE_DIAG"] == "3":
+            # every GB of the read arrays against the map's chunk and the next chunk of its run: does a PART of the read-mostly
+            # slab share a zone with one of them?
+            lo = min(t.data_ptr() for t in (d_pixels, d_weights, d_tod))
+            hi = max(t.data_ptr() + t.numel() * t.element_size() for t in (d_pixels, d_weights, d_tod))
+            # (the slab's chunks are 1 GB from ITS base, which is only 2 MB aligned: walk down to it)
+            sbase = d_zmap.data_ptr() // (2 << 20) * (2 << 20)
+            while capi.arena_block_zone(sbase - (2 << 20), 1)[0]:
+                sbase -= 2 << 20
+            zbase = sbase + (d_zmap.data_ptr() - sbase) // gb * gb
+            per_gb = {}
+            for name, cptr in (("map_chunk", zbase), ("next_chunk", zbase + gb)):
+                inside, own, other = capi.arena_block_zone(cptr, gb)
+                if not inside or own:
+                    continue
+                per_gb[name] = [round(4.0 * gb / (capi.probe_stream_split([lo + k * gb, cptr], gb) * 1e-3) / 1e12, 2)
+                                for k in range(int((hi - lo) // gb))]
+            zone_diag["read_GBs_vs_chunk"] = per_gb
+            zone_diag["read_arrays_GB_offsets"] = {n: round((t.data_ptr() - lo) / gb, 2) for n, t in
+                                                   (("pixels", d_pixels), ("weights", d_weights), ("tod", d_tod))}
+        if os.environ["TOAST_BENCH_ZONE_DIAG"] in ("2", "3"):
             # does the level of build_noise_weighted follow the place of ITS MAP?  The same launch into maps at other places
             # of the arena (kept alive: every next one lies elsewhere): scatter blocks, streamed blocks, the read-mostly slab
             sweep, keep = [], []

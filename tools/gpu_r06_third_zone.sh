@@ -18,15 +18,20 @@ def rng(suffix):
 print('%s value %.2f scan %.3f bnw %.3f setup %.2f | reads vs P %s  vs Q %s  vs zmap %s | P-Q %s  P-zmap %s  Q-zmap %s | third %s' % (
     sys.argv[2], d['value'] / 1e9, k['scan'], k['bnw'], d.get('setup_s', 0), rng('tod2:P'), rng('tod2:Q'), rng('zmap'),
     z.get('tod2:P vs tod2:Q'), z.get('tod2:P vs zmap'), z.get('tod2:Q vs zmap'), z.get('slabs_third_zone')))
+if 'read_GBs_vs_chunk' in z:
+    print('   read arrays at GB', z['read_arrays_GB_offsets'])
+    for n, v in z['read_GBs_vs_chunk'].items():
+        print('   %-10s' % n, ' '.join('%.2f' % x for x in v))
 if 'bnw_ms_by_map_place' in z:
     print('   bnw by map place:', ' '.join('%s/%s@%+.1f=%.3f' % (a[0][:3], a[2], a[3], a[1]) for a in z['bnw_ms_by_map_place']))
 PY
-    grep "vmm slab" gpurun_out/$tag/$label$i.err | cut -c1-260
+    grep "vmm slab\|vmm survey" gpurun_out/$tag/$label$i.err | cut -c1-260
   done
 }
 for w in $which; do
   case $w in
     DEFAULT) one DEFAULT TOAST_HIP_ARENA_THIRD_ZONE=1 | tee gpurun_out/$tag/default.txt;;
     TWO) one TWO TOAST_HIP_ARENA_THIRD_ZONE=0 | tee gpurun_out/$tag/two.txt;;
+    ENDS) one ENDS TOAST_HIP_ARENA_SURVEY=0 | tee gpurun_out/$tag/ends.txt;;
   esac
 done
