@@ -119,6 +119,8 @@ typedef struct toast_hip_arena_stats_t {
     double search_ms;             /* wall time of the searches (part of interleave_ms) */
     int64_t slabs_third_zone;     /* slabs whose BOTH chunk classes are clear of the read-mostly slab: a written timestream there
                                    * shares an HBM zone with none of the streams the sweeps read (csrc/vmm_slab.cpp) */
+    int64_t read_mostly_zones;    /* HBM zones the last survey found in the range the read-mostly arrays fill (1-3; 0: none
+                                   * surveyed): both chunk classes leave the readers' zone only when it is ONE zone throughout */
 } toast_hip_arena_stats_t;
 int toast_hip_arena_stats(toast_hip_arena_stats_t * out);
 /* Did the zone placement work out?  placement_ok = 1: an interleaved slab stands and every slot meant for the other HBM

@@ -316,7 +316,7 @@ class _ArenaStats(C.Structure):
                 ("chunks_created", C.c_int64), ("interleave_ms", C.c_double), ("same_zone_TBs", C.c_double),
                 ("chunks_other_wanted", C.c_int64), ("searches", C.c_int64), ("searches_exhausted", C.c_int64),
                 ("searches_capped_ms", C.c_int64), ("probes", C.c_int64), ("probes_by_clock", C.c_int64),
-                ("create_ms_per_chunk", C.c_double), ("search_ms", C.c_double), ("slabs_third_zone", C.c_int64)]
+                ("create_ms_per_chunk", C.c_double), ("search_ms", C.c_double), ("slabs_third_zone", C.c_int64), ("read_mostly_zones", C.c_int64)]
 
 
 def alloc_stats():

@@ -867,6 +867,36 @@ ZoneRefs zone_references_take(size_t bytes) {
     return r;
 }
 
+bool read_mostly_free_range(const char ** base, size_t * lo, size_t * hi) {
+    if (alloc_policy().plain || big_arena().capacity() < (size_t(8) << 30)) return false;
+    const char * b0 = nullptr;
+    size_t lo0 = 0, hi0 = 0;
+    // (a placement that never places: every free range passes by)
+    (void)big_arena().alloc_placed(size_t(2) << 20, [&](const char * b, size_t l, size_t h, size_t) {
+        if (h - l > hi0 - lo0) {
+            b0 = b;
+            lo0 = l;
+            hi0 = h;
+        }
+        return SIZE_MAX;
+    });
+    if (b0 == nullptr) return false;
+    *base = b0;
+    *lo = lo0;
+    *hi = hi0;
+    return true;
+}
+
+void * read_mostly_take_at(const char * base, size_t offset, size_t bytes) {
+    return big_arena().alloc_placed(bytes, [&](const char * b, size_t l, size_t h, size_t need) {
+        return (b == base && l <= offset && offset + need <= h) ? offset : SIZE_MAX;
+    });
+}
+
+void read_mostly_release(void * p) {
+    if (p != nullptr) (void)big_arena().release(p);
+}
+
 void zone_references_release(const ZoneRefs & r) {
     if (r.first != nullptr) (void)big_arena().release(r.first);
     if (r.last != nullptr && r.last != r.first) (void)big_arena().release(r.last);
@@ -1305,6 +1335,7 @@ int toast_hip_arena_stats(toast_hip_arena_stats_t * out) {
         out->create_ms_per_chunk = v.create_ms_per_chunk;
         out->search_ms = v.search_ms;
         out->slabs_third_zone = v.slabs_third_zone;
+        out->read_mostly_zones = v.read_mostly_zones;
     });
 }
 

@@ -134,6 +134,12 @@ struct ZoneRefs {
 };
 ZoneRefs zone_references_take(size_t bytes);
 void zone_references_release(const ZoneRefs & r);
+// For the zone survey of the read-mostly range (vmm_slab.cpp): the largest free range of the arena the read-mostly arrays
+// come from -- where they are going to lie, in address order -- (false: no such slab yet, or a token reservation), a block
+// of it at a given offset (nullptr when somebody else's allocation got there first), and its return.
+bool read_mostly_free_range(const char ** base, size_t * lo, size_t * hi);
+void * read_mostly_take_at(const char * base, size_t offset, size_t bytes);
+void read_mostly_release(void * p);
 bool vmm_slab_give(void * p);       // false: not one of them
 struct VmmSlabStats {
     int64_t slabs = 0;               // interleaved slabs alive
@@ -151,6 +157,7 @@ struct VmmSlabStats {
     int64_t searches_exhausted = 0;  // ... that ran out of a budget before both classes were full
     int64_t searches_capped_ms = 0;  // ... that hit the hard cap in ms (a subset of the exhausted ones)
     int64_t probes_by_clock = 0;     // probes timed by the device clock (the rest: HIP events)
+    int64_t read_mostly_zones = 0;   // zones the last survey found in the read-mostly range (0: none surveyed)
     int64_t slabs_third_zone = 0;    // slabs whose BOTH chunk classes are clear of the read-mostly slab (two other zones)
     double create_ms_per_chunk = 0.0;   // the last search's average hipMemCreate time per chunk (0.1: clean memory; 20-50: the
                                         // driver is still clearing what another process returned)

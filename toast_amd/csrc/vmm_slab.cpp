@@ -142,6 +142,90 @@ double gap_threshold(std::vector<double> r, double level, double min_gap) {
     return (r[r.size() / 2] > (1.0 + 1.7 * min_gap) * level) ? 0.0 : 1.0e300;
 }
 
+// ---- the zone survey of a range (round 6, profiles/r06_f) ------------------------------------------------------------------
+// K blocks of `chunk` bytes spread over a range are sorted into HBM zones: every block against the first one (one read +
+// write pass each: two levels ~13 % apart), the ones in another zone against the last of them.
+struct ZoneSurvey {
+    std::vector<int> label;      // per block: 0 / 1 / 2, -1 = could not be had
+    int zones = 0;
+    std::string map;             // X / Y / Z / ? per block, address order
+};
+
+std::vector<size_t> survey_offsets(size_t lo, size_t hi, size_t chunk) {
+    const size_t len = hi - lo, gr = size_t(2) << 20;
+    int K = (int)(len / (size_t(4) << 30)) + 1;
+    K = K < 3 ? 3 : (K > 16 ? 16 : K);
+    std::vector<size_t> at((size_t)K);
+    for (int k = 0; k < K; ++k) at[(size_t)k] = (lo + (size_t)((double)(len - chunk) * k / (K - 1))) / gr * gr;
+    at[0] = (lo + gr - 1) / gr * gr;
+    return at;
+}
+
+template <class Take, class Release, class Pass>
+ZoneSurvey survey_zones(int K, Take take, Release release, Pass pass, size_t chunk, double gap) {
+    struct Borrowed {
+        void * p;
+        Release & give;
+        ~Borrowed() {
+            if (p != nullptr) give(p);
+        }
+    };
+    ZoneSurvey zs;
+    zs.label.assign((size_t)K, -1);
+    Borrowed start{take(0), release};
+    if (start.p == nullptr) return zs;
+    zs.label[0] = 0;
+    const double level0 = pass(start.p, static_cast<char *>(start.p) + chunk / 2, chunk / 2);
+    std::vector<double> r0((size_t)K, -1.0), valid;
+    for (int k = 1; k < K; ++k) {
+        Borrowed b{take(k), release};
+        if (b.p == nullptr) continue;
+        r0[(size_t)k] = pass(start.p, b.p, chunk);
+        valid.push_back(r0[(size_t)k]);
+    }
+    const double thr0 = gap_threshold(valid, level0, gap);
+    std::vector<int> other;
+    for (int k = 1; k < K; ++k) {
+        if (r0[(size_t)k] < 0.0) continue;
+        if (r0[(size_t)k] > thr0) other.push_back(k);
+        else zs.label[(size_t)k] = 0;
+    }
+    if (!other.empty()) {
+        // the blocks of another zone than the first one's: one zone or two?  Against the LAST of them that can be had
+        int k1 = -1;
+        void * p1 = nullptr;
+        for (size_t j = other.size(); j-- > 0 && p1 == nullptr;) {
+            p1 = take(other[j]);
+            if (p1 != nullptr) k1 = other[j];
+        }
+        Borrowed rep1{p1, release};
+        if (rep1.p != nullptr) {
+            zs.label[(size_t)k1] = 1;
+            const double level1 = pass(rep1.p, static_cast<char *>(rep1.p) + chunk / 2, chunk / 2);
+            std::vector<double> r1((size_t)K, -1.0), valid1;
+            for (int k : other) {
+                if (k == k1) continue;
+                Borrowed b{take(k), release};
+                if (b.p == nullptr) continue;
+                r1[(size_t)k] = pass(rep1.p, b.p, chunk);
+                valid1.push_back(r1[(size_t)k]);
+            }
+            const double thr1 = gap_threshold(valid1, level1, gap);
+            for (int k : other) {
+                if (k != k1 && r1[(size_t)k] >= 0.0) zs.label[(size_t)k] = r1[(size_t)k] > thr1 ? 2 : 1;
+            }
+        }
+    }
+    bool seen[3] = {false, false, false};
+    for (int k = 0; k < K; ++k) {
+        const int z = zs.label[(size_t)k];
+        if (z >= 0) seen[z] = true;
+        zs.map += z < 0 ? '?' : (char)('X' + z);
+    }
+    zs.zones = (int)seen[0] + (int)seen[1] + (int)seen[2];
+    return zs;
+}
+
 bool map_chunk(char * va, size_t chunk, hipMemGenericAllocationHandle_t h, int dev) {
     if (hipMemMap(va, chunk, 0, h, 0) != hipSuccess) {
         (void)hipGetLastError();
@@ -172,6 +256,8 @@ struct SearchOutcome {
     size_t want_other = 0;
     size_t probes_clock = 0;
     bool exhausted = false, capped = false, third = false;
+    int zones = 0;               // zones the survey found in the read-mostly range (0: no survey)
+    std::string zone_map;        // ... one letter per surveyed block
     double create_ms = 0.0, search_ms = 0.0;
 };
 
@@ -199,6 +285,7 @@ void register_slab(char * base, size_t n, size_t chunk, const std::vector<hipMem
         g_vmm_stats.searches_exhausted += so.exhausted ? 1 : 0;
         g_vmm_stats.searches_capped_ms += so.capped ? 1 : 0;
         g_vmm_stats.slabs_third_zone += so.third ? 1 : 0;
+        if (so.zones > 0) g_vmm_stats.read_mostly_zones = so.zones;
         g_vmm_stats.probes_by_clock += (int64_t)so.probes_clock;
         g_vmm_stats.create_ms_per_chunk = created > 0 ? so.create_ms / (double)created : 0.0;
         g_vmm_stats.search_ms += so.search_ms;
@@ -209,6 +296,9 @@ void register_slab(char * base, size_t n, size_t chunk, const std::vector<hipMem
                                  "(%.2f ms each), %zu probes (%zu by the device clock), %.1f ms%s%s\n",
                          n, chunk >> 20, (void *)base, how, other, so.want_other, created, created ? so.create_ms / (double)created : 0.0, probes,
                          so.probes_clock, ms_since(t_start), so.exhausted ? ", search budget exhausted" : "", so.capped ? " (hard cap in ms)" : "");
+            if (!so.zone_map.empty()) {
+                std::fprintf(stderr, "[toast_hip] vmm survey    zones of the read-mostly range, a block every ~4 GB: %s\n", so.zone_map.c_str());
+            }
         }
     }
 }
@@ -320,12 +410,43 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
     std::vector<size_t> cls_odd, cls_even;       // candidates for the odd slots (other than every reference) and the rest
     std::vector<size_t> grp_a, grp_b;            // third-zone split of cls_odd: same zone as the anchor / the other one
     bool third_done = false;
+    bool prefer_end_zone = false;               // even slots: chunks of the END's zone first (see the survey below)
     try {
         if (n_ref >= 1) {
             ref[0] = static_cast<char *>(ext.last);
             if (n_ref == 2) ref[1] = static_cast<char *>(ext.first);
             for (int k = 0; k < n_ref; ++k) level[k] = pass(ref[k], ref[k] + chunk / 2, chunk / 2);
         }
+        // The two ends say nothing about the middle: the driver hands a 56 GB slab out in runs of several zones, and on a box
+        // whose memory is fragmented the third-zone split below -- both chunk classes out of the ends' zone -- put the map
+        // and the written timestreams into the zones of the slab's MIDDLE, where half of the arrays lay
+        // (build_noise_weighted 5.52 instead of 5.27 ms, scan_map 6.32 instead of 6.15: profiles/r06_f section 5).  A block
+        // every ~4 GB of the range is sorted into zones first; the split is for a range that is ONE zone throughout.
+        int survey_zones_n = 0;
+        std::string survey_map;
+        // (its ~K + 3 passes come out of the search's budget: no survey -- and no split -- on a budget that is smaller than that)
+        if (pol.third && n_ref == 2 && pol.search_probes >= 64) {
+            const char * rb = nullptr;
+            size_t rlo = 0, rhi = 0;
+            // (the two references are live blocks at its ends: the free range lies between them)
+            if (read_mostly_free_range(&rb, &rlo, &rhi) && rhi - rlo >= 3 * chunk) {
+                const std::vector<size_t> at = survey_offsets(rlo, rhi, chunk);
+                const ZoneSurvey zs = survey_zones(
+                    (int)at.size(), [&](int k) { return read_mostly_take_at(rb, at[(size_t)k], chunk); },
+                    [](void * b) { read_mostly_release(b); }, pass, chunk, pol.gap);
+                survey_zones_n = zs.zones;
+                survey_map = zs.map;
+                // The front half of the range -- where the arrays come first -- in the zone of its START, its END in another
+                // one: the even slots ("the rest") then belong into the END's zone, not into the one all the readers are in
+                // (scan_map 6.32 instead of 6.15 ms when they fell into it)
+                const size_t K = zs.label.size();
+                bool front_one = K >= 4 && zs.label[K - 1] > 0;
+                for (size_t k = 0; k < (K + 1) / 2 && front_one; ++k) front_one = zs.label[k] == 0;
+                prefer_end_zone = front_one;
+            }
+        }
+        so.zones = survey_zones_n;
+        so.zone_map = survey_map;
         const auto t_search = std::chrono::steady_clock::now();
         size_t streak = 0, last_odd = 0, last_even = 0;
         // Third-zone split (default; TOAST_HIP_ARENA_THIRD_ZONE=0 turns it off; profiles/r06_e).  When the read-mostly slab lies inside ONE zone X
@@ -333,7 +454,7 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
         // and a written timestream whose rows are spread over THOSE two shares a zone with none of the streams the sweeps
         // read (P = X puts half of its rows next to pixels, weights and the read timestream: scan_map 6.33 instead of 6.08 ms).
         // The clear chunks are told apart by one more pass each against the first of them (the anchor).
-        size_t anchor = SIZE_MAX, last_a = 0, last_b = 0;
+        size_t anchor = SIZE_MAX, last_a = 0, last_b = 0, last_pref = 0;
         double level2 = 0.0;
         while (cand.size() < max_create) {
             // the budget is counted in measuring passes; wall time is a hard cap only (and reported): on a box whose memory the
@@ -403,7 +524,7 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
             if (pol.third && n_ref == 2 && (long)probes < pol.search_probes / 2 && cand.size() < n + 96) {
                 // a chunk that is clear of the slab's end but not of its start: the slab straddles two zones, the chunks
                 // that are clear of both belong to ONE zone -- nothing to split
-                bool straddles = false;
+                bool straddles = survey_zones_n != 1;        // (the range between the ends changes zone, or could not be surveyed)
                 for (const Cand & d : cand) straddles |= (d.r[0] > thr[0] && d.r[1] >= 0.0 && !(d.r[1] > thr[1]));
                 if (!straddles) {
                     third_open = true;
@@ -446,13 +567,22 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
                     }
                 }
             }
-            if (!third_open && cls_odd.size() >= want_odd && cls_even.size() >= want_even) {
+            // (reference 0 is the END of the range: "not clear of it" = in its zone)
+            size_t pref_even = 0;
+            if (prefer_end_zone) {
+                for (size_t i : cls_even) pref_even += (cand[i].r[0] >= 0.0 && !(cand[i].r[0] > thr[0])) ? 1 : 0;
+            }
+            const bool want_pref = prefer_end_zone && (long)probes < pol.search_probes / 2 && cand.size() < n + 96;
+            if (!third_open && cls_odd.size() >= want_odd && cls_even.size() >= want_even &&
+                (!want_pref || pref_even >= want_even)) {
                 full = true;
                 break;
             }
             // did this chunk add to a class that is still short?
             bool useful = (cls_odd.size() > last_odd && last_odd < want_odd) ||
-                          (cls_even.size() > last_even && last_even < want_even);
+                          (cls_even.size() > last_even && last_even < want_even) ||
+                          (want_pref && pref_even > last_pref && last_pref < want_even);
+            last_pref = pref_even;
             if (third_open) {
                 useful = (grp_a.size() > last_a) || (grp_b.size() > last_b) || cls_odd.size() > last_odd;
                 last_a = grp_a.size();
@@ -494,6 +624,10 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
         cls_even = ge;       // (nothing is topped up below: both lists are full)
         cls_odd = go;
     } else {
+        if (prefer_end_zone) {
+            std::stable_partition(cls_even.begin(), cls_even.end(),
+                                  [&](size_t i) { return cand[i].r[0] >= 0.0 && !(cand[i].r[0] > thr[0]); });
+        }
         odd.assign(cls_odd.begin(), cls_odd.begin() + (long)take_o);
         even.assign(cls_even.begin(), cls_even.begin() + (long)take_e);
     }
