@@ -152,7 +152,9 @@ def test_mapmaker_default_routes_within_the_scatter_floor(case):
     assert a["fused_final"] and routes["full_pointing=False"]["fused_final"]
     # the right-hand side's A^T N^-1 d in the covariance pass's sweep (the default with cached pointing:
     # k_build_cov_pair_v2<true, true>) and as the reference's separate operator; on the fly the right-hand side bins itself
-    assert a["rhs_with_cov"] == (True,) and routes["full_pointing=False"]["rhs_with_cov"] is None
+    # (one kernel with the detector-pair, two-samples-per-lane form; the separate sweeps behind the same call otherwise)
+    one_kernel = os.environ.get("TOAST_HIP_PAIR", "1") != "0" and os.environ.get("TOAST_HIP_VEC2", "1") != "0"
+    assert a["rhs_with_cov"] == (one_kernel,) and routes["full_pointing=False"]["rhs_with_cov"] is None
     routes["right-hand side binned on its own (TOAST_HIP_FUSED_COV_RHS=0)"] = _run(case, cov_rhs=False)
     assert routes["right-hand side binned on its own (TOAST_HIP_FUSED_COV_RHS=0)"]["rhs_with_cov"] is None
     routes["two-operator final binning (TOAST_HIP_FUSED_FINAL=0)"] = _run(case, fused_final=False)

@@ -2779,11 +2779,13 @@ int offset_accumulate_impl(
         d_det_flags, det_flag_mask, use_d, d_shared_flags, shared_flag_mask, use_s,                 \
         make_fastdiv(n_pix_submap), n_samp
 #define TH_OA_ARGS2 TH_OA_ARGS, (const int32_t *)(d + o_di), d_signal
-        const bool v2 = vec2_lanes() && nnz == 3 && (n_samp & 1) == 0 && rows_16b(d_pixels) && rows_16b(d_weights) &&
-                        (!use_d || rows_16b(d_det_flags)) && (!use_s || rows_16b(d_shared_flags));
+        const bool can2 = nnz == 3 && (n_samp & 1) == 0 && rows_16b(d_pixels) && rows_16b(d_weights) &&
+                          (!use_d || rows_16b(d_det_flags)) && (!use_s || rows_16b(d_shared_flags));
+        const bool v2 = vec2_lanes() && can2;
         if (d_signal != nullptr) {
-            // the cleaned-signal form exists for the two-samples-per-lane kernel only (what cached IQU pointing gets)
-            if (!(v2 && rows_16b(d_signal))) {
+            // the cleaned-signal form exists for the two-samples-per-lane kernel only (what cached IQU pointing gets); the
+            // tuning switch that compares one with two samples per lane (TOAST_HIP_VEC2=0) does not take it away
+            if (!(can2 && rows_16b(d_signal))) {
                 fail_arg("offset_clean_accumulate: needs nnz = 3, an even number of samples per row and 16-byte aligned rows");
             }
             const bool pr = pair_detectors() && n_det >= 2;
