@@ -698,6 +698,8 @@ def test_written_timestreams_avoid_the_zone_of_the_read_mostly_slab():
         cross = {"%s-%s" % (rn, cn): rate(rp, cp, gb // 2) for rn, rp in (("start", rd), ("end", rd + 39 * gb + gb // 2)) for cn, cp in cls.items()}
         cross["P-Q"] = rate(cls["P"], cls["Q"], gb // 2)
         st = capi.alloc_stats()
+        # (the split is for a read-mostly range that the survey found in ONE zone throughout)
+        assert st["read_mostly_zones"] in (0, 1, 2, 3) and (st["slabs_third_zone"] == 0 or st["read_mostly_zones"] == 1), st
         print("THIRD", st["slabs_third_zone"], st["placement_ok"], st["search_exhausted"], round(max(same, same1), 3), cross)
     """)
     env = dict(os.environ)
