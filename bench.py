@@ -810,7 +810,8 @@ def run(args, workload, world, rank, dev, headline=True):
         mix_scan = lambda: capi.probe_byte_mix(d_pixels.data_ptr(), d_weights.data_ptr(), d_tod.data_ptr(), d_tod2.data_ptr(),    # noqa: E731
                                                n_det, n_samp, stream)
         mix_bnw = lambda: capi.probe_byte_mix(d_pixels.data_ptr(), d_weights.data_ptr(), d_tod.data_ptr(), 0, n_det, n_samp, stream)    # noqa: E731
-        mix_scan(); mix_bnw()
+        mix_scan()
+        mix_bnw()
         t_ms, t_mb = timed(mix_scan, 5), timed(mix_bnw, 5)
         roofline["stream_ceiling"].update({
             "scan_map_byte_mix_ms": t_ms, "scan_map_byte_mix_GBs": 48.0 * nsamp_tot / t_ms / 1e6,
@@ -1064,11 +1065,14 @@ def run(args, workload, world, rank, dev, headline=True):
         fused_flag = [False]
 
         def cov_only():
-            d_invcov.zero_(); d_hits.zero_()
+            d_invcov.zero_()
+            d_hits.zero_()
             D.build_cov_hits_signal(d_g2l.data_ptr(), d_invcov.data_ptr(), d_hits.data_ptr(), 0, *cov_args())
 
         def cov_and_signal():
-            d_invcov.zero_(); d_hits.zero_(); d_zmap.zero_()
+            d_invcov.zero_()
+            d_hits.zero_()
+            d_zmap.zero_()
             fused_flag[0] = D.build_cov_hits_signal(d_g2l.data_ptr(), d_invcov.data_ptr(), d_hits.data_ptr(),
                                                     d_zmap.data_ptr(), *cov_args())
 
