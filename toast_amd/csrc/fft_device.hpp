@@ -282,6 +282,7 @@ struct Params {
     const int32_t * knot_hint0;   // interval index at every bin j of the FIRST block, j = 0 .. N1 - 1
     const char * tab_blob;        // fft_reg.hip: [n_kern][tab_bytes] knots | mag | ang | 16-bit hints as the row pass keeps
     int tab_bytes;                // them in LDS (KTabSel<true> layout, a multiple of 16 bytes), or nullptr / 0
+    int tab_copy_bytes;           // ... its part without the hints (knots | mag | ang, rounded up to 16 bytes)
     const double2 * wrow;         // fft_reg.hip: stage twiddles of the 2048-point row transform (128 + 16 entries)
     const double2 * wcol;         // fft_reg.hip: stage twiddles of the column transform (cols_reg_twiddles), or nullptr
     int per_det, deconvolve;

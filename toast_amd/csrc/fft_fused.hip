@@ -800,6 +800,7 @@ void convolve(double * d_tod, const int32_t * d_idx, int64_t n_det, int64_t n_sa
     p.knot_hint0 = d_hint0;
     p.tab_blob = blob_bytes ? scratch + hint_bytes : nullptr;
     p.tab_bytes = blob_bytes ? (int)tab_bytes : 0;
+    p.tab_copy_bytes = blob_bytes ? (int)((((size_t)n_knot + (size_t)4 * (n_knot - 1) * (d_ang ? 2 : 1)) * sizeof(double) + 15) & ~size_t(15)) : 0;
     p.work = (double2 *)(scratch + hint_bytes + blob_bytes);
     hipLaunchKernelGGL(k_knot_hint, dim3((unsigned)((n_hint + n_hint0 + 255) / 256)), dim3(256), 0, st, d_knots,
                        (int)n_knot, fstep, p.log_n1, n_hint, d_hint, d_hint16, d_hint0);

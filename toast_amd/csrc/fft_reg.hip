@@ -394,7 +394,10 @@ __device__ __forceinline__ void row_fft_2048_p16(double2 (&v)[16], double * smd,
     reg_butterflies<11, 16, 16>(v, l, mirror_out, 7, nullptr);
 }
 
-template <bool TLDS, bool CPLX>
+// HG (the default; TOAST_HIP_FFT_HINTS=lds turns it off): the 16-bit interval hints (4 KB, two look-ups per bin, the same for
+// every workgroup: cache resident) stay in global memory -- 40 172 B of LDS instead of 44 272: FOUR workgroups per CU
+// instead of three (cfg-3 call 18.59-18.65 -> 18.33-18.43 ms, the 2^23 call 42.5-42.7 -> 41.5 ms; profiles/r06_c)
+template <bool TLDS, bool CPLX, bool HG = false>
 __global__ __launch_bounds__(256, 3) void k_fft_rows_reg16(const Params p) {
     extern __shared__ double2 sm[];           // 2 x 17 KB exchange buffers (one per row), stage twiddles, kernel tables
     const int tid = threadIdx.x;
@@ -409,7 +412,7 @@ __global__ __launch_bounds__(256, 3) void k_fft_rows_reg16(const Params p) {
     double2 * s_w = sm + 2 * (kPadRow / 2);                        // 144 stage twiddles
     char * s_tab = reinterpret_cast<char *>(s_w + 144);           // the kernel tables
     uint4 tc[3];
-    const int n_chunk = TLDS ? (p.tab_bytes >> 4) : 0;            // <= 768 (launch_rows_reg16)
+    const int n_chunk = TLDS ? ((HG ? p.tab_copy_bytes : p.tab_bytes) >> 4) : 0;            // <= 768 (launch_rows_reg16)
     if (TLDS) {
         const uint4 * __restrict__ g_tab = reinterpret_cast<const uint4 *>(p.tab_blob + kern * (int64_t)p.tab_bytes);
 #pragma unroll
@@ -440,7 +443,8 @@ __global__ __launch_bounds__(256, 3) void k_fft_rows_reg16(const Params p) {
         kt.knots = s_knots;
         kt.mc = s_knots + p.n_knot;
         kt.ac = CPLX ? kt.mc + n_coef : nullptr;
-        kt.hint = reinterpret_cast<const typename KTabSel<TLDS>::H *>(kt.mc + n_coef * (CPLX ? 2 : 1));
+        if constexpr (HG) kt.hint = p.knot_hint16;
+        else kt.hint = reinterpret_cast<const typename KTabSel<TLDS>::H *>(kt.mc + n_coef * (CPLX ? 2 : 1));
         kt.hint0 = p.knot_hint0;
         kt.log_n1 = p.log_n1;
         kt.fstep = p.fstep;
@@ -898,13 +902,24 @@ void launch_rows_reg16(const Params & p, unsigned n_det, bool tab_lds, size_t ta
         set(reinterpret_cast<const void *>(&k_fft_rows_reg16<true, true>));
         set(reinterpret_cast<const void *>(&k_fft_rows_reg16<false, false>));
         set(reinterpret_cast<const void *>(&k_fft_rows_reg16<false, true>));
+        set(reinterpret_cast<const void *>(&k_fft_rows_reg16<true, false, true>));
+        set(reinterpret_cast<const void *>(&k_fft_rows_reg16<true, true, true>));
         attr_set = true;
     }
     const int n_pair = (1 << p.log_n1) / 2 - 1;                  // row pairs g = 1 .. N1 / 2 - 1
     if (n_pair <= 0) return;
     const dim3 grid((unsigned)n_pair, n_det);
     const bool cplx = p.ang_coef != nullptr;
-    if (tab_lds && p.tab_blob != nullptr && tab_bytes <= kTabLdsReg) {
+    // (TOAST_HIP_FFT_HINTS=lds: the hints in LDS with the other tables, three workgroups per CU -- rounds 5-6a)
+    static const bool hints_global = [] {
+        const char * e = std::getenv("TOAST_HIP_FFT_HINTS");
+        return !(e != nullptr && std::string(e) == "lds");
+    }();
+    if (hints_global && tab_lds && p.tab_blob != nullptr && tab_bytes <= kTabLdsReg) {
+        const size_t lds = rows_reg16_lds((size_t)p.tab_copy_bytes);
+        if (cplx) hipLaunchKernelGGL((k_fft_rows_reg16<true, true, true>), grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((k_fft_rows_reg16<true, false, true>), grid, dim3(256), lds, st, p);
+    } else if (tab_lds && p.tab_blob != nullptr && tab_bytes <= kTabLdsReg) {
         if (cplx) hipLaunchKernelGGL((k_fft_rows_reg16<true, true>), grid, dim3(256), rows_reg16_lds(tab_bytes), st, p);
         else hipLaunchKernelGGL((k_fft_rows_reg16<true, false>), grid, dim3(256), rows_reg16_lds(tab_bytes), st, p);
     } else {
