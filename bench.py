@@ -1029,7 +1029,12 @@ def run(args, workload, world, rank, dev, headline=True):
         if workload == "cfg3" and headline and world == 1 and not args.no_fft_long:
             ld, ls = 512, 2880000
             try:
-                d_long = torch.empty((ld, ls), dtype=torch.float64, device=dev).normal_(0.0, 1.0)
+                # (a timestream block of the arena, like the signal ops.NoiseFilter registers: streamed kind)
+                if args.torch_alloc:
+                    d_long = torch.empty((ld, ls), dtype=torch.float64, device=dev)
+                else:
+                    d_long = manager_tensor(ld * ls * 8, torch.float64, (ld, ls), streamed=True)
+                d_long.normal_(0.0, 1.0)
                 lidx = np.arange(ld, dtype=np.int32)
                 lkern = np.tile(kern, (ld, 1)) * np.linspace(0.9, 1.1, ld)[:, None]
                 long_call = lambda: hipfft.convolve_dev(d_long.data_ptr(), lidx, ls, rate, kfreq, lkern, stream=stream)
@@ -1044,6 +1049,8 @@ def run(args, workload, world, rank, dev, headline=True):
                     "pipeline_bytes_per_sample": lpb,
                     "pipeline_frac": (lpb * float(ld) * ls / (t_long * 1e-3) / 1e9 / HBM_PEAK_GBS) if lpb else None,
                 }
+                if not args.torch_alloc:
+                    manager_release(d_long)
                 del d_long
             except RuntimeError as err:      # noqa: PERF203 -- an extra: the headline must not depend on it
                 out["fft_noise_weight"]["long"] = {"error": repr(err)[:200]}
