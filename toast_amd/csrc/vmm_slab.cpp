@@ -133,7 +133,10 @@ double gap_threshold(std::vector<double> r, double level, double min_gap) {
     double best = 0.0, thr = -1.0;
     for (size_t i = 1; i < r.size(); ++i) {
         const double gap = (r[i] - r[i - 1]) / r[i];
-        if (gap > best && gap >= min_gap) {
+        // (what lies above a gap must be ABOVE the level a range shows with itself: one slow outlier below a single level
+        //  -- 4.85 under 5.13 5.13 5.16 5.17, all of them in the reference's zone -- is not a second level; taken for one, it
+        //  put the maps into the zone of every array the kernels read: build_noise_weighted 5.89 ms, profiles/r06_f section 6)
+        if (gap > best && gap >= min_gap && r[i] > (1.0 + min_gap) * level) {
             best = gap;
             thr = 0.5 * (r[i] + r[i - 1]);
         }
@@ -388,16 +391,7 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
         }
         if (r.empty()) return 1.0e300;
         std::sort(r.begin(), r.end());
-        double best = 0.0, thr = -1.0;
-        for (size_t i = 1; i < r.size(); ++i) {
-            const double gap = (r[i] - r[i - 1]) / r[i];
-            if (gap > best && gap >= pol.gap) {
-                best = gap;
-                thr = 0.5 * (r[i] + r[i - 1]);
-            }
-        }
-        if (thr > 0.0) return thr;
-        return (r[r.size() / 2] > (1.0 + 1.7 * pol.gap) * level) ? 0.0 : 1.0e300;     // all "other" : all "same"
+        return gap_threshold(r, level, pol.gap);      // (0: all "other", 1e300: all "same")
     };
     size_t want_odd = 0;                         // slots of the other zone ("odd": round 4's name for them)
     for (size_t k = 0; k < n; ++k) want_odd += vmm_slot_other(k) ? 1 : 0;

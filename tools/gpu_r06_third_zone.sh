@@ -25,13 +25,12 @@ if 'read_GBs_vs_chunk' in z:
 if 'bnw_ms_by_map_place' in z:
     print('   bnw by map place:', ' '.join('%s/%s@%+.1f=%.3f' % (a[0][:3], a[2], a[3], a[1]) for a in z['bnw_ms_by_map_place']))
 PY
-    grep "vmm slab\|vmm survey" gpurun_out/$tag/$label$i.err | cut -c1-260
+    grep "vmm slab\|vmm survey\|plain slab" gpurun_out/$tag/$label$i.err | cut -c1-260
   done
 }
 for w in $which; do
   case $w in
     DEFAULT) one DEFAULT TOAST_HIP_ARENA_THIRD_ZONE=1 | tee gpurun_out/$tag/default.txt;;
     TWO) one TWO TOAST_HIP_ARENA_THIRD_ZONE=0 | tee gpurun_out/$tag/two.txt;;
-    ENDS) one ENDS TOAST_HIP_ARENA_SURVEY=0 | tee gpurun_out/$tag/ends.txt;;
   esac
 done
