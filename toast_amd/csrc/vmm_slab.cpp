@@ -145,6 +145,15 @@ double gap_threshold(std::vector<double> r, double level, double min_gap) {
     return (r[r.size() / 2] > (1.0 + 1.7 * min_gap) * level) ? 0.0 : 1.0e300;
 }
 
+// TOAST_HIP_ARENA_SURVEY_REFS=0: the survey only gates the third-zone split; the chunks are measured against the two ENDS
+bool survey_refs_enabled() {
+    static const bool on = [] {
+        const char * e = std::getenv("TOAST_HIP_ARENA_SURVEY_REFS");
+        return !(e != nullptr && e[0] == '0');
+    }();
+    return on;
+}
+
 // ---- the zone survey of a range (round 6, profiles/r06_f) ------------------------------------------------------------------
 // K blocks of `chunk` bytes spread over a range are sorted into HBM zones: every block against the first one (one read +
 // write pass each: two levels ~13 % apart), the ones in another zone against the last of them.
@@ -404,7 +413,9 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
     std::vector<size_t> cls_odd, cls_even;       // candidates for the odd slots (other than every reference) and the rest
     std::vector<size_t> grp_a, grp_b;            // third-zone split of cls_odd: same zone as the anchor / the other one
     bool third_done = false;
-    bool prefer_end_zone = false;               // even slots: chunks of the END's zone first (see the survey below)
+    bool prefer_end_zone = false;               // even slots: chunks of reference 0's zone first (see the survey below)
+    bool refs_by_weight = false;                // the references are blocks of the two heaviest zones of the range, not its ends
+    std::vector<void *> survey_held;            // ... held until the search is over
     try {
         if (n_ref >= 1) {
             ref[0] = static_cast<char *>(ext.last);
@@ -437,6 +448,36 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
                 bool front_one = K >= 4 && zs.label[K - 1] > 0;
                 for (size_t k = 0; k < (K + 1) / 2 && front_one; ++k) front_one = zs.label[k] == 0;
                 prefer_end_zone = front_one;
+                // Two or three zones in the range: the references become one block of each of the two HEAVIEST zones -- the
+                // arrays are placed in address order, block k of K counts K - k -- instead of the two ends: "clear of both"
+                // is then the lightest zone of the range (or one it does not touch), and the even slots prefer the second
+                // heaviest (reference 0) to the heaviest.  (XXXXXXZZZYYYX: the ends are both X, "clear of X" was Z or Y as
+                // they came, the rest X -- the zone of nearly every array: scan_map 6.28-6.30 ms.)
+                if (zs.zones >= 2 && survey_refs_enabled()) {
+                    double w[3] = {0.0, 0.0, 0.0};
+                    int first_of[3] = {-1, -1, -1};
+                    for (size_t k = 0; k < K; ++k) {
+                        const int z = zs.label[k];
+                        if (z < 0) continue;
+                        w[z] += (double)(K - k);
+                        if (first_of[z] < 0) first_of[z] = (int)k;
+                    }
+                    int order[3] = {0, 1, 2};
+                    std::sort(order, order + 3, [&](int a, int b) { return w[a] > w[b]; });
+                    void * heavy = read_mostly_take_at(rb, at[(size_t)first_of[order[0]]], chunk);
+                    void * second = read_mostly_take_at(rb, at[(size_t)first_of[order[1]]], chunk);
+                    if (heavy != nullptr && second != nullptr) {
+                        survey_held = {heavy, second};
+                        ref[1] = static_cast<char *>(heavy);
+                        ref[0] = static_cast<char *>(second);
+                        for (int k = 0; k < 2; ++k) level[k] = pass(ref[k], ref[k] + chunk / 2, chunk / 2);
+                        prefer_end_zone = true;          // (reference 0 = the lighter of the two: first choice of the even slots)
+                        refs_by_weight = true;
+                    } else {
+                        read_mostly_release(heavy);
+                        read_mostly_release(second);
+                    }
+                }
             }
         }
         so.zones = survey_zones_n;
@@ -594,6 +635,7 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
     so.exhausted = !full;
     for (void * sp : spacers) (void)hipFree(sp);
     zone_references_release(ext);
+    for (void * b : survey_held) read_mostly_release(b);
     for (const Cand & c : cand) (void)hipMemUnmap(c.at, chunk);
     (void)hipMemAddressFree(own_res, own_n * chunk);
     const size_t created = cand.size();
@@ -689,7 +731,8 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
     so.third = third_done;
     register_slab(base, n, chunk, slot, take_o, created, probes, level[0], t_start,
                   third_done ? "both classes clear of the read-mostly slab: two other zones"
-                             : (n_ref == 2 ? "against both ends of the read-mostly slab"
+                             : (refs_by_weight ? "against the two heaviest zones of the read-mostly range"
+                                : n_ref == 2 ? "against both ends of the read-mostly slab"
                                            : (n_ref == 1 ? "against the read-mostly slab" : "against its first chunk")),
                   n_ref, so);
     return base;

@@ -32,5 +32,6 @@ for w in $which; do
   case $w in
     DEFAULT) one DEFAULT TOAST_HIP_ARENA_THIRD_ZONE=1 | tee gpurun_out/$tag/default.txt;;
     TWO) one TWO TOAST_HIP_ARENA_THIRD_ZONE=0 | tee gpurun_out/$tag/two.txt;;
+    ENDS) one ENDS TOAST_HIP_ARENA_SURVEY_REFS=0 | tee gpurun_out/$tag/ends.txt;;
   esac
 done
