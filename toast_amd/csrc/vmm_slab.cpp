@@ -453,7 +453,9 @@ void * vmm_slab_take(size_t bytes, hipStream_t st) {
                 // is then the lightest zone of the range (or one it does not touch), and the even slots prefer the second
                 // heaviest (reference 0) to the heaviest.  (XXXXXXZZZYYYX: the ends are both X, "clear of X" was Z or Y as
                 // they came, the rest X -- the zone of nearly every array: scan_map 6.28-6.30 ms.)
-                if (zs.zones >= 2 && survey_refs_enabled()) {
+                // (ranges of up to 64 GB: on a 112 GB range -- the cfg-4 shard, a block every 7 GB -- the two ends did better,
+                //  64.2-64.5 against 62.2-62.6 G in alternating processes, and the search for the rarest zone took 2.5-4.3 s)
+                if (zs.zones >= 2 && survey_refs_enabled() && rhi - rlo <= (size_t(64) << 30)) {
                     double w[3] = {0.0, 0.0, 0.0};
                     int first_of[3] = {-1, -1, -1};
                     for (size_t k = 0; k < K; ++k) {
