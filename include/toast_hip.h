@@ -145,6 +145,11 @@ int toast_hip_arena_reserve_streamed(size_t bytes);
  * Waits for a slab that toast_hip_accel_assign_device is still building. */
 int toast_hip_arena_block_zone(const void * device_ptr, size_t bytes, int * interleaved, int * chunks_own_zone,
                                int * chunks_other_zone);
+/* The rule that sorts the candidate chunks of a zone-interleaved slab into "same zone as the reference" and "another zone",
+ * applied to given rates (no device needed): the middle of the largest relative gap between neighbouring rates -- a gap counts
+ * when it is at least TOAST_HIP_ARENA_ZONE_GAP (3.5 %) wide AND its upper side lies above (1 + that) x `level`, the rate a range
+ * shows with itself -- or, with one level only, 0 (every rate is "another zone") / 1e300 (every rate is "the same"). */
+int toast_hip_arena_zone_threshold(const double * rates, int n, double level, double * threshold);
 /* The sub-allocation logic exercised on HOST memory (no device needed): n_ops random allocations / releases with the
  * bookkeeping and the contents of every live block checked after each step.  0 = sound. */
 int toast_hip_arena_selftest(uint64_t seed, int n_ops, size_t granule, size_t slab_bytes, size_t max_block);

@@ -212,6 +212,29 @@ def test_arena_suballocation_on_host_memory():
         capi.arena_selftest(1, 10, 0, 1 << 20, 100)
 
 
+def test_zone_search_threshold_rule():
+    """The rule that sorts measured rates (TB/s x 1e9 in the library; any unit here) into "same zone as the reference" and
+    "another zone" (csrc/vmm_slab.cpp gap_threshold), on rates taken from runs on the MI355X: two levels are split at the
+    middle of their gap; ONE level with a slow outlier under it is not split (round 6: 5.16 5.17 5.13 4.85 5.13, all in the
+    reference's zone, had been split at 4.99 -- the maps went into the zone of every array the kernels read); one level
+    alone is judged against the level a range shows with itself."""
+    from toast_amd import capi
+
+    level = 5.19
+    # two levels, a few per cent wide each
+    thr = capi.arena_zone_threshold([5.07, 5.06, 5.18, 5.02, 4.90, 5.17, 5.74, 5.75, 5.66, 5.68], level)
+    assert 5.18 < thr < 5.66
+    # ... also with a slow outlier below the lower one: the gap under the UPPER level is the one that counts
+    thr = capi.arena_zone_threshold([4.40, 5.05, 5.08, 5.70, 5.72], level)
+    assert 5.08 < thr < 5.70
+    # one level with an outlier under it: no split, and the level is "the same zone"
+    assert capi.arena_zone_threshold([5.16, 5.17, 5.13, 4.85, 5.13], level) > 1e299
+    # one level well above what a range shows with itself: "another zone" for all of them
+    assert capi.arena_zone_threshold([5.75, 5.72, 5.64, 5.61], level) == 0.0
+    # nothing measured yet: everything counts as "the same"
+    assert capi.arena_zone_threshold([], level) > 1e299
+
+
 def test_fft_mirror_tile_order_is_a_permutation_that_keeps_partners_on_one_xcd():
     """toast_hip_fft_mirror_tile_order (host only): the forward column pass' tile order.  Restated here from the definition
     of the padded series (reference src/toast/fft.py:163-188: sample i of the padded series is the timestream at i - n_buffer,

@@ -359,6 +359,15 @@ def arena_block_zone(device_ptr, nbytes):
     return bool(a.value), int(b.value), int(c.value)
 
 
+def arena_zone_threshold(rates, level):
+    """The zone search's class threshold on given rates (toast_hip_arena_zone_threshold; no device needed)."""
+    r = np.ascontiguousarray(rates, dtype=np.float64)
+    thr = C.c_double(0.0)
+    _check(real_lib().toast_hip_arena_zone_threshold(r.ctypes.data_as(C.c_void_p), C.c_int(r.size), C.c_double(float(level)),
+                                                     C.byref(thr)))
+    return float(thr.value)
+
+
 def arena_selftest(seed, n_ops, granule, slab_bytes, max_block):
     """The arena's sub-allocation logic on host memory (toast_hip_arena_selftest); raises on an inconsistency."""
     _check(real_lib().toast_hip_arena_selftest(C.c_uint64(int(seed)), C.c_int(int(n_ops)), C.c_size_t(int(granule)),

@@ -1384,6 +1384,13 @@ int toast_hip_arena_block_zone(const void * device_ptr, size_t bytes, int * inte
 // bytes against an arena with the given granule and slab size; after every step the bookkeeping is checked, live blocks
 // are checked for overlap through a byte pattern, and at the end everything is released and every slab must be one
 // free range again.  0 = sound; otherwise the first inconsistency is in toast_hip_last_error().
+int toast_hip_arena_zone_threshold(const double * rates, int n, double level, double * threshold) {
+    return guarded([&] {
+        if (rates == nullptr || threshold == nullptr || n < 0) fail_arg("toast_hip_arena_zone_threshold: null argument");
+        *threshold = vmm_zone_threshold(rates, n, level);
+    });
+}
+
 int toast_hip_arena_selftest(uint64_t seed, int n_ops, size_t granule, size_t slab_bytes, size_t max_block) {
     return guarded([&] {
         if (granule == 0 || slab_bytes < granule || max_block == 0) fail_arg("toast_hip_arena_selftest: bad sizes");

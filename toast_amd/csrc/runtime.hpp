@@ -141,6 +141,7 @@ bool read_mostly_free_range(const char ** base, size_t * lo, size_t * hi);
 void * read_mostly_take_at(const char * base, size_t offset, size_t bytes);
 void read_mostly_release(void * p);
 bool vmm_slab_give(void * p);       // false: not one of them
+double vmm_zone_threshold(const double * rates, int n, double level);      // the zone search's class threshold on given rates
 struct VmmSlabStats {
     int64_t slabs = 0;               // interleaved slabs alive
     int64_t chunks = 0;              // chunks mapped into slabs so far

@@ -824,4 +824,9 @@ bool vmm_slab_give(void * p) {
     return true;
 }
 
+// the class threshold of the zone search on given rates (no device): toast_hip_arena_zone_threshold, tests/test_capi_load.py
+double vmm_zone_threshold(const double * rates, int n, double level) {
+    return gap_threshold(std::vector<double>(rates, rates + (n > 0 ? n : 0)), level, policy().gap);
+}
+
 }  // namespace toast_hip
